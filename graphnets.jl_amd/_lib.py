@@ -1,0 +1,126 @@
+"""ctypes binding of libgnx.so — exactly the symbols include/gnx.h declares.
+
+There is no fallback of any kind: if the shared library is missing or a symbol cannot be resolved the import
+fails loudly; if no GPU is visible every compute entry point returns a HIP error that is raised as GnxError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgnx.so")
+
+# status codes (include/gnx.h)
+GNX_OK = 0
+ERR_INVALID_ARG, ERR_NO_GRAPHS, ERR_ADJ_SHAPE, ERR_ADJ_VALUE, ERR_ALL_NOTHING = -1, -2, -3, -4, -5
+ERR_DIMS, ERR_CSC, ERR_WORKSPACE, ERR_TOO_LARGE, ERR_COUNT_MISMATCH = -6, -7, -8, -9, -10
+ACT = dict(identity=0, relu=1, tanh=2, sigmoid=3, gelu=4)
+ELEM_U8, ELEM_I32, ELEM_I64, ELEM_F32, ELEM_F64 = 0, 1, 2, 3, 4
+FLAG_FORCE_GENERIC, FLAG_NO_MFMA = 0x1, 0x2
+
+_fp = C.c_void_p  # device float*
+
+
+class GraphsInfo(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_graphs", "n_nodes", "n_edges", "node_block_size", "edge_block_size",
+                                         "n_tiles", "max_in_degree")] + [("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Dense(C.Structure):
+    _fields_ = [("weight", _fp), ("bias", _fp), ("act", C.c_int32), ("reserved", C.c_int32)]
+
+
+class BlockParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("de", "dn", "dg", "oe", "on", "og")] + \
+               [("edgefn", Dense), ("nodefn", Dense), ("graphfn", Dense)]
+
+
+class LayerNorm(C.Structure):
+    _fields_ = [("gamma", _fp), ("beta", _fp)]
+
+
+class Ffn(C.Structure):
+    _fields_ = [("fc1", Dense), ("fc2", Dense)]
+
+
+class CoreParams(C.Structure):
+    _fields_ = [("block", BlockParams), ("ln1", LayerNorm * 3), ("ln2", LayerNorm * 3), ("ff", Ffn * 3),
+                ("eps", C.c_float), ("eps_mode", C.c_int32)]
+
+
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
+
+
+class GnxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gnx error {code}: {msg}")
+        self.code = code
+
+
+# every exported symbol of include/gnx.h with (restype, argtypes)
+_pp = C.POINTER(C.c_void_p)
+_i64p = C.POINTER(C.c_int64)
+_FWD = [C.c_void_p, C.c_void_p, _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+SIGNATURES = {
+    "gnx_version": (C.c_int32, []),
+    "gnx_last_error": (C.c_char_p, []),
+    "gnx_graphs_create_dense": (C.c_int32, [_pp, _i64p, C.c_int64, C.c_int32, C.c_int32, _pp]),
+    "gnx_graphs_create_csc": (C.c_int32, [_pp, _pp, _i64p, C.c_int64, C.c_int32, _pp]),
+    "gnx_graphs_destroy": (C.c_int32, [C.c_void_p]),
+    "gnx_graphs_get_info": (C.c_int32, [C.c_void_p, C.POINTER(GraphsInfo)]),
+    "gnx_graphs_get_offsets": (C.c_int32, [C.c_void_p, _i64p, _i64p]),
+    "gnx_graphs_get_csc": (C.c_int32, [C.c_void_p, _i64p, _i64p]),
+    "gnx_block_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BlockParams), C.c_int64]),
+    "gnx_block_forward": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + _FWD[2:]),
+    "gnx_core_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(CoreParams), C.c_int64]),
+    "gnx_core_forward": (C.c_int32, [C.c_void_p, C.POINTER(CoreParams)] + _FWD[2:]),
+    "gnx_pad_features": (C.c_int32, [C.c_void_p, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),
+    "gnx_unpad_features": (C.c_int32, [C.c_void_p, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),
+    "gnx_profile_enable": (C.c_int32, [C.c_int32]),
+    "gnx_profile_reset": (C.c_int32, []),
+    "gnx_profile_read": (C.c_int32, [C.POINTER(ProfileEntry), C.c_int32, C.POINTER(C.c_int32)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libgnx.so.  torch is imported first so that the library's libamdhip64.so.7 dependency resolves to
+    the HIP runtime torch already loaded (one runtime per process: streams and pointers are shared)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python graphnets.jl_amd/build.py` "
+                          "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+    import torch  # noqa: F401  (side effect: loads torch's libamdhip64 with RTLD_GLOBAL-equivalent soname match)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != GNX_OK:
+        raise GnxError(rc, load().gnx_last_error().decode("utf-8", "replace"))
+
+
+def profile_enable(on=True):
+    check(load().gnx_profile_enable(1 if on else 0))
+
+
+def profile_reset():
+    check(load().gnx_profile_reset())
+
+
+def profile_read():
+    lib = load()
+    n = C.c_int32(0)
+    buf = (ProfileEntry * 64)()
+    check(lib.gnx_profile_read(buf, 64, C.byref(n)))
+    return {buf[i].name.decode(): dict(launches=buf[i].launches, total_ms=buf[i].total_ms) for i in range(min(n.value, 64))}

@@ -1,0 +1,604 @@
+"""Host-side mirror of GraphNets.jl's public interface for the GNBlock / GNCore forward path.
+
+Same names, argument meaning and error behaviour as the reference (`/root/reference/src/GraphNets.jl:12-50`), with
+the compute done by libgnx.so (hand-written HIP, gfx950) through the C ABI in include/gnx.h.  Julia is not
+available in this image, so this mirror is Python; the Julia `ccall` shim over the same ABI is julia/GraphNetsHIP.jl.
+
+Conventions that make it read like the reference:
+  * arrays keep Julia's shapes — ef (DE, E, B), nf (DN, N, B), gf (DG, B) — as torch tensors whose strides are
+    column-major, i.e. the bytes are Julia's bytes (and the C ABI's packed [B][T][D] rows); indices are 0-based;
+  * `nothing` is `None`; `@assert` failures are `AssertionError`;
+  * the batched tuple is packed, not padded: `batch(x).ef` is (DE, ΣE, 1) for a vector of graphs instead of the
+    reference's (DE, PN², B).  `unbatch`, `efview`/`nfview`/`gfview`, `flatunpaddednf/ef` return exactly what the
+    reference returns; `padded(x)` materialises the reference's padded layout when it is wanted.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GnxError, check
+
+__all__ = ["GNGraphBatch", "NT", "batch", "unbatch", "efview", "nfview", "gfview", "flatunpaddednf", "flatunpaddedef",
+           "Dense", "LayerNorm", "GNBlock", "GNCore", "GNCoreList", "GNFeedForward", "GNGraphNorm", "zerodim2nothing",
+           "padded", "GnxError"]
+
+_KEYS = ("graphs", "ef", "nf", "gf")
+
+
+class NT:
+    """The reference's NamedTuple `(graphs, ef, nf, gf)` (batch.jl:58-63)."""
+    __slots__ = _KEYS
+
+    def __init__(self, graphs=None, ef=None, nf=None, gf=None):
+        self.graphs, self.ef, self.nf, self.gf = graphs, ef, nf, gf
+
+    def keys(self):
+        return _KEYS
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    def __iter__(self):
+        return iter((self.graphs, self.ef, self.nf, self.gf))
+
+    def _replace(self, **kw):
+        d = {k: getattr(self, k) for k in _KEYS}
+        d.update(kw)
+        return NT(**d)
+
+    def __repr__(self):
+        sh = lambda a: None if a is None else (tuple(a.shape) if hasattr(a, "shape") else f"list[{len(a)}]")
+        return f"NT(graphs={type(self.graphs).__name__}, ef={sh(self.ef)}, nf={sh(self.nf)}, gf={sh(self.gf)})"
+
+
+def _as_nt(t):
+    if isinstance(t, NT):
+        return t
+    if isinstance(t, dict):
+        assert set(t.keys()) == set(_KEYS), "keys must be (graphs, ef, nf, gf)"  # batch.jl:54
+        return NT(**t)
+    if hasattr(t, "_asdict"):
+        d = t._asdict()
+        assert set(d.keys()) == set(_KEYS)
+        return NT(**d)
+    return NT(*(getattr(t, k) for k in _KEYS))
+
+
+def _device(device=None):
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cuda", 0)
+    return torch.device(device)
+
+
+def _np(a):
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# GNGraphBatch — replaces the struct of dense broadcasters (gngraphbatch.jl:1-54) by a libgnx handle
+# ------------------------------------------------------------------------------------------------------------
+class GNGraphBatch:
+    """`GNGraphBatch(adj_mats)`; `GNGraphBatch.from_csc(colptrs, rowvals, n_nodes)` is the sparse constructor
+    (API extension: dense N×N input cannot hold BASELINE configs 2-5)."""
+
+    def __init__(self, adj_mats=None, *, device=None, _csc=None):
+        lib = _lib.load()
+        self.device = _device(device)
+        self._h = C.c_void_p(None)
+        self._ws = {}
+        self._masks = None
+        keep = []
+        with torch.cuda.device(self.device):
+            if _csc is not None:
+                colptrs, rowvals, n_nodes = _csc
+                G = len(n_nodes)
+                cps = [np.ascontiguousarray(c, dtype=np.int64) for c in colptrs]
+                rvs = [np.ascontiguousarray(r, dtype=np.int64) for r in rowvals]
+                keep += cps + rvs
+                cpp = (C.c_void_p * max(G, 1))(*[c.ctypes.data for c in cps])
+                rvp = (C.c_void_p * max(G, 1))(*[r.ctypes.data for r in rvs])
+                nn = np.ascontiguousarray(n_nodes, dtype=np.int64)
+                check(lib.gnx_graphs_create_csc(cpp, rvp, nn.ctypes.data_as(C.POINTER(C.c_int64)), G, 0, C.byref(self._h)))
+                self.adj_mats = None
+            else:
+                mats = [_np(a) for a in adj_mats]
+                for a in mats:
+                    assert a.ndim == 2, "adjacency matrix must be 2-D (checks.jl:11)"
+                    assert a.shape[0] == a.shape[1], "adjacency matrix must be square"
+                self.adj_mats = mats
+                conv, kind = [], _lib.ELEM_I64
+                for a in mats:
+                    if a.dtype == np.float32:
+                        kind_a, b = _lib.ELEM_F32, a
+                    elif a.dtype.kind == "f":
+                        kind_a, b = _lib.ELEM_F64, a.astype(np.float64)
+                    else:
+                        kind_a, b = _lib.ELEM_I64, a.astype(np.int64)
+                    conv.append((kind_a, np.ascontiguousarray(b)))
+                kinds = {k for k, _ in conv}
+                if len(kinds) > 1:  # mixed element types: promote to float64
+                    conv = [(_lib.ELEM_F64, np.ascontiguousarray(b.astype(np.float64))) for _, b in conv]
+                kind = conv[0][0] if conv else _lib.ELEM_I64
+                keep += [b for _, b in conv]
+                G = len(mats)
+                ptrs = (C.c_void_p * max(G, 1))(*[b.ctypes.data for _, b in conv])
+                nn = np.asarray([a.shape[0] for a in mats], dtype=np.int64)
+                check(lib.gnx_graphs_create_dense(ptrs, nn.ctypes.data_as(C.POINTER(C.c_int64)), G, kind, 1, C.byref(self._h)))
+        info = _lib.GraphsInfo()
+        check(lib.gnx_graphs_get_info(self._h, C.byref(info)))
+        self.n_graphs, self.n_nodes, self.n_edges = info.n_graphs, info.n_nodes, info.n_edges
+        self.node_block_size, self.edge_block_size = info.node_block_size, info.edge_block_size  # gngraphbatch.jl:35-36
+        self.n_tiles, self.max_in_degree = info.n_tiles, info.max_in_degree
+        self.node_off = np.zeros(self.n_graphs + 1, dtype=np.int64)
+        self.edge_off = np.zeros(self.n_graphs + 1, dtype=np.int64)
+        check(lib.gnx_graphs_get_offsets(self._h, self.node_off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                         self.edge_off.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    @classmethod
+    def from_csc(cls, colptrs, rowvals, n_nodes, device=None):
+        """Per-graph 0-based CSC: colptrs[g] (N_g+1), rowvals[g] = local source index of every edge (sorted inside
+        a column).  CSC nz order is the reference edge order (pad.jl:30)."""
+        return cls(device=device, _csc=(colptrs, rowvals, n_nodes))
+
+    def __len__(self):
+        return self.n_graphs
+
+    def csc(self):
+        """Global 0-based (colptr[N+1], rowval[E]) host copies."""
+        colptr = np.zeros(self.n_nodes + 1, dtype=np.int64)
+        rowval = np.zeros(max(self.n_edges, 1), dtype=np.int64)
+        check(_lib.load().gnx_graphs_get_csc(self._h, colptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                             rowval.ctypes.data_as(C.POINTER(C.c_int64))))
+        return colptr, rowval[: self.n_edges]
+
+    def _unpadders(self):
+        """flat_node_unpadder / flat_edge_unpadder Bool masks (gngraphbatch.jl:113-134), built on demand."""
+        if self._masks is None:
+            PN, B = self.node_block_size, self.n_graphs
+            nm = np.zeros(B * PN, dtype=bool)
+            em = np.zeros(B * PN * PN, dtype=bool)
+            colptr, rowval = self.csc()
+            dst = np.repeat(np.arange(self.n_nodes), np.diff(colptr))
+            for g in range(B):
+                n0, n1, e0, e1 = self.node_off[g], self.node_off[g + 1], self.edge_off[g], self.edge_off[g + 1]
+                nm[g * PN: g * PN + (n1 - n0)] = True
+                em[g * PN * PN + (rowval[e0:e1] - n0) + PN * (dst[e0:e1] - n0)] = True
+            self._masks = (nm, em)
+        return self._masks
+
+    @property
+    def flat_node_unpadder(self):
+        return self._unpadders()[0]
+
+    @property
+    def flat_edge_unpadder(self):
+        return self._unpadders()[1]
+
+    def workspace(self, nbytes):
+        """Device scratch reused across calls on this handle (calls on one stream are ordered)."""
+        nbytes = int(nbytes)
+        ws = self._ws.get("buf")
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+            self._ws["buf"] = ws
+        return ws
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().gnx_graphs_destroy(self._h)
+                self._h = C.c_void_p(None)
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------------------
+# layout helpers: Julia-shaped column-major views over packed [R][T][D] storage
+# ------------------------------------------------------------------------------------------------------------
+def _jl(c):
+    """packed [R][T][D] contiguous tensor → Julia-shaped (D, T, R) view of the same bytes."""
+    return None if c is None else c.permute(2, 1, 0)
+
+
+def _packed(j):
+    """Julia-shaped (D, T, R) tensor → contiguous [R][T][D] (no copy when it already is one of our views)."""
+    return None if j is None else j.permute(2, 1, 0).contiguous()
+
+
+def _dev_f32(a, device):
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(_np(a), dtype=np.float32))
+    return t.to(device=device, dtype=torch.float32)
+
+
+def _ndim(a):
+    return a.dim() if isinstance(a, torch.Tensor) else np.ndim(a)
+
+
+def _size(a, d):
+    return a.shape[d]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# checks (src/checks.jl) — same assertions, AssertionError like Julia's @assert
+# ------------------------------------------------------------------------------------------------------------
+def _checks_shared(adj, ef, nf, gf):
+    if ef is not None:
+        assert _ndim(ef) == 3, "ndims(ef) != 3"  # checks.jl:63-84 (C, T, B)
+    if nf is not None:
+        assert _ndim(nf) == 3, "ndims(nf) != 3"
+    if gf is not None:
+        assert _ndim(gf) == 2, f"{_ndim(gf)} != 2"  # (C, B)
+    bs = [_size(ef, 2)] if ef is not None else []
+    bs += [_size(nf, 2)] if nf is not None else []
+    bs += [_size(gf, 1)] if gf is not None else []
+    assert len(set(bs)) <= 1, "batch sizes differ (checks.jl:169-183)"
+    a = _np(adj)
+    if ef is not None:
+        ne = int((a == 1).sum())
+        assert _size(ef, 1) == ne, f"{_size(ef, 1)} != num_edges"  # checks.jl:44
+    if nf is not None:
+        assert _size(nf, 1) == a.shape[0], f"{_size(nf, 1)} != {a.shape[0]}"  # checks.jl:45
+
+
+def _checks_vector(adjs, ef, nf, gf):
+    assert len(adjs) > 0  # checks.jl:8
+    for name, v in (("ef", ef), ("nf", nf), ("gf", gf)):
+        if v is not None:
+            assert len(v) == len(adjs), f"length(adj_mats) != length({name}) (checks.jl:136-163)"
+    for a in adjs:
+        assert _ndim(a) == 2  # checks.jl:11
+    for g, a in enumerate(adjs):
+        a = _np(a)
+        if ef is not None:
+            assert _ndim(ef[g]) == 2
+            assert _size(ef[g], 1) == int((a == 1).sum()), f"{_size(ef[g], 1)} != num_edges"
+        if nf is not None:
+            assert _ndim(nf[g]) == 2, f"{_ndim(nf[g])} != 2"
+            assert _size(nf[g], 1) == a.shape[0], f"{_size(nf[g], 1)} != {a.shape[0]}"
+        if gf is not None:
+            assert _ndim(gf[g]) == 1
+
+
+# ------------------------------------------------------------------------------------------------------------
+# batch / unbatch / views (src/batch.jl, src/unbatch.jl, src/unpad.jl, src/views.jl)
+# ------------------------------------------------------------------------------------------------------------
+def _is_matrix(g):
+    return isinstance(g, (np.ndarray, torch.Tensor)) and g.ndim == 2
+
+
+def batch(t, device=None):
+    """`batch(t::NamedTuple)` (batch.jl:53-64).  `graphs` is one adjacency matrix (shared by the whole data batch),
+    a vector of adjacency matrices, or an existing GNGraphBatch (e.g. from_csc)."""
+    if isinstance(t, dict):
+        assert set(t.keys()) == set(_KEYS), "keys must be (graphs, ef, nf, gf)"
+    t = _as_nt(t)
+    graphs, ef, nf, gf = t
+    assert not (ef is None and nf is None and gf is None), "ef, nf and gf are all nothing (batch.jl:56)"
+    dev = _device(device)
+    if isinstance(graphs, GNGraphBatch):
+        shared = graphs.n_graphs == 1 and not isinstance(next(x for x in (ef, nf, gf) if x is not None), (list, tuple))
+        g = graphs
+        dev = g.device
+    elif _is_matrix(graphs):
+        shared = True
+        _checks_shared(graphs, ef, nf, gf)
+        g = GNGraphBatch([graphs], device=dev)
+    else:
+        shared = False
+        graphs = list(graphs)
+        _checks_vector(graphs, ef, nf, gf)
+        g = GNGraphBatch(graphs, device=dev)
+    if shared:
+        bef = None if ef is None else _jl(_packed(_dev_f32(ef, dev)))
+        bnf = None if nf is None else _jl(_packed(_dev_f32(nf, dev)))
+        bgf = None if gf is None else _jl(_dev_f32(gf, dev).t().contiguous()[:, None, :])  # (DG,B) → [B][1][DG]
+        for name, a, T in (("ef", bef, g.n_edges), ("nf", bnf, g.n_nodes)):
+            if a is not None:
+                assert a.shape[1] == T, f"size({name}, 2) = {a.shape[1]} != {T} (checks.jl:41-46)"
+    else:
+        cat = lambda items: torch.cat([_dev_f32(x, dev).t() for x in items], dim=0).contiguous()[None]  # [1][ΣT][D]
+        bef = None if ef is None else _jl(cat(ef))
+        bnf = None if nf is None else _jl(cat(nf))
+        bgf = None if gf is None else _jl(torch.stack([_dev_f32(x, dev) for x in gf]).contiguous()[None])  # [1][G][DG]
+        for name, a, T in (("ef", bef, g.n_edges), ("nf", bnf, g.n_nodes), ("gf", bgf, g.n_graphs)):
+            if a is not None:
+                assert a.shape[1] == T, f"{name}: {a.shape[1]} columns != {T} (checks.jl:41-46)"
+    return NT(g, bef, bnf, bgf)
+
+
+def _shared_like(g):
+    return g.n_graphs == 1  # unbatch.jl:15-17: a 1-graph batch unbatches through the shared-adjacency branch
+
+
+def unbatch(t):
+    """`unbatch` (unbatch.jl:6-39): the inverse of `batch`; results alias the batched arrays (views, like
+    unpad.jl's @view)."""
+    t = _as_nt(t)
+    g, ef, nf, gf = t
+    assert not (ef is None and nf is None and gf is None)
+    if _shared_like(g):
+        graphs = g.adj_mats[0] if g.adj_mats is not None else g
+        return NT(graphs, ef, nf, None if gf is None else gf[:, 0, :])  # gf → (DG, B) (unpad.jl:19-21)
+    eo, no = g.edge_off, g.node_off
+    efs = None if ef is None else [ef[:, eo[i]:eo[i + 1], 0] for i in range(g.n_graphs)]
+    nfs = None if nf is None else [nf[:, no[i]:no[i + 1], 0] for i in range(g.n_graphs)]
+    gfs = None if gf is None else [gf[:, i, 0] for i in range(g.n_graphs)]
+    return NT(g.adj_mats if g.adj_mats is not None else g, efs, nfs, gfs)
+
+
+def efview(t, d1, d2, d3):
+    """`efview(t, d1, d2, d3)` (views.jl:6-31): d2 indexes the real edges of graph/batch element d3 in edge order."""
+    t = _as_nt(t)
+    if t.ef is None:
+        return None
+    if _shared_like(t.graphs):
+        return t.ef[d1, d2, d3]
+    eo = t.graphs.edge_off
+    return t.ef[:, eo[d3]:eo[d3 + 1], 0][d1, d2]
+
+
+def nfview(t, d1, d2, d3):
+    """`nfview(t, d1, d2, d3)` (views.jl:38-61)."""
+    t = _as_nt(t)
+    if t.nf is None:
+        return None
+    if _shared_like(t.graphs):
+        return t.nf[d1, d2, d3]
+    no = t.graphs.node_off
+    return t.nf[:, no[d3]:no[d3 + 1], 0][d1, d2]
+
+
+def gfview(t, d1, d2):
+    """`gfview(t, d1, d2)` (views.jl:68-78)."""
+    t = _as_nt(t)
+    if t.gf is None:
+        return None
+    return t.gf[d1, 0, d2] if _shared_like(t.graphs) else t.gf[d1, d2, 0]
+
+
+def _flat(a):
+    D, T, R = a.shape
+    return a.permute(2, 1, 0).reshape(R * T, D).t()  # (D, T*R), column t + T*r — Julia's reshape(a, D, T*B)
+
+
+def flatunpaddednf(t):
+    """`flatunpaddednf` (views.jl:80-88): (DN, ΣN) over all real nodes, graph-major.  The packed layout already is it."""
+    return _flat(_as_nt(t).nf)
+
+
+def flatunpaddedef(t):
+    """`flatunpaddedef` (views.jl:90-98)."""
+    return _flat(_as_nt(t).ef)
+
+
+def zerodim2nothing(t):
+    """gnblock.jl:71-78."""
+    t = _as_nt(t)
+    z = lambda a: None if (a is None or a.shape[0] == 0) else a
+    return NT(t.graphs, z(t.ef), z(t.nf), z(t.gf))
+
+
+def padded(t):
+    """The reference's padded batched arrays — ef (DE, PN², B), nf (DN, PN, B), gf (DG, 1, B) — with zeros in the
+    pads (the reference leaves act(bias) junk there; SURVEY §8b 'raw padded arrays')."""
+    t = _as_nt(t)
+    g = t.graphs
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(g.device).cuda_stream
+    out = {}
+    for key, kind, PT in (("ef", 0, g.edge_block_size), ("nf", 1, g.node_block_size)):
+        a = getattr(t, key)
+        if a is None:
+            out[key] = None
+            continue
+        c = _packed(a)
+        R, T, D = c.shape
+        B = R if g.n_graphs == 1 else g.n_graphs
+        p = torch.empty((B, PT, D), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(lib.gnx_pad_features(g._h, kind, c.data_ptr(), D, R, p.data_ptr(), stream))
+        out[key] = _jl(p)
+    gf = t.gf
+    if gf is not None and not _shared_like(g):
+        gf = gf.permute(0, 2, 1)  # (DG, G, 1) → (DG, 1, G)
+    return NT(g, out["ef"], out["nf"], gf)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# layers
+# ------------------------------------------------------------------------------------------------------------
+def _colmajor(w):
+    """(out, in) tensor whose storage is column-major — the bytes of Flux's Dense.weight."""
+    return w.t().contiguous().t()
+
+
+class Dense:
+    """Flux `Dense(in => out, σ)`: weight (out, in) glorot-uniform, bias zeros."""
+
+    def __init__(self, in_dim, out_dim, act="identity", device=None, generator=None):
+        dev = _device(device)
+        s = math.sqrt(6.0 / (in_dim + out_dim)) if in_dim + out_dim > 0 else 0.0
+        w = (torch.rand((in_dim, out_dim), generator=generator) * 2 - 1) * s  # stored transposed → column-major
+        self.weight = w.to(dev).t()
+        self.bias = torch.zeros(out_dim, device=dev)
+        self.act = act
+
+    @classmethod
+    def from_numpy(cls, W, b, act="identity", device=None):
+        self = cls.__new__(cls)
+        dev = _device(device)
+        self.weight = _colmajor(torch.from_numpy(np.asarray(W, dtype=np.float32)).to(dev))
+        self.bias = None if b is None else torch.from_numpy(np.asarray(b, dtype=np.float32)).to(dev)
+        self.act = act if isinstance(act, str) else {v: k for k, v in _lib.ACT.items()}[act]
+        return self
+
+    def _c(self, keep):
+        w = self.weight
+        if w.dim() != 2 or (w.numel() > 0 and (w.stride(0) != 1 or w.stride(1) != w.shape[0])) or w.dtype != torch.float32:
+            w = _colmajor(w.float())
+        keep.append(w)
+        b = self.bias
+        if b is not None:
+            b = b.float().contiguous()
+            keep.append(b)
+        return _lib.Dense(w.data_ptr() if w.numel() else None, None if b is None or b.numel() == 0 else b.data_ptr(),
+                          _lib.ACT[self.act], 0)
+
+
+class LayerNorm:
+    """Flux `LayerNorm(d)`: γ = ones, β = zeros, ε = 1e-5."""
+
+    def __init__(self, d, device=None):
+        dev = _device(device)
+        self.gamma = torch.ones(d, device=dev)
+        self.beta = torch.zeros(d, device=dev)
+
+    def _c(self, keep):
+        g, b = self.gamma.float().contiguous(), self.beta.float().contiguous()
+        keep += [g, b]
+        return _lib.LayerNorm(g.data_ptr(), b.data_ptr())
+
+
+def _pair(in_dims, out_dims):
+    if out_dims is None:
+        in_dims, out_dims = in_dims  # GNBlock((in, out)) ~ `in => out`
+    return tuple(int(d) for d in in_dims), tuple(int(d) for d in out_dims)
+
+
+def _forward_common(x, in_dims):
+    x = _as_nt(x)
+    g, ef, nf, gf = x
+    assert isinstance(g, GNGraphBatch), "x must come from batch()"
+    present = [a for a in (ef, nf, gf) if a is not None]
+    assert present, "ef, nf and gf are all nothing"
+    R = present[0].shape[2]
+    for name, a, d, T in (("ef", ef, in_dims[0], g.n_edges), ("nf", nf, in_dims[1], g.n_nodes), ("gf", gf, in_dims[2], g.n_graphs)):
+        if a is None:
+            assert d == 0, f"{name} is nothing but the layer expects width {d}"
+        else:
+            assert a.shape[0] == d, f"DimensionMismatch: {name} has {a.shape[0]} rows, layer expects {d}"
+            assert a.shape[1] == T and a.shape[2] == R, f"{name} has shape {tuple(a.shape)}, expected (*, {T}, {R})"
+    return g, _packed(ef), _packed(nf), _packed(gf), R
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class GNBlock:
+    """`GNBlock(in => out; dropout=0)` (gnblock.jl:47-61).  `block(x)` = gnblock.jl:63-69 via gnx_block_forward."""
+
+    def __init__(self, in_dims, out_dims=None, dropout=0, device=None, generator=None, act=("identity",) * 3):
+        in_dims, out_dims = _pair(in_dims, out_dims)
+        assert any(d > 0 for d in in_dims)  # gnblock.jl:48
+        assert any(d > 0 for d in out_dims)  # gnblock.jl:49
+        de, dn, dg = in_dims
+        oe, on, og = out_dims
+        self.in_dims, self.out_dims = in_dims, out_dims
+        self.edgefn = Dense(de + 2 * dn + dg, oe, act[0], device, generator)  # gnblock.jl:52,56
+        self.nodefn = Dense(dn + oe + dg, on, act[1], device, generator)      # gnblock.jl:53,57
+        self.graphfn = Dense(on + oe + dg, og, act[2], device, generator)     # gnblock.jl:54,58
+        self.dropout = dropout  # stored, never applied by the forward (gnblock.jl:63-69)
+        self.flags = 0
+
+    def _c(self, keep):
+        p = _lib.BlockParams()
+        p.de, p.dn, p.dg = self.in_dims
+        p.oe, p.on, p.og = self.out_dims
+        p.edgefn, p.nodefn, p.graphfn = self.edgefn._c(keep), self.nodefn._c(keep), self.graphfn._c(keep)
+        return p
+
+    def __call__(self, x, flags=None):
+        g, ef, nf, gf, R = _forward_common(x, self.in_dims)
+        lib = _lib.load()
+        keep = []
+        p = self._c(keep)
+        oe, on, og = self.out_dims
+        dev = g.device
+        mk = lambda T, d: torch.empty((R, T, d), dtype=torch.float32, device=dev) if d > 0 else None
+        eo, no, go = mk(g.n_edges, oe), mk(g.n_nodes, on), mk(g.n_graphs, og)
+        with torch.cuda.device(dev):
+            ws = g.workspace(lib.gnx_block_workspace_bytes(g._h, C.byref(p), R))
+            check(lib.gnx_block_forward(g._h, C.byref(p), _ptr(ef), _ptr(nf), _ptr(gf), R, _ptr(eo), _ptr(no), _ptr(go),
+                                        ws.data_ptr(), ws.numel(), self.flags if flags is None else flags,
+                                        torch.cuda.current_stream(dev).cuda_stream))
+        return NT(g, _jl(eo), _jl(no), _jl(go))  # zero-width outputs are None (gnblock.jl:71-78)
+
+
+class GNFeedForward:
+    """gnfeedforward.jl:17-40: per entity `Chain(Dense(d => 4d, relu), Dense(4d => d), Dropout(p))`."""
+
+    def __init__(self, dims, dropout=0, device=None, generator=None):
+        assert all(d > 0 for d in dims)  # gnfeedforward.jl:18
+        mk = lambda d: (Dense(d, 4 * d, "relu", device, generator), Dense(4 * d, d, "identity", device, generator))
+        self.eff, self.nff, self.gff = mk(dims[0]), mk(dims[1]), mk(dims[2])
+        self.dropout = dropout
+
+
+class GNGraphNorm:
+    """gngraphnorm.jl:9-17."""
+
+    def __init__(self, dims, device=None):
+        assert all(d > 0 for d in dims)  # gngraphnorm.jl:10
+        self.edgeln, self.nodeln, self.graphln = (LayerNorm(d, device) for d in dims)
+
+
+class GNCore:
+    """`GNCore(dims; dropout=0)` (gncore.jl:46-54): `core(x) = x + block(gn1(x)) + ffwd(gn2(x))` (gncore.jl:56-59)
+    via gnx_core_forward.  Inference semantics: Dropout is the identity (Flux test mode).
+    `eps_mode` 0 = Flux 0.14 `normalise` (x-μ)/(σ+ε); 1 = (x-μ)/sqrt(σ²+ε)."""
+
+    def __init__(self, dims, dropout=0, device=None, generator=None, eps=1e-5, eps_mode=0):
+        dims = tuple(int(d) for d in dims)
+        assert any(d > 0 for d in dims)  # gncore.jl:47
+        self.dims = dims
+        self.block = GNBlock(dims, dims, dropout=dropout, device=device, generator=generator)
+        self.ffwd = GNFeedForward(dims, dropout=dropout, device=device, generator=generator)
+        self.gn1 = GNGraphNorm(dims, device)
+        self.gn2 = GNGraphNorm(dims, device)
+        self.eps, self.eps_mode = eps, eps_mode
+        self.flags = 0
+
+    def _c(self, keep):
+        p = _lib.CoreParams()
+        p.block = self.block._c(keep)
+        for i, (l1, l2, ff) in enumerate(zip((self.gn1.edgeln, self.gn1.nodeln, self.gn1.graphln),
+                                             (self.gn2.edgeln, self.gn2.nodeln, self.gn2.graphln),
+                                             (self.ffwd.eff, self.ffwd.nff, self.ffwd.gff))):
+            p.ln1[i], p.ln2[i] = l1._c(keep), l2._c(keep)
+            p.ff[i].fc1, p.ff[i].fc2 = ff[0]._c(keep), ff[1]._c(keep)
+        p.eps, p.eps_mode = self.eps, self.eps_mode
+        return p
+
+    def __call__(self, x, flags=None):
+        x = _as_nt(x)
+        assert x.ef is not None and x.nf is not None and x.gf is not None, "GNCore needs ef, nf and gf (gncore.jl:61-68)"
+        g, ef, nf, gf, R = _forward_common(x, self.dims)
+        lib = _lib.load()
+        keep = []
+        p = self._c(keep)
+        dev = g.device
+        eo, no, go = torch.empty_like(ef), torch.empty_like(nf), torch.empty_like(gf)
+        with torch.cuda.device(dev):
+            ws = g.workspace(lib.gnx_core_workspace_bytes(g._h, C.byref(p), R))
+            check(lib.gnx_core_forward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), R, eo.data_ptr(),
+                                       no.data_ptr(), go.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       self.flags if flags is None else flags, torch.cuda.current_stream(dev).cuda_stream))
+        return NT(g, _jl(eo), _jl(no), _jl(go))
+
+
+class GNCoreList:
+    """`GNCoreList(list)` (gncorelist.jl:37-45): left fold of the cores over x."""
+
+    def __init__(self, cores):
+        self.list = list(cores)
+
+    def __call__(self, x):
+        for fn in self.list:
+            x = fn(x)
+        return x

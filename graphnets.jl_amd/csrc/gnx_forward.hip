@@ -1,0 +1,189 @@
+// C-ABI entry points of the forward path: argument validation (mirroring the reference's assertions), workspace
+// carving and kernel-path selection.  No allocation and no synchronisation happens here, so every call is
+// asynchronous on the caller's stream and can be captured into a hipGraph.
+#include "gnx_device.h"
+
+namespace gnx {
+
+// implemented in gnx_generic.hip / gnx_narrow.hip / gnx_wide.hip
+int32_t launch_block_generic(const BlockArgs& a, int64_t R, int tile_n_cap, hipStream_t s);
+int32_t launch_graph(const BlockArgs& a, int64_t R, hipStream_t s);
+int32_t launch_layernorm2(const float* x, size_t rows, int d, const gnx_layernorm& l1, const gnx_layernorm& l2, float eps,
+                          int eps_mode, float* y1, float* y2, hipStream_t s);
+int32_t launch_ffn_residual(const float* z, const float* x, size_t rows, int d, const gnx_ffn& ff, float* out, hipStream_t s);
+int32_t launch_pad(const gnx_graphs* h, int kind, bool pad, const float* src, int d, int64_t R, float* dst, hipStream_t s);
+// returns 1 when the path does not apply to these dims (caller falls through to the next path)
+int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s);
+int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s);
+size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R);
+
+static int32_t check_block(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
+  if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
+  if (R <= 0) return fail(GNX_ERR_INVALID_ARG, "n_replicas must be >= 1");
+  if (R > 1 && h->G != 1)
+    return fail(GNX_ERR_INVALID_ARG, "n_replicas > 1 needs a single-graph handle (shared adjacency, batch.jl:66)");
+  if (R > 65535) return fail(GNX_ERR_TOO_LARGE, "n_replicas exceeds the grid limit (65535)");
+  const int d[6] = {p->de, p->dn, p->dg, p->oe, p->on, p->og};
+  for (int i = 0; i < 6; ++i)
+    if (d[i] < 0) return fail(GNX_ERR_DIMS, "negative feature width");
+  if (p->de + p->dn + p->dg == 0) return fail(GNX_ERR_DIMS, "all input widths are 0 (gnblock.jl:48, batch.jl:56)");
+  if (p->oe + p->on + p->og == 0) return fail(GNX_ERR_DIMS, "all output widths are 0 (gnblock.jl:49)");
+  const gnx_dense* fn[3] = {&p->edgefn, &p->nodefn, &p->graphfn};
+  const int out[3] = {p->oe, p->on, p->og};
+  const int in[3] = {p->de + 2 * p->dn + p->dg, p->oe + p->dn + p->dg, p->oe + p->on + p->dg};
+  for (int i = 0; i < 3; ++i) {
+    if (out[i] > 0 && in[i] > 0 && !fn[i]->weight) return fail(GNX_ERR_INVALID_ARG, "Dense weight is NULL");
+    if (fn[i]->act < GNX_ACT_IDENTITY || fn[i]->act > GNX_ACT_GELU) return fail(GNX_ERR_INVALID_ARG, "unknown activation");
+  }
+  return GNX_OK;
+}
+
+struct BlockWs {
+  size_t agg_off, part_off, total;
+};
+
+static BlockWs block_ws(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
+  BlockWs w;
+  w.agg_off = 0;
+  const size_t agg = align_up(sizeof(float) * (size_t)R * h->N * p->oe, 256);
+  w.part_off = agg;
+  const size_t part = align_up(sizeof(float) * (size_t)R * h->n_tiles() * (p->oe + p->on), 256);
+  w.total = agg + part + 256;
+  return w;
+}
+
+static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf,
+                                  const float* gf, int64_t R, float* ef_out, float* nf_out, float* gf_out, void* ws,
+                                  size_t ws_bytes, uint32_t flags, hipStream_t s) {
+  int32_t rc = check_block(h, p, R);
+  if (rc) return rc;
+  if ((p->de > 0 && !ef) || (p->dn > 0 && !nf) || (p->dg > 0 && !gf))
+    return fail(GNX_ERR_INVALID_ARG, "an input with non-zero width is NULL (width 0 <=> nothing)");
+  if ((p->oe > 0 && !ef_out) || (p->on > 0 && !nf_out) || (p->og > 0 && !gf_out))
+    return fail(GNX_ERR_INVALID_ARG, "an output with non-zero width is NULL");
+  const BlockWs w = block_ws(h, p, R);
+  if (!ws || ws_bytes < w.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_block_workspace_bytes()");
+  if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");
+
+  BlockArgs a;
+  a.de = p->de; a.dn = p->dn; a.dg = p->dg;
+  a.oe = p->oe; a.on = p->on; a.og = p->og;
+  a.We = p->edgefn.weight; a.be = p->edgefn.bias; a.act_e = p->edgefn.act;
+  a.Wn = p->nodefn.weight; a.bn = p->nodefn.bias; a.act_n = p->nodefn.act;
+  a.Wg = p->graphfn.weight; a.bg = p->graphfn.bias; a.act_g = p->graphfn.act;
+  a.ef = p->de ? ef : nullptr; a.nf = p->dn ? nf : nullptr; a.gf = p->dg ? gf : nullptr;
+  a.ef_out = ef_out; a.nf_out = nf_out; a.gf_out = gf_out;
+  a.agg = reinterpret_cast<float*>(static_cast<char*>(ws) + w.agg_off);
+  a.partials = reinterpret_cast<float*>(static_cast<char*>(ws) + w.part_off);
+  a.colptr = h->d_colptr; a.rowval = h->d_rowval; a.node_off = h->d_node_off; a.edge_off = h->d_edge_off;
+  a.tile_off = h->d_tile_off; a.tiles = h->d_tiles;
+  a.N = (int)h->N; a.E = (int)h->E; a.G = (int)h->G; a.n_tiles = (int)h->n_tiles();
+
+  if (!(flags & GNX_FLAG_FORCE_GENERIC)) {
+    if (!(flags & GNX_FLAG_NO_MFMA)) {
+      rc = launch_block_wide(h, a, R, s);
+      if (rc != 1) return rc;
+    }
+    rc = launch_block_narrow(h, a, R, s);
+    if (rc != 1) return rc;
+  }
+  return launch_block_generic(a, R, h->tile_n_cap, s);
+}
+
+}  // namespace gnx
+
+using namespace gnx;
+
+extern "C" {
+
+size_t gnx_block_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
+  if (!h || !p || R <= 0) return 0;
+  return block_ws(h, p, R).total;
+}
+
+int32_t gnx_block_forward(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf, const float* gf,
+                          int64_t R, float* ef_out, float* nf_out, float* gf_out, void* ws, size_t ws_bytes, uint32_t flags,
+                          void* stream) {
+  return block_forward_impl(h, p, ef, nf, gf, R, ef_out, nf_out, gf_out, ws, ws_bytes, flags, (hipStream_t)stream);
+}
+
+// workspace of a core: LN1 and LN2 outputs for edges, nodes, graphs, then the block workspace
+static void core_ws(const gnx_graphs* h, const gnx_core_params* p, int64_t R, size_t off[7], size_t* total) {
+  const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
+  const int d[3] = {p->block.de, p->block.dn, p->block.dg};
+  size_t o = 0;
+  for (int t = 0; t < 3; ++t) {
+    off[2 * t] = o; o += align_up(sizeof(float) * rows[t] * d[t], 256);
+    off[2 * t + 1] = o; o += align_up(sizeof(float) * rows[t] * d[t], 256);
+  }
+  off[6] = o;
+  *total = o + block_ws(h, &p->block, R).total;
+}
+
+size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t R) {
+  if (!h || !p || R <= 0) return 0;
+  size_t off[7], total;
+  core_ws(h, p, R, off, &total);
+  return total;
+}
+
+int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf, const float* gf,
+                         int64_t R, float* ef_out, float* nf_out, float* gf_out, void* ws, size_t ws_bytes, uint32_t flags,
+                         void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
+  const gnx_block_params& b = p->block;
+  // GNFeedForward / GNGraphNorm need all three widths > 0 and graphnetadd needs all three present
+  // (gnfeedforward.jl:18, gngraphnorm.jl:10, gncore.jl:61-68); the block maps dims => dims (gncore.jl:49).
+  if (b.de <= 0 || b.dn <= 0 || b.dg <= 0) return fail(GNX_ERR_DIMS, "GNCore needs all(dims .> 0) (gnfeedforward.jl:18)");
+  if (b.oe != b.de || b.on != b.dn || b.og != b.dg) return fail(GNX_ERR_DIMS, "GNCore's block must map dims => dims (gncore.jl:49)");
+  int32_t rc = check_block(h, &b, R);
+  if (rc) return rc;
+  if (!ef || !nf || !gf || !ef_out || !nf_out || !gf_out) return fail(GNX_ERR_INVALID_ARG, "GNCore needs ef, nf, gf and all outputs");
+  for (int t = 0; t < 3; ++t) {
+    if (!p->ln1[t].gamma || !p->ln1[t].beta || !p->ln2[t].gamma || !p->ln2[t].beta) return fail(GNX_ERR_INVALID_ARG, "LayerNorm parameter is NULL");
+    if (!p->ff[t].fc1.weight || !p->ff[t].fc2.weight) return fail(GNX_ERR_INVALID_ARG, "FeedForward weight is NULL");
+  }
+  if (p->eps_mode != 0 && p->eps_mode != 1) return fail(GNX_ERR_INVALID_ARG, "eps_mode must be 0 or 1");
+  const int dmax = b.de > b.dn ? (b.de > b.dg ? b.de : b.dg) : (b.dn > b.dg ? b.dn : b.dg);
+  if ((size_t)dmax * 5 * 4 * sizeof(float) > 160 * 1024) return fail(GNX_ERR_DIMS, "GNCore width too large for the generic FFN kernel (5*d*16 B of LDS)");
+  size_t off[7], total;
+  core_ws(h, p, R, off, &total);
+  if (!ws || ws_bytes < total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_core_workspace_bytes()");
+  if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");
+  char* base = static_cast<char*>(ws);
+  const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
+  const int d[3] = {b.de, b.dn, b.dg};
+  const float* x[3] = {ef, nf, gf};
+  float* out[3] = {ef_out, nf_out, gf_out};
+  float* l1[3];
+  float* l2[3];
+  for (int t = 0; t < 3; ++t) {
+    l1[t] = reinterpret_cast<float*>(base + off[2 * t]);
+    l2[t] = reinterpret_cast<float*>(base + off[2 * t + 1]);
+    if ((rc = launch_layernorm2(x[t], rows[t], d[t], p->ln1[t], p->ln2[t], p->eps, p->eps_mode, l1[t], l2[t], s))) return rc;
+  }
+  rc = block_forward_impl(h, &b, l1[0], l1[1], l1[2], R, out[0], out[1], out[2], base + off[6], ws_bytes - off[6], flags, s);
+  if (rc) return rc;
+  for (int t = 0; t < 3; ++t)
+    if ((rc = launch_ffn_residual(l2[t], x[t], rows[t], d[t], p->ff[t], out[t], s))) return rc;
+  return GNX_OK;
+}
+
+static int32_t pad_impl(const gnx_graphs* h, int32_t kind, bool pad, const float* src, int32_t d, int64_t R, float* dst, void* stream) {
+  if (!h || !src || !dst) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  if (kind != 0 && kind != 1) return fail(GNX_ERR_INVALID_ARG, "kind must be 0 (edges) or 1 (nodes)");
+  if (d <= 0 || R <= 0) return fail(GNX_ERR_INVALID_ARG, "d and n_replicas must be >= 1");
+  if (R > 1 && h->G != 1) return fail(GNX_ERR_INVALID_ARG, "n_replicas > 1 needs a single-graph handle");
+  return launch_pad(h, kind, pad, src, d, R, dst, (hipStream_t)stream);
+}
+
+int32_t gnx_pad_features(const gnx_graphs* h, int32_t kind, const float* packed, int32_t d, int64_t R, float* padded, void* stream) {
+  return pad_impl(h, kind, true, packed, d, R, padded, stream);
+}
+
+int32_t gnx_unpad_features(const gnx_graphs* h, int32_t kind, const float* padded, int32_t d, int64_t R, float* packed, void* stream) {
+  return pad_impl(h, kind, false, padded, d, R, packed, stream);
+}
+
+}  // extern "C"

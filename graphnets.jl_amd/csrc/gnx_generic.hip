@@ -1,0 +1,305 @@
+// Dimension-generic kernels (any DE/DN/DG/DE'/DN'/DG', any activation): the always-available HIP path and the
+// cross-check for the specialised kernels.  Lanes run along the feature dimension so that global reads/writes of
+// feature rows are coalesced; every reduction has a fixed order (no atomics) so results are bitwise reproducible.
+//
+// Reference semantics: src/edgefninput.jl:1-47, src/nodefninput.jl:1-24, src/graphfninput.jl:1-13,
+// src/gnblock.jl:63-69, src/gngraphnorm.jl:19-26, src/gnfeedforward.jl:27-40, src/gncore.jl:56-68.
+#include "gnx_device.h"
+
+namespace gnx {
+
+// ---------------------------------------------------------------------------------------------------------
+// edge update: ef'[e] = act(We * [ef_e ; nf_src ; nf_dst ; gf_g] + be)          one workgroup per (tile, replica)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edge_generic(BlockArgs a) {
+  extern __shared__ int s_cp[];
+  const Tile t = a.tiles[blockIdx.x];
+  const size_t r = blockIdx.y;
+  const int nn = t.n1 - t.n0;
+  for (int i = threadIdx.x; i <= nn; i += blockDim.x) s_cp[i] = a.colptr[t.n0 + i];
+  __syncthreads();
+  const float* ef = a.ef ? a.ef + r * (size_t)a.E * a.de : nullptr;
+  const float* nf = a.nf ? a.nf + r * (size_t)a.N * a.dn : nullptr;
+  const float* gf = a.gf ? a.gf + (r * (size_t)a.G + t.g) * a.dg : nullptr;
+  float* out = a.ef_out + r * (size_t)a.E * a.oe;
+  const int oe = a.oe;
+  const int total = (t.e1 - t.e0) * oe;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int el = idx / oe, j = idx - el * oe;
+    const int e = t.e0 + el;
+    float acc = a.be ? a.be[j] : 0.f;
+    const float* w = a.We + j;
+    if (a.de) {
+      const float* x = ef + (size_t)e * a.de;
+      for (int k = 0; k < a.de; ++k, w += oe) acc = fmaf(*w, x[k], acc);
+    }
+    if (a.dn) {
+      const float* xs = nf + (size_t)a.rowval[e] * a.dn;
+      for (int k = 0; k < a.dn; ++k, w += oe) acc = fmaf(*w, xs[k], acc);
+      const float* xd = nf + (size_t)(t.n0 + segment_of(s_cp, nn, e)) * a.dn;
+      for (int k = 0; k < a.dn; ++k, w += oe) acc = fmaf(*w, xd[k], acc);
+    }
+    for (int k = 0; k < a.dg; ++k, w += oe) acc = fmaf(*w, gf[k], acc);
+    out[(size_t)e * oe + j] = act_apply(acc, a.act_e);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// node update: agg[n] = sum_{e->n} ef'[e];  nf'[n] = act(Wn * [agg_n ; nf_n ; gf_g] + bn);  per-tile partial sums
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_node_generic(BlockArgs a) {
+  const Tile t = a.tiles[blockIdx.x];
+  const size_t r = blockIdx.y;
+  const int nn = t.n1 - t.n0;
+  const int oe = a.oe, on = a.on;
+  const float* efo = a.ef_out + r * (size_t)a.E * oe;
+  float* agg = a.agg + (r * (size_t)a.N + t.n0) * oe;
+  // phase 1: contiguous segmented sums (edges are dst-sorted, src/pad.jl:30)
+  for (int idx = threadIdx.x; idx < nn * oe; idx += blockDim.x) {
+    const int n = idx / oe, k = idx - n * oe;
+    float s = 0.f;
+    const int e1 = a.colptr[t.n0 + n + 1];
+    for (int e = a.colptr[t.n0 + n]; e < e1; ++e) s += efo[(size_t)e * oe + k];
+    agg[(size_t)n * oe + k] = s;
+  }
+  __syncthreads();
+  const float* nf = a.nf ? a.nf + (r * (size_t)a.N + t.n0) * a.dn : nullptr;
+  const float* gf = a.gf ? a.gf + (r * (size_t)a.G + t.g) * a.dg : nullptr;
+  float* nfo = a.nf_out + (r * (size_t)a.N + t.n0) * on;
+  for (int idx = threadIdx.x; idx < nn * on; idx += blockDim.x) {
+    const int n = idx / on, j = idx - n * on;
+    float acc = a.bn ? a.bn[j] : 0.f;
+    const float* w = a.Wn + j;
+    const float* x = agg + (size_t)n * oe;
+    for (int k = 0; k < oe; ++k, w += on) acc = fmaf(*w, x[k], acc);
+    if (a.dn) {
+      const float* xn = nf + (size_t)n * a.dn;
+      for (int k = 0; k < a.dn; ++k, w += on) acc = fmaf(*w, xn[k], acc);
+    }
+    for (int k = 0; k < a.dg; ++k, w += on) acc = fmaf(*w, gf[k], acc);
+    nfo[(size_t)n * on + j] = act_apply(acc, a.act_n);
+  }
+  if (a.og == 0) return;
+  __syncthreads();
+  // phase 3: this tile's contribution to the graph-level sums, fixed order over the tile's nodes
+  float* part = a.partials + (r * (size_t)a.n_tiles + blockIdx.x) * (oe + on);
+  for (int c = threadIdx.x; c < oe + on; c += blockDim.x) {
+    float s = 0.f;
+    if (c < oe) {
+      for (int n = 0; n < nn; ++n) s += agg[(size_t)n * oe + c];
+    } else {
+      for (int n = 0; n < nn; ++n) s += nfo[(size_t)n * on + (c - oe)];
+    }
+    part[c] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// graph update: gf'[g] = act(Wg * [sum_e ef' ; sum_n nf' ; gf_g] + bg)         one workgroup per (graph, replica)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_graph(BlockArgs a) {
+  extern __shared__ float s_f[];
+  const int g = blockIdx.x;
+  const size_t r = blockIdx.y;
+  const int C = a.oe + a.on;
+  const int t0 = a.tile_off[g], t1 = a.tile_off[g + 1];
+  const int cpp = C < 256 ? C : 256;           // columns per pass
+  const int nsl = cpp > 0 ? 256 / cpp : 1;     // tile slices summed in parallel
+  float* s_part = s_f;                         // [nsl][C]
+  float* s_x = s_f + (size_t)nsl * C;          // [C + dg]
+  const float* part = a.partials + r * (size_t)a.n_tiles * C;
+  if (cpp > 0) {
+    const int sl = threadIdx.x / cpp, cc = threadIdx.x - sl * cpp;
+    if (sl < nsl) {
+      for (int c = cc; c < C; c += cpp) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // 4 independent chains, combined in a fixed order
+        int ti = t0 + sl;
+        for (; ti + 3 * nsl < t1; ti += 4 * nsl) {
+          s0 += part[(size_t)ti * C + c];
+          s1 += part[(size_t)(ti + nsl) * C + c];
+          s2 += part[(size_t)(ti + 2 * nsl) * C + c];
+          s3 += part[(size_t)(ti + 3 * nsl) * C + c];
+        }
+        for (; ti < t1; ti += nsl) s0 += part[(size_t)ti * C + c];
+        s_part[(size_t)sl * C + c] = (s0 + s1) + (s2 + s3);
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int sl = 0; sl < nsl; ++sl) s += s_part[(size_t)sl * C + c];
+    s_x[c] = s;
+  }
+  const float* gf = a.gf ? a.gf + (r * (size_t)a.G + g) * a.dg : nullptr;
+  for (int k = threadIdx.x; k < a.dg; k += blockDim.x) s_x[C + k] = gf[k];
+  __syncthreads();
+  const int K = C + a.dg, og = a.og;
+  float* out = a.gf_out + (r * (size_t)a.G + g) * og;
+  for (int j = threadIdx.x; j < og; j += blockDim.x) {
+    float acc = a.bg ? a.bg[j] : 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(a.Wg[(size_t)k * og + j], s_x[k], acc);
+    out[j] = act_apply(acc, a.act_g);
+  }
+}
+
+size_t graph_kernel_lds_bytes(int oe, int on, int dg) {
+  const int C = oe + on;
+  const int cpp = C < 256 ? C : 256;
+  const int nsl = cpp > 0 ? 256 / cpp : 1;
+  return sizeof(float) * ((size_t)nsl * C + C + dg + 1);
+}
+
+int32_t launch_graph(const BlockArgs& a, int64_t R, hipStream_t s) {
+  if (a.og == 0) return GNX_OK;
+  ProfScope ps("k_graph", s);
+  hipLaunchKernelGGL(k_graph, dim3((unsigned)a.G, (unsigned)R), dim3(256), graph_kernel_lds_bytes(a.oe, a.on, a.dg), s, a);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+int32_t launch_block_generic(const BlockArgs& a, int64_t R, int tile_n_cap, hipStream_t s) {
+  const dim3 grid((unsigned)a.n_tiles, (unsigned)R);
+  if (a.oe > 0 && a.E > 0) {
+    ProfScope ps("k_edge_generic", s);
+    hipLaunchKernelGGL(k_edge_generic, grid, dim3(256), sizeof(int) * (size_t)(tile_n_cap + 1), s, a);
+    GNX_HIP(hipGetLastError());
+  }
+  {
+    ProfScope ps("k_node_generic", s);
+    hipLaunchKernelGGL(k_node_generic, grid, dim3(256), 0, s, a);
+    GNX_HIP(hipGetLastError());
+  }
+  return launch_graph(a, R, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GNCore pieces (generic): two LayerNorms sharing statistics, and FFN + residual
+// ---------------------------------------------------------------------------------------------------------
+// One wave per row.  y1 = g1*xhat+b1, y2 = g2*xhat+b2 (gn1 and gn2 normalise the same x, gncore.jl:56-59).
+__global__ __launch_bounds__(256) void k_layernorm2(const float* __restrict__ x, size_t rows, int d, const float* g1,
+                                                    const float* b1, const float* g2, const float* b2, float eps,
+                                                    int eps_mode, float* __restrict__ y1, float* __restrict__ y2) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * d;
+  float s = 0.f;
+  for (int k = lane; k < d; k += 64) s += xr[k];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mu = s / (float)d;
+  float v = 0.f;
+  for (int k = lane; k < d; k += 64) { const float c = xr[k] - mu; v = fmaf(c, c, v); }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v /= (float)d;
+  const float inv = eps_mode == 0 ? 1.f / (sqrtf(v) + eps) : 1.f / sqrtf(v + eps);
+  for (int k = lane; k < d; k += 64) {
+    const float xh = (xr[k] - mu) * inv;
+    y1[row * d + k] = fmaf(g1[k], xh, b1[k]);
+    y2[row * d + k] = fmaf(g2[k], xh, b2[k]);
+  }
+}
+
+// One wave per row: out[row] += x[row] + W2*relu(W1*z[row]+b1)+b2  (z = LN2(x); out already holds block(LN1 x)).
+__global__ __launch_bounds__(256) void k_ffn_residual(const float* __restrict__ z, const float* __restrict__ x,
+                                                      size_t rows, int d, gnx_dense fc1, gnx_dense fc2,
+                                                      float* __restrict__ out) {
+  extern __shared__ float s_f[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t row = (size_t)blockIdx.x * 4 + wv;
+  if (row >= rows) return;
+  const int h = 4 * d;
+  float* s_z = s_f + (size_t)wv * (d + h);
+  float* s_h = s_z + d;
+  for (int k = lane; k < d; k += 64) s_z[k] = z[row * d + k];
+  __builtin_amdgcn_wave_barrier();
+  for (int j = lane; j < h; j += 64) {
+    float acc = fc1.bias ? fc1.bias[j] : 0.f;
+    for (int k = 0; k < d; ++k) acc = fmaf(fc1.weight[(size_t)k * h + j], s_z[k], acc);
+    s_h[j] = act_apply(acc, fc1.act);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int j = lane; j < d; j += 64) {
+    float acc = fc2.bias ? fc2.bias[j] : 0.f;
+    for (int k = 0; k < h; ++k) acc = fmaf(fc2.weight[(size_t)k * d + j], s_h[k], acc);
+    out[row * d + j] += x[row * d + j] + act_apply(acc, fc2.act);
+  }
+}
+
+int32_t launch_layernorm2(const float* x, size_t rows, int d, const gnx_layernorm& l1, const gnx_layernorm& l2, float eps,
+                          int eps_mode, float* y1, float* y2, hipStream_t s) {
+  if (rows == 0 || d == 0) return GNX_OK;
+  ProfScope ps("k_layernorm2", s);
+  hipLaunchKernelGGL(k_layernorm2, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, d, l1.gamma, l1.beta, l2.gamma,
+                     l2.beta, eps, eps_mode, y1, y2);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+int32_t launch_ffn_residual(const float* z, const float* x, size_t rows, int d, const gnx_ffn& ff, float* out, hipStream_t s) {
+  if (rows == 0 || d == 0) return GNX_OK;
+  ProfScope ps("k_ffn_residual", s);
+  hipLaunchKernelGGL(k_ffn_residual, dim3((unsigned)((rows + 3) / 4)), dim3(256), sizeof(float) * 4 * (size_t)(5 * d), s, z, x, rows,
+                     d, ff.fc1, ff.fc2, out);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// reference-layout bridges (src/pad.jl:12-64, src/unpad.jl:1-17)
+// ---------------------------------------------------------------------------------------------------------
+// edges: slot = src_local + PN * dst_local inside graph g's PN^2 grid (column-major, adjacency padded to PN).
+template <bool PAD>
+__global__ void k_pad_edges(const int* colptr, const int* rowval, const int* node_off, int N, int E, int G, int PN, int d,
+                            int64_t R, const float* src, float* dst) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)R * E * d;
+  if (idx >= total) return;
+  const int k = (int)(idx % d);
+  const size_t re = idx / d;
+  const int e = (int)(re % E);
+  const size_t r = re / E;
+  const int n = segment_of(colptr, N, e);
+  const int g = segment_of(node_off, G, n);
+  const int base = node_off[g];
+  const size_t slot = (size_t)(rowval[e] - base) + (size_t)PN * (n - base);
+  const size_t b = G == 1 ? r : (size_t)g;
+  const size_t pidx = (b * PN * PN + slot) * d + k;
+  if (PAD) dst[pidx] = src[idx]; else dst[idx] = src[pidx];
+}
+
+template <bool PAD>
+__global__ void k_pad_nodes(const int* node_off, int N, int G, int PN, int d, int64_t R, const float* src, float* dst) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)R * N * d;
+  if (idx >= total) return;
+  const int k = (int)(idx % d);
+  const size_t rn = idx / d;
+  const int n = (int)(rn % N);
+  const size_t r = rn / N;
+  const int g = segment_of(node_off, G, n);
+  const size_t b = G == 1 ? r : (size_t)g;
+  const size_t pidx = (b * PN + (n - node_off[g])) * d + k;
+  if (PAD) dst[pidx] = src[idx]; else dst[idx] = src[pidx];
+}
+
+int32_t launch_pad(const gnx_graphs* h, int kind, bool pad, const float* src, int d, int64_t R, float* dst, hipStream_t s) {
+  const size_t B = h->G == 1 ? (size_t)R : (size_t)h->G;
+  const size_t T = kind == 0 ? (size_t)h->E : (size_t)h->N;
+  const size_t PT = kind == 0 ? (size_t)h->PN * h->PN : (size_t)h->PN;
+  if (pad) GNX_HIP(hipMemsetAsync(dst, 0, B * PT * d * sizeof(float), s));
+  const size_t total = (size_t)R * T * d;
+  if (total == 0) return GNX_OK;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (kind == 0) {
+    if (pad) hipLaunchKernelGGL(k_pad_edges<true>, dim3(grid), dim3(256), 0, s, h->d_colptr, h->d_rowval, h->d_node_off, (int)h->N, (int)h->E, (int)h->G, (int)h->PN, d, R, src, dst);
+    else hipLaunchKernelGGL(k_pad_edges<false>, dim3(grid), dim3(256), 0, s, h->d_colptr, h->d_rowval, h->d_node_off, (int)h->N, (int)h->E, (int)h->G, (int)h->PN, d, R, src, dst);
+  } else {
+    if (pad) hipLaunchKernelGGL(k_pad_nodes<true>, dim3(grid), dim3(256), 0, s, h->d_node_off, (int)h->N, (int)h->G, (int)h->PN, d, R, src, dst);
+    else hipLaunchKernelGGL(k_pad_nodes<false>, dim3(grid), dim3(256), 0, s, h->d_node_off, (int)h->N, (int)h->G, (int)h->PN, d, R, src, dst);
+  }
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+}  // namespace gnx

@@ -1,0 +1,245 @@
+// Graph-batch handles: the MI355X-side replacement of GNGraphBatch (reference src/gngraphbatch.jl:33-54).
+// The reference precomputes seven dense one-hot "broadcaster" tensors over a padded PN^2 edge grid; here the same
+// index semantics are held as CSC (colptr/rowval), per-graph offsets and a tile table, all int32 in HBM.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "gnx_internal.h"
+
+namespace gnx {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int32_t fail(int32_t code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+int32_t hip_fail(hipError_t e, const char* what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  (void)hipGetLastError();
+  return (int32_t)e > 0 ? (int32_t)e : 1;
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  int x = atoi(v);
+  return x > 0 ? x : dflt;
+}
+
+template <typename T>
+static inline int adj_value(const void* base, int64_t idx, bool* ok) {
+  T v = reinterpret_cast<const T*>(base)[idx];
+  if (v == (T)0) return 0;
+  if (v == (T)1) return 1;
+  *ok = false;
+  return 0;
+}
+
+static int adj_at(const void* base, int32_t kind, int64_t idx, bool* ok) {
+  switch (kind) {
+    case GNX_ELEM_U8: return adj_value<uint8_t>(base, idx, ok);
+    case GNX_ELEM_I32: return adj_value<int32_t>(base, idx, ok);
+    case GNX_ELEM_I64: return adj_value<int64_t>(base, idx, ok);
+    case GNX_ELEM_F32: return adj_value<float>(base, idx, ok);
+    case GNX_ELEM_F64: return adj_value<double>(base, idx, ok);
+    default: *ok = false; return 0;
+  }
+}
+
+// Build tiles, upload, finish the handle.  h_colptr / h_rowval (global) / h_node_off / h_edge_off are filled.
+static int32_t finalize(gnx_graphs* h) {
+  if (h->N >= (int64_t)INT32_MAX || h->E >= (int64_t)INT32_MAX)
+    return fail(GNX_ERR_TOO_LARGE, "graph batch exceeds int32 device indices");
+  GNX_HIP(hipGetDevice(&h->device));
+  h->tile_e_cap = env_int("GNX_TILE_E", 512);
+  h->tile_n_cap = env_int("GNX_TILE_N", 128);
+  // greedy tiling inside each graph: add nodes while edges <= cap and nodes <= cap; a node whose in-degree
+  // exceeds the cap becomes a single-node tile (kernels loop over its edges).
+  h->h_tile_off.assign(h->G + 1, 0);
+  h->max_in_degree = 0;
+  for (int64_t g = 0; g < h->G; ++g) {
+    h->h_tile_off[g] = (int32_t)h->h_tiles.size();
+    int64_t n = h->h_node_off[g];
+    const int64_t nend = h->h_node_off[g + 1];
+    while (n < nend) {
+      int64_t n1 = n;
+      const int64_t e0 = h->h_colptr[n];
+      while (n1 < nend && (n1 - n) < h->tile_n_cap) {
+        const int64_t deg = h->h_colptr[n1 + 1] - h->h_colptr[n1];
+        h->max_in_degree = std::max(h->max_in_degree, deg);
+        if (n1 > n && h->h_colptr[n1 + 1] - e0 > h->tile_e_cap) break;
+        ++n1;
+      }
+      gnx::Tile t;
+      t.n0 = (int32_t)n; t.n1 = (int32_t)n1;
+      t.e0 = (int32_t)e0; t.e1 = (int32_t)h->h_colptr[n1];
+      t.g = (int32_t)g;
+      t.win0 = (int32_t)h->h_node_off[g]; t.win1 = (int32_t)nend;
+      t.flags = 0;
+      h->h_tiles.push_back(t);
+      n = n1;
+    }
+  }
+  h->h_tile_off[h->G] = (int32_t)h->h_tiles.size();
+
+  auto upload32 = [&](const std::vector<int64_t>& src, int32_t** dst) -> int32_t {
+    std::vector<int32_t> tmp(src.size());
+    for (size_t i = 0; i < src.size(); ++i) tmp[i] = (int32_t)src[i];
+    GNX_HIP(hipMalloc((void**)dst, std::max<size_t>(tmp.size(), 1) * sizeof(int32_t)));
+    if (!tmp.empty()) GNX_HIP(hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return GNX_OK;
+  };
+  int32_t rc;
+  if ((rc = upload32(h->h_colptr, &h->d_colptr))) return rc;
+  if ((rc = upload32(h->h_rowval, &h->d_rowval))) return rc;
+  if ((rc = upload32(h->h_node_off, &h->d_node_off))) return rc;
+  if ((rc = upload32(h->h_edge_off, &h->d_edge_off))) return rc;
+  GNX_HIP(hipMalloc((void**)&h->d_tile_off, h->h_tile_off.size() * sizeof(int32_t)));
+  GNX_HIP(hipMemcpy(h->d_tile_off, h->h_tile_off.data(), h->h_tile_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  GNX_HIP(hipMalloc((void**)&h->d_tiles, std::max<size_t>(h->h_tiles.size(), 1) * sizeof(gnx::Tile)));
+  if (!h->h_tiles.empty())
+    GNX_HIP(hipMemcpy(h->d_tiles, h->h_tiles.data(), h->h_tiles.size() * sizeof(gnx::Tile), hipMemcpyHostToDevice));
+  return GNX_OK;
+}
+
+}  // namespace gnx
+
+using namespace gnx;
+
+extern "C" {
+
+int32_t gnx_version(void) { return GNX_VERSION; }
+const char* gnx_last_error(void) { return g_last_error.c_str(); }
+
+int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n_nodes, int64_t n_graphs, int32_t elem_kind,
+                                int32_t row_major, gnx_graphs** out) {
+  if (!out) return fail(GNX_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (n_graphs <= 0) return fail(GNX_ERR_NO_GRAPHS, "length(adj_mats) must be > 0 (checks.jl:8)");
+  if (!adj || !n_nodes) return fail(GNX_ERR_INVALID_ARG, "adj / n_nodes is NULL");
+  if (elem_kind < GNX_ELEM_U8 || elem_kind > GNX_ELEM_F64) return fail(GNX_ERR_INVALID_ARG, "bad elem_kind");
+  gnx_graphs* h = new gnx_graphs();
+  h->G = n_graphs;
+  h->h_node_off.push_back(0);
+  h->h_edge_off.push_back(0);
+  h->h_colptr.push_back(0);
+  for (int64_t g = 0; g < n_graphs; ++g) {
+    const int64_t n = n_nodes[g];
+    if (n <= 0 || !adj[g]) {
+      delete h;
+      return fail(GNX_ERR_ADJ_SHAPE, "adjacency matrix must be N x N with N >= 1 (checks.jl:11)");
+    }
+    h->PN = std::max(h->PN, n);
+    const int64_t base = h->h_node_off.back();
+    bool ok = true;
+    for (int64_t j = 0; j < n; ++j) {      // destination (column) — slowest
+      for (int64_t i = 0; i < n; ++i) {    // source (row)
+        const int64_t idx = row_major ? i * n + j : j * n + i;
+        if (adj_at(adj[g], elem_kind, idx, &ok)) h->h_rowval.push_back(base + i);
+      }
+      h->h_colptr.push_back((int64_t)h->h_rowval.size());
+    }
+    if (!ok) {
+      delete h;
+      return fail(GNX_ERR_ADJ_VALUE, "adjacency entries must be exactly 0 or 1 (pad.jl:30, gngraphbatch.jl:207)");
+    }
+    h->h_node_off.push_back(base + n);
+    h->h_edge_off.push_back((int64_t)h->h_rowval.size());
+  }
+  h->N = h->h_node_off.back();
+  h->E = h->h_edge_off.back();
+  int32_t rc = finalize(h);
+  if (rc) { gnx_graphs_destroy(h); return rc; }
+  *out = h;
+  return GNX_OK;
+}
+
+int32_t gnx_graphs_create_csc(const int64_t* const* colptr, const int64_t* const* rowval, const int64_t* n_nodes,
+                              int64_t n_graphs, int32_t index_base, gnx_graphs** out) {
+  if (!out) return fail(GNX_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (n_graphs <= 0) return fail(GNX_ERR_NO_GRAPHS, "length(adj_mats) must be > 0 (checks.jl:8)");
+  if (!colptr || !rowval || !n_nodes) return fail(GNX_ERR_INVALID_ARG, "colptr / rowval / n_nodes is NULL");
+  if (index_base != 0 && index_base != 1) return fail(GNX_ERR_INVALID_ARG, "index_base must be 0 or 1");
+  gnx_graphs* h = new gnx_graphs();
+  h->G = n_graphs;
+  h->h_node_off.push_back(0);
+  h->h_edge_off.push_back(0);
+  h->h_colptr.push_back(0);
+  for (int64_t g = 0; g < n_graphs; ++g) {
+    const int64_t n = n_nodes[g];
+    if (n <= 0 || !colptr[g]) { delete h; return fail(GNX_ERR_ADJ_SHAPE, "graph must have N >= 1 nodes and a colptr"); }
+    h->PN = std::max(h->PN, n);
+    const int64_t base = h->h_node_off.back(), ebase = h->h_edge_off.back();
+    const int64_t* cp = colptr[g];
+    const int64_t* rv = rowval[g];
+    if (cp[0] != index_base) { delete h; return fail(GNX_ERR_CSC, "colptr[0] must equal index_base"); }
+    for (int64_t j = 0; j < n; ++j) {
+      const int64_t a = cp[j] - index_base, b = cp[j + 1] - index_base;
+      if (b < a || b - a > n) { delete h; return fail(GNX_ERR_CSC, "colptr must be non-decreasing with at most N entries per column"); }
+      if (b > a && !rv) { delete h; return fail(GNX_ERR_CSC, "rowval is NULL but the graph has edges"); }
+      int64_t prev = -1;
+      for (int64_t k = a; k < b; ++k) {
+        const int64_t i = rv[k] - index_base;
+        if (i < 0 || i >= n || i <= prev) { delete h; return fail(GNX_ERR_CSC, "rowval out of range or not strictly increasing inside a column"); }
+        prev = i;
+        h->h_rowval.push_back(base + i);
+      }
+      h->h_colptr.push_back(ebase + b);
+    }
+    h->h_node_off.push_back(base + n);
+    h->h_edge_off.push_back((int64_t)h->h_rowval.size());
+  }
+  h->N = h->h_node_off.back();
+  h->E = h->h_edge_off.back();
+  int32_t rc = finalize(h);
+  if (rc) { gnx_graphs_destroy(h); return rc; }
+  *out = h;
+  return GNX_OK;
+}
+
+int32_t gnx_graphs_destroy(gnx_graphs* h) {
+  if (!h) return GNX_OK;
+  (void)hipFree(h->d_colptr);
+  (void)hipFree(h->d_rowval);
+  (void)hipFree(h->d_node_off);
+  (void)hipFree(h->d_edge_off);
+  (void)hipFree(h->d_tile_off);
+  (void)hipFree(h->d_tiles);
+  (void)hipFree(h->d_pad_edge_slot);
+  delete h;
+  return GNX_OK;
+}
+
+int32_t gnx_graphs_get_info(const gnx_graphs* h, gnx_graphs_info* out) {
+  if (!h || !out) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  out->n_graphs = h->G;
+  out->n_nodes = h->N;
+  out->n_edges = h->E;
+  out->node_block_size = h->PN;
+  out->edge_block_size = h->PN * h->PN;
+  out->n_tiles = h->n_tiles();
+  out->max_in_degree = h->max_in_degree;
+  out->device = h->device;
+  out->reserved = 0;
+  return GNX_OK;
+}
+
+int32_t gnx_graphs_get_offsets(const gnx_graphs* h, int64_t* node_off, int64_t* edge_off) {
+  if (!h) return fail(GNX_ERR_INVALID_ARG, "NULL handle");
+  if (node_off) memcpy(node_off, h->h_node_off.data(), h->h_node_off.size() * sizeof(int64_t));
+  if (edge_off) memcpy(edge_off, h->h_edge_off.data(), h->h_edge_off.size() * sizeof(int64_t));
+  return GNX_OK;
+}
+
+int32_t gnx_graphs_get_csc(const gnx_graphs* h, int64_t* colptr, int64_t* rowval) {
+  if (!h) return fail(GNX_ERR_INVALID_ARG, "NULL handle");
+  if (colptr) memcpy(colptr, h->h_colptr.data(), h->h_colptr.size() * sizeof(int64_t));
+  if (rowval && !h->h_rowval.empty()) memcpy(rowval, h->h_rowval.data(), h->h_rowval.size() * sizeof(int64_t));
+  return GNX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Internal declarations shared by the translation units of libgnx.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "gnx.h"
+
+namespace gnx {
+
+// A work tile: a contiguous node range [n0, n1) of ONE graph and its (contiguous, dst-sorted) in-edges
+// [e0, e1) = [colptr[n0], colptr[n1]).  Because the reference's edge order is CSC order
+// (src/pad.jl:30), every edge->node sum is complete inside its tile: no atomics, fixed summation order.
+struct Tile {
+  int32_t n0, n1;
+  int32_t e0, e1;
+  int32_t g;        // graph id
+  int32_t win0;     // [win0, win1): node window containing every source of the tile's edges = the graph's
+  int32_t win1;     // node range (sources never leave the graph)
+  int32_t flags;
+};
+
+}  // namespace gnx
+
+struct gnx_graphs {
+  int64_t G = 0, N = 0, E = 0, PN = 0;
+  int64_t max_in_degree = 0;
+  int device = 0;
+  // host copies (int64, 0-based, global)
+  std::vector<int64_t> h_node_off, h_edge_off, h_colptr, h_rowval;
+  std::vector<gnx::Tile> h_tiles;
+  std::vector<int32_t> h_tile_off;  // [G+1] tiles of graph g = [tile_off[g], tile_off[g+1])
+  // device copies (int32)
+  int32_t* d_colptr = nullptr;    // [N+1]
+  int32_t* d_rowval = nullptr;    // [E] global source node id
+  int32_t* d_node_off = nullptr;  // [G+1]
+  int32_t* d_edge_off = nullptr;  // [G+1]
+  int32_t* d_tile_off = nullptr;  // [G+1]
+  gnx::Tile* d_tiles = nullptr;   // [n_tiles]
+  int32_t* d_pad_edge_slot = nullptr;  // [E] slot of edge e inside its graph's PN^2 grid (column-major, padded)
+  int32_t tile_e_cap = 0, tile_n_cap = 0;
+  int64_t n_tiles() const { return (int64_t)h_tiles.size(); }
+};
+
+namespace gnx {
+
+void set_error(const std::string& msg);
+int32_t fail(int32_t code, const std::string& msg);
+int32_t hip_fail(hipError_t e, const char* what);
+
+#define GNX_HIP(expr)                                        \
+  do {                                                       \
+    hipError_t _e = (expr);                                  \
+    if (_e != hipSuccess) return gnx::hip_fail(_e, #expr);   \
+  } while (0)
+
+// profiling (gnx_profile.cpp)
+struct ProfScope {
+  ProfScope(const char* name, hipStream_t s);
+  ~ProfScope();
+  int slot;
+  hipStream_t stream;
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace gnx

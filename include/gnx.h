@@ -1,0 +1,182 @@
+/*
+ * gnx.h — C ABI of libgnx.so: MI355X (gfx950) native GNBlock / GNCore forward for GraphNets.jl.
+ *
+ * The reference has no FFI; its boundary for this path is the Julia callable API exported at
+ * src/GraphNets.jl:12-50.  Each entry point below names the reference interface it replaces; the Julia-side
+ * `ccall` binding a maintainer would add is shown in INTEGRATION.md (and shipped in julia/GraphNetsHIP.jl).
+ *
+ * Conventions
+ *   - Every function returns int32 status: 0 = GNX_OK; < 0 = invalid argument (mirrors an `@assert` of the
+ *     reference, src/checks.jl, src/batch.jl:54-56, src/gnblock.jl:48-49); > 0 = a hipError_t value.  A
+ *     message is available from gnx_last_error() (thread-local).  Nothing throws across the ABI.
+ *   - Feature buffers are DEVICE pointers, fp32, packed rows: ef [R][E][DE], nf [R][N][DN], gf [R][G][DG]
+ *     (row-major) — byte-identical to Julia's column-major (D, T, R) arrays and, for vector-of-graphs
+ *     batches (R = 1), to flatunpaddedef / flatunpaddednf (src/views.jl:80-98).  R = number of replicas of
+ *     the graph structure: the data batch size B of a shared-adjacency batch (src/batch.jl:66), 1 otherwise.
+ *     E, N, G are totals over the graphs of the handle.  NULL <=> `nothing`.
+ *   - Edge order inside a graph = order of the ones of vec(A) column-major (src/pad.jl:30): sorted by
+ *     destination j then source i, A[i,j] = 1 meaning i -> j (src/gngraphbatch.jl:194-211).
+ *   - Dense weights are (out x in) column-major = Flux `Dense.weight` bytes: W[k*out + j]; device pointers.
+ *   - The caller owns every buffer; the library owns only gnx_graphs handles.  `stream` is a hipStream_t
+ *     (NULL = default stream); calls are asynchronous on it and hipGraph-capturable (no allocation, no sync).
+ *   - The library uses the calling thread's current HIP device; a handle lives on the device it was created on.
+ */
+#ifndef GNX_H
+#define GNX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNX_VERSION 100 /* 0.1.0 */
+
+#if defined(__GNUC__)
+#define GNX_API __attribute__((visibility("default")))
+#else
+#define GNX_API
+#endif
+
+/* status codes (negative = argument errors, named after the reference assertion they mirror) */
+#define GNX_OK 0
+#define GNX_ERR_INVALID_ARG (-1)   /* NULL where a pointer is required, negative size, bad enum            */
+#define GNX_ERR_NO_GRAPHS (-2)     /* checks.jl:8    @assert length(adj_mats) > 0                           */
+#define GNX_ERR_ADJ_SHAPE (-3)     /* checks.jl:11   adjacency must be square (N x N), N >= 1               */
+#define GNX_ERR_ADJ_VALUE (-4)     /* gngraphbatch.jl:207 / pad.jl:30  entries must be 0 or 1               */
+#define GNX_ERR_ALL_NOTHING (-5)   /* batch.jl:56    ef, nf, gf all `nothing`                               */
+#define GNX_ERR_DIMS (-6)          /* gnblock.jl:48-49, gnfeedforward.jl:18, gngraphnorm.jl:10              */
+#define GNX_ERR_CSC (-7)           /* malformed CSC: colptr not monotone, rowval out of range / unsorted    */
+#define GNX_ERR_WORKSPACE (-8)     /* workspace NULL or smaller than gnx_*_workspace_bytes()                */
+#define GNX_ERR_TOO_LARGE (-9)     /* N or E does not fit the int32 device indices                          */
+#define GNX_ERR_COUNT_MISMATCH (-10) /* checks.jl:41-46 size(ef,2)==num_edges, size(nf,2)==num_nodes        */
+
+/* activations (Flux/NNlib): identity is the GNBlock default (gnblock.jl:55-60); relu is used by FeedForward */
+#define GNX_ACT_IDENTITY 0
+#define GNX_ACT_RELU 1
+#define GNX_ACT_TANH 2
+#define GNX_ACT_SIGMOID 3
+#define GNX_ACT_GELU 4 /* NNlib.gelu (tanh form) */
+
+/* element kinds of dense adjacency input */
+#define GNX_ELEM_U8 0
+#define GNX_ELEM_I32 1
+#define GNX_ELEM_I64 2
+#define GNX_ELEM_F32 3
+#define GNX_ELEM_F64 4
+
+/* forward flags */
+#define GNX_FLAG_FORCE_GENERIC 0x1u /* use the dimension-generic kernels even when a specialised path exists */
+#define GNX_FLAG_NO_MFMA 0x2u       /* never pick the MFMA path                                               */
+
+typedef struct gnx_graphs gnx_graphs; /* opaque; replaces GNGraphBatch (src/gngraphbatch.jl:1-54) */
+
+typedef struct gnx_graphs_info {
+  int64_t n_graphs;        /* G = length(adj_mats)                                   */
+  int64_t n_nodes;         /* sum of N_g                                             */
+  int64_t n_edges;         /* sum of E_g                                             */
+  int64_t node_block_size; /* PN = max N_g           (gngraphbatch.jl:35)            */
+  int64_t edge_block_size; /* PN^2                   (gngraphbatch.jl:36)            */
+  int64_t n_tiles;         /* work tiles (node ranges) the kernels iterate over      */
+  int64_t max_in_degree;
+  int32_t device;
+  int32_t reserved;
+} gnx_graphs_info;
+
+/* One Flux `Dense(in => out, act)`: y = act.(W*x .+ b).  bias may be NULL (= zeros). */
+typedef struct gnx_dense {
+  const float* weight; /* (out x in) column-major, device */
+  const float* bias;   /* (out), device, or NULL          */
+  int32_t act;         /* GNX_ACT_*                       */
+  int32_t reserved;
+} gnx_dense;
+
+/* GNBlock((de,dn,dg) => (oe,on,og)) (src/gnblock.jl:47-61): edgefn in = de+2dn+dg, nodefn in = oe+dn+dg
+ * (order agg, nf, gf: nodefninput.jl:2-6), graphfn in = oe+on+dg (order edges, nodes, gf: graphfninput.jl:2-6). */
+typedef struct gnx_block_params {
+  int32_t de, dn, dg; /* input widths; 0 <=> that input is `nothing` */
+  int32_t oe, on, og; /* output widths; 0 <=> that output is `nothing` (gnblock.jl:71-78) */
+  gnx_dense edgefn, nodefn, graphfn;
+} gnx_block_params;
+
+typedef struct gnx_layernorm { /* Flux LayerNorm(d): gamma .* xhat .+ beta */
+  const float* gamma;
+  const float* beta;
+} gnx_layernorm;
+
+typedef struct gnx_ffn { /* FeedForward (gnfeedforward.jl:27-31): Dense(d=>4d, relu), Dense(4d=>d); Dropout = identity */
+  gnx_dense fc1, fc2;
+} gnx_ffn;
+
+/* GNCore(dims) (src/gncore.jl:46-59): y = x + block(gn1(x)) + ffwd(gn2(x)); index 0/1/2 = edge/node/graph. */
+typedef struct gnx_core_params {
+  gnx_block_params block; /* dims => dims */
+  gnx_layernorm ln1[3], ln2[3];
+  gnx_ffn ff[3];
+  float eps;        /* 1e-5 */
+  int32_t eps_mode; /* 0: (x-mu)/(sigma+eps) (Flux 0.14 normalise);  1: (x-mu)/sqrt(sigma^2+eps) */
+} gnx_core_params;
+
+typedef struct gnx_profile_entry {
+  char name[48];
+  int64_t launches;
+  double total_ms;
+} gnx_profile_entry;
+
+/* ---- library ---- */
+GNX_API int32_t gnx_version(void);
+GNX_API const char* gnx_last_error(void);
+
+/* ---- graph handles: replace batchgraphs / GNGraphBatch(adj_mats) (src/batch.jl:66-67, src/gngraphbatch.jl:33-54) ---- */
+
+/* adj[g] points at an n_nodes[g] x n_nodes[g] matrix of `elem_kind`, HOST memory; `row_major` = 0 for Julia
+ * (column-major) input, 1 for C/numpy.  Entries must be exactly 0 or 1. */
+GNX_API int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n_nodes, int64_t n_graphs, int32_t elem_kind,
+                                int32_t row_major, gnx_graphs** out);
+
+/* Per-graph CSC (Julia SparseMatrixCSC colptr / rowval, HOST memory): colptr[g] has n_nodes[g]+1 entries,
+ * rowval[g] the local source index of every edge, sorted strictly increasing inside a column; index_base is 1
+ * for Julia arrays, 0 for C.  The nz order of CSC *is* the reference edge order.  (API extension: the reference
+ * only accepts dense matrices, which cannot hold BASELINE configs 2-5.) */
+GNX_API int32_t gnx_graphs_create_csc(const int64_t* const* colptr, const int64_t* const* rowval, const int64_t* n_nodes,
+                              int64_t n_graphs, int32_t index_base, gnx_graphs** out);
+
+GNX_API int32_t gnx_graphs_destroy(gnx_graphs* h);
+GNX_API int32_t gnx_graphs_get_info(const gnx_graphs* h, gnx_graphs_info* out);
+/* host copies, 0-based: node_off[G+1], edge_off[G+1] (what unpadnf/unpadef/efview/nfview index with,
+ * src/unpad.jl:1-25, src/views.jl:6-98); any pointer may be NULL */
+GNX_API int32_t gnx_graphs_get_offsets(const gnx_graphs* h, int64_t* node_off, int64_t* edge_off);
+/* host copies, 0-based global CSC: colptr[N+1], rowval[E] (global source node id) */
+GNX_API int32_t gnx_graphs_get_csc(const gnx_graphs* h, int64_t* colptr, int64_t* rowval);
+
+/* ---- forward: replaces (m::GNBlock)(x) (src/gnblock.jl:63-69) ---- */
+GNX_API size_t gnx_block_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t n_replicas);
+GNX_API int32_t gnx_block_forward(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf,
+                          const float* gf, int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out,
+                          void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+
+/* ---- forward: replaces (m::GNCore)(x) (src/gncore.jl:56-68); GNCoreList = caller-side fold (gncorelist.jl:43-45) ---- */
+GNX_API size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t n_replicas);
+GNX_API int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf,
+                         const float* gf, int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out,
+                         void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+
+/* ---- reference-layout bridges: padef/padnf and unpadef/unpadnf (src/pad.jl:12-64, src/unpad.jl:1-17) ----
+ * kind 0 = edges: packed [R][E][d] <-> padded [B][PN^2][d];  kind 1 = nodes: packed [R][N][d] <-> padded [B][PN][d],
+ * where B = R (one graph in the handle) or G (R must be 1).  Pads are written as zeros. */
+GNX_API int32_t gnx_pad_features(const gnx_graphs* h, int32_t kind, const float* packed, int32_t d, int64_t n_replicas,
+                         float* padded, void* stream);
+GNX_API int32_t gnx_unpad_features(const gnx_graphs* h, int32_t kind, const float* padded, int32_t d, int64_t n_replicas,
+                           float* packed, void* stream);
+
+/* ---- per-kernel HIP-event timing (bench/roofline evidence) ---- */
+GNX_API int32_t gnx_profile_enable(int32_t on);
+GNX_API int32_t gnx_profile_reset(void);
+/* synchronises the recorded events; writes up to `max` entries, returns how many exist in *n */
+GNX_API int32_t gnx_profile_read(gnx_profile_entry* out, int32_t max, int32_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNX_H */

@@ -1,0 +1,70 @@
+"""CPU-side checks of the C-ABI boundary: libgnx.so loads, exports every symbol include/gnx.h declares, validates
+arguments before touching the GPU, and fails loudly (no fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    import graphnets_jl_amd as gn
+    return gn._lib.load()
+
+
+def _declared():
+    with open(os.path.join(ROOT, "include", "gnx.h")) as f:
+        return re.findall(r"^GNX_API [\w\s\*]+?\b(gnx_\w+)\(", f.read(), flags=re.M)
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    import graphnets_jl_amd as gn
+    names = _declared()
+    assert len(names) >= 17
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/gnx.h but not exported by libgnx.so"
+    assert set(names) == set(gn._lib.SIGNATURES), "python binding and header disagree"
+    assert lib.gnx_version() == 100
+
+
+def test_struct_layouts_match_header():
+    import graphnets_jl_amd as gn
+    L = gn._lib
+    assert C.sizeof(L.Dense) == 24 and C.sizeof(L.BlockParams) == 24 + 3 * 24
+    assert C.sizeof(L.CoreParams) == 96 + 6 * 16 + 3 * 48 + 8
+    assert C.sizeof(L.GraphsInfo) == 64 and C.sizeof(L.ProfileEntry) == 64
+
+
+def test_argument_validation_happens_before_any_gpu_work(lib):
+    h = C.c_void_p(None)
+    nn = (C.c_int64 * 1)(2)
+    bad = np.array([[1, 2], [0, 1]], dtype=np.int64)
+    ptrs = (C.c_void_p * 1)(bad.ctypes.data)
+    assert lib.gnx_graphs_create_dense(ptrs, nn, 0, 2, 1, C.byref(h)) == -2   # GNX_ERR_NO_GRAPHS (checks.jl:8)
+    assert lib.gnx_graphs_create_dense(ptrs, nn, 1, 2, 1, C.byref(h)) == -4   # GNX_ERR_ADJ_VALUE (pad.jl:30)
+    assert b"0 or 1" in lib.gnx_last_error()
+    assert lib.gnx_graphs_create_dense(ptrs, nn, 1, 9, 1, C.byref(h)) == -1   # bad elem kind
+    cp = np.array([0, 1, 3], dtype=np.int64)
+    rv = np.array([0, 1, 0], dtype=np.int64)                                   # unsorted inside column 1
+    cpp, rvp = (C.c_void_p * 1)(cp.ctypes.data), (C.c_void_p * 1)(rv.ctypes.data)
+    assert lib.gnx_graphs_create_csc(cpp, rvp, nn, 1, 0, C.byref(h)) == -7    # GNX_ERR_CSC
+    assert lib.gnx_block_workspace_bytes(None, None, 1) == 0
+
+
+def test_no_silent_cpu_fallback(lib):
+    """Without a GPU a well-formed request must fail with a HIP error (> 0), never compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p(None)
+    nn = (C.c_int64 * 1)(2)
+    ok = np.array([[1, 0], [1, 1]], dtype=np.int64)
+    ptrs = (C.c_void_p * 1)(ok.ctypes.data)
+    assert lib.gnx_graphs_create_dense(ptrs, nn, 1, 2, 1, C.byref(h)) > 0
+    assert not h.value

@@ -1,0 +1,256 @@
+"""GPU parity of the HIP GNBlock forward against the float64 oracle, through the C ABI (libgnx.so).
+
+Mirrors the reference's tests (/root/reference/test/runtests.jl): README examples and shapes (:118-326, :627-652),
+batch invariance (:62-116), batch/unbatch identity (:328-390), all `nothing` combinations (:519-625)."""
+import itertools
+
+import numpy as np
+import pytest
+
+from oracle import gn_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+README_ADJ = np.array([[1, 0, 1], [1, 1, 0], [0, 0, 1]])
+README_ADJ2 = np.array([[1, 0, 1, 0], [1, 1, 0, 1], [0, 0, 1, 0], [1, 1, 0, 1]])
+
+
+@pytest.fixture(scope="module")
+def gn():
+    import graphnets_jl_amd as gn
+    return gn
+
+
+PATHS = [pytest.param(0, id="default"), pytest.param(1, id="generic")]  # GNX_FLAG_FORCE_GENERIC = 1
+
+
+def _check_block(gn, p, g, csc, ef, nf, gf, flags):
+    blk = U.block_from_params(gn, p)
+    y = blk(U.to_nt(gn, g, ef, nf, gf), flags=flags)
+    ref, scale = O.block_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r, s, name)
+    return y
+
+
+def _csc_of(g):
+    colptr, rowval = g.csc()
+    return colptr, rowval, g.node_off, g.edge_off
+
+
+@pytest.mark.parametrize("flags", PATHS)
+def test_readme_example_1(gn, flags):
+    """README ex.1 / BASELINE config 1: shared 3-node/5-edge adjacency, batch_size 2, (10,5,0)=>(3,4,5)."""
+    rng = np.random.default_rng(1)
+    p = O.make_block_params(rng, (10, 5, 0), (3, 4, 5))
+    ef = rng.random((10, 5, 2), dtype=np.float32)
+    nf = rng.random((5, 3, 2), dtype=np.float32)
+    x = gn.batch(dict(graphs=README_ADJ, ef=ef, nf=nf, gf=None))
+    blk = U.block_from_params(gn, p)
+    blk.flags = flags
+    y = gn.unbatch(blk(x))
+    assert tuple(y.ef.shape) == (3, 5, 2) and tuple(y.nf.shape) == (4, 3, 2) and tuple(y.gf.shape) == (5, 2)
+    ref = O.unbatch_dense(O.block_forward_dense(p, O.batch_dense(README_ADJ, ef, nf, None)))
+    np.testing.assert_allclose(y.ef.cpu().numpy(), ref["ef"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(y.nf.cpu().numpy(), ref["nf"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(y.gf.cpu().numpy(), ref["gf"], rtol=1e-5, atol=1e-5)
+    # views (views.jl): first batch element
+    assert tuple(gn.efview(blk(x), slice(None), slice(None), 0).shape) == (3, 5)
+    np.testing.assert_allclose(gn.nfview(blk(x), slice(None), slice(None), 1).cpu().numpy(), ref["nf"][:, :, 1], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gn.gfview(blk(x), slice(None), 1).cpu().numpy(), ref["gf"][:, 1], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("flags", PATHS)
+def test_readme_example_2_vector_of_graphs(gn, flags):
+    """README ex.2: two graphs of different structure; outputs are vectors of per-graph arrays."""
+    rng = np.random.default_rng(2)
+    adjs = [README_ADJ, README_ADJ2]
+    p = O.make_block_params(rng, (10, 5, 0), (3, 4, 5))
+    ef = [rng.random((10, int(a.sum())), dtype=np.float32) for a in adjs]
+    nf = [rng.random((5, a.shape[0]), dtype=np.float32) for a in adjs]
+    x = gn.batch(dict(graphs=adjs, ef=ef, nf=nf, gf=None))
+    assert x.graphs.node_block_size == 4 and x.graphs.edge_block_size == 16
+    blk = U.block_from_params(gn, p)
+    blk.flags = flags
+    yb = blk(x)
+    y = gn.unbatch(yb)
+    ref = O.unbatch_dense(O.block_forward_dense(p, O.batch_dense(adjs, ef, nf, None)))
+    for i in range(2):
+        assert tuple(y.ef[i].shape) == (3, int(adjs[i].sum())) and tuple(y.nf[i].shape) == (4, adjs[i].shape[0])
+        np.testing.assert_allclose(y.ef[i].cpu().numpy(), ref["ef"][i], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(y.nf[i].cpu().numpy(), ref["nf"][i], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(y.gf[i].cpu().numpy(), ref["gf"][i], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(gn.efview(yb, slice(None), slice(None), i).cpu().numpy(), ref["ef"][i], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(gn.gfview(yb, slice(None), i).cpu().numpy(), ref["gf"][i], rtol=1e-5, atol=1e-5)
+    # flatunpadded* == graph-major packed (views.jl:80-98) and padded() == the reference's padded arrays on real slots
+    dense = O.block_forward_dense(p, O.batch_dense(adjs, ef, nf, None))
+    np.testing.assert_allclose(gn.flatunpaddednf(yb).cpu().numpy(), O.flat_from_dense(dense, "nf"), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gn.flatunpaddedef(yb).cpu().numpy(), O.flat_from_dense(dense, "ef"), rtol=1e-5, atol=1e-5)
+    pad = gn.padded(yb)
+    assert tuple(pad.ef.shape) == (3, 16, 2) and tuple(pad.nf.shape) == (4, 4, 2) and tuple(pad.gf.shape) == (5, 1, 2)
+    em = dense["graphs"].flat_edge_unpadder.reshape(16, 2, order="F")
+    pe = pad.ef.cpu().numpy()
+    for b in range(2):
+        np.testing.assert_allclose(pe[:, em[:, b], b], dense["ef"][:, em[:, b], b], rtol=1e-5, atol=1e-5)
+        assert np.all(pe[:, ~em[:, b], b] == 0)
+    assert np.array_equal(x.graphs.flat_edge_unpadder, dense["graphs"].flat_edge_unpadder)
+    assert np.array_equal(x.graphs.flat_node_unpadder, dense["graphs"].flat_node_unpadder)
+
+
+IN_COMBOS = [d for d in itertools.product((0, 3), (0, 2), (0, 4)) if any(d)]
+
+
+@pytest.mark.parametrize("flags", PATHS)
+@pytest.mark.parametrize("in_dims", IN_COMBOS)
+@pytest.mark.parametrize("out_dims", [(3, 4, 5), (2, 0, 3), (0, 2, 2), (2, 3, 0)])
+def test_nothing_combinations(gn, in_dims, out_dims, flags):
+    """7 edge / 4 node / 2 graph input forms (edgefninput.jl, nodefninput.jl, graphfninput.jl) and zero-width
+    outputs → nothing (gnblock.jl:71-78); heterogeneous batch incl. an edgeless graph and a 1-node graph."""
+    rng = np.random.default_rng(abs(hash((in_dims, out_dims))) % 2**31)
+    adjs = U.random_graphs(rng, (5, 1, 9, 3, 14), 0.4)
+    adjs[3][:] = 0  # graph without edges
+    g = gn.GNGraphBatch(adjs)
+    csc = O.csc_from_adj(adjs)
+    assert np.array_equal(csc[0], g.csc()[0]) and np.array_equal(csc[1], g.csc()[1])
+    p = O.make_block_params(rng, in_dims, out_dims, act=(1, 0, 2))
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, in_dims)
+    y = _check_block(gn, p, g, csc, ef, nf, gf, flags)
+    for got, d in zip((y.ef, y.nf, y.gf), out_dims):
+        assert (got is None) == (d == 0)
+
+
+@pytest.mark.parametrize("flags", PATHS)
+@pytest.mark.parametrize("act", [(0, 0, 0), (1, 2, 3), (4, 4, 1)])
+def test_activations_shared_batch(gn, act, flags):
+    rng = np.random.default_rng(5 + sum(act))
+    adj = U.random_graphs(rng, (23,), 0.3)[0]
+    g = gn.GNGraphBatch([adj])
+    p = O.make_block_params(rng, (6, 7, 3), (5, 6, 4), act=act)
+    ef, nf, gf = U.packed_inputs(rng, 3, g.n_edges, g.n_nodes, 1, (6, 7, 3))
+    _check_block(gn, p, g, O.csc_from_adj([adj]), ef, nf, gf, flags)
+
+
+@pytest.mark.parametrize("flags", PATHS)
+def test_batch_invariance(gn, flags):
+    """runtests.jl:62-116 through the HIP path: A alone == A inside [A, B]; (0,2,0)→(2,2,2)→(2,2,2), ef=gf=nothing."""
+    rng = np.random.default_rng(3)
+    enc = U.block_from_params(gn, O.make_block_params(rng, (0, 2, 0), (2, 2, 2)))
+    dec = U.block_from_params(gn, O.make_block_params(rng, (2, 2, 2), (2, 2, 2)))
+    enc.flags = dec.flags = flags
+    A, B = np.ones((2, 2), dtype=int), np.ones((3, 3), dtype=int)
+    nfs = [rng.random((2, 2), dtype=np.float32), rng.random((2, 3), dtype=np.float32)]
+    y1 = dec(enc(gn.batch(dict(graphs=[A], ef=None, nf=nfs[:1], gf=None))))
+    yn = dec(enc(gn.batch(dict(graphs=[A, B], ef=None, nf=nfs, gf=None))))
+    s = slice(None)
+    for a, b in ((gn.nfview(y1, s, s, 0), gn.nfview(yn, s, s, 0)), (gn.efview(y1, s, s, 0), gn.efview(yn, s, s, 0)),
+                 (gn.gfview(y1, s, 0), gn.gfview(yn, s, 0))):
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_batch_inverse_2d_and_3d(gn):
+    """runtests.jl:328-390: unbatch(batch(x)) == x exactly."""
+    rng = np.random.default_rng(5)
+    adjs = [README_ADJ, README_ADJ2]
+    ef = [rng.random((10, int(a.sum())), dtype=np.float32) for a in adjs]
+    nf = [rng.random((5, a.shape[0]), dtype=np.float32) for a in adjs]
+    gf = [rng.random((3,), dtype=np.float32) for a in adjs]
+    y = gn.unbatch(gn.batch(dict(graphs=adjs, ef=ef, nf=nf, gf=gf)))
+    for got, ref in ((y.ef, ef), (y.nf, nf), (y.gf, gf)):
+        for a, b in zip(got, ref):
+            assert np.array_equal(a.cpu().numpy(), b)
+    ef, nf, gf = rng.random((10, 5, 2), dtype=np.float32), rng.random((5, 3, 2), dtype=np.float32), rng.random((3, 2), dtype=np.float32)
+    y = gn.unbatch(gn.batch(dict(graphs=README_ADJ, ef=ef, nf=nf, gf=gf)))
+    assert np.array_equal(y.ef.cpu().numpy(), ef) and np.array_equal(y.nf.cpu().numpy(), nf) and np.array_equal(y.gf.cpu().numpy(), gf)
+    assert np.array_equal(y.graphs, README_ADJ)
+
+
+def test_no_graph_features_output(gn):
+    """runtests.jl:118-164: (10,5,0)=>(3,4,0) → y.gf === nothing."""
+    rng = np.random.default_rng(8)
+    blk = gn.GNBlock((10, 5, 0), (3, 4, 0))
+    x = gn.batch(dict(graphs=README_ADJ, ef=rng.random((10, 5, 2), dtype=np.float32), nf=rng.random((5, 3, 2), dtype=np.float32), gf=None))
+    y = gn.unbatch(blk(x))
+    assert tuple(y.ef.shape) == (3, 5, 2) and tuple(y.nf.shape) == (4, 3, 2) and y.gf is None
+
+
+def test_checks_mirror_reference_assertions(gn):
+    rng = np.random.default_rng(9)
+    with pytest.raises(AssertionError):  # batch.jl:56
+        gn.batch(dict(graphs=README_ADJ, ef=None, nf=None, gf=None))
+    with pytest.raises(AssertionError):  # checks.jl:44 wrong edge count
+        gn.batch(dict(graphs=README_ADJ, ef=rng.random((10, 4, 2), dtype=np.float32), nf=None, gf=None))
+    with pytest.raises(AssertionError):  # checks.jl:45 wrong node count
+        gn.batch(dict(graphs=[README_ADJ], ef=None, nf=[rng.random((5, 4), dtype=np.float32)], gf=None))
+    with pytest.raises(AssertionError):  # gnblock.jl:48
+        gn.GNBlock((0, 0, 0), (1, 1, 1))
+    with pytest.raises(gn.GnxError) as e:  # pad.jl:30 / gngraphbatch.jl:207: entries must be 0/1
+        gn.GNGraphBatch([np.array([[1, 2], [0, 1]])])
+    assert e.value.code == -4
+
+
+@pytest.mark.parametrize("flags", PATHS)
+@pytest.mark.parametrize("dims", [((10, 5, 0), (3, 4, 5)), ((8, 8, 8), (16, 8, 4))])
+def test_er_graph_many_tiles(gn, dims, flags):
+    """One 2000-node / 20000-edge Erdős–Rényi graph (C2's recipe, scaled): many tiles, two replicas."""
+    rng = np.random.default_rng(12)
+    colptr, rowval = U.er_csc(rng, 2000, 20000)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [2000])
+    assert g.n_tiles > 10
+    p = O.make_block_params(rng, *dims)
+    ef, nf, gf = U.packed_inputs(rng, 2, 20000, 2000, 1, dims[0])
+    _check_block(gn, p, g, _csc_of(g), ef, nf, gf, flags)
+
+
+@pytest.mark.parametrize("flags", PATHS)
+def test_skewed_degrees_and_isolated_nodes(gn, flags):
+    """A hub with 3000 in-edges (more than one tile's edge capacity), nodes without in-edges, self loops."""
+    rng = np.random.default_rng(13)
+    N = 3200
+    colptr = np.zeros(N + 1, dtype=np.int64)
+    rows = []
+    for j in range(N):
+        if j == 7:
+            r = np.sort(rng.choice(N, 3000, replace=False))
+        elif j % 5 == 0:
+            r = np.zeros(0, dtype=np.int64)
+        else:
+            r = np.sort(rng.choice(N, rng.integers(1, 6), replace=False))
+        rows.append(r)
+        colptr[j + 1] = colptr[j] + len(r)
+    rowval = np.concatenate(rows).astype(np.int64)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [N])
+    assert g.max_in_degree == 3000
+    p = O.make_block_params(rng, (4, 3, 2), (3, 4, 5))
+    ef, nf, gf = U.packed_inputs(rng, 1, len(rowval), N, 1, (4, 3, 2))
+    _check_block(gn, p, g, _csc_of(g), ef, nf, gf, flags)
+
+
+@pytest.mark.parametrize("flags", PATHS)
+def test_heterogeneous_batch_64_graphs(gn, flags):
+    """BASELINE config 3 scaled down: 64 random graphs, 32..256 nodes each, GNGraphBatch padding path."""
+    rng = np.random.default_rng(14)
+    sizes = rng.integers(32, 257, 64)
+    colptrs, rowvals = [], []
+    for n in sizes:
+        cp, rv = U.er_csc(rng, int(n), int(0.05 * n * n))
+        colptrs.append(cp); rowvals.append(rv)
+    g = gn.GNGraphBatch.from_csc(colptrs, rowvals, [int(n) for n in sizes])
+    assert g.node_block_size == sizes.max()
+    p = O.make_block_params(rng, (10, 5, 0), (3, 4, 5))
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, (10, 5, 0))
+    _check_block(gn, p, g, _csc_of(g), ef, nf, gf, flags)
+
+
+def test_results_are_bitwise_reproducible(gn):
+    """Atomic-free, fixed-order reductions: two runs give identical bits."""
+    rng = np.random.default_rng(15)
+    colptr, rowval = U.er_csc(rng, 1000, 12000)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [1000])
+    blk = U.block_from_params(gn, O.make_block_params(rng, (10, 5, 0), (3, 4, 5)))
+    ef, nf, gf = U.packed_inputs(rng, 1, 12000, 1000, 1, (10, 5, 0))
+    x = U.to_nt(gn, g, ef, nf, gf)
+    a, b = blk(x), blk(x)
+    for u, v in ((a.ef, b.ef), (a.nf, b.nf), (a.gf, b.gf)):
+        assert np.array_equal(u.cpu().numpy(), v.cpu().numpy())

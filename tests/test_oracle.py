@@ -198,3 +198,41 @@ def test_layernorm_eps_conventions():
     np.testing.assert_allclose(m0[:, 0], (x[:, 0] - x.mean()) / (sigma + 1e-5))
     m1 = O.layernorm(x, np.ones(3), np.zeros(3), eps=1e-5, eps_mode=1)
     np.testing.assert_allclose(m1[:, 0], (x[:, 0] - x.mean()) / np.sqrt(sigma**2 + 1e-5))
+
+
+def _rand_csc(rng, sizes, p):
+    adjs = [(rng.random((n, n)) < p).astype(np.int64) for n in sizes]
+    return adjs, O.csc_from_adj(adjs)
+
+
+@pytest.mark.parametrize("in_dims", IN_COMBOS)
+def test_c_port_block_matches_float64_oracle(in_dims):
+    from oracle import c_port
+    rng = np.random.default_rng(21 + sum(in_dims))
+    adjs, csc = _rand_csc(rng, (7, 1, 12, 30), 0.3)
+    N, E, G = csc[2][-1], csc[3][-1], 4
+    out_dims = (3, 4, 5)
+    p = O.make_block_params(rng, in_dims, out_dims, act=(O.ACT_RELU, O.ACT_IDENTITY, O.ACT_TANH))
+    R = 2
+    ef = rng.random((R, E, in_dims[0]), dtype=np.float32) if in_dims[0] else None
+    nf = rng.random((R, N, in_dims[1]), dtype=np.float32) if in_dims[1] else None
+    gf = rng.random((R, G, in_dims[2]), dtype=np.float32) if in_dims[2] else None
+    ref, scale = O.block_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    got = c_port.block_forward(p, csc, ef, nf, gf)
+    for g_, r_, s_ in zip(got, ref, scale):
+        assert np.all(np.abs(g_ - r_) <= 1e-5 * s_)
+
+
+def test_c_port_core_matches_float64_oracle():
+    from oracle import c_port
+    rng = np.random.default_rng(33)
+    adjs, csc = _rand_csc(rng, (9, 17, 4), 0.4)
+    N, E, G = csc[2][-1], csc[3][-1], 3
+    dims = (6, 5, 3)
+    for eps_mode in (0, 1):
+        p = O.make_core_params(rng, dims, eps_mode=eps_mode)
+        ef, nf, gf = (rng.random((1, T, d), dtype=np.float32) for T, d in zip((E, N, G), dims))
+        ref = O.core_forward_sparse(p, csc, ef, nf, gf)
+        got = c_port.core_forward(p, csc, ef, nf, gf)
+        for g_, r_ in zip(got, ref):
+            np.testing.assert_allclose(g_, r_, rtol=2e-4, atol=2e-4)  # LayerNorm amplifies fp32 rounding by 1/sigma
