@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py — edges updated/sec of the GNBlock forward on a 1M-edge batch (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dims readme|core] [--workload c2|hetero]
+
+A "step" is one GNBlock forward (edge + node + graph update) over one resident batch.
+  N = 1 : BASELINE configs[1] — one shared Erdős–Rényi graph, 100k nodes / 1M edges, batch_size 1.  The K timed steps
+          are captured into ONE hipGraph (the step is ~10-20 µs of GPU work; eager launches from Python would time the
+          host) and rotate over NSETS disjoint buffer sets so the footprint (>256 MiB) defeats the Infinity Cache:
+          `value` is a cache-cold, HBM-resident number.  `warm_ms_per_step` (one buffer set, cache-resident) is extra.
+  N > 1 : BASELINE configs[4], weak scaling — every rank holds its own 1M-edge shard of 512 random graphs (32..256
+          nodes) of a global N*512-graph heterogeneous batch (4096 graphs at N = 8); graphs never cross ranks; the only
+          collective is the RCCL all-gather of gf' (overlapped with the next step on a side stream).
+Timing: W warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize(), MAX over ranks.
+Rank 0 prints ONE JSON line.  `roofline` comes from a second pass over the same K steps with per-kernel HIP events
+(gnx_profile_*), `cpu_baseline` from the oracle's C restatement (test infrastructure) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFS = 157.3  # exact-f32 MFMA (v_mfma_f32_32x32x2_f32); no xf32 on gfx950
+NSETS = 8                  # rotating buffer sets: 8 x ~60 MB > 256 MiB Infinity Cache
+DIMS = {"readme": ((10, 5, 0), (3, 4, 5)), "core": ((128, 64, 32), (128, 64, 32))}
+
+
+def make_c2(seed=2, N=100_000, E=1_000_000):
+    """E distinct directed pairs (self-loops possible), reference edge order (dst, then src)."""
+    rng = np.random.default_rng(seed)
+    k = np.unique(rng.integers(0, N * N, int(E * 1.1)))
+    k = np.sort(rng.permutation(k)[:E])
+    dst, src = k // N, k % N
+    colptr = np.zeros(N + 1, dtype=np.int64)
+    np.add.at(colptr, dst + 1, 1)
+    return [np.cumsum(colptr)], [src.astype(np.int64)], [N]
+
+
+def make_hetero(seed, G=512, E=1_000_000):
+    """G graphs, n_g ~ U{32..256}, constant density, exactly E edges in total."""
+    rng = np.random.default_rng(seed)
+    n = rng.integers(32, 257, G)
+    dens = E / float((n.astype(np.int64) ** 2).sum())
+    eg = np.floor(dens * n.astype(np.float64) ** 2).astype(np.int64)
+    short = E - int(eg.sum())
+    eg[np.argsort(-n)[:short]] += 1
+    colptrs, rowvals = [], []
+    for ng, e in zip(n, eg):
+        ng = int(ng)
+        k = np.sort(rng.choice(ng * ng, int(e), replace=False))
+        cp = np.zeros(ng + 1, dtype=np.int64)
+        np.add.at(cp, k // ng + 1, 1)
+        colptrs.append(np.cumsum(cp)); rowvals.append((k % ng).astype(np.int64))
+    return colptrs, rowvals, [int(x) for x in n]
+
+
+def algorithmic_bytes(E, N, G, din, dout):
+    """every tensor once, gathers counted per node, no intermediates."""
+    (de, dn, dg), (oe, on, og) = din, dout
+    ke, kn, kg = de + 2 * dn + dg, oe + dn + dg, oe + on + dg
+    b = 4 * (E * (de + oe) + N * (dn + on) + G * (dg + og)) + 4 * E + 4 * (N + 1)
+    if G > 1:
+        b += 8 * (G + 1)
+    return b + 4 * (ke * oe + oe + kn * on + on + kg * og + og)
+
+
+def algorithmic_flops(E, N, G, din, dout):
+    (de, dn, dg), (oe, on, og) = din, dout
+    return 2 * (E * (de + 2 * dn + dg) * oe + N * (oe + dn + dg) * on + G * (oe + on + dg) * og)
+
+
+def glorot(rng, out_d, in_d):
+    s = np.sqrt(6.0 / max(in_d + out_d, 1))
+    return rng.uniform(-s, s, size=(out_d, in_d)).astype(np.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--dims", choices=list(DIMS), default="readme")
+    ap.add_argument("--workload", choices=["c2", "hetero"], default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flags", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import graphnets_jl_amd as gn
+    from graphnets_jl_amd.dist import GfGather
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    K, W = args.steps, args.warmup
+    din, dout = DIMS[args.dims]
+    workload = args.workload or ("c2" if world == 1 else "hetero")
+
+    # ---- synthetic batch (rank-local shard) ----
+    if workload == "c2":
+        colptrs, rowvals, nn = make_c2()
+        wl_name = "C2: one shared Erdos-Renyi graph, 100k nodes / 1M edges, batch_size=1 (BASELINE configs[1])"
+    else:
+        colptrs, rowvals, nn = make_hetero(seed=3 + rank)
+        wl_name = (f"heterogeneous batch, {512 * world} random graphs (32-256 nodes) sharded by graph, 512 graphs / 1M edges "
+                   f"per GPU (BASELINE configs[{2 if world == 1 else 4}])")
+    g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
+    E, N, G = g.n_edges, g.n_nodes, g.n_graphs
+    rng = np.random.default_rng(100)  # identical weights on every rank
+    blk = gn.GNBlock(din, dout, device=dev)
+    (de, dn, dg), (oe, on, og) = din, dout
+    blk.edgefn = gn.Dense.from_numpy(glorot(rng, oe, de + 2 * dn + dg), np.zeros(oe, np.float32), device=dev)
+    blk.nodefn = gn.Dense.from_numpy(glorot(rng, on, oe + dn + dg), np.zeros(on, np.float32), device=dev)
+    blk.graphfn = gn.Dense.from_numpy(glorot(rng, og, oe + on + dg), np.zeros(og, np.float32), device=dev)
+    plan = gn.BlockPlan(blk, g, R=1, flags=args.flags)
+    nsets = NSETS if args.dims == "readme" else 2
+    tg = torch.Generator(device=dev); tg.manual_seed(1234 + rank)
+    mk = lambda T, d: torch.rand((1, T, d), generator=tg, device=dev, dtype=torch.float32) if d > 0 else None
+    sets = [dict(ef=mk(E, de), nf=mk(N, dn), gf=mk(G, dg), out=plan.outputs()) for _ in range(nsets)]
+    gather = GfGather([np.arange(r * G, (r + 1) * G) for r in range(world)], rank, world, og, dev) if world > 1 else None
+
+    def step(i, s=None):
+        b = sets[i % nsets]
+        plan(b["ef"], b["nf"], b["gf"], *b["out"], stream=s)
+        if gather is not None:
+            gather.start(b["out"][2][0])
+
+    def sync_all():
+        if gather is not None:
+            gather.finish()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def timed(run):
+        sync_all()
+        t0 = time.perf_counter()
+        run()
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for i in range(W):  # warm-up (also loads the code objects)
+        step(i)
+    sync_all()
+
+    extra = {}
+    if world == 1:
+        def capture(nsteps, rotate):
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                for i in range(nsteps):
+                    step(i if rotate else 0)
+            return cg
+        cold = capture(K, True)
+        cold.replay(); torch.cuda.synchronize(dev)
+        dt = min(timed(cold.replay) for _ in range(3))
+        warm = capture(K, False)
+        warm.replay(); torch.cuda.synchronize(dev)
+        extra["warm_ms_per_step"] = round(min(timed(warm.replay) for _ in range(3)) / K * 1e3, 6)
+        extra["launch"] = f"hipGraph of {K} steps, {nsets} rotating buffer sets (cache-cold)"
+    else:
+        dt = timed(lambda: [step(i) for i in range(K)])
+        extra["launch"] = "eager, all-gather of gf' overlapped on a side stream"
+    ms_per_step = dt / K * 1e3
+    value = E * world / (dt / K)
+
+    # ---- roofline: the same K steps again with per-kernel HIP events; the GPU is kept busy behind a spin kernel
+    # so that the events bracket kernel execution, not host launch gaps ----
+    roof = None
+    if rank == 0:
+        gn.profile_reset(); gn.profile_enable(True)
+        torch.cuda._sleep(int(2.0e9 * 0.02))
+        for i in range(K):
+            b = sets[i % nsets]
+            plan(b["ef"], b["nf"], b["gf"], *b["out"])
+        torch.cuda.synchronize(dev)
+        gn.profile_enable(False)
+        prof = gn.profile_read(); gn.profile_reset()
+        kern = {k: v["total_ms"] / max(v["launches"], 1) * 1e3 for k, v in prof.items()}  # avg µs per launch
+        dom = max(kern, key=kern.get)
+        dur_s = kern[dom] * 1e-6
+        abytes, aflops = algorithmic_bytes(E, N, G, din, dout), algorithmic_flops(E, N, G, din, dout)
+        hbm_t, mfma_t = abytes / (HBM_PEAK_GBS * 1e9), aflops / (MFMA_F32_PEAK_TFS * 1e12)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.dims}.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+        if hbm_t >= mfma_t:
+            a = abytes / dur_s / 1e9
+            roof = dict(bound="hbm", achieved=round(a, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(a / HBM_PEAK_GBS, 4), traffic=traffic)
+        else:
+            a = aflops / dur_s / 1e12
+            roof = dict(bound="mfma", achieved=round(a, 3), peak=MFMA_F32_PEAK_TFS, unit="TFLOP/s", frac=round(a / MFMA_F32_PEAK_TFS, 4), traffic=traffic)
+        roof.update(kernel=dom, kernel_us=round(kern[dom], 3), algorithmic_bytes=abytes, algorithmic_flops=aflops,
+                    bytes_per_edge=round(abytes / E, 2), all_kernels_us={k: round(v, 3) for k, v in kern.items()})
+
+    # ---- CPU baseline: the oracle's C restatement ("port") on the host cores, rank 0, N = 1 only ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_port
+        from oracle import gn_oracle as O
+        p = dict(in_dims=din, out_dims=dout, We=blk.edgefn.weight.cpu().numpy(), be=np.zeros(oe, np.float32),
+                 Wn=blk.nodefn.weight.cpu().numpy(), bn=np.zeros(on, np.float32), Wg=blk.graphfn.weight.cpu().numpy(),
+                 bg=np.zeros(og, np.float32), act_e=0, act_n=0, act_g=0)
+        b = sets[0]
+        host = lambda a: None if a is None else a.cpu().numpy()
+        csc = (*g.csc(), g.node_off, g.edge_off)
+        cores = min(os.cpu_count() or 1, c_port.max_threads())
+        runner = c_port.BlockRunner(p, csc, host(b["ef"]), host(b["nf"]), host(b["gf"]), nthreads=cores)
+        runner.run()
+        t_budget, times = (3.0 if args.dims == "readme" else 12.0), []
+        t_start = time.perf_counter()
+        while time.perf_counter() - t_start < t_budget or len(times) < 3:
+            t0 = time.perf_counter(); out = runner.run(); times.append(time.perf_counter() - t0)
+        cpu = dict(value=round(E / float(np.median(times)), 1), unit="edges/s", cores=cores, kind="port",
+                   sample=f"{len(times)} full forwards of the same 1M-edge batch (median), oracle/gn_oracle_c.c with OpenMP on {cores} threads")
+        # the checker also checks: HIP output of set 0 vs the C port on the same inputs (loose: both fp32)
+        plan(b["ef"], b["nf"], b["gf"], *b["out"]); torch.cuda.synchronize(dev)
+        for got, ref in zip(b["out"], out):
+            if got is not None:
+                assert np.allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(ref).max()))), "HIP vs CPU port mismatch"
+
+    if rank == 0:
+        line = {
+            "metric": "edges updated/sec, GNBlock fwd, 1M-edge batch", "value": round(value, 1), "unit": "edges/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl_name, "dims": f"{din}=>{dout}", "edges_per_gpu": E, "nodes_per_gpu": N,
+                       "graphs_per_gpu": G, "parallelism": f"graph-sharded x{world}" if world > 1 else "single GPU", **extra},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -602,3 +602,29 @@ class GNCoreList:
         for fn in self.list:
             x = fn(x)
         return x
+
+
+class BlockPlan:
+    """A pre-bound `gnx_block_forward` call: parameter struct, workspace and handle are fixed, so one step is ONE
+    ctypes call on packed [R][T][D] tensors — what hipGraph capture and the bench loop want.  No allocation here."""
+
+    def __init__(self, block, g, R=1, flags=None):
+        self.block, self.g, self.R = block, g, int(R)
+        self.flags = block.flags if flags is None else flags
+        self._keep = []
+        self.p = block._c(self._keep)
+        self.lib = _lib.load()
+        with torch.cuda.device(g.device):
+            nbytes = self.lib.gnx_block_workspace_bytes(g._h, C.byref(self.p), self.R)
+        self.ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=g.device)
+
+    def outputs(self):
+        oe, on, og = self.block.out_dims
+        g, R = self.g, self.R
+        mk = lambda T, d: torch.empty((R, T, d), dtype=torch.float32, device=g.device) if d > 0 else None
+        return mk(g.n_edges, oe), mk(g.n_nodes, on), mk(g.n_graphs, og)
+
+    def __call__(self, ef, nf, gf, eo, no, go, stream=None):
+        s = torch.cuda.current_stream(self.g.device).cuda_stream if stream is None else stream
+        check(self.lib.gnx_block_forward(self.g._h, C.byref(self.p), _ptr(ef), _ptr(nf), _ptr(gf), self.R, _ptr(eo), _ptr(no),
+                                         _ptr(go), self.ws.data_ptr(), self.ws.numel(), self.flags, s))

@@ -108,3 +108,24 @@ def core_forward(p, csc, ef, nf, gf, nthreads=0):
 
 def max_threads():
     return lib().gn_oracle_max_threads()
+
+
+class BlockRunner:
+    """Pre-bound call of the C restatement for timing (bench.py's cpu_baseline leg): buffers allocated and touched once."""
+
+    def __init__(self, p, csc, ef, nf, gf, nthreads=0):
+        self.keep = []
+        self.ps = _block_struct(p, self.keep)
+        colptr, rowval, node_off, edge_off = csc
+        self.N, self.E, self.G = len(colptr) - 1, len(rowval), len(node_off) - 1
+        self.R = next(a.shape[0] for a in (ef, nf, gf) if a is not None)
+        oe, on, og = p["out_dims"]
+        self.out = [np.zeros((self.R, T, d), dtype=np.float32) for T, d in ((self.E, oe), (self.N, on), (self.G, og))]
+        self.args = (C.c_int64(self.N), C.c_int64(self.E), C.c_int64(self.G), *_csc_ptrs(csc, self.keep), C.byref(self.ps),
+                     _f(ef, self.keep), _f(nf, self.keep), _f(gf, self.keep), C.c_int64(self.R),
+                     *[o.ctypes.data_as(_fp) for o in self.out], C.c_int(nthreads))
+        self.fn = lib().gn_oracle_block_forward_f32
+
+    def run(self):
+        assert self.fn(*self.args) == 0
+        return self.out
