@@ -1,6 +1,8 @@
 // C-ABI entry points of the forward path: argument validation (mirroring the reference's assertions), workspace
 // carving and kernel-path selection.  No allocation and no synchronisation happens here, so every call is
 // asynchronous on the caller's stream and can be captured into a hipGraph.
+#include <cstdlib>
+
 #include "gnx_device.h"
 
 namespace gnx {
@@ -78,6 +80,8 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   a.colptr = h->d_colptr; a.rowval = h->d_rowval; a.node_off = h->d_node_off; a.edge_off = h->d_edge_off;
   a.tile_off = h->d_tile_off; a.tiles = h->d_tiles;
   a.N = (int)h->N; a.E = (int)h->E; a.G = (int)h->G; a.n_tiles = (int)h->n_tiles();
+  static const int ablate = getenv("GNX_ABLATE") ? atoi(getenv("GNX_ABLATE")) : 0;
+  a.ablate = ablate;
 
   if (!(flags & GNX_FLAG_FORCE_GENERIC)) {
     if (!(flags & GNX_FLAG_NO_MFMA)) {

@@ -97,14 +97,15 @@ __global__ __launch_bounds__(256) void k_node_generic(BlockArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // graph update: gf'[g] = act(Wg * [sum_e ef' ; sum_n nf' ; gf_g] + bg)         one workgroup per (graph, replica)
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_graph(BlockArgs a) {
+constexpr int kGraphThreads = 1024;
+__global__ __launch_bounds__(kGraphThreads) void k_graph(BlockArgs a) {
   extern __shared__ float s_f[];
   const int g = blockIdx.x;
   const size_t r = blockIdx.y;
   const int C = a.oe + a.on;
   const int t0 = a.tile_off[g], t1 = a.tile_off[g + 1];
-  const int cpp = C < 256 ? C : 256;           // columns per pass
-  const int nsl = cpp > 0 ? 256 / cpp : 1;     // tile slices summed in parallel
+  const int cpp = C < kGraphThreads ? C : kGraphThreads;  // columns per pass
+  const int nsl = cpp > 0 ? kGraphThreads / cpp : 1;      // tile slices summed in parallel
   float* s_part = s_f;                         // [nsl][C]
   float* s_x = s_f + (size_t)nsl * C;          // [C + dg]
   const float* part = a.partials + r * (size_t)a.n_tiles * C;
@@ -112,15 +113,24 @@ __global__ __launch_bounds__(256) void k_graph(BlockArgs a) {
     const int sl = threadIdx.x / cpp, cc = threadIdx.x - sl * cpp;
     if (sl < nsl) {
       for (int c = cc; c < C; c += cpp) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // 4 independent chains, combined in a fixed order
-        int ti = t0 + sl;
-        for (; ti + 3 * nsl < t1; ti += 4 * nsl) {
-          s0 += part[(size_t)ti * C + c];
-          s1 += part[(size_t)(ti + nsl) * C + c];
-          s2 += part[(size_t)(ti + 2 * nsl) * C + c];
-          s3 += part[(size_t)(ti + 3 * nsl) * C + c];
+        // 16 independent chains (the loads are what costs: keep 16 in flight), combined in a fixed order
+        float s16[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s16[u] = 0.f;
+        // every pass issues 16 predicated loads at once (no serial tail: a tail loop would pay one L2/HBM round trip
+        // per row, which is what made this kernel 8 us for 2k tiles)
+        for (int ti = t0 + sl; ti < t1; ti += 16 * nsl) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int tj = ti + u * nsl;
+            if (tj < t1) s16[u] += part[(size_t)tj * C + c];
+          }
         }
-        for (; ti < t1; ti += nsl) s0 += part[(size_t)ti * C + c];
+#pragma unroll
+        for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+          for (int u = 0; u < w; ++u) s16[u] += s16[u + w];
+        const float s0 = s16[0], s1 = 0.f, s2 = 0.f, s3 = 0.f;
         s_part[(size_t)sl * C + c] = (s0 + s1) + (s2 + s3);
       }
     }
@@ -145,15 +155,15 @@ __global__ __launch_bounds__(256) void k_graph(BlockArgs a) {
 
 size_t graph_kernel_lds_bytes(int oe, int on, int dg) {
   const int C = oe + on;
-  const int cpp = C < 256 ? C : 256;
-  const int nsl = cpp > 0 ? 256 / cpp : 1;
+  const int cpp = C < kGraphThreads ? C : kGraphThreads;
+  const int nsl = cpp > 0 ? kGraphThreads / cpp : 1;
   return sizeof(float) * ((size_t)nsl * C + C + dg + 1);
 }
 
 int32_t launch_graph(const BlockArgs& a, int64_t R, hipStream_t s) {
   if (a.og == 0) return GNX_OK;
   ProfScope ps("k_graph", s);
-  hipLaunchKernelGGL(k_graph, dim3((unsigned)a.G, (unsigned)R), dim3(256), graph_kernel_lds_bytes(a.oe, a.on, a.dg), s, a);
+  hipLaunchKernelGGL(k_graph, dim3((unsigned)a.G, (unsigned)R), dim3(kGraphThreads), graph_kernel_lds_bytes(a.oe, a.on, a.dg), s, a);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }

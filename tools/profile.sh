@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): kernel-trace stats and, in SEPARATE passes, the HBM traffic counters of bench.py.
+# Runs on the GPU box (via gpurun): kernel-trace stats and, in SEPARATE passes, PMC counters of bench.py.
 # Usage: tools/profile.sh <tag> [bench args...]   → gpurun_out/prof_<tag>/...
 set -u
 TAG=${1:-r01}; shift || true
@@ -11,4 +11,9 @@ BENCH="python3 $REPO/bench.py --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/kt.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/pmc_write.log" 2>&1
-find "$OUT" -name "*.csv" | head -20
+if [ "${GNX_PROF_SQ:-0}" = "1" ]; then
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --kernel-trace --output-format csv -d "$OUT/pmc_sq1" -- $BENCH > "$OUT/pmc_sq1.log" 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_sq2" -- $BENCH > "$OUT/pmc_sq2.log" 2>&1
+fi
+python3 $REPO/tools/summarize_prof.py "$OUT" "$OUT/summary" > "$OUT/summary.txt" 2>&1
+tail -60 "$OUT/summary.txt"

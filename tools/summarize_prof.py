@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output (gpurun_out/prof_<tag>/...) into small, committable files under profiles/.
+
+  python tools/summarize_prof.py gpurun_out/prof_<tag> profiles/<name> [--dims readme]
+writes <name>_kernel_stats.csv (gnx kernels: calls, avg/min/max ns) and <name>_pmc.json (per-kernel mean of every
+collected counter; FETCH_SIZE / WRITE_SIZE converted to bytes with the gfx950 corrections of MI355X_MICROARCH.md §HBM:
+both counters are in KiB; FETCH_SIZE under-reports wide coalesced reads by exactly 2x, so it is doubled)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.split("(")[0]
+    return name.split("::")[-1].split("<")[0]
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    dims = sys.argv[sys.argv.index("--dims") + 1] if "--dims" in sys.argv else None
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    stats = defaultdict(list)
+    for f in glob.glob(os.path.join(src, "kt", "**", "*_kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "gnx::" in row["Kernel_Name"]:
+                stats[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    with open(dst + "_kernel_stats.csv", "w") as out:
+        out.write("kernel,calls,avg_ns,min_ns,max_ns,total_ns\n")
+        for k, v in sorted(stats.items(), key=lambda kv: -sum(kv[1])):
+            out.write(f"{k},{len(v)},{sum(v) / len(v):.1f},{min(v)},{max(v)},{sum(v)}\n")
+    pmc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "gnx::" in row["Kernel_Name"]:
+                pmc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    res = {}
+    for k, cs in pmc.items():
+        res[k] = {c: sum(v) / len(v) for c, v in cs.items()}
+        res[k]["launches_sampled"] = max(len(v) for v in cs.values())
+        if "FETCH_SIZE" in cs or "WRITE_SIZE" in cs:
+            fetch = res[k].get("FETCH_SIZE", 0.0) * 1024 * 2  # KiB -> B, x2 gfx950 wide-read correction
+            write = res[k].get("WRITE_SIZE", 0.0) * 1024
+            res[k]["hbm_fetch_bytes_corrected"] = fetch
+            res[k]["hbm_write_bytes"] = write
+            res[k]["hbm_bytes_per_launch"] = fetch + write
+        if k in stats:
+            res[k]["avg_ns"] = sum(stats[k]) / len(stats[k])
+    with open(dst + "_pmc.json", "w") as out:
+        json.dump(res, out, indent=1, sort_keys=True)
+    if dims:
+        with open(os.path.join(os.path.dirname(dst) or ".", f"traffic_{dims}.json"), "w") as out:
+            json.dump({k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in res.items() if "hbm_bytes_per_launch" in v}, out, indent=1)
+    print(open(dst + "_kernel_stats.csv").read())
+    print(json.dumps(res, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
