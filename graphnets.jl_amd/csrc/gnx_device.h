@@ -22,7 +22,9 @@ struct BlockArgs {
   const int* edge_off;
   const int* tile_off;
   const Tile* tiles;
-  int N, E, G, n_tiles;
+  const int* wtile_off;
+  const Tile* wtiles;
+  int N, E, G, n_tiles, n_wtiles;
   int ablate;  // timing experiments only (GNX_ABLATE): 1 no ef loads, 2 no src gather, 4 no ef' stores, 8 no nf' stores, 16 no rowval
 };
 

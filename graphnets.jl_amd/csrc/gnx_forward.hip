@@ -1,6 +1,7 @@
 // C-ABI entry points of the forward path: argument validation (mirroring the reference's assertions), workspace
 // carving and kernel-path selection.  No allocation and no synchronisation happens here, so every call is
 // asynchronous on the caller's stream and can be captured into a hipGraph.
+#include <algorithm>
 #include <cstdlib>
 
 #include "gnx_device.h"
@@ -49,7 +50,8 @@ static BlockWs block_ws(const gnx_graphs* h, const gnx_block_params* p, int64_t 
   w.agg_off = 0;
   const size_t agg = align_up(sizeof(float) * (size_t)R * h->N * p->oe, 256);
   w.part_off = agg;
-  const size_t part = align_up(sizeof(float) * (size_t)R * h->n_tiles() * (p->oe + p->on), 256);
+  const size_t prow = (size_t)std::max<int64_t>(h->n_tiles(), (h->n_wtiles() + 3) / 4 * 4 + 4);
+  const size_t part = align_up(sizeof(float) * (size_t)R * prow * (p->oe + p->on), 256);
   w.total = agg + part + 256;
   return w;
 }
@@ -79,6 +81,7 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   a.partials = reinterpret_cast<float*>(static_cast<char*>(ws) + w.part_off);
   a.colptr = h->d_colptr; a.rowval = h->d_rowval; a.node_off = h->d_node_off; a.edge_off = h->d_edge_off;
   a.tile_off = h->d_tile_off; a.tiles = h->d_tiles;
+  a.wtile_off = h->d_wtile_off; a.wtiles = h->d_wtiles; a.n_wtiles = (int)h->n_wtiles();
   a.N = (int)h->N; a.E = (int)h->E; a.G = (int)h->G; a.n_tiles = (int)h->n_tiles();
   static const int ablate = getenv("GNX_ABLATE") ? atoi(getenv("GNX_ABLATE")) : 0;
   a.ablate = ablate;

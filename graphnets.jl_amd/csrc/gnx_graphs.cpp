@@ -58,32 +58,38 @@ static int32_t finalize(gnx_graphs* h) {
   h->tile_n_cap = env_int("GNX_TILE_N", 128);
   // greedy tiling inside each graph: add nodes while edges <= cap and nodes <= cap; a node whose in-degree
   // exceeds the cap becomes a single-node tile (kernels loop over its edges).
-  h->h_tile_off.assign(h->G + 1, 0);
-  h->max_in_degree = 0;
-  for (int64_t g = 0; g < h->G; ++g) {
-    h->h_tile_off[g] = (int32_t)h->h_tiles.size();
-    int64_t n = h->h_node_off[g];
-    const int64_t nend = h->h_node_off[g + 1];
-    while (n < nend) {
-      int64_t n1 = n;
-      const int64_t e0 = h->h_colptr[n];
-      while (n1 < nend && (n1 - n) < h->tile_n_cap) {
-        const int64_t deg = h->h_colptr[n1 + 1] - h->h_colptr[n1];
-        h->max_in_degree = std::max(h->max_in_degree, deg);
-        if (n1 > n && h->h_colptr[n1 + 1] - e0 > h->tile_e_cap) break;
-        ++n1;
+  auto build_tiles = [&](int e_cap, int n_cap, std::vector<gnx::Tile>& tiles, std::vector<int32_t>& off) {
+    off.assign(h->G + 1, 0);
+    for (int64_t g = 0; g < h->G; ++g) {
+      off[g] = (int32_t)tiles.size();
+      int64_t n = h->h_node_off[g];
+      const int64_t nend = h->h_node_off[g + 1];
+      while (n < nend) {
+        int64_t n1 = n;
+        const int64_t e0 = h->h_colptr[n];
+        while (n1 < nend && (n1 - n) < n_cap) {
+          const int64_t deg = h->h_colptr[n1 + 1] - h->h_colptr[n1];
+          h->max_in_degree = std::max(h->max_in_degree, deg);
+          if (n1 > n && h->h_colptr[n1 + 1] - e0 > e_cap) break;
+          ++n1;
+        }
+        gnx::Tile t;
+        t.n0 = (int32_t)n; t.n1 = (int32_t)n1;
+        t.e0 = (int32_t)e0; t.e1 = (int32_t)h->h_colptr[n1];
+        t.g = (int32_t)g;
+        t.win0 = (int32_t)h->h_node_off[g]; t.win1 = (int32_t)nend;
+        t.flags = 0;
+        tiles.push_back(t);
+        n = n1;
       }
-      gnx::Tile t;
-      t.n0 = (int32_t)n; t.n1 = (int32_t)n1;
-      t.e0 = (int32_t)e0; t.e1 = (int32_t)h->h_colptr[n1];
-      t.g = (int32_t)g;
-      t.win0 = (int32_t)h->h_node_off[g]; t.win1 = (int32_t)nend;
-      t.flags = 0;
-      h->h_tiles.push_back(t);
-      n = n1;
     }
-  }
-  h->h_tile_off[h->G] = (int32_t)h->h_tiles.size();
+    off[h->G] = (int32_t)tiles.size();
+  };
+  h->max_in_degree = 0;
+  build_tiles(h->tile_e_cap, h->tile_n_cap, h->h_tiles, h->h_tile_off);
+  h->wtile_e_cap = env_int("GNX_WTILE_E", 128);
+  if (h->wtile_e_cap != 64 && h->wtile_e_cap != 128 && h->wtile_e_cap != 256) h->wtile_e_cap = 128;
+  build_tiles(h->wtile_e_cap, 64, h->h_wtiles, h->h_wtile_off);
 
   auto upload32 = [&](const std::vector<int64_t>& src, int32_t** dst) -> int32_t {
     std::vector<int32_t> tmp(src.size());
@@ -102,6 +108,11 @@ static int32_t finalize(gnx_graphs* h) {
   GNX_HIP(hipMalloc((void**)&h->d_tiles, std::max<size_t>(h->h_tiles.size(), 1) * sizeof(gnx::Tile)));
   if (!h->h_tiles.empty())
     GNX_HIP(hipMemcpy(h->d_tiles, h->h_tiles.data(), h->h_tiles.size() * sizeof(gnx::Tile), hipMemcpyHostToDevice));
+  GNX_HIP(hipMalloc((void**)&h->d_wtile_off, h->h_wtile_off.size() * sizeof(int32_t)));
+  GNX_HIP(hipMemcpy(h->d_wtile_off, h->h_wtile_off.data(), h->h_wtile_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  GNX_HIP(hipMalloc((void**)&h->d_wtiles, std::max<size_t>(h->h_wtiles.size(), 1) * sizeof(gnx::Tile)));
+  if (!h->h_wtiles.empty())
+    GNX_HIP(hipMemcpy(h->d_wtiles, h->h_wtiles.data(), h->h_wtiles.size() * sizeof(gnx::Tile), hipMemcpyHostToDevice));
   return GNX_OK;
 }
 
@@ -209,6 +220,8 @@ int32_t gnx_graphs_destroy(gnx_graphs* h) {
   (void)hipFree(h->d_edge_off);
   (void)hipFree(h->d_tile_off);
   (void)hipFree(h->d_tiles);
+  (void)hipFree(h->d_wtile_off);
+  (void)hipFree(h->d_wtiles);
   (void)hipFree(h->d_pad_edge_slot);
   delete h;
   return GNX_OK;

@@ -32,6 +32,9 @@ struct gnx_graphs {
   std::vector<int64_t> h_node_off, h_edge_off, h_colptr, h_rowval;
   std::vector<gnx::Tile> h_tiles;
   std::vector<int32_t> h_tile_off;  // [G+1] tiles of graph g = [tile_off[g], tile_off[g+1])
+  // wave tiles: same idea at wavefront granularity (<= wtile_e_cap edges, <= 64 nodes), one wave64 per tile
+  std::vector<gnx::Tile> h_wtiles;
+  std::vector<int32_t> h_wtile_off;
   // device copies (int32)
   int32_t* d_colptr = nullptr;    // [N+1]
   int32_t* d_rowval = nullptr;    // [E] global source node id
@@ -39,9 +42,13 @@ struct gnx_graphs {
   int32_t* d_edge_off = nullptr;  // [G+1]
   int32_t* d_tile_off = nullptr;  // [G+1]
   gnx::Tile* d_tiles = nullptr;   // [n_tiles]
+  int32_t* d_wtile_off = nullptr; // [G+1]
+  gnx::Tile* d_wtiles = nullptr;  // [n_wtiles]
+  int32_t wtile_e_cap = 0;
   int32_t* d_pad_edge_slot = nullptr;  // [E] slot of edge e inside its graph's PN^2 grid (column-major, padded)
   int32_t tile_e_cap = 0, tile_n_cap = 0;
   int64_t n_tiles() const { return (int64_t)h_tiles.size(); }
+  int64_t n_wtiles() const { return (int64_t)h_wtiles.size(); }
 };
 
 namespace gnx {

@@ -95,358 +95,331 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-// Deterministic block sum of C per-thread values: DPP row sums -> 16 row leaders write LDS -> fixed-order add.
-// After the call, s_red[r*C + c] (r = 0..15) are visible to every thread (one barrier inside).
-template <int C>
-__device__ __forceinline__ void block_rows_to_lds(const float (&v)[C > 0 ? C : 1], float* s_red) {
-  const int lane = threadIdx.x & 63, row = threadIdx.x >> 4;
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float x = row16_sum(v[c]);
-    if ((lane & 15) == 0) s_red[row * C + c] = x;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-__device__ __forceinline__ float sum16(const float* s_red, int C, int c) {
-  float s = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) s += s_red[r * C + c];
-  return s;
-}
-
 }  // namespace
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release/acquire fence that makes hipcc
-// drain vmcnt as well, which would wait for the next tile's prefetch loads (and this tile's output stores) at every
-// barrier; the data exchanged between the waves of this kernel goes through LDS only.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// sum over the 64 lanes of the wave, same bits in every lane, fixed association
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
 
-// Per-thread registers of one tile in flight.
-template <int DE, int DN, int EPT, int NV_ND>
-struct Stage {
-  Tile t;                                // wave-uniform
-  int cp0, cp1;                          // tile-local in-edge range of this thread's node
-  float xn[DN > 0 ? DN : 1];             // this thread's node row
-  float x[EPT][DE > 0 ? DE : 1];         // this thread's edge rows (first chunk)
-  int src[EPT];                          // their global source node ids
-  float xs[EPT][DN > 0 ? DN : 1];        // gathered source rows
-  float4 v_nd[NV_ND];                    // WINDOW: this thread's slice of the graph's node rows, on its way to LDS
-};
-
-// TE / TN: compile-time tile capacities (edges per chunk, nodes per tile; TN <= 256 = one node per thread and a dst
-// index fits a byte).  WINDOW: every graph has <= WIN nodes, so a graph's node rows are staged in LDS once per graph
-// and nf[src] (edgefninput.jl:4) is gathered from LDS; otherwise nf[src] is a row gather from L2/HBM.
+// =========================================================================================================
+// k_block_wave — the whole GNBlock edge + node update, ONE WAVEFRONT PER TILE.
 //
-// Persistent + software pipelined: a workgroup walks `tiles_per_wg` consecutive tiles; while tile i is computed, the
-// loads of tile i+1 (ef rows, rowval, colptr, node rows) are already in flight and its nf[src] gather is issued in
-// the middle of tile i — one memory round trip per tile is exposed instead of three.
-template <int DE, int DN, int DG, int OE, int ON, int TE, int TN, bool WINDOW>
-__global__ __launch_bounds__(kThreads) void k_block_fused(BlockArgs a, int tiles_per_wg) {
-  constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1;
-  constexpr int WIN = 256;
-  constexpr int EPT = TE / kThreads;                              // edges per thread and chunk
-  constexpr int NV_ND = WINDOW ? (WIN * DN / 4) / kThreads + 1 : 1;
+// A wave tile is a node range of one graph with <= 64 nodes and <= 64*EPT in-edges (contiguous, CSC order).  The
+// wave owns every edge that aggregates into its nodes, so the edge->node sum needs no atomics and no workgroup
+// barrier: lanes exchange data through a wave-private LDS slice (LDS operations of one wave execute in order), and
+// reductions are DPP + readlane.  A workgroup is just four independent waves; 28-32 of them are resident per CU at
+// different points of their (load -> gather -> compute -> store) chain, which is what overlaps HBM with compute.
+//   lanes as EDGES : EPT edges per lane — ef row (dword-aligned 16-B loads), rowval, nf[src] row gather, W*x, store
+//   lanes as NODES : lane n < nn — colptr, own nf row, pd[n] = b + We[:,dst]*nf[n] (+ gf fold), segmented sum of
+//                    ef' from LDS, node update, store
+// =========================================================================================================
+template <int DE, int DN, int DG, int OE, int ON, int EPT>
+__global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_stride) {
+  constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1;
+  constexpr int TEW = 64 * EPT;
   constexpr int C = OE + ON, C1 = C > 0 ? C : 1;
-  static_assert(TE % kThreads == 0 && TN <= 256, "tile shape");
-  using St = Stage<DE, DN, EPT, NV_ND>;
-  __shared__ __attribute__((aligned(16))) float s_out[TE * OE + 4];            // ef' of the tile (for the node sums)
-  __shared__ __attribute__((aligned(16))) float s_pd[TN * OE + 4];             // per node: bias' + We[:, dst-seg] * nf[n]
-  __shared__ __attribute__((aligned(16))) float s_nd[WINDOW ? WIN * DN + 8 : 4];  // the current graph's node rows
-  __shared__ float s_red[16 * C1 + 4];
-  __shared__ unsigned char s_dst[TE + 4];                                      // tile-local destination of each edge
+  constexpr int WAVES = kThreads / 64;
+  __shared__ __attribute__((aligned(16))) float s_out_all[WAVES][TEW * OE + 4];  // ef' of the wave's tile
+  __shared__ __attribute__((aligned(16))) float s_pd_all[WAVES][64 * OE + 4];    // per node: bias' + We[:, dst-seg]*nf[n]
+  __shared__ unsigned char s_dst_all[WAVES][TEW + 4];                             // tile-local destination of each edge
+
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wt = __builtin_amdgcn_readfirstlane(xcd_tile(blockIdx.x, gridDim.x) * WAVES + wv);
+  if (wt >= a.n_wtiles) return;  // wave-uniform; the kernel has no workgroup barrier
+  float* s_out = s_out_all[wv];
+  float* s_pd = s_pd_all[wv];
+  unsigned char* s_dst = s_dst_all[wv];
+
+  typedef const int __attribute__((address_space(4))) * cintp;
+  const cintp tw = reinterpret_cast<cintp>(reinterpret_cast<uintptr_t>(a.wtiles)) + (size_t)wt * (sizeof(Tile) / sizeof(int));
+  const int n0 = tw[0], n1 = tw[1], e0 = tw[2], e1 = tw[3], g = tw[4];  // s_load_dwordx8
+  const int nn = n1 - n0, ne = e1 - e0;
 
   const size_t r = blockIdx.y;
   const float* __restrict__ ef = DE > 0 ? a.ef + r * (size_t)a.E * DE : nullptr;
   const float* __restrict__ nf = DN > 0 ? a.nf + r * (size_t)a.N * DN : nullptr;
+  const cfloatp gf = DG > 0 ? as_const(a.gf + (r * (size_t)a.G + g) * DG) : nullptr;
   const cfloatp We = as_const(a.We);
   const cfloatp Wn = as_const(a.Wn);
   const cfloatp be = as_const(a.be);
   const cfloatp bn = as_const(a.bn);
-  const int tid = threadIdx.x;
-  const int wg = xcd_tile(blockIdx.x, gridDim.x);
-  const int ti0 = wg * tiles_per_wg;
-  const int ti1 = ti0 + tiles_per_wg < a.n_tiles ? ti0 + tiles_per_wg : a.n_tiles;
-  typedef const int __attribute__((address_space(4))) * cintp;
-  const cintp tile_words = reinterpret_cast<cintp>(reinterpret_cast<uintptr_t>(a.tiles));  // scalar loads (s_load_dwordx8)
-  auto load_tile = [&](int i) {
-    Tile t;
-    const cintp w = tile_words + (size_t)i * (sizeof(Tile) / sizeof(int));
-    t.n0 = w[0]; t.n1 = w[1]; t.e0 = w[2]; t.e1 = w[3]; t.g = w[4]; t.win0 = w[5]; t.win1 = w[6]; t.flags = w[7];
-    return t;
-  };
 
-  // stage 1: every load whose address depends on the tile only
-  auto stage1 = [&](St& st, int staged_g) {
-    const Tile& t = st.t;
-    const int nn = t.n1 - t.n0, ne = t.e1 - t.e0;
-    const int cn = ne < TE ? ne : TE;
-    st.cp0 = st.cp1 = 0;
-    if (tid < nn) {
-      st.cp0 = a.colptr[t.n0 + tid] - t.e0;
-      st.cp1 = a.colptr[t.n0 + tid + 1] - t.e0;
-      if constexpr (DN > 0) load_row<DN>(nf + (size_t)(t.n0 + tid) * DN, st.xn);
-    }
+  // ---- issue every load up front, branch-free (indices clamped into the tile; results of clamped lanes unused) ----
+  const bool is_node = lane < nn;
+  const int nl = lane < nn ? lane : nn - 1;
+  const int cp0 = a.colptr[n0 + nl], cp1 = a.colptr[n0 + nl + 1];
+  float xn[DN1];
+  if constexpr (DN > 0) load_row<DN>(nf + (size_t)(n0 + nl) * DN, xn);
+  const int cn0 = ne < TEW ? ne : TEW;
+  float x[EPT][DE1];
+  float xs[EPT][DN1];
+  int src[EPT];
 #pragma unroll
-    for (int i = 0; i < EPT; ++i) {
-      const int el = tid + i * kThreads;
-      st.src[i] = t.n0;
-      if (el < cn) {
-        if constexpr (DE > 0) {
-          if (!(a.ablate & 1)) load_row<DE>(ef + (size_t)(t.e0 + el) * DE, st.x[i]);
-        }
+  for (int i = 0; i < EPT; ++i) {
+    int ec = lane + 64 * i;
+    ec = ec < cn0 ? ec : cn0 - 1;
+    int e = e0 + (ec > 0 ? ec : 0);
+    e = e < a.E ? e : a.E - 1;
+    if constexpr (DE > 0) load_row<DE>(ef + (size_t)e * DE, x[i]);
+    if constexpr (DN > 0) src[i] = a.rowval[e];
+  }
+  if constexpr (DN > 0) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) load_row<DN>(nf + (size_t)src[i] * DN, xs[i]);
+  }
+
+  // ---- lanes as nodes: destination index of each in-edge, per-node part of the edge update ----
+  //   pd[n] = be + We[:, gf-seg] * gf[g] + We[:, dst-seg] * nf[n]      (edgefninput.jl:5-6 hoisted out of the edge loop)
+  if (is_node) {
+    if (nn > 1)
+      for (int e = cp0 - e0; e < cp1 - e0; ++e) s_dst[e] = (unsigned char)lane;
+    if constexpr (OE > 0) {
+#pragma unroll
+      for (int j = 0; j < OE; ++j) {
+        float b = a.be ? be[j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < DG; ++k) b = fmaf(We[(DE + 2 * DN + k) * OE + j], gf[k], b);
+#pragma unroll
+        for (int k = 0; k < DN; ++k) b = fmaf(We[(DE + DN + k) * OE + j], xn[k], b);
+        s_pd[lane * OE + j] = b;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- lanes as edges ----
+  float psum[OE1];  // single-node tiles only: this lane's share of the node's edge sum
+#pragma unroll
+  for (int j = 0; j < OE1; ++j) psum[j] = 0.f;
+  for (int c0 = 0; c0 < ne; c0 += TEW) {
+    const int cn = (ne - c0) < TEW ? (ne - c0) : TEW;
+    if (c0 > 0) {  // further chunks of a single-node tile with a huge in-degree: loaded in place
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        int ec = lane + 64 * i;
+        ec = ec < cn ? ec : cn - 1;
+        const int e = e0 + c0 + ec;
+        if constexpr (DE > 0) load_row<DE>(ef + (size_t)e * DE, x[i]);
         if constexpr (DN > 0) {
-          if (!(a.ablate & 16)) st.src[i] = a.rowval[t.e0 + el];
+          src[i] = a.rowval[e];
+          load_row<DN>(nf + (size_t)src[i] * DN, xs[i]);
         }
       }
     }
-    if constexpr (WINDOW && DN > 0) {
-      if (t.g != staged_g) {  // node rows of the graph, flat and 16-B coalesced (tail/head handled at write time)
-        const float* gnd = nf + (size_t)t.win0 * DN;
-        const int n = (t.win1 - t.win0) * DN;
-        const int head = (int)(((16u - (unsigned)((uintptr_t)gnd & 15u)) & 15u) >> 2);
-        const int h = head < n ? head : n;
-        const int n4 = (n - h) >> 2;
-        const float4* g4 = reinterpret_cast<const float4*>(gnd + h);
+    if constexpr (OE > 0) {
 #pragma unroll
-        for (int i = 0; i < NV_ND; ++i) {
-          const int q = tid + i * kThreads;
-          if (q < n4) st.v_nd[i] = g4[q];
-        }
-      }
-    }
-  };
-  // stage 2: the source-row gather (address depends on rowval)
-  auto stage2 = [&](St& st) {
-    if constexpr (DN > 0 && !WINDOW) {
-      const int ne = st.t.e1 - st.t.e0;
-      const int cn = ne < TE ? ne : TE;
+      for (int i = 0; i < EPT; ++i) {
+        const int el = lane + 64 * i;
+        if (el < cn) {
+          const int dl = nn > 1 ? (int)s_dst[el] : 0;
+          float acc[OE1];
 #pragma unroll
-      for (int i = 0; i < EPT; ++i)
-        if (tid + i * kThreads < cn && !(a.ablate & 2)) load_row<DN>(nf + (size_t)st.src[i] * DN, st.xs[i]);
-    }
-  };
-
-  if (ti0 >= ti1) return;
-  St cur, nxt;
-  cur.t = load_tile(ti0);
-  int staged_g = -1;  // graph whose node rows are in s_nd
-  stage1(cur, staged_g);
-  if (ti0 + 1 < ti1) nxt.t = load_tile(ti0 + 1);
-  stage2(cur);
-
-  for (int ti = ti0; ti < ti1; ++ti) {
-    const bool has_next = ti + 1 < ti1;
-    const Tile t = cur.t;
-    const int nn = t.n1 - t.n0, ne = t.e1 - t.e0;
-    const bool is_node = tid < nn;
-    const cfloatp gf = DG > 0 ? as_const(a.gf + (r * (size_t)a.G + t.g) * DG) : nullptr;
-    if (has_next) stage1(nxt, t.g);  // prefetch: in flight during everything below
-    Tile t2 = t;
-    if (ti + 2 < ti1) t2 = load_tile(ti + 2);
-
-    // ---- node prep: destination index of every in-edge, per-node part of the edge update, node window ----
-    //   pd[n] = be + We[:, gf-seg] * gf[g] + We[:, dst-seg] * nf[n]     (edgefninput.jl:5-6 hoisted out of the edge loop)
-    if (is_node) {
-      if (nn > 1)
-        for (int e = cur.cp0; e < cur.cp1; ++e) s_dst[e] = (unsigned char)tid;
-      if constexpr (OE > 0) {
+          for (int j = 0; j < OE; ++j) acc[j] = s_pd[dl * OE + j];
 #pragma unroll
-        for (int j = 0; j < OE; ++j) {
-          float b = a.be ? be[j] : 0.f;
+          for (int k = 0; k < DE; ++k)
 #pragma unroll
-          for (int k = 0; k < DG; ++k) b = fmaf(We[(DE + 2 * DN + k) * OE + j], gf[k], b);
+            for (int j = 0; j < OE; ++j) acc[j] = fmaf(We[k * OE + j], x[i][k], acc[j]);
 #pragma unroll
-          for (int k = 0; k < DN; ++k) b = fmaf(We[(DE + DN + k) * OE + j], cur.xn[k], b);
-          s_pd[tid * OE + j] = b;
-        }
-      }
-    }
-    if constexpr (WINDOW && DN > 0) {
-      if (t.g != staged_g) {
-        const float* gnd = nf + (size_t)t.win0 * DN;
-        const int n = (t.win1 - t.win0) * DN;
-        const int head = (int)(((16u - (unsigned)((uintptr_t)gnd & 15u)) & 15u) >> 2);
-        const int h = head < n ? head : n;
-        const int n4 = (n - h) >> 2;
-        if (tid < h) s_nd[tid] = gnd[tid];
-        const int done = h + 4 * n4;
-        if (tid < n - done) s_nd[done + tid] = gnd[done + tid];
+          for (int k = 0; k < DN; ++k)
 #pragma unroll
-        for (int i = 0; i < NV_ND; ++i) {
-          const int q = tid + i * kThreads;
-          if (q < n4) {
-            float* d = s_nd + h + 4 * q;
-            d[0] = cur.v_nd[i].x; d[1] = cur.v_nd[i].y; d[2] = cur.v_nd[i].z; d[3] = cur.v_nd[i].w;
-          }
-        }
-        staged_g = t.g;
-      }
-    }
-    lds_barrier();
-
-    // ---- edge update: first chunk from the prefetched registers, further chunks (single-node tile with a huge
-    //      in-degree only) loaded in place ----
-    float psum[OE1];
+            for (int j = 0; j < OE; ++j) acc[j] = fmaf(We[(DE + k) * OE + j], xs[i][k], acc[j]);
 #pragma unroll
-    for (int j = 0; j < OE1; ++j) psum[j] = 0.f;
-    for (int c0 = 0; c0 < ne; c0 += TE) {
-      const int cn = (ne - c0) < TE ? (ne - c0) : TE;
-      if (c0 > 0) {
+          for (int j = 0; j < OE; ++j) acc[j] = act_apply(acc[j], a.act_e);
+          store_row<OE>(a.ef_out + (r * (size_t)a.E + e0 + c0 + el) * OE, acc);
+          if (nn > 1) {
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-          const int el = tid + i * kThreads;
-          if (el < cn) {
-            if constexpr (DE > 0) load_row<DE>(ef + (size_t)(t.e0 + c0 + el) * DE, cur.x[i]);
-            if constexpr (DN > 0) {
-              cur.src[i] = a.rowval[t.e0 + c0 + el];
-              if constexpr (!WINDOW) load_row<DN>(nf + (size_t)cur.src[i] * DN, cur.xs[i]);
-            }
-          }
-        }
-      }
-      if constexpr (OE > 0) {
+            for (int j = 0; j < OE; ++j) s_out[el * OE + j] = acc[j];
+          } else {
 #pragma unroll
-        for (int i = 0; i < EPT; ++i) {
-          const int el = tid + i * kThreads;
-          if (el < cn) {
-            const int dl = nn > 1 ? (int)s_dst[el] : 0;
-            float acc[OE1];
-#pragma unroll
-            for (int j = 0; j < OE; ++j) acc[j] = s_pd[dl * OE + j];
-            if constexpr (DE > 0) {
-#pragma unroll
-              for (int k = 0; k < DE; ++k)
-#pragma unroll
-                for (int j = 0; j < OE; ++j) acc[j] = fmaf(We[k * OE + j], cur.x[i][k], acc[j]);
-            }
-            if constexpr (DN > 0) {
-              if constexpr (WINDOW) {
-#pragma unroll
-                for (int k = 0; k < DN; ++k) cur.xs[i][k] = s_nd[(cur.src[i] - t.win0) * DN + k];
-              }
-#pragma unroll
-              for (int k = 0; k < DN; ++k)
-#pragma unroll
-                for (int j = 0; j < OE; ++j) acc[j] = fmaf(We[(DE + k) * OE + j], cur.xs[i][k], acc[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < OE; ++j) acc[j] = act_apply(acc[j], a.act_e);
-            if (!(a.ablate & 4)) store_row<OE>(a.ef_out + (r * (size_t)a.E + t.e0 + c0 + el) * OE, acc);
-            if (nn > 1) {
-#pragma unroll
-              for (int j = 0; j < OE; ++j) s_out[el * OE + j] = acc[j];
-            } else {
-#pragma unroll
-              for (int j = 0; j < OE; ++j) psum[j] += acc[j];
-            }
+            for (int j = 0; j < OE; ++j) psum[j] += acc[j];
           }
         }
       }
     }
-    if (has_next) stage2(nxt);  // next tile's gather flies during the node phase below
+  }
+  __builtin_amdgcn_wave_barrier();
 
-    // ---- node update ----
-    float v[C1];  // per-thread contribution to the tile's graph-level partial sums: [agg ; nf']
+  // ---- lanes as nodes: edge->node sum (nodefninput.jl:3), node update ----
+  float v[C1];  // per-lane contribution to the tile's graph-level partial sums: [agg ; nf']
 #pragma unroll
-    for (int c = 0; c < C1; ++c) v[c] = 0.f;
+  for (int c = 0; c < C1; ++c) v[c] = 0.f;
+  if constexpr (OE > 0) {
     if (nn == 1) {
-      // every edge of the tile aggregates into its only node: agg = block-wide sum of the per-thread shares
-      if constexpr (OE > 0) {
-        block_rows_to_lds<OE>(psum, s_red);
-        if (tid == 0) {
 #pragma unroll
-          for (int j = 0; j < OE; ++j) v[j] = sum16(s_red, OE, j);
-        }
-        lds_barrier();  // s_red is reused below
+      for (int j = 0; j < OE; ++j) {
+        const float tot = wave_sum(psum[j]);
+        v[j] = lane == 0 ? tot : 0.f;
       }
-    } else {
-      lds_barrier();  // s_out complete
-      if constexpr (OE > 0) {
-        if (is_node) {  // contiguous segmented sum (edges are dst-sorted, src/pad.jl:30), fixed order
-          for (int e = cur.cp0; e < cur.cp1; ++e) {
+    } else if (is_node) {  // contiguous segmented sum (edges are dst-sorted, src/pad.jl:30), fixed order
+      for (int e = cp0 - e0; e < cp1 - e0; ++e) {
 #pragma unroll
-            for (int j = 0; j < OE; ++j) v[j] += s_out[e * OE + j];
-          }
-        }
+        for (int j = 0; j < OE; ++j) v[j] += s_out[e * OE + j];
       }
     }
-    if constexpr (ON > 0) {
-      if (is_node) {
-        float acc[ON1];
+  }
+  if constexpr (ON > 0) {
+    if (is_node) {
+      float acc[ON1];
 #pragma unroll
-        for (int j = 0; j < ON; ++j) {
-          float b = a.bn ? bn[j] : 0.f;
+      for (int j = 0; j < ON; ++j) {
+        float b = a.bn ? bn[j] : 0.f;
 #pragma unroll
-          for (int k = 0; k < DG; ++k) b = fmaf(Wn[(OE + DN + k) * ON + j], gf[k], b);
-          acc[j] = b;
-        }
-#pragma unroll
-        for (int k = 0; k < OE; ++k)
-#pragma unroll
-          for (int j = 0; j < ON; ++j) acc[j] = fmaf(Wn[k * ON + j], v[k], acc[j]);
-#pragma unroll
-        for (int k = 0; k < DN; ++k)
-#pragma unroll
-          for (int j = 0; j < ON; ++j) acc[j] = fmaf(Wn[(OE + k) * ON + j], cur.xn[k], acc[j]);
-#pragma unroll
-        for (int j = 0; j < ON; ++j) {
-          acc[j] = act_apply(acc[j], a.act_n);
-          v[OE + j] = acc[j];
-        }
-        if (!(a.ablate & 8)) store_row<ON>(a.nf_out + (r * (size_t)a.N + t.n0 + tid) * ON, acc);
+        for (int k = 0; k < DG; ++k) b = fmaf(Wn[(OE + DN + k) * ON + j], gf[k], b);
+        acc[j] = b;
       }
+#pragma unroll
+      for (int k = 0; k < OE; ++k)
+#pragma unroll
+        for (int j = 0; j < ON; ++j) acc[j] = fmaf(Wn[k * ON + j], v[k], acc[j]);
+#pragma unroll
+      for (int k = 0; k < DN; ++k)
+#pragma unroll
+        for (int j = 0; j < ON; ++j) acc[j] = fmaf(Wn[(OE + k) * ON + j], xn[k], acc[j]);
+#pragma unroll
+      for (int j = 0; j < ON; ++j) {
+        acc[j] = act_apply(acc[j], a.act_n);
+        v[OE + j] = acc[j];
+      }
+      store_row<ON>(a.nf_out + (r * (size_t)a.N + n0 + lane) * ON, acc);
     }
+  }
 
-    // ---- per-tile partial sums for the graph update (graphfninput.jl:3-4): sum_e ef' = sum_n agg[n], sum_n nf' ----
-    if (a.og > 0) {
-      if constexpr (C > 0) {
-        block_rows_to_lds<C>(v, s_red);
-        if (tid < C) a.partials[(r * (size_t)a.n_tiles + ti) * C + tid] = sum16(s_red, C, tid);
+  // ---- per-tile partial sums for the graph update (graphfninput.jl:3-4): sum_e ef' = sum_n agg[n], sum_n nf'.
+  //      Stored transposed [c][tile] so the graph kernel reads them with 16-B loads. ----
+  if (a.og > 0) {
+    if constexpr (C > 0) {
+      float mine = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float tot = wave_sum(v[c]);
+        mine = lane == c ? tot : mine;
       }
-    } else {
-      lds_barrier();  // s_out / s_pd / s_dst are rewritten by the next tile
+      if (lane < C) a.partials[(r * C + lane) * (size_t)prow_stride + wt] = mine;
     }
-    cur = nxt;
-    nxt.t = t2;
   }
 }
 
-int32_t launch_graph(const BlockArgs& a, int64_t R, hipStream_t s);
+// Graph update for the wave path: gf'[g] = act(Wg * [sum_e ef' ; sum_n nf' ; gf_g] + bg) from transposed partials
+// [C][prow_stride].  Latency is everything here (a few KB of work): EVERY global load — this thread's partial quads,
+// its slice of Wg / bg / gf — is issued before the first wait, so the kernel pays one memory round trip; the sums
+// are reduced with DPP + one LDS hop in a fixed order.
+template <int C>
+__global__ void k_graph_t(BlockArgs a, int prow_stride) {
+  extern __shared__ float s_g[];
+  constexpr int MAXQ = 2;  // quads per thread kept in registers per pass
+  const int g = blockIdx.x;
+  const size_t r = blockIdx.y;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int t0 = a.wtile_off[g], t1 = a.wtile_off[g + 1];
+  const float* __restrict__ base = a.partials + r * C * (size_t)prow_stride;
+  const int K = C + a.dg, og = a.og;
+  const int nrow16 = nthr >> 4;
+  float* s_x = s_g + (size_t)nrow16 * C;  // [K]   graph-function input
+  float* s_w = s_x + K + 4;               // [K*og] weights, [og] bias
 
-template <int DE, int DN, int DG, int OE, int ON, int TE, int TN>
-static int32_t launch_fused_t(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s) {
-  // LDS node window only when EVERY graph fits it (then every source of an edge is inside the staged rows)
-  static const bool no_window = getenv("GNX_NO_WINDOW") != nullptr;
-  static const int wg_per_cu = getenv("GNX_WG_PER_CU") ? atoi(getenv("GNX_WG_PER_CU")) : 4;
-  static const int fixed_k = getenv("GNX_TILES_PER_WG") ? atoi(getenv("GNX_TILES_PER_WG")) : 0;
-  const bool window = DN > 0 && h->PN <= 256 && !no_window;
-  // persistent grid: about wg_per_cu workgroups per CU (256 CUs), each walking K consecutive tiles
-  int K = fixed_k > 0 ? fixed_k : (int)((a.n_tiles + 256 * wg_per_cu - 1) / (256 * wg_per_cu));
-  if (K < 1) K = 1;
-  const unsigned grid = (unsigned)((a.n_tiles + K - 1) / K);
+  // prefetch weights / bias / gf (tiny, L2) — independent of the partial sums
+  const int nw = K * og;
+  float w_reg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + i * nthr;
+    w_reg[i] = idx < nw ? a.Wg[idx] : (idx < nw + og ? (a.bg ? a.bg[idx - nw] : 0.f) : 0.f);
+  }
+  float gf_reg = 0.f;
+  if (tid < a.dg) gf_reg = a.gf[(r * (size_t)a.G + g) * a.dg + tid];
+
+  float acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+  for (int q0 = (t0 >> 2) + tid; 4 * q0 < t1; q0 += MAXQ * nthr) {
+    float4 val[MAXQ][C];
+#pragma unroll
+    for (int u = 0; u < MAXQ; ++u) {
+      const int q = q0 + u * nthr;
+      if (4 * q < t1) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) val[u][c] = *reinterpret_cast<const float4*>(base + (size_t)c * prow_stride + 4 * q);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < MAXQ; ++u) {
+      const int row = 4 * (q0 + u * nthr);
+      if (row < t1) {
+        const bool k0 = row >= t0, k1 = row + 1 >= t0 && row + 1 < t1, k2 = row + 2 >= t0 && row + 2 < t1, k3 = row + 3 < t1;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          acc[c] += ((k0 ? val[u][c].x : 0.f) + (k1 ? val[u][c].y : 0.f)) + ((k2 ? val[u][c].z : 0.f) + (k3 ? val[u][c].w : 0.f));
+      }
+    }
+  }
+  // weights to LDS (loads have long since landed)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + i * nthr;
+    if (idx < nw + og) s_w[idx] = w_reg[i];
+  }
+  for (int idx = tid + 4 * nthr; idx < nw + og; idx += nthr) s_w[idx] = idx < nw ? a.Wg[idx] : (a.bg ? a.bg[idx - nw] : 0.f);
+  if (tid < a.dg) s_x[C + tid] = gf_reg;
+  for (int k = tid + nthr; k < a.dg; k += nthr) s_x[C + k] = a.gf[(r * (size_t)a.G + g) * a.dg + k];
+  const int lane = tid & 63, row16 = tid >> 4;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float x = row16_sum(acc[c]);
+    if ((lane & 15) == 0) s_g[row16 * C + c] = x;
+  }
+  __syncthreads();
+  // second stage: wave 0 sums the <= 64 row sums of every column (fixed order: DPP tree + 4 readlanes)
+  if (tid < 64) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float x = wave_sum(tid < nrow16 ? s_g[tid * C + c] : 0.f);
+      if (tid == 0) s_x[c] = x;
+    }
+  }
+  __syncthreads();
+  float* out = a.gf_out + (r * (size_t)a.G + g) * og;
+  for (int j = tid; j < og; j += nthr) {
+    float y = s_w[nw + j];
+    for (int k = 0; k < K; ++k) y = fmaf(s_w[k * og + j], s_x[k], y);
+    out[j] = act_apply(y, a.act_g);
+  }
+}
+
+template <int DE, int DN, int DG, int OE, int ON, int EPT>
+static int32_t launch_wave_t(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s) {
+  constexpr int C = OE + ON;
+  const int prow_stride = (int)((h->n_wtiles() + 3) / 4 * 4 + 4);
+  const unsigned grid = (unsigned)((a.n_wtiles + 3) / 4);
   {
-    ProfScope ps("k_block_fused", s);
-    if (window)
-      hipLaunchKernelGGL((k_block_fused<DE, DN, DG, OE, ON, TE, TN, true>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, K);
-    else
-      hipLaunchKernelGGL((k_block_fused<DE, DN, DG, OE, ON, TE, TN, false>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, K);
+    ProfScope ps("k_block_wave", s);
+    hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, prow_stride);
     GNX_HIP(hipGetLastError());
   }
-  return launch_graph(a, R, s);
+  if (a.og > 0) {
+    if constexpr (C > 0) {
+      // block size by the number of partial rows per graph: 1024 threads cover 4096 rows per pass
+      const int64_t rows_per_graph = (h->n_wtiles() + h->G - 1) / h->G;
+      const int threads = rows_per_graph > 1024 ? 1024 : (rows_per_graph > 128 ? 256 : 64);
+      const size_t lds = sizeof(float) * ((size_t)(threads / 16) * C + (C + a.dg + 4) + (size_t)(C + a.dg + 1) * a.og + 8);
+      ProfScope ps("k_graph_t", s);
+      hipLaunchKernelGGL((k_graph_t<C>), dim3((unsigned)a.G, (unsigned)R), dim3(threads), lds, s, a, prow_stride);
+      GNX_HIP(hipGetLastError());
+    }
+  }
+  return GNX_OK;
 }
-
-template <int DE, int DN, int DG, int OE, int ON, int TE, int TN>
-constexpr bool fused_fits() { return (size_t)TE * (4 * OE + 1) + 256 * 4 * (size_t)DN + (size_t)TN * 4 * OE + 16 * 4 * (OE + ON) + 512 <= 60 * 1024; }
 
 template <int DE, int DN, int DG, int OE, int ON>
 static int32_t launch_fused(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s) {
-  // the kernel's tile shape must cover the handle's tile caps (GNX_TILE_E / GNX_TILE_N at handle creation)
-  if (h->tile_e_cap <= 256 && h->tile_n_cap <= 64) {
-    if constexpr (fused_fits<DE, DN, DG, OE, ON, 256, 64>()) return launch_fused_t<DE, DN, DG, OE, ON, 256, 64>(h, a, R, s);
-  } else if (h->tile_e_cap <= 512 && h->tile_n_cap <= 128) {
-    if constexpr (fused_fits<DE, DN, DG, OE, ON, 512, 128>()) return launch_fused_t<DE, DN, DG, OE, ON, 512, 128>(h, a, R, s);
-  } else if (h->tile_e_cap <= 1024 && h->tile_n_cap <= 256) {
-    if constexpr (fused_fits<DE, DN, DG, OE, ON, 1024, 256>()) return launch_fused_t<DE, DN, DG, OE, ON, 1024, 256>(h, a, R, s);
+  // the kernel's EPT must match the handle's wave-tile edge cap (GNX_WTILE_E at handle creation: 64, 128 or 256)
+  if (h->wtile_e_cap == 64) return launch_wave_t<DE, DN, DG, OE, ON, 1>(h, a, R, s);
+  if (h->wtile_e_cap == 128) return launch_wave_t<DE, DN, DG, OE, ON, 2>(h, a, R, s);
+  if (h->wtile_e_cap == 256) {
+    if constexpr ((DE + DN) * 4 <= 64) return launch_wave_t<DE, DN, DG, OE, ON, 4>(h, a, R, s);
   }
   return 1;
 }
@@ -464,7 +437,7 @@ static int32_t launch_fused(const gnx_graphs* h, const BlockArgs& a, int64_t R, 
   X(10, 5, 0, 10, 5)
 
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s) {
-  if (h->tile_n_cap > 256 || a.n_tiles == 0) return 1;
+  if (a.n_wtiles == 0 || a.E == 0) return 1;
   // 16-B vector copies assume fp32-aligned buffers (always true for fp32 arrays); nothing else is required
 #define GNX_CASE(DE, DN, DG, OE, ON) \
   if (a.de == DE && a.dn == DN && a.dg == DG && a.oe == OE && a.on == ON) return launch_fused<DE, DN, DG, OE, ON>(h, a, R, s);
