@@ -1,0 +1,79 @@
+"""GPU parity of GNCore / GNCoreList / composite models (reference tests: runtests.jl:166-326, :685-735)."""
+import numpy as np
+import pytest
+
+from oracle import gn_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+README_ADJ = np.array([[1, 0, 1], [1, 1, 0], [0, 0, 1]])
+
+
+@pytest.fixture(scope="module")
+def gn():
+    import graphnets_jl_amd as gn
+    return gn
+
+
+@pytest.mark.parametrize("eps_mode", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1], ids=["default", "generic"])
+def test_core_shared_batch(gn, eps_mode, flags):
+    """GNCore(3,4,5) on the README graph, batch_size 2 (gncore.jl docstring, runtests.jl:685-709)."""
+    rng = np.random.default_rng(40 + eps_mode)
+    p = O.make_core_params(rng, (3, 4, 5), eps_mode=eps_mode)
+    ef, nf, gf = rng.random((3, 5, 2), dtype=np.float32), rng.random((4, 3, 2), dtype=np.float32), rng.random((5, 2), dtype=np.float32)
+    core = U.core_from_params(gn, p)
+    core.flags = flags
+    y = gn.unbatch(core(gn.batch(dict(graphs=README_ADJ, ef=ef, nf=nf, gf=gf))))
+    assert tuple(y.ef.shape) == (3, 5, 2) and tuple(y.nf.shape) == (4, 3, 2) and tuple(y.gf.shape) == (5, 2)
+    ref = O.unbatch_dense(O.core_forward_dense(p, O.batch_dense(README_ADJ, ef, nf, gf)))
+    for k in ("ef", "nf", "gf"):
+        np.testing.assert_allclose(getattr(y, k).cpu().numpy(), ref[k], rtol=2e-4, atol=2e-4)
+
+
+def test_core_hetero_batch_and_corelist(gn):
+    """GNCoreList([core, core]) (gncorelist.jl:43-45) on a heterogeneous batch of random graphs."""
+    rng = np.random.default_rng(42)
+    adjs = U.random_graphs(rng, (6, 11, 3, 17), 0.35)
+    dims = (6, 5, 3)
+    ps = [O.make_core_params(rng, dims), O.make_core_params(rng, dims)]
+    g = gn.GNGraphBatch(adjs)
+    csc = O.csc_from_adj(adjs)
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims)
+    model = gn.GNCoreList([U.core_from_params(gn, p) for p in ps])
+    y = model(U.to_nt(gn, g, ef, nf, gf))
+    r = (ef, nf, gf)
+    for p in ps:
+        r = O.core_forward_sparse(p, csc, *r)
+    for got, ref in zip((y.ef, y.nf, y.gf), r):
+        np.testing.assert_allclose(U.from_jl(got), ref, rtol=5e-4, atol=5e-4)
+
+
+def test_readme_example_3_encoder_core_decoder(gn):
+    """README ex.3 / runtests.jl:271-326: GNBlock(in=>core) -> GNCoreList(2 x GNCore(core)) -> GNBlock(core=>out),
+    core_dims (10,5,3); here the composite IS executed and checked (the reference test only calls `block`)."""
+    rng = np.random.default_rng(43)
+    in_dims, core_dims, out_dims = (10, 5, 0), (10, 5, 3), (3, 4, 5)
+    pe, pd = O.make_block_params(rng, in_dims, core_dims), O.make_block_params(rng, core_dims, out_dims)
+    pcs = [O.make_core_params(rng, core_dims) for _ in range(2)]
+    ef, nf = rng.random((10, 5, 2), dtype=np.float32), rng.random((5, 3, 2), dtype=np.float32)
+    enc, dec = U.block_from_params(gn, pe), U.block_from_params(gn, pd)
+    cores = gn.GNCoreList([U.core_from_params(gn, p) for p in pcs])
+    y = gn.unbatch(dec(cores(enc(gn.batch(dict(graphs=README_ADJ, ef=ef, nf=nf, gf=None))))))
+    assert tuple(y.ef.shape) == (3, 5, 2) and tuple(y.nf.shape) == (4, 3, 2) and tuple(y.gf.shape) == (5, 2)
+    x = O.block_forward_dense(pe, O.batch_dense(README_ADJ, ef, nf, None))
+    for p in pcs:
+        x = O.core_forward_dense(p, x)
+    ref = O.unbatch_dense(O.block_forward_dense(pd, x))
+    for k in ("ef", "nf", "gf"):
+        np.testing.assert_allclose(getattr(y, k).cpu().numpy(), ref[k], rtol=1e-3, atol=1e-3)
+
+
+def test_core_requires_all_features(gn):
+    core = gn.GNCore((3, 4, 5))
+    rng = np.random.default_rng(44)
+    x = gn.batch(dict(graphs=README_ADJ, ef=rng.random((3, 5, 2), dtype=np.float32), nf=rng.random((4, 3, 2), dtype=np.float32), gf=None))
+    with pytest.raises(AssertionError):  # graphnetadd needs ef, nf and gf (gncore.jl:61-68)
+        core(x)
+    with pytest.raises(AssertionError):  # gnfeedforward.jl:18 all(dims .> 0)
+        gn.GNCore((3, 0, 5))
