@@ -1,0 +1,189 @@
+# GraphNetsHIP.jl — thin `ccall` shim over libgnx.so (include/gnx.h) that keeps GraphNets.jl's API for the forward
+# hot path: GNBlock(in => out), block(x), GNCore, GNCoreList, batch, unbatch, efview/nfview/gfview, flatunpadded*.
+#
+# Status: shipped as source.  Julia is not installed in the build image nor on the GPU box, so this file is NOT
+# exercised by the test-suite; the tested host mirror of the same ABI is graphnets.jl_amd/api.py.  Host `Array`s are
+# staged through `hipMalloc`/`hipMemcpy` (libamdhip64); with AMDGPU.jl, `ROCArray` pointers can be passed straight
+# to the `gnx_*` calls instead (the ABI takes raw device pointers).
+#
+# Layout note: a Julia `Array{Float32,3}` of size (D, T, B) is byte-identical to the ABI's packed [B][T][D] rows, and
+# `Dense.weight` (out × in, column-major) is byte-identical to `gnx_dense.weight`; nothing is transposed or copied on
+# the host.  The batched tuple is PACKED: `x.ef` is (DE, ΣE, 1) for a vector of graphs instead of the reference's
+# padded (DE, PN², B); `unbatch`/views/`flatunpadded*` return what the reference returns.
+module GraphNetsHIP
+
+export GNGraphBatch, GNBlock, GNCore, GNCoreList, Dense, LayerNorm, batch, unbatch,
+       efview, nfview, gfview, flatunpaddednf, flatunpaddedef, zerodim2nothing
+
+const libgnx = get(ENV, "GNX_LIB", joinpath(@__DIR__, "..", "graphnets.jl_amd", "libgnx.so"))
+const libhip = get(ENV, "GNX_HIP_LIB", "libamdhip64.so")
+
+# ---- error handling: every gnx_* returns Int32 (0 ok, <0 argument error mirroring an @assert, >0 hipError_t) ----
+function check(rc::Integer)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:gnx_last_error, libgnx), Cstring, ()))
+    rc < 0 ? throw(AssertionError("gnx $(rc): $(msg)")) : error("gnx HIP error $(rc): $(msg)")
+end
+hipcheck(rc) = rc == 0 ? nothing : error("HIP error $(rc)")
+
+# ---- tiny device-buffer helper (replace by AMDGPU.ROCArray if available) ----
+mutable struct DevBuf
+    ptr::Ptr{Cvoid}
+    bytes::Int
+    function DevBuf(bytes::Integer)
+        p = Ref{Ptr{Cvoid}}(C_NULL)
+        hipcheck(ccall((:hipMalloc, libhip), Cint, (Ptr{Ptr{Cvoid}}, Csize_t), p, max(bytes, 16)))
+        b = new(p[], bytes)
+        finalizer(x -> ccall((:hipFree, libhip), Cint, (Ptr{Cvoid},), x.ptr), b)
+        b
+    end
+end
+function upload(a::Array{Float32})
+    b = DevBuf(sizeof(a))
+    hipcheck(ccall((:hipMemcpy, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), b.ptr, a, sizeof(a), 1))
+    b
+end
+upload(::Nothing) = nothing
+function download!(a::Array{Float32}, b::DevBuf)
+    hipcheck(ccall((:hipMemcpy, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), a, b.ptr, sizeof(a), 2))
+    a
+end
+devptr(b::DevBuf) = Ptr{Cfloat}(b.ptr)
+devptr(::Nothing) = Ptr{Cfloat}(C_NULL)
+
+# ---- C structs of include/gnx.h ----
+struct GnxDense
+    weight::Ptr{Cfloat}; bias::Ptr{Cfloat}; act::Int32; reserved::Int32
+end
+struct GnxBlockParams
+    de::Int32; dn::Int32; dg::Int32; oe::Int32; on::Int32; og::Int32
+    edgefn::GnxDense; nodefn::GnxDense; graphfn::GnxDense
+end
+struct GnxGraphsInfo
+    n_graphs::Int64; n_nodes::Int64; n_edges::Int64; node_block_size::Int64; edge_block_size::Int64
+    n_tiles::Int64; max_in_degree::Int64; device::Int32; reserved::Int32
+end
+const ACT = Dict(identity => 0, :relu => 1, :tanh => 2, :sigmoid => 3, :gelu => 4)
+
+# ---- GNGraphBatch(adj_mats)  (replaces src/gngraphbatch.jl:33-54) ----
+mutable struct GNGraphBatch
+    handle::Ptr{Cvoid}
+    adj_mats::Vector
+    node_block_size::Int
+    edge_block_size::Int
+    node_off::Vector{Int64}   # 0-based offsets of each graph's nodes / edges in the packed arrays
+    edge_off::Vector{Int64}
+    function GNGraphBatch(adj_mats::AbstractVector)
+        @assert length(adj_mats) > 0
+        mats = [Matrix{Float32}(a) for a in adj_mats]            # column-major, as Julia stores them
+        ptrs = [pointer(m) for m in mats]
+        nn = Int64[size(m, 1) for m in mats]
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve mats check(ccall((:gnx_graphs_create_dense, libgnx), Int32,
+            (Ptr{Ptr{Cvoid}}, Ptr{Int64}, Int64, Int32, Int32, Ptr{Ptr{Cvoid}}),
+            ptrs, nn, length(mats), 3 #=GNX_ELEM_F32=#, 0 #=column-major=#, h))
+        info = Ref{GnxGraphsInfo}()
+        check(ccall((:gnx_graphs_get_info, libgnx), Int32, (Ptr{Cvoid}, Ptr{GnxGraphsInfo}), h[], info))
+        no = zeros(Int64, length(mats) + 1); eo = zeros(Int64, length(mats) + 1)
+        check(ccall((:gnx_graphs_get_offsets, libgnx), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), h[], no, eo))
+        g = new(h[], collect(adj_mats), info[].node_block_size, info[].edge_block_size, no, eo)
+        finalizer(x -> ccall((:gnx_graphs_destroy, libgnx), Int32, (Ptr{Cvoid},), x.handle), g)
+        g
+    end
+end
+nnodes(g::GNGraphBatch) = Int(g.node_off[end]); nedges(g::GNGraphBatch) = Int(g.edge_off[end])
+ngraphs(g::GNGraphBatch) = length(g.adj_mats)
+
+# ---- batch / unbatch / views  (src/batch.jl:53-64, src/unbatch.jl, src/unpad.jl, src/views.jl) ----
+function batch(t::NamedTuple)
+    @assert Set(keys(t)) == Set((:graphs, :ef, :nf, :gf))
+    (; graphs, ef, nf, gf) = t
+    @assert !isnothing(ef) || !isnothing(nf) || !isnothing(gf)
+    if graphs isa AbstractMatrix                                  # shared adjacency: ef (DE,E,B), nf (DN,N,B), gf (DG,B)
+        g = GNGraphBatch([graphs])
+        isnothing(ef) || @assert ndims(ef) == 3 && size(ef, 2) == nedges(g) "$(size(ef, 2)) != num_edges"
+        isnothing(nf) || @assert ndims(nf) == 3 && size(nf, 2) == nnodes(g)
+        isnothing(gf) || @assert ndims(gf) == 2
+        return (graphs=g, ef=ef, nf=nf, gf=isnothing(gf) ? nothing : reshape(gf, size(gf, 1), 1, size(gf, 2)))
+    end
+    g = GNGraphBatch(graphs)                                      # vector of graphs: pack graph-major
+    cat2(v) = isnothing(v) ? nothing : reshape(reduce(hcat, v), size(v[1], 1), :, 1)
+    isnothing(ef) || @assert length(ef) == ngraphs(g)
+    isnothing(nf) || @assert length(nf) == ngraphs(g)
+    bef, bnf = cat2(ef), cat2(nf)
+    isnothing(bef) || @assert size(bef, 2) == nedges(g)
+    isnothing(bnf) || @assert size(bnf, 2) == nnodes(g)
+    (graphs=g, ef=bef, nf=bnf, gf=isnothing(gf) ? nothing : reshape(reduce(hcat, gf), length(gf[1]), :, 1))
+end
+
+sharedlike(g::GNGraphBatch) = ngraphs(g) == 1                      # unbatch.jl:15-17
+function unbatch(t::NamedTuple)
+    (; graphs, ef, nf, gf) = t
+    g = graphs
+    if sharedlike(g)
+        return (graphs=g.adj_mats[1], ef=ef, nf=nf, gf=isnothing(gf) ? nothing : reshape(gf, size(gf, 1), :))
+    end
+    rng(off, i) = (off[i]+1):off[i+1]
+    (graphs=g.adj_mats,
+     ef=isnothing(ef) ? nothing : [view(ef, :, rng(g.edge_off, i), 1) for i in 1:ngraphs(g)],
+     nf=isnothing(nf) ? nothing : [view(nf, :, rng(g.node_off, i), 1) for i in 1:ngraphs(g)],
+     gf=isnothing(gf) ? nothing : [view(gf, :, i, 1) for i in 1:ngraphs(g)])
+end
+efview(t::NamedTuple, d1, d2, d3) = isnothing(t.ef) ? nothing :
+    sharedlike(t.graphs) ? view(t.ef, d1, d2, d3) : view(view(t.ef, :, (t.graphs.edge_off[d3]+1):t.graphs.edge_off[d3+1], 1), d1, d2)
+nfview(t::NamedTuple, d1, d2, d3) = isnothing(t.nf) ? nothing :
+    sharedlike(t.graphs) ? view(t.nf, d1, d2, d3) : view(view(t.nf, :, (t.graphs.node_off[d3]+1):t.graphs.node_off[d3+1], 1), d1, d2)
+gfview(t::NamedTuple, d1, d2) = isnothing(t.gf) ? nothing :
+    sharedlike(t.graphs) ? view(t.gf, d1, 1, d2) : view(t.gf, d1, d2, 1)
+flatunpaddednf(t::NamedTuple) = reshape(t.nf, size(t.nf, 1), :)       # the packed layout already is it (views.jl:80-88)
+flatunpaddedef(t::NamedTuple) = reshape(t.ef, size(t.ef, 1), :)
+zerodim2nothing(t::NamedTuple) = (graphs=t.graphs, ef=t.ef, nf=t.nf, gf=t.gf)  # zero-width outputs are already `nothing`
+
+# ---- layers ----
+struct Dense
+    weight::Matrix{Float32}; bias::Vector{Float32}; σ
+end
+glorot(out, in) = (rand(Float32, out, in) .* 2f0 .- 1f0) .* sqrt(6f0 / max(in + out, 1))
+Dense(in::Integer, out::Integer, σ=identity) = Dense(glorot(out, in), zeros(Float32, out), σ)
+actcode(σ) = get(ACT, σ, get(ACT, Symbol(σ), nothing))
+
+struct GNBlock
+    edgefn::Dense; nodefn::Dense; graphfn::Dense; dropout
+    in::NTuple{3,Int}; out::NTuple{3,Int}
+end
+function GNBlock((in, out)::Pair; dropout=0)                          # src/gnblock.jl:47-61
+    @assert any(in .> (0, 0, 0)); @assert any(out .> (0, 0, 0))
+    (de, dn, dg), (oe, on, og) = in, out
+    GNBlock(Dense(de + 2dn + dg, oe), Dense(dn + oe + dg, on), Dense(on + oe + dg, og), dropout, Tuple(in), Tuple(out))
+end
+
+function (m::GNBlock)(x)                                              # src/gnblock.jl:63-69 → gnx_block_forward
+    (; graphs, ef, nf, gf) = x
+    g::GNGraphBatch = graphs
+    R = size(something(ef, nf, gf), 3)
+    (oe, on, og) = m.out
+    W = [upload(m.edgefn.weight), upload(m.nodefn.weight), upload(m.graphfn.weight)]
+    B = [upload(m.edgefn.bias), upload(m.nodefn.bias), upload(m.graphfn.bias)]
+    mk(d::Dense, w, b) = GnxDense(devptr(w), devptr(b), Int32(actcode(d.σ)), 0)
+    p = Ref(GnxBlockParams(m.in..., m.out..., mk(m.edgefn, W[1], B[1]), mk(m.nodefn, W[2], B[2]), mk(m.graphfn, W[3], B[3])))
+    d_ef, d_nf, d_gf = upload(ef), upload(nf), upload(gf)
+    o_ef, o_nf, o_gf = zeros(Float32, oe, nedges(g), R), zeros(Float32, on, nnodes(g), R), zeros(Float32, og, ngraphs(g), R)
+    b_ef, b_nf, b_gf = DevBuf(sizeof(o_ef)), DevBuf(sizeof(o_nf)), DevBuf(sizeof(o_gf))
+    wsb = ccall((:gnx_block_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxBlockParams}, Int64), g.handle, p, R)
+    ws = DevBuf(wsb)
+    GC.@preserve W B d_ef d_nf d_gf b_ef b_nf b_gf ws check(ccall((:gnx_block_forward, libgnx), Int32,
+        (Ptr{Cvoid}, Ptr{GnxBlockParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat},
+         Ptr{Cvoid}, Csize_t, UInt32, Ptr{Cvoid}),
+        g.handle, p, devptr(d_ef), devptr(d_nf), devptr(d_gf), R, devptr(b_ef), devptr(b_nf), devptr(b_gf),
+        ws.ptr, wsb, UInt32(0), C_NULL))
+    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
+    (graphs=g, ef=oe == 0 ? nothing : download!(o_ef, b_ef), nf=on == 0 ? nothing : download!(o_nf, b_nf),
+     gf=og == 0 ? nothing : download!(o_gf, b_gf))                    # zero-width outputs → nothing (gnblock.jl:71-78)
+end
+
+# GNCore / GNCoreList follow the same pattern with gnx_core_params / gnx_core_forward (include/gnx.h); GNCoreList is
+# `foldl((x, f) -> f(x), list; init=x)` exactly as src/gncorelist.jl:43-45.
+struct GNCoreList{T}; list::T; end
+(m::GNCoreList)(x) = foldl((i, fn) -> fn(i), m.list; init=x)
+
+end # module
