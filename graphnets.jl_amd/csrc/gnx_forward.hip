@@ -51,7 +51,8 @@ static BlockWs block_ws(const gnx_graphs* h, const gnx_block_params* p, int64_t 
   const size_t agg = align_up(sizeof(float) * (size_t)R * h->N * p->oe, 256);
   w.part_off = agg;
   const size_t prow = (size_t)std::max<int64_t>(h->n_tiles(), (h->n_wtiles() + 3) / 4 * 4 + 4);
-  const size_t part = align_up(sizeof(float) * (size_t)R * prow * (p->oe + p->on), 256);
+  const size_t wide_part = wide_workspace_bytes(h, p, R);
+  const size_t part = align_up(std::max(sizeof(float) * (size_t)R * prow * (p->oe + p->on), wide_part), 256);
   w.total = agg + part + 256;
   return w;
 }
@@ -87,12 +88,12 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   a.ablate = ablate;
 
   if (!(flags & GNX_FLAG_FORCE_GENERIC)) {
+    rc = launch_block_narrow(h, a, R, s);  // fused wave-per-tile kernel for the instantiated narrow width sets
+    if (rc != 1) return rc;
     if (!(flags & GNX_FLAG_NO_MFMA)) {
-      rc = launch_block_wide(h, a, R, s);
+      rc = launch_block_wide(h, a, R, s);  // fp32 MFMA gathered-row GEMMs
       if (rc != 1) return rc;
     }
-    rc = launch_block_narrow(h, a, R, s);
-    if (rc != 1) return rc;
   }
   return launch_block_generic(a, R, h->tile_n_cap, s);
 }

@@ -120,11 +120,11 @@ __global__ __launch_bounds__(kGraphThreads) void k_graph(BlockArgs a) {
         // every pass issues 16 predicated loads at once (no serial tail: a tail loop would pay one L2/HBM round trip
         // per row, which is what made this kernel 8 us for 2k tiles)
         for (int ti = t0 + sl; ti < t1; ti += 16 * nsl) {
+          float v16[16];  // unconditional (clamped) loads: all 16 in flight; duplicates discarded by the select
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            const int tj = ti + u * nsl;
-            if (tj < t1) s16[u] += part[(size_t)tj * C + c];
-          }
+          for (int u = 0; u < 16; ++u) v16[u] = part[(size_t)min(ti + u * nsl, t1 - 1) * C + c];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) s16[u] += ti + u * nsl < t1 ? v16[u] : 0.f;
         }
 #pragma unroll
         for (int w = 8; w > 0; w >>= 1)

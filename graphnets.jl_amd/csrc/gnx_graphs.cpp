@@ -108,6 +108,43 @@ static int32_t finalize(gnx_graphs* h) {
   GNX_HIP(hipMalloc((void**)&h->d_tiles, std::max<size_t>(h->h_tiles.size(), 1) * sizeof(gnx::Tile)));
   if (!h->h_tiles.empty())
     GNX_HIP(hipMemcpy(h->d_tiles, h->h_tiles.data(), h->h_tiles.size() * sizeof(gnx::Tile), hipMemcpyHostToDevice));
+  // wide path tables: 128-row chunks that never cross a graph boundary (so a tile has ONE per-graph bias)
+  {
+    const int BM = 128;
+    h->h_etile_off.assign(h->G + 1, 0);
+    h->h_ntile_off.assign(h->G + 1, 0);
+    for (int64_t g = 0; g < h->G; ++g) {
+      h->h_etile_off[g] = (int32_t)h->h_etiles.size();
+      h->h_ntile_off[g] = (int32_t)h->h_ntiles.size();
+      for (int64_t e = h->h_edge_off[g]; e < h->h_edge_off[g + 1]; e += BM) {
+        gnx::Tile t{};
+        t.e0 = (int32_t)e; t.e1 = (int32_t)std::min<int64_t>(e + BM, h->h_edge_off[g + 1]); t.g = (int32_t)g;
+        t.n0 = (int32_t)h->h_node_off[g]; t.n1 = (int32_t)h->h_node_off[g + 1];
+        h->h_etiles.push_back(t);
+      }
+      for (int64_t n = h->h_node_off[g]; n < h->h_node_off[g + 1]; n += BM) {
+        gnx::Tile t{};
+        t.n0 = (int32_t)n; t.n1 = (int32_t)std::min<int64_t>(n + BM, h->h_node_off[g + 1]); t.g = (int32_t)g;
+        t.e0 = (int32_t)h->h_colptr[t.n0]; t.e1 = (int32_t)h->h_colptr[t.n1];
+        h->h_ntiles.push_back(t);
+      }
+    }
+    h->h_etile_off[h->G] = (int32_t)h->h_etiles.size();
+    h->h_ntile_off[h->G] = (int32_t)h->h_ntiles.size();
+    auto up = [&](const void* src, size_t bytes, void** dst) -> int32_t {
+      GNX_HIP(hipMalloc(dst, std::max<size_t>(bytes, 16)));
+      if (bytes) GNX_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+      return GNX_OK;
+    };
+    if ((rc = up(h->h_etiles.data(), h->h_etiles.size() * sizeof(gnx::Tile), (void**)&h->d_etiles))) return rc;
+    if ((rc = up(h->h_ntiles.data(), h->h_ntiles.size() * sizeof(gnx::Tile), (void**)&h->d_ntiles))) return rc;
+    if ((rc = up(h->h_etile_off.data(), h->h_etile_off.size() * sizeof(int32_t), (void**)&h->d_etile_off))) return rc;
+    if ((rc = up(h->h_ntile_off.data(), h->h_ntile_off.size() * sizeof(int32_t), (void**)&h->d_ntile_off))) return rc;
+    std::vector<int32_t> dst((size_t)h->E);
+    for (int64_t n = 0; n < h->N; ++n)
+      for (int64_t e = h->h_colptr[n]; e < h->h_colptr[n + 1]; ++e) dst[(size_t)e] = (int32_t)n;
+    if ((rc = up(dst.data(), dst.size() * sizeof(int32_t), (void**)&h->d_edge_dst))) return rc;
+  }
   GNX_HIP(hipMalloc((void**)&h->d_wtile_off, h->h_wtile_off.size() * sizeof(int32_t)));
   GNX_HIP(hipMemcpy(h->d_wtile_off, h->h_wtile_off.data(), h->h_wtile_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   GNX_HIP(hipMalloc((void**)&h->d_wtiles, std::max<size_t>(h->h_wtiles.size(), 1) * sizeof(gnx::Tile)));
@@ -221,6 +258,11 @@ int32_t gnx_graphs_destroy(gnx_graphs* h) {
   (void)hipFree(h->d_tile_off);
   (void)hipFree(h->d_tiles);
   (void)hipFree(h->d_wtile_off);
+  (void)hipFree(h->d_edge_dst);
+  (void)hipFree(h->d_etiles);
+  (void)hipFree(h->d_ntiles);
+  (void)hipFree(h->d_etile_off);
+  (void)hipFree(h->d_ntile_off);
   (void)hipFree(h->d_wtiles);
   (void)hipFree(h->d_pad_edge_slot);
   delete h;

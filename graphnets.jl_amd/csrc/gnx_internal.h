@@ -43,6 +43,14 @@ struct gnx_graphs {
   int32_t* d_tile_off = nullptr;  // [G+1]
   gnx::Tile* d_tiles = nullptr;   // [n_tiles]
   int32_t* d_wtile_off = nullptr; // [G+1]
+  // wide (MFMA) path: destination node of every edge, and 128-row chunks of each graph's edges / nodes
+  int32_t* d_edge_dst = nullptr;  // [E]
+  std::vector<gnx::Tile> h_etiles, h_ntiles;
+  std::vector<int32_t> h_etile_off, h_ntile_off;
+  gnx::Tile* d_etiles = nullptr;
+  gnx::Tile* d_ntiles = nullptr;
+  int32_t* d_etile_off = nullptr;
+  int32_t* d_ntile_off = nullptr;
   gnx::Tile* d_wtiles = nullptr;  // [n_wtiles]
   int32_t wtile_e_cap = 0;
   int32_t* d_pad_edge_slot = nullptr;  // [E] slot of edge e inside its graph's PN^2 grid (column-major, padded)

@@ -1,6 +1,436 @@
-// placeholder until the MFMA wide path lands
+// Wide-feature path: the per-edge and per-node Dense updates as gathered-row GEMMs on the fp32 matrix cores.
+//
+//   out[m, :] = act( sum over segments  A_seg[row_seg(m), :] * W[seg rows, :]  +  bias'[g] )
+//
+// edge update (edgefninput.jl:1-8 + gnblock.jl:65):  segments  ef[m] | nf[src(m)] | nf[dst(m)]          (gf folded)
+// node update (nodefninput.jl:1-7 + gnblock.jl:66):  segments  sum_{e->m} ef'[e] | nf[m]                (gf folded)
+// The one-hot batched matmuls of the reference become row indices; the `vcat` never exists — every segment is just a
+// range of K-chunks of the same GEMM; gf[g] (constant per graph, and a tile never crosses a graph) is folded into the
+// tile's bias: bias'[g] = b + W[gf rows]^T gf[g].
+//
+// MI355X mapping: v_mfma_f32_32x32x2_f32 (exact fp32 — the 1e-5 bar rules out bf16/fp16, and gfx950 has no xf32),
+// 256-thread workgroup = 4 waves, tile 128 rows x BN cols, K streamed in 32-wide chunks through LDS (A padded to a
+// 33-float row stride: conflict-free ds_read_b32 for the 32x32x2 A fragment; B = W rows as stored by Flux), next chunk
+// prefetched into registers while the current one is on the matrix cores.  Epilogue: bias' + activation, 128-B row
+// segments to HBM, and fixed-order column sums of the tile (the graph update's partial sums, graphfninput.jl:3-4).
+#include <algorithm>
+
 #include "gnx_device.h"
+
 namespace gnx {
-int32_t launch_block_wide(const gnx_graphs*, const BlockArgs&, int64_t, hipStream_t) { return 1; }
-size_t wide_workspace_bytes(const gnx_graphs*, const gnx_block_params*, int64_t) { return 0; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;   // rows (edges or nodes) per workgroup tile
+constexpr int KC = 32;    // K chunk
+constexpr int LDA = KC + 1;
+constexpr int WT = 256;   // threads
+
+struct WSeg {
+  const float* base;  // replica 0
+  size_t rep_stride;  // floats between replicas
+  int width;          // K extent of this segment
+  int mode;           // 0: row m itself, 1: row idx_a[m], 2: row idx_b[m], 3: sum of rows [cp[m], cp[m+1]) of base
+  int w_row0;         // first row of W (= first input feature index) of this segment
+};
+
+struct WideArgs {
+  const Tile* tiles;
+  int row_kind;  // 0: rows = edges [e0, e1) of the tile, 1: rows = nodes [n0, n1)
+  WSeg seg[3];
+  int nseg;
+  const int* idx_a;  // rowval  (global source node of every edge)
+  const int* idx_b;  // edge_dst (global destination node of every edge)
+  const int* cp;     // colptr
+  const float* W;    // (OUT x K) column-major == [K][OUT] row-major
+  const float* bias;
+  int OUT, act;
+  const float* gf;   // replica 0, [G][dg]
+  size_t gf_rep_stride;
+  int dg, gf_w_row0;
+  float* out;
+  size_t out_rep_stride;
+  float* colsum;     // [R][n_tiles][OUT] or nullptr
+  size_t colsum_rep_stride;
+};
+
+template <int BN>
+struct WaveLayout {
+  static constexpr int WM = BN == 32 ? 4 : 2;
+  static constexpr int WN = 4 / WM;
+  static constexpr int TM = BM / (WM * 32);
+  static constexpr int TN = BN / (WN * 32);
+};
+
+template <int BN, bool VEC4>
+__global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
+  using L = WaveLayout<BN>;
+  constexpr int NB4 = (KC * BN / 4) / WT;  // float4 of the B chunk per thread
+  __shared__ __attribute__((aligned(16))) float sA[BM * LDA];
+  __shared__ __attribute__((aligned(16))) float sB[KC * BN];
+  __shared__ int s_ia[BM], s_ib[BM];  // gather indices, or colptr range for the segment-sum mode
+  __shared__ float s_bias[BN];
+  __shared__ float s_cs[L::WM][BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / L::WN, wn = wv % L::WN;
+  const Tile t = a.tiles[blockIdx.x];
+  const int n0 = blockIdx.y * BN;
+  const size_t r = blockIdx.z;
+  const int row0 = a.row_kind == 0 ? t.e0 : t.n0;
+  const int rows = (a.row_kind == 0 ? t.e1 : t.n1) - row0;
+
+  // per-row indices
+  bool need_cp = false;
+  for (int s = 0; s < a.nseg; ++s) need_cp |= a.seg[s].mode == 3;
+  if (tid < BM) {
+    const int m = tid < rows ? tid : rows - 1;
+    if (need_cp) {
+      s_ia[tid] = a.cp[row0 + m];
+      s_ib[tid] = tid < rows ? a.cp[row0 + m + 1] : s_ia[tid];
+    } else if (a.row_kind == 0) {
+      s_ia[tid] = a.idx_a[row0 + m];
+      s_ib[tid] = a.idx_b[row0 + m];
+    }
+  }
+  // tile bias: b + W[gf rows]^T gf[g]
+  if (tid < BN) {
+    const int n = n0 + tid;
+    float b = 0.f;
+    if (n < a.OUT) {
+      b = a.bias ? a.bias[n] : 0.f;
+      const float* gf = a.gf ? a.gf + r * a.gf_rep_stride + (size_t)t.g * a.dg : nullptr;
+      for (int k = 0; k < a.dg; ++k) b = fmaf(a.W[(size_t)(a.gf_w_row0 + k) * a.OUT + n], gf[k], b);
+    }
+    s_bias[tid] = b;
+  }
+  __syncthreads();
+
+  f32x16 acc[L::TM][L::TN];
+#pragma unroll
+  for (int i = 0; i < L::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < L::TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  float4 ra[4];
+  float4 rb[NB4];
+  const int a_c4 = tid & 7, a_r = tid >> 3;
+
+  auto load_chunk = [&](int si, int kc) {
+    const WSeg sg = a.seg[si];
+    const float* base = sg.base + r * sg.rep_stride;
+    const int k = kc + 4 * a_c4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = a_r + 32 * i;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < rows && k < sg.width) {
+        if (sg.mode == 3) {
+          for (int e = s_ia[row]; e < s_ib[row]; ++e) {
+            const float* p = base + (size_t)e * sg.width + k;
+            if (VEC4) {
+              const float4 u = *reinterpret_cast<const float4*>(p);
+              v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+            } else {
+              v.x += p[0];
+              if (k + 1 < sg.width) v.y += p[1];
+              if (k + 2 < sg.width) v.z += p[2];
+              if (k + 3 < sg.width) v.w += p[3];
+            }
+          }
+        } else {
+          const int grow = sg.mode == 0 ? row0 + row : (sg.mode == 1 ? s_ia[row] : s_ib[row]);
+          const float* p = base + (size_t)grow * sg.width + k;
+          if (VEC4) {
+            v = *reinterpret_cast<const float4*>(p);
+          } else {
+            v.x = p[0];
+            if (k + 1 < sg.width) v.y = p[1];
+            if (k + 2 < sg.width) v.z = p[2];
+            if (k + 3 < sg.width) v.w = p[3];
+          }
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int q = tid + WT * i;
+      const int kk = q / (BN / 4), c4 = q % (BN / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int n = n0 + 4 * c4;
+      if (kc + kk < sg.width && n < a.OUT) {
+        const float* p = a.W + (size_t)(sg.w_row0 + kc + kk) * a.OUT + n;
+        if (VEC4) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          v.x = p[0];
+          if (n + 1 < a.OUT) v.y = p[1];
+          if (n + 2 < a.OUT) v.z = p[2];
+          if (n + 3 < a.OUT) v.w = p[3];
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* d = sA + (a_r + 32 * i) * LDA + 4 * a_c4;
+      d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < NB4; ++i) {
+      const int q = tid + WT * i;
+      *reinterpret_cast<float4*>(sB + 4 * q) = rb[i];  // q = kk*(BN/4) + c4  ->  sB[kk][4*c4]
+    }
+  };
+
+  int si = 0, kc = 0;
+  while (si < a.nseg && a.seg[si].width == 0) ++si;
+  if (si < a.nseg) load_chunk(si, kc);
+  while (si < a.nseg) {
+    __syncthreads();  // everyone is done reading the previous chunk
+    store_chunk();
+    __syncthreads();
+    // advance and prefetch the next chunk while the matrix cores work on this one
+    kc += KC;
+    if (kc >= a.seg[si].width) {
+      kc = 0;
+      ++si;
+      while (si < a.nseg && a.seg[si].width == 0) ++si;
+    }
+    if (si < a.nseg) load_chunk(si, kc);
+    const int hi = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kk = 0; kk < KC / 2; ++kk) {
+      float fa[L::TM], fb[L::TN];
+#pragma unroll
+      for (int i = 0; i < L::TM; ++i) fa[i] = sA[((wm * L::TM + i) * 32 + l31) * LDA + 2 * kk + hi];
+#pragma unroll
+      for (int j = 0; j < L::TN; ++j) fb[j] = sB[(2 * kk + hi) * BN + (wn * L::TN + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < L::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < L::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: bias' + activation, store, column sums ----
+  float* out = a.out + r * a.out_rep_stride;
+  const int hi = lane >> 5, l31 = lane & 31;
+  float cs[L::TN];
+#pragma unroll
+  for (int j = 0; j < L::TN; ++j) cs[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < L::TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < L::TN; ++j) {
+      const int col = (wn * L::TN + j) * 32 + l31;
+      const float b = s_bias[col];
+      const bool col_ok = n0 + col < a.OUT;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (wm * L::TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;  // C/D layout of 32x32 MFMA
+        float v = act_apply(acc[i][j][q] + b, a.act);
+        if (row < rows && col_ok) out[(size_t)(row0 + row) * a.OUT + n0 + col] = v; else v = 0.f;
+        cs[j] += v;
+      }
+    }
+  }
+  if (a.colsum) {
+#pragma unroll
+    for (int j = 0; j < L::TN; ++j) {
+      const float other = __shfl_xor(cs[j], 32);
+      const float tot = hi == 0 ? cs[j] + other : other + cs[j];  // same association in both halves
+      if (hi == 0) s_cs[wm][(wn * L::TN + j) * 32 + l31] = tot;
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.OUT) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < L::WM; ++w) s += s_cs[w][tid];
+      a.colsum[r * a.colsum_rep_stride + (size_t)blockIdx.x * a.OUT + n0 + tid] = s;
+    }
+  }
 }
+
+// ---- graph update for the wide path: two-stage fixed-order reduction of the per-tile column sums ----
+// stage 1: out2[r][g][s][c] = sum over the s-th slice of graph g's tile rows of in[r][tile][c]
+__global__ void k_colsum_slices(const float* in, size_t in_rep_stride, const int* tile_off, int C, int S, float* out2, int G) {
+  const int g = blockIdx.x, s = blockIdx.y;
+  const size_t r = blockIdx.z;
+  const int t0 = tile_off[g], t1 = tile_off[g + 1];
+  const int per = (t1 - t0 + S - 1) / S;
+  const int a0 = t0 + s * per, a1 = min(a0 + per, t1);
+  const float* base = in + r * in_rep_stride;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+    // loads are made unconditional by clamping the row (a predicated load cannot be hoisted over its branch, which
+    // serialises one memory round trip per row); the clamped duplicates are discarded by the select
+    for (int ti = a0; ti < a1; ti += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = base[(size_t)min(ti + u, a1 - 1) * C + c];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u] += ti + u < a1 ? v[u] : 0.f;
+    }
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+      for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
+    out2[((r * G + g) * S + s) * (size_t)C + c] = acc[0];
+  }
+}
+
+// stage 2: gf'[g] = act(Wg * [sum_e ef' ; sum_n nf' ; gf_g] + bg).  Latency-bound, so the work is laid out for ONE
+// round trip per phase: thread k owns input feature k — it reads 32 weights W[k][j0..j0+32) (32 independent loads) and
+// contributes W[k][j]*x[k]; the 256 contributions per output are then added in a fixed order from LDS.
+__global__ __launch_bounds__(256) void k_graph_final(const float* pe2, const float* pn2, int S, BlockArgs a) {
+  extern __shared__ float s_gf[];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const size_t r = blockIdx.y;
+  const int oe = a.oe, on = a.on, C = oe + on, K = C + a.dg, og = a.og;
+  float* s_x = s_gf;                 // [K]
+  float* s_p = s_gf + K + 4;         // [256][33]
+  for (int c = tid; c < C; c += 256) {
+    const float* p = c < oe ? pe2 + ((r * a.G + g) * S) * (size_t)oe + c : pn2 + ((r * a.G + g) * S) * (size_t)on + (c - oe);
+    const int stride = c < oe ? oe : on;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    for (int i = 0; i < S; i += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)min(i + u, S - 1) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += i + u < S ? v[u] : 0.f;
+    }
+    s_x[c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  }
+  const float* gf = a.gf ? a.gf + (r * (size_t)a.G + g) * a.dg : nullptr;
+  for (int k = tid; k < a.dg; k += 256) s_x[C + k] = gf[k];
+  __syncthreads();
+  float* out = a.gf_out + (r * (size_t)a.G + g) * og;
+  for (int j0 = 0; j0 < og; j0 += 32) {
+    float part[32];
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj) part[jj] = 0.f;
+    for (int k = tid; k < K; k += 256) {
+      float w[32];
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj) w[jj] = j0 + jj < og ? a.Wg[(size_t)k * og + j0 + jj] : 0.f;
+      const float xk = s_x[k];
+#pragma unroll
+      for (int jj = 0; jj < 32; ++jj) part[jj] = fmaf(w[jj], xk, part[jj]);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 32; ++jj) s_p[tid * 33 + jj] = part[jj];
+    __syncthreads();
+    if (tid < 32 && j0 + tid < og) {
+      float y = a.bg ? a.bg[j0 + tid] : 0.f;
+      for (int t = 0; t < 256; ++t) y += s_p[t * 33 + tid];
+      out[j0 + tid] = act_apply(y, a.act_g);
+    }
+    __syncthreads();
+  }
+}
+
+static int wide_slices(const gnx_graphs* h) {
+  int64_t mx = 1;
+  for (int64_t g = 0; g < h->G; ++g) mx = std::max<int64_t>(mx, h->h_etile_off[g + 1] - h->h_etile_off[g]);
+  int S = (int)((mx + 63) / 64);
+  return S < 1 ? 1 : (S > 64 ? 64 : S);
+}
+
+size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
+  const size_t per_tile = sizeof(float) * (size_t)R * ((size_t)h->h_etiles.size() * p->oe + (size_t)h->h_ntiles.size() * p->on);
+  const size_t stage2 = sizeof(float) * (size_t)R * h->G * wide_slices(h) * (size_t)(p->oe + p->on);
+  return align_up(per_tile, 256) + align_up(stage2, 256) + 512;
+}
+
+template <int BN>
+static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64_t R, hipStream_t s, const char* name) {
+  if (n_tiles == 0 || w.OUT == 0) return GNX_OK;
+  ProfScope ps(name, s);
+  const dim3 grid(n_tiles, (unsigned)((w.OUT + BN - 1) / BN), (unsigned)R);
+  if (vec4) hipLaunchKernelGGL((k_rows_gemm<BN, true>), grid, dim3(WT), 0, s, w);
+  else hipLaunchKernelGGL((k_rows_gemm<BN, false>), grid, dim3(WT), 0, s, w);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+static int32_t launch_gemm_any(const WideArgs& w, bool vec4, unsigned n_tiles, int64_t R, hipStream_t s, const char* name) {
+  if (w.OUT > 64) return launch_gemm<128>(w, vec4, n_tiles, R, s, name);
+  if (w.OUT > 32) return launch_gemm<64>(w, vec4, n_tiles, R, s, name);
+  return launch_gemm<32>(w, vec4, n_tiles, R, s, name);
+}
+
+int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s) {
+  static const bool off = getenv("GNX_NO_WIDE") != nullptr;
+  if (off) return 1;
+  const int ke = a.de + 2 * a.dn + a.dg, kn = a.oe + a.dn + a.dg;
+  // the matrix-core path pays when the update is a real GEMM; tiny widths stay on the other paths
+  if (std::max(std::max(ke, a.oe), std::max(kn, a.on)) < 32) return 1;
+  if (a.E == 0 && a.oe > 0) return 1;
+  const bool al16 = ((uintptr_t)a.ef | (uintptr_t)a.nf | (uintptr_t)a.We | (uintptr_t)a.Wn | (uintptr_t)a.ef_out) % 16 == 0;
+  const size_t n_et = h->h_etiles.size(), n_nt = h->h_ntiles.size();
+  // workspace layout inside a.partials (sized by gnx_block_workspace_bytes >= wide_workspace_bytes)
+  float* pe = a.partials;
+  float* pn = pe + (size_t)R * n_et * a.oe;
+  const int S = wide_slices(h);
+  float* stage2 = reinterpret_cast<float*>(reinterpret_cast<char*>(a.partials) +
+                                           align_up(sizeof(float) * (size_t)R * (n_et * a.oe + n_nt * a.on), 256));
+  float* pe2 = stage2;
+  float* pn2 = pe2 + (size_t)R * h->G * S * a.oe;
+  int32_t rc;
+  if (a.oe > 0) {
+    WideArgs w{};
+    w.tiles = h->d_etiles; w.row_kind = 0;
+    int ns = 0;
+    if (a.de) w.seg[ns++] = WSeg{a.ef, (size_t)a.E * a.de, a.de, 0, 0};
+    if (a.dn) {
+      w.seg[ns++] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 1, a.de};
+      w.seg[ns++] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 2, a.de + a.dn};
+    }
+    w.nseg = ns;
+    w.idx_a = a.rowval; w.idx_b = h->d_edge_dst; w.cp = a.colptr;
+    w.W = a.We; w.bias = a.be; w.OUT = a.oe; w.act = a.act_e;
+    w.gf = a.gf; w.gf_rep_stride = (size_t)a.G * a.dg; w.dg = a.dg; w.gf_w_row0 = a.de + 2 * a.dn;
+    w.out = a.ef_out; w.out_rep_stride = (size_t)a.E * a.oe;
+    w.colsum = a.og > 0 ? pe : nullptr; w.colsum_rep_stride = n_et * (size_t)a.oe;
+    const bool vec4 = al16 && a.de % 4 == 0 && a.dn % 4 == 0 && a.oe % 4 == 0;
+    if ((rc = launch_gemm_any(w, vec4, (unsigned)n_et, R, s, "k_rows_gemm_edge"))) return rc;
+  }
+  if (a.on > 0) {
+    WideArgs w{};
+    w.tiles = h->d_ntiles; w.row_kind = 1;
+    int ns = 0;
+    if (a.oe) w.seg[ns++] = WSeg{a.ef_out, (size_t)a.E * a.oe, a.oe, 3, 0};
+    if (a.dn) w.seg[ns++] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 0, a.oe};
+    w.nseg = ns;
+    w.idx_a = nullptr; w.idx_b = nullptr; w.cp = a.colptr;
+    w.W = a.Wn; w.bias = a.bn; w.OUT = a.on; w.act = a.act_n;
+    w.gf = a.gf; w.gf_rep_stride = (size_t)a.G * a.dg; w.dg = a.dg; w.gf_w_row0 = a.oe + a.dn;
+    w.out = a.nf_out; w.out_rep_stride = (size_t)a.N * a.on;
+    w.colsum = a.og > 0 ? pn : nullptr; w.colsum_rep_stride = n_nt * (size_t)a.on;
+    const bool al = al16 && ((uintptr_t)a.nf_out % 16 == 0);
+    const bool vec4 = al && a.oe % 4 == 0 && a.dn % 4 == 0 && a.on % 4 == 0;
+    if ((rc = launch_gemm_any(w, vec4, (unsigned)n_nt, R, s, "k_rows_gemm_node"))) return rc;
+  }
+  if (a.og > 0) {
+    ProfScope ps("k_graph_wide", s);
+    if (a.oe > 0) hipLaunchKernelGGL(k_colsum_slices, dim3((unsigned)a.G, (unsigned)S, (unsigned)R), dim3(128), 0, s, pe, n_et * (size_t)a.oe, h->d_etile_off, a.oe, S, pe2, a.G);
+    if (a.on > 0) hipLaunchKernelGGL(k_colsum_slices, dim3((unsigned)a.G, (unsigned)S, (unsigned)R), dim3(128), 0, s, pn, n_nt * (size_t)a.on, h->d_ntile_off, a.on, S, pn2, a.G);
+    const size_t lds = sizeof(float) * ((size_t)(a.oe + a.on + a.dg + 4) + 256 * 33 + 4);
+    hipLaunchKernelGGL(k_graph_final, dim3((unsigned)a.G, (unsigned)R), dim3(256), lds, s, pe2, pn2, S, a);
+    GNX_HIP(hipGetLastError());
+  }
+  return GNX_OK;
+}
+
+}  // namespace gnx

@@ -1,0 +1,103 @@
+"""GPU parity of the fp32-MFMA wide path (k_rows_gemm) against the float64 oracle: core dims, encoder/decoder shapes
+of README ex.3 at core_dims (128,64,32) (BASELINE config 4), unaligned widths, replicas, heterogeneous batches."""
+import numpy as np
+import pytest
+
+from oracle import gn_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gn():
+    import graphnets_jl_amd as gn
+    return gn
+
+
+def _check(gn, p, g, csc, ef, nf, gf, flags=0):
+    blk = U.block_from_params(gn, p)
+    y = blk(U.to_nt(gn, g, ef, nf, gf), flags=flags)
+    ref, scale = O.block_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r, s, name)
+    return y
+
+
+DIMS = [
+    pytest.param(((128, 64, 32), (128, 64, 32)), id="core"),
+    pytest.param(((10, 5, 0), (128, 64, 32)), id="encoder"),
+    pytest.param(((128, 64, 32), (3, 4, 5)), id="decoder"),
+    pytest.param(((33, 17, 5), (40, 35, 7)), id="unaligned"),
+    pytest.param(((0, 48, 0), (64, 0, 16)), id="no-ef-in_no-nf-out"),
+    pytest.param(((64, 0, 8), (0, 96, 8)), id="no-ef-out"),
+]
+
+
+@pytest.mark.parametrize("dims", DIMS)
+def test_wide_er_graph(gn, dims):
+    rng = np.random.default_rng(50)
+    N, E = 700, 5000
+    colptr, rowval = U.er_csc(rng, N, E)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [N])
+    p = O.make_block_params(rng, *dims, act=(1, 0, 2))
+    ef, nf, gf = U.packed_inputs(rng, 1, E, N, 1, dims[0])
+    _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
+
+
+def test_wide_uses_mfma_kernels(gn):
+    rng = np.random.default_rng(51)
+    colptr, rowval = U.er_csc(rng, 300, 2000)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [300])
+    p = O.make_block_params(rng, (128, 64, 32), (128, 64, 32))
+    ef, nf, gf = U.packed_inputs(rng, 1, 2000, 300, 1, (128, 64, 32))
+    gn.profile_reset(); gn.profile_enable(True)
+    _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
+    gn.profile_enable(False)
+    names = set(gn.profile_read()); gn.profile_reset()
+    assert {"k_rows_gemm_edge", "k_rows_gemm_node", "k_graph_wide"} <= names, names
+
+
+def test_wide_replicas_and_hub(gn):
+    """shared graph with 3 replicas, one node with 900 in-edges (segment sum spanning many rows), isolated nodes."""
+    rng = np.random.default_rng(52)
+    N = 1000
+    colptr = np.zeros(N + 1, dtype=np.int64)
+    rows = []
+    for j in range(N):
+        r = np.sort(rng.choice(N, 900, replace=False)) if j == 3 else (np.zeros(0, dtype=np.int64) if j % 4 == 0 else np.sort(rng.choice(N, rng.integers(1, 5), replace=False)))
+        rows.append(r); colptr[j + 1] = colptr[j] + len(r)
+    rowval = np.concatenate(rows).astype(np.int64)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [N])
+    dims = ((64, 32, 16), (64, 32, 16))
+    p = O.make_block_params(rng, *dims)
+    ef, nf, gf = U.packed_inputs(rng, 3, len(rowval), N, 1, dims[0])
+    _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
+
+
+def test_wide_heterogeneous_batch(gn):
+    rng = np.random.default_rng(53)
+    sizes = rng.integers(32, 200, 24)
+    cps, rvs = [], []
+    for n in sizes:
+        cp, rv = U.er_csc(rng, int(n), int(0.06 * n * n))
+        cps.append(cp); rvs.append(rv)
+    g = gn.GNGraphBatch.from_csc(cps, rvs, [int(n) for n in sizes])
+    dims = ((128, 64, 32), (128, 64, 32))
+    p = O.make_block_params(rng, *dims)
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims[0])
+    _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
+
+
+def test_wide_matches_generic_path(gn):
+    rng = np.random.default_rng(54)
+    colptr, rowval = U.er_csc(rng, 400, 3000)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [400])
+    dims = ((96, 40, 8), (72, 48, 24))
+    p = O.make_block_params(rng, *dims)
+    ef, nf, gf = U.packed_inputs(rng, 1, 3000, 400, 1, dims[0])
+    blk = U.block_from_params(gn, p)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    a, b = blk(x, flags=0), blk(x, flags=1)
+    for u, v in ((a.ef, b.ef), (a.nf, b.nf), (a.gf, b.gf)):
+        np.testing.assert_allclose(U.from_jl(u), U.from_jl(v), rtol=2e-4, atol=2e-4)
