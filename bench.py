@@ -81,6 +81,44 @@ def glorot(rng, out_d, in_d):
     return rng.uniform(-s, s, size=(out_d, in_d)).astype(np.float32)
 
 
+def bench_c4(args, gn, torch, dev):
+    """BASELINE configs[3]: Encoder -> 2 x GNCore -> Decoder (README ex.3) at core_dims (128,64,32) on the C2 graph.
+    One "step" = the whole 4-layer model forward; reported as edges/s through the model."""
+    colptrs, rowvals, nn = make_c2()
+    g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
+    core = (128, 64, 32)
+    gen = torch.Generator(); gen.manual_seed(0)
+    model = [gn.GNBlock((10, 5, 0), core, device=dev, generator=gen), gn.GNCore(core, device=dev, generator=gen),
+             gn.GNCore(core, device=dev, generator=gen), gn.GNBlock(core, (3, 4, 5), device=dev, generator=gen)]
+    tg = torch.Generator(device=dev); tg.manual_seed(1)
+    x = gn.NT(g, torch.rand((1, g.n_edges, 10), generator=tg, device=dev).permute(2, 1, 0),
+              torch.rand((1, g.n_nodes, 5), generator=tg, device=dev).permute(2, 1, 0), None)
+
+    def fwd():
+        y = x
+        for layer in model:
+            y = layer(y)
+        return y
+    for _ in range(max(args.warmup, 1)):
+        fwd()
+    torch.cuda.synchronize(dev)
+    gn.profile_reset(); gn.profile_enable(True)
+    fwd(); torch.cuda.synchronize(dev)
+    gn.profile_enable(False)
+    kern = {k: round(v["total_ms"] * 1e3, 1) for k, v in gn.profile_read().items()}; gn.profile_reset()
+    K = args.steps
+    t0 = time.perf_counter()
+    for _ in range(K):
+        fwd()
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / K
+    flops = 699.2e9  # SURVEY 8d: whole-model algorithmic FLOPs at 1M edges
+    print(json.dumps({"metric": "edges/sec through Encoder->2xGNCore(128,64,32)->Decoder, 1M-edge graph (BASELINE configs[3])",
+                      "value": round(g.n_edges / dt, 1), "unit": "edges/s", "ms_per_step": round(dt * 1e3, 4), "steps": K,
+                      "algorithmic_tflops": round(flops / dt / 1e12, 2), "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFS,
+                      "frac_of_mfma_peak": round(flops / dt / 1e12 / MFMA_F32_PEAK_TFS, 4), "kernel_us_one_forward": kern}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +128,8 @@ def main():
     ap.add_argument("--workload", choices=["c2", "hetero"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--model", choices=["block", "c4"], default="block",
+                    help="c4: BASELINE configs[3] — encoder -> 2 x GNCore(128,64,32) -> decoder on the C2 graph (extra; not the headline line)")
     args = ap.parse_args()
 
     import torch
@@ -107,6 +147,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     K, W = args.steps, args.warmup
+    if args.model == "c4":
+        return bench_c4(args, gn, torch, dev)
     din, dout = DIMS[args.dims]
     workload = args.workload or ("c2" if world == 1 else "hetero")
 

@@ -19,6 +19,8 @@ int32_t launch_pad(const gnx_graphs* h, int kind, bool pad, const float* src, in
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s);
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s);
 size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R);
+int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K, const gnx_dense& d, int OUT, const float* add1,
+                          const float* add2, float* out, int64_t R, hipStream_t s, const char* name);
 
 static int32_t check_block(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
   if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
@@ -115,22 +117,27 @@ int32_t gnx_block_forward(const gnx_graphs* h, const gnx_block_params* p, const 
   return block_forward_impl(h, p, ef, nf, gf, R, ef_out, nf_out, gf_out, ws, ws_bytes, flags, (hipStream_t)stream);
 }
 
-// workspace of a core: LN1 and LN2 outputs for edges, nodes, graphs, then the block workspace
-static void core_ws(const gnx_graphs* h, const gnx_core_params* p, int64_t R, size_t off[7], size_t* total) {
+// FeedForward width from which the two Dense layers run on the matrix cores (hidden activations staged in HBM)
+static bool ffn_on_mfma(int d) { return d >= 32; }
+
+// workspace of a core: LN1 and LN2 outputs for edges, nodes, graphs, the FFN hidden buffer, then the block workspace
+static void core_ws(const gnx_graphs* h, const gnx_core_params* p, int64_t R, size_t off[8], size_t* total) {
   const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
   const int d[3] = {p->block.de, p->block.dn, p->block.dg};
-  size_t o = 0;
+  size_t o = 0, hidden = 0;
   for (int t = 0; t < 3; ++t) {
     off[2 * t] = o; o += align_up(sizeof(float) * rows[t] * d[t], 256);
     off[2 * t + 1] = o; o += align_up(sizeof(float) * rows[t] * d[t], 256);
+    if (ffn_on_mfma(d[t])) hidden = std::max(hidden, sizeof(float) * rows[t] * 4 * (size_t)d[t]);
   }
-  off[6] = o;
+  off[6] = o; o += align_up(hidden, 256);
+  off[7] = o;
   *total = o + block_ws(h, &p->block, R).total;
 }
 
 size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t R) {
   if (!h || !p || R <= 0) return 0;
-  size_t off[7], total;
+  size_t off[8], total;
   core_ws(h, p, R, off, &total);
   return total;
 }
@@ -153,9 +160,15 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     if (!p->ff[t].fc1.weight || !p->ff[t].fc2.weight) return fail(GNX_ERR_INVALID_ARG, "FeedForward weight is NULL");
   }
   if (p->eps_mode != 0 && p->eps_mode != 1) return fail(GNX_ERR_INVALID_ARG, "eps_mode must be 0 or 1");
-  const int dmax = b.de > b.dn ? (b.de > b.dg ? b.de : b.dg) : (b.dn > b.dg ? b.dn : b.dg);
-  if ((size_t)dmax * 5 * 4 * sizeof(float) > 160 * 1024) return fail(GNX_ERR_DIMS, "GNCore width too large for the generic FFN kernel (5*d*16 B of LDS)");
-  size_t off[7], total;
+  {
+    const int dd[3] = {b.de, b.dn, b.dg};
+    for (int t = 0; t < 3; ++t) {
+      const bool generic = !ffn_on_mfma(dd[t]) || (flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA));
+      if (generic && (size_t)dd[t] * 5 * 4 * sizeof(float) > 64 * 1024)
+        return fail(GNX_ERR_DIMS, "GNCore width too large for the generic FFN kernel (80*d bytes of LDS)");
+    }
+  }
+  size_t off[8], total;
   core_ws(h, p, R, off, &total);
   if (!ws || ws_bytes < total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_core_workspace_bytes()");
   if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");
@@ -171,10 +184,18 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     l2[t] = reinterpret_cast<float*>(base + off[2 * t + 1]);
     if ((rc = launch_layernorm2(x[t], rows[t], d[t], p->ln1[t], p->ln2[t], p->eps, p->eps_mode, l1[t], l2[t], s))) return rc;
   }
-  rc = block_forward_impl(h, &b, l1[0], l1[1], l1[2], R, out[0], out[1], out[2], base + off[6], ws_bytes - off[6], flags, s);
+  rc = block_forward_impl(h, &b, l1[0], l1[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s);
   if (rc) return rc;
-  for (int t = 0; t < 3; ++t)
-    if ((rc = launch_ffn_residual(l2[t], x[t], rows[t], d[t], p->ff[t], out[t], s))) return rc;
+  float* hidden = reinterpret_cast<float*>(base + off[6]);
+  for (int t = 0; t < 3; ++t) {
+    if (ffn_on_mfma(d[t]) && !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA))) {
+      // out = block(LN1 x) + x + fc2(relu(fc1(LN2 x)))      (gncore.jl:56-68, gnfeedforward.jl:27-31)
+      if ((rc = launch_dense_rows(h, t, l2[t], d[t], p->ff[t].fc1, 4 * d[t], nullptr, nullptr, hidden, R, s, "k_rows_gemm_ff1"))) return rc;
+      if ((rc = launch_dense_rows(h, t, hidden, 4 * d[t], p->ff[t].fc2, d[t], out[t], x[t], out[t], R, s, "k_rows_gemm_ff2"))) return rc;
+    } else if ((rc = launch_ffn_residual(l2[t], x[t], rows[t], d[t], p->ff[t], out[t], s))) {
+      return rc;
+    }
+  }
   return GNX_OK;
 }
 

@@ -138,6 +138,12 @@ static int32_t finalize(gnx_graphs* h) {
     };
     if ((rc = up(h->h_etiles.data(), h->h_etiles.size() * sizeof(gnx::Tile), (void**)&h->d_etiles))) return rc;
     if ((rc = up(h->h_ntiles.data(), h->h_ntiles.size() * sizeof(gnx::Tile), (void**)&h->d_ntiles))) return rc;
+    for (int64_t g0 = 0; g0 < h->G; g0 += BM) {
+      gnx::Tile t{};
+      t.n0 = (int32_t)g0; t.n1 = (int32_t)std::min<int64_t>(g0 + BM, h->G); t.g = (int32_t)g0;
+      h->h_gtiles.push_back(t);
+    }
+    if ((rc = up(h->h_gtiles.data(), h->h_gtiles.size() * sizeof(gnx::Tile), (void**)&h->d_gtiles))) return rc;
     if ((rc = up(h->h_etile_off.data(), h->h_etile_off.size() * sizeof(int32_t), (void**)&h->d_etile_off))) return rc;
     if ((rc = up(h->h_ntile_off.data(), h->h_ntile_off.size() * sizeof(int32_t), (void**)&h->d_ntile_off))) return rc;
     std::vector<int32_t> dst((size_t)h->E);
@@ -261,6 +267,7 @@ int32_t gnx_graphs_destroy(gnx_graphs* h) {
   (void)hipFree(h->d_edge_dst);
   (void)hipFree(h->d_etiles);
   (void)hipFree(h->d_ntiles);
+  (void)hipFree(h->d_gtiles);
   (void)hipFree(h->d_etile_off);
   (void)hipFree(h->d_ntile_off);
   (void)hipFree(h->d_wtiles);

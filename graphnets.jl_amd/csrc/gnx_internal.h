@@ -45,10 +45,11 @@ struct gnx_graphs {
   int32_t* d_wtile_off = nullptr; // [G+1]
   // wide (MFMA) path: destination node of every edge, and 128-row chunks of each graph's edges / nodes
   int32_t* d_edge_dst = nullptr;  // [E]
-  std::vector<gnx::Tile> h_etiles, h_ntiles;
+  std::vector<gnx::Tile> h_etiles, h_ntiles, h_gtiles;  // h_gtiles: 128-row chunks of the graph rows (n0/n1 = graph ids)
   std::vector<int32_t> h_etile_off, h_ntile_off;
   gnx::Tile* d_etiles = nullptr;
   gnx::Tile* d_ntiles = nullptr;
+  gnx::Tile* d_gtiles = nullptr;
   int32_t* d_etile_off = nullptr;
   int32_t* d_ntile_off = nullptr;
   gnx::Tile* d_wtiles = nullptr;  // [n_wtiles]

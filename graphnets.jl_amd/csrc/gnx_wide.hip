@@ -52,6 +52,8 @@ struct WideArgs {
   size_t out_rep_stride;
   float* colsum;     // [R][n_tiles][OUT] or nullptr
   size_t colsum_rep_stride;
+  const float* add1;  // optional residual inputs with the layout of `out` (may alias `out`): v = act(..) + add1 + add2
+  const float* add2;
 };
 
 template <int BN>
@@ -81,14 +83,17 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
   const int rows = (a.row_kind == 0 ? t.e1 : t.n1) - row0;
 
   // per-row indices
-  bool need_cp = false;
-  for (int s = 0; s < a.nseg; ++s) need_cp |= a.seg[s].mode == 3;
+  bool need_cp = false, need_idx = false;
+  for (int s = 0; s < a.nseg; ++s) {
+    need_cp |= a.seg[s].mode == 3;
+    need_idx |= a.seg[s].mode == 1 || a.seg[s].mode == 2;
+  }
   if (tid < BM) {
     const int m = tid < rows ? tid : rows - 1;
     if (need_cp) {
       s_ia[tid] = a.cp[row0 + m];
       s_ib[tid] = tid < rows ? a.cp[row0 + m + 1] : s_ia[tid];
-    } else if (a.row_kind == 0) {
+    } else if (need_idx) {
       s_ia[tid] = a.idx_a[row0 + m];
       s_ib[tid] = a.idx_b[row0 + m];
     }
@@ -235,7 +240,14 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
       for (int q = 0; q < 16; ++q) {
         const int row = (wm * L::TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;  // C/D layout of 32x32 MFMA
         float v = act_apply(acc[i][j][q] + b, a.act);
-        if (row < rows && col_ok) out[(size_t)(row0 + row) * a.OUT + n0 + col] = v; else v = 0.f;
+        if (row < rows && col_ok) {
+          const size_t o = (size_t)(row0 + row) * a.OUT + n0 + col;
+          if (a.add1) v += a.add1[r * a.out_rep_stride + o];
+          if (a.add2) v += a.add2[r * a.out_rep_stride + o];
+          out[o] = v;
+        } else {
+          v = 0.f;
+        }
         cs[j] += v;
       }
     }
@@ -356,6 +368,15 @@ size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int6
 template <int BN>
 static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64_t R, hipStream_t s, const char* name) {
   if (n_tiles == 0 || w.OUT == 0) return GNX_OK;
+  // host-side operand check before any launch: a kernel fault can take the whole node down
+  if (!w.tiles || !w.W || !w.out) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: tiles / W / out is NULL");
+  for (int i = 0; i < w.nseg; ++i) {
+    const WSeg& g = w.seg[i];
+    if (g.width > 0 && !g.base) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: segment base is NULL");
+    if ((g.mode == 1 && !w.idx_a) || (g.mode == 2 && !w.idx_b) || (g.mode == 3 && !w.cp))
+      return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: index array required by a segment mode is NULL");
+  }
+  if (w.dg > 0 && !w.gf) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: gf is NULL but dg > 0");
   ProfScope ps(name, s);
   const dim3 grid(n_tiles, (unsigned)((w.OUT + BN - 1) / BN), (unsigned)R);
   if (vec4) hipLaunchKernelGGL((k_rows_gemm<BN, true>), grid, dim3(WT), 0, s, w);
@@ -368,6 +389,27 @@ static int32_t launch_gemm_any(const WideArgs& w, bool vec4, unsigned n_tiles, i
   if (w.OUT > 64) return launch_gemm<128>(w, vec4, n_tiles, R, s, name);
   if (w.OUT > 32) return launch_gemm<64>(w, vec4, n_tiles, R, s, name);
   return launch_gemm<32>(w, vec4, n_tiles, R, s, name);
+}
+
+// y[rows, OUT] = act(A[rows, K] * W + b) (+ add1 + add2) over ALL rows of one entity type (0 edges, 1 nodes, 2 graphs):
+// the position-wise Dense layers of GNFeedForward (gnfeedforward.jl:27-40) on the matrix cores.
+int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K, const gnx_dense& d, int OUT, const float* add1,
+                          const float* add2, float* out, int64_t R, hipStream_t s, const char* name) {
+  const size_t nrows = entity == 0 ? (size_t)h->E : (entity == 1 ? (size_t)h->N : (size_t)h->G);
+  if (nrows == 0 || OUT == 0) return GNX_OK;
+  WideArgs w{};
+  w.tiles = entity == 0 ? h->d_etiles : (entity == 1 ? h->d_ntiles : h->d_gtiles);
+  w.row_kind = entity == 0 ? 0 : 1;
+  w.seg[0] = WSeg{A, nrows * (size_t)K, K, 0, 0};
+  w.nseg = 1;
+  w.W = d.weight; w.bias = d.bias; w.OUT = OUT; w.act = d.act;
+  w.gf = nullptr; w.dg = 0;
+  w.out = out; w.out_rep_stride = nrows * (size_t)OUT;
+  w.colsum = nullptr;
+  w.add1 = add1; w.add2 = add2;
+  const unsigned n_tiles = (unsigned)(entity == 0 ? h->h_etiles.size() : (entity == 1 ? h->h_ntiles.size() : h->h_gtiles.size()));
+  const bool al16 = ((uintptr_t)A | (uintptr_t)d.weight | (uintptr_t)out) % 16 == 0;
+  return launch_gemm_any(w, al16 && K % 4 == 0 && OUT % 4 == 0, n_tiles, R, s, name);
 }
 
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s) {

@@ -77,3 +77,49 @@ def test_core_requires_all_features(gn):
         core(x)
     with pytest.raises(AssertionError):  # gnfeedforward.jl:18 all(dims .> 0)
         gn.GNCore((3, 0, 5))
+
+
+@pytest.mark.parametrize("flags", [0, 1], ids=["mfma", "generic"])
+def test_core_wide_dims(gn, flags):
+    """GNCore at widths where block and FeedForward run on the matrix cores (k_rows_gemm_*), vs the oracle."""
+    rng = np.random.default_rng(45)
+    dims = (64, 48, 32)
+    colptr, rowval = U.er_csc(rng, 300, 2500)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [300])
+    p = O.make_core_params(rng, dims)
+    ef, nf, gf = U.packed_inputs(rng, 2, 2500, 300, 1, dims)
+    core = U.core_from_params(gn, p)
+    if flags == 0:
+        gn.profile_reset(); gn.profile_enable(True)
+    y = core(U.to_nt(gn, g, ef, nf, gf), flags=flags)
+    if flags == 0:
+        gn.profile_enable(False)
+        names = set(gn.profile_read()); gn.profile_reset()
+        assert {"k_rows_gemm_ff1", "k_rows_gemm_ff2", "k_rows_gemm_edge"} <= names, names
+    ref = O.core_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
+    for got, r in zip((y.ef, y.nf, y.gf), ref):
+        got = U.from_jl(got)
+        assert np.max(np.abs(got - r)) <= 2e-4 * max(1.0, float(np.abs(r).max()))
+
+
+def test_config4_shape_encoder_2cores_decoder_wide(gn):
+    """BASELINE config 4 at reduced size: enc (10,5,0)=>(128,64,32), 2 x GNCore(128,64,32), dec =>(3,4,5)."""
+    rng = np.random.default_rng(46)
+    core_dims = (128, 64, 32)
+    colptr, rowval = U.er_csc(rng, 200, 1500)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [200])
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    pe, pd = O.make_block_params(rng, (10, 5, 0), core_dims), O.make_block_params(rng, core_dims, (3, 4, 5))
+    pcs = [O.make_core_params(rng, core_dims) for _ in range(2)]
+    ef, nf, _ = U.packed_inputs(rng, 1, 1500, 200, 1, (10, 5, 0))
+    model = [U.block_from_params(gn, pe)] + [U.core_from_params(gn, p) for p in pcs] + [U.block_from_params(gn, pd)]
+    y = U.to_nt(gn, g, ef, nf, None)
+    for layer in model:
+        y = layer(y)
+    r = O.block_forward_sparse(pe, csc, ef, nf, None)
+    for p in pcs:
+        r = O.core_forward_sparse(p, csc, *r)
+    r = O.block_forward_sparse(pd, csc, *r)
+    for got, ref in zip((y.ef, y.nf, y.gf), r):
+        got = U.from_jl(got)
+        assert np.max(np.abs(got - ref)) <= 1e-3 * max(1.0, float(np.abs(ref).max()))
