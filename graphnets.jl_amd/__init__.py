@@ -4,7 +4,7 @@ The directory name follows the project naming contract and is not a valid Python
 `graphnets_jl_amd` (the one-line loader module at the repo root).
 """
 from . import _lib
-from ._lib import GnxError, LIB_PATH, profile_enable, profile_read, profile_reset
+from ._lib import GnxError, LIB_PATH, profile_calibrate, profile_enable, profile_read, profile_reset
 from .api import (NT, BlockPlan, Dense, GNBlock, GNCore, GNCoreList, GNFeedForward, GNGraphBatch, GNGraphNorm, LayerNorm, batch,
                   efview, flatunpaddedef, flatunpaddednf, gfview, nfview, padded, unbatch, zerodim2nothing)
 

@@ -80,6 +80,7 @@ SIGNATURES = {
     "gnx_unpad_features": (C.c_int32, [C.c_void_p, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),
     "gnx_profile_enable": (C.c_int32, [C.c_int32]),
     "gnx_profile_reset": (C.c_int32, []),
+    "gnx_profile_calibrate": (C.c_int32, [C.c_int32, C.c_void_p]),
     "gnx_profile_read": (C.c_int32, [C.POINTER(ProfileEntry), C.c_int32, C.POINTER(C.c_int32)]),
 }
 
@@ -116,6 +117,10 @@ def profile_enable(on=True):
 
 def profile_reset():
     check(load().gnx_profile_reset())
+
+
+def profile_calibrate(n, stream):
+    check(load().gnx_profile_calibrate(int(n), stream))
 
 
 def profile_read():

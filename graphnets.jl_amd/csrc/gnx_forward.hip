@@ -15,6 +15,7 @@ int32_t launch_layernorm2(const float* x, size_t rows, int d, const gnx_layernor
                           int eps_mode, float* y1, float* y2, hipStream_t s);
 int32_t launch_ffn_residual(const float* z, const float* x, size_t rows, int d, const gnx_ffn& ff, float* out, hipStream_t s);
 int32_t launch_pad(const gnx_graphs* h, int kind, bool pad, const float* src, int d, int64_t R, float* dst, hipStream_t s);
+int32_t launch_calibration(int n, hipStream_t s);
 // returns 1 when the path does not apply to these dims (caller falls through to the next path)
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s);
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s);
@@ -210,6 +211,8 @@ static int32_t pad_impl(const gnx_graphs* h, int32_t kind, bool pad, const float
 int32_t gnx_pad_features(const gnx_graphs* h, int32_t kind, const float* packed, int32_t d, int64_t R, float* padded, void* stream) {
   return pad_impl(h, kind, true, packed, d, R, padded, stream);
 }
+
+int32_t gnx_profile_calibrate(int32_t n, void* stream) { return launch_calibration(n, (hipStream_t)stream); }
 
 int32_t gnx_unpad_features(const gnx_graphs* h, int32_t kind, const float* padded, int32_t d, int64_t R, float* packed, void* stream) {
   return pad_impl(h, kind, false, padded, d, R, packed, stream);

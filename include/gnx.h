@@ -173,6 +173,8 @@ GNX_API int32_t gnx_unpad_features(const gnx_graphs* h, int32_t kind, const floa
 /* ---- per-kernel HIP-event timing (bench/roofline evidence) ---- */
 GNX_API int32_t gnx_profile_enable(int32_t on);
 GNX_API int32_t gnx_profile_reset(void);
+/* n empty launches through the same event bracket (entry "__empty_bracket__"): the bracket's own cost */
+GNX_API int32_t gnx_profile_calibrate(int32_t n, void* stream);
 /* synchronises the recorded events; writes up to `max` entries, returns how many exist in *n */
 GNX_API int32_t gnx_profile_read(gnx_profile_entry* out, int32_t max, int32_t* n);
 

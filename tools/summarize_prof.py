@@ -14,8 +14,12 @@ from collections import defaultdict
 
 
 def short(name):
-    name = name.split("(")[0]
-    return name.split("::")[-1].split("<")[0]
+    """gnx::k_rows_gemm<128, true>(gnx::WideArgs) -> k_rows_gemm<128,true>"""
+    name = name.split("(")[0].split("::")[-1].replace(" ", "")
+    return name if name.startswith("k_rows_gemm") else name.split("<")[0]
+
+
+ALIASES = {"k_rows_gemm<128,true>": "k_rows_gemm_edge", "k_rows_gemm<64,true>": "k_rows_gemm_node"}  # at core dims
 
 
 def main():
@@ -52,7 +56,9 @@ def main():
         json.dump(res, out, indent=1, sort_keys=True)
     if dims:
         with open(os.path.join(os.path.dirname(dst) or ".", f"traffic_{dims}.json"), "w") as out:
-            json.dump({k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in res.items() if "hbm_bytes_per_launch" in v}, out, indent=1)
+            tr = {k: {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"]} for k, v in res.items() if "hbm_bytes_per_launch" in v}
+            tr.update({ALIASES[k]: v for k, v in list(tr.items()) if k in ALIASES})
+            json.dump(tr, out, indent=1)
     print(open(dst + "_kernel_stats.csv").read())
     print(json.dumps(res, indent=1, sort_keys=True))
 
