@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFS = 157.3  # exact-f32 MFMA (v_mfma_f32_32x32x2_f32); no xf32 on gfx950
 NSETS = 8                  # rotating buffer sets: 8 x ~60 MB > 256 MiB Infinity Cache
+NULL_KERNEL_ROCPROF_US = 3.64  # rocprofv3 kernel-trace duration of an empty launch (profiles/r01_readme_rocprofv3_kernel_stats_raw.csv, gnx::k_null)
 DIMS = {"readme": ((10, 5, 0), (3, 4, 5)), "core": ((128, 64, 32), (128, 64, 32))}
 
 
@@ -240,8 +241,11 @@ def main():
         gn.profile_enable(False)
         prof = gn.profile_read(); gn.profile_reset()
         raw = {k: v["total_ms"] / max(v["launches"], 1) * 1e3 for k, v in prof.items()}  # avg µs per launch, event bracket
-        bracket = raw.pop("__empty_bracket__", 0.0)  # what the bracket costs around an empty launch
-        kern = {k: max(v - bracket, 0.0) for k, v in raw.items()}
+        # An event bracket around an EMPTY launch costs `bracket` µs, of which rocprofv3 itself attributes
+        # NULL_KERNEL_ROCPROF_US to the (empty) kernel; the rest is what the bracket adds to any kernel's duration.
+        bracket = raw.pop("__empty_bracket__", 0.0)
+        overhead = max(bracket - NULL_KERNEL_ROCPROF_US, 0.0)
+        kern = {k: max(v - overhead, 0.0) for k, v in raw.items()}
         dom = max(kern, key=kern.get)
         dur_s = kern[dom] * 1e-6
         abytes, aflops = algorithmic_bytes(E, N, G, din, dout), algorithmic_flops(E, N, G, din, dout)
@@ -257,7 +261,7 @@ def main():
         else:
             a = aflops / dur_s / 1e12
             roof = dict(bound="mfma", achieved=round(a, 3), peak=MFMA_F32_PEAK_TFS, unit="TFLOP/s", frac=round(a / MFMA_F32_PEAK_TFS, 4), traffic=traffic)
-        roof.update(kernel=dom, kernel_us=round(kern[dom], 3), event_bracket_us=round(bracket, 3), algorithmic_bytes=abytes, algorithmic_flops=aflops,
+        roof.update(kernel=dom, kernel_us=round(kern[dom], 3), event_bracket_overhead_us=round(overhead, 3), algorithmic_bytes=abytes, algorithmic_flops=aflops,
                     bytes_per_edge=round(abytes / E, 2), all_kernels_us={k: round(v, 3) for k, v in kern.items()})
 
     # ---- CPU baseline: the oracle's C restatement ("port") on the host cores, rank 0, N = 1 only ----
