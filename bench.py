@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--workload", choices=["c2", "hetero"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path even with one rank (testing)")
     ap.add_argument("--model", choices=["block", "c4"], default="block",
                     help="c4: BASELINE configs[3] — encoder -> 2 x GNCore(128,64,32) -> decoder on the C2 graph (extra; not the headline line)")
     args = ap.parse_args()
@@ -145,13 +146,16 @@ def main():
         raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
+        if "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29511"))
         dist.init_process_group("nccl", device_id=dev)
     K, W = args.steps, args.warmup
     if args.model == "c4":
         return bench_c4(args, gn, torch, dev)
     din, dout = DIMS[args.dims]
-    workload = args.workload or ("c2" if world == 1 else "hetero")
+    workload = args.workload or ("hetero" if multi else "c2")
 
     # ---- synthetic batch (rank-local shard) ----
     if workload == "c2":
@@ -174,19 +178,25 @@ def main():
     tg = torch.Generator(device=dev); tg.manual_seed(1234 + rank)
     mk = lambda T, d: torch.rand((1, T, d), generator=tg, device=dev, dtype=torch.float32) if d > 0 else None
     sets = [dict(ef=mk(E, de), nf=mk(N, dn), gf=mk(G, dg), out=plan.outputs()) for _ in range(nsets)]
-    gather = GfGather([np.arange(r * G, (r + 1) * G) for r in range(world)], rank, world, og, dev) if world > 1 else None
+    # N > 1: M steps of compute are captured into one hipGraph that writes the M gf' tables into a stacked buffer, and
+    # ONE all-gather moves the whole stack (fewer, larger collectives: the per-step message is only G*DG' floats = 10 KB,
+    # pure latency on xGMI); the gather runs on a side stream and overlaps the next M steps.
+    M = 1
+    if multi:
+        M = max(m for m in range(1, 65) if K % m == 0)
+    gf_stack = torch.zeros((M, G, og), dtype=torch.float32, device=dev) if multi else None
+    gather = GfGather([np.arange(r * M * G, (r + 1) * M * G) for r in range(world)], rank, world, og, dev) if multi else None
 
-    def step(i, s=None):
+    def step(i, s=None, slot=None):
         b = sets[i % nsets]
-        plan(b["ef"], b["nf"], b["gf"], *b["out"], stream=s)
-        if gather is not None:
-            gather.start(b["out"][2][0])
+        go = b["out"][2] if slot is None else gf_stack[slot:slot + 1]
+        plan(b["ef"], b["nf"], b["gf"], b["out"][0], b["out"][1], go, stream=s)
 
     def sync_all():
-        if gather is not None:
+        if gather is not None and gather._ready is not None:
             gather.finish()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -196,7 +206,7 @@ def main():
         run()
         sync_all()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -207,7 +217,7 @@ def main():
     sync_all()
 
     extra = {}
-    if world == 1:
+    if not multi:
         def capture(nsteps, rotate):
             cg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(cg):
@@ -222,8 +232,26 @@ def main():
         extra["warm_ms_per_step"] = round(min(timed(warm.replay) for _ in range(3)) / K * 1e3, 6)
         extra["launch"] = f"hipGraph of {K} steps, {nsets} rotating buffer sets (cache-cold)"
     else:
-        dt = timed(lambda: [step(i) for i in range(K)])
-        extra["launch"] = "eager, all-gather of gf' overlapped on a side stream"
+        cgs = []
+        for base in range(0, min(K, nsets * M), M):  # enough distinct graphs to keep rotating over all buffer sets
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                for m in range(M):
+                    step(base + m, slot=m)
+            cgs.append(cg)
+        copied = torch.cuda.Event()
+
+        def run():
+            for j in range(K // M):
+                torch.cuda.current_stream(dev).wait_event(copied) if j else None  # previous stack has left gf_stack
+                cgs[j % len(cgs)].replay()
+                gather.start(gf_stack.view(M * G, og))
+                copied.record(gather.comm_stream) if gather.comm_stream is not None else copied.record()
+        run(); sync_all()
+        dt = min(timed(run) for _ in range(3))
+        gf_all = gather.finish() if gather._ready is not None else gather.recv
+        assert gf_all.shape[0] == world * M * G
+        extra["launch"] = f"hipGraph of {M} steps per replay; one RCCL all-gather of the {M} stacked gf' tables per replay, overlapped on a side stream"
     ms_per_step = dt / K * 1e3
     value = E * world / (dt / K)
 
@@ -266,7 +294,7 @@ def main():
 
     # ---- CPU baseline: the oracle's C restatement ("port") on the host cores, rank 0, N = 1 only ----
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         from oracle import c_port
         from oracle import gn_oracle as O
         p = dict(in_dims=din, out_dims=dout, We=blk.edgefn.weight.cpu().numpy(), be=np.zeros(oe, np.float32),
@@ -300,7 +328,8 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if multi:
+        dist.barrier()
         dist.destroy_process_group()
 
 

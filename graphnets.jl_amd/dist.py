@@ -47,6 +47,7 @@ class GfGather:
         self.is_cuda = torch.device(device).type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=device) if (self.is_cuda and overlap) else None
         self._ready = None
+        self._ev = self._ready_ev = None
 
     def start(self, gf_local):
         """gf_local: (n_local, dg) rows of this rank's graphs (shard order).  Asynchronous on GPUs."""
@@ -55,14 +56,15 @@ class GfGather:
             self.send[:n].copy_(gf_local)
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group) if self.is_cuda else self._gather_cpu()
             return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
+        if self._ev is None:
+            self._ev, self._ready_ev = torch.cuda.Event(), torch.cuda.Event()
+        self._ev.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(ev)
+            self.comm_stream.wait_event(self._ev)
             self.send[:n].copy_(gf_local, non_blocking=True)
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-            self._ready = torch.cuda.Event()
-            self._ready.record(self.comm_stream)
+            self._ready_ev.record(self.comm_stream)
+            self._ready = self._ready_ev
 
     def _gather_cpu(self):
         parts = [torch.empty_like(self.send) for _ in range(self.world)]
