@@ -6,7 +6,8 @@ The directory name follows the project naming contract and is not a valid Python
 from . import _lib
 from ._lib import GnxError, LIB_PATH, profile_calibrate, profile_enable, profile_read, profile_reset
 from .api import (NT, BlockPlan, Dense, GNBlock, GNCore, GNCoreList, GNFeedForward, GNGraphBatch, GNGraphNorm, LayerNorm, batch,
-                  efview, flatunpaddedef, flatunpaddednf, gfview, nfview, padded, unbatch, zerodim2nothing)
+                  efview, flatunpaddedef, flatunpaddednf, getedgefninput, getgraphfninput, getnodefninput, gfview, nfview,
+                  padded, unbatch, zerodim2nothing)
 
 FLAG_FORCE_GENERIC = _lib.FLAG_FORCE_GENERIC
 FLAG_NO_MFMA = _lib.FLAG_NO_MFMA

@@ -25,7 +25,7 @@ from ._lib import GnxError, check
 
 __all__ = ["GNGraphBatch", "NT", "batch", "unbatch", "efview", "nfview", "gfview", "flatunpaddednf", "flatunpaddedef",
            "Dense", "LayerNorm", "GNBlock", "GNCore", "GNCoreList", "GNFeedForward", "GNGraphNorm", "zerodim2nothing",
-           "padded", "GnxError"]
+           "padded", "GnxError", "getedgefninput", "getnodefninput", "getgraphfninput"]
 
 _KEYS = ("graphs", "ef", "nf", "gf")
 
@@ -407,6 +407,38 @@ def padded(t):
     if gf is not None and not _shared_like(g):
         gf = gf.permute(0, 2, 1)  # (DG, G, 1) → (DG, 1, G)
     return NT(g, out["ef"], out["nf"], gf)
+
+
+def _fn_input(kind, graphs, ef, nf, gf):
+    g = graphs
+    assert isinstance(g, GNGraphBatch), "graphs must be the GNGraphBatch of a batched tuple"
+    present = [a for a in (ef, nf, gf) if a is not None]
+    assert present, "ef, nf and gf are all nothing"
+    R = present[0].shape[2]
+    c = [_packed(a) for a in (ef, nf, gf)]
+    d = [0 if a is None else a.shape[2] for a in c]
+    T = (g.n_edges, g.n_nodes, g.n_graphs)[kind]
+    K = d[0] + (2 if kind == 0 else 1) * d[1] + d[2]
+    out = torch.empty((R, T, K), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        check(_lib.load().gnx_fn_input(g._h, kind, _ptr(c[0]), d[0], _ptr(c[1]), d[1], _ptr(c[2]), d[2], R, out.data_ptr(),
+                                       torch.cuda.current_stream(g.device).cuda_stream))
+    return _jl(out)
+
+
+def getedgefninput(graphs, edge_features, node_features, graph_features):
+    """`getedgefninput` (edgefninput.jl:1-47): vcat(ef, nf⊗src, nf⊗dst, gf⊗g2e) per real edge — (K_e, ΣE, R), packed."""
+    return _fn_input(0, graphs, edge_features, node_features, graph_features)
+
+
+def getnodefninput(graphs, edge_features, node_features, graph_features):
+    """`getnodefninput` (nodefninput.jl:1-24): vcat(Σ_{e→n} ef, nf, gf⊗g2n) per real node."""
+    return _fn_input(1, graphs, edge_features, node_features, graph_features)
+
+
+def getgraphfninput(graphs, edge_features, node_features, graph_features):
+    """`getgraphfninput` (graphfninput.jl:1-13): vcat(Σ_e ef, Σ_n nf, gf) per graph."""
+    return _fn_input(2, graphs, edge_features, node_features, graph_features)
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -16,6 +16,8 @@ int32_t launch_layernorm2(const float* x, size_t rows, int d, const gnx_layernor
 int32_t launch_ffn_residual(const float* z, const float* x, size_t rows, int d, const gnx_ffn& ff, float* out, hipStream_t s);
 int32_t launch_pad(const gnx_graphs* h, int kind, bool pad, const float* src, int d, int64_t R, float* dst, hipStream_t s);
 int32_t launch_calibration(int n, hipStream_t s);
+int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, const float* nf, int dn, const float* gf, int dg,
+                        int64_t R, float* out, hipStream_t s);
 // returns 1 when the path does not apply to these dims (caller falls through to the next path)
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s);
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s);
@@ -210,6 +212,21 @@ static int32_t pad_impl(const gnx_graphs* h, int32_t kind, bool pad, const float
 
 int32_t gnx_pad_features(const gnx_graphs* h, int32_t kind, const float* packed, int32_t d, int64_t R, float* padded, void* stream) {
   return pad_impl(h, kind, true, packed, d, R, padded, stream);
+}
+
+int32_t gnx_fn_input(const gnx_graphs* h, int32_t kind, const float* ef, int32_t de, const float* nf, int32_t dn, const float* gf,
+                     int32_t dg, int64_t R, float* out, void* stream) {
+  if (!h || !out) return fail(GNX_ERR_INVALID_ARG, "NULL handle or output");
+  if (kind < 0 || kind > 2) return fail(GNX_ERR_INVALID_ARG, "kind must be 0 (edge), 1 (node) or 2 (graph)");
+  if (de < 0 || dn < 0 || dg < 0) return fail(GNX_ERR_DIMS, "negative feature width");
+  if (!ef) de = 0;
+  if (!nf) dn = 0;
+  if (!gf) dg = 0;
+  if (de + dn + dg == 0) return fail(GNX_ERR_ALL_NOTHING, "ef, nf and gf are all nothing");
+  if (kind >= 1 && de == 0) return fail(GNX_ERR_INVALID_ARG, "node / graph function inputs need the updated edge features (nodefninput.jl, graphfninput.jl)");
+  if (kind == 2 && dn == 0) return fail(GNX_ERR_INVALID_ARG, "the graph function input needs the updated node features (graphfninput.jl:1-13)");
+  if (R <= 0 || (R > 1 && h->G != 1) || R > 65535) return fail(GNX_ERR_INVALID_ARG, "bad n_replicas");
+  return launch_fn_input(h, kind, ef, de, nf, dn, gf, dg, R, out, (hipStream_t)stream);
 }
 
 int32_t gnx_profile_calibrate(int32_t n, void* stream) { return launch_calibration(n, (hipStream_t)stream); }

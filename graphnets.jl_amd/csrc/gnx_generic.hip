@@ -293,6 +293,89 @@ __global__ void k_pad_nodes(const int* node_off, int N, int G, int PN, int d, in
   if (PAD) dst[pidx] = src[idx]; else dst[idx] = src[pidx];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// materialised update-function inputs (the reference's exported building blocks)
+// ---------------------------------------------------------------------------------------------------------
+struct FnInArgs {
+  const float *ef, *nf, *gf;
+  int de, dn, dg, N, E, G;
+  const int *colptr, *rowval, *edge_dst, *node_off, *edge_off;
+  float* out;
+};
+
+// one thread per output element; lanes run along the concatenated feature dim (coalesced row writes)
+__global__ void k_fn_input_edge(FnInArgs a) {
+  const int K = a.de + 2 * a.dn + a.dg;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t r = blockIdx.y;
+  if (idx >= (size_t)a.E * K) return;
+  const int e = (int)(idx / K), k = (int)(idx % K);
+  float v;
+  if (k < a.de) v = a.ef[(r * a.E + e) * a.de + k];
+  else if (k < a.de + a.dn) v = a.nf[(r * a.N + a.rowval[e]) * a.dn + (k - a.de)];
+  else if (k < a.de + 2 * a.dn) v = a.nf[(r * a.N + a.edge_dst[e]) * a.dn + (k - a.de - a.dn)];
+  else v = a.gf[(r * a.G + segment_of(a.edge_off, a.G, e)) * a.dg + (k - a.de - 2 * a.dn)];
+  a.out[r * (size_t)a.E * K + idx] = v;
+}
+
+__global__ void k_fn_input_node(FnInArgs a) {
+  const int K = a.de + a.dn + a.dg;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t r = blockIdx.y;
+  if (idx >= (size_t)a.N * K) return;
+  const int n = (int)(idx / K), k = (int)(idx % K);
+  float v = 0.f;
+  if (k < a.de) {
+    for (int e = a.colptr[n]; e < a.colptr[n + 1]; ++e) v += a.ef[(r * a.E + e) * a.de + k];  // CSC order
+  } else if (k < a.de + a.dn) {
+    v = a.nf[(r * a.N + n) * a.dn + (k - a.de)];
+  } else {
+    v = a.gf[(r * a.G + segment_of(a.node_off, a.G, n)) * a.dg + (k - a.de - a.dn)];
+  }
+  a.out[r * (size_t)a.N * K + idx] = v;
+}
+
+// one workgroup per (graph, replica); every column is summed by the whole workgroup in a fixed order
+__global__ __launch_bounds__(256) void k_fn_input_graph(FnInArgs a) {
+  __shared__ float s_red[256];
+  const int K = a.de + a.dn + a.dg, g = blockIdx.x, tid = threadIdx.x;
+  const size_t r = blockIdx.y;
+  float* out = a.out + (r * a.G + g) * (size_t)K;
+  for (int k = 0; k < a.de + a.dn; ++k) {
+    const bool edge = k < a.de;
+    const int t0 = edge ? a.edge_off[g] : a.node_off[g], t1 = edge ? a.edge_off[g + 1] : a.node_off[g + 1];
+    const float* base = edge ? a.ef + r * (size_t)a.E * a.de + k : a.nf + r * (size_t)a.N * a.dn + (k - a.de);
+    const int stride = edge ? a.de : a.dn;
+    float s = 0.f;
+    for (int t = t0 + tid; t < t1; t += 256) s += base[(size_t)t * stride];
+    s_red[tid] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (tid < w) s_red[tid] += s_red[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) out[k] = s_red[0];
+    __syncthreads();
+  }
+  for (int k = tid; k < a.dg; k += 256) out[a.de + a.dn + k] = a.gf[(r * a.G + g) * a.dg + k];
+}
+
+int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, const float* nf, int dn, const float* gf, int dg,
+                        int64_t R, float* out, hipStream_t s) {
+  FnInArgs a{ef, nf, gf, de, dn, dg, (int)h->N, (int)h->E, (int)h->G, h->d_colptr, h->d_rowval, h->d_edge_dst, h->d_node_off, h->d_edge_off, out};
+  if (kind == 0) {
+    const size_t total = (size_t)h->E * (de + 2 * dn + dg);
+    if (total) hipLaunchKernelGGL(k_fn_input_edge, dim3((unsigned)((total + 255) / 256), (unsigned)R), dim3(256), 0, s, a);
+  } else if (kind == 1) {
+    const size_t total = (size_t)h->N * (de + dn + dg);
+    if (total) hipLaunchKernelGGL(k_fn_input_node, dim3((unsigned)((total + 255) / 256), (unsigned)R), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(k_fn_input_graph, dim3((unsigned)h->G, (unsigned)R), dim3(256), 0, s, a);
+  }
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
 __global__ void k_null() {}
 
 // n empty launches through the same event bracket as the real kernels: what a bracket costs by itself (bench.py

@@ -162,6 +162,16 @@ GNX_API int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, 
                          const float* gf, int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out,
                          void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
+/* ---- materialised update-function inputs: the reference's exported building blocks getedgefninput /
+ * getnodefninput / getgraphfninput (src/edgefninput.jl:1-47, src/nodefninput.jl:1-24, src/graphfninput.jl:1-13).
+ * The forward never materialises them; these exist for callers that use the building blocks directly.
+ *   kind 0 (edge):  out [R][E][de+2dn+dg] = [ef ; nf[src] ; nf[dst] ; gf[g]]
+ *   kind 1 (node):  out [R][N][de+dn+dg]  = [sum_{e->n} ef ; nf ; gf[g]]        (ef = the UPDATED edge features)
+ *   kind 2 (graph): out [R][G][de+dn+dg]  = [sum_e ef ; sum_n nf ; gf]
+ * A width of 0 / a NULL pointer drops that segment exactly like the `nothing` methods of the reference. */
+GNX_API int32_t gnx_fn_input(const gnx_graphs* h, int32_t kind, const float* ef, int32_t de, const float* nf, int32_t dn,
+                     const float* gf, int32_t dg, int64_t n_replicas, float* out, void* stream);
+
 /* ---- reference-layout bridges: padef/padnf and unpadef/unpadnf (src/pad.jl:12-64, src/unpad.jl:1-17) ----
  * kind 0 = edges: packed [R][E][d] <-> padded [B][PN^2][d];  kind 1 = nodes: packed [R][N][d] <-> padded [B][PN][d],
  * where B = R (one graph in the handle) or G (R must be 1).  Pads are written as zeros. */

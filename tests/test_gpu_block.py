@@ -254,3 +254,33 @@ def test_results_are_bitwise_reproducible(gn):
     a, b = blk(x), blk(x)
     for u, v in ((a.ef, b.ef), (a.nf, b.nf), (a.gf, b.gf)):
         assert np.array_equal(u.cpu().numpy(), v.cpu().numpy())
+
+
+@pytest.mark.parametrize("in_dims", IN_COMBOS)
+def test_exported_fn_input_building_blocks(gn, in_dims):
+    """getedgefninput / getnodefninput / getgraphfninput (exported at src/GraphNets.jl:26-32) against the dense-form
+    oracle's literal vcat/batched_mul restatement, on the real (unpadded) slots, for every `nothing` combination."""
+    rng = np.random.default_rng(60 + sum(in_dims))
+    adjs = U.random_graphs(rng, (4, 7, 2), 0.5)
+    de, dn, dg = in_dims
+    ef = [rng.random((de, int(a.sum())), dtype=np.float32) for a in adjs] if de else None
+    nf = [rng.random((dn, a.shape[0]), dtype=np.float32) for a in adjs] if dn else None
+    gf = [rng.random((dg,), dtype=np.float32) for a in adjs] if dg else None
+    x = gn.batch(dict(graphs=adjs, ef=ef, nf=nf, gf=gf))
+    xd = O.batch_dense(adjs, ef, nf, gf)
+    g = xd["graphs"]
+    em = g.flat_edge_unpadder.reshape(g.edge_block_size, len(adjs), order="F")
+    nm = g.flat_node_unpadder.reshape(g.node_block_size, len(adjs), order="F")
+    got = gn.getedgefninput(x.graphs, x.ef, x.nf, x.gf).cpu().numpy()[:, :, 0]
+    ref = O.getedgefninput_dense(g, xd["ef"], xd["nf"], xd["gf"]) if de else O._vcat(
+        ([O.batched_mul(xd["nf"], g.srcnode2edge), O.batched_mul(xd["nf"], g.dstnode2edge)] if dn else []) +
+        ([O.batched_mul(xd["gf"], g.graph2edge)] if dg else []))
+    ref_flat = np.concatenate([ref[:, em[:, b], b] for b in range(len(adjs))], axis=1)
+    np.testing.assert_allclose(got, ref_flat, rtol=1e-6, atol=1e-6)
+    if de and dn:  # node / graph inputs take the (updated) edge and node features: reuse ef, nf as stand-ins
+        got = gn.getnodefninput(x.graphs, x.ef, x.nf, x.gf).cpu().numpy()[:, :, 0]
+        ref = O.getnodefninput_dense(g, xd["ef"], xd["nf"], xd["gf"])
+        np.testing.assert_allclose(got, np.concatenate([ref[:, nm[:, b], b] for b in range(len(adjs))], axis=1), rtol=1e-5, atol=1e-5)
+        got = gn.getgraphfninput(x.graphs, x.ef, x.nf, x.gf).cpu().numpy()[:, :, 0]
+        ref = O.getgraphfninput_dense(g, xd["ef"], xd["nf"], xd["gf"])
+        np.testing.assert_allclose(got, ref[:, 0, :], rtol=1e-5, atol=1e-5)
