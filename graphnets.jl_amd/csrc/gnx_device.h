@@ -25,7 +25,6 @@ struct BlockArgs {
   const int* wtile_off;
   const Tile* wtiles;
   int N, E, G, n_tiles, n_wtiles;
-  int ablate;  // timing experiments only (GNX_ABLATE): 1 no ef loads, 2 no src gather, 4 no ef' stores, 8 no nf' stores, 16 no rowval
 };
 
 __device__ __forceinline__ float act_apply(float x, int act) {

@@ -89,8 +89,6 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   a.tile_off = h->d_tile_off; a.tiles = h->d_tiles;
   a.wtile_off = h->d_wtile_off; a.wtiles = h->d_wtiles; a.n_wtiles = (int)h->n_wtiles();
   a.N = (int)h->N; a.E = (int)h->E; a.G = (int)h->G; a.n_tiles = (int)h->n_tiles();
-  static const int ablate = getenv("GNX_ABLATE") ? atoi(getenv("GNX_ABLATE")) : 0;
-  a.ablate = ablate;
 
   if (!(flags & GNX_FLAG_FORCE_GENERIC)) {
     rc = launch_block_narrow(h, a, R, s);  // fused wave-per-tile kernel for the instantiated narrow width sets
