@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--workload", choices=["c2", "hetero"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--overlap", action="store_true",
+                    help="two-phase steps: graph update of step i on a second stream (measured SLOWER inside a hipGraph: the "
+                         "fork/join costs more than the 5 us it hides — 35.7 vs 27.7 us/step — so it is off by default)")
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path even with one rank (testing)")
     ap.add_argument("--model", choices=["block", "c4"], default="block",
                     help="c4: BASELINE configs[3] — encoder -> 2 x GNCore(128,64,32) -> decoder on the C2 graph (extra; not the headline line)")
@@ -177,7 +180,8 @@ def main():
     nsets = NSETS if args.dims == "readme" else 2
     tg = torch.Generator(device=dev); tg.manual_seed(1234 + rank)
     mk = lambda T, d: torch.rand((1, T, d), generator=tg, device=dev, dtype=torch.float32) if d > 0 else None
-    sets = [dict(ef=mk(E, de), nf=mk(N, dn), gf=mk(G, dg), out=plan.outputs()) for _ in range(nsets)]
+    sets = [dict(ef=mk(E, de), nf=mk(N, dn), gf=mk(G, dg), out=plan.outputs(), ws=plan.new_workspace()) for _ in range(nsets)]
+    side = torch.cuda.Stream(device=dev)  # the graph update (a few KB, pure latency) runs here and overlaps the next step
     # N > 1: M steps of compute are captured into one hipGraph that writes the M gf' tables into a stacked buffer, and
     # ONE all-gather moves the whole stack (fewer, larger collectives: the per-step message is only G*DG' floats = 10 KB,
     # pure latency on xGMI); the gather runs on a side stream and overlaps the next M steps.
@@ -187,10 +191,19 @@ def main():
     gf_stack = torch.zeros((M, G, og), dtype=torch.float32, device=dev) if multi else None
     gather = GfGather([np.arange(r * M * G, (r + 1) * M * G) for r in range(world)], rank, world, og, dev) if multi else None
 
-    def step(i, s=None, slot=None):
+    def step(i, s=None, slot=None, overlap=False):
+        """One GNBlock forward.  `overlap`: two-phase form — edge+node update on the current stream, graph update on
+        the side stream behind an event, so it leaves the critical path (joined before the timed region ends)."""
         b = sets[i % nsets]
         go = b["out"][2] if slot is None else gf_stack[slot:slot + 1]
-        plan(b["ef"], b["nf"], b["gf"], b["out"][0], b["out"][1], go, stream=s)
+        if not overlap or og == 0:
+            plan(b["ef"], b["nf"], b["gf"], b["out"][0], b["out"][1], go, stream=s, ws=b["ws"])
+            return
+        cur = torch.cuda.current_stream(dev)
+        plan(b["ef"], b["nf"], b["gf"], b["out"][0], b["out"][1], go, ws=b["ws"], defer_graph_update=True)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            plan.graph_update(b["gf"], go, ws=b["ws"])
 
     def sync_all():
         if gather is not None and gather._ready is not None:
@@ -222,7 +235,8 @@ def main():
             cg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(cg):
                 for i in range(nsteps):
-                    step(i if rotate else 0)
+                    step(i if rotate else (i & 1), overlap=args.overlap)  # warm: 2 sets (120 MB, cache-resident)
+                torch.cuda.current_stream(dev).wait_stream(side)  # join: every graph update is inside the timed region
             return cg
         cold = capture(K, True)
         cold.replay(); torch.cuda.synchronize(dev)
@@ -230,14 +244,16 @@ def main():
         warm = capture(K, False)
         warm.replay(); torch.cuda.synchronize(dev)
         extra["warm_ms_per_step"] = round(min(timed(warm.replay) for _ in range(3)) / K * 1e3, 6)
-        extra["launch"] = f"hipGraph of {K} steps, {nsets} rotating buffer sets (cache-cold)"
+        extra["launch"] = (f"hipGraph of {K} steps, {nsets} rotating buffer sets (cache-cold); " +
+                           ("single stream" if not args.overlap else "graph update of step i on a 2nd stream, overlapping step i+1 (joined inside the timed region)"))
     else:
         cgs = []
         for base in range(0, min(K, nsets * M), M):  # enough distinct graphs to keep rotating over all buffer sets
             cg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(cg):
                 for m in range(M):
-                    step(base + m, slot=m)
+                    step(base + m, slot=m, overlap=args.overlap)
+                torch.cuda.current_stream(dev).wait_stream(side)
             cgs.append(cg)
         copied = torch.cuda.Event()
 

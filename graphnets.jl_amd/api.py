@@ -656,7 +656,20 @@ class BlockPlan:
         mk = lambda T, d: torch.empty((R, T, d), dtype=torch.float32, device=g.device) if d > 0 else None
         return mk(g.n_edges, oe), mk(g.n_nodes, on), mk(g.n_graphs, og)
 
-    def __call__(self, ef, nf, gf, eo, no, go, stream=None):
+    def __call__(self, ef, nf, gf, eo, no, go, stream=None, ws=None, defer_graph_update=False):
+        """`defer_graph_update`: stop after the edge + node update (GNX_FLAG_DEFER_GRAPH_UPDATE); finish with
+        `graph_update` — typically on a second stream so that it overlaps the next batch."""
         s = torch.cuda.current_stream(self.g.device).cuda_stream if stream is None else stream
+        ws = self.ws if ws is None else ws
+        flags = self.flags | (_lib.FLAG_DEFER_GRAPH_UPDATE if defer_graph_update else 0)
         check(self.lib.gnx_block_forward(self.g._h, C.byref(self.p), _ptr(ef), _ptr(nf), _ptr(gf), self.R, _ptr(eo), _ptr(no),
-                                         _ptr(go), self.ws.data_ptr(), self.ws.numel(), self.flags, s))
+                                         _ptr(go), ws.data_ptr(), ws.numel(), flags, s))
+
+    def new_workspace(self):
+        return torch.empty_like(self.ws)
+
+    def graph_update(self, gf, go, stream=None, ws=None):
+        s = torch.cuda.current_stream(self.g.device).cuda_stream if stream is None else stream
+        ws = self.ws if ws is None else ws
+        check(self.lib.gnx_block_graph_update(self.g._h, C.byref(self.p), _ptr(gf), self.R, _ptr(go), ws.data_ptr(), ws.numel(),
+                                              self.flags, s))

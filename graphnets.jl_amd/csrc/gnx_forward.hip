@@ -9,7 +9,7 @@
 namespace gnx {
 
 // implemented in gnx_generic.hip / gnx_narrow.hip / gnx_wide.hip
-int32_t launch_block_generic(const BlockArgs& a, int64_t R, int tile_n_cap, hipStream_t s);
+int32_t launch_block_generic(const BlockArgs& a, int64_t R, int tile_n_cap, hipStream_t s, int phase);
 int32_t launch_graph(const BlockArgs& a, int64_t R, hipStream_t s);
 int32_t launch_layernorm2(const float* x, size_t rows, int d, const gnx_layernorm& l1, const gnx_layernorm& l2, float eps,
                           int eps_mode, float* y1, float* y2, hipStream_t s);
@@ -19,8 +19,9 @@ int32_t launch_calibration(int n, hipStream_t s);
 int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, const float* nf, int dn, const float* gf, int dg,
                         int64_t R, float* out, hipStream_t s);
 // returns 1 when the path does not apply to these dims (caller falls through to the next path)
-int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s);
-int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s);
+// phase bit 1: edge + node update (leaves per-tile partial sums in the workspace); bit 2: graph update from them
+int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase);
+int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase);
 size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R);
 int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K, const gnx_dense& d, int OUT, const float* add1,
                           const float* add2, float* out, int64_t R, hipStream_t s, const char* name);
@@ -64,13 +65,18 @@ static BlockWs block_ws(const gnx_graphs* h, const gnx_block_params* p, int64_t 
 
 static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf,
                                   const float* gf, int64_t R, float* ef_out, float* nf_out, float* gf_out, void* ws,
-                                  size_t ws_bytes, uint32_t flags, hipStream_t s) {
+                                  size_t ws_bytes, uint32_t flags, hipStream_t s, int phase = 3) {
   int32_t rc = check_block(h, p, R);
   if (rc) return rc;
-  if ((p->de > 0 && !ef) || (p->dn > 0 && !nf) || (p->dg > 0 && !gf))
-    return fail(GNX_ERR_INVALID_ARG, "an input with non-zero width is NULL (width 0 <=> nothing)");
-  if ((p->oe > 0 && !ef_out) || (p->on > 0 && !nf_out) || (p->og > 0 && !gf_out))
-    return fail(GNX_ERR_INVALID_ARG, "an output with non-zero width is NULL");
+  if (phase & 1) {
+    if ((p->de > 0 && !ef) || (p->dn > 0 && !nf) || (p->dg > 0 && !gf))
+      return fail(GNX_ERR_INVALID_ARG, "an input with non-zero width is NULL (width 0 <=> nothing)");
+    if ((p->oe > 0 && !ef_out) || (p->on > 0 && !nf_out))
+      return fail(GNX_ERR_INVALID_ARG, "an output with non-zero width is NULL");
+  }
+  if (phase & 2) {
+    if ((p->dg > 0 && !gf) || (p->og > 0 && !gf_out)) return fail(GNX_ERR_INVALID_ARG, "gf / gf_out is NULL");
+  }
   const BlockWs w = block_ws(h, p, R);
   if (!ws || ws_bytes < w.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_block_workspace_bytes()");
   if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");
@@ -91,14 +97,14 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   a.N = (int)h->N; a.E = (int)h->E; a.G = (int)h->G; a.n_tiles = (int)h->n_tiles();
 
   if (!(flags & GNX_FLAG_FORCE_GENERIC)) {
-    rc = launch_block_narrow(h, a, R, s);  // fused wave-per-tile kernel for the instantiated narrow width sets
+    rc = launch_block_narrow(h, a, R, s, phase);  // fused wave-per-tile kernel for the instantiated narrow width sets
     if (rc != 1) return rc;
     if (!(flags & GNX_FLAG_NO_MFMA)) {
-      rc = launch_block_wide(h, a, R, s);  // fp32 MFMA gathered-row GEMMs
+      rc = launch_block_wide(h, a, R, s, phase);  // fp32 MFMA gathered-row GEMMs
       if (rc != 1) return rc;
     }
   }
-  return launch_block_generic(a, R, h->tile_n_cap, s);
+  return launch_block_generic(a, R, h->tile_n_cap, s, phase);
 }
 
 }  // namespace gnx
@@ -115,7 +121,14 @@ size_t gnx_block_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p,
 int32_t gnx_block_forward(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf, const float* gf,
                           int64_t R, float* ef_out, float* nf_out, float* gf_out, void* ws, size_t ws_bytes, uint32_t flags,
                           void* stream) {
-  return block_forward_impl(h, p, ef, nf, gf, R, ef_out, nf_out, gf_out, ws, ws_bytes, flags, (hipStream_t)stream);
+  return block_forward_impl(h, p, ef, nf, gf, R, ef_out, nf_out, gf_out, ws, ws_bytes, flags, (hipStream_t)stream,
+                            (flags & GNX_FLAG_DEFER_GRAPH_UPDATE) ? 1 : 3);
+}
+
+int32_t gnx_block_graph_update(const gnx_graphs* h, const gnx_block_params* p, const float* gf, int64_t R, float* gf_out, void* ws,
+                               size_t ws_bytes, uint32_t flags, void* stream) {
+  // the kernels of this phase read only gf, the graph function's parameters and the workspace
+  return block_forward_impl(h, p, nullptr, nullptr, gf, R, nullptr, nullptr, gf_out, ws, ws_bytes, flags, (hipStream_t)stream, 2);
 }
 
 // FeedForward width from which the two Dense layers run on the matrix cores (hidden activations staged in HBM)

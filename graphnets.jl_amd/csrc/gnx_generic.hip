@@ -168,19 +168,19 @@ int32_t launch_graph(const BlockArgs& a, int64_t R, hipStream_t s) {
   return GNX_OK;
 }
 
-int32_t launch_block_generic(const BlockArgs& a, int64_t R, int tile_n_cap, hipStream_t s) {
+int32_t launch_block_generic(const BlockArgs& a, int64_t R, int tile_n_cap, hipStream_t s, int phase) {
   const dim3 grid((unsigned)a.n_tiles, (unsigned)R);
-  if (a.oe > 0 && a.E > 0) {
+  if ((phase & 1) && a.oe > 0 && a.E > 0) {
     ProfScope ps("k_edge_generic", s);
     hipLaunchKernelGGL(k_edge_generic, grid, dim3(256), sizeof(int) * (size_t)(tile_n_cap + 1), s, a);
     GNX_HIP(hipGetLastError());
   }
-  {
+  if (phase & 1) {
     ProfScope ps("k_node_generic", s);
     hipLaunchKernelGGL(k_node_generic, grid, dim3(256), 0, s, a);
     GNX_HIP(hipGetLastError());
   }
-  return launch_graph(a, R, s);
+  return (phase & 2) ? launch_graph(a, R, s) : GNX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------

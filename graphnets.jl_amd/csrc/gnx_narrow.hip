@@ -390,16 +390,16 @@ __global__ void k_graph_t(BlockArgs a, int prow_stride) {
 }
 
 template <int DE, int DN, int DG, int OE, int ON, int EPT>
-static int32_t launch_wave_t(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s) {
+static int32_t launch_wave_t(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   constexpr int C = OE + ON;
   const int prow_stride = (int)((h->n_wtiles() + 3) / 4 * 4 + 4);
   const unsigned grid = (unsigned)((a.n_wtiles + 3) / 4);
-  {
+  if (phase & 1) {
     ProfScope ps("k_block_wave", s);
     hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, prow_stride);
     GNX_HIP(hipGetLastError());
   }
-  if (a.og > 0) {
+  if ((phase & 2) && a.og > 0) {
     if constexpr (C > 0) {
       // block size by the number of partial rows per graph: 1024 threads cover 4096 rows per pass
       const int64_t rows_per_graph = (h->n_wtiles() + h->G - 1) / h->G;
@@ -414,12 +414,12 @@ static int32_t launch_wave_t(const gnx_graphs* h, const BlockArgs& a, int64_t R,
 }
 
 template <int DE, int DN, int DG, int OE, int ON>
-static int32_t launch_fused(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s) {
+static int32_t launch_fused(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   // the kernel's EPT must match the handle's wave-tile edge cap (GNX_WTILE_E at handle creation: 64, 128 or 256)
-  if (h->wtile_e_cap == 64) return launch_wave_t<DE, DN, DG, OE, ON, 1>(h, a, R, s);
-  if (h->wtile_e_cap == 128) return launch_wave_t<DE, DN, DG, OE, ON, 2>(h, a, R, s);
+  if (h->wtile_e_cap == 64) return launch_wave_t<DE, DN, DG, OE, ON, 1>(h, a, R, s, phase);
+  if (h->wtile_e_cap == 128) return launch_wave_t<DE, DN, DG, OE, ON, 2>(h, a, R, s, phase);
   if (h->wtile_e_cap == 256) {
-    if constexpr ((DE + DN) * 4 <= 64) return launch_wave_t<DE, DN, DG, OE, ON, 4>(h, a, R, s);
+    if constexpr ((DE + DN) * 4 <= 64) return launch_wave_t<DE, DN, DG, OE, ON, 4>(h, a, R, s, phase);
   }
   return 1;
 }
@@ -436,11 +436,11 @@ static int32_t launch_fused(const gnx_graphs* h, const BlockArgs& a, int64_t R, 
   X(10, 5, 3, 10, 5)       \
   X(10, 5, 0, 10, 5)
 
-int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s) {
+int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   if (a.n_wtiles == 0 || a.E == 0) return 1;
   // 16-B vector copies assume fp32-aligned buffers (always true for fp32 arrays); nothing else is required
 #define GNX_CASE(DE, DN, DG, OE, ON) \
-  if (a.de == DE && a.dn == DN && a.dg == DG && a.oe == OE && a.on == ON) return launch_fused<DE, DN, DG, OE, ON>(h, a, R, s);
+  if (a.de == DE && a.dn == DN && a.dg == DG && a.oe == OE && a.on == ON) return launch_fused<DE, DN, DG, OE, ON>(h, a, R, s, phase);
   GNX_NARROW_DIMS(GNX_CASE)
 #undef GNX_CASE
   return 1;

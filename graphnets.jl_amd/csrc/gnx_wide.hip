@@ -412,7 +412,7 @@ int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K
   return launch_gemm_any(w, al16 && K % 4 == 0 && OUT % 4 == 0, n_tiles, R, s, name);
 }
 
-int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s) {
+int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   static const bool off = getenv("GNX_NO_WIDE") != nullptr;
   if (off) return 1;
   const int ke = a.de + 2 * a.dn + a.dg, kn = a.oe + a.dn + a.dg;
@@ -430,7 +430,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   float* pe2 = stage2;
   float* pn2 = pe2 + (size_t)R * h->G * S * a.oe;
   int32_t rc;
-  if (a.oe > 0) {
+  if ((phase & 1) && a.oe > 0) {
     WideArgs w{};
     w.tiles = h->d_etiles; w.row_kind = 0;
     int ns = 0;
@@ -448,7 +448,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     const bool vec4 = al16 && a.de % 4 == 0 && a.dn % 4 == 0 && a.oe % 4 == 0;
     if ((rc = launch_gemm_any(w, vec4, (unsigned)n_et, R, s, "k_rows_gemm_edge"))) return rc;
   }
-  if (a.on > 0) {
+  if ((phase & 1) && a.on > 0) {
     WideArgs w{};
     w.tiles = h->d_ntiles; w.row_kind = 1;
     int ns = 0;
@@ -464,7 +464,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     const bool vec4 = al && a.oe % 4 == 0 && a.dn % 4 == 0 && a.on % 4 == 0;
     if ((rc = launch_gemm_any(w, vec4, (unsigned)n_nt, R, s, "k_rows_gemm_node"))) return rc;
   }
-  if (a.og > 0) {
+  if ((phase & 2) && a.og > 0) {
     ProfScope ps("k_graph_wide", s);
     if (a.oe > 0) hipLaunchKernelGGL(k_colsum_slices, dim3((unsigned)a.G, (unsigned)S, (unsigned)R), dim3(128), 0, s, pe, n_et * (size_t)a.oe, h->d_etile_off, a.oe, S, pe2, a.G);
     if (a.on > 0) hipLaunchKernelGGL(k_colsum_slices, dim3((unsigned)a.G, (unsigned)S, (unsigned)R), dim3(128), 0, s, pn, n_nt * (size_t)a.on, h->d_ntile_off, a.on, S, pn2, a.G);

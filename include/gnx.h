@@ -69,6 +69,8 @@ extern "C" {
 /* forward flags */
 #define GNX_FLAG_FORCE_GENERIC 0x1u /* use the dimension-generic kernels even when a specialised path exists */
 #define GNX_FLAG_NO_MFMA 0x2u       /* never pick the MFMA path                                               */
+#define GNX_FLAG_DEFER_GRAPH_UPDATE 0x4u /* gnx_block_forward stops after the edge+node update and leaves the per-tile
+                                          * partial sums in the workspace; gnx_block_graph_update finishes gf' later   */
 
 typedef struct gnx_graphs gnx_graphs; /* opaque; replaces GNGraphBatch (src/gngraphbatch.jl:1-54) */
 
@@ -155,6 +157,14 @@ GNX_API size_t gnx_block_workspace_bytes(const gnx_graphs* h, const gnx_block_pa
 GNX_API int32_t gnx_block_forward(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf,
                           const float* gf, int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out,
                           void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+
+/* Second phase of a deferred block forward: gf'[g] = graphfn([sum_e ef' ; sum_n nf' ; gf_g]) (src/gnblock.jl:67,
+ * src/graphfninput.jl:1-13) from the partial sums a gnx_block_forward(..., GNX_FLAG_DEFER_GRAPH_UPDATE, ...) call left
+ * in `workspace` (same handle, params, n_replicas, flags and workspace; the workspace must not be reused in between).
+ * It is a few KB of work that only the caller of gf' waits for: launched on a second stream (after an event recorded
+ * behind the first phase) it overlaps the next batch's edge/node update instead of sitting on the critical path. */
+GNX_API int32_t gnx_block_graph_update(const gnx_graphs* h, const gnx_block_params* p, const float* gf, int64_t n_replicas,
+                               float* gf_out, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* ---- forward: replaces (m::GNCore)(x) (src/gncore.jl:56-68); GNCoreList = caller-side fold (gncorelist.jl:43-45) ---- */
 GNX_API size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t n_replicas);

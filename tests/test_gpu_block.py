@@ -284,3 +284,30 @@ def test_exported_fn_input_building_blocks(gn, in_dims):
         got = gn.getgraphfninput(x.graphs, x.ef, x.nf, x.gf).cpu().numpy()[:, :, 0]
         ref = O.getgraphfninput_dense(g, xd["ef"], xd["nf"], xd["gf"])
         np.testing.assert_allclose(got, ref[:, 0, :], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dims", [((10, 5, 0), (3, 4, 5)), ((128, 64, 32), (128, 64, 32)), ((5, 6, 7), (7, 6, 5))], ids=["narrow", "wide", "generic"])
+def test_deferred_graph_update_on_second_stream(gn, dims):
+    """GNX_FLAG_DEFER_GRAPH_UPDATE + gnx_block_graph_update (second stream, event-ordered) == the one-call forward, bitwise."""
+    import torch
+    rng = np.random.default_rng(70)
+    colptr, rowval = U.er_csc(rng, 500, 4000)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [500])
+    blk = U.block_from_params(gn, O.make_block_params(rng, *dims))
+    ef, nf, gf = U.packed_inputs(rng, 1, 4000, 500, 1, dims[0])
+    dev = g.device
+    t = lambda a: None if a is None else torch.from_numpy(a).to(dev)
+    ef, nf, gf = t(ef), t(nf), t(gf)
+    plan = gn.BlockPlan(blk, g)
+    o1, o2 = plan.outputs(), plan.outputs()
+    plan(ef, nf, gf, *o1)
+    ws2 = plan.new_workspace()
+    side = torch.cuda.Stream(device=dev)
+    plan(ef, nf, gf, *o2, ws=ws2, defer_graph_update=True)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        plan.graph_update(gf, o2[2], ws=ws2)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
