@@ -30,7 +30,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 MFMA_F32_PEAK_TFS = 157.3  # exact-f32 MFMA (v_mfma_f32_32x32x2_f32); no xf32 on gfx950
 NSETS = 8                  # rotating buffer sets: 8 x ~60 MB > 256 MiB Infinity Cache
 NULL_KERNEL_ROCPROF_US = 3.64  # rocprofv3 kernel-trace duration of an empty launch (profiles/r01_readme_rocprofv3_kernel_stats_raw.csv, gnx::k_null)
-DIMS = {"readme": ((10, 5, 0), (3, 4, 5)), "core": ((128, 64, 32), (128, 64, 32))}
+DIMS = {"readme": ((10, 5, 0), (3, 4, 5)), "core": ((128, 64, 32), (128, 64, 32)),
+        "odd": ((7, 3, 2), (5, 6, 1)), "mid": ((20, 10, 4), (12, 9, 3))}  # odd: generic kernels; mid: MFMA path
 
 
 def make_c2(seed=2, N=100_000, E=1_000_000):
@@ -177,7 +178,7 @@ def main():
     blk.nodefn = gn.Dense.from_numpy(glorot(rng, on, oe + dn + dg), np.zeros(on, np.float32), device=dev)
     blk.graphfn = gn.Dense.from_numpy(glorot(rng, og, oe + on + dg), np.zeros(og, np.float32), device=dev)
     plan = gn.BlockPlan(blk, g, R=1, flags=args.flags)
-    nsets = NSETS if args.dims == "readme" else 2
+    nsets = 2 if args.dims == "core" else NSETS
     tg = torch.Generator(device=dev); tg.manual_seed(1234 + rank)
     mk = lambda T, d: torch.rand((1, T, d), generator=tg, device=dev, dtype=torch.float32) if d > 0 else None
     sets = [dict(ef=mk(E, de), nf=mk(N, dn), gf=mk(G, dg), out=plan.outputs(), ws=plan.new_workspace()) for _ in range(nsets)]
