@@ -14,6 +14,9 @@
 // prefetched into registers while the current one is on the matrix cores.  Epilogue: bias' + activation, 128-B row
 // segments to HBM, and fixed-order column sums of the tile (the graph update's partial sums, graphfninput.jl:3-4).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 #include "gnx_device.h"
 
@@ -45,16 +48,20 @@ struct WideArgs {
   const float* W;    // (OUT x K) column-major == [K][OUT] row-major
   const float* bias;
   int OUT, act;
-  const float* gf;   // replica 0, [G][dg]
-  size_t gf_rep_stride;
-  int dg, gf_w_row0;
+  const float* bias_g;  // [R][G][OUT] per-graph bias with gf folded in (k_fold_bias), or nullptr: use `bias`
+  int n_graphs;
   float* out;
   size_t out_rep_stride;
   float* colsum;     // [R][n_tiles][OUT] or nullptr
   size_t colsum_rep_stride;
   const float* add1;  // optional residual inputs with the layout of `out` (may alias `out`): v = act(..) + add1 + add2
   const float* add2;
+  unsigned long long* stamps;  // diagnostic builds only (GNX_WIDE_STAMPS): [tile][8] shader-clock stamps of wave 0
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits until every global
+// STORE of the wave has been acknowledged — in the epilogue that is a full HBM write round trip per barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int BN>
 struct WaveLayout {
@@ -68,8 +75,12 @@ template <int BN, bool VEC4>
 __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
   using L = WaveLayout<BN>;
   constexpr int NB4 = (KC * BN / 4) / WT;  // float4 of the B chunk per thread
-  __shared__ __attribute__((aligned(16))) float sA[BM * LDA];
-  __shared__ __attribute__((aligned(16))) float sB[KC * BN];
+  constexpr int LDC = BN + 4;                       // epilogue staging: [64 rows][BN + 4]
+  constexpr int POOL = (BM * LDA + KC * BN) > 64 * LDC ? (BM * LDA + KC * BN) : 64 * LDC;
+  __shared__ __attribute__((aligned(16))) float s_pool[POOL];
+  float* sA = s_pool;                               // [BM][LDA]
+  float* sB = s_pool + BM * LDA;                    // [KC][BN]   (BM*LDA*4 is a multiple of 16)
+  float* sC = s_pool;                               // reused after the K loop
   __shared__ int s_ia[BM], s_ib[BM];  // gather indices, or colptr range for the segment-sum mode
   __shared__ float s_bias[BN];
   __shared__ float s_cs[L::WM][BN];
@@ -82,6 +93,10 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
   const int row0 = a.row_kind == 0 ? t.e0 : t.n0;
   const int rows = (a.row_kind == 0 ? t.e1 : t.n1) - row0;
 
+#ifdef GNX_WIDE_STAMPS_BUILD  // diagnostic build only (hipcc -DGNX_WIDE_STAMPS_BUILD): the shipped kernel executes no stamp
+  unsigned long long st[6];
+  st[0] = clock64();
+#endif
   // per-row indices
   bool need_cp = false, need_idx = false;
   for (int s = 0; s < a.nseg; ++s) {
@@ -98,15 +113,12 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
       s_ib[tid] = a.idx_b[row0 + m];
     }
   }
-  // tile bias: b + W[gf rows]^T gf[g]
+  // tile bias: b + W[gf rows]^T gf[g], folded once per graph by k_fold_bias (a per-tile fold is a runtime-length chain
+  // of dependent global loads: 32 round trips, more than the tile's whole MFMA time)
   if (tid < BN) {
     const int n = n0 + tid;
     float b = 0.f;
-    if (n < a.OUT) {
-      b = a.bias ? a.bias[n] : 0.f;
-      const float* gf = a.gf ? a.gf + r * a.gf_rep_stride + (size_t)t.g * a.dg : nullptr;
-      for (int k = 0; k < a.dg; ++k) b = fmaf(a.W[(size_t)(a.gf_w_row0 + k) * a.OUT + n], gf[k], b);
-    }
+    if (n < a.OUT) b = a.bias_g ? a.bias_g[(r * a.n_graphs + t.g) * (size_t)a.OUT + n] : (a.bias ? a.bias[n] : 0.f);
     s_bias[tid] = b;
   }
   __syncthreads();
@@ -194,12 +206,23 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
   };
 
   int si = 0, kc = 0;
+#ifdef GNX_WIDE_STAMPS_BUILD
+  st[1] = clock64();
+  unsigned long long t_sync = 0, t_mfma = 0;
+#endif
   while (si < a.nseg && a.seg[si].width == 0) ++si;
   if (si < a.nseg) load_chunk(si, kc);
   while (si < a.nseg) {
+#ifdef GNX_WIDE_STAMPS_BUILD
+    const unsigned long long tA = clock64();
+#endif
     __syncthreads();  // everyone is done reading the previous chunk
     store_chunk();
     __syncthreads();
+#ifdef GNX_WIDE_STAMPS_BUILD
+    const unsigned long long tB = clock64();
+    t_sync += tB - tA;
+#endif
     // advance and prefetch the next chunk while the matrix cores work on this one
     kc += KC;
     if (kc >= a.seg[si].width) {
@@ -221,9 +244,16 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
 #pragma unroll
         for (int j = 0; j < L::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
+#ifdef GNX_WIDE_STAMPS_BUILD
+    t_mfma += clock64() - tB;
+#endif
   }
+#ifdef GNX_WIDE_STAMPS_BUILD
+  st[2] = clock64();
+#endif
 
-  // ---- epilogue: bias' + activation, store, column sums ----
+  // ---- epilogue: bias' + activation in registers, then the tile goes through LDS (two 64-row passes) so that HBM sees
+  //      full-row 16-B vector stores (the direct C/D layout store is 64 dword stores per lane: store-issue bound) ----
   float* out = a.out + r * a.out_rep_stride;
   const int hi = lane >> 5, l31 = lane & 31;
   float cs[L::TN];
@@ -239,16 +269,53 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (wm * L::TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;  // C/D layout of 32x32 MFMA
-        float v = act_apply(acc[i][j][q] + b, a.act);
-        if (row < rows && col_ok) {
-          const size_t o = (size_t)(row0 + row) * a.OUT + n0 + col;
-          if (a.add1) v += a.add1[r * a.out_rep_stride + o];
-          if (a.add2) v += a.add2[r * a.out_rep_stride + o];
-          out[o] = v;
-        } else {
-          v = 0.f;
+        const float v = (row < rows && col_ok) ? act_apply(acc[i][j][q] + b, a.act) : 0.f;
+        acc[i][j][q] = v;
+        cs[j] += v;  // column sums are taken BEFORE the residual adds (they feed the graph update of a block)
+      }
+    }
+  }
+  constexpr int NC4 = (64 * BN / 4) / WT;  // float4 per thread and pass
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    lds_barrier();  // K-loop readers (pass 0) / previous pass readers are done with the pool
+#pragma unroll
+    for (int i = 0; i < L::TM; ++i) {
+      const int rbase = (wm * L::TM + i) * 32;  // 32-row block of this wave
+      if (rbase / 64 == pass) {
+#pragma unroll
+        for (int j = 0; j < L::TN; ++j) {
+          const int col = (wn * L::TN + j) * 32 + l31;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) sC[(rbase - 64 * pass + (q & 3) + 8 * (q >> 2) + 4 * hi) * LDC + col] = acc[i][j][q];
         }
-        cs[j] += v;
+      }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < NC4; ++i) {
+      const int idx = tid + WT * i;
+      const int lr = idx / (BN / 4), c4 = idx % (BN / 4);
+      const int row = 64 * pass + lr, n = n0 + 4 * c4;
+      if (row < rows && n < a.OUT) {
+        float4 v = *reinterpret_cast<const float4*>(sC + lr * LDC + 4 * c4);
+        const size_t o = (size_t)(row0 + row) * a.OUT + n;
+        if (VEC4) {
+          if (a.add1) { const float4 u = *reinterpret_cast<const float4*>(a.add1 + r * a.out_rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+          if (a.add2) { const float4 u = *reinterpret_cast<const float4*>(a.add2 + r * a.out_rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+          *reinterpret_cast<float4*>(out + o) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e < a.OUT) {
+              float y = vv[e];
+              if (a.add1) y += a.add1[r * a.out_rep_stride + o + e];
+              if (a.add2) y += a.add2[r * a.out_rep_stride + o + e];
+              out[o + e] = y;
+            }
+          }
+        }
       }
     }
   }
@@ -259,13 +326,46 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
       const float tot = hi == 0 ? cs[j] + other : other + cs[j];  // same association in both halves
       if (hi == 0) s_cs[wm][(wn * L::TN + j) * 32 + l31] = tot;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < BN && n0 + tid < a.OUT) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < L::WM; ++w) s += s_cs[w][tid];
       a.colsum[r * a.colsum_rep_stride + (size_t)blockIdx.x * a.OUT + n0 + tid] = s;
     }
+  }
+#ifdef GNX_WIDE_STAMPS_BUILD
+  if (a.stamps && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+    o[0] = st[1] - st[0]; o[1] = t_sync; o[2] = t_mfma; o[3] = clock64() - st[2]; o[4] = clock64() - st[0];
+  }
+#endif
+}
+
+// bias'[r][g][n] = b[n] + sum_k W[(w_row0 + k)*OUT + n] * gf[r][g][k]      (the gf segment of edgefninput.jl:6 /
+// nodefninput.jl:5: constant per graph, so it is a rank-1 fold instead of K more columns of every row's GEMM)
+__global__ void k_fold_bias(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ gf, int dg,
+                            int w_row0, int OUT, int G, float* __restrict__ out) {
+  const int g = blockIdx.x;
+  const size_t r = blockIdx.y;
+  const float* gfg = gf + (r * G + g) * (size_t)dg;
+  for (int n = threadIdx.x; n < OUT; n += blockDim.x) {
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    for (int k = 0; k < dg; k += 8) {
+      float w[8], x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {  // clamped, unconditional loads: 16 in flight
+        const int kk = min(k + u, dg - 1);
+        w[u] = W[(size_t)(w_row0 + kk) * OUT + n];
+        x[u] = gfg[kk];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] = fmaf(w[u], k + u < dg ? x[u] : 0.f, acc[u]);
+    }
+    const float b = bias ? bias[n] : 0.f;
+    out[(r * G + g) * (size_t)OUT + n] = b + (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])));
   }
 }
 
@@ -362,7 +462,8 @@ static int wide_slices(const gnx_graphs* h) {
 size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
   const size_t per_tile = sizeof(float) * (size_t)R * ((size_t)h->h_etiles.size() * p->oe + (size_t)h->h_ntiles.size() * p->on);
   const size_t stage2 = sizeof(float) * (size_t)R * h->G * wide_slices(h) * (size_t)(p->oe + p->on);
-  return align_up(per_tile, 256) + align_up(stage2, 256) + 512;
+  const size_t bias_g = sizeof(float) * (size_t)R * h->G * (size_t)(p->oe + p->on);
+  return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + 512;
 }
 
 template <int BN>
@@ -376,7 +477,6 @@ static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64
     if ((g.mode == 1 && !w.idx_a) || (g.mode == 2 && !w.idx_b) || (g.mode == 3 && !w.cp))
       return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: index array required by a segment mode is NULL");
   }
-  if (w.dg > 0 && !w.gf) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: gf is NULL but dg > 0");
   ProfScope ps(name, s);
   const dim3 grid(n_tiles, (unsigned)((w.OUT + BN - 1) / BN), (unsigned)R);
   if (vec4) hipLaunchKernelGGL((k_rows_gemm<BN, true>), grid, dim3(WT), 0, s, w);
@@ -403,7 +503,7 @@ int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K
   w.seg[0] = WSeg{A, nrows * (size_t)K, K, 0, 0};
   w.nseg = 1;
   w.W = d.weight; w.bias = d.bias; w.OUT = OUT; w.act = d.act;
-  w.gf = nullptr; w.dg = 0;
+  w.bias_g = nullptr; w.n_graphs = (int)h->G;
   w.out = out; w.out_rep_stride = nrows * (size_t)OUT;
   w.colsum = nullptr;
   w.add1 = add1; w.add2 = add2;
@@ -429,7 +529,15 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
                                            align_up(sizeof(float) * (size_t)R * (n_et * a.oe + n_nt * a.on), 256));
   float* pe2 = stage2;
   float* pn2 = pe2 + (size_t)R * h->G * S * a.oe;
+  float* bias_e = reinterpret_cast<float*>(reinterpret_cast<char*>(stage2) + align_up(sizeof(float) * (size_t)R * h->G * S * (a.oe + a.on), 256));
+  float* bias_n = bias_e + (size_t)R * h->G * a.oe;
   int32_t rc;
+  if ((phase & 1) && a.dg > 0) {  // fold gf into per-graph biases (one tiny launch per update function)
+    ProfScope ps("k_fold_bias", s);
+    if (a.oe > 0) hipLaunchKernelGGL(k_fold_bias, dim3((unsigned)a.G, (unsigned)R), dim3(128), 0, s, a.We, a.be, a.gf, a.dg, a.de + 2 * a.dn, a.oe, a.G, bias_e);
+    if (a.on > 0) hipLaunchKernelGGL(k_fold_bias, dim3((unsigned)a.G, (unsigned)R), dim3(128), 0, s, a.Wn, a.bn, a.gf, a.dg, a.oe + a.dn, a.on, a.G, bias_n);
+    GNX_HIP(hipGetLastError());
+  }
   if ((phase & 1) && a.oe > 0) {
     WideArgs w{};
     w.tiles = h->d_etiles; w.row_kind = 0;
@@ -442,11 +550,28 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     w.nseg = ns;
     w.idx_a = a.rowval; w.idx_b = h->d_edge_dst; w.cp = a.colptr;
     w.W = a.We; w.bias = a.be; w.OUT = a.oe; w.act = a.act_e;
-    w.gf = a.gf; w.gf_rep_stride = (size_t)a.G * a.dg; w.dg = a.dg; w.gf_w_row0 = a.de + 2 * a.dn;
+    w.bias_g = a.dg > 0 ? bias_e : nullptr; w.n_graphs = a.G;
     w.out = a.ef_out; w.out_rep_stride = (size_t)a.E * a.oe;
     w.colsum = a.og > 0 ? pe : nullptr; w.colsum_rep_stride = n_et * (size_t)a.oe;
     const bool vec4 = al16 && a.de % 4 == 0 && a.dn % 4 == 0 && a.oe % 4 == 0;
+#ifdef GNX_WIDE_STAMPS_BUILD
+    static unsigned long long* d_stamps = nullptr;
+    static const bool want_stamps = getenv("GNX_WIDE_STAMPS") != nullptr;
+    if (want_stamps && !d_stamps) { (void)hipMalloc((void**)&d_stamps, n_et * 8 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, n_et * 8 * sizeof(unsigned long long)); }
+    w.stamps = want_stamps ? d_stamps : nullptr;
+#endif
     if ((rc = launch_gemm_any(w, vec4, (unsigned)n_et, R, s, "k_rows_gemm_edge"))) return rc;
+#ifdef GNX_WIDE_STAMPS_BUILD
+    if (want_stamps) {
+      (void)hipStreamSynchronize(s);
+      std::vector<unsigned long long> hs(n_et * 8);
+      (void)hipMemcpy(hs.data(), d_stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      double m[5] = {0, 0, 0, 0, 0};
+      for (size_t i = 0; i < n_et; ++i) for (int j = 0; j < 5; ++j) m[j] += (double)hs[i * 8 + j];
+      fprintf(stderr, "[gnx stamps] edge gemm per tile (shader clocks, wave 0): prologue %.0f  sync+store %.0f  mfma-loop %.0f  epilogue %.0f  total %.0f\n",
+              m[0] / n_et, m[1] / n_et, m[2] / n_et, m[3] / n_et, m[4] / n_et);
+    }
+#endif
   }
   if ((phase & 1) && a.on > 0) {
     WideArgs w{};
@@ -457,7 +582,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     w.nseg = ns;
     w.idx_a = nullptr; w.idx_b = nullptr; w.cp = a.colptr;
     w.W = a.Wn; w.bias = a.bn; w.OUT = a.on; w.act = a.act_n;
-    w.gf = a.gf; w.gf_rep_stride = (size_t)a.G * a.dg; w.dg = a.dg; w.gf_w_row0 = a.oe + a.dn;
+    w.bias_g = a.dg > 0 ? bias_n : nullptr; w.n_graphs = a.G;
     w.out = a.nf_out; w.out_rep_stride = (size_t)a.N * a.on;
     w.colsum = a.og > 0 ? pn : nullptr; w.colsum_rep_stride = n_nt * (size_t)a.on;
     const bool al = al16 && ((uintptr_t)a.nf_out % 16 == 0);
