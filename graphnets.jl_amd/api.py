@@ -25,7 +25,8 @@ from ._lib import GnxError, check
 
 __all__ = ["GNGraphBatch", "NT", "batch", "unbatch", "efview", "nfview", "gfview", "flatunpaddednf", "flatunpaddedef",
            "Dense", "LayerNorm", "GNBlock", "GNCore", "GNCoreList", "GNFeedForward", "GNGraphNorm", "zerodim2nothing",
-           "padded", "GnxError", "getedgefninput", "getnodefninput", "getgraphfninput"]
+           "padded", "GnxError", "getedgefninput", "getnodefninput", "getgraphfninput",
+           "unpaddedcollapsedef", "flatunpaddedcollapsedef"]
 
 _KEYS = ("graphs", "ef", "nf", "gf")
 
@@ -407,6 +408,38 @@ def padded(t):
     if gf is not None and not _shared_like(g):
         gf = gf.permute(0, 2, 1)  # (DG, G, 1) → (DG, 1, G)
     return NT(g, out["ef"], out["nf"], gf)
+
+
+def _collapse(t):
+    t = _as_nt(t)
+    g, ef = t.graphs, t.ef
+    assert ef is not None, "collapsing needs edge features"
+    lib = _lib.load()
+    off = np.zeros(g.n_graphs + 1, dtype=np.int64)
+    with torch.cuda.device(g.device):
+        check(lib.gnx_collapse_offsets(g._h, off.ctypes.data_as(C.POINTER(C.c_int64))))
+        c = _packed(ef)
+        R, _, D = c.shape
+        out = torch.empty((R, int(off[-1]), D), dtype=torch.float32, device=g.device)
+        check(lib.gnx_collapse_edges(g._h, c.data_ptr(), D, R, out.data_ptr(), torch.cuda.current_stream(g.device).cuda_stream))
+    return _jl(out), off
+
+
+def unpaddedcollapsedef(t):
+    """`unpaddedcollapsedef` (gngraphbatch.jl:87-107): per graph / batch element, the symmetric averages
+    (ef[i->j] + ef[j->i]) / 2 over the real edges of the lower triangle (i >= j), in edge order.  A missing reverse edge
+    contributes 0 (the reference reads the padded slot there)."""
+    out, off = _collapse(t)
+    g = _as_nt(t).graphs
+    if _shared_like(g):
+        return [out[:, :, b] for b in range(out.shape[2])]
+    return [out[:, off[i]:off[i + 1], 0] for i in range(g.n_graphs)]
+
+
+def flatunpaddedcollapsedef(t):
+    """`flatunpaddedcollapsedef` (gngraphbatch.jl:109-111): hcat of `unpaddedcollapsedef`."""
+    out, _ = _collapse(t)
+    return _flat(out)
 
 
 def _fn_input(kind, graphs, ef, nf, gf):

@@ -16,6 +16,7 @@ int32_t launch_layernorm2(const float* x, size_t rows, int d, const gnx_layernor
 int32_t launch_ffn_residual(const float* z, const float* x, size_t rows, int d, const gnx_ffn& ff, float* out, hipStream_t s);
 int32_t launch_pad(const gnx_graphs* h, int kind, bool pad, const float* src, int d, int64_t R, float* dst, hipStream_t s);
 int32_t launch_calibration(int n, hipStream_t s);
+int32_t launch_collapse(const gnx_graphs* h, const float* ef, int d, int64_t R, float* out, hipStream_t s);
 int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, const float* nf, int dn, const float* gf, int dg,
                         int64_t R, float* out, hipStream_t s);
 // returns 1 when the path does not apply to these dims (caller falls through to the next path)
@@ -108,6 +109,8 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
 }
 
 }  // namespace gnx
+
+extern "C" int32_t gnx_ensure_collapse(const gnx_graphs* h);
 
 using namespace gnx;
 
@@ -223,6 +226,14 @@ static int32_t pad_impl(const gnx_graphs* h, int32_t kind, bool pad, const float
 
 int32_t gnx_pad_features(const gnx_graphs* h, int32_t kind, const float* packed, int32_t d, int64_t R, float* padded, void* stream) {
   return pad_impl(h, kind, true, packed, d, R, padded, stream);
+}
+
+int32_t gnx_collapse_edges(const gnx_graphs* h, const float* ef, int32_t d, int64_t R, float* out, void* stream) {
+  if (!h || !ef || !out) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  if (d <= 0 || R <= 0 || (R > 1 && h->G != 1) || R > 65535) return fail(GNX_ERR_INVALID_ARG, "bad d / n_replicas");
+  int32_t rc = gnx_ensure_collapse(h);
+  if (rc) return rc;
+  return launch_collapse(h, ef, d, R, out, (hipStream_t)stream);
 }
 
 int32_t gnx_fn_input(const gnx_graphs* h, int32_t kind, const float* ef, int32_t de, const float* nf, int32_t dn, const float* gf,

@@ -376,6 +376,29 @@ int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, 
   return GNX_OK;
 }
 
+// out[r][c][k] = (ef[r][edge[c]][k] + ef[r][rev[c]][k]) / 2   (collapsef, gngraphbatch.jl:83-85, on real edges only)
+__global__ void k_collapse(const int* __restrict__ edge, const int* __restrict__ rev, int n, int d, int E, const float* __restrict__ ef,
+                           float* __restrict__ out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t r = blockIdx.y;
+  if (idx >= (size_t)n * d) return;
+  const int c = (int)(idx / d), k = (int)(idx % d);
+  const float* base = ef + r * (size_t)E * d;
+  const int rv = rev[c];
+  const float a = base[(size_t)edge[c] * d + k];
+  const float b = rv >= 0 ? base[(size_t)rv * d + k] : 0.f;
+  out[r * (size_t)n * d + idx] = (a + b) / 2.f;
+}
+
+int32_t launch_collapse(const gnx_graphs* h, const float* ef, int d, int64_t R, float* out, hipStream_t s) {
+  const size_t n = (size_t)h->h_collapse_off.back();
+  if (n == 0) return GNX_OK;
+  hipLaunchKernelGGL(k_collapse, dim3((unsigned)((n * d + 255) / 256), (unsigned)R), dim3(256), 0, s, h->d_collapse_edge, h->d_collapse_rev,
+                     (int)n, d, (int)h->E, ef, out);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
 __global__ void k_null() {}
 
 // n empty launches through the same event bracket as the real kernels: what a bracket costs by itself (bench.py

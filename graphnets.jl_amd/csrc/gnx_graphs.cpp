@@ -272,7 +272,51 @@ int32_t gnx_graphs_destroy(gnx_graphs* h) {
   (void)hipFree(h->d_ntile_off);
   (void)hipFree(h->d_wtiles);
   (void)hipFree(h->d_pad_edge_slot);
+  (void)hipFree(h->d_collapse_edge);
+  (void)hipFree(h->d_collapse_rev);
   delete h;
+  return GNX_OK;
+}
+
+// lower-triangle edge list + reverse-edge lookup (gngraphbatch.jl:56-81 as index tables instead of a PN^2 x PN(PN+1)/2 matrix)
+static int32_t build_collapse(const gnx_graphs* h) {
+  std::vector<int32_t> edge, rev;
+  h->h_collapse_off.assign(h->G + 1, 0);
+  for (int64_t g = 0; g < h->G; ++g) {
+    for (int64_t j = h->h_node_off[g]; j < h->h_node_off[g + 1]; ++j) {   // destination (column), edge order
+      for (int64_t e = h->h_colptr[j]; e < h->h_colptr[j + 1]; ++e) {
+        const int64_t i = h->h_rowval[e];                                  // source (row), global id
+        if (i < j) continue;                                               // keep the lower triangle i >= j
+        int64_t r = -1;                                                    // reverse edge j -> i: row j in column i
+        const int64_t* b = h->h_rowval.data() + h->h_colptr[i];
+        const int64_t* en = h->h_rowval.data() + h->h_colptr[i + 1];
+        const int64_t* it = std::lower_bound(b, en, j);
+        if (it != en && *it == j) r = it - h->h_rowval.data();
+        edge.push_back((int32_t)e);
+        rev.push_back((int32_t)r);
+      }
+    }
+    h->h_collapse_off[g + 1] = (int64_t)edge.size();
+  }
+  GNX_HIP(hipMalloc((void**)&h->d_collapse_edge, std::max<size_t>(edge.size(), 1) * sizeof(int32_t)));
+  GNX_HIP(hipMalloc((void**)&h->d_collapse_rev, std::max<size_t>(edge.size(), 1) * sizeof(int32_t)));
+  if (!edge.empty()) {
+    GNX_HIP(hipMemcpy(h->d_collapse_edge, edge.data(), edge.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    GNX_HIP(hipMemcpy(h->d_collapse_rev, rev.data(), rev.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  return GNX_OK;
+}
+
+int32_t gnx_ensure_collapse(const gnx_graphs* h) {
+  std::call_once(h->collapse_once, [&] { h->collapse_rc = build_collapse(h); });
+  return h->collapse_rc;
+}
+
+int32_t gnx_collapse_offsets(const gnx_graphs* h, int64_t* off) {
+  if (!h || !off) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  int32_t rc = gnx_ensure_collapse(h);
+  if (rc) return rc;
+  memcpy(off, h->h_collapse_off.data(), h->h_collapse_off.size() * sizeof(int64_t));
   return GNX_OK;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -56,6 +57,12 @@ struct gnx_graphs {
   int32_t wtile_e_cap = 0;
   int32_t* d_pad_edge_slot = nullptr;  // [E] slot of edge e inside its graph's PN^2 grid (column-major, padded)
   int32_t tile_e_cap = 0, tile_n_cap = 0;
+  // edge collapsing tables (built on first use; the handle stays logically immutable)
+  mutable std::once_flag collapse_once;
+  mutable std::vector<int64_t> h_collapse_off;  // [G+1]
+  mutable int32_t* d_collapse_edge = nullptr;   // [n_collapsed] edge id of i->j (i >= j)
+  mutable int32_t* d_collapse_rev = nullptr;    // [n_collapsed] edge id of j->i, or -1
+  mutable int32_t collapse_rc = 0;
   int64_t n_tiles() const { return (int64_t)h_tiles.size(); }
   int64_t n_wtiles() const { return (int64_t)h_wtiles.size(); }
 };

@@ -182,6 +182,16 @@ GNX_API int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, 
 GNX_API int32_t gnx_fn_input(const gnx_graphs* h, int32_t kind, const float* ef, int32_t de, const float* nf, int32_t dn,
                      const float* gf, int32_t dg, int64_t n_replicas, float* out, void* stream);
 
+/* ---- edge collapsing: unpaddedcollapsedef / flatunpaddedcollapsedef (src/gngraphbatch.jl:56-111, exported at
+ * src/GraphNets.jl:50; reference tests test/runtests.jl:4-59).  For every real edge i->j with i >= j (the lower
+ * triangle of the adjacency matrix, in edge order) the symmetric average (ef[i->j] + ef[j->i]) / 2; a self loop gives
+ * ef[i->i].  If the reverse edge does not exist it contributes 0 (the reference reads the padded slot there, which is
+ * 0 for batched inputs and junk for block outputs).
+ * gnx_collapse_offsets: off[G+1] = per-graph offsets into the collapsed rows (off[G] = total).
+ * gnx_collapse_edges:   out [R][total][d] from ef [R][E][d]. */
+GNX_API int32_t gnx_collapse_offsets(const gnx_graphs* h, int64_t* off);
+GNX_API int32_t gnx_collapse_edges(const gnx_graphs* h, const float* ef, int32_t d, int64_t n_replicas, float* out, void* stream);
+
 /* ---- reference-layout bridges: padef/padnf and unpadef/unpadnf (src/pad.jl:12-64, src/unpad.jl:1-17) ----
  * kind 0 = edges: packed [R][E][d] <-> padded [B][PN^2][d];  kind 1 = nodes: packed [R][N][d] <-> padded [B][PN][d],
  * where B = R (one graph in the handle) or G (R must be 1).  Pads are written as zeros. */

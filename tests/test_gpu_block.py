@@ -311,3 +311,28 @@ def test_deferred_graph_update_on_second_stream(gn, dims):
     torch.cuda.synchronize(dev)
     for a, b in zip(o1, o2):
         assert torch.equal(a, b)
+
+
+def test_edge_collapsing(gn):
+    """test/runtests.jl:4-59: flatunpaddedcollapsedef on fully connected 2- and 3-node graphs after two stacked blocks;
+    the reference indexes the raw padded array (`ef[:, slot, graph]`, 1-based slots of the PN^2 grid) — here through
+    padded()."""
+    rng = np.random.default_rng(90)
+    enc, dec = gn.GNBlock((0, 2, 0), (2, 2, 2)), gn.GNBlock((2, 2, 2), (2, 2, 2))
+    A, B = np.ones((2, 2), dtype=int), np.ones((3, 3), dtype=int)
+    nf = [rng.random((2, 2), dtype=np.float32), rng.random((2, 3), dtype=np.float32)]
+    y = dec(enc(gn.batch(dict(graphs=[A, B], ef=None, nf=nf, gf=None))))
+    flat = gn.flatunpaddedcollapsedef(y).cpu().numpy()
+    ef = gn.padded(y).ef.cpu().numpy()  # (2, 9, 2), PN = 3
+    s = lambda slot, g: ef[:, slot - 1, g]  # 1-based slot as in the reference test
+    assert flat.shape == (2, 9)
+    expect = [s(1, 0), (s(2, 0) + s(4, 0)) / 2, s(5, 0),
+              s(1, 1), (s(2, 1) + s(4, 1)) / 2, (s(3, 1) + s(7, 1)) / 2, s(5, 1), (s(6, 1) + s(8, 1)) / 2, s(9, 1)]
+    for c, e in enumerate(expect):
+        np.testing.assert_allclose(flat[:, c], e, rtol=1e-6, atol=1e-6)
+    per_graph = gn.unpaddedcollapsedef(y)
+    assert [tuple(a.shape) for a in per_graph] == [(2, 3), (2, 6)]
+    # a graph with a one-way edge: the missing reverse contributes 0
+    adj = np.array([[1, 0], [1, 0]])  # edges 0->0, 1->0 ; lower triangle: (0,0) and (1,0); reverse of 1->0 is 0->1: absent
+    x = gn.batch(dict(graphs=adj, ef=np.array([[[1.0], [4.0]]], dtype=np.float32).reshape(1, 2, 1), nf=None, gf=None))
+    np.testing.assert_allclose(gn.flatunpaddedcollapsedef(x).cpu().numpy(), [[1.0, 2.0]])
