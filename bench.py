@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--workload", choices=["c2", "hetero"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--dense-baseline", action="store_true",
+                    help="also time the RESTATEMENT OF THE REFERENCE'S FORMULATION (padded one-hot batched matmuls, numpy/BLAS on the "
+                         "host; BASELINE.md B2) on README ex.1 and on a 64-graph batch with PN <= 64")
     ap.add_argument("--overlap", action="store_true",
                     help="two-phase steps: graph update of step i on a second stream (measured SLOWER inside a hipGraph: the "
                          "fork/join costs more than the 5 us it hides — 35.7 vs 27.7 us/step — so it is off by default)")
@@ -335,6 +338,22 @@ def main():
             if got is not None:
                 assert np.allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(ref).max()))), "HIP vs CPU port mismatch"
 
+    dense = None
+    if rank == 0 and args.dense_baseline:
+        from oracle import gn_oracle as O
+        rngd = np.random.default_rng(7)
+        pd_ = O.make_block_params(rngd, din, dout) if args.dims == "readme" else O.make_block_params(rngd, (10, 5, 0), (3, 4, 5))
+        dense = {}
+        for name, adjs in (("README ex.1 (3 nodes, 5 edges, batch 2)", [np.array([[1, 0, 1], [1, 1, 0], [0, 0, 1]])] * 2),
+                           ("64 graphs, 16..64 nodes, density 0.1", [(rngd.random((n, n)) < 0.1).astype(np.int64) for n in rngd.integers(16, 65, 64)])):
+            efs = [rngd.random((10, int(a_.sum())), dtype=np.float32) for a_ in adjs]
+            nfs = [rngd.random((5, a_.shape[0]), dtype=np.float32) for a_ in adjs]
+            t0 = time.perf_counter(); xb = O.batch_dense(adjs, efs, nfs, None); t_batch = time.perf_counter() - t0
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter(); O.block_forward_dense(pd_, xb); ts.append(time.perf_counter() - t0)
+            ne = int(sum(a_.sum() for a_ in adjs))
+            dense[name] = dict(edges=ne, batch_s=round(t_batch, 4), forward_s=round(min(ts), 4), edges_per_s=round(ne / min(ts), 1))
     if rank == 0:
         line = {
             "metric": "edges updated/sec, GNBlock fwd, 1M-edge batch", "value": round(value, 1), "unit": "edges/s",
@@ -344,6 +363,8 @@ def main():
                        "graphs_per_gpu": G, "parallelism": f"graph-sharded x{world}" if world > 1 else "single GPU", **extra},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if dense is not None:
+            line["cpu_dense_formulation_restatement"] = dense  # NOT the reference: its formulation restated in numpy (B2)
         print(json.dumps(line))
     if multi:
         dist.barrier()
