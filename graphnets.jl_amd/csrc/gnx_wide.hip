@@ -54,6 +54,10 @@ struct WideArgs {
   size_t out_rep_stride;
   float* colsum;     // [R][n_tiles][OUT] or nullptr
   size_t colsum_rep_stride;
+  // node-projection form of the edge update: out = act(acc + bias' + gadd_a[idx_a[m]] + gadd_b[idx_b[m]]), tables [R][rows][OUT]
+  const float* gadd_a;
+  const float* gadd_b;
+  size_t gadd_rep_stride;
   const float* add1;  // optional residual inputs with the layout of `out` (may alias `out`): v = act(..) + add1 + add2
   const float* add2;
   unsigned long long* stamps;  // diagnostic builds only (GNX_WIDE_STAMPS): [tile][8] shader-clock stamps of wave 0
@@ -82,8 +86,7 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
   float* sB = s_pool + BM * LDA;                    // [KC][BN]   (BM*LDA*4 is a multiple of 16)
   float* sC = s_pool;                               // reused after the K loop
   __shared__ int s_ia[BM], s_ib[BM];  // gather indices, or colptr range for the segment-sum mode
-  __shared__ float s_bias[BN];
-  __shared__ float s_cs[L::WM][BN];
+  __shared__ __attribute__((aligned(16))) float s_bias[BN];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / L::WN, wn = wv % L::WN;
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
     need_cp |= a.seg[s].mode == 3;
     need_idx |= a.seg[s].mode == 1 || a.seg[s].mode == 2;
   }
+  need_idx |= a.gadd_a != nullptr;
   if (tid < BM) {
     const int m = tid < rows ? tid : rows - 1;
     if (need_cp) {
@@ -252,30 +256,15 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
   st[2] = clock64();
 #endif
 
-  // ---- epilogue: bias' + activation in registers, then the tile goes through LDS (two 64-row passes) so that HBM sees
-  //      full-row 16-B vector stores (the direct C/D layout store is 64 dword stores per lane: store-issue bound) ----
+  // ---- epilogue: the tile goes through LDS (two 64-row passes) so that HBM sees full-row 16-B vector stores (the direct
+  //      C/D-layout store is 64 dword stores per lane); bias', the gathered node projections, the activation, the column
+  //      sums for the graph update and the residual adds are applied on the vectorised side ----
   float* out = a.out + r * a.out_rep_stride;
   const int hi = lane >> 5, l31 = lane & 31;
-  float cs[L::TN];
-#pragma unroll
-  for (int j = 0; j < L::TN; ++j) cs[j] = 0.f;
-#pragma unroll
-  for (int i = 0; i < L::TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < L::TN; ++j) {
-      const int col = (wn * L::TN + j) * 32 + l31;
-      const float b = s_bias[col];
-      const bool col_ok = n0 + col < a.OUT;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (wm * L::TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;  // C/D layout of 32x32 MFMA
-        const float v = (row < rows && col_ok) ? act_apply(acc[i][j][q] + b, a.act) : 0.f;
-        acc[i][j][q] = v;
-        cs[j] += v;  // column sums are taken BEFORE the residual adds (they feed the graph update of a block)
-      }
-    }
-  }
   constexpr int NC4 = (64 * BN / 4) / WT;  // float4 per thread and pass
+  constexpr int NG = WT / (BN / 4);        // row groups that share a column quad
+  const bool gadd = a.gadd_a != nullptr;
+  float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     lds_barrier();  // K-loop readers (pass 0) / previous pass readers are done with the pool
@@ -287,7 +276,8 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
         for (int j = 0; j < L::TN; ++j) {
           const int col = (wn * L::TN + j) * 32 + l31;
 #pragma unroll
-          for (int q = 0; q < 16; ++q) sC[(rbase - 64 * pass + (q & 3) + 8 * (q >> 2) + 4 * hi) * LDC + col] = acc[i][j][q];
+          for (int q = 0; q < 16; ++q)  // C/D layout of the 32x32 MFMA: row = (q&3) + 8*(q>>2) + 4*hi
+            sC[(rbase - 64 * pass + (q & 3) + 8 * (q >> 2) + 4 * hi) * LDC + col] = acc[i][j][q];
         }
       }
     }
@@ -299,17 +289,30 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
       const int row = 64 * pass + lr, n = n0 + 4 * c4;
       if (row < rows && n < a.OUT) {
         float4 v = *reinterpret_cast<const float4*>(sC + lr * LDC + 4 * c4);
+        const float4 b = *reinterpret_cast<const float4*>(s_bias + 4 * c4);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         const size_t o = (size_t)(row0 + row) * a.OUT + n;
         if (VEC4) {
+          if (gadd) {
+            const float4 p = *reinterpret_cast<const float4*>(a.gadd_a + r * a.gadd_rep_stride + (size_t)s_ia[row] * a.OUT + n);
+            const float4 d = *reinterpret_cast<const float4*>(a.gadd_b + r * a.gadd_rep_stride + (size_t)s_ib[row] * a.OUT + n);
+            v.x += p.x + d.x; v.y += p.y + d.y; v.z += p.z + d.z; v.w += p.w + d.w;
+          }
+          v.x = act_apply(v.x, a.act); v.y = act_apply(v.y, a.act); v.z = act_apply(v.z, a.act); v.w = act_apply(v.w, a.act);
+          cs4.x += v.x; cs4.y += v.y; cs4.z += v.z; cs4.w += v.w;  // column sums BEFORE the residual adds
           if (a.add1) { const float4 u = *reinterpret_cast<const float4*>(a.add1 + r * a.out_rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
           if (a.add2) { const float4 u = *reinterpret_cast<const float4*>(a.add2 + r * a.out_rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
           *reinterpret_cast<float4*>(out + o) = v;
         } else {
-          const float vv[4] = {v.x, v.y, v.z, v.w};
+          float vv[4] = {v.x, v.y, v.z, v.w};
+          float* cc = reinterpret_cast<float*>(&cs4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (n + e < a.OUT) {
               float y = vv[e];
+              if (gadd) y += a.gadd_a[r * a.gadd_rep_stride + (size_t)s_ia[row] * a.OUT + n + e] + a.gadd_b[r * a.gadd_rep_stride + (size_t)s_ib[row] * a.OUT + n + e];
+              y = act_apply(y, a.act);
+              cc[e] += y;
               if (a.add1) y += a.add1[r * a.out_rep_stride + o + e];
               if (a.add2) y += a.add2[r * a.out_rep_stride + o + e];
               out[o + e] = y;
@@ -319,19 +322,19 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
       }
     }
   }
-  if (a.colsum) {
-#pragma unroll
-    for (int j = 0; j < L::TN; ++j) {
-      const float other = __shfl_xor(cs[j], 32);
-      const float tot = hi == 0 ? cs[j] + other : other + cs[j];  // same association in both halves
-      if (hi == 0) s_cs[wm][(wn * L::TN + j) * 32 + l31] = tot;
+  if (a.colsum) {  // fixed-order reduction over the NG row groups that share a column quad
+    lds_barrier();
+    float* s_cs = sC;  // [NG][BN]
+    {
+      const int c4 = tid % (BN / 4), grp = tid / (BN / 4);
+      *reinterpret_cast<float4*>(s_cs + grp * BN + 4 * c4) = cs4;
     }
     lds_barrier();
     if (tid < BN && n0 + tid < a.OUT) {
-      float s = 0.f;
+      float sum = 0.f;
 #pragma unroll
-      for (int w = 0; w < L::WM; ++w) s += s_cs[w][tid];
-      a.colsum[r * a.colsum_rep_stride + (size_t)blockIdx.x * a.OUT + n0 + tid] = s;
+      for (int w = 0; w < NG; ++w) sum += s_cs[w * BN + tid];
+      a.colsum[r * a.colsum_rep_stride + (size_t)blockIdx.x * a.OUT + n0 + tid] = sum;
     }
   }
 #ifdef GNX_WIDE_STAMPS_BUILD
@@ -463,7 +466,8 @@ size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int6
   const size_t per_tile = sizeof(float) * (size_t)R * ((size_t)h->h_etiles.size() * p->oe + (size_t)h->h_ntiles.size() * p->on);
   const size_t stage2 = sizeof(float) * (size_t)R * h->G * wide_slices(h) * (size_t)(p->oe + p->on);
   const size_t bias_g = sizeof(float) * (size_t)R * h->G * (size_t)(p->oe + p->on);
-  return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + 512;
+  const size_t proj = sizeof(float) * 2 * (size_t)R * h->N * (size_t)p->oe;  // node projections Ps, Pd
+  return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + 512;
 }
 
 template <int BN>
@@ -474,7 +478,7 @@ static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64
   for (int i = 0; i < w.nseg; ++i) {
     const WSeg& g = w.seg[i];
     if (g.width > 0 && !g.base) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: segment base is NULL");
-    if ((g.mode == 1 && !w.idx_a) || (g.mode == 2 && !w.idx_b) || (g.mode == 3 && !w.cp))
+    if ((g.mode == 1 && !w.idx_a) || (g.mode == 2 && !w.idx_b) || (g.mode == 3 && !w.cp) || (w.gadd_a && (!w.gadd_b || !w.idx_a || !w.idx_b)))
       return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: index array required by a segment mode is NULL");
   }
   ProfScope ps(name, s);
@@ -531,26 +535,49 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   float* pn2 = pe2 + (size_t)R * h->G * S * a.oe;
   float* bias_e = reinterpret_cast<float*>(reinterpret_cast<char*>(stage2) + align_up(sizeof(float) * (size_t)R * h->G * S * (a.oe + a.on), 256));
   float* bias_n = bias_e + (size_t)R * h->G * a.oe;
-  int32_t rc;
+  float* proj_s = reinterpret_cast<float*>(reinterpret_cast<char*>(bias_e) + align_up(sizeof(float) * (size_t)R * h->G * (a.oe + a.on), 256));
+  float* proj_d = proj_s + (size_t)R * h->N * a.oe;
+  int32_t rc = GNX_OK;
   if ((phase & 1) && a.dg > 0) {  // fold gf into per-graph biases (one tiny launch per update function)
     ProfScope ps("k_fold_bias", s);
     if (a.oe > 0) hipLaunchKernelGGL(k_fold_bias, dim3((unsigned)a.G, (unsigned)R), dim3(128), 0, s, a.We, a.be, a.gf, a.dg, a.de + 2 * a.dn, a.oe, a.G, bias_e);
     if (a.on > 0) hipLaunchKernelGGL(k_fold_bias, dim3((unsigned)a.G, (unsigned)R), dim3(128), 0, s, a.Wn, a.bn, a.gf, a.dg, a.oe + a.dn, a.on, a.G, bias_n);
     GNX_HIP(hipGetLastError());
   }
+  // Node-projection form (edgefninput.jl:2-7 regrouped): W*[ef; nf_s; nf_d; gf] = We_e*ef + (We_s*nf)[src] + (We_d*nf + b')[dst].
+  // The 2*dn columns of nf are multiplied once per NODE (two small GEMMs) instead of once per EDGE; the edge GEMM keeps
+  // K = de and gathers two projected rows in its epilogue.  Same mathematics, different (still fixed) summation order.
+  static const bool no_project = getenv("GNX_NO_PROJECT") != nullptr;
+  const bool project = !no_project && a.oe > 0 && a.dn >= 16 && a.E >= 2 * (int64_t)a.N;
+  if ((phase & 1) && project) {
+    for (int which = 0; which < 2; ++which) {
+      WideArgs w{};
+      w.tiles = h->d_ntiles; w.row_kind = 1;
+      w.seg[0] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 0, 0};
+      w.nseg = 1;
+      w.W = a.We + (size_t)(a.de + which * a.dn) * a.oe;  // rows of the src / dst segment
+      w.bias = which == 1 ? a.be : nullptr;               // bias (+ gf fold) rides on the dst projection
+      w.bias_g = (which == 1 && a.dg > 0) ? bias_e : nullptr; w.n_graphs = a.G;
+      w.OUT = a.oe; w.act = GNX_ACT_IDENTITY;
+      w.out = which == 0 ? proj_s : proj_d; w.out_rep_stride = (size_t)a.N * a.oe;
+      const bool v4 = al16 && a.dn % 4 == 0 && a.oe % 4 == 0;
+      if ((rc = launch_gemm_any(w, v4, (unsigned)n_nt, R, s, "k_rows_gemm_proj"))) return rc;
+    }
+  }
   if ((phase & 1) && a.oe > 0) {
     WideArgs w{};
     w.tiles = h->d_etiles; w.row_kind = 0;
     int ns = 0;
     if (a.de) w.seg[ns++] = WSeg{a.ef, (size_t)a.E * a.de, a.de, 0, 0};
-    if (a.dn) {
+    if (a.dn && !project) {
       w.seg[ns++] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 1, a.de};
       w.seg[ns++] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 2, a.de + a.dn};
     }
     w.nseg = ns;
+    if (project) { w.gadd_a = proj_s; w.gadd_b = proj_d; w.gadd_rep_stride = (size_t)a.N * a.oe; }
     w.idx_a = a.rowval; w.idx_b = h->d_edge_dst; w.cp = a.colptr;
-    w.W = a.We; w.bias = a.be; w.OUT = a.oe; w.act = a.act_e;
-    w.bias_g = a.dg > 0 ? bias_e : nullptr; w.n_graphs = a.G;
+    w.W = a.We; w.bias = project ? nullptr : a.be; w.OUT = a.oe; w.act = a.act_e;
+    w.bias_g = (!project && a.dg > 0) ? bias_e : nullptr; w.n_graphs = a.G;
     w.out = a.ef_out; w.out_rep_stride = (size_t)a.E * a.oe;
     w.colsum = a.og > 0 ? pe : nullptr; w.colsum_rep_stride = n_et * (size_t)a.oe;
     const bool vec4 = al16 && a.de % 4 == 0 && a.dn % 4 == 0 && a.oe % 4 == 0;
