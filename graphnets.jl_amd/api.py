@@ -26,7 +26,7 @@ from ._lib import GnxError, check
 __all__ = ["GNGraphBatch", "NT", "batch", "unbatch", "efview", "nfview", "gfview", "flatunpaddednf", "flatunpaddedef",
            "Dense", "LayerNorm", "GNBlock", "GNCore", "GNCoreList", "GNFeedForward", "GNGraphNorm", "zerodim2nothing",
            "padded", "GnxError", "getedgefninput", "getnodefninput", "getgraphfninput",
-           "unpaddedcollapsedef", "flatunpaddedcollapsedef"]
+           "unpaddedcollapsedef", "flatunpaddedcollapsedef", "BlockPlan", "Graphed"]
 
 _KEYS = ("graphs", "ef", "nf", "gf")
 
@@ -706,3 +706,42 @@ class BlockPlan:
         ws = self.ws if ws is None else ws
         check(self.lib.gnx_block_graph_update(self.g._h, C.byref(self.p), _ptr(gf), self.R, _ptr(go), ws.data_ptr(), ws.numel(),
                                               self.flags, s))
+
+
+class Graphed:
+    """A model forward captured ONCE into a hipGraph and replayed: `g = Graphed(model, x); y = g(x2)`.
+
+    At README-sized widths a GNBlock is ~25 us of GPU work while an eager call costs more than that on the host, so a
+    multi-layer model (README ex.3: encoder -> GNCoreList -> decoder) is launch-bound; replaying one graph removes the
+    per-layer host work.  Every `gnx_*` forward is capture-safe (no allocation, no synchronisation).  `model` is any
+    callable on the batched tuple; the graph structure (the GNGraphBatch) and the feature shapes are fixed at capture,
+    feature VALUES are copied into the captured input buffers at each call; the returned tuple aliases the captured output
+    buffers (valid until the next call)."""
+
+    def __init__(self, model, x, warmup=2):
+        x = _as_nt(x)
+        self.g = x.graphs
+        dev = self.g.device
+        self._in = {k: None if getattr(x, k) is None else _packed(getattr(x, k)).clone() for k in ("ef", "nf", "gf")}
+        static = NT(self.g, *(_jl(self._in[k]) for k in ("ef", "nf", "gf")))
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up off the capture: loads code objects, sizes the workspace
+            for _ in range(max(warmup, 1)):
+                model(static)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._out = model(static)
+
+    def __call__(self, x):
+        x = _as_nt(x)
+        assert x.graphs is self.g, "a Graphed model is bound to the GNGraphBatch it was captured with"
+        for k in ("ef", "nf", "gf"):
+            a, buf = getattr(x, k), self._in[k]
+            assert (a is None) == (buf is None), f"{k}: presence differs from the captured call"
+            if a is not None:
+                buf.copy_(a.permute(2, 1, 0))
+        self.graph.replay()
+        return self._out

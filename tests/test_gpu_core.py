@@ -123,3 +123,35 @@ def test_config4_shape_encoder_2cores_decoder_wide(gn):
     for got, ref in zip((y.ef, y.nf, y.gf), r):
         got = U.from_jl(got)
         assert np.max(np.abs(got - ref)) <= 1e-3 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_graphed_model_replay_matches_eager(gn):
+    """README ex.3 model captured once into a hipGraph (gn.Graphed) and replayed on new feature values."""
+    import time
+    import torch
+    rng = np.random.default_rng(47)
+    in_dims, core_dims, out_dims = (10, 5, 0), (10, 5, 3), (3, 4, 5)
+    enc, dec = gn.GNBlock(in_dims, core_dims), gn.GNBlock(core_dims, out_dims)
+    cores = gn.GNCoreList([gn.GNCore(core_dims) for _ in range(2)])
+    model = lambda x: dec(cores(enc(x)))
+    colptr, rowval = U.er_csc(rng, 500, 4000)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [500])
+    mk = lambda: U.to_nt(gn, g, *U.packed_inputs(rng, 1, 4000, 500, 1, in_dims))
+    x1, x2 = mk(), mk()
+    graphed = gn.Graphed(model, x1)
+    for x in (x1, x2, x1):
+        y_eager = model(x)
+        y_graph = graphed(x)
+        for a, b in ((y_eager.ef, y_graph.ef), (y_eager.nf, y_graph.nf), (y_eager.gf, y_graph.gf)):
+            assert torch.equal(a, b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        model(x1)
+    torch.cuda.synchronize(); t_eager = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(50):
+        graphed.graph.replay()
+    torch.cuda.synchronize(); t_graph = time.perf_counter() - t0
+    print(f"README ex.3 model, 4k-edge graph: eager {t_eager / 50 * 1e6:.0f} us / forward, hipGraph replay {t_graph / 50 * 1e6:.0f} us")
+    assert t_graph < t_eager
