@@ -149,16 +149,26 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < rows && k < sg.width) {
         if (sg.mode == 3) {
-          for (int e = s_ia[row]; e < s_ib[row]; ++e) {
-            const float* p = base + (size_t)e * sg.width + k;
-            if (VEC4) {
-              const float4 u = *reinterpret_cast<const float4*>(p);
-              v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-            } else {
-              v.x += p[0];
-              if (k + 1 < sg.width) v.y += p[1];
-              if (k + 2 < sg.width) v.z += p[2];
-              if (k + 3 < sg.width) v.w += p[3];
+          // segment sum over the node's in-edges (CSC range), 4 rows in flight: unconditional clamped loads (a load
+          // inside the guarded loop body cannot be hoisted, which costs one memory round trip per edge)
+          const int e0 = s_ia[row], e1 = s_ib[row];
+          for (int e = e0; e < e1; e += 4) {
+            float4 u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float* p = base + (size_t)min(e + j, e1 - 1) * sg.width + k;
+              if (VEC4) {
+                u[j] = *reinterpret_cast<const float4*>(p);
+              } else {
+                u[j].x = p[0];
+                u[j].y = k + 1 < sg.width ? p[1] : 0.f;
+                u[j].z = k + 2 < sg.width ? p[2] : 0.f;
+                u[j].w = k + 3 < sg.width ? p[3] : 0.f;
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (e + j < e1) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
             }
           }
         } else {
