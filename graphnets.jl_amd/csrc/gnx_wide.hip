@@ -25,8 +25,6 @@ namespace gnx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;   // rows (edges or nodes) per workgroup tile
-constexpr int KC = 32;    // K chunk
-constexpr int LDA = KC + 1;
 constexpr int WT = 256;   // threads
 
 struct WSeg {
@@ -75,9 +73,13 @@ struct WaveLayout {
   static constexpr int TN = BN / (WN * 32);
 };
 
-template <int BN, bool VEC4>
+template <int BN, bool VEC4, int KC>
 __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
   using L = WaveLayout<BN>;
+  constexpr int LDA = KC + 1;               // A row stride: odd => conflict-free ds_read_b32 of the A fragment
+  constexpr int C4R = KC / 4;               // float4 per A row chunk
+  constexpr int RPP = WT / C4R;             // A rows loaded per pass of the workgroup
+  constexpr int NA4 = BM / RPP;             // float4 of the A chunk per thread
   constexpr int NB4 = (KC * BN / 4) / WT;  // float4 of the B chunk per thread
   constexpr int LDC = BN + 4;                       // epilogue staging: [64 rows][BN + 4]
   constexpr int POOL = (BM * LDA + KC * BN) > 64 * LDC ? (BM * LDA + KC * BN) : 64 * LDC;
@@ -135,17 +137,17 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  float4 ra[4];
+  float4 ra[NA4];
   float4 rb[NB4];
-  const int a_c4 = tid & 7, a_r = tid >> 3;
+  const int a_c4 = tid % C4R, a_r = tid / C4R;
 
   auto load_chunk = [&](int si, int kc) {
     const WSeg sg = a.seg[si];
     const float* base = sg.base + r * sg.rep_stride;
     const int k = kc + 4 * a_c4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = a_r + 32 * i;
+    for (int i = 0; i < NA4; ++i) {
+      const int row = a_r + RPP * i;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < rows && k < sg.width) {
         if (sg.mode == 3) {
@@ -208,8 +210,8 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float* d = sA + (a_r + 32 * i) * LDA + 4 * a_c4;
+    for (int i = 0; i < NA4; ++i) {
+      float* d = sA + (a_r + RPP * i) * LDA + 4 * a_c4;
       d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
     }
 #pragma unroll
@@ -493,14 +495,15 @@ static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64
   }
   ProfScope ps(name, s);
   const dim3 grid(n_tiles, (unsigned)((w.OUT + BN - 1) / BN), (unsigned)R);
-  if (vec4) hipLaunchKernelGGL((k_rows_gemm<BN, true>), grid, dim3(WT), 0, s, w);
-  else hipLaunchKernelGGL((k_rows_gemm<BN, false>), grid, dim3(WT), 0, s, w);
+  // K chunk 32: measured against 64 (fewer barriers but 2 instead of 3 waves/SIMD): 466 vs 616 us on the edge GEMM
+  if (vec4) hipLaunchKernelGGL((k_rows_gemm<BN, true, 32>), grid, dim3(WT), 0, s, w);
+  else hipLaunchKernelGGL((k_rows_gemm<BN, false, 32>), grid, dim3(WT), 0, s, w);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
 
 static int32_t launch_gemm_any(const WideArgs& w, bool vec4, unsigned n_tiles, int64_t R, hipStream_t s, const char* name) {
-  if (w.OUT > 64) return launch_gemm<128>(w, vec4, n_tiles, R, s, name);
+  if (w.OUT > 64) return launch_gemm<128>(w, vec4, n_tiles, R, s, name);  // 128-wide tiles beat 64-wide ones for OUT = 128
   if (w.OUT > 32) return launch_gemm<64>(w, vec4, n_tiles, R, s, name);
   return launch_gemm<32>(w, vec4, n_tiles, R, s, name);
 }
