@@ -1,0 +1,146 @@
+// Device-side GNGraphBatch construction: dense 0/1 adjacency matrices -> CSC on the GPU.
+// The reference builds its batch with single-threaded Julia loops over every PN^2 slot (src/gngraphbatch.jl:33-54,
+// src/pad.jl:26-64); the host path of gnx_graphs_create_dense does the same O(sum N_g^2) scan in C++.  For large dense
+// batches (BASELINE config 5: 4096 graphs, ~85M adjacency entries) the scan/compaction runs here instead:
+//   k_adj_count : one wavefront per (graph, destination column): lanes stride over the rows, ballot + popcount
+//   scan        : two-level exclusive prefix sum of the per-column counts -> colptr
+//   k_adj_fill  : same traversal, ballot-prefix compaction of the source ids into rowval (edge order = CSC order)
+#include <algorithm>
+
+#include "gnx_internal.h"
+
+namespace gnx {
+
+struct AdjMeta {
+  const int64_t* adj_off;   // [G] element offset of graph g's matrix in the packed buffer
+  const int32_t* n;         // [G]
+  const int32_t* node_off;  // [G+1]
+  int G;
+  int elem_kind, row_major;
+};
+
+__device__ __forceinline__ int adj_elem(const void* base, int kind, int64_t idx, int* bad) {
+  double v;
+  switch (kind) {
+    case GNX_ELEM_U8: v = reinterpret_cast<const uint8_t*>(base)[idx]; break;
+    case GNX_ELEM_I32: v = reinterpret_cast<const int32_t*>(base)[idx]; break;
+    case GNX_ELEM_I64: v = (double)reinterpret_cast<const int64_t*>(base)[idx]; break;
+    case GNX_ELEM_F32: v = reinterpret_cast<const float*>(base)[idx]; break;
+    default: v = reinterpret_cast<const double*>(base)[idx]; break;
+  }
+  if (v == 0.0) return 0;
+  if (v == 1.0) return 1;
+  *bad = 1;
+  return 0;
+}
+
+// FILL = false: counts[c] = #ones of column c;  FILL = true: rowval[colptr[c] + k] = global source id of the k-th one
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_adj_columns(const void* adj, AdjMeta m, int N, int* counts_or_colptr, int* rowval, int* bad_flag) {
+  const int lane = threadIdx.x & 63;
+  const int c = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);  // global column = destination node
+  if (c >= N) return;
+  int lo = 0, hi = m.G;  // graph of column c
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (m.node_off[mid] <= c) lo = mid; else hi = mid; }
+  const int g = lo, n = m.n[g], j = c - m.node_off[g];
+  const int64_t base = m.adj_off[g];
+  int bad = 0, total = 0;
+  const int out0 = FILL ? counts_or_colptr[c] : 0;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    int one = 0;
+    if (i < n) one = adj_elem(adj, m.elem_kind, base + (m.row_major ? (int64_t)i * n + j : (int64_t)j * n + i), &bad);
+    const unsigned long long mask = __ballot(one);
+    if (FILL && one) rowval[out0 + total + __popcll(mask & ((1ull << lane) - 1ull))] = m.node_off[g] + i;
+    total += __popcll(mask);
+  }
+  if (!FILL) {
+    if (lane == 0) counts_or_colptr[c] = total;
+    if (bad) atomicOr(bad_flag, 1);
+  }
+}
+
+// exclusive scan, two levels: 2048 elements per block
+constexpr int SCAN_B = 2048;
+__global__ __launch_bounds__(256) void k_scan_blocks(const int* in, int n, int* out, int* block_sums) {
+  __shared__ int s[256];
+  const int b0 = blockIdx.x * SCAN_B, t = threadIdx.x;
+  int v[8], sum = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { const int i = b0 + t * 8 + u; v[u] = i < n ? in[i] : 0; sum += v[u]; }
+  s[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int x = t >= off ? s[t - off] : 0;
+    __syncthreads();
+    s[t] += x;
+    __syncthreads();
+  }
+  int run = s[t] - sum;  // exclusive prefix of this thread inside the block
+#pragma unroll
+  for (int u = 0; u < 8; ++u) { const int i = b0 + t * 8 + u; if (i < n) out[i] = run; run += v[u]; }
+  if (t == 255 && block_sums) block_sums[blockIdx.x] = s[255];
+}
+__global__ void k_scan_add(int* out, int n, const int* block_prefix) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] += block_prefix[i / SCAN_B];
+}
+
+// Returns 1 when the device path does not apply (caller falls back to the host scan).
+int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int64_t G, int32_t elem_kind, int32_t row_major,
+                            std::vector<int64_t>& h_colptr, std::vector<int64_t>& h_rowval, const std::vector<int64_t>& h_node_off) {
+  const int64_t N = h_node_off.back();
+  if (N <= 0 || N + 1 > (int64_t)SCAN_B * SCAN_B) return 1;  // two-level scan capacity
+  static const size_t esz_tab[5] = {1, 4, 8, 4, 8};
+  const size_t esz = esz_tab[elem_kind];
+  std::vector<int64_t> adj_off(G);
+  std::vector<int32_t> n32(G), node_off32(G + 1);
+  int64_t total = 0;
+  for (int64_t g = 0; g < G; ++g) { adj_off[g] = total; total += n_nodes[g] * n_nodes[g]; n32[g] = (int32_t)n_nodes[g]; node_off32[g] = (int32_t)h_node_off[g]; }
+  node_off32[G] = (int32_t)N;
+  void* d_adj = nullptr; int64_t* d_off = nullptr; int32_t *d_n = nullptr, *d_noff = nullptr, *d_cnt = nullptr, *d_cp = nullptr, *d_bs = nullptr, *d_bp = nullptr, *d_rv = nullptr, *d_bad = nullptr;
+  auto cleanup = [&]() { for (void* p : {d_adj, (void*)d_off, (void*)d_n, (void*)d_noff, (void*)d_cnt, (void*)d_cp, (void*)d_bs, (void*)d_bp, (void*)d_rv, (void*)d_bad}) (void)hipFree(p); };
+#define GNX_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return hip_fail(_e, #expr); } } while (0)
+  GNX_TRY(hipMalloc(&d_adj, (size_t)total * esz));
+  for (int64_t g = 0; g < G; ++g)
+    GNX_TRY(hipMemcpy(static_cast<char*>(d_adj) + (size_t)adj_off[g] * esz, adj[g], (size_t)(n_nodes[g] * n_nodes[g]) * esz, hipMemcpyHostToDevice));
+  GNX_TRY(hipMalloc((void**)&d_off, G * sizeof(int64_t)));
+  GNX_TRY(hipMalloc((void**)&d_n, G * sizeof(int32_t)));
+  GNX_TRY(hipMalloc((void**)&d_noff, (G + 1) * sizeof(int32_t)));
+  GNX_TRY(hipMemcpy(d_off, adj_off.data(), G * sizeof(int64_t), hipMemcpyHostToDevice));
+  GNX_TRY(hipMemcpy(d_n, n32.data(), G * sizeof(int32_t), hipMemcpyHostToDevice));
+  GNX_TRY(hipMemcpy(d_noff, node_off32.data(), (G + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  const int nb = (int)((N + 1 + SCAN_B - 1) / SCAN_B);
+  GNX_TRY(hipMalloc((void**)&d_cnt, (N + 1) * sizeof(int32_t)));
+  GNX_TRY(hipMalloc((void**)&d_cp, (N + 1) * sizeof(int32_t)));
+  GNX_TRY(hipMalloc((void**)&d_bs, SCAN_B * sizeof(int32_t)));
+  GNX_TRY(hipMalloc((void**)&d_bp, SCAN_B * sizeof(int32_t)));
+  GNX_TRY(hipMalloc((void**)&d_bad, sizeof(int32_t)));
+  GNX_TRY(hipMemset(d_cnt, 0, (N + 1) * sizeof(int32_t)));
+  GNX_TRY(hipMemset(d_bs, 0, SCAN_B * sizeof(int32_t)));
+  GNX_TRY(hipMemset(d_bad, 0, sizeof(int32_t)));
+  AdjMeta m{d_off, d_n, d_noff, (int)G, elem_kind, row_major};
+  const unsigned grid = (unsigned)((N * 64 + 255) / 256);
+  hipLaunchKernelGGL(k_adj_columns<false>, dim3(grid), dim3(256), 0, 0, d_adj, m, (int)N, d_cnt, (int*)nullptr, d_bad);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, 0, d_cnt, (int)(N + 1), d_cp, d_bs);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, 0, d_bs, SCAN_B, d_bp, (int*)nullptr);
+  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, 0, d_cp, (int)(N + 1), d_bp);
+  GNX_TRY(hipGetLastError());
+  int32_t bad = 0, E = 0;
+  GNX_TRY(hipMemcpy(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (bad) { cleanup(); return fail(GNX_ERR_ADJ_VALUE, "adjacency entries must be exactly 0 or 1 (pad.jl:30, gngraphbatch.jl:207)"); }
+  GNX_TRY(hipMemcpy(&E, d_cp + N, sizeof(int32_t), hipMemcpyDeviceToHost));
+  GNX_TRY(hipMalloc((void**)&d_rv, std::max<size_t>((size_t)E, 1) * sizeof(int32_t)));
+  hipLaunchKernelGGL(k_adj_columns<true>, dim3(grid), dim3(256), 0, 0, d_adj, m, (int)N, d_cp, d_rv, d_bad);
+  GNX_TRY(hipGetLastError());
+  std::vector<int32_t> cp32(N + 1), rv32((size_t)E);
+  GNX_TRY(hipMemcpy(cp32.data(), d_cp, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (E) GNX_TRY(hipMemcpy(rv32.data(), d_rv, (size_t)E * sizeof(int32_t), hipMemcpyDeviceToHost));
+  cleanup();
+#undef GNX_TRY
+  h_colptr.assign(cp32.begin(), cp32.end());
+  h_rowval.assign(rv32.begin(), rv32.end());
+  return GNX_OK;
+}
+
+}  // namespace gnx

@@ -161,6 +161,11 @@ static int32_t finalize(gnx_graphs* h) {
 
 }  // namespace gnx
 
+namespace gnx {
+int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int64_t G, int32_t elem_kind, int32_t row_major,
+                            std::vector<int64_t>& h_colptr, std::vector<int64_t>& h_rowval, const std::vector<int64_t>& h_node_off);
+}
+
 using namespace gnx;
 
 extern "C" {
@@ -178,8 +183,7 @@ int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n_nodes, 
   gnx_graphs* h = new gnx_graphs();
   h->G = n_graphs;
   h->h_node_off.push_back(0);
-  h->h_edge_off.push_back(0);
-  h->h_colptr.push_back(0);
+  int64_t total_entries = 0;
   for (int64_t g = 0; g < n_graphs; ++g) {
     const int64_t n = n_nodes[g];
     if (n <= 0 || !adj[g]) {
@@ -187,21 +191,40 @@ int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n_nodes, 
       return fail(GNX_ERR_ADJ_SHAPE, "adjacency matrix must be N x N with N >= 1 (checks.jl:11)");
     }
     h->PN = std::max(h->PN, n);
-    const int64_t base = h->h_node_off.back();
-    bool ok = true;
-    for (int64_t j = 0; j < n; ++j) {      // destination (column) — slowest
-      for (int64_t i = 0; i < n; ++i) {    // source (row)
-        const int64_t idx = row_major ? i * n + j : j * n + i;
-        if (adj_at(adj[g], elem_kind, idx, &ok)) h->h_rowval.push_back(base + i);
+    h->h_node_off.push_back(h->h_node_off.back() + n);
+    total_entries += n * n;
+  }
+  // large dense batches: scan + compaction on the GPU (gnx_build_device.hip); small ones on the host (no launch cost)
+  static const int64_t dev_threshold = getenv("GNX_BUILD_DEVICE_MIN") ? atoll(getenv("GNX_BUILD_DEVICE_MIN")) : (1 << 22);
+  bool built = false;
+  if (total_entries >= dev_threshold) {
+    const int32_t rc = build_csc_on_device(adj, n_nodes, n_graphs, elem_kind, row_major, h->h_colptr, h->h_rowval, h->h_node_off);
+    if (rc != 1 && rc != GNX_OK) { delete h; return rc; }
+    built = rc == GNX_OK;
+  }
+  if (built) {
+    for (int64_t g = 0; g <= n_graphs; ++g) h->h_edge_off.push_back(h->h_colptr[(size_t)h->h_node_off[g]]);
+  } else {
+    h->h_edge_off.push_back(0);
+    h->h_colptr.assign(1, 0);
+    h->h_rowval.clear();
+    for (int64_t g = 0; g < n_graphs; ++g) {
+      const int64_t n = n_nodes[g];
+      const int64_t base = h->h_node_off[g];
+      bool ok = true;
+      for (int64_t j = 0; j < n; ++j) {      // destination (column) — slowest
+        for (int64_t i = 0; i < n; ++i) {    // source (row)
+          const int64_t idx = row_major ? i * n + j : j * n + i;
+          if (adj_at(adj[g], elem_kind, idx, &ok)) h->h_rowval.push_back(base + i);
+        }
+        h->h_colptr.push_back((int64_t)h->h_rowval.size());
       }
-      h->h_colptr.push_back((int64_t)h->h_rowval.size());
+      if (!ok) {
+        delete h;
+        return fail(GNX_ERR_ADJ_VALUE, "adjacency entries must be exactly 0 or 1 (pad.jl:30, gngraphbatch.jl:207)");
+      }
+      h->h_edge_off.push_back((int64_t)h->h_rowval.size());
     }
-    if (!ok) {
-      delete h;
-      return fail(GNX_ERR_ADJ_VALUE, "adjacency entries must be exactly 0 or 1 (pad.jl:30, gngraphbatch.jl:207)");
-    }
-    h->h_node_off.push_back(base + n);
-    h->h_edge_off.push_back((int64_t)h->h_rowval.size());
   }
   h->N = h->h_node_off.back();
   h->E = h->h_edge_off.back();
@@ -271,7 +294,6 @@ int32_t gnx_graphs_destroy(gnx_graphs* h) {
   (void)hipFree(h->d_etile_off);
   (void)hipFree(h->d_ntile_off);
   (void)hipFree(h->d_wtiles);
-  (void)hipFree(h->d_pad_edge_slot);
   (void)hipFree(h->d_collapse_edge);
   (void)hipFree(h->d_collapse_rev);
   delete h;

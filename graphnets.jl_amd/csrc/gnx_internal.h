@@ -18,9 +18,9 @@ struct Tile {
   int32_t n0, n1;
   int32_t e0, e1;
   int32_t g;        // graph id
-  int32_t win0;     // [win0, win1): node window containing every source of the tile's edges = the graph's
-  int32_t win1;     // node range (sources never leave the graph)
-  int32_t flags;
+  int32_t win0;     // [win0, win1): the graph's node range — every source of the tile's edges lies inside it
+  int32_t win1;
+  int32_t flags;    // reserved (keeps the record 32 B = one s_load_dwordx8)
 };
 
 }  // namespace gnx
@@ -55,7 +55,6 @@ struct gnx_graphs {
   int32_t* d_ntile_off = nullptr;
   gnx::Tile* d_wtiles = nullptr;  // [n_wtiles]
   int32_t wtile_e_cap = 0;
-  int32_t* d_pad_edge_slot = nullptr;  // [E] slot of edge e inside its graph's PN^2 grid (column-major, padded)
   int32_t tile_e_cap = 0, tile_n_cap = 0;
   // edge collapsing tables (built on first use; the handle stays logically immutable)
   mutable std::once_flag collapse_once;

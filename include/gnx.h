@@ -50,7 +50,8 @@ extern "C" {
 #define GNX_ERR_CSC (-7)           /* malformed CSC: colptr not monotone, rowval out of range / unsorted    */
 #define GNX_ERR_WORKSPACE (-8)     /* workspace NULL or smaller than gnx_*_workspace_bytes()                */
 #define GNX_ERR_TOO_LARGE (-9)     /* N or E does not fit the int32 device indices                          */
-#define GNX_ERR_COUNT_MISMATCH (-10) /* checks.jl:41-46 size(ef,2)==num_edges, size(nf,2)==num_nodes        */
+#define GNX_ERR_COUNT_MISMATCH (-10) /* checks.jl:41-46 size(ef,2)==num_edges, size(nf,2)==num_nodes — raised by the host
+                                      * shims (the ABI sees pointers only); reserved here so the codes stay in one place  */
 
 /* activations (Flux/NNlib): identity is the GNBlock default (gnblock.jl:55-60); relu is used by FeedForward */
 #define GNX_ACT_IDENTITY 0

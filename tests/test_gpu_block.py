@@ -336,3 +336,41 @@ def test_edge_collapsing(gn):
     adj = np.array([[1, 0], [1, 0]])  # edges 0->0, 1->0 ; lower triangle: (0,0) and (1,0); reverse of 1->0 is 0->1: absent
     x = gn.batch(dict(graphs=adj, ef=np.array([[[1.0], [4.0]]], dtype=np.float32).reshape(1, 2, 1), nf=None, gf=None))
     np.testing.assert_allclose(gn.flatunpaddedcollapsedef(x).cpu().numpy(), [[1.0, 2.0]])
+
+
+def test_device_side_batch_construction(gn):
+    """large dense batches are scanned/compacted into CSC on the GPU (gnx_build_device.hip).  The result must
+    equal the oracle's column-major edge order (pad.jl:30) for row-major (numpy) and column-major (Julia) input alike,
+    and non-0/1 entries must still be rejected (pad.jl:30, gngraphbatch.jl:207)."""
+    import ctypes as C
+    rng = np.random.default_rng(95)
+    sizes = rng.integers(32, 257, 200)
+    adjs = [(rng.random((n, n)) < 0.07).astype(np.float32) for n in sizes]
+    assert sum(a.size for a in adjs) >= (1 << 22)  # above the device-path threshold
+    g = gn.GNGraphBatch(adjs)
+    colptr, rowval, node_off, edge_off = O.csc_from_adj(adjs)
+    gc, gr = g.csc()
+    assert np.array_equal(gc, colptr) and np.array_equal(gr, rowval)
+    assert np.array_equal(g.node_off, node_off) and np.array_equal(g.edge_off, edge_off)
+    # column-major input (what Julia hands over): pass the transposes with row_major = 0
+    lib = gn._lib.load()
+    tr = [np.ascontiguousarray(a.T) for a in adjs]
+    ptrs = (C.c_void_p * len(tr))(*[a.ctypes.data for a in tr])
+    nn = np.asarray([a.shape[0] for a in tr], dtype=np.int64)
+    h = C.c_void_p(None)
+    gn._lib.check(lib.gnx_graphs_create_dense(ptrs, nn.ctypes.data_as(C.POINTER(C.c_int64)), len(tr), gn._lib.ELEM_F32, 0, C.byref(h)))
+    cp2 = np.zeros(len(colptr), dtype=np.int64); rv2 = np.zeros(len(rowval), dtype=np.int64)
+    gn._lib.check(lib.gnx_graphs_get_csc(h, cp2.ctypes.data_as(C.POINTER(C.c_int64)), rv2.ctypes.data_as(C.POINTER(C.c_int64))))
+    lib.gnx_graphs_destroy(h)
+    assert np.array_equal(cp2, colptr) and np.array_equal(rv2, rowval)
+    adjs[57][3, 4] = 2.0
+    with pytest.raises(gn.GnxError) as e:
+        gn.GNGraphBatch(adjs)
+    assert e.value.code == -4
+    # and a forward on the device-built handle
+    adjs[57][3, 4] = 1.0
+    g = gn.GNGraphBatch(adjs)
+    csc = O.csc_from_adj(adjs)
+    p = O.make_block_params(rng, (10, 5, 0), (3, 4, 5))
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, (10, 5, 0))
+    _check_block(gn, p, g, csc, ef, nf, gf, 0)
