@@ -88,7 +88,7 @@ def bench_c4(args, gn, torch, dev):
     One "step" = the whole 4-layer model forward; reported as edges/s through the model."""
     colptrs, rowvals, nn = make_c2()
     g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
-    core = (128, 64, 32)
+    core = tuple(int(v) for v in args.core_dims.split(","))
     gen = torch.Generator(); gen.manual_seed(0)
     model = [gn.GNBlock((10, 5, 0), core, device=dev, generator=gen), gn.GNCore(core, device=dev, generator=gen),
              gn.GNCore(core, device=dev, generator=gen), gn.GNBlock(core, (3, 4, 5), device=dev, generator=gen)]
@@ -114,7 +114,7 @@ def bench_c4(args, gn, torch, dev):
         fwd()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / K
-    flops = 699.2e9  # whole-model algorithmic FLOPs at 1M edges
+    flops = 699.2e9 if core == (128, 64, 32) else float("nan")  # whole-model algorithmic FLOPs at 1M edges
     print(json.dumps({"metric": "edges/sec through Encoder->2xGNCore(128,64,32)->Decoder, 1M-edge graph (BASELINE configs[3])",
                       "value": round(g.n_edges / dt, 1), "unit": "edges/s", "ms_per_step": round(dt * 1e3, 4), "steps": K,
                       "algorithmic_tflops": round(flops / dt / 1e12, 2), "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFS,
@@ -137,6 +137,7 @@ def main():
                     help="two-phase steps: graph update of step i on a second stream (measured SLOWER inside a hipGraph: the "
                          "fork/join costs more than the 5 us it hides — 35.7 vs 27.7 us/step — so it is off by default)")
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path even with one rank (testing)")
+    ap.add_argument("--core-dims", type=str, default="128,64,32", help="core widths for --model c4 (README ex.3 uses 10,5,3)")
     ap.add_argument("--model", choices=["block", "c4"], default="block",
                     help="c4: BASELINE configs[3] — encoder -> 2 x GNCore(128,64,32) -> decoder on the C2 graph (extra; not the headline line)")
     args = ap.parse_args()

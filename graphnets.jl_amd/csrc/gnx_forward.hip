@@ -24,6 +24,11 @@ int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, 
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase);
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase);
 size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R);
+// narrow-width GNCore kernels (gnx_core_narrow.hip)
+bool core_narrow_width(int d);
+int32_t launch_ln1_rows(const float* x, size_t rows, int d, const gnx_layernorm& l1, float eps, int eps_mode, float* y, hipStream_t s);
+int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm& l2, const gnx_ffn& ff, float eps, int eps_mode,
+                         float* out, hipStream_t s);
 int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K, const gnx_dense& d, int OUT, const float* add1,
                           const float* add2, float* out, int64_t R, hipStream_t s, const char* name);
 
@@ -199,7 +204,11 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   for (int t = 0; t < 3; ++t) {
     l1[t] = reinterpret_cast<float*>(base + off[2 * t]);
     l2[t] = reinterpret_cast<float*>(base + off[2 * t + 1]);
-    if ((rc = launch_layernorm2(x[t], rows[t], d[t], p->ln1[t], p->ln2[t], p->eps, p->eps_mode, l1[t], l2[t], s))) return rc;
+    // narrow widths: only gn1(x) is materialised (the block needs it); gn2 is recomputed inside k_core_post
+    const bool narrow = core_narrow_width(d[t]) && !(flags & GNX_FLAG_FORCE_GENERIC);
+    if (narrow) rc = launch_ln1_rows(x[t], rows[t], d[t], p->ln1[t], p->eps, p->eps_mode, l1[t], s);
+    else rc = launch_layernorm2(x[t], rows[t], d[t], p->ln1[t], p->ln2[t], p->eps, p->eps_mode, l1[t], l2[t], s);
+    if (rc) return rc;
   }
   rc = block_forward_impl(h, &b, l1[0], l1[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s);
   if (rc) return rc;
@@ -209,6 +218,8 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       // out = block(LN1 x) + x + fc2(relu(fc1(LN2 x)))      (gncore.jl:56-68, gnfeedforward.jl:27-31)
       if ((rc = launch_dense_rows(h, t, l2[t], d[t], p->ff[t].fc1, 4 * d[t], nullptr, nullptr, hidden, R, s, "k_rows_gemm_ff1"))) return rc;
       if ((rc = launch_dense_rows(h, t, hidden, 4 * d[t], p->ff[t].fc2, d[t], out[t], x[t], out[t], R, s, "k_rows_gemm_ff2"))) return rc;
+    } else if (core_narrow_width(d[t]) && !(flags & GNX_FLAG_FORCE_GENERIC)) {
+      if ((rc = launch_core_post(x[t], rows[t], d[t], p->ln2[t], p->ff[t], p->eps, p->eps_mode, out[t], s))) return rc;
     } else if ((rc = launch_ffn_residual(l2[t], x[t], rows[t], d[t], p->ff[t], out[t], s))) {
       return rc;
     }
