@@ -26,7 +26,7 @@ from ._lib import GnxError, check
 __all__ = ["GNGraphBatch", "NT", "batch", "unbatch", "efview", "nfview", "gfview", "flatunpaddednf", "flatunpaddedef",
            "Dense", "LayerNorm", "GNBlock", "GNCore", "GNCoreList", "GNFeedForward", "GNGraphNorm", "zerodim2nothing",
            "padded", "GnxError", "getedgefninput", "getnodefninput", "getgraphfninput",
-           "unpaddedcollapsedef", "flatunpaddedcollapsedef", "BlockPlan", "Graphed"]
+           "unpaddedcollapsedef", "flatunpaddedcollapsedef", "BlockPlan", "Graphed", "logitcrossentropy"]
 
 _KEYS = ("graphs", "ef", "nf", "gf")
 
@@ -440,6 +440,22 @@ def flatunpaddedcollapsedef(t):
     """`flatunpaddedcollapsedef` (gngraphbatch.jl:109-111): hcat of `unpaddedcollapsedef`."""
     out, _ = _collapse(t)
     return _flat(out)
+
+
+def logitcrossentropy(yhat, y):
+    """`Flux.logitcrossentropy(ŷ, y)` on (d, cols) arrays such as `flatunpaddednf(ŷ)` (examples/sort/sort.jl:69-81):
+    mean over columns of -sum(y .* logsoftmax(ŷ; dims=1); dims=1).  Returns a 0-d device tensor."""
+    assert yhat.dim() == 2 and tuple(yhat.shape) == tuple(y.shape), "ŷ and y must be (d, cols) arrays of the same size"
+    lib = _lib.load()
+    a = yhat.t().contiguous().float()   # [cols][d] rows = the bytes of a column-major (d, cols) array
+    b = y.to(yhat.device).t().contiguous().float()
+    cols, d = a.shape
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    ws = torch.empty(max(int(lib.gnx_xent_workspace_bytes(cols)), 16), dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib.gnx_logit_cross_entropy(a.data_ptr(), b.data_ptr(), d, cols, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          torch.cuda.current_stream(a.device).cuda_stream))
+    return out
 
 
 def _fn_input(kind, graphs, ef, nf, gf):

@@ -4,6 +4,8 @@
 //
 // Reference semantics: src/edgefninput.jl:1-47, src/nodefninput.jl:1-24, src/graphfninput.jl:1-13,
 // src/gnblock.jl:63-69, src/gngraphnorm.jl:19-26, src/gnfeedforward.jl:27-40, src/gncore.jl:56-68.
+#include <algorithm>
+
 #include "gnx_device.h"
 
 namespace gnx {
@@ -395,6 +397,53 @@ int32_t launch_collapse(const gnx_graphs* h, const float* ef, int d, int64_t R, 
   if (n == 0) return GNX_OK;
   hipLaunchKernelGGL(k_collapse, dim3((unsigned)((n * d + 255) / 256), (unsigned)R), dim3(256), 0, s, h->d_collapse_edge, h->d_collapse_rev,
                      (int)n, d, (int)h->E, ef, out);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// readout: logitcrossentropy over packed columns (examples/sort/sort.jl:69-81)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_xent_partial(const float* __restrict__ logits, const float* __restrict__ targets, int d,
+                                                      size_t cols, float* __restrict__ partial) {
+  __shared__ float s_red[256];
+  float acc = 0.f;
+  for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < cols; c += (size_t)gridDim.x * 256) {
+    const float* x = logits + c * d;
+    const float* y = targets + c * d;
+    float mx = x[0];
+    for (int k = 1; k < d; ++k) mx = fmaxf(mx, x[k]);
+    float se = 0.f, dot = 0.f, ysum = 0.f;
+    for (int k = 0; k < d; ++k) { se += expf(x[k] - mx); dot = fmaf(y[k], x[k], dot); ysum += y[k]; }
+    acc += ysum * (mx + logf(se)) - dot;  // -sum_k y_k (x_k - logsumexp(x))
+  }
+  s_red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) s_red[threadIdx.x] += s_red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0];
+}
+__global__ __launch_bounds__(256) void k_xent_final(const float* __restrict__ partial, int n, size_t cols, float* __restrict__ out) {
+  __shared__ float s_red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+  s_red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) s_red[threadIdx.x] += s_red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = s_red[0] / (float)cols;
+}
+
+int xent_blocks(int64_t cols) { return (int)std::min<int64_t>(std::max<int64_t>((cols + 255) / 256, 1), 1024); }
+
+int32_t launch_xent(const float* logits, const float* targets, int d, int64_t cols, float* out, float* ws, hipStream_t s) {
+  const int nb = xent_blocks(cols);
+  hipLaunchKernelGGL(k_xent_partial, dim3(nb), dim3(256), 0, s, logits, targets, d, (size_t)cols, ws);
+  hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, s, ws, nb, (size_t)cols, out);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }

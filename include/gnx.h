@@ -193,6 +193,15 @@ GNX_API int32_t gnx_fn_input(const gnx_graphs* h, int32_t kind, const float* ef,
 GNX_API int32_t gnx_collapse_offsets(const gnx_graphs* h, int64_t* off);
 GNX_API int32_t gnx_collapse_edges(const gnx_graphs* h, const float* ef, int32_t d, int64_t n_replicas, float* out, void* stream);
 
+/* ---- readout loss on packed outputs: Flux.logitcrossentropy(yhat, y) over the columns of
+ * flatunpaddednf / flatunpaddedef, as used by the reference's only end-to-end workload (examples/sort/sort.jl:69-81):
+ *   loss = mean over columns c of  -sum_k y[k,c] * logsoftmax(yhat[:,c])[k]
+ * logits / targets: device [cols][d] rows (= Julia (d, cols) column-major); loss_out: ONE device float.
+ * workspace: gnx_xent_workspace_bytes(cols) bytes.  Deterministic two-stage reduction. */
+GNX_API size_t gnx_xent_workspace_bytes(int64_t cols);
+GNX_API int32_t gnx_logit_cross_entropy(const float* logits, const float* targets, int32_t d, int64_t cols, float* loss_out,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- reference-layout bridges: padef/padnf and unpadef/unpadnf (src/pad.jl:12-64, src/unpad.jl:1-17) ----
  * kind 0 = edges: packed [R][E][d] <-> padded [B][PN^2][d];  kind 1 = nodes: packed [R][N][d] <-> padded [B][PN][d],
  * where B = R (one graph in the handle) or G (R must be 1).  Pads are written as zeros. */

@@ -374,3 +374,21 @@ def test_device_side_batch_construction(gn):
     p = O.make_block_params(rng, (10, 5, 0), (3, 4, 5))
     ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, (10, 5, 0))
     _check_block(gn, p, g, csc, ef, nf, gf, 0)
+
+
+def test_readout_logitcrossentropy(gn):
+    """SURVEY 8f f2 / examples/sort/sort.jl:69-81: loss = logitcrossentropy(flatunpaddednf(ŷ), y_nf) + (same on ef)."""
+    import torch
+    rng = np.random.default_rng(96)
+    adjs = U.random_graphs(rng, (6, 9, 4), 0.5)
+    blk = gn.GNBlock((0, 3, 0), (4, 5, 0))
+    nf = [rng.random((3, a.shape[0]), dtype=np.float32) for a in adjs]
+    y = blk(gn.batch(dict(graphs=adjs, ef=None, nf=nf, gf=None)))
+    for flat in (gn.flatunpaddednf(y), gn.flatunpaddedef(y)):
+        d, cols = flat.shape
+        tgt = np.eye(d, dtype=np.float32)[rng.integers(0, d, cols)].T  # one-hot columns
+        got = float(gn.logitcrossentropy(flat, torch.from_numpy(tgt)))
+        x = flat.double().cpu().numpy()
+        lse = np.log(np.exp(x - x.max(0)).sum(0)) + x.max(0)
+        ref = float(np.mean(-(tgt * (x - lse)).sum(0)))
+        assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref))
