@@ -36,6 +36,14 @@ class BlockParams(C.Structure):
                [("edgefn", Dense), ("nodefn", Dense), ("graphfn", Dense)]
 
 
+class DenseGrad(C.Structure):
+    _fields_ = [("weight", _fp), ("bias", _fp)]
+
+
+class BlockGrads(C.Structure):
+    _fields_ = [("edgefn", DenseGrad), ("nodefn", DenseGrad), ("graphfn", DenseGrad)]
+
+
 class LayerNorm(C.Structure):
     _fields_ = [("gamma", _fp), ("beta", _fp)]
 
@@ -75,6 +83,9 @@ SIGNATURES = {
     "gnx_block_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BlockParams), C.c_int64]),
     "gnx_block_forward": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + _FWD[2:]),
     "gnx_block_graph_update": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams), _fp, C.c_int64, _fp, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
+    "gnx_block_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BlockParams), C.c_int64]),
+    "gnx_block_backward": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + [_fp] * 9 + [C.c_int64] + [_fp] * 3 +
+                           [C.POINTER(BlockGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnx_core_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(CoreParams), C.c_int64]),
     "gnx_core_forward": (C.c_int32, [C.c_void_p, C.POINTER(CoreParams)] + _FWD[2:]),
     "gnx_fn_input": (C.c_int32, [C.c_void_p, C.c_int32, _fp, C.c_int32, _fp, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),

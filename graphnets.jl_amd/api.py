@@ -594,8 +594,17 @@ class GNBlock:
         p.edgefn, p.nodefn, p.graphfn = self.edgefn._c(keep), self.nodefn._c(keep), self.graphfn._c(keep)
         return p
 
+    def _trainable(self, tensors):
+        ps = [self.edgefn.weight, self.edgefn.bias, self.nodefn.weight, self.nodefn.bias, self.graphfn.weight, self.graphfn.bias]
+        return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in list(tensors) + ps)
+
     def __call__(self, x, flags=None):
         g, ef, nf, gf, R = _forward_common(x, self.in_dims)
+        if self._trainable((ef, nf, gf)):  # differentiable call: gnx_block_backward is the pullback
+            outs = iter(_BlockFn.apply(self, g, R, ef, nf, gf, self.edgefn.weight, self.edgefn.bias, self.nodefn.weight, self.nodefn.bias,
+                                       self.graphfn.weight, self.graphfn.bias))
+            eo, no, go = (next(outs) if d > 0 else None for d in self.out_dims)
+            return NT(g, _jl(eo), _jl(no), _jl(go))
         lib = _lib.load()
         keep = []
         p = self._c(keep)
@@ -609,6 +618,61 @@ class GNBlock:
                                         ws.data_ptr(), ws.numel(), self.flags if flags is None else flags,
                                         torch.cuda.current_stream(dev).cuda_stream))
         return NT(g, _jl(eo), _jl(no), _jl(go))  # zero-width outputs are None (gnblock.jl:71-78)
+
+
+class _BlockFn(torch.autograd.Function):
+    """torch autograd node of one GNBlock call: forward = gnx_block_forward, backward = gnx_block_backward (the analogue of
+    the Zygote `rrule` the Julia shim would define).  Tensors are packed [R][T][D]; weights (out, in) column-major."""
+
+    @staticmethod
+    def forward(ctx, block, g, R, ef, nf, gf, We, be, Wn, bn, Wg, bg):
+        lib = _lib.load()
+        keep = []
+        p = block._c(keep)
+        oe, on, og = block.out_dims
+        dev = g.device
+        mk = lambda T, d: torch.empty((R, T, d), dtype=torch.float32, device=dev) if d > 0 else None
+        eo, no, go = mk(g.n_edges, oe), mk(g.n_nodes, on), mk(g.n_graphs, og)
+        with torch.cuda.device(dev):
+            ws = g.workspace(lib.gnx_block_workspace_bytes(g._h, C.byref(p), R))
+            check(lib.gnx_block_forward(g._h, C.byref(p), _ptr(ef), _ptr(nf), _ptr(gf), R, _ptr(eo), _ptr(no), _ptr(go), ws.data_ptr(),
+                                        ws.numel(), block.flags, torch.cuda.current_stream(dev).cuda_stream))
+        ctx.block, ctx.g, ctx.R = block, g, R
+        ctx.saved = (ef, nf, gf, eo, no, go)
+        outs = tuple(o for o in (eo, no, go) if o is not None)
+        ctx.present = tuple(o is not None for o in (eo, no, go))
+        ctx.mark_non_differentiable()
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        lib = _lib.load()
+        block, g, R = ctx.block, ctx.g, ctx.R
+        ef, nf, gf, eo, no, go = ctx.saved
+        it = iter(gouts)
+        ge, gn_, gg = (next(it) if pr else None for pr in ctx.present)
+        cont = lambda t: None if t is None else t.contiguous()
+        ge, gn_, gg = cont(ge), cont(gn_), cont(gg)
+        keep = []
+        p = block._c(keep)
+        dev = g.device
+        need = ctx.needs_input_grad  # (block, g, R, ef, nf, gf, We, be, Wn, bn, Wg, bg)
+        d_ef = torch.empty_like(ef) if ef is not None and need[3] else None
+        d_nf = torch.empty_like(nf) if nf is not None and need[4] else None
+        d_gf = torch.empty_like(gf) if gf is not None and need[5] else None
+        layers = (block.edgefn, block.nodefn, block.graphfn)
+        gW = [torch.empty((l.weight.shape[1], l.weight.shape[0]), dtype=torch.float32, device=dev) if need[6 + 2 * i] else None for i, l in enumerate(layers)]
+        gb = [torch.empty_like(l.bias) if (l.bias is not None and need[7 + 2 * i]) else None for i, l in enumerate(layers)]
+        grads = _lib.BlockGrads(*[_lib.DenseGrad(_ptr(w) if (w is not None and w.numel()) else None, _ptr(b) if (b is not None and b.numel()) else None)
+                                  for w, b in zip(gW, gb)])
+        with torch.cuda.device(dev):
+            nb = lib.gnx_block_backward_workspace_bytes(g._h, C.byref(p), R)
+            ws = torch.empty(max(int(nb), 256), dtype=torch.uint8, device=dev)
+            check(lib.gnx_block_backward(g._h, C.byref(p), _ptr(ef), _ptr(nf), _ptr(gf), _ptr(eo), _ptr(no), _ptr(go), _ptr(ge), _ptr(gn_),
+                                         _ptr(gg), R, _ptr(d_ef), _ptr(d_nf), _ptr(d_gf), C.byref(grads), ws.data_ptr(), ws.numel(),
+                                         torch.cuda.current_stream(dev).cuda_stream))
+        gWt = [None if w is None else w.t() for w in gW]  # (out, in) view with column-major storage, like the weights
+        return (None, None, None, d_ef, d_nf, d_gf, gWt[0], gb[0], gWt[1], gb[1], gWt[2], gb[2])
 
 
 class GNFeedForward:

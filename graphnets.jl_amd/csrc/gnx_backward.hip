@@ -1,0 +1,270 @@
+// Backward pass of the GNBlock forward — dimension-generic, deterministic, correctness first.
+//
+// Forward (src/gnblock.jl:63-69):  ef' = se(We Xe + be), Xe = [ef ; nf[src] ; nf[dst] ; gf[g]]
+//                                  nf' = sn(Wn Xn + bn), Xn = [sum_{e->n} ef' ; nf ; gf[g]]
+//                                  gf' = sg(Wg Xg + bg), Xg = [sum_e ef' ; sum_n nf' ; gf]
+// Backward, with upstream gradients G_ef', G_nf', G_gf':
+//   graph:  dg = G_gf' * sg'            dXg = Wg^T dg                       dWg = dg Xg^T
+//   node :  dn = (G_nf' + dXg[nodes]) * sn'      dXn = Wn^T dn              dWn = sum_n dn Xn^T
+//   edge :  de = (G_ef' + dXg[edges] + dXn[dst][agg]) * se'   dXe = We^T de   dWe = sum_e de Xe^T
+//   d_ef = dXe[ef] ; d_nf[n] = dXn[n][nf] + sum_{e: dst=n} dXe[e][dst-seg] + sum_{e: src=n} dXe[e][src-seg] ;
+//   d_gf[g] = dXg[g][gf] + sum_{n in g} dXn[n][gf] + sum_{e in g} dXe[e][gf]
+// The three function inputs are materialised by the forward's building-block kernels (k_fn_input_*); the gather<->scatter
+// duality of nf[src] is resolved with a CSR view (out-edges per node) instead of atomics; every sum has a fixed order.
+#include <algorithm>
+
+#include "gnx_device.h"
+
+extern "C" int32_t gnx_ensure_csr(const gnx_graphs* h);
+
+namespace gnx {
+
+int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, const float* nf, int dn, const float* gf, int dg,
+                        int64_t R, float* out, hipStream_t s);
+
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+  switch (act) {
+    case GNX_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case GNX_ACT_TANH: return 1.f - y * y;
+    case GNX_ACT_SIGMOID: return y * (1.f - y);
+    default: return 1.f;
+  }
+}
+
+// delta[m][j] = (G[m][j] + extra1[i1(m)][o1 + j] + extra2[i2(m)][o2 + j]) * act'(out[m][j]);  one thread per element.
+// kind 0: rows = graphs (no extras); 1: rows = nodes (extra1 = dXg rows by graph); 2: rows = edges (extra1 = dXg by graph,
+// extra2 = dXn by destination node).
+struct DeltaArgs {
+  const float* G; const float* out; float* delta;
+  const float* ex1; int ex1_stride, ex1_off;
+  const float* ex2; int ex2_stride, ex2_off;
+  const int* seg_off;   // node_off / edge_off (graph of a row)
+  const int* edge_dst;
+  int J, rows, n_seg, act, kind;
+};
+__global__ void k_bw_delta(DeltaArgs a, size_t ex1_rep, size_t ex2_rep) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t r = blockIdx.y;
+  if (idx >= (size_t)a.rows * a.J) return;
+  const int m = (int)(idx / a.J), j = (int)(idx % a.J);
+  const size_t o = r * (size_t)a.rows * a.J + idx;
+  float g = a.G ? a.G[o] : 0.f;
+  if (a.kind >= 1 && a.ex1) g += a.ex1[r * ex1_rep + (size_t)segment_of(a.seg_off, a.n_seg, m) * a.ex1_stride + a.ex1_off + j];
+  if (a.kind == 2 && a.ex2) g += a.ex2[r * ex2_rep + (size_t)a.edge_dst[m] * a.ex2_stride + a.ex2_off + j];
+  a.delta[o] = g * act_grad_from_out(a.out[o], a.act);
+}
+
+// dX[m][k] = sum_j W[k*J + j] * delta[m][j]   (W is (J x K) column-major); one thread per (m, k)
+__global__ void k_bw_dx(const float* __restrict__ delta, const float* __restrict__ W, int rows, int J, int K, float* __restrict__ dX,
+                        int k0, int k1, float* __restrict__ direct, int direct_w) {
+  // columns [k0, k1) additionally go to `direct` (row stride direct_w) — e.g. the ef segment of dXe is d_ef itself
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t r = blockIdx.y;
+  if (idx >= (size_t)rows * K) return;
+  const int m = (int)(idx / K), k = (int)(idx % K);
+  const float* d = delta + (r * rows + m) * (size_t)J;
+  float acc = 0.f;
+  for (int j = 0; j < J; ++j) acc = fmaf(W[(size_t)k * J + j], d[j], acc);
+  dX[r * (size_t)rows * K + idx] = acc;
+  if (direct && k >= k0 && k < k1) direct[(r * rows + m) * (size_t)direct_w + (k - k0)] = acc;
+}
+
+// d_nf[n][k] = dXn[n][a_off+k] + sum_{in-edges} dXe[e][dst_off+k] + sum_{out-edges} dXe[e][src_off+k]
+__global__ void k_bw_dnf(const float* dXn, int Kn, int n_off, const float* dXe, int Ke, int src_off, int dst_off, const int* colptr,
+                         const int* csr_ptr, const int* csr_eid, int N, int E, int dn, float* d_nf) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t r = blockIdx.y;
+  if (idx >= (size_t)N * dn) return;
+  const int n = (int)(idx / dn), k = (int)(idx % dn);
+  float acc = dXn ? dXn[(r * N + n) * (size_t)Kn + n_off + k] : 0.f;
+  if (dXe) {
+    const float* base = dXe + r * (size_t)E * Ke;
+    for (int e = colptr[n]; e < colptr[n + 1]; ++e) acc += base[(size_t)e * Ke + dst_off + k];
+    for (int i = csr_ptr[n]; i < csr_ptr[n + 1]; ++i) acc += base[(size_t)csr_eid[i] * Ke + src_off + k];
+  }
+  d_nf[r * (size_t)N * dn + idx] = acc;
+}
+
+// d_gf[g][k] = dXg[g][g_off+k] + sum_{n in g} dXn[n][n_off+k] + sum_{e in g} dXe[e][e_off+k]; one workgroup per (g, r)
+__global__ __launch_bounds__(256) void k_bw_dgf(const float* dXg, int Kg, int g_off, const float* dXn, int Kn, int n_off, const float* dXe,
+                                                int Ke, int e_off, const int* node_off, const int* edge_off, int N, int E, int G, int dg,
+                                                float* d_gf) {
+  __shared__ float s_red[256];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const size_t r = blockIdx.y;
+  for (int k = 0; k < dg; ++k) {
+    float s = 0.f;
+    if (dXn) for (int n = node_off[g] + tid; n < node_off[g + 1]; n += 256) s += dXn[(r * N + n) * (size_t)Kn + n_off + k];
+    float s2 = 0.f;
+    if (dXe) for (int e = edge_off[g] + tid; e < edge_off[g + 1]; e += 256) s2 += dXe[(r * E + e) * (size_t)Ke + e_off + k];
+    s_red[tid] = s + s2;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (tid < w) s_red[tid] += s_red[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) d_gf[(r * G + g) * (size_t)dg + k] = s_red[0] + (dXg ? dXg[(r * G + g) * (size_t)Kg + g_off + k] : 0.f);
+    __syncthreads();
+  }
+}
+
+// weight / bias gradients: dW[k*J + j] = sum_m delta[m][j] * X[m][k], db[j] = sum_m delta[m][j]  over ALL rows (and replicas).
+// stage 1: one workgroup per chunk of CH rows: threads over the (j, k) pairs, rows looped in order -> partial[chunk][J*(K+1)]
+constexpr int BW_CH = 256;
+__global__ __launch_bounds__(256) void k_bw_dw_partial(const float* __restrict__ delta, const float* __restrict__ X, size_t rows, int J, int K,
+                                                       float* __restrict__ partial) {
+  const size_t m0 = (size_t)blockIdx.x * BW_CH;
+  const size_t m1 = m0 + BW_CH < rows ? m0 + BW_CH : rows;
+  const int P = J * (K + 1);  // pair index p: k = p / J (k == K -> bias), j = p % J
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const int k = p / J, j = p % J;
+    float acc = 0.f;
+    if (k < K) { for (size_t m = m0; m < m1; ++m) acc = fmaf(delta[m * J + j], X[m * K + k], acc); }
+    else { for (size_t m = m0; m < m1; ++m) acc += delta[m * J + j]; }
+    partial[(size_t)blockIdx.x * P + p] = acc;
+  }
+}
+// stage 2: fixed-order sum over the chunks, 16 loads in flight
+__global__ void k_bw_dw_final(const float* __restrict__ partial, int nchunks, int J, int K, float* __restrict__ dW, float* __restrict__ db) {
+  const int P = J * (K + 1);
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float acc[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+  for (int c = 0; c < nchunks; c += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)min(c + u, nchunks - 1) * P + p];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] += c + u < nchunks ? v[u] : 0.f;
+  }
+#pragma unroll
+  for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+    for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
+  const int k = p / J, j = p % J;
+  if (k < K) { if (dW) dW[(size_t)k * J + j] = acc[0]; }
+  else if (db) db[j] = acc[0];
+}
+
+struct BwLayout {
+  size_t Xe, Xn, Xg, de_, dn_, dg_, dXe, dXn, dXg, part, total;
+};
+static BwLayout bw_layout(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
+  const size_t E = h->E, N = h->N, G = h->G;
+  const size_t Ke = p->de + 2 * p->dn + p->dg, Kn = p->oe + p->dn + p->dg, Kg = p->oe + p->on + p->dg;
+  BwLayout L{};
+  size_t o = 0;
+  auto take = [&](size_t floats) { const size_t at = o; o += align_up(floats * sizeof(float), 256); return at; };
+  L.Xe = take(R * E * Ke); L.Xn = take(R * N * Kn); L.Xg = take(R * G * Kg);
+  L.de_ = take(R * E * p->oe); L.dn_ = take(R * N * p->on); L.dg_ = take(R * G * p->og);
+  L.dXe = take(R * E * Ke); L.dXn = take(R * N * Kn); L.dXg = take(R * G * Kg);
+  const size_t ch_e = (R * E + BW_CH - 1) / BW_CH, ch_n = (R * N + BW_CH - 1) / BW_CH, ch_g = (R * G + BW_CH - 1) / BW_CH;
+  const size_t pmax = std::max({ch_e * p->oe * (Ke + 1), ch_n * p->on * (Kn + 1), ch_g * p->og * (Kg + 1)});
+  L.part = take(pmax);
+  L.total = o + 256;
+  return L;
+}
+
+static int32_t dw_reduce(const float* delta, const float* X, size_t rows, int J, int K, const gnx_dense_grad& g, float* partial, hipStream_t s) {
+  if (J == 0 || rows == 0 || (!g.weight && !g.bias)) {
+    return GNX_OK;
+  }
+  const int nchunks = (int)((rows + BW_CH - 1) / BW_CH);
+  const int P = J * (K + 1);
+  hipLaunchKernelGGL(k_bw_dw_partial, dim3(nchunks), dim3(256), 0, s, delta, X, rows, J, K, partial);
+  hipLaunchKernelGGL(k_bw_dw_final, dim3((P + 255) / 256), dim3(256), 0, s, partial, nchunks, J, K, g.weight, g.bias);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+}  // namespace gnx
+
+using namespace gnx;
+
+extern "C" {
+
+size_t gnx_block_backward_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
+  if (!h || !p || R <= 0) return 0;
+  return bw_layout(h, p, R).total;
+}
+
+int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf, const float* gf,
+                           const float* ef_out, const float* nf_out, const float* gf_out, const float* g_ef_out, const float* g_nf_out,
+                           const float* g_gf_out, int64_t R, float* d_ef, float* d_nf, float* d_gf, const gnx_block_grads* grads,
+                           void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
+  if (R <= 0 || (R > 1 && h->G != 1) || R > 65535) return fail(GNX_ERR_INVALID_ARG, "bad n_replicas");
+  const int de = p->de, dn = p->dn, dg = p->dg, oe = p->oe, on = p->on, og = p->og;
+  if (de < 0 || dn < 0 || dg < 0 || oe < 0 || on < 0 || og < 0 || de + dn + dg == 0 || oe + on + og == 0) return fail(GNX_ERR_DIMS, "bad widths");
+  if ((de && !ef) || (dn && !nf) || (dg && !gf)) return fail(GNX_ERR_INVALID_ARG, "a forward input with non-zero width is NULL");
+  if ((oe && !ef_out) || (on && !nf_out) || (og && !gf_out)) return fail(GNX_ERR_INVALID_ARG, "a forward output with non-zero width is NULL");
+  const int acts[3] = {p->edgefn.act, p->nodefn.act, p->graphfn.act};
+  for (int a : acts)
+    if (a == GNX_ACT_GELU || a < 0 || a > GNX_ACT_GELU) return fail(GNX_ERR_INVALID_ARG, "backward supports identity / relu / tanh / sigmoid");
+  const BwLayout L = bw_layout(h, p, R);
+  if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_block_backward_workspace_bytes()");
+  int32_t rc = gnx_ensure_csr(h);
+  if (rc) return rc;
+  char* base = static_cast<char*>(ws);
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+  float *Xe = F(L.Xe), *Xn = F(L.Xn), *Xg = F(L.Xg), *dlt_e = F(L.de_), *dlt_n = F(L.dn_), *dlt_g = F(L.dg_);
+  float *dXe = F(L.dXe), *dXn = F(L.dXn), *dXg = F(L.dXg), *part = F(L.part);
+  const int E = (int)h->E, N = (int)h->N, G = (int)h->G;
+  const int Ke = de + 2 * dn + dg, Kn = oe + dn + dg, Kg = oe + on + dg;
+  const gnx_block_grads none{};
+  const gnx_block_grads& gr = grads ? *grads : none;
+  auto blocks = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  const unsigned Ru = (unsigned)R;
+
+  // function inputs, exactly as the forward's building blocks define them
+  if (oe && E && (rc = launch_fn_input(h, 0, ef, de, nf, dn, gf, dg, R, Xe, s))) return rc;
+  if (on && (rc = launch_fn_input(h, 1, ef_out, oe, nf, dn, gf, dg, R, Xn, s))) return rc;
+  if (og && (rc = launch_fn_input(h, 2, ef_out, oe, nf_out, on, gf, dg, R, Xg, s))) return rc;
+
+  // graph level
+  const bool have_g = og > 0;
+  if (have_g) {
+    DeltaArgs a{g_gf_out, gf_out, dlt_g, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, og, G, G, acts[2], 0};
+    hipLaunchKernelGGL(k_bw_delta, dim3(blocks((size_t)G * og).x, Ru), dim3(256), 0, s, a, (size_t)0, (size_t)0);
+    hipLaunchKernelGGL(k_bw_dx, dim3(blocks((size_t)G * Kg).x, Ru), dim3(256), 0, s, dlt_g, p->graphfn.weight, G, og, Kg, dXg, 0, 0, (float*)nullptr, 0);
+    if ((rc = dw_reduce(dlt_g, Xg, (size_t)R * G, og, Kg, gr.graphfn, part, s))) return rc;
+  }
+  // node level
+  const bool have_n = on > 0;
+  if (have_n) {
+    DeltaArgs a{g_nf_out, nf_out, dlt_n, have_g ? dXg : nullptr, Kg, oe, nullptr, 0, 0, h->d_node_off, nullptr, on, N, G, acts[1], 1};
+    hipLaunchKernelGGL(k_bw_delta, dim3(blocks((size_t)N * on).x, Ru), dim3(256), 0, s, a, (size_t)G * Kg, (size_t)0);
+    hipLaunchKernelGGL(k_bw_dx, dim3(blocks((size_t)N * Kn).x, Ru), dim3(256), 0, s, dlt_n, p->nodefn.weight, N, on, Kn, dXn, 0, 0, (float*)nullptr, 0);
+    if ((rc = dw_reduce(dlt_n, Xn, (size_t)R * N, on, Kn, gr.nodefn, part, s))) return rc;
+  }
+  // edge level
+  const bool have_e = oe > 0 && E > 0;
+  if (have_e) {
+    DeltaArgs a{g_ef_out, ef_out, dlt_e, have_g ? dXg : nullptr, Kg, 0, have_n ? dXn : nullptr, Kn, 0, h->d_edge_off, h->d_edge_dst, oe, E, G, acts[0], 2};
+    hipLaunchKernelGGL(k_bw_delta, dim3(blocks((size_t)E * oe).x, Ru), dim3(256), 0, s, a, (size_t)G * Kg, (size_t)N * Kn);
+    hipLaunchKernelGGL(k_bw_dx, dim3(blocks((size_t)E * Ke).x, Ru), dim3(256), 0, s, dlt_e, p->edgefn.weight, E, oe, Ke, dXe, 0, de, d_ef, de);
+    if ((rc = dw_reduce(dlt_e, Xe, (size_t)R * E, oe, Ke, gr.edgefn, part, s))) return rc;
+  } else {
+    if (d_ef && de && E) GNX_HIP(hipMemsetAsync(d_ef, 0, sizeof(float) * (size_t)R * E * de, s));
+    if (gr.edgefn.weight && oe) GNX_HIP(hipMemsetAsync(gr.edgefn.weight, 0, sizeof(float) * (size_t)oe * Ke, s));
+    if (gr.edgefn.bias && oe) GNX_HIP(hipMemsetAsync(gr.edgefn.bias, 0, sizeof(float) * (size_t)oe, s));
+  }
+  if (!have_n) {
+    if (gr.nodefn.weight && on) GNX_HIP(hipMemsetAsync(gr.nodefn.weight, 0, sizeof(float) * (size_t)on * Kn, s));
+    if (gr.nodefn.bias && on) GNX_HIP(hipMemsetAsync(gr.nodefn.bias, 0, sizeof(float) * (size_t)on, s));
+  }
+  // input gradients that need sums
+  if (d_nf && dn)
+    hipLaunchKernelGGL(k_bw_dnf, dim3(blocks((size_t)N * dn).x, Ru), dim3(256), 0, s, have_n ? dXn : nullptr, Kn, oe, have_e ? dXe : nullptr, Ke, de,
+                       de + dn, h->d_colptr, h->d_csr_ptr, h->d_csr_eid, N, E, dn, d_nf);
+  if (d_gf && dg)
+    hipLaunchKernelGGL(k_bw_dgf, dim3((unsigned)G, Ru), dim3(256), 0, s, have_g ? dXg : nullptr, Kg, oe + on, have_n ? dXn : nullptr, Kn, oe + dn,
+                       have_e ? dXe : nullptr, Ke, de + 2 * dn, h->d_node_off, h->d_edge_off, N, E, G, dg, d_gf);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+}  // extern "C"

@@ -296,6 +296,8 @@ int32_t gnx_graphs_destroy(gnx_graphs* h) {
   (void)hipFree(h->d_wtiles);
   (void)hipFree(h->d_collapse_edge);
   (void)hipFree(h->d_collapse_rev);
+  (void)hipFree(h->d_csr_ptr);
+  (void)hipFree(h->d_csr_eid);
   delete h;
   return GNX_OK;
 }
@@ -327,6 +329,24 @@ static int32_t build_collapse(const gnx_graphs* h) {
     GNX_HIP(hipMemcpy(h->d_collapse_rev, rev.data(), rev.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   return GNX_OK;
+}
+
+static int32_t build_csr(const gnx_graphs* h) {
+  std::vector<int32_t> ptr((size_t)h->N + 1, 0), eid((size_t)h->E);
+  for (int64_t e = 0; e < h->E; ++e) ptr[(size_t)h->h_rowval[e] + 1]++;
+  for (int64_t n = 0; n < h->N; ++n) ptr[n + 1] += ptr[n];
+  std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+  for (int64_t e = 0; e < h->E; ++e) eid[(size_t)fill[(size_t)h->h_rowval[e]]++] = (int32_t)e;  // ascending e inside a source: fixed order
+  GNX_HIP(hipMalloc((void**)&h->d_csr_ptr, ptr.size() * sizeof(int32_t)));
+  GNX_HIP(hipMalloc((void**)&h->d_csr_eid, std::max<size_t>(eid.size(), 1) * sizeof(int32_t)));
+  GNX_HIP(hipMemcpy(h->d_csr_ptr, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (!eid.empty()) GNX_HIP(hipMemcpy(h->d_csr_eid, eid.data(), eid.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  return GNX_OK;
+}
+
+int32_t gnx_ensure_csr(const gnx_graphs* h) {
+  std::call_once(h->csr_once, [&] { h->csr_rc = build_csr(h); });
+  return h->csr_rc;
 }
 
 int32_t gnx_ensure_collapse(const gnx_graphs* h) {

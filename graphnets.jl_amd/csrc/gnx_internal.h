@@ -62,6 +62,11 @@ struct gnx_graphs {
   mutable int32_t* d_collapse_edge = nullptr;   // [n_collapsed] edge id of i->j (i >= j)
   mutable int32_t* d_collapse_rev = nullptr;    // [n_collapsed] edge id of j->i, or -1
   mutable int32_t collapse_rc = 0;
+  // CSR view for the backward pass (out-edges of every node, edge ids in CSC numbering), built on first use
+  mutable std::once_flag csr_once;
+  mutable int32_t* d_csr_ptr = nullptr;  // [N+1]
+  mutable int32_t* d_csr_eid = nullptr;  // [E]
+  mutable int32_t csr_rc = 0;
   int64_t n_tiles() const { return (int64_t)h_tiles.size(); }
   int64_t n_wtiles() const { return (int64_t)h_wtiles.size(); }
 };

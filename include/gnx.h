@@ -167,6 +167,26 @@ GNX_API int32_t gnx_block_forward(const gnx_graphs* h, const gnx_block_params* p
 GNX_API int32_t gnx_block_graph_update(const gnx_graphs* h, const gnx_block_params* p, const float* gf, int64_t n_replicas,
                                float* gf_out, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
+/* ---- backward of the block: what a Zygote `rrule` / torch autograd function for (m::GNBlock)(x) needs.
+ * Inputs: the forward's inputs (ef, nf, gf), its outputs (ef_out, nf_out, gf_out) and the upstream gradients with the
+ * outputs' shapes (g_*; NULL = zero).  Outputs (all optional, NULL = not wanted): gradients w.r.t. the inputs (d_ef, d_nf,
+ * d_gf, input shapes) and w.r.t. the parameters (grads->*.weight in the (out x in) column-major layout of the weights,
+ * grads->*.bias), OVERWRITTEN.  Deterministic: segmented sums in CSC order, the nf[src] gradient is gathered through a
+ * CSR view of the same graph (no atomics), weight gradients are two-stage fixed-order reductions.
+ * Activations identity / relu / tanh / sigmoid differentiate from the stored outputs; gelu is not supported here. */
+typedef struct gnx_dense_grad {
+  float* weight; /* (out x in) column-major, device, or NULL */
+  float* bias;   /* (out), device, or NULL                   */
+} gnx_dense_grad;
+typedef struct gnx_block_grads {
+  gnx_dense_grad edgefn, nodefn, graphfn;
+} gnx_block_grads;
+GNX_API size_t gnx_block_backward_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t n_replicas);
+GNX_API int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf, const float* gf,
+                           const float* ef_out, const float* nf_out, const float* gf_out, const float* g_ef_out,
+                           const float* g_nf_out, const float* g_gf_out, int64_t n_replicas, float* d_ef, float* d_nf,
+                           float* d_gf, const gnx_block_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- forward: replaces (m::GNCore)(x) (src/gncore.jl:56-68); GNCoreList = caller-side fold (gncorelist.jl:43-45) ---- */
 GNX_API size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t n_replicas);
 GNX_API int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf,
