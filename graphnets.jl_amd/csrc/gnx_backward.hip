@@ -108,44 +108,106 @@ __global__ __launch_bounds__(256) void k_bw_dgf(const float* dXg, int Kg, int g_
   }
 }
 
+// per-graph column sums of a row tensor (sum_e ef', sum_n nf' for Xg), two stages, fixed order:
+// stage 1: workgroup (slice s of graph g): thread (grp, c) strides over the slice's rows for column c -> partial[g][s][c]
+__global__ __launch_bounds__(256) void k_bw_colsum1(const float* __restrict__ in, int d, int rows_total, const int* __restrict__ off, int S,
+                                                    int G, float* __restrict__ partial) {
+  __shared__ float s_red[256];
+  const int sl = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const size_t r = blockIdx.z;
+  const int t0 = off[g], t1 = off[g + 1];
+  const int per = (t1 - t0 + S - 1) / S;
+  const int a0 = t0 + sl * per, a1 = min(a0 + per, t1);
+  const float* base = in + r * (size_t)rows_total * d;
+  for (int c0 = 0; c0 < d; c0 += 256) {
+    const int dc = min(d - c0, 256);         // columns handled in this pass
+    const int groups = 256 / dc;             // row groups working in parallel
+    const int c = tid % dc, grp = tid / dc;
+    float acc = 0.f;
+    if (grp < groups && a1 > a0) {
+      for (int m = a0 + grp; m < a1; m += 8 * groups) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = base[(size_t)min(m + u * groups, a1 - 1) * d + c0 + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += m + u * groups < a1 ? v[u] : 0.f;
+      }
+    }
+    s_red[tid] = grp < groups ? acc : 0.f;
+    __syncthreads();
+    if (tid < dc) {
+      float t = 0.f;
+      for (int q = 0; q < groups; ++q) t += s_red[q * dc + tid];
+      partial[((r * G + g) * S + sl) * (size_t)d + c0 + tid] = t;
+    }
+    __syncthreads();
+  }
+}
+// stage 2: out[(r*G+g)*out_stride + out_off + c] = sum_s partial[g][s][c]
+__global__ void k_bw_colsum2(const float* __restrict__ partial, int d, int S, int G, float* __restrict__ out, int out_stride, int out_off) {
+  const int g = blockIdx.x;
+  const size_t r = blockIdx.y;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float acc = 0.f;
+    for (int sl = 0; sl < S; ++sl) acc += partial[((r * G + g) * S + sl) * (size_t)d + c];
+    out[(r * G + g) * (size_t)out_stride + out_off + c] = acc;
+  }
+}
+__global__ void k_bw_copy_gf(const float* __restrict__ gf, int dg, int GR, float* __restrict__ out, int out_stride, int out_off) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= GR * dg) return;
+  out[(size_t)(idx / dg) * out_stride + out_off + idx % dg] = gf[idx];
+}
+
 // weight / bias gradients: dW[k*J + j] = sum_m delta[m][j] * X[m][k], db[j] = sum_m delta[m][j]  over ALL rows (and replicas).
 // stage 1: one workgroup per chunk of CH rows: threads over the (j, k) pairs, rows looped in order -> partial[chunk][J*(K+1)]
-constexpr int BW_CH = 256;
+constexpr int BW_CH = 2048;
+// stage 1: one workgroup per chunk of BW_CH rows; thread = (pair p, row slice): every slice walks its rows in order, the slices
+// are then added in order through LDS.  (All threads of a workgroup read the same few rows: L1 broadcasts.)
 __global__ __launch_bounds__(256) void k_bw_dw_partial(const float* __restrict__ delta, const float* __restrict__ X, size_t rows, int J, int K,
                                                        float* __restrict__ partial) {
+  __shared__ float s_red[256];
   const size_t m0 = (size_t)blockIdx.x * BW_CH;
   const size_t m1 = m0 + BW_CH < rows ? m0 + BW_CH : rows;
   const int P = J * (K + 1);  // pair index p: k = p / J (k == K -> bias), j = p % J
-  for (int p = threadIdx.x; p < P; p += 256) {
-    const int k = p / J, j = p % J;
+  const int tid = threadIdx.x;
+  for (int p0 = 0; p0 < P; p0 += 256) {
+    const int pc = min(P - p0, 256);
+    const int nsl = 256 / pc;
+    const int pl = tid % pc, sl = tid / pc;
     float acc = 0.f;
-    if (k < K) { for (size_t m = m0; m < m1; ++m) acc = fmaf(delta[m * J + j], X[m * K + k], acc); }
-    else { for (size_t m = m0; m < m1; ++m) acc += delta[m * J + j]; }
-    partial[(size_t)blockIdx.x * P + p] = acc;
+    if (sl < nsl) {
+      const int p = p0 + pl, k = p / J, j = p % J;
+      if (k < K) { for (size_t m = m0 + sl; m < m1; m += nsl) acc = fmaf(delta[m * J + j], X[m * K + k], acc); }
+      else { for (size_t m = m0 + sl; m < m1; m += nsl) acc += delta[m * J + j]; }
+    }
+    s_red[tid] = sl < nsl ? acc : 0.f;
+    __syncthreads();
+    if (tid < pc) {
+      float t = 0.f;
+      for (int q = 0; q < nsl; ++q) t += s_red[q * pc + tid];
+      partial[(size_t)blockIdx.x * P + p0 + tid] = t;
+    }
+    __syncthreads();
   }
 }
-// stage 2: fixed-order sum over the chunks, 16 loads in flight
-__global__ void k_bw_dw_final(const float* __restrict__ partial, int nchunks, int J, int K, float* __restrict__ dW, float* __restrict__ db) {
-  const int P = J * (K + 1);
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  float acc[16];
-#pragma unroll
-  for (int u = 0; u < 16; ++u) acc[u] = 0.f;
-  for (int c = 0; c < nchunks; c += 16) {
-    float v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = partial[(size_t)min(c + u, nchunks - 1) * P + p];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) acc[u] += c + u < nchunks ? v[u] : 0.f;
+// stage 2: one workgroup per pair, threads over the chunks, fixed-order LDS tree
+__global__ __launch_bounds__(256) void k_bw_dw_final(const float* __restrict__ partial, int nchunks, int J, int K, float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float s_red[256];
+  const int P = J * (K + 1), p = blockIdx.x, tid = threadIdx.x;
+  float acc = 0.f;
+  for (int c = tid; c < nchunks; c += 256) acc += partial[(size_t)c * P + p];
+  s_red[tid] = acc;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) s_red[tid] += s_red[tid + w];
+    __syncthreads();
   }
-#pragma unroll
-  for (int w = 8; w > 0; w >>= 1)
-#pragma unroll
-    for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
-  const int k = p / J, j = p % J;
-  if (k < K) { if (dW) dW[(size_t)k * J + j] = acc[0]; }
-  else if (db) db[j] = acc[0];
+  if (tid == 0) {
+    const int k = p / J, j = p % J;
+    if (k < K) { if (dW) dW[(size_t)k * J + j] = s_red[0]; }
+    else if (db) db[j] = s_red[0];
+  }
 }
 
 struct BwLayout {
@@ -162,7 +224,8 @@ static BwLayout bw_layout(const gnx_graphs* h, const gnx_block_params* p, int64_
   L.dXe = take(R * E * Ke); L.dXn = take(R * N * Kn); L.dXg = take(R * G * Kg);
   const size_t ch_e = (R * E + BW_CH - 1) / BW_CH, ch_n = (R * N + BW_CH - 1) / BW_CH, ch_g = (R * G + BW_CH - 1) / BW_CH;
   const size_t pmax = std::max({ch_e * p->oe * (Ke + 1), ch_n * p->on * (Kn + 1), ch_g * p->og * (Kg + 1)});
-  L.part = take(pmax);
+  const size_t cs = (size_t)R * G * 256 * std::max(p->oe, p->on);  // per-graph column-sum slices
+  L.part = take(std::max(pmax, cs));
   L.total = o + 256;
   return L;
 }
@@ -174,7 +237,7 @@ static int32_t dw_reduce(const float* delta, const float* X, size_t rows, int J,
   const int nchunks = (int)((rows + BW_CH - 1) / BW_CH);
   const int P = J * (K + 1);
   hipLaunchKernelGGL(k_bw_dw_partial, dim3(nchunks), dim3(256), 0, s, delta, X, rows, J, K, partial);
-  hipLaunchKernelGGL(k_bw_dw_final, dim3((P + 255) / 256), dim3(256), 0, s, partial, nchunks, J, K, g.weight, g.bias);
+  hipLaunchKernelGGL(k_bw_dw_final, dim3(P), dim3(256), 0, s, partial, nchunks, J, K, g.weight, g.bias);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -222,7 +285,20 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   // function inputs, exactly as the forward's building blocks define them
   if (oe && E && (rc = launch_fn_input(h, 0, ef, de, nf, dn, gf, dg, R, Xe, s))) return rc;
   if (on && (rc = launch_fn_input(h, 1, ef_out, oe, nf, dn, gf, dg, R, Xn, s))) return rc;
-  if (og && (rc = launch_fn_input(h, 2, ef_out, oe, nf_out, on, gf, dg, R, Xg, s))) return rc;
+  if (og) {  // Xg = [sum_e ef' ; sum_n nf' ; gf] with parallel two-stage column sums (one workgroup per graph would walk 1M rows)
+    auto colsum = [&](const float* in, int d, int rows_total, const int* off, int64_t max_rows, int out_off) {
+      if (d == 0) return;
+      int S = (int)std::min<int64_t>(std::max<int64_t>(max_rows / 2048, 1), 256);
+      hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S, (unsigned)G, Ru), dim3(256), 0, s, in, d, rows_total, off, S, G, part);
+      hipLaunchKernelGGL(k_bw_colsum2, dim3((unsigned)G, Ru), dim3(64), 0, s, part, d, S, G, Xg, Kg, out_off);
+    };
+    int64_t me = 1, mn = 1;
+    for (int64_t g = 0; g < h->G; ++g) { me = std::max(me, h->h_edge_off[g + 1] - h->h_edge_off[g]); mn = std::max(mn, h->h_node_off[g + 1] - h->h_node_off[g]); }
+    colsum(ef_out, oe, E, h->d_edge_off, me, 0);
+    colsum(nf_out, on, N, h->d_node_off, mn, oe);
+    if (dg) hipLaunchKernelGGL(k_bw_copy_gf, blocks((size_t)R * G * dg), dim3(256), 0, s, gf, dg, (int)(R * G), Xg, Kg, oe + on);
+    GNX_HIP(hipGetLastError());
+  }
 
   // graph level
   const bool have_g = og > 0;
