@@ -19,7 +19,7 @@ def short(name):
     return name if name.startswith("k_rows_gemm") else name.split("<")[0]
 
 
-ALIASES = {"k_rows_gemm<128,true>": "k_rows_gemm_edge", "k_rows_gemm<64,true>": "k_rows_gemm_node"}  # at core dims
+ALIASES = {"k_rows_gemm<128,true,32>": "k_rows_gemm_edge", "k_rows_gemm<64,true,32>": "k_rows_gemm_node"}  # at core dims (the <128> rows also hold the two projection GEMMs)
 
 
 def main():
