@@ -44,6 +44,18 @@ class BlockGrads(C.Structure):
     _fields_ = [("edgefn", DenseGrad), ("nodefn", DenseGrad), ("graphfn", DenseGrad)]
 
 
+class LayerNormGrad(C.Structure):
+    _fields_ = [("gamma", _fp), ("beta", _fp)]
+
+
+class FfnGrad(C.Structure):
+    _fields_ = [("fc1", DenseGrad), ("fc2", DenseGrad)]
+
+
+class CoreGrads(C.Structure):
+    _fields_ = [("block", BlockGrads), ("ln1", LayerNormGrad * 3), ("ln2", LayerNormGrad * 3), ("ff", FfnGrad * 3)]
+
+
 class LayerNorm(C.Structure):
     _fields_ = [("gamma", _fp), ("beta", _fp)]
 
@@ -86,6 +98,8 @@ SIGNATURES = {
     "gnx_block_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BlockParams), C.c_int64]),
     "gnx_block_backward": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + [_fp] * 9 + [C.c_int64] + [_fp] * 3 +
                            [C.POINTER(BlockGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "gnx_core_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "gnx_core_backward": (C.c_int32, [C.c_void_p, C.c_void_p] + [_fp] * 6 + [C.c_int64] + [_fp] * 3 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnx_core_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(CoreParams), C.c_int64]),
     "gnx_core_forward": (C.c_int32, [C.c_void_p, C.POINTER(CoreParams)] + _FWD[2:]),
     "gnx_fn_input": (C.c_int32, [C.c_void_p, C.c_int32, _fp, C.c_int32, _fp, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),

@@ -720,10 +720,29 @@ class GNCore:
         p.eps, p.eps_mode = self.eps, self.eps_mode
         return p
 
+    def _param_list(self):
+        """Order = gnx_core_grads: block (edge, node, graph: weight, bias), ln1 x3 (gamma, beta), ln2 x3, ff x3 (W1, b1, W2, b2)."""
+        ps = []
+        for l in (self.block.edgefn, self.block.nodefn, self.block.graphfn):
+            ps += [l.weight, l.bias]
+        for gnorm in (self.gn1, self.gn2):
+            for ln in (gnorm.edgeln, gnorm.nodeln, gnorm.graphln):
+                ps += [ln.gamma, ln.beta]
+        for ff in (self.ffwd.eff, self.ffwd.nff, self.ffwd.gff):
+            ps += [ff[0].weight, ff[0].bias, ff[1].weight, ff[1].bias]
+        return ps
+
+    def parameters(self):
+        return self._param_list()
+
     def __call__(self, x, flags=None):
         x = _as_nt(x)
         assert x.ef is not None and x.nf is not None and x.gf is not None, "GNCore needs ef, nf and gf (gncore.jl:61-68)"
         g, ef, nf, gf, R = _forward_common(x, self.dims)
+        plist = self._param_list()
+        if torch.is_grad_enabled() and any(t.requires_grad for t in [ef, nf, gf] + plist):
+            eo, no, go = _CoreFn.apply(self, g, R, ef, nf, gf, *plist)
+            return NT(g, _jl(eo), _jl(no), _jl(go))
         lib = _lib.load()
         keep = []
         p = self._c(keep)
@@ -735,6 +754,56 @@ class GNCore:
                                        no.data_ptr(), go.data_ptr(), ws.data_ptr(), ws.numel(),
                                        self.flags if flags is None else flags, torch.cuda.current_stream(dev).cuda_stream))
         return NT(g, _jl(eo), _jl(no), _jl(go))
+
+
+class _CoreFn(torch.autograd.Function):
+    """torch autograd node of one GNCore call: forward = gnx_core_forward, backward = gnx_core_backward."""
+
+    @staticmethod
+    def forward(ctx, core, g, R, ef, nf, gf, *params):
+        lib = _lib.load()
+        keep = []
+        p = core._c(keep)
+        dev = g.device
+        eo, no, go = torch.empty_like(ef), torch.empty_like(nf), torch.empty_like(gf)
+        with torch.cuda.device(dev):
+            ws = g.workspace(lib.gnx_core_workspace_bytes(g._h, C.byref(p), R))
+            check(lib.gnx_core_forward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), R, eo.data_ptr(), no.data_ptr(),
+                                       go.data_ptr(), ws.data_ptr(), ws.numel(), core.flags, torch.cuda.current_stream(dev).cuda_stream))
+        ctx.core, ctx.g, ctx.R, ctx.saved = core, g, R, (ef, nf, gf)
+        return eo, no, go
+
+    @staticmethod
+    def backward(ctx, ge, gn_, gg):
+        lib = _lib.load()
+        core, g, R = ctx.core, ctx.g, ctx.R
+        ef, nf, gf = ctx.saved
+        dev = g.device
+        cont = lambda t: None if t is None else t.contiguous()
+        ge, gn_, gg = cont(ge), cont(gn_), cont(gg)
+        keep = []
+        p = core._c(keep)
+        plist = core._param_list()
+        out = [torch.empty((q.shape[1], q.shape[0]), dtype=torch.float32, device=dev).t() if q.dim() == 2 else torch.empty_like(q) for q in plist]
+        gr = _lib.CoreGrads()
+        wptr = lambda t: t.t().data_ptr() if t.dim() == 2 else t.data_ptr()  # the (in, out)-contiguous storage under the (out, in) view
+        it = iter(out)
+        for dst in (gr.block.edgefn, gr.block.nodefn, gr.block.graphfn):
+            dst.weight, dst.bias = wptr(next(it)), wptr(next(it))
+        for arr in (gr.ln1, gr.ln2):
+            for i in range(3):
+                arr[i].gamma, arr[i].beta = wptr(next(it)), wptr(next(it))
+        for i in range(3):
+            gr.ff[i].fc1.weight, gr.ff[i].fc1.bias = wptr(next(it)), wptr(next(it))
+            gr.ff[i].fc2.weight, gr.ff[i].fc2.bias = wptr(next(it)), wptr(next(it))
+        d_ef, d_nf, d_gf = torch.empty_like(ef), torch.empty_like(nf), torch.empty_like(gf)
+        with torch.cuda.device(dev):
+            nb = lib.gnx_core_backward_workspace_bytes(g._h, C.byref(p), R)
+            ws = torch.empty(max(int(nb), 256), dtype=torch.uint8, device=dev)
+            check(lib.gnx_core_backward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), _ptr(ge), _ptr(gn_), _ptr(gg), R,
+                                        d_ef.data_ptr(), d_nf.data_ptr(), d_gf.data_ptr(), C.byref(gr), ws.data_ptr(), ws.numel(),
+                                        torch.cuda.current_stream(dev).cuda_stream))
+        return (None, None, None, d_ef, d_nf, d_gf, *out)
 
 
 class GNCoreList:

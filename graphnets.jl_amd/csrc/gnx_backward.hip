@@ -242,6 +242,86 @@ static int32_t dw_reduce(const float* delta, const float* X, size_t rows, int J,
   return GNX_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// GNCore backward pieces
+// ---------------------------------------------------------------------------------------------------------
+// y[m][j] = act(sum_k W[k*J + j] * x[m][k] + b[j]);  one thread per (m, j)   (recomputation of the FeedForward hidden layer)
+__global__ void k_fw_dense(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b, size_t rows, int K, int J,
+                           int act, float* __restrict__ y) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * J) return;
+  const size_t m = idx / J;
+  const int j = (int)(idx % J);
+  float acc = b ? b[j] : 0.f;
+  const float* xr = x + m * K;
+  for (int k = 0; k < K; ++k) acc = fmaf(W[(size_t)k * J + j], xr[k], acc);
+  y[idx] = act_apply(acc, act);
+}
+
+// LayerNorm pullback for BOTH norms of a GNCore (they normalise the same x): one wave per row.
+//   xhat = (x - mu) / s,  s = sigma + eps (mode 0) or sqrt(sigma^2 + eps) (mode 1);  y_i = gamma_i xhat + beta_i
+//   dxhat = dy1*gamma1 + dy2*gamma2;  dx = (dxhat - mean(dxhat)) / s - c * sum(dxhat*c) / (D * q),  c = x - mu,
+//   q = sigma*s^2 (mode 0) or s^3 (mode 1);  dx_out = resid + dx.   t1 = dy1*xhat, t2 = dy2*xhat feed the gamma gradients.
+__global__ __launch_bounds__(256) void k_ln_backward(const float* __restrict__ x, size_t rows, int d, const float* g1, const float* g2,
+                                                     const float* __restrict__ dy1, const float* __restrict__ dy2,
+                                                     const float* __restrict__ resid, float eps, int eps_mode, float* __restrict__ dx,
+                                                     float* __restrict__ t1, float* __restrict__ t2) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * d;
+  float s = 0.f;
+  for (int k = lane; k < d; k += 64) s += xr[k];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mu = s / (float)d;
+  float v = 0.f;
+  for (int k = lane; k < d; k += 64) { const float c = xr[k] - mu; v = fmaf(c, c, v); }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v /= (float)d;
+  const float sigma = sqrtf(v);
+  const float sden = eps_mode == 0 ? sigma + eps : sqrtf(v + eps);
+  const float q = eps_mode == 0 ? sigma * sden * sden : sden * sden * sden;
+  float sum_dxh = 0.f, sum_dxh_c = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    const float c = xr[k] - mu;
+    const float a1 = dy1 ? dy1[row * d + k] : 0.f, a2 = dy2 ? dy2[row * d + k] : 0.f;
+    const float dxh = a1 * g1[k] + a2 * g2[k];
+    sum_dxh += dxh;
+    sum_dxh_c = fmaf(dxh, c, sum_dxh_c);
+    const float xh = c / sden;
+    if (t1) t1[row * d + k] = a1 * xh;
+    if (t2) t2[row * d + k] = a2 * xh;
+  }
+  for (int o = 32; o > 0; o >>= 1) { sum_dxh += __shfl_xor(sum_dxh, o); sum_dxh_c += __shfl_xor(sum_dxh_c, o); }
+  const float mean_dxh = sum_dxh / (float)d;
+  const float coef = q > 0.f ? sum_dxh_c / ((float)d * q) : 0.f;
+  if (dx) {
+    for (int k = lane; k < d; k += 64) {
+      const float c = xr[k] - mu;
+      const float a1 = dy1 ? dy1[row * d + k] : 0.f, a2 = dy2 ? dy2[row * d + k] : 0.f;
+      const float dxh = a1 * g1[k] + a2 * g2[k];
+      dx[row * d + k] = (resid ? resid[row * d + k] : 0.f) + (dxh - mean_dxh) / sden - c * coef;
+    }
+  }
+}
+
+int32_t launch_layernorm2(const float* x, size_t rows, int d, const gnx_layernorm& l1, const gnx_layernorm& l2, float eps, int eps_mode,
+                          float* y1, float* y2, hipStream_t s);
+
+// column sums over ALL rows of a [rows][d] tensor -> out[d] (one "graph" spanning everything), via the two-stage kernels
+static int32_t colsum_all(const float* in, size_t rows, int d, float* out, float* part, int* d_off2, hipStream_t s) {
+  if (!out || d == 0) return GNX_OK;
+  if (rows == 0) { GNX_HIP(hipMemsetAsync(out, 0, sizeof(float) * d, s)); return GNX_OK; }
+  const int S = (int)std::min<size_t>(std::max<size_t>(rows / 2048, 1), 256);
+  hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S, 1, 1), dim3(256), 0, s, in, d, (int)rows, d_off2, S, 1, part);
+  hipLaunchKernelGGL(k_bw_colsum2, dim3(1, 1), dim3(64), 0, s, part, d, S, 1, out, d, 0);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+__global__ void k_set_off2(int* off2, int rows) { off2[0] = 0; off2[1] = rows; }
+
 }  // namespace gnx
 
 using namespace gnx;
@@ -339,6 +419,120 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   if (d_gf && dg)
     hipLaunchKernelGGL(k_bw_dgf, dim3((unsigned)G, Ru), dim3(256), 0, s, have_g ? dXg : nullptr, Kg, oe + on, have_n ? dXn : nullptr, Kn, oe + dn,
                        have_e ? dXe : nullptr, Ke, de + 2 * dn, h->d_node_off, h->d_edge_off, N, E, G, dg, d_gf);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+
+// ---- GNCore backward ----
+namespace {
+struct CoreBwLayout {
+  size_t l1[3], l2[3], bout[3], dl1[3], dz2[3], h, dh, t1, t2, off2, blk_fw, blk_bw, part, total;
+};
+CoreBwLayout core_bw_layout(const gnx_graphs* h, const gnx_core_params* p, int64_t R) {
+  const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
+  const int d[3] = {p->block.de, p->block.dn, p->block.dg};
+  CoreBwLayout L{};
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
+  size_t hmax = 0, tmax = 0;
+  for (int t = 0; t < 3; ++t) {
+    const size_t b = sizeof(float) * rows[t] * d[t];
+    L.l1[t] = take(b); L.l2[t] = take(b); L.bout[t] = take(b); L.dl1[t] = take(b); L.dz2[t] = take(b);
+    hmax = std::max(hmax, sizeof(float) * rows[t] * 4 * (size_t)d[t]);
+    tmax = std::max(tmax, b);
+  }
+  L.h = take(hmax); L.dh = take(hmax); L.t1 = take(tmax); L.t2 = take(tmax); L.off2 = take(64);
+  L.blk_fw = take(gnx_block_workspace_bytes(h, &p->block, R));
+  L.blk_bw = take(gnx_block_backward_workspace_bytes(h, &p->block, R));
+  size_t pmax = sizeof(float) * 256 * 4 * (size_t)std::max(d[0], std::max(d[1], d[2]));
+  for (int t = 0; t < 3; ++t) {
+    const size_t ch = (rows[t] + BW_CH - 1) / BW_CH;
+    pmax = std::max(pmax, sizeof(float) * ch * (size_t)(4 * d[t]) * (d[t] + 1));
+    pmax = std::max(pmax, sizeof(float) * ch * (size_t)d[t] * (4 * d[t] + 1));
+  }
+  L.part = take(pmax);
+  L.total = o + 256;
+  return L;
+}
+}  // namespace
+
+size_t gnx_core_backward_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t R) {
+  if (!h || !p || R <= 0) return 0;
+  return core_bw_layout(h, p, R).total;
+}
+
+int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf, const float* gf,
+                          const float* g_ef_out, const float* g_nf_out, const float* g_gf_out, int64_t R, float* d_ef, float* d_nf,
+                          float* d_gf, const gnx_core_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
+  const gnx_block_params& b = p->block;
+  if (b.de <= 0 || b.dn <= 0 || b.dg <= 0 || b.oe != b.de || b.on != b.dn || b.og != b.dg) return fail(GNX_ERR_DIMS, "GNCore needs dims => dims with all(dims .> 0)");
+  if (!ef || !nf || !gf) return fail(GNX_ERR_INVALID_ARG, "GNCore needs ef, nf and gf");
+  if (R <= 0 || (R > 1 && h->G != 1) || R > 65535) return fail(GNX_ERR_INVALID_ARG, "bad n_replicas");
+  for (int t = 0; t < 3; ++t) {
+    if (p->ff[t].fc2.act != GNX_ACT_IDENTITY || p->ff[t].fc1.act == GNX_ACT_GELU) return fail(GNX_ERR_INVALID_ARG, "core backward: fc2 must be identity, fc1 not gelu");
+  }
+  const CoreBwLayout L = core_bw_layout(h, p, R);
+  if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_core_backward_workspace_bytes()");
+  char* base = static_cast<char*>(ws);
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+  const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
+  const int d[3] = {b.de, b.dn, b.dg};
+  const float* x[3] = {ef, nf, gf};
+  const float* gout[3] = {g_ef_out, g_nf_out, g_gf_out};
+  float* dxo[3] = {d_ef, d_nf, d_gf};
+  const gnx_core_grads none{};
+  const gnx_core_grads& gr = grads ? *grads : none;
+  int32_t rc;
+  auto blocks = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  int* off2 = reinterpret_cast<int*>(base + L.off2);
+  float* part = F(L.part);
+
+  // 1. recompute gn1(x), gn2(x) and the block's outputs
+  for (int t = 0; t < 3; ++t)
+    if ((rc = launch_layernorm2(x[t], rows[t], d[t], p->ln1[t], p->ln2[t], p->eps, p->eps_mode, F(L.l1[t]), F(L.l2[t]), s))) return rc;
+  if ((rc = gnx_block_forward(h, &b, F(L.l1[0]), F(L.l1[1]), F(L.l1[2]), R, F(L.bout[0]), F(L.bout[1]), F(L.bout[2]), base + L.blk_fw,
+                              gnx_block_workspace_bytes(h, &b, R), 0, stream))) return rc;
+  // 2. FeedForward pullback per entity: f = W2 h + b2, h = act1(W1 z + b1), z = gn2(x); upstream of f is g_out
+  for (int t = 0; t < 3; ++t) {
+    float* dz2 = F(L.dz2[t]);
+    if (rows[t] == 0) continue;
+    const int D = d[t], H = 4 * d[t];
+    if (!gout[t]) {  // no upstream gradient on this entity: the FeedForward branch contributes nothing
+      GNX_HIP(hipMemsetAsync(dz2, 0, sizeof(float) * rows[t] * D, s));
+      if (gr.ff[t].fc1.weight) GNX_HIP(hipMemsetAsync(gr.ff[t].fc1.weight, 0, sizeof(float) * (size_t)H * D, s));
+      if (gr.ff[t].fc1.bias) GNX_HIP(hipMemsetAsync(gr.ff[t].fc1.bias, 0, sizeof(float) * H, s));
+      if (gr.ff[t].fc2.weight) GNX_HIP(hipMemsetAsync(gr.ff[t].fc2.weight, 0, sizeof(float) * (size_t)H * D, s));
+      if (gr.ff[t].fc2.bias) GNX_HIP(hipMemsetAsync(gr.ff[t].fc2.bias, 0, sizeof(float) * D, s));
+      continue;
+    }
+    float* hbuf = F(L.h); float* dh = F(L.dh);
+    hipLaunchKernelGGL(k_fw_dense, blocks(rows[t] * H), dim3(256), 0, s, F(L.l2[t]), p->ff[t].fc1.weight, p->ff[t].fc1.bias, rows[t], D, H, p->ff[t].fc1.act, hbuf);
+    if ((rc = dw_reduce(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, s))) return rc;                       // dW2 = g^T h
+    hipLaunchKernelGGL(k_bw_dx, dim3(blocks(rows[t] * H).x, 1), dim3(256), 0, s, gout[t], p->ff[t].fc2.weight, (int)rows[t], D, H, dh, 0, 0, (float*)nullptr, 0);
+    DeltaArgs a{dh, hbuf, dh, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, H, (int)rows[t], 1, p->ff[t].fc1.act, 0};  // delta1 = dh * act1'(h), in place
+    hipLaunchKernelGGL(k_bw_delta, dim3(blocks(rows[t] * H).x, 1), dim3(256), 0, s, a, (size_t)0, (size_t)0);
+    if ((rc = dw_reduce(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1, part, s))) return rc;                      // dW1 = delta1^T z
+    hipLaunchKernelGGL(k_bw_dx, dim3(blocks(rows[t] * D).x, 1), dim3(256), 0, s, dh, p->ff[t].fc1.weight, (int)rows[t], H, D, dz2, 0, 0, (float*)nullptr, 0);
+    GNX_HIP(hipGetLastError());
+  }
+  // 3. block pullback: inputs gn1(x), outputs recomputed above, upstream g_out -> gradients w.r.t. gn1(x)
+  if ((rc = gnx_block_backward(h, &b, F(L.l1[0]), F(L.l1[1]), F(L.l1[2]), F(L.bout[0]), F(L.bout[1]), F(L.bout[2]), g_ef_out, g_nf_out, g_gf_out, R,
+                               F(L.dl1[0]), F(L.dl1[1]), F(L.dl1[2]), &gr.block, base + L.blk_bw, gnx_block_backward_workspace_bytes(h, &b, R), stream))) return rc;
+  // 4. LayerNorm pullbacks (both norms at once) + residual; gamma/beta gradients as column sums over all rows
+  for (int t = 0; t < 3; ++t) {
+    if (rows[t] == 0) continue;
+    float* t1 = F(L.t1); float* t2 = F(L.t2);
+    hipLaunchKernelGGL(k_ln_backward, dim3((unsigned)((rows[t] + 3) / 4)), dim3(256), 0, s, x[t], rows[t], d[t], p->ln1[t].gamma, p->ln2[t].gamma, F(L.dl1[t]),
+                       F(L.dz2[t]), gout[t], p->eps, p->eps_mode, dxo[t], t1, t2);
+    hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows[t]);
+    if ((rc = colsum_all(t1, rows[t], d[t], gr.ln1[t].gamma, part, off2, s))) return rc;
+    if ((rc = colsum_all(F(L.dl1[t]), rows[t], d[t], gr.ln1[t].beta, part, off2, s))) return rc;
+    if ((rc = colsum_all(t2, rows[t], d[t], gr.ln2[t].gamma, part, off2, s))) return rc;
+    if ((rc = colsum_all(F(L.dz2[t]), rows[t], d[t], gr.ln2[t].beta, part, off2, s))) return rc;
+  }
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }

@@ -187,6 +187,27 @@ GNX_API int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* 
                            const float* g_nf_out, const float* g_gf_out, int64_t n_replicas, float* d_ef, float* d_nf,
                            float* d_gf, const gnx_block_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward of (m::GNCore)(x) = x + block(gn1(x)) + ffwd(gn2(x)) (src/gncore.jl:56-68).  Takes the forward's INPUTS and the
+ * upstream gradients; the intermediates (both LayerNorms, the block's outputs, the FeedForward hidden activations) are
+ * recomputed into the workspace.  Gradient buffers are optional (NULL = not wanted) and overwritten.  FeedForward: fc1 with
+ * identity / relu / tanh / sigmoid, fc2 with identity (the reference's Chain(Dense(d,4d,relu), Dense(4d,d))). */
+typedef struct gnx_layernorm_grad {
+  float* gamma;
+  float* beta;
+} gnx_layernorm_grad;
+typedef struct gnx_ffn_grad {
+  gnx_dense_grad fc1, fc2;
+} gnx_ffn_grad;
+typedef struct gnx_core_grads {
+  gnx_block_grads block;
+  gnx_layernorm_grad ln1[3], ln2[3];
+  gnx_ffn_grad ff[3];
+} gnx_core_grads;
+GNX_API size_t gnx_core_backward_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t n_replicas);
+GNX_API int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf, const float* gf,
+                          const float* g_ef_out, const float* g_nf_out, const float* g_gf_out, int64_t n_replicas, float* d_ef,
+                          float* d_nf, float* d_gf, const gnx_core_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- forward: replaces (m::GNCore)(x) (src/gncore.jl:56-68); GNCoreList = caller-side fold (gncorelist.jl:43-45) ---- */
 GNX_API size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t n_replicas);
 GNX_API int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf,

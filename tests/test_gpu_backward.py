@@ -127,3 +127,66 @@ def test_backward_is_deterministic_and_trains(gn):
         opt.step()
     last = float(loss_fn().detach())
     assert np.isfinite(last) and last < 0.7 * first, (first, last)
+
+
+def _torch_ln(x, gamma, beta, eps, eps_mode):
+    mu = x.mean(dim=1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=1, keepdim=True)
+    xh = (x - mu) / (var.sqrt() + eps) if eps_mode == 0 else (x - mu) / (var + eps).sqrt()
+    return xh * gamma + beta
+
+
+@pytest.mark.parametrize("eps_mode", [0, 1])
+@pytest.mark.parametrize("dims", [(3, 4, 5), (10, 5, 3), (40, 36, 33)], ids=str)
+def test_core_backward_matches_torch_autograd(gn, dims, eps_mode):
+    """gnx_core_backward (LayerNorm + FeedForward + block pullbacks, residual) against torch float64 autograd."""
+    rng = np.random.default_rng(400 + sum(dims) + eps_mode)
+    sizes = rng.integers(4, 25, 5)
+    cps, rvs = [], []
+    for n in sizes:
+        cp, rv = U.er_csc(rng, int(n), int(0.2 * n * n) + 1)
+        cps.append(cp); rvs.append(rv)
+    g = gn.GNGraphBatch.from_csc(cps, rvs, [int(n) for n in sizes])
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    p = O.make_core_params(rng, dims, eps_mode=eps_mode)
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims)
+    # reference
+    T = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    W = {k: T(v) for k, v in p.items() if isinstance(v, np.ndarray)}
+    Wb = {k: T(p["block"][k]) for k in ("We", "be", "Wn", "bn", "Wg", "bg")}
+    xs = [T(ef[0]), T(nf[0]), T(gf[0])]
+    l1 = [_torch_ln(x, W[f"ln1_{t}_gamma"], W[f"ln1_{t}_beta"], p["eps"], eps_mode) for x, t in zip(xs, "eng")]
+    l2 = [_torch_ln(x, W[f"ln2_{t}_gamma"], W[f"ln2_{t}_beta"], p["eps"], eps_mode) for x, t in zip(xs, "eng")]
+    blk = _torch_block(p["block"], csc, l1[0], l1[1], l1[2], Wb)
+    outs_r = []
+    for x, z, b, t in zip(xs, l2, blk, "eng"):
+        hdn = torch.relu(z @ W[f"ff_{t}_W1"].T + W[f"ff_{t}_b1"])
+        outs_r.append(x + b + hdn @ W[f"ff_{t}_W2"].T + W[f"ff_{t}_b2"])
+    cot = [torch.from_numpy(rng.standard_normal(tuple(o.shape))) for o in outs_r]
+    sum((o * c).sum() for o, c in zip(outs_r, cot)).backward()
+    # HIP
+    core = U.core_from_params(gn, p)
+    for q in core.parameters():
+        q.requires_grad_(True)
+    dev = g.device
+    leaf = lambda a: torch.from_numpy(a).to(dev).requires_grad_(True)
+    xt = [leaf(ef), leaf(nf), leaf(gf)]
+    y = core(gn.NT(g, *(t.permute(2, 1, 0) for t in xt)))
+    loss = sum((o.permute(2, 1, 0)[0] * c.to(dev).float()).sum() for o, c in zip((y.ef, y.nf, y.gf), cot))
+    loss.backward()
+
+    def close(got, ref, what):
+        ref = ref.detach().numpy(); got = got.detach().double().cpu().numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.max(np.abs(got - ref)) <= 1e-3 * scale, f"{what}: max err {np.max(np.abs(got - ref)):.3e} (scale {scale:.3g})"
+
+    for name, t, r in zip(("d_ef", "d_nf", "d_gf"), xt, xs):
+        close(t.grad[0], r.grad, name)
+    refs = [Wb[k].grad for k in ("We", "be", "Wn", "bn", "Wg", "bg")]
+    for ln in ("ln1", "ln2"):
+        for t in "eng":
+            refs += [W[f"{ln}_{t}_gamma"].grad, W[f"{ln}_{t}_beta"].grad]
+    for t in "eng":
+        refs += [W[f"ff_{t}_W1"].grad, W[f"ff_{t}_b1"].grad, W[f"ff_{t}_W2"].grad, W[f"ff_{t}_b2"].grad]
+    for i, (q, r) in enumerate(zip(core.parameters(), refs)):
+        close(q.grad, r, f"param[{i}]")
