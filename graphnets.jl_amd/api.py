@@ -442,20 +442,38 @@ def flatunpaddedcollapsedef(t):
     return _flat(out)
 
 
+class _XentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):  # a, b: [cols][d] contiguous
+        lib = _lib.load()
+        cols, d = a.shape
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ws = torch.empty(max(int(lib.gnx_xent_workspace_bytes(cols)), 16), dtype=torch.uint8, device=a.device)
+        with torch.cuda.device(a.device):
+            check(lib.gnx_logit_cross_entropy(a.data_ptr(), b.data_ptr(), d, cols, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              torch.cuda.current_stream(a.device).cuda_stream))
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        cols, d = a.shape
+        dl = torch.empty_like(a)
+        up = g.reshape(1).float().contiguous()
+        with torch.cuda.device(a.device):
+            check(_lib.load().gnx_logit_cross_entropy_backward(a.data_ptr(), b.data_ptr(), d, cols, up.data_ptr(), dl.data_ptr(),
+                                                               torch.cuda.current_stream(a.device).cuda_stream))
+        return dl, None
+
+
 def logitcrossentropy(yhat, y):
     """`Flux.logitcrossentropy(ŷ, y)` on (d, cols) arrays such as `flatunpaddednf(ŷ)` (examples/sort/sort.jl:69-81):
-    mean over columns of -sum(y .* logsoftmax(ŷ; dims=1); dims=1).  Returns a 0-d device tensor."""
+    mean over columns of -sum(y .* logsoftmax(ŷ; dims=1); dims=1).  Returns a 0-d device tensor; differentiable w.r.t. ŷ."""
     assert yhat.dim() == 2 and tuple(yhat.shape) == tuple(y.shape), "ŷ and y must be (d, cols) arrays of the same size"
-    lib = _lib.load()
     a = yhat.t().contiguous().float()   # [cols][d] rows = the bytes of a column-major (d, cols) array
     b = y.to(yhat.device).t().contiguous().float()
-    cols, d = a.shape
-    out = torch.empty((), dtype=torch.float32, device=a.device)
-    ws = torch.empty(max(int(lib.gnx_xent_workspace_bytes(cols)), 16), dtype=torch.uint8, device=a.device)
-    with torch.cuda.device(a.device):
-        check(lib.gnx_logit_cross_entropy(a.data_ptr(), b.data_ptr(), d, cols, out.data_ptr(), ws.data_ptr(), ws.numel(),
-                                          torch.cuda.current_stream(a.device).cuda_stream))
-    return out
+    return _XentFn.apply(a, b)
 
 
 def _fn_input(kind, graphs, ef, nf, gf):

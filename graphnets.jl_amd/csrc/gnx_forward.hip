@@ -17,6 +17,7 @@ int32_t launch_ffn_residual(const float* z, const float* x, size_t rows, int d, 
 int32_t launch_pad(const gnx_graphs* h, int kind, bool pad, const float* src, int d, int64_t R, float* dst, hipStream_t s);
 int32_t launch_calibration(int n, hipStream_t s);
 int xent_blocks(int64_t cols);
+int32_t launch_xent_backward(const float* logits, const float* targets, int d, int64_t cols, const float* upstream, float* dl, hipStream_t s);
 int32_t launch_xent(const float* logits, const float* targets, int d, int64_t cols, float* out, float* ws, hipStream_t s);
 int32_t launch_collapse(const gnx_graphs* h, const float* ef, int d, int64_t R, float* out, hipStream_t s);
 int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, const float* nf, int dn, const float* gf, int dg,
@@ -249,6 +250,13 @@ int32_t gnx_logit_cross_entropy(const float* logits, const float* targets, int32
   if (d <= 0 || cols <= 0) return fail(GNX_ERR_INVALID_ARG, "d and cols must be >= 1");
   if (!ws || ws_bytes < gnx_xent_workspace_bytes(cols)) return fail(GNX_ERR_WORKSPACE, "workspace missing or too small");
   return launch_xent(logits, targets, d, cols, loss_out, static_cast<float*>(ws), (hipStream_t)stream);
+}
+
+int32_t gnx_logit_cross_entropy_backward(const float* logits, const float* targets, int32_t d, int64_t cols, const float* upstream,
+                                         float* d_logits, void* stream) {
+  if (!logits || !targets || !upstream || !d_logits) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  if (d <= 0 || cols <= 0) return fail(GNX_ERR_INVALID_ARG, "d and cols must be >= 1");
+  return launch_xent_backward(logits, targets, d, cols, upstream, d_logits, (hipStream_t)stream);
 }
 
 int32_t gnx_collapse_edges(const gnx_graphs* h, const float* ef, int32_t d, int64_t R, float* out, void* stream) {

@@ -438,6 +438,26 @@ __global__ __launch_bounds__(256) void k_xent_final(const float* __restrict__ pa
   if (threadIdx.x == 0) out[0] = s_red[0] / (float)cols;
 }
 
+__global__ void k_xent_backward(const float* __restrict__ logits, const float* __restrict__ targets, int d, size_t cols,
+                                const float* __restrict__ upstream, float* __restrict__ dl) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const float* x = logits + c * d;
+  const float* y = targets + c * d;
+  float mx = x[0];
+  for (int k = 1; k < d; ++k) mx = fmaxf(mx, x[k]);
+  float se = 0.f, ysum = 0.f;
+  for (int k = 0; k < d; ++k) { se += expf(x[k] - mx); ysum += y[k]; }
+  const float g = upstream[0] / (float)cols;
+  for (int k = 0; k < d; ++k) dl[c * d + k] = g * (ysum * expf(x[k] - mx) / se - y[k]);
+}
+
+int32_t launch_xent_backward(const float* logits, const float* targets, int d, int64_t cols, const float* upstream, float* dl, hipStream_t s) {
+  hipLaunchKernelGGL(k_xent_backward, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, logits, targets, d, (size_t)cols, upstream, dl);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
 int xent_blocks(int64_t cols) { return (int)std::min<int64_t>(std::max<int64_t>((cols + 255) / 256, 1), 1024); }
 
 int32_t launch_xent(const float* logits, const float* targets, int d, int64_t cols, float* out, float* ws, hipStream_t s) {

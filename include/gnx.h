@@ -243,6 +243,11 @@ GNX_API size_t gnx_xent_workspace_bytes(int64_t cols);
 GNX_API int32_t gnx_logit_cross_entropy(const float* logits, const float* targets, int32_t d, int64_t cols, float* loss_out,
                                 void* workspace, size_t workspace_bytes, void* stream);
 
+/* pullback of gnx_logit_cross_entropy w.r.t. the logits: d_logits[c][k] = g * (sum_k' y[k',c] * softmax(yhat[:,c])[k] - y[k,c]) / cols,
+ * g = *upstream (ONE device float, the gradient of the scalar loss) */
+GNX_API int32_t gnx_logit_cross_entropy_backward(const float* logits, const float* targets, int32_t d, int64_t cols,
+                                         const float* upstream, float* d_logits, void* stream);
+
 /* ---- reference-layout bridges: padef/padnf and unpadef/unpadnf (src/pad.jl:12-64, src/unpad.jl:1-17) ----
  * kind 0 = edges: packed [R][E][d] <-> padded [B][PN^2][d];  kind 1 = nodes: packed [R][N][d] <-> padded [B][PN][d],
  * where B = R (one graph in the handle) or G (R must be 1).  Pads are written as zeros. */

@@ -190,3 +190,33 @@ def test_core_backward_matches_torch_autograd(gn, dims, eps_mode):
         refs += [W[f"ff_{t}_W1"].grad, W[f"ff_{t}_b1"].grad, W[f"ff_{t}_W2"].grad, W[f"ff_{t}_b2"].grad]
     for i, (q, r) in enumerate(zip(core.parameters(), refs)):
         close(q.grad, r, f"param[{i}]")
+
+
+def test_readout_loss_is_differentiable(gn):
+    rng = np.random.default_rng(500)
+    yhat = torch.from_numpy(rng.standard_normal((5, 37)).astype(np.float32)).cuda().requires_grad_(True)
+    tgt = torch.from_numpy(np.eye(5, dtype=np.float32)[rng.integers(0, 5, 37)].T.copy()).cuda()
+    gn.logitcrossentropy(yhat, tgt).backward()
+    ref = yhat.detach().double().cpu().requires_grad_(True)
+    torch.nn.functional.cross_entropy(ref.t(), tgt.cpu().argmax(0)).backward()
+    assert torch.allclose(yhat.grad.double().cpu(), ref.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_end_to_end_training_sort_example(gn):
+    """examples/train_sort.py (analogue of the reference's examples/sort): the loss must go down when a
+    GNBlock -> 2 x GNCore -> GNBlock model is trained with AdamW through the HIP forward and backward kernels."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_sort.py")
+    spec = importlib.util.spec_from_file_location("train_sort", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    sys.argv = ["train_sort.py", "--iters", "120", "--graphs", "32", "--n", "6", "--width", "8"]
+    try:
+        hist = mod.main()
+    finally:
+        sys.argv = argv
+    assert np.isfinite(hist).all()
+    assert np.mean(hist[-10:]) < 0.75 * np.mean(hist[:5]), (hist[:5], hist[-10:])
