@@ -31,7 +31,7 @@ MFMA_F32_PEAK_TFS = 157.3  # exact-f32 MFMA (v_mfma_f32_32x32x2_f32); no xf32 on
 NSETS = 8                  # rotating buffer sets: 8 x ~60 MB > 256 MiB Infinity Cache
 NULL_KERNEL_ROCPROF_US = 3.64  # rocprofv3 kernel-trace duration of an empty launch (profiles/r01_readme_rocprofv3_kernel_stats_raw.csv, gnx::k_null)
 DIMS = {"readme": ((10, 5, 0), (3, 4, 5)), "core": ((128, 64, 32), (128, 64, 32)),
-        "odd": ((7, 3, 2), (5, 6, 1)), "mid": ((20, 10, 4), (12, 9, 3))}  # odd: generic kernels; mid: MFMA path
+        "odd": ((7, 3, 2), (5, 6, 1)), "mid": ((20, 10, 4), (12, 9, 3))}  # odd: fused kernel specialised at run time (GNX_JIT=0: generic kernels); mid: generic/MFMA path
 
 
 def make_c2(seed=2, N=100_000, E=1_000_000):

@@ -110,6 +110,8 @@ SIGNATURES = {
     "gnx_logit_cross_entropy_backward": (C.c_int32, [_fp, _fp, C.c_int32, C.c_int64, _fp, _fp, C.c_void_p]),
     "gnx_pad_features": (C.c_int32, [C.c_void_p, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),
     "gnx_unpad_features": (C.c_int32, [C.c_void_p, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),
+    "gnx_jit_precompile": (C.c_int32, [C.POINTER(BlockParams), C.c_int32, C.POINTER(C.c_size_t)]),
+    "gnx_jit_stats": (C.c_int32, [_i64p]),
     "gnx_profile_enable": (C.c_int32, [C.c_int32]),
     "gnx_profile_reset": (C.c_int32, []),
     "gnx_profile_calibrate": (C.c_int32, [C.c_int32, C.c_void_p]),

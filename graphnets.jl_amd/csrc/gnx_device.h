@@ -1,10 +1,25 @@
 // Device-side argument block and helpers shared by the kernel translation units.
+// This header and gnx_wave_kernel.h are ALSO the source text of the run-time specialised kernels (gnx_jit.cpp compiles
+// them with hiprtc for width sets outside the ahead-of-time list), so they depend on nothing but the HIP device
+// runtime: no host headers, no fixed-width typedefs.
 #pragma once
+#ifndef GNX_JIT
 #include <hip/hip_runtime.h>
-
-#include "gnx_internal.h"
+#endif
 
 namespace gnx {
+
+// A work tile: a contiguous node range [n0, n1) of ONE graph and its (contiguous, dst-sorted) in-edges
+// [e0, e1) = [colptr[n0], colptr[n1]).  Because the reference's edge order is CSC order
+// (src/pad.jl:30), every edge->node sum is complete inside its tile: no atomics, fixed summation order.
+struct Tile {
+  int n0, n1;
+  int e0, e1;
+  int g;        // graph id
+  int win0;     // [win0, win1): the graph's node range — every source of the tile's edges lies inside it
+  int win1;
+  int flags;    // reserved (keeps the record 32 B = one s_load_dwordx8)
+};
 
 // Everything a block-forward kernel needs, passed by value (lives in SGPRs / kernarg segment).
 struct BlockArgs {
@@ -27,12 +42,13 @@ struct BlockArgs {
   int N, E, G, n_tiles, n_wtiles;
 };
 
+// activation codes = GNX_ACT_* of include/gnx.h (static_assert'ed in gnx_forward.hip)
 __device__ __forceinline__ float act_apply(float x, int act) {
   switch (act) {
-    case GNX_ACT_RELU: return fmaxf(x, 0.f);
-    case GNX_ACT_TANH: return tanhf(x);
-    case GNX_ACT_SIGMOID: return 1.f / (1.f + expf(-x));
-    case GNX_ACT_GELU: return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+    case 1: return fmaxf(x, 0.f);
+    case 2: return tanhf(x);
+    case 3: return 1.f / (1.f + expf(-x));
+    case 4: return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));  // NNlib.gelu (tanh form)
     default: return x;
   }
 }
@@ -48,3 +64,7 @@ __device__ __forceinline__ int segment_of(const int* cp, int n, int e) {
 }
 
 }  // namespace gnx
+
+#ifndef GNX_JIT
+#include "gnx_internal.h"
+#endif

@@ -25,6 +25,9 @@ int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, 
 // returns 1 when the path does not apply to these dims (caller falls through to the next path)
 // phase bit 1: edge + node update (leaves per-tile partial sums in the workspace); bit 2: graph update from them
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase);
+void warm_block_narrow(const gnx_graphs* h, const gnx_block_params* p);
+static_assert(GNX_ACT_IDENTITY == 0 && GNX_ACT_RELU == 1 && GNX_ACT_TANH == 2 && GNX_ACT_SIGMOID == 3 && GNX_ACT_GELU == 4,
+              "act_apply (gnx_device.h) hard-codes the activation codes");
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase);
 size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R);
 // narrow-width GNCore kernels (gnx_core_narrow.hip)
@@ -106,7 +109,7 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   a.N = (int)h->N; a.E = (int)h->E; a.G = (int)h->G; a.n_tiles = (int)h->n_tiles();
 
   if (!(flags & GNX_FLAG_FORCE_GENERIC)) {
-    rc = launch_block_narrow(h, a, R, s, phase);  // fused wave-per-tile kernel for the instantiated narrow width sets
+    rc = launch_block_narrow(h, a, R, s, phase);  // fused wave-per-tile kernel: ahead-of-time width sets, else specialised at run time
     if (rc != 1) return rc;
     if (!(flags & GNX_FLAG_NO_MFMA)) {
       rc = launch_block_wide(h, a, R, s, phase);  // fp32 MFMA gathered-row GEMMs
@@ -126,6 +129,7 @@ extern "C" {
 
 size_t gnx_block_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
   if (!h || !p || R <= 0) return 0;
+  if (check_block(h, p, R) == GNX_OK) warm_block_narrow(h, p);  // run-time specialisation happens here, not in a capture
   return block_ws(h, p, R).total;
 }
 

@@ -9,21 +9,7 @@
 
 #include "gnx.h"
 
-namespace gnx {
-
-// A work tile: a contiguous node range [n0, n1) of ONE graph and its (contiguous, dst-sorted) in-edges
-// [e0, e1) = [colptr[n0], colptr[n1]).  Because the reference's edge order is CSC order
-// (src/pad.jl:30), every edge->node sum is complete inside its tile: no atomics, fixed summation order.
-struct Tile {
-  int32_t n0, n1;
-  int32_t e0, e1;
-  int32_t g;        // graph id
-  int32_t win0;     // [win0, win1): the graph's node range — every source of the tile's edges lies inside it
-  int32_t win1;
-  int32_t flags;    // reserved (keeps the record 32 B = one s_load_dwordx8)
-};
-
-}  // namespace gnx
+#include "gnx_device.h"  // gnx::Tile, gnx::BlockArgs
 
 struct gnx_graphs {
   int64_t G = 0, N = 0, E = 0, PN = 0;

@@ -1,393 +1,22 @@
-// Fused GNBlock kernel for narrow feature widths (README-sized dims): ONE launch does the edge update, the
-// edge->node segmented sum, the node update and the per-tile partial sums of the graph update.
+// Fused GNBlock path for narrow feature widths (README-sized dims): ONE launch does the edge update, the
+// edge->node segmented sum, the node update and the per-tile partial sums of the graph update; a second tiny launch
+// finishes the graph update.  The kernels themselves live in gnx_wave_kernel.h (self-contained device code).
 //
 // Why it can be fused: the reference's edge order is CSC order (src/pad.jl:30 — sorted by destination), so the
-// in-edges of a node range [n0, n1) are the contiguous edge range [colptr[n0], colptr[n1]).  A workgroup that owns
+// in-edges of a node range [n0, n1) are the contiguous edge range [colptr[n0], colptr[n1]).  A wavefront that owns
 // a node tile therefore owns every edge that aggregates into it: ef' never has to be re-read from HBM, the
 // edge->node sum (nodefninput.jl:3) needs no atomics, and its order is fixed.
 //
-// Data movement per tile (256 threads, wave64):
-//   HBM -> LDS   ef rows of the tile as ONE flat contiguous range, 16-B loads (coalesced along the feature dim);
-//                node rows: the tile's own nodes, or the whole graph's node window when it is small (then the
-//                nf[src] gather of edgefninput.jl:4 is served from LDS; otherwise it is a global/L2 row gather)
-//   compute      weights are wave-uniform -> scalar loads / SGPR operands; gf[g] is folded into a per-tile bias
-//   LDS -> HBM   ef' and nf' of the tile as flat contiguous ranges, 16-B stores
-// Dims are template parameters (fully unrolled FMAs); launch_block_narrow() dispatches over the instantiated
-// set and reports "not applicable" (1) otherwise, in which case the generic kernels run.
+// Widths are template parameters (fully unrolled FMAs, weights as scalar operands).  launch_block_narrow() first
+// looks the width set up in the ahead-of-time list below; any other width set with every width <= 16 is specialised
+// at run time (gnx_jit.cpp: hiprtc on the same header text) — the analogue of Julia compiling a GNBlock for its own
+// dims on first use.  1 ("not applicable") sends the caller on to the MFMA / generic kernels.
 #include <cstdlib>
 
 #include "gnx_device.h"
+#include "gnx_wave_kernel.h"
 
 namespace gnx {
-
-namespace {
-
-constexpr int kThreads = 256;
-
-// dword-aligned multi-dword accesses: gfx950 global loads/stores of 8/12/16 B only need 4-B alignment, so a feature
-// row of D floats moves in ceil(D/4) instructions whatever D is.
-struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
-struct __attribute__((packed, aligned(4))) F3u { float x, y, z; };
-struct __attribute__((packed, aligned(4))) F2u { float x, y; };
-
-// Weights / biases are read-only for the whole launch and their indices are wave-uniform.  Reading them through the
-// constant address space makes hipcc emit scalar loads (s_load_*, SGPR operands of v_fma) instead of per-lane vector
-// loads — with plain global pointers the stores of this kernel make them "clobberable" and they land in VGPRs.
-typedef const float __attribute__((address_space(4))) * cfloatp;
-__device__ __forceinline__ cfloatp as_const(const float* p) { return reinterpret_cast<cfloatp>(reinterpret_cast<uintptr_t>(p)); }
-
-template <int D>
-__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&x)[D > 0 ? D : 1]) {
-  constexpr int Q = D / 4, R = D % 4;
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const F4u v = *reinterpret_cast<const F4u*>(p + 4 * q);
-    x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-  }
-  if constexpr (R == 3) {
-    const F3u v = *reinterpret_cast<const F3u*>(p + 4 * Q);
-    x[4 * Q] = v.x; x[4 * Q + 1] = v.y; x[4 * Q + 2] = v.z;
-  } else if constexpr (R == 2) {
-    const F2u v = *reinterpret_cast<const F2u*>(p + 4 * Q);
-    x[4 * Q] = v.x; x[4 * Q + 1] = v.y;
-  } else if constexpr (R == 1) {
-    x[4 * Q] = p[4 * Q];
-  }
-}
-
-template <int D>
-__device__ __forceinline__ void store_row(float* __restrict__ p, const float (&x)[D > 0 ? D : 1]) {
-  constexpr int Q = D / 4, R = D % 4;
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    F4u v; v.x = x[4 * q]; v.y = x[4 * q + 1]; v.z = x[4 * q + 2]; v.w = x[4 * q + 3];
-    *reinterpret_cast<F4u*>(p + 4 * q) = v;
-  }
-  if constexpr (R == 3) {
-    F3u v; v.x = x[4 * Q]; v.y = x[4 * Q + 1]; v.z = x[4 * Q + 2];
-    *reinterpret_cast<F3u*>(p + 4 * Q) = v;
-  } else if constexpr (R == 2) {
-    F2u v; v.x = x[4 * Q]; v.y = x[4 * Q + 1];
-    *reinterpret_cast<F2u*>(p + 4 * Q) = v;
-  } else if constexpr (R == 1) {
-    p[4 * Q] = x[4 * Q];
-  }
-}
-
-// XCD-aware block -> tile map: blocks b and b+8 share an XCD (and its L2), so give every XCD one contiguous
-// chunk of tiles; tiles of one graph (which share the graph's node rows) then meet in one L2.  Bijective for any nt.
-__device__ __forceinline__ int xcd_tile(int b, int nt) {
-  const int per = nt >> 3, rem = nt & 7;
-  const int x = b & 7, i = b >> 3;
-  return x * per + (x < rem ? x : rem) + i;
-}
-
-// sum over the 16 lanes of a DPP row, result in every lane of the row; pure VALU (no LDS), order-symmetric
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);  // row_half_mirror
-  v = dpp_add<0x140>(v);  // row_mirror
-  return v;
-}
-
-}  // namespace
-
-__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-// sum over the 64 lanes of the wave, same bits in every lane, fixed association
-__device__ __forceinline__ float wave_sum(float v) {
-  v = row16_sum(v);
-  return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
-}
-
-// =========================================================================================================
-// k_block_wave — the whole GNBlock edge + node update, ONE WAVEFRONT PER TILE.
-//
-// A wave tile is a node range of one graph with <= 64 nodes and <= 64*EPT in-edges (contiguous, CSC order).  The
-// wave owns every edge that aggregates into its nodes, so the edge->node sum needs no atomics and no workgroup
-// barrier: lanes exchange data through a wave-private LDS slice (LDS operations of one wave execute in order), and
-// reductions are DPP + readlane.  A workgroup is just four independent waves; 28-32 of them are resident per CU at
-// different points of their (load -> gather -> compute -> store) chain, which is what overlaps HBM with compute.
-//   lanes as EDGES : EPT edges per lane — ef row (dword-aligned 16-B loads), rowval, nf[src] row gather, W*x, store
-//   lanes as NODES : lane n < nn — colptr, own nf row, pd[n] = b + We[:,dst]*nf[n] (+ gf fold), segmented sum of
-//                    ef' from LDS, node update, store
-// =========================================================================================================
-template <int DE, int DN, int DG, int OE, int ON, int EPT>
-__global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_stride) {
-  constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1;
-  constexpr int TEW = 64 * EPT;
-  constexpr int C = OE + ON, C1 = C > 0 ? C : 1;
-  constexpr int WAVES = kThreads / 64;
-  __shared__ __attribute__((aligned(16))) float s_out_all[WAVES][TEW * OE + 4];  // ef' of the wave's tile
-  __shared__ __attribute__((aligned(16))) float s_pd_all[WAVES][64 * OE + 4];    // per node: bias' + We[:, dst-seg]*nf[n]
-  __shared__ unsigned char s_dst_all[WAVES][TEW + 4];                             // tile-local destination of each edge
-
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wt = __builtin_amdgcn_readfirstlane(xcd_tile(blockIdx.x, gridDim.x) * WAVES + wv);
-  if (wt >= a.n_wtiles) return;  // wave-uniform; the kernel has no workgroup barrier
-  float* s_out = s_out_all[wv];
-  float* s_pd = s_pd_all[wv];
-  unsigned char* s_dst = s_dst_all[wv];
-
-  typedef const int __attribute__((address_space(4))) * cintp;
-  const cintp tw = reinterpret_cast<cintp>(reinterpret_cast<uintptr_t>(a.wtiles)) + (size_t)wt * (sizeof(Tile) / sizeof(int));
-  const int n0 = tw[0], n1 = tw[1], e0 = tw[2], e1 = tw[3], g = tw[4];  // s_load_dwordx8
-  const int nn = n1 - n0, ne = e1 - e0;
-
-  const size_t r = blockIdx.y;
-  const float* __restrict__ ef = DE > 0 ? a.ef + r * (size_t)a.E * DE : nullptr;
-  const float* __restrict__ nf = DN > 0 ? a.nf + r * (size_t)a.N * DN : nullptr;
-  const cfloatp gf = DG > 0 ? as_const(a.gf + (r * (size_t)a.G + g) * DG) : nullptr;
-  const cfloatp We = as_const(a.We);
-  const cfloatp Wn = as_const(a.Wn);
-  const cfloatp be = as_const(a.be);
-  const cfloatp bn = as_const(a.bn);
-
-  // ---- issue every load up front, branch-free (indices clamped into the tile; results of clamped lanes unused) ----
-  const bool is_node = lane < nn;
-  const int nl = lane < nn ? lane : nn - 1;
-  const int cp0 = a.colptr[n0 + nl], cp1 = a.colptr[n0 + nl + 1];
-  float xn[DN1];
-  if constexpr (DN > 0) load_row<DN>(nf + (size_t)(n0 + nl) * DN, xn);
-  const int cn0 = ne < TEW ? ne : TEW;
-  float x[EPT][DE1];
-  float xs[EPT][DN1];
-  int src[EPT];
-#pragma unroll
-  for (int i = 0; i < EPT; ++i) {
-    int ec = lane + 64 * i;
-    ec = ec < cn0 ? ec : cn0 - 1;
-    int e = e0 + (ec > 0 ? ec : 0);
-    e = e < a.E ? e : a.E - 1;
-    if constexpr (DE > 0) load_row<DE>(ef + (size_t)e * DE, x[i]);
-    if constexpr (DN > 0) src[i] = a.rowval[e];
-  }
-  if constexpr (DN > 0) {
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) load_row<DN>(nf + (size_t)src[i] * DN, xs[i]);
-  }
-
-  // ---- lanes as nodes: destination index of each in-edge, per-node part of the edge update ----
-  //   pd[n] = be + We[:, gf-seg] * gf[g] + We[:, dst-seg] * nf[n]      (edgefninput.jl:5-6 hoisted out of the edge loop)
-  if (is_node) {
-    if (nn > 1)
-      for (int e = cp0 - e0; e < cp1 - e0; ++e) s_dst[e] = (unsigned char)lane;
-    if constexpr (OE > 0) {
-#pragma unroll
-      for (int j = 0; j < OE; ++j) {
-        float b = a.be ? be[j] : 0.f;
-#pragma unroll
-        for (int k = 0; k < DG; ++k) b = fmaf(We[(DE + 2 * DN + k) * OE + j], gf[k], b);
-#pragma unroll
-        for (int k = 0; k < DN; ++k) b = fmaf(We[(DE + DN + k) * OE + j], xn[k], b);
-        s_pd[lane * OE + j] = b;
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-
-  // ---- lanes as edges ----
-  float psum[OE1];  // single-node tiles only: this lane's share of the node's edge sum
-#pragma unroll
-  for (int j = 0; j < OE1; ++j) psum[j] = 0.f;
-  for (int c0 = 0; c0 < ne; c0 += TEW) {
-    const int cn = (ne - c0) < TEW ? (ne - c0) : TEW;
-    if (c0 > 0) {  // further chunks of a single-node tile with a huge in-degree: loaded in place
-#pragma unroll
-      for (int i = 0; i < EPT; ++i) {
-        int ec = lane + 64 * i;
-        ec = ec < cn ? ec : cn - 1;
-        const int e = e0 + c0 + ec;
-        if constexpr (DE > 0) load_row<DE>(ef + (size_t)e * DE, x[i]);
-        if constexpr (DN > 0) {
-          src[i] = a.rowval[e];
-          load_row<DN>(nf + (size_t)src[i] * DN, xs[i]);
-        }
-      }
-    }
-    if constexpr (OE > 0) {
-#pragma unroll
-      for (int i = 0; i < EPT; ++i) {
-        const int el = lane + 64 * i;
-        if (el < cn) {
-          const int dl = nn > 1 ? (int)s_dst[el] : 0;
-          float acc[OE1];
-#pragma unroll
-          for (int j = 0; j < OE; ++j) acc[j] = s_pd[dl * OE + j];
-#pragma unroll
-          for (int k = 0; k < DE; ++k)
-#pragma unroll
-            for (int j = 0; j < OE; ++j) acc[j] = fmaf(We[k * OE + j], x[i][k], acc[j]);
-#pragma unroll
-          for (int k = 0; k < DN; ++k)
-#pragma unroll
-            for (int j = 0; j < OE; ++j) acc[j] = fmaf(We[(DE + k) * OE + j], xs[i][k], acc[j]);
-#pragma unroll
-          for (int j = 0; j < OE; ++j) acc[j] = act_apply(acc[j], a.act_e);
-          store_row<OE>(a.ef_out + (r * (size_t)a.E + e0 + c0 + el) * OE, acc);
-          if (nn > 1) {
-#pragma unroll
-            for (int j = 0; j < OE; ++j) s_out[el * OE + j] = acc[j];
-          } else {
-#pragma unroll
-            for (int j = 0; j < OE; ++j) psum[j] += acc[j];
-          }
-        }
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-
-  // ---- lanes as nodes: edge->node sum (nodefninput.jl:3), node update ----
-  float v[C1];  // per-lane contribution to the tile's graph-level partial sums: [agg ; nf']
-#pragma unroll
-  for (int c = 0; c < C1; ++c) v[c] = 0.f;
-  if constexpr (OE > 0) {
-    if (nn == 1) {
-#pragma unroll
-      for (int j = 0; j < OE; ++j) {
-        const float tot = wave_sum(psum[j]);
-        v[j] = lane == 0 ? tot : 0.f;
-      }
-    } else if (is_node) {  // contiguous segmented sum (edges are dst-sorted, src/pad.jl:30), fixed order
-      for (int e = cp0 - e0; e < cp1 - e0; ++e) {
-#pragma unroll
-        for (int j = 0; j < OE; ++j) v[j] += s_out[e * OE + j];
-      }
-    }
-  }
-  if constexpr (ON > 0) {
-    if (is_node) {
-      float acc[ON1];
-#pragma unroll
-      for (int j = 0; j < ON; ++j) {
-        float b = a.bn ? bn[j] : 0.f;
-#pragma unroll
-        for (int k = 0; k < DG; ++k) b = fmaf(Wn[(OE + DN + k) * ON + j], gf[k], b);
-        acc[j] = b;
-      }
-#pragma unroll
-      for (int k = 0; k < OE; ++k)
-#pragma unroll
-        for (int j = 0; j < ON; ++j) acc[j] = fmaf(Wn[k * ON + j], v[k], acc[j]);
-#pragma unroll
-      for (int k = 0; k < DN; ++k)
-#pragma unroll
-        for (int j = 0; j < ON; ++j) acc[j] = fmaf(Wn[(OE + k) * ON + j], xn[k], acc[j]);
-#pragma unroll
-      for (int j = 0; j < ON; ++j) {
-        acc[j] = act_apply(acc[j], a.act_n);
-        v[OE + j] = acc[j];
-      }
-      store_row<ON>(a.nf_out + (r * (size_t)a.N + n0 + lane) * ON, acc);
-    }
-  }
-
-  // ---- per-tile partial sums for the graph update (graphfninput.jl:3-4): sum_e ef' = sum_n agg[n], sum_n nf'.
-  //      Stored transposed [c][tile] so the graph kernel reads them with 16-B loads. ----
-  if (a.og > 0) {
-    if constexpr (C > 0) {
-      float mine = 0.f;
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const float tot = wave_sum(v[c]);
-        mine = lane == c ? tot : mine;
-      }
-      if (lane < C) a.partials[(r * C + lane) * (size_t)prow_stride + wt] = mine;
-    }
-  }
-}
-
-// Graph update for the wave path: gf'[g] = act(Wg * [sum_e ef' ; sum_n nf' ; gf_g] + bg) from transposed partials
-// [C][prow_stride].  Latency is everything here (a few KB of work): EVERY global load — this thread's partial quads,
-// its slice of Wg / bg / gf — is issued before the first wait, so the kernel pays one memory round trip; the sums
-// are reduced with DPP + one LDS hop in a fixed order.
-template <int C>
-__global__ void k_graph_t(BlockArgs a, int prow_stride) {
-  extern __shared__ float s_g[];
-  constexpr int MAXQ = 2;  // quads per thread kept in registers per pass
-  const int g = blockIdx.x;
-  const size_t r = blockIdx.y;
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int t0 = a.wtile_off[g], t1 = a.wtile_off[g + 1];
-  const float* __restrict__ base = a.partials + r * C * (size_t)prow_stride;
-  const int K = C + a.dg, og = a.og;
-  const int nrow16 = nthr >> 4;
-  float* s_x = s_g + (size_t)nrow16 * C;  // [K]   graph-function input
-  float* s_w = s_x + K + 4;               // [K*og] weights, [og] bias
-
-  // prefetch weights / bias / gf (tiny, L2) — independent of the partial sums
-  const int nw = K * og;
-  float w_reg[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + i * nthr;
-    w_reg[i] = idx < nw ? a.Wg[idx] : (idx < nw + og ? (a.bg ? a.bg[idx - nw] : 0.f) : 0.f);
-  }
-  float gf_reg = 0.f;
-  if (tid < a.dg) gf_reg = a.gf[(r * (size_t)a.G + g) * a.dg + tid];
-
-  float acc[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) acc[c] = 0.f;
-  for (int q0 = (t0 >> 2) + tid; 4 * q0 < t1; q0 += MAXQ * nthr) {
-    float4 val[MAXQ][C];
-#pragma unroll
-    for (int u = 0; u < MAXQ; ++u) {
-      const int q = q0 + u * nthr;
-      if (4 * q < t1) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) val[u][c] = *reinterpret_cast<const float4*>(base + (size_t)c * prow_stride + 4 * q);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < MAXQ; ++u) {
-      const int row = 4 * (q0 + u * nthr);
-      if (row < t1) {
-        const bool k0 = row >= t0, k1 = row + 1 >= t0 && row + 1 < t1, k2 = row + 2 >= t0 && row + 2 < t1, k3 = row + 3 < t1;
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-          acc[c] += ((k0 ? val[u][c].x : 0.f) + (k1 ? val[u][c].y : 0.f)) + ((k2 ? val[u][c].z : 0.f) + (k3 ? val[u][c].w : 0.f));
-      }
-    }
-  }
-  // weights to LDS (loads have long since landed)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + i * nthr;
-    if (idx < nw + og) s_w[idx] = w_reg[i];
-  }
-  for (int idx = tid + 4 * nthr; idx < nw + og; idx += nthr) s_w[idx] = idx < nw ? a.Wg[idx] : (a.bg ? a.bg[idx - nw] : 0.f);
-  if (tid < a.dg) s_x[C + tid] = gf_reg;
-  for (int k = tid + nthr; k < a.dg; k += nthr) s_x[C + k] = a.gf[(r * (size_t)a.G + g) * a.dg + k];
-  const int lane = tid & 63, row16 = tid >> 4;
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float x = row16_sum(acc[c]);
-    if ((lane & 15) == 0) s_g[row16 * C + c] = x;
-  }
-  __syncthreads();
-  // second stage: wave 0 sums the <= 64 row sums of every column (fixed order: DPP tree + 4 readlanes)
-  if (tid < 64) {
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float x = wave_sum(tid < nrow16 ? s_g[tid * C + c] : 0.f);
-      if (tid == 0) s_x[c] = x;
-    }
-  }
-  __syncthreads();
-  float* out = a.gf_out + (r * (size_t)a.G + g) * og;
-  for (int j = tid; j < og; j += nthr) {
-    float y = s_w[nw + j];
-    for (int k = 0; k < K; ++k) y = fmaf(s_w[k * og + j], s_x[k], y);
-    out[j] = act_apply(y, a.act_g);
-  }
-}
 
 template <int DE, int DN, int DG, int OE, int ON, int EPT>
 static int32_t launch_wave_t(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
@@ -436,6 +65,48 @@ static int32_t launch_fused(const gnx_graphs* h, const BlockArgs& a, int64_t R, 
   X(10, 5, 3, 10, 5)       \
   X(10, 5, 0, 10, 5)
 
+bool jit_eligible(const BlockArgs& a, int ept);
+int32_t jit_get(const BlockArgs& a, int ept, hipStream_t s, hipFunction_t* block, hipFunction_t* graph);
+
+// Same launch geometry as launch_wave_t, kernels specialised at run time (gnx_jit.cpp) for this width set.
+static int32_t launch_wave_jit(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
+  const int ept = h->wtile_e_cap / 64;
+  if (ept * 64 != h->wtile_e_cap || (ept != 1 && ept != 2 && ept != 4)) return 1;
+  hipFunction_t fb = nullptr, fg = nullptr;
+  const int32_t rc = jit_get(a, ept, s, &fb, &fg);
+  if (rc) return rc;
+  const int C = a.oe + a.on;
+  BlockArgs aa = a;
+  int prow_stride = (int)((h->n_wtiles() + 3) / 4 * 4 + 4);
+  void* params[] = {&aa, &prow_stride};
+  if (phase & 1) {
+    ProfScope ps("k_block_wave", s);
+    GNX_HIP(hipModuleLaunchKernel(fb, (unsigned)((a.n_wtiles + 3) / 4), (unsigned)R, 1, kThreads, 1, 1, 0, s, params, nullptr));
+  }
+  if ((phase & 2) && a.og > 0) {
+    const int64_t rows_per_graph = (h->n_wtiles() + h->G - 1) / h->G;
+    const int threads = rows_per_graph > 1024 ? 1024 : (rows_per_graph > 128 ? 256 : 64);
+    const size_t lds = sizeof(float) * ((size_t)(threads / 16) * C + (C + a.dg + 4) + (size_t)(C + a.dg + 1) * a.og + 8);
+    ProfScope ps("k_graph_t", s);
+    GNX_HIP(hipModuleLaunchKernel(fg, (unsigned)a.G, (unsigned)R, 1, threads, 1, 1, (unsigned)lds, s, params, nullptr));
+  }
+  return GNX_OK;
+}
+
+// compiles + loads the run-time specialised kernels of this width set ahead of the first forward (called from
+// gnx_block_workspace_bytes, which every caller runs before a forward and never inside a stream capture)
+void warm_block_narrow(const gnx_graphs* h, const gnx_block_params* p) {
+  BlockArgs a{};
+  a.de = p->de; a.dn = p->dn; a.dg = p->dg; a.oe = p->oe; a.on = p->on; a.og = p->og;
+#define GNX_CASE(DE, DN, DG, OE, ON) \
+  if (a.de == DE && a.dn == DN && a.dg == DG && a.oe == OE && a.on == ON) return;
+  GNX_NARROW_DIMS(GNX_CASE)
+#undef GNX_CASE
+  if (h->n_wtiles() == 0 || h->E == 0) return;
+  hipFunction_t fb, fg;
+  (void)jit_get(a, h->wtile_e_cap / 64, nullptr, &fb, &fg);
+}
+
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   if (a.n_wtiles == 0 || a.E == 0) return 1;
   // 16-B vector copies assume fp32-aligned buffers (always true for fp32 arrays); nothing else is required
@@ -443,7 +114,7 @@ int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, 
   if (a.de == DE && a.dn == DN && a.dg == DG && a.oe == OE && a.on == ON) return launch_fused<DE, DN, DG, OE, ON>(h, a, R, s, phase);
   GNX_NARROW_DIMS(GNX_CASE)
 #undef GNX_CASE
-  return 1;
+  return launch_wave_jit(h, a, R, s, phase);  // any other narrow width set: compiled on first use (1 if not eligible)
 }
 
 }  // namespace gnx

@@ -256,6 +256,17 @@ GNX_API int32_t gnx_pad_features(const gnx_graphs* h, int32_t kind, const float*
 GNX_API int32_t gnx_unpad_features(const gnx_graphs* h, int32_t kind, const float* padded, int32_t d, int64_t n_replicas,
                            float* packed, void* stream);
 
+/* ---- run-time specialisation (the analogue of Julia compiling a GNBlock for its own widths on first use) -----------
+ * The fused one-launch kernel is compiled ahead of time for the README / benchmark width sets; for any other width set
+ * with every width <= 16 it is compiled at run time with hiprtc (gfx950), once per process and device, the first time
+ * gnx_block_workspace_bytes / gnx_block_forward sees the width set (never while the stream is being captured: such a
+ * call runs the generic kernels).  GNX_JIT=0 disables it; GNX_JIT_CACHE=<dir> keeps the code objects on disk.
+ * If hiprtc is unavailable the generic HIP kernels run instead.
+ * gnx_jit_precompile: compile only (no GPU needed) — build-time / CI check; *code_bytes = size of the code object.
+ * gnx_jit_stats: out = {compiled, disk-cache hits, failures, first uses inside a capture}. */
+GNX_API int32_t gnx_jit_precompile(const gnx_block_params* p, int32_t wtile_e_cap, size_t* code_bytes);
+GNX_API int32_t gnx_jit_stats(int64_t out[4]);
+
 /* ---- per-kernel HIP-event timing (bench/roofline evidence) ---- */
 GNX_API int32_t gnx_profile_enable(int32_t on);
 GNX_API int32_t gnx_profile_reset(void);

@@ -68,3 +68,17 @@ def test_no_silent_cpu_fallback(lib):
     ptrs = (C.c_void_p * 1)(ok.ctypes.data)
     assert lib.gnx_graphs_create_dense(ptrs, nn, 1, 2, 1, C.byref(h)) > 0
     assert not h.value
+
+
+def test_runtime_specialised_kernel_source_compiles_for_gfx950(lib):
+    """The kernel text embedded in libgnx.so (csrc/gnx_device.h + gnx_wave_kernel.h) compiles with hiprtc for an
+    unlisted width set — no GPU needed for the compile step; ineligible width sets are refused."""
+    import graphnets_jl_amd as gn
+    L = gn._lib
+    n = C.c_size_t(0)
+    assert lib.gnx_jit_precompile(C.byref(L.BlockParams(7, 3, 2, 5, 6, 1)), 128, C.byref(n)) == 0, lib.gnx_last_error()
+    assert n.value > 4096
+    assert lib.gnx_jit_precompile(C.byref(L.BlockParams(40, 3, 2, 5, 6, 1)), 128, C.byref(n)) == -6   # GNX_ERR_DIMS: too wide
+    assert lib.gnx_jit_precompile(C.byref(L.BlockParams(7, 3, 2, 5, 6, 1)), 100, C.byref(n)) == -1
+    st = (C.c_int64 * 4)()
+    assert lib.gnx_jit_stats(st) == 0 and st[0] >= 1 and st[2] == 0

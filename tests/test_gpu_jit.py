@@ -1,0 +1,135 @@
+"""Run-time specialised fused kernels (csrc/gnx_jit.cpp): width sets outside the ahead-of-time list are compiled with
+hiprtc on first use and must agree with the float64 oracle (1e-5 of the magnitude bound) like every other path."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import gn_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gn():
+    import graphnets_jl_amd as gn
+    return gn
+
+
+def _stats():
+    lib = sys.modules["graphnets_jl_amd._lib"].load()
+    out = (C.c_int64 * 4)()
+    assert lib.gnx_jit_stats(out) == 0
+    return dict(zip(("compiled", "disk_hits", "failures", "capture_misses"), out))
+
+
+def _check(gn, p, g, ef, nf, gf, flags=0):
+    blk = U.block_from_params(gn, p)
+    y = blk(U.to_nt(gn, g, ef, nf, gf), flags=flags)
+    colptr, rowval = g.csc()
+    ref, scale = O.block_forward_sparse(p, (colptr, rowval, g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r, s, name)
+    return y
+
+
+WIDTHS = [((7, 3, 2), (5, 6, 1)), ((1, 1, 1), (1, 1, 1)), ((16, 16, 16), (16, 16, 16)), ((0, 9, 0), (13, 0, 2)),
+          ((11, 0, 0), (2, 7, 3)), ((0, 0, 6), (4, 3, 0)), ((6, 15, 1), (1, 12, 9)), ((13, 2, 7), (0, 5, 4))]
+
+
+@pytest.mark.parametrize("dims", WIDTHS, ids=[f"{a}-{b}".replace(" ", "") for a, b in WIDTHS])
+def test_unlisted_width_sets_run_the_fused_kernel(gn, dims):
+    """heterogeneous batch (many tiles, several graphs per tile boundary), two activations; the fused path must have been
+    compiled (stats) and agree with the oracle AND with the generic kernels."""
+    before = _stats()
+    rng = np.random.default_rng(sum(dims[0]) * 31 + sum(dims[1]))
+    sizes = rng.integers(3, 200, 40)
+    cps, rvs = zip(*(U.er_csc(rng, int(n), int(0.08 * n * n) + 1) for n in sizes))
+    g = gn.GNGraphBatch.from_csc(list(cps), list(rvs), [int(n) for n in sizes])
+    p = O.make_block_params(rng, *dims)
+    p["act_e"], p["act_n"], p["act_g"] = 1, 2, 0
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims[0])
+    y = _check(gn, p, g, ef, nf, gf)
+    after = _stats()
+    assert after["failures"] == before["failures"] == 0
+    assert after["compiled"] + after["disk_hits"] == before["compiled"] + before["disk_hits"] + 1
+    yg = _check(gn, p, g, ef, nf, gf, flags=1)
+    for a, b in ((y.ef, yg.ef), (y.nf, yg.nf), (y.gf, yg.gf)):
+        assert (a is None) == (b is None)
+
+
+def test_hub_node_and_replicas(gn):
+    """single-node tiles walked in chunks (in-degree 3000) + isolated nodes, shared adjacency with 3 replicas"""
+    rng = np.random.default_rng(77)
+    N = 3100
+    rows = [np.sort(rng.choice(N, 3000, replace=False)) if j == 5 else
+            (np.zeros(0, dtype=np.int64) if j % 4 == 0 else np.sort(rng.choice(N, rng.integers(1, 5), replace=False))) for j in range(N)]
+    colptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    rowval = np.concatenate(rows).astype(np.int64)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [N])
+    dims = ((9, 4, 2), (6, 2, 3))
+    p = O.make_block_params(rng, *dims)
+    ef, nf, gf = U.packed_inputs(rng, 3, len(rowval), N, 1, dims[0])
+    _check(gn, p, g, ef, nf, gf)
+    assert _stats()["failures"] == 0
+
+
+def test_first_use_inside_a_capture_never_compiles(gn):
+    """Graphed warms the model up before capturing, so the specialised kernels are in place when the capture starts
+    (capture_misses stays 0) and the replay matches the eager result bit for bit."""
+    import torch
+    rng = np.random.default_rng(78)
+    colptr, rowval = U.er_csc(rng, 1500, 15000)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [1500])
+    dims = ((5, 7, 3), (4, 2, 6))
+    blk = U.block_from_params(gn, O.make_block_params(rng, *dims))
+    ef, nf, gf = U.packed_inputs(rng, 1, 15000, 1500, 1, dims[0])
+    x = U.to_nt(gn, g, ef, nf, gf)
+    before = _stats()
+    graphed = gn.Graphed(blk, x)
+    y = graphed(x)
+    torch.cuda.synchronize()
+    e = blk(x)
+    after = _stats()
+    assert after["capture_misses"] == before["capture_misses"] and after["failures"] == 0
+    for a, b in ((y.ef, e.ef), (y.nf, e.nf), (y.gf, e.gf)):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+
+
+def test_code_objects_can_be_kept_on_disk(gn, tmp_path):
+    os.environ["GNX_JIT_CACHE"] = str(tmp_path)
+    try:
+        rng = np.random.default_rng(79)
+        colptr, rowval = U.er_csc(rng, 300, 2000)
+        g = gn.GNGraphBatch.from_csc([colptr], [rowval], [300])
+        dims = ((3, 8, 1), (2, 5, 2))
+        p = O.make_block_params(rng, *dims)
+        ef, nf, gf = U.packed_inputs(rng, 1, 2000, 300, 1, dims[0])
+        _check(gn, p, g, ef, nf, gf)
+        files = [f for f in os.listdir(tmp_path) if f.startswith("gnx_wave_3_8_1_2_5_")]
+        assert len(files) == 1 and os.path.getsize(tmp_path / files[0]) > 4096
+        # a compile-only request for the same width set is now served from the file
+        lib = sys.modules["graphnets_jl_amd._lib"]
+        before = _stats()
+        n = C.c_size_t(0)
+        assert lib.load().gnx_jit_precompile(C.byref(lib.BlockParams(3, 8, 1, 2, 5, 2)), 128, C.byref(n)) == 0
+        assert _stats()["disk_hits"] == before["disk_hits"] + 1 and n.value > 4096
+    finally:
+        del os.environ["GNX_JIT_CACHE"]
+
+
+def test_jit_can_be_disabled(gn):
+    os.environ["GNX_JIT"] = "0"
+    try:
+        rng = np.random.default_rng(80)
+        colptr, rowval = U.er_csc(rng, 300, 2000)
+        g = gn.GNGraphBatch.from_csc([colptr], [rowval], [300])
+        dims = ((2, 9, 1), (3, 3, 3))
+        before = _stats()
+        _check(gn, O.make_block_params(rng, *dims), g, *U.packed_inputs(rng, 1, 2000, 300, 1, dims[0]))
+        assert _stats() == before
+    finally:
+        del os.environ["GNX_JIT"]
