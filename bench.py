@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--dims", choices=list(DIMS), default="readme")
+    ap.add_argument("--dims", default="readme", help="a preset (%s) or explicit widths de,dn,dg:oe,on,og" % ", ".join(DIMS))
     ap.add_argument("--workload", choices=["c2", "hetero"], default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
@@ -162,7 +162,11 @@ def main():
     K, W = args.steps, args.warmup
     if args.model == "c4":
         return bench_c4(args, gn, torch, dev)
-    din, dout = DIMS[args.dims]
+    if args.dims in DIMS:
+        din, dout = DIMS[args.dims]
+    else:
+        din, dout = (tuple(int(v) for v in part.split(",")) for part in args.dims.split(":"))
+        assert len(din) == 3 and len(dout) == 3, "--dims de,dn,dg:oe,on,og"
     workload = args.workload or ("hetero" if multi else "c2")
 
     # ---- synthetic batch (rank-local shard) ----
@@ -182,7 +186,7 @@ def main():
     blk.nodefn = gn.Dense.from_numpy(glorot(rng, on, oe + dn + dg), np.zeros(on, np.float32), device=dev)
     blk.graphfn = gn.Dense.from_numpy(glorot(rng, og, oe + on + dg), np.zeros(og, np.float32), device=dev)
     plan = gn.BlockPlan(blk, g, R=1, flags=args.flags)
-    nsets = 2 if args.dims == "core" else NSETS
+    nsets = 2 if max(din + dout) >= 64 else NSETS
     tg = torch.Generator(device=dev); tg.manual_seed(1234 + rank)
     mk = lambda T, d: torch.rand((1, T, d), generator=tg, device=dev, dtype=torch.float32) if d > 0 else None
     sets = [dict(ef=mk(E, de), nf=mk(N, dn), gf=mk(G, dg), out=plan.outputs(), ws=plan.new_workspace()) for _ in range(nsets)]
@@ -300,7 +304,7 @@ def main():
         abytes, aflops = algorithmic_bytes(E, N, G, din, dout), algorithmic_flops(E, N, G, din, dout)
         hbm_t, mfma_t = abytes / (HBM_PEAK_GBS * 1e9), aflops / (MFMA_F32_PEAK_TFS * 1e12)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.dims}.json")
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.dims.replace(':', '_').replace(',', '-')}.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")

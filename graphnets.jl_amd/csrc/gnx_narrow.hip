@@ -100,7 +100,7 @@ void warm_block_narrow(const gnx_graphs* h, const gnx_block_params* p) {
   a.de = p->de; a.dn = p->dn; a.dg = p->dg; a.oe = p->oe; a.on = p->on; a.og = p->og;
 #define GNX_CASE(DE, DN, DG, OE, ON) \
   if (a.de == DE && a.dn == DN && a.dg == DG && a.oe == OE && a.on == ON) return;
-  GNX_NARROW_DIMS(GNX_CASE)
+  if (!getenv("GNX_JIT_ALL")) { GNX_NARROW_DIMS(GNX_CASE) }
 #undef GNX_CASE
   if (h->n_wtiles() == 0 || h->E == 0) return;
   hipFunction_t fb, fg;
@@ -109,6 +109,8 @@ void warm_block_narrow(const gnx_graphs* h, const gnx_block_params* p) {
 
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   if (a.n_wtiles == 0 || a.E == 0) return 1;
+  static const bool jit_all = getenv("GNX_JIT_ALL") != nullptr;  // testing: run-time specialise even the listed width sets
+  if (jit_all && launch_wave_jit(h, a, R, s, phase) == GNX_OK) return GNX_OK;
   // 16-B vector copies assume fp32-aligned buffers (always true for fp32 arrays); nothing else is required
 #define GNX_CASE(DE, DN, DG, OE, ON) \
   if (a.de == DE && a.dn == DN && a.dg == DG && a.oe == OE && a.on == ON) return launch_fused<DE, DN, DG, OE, ON>(h, a, R, s, phase);

@@ -60,6 +60,68 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&x
   }
 }
 
+// activation of a whole register row: ONE (wave-uniform) switch, the loop inside each case
+template <int N>
+__device__ __forceinline__ void act_row(float (&v)[N], int act) {
+  switch (act) {
+    case 0: break;
+    case 1:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = fmaxf(v[j], 0.f);
+      break;
+    default:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = act_apply(v[j], act);
+      break;
+  }
+}
+
+// stands in for a NULL bias (Dense(...; bias=false)) so that the bias read needs no branch
+__constant__ float k_zero_bias[32] = {0.f};
+
+// acc[m][j] += sum_{k<K} W[k*OUT + j] * x[m][k] for M register rows at once; W = first of K j-contiguous weight rows,
+// read through the scalar cache.  With many weights the rows are streamed in GROUPS (<= 32 scalars) separated by
+// scheduling fences and an opaque pointer, so that only one group of SGPR weights is live at a time: unfenced, the
+// compiler hoists every s_load of the fully unrolled product to the top and spills SGPRs into VGPR lanes (one
+// v_readlane per use) once K*OUT exceeds the ~100 available scalars.
+#ifndef GNX_FENCE_T
+#define GNX_FENCE_T 48  // products with at most this many weights are left to the compiler
+#endif
+#ifndef GNX_FENCE_G
+#define GNX_FENCE_G 32  // scalars per fenced group
+#endif
+template <int K, int OUT, int M, int KX>
+__device__ __forceinline__ void fma_rows(cfloatp W, const float (&x)[M][KX], float (&acc)[M][OUT > 0 ? OUT : 1]) {
+  if constexpr (K > 0 && OUT > 0) {
+    if constexpr (K * OUT <= GNX_FENCE_T) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+          for (int j = 0; j < OUT; ++j) acc[m][j] = fmaf(W[k * OUT + j], x[m][k], acc[m][j]);
+    } else {
+      constexpr int KG = GNX_FENCE_G / OUT > 0 ? GNX_FENCE_G / OUT : 1;
+#pragma unroll
+      for (int k0 = 0; k0 < K; k0 += KG) {
+        cfloatp Wk = W + k0 * OUT;
+        // the group's weight pointer becomes available only once the previous group's last FMA has been issued: the
+        // loads are invariant (no memory chain), a data dependency is the one fence that instruction selection honours
+        asm volatile("" : "+s"(Wk) : "v"(acc[M - 1][OUT - 1]));
+#pragma unroll
+        for (int kk = 0; kk < KG; ++kk) {
+          if (k0 + kk < K) {
+#pragma unroll
+            for (int m = 0; m < M; ++m)
+#pragma unroll
+              for (int j = 0; j < OUT; ++j) acc[m][j] = fmaf(Wk[kk * OUT + j], x[m][k0 + kk], acc[m][j]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // XCD-aware block -> tile map: blocks b and b+8 share an XCD (and its L2), so give every XCD one contiguous
 // chunk of tiles; tiles of one graph (which share the graph's node rows) then meet in one L2.  Bijective for any nt.
 __device__ __forceinline__ int xcd_tile(int b, int nt) {
@@ -104,7 +166,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // =========================================================================================================
 template <int DE, int DN, int DG, int OE, int ON, int EPT>
 __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_stride) {
-  constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1;
+  constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1, DG1 = DG > 0 ? DG : 1;
   constexpr int TEW = 64 * EPT;
   constexpr int C = OE + ON, C1 = C > 0 ? C : 1;
   constexpr int WAVES = kThreads / 64;
@@ -131,15 +193,15 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
   const cfloatp gf = DG > 0 ? as_const(a.gf + (r * (size_t)a.G + g) * DG) : nullptr;
   const cfloatp We = as_const(a.We);
   const cfloatp Wn = as_const(a.Wn);
-  const cfloatp be = as_const(a.be);
-  const cfloatp bn = as_const(a.bn);
+  const cfloatp be = as_const(a.be ? a.be : k_zero_bias);
+  const cfloatp bn = as_const(a.bn ? a.bn : k_zero_bias);
 
   // ---- issue every load up front, branch-free (indices clamped into the tile; results of clamped lanes unused) ----
   const bool is_node = lane < nn;
   const int nl = lane < nn ? lane : nn - 1;
   const int cp0 = a.colptr[n0 + nl], cp1 = a.colptr[n0 + nl + 1];
-  float xn[DN1];
-  if constexpr (DN > 0) load_row<DN>(nf + (size_t)(n0 + nl) * DN, xn);
+  float xn[1][DN1];
+  if constexpr (DN > 0) load_row<DN>(nf + (size_t)(n0 + nl) * DN, xn[0]);
   const int cn0 = ne < TEW ? ne : TEW;
   float x[EPT][DE1];
   float xs[EPT][DN1];
@@ -158,21 +220,22 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
     for (int i = 0; i < EPT; ++i) load_row<DN>(nf + (size_t)src[i] * DN, xs[i]);
   }
 
+  float gfr[1][DG1];
+#pragma unroll
+  for (int k = 0; k < DG; ++k) gfr[0][k] = gf[k];
   // ---- lanes as nodes: destination index of each in-edge, per-node part of the edge update ----
   //   pd[n] = be + We[:, gf-seg] * gf[g] + We[:, dst-seg] * nf[n]      (edgefninput.jl:5-6 hoisted out of the edge loop)
   if (is_node) {
     if (nn > 1)
       for (int e = cp0 - e0; e < cp1 - e0; ++e) s_dst[e] = (unsigned char)lane;
-    if constexpr (OE > 0) {
+    if constexpr (OE > 0) {  // weight rows are read j-contiguous (one s_load_dwordx{4,8,16} per row)
+      float b[1][OE1];
 #pragma unroll
-      for (int j = 0; j < OE; ++j) {
-        float b = a.be ? be[j] : 0.f;
+      for (int j = 0; j < OE; ++j) b[0][j] = be[j];
+      fma_rows<DG, OE, 1, DG1>(We + (DE + 2 * DN) * OE, gfr, b);
+      fma_rows<DN, OE, 1, DN1>(We + (DE + DN) * OE, xn, b);
 #pragma unroll
-        for (int k = 0; k < DG; ++k) b = fmaf(We[(DE + 2 * DN + k) * OE + j], gf[k], b);
-#pragma unroll
-        for (int k = 0; k < DN; ++k) b = fmaf(We[(DE + DN + k) * OE + j], xn[k], b);
-        s_pd[lane * OE + j] = b;
-      }
+      for (int j = 0; j < OE; ++j) s_pd[lane * OE + j] = b[0][j];
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -196,6 +259,38 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
         }
       }
     }
+    constexpr int KE = DE + DN;  // weight rows applied per edge (the dst / gf rows were hoisted into pd)
+    if constexpr (OE > 0 && KE * OE > 96) {
+      // Many weights: all EPT edges of the lane advance together over groups of weight rows (fma_rows)
+      float acc[EPT][OE1];
+      bool valid[EPT];
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int el = lane + 64 * i;
+        valid[i] = el < cn;
+        const int elc = valid[i] ? el : cn - 1;
+        const int dl = nn > 1 ? (int)s_dst[elc] : 0;
+#pragma unroll
+        for (int j = 0; j < OE; ++j) acc[i][j] = s_pd[dl * OE + j];
+      }
+      fma_rows<DE, OE, EPT, DE1>(We, x, acc);
+      fma_rows<DN, OE, EPT, DN1>(We + DE * OE, xs, acc);
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) {
+        const int el = lane + 64 * i;
+        act_row<OE1>(acc[i], a.act_e);
+        if (valid[i]) {
+          store_row<OE>(a.ef_out + (r * (size_t)a.E + e0 + c0 + el) * OE, acc[i]);
+          if (nn > 1) {
+#pragma unroll
+            for (int j = 0; j < OE; ++j) s_out[el * OE + j] = acc[i][j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < OE; ++j) psum[j] += acc[i][j];
+          }
+        }
+      }
+    } else
     if constexpr (OE > 0) {
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
@@ -213,8 +308,7 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
           for (int k = 0; k < DN; ++k)
 #pragma unroll
             for (int j = 0; j < OE; ++j) acc[j] = fmaf(We[(DE + k) * OE + j], xs[i][k], acc[j]);
-#pragma unroll
-          for (int j = 0; j < OE; ++j) acc[j] = act_apply(acc[j], a.act_e);
+          act_row<OE1>(acc, a.act_e);
           store_row<OE>(a.ef_out + (r * (size_t)a.E + e0 + c0 + el) * OE, acc);
           if (nn > 1) {
 #pragma unroll
@@ -249,27 +343,19 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
   }
   if constexpr (ON > 0) {
     if (is_node) {
-      float acc[ON1];
+      float acc1[1][ON1];
+      float (&acc)[ON1] = acc1[0];
 #pragma unroll
-      for (int j = 0; j < ON; ++j) {
-        float b = a.bn ? bn[j] : 0.f;
+      for (int j = 0; j < ON; ++j) acc[j] = bn[j];
+      fma_rows<DG, ON, 1, DG1>(Wn + (OE + DN) * ON, gfr, acc1);
+      float vin[1][OE1];
 #pragma unroll
-        for (int k = 0; k < DG; ++k) b = fmaf(Wn[(OE + DN + k) * ON + j], gf[k], b);
-        acc[j] = b;
-      }
+      for (int k = 0; k < OE; ++k) vin[0][k] = v[k];
+      fma_rows<OE, ON, 1, OE1>(Wn, vin, acc1);
+      fma_rows<DN, ON, 1, DN1>(Wn + OE * ON, xn, acc1);
+      act_row<ON1>(acc, a.act_n);
 #pragma unroll
-      for (int k = 0; k < OE; ++k)
-#pragma unroll
-        for (int j = 0; j < ON; ++j) acc[j] = fmaf(Wn[k * ON + j], v[k], acc[j]);
-#pragma unroll
-      for (int k = 0; k < DN; ++k)
-#pragma unroll
-        for (int j = 0; j < ON; ++j) acc[j] = fmaf(Wn[(OE + k) * ON + j], xn[k], acc[j]);
-#pragma unroll
-      for (int j = 0; j < ON; ++j) {
-        acc[j] = act_apply(acc[j], a.act_n);
-        v[OE + j] = acc[j];
-      }
+      for (int j = 0; j < ON; ++j) v[OE + j] = acc[j];
       store_row<ON>(a.nf_out + (r * (size_t)a.N + n0 + lane) * ON, acc);
     }
   }
@@ -321,24 +407,31 @@ __global__ void k_graph_t(BlockArgs a, int prow_stride) {
   float acc[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) acc[c] = 0.f;
-  for (int q0 = (t0 >> 2) + tid; 4 * q0 < t1; q0 += MAXQ * nthr) {
-    float4 val[MAXQ][C];
+  // columns in passes of <= CC so that the in-flight quads (MAXQ * CC float4) stay in registers for any C
+  constexpr int CC = C <= 8 ? C : 8;
 #pragma unroll
-    for (int u = 0; u < MAXQ; ++u) {
-      const int q = q0 + u * nthr;
-      if (4 * q < t1) {
+  for (int cb = 0; cb < C; cb += CC) {
+    for (int q0 = (t0 >> 2) + tid; 4 * q0 < t1; q0 += MAXQ * nthr) {
+      float4 val[MAXQ][CC];
 #pragma unroll
-        for (int c = 0; c < C; ++c) val[u][c] = *reinterpret_cast<const float4*>(base + (size_t)c * prow_stride + 4 * q);
+      for (int u = 0; u < MAXQ; ++u) {
+        const int q = q0 + u * nthr;
+        if (4 * q < t1) {
+#pragma unroll
+          for (int c = 0; c < CC; ++c)
+            if (cb + c < C) val[u][c] = *reinterpret_cast<const float4*>(base + (size_t)(cb + c) * prow_stride + 4 * q);
+        }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < MAXQ; ++u) {
-      const int row = 4 * (q0 + u * nthr);
-      if (row < t1) {
-        const bool k0 = row >= t0, k1 = row + 1 >= t0 && row + 1 < t1, k2 = row + 2 >= t0 && row + 2 < t1, k3 = row + 3 < t1;
+      for (int u = 0; u < MAXQ; ++u) {
+        const int row = 4 * (q0 + u * nthr);
+        if (row < t1) {
+          const bool k0 = row >= t0, k1 = row + 1 >= t0 && row + 1 < t1, k2 = row + 2 >= t0 && row + 2 < t1, k3 = row + 3 < t1;
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-          acc[c] += ((k0 ? val[u][c].x : 0.f) + (k1 ? val[u][c].y : 0.f)) + ((k2 ? val[u][c].z : 0.f) + (k3 ? val[u][c].w : 0.f));
+          for (int c = 0; c < CC; ++c)
+            if (cb + c < C)
+              acc[cb + c] += ((k0 ? val[u][c].x : 0.f) + (k1 ? val[u][c].y : 0.f)) + ((k2 ? val[u][c].z : 0.f) + (k3 ? val[u][c].w : 0.f));
+        }
       }
     }
   }

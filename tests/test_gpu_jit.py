@@ -36,7 +36,7 @@ def _check(gn, p, g, ef, nf, gf, flags=0):
     return y
 
 
-WIDTHS = [((7, 3, 2), (5, 6, 1)), ((1, 1, 1), (1, 1, 1)), ((16, 16, 16), (16, 16, 16)), ((0, 9, 0), (13, 0, 2)),
+WIDTHS = [((7, 3, 2), (5, 6, 1)), ((1, 1, 1), (1, 1, 1)), ((16, 12, 4), (12, 16, 5)), ((0, 9, 0), (13, 0, 2)),
           ((11, 0, 0), (2, 7, 3)), ((0, 0, 6), (4, 3, 0)), ((6, 15, 1), (1, 12, 9)), ((13, 2, 7), (0, 5, 4))]
 
 
