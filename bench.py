@@ -115,7 +115,7 @@ def bench_c4(args, gn, torch, dev):
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / K
     flops = 699.2e9 if core == (128, 64, 32) else float("nan")  # whole-model algorithmic FLOPs at 1M edges
-    print(json.dumps({"metric": "edges/sec through Encoder->2xGNCore(128,64,32)->Decoder, 1M-edge graph (BASELINE configs[3])",
+    print(json.dumps({"metric": "edges/sec through Encoder->2xGNCore(%s)->Decoder, 1M-edge graph (BASELINE configs[3])" % ",".join(map(str, core)),
                       "value": round(g.n_edges / dt, 1), "unit": "edges/s", "ms_per_step": round(dt * 1e3, 4), "steps": K,
                       "algorithmic_tflops": round(flops / dt / 1e12, 2), "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFS,
                       "frac_of_mfma_peak": round(flops / dt / 1e12 / MFMA_F32_PEAK_TFS, 4), "kernel_us_one_forward": kern}))

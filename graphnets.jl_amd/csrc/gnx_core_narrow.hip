@@ -6,38 +6,11 @@
 // At d = 10 a wave-per-row kernel keeps 54 of 64 lanes idle and the hidden tile bounced through LDS; here a row is
 // D registers of one lane and the kernel is a pure stream: x in, (block_out in,) out.
 #include "gnx_device.h"
+#include "gnx_wave_kernel.h"  // load_row / store_row / fma_rows / act_row
 
 namespace gnx {
 
 namespace {
-
-struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
-struct __attribute__((packed, aligned(4))) F3u { float x, y, z; };
-struct __attribute__((packed, aligned(4))) F2u { float x, y; };
-typedef const float __attribute__((address_space(4))) * cfloatp;
-__device__ __forceinline__ cfloatp as_const(const float* p) { return reinterpret_cast<cfloatp>(reinterpret_cast<uintptr_t>(p)); }
-
-template <int D>
-__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&x)[D]) {
-  constexpr int Q = D / 4, R = D % 4;
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const F4u v = *reinterpret_cast<const F4u*>(p + 4 * q);
-    x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-  }
-  if constexpr (R == 3) { const F3u v = *reinterpret_cast<const F3u*>(p + 4 * Q); x[4 * Q] = v.x; x[4 * Q + 1] = v.y; x[4 * Q + 2] = v.z; }
-  else if constexpr (R == 2) { const F2u v = *reinterpret_cast<const F2u*>(p + 4 * Q); x[4 * Q] = v.x; x[4 * Q + 1] = v.y; }
-  else if constexpr (R == 1) { x[4 * Q] = p[4 * Q]; }
-}
-template <int D>
-__device__ __forceinline__ void store_row(float* __restrict__ p, const float (&x)[D]) {
-  constexpr int Q = D / 4, R = D % 4;
-#pragma unroll
-  for (int q = 0; q < Q; ++q) { F4u v; v.x = x[4 * q]; v.y = x[4 * q + 1]; v.z = x[4 * q + 2]; v.w = x[4 * q + 3]; *reinterpret_cast<F4u*>(p + 4 * q) = v; }
-  if constexpr (R == 3) { F3u v; v.x = x[4 * Q]; v.y = x[4 * Q + 1]; v.z = x[4 * Q + 2]; *reinterpret_cast<F3u*>(p + 4 * Q) = v; }
-  else if constexpr (R == 2) { F2u v; v.x = x[4 * Q]; v.y = x[4 * Q + 1]; *reinterpret_cast<F2u*>(p + 4 * Q) = v; }
-  else if constexpr (R == 1) { p[4 * Q] = x[4 * Q]; }
-}
 
 // xhat = (x - mu) * rstd over the D registers of a row; eps_mode 0: 1/(sigma+eps) (Flux 0.14 normalise), 1: 1/sqrt(var+eps)
 template <int D>
@@ -77,28 +50,33 @@ __global__ __launch_bounds__(256) void k_core_post(const float* __restrict__ x, 
   const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   constexpr int H = 4 * D;
+  constexpr int HB = D % 2 == 0 ? 8 : 4;  // hidden units per pass (divides 4D)
   const cfloatp g = as_const(gamma2), b = as_const(beta2);
-  const cfloatp W1 = as_const(fc1.weight), b1 = as_const(fc1.bias), W2 = as_const(fc2.weight), b2 = as_const(fc2.bias);
-  float xr[D], z[D], acc[D], blk[D];
+  const cfloatp W1 = as_const(fc1.weight), W2 = as_const(fc2.weight);
+  const cfloatp b1 = as_const(fc1.bias ? fc1.bias : k_zero_bias), b2 = as_const(fc2.bias ? fc2.bias : k_zero_bias);
+  float xr[D], z[1][D], acc[1][D], blk[D];
   load_row<D>(x + row * D, xr);
   load_row<D>(out + row * D, blk);  // block(gn1(x)) written by the block forward
 #pragma unroll
-  for (int k = 0; k < D; ++k) z[k] = xr[k];
-  normalise<D>(z, eps, eps_mode);
+  for (int k = 0; k < D; ++k) z[0][k] = xr[k];
+  normalise<D>(z[0], eps, eps_mode);
 #pragma unroll
-  for (int k = 0; k < D; ++k) { z[k] = fmaf(g[k], z[k], b[k]); acc[k] = fc2.bias ? b2[k] : 0.f; }
+  for (int k = 0; k < D; ++k) { z[0][k] = fmaf(g[k], z[0][k], b[k]); acc[0][k] = b2[k]; }
+  // HB hidden units at a time, produced and consumed in registers: h = act(W1[:, j0:j0+HB]' z + b1) with W1's rows read
+  // j-contiguous (W1 is (4D x D) column-major: element (j, k) at k*4D + j), then acc += W2[:, j0:j0+HB] h
 #pragma unroll
-  for (int j = 0; j < H; ++j) {  // hidden unit j: produced and consumed in registers
-    float h = fc1.bias ? b1[j] : 0.f;
+  for (int j0 = 0; j0 < H; j0 += HB) {
+    float h[1][HB];
 #pragma unroll
-    for (int k = 0; k < D; ++k) h = fmaf(W1[k * H + j], z[k], h);
-    h = act_apply(h, fc1.act);
-#pragma unroll
-    for (int i = 0; i < D; ++i) acc[i] = fmaf(W2[j * D + i], h, acc[i]);
+    for (int jj = 0; jj < HB; ++jj) h[0][jj] = b1[j0 + jj];
+    fma_rows<D, HB, 1, D, H>(W1 + j0, z, h);
+    act_row<HB>(h[0], fc1.act);
+    fma_rows<HB, D, 1, HB>(W2 + j0 * D, h, acc);
   }
+  act_row<D>(acc[0], fc2.act);
 #pragma unroll
-  for (int k = 0; k < D; ++k) acc[k] = xr[k] + blk[k] + act_apply(acc[k], fc2.act);
-  store_row<D>(out + row * D, acc);
+  for (int k = 0; k < D; ++k) acc[0][k] = xr[k] + blk[k] + acc[0][k];
+  store_row<D>(out + row * D, acc[0]);
 }
 
 #define GNX_CORE_WIDTHS(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)

@@ -77,9 +77,9 @@ __device__ __forceinline__ void act_row(float (&v)[N], int act) {
 }
 
 // stands in for a NULL bias (Dense(...; bias=false)) so that the bias read needs no branch
-__constant__ float k_zero_bias[32] = {0.f};
+__constant__ float k_zero_bias[64] = {0.f};
 
-// acc[m][j] += sum_{k<K} W[k*OUT + j] * x[m][k] for M register rows at once; W = first of K j-contiguous weight rows,
+// acc[m][j] += sum_{k<K} W[k*LD + j] * x[m][k] for M register rows at once; W = first of K j-contiguous weight rows,
 // read through the scalar cache.  With many weights the rows are streamed in GROUPS (<= 32 scalars) separated by
 // scheduling fences and an opaque pointer, so that only one group of SGPR weights is live at a time: unfenced, the
 // compiler hoists every s_load of the fully unrolled product to the top and spills SGPRs into VGPR lanes (one
@@ -90,7 +90,7 @@ __constant__ float k_zero_bias[32] = {0.f};
 #ifndef GNX_FENCE_G
 #define GNX_FENCE_G 32  // scalars per fenced group
 #endif
-template <int K, int OUT, int M, int KX>
+template <int K, int OUT, int M, int KX, int LD = OUT>  // LD: distance between weight rows (>= OUT)
 __device__ __forceinline__ void fma_rows(cfloatp W, const float (&x)[M][KX], float (&acc)[M][OUT > 0 ? OUT : 1]) {
   if constexpr (K > 0 && OUT > 0) {
     if constexpr (K * OUT <= GNX_FENCE_T) {
@@ -99,12 +99,12 @@ __device__ __forceinline__ void fma_rows(cfloatp W, const float (&x)[M][KX], flo
 #pragma unroll
         for (int m = 0; m < M; ++m)
 #pragma unroll
-          for (int j = 0; j < OUT; ++j) acc[m][j] = fmaf(W[k * OUT + j], x[m][k], acc[m][j]);
+          for (int j = 0; j < OUT; ++j) acc[m][j] = fmaf(W[k * LD + j], x[m][k], acc[m][j]);
     } else {
       constexpr int KG = GNX_FENCE_G / OUT > 0 ? GNX_FENCE_G / OUT : 1;
 #pragma unroll
       for (int k0 = 0; k0 < K; k0 += KG) {
-        cfloatp Wk = W + k0 * OUT;
+        cfloatp Wk = W + k0 * LD;
         // the group's weight pointer becomes available only once the previous group's last FMA has been issued: the
         // loads are invariant (no memory chain), a data dependency is the one fence that instruction selection honours
         asm volatile("" : "+s"(Wk) : "v"(acc[M - 1][OUT - 1]));
@@ -114,7 +114,7 @@ __device__ __forceinline__ void fma_rows(cfloatp W, const float (&x)[M][KX], flo
 #pragma unroll
             for (int m = 0; m < M; ++m)
 #pragma unroll
-              for (int j = 0; j < OUT; ++j) acc[m][j] = fmaf(Wk[kk * OUT + j], x[m][k0 + kk], acc[m][j]);
+              for (int j = 0; j < OUT; ++j) acc[m][j] = fmaf(Wk[kk * LD + j], x[m][k0 + kk], acc[m][j]);
           }
         }
       }

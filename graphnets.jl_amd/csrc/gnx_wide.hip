@@ -58,6 +58,7 @@ struct WideArgs {
   size_t gadd_rep_stride;
   const float* add1;  // optional residual inputs with the layout of `out` (may alias `out`): v = act(..) + add1 + add2
   const float* add2;
+  int n_rtiles, n_ctiles;      // row tiles / column tiles of this launch (set by launch_gemm)
   unsigned long long* stamps;  // diagnostic builds only (GNX_WIDE_STAMPS): [tile][8] shader-clock stamps of wave 0
 };
 
@@ -92,8 +93,21 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / L::WN, wn = wv % L::WN;
-  const Tile t = a.tiles[blockIdx.x];
-  const int n0 = blockIdx.y * BN;
+  // block -> (row tile, column tile).  With several column tiles the SAME A rows are needed by all of them: blocks b and
+  // b+8 land on the same XCD (round-robin dispatch), so the column tiles of a row tile are placed 8 blocks apart — they
+  // run close in time on one XCD and the A tile is fetched from HBM once and re-read from that XCD's L2.
+  int tile_id, ctile;
+  if (a.n_ctiles > 1) {
+    const int b = blockIdx.x;
+    ctile = (b >> 3) % a.n_ctiles;
+    tile_id = (b / (8 * a.n_ctiles)) * 8 + (b & 7);
+    if (tile_id >= a.n_rtiles) return;  // grid padded to a multiple of 8 row tiles (whole block leaves: no barrier yet)
+  } else {
+    tile_id = blockIdx.x;
+    ctile = 0;
+  }
+  const Tile t = a.tiles[tile_id];
+  const int n0 = ctile * BN;
   const size_t r = blockIdx.z;
   const int row0 = a.row_kind == 0 ? t.e0 : t.n0;
   const int rows = (a.row_kind == 0 ? t.e1 : t.n1) - row0;
@@ -346,12 +360,12 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
       float sum = 0.f;
 #pragma unroll
       for (int w = 0; w < NG; ++w) sum += s_cs[w * BN + tid];
-      a.colsum[r * a.colsum_rep_stride + (size_t)blockIdx.x * a.OUT + n0 + tid] = sum;
+      a.colsum[r * a.colsum_rep_stride + (size_t)tile_id * a.OUT + n0 + tid] = sum;
     }
   }
 #ifdef GNX_WIDE_STAMPS_BUILD
-  if (a.stamps && tid == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-    unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+  if (a.stamps && tid == 0 && ctile == 0 && blockIdx.z == 0) {
+    unsigned long long* o = a.stamps + (size_t)tile_id * 8;
     o[0] = st[1] - st[0]; o[1] = t_sync; o[2] = t_mfma; o[3] = clock64() - st[2]; o[4] = clock64() - st[0];
   }
 #endif
@@ -494,10 +508,14 @@ static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64
       return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: index array required by a segment mode is NULL");
   }
   ProfScope ps(name, s);
-  const dim3 grid(n_tiles, (unsigned)((w.OUT + BN - 1) / BN), (unsigned)R);
+  WideArgs wa = w;
+  wa.n_rtiles = (int)n_tiles;
+  wa.n_ctiles = (w.OUT + BN - 1) / BN;
+  const unsigned gx = wa.n_ctiles > 1 ? (n_tiles + 7) / 8 * 8 * (unsigned)wa.n_ctiles : n_tiles;
+  const dim3 grid(gx, 1, (unsigned)R);
   // K chunk 32: measured against 64 (fewer barriers but 2 instead of 3 waves/SIMD): 466 vs 616 us on the edge GEMM
-  if (vec4) hipLaunchKernelGGL((k_rows_gemm<BN, true, 32>), grid, dim3(WT), 0, s, w);
-  else hipLaunchKernelGGL((k_rows_gemm<BN, false, 32>), grid, dim3(WT), 0, s, w);
+  if (vec4) hipLaunchKernelGGL((k_rows_gemm<BN, true, 32>), grid, dim3(WT), 0, s, wa);
+  else hipLaunchKernelGGL((k_rows_gemm<BN, false, 32>), grid, dim3(WT), 0, s, wa);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
