@@ -212,6 +212,58 @@ __global__ __launch_bounds__(256) void k_layernorm2(const float* __restrict__ x,
   }
 }
 
+// sum over the 16 lanes of a DPP row (result in every lane of the row), fixed order
+__device__ __forceinline__ float row16_sum_g(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+// Widths that are multiples of 64 (GNCore at 128/64, the sort example's 384): 16 lanes per row, every lane keeps its
+// Q = d/64 float4 of the row in registers (x is read ONCE, 16-B accesses), statistics by DPP row reductions (a DPP row
+// is exactly the 16 lanes of one LayerNorm row), both outputs written from registers.  4 rows per wave, 16 per block.
+template <int Q>
+__global__ __launch_bounds__(256) void k_layernorm2_v4(const float* __restrict__ x, size_t rows, const float* __restrict__ g1,
+                                                       const float* __restrict__ b1, const float* __restrict__ g2,
+                                                       const float* __restrict__ b2, float eps, int eps_mode,
+                                                       float* __restrict__ y1, float* __restrict__ y2) {
+  constexpr int D = 64 * Q;
+  const int sub = threadIdx.x & 15;
+  size_t row = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = row < rows;
+  row = live ? row : rows - 1;  // clamped: every lane takes part in the DPP reductions
+  const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+  float4 v[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) v[q] = xr[sub + 16 * q];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+  const float mu = row16_sum_g(s) * (1.f / (float)D);
+  float var = 0.f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    v[q].x -= mu; v[q].y -= mu; v[q].z -= mu; v[q].w -= mu;
+    var = fmaf(v[q].x, v[q].x, var); var = fmaf(v[q].y, v[q].y, var); var = fmaf(v[q].z, v[q].z, var); var = fmaf(v[q].w, v[q].w, var);
+  }
+  var = row16_sum_g(var) * (1.f / (float)D);
+  const float inv = eps_mode == 0 ? 1.f / (sqrtf(var) + eps) : 1.f / sqrtf(var + eps);
+  if (!live) return;
+  float4* o1 = reinterpret_cast<float4*>(y1 + row * D);
+  float4* o2 = reinterpret_cast<float4*>(y2 + row * D);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int c = sub + 16 * q;
+    const float4 ga = reinterpret_cast<const float4*>(g1)[c], ba = reinterpret_cast<const float4*>(b1)[c];
+    const float4 gb = reinterpret_cast<const float4*>(g2)[c], bb = reinterpret_cast<const float4*>(b2)[c];
+    const float4 xh = make_float4(v[q].x * inv, v[q].y * inv, v[q].z * inv, v[q].w * inv);
+    o1[c] = make_float4(fmaf(ga.x, xh.x, ba.x), fmaf(ga.y, xh.y, ba.y), fmaf(ga.z, xh.z, ba.z), fmaf(ga.w, xh.w, ba.w));
+    o2[c] = make_float4(fmaf(gb.x, xh.x, bb.x), fmaf(gb.y, xh.y, bb.y), fmaf(gb.z, xh.z, bb.z), fmaf(gb.w, xh.w, bb.w));
+  }
+}
+
 // One wave per row: out[row] += x[row] + W2*relu(W1*z[row]+b1)+b2  (z = LN2(x); out already holds block(LN1 x)).
 __global__ __launch_bounds__(256) void k_ffn_residual(const float* __restrict__ z, const float* __restrict__ x,
                                                       size_t rows, int d, gnx_dense fc1, gnx_dense fc2,
@@ -242,6 +294,17 @@ int32_t launch_layernorm2(const float* x, size_t rows, int d, const gnx_layernor
                           int eps_mode, float* y1, float* y2, hipStream_t s) {
   if (rows == 0 || d == 0) return GNX_OK;
   ProfScope ps("k_layernorm2", s);
+  const bool al16 = (((uintptr_t)x | (uintptr_t)y1 | (uintptr_t)y2 | (uintptr_t)l1.gamma | (uintptr_t)l1.beta | (uintptr_t)l2.gamma | (uintptr_t)l2.beta) & 15) == 0;
+  if (al16 && d % 64 == 0 && d <= 512) {
+    const dim3 grid((unsigned)((rows + 15) / 16));
+    switch (d / 64) {
+#define GNX_LN_CASE(Q) case Q: hipLaunchKernelGGL((k_layernorm2_v4<Q>), grid, dim3(256), 0, s, x, rows, l1.gamma, l1.beta, l2.gamma, l2.beta, eps, eps_mode, y1, y2); break;
+      GNX_LN_CASE(1) GNX_LN_CASE(2) GNX_LN_CASE(3) GNX_LN_CASE(4) GNX_LN_CASE(5) GNX_LN_CASE(6) GNX_LN_CASE(7) GNX_LN_CASE(8)
+#undef GNX_LN_CASE
+    }
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+  }
   hipLaunchKernelGGL(k_layernorm2, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, d, l1.gamma, l1.beta, l2.gamma,
                      l2.beta, eps, eps_mode, y1, y2);
   GNX_HIP(hipGetLastError());

@@ -262,17 +262,27 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
     }
     if (si < a.nseg) load_chunk(si, kc);
     const int hi = lane >> 5, l31 = lane & 31;
+    // fragments of k-step kk+1 are requested from LDS before the MFMAs of step kk are issued (explicit two-deep
+    // register pipeline: left to itself the compiler places each ds_read right in front of its first use)
+    float fa[2][L::TM], fb[2][L::TN];
+#pragma unroll
+    for (int i = 0; i < L::TM; ++i) fa[0][i] = sA[((wm * L::TM + i) * 32 + l31) * LDA + hi];
+#pragma unroll
+    for (int j = 0; j < L::TN; ++j) fb[0][j] = sB[hi * BN + (wn * L::TN + j) * 32 + l31];
 #pragma unroll
     for (int kk = 0; kk < KC / 2; ++kk) {
-      float fa[L::TM], fb[L::TN];
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < KC / 2) {
 #pragma unroll
-      for (int i = 0; i < L::TM; ++i) fa[i] = sA[((wm * L::TM + i) * 32 + l31) * LDA + 2 * kk + hi];
+        for (int i = 0; i < L::TM; ++i) fa[nxt][i] = sA[((wm * L::TM + i) * 32 + l31) * LDA + 2 * (kk + 1) + hi];
 #pragma unroll
-      for (int j = 0; j < L::TN; ++j) fb[j] = sB[(2 * kk + hi) * BN + (wn * L::TN + j) * 32 + l31];
+        for (int j = 0; j < L::TN; ++j) fb[nxt][j] = sB[(2 * (kk + 1) + hi) * BN + (wn * L::TN + j) * 32 + l31];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads above in front of this step's MFMAs
 #pragma unroll
       for (int i = 0; i < L::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < L::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < L::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
     }
 #ifdef GNX_WIDE_STAMPS_BUILD
     t_mfma += clock64() - tB;
