@@ -144,14 +144,16 @@ def test_graphed_model_replay_matches_eager(gn):
         y_graph = graphed(x)
         for a, b in ((y_eager.ef, y_graph.ef), (y_eager.nf, y_graph.nf), (y_eager.gf, y_graph.gf)):
             assert torch.equal(a, b)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(50):
-        model(x1)
-    torch.cuda.synchronize(); t_eager = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for _ in range(50):
-        graphed.graph.replay()
-    torch.cuda.synchronize(); t_graph = time.perf_counter() - t0
-    print(f"README ex.3 model, 4k-edge graph: eager {t_eager / 50 * 1e6:.0f} us / forward, hipGraph replay {t_graph / 50 * 1e6:.0f} us")
+    def best_of(fn, reps=5, n=50):  # best of several repetitions: one-off stalls of the shared box must not decide the test
+        best = float("inf")
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t0) / n)
+        return best
+    t_eager, t_graph = best_of(lambda: model(x1)), best_of(graphed.graph.replay)
+    print(f"README ex.3 model, 4k-edge graph: eager {t_eager * 1e6:.0f} us / forward, hipGraph replay {t_graph * 1e6:.0f} us")
     assert t_graph < t_eager
