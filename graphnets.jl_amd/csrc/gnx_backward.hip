@@ -19,6 +19,15 @@ extern "C" int32_t gnx_ensure_csr(const gnx_graphs* h);
 
 namespace gnx {
 
+// matrix-core primitives (gnx_backward_wide.hip)
+bool bw_use_mfma(size_t rows, int J, int K);
+size_t dw_mfma_partial_floats(size_t rows, int J, int K);
+int32_t dw_mfma(const float* delta, const float* X, size_t rows, int J, int K, float* dW, float* partial, hipStream_t s);
+int32_t dx_mfma(const gnx_graphs* h, int entity, const float* delta, const float* W, int J, int K, int ka, int kb, float* out, int64_t R,
+                float* WT, bool fill, hipStream_t s, const char* name);
+int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K, const gnx_dense& d, int OUT, const float* add1,
+                          const float* add2, float* out, int64_t R, hipStream_t s, const char* name);
+
 int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, const float* nf, int dn, const float* gf, int dg,
                         int64_t R, float* out, hipStream_t s);
 
@@ -85,40 +94,17 @@ __global__ void k_bw_dnf(const float* dXn, int Kn, int n_off, const float* dXe, 
   d_nf[r * (size_t)N * dn + idx] = acc;
 }
 
-// d_gf[g][k] = dXg[g][g_off+k] + sum_{n in g} dXn[n][n_off+k] + sum_{e in g} dXe[e][e_off+k]; one workgroup per (g, r)
-__global__ __launch_bounds__(256) void k_bw_dgf(const float* dXg, int Kg, int g_off, const float* dXn, int Kn, int n_off, const float* dXe,
-                                                int Ke, int e_off, const int* node_off, const int* edge_off, int N, int E, int G, int dg,
-                                                float* d_gf) {
-  __shared__ float s_red[256];
-  const int g = blockIdx.x, tid = threadIdx.x;
-  const size_t r = blockIdx.y;
-  for (int k = 0; k < dg; ++k) {
-    float s = 0.f;
-    if (dXn) for (int n = node_off[g] + tid; n < node_off[g + 1]; n += 256) s += dXn[(r * N + n) * (size_t)Kn + n_off + k];
-    float s2 = 0.f;
-    if (dXe) for (int e = edge_off[g] + tid; e < edge_off[g + 1]; e += 256) s2 += dXe[(r * E + e) * (size_t)Ke + e_off + k];
-    s_red[tid] = s + s2;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-      if (tid < w) s_red[tid] += s_red[tid + w];
-      __syncthreads();
-    }
-    if (tid == 0) d_gf[(r * G + g) * (size_t)dg + k] = s_red[0] + (dXg ? dXg[(r * G + g) * (size_t)Kg + g_off + k] : 0.f);
-    __syncthreads();
-  }
-}
-
 // per-graph column sums of a row tensor (sum_e ef', sum_n nf' for Xg), two stages, fixed order:
 // stage 1: workgroup (slice s of graph g): thread (grp, c) strides over the slice's rows for column c -> partial[g][s][c]
 __global__ __launch_bounds__(256) void k_bw_colsum1(const float* __restrict__ in, int d, int rows_total, const int* __restrict__ off, int S,
-                                                    int G, float* __restrict__ partial) {
+                                                    int G, float* __restrict__ partial, int ld, int coff) {  // ld: row length of `in`, coff: first column
   __shared__ float s_red[256];
   const int sl = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
   const size_t r = blockIdx.z;
   const int t0 = off[g], t1 = off[g + 1];
   const int per = (t1 - t0 + S - 1) / S;
   const int a0 = t0 + sl * per, a1 = min(a0 + per, t1);
-  const float* base = in + r * (size_t)rows_total * d;
+  const float* base = in + r * (size_t)rows_total * ld + coff;
   for (int c0 = 0; c0 < d; c0 += 256) {
     const int dc = min(d - c0, 256);         // columns handled in this pass
     const int groups = 256 / dc;             // row groups working in parallel
@@ -128,7 +114,7 @@ __global__ __launch_bounds__(256) void k_bw_colsum1(const float* __restrict__ in
       for (int m = a0 + grp; m < a1; m += 8 * groups) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = base[(size_t)min(m + u * groups, a1 - 1) * d + c0 + c];
+        for (int u = 0; u < 8; ++u) v[u] = base[(size_t)min(m + u * groups, a1 - 1) * ld + c0 + c];
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += m + u * groups < a1 ? v[u] : 0.f;
       }
@@ -144,14 +130,22 @@ __global__ __launch_bounds__(256) void k_bw_colsum1(const float* __restrict__ in
   }
 }
 // stage 2: out[(r*G+g)*out_stride + out_off + c] = sum_s partial[g][s][c]
-__global__ void k_bw_colsum2(const float* __restrict__ partial, int d, int S, int G, float* __restrict__ out, int out_stride, int out_off) {
+__global__ void k_bw_colsum2(const float* __restrict__ partial, int d, int S, int G, float* __restrict__ out, int out_stride, int out_off,
+                             int accumulate) {
   const int g = blockIdx.x;
   const size_t r = blockIdx.y;
   for (int c = threadIdx.x; c < d; c += blockDim.x) {
     float acc = 0.f;
     for (int sl = 0; sl < S; ++sl) acc += partial[((r * G + g) * S + sl) * (size_t)d + c];
-    out[(r * G + g) * (size_t)out_stride + out_off + c] = acc;
+    float* o = out + (r * G + g) * (size_t)out_stride + out_off + c;
+    *o = accumulate ? *o + acc : acc;
   }
+}
+// d_gf[g][k] = dXg[g][g_off + k] (or 0): the graph function's own share; the node / edge shares are added by column sums
+__global__ void k_bw_dgf_init(const float* __restrict__ dXg, int Kg, int g_off, int GR, int dg, float* __restrict__ d_gf) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= GR * dg) return;
+  d_gf[idx] = dXg ? dXg[(size_t)(idx / dg) * Kg + g_off + idx % dg] : 0.f;
 }
 __global__ void k_bw_copy_gf(const float* __restrict__ gf, int dg, int GR, float* __restrict__ out, int out_stride, int out_off) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,8 +204,11 @@ __global__ __launch_bounds__(256) void k_bw_dw_final(const float* __restrict__ p
   }
 }
 
+static int32_t colsum_all(const float* in, size_t rows, int d, float* out, float* part, int* d_off2, hipStream_t s);
+__global__ void k_set_off2(int* off2, int rows);
+
 struct BwLayout {
-  size_t Xe, Xn, Xg, de_, dn_, dg_, dXe, dXn, dXg, part, total;
+  size_t Xe, Xn, Xg, de_, dn_, dg_, dXe, dXn, dXg, part, wt, off2, total;
 };
 static BwLayout bw_layout(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
   const size_t E = h->E, N = h->N, G = h->G;
@@ -224,8 +221,11 @@ static BwLayout bw_layout(const gnx_graphs* h, const gnx_block_params* p, int64_
   L.dXe = take(R * E * Ke); L.dXn = take(R * N * Kn); L.dXg = take(R * G * Kg);
   const size_t ch_e = (R * E + BW_CH - 1) / BW_CH, ch_n = (R * N + BW_CH - 1) / BW_CH, ch_g = (R * G + BW_CH - 1) / BW_CH;
   const size_t pmax = std::max({ch_e * p->oe * (Ke + 1), ch_n * p->on * (Kn + 1), ch_g * p->og * (Kg + 1)});
-  const size_t cs = (size_t)R * G * 256 * std::max(p->oe, p->on);  // per-graph column-sum slices
-  L.part = take(std::max(pmax, cs));
+  const size_t cs = std::max((size_t)R * G * 256, (size_t)2048) * std::max({p->oe, p->on, 1});  // column-sum slices
+  const size_t pm = std::max(dw_mfma_partial_floats(R * E, p->oe, (int)Ke), dw_mfma_partial_floats(R * N, p->on, (int)Kn));
+  L.part = take(std::max({pmax, cs, pm}));
+  L.wt = take(std::max({(size_t)p->oe * Ke, (size_t)p->on * Kn, (size_t)p->og * Kg}));
+  L.off2 = take(16);
   L.total = o + 256;
   return L;
 }
@@ -309,13 +309,35 @@ __global__ __launch_bounds__(256) void k_ln_backward(const float* __restrict__ x
 int32_t launch_layernorm2(const float* x, size_t rows, int d, const gnx_layernorm& l1, const gnx_layernorm& l2, float eps, int eps_mode,
                           float* y1, float* y2, hipStream_t s);
 
-// column sums over ALL rows of a [rows][d] tensor -> out[d] (one "graph" spanning everything), via the two-stage kernels
+// stage 2 for many slices: out[c] = sum_s partial[s][c]; 64 columns per workgroup, 4 slice groups, fixed order
+__global__ __launch_bounds__(256) void k_bw_colsum_final(const float* __restrict__ partial, int d, int S, float* __restrict__ out) {
+  __shared__ float s_red[4][64];
+  const int tid = threadIdx.x, cl = tid & 63, sg = tid >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float acc = 0.f;
+  if (c < d) {
+    for (int sl = sg; sl < S; sl += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)min(sl + 4 * u, S - 1) * d + c];  // clamped: value unused past S
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += sl + 4 * u < S ? v[u] : 0.f;
+    }
+  }
+  s_red[sg][cl] = acc;
+  __syncthreads();
+  if (tid < 64 && c < d) out[c] = (s_red[0][cl] + s_red[1][cl]) + (s_red[2][cl] + s_red[3][cl]);
+}
+
+// column sums over ALL rows of a [rows][d] tensor -> out[d] (one "graph" spanning everything): up to 2048 row slices in
+// stage 1 (k_bw_colsum1: enough workgroups to pull HBM bandwidth), parallel fixed-order stage 2
 static int32_t colsum_all(const float* in, size_t rows, int d, float* out, float* part, int* d_off2, hipStream_t s) {
   if (!out || d == 0) return GNX_OK;
   if (rows == 0) { GNX_HIP(hipMemsetAsync(out, 0, sizeof(float) * d, s)); return GNX_OK; }
-  const int S = (int)std::min<size_t>(std::max<size_t>(rows / 2048, 1), 256);
-  hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S, 1, 1), dim3(256), 0, s, in, d, (int)rows, d_off2, S, 1, part);
-  hipLaunchKernelGGL(k_bw_colsum2, dim3(1, 1), dim3(64), 0, s, part, d, S, 1, out, d, 0);
+  ProfScope ps("bw_colsum_all", s);
+  const int S = (int)std::min<size_t>(std::max<size_t>(rows / 512, 1), 2048);
+  hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S, 1, 1), dim3(256), 0, s, in, d, (int)rows, d_off2, S, 1, part, d, 0);
+  hipLaunchKernelGGL(k_bw_colsum_final, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, s, part, d, S, out);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -354,28 +376,34 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   char* base = static_cast<char*>(ws);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
   float *Xe = F(L.Xe), *Xn = F(L.Xn), *Xg = F(L.Xg), *dlt_e = F(L.de_), *dlt_n = F(L.dn_), *dlt_g = F(L.dg_);
-  float *dXe = F(L.dXe), *dXn = F(L.dXn), *dXg = F(L.dXg), *part = F(L.part);
+  float *dXe = F(L.dXe), *dXn = F(L.dXn), *dXg = F(L.dXg), *part = F(L.part), *wt = F(L.wt);
+  int* off2 = reinterpret_cast<int*>(base + L.off2);
+  int dxe_stride = 0, dxe_col0 = 0;  // row length / first column of what dXe holds (set below)
   const int E = (int)h->E, N = (int)h->N, G = (int)h->G;
   const int Ke = de + 2 * dn + dg, Kn = oe + dn + dg, Kg = oe + on + dg;
+  dxe_stride = Ke;
   const gnx_block_grads none{};
   const gnx_block_grads& gr = grads ? *grads : none;
   auto blocks = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
   const unsigned Ru = (unsigned)R;
 
+  // per-graph column sums of a column block of a row tensor, two stages, fixed order
+  int64_t me = 1, mn = 1;
+  for (int64_t g = 0; g < h->G; ++g) { me = std::max(me, h->h_edge_off[g + 1] - h->h_edge_off[g]); mn = std::max(mn, h->h_node_off[g + 1] - h->h_node_off[g]); }
+  auto colsum = [&](const float* in, int d, int ld, int coff, int rows_total, const int* off, int64_t max_rows, float* out, int out_stride, int out_off,
+                    int accumulate) {
+    if (d == 0) return;
+    const int S = (int)std::min<int64_t>(std::max<int64_t>(max_rows / 2048, 1), 256);
+    hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S, (unsigned)G, Ru), dim3(256), 0, s, in, d, rows_total, off, S, G, part, ld, coff);
+    hipLaunchKernelGGL(k_bw_colsum2, dim3((unsigned)G, Ru), dim3(64), 0, s, part, d, S, G, out, out_stride, out_off, accumulate);
+  };
   // function inputs, exactly as the forward's building blocks define them
+  { ProfScope ps("bw_fn_inputs", s);
   if (oe && E && (rc = launch_fn_input(h, 0, ef, de, nf, dn, gf, dg, R, Xe, s))) return rc;
-  if (on && (rc = launch_fn_input(h, 1, ef_out, oe, nf, dn, gf, dg, R, Xn, s))) return rc;
+  if (on && (rc = launch_fn_input(h, 1, ef_out, oe, nf, dn, gf, dg, R, Xn, s))) return rc; }
   if (og) {  // Xg = [sum_e ef' ; sum_n nf' ; gf] with parallel two-stage column sums (one workgroup per graph would walk 1M rows)
-    auto colsum = [&](const float* in, int d, int rows_total, const int* off, int64_t max_rows, int out_off) {
-      if (d == 0) return;
-      int S = (int)std::min<int64_t>(std::max<int64_t>(max_rows / 2048, 1), 256);
-      hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S, (unsigned)G, Ru), dim3(256), 0, s, in, d, rows_total, off, S, G, part);
-      hipLaunchKernelGGL(k_bw_colsum2, dim3((unsigned)G, Ru), dim3(64), 0, s, part, d, S, G, Xg, Kg, out_off);
-    };
-    int64_t me = 1, mn = 1;
-    for (int64_t g = 0; g < h->G; ++g) { me = std::max(me, h->h_edge_off[g + 1] - h->h_edge_off[g]); mn = std::max(mn, h->h_node_off[g + 1] - h->h_node_off[g]); }
-    colsum(ef_out, oe, E, h->d_edge_off, me, 0);
-    colsum(nf_out, on, N, h->d_node_off, mn, oe);
+    colsum(ef_out, oe, oe, 0, E, h->d_edge_off, me, Xg, Kg, 0, 0);
+    colsum(nf_out, on, on, 0, N, h->d_node_off, mn, Xg, Kg, oe, 0);
     if (dg) hipLaunchKernelGGL(k_bw_copy_gf, blocks((size_t)R * G * dg), dim3(256), 0, s, gf, dg, (int)(R * G), Xg, Kg, oe + on);
     GNX_HIP(hipGetLastError());
   }
@@ -393,16 +421,35 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   if (have_n) {
     DeltaArgs a{g_nf_out, nf_out, dlt_n, have_g ? dXg : nullptr, Kg, oe, nullptr, 0, 0, h->d_node_off, nullptr, on, N, G, acts[1], 1};
     hipLaunchKernelGGL(k_bw_delta, dim3(blocks((size_t)N * on).x, Ru), dim3(256), 0, s, a, (size_t)G * Kg, (size_t)0);
-    hipLaunchKernelGGL(k_bw_dx, dim3(blocks((size_t)N * Kn).x, Ru), dim3(256), 0, s, dlt_n, p->nodefn.weight, N, on, Kn, dXn, 0, 0, (float*)nullptr, 0);
-    if ((rc = dw_reduce(dlt_n, Xn, (size_t)R * N, on, Kn, gr.nodefn, part, s))) return rc;
+    if (bw_use_mfma((size_t)R * N, on, Kn)) {  // matrix cores: dXn = dn Wn^T, dWn = Xn^T dn, dbn = column sums
+      if ((rc = dx_mfma(h, 1, dlt_n, p->nodefn.weight, on, Kn, 0, Kn, dXn, R, wt, true, s, "bw_dx_node"))) return rc;
+      if ((rc = dw_mfma(dlt_n, Xn, (size_t)R * N, on, Kn, gr.nodefn.weight, part, s))) return rc;
+      hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)(R * N));
+      if ((rc = colsum_all(dlt_n, (size_t)R * N, on, gr.nodefn.bias, part, off2, s))) return rc;
+    } else {
+      hipLaunchKernelGGL(k_bw_dx, dim3(blocks((size_t)N * Kn).x, Ru), dim3(256), 0, s, dlt_n, p->nodefn.weight, N, on, Kn, dXn, 0, 0, (float*)nullptr, 0);
+      if ((rc = dw_reduce(dlt_n, Xn, (size_t)R * N, on, Kn, gr.nodefn, part, s))) return rc;
+    }
   }
   // edge level
   const bool have_e = oe > 0 && E > 0;
   if (have_e) {
     DeltaArgs a{g_ef_out, ef_out, dlt_e, have_g ? dXg : nullptr, Kg, 0, have_n ? dXn : nullptr, Kn, 0, h->d_edge_off, h->d_edge_dst, oe, E, G, acts[0], 2};
-    hipLaunchKernelGGL(k_bw_delta, dim3(blocks((size_t)E * oe).x, Ru), dim3(256), 0, s, a, (size_t)G * Kg, (size_t)N * Kn);
-    hipLaunchKernelGGL(k_bw_dx, dim3(blocks((size_t)E * Ke).x, Ru), dim3(256), 0, s, dlt_e, p->edgefn.weight, E, oe, Ke, dXe, 0, de, d_ef, de);
-    if ((rc = dw_reduce(dlt_e, Xe, (size_t)R * E, oe, Ke, gr.edgefn, part, s))) return rc;
+    { ProfScope ps("bw_delta_edge", s);
+    hipLaunchKernelGGL(k_bw_delta, dim3(blocks((size_t)E * oe).x, Ru), dim3(256), 0, s, a, (size_t)G * Kg, (size_t)N * Kn); }
+    if (bw_use_mfma((size_t)R * E, oe, Ke)) {
+      // matrix cores: the ef columns of dXe ARE d_ef; the remaining columns [de, Ke) go to dXe with row length Ke - de
+      const bool want_ef = d_ef && de;
+      if (want_ef && (rc = dx_mfma(h, 0, dlt_e, p->edgefn.weight, oe, Ke, 0, de, d_ef, R, wt, true, s, "bw_dx_edge_ef"))) return rc;
+      if ((rc = dx_mfma(h, 0, dlt_e, p->edgefn.weight, oe, Ke, de, Ke, dXe, R, wt, !want_ef, s, "bw_dx_edge_rest"))) return rc;
+      dxe_stride = Ke - de; dxe_col0 = de;
+      if ((rc = dw_mfma(dlt_e, Xe, (size_t)R * E, oe, Ke, gr.edgefn.weight, part, s))) return rc;
+      hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)(R * E));
+      if ((rc = colsum_all(dlt_e, (size_t)R * E, oe, gr.edgefn.bias, part, off2, s))) return rc;
+    } else {
+      hipLaunchKernelGGL(k_bw_dx, dim3(blocks((size_t)E * Ke).x, Ru), dim3(256), 0, s, dlt_e, p->edgefn.weight, E, oe, Ke, dXe, 0, de, d_ef, de);
+      if ((rc = dw_reduce(dlt_e, Xe, (size_t)R * E, oe, Ke, gr.edgefn, part, s))) return rc;
+    }
   } else {
     if (d_ef && de && E) GNX_HIP(hipMemsetAsync(d_ef, 0, sizeof(float) * (size_t)R * E * de, s));
     if (gr.edgefn.weight && oe) GNX_HIP(hipMemsetAsync(gr.edgefn.weight, 0, sizeof(float) * (size_t)oe * Ke, s));
@@ -413,12 +460,17 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
     if (gr.nodefn.bias && on) GNX_HIP(hipMemsetAsync(gr.nodefn.bias, 0, sizeof(float) * (size_t)on, s));
   }
   // input gradients that need sums
-  if (d_nf && dn)
-    hipLaunchKernelGGL(k_bw_dnf, dim3(blocks((size_t)N * dn).x, Ru), dim3(256), 0, s, have_n ? dXn : nullptr, Kn, oe, have_e ? dXe : nullptr, Ke, de,
-                       de + dn, h->d_colptr, h->d_csr_ptr, h->d_csr_eid, N, E, dn, d_nf);
-  if (d_gf && dg)
-    hipLaunchKernelGGL(k_bw_dgf, dim3((unsigned)G, Ru), dim3(256), 0, s, have_g ? dXg : nullptr, Kg, oe + on, have_n ? dXn : nullptr, Kn, oe + dn,
-                       have_e ? dXe : nullptr, Ke, de + 2 * dn, h->d_node_off, h->d_edge_off, N, E, G, dg, d_gf);
+  if (d_nf && dn) {
+    ProfScope ps("bw_dnf", s);
+    hipLaunchKernelGGL(k_bw_dnf, dim3(blocks((size_t)N * dn).x, Ru), dim3(256), 0, s, have_n ? dXn : nullptr, Kn, oe, have_e ? dXe : nullptr, dxe_stride,
+                       de - dxe_col0, de + dn - dxe_col0, h->d_colptr, h->d_csr_ptr, h->d_csr_eid, N, E, dn, d_nf);
+  }
+  if (d_gf && dg) {  // d_gf[g] = dXg[g][gf cols] + sum_{n in g} dXn[n][gf cols] + sum_{e in g} dXe[e][gf cols]
+    ProfScope ps("bw_dgf", s);
+    hipLaunchKernelGGL(k_bw_dgf_init, blocks((size_t)R * G * dg), dim3(256), 0, s, have_g ? dXg : nullptr, Kg, oe + on, (int)(R * G), dg, d_gf);
+    if (have_n) colsum(dXn, dg, Kn, oe + dn, N, h->d_node_off, mn, d_gf, dg, 0, 1);
+    if (have_e) colsum(dXe, dg, dxe_stride, de + 2 * dn - dxe_col0, E, h->d_edge_off, me, d_gf, dg, 0, 1);
+  }
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -427,7 +479,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
 // ---- GNCore backward ----
 namespace {
 struct CoreBwLayout {
-  size_t l1[3], l2[3], bout[3], dl1[3], dz2[3], h, dh, t1, t2, off2, blk_fw, blk_bw, part, total;
+  size_t l1[3], l2[3], bout[3], dl1[3], dz2[3], h, dh, t1, t2, off2, blk_fw, blk_bw, part, wt, total;
 };
 CoreBwLayout core_bw_layout(const gnx_graphs* h, const gnx_core_params* p, int64_t R) {
   const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
@@ -445,13 +497,15 @@ CoreBwLayout core_bw_layout(const gnx_graphs* h, const gnx_core_params* p, int64
   L.h = take(hmax); L.dh = take(hmax); L.t1 = take(tmax); L.t2 = take(tmax); L.off2 = take(64);
   L.blk_fw = take(gnx_block_workspace_bytes(h, &p->block, R));
   L.blk_bw = take(gnx_block_backward_workspace_bytes(h, &p->block, R));
-  size_t pmax = sizeof(float) * 256 * 4 * (size_t)std::max(d[0], std::max(d[1], d[2]));
+  size_t pmax = sizeof(float) * 2048 * 4 * (size_t)std::max(d[0], std::max(d[1], d[2]));
   for (int t = 0; t < 3; ++t) {
     const size_t ch = (rows[t] + BW_CH - 1) / BW_CH;
     pmax = std::max(pmax, sizeof(float) * ch * (size_t)(4 * d[t]) * (d[t] + 1));
     pmax = std::max(pmax, sizeof(float) * ch * (size_t)d[t] * (4 * d[t] + 1));
+    pmax = std::max(pmax, sizeof(float) * dw_mfma_partial_floats(rows[t], 4 * d[t], d[t]));
   }
   L.part = take(pmax);
+  L.wt = take(sizeof(float) * 4 * (size_t)std::max(d[0], std::max(d[1], d[2])) * std::max(d[0], std::max(d[1], d[2])));
   L.total = o + 256;
   return L;
 }
@@ -509,6 +563,22 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
       continue;
     }
     float* hbuf = F(L.h); float* dh = F(L.dh);
+    if (bw_use_mfma(rows[t], D, H)) {  // matrix cores (gnx_backward_wide.hip); rows[t] = R * (rows of entity t)
+      float* wt = F(L.wt);
+      if ((rc = launch_dense_rows(h, t, F(L.l2[t]), D, p->ff[t].fc1, H, nullptr, nullptr, hbuf, R, s, "bw_ff1_recompute"))) return rc;
+      if ((rc = dw_mfma(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2.weight, part, s))) return rc;                   // dW2 = h^T g
+      hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows[t]);
+      if ((rc = colsum_all(gout[t], rows[t], D, gr.ff[t].fc2.bias, part, off2, s))) return rc;
+      if ((rc = dx_mfma(h, t, gout[t], p->ff[t].fc2.weight, D, H, 0, H, dh, R, wt, true, s, "bw_dx_ff2"))) return rc;   // dh = g W2^T
+      DeltaArgs a{dh, hbuf, dh, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, H, (int)rows[t], 1, p->ff[t].fc1.act, 0};
+      { ProfScope ps("bw_delta_hidden", s);
+        hipLaunchKernelGGL(k_bw_delta, dim3(blocks(rows[t] * H).x, 1), dim3(256), 0, s, a, (size_t)0, (size_t)0); }
+      if ((rc = dw_mfma(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1.weight, part, s))) return rc;                  // dW1 = z^T delta1
+      if ((rc = colsum_all(dh, rows[t], H, gr.ff[t].fc1.bias, part, off2, s))) return rc;
+      if ((rc = dx_mfma(h, t, dh, p->ff[t].fc1.weight, H, D, 0, D, dz2, R, wt, true, s, "bw_dx_ff1"))) return rc;        // dz2 = delta1 W1^T
+      GNX_HIP(hipGetLastError());
+      continue;
+    }
     hipLaunchKernelGGL(k_fw_dense, blocks(rows[t] * H), dim3(256), 0, s, F(L.l2[t]), p->ff[t].fc1.weight, p->ff[t].fc1.bias, rows[t], D, H, p->ff[t].fc1.act, hbuf);
     if ((rc = dw_reduce(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, s))) return rc;                       // dW2 = g^T h
     hipLaunchKernelGGL(k_bw_dx, dim3(blocks(rows[t] * H).x, 1), dim3(256), 0, s, gout[t], p->ff[t].fc2.weight, (int)rows[t], D, H, dh, 0, 0, (float*)nullptr, 0);
@@ -525,8 +595,9 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
   for (int t = 0; t < 3; ++t) {
     if (rows[t] == 0) continue;
     float* t1 = F(L.t1); float* t2 = F(L.t2);
+    { ProfScope ps("bw_layernorm", s);
     hipLaunchKernelGGL(k_ln_backward, dim3((unsigned)((rows[t] + 3) / 4)), dim3(256), 0, s, x[t], rows[t], d[t], p->ln1[t].gamma, p->ln2[t].gamma, F(L.dl1[t]),
-                       F(L.dz2[t]), gout[t], p->eps, p->eps_mode, dxo[t], t1, t2);
+                       F(L.dz2[t]), gout[t], p->eps, p->eps_mode, dxo[t], t1, t2); }
     hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows[t]);
     if ((rc = colsum_all(t1, rows[t], d[t], gr.ln1[t].gamma, part, off2, s))) return rc;
     if ((rc = colsum_all(F(L.dl1[t]), rows[t], d[t], gr.ln1[t].beta, part, off2, s))) return rc;

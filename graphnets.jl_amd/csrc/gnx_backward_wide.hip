@@ -1,0 +1,165 @@
+// Matrix-core versions of the two heavy primitives of the backward pass (gnx_backward.hip) for wide feature widths:
+//   dX = delta * W^T        rows x J times J x K       -> k_rows_gemm (gnx_wide.hip) on a transposed copy of W
+//   dW = X^T * delta        K x J, reduced over ALL rows -> k_dw_gemm below: split over row chunks, fixed-order final sum
+// Both are exact fp32 (v_mfma_f32_32x32x2_f32) with a fixed summation order, like the forward.
+#include <algorithm>
+
+#include "gnx_device.h"
+
+namespace gnx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int K, const float* B, int ldw, int OUT, float* out, int64_t R,
+                           hipStream_t s, const char* name);
+
+// WT[j*K + k] = W[k*J + j]   (W = [K][J] row-major, i.e. the (J x K) column-major Dense weight)
+__global__ void k_transpose_w(const float* __restrict__ W, int K, int J, float* __restrict__ WT) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= K * J) return;
+  const int j = idx / K, k = idx % K;
+  WT[idx] = W[(size_t)k * J + j];
+}
+
+// partial[chunk][k][j] = sum_{m in chunk} X[m][k] * D[m][j] for one 128 x 128 tile of (k, j).
+// Workgroup = 4 waves, each a 64 x 64 quadrant (2 x 2 MFMA blocks); rows stream through LDS 32 at a time as TWO row-major
+// panels (X[32][128], D[32][128], coalesced 16-B loads, next panel prefetched into registers during the MFMAs).  The MFMA
+// reduction index is the ROW: A fragment = X[row 2s+hi][k-col l31], B fragment = D[row 2s+hi][j-col l31] — both are
+// 32 consecutive floats of one LDS row per half-wave: conflict-free without padding.
+template <bool VEC4>
+__global__ __launch_bounds__(256) void k_dw_gemm(const float* __restrict__ X, int K, const float* __restrict__ D, int J, size_t rows, int CH,
+                                                 float* __restrict__ partial) {
+  constexpr int RC = 32;
+  __shared__ __attribute__((aligned(16))) float sX[RC * 128];
+  __shared__ __attribute__((aligned(16))) float sD[RC * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int hi = lane >> 5, l31 = lane & 31;
+  const int k0 = blockIdx.y * 128, j0 = blockIdx.z * 128;
+  const size_t m0 = (size_t)blockIdx.x * CH;
+  const size_t m1 = m0 + CH < rows ? m0 + CH : rows;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  float4 rx[4], rd[4];
+  auto load4 = [](const float* p, int avail) {  // up to 4 floats starting at p, `avail` of them inside the matrix
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (avail >= 4 && VEC4) return *reinterpret_cast<const float4*>(p);
+    if (avail > 0) v.x = p[0];
+    if (avail > 1) v.y = p[1];
+    if (avail > 2) v.z = p[2];
+    if (avail > 3) v.w = p[3];
+    return v;
+  };
+  auto load = [&](size_t mb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i, row = q >> 5, c4 = q & 31;
+      const size_t m = mb + row;
+      const bool in = m < m1;
+      rx[i] = load4(X + m * K + k0 + 4 * c4, in ? K - (k0 + 4 * c4) : 0);
+      rd[i] = load4(D + m * J + j0 + 4 * c4, in ? J - (j0 + 4 * c4) : 0);
+    }
+  };
+  if (m0 < m1) load(m0);
+  for (size_t mb = m0; mb < m1; mb += RC) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + 256 * i;
+      *reinterpret_cast<float4*>(sX + 4 * q) = rx[i];
+      *reinterpret_cast<float4*>(sD + 4 * q) = rd[i];
+    }
+    __syncthreads();
+    if (mb + RC < m1) load(mb + RC);
+#pragma unroll
+    for (int sp = 0; sp < RC / 2; ++sp) {
+      float fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = sX[(2 * sp + hi) * 128 + (wm * 2 + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = sD[(2 * sp + hi) * 128 + (wn * 2 + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* out = partial + (size_t)blockIdx.x * K * J;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int jj = j0 + (wn * 2 + j) * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {  // C/D layout of the 32x32 MFMA: row = (q&3) + 8*(q>>2) + 4*hi, column = l31
+        const int k = k0 + (wm * 2 + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi;
+        if (k < K && jj < J) out[(size_t)k * J + jj] = acc[i][j][q];
+      }
+    }
+}
+
+// dW[p] = sum over chunks (in order) of partial[c][p]
+__global__ void k_dw_final2(const float* __restrict__ partial, int nchunks, size_t KJ, float* __restrict__ dW) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= KJ) return;
+  float acc = 0.f;
+  for (int c = 0; c < nchunks; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)min(c + u, nchunks - 1) * KJ + p];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += c + u < nchunks ? v[u] : 0.f;
+  }
+  dW[p] = acc;
+}
+
+bool bw_use_mfma(size_t rows, int J, int K) {
+  static const bool off = getenv("GNX_BW_GENERIC") != nullptr;
+  return !off && rows >= 4096 && (size_t)J * K >= 1024 && J >= 8 && K >= 8;
+}
+
+int dw_mfma_chunk_rows(size_t rows) { return (int)std::max<size_t>(1024, (rows + 1023) / 1024); }
+size_t dw_mfma_partial_floats(size_t rows, int J, int K) {
+  const size_t ch = dw_mfma_chunk_rows(rows);
+  return (rows + ch - 1) / ch * (size_t)J * K;
+}
+
+// dW[k*J + j] = sum_m X[m][k] * delta[m][j] over `rows` rows (all replicas).  partial: dw_mfma_partial_floats() floats.
+int32_t dw_mfma(const float* delta, const float* X, size_t rows, int J, int K, float* dW, float* partial, hipStream_t s) {
+  if (!dW || rows == 0 || J == 0 || K == 0) return GNX_OK;
+  const int CH = dw_mfma_chunk_rows(rows);
+  const unsigned nch = (unsigned)((rows + CH - 1) / CH);
+  const dim3 grid(nch, (unsigned)((K + 127) / 128), (unsigned)((J + 127) / 128));
+  const bool v4 = (((uintptr_t)delta | (uintptr_t)X) & 15) == 0 && J % 4 == 0 && K % 4 == 0;
+  {
+    ProfScope ps("k_dw_gemm", s);
+    if (v4) hipLaunchKernelGGL((k_dw_gemm<true>), grid, dim3(256), 0, s, X, K, delta, J, rows, CH, partial);
+    else hipLaunchKernelGGL((k_dw_gemm<false>), grid, dim3(256), 0, s, X, K, delta, J, rows, CH, partial);
+  }
+  const size_t KJ = (size_t)K * J;
+  {
+    ProfScope ps("k_dw_final2", s);
+    hipLaunchKernelGGL(k_dw_final2, dim3((unsigned)((KJ + 255) / 256)), dim3(256), 0, s, partial, (int)nch, KJ, dW);
+  }
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+// dX[:, ka:kb) = delta * W^T[:, ka:kb) on the matrix cores.  WT: K*J floats of workspace, filled here when `fill` is set.
+int32_t dx_mfma(const gnx_graphs* h, int entity, const float* delta, const float* W, int J, int K, int ka, int kb, float* out, int64_t R,
+                float* WT, bool fill, hipStream_t s, const char* name) {
+  if (kb <= ka || J == 0) return GNX_OK;
+  if (fill) {
+    hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)((K * J + 255) / 256)), dim3(256), 0, s, W, K, J, WT);
+    GNX_HIP(hipGetLastError());
+  }
+  return launch_rows_matmul(h, entity, delta, J, WT + ka, K, kb - ka, out, R, s, name);
+}
+
+}  // namespace gnx

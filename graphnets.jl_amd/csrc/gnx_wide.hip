@@ -44,6 +44,7 @@ struct WideArgs {
   const int* idx_b;  // edge_dst (global destination node of every edge)
   const int* cp;     // colptr
   const float* W;    // (OUT x K) column-major == [K][OUT] row-major
+  int ldw;           // distance between rows of W (0: OUT) — lets a launch multiply by a column block of a wider matrix
   const float* bias;
   int OUT, act;
   const float* bias_g;  // [R][G][OUT] per-graph bias with gf folded in (k_fold_bias), or nullptr: use `bias`
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int n = n0 + 4 * c4;
       if (kc + kk < sg.width && n < a.OUT) {
-        const float* p = a.W + (size_t)(sg.w_row0 + kc + kk) * a.OUT + n;
+        const float* p = a.W + (size_t)(sg.w_row0 + kc + kk) * (a.ldw ? a.ldw : a.OUT) + n;
         if (VEC4) {
           v = *reinterpret_cast<const float4*>(p);
         } else {
@@ -555,6 +556,25 @@ int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K
   const unsigned n_tiles = (unsigned)(entity == 0 ? h->h_etiles.size() : (entity == 1 ? h->h_ntiles.size() : h->h_gtiles.size()));
   const bool al16 = ((uintptr_t)A | (uintptr_t)d.weight | (uintptr_t)out) % 16 == 0;
   return launch_gemm_any(w, al16 && K % 4 == 0 && OUT % 4 == 0, n_tiles, R, s, name);
+}
+
+// out[rows, OUT] = A[rows, K] * B over all rows of one entity type, B = [K][OUT] block of a matrix with row distance ldw
+// (no bias, no activation): the dX = delta * W^T products of the backward pass (gnx_backward.hip), B = transposed weights.
+int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int K, const float* B, int ldw, int OUT, float* out, int64_t R,
+                           hipStream_t s, const char* name) {
+  const size_t nrows = entity == 0 ? (size_t)h->E : (entity == 1 ? (size_t)h->N : (size_t)h->G);
+  if (nrows == 0 || OUT == 0 || K == 0) return GNX_OK;
+  WideArgs w{};
+  w.tiles = entity == 0 ? h->d_etiles : (entity == 1 ? h->d_ntiles : h->d_gtiles);
+  w.row_kind = entity == 0 ? 0 : 1;
+  w.seg[0] = WSeg{A, nrows * (size_t)K, K, 0, 0};
+  w.nseg = 1;
+  w.W = B; w.ldw = ldw; w.bias = nullptr; w.OUT = OUT; w.act = GNX_ACT_IDENTITY;
+  w.n_graphs = (int)h->G;
+  w.out = out; w.out_rep_stride = nrows * (size_t)OUT;
+  const unsigned n_tiles = (unsigned)(entity == 0 ? h->h_etiles.size() : (entity == 1 ? h->h_ntiles.size() : h->h_gtiles.size()));
+  const bool al16 = ((uintptr_t)A | (uintptr_t)B | (uintptr_t)out) % 16 == 0;
+  return launch_gemm_any(w, al16 && K % 4 == 0 && OUT % 4 == 0 && ldw % 4 == 0, n_tiles, R, s, name);
 }
 
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {

@@ -17,8 +17,9 @@ def gn():
     return gn
 
 
-def _torch_block(p, csc, ef, nf, gf, W):
-    """float64 torch restatement of SURVEY Appendix A (one replica); W = dict of leaf tensors."""
+def _torch_block(p, csc, ef, nf, gf, W, pre=None):
+    """float64 torch restatement of SURVEY Appendix A (one replica); W = dict of leaf tensors.  `pre` (a list) receives the
+    three pre-activations."""
     colptr, rowval, node_off, edge_off = (torch.from_numpy(np.asarray(a)) for a in csc)
     N, G = len(colptr) - 1, len(node_off) - 1
     dst = torch.repeat_interleave(torch.arange(N), colptr[1:] - colptr[:-1])
@@ -26,12 +27,17 @@ def _torch_block(p, csc, ef, nf, gf, W):
     eg = torch.repeat_interleave(torch.arange(G), edge_off[1:] - edge_off[:-1])
     cat = lambda parts: torch.cat([q for q in parts if q is not None], dim=1)
     Xe = cat([ef, None if nf is None else nf[rowval], None if nf is None else nf[dst], None if gf is None else gf[eg]])
-    he = ACT[p["act_e"]](Xe @ W["We"].T + W["be"])
+    ze = Xe @ W["We"].T + W["be"]
+    he = ACT[p["act_e"]](ze)
     agg = torch.zeros((N, he.shape[1]), dtype=torch.float64).index_add(0, dst, he)
-    hn = ACT[p["act_n"]](cat([agg, nf, None if gf is None else gf[ng]]) @ W["Wn"].T + W["bn"])
+    zn = cat([agg, nf, None if gf is None else gf[ng]]) @ W["Wn"].T + W["bn"]
+    hn = ACT[p["act_n"]](zn)
     se = torch.zeros((G, he.shape[1]), dtype=torch.float64).index_add(0, eg, he)
     sn = torch.zeros((G, hn.shape[1]), dtype=torch.float64).index_add(0, ng, hn)
-    hg = ACT[p["act_g"]](cat([se, sn, gf]) @ W["Wg"].T + W["bg"])
+    zg = cat([se, sn, gf]) @ W["Wg"].T + W["bg"]
+    hg = ACT[p["act_g"]](zg)
+    if pre is not None:
+        pre.extend([ze, zn, zg])
     return he, hn, hg
 
 
@@ -39,15 +45,42 @@ DIMS = [((10, 5, 0), (3, 4, 5)), ((3, 2, 4), (3, 4, 5)), ((0, 2, 0), (2, 2, 2)),
         ((40, 24, 8), (36, 20, 12))]
 
 
-@pytest.mark.parametrize("dims", DIMS, ids=[str(d) for d in DIMS])
-@pytest.mark.parametrize("act", [(0, 0, 0), (1, 2, 3)], ids=["identity", "relu-tanh-sigmoid"])
-def test_block_backward_matches_torch_autograd(gn, dims, act):
-    rng = np.random.default_rng(200 + sum(dims[0]) + sum(act))
-    sizes = rng.integers(5, 40, 6)
+def _graphs(rng, big):
+    """small: 6 graphs of 5..40 nodes (generic kernels); big: 3 graphs of 1500..2200 nodes, 4 edges per node — enough rows
+    (>= 4096 nodes and edges) for the matrix-core dX / dW kernels of the backward to be selected."""
+    sizes = rng.integers(1500, 2200, 3) if big else rng.integers(5, 40, 6)
     cps, rvs = [], []
     for n in sizes:
-        cp, rv = U.er_csc(rng, int(n), int(0.15 * n * n) + 1)
+        cp, rv = U.er_csc(rng, int(n), 4 * int(n) if big else int(0.15 * n * n) + 1)
         cps.append(cp); rvs.append(rv)
+    return sizes, cps, rvs
+
+
+BIG_DIMS = [((40, 24, 8), (36, 20, 12)), ((37, 22, 5), (35, 19, 7)), ((128, 64, 32), (128, 64, 32))]
+
+
+def _kink_free(pre_acts, margin=5e-6):
+    """relu is not differentiable at 0: an fp32 pre-activation within rounding distance of 0 can land on the other side
+    of the kink than the float64 reference and legitimately flip one derivative from 0 to 1.  The comparisons below are
+    only meaningful on data without such elements (small cases: re-draw; big cases use smooth activations)."""
+    return all(float(t.detach().abs().min()) > margin for t in pre_acts if t.numel())
+
+
+@pytest.mark.parametrize("dims", DIMS + BIG_DIMS, ids=[str(d) for d in DIMS] + ["mfma-" + str(d) for d in BIG_DIMS])
+@pytest.mark.parametrize("act", [(0, 0, 0), (1, 2, 3)], ids=["identity", "relu-tanh-sigmoid"])
+def test_block_backward_matches_torch_autograd(gn, dims, act, request):
+    big = "mfma-" in request.node.callspec.id
+    if big and act[0] == 1:
+        act = (2, 2, 3)  # ~800k edge outputs: some pre-activation always sits on the relu kink; tanh keeps the check meaningful
+    for attempt in range(20):
+        rng = np.random.default_rng(200 + sum(dims[0]) + sum(act) + 1000 * attempt)
+        if _block_backward_case(gn, dims, act, big, rng):
+            return
+    pytest.fail("no kink-free draw in 20 attempts")
+
+
+def _block_backward_case(gn, dims, act, big, rng):
+    sizes, cps, rvs = _graphs(rng, big)
     g = gn.GNGraphBatch.from_csc(cps, rvs, [int(n) for n in sizes])
     csc = (*g.csc(), g.node_off, g.edge_off)
     p = O.make_block_params(rng, *dims, act=act)
@@ -56,7 +89,10 @@ def test_block_backward_matches_torch_autograd(gn, dims, act):
     W = {k: torch.tensor(p[k], dtype=torch.float64, requires_grad=True) for k in ("We", "be", "Wn", "bn", "Wg", "bg")}
     t64 = lambda a: None if a is None else torch.tensor(a[0], dtype=torch.float64, requires_grad=True)
     ef_r, nf_r, gf_r = t64(ef), t64(nf), t64(gf)
-    outs_r = _torch_block(p, csc, ef_r, nf_r, gf_r, W)
+    pre = []
+    outs_r = _torch_block(p, csc, ef_r, nf_r, gf_r, W, pre)
+    if not _kink_free([z for z, a in zip(pre, act) if a == 1]):
+        return False
     cot = [torch.from_numpy(rng.standard_normal(tuple(o.shape))) for o in outs_r]  # random cotangents
     loss_r = sum((o * c).sum() for o, c in zip(outs_r, cot) if o.shape[1] > 0)
     loss_r.backward()
@@ -90,6 +126,7 @@ def test_block_backward_matches_torch_autograd(gn, dims, act):
         if layer.weight.numel():
             close(layer.weight.grad, W[kw].grad, f"dW_{name}")
             close(layer.bias.grad, W[kb].grad, f"db_{name}")
+    return True
 
 
 def test_backward_is_deterministic_and_trains(gn):
@@ -137,18 +174,24 @@ def _torch_ln(x, gamma, beta, eps, eps_mode):
 
 
 @pytest.mark.parametrize("eps_mode", [0, 1])
-@pytest.mark.parametrize("dims", [(3, 4, 5), (10, 5, 3), (40, 36, 33)], ids=str)
-def test_core_backward_matches_torch_autograd(gn, dims, eps_mode):
-    """gnx_core_backward (LayerNorm + FeedForward + block pullbacks, residual) against torch float64 autograd."""
-    rng = np.random.default_rng(400 + sum(dims) + eps_mode)
-    sizes = rng.integers(4, 25, 5)
-    cps, rvs = [], []
-    for n in sizes:
-        cp, rv = U.er_csc(rng, int(n), int(0.2 * n * n) + 1)
-        cps.append(cp); rvs.append(rv)
+@pytest.mark.parametrize("dims,big", [((3, 4, 5), False), ((10, 5, 3), False), ((40, 36, 33), False), ((40, 36, 33), True), ((64, 32, 16), True)],
+                         ids=lambda v: str(v))
+def test_core_backward_matches_torch_autograd(gn, dims, big, eps_mode):
+    """gnx_core_backward (LayerNorm + FeedForward + block pullbacks, residual) against torch float64 autograd.  Small cases
+    use the reference's relu FeedForward on kink-free draws; the big (matrix-core) cases use tanh as the hidden activation."""
+    for attempt in range(20):
+        rng = np.random.default_rng(400 + sum(dims) + eps_mode + 1000 * attempt)
+        if _core_backward_case(gn, dims, big, eps_mode, rng):
+            return
+    pytest.fail("no kink-free draw in 20 attempts")
+
+
+def _core_backward_case(gn, dims, big, eps_mode, rng):
+    sizes, cps, rvs = _graphs(rng, big)
     g = gn.GNGraphBatch.from_csc(cps, rvs, [int(n) for n in sizes])
     csc = (*g.csc(), g.node_off, g.edge_off)
     p = O.make_core_params(rng, dims, eps_mode=eps_mode)
+    hidden_act = "tanh" if big else "relu"
     ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims)
     # reference
     T = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
@@ -158,14 +201,21 @@ def test_core_backward_matches_torch_autograd(gn, dims, eps_mode):
     l1 = [_torch_ln(x, W[f"ln1_{t}_gamma"], W[f"ln1_{t}_beta"], p["eps"], eps_mode) for x, t in zip(xs, "eng")]
     l2 = [_torch_ln(x, W[f"ln2_{t}_gamma"], W[f"ln2_{t}_beta"], p["eps"], eps_mode) for x, t in zip(xs, "eng")]
     blk = _torch_block(p["block"], csc, l1[0], l1[1], l1[2], Wb)
-    outs_r = []
+    outs_r, pre = [], []
     for x, z, b, t in zip(xs, l2, blk, "eng"):
-        hdn = torch.relu(z @ W[f"ff_{t}_W1"].T + W[f"ff_{t}_b1"])
+        zh = z @ W[f"ff_{t}_W1"].T + W[f"ff_{t}_b1"]
+        pre.append(zh)
+        hdn = torch.tanh(zh) if big else torch.relu(zh)
         outs_r.append(x + b + hdn @ W[f"ff_{t}_W2"].T + W[f"ff_{t}_b2"])
+    if not big and not _kink_free(pre):
+        return False
     cot = [torch.from_numpy(rng.standard_normal(tuple(o.shape))) for o in outs_r]
     sum((o * c).sum() for o, c in zip(outs_r, cot)).backward()
     # HIP
     core = U.core_from_params(gn, p)
+    for name, t in (("eff", "e"), ("nff", "n"), ("gff", "g")):
+        fc1, fc2 = getattr(core.ffwd, name)
+        setattr(core.ffwd, name, (gn.Dense.from_numpy(p[f"ff_{t}_W1"], p[f"ff_{t}_b1"], hidden_act, None), fc2))
     for q in core.parameters():
         q.requires_grad_(True)
     dev = g.device
@@ -190,6 +240,7 @@ def test_core_backward_matches_torch_autograd(gn, dims, eps_mode):
         refs += [W[f"ff_{t}_W1"].grad, W[f"ff_{t}_b1"].grad, W[f"ff_{t}_W2"].grad, W[f"ff_{t}_b2"].grad]
     for i, (q, r) in enumerate(zip(core.parameters(), refs)):
         close(q.grad, r, f"param[{i}]")
+    return True
 
 
 def test_readout_loss_is_differentiable(gn):
