@@ -24,21 +24,13 @@ bool bw_use_mfma(size_t rows, int J, int K);
 size_t dw_mfma_partial_floats(size_t rows, int J, int K);
 int32_t dw_mfma(const float* delta, const float* X, size_t rows, int J, int K, float* dW, float* partial, hipStream_t s);
 int32_t dx_mfma(const gnx_graphs* h, int entity, const float* delta, const float* W, int J, int K, int ka, int kb, float* out, int64_t R,
-                float* WT, bool fill, hipStream_t s, const char* name);
+                float* WT, bool fill, hipStream_t s, const char* name, const float* gmul = nullptr, int gmul_act = 0,
+                float* tile_colsum = nullptr, int* n_tiles_out = nullptr);
 int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K, const gnx_dense& d, int OUT, const float* add1,
                           const float* add2, float* out, int64_t R, hipStream_t s, const char* name);
 
 int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, const float* nf, int dn, const float* gf, int dg,
                         int64_t R, float* out, hipStream_t s);
-
-__device__ __forceinline__ float act_grad_from_out(float y, int act) {
-  switch (act) {
-    case GNX_ACT_RELU: return y > 0.f ? 1.f : 0.f;
-    case GNX_ACT_TANH: return 1.f - y * y;
-    case GNX_ACT_SIGMOID: return y * (1.f - y);
-    default: return 1.f;
-  }
-}
 
 // delta[m][j] = (G[m][j] + extra1[i1(m)][o1 + j] + extra2[i2(m)][o2 + j]) * act'(out[m][j]);  one thread per element.
 // kind 0: rows = graphs (no extras); 1: rows = nodes (extra1 = dXg rows by graph); 2: rows = edges (extra1 = dXg by graph,
@@ -306,11 +298,117 @@ __global__ __launch_bounds__(256) void k_ln_backward(const float* __restrict__ x
   }
 }
 
+// LayerNorm pullback for widths that are multiples of 64 (same mathematics as k_ln_backward): 16 lanes per row (= one DPP
+// row), the row's x / dy1 / dy2 live in registers, statistics by DPP; a workgroup walks 8 x 16 rows and keeps the column
+// partial sums of the four parameter gradients (dgamma1 = sum dy1*xhat, dbeta1 = sum dy1, same for norm 2) in registers,
+// reduced over its 16 row slots through LDS in a fixed order -> cpart[block][4][D]; no t1 / t2 tensors, no extra passes.
+__device__ __forceinline__ float row16_sum_b(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+constexpr int LNB_ROWS = 128;  // rows per workgroup
+template <int Q>
+__global__ __launch_bounds__(256) void k_ln_backward_v4(const float* __restrict__ x, size_t rows, const float* __restrict__ g1, const float* __restrict__ g2,
+                                                        const float* __restrict__ dy1, const float* __restrict__ dy2, const float* __restrict__ resid,
+                                                        float eps, int eps_mode, float* __restrict__ dx, float* __restrict__ cpart) {
+  constexpr int D = 64 * Q;
+  __shared__ __attribute__((aligned(16))) float s_red[16 * D];
+  const int tid = threadIdx.x, sub = tid & 15, slot = tid >> 4;
+  float4 ga[Q], gb[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) { ga[q] = reinterpret_cast<const float4*>(g1)[sub + 16 * q]; gb[q] = reinterpret_cast<const float4*>(g2)[sub + 16 * q]; }
+  float4 cg1[Q], cb1[Q], cg2[Q], cb2[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) cg1[q] = cb1[q] = cg2[q] = cb2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t row_base = (size_t)blockIdx.x * LNB_ROWS;
+  for (int it = 0; it < LNB_ROWS / 16; ++it) {
+    size_t row = row_base + it * 16 + slot;
+    const bool live = row < rows;
+    row = live ? row : rows - 1;  // clamped: all lanes take part in the DPP reductions
+    float4 c[Q], a1[Q], a2[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      c[q] = reinterpret_cast<const float4*>(x + row * D)[sub + 16 * q];
+      a1[q] = reinterpret_cast<const float4*>(dy1 + row * D)[sub + 16 * q];
+      a2[q] = reinterpret_cast<const float4*>(dy2 + row * D)[sub + 16 * q];
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) sm += (c[q].x + c[q].y) + (c[q].z + c[q].w);
+    const float mu = row16_sum_b(sm) * (1.f / (float)D);
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      c[q].x -= mu; c[q].y -= mu; c[q].z -= mu; c[q].w -= mu;
+      var = fmaf(c[q].x, c[q].x, var); var = fmaf(c[q].y, c[q].y, var); var = fmaf(c[q].z, c[q].z, var); var = fmaf(c[q].w, c[q].w, var);
+    }
+    var = row16_sum_b(var) * (1.f / (float)D);
+    const float sigma = sqrtf(var);
+    const float sden = eps_mode == 0 ? sigma + eps : sqrtf(var + eps);
+    const float qd = eps_mode == 0 ? sigma * sden * sden : sden * sden * sden;
+    const float inv = 1.f / sden;
+    float4 dxh[Q];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      dxh[q] = make_float4(a1[q].x * ga[q].x + a2[q].x * gb[q].x, a1[q].y * ga[q].y + a2[q].y * gb[q].y,
+                           a1[q].z * ga[q].z + a2[q].z * gb[q].z, a1[q].w * ga[q].w + a2[q].w * gb[q].w);
+      s1 += (dxh[q].x + dxh[q].y) + (dxh[q].z + dxh[q].w);
+      s2 = fmaf(dxh[q].x, c[q].x, s2); s2 = fmaf(dxh[q].y, c[q].y, s2); s2 = fmaf(dxh[q].z, c[q].z, s2); s2 = fmaf(dxh[q].w, c[q].w, s2);
+    }
+    const float mean_dxh = row16_sum_b(s1) * (1.f / (float)D);
+    const float tot = row16_sum_b(s2);
+    const float coef = qd > 0.f ? tot / ((float)D * qd) : 0.f;
+    if (live) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const float4 xh = make_float4(c[q].x * inv, c[q].y * inv, c[q].z * inv, c[q].w * inv);
+        cg1[q].x = fmaf(a1[q].x, xh.x, cg1[q].x); cg1[q].y = fmaf(a1[q].y, xh.y, cg1[q].y); cg1[q].z = fmaf(a1[q].z, xh.z, cg1[q].z); cg1[q].w = fmaf(a1[q].w, xh.w, cg1[q].w);
+        cg2[q].x = fmaf(a2[q].x, xh.x, cg2[q].x); cg2[q].y = fmaf(a2[q].y, xh.y, cg2[q].y); cg2[q].z = fmaf(a2[q].z, xh.z, cg2[q].z); cg2[q].w = fmaf(a2[q].w, xh.w, cg2[q].w);
+        cb1[q].x += a1[q].x; cb1[q].y += a1[q].y; cb1[q].z += a1[q].z; cb1[q].w += a1[q].w;
+        cb2[q].x += a2[q].x; cb2[q].y += a2[q].y; cb2[q].z += a2[q].z; cb2[q].w += a2[q].w;
+        if (dx) {
+          float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (resid) rr = reinterpret_cast<const float4*>(resid + row * D)[sub + 16 * q];
+          float4 o;
+          o.x = rr.x + (dxh[q].x - mean_dxh) * inv - c[q].x * coef;
+          o.y = rr.y + (dxh[q].y - mean_dxh) * inv - c[q].y * coef;
+          o.z = rr.z + (dxh[q].z - mean_dxh) * inv - c[q].z * coef;
+          o.w = rr.w + (dxh[q].w - mean_dxh) * inv - c[q].w * coef;
+          reinterpret_cast<float4*>(dx + row * D)[sub + 16 * q] = o;
+        }
+      }
+    }
+  }
+  // column partial sums of the workgroup: one quantity at a time through LDS [16 slots][D], summed over the slots in order
+  float* outp = cpart + (size_t)blockIdx.x * 4 * D;
+#pragma unroll
+  for (int which = 0; which < 4; ++which) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const float4 v = which == 0 ? cg1[q] : (which == 1 ? cb1[q] : (which == 2 ? cg2[q] : cb2[q]));
+      reinterpret_cast<float4*>(s_red + slot * D)[sub + 16 * q] = v;
+    }
+    __syncthreads();
+    for (int cidx = tid; cidx < D; cidx += 256) {
+      float acc = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) acc += s_red[sl * D + cidx];
+      outp[which * D + cidx] = acc;
+    }
+  }
+}
+
 int32_t launch_layernorm2(const float* x, size_t rows, int d, const gnx_layernorm& l1, const gnx_layernorm& l2, float eps, int eps_mode,
                           float* y1, float* y2, hipStream_t s);
 
 // stage 2 for many slices: out[c] = sum_s partial[s][c]; 64 columns per workgroup, 4 slice groups, fixed order
-__global__ __launch_bounds__(256) void k_bw_colsum_final(const float* __restrict__ partial, int d, int S, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_bw_colsum_final(const float* __restrict__ partial, int d, int S, float* __restrict__ out, int ld = 0) {
+  ld = ld ? ld : d;  // distance between slices
   __shared__ float s_red[4][64];
   const int tid = threadIdx.x, cl = tid & 63, sg = tid >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -319,7 +417,7 @@ __global__ __launch_bounds__(256) void k_bw_colsum_final(const float* __restrict
     for (int sl = sg; sl < S; sl += 32) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)min(sl + 4 * u, S - 1) * d + c];  // clamped: value unused past S
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)min(sl + 4 * u, S - 1) * ld + c];  // clamped: value unused past S
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += sl + 4 * u < S ? v[u] : 0.f;
     }
@@ -479,7 +577,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
 // ---- GNCore backward ----
 namespace {
 struct CoreBwLayout {
-  size_t l1[3], l2[3], bout[3], dl1[3], dz2[3], h, dh, t1, t2, off2, blk_fw, blk_bw, part, wt, total;
+  size_t l1[3], l2[3], bout[3], dl1[3], dz2[3], h, dh, t1, t2, off2, blk_fw, blk_bw, part, wt, tcs, lnpart, total;
 };
 CoreBwLayout core_bw_layout(const gnx_graphs* h, const gnx_core_params* p, int64_t R) {
   const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
@@ -506,6 +604,13 @@ CoreBwLayout core_bw_layout(const gnx_graphs* h, const gnx_core_params* p, int64
   }
   L.part = take(pmax);
   L.wt = take(sizeof(float) * 4 * (size_t)std::max(d[0], std::max(d[1], d[2])) * std::max(d[0], std::max(d[1], d[2])));
+  size_t tcs = 0;  // per-tile column sums of delta1 (tiles of the matrix-core path: 128-row chunks per graph)
+  const size_t nt[3] = {h->h_etiles.size(), h->h_ntiles.size(), h->h_gtiles.size()};
+  for (int t = 0; t < 3; ++t) tcs = std::max(tcs, sizeof(float) * (size_t)R * nt[t] * 4 * d[t]);
+  L.tcs = take(tcs);
+  size_t lnp = 0;  // k_ln_backward_v4: [blocks][4][D] column partial sums
+  for (int t = 0; t < 3; ++t) lnp = std::max(lnp, sizeof(float) * ((rows[t] + 127) / 128) * 4 * (size_t)d[t]);
+  L.lnpart = take(lnp);
   L.total = o + 256;
   return L;
 }
@@ -569,12 +674,15 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
       if ((rc = dw_mfma(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2.weight, part, s))) return rc;                   // dW2 = h^T g
       hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows[t]);
       if ((rc = colsum_all(gout[t], rows[t], D, gr.ff[t].fc2.bias, part, off2, s))) return rc;
-      if ((rc = dx_mfma(h, t, gout[t], p->ff[t].fc2.weight, D, H, 0, H, dh, R, wt, true, s, "bw_dx_ff2"))) return rc;   // dh = g W2^T
-      DeltaArgs a{dh, hbuf, dh, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, H, (int)rows[t], 1, p->ff[t].fc1.act, 0};
-      { ProfScope ps("bw_delta_hidden", s);
-        hipLaunchKernelGGL(k_bw_delta, dim3(blocks(rows[t] * H).x, 1), dim3(256), 0, s, a, (size_t)0, (size_t)0); }
+      // delta1 = (g W2^T) .* act1'(h) in the GEMM epilogue, with per-tile column sums of delta1 for db1
+      int n_tiles = 0;
+      float* tcs = gr.ff[t].fc1.bias ? F(L.tcs) : nullptr;
+      if ((rc = dx_mfma(h, t, gout[t], p->ff[t].fc2.weight, D, H, 0, H, dh, R, wt, true, s, "bw_dx_ff2", hbuf, p->ff[t].fc1.act, tcs, &n_tiles))) return rc;
       if ((rc = dw_mfma(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1.weight, part, s))) return rc;                  // dW1 = z^T delta1
-      if ((rc = colsum_all(dh, rows[t], H, gr.ff[t].fc1.bias, part, off2, s))) return rc;
+      if (tcs) {
+        ProfScope ps("bw_colsum_all", s);
+        hipLaunchKernelGGL(k_bw_colsum_final, dim3((unsigned)((H + 63) / 64)), dim3(256), 0, s, tcs, H, (int)(R * n_tiles), gr.ff[t].fc1.bias);
+      }
       if ((rc = dx_mfma(h, t, dh, p->ff[t].fc1.weight, H, D, 0, D, dz2, R, wt, true, s, "bw_dx_ff1"))) return rc;        // dz2 = delta1 W1^T
       GNX_HIP(hipGetLastError());
       continue;
@@ -595,6 +703,27 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
   for (int t = 0; t < 3; ++t) {
     if (rows[t] == 0) continue;
     float* t1 = F(L.t1); float* t2 = F(L.t2);
+    const bool al16 = (((uintptr_t)x[t] | (uintptr_t)F(L.dl1[t]) | (uintptr_t)F(L.dz2[t]) | (uintptr_t)gout[t] | (uintptr_t)dxo[t] | (uintptr_t)p->ln1[t].gamma |
+                        (uintptr_t)p->ln2[t].gamma) & 15) == 0;
+    if (al16 && d[t] % 64 == 0 && d[t] <= 512 && rows[t] >= 1024) {
+      const unsigned nb = (unsigned)((rows[t] + LNB_ROWS - 1) / LNB_ROWS);
+      float* cpart = F(L.lnpart);
+      {
+        ProfScope ps("bw_layernorm", s);
+        switch (d[t] / 64) {
+#define GNX_LNB_CASE(Q) case Q: hipLaunchKernelGGL((k_ln_backward_v4<Q>), dim3(nb), dim3(256), 0, s, x[t], rows[t], p->ln1[t].gamma, p->ln2[t].gamma, \
+                                                   F(L.dl1[t]), F(L.dz2[t]), gout[t], p->eps, p->eps_mode, dxo[t], cpart); break;
+          GNX_LNB_CASE(1) GNX_LNB_CASE(2) GNX_LNB_CASE(3) GNX_LNB_CASE(4) GNX_LNB_CASE(5) GNX_LNB_CASE(6) GNX_LNB_CASE(7) GNX_LNB_CASE(8)
+#undef GNX_LNB_CASE
+        }
+      }
+      ProfScope ps("bw_colsum_all", s);
+      float* outs[4] = {gr.ln1[t].gamma, gr.ln1[t].beta, gr.ln2[t].gamma, gr.ln2[t].beta};
+      for (int w = 0; w < 4; ++w)
+        if (outs[w]) hipLaunchKernelGGL(k_bw_colsum_final, dim3((unsigned)((d[t] + 63) / 64)), dim3(256), 0, s, cpart + (size_t)w * d[t], d[t], (int)nb, outs[w], 4 * d[t]);
+      GNX_HIP(hipGetLastError());
+      continue;
+    }
     { ProfScope ps("bw_layernorm", s);
     hipLaunchKernelGGL(k_ln_backward, dim3((unsigned)((rows[t] + 3) / 4)), dim3(256), 0, s, x[t], rows[t], d[t], p->ln1[t].gamma, p->ln2[t].gamma, F(L.dl1[t]),
                        F(L.dz2[t]), gout[t], p->eps, p->eps_mode, dxo[t], t1, t2); }

@@ -11,7 +11,7 @@ namespace gnx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int K, const float* B, int ldw, int OUT, float* out, int64_t R,
-                           hipStream_t s, const char* name);
+                           hipStream_t s, const char* name, const float* gmul, int gmul_act, float* tile_colsum, int* n_tiles_out);
 
 // WT[j*K + k] = W[k*J + j]   (W = [K][J] row-major, i.e. the (J x K) column-major Dense weight)
 __global__ void k_transpose_w(const float* __restrict__ W, int K, int J, float* __restrict__ WT) {
@@ -152,14 +152,15 @@ int32_t dw_mfma(const float* delta, const float* X, size_t rows, int J, int K, f
 }
 
 // dX[:, ka:kb) = delta * W^T[:, ka:kb) on the matrix cores.  WT: K*J floats of workspace, filled here when `fill` is set.
+// Optional: out *= act'(gmul) in the epilogue, and per-tile column sums of the result (tile_colsum, *n_tiles_out tiles).
 int32_t dx_mfma(const gnx_graphs* h, int entity, const float* delta, const float* W, int J, int K, int ka, int kb, float* out, int64_t R,
-                float* WT, bool fill, hipStream_t s, const char* name) {
+                float* WT, bool fill, hipStream_t s, const char* name, const float* gmul, int gmul_act, float* tile_colsum, int* n_tiles_out) {
   if (kb <= ka || J == 0) return GNX_OK;
   if (fill) {
     hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)((K * J + 255) / 256)), dim3(256), 0, s, W, K, J, WT);
     GNX_HIP(hipGetLastError());
   }
-  return launch_rows_matmul(h, entity, delta, J, WT + ka, K, kb - ka, out, R, s, name);
+  return launch_rows_matmul(h, entity, delta, J, WT + ka, K, kb - ka, out, R, s, name, gmul, gmul_act, tile_colsum, n_tiles_out);
 }
 
 }  // namespace gnx

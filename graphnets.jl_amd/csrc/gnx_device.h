@@ -53,6 +53,16 @@ __device__ __forceinline__ float act_apply(float x, int act) {
   }
 }
 
+// derivative of the activation expressed through its OUTPUT y (what the backward pass has): relu, tanh, sigmoid, identity
+__device__ __forceinline__ float act_grad_from_out(float y, int act) {
+  switch (act) {
+    case 1: return y > 0.f ? 1.f : 0.f;
+    case 2: return 1.f - y * y;
+    case 3: return y * (1.f - y);
+    default: return 1.f;
+  }
+}
+
 // index i in [0, n) with cp[i] <= e < cp[i+1] (cp non-decreasing, cp[0] <= e < cp[n]); skips empty segments.
 __device__ __forceinline__ int segment_of(const int* cp, int n, int e) {
   int lo = 0, hi = n;

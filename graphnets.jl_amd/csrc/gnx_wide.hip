@@ -59,6 +59,8 @@ struct WideArgs {
   size_t gadd_rep_stride;
   const float* add1;  // optional residual inputs with the layout of `out` (may alias `out`): v = act(..) + add1 + add2
   const float* add2;
+  const float* gmul;  // optional, layout of `out`: v *= act'(gmul) (derivative through the stored output, act = gmul_act) BEFORE the
+  int gmul_act;       // column sums — the backward's  delta = (g W^T) .* act'(h)  in the GEMM epilogue
   int n_rtiles, n_ctiles;      // row tiles / column tiles of this launch (set by launch_gemm)
   unsigned long long* stamps;  // diagnostic builds only (GNX_WIDE_STAMPS): [tile][8] shader-clock stamps of wave 0
 };
@@ -336,6 +338,11 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
             v.x += p.x + d.x; v.y += p.y + d.y; v.z += p.z + d.z; v.w += p.w + d.w;
           }
           v.x = act_apply(v.x, a.act); v.y = act_apply(v.y, a.act); v.z = act_apply(v.z, a.act); v.w = act_apply(v.w, a.act);
+          if (a.gmul) {
+            const float4 u = *reinterpret_cast<const float4*>(a.gmul + r * a.out_rep_stride + o);
+            v.x *= act_grad_from_out(u.x, a.gmul_act); v.y *= act_grad_from_out(u.y, a.gmul_act);
+            v.z *= act_grad_from_out(u.z, a.gmul_act); v.w *= act_grad_from_out(u.w, a.gmul_act);
+          }
           cs4.x += v.x; cs4.y += v.y; cs4.z += v.z; cs4.w += v.w;  // column sums BEFORE the residual adds
           if (a.add1) { const float4 u = *reinterpret_cast<const float4*>(a.add1 + r * a.out_rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
           if (a.add2) { const float4 u = *reinterpret_cast<const float4*>(a.add2 + r * a.out_rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
@@ -349,6 +356,7 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
               float y = vv[e];
               if (gadd) y += a.gadd_a[r * a.gadd_rep_stride + (size_t)s_ia[row] * a.OUT + n + e] + a.gadd_b[r * a.gadd_rep_stride + (size_t)s_ib[row] * a.OUT + n + e];
               y = act_apply(y, a.act);
+              if (a.gmul) y *= act_grad_from_out(a.gmul[r * a.out_rep_stride + o + e], a.gmul_act);
               cc[e] += y;
               if (a.add1) y += a.add1[r * a.out_rep_stride + o + e];
               if (a.add2) y += a.add2[r * a.out_rep_stride + o + e];
@@ -560,8 +568,10 @@ int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K
 
 // out[rows, OUT] = A[rows, K] * B over all rows of one entity type, B = [K][OUT] block of a matrix with row distance ldw
 // (no bias, no activation): the dX = delta * W^T products of the backward pass (gnx_backward.hip), B = transposed weights.
+// Optional epilogue: out *= act'(gmul) (gmul: stored forward output with the layout of out), and per-tile column sums of the
+// result into tile_colsum [R][n_tiles][OUT] (n_tiles returned through *n_tiles_out) for a bias gradient.
 int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int K, const float* B, int ldw, int OUT, float* out, int64_t R,
-                           hipStream_t s, const char* name) {
+                           hipStream_t s, const char* name, const float* gmul, int gmul_act, float* tile_colsum, int* n_tiles_out) {
   const size_t nrows = entity == 0 ? (size_t)h->E : (entity == 1 ? (size_t)h->N : (size_t)h->G);
   if (nrows == 0 || OUT == 0 || K == 0) return GNX_OK;
   WideArgs w{};
@@ -573,7 +583,10 @@ int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int 
   w.n_graphs = (int)h->G;
   w.out = out; w.out_rep_stride = nrows * (size_t)OUT;
   const unsigned n_tiles = (unsigned)(entity == 0 ? h->h_etiles.size() : (entity == 1 ? h->h_ntiles.size() : h->h_gtiles.size()));
-  const bool al16 = ((uintptr_t)A | (uintptr_t)B | (uintptr_t)out) % 16 == 0;
+  w.gmul = gmul; w.gmul_act = gmul_act;
+  w.colsum = tile_colsum; w.colsum_rep_stride = (size_t)n_tiles * OUT;
+  if (n_tiles_out) *n_tiles_out = (int)n_tiles;
+  const bool al16 = ((uintptr_t)A | (uintptr_t)B | (uintptr_t)out | (uintptr_t)gmul) % 16 == 0;
   return launch_gemm_any(w, al16 && K % 4 == 0 && OUT % 4 == 0 && ldw % 4 == 0, n_tiles, R, s, name);
 }
 
