@@ -26,6 +26,11 @@ int32_t dw_mfma(const float* delta, const float* X, size_t rows, int J, int K, f
 int32_t dx_mfma(const gnx_graphs* h, int entity, const float* delta, const float* W, int J, int K, int ka, int kb, float* out, int64_t R,
                 float* WT, bool fill, hipStream_t s, const char* name, const float* gmul = nullptr, int gmul_act = 0,
                 float* tile_colsum = nullptr, int* n_tiles_out = nullptr);
+int32_t transpose_w(const float* W, int K, int J, float* WT, hipStream_t s);
+int32_t rows_times_wt(const gnx_graphs* h, int entity, const float* A, int J, const float* WT, int K, int ka, int kb, float* out, const float* add1,
+                      int64_t R, hipStream_t s, const char* name);
+int32_t segsum_rows(const float* src, const int* ptr, const int* idx, int N, int E, int D, int64_t R, float* out, hipStream_t s, const char* name);
+int32_t add_cols(const float* in, int ld, int off, size_t rows, int d, float* out, int accumulate, hipStream_t s);
 int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K, const gnx_dense& d, int OUT, const float* add1,
                           const float* add2, float* out, int64_t R, hipStream_t s, const char* name);
 
@@ -53,6 +58,34 @@ __global__ void k_bw_delta(DeltaArgs a, size_t ex1_rep, size_t ex2_rep) {
   if (a.kind >= 1 && a.ex1) g += a.ex1[r * ex1_rep + (size_t)segment_of(a.seg_off, a.n_seg, m) * a.ex1_stride + a.ex1_off + j];
   if (a.kind == 2 && a.ex2) g += a.ex2[r * ex2_rep + (size_t)a.edge_dst[m] * a.ex2_stride + a.ex2_off + j];
   a.delta[o] = g * act_grad_from_out(a.out[o], a.act);
+}
+// the same, four columns per thread with 16-B accesses (J % 4 == 0, every base / stride / offset a multiple of 4 floats)
+__global__ void k_bw_delta_v4(DeltaArgs a, size_t ex1_rep, size_t ex2_rep) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t r = blockIdx.y;
+  const int J4 = a.J >> 2;
+  if (idx >= (size_t)a.rows * J4) return;
+  const int m = (int)(idx / J4), j = 4 * (int)(idx % J4);
+  const size_t o = r * (size_t)a.rows * a.J + (size_t)m * a.J + j;
+  float4 g = a.G ? *reinterpret_cast<const float4*>(a.G + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 y = *reinterpret_cast<const float4*>(a.out + o);
+  if (a.kind >= 1 && a.ex1) {
+    const float4 u = *reinterpret_cast<const float4*>(a.ex1 + r * ex1_rep + (size_t)segment_of(a.seg_off, a.n_seg, m) * a.ex1_stride + a.ex1_off + j);
+    g.x += u.x; g.y += u.y; g.z += u.z; g.w += u.w;
+  }
+  if (a.kind == 2 && a.ex2) {
+    const float4 u = *reinterpret_cast<const float4*>(a.ex2 + r * ex2_rep + (size_t)a.edge_dst[m] * a.ex2_stride + a.ex2_off + j);
+    g.x += u.x; g.y += u.y; g.z += u.z; g.w += u.w;
+  }
+  g.x *= act_grad_from_out(y.x, a.act); g.y *= act_grad_from_out(y.y, a.act); g.z *= act_grad_from_out(y.z, a.act); g.w *= act_grad_from_out(y.w, a.act);
+  *reinterpret_cast<float4*>(a.delta + o) = g;
+}
+static void launch_delta(const DeltaArgs& a, size_t ex1_rep, size_t ex2_rep, unsigned Ru, hipStream_t s) {
+  const bool al = (((uintptr_t)a.G | (uintptr_t)a.out | (uintptr_t)a.delta | (uintptr_t)a.ex1 | (uintptr_t)a.ex2) & 15) == 0;
+  const bool v4 = al && a.J % 4 == 0 && a.ex1_stride % 4 == 0 && a.ex1_off % 4 == 0 && a.ex2_stride % 4 == 0 && a.ex2_off % 4 == 0 && ex1_rep % 4 == 0 &&
+                  ex2_rep % 4 == 0;
+  if (v4) hipLaunchKernelGGL(k_bw_delta_v4, dim3((unsigned)(((size_t)a.rows * (a.J / 4) + 255) / 256), Ru), dim3(256), 0, s, a, ex1_rep, ex2_rep);
+  else hipLaunchKernelGGL(k_bw_delta, dim3((unsigned)(((size_t)a.rows * a.J + 255) / 256), Ru), dim3(256), 0, s, a, ex1_rep, ex2_rep);
 }
 
 // dX[m][k] = sum_j W[k*J + j] * delta[m][j]   (W is (J x K) column-major); one thread per (m, k)
@@ -200,7 +233,7 @@ static int32_t colsum_all(const float* in, size_t rows, int d, float* out, float
 __global__ void k_set_off2(int* off2, int rows);
 
 struct BwLayout {
-  size_t Xe, Xn, Xg, de_, dn_, dg_, dXe, dXn, dXg, part, wt, off2, total;
+  size_t Xe, Xn, Xg, de_, dn_, dg_, dXe, dXn, dXg, part, wt, off2, ssrc, sdst, sg, tnf, total;
 };
 static BwLayout bw_layout(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
   const size_t E = h->E, N = h->N, G = h->G;
@@ -218,6 +251,7 @@ static BwLayout bw_layout(const gnx_graphs* h, const gnx_block_params* p, int64_
   L.part = take(std::max({pmax, cs, pm}));
   L.wt = take(std::max({(size_t)p->oe * Ke, (size_t)p->on * Kn, (size_t)p->og * Kg}));
   L.off2 = take(16);
+  L.ssrc = take(R * N * p->oe); L.sdst = take(R * N * p->oe); L.sg = take(R * G * p->oe); L.tnf = take(R * N * p->dn);
   L.total = o + 256;
   return L;
 }
@@ -495,9 +529,11 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
     hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S, (unsigned)G, Ru), dim3(256), 0, s, in, d, rows_total, off, S, G, part, ld, coff);
     hipLaunchKernelGGL(k_bw_colsum2, dim3((unsigned)G, Ru), dim3(64), 0, s, part, d, S, G, out, out_stride, out_off, accumulate);
   };
+  // Edge level on the matrix cores: regrouped (see below) — the edge function's input Xe is never materialised.
+  const bool mfma_e = oe > 0 && E > 0 && bw_use_mfma((size_t)R * E, oe, Ke);
   // function inputs, exactly as the forward's building blocks define them
   { ProfScope ps("bw_fn_inputs", s);
-  if (oe && E && (rc = launch_fn_input(h, 0, ef, de, nf, dn, gf, dg, R, Xe, s))) return rc;
+  if (oe && E && !mfma_e && (rc = launch_fn_input(h, 0, ef, de, nf, dn, gf, dg, R, Xe, s))) return rc;
   if (on && (rc = launch_fn_input(h, 1, ef_out, oe, nf, dn, gf, dg, R, Xn, s))) return rc; }
   if (og) {  // Xg = [sum_e ef' ; sum_n nf' ; gf] with parallel two-stage column sums (one workgroup per graph would walk 1M rows)
     colsum(ef_out, oe, oe, 0, E, h->d_edge_off, me, Xg, Kg, 0, 0);
@@ -518,7 +554,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   const bool have_n = on > 0;
   if (have_n) {
     DeltaArgs a{g_nf_out, nf_out, dlt_n, have_g ? dXg : nullptr, Kg, oe, nullptr, 0, 0, h->d_node_off, nullptr, on, N, G, acts[1], 1};
-    hipLaunchKernelGGL(k_bw_delta, dim3(blocks((size_t)N * on).x, Ru), dim3(256), 0, s, a, (size_t)G * Kg, (size_t)0);
+    launch_delta(a, (size_t)G * Kg, (size_t)0, Ru, s);
     if (bw_use_mfma((size_t)R * N, on, Kn)) {  // matrix cores: dXn = dn Wn^T, dWn = Xn^T dn, dbn = column sums
       if ((rc = dx_mfma(h, 1, dlt_n, p->nodefn.weight, on, Kn, 0, Kn, dXn, R, wt, true, s, "bw_dx_node"))) return rc;
       if ((rc = dw_mfma(dlt_n, Xn, (size_t)R * N, on, Kn, gr.nodefn.weight, part, s))) return rc;
@@ -534,14 +570,43 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   if (have_e) {
     DeltaArgs a{g_ef_out, ef_out, dlt_e, have_g ? dXg : nullptr, Kg, 0, have_n ? dXn : nullptr, Kn, 0, h->d_edge_off, h->d_edge_dst, oe, E, G, acts[0], 2};
     { ProfScope ps("bw_delta_edge", s);
-    hipLaunchKernelGGL(k_bw_delta, dim3(blocks((size_t)E * oe).x, Ru), dim3(256), 0, s, a, (size_t)G * Kg, (size_t)N * Kn); }
-    if (bw_use_mfma((size_t)R * E, oe, Ke)) {
-      // matrix cores: the ef columns of dXe ARE d_ef; the remaining columns [de, Ke) go to dXe with row length Ke - de
-      const bool want_ef = d_ef && de;
-      if (want_ef && (rc = dx_mfma(h, 0, dlt_e, p->edgefn.weight, oe, Ke, 0, de, d_ef, R, wt, true, s, "bw_dx_edge_ef"))) return rc;
-      if ((rc = dx_mfma(h, 0, dlt_e, p->edgefn.weight, oe, Ke, de, Ke, dXe, R, wt, !want_ef, s, "bw_dx_edge_rest"))) return rc;
-      dxe_stride = Ke - de; dxe_col0 = de;
-      if ((rc = dw_mfma(dlt_e, Xe, (size_t)R * E, oe, Ke, gr.edgefn.weight, part, s))) return rc;
+    launch_delta(a, (size_t)G * Kg, (size_t)N * Kn, Ru, s); }
+    if (mfma_e) {
+      // Matrix cores, regrouped so that only the ef block is a per-edge product.  With de = delta of the edges and
+      //   S_dst[n] = sum_{e: dst = n} de[e]  (contiguous CSC segments)   S_src[n] = sum_{e: src = n} de[e]  (CSR view)   S_g = sum_{n in g} S_dst[n]
+      //   d_ef = de We_ef^T                                 dWe[ef rows]  = ef^T de
+      //   d_nf += S_src We_src^T + S_dst We_dst^T           dWe[src rows] = nf^T S_src     dWe[dst rows] = nf^T S_dst
+      //   d_gf += S_g We_gf^T                               dWe[gf rows]  = gf^T S_g
+      // (sum_e nf[src(e)]^T de[e] = sum_n nf[n]^T S_src[n]: the gathered operand never exists), every sum in a fixed order.
+      float *S_src = F(L.ssrc), *S_dst = F(L.sdst), *S_g = F(L.sg), *T_nf = F(L.tnf);
+      if ((rc = transpose_w(p->edgefn.weight, Ke, oe, wt, s))) return rc;
+      if (d_ef && de && (rc = rows_times_wt(h, 0, dlt_e, oe, wt, Ke, 0, de, d_ef, nullptr, R, s, "bw_dx_edge_ef"))) return rc;
+      const bool need_seg = (dn > 0 && (d_nf || gr.edgefn.weight)) || (dg > 0 && (d_gf || gr.edgefn.weight));
+      if (need_seg) {
+        if ((rc = segsum_rows(dlt_e, h->d_colptr, nullptr, N, E, oe, R, S_dst, s, "bw_segsum_dst"))) return rc;
+        if (dn && (rc = segsum_rows(dlt_e, h->d_csr_ptr, h->d_csr_eid, N, E, oe, R, S_src, s, "bw_segsum_src"))) return rc;
+        if (dg) colsum(S_dst, oe, oe, 0, N, h->d_node_off, mn, S_g, oe, 0, 0);
+      }
+      if (d_nf && dn) {  // the node function's own share (dXn nf columns) is added below
+        if ((rc = rows_times_wt(h, 1, S_src, oe, wt, Ke, de, de + dn, T_nf, nullptr, R, s, "bw_dx_nf_src"))) return rc;
+        if ((rc = rows_times_wt(h, 1, S_dst, oe, wt, Ke, de + dn, de + 2 * dn, d_nf, T_nf, R, s, "bw_dx_nf_dst"))) return rc;
+        if (have_n && (rc = add_cols(dXn, Kn, oe, (size_t)R * N, dn, d_nf, 1, s))) return rc;
+      }
+      if (dg) {  // dXe_g[g][:] = S_g[g] We^T (G rows: generic), its gf columns are the edges' share of d_gf
+        hipLaunchKernelGGL(k_bw_dx, dim3(blocks((size_t)G * Ke).x, Ru), dim3(256), 0, s, S_g, p->edgefn.weight, G, oe, Ke, dXe, 0, 0, (float*)nullptr, 0);
+      }
+      if (gr.edgefn.weight) {
+        float* dW = gr.edgefn.weight;
+        auto dw_any = [&](const float* delta, const float* X, size_t rows, int K, float* out) -> int32_t {
+          if (K == 0) return GNX_OK;
+          if (bw_use_mfma(rows, oe, K)) return dw_mfma(delta, X, rows, oe, K, out, part, s);
+          return dw_reduce(delta, X, rows, oe, K, gnx_dense_grad{out, nullptr}, part, s);
+        };
+        if ((rc = dw_any(dlt_e, ef, (size_t)R * E, de, dW))) return rc;
+        if ((rc = dw_any(S_src, nf, (size_t)R * N, dn, dW + (size_t)de * oe))) return rc;
+        if ((rc = dw_any(S_dst, nf, (size_t)R * N, dn, dW + (size_t)(de + dn) * oe))) return rc;
+        if ((rc = dw_any(S_g, gf, (size_t)R * G, dg, dW + (size_t)(de + 2 * dn) * oe))) return rc;
+      }
       hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)(R * E));
       if ((rc = colsum_all(dlt_e, (size_t)R * E, oe, gr.edgefn.bias, part, off2, s))) return rc;
     } else {
@@ -558,7 +623,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
     if (gr.nodefn.bias && on) GNX_HIP(hipMemsetAsync(gr.nodefn.bias, 0, sizeof(float) * (size_t)on, s));
   }
   // input gradients that need sums
-  if (d_nf && dn) {
+  if (d_nf && dn && !mfma_e) {
     ProfScope ps("bw_dnf", s);
     hipLaunchKernelGGL(k_bw_dnf, dim3(blocks((size_t)N * dn).x, Ru), dim3(256), 0, s, have_n ? dXn : nullptr, Kn, oe, have_e ? dXe : nullptr, dxe_stride,
                        de - dxe_col0, de + dn - dxe_col0, h->d_colptr, h->d_csr_ptr, h->d_csr_eid, N, E, dn, d_nf);
@@ -567,7 +632,8 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
     ProfScope ps("bw_dgf", s);
     hipLaunchKernelGGL(k_bw_dgf_init, blocks((size_t)R * G * dg), dim3(256), 0, s, have_g ? dXg : nullptr, Kg, oe + on, (int)(R * G), dg, d_gf);
     if (have_n) colsum(dXn, dg, Kn, oe + dn, N, h->d_node_off, mn, d_gf, dg, 0, 1);
-    if (have_e) colsum(dXe, dg, dxe_stride, de + 2 * dn - dxe_col0, E, h->d_edge_off, me, d_gf, dg, 0, 1);
+    if (have_e && mfma_e) { if ((rc = add_cols(dXe, Ke, de + 2 * dn, (size_t)R * G, dg, d_gf, 1, s))) return rc; }  // dXe holds S_g We^T here
+    else if (have_e) colsum(dXe, dg, dxe_stride, de + 2 * dn - dxe_col0, E, h->d_edge_off, me, d_gf, dg, 0, 1);
   }
   GNX_HIP(hipGetLastError());
   return GNX_OK;

@@ -11,7 +11,7 @@ namespace gnx {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int K, const float* B, int ldw, int OUT, float* out, int64_t R,
-                           hipStream_t s, const char* name, const float* gmul, int gmul_act, float* tile_colsum, int* n_tiles_out);
+                           hipStream_t s, const char* name, const float* gmul, int gmul_act, float* tile_colsum, int* n_tiles_out, const float* add1);
 
 // WT[j*K + k] = W[k*J + j]   (W = [K][J] row-major, i.e. the (J x K) column-major Dense weight)
 __global__ void k_transpose_w(const float* __restrict__ W, int K, int J, float* __restrict__ WT) {
@@ -160,7 +160,90 @@ int32_t dx_mfma(const gnx_graphs* h, int entity, const float* delta, const float
     hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)((K * J + 255) / 256)), dim3(256), 0, s, W, K, J, WT);
     GNX_HIP(hipGetLastError());
   }
-  return launch_rows_matmul(h, entity, delta, J, WT + ka, K, kb - ka, out, R, s, name, gmul, gmul_act, tile_colsum, n_tiles_out);
+  return launch_rows_matmul(h, entity, delta, J, WT + ka, K, kb - ka, out, R, s, name, gmul, gmul_act, tile_colsum, n_tiles_out, nullptr);
+}
+
+int32_t transpose_w(const float* W, int K, int J, float* WT, hipStream_t s) {
+  if (K * J == 0) return GNX_OK;
+  hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)((K * J + 255) / 256)), dim3(256), 0, s, W, K, J, WT);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+// out[rows, kb-ka) = A[rows, J] * WT[:, ka:kb) (+ add1) over the rows of one entity type; WT = transposed weights ([J][K])
+int32_t rows_times_wt(const gnx_graphs* h, int entity, const float* A, int J, const float* WT, int K, int ka, int kb, float* out, const float* add1,
+                      int64_t R, hipStream_t s, const char* name) {
+  if (kb <= ka || J == 0) return GNX_OK;
+  return launch_rows_matmul(h, entity, A, J, WT + ka, K, kb - ka, out, R, s, name, nullptr, 0, nullptr, nullptr, add1);
+}
+
+// out[n][:] = sum over t in [ptr[n], ptr[n+1]) of src[idx ? idx[t] : t][:], in order, 4 rows in flight (clamped loads);
+// thread = (node, 4-column chunk).  idx == nullptr: the in-edges of a node (CSC, contiguous); idx = csr_eid: its out-edges.
+template <bool VEC4>
+__global__ void k_segsum_rows(const float* __restrict__ src, const int* __restrict__ ptr, const int* __restrict__ idx, int N, int E, int D,
+                              float* __restrict__ out) {
+  const int D4 = (D + 3) / 4;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)N * D4) return;
+  const int n = (int)(gid / D4), c = 4 * (int)(gid % D4);
+  const size_t r = blockIdx.y;
+  const float* base = src + r * (size_t)E * D + c;
+  const int t0 = ptr[n], t1 = ptr[n + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = t0; t < t1; t += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int tt = min(t + j, t1 - 1);
+      const float* p = base + (size_t)(idx ? idx[tt] : tt) * D;
+      if (VEC4) {
+        v[j] = *reinterpret_cast<const float4*>(p);
+      } else {
+        v[j].x = p[0];
+        v[j].y = c + 1 < D ? p[1] : 0.f;
+        v[j].z = c + 2 < D ? p[2] : 0.f;
+        v[j].w = c + 3 < D ? p[3] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (t + j < t1) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+  }
+  float* o = out + (r * N + n) * (size_t)D + c;
+  if (VEC4) {
+    *reinterpret_cast<float4*>(o) = acc;
+  } else {
+    o[0] = acc.x;
+    if (c + 1 < D) o[1] = acc.y;
+    if (c + 2 < D) o[2] = acc.z;
+    if (c + 3 < D) o[3] = acc.w;
+  }
+}
+
+int32_t segsum_rows(const float* src, const int* ptr, const int* idx, int N, int E, int D, int64_t R, float* out, hipStream_t s, const char* name) {
+  if (N == 0 || D == 0) return GNX_OK;
+  ProfScope ps(name, s);
+  const size_t total = (size_t)N * ((D + 3) / 4);
+  const dim3 grid((unsigned)((total + 255) / 256), (unsigned)R);
+  const bool v4 = D % 4 == 0 && (((uintptr_t)src | (uintptr_t)out) & 15) == 0;
+  if (v4) hipLaunchKernelGGL((k_segsum_rows<true>), grid, dim3(256), 0, s, src, ptr, idx, N, E, D, out);
+  else hipLaunchKernelGGL((k_segsum_rows<false>), grid, dim3(256), 0, s, src, ptr, idx, N, E, D, out);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+// out[m][k] (+)= in[m*ld + off + k]   (k < d)
+__global__ void k_add_cols(const float* __restrict__ in, int ld, int off, size_t rows, int d, float* __restrict__ out, int accumulate) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * d) return;
+  const float v = in[(idx / d) * ld + off + idx % d];
+  out[idx] = accumulate ? out[idx] + v : v;
+}
+int32_t add_cols(const float* in, int ld, int off, size_t rows, int d, float* out, int accumulate, hipStream_t s) {
+  if (rows * d == 0) return GNX_OK;
+  hipLaunchKernelGGL(k_add_cols, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, s, in, ld, off, rows, d, out, accumulate);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
 }
 
 }  // namespace gnx

@@ -571,7 +571,7 @@ int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K
 // Optional epilogue: out *= act'(gmul) (gmul: stored forward output with the layout of out), and per-tile column sums of the
 // result into tile_colsum [R][n_tiles][OUT] (n_tiles returned through *n_tiles_out) for a bias gradient.
 int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int K, const float* B, int ldw, int OUT, float* out, int64_t R,
-                           hipStream_t s, const char* name, const float* gmul, int gmul_act, float* tile_colsum, int* n_tiles_out) {
+                           hipStream_t s, const char* name, const float* gmul, int gmul_act, float* tile_colsum, int* n_tiles_out, const float* add1) {
   const size_t nrows = entity == 0 ? (size_t)h->E : (entity == 1 ? (size_t)h->N : (size_t)h->G);
   if (nrows == 0 || OUT == 0 || K == 0) return GNX_OK;
   WideArgs w{};
@@ -584,9 +584,10 @@ int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int 
   w.out = out; w.out_rep_stride = nrows * (size_t)OUT;
   const unsigned n_tiles = (unsigned)(entity == 0 ? h->h_etiles.size() : (entity == 1 ? h->h_ntiles.size() : h->h_gtiles.size()));
   w.gmul = gmul; w.gmul_act = gmul_act;
+  w.add1 = add1;  // optional residual with the layout of out (may alias it)
   w.colsum = tile_colsum; w.colsum_rep_stride = (size_t)n_tiles * OUT;
   if (n_tiles_out) *n_tiles_out = (int)n_tiles;
-  const bool al16 = ((uintptr_t)A | (uintptr_t)B | (uintptr_t)out | (uintptr_t)gmul) % 16 == 0;
+  const bool al16 = ((uintptr_t)A | (uintptr_t)B | (uintptr_t)out | (uintptr_t)gmul | (uintptr_t)add1) % 16 == 0;
   return launch_gemm_any(w, al16 && K % 4 == 0 && OUT % 4 == 0 && ldw % 4 == 0, n_tiles, R, s, name);
 }
 
