@@ -16,14 +16,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import graphnets_jl_amd as gn  # noqa: E402
 
 
-def make_batch(rng, n_graphs, n, device):
+def make_batch(rng, n_graphs, n, device, vocab=0):
+    """vocab = 0: n random reals per graph as a 1-wide node feature; vocab > 0: the reference's setup — 2..n random integers in
+    1..vocab per graph, one-hot node features of width vocab (sort.jl:13-26)."""
     adjs, nfs, tn, te = [], [], [], []
+    n_max = n
     for _ in range(n_graphs):
-        x = rng.random(n).astype(np.float32)
+        if vocab:
+            n = int(rng.integers(2, n_max + 1))
+            ints = rng.integers(1, vocab + 1, n)
+            x = ints.astype(np.float32) + 1e-3 * rng.random(n).astype(np.float32)  # ties broken at random for the targets
+        else:
+            x = rng.random(n).astype(np.float32)
         order = np.argsort(x)
         rank = np.empty(n, dtype=np.int64); rank[order] = np.arange(n)
         adjs.append(np.ones((n, n), dtype=np.int64))
-        nfs.append(x[None, :])
+        nfs.append(np.eye(vocab, dtype=np.float32)[ints - 1].T.copy() if vocab else x[None, :])
         tn.append(np.stack([rank == 0, rank != 0]).astype(np.float32))                     # (2, n): is-minimum one-hot
         succ = (rank[None, :] == rank[:, None] + 1)                                        # succ[i, j]: x_j follows x_i
         flat = succ.flatten(order="F")                                                     # edge order = column-major ones
@@ -39,11 +47,17 @@ def main():
     ap.add_argument("--n", type=int, default=8)
     ap.add_argument("--width", type=int, default=16)
     ap.add_argument("--lr", type=float, default=3e-3)
+    ap.add_argument("--profile", action="store_true", help="per-kernel GPU time of the last iteration (gnx_profile_*)")
+    ap.add_argument("--vocab", type=int, default=0, help="one-hot integer inputs like the reference (sort.jl uses 100)")
+    ap.add_argument("--reference-config", action="store_true",
+                    help="the reference's sizes: vocab 100, 2..10 nodes, core width 384, batch 4, 2 cores (sort.jl:11-16,86-89,116)")
     args = ap.parse_args()
+    if args.reference_config:
+        args.vocab, args.n, args.width, args.graphs = 100, 10, 384, 4
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     w = args.width
-    enc = gn.GNBlock((0, 1, 0), (w, w, w), device=dev, act=("relu", "relu", "relu"))
+    enc = gn.GNBlock((0, args.vocab or 1, 0), (w, w, w), device=dev, act=("relu", "relu", "relu"))
     cores = gn.GNCoreList([gn.GNCore((w, w, w), device=dev) for _ in range(2)])
     dec = gn.GNBlock((w, w, w), (2, 2, 0), device=dev)
     params = []
@@ -58,8 +72,14 @@ def main():
     opt = torch.optim.AdamW(params, lr=args.lr)
     rng = np.random.default_rng(0)
     hist = []
+    import time
+    t_start = None
     for it in range(args.iters):
-        x, tn, te = make_batch(rng, args.graphs, args.n, dev)
+        if it == min(10, args.iters - 1):
+            torch.cuda.synchronize(); t_start = (time.perf_counter(), it)
+        x, tn, te = make_batch(rng, args.graphs, args.n, dev, args.vocab)
+        if args.profile and it == args.iters - 1:
+            torch.cuda.synchronize(); gn._lib.profile_enable(True); gn._lib.profile_reset()
         y = dec(cores(enc(x)))
         loss = gn.logitcrossentropy(gn.flatunpaddednf(y), tn) + gn.logitcrossentropy(gn.flatunpaddedef(y), te)
         opt.zero_grad()
@@ -69,6 +89,13 @@ def main():
         if it % 50 == 0 or it == args.iters - 1:
             acc = float((gn.flatunpaddednf(y).argmax(0) == tn.argmax(0)).float().mean())
             print(f"iter {it:4d}  loss {hist[-1]:.4f}  node accuracy {acc:.3f}")
+    torch.cuda.synchronize()
+    if args.profile:
+        prof = sorted(((v["total_ms"] * 1e3, k, v["launches"]) for k, v in gn._lib.profile_read().items() if not k.startswith("__")), reverse=True)
+        gn._lib.profile_enable(False)
+        print("last iteration, gnx kernels (us, launches):", [(round(t, 1), k, n) for t, k, n in prof], "total %.1f us" % sum(t for t, _, _ in prof))
+    if t_start and args.iters - t_start[1] > 0:
+        print(f"{(time.perf_counter() - t_start[0]) / (args.iters - t_start[1]) * 1e3:.2f} ms / training iteration (forward + backward + AdamW, incl. host batch construction)")
     return hist
 
 

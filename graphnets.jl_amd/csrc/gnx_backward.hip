@@ -232,6 +232,23 @@ __global__ __launch_bounds__(256) void k_bw_dw_final(const float* __restrict__ p
 static int32_t colsum_all(const float* in, size_t rows, int d, float* out, float* part, int* d_off2, hipStream_t s);
 __global__ void k_set_off2(int* off2, int rows);
 
+// Few rows, many weights (the reference's sort example: 4 graphs of <= 10 nodes at width 384): one THREAD per (k, j) pair
+// walks all rows in order — the chunked kernels above would put every pair on one workgroup.  k == K is the bias.
+__global__ void k_bw_dw_small(const float* __restrict__ delta, const float* __restrict__ X, int rows, int J, int K, float* __restrict__ dW,
+                              float* __restrict__ db) {
+  const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (size_t)J * (K + 1)) return;
+  const int k = (int)(p / J), j = (int)(p % J);
+  float acc = 0.f;
+  if (k < K) {
+    for (int m = 0; m < rows; ++m) acc = fmaf(delta[(size_t)m * J + j], X[(size_t)m * K + k], acc);
+    if (dW) dW[p] = acc;
+  } else {
+    for (int m = 0; m < rows; ++m) acc += delta[(size_t)m * J + j];
+    if (db) db[j] = acc;
+  }
+}
+
 struct BwLayout {
   size_t Xe, Xn, Xg, de_, dn_, dg_, dXe, dXn, dXg, part, wt, off2, ssrc, sdst, sg, tnf, total;
 };
@@ -262,6 +279,12 @@ static int32_t dw_reduce(const float* delta, const float* X, size_t rows, int J,
   }
   const int nchunks = (int)((rows + BW_CH - 1) / BW_CH);
   const int P = J * (K + 1);
+  ProfScope ps("bw_dw_generic", s);
+  if (nchunks <= 2 && P >= 4096) {
+    hipLaunchKernelGGL(k_bw_dw_small, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, delta, X, (int)rows, J, K, g.weight, g.bias);
+    GNX_HIP(hipGetLastError());
+    return GNX_OK;
+  }
   hipLaunchKernelGGL(k_bw_dw_partial, dim3(nchunks), dim3(256), 0, s, delta, X, rows, J, K, partial);
   hipLaunchKernelGGL(k_bw_dw_final, dim3(P), dim3(256), 0, s, partial, nchunks, J, K, g.weight, g.bias);
   GNX_HIP(hipGetLastError());

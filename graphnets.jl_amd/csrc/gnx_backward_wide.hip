@@ -121,10 +121,13 @@ __global__ void k_dw_final2(const float* __restrict__ partial, int nchunks, size
 
 bool bw_use_mfma(size_t rows, int J, int K) {
   static const bool off = getenv("GNX_BW_GENERIC") != nullptr;
-  return !off && rows >= 4096 && (size_t)J * K >= 1024 && J >= 8 && K >= 8;
+  // also for small batches of wide layers (the reference's sort example: a few hundred rows at width 384): the generic
+  // kernels put one thread on each (row, k) with strided weight reads, the GEMM tiles read the weights coalesced
+  return !off && rows >= 64 && (size_t)J * K >= 1024 && J >= 8 && K >= 8;
 }
 
-int dw_mfma_chunk_rows(size_t rows) { return (int)std::max<size_t>(1024, (rows + 1023) / 1024); }
+// rows per workgroup of k_dw_gemm: at most 1024 chunks; small batches get 128-row chunks so that several workgroups share the rows
+int dw_mfma_chunk_rows(size_t rows) { return (int)((std::max<size_t>(128, (rows + 1023) / 1024) + 31) / 32 * 32); }
 size_t dw_mfma_partial_floats(size_t rows, int J, int K) {
   const size_t ch = dw_mfma_chunk_rows(rows);
   return (rows + ch - 1) / ch * (size_t)J * K;

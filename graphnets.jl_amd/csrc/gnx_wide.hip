@@ -500,6 +500,82 @@ __global__ __launch_bounds__(256) void k_graph_final(const float* pe2, const flo
   }
 }
 
+// ---- few rows, wide layers (graph-level Dense of a small batch: M = R*G <= 8 rows, K and N in the hundreds) ----
+// y[m][n] = act(b[n] + sum_k x[m][k] * W[(w_row0 + k) * ldw + n]).  The work is a handful of GEMVs: what matters is the
+// number of dependent memory round trips.  1024 threads = 64 output lanes x 16 K-slices, every thread keeps 8 weight loads
+// in flight (coalesced 256-B rows), the 16 slices are added in a fixed order from LDS.
+__global__ __launch_bounds__(1024) void k_skinny_dense(const float* __restrict__ x, int ldx, int M, int K, const float* __restrict__ W, int w_row0,
+                                                       int ldw, const float* __restrict__ bias, int N, int act, float* __restrict__ y, int ldy) {
+  extern __shared__ float s_sk[];  // [M][K] inputs, reused as [16][8][64] partial sums
+  const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  for (int i = tid; i < M * K; i += 1024) s_sk[i] = x[(size_t)(i / K) * ldx + i % K];
+  __syncthreads();
+  const int per = (K + 15) / 16, k0 = ks * per, k1 = min(k0 + per, K);
+  float acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+  const int nc = n < N ? n : N - 1;
+  for (int k = k0; k < k1; k += 8) {
+    float w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = W[(size_t)(w_row0 + min(k + u, k1 - 1)) * ldw + nc];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (k + u < k1) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = fmaf(w[u], m < M ? s_sk[m * K + k + u] : 0.f, acc[m]);
+      }
+    }
+  }
+  __syncthreads();  // everyone is done reading the inputs: the buffer becomes the partial-sum table
+#pragma unroll
+  for (int m = 0; m < 8; ++m) s_sk[(ks * 8 + m) * 64 + lane] = acc[m];
+  __syncthreads();
+  if (tid < 64 * 8) {
+    const int m = tid >> 6, l = tid & 63, nn = blockIdx.x * 64 + l;
+    if (m < M && nn < N) {
+      float v = bias ? bias[nn] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += s_sk[(q * 8 + m) * 64 + l];
+      y[(size_t)m * ldy + nn] = act_apply(v, act);
+    }
+  }
+}
+static bool skinny_ok(int64_t M, int K, int N) { return M >= 1 && M <= 8 && (size_t)K * N >= 4096 && K >= 16; }
+static int32_t launch_skinny(const float* x, int ldx, int M, int K, const float* W, int w_row0, int ldw, const float* bias, int N, int act, float* y,
+                             int ldy, hipStream_t s) {
+  const size_t lds = sizeof(float) * std::max<size_t>((size_t)M * K, 16 * 8 * 64);
+  hipLaunchKernelGGL(k_skinny_dense, dim3((unsigned)((N + 63) / 64)), dim3(1024), lds, s, x, ldx, M, K, W, w_row0, ldw, bias, N, act, y, ldy);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+// Xg[r*G + g][:] = [sum_e ef' ; sum_n nf' ; gf_g] from the stage-1 slices (the input of the graph function)
+__global__ __launch_bounds__(256) void k_graph_x(const float* pe2, const float* pn2, int S, BlockArgs a, float* __restrict__ xg) {
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const size_t r = blockIdx.y;
+  const int oe = a.oe, on = a.on, C = oe + on, K = C + a.dg;
+  float* out = xg + (r * a.G + g) * (size_t)K;
+  for (int c = tid; c < C; c += 256) {
+    const float* p = c < oe ? pe2 + ((r * a.G + g) * S) * (size_t)oe + c : pn2 + ((r * a.G + g) * S) * (size_t)on + (c - oe);
+    const int stride = c < oe ? oe : on;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    for (int i = 0; i < S; i += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)min(i + u, S - 1) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += i + u < S ? v[u] : 0.f;
+    }
+    out[c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  }
+  const float* gf = a.gf ? a.gf + (r * (size_t)a.G + g) * a.dg : nullptr;
+  for (int k = tid; k < a.dg; k += 256) out[C + k] = gf[k];
+}
+
 static int wide_slices(const gnx_graphs* h) {
   int64_t mx = 1;
   for (int64_t g = 0; g < h->G; ++g) mx = std::max<int64_t>(mx, h->h_etile_off[g + 1] - h->h_etile_off[g]);
@@ -512,7 +588,8 @@ size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int6
   const size_t stage2 = sizeof(float) * (size_t)R * h->G * wide_slices(h) * (size_t)(p->oe + p->on);
   const size_t bias_g = sizeof(float) * (size_t)R * h->G * (size_t)(p->oe + p->on);
   const size_t proj = sizeof(float) * 2 * (size_t)R * h->N * (size_t)p->oe;  // node projections Ps, Pd
-  return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + 512;
+  const size_t xg = sizeof(float) * (size_t)R * h->G * (size_t)(p->oe + p->on + p->dg);  // graph-function input (small batches)
+  return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + align_up(xg, 256) + 512;
 }
 
 template <int BN>
@@ -540,8 +617,13 @@ static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64
 }
 
 static int32_t launch_gemm_any(const WideArgs& w, bool vec4, unsigned n_tiles, int64_t R, hipStream_t s, const char* name) {
-  if (w.OUT > 64) return launch_gemm<128>(w, vec4, n_tiles, R, s, name);  // 128-wide tiles beat 64-wide ones for OUT = 128
-  if (w.OUT > 32) return launch_gemm<64>(w, vec4, n_tiles, R, s, name);
+  int bn = w.OUT > 64 ? 128 : (w.OUT > 32 ? 64 : 32);  // 128-wide tiles beat 64-wide ones for OUT = 128 on a full GPU
+  // A launch that cannot fill the 256 CUs (small batches: the reference's sort example has 4 graphs) is pure latency: every
+  // workgroup walks its K chunks alone, paying a 128-wide tile's MFMA time per chunk for a handful of rows.  Narrower column
+  // tiles give more workgroups and 2-4x less matrix-core time per chunk.
+  while (bn > 32 && (size_t)n_tiles * ((w.OUT + bn - 1) / bn) * (size_t)R < 256) bn >>= 1;
+  if (bn == 128) return launch_gemm<128>(w, vec4, n_tiles, R, s, name);
+  if (bn == 64) return launch_gemm<64>(w, vec4, n_tiles, R, s, name);
   return launch_gemm<32>(w, vec4, n_tiles, R, s, name);
 }
 
@@ -615,8 +697,13 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   int32_t rc = GNX_OK;
   if ((phase & 1) && a.dg > 0) {  // fold gf into per-graph biases (one tiny launch per update function)
     ProfScope ps("k_fold_bias", s);
+    if (skinny_ok(R * a.G, a.dg, std::max(a.oe, a.on))) {  // a few graphs, wide layers: one round-trip-lean GEMV kernel per function
+      if (a.oe > 0 && (rc = launch_skinny(a.gf, a.dg, (int)(R * a.G), a.dg, a.We, a.de + 2 * a.dn, a.oe, a.be, a.oe, GNX_ACT_IDENTITY, bias_e, a.oe, s))) return rc;
+      if (a.on > 0 && (rc = launch_skinny(a.gf, a.dg, (int)(R * a.G), a.dg, a.Wn, a.oe + a.dn, a.on, a.bn, a.on, GNX_ACT_IDENTITY, bias_n, a.on, s))) return rc;
+    } else {
     if (a.oe > 0) hipLaunchKernelGGL(k_fold_bias, dim3((unsigned)a.G, (unsigned)R), dim3(128), 0, s, a.We, a.be, a.gf, a.dg, a.de + 2 * a.dn, a.oe, a.G, bias_e);
     if (a.on > 0) hipLaunchKernelGGL(k_fold_bias, dim3((unsigned)a.G, (unsigned)R), dim3(128), 0, s, a.Wn, a.bn, a.gf, a.dg, a.oe + a.dn, a.on, a.G, bias_n);
+    }
     GNX_HIP(hipGetLastError());
   }
   // Node-projection form (edgefninput.jl:2-7 regrouped): W*[ef; nf_s; nf_d; gf] = We_e*ef + (We_s*nf)[src] + (We_d*nf + b')[dst].
@@ -695,8 +782,15 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     ProfScope ps("k_graph_wide", s);
     if (a.oe > 0) hipLaunchKernelGGL(k_colsum_slices, dim3((unsigned)a.G, (unsigned)S, (unsigned)R), dim3(128), 0, s, pe, n_et * (size_t)a.oe, h->d_etile_off, a.oe, S, pe2, a.G);
     if (a.on > 0) hipLaunchKernelGGL(k_colsum_slices, dim3((unsigned)a.G, (unsigned)S, (unsigned)R), dim3(128), 0, s, pn, n_nt * (size_t)a.on, h->d_ntile_off, a.on, S, pn2, a.G);
-    const size_t lds = sizeof(float) * ((size_t)(a.oe + a.on + a.dg + 4) + 256 * 33 + 4);
-    hipLaunchKernelGGL(k_graph_final, dim3((unsigned)a.G, (unsigned)R), dim3(256), lds, s, pe2, pn2, S, a);
+    const int Kg = a.oe + a.on + a.dg;
+    if (skinny_ok(R * a.G, Kg, a.og)) {  // small batch, wide layers: assemble Xg, then the round-trip-lean GEMV kernel
+      float* xg = reinterpret_cast<float*>(reinterpret_cast<char*>(proj_s) + align_up(sizeof(float) * 2 * (size_t)R * h->N * a.oe, 256));
+      hipLaunchKernelGGL(k_graph_x, dim3((unsigned)a.G, (unsigned)R), dim3(256), 0, s, pe2, pn2, S, a, xg);
+      if ((rc = launch_skinny(xg, Kg, (int)(R * a.G), Kg, a.Wg, 0, a.og, a.bg, a.og, a.act_g, a.gf_out, a.og, s))) return rc;
+    } else {
+      const size_t lds = sizeof(float) * ((size_t)(a.oe + a.on + a.dg + 4) + 256 * 33 + 4);
+      hipLaunchKernelGGL(k_graph_final, dim3((unsigned)a.G, (unsigned)R), dim3(256), lds, s, pe2, pn2, S, a);
+    }
     GNX_HIP(hipGetLastError());
   }
   return GNX_OK;
