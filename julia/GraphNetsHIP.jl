@@ -181,8 +181,59 @@ function (m::GNBlock)(x)                                              # src/gnbl
      gf=og == 0 ? nothing : download!(o_gf, b_gf))                    # zero-width outputs → nothing (gnblock.jl:71-78)
 end
 
-# GNCore / GNCoreList follow the same pattern with gnx_core_params / gnx_core_forward (include/gnx.h); GNCoreList is
-# `foldl((x, f) -> f(x), list; init=x)` exactly as src/gncorelist.jl:43-45.
+# ---- GNCore (src/gncore.jl:46-68): core(x) = x + block(gn1(x)) + ffwd(gn2(x)) → gnx_core_forward ----
+struct LayerNorm                                                       # Flux.LayerNorm(d): diag scale γ, bias β
+    γ::Vector{Float32}; β::Vector{Float32}
+end
+LayerNorm(d::Integer) = LayerNorm(ones(Float32, d), zeros(Float32, d))
+
+struct GnxLayerNorm; gamma::Ptr{Cfloat}; beta::Ptr{Cfloat}; end       # gnx_layernorm
+struct GnxFfn; fc1::GnxDense; fc2::GnxDense; end                       # gnx_ffn
+struct GnxCoreParams                                                   # gnx_core_params (344 bytes)
+    block::GnxBlockParams
+    ln1::NTuple{3,GnxLayerNorm}; ln2::NTuple{3,GnxLayerNorm}; ff::NTuple{3,GnxFfn}
+    eps::Cfloat; eps_mode::Int32
+end
+
+struct GNCore
+    block::GNBlock
+    ffwd::NTuple{3,Tuple{Dense,Dense}}                                 # gnfeedforward.jl:17-31: Dense(d => 4d, relu), Dense(4d => d)
+    gn1::NTuple{3,LayerNorm}; gn2::NTuple{3,LayerNorm}                 # gngraphnorm.jl:9-17
+    dims::NTuple{3,Int}
+end
+function GNCore(dims; dropout=0)                                       # src/gncore.jl:46-54
+    @assert all(dims .> 0)                                             # gnfeedforward.jl:18, gngraphnorm.jl:10
+    d = Tuple(dims)
+    GNCore(GNBlock(d => d; dropout), map(k -> (Dense(k, 4k, :relu), Dense(4k, k)), d), map(LayerNorm, d), map(LayerNorm, d), d)
+end
+
+function (m::GNCore)(x)                                                # src/gncore.jl:56-68
+    (; graphs, ef, nf, gf) = x
+    @assert ef !== nothing && nf !== nothing && gf !== nothing         # graphnetadd needs all three (gncore.jl:61-68)
+    g::GNGraphBatch = graphs
+    R = size(ef, 3)
+    keep = DevBuf[]                                                    # device copies of every parameter, alive across the ccall
+    up(a) = (b = upload(a); push!(keep, b); devptr(b))
+    dn(d::Dense) = GnxDense(up(d.weight), up(d.bias), Int32(actcode(d.σ)), 0)
+    ln(l::LayerNorm) = GnxLayerNorm(up(l.γ), up(l.β))
+    b = m.block
+    bp = GnxBlockParams(b.in..., b.out..., dn(b.edgefn), dn(b.nodefn), dn(b.graphfn))
+    p = Ref(GnxCoreParams(bp, map(ln, m.gn1), map(ln, m.gn2), map(t -> GnxFfn(dn(t[1]), dn(t[2])), m.ffwd), 1f-5, Int32(0)))
+    d_ef, d_nf, d_gf = upload(ef), upload(nf), upload(gf)
+    o_ef, o_nf, o_gf = similar(ef), similar(nf), similar(gf)
+    b_ef, b_nf, b_gf = DevBuf(sizeof(o_ef)), DevBuf(sizeof(o_nf)), DevBuf(sizeof(o_gf))
+    wsb = ccall((:gnx_core_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxCoreParams}, Int64), g.handle, p, R)
+    ws = DevBuf(wsb)
+    GC.@preserve keep d_ef d_nf d_gf b_ef b_nf b_gf ws check(ccall((:gnx_core_forward, libgnx), Int32,
+        (Ptr{Cvoid}, Ptr{GnxCoreParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat},
+         Ptr{Cvoid}, Csize_t, UInt32, Ptr{Cvoid}),
+        g.handle, p, devptr(d_ef), devptr(d_nf), devptr(d_gf), R, devptr(b_ef), devptr(b_nf), devptr(b_gf),
+        ws.ptr, wsb, UInt32(0), C_NULL))
+    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
+    (graphs=g, ef=download!(o_ef, b_ef), nf=download!(o_nf, b_nf), gf=download!(o_gf, b_gf))
+end
+
+# GNCoreList is `foldl((x, f) -> f(x), list; init=x)` exactly as src/gncorelist.jl:43-45.
 struct GNCoreList{T}; list::T; end
 (m::GNCoreList)(x) = foldl((i, fn) -> fn(i), m.list; init=x)
 
