@@ -375,10 +375,25 @@ def main():
         }
         if dense is not None:
             line["cpu_dense_formulation_restatement"] = dense  # NOT the reference: its formulation restated in numpy (B2)
-        print(json.dumps(line))
+    # The JSON line must be the LAST thing on stdout: with NCCL_DEBUG=VERSION (set on the GPU boxes) RCCL writes its version
+    # banner through C stdio, which on a pipe is only flushed at exit — after Python's print.  Every rank tears the process
+    # group down and flushes C stdio first; rank 0 prints once the others are done.
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        if multi:
+            time.sleep(0.5)  # the other ranks' (already flushed) output reaches the launcher's pipe first
+        print(json.dumps(line), flush=True)
+
+
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":
