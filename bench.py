@@ -167,12 +167,15 @@ def main():
     else:
         din, dout = (tuple(int(v) for v in part.split(",")) for part in args.dims.split(":"))
         assert len(din) == 3 and len(dout) == 3, "--dims de,dn,dg:oe,on,og"
-    workload = args.workload or ("hetero" if multi else "c2")
+    # Weak scaling keeps the per-GPU work of the headline config: a batch of `world` C2-sized graphs sharded by graph (one
+    # 100k-node / 1M-edge graph per GPU), gf' all-gathered.  `--workload hetero` gives BASELINE configs[4] (512 graphs per GPU).
+    workload = args.workload or "c2"
 
     # ---- synthetic batch (rank-local shard) ----
     if workload == "c2":
-        colptrs, rowvals, nn = make_c2()
-        wl_name = "C2: one shared Erdos-Renyi graph, 100k nodes / 1M edges, batch_size=1 (BASELINE configs[1])"
+        colptrs, rowvals, nn = make_c2(seed=2 + rank)
+        wl_name = ("C2: one shared Erdos-Renyi graph, 100k nodes / 1M edges, batch_size=1 (BASELINE configs[1])" if world == 1 else
+                   f"batch of {world} C2-sized Erdos-Renyi graphs (100k nodes / 1M edges each) sharded by graph, one per GPU; gf' all-gathered")
     else:
         colptrs, rowvals, nn = make_hetero(seed=3 + rank)
         wl_name = (f"heterogeneous batch, {512 * world} random graphs (32-256 nodes) sharded by graph, 512 graphs / 1M edges "
@@ -196,7 +199,7 @@ def main():
     # pure latency on xGMI); the gather runs on a side stream and overlaps the next M steps.
     M = 1
     if multi:
-        M = max(m for m in range(1, 65) if K % m == 0)
+        M = max(m for m in range(1, 257) if K % m == 0)
     gf_stack = torch.zeros((M, G, og), dtype=torch.float32, device=dev) if multi else None
     gather = GfGather([np.arange(r * M * G, (r + 1) * M * G) for r in range(world)], rank, world, og, dev) if multi else None
 
