@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dims", default="readme", help="a preset (%s) or explicit widths de,dn,dg:oe,on,og" % ", ".join(DIMS))
     ap.add_argument("--workload", choices=["c2", "hetero"], default=None)
+    ap.add_argument("--hetero-graphs", type=int, default=512, help="graphs per GPU of the hetero workload (C3: 512; C5: 4096)")
+    ap.add_argument("--hetero-edges", type=int, default=1_000_000, help="edges per GPU of the hetero workload (C5w: 8000000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--dense-baseline", action="store_true",
@@ -177,9 +179,9 @@ def main():
         wl_name = ("C2: one shared Erdos-Renyi graph, 100k nodes / 1M edges, batch_size=1 (BASELINE configs[1])" if world == 1 else
                    f"batch of {world} C2-sized Erdos-Renyi graphs (100k nodes / 1M edges each) sharded by graph, one per GPU; gf' all-gathered")
     else:
-        colptrs, rowvals, nn = make_hetero(seed=3 + rank)
-        wl_name = (f"heterogeneous batch, {512 * world} random graphs (32-256 nodes) sharded by graph, 512 graphs / 1M edges "
-                   f"per GPU (BASELINE configs[{2 if world == 1 else 4}])")
+        colptrs, rowvals, nn = make_hetero(seed=3 + rank, G=args.hetero_graphs, E=args.hetero_edges)
+        wl_name = (f"heterogeneous batch, {args.hetero_graphs * world} random graphs (32-256 nodes) sharded by graph, {args.hetero_graphs} graphs / "
+                   f"{args.hetero_edges / 1e6:g}M edges per GPU (BASELINE configs[{2 if world == 1 else 4}] law)")
     g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
     E, N, G = g.n_edges, g.n_nodes, g.n_graphs
     rng = np.random.default_rng(100)  # identical weights on every rank
