@@ -24,6 +24,9 @@ namespace gnx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef GNX_GEMM_WAVES  // at least 4 waves per SIMD: the accumulators move from AGPRs into a 128-register budget (3 spilled VGPRs at BN = 128);
+#define GNX_GEMM_WAVES __attribute__((amdgpu_waves_per_eu(4)))  // a 4th workgroup per CU covers the others' epilogues: C4 8.50 -> 8.10 ms
+#endif
 constexpr int BM = 128;   // rows (edges or nodes) per workgroup tile
 constexpr int WT = 256;   // threads
 
@@ -78,7 +81,7 @@ struct WaveLayout {
 };
 
 template <int BN, bool VEC4, int KC>
-__global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
+__global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   using L = WaveLayout<BN>;
   constexpr int LDA = KC + 1;               // A row stride: odd => conflict-free ds_read_b32 of the A fragment
   constexpr int C4R = KC / 4;               // float4 per A row chunk
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(WT) void k_rows_gemm(WideArgs a) {
 #endif
 
   // ---- epilogue: the tile goes through LDS (two 64-row passes) so that HBM sees full-row 16-B vector stores (the direct
-  //      C/D-layout store is 64 dword stores per lane); bias', the gathered node projections, the activation, the column
+  //      C/D-layout store is 64 dword stores per lane — measured: ff1 3.43 vs 2.84 ms, ff2 3.08 vs 2.55 ms on C4); bias', the gathered node projections, the activation, the column
   //      sums for the graph update and the residual adds are applied on the vectorised side ----
   float* out = a.out + r * a.out_rep_stride;
   const int hi = lane >> 5, l31 = lane & 31;
@@ -610,8 +613,30 @@ static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64
   const unsigned gx = wa.n_ctiles > 1 ? (n_tiles + 7) / 8 * 8 * (unsigned)wa.n_ctiles : n_tiles;
   const dim3 grid(gx, 1, (unsigned)R);
   // K chunk 32: measured against 64 (fewer barriers but 2 instead of 3 waves/SIMD): 466 vs 616 us on the edge GEMM
+#ifdef GNX_WIDE_STAMPS_BUILD  // diagnostic build (GNX_CXXFLAGS=-DGNX_WIDE_STAMPS_BUILD) + GNX_WIDE_STAMPS=1: per-phase shader clocks of every launch
+  static unsigned long long* d_stamps = nullptr;
+  static size_t stamps_cap = 0;
+  static const bool want_stamps = getenv("GNX_WIDE_STAMPS") != nullptr;
+  if (want_stamps && stamps_cap < n_tiles) {
+    if (d_stamps) (void)hipFree(d_stamps);
+    stamps_cap = (size_t)n_tiles * 2;
+    (void)hipMalloc((void**)&d_stamps, stamps_cap * 8 * sizeof(unsigned long long));
+  }
+  if (want_stamps) { (void)hipMemsetAsync(d_stamps, 0, (size_t)n_tiles * 8 * sizeof(unsigned long long), s); wa.stamps = d_stamps; }
+#endif
   if (vec4) hipLaunchKernelGGL((k_rows_gemm<BN, true, 32>), grid, dim3(WT), 0, s, wa);
   else hipLaunchKernelGGL((k_rows_gemm<BN, false, 32>), grid, dim3(WT), 0, s, wa);
+#ifdef GNX_WIDE_STAMPS_BUILD
+  if (want_stamps) {
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> hs((size_t)n_tiles * 8);
+    (void)hipMemcpy(hs.data(), d_stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    double m[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < n_tiles; ++i) for (int j = 0; j < 5; ++j) m[j] += (double)hs[i * 8 + j];
+    fprintf(stderr, "[gnx stamps] %s BN=%d tiles=%u ctiles=%d: per tile (shader clocks, wave 0 of column tile 0): prologue %.0f  sync+store %.0f  mfma-loop %.0f  epilogue %.0f  total %.0f\n",
+            name, BN, n_tiles, wa.n_ctiles, m[0] / n_tiles, m[1] / n_tiles, m[2] / n_tiles, m[3] / n_tiles, m[4] / n_tiles);
+  }
+#endif
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -743,24 +768,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     w.out = a.ef_out; w.out_rep_stride = (size_t)a.E * a.oe;
     w.colsum = a.og > 0 ? pe : nullptr; w.colsum_rep_stride = n_et * (size_t)a.oe;
     const bool vec4 = al16 && a.de % 4 == 0 && a.dn % 4 == 0 && a.oe % 4 == 0;
-#ifdef GNX_WIDE_STAMPS_BUILD
-    static unsigned long long* d_stamps = nullptr;
-    static const bool want_stamps = getenv("GNX_WIDE_STAMPS") != nullptr;
-    if (want_stamps && !d_stamps) { (void)hipMalloc((void**)&d_stamps, n_et * 8 * sizeof(unsigned long long)); (void)hipMemset(d_stamps, 0, n_et * 8 * sizeof(unsigned long long)); }
-    w.stamps = want_stamps ? d_stamps : nullptr;
-#endif
     if ((rc = launch_gemm_any(w, vec4, (unsigned)n_et, R, s, "k_rows_gemm_edge"))) return rc;
-#ifdef GNX_WIDE_STAMPS_BUILD
-    if (want_stamps) {
-      (void)hipStreamSynchronize(s);
-      std::vector<unsigned long long> hs(n_et * 8);
-      (void)hipMemcpy(hs.data(), d_stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-      double m[5] = {0, 0, 0, 0, 0};
-      for (size_t i = 0; i < n_et; ++i) for (int j = 0; j < 5; ++j) m[j] += (double)hs[i * 8 + j];
-      fprintf(stderr, "[gnx stamps] edge gemm per tile (shader clocks, wave 0): prologue %.0f  sync+store %.0f  mfma-loop %.0f  epilogue %.0f  total %.0f\n",
-              m[0] / n_et, m[1] / n_et, m[2] / n_et, m[3] / n_et, m[4] / n_et);
-    }
-#endif
   }
   if ((phase & 1) && a.on > 0) {
     WideArgs w{};
