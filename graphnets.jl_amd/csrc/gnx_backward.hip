@@ -519,8 +519,8 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   if (R <= 0 || (R > 1 && h->G != 1) || R > 65535) return fail(GNX_ERR_INVALID_ARG, "bad n_replicas");
   const int de = p->de, dn = p->dn, dg = p->dg, oe = p->oe, on = p->on, og = p->og;
   if (de < 0 || dn < 0 || dg < 0 || oe < 0 || on < 0 || og < 0 || de + dn + dg == 0 || oe + on + og == 0) return fail(GNX_ERR_DIMS, "bad widths");
-  if ((de && !ef) || (dn && !nf) || (dg && !gf)) return fail(GNX_ERR_INVALID_ARG, "a forward input with non-zero width is NULL");
-  if ((oe && !ef_out) || (on && !nf_out) || (og && !gf_out)) return fail(GNX_ERR_INVALID_ARG, "a forward output with non-zero width is NULL");
+  if ((de && !ef && h->E > 0) || (dn && !nf) || (dg && !gf)) return fail(GNX_ERR_INVALID_ARG, "a forward input with non-zero width is NULL");
+  if ((oe && !ef_out && h->E > 0) || (on && !nf_out) || (og && !gf_out)) return fail(GNX_ERR_INVALID_ARG, "a forward output with non-zero width is NULL");
   const int acts[3] = {p->edgefn.act, p->nodefn.act, p->graphfn.act};
   for (int a : acts)
     if (a == GNX_ACT_GELU || a < 0 || a > GNX_ACT_GELU) return fail(GNX_ERR_INVALID_ARG, "backward supports identity / relu / tanh / sigmoid");
@@ -717,7 +717,7 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
   if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
   const gnx_block_params& b = p->block;
   if (b.de <= 0 || b.dn <= 0 || b.dg <= 0 || b.oe != b.de || b.on != b.dn || b.og != b.dg) return fail(GNX_ERR_DIMS, "GNCore needs dims => dims with all(dims .> 0)");
-  if (!ef || !nf || !gf) return fail(GNX_ERR_INVALID_ARG, "GNCore needs ef, nf and gf");
+  if ((!ef && h->E > 0) || !nf || !gf) return fail(GNX_ERR_INVALID_ARG, "GNCore needs ef, nf and gf");
   if (R <= 0 || (R > 1 && h->G != 1) || R > 65535) return fail(GNX_ERR_INVALID_ARG, "bad n_replicas");
   for (int t = 0; t < 3; ++t) {
     if (p->ff[t].fc2.act != GNX_ACT_IDENTITY || p->ff[t].fc1.act == GNX_ACT_GELU) return fail(GNX_ERR_INVALID_ARG, "core backward: fc2 must be identity, fc1 not gelu");

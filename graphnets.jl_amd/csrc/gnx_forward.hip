@@ -81,9 +81,10 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   int32_t rc = check_block(h, p, R);
   if (rc) return rc;
   if (phase & 1) {
-    if ((p->de > 0 && !ef) || (p->dn > 0 && !nf) || (p->dg > 0 && !gf))
+    // a batch without a single edge has (DE, 0) edge features: its (empty) buffers may be NULL
+    if ((p->de > 0 && !ef && h->E > 0) || (p->dn > 0 && !nf) || (p->dg > 0 && !gf))
       return fail(GNX_ERR_INVALID_ARG, "an input with non-zero width is NULL (width 0 <=> nothing)");
-    if ((p->oe > 0 && !ef_out) || (p->on > 0 && !nf_out))
+    if ((p->oe > 0 && !ef_out && h->E > 0) || (p->on > 0 && !nf_out))
       return fail(GNX_ERR_INVALID_ARG, "an output with non-zero width is NULL");
   }
   if (phase & 2) {
@@ -183,7 +184,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   if (b.oe != b.de || b.on != b.dn || b.og != b.dg) return fail(GNX_ERR_DIMS, "GNCore's block must map dims => dims (gncore.jl:49)");
   int32_t rc = check_block(h, &b, R);
   if (rc) return rc;
-  if (!ef || !nf || !gf || !ef_out || !nf_out || !gf_out) return fail(GNX_ERR_INVALID_ARG, "GNCore needs ef, nf, gf and all outputs");
+  if (((!ef || !ef_out) && h->E > 0) || !nf || !gf || !nf_out || !gf_out) return fail(GNX_ERR_INVALID_ARG, "GNCore needs ef, nf, gf and all outputs");
   for (int t = 0; t < 3; ++t) {
     if (!p->ln1[t].gamma || !p->ln1[t].beta || !p->ln2[t].gamma || !p->ln2[t].beta) return fail(GNX_ERR_INVALID_ARG, "LayerNorm parameter is NULL");
     if (!p->ff[t].fc1.weight || !p->ff[t].fc2.weight) return fail(GNX_ERR_INVALID_ARG, "FeedForward weight is NULL");

@@ -1,0 +1,133 @@
+"""Seeded randomised parity sweep: random width sets (0 = `nothing`, narrow, mid, wide), random batches (single nodes,
+graphs without edges, hubs, replicas of a shared graph), random activations — every dispatch path (ahead-of-time fused
+kernel, run-time specialised kernel, matrix-core path, generic kernels) against the float64 oracle at 1e-5 of the magnitude
+bound, and GNCore against its oracle at 2e-4."""
+import numpy as np
+import pytest
+
+from oracle import gn_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+WIDTHS = [0, 1, 2, 3, 5, 8, 12, 16, 20, 33, 40, 64]
+
+
+@pytest.fixture(scope="module")
+def gn():
+    import graphnets_jl_amd as gn
+    return gn
+
+
+def _random_batch(rng, gn):
+    shared = rng.random() < 0.3
+    G = 1 if shared else int(rng.integers(1, 7))
+    cps, rvs, sizes = [], [], []
+    for _ in range(G):
+        n = int(rng.choice([1, 2, 3, 7, 20, 60, 150]))
+        kind = rng.integers(0, 4)
+        if kind == 0:                                   # no edges at all
+            cp, rv = np.zeros(n + 1, dtype=np.int64), np.zeros(0, dtype=np.int64)
+        elif kind == 1:                                 # fully connected (the reference's sort example)
+            cp, rv = np.arange(n + 1, dtype=np.int64) * n, np.tile(np.arange(n, dtype=np.int64), n)
+        else:
+            cp, rv = U.er_csc(rng, n, int(rng.integers(1, max(2, n * n // 3))))
+        cps.append(cp); rvs.append(rv); sizes.append(n)
+    g = gn.GNGraphBatch.from_csc(cps, rvs, sizes)
+    R = int(rng.integers(1, 4)) if shared else 1
+    return g, R
+
+
+def _dims(rng, core=False):
+    if core:
+        d = tuple(int(rng.choice([1, 3, 5, 8, 12, 16, 20, 33, 40, 64])) for _ in range(3))
+        return d, d
+    while True:
+        din = tuple(int(rng.choice(WIDTHS)) for _ in range(3))
+        dout = tuple(int(rng.choice(WIDTHS)) for _ in range(3))
+        if sum(din) > 0 and sum(dout) > 0:
+            return din, dout
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_block(gn, seed):
+    rng = np.random.default_rng(9000 + seed)
+    g, R = _random_batch(rng, gn)
+    din, dout = _dims(rng)
+    p = O.make_block_params(rng, din, dout, act=tuple(int(a) for a in rng.integers(0, 5, 3)))
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, g.n_graphs, din)
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    ref, scale = O.block_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    blk = U.block_from_params(gn, p)
+    for flags in (0, 1, 2):  # default dispatch, generic kernels, no matrix cores
+        y = blk(U.to_nt(gn, g, ef, nf, gf), flags=flags)
+        for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+            U.assert_close(U.from_jl(got), r, s, f"seed {seed} dims {din}=>{dout} R={R} flags={flags} {name}")
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_core(gn, seed):
+    rng = np.random.default_rng(9500 + seed)
+    g, R = _random_batch(rng, gn)
+    dims, _ = _dims(rng, core=True)
+    p = O.make_core_params(rng, dims, eps_mode=int(rng.integers(0, 2)))
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, g.n_graphs, dims)
+    if g.n_edges == 0:
+        ef = np.zeros((R, 0, dims[0]), dtype=np.float32)
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    ref = O.core_forward_sparse(p, csc, ef, nf, gf)
+    core = U.core_from_params(gn, p)
+    for flags in (0, 1):
+        y = core(U.to_nt(gn, g, ef, nf, gf), flags=flags)
+        for name, got, r in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref):
+            np.testing.assert_allclose(U.from_jl(got), r, rtol=2e-4, atol=2e-4, err_msg=f"seed {seed} dims {dims} R={R} flags={flags} {name}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_block_backward(gn, seed):
+    """gnx_block_backward on random width sets / batches (smooth activations: no relu kink) against torch float64 autograd."""
+    import torch
+    from tests.test_gpu_backward import _torch_block
+    rng = np.random.default_rng(9800 + seed)
+    g, _ = _random_batch(rng, gn)
+    din, dout = _dims(rng)
+    p = O.make_block_params(rng, din, dout, act=tuple(int(a) for a in rng.choice([0, 2, 3], 3)))
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, din)
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    W = {k: torch.tensor(p[k], dtype=torch.float64, requires_grad=True) for k in ("We", "be", "Wn", "bn", "Wg", "bg")}
+    t64 = lambda a: None if a is None else torch.tensor(a[0], dtype=torch.float64, requires_grad=True)
+    ef_r, nf_r, gf_r = t64(ef), t64(nf), t64(gf)
+    outs_r = _torch_block(p, csc, ef_r, nf_r, gf_r, W)
+    cot = [torch.from_numpy(rng.standard_normal(tuple(o.shape))) for o in outs_r]
+    terms = [(o * c).sum() for o, c in zip(outs_r, cot) if o.numel() > 0]
+    if not terms:
+        pytest.skip("no output elements")
+    sum(terms).backward()
+    blk = U.block_from_params(gn, p)
+    for layer in (blk.edgefn, blk.nodefn, blk.graphfn):
+        layer.weight.requires_grad_(True); layer.bias.requires_grad_(True)
+    dev = g.device
+    leaf = lambda a: None if a is None else torch.from_numpy(a).to(dev).requires_grad_(True)
+    ef_t, nf_t, gf_t = leaf(ef), leaf(nf), leaf(gf)
+    jl = lambda t: None if t is None else t.permute(2, 1, 0)
+    y = blk(gn.NT(g, jl(ef_t), jl(nf_t), jl(gf_t)))
+    loss = 0.0
+    for o, c in zip((y.ef, y.nf, y.gf), cot):
+        if o is not None and o.numel() > 0:
+            loss = loss + (o.permute(2, 1, 0)[0] * c.to(dev).float()).sum()
+    loss.backward()
+
+    def close(got, ref, what):
+        if ref is None or got is None:
+            return
+        ref = ref.detach().numpy(); got = got.detach().double().cpu().numpy()
+        scale = max(1.0, float(np.abs(ref).max())) if ref.size else 1.0
+        assert got.shape == ref.shape and (ref.size == 0 or np.max(np.abs(got - ref)) <= 5e-4 * scale), \
+            f"seed {seed} dims {din}=>{dout} {what}: max err {np.max(np.abs(got - ref)) if ref.size else 0:.3e} (scale {scale:.3g})"
+
+    for name, t, r in (("d_ef", ef_t, ef_r), ("d_nf", nf_t, nf_r), ("d_gf", gf_t, gf_r)):
+        if t is not None and r.grad is not None and t.grad is not None:
+            close(t.grad[0], r.grad, name)
+    for name, layer, kw, kb in (("edge", blk.edgefn, "We", "be"), ("node", blk.nodefn, "Wn", "bn"), ("graph", blk.graphfn, "Wg", "bg")):
+        if layer.weight.numel() and W[kw].grad is not None and layer.weight.grad is not None:
+            close(layer.weight.grad, W[kw].grad, f"dW_{name}")
+            close(layer.bias.grad, W[kb].grad, f"db_{name}")
