@@ -131,3 +131,39 @@ def test_random_block_backward(gn, seed):
         if layer.weight.numel() and W[kw].grad is not None and layer.weight.grad is not None:
             close(layer.weight.grad, W[kw].grad, f"dW_{name}")
             close(layer.bias.grad, W[kb].grad, f"db_{name}")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_dense_adjacency_api(gn, seed):
+    """The reference-facing API end to end on random vectors of dense adjacency matrices — batch, block, unbatch, views,
+    flatunpadded*, padded — against the LITERAL dense one-hot restatement of the reference (oracle form (i))."""
+    rng = np.random.default_rng(9900 + seed)
+    G = int(rng.integers(1, 5))
+    adjs = [(rng.random((n, n)) < rng.choice([0.0, 0.2, 0.6, 1.0])).astype(np.int64) for n in rng.integers(1, 9, G)]
+    din, dout = _dims(rng)
+    din = tuple(min(d, 12) for d in din); dout = tuple(min(d, 12) for d in dout)
+    if sum(din) == 0 or sum(dout) == 0:
+        din, dout = (3, 2, 1), (2, 3, 1)
+    p = O.make_block_params(rng, din, dout, act=tuple(int(a) for a in rng.integers(0, 5, 3)))
+    mk = lambda d, cols: rng.random((d, cols), dtype=np.float32)
+    ef = [mk(din[0], int(a.sum())) for a in adjs] if din[0] else None
+    nf = [mk(din[1], a.shape[0]) for a in adjs] if din[1] else None
+    gf = [rng.random(din[2], dtype=np.float32) for _ in adjs] if din[2] else None
+    x = gn.batch(dict(graphs=adjs, ef=ef, nf=nf, gf=gf))
+    yb = U.block_from_params(gn, p)(x)
+    y = gn.unbatch(yb)
+    dense = O.block_forward_dense(p, O.batch_dense(adjs, ef, nf, gf))
+    ref = O.unbatch_dense(dense)
+    for i in range(G):
+        for k in ("ef", "nf", "gf"):
+            got, r = getattr(y, k), ref[k]
+            if r is None:
+                assert got is None
+                continue
+            np.testing.assert_allclose(got[i].cpu().numpy(), r[i], rtol=2e-5, atol=2e-5, err_msg=f"seed {seed} graph {i} {k}")
+    if dout[1]:
+        np.testing.assert_allclose(gn.flatunpaddednf(yb).cpu().numpy(), O.flat_from_dense(dense, "nf"), rtol=2e-5, atol=2e-5)
+    if dout[0]:
+        np.testing.assert_allclose(gn.flatunpaddedef(yb).cpu().numpy(), O.flat_from_dense(dense, "ef"), rtol=2e-5, atol=2e-5)
+    assert np.array_equal(x.graphs.flat_edge_unpadder, dense["graphs"].flat_edge_unpadder)
+    assert np.array_equal(x.graphs.flat_node_unpadder, dense["graphs"].flat_node_unpadder)
