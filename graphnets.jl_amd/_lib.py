@@ -17,7 +17,7 @@ ERR_INVALID_ARG, ERR_NO_GRAPHS, ERR_ADJ_SHAPE, ERR_ADJ_VALUE, ERR_ALL_NOTHING = 
 ERR_DIMS, ERR_CSC, ERR_WORKSPACE, ERR_TOO_LARGE, ERR_COUNT_MISMATCH = -6, -7, -8, -9, -10
 ACT = dict(identity=0, relu=1, tanh=2, sigmoid=3, gelu=4)
 ELEM_U8, ELEM_I32, ELEM_I64, ELEM_F32, ELEM_F64 = 0, 1, 2, 3, 4
-FLAG_FORCE_GENERIC, FLAG_NO_MFMA, FLAG_DEFER_GRAPH_UPDATE = 0x1, 0x2, 0x4
+FLAG_FORCE_GENERIC, FLAG_NO_MFMA, FLAG_DEFER_GRAPH_UPDATE, FLAG_NO_GRAPH = 0x1, 0x2, 0x4, 0x8
 
 _fp = C.c_void_p  # device float*
 
@@ -69,6 +69,10 @@ class CoreParams(C.Structure):
                 ("eps", C.c_float), ("eps_mode", C.c_int32)]
 
 
+class Layer(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("params", C.c_void_p)]
+
+
 class ProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
 
@@ -110,6 +114,10 @@ SIGNATURES = {
     "gnx_logit_cross_entropy_backward": (C.c_int32, [_fp, _fp, C.c_int32, C.c_int64, _fp, _fp, C.c_void_p]),
     "gnx_pad_features": (C.c_int32, [C.c_void_p, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),
     "gnx_unpad_features": (C.c_int32, [C.c_void_p, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),
+    "gnx_model_create": (C.c_int32, [C.c_void_p, C.POINTER(Layer), C.c_int32, C.c_int64, _pp]),
+    "gnx_model_destroy": (C.c_int32, [C.c_void_p]),
+    "gnx_model_out_dims": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "gnx_model_forward": (C.c_int32, [C.c_void_p] + [_fp] * 6 + [C.c_uint32, C.c_void_p]),
     "gnx_jit_precompile": (C.c_int32, [C.POINTER(BlockParams), C.c_int32, C.POINTER(C.c_size_t)]),
     "gnx_jit_stats": (C.c_int32, [_i64p]),
     "gnx_profile_enable": (C.c_int32, [C.c_int32]),

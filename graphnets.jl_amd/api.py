@@ -875,6 +875,60 @@ class BlockPlan:
                                               self.flags, s))
 
 
+class Model:
+    """A chain of GNBlock / GNCore layers as ONE hipGraph inside libgnx (`gnx_model_*`, include/gnx.h) — what a Julia or C
+    caller uses instead of `Graphed` (which needs torch's graph capture).  `m = Model([enc, core1, core2, dec], x)`;
+    `y = m(x2)`: feature values are copied into the model's static input buffers, the whole chain is replayed with one
+    hipGraphLaunch, the returned tuple aliases the model's static output buffers (valid until the next call)."""
+
+    def __init__(self, layers, x, flags=0):
+        x = _as_nt(x)
+        self.g = x.graphs
+        self.layers = list(layers)
+        self.flags = flags
+        lib = _lib.load()
+        dev = self.g.device
+        present = [a for a in (x.ef, x.nf, x.gf) if a is not None]
+        self.R = present[0].shape[2]
+        self._keep = []
+        self._params = [l._c(self._keep) for l in self.layers]
+        arr = (_lib.Layer * len(self.layers))()
+        for i, (l, p) in enumerate(zip(self.layers, self._params)):
+            arr[i].kind = 1 if isinstance(l, GNCore) else 0
+            arr[i].params = C.addressof(p)
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            check(lib.gnx_model_create(self.g._h, arr, len(self.layers), self.R, C.byref(h)))
+        self.handle = h
+        dims = (C.c_int32 * 3)()
+        check(lib.gnx_model_out_dims(h, dims))
+        rows = (self.g.n_edges, self.g.n_nodes, self.g.n_graphs)
+        self._in = {k: None if getattr(x, k) is None else _packed(getattr(x, k)).clone() for k in ("ef", "nf", "gf")}
+        self._out = [torch.empty((self.R, t, int(d)), dtype=torch.float32, device=dev) if d > 0 else None for t, d in zip(rows, dims)]
+
+    def __call__(self, x):
+        x = _as_nt(x)
+        assert x.graphs is self.g, "a Model is bound to the GNGraphBatch it was created with"
+        for k in ("ef", "nf", "gf"):
+            a, buf = getattr(x, k), self._in[k]
+            assert (a is None) == (buf is None), f"{k}: presence differs from the creating call"
+            if a is not None:
+                buf.copy_(a.permute(2, 1, 0))
+        dev = self.g.device
+        with torch.cuda.device(dev):
+            check(_lib.load().gnx_model_forward(self.handle, _ptr(self._in["ef"]), _ptr(self._in["nf"]), _ptr(self._in["gf"]), _ptr(self._out[0]),
+                                                _ptr(self._out[1]), _ptr(self._out[2]), self.flags, torch.cuda.current_stream(dev).cuda_stream))
+        return NT(self.g, *(_jl(o) for o in self._out))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.load().gnx_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 class Graphed:
     """A model forward captured ONCE into a hipGraph and replayed: `g = Graphed(model, x); y = g(x2)`.
 

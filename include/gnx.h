@@ -256,6 +256,31 @@ GNX_API int32_t gnx_pad_features(const gnx_graphs* h, int32_t kind, const float*
 GNX_API int32_t gnx_unpad_features(const gnx_graphs* h, int32_t kind, const float* padded, int32_t d, int64_t n_replicas,
                            float* packed, void* stream);
 
+/* ---- a list of layers as ONE hipGraph: replaces a host-side chain such as the reference's
+ *      `decoder(core(encoder(x)))` (examples/sort/sort.jl:68-75; GNCoreList is a foldl, src/gncorelist.jl:43-45) ------------
+ * At README-sized widths a layer is ~25 us of GPU work, less than the host spends launching it: a multi-layer model is
+ * launch-bound.  gnx_model_create copies the layer descriptors (NOT the weights: the device pointers inside stay the
+ * caller's and must stay valid), sizes every intermediate tensor and workspace once (library-owned device memory, freed by
+ * gnx_model_destroy) and compiles any run-time specialised kernel.  gnx_model_forward runs the layers back to back on
+ * `stream`; the first call with a given set of input/output pointers captures them into a hipGraph (on an internal stream),
+ * later calls with the same pointers replay it with one hipGraphLaunch (new pointers: re-capture).  GNX_FLAG_NO_GRAPH runs
+ * eagerly.  Layer i's output widths must equal layer i+1's input widths (GNX_ERR_DIMS).  One forward at a time per model. */
+typedef struct gnx_model gnx_model;
+#define GNX_LAYER_BLOCK 0
+#define GNX_LAYER_CORE 1
+typedef struct gnx_layer {
+  int32_t kind;       /* GNX_LAYER_BLOCK: params -> gnx_block_params; GNX_LAYER_CORE: params -> gnx_core_params */
+  int32_t reserved;
+  const void* params;
+} gnx_layer;
+#define GNX_FLAG_NO_GRAPH 0x8u
+GNX_API int32_t gnx_model_create(const gnx_graphs* h, const gnx_layer* layers, int32_t n_layers, int64_t n_replicas, gnx_model** out);
+GNX_API int32_t gnx_model_destroy(gnx_model* m);
+/* widths of the model's output (DE', DN', DG'); 0 <=> nothing */
+GNX_API int32_t gnx_model_out_dims(const gnx_model* m, int32_t dims[3]);
+GNX_API int32_t gnx_model_forward(gnx_model* m, const float* ef, const float* nf, const float* gf, float* ef_out, float* nf_out,
+                          float* gf_out, uint32_t flags, void* stream);
+
 /* ---- run-time specialisation (the analogue of Julia compiling a GNBlock for its own widths on first use) -----------
  * The fused one-launch kernel is compiled ahead of time for the README / benchmark width sets; for any other width set
  * with every width <= 16 it is compiled at run time with hiprtc (gfx950), once per process and device, the first time

@@ -157,3 +157,45 @@ def test_graphed_model_replay_matches_eager(gn):
     t_eager, t_graph = best_of(lambda: model(x1)), best_of(graphed.graph.replay)
     print(f"README ex.3 model, 4k-edge graph: eager {t_eager * 1e6:.0f} us / forward, hipGraph replay {t_graph * 1e6:.0f} us")
     assert t_graph < t_eager
+
+
+def test_c_level_model_graph_matches_eager(gn):
+    """gnx_model_*: the README ex.3 chain (encoder -> 2 x GNCore -> decoder) as ONE hipGraph inside libgnx — first call
+    captures, later calls replay with new feature values; results equal the eager layer-by-layer chain bit for bit."""
+    import torch
+    rng = np.random.default_rng(48)
+    in_dims, core_dims, out_dims = (10, 5, 0), (10, 5, 3), (3, 4, 5)
+    enc, dec = gn.GNBlock(in_dims, core_dims), gn.GNBlock(core_dims, out_dims)
+    cores = [gn.GNCore(core_dims) for _ in range(2)]
+    eager = lambda x: dec(cores[1](cores[0](enc(x))))
+    colptr, rowval = U.er_csc(rng, 500, 4000)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [500])
+    mk = lambda: U.to_nt(gn, g, *U.packed_inputs(rng, 1, 4000, 500, 1, in_dims))
+    x1, x2 = mk(), mk()
+    model = gn.Model([enc, cores[0], cores[1], dec], x1)
+    for x in (x1, x2, x1, x2):
+        ye, ym = eager(x), model(x)
+        for a, b in ((ye.ef, ym.ef), (ye.nf, ym.nf), (ye.gf, ym.gf)):
+            assert torch.equal(a, b)
+    # eager mode through the same entry point, and a mismatching chain is refused
+    model.flags = 0x8  # GNX_FLAG_NO_GRAPH
+    ym = model(x1)
+    assert torch.equal(ym.ef, eager(x1).ef)
+    with pytest.raises(Exception, match="widths"):
+        gn.Model([enc, dec, enc], x1)
+
+    def best_of(fn, reps=5, n=50):
+        best = float("inf")
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = __import__("time").perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            best = min(best, (__import__("time").perf_counter() - t0) / n)
+        return best
+    model.flags = 0
+    model(x1)
+    t_eager, t_model = best_of(lambda: eager(x1)), best_of(lambda: model(x1))
+    print(f"README ex.3 model, 4k-edge graph: eager {t_eager * 1e6:.0f} us / forward, gnx_model replay {t_model * 1e6:.0f} us")
+    assert t_model < t_eager
