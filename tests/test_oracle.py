@@ -236,3 +236,36 @@ def test_c_port_core_matches_float64_oracle():
         got = c_port.core_forward(p, csc, ef, nf, gf)
         for g_, r_ in zip(got, ref):
             np.testing.assert_allclose(g_, r_, rtol=2e-4, atol=2e-4)  # LayerNorm amplifies fp32 rounding by 1/sigma
+
+
+def test_three_independent_restatements_agree():
+    """Absolute numerics cannot be pinned to the reference (Julia, no golden values): what CAN be checked on the CPU is
+    that three restatements written independently of each other agree to float64 rounding — the literal one-hot
+    batched-matmul form (oracle i), the sparse CSC form (oracle ii) and a torch index_select / index_add form (the one
+    the backward tests differentiate) — on a heterogeneous batch with every activation."""
+    import torch
+    from tests.test_gpu_backward import _torch_block
+    rng = np.random.default_rng(77)
+    adjs = [(rng.random((n, n)) < 0.4).astype(np.int64) for n in (1, 4, 7, 3)]
+    din, dout = (5, 3, 2), (4, 6, 3)
+    for act in [(0, 0, 0), (1, 2, 3), (4, 1, 2)]:
+        p = O.make_block_params(rng, din, dout, act=act)
+        ef = [rng.random((din[0], int(a.sum())), dtype=np.float32) for a in adjs]
+        nf = [rng.random((din[1], a.shape[0]), dtype=np.float32) for a in adjs]
+        gf = [rng.random(din[2], dtype=np.float32) for _ in adjs]
+        dense = O.unbatch_dense(O.block_forward_dense(p, O.batch_dense(adjs, ef, nf, gf)))
+        csc = O.csc_from_adj(adjs)
+        pk = lambda parts: np.concatenate([np.atleast_2d(q.T) if q.ndim == 2 else q[None, :] for q in parts], axis=0)[None]
+        sp = O.block_forward_sparse(p, csc, pk(ef), pk(nf), pk(gf))
+        if act[0] != 4 and act[1] != 4 and act[2] != 4:  # the torch form has no gelu
+            W = {k: torch.tensor(p[k], dtype=torch.float64) for k in ("We", "be", "Wn", "bn", "Wg", "bg")}
+            t = lambda a: torch.tensor(a[0], dtype=torch.float64)
+            th = _torch_block(p, csc, t(pk(ef)), t(pk(nf)), t(pk(gf)), W)
+            for a, b in zip(th, sp):
+                np.testing.assert_allclose(a.numpy(), b[0], rtol=1e-12, atol=1e-12)
+        off_n = np.concatenate([[0], np.cumsum([a.shape[0] for a in adjs])])
+        off_e = np.concatenate([[0], np.cumsum([int(a.sum()) for a in adjs])])
+        for i in range(len(adjs)):
+            np.testing.assert_allclose(dense["ef"][i].T, sp[0][0, off_e[i]:off_e[i + 1]], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(dense["nf"][i].T, sp[1][0, off_n[i]:off_n[i + 1]], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(dense["gf"][i], sp[2][0, i], rtol=1e-12, atol=1e-12)
