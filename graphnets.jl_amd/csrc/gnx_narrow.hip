@@ -8,7 +8,7 @@
 // edge->node sum (nodefninput.jl:3) needs no atomics, and its order is fixed.
 //
 // Widths are template parameters (fully unrolled FMAs, weights as scalar operands).  launch_block_narrow() first
-// looks the width set up in the ahead-of-time list below; any other width set with every width <= 16 is specialised
+// looks the width set up in the ahead-of-time list below; any other width set with every width <= 32 (and <= 1024 weights) is specialised
 // at run time (gnx_jit.cpp: hiprtc on the same header text) — the analogue of Julia compiling a GNBlock for its own
 // dims on first use.  1 ("not applicable") sends the caller on to the MFMA / generic kernels.
 #include <cstdlib>

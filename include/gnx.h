@@ -283,7 +283,7 @@ GNX_API int32_t gnx_model_forward(gnx_model* m, const float* ef, const float* nf
 
 /* ---- run-time specialisation (the analogue of Julia compiling a GNBlock for its own widths on first use) -----------
  * The fused one-launch kernel is compiled ahead of time for the README / benchmark width sets; for any other width set
- * with every width <= 16 it is compiled at run time with hiprtc (gfx950), once per process and device, the first time
+ * with every width <= 32 (and at most 1024 weights in the edge and node functions) it is compiled at run time with hiprtc (gfx950), once per process and device, the first time
  * gnx_block_workspace_bytes / gnx_block_forward sees the width set (never while the stream is being captured: such a
  * call runs the generic kernels).  GNX_JIT=0 disables it; GNX_JIT_CACHE=<dir> keeps the code objects on disk.
  * If hiprtc is unavailable the generic HIP kernels run instead.

@@ -78,7 +78,8 @@ def test_runtime_specialised_kernel_source_compiles_for_gfx950(lib):
     n = C.c_size_t(0)
     assert lib.gnx_jit_precompile(C.byref(L.BlockParams(7, 3, 2, 5, 6, 1)), 128, C.byref(n)) == 0, lib.gnx_last_error()
     assert n.value > 4096
-    assert lib.gnx_jit_precompile(C.byref(L.BlockParams(40, 3, 2, 5, 6, 1)), 128, C.byref(n)) == -6   # GNX_ERR_DIMS: too wide
+    assert lib.gnx_jit_precompile(C.byref(L.BlockParams(40, 3, 2, 5, 6, 1)), 128, C.byref(n)) == -6   # GNX_ERR_DIMS: too wide (> 32)
+    assert lib.gnx_jit_precompile(C.byref(L.BlockParams(24, 4, 0, 3, 4, 5)), 128, C.byref(n)) == 0    # mid widths are eligible
     assert lib.gnx_jit_precompile(C.byref(L.BlockParams(16, 16, 16, 16, 16, 16)), 128, C.byref(n)) == -6  # too many weights: MFMA path
     assert lib.gnx_jit_precompile(C.byref(L.BlockParams(7, 3, 2, 5, 6, 1)), 100, C.byref(n)) == -1
     st = (C.c_int64 * 4)()

@@ -9,7 +9,7 @@ from oracle import gn_oracle as O
 from tests import util as U
 
 pytestmark = pytest.mark.gpu
-WIDTHS = [0, 1, 2, 3, 5, 8, 12, 16, 20, 33, 40, 64]
+WIDTHS = [0, 1, 2, 3, 5, 8, 12, 16, 20, 24, 28, 32, 33, 40, 64]
 
 
 @pytest.fixture(scope="module")
@@ -48,7 +48,7 @@ def _dims(rng, core=False):
             return din, dout
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(60))
 def test_random_block(gn, seed):
     rng = np.random.default_rng(9000 + seed)
     g, R = _random_batch(rng, gn)
