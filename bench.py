@@ -239,7 +239,7 @@ def main():
             dt = float(t.item())
         return dt
 
-    for i in range(W):  # warm-up (also loads the code objects)
+    for i in range(max(W, 2)):  # warm-up (also loads the code objects: at least two eager steps before any capture, whatever W is)
         step(i)
     sync_all()
 
