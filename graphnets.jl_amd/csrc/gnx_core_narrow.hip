@@ -12,22 +12,6 @@ namespace gnx {
 
 namespace {
 
-// xhat = (x - mu) * rstd over the D registers of a row; eps_mode 0: 1/(sigma+eps) (Flux 0.14 normalise), 1: 1/sqrt(var+eps)
-template <int D>
-__device__ __forceinline__ void normalise(float (&x)[D], float eps, int eps_mode) {
-  float mu = 0.f;
-#pragma unroll
-  for (int k = 0; k < D; ++k) mu += x[k];
-  mu /= (float)D;
-  float var = 0.f;
-#pragma unroll
-  for (int k = 0; k < D; ++k) { x[k] -= mu; var = fmaf(x[k], x[k], var); }
-  var /= (float)D;
-  const float rstd = eps_mode == 0 ? 1.f / (sqrtf(var) + eps) : 1.f / sqrtf(var + eps);
-#pragma unroll
-  for (int k = 0; k < D; ++k) x[k] *= rstd;
-}
-
 }  // namespace
 
 template <int D>

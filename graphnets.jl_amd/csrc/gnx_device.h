@@ -40,6 +40,12 @@ struct BlockArgs {
   const int* wtile_off;
   const Tile* wtiles;
   int N, E, G, n_tiles, n_wtiles;
+  // optional LayerNorm applied to the inputs as they are loaded (GNCore: block(gn1(x)) without materialising gn1(x)); fused
+  // narrow path only.  ln_g[t] == nullptr <=> off.  t = 0 edges, 1 nodes, 2 graphs.
+  const float* ln_g[3];
+  const float* ln_b[3];
+  float ln_eps;
+  int ln_mode;
 };
 
 // activation codes = GNX_ACT_* of include/gnx.h (static_assert'ed in gnx_forward.hip)

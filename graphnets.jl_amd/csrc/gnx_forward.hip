@@ -26,6 +26,7 @@ int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, 
 // phase bit 1: edge + node update (leaves per-tile partial sums in the workspace); bit 2: graph update from them
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase);
 void warm_block_narrow(const gnx_graphs* h, const gnx_block_params* p);
+bool block_narrow_ready(const gnx_graphs* h, const BlockArgs& a, hipStream_t s);
 static_assert(GNX_ACT_IDENTITY == 0 && GNX_ACT_RELU == 1 && GNX_ACT_TANH == 2 && GNX_ACT_SIGMOID == 3 && GNX_ACT_GELU == 4,
               "act_apply (gnx_device.h) hard-codes the activation codes");
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase);
@@ -75,9 +76,12 @@ static BlockWs block_ws(const gnx_graphs* h, const gnx_block_params* p, int64_t 
   return w;
 }
 
+// ln1 (optional, 3 entries): LayerNorm applied to the inputs on load — only together with *fused_ln: the caller passes a bool
+// that is set when the fused narrow kernel took the call; otherwise nothing was launched and the caller must normalise itself.
 static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf,
                                   const float* gf, int64_t R, float* ef_out, float* nf_out, float* gf_out, void* ws,
-                                  size_t ws_bytes, uint32_t flags, hipStream_t s, int phase = 3) {
+                                  size_t ws_bytes, uint32_t flags, hipStream_t s, int phase = 3, const gnx_layernorm* ln1 = nullptr,
+                                  float ln_eps = 0.f, int ln_mode = 0, bool* fused_ln = nullptr) {
   int32_t rc = check_block(h, p, R);
   if (rc) return rc;
   if (phase & 1) {
@@ -94,7 +98,7 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   if (!ws || ws_bytes < w.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_block_workspace_bytes()");
   if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");
 
-  BlockArgs a;
+  BlockArgs a{};
   a.de = p->de; a.dn = p->dn; a.dg = p->dg;
   a.oe = p->oe; a.on = p->on; a.og = p->og;
   a.We = p->edgefn.weight; a.be = p->edgefn.bias; a.act_e = p->edgefn.act;
@@ -109,6 +113,15 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   a.wtile_off = h->d_wtile_off; a.wtiles = h->d_wtiles; a.n_wtiles = (int)h->n_wtiles();
   a.N = (int)h->N; a.E = (int)h->E; a.G = (int)h->G; a.n_tiles = (int)h->n_tiles();
 
+  if (ln1) {
+    *fused_ln = false;
+    if (flags & GNX_FLAG_FORCE_GENERIC) return GNX_OK;
+    for (int t = 0; t < 3; ++t) { a.ln_g[t] = ln1[t].gamma; a.ln_b[t] = ln1[t].beta; }
+    a.ln_eps = ln_eps; a.ln_mode = ln_mode;
+    if (!block_narrow_ready(h, a, s)) return GNX_OK;  // nothing launched: the caller runs gn1 as its own kernels
+    *fused_ln = true;
+    return launch_block_narrow(h, a, R, s, phase);
+  }
   if (!(flags & GNX_FLAG_FORCE_GENERIC)) {
     rc = launch_block_narrow(h, a, R, s, phase);  // fused wave-per-tile kernel: ahead-of-time width sets, else specialised at run time
     if (rc != 1) return rc;
@@ -212,14 +225,26 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   for (int t = 0; t < 3; ++t) {
     l1[t] = reinterpret_cast<float*>(base + off[2 * t]);
     l2[t] = reinterpret_cast<float*>(base + off[2 * t + 1]);
-    // narrow widths: only gn1(x) is materialised (the block needs it); gn2 is recomputed inside k_core_post
-    const bool narrow = core_narrow_width(d[t]) && !(flags & GNX_FLAG_FORCE_GENERIC);
-    if (narrow) rc = launch_ln1_rows(x[t], rows[t], d[t], p->ln1[t], p->eps, p->eps_mode, l1[t], s);
-    else rc = launch_layernorm2(x[t], rows[t], d[t], p->ln1[t], p->ln2[t], p->eps, p->eps_mode, l1[t], l2[t], s);
+  }
+  // All three widths narrow: the fused block kernel normalises its inputs as it loads them (gn1 never materialised) when it
+  // is available for this width set; gn2 is recomputed inside k_core_post either way.
+  bool fused_ln = false;
+  const bool all_narrow = core_narrow_width(d[0]) && core_narrow_width(d[1]) && core_narrow_width(d[2]) && !(flags & GNX_FLAG_FORCE_GENERIC);
+  if (all_narrow) {
+    rc = block_forward_impl(h, &b, ef, nf, gf, R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, 3, p->ln1, p->eps, p->eps_mode, &fused_ln);
     if (rc) return rc;
   }
-  rc = block_forward_impl(h, &b, l1[0], l1[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s);
-  if (rc) return rc;
+  if (!fused_ln) {
+    for (int t = 0; t < 3; ++t) {
+      // narrow widths: only gn1(x) is materialised (the block needs it); gn2 is recomputed inside k_core_post
+      const bool narrow = core_narrow_width(d[t]) && !(flags & GNX_FLAG_FORCE_GENERIC);
+      if (narrow) rc = launch_ln1_rows(x[t], rows[t], d[t], p->ln1[t], p->eps, p->eps_mode, l1[t], s);
+      else rc = launch_layernorm2(x[t], rows[t], d[t], p->ln1[t], p->ln2[t], p->eps, p->eps_mode, l1[t], l2[t], s);
+      if (rc) return rc;
+    }
+    rc = block_forward_impl(h, &b, l1[0], l1[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s);
+    if (rc) return rc;
+  }
   float* hidden = reinterpret_cast<float*>(base + off[6]);
   for (int t = 0; t < 3; ++t) {
     if (ffn_on_mfma(d[t]) && !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA))) {

@@ -18,14 +18,14 @@
 
 namespace gnx {
 
-template <int DE, int DN, int DG, int OE, int ON, int EPT>
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false>
 static int32_t launch_wave_t(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   constexpr int C = OE + ON;
   const int prow_stride = (int)((h->n_wtiles() + 3) / 4 * 4 + 4);
   const unsigned grid = (unsigned)((a.n_wtiles + 3) / 4);
   if (phase & 1) {
     ProfScope ps("k_block_wave", s);
-    hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, prow_stride);
+    hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, LN>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, prow_stride);
     GNX_HIP(hipGetLastError());
   }
   if ((phase & 2) && a.og > 0) {
@@ -107,8 +107,40 @@ void warm_block_narrow(const gnx_graphs* h, const gnx_block_params* p) {
   (void)jit_get(a, h->wtile_e_cap / 64, nullptr, &fb, &fg);
 }
 
+static bool wants_ln(const BlockArgs& a) { return a.ln_g[0] || a.ln_g[1] || a.ln_g[2]; }
+
+// LayerNorm-on-load variant (GNCore: block(gn1(x)) straight from x): ahead of time for the README ex.3 core widths at the
+// default wave-tile size, any other eligible width set through the run-time specialiser.
+static bool ln_aot(const gnx_graphs* h, const BlockArgs& a) {
+  return a.de == 10 && a.dn == 5 && a.dg == 3 && a.oe == 10 && a.on == 5 && h->wtile_e_cap == 128;
+}
+
+// Can the fused kernel run this width set (with LayerNorm on load if a.ln_g is set) right now?  Compiles the run-time
+// specialised kernel if needed — except while `s` is being captured.  The GNCore forward asks before it decides to skip the
+// separate gn1 kernels.
+bool block_narrow_ready(const gnx_graphs* h, const BlockArgs& a, hipStream_t s) {
+  if (a.n_wtiles == 0 || a.E == 0) return false;
+  if (wants_ln(a)) {
+    if (ln_aot(h, a)) return true;
+  } else {
+#define GNX_CASE(DE, DN, DG, OE, ON) \
+    if (a.de == DE && a.dn == DN && a.dg == DG && a.oe == OE && a.on == ON) return h->wtile_e_cap == 64 || h->wtile_e_cap == 128 || h->wtile_e_cap == 256;
+    GNX_NARROW_DIMS(GNX_CASE)
+#undef GNX_CASE
+  }
+  const int ept = h->wtile_e_cap / 64;
+  if (ept * 64 != h->wtile_e_cap || (ept != 1 && ept != 2 && ept != 4)) return false;
+  hipFunction_t fb, fg;
+  return jit_get(a, ept, s, &fb, &fg) == GNX_OK;
+}
+
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   if (a.n_wtiles == 0 || a.E == 0) return 1;
+  if (wants_ln(a)) {  // only reached after block_narrow_ready(): a miss here would silently drop the LayerNorm
+    if (ln_aot(h, a)) return launch_wave_t<10, 5, 3, 10, 5, 2, true>(h, a, R, s, phase);
+    const int32_t rc = launch_wave_jit(h, a, R, s, phase);
+    return rc == 1 ? fail(GNX_ERR_INVALID_ARG, "internal: LayerNorm-on-load requested but the fused kernel is not available") : rc;
+  }
   static const bool jit_all = getenv("GNX_JIT_ALL") != nullptr;  // testing: run-time specialise even the listed width sets
   if (jit_all && launch_wave_jit(h, a, R, s, phase) == GNX_OK) return GNX_OK;
   // 16-B vector copies assume fp32-aligned buffers (always true for fp32 arrays); nothing else is required

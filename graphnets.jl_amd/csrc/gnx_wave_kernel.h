@@ -122,6 +122,32 @@ __device__ __forceinline__ void fma_rows(cfloatp W, const float (&x)[M][KX], flo
   }
 }
 
+// xhat = (x - mu) * rstd over the D registers of a row; eps_mode 0: 1/(sigma+eps) (Flux 0.14 normalise), 1: 1/sqrt(var+eps)
+template <int D>
+__device__ __forceinline__ void normalise(float (&x)[D], float eps, int eps_mode) {
+  float mu = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) mu += x[k];
+  mu /= (float)D;
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < D; ++k) { x[k] -= mu; var = fmaf(x[k], x[k], var); }
+  var /= (float)D;
+  const float rstd = eps_mode == 0 ? 1.f / (sqrtf(var) + eps) : 1.f / sqrtf(var + eps);
+#pragma unroll
+  for (int k = 0; k < D; ++k) x[k] *= rstd;
+}
+// LayerNorm of a register row with scalar-operand affine parameters (gngraphnorm.jl:19-26)
+template <int D>
+__device__ __forceinline__ void ln_row(float (&x)[D > 0 ? D : 1], const float* g, const float* b, float eps, int eps_mode) {
+  if constexpr (D > 0) {
+    normalise<D>(x, eps, eps_mode);
+    const cfloatp gc = as_const(g), bc = as_const(b);
+#pragma unroll
+    for (int k = 0; k < D; ++k) x[k] = fmaf(gc[k], x[k], bc[k]);
+  }
+}
+
 // XCD-aware block -> tile map: blocks b and b+8 share an XCD (and its L2), so give every XCD one contiguous
 // chunk of tiles; tiles of one graph (which share the graph's node rows) then meet in one L2.  Bijective for any nt.
 __device__ __forceinline__ int xcd_tile(int b, int nt) {
@@ -164,7 +190,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 //   lanes as NODES : lane n < nn — colptr, own nf row, pd[n] = b + We[:,dst]*nf[n] (+ gf fold), segmented sum of
 //                    ef' from LDS, node update, store
 // =========================================================================================================
-template <int DE, int DN, int DG, int OE, int ON, int EPT>
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false>  // LN: LayerNorm the inputs on load (BlockArgs::ln_*)
 __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_stride) {
   constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1, DG1 = DG > 0 ? DG : 1;
   constexpr int TEW = 64 * EPT;
@@ -223,6 +249,10 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
   float gfr[1][DG1];
 #pragma unroll
   for (int k = 0; k < DG; ++k) gfr[0][k] = gf[k];
+  if constexpr (LN) {  // gn1(x) applied in registers: rows are normalised as they arrive (gathered rows once per edge)
+    ln_row<DN>(xn[0], a.ln_g[1], a.ln_b[1], a.ln_eps, a.ln_mode);
+    ln_row<DG>(gfr[0], a.ln_g[2], a.ln_b[2], a.ln_eps, a.ln_mode);
+  }  // (the edge rows and the gathered rows are normalised at the start of the edge phase: their loads are still in flight)
   // ---- lanes as nodes: destination index of each in-edge, per-node part of the edge update ----
   //   pd[n] = be + We[:, gf-seg] * gf[g] + We[:, dst-seg] * nf[n]      (edgefninput.jl:5-6 hoisted out of the edge loop)
   if (is_node) {
@@ -256,6 +286,19 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
         if constexpr (DN > 0) {
           src[i] = a.rowval[e];
           load_row<DN>(nf + (size_t)src[i] * DN, xs[i]);
+        }
+        if constexpr (LN) {
+          ln_row<DE>(x[i], a.ln_g[0], a.ln_b[0], a.ln_eps, a.ln_mode);
+          ln_row<DN>(xs[i], a.ln_g[1], a.ln_b[1], a.ln_eps, a.ln_mode);
+        }
+      }
+    }
+    if constexpr (LN) {
+      if (c0 == 0) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+          ln_row<DE>(x[i], a.ln_g[0], a.ln_b[0], a.ln_eps, a.ln_mode);
+          ln_row<DN>(xs[i], a.ln_g[1], a.ln_b[1], a.ln_eps, a.ln_mode);
         }
       }
     }
@@ -442,8 +485,20 @@ __global__ void k_graph_t(BlockArgs a, int prow_stride) {
     if (idx < nw + og) s_w[idx] = w_reg[i];
   }
   for (int idx = tid + 4 * nthr; idx < nw + og; idx += nthr) s_w[idx] = idx < nw ? a.Wg[idx] : (a.bg ? a.bg[idx - nw] : 0.f);
-  if (tid < a.dg) s_x[C + tid] = gf_reg;
-  for (int k = tid + nthr; k < a.dg; k += nthr) s_x[C + k] = a.gf[(r * (size_t)a.G + g) * a.dg + k];
+  if (a.ln_g[2] && a.dg > 0) {  // GNCore: the graph function sees gn1(gf); a few values, every thread computes the statistics
+    const float* gp = a.gf + (r * (size_t)a.G + g) * a.dg;
+    float mu = 0.f;
+    for (int k = 0; k < a.dg; ++k) mu += gp[k];
+    mu /= (float)a.dg;
+    float var = 0.f;
+    for (int k = 0; k < a.dg; ++k) { const float c = gp[k] - mu; var = fmaf(c, c, var); }
+    var /= (float)a.dg;
+    const float rstd = a.ln_mode == 0 ? 1.f / (sqrtf(var) + a.ln_eps) : 1.f / sqrtf(var + a.ln_eps);
+    for (int k = tid; k < a.dg; k += nthr) s_x[C + k] = fmaf(a.ln_g[2][k], (gp[k] - mu) * rstd, a.ln_b[2][k]);
+  } else {
+    if (tid < a.dg) s_x[C + tid] = gf_reg;
+    for (int k = tid + nthr; k < a.dg; k += nthr) s_x[C + k] = a.gf[(r * (size_t)a.G + g) * a.dg + k];
+  }
   const int lane = tid & 63, row16 = tid >> 4;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
