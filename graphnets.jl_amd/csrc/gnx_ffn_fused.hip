@@ -1,0 +1,234 @@
+// Fused position-wise FeedForward of a GNCore on the fp32 matrix cores (gnfeedforward.jl:27-40, gncore.jl:56-68):
+//
+//     out[m, :] = add1[m, :] + add2[m, :] + b2 + W2^T act1(W1^T z[m, :] + b1)          z = gn2(x), add1 = block output, add2 = x
+//
+// The two-GEMM form writes the (rows x 4D) hidden activations to HBM and reads them back (2 x 2 GB per core at C4's edge
+// width) and its epilogues — 35-45 % of a tile's lifetime by the shader-clock stamps — are bursts of exactly that traffic.
+// Here a workgroup keeps a 128-row tile for the whole FeedForward: the hidden layer is produced 64 units at a time on the
+// matrix cores, activated, parked in LDS in A-operand layout and immediately consumed by the second GEMM, whose 128 x D
+// accumulator lives in registers across all 4D/64 slices.  HBM sees z once (re-streamed per slice from L2), the residuals
+// and the output once, and nothing of the hidden layer.
+//   per slice: GEMM1 (K = D, in 32-wide chunks: z chunk + W1 chunk through LDS) -> bias, activation -> sH[128][65]
+//              GEMM2 (K = 64, two chunks: A = sH, W2 chunk through LDS) -> accO
+// 512 threads = 8 waves as 4 (row blocks) x 2 (column halves); v_mfma_f32_32x32x2_f32 (exact fp32); 58 KB of LDS -> 2 workgroups
+// (16 waves) per CU.
+#include <algorithm>
+#include <type_traits>
+
+#include "gnx_device.h"
+
+namespace gnx {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // staging registers: a first-class vector (HIP's float4 struct copies as memcpy
+                                                            // and the arrays of it ended up in LDS / scratch here)
+
+namespace {
+constexpr int FBM = 128;   // rows per workgroup
+constexpr int FHS = 64;    // hidden units per slice
+constexpr int FKC = 32;    // K chunk
+// compile-time loop: the step index must be a constant inside the body (register arrays stay registers, branches fold)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+__device__ __forceinline__ void lds_barrier_f() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+}  // namespace
+
+struct FfnArgs {
+  const Tile* tiles;
+  int row_kind;            // 0: rows = edges of the tile, 1: rows = nodes / graphs (n0, n1)
+  const float* z;          // [R][rows][D]  gn2(x)
+  const float* W1;         // (4D x D) column-major == [D][4D] row-major
+  const float* b1;         // [4D] or nullptr
+  const float* W2;         // (D x 4D) column-major == [4D][D] row-major
+  const float* b2;         // [D] or nullptr
+  const float* add1;       // [R][rows][D] or nullptr
+  const float* add2;
+  float* out;              // [R][rows][D]
+  size_t rep_stride;       // rows_total * D
+  int act1;
+};
+
+template <int D>
+__global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
+  constexpr int H = 4 * D;
+  constexpr int LDA = FKC + 1;                 // z chunk row stride (odd: conflict-free A fragments)
+  constexpr int LDH = FHS + 1;                 // hidden slice row stride
+  constexpr int TNO = D / 64;                  // 32-column output blocks per wave (wave = 64 rows x D/2 columns)
+  constexpr int NC1 = D / FKC;                 // chunks of GEMM1
+  constexpr int NT = 512;
+  constexpr int NB1 = (FKC * FHS / 4) / NT;    // float4 of a W1 chunk [32][64] per thread (= 1)
+  constexpr int NB2 = (FKC * D / 4) / NT;      // float4 of a W2 chunk [32][D] per thread (= D/64)
+  constexpr int POOLF = FBM * LDA + FKC * FHS; // sA [128][33] + W1 chunk [32][64]; the W2 chunk [32][D] of GEMM2 reuses the sA region
+  static_assert(FKC * D <= FBM * LDA, "the W2 chunk must fit in the z-chunk region");
+  __shared__ __attribute__((aligned(16))) float s_pool[POOLF + FBM * LDH];  // 58 KB -> two workgroups per CU
+  float* sA = s_pool;                 // [128][33]   z chunk (GEMM1)
+  float* sB1 = s_pool + FBM * LDA;    // [32][64]    W1 chunk (GEMM1)
+  float* sB2 = s_pool;                // [32][D]     W2 chunk (GEMM2; sA is idle then)
+  float* sH = s_pool + POOLF;         // [128][65]   activated hidden slice
+  float* sC = s_pool;                 // epilogue staging [64][D + 4]
+  static_assert(64 * (D + 4) <= POOLF + FBM * LDH, "epilogue staging must fit");
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;  // wm 0..3: rows 32*wm.., wn: column half
+  const int hi = lane >> 5, l31 = lane & 31;
+  const Tile t = a.tiles[blockIdx.x];
+  const size_t r = blockIdx.y;
+  const int row0 = a.row_kind == 0 ? t.e0 : t.n0;
+  const int rows = (a.row_kind == 0 ? t.e1 : t.n1) - row0;
+  const float* __restrict__ zb = a.z + r * a.rep_stride + (size_t)row0 * D;
+
+  f32x16 accO[TNO];
+#pragma unroll
+  for (int j = 0; j < TNO; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accO[j][q] = 0.f;
+
+  // register staging of the next chunk (global -> registers during the MFMAs of the current one -> LDS)
+  f32x4 ra[2];        // z chunk: 128 rows x 8 float4 = 1024 float4 -> 2 per thread
+  f32x4 rb1[NB1], rb2[NB2];  // W1 chunk / W2 chunk (separate arrays: a shared one is demoted to LDS by the compiler)
+  const int a_c4 = tid & 7, a_r = tid >> 3;  // z chunk: thread -> (row a_r + 64 i, float4 a_c4)
+
+  // chunk schedule of one slice: 0 .. NC1-1 = GEMM1 chunks, NC1, NC1+1 = GEMM2 chunks
+  constexpr int NSTEP = NC1 + 2;
+  auto load_step = [&](int hs, int st) {
+    if (st < NC1) {
+      const int kc = st * FKC;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = a_r + 64 * i;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        ra[i] = row < rows ? *reinterpret_cast<const f32x4*>(zb + (size_t)row * D + kc + 4 * a_c4) : zero;
+      }
+#pragma unroll
+      for (int i = 0; i < NB1; ++i) {  // W1[(kc + kk) * H + hs*64 + 4*c4], chunk [32][64]: 16 float4 per row
+        const int q = tid + NT * i, kk = q >> 4, c4 = q & 15;
+        rb1[i] = *reinterpret_cast<const f32x4*>(a.W1 + (size_t)(kc + kk) * H + hs * FHS + 4 * c4);
+      }
+    } else {
+      const int k0 = hs * FHS + (st - NC1) * FKC;  // rows of W2
+#pragma unroll
+      for (int i = 0; i < NB2; ++i) {  // chunk [32][D]: D/4 float4 per row
+        const int q = tid + NT * i, kk = q / (D / 4), c4 = q % (D / 4);
+        rb2[i] = *reinterpret_cast<const f32x4*>(a.W2 + (size_t)(k0 + kk) * D + 4 * c4);
+      }
+    }
+  };
+  auto store_step = [&](int st) {
+    if (st < NC1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float* d = sA + (a_r + 64 * i) * LDA + 4 * a_c4;
+        d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+      }
+#pragma unroll
+      for (int i = 0; i < NB1; ++i) *reinterpret_cast<f32x4*>(sB1 + 4 * (tid + NT * i)) = rb1[i];  // [kk][64]
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB2; ++i) *reinterpret_cast<f32x4*>(sB2 + 4 * (tid + NT * i)) = rb2[i];  // [kk][D]
+    }
+  };
+
+  load_step(0, 0);
+  for (int hs = 0; hs < H / FHS; ++hs) {
+    f32x16 accH;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accH[q] = 0.f;
+    for (int st = 0; st < NSTEP; ++st) {
+      __syncthreads();  // readers of the previous chunk are done (and, at st == NC1, sH has been written by everyone)
+      store_step(st);
+      __syncthreads();
+      // prefetch the next step (possibly the first chunk of the next slice)
+      if (st + 1 < NSTEP) load_step(hs, st + 1);
+      else if (hs + 1 < H / FHS) load_step(hs + 1, 0);
+      if (st < NC1) {
+        // GEMM1: accH[32 x 32 per wave] += z chunk * W1 chunk     (wave rows 32*wm.., hidden columns 32*wn..)
+#pragma unroll
+        for (int kk = 0; kk < FKC / 2; ++kk) {
+          const float fb = sB1[(2 * kk + hi) * FHS + wn * 32 + l31];
+          const float fa = sA[(wm * 32 + l31) * LDA + 2 * kk + hi];
+          accH = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, accH, 0, 0, 0);
+        }
+        if (st == NC1 - 1) {
+          // hidden slice: bias + activation, parked in LDS as the A operand of GEMM2 (C/D layout: row = (q&3)+8(q>>2)+4hi)
+          const int hcol = wn * 32 + l31;
+          const float b = a.b1 ? a.b1[hs * FHS + hcol] : 0.f;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) sH[(wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi) * LDH + hcol] = act_apply(accH[q] + b, a.act1);
+        }
+      } else {
+        // GEMM2: accO[64 x D/2 per wave] += sH[:, 32-wide k range] * W2 chunk
+        const int kb = (st - NC1) * FKC;
+#pragma unroll
+        for (int kk = 0; kk < FKC / 2; ++kk) {
+          float fb[TNO];
+          const float fa = sH[(wm * 32 + l31) * LDH + kb + 2 * kk + hi];
+#pragma unroll
+          for (int j = 0; j < TNO; ++j) fb[j] = sB2[(2 * kk + hi) * D + (wn * TNO + j) * 32 + l31];
+#pragma unroll
+          for (int j = 0; j < TNO; ++j) accO[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb[j], accO[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: two 64-row passes through LDS -> full-row 16-B stores with bias and the two residuals ----
+  constexpr int LDC = D + 4;
+  constexpr int NC4 = (64 * D / 4) / NT;
+  float* out = a.out + r * a.rep_stride;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    lds_barrier_f();
+    if ((wm >> 1) == pass) {
+#pragma unroll
+      for (int j = 0; j < TNO; ++j) {
+        const int col = (wn * TNO + j) * 32 + l31;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sC[((wm & 1) * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi) * LDC + col] = accO[j][q];
+      }
+    }
+    lds_barrier_f();
+#pragma unroll
+    for (int i = 0; i < NC4; ++i) {
+      const int idx = tid + NT * i;
+      const int lr = idx / (D / 4), c4 = idx % (D / 4);
+      const int row = 64 * pass + lr;
+      if (row < rows) {
+        float4 v = *reinterpret_cast<const float4*>(sC + lr * LDC + 4 * c4);
+        if (a.b2) { const float4 b = *reinterpret_cast<const float4*>(a.b2 + 4 * c4); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        const size_t o = (size_t)(row0 + row) * D + 4 * c4;
+        if (a.add1) { const float4 u = *reinterpret_cast<const float4*>(a.add1 + r * a.rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        if (a.add2) { const float4 u = *reinterpret_cast<const float4*>(a.add2 + r * a.rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        *reinterpret_cast<float4*>(out + o) = v;
+      }
+    }
+  }
+}
+
+// out = add1 + add2 + fc2(act1(fc1(z))) over all rows of one entity type.  1 = not applicable (the caller runs the two GEMMs).
+int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, float* out,
+                         int64_t R, hipStream_t s) {
+  static const bool off = getenv("GNX_NO_FFN_FUSED") != nullptr;
+  if (off || (d != 64 && d != 128) || ff.fc2.act != GNX_ACT_IDENTITY) return 1;
+  const size_t nrows = entity == 0 ? (size_t)h->E : (entity == 1 ? (size_t)h->N : (size_t)h->G);
+  if (nrows == 0) return GNX_OK;
+  const uintptr_t al = (uintptr_t)z | (uintptr_t)ff.fc1.weight | (uintptr_t)ff.fc2.weight | (uintptr_t)ff.fc2.bias | (uintptr_t)add1 | (uintptr_t)add2 | (uintptr_t)out;
+  if (al & 15) return 1;
+  FfnArgs a{};
+  a.tiles = entity == 0 ? h->d_etiles : (entity == 1 ? h->d_ntiles : h->d_gtiles);
+  a.row_kind = entity == 0 ? 0 : 1;
+  a.z = z; a.W1 = ff.fc1.weight; a.b1 = ff.fc1.bias; a.W2 = ff.fc2.weight; a.b2 = ff.fc2.bias;
+  a.add1 = add1; a.add2 = add2; a.out = out; a.rep_stride = nrows * (size_t)d; a.act1 = ff.fc1.act;
+  const unsigned n_tiles = (unsigned)(entity == 0 ? h->h_etiles.size() : (entity == 1 ? h->h_ntiles.size() : h->h_gtiles.size()));
+  if (!a.tiles || !z || !ff.fc1.weight || !ff.fc2.weight || !out) return fail(GNX_ERR_INVALID_ARG, "k_ffn_fused: NULL operand");
+  ProfScope ps("k_ffn_fused", s);
+  if (d == 128) hipLaunchKernelGGL((k_ffn_fused<128>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((k_ffn_fused<64>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+}  // namespace gnx

@@ -34,6 +34,8 @@ size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int6
 // narrow-width GNCore kernels (gnx_core_narrow.hip)
 bool core_narrow_width(int d);
 int32_t launch_ln1_rows(const float* x, size_t rows, int d, const gnx_layernorm& l1, float eps, int eps_mode, float* y, hipStream_t s);
+int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, float* out,
+                         int64_t R, hipStream_t s);
 int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm& l2, const gnx_ffn& ff, float eps, int eps_mode,
                          float* out, hipStream_t s);
 int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K, const gnx_dense& d, int OUT, const float* add1,
@@ -249,6 +251,9 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   for (int t = 0; t < 3; ++t) {
     if (ffn_on_mfma(d[t]) && !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA))) {
       // out = block(LN1 x) + x + fc2(relu(fc1(LN2 x)))      (gncore.jl:56-68, gnfeedforward.jl:27-31)
+      rc = launch_ffn_fused(h, t, l2[t], d[t], p->ff[t], out[t], x[t], out[t], R, s);  // hidden layer never leaves the chip (d = 64, 128)
+      if (rc == GNX_OK) continue;
+      if (rc != 1) return rc;
       if ((rc = launch_dense_rows(h, t, l2[t], d[t], p->ff[t].fc1, 4 * d[t], nullptr, nullptr, hidden, R, s, "k_rows_gemm_ff1"))) return rc;
       if ((rc = launch_dense_rows(h, t, hidden, 4 * d[t], p->ff[t].fc2, d[t], out[t], x[t], out[t], R, s, "k_rows_gemm_ff2"))) return rc;
     } else if (core_narrow_width(d[t]) && !(flags & GNX_FLAG_FORCE_GENERIC)) {
