@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgnx.so")
+LIB_PATH = os.environ.get("GNX_LIB_PATH") or os.path.join(_HERE, "libgnx.so")  # GNX_LIB_PATH: A/B runs of two builds in one session
 
 # status codes (include/gnx.h)
 GNX_OK = 0

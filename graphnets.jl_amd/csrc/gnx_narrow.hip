@@ -18,28 +18,33 @@
 
 namespace gnx {
 
-template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false>
-static int32_t launch_wave_t(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN, bool ONEG>
+static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   constexpr int C = OE + ON;
   const int prow_stride = (int)((h->n_wtiles() + 3) / 4 * 4 + 4);
   const unsigned grid = (unsigned)((a.n_wtiles + 3) / 4);
   if (phase & 1) {
     ProfScope ps("k_block_wave", s);
-    hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, LN>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, prow_stride);
+    hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, prow_stride);
     GNX_HIP(hipGetLastError());
   }
   if ((phase & 2) && a.og > 0) {
     if constexpr (C > 0) {
       // block size by the number of partial rows per graph: 1024 threads cover 4096 rows per pass
-      const int64_t rows_per_graph = (h->n_wtiles() + h->G - 1) / h->G;
+      const int64_t rows_per_graph = h->G == 1 ? (h->n_wtiles() + 3) / 4 : (h->n_wtiles() + h->G - 1) / h->G;  // G == 1: one row per workgroup
       const int threads = rows_per_graph > 1024 ? 1024 : (rows_per_graph > 128 ? 256 : 64);
       const size_t lds = sizeof(float) * ((size_t)(threads / 16) * C + (C + a.dg + 4) + (size_t)(C + a.dg + 1) * a.og + 8);
       ProfScope ps("k_graph_t", s);
-      hipLaunchKernelGGL((k_graph_t<C>), dim3((unsigned)a.G, (unsigned)R), dim3(threads), lds, s, a, prow_stride);
+      hipLaunchKernelGGL((k_graph_t<C, ONEG>), dim3((unsigned)a.G, (unsigned)R), dim3(threads), lds, s, a, prow_stride);
       GNX_HIP(hipGetLastError());
     }
   }
   return GNX_OK;
+}
+
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false>
+static int32_t launch_wave_t(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
+  return h->G == 1 ? launch_wave_g<DE, DN, DG, OE, ON, EPT, LN, true>(h, a, R, s, phase) : launch_wave_g<DE, DN, DG, OE, ON, EPT, LN, false>(h, a, R, s, phase);
 }
 
 template <int DE, int DN, int DG, int OE, int ON>
@@ -84,7 +89,7 @@ static int32_t launch_wave_jit(const gnx_graphs* h, const BlockArgs& a, int64_t 
     GNX_HIP(hipModuleLaunchKernel(fb, (unsigned)((a.n_wtiles + 3) / 4), (unsigned)R, 1, kThreads, 1, 1, 0, s, params, nullptr));
   }
   if ((phase & 2) && a.og > 0) {
-    const int64_t rows_per_graph = (h->n_wtiles() + h->G - 1) / h->G;
+    const int64_t rows_per_graph = h->G == 1 ? (h->n_wtiles() + 3) / 4 : (h->n_wtiles() + h->G - 1) / h->G;
     const int threads = rows_per_graph > 1024 ? 1024 : (rows_per_graph > 128 ? 256 : 64);
     const size_t lds = sizeof(float) * ((size_t)(threads / 16) * C + (C + a.dg + 4) + (size_t)(C + a.dg + 1) * a.og + 8);
     ProfScope ps("k_graph_t", s);
@@ -98,6 +103,7 @@ static int32_t launch_wave_jit(const gnx_graphs* h, const BlockArgs& a, int64_t 
 void warm_block_narrow(const gnx_graphs* h, const gnx_block_params* p) {
   BlockArgs a{};
   a.de = p->de; a.dn = p->dn; a.dg = p->dg; a.oe = p->oe; a.on = p->on; a.og = p->og;
+  a.G = (int)h->G;  // selects the one-graph / several-graphs variant of the kernel
 #define GNX_CASE(DE, DN, DG, OE, ON) \
   if (a.de == DE && a.dn == DN && a.dg == DG && a.oe == OE && a.on == ON) return;
   if (!getenv("GNX_JIT_ALL")) { GNX_NARROW_DIMS(GNX_CASE) }

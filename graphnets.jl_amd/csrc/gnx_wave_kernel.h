@@ -190,7 +190,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 //   lanes as NODES : lane n < nn — colptr, own nf row, pd[n] = b + We[:,dst]*nf[n] (+ gf fold), segmented sum of
 //                    ef' from LDS, node update, store
 // =========================================================================================================
-template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false>  // LN: LayerNorm the inputs on load (BlockArgs::ln_*)
+// LN: LayerNorm the inputs on load (BlockArgs::ln_*).  ONEG: the batch is ONE graph (see below)
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false>
 __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_stride) {
   constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1, DG1 = DG > 0 ? DG : 1;
   constexpr int TEW = 64 * EPT;
@@ -203,7 +204,15 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wt = __builtin_amdgcn_readfirstlane(xcd_tile(blockIdx.x, gridDim.x) * WAVES + wv);
-  if (wt >= a.n_wtiles) return;  // wave-uniform; the kernel has no workgroup barrier
+  // ONEG (one graph): the four waves of a workgroup all belong to it, so their graph-update partial sums are added in the
+  // workgroup (one barrier at the very end) and k_graph_t reads a quarter of the rows.  Several graphs: a workgroup may
+  // straddle two graphs, every wave stores its own row and the kernel has no workgroup barrier at all.  (A template
+  // parameter, not a run-time branch: the mere presence of the barrier path cost the multi-graph case 4 %.)
+  const bool active = wt < a.n_wtiles;  // wave-uniform
+  if constexpr (!ONEG) { if (!active) return; }
+  float mine = 0.f;  // lane c < C: this wave's total of graph-update column c
+  do {
+  if constexpr (ONEG) { if (!active) break; }
   float* s_out = s_out_all[wv];
   float* s_pd = s_pd_all[wv];
   unsigned char* s_dst = s_dst_all[wv];
@@ -407,13 +416,28 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
   //      Stored transposed [c][tile] so the graph kernel reads them with 16-B loads. ----
   if (a.og > 0) {
     if constexpr (C > 0) {
-      float mine = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const float tot = wave_sum(v[c]);
         mine = lane == c ? tot : mine;
       }
-      if (lane < C) a.partials[(r * C + lane) * (size_t)prow_stride + wt] = mine;
+    }
+  }
+  } while (0);
+  if (a.og > 0) {
+    if constexpr (C > 0) {
+      const size_t r = blockIdx.y;
+      if constexpr (ONEG) {
+        __shared__ float s_blk[WAVES][C1];
+        if (lane < C) s_blk[wv][lane] = mine;
+        __syncthreads();
+        if (wv == 0 && lane < C) {
+          const float tot = (s_blk[0][lane] + s_blk[1][lane]) + (s_blk[2][lane] + s_blk[3][lane]);
+          a.partials[(r * C + lane) * (size_t)prow_stride + xcd_tile(blockIdx.x, gridDim.x)] = tot;
+        }
+      } else {
+        if (lane < C) a.partials[(r * C + lane) * (size_t)prow_stride + wt] = mine;
+      }
     }
   }
 }
@@ -422,14 +446,15 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
 // [C][prow_stride].  Latency is everything here (a few KB of work): EVERY global load — this thread's partial quads,
 // its slice of Wg / bg / gf — is issued before the first wait, so the kernel pays one memory round trip; the sums
 // are reduced with DPP + one LDS hop in a fixed order.
-template <int C>
+template <int C, bool ONEG = false>
 __global__ void k_graph_t(BlockArgs a, int prow_stride) {
   extern __shared__ float s_g[];
   constexpr int MAXQ = 2;  // quads per thread kept in registers per pass
   const int g = blockIdx.x;
   const size_t r = blockIdx.y;
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int t0 = a.wtile_off[g], t1 = a.wtile_off[g + 1];
+  // one graph: k_block_wave stored one row per WORKGROUP (4 wave tiles); several graphs: one row per wave tile
+  const int t0 = ONEG ? 0 : a.wtile_off[g], t1 = ONEG ? (a.n_wtiles + 3) / 4 : a.wtile_off[g + 1];
   const float* __restrict__ base = a.partials + r * C * (size_t)prow_stride;
   const int K = C + a.dg, og = a.og;
   const int nrow16 = nthr >> 4;
