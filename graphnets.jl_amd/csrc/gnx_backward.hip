@@ -197,8 +197,19 @@ __global__ __launch_bounds__(256) void k_bw_dw_partial(const float* __restrict__
     float acc = 0.f;
     if (sl < nsl) {
       const int p = p0 + pl, k = p / J, j = p % J;
-      if (k < K) { for (size_t m = m0 + sl; m < m1; m += nsl) acc = fmaf(delta[m * J + j], X[m * K + k], acc); }
-      else { for (size_t m = m0 + sl; m < m1; m += nsl) acc += delta[m * J + j]; }
+      // 8 rows in flight per thread (clamped, unconditional loads: a load inside the guarded loop body costs one memory
+      // round trip per row)
+      for (size_t m = m0 + sl; m < m1; m += 8 * (size_t)nsl) {
+        float dv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const size_t mm = m + (size_t)u * nsl < m1 ? m + (size_t)u * nsl : m1 - 1;
+          dv[u] = delta[mm * J + j];
+          xv[u] = k < K ? X[mm * K + k] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = m + (size_t)u * nsl < m1 ? fmaf(dv[u], xv[u], acc) : acc;
+      }
     }
     s_red[tid] = sl < nsl ? acc : 0.f;
     __syncthreads();
@@ -247,6 +258,13 @@ __global__ void k_bw_dw_small(const float* __restrict__ delta, const float* __re
     for (int m = 0; m < rows; ++m) acc += delta[(size_t)m * J + j];
     if (db) db[j] = acc;
   }
+}
+
+// generic dX launch with a profiling scope
+static void launch_bw_dx(dim3 grid, hipStream_t s, const float* delta, const float* W, int rows, int J, int K, float* dX, int k0, int k1, float* direct,
+                         int direct_w) {
+  ProfScope ps("bw_dx_generic", s);
+  hipLaunchKernelGGL(k_bw_dx, grid, dim3(256), 0, s, delta, W, rows, J, K, dX, k0, k1, direct, direct_w);
 }
 
 struct BwLayout {
@@ -570,7 +588,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   if (have_g) {
     DeltaArgs a{g_gf_out, gf_out, dlt_g, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, og, G, G, acts[2], 0};
     hipLaunchKernelGGL(k_bw_delta, dim3(blocks((size_t)G * og).x, Ru), dim3(256), 0, s, a, (size_t)0, (size_t)0);
-    hipLaunchKernelGGL(k_bw_dx, dim3(blocks((size_t)G * Kg).x, Ru), dim3(256), 0, s, dlt_g, p->graphfn.weight, G, og, Kg, dXg, 0, 0, (float*)nullptr, 0);
+    launch_bw_dx(dim3(blocks((size_t)G * Kg).x, Ru), s, dlt_g, p->graphfn.weight, G, og, Kg, dXg, 0, 0, (float*)nullptr, 0);
     if ((rc = dw_reduce(dlt_g, Xg, (size_t)R * G, og, Kg, gr.graphfn, part, s))) return rc;
   }
   // node level
@@ -584,7 +602,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
       hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)(R * N));
       if ((rc = colsum_all(dlt_n, (size_t)R * N, on, gr.nodefn.bias, part, off2, s))) return rc;
     } else {
-      hipLaunchKernelGGL(k_bw_dx, dim3(blocks((size_t)N * Kn).x, Ru), dim3(256), 0, s, dlt_n, p->nodefn.weight, N, on, Kn, dXn, 0, 0, (float*)nullptr, 0);
+      launch_bw_dx(dim3(blocks((size_t)N * Kn).x, Ru), s, dlt_n, p->nodefn.weight, N, on, Kn, dXn, 0, 0, (float*)nullptr, 0);
       if ((rc = dw_reduce(dlt_n, Xn, (size_t)R * N, on, Kn, gr.nodefn, part, s))) return rc;
     }
   }
@@ -616,7 +634,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
         if (have_n && (rc = add_cols(dXn, Kn, oe, (size_t)R * N, dn, d_nf, 1, s))) return rc;
       }
       if (dg) {  // dXe_g[g][:] = S_g[g] We^T (G rows: generic), its gf columns are the edges' share of d_gf
-        hipLaunchKernelGGL(k_bw_dx, dim3(blocks((size_t)G * Ke).x, Ru), dim3(256), 0, s, S_g, p->edgefn.weight, G, oe, Ke, dXe, 0, 0, (float*)nullptr, 0);
+        launch_bw_dx(dim3(blocks((size_t)G * Ke).x, Ru), s, S_g, p->edgefn.weight, G, oe, Ke, dXe, 0, 0, (float*)nullptr, 0);
       }
       if (gr.edgefn.weight) {
         float* dW = gr.edgefn.weight;
@@ -633,7 +651,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
       hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)(R * E));
       if ((rc = colsum_all(dlt_e, (size_t)R * E, oe, gr.edgefn.bias, part, off2, s))) return rc;
     } else {
-      hipLaunchKernelGGL(k_bw_dx, dim3(blocks((size_t)E * Ke).x, Ru), dim3(256), 0, s, dlt_e, p->edgefn.weight, E, oe, Ke, dXe, 0, de, d_ef, de);
+      launch_bw_dx(dim3(blocks((size_t)E * Ke).x, Ru), s, dlt_e, p->edgefn.weight, E, oe, Ke, dXe, 0, de, d_ef, de);
       if ((rc = dw_reduce(dlt_e, Xe, (size_t)R * E, oe, Ke, gr.edgefn, part, s))) return rc;
     }
   } else {
@@ -776,13 +794,14 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
       GNX_HIP(hipGetLastError());
       continue;
     }
-    hipLaunchKernelGGL(k_fw_dense, blocks(rows[t] * H), dim3(256), 0, s, F(L.l2[t]), p->ff[t].fc1.weight, p->ff[t].fc1.bias, rows[t], D, H, p->ff[t].fc1.act, hbuf);
+    { ProfScope ps("bw_fw_dense_generic", s);
+    hipLaunchKernelGGL(k_fw_dense, blocks(rows[t] * H), dim3(256), 0, s, F(L.l2[t]), p->ff[t].fc1.weight, p->ff[t].fc1.bias, rows[t], D, H, p->ff[t].fc1.act, hbuf); }
     if ((rc = dw_reduce(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, s))) return rc;                       // dW2 = g^T h
-    hipLaunchKernelGGL(k_bw_dx, dim3(blocks(rows[t] * H).x, 1), dim3(256), 0, s, gout[t], p->ff[t].fc2.weight, (int)rows[t], D, H, dh, 0, 0, (float*)nullptr, 0);
+    launch_bw_dx(dim3(blocks(rows[t] * H).x, 1), s, gout[t], p->ff[t].fc2.weight, (int)rows[t], D, H, dh, 0, 0, (float*)nullptr, 0);
     DeltaArgs a{dh, hbuf, dh, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, H, (int)rows[t], 1, p->ff[t].fc1.act, 0};  // delta1 = dh * act1'(h), in place
     hipLaunchKernelGGL(k_bw_delta, dim3(blocks(rows[t] * H).x, 1), dim3(256), 0, s, a, (size_t)0, (size_t)0);
     if ((rc = dw_reduce(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1, part, s))) return rc;                      // dW1 = delta1^T z
-    hipLaunchKernelGGL(k_bw_dx, dim3(blocks(rows[t] * D).x, 1), dim3(256), 0, s, dh, p->ff[t].fc1.weight, (int)rows[t], H, D, dz2, 0, 0, (float*)nullptr, 0);
+    launch_bw_dx(dim3(blocks(rows[t] * D).x, 1), s, dh, p->ff[t].fc1.weight, (int)rows[t], H, D, dz2, 0, 0, (float*)nullptr, 0);
     GNX_HIP(hipGetLastError());
   }
   // 3. block pullback: inputs gn1(x), outputs recomputed above, upstream g_out -> gradients w.r.t. gn1(x)
