@@ -322,7 +322,13 @@ __global__ void k_fw_dense(const float* __restrict__ x, const float* __restrict_
   const int j = (int)(idx % J);
   float acc = b ? b[j] : 0.f;
   const float* xr = x + m * K;
-  for (int k = 0; k < K; ++k) acc = fmaf(W[(size_t)k * J + j], xr[k], acc);
+  for (int k = 0; k < K; k += 8) {
+    float w[8], xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int kk = k + u < K ? k + u : K - 1; w[u] = W[(size_t)kk * J + j]; xv[u] = xr[kk]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = k + u < K ? fmaf(w[u], xv[u], acc) : acc;
+  }
   y[idx] = act_apply(acc, act);
 }
 
