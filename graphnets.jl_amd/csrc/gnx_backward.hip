@@ -20,7 +20,8 @@ extern "C" int32_t gnx_ensure_csr(const gnx_graphs* h);
 namespace gnx {
 
 // matrix-core primitives (gnx_backward_wide.hip)
-bool bw_use_mfma(size_t rows, int J, int K);
+bool bw_use_mfma(size_t rows, int J, int K);     // dX
+bool bw_use_mfma_dw(size_t rows, int J, int K);  // dW
 size_t dw_mfma_partial_floats(size_t rows, int J, int K);
 int32_t dw_mfma(const float* delta, const float* X, size_t rows, int J, int K, float* dW, float* partial, hipStream_t s);
 int32_t dx_mfma(const gnx_graphs* h, int entity, const float* delta, const float* W, int J, int K, int ka, int kb, float* out, int64_t R,
@@ -309,6 +310,14 @@ static int32_t dw_reduce(const float* delta, const float* X, size_t rows, int J,
   return GNX_OK;
 }
 
+// weight + bias gradient of one Dense: matrix cores for real matrices (bias by column sums), the generic reduction otherwise
+static int32_t dw_auto(const float* delta, const float* X, size_t rows, int J, int K, const gnx_dense_grad& g, float* partial, int* off2, hipStream_t s) {
+  if (!bw_use_mfma_dw(rows, J, K)) return dw_reduce(delta, X, rows, J, K, g, partial, s);
+  int32_t rc = dw_mfma(delta, X, rows, J, K, g.weight, partial, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows);
+  return colsum_all(delta, rows, J, g.bias, partial, off2, s);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // GNCore backward pieces
@@ -604,9 +613,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
     launch_delta(a, (size_t)G * Kg, (size_t)0, Ru, s);
     if (bw_use_mfma((size_t)R * N, on, Kn)) {  // matrix cores: dXn = dn Wn^T, dWn = Xn^T dn, dbn = column sums
       if ((rc = dx_mfma(h, 1, dlt_n, p->nodefn.weight, on, Kn, 0, Kn, dXn, R, wt, true, s, "bw_dx_node"))) return rc;
-      if ((rc = dw_mfma(dlt_n, Xn, (size_t)R * N, on, Kn, gr.nodefn.weight, part, s))) return rc;
-      hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)(R * N));
-      if ((rc = colsum_all(dlt_n, (size_t)R * N, on, gr.nodefn.bias, part, off2, s))) return rc;
+      if ((rc = dw_auto(dlt_n, Xn, (size_t)R * N, on, Kn, gr.nodefn, part, off2, s))) return rc;
     } else {
       launch_bw_dx(dim3(blocks((size_t)N * Kn).x, Ru), s, dlt_n, p->nodefn.weight, N, on, Kn, dXn, 0, 0, (float*)nullptr, 0);
       if ((rc = dw_reduce(dlt_n, Xn, (size_t)R * N, on, Kn, gr.nodefn, part, s))) return rc;
@@ -646,7 +653,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
         float* dW = gr.edgefn.weight;
         auto dw_any = [&](const float* delta, const float* X, size_t rows, int K, float* out) -> int32_t {
           if (K == 0) return GNX_OK;
-          if (bw_use_mfma(rows, oe, K)) return dw_mfma(delta, X, rows, oe, K, out, part, s);
+          if (bw_use_mfma_dw(rows, oe, K)) return dw_mfma(delta, X, rows, oe, K, out, part, s);
           return dw_reduce(delta, X, rows, oe, K, gnx_dense_grad{out, nullptr}, part, s);
         };
         if ((rc = dw_any(dlt_e, ef, (size_t)R * E, de, dW))) return rc;
@@ -784,14 +791,15 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
     if (bw_use_mfma(rows[t], D, H)) {  // matrix cores (gnx_backward_wide.hip); rows[t] = R * (rows of entity t)
       float* wt = F(L.wt);
       if ((rc = launch_dense_rows(h, t, F(L.l2[t]), D, p->ff[t].fc1, H, nullptr, nullptr, hbuf, R, s, "bw_ff1_recompute"))) return rc;
-      if ((rc = dw_mfma(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2.weight, part, s))) return rc;                   // dW2 = h^T g
-      hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows[t]);
-      if ((rc = colsum_all(gout[t], rows[t], D, gr.ff[t].fc2.bias, part, off2, s))) return rc;
+      if ((rc = dw_auto(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, off2, s))) return rc;                     // dW2 = h^T g, db2
       // delta1 = (g W2^T) .* act1'(h) in the GEMM epilogue, with per-tile column sums of delta1 for db1
       int n_tiles = 0;
-      float* tcs = gr.ff[t].fc1.bias ? F(L.tcs) : nullptr;
+      const bool dw1_mfma = bw_use_mfma_dw(rows[t], H, D);
+      float* tcs = gr.ff[t].fc1.bias && dw1_mfma ? F(L.tcs) : nullptr;
       if ((rc = dx_mfma(h, t, gout[t], p->ff[t].fc2.weight, D, H, 0, H, dh, R, wt, true, s, "bw_dx_ff2", hbuf, p->ff[t].fc1.act, tcs, &n_tiles))) return rc;
-      if ((rc = dw_mfma(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1.weight, part, s))) return rc;                  // dW1 = z^T delta1
+      if (dw1_mfma) rc = dw_mfma(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1.weight, part, s);                   // dW1 = z^T delta1
+      else rc = dw_reduce(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1, part, s);                                   // (+ db1)
+      if (rc) return rc;
       if (tcs) {
         ProfScope ps("bw_colsum_all", s);
         hipLaunchKernelGGL(k_bw_colsum_final, dim3((unsigned)((H + 63) / 64)), dim3(256), 0, s, tcs, H, (int)(R * n_tiles), gr.ff[t].fc1.bias);

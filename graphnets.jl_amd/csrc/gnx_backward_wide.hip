@@ -119,10 +119,18 @@ __global__ void k_dw_final2(const float* __restrict__ partial, int nchunks, size
   dW[p] = acc;
 }
 
+// dX = delta W^T on the matrix cores: also for narrow layers (from J*K = 64) and small batches of wide layers — the generic
+// kernel puts one thread on each (row, k) with strided weight reads, the GEMM tiles read the weights coalesced and waste
+// matrix-core time that nobody else wants (GNCore(10,5,3) FeedForward dX: 1.19 ms -> 0.30 ms on 1M edges).
 bool bw_use_mfma(size_t rows, int J, int K) {
   static const bool off = getenv("GNX_BW_GENERIC") != nullptr;
-  // also for small batches of wide layers (the reference's sort example: a few hundred rows at width 384): the generic
-  // kernels put one thread on each (row, k) with strided weight reads, the GEMM tiles read the weights coalesced
+  static const int min_w = getenv("GNX_BW_MFMA_MIN") ? atoi(getenv("GNX_BW_MFMA_MIN")) : 64;
+  return !off && rows >= 64 && (size_t)J * K >= (size_t)min_w && J >= 2 && K >= 2;
+}
+// dW = X^T delta on the matrix cores only for real matrices: a 128 x 128 tile per row chunk is wasted on a 10 x 40 gradient
+// (GNCore(10,5,3): 0.70 ms + partial traffic against 0.54 ms for the row-parallel generic reduction)
+bool bw_use_mfma_dw(size_t rows, int J, int K) {
+  static const bool off = getenv("GNX_BW_GENERIC") != nullptr;
   return !off && rows >= 64 && (size_t)J * K >= 1024 && J >= 8 && K >= 8;
 }
 
