@@ -9,7 +9,10 @@ from oracle import gn_oracle as O
 from tests import util as U
 
 pytestmark = pytest.mark.gpu
+import os
+
 WIDTHS = [0, 1, 2, 3, 5, 8, 12, 16, 20, 24, 28, 32, 33, 40, 64]
+EXTRA = int(os.environ.get("GNX_FUZZ_EXTRA", "0"))  # one-off deeper sweeps: GNX_FUZZ_EXTRA=300 python -m pytest tests/test_gpu_fuzz.py -m gpu
 
 
 @pytest.fixture(scope="module")
@@ -48,7 +51,7 @@ def _dims(rng, core=False):
             return din, dout
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(60 + EXTRA))
 def test_random_block(gn, seed):
     rng = np.random.default_rng(9000 + seed)
     g, R = _random_batch(rng, gn)
@@ -64,7 +67,7 @@ def test_random_block(gn, seed):
             U.assert_close(U.from_jl(got), r, s, f"seed {seed} dims {din}=>{dout} R={R} flags={flags} {name}")
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 + EXTRA // 4))
 def test_random_core(gn, seed):
     rng = np.random.default_rng(9500 + seed)
     g, R = _random_batch(rng, gn)
@@ -79,10 +82,12 @@ def test_random_core(gn, seed):
     for flags in (0, 1):
         y = core(U.to_nt(gn, g, ef, nf, gf), flags=flags)
         for name, got, r in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref):
-            np.testing.assert_allclose(U.from_jl(got), r, rtol=2e-4, atol=2e-4, err_msg=f"seed {seed} dims {dims} R={R} flags={flags} {name}")
+            # graph-level values are sums over whole graphs: the absolute tolerance scales with the tensor's magnitude
+            np.testing.assert_allclose(U.from_jl(got), r, rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(r).max()) if r.size else 1.0),
+                                       err_msg=f"seed {seed} dims {dims} R={R} flags={flags} {name}")
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 + EXTRA // 4))
 def test_random_block_backward(gn, seed):
     """gnx_block_backward on random width sets / batches (smooth activations: no relu kink) against torch float64 autograd."""
     import torch
