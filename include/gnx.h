@@ -17,8 +17,11 @@
  *   - Edge order inside a graph = order of the ones of vec(A) column-major (src/pad.jl:30): sorted by
  *     destination j then source i, A[i,j] = 1 meaning i -> j (src/gngraphbatch.jl:194-211).
  *   - Dense weights are (out x in) column-major = Flux `Dense.weight` bytes: W[k*out + j]; device pointers.
- *   - The caller owns every buffer; the library owns only gnx_graphs handles.  `stream` is a hipStream_t
- *     (NULL = default stream); calls are asynchronous on it and hipGraph-capturable (no allocation, no sync).
+ *   - The caller owns every buffer; the library owns only gnx_graphs handles (and, for gnx_model, the model's intermediate
+ *     tensors).  `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on it and hipGraph-capturable (no
+ *     allocation, no sync) with three documented exceptions that happen once, outside any capture: the first use of a width
+ *     set that needs a run-time specialised kernel (see gnx_jit_*), the first backward / edge-collapsing call on a handle
+ *     (builds the CSR / collapse tables of the handle), and gnx_model_forward (which manages its own hipGraph).
  *   - The library uses the calling thread's current HIP device; a handle lives on the device it was created on.
  */
 #ifndef GNX_H
