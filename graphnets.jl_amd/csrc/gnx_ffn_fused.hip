@@ -232,3 +232,4 @@ int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d,
 }
 
 }  // namespace gnx
+
