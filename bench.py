@@ -5,19 +5,26 @@
 
 A "step" is one GNBlock forward (edge + node + graph update) over one resident batch.
   N = 1 : BASELINE configs[1] — one shared Erdős–Rényi graph, 100k nodes / 1M edges, batch_size 1.  The K timed steps
-          are captured into ONE hipGraph (the step is ~10-20 µs of GPU work; eager launches from Python would time the
+          are captured into ONE hipGraph (the step is ~20 µs of GPU work; eager launches from Python would time the
           host) and rotate over NSETS disjoint buffer sets so the footprint (>256 MiB) defeats the Infinity Cache:
-          `value` is a cache-cold, HBM-resident number.  `warm_ms_per_step` (one buffer set, cache-resident) is extra.
-  N > 1 : BASELINE configs[4], weak scaling — every rank holds its own 1M-edge shard of 512 random graphs (32..256
-          nodes) of a global N*512-graph heterogeneous batch (4096 graphs at N = 8); graphs never cross ranks; the only
-          collective is the RCCL all-gather of gf' (overlapped with the next step on a side stream).
-Timing: W warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize(), MAX over ranks.
-Rank 0 prints ONE JSON line.  `roofline` comes from a second pass over the same K steps with per-kernel HIP events
-(gnx_profile_*), `cpu_baseline` from the oracle's C restatement (test infrastructure) on the host cores.
+          `value` is a cache-cold, HBM-resident number.  `warm_ms_per_step` (two buffer sets, cache-resident) is extra.
+  N > 1 : BASELINE configs[4], weak scaling — ONE heterogeneous batch of N*512 random graphs (32..256 nodes, N*1M edges;
+          4096 graphs at N = 8) is sharded BY GRAPH with the product's partitioner (equal graph counts, snake order by
+          edge count: graphnets.jl_amd/dist.py); every rank builds the handle of its own 512 graphs / ~1M edges; graphs
+          never cross ranks; the only collective is the RCCL all-gather of gf' into original graph order (stacked over the
+          steps of one hipGraph replay, on a side stream).
+          `python bench.py --gpus N` starts its own N ranks (python -m torch.distributed.run, before anything touches a
+          GPU); under an external torchrun (RANK / WORLD_SIZE set) it is one of the ranks.
+Timing: W warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize(), MAX over ranks; the K-step
+region is run three times and the MEDIAN is reported (`timing` says so).  Rank 0 prints ONE JSON line.
+`roofline` comes from a second pass over the same K steps with per-kernel HIP events (gnx_profile_*); `cpu_baseline` from
+the oracle's C restatement (test infrastructure) on the host cores.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,9 +36,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFS = 157.3  # exact-f32 MFMA (v_mfma_f32_32x32x2_f32); no xf32 on gfx950
 NSETS = 8                  # rotating buffer sets: 8 x ~60 MB > 256 MiB Infinity Cache
-NULL_KERNEL_ROCPROF_US = 3.64  # rocprofv3 kernel-trace duration of an empty launch (profiles/r01_readme_rocprofv3_kernel_stats_raw.csv, gnx::k_null)
 DIMS = {"readme": ((10, 5, 0), (3, 4, 5)), "core": ((128, 64, 32), (128, 64, 32)),
         "odd": ((7, 3, 2), (5, 6, 1)), "mid": ((20, 10, 4), (12, 9, 3))}  # odd: fused kernel specialised at run time (GNX_JIT=0: generic kernels); mid: generic/MFMA path
+KERNEL_SOURCES = ("gnx_wave_kernel.h", "gnx_device.h", "gnx_narrow.hip", "gnx_wide.hip", "gnx_generic.hip", "gnx_forward.hip", "gnx_ffn_fused.hip",
+                  "gnx_core_narrow.hip", "gnx_graphs.cpp")
+
+
+def kernel_source_sha():
+    """sha256 over the kernel sources: a committed traffic / calibration profile is only quoted while it describes THIS code."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "graphnets.jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def make_c2(seed=2, N=100_000, E=1_000_000):
@@ -45,22 +62,38 @@ def make_c2(seed=2, N=100_000, E=1_000_000):
     return [np.cumsum(colptr)], [src.astype(np.int64)], [N]
 
 
-def make_hetero(seed, G=512, E=1_000_000):
-    """G graphs, n_g ~ U{32..256}, constant density, exactly E edges in total."""
+def hetero_spec(seed, G=512, E=1_000_000):
+    """SURVEY §8d C3/C5 law: G graphs, n_g ~ U{32..256}, constant density, exactly E edges in total.
+    Returns (n_g[G], e_g[G]) — cheap, every rank computes it for the whole batch."""
     rng = np.random.default_rng(seed)
     n = rng.integers(32, 257, G)
     dens = E / float((n.astype(np.int64) ** 2).sum())
     eg = np.floor(dens * n.astype(np.float64) ** 2).astype(np.int64)
     short = E - int(eg.sum())
-    eg[np.argsort(-n)[:short]] += 1
+    eg[np.argsort(-n, kind="stable")[:short]] += 1
+    return n.astype(np.int64), eg
+
+
+def hetero_graph(seed, i, n, e):
+    """Graph i of the batch `seed`: e distinct directed pairs of an n-node graph in reference edge order, drawn from a
+    generator that depends on (seed, i) only — a rank generates just the graphs of its shard."""
+    rng = np.random.default_rng([int(seed), int(i)])
+    n, e = int(n), int(e)
+    k = np.sort(rng.choice(n * n, e, replace=False))
+    cp = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(cp, k // n + 1, 1)
+    return np.cumsum(cp), (k % n).astype(np.int64)
+
+
+def make_hetero(seed, G=512, E=1_000_000, only=None):
+    """The whole batch (or the graphs `only`, ascending original ids) as per-graph CSC lists."""
+    n, eg = hetero_spec(seed, G, E)
+    ids = range(G) if only is None else [int(i) for i in only]
     colptrs, rowvals = [], []
-    for ng, e in zip(n, eg):
-        ng = int(ng)
-        k = np.sort(rng.choice(ng * ng, int(e), replace=False))
-        cp = np.zeros(ng + 1, dtype=np.int64)
-        np.add.at(cp, k // ng + 1, 1)
-        colptrs.append(np.cumsum(cp)); rowvals.append((k % ng).astype(np.int64))
-    return colptrs, rowvals, [int(x) for x in n]
+    for i in ids:
+        cp, rv = hetero_graph(seed, i, n[i], eg[i])
+        colptrs.append(cp); rowvals.append(rv)
+    return colptrs, rowvals, [int(n[i]) for i in ids]
 
 
 def algorithmic_bytes(E, N, G, din, dout):
@@ -76,6 +109,14 @@ def algorithmic_bytes(E, N, G, din, dout):
 def algorithmic_flops(E, N, G, din, dout):
     (de, dn, dg), (oe, on, og) = din, dout
     return 2 * (E * (de + 2 * dn + dg) * oe + N * (oe + dn + dg) * on + G * (oe + on + dg) * og)
+
+
+def executed_flops(E, N, G, din, dout):
+    """FLOPs the MFMA path actually executes: gf is folded into a per-graph bias and, when dn >= 16, the nf columns of the
+    edge function are projected once per NODE (W*[ef;nf_s;nf_d] = We*ef + (Ws*nf)[src] + (Wd*nf)[dst])."""
+    (de, dn, dg), (oe, on, og) = din, dout
+    edge = E * de * oe + (2 * N * dn * oe if dn >= 16 else 2 * E * dn * oe)
+    return 2 * (edge + N * (oe + dn) * on + G * (oe + on + dg) * og + G * dg * (oe + on))
 
 
 def glorot(rng, out_d, in_d):
@@ -114,11 +155,51 @@ def bench_c4(args, gn, torch, dev):
         fwd()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / K
-    flops = 699.2e9 if core == (128, 64, 32) else float("nan")  # whole-model algorithmic FLOPs at 1M edges
-    print(json.dumps({"metric": "edges/sec through Encoder->2xGNCore(%s)->Decoder, 1M-edge graph (BASELINE configs[3])" % ",".join(map(str, core)),
-                      "value": round(g.n_edges / dt, 1), "unit": "edges/s", "ms_per_step": round(dt * 1e3, 4), "steps": K,
-                      "algorithmic_tflops": round(flops / dt / 1e12, 2), "mfma_f32_peak_tflops": MFMA_F32_PEAK_TFS,
-                      "frac_of_mfma_peak": round(flops / dt / 1e12 / MFMA_F32_PEAK_TFS, 4), "kernel_us_one_forward": kern}))
+    E, N = g.n_edges, g.n_nodes
+    if core == (128, 64, 32):
+        aflops = 699.2e9  # whole-model algorithmic FLOPs at 1M edges
+    else:
+        aflops = float("nan")
+    # executed: enc + dec blocks, two cores = block + FeedForward 16*(E*de^2 + N*dn^2 + G*dg^2) each
+    ce, cn, cg = core
+    ex = (executed_flops(E, N, 1, (10, 5, 0), core) + executed_flops(E, N, 1, core, (3, 4, 5)) +
+          2 * (executed_flops(E, N, 1, core, core) + 16 * (E * ce * ce + N * cn * cn + cg * cg)))
+    line = {"metric": "edges/sec through Encoder->2xGNCore(%s)->Decoder, 1M-edge graph (BASELINE configs[3])" % ",".join(map(str, core)),
+            "value": round(E / dt, 1), "unit": "edges/s", "ms_per_step": round(dt * 1e3, 4), "steps": K, "dtype": "f32",
+            "roofline": {"bound": "mfma", "achieved": round(ex / dt / 1e12, 2), "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
+                         "frac": round(ex / dt / 1e12 / MFMA_F32_PEAK_TFS, 4), "counts": "EXECUTED flops of the whole model / whole-step time",
+                         "executed_flops": ex, "algorithmic_flops": aflops, "algorithmic_tflops": round(aflops / dt / 1e12, 2), "traffic": None},
+            "kernel_us_one_forward": kern}
+    assert line["roofline"]["frac"] <= 1.0
+    print(json.dumps(line))
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as a CHILD job before this process has touched
+    a GPU (a process that has initialised HIP must never exec or fork into GPU work), relay its output, exit with its code."""
+    port = int(os.environ.get("MASTER_PORT", 29500 + os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def load_traffic(dims_key, kernel, sha):
+    """HBM bytes per launch of `kernel` from the committed PMC profile of this width set — only while the profile was taken
+    on the kernel sources that are running now (source_sha); otherwise None (a stale number is worse than none)."""
+    tpath = os.path.join(ROOT, "profiles", f"traffic_{dims_key}.json")
+    if not os.path.exists(tpath):
+        return None, None
+    with open(tpath) as f:
+        t = json.load(f)
+    meta = t.get("_meta", {})
+    src = {"file": os.path.relpath(tpath, ROOT), "commit": meta.get("commit"), "date": meta.get("date"), "source_sha": meta.get("source_sha"),
+           "current_source_sha": sha}
+    if meta.get("source_sha") != sha:
+        src["stale"] = True
+        return None, src
+    return t.get(kernel, {}).get("hbm_bytes_per_launch"), src
 
 
 def main():
@@ -127,8 +208,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dims", default="readme", help="a preset (%s) or explicit widths de,dn,dg:oe,on,og" % ", ".join(DIMS))
-    ap.add_argument("--workload", choices=["c2", "hetero"], default=None)
-    ap.add_argument("--hetero-graphs", type=int, default=512, help="graphs per GPU of the hetero workload (C3: 512; C5: 4096)")
+    ap.add_argument("--workload", choices=["c2", "hetero"], default=None, help="default: c2 at N = 1 (BASELINE configs[1]), hetero at N > 1 (configs[4])")
+    ap.add_argument("--hetero-graphs", type=int, default=512, help="graphs per GPU of the hetero workload (C3: 512; C5 on one GPU: 4096)")
     ap.add_argument("--hetero-edges", type=int, default=1_000_000, help="edges per GPU of the hetero workload (C5w: 8000000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
@@ -139,21 +220,25 @@ def main():
                     help="two-phase steps: graph update of step i on a second stream (measured SLOWER inside a hipGraph: the "
                          "fork/join costs more than the 5 us it hides — 35.7 vs 27.7 us/step — so it is off by default)")
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path even with one rank (testing)")
+    ap.add_argument("--two-launch", action="store_true", help="graph update as its own kernel (k_graph_t) instead of the last-arriver ticket")
     ap.add_argument("--core-dims", type=str, default="128,64,32", help="core widths for --model c4 (README ex.3 uses 10,5,3)")
     ap.add_argument("--model", choices=["block", "c4"], default="block",
                     help="c4: BASELINE configs[3] — encoder -> 2 x GNCore(128,64,32) -> decoder on the C2 graph (extra; not the headline line)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))  # nothing has touched a GPU yet (torch is not even imported)
+
     import torch
     import torch.distributed as dist
     import graphnets_jl_amd as gn
-    from graphnets_jl_amd.dist import GfGather
+    from graphnets_jl_amd.dist import GfGather, partition_graphs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
@@ -169,19 +254,23 @@ def main():
     else:
         din, dout = (tuple(int(v) for v in part.split(",")) for part in args.dims.split(":"))
         assert len(din) == 3 and len(dout) == 3, "--dims de,dn,dg:oe,on,og"
-    # Weak scaling keeps the per-GPU work of the headline config: a batch of `world` C2-sized graphs sharded by graph (one
-    # 100k-node / 1M-edge graph per GPU), gf' all-gathered.  `--workload hetero` gives BASELINE configs[4] (512 graphs per GPU).
-    workload = args.workload or "c2"
+    workload = args.workload or ("hetero" if multi else "c2")
 
     # ---- synthetic batch (rank-local shard) ----
+    shards = None
     if workload == "c2":
         colptrs, rowvals, nn = make_c2(seed=2 + rank)
+        shards = [np.asarray([r]) for r in range(world)]
         wl_name = ("C2: one shared Erdos-Renyi graph, 100k nodes / 1M edges, batch_size=1 (BASELINE configs[1])" if world == 1 else
                    f"batch of {world} C2-sized Erdos-Renyi graphs (100k nodes / 1M edges each) sharded by graph, one per GPU; gf' all-gathered")
     else:
-        colptrs, rowvals, nn = make_hetero(seed=3 + rank, G=args.hetero_graphs, E=args.hetero_edges)
-        wl_name = (f"heterogeneous batch, {args.hetero_graphs * world} random graphs (32-256 nodes) sharded by graph, {args.hetero_graphs} graphs / "
-                   f"{args.hetero_edges / 1e6:g}M edges per GPU (BASELINE configs[{2 if world == 1 else 4}] law)")
+        Gtot, Etot = args.hetero_graphs * world, args.hetero_edges * world
+        seed = 3 if Gtot == 512 else (5 if Gtot == 4096 else 1000 + Gtot)  # C3 = seed 3, C5 = seed 5
+        n_all, e_all = hetero_spec(seed, Gtot, Etot)
+        shards = partition_graphs(e_all, world)  # the product's partitioner: equal graph counts, snake order by edge count
+        colptrs, rowvals, nn = make_hetero(seed, Gtot, Etot, only=shards[rank])
+        wl_name = (f"ONE heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {world} GPU(s): "
+                   f"{len(shards[rank])} graphs / {int(e_all[shards[rank]].sum())} edges on rank 0 (BASELINE configs[{2 if Gtot == 512 and world == 1 else 4}] law)")
     g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
     E, N, G = g.n_edges, g.n_nodes, g.n_graphs
     rng = np.random.default_rng(100)  # identical weights on every rank
@@ -191,25 +280,27 @@ def main():
     blk.nodefn = gn.Dense.from_numpy(glorot(rng, on, oe + dn + dg), np.zeros(on, np.float32), device=dev)
     blk.graphfn = gn.Dense.from_numpy(glorot(rng, og, oe + on + dg), np.zeros(og, np.float32), device=dev)
     plan = gn.BlockPlan(blk, g, R=1, flags=args.flags)
+    if args.two_launch:
+        plan.flags &= ~gn._lib.FLAG_WS_TICKETS
     nsets = 2 if max(din + dout) >= 64 else NSETS
     tg = torch.Generator(device=dev); tg.manual_seed(1234 + rank)
     mk = lambda T, d: torch.rand((1, T, d), generator=tg, device=dev, dtype=torch.float32) if d > 0 else None
     sets = [dict(ef=mk(E, de), nf=mk(N, dn), gf=mk(G, dg), out=plan.outputs(), ws=plan.new_workspace()) for _ in range(nsets)]
-    side = torch.cuda.Stream(device=dev)  # the graph update (a few KB, pure latency) runs here and overlaps the next step
+    side = torch.cuda.Stream(device=dev)  # --overlap: the graph update (a few KB, pure latency) runs here
     # N > 1: M steps of compute are captured into one hipGraph that writes the M gf' tables into a stacked buffer, and
     # ONE all-gather moves the whole stack (fewer, larger collectives: the per-step message is only G*DG' floats = 10 KB,
     # pure latency on xGMI); the gather runs on a side stream and overlaps the next M steps.
     M = 1
     if multi:
         M = max(m for m in range(1, 257) if K % m == 0)
-    gf_stack = torch.zeros((M, G, og), dtype=torch.float32, device=dev) if multi else None
-    gather = GfGather([np.arange(r * M * G, (r + 1) * M * G) for r in range(world)], rank, world, og, dev) if multi else None
+    gather = GfGather(shards, rank, world, og, dev, stack=M) if multi else None
+    gf_stack = gather.send if multi else None  # [M][max_count][og]: the graph update writes straight into the send buffer
 
     def step(i, s=None, slot=None, overlap=False):
         """One GNBlock forward.  `overlap`: two-phase form — edge+node update on the current stream, graph update on
         the side stream behind an event, so it leaves the critical path (joined before the timed region ends)."""
         b = sets[i % nsets]
-        go = b["out"][2] if slot is None else gf_stack[slot:slot + 1]
+        go = b["out"][2] if slot is None else gf_stack[slot:slot + 1, :G]
         if not overlap or og == 0:
             plan(b["ef"], b["nf"], b["gf"], b["out"][0], b["out"][1], go, stream=s, ws=b["ws"])
             return
@@ -254,13 +345,15 @@ def main():
             return cg
         cold = capture(K, True)
         cold.replay(); torch.cuda.synchronize(dev)
-        dt = min(timed(cold.replay) for _ in range(3))
+        reps = sorted(timed(cold.replay) for _ in range(3))
+        dt = reps[1]
         warm = capture(K, False)
         warm.replay(); torch.cuda.synchronize(dev)
-        extra["warm_ms_per_step"] = round(min(timed(warm.replay) for _ in range(3)) / K * 1e3, 6)
+        extra["warm_ms_per_step"] = round(sorted(timed(warm.replay) for _ in range(3))[1] / K * 1e3, 6)
         extra["launch"] = (f"hipGraph of {K} steps, {nsets} rotating buffer sets (cache-cold); " +
                            ("single stream" if not args.overlap else "graph update of step i on a 2nd stream, overlapping step i+1 (joined inside the timed region)"))
     else:
+        assert gf_stack.shape[1] == G or world > 1, "one rank: every graph is local"
         cgs = []
         for base in range(0, min(K, nsets * M), M):  # enough distinct graphs to keep rotating over all buffer sets
             cg = torch.cuda.CUDAGraph()
@@ -273,17 +366,25 @@ def main():
 
         def run():
             for j in range(K // M):
-                torch.cuda.current_stream(dev).wait_event(copied) if j else None  # previous stack has left gf_stack
+                torch.cuda.current_stream(dev).wait_event(copied) if j else None  # previous stack has left the send buffer
                 cgs[j % len(cgs)].replay()
-                gather.start(gf_stack.view(M * G, og))
+                gather.start_inplace()
                 copied.record(gather.comm_stream) if gather.comm_stream is not None else copied.record()
         run(); sync_all()
-        dt = min(timed(run) for _ in range(3))
-        gf_all = gather.finish() if gather._ready is not None else gather.recv
-        assert gf_all.shape[0] == world * M * G
+        reps = sorted(timed(run) for _ in range(3))
+        dt = reps[1]
+        gf_all = gather.finish() if gather._ready is not None else gather.result()
+        assert tuple(gf_all.reshape(M, -1, og).shape) == (M, gather.G, og)
         extra["launch"] = f"hipGraph of {M} steps per replay; one RCCL all-gather of the {M} stacked gf' tables per replay, overlapped on a side stream"
+    extra["timing"] = f"median of 3 runs of the {K}-step region ({[round(r / K * 1e6, 2) for r in reps]} us/step)"
     ms_per_step = dt / K * 1e3
-    value = E * world / (dt / K)
+    if multi:  # whole-job edges: every rank's shard
+        t = torch.tensor([float(E)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t)
+        E_job = int(t.item())
+    else:
+        E_job = E
+    value = E_job / (dt / K)
 
     # ---- roofline: the same K steps again with per-kernel HIP events; the GPU is kept busy behind a spin kernel
     # so that the events bracket kernel execution, not host launch gaps ----
@@ -293,45 +394,51 @@ def main():
         torch.cuda._sleep(int(2.0e9 * 0.02))
         for i in range(K):
             b = sets[i % nsets]
-            plan(b["ef"], b["nf"], b["gf"], *b["out"])
+            plan(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"])
         gn.profile_calibrate(K, torch.cuda.current_stream(dev).cuda_stream)
         torch.cuda.synchronize(dev)
         gn.profile_enable(False)
         prof = gn.profile_read(); gn.profile_reset()
         raw = {k: v["total_ms"] / max(v["launches"], 1) * 1e3 for k, v in prof.items()}  # avg µs per launch, event bracket
-        # An event bracket around an EMPTY launch costs `bracket` µs, of which rocprofv3 itself attributes
-        # NULL_KERNEL_ROCPROF_US to the (empty) kernel; the rest is what the bracket adds to any kernel's duration.
+        # An event bracket around an EMPTY launch costs `bracket` µs, of which rocprofv3 itself attributes `null_us` to the
+        # (empty) kernel (profiles/calibration.json, with the profile it was read from); the rest is what the bracket adds to
+        # any kernel's duration.
+        with open(os.path.join(ROOT, "profiles", "calibration.json")) as f:
+            calib = json.load(f)
         bracket = raw.pop("__empty_bracket__", 0.0)
-        overhead = max(bracket - NULL_KERNEL_ROCPROF_US, 0.0)
+        overhead = max(bracket - calib["null_kernel_rocprof_us"], 0.0)
         kern = {k: max(v - overhead, 0.0) for k, v in raw.items()}
         dom = max(kern, key=kern.get)
         dur_s = kern[dom] * 1e-6
+        step_s = ms_per_step * 1e-3
         abytes, aflops = algorithmic_bytes(E, N, G, din, dout), algorithmic_flops(E, N, G, din, dout)
         hbm_t, mfma_t = abytes / (HBM_PEAK_GBS * 1e9), aflops / (MFMA_F32_PEAK_TFS * 1e12)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.dims.replace(':', '_').replace(',', '-')}.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+        dims_key = args.dims.replace(":", "_").replace(",", "-") + ("" if workload == "c2" else f"_hetero{G}")
+        traffic, tsrc = load_traffic(dims_key, dom, kernel_source_sha())
         if hbm_t >= mfma_t:
             a = abytes / dur_s / 1e9
-            roof = dict(bound="hbm", achieved=round(a, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(a / HBM_PEAK_GBS, 4), traffic=traffic)
+            roof = dict(bound="hbm", achieved=round(a, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(a / HBM_PEAK_GBS, 4),
+                        frac_whole_step=round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=tsrc,
+                        counts="algorithmic bytes of the whole block / duration of the dominant kernel (frac) or of the whole step (frac_whole_step)")
         else:
-            a = aflops / dur_s / 1e12
-            roof = dict(bound="mfma", achieved=round(a, 3), peak=MFMA_F32_PEAK_TFS, unit="TFLOP/s", frac=round(a / MFMA_F32_PEAK_TFS, 4), traffic=traffic)
-            # `achieved` counts the ALGORITHMIC FLOPs of the reference formulation (every edge multiplies its full
-            # [ef; nf_src; nf_dst; gf] row).  The kernels execute fewer: gf is folded into a per-graph bias and, when dn >= 16,
-            # the nf columns are projected once per NODE (W*[ef;nf_s;nf_d] = We*ef + (Ws*nf)[src] + (Wd*nf)[dst]).
-            ex = 2 * (E * de * oe + (2 * N * dn * oe if dn >= 16 else 2 * E * dn * oe) + N * (oe + dn) * on + G * (oe + on + dg) * og)
-            roof.update(executed_flops=ex, executed_tflops_whole_block=round(ex / (ms_per_step * 1e-3) / 1e12, 2))
-        roof.update(kernel=dom, kernel_us=round(kern[dom], 3), event_bracket_overhead_us=round(overhead, 3), algorithmic_bytes=abytes, algorithmic_flops=aflops,
+            # MFMA-bound: priced on the flops the kernels EXECUTE (never more than the peak); the algorithmic rate of the
+            # reference formulation (every edge multiplies its full [ef; nf_src; nf_dst; gf] row) is reported beside it
+            ex = executed_flops(E, N, G, din, dout)
+            a = ex / step_s / 1e12
+            roof = dict(bound="mfma", achieved=round(a, 3), peak=MFMA_F32_PEAK_TFS, unit="TFLOP/s", frac=round(a / MFMA_F32_PEAK_TFS, 4),
+                        frac_whole_step=round(a / MFMA_F32_PEAK_TFS, 4), traffic=traffic, traffic_source=tsrc,
+                        counts="EXECUTED flops of the whole block / whole-step time (the block is several GEMM launches)",
+                        executed_flops=ex, algorithmic_tflops_whole_step=round(aflops / step_s / 1e12, 2),
+                        hbm_frac_whole_step=round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 4))
+        assert roof["frac"] <= 1.0 and roof["frac_whole_step"] <= 1.0, "a roofline fraction above 1 is an accounting error"
+        roof.update(kernel=dom, kernel_us=round(kern[dom], 3), event_bracket_overhead_us=round(overhead, 3),
+                    event_calibration=calib, algorithmic_bytes=abytes, algorithmic_flops=aflops,
                     bytes_per_edge=round(abytes / E, 2), all_kernels_us={k: round(v, 3) for k, v in kern.items()})
 
     # ---- CPU baseline: the oracle's C restatement ("port") on the host cores, rank 0, N = 1 only ----
     cpu = None
     if rank == 0 and not multi and not args.no_cpu_baseline:
         from oracle import c_port
-        from oracle import gn_oracle as O
         p = dict(in_dims=din, out_dims=dout, We=blk.edgefn.weight.cpu().numpy(), be=np.zeros(oe, np.float32),
                  Wn=blk.nodefn.weight.cpu().numpy(), bn=np.zeros(on, np.float32), Wg=blk.graphfn.weight.cpu().numpy(),
                  bg=np.zeros(og, np.float32), act_e=0, act_n=0, act_g=0)
@@ -348,7 +455,7 @@ def main():
         cpu = dict(value=round(E / float(np.median(times)), 1), unit="edges/s", cores=cores, kind="port",
                    sample=f"{len(times)} full forwards of the same 1M-edge batch (median), oracle/gn_oracle_c.c with OpenMP on {cores} threads")
         # the checker also checks: HIP output of set 0 vs the C port on the same inputs (loose: both fp32)
-        plan(b["ef"], b["nf"], b["gf"], *b["out"]); torch.cuda.synchronize(dev)
+        plan(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"]); torch.cuda.synchronize(dev)
         for got, ref in zip(b["out"], out):
             if got is not None:
                 assert np.allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=1e-3 * max(1.0, float(np.abs(ref).max()))), "HIP vs CPU port mismatch"
@@ -375,7 +482,8 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_name, "dims": f"{din}=>{dout}", "edges_per_gpu": E, "nodes_per_gpu": N,
-                       "graphs_per_gpu": G, "parallelism": f"graph-sharded x{world}" if world > 1 else "single GPU", **extra},
+                       "graphs_per_gpu": G, "edges_whole_job": E_job, "parallelism": f"graph-sharded x{world}" if world > 1 else "single GPU",
+                       "graph_update": "k_graph_t (second launch)" if args.two_launch else "in the same launch (last-arriver ticket) where the fused kernel applies", **extra},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if dense is not None:

@@ -180,13 +180,19 @@ class GNGraphBatch:
     def flat_edge_unpadder(self):
         return self._unpadders()[1]
 
-    def workspace(self, nbytes):
-        """Device scratch reused across calls on this handle (calls on one stream are ordered)."""
-        nbytes = int(nbytes)
-        ws = self._ws.get("buf")
-        if ws is None or ws.numel() < nbytes:
-            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
-            self._ws["buf"] = ws
+    def workspace(self, nbytes, layout):
+        """Device scratch for one forward call on this handle, reused across calls with the same workspace LAYOUT (layer kind,
+        widths, replicas) ON THE SAME STREAM (calls on one stream are ordered).  A buffer is never replaced, shrunk or handed
+        to a call with another layout: a hipGraph that captured a call keeps replaying into the buffer it captured (the handle
+        holds it for its whole life), and two streams never share scratch.  Every buffer is zero-filled once, which is what
+        gnx_*_workspace_init asks for, and afterwards only sees gnx calls of its own layout, so the layers pass
+        GNX_FLAG_WS_TICKETS (single-launch graph update)."""
+        nbytes = max(int(nbytes), 256)
+        key = (torch.cuda.current_stream(self.device).cuda_stream, layout, nbytes)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
         return ws
 
     def __del__(self):
@@ -619,8 +625,8 @@ class GNBlock:
     def __call__(self, x, flags=None):
         g, ef, nf, gf, R = _forward_common(x, self.in_dims)
         if self._trainable((ef, nf, gf)):  # differentiable call: gnx_block_backward is the pullback
-            outs = iter(_BlockFn.apply(self, g, R, ef, nf, gf, self.edgefn.weight, self.edgefn.bias, self.nodefn.weight, self.nodefn.bias,
-                                       self.graphfn.weight, self.graphfn.bias))
+            outs = iter(_BlockFn.apply(self, g, R, self.flags if flags is None else flags, ef, nf, gf, self.edgefn.weight, self.edgefn.bias,
+                                       self.nodefn.weight, self.nodefn.bias, self.graphfn.weight, self.graphfn.bias))
             eo, no, go = (next(outs) if d > 0 else None for d in self.out_dims)
             return NT(g, _jl(eo), _jl(no), _jl(go))
         lib = _lib.load()
@@ -631,9 +637,9 @@ class GNBlock:
         mk = lambda T, d: torch.empty((R, T, d), dtype=torch.float32, device=dev) if d > 0 else None
         eo, no, go = mk(g.n_edges, oe), mk(g.n_nodes, on), mk(g.n_graphs, og)
         with torch.cuda.device(dev):
-            ws = g.workspace(lib.gnx_block_workspace_bytes(g._h, C.byref(p), R))
+            ws = g.workspace(lib.gnx_block_workspace_bytes(g._h, C.byref(p), R), ("block", self.in_dims, self.out_dims, R))
             check(lib.gnx_block_forward(g._h, C.byref(p), _ptr(ef), _ptr(nf), _ptr(gf), R, _ptr(eo), _ptr(no), _ptr(go),
-                                        ws.data_ptr(), ws.numel(), self.flags if flags is None else flags,
+                                        ws.data_ptr(), ws.numel(), (self.flags if flags is None else flags) | _lib.FLAG_WS_TICKETS,
                                         torch.cuda.current_stream(dev).cuda_stream))
         return NT(g, _jl(eo), _jl(no), _jl(go))  # zero-width outputs are None (gnblock.jl:71-78)
 
@@ -643,7 +649,7 @@ class _BlockFn(torch.autograd.Function):
     the Zygote `rrule` the Julia shim would define).  Tensors are packed [R][T][D]; weights (out, in) column-major."""
 
     @staticmethod
-    def forward(ctx, block, g, R, ef, nf, gf, We, be, Wn, bn, Wg, bg):
+    def forward(ctx, block, g, R, flags, ef, nf, gf, We, be, Wn, bn, Wg, bg):
         lib = _lib.load()
         keep = []
         p = block._c(keep)
@@ -652,21 +658,25 @@ class _BlockFn(torch.autograd.Function):
         mk = lambda T, d: torch.empty((R, T, d), dtype=torch.float32, device=dev) if d > 0 else None
         eo, no, go = mk(g.n_edges, oe), mk(g.n_nodes, on), mk(g.n_graphs, og)
         with torch.cuda.device(dev):
-            ws = g.workspace(lib.gnx_block_workspace_bytes(g._h, C.byref(p), R))
+            ws = g.workspace(lib.gnx_block_workspace_bytes(g._h, C.byref(p), R), ("block", block.in_dims, block.out_dims, R))
             check(lib.gnx_block_forward(g._h, C.byref(p), _ptr(ef), _ptr(nf), _ptr(gf), R, _ptr(eo), _ptr(no), _ptr(go), ws.data_ptr(),
-                                        ws.numel(), block.flags, torch.cuda.current_stream(dev).cuda_stream))
+                                        ws.numel(), flags | _lib.FLAG_WS_TICKETS, torch.cuda.current_stream(dev).cuda_stream))
         ctx.block, ctx.g, ctx.R = block, g, R
-        ctx.saved = (ef, nf, gf, eo, no, go)
+        # tensors go through save_for_backward (no ctx -> output -> grad_fn -> ctx cycle; in-place modification is detected);
+        # ctx keeps only which of the six slots were present
+        six = (ef, nf, gf, eo, no, go)
+        ctx.slots = tuple(t is not None for t in six)
+        ctx.save_for_backward(*[t for t in six if t is not None])
         outs = tuple(o for o in (eo, no, go) if o is not None)
         ctx.present = tuple(o is not None for o in (eo, no, go))
-        ctx.mark_non_differentiable()
         return outs
 
     @staticmethod
     def backward(ctx, *gouts):
         lib = _lib.load()
         block, g, R = ctx.block, ctx.g, ctx.R
-        ef, nf, gf, eo, no, go = ctx.saved
+        sv = iter(ctx.saved_tensors)
+        ef, nf, gf, eo, no, go = (next(sv) if present else None for present in ctx.slots)
         it = iter(gouts)
         ge, gn_, gg = (next(it) if pr else None for pr in ctx.present)
         cont = lambda t: None if t is None else t.contiguous()
@@ -674,7 +684,7 @@ class _BlockFn(torch.autograd.Function):
         keep = []
         p = block._c(keep)
         dev = g.device
-        need = ctx.needs_input_grad  # (block, g, R, ef, nf, gf, We, be, Wn, bn, Wg, bg)
+        need = ctx.needs_input_grad[1:]  # (g, R, flags, ef, nf, gf, We, be, Wn, bn, Wg, bg) -> ef is need[3]
         d_ef = torch.empty_like(ef) if ef is not None and need[3] else None
         d_nf = torch.empty_like(nf) if nf is not None and need[4] else None
         d_gf = torch.empty_like(gf) if gf is not None and need[5] else None
@@ -690,7 +700,7 @@ class _BlockFn(torch.autograd.Function):
                                          _ptr(gg), R, _ptr(d_ef), _ptr(d_nf), _ptr(d_gf), C.byref(grads), ws.data_ptr(), ws.numel(),
                                          torch.cuda.current_stream(dev).cuda_stream))
         gWt = [None if w is None else w.t() for w in gW]  # (out, in) view with column-major storage, like the weights
-        return (None, None, None, d_ef, d_nf, d_gf, gWt[0], gb[0], gWt[1], gb[1], gWt[2], gb[2])
+        return (None, None, None, None, d_ef, d_nf, d_gf, gWt[0], gb[0], gWt[1], gb[1], gWt[2], gb[2])
 
 
 class GNFeedForward:
@@ -759,7 +769,7 @@ class GNCore:
         g, ef, nf, gf, R = _forward_common(x, self.dims)
         plist = self._param_list()
         if torch.is_grad_enabled() and any(t.requires_grad for t in [ef, nf, gf] + plist):
-            eo, no, go = _CoreFn.apply(self, g, R, ef, nf, gf, *plist)
+            eo, no, go = _CoreFn.apply(self, g, R, self.flags if flags is None else flags, ef, nf, gf, *plist)
             return NT(g, _jl(eo), _jl(no), _jl(go))
         lib = _lib.load()
         keep = []
@@ -767,10 +777,10 @@ class GNCore:
         dev = g.device
         eo, no, go = torch.empty_like(ef), torch.empty_like(nf), torch.empty_like(gf)
         with torch.cuda.device(dev):
-            ws = g.workspace(lib.gnx_core_workspace_bytes(g._h, C.byref(p), R))
+            ws = g.workspace(lib.gnx_core_workspace_bytes(g._h, C.byref(p), R), ("core", self.dims, R))
             check(lib.gnx_core_forward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), R, eo.data_ptr(),
                                        no.data_ptr(), go.data_ptr(), ws.data_ptr(), ws.numel(),
-                                       self.flags if flags is None else flags, torch.cuda.current_stream(dev).cuda_stream))
+                                       (self.flags if flags is None else flags) | _lib.FLAG_WS_TICKETS, torch.cuda.current_stream(dev).cuda_stream))
         return NT(g, _jl(eo), _jl(no), _jl(go))
 
 
@@ -778,24 +788,25 @@ class _CoreFn(torch.autograd.Function):
     """torch autograd node of one GNCore call: forward = gnx_core_forward, backward = gnx_core_backward."""
 
     @staticmethod
-    def forward(ctx, core, g, R, ef, nf, gf, *params):
+    def forward(ctx, core, g, R, flags, ef, nf, gf, *params):
         lib = _lib.load()
         keep = []
         p = core._c(keep)
         dev = g.device
         eo, no, go = torch.empty_like(ef), torch.empty_like(nf), torch.empty_like(gf)
         with torch.cuda.device(dev):
-            ws = g.workspace(lib.gnx_core_workspace_bytes(g._h, C.byref(p), R))
+            ws = g.workspace(lib.gnx_core_workspace_bytes(g._h, C.byref(p), R), ("core", core.dims, R))
             check(lib.gnx_core_forward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), R, eo.data_ptr(), no.data_ptr(),
-                                       go.data_ptr(), ws.data_ptr(), ws.numel(), core.flags, torch.cuda.current_stream(dev).cuda_stream))
-        ctx.core, ctx.g, ctx.R, ctx.saved = core, g, R, (ef, nf, gf)
+                                       go.data_ptr(), ws.data_ptr(), ws.numel(), flags | _lib.FLAG_WS_TICKETS, torch.cuda.current_stream(dev).cuda_stream))
+        ctx.core, ctx.g, ctx.R = core, g, R
+        ctx.save_for_backward(ef, nf, gf)
         return eo, no, go
 
     @staticmethod
     def backward(ctx, ge, gn_, gg):
         lib = _lib.load()
         core, g, R = ctx.core, ctx.g, ctx.R
-        ef, nf, gf = ctx.saved
+        ef, nf, gf = ctx.saved_tensors
         dev = g.device
         cont = lambda t: None if t is None else t.contiguous()
         ge, gn_, gg = cont(ge), cont(gn_), cont(gg)
@@ -821,7 +832,7 @@ class _CoreFn(torch.autograd.Function):
             check(lib.gnx_core_backward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), _ptr(ge), _ptr(gn_), _ptr(gg), R,
                                         d_ef.data_ptr(), d_nf.data_ptr(), d_gf.data_ptr(), C.byref(gr), ws.data_ptr(), ws.numel(),
                                         torch.cuda.current_stream(dev).cuda_stream))
-        return (None, None, None, d_ef, d_nf, d_gf, *out)
+        return (None, None, None, None, d_ef, d_nf, d_gf, *out)
 
 
 class GNCoreList:
@@ -848,7 +859,8 @@ class BlockPlan:
         self.lib = _lib.load()
         with torch.cuda.device(g.device):
             nbytes = self.lib.gnx_block_workspace_bytes(g._h, C.byref(self.p), self.R)
-        self.ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=g.device)
+        self.ws = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=g.device)  # zero-filled = gnx_block_workspace_init
+        self.flags |= _lib.FLAG_WS_TICKETS
 
     def outputs(self):
         oe, on, og = self.block.out_dims
@@ -866,7 +878,12 @@ class BlockPlan:
                                          _ptr(go), ws.data_ptr(), ws.numel(), flags, s))
 
     def new_workspace(self):
-        return torch.empty_like(self.ws)
+        """A further initialised workspace (one per buffer set when steps on different sets may overlap)."""
+        ws = torch.empty_like(self.ws)
+        with torch.cuda.device(self.g.device):
+            check(self.lib.gnx_block_workspace_init(self.g._h, C.byref(self.p), self.R, ws.data_ptr(), ws.numel(),
+                                                    torch.cuda.current_stream(self.g.device).cuda_stream))
+        return ws
 
     def graph_update(self, gf, go, stream=None, ws=None):
         s = torch.cuda.current_stream(self.g.device).cuda_stream if stream is None else stream

@@ -18,7 +18,8 @@ struct Tile {
   int g;        // graph id
   int win0;     // [win0, win1): the graph's node range — every source of the tile's edges lies inside it
   int win1;
-  int flags;    // reserved (keeps the record 32 B = one s_load_dwordx8)
+  int flags;    // wave tiles: number of wave tiles of graph g (the arrival count of the graph's ticket); else 0.
+                // Keeps the record 32 B = one s_load_dwordx8.
 };
 
 // Everything a block-forward kernel needs, passed by value (lives in SGPRs / kernarg segment).
@@ -46,6 +47,11 @@ struct BlockArgs {
   const float* ln_b[3];
   float ln_eps;
   int ln_mode;
+  // single-launch graph update (fused narrow path, GNX_FLAG_WS_TICKETS): arrival counters in the workspace, zero before the
+  // launch and zero again after it (the last arriver resets its counter).  One graph: tickets[r] counts workgroups of replica
+  // r; several graphs: tickets[g] counts the wave tiles of graph g.  nullptr <=> two-launch form (k_graph_t).
+  unsigned* tickets;
+  int nf_prefetch_bytes;  // one graph: bytes of nf (per replica) every XCD pulls into its L2 at kernel start; 0 = off
 };
 
 // activation codes = GNX_ACT_* of include/gnx.h (static_assert'ed in gnx_forward.hip)

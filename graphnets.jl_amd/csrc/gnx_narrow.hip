@@ -18,22 +18,43 @@
 
 namespace gnx {
 
+// Does the single-launch form (graph update by the last arriver, BlockArgs::tickets) apply?  The tail reuses the kernel's
+// LDS: the whole workgroup's slices (one graph: 256 threads) or the finishing wave's own slice (several graphs: 64 threads).
+static bool ticket_fits(const BlockArgs& a, int ept, bool oneg) {
+  if (!a.tickets || a.og <= 0 || a.oe + a.on <= 0) return false;
+  const int have = wave_slice_floats(a.oe, ept) * (oneg ? kThreads / 64 : 1);
+  return graph_update_lds_floats(a.oe + a.on, a.dg, a.og, oneg ? kThreads : 64) <= have;
+}
+
+static void graph_launch_geometry(const gnx_graphs* h, const BlockArgs& a, int C, int* threads, size_t* lds) {
+  // block size by the number of partial rows per graph: 1024 threads cover 4096 rows per pass
+  const int64_t rows_per_graph = h->G == 1 ? (h->n_wtiles() + 3) / 4 : (h->n_wtiles() + h->G - 1) / h->G;  // G == 1: one row per workgroup
+  *threads = rows_per_graph > 1024 ? 1024 : (rows_per_graph > 128 ? 256 : 64);
+  *lds = sizeof(float) * (size_t)graph_update_lds_floats(C, a.dg, a.og, *threads);
+}
+
 template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN, bool ONEG>
 static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   constexpr int C = OE + ON;
   const int prow_stride = (int)((h->n_wtiles() + 3) / 4 * 4 + 4);
   const unsigned grid = (unsigned)((a.n_wtiles + 3) / 4);
+  // single launch only when the whole block is asked for (phase 3): a deferred graph update keeps the two-launch form
+  const bool ticket = phase == 3 && ticket_fits(a, EPT, ONEG);
   if (phase & 1) {
     ProfScope ps("k_block_wave", s);
-    hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, prow_stride);
+    if (ticket) hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG, true>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, prow_stride);
+    else {
+      BlockArgs b = a;
+      b.tickets = nullptr;
+      hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG, false>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, b, prow_stride);
+    }
     GNX_HIP(hipGetLastError());
   }
-  if ((phase & 2) && a.og > 0) {
+  if ((phase & 2) && a.og > 0 && !ticket) {
     if constexpr (C > 0) {
-      // block size by the number of partial rows per graph: 1024 threads cover 4096 rows per pass
-      const int64_t rows_per_graph = h->G == 1 ? (h->n_wtiles() + 3) / 4 : (h->n_wtiles() + h->G - 1) / h->G;  // G == 1: one row per workgroup
-      const int threads = rows_per_graph > 1024 ? 1024 : (rows_per_graph > 128 ? 256 : 64);
-      const size_t lds = sizeof(float) * ((size_t)(threads / 16) * C + (C + a.dg + 4) + (size_t)(C + a.dg + 1) * a.og + 8);
+      int threads;
+      size_t lds;
+      graph_launch_geometry(h, a, C, &threads, &lds);
       ProfScope ps("k_graph_t", s);
       hipLaunchKernelGGL((k_graph_t<C, ONEG>), dim3((unsigned)a.G, (unsigned)R), dim3(threads), lds, s, a, prow_stride);
       GNX_HIP(hipGetLastError());
@@ -71,27 +92,33 @@ static int32_t launch_fused(const gnx_graphs* h, const BlockArgs& a, int64_t R, 
   X(10, 5, 0, 10, 5)
 
 bool jit_eligible(const BlockArgs& a, int ept);
-int32_t jit_get(const BlockArgs& a, int ept, hipStream_t s, hipFunction_t* block, hipFunction_t* graph);
+int32_t jit_get(const BlockArgs& a, int ept, bool ticket, hipStream_t s, hipFunction_t* block, hipFunction_t* graph);
 
 // Same launch geometry as launch_wave_t, kernels specialised at run time (gnx_jit.cpp) for this width set.
 static int32_t launch_wave_jit(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   const int ept = h->wtile_e_cap / 64;
   if (ept * 64 != h->wtile_e_cap || (ept != 1 && ept != 2 && ept != 4)) return 1;
+  bool ticket = phase == 3 && ticket_fits(a, ept, h->G == 1);
   hipFunction_t fb = nullptr, fg = nullptr;
-  const int32_t rc = jit_get(a, ept, s, &fb, &fg);
+  int32_t rc = jit_get(a, ept, ticket, s, &fb, &fg);
+  if (rc == 1 && ticket) {  // single-launch variant not loaded (first seen inside a capture): the two-launch pair may be
+    ticket = false;
+    rc = jit_get(a, ept, false, s, &fb, &fg);
+  }
   if (rc) return rc;
   const int C = a.oe + a.on;
   BlockArgs aa = a;
+  if (!ticket) aa.tickets = nullptr;
   int prow_stride = (int)((h->n_wtiles() + 3) / 4 * 4 + 4);
   void* params[] = {&aa, &prow_stride};
   if (phase & 1) {
     ProfScope ps("k_block_wave", s);
     GNX_HIP(hipModuleLaunchKernel(fb, (unsigned)((a.n_wtiles + 3) / 4), (unsigned)R, 1, kThreads, 1, 1, 0, s, params, nullptr));
   }
-  if ((phase & 2) && a.og > 0) {
-    const int64_t rows_per_graph = h->G == 1 ? (h->n_wtiles() + 3) / 4 : (h->n_wtiles() + h->G - 1) / h->G;
-    const int threads = rows_per_graph > 1024 ? 1024 : (rows_per_graph > 128 ? 256 : 64);
-    const size_t lds = sizeof(float) * ((size_t)(threads / 16) * C + (C + a.dg + 4) + (size_t)(C + a.dg + 1) * a.og + 8);
+  if ((phase & 2) && a.og > 0 && !ticket) {
+    int threads;
+    size_t lds;
+    graph_launch_geometry(h, a, C, &threads, &lds);
     ProfScope ps("k_graph_t", s);
     GNX_HIP(hipModuleLaunchKernel(fg, (unsigned)a.G, (unsigned)R, 1, threads, 1, 1, (unsigned)lds, s, params, nullptr));
   }
@@ -110,7 +137,9 @@ void warm_block_narrow(const gnx_graphs* h, const gnx_block_params* p) {
 #undef GNX_CASE
   if (h->n_wtiles() == 0 || h->E == 0) return;
   hipFunction_t fb, fg;
-  (void)jit_get(a, h->wtile_e_cap / 64, nullptr, &fb, &fg);
+  (void)jit_get(a, h->wtile_e_cap / 64, false, nullptr, &fb, &fg);
+  a.tickets = reinterpret_cast<unsigned*>(1);  // (only tested for non-NULL) also the single-launch variant, if it fits
+  if (ticket_fits(a, h->wtile_e_cap / 64, h->G == 1)) (void)jit_get(a, h->wtile_e_cap / 64, true, nullptr, &fb, &fg);
 }
 
 static bool wants_ln(const BlockArgs& a) { return a.ln_g[0] || a.ln_g[1] || a.ln_g[2]; }
@@ -137,7 +166,7 @@ bool block_narrow_ready(const gnx_graphs* h, const BlockArgs& a, hipStream_t s) 
   const int ept = h->wtile_e_cap / 64;
   if (ept * 64 != h->wtile_e_cap || (ept != 1 && ept != 2 && ept != 4)) return false;
   hipFunction_t fb, fg;
-  return jit_get(a, ept, s, &fb, &fg) == GNX_OK;
+  return jit_get(a, ept, false, s, &fb, &fg) == GNX_OK;
 }
 
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {

@@ -179,6 +179,133 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // =========================================================================================================
+// Graph update from the transposed partial sums [C][prow_stride]:
+//   gf'[g] = act(Wg * [sum_e ef' ; sum_n nf' ; gf_g] + bg)                       (graphfninput.jl:1-13, gnblock.jl:67)
+// Shared by k_graph_t (its own launch, plain loads) and by the tail of k_block_wave<..., TICKET> (executed by the
+// workgroup / wave whose ticket add came last; WT: the partial sums were stored write-through by OTHER workgroups, so
+// every load of them is an sc1 load — MI355X_MICROARCH "Valid forms": sc1 payload, drained, agent-scope ticket add,
+// last arriver loads sc1 after its add has returned).
+// Latency is everything here (a few KB of work): EVERY global load — this thread's partial quads, its slice of
+// Wg / bg / gf — is issued before the first wait; the sums are reduced with DPP + one LDS hop in a fixed order, which
+// depends only on (t0, t1, nthr): results are bitwise reproducible whichever workgroup arrives last.
+// WAVE: executed by ONE wavefront (nthr = 64) — LDS operations of one wave execute in order, no workgroup barrier.
+// s_g: (nthr/16)*C + (C+dg+4) + (C+dg+1)*og floats of LDS.
+// =========================================================================================================
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+template <int C, int MAXQ, bool WT, bool WAVE>
+__device__ __forceinline__ void graph_update_rows(const BlockArgs& a, int prow_stride, int g, size_t r, int t0, int t1, int tid, int nthr, float* s_g) {
+  const float* __restrict__ base = a.partials + r * C * (size_t)prow_stride;
+  const int K = C + a.dg, og = a.og;
+  const int nrow16 = nthr >> 4;
+  float* s_x = s_g + (size_t)nrow16 * C;  // [K]   graph-function input
+  float* s_w = s_x + K + 4;               // [K*og] weights, [og] bias
+
+  // prefetch weights / bias / gf (tiny, L2) — independent of the partial sums
+  const int nw = K * og;
+  float w_reg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + i * nthr;
+    w_reg[i] = idx < nw ? a.Wg[idx] : (idx < nw + og ? (a.bg ? a.bg[idx - nw] : 0.f) : 0.f);
+  }
+  float gf_reg = 0.f;
+  if (tid < a.dg) gf_reg = a.gf[(r * (size_t)a.G + g) * a.dg + tid];
+
+  float acc[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) acc[c] = 0.f;
+  // columns in passes of <= CC so that the in-flight quads (MAXQ * CC float4) stay in registers for any C
+  constexpr int CC = C <= 8 ? C : 8;
+#pragma unroll
+  for (int cb = 0; cb < C; cb += CC) {
+    for (int q0 = (t0 >> 2) + tid; 4 * q0 < t1; q0 += MAXQ * nthr) {
+      float4 val[MAXQ][CC];
+#pragma unroll
+      for (int u = 0; u < MAXQ; ++u) {
+        const int q = q0 + u * nthr;
+        if (4 * q < t1) {
+#pragma unroll
+          for (int c = 0; c < CC; ++c)
+            if (cb + c < C) {
+              const float* src = base + (size_t)(cb + c) * prow_stride + 4 * q;
+              if constexpr (WT) {
+                // 16-B sc1 load (bypasses this CU's L1, which other workgroups' stores never refresh)
+                const v4u_t x = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 16, 0x00020000), 0, 0, 16);
+                val[u][c] = make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+              } else {
+                val[u][c] = *reinterpret_cast<const float4*>(src);
+              }
+            }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < MAXQ; ++u) {
+        const int row = 4 * (q0 + u * nthr);
+        if (row < t1) {
+          const bool k0 = row >= t0, k1 = row + 1 >= t0 && row + 1 < t1, k2 = row + 2 >= t0 && row + 2 < t1, k3 = row + 3 < t1;
+#pragma unroll
+          for (int c = 0; c < CC; ++c)
+            if (cb + c < C)
+              acc[cb + c] += ((k0 ? val[u][c].x : 0.f) + (k1 ? val[u][c].y : 0.f)) + ((k2 ? val[u][c].z : 0.f) + (k3 ? val[u][c].w : 0.f));
+        }
+      }
+    }
+  }
+  // weights to LDS (loads have long since landed)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + i * nthr;
+    if (idx < nw + og) s_w[idx] = w_reg[i];
+  }
+  for (int idx = tid + 4 * nthr; idx < nw + og; idx += nthr) s_w[idx] = idx < nw ? a.Wg[idx] : (a.bg ? a.bg[idx - nw] : 0.f);
+  if (a.ln_g[2] && a.dg > 0) {  // GNCore: the graph function sees gn1(gf); a few values, every thread computes the statistics
+    const float* gp = a.gf + (r * (size_t)a.G + g) * a.dg;
+    float mu = 0.f;
+    for (int k = 0; k < a.dg; ++k) mu += gp[k];
+    mu /= (float)a.dg;
+    float var = 0.f;
+    for (int k = 0; k < a.dg; ++k) { const float c = gp[k] - mu; var = fmaf(c, c, var); }
+    var /= (float)a.dg;
+    const float rstd = a.ln_mode == 0 ? 1.f / (sqrtf(var) + a.ln_eps) : 1.f / sqrtf(var + a.ln_eps);
+    for (int k = tid; k < a.dg; k += nthr) s_x[C + k] = fmaf(a.ln_g[2][k], (gp[k] - mu) * rstd, a.ln_b[2][k]);
+  } else {
+    if (tid < a.dg) s_x[C + tid] = gf_reg;
+    for (int k = tid + nthr; k < a.dg; k += nthr) s_x[C + k] = a.gf[(r * (size_t)a.G + g) * a.dg + k];
+  }
+  const int lane = tid & 63, row16 = tid >> 4;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float x = row16_sum(acc[c]);
+    if ((lane & 15) == 0) s_g[row16 * C + c] = x;
+  }
+  if constexpr (WAVE) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+  // second stage: wave 0 sums the <= 64 row sums of every column (fixed order: DPP tree + 4 readlanes)
+  if (tid < 64) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float x = wave_sum(tid < nrow16 ? s_g[tid * C + c] : 0.f);
+      if (tid == 0) s_x[c] = x;
+    }
+  }
+  if constexpr (WAVE) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+  float* out = a.gf_out + (r * (size_t)a.G + g) * og;
+  for (int j = tid; j < og; j += nthr) {
+    float y = s_w[nw + j];
+    for (int k = 0; k < K; ++k) y = fmaf(s_w[k * og + j], s_x[k], y);
+    out[j] = act_apply(y, a.act_g);
+  }
+}
+
+// LDS floats graph_update_rows needs with nthr threads (host side: decides whether the single-launch form fits)
+__host__ __device__ constexpr int graph_update_lds_floats(int C, int dg, int og, int nthr) {
+  return (nthr / 16) * C + (C + dg + 4) + (C + dg + 1) * og + 8;
+}
+// per-wave LDS slice of k_block_wave, in floats: [ef' of the tile | per-node projections | tile-local dst of each edge]
+__host__ __device__ constexpr int wave_slice_floats(int OE, int EPT) {
+  return (64 * EPT * OE + 4) + (64 * OE + 4) + (64 * EPT + 4 + 15) / 16 * 4;
+}
+
+// =========================================================================================================
 // k_block_wave — the whole GNBlock edge + node update, ONE WAVEFRONT PER TILE.
 //
 // A wave tile is a node range of one graph with <= 64 nodes and <= 64*EPT in-edges (contiguous, CSC order).  The
@@ -190,36 +317,44 @@ __device__ __forceinline__ float wave_sum(float v) {
 //   lanes as NODES : lane n < nn — colptr, own nf row, pd[n] = b + We[:,dst]*nf[n] (+ gf fold), segmented sum of
 //                    ef' from LDS, node update, store
 // =========================================================================================================
-// LN: LayerNorm the inputs on load (BlockArgs::ln_*).  ONEG: the batch is ONE graph (see below)
-template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false>
-__global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_stride) {
+// LN: LayerNorm the inputs on load (BlockArgs::ln_*).  ONEG: the batch is ONE graph (see below).
+// TICKET: the graph update runs inside this launch — the workgroup (ONEG) / wave (several graphs) whose ticket add
+// comes last reduces the partial sums and writes gf'; otherwise k_graph_t does it in a second launch.
+// SGPR budget: a CU admits floor(800 / (ceil(sgpr/16)*16 + 16)) 256-thread workgroups (MI355X_MICROARCH, residency): 8 up to 80
+// SGPRs, 7 up to 96, 6 beyond.  C2 is 2032 workgroups = ONE round at 8 per CU (2048 slots) but 1.13 rounds at 7.
+#ifndef GNX_WAVE_SGPRS
+#define GNX_WAVE_SGPRS 80
+#endif
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false, bool TICKET = false>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_SGPRS))) void k_block_wave(BlockArgs a, int prow_stride) {
   constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1, DG1 = DG > 0 ? DG : 1;
   constexpr int TEW = 64 * EPT;
   constexpr int C = OE + ON, C1 = C > 0 ? C : 1;
   constexpr int WAVES = kThreads / 64;
-  __shared__ __attribute__((aligned(16))) float s_out_all[WAVES][TEW * OE + 4];  // ef' of the wave's tile
-  __shared__ __attribute__((aligned(16))) float s_pd_all[WAVES][64 * OE + 4];    // per node: bias' + We[:, dst-seg]*nf[n]
-  __shared__ unsigned char s_dst_all[WAVES][TEW + 4];                             // tile-local destination of each edge
+  constexpr int WSL = wave_slice_floats(OE, EPT);
+  __shared__ __attribute__((aligned(16))) float s_mem[WAVES * WSL];  // one slice per wave (the TICKET tail reuses it)
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wt = __builtin_amdgcn_readfirstlane(xcd_tile(blockIdx.x, gridDim.x) * WAVES + wv);
   // ONEG (one graph): the four waves of a workgroup all belong to it, so their graph-update partial sums are added in the
-  // workgroup (one barrier at the very end) and k_graph_t reads a quarter of the rows.  Several graphs: a workgroup may
+  // workgroup (one barrier at the very end) and the graph update reads a quarter of the rows.  Several graphs: a workgroup may
   // straddle two graphs, every wave stores its own row and the kernel has no workgroup barrier at all.  (A template
   // parameter, not a run-time branch: the mere presence of the barrier path cost the multi-graph case 4 %.)
   const bool active = wt < a.n_wtiles;  // wave-uniform
   if constexpr (!ONEG) { if (!active) return; }
   float mine = 0.f;  // lane c < C: this wave's total of graph-update column c
+  int tile_g = 0, tile_cnt = 0;
   do {
   if constexpr (ONEG) { if (!active) break; }
-  float* s_out = s_out_all[wv];
-  float* s_pd = s_pd_all[wv];
-  unsigned char* s_dst = s_dst_all[wv];
+  float* s_out = s_mem + wv * WSL;                                        // ef' of the wave's tile
+  float* s_pd = s_out + (TEW * OE + 4);                                   // per node: bias' + We[:, dst-seg]*nf[n]
+  unsigned char* s_dst = reinterpret_cast<unsigned char*>(s_pd + (64 * OE + 4));  // tile-local destination of each edge
 
   typedef const int __attribute__((address_space(4))) * cintp;
   const cintp tw = reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.wtiles)) + (size_t)wt * (sizeof(Tile) / sizeof(int));
   const int n0 = tw[0], n1 = tw[1], e0 = tw[2], e1 = tw[3], g = tw[4];  // s_load_dwordx8
+  if constexpr (TICKET && !ONEG) { tile_g = g; tile_cnt = tw[7]; }
   const int nn = n1 - n0, ne = e1 - e0;
 
   const size_t r = blockIdx.y;
@@ -230,6 +365,15 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
   const cfloatp Wn = as_const(a.Wn);
   const cfloatp be = as_const(a.be ? a.be : k_zero_bias);
   const cfloatp bn = as_const(a.bn ? a.bn : k_zero_bias);
+
+  // ---- one graph: every XCD pulls the whole node table into its L2 as a coalesced stream while the edge rows are on their
+  //      way (blocks b and b+8 share an XCD), instead of discovering it line by line through the 20-byte gathers.  One dword
+  //      per 64 bytes; the value is consumed (below) where the edge rows are waited for anyway (loads return in order). ----
+  float pf = 0.f;
+  if constexpr (ONEG && DN > 0) {
+    const int off = (((int)blockIdx.x >> 3) * WAVES + wv) * 4096 + lane * 64;
+    if (off < a.nf_prefetch_bytes) pf = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(nf) + off);
+  }
 
   // ---- issue every load up front, branch-free (indices clamped into the tile; results of clamped lanes unused) ----
   const bool is_node = lane < nn;
@@ -254,6 +398,7 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
 #pragma unroll
     for (int i = 0; i < EPT; ++i) load_row<DN>(nf + (size_t)src[i] * DN, xs[i]);
   }
+  if constexpr (ONEG && DN > 0) asm volatile("" ::"v"(pf));
 
   float gfr[1][DG1];
 #pragma unroll
@@ -413,7 +558,7 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
   }
 
   // ---- per-tile partial sums for the graph update (graphfninput.jl:3-4): sum_e ef' = sum_n agg[n], sum_n nf'.
-  //      Stored transposed [c][tile] so the graph kernel reads them with 16-B loads. ----
+  //      Stored transposed [c][tile] so the graph update reads them with 16-B loads. ----
   if (a.og > 0) {
     if constexpr (C > 0) {
 #pragma unroll
@@ -429,123 +574,64 @@ __global__ __launch_bounds__(kThreads) void k_block_wave(BlockArgs a, int prow_s
       const size_t r = blockIdx.y;
       if constexpr (ONEG) {
         __shared__ float s_blk[WAVES][C1];
+        __shared__ int s_last;
         if (lane < C) s_blk[wv][lane] = mine;
         __syncthreads();
-        if (wv == 0 && lane < C) {
-          const float tot = (s_blk[0][lane] + s_blk[1][lane]) + (s_blk[2][lane] + s_blk[3][lane]);
-          a.partials[(r * C + lane) * (size_t)prow_stride + xcd_tile(blockIdx.x, gridDim.x)] = tot;
+        if (wv == 0) {
+          if (lane < C) {
+            const float tot = (s_blk[0][lane] + s_blk[1][lane]) + (s_blk[2][lane] + s_blk[3][lane]);
+            float* dst = a.partials + (r * C + lane) * (size_t)prow_stride + xcd_tile(blockIdx.x, gridDim.x);
+            if constexpr (TICKET) __hip_atomic_store(dst, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through (sc1)
+            else *dst = tot;
+          }
+          if constexpr (TICKET) {
+            // the storing wave drains its write-through stores, THEN one lane takes the workgroup's ticket
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned prev = 0;
+            if (lane == 0) prev = __hip_atomic_fetch_add(a.tickets + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prev = __builtin_amdgcn_readfirstlane(prev);
+            if (lane == 0) s_last = prev == gridDim.x - 1 ? 1 : 0;
+          }
+        }
+        if constexpr (TICKET) {
+          __syncthreads();  // the ticket add has returned before any wave of the last workgroup loads a partial sum
+          if (s_last) {
+            __syncthreads();  // (every wave has read s_last before the scratch below is reused)
+            graph_update_rows<C, 1, true, false>(a, prow_stride, 0, r, 0, (int)gridDim.x, (int)threadIdx.x, kThreads, s_mem);
+            if (threadIdx.x == 0) __hip_atomic_store(a.tickets + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+          }
         }
       } else {
-        if (lane < C) a.partials[(r * C + lane) * (size_t)prow_stride + wt] = mine;
+        if (lane < C) {
+          float* dst = a.partials + (r * C + lane) * (size_t)prow_stride + wt;
+          if constexpr (TICKET) __hip_atomic_store(dst, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *dst = mine;
+        }
+        if constexpr (TICKET) {
+          // one ticket per GRAPH, counted in wave tiles: the wave that completes its graph reduces the graph's rows
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          unsigned prev = 0;
+          if (lane == 0) prev = __hip_atomic_fetch_add(a.tickets + tile_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          prev = __builtin_amdgcn_readfirstlane(prev);
+          if ((int)prev == tile_cnt - 1) {
+            const int t0 = a.wtile_off[tile_g];
+            graph_update_rows<C, 1, true, true>(a, prow_stride, tile_g, r, t0, t0 + tile_cnt, lane, 64, s_mem + wv * WSL);
+            if (lane == 0) __hip_atomic_store(a.tickets + tile_g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
       }
     }
   }
 }
 
-// Graph update for the wave path: gf'[g] = act(Wg * [sum_e ef' ; sum_n nf' ; gf_g] + bg) from transposed partials
-// [C][prow_stride].  Latency is everything here (a few KB of work): EVERY global load — this thread's partial quads,
-// its slice of Wg / bg / gf — is issued before the first wait, so the kernel pays one memory round trip; the sums
-// are reduced with DPP + one LDS hop in a fixed order.
+// Graph update for the wave path as its own launch (two-launch form): one workgroup per graph.
 template <int C, bool ONEG = false>
 __global__ void k_graph_t(BlockArgs a, int prow_stride) {
   extern __shared__ float s_g[];
-  constexpr int MAXQ = 2;  // quads per thread kept in registers per pass
   const int g = blockIdx.x;
-  const size_t r = blockIdx.y;
-  const int tid = threadIdx.x, nthr = blockDim.x;
   // one graph: k_block_wave stored one row per WORKGROUP (4 wave tiles); several graphs: one row per wave tile
   const int t0 = ONEG ? 0 : a.wtile_off[g], t1 = ONEG ? (a.n_wtiles + 3) / 4 : a.wtile_off[g + 1];
-  const float* __restrict__ base = a.partials + r * C * (size_t)prow_stride;
-  const int K = C + a.dg, og = a.og;
-  const int nrow16 = nthr >> 4;
-  float* s_x = s_g + (size_t)nrow16 * C;  // [K]   graph-function input
-  float* s_w = s_x + K + 4;               // [K*og] weights, [og] bias
-
-  // prefetch weights / bias / gf (tiny, L2) — independent of the partial sums
-  const int nw = K * og;
-  float w_reg[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + i * nthr;
-    w_reg[i] = idx < nw ? a.Wg[idx] : (idx < nw + og ? (a.bg ? a.bg[idx - nw] : 0.f) : 0.f);
-  }
-  float gf_reg = 0.f;
-  if (tid < a.dg) gf_reg = a.gf[(r * (size_t)a.G + g) * a.dg + tid];
-
-  float acc[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) acc[c] = 0.f;
-  // columns in passes of <= CC so that the in-flight quads (MAXQ * CC float4) stay in registers for any C
-  constexpr int CC = C <= 8 ? C : 8;
-#pragma unroll
-  for (int cb = 0; cb < C; cb += CC) {
-    for (int q0 = (t0 >> 2) + tid; 4 * q0 < t1; q0 += MAXQ * nthr) {
-      float4 val[MAXQ][CC];
-#pragma unroll
-      for (int u = 0; u < MAXQ; ++u) {
-        const int q = q0 + u * nthr;
-        if (4 * q < t1) {
-#pragma unroll
-          for (int c = 0; c < CC; ++c)
-            if (cb + c < C) val[u][c] = *reinterpret_cast<const float4*>(base + (size_t)(cb + c) * prow_stride + 4 * q);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < MAXQ; ++u) {
-        const int row = 4 * (q0 + u * nthr);
-        if (row < t1) {
-          const bool k0 = row >= t0, k1 = row + 1 >= t0 && row + 1 < t1, k2 = row + 2 >= t0 && row + 2 < t1, k3 = row + 3 < t1;
-#pragma unroll
-          for (int c = 0; c < CC; ++c)
-            if (cb + c < C)
-              acc[cb + c] += ((k0 ? val[u][c].x : 0.f) + (k1 ? val[u][c].y : 0.f)) + ((k2 ? val[u][c].z : 0.f) + (k3 ? val[u][c].w : 0.f));
-        }
-      }
-    }
-  }
-  // weights to LDS (loads have long since landed)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + i * nthr;
-    if (idx < nw + og) s_w[idx] = w_reg[i];
-  }
-  for (int idx = tid + 4 * nthr; idx < nw + og; idx += nthr) s_w[idx] = idx < nw ? a.Wg[idx] : (a.bg ? a.bg[idx - nw] : 0.f);
-  if (a.ln_g[2] && a.dg > 0) {  // GNCore: the graph function sees gn1(gf); a few values, every thread computes the statistics
-    const float* gp = a.gf + (r * (size_t)a.G + g) * a.dg;
-    float mu = 0.f;
-    for (int k = 0; k < a.dg; ++k) mu += gp[k];
-    mu /= (float)a.dg;
-    float var = 0.f;
-    for (int k = 0; k < a.dg; ++k) { const float c = gp[k] - mu; var = fmaf(c, c, var); }
-    var /= (float)a.dg;
-    const float rstd = a.ln_mode == 0 ? 1.f / (sqrtf(var) + a.ln_eps) : 1.f / sqrtf(var + a.ln_eps);
-    for (int k = tid; k < a.dg; k += nthr) s_x[C + k] = fmaf(a.ln_g[2][k], (gp[k] - mu) * rstd, a.ln_b[2][k]);
-  } else {
-    if (tid < a.dg) s_x[C + tid] = gf_reg;
-    for (int k = tid + nthr; k < a.dg; k += nthr) s_x[C + k] = a.gf[(r * (size_t)a.G + g) * a.dg + k];
-  }
-  const int lane = tid & 63, row16 = tid >> 4;
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float x = row16_sum(acc[c]);
-    if ((lane & 15) == 0) s_g[row16 * C + c] = x;
-  }
-  __syncthreads();
-  // second stage: wave 0 sums the <= 64 row sums of every column (fixed order: DPP tree + 4 readlanes)
-  if (tid < 64) {
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const float x = wave_sum(tid < nrow16 ? s_g[tid * C + c] : 0.f);
-      if (tid == 0) s_x[c] = x;
-    }
-  }
-  __syncthreads();
-  float* out = a.gf_out + (r * (size_t)a.G + g) * og;
-  for (int j = tid; j < og; j += nthr) {
-    float y = s_w[nw + j];
-    for (int k = 0; k < K; ++k) y = fmaf(s_w[k * og + j], s_x[k], y);
-    out[j] = act_apply(y, a.act_g);
-  }
+  graph_update_rows<C, 2, false, false>(a, prow_stride, g, blockIdx.y, t0, t1, (int)threadIdx.x, (int)blockDim.x, s_g);
 }
 
 }  // namespace gnx

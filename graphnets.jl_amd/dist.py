@@ -31,52 +31,83 @@ class GfGather:
 
     Shards may differ by one graph, so every rank contributes `max_count` rows (zero padded) to
     all_gather_into_tensor; a precomputed index table undoes the padding and the partition permutation.
+    `stack` = M > 1: M tables (the gf' of M consecutive steps) travel in ONE collective — send is [M][max_count][dg],
+    the result [M][G][dg] ("fewer, larger collectives": one table is <= 64 KB, pure latency on xGMI).
     On GPUs the collective runs on its own stream so that it overlaps the next forward (xGMI is point-to-point and
-    the message is <= 64 KB/rank: the gather is latency-bound, so hiding it is what matters)."""
+    the message is small: the gather is latency-bound, so hiding it is what matters)."""
 
-    def __init__(self, shards, rank, world_size, dg, device, group=None, overlap=True):
+    def __init__(self, shards, rank, world_size, dg, device, group=None, overlap=True, stack=1):
         self.shards, self.rank, self.world, self.dg, self.device, self.group = shards, rank, world_size, dg, device, group
+        self.stack = int(stack)
         self.max_count = max(len(s) for s in shards)
         self.G = int(sum(len(s) for s in shards))
-        src = np.zeros(self.G, dtype=np.int64)  # row of the gathered [world*max_count] table for original graph id
+        M, mc = self.stack, self.max_count
+        # row of the gathered [world][M][max_count] table for (step m, original graph id)
+        src = np.zeros((M, self.G), dtype=np.int64)
         for r, s in enumerate(shards):
-            src[s] = r * self.max_count + np.arange(len(s))
-        self.src_index = torch.from_numpy(src).to(device)
-        self.send = torch.zeros((self.max_count, dg), dtype=torch.float32, device=device)
-        self.recv = torch.empty((world_size * self.max_count, dg), dtype=torch.float32, device=device)
+            for m in range(M):
+                src[m, s] = (r * M + m) * mc + np.arange(len(s))
+        self.src_index = torch.from_numpy(src.reshape(-1)).to(device)
+        self.send = torch.zeros((M, mc, dg), dtype=torch.float32, device=device)
+        self.recv = torch.empty((world_size * M * mc, dg), dtype=torch.float32, device=device)
         self.is_cuda = torch.device(device).type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=device) if (self.is_cuda and overlap) else None
         self._ready = None
         self._ev = self._ready_ev = None
 
     def start(self, gf_local):
-        """gf_local: (n_local, dg) rows of this rank's graphs (shard order).  Asynchronous on GPUs."""
-        n = gf_local.shape[0]
+        """gf_local: (n_local, dg) rows of this rank's graphs in shard order — or (M, n_local, dg) with stack = M.
+        Asynchronous on GPUs."""
+        g3 = gf_local if gf_local.dim() == 3 else gf_local[None]
+        n = g3.shape[1]
         if self.comm_stream is None:
-            self.send[:n].copy_(gf_local)
-            dist.all_gather_into_tensor(self.recv, self.send, group=self.group) if self.is_cuda else self._gather_cpu()
+            self.send[:, :n].copy_(g3)
+            self.start_inplace()
             return
         if self._ev is None:
             self._ev, self._ready_ev = torch.cuda.Event(), torch.cuda.Event()
         self._ev.record(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(self._ev)
-            self.send[:n].copy_(gf_local, non_blocking=True)
-            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+            self.send[:, :n].copy_(g3, non_blocking=True)
+            dist.all_gather_into_tensor(self.recv, self.send.view(-1, self.dg), group=self.group)
+            self._ready_ev.record(self.comm_stream)
+            self._ready = self._ready_ev
+
+    def start_inplace(self):
+        """The forward wrote its gf' rows straight into `self.send[m, :n_local]` (no staging copy)."""
+        if self.comm_stream is None:
+            if self.is_cuda:
+                dist.all_gather_into_tensor(self.recv, self.send.view(-1, self.dg), group=self.group)
+            else:
+                self._gather_cpu()
+            return
+        if self._ev is None:
+            self._ev, self._ready_ev = torch.cuda.Event(), torch.cuda.Event()
+        self._ev.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(self._ev)
+            dist.all_gather_into_tensor(self.recv, self.send.view(-1, self.dg), group=self.group)
             self._ready_ev.record(self.comm_stream)
             self._ready = self._ready_ev
 
     def _gather_cpu(self):
-        parts = [torch.empty_like(self.send) for _ in range(self.world)]
-        dist.all_gather(parts, self.send, group=self.group)
+        flat = self.send.view(-1, self.dg)
+        parts = [torch.empty_like(flat) for _ in range(self.world)]
+        dist.all_gather(parts, flat, group=self.group)
         self.recv.copy_(torch.cat(parts, dim=0))
 
+    def result(self):
+        """(G, dg) — or (M, G, dg) with stack = M — in original graph order, from the last completed gather."""
+        out = self.recv.index_select(0, self.src_index)
+        return out.view(self.stack, self.G, self.dg) if self.stack > 1 else out
+
     def finish(self):
-        """Full (G, dg) table in original graph order (waits for the collective on the current stream)."""
+        """Waits for the collective on the current stream, then `result()`."""
         if self._ready is not None:
             torch.cuda.current_stream(self.device).wait_event(self._ready)
             self._ready = None
-        return self.recv.index_select(0, self.src_index)
+        return self.result()
 
 
 def sharded_block_forward(forward_fn, x_local, gather: GfGather):

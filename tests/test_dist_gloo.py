@@ -70,3 +70,62 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     p = O.make_block_params(np.random.default_rng(1), (3, 4, 0), (2, 3, 5))
     _, _, gf = O.block_forward_sparse(p, O.csc_from_adj(adjs), np.concatenate(ef)[None], np.concatenate(nf)[None], None)
     np.testing.assert_allclose(np.load(out), gf[0], rtol=1e-6, atol=1e-6)
+
+
+def _stack_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import graphnets_jl_amd  # noqa: F401
+    from graphnets_jl_amd.dist import GfGather, partition_graphs
+    counts = np.random.default_rng(3).integers(1, 50, 7)  # 7 graphs over 2 ranks: unequal shards (4 + 3)
+    shards = partition_graphs(counts, world)
+    ga = GfGather(shards, rank, world, dg=2, device="cpu", stack=3)
+    # row (m, g) of the full table holds [100*m + g, rank that owns g]
+    for m in range(3):
+        for j, gid in enumerate(shards[rank]):
+            ga.send[m, j, 0], ga.send[m, j, 1] = 100 * m + int(gid), rank
+    ga.start_inplace()
+    res = ga.finish()
+    if rank == 0:
+        np.save(out, res.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_stacked_gather_restores_original_graph_order(tmp_path):
+    """M stacked gf' tables in one collective, unequal shards: every (step, graph) row lands at its original graph id."""
+    from graphnets_jl_amd.dist import partition_graphs
+    out = str(tmp_path / "stack.npy")
+    mp.spawn(_stack_worker, args=(2, 29500 + (os.getpid() + 7) % 2000, out), nprocs=2, join=True)
+    res = np.load(out)
+    assert res.shape == (3, 7, 2)
+    shards = partition_graphs(np.random.default_rng(3).integers(1, 50, 7), 2)
+    owner = np.zeros(7)
+    owner[shards[1]] = 1
+    for m in range(3):
+        np.testing.assert_array_equal(res[m, :, 0], 100 * m + np.arange(7))
+        np.testing.assert_array_equal(res[m, :, 1], owner)
+
+
+def test_bench_hetero_generators_and_self_launch(monkeypatch):
+    """bench.py: the heterogeneous batch has exactly the requested totals, a rank can generate just its shard, and
+    `--gpus N` outside torchrun starts N ranks as a child job (never an exec of this process)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    n, e = bench.hetero_spec(5, 4096, 1_000_000)
+    assert len(n) == 4096 and int(e.sum()) == 1_000_000 and n.min() >= 32 and n.max() <= 256 and (e <= n * n).all()
+    cps, rvs, nn = bench.make_hetero(5, 4096, 1_000_000, only=[7, 4000])
+    cp2, rv2 = bench.hetero_graph(5, 4000, n[4000], e[4000])
+    assert nn == [int(n[7]), int(n[4000])] and np.array_equal(cps[1], cp2) and np.array_equal(rvs[1], rv2) and cps[1][-1] == e[4000]
+    seen = {}
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: seen.setdefault("cmd", cmd) and 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert "127.0.0.1" in cmd

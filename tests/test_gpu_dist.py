@@ -1,0 +1,118 @@
+"""BASELINE configs[4] on the GPU: the 4096-graph heterogeneous batch on one MI355X against the oracle, and the by-graph
+sharded path — partition, per-rank forward, all-gather of gf', permutation back to original graph order — through real RCCL
+(world 1) and through 8 virtual ranks on one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import bench
+from oracle import gn_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gn():
+    import graphnets_jl_amd as gn
+    return gn
+
+
+@pytest.mark.parametrize("dims", [((10, 5, 0), (3, 4, 5)), ((10, 5, 3), (10, 5, 3))], ids=["readme", "with-gf"])
+def test_config5_4096_graphs_1m_edges_one_gpu(gn, dims):
+    """BASELINE configs[4]'s batch (C5 law: 4096 graphs, 32..256 nodes, exactly 1M edges, seed 5) on ONE GPU vs the oracle."""
+    colptrs, rowvals, nn = bench.make_hetero(5, 4096, 1_000_000)
+    g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn)
+    assert g.n_graphs == 4096 and g.n_edges == 1_000_000
+    rng = np.random.default_rng(500)
+    p = O.make_block_params(rng, *dims)
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims[0])
+    y = U.block_from_params(gn, p)(U.to_nt(gn, g, ef, nf, gf))
+    ref, scale = O.block_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r, s, name)
+
+
+def _sharded_forward(gn, world, rank, shards, colptrs, rowvals, nn, ef, nf, node_off, edge_off, blk, gather):
+    """What one rank does: handle of ITS graphs, forward on ITS feature rows, gf' rows into the gather's send buffer."""
+    import torch
+    mine = shards[rank]
+    g = gn.GNGraphBatch.from_csc([colptrs[i] for i in mine], [rowvals[i] for i in mine], [nn[i] for i in mine])
+    efl = np.concatenate([ef[0, edge_off[i]:edge_off[i + 1]] for i in mine])[None]
+    nfl = np.concatenate([nf[0, node_off[i]:node_off[i + 1]] for i in mine])[None]
+    plan = gn.BlockPlan(blk, g)
+    eo, no, _ = plan.outputs()
+    plan(torch.from_numpy(efl).to(g.device), torch.from_numpy(nfl).to(g.device), None, eo, no, gather.send[:, :len(mine)])
+    return eo, no
+
+
+def test_by_graph_sharding_eight_virtual_ranks_equals_the_oracle(gn):
+    """The whole N > 1 data path except the wire: 8 shards of the 4096-graph batch run one after the other on this GPU, their
+    send buffers are concatenated exactly as all_gather_into_tensor would, GfGather's index table restores original graph
+    order — gf' of the WHOLE batch (and every shard's ef', nf') equals the oracle's single-process result."""
+    import torch
+    world, G, E = 8, 4096, 1_000_000
+    from graphnets_jl_amd.dist import GfGather, partition_graphs
+    colptrs, rowvals, nn = bench.make_hetero(5, G, E)
+    n_all, e_all = bench.hetero_spec(5, G, E)
+    shards = partition_graphs(e_all, world)
+    assert all(len(s) == G // world for s in shards)
+    loads = np.array([e_all[s].sum() for s in shards], dtype=np.float64)
+    assert loads.max() / loads.mean() < 1.01
+    node_off, edge_off = np.concatenate([[0], np.cumsum(nn)]), np.concatenate([[0], np.cumsum(e_all)])
+    dims = ((10, 5, 0), (3, 4, 5))
+    rng = np.random.default_rng(501)
+    p = O.make_block_params(rng, *dims)
+    ef, nf, _ = U.packed_inputs(rng, 1, E, int(node_off[-1]), G, dims[0])
+    blk = U.block_from_params(gn, p)
+    gathers = [GfGather(shards, r, world, 5, "cuda", overlap=False) for r in range(world)]
+    outs = [_sharded_forward(gn, world, r, shards, colptrs, rowvals, nn, ef, nf, node_off, edge_off, blk, gathers[r]) for r in range(world)]
+    torch.cuda.synchronize()
+    wire = torch.cat([gt.send.view(-1, 5) for gt in gathers], dim=0)  # = all_gather_into_tensor of the 8 send buffers
+    gathers[0].recv.copy_(wire)
+    gf_all = gathers[0].result().cpu().numpy()
+    cp = np.concatenate([[0]] + [c[1:] + edge_off[i] for i, c in enumerate(colptrs)])
+    rv = np.concatenate([r + node_off[i] for i, r in enumerate(rowvals)])
+    ref, scale = O.block_forward_sparse(p, (cp, rv, node_off, edge_off), ef, nf, None, return_scale=True)
+    U.assert_close(gf_all[None], ref[2], scale[2], "gathered gf' in original graph order")
+    for r in range(world):
+        eidx = np.concatenate([np.arange(edge_off[i], edge_off[i + 1]) for i in shards[r]])
+        nidx = np.concatenate([np.arange(node_off[i], node_off[i + 1]) for i in shards[r]])
+        U.assert_close(outs[r][0].cpu().numpy(), ref[0][:, eidx], scale[0][:, eidx], f"ef' of shard {r}")
+        U.assert_close(outs[r][1].cpu().numpy(), ref[1][:, nidx], scale[1][:, nidx], f"nf' of shard {r}")
+
+
+def test_gfgather_through_rccl_world_1(gn):
+    """The collective itself: torch.distributed "nccl" (= RCCL) with one rank, stacked tables, side stream."""
+    import torch
+    import torch.distributed as dist
+    from graphnets_jl_amd.dist import GfGather
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        shards = [np.array([3, 0, 2, 1])[np.argsort([3, 0, 2, 1])]]  # one rank owns every graph
+        ga = GfGather(shards, 0, 1, 5, "cuda", stack=3)
+        x = torch.rand((3, 4, 5), device="cuda")
+        ga.start(x)
+        out = ga.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(out, x)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_bench_force_dist_runs_the_multi_gpu_code_path():
+    """`bench.py --force-dist`: the N > 1 branch (hetero shard, hipGraphs of stacked steps, RCCL all-gather on a side stream)
+    with one rank, as its own process; the JSON line parses and names configs[4]'s workload."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "16", "--warmup", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=850)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 1e9 and "sharded by graph" in line["config"]["workload"]
+    assert line["config"]["graphs_per_gpu"] == 512 and line["roofline"]["frac"] <= 1.0

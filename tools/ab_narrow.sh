@@ -1,0 +1,24 @@
+#!/bin/bash
+# A/B of the fused narrow kernel's variants on the GPU box (each line = one bench.py process; values in us/step).
+# Usage: tools/ab_narrow.sh [extra bench args]   -> gpurun_out/ab_narrow.log
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out; mkdir -p $OUT
+LOG=$OUT/ab_narrow.log; : > $LOG
+run() {  # name, env..., -- args
+  name=$1; shift
+  envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  for rep in 1 2; do
+    line=$(env "${envs[@]}" python3 $REPO/bench.py --no-cpu-baseline --steps 200 "$@" 2>/dev/null | tail -1)
+    echo "$name rep$rep $(echo "$line" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print("us/step", round(d["ms_per_step"]*1e3,2), "warm", round(d["config"].get("warm_ms_per_step",0)*1e3,2), "kernels", r["all_kernels_us"], "frac", r["frac"], "whole", r["frac_whole_step"])' 2>&1)" | tee -a $LOG
+  done
+}
+run ticket_sgpr80 X=1 -- "$@"
+run twolaunch_sgpr80 X=1 -- --two-launch "$@"
+run ticket_noprefetch GNX_NF_PREFETCH_MAX=0 -- "$@"
+run jit_ticket_sgpr80 GNX_JIT_ALL=1 -- "$@"
+run jit_ticket_sgpr102 GNX_JIT_ALL=1 GNX_JIT_DEFS=-DGNX_WAVE_SGPRS=102 -- "$@"
+run jit_twolaunch_sgpr102 GNX_JIT_ALL=1 GNX_JIT_DEFS=-DGNX_WAVE_SGPRS=102 -- --two-launch "$@"
+run hetero_ticket X=1 -- --workload hetero "$@"
+run hetero_twolaunch X=1 -- --workload hetero --two-launch "$@"
+run hetero4096_ticket X=1 -- --workload hetero --hetero-graphs 4096 "$@"
+run hetero4096_twolaunch X=1 -- --workload hetero --hetero-graphs 4096 --two-launch "$@"
