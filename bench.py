@@ -211,6 +211,7 @@ def main():
     ap.add_argument("--workload", choices=["c2", "hetero"], default=None, help="default: c2 at N = 1 (BASELINE configs[1]), hetero at N > 1 (configs[4])")
     ap.add_argument("--hetero-graphs", type=int, default=512, help="graphs per GPU of the hetero workload (C3: 512; C5 on one GPU: 4096)")
     ap.add_argument("--hetero-edges", type=int, default=1_000_000, help="edges per GPU of the hetero workload (C5w: 8000000)")
+    ap.add_argument("--c2-scale", type=float, default=1.0, help="scale C2's nodes and edges by this factor (size sweeps; 1 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--dense-baseline", action="store_true",
@@ -259,7 +260,7 @@ def main():
     # ---- synthetic batch (rank-local shard) ----
     shards = None
     if workload == "c2":
-        colptrs, rowvals, nn = make_c2(seed=2 + rank)
+        colptrs, rowvals, nn = make_c2(seed=2 + rank, N=int(100_000 * args.c2_scale), E=int(1_000_000 * args.c2_scale))
         shards = [np.asarray([r]) for r in range(world)]
         wl_name = ("C2: one shared Erdos-Renyi graph, 100k nodes / 1M edges, batch_size=1 (BASELINE configs[1])" if world == 1 else
                    f"batch of {world} C2-sized Erdos-Renyi graphs (100k nodes / 1M edges each) sharded by graph, one per GPU; gf' all-gathered")

@@ -51,8 +51,17 @@ struct BlockArgs {
   // launch and zero again after it (the last arriver resets its counter).  One graph: tickets[r] counts workgroups of replica
   // r; several graphs: tickets[g] counts the wave tiles of graph g.  nullptr <=> two-launch form (k_graph_t).
   unsigned* tickets;
-  int nf_prefetch_bytes;  // one graph: bytes of nf (per replica) every XCD pulls into its L2 at kernel start; 0 = off
 };
+
+// Arrival counters ("tickets") of the single-launch graph update, in the head of the workspace: every counter on a 128-byte
+// line of its own (counters sharing a line serialise at its memory channel).  One graph: per replica a top counter +
+// kTicketShards shard counters (workgroup b arrives at shard b % 64, a shard's last arriver at the top counter: thousands of adds
+// to ONE word would serialise at ~12 ns each); several graphs: one counter per graph.
+constexpr int kTicketStride = 32;
+constexpr int kTicketShards = 64;
+__host__ __device__ constexpr long ticket_words(long R, long G) {
+  return (G == 1 ? R * (1 + kTicketShards) : G) * kTicketStride;
+}
 
 // activation codes = GNX_ACT_* of include/gnx.h (static_assert'ed in gnx_forward.hip)
 __device__ __forceinline__ float act_apply(float x, int act) {

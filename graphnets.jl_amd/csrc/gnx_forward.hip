@@ -70,13 +70,15 @@ struct BlockWs {
 // gnx_block_workspace_init() is one memset of the head of the buffer.
 static BlockWs block_ws(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
   BlockWs w;
-  w.tick_bytes = align_up(sizeof(unsigned) * (size_t)std::max<int64_t>(R, h->G), 256);
+  w.tick_bytes = align_up(sizeof(unsigned) * (size_t)ticket_words(R, h->G), 256);
   w.agg_off = w.tick_bytes;
   const size_t agg = align_up(sizeof(float) * (size_t)R * h->N * p->oe, 256);
   w.part_off = w.agg_off + agg;
-  const size_t prow = (size_t)std::max<int64_t>(h->n_tiles(), (h->n_wtiles() + 3) / 4 * 4 + 4);
+  // partial-sum rows: generic path [n_tiles][C]; fused narrow path [n_wtiles (or workgroups)][4*ceil(C/4)]
+  const size_t C = (size_t)(p->oe + p->on);
+  const size_t rows_bytes = std::max((size_t)h->n_tiles() * C, (size_t)h->n_wtiles() * ((C + 3) / 4 * 4));
   const size_t wide_part = wide_workspace_bytes(h, p, R);
-  const size_t part = align_up(std::max(sizeof(float) * (size_t)R * prow * (p->oe + p->on), wide_part), 256);
+  const size_t part = align_up(std::max(sizeof(float) * (size_t)R * rows_bytes, wide_part), 256);
   w.total = w.part_off + part + 256;
   return w;
 }
@@ -120,10 +122,6 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   // single-launch graph update: only on a workspace the caller has declared initialised (gnx_block_workspace_init)
   static const bool no_tickets = getenv("GNX_NO_TICKETS") != nullptr;  // A/B measurements
   a.tickets = ((flags & GNX_FLAG_WS_TICKETS) && !no_tickets) ? reinterpret_cast<unsigned*>(ws) : nullptr;
-  // one graph whose node table fits an XCD's L2 (4 MiB, shared with the streams): every XCD prefetches it (gnx_wave_kernel.h)
-  static const int64_t pf_max = getenv("GNX_NF_PREFETCH_MAX") ? atoll(getenv("GNX_NF_PREFETCH_MAX")) : (3 << 20);
-  const int64_t nf_bytes = (int64_t)h->N * p->dn * (int64_t)sizeof(float);
-  a.nf_prefetch_bytes = (h->G == 1 && nf_bytes <= pf_max) ? (int)nf_bytes : 0;
 
   if (ln1) {
     *fused_ln = false;

@@ -41,6 +41,7 @@ struct gnx_graphs {
   int32_t* d_ntile_off = nullptr;
   gnx::Tile* d_wtiles = nullptr;  // [n_wtiles]
   int32_t wtile_e_cap = 0;
+  int32_t max_wtiles_per_graph = 0;
   int32_t tile_e_cap = 0, tile_n_cap = 0;
   // edge collapsing tables (built on first use; the handle stays logically immutable)
   mutable std::once_flag collapse_once;

@@ -179,22 +179,57 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // =========================================================================================================
-// Graph update from the transposed partial sums [C][prow_stride]:
+// Graph update from the per-tile partial sums, rows of CP = 4*ceil(C/4) floats [sum_e ef' ; sum_n nf' ; pad]:
 //   gf'[g] = act(Wg * [sum_e ef' ; sum_n nf' ; gf_g] + bg)                       (graphfninput.jl:1-13, gnblock.jl:67)
 // Shared by k_graph_t (its own launch, plain loads) and by the tail of k_block_wave<..., TICKET> (executed by the
-// workgroup / wave whose ticket add came last; WT: the partial sums were stored write-through by OTHER workgroups, so
-// every load of them is an sc1 load — MI355X_MICROARCH "Valid forms": sc1 payload, drained, agent-scope ticket add,
-// last arriver loads sc1 after its add has returned).
-// Latency is everything here (a few KB of work): EVERY global load — this thread's partial quads, its slice of
-// Wg / bg / gf — is issued before the first wait; the sums are reduced with DPP + one LDS hop in a fixed order, which
-// depends only on (t0, t1, nthr): results are bitwise reproducible whichever workgroup arrives last.
+// workgroup / wave whose ticket add came last; WT: the rows were stored write-through by OTHER workgroups, so every
+// load of them is an sc1 load — MI355X_MICROARCH "Valid forms": sc1 payload, drained, agent-scope ticket add, last
+// arriver loads sc1 after its add has returned).
+// Latency is everything here (a few KB of work): the thread's rows (<= 8 float4 in flight), its slice of Wg / bg / gf
+// are all issued before the first wait; the sums are reduced with DPP + one LDS hop in a fixed order which depends only
+// on (t0, t1, nthr) — both forms use the same nthr, so their results are bitwise equal.
 // WAVE: executed by ONE wavefront (nthr = 64) — LDS operations of one wave execute in order, no workgroup barrier.
 // s_g: (nthr/16)*C + (C+dg+4) + (C+dg+1)*og floats of LDS.
 // =========================================================================================================
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-template <int C, int MAXQ, bool WT, bool WAVE>
-__device__ __forceinline__ void graph_update_rows(const BlockArgs& a, int prow_stride, int g, size_t r, int t0, int t1, int tid, int nthr, float* s_g) {
-  const float* __restrict__ base = a.partials + r * C * (size_t)prow_stride;
+
+// `base` is wave-uniform (derived from kernel arguments): the buffer descriptor lives in SGPRs, the lane's row is the byte
+// offset.  (A descriptor built from a per-lane pointer makes hipcc wrap every access in a readfirstlane "waterfall" loop.)
+template <bool WT>
+__device__ __forceinline__ float4 load_partial4(const float* base, unsigned byte_off) {
+  if constexpr (WT) {
+    // 16-B sc1 load (bypasses this CU's L1, which other workgroups' stores never refresh)
+    const v4u_t x = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000), byte_off, 0, 16);
+    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+  } else {
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+  }
+}
+
+// One partial-sum row: lane c < C holds column c in `mine`; lane q < CP/4 stores columns 4q..4q+3 as ONE 16-byte store
+// (write-through when another workgroup will read it in this launch: a 16-B sc1 store is one fabric write, a dword is too —
+// seven of them per row cost 3x the whole kernel).
+template <int C, bool WT>
+__device__ __forceinline__ void store_partial_row(float mine, float* base, unsigned row_byte_off, int lane) {
+  constexpr int Q = (C + 3) / 4;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    v4u_t v;
+    v.x = __float_as_uint(readlane_f(mine, 4 * q));
+    v.y = 4 * q + 1 < C ? __float_as_uint(readlane_f(mine, 4 * q + 1)) : 0u;
+    v.z = 4 * q + 2 < C ? __float_as_uint(readlane_f(mine, 4 * q + 2)) : 0u;
+    v.w = 4 * q + 3 < C ? __float_as_uint(readlane_f(mine, 4 * q + 3)) : 0u;
+    if (lane == q) {
+      if constexpr (WT) __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000), row_byte_off + 16 * q, 0, 16);
+      else *reinterpret_cast<v4u_t*>(reinterpret_cast<char*>(base) + row_byte_off + 16 * q) = v;
+    }
+  }
+}
+
+template <int C, bool WT, bool WAVE, int F4_IN_FLIGHT>
+__device__ __forceinline__ void graph_update_rows(const BlockArgs& a, const float* __restrict__ base, int g, size_t r, int t0, int t1, int tid, int nthr, float* s_g) {
+  constexpr int Q = (C + 3) / 4, CP = 4 * Q;
+  constexpr int RIF = Q >= F4_IN_FLIGHT ? 1 : F4_IN_FLIGHT / Q;  // rows in flight per thread; the per-thread accumulation order (rows ascending) does not depend on it
   const int K = C + a.dg, og = a.og;
   const int nrow16 = nthr >> 4;
   float* s_x = s_g + (size_t)nrow16 * C;  // [K]   graph-function input
@@ -211,43 +246,24 @@ __device__ __forceinline__ void graph_update_rows(const BlockArgs& a, int prow_s
   float gf_reg = 0.f;
   if (tid < a.dg) gf_reg = a.gf[(r * (size_t)a.G + g) * a.dg + tid];
 
-  float acc[C];
+  float acc[Q][4];
 #pragma unroll
-  for (int c = 0; c < C; ++c) acc[c] = 0.f;
-  // columns in passes of <= CC so that the in-flight quads (MAXQ * CC float4) stay in registers for any C
-  constexpr int CC = C <= 8 ? C : 8;
+  for (int q = 0; q < Q; ++q) acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
+  for (int row0 = t0 + tid; row0 < t1; row0 += RIF * nthr) {
+    float4 val[RIF][Q];
 #pragma unroll
-  for (int cb = 0; cb < C; cb += CC) {
-    for (int q0 = (t0 >> 2) + tid; 4 * q0 < t1; q0 += MAXQ * nthr) {
-      float4 val[MAXQ][CC];
+    for (int u = 0; u < RIF; ++u) {
+      const int row = row0 + u * nthr;
+      if (row < t1) {
 #pragma unroll
-      for (int u = 0; u < MAXQ; ++u) {
-        const int q = q0 + u * nthr;
-        if (4 * q < t1) {
-#pragma unroll
-          for (int c = 0; c < CC; ++c)
-            if (cb + c < C) {
-              const float* src = base + (size_t)(cb + c) * prow_stride + 4 * q;
-              if constexpr (WT) {
-                // 16-B sc1 load (bypasses this CU's L1, which other workgroups' stores never refresh)
-                const v4u_t x = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 16, 0x00020000), 0, 0, 16);
-                val[u][c] = make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
-              } else {
-                val[u][c] = *reinterpret_cast<const float4*>(src);
-              }
-            }
-        }
+        for (int q = 0; q < Q; ++q) val[u][q] = load_partial4<WT>(base, (unsigned)row * (CP * 4u) + 16u * q);
       }
+    }
 #pragma unroll
-      for (int u = 0; u < MAXQ; ++u) {
-        const int row = 4 * (q0 + u * nthr);
-        if (row < t1) {
-          const bool k0 = row >= t0, k1 = row + 1 >= t0 && row + 1 < t1, k2 = row + 2 >= t0 && row + 2 < t1, k3 = row + 3 < t1;
+    for (int u = 0; u < RIF; ++u) {
+      if (row0 + u * nthr < t1) {
 #pragma unroll
-          for (int c = 0; c < CC; ++c)
-            if (cb + c < C)
-              acc[cb + c] += ((k0 ? val[u][c].x : 0.f) + (k1 ? val[u][c].y : 0.f)) + ((k2 ? val[u][c].z : 0.f) + (k3 ? val[u][c].w : 0.f));
-        }
+        for (int q = 0; q < Q; ++q) { acc[q][0] += val[u][q].x; acc[q][1] += val[u][q].y; acc[q][2] += val[u][q].z; acc[q][3] += val[u][q].w; }
       }
     }
   }
@@ -275,7 +291,7 @@ __device__ __forceinline__ void graph_update_rows(const BlockArgs& a, int prow_s
   const int lane = tid & 63, row16 = tid >> 4;
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    const float x = row16_sum(acc[c]);
+    const float x = row16_sum(acc[c >> 2][c & 3]);
     if ((lane & 15) == 0) s_g[row16 * C + c] = x;
   }
   if constexpr (WAVE) __builtin_amdgcn_wave_barrier(); else __syncthreads();
@@ -326,7 +342,7 @@ __host__ __device__ constexpr int wave_slice_floats(int OE, int EPT) {
 #define GNX_WAVE_SGPRS 80
 #endif
 template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false, bool TICKET = false>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_SGPRS))) void k_block_wave(BlockArgs a, int prow_stride) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_SGPRS))) void k_block_wave(BlockArgs a, int n_rows) {
   constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1, DG1 = DG > 0 ? DG : 1;
   constexpr int TEW = 64 * EPT;
   constexpr int C = OE + ON, C1 = C > 0 ? C : 1;
@@ -366,15 +382,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
   const cfloatp be = as_const(a.be ? a.be : k_zero_bias);
   const cfloatp bn = as_const(a.bn ? a.bn : k_zero_bias);
 
-  // ---- one graph: every XCD pulls the whole node table into its L2 as a coalesced stream while the edge rows are on their
-  //      way (blocks b and b+8 share an XCD), instead of discovering it line by line through the 20-byte gathers.  One dword
-  //      per 64 bytes; the value is consumed (below) where the edge rows are waited for anyway (loads return in order). ----
-  float pf = 0.f;
-  if constexpr (ONEG && DN > 0) {
-    const int off = (((int)blockIdx.x >> 3) * WAVES + wv) * 4096 + lane * 64;
-    if (off < a.nf_prefetch_bytes) pf = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(nf) + off);
-  }
-
   // ---- issue every load up front, branch-free (indices clamped into the tile; results of clamped lanes unused) ----
   const bool is_node = lane < nn;
   const int nl = lane < nn ? lane : nn - 1;
@@ -398,8 +405,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
 #pragma unroll
     for (int i = 0; i < EPT; ++i) load_row<DN>(nf + (size_t)src[i] * DN, xs[i]);
   }
-  if constexpr (ONEG && DN > 0) asm volatile("" ::"v"(pf));
-
   float gfr[1][DG1];
 #pragma unroll
   for (int k = 0; k < DG; ++k) gfr[0][k] = gf[k];
@@ -572,51 +577,58 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
   if (a.og > 0) {
     if constexpr (C > 0) {
       const size_t r = blockIdx.y;
+      constexpr int CP = (C + 3) / 4 * 4;
+      float* __restrict__ pbase = a.partials + r * (size_t)n_rows * CP;
       if constexpr (ONEG) {
         __shared__ float s_blk[WAVES][C1];
         __shared__ int s_last;
         if (lane < C) s_blk[wv][lane] = mine;
         __syncthreads();
         if (wv == 0) {
-          if (lane < C) {
-            const float tot = (s_blk[0][lane] + s_blk[1][lane]) + (s_blk[2][lane] + s_blk[3][lane]);
-            float* dst = a.partials + (r * C + lane) * (size_t)prow_stride + xcd_tile(blockIdx.x, gridDim.x);
-            if constexpr (TICKET) __hip_atomic_store(dst, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through (sc1)
-            else *dst = tot;
-          }
+          float tot = 0.f;
+          if (lane < C) tot = (s_blk[0][lane] + s_blk[1][lane]) + (s_blk[2][lane] + s_blk[3][lane]);
+          store_partial_row<C, TICKET>(tot, pbase, (unsigned)xcd_tile(blockIdx.x, gridDim.x) * (CP * 4u), lane);
           if constexpr (TICKET) {
-            // the storing wave drains its write-through stores, THEN one lane takes the workgroup's ticket
+            // the storing wave drains its write-through stores, THEN one lane takes the workgroup's ticket: shard b % 64
+            // first (2032 adds to ONE word serialise at ~12 ns each: 25 us), the shard's last arriver goes on to the top counter
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned prev = 0;
-            if (lane == 0) prev = __hip_atomic_fetch_add(a.tickets + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            prev = __builtin_amdgcn_readfirstlane(prev);
-            if (lane == 0) s_last = prev == gridDim.x - 1 ? 1 : 0;
+            unsigned* tk = a.tickets + r * (size_t)((1 + kTicketShards) * kTicketStride);
+            const int shard = blockIdx.x & (kTicketShards - 1);
+            const unsigned shard_n = (gridDim.x - shard + kTicketShards - 1) / kTicketShards;
+            const unsigned top_n = gridDim.x < (unsigned)kTicketShards ? gridDim.x : (unsigned)kTicketShards;
+            int last = 0;
+            if (lane == 0) {
+              unsigned* ts = tk + (1 + shard) * kTicketStride;
+              if (__hip_atomic_fetch_add(ts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shard_n - 1) {
+                __hip_atomic_store(ts, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                last = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == top_n - 1;
+              }
+              s_last = last;
+            }
           }
         }
         if constexpr (TICKET) {
-          __syncthreads();  // the ticket add has returned before any wave of the last workgroup loads a partial sum
+          __syncthreads();  // the ticket adds have returned before any wave of the last workgroup loads a partial sum
           if (s_last) {
             __syncthreads();  // (every wave has read s_last before the scratch below is reused)
-            graph_update_rows<C, 1, true, false>(a, prow_stride, 0, r, 0, (int)gridDim.x, (int)threadIdx.x, kThreads, s_mem);
-            if (threadIdx.x == 0) __hip_atomic_store(a.tickets + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            graph_update_rows<C, true, false, 4>(a, pbase, 0, r, 0, (int)gridDim.x, (int)threadIdx.x, kThreads, s_mem);
+            if (threadIdx.x == 0)
+              __hip_atomic_store(a.tickets + r * (size_t)((1 + kTicketShards) * kTicketStride), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       } else {
-        if (lane < C) {
-          float* dst = a.partials + (r * C + lane) * (size_t)prow_stride + wt;
-          if constexpr (TICKET) __hip_atomic_store(dst, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else *dst = mine;
-        }
+        store_partial_row<C, TICKET>(mine, pbase, (unsigned)wt * (CP * 4u), lane);
         if constexpr (TICKET) {
           // one ticket per GRAPH, counted in wave tiles: the wave that completes its graph reduces the graph's rows
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          unsigned* tk = a.tickets + (size_t)tile_g * kTicketStride;
           unsigned prev = 0;
-          if (lane == 0) prev = __hip_atomic_fetch_add(a.tickets + tile_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) prev = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           prev = __builtin_amdgcn_readfirstlane(prev);
           if ((int)prev == tile_cnt - 1) {
             const int t0 = a.wtile_off[tile_g];
-            graph_update_rows<C, 1, true, true>(a, prow_stride, tile_g, r, t0, t0 + tile_cnt, lane, 64, s_mem + wv * WSL);
-            if (lane == 0) __hip_atomic_store(a.tickets + tile_g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            graph_update_rows<C, true, true, 4>(a, pbase, tile_g, r, t0, t0 + tile_cnt, lane, 64, s_mem + wv * WSL);
+            if (lane == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }
@@ -624,14 +636,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
   }
 }
 
-// Graph update for the wave path as its own launch (two-launch form): one workgroup per graph.
+// Graph update for the wave path as its own launch (two-launch form): one workgroup per graph, the same thread count as the
+// single-launch tail (256 for one graph, 64 per graph of a several-graph batch with <= 256 rows per graph).
 template <int C, bool ONEG = false>
-__global__ void k_graph_t(BlockArgs a, int prow_stride) {
+__global__ void k_graph_t(BlockArgs a, int n_rows) {
   extern __shared__ float s_g[];
+  constexpr int CP = (C + 3) / 4 * 4;
   const int g = blockIdx.x;
   // one graph: k_block_wave stored one row per WORKGROUP (4 wave tiles); several graphs: one row per wave tile
   const int t0 = ONEG ? 0 : a.wtile_off[g], t1 = ONEG ? (a.n_wtiles + 3) / 4 : a.wtile_off[g + 1];
-  graph_update_rows<C, 2, false, false>(a, prow_stride, g, blockIdx.y, t0, t1, (int)threadIdx.x, (int)blockDim.x, s_g);
+  const float* base = a.partials + blockIdx.y * (size_t)n_rows * CP;
+  if (blockDim.x == 64) graph_update_rows<C, false, true, 16>(a, base, g, blockIdx.y, t0, t1, (int)threadIdx.x, 64, s_g);
+  else graph_update_rows<C, false, false, 16>(a, base, g, blockIdx.y, t0, t1, (int)threadIdx.x, (int)blockDim.x, s_g);
 }
 
 }  // namespace gnx

@@ -20,6 +20,12 @@ def gn():
     return gn
 
 
+@pytest.fixture(autouse=True)
+def _single_launch_at_every_size(monkeypatch):
+    """By default only launch-bound batches (<= 1024 wave tiles) take the single-launch form; these tests want it everywhere."""
+    monkeypatch.setenv("GNX_TICKET_MAX_ROWS", "100000000")
+
+
 def _plan_pair(gn, g, dims, seed, R=1):
     """(block, single-launch plan, two-launch plan, inputs) on the same handle and parameters."""
     import torch
@@ -106,6 +112,17 @@ def test_ticket_handoff_under_load_in_a_hipgraph(gn):
             torch.cuda.synchronize()
             for i in range(steps):
                 assert torch.equal(gfs[i], want[i % nset][0]), f"replay {rep}, step {i}"
+
+
+def test_default_policy_small_batches_single_launch_big_ones_two(gn, monkeypatch):
+    monkeypatch.delenv("GNX_TICKET_MAX_ROWS")
+    rng = np.random.default_rng(9)
+    small = gn.GNGraphBatch.from_csc(*[[a] for a in U.er_csc(rng, 2000, 20000)], [2000])
+    big = gn.GNGraphBatch.from_csc(*bench.make_c2())
+    for g, want_graph_kernel in ((small, False), (big, True)):
+        _, one, _, _, xt = _plan_pair(gn, g, ((10, 5, 0), (3, 4, 5)), 14)
+        o = one.outputs()
+        assert ("k_graph_t" in _kernels_of(gn, lambda: one(*xt, *o))) == want_graph_kernel
 
 
 def test_uninitialised_workspace_is_only_used_without_the_flag(gn):

@@ -12,13 +12,7 @@ run() {  # name, env..., -- args
     echo "$name rep$rep $(echo "$line" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print("us/step", round(d["ms_per_step"]*1e3,2), "warm", round(d["config"].get("warm_ms_per_step",0)*1e3,2), "kernels", r["all_kernels_us"], "frac", r["frac"], "whole", r["frac_whole_step"])' 2>&1)" | tee -a $LOG
   done
 }
-run ticket_sgpr80 X=1 -- "$@"
-run twolaunch_sgpr80 X=1 -- --two-launch "$@"
-run ticket_noprefetch GNX_NF_PREFETCH_MAX=0 -- "$@"
-run jit_ticket_sgpr80 GNX_JIT_ALL=1 -- "$@"
-run jit_ticket_sgpr102 GNX_JIT_ALL=1 GNX_JIT_DEFS=-DGNX_WAVE_SGPRS=102 -- "$@"
-run jit_twolaunch_sgpr102 GNX_JIT_ALL=1 GNX_JIT_DEFS=-DGNX_WAVE_SGPRS=102 -- --two-launch "$@"
-run hetero_ticket X=1 -- --workload hetero "$@"
-run hetero_twolaunch X=1 -- --workload hetero --two-launch "$@"
-run hetero4096_ticket X=1 -- --workload hetero --hetero-graphs 4096 "$@"
-run hetero4096_twolaunch X=1 -- --workload hetero --hetero-graphs 4096 --two-launch "$@"
+for sc in 0.005 0.02 0.05 0.1 0.2 0.4 1.0; do
+run c2x${sc}_ticket GNX_TICKET_MAX_ROWS=100000000 -- --c2-scale $sc "$@"
+run c2x${sc}_twolaunch X=1 -- --c2-scale $sc --two-launch "$@"
+done
