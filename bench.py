@@ -221,7 +221,6 @@ def main():
                     help="two-phase steps: graph update of step i on a second stream (measured SLOWER inside a hipGraph: the "
                          "fork/join costs more than the 5 us it hides — 35.7 vs 27.7 us/step — so it is off by default)")
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path even with one rank (testing)")
-    ap.add_argument("--two-launch", action="store_true", help="graph update as its own kernel (k_graph_t) instead of the last-arriver ticket")
     ap.add_argument("--core-dims", type=str, default="128,64,32", help="core widths for --model c4 (README ex.3 uses 10,5,3)")
     ap.add_argument("--model", choices=["block", "c4"], default="block",
                     help="c4: BASELINE configs[3] — encoder -> 2 x GNCore(128,64,32) -> decoder on the C2 graph (extra; not the headline line)")
@@ -281,8 +280,6 @@ def main():
     blk.nodefn = gn.Dense.from_numpy(glorot(rng, on, oe + dn + dg), np.zeros(on, np.float32), device=dev)
     blk.graphfn = gn.Dense.from_numpy(glorot(rng, og, oe + on + dg), np.zeros(og, np.float32), device=dev)
     plan = gn.BlockPlan(blk, g, R=1, flags=args.flags)
-    if args.two_launch:
-        plan.flags &= ~gn._lib.FLAG_WS_TICKETS
     nsets = 2 if max(din + dout) >= 64 else NSETS
     tg = torch.Generator(device=dev); tg.manual_seed(1234 + rank)
     mk = lambda T, d: torch.rand((1, T, d), generator=tg, device=dev, dtype=torch.float32) if d > 0 else None
@@ -483,8 +480,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_name, "dims": f"{din}=>{dout}", "edges_per_gpu": E, "nodes_per_gpu": N,
-                       "graphs_per_gpu": G, "edges_whole_job": E_job, "parallelism": f"graph-sharded x{world}" if world > 1 else "single GPU",
-                       "graph_update": "k_graph_t (second launch)" if args.two_launch else "in the same launch (last-arriver ticket) where the fused kernel applies", **extra},
+                       "graphs_per_gpu": G, "edges_whole_job": E_job, "parallelism": f"graph-sharded x{world}" if world > 1 else "single GPU", **extra},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if dense is not None:

@@ -17,7 +17,7 @@ ERR_INVALID_ARG, ERR_NO_GRAPHS, ERR_ADJ_SHAPE, ERR_ADJ_VALUE, ERR_ALL_NOTHING = 
 ERR_DIMS, ERR_CSC, ERR_WORKSPACE, ERR_TOO_LARGE, ERR_COUNT_MISMATCH = -6, -7, -8, -9, -10
 ACT = dict(identity=0, relu=1, tanh=2, sigmoid=3, gelu=4)
 ELEM_U8, ELEM_I32, ELEM_I64, ELEM_F32, ELEM_F64 = 0, 1, 2, 3, 4
-FLAG_FORCE_GENERIC, FLAG_NO_MFMA, FLAG_DEFER_GRAPH_UPDATE, FLAG_NO_GRAPH, FLAG_WS_TICKETS = 0x1, 0x2, 0x4, 0x8, 0x10
+FLAG_FORCE_GENERIC, FLAG_NO_MFMA, FLAG_DEFER_GRAPH_UPDATE, FLAG_NO_GRAPH = 0x1, 0x2, 0x4, 0x8
 
 _fp = C.c_void_p  # device float*
 
@@ -97,8 +97,6 @@ SIGNATURES = {
     "gnx_graphs_get_offsets": (C.c_int32, [C.c_void_p, _i64p, _i64p]),
     "gnx_graphs_get_csc": (C.c_int32, [C.c_void_p, _i64p, _i64p]),
     "gnx_block_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BlockParams), C.c_int64]),
-    "gnx_block_workspace_init": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams), C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "gnx_core_workspace_init": (C.c_int32, [C.c_void_p, C.POINTER(CoreParams), C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnx_block_forward": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + _FWD[2:]),
     "gnx_block_graph_update": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams), _fp, C.c_int64, _fp, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "gnx_block_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BlockParams), C.c_int64]),

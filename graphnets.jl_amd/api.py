@@ -184,14 +184,12 @@ class GNGraphBatch:
         """Device scratch for one forward call on this handle, reused across calls with the same workspace LAYOUT (layer kind,
         widths, replicas) ON THE SAME STREAM (calls on one stream are ordered).  A buffer is never replaced, shrunk or handed
         to a call with another layout: a hipGraph that captured a call keeps replaying into the buffer it captured (the handle
-        holds it for its whole life), and two streams never share scratch.  Every buffer is zero-filled once, which is what
-        gnx_*_workspace_init asks for, and afterwards only sees gnx calls of its own layout, so the layers pass
-        GNX_FLAG_WS_TICKETS (single-launch graph update)."""
+        holds it for its whole life), and two streams never share scratch."""
         nbytes = max(int(nbytes), 256)
         key = (torch.cuda.current_stream(self.device).cuda_stream, layout, nbytes)
         ws = self._ws.get(key)
         if ws is None:
-            ws = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             self._ws[key] = ws
         return ws
 
@@ -639,7 +637,7 @@ class GNBlock:
         with torch.cuda.device(dev):
             ws = g.workspace(lib.gnx_block_workspace_bytes(g._h, C.byref(p), R), ("block", self.in_dims, self.out_dims, R))
             check(lib.gnx_block_forward(g._h, C.byref(p), _ptr(ef), _ptr(nf), _ptr(gf), R, _ptr(eo), _ptr(no), _ptr(go),
-                                        ws.data_ptr(), ws.numel(), (self.flags if flags is None else flags) | _lib.FLAG_WS_TICKETS,
+                                        ws.data_ptr(), ws.numel(), (self.flags if flags is None else flags),
                                         torch.cuda.current_stream(dev).cuda_stream))
         return NT(g, _jl(eo), _jl(no), _jl(go))  # zero-width outputs are None (gnblock.jl:71-78)
 
@@ -660,7 +658,7 @@ class _BlockFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws = g.workspace(lib.gnx_block_workspace_bytes(g._h, C.byref(p), R), ("block", block.in_dims, block.out_dims, R))
             check(lib.gnx_block_forward(g._h, C.byref(p), _ptr(ef), _ptr(nf), _ptr(gf), R, _ptr(eo), _ptr(no), _ptr(go), ws.data_ptr(),
-                                        ws.numel(), flags | _lib.FLAG_WS_TICKETS, torch.cuda.current_stream(dev).cuda_stream))
+                                        ws.numel(), flags, torch.cuda.current_stream(dev).cuda_stream))
         ctx.block, ctx.g, ctx.R = block, g, R
         # tensors go through save_for_backward (no ctx -> output -> grad_fn -> ctx cycle; in-place modification is detected);
         # ctx keeps only which of the six slots were present
@@ -780,7 +778,7 @@ class GNCore:
             ws = g.workspace(lib.gnx_core_workspace_bytes(g._h, C.byref(p), R), ("core", self.dims, R))
             check(lib.gnx_core_forward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), R, eo.data_ptr(),
                                        no.data_ptr(), go.data_ptr(), ws.data_ptr(), ws.numel(),
-                                       (self.flags if flags is None else flags) | _lib.FLAG_WS_TICKETS, torch.cuda.current_stream(dev).cuda_stream))
+                                       (self.flags if flags is None else flags), torch.cuda.current_stream(dev).cuda_stream))
         return NT(g, _jl(eo), _jl(no), _jl(go))
 
 
@@ -797,7 +795,7 @@ class _CoreFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws = g.workspace(lib.gnx_core_workspace_bytes(g._h, C.byref(p), R), ("core", core.dims, R))
             check(lib.gnx_core_forward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), R, eo.data_ptr(), no.data_ptr(),
-                                       go.data_ptr(), ws.data_ptr(), ws.numel(), flags | _lib.FLAG_WS_TICKETS, torch.cuda.current_stream(dev).cuda_stream))
+                                       go.data_ptr(), ws.data_ptr(), ws.numel(), flags, torch.cuda.current_stream(dev).cuda_stream))
         ctx.core, ctx.g, ctx.R = core, g, R
         ctx.save_for_backward(ef, nf, gf)
         return eo, no, go
@@ -859,8 +857,7 @@ class BlockPlan:
         self.lib = _lib.load()
         with torch.cuda.device(g.device):
             nbytes = self.lib.gnx_block_workspace_bytes(g._h, C.byref(self.p), self.R)
-        self.ws = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=g.device)  # zero-filled = gnx_block_workspace_init
-        self.flags |= _lib.FLAG_WS_TICKETS
+        self.ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=g.device)
 
     def outputs(self):
         oe, on, og = self.block.out_dims
@@ -878,12 +875,8 @@ class BlockPlan:
                                          _ptr(go), ws.data_ptr(), ws.numel(), flags, s))
 
     def new_workspace(self):
-        """A further initialised workspace (one per buffer set when steps on different sets may overlap)."""
-        ws = torch.empty_like(self.ws)
-        with torch.cuda.device(self.g.device):
-            check(self.lib.gnx_block_workspace_init(self.g._h, C.byref(self.p), self.R, ws.data_ptr(), ws.numel(),
-                                                    torch.cuda.current_stream(self.g.device).cuda_stream))
-        return ws
+        """A further workspace (one per buffer set when steps on different sets may overlap)."""
+        return torch.empty_like(self.ws)
 
     def graph_update(self, gf, go, stream=None, ws=None):
         s = torch.cuda.current_stream(self.g.device).cuda_stream if stream is None else stream

@@ -125,7 +125,7 @@ __global__ void k_bw_dnf(const float* dXn, int Kn, int n_off, const float* dXe, 
 __global__ __launch_bounds__(256) void k_bw_colsum1(const float* __restrict__ in, int d, int rows_total, const int* __restrict__ off, int S,
                                                     int G, float* __restrict__ partial, int ld, int coff) {  // ld: row length of `in`, coff: first column
   __shared__ float s_red[256];
-  const int sl = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+  const int sl = blockIdx.x % S, g = blockIdx.x / S, tid = threadIdx.x;  // (slice, graph) flattened into grid.x: grid.y/z stop at 65535
   const size_t r = blockIdx.z;
   const int t0 = off[g], t1 = off[g + 1];
   const int per = (t1 - t0 + S - 1) / S;
@@ -582,7 +582,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
                     int accumulate) {
     if (d == 0) return;
     const int S = (int)std::min<int64_t>(std::max<int64_t>(max_rows / 2048, 1), 256);
-    hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S, (unsigned)G, Ru), dim3(256), 0, s, in, d, rows_total, off, S, G, part, ld, coff);
+    hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S * (unsigned)G, 1, Ru), dim3(256), 0, s, in, d, rows_total, off, S, G, part, ld, coff);
     hipLaunchKernelGGL(k_bw_colsum2, dim3((unsigned)G, Ru), dim3(64), 0, s, part, d, S, G, out, out_stride, out_off, accumulate);
   };
   // Edge level on the matrix cores: regrouped (see below) — the edge function's input Xe is never materialised.

@@ -18,8 +18,7 @@ struct Tile {
   int g;        // graph id
   int win0;     // [win0, win1): the graph's node range — every source of the tile's edges lies inside it
   int win1;
-  int flags;    // wave tiles: number of wave tiles of graph g (the arrival count of the graph's ticket); else 0.
-                // Keeps the record 32 B = one s_load_dwordx8.
+  int flags;    // wave tiles: number of wave tiles of graph g; else 0.  Keeps the record 32 B = one s_load_dwordx8.
 };
 
 // Everything a block-forward kernel needs, passed by value (lives in SGPRs / kernarg segment).
@@ -47,21 +46,7 @@ struct BlockArgs {
   const float* ln_b[3];
   float ln_eps;
   int ln_mode;
-  // single-launch graph update (fused narrow path, GNX_FLAG_WS_TICKETS): arrival counters in the workspace, zero before the
-  // launch and zero again after it (the last arriver resets its counter).  One graph: tickets[r] counts workgroups of replica
-  // r; several graphs: tickets[g] counts the wave tiles of graph g.  nullptr <=> two-launch form (k_graph_t).
-  unsigned* tickets;
 };
-
-// Arrival counters ("tickets") of the single-launch graph update, in the head of the workspace: every counter on a 128-byte
-// line of its own (counters sharing a line serialise at its memory channel).  One graph: per replica a top counter +
-// kTicketShards shard counters (workgroup b arrives at shard b % 64, a shard's last arriver at the top counter: thousands of adds
-// to ONE word would serialise at ~12 ns each); several graphs: one counter per graph.
-constexpr int kTicketStride = 32;
-constexpr int kTicketShards = 64;
-__host__ __device__ constexpr long ticket_words(long R, long G) {
-  return (G == 1 ? R * (1 + kTicketShards) : G) * kTicketStride;
-}
 
 // activation codes = GNX_ACT_* of include/gnx.h (static_assert'ed in gnx_forward.hip)
 __device__ __forceinline__ float act_apply(float x, int act) {

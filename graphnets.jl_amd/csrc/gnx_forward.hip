@@ -63,15 +63,12 @@ static int32_t check_block(const gnx_graphs* h, const gnx_block_params* p, int64
 }
 
 struct BlockWs {
-  size_t tick_bytes, agg_off, part_off, total;
+  size_t agg_off, part_off, total;
 };
 
-// Layout: [tickets | agg | partials].  The tickets (arrival counters of the single-launch graph update) come first so that
-// gnx_block_workspace_init() is one memset of the head of the buffer.
 static BlockWs block_ws(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
   BlockWs w;
-  w.tick_bytes = align_up(sizeof(unsigned) * (size_t)ticket_words(R, h->G), 256);
-  w.agg_off = w.tick_bytes;
+  w.agg_off = 0;
   const size_t agg = align_up(sizeof(float) * (size_t)R * h->N * p->oe, 256);
   w.part_off = w.agg_off + agg;
   // partial-sum rows: generic path [n_tiles][C]; fused narrow path [n_wtiles (or workgroups)][4*ceil(C/4)]
@@ -119,9 +116,6 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   a.tile_off = h->d_tile_off; a.tiles = h->d_tiles;
   a.wtile_off = h->d_wtile_off; a.wtiles = h->d_wtiles; a.n_wtiles = (int)h->n_wtiles();
   a.N = (int)h->N; a.E = (int)h->E; a.G = (int)h->G; a.n_tiles = (int)h->n_tiles();
-  // single-launch graph update: only on a workspace the caller has declared initialised (gnx_block_workspace_init)
-  static const bool no_tickets = getenv("GNX_NO_TICKETS") != nullptr;  // A/B measurements
-  a.tickets = ((flags & GNX_FLAG_WS_TICKETS) && !no_tickets) ? reinterpret_cast<unsigned*>(ws) : nullptr;
 
   if (ln1) {
     *fused_ln = false;
@@ -150,22 +144,6 @@ extern "C" int32_t gnx_ensure_collapse(const gnx_graphs* h);
 using namespace gnx;
 
 extern "C" {
-
-int32_t gnx_block_workspace_init(const gnx_graphs* h, const gnx_block_params* p, int64_t R, void* ws, size_t ws_bytes, void* stream) {
-  int32_t rc = check_block(h, p, R);
-  if (rc) return rc;
-  const BlockWs w = block_ws(h, p, R);
-  if (!ws || ws_bytes < w.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_block_workspace_bytes()");
-  GNX_HIP(hipMemsetAsync(ws, 0, w.tick_bytes, (hipStream_t)stream));
-  return GNX_OK;
-}
-
-int32_t gnx_core_workspace_init(const gnx_graphs* h, const gnx_core_params* p, int64_t R, void* ws, size_t ws_bytes, void* stream) {
-  if (!h || !p || R <= 0) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
-  const size_t total = gnx_core_workspace_bytes(h, p, R), blk = block_ws(h, &p->block, R).total;
-  if (!ws || ws_bytes < total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_core_workspace_bytes()");
-  return gnx_block_workspace_init(h, &p->block, R, static_cast<char*>(ws) + (total - blk), blk, stream);
-}
 
 size_t gnx_block_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
   if (!h || !p || R <= 0) return 0;

@@ -90,7 +90,7 @@ static int32_t finalize(gnx_graphs* h) {
   h->wtile_e_cap = env_int("GNX_WTILE_E", 128);
   if (h->wtile_e_cap != 64 && h->wtile_e_cap != 128 && h->wtile_e_cap != 256) h->wtile_e_cap = 128;
   build_tiles(h->wtile_e_cap, 64, h->h_wtiles, h->h_wtile_off);
-  for (int64_t g = 0; g < h->G; ++g) {  // arrival count of the graph's ticket (single-launch graph update)
+  for (int64_t g = 0; g < h->G; ++g) {  // wave tiles per graph (graph-update launch geometry)
     const int32_t cnt = h->h_wtile_off[g + 1] - h->h_wtile_off[g];
     h->max_wtiles_per_graph = std::max(h->max_wtiles_per_graph, cnt);
     for (int32_t t = h->h_wtile_off[g]; t < h->h_wtile_off[g + 1]; ++t) h->h_wtiles[(size_t)t].flags = cnt;

@@ -102,14 +102,10 @@ int32_t gnx_model_create(const gnx_graphs* h, const gnx_layer* layers, int32_t n
     L.ws_bytes = L.kind == GNX_LAYER_BLOCK ? gnx_block_workspace_bytes(h, &L.block, R) : gnx_core_workspace_bytes(h, &L.core, R);
     if (L.ws_bytes == 0) { for (void* q : m->owned) (void)hipFree(q); return fail(GNX_ERR_DIMS, "gnx_model_create: a layer's parameters were rejected (widths)"); }
     int32_t rc = alloc(L.ws_bytes, &L.ws);
-    // the model owns its workspaces: initialise them once, every forward then runs the single-launch graph update
-    if (!rc) rc = L.kind == GNX_LAYER_BLOCK ? gnx_block_workspace_init(h, &L.block, R, L.ws, L.ws_bytes, nullptr)
-                                            : gnx_core_workspace_init(h, &L.core, R, L.ws, L.ws_bytes, nullptr);
     if (!rc && i + 1 < n_layers)
       for (int t = 0; t < 3 && !rc; ++t) rc = alloc(sizeof(float) * rows[t] * (size_t)L.out[t], reinterpret_cast<void**>(&L.y[t]));
     if (rc) { for (void* q : m->owned) (void)hipFree(q); return rc; }
   }
-  GNX_HIP(hipStreamSynchronize(nullptr));  // the workspace memsets
   *out = m.release();
   return GNX_OK;
 }
@@ -134,7 +130,7 @@ int32_t gnx_model_forward(gnx_model* m, const float* ef, const float* nf, const 
   if (!m) return fail(GNX_ERR_INVALID_ARG, "NULL model");
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(m->mu);
-  const uint32_t lflags = (flags & ~GNX_FLAG_NO_GRAPH) | GNX_FLAG_WS_TICKETS;  // library-owned, initialised workspaces
+  const uint32_t lflags = flags & ~GNX_FLAG_NO_GRAPH;
   if (flags & GNX_FLAG_NO_GRAPH) return run_layers(m, ef, nf, gf, ef_out, nf_out, gf_out, lflags, s);
   const void* ptrs[6] = {ef, nf, gf, ef_out, nf_out, gf_out};
   if (!m->exec || std::memcmp(ptrs, m->cap_ptrs, sizeof ptrs) != 0 || m->cap_flags != lflags) {

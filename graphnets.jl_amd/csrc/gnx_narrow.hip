@@ -21,29 +21,11 @@ namespace gnx {
 // Rows of the partial-sum table per replica: one per workgroup (one graph) or one per wave tile (several graphs).
 static int partial_rows(const gnx_graphs* h) { return (int)(h->G == 1 ? (h->n_wtiles() + 3) / 4 : h->n_wtiles()); }
 
-// Thread count of the graph update — the SAME in both forms (second launch / tail of the fused kernel), so that their
-// results are bitwise equal: 256 for one graph; 64 (one wavefront) per graph of a several-graph batch whose graphs have
-// <= 256 rows; bigger graphs only exist in the two-launch form (1024 threads cover 8192 rows per pass).
+// Threads of the graph update: one wavefront per graph while a graph has <= 256 partial rows (the usual heterogeneous batch:
+// C3 has ~16 rows per graph, C5 ~3), else 256, and 1024 from 1024 rows on (C2: 2032 rows, two per thread in flight at once).
 static int graph_update_threads(const gnx_graphs* h) {
-  if (h->G == 1) return kThreads;
-  return h->max_wtiles_per_graph <= 256 ? 64 : (h->max_wtiles_per_graph > 2048 ? 1024 : 256);
-}
-
-// Does the single-launch form (graph update by the last arriver, BlockArgs::tickets) apply?  The tail reuses the kernel's
-// LDS: the whole workgroup's slices (one graph: 256 threads) or the finishing wave's own slice (several graphs: 64 threads).
-static bool ticket_fits(const gnx_graphs* h, const BlockArgs& a, int ept) {
-  if (!a.tickets || a.og <= 0 || a.oe + a.on <= 0) return false;
-  // The in-launch hand-off (write-through rows, drain, one or two ticket round trips, sc1 reads) costs about as much as a
-  // kernel boundary plus k_graph_t once the chip is full: measured on C2 28.0 vs 26.8 us/step, 4096 graphs 25.5 vs 24.6, 512
-  // graphs 20.6 vs 20.7 (profiles/r02_ab_single_launch_and_sc1_stores.log).  It wins for launch-bound sizes, where the second
-  // launch is most of the step: small batches take the single-launch form, big ones keep two launches.
-  const char* env = getenv("GNX_TICKET_MAX_ROWS");  // read per call (tests and sweeps change it inside one process)
-  const int64_t max_rows = env ? atoll(env) : 1024;
-  if (h->n_wtiles() > max_rows) return false;
-  const bool oneg = h->G == 1;
-  if (!oneg && graph_update_threads(h) != 64) return false;
-  const int have = wave_slice_floats(a.oe, ept) * (oneg ? kThreads / 64 : 1);
-  return graph_update_lds_floats(a.oe + a.on, a.dg, a.og, oneg ? kThreads : 64) <= have;
+  const int64_t rows = h->G == 1 ? (h->n_wtiles() + 3) / 4 : h->max_wtiles_per_graph;
+  return rows <= 256 ? 64 : (rows >= 1024 ? 1024 : 256);
 }
 
 template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN, bool ONEG>
@@ -51,19 +33,12 @@ static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R,
   constexpr int C = OE + ON;
   const int n_rows = partial_rows(h);
   const unsigned grid = (unsigned)((a.n_wtiles + 3) / 4);
-  // single launch only when the whole block is asked for (phase 3): a deferred graph update keeps the two-launch form
-  const bool ticket = phase == 3 && ticket_fits(h, a, EPT);
   if (phase & 1) {
     ProfScope ps("k_block_wave", s);
-    if (ticket) hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG, true>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, n_rows);
-    else {
-      BlockArgs b = a;
-      b.tickets = nullptr;
-      hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG, false>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, b, n_rows);
-    }
+    hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, n_rows);
     GNX_HIP(hipGetLastError());
   }
-  if ((phase & 2) && a.og > 0 && !ticket) {
+  if ((phase & 2) && a.og > 0) {
     if constexpr (C > 0) {
       const int threads = graph_update_threads(h);
       const size_t lds = sizeof(float) * (size_t)graph_update_lds_floats(C, a.dg, a.og, threads);
@@ -104,30 +79,24 @@ static int32_t launch_fused(const gnx_graphs* h, const BlockArgs& a, int64_t R, 
   X(10, 5, 0, 10, 5)
 
 bool jit_eligible(const BlockArgs& a, int ept);
-int32_t jit_get(const BlockArgs& a, int ept, bool ticket, hipStream_t s, hipFunction_t* block, hipFunction_t* graph);
+int32_t jit_get(const BlockArgs& a, int ept, hipStream_t s, hipFunction_t* block, hipFunction_t* graph);
 
 // Same launch geometry as launch_wave_t, kernels specialised at run time (gnx_jit.cpp) for this width set.
 static int32_t launch_wave_jit(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   const int ept = h->wtile_e_cap / 64;
   if (ept * 64 != h->wtile_e_cap || (ept != 1 && ept != 2 && ept != 4)) return 1;
-  bool ticket = phase == 3 && ticket_fits(h, a, ept);
   hipFunction_t fb = nullptr, fg = nullptr;
-  int32_t rc = jit_get(a, ept, ticket, s, &fb, &fg);
-  if (rc == 1 && ticket) {  // single-launch variant not loaded (first seen inside a capture): the two-launch pair may be
-    ticket = false;
-    rc = jit_get(a, ept, false, s, &fb, &fg);
-  }
+  const int32_t rc = jit_get(a, ept, s, &fb, &fg);
   if (rc) return rc;
   const int C = a.oe + a.on;
   BlockArgs aa = a;
-  if (!ticket) aa.tickets = nullptr;
   int n_rows = partial_rows(h);
   void* params[] = {&aa, &n_rows};
   if (phase & 1) {
     ProfScope ps("k_block_wave", s);
     GNX_HIP(hipModuleLaunchKernel(fb, (unsigned)((a.n_wtiles + 3) / 4), (unsigned)R, 1, kThreads, 1, 1, 0, s, params, nullptr));
   }
-  if ((phase & 2) && a.og > 0 && !ticket) {
+  if ((phase & 2) && a.og > 0) {
     const int threads = graph_update_threads(h);
     const size_t lds = sizeof(float) * (size_t)graph_update_lds_floats(C, a.dg, a.og, threads);
     ProfScope ps("k_graph_t", s);
@@ -148,9 +117,7 @@ void warm_block_narrow(const gnx_graphs* h, const gnx_block_params* p) {
 #undef GNX_CASE
   if (h->n_wtiles() == 0 || h->E == 0) return;
   hipFunction_t fb, fg;
-  (void)jit_get(a, h->wtile_e_cap / 64, false, nullptr, &fb, &fg);
-  a.tickets = reinterpret_cast<unsigned*>(1);  // (only tested for non-NULL) also the single-launch variant, if it fits
-  if (ticket_fits(h, a, h->wtile_e_cap / 64)) (void)jit_get(a, h->wtile_e_cap / 64, true, nullptr, &fb, &fg);
+  (void)jit_get(a, h->wtile_e_cap / 64, nullptr, &fb, &fg);
 }
 
 static bool wants_ln(const BlockArgs& a) { return a.ln_g[0] || a.ln_g[1] || a.ln_g[2]; }
@@ -177,7 +144,7 @@ bool block_narrow_ready(const gnx_graphs* h, const BlockArgs& a, hipStream_t s) 
   const int ept = h->wtile_e_cap / 64;
   if (ept * 64 != h->wtile_e_cap || (ept != 1 && ept != 2 && ept != 4)) return false;
   hipFunction_t fb, fg;
-  return jit_get(a, ept, false, s, &fb, &fg) == GNX_OK;
+  return jit_get(a, ept, s, &fb, &fg) == GNX_OK;
 }
 
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {

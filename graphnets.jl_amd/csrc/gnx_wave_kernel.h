@@ -181,52 +181,35 @@ __device__ __forceinline__ float wave_sum(float v) {
 // =========================================================================================================
 // Graph update from the per-tile partial sums, rows of CP = 4*ceil(C/4) floats [sum_e ef' ; sum_n nf' ; pad]:
 //   gf'[g] = act(Wg * [sum_e ef' ; sum_n nf' ; gf_g] + bg)                       (graphfninput.jl:1-13, gnblock.jl:67)
-// Shared by k_graph_t (its own launch, plain loads) and by the tail of k_block_wave<..., TICKET> (executed by the
-// workgroup / wave whose ticket add came last; WT: the rows were stored write-through by OTHER workgroups, so every
-// load of them is an sc1 load — MI355X_MICROARCH "Valid forms": sc1 payload, drained, agent-scope ticket add, last
-// arriver loads sc1 after its add has returned).
-// Latency is everything here (a few KB of work): the thread's rows (<= 8 float4 in flight), its slice of Wg / bg / gf
+// Latency is everything here (a few KB of work): the thread's rows (<= 16 float4 in flight), its slice of Wg / bg / gf
 // are all issued before the first wait; the sums are reduced with DPP + one LDS hop in a fixed order which depends only
-// on (t0, t1, nthr) — both forms use the same nthr, so their results are bitwise equal.
+// on (t0, t1, nthr): bitwise reproducible.
 // WAVE: executed by ONE wavefront (nthr = 64) — LDS operations of one wave execute in order, no workgroup barrier.
 // s_g: (nthr/16)*C + (C+dg+4) + (C+dg+1)*og floats of LDS.
+//
+// (Round 2 also built the graph update INTO k_block_wave — write-through rows, drained, sharded line-spaced arrival tickets,
+// the last arriver reads the rows with sc1 loads — bitwise equal to this form and slower or equal at every size: C2 27.4 vs
+// 26.7 us/step, 4096 graphs 25.5 vs 24.6, 512 graphs 20.6 vs 20.7, 5k edges 8.6 vs 8.3: on MI355X the in-launch hand-off costs
+// what a kernel boundary plus this kernel costs.  profiles/r02_ab_single_launch_*.log; the code is in the history.)
 // =========================================================================================================
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 
-// `base` is wave-uniform (derived from kernel arguments): the buffer descriptor lives in SGPRs, the lane's row is the byte
-// offset.  (A descriptor built from a per-lane pointer makes hipcc wrap every access in a readfirstlane "waterfall" loop.)
-template <bool WT>
-__device__ __forceinline__ float4 load_partial4(const float* base, unsigned byte_off) {
-  if constexpr (WT) {
-    // 16-B sc1 load (bypasses this CU's L1, which other workgroups' stores never refresh)
-    const v4u_t x = __builtin_amdgcn_raw_buffer_load_b128(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000), byte_off, 0, 16);
-    return make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
-  } else {
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
-  }
-}
-
-// One partial-sum row: lane c < C holds column c in `mine`; lane q < CP/4 stores columns 4q..4q+3 as ONE 16-byte store
-// (write-through when another workgroup will read it in this launch: a 16-B sc1 store is one fabric write, a dword is too —
-// seven of them per row cost 3x the whole kernel).
-template <int C, bool WT>
-__device__ __forceinline__ void store_partial_row(float mine, float* base, unsigned row_byte_off, int lane) {
+// One partial-sum row: lane c < C holds column c in `mine`; lane q < CP/4 stores columns 4q..4q+3 as ONE 16-byte store.
+template <int C>
+__device__ __forceinline__ void store_partial_row(float mine, float* row, int lane) {
   constexpr int Q = (C + 3) / 4;
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    v4u_t v;
-    v.x = __float_as_uint(readlane_f(mine, 4 * q));
-    v.y = 4 * q + 1 < C ? __float_as_uint(readlane_f(mine, 4 * q + 1)) : 0u;
-    v.z = 4 * q + 2 < C ? __float_as_uint(readlane_f(mine, 4 * q + 2)) : 0u;
-    v.w = 4 * q + 3 < C ? __float_as_uint(readlane_f(mine, 4 * q + 3)) : 0u;
-    if (lane == q) {
-      if constexpr (WT) __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000), row_byte_off + 16 * q, 0, 16);
-      else *reinterpret_cast<v4u_t*>(reinterpret_cast<char*>(base) + row_byte_off + 16 * q) = v;
-    }
+    float4 v;
+    v.x = readlane_f(mine, 4 * q);
+    v.y = 4 * q + 1 < C ? readlane_f(mine, 4 * q + 1) : 0.f;
+    v.z = 4 * q + 2 < C ? readlane_f(mine, 4 * q + 2) : 0.f;
+    v.w = 4 * q + 3 < C ? readlane_f(mine, 4 * q + 3) : 0.f;
+    if (lane == q) *reinterpret_cast<float4*>(row + 4 * q) = v;
   }
 }
 
-template <int C, bool WT, bool WAVE, int F4_IN_FLIGHT>
+template <int C, bool WAVE, int F4_IN_FLIGHT>
 __device__ __forceinline__ void graph_update_rows(const BlockArgs& a, const float* __restrict__ base, int g, size_t r, int t0, int t1, int tid, int nthr, float* s_g) {
   constexpr int Q = (C + 3) / 4, CP = 4 * Q;
   constexpr int RIF = Q >= F4_IN_FLIGHT ? 1 : F4_IN_FLIGHT / Q;  // rows in flight per thread; the per-thread accumulation order (rows ascending) does not depend on it
@@ -256,7 +239,7 @@ __device__ __forceinline__ void graph_update_rows(const BlockArgs& a, const floa
       const int row = row0 + u * nthr;
       if (row < t1) {
 #pragma unroll
-        for (int q = 0; q < Q; ++q) val[u][q] = load_partial4<WT>(base, (unsigned)row * (CP * 4u) + 16u * q);
+        for (int q = 0; q < Q; ++q) val[u][q] = *reinterpret_cast<const float4*>(base + (size_t)row * CP + 4 * q);
       }
     }
 #pragma unroll
@@ -312,7 +295,7 @@ __device__ __forceinline__ void graph_update_rows(const BlockArgs& a, const floa
   }
 }
 
-// LDS floats graph_update_rows needs with nthr threads (host side: decides whether the single-launch form fits)
+// LDS floats graph_update_rows needs with nthr threads
 __host__ __device__ constexpr int graph_update_lds_floats(int C, int dg, int og, int nthr) {
   return (nthr / 16) * C + (C + dg + 4) + (C + dg + 1) * og + 8;
 }
@@ -334,21 +317,19 @@ __host__ __device__ constexpr int wave_slice_floats(int OE, int EPT) {
 //                    ef' from LDS, node update, store
 // =========================================================================================================
 // LN: LayerNorm the inputs on load (BlockArgs::ln_*).  ONEG: the batch is ONE graph (see below).
-// TICKET: the graph update runs inside this launch — the workgroup (ONEG) / wave (several graphs) whose ticket add
-// comes last reduces the partial sums and writes gf'; otherwise k_graph_t does it in a second launch.
 // SGPR budget: a CU admits floor(800 / (ceil(sgpr/16)*16 + 16)) 256-thread workgroups (MI355X_MICROARCH, residency): 8 up to 80
 // SGPRs, 7 up to 96, 6 beyond.  C2 is 2032 workgroups = ONE round at 8 per CU (2048 slots) but 1.13 rounds at 7.
 #ifndef GNX_WAVE_SGPRS
 #define GNX_WAVE_SGPRS 80
 #endif
-template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false, bool TICKET = false>
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_SGPRS))) void k_block_wave(BlockArgs a, int n_rows) {
   constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1, DG1 = DG > 0 ? DG : 1;
   constexpr int TEW = 64 * EPT;
   constexpr int C = OE + ON, C1 = C > 0 ? C : 1;
   constexpr int WAVES = kThreads / 64;
   constexpr int WSL = wave_slice_floats(OE, EPT);
-  __shared__ __attribute__((aligned(16))) float s_mem[WAVES * WSL];  // one slice per wave (the TICKET tail reuses it)
+  __shared__ __attribute__((aligned(16))) float s_mem[WAVES * WSL];  // one slice per wave
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -360,7 +341,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
   const bool active = wt < a.n_wtiles;  // wave-uniform
   if constexpr (!ONEG) { if (!active) return; }
   float mine = 0.f;  // lane c < C: this wave's total of graph-update column c
-  int tile_g = 0, tile_cnt = 0;
   do {
   if constexpr (ONEG) { if (!active) break; }
   float* s_out = s_mem + wv * WSL;                                        // ef' of the wave's tile
@@ -370,7 +350,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
   typedef const int __attribute__((address_space(4))) * cintp;
   const cintp tw = reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.wtiles)) + (size_t)wt * (sizeof(Tile) / sizeof(int));
   const int n0 = tw[0], n1 = tw[1], e0 = tw[2], e1 = tw[3], g = tw[4];  // s_load_dwordx8
-  if constexpr (TICKET && !ONEG) { tile_g = g; tile_cnt = tw[7]; }
   const int nn = n1 - n0, ne = e1 - e0;
 
   const size_t r = blockIdx.y;
@@ -581,63 +560,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
       float* __restrict__ pbase = a.partials + r * (size_t)n_rows * CP;
       if constexpr (ONEG) {
         __shared__ float s_blk[WAVES][C1];
-        __shared__ int s_last;
         if (lane < C) s_blk[wv][lane] = mine;
         __syncthreads();
         if (wv == 0) {
           float tot = 0.f;
           if (lane < C) tot = (s_blk[0][lane] + s_blk[1][lane]) + (s_blk[2][lane] + s_blk[3][lane]);
-          store_partial_row<C, TICKET>(tot, pbase, (unsigned)xcd_tile(blockIdx.x, gridDim.x) * (CP * 4u), lane);
-          if constexpr (TICKET) {
-            // the storing wave drains its write-through stores, THEN one lane takes the workgroup's ticket: shard b % 64
-            // first (2032 adds to ONE word serialise at ~12 ns each: 25 us), the shard's last arriver goes on to the top counter
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned* tk = a.tickets + r * (size_t)((1 + kTicketShards) * kTicketStride);
-            const int shard = blockIdx.x & (kTicketShards - 1);
-            const unsigned shard_n = (gridDim.x - shard + kTicketShards - 1) / kTicketShards;
-            const unsigned top_n = gridDim.x < (unsigned)kTicketShards ? gridDim.x : (unsigned)kTicketShards;
-            int last = 0;
-            if (lane == 0) {
-              unsigned* ts = tk + (1 + shard) * kTicketStride;
-              if (__hip_atomic_fetch_add(ts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shard_n - 1) {
-                __hip_atomic_store(ts, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-                last = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == top_n - 1;
-              }
-              s_last = last;
-            }
-          }
-        }
-        if constexpr (TICKET) {
-          __syncthreads();  // the ticket adds have returned before any wave of the last workgroup loads a partial sum
-          if (s_last) {
-            __syncthreads();  // (every wave has read s_last before the scratch below is reused)
-            graph_update_rows<C, true, false, 4>(a, pbase, 0, r, 0, (int)gridDim.x, (int)threadIdx.x, kThreads, s_mem);
-            if (threadIdx.x == 0)
-              __hip_atomic_store(a.tickets + r * (size_t)((1 + kTicketShards) * kTicketStride), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+          store_partial_row<C>(tot, pbase + (size_t)xcd_tile(blockIdx.x, gridDim.x) * CP, lane);
         }
       } else {
-        store_partial_row<C, TICKET>(mine, pbase, (unsigned)wt * (CP * 4u), lane);
-        if constexpr (TICKET) {
-          // one ticket per GRAPH, counted in wave tiles: the wave that completes its graph reduces the graph's rows
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          unsigned* tk = a.tickets + (size_t)tile_g * kTicketStride;
-          unsigned prev = 0;
-          if (lane == 0) prev = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          prev = __builtin_amdgcn_readfirstlane(prev);
-          if ((int)prev == tile_cnt - 1) {
-            const int t0 = a.wtile_off[tile_g];
-            graph_update_rows<C, true, true, 4>(a, pbase, tile_g, r, t0, t0 + tile_cnt, lane, 64, s_mem + wv * WSL);
-            if (lane == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
+        store_partial_row<C>(mine, pbase + (size_t)wt * CP, lane);
       }
     }
   }
 }
 
-// Graph update for the wave path as its own launch (two-launch form): one workgroup per graph, the same thread count as the
-// single-launch tail (256 for one graph, 64 per graph of a several-graph batch with <= 256 rows per graph).
+// Graph update for the wave path: one workgroup per graph (one wavefront when the graph has <= 256 partial rows).
 template <int C, bool ONEG = false>
 __global__ void k_graph_t(BlockArgs a, int n_rows) {
   extern __shared__ float s_g[];
@@ -646,8 +583,8 @@ __global__ void k_graph_t(BlockArgs a, int n_rows) {
   // one graph: k_block_wave stored one row per WORKGROUP (4 wave tiles); several graphs: one row per wave tile
   const int t0 = ONEG ? 0 : a.wtile_off[g], t1 = ONEG ? (a.n_wtiles + 3) / 4 : a.wtile_off[g + 1];
   const float* base = a.partials + blockIdx.y * (size_t)n_rows * CP;
-  if (blockDim.x == 64) graph_update_rows<C, false, true, 16>(a, base, g, blockIdx.y, t0, t1, (int)threadIdx.x, 64, s_g);
-  else graph_update_rows<C, false, false, 16>(a, base, g, blockIdx.y, t0, t1, (int)threadIdx.x, (int)blockDim.x, s_g);
+  if (blockDim.x == 64) graph_update_rows<C, true, 16>(a, base, g, blockIdx.y, t0, t1, (int)threadIdx.x, 64, s_g);
+  else graph_update_rows<C, false, 16>(a, base, g, blockIdx.y, t0, t1, (int)threadIdx.x, (int)blockDim.x, s_g);
 }
 
 }  // namespace gnx

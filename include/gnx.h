@@ -76,10 +76,6 @@ extern "C" {
 #define GNX_FLAG_DEFER_GRAPH_UPDATE 0x4u /* gnx_block_forward stops after the edge+node update and leaves the per-tile
                                           * partial sums in the workspace; gnx_block_graph_update finishes gf' later   */
 
-#define GNX_FLAG_WS_TICKETS 0x10u /* the workspace was initialised with gnx_block_workspace_init / gnx_core_workspace_init and
-                                   * has only been passed to gnx_* calls since: the fused narrow path then finishes the graph
-                                   * update inside its ONE launch (last-arriver ticket) instead of a second kernel          */
-
 typedef struct gnx_graphs gnx_graphs; /* opaque; replaces GNGraphBatch (src/gngraphbatch.jl:1-54) */
 
 typedef struct gnx_graphs_info {
@@ -166,14 +162,6 @@ GNX_API int32_t gnx_block_forward(const gnx_graphs* h, const gnx_block_params* p
                           const float* gf, int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out,
                           void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
-/* Optional, once per workspace buffer: zeroes the arrival counters at the head of the workspace (asynchronous on `stream`).
- * A workspace initialised this way — and since used only by gnx_* calls, which leave the counters zero again — may be passed
- * with GNX_FLAG_WS_TICKETS: the fused narrow-width path then computes gf' in the same launch as the edge and node update (the
- * workgroup / wavefront that completes a graph last reduces the graph's partial sums: graphfninput.jl:1-13 with no second
- * kernel).  Results are bitwise identical to the two-launch form.  Two forwards must not share one workspace concurrently. */
-GNX_API int32_t gnx_block_workspace_init(const gnx_graphs* h, const gnx_block_params* p, int64_t n_replicas, void* workspace,
-                                 size_t workspace_bytes, void* stream);
-
 /* Second phase of a deferred block forward: gf'[g] = graphfn([sum_e ef' ; sum_n nf' ; gf_g]) (src/gnblock.jl:67,
  * src/graphfninput.jl:1-13) from the partial sums a gnx_block_forward(..., GNX_FLAG_DEFER_GRAPH_UPDATE, ...) call left
  * in `workspace` (same handle, params, n_replicas, flags and workspace; the workspace must not be reused in between).
@@ -225,8 +213,6 @@ GNX_API int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p,
 
 /* ---- forward: replaces (m::GNCore)(x) (src/gncore.jl:56-68); GNCoreList = caller-side fold (gncorelist.jl:43-45) ---- */
 GNX_API size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t n_replicas);
-GNX_API int32_t gnx_core_workspace_init(const gnx_graphs* h, const gnx_core_params* p, int64_t n_replicas, void* workspace,
-                                size_t workspace_bytes, void* stream); /* as gnx_block_workspace_init, for a core workspace */
 GNX_API int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf,
                          const float* gf, int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out,
                          void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);

@@ -383,10 +383,34 @@ def _dense_rows(W, b, act, X):
     return apply_act(X @ np.asarray(W, dtype=F64).T + np.asarray(b, dtype=F64)[None, :], act)
 
 
-def block_forward_sparse(p, csc, ef, nf, gf, return_scale=False):
+_CHUNK = 1 << 17  # rows per chunk of the row-wise stages: bounds the temporaries at BASELINE's 1M-edge / 128-wide sizes
+
+
+def _segsum(v, seg, n):
+    """out[seg[k]] += v[k] with np.bincount per column (vectorised; np.add.at is an order of magnitude slower)."""
+    out = np.empty((n, v.shape[1]), dtype=v.dtype)
+    for c in range(v.shape[1]):
+        out[:, c] = np.bincount(seg, weights=v[:, c], minlength=n)
+    return out
+
+
+def _scale_rows(S, W, b):
+    """Error scale of a Dense: S·|W|ᵀ + |b| in float32 (a bound only needs a few digits; sgemm is what makes the
+    full-size scales affordable)."""
+    return S.astype(np.float32, copy=False) @ np.abs(np.asarray(W, dtype=np.float32)).T + np.abs(np.asarray(b, dtype=np.float32))[None, :]
+
+
+def block_forward_sparse(p, csc, ef, nf, gf, return_scale=False, in_scale=None):
     """SURVEY Appendix A on packed data.  ef (R,E,DE) | None, nf (R,N,DN) | None, gf (R,G,DG) | None.
-    Returns (ef', nf', gf') with zero-width outputs as None.  With `return_scale` also returns, per output,
-    the magnitude bound |W|·|x| + |b| (sums taken over absolute values) used as the tolerance scale."""
+    Returns (ef', nf', gf') with zero-width outputs as None.  With `return_scale` also returns, per output, the
+    magnitude bound |W|·S + |b| that the parity tests use as the tolerance scale: S = |x| for exact inputs, or the
+    `in_scale` triple (each >= |input|, same shapes) when the inputs are themselves computed results — the bound then
+    also covers the first-order propagation of their error (a perturbation δ <= c·eps·S of the inputs moves the outputs
+    by at most c·eps·(|W|·S)).  This is a WORST-CASE bound (every rounding error aligned): right for one layer, vacuous for a
+    deep chain through million-term sums and LayerNorm's 1/σ — chains are checked layer by layer from the float32-rounded
+    oracle input of each layer instead (tests/test_gpu_fullsize.py).  (A quadrature / probabilistic scale was tried and is
+    wrong here: gf and the gathered node rows are shared by many edges, their errors are fully correlated in the next sum.)
+    The edge stage runs in row chunks (1M edges x 288 inputs would be 2.3 GB at once)."""
     colptr, rowval, node_off, edge_off = csc
     N, E, G = len(colptr) - 1, len(rowval), len(node_off) - 1
     R = next(a.shape[0] for a in (ef, nf, gf) if a is not None)
@@ -394,44 +418,62 @@ def block_forward_sparse(p, csc, ef, nf, gf, return_scale=False):
     node_graph = np.repeat(np.arange(G), np.diff(node_off))
     edge_graph = np.repeat(np.arange(G), np.diff(edge_off))
     oe, on, og = p["out_dims"]
-    outs = ([], [], [])
-    scales = ([], [], [])
+    We, Wn, Wg = (np.asarray(p[k], dtype=F64) for k in ("We", "Wn", "Wg"))
+    want = return_scale
+    sin = in_scale if in_scale is not None else (None, None, None)
+    outs, scales = ([], [], []), ([], [], [])
     for r in range(R):
-        parts = []
-        if ef is not None:
-            parts.append(np.asarray(ef[r], dtype=F64))
+        efr = None if ef is None else ef[r]
+        nfr = None if nf is None else np.asarray(nf[r], dtype=F64)
+        gfr = None if gf is None else np.asarray(gf[r], dtype=F64)
+        s_ef = None if (ef is None or not want) else (np.abs(efr) if sin[0] is None else sin[0][r])
+        s_nf = None if (nf is None or not want) else (np.abs(nfr) if sin[1] is None else sin[1][r]).astype(np.float32)
+        s_gf = None if (gf is None or not want) else (np.abs(gfr) if sin[2] is None else sin[2][r]).astype(np.float32)
+        he = np.empty((E, oe), dtype=F64)
+        se = np.empty((E, oe), dtype=np.float32) if want else None
+        for c0 in range(0, max(E, 1), _CHUNK):
+            c1 = min(E, c0 + _CHUNK)
+            if c1 <= c0:
+                break
+            parts, sparts = [], []
+            if ef is not None:
+                parts.append(np.asarray(efr[c0:c1], dtype=F64))
+                if want:
+                    sparts.append(np.asarray(s_ef[c0:c1], dtype=np.float32))
+            if nf is not None:
+                parts += [nfr[rowval[c0:c1]], nfr[dst[c0:c1]]]
+                if want:
+                    sparts += [s_nf[rowval[c0:c1]], s_nf[dst[c0:c1]]]
+            if gf is not None:
+                parts.append(gfr[edge_graph[c0:c1]])
+                if want:
+                    sparts.append(s_gf[edge_graph[c0:c1]])
+            Xe = np.concatenate(parts, axis=1) if parts else np.zeros((c1 - c0, 0))
+            he[c0:c1] = _dense_rows(We, p["be"], p["act_e"], Xe)
+            if want:
+                se[c0:c1] = _scale_rows(np.concatenate(sparts, axis=1), We, p["be"])
+
+        parts = [_segsum(he, dst, N)]
+        sparts = [_segsum(se, dst, N).astype(np.float32)] if want else None
         if nf is not None:
-            nfr = np.asarray(nf[r], dtype=F64)
-            parts += [nfr[rowval], nfr[dst]]
+            parts.append(nfr)
+            if want:
+                sparts.append(s_nf)
         if gf is not None:
-            gfr = np.asarray(gf[r], dtype=F64)
-            parts.append(gfr[edge_graph])
-        Xe = np.concatenate(parts, axis=1) if parts else np.zeros((E, 0))
-        he = _dense_rows(p["We"], p["be"], p["act_e"], Xe)
-        se = np.abs(Xe) @ np.abs(np.asarray(p["We"], dtype=F64)).T + np.abs(p["be"])[None, :]
+            parts.append(gfr[node_graph])
+            if want:
+                sparts.append(s_gf[node_graph])
+        hn = _dense_rows(Wn, p["bn"], p["act_n"], np.concatenate(parts, axis=1))
+        sn = _scale_rows(np.concatenate(sparts, axis=1), Wn, p["bn"]) if want else None
 
-        def segsum(v, seg, n):
-            out = np.zeros((n, v.shape[1]), dtype=F64)
-            np.add.at(out, seg, v)
-            return out
-
-        parts = [segsum(he, dst, N)]
-        sparts = [segsum(se, dst, N)]
-        if nf is not None:
-            parts.append(nfr); sparts.append(np.abs(nfr))
+        parts = [_segsum(he, edge_graph, G), _segsum(hn, node_graph, G)]
+        sparts = [_segsum(se, edge_graph, G).astype(np.float32), _segsum(sn, node_graph, G).astype(np.float32)] if want else None
         if gf is not None:
-            parts.append(gfr[node_graph]); sparts.append(np.abs(gfr[node_graph]))
-        Xn = np.concatenate(parts, axis=1)
-        hn = _dense_rows(p["Wn"], p["bn"], p["act_n"], Xn)
-        sn = np.concatenate(sparts, axis=1) @ np.abs(np.asarray(p["Wn"], dtype=F64)).T + np.abs(p["bn"])[None, :]
-
-        parts = [segsum(he, edge_graph, G), segsum(hn, node_graph, G)]
-        sparts = [segsum(se, edge_graph, G), segsum(sn, node_graph, G)]
-        if gf is not None:
-            parts.append(gfr); sparts.append(np.abs(gfr))
-        Xg = np.concatenate(parts, axis=1)
-        hg = _dense_rows(p["Wg"], p["bg"], p["act_g"], Xg)
-        sg = np.concatenate(sparts, axis=1) @ np.abs(np.asarray(p["Wg"], dtype=F64)).T + np.abs(p["bg"])[None, :]
+            parts.append(gfr)
+            if want:
+                sparts.append(s_gf)
+        hg = _dense_rows(Wg, p["bg"], p["act_g"], np.concatenate(parts, axis=1))
+        sg = _scale_rows(np.concatenate(sparts, axis=1), Wg, p["bg"]) if want else None
         for lst, v in zip(outs, (he, hn, hg)):
             lst.append(v)
         for lst, v in zip(scales, (se, sn, sg)):
@@ -442,19 +484,73 @@ def block_forward_sparse(p, csc, ef, nf, gf, return_scale=False):
     return res
 
 
-def core_forward_sparse(p, csc, ef, nf, gf):
-    """GNCore on packed data (all three inputs required, gncore.jl:61-68)."""
+def layernorm_scale(x, s, gamma, beta, eps=1e-5, eps_mode=0):
+    """Error scale of LayerNorm(x) over the last axis for an input that carries the error scale s >= |x| (first order,
+    worst case): δμ <= mean(s), δ(x-μ) <= s + mean(s) =: sc, δσ <= sqrt(mean(sc²)) =: q (Cauchy-Schwarz on
+    mean((x-μ)·δ(x-μ))/σ), hence δx̂ <= (sc + |x̂|·q) / (σ+ε); the affine part adds its own rounding |γ·x̂| + |β|.
+    LayerNorm divides by σ: for U[0,1) inputs (σ ≈ 0.29) the scale grows about 3.5x — that is arithmetic, not slack."""
+    x = np.asarray(x, dtype=F64)
+    s = np.asarray(s, dtype=F64)
+    mu = x.mean(axis=-1, keepdims=True)
+    xc = x - mu
+    var = (xc ** 2).mean(axis=-1, keepdims=True)
+    den = (np.sqrt(var) + eps) if eps_mode == 0 else np.sqrt(var + eps)
+    xhat = xc / den
+    sc = s + s.mean(axis=-1, keepdims=True)
+    q = np.sqrt((sc ** 2).mean(axis=-1, keepdims=True))
+    g = np.abs(np.asarray(gamma, dtype=F64))
+    return (g * ((sc + np.abs(xhat) * q) / den + np.abs(xhat)) + np.abs(np.asarray(beta, dtype=F64))).astype(np.float32)
+
+
+def _ffn_rows(p, t, x2, s2):
+    """FeedForward (gnfeedforward.jl:27-31) on rows, in chunks (the 4d-wide hidden layer of 1M x 128 rows is 4 GB in float64);
+    returns (ff, scale | None)."""
+    W1, b1, W2, b2 = p[f"ff_{t}_W1"], p[f"ff_{t}_b1"], p[f"ff_{t}_W2"], p[f"ff_{t}_b2"]
+    rows = x2.reshape(-1, x2.shape[-1])
+    ff = np.empty_like(rows)
+    sc = None if s2 is None else np.empty(rows.shape, dtype=np.float32)
+    srows = None if s2 is None else s2.reshape(-1, s2.shape[-1])
+    for c0 in range(0, rows.shape[0], _CHUNK):
+        c1 = min(rows.shape[0], c0 + _CHUNK)
+        h = _dense_rows(W1, b1, ACT_RELU, rows[c0:c1])
+        ff[c0:c1] = _dense_rows(W2, b2, ACT_IDENTITY, h)  # Dropout: identity in test mode
+        if sc is not None:
+            sc[c0:c1] = _scale_rows(_scale_rows(srows[c0:c1], W1, b1), W2, b2)
+    return ff.reshape(x2.shape), (None if sc is None else sc.reshape(x2.shape))
+
+
+def core_forward_sparse(p, csc, ef, nf, gf, return_scale=False, in_scale=None):
+    """GNCore on packed data (all three inputs required, gncore.jl:61-68): y = x + block(gn1(x)) + ffwd(gn2(x)).
+    `return_scale` / `in_scale` as in block_forward_sparse: the scale of every output is |x| (or its incoming scale) + the
+    block's scale for inputs carrying gn1's scale + the FeedForward's scale for inputs carrying gn2's scale, so a chain of
+    layers can hand each layer's scale to the next (tests: `<= 1e-5 * scale` at every depth)."""
     xs = dict(e=np.asarray(ef, dtype=F64), n=np.asarray(nf, dtype=F64), g=np.asarray(gf, dtype=F64))
+    sx = None
+    if return_scale:
+        sin = in_scale if in_scale is not None else (None, None, None)
+        sx = {t: (np.abs(xs[t]).astype(np.float32) if si is None else np.asarray(si, dtype=np.float32)) for t, si in zip("eng", sin)}
     ln = lambda which: {t: layernorm(xs[t], p[f"{which}_{t}_gamma"], p[f"{which}_{t}_beta"], p["eps"], p["eps_mode"], axis=-1)
                         for t in "eng"}
-    x1, x2 = ln("ln1"), ln("ln2")
-    be, bn, bg = block_forward_sparse(p["block"], csc, x1["e"], x1["n"], x1["g"])
-    out = []
-    for t, blk in zip("eng", (be, bn, bg)):
-        x = x2[t]
-        h = _dense_rows(p[f"ff_{t}_W1"], p[f"ff_{t}_b1"], ACT_RELU, x.reshape(-1, x.shape[-1]))
-        ff = _dense_rows(p[f"ff_{t}_W2"], p[f"ff_{t}_b2"], ACT_IDENTITY, h).reshape(x.shape)
-        out.append(xs[t] + blk + ff)
+    lns = lambda which: {t: layernorm_scale(xs[t], sx[t], p[f"{which}_{t}_gamma"], p[f"{which}_{t}_beta"], p["eps"], p["eps_mode"])
+                         for t in "eng"}
+    x1 = ln("ln1")
+    if return_scale:
+        s1 = lns("ln1")
+        blk, sblk = block_forward_sparse(p["block"], csc, x1["e"], x1["n"], x1["g"], return_scale=True, in_scale=(s1["e"], s1["n"], s1["g"]))
+        del s1
+    else:
+        blk, sblk = block_forward_sparse(p["block"], csc, x1["e"], x1["n"], x1["g"]), (None, None, None)
+    del x1
+    out, scales = [], []
+    for i, t in enumerate("eng"):
+        x2 = layernorm(xs[t], p[f"ln2_{t}_gamma"], p[f"ln2_{t}_beta"], p["eps"], p["eps_mode"], axis=-1)
+        s2 = layernorm_scale(xs[t], sx[t], p[f"ln2_{t}_gamma"], p[f"ln2_{t}_beta"], p["eps"], p["eps_mode"]) if return_scale else None
+        ff, sff = _ffn_rows(p, t, x2, s2)
+        out.append(xs[t] + blk[i] + ff)
+        if return_scale:
+            scales.append(sx[t] + sblk[i] + sff)
+    if return_scale:
+        return tuple(out), tuple(scales)
     return tuple(out)
 
 

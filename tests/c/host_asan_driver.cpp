@@ -1,0 +1,161 @@
+// AddressSanitizer build of libgnx's HOST shim (gnx_graphs.cpp, gnx_model.cpp, gnx_jit.cpp, gnx_profile.cpp), driven on the CPU
+// ("build -fsanitize=address host shim").  The kernels live in .hip translation units that a host sanitizer cannot
+// see; the handful of device-side entry points the shim calls are stubbed here to answer "no device" — what the real ones
+// answer on a box without a GPU.  What runs under ASan: adjacency / CSC validation and conversion, tile-table construction,
+// every error path that must free a half-built handle, model-descriptor validation, the run-time kernel specialiser's
+// source handling (hiprtc compiles gfx950 code without a GPU) and the profiling registry.
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "gnx_internal.h"
+
+extern "C" const char gnx_jit_source[] = R"(
+namespace gnx { struct BlockArgs { int x; };
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN, bool ONEG> __global__ void k_block_wave(BlockArgs a, int n) {}
+template <int C, bool ONEG> __global__ void k_graph_t(BlockArgs a, int n) {} }
+)";
+
+namespace gnx {
+int32_t build_csc_on_device(const void* const*, const int64_t*, int64_t, int32_t, int32_t, std::vector<int64_t>&, std::vector<int64_t>&,
+                            const std::vector<int64_t>&) {
+  return fail(100, "stub: no device");
+}
+}  // namespace gnx
+extern "C" {
+size_t gnx_block_workspace_bytes(const gnx_graphs*, const gnx_block_params*, int64_t) { return 256; }
+size_t gnx_core_workspace_bytes(const gnx_graphs*, const gnx_core_params*, int64_t) { return 256; }
+int32_t gnx_block_forward(const gnx_graphs*, const gnx_block_params*, const float*, const float*, const float*, int64_t, float*, float*, float*, void*,
+                          size_t, uint32_t, void*) { return 100; }
+int32_t gnx_core_forward(const gnx_graphs*, const gnx_core_params*, const float*, const float*, const float*, int64_t, float*, float*, float*, void*,
+                         size_t, uint32_t, void*) { return 100; }
+}
+
+static int failures = 0;
+#define EXPECT(cond)                                                      \
+  do {                                                                    \
+    if (!(cond)) { ++failures; fprintf(stderr, "FAILED %s:%d: %s (last error: %s)\n", __FILE__, __LINE__, #cond, gnx_last_error()); } \
+  } while (0)
+
+int main() {
+  std::mt19937 rng(7);
+  // ---- dense adjacency: validation, every element kind, row/column-major; creation then fails at the device (no GPU) and
+  //      the half-built handle must be released without a leak ----
+  for (int trial = 0; trial < 50; ++trial) {
+    const int G = 1 + (int)(rng() % 6);
+    std::vector<std::vector<double>> mats64(G);
+    std::vector<std::vector<int32_t>> mats32(G);
+    std::vector<const void*> p64(G), p32(G);
+    std::vector<int64_t> nn(G);
+    for (int g = 0; g < G; ++g) {
+      const int n = 1 + (int)(rng() % 40);
+      nn[g] = n;
+      mats64[g].resize((size_t)n * n);
+      mats32[g].resize((size_t)n * n);
+      for (size_t i = 0; i < mats64[g].size(); ++i) { const int v = rng() % 4 == 0; mats64[g][i] = v; mats32[g][i] = v; }
+      p64[g] = mats64[g].data(); p32[g] = mats32[g].data();
+    }
+    gnx_graphs* h = nullptr;
+    int32_t rc = gnx_graphs_create_dense(p64.data(), nn.data(), G, GNX_ELEM_F64, trial & 1, &h);
+    EXPECT(rc != GNX_OK || h != nullptr);  // no GPU here: a HIP error code (> 0) and no handle, or (with a GPU) a handle
+    if (h) gnx_graphs_destroy(h);
+    h = nullptr;
+    rc = gnx_graphs_create_dense(p32.data(), nn.data(), G, GNX_ELEM_I32, trial & 1, &h);
+    if (h) gnx_graphs_destroy(h);
+    mats32[0][0] = 7;  // not 0/1
+    h = nullptr;
+    EXPECT(gnx_graphs_create_dense(p32.data(), nn.data(), G, GNX_ELEM_I32, 0, &h) == GNX_ERR_ADJ_VALUE && h == nullptr);
+  }
+  // ---- CSC input: well-formed (then the device step fails or succeeds), and every malformation ----
+  for (int trial = 0; trial < 50; ++trial) {
+    const int G = 1 + (int)(rng() % 5), base = trial & 1;
+    std::vector<std::vector<int64_t>> cps(G), rvs(G);
+    std::vector<const int64_t*> cpp(G), rvp(G);
+    std::vector<int64_t> nn(G);
+    for (int g = 0; g < G; ++g) {
+      const int n = 1 + (int)(rng() % 300);
+      nn[g] = n;
+      cps[g].push_back(base);
+      for (int j = 0; j < n; ++j) {
+        int64_t deg = 0;
+        for (int i = 0; i < n; ++i)
+          if (rng() % 16 == 0) { rvs[g].push_back(i + base); ++deg; }
+        cps[g].push_back(cps[g].back() + deg);
+      }
+      if (rvs[g].empty()) rvs[g].push_back(base);  // keeps .data() non-NULL; not referenced when there are no edges
+      cpp[g] = cps[g].data(); rvp[g] = rvs[g].data();
+    }
+    gnx_graphs* h = nullptr;
+    int32_t rc = gnx_graphs_create_csc(cpp.data(), rvp.data(), nn.data(), G, base, &h);
+    EXPECT((rc == GNX_OK) == (h != nullptr));
+    if (h) {
+      gnx_graphs_info info;
+      EXPECT(gnx_graphs_get_info(h, &info) == GNX_OK && info.n_graphs == G);
+      std::vector<int64_t> no(G + 1), eo(G + 1);
+      EXPECT(gnx_graphs_get_offsets(h, no.data(), eo.data()) == GNX_OK);
+      gnx_graphs_destroy(h);
+    }
+    // malformed: colptr decreasing
+    if (nn[0] >= 2) {
+      auto bad = cps[0];
+      bad[1] = bad[0] - 1;
+      cpp[0] = bad.data();
+      h = nullptr;
+      EXPECT(gnx_graphs_create_csc(cpp.data(), rvp.data(), nn.data(), G, base, &h) == GNX_ERR_CSC && h == nullptr);
+      cpp[0] = cps[0].data();
+    }
+    // malformed: source index out of range
+    if (cps[0].back() > base) {
+      auto bad = rvs[0];
+      bad[0] = nn[0] + base + 5;
+      rvp[0] = bad.data();
+      h = nullptr;
+      EXPECT(gnx_graphs_create_csc(cpp.data(), rvp.data(), nn.data(), G, base, &h) == GNX_ERR_CSC && h == nullptr);
+      rvp[0] = rvs[0].data();
+    }
+  }
+  {
+    gnx_graphs* h = nullptr;
+    EXPECT(gnx_graphs_create_csc(nullptr, nullptr, nullptr, 1, 0, &h) == GNX_ERR_INVALID_ARG);
+    EXPECT(gnx_graphs_create_csc(nullptr, nullptr, nullptr, 0, 0, &h) == GNX_ERR_NO_GRAPHS);
+    EXPECT(gnx_graphs_destroy(nullptr) == GNX_OK);
+    gnx_graphs_info info;
+    EXPECT(gnx_graphs_get_info(nullptr, &info) != GNX_OK);
+  }
+  // ---- model descriptors ----
+  {
+    gnx_model* m = nullptr;
+    gnx_layer l{};
+    EXPECT(gnx_model_create(nullptr, &l, 1, 1, &m) != GNX_OK && m == nullptr);
+    EXPECT(gnx_model_destroy(nullptr) == GNX_OK);
+    int32_t dims[3];
+    EXPECT(gnx_model_out_dims(nullptr, dims) != GNX_OK);
+  }
+  // ---- run-time specialiser: compile-only entry (no GPU needed); the stub source above stands in for the kernel text ----
+  {
+    gnx_block_params p{};
+    p.de = 7; p.dn = 3; p.dg = 2; p.oe = 5; p.on = 6; p.og = 1;
+    size_t bytes = 0;
+    const int32_t rc = gnx_jit_precompile(&p, 128, &bytes);
+    EXPECT(rc == GNX_OK ? bytes > 0 : gnx_last_error()[0] != 0);  // hiprtc present: a code object; absent: a message
+    EXPECT(gnx_jit_precompile(&p, 100, &bytes) == GNX_ERR_INVALID_ARG);
+    p.oe = 500;
+    EXPECT(gnx_jit_precompile(&p, 128, &bytes) == GNX_ERR_DIMS);
+    int64_t st[4];
+    EXPECT(gnx_jit_stats(st) == GNX_OK);
+  }
+  // ---- profiling registry ----
+  {
+    EXPECT(gnx_profile_enable(1) == GNX_OK);
+    EXPECT(gnx_profile_reset() == GNX_OK);
+    gnx_profile_entry e[4];
+    int32_t n = -1;
+    EXPECT(gnx_profile_read(e, 4, &n) == GNX_OK && n == 0);
+    EXPECT(gnx_profile_enable(0) == GNX_OK);
+  }
+  if (failures) { fprintf(stderr, "%d expectation(s) failed\n", failures); return 1; }
+  printf("host_asan_driver: ok\n");
+  return 0;
+}

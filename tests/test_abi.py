@@ -84,3 +84,39 @@ def test_runtime_specialised_kernel_source_compiles_for_gfx950(lib):
     assert lib.gnx_jit_precompile(C.byref(L.BlockParams(7, 3, 2, 5, 6, 1)), 100, C.byref(n)) == -1
     st = (C.c_int64 * 4)()
     assert lib.gnx_jit_stats(st) == 0 and st[0] >= 1 and st[2] == 0
+
+
+def _make_c_tests():
+    import subprocess
+    import __graft_entry__ as ge
+    ge.build()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c")])
+    return os.path.join(ROOT, "tests", "c", "_build")
+
+
+def test_c_language_binding_compiles_links_and_validates():
+    """tests/c/abi_smoke.c — include/gnx.h consumed by a C compiler (gcc, -Wall -Werror), struct layout by the compiler, linked
+    against libgnx.so like a `ccall` host: symbol resolution, version, argument validation (no GPU needed for these)."""
+    import subprocess
+    out = subprocess.run([os.path.join(_make_c_tests(), "abi_smoke"), "--symbols"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "symbols ok" in out.stdout
+
+
+def test_host_shim_under_address_sanitizer():
+    """libgnx's host translation units built with g++ -fsanitize=address,undefined and driven through adjacency /
+    CSC validation, tile construction, failed handle creation, model validation, the run-time specialiser and the profiler."""
+    import subprocess
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run([os.path.join(_make_c_tests(), "host_asan_driver")], capture_output=True, text=True, env=env)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "host_asan_driver: ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_readme_example_1_through_the_c_abi_from_c():
+    """The full C program: README example 1 built, run on the GPU and checked against an inline double-precision evaluation."""
+    import subprocess
+    out = subprocess.run([os.path.join(_make_c_tests(), "abi_smoke")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "max |hip - double|" in out.stdout

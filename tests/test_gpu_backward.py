@@ -45,9 +45,18 @@ DIMS = [((10, 5, 0), (3, 4, 5)), ((3, 2, 4), (3, 4, 5)), ((0, 2, 0), (2, 2, 2)),
         ((40, 24, 8), (36, 20, 12))]
 
 
-def _graphs(rng, big):
+def _graphs(rng, big, many=False):
     """small: 6 graphs of 5..40 nodes (generic kernels); big: 3 graphs of 1500..2200 nodes, 4 edges per node — enough rows
     (>= 4096 nodes and edges) for the matrix-core dX / dW kernels of the backward to be selected."""
+    if many:  # more graphs than a grid's y / z extent (65535): 70k graphs of 2 or 3 nodes
+        sizes = rng.integers(2, 4, 70_000)
+        cps, rvs = [], []
+        for n in sizes:
+            k = np.sort(rng.choice(int(n) * int(n), 2, replace=False))
+            cp = np.zeros(int(n) + 1, dtype=np.int64)
+            np.add.at(cp, k // int(n) + 1, 1)
+            cps.append(np.cumsum(cp)); rvs.append((k % int(n)).astype(np.int64))
+        return sizes, cps, rvs
     sizes = rng.integers(1500, 2200, 3) if big else rng.integers(5, 40, 6)
     cps, rvs = [], []
     for n in sizes:
@@ -79,8 +88,8 @@ def test_block_backward_matches_torch_autograd(gn, dims, act, request):
     pytest.fail("no kink-free draw in 20 attempts")
 
 
-def _block_backward_case(gn, dims, act, big, rng):
-    sizes, cps, rvs = _graphs(rng, big)
+def _block_backward_case(gn, dims, act, big, rng, many=False):
+    sizes, cps, rvs = _graphs(rng, big, many)
     g = gn.GNGraphBatch.from_csc(cps, rvs, [int(n) for n in sizes])
     csc = (*g.csc(), g.node_off, g.edge_off)
     p = O.make_block_params(rng, *dims, act=act)
@@ -127,6 +136,11 @@ def _block_backward_case(gn, dims, act, big, rng):
             close(layer.weight.grad, W[kw].grad, f"dW_{name}")
             close(layer.bias.grad, W[kb].grad, f"db_{name}")
     return True
+
+
+def test_block_forward_backward_with_more_than_65535_graphs(gn):
+    """70 000 tiny graphs: the graph index must not sit in a grid dimension that stops at 65535 (forward and backward)."""
+    assert _block_backward_case(gn, ((3, 2, 4), (3, 4, 5)), (0, 0, 0), False, np.random.default_rng(777), many=True)
 
 
 def test_backward_is_deterministic_and_trains(gn):

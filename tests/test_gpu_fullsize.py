@@ -82,3 +82,33 @@ def test_full_size_affinity_and_reproducibility(gn):
         assert float((lhs - rhs).abs().max()) <= tol
     again = blk(U.to_nt(gn, g, *x))
     assert torch.equal(again.ef, fx.ef) and torch.equal(again.nf, fx.nf) and torch.equal(again.gf, fx.gf)
+
+
+def test_config4_full_size_encoder_2cores_decoder(gn):
+    """BASELINE configs[3] at its stated size: Encoder (10,5,0)=>(128,64,32) -> 2 x GNCore(128,64,32) -> Decoder =>(3,4,5) on
+    the 100k-node / 1M-edge graph, against the float64 oracle (chunked): every layer elementwise at 1e-5·scale from the
+    float32-rounded oracle input of that layer, and the free-running chain normwise at 1e-5 (tests/util.py::check_chain)."""
+    g, csc = _graph(gn, bench.make_c2)
+    rng = np.random.default_rng(110)
+    core = (128, 64, 32)
+    pe, pd = O.make_block_params(rng, (10, 5, 0), core), O.make_block_params(rng, core, (3, 4, 5))
+    pcs = [O.make_core_params(rng, core) for _ in range(2)]
+    layers = [("block", pe, U.block_from_params(gn, pe))] + [("core", p, U.core_from_params(gn, p)) for p in pcs] + [("block", pd, U.block_from_params(gn, pd))]
+    ef, nf, _ = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, 1, (10, 5, 0))
+    stats = U.check_chain(gn, g, csc, layers, (ef, nf, None), "config 4 at 1M edges")
+    print("config 4, 1M edges: worst layer-wise ratio to 1e-5*scale / end-to-end normwise error:", stats)
+
+
+@pytest.mark.parametrize("which", ["c2", "c3"])
+def test_core_dims_block_full_size(gn, which):
+    """The matrix-core path at BASELINE sizes: GNBlock (128,64,32)=>(128,64,32) on the 1M-edge C2 graph (one graph, 7813 row
+    tiles, 8 column tiles per XCD group) and on the 512-graph C3 batch, elementwise at 1e-5·scale."""
+    g, csc = _graph(gn, bench.make_c2 if which == "c2" else (lambda: bench.make_hetero(3)))
+    rng = np.random.default_rng(111)
+    dims = ((128, 64, 32), (128, 64, 32))
+    p = O.make_block_params(rng, *dims)
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims[0])
+    y = U.block_from_params(gn, p)(U.to_nt(gn, g, ef, nf, gf))
+    ref, scale = O.block_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r, s, name)

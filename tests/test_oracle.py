@@ -269,3 +269,29 @@ def test_three_independent_restatements_agree():
             np.testing.assert_allclose(dense["ef"][i].T, sp[0][0, off_e[i]:off_e[i + 1]], rtol=1e-12, atol=1e-12)
             np.testing.assert_allclose(dense["nf"][i].T, sp[1][0, off_n[i]:off_n[i + 1]], rtol=1e-12, atol=1e-12)
             np.testing.assert_allclose(dense["gf"][i], sp[2][0, i], rtol=1e-12, atol=1e-12)
+
+
+def test_propagated_error_scale_bounds_the_effect_of_input_perturbations():
+    """`return_scale` / `in_scale` (the parity tests' tolerance scale): perturb every input by at most eta * s and the outputs
+    move by at most eta * scale_out (first order), for a block, a core (LayerNorm's 1/σ!) and a core fed by a block."""
+    rng = np.random.default_rng(77)
+    adjs = [(rng.random((n, n)) < 0.4).astype(np.int64) for n in (5, 9, 3, 12)]
+    csc = O.csc_from_adj(adjs)
+    E, N, G = len(csc[1]), len(csc[0]) - 1, len(adjs)
+    dims = (6, 5, 3)
+    pb, pc = O.make_block_params(rng, dims, dims), O.make_core_params(rng, dims)
+    x = [rng.random((1, T, d)) for T, d in zip((E, N, G), dims)]
+    eta = 1e-7
+    for trial in range(5):
+        xp = [a + eta * np.abs(a) * rng.uniform(-1, 1, a.shape) for a in x]
+        for fwd in (lambda z, sc=None: O.block_forward_sparse(pb, csc, *z, return_scale=True, in_scale=sc),
+                    lambda z, sc=None: O.core_forward_sparse(pc, csc, *z, return_scale=True, in_scale=sc)):
+            (y, s), (yp, _) = fwd(x), fwd(xp)
+            for a, b, sc in zip(y, yp, s):
+                assert np.all(np.abs(a - b) <= 1.01 * eta * sc + 1e-13)
+        # chained: the block's scale is the core's in_scale
+        (y1, s1), (y1p, _) = O.block_forward_sparse(pb, csc, *x, return_scale=True), O.block_forward_sparse(pb, csc, *xp, return_scale=True)
+        (y2, s2) = O.core_forward_sparse(pc, csc, *y1, return_scale=True, in_scale=s1)
+        y2p = O.core_forward_sparse(pc, csc, *y1p)
+        for a, b, sc in zip(y2, y2p, s2):
+            assert np.all(np.abs(a - b) <= 1.01 * eta * sc + 1e-13)

@@ -12,7 +12,6 @@ run() {  # name, env..., -- args
     echo "$name rep$rep $(echo "$line" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); r=d["roofline"]; print("us/step", round(d["ms_per_step"]*1e3,2), "warm", round(d["config"].get("warm_ms_per_step",0)*1e3,2), "kernels", r["all_kernels_us"], "frac", r["frac"], "whole", r["frac_whole_step"])' 2>&1)" | tee -a $LOG
   done
 }
-for sc in 0.005 0.02 0.05 0.1 0.2 0.4 1.0; do
-run c2x${sc}_ticket GNX_TICKET_MAX_ROWS=100000000 -- --c2-scale $sc "$@"
-run c2x${sc}_twolaunch X=1 -- --c2-scale $sc --two-launch "$@"
-done
+run c2 X=1 -- "$@"
+run hetero512 X=1 -- --workload hetero "$@"
+run hetero4096 X=1 -- --workload hetero --hetero-graphs 4096 "$@"

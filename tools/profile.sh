@@ -19,5 +19,5 @@ if [ "${GNX_PROF_MFMA:-0}" = "1" ]; then
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/pmc_mfma" -- $BENCH > "$OUT/pmc_mfma.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d "$OUT/pmc_mix" -- $BENCH > "$OUT/pmc_mix.log" 2>&1
 fi
-python3 $REPO/tools/summarize_prof.py "$OUT" "$OUT/summary" > "$OUT/summary.txt" 2>&1
+python3 $REPO/tools/summarize_prof.py "$OUT" "$OUT/summary" ${GNX_PROF_DIMS:+--dims $GNX_PROF_DIMS} > "$OUT/summary.txt" 2>&1
 tail -60 "$OUT/summary.txt"
