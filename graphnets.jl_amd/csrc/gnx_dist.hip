@@ -1,0 +1,260 @@
+// gnx_dist_* — the by-graph sharded forward reachable from the C boundary (SURVEY §8e, §8b "gnx_dist_*"; north_star:
+// "heterogeneous-graph batches shard by graph across the 8 GPUs of one node with RCCL all-gather of graph-level features over
+// xGMI only for the graph update").  The reference has no multi-device code at all (no Distributed / MPI / NCCL anywhere in
+// /root/reference/src); what makes the sharding legal is that every term of a graph's edge, node and graph update depends on
+// that graph only (src/gngraphbatch.jl builds every broadcaster per batch slice; NNlib.batched_mul never mixes batch indices).
+//
+// Design: ONE host process (a Julia session, a C program) drives n devices — ncclCommInitAll, one communication stream per
+// device, ncclGroupStart/End around the n all-gathers.  Whole graphs are assigned to ranks (gnx_dist_partition: equal graph
+// counts, snake order by edge count); every rank runs gnx_block_forward on the handle of ITS graphs; the only collective is
+// ONE all-gather of gf' (<= 64 KB per rank: latency-bound on xGMI, so it runs on the communication streams and the caller's
+// streams only wait for an event); a per-device index table restores the ORIGINAL graph order.  RCCL is dlopen'ed
+// (librccl.so.1): libgnx.so has no link-time dependency on it, and a process that already carries an RCCL (torch) shares it.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+#include "gnx_internal.h"
+
+namespace gnx {
+namespace {
+
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+#define GNX_SYM(field, sym) *reinterpret_cast<void**>(&r.field) = dlsym(r.lib, sym)
+    GNX_SYM(CommInitAll, "ncclCommInitAll");
+    GNX_SYM(CommDestroy, "ncclCommDestroy");
+    GNX_SYM(AllGather, "ncclAllGather");
+    GNX_SYM(GroupStart, "ncclGroupStart");
+    GNX_SYM(GroupEnd, "ncclGroupEnd");
+    GNX_SYM(GetErrorString, "ncclGetErrorString");
+#undef GNX_SYM
+    r.ok = r.CommInitAll && r.CommDestroy && r.AllGather && r.GroupStart && r.GroupEnd && r.GetErrorString;
+  });
+  return r;
+}
+
+int32_t nccl_fail(ncclResult_t e, const char* what) {
+  set_error(std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(e) : "RCCL error"));
+  return 1000 + (int32_t)e;  // > 0 like a HIP error; RCCL results are offset so the two ranges do not collide
+}
+#define GNX_NCCL(expr)                                          \
+  do {                                                          \
+    ncclResult_t _e = (expr);                                   \
+    if (_e != ncclSuccess) return gnx::nccl_fail(_e, #expr);    \
+  } while (0)
+
+// gf_all[g][:] = recv[src[g]][:]  (undoes the zero padding of unequal shards and the partition's permutation)
+__global__ void k_dist_permute(const float* __restrict__ recv, const int* __restrict__ src, int G, int og, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < G * og) {
+    const int g = i / og, j = i - g * og;
+    out[i] = recv[(size_t)src[g] * og + j];
+  }
+}
+
+}  // namespace
+}  // namespace gnx
+
+struct gnx_dist {
+  int n = 0;
+  int64_t G = 0;
+  int og = 0;
+  int64_t max_count = 0;
+  std::vector<int> dev;
+  std::vector<int64_t> count;          // graphs of rank r
+  std::vector<ncclComm_t> comm;
+  std::vector<hipStream_t> cstream;    // communication stream of device r
+  std::vector<hipEvent_t> ev_in, ev_out;
+  std::vector<float*> send, recv;      // [max_count][og], [n * max_count][og] on device r
+  std::vector<int*> src;               // [G] row of recv for original graph g, on device r
+};
+
+using namespace gnx;
+
+extern "C" {
+
+int32_t gnx_dist_partition(const int64_t* edge_counts, int64_t n_graphs, int32_t n_ranks, int64_t* shard_off, int64_t* shard_graphs) {
+  if (!edge_counts || !shard_off || !shard_graphs) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  if (n_graphs <= 0) return fail(GNX_ERR_NO_GRAPHS, "n_graphs must be > 0");
+  if (n_ranks <= 0) return fail(GNX_ERR_INVALID_ARG, "n_ranks must be >= 1");
+  // graphs by edge count, descending (stable: ties keep ascending ids), dealt in snake order: rank 0..R-1, R-1..0, ...
+  std::vector<int64_t> order((size_t)n_graphs);
+  std::iota(order.begin(), order.end(), (int64_t)0);
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return edge_counts[a] > edge_counts[b]; });
+  std::vector<std::vector<int64_t>> shards((size_t)n_ranks);
+  for (int64_t i = 0; i < n_graphs; ++i) {
+    const int64_t rnd = i / n_ranks, pos = i % n_ranks;
+    shards[(size_t)(rnd % 2 == 0 ? pos : n_ranks - 1 - pos)].push_back(order[(size_t)i]);
+  }
+  int64_t o = 0;
+  for (int32_t r = 0; r < n_ranks; ++r) {
+    std::sort(shards[(size_t)r].begin(), shards[(size_t)r].end());  // a rank keeps its graphs in original order
+    shard_off[r] = o;
+    for (int64_t gidx : shards[(size_t)r]) shard_graphs[o++] = gidx;
+  }
+  shard_off[n_ranks] = o;
+  return GNX_OK;
+}
+
+int32_t gnx_dist_destroy(gnx_dist* d) {
+  if (!d) return GNX_OK;
+  for (int r = 0; r < d->n; ++r) {
+    (void)hipSetDevice(d->dev[(size_t)r]);
+    if ((size_t)r < d->cstream.size() && d->cstream[(size_t)r]) (void)hipStreamSynchronize(d->cstream[(size_t)r]);
+    if ((size_t)r < d->comm.size() && d->comm[(size_t)r] && rccl().ok) (void)rccl().CommDestroy(d->comm[(size_t)r]);
+    if ((size_t)r < d->send.size()) (void)hipFree(d->send[(size_t)r]);
+    if ((size_t)r < d->recv.size()) (void)hipFree(d->recv[(size_t)r]);
+    if ((size_t)r < d->src.size()) (void)hipFree(d->src[(size_t)r]);
+    if ((size_t)r < d->ev_in.size() && d->ev_in[(size_t)r]) (void)hipEventDestroy(d->ev_in[(size_t)r]);
+    if ((size_t)r < d->ev_out.size() && d->ev_out[(size_t)r]) (void)hipEventDestroy(d->ev_out[(size_t)r]);
+    if ((size_t)r < d->cstream.size() && d->cstream[(size_t)r]) (void)hipStreamDestroy(d->cstream[(size_t)r]);
+  }
+  delete d;
+  return GNX_OK;
+}
+
+int32_t gnx_dist_create(const int32_t* device_ids, int32_t n_devices, const int64_t* shard_off, const int64_t* shard_graphs, int64_t n_graphs,
+                        int32_t og, gnx_dist** out) {
+  if (!out) return fail(GNX_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (!device_ids || !shard_off || !shard_graphs) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  if (n_devices <= 0 || n_graphs <= 0 || og <= 0) return fail(GNX_ERR_INVALID_ARG, "n_devices, n_graphs and og must be >= 1");
+  if (shard_off[0] != 0 || shard_off[n_devices] != n_graphs) return fail(GNX_ERR_INVALID_ARG, "shard_off must run from 0 to n_graphs");
+  std::vector<char> seen((size_t)n_graphs, 0);
+  for (int r = 0; r < n_devices; ++r) {
+    if (shard_off[r + 1] < shard_off[r]) return fail(GNX_ERR_INVALID_ARG, "shard_off must be non-decreasing");
+    for (int64_t i = shard_off[r]; i < shard_off[r + 1]; ++i) {
+      const int64_t gidx = shard_graphs[i];
+      if (gidx < 0 || gidx >= n_graphs || seen[(size_t)gidx]) return fail(GNX_ERR_INVALID_ARG, "shard_graphs must be a permutation of 0..n_graphs-1");
+      seen[(size_t)gidx] = 1;
+    }
+  }
+  if (!rccl().ok) return fail(GNX_ERR_INVALID_ARG, "RCCL is not available (librccl.so.1 could not be loaded)");
+  int prev_dev = 0;
+  (void)hipGetDevice(&prev_dev);
+  gnx_dist* d = new gnx_dist();
+  d->n = n_devices; d->G = n_graphs; d->og = og;
+  d->dev.assign(device_ids, device_ids + n_devices);
+  for (int r = 0; r < n_devices; ++r) {
+    d->count.push_back(shard_off[r + 1] - shard_off[r]);
+    d->max_count = std::max(d->max_count, d->count.back());
+  }
+  d->comm.assign((size_t)n_devices, nullptr);
+  d->cstream.assign((size_t)n_devices, nullptr);
+  d->ev_in.assign((size_t)n_devices, nullptr);
+  d->ev_out.assign((size_t)n_devices, nullptr);
+  d->send.assign((size_t)n_devices, nullptr);
+  d->recv.assign((size_t)n_devices, nullptr);
+  d->src.assign((size_t)n_devices, nullptr);
+  auto bail = [&](int32_t rc) { gnx_dist_destroy(d); (void)hipSetDevice(prev_dev); return rc; };
+  {
+    const ncclResult_t e = rccl().CommInitAll(d->comm.data(), n_devices, d->dev.data());
+    if (e != ncclSuccess) return bail(nccl_fail(e, "ncclCommInitAll"));
+  }
+  // row of the gathered [n][max_count] table for original graph g
+  std::vector<int> src((size_t)n_graphs);
+  for (int r = 0; r < n_devices; ++r)
+    for (int64_t i = shard_off[r]; i < shard_off[r + 1]; ++i) src[(size_t)shard_graphs[i]] = (int)(r * d->max_count + (i - shard_off[r]));
+  const size_t row = sizeof(float) * (size_t)og;
+  for (int r = 0; r < n_devices; ++r) {
+    hipError_t e = hipSetDevice(d->dev[(size_t)r]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->cstream[(size_t)r], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_in[(size_t)r], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->ev_out[(size_t)r], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->send[(size_t)r], row * (size_t)d->max_count);
+    if (e == hipSuccess) e = hipMemset(d->send[(size_t)r], 0, row * (size_t)d->max_count);  // padding rows stay zero
+    if (e == hipSuccess) e = hipMalloc((void**)&d->recv[(size_t)r], row * (size_t)d->max_count * (size_t)n_devices);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->src[(size_t)r], sizeof(int) * (size_t)n_graphs);
+    if (e == hipSuccess) e = hipMemcpy(d->src[(size_t)r], src.data(), sizeof(int) * (size_t)n_graphs, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(hip_fail(e, "gnx_dist_create: per-device setup"));
+  }
+  (void)hipSetDevice(prev_dev);
+  *out = d;
+  return GNX_OK;
+}
+
+int32_t gnx_dist_allgather_gf(gnx_dist* d, const float* const* gf_local, float* const* gf_all, void* const* streams) {
+  if (!d || !gf_local || !gf_all) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  for (int r = 0; r < d->n; ++r)
+    if ((d->count[(size_t)r] > 0 && !gf_local[r]) || !gf_all[r]) return fail(GNX_ERR_INVALID_ARG, "gf_local / gf_all of a rank is NULL");
+  int prev_dev = 0;
+  (void)hipGetDevice(&prev_dev);
+  const size_t row = sizeof(float) * (size_t)d->og;
+  // the producers' streams hand over to the communication streams; local rows go into the (zero padded) send buffers
+  for (int r = 0; r < d->n; ++r) {
+    GNX_HIP(hipSetDevice(d->dev[(size_t)r]));
+    hipStream_t us = streams ? (hipStream_t)streams[r] : nullptr;
+    GNX_HIP(hipEventRecord(d->ev_in[(size_t)r], us));
+    GNX_HIP(hipStreamWaitEvent(d->cstream[(size_t)r], d->ev_in[(size_t)r], 0));
+    if (d->count[(size_t)r] > 0)
+      GNX_HIP(hipMemcpyAsync(d->send[(size_t)r], gf_local[r], row * (size_t)d->count[(size_t)r], hipMemcpyDeviceToDevice, d->cstream[(size_t)r]));
+  }
+  GNX_NCCL(rccl().GroupStart());
+  for (int r = 0; r < d->n; ++r) {
+    const ncclResult_t e = rccl().AllGather(d->send[(size_t)r], d->recv[(size_t)r], (size_t)d->max_count * (size_t)d->og, ncclFloat, d->comm[(size_t)r],
+                                            d->cstream[(size_t)r]);
+    if (e != ncclSuccess) { (void)rccl().GroupEnd(); return nccl_fail(e, "ncclAllGather"); }
+  }
+  GNX_NCCL(rccl().GroupEnd());
+  for (int r = 0; r < d->n; ++r) {
+    GNX_HIP(hipSetDevice(d->dev[(size_t)r]));
+    const int total = (int)(d->G * d->og);
+    hipLaunchKernelGGL(k_dist_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d->cstream[(size_t)r], d->recv[(size_t)r], d->src[(size_t)r],
+                       (int)d->G, d->og, gf_all[r]);
+    GNX_HIP(hipGetLastError());
+    GNX_HIP(hipEventRecord(d->ev_out[(size_t)r], d->cstream[(size_t)r]));
+    GNX_HIP(hipStreamWaitEvent(streams ? (hipStream_t)streams[r] : nullptr, d->ev_out[(size_t)r], 0));
+  }
+  (void)hipSetDevice(prev_dev);
+  return GNX_OK;
+}
+
+int32_t gnx_dist_block_forward(gnx_dist* d, const gnx_graphs* const* h, const gnx_block_params* const* p, const float* const* ef,
+                               const float* const* nf, const float* const* gf, float* const* ef_out, float* const* nf_out,
+                               float* const* gf_out_local, float* const* gf_all, void* const* workspace, const size_t* workspace_bytes,
+                               uint32_t flags, void* const* streams) {
+  if (!d || !h || !p || !workspace || !workspace_bytes) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  int prev_dev = 0;
+  (void)hipGetDevice(&prev_dev);
+  for (int r = 0; r < d->n; ++r) {
+    if (!h[r] || !p[r]) return fail(GNX_ERR_INVALID_ARG, "handle / params of a rank is NULL");
+    if (h[r]->G != d->count[(size_t)r]) return fail(GNX_ERR_COUNT_MISMATCH, "a rank's handle does not hold the graphs of its shard");
+    if (p[r]->og != d->og) return fail(GNX_ERR_DIMS, "og differs from the communicator's");
+    if (h[r]->device != d->dev[(size_t)r]) return fail(GNX_ERR_INVALID_ARG, "a rank's handle lives on another device");
+  }
+  for (int r = 0; r < d->n; ++r) {  // launches are asynchronous: the n devices run concurrently
+    GNX_HIP(hipSetDevice(d->dev[(size_t)r]));
+    const int32_t rc = gnx_block_forward(h[r], p[r], ef ? ef[r] : nullptr, nf ? nf[r] : nullptr, gf ? gf[r] : nullptr, 1, ef_out ? ef_out[r] : nullptr,
+                                         nf_out ? nf_out[r] : nullptr, gf_out_local ? gf_out_local[r] : nullptr, workspace[r], workspace_bytes[r], flags,
+                                         streams ? streams[r] : nullptr);
+    if (rc) { (void)hipSetDevice(prev_dev); return rc; }
+  }
+  (void)hipSetDevice(prev_dev);
+  return gnx_dist_allgather_gf(d, gf_out_local, gf_all, streams);
+}
+
+}  // extern "C"

@@ -15,15 +15,16 @@ import torch.distributed as dist
 
 def partition_graphs(edge_counts, world_size):
     """Assign whole graphs to ranks: equal graph counts (±1), balanced by edge count (sort by E_g descending, then
-    deal in a snake/boustrophedon order).  Returns a list of int64 index arrays (original graph ids, ascending)."""
-    edge_counts = np.asarray(edge_counts, dtype=np.int64)
-    order = np.argsort(-edge_counts, kind="stable")
-    shards = [[] for _ in range(world_size)]
-    for i, gidx in enumerate(order):
-        rnd, pos = divmod(i, world_size)
-        r = pos if rnd % 2 == 0 else world_size - 1 - pos
-        shards[r].append(int(gidx))
-    return [np.asarray(sorted(s), dtype=np.int64) for s in shards]
+    deal in a snake/boustrophedon order) — `gnx_dist_partition` of the C boundary (one implementation for the Python
+    mirror, the Julia shim and C hosts).  Returns a list of int64 index arrays (original graph ids, ascending)."""
+    import ctypes as C
+    from . import _lib
+    counts = np.ascontiguousarray(edge_counts, dtype=np.int64)
+    off = np.zeros(world_size + 1, dtype=np.int64)
+    ids = np.zeros(len(counts), dtype=np.int64)
+    p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    _lib.check(_lib.load().gnx_dist_partition(p64(counts), len(counts), int(world_size), p64(off), p64(ids)))
+    return [ids[off[r]:off[r + 1]].copy() for r in range(world_size)]
 
 
 class GfGather:

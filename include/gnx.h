@@ -284,6 +284,35 @@ GNX_API int32_t gnx_model_out_dims(const gnx_model* m, int32_t dims[3]);
 GNX_API int32_t gnx_model_forward(gnx_model* m, const float* ef, const float* nf, const float* gf, float* ef_out, float* nf_out,
                           float* gf_out, uint32_t flags, void* stream);
 
+/* ---- multi-GPU: whole graphs sharded over the devices of ONE host process, gf' all-gathered ------------
+ * The reference has no multi-device code (nothing to cite in /root/reference/src); the contract is BASELINE.json's north_star:
+ * "heterogeneous-graph batches shard by graph across the 8 GPUs of one node with RCCL all-gather of graph-level features".
+ * Every term of a graph's edge, node and graph update depends on that graph only, so a rank needs nothing from another rank:
+ * it builds a gnx_graphs handle of ITS graphs (gnx_graphs_create_*) and keeps its ef / nf / gf rows resident; the only
+ * collective is one all-gather of gf'.  One process drives all devices (ncclCommInitAll, ncclGroupStart/End), which is how a
+ * Julia session uses a multi-GPU node.  RCCL is loaded at run time (librccl.so.1).
+ *
+ * gnx_dist_partition (host only): equal graph counts per rank (+-1), balanced by edge count — graphs sorted by E_g descending
+ * (ties: ascending id), dealt to ranks in snake order 0..R-1, R-1..0, ...; rank r owns the original graph ids
+ * shard_graphs[shard_off[r] .. shard_off[r+1]), ascending.  shard_off has n_ranks+1 entries, shard_graphs n_graphs.
+ * gnx_dist_create: communicator over device_ids[0..n) plus the gather plan of a partition (any permutation of the graphs:
+ * rank r's local handle holds its graphs in the order they appear in shard_graphs) for gf' rows of `og` floats.
+ * gnx_dist_allgather_gf: gf_local[r] = device-r rows [count_r][og] of rank r's graphs; afterwards gf_all[r] = device-r table
+ * [n_graphs][og] in ORIGINAL graph order on every rank.  streams[r] (NULL array / entry = default stream): the stream of
+ * device r that produced gf_local[r]; the collective runs on internal streams behind it and gf_all[r] is ready on it.
+ * gnx_dist_block_forward: per rank gnx_block_forward(h[r], p[r], ...; n_replicas = 1) on device r (parameters replicated by
+ * the caller: p[r] points at device-r copies), then the all-gather of gf'.  Arrays have one entry per rank. */
+typedef struct gnx_dist gnx_dist;
+GNX_API int32_t gnx_dist_partition(const int64_t* edge_counts, int64_t n_graphs, int32_t n_ranks, int64_t* shard_off, int64_t* shard_graphs);
+GNX_API int32_t gnx_dist_create(const int32_t* device_ids, int32_t n_devices, const int64_t* shard_off, const int64_t* shard_graphs,
+                        int64_t n_graphs, int32_t og, gnx_dist** out);
+GNX_API int32_t gnx_dist_destroy(gnx_dist* d);
+GNX_API int32_t gnx_dist_allgather_gf(gnx_dist* d, const float* const* gf_local, float* const* gf_all, void* const* streams);
+GNX_API int32_t gnx_dist_block_forward(gnx_dist* d, const gnx_graphs* const* h, const gnx_block_params* const* p, const float* const* ef,
+                               const float* const* nf, const float* const* gf, float* const* ef_out, float* const* nf_out,
+                               float* const* gf_out_local, float* const* gf_all, void* const* workspace, const size_t* workspace_bytes,
+                               uint32_t flags, void* const* streams);
+
 /* ---- run-time specialisation (the analogue of Julia compiling a GNBlock for its own widths on first use) -----------
  * The fused one-launch kernel is compiled ahead of time for the README / benchmark width sets; for any other width set
  * with every width <= 32 (and at most 1024 weights in the edge and node functions) it is compiled at run time with hiprtc (gfx950), once per process and device, the first time

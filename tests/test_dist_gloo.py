@@ -129,3 +129,27 @@ def test_bench_hetero_generators_and_self_launch(monkeypatch):
     cmd = seen["cmd"]
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
     assert "127.0.0.1" in cmd
+
+
+def test_c_partition_equals_the_specified_rule():
+    """gnx_dist_partition against an independent restatement of its rule: sort by edge count descending (stable), deal in snake
+    order, every rank keeps ascending original ids; also odd sizes and more ranks than graphs."""
+    sys.path.insert(0, ROOT)
+    import graphnets_jl_amd  # noqa: F401
+    from graphnets_jl_amd.dist import partition_graphs
+
+    def rule(counts, world):
+        order = np.argsort(-np.asarray(counts, dtype=np.int64), kind="stable")
+        shards = [[] for _ in range(world)]
+        for i, gidx in enumerate(order):
+            rnd, pos = divmod(i, world)
+            shards[pos if rnd % 2 == 0 else world - 1 - pos].append(int(gidx))
+        return [np.asarray(sorted(s), dtype=np.int64) for s in shards]
+
+    rng = np.random.default_rng(11)
+    for G, world in ((4096, 8), (7, 2), (3, 8), (1, 1), (1000, 3)):
+        counts = rng.integers(0, 5000, G)
+        got, want = partition_graphs(counts, world), rule(counts, world)
+        assert len(got) == world
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b)

@@ -116,3 +116,64 @@ def test_bench_force_dist_runs_the_multi_gpu_code_path():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 1e9 and "sharded by graph" in line["config"]["workload"]
     assert line["config"]["graphs_per_gpu"] == 512 and line["roofline"]["frac"] <= 1.0
+
+
+def test_gnx_dist_c_entry_points_world_1(gn):
+    """The sharded path through the C boundary (what the Julia shim binds): gnx_dist_partition, gnx_dist_create (ncclCommInitAll
+    over one device), gnx_dist_block_forward = per-rank gnx_block_forward + ncclAllGather of gf' + restoration of the ORIGINAL
+    graph order.  With one device the single rank holds every graph — in a shuffled order, so the index table is exercised."""
+    import ctypes as C
+    import torch
+    lib = gn._lib.load()
+    rng = np.random.default_rng(77)
+    G = 24
+    adjs = [(rng.random((n, n)) < 0.3).astype(np.int64) for n in rng.integers(3, 30, G)]
+    e_counts = np.array([int(a.sum()) for a in adjs], dtype=np.int64)
+    p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    off, ids = np.zeros(2, dtype=np.int64), np.zeros(G, dtype=np.int64)
+    gn._lib.check(lib.gnx_dist_partition(p64(e_counts), G, 1, p64(off), p64(ids)))
+    assert off.tolist() == [0, G] and ids.tolist() == list(range(G))
+    order = rng.permutation(G).astype(np.int64)  # the rank's local order of its graphs
+    dims = ((4, 3, 2), (3, 4, 5))
+    p = O.make_block_params(rng, *dims)
+    ef = [rng.random((int(a.sum()), 4), dtype=np.float32) for a in adjs]
+    nf = [rng.random((a.shape[0], 3), dtype=np.float32) for a in adjs]
+    gf = rng.random((G, 2), dtype=np.float32)
+    # local handle and local rows in the SHUFFLED order
+    g = gn.GNGraphBatch([adjs[i] for i in order])
+    dev = g.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    efl, nfl, gfl = t(np.concatenate([ef[i] for i in order])), t(np.concatenate([nf[i] for i in order])), t(gf[order])
+    blk = U.block_from_params(gn, p)
+    keep = []
+    bp = blk._c(keep)
+    eo = torch.empty((g.n_edges, 3), device=dev); no = torch.empty((g.n_nodes, 4), device=dev)
+    gl = torch.empty((G, 5), device=dev); gall = torch.full((G, 5), float("nan"), device=dev)
+    ws = torch.empty(int(lib.gnx_block_workspace_bytes(g._h, C.byref(bp), 1)), dtype=torch.uint8, device=dev)
+    d = C.c_void_p()
+    devs = (C.c_int32 * 1)(dev.index or 0)
+    gn._lib.check(lib.gnx_dist_create(devs, 1, p64(off), p64(order), G, 5, C.byref(d)))
+    try:
+        arr = lambda v: (C.c_void_p * 1)(v)
+        nbytes = (C.c_size_t * 1)(ws.numel())
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        for _ in range(3):  # repeated calls reuse the communicator and its buffers
+            gall.fill_(float("nan"))
+            gn._lib.check(lib.gnx_dist_block_forward(d, arr(g._h.value), arr(C.addressof(bp)), arr(efl.data_ptr()), arr(nfl.data_ptr()), arr(gfl.data_ptr()),
+                                                     arr(eo.data_ptr()), arr(no.data_ptr()), arr(gl.data_ptr()), arr(gall.data_ptr()), arr(ws.data_ptr()),
+                                                     nbytes, 0, arr(stream)))
+            torch.cuda.synchronize()
+            # oracle on the batch in ORIGINAL order
+            ref, scale = O.block_forward_sparse(p, O.csc_from_adj(adjs), np.concatenate(ef)[None], np.concatenate(nf)[None], gf[None], return_scale=True)
+            U.assert_close(gall.cpu().numpy()[None], ref[2], scale[2], "gf' gathered into original graph order")
+            U.assert_close(gl.cpu().numpy()[None], ref[2][:, order], scale[2][:, order], "local gf' rows (shard order)")
+        # argument checks: a handle that does not match the shard, a partition that is not a permutation
+        g2 = gn.GNGraphBatch(adjs[:5])
+        rc = lib.gnx_dist_block_forward(d, arr(g2._h.value), arr(C.addressof(bp)), arr(efl.data_ptr()), arr(nfl.data_ptr()), arr(gfl.data_ptr()),
+                                        arr(eo.data_ptr()), arr(no.data_ptr()), arr(gl.data_ptr()), arr(gall.data_ptr()), arr(ws.data_ptr()), nbytes, 0, arr(stream))
+        assert rc == gn._lib.ERR_COUNT_MISMATCH
+    finally:
+        gn._lib.check(lib.gnx_dist_destroy(d))
+    bad = order.copy(); bad[0] = bad[1]
+    d2 = C.c_void_p()
+    assert lib.gnx_dist_create(devs, 1, p64(off), p64(bad), G, 5, C.byref(d2)) == gn._lib.ERR_INVALID_ARG

@@ -1,0 +1,18 @@
+#!/bin/bash
+# One round's profile set on the GPU box: kernel-trace + FETCH/WRITE PMC passes of bench.py for the headline config (C2, README
+# dims), the heterogeneous batches (C3: 512 graphs, C5: 4096 graphs) and the C4 model; summaries land in gpurun_out/prof_<tag>/.
+# Usage: tools/profile_round.sh r02
+set -u
+R=${1:-r02}
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $REPO
+GNX_PROF_DIMS=readme bash tools/profile.sh ${R}_readme --steps 100 > gpurun_out/prof_${R}_readme.out 2>&1
+GNX_PROF_DIMS=readme_hetero512 bash tools/profile.sh ${R}_hetero512 --steps 100 --workload hetero > gpurun_out/prof_${R}_hetero512.out 2>&1
+GNX_PROF_DIMS=readme_hetero4096 bash tools/profile.sh ${R}_hetero4096 --steps 100 --workload hetero --hetero-graphs 4096 > gpurun_out/prof_${R}_hetero4096.out 2>&1
+GNX_PROF_SQ=0 GNX_PROF_MFMA=1 GNX_PROF_DIMS=core bash tools/profile.sh ${R}_core --steps 20 --dims core > gpurun_out/prof_${R}_core.out 2>&1
+# C4 model: kernel trace only (one forward is ~8 ms)
+OUT=$REPO/gpurun_out/prof_${R}_c4; mkdir -p $OUT
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $REPO/bench.py --model c4 --steps 5 --warmup 2 > $OUT/kt.log 2>&1)
+python3 tools/summarize_prof.py $OUT $OUT/summary > $OUT/summary.txt 2>&1
+for t in readme hetero512 hetero4096 core c4; do echo "== $t"; head -12 gpurun_out/prof_${R}_$t/summary_kernel_stats.csv; done
+ls gpurun_out/prof_${R}_readme/ profiles/ | head -40
