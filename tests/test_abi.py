@@ -31,6 +31,13 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f"{n} declared in include/gnx.h but not exported by libgnx.so"
     assert set(names) == set(gn._lib.SIGNATURES), "python binding and header disagree"
     assert lib.gnx_version() == 100
+    # ... and with the same number of parameters (ctypes would only notice at call time)
+    with open(os.path.join(ROOT, "include", "gnx.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    for m in re.finditer(r"GNX_API [\w\s\*]+?\b(gnx_\w+)\(([^;]*?)\);", text, flags=re.S):
+        name, params = m.group(1), m.group(2).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(gn._lib.SIGNATURES[name][1]), f"{name}: header declares {n} parameters, the binding {len(gn._lib.SIGNATURES[name][1])}"
 
 
 def test_struct_layouts_match_header():
