@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
 // ring, ONE barrier per 32-MFMA step instead of two per 16-MFMA step, fragment reads batched 8 k-steps ahead; 131 KB of LDS, so
 // one 8-wave workgroup per CU — and measured it on C4: 3.15 vs 2.42 ms per edge FeedForward, matrix-core busy 55 % vs 72 %
 // (profiles/r02_ab_ffn_zres.log, profiles/r02_c4_pmc_ffn_fused_vs_zres.json).  At two waves per SIMD nothing covers a wave that
-// waits at the barrier; the two independent 8-wave workgroups of this kernel fill each other's gaps.  Code: git history.)
+// waits at the barrier; the two independent 8-wave workgroups of this kernel fill each other's gaps.  Not kept.)
 
 // out = add1 + add2 + fc2(act1(fc1(z))) over all rows of one entity type.  1 = not applicable (the caller runs the two GEMMs).
 int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, float* out,
