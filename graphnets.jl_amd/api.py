@@ -113,11 +113,15 @@ class GNGraphBatch:
                     assert a.shape[0] == a.shape[1], "adjacency matrix must be square"
                 self.adj_mats = mats
                 conv, kind = [], _lib.ELEM_I64
-                for a in mats:
+                for a in mats:  # element types the ABI reads natively are passed as they are (a bool / uint8 matrix is 8x fewer bytes than int64)
                     if a.dtype == np.float32:
                         kind_a, b = _lib.ELEM_F32, a
                     elif a.dtype.kind == "f":
                         kind_a, b = _lib.ELEM_F64, a.astype(np.float64)
+                    elif a.dtype in (np.bool_, np.uint8):
+                        kind_a, b = _lib.ELEM_U8, a.view(np.uint8)
+                    elif a.dtype == np.int32:
+                        kind_a, b = _lib.ELEM_I32, a
                     else:
                         kind_a, b = _lib.ELEM_I64, a.astype(np.int64)
                     conv.append((kind_a, np.ascontiguousarray(b)))
