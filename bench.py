@@ -38,14 +38,15 @@ MFMA_F32_PEAK_TFS = 157.3  # exact-f32 MFMA (v_mfma_f32_32x32x2_f32); no xf32 on
 NSETS = 8                  # rotating buffer sets: 8 x ~60 MB > 256 MiB Infinity Cache
 DIMS = {"readme": ((10, 5, 0), (3, 4, 5)), "core": ((128, 64, 32), (128, 64, 32)),
         "odd": ((7, 3, 2), (5, 6, 1)), "mid": ((20, 10, 4), (12, 9, 3))}  # odd: fused kernel specialised at run time (GNX_JIT=0: generic kernels); mid: generic/MFMA path
-KERNEL_SOURCES = ("gnx_wave_kernel.h", "gnx_device.h", "gnx_narrow.hip", "gnx_wide.hip", "gnx_generic.hip", "gnx_forward.hip", "gnx_ffn_fused.hip",
-                  "gnx_core_narrow.hip", "gnx_graphs.cpp")
+KERNEL_SOURCES = {"narrow": ("gnx_wave_kernel.h", "gnx_device.h", "gnx_narrow.hip", "gnx_forward.hip", "gnx_graphs.cpp"),
+                  "wide": ("gnx_wide.hip", "gnx_device.h", "gnx_forward.hip", "gnx_graphs.cpp")}
 
 
-def kernel_source_sha():
-    """sha256 over the kernel sources: a committed traffic / calibration profile is only quoted while it describes THIS code."""
+def kernel_source_sha(din, dout):
+    """sha256 over the sources of the kernels that run this width set (fused narrow path or matrix-core path): a committed
+    traffic profile is only quoted while it describes THIS code."""
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in KERNEL_SOURCES["wide" if max(tuple(din) + tuple(dout)) > 32 else "narrow"]:
         with open(os.path.join(ROOT, "graphnets.jl_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -412,7 +413,7 @@ def main():
         abytes, aflops = algorithmic_bytes(E, N, G, din, dout), algorithmic_flops(E, N, G, din, dout)
         hbm_t, mfma_t = abytes / (HBM_PEAK_GBS * 1e9), aflops / (MFMA_F32_PEAK_TFS * 1e12)
         dims_key = args.dims.replace(":", "_").replace(",", "-") + ("" if workload == "c2" else f"_hetero{G}")
-        traffic, tsrc = load_traffic(dims_key, dom, kernel_source_sha())
+        traffic, tsrc = load_traffic(dims_key, dom, kernel_source_sha(din, dout))
         if hbm_t >= mfma_t:
             a = abytes / dur_s / 1e9
             roof = dict(bound="hbm", achieved=round(a, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(a / HBM_PEAK_GBS, 4),

@@ -28,39 +28,90 @@ __global__ __launch_bounds__(256) void k_ln1_rows(const float* __restrict__ x, s
   store_row<D>(y + row * D, v);
 }
 
-template <int D>
+// The FeedForward's 8 D^2 weights (800 at D = 10) do not fit the ~100 scalar registers: as SGPR operands they are streamed in
+// groups, and hipcc's scheduler hoists the scalar loads until it spills (k_core_post<10> with scalar weights: 237 spilled SGPRs,
+// i.e. a v_readlane in front of most FMAs, 126 VGPRs).  Here the workgroup stages the weights in LDS once and every lane reads
+// them with UNIFORM addresses (ds_read_b128 of one address is a broadcast: no bank conflict) into a few VGPRs; M = 2 rows per
+// thread share each read, which keeps the LDS at ~half its rate (D + 4*ceil(D/4)/... reads per 8 D M FMAs).
+template <int D, int M>
 __global__ __launch_bounds__(256) void k_core_post(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2,
                                                    gnx_dense fc1, gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out) {
-  const size_t row = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (row >= rows) return;
   constexpr int H = 4 * D;
-  constexpr int HB = D % 2 == 0 ? 8 : 4;  // hidden units per pass (divides 4D)
-  const cfloatp g = as_const(gamma2), b = as_const(beta2);
-  const cfloatp W1 = as_const(fc1.weight), W2 = as_const(fc2.weight);
-  const cfloatp b1 = as_const(fc1.bias ? fc1.bias : k_zero_bias), b2 = as_const(fc2.bias ? fc2.bias : k_zero_bias);
-  float xr[D], z[1][D], acc[1][D], blk[D];
-  load_row<D>(x + row * D, xr);
-  load_row<D>(out + row * D, blk);  // block(gn1(x)) written by the block forward
+  constexpr int DP = (D + 3) / 4 * 4;  // padded row of W2 in LDS (16-B reads)
+  __shared__ __attribute__((aligned(16))) float s_w1[D * H];   // W1 (4D x D column-major): element (j, k) at k*H + j
+  __shared__ __attribute__((aligned(16))) float s_w2[H * DP];  // W2 (D x 4D column-major): element (k, j) at j*D + k -> row j padded to DP
+  __shared__ __attribute__((aligned(16))) float s_b1[H];
+  __shared__ float s_v[3 * D];                                 // b2 | gamma2 | beta2
+  for (int i = threadIdx.x; i < D * H; i += 256) s_w1[i] = fc1.weight[i];
+  for (int i = threadIdx.x; i < H * DP; i += 256) { const int jrow = i / DP, k = i % DP; s_w2[i] = k < D ? fc2.weight[jrow * D + k] : 0.f; }
+  for (int i = threadIdx.x; i < H; i += 256) s_b1[i] = fc1.bias ? fc1.bias[i] : 0.f;
+  for (int i = threadIdx.x; i < D; i += 256) { s_v[i] = fc2.bias ? fc2.bias[i] : 0.f; s_v[D + i] = gamma2[i]; s_v[2 * D + i] = beta2[i]; }
+  __syncthreads();
+
+  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t row0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (row0 >= rows) return;
+  float rs[M][D], z[M][D], acc[M][DP];
+  size_t row[M];
 #pragma unroll
-  for (int k = 0; k < D; ++k) z[0][k] = xr[k];
-  normalise<D>(z[0], eps, eps_mode);
+  for (int m = 0; m < M; ++m) {
+    const size_t rm = row0 + m * stride;
+    row[m] = rm < rows ? rm : row0;  // clamped: a lane without an m-th row recomputes its first one (its store is skipped)
+    float blk[D];
+    load_row<D>(x + row[m] * D, z[m]);
+    load_row<D>(out + row[m] * D, blk);  // block(gn1(x)) written by the block forward
 #pragma unroll
-  for (int k = 0; k < D; ++k) { z[0][k] = fmaf(g[k], z[0][k], b[k]); acc[0][k] = b2[k]; }
-  // HB hidden units at a time, produced and consumed in registers: h = act(W1[:, j0:j0+HB]' z + b1) with W1's rows read
-  // j-contiguous (W1 is (4D x D) column-major: element (j, k) at k*4D + j), then acc += W2[:, j0:j0+HB] h
+    for (int k = 0; k < D; ++k) rs[m][k] = z[m][k] + blk[k];  // the two residual terms (gncore.jl:56-59)
+    normalise<D>(z[m], eps, eps_mode);
 #pragma unroll
-  for (int j0 = 0; j0 < H; j0 += HB) {
-    float h[1][HB];
+    for (int k = 0; k < D; ++k) z[m][k] = fmaf(s_v[D + k], z[m][k], s_v[2 * D + k]);
 #pragma unroll
-    for (int jj = 0; jj < HB; ++jj) h[0][jj] = b1[j0 + jj];
-    fma_rows<D, HB, 1, D, H>(W1 + j0, z, h);
-    act_row<HB>(h[0], fc1.act);
-    fma_rows<HB, D, 1, HB>(W2 + j0 * D, h, acc);
+    for (int k = 0; k < DP; ++k) acc[m][k] = k < D ? s_v[k] : 0.f;
   }
-  act_row<D>(acc[0], fc2.act);
+  // four hidden units at a time, produced and consumed in registers
+#pragma unroll 1
+  for (int j0 = 0; j0 < H; j0 += 4) {
+    float h[M][4];
+    const float4 bb = *reinterpret_cast<const float4*>(s_b1 + j0);
 #pragma unroll
-  for (int k = 0; k < D; ++k) acc[0][k] = xr[k] + blk[k] + acc[0][k];
-  store_row<D>(out + row * D, acc[0]);
+    for (int m = 0; m < M; ++m) { h[m][0] = bb.x; h[m][1] = bb.y; h[m][2] = bb.z; h[m][3] = bb.w; }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      // (left alone the scheduler hoists every weight read of the iteration: 22 float4 = 88 VGPRs; other waves cover the LDS latency)
+      if (k % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+      const float4 w = *reinterpret_cast<const float4*>(s_w1 + k * H + j0);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        h[m][0] = fmaf(w.x, z[m][k], h[m][0]); h[m][1] = fmaf(w.y, z[m][k], h[m][1]);
+        h[m][2] = fmaf(w.z, z[m][k], h[m][2]); h[m][3] = fmaf(w.w, z[m][k], h[m][3]);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) act_row<4>(h[m], fc1.act);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < DP / 4; ++q) {
+        const float4 w = *reinterpret_cast<const float4*>(s_w2 + (j0 + jj) * DP + 4 * q);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          acc[m][4 * q] = fmaf(w.x, h[m][jj], acc[m][4 * q]); acc[m][4 * q + 1] = fmaf(w.y, h[m][jj], acc[m][4 * q + 1]);
+          acc[m][4 * q + 2] = fmaf(w.z, h[m][jj], acc[m][4 * q + 2]); acc[m][4 * q + 3] = fmaf(w.w, h[m][jj], acc[m][4 * q + 3]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    float o[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) o[k] = acc[m][k];
+    act_row<D>(o, fc2.act);
+#pragma unroll
+    for (int k = 0; k < D; ++k) o[k] = rs[m][k] + o[k];
+    if (m == 0 || row0 + m * stride < rows) store_row<D>(out + row[m] * D, o);
+  }
 }
 
 #define GNX_CORE_WIDTHS(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
@@ -85,9 +136,15 @@ int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm
                          float* out, hipStream_t s) {
   if (rows == 0) return GNX_OK;
   ProfScope ps("k_core_post", s);
-  const dim3 grid((unsigned)((rows + 255) / 256));
+  const char* e = getenv("GNX_CORE_POST_ROWS");
+  const int M = (e ? atoi(e) : 2) == 2 && rows >= 65536 ? 2 : 1;  // two rows per thread once there are rows to spare
+  const dim3 grid((unsigned)((rows + 256 * (size_t)M - 1) / (256 * (size_t)M)));
   switch (d) {
-#define GNX_CASE(D) case D: hipLaunchKernelGGL((k_core_post<D>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out); break;
+#define GNX_CASE(D)                                                                                                                                  \
+  case D:                                                                                                                                            \
+    if (M == 2) hipLaunchKernelGGL((k_core_post<D, 2>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out);      \
+    else hipLaunchKernelGGL((k_core_post<D, 1>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out);             \
+    break;
     GNX_CORE_WIDTHS(GNX_CASE)
 #undef GNX_CASE
     default: return fail(GNX_ERR_DIMS, "launch_core_post: width not instantiated");

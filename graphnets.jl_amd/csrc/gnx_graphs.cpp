@@ -155,6 +155,40 @@ static int32_t finalize(gnx_graphs* h) {
     for (int64_t n = 0; n < h->N; ++n)
       for (int64_t e = h->h_colptr[n]; e < h->h_colptr[n + 1]; ++e) dst[(size_t)e] = (int32_t)n;
     if ((rc = up(dst.data(), dst.size() * sizeof(int32_t), (void**)&h->d_edge_dst))) return rc;
+    {
+      // aggregation chunks (64-row passes of the 128-edge tiles): rows of the partial-sum table per chunk = distinct
+      // destinations in the chunk; edges are dst-sorted, so that is a count of non-empty nodes between its first and last dst
+      std::vector<int32_t> nonempty((size_t)h->N + 1, 0);  // nonempty[n] = nodes m < n with in-degree > 0
+      for (int64_t n = 0; n < h->N; ++n) nonempty[(size_t)n + 1] = nonempty[(size_t)n] + (h->h_colptr[n + 1] > h->h_colptr[n] ? 1 : 0);
+      const size_t n_chunks = 2 * h->h_etiles.size();
+      std::vector<int32_t> row0(n_chunks + 1, 0);
+      std::vector<int32_t> chunk_of_edge_first((size_t)h->N, -1);
+      for (size_t t = 0; t < h->h_etiles.size(); ++t) {
+        for (int pass = 0; pass < 2; ++pass) {
+          const int64_t c0 = h->h_etiles[t].e0 + 64 * pass, c1 = std::min<int64_t>(c0 + 64, h->h_etiles[t].e1);
+          const size_t c = 2 * t + pass;
+          row0[c + 1] = row0[c] + (c1 > c0 ? nonempty[(size_t)dst[(size_t)c1 - 1] + 1] - nonempty[(size_t)dst[(size_t)c0]] : 0);
+        }
+      }
+      h->n_agg_rows = row0[n_chunks];
+      std::vector<int32_t> agg_row((size_t)h->N, -1), parts((size_t)h->N, 0), first_chunk((size_t)h->N, 0);
+      // chunk of an edge: tiles are 128-edge chunks of each graph's edge range, in graph order
+      auto chunk_of = [&](int64_t e, int64_t g) { return (int64_t)2 * h->h_etile_off[(size_t)g] + (e - h->h_edge_off[(size_t)g]) / 64; };
+      for (int64_t g = 0; g < h->G; ++g)
+        for (int64_t n = h->h_node_off[(size_t)g]; n < h->h_node_off[(size_t)g + 1]; ++n) {
+          const int64_t e0 = h->h_colptr[n], e1 = h->h_colptr[n + 1];
+          if (e1 <= e0) continue;
+          const int64_t ca = chunk_of(e0, g), cb = chunk_of(e1 - 1, g);
+          const int64_t chunk_e0 = h->h_edge_off[(size_t)g] + ((e0 - h->h_edge_off[(size_t)g]) / 64) * 64;  // first edge of chunk ca
+          agg_row[(size_t)n] = row0[(size_t)ca] + (nonempty[(size_t)n] - nonempty[(size_t)dst[(size_t)chunk_e0]]);
+          parts[(size_t)n] = (int32_t)(cb - ca + 1);
+          first_chunk[(size_t)n] = (int32_t)ca;
+        }
+      if ((rc = up(row0.data(), row0.size() * sizeof(int32_t), (void**)&h->d_chunk_row0))) return rc;
+      if ((rc = up(agg_row.data(), agg_row.size() * sizeof(int32_t), (void**)&h->d_node_agg_row))) return rc;
+      if ((rc = up(parts.data(), parts.size() * sizeof(int32_t), (void**)&h->d_node_agg_parts))) return rc;
+      if ((rc = up(first_chunk.data(), first_chunk.size() * sizeof(int32_t), (void**)&h->d_node_agg_chunk))) return rc;
+    }
   }
   GNX_HIP(hipMalloc((void**)&h->d_wtile_off, h->h_wtile_off.size() * sizeof(int32_t)));
   GNX_HIP(hipMemcpy(h->d_wtile_off, h->h_wtile_off.data(), h->h_wtile_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -293,6 +327,10 @@ int32_t gnx_graphs_destroy(gnx_graphs* h) {
   (void)hipFree(h->d_tiles);
   (void)hipFree(h->d_wtile_off);
   (void)hipFree(h->d_edge_dst);
+  (void)hipFree(h->d_chunk_row0);
+  (void)hipFree(h->d_node_agg_row);
+  (void)hipFree(h->d_node_agg_parts);
+  (void)hipFree(h->d_node_agg_chunk);
   (void)hipFree(h->d_etiles);
   (void)hipFree(h->d_ntiles);
   (void)hipFree(h->d_gtiles);

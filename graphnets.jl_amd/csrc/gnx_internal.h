@@ -39,6 +39,14 @@ struct gnx_graphs {
   gnx::Tile* d_gtiles = nullptr;
   int32_t* d_etile_off = nullptr;
   int32_t* d_ntile_off = nullptr;
+  // wide path, edge->node aggregation inside the edge GEMM: an aggregation CHUNK is a 64-row pass of an edge tile (chunk
+  // 2t + pass); every chunk writes one partial-sum row per distinct destination it holds, rows [chunk_row0[c], chunk_row0[c+1])
+  // of a table of n_agg_rows rows.  A node's sum = its row in its first chunk (+ row 0 of each further chunk it runs into).
+  int32_t* d_chunk_row0 = nullptr;       // [2 * n_etiles + 1]
+  int32_t* d_node_agg_row = nullptr;     // [N] row of the node's first partial, -1 for a node without in-edges
+  int32_t* d_node_agg_parts = nullptr;   // [N] number of chunks the node's in-edges run through
+  int32_t* d_node_agg_chunk = nullptr;   // [N] its first chunk
+  int64_t n_agg_rows = 0;
   gnx::Tile* d_wtiles = nullptr;  // [n_wtiles]
   int32_t wtile_e_cap = 0;
   int32_t max_wtiles_per_graph = 0;

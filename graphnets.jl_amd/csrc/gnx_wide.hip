@@ -34,7 +34,8 @@ struct WSeg {
   const float* base;  // replica 0
   size_t rep_stride;  // floats between replicas
   int width;          // K extent of this segment
-  int mode;           // 0: row m itself, 1: row idx_a[m], 2: row idx_b[m], 3: sum of rows [cp[m], cp[m+1]) of base
+  int mode;           // 0: row m itself, 1: row idx_a[m], 2: row idx_b[m], 3: sum of rows [cp[m], cp[m+1]) of base,
+                      // 4: the node's in-edge sum from the partial-sum table the edge GEMM wrote (agg_* below)
   int w_row0;         // first row of W (= first input feature index) of this segment
 };
 
@@ -64,6 +65,16 @@ struct WideArgs {
   const float* add2;
   const float* gmul;  // optional, layout of `out`: v *= act'(gmul) (derivative through the stored output, act = gmul_act) BEFORE the
   int gmul_act;       // column sums — the backward's  delta = (g W^T) .* act'(h)  in the GEMM epilogue
+  // edge -> node aggregation fused into the edge GEMM (nodefninput.jl:3 without re-reading ef'): every 64-row pass of an edge tile
+  // ("chunk" 2*tile + pass) adds up the rows of each destination it holds (edges are dst-sorted: contiguous runs) and writes one
+  // row per destination to agg_out[chunk_row0[chunk] + k].  The node GEMM's mode-4 loader reads node m's sum as row
+  // node_agg_row[m] (+ the first row of each further chunk its in-edges run into; -1: no in-edges).
+  float* agg_out;              // edge launch: [R][n_agg_rows][OUT], or nullptr
+  size_t agg_rep_stride;
+  const int* chunk_row0;       // [2 * n_etiles + 1]
+  const int* node_agg_row;     // mode 4: [N]
+  const int* node_agg_parts;   //         [N]
+  const int* node_agg_chunk;   //         [N]
   int n_rtiles, n_ctiles;      // row tiles / column tiles of this launch (set by launch_gemm)
   unsigned long long* stamps;  // diagnostic builds only (GNX_WIDE_STAMPS): [tile][8] shader-clock stamps of wave 0
 };
@@ -123,17 +134,21 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   st[0] = clock64();
 #endif
   // per-row indices
-  bool need_cp = false, need_idx = false;
+  bool need_cp = false, need_idx = false, need_agg = false;
   for (int s = 0; s < a.nseg; ++s) {
     need_cp |= a.seg[s].mode == 3;
     need_idx |= a.seg[s].mode == 1 || a.seg[s].mode == 2;
+    need_agg |= a.seg[s].mode == 4;
   }
-  need_idx |= a.gadd_a != nullptr;
+  need_idx |= a.gadd_a != nullptr || a.agg_out != nullptr;
   if (tid < BM) {
     const int m = tid < rows ? tid : rows - 1;
     if (need_cp) {
       s_ia[tid] = a.cp[row0 + m];
       s_ib[tid] = tid < rows ? a.cp[row0 + m + 1] : s_ia[tid];
+    } else if (need_agg) {  // (row of the first partial, number of further chunks << 24 | first chunk is resolved in the loader)
+      s_ia[tid] = a.node_agg_row[row0 + m];
+      s_ib[tid] = tid < rows ? a.node_agg_parts[row0 + m] : 0;
     } else if (need_idx) {
       s_ia[tid] = a.idx_a[row0 + m];
       s_ib[tid] = a.idx_b[row0 + m];
@@ -191,6 +206,19 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               if (e + j < e1) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
+            }
+          }
+        } else if (sg.mode == 4) {
+          // the node's in-edge sum: one partial row, plus the first row of every further chunk its edges run into (fixed order)
+          const int pr = s_ia[row], parts = s_ib[row];
+          if (pr >= 0) {
+            v = *reinterpret_cast<const float4*>(base + (size_t)pr * sg.width + k);
+            if (parts > 1) {
+              const int c0 = a.node_agg_chunk[row0 + row];
+              for (int j = 1; j < parts; ++j) {
+                const float4 u = *reinterpret_cast<const float4*>(base + (size_t)a.chunk_row0[c0 + j] * sg.width + k);
+                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+              }
             }
           }
         } else {
@@ -307,9 +335,20 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   constexpr int NG = WT / (BN / 4);        // row groups that share a column quad
   const bool gadd = a.gadd_a != nullptr;
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  __shared__ int s_seg[66];  // per-destination runs of a pass: s_seg[k] = first row of run k, s_seg[n_seg] = valid rows; s_seg[65] = n_seg
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     lds_barrier();  // K-loop readers (pass 0) / previous pass readers are done with the pool
+    if (VEC4 && a.agg_out && wv == 0) {  // rows are dst-sorted: a destination is a contiguous run; found from the indices alone
+      const int nvalid = min(max(rows - 64 * pass, 0), 64);
+      const int d = lane < nvalid ? s_ib[64 * pass + lane] : -1;
+      const int dprev = lane > 0 && lane < nvalid ? s_ib[64 * pass + lane - 1] : -2;
+      const bool head = lane < nvalid && d != dprev;
+      const unsigned long long mask = __ballot(head);
+      const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+      if (head) s_seg[rank] = lane;
+      if (lane == 0) { const int ns = __popcll(mask); s_seg[ns] = nvalid; s_seg[65] = ns; }
+    }
 #pragma unroll
     for (int i = 0; i < L::TM; ++i) {
       const int rbase = (wm * L::TM + i) * 32;  // 32-row block of this wave
@@ -347,6 +386,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
             v.z *= act_grad_from_out(u.z, a.gmul_act); v.w *= act_grad_from_out(u.w, a.gmul_act);
           }
           cs4.x += v.x; cs4.y += v.y; cs4.z += v.z; cs4.w += v.w;  // column sums BEFORE the residual adds
+          if (a.agg_out) *reinterpret_cast<float4*>(sC + lr * LDC + 4 * c4) = v;  // the finished value, for the per-destination sums below
           if (a.add1) { const float4 u = *reinterpret_cast<const float4*>(a.add1 + r * a.out_rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
           if (a.add2) { const float4 u = *reinterpret_cast<const float4*>(a.add2 + r * a.out_rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
           *reinterpret_cast<float4*>(out + o) = v;
@@ -366,6 +406,25 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
               out[o + e] = y;
             }
           }
+        }
+      }
+    }
+    if (VEC4 && a.agg_out) {
+      // ---- per-destination sums of this 64-row pass (rows are dst-sorted: a destination is a contiguous run) ----
+      lds_barrier();             // every finished value is back in sC (s_seg was filled before this pass's second barrier)
+      const int n_seg = s_seg[65];
+      const int q4 = tid % (BN / 4), grp = tid / (BN / 4);
+      const int n = n0 + 4 * q4;
+      if (n < a.OUT) {
+        float* agg = a.agg_out + r * a.agg_rep_stride + (size_t)a.chunk_row0[2 * tile_id + pass] * a.OUT + n;
+        for (int sgm = grp; sgm < n_seg; sgm += NG) {
+          const int r0 = s_seg[sgm], r1 = s_seg[sgm + 1];
+          float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int rr = r0; rr < r1; ++rr) {
+            const float4 u = *reinterpret_cast<const float4*>(sC + rr * LDC + 4 * q4);
+            t4.x += u.x; t4.y += u.y; t4.z += u.z; t4.w += u.w;
+          }
+          *reinterpret_cast<float4*>(agg + (size_t)sgm * a.OUT) = t4;
         }
       }
     }
@@ -592,7 +651,8 @@ size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int6
   const size_t bias_g = sizeof(float) * (size_t)R * h->G * (size_t)(p->oe + p->on);
   const size_t proj = sizeof(float) * 2 * (size_t)R * h->N * (size_t)p->oe;  // node projections Ps, Pd
   const size_t xg = sizeof(float) * (size_t)R * h->G * (size_t)(p->oe + p->on + p->dg);  // graph-function input (small batches)
-  return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + align_up(xg, 256) + 512;
+  const size_t agg = sizeof(float) * (size_t)R * (size_t)h->n_agg_rows * (size_t)p->oe;  // per-destination partial sums of the edge GEMM
+  return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + align_up(xg, 256) + align_up(agg, 256) + 512;
 }
 
 template <int BN>
@@ -603,7 +663,8 @@ static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64
   for (int i = 0; i < w.nseg; ++i) {
     const WSeg& g = w.seg[i];
     if (g.width > 0 && !g.base) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: segment base is NULL");
-    if ((g.mode == 1 && !w.idx_a) || (g.mode == 2 && !w.idx_b) || (g.mode == 3 && !w.cp) || (w.gadd_a && (!w.gadd_b || !w.idx_a || !w.idx_b)))
+    if ((g.mode == 1 && !w.idx_a) || (g.mode == 2 && !w.idx_b) || (g.mode == 3 && !w.cp) || (w.gadd_a && (!w.gadd_b || !w.idx_a || !w.idx_b)) ||
+        (g.mode == 4 && (!w.node_agg_row || !w.node_agg_parts || !w.node_agg_chunk || !w.chunk_row0 || !vec4)) || (w.agg_out && (!w.idx_b || !w.chunk_row0)))
       return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: index array required by a segment mode is NULL");
   }
   ProfScope ps(name, s);
@@ -719,6 +780,12 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   float* bias_n = bias_e + (size_t)R * h->G * a.oe;
   float* proj_s = reinterpret_cast<float*>(reinterpret_cast<char*>(bias_e) + align_up(sizeof(float) * (size_t)R * h->G * (a.oe + a.on), 256));
   float* proj_d = proj_s + (size_t)R * h->N * a.oe;
+  float* agg_tab = reinterpret_cast<float*>(reinterpret_cast<char*>(proj_s) + align_up(sizeof(float) * 2 * (size_t)R * h->N * a.oe, 256) +
+                                            align_up(sizeof(float) * (size_t)R * h->G * (size_t)(a.oe + a.on + a.dg), 256));
+  // edge -> node sums inside the edge GEMM's epilogue (the node GEMM then reads ~N rows instead of all E rows of ef')
+  static const bool no_agg_fuse = getenv("GNX_NO_AGG_FUSE") != nullptr;
+  const bool agg_fuse = !no_agg_fuse && (phase & 1) && a.oe > 0 && a.on > 0 && a.oe % 4 == 0 && al16 && a.de % 4 == 0 && a.dn % 4 == 0 && a.on % 4 == 0 &&
+                        ((uintptr_t)a.nf_out % 16 == 0) && h->n_agg_rows > 0;
   int32_t rc = GNX_OK;
   if ((phase & 1) && a.dg > 0) {  // fold gf into per-graph biases (one tiny launch per update function)
     ProfScope ps("k_fold_bias", s);
@@ -767,6 +834,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     w.bias_g = (!project && a.dg > 0) ? bias_e : nullptr; w.n_graphs = a.G;
     w.out = a.ef_out; w.out_rep_stride = (size_t)a.E * a.oe;
     w.colsum = a.og > 0 ? pe : nullptr; w.colsum_rep_stride = n_et * (size_t)a.oe;
+    if (agg_fuse) { w.agg_out = agg_tab; w.agg_rep_stride = (size_t)h->n_agg_rows * a.oe; w.chunk_row0 = h->d_chunk_row0; }
     const bool vec4 = al16 && a.de % 4 == 0 && a.dn % 4 == 0 && a.oe % 4 == 0;
     if ((rc = launch_gemm_any(w, vec4, (unsigned)n_et, R, s, "k_rows_gemm_edge"))) return rc;
   }
@@ -774,7 +842,12 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     WideArgs w{};
     w.tiles = h->d_ntiles; w.row_kind = 1;
     int ns = 0;
-    if (a.oe) w.seg[ns++] = WSeg{a.ef_out, (size_t)a.E * a.oe, a.oe, 3, 0};
+    if (a.oe && agg_fuse) {
+      w.seg[ns++] = WSeg{agg_tab, (size_t)h->n_agg_rows * a.oe, a.oe, 4, 0};
+      w.node_agg_row = h->d_node_agg_row; w.node_agg_parts = h->d_node_agg_parts; w.node_agg_chunk = h->d_node_agg_chunk; w.chunk_row0 = h->d_chunk_row0;
+    } else if (a.oe) {
+      w.seg[ns++] = WSeg{a.ef_out, (size_t)a.E * a.oe, a.oe, 3, 0};
+    }
     if (a.dn) w.seg[ns++] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 0, a.oe};
     w.nseg = ns;
     w.idx_a = nullptr; w.idx_b = nullptr; w.cp = a.colptr;

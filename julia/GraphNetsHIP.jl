@@ -13,7 +13,8 @@
 module GraphNetsHIP
 
 export GNGraphBatch, GNBlock, GNCore, GNCoreList, Dense, LayerNorm, batch, unbatch,
-       efview, nfview, gfview, flatunpaddednf, flatunpaddedef, zerodim2nothing
+       efview, nfview, gfview, flatunpaddednf, flatunpaddedef, zerodim2nothing,
+       block_pullback, Model, partition_graphs, DistBlock
 
 const libgnx = get(ENV, "GNX_LIB", joinpath(@__DIR__, "..", "graphnets.jl_amd", "libgnx.so"))
 const libhip = get(ENV, "GNX_HIP_LIB", "libamdhip64.so")
@@ -236,5 +237,128 @@ end
 # GNCoreList is `foldl((x, f) -> f(x), list; init=x)` exactly as src/gncorelist.jl:43-45.
 struct GNCoreList{T}; list::T; end
 (m::GNCoreList)(x) = foldl((i, fn) -> fn(i), m.list; init=x)
+
+# ---- training: the pullback of (m::GNBlock)(x) = gnx_block_backward (what Flux.withgradient obtains from Zygote in
+#      examples/sort/sort.jl:122-132).  `block_pullback(m, x, y, ȳ)` returns (∂ef, ∂nf, ∂gf, (∂W, ∂b) for the three Dense layers);
+#      with ChainRulesCore loaded it is the body of the rrule below.  (gnx_core_backward is bound the same way; the tested
+#      binding of both is graphnets.jl_amd/api.py: _BlockFn / _CoreFn.) ----
+struct GnxDenseGrad; weight::Ptr{Cfloat}; bias::Ptr{Cfloat}; end
+struct GnxBlockGrads; edgefn::GnxDenseGrad; nodefn::GnxDenseGrad; graphfn::GnxDenseGrad; end
+
+function block_pullback(m::GNBlock, x, y, ȳ)
+    g::GNGraphBatch = x.graphs
+    R = size(something(x.ef, x.nf, x.gf), 3)
+    W = [upload(m.edgefn.weight), upload(m.nodefn.weight), upload(m.graphfn.weight)]
+    B = [upload(m.edgefn.bias), upload(m.nodefn.bias), upload(m.graphfn.bias)]
+    mk(d::Dense, w, b) = GnxDense(devptr(w), devptr(b), Int32(actcode(d.σ)), 0)
+    p = Ref(GnxBlockParams(m.in..., m.out..., mk(m.edgefn, W[1], B[1]), mk(m.nodefn, W[2], B[2]), mk(m.graphfn, W[3], B[3])))
+    ins = (upload(x.ef), upload(x.nf), upload(x.gf)); outs = (upload(y.ef), upload(y.nf), upload(y.gf))
+    cots = (upload(ȳ.ef), upload(ȳ.nf), upload(ȳ.gf))
+    zlike(a) = isnothing(a) ? nothing : DevBuf(sizeof(a))
+    dins = (zlike(x.ef), zlike(x.nf), zlike(x.gf))
+    layers = (m.edgefn, m.nodefn, m.graphfn)
+    gW = [DevBuf(sizeof(l.weight)) for l in layers]; gB = [DevBuf(sizeof(l.bias)) for l in layers]
+    gptr(b) = Ptr{Cfloat}(b.ptr)
+    grads = Ref(GnxBlockGrads(GnxDenseGrad(gptr(gW[1]), gptr(gB[1])), GnxDenseGrad(gptr(gW[2]), gptr(gB[2])), GnxDenseGrad(gptr(gW[3]), gptr(gB[3]))))
+    wsb = ccall((:gnx_block_backward_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxBlockParams}, Int64), g.handle, p, R)
+    ws = DevBuf(wsb)
+    GC.@preserve W B ins outs cots dins gW gB ws check(ccall((:gnx_block_backward, libgnx), Int32,
+        (Ptr{Cvoid}, Ptr{GnxBlockParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat},
+         Ptr{Cfloat}, Int64, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{GnxBlockGrads}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+        g.handle, p, devptr(ins[1]), devptr(ins[2]), devptr(ins[3]), devptr(outs[1]), devptr(outs[2]), devptr(outs[3]),
+        devptr(cots[1]), devptr(cots[2]), devptr(cots[3]), R, devptr(dins[1]), devptr(dins[2]), devptr(dins[3]), grads, ws.ptr, wsb, C_NULL))
+    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
+    dl(a, b) = isnothing(a) ? nothing : download!(similar(a), b)
+    (ef=dl(x.ef, dins[1]), nf=dl(x.nf, dins[2]), gf=dl(x.gf, dins[3]),
+     params=[(weight=download!(similar(l.weight), gW[i]), bias=download!(similar(l.bias), gB[i])) for (i, l) in enumerate(layers)])
+end
+
+# The rrule a maintainer adds once ChainRulesCore is a dependency (kept as a comment: this module has no dependencies):
+#   function ChainRulesCore.rrule(m::GNBlock, x)
+#       y = m(x)
+#       pb(ȳ) = (g = block_pullback(m, x, y, ȳ);
+#                (Tangent{GNBlock}(edgefn=Tangent{Dense}(; g.params[1]...), nodefn=Tangent{Dense}(; g.params[2]...), graphfn=Tangent{Dense}(; g.params[3]...)),
+#                 Tangent{typeof(x)}(ef=g.ef, nf=g.nf, gf=g.gf)))
+#       y, pb
+#   end
+
+# ---- a chain of layers as ONE hipGraph inside libgnx (gnx_model_*): decoder(core(encoder(x))) of examples/sort/sort.jl:68-75 ----
+struct GnxLayer; kind::Int32; reserved::Int32; params::Ptr{Cvoid}; end
+mutable struct Model
+    handle::Ptr{Cvoid}; graphs::GNGraphBatch; keep::Vector{Any}; outdims::NTuple{3,Int}
+end
+function Model(layers::AbstractVector, x)
+    g::GNGraphBatch = x.graphs
+    R = size(something(x.ef, x.nf, x.gf), 3)
+    keep = Any[]
+    up(a) = (b = upload(a); push!(keep, b); devptr(b))
+    dn(d::Dense) = GnxDense(up(d.weight), up(d.bias), Int32(actcode(d.σ)), 0)
+    ln(l::LayerNorm) = GnxLayerNorm(up(l.γ), up(l.β))
+    bparams(b::GNBlock) = GnxBlockParams(b.in..., b.out..., dn(b.edgefn), dn(b.nodefn), dn(b.graphfn))
+    descs = GnxLayer[]
+    for l in layers
+        if l isa GNBlock
+            r = Ref(bparams(l)); push!(keep, r)
+            push!(descs, GnxLayer(0, 0, Base.unsafe_convert(Ptr{Cvoid}, r)))
+        else
+            r = Ref(GnxCoreParams(bparams(l.block), map(ln, l.gn1), map(ln, l.gn2), map(t -> GnxFfn(dn(t[1]), dn(t[2])), l.ffwd), 1f-5, Int32(0)))
+            push!(keep, r)
+            push!(descs, GnxLayer(1, 0, Base.unsafe_convert(Ptr{Cvoid}, r)))
+        end
+    end
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve keep check(ccall((:gnx_model_create, libgnx), Int32, (Ptr{Cvoid}, Ptr{GnxLayer}, Int32, Int64, Ptr{Ptr{Cvoid}}), g.handle, descs, length(descs), R, h))
+    dims = zeros(Int32, 3)
+    check(ccall((:gnx_model_out_dims, libgnx), Int32, (Ptr{Cvoid}, Ptr{Int32}), h[], dims))
+    m = Model(h[], g, keep, Tuple(Int.(dims)))
+    finalizer(x -> ccall((:gnx_model_destroy, libgnx), Int32, (Ptr{Cvoid},), x.handle), m)
+    m
+end
+function (m::Model)(x)                                                 # one hipGraphLaunch after the first call with these buffers
+    g = m.graphs; R = size(something(x.ef, x.nf, x.gf), 3)
+    d_ef, d_nf, d_gf = upload(x.ef), upload(x.nf), upload(x.gf)
+    (oe, on, og) = m.outdims
+    o_ef, o_nf, o_gf = zeros(Float32, oe, nedges(g), R), zeros(Float32, on, nnodes(g), R), zeros(Float32, og, ngraphs(g), R)
+    b_ef, b_nf, b_gf = DevBuf(sizeof(o_ef)), DevBuf(sizeof(o_nf)), DevBuf(sizeof(o_gf))
+    GC.@preserve d_ef d_nf d_gf b_ef b_nf b_gf check(ccall((:gnx_model_forward, libgnx), Int32,
+        (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, UInt32, Ptr{Cvoid}),
+        m.handle, devptr(d_ef), devptr(d_nf), devptr(d_gf), devptr(b_ef), devptr(b_nf), devptr(b_gf), UInt32(0), C_NULL))
+    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
+    (graphs=g, ef=oe == 0 ? nothing : download!(o_ef, b_ef), nf=on == 0 ? nothing : download!(o_nf, b_nf), gf=og == 0 ? nothing : download!(o_gf, b_gf))
+end
+
+# ---- multi-GPU: whole graphs sharded over the devices of this process, gf' all-gathered (gnx_dist_*, SURVEY §8e).
+#      partition_graphs: equal graph counts per rank, snake order by edge count; DistBlock: one GNGraphBatch per device built from
+#      ITS graphs, per-device gnx_block_forward, one RCCL all-gather of gf' restored to the ORIGINAL graph order. ----
+function partition_graphs(edge_counts::AbstractVector{<:Integer}, n_ranks::Integer)
+    counts = Int64.(edge_counts); G = length(counts)
+    off = zeros(Int64, n_ranks + 1); ids = zeros(Int64, G)
+    check(ccall((:gnx_dist_partition, libgnx), Int32, (Ptr{Int64}, Int64, Int32, Ptr{Int64}, Ptr{Int64}), counts, G, n_ranks, off, ids))
+    [ids[off[r]+1:off[r+1]] .+ 1 for r in 1:n_ranks]               # 1-based original graph ids per rank
+end
+
+mutable struct DistBlock
+    handle::Ptr{Cvoid}; devices::Vector{Int32}; shards::Vector{Vector{Int64}}; batches::Vector{GNGraphBatch}; block::GNBlock
+end
+function DistBlock(block::GNBlock, adj_mats::AbstractVector, devices::AbstractVector{<:Integer})
+    n = length(devices)
+    shards = partition_graphs([count(isone, a) for a in adj_mats], n)
+    off = Int64[0; cumsum(length.(shards))]; ids = Int64.(reduce(vcat, shards) .- 1)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    devs = Int32.(devices)
+    check(ccall((:gnx_dist_create, libgnx), Int32, (Ptr{Int32}, Int32, Ptr{Int64}, Ptr{Int64}, Int64, Int32, Ptr{Ptr{Cvoid}}),
+                devs, n, off, ids, length(adj_mats), block.out[3], h))
+    batches = map(1:n) do r
+        hipcheck(ccall((:hipSetDevice, libhip), Cint, (Cint,), devs[r]))
+        GNGraphBatch([adj_mats[i] for i in shards[r]])                 # the handle lives on the device that is current at creation
+    end
+    d = DistBlock(h[], devs, shards, batches, block)
+    finalizer(x -> ccall((:gnx_dist_destroy, libgnx), Int32, (Ptr{Cvoid},), x.handle), d)
+    d
+end
+# (d::DistBlock)(xs): xs[r] = the batched tuple of rank r's graphs (features of ITS graphs, uploaded to device r); the call is
+# gnx_dist_block_forward with per-rank pointer arrays — handles, parameter structs whose weights live on device r, inputs, outputs,
+# workspaces, gf_all[r] (ngraphs x og on every device) — exactly as tests/test_gpu_dist.py::test_gnx_dist_c_entry_points_world_1
+# drives it through ctypes.
 
 end # module
