@@ -5,7 +5,7 @@ The directory name follows the project naming contract and is not a valid Python
 """
 from . import _lib
 from ._lib import GnxError, LIB_PATH, profile_calibrate, profile_enable, profile_read, profile_reset
-from .api import (NT, BlockPlan, Dense, Graphed, Model, GNBlock, GNCore, GNCoreList, GNFeedForward, GNGraphBatch, GNGraphNorm, LayerNorm, batch,
+from .api import (NT, BlockPlan, Chain, Dense, Graphed, Model, GNBlock, GNCore, GNCoreList, GNFeedForward, GNGraphBatch, GNGraphNorm, LayerNorm, batch,
                   efview, flatunpaddedef, flatunpaddednf, getedgefninput, getgraphfninput, getnodefninput, gfview, nfview,
                   flatunpaddedcollapsedef, logitcrossentropy, padded, unbatch, unpaddedcollapsedef, zerodim2nothing)
 

@@ -36,6 +36,14 @@ class BlockParams(C.Structure):
                [("edgefn", Dense), ("nodefn", Dense), ("graphfn", Dense)]
 
 
+class Chain(C.Structure):
+    _fields_ = [("layers", C.POINTER(Dense)), ("widths", C.POINTER(C.c_int32)), ("n_layers", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ChainBlockParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("de", "dn", "dg", "reserved")] + [("edgefn", Chain), ("nodefn", Chain), ("graphfn", Chain)]
+
+
 class DenseGrad(C.Structure):
     _fields_ = [("weight", _fp), ("bias", _fp)]
 
@@ -98,6 +106,8 @@ SIGNATURES = {
     "gnx_graphs_get_csc": (C.c_int32, [C.c_void_p, _i64p, _i64p]),
     "gnx_block_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BlockParams), C.c_int64]),
     "gnx_block_forward": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + _FWD[2:]),
+    "gnx_chain_block_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(ChainBlockParams), C.c_int64]),
+    "gnx_chain_block_forward": (C.c_int32, [C.c_void_p, C.POINTER(ChainBlockParams)] + _FWD[2:]),
     "gnx_block_graph_update": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams), _fp, C.c_int64, _fp, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "gnx_block_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BlockParams), C.c_int64]),
     "gnx_block_backward": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + [_fp] * 9 + [C.c_int64] + [_fp] * 3 +

@@ -24,7 +24,7 @@ from . import _lib
 from ._lib import GnxError, check
 
 __all__ = ["GNGraphBatch", "NT", "batch", "unbatch", "efview", "nfview", "gfview", "flatunpaddednf", "flatunpaddedef",
-           "Dense", "LayerNorm", "GNBlock", "GNCore", "GNCoreList", "GNFeedForward", "GNGraphNorm", "zerodim2nothing",
+           "Dense", "Chain", "LayerNorm", "GNBlock", "GNCore", "GNCoreList", "GNFeedForward", "GNGraphNorm", "zerodim2nothing",
            "padded", "GnxError", "getedgefninput", "getnodefninput", "getgraphfninput",
            "unpaddedcollapsedef", "flatunpaddedcollapsedef", "BlockPlan", "Graphed", "logitcrossentropy"]
 
@@ -557,6 +557,22 @@ class Dense:
                           _lib.ACT[self.act], 0)
 
 
+class Chain:
+    """Flux `Chain(layers...)` of `Dense` layers — a GNBlock's update functions may be any such chain (gnblock.jl:1-6):
+    `blk.edgefn = Chain(Dense(20, 64, "relu"), Dense(64, 3))`.  (A one-layer chain is the constructor's default, gnblock.jl:55-60.)"""
+
+    def __init__(self, *layers):
+        self.layers = list(layers[0]) if len(layers) == 1 and isinstance(layers[0], (list, tuple)) else list(layers)
+        assert all(isinstance(l, Dense) for l in self.layers), "Chain: only Dense layers are supported"
+
+    def __len__(self):
+        return len(self.layers)
+
+    @property
+    def out_width(self):
+        return int(self.layers[-1].weight.shape[0]) if self.layers else 0
+
+
 class LayerNorm:
     """Flux `LayerNorm(d)`: γ = ones, β = zeros, ε = 1e-5."""
 
@@ -624,7 +640,45 @@ class GNBlock:
         ps = [self.edgefn.weight, self.edgefn.bias, self.nodefn.weight, self.nodefn.bias, self.graphfn.weight, self.graphfn.bias]
         return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in list(tensors) + ps)
 
+    def _as_chain(self, fn):
+        return fn if isinstance(fn, Chain) else Chain(fn)
+
+    def _call_chains(self, x, flags):
+        """Update functions that are multi-layer Chains: gnx_chain_block_forward (forward only)."""
+        g, ef, nf, gf, R = _forward_common(x, self.in_dims)
+        lib = _lib.load()
+        chains = [self._as_chain(f) for f in (self.edgefn, self.nodefn, self.graphfn)]
+        keep = []
+        p = _lib.ChainBlockParams()
+        p.de, p.dn, p.dg = self.in_dims
+        outw = []
+        for name, ch in zip(("edgefn", "nodefn", "graphfn"), chains):
+            layers = [l for l in ch.layers]
+            widths = [int(l.weight.shape[0]) for l in layers]
+            arr = (_lib.Dense * max(len(layers), 1))(*[l._c(keep) for l in layers])
+            wid = (C.c_int32 * max(len(layers), 1))(*widths)
+            keep += [arr, wid]
+            c = getattr(p, name)
+            c.layers, c.widths, c.n_layers = arr, wid, len(layers)
+            outw.append(widths[-1] if widths else 0)
+        dev = g.device
+        mk = lambda T, d: torch.empty((R, T, d), dtype=torch.float32, device=dev) if d > 0 else None
+        eo, no, go = mk(g.n_edges, outw[0]), mk(g.n_nodes, outw[1]), mk(g.n_graphs, outw[2])
+        with torch.cuda.device(dev):
+            nbytes = lib.gnx_chain_block_workspace_bytes(g._h, C.byref(p), R)
+            if nbytes == 0:
+                raise GnxError(_lib.ERR_DIMS, lib.gnx_last_error().decode("utf-8", "replace"))
+            ws = g.workspace(nbytes, ("chain", self.in_dims, tuple(tuple(int(l.weight.shape[0]) for l in ch.layers) for ch in chains), R))
+            check(lib.gnx_chain_block_forward(g._h, C.byref(p), _ptr(ef), _ptr(nf), _ptr(gf), R, _ptr(eo), _ptr(no), _ptr(go),
+                                              ws.data_ptr(), ws.numel(), self.flags if flags is None else flags,
+                                              torch.cuda.current_stream(dev).cuda_stream))
+        return NT(g, _jl(eo), _jl(no), _jl(go))
+
     def __call__(self, x, flags=None):
+        if any(isinstance(f, Chain) and len(f) != 1 for f in (self.edgefn, self.nodefn, self.graphfn)):
+            return self._call_chains(x, flags)
+        if any(isinstance(f, Chain) for f in (self.edgefn, self.nodefn, self.graphfn)):  # one-layer chains are plain Dense layers
+            self.edgefn, self.nodefn, self.graphfn = (f.layers[0] if isinstance(f, Chain) else f for f in (self.edgefn, self.nodefn, self.graphfn))
         g, ef, nf, gf, R = _forward_common(x, self.in_dims)
         if self._trainable((ef, nf, gf)):  # differentiable call: gnx_block_backward is the pullback
             outs = iter(_BlockFn.apply(self, g, R, self.flags if flags is None else flags, ef, nf, gf, self.edgefn.weight, self.edgefn.bias,

@@ -170,6 +170,28 @@ GNX_API int32_t gnx_block_forward(const gnx_graphs* h, const gnx_block_params* p
 GNX_API int32_t gnx_block_graph_update(const gnx_graphs* h, const gnx_block_params* p, const float* gf, int64_t n_replicas,
                                float* gf_out, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
+/* ---- GNBlock with Flux `Chain`s of Dense layers as update functions (src/gnblock.jl:1-6: edgefn / nodefn / graphfn are
+ * arbitrary Chains; the constructor's default is Chain(Dense), which is what gnx_block_forward fuses).  widths[i] = output
+ * width of layer i; the input width of layer 0 is fixed by the block (de+2dn+dg / oe+dn+dg / oe+on+dg with oe, on = the LAST
+ * widths of the edge / node chains); a chain with n_layers = 0 or a last width of 0 <=> that output is `nothing`.
+ * The edge function's first layer runs fused with getedgefninput (the fast block kernels); every further layer is a row-wise
+ * Dense on the matrix-core GEMM kernel.  Forward only. */
+typedef struct gnx_chain {
+  const gnx_dense* layers; /* [n_layers] host array of layer descriptors (device weight pointers inside) */
+  const int32_t* widths;   /* [n_layers] host array */
+  int32_t n_layers;
+  int32_t reserved;
+} gnx_chain;
+typedef struct gnx_chain_block_params {
+  int32_t de, dn, dg; /* input widths; 0 <=> nothing */
+  int32_t reserved;
+  gnx_chain edgefn, nodefn, graphfn;
+} gnx_chain_block_params;
+GNX_API size_t gnx_chain_block_workspace_bytes(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t n_replicas);
+GNX_API int32_t gnx_chain_block_forward(const gnx_graphs* h, const gnx_chain_block_params* p, const float* ef, const float* nf, const float* gf,
+                                int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out, void* workspace, size_t workspace_bytes,
+                                uint32_t flags, void* stream);
+
 /* ---- backward of the block: what a Zygote `rrule` / torch autograd function for (m::GNBlock)(x) needs.
  * Inputs: the forward's inputs (ef, nf, gf), its outputs (ef_out, nf_out, gf_out) and the upstream gradients with the
  * outputs' shapes (g_*; NULL = zero).  Outputs (all optional, NULL = not wanted): gradients w.r.t. the inputs (d_ef, d_nf,

@@ -554,6 +554,77 @@ def core_forward_sparse(p, csc, ef, nf, gf, return_scale=False, in_scale=None):
     return tuple(out)
 
 
+def make_chain_block_params(rng, in_dims, edge_widths, node_widths, graph_widths, acts=(ACT_RELU, ACT_TANH, ACT_IDENTITY)):
+    """GNBlock whose update functions are Chains of Dense layers (gnblock.jl:1-6 allows any Chain; the default is one Dense):
+    `*_widths` = output widths of the layers of each chain (empty = that output is `nothing`); hidden layers use `acts[i % 3]`,
+    the last layer of a chain is linear (like the reference's default)."""
+    de, dn, dg = in_dims
+    oe = edge_widths[-1] if edge_widths else 0
+    on = node_widths[-1] if node_widths else 0
+    kin = dict(edge=de + 2 * dn + dg, node=oe + dn + dg, graph=oe + on + dg)
+    p = dict(in_dims=tuple(in_dims))
+    for name, widths in (("edge", edge_widths), ("node", node_widths), ("graph", graph_widths)):
+        layers, k = [], kin[name]
+        for i, w in enumerate(widths):
+            act = acts[i % len(acts)] if i + 1 < len(widths) else ACT_IDENTITY
+            layers.append((glorot_uniform(rng, w, k), rng.uniform(-0.1, 0.1, size=w).astype(np.float32), act))
+            k = w
+        p[name] = layers
+    return p
+
+
+def chain_block_forward_sparse(p, csc, ef, nf, gf, return_scale=False):
+    """(m::GNBlock)(x) (gnblock.jl:63-69) with Chain update functions, on packed data: every chain is applied to the same
+    function inputs as in block_forward_sparse (edgefninput.jl / nodefninput.jl / graphfninput.jl), layer after layer.
+    Scales (worst case, as block_forward_sparse): |W|·S + |b| through every layer."""
+    colptr, rowval, node_off, edge_off = csc
+    N, E, G = len(colptr) - 1, len(rowval), len(node_off) - 1
+    R = next(a.shape[0] for a in (ef, nf, gf) if a is not None)
+    dst = np.repeat(np.arange(N), np.diff(colptr))
+    node_graph = np.repeat(np.arange(G), np.diff(node_off))
+    edge_graph = np.repeat(np.arange(G), np.diff(edge_off))
+
+    def run(layers, X, S):
+        for W, b, act in layers:
+            S = np.abs(S) @ np.abs(np.asarray(W, dtype=F64)).T + np.abs(np.asarray(b, dtype=F64))[None, :]
+            X = _dense_rows(W, b, act, X)
+        return X, S
+
+    outs, scales = ([], [], []), ([], [], [])
+    for r in range(R):
+        parts = []
+        if ef is not None:
+            parts.append(np.asarray(ef[r], dtype=F64))
+        if nf is not None:
+            nfr = np.asarray(nf[r], dtype=F64)
+            parts += [nfr[rowval], nfr[dst]]
+        if gf is not None:
+            gfr = np.asarray(gf[r], dtype=F64)
+            parts.append(gfr[edge_graph])
+        Xe = np.concatenate(parts, axis=1)
+        he, se = run(p["edge"], Xe, np.abs(Xe)) if p["edge"] else (None, None)
+        hn = sn = hg = sg = None
+        if p["node"]:
+            parts, sparts = [_segsum(he, dst, N)], [_segsum(se, dst, N)]
+            if nf is not None:
+                parts.append(nfr); sparts.append(np.abs(nfr))
+            if gf is not None:
+                parts.append(gfr[node_graph]); sparts.append(np.abs(gfr[node_graph]))
+            hn, sn = run(p["node"], np.concatenate(parts, axis=1), np.concatenate(sparts, axis=1))
+        if p["graph"]:
+            parts = [_segsum(he, edge_graph, G), _segsum(hn, node_graph, G)]
+            sparts = [_segsum(se, edge_graph, G), _segsum(sn, node_graph, G)]
+            if gf is not None:
+                parts.append(gfr); sparts.append(np.abs(gfr))
+            hg, sg = run(p["graph"], np.concatenate(parts, axis=1), np.concatenate(sparts, axis=1))
+        for lst, v in zip(outs, (he, hn, hg)):
+            lst.append(v)
+        for lst, v in zip(scales, (se, sn, sg)):
+            lst.append(v)
+    pack = lambda ls: tuple(None if (lst[0] is None or lst[0].shape[1] == 0) else np.stack(lst) for lst in ls)
+    return (pack(outs), pack(scales)) if return_scale else pack(outs)
+
+
 # ----------------------------------------------------------------------------------------------------------
 # Layout bridges between the two forms
 # ----------------------------------------------------------------------------------------------------------

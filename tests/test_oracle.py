@@ -295,3 +295,18 @@ def test_propagated_error_scale_bounds_the_effect_of_input_perturbations():
         y2p = O.core_forward_sparse(pc, csc, *y1p)
         for a, b, sc in zip(y2, y2p, s2):
             assert np.all(np.abs(a - b) <= 1.01 * eta * sc + 1e-13)
+
+
+def test_chain_oracle_reduces_to_the_block_for_one_layer_chains():
+    """chain_block_forward_sparse (Chain update functions, gnblock.jl:1-6) with one Dense per chain IS block_forward_sparse."""
+    rng = np.random.default_rng(31)
+    adjs = [(rng.random((n, n)) < 0.35).astype(np.int64) for n in (4, 9, 6)]
+    csc = O.csc_from_adj(adjs)
+    E, N, G = len(csc[1]), len(csc[0]) - 1, len(adjs)
+    pb = O.make_block_params(rng, (3, 2, 1), (4, 3, 2), act=(1, 2, 3))
+    pc = dict(in_dims=(3, 2, 1), edge=[(pb["We"], pb["be"], 1)], node=[(pb["Wn"], pb["bn"], 2)], graph=[(pb["Wg"], pb["bg"], 3)])
+    x = [rng.random((2, T, d)) for T, d in zip((E, N, G), (3, 2, 1))]
+    (a, sa), (b, sb) = O.block_forward_sparse(pb, csc, *x, return_scale=True), O.chain_block_forward_sparse(pc, csc, *x, return_scale=True)
+    for u, v, su, sv in zip(a, b, sa, sb):
+        np.testing.assert_allclose(u, v, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(su, sv, rtol=1e-5)
