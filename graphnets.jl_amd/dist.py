@@ -98,17 +98,21 @@ class GfGather:
         dist.all_gather(parts, flat, group=self.group)
         self.recv.copy_(torch.cat(parts, dim=0))
 
-    def result(self):
-        """(G, dg) — or (M, G, dg) with stack = M — in original graph order, from the last completed gather."""
-        out = self.recv.index_select(0, self.src_index)
-        return out.view(self.stack, self.G, self.dg) if self.stack > 1 else out
+    def result(self, out=None):
+        """(G, dg) — or (M, G, dg) with stack = M — in original graph order, from the last completed gather.
+        `out`: a preallocated (M*G, dg) tensor to write into (no allocation on the hot path)."""
+        if out is not None:
+            torch.index_select(self.recv, 0, self.src_index, out=out)
+        else:
+            out = self.recv.index_select(0, self.src_index)
+        return out.view(self.stack, self.G, self.dg) if self.stack > 1 else out.view(self.G, self.dg)
 
-    def finish(self):
+    def finish(self, out=None):
         """Waits for the collective on the current stream, then `result()`."""
         if self._ready is not None:
             torch.cuda.current_stream(self.device).wait_event(self._ready)
             self._ready = None
-        return self.result()
+        return self.result(out)
 
 
 def sharded_block_forward(forward_fn, x_local, gather: GfGather):
