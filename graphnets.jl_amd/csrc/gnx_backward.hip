@@ -264,6 +264,7 @@ __global__ void k_bw_dw_small(const float* __restrict__ delta, const float* __re
 // generic dX launch with a profiling scope
 static void launch_bw_dx(dim3 grid, hipStream_t s, const float* delta, const float* W, int rows, int J, int K, float* dX, int k0, int k1, float* direct,
                          int direct_w) {
+  if (grid.x == 0 || grid.y == 0) return;  // a function without inputs (K = 0: e.g. a node function when oe = dn = dg = 0) has no dX
   ProfScope ps("bw_dx_generic", s);
   hipLaunchKernelGGL(k_bw_dx, grid, dim3(256), 0, s, delta, W, rows, J, K, dX, k0, k1, direct, direct_w);
 }
