@@ -24,8 +24,10 @@ namespace gnx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef GNX_GEMM_WAVES  // at least 4 waves per SIMD: the accumulators move from AGPRs into a 128-register budget (3 spilled VGPRs at BN = 128);
-#define GNX_GEMM_WAVES __attribute__((amdgpu_waves_per_eu(4)))  // a 4th workgroup per CU covers the others' epilogues: C4 8.50 -> 8.10 ms
+#ifndef GNX_GEMM_WAVES  // 3 waves per SIMD = 3 workgroups per CU with a 168-register budget: NO spilled register at BN = 128.  A 4th workgroup
+// (128 registers, ~20 spilled) is slower once the loads are pipelined: a scratch reload is a vector-memory operation, so the wait
+// in front of its first use also waits for every global load issued before it (edge GEMM 433 vs 462 us).
+#define GNX_GEMM_WAVES __attribute__((amdgpu_waves_per_eu(3)))
 #endif
 constexpr int BM = 128;   // rows (edges or nodes) per workgroup tile
 constexpr int WT = 256;   // threads
@@ -76,8 +78,47 @@ struct WideArgs {
   const int* node_agg_parts;   //         [N]
   const int* node_agg_chunk;   //         [N]
   int n_rtiles, n_ctiles;      // row tiles / column tiles of this launch (set by launch_gemm)
+  int epi;                     // EPI_* (set by launch_gemm)
+  int stagger;                 // start delay per residency slot (units of 64*127 clocks), 0 = none (set by launch_gemm)
   unsigned long long* stamps;  // diagnostic builds only (GNX_WIDE_STAMPS): [tile][8] shader-clock stamps of wave 0
 };
+
+// what the VEC4 epilogue reads from global memory besides the accumulators (WideArgs::epi, set by launch_gemm from the pointers)
+enum { EPI_NONE = 0, EPI_GADD = 1, EPI_ADD1 = 2, EPI_ADD12 = 3, EPI_GMUL = 4, EPI_GMUL_ADD = 5 };
+
+// activation of N registers: ONE wave-uniform switch with the loop inside each case (a switch per element puts a branch — and a
+// wait for everything in flight — between the elements)
+template <int N>
+__device__ __forceinline__ void act_apply_n(float* v, int act) {
+  switch (act) {
+    case 0: break;
+    case 1:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = fmaxf(v[j], 0.f);
+      break;
+    case 2:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = act_apply(v[j], 2);
+      break;
+    case 3:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = act_apply(v[j], 3);
+      break;
+    default:
+#pragma unroll
+      for (int j = 0; j < N; ++j) v[j] = act_apply(v[j], 4);
+      break;
+  }
+}
+
+// 16-B access at a wave-uniform base plus a 32-bit element offset: one VGPR of address instead of a 64-bit pair per access
+// (global_load_dwordx4 v, v_off, s[base]).  The hosts keep every table addressed this way below 4 GB (launch_gemm).
+__device__ __forceinline__ float4 ld4(const float* ubase, unsigned off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ubase) + (off << 2));
+}
+__device__ __forceinline__ void st4(float* ubase, unsigned off, float4 v) {
+  *reinterpret_cast<float4*>(reinterpret_cast<char*>(ubase) + (off << 2)) = v;
+}
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits until every global
 // STORE of the wave has been acknowledged — in the epilogue that is a full HBM write round trip per barrier.
@@ -91,7 +132,18 @@ struct WaveLayout {
   static constexpr int TN = BN / (WN * 32);
 };
 
-template <int BN, bool VEC4, int KC>
+// NL = number of epilogue operand streams read from global memory (EPI_* below): 0, 1 or 2 float4 per output quad.  The VEC4
+// epilogue requests them a GROUP of row quads ahead (straight-line code: the operands of group g+1 are in flight while group g
+// is finished and stored).  Written as one load -> use -> store per quad, every quad paid a full memory round trip (vmcnt
+// counts stores too: the wait for the quad's operands also waited for the previous quad's store) — 16 serial round trips per
+// tile, 55 of a tile's 63 us on the 1M-edge edge GEMM.
+// TRANS: the activation may be tanh / sigmoid / gelu.  Their expansions need ~10 temporaries per element: with them in the code the
+// register allocator parks the operands in flight in scratch memory (load, wait, scratch store) on EVERY path, relu's included —
+// so identity / relu launches get an instantiation without them.
+// SEGSUM: some segment is a sum of rows (modes 3 / 4, the node update).  Their loops and index tables cost the plain / gathered
+// loader registers it does not have (spilled LDS addresses are reloaded from scratch memory in front of every access, and a
+// scratch reload waits on vmcnt, i.e. for the global loads just issued): the edge / FeedForward launches get a kernel without them.
+template <int BN, bool VEC4, int KC, int NL, bool TRANS, bool SEGSUM>
 __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   using L = WaveLayout<BN>;
   constexpr int LDA = KC + 1;               // A row stride: odd => conflict-free ds_read_b32 of the A fragment
@@ -123,7 +175,14 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
     tile_id = blockIdx.x;
     ctile = 0;
   }
+  if (a.stagger > 0 && blockIdx.x < 1024) {
+    const int slot = blockIdx.x >> 8;
+    for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  tile_id = __builtin_amdgcn_readfirstlane(tile_id);  // wave-uniform by construction: lets the tile / chunk table reads be scalar loads
   const Tile t = a.tiles[tile_id];
+  int agg_row0[2] = {0, 0};  // first partial-sum row of the tile's two 64-row passes (read here: in the epilogue the load would wait for every store in flight)
+  if (VEC4 && a.agg_out) { agg_row0[0] = a.chunk_row0[2 * tile_id]; agg_row0[1] = a.chunk_row0[2 * tile_id + 1]; }
   const int n0 = ctile * BN;
   const size_t r = blockIdx.z;
   const int row0 = a.row_kind == 0 ? t.e0 : t.n0;
@@ -172,20 +231,64 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-  float4 ra[NA4];
-  float4 rb[NB4];
+  // ONE register array serves the K loop's chunk staging (A quads, then B quads) and, from the last chunk on, the epilogue's
+  // first operand group: declared separately, the compiler keeps both sets alive through the loop and spills
+  constexpr int NC4_ = (64 * BN / 4) / WT, GRP_ = NC4_ > 4 ? 4 : NC4_;
+  constexpr int NSTG = NA4 + NB4 > 2 * GRP_ ? NA4 + NB4 : 2 * GRP_;
+  float4 stg[NSTG];
+  float4 stg1[2 * GRP_];  // second operand buffer (epilogue only)
+#define ra(i) stg[i]
+#define rb(i) stg[NA4 + (i)]
   const int a_c4 = tid % C4R, a_r = tid / C4R;
 
+  // The mode is tested ONCE per chunk, outside the row loop, and the plain / gathered modes are straight-line code with
+  // unconditional loads of clamped addresses: with the test inside the loop every row's load sat in its own branch and the
+  // compiler's counter merge at each join put an `s_waitcnt vmcnt(0)` between the rows — four serial memory round trips per
+  // chunk (measured with the stamp build: 34 of the K loop's 57 k clocks on the 1M-edge edge GEMM were spent issuing loads).
+  unsigned okmask = 0;  // bit i: ra(i) holds data (else zero), bit NA4 + i: rb(i) — applied when the chunk goes to LDS
   auto load_chunk = [&](int si, int kc) {
+    okmask = 0;
     const WSeg sg = a.seg[si];
     const float* base = sg.base + r * sg.rep_stride;
     const int k = kc + 4 * a_c4;
+    if (!SEGSUM || sg.mode <= 2) {
+      if (VEC4) {
+        const bool kok = k < sg.width;
+        const int kcl = kok ? k : 0;
+        const float* ub = sg.mode == 0 ? base + (size_t)row0 * sg.width : base;  // uniform: the tile's first row, or the gathered table
 #pragma unroll
-    for (int i = 0; i < NA4; ++i) {
-      const int row = a_r + RPP * i;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < rows && k < sg.width) {
-        if (sg.mode == 3) {
+        for (int i = 0; i < NA4; ++i) {
+          const int row = a_r + RPP * i;
+          const int rc = min(row, rows - 1);
+          const int ia = s_ia[rc], ib = s_ib[rc];
+          const int grow = sg.mode == 0 ? rc : (sg.mode == 1 ? ia : ib);
+          ra(i) = ld4(ub, (unsigned)grow * (unsigned)sg.width + (unsigned)kcl);
+        }
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) okmask |= (kok && a_r + RPP * i < rows) ? (1u << i) : 0u;  // zeroed in store_chunk: a select HERE waits for the load
+      } else {
+        okmask |= (1u << NA4) - 1u;
+#pragma unroll
+        for (int i = 0; i < NA4; ++i) {
+          const int row = a_r + RPP * i;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (row < rows && k < sg.width) {
+            const int grow = sg.mode == 0 ? row0 + row : (sg.mode == 1 ? s_ia[row] : s_ib[row]);
+            const float* p = base + (size_t)grow * sg.width + k;
+            v.x = p[0];
+            if (k + 1 < sg.width) v.y = p[1];
+            if (k + 2 < sg.width) v.z = p[2];
+            if (k + 3 < sg.width) v.w = p[3];
+          }
+          ra(i) = v;
+        }
+      }
+    } else if (SEGSUM && sg.mode == 3) {
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) {
+        const int row = a_r + RPP * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows && k < sg.width) {
           // segment sum over the node's in-edges (CSC range), 4 rows in flight: unconditional clamped loads (a load
           // inside the guarded loop body cannot be hoisted, which costs one memory round trip per edge)
           const int e0 = s_ia[row], e1 = s_ib[row];
@@ -208,74 +311,159 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
               if (e + j < e1) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
             }
           }
-        } else if (sg.mode == 4) {
-          // the node's in-edge sum: one partial row, plus the first row of every further chunk its edges run into (fixed order)
-          const int pr = s_ia[row], parts = s_ib[row];
-          if (pr >= 0) {
-            v = *reinterpret_cast<const float4*>(base + (size_t)pr * sg.width + k);
-            if (parts > 1) {
-              const int c0 = a.node_agg_chunk[row0 + row];
-              for (int j = 1; j < parts; ++j) {
-                const float4 u = *reinterpret_cast<const float4*>(base + (size_t)a.chunk_row0[c0 + j] * sg.width + k);
-                v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-              }
-            }
-          }
-        } else {
-          const int grow = sg.mode == 0 ? row0 + row : (sg.mode == 1 ? s_ia[row] : s_ib[row]);
-          const float* p = base + (size_t)grow * sg.width + k;
-          if (VEC4) {
-            v = *reinterpret_cast<const float4*>(p);
-          } else {
-            v.x = p[0];
-            if (k + 1 < sg.width) v.y = p[1];
-            if (k + 2 < sg.width) v.z = p[2];
-            if (k + 3 < sg.width) v.w = p[3];
+        }
+        ra(i) = v;
+      }
+      okmask |= (1u << NA4) - 1u;
+    } else if (SEGSUM) {
+      // mode 4 — the node's in-edge sum: one partial row, plus the first row of every further chunk its edges run into (fixed
+      // order).  First partials of all rows in one go (clamped, unconditional), the rare further parts after them.
+      const bool kok = k < sg.width;
+      const int kcl = kok ? k : 0;
+      int pr[NA4], parts[NA4];
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) {
+        const int rc = min(a_r + RPP * i, rows - 1);
+        pr[i] = s_ia[rc];
+        parts[i] = a_r + RPP * i < rows ? s_ib[rc] : 0;
+        ra(i) = ld4(base, (unsigned)max(pr[i], 0) * (unsigned)sg.width + (unsigned)kcl);
+      }
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) {
+        if (!(kok && pr[i] >= 0 && a_r + RPP * i < rows)) ra(i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else if (parts[i] > 1) {
+          const int c0 = a.node_agg_chunk[row0 + a_r + RPP * i];
+          for (int j = 1; j < parts[i]; ++j) {
+            const float4 u = *reinterpret_cast<const float4*>(base + (size_t)a.chunk_row0[c0 + j] * sg.width + k);
+            ra(i).x += u.x; ra(i).y += u.y; ra(i).z += u.z; ra(i).w += u.w;
           }
         }
       }
-      ra[i] = v;
+      okmask |= (1u << NA4) - 1u;
     }
+    const int ldw = a.ldw ? a.ldw : a.OUT;
+    if (VEC4) {
 #pragma unroll
-    for (int i = 0; i < NB4; ++i) {
-      const int q = tid + WT * i;
-      const int kk = q / (BN / 4), c4 = q % (BN / 4);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int n = n0 + 4 * c4;
-      if (kc + kk < sg.width && n < a.OUT) {
-        const float* p = a.W + (size_t)(sg.w_row0 + kc + kk) * (a.ldw ? a.ldw : a.OUT) + n;
-        if (VEC4) {
-          v = *reinterpret_cast<const float4*>(p);
-        } else {
+      for (int i = 0; i < NB4; ++i) {
+        const int q = tid + WT * i;
+        const int kk = q / (BN / 4), c4 = q % (BN / 4);
+        const int n = n0 + 4 * c4;
+        const bool ok = kc + kk < sg.width && n < a.OUT;
+        rb(i) = ld4(a.W + (size_t)(sg.w_row0 + kc) * ldw + n0, ok ? (unsigned)kk * (unsigned)ldw + 4u * c4 : 0u);
+        okmask |= ok ? (1u << (NA4 + i)) : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB4; ++i) {
+        const int q = tid + WT * i;
+        const int kk = q / (BN / 4), c4 = q % (BN / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int n = n0 + 4 * c4;
+        if (kc + kk < sg.width && n < a.OUT) {
+          const float* p = a.W + (size_t)(sg.w_row0 + kc + kk) * ldw + n;
           v.x = p[0];
           if (n + 1 < a.OUT) v.y = p[1];
           if (n + 2 < a.OUT) v.z = p[2];
           if (n + 3 < a.OUT) v.w = p[3];
         }
+        rb(i) = v;
       }
-      rb[i] = v;
+      okmask |= ((1u << NB4) - 1u) << NA4;
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
       float* d = sA + (a_r + RPP * i) * LDA + 4 * a_c4;
-      d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+      const bool ok = (okmask >> i) & 1u;
+      d[0] = ok ? ra(i).x : 0.f; d[1] = ok ? ra(i).y : 0.f; d[2] = ok ? ra(i).z : 0.f; d[3] = ok ? ra(i).w : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
       const int q = tid + WT * i;
-      *reinterpret_cast<float4*>(sB + 4 * q) = rb[i];  // q = kk*(BN/4) + c4  ->  sB[kk][4*c4]
+      const bool ok = (okmask >> (NA4 + i)) & 1u;
+      *reinterpret_cast<float4*>(sB + 4 * q) = ok ? rb(i) : make_float4(0.f, 0.f, 0.f, 0.f);  // q = kk*(BN/4) + c4  ->  sB[kk][4*c4]
     }
   };
 
+  const int hi = lane >> 5, l31 = lane & 31;
+  // ---- epilogue operands (declared here: the first group is requested during the LAST chunk's matrix-core work) ----
+  float* out = a.out + r * a.out_rep_stride;
+  constexpr int NC4 = (64 * BN / 4) / WT;  // float4 per thread and pass
+  constexpr int NG = WT / (BN / 4);        // row groups that share a column quad
+  const bool gadd = a.gadd_a != nullptr;
+  float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // VEC4 epilogue: thread = (column quad q4, row lr0 + NG*i of the pass), GRP row quads per step
+  constexpr int GRP = NC4 > 4 ? 4 : NC4;
+  constexpr int NGRP = NC4 / GRP;
+  constexpr int NTG = 2 * NGRP;            // operand groups of the tile, in order (pass, group): group t lives in buffer t & 1
+  const int q4 = tid % (BN / 4), lr0 = tid / (BN / 4);
+  const int ncol = n0 + 4 * q4;
+  const bool col_ok = ncol < a.OUT;
+  float* out_tile = out + (size_t)row0 * a.OUT;
+  static_assert(GRP == GRP_, "operand group size");
+  // operand streams X / Y, double-buffered over the groups: buffer 0 = the chunk staging registers, buffer 1 = stg1
+#define ex(b, u) ((b) == 0 ? stg[u] : stg1[u])
+#define ey(b, u) ((b) == 0 ? stg[GRP + (u)] : stg1[GRP + (u)])
+  const float* xb = nullptr;
+  const float* yb = nullptr;
+  int xk = 0, yk = 0;  // row of the operand: 0 the output row itself, 1 idx_a[row], 2 idx_b[row]
+  if (VEC4 && NL > 0) {
+    const size_t own = r * a.out_rep_stride + (size_t)row0 * a.OUT;  // operands with the layout of `out`: the tile's first row
+    switch (a.epi) {
+      case EPI_GADD: xb = a.gadd_a + r * a.gadd_rep_stride; yb = a.gadd_b + r * a.gadd_rep_stride; xk = 1; yk = 2; break;
+      case EPI_ADD1: xb = a.add1 + own; break;
+      case EPI_ADD12: xb = a.add1 + own; yb = a.add2 + own; break;
+      case EPI_GMUL: xb = a.gmul + own; break;
+      default: xb = a.gmul + own; yb = a.add1 + own; break;  // EPI_GMUL_ADD
+    }
+  }
+  auto issue_operands = [&](int pass, int g, int buf) {  // unconditional loads of clamped rows / columns: nothing to branch around
+    const int nc = col_ok ? ncol : 0;
+#pragma unroll
+    for (int u = 0; u < GRP; ++u) {
+      const int row = min(64 * pass + lr0 + NG * (g * GRP + u), rows - 1);
+      const int ia = s_ia[row], ib = s_ib[row];  // (read unconditionally: a select, not a branch around an LDS read)
+      const float4 xv = ld4(xb, (unsigned)(xk == 0 ? row : ia) * (unsigned)a.OUT + (unsigned)nc);
+      if (buf == 0) stg[u] = xv; else stg1[u] = xv;
+      if (NL == 2) {
+        const float4 yv = ld4(yb, (unsigned)(yk == 0 ? row : ib) * (unsigned)a.OUT + (unsigned)nc);
+        if (buf == 0) stg[GRP + u] = yv; else stg1[GRP + u] = yv;
+      }
+    }
+  };
   int si = 0, kc = 0;
 #ifdef GNX_WIDE_STAMPS_BUILD
   st[1] = clock64();
-  unsigned long long t_sync = 0, t_mfma = 0;
+  unsigned long long t_sync = 0, t_mfma = 0, t_issue = 0;
 #endif
+  // the matrix-core work of the chunk in LDS.  Fragments of k-step kk+1 are requested from LDS before the MFMAs of step kk are
+  // issued (explicit two-deep register pipeline: left to itself the compiler places each ds_read right in front of its first use)
+  auto mma_chunk = [&]() {
+    float fa[2][L::TM], fb[2][L::TN];
+#pragma unroll
+    for (int i = 0; i < L::TM; ++i) fa[0][i] = sA[((i * L::WM + wm) * 32 + l31) * LDA + hi];
+#pragma unroll
+    for (int j = 0; j < L::TN; ++j) fb[0][j] = sB[hi * BN + (wn * L::TN + j) * 32 + l31];
+#pragma unroll
+    for (int kk = 0; kk < KC / 2; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < KC / 2) {
+#pragma unroll
+        for (int i = 0; i < L::TM; ++i) fa[nxt][i] = sA[((i * L::WM + wm) * 32 + l31) * LDA + 2 * (kk + 1) + hi];
+#pragma unroll
+        for (int j = 0; j < L::TN; ++j) fb[nxt][j] = sB[(2 * (kk + 1) + hi) * BN + (wn * L::TN + j) * 32 + l31];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads above in front of this step's MFMAs
+#pragma unroll
+      for (int i = 0; i < L::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < L::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+    }
+  };
   while (si < a.nseg && a.seg[si].width == 0) ++si;
   if (si < a.nseg) load_chunk(si, kc);
+  else if (VEC4 && NL > 0) issue_operands(0, 0, 0);  // (no K at all: bias / operands only)
   while (si < a.nseg) {
 #ifdef GNX_WIDE_STAMPS_BUILD
     const unsigned long long tA = clock64();
@@ -295,33 +483,16 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       while (si < a.nseg && a.seg[si].width == 0) ++si;
     }
     if (si < a.nseg) load_chunk(si, kc);
-    const int hi = lane >> 5, l31 = lane & 31;
-    // fragments of k-step kk+1 are requested from LDS before the MFMAs of step kk are issued (explicit two-deep
-    // register pipeline: left to itself the compiler places each ds_read right in front of its first use)
-    float fa[2][L::TM], fb[2][L::TN];
-#pragma unroll
-    for (int i = 0; i < L::TM; ++i) fa[0][i] = sA[((wm * L::TM + i) * 32 + l31) * LDA + hi];
-#pragma unroll
-    for (int j = 0; j < L::TN; ++j) fb[0][j] = sB[hi * BN + (wn * L::TN + j) * 32 + l31];
-#pragma unroll
-    for (int kk = 0; kk < KC / 2; ++kk) {
-      const int cur = kk & 1, nxt = cur ^ 1;
-      if (kk + 1 < KC / 2) {
-#pragma unroll
-        for (int i = 0; i < L::TM; ++i) fa[nxt][i] = sA[((wm * L::TM + i) * 32 + l31) * LDA + 2 * (kk + 1) + hi];
-#pragma unroll
-        for (int j = 0; j < L::TN; ++j) fb[nxt][j] = sB[(2 * (kk + 1) + hi) * BN + (wn * L::TN + j) * 32 + l31];
-      }
-      __builtin_amdgcn_sched_barrier(0);  // keep the reads above in front of this step's MFMAs
-#pragma unroll
-      for (int i = 0; i < L::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < L::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
-    }
+    else if (VEC4 && NL > 0) issue_operands(0, 0, 0);  // last chunk: the staging registers are free — the epilogue's first operand group takes them
+#ifdef GNX_WIDE_STAMPS_BUILD
+    t_issue += clock64() - tB;
+#endif
+    mma_chunk();
 #ifdef GNX_WIDE_STAMPS_BUILD
     t_mfma += clock64() - tB;
 #endif
   }
+  if (VEC4 && NL > 0 && NTG > 1) issue_operands(NGRP > 1 ? 0 : 1, NGRP > 1 ? 1 : 0, 1);  // second group: buffer 1
 #ifdef GNX_WIDE_STAMPS_BUILD
   st[2] = clock64();
 #endif
@@ -329,12 +500,6 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   // ---- epilogue: the tile goes through LDS (two 64-row passes) so that HBM sees full-row 16-B vector stores (the direct
   //      C/D-layout store is 64 dword stores per lane — measured: ff1 3.43 vs 2.84 ms, ff2 3.08 vs 2.55 ms on C4); bias', the gathered node projections, the activation, the column
   //      sums for the graph update and the residual adds are applied on the vectorised side ----
-  float* out = a.out + r * a.out_rep_stride;
-  const int hi = lane >> 5, l31 = lane & 31;
-  constexpr int NC4 = (64 * BN / 4) / WT;  // float4 per thread and pass
-  constexpr int NG = WT / (BN / 4);        // row groups that share a column quad
-  const bool gadd = a.gadd_a != nullptr;
-  float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
   __shared__ int s_seg[66];  // per-destination runs of a pass: s_seg[k] = first row of run k, s_seg[n_seg] = valid rows; s_seg[65] = n_seg
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -351,8 +516,8 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < L::TM; ++i) {
-      const int rbase = (wm * L::TM + i) * 32;  // 32-row block of this wave
-      if (rbase / 64 == pass) {
+      const int rbase = (i * L::WM + wm) * 32;  // 32-row block of this wave (interleaved: every wave hands half of its accumulators to pass 0)
+      if (L::TM == 2 ? i == pass : rbase / 64 == pass) {  // (TM = 2: block i of every wave belongs to pass i — a compile-time test, so pass 0 frees half of the accumulators)
 #pragma unroll
         for (int j = 0; j < L::TN; ++j) {
           const int col = (wn * L::TN + j) * 32 + l31;
@@ -363,6 +528,61 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       }
     }
     lds_barrier();
+    if constexpr (VEC4) {
+#pragma unroll
+      for (int g = 0; g < NGRP; ++g) {
+        const int tg = pass * NGRP + g, cur = tg & 1;
+        float4 v[GRP];
+        const float4 b = *reinterpret_cast<const float4*>(s_bias + 4 * q4);
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+          v[u] = *reinterpret_cast<const float4*>(sC + (lr0 + NG * (g * GRP + u)) * LDC + 4 * q4);
+          v[u].x += b.x; v[u].y += b.y; v[u].z += b.z; v[u].w += b.w;
+        }
+        if (NL == 2 && a.epi == EPI_GADD) {
+#pragma unroll
+          for (int u = 0; u < GRP; ++u) {
+            const float4 p = ex(cur, u), d = ey(cur, u);
+            v[u].x += p.x + d.x; v[u].y += p.y + d.y; v[u].z += p.z + d.z; v[u].w += p.w + d.w;
+          }
+        }
+        if (TRANS) {
+          act_apply_n<4 * GRP>(reinterpret_cast<float*>(v), a.act);
+        } else if (a.act == 1) {
+#pragma unroll
+          for (int u = 0; u < GRP; ++u) { v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f); }
+        }
+        if (NL > 0 && (a.epi == EPI_GMUL || a.epi == EPI_GMUL_ADD)) {
+#pragma unroll
+          for (int u = 0; u < GRP; ++u) {
+            const float4 x = ex(cur, u);
+            v[u].x *= act_grad_from_out(x.x, a.gmul_act); v[u].y *= act_grad_from_out(x.y, a.gmul_act);
+            v[u].z *= act_grad_from_out(x.z, a.gmul_act); v[u].w *= act_grad_from_out(x.w, a.gmul_act);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+          const int lr = lr0 + NG * (g * GRP + u);
+          const bool ok = 64 * pass + lr < rows && col_ok;
+          if (ok) { cs4.x += v[u].x; cs4.y += v[u].y; cs4.z += v[u].z; cs4.w += v[u].w; }  // column sums BEFORE the residual adds
+          if (a.agg_out) *reinterpret_cast<float4*>(sC + lr * LDC + 4 * q4) = v[u];       // the finished value, for the per-destination sums below
+        }
+        if (NL > 0 && (a.epi == EPI_ADD1 || a.epi == EPI_ADD12)) {
+#pragma unroll
+          for (int u = 0; u < GRP; ++u) { const float4 x = ex(cur, u); v[u].x += x.x; v[u].y += x.y; v[u].z += x.z; v[u].w += x.w; }
+        }
+        if (NL == 2 && (a.epi == EPI_ADD12 || a.epi == EPI_GMUL_ADD)) {
+#pragma unroll
+          for (int u = 0; u < GRP; ++u) { const float4 y = ey(cur, u); v[u].x += y.x; v[u].y += y.y; v[u].z += y.z; v[u].w += y.w; }
+        }
+        if (NL > 0 && tg + 2 < NTG) issue_operands((tg + 2) / NGRP, (tg + 2) % NGRP, cur);  // this buffer is consumed: refill it, BEFORE the stores
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+          const int row = 64 * pass + lr0 + NG * (g * GRP + u);
+          if (row < rows && col_ok) st4(out_tile, (unsigned)row * (unsigned)a.OUT + (unsigned)ncol, v[u]);
+        }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < NC4; ++i) {
       const int idx = tid + WT * i;
@@ -373,41 +593,23 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
         const float4 b = *reinterpret_cast<const float4*>(s_bias + 4 * c4);
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         const size_t o = (size_t)(row0 + row) * a.OUT + n;
-        if (VEC4) {
-          if (gadd) {
-            const float4 p = *reinterpret_cast<const float4*>(a.gadd_a + r * a.gadd_rep_stride + (size_t)s_ia[row] * a.OUT + n);
-            const float4 d = *reinterpret_cast<const float4*>(a.gadd_b + r * a.gadd_rep_stride + (size_t)s_ib[row] * a.OUT + n);
-            v.x += p.x + d.x; v.y += p.y + d.y; v.z += p.z + d.z; v.w += p.w + d.w;
-          }
-          v.x = act_apply(v.x, a.act); v.y = act_apply(v.y, a.act); v.z = act_apply(v.z, a.act); v.w = act_apply(v.w, a.act);
-          if (a.gmul) {
-            const float4 u = *reinterpret_cast<const float4*>(a.gmul + r * a.out_rep_stride + o);
-            v.x *= act_grad_from_out(u.x, a.gmul_act); v.y *= act_grad_from_out(u.y, a.gmul_act);
-            v.z *= act_grad_from_out(u.z, a.gmul_act); v.w *= act_grad_from_out(u.w, a.gmul_act);
-          }
-          cs4.x += v.x; cs4.y += v.y; cs4.z += v.z; cs4.w += v.w;  // column sums BEFORE the residual adds
-          if (a.agg_out) *reinterpret_cast<float4*>(sC + lr * LDC + 4 * c4) = v;  // the finished value, for the per-destination sums below
-          if (a.add1) { const float4 u = *reinterpret_cast<const float4*>(a.add1 + r * a.out_rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-          if (a.add2) { const float4 u = *reinterpret_cast<const float4*>(a.add2 + r * a.out_rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-          *reinterpret_cast<float4*>(out + o) = v;
-        } else {
-          float vv[4] = {v.x, v.y, v.z, v.w};
-          float* cc = reinterpret_cast<float*>(&cs4);
+        float vv[4] = {v.x, v.y, v.z, v.w};
+        float* cc = reinterpret_cast<float*>(&cs4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (n + e < a.OUT) {
-              float y = vv[e];
-              if (gadd) y += a.gadd_a[r * a.gadd_rep_stride + (size_t)s_ia[row] * a.OUT + n + e] + a.gadd_b[r * a.gadd_rep_stride + (size_t)s_ib[row] * a.OUT + n + e];
-              y = act_apply(y, a.act);
-              if (a.gmul) y *= act_grad_from_out(a.gmul[r * a.out_rep_stride + o + e], a.gmul_act);
-              cc[e] += y;
-              if (a.add1) y += a.add1[r * a.out_rep_stride + o + e];
-              if (a.add2) y += a.add2[r * a.out_rep_stride + o + e];
-              out[o + e] = y;
-            }
+        for (int e = 0; e < 4; ++e) {
+          if (n + e < a.OUT) {
+            float y = vv[e];
+            if (gadd) y += a.gadd_a[r * a.gadd_rep_stride + (size_t)s_ia[row] * a.OUT + n + e] + a.gadd_b[r * a.gadd_rep_stride + (size_t)s_ib[row] * a.OUT + n + e];
+            y = act_apply(y, a.act);
+            if (a.gmul) y *= act_grad_from_out(a.gmul[r * a.out_rep_stride + o + e], a.gmul_act);
+            cc[e] += y;
+            if (a.add1) y += a.add1[r * a.out_rep_stride + o + e];
+            if (a.add2) y += a.add2[r * a.out_rep_stride + o + e];
+            out[o + e] = y;
           }
         }
       }
+    }
     }
     if (VEC4 && a.agg_out) {
       // ---- per-destination sums of this 64-row pass (rows are dst-sorted: a destination is a contiguous run) ----
@@ -416,7 +618,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       const int q4 = tid % (BN / 4), grp = tid / (BN / 4);
       const int n = n0 + 4 * q4;
       if (n < a.OUT) {
-        float* agg = a.agg_out + r * a.agg_rep_stride + (size_t)a.chunk_row0[2 * tile_id + pass] * a.OUT + n;
+        float* agg = a.agg_out + r * a.agg_rep_stride + (size_t)agg_row0[pass] * a.OUT + n;
         for (int sgm = grp; sgm < n_seg; sgm += NG) {
           const int r0 = s_seg[sgm], r1 = s_seg[sgm + 1];
           float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -448,6 +650,8 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   if (a.stamps && tid == 0 && ctile == 0 && blockIdx.z == 0) {
     unsigned long long* o = a.stamps + (size_t)tile_id * 8;
     o[0] = st[1] - st[0]; o[1] = t_sync; o[2] = t_mfma; o[3] = clock64() - st[2]; o[4] = clock64() - st[0];
+    o[5] = st[0]; o[6] = t_issue;  // absolute tile start; time to issue the next chunk's global loads (part of o[2])
+    o[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);  // XCC_ID, HW_ID
   }
 #endif
 }
@@ -685,17 +889,43 @@ static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64
   }
   if (want_stamps) { (void)hipMemsetAsync(d_stamps, 0, (size_t)n_tiles * 8 * sizeof(unsigned long long), s); wa.stamps = d_stamps; }
 #endif
-  if (vec4) hipLaunchKernelGGL((k_rows_gemm<BN, true, 32>), grid, dim3(WT), 0, s, wa);
-  else hipLaunchKernelGGL((k_rows_gemm<BN, false, 32>), grid, dim3(WT), 0, s, wa);
+  const float* a1 = w.add1 ? w.add1 : w.add2;  // a lone add2 is an add1
+  const float* a2 = w.add1 ? w.add2 : nullptr;
+  wa.add1 = a1; wa.add2 = a2;
+  if (w.gadd_a && (a1 || w.gmul)) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: gathered addends cannot be combined with residual / gmul operands");
+  if (w.gmul && a2) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: gmul takes at most one residual operand");
+  wa.epi = w.gadd_a ? EPI_GADD : (w.gmul ? (a1 ? EPI_GMUL_ADD : EPI_GMUL) : (a2 ? EPI_ADD12 : (a1 ? EPI_ADD1 : EPI_NONE)));
+  const int nl = wa.epi == EPI_NONE ? 0 : ((wa.epi == EPI_ADD1 || wa.epi == EPI_GMUL) ? 1 : 2);
+  static const int stagger_env = getenv("GNX_GEMM_STAGGER") ? atoi(getenv("GNX_GEMM_STAGGER")) : 0;
+  wa.stagger = (n_tiles >= 2048 && wa.n_ctiles == 1) ? stagger_env : 0;
+  const bool trans = w.act > 1;
+  bool segsum = false;
+  for (int i = 0; i < w.nseg; ++i) segsum |= w.seg[i].mode >= 3;
+#define GNX_GEMM_LAUNCH(V, N, T, S) hipLaunchKernelGGL((k_rows_gemm<BN, V, 32, N, T, S>), grid, dim3(WT), 0, s, wa)
+#define GNX_GEMM_LAUNCH_T(V, N, S) do { if (trans) GNX_GEMM_LAUNCH(V, N, true, S); else GNX_GEMM_LAUNCH(V, N, false, S); } while (0)
+  if (!vec4) GNX_GEMM_LAUNCH(false, 0, true, true);
+  else if (segsum) {  // node update: never with epilogue operands
+    if (nl != 0) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: a segment-sum launch takes no epilogue operands");
+    GNX_GEMM_LAUNCH_T(true, 0, true);
+  } else if (nl == 0) GNX_GEMM_LAUNCH_T(true, 0, false);
+  else if (nl == 1) GNX_GEMM_LAUNCH_T(true, 1, false);
+  else GNX_GEMM_LAUNCH_T(true, 2, false);
+#undef GNX_GEMM_LAUNCH_T
+#undef GNX_GEMM_LAUNCH
 #ifdef GNX_WIDE_STAMPS_BUILD
   if (want_stamps) {
     (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> hs((size_t)n_tiles * 8);
     (void)hipMemcpy(hs.data(), d_stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    double m[5] = {0, 0, 0, 0, 0};
-    for (size_t i = 0; i < n_tiles; ++i) for (int j = 0; j < 5; ++j) m[j] += (double)hs[i * 8 + j];
-    fprintf(stderr, "[gnx stamps] %s BN=%d tiles=%u ctiles=%d: per tile (shader clocks, wave 0 of column tile 0): prologue %.0f  sync+store %.0f  mfma-loop %.0f  epilogue %.0f  total %.0f\n",
-            name, BN, n_tiles, wa.n_ctiles, m[0] / n_tiles, m[1] / n_tiles, m[2] / n_tiles, m[3] / n_tiles, m[4] / n_tiles);
+    if (const char* dump = getenv("GNX_WIDE_STAMPS_DUMP")) {  // raw [tile][8] table of the largest launch, for offline timelines
+      char path[512];
+      snprintf(path, sizeof path, "%s_%s.bin", dump, name);  // (the last launch of each name wins)
+      if (FILE* f = fopen(path, "wb")) { fwrite(hs.data(), 8, hs.size(), f); fclose(f); }
+    }
+    double m[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < n_tiles; ++i) for (int j = 0; j < 7; ++j) m[j] += (double)hs[i * 8 + j];
+    fprintf(stderr, "[gnx stamps] %s BN=%d tiles=%u ctiles=%d: per tile (shader clocks, wave 0 of column tile 0): prologue %.0f  sync+store %.0f  mfma-loop %.0f (of which issuing the next chunk's loads %.0f)  epilogue %.0f  total %.0f\n",
+            name, BN, n_tiles, wa.n_ctiles, m[0] / n_tiles, m[1] / n_tiles, m[2] / n_tiles, m[6] / n_tiles, m[3] / n_tiles, m[4] / n_tiles);
   }
 #endif
   GNX_HIP(hipGetLastError());
