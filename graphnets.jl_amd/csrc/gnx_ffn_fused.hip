@@ -175,12 +175,30 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
     }
   }
 
-  // ---- epilogue: two 64-row passes through LDS -> full-row 16-B stores with bias and the two residuals ----
+  // ---- epilogue: two 64-row passes through LDS -> full-row 16-B stores with bias and the two residuals.  The residual rows of a
+  //      pass are requested in one go (unconditional loads of clamped rows) before the pass's LDS traffic, pass 1's before pass 0's
+  //      stores: one load -> add -> store per quad is a memory round trip per quad (vmcnt counts the stores too) ----
   constexpr int LDC = D + 4;
   constexpr int NC4 = (64 * D / 4) / NT;
-  float* out = a.out + r * a.rep_stride;
+  float* out_tile = a.out + r * a.rep_stride + (size_t)row0 * D;
+  const float* add1_tile = a.add1 ? a.add1 + r * a.rep_stride + (size_t)row0 * D : nullptr;
+  const float* add2_tile = a.add2 ? a.add2 + r * a.rep_stride + (size_t)row0 * D : nullptr;
+  const int q4 = tid % (D / 4), lr0 = tid / (D / 4);
+  constexpr int NGR = NT / (D / 4);  // rows between the quads of a thread
+  f32x4 u1[2][NC4], u2[2][NC4];
+  auto issue_residuals = [&](int pass) {
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < NC4; ++i) {
+      const unsigned off = (unsigned)min(64 * pass + lr0 + NGR * i, rows - 1) * D + 4u * q4;
+      if (add1_tile) u1[pass][i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(add1_tile) + (off << 2));
+      if (add2_tile) u2[pass][i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(add2_tile) + (off << 2));
+    }
+  };
+  issue_residuals(0);
+  f32x4 b2v = {0.f, 0.f, 0.f, 0.f};
+  if (a.b2) b2v = *reinterpret_cast<const f32x4*>(a.b2 + 4 * q4);
+  static_for<0, 2>([&](auto pass_c) {
+    constexpr int pass = decltype(pass_c)::value;
     lds_barrier_f();
     if ((wm >> 1) == pass) {
 #pragma unroll
@@ -191,21 +209,24 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
       }
     }
     lds_barrier_f();
+    f32x4 v[NC4];
+#pragma unroll
+    for (int i = 0; i < NC4; ++i) v[i] = *reinterpret_cast<const f32x4*>(sC + (lr0 + NGR * i) * LDC + 4 * q4) + b2v;
+    if (add1_tile) {
+#pragma unroll
+      for (int i = 0; i < NC4; ++i) v[i] += u1[pass][i];
+    }
+    if (add2_tile) {
+#pragma unroll
+      for (int i = 0; i < NC4; ++i) v[i] += u2[pass][i];
+    }
+    if (pass == 0) issue_residuals(1);  // BEFORE pass 0's stores
 #pragma unroll
     for (int i = 0; i < NC4; ++i) {
-      const int idx = tid + NT * i;
-      const int lr = idx / (D / 4), c4 = idx % (D / 4);
-      const int row = 64 * pass + lr;
-      if (row < rows) {
-        float4 v = *reinterpret_cast<const float4*>(sC + lr * LDC + 4 * c4);
-        if (a.b2) { const float4 b = *reinterpret_cast<const float4*>(a.b2 + 4 * c4); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-        const size_t o = (size_t)(row0 + row) * D + 4 * c4;
-        if (a.add1) { const float4 u = *reinterpret_cast<const float4*>(a.add1 + r * a.rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-        if (a.add2) { const float4 u = *reinterpret_cast<const float4*>(a.add2 + r * a.rep_stride + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
-        *reinterpret_cast<float4*>(out + o) = v;
-      }
+      const int row = 64 * pass + lr0 + NGR * i;
+      if (row < rows) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(out_tile) + (((unsigned)row * D + 4u * q4) << 2)) = v[i];
     }
-  }
+  });
 }
 
 // (Round 2 built the variant this structure suggests — z tile RESIDENT in LDS for the whole tile, weights through a two-deep LDS

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   float* sB = s_pool + BM * LDA;                    // [KC][BN]   (BM*LDA*4 is a multiple of 16)
   float* sC = s_pool;                               // reused after the K loop
   __shared__ int s_ia[BM], s_ib[BM];  // gather indices, or colptr range for the segment-sum mode
+  __shared__ int s_ic[SEGSUM ? BM : 1];  // mode 4: row of the node's SECOND partial sum (-1: none)
   __shared__ __attribute__((aligned(16))) float s_bias[BN];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -206,8 +207,12 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       s_ia[tid] = a.cp[row0 + m];
       s_ib[tid] = tid < rows ? a.cp[row0 + m + 1] : s_ia[tid];
     } else if (need_agg) {  // (row of the first partial, number of further chunks << 24 | first chunk is resolved in the loader)
+      const int parts = tid < rows ? a.node_agg_parts[row0 + m] : 0;
       s_ia[tid] = a.node_agg_row[row0 + m];
-      s_ib[tid] = tid < rows ? a.node_agg_parts[row0 + m] : 0;
+      s_ib[tid] = parts;
+      // a node whose in-edges run into a second 64-row chunk (one in ~6 on the ER graph): resolve that row ONCE here — in the chunk
+      // loader the lookup is two dependent loads in front of the row load, per chunk
+      if (SEGSUM) s_ic[tid] = parts > 1 ? a.chunk_row0[a.node_agg_chunk[row0 + m] + 1] : -1;
     } else if (need_idx) {
       s_ia[tid] = a.idx_a[row0 + m];
       s_ib[tid] = a.idx_b[row0 + m];
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   constexpr int NSTG = NA4 + NB4 > 2 * GRP_ ? NA4 + NB4 : 2 * GRP_;
   float4 stg[NSTG];
   float4 stg1[2 * GRP_];  // second operand buffer (epilogue only)
+  float4 rs[SEGSUM ? NA4 : 1];  // mode 4: second partial-sum rows of the chunk
 #define ra(i) stg[i]
 #define rb(i) stg[NA4 + (i)]
   const int a_c4 = tid % C4R, a_r = tid / C4R;
@@ -316,30 +322,37 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       }
       okmask |= (1u << NA4) - 1u;
     } else if (SEGSUM) {
-      // mode 4 — the node's in-edge sum: one partial row, plus the first row of every further chunk its edges run into (fixed
-      // order).  First partials of all rows in one go (clamped, unconditional), the rare further parts after them.
+      // mode 4 — the node's in-edge sum: the first and the second partial row of every tile row in one go (clamped,
+      // unconditional loads; added when the chunk goes to LDS), the rare further parts (in-degree beyond two chunks) after them
       const bool kok = k < sg.width;
       const int kcl = kok ? k : 0;
-      int pr[NA4], parts[NA4];
+      bool more = false;
 #pragma unroll
       for (int i = 0; i < NA4; ++i) {
         const int rc = min(a_r + RPP * i, rows - 1);
-        pr[i] = s_ia[rc];
-        parts[i] = a_r + RPP * i < rows ? s_ib[rc] : 0;
-        ra(i) = ld4(base, (unsigned)max(pr[i], 0) * (unsigned)sg.width + (unsigned)kcl);
+        const int pr = s_ia[rc], p2 = s_ic[SEGSUM ? rc : 0];
+        const bool ok = kok && pr >= 0 && a_r + RPP * i < rows;
+        ra(i) = ld4(base, (unsigned)max(pr, 0) * (unsigned)sg.width + (unsigned)kcl);
+        rs[SEGSUM ? i : 0] = ld4(base, (unsigned)max(p2, 0) * (unsigned)sg.width + (unsigned)kcl);
+        okmask |= ok ? (1u << i) : 0u;
+        okmask |= (ok && p2 >= 0) ? (1u << (NA4 + NB4 + i)) : 0u;
+        more |= ok && s_ib[rc] > 2;
       }
+      if (more) {
 #pragma unroll
-      for (int i = 0; i < NA4; ++i) {
-        if (!(kok && pr[i] >= 0 && a_r + RPP * i < rows)) ra(i) = make_float4(0.f, 0.f, 0.f, 0.f);
-        else if (parts[i] > 1) {
-          const int c0 = a.node_agg_chunk[row0 + a_r + RPP * i];
-          for (int j = 1; j < parts[i]; ++j) {
-            const float4 u = *reinterpret_cast<const float4*>(base + (size_t)a.chunk_row0[c0 + j] * sg.width + k);
-            ra(i).x += u.x; ra(i).y += u.y; ra(i).z += u.z; ra(i).w += u.w;
+        for (int i = 0; i < NA4; ++i) {
+          const int rc = min(a_r + RPP * i, rows - 1);
+          const int parts = s_ib[rc];
+          if (((okmask >> i) & 1u) && parts > 2) {
+            const int c0 = a.node_agg_chunk[row0 + rc];
+            for (int j = 2; j < parts; ++j) {
+              const float4 u = ld4(base, (unsigned)a.chunk_row0[c0 + j] * (unsigned)sg.width + (unsigned)k);
+              float4& t4 = rs[SEGSUM ? i : 0];
+              t4.x += u.x; t4.y += u.y; t4.z += u.z; t4.w += u.w;
+            }
           }
         }
       }
-      okmask |= (1u << NA4) - 1u;
     }
     const int ldw = a.ldw ? a.ldw : a.OUT;
     if (VEC4) {
@@ -376,7 +389,10 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
     for (int i = 0; i < NA4; ++i) {
       float* d = sA + (a_r + RPP * i) * LDA + 4 * a_c4;
       const bool ok = (okmask >> i) & 1u;
-      d[0] = ok ? ra(i).x : 0.f; d[1] = ok ? ra(i).y : 0.f; d[2] = ok ? ra(i).z : 0.f; d[3] = ok ? ra(i).w : 0.f;
+      float4 v = ra(i);
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (SEGSUM && ((okmask >> (NA4 + NB4 + i)) & 1u)) { const float4 u = rs[SEGSUM ? i : 0]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
