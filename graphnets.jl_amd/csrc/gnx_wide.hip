@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "gnx_device.h"
@@ -37,8 +38,10 @@ struct WSeg {
   size_t rep_stride;  // floats between replicas
   int width;          // K extent of this segment
   int mode;           // 0: row m itself, 1: row idx_a[m], 2: row idx_b[m], 3: sum of rows [cp[m], cp[m+1]) of base,
-                      // 4: the node's in-edge sum from the partial-sum table the edge GEMM wrote (agg_* below)
+                      // 4: the node's in-edge sum from the partial-sum table the edge GEMM wrote (agg_* below),
+                      // 5: the narrow segments WideArgs::pk side by side in ONE K range (set by launch_gemm)
   int w_row0;         // first row of W (= first input feature index) of this segment
+  int vec;            // rows can be read as 16-B quads (width % 4 == 0, 16-B aligned base): set by launch_gemm
 };
 
 struct WideArgs {
@@ -79,6 +82,8 @@ struct WideArgs {
   const int* node_agg_chunk;   //         [N]
   int n_rtiles, n_ctiles;      // row tiles / column tiles of this launch (set by launch_gemm)
   int epi;                     // EPI_* (set by launch_gemm)
+  WSeg pk[3];                  // mode 5: the packed segments (modes 0-2), their W rows consecutive from seg[0].w_row0
+  int npk;
   int stagger;                 // start delay per residency slot (units of 64*127 clocks), 0 = none (set by launch_gemm)
   unsigned long long* stamps;  // diagnostic builds only (GNX_WIDE_STAMPS): [tile][8] shader-clock stamps of wave 0
 };
@@ -116,6 +121,9 @@ __device__ __forceinline__ void act_apply_n(float* v, int act) {
 __device__ __forceinline__ float4 ld4(const float* ubase, unsigned off) {
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ubase) + (off << 2));
 }
+__device__ __forceinline__ float ld1(const float* ubase, unsigned off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + (off << 2));
+}
 __device__ __forceinline__ void st4(float* ubase, unsigned off, float4 v) {
   *reinterpret_cast<float4*>(reinterpret_cast<char*>(ubase) + (off << 2)) = v;
 }
@@ -140,12 +148,17 @@ struct WaveLayout {
 // TRANS: the activation may be tanh / sigmoid / gelu.  Their expansions need ~10 temporaries per element: with them in the code the
 // register allocator parks the operands in flight in scratch memory (load, wait, scratch store) on EVERY path, relu's included —
 // so identity / relu launches get an instantiation without them.
-// SEGSUM: some segment is a sum of rows (modes 3 / 4, the node update).  Their loops and index tables cost the plain / gathered
-// loader registers it does not have (spilled LDS addresses are reloaded from scratch memory in front of every access, and a
-// scratch reload waits on vmcnt, i.e. for the global loads just issued): the edge / FeedForward launches get a kernel without them.
-template <int BN, bool VEC4, int KC, int NL, bool TRANS, bool SEGSUM>
+// VEC4: W, the output and the epilogue operands are accessed as 16-B quads (OUT % 4 == 0, aligned); else element by element.
+// LD: what the loader knows — 0: quad rows of modes 0-2; 1: also sums of rows (modes 3 / 4, the node update); 2: also segments whose
+// rows are not quads (width % 4 != 0: element loads) and the packed form of narrow segments (mode 5).  Their loops and index tables
+// cost the plain / gathered quad loader registers it does not have (spilled LDS addresses are reloaded from scratch memory in front of every access,
+// and a scratch reload waits on vmcnt, i.e. for the global loads just issued): launches whose segments are all quad rows of
+// modes 0-2 (the core's edge update, the FeedForward layers, the projections) get a kernel without them.
+template <int BN, bool VEC4, int KC, int NL, bool TRANS, int LD>
 __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   using L = WaveLayout<BN>;
+  constexpr bool FULL = LD >= 1;   // loader with the row-sum modes 3 / 4
+  constexpr bool ELEM = LD >= 2;   // ... and element-wise / packed segments
   constexpr int LDA = KC + 1;               // A row stride: odd => conflict-free ds_read_b32 of the A fragment
   constexpr int C4R = KC / 4;               // float4 per A row chunk
   constexpr int RPP = WT / C4R;             // A rows loaded per pass of the workgroup
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   float* sB = s_pool + BM * LDA;                    // [KC][BN]   (BM*LDA*4 is a multiple of 16)
   float* sC = s_pool;                               // reused after the K loop
   __shared__ int s_ia[BM], s_ib[BM];  // gather indices, or colptr range for the segment-sum mode
-  __shared__ int s_ic[SEGSUM ? BM : 1];  // mode 4: row of the node's SECOND partial sum (-1: none)
+  __shared__ int s_ic[FULL ? BM : 1];  // mode 4: row of the node's SECOND partial sum (-1: none)
   __shared__ __attribute__((aligned(16))) float s_bias[BN];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -200,6 +213,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
     need_idx |= a.seg[s].mode == 1 || a.seg[s].mode == 2;
     need_agg |= a.seg[s].mode == 4;
   }
+  for (int s = 0; s < a.npk; ++s) need_idx |= a.pk[s].mode != 0;
   need_idx |= a.gadd_a != nullptr || a.agg_out != nullptr;
   if (tid < BM) {
     const int m = tid < rows ? tid : rows - 1;
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       s_ib[tid] = parts;
       // a node whose in-edges run into a second 64-row chunk (one in ~6 on the ER graph): resolve that row ONCE here — in the chunk
       // loader the lookup is two dependent loads in front of the row load, per chunk
-      if (SEGSUM) s_ic[tid] = parts > 1 ? a.chunk_row0[a.node_agg_chunk[row0 + m] + 1] : -1;
+      if (FULL) s_ic[tid] = parts > 1 ? a.chunk_row0[a.node_agg_chunk[row0 + m] + 1] : -1;
     } else if (need_idx) {
       s_ia[tid] = a.idx_a[row0 + m];
       s_ib[tid] = a.idx_b[row0 + m];
@@ -242,86 +256,120 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   constexpr int NSTG = NA4 + NB4 > 2 * GRP_ ? NA4 + NB4 : 2 * GRP_;
   float4 stg[NSTG];
   float4 stg1[2 * GRP_];  // second operand buffer (epilogue only)
-  float4 rs[SEGSUM ? NA4 : 1];  // mode 4: second partial-sum rows of the chunk
+  float4 rs[FULL ? NA4 : 1];  // mode 4: second partial-sum rows of the chunk
 #define ra(i) stg[i]
 #define rb(i) stg[NA4 + (i)]
   const int a_c4 = tid % C4R, a_r = tid / C4R;
 
-  // The mode is tested ONCE per chunk, outside the row loop, and the plain / gathered modes are straight-line code with
-  // unconditional loads of clamped addresses: with the test inside the loop every row's load sat in its own branch and the
-  // compiler's counter merge at each join put an `s_waitcnt vmcnt(0)` between the rows — four serial memory round trips per
-  // chunk (measured with the stamp build: 34 of the K loop's 57 k clocks on the 1M-edge edge GEMM were spent issuing loads).
-  unsigned okmask = 0;  // bit i: ra(i) holds data (else zero), bit NA4 + i: rb(i) — applied when the chunk goes to LDS
+  // The mode is tested ONCE per chunk, outside the row loop, and every mode is straight-line code with unconditional loads of
+  // clamped addresses whose validity is recorded in bit masks and applied when the chunk goes to LDS: with a test in front of each
+  // load every load sat in its own branch and the compiler's counter merge at each join put an `s_waitcnt vmcnt(0)` between
+  // them (four serial memory round trips per chunk — by the stamp build 34 of the K loop's 57 k clocks on the 1M-edge edge GEMM
+  // went into issuing loads); a select on the loaded value at this point waits for the load just the same.
+  unsigned okmask = 0;  // quads: bit i: ra(i) holds data (else zero), bit NA4 + i: rb(i), bit NA4 + NB4 + i: rs[i]
+  unsigned emask = 0;   // elements of element-wise loaded quads (FULL / !VEC4): bit 4 i + e: ra(i)[e], bit 16 + 4 i + e: rb(i)[e]
   auto load_chunk = [&](int si, int kc) {
     okmask = 0;
+    emask = 0;
     const WSeg sg = a.seg[si];
     const float* base = sg.base + r * sg.rep_stride;
     const int k = kc + 4 * a_c4;
-    if (!SEGSUM || sg.mode <= 2) {
-      if (VEC4) {
-        const bool kok = k < sg.width;
-        const int kcl = kok ? k : 0;
-        const float* ub = sg.mode == 0 ? base + (size_t)row0 * sg.width : base;  // uniform: the tile's first row, or the gathered table
+    if (!FULL || (sg.mode <= 2 && (!ELEM || sg.vec))) {
+      const bool kok = k < sg.width;
+      const int kcl = kok ? k : 0;
+      const float* ub = sg.mode == 0 ? base + (size_t)row0 * sg.width : base;  // uniform: the tile's first row, or the gathered table
 #pragma unroll
-        for (int i = 0; i < NA4; ++i) {
-          const int row = a_r + RPP * i;
-          const int rc = min(row, rows - 1);
-          const int ia = s_ia[rc], ib = s_ib[rc];
-          const int grow = sg.mode == 0 ? rc : (sg.mode == 1 ? ia : ib);
-          ra(i) = ld4(ub, (unsigned)grow * (unsigned)sg.width + (unsigned)kcl);
+      for (int i = 0; i < NA4; ++i) {
+        const int row = a_r + RPP * i;
+        const int rc = min(row, rows - 1);
+        const int ia = s_ia[rc], ib = s_ib[rc];
+        const int grow = sg.mode == 0 ? rc : (sg.mode == 1 ? ia : ib);
+        ra(i) = ld4(ub, (unsigned)grow * (unsigned)sg.width + (unsigned)kcl);
+        const bool ok = kok && row < rows;
+        okmask |= ok ? (1u << i) : 0u;
+        if (FULL) emask |= ok ? (15u << (4 * i)) : 0u;
+      }
+    } else if (ELEM && sg.mode <= 2) {
+      // rows that are not quads (width % 4 != 0): element loads
+      const float* ub = sg.mode == 0 ? base + (size_t)row0 * sg.width : base;
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) {
+        const int row = a_r + RPP * i;
+        const int rc = min(row, rows - 1);
+        const int ia = s_ia[rc], ib = s_ib[rc];
+        const unsigned ro = (unsigned)(sg.mode == 0 ? rc : (sg.mode == 1 ? ia : ib)) * (unsigned)sg.width;
+        float4 v;
+        v.x = ld1(ub, ro + (unsigned)min(k, sg.width - 1));
+        v.y = ld1(ub, ro + (unsigned)min(k + 1, sg.width - 1));
+        v.z = ld1(ub, ro + (unsigned)min(k + 2, sg.width - 1));
+        v.w = ld1(ub, ro + (unsigned)min(k + 3, sg.width - 1));
+        ra(i) = v;
+        if (row < rows) emask |= ((k < sg.width ? 1u : 0u) | (k + 1 < sg.width ? 2u : 0u) | (k + 2 < sg.width ? 4u : 0u) | (k + 3 < sg.width ? 8u : 0u)) << (4 * i);
+      }
+    } else if (ELEM && sg.mode == 5) {
+      // narrow segments side by side in one K range (e.g. the encoder's [ef(10) | nf_src(5) | nf_dst(5)]: one chunk instead of
+      // three): element kk of the range belongs to segment (kk >= p1) + (kk >= p2)
+      const int p1 = a.pk[0].width, p2 = a.npk > 1 ? p1 + a.pk[1].width : 0x7fffffff;
+      const float* b0 = a.pk[0].base + r * a.pk[0].rep_stride;
+      const float* b1 = a.npk > 1 ? a.pk[1].base + r * a.pk[1].rep_stride : b0;
+      const float* b2 = a.npk > 2 ? a.pk[2].base + r * a.pk[2].rep_stride : b0;
+      const int w0 = a.pk[0].width, w1 = a.npk > 1 ? a.pk[1].width : 1, w2 = a.npk > 2 ? a.pk[2].width : 1;
+      const int m0 = a.pk[0].mode, m1 = a.npk > 1 ? a.pk[1].mode : 0, m2 = a.npk > 2 ? a.pk[2].mode : 0;
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) {
+        const int row = a_r + RPP * i;
+        const int rc = min(row, rows - 1);
+        const int ia = s_ia[rc], ib = s_ib[rc], own = row0 + rc;
+        const int r0 = m0 == 0 ? own : (m0 == 1 ? ia : ib), r1 = m1 == 0 ? own : (m1 == 1 ? ia : ib), r2 = m2 == 0 ? own : (m2 == 1 ? ia : ib);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kk = min(k + e, sg.width - 1);
+          const bool s1 = kk >= p1, s2 = kk >= p2;
+          const float* b = s2 ? b2 : (s1 ? b1 : b0);
+          const unsigned off = s2 ? (unsigned)r2 * (unsigned)w2 + (unsigned)(kk - p2) : (s1 ? (unsigned)r1 * (unsigned)w1 + (unsigned)(kk - p1) : (unsigned)r0 * (unsigned)w0 + (unsigned)kk);
+          v[e] = b[off];
+          emask |= (row < rows && k + e < sg.width) ? (1u << (4 * i + e)) : 0u;
         }
-#pragma unroll
-        for (int i = 0; i < NA4; ++i) okmask |= (kok && a_r + RPP * i < rows) ? (1u << i) : 0u;  // zeroed in store_chunk: a select HERE waits for the load
-      } else {
-        okmask |= (1u << NA4) - 1u;
+        ra(i) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    } else if (FULL && sg.mode == 3) {
+      // segment sum over the node's in-edges (CSC range), 4 rows in flight: unconditional clamped loads (a load inside the
+      // guarded loop body cannot be hoisted, which costs one memory round trip per edge); quad / element form chosen outside
+      auto segsum_rows = [&](auto vec_c) {
+        constexpr bool VEC = decltype(vec_c)::value;
 #pragma unroll
         for (int i = 0; i < NA4; ++i) {
           const int row = a_r + RPP * i;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
           if (row < rows && k < sg.width) {
-            const int grow = sg.mode == 0 ? row0 + row : (sg.mode == 1 ? s_ia[row] : s_ib[row]);
-            const float* p = base + (size_t)grow * sg.width + k;
-            v.x = p[0];
-            if (k + 1 < sg.width) v.y = p[1];
-            if (k + 2 < sg.width) v.z = p[2];
-            if (k + 3 < sg.width) v.w = p[3];
+            const int e0 = s_ia[row], e1 = s_ib[row];
+            for (int e = e0; e < e1; e += 4) {
+              float4 u[4];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float* p = base + (size_t)min(e + j, e1 - 1) * sg.width + k;
+                if (VEC) {
+                  u[j] = *reinterpret_cast<const float4*>(p);
+                } else {
+                  u[j].x = p[0];
+                  u[j].y = k + 1 < sg.width ? p[1] : 0.f;
+                  u[j].z = k + 2 < sg.width ? p[2] : 0.f;
+                  u[j].w = k + 3 < sg.width ? p[3] : 0.f;
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if (e + j < e1) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
+              }
+            }
           }
           ra(i) = v;
         }
-      }
-    } else if (SEGSUM && sg.mode == 3) {
-#pragma unroll
-      for (int i = 0; i < NA4; ++i) {
-        const int row = a_r + RPP * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < rows && k < sg.width) {
-          // segment sum over the node's in-edges (CSC range), 4 rows in flight: unconditional clamped loads (a load
-          // inside the guarded loop body cannot be hoisted, which costs one memory round trip per edge)
-          const int e0 = s_ia[row], e1 = s_ib[row];
-          for (int e = e0; e < e1; e += 4) {
-            float4 u[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float* p = base + (size_t)min(e + j, e1 - 1) * sg.width + k;
-              if (VEC4) {
-                u[j] = *reinterpret_cast<const float4*>(p);
-              } else {
-                u[j].x = p[0];
-                u[j].y = k + 1 < sg.width ? p[1] : 0.f;
-                u[j].z = k + 2 < sg.width ? p[2] : 0.f;
-                u[j].w = k + 3 < sg.width ? p[3] : 0.f;
-              }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (e + j < e1) { v.x += u[j].x; v.y += u[j].y; v.z += u[j].z; v.w += u[j].w; }
-            }
-          }
-        }
-        ra(i) = v;
-      }
-      okmask |= (1u << NA4) - 1u;
-    } else if (SEGSUM) {
+      };
+      if (!ELEM || sg.vec) segsum_rows(std::true_type{}); else segsum_rows(std::false_type{});
+      emask |= 0xffffu;
+    } else if (FULL) {
       // mode 4 — the node's in-edge sum: the first and the second partial row of every tile row in one go (clamped,
       // unconditional loads; added when the chunk goes to LDS), the rare further parts (in-degree beyond two chunks) after them
       const bool kok = k < sg.width;
@@ -330,11 +378,11 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
 #pragma unroll
       for (int i = 0; i < NA4; ++i) {
         const int rc = min(a_r + RPP * i, rows - 1);
-        const int pr = s_ia[rc], p2 = s_ic[SEGSUM ? rc : 0];
+        const int pr = s_ia[rc], p2 = s_ic[FULL ? rc : 0];
         const bool ok = kok && pr >= 0 && a_r + RPP * i < rows;
         ra(i) = ld4(base, (unsigned)max(pr, 0) * (unsigned)sg.width + (unsigned)kcl);
-        rs[SEGSUM ? i : 0] = ld4(base, (unsigned)max(p2, 0) * (unsigned)sg.width + (unsigned)kcl);
-        okmask |= ok ? (1u << i) : 0u;
+        rs[FULL ? i : 0] = ld4(base, (unsigned)max(p2, 0) * (unsigned)sg.width + (unsigned)kcl);
+        emask |= ok ? (15u << (4 * i)) : 0u;
         okmask |= (ok && p2 >= 0) ? (1u << (NA4 + NB4 + i)) : 0u;
         more |= ok && s_ib[rc] > 2;
       }
@@ -343,11 +391,11 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
         for (int i = 0; i < NA4; ++i) {
           const int rc = min(a_r + RPP * i, rows - 1);
           const int parts = s_ib[rc];
-          if (((okmask >> i) & 1u) && parts > 2) {
+          if (((emask >> (4 * i)) & 1u) && parts > 2) {
             const int c0 = a.node_agg_chunk[row0 + rc];
             for (int j = 2; j < parts; ++j) {
               const float4 u = ld4(base, (unsigned)a.chunk_row0[c0 + j] * (unsigned)sg.width + (unsigned)k);
-              float4& t4 = rs[SEGSUM ? i : 0];
+              float4& t4 = rs[FULL ? i : 0];
               t4.x += u.x; t4.y += u.y; t4.z += u.z; t4.w += u.w;
             }
           }
@@ -355,50 +403,55 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       }
     }
     const int ldw = a.ldw ? a.ldw : a.OUT;
-    if (VEC4) {
+    const float* wb = a.W + (size_t)(sg.w_row0 + kc) * ldw + n0;  // uniform: first row of the chunk, first column of the tile
 #pragma unroll
-      for (int i = 0; i < NB4; ++i) {
-        const int q = tid + WT * i;
-        const int kk = q / (BN / 4), c4 = q % (BN / 4);
-        const int n = n0 + 4 * c4;
-        const bool ok = kc + kk < sg.width && n < a.OUT;
-        rb(i) = ld4(a.W + (size_t)(sg.w_row0 + kc) * ldw + n0, ok ? (unsigned)kk * (unsigned)ldw + 4u * c4 : 0u);
+    for (int i = 0; i < NB4; ++i) {
+      const int q = tid + WT * i;
+      const int kk = q / (BN / 4), c4 = q % (BN / 4);
+      const int n = n0 + 4 * c4;
+      const bool rok = kc + kk < sg.width;
+      const unsigned ro = rok ? (unsigned)kk * (unsigned)ldw : 0u;
+      if (VEC4) {
+        const bool ok = rok && n < a.OUT;
+        rb(i) = ld4(wb, ok ? ro + 4u * c4 : 0u);
         okmask |= ok ? (1u << (NA4 + i)) : 0u;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NB4; ++i) {
-        const int q = tid + WT * i;
-        const int kk = q / (BN / 4), c4 = q % (BN / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int n = n0 + 4 * c4;
-        if (kc + kk < sg.width && n < a.OUT) {
-          const float* p = a.W + (size_t)(sg.w_row0 + kc + kk) * ldw + n;
-          v.x = p[0];
-          if (n + 1 < a.OUT) v.y = p[1];
-          if (n + 2 < a.OUT) v.z = p[2];
-          if (n + 3 < a.OUT) v.w = p[3];
-        }
+      } else {
+        const int nl = a.OUT - 1 - n0;  // last valid column of the tile (>= 0)
+        float4 v;
+        v.x = ld1(wb, ro + (unsigned)min(4 * c4, nl));
+        v.y = ld1(wb, ro + (unsigned)min(4 * c4 + 1, nl));
+        v.z = ld1(wb, ro + (unsigned)min(4 * c4 + 2, nl));
+        v.w = ld1(wb, ro + (unsigned)min(4 * c4 + 3, nl));
         rb(i) = v;
+        if (rok) emask |= ((n < a.OUT ? 1u : 0u) | (n + 1 < a.OUT ? 2u : 0u) | (n + 2 < a.OUT ? 4u : 0u) | (n + 3 < a.OUT ? 8u : 0u)) << (16 + 4 * i);
       }
-      okmask |= ((1u << NB4) - 1u) << NA4;
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
       float* d = sA + (a_r + RPP * i) * LDA + 4 * a_c4;
-      const bool ok = (okmask >> i) & 1u;
       float4 v = ra(i);
-      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (SEGSUM && ((okmask >> (NA4 + NB4 + i)) & 1u)) { const float4 u = rs[SEGSUM ? i : 0]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+      if (FULL) {
+        const unsigned m = emask >> (4 * i);
+        v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+        if ((okmask >> (NA4 + NB4 + i)) & 1u) { const float4 u = rs[FULL ? i : 0]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+      } else if (!((okmask >> i) & 1u)) {
+        v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
       const int q = tid + WT * i;
-      const bool ok = (okmask >> (NA4 + i)) & 1u;
-      *reinterpret_cast<float4*>(sB + 4 * q) = ok ? rb(i) : make_float4(0.f, 0.f, 0.f, 0.f);  // q = kk*(BN/4) + c4  ->  sB[kk][4*c4]
+      float4 v = rb(i);
+      if (VEC4) {
+        if (!((okmask >> (NA4 + i)) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        const unsigned m = emask >> (16 + 4 * i);
+        v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(sB + 4 * q) = v;  // q = kk*(BN/4) + c4  ->  sB[kk][4*c4]
     }
   };
 
@@ -407,7 +460,6 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   float* out = a.out + r * a.out_rep_stride;
   constexpr int NC4 = (64 * BN / 4) / WT;  // float4 per thread and pass
   constexpr int NG = WT / (BN / 4);        // row groups that share a column quad
-  const bool gadd = a.gadd_a != nullptr;
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // VEC4 epilogue: thread = (column quad q4, row lr0 + NG*i of the pass), GRP row quads per step
   constexpr int GRP = NC4 > 4 ? 4 : NC4;
@@ -424,7 +476,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   const float* xb = nullptr;
   const float* yb = nullptr;
   int xk = 0, yk = 0;  // row of the operand: 0 the output row itself, 1 idx_a[row], 2 idx_b[row]
-  if (VEC4 && NL > 0) {
+  if (NL > 0) {
     const size_t own = r * a.out_rep_stride + (size_t)row0 * a.OUT;  // operands with the layout of `out`: the tile's first row
     switch (a.epi) {
       case EPI_GADD: xb = a.gadd_a + r * a.gadd_rep_stride; yb = a.gadd_b + r * a.gadd_rep_stride; xk = 1; yk = 2; break;
@@ -434,16 +486,22 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       default: xb = a.gmul + own; yb = a.add1 + own; break;  // EPI_GMUL_ADD
     }
   }
+  // one output quad's worth of an operand row: a 16-B load, or (rows that are not quads) four element loads of clamped columns
+  auto ldq = [&](const float* ub, unsigned rowoff) -> float4 {
+    if (VEC4) return ld4(ub, rowoff + (unsigned)(col_ok ? ncol : 0));
+    const int last = a.OUT - 1;
+    return make_float4(ld1(ub, rowoff + (unsigned)min(ncol, last)), ld1(ub, rowoff + (unsigned)min(ncol + 1, last)),
+                       ld1(ub, rowoff + (unsigned)min(ncol + 2, last)), ld1(ub, rowoff + (unsigned)min(ncol + 3, last)));
+  };
   auto issue_operands = [&](int pass, int g, int buf) {  // unconditional loads of clamped rows / columns: nothing to branch around
-    const int nc = col_ok ? ncol : 0;
 #pragma unroll
     for (int u = 0; u < GRP; ++u) {
       const int row = min(64 * pass + lr0 + NG * (g * GRP + u), rows - 1);
       const int ia = s_ia[row], ib = s_ib[row];  // (read unconditionally: a select, not a branch around an LDS read)
-      const float4 xv = ld4(xb, (unsigned)(xk == 0 ? row : ia) * (unsigned)a.OUT + (unsigned)nc);
+      const float4 xv = ldq(xb, (unsigned)(xk == 0 ? row : ia) * (unsigned)a.OUT);
       if (buf == 0) stg[u] = xv; else stg1[u] = xv;
       if (NL == 2) {
-        const float4 yv = ld4(yb, (unsigned)(yk == 0 ? row : ib) * (unsigned)a.OUT + (unsigned)nc);
+        const float4 yv = ldq(yb, (unsigned)(yk == 0 ? row : ib) * (unsigned)a.OUT);
         if (buf == 0) stg[GRP + u] = yv; else stg1[GRP + u] = yv;
       }
     }
@@ -479,7 +537,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   };
   while (si < a.nseg && a.seg[si].width == 0) ++si;
   if (si < a.nseg) load_chunk(si, kc);
-  else if (VEC4 && NL > 0) issue_operands(0, 0, 0);  // (no K at all: bias / operands only)
+  else if (NL > 0) issue_operands(0, 0, 0);  // (no K at all: bias / operands only)
   while (si < a.nseg) {
 #ifdef GNX_WIDE_STAMPS_BUILD
     const unsigned long long tA = clock64();
@@ -499,7 +557,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       while (si < a.nseg && a.seg[si].width == 0) ++si;
     }
     if (si < a.nseg) load_chunk(si, kc);
-    else if (VEC4 && NL > 0) issue_operands(0, 0, 0);  // last chunk: the staging registers are free — the epilogue's first operand group takes them
+    else if (NL > 0) issue_operands(0, 0, 0);  // last chunk: the staging registers are free — the epilogue's first operand group takes them
 #ifdef GNX_WIDE_STAMPS_BUILD
     t_issue += clock64() - tB;
 #endif
@@ -508,7 +566,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
     t_mfma += clock64() - tB;
 #endif
   }
-  if (VEC4 && NL > 0 && NTG > 1) issue_operands(NGRP > 1 ? 0 : 1, NGRP > 1 ? 1 : 0, 1);  // second group: buffer 1
+  if (NL > 0 && NTG > 1) issue_operands(NGRP > 1 ? 0 : 1, NGRP > 1 ? 1 : 0, 1);  // second group: buffer 1
 #ifdef GNX_WIDE_STAMPS_BUILD
   st[2] = clock64();
 #endif
@@ -544,7 +602,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       }
     }
     lds_barrier();
-    if constexpr (VEC4) {
+    {
 #pragma unroll
       for (int g = 0; g < NGRP; ++g) {
         const int tg = pass * NGRP + g, cur = tg & 1;
@@ -581,7 +639,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
           const int lr = lr0 + NG * (g * GRP + u);
           const bool ok = 64 * pass + lr < rows && col_ok;
           if (ok) { cs4.x += v[u].x; cs4.y += v[u].y; cs4.z += v[u].z; cs4.w += v[u].w; }  // column sums BEFORE the residual adds
-          if (a.agg_out) *reinterpret_cast<float4*>(sC + lr * LDC + 4 * q4) = v[u];       // the finished value, for the per-destination sums below
+          if (VEC4 && a.agg_out) *reinterpret_cast<float4*>(sC + lr * LDC + 4 * q4) = v[u];       // the finished value, for the per-destination sums below
         }
         if (NL > 0 && (a.epi == EPI_ADD1 || a.epi == EPI_ADD12)) {
 #pragma unroll
@@ -595,37 +653,19 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
 #pragma unroll
         for (int u = 0; u < GRP; ++u) {
           const int row = 64 * pass + lr0 + NG * (g * GRP + u);
-          if (row < rows && col_ok) st4(out_tile, (unsigned)row * (unsigned)a.OUT + (unsigned)ncol, v[u]);
-        }
-      }
-    } else {
-#pragma unroll
-    for (int i = 0; i < NC4; ++i) {
-      const int idx = tid + WT * i;
-      const int lr = idx / (BN / 4), c4 = idx % (BN / 4);
-      const int row = 64 * pass + lr, n = n0 + 4 * c4;
-      if (row < rows && n < a.OUT) {
-        float4 v = *reinterpret_cast<const float4*>(sC + lr * LDC + 4 * c4);
-        const float4 b = *reinterpret_cast<const float4*>(s_bias + 4 * c4);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-        const size_t o = (size_t)(row0 + row) * a.OUT + n;
-        float vv[4] = {v.x, v.y, v.z, v.w};
-        float* cc = reinterpret_cast<float*>(&cs4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (n + e < a.OUT) {
-            float y = vv[e];
-            if (gadd) y += a.gadd_a[r * a.gadd_rep_stride + (size_t)s_ia[row] * a.OUT + n + e] + a.gadd_b[r * a.gadd_rep_stride + (size_t)s_ib[row] * a.OUT + n + e];
-            y = act_apply(y, a.act);
-            if (a.gmul) y *= act_grad_from_out(a.gmul[r * a.out_rep_stride + o + e], a.gmul_act);
-            cc[e] += y;
-            if (a.add1) y += a.add1[r * a.out_rep_stride + o + e];
-            if (a.add2) y += a.add2[r * a.out_rep_stride + o + e];
-            out[o + e] = y;
+          if (row < rows && col_ok) {
+            const unsigned o = (unsigned)row * (unsigned)a.OUT + (unsigned)ncol;
+            if (VEC4) {
+              st4(out_tile, o, v[u]);
+            } else {  // rows that are not quads: element stores of the valid columns
+              out_tile[o] = v[u].x;
+              if (ncol + 1 < a.OUT) out_tile[o + 1] = v[u].y;
+              if (ncol + 2 < a.OUT) out_tile[o + 2] = v[u].z;
+              if (ncol + 3 < a.OUT) out_tile[o + 3] = v[u].w;
+            }
           }
         }
       }
-    }
     }
     if (VEC4 && a.agg_out) {
       // ---- per-destination sums of this 64-row pass (rows are dst-sorted: a destination is a contiguous run) ----
@@ -875,26 +915,62 @@ size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int6
   return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + align_up(xg, 256) + align_up(agg, 256) + 512;
 }
 
+static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// W, the output and the epilogue operands can be accessed as 16-B quads
+static bool out_vec(const WideArgs& w) {
+  return w.OUT % 4 == 0 && (w.ldw == 0 || w.ldw % 4 == 0) && al16(w.W) && al16(w.out) && w.out_rep_stride % 4 == 0 && al16(w.gadd_a) && al16(w.gadd_b) &&
+         w.gadd_rep_stride % 4 == 0 && al16(w.add1) && al16(w.add2) && al16(w.gmul);
+}
+
 template <int BN>
-static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64_t R, hipStream_t s, const char* name) {
+static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipStream_t s, const char* name) {
   if (n_tiles == 0 || w.OUT == 0) return GNX_OK;
   // host-side operand check before any launch: a kernel fault can take the whole node down
   if (!w.tiles || !w.W || !w.out) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: tiles / W / out is NULL");
+  const bool vec4 = out_vec(w);
+  WideArgs wa = w;
+  int ld = 0;  // loader class (template parameter LD)
   for (int i = 0; i < w.nseg; ++i) {
-    const WSeg& g = w.seg[i];
+    WSeg& g = wa.seg[i];
     if (g.width > 0 && !g.base) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: segment base is NULL");
     if ((g.mode == 1 && !w.idx_a) || (g.mode == 2 && !w.idx_b) || (g.mode == 3 && !w.cp) || (w.gadd_a && (!w.gadd_b || !w.idx_a || !w.idx_b)) ||
-        (g.mode == 4 && (!w.node_agg_row || !w.node_agg_parts || !w.node_agg_chunk || !w.chunk_row0 || !vec4)) || (w.agg_out && (!w.idx_b || !w.chunk_row0)))
+        (g.mode == 4 && (!w.node_agg_row || !w.node_agg_parts || !w.node_agg_chunk || !w.chunk_row0)) || (w.agg_out && (!w.idx_b || !w.chunk_row0)))
       return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: index array required by a segment mode is NULL");
+    if (g.mode < 0 || g.mode > 4) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: segment mode");
+    g.vec = g.width % 4 == 0 && al16(g.base) && g.rep_stride % 4 == 0;
+    if (g.mode == 4 && !g.vec) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: the partial-sum table must be readable as quads");
+    if (g.width > 0) ld = std::max(ld, !g.vec ? 2 : (g.mode >= 3 ? 1 : 0));
+  }
+  if (w.agg_out && (!vec4 || !al16(w.agg_out) || w.agg_rep_stride % 4 != 0)) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: fused aggregation needs quad outputs");
+  // narrow segments (modes 0-2, consecutive rows of W) that need fewer K chunks side by side than one after the other
+  // (the encoder's [ef(10) | nf_src(5) | nf_dst(5)]: one chunk of 32 instead of three): packed into ONE range, element loads
+  wa.npk = 0;
+  {
+    int live[3], nl_ = 0, ktot = 0, chunks = 0;
+    bool can = true;
+    for (int i = 0; i < w.nseg; ++i) {
+      if (w.seg[i].width == 0) continue;
+      can &= w.seg[i].mode <= 2 && (nl_ == 0 || w.seg[i].w_row0 == w.seg[live[nl_ - 1]].w_row0 + w.seg[live[nl_ - 1]].width);
+      live[nl_++] = i;
+      ktot += w.seg[i].width;
+      chunks += (w.seg[i].width + 31) / 32;
+    }
+    if (can && nl_ >= 2 && (ktot + 31) / 32 < chunks) {
+      for (int i = 0; i < nl_; ++i) wa.pk[i] = wa.seg[live[i]];
+      wa.npk = nl_;
+      wa.seg[0] = WSeg{wa.pk[0].base, 0, ktot, 5, wa.pk[0].w_row0, 0};
+      wa.nseg = 1;
+      ld = 2;
+    }
   }
   ProfScope ps(name, s);
-  WideArgs wa = w;
   wa.n_rtiles = (int)n_tiles;
   wa.n_ctiles = (w.OUT + BN - 1) / BN;
   const unsigned gx = wa.n_ctiles > 1 ? (n_tiles + 7) / 8 * 8 * (unsigned)wa.n_ctiles : n_tiles;
   const dim3 grid(gx, 1, (unsigned)R);
   // K chunk 32: measured against 64 (fewer barriers but 2 instead of 3 waves/SIMD): 466 vs 616 us on the edge GEMM
-#ifdef GNX_WIDE_STAMPS_BUILD  // diagnostic build (GNX_CXXFLAGS=-DGNX_WIDE_STAMPS_BUILD) + GNX_WIDE_STAMPS=1: per-phase shader clocks of every launch
+#ifdef GNX_WIDE_STAMPS_BUILD  // diagnostic build (tools/build_stamps.sh) + GNX_WIDE_STAMPS=1: per-phase shader clocks of every launch
   static unsigned long long* d_stamps = nullptr;
   static size_t stamps_cap = 0;
   static const bool want_stamps = getenv("GNX_WIDE_STAMPS") != nullptr;
@@ -915,25 +991,25 @@ static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64
   static const int stagger_env = getenv("GNX_GEMM_STAGGER") ? atoi(getenv("GNX_GEMM_STAGGER")) : 0;
   wa.stagger = (n_tiles >= 2048 && wa.n_ctiles == 1) ? stagger_env : 0;
   const bool trans = w.act > 1;
-  bool segsum = false;
-  for (int i = 0; i < w.nseg; ++i) segsum |= w.seg[i].mode >= 3;
-#define GNX_GEMM_LAUNCH(V, N, T, S) hipLaunchKernelGGL((k_rows_gemm<BN, V, 32, N, T, S>), grid, dim3(WT), 0, s, wa)
-#define GNX_GEMM_LAUNCH_T(V, N, S) do { if (trans) GNX_GEMM_LAUNCH(V, N, true, S); else GNX_GEMM_LAUNCH(V, N, false, S); } while (0)
-  if (!vec4) GNX_GEMM_LAUNCH(false, 0, true, true);
-  else if (segsum) {  // node update: never with epilogue operands
-    if (nl != 0) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: a segment-sum launch takes no epilogue operands");
-    GNX_GEMM_LAUNCH_T(true, 0, true);
-  } else if (nl == 0) GNX_GEMM_LAUNCH_T(true, 0, false);
-  else if (nl == 1) GNX_GEMM_LAUNCH_T(true, 1, false);
-  else GNX_GEMM_LAUNCH_T(true, 2, false);
-#undef GNX_GEMM_LAUNCH_T
+  // instantiations: quad outputs with the lean loader (every NL), quad outputs with the full loader and no operands (node update,
+  // encoder), element outputs with the full loader (every NL; also takes the rare quad-output + full-loader + operands launches)
+#define GNX_GEMM_LAUNCH(V, N, T, F) hipLaunchKernelGGL((k_rows_gemm<BN, V, 32, N, T, F>), grid, dim3(WT), 0, s, wa)
+#define GNX_GEMM_LAUNCH_N(V, T, F) do { if (nl == 0) GNX_GEMM_LAUNCH(V, 0, T, F); else if (nl == 1) GNX_GEMM_LAUNCH(V, 1, T, F); else GNX_GEMM_LAUNCH(V, 2, T, F); } while (0)
+  if (vec4 && ld == 0) { if (trans) GNX_GEMM_LAUNCH_N(true, true, 0); else GNX_GEMM_LAUNCH_N(true, false, 0); }
+  else if (vec4 && nl == 0 && ld == 1) { if (trans) GNX_GEMM_LAUNCH(true, 0, true, 1); else GNX_GEMM_LAUNCH(true, 0, false, 1); }
+  else if (vec4 && nl == 0) { if (trans) GNX_GEMM_LAUNCH(true, 0, true, 2); else GNX_GEMM_LAUNCH(true, 0, false, 2); }
+  else {
+    if (w.agg_out) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: fused aggregation with epilogue operands needs the lean loader");
+    if (trans) GNX_GEMM_LAUNCH_N(false, true, 2); else GNX_GEMM_LAUNCH_N(false, false, 2);
+  }
+#undef GNX_GEMM_LAUNCH_N
 #undef GNX_GEMM_LAUNCH
 #ifdef GNX_WIDE_STAMPS_BUILD
   if (want_stamps) {
     (void)hipStreamSynchronize(s);
     std::vector<unsigned long long> hs((size_t)n_tiles * 8);
     (void)hipMemcpy(hs.data(), d_stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-    if (const char* dump = getenv("GNX_WIDE_STAMPS_DUMP")) {  // raw [tile][8] table of the largest launch, for offline timelines
+    if (const char* dump = getenv("GNX_WIDE_STAMPS_DUMP")) {  // raw [tile][8] table, for offline timelines
       char path[512];
       snprintf(path, sizeof path, "%s_%s.bin", dump, name);  // (the last launch of each name wins)
       if (FILE* f = fopen(path, "wb")) { fwrite(hs.data(), 8, hs.size(), f); fclose(f); }
@@ -948,15 +1024,15 @@ static int32_t launch_gemm(const WideArgs& w, bool vec4, unsigned n_tiles, int64
   return GNX_OK;
 }
 
-static int32_t launch_gemm_any(const WideArgs& w, bool vec4, unsigned n_tiles, int64_t R, hipStream_t s, const char* name) {
+static int32_t launch_gemm_any(const WideArgs& w, unsigned n_tiles, int64_t R, hipStream_t s, const char* name) {
   int bn = w.OUT > 64 ? 128 : (w.OUT > 32 ? 64 : 32);  // 128-wide tiles beat 64-wide ones for OUT = 128 on a full GPU
   // A launch that cannot fill the 256 CUs (small batches: the reference's sort example has 4 graphs) is pure latency: every
   // workgroup walks its K chunks alone, paying a 128-wide tile's MFMA time per chunk for a handful of rows.  Narrower column
   // tiles give more workgroups and 2-4x less matrix-core time per chunk.
   while (bn > 32 && (size_t)n_tiles * ((w.OUT + bn - 1) / bn) * (size_t)R < 256) bn >>= 1;
-  if (bn == 128) return launch_gemm<128>(w, vec4, n_tiles, R, s, name);
-  if (bn == 64) return launch_gemm<64>(w, vec4, n_tiles, R, s, name);
-  return launch_gemm<32>(w, vec4, n_tiles, R, s, name);
+  if (bn == 128) return launch_gemm<128>(w, n_tiles, R, s, name);
+  if (bn == 64) return launch_gemm<64>(w, n_tiles, R, s, name);
+  return launch_gemm<32>(w, n_tiles, R, s, name);
 }
 
 // y[rows, OUT] = act(A[rows, K] * W + b) (+ add1 + add2) over ALL rows of one entity type (0 edges, 1 nodes, 2 graphs):
@@ -976,8 +1052,7 @@ int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K
   w.colsum = nullptr;
   w.add1 = add1; w.add2 = add2;
   const unsigned n_tiles = (unsigned)(entity == 0 ? h->h_etiles.size() : (entity == 1 ? h->h_ntiles.size() : h->h_gtiles.size()));
-  const bool al16 = ((uintptr_t)A | (uintptr_t)d.weight | (uintptr_t)out) % 16 == 0;
-  return launch_gemm_any(w, al16 && K % 4 == 0 && OUT % 4 == 0, n_tiles, R, s, name);
+  return launch_gemm_any(w, n_tiles, R, s, name);
 }
 
 // out[rows, OUT] = A[rows, K] * B over all rows of one entity type, B = [K][OUT] block of a matrix with row distance ldw
@@ -1001,8 +1076,7 @@ int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int 
   w.add1 = add1;  // optional residual with the layout of out (may alias it)
   w.colsum = tile_colsum; w.colsum_rep_stride = (size_t)n_tiles * OUT;
   if (n_tiles_out) *n_tiles_out = (int)n_tiles;
-  const bool al16 = ((uintptr_t)A | (uintptr_t)B | (uintptr_t)out | (uintptr_t)gmul | (uintptr_t)add1) % 16 == 0;
-  return launch_gemm_any(w, al16 && K % 4 == 0 && OUT % 4 == 0 && ldw % 4 == 0, n_tiles, R, s, name);
+  return launch_gemm_any(w, n_tiles, R, s, name);
 }
 
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
@@ -1012,7 +1086,8 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   // the matrix-core path pays when the update is a real GEMM; tiny widths stay on the other paths
   if (std::max(std::max(ke, a.oe), std::max(kn, a.on)) < 32) return 1;
   if (a.E == 0 && a.oe > 0) return 1;
-  const bool al16 = ((uintptr_t)a.ef | (uintptr_t)a.nf | (uintptr_t)a.We | (uintptr_t)a.Wn | (uintptr_t)a.ef_out) % 16 == 0;
+  // gathered tables (node features, node projections, partial sums) are addressed with 32-bit element offsets
+  if ((size_t)h->N * (size_t)std::max(std::max(a.oe, a.dn), 1) * sizeof(float) >= (1ull << 32)) return 1;
   const size_t n_et = h->h_etiles.size(), n_nt = h->h_ntiles.size();
   // workspace layout inside a.partials (sized by gnx_block_workspace_bytes >= wide_workspace_bytes)
   float* pe = a.partials;
@@ -1030,8 +1105,16 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
                                             align_up(sizeof(float) * (size_t)R * h->G * (size_t)(a.oe + a.on + a.dg), 256));
   // edge -> node sums inside the edge GEMM's epilogue (the node GEMM then reads ~N rows instead of all E rows of ef')
   static const bool no_agg_fuse = getenv("GNX_NO_AGG_FUSE") != nullptr;
-  const bool agg_fuse = !no_agg_fuse && (phase & 1) && a.oe > 0 && a.on > 0 && a.oe % 4 == 0 && al16 && a.de % 4 == 0 && a.dn % 4 == 0 && a.on % 4 == 0 &&
-                        ((uintptr_t)a.nf_out % 16 == 0) && h->n_agg_rows > 0;
+  // Node-projection form (edgefninput.jl:2-7 regrouped): W*[ef; nf_s; nf_d; gf] = We_e*ef + (We_s*nf)[src] + (We_d*nf + b')[dst].
+  // The 2*dn columns of nf are multiplied once per NODE (two small GEMMs) instead of once per EDGE; the edge GEMM keeps
+  // K = de and gathers two projected rows in its epilogue.  Same mathematics, different (still fixed) summation order.
+  static const bool no_project = getenv("GNX_NO_PROJECT") != nullptr;
+  const bool project = !no_project && a.oe > 0 && a.dn >= 16 && a.E >= 2 * (int64_t)a.N;
+  // (needs quad outputs, and — with the projections' epilogue operands — an ef whose rows are quads: see launch_gemm's instantiations)
+  const bool edge_out_vec = a.oe % 4 == 0 && al16(a.We) && al16(a.ef_out) && ((size_t)a.E * a.oe) % 4 == 0 && ((size_t)a.N * a.oe) % 4 == 0;
+  const bool ef_vec = a.de % 4 == 0 && al16(a.ef) && ((size_t)a.E * a.de) % 4 == 0;
+  const bool agg_fuse = !no_agg_fuse && (phase & 1) && a.oe > 0 && a.on > 0 && edge_out_vec && (!project || ef_vec) && h->n_agg_rows > 0 &&
+                        (size_t)h->n_agg_rows * a.oe * sizeof(float) < (1ull << 32);
   int32_t rc = GNX_OK;
   if ((phase & 1) && a.dg > 0) {  // fold gf into per-graph biases (one tiny launch per update function)
     ProfScope ps("k_fold_bias", s);
@@ -1044,11 +1127,6 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     }
     GNX_HIP(hipGetLastError());
   }
-  // Node-projection form (edgefninput.jl:2-7 regrouped): W*[ef; nf_s; nf_d; gf] = We_e*ef + (We_s*nf)[src] + (We_d*nf + b')[dst].
-  // The 2*dn columns of nf are multiplied once per NODE (two small GEMMs) instead of once per EDGE; the edge GEMM keeps
-  // K = de and gathers two projected rows in its epilogue.  Same mathematics, different (still fixed) summation order.
-  static const bool no_project = getenv("GNX_NO_PROJECT") != nullptr;
-  const bool project = !no_project && a.oe > 0 && a.dn >= 16 && a.E >= 2 * (int64_t)a.N;
   if ((phase & 1) && project) {
     for (int which = 0; which < 2; ++which) {
       WideArgs w{};
@@ -1060,8 +1138,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
       w.bias_g = (which == 1 && a.dg > 0) ? bias_e : nullptr; w.n_graphs = a.G;
       w.OUT = a.oe; w.act = GNX_ACT_IDENTITY;
       w.out = which == 0 ? proj_s : proj_d; w.out_rep_stride = (size_t)a.N * a.oe;
-      const bool v4 = al16 && a.dn % 4 == 0 && a.oe % 4 == 0;
-      if ((rc = launch_gemm_any(w, v4, (unsigned)n_nt, R, s, "k_rows_gemm_proj"))) return rc;
+      if ((rc = launch_gemm_any(w, (unsigned)n_nt, R, s, "k_rows_gemm_proj"))) return rc;
     }
   }
   if ((phase & 1) && a.oe > 0) {
@@ -1081,8 +1158,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     w.out = a.ef_out; w.out_rep_stride = (size_t)a.E * a.oe;
     w.colsum = a.og > 0 ? pe : nullptr; w.colsum_rep_stride = n_et * (size_t)a.oe;
     if (agg_fuse) { w.agg_out = agg_tab; w.agg_rep_stride = (size_t)h->n_agg_rows * a.oe; w.chunk_row0 = h->d_chunk_row0; }
-    const bool vec4 = al16 && a.de % 4 == 0 && a.dn % 4 == 0 && a.oe % 4 == 0;
-    if ((rc = launch_gemm_any(w, vec4, (unsigned)n_et, R, s, "k_rows_gemm_edge"))) return rc;
+    if ((rc = launch_gemm_any(w, (unsigned)n_et, R, s, "k_rows_gemm_edge"))) return rc;
   }
   if ((phase & 1) && a.on > 0) {
     WideArgs w{};
@@ -1101,9 +1177,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     w.bias_g = a.dg > 0 ? bias_n : nullptr; w.n_graphs = a.G;
     w.out = a.nf_out; w.out_rep_stride = (size_t)a.N * a.on;
     w.colsum = a.og > 0 ? pn : nullptr; w.colsum_rep_stride = n_nt * (size_t)a.on;
-    const bool al = al16 && ((uintptr_t)a.nf_out % 16 == 0);
-    const bool vec4 = al && a.oe % 4 == 0 && a.dn % 4 == 0 && a.on % 4 == 0;
-    if ((rc = launch_gemm_any(w, vec4, (unsigned)n_nt, R, s, "k_rows_gemm_node"))) return rc;
+    if ((rc = launch_gemm_any(w, (unsigned)n_nt, R, s, "k_rows_gemm_node"))) return rc;
   }
   if ((phase & 2) && a.og > 0) {
     ProfScope ps("k_graph_wide", s);
