@@ -46,6 +46,9 @@ struct BlockArgs {
   const float* ln_b[3];
   float ln_eps;
   int ln_mode;
+  // matrix-core path: row statistics [R][rows][2] (mean, inv) of ef / nf when THEY are to be normalised on load (then ln_g / ln_b
+  // hold gamma / beta; gf arrives normalised); nullptr <=> the input is used as it is
+  const float* ln_stats[3];
 };
 
 // activation codes = GNX_ACT_* of include/gnx.h (static_assert'ed in gnx_forward.hip)

@@ -51,6 +51,11 @@ struct FfnArgs {
   float* out;              // [R][rows][D]
   size_t rep_stride;       // rows_total * D
   int act1;
+  // z = gn2(x) computed on load: z points at x, ln_stats at [R][rows_total][2] (mean, inv) from k_ln_stats_v4, ln_g / ln_b at gamma /
+  // beta of gn2 — (x - mean) * inv, then fma(gamma, ., beta), the arithmetic of k_layernorm2_v4 (nullptr: z is used as it is)
+  const float* ln_stats;
+  const float* ln_g;
+  const float* ln_b;
 };
 
 template <int D>
@@ -72,6 +77,8 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   float* sH = s_pool + POOLF;         // [128][65]   activated hidden slice
   float* sC = s_pool;                 // epilogue staging [64][D + 4]
   static_assert(64 * (D + 4) <= POOLF + FBM * LDH, "epilogue staging must fit");
+  __shared__ float2 s_ln[FBM];                                        // (mean, inv) of the tile's rows
+  __shared__ __attribute__((aligned(16))) f32x4 s_lng[D / 4], s_lnb[D / 4];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;  // wm 0..3: rows 32*wm.., wn: column half
   const int hi = lane >> 5, l31 = lane & 31;
@@ -80,6 +87,18 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   const int row0 = a.row_kind == 0 ? t.e0 : t.n0;
   const int rows = (a.row_kind == 0 ? t.e1 : t.n1) - row0;
   const float* __restrict__ zb = a.z + r * a.rep_stride + (size_t)row0 * D;
+
+  const bool ln = a.ln_stats != nullptr;
+  if (ln) {
+    if (tid < FBM) s_ln[tid] = reinterpret_cast<const float2*>(a.ln_stats + r * (a.rep_stride / D) * 2)[row0 + (tid < rows ? tid : rows - 1)];
+    if (tid >= FBM && tid < FBM + D / 4) { s_lng[tid - FBM] = reinterpret_cast<const f32x4*>(a.ln_g)[tid - FBM]; s_lnb[tid - FBM] = reinterpret_cast<const f32x4*>(a.ln_b)[tid - FBM]; }
+  }
+  float2 st_row[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};  // statistics of this thread's two z rows: the same in every step
+  if (ln) {
+    __syncthreads();
+    st_row[0] = s_ln[tid >> 3];
+    st_row[1] = s_ln[(tid >> 3) + 64];
+  }
 
   f32x16 accO[TNO];
 #pragma unroll
@@ -122,7 +141,14 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         float* d = sA + (a_r + 64 * i) * LDA + 4 * a_c4;
-        d[0] = ra[i].x; d[1] = ra[i].y; d[2] = ra[i].z; d[3] = ra[i].w;
+        f32x4 v = ra[i];
+        if (ln && a_r + 64 * i < rows) {  // (rows beyond the tile stay zero)
+          const float2 st2 = st_row[i];
+          const f32x4 g = s_lng[st * (FKC / 4) + a_c4], b = s_lnb[st * (FKC / 4) + a_c4];
+          v.x = fmaf(g.x, (v.x - st2.x) * st2.y, b.x); v.y = fmaf(g.y, (v.y - st2.x) * st2.y, b.y);
+          v.z = fmaf(g.z, (v.z - st2.x) * st2.y, b.z); v.w = fmaf(g.w, (v.w - st2.x) * st2.y, b.w);
+        }
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
       }
 #pragma unroll
       for (int i = 0; i < NB1; ++i) *reinterpret_cast<f32x4*>(sB1 + 4 * (tid + NT * i)) = rb1[i];  // [kk][64]
@@ -236,19 +262,27 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
 // waits at the barrier; the two independent 8-wave workgroups of this kernel fill each other's gaps.  Not kept.)
 
 // out = add1 + add2 + fc2(act1(fc1(z))) over all rows of one entity type.  1 = not applicable (the caller runs the two GEMMs).
-int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, float* out,
-                         int64_t R, hipStream_t s) {
+// does launch_ffn_fused take this FeedForward (else 1 = "not applicable")
+bool ffn_fused_applies(const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, const float* out) {
   static const bool off = getenv("GNX_NO_FFN_FUSED") != nullptr;
-  if (off || (d != 64 && d != 128) || ff.fc2.act != GNX_ACT_IDENTITY) return 1;
+  if (off || (d != 64 && d != 128) || ff.fc2.act != GNX_ACT_IDENTITY) return false;
+  const uintptr_t al = (uintptr_t)z | (uintptr_t)ff.fc1.weight | (uintptr_t)ff.fc2.weight | (uintptr_t)ff.fc2.bias | (uintptr_t)add1 | (uintptr_t)add2 | (uintptr_t)out;
+  return (al & 15) == 0;
+}
+
+int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, float* out,
+                         int64_t R, hipStream_t s, const float* ln_stats, const gnx_layernorm* ln) {
+  if (!ffn_fused_applies(z, d, ff, add1, add2, out)) return ln_stats ? fail(GNX_ERR_INVALID_ARG, "k_ffn_fused: LayerNorm on load asked for a FeedForward it does not take") : 1;
   const size_t nrows = entity == 0 ? (size_t)h->E : (entity == 1 ? (size_t)h->N : (size_t)h->G);
   if (nrows == 0) return GNX_OK;
-  const uintptr_t al = (uintptr_t)z | (uintptr_t)ff.fc1.weight | (uintptr_t)ff.fc2.weight | (uintptr_t)ff.fc2.bias | (uintptr_t)add1 | (uintptr_t)add2 | (uintptr_t)out;
-  if (al & 15) return 1;
+  if (ln_stats && (!ln || !ln->gamma || !ln->beta || ((uintptr_t)ln->gamma & 15) || ((uintptr_t)ln->beta & 15) || ((uintptr_t)ln_stats & 7)))
+    return fail(GNX_ERR_INVALID_ARG, "k_ffn_fused: LayerNorm parameters missing or misaligned");
   FfnArgs a{};
   a.tiles = entity == 0 ? h->d_etiles : (entity == 1 ? h->d_ntiles : h->d_gtiles);
   a.row_kind = entity == 0 ? 0 : 1;
   a.z = z; a.W1 = ff.fc1.weight; a.b1 = ff.fc1.bias; a.W2 = ff.fc2.weight; a.b2 = ff.fc2.bias;
   a.add1 = add1; a.add2 = add2; a.out = out; a.rep_stride = nrows * (size_t)d; a.act1 = ff.fc1.act;
+  if (ln_stats) { a.ln_stats = ln_stats; a.ln_g = ln->gamma; a.ln_b = ln->beta; }
   const unsigned n_tiles = (unsigned)(entity == 0 ? h->h_etiles.size() : (entity == 1 ? h->h_ntiles.size() : h->h_gtiles.size()));
   if (!a.tiles || !z || !ff.fc1.weight || !ff.fc2.weight || !out) return fail(GNX_ERR_INVALID_ARG, "k_ffn_fused: NULL operand");
   ProfScope ps("k_ffn_fused", s);

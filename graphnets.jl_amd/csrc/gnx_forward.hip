@@ -35,7 +35,11 @@ size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int6
 bool core_narrow_width(int d);
 int32_t launch_ln1_rows(const float* x, size_t rows, int d, const gnx_layernorm& l1, float eps, int eps_mode, float* y, hipStream_t s);
 int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, float* out,
-                         int64_t R, hipStream_t s);
+                         int64_t R, hipStream_t s, const float* ln_stats = nullptr, const gnx_layernorm* ln = nullptr);
+bool ffn_fused_applies(const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, const float* out);
+bool block_wide_ln_applies(const gnx_graphs* h, const BlockArgs& a);
+bool ln_stats_applies(const float* x, int d);
+int32_t launch_ln_stats(const float* x, size_t rows, int d, float eps, int eps_mode, float* stats, hipStream_t s);
 int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm& l2, const gnx_ffn& ff, float eps, int eps_mode,
                          float* out, hipStream_t s);
 int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K, const gnx_dense& d, int OUT, const float* add1,
@@ -85,7 +89,7 @@ static BlockWs block_ws(const gnx_graphs* h, const gnx_block_params* p, int64_t 
 static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf,
                                   const float* gf, int64_t R, float* ef_out, float* nf_out, float* gf_out, void* ws,
                                   size_t ws_bytes, uint32_t flags, hipStream_t s, int phase = 3, const gnx_layernorm* ln1 = nullptr,
-                                  float ln_eps = 0.f, int ln_mode = 0, bool* fused_ln = nullptr) {
+                                  float ln_eps = 0.f, int ln_mode = 0, bool* fused_ln = nullptr, const float* const* wide_ln_stats = nullptr) {
   int32_t rc = check_block(h, p, R);
   if (rc) return rc;
   if (phase & 1) {
@@ -117,6 +121,15 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   a.wtile_off = h->d_wtile_off; a.wtiles = h->d_wtiles; a.n_wtiles = (int)h->n_wtiles();
   a.N = (int)h->N; a.E = (int)h->E; a.G = (int)h->G; a.n_tiles = (int)h->n_tiles();
 
+  if (ln1 && wide_ln_stats) {
+    // matrix-core path with ef / nf normalised on load from their row statistics (gf arrives normalised).  wide_ln_stats[0] == nullptr:
+    // only ASK whether this block takes that form (nothing is launched)
+    for (int t = 0; t < 2; ++t) { a.ln_g[t] = ln1[t].gamma; a.ln_b[t] = ln1[t].beta; }
+    *fused_ln = !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA)) && block_wide_ln_applies(h, a);
+    if (!*fused_ln || !wide_ln_stats[0]) return GNX_OK;
+    a.ln_stats[0] = wide_ln_stats[0]; a.ln_stats[1] = wide_ln_stats[1];
+    return launch_block_wide(h, a, R, s, phase);
+  }
   if (ln1) {
     *fused_ln = false;
     if (flags & GNX_FLAG_FORCE_GENERIC) return GNX_OK;
@@ -238,7 +251,32 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     rc = block_forward_impl(h, &b, ef, nf, gf, R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, 3, p->ln1, p->eps, p->eps_mode, &fused_ln);
     if (rc) return rc;
   }
-  if (!fused_ln) {
+  // Wide edges and nodes: the matrix-core kernels normalise x as they load it (block: gn1, fused FeedForward: gn2) from one pass of
+  // row statistics — neither LayerNorm output of ef / nf exists in HBM.  Taken when the block runs in the projected quad-row form
+  // and both FeedForwards are the fused kernel's; gf (G rows) is normalised by the ordinary kernel.
+  const bool no_ln_fuse = getenv("GNX_NO_LN_FUSE") != nullptr;  // (read per call: tests compare the two forms in one process)
+  bool wide_ln = false;
+  if (!fused_ln && !all_narrow && !no_ln_fuse && !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA)) && h->E > 0) {
+    const float* ask[2] = {nullptr, nullptr};
+    bool ok = true;
+    for (int t = 0; t < 2; ++t)
+      ok = ok && ln_stats_applies(x[t], d[t]) && ffn_fused_applies(x[t], d[t], p->ff[t], out[t], x[t], out[t]) &&
+           (((uintptr_t)p->ln2[t].gamma | (uintptr_t)p->ln2[t].beta) & 15) == 0;
+    if (ok) {
+      rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, 3, p->ln1, p->eps, p->eps_mode, &wide_ln, ask);
+      if (rc) return rc;
+    }
+  }
+  if (wide_ln) {
+    const float* stats[2] = {l1[0], l1[1]};  // the (unused) gn1 buffers hold the statistics: 2 floats per row
+    for (int t = 0; t < 2; ++t)
+      if ((rc = launch_ln_stats(x[t], rows[t], d[t], p->eps, p->eps_mode, l1[t], s))) return rc;
+    if ((rc = launch_layernorm2(x[2], rows[2], d[2], p->ln1[2], p->ln2[2], p->eps, p->eps_mode, l1[2], l2[2], s))) return rc;
+    bool took = false;
+    rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, 3, p->ln1, p->eps, p->eps_mode, &took, stats);
+    if (rc) return rc;
+    if (!took) return fail(GNX_ERR_INVALID_ARG, "gnx_core_forward: the block declined the form it had accepted");
+  } else if (!fused_ln) {
     for (int t = 0; t < 3; ++t) {
       // narrow widths: only gn1(x) is materialised (the block needs it); gn2 is recomputed inside k_core_post
       const bool narrow = core_narrow_width(d[t]) && !(flags & GNX_FLAG_FORCE_GENERIC);
@@ -253,6 +291,10 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   for (int t = 0; t < 3; ++t) {
     if (ffn_on_mfma(d[t]) && !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA))) {
       // out = block(LN1 x) + x + fc2(relu(fc1(LN2 x)))      (gncore.jl:56-68, gnfeedforward.jl:27-31)
+      if (wide_ln && t < 2) {
+        if ((rc = launch_ffn_fused(h, t, x[t], d[t], p->ff[t], out[t], x[t], out[t], R, s, l1[t], &p->ln2[t]))) return rc;
+        continue;
+      }
       rc = launch_ffn_fused(h, t, l2[t], d[t], p->ff[t], out[t], x[t], out[t], R, s);  // hidden layer never leaves the chip (d = 64, 128)
       if (rc == GNX_OK) continue;
       if (rc != 1) return rc;

@@ -264,6 +264,52 @@ __global__ __launch_bounds__(256) void k_layernorm2_v4(const float* __restrict__
   }
 }
 
+// Row statistics only — stats[row] = (mean, 1/(sigma + eps) or 1/sqrt(var + eps)) with exactly the arithmetic of k_layernorm2_v4: the
+// matrix-core kernels of a wide GNCore normalise x as they LOAD it ((x - mean) * inv, then fma(gamma, ., beta): bit-identical to the
+// materialised gn1(x) / gn2(x)), so neither LayerNorm output is written to or read back from HBM (gncore.jl:56-59).
+template <int Q>
+__global__ __launch_bounds__(256) void k_ln_stats_v4(const float* __restrict__ x, size_t rows, float eps, int eps_mode, float2* __restrict__ stats) {
+  constexpr int D = 64 * Q;
+  const int sub = threadIdx.x & 15;
+  size_t row = (size_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = row < rows;
+  row = live ? row : rows - 1;  // clamped: every lane takes part in the DPP reductions
+  const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+  float4 v[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) v[q] = xr[sub + 16 * q];
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+  const float mu = row16_sum_g(s) * (1.f / (float)D);
+  float var = 0.f;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    v[q].x -= mu; v[q].y -= mu; v[q].z -= mu; v[q].w -= mu;
+    var = fmaf(v[q].x, v[q].x, var); var = fmaf(v[q].y, v[q].y, var); var = fmaf(v[q].z, v[q].z, var); var = fmaf(v[q].w, v[q].w, var);
+  }
+  var = row16_sum_g(var) * (1.f / (float)D);
+  const float inv = eps_mode == 0 ? 1.f / (sqrtf(var) + eps) : 1.f / sqrtf(var + eps);
+  if (live && sub == 0) stats[row] = make_float2(mu, inv);
+}
+
+// 1: this width / alignment is not covered (the caller materialises the LayerNorm outputs instead)
+bool ln_stats_applies(const float* x, int d) { return ((uintptr_t)x & 15) == 0 && d % 64 == 0 && d <= 512; }
+
+int32_t launch_ln_stats(const float* x, size_t rows, int d, float eps, int eps_mode, float* stats, hipStream_t s) {
+  if (rows == 0) return GNX_OK;
+  if (!ln_stats_applies(x, d) || ((uintptr_t)stats & 7)) return fail(GNX_ERR_INVALID_ARG, "launch_ln_stats: width / alignment not covered");
+  ProfScope ps("k_ln_stats", s);
+  const dim3 grid((unsigned)((rows + 15) / 16));
+  switch (d / 64) {
+#define GNX_LN_CASE(Q) case Q: hipLaunchKernelGGL((k_ln_stats_v4<Q>), grid, dim3(256), 0, s, x, rows, eps, eps_mode, reinterpret_cast<float2*>(stats)); break;
+    GNX_LN_CASE(1) GNX_LN_CASE(2) GNX_LN_CASE(3) GNX_LN_CASE(4) GNX_LN_CASE(5) GNX_LN_CASE(6) GNX_LN_CASE(7) GNX_LN_CASE(8)
+#undef GNX_LN_CASE
+  }
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
 // One wave per row: out[row] += x[row] + W2*relu(W1*z[row]+b1)+b2  (z = LN2(x); out already holds block(LN1 x)).
 __global__ __launch_bounds__(256) void k_ffn_residual(const float* __restrict__ z, const float* __restrict__ x,
                                                       size_t rows, int d, gnx_dense fc1, gnx_dense fc2,

@@ -42,6 +42,7 @@ struct WSeg {
                       // 5: the narrow segments WideArgs::pk side by side in ONE K range (set by launch_gemm)
   int w_row0;         // first row of W (= first input feature index) of this segment
   int vec;            // rows can be read as 16-B quads (width % 4 == 0, 16-B aligned base): set by launch_gemm
+  int ln;             // LayerNorm on load (WideArgs::ln_*): mode 0, quad rows, width <= 256
 };
 
 struct WideArgs {
@@ -82,6 +83,13 @@ struct WideArgs {
   const int* node_agg_chunk;   //         [N]
   int n_rtiles, n_ctiles;      // row tiles / column tiles of this launch (set by launch_gemm)
   int epi;                     // EPI_* (set by launch_gemm)
+  // LayerNorm applied to the rows of ONE mode-0 segment as they are loaded (GNCore's gn1 / gn2 never materialised, gncore.jl:56-59):
+  // (x - mean) * inv, then fma(gamma, ., beta) — the arithmetic of k_layernorm2_v4, statistics from k_ln_stats_v4
+  const float* ln_stats;       // [R][rows of the entity][2] (mean, inv), or nullptr
+  size_t ln_rep_stride;        // floats between replicas of ln_stats
+  const float* ln_g;           // [width of the segment]
+  const float* ln_b;
+  int ln_width;                // (set by launch_gemm)
   WSeg pk[3];                  // mode 5: the packed segments (modes 0-2), their W rows consecutive from seg[0].w_row0
   int npk;
   int stagger;                 // start delay per residency slot (units of 64*127 clocks), 0 = none (set by launch_gemm)
@@ -173,6 +181,10 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   __shared__ int s_ia[BM], s_ib[BM];  // gather indices, or colptr range for the segment-sum mode
   __shared__ int s_ic[FULL ? BM : 1];  // mode 4: row of the node's SECOND partial sum (-1: none)
   __shared__ __attribute__((aligned(16))) float s_bias[BN];
+  constexpr bool LNOK = VEC4 && LD <= 1;  // LayerNorm on load: the quad loaders only
+  __shared__ float2 s_ln[LNOK ? BM : 1];                               // (mean, inv) of the tile's rows
+  __shared__ __attribute__((aligned(16))) float4 s_lng[LNOK ? 64 : 1];  // gamma, beta of the normalised segment (width <= 256)
+  __shared__ __attribute__((aligned(16))) float4 s_lnb[LNOK ? 64 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / L::WN, wn = wv % L::WN;
@@ -232,6 +244,15 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       s_ib[tid] = a.idx_b[row0 + m];
     }
   }
+  if (LNOK && a.ln_stats) {
+    if (tid < BM) s_ln[tid] = reinterpret_cast<const float2*>(a.ln_stats + r * a.ln_rep_stride)[row0 + (tid < rows ? tid : rows - 1)];
+    if (tid >= BM && tid < BM + 64) {
+      const int q = tid - BM;
+      const bool in = 4 * q < a.ln_width;
+      s_lng[q] = in ? reinterpret_cast<const float4*>(a.ln_g)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s_lnb[q] = in ? reinterpret_cast<const float4*>(a.ln_b)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   // tile bias: b + W[gf rows]^T gf[g], folded once per graph by k_fold_bias (a per-tile fold is a runtime-length chain
   // of dependent global loads: 32 round trips, more than the tile's whole MFMA time)
   if (tid < BN) {
@@ -267,11 +288,13 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   // them (four serial memory round trips per chunk — by the stamp build 34 of the K loop's 57 k clocks on the 1M-edge edge GEMM
   // went into issuing loads); a select on the loaded value at this point waits for the load just the same.
   unsigned okmask = 0;  // quads: bit i: ra(i) holds data (else zero), bit NA4 + i: rb(i), bit NA4 + NB4 + i: rs[i]
+  int pend_ln = -1;     // the chunk in the staging registers is columns [pend_ln, pend_ln + KC) of the normalised segment (-1: plain)
   unsigned emask = 0;   // elements of element-wise loaded quads (FULL / !VEC4): bit 4 i + e: ra(i)[e], bit 16 + 4 i + e: rb(i)[e]
   auto load_chunk = [&](int si, int kc) {
     okmask = 0;
     emask = 0;
     const WSeg sg = a.seg[si];
+    pend_ln = (LNOK && sg.ln) ? kc : -1;
     const float* base = sg.base + r * sg.rep_stride;
     const int k = kc + 4 * a_c4;
     if (!FULL || (sg.mode <= 2 && (!ELEM || sg.vec))) {
@@ -432,6 +455,12 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
     for (int i = 0; i < NA4; ++i) {
       float* d = sA + (a_r + RPP * i) * LDA + 4 * a_c4;
       float4 v = ra(i);
+      if (LNOK && pend_ln >= 0) {  // (columns beyond the segment read gamma / beta of valid LDS slots and are zeroed by the masks below)
+        const float2 st = s_ln[a_r + RPP * i];
+        const float4 g = s_lng[((pend_ln >> 2) + a_c4) & 63], b = s_lnb[((pend_ln >> 2) + a_c4) & 63];
+        v.x = fmaf(g.x, (v.x - st.x) * st.y, b.x); v.y = fmaf(g.y, (v.y - st.x) * st.y, b.y);
+        v.z = fmaf(g.z, (v.z - st.x) * st.y, b.z); v.w = fmaf(g.w, (v.w - st.x) * st.y, b.w);
+      }
       if (FULL) {
         const unsigned m = emask >> (4 * i);
         v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
@@ -931,6 +960,7 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
   const bool vec4 = out_vec(w);
   WideArgs wa = w;
   int ld = 0;  // loader class (template parameter LD)
+  bool has_ln = false;
   for (int i = 0; i < w.nseg; ++i) {
     WSeg& g = wa.seg[i];
     if (g.width > 0 && !g.base) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: segment base is NULL");
@@ -940,6 +970,9 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
     if (g.mode < 0 || g.mode > 4) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: segment mode");
     g.vec = g.width % 4 == 0 && al16(g.base) && g.rep_stride % 4 == 0;
     if (g.mode == 4 && !g.vec) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: the partial-sum table must be readable as quads");
+    if (g.ln && (!w.ln_stats || !w.ln_g || !w.ln_b || g.mode != 0 || !g.vec || g.width > 256 || !al16(w.ln_g) || !al16(w.ln_b) || ((uintptr_t)w.ln_stats & 7)))
+      return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: LayerNorm on load needs a quad-row mode-0 segment of width <= 256");
+    if (g.ln) { has_ln = true; wa.ln_width = g.width; }
     if (g.width > 0) ld = std::max(ld, !g.vec ? 2 : (g.mode >= 3 ? 1 : 0));
   }
   if (w.agg_out && (!vec4 || !al16(w.agg_out) || w.agg_rep_stride % 4 != 0)) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: fused aggregation needs quad outputs");
@@ -956,7 +989,7 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
       ktot += w.seg[i].width;
       chunks += (w.seg[i].width + 31) / 32;
     }
-    if (can && nl_ >= 2 && (ktot + 31) / 32 < chunks) {
+    if (!has_ln && can && nl_ >= 2 && (ktot + 31) / 32 < chunks) {
       for (int i = 0; i < nl_; ++i) wa.pk[i] = wa.seg[live[i]];
       wa.npk = nl_;
       wa.seg[0] = WSeg{wa.pk[0].base, 0, ktot, 5, wa.pk[0].w_row0, 0};
@@ -964,6 +997,8 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
       ld = 2;
     }
   }
+  if (has_ln && (!vec4 || ld > 1 || wa.npk)) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: LayerNorm on load needs quad outputs and quad-row segments");
+  if (!has_ln) wa.ln_stats = nullptr;
   ProfScope ps(name, s);
   wa.n_rtiles = (int)n_tiles;
   wa.n_ctiles = (w.OUT + BN - 1) / BN;
@@ -1079,15 +1114,37 @@ int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int 
   return launch_gemm_any(w, n_tiles, R, s, name);
 }
 
-int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
+// does launch_block_wide take this block (else 1 = "not applicable": the caller's next path), and in which form
+static bool wide_applies(const gnx_graphs* h, const BlockArgs& a, bool* project_out) {
   static const bool off = getenv("GNX_NO_WIDE") != nullptr;
-  if (off) return 1;
+  if (off) return false;
   const int ke = a.de + 2 * a.dn + a.dg, kn = a.oe + a.dn + a.dg;
   // the matrix-core path pays when the update is a real GEMM; tiny widths stay on the other paths
-  if (std::max(std::max(ke, a.oe), std::max(kn, a.on)) < 32) return 1;
-  if (a.E == 0 && a.oe > 0) return 1;
+  if (std::max(std::max(ke, a.oe), std::max(kn, a.on)) < 32) return false;
+  if (a.E == 0 && a.oe > 0) return false;
   // gathered tables (node features, node projections, partial sums) are addressed with 32-bit element offsets
-  if ((size_t)h->N * (size_t)std::max(std::max(a.oe, a.dn), 1) * sizeof(float) >= (1ull << 32)) return 1;
+  if ((size_t)h->N * (size_t)std::max(std::max(a.oe, a.dn), 1) * sizeof(float) >= (1ull << 32)) return false;
+  // Node-projection form (edgefninput.jl:2-7 regrouped): W*[ef; nf_s; nf_d; gf] = We_e*ef + (We_s*nf)[src] + (We_d*nf + b')[dst].
+  // The 2*dn columns of nf are multiplied once per NODE (two small GEMMs) instead of once per EDGE; the edge GEMM keeps
+  // K = de and gathers two projected rows in its epilogue.  Same mathematics, different (still fixed) summation order.
+  static const bool no_project = getenv("GNX_NO_PROJECT") != nullptr;
+  *project_out = !no_project && a.oe > 0 && a.dn >= 16 && a.E >= 2 * (int64_t)a.N;
+  return true;
+}
+
+// The wide path can normalise ef and nf as it loads them (BlockArgs::ln_stats): every launch that reads them is then a quad-row,
+// quad-output GEMM with the features as mode-0 segments — the projected form with widths that are multiples of 4.
+bool block_wide_ln_applies(const gnx_graphs* h, const BlockArgs& a) {
+  bool project = false;
+  if (!wide_applies(h, a, &project) || !project) return false;
+  return a.de % 4 == 0 && a.dn % 4 == 0 && a.oe % 4 == 0 && a.on % 4 == 0 && a.de <= 256 && a.dn <= 256 && a.on > 0 && al16(a.ef) && al16(a.nf) &&
+         al16(a.We) && al16(a.Wn) && al16(a.ef_out) && al16(a.nf_out) && al16(a.ln_g[0]) && al16(a.ln_b[0]) && al16(a.ln_g[1]) && al16(a.ln_b[1]);
+}
+
+int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
+  bool project = false;
+  if (!wide_applies(h, a, &project)) return 1;
+  if ((a.ln_stats[0] || a.ln_stats[1]) && !block_wide_ln_applies(h, a)) return fail(GNX_ERR_INVALID_ARG, "launch_block_wide: LayerNorm on load is not applicable to this block");
   const size_t n_et = h->h_etiles.size(), n_nt = h->h_ntiles.size();
   // workspace layout inside a.partials (sized by gnx_block_workspace_bytes >= wide_workspace_bytes)
   float* pe = a.partials;
@@ -1105,11 +1162,6 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
                                             align_up(sizeof(float) * (size_t)R * h->G * (size_t)(a.oe + a.on + a.dg), 256));
   // edge -> node sums inside the edge GEMM's epilogue (the node GEMM then reads ~N rows instead of all E rows of ef')
   static const bool no_agg_fuse = getenv("GNX_NO_AGG_FUSE") != nullptr;
-  // Node-projection form (edgefninput.jl:2-7 regrouped): W*[ef; nf_s; nf_d; gf] = We_e*ef + (We_s*nf)[src] + (We_d*nf + b')[dst].
-  // The 2*dn columns of nf are multiplied once per NODE (two small GEMMs) instead of once per EDGE; the edge GEMM keeps
-  // K = de and gathers two projected rows in its epilogue.  Same mathematics, different (still fixed) summation order.
-  static const bool no_project = getenv("GNX_NO_PROJECT") != nullptr;
-  const bool project = !no_project && a.oe > 0 && a.dn >= 16 && a.E >= 2 * (int64_t)a.N;
   // (needs quad outputs, and — with the projections' epilogue operands — an ef whose rows are quads: see launch_gemm's instantiations)
   const bool edge_out_vec = a.oe % 4 == 0 && al16(a.We) && al16(a.ef_out) && ((size_t)a.E * a.oe) % 4 == 0 && ((size_t)a.N * a.oe) % 4 == 0;
   const bool ef_vec = a.de % 4 == 0 && al16(a.ef) && ((size_t)a.E * a.de) % 4 == 0;
@@ -1133,6 +1185,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
       w.tiles = h->d_ntiles; w.row_kind = 1;
       w.seg[0] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 0, 0};
       w.nseg = 1;
+      if (a.ln_stats[1]) { w.seg[0].ln = 1; w.ln_stats = a.ln_stats[1]; w.ln_rep_stride = 2 * (size_t)a.N; w.ln_g = a.ln_g[1]; w.ln_b = a.ln_b[1]; }
       w.W = a.We + (size_t)(a.de + which * a.dn) * a.oe;  // rows of the src / dst segment
       w.bias = which == 1 ? a.be : nullptr;               // bias (+ gf fold) rides on the dst projection
       w.bias_g = (which == 1 && a.dg > 0) ? bias_e : nullptr; w.n_graphs = a.G;
@@ -1145,7 +1198,10 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     WideArgs w{};
     w.tiles = h->d_etiles; w.row_kind = 0;
     int ns = 0;
-    if (a.de) w.seg[ns++] = WSeg{a.ef, (size_t)a.E * a.de, a.de, 0, 0};
+    if (a.de) {
+      w.seg[ns++] = WSeg{a.ef, (size_t)a.E * a.de, a.de, 0, 0};
+      if (a.ln_stats[0]) { w.seg[ns - 1].ln = 1; w.ln_stats = a.ln_stats[0]; w.ln_rep_stride = 2 * (size_t)a.E; w.ln_g = a.ln_g[0]; w.ln_b = a.ln_b[0]; }
+    }
     if (a.dn && !project) {
       w.seg[ns++] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 1, a.de};
       w.seg[ns++] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 2, a.de + a.dn};
@@ -1170,7 +1226,10 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     } else if (a.oe) {
       w.seg[ns++] = WSeg{a.ef_out, (size_t)a.E * a.oe, a.oe, 3, 0};
     }
-    if (a.dn) w.seg[ns++] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 0, a.oe};
+    if (a.dn) {
+      w.seg[ns++] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 0, a.oe};
+      if (a.ln_stats[1]) { w.seg[ns - 1].ln = 1; w.ln_stats = a.ln_stats[1]; w.ln_rep_stride = 2 * (size_t)a.N; w.ln_g = a.ln_g[1]; w.ln_b = a.ln_b[1]; }
+    }
     w.nseg = ns;
     w.idx_a = nullptr; w.idx_b = nullptr; w.cp = a.colptr;
     w.W = a.Wn; w.bias = a.bn; w.OUT = a.on; w.act = a.act_n;

@@ -109,6 +109,41 @@ def test_core_wide_dims(gn, flags):
         U.assert_close(U.from_jl(got), r, s, name)
 
 
+@pytest.mark.parametrize("R,eps_mode", [(1, 0), (2, 1)])
+def test_core_wide_layernorm_on_load_equals_materialised(gn, R, eps_mode):
+    """GNCore(128,64,32): the matrix-core kernels normalise ef / nf as they load them (row statistics from k_ln_stats; gn1 / gn2
+    never written) — bit-identical to the materialised LayerNorm form (GNX_NO_LN_FUSE=1), and within the bound of the oracle."""
+    import os
+    rng = np.random.default_rng(4700 + R)
+    dims = (128, 64, 32)
+    colptr, rowval = U.er_csc(rng, 700, 9000)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [700])
+    p = O.make_core_params(rng, dims, eps_mode=eps_mode)
+    ef, nf, gf = U.packed_inputs(rng, R, 9000, 700, 1, dims)
+    ef = ef + 3.0  # a mean far from zero: the statistics matter
+    core = U.core_from_params(gn, p)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    gn.profile_reset(); gn.profile_enable(True)
+    y = core(x)
+    gn.profile_enable(False)
+    names = set(gn.profile_read()); gn.profile_reset()
+    assert "k_ln_stats" in names and "k_ffn_fused" in names, names
+    os.environ["GNX_NO_LN_FUSE"] = "1"
+    try:
+        gn.profile_enable(True)
+        y0 = core(x)
+        gn.profile_enable(False)
+        names0 = set(gn.profile_read()); gn.profile_reset()
+    finally:
+        del os.environ["GNX_NO_LN_FUSE"]
+    assert "k_ln_stats" not in names0 and "k_layernorm2" in names0, names0
+    for name, a, b in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), (y0.ef, y0.nf, y0.gf)):
+        assert np.array_equal(U.from_jl(a), U.from_jl(b)), f"{name}: LayerNorm on load differs from the materialised form"
+    ref, scale = O.core_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r, s, name)
+
+
 def test_config4_shape_encoder_2cores_decoder_wide(gn):
     """BASELINE config 4 at reduced size: enc (10,5,0)=>(128,64,32), 2 x GNCore(128,64,32), dec =>(3,4,5)."""
     rng = np.random.default_rng(46)
