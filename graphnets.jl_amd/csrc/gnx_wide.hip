@@ -81,7 +81,13 @@ struct WideArgs {
   const int* node_agg_row;     // mode 4: [N]
   const int* node_agg_parts;   //         [N]
   const int* node_agg_chunk;   //         [N]
-  int n_rtiles, n_ctiles;      // row tiles / column tiles of this launch (set by launch_gemm)
+  // a SECOND weight block / bias / output of the same shape over the same rows (the src and dst node projections): its column tiles
+  // run next to the first one's on the same XCD, the A tile is fetched once
+  const float* W2;
+  const float* bias2;
+  const float* bias_g2;
+  float* out2;
+  int n_rtiles, n_ctiles;      // row tiles / column tiles of this launch (set by launch_gemm; W2: both halves)
   int epi;                     // EPI_* (set by launch_gemm)
   // LayerNorm applied to the rows of ONE mode-0 segment as they are loaded (GNCore's gn1 / gn2 never materialised, gncore.jl:56-59):
   // (x - mean) * inv, then fma(gamma, ., beta) — the arithmetic of k_layernorm2_v4, statistics from k_ln_stats_v4
@@ -205,6 +211,14 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
     const int slot = blockIdx.x >> 8;
     for (int i = 0; i < slot * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
+  const float* Wsel = a.W;
+  const float* bias_sel = a.bias;
+  const float* bias_g_sel = a.bias_g;
+  float* out_sel = a.out;
+  if (a.W2) {
+    const int nct1 = a.n_ctiles >> 1;
+    if (ctile >= nct1) { ctile -= nct1; Wsel = a.W2; bias_sel = a.bias2; bias_g_sel = a.bias_g2; out_sel = a.out2; }
+  }
   tile_id = __builtin_amdgcn_readfirstlane(tile_id);  // wave-uniform by construction: lets the tile / chunk table reads be scalar loads
   const Tile t = a.tiles[tile_id];
   int agg_row0[2] = {0, 0};  // first partial-sum row of the tile's two 64-row passes (read here: in the epilogue the load would wait for every store in flight)
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   if (tid < BN) {
     const int n = n0 + tid;
     float b = 0.f;
-    if (n < a.OUT) b = a.bias_g ? a.bias_g[(r * a.n_graphs + t.g) * (size_t)a.OUT + n] : (a.bias ? a.bias[n] : 0.f);
+    if (n < a.OUT) b = bias_g_sel ? bias_g_sel[(r * a.n_graphs + t.g) * (size_t)a.OUT + n] : (bias_sel ? bias_sel[n] : 0.f);
     s_bias[tid] = b;
   }
   __syncthreads();
@@ -426,7 +440,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       }
     }
     const int ldw = a.ldw ? a.ldw : a.OUT;
-    const float* wb = a.W + (size_t)(sg.w_row0 + kc) * ldw + n0;  // uniform: first row of the chunk, first column of the tile
+    const float* wb = Wsel + (size_t)(sg.w_row0 + kc) * ldw + n0;  // uniform: first row of the chunk, first column of the tile
 #pragma unroll
     for (int i = 0; i < NB4; ++i) {
       const int q = tid + WT * i;
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
 
   const int hi = lane >> 5, l31 = lane & 31;
   // ---- epilogue operands (declared here: the first group is requested during the LAST chunk's matrix-core work) ----
-  float* out = a.out + r * a.out_rep_stride;
+  float* out = out_sel + r * a.out_rep_stride;
   constexpr int NC4 = (64 * BN / 4) / WT;  // float4 per thread and pass
   constexpr int NG = WT / (BN / 4);        // row groups that share a column quad
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -949,7 +963,7 @@ static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // W, the output and the epilogue operands can be accessed as 16-B quads
 static bool out_vec(const WideArgs& w) {
   return w.OUT % 4 == 0 && (w.ldw == 0 || w.ldw % 4 == 0) && al16(w.W) && al16(w.out) && w.out_rep_stride % 4 == 0 && al16(w.gadd_a) && al16(w.gadd_b) &&
-         w.gadd_rep_stride % 4 == 0 && al16(w.add1) && al16(w.add2) && al16(w.gmul);
+         w.gadd_rep_stride % 4 == 0 && al16(w.add1) && al16(w.add2) && al16(w.gmul) && al16(w.W2) && al16(w.out2);
 }
 
 template <int BN>
@@ -1001,7 +1015,8 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
   if (!has_ln) wa.ln_stats = nullptr;
   ProfScope ps(name, s);
   wa.n_rtiles = (int)n_tiles;
-  wa.n_ctiles = (w.OUT + BN - 1) / BN;
+  wa.n_ctiles = (w.OUT + BN - 1) / BN * (w.W2 ? 2 : 1);
+  if (w.W2 && (!w.out2 || w.colsum || w.agg_out)) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: second weight block needs its own output and no column sums");
   const unsigned gx = wa.n_ctiles > 1 ? (n_tiles + 7) / 8 * 8 * (unsigned)wa.n_ctiles : n_tiles;
   const dim3 grid(gx, 1, (unsigned)R);
   // K chunk 32: measured against 64 (fewer barriers but 2 instead of 3 waves/SIMD): 466 vs 616 us on the edge GEMM
@@ -1179,20 +1194,18 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     }
     GNX_HIP(hipGetLastError());
   }
-  if ((phase & 1) && project) {
-    for (int which = 0; which < 2; ++which) {
-      WideArgs w{};
-      w.tiles = h->d_ntiles; w.row_kind = 1;
-      w.seg[0] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 0, 0};
-      w.nseg = 1;
-      if (a.ln_stats[1]) { w.seg[0].ln = 1; w.ln_stats = a.ln_stats[1]; w.ln_rep_stride = 2 * (size_t)a.N; w.ln_g = a.ln_g[1]; w.ln_b = a.ln_b[1]; }
-      w.W = a.We + (size_t)(a.de + which * a.dn) * a.oe;  // rows of the src / dst segment
-      w.bias = which == 1 ? a.be : nullptr;               // bias (+ gf fold) rides on the dst projection
-      w.bias_g = (which == 1 && a.dg > 0) ? bias_e : nullptr; w.n_graphs = a.G;
-      w.OUT = a.oe; w.act = GNX_ACT_IDENTITY;
-      w.out = which == 0 ? proj_s : proj_d; w.out_rep_stride = (size_t)a.N * a.oe;
-      if ((rc = launch_gemm_any(w, (unsigned)n_nt, R, s, "k_rows_gemm_proj"))) return rc;
-    }
+  if ((phase & 1) && project) {  // both projections in ONE launch (the second weight block of k_rows_gemm): nf is read once
+    WideArgs w{};
+    w.tiles = h->d_ntiles; w.row_kind = 1;
+    w.seg[0] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 0, 0};
+    w.nseg = 1;
+    if (a.ln_stats[1]) { w.seg[0].ln = 1; w.ln_stats = a.ln_stats[1]; w.ln_rep_stride = 2 * (size_t)a.N; w.ln_g = a.ln_g[1]; w.ln_b = a.ln_b[1]; }
+    w.W = a.We + (size_t)a.de * a.oe;              // rows of the src segment
+    w.W2 = a.We + (size_t)(a.de + a.dn) * a.oe;    // rows of the dst segment: bias (+ gf fold) rides on the dst projection
+    w.bias2 = a.be; w.bias_g2 = a.dg > 0 ? bias_e : nullptr; w.n_graphs = a.G;
+    w.OUT = a.oe; w.act = GNX_ACT_IDENTITY;
+    w.out = proj_s; w.out2 = proj_d; w.out_rep_stride = (size_t)a.N * a.oe;
+    if ((rc = launch_gemm_any(w, (unsigned)n_nt, R, s, "k_rows_gemm_proj"))) return rc;
   }
   if ((phase & 1) && a.oe > 0) {
     WideArgs w{};
