@@ -58,8 +58,9 @@ struct FfnArgs {
   const float* ln_b;
 };
 
+// (4 waves per SIMD = two workgroups per CU: without the attribute the compiler takes 130+ registers and the second workgroup is gone)
 template <int D>
-__global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_ffn_fused(FfnArgs a) {
   constexpr int H = 4 * D;
   constexpr int LDA = FKC + 1;                 // z chunk row stride (odd: conflict-free A fragments)
   constexpr int LDH = FHS + 1;                 // hidden slice row stride
@@ -77,6 +78,9 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   float* sH = s_pool + POOLF;         // [128][65]   activated hidden slice
   float* sC = s_pool;                 // epilogue staging [64][D + 4]
   static_assert(64 * (D + 4) <= POOLF + FBM * LDH, "epilogue staging must fit");
+  __shared__ float s_b1[H];                                           // fc1 bias: read once per hidden slice — as a global load the
+                                                                      // read sits in front of its use and its wait (vmcnt is in order)
+                                                                      // also waits for the next step's prefetch
   __shared__ float2 s_ln[FBM];                                        // (mean, inv) of the tile's rows
   __shared__ __attribute__((aligned(16))) f32x4 s_lng[D / 4], s_lnb[D / 4];
 
@@ -88,17 +92,13 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
   const int rows = (a.row_kind == 0 ? t.e1 : t.n1) - row0;
   const float* __restrict__ zb = a.z + r * a.rep_stride + (size_t)row0 * D;
 
+  for (int i = tid; i < H; i += NT) s_b1[i] = a.b1 ? a.b1[i] : 0.f;  // (visible after the first barrier of the step loop)
   const bool ln = a.ln_stats != nullptr;
   if (ln) {
     if (tid < FBM) s_ln[tid] = reinterpret_cast<const float2*>(a.ln_stats + r * (a.rep_stride / D) * 2)[row0 + (tid < rows ? tid : rows - 1)];
     if (tid >= FBM && tid < FBM + D / 4) { s_lng[tid - FBM] = reinterpret_cast<const f32x4*>(a.ln_g)[tid - FBM]; s_lnb[tid - FBM] = reinterpret_cast<const f32x4*>(a.ln_b)[tid - FBM]; }
   }
-  float2 st_row[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};  // statistics of this thread's two z rows: the same in every step
-  if (ln) {
-    __syncthreads();
-    st_row[0] = s_ln[tid >> 3];
-    st_row[1] = s_ln[(tid >> 3) + 64];
-  }
+  // (s_ln / s_lng / s_lnb / s_b1 are visible after the first barrier of the step loop, which precedes the first store_step)
 
   f32x16 accO[TNO];
 #pragma unroll
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
         float* d = sA + (a_r + 64 * i) * LDA + 4 * a_c4;
         f32x4 v = ra[i];
         if (ln && a_r + 64 * i < rows) {  // (rows beyond the tile stay zero)
-          const float2 st2 = st_row[i];
+          const float2 st2 = s_ln[a_r + 64 * i];
           const f32x4 g = s_lng[st * (FKC / 4) + a_c4], b = s_lnb[st * (FKC / 4) + a_c4];
           v.x = fmaf(g.x, (v.x - st2.x) * st2.y, b.x); v.y = fmaf(g.y, (v.y - st2.x) * st2.y, b.y);
           v.z = fmaf(g.z, (v.z - st2.x) * st2.y, b.z); v.w = fmaf(g.w, (v.w - st2.x) * st2.y, b.w);
@@ -181,9 +181,23 @@ __global__ __launch_bounds__(512) void k_ffn_fused(FfnArgs a) {
         if (st == NC1 - 1) {
           // hidden slice: bias + activation, parked in LDS as the A operand of GEMM2 (C/D layout: row = (q&3)+8(q>>2)+4hi)
           const int hcol = wn * 32 + l31;
-          const float b = a.b1 ? a.b1[hs * FHS + hcol] : 0.f;
+          const float b = s_b1[hs * FHS + hcol];
+          float hv[16];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) sH[(wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi) * LDH + hcol] = act_apply(accH[q] + b, a.act1);
+          for (int q = 0; q < 16; ++q) hv[q] = accH[q] + b;
+          switch (a.act1) {  // ONE wave-uniform switch, the loop inside each case (a switch per element is 16 branch chains)
+            case 0: break;
+            case 1:
+#pragma unroll
+              for (int q = 0; q < 16; ++q) hv[q] = fmaxf(hv[q], 0.f);
+              break;
+            default:
+#pragma unroll
+              for (int q = 0; q < 16; ++q) hv[q] = act_apply(hv[q], a.act1);
+              break;
+          }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) sH[(wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi) * LDH + hcol] = hv[q];
         }
       } else {
         // GEMM2: accO[64 x D/2 per wave] += sH[:, 32-wide k range] * W2 chunk
