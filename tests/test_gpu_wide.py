@@ -45,6 +45,57 @@ def test_wide_er_graph(gn, dims):
     _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
 
 
+# One case per instantiation family of k_rows_gemm (gnx_wide.hip): loader class (quad rows / row sums / element + packed segments),
+# quad or element outputs, epilogue operands (projected form: two gathered addends), transcendental activations, replicas.
+VARIANTS = [
+    # (din, dout, acts, R, E)                                                       what it exercises
+    pytest.param((128, 64, 32), (128, 64, 32), (2, 3, 4), 1, 5000, id="lean-loader_tanh-sigmoid-gelu"),
+    pytest.param((64, 32, 8), (64, 32, 8), (1, 1, 1), 3, 5000, id="lean-loader_replicas"),
+    pytest.param((10, 5, 3), (128, 64, 32), (1, 2, 0), 2, 5000, id="packed-narrow-segments_quad-out_fused-agg"),
+    pytest.param((8, 4, 4), (64, 64, 4), (1, 1, 1), 1, 5000, id="packed-quad-segments"),
+    pytest.param((128, 64, 32), (10, 5, 3), (1, 1, 1), 1, 5000, id="projected_element-out_two-operands"),
+    pytest.param((126, 64, 32), (64, 32, 8), (2, 1, 0), 1, 5000, id="projected_element-ef_quad-out"),
+    pytest.param((64, 18, 6), (36, 34, 7), (1, 3, 1), 2, 5000, id="projected_element-nf_quad-edge-out_element-node-out"),
+    pytest.param((40, 12, 0), (48, 40, 0), (4, 1, 0), 1, 5000, id="direct-form_gathered-quad-segments"),
+    pytest.param((33, 15, 1), (35, 33, 2), (1, 1, 1), 1, 5000, id="direct-form_element-everything"),
+    pytest.param((64, 64, 16), (64, 64, 16), (1, 1, 1), 1, 900, id="sparse_E<2N_no-projection"),
+    pytest.param((0, 64, 8), (128, 0, 8), (1, 0, 2), 1, 5000, id="no-ef-in_no-nf-out"),
+    pytest.param((192, 64, 0), (128, 128, 0), (1, 1, 0), 1, 5000, id="K-192_node-out-128"),
+]
+
+
+@pytest.mark.parametrize("din,dout,acts,R,E", VARIANTS)
+def test_wide_gemm_variants(gn, din, dout, acts, R, E):
+    rng = np.random.default_rng(5200 + E + sum(din))
+    N = 700
+    colptr, rowval = U.er_csc(rng, N, E)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [N])
+    p = O.make_block_params(rng, din, dout, act=acts)
+    ef, nf, gf = U.packed_inputs(rng, R, E, N, 1, din)
+    gn.profile_reset(); gn.profile_enable(True)
+    _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
+    gn.profile_enable(False)
+    names = set(gn.profile_read()); gn.profile_reset()
+    assert any(n.startswith("k_rows_gemm") for n in names), names
+
+
+def test_wide_hub_node_many_partial_sums(gn):
+    """A destination whose in-edges span more than two 64-row chunks of the edge GEMM (in-degree 400): the node update reads its
+    sum as first partial + second partial + the rare further ones."""
+    rng = np.random.default_rng(53)
+    N = 600
+    src = np.concatenate([rng.integers(0, N, 3000), rng.integers(0, N, 400)])
+    dst = np.concatenate([rng.integers(0, N, 3000), np.full(400, 17)])
+    pairs = np.unique(np.stack([dst, src], 1), axis=0)  # sorted by (dst, src): CSC order, no duplicates
+    colptr = np.zeros(N + 1, np.int64); np.add.at(colptr, pairs[:, 0] + 1, 1); colptr = np.cumsum(colptr)
+    g = gn.GNGraphBatch.from_csc([colptr], [pairs[:, 1]], [N])
+    E = len(pairs)
+    dims = (64, 32, 8)
+    p = O.make_block_params(rng, dims, dims)
+    ef, nf, gf = U.packed_inputs(rng, 1, E, N, 1, dims)
+    _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
+
+
 def test_wide_uses_mfma_kernels(gn):
     rng = np.random.default_rng(51)
     colptr, rowval = U.er_csc(rng, 300, 2000)
