@@ -552,7 +552,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   int si = 0, kc = 0;
 #ifdef GNX_WIDE_STAMPS_BUILD
   st[1] = clock64();
-  unsigned long long t_sync = 0, t_mfma = 0, t_issue = 0;
+  unsigned long long t_sync = 0, t_mfma = 0, t_issue = 0, t_estage = 0, t_egroups = 0, t_eagg = 0;
 #endif
   // the matrix-core work of the chunk in LDS.  Fragments of k-step kk+1 are requested from LDS before the MFMAs of step kk are
   // issued (explicit two-deep register pipeline: left to itself the compiler places each ds_read right in front of its first use)
@@ -620,6 +620,9 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   __shared__ int s_seg[66];  // per-destination runs of a pass: s_seg[k] = first row of run k, s_seg[n_seg] = valid rows; s_seg[65] = n_seg
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
+#ifdef GNX_WIDE_STAMPS_BUILD
+    const unsigned long long te0 = clock64();
+#endif
     lds_barrier();  // K-loop readers (pass 0) / previous pass readers are done with the pool
     if (VEC4 && a.agg_out && wv == 0) {  // rows are dst-sorted: a destination is a contiguous run; found from the indices alone
       const int nvalid = min(max(rows - 64 * pass, 0), 64);
@@ -645,6 +648,10 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       }
     }
     lds_barrier();
+#ifdef GNX_WIDE_STAMPS_BUILD
+    const unsigned long long te1 = clock64();
+    t_estage += te1 - te0;
+#endif
     {
 #pragma unroll
       for (int g = 0; g < NGRP; ++g) {
@@ -710,6 +717,10 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
         }
       }
     }
+#ifdef GNX_WIDE_STAMPS_BUILD
+    const unsigned long long te2 = clock64();
+    t_egroups += te2 - te1;
+#endif
     if (VEC4 && a.agg_out) {
       // ---- per-destination sums of this 64-row pass (rows are dst-sorted: a destination is a contiguous run) ----
       lds_barrier();             // every finished value is back in sC (s_seg was filled before this pass's second barrier)
@@ -721,7 +732,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
         for (int sgm = grp; sgm < n_seg; sgm += NG) {
           const int r0 = s_seg[sgm], r1 = s_seg[sgm + 1];
           float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          for (int rr = r0; rr < r1; ++rr) {
+          for (int rr = r0; rr < r1; ++rr) {  // (four clamped rows per step, requested together: measured no faster)
             const float4 u = *reinterpret_cast<const float4*>(sC + rr * LDC + 4 * q4);
             t4.x += u.x; t4.y += u.y; t4.z += u.z; t4.w += u.w;
           }
@@ -730,6 +741,9 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       }
     }
   }
+#ifdef GNX_WIDE_STAMPS_BUILD
+  // (agg time = epilogue - stage - groups - colsum tail; reported as the remainder)
+#endif
   if (a.colsum) {  // fixed-order reduction over the NG row groups that share a column quad
     lds_barrier();
     float* s_cs = sC;  // [NG][BN]
@@ -749,7 +763,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   if (a.stamps && tid == 0 && ctile == 0 && blockIdx.z == 0) {
     unsigned long long* o = a.stamps + (size_t)tile_id * 8;
     o[0] = st[1] - st[0]; o[1] = t_sync; o[2] = t_mfma; o[3] = clock64() - st[2]; o[4] = clock64() - st[0];
-    o[5] = st[0]; o[6] = t_issue;  // absolute tile start; time to issue the next chunk's global loads (part of o[2])
+    o[5] = t_estage | (t_egroups << 32); o[6] = t_issue;  // epilogue: staging (barrier, acc -> LDS, barrier) | operand groups; loads issue time (part of o[2])
     o[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);  // XCC_ID, HW_ID
   }
 #endif
@@ -1064,10 +1078,13 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
       snprintf(path, sizeof path, "%s_%s.bin", dump, name);  // (the last launch of each name wins)
       if (FILE* f = fopen(path, "wb")) { fwrite(hs.data(), 8, hs.size(), f); fclose(f); }
     }
-    double m[7] = {0, 0, 0, 0, 0, 0, 0};
-    for (size_t i = 0; i < n_tiles; ++i) for (int j = 0; j < 7; ++j) m[j] += (double)hs[i * 8 + j];
-    fprintf(stderr, "[gnx stamps] %s BN=%d tiles=%u ctiles=%d: per tile (shader clocks, wave 0 of column tile 0): prologue %.0f  sync+store %.0f  mfma-loop %.0f (of which issuing the next chunk's loads %.0f)  epilogue %.0f  total %.0f\n",
-            name, BN, n_tiles, wa.n_ctiles, m[0] / n_tiles, m[1] / n_tiles, m[2] / n_tiles, m[6] / n_tiles, m[3] / n_tiles, m[4] / n_tiles);
+    double m[7] = {0, 0, 0, 0, 0, 0, 0}, e_stage = 0, e_groups = 0;
+    for (size_t i = 0; i < n_tiles; ++i) {
+      for (int j = 0; j < 7; ++j) m[j] += (double)hs[i * 8 + j];
+      e_stage += (double)(hs[i * 8 + 5] & 0xffffffffull); e_groups += (double)(hs[i * 8 + 5] >> 32);
+    }
+    fprintf(stderr, "[gnx stamps] %s BN=%d tiles=%u ctiles=%d: per tile (shader clocks, wave 0 of column tile 0): prologue %.0f  sync+store %.0f  mfma-loop %.0f (of which issuing the next chunk's loads %.0f)  epilogue %.0f (staging %.0f, operand groups + stores %.0f, rest: per-destination / column sums)  total %.0f\n",
+            name, BN, n_tiles, wa.n_ctiles, m[0] / n_tiles, m[1] / n_tiles, m[2] / n_tiles, m[6] / n_tiles, m[3] / n_tiles, e_stage / n_tiles, e_groups / n_tiles, m[4] / n_tiles);
   }
 #endif
   GNX_HIP(hipGetLastError());
