@@ -30,6 +30,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // in front of its first use also waits for every global load issued before it (edge GEMM 433 vs 462 us).
 #define GNX_GEMM_WAVES __attribute__((amdgpu_waves_per_eu(3)))
 #endif
+#ifndef GNX_GEMM_GRP  // row quads per epilogue operand group (two groups in flight)
+#define GNX_GEMM_GRP 2
+#endif
 constexpr int BM = 128;   // rows (edges or nodes) per workgroup tile
 constexpr int WT = 256;   // threads
 
@@ -287,10 +290,9 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
 
   // ONE register array serves the K loop's chunk staging (A quads, then B quads) and, from the last chunk on, the epilogue's
   // first operand group: declared separately, the compiler keeps both sets alive through the loop and spills
-  constexpr int NC4_ = (64 * BN / 4) / WT, GRP_ = NC4_ > 4 ? 4 : NC4_;
-  constexpr int NSTG = NA4 + NB4 > 2 * GRP_ ? NA4 + NB4 : 2 * GRP_;
-  float4 stg[NSTG];
-  float4 stg1[2 * GRP_];  // second operand buffer (epilogue only)
+  constexpr int NC4_ = (64 * BN / 4) / WT, GRP_ = NC4_ > GNX_GEMM_GRP ? GNX_GEMM_GRP : NC4_;
+  constexpr int NSTG = NA4 + NB4 > 4 * GRP_ ? NA4 + NB4 : 4 * GRP_;
+  float4 stg[NSTG];  // K loop: A quads, B quads; epilogue: two operand buffers of 2 GRP quads each
   float4 rs[FULL ? NA4 : 1];  // mode 4: second partial-sum rows of the chunk
 #define ra(i) stg[i]
 #define rb(i) stg[NA4 + (i)]
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   constexpr int NG = WT / (BN / 4);        // row groups that share a column quad
   float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // VEC4 epilogue: thread = (column quad q4, row lr0 + NG*i of the pass), GRP row quads per step
-  constexpr int GRP = NC4 > 4 ? 4 : NC4;
+  constexpr int GRP = NC4 > GNX_GEMM_GRP ? GNX_GEMM_GRP : NC4;
   constexpr int NGRP = NC4 / GRP;
   constexpr int NTG = 2 * NGRP;            // operand groups of the tile, in order (pass, group): group t lives in buffer t & 1
   const int q4 = tid % (BN / 4), lr0 = tid / (BN / 4);
@@ -513,9 +515,9 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   const bool col_ok = ncol < a.OUT;
   float* out_tile = out + (size_t)row0 * a.OUT;
   static_assert(GRP == GRP_, "operand group size");
-  // operand streams X / Y, double-buffered over the groups: buffer 0 = the chunk staging registers, buffer 1 = stg1
-#define ex(b, u) ((b) == 0 ? stg[u] : stg1[u])
-#define ey(b, u) ((b) == 0 ? stg[GRP + (u)] : stg1[GRP + (u)])
+  // operand streams X / Y, double-buffered over the groups, both buffers in the chunk staging registers
+#define ex(b, u) stg[(b) * 2 * GRP + (u)]
+#define ey(b, u) stg[(b) * 2 * GRP + GRP + (u)]
   const float* xb = nullptr;
   const float* yb = nullptr;
   int xk = 0, yk = 0;  // row of the operand: 0 the output row itself, 1 idx_a[row], 2 idx_b[row]
@@ -542,10 +544,10 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       const int row = min(64 * pass + lr0 + NG * (g * GRP + u), rows - 1);
       const int ia = s_ia[row], ib = s_ib[row];  // (read unconditionally: a select, not a branch around an LDS read)
       const float4 xv = ldq(xb, (unsigned)(xk == 0 ? row : ia) * (unsigned)a.OUT);
-      if (buf == 0) stg[u] = xv; else stg1[u] = xv;
+      ex(buf, u) = xv;
       if (NL == 2) {
         const float4 yv = ldq(yb, (unsigned)(yk == 0 ? row : ib) * (unsigned)a.OUT);
-        if (buf == 0) stg[GRP + u] = yv; else stg1[GRP + u] = yv;
+        ey(buf, u) = yv;
       }
     }
   };
@@ -580,7 +582,10 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   };
   while (si < a.nseg && a.seg[si].width == 0) ++si;
   if (si < a.nseg) load_chunk(si, kc);
-  else if (NL > 0) issue_operands(0, 0, 0);  // (no K at all: bias / operands only)
+  else if (NL > 0) {  // (no K at all: bias / operands only)
+    issue_operands(0, 0, 0);
+    if (NTG > 1) issue_operands(NGRP > 1 ? 0 : 1, NGRP > 1 ? 1 : 0, 1);
+  }
   while (si < a.nseg) {
 #ifdef GNX_WIDE_STAMPS_BUILD
     const unsigned long long tA = clock64();
@@ -600,7 +605,10 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       while (si < a.nseg && a.seg[si].width == 0) ++si;
     }
     if (si < a.nseg) load_chunk(si, kc);
-    else if (NL > 0) issue_operands(0, 0, 0);  // last chunk: the staging registers are free — the epilogue's first operand group takes them
+    else if (NL > 0) {  // last chunk: the staging registers are free — the epilogue's first two operand groups take them
+      issue_operands(0, 0, 0);
+      if (NTG > 1) issue_operands(NGRP > 1 ? 0 : 1, NGRP > 1 ? 1 : 0, 1);
+    }
 #ifdef GNX_WIDE_STAMPS_BUILD
     t_issue += clock64() - tB;
 #endif
@@ -609,7 +617,6 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
     t_mfma += clock64() - tB;
 #endif
   }
-  if (NL > 0 && NTG > 1) issue_operands(NGRP > 1 ? 0 : 1, NGRP > 1 ? 1 : 0, 1);  // second group: buffer 1
 #ifdef GNX_WIDE_STAMPS_BUILD
   st[2] = clock64();
 #endif
