@@ -195,8 +195,26 @@ static void core_ws(const gnx_graphs* h, const gnx_core_params* p, int64_t R, si
   *total = o + block_ws(h, &p->block, R).total;
 }
 
+// side stream + fork / join events of the handle (see gnx_internal.h); failure just leaves the core on one stream
+static void ensure_aux(const gnx_graphs* h) {
+  std::call_once(h->aux_once, [h]() {
+    hipStream_t st = nullptr;
+    hipEvent_t e1 = nullptr, e2 = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess) {
+      h->aux_stream = st; h->aux_fork = e1; h->aux_join = e2;
+    } else {
+      if (e1) (void)hipEventDestroy(e1);
+      if (e2) (void)hipEventDestroy(e2);
+      if (st) (void)hipStreamDestroy(st);
+      (void)hipGetLastError();
+    }
+  });
+}
+
 size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t R) {
   if (!h || !p || R <= 0) return 0;
+  ensure_aux(h);
   size_t off[8], total;
   core_ws(h, p, R, off, &total);
   return total;
@@ -272,10 +290,45 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     for (int t = 0; t < 2; ++t)
       if ((rc = launch_ln_stats(x[t], rows[t], d[t], p->eps, p->eps_mode, l1[t], s))) return rc;
     if ((rc = launch_layernorm2(x[2], rows[2], d[2], p->ln1[2], p->ln2[2], p->eps, p->eps_mode, l1[2], l2[2], s))) return rc;
+    // The graph level of the core — the block's graph update (four 5-us launches) and the G-row FeedForward — is independent of the edge /
+    // node FeedForwards that follow the block: it runs on the handle's side stream behind them (fork after the node update, join
+    // before returning; inside a capture the side stream joins the captured graph).  GNX_NO_FORK=1: everything on the caller's stream.
+    static const bool no_fork = getenv("GNX_NO_FORK") != nullptr;
+    const bool fork = !no_fork && h->aux_stream != nullptr && !profile_enabled();
     bool took = false;
-    rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, 3, p->ln1, p->eps, p->eps_mode, &took, stats);
+    rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, fork ? 1 : 3, p->ln1, p->eps, p->eps_mode, &took, stats);
     if (rc) return rc;
     if (!took) return fail(GNX_ERR_INVALID_ARG, "gnx_core_forward: the block declined the form it had accepted");
+    if (fork) {
+      hipStream_t ax = h->aux_stream;
+      GNX_HIP(hipEventRecord(h->aux_fork, s));
+      GNX_HIP(hipStreamWaitEvent(ax, h->aux_fork, 0));
+      rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, ax, 2, p->ln1, p->eps, p->eps_mode, &took, stats);
+      if (rc == GNX_OK) {  // the G-row FeedForward: out = gf' + gf + FF(gn2(gf)); the hidden buffer is its alone (the wide FeedForwards are the fused kernel)
+        float* hidden2 = reinterpret_cast<float*>(base + off[6]);
+        rc = launch_ffn_fused(h, 2, l2[2], d[2], p->ff[2], out[2], x[2], out[2], R, ax);
+        if (rc == 1) {
+          if (ffn_on_mfma(d[2])) {
+            rc = launch_dense_rows(h, 2, l2[2], d[2], p->ff[2].fc1, 4 * d[2], nullptr, nullptr, hidden2, R, ax, "k_rows_gemm_ff1");
+            if (rc == GNX_OK) rc = launch_dense_rows(h, 2, hidden2, 4 * d[2], p->ff[2].fc2, d[2], out[2], x[2], out[2], R, ax, "k_rows_gemm_ff2");
+          } else if (core_narrow_width(d[2])) {
+            rc = launch_core_post(x[2], rows[2], d[2], p->ln2[2], p->ff[2], p->eps, p->eps_mode, out[2], ax);
+          } else {
+            rc = launch_ffn_residual(l2[2], x[2], rows[2], d[2], p->ff[2], out[2], ax);
+          }
+        }
+      }
+      // the join is recorded even after a failure: a capture must not end with the side stream un-joined
+      const hipError_t e1 = hipEventRecord(h->aux_join, ax);
+      int32_t rc2 = GNX_OK;
+      for (int t = 0; t < 2 && rc2 == GNX_OK; ++t) rc2 = launch_ffn_fused(h, t, x[t], d[t], p->ff[t], out[t], x[t], out[t], R, s, l1[t], &p->ln2[t]);
+      const hipError_t e2 = hipStreamWaitEvent(s, h->aux_join, 0);
+      if (rc) return rc;
+      if (rc2) return rc2;
+      GNX_HIP(e1);
+      GNX_HIP(e2);
+      return GNX_OK;
+    }
   } else if (!fused_ln) {
     for (int t = 0; t < 3; ++t) {
       // narrow widths: only gn1(x) is materialised (the block needs it); gn2 is recomputed inside k_core_post

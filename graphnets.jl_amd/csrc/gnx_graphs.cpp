@@ -341,6 +341,9 @@ int32_t gnx_graphs_destroy(gnx_graphs* h) {
   (void)hipFree(h->d_collapse_rev);
   (void)hipFree(h->d_csr_ptr);
   (void)hipFree(h->d_csr_eid);
+  if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
+  if (h->aux_join) (void)hipEventDestroy(h->aux_join);
+  if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   delete h;
   return GNX_OK;
 }

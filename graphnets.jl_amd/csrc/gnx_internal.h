@@ -62,6 +62,11 @@ struct gnx_graphs {
   mutable int32_t* d_csr_ptr = nullptr;  // [N+1]
   mutable int32_t* d_csr_eid = nullptr;  // [E]
   mutable int32_t csr_rc = 0;
+  // side stream for the small graph-level launches of a wide GNCore (forked behind the edge / node FeedForward and joined before the
+  // core returns; created by gnx_core_workspace_bytes, i.e. outside any stream capture).  One forward at a time per handle.
+  mutable std::once_flag aux_once;
+  mutable hipStream_t aux_stream = nullptr;
+  mutable hipEvent_t aux_fork = nullptr, aux_join = nullptr;
   int64_t n_tiles() const { return (int64_t)h_tiles.size(); }
   int64_t n_wtiles() const { return (int64_t)h_wtiles.size(); }
 };
@@ -85,6 +90,8 @@ struct ProfScope {
   int slot;
   hipStream_t stream;
 };
+
+bool profile_enabled();  // per-kernel timing is on: callers keep everything on one stream (overlapped kernels would share their time)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

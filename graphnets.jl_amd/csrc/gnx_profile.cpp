@@ -38,6 +38,8 @@ ProfScope::ProfScope(const char* name, hipStream_t s) : slot(-1), stream(s) {
   g_records.push_back(r);
 }
 
+bool profile_enabled() { return g_enabled; }
+
 ProfScope::~ProfScope() {
   if (slot < 0) return;
   std::lock_guard<std::mutex> lk(g_mu);

@@ -235,59 +235,6 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
   unsigned long long st[6];
   st[0] = clock64();
 #endif
-  // per-row indices
-  bool need_cp = false, need_idx = false, need_agg = false;
-  for (int s = 0; s < a.nseg; ++s) {
-    need_cp |= a.seg[s].mode == 3;
-    need_idx |= a.seg[s].mode == 1 || a.seg[s].mode == 2;
-    need_agg |= a.seg[s].mode == 4;
-  }
-  for (int s = 0; s < a.npk; ++s) need_idx |= a.pk[s].mode != 0;
-  need_idx |= a.gadd_a != nullptr || a.agg_out != nullptr;
-  if (tid < BM) {
-    const int m = tid < rows ? tid : rows - 1;
-    if (need_cp) {
-      s_ia[tid] = a.cp[row0 + m];
-      s_ib[tid] = tid < rows ? a.cp[row0 + m + 1] : s_ia[tid];
-    } else if (need_agg) {  // (row of the first partial, number of further chunks << 24 | first chunk is resolved in the loader)
-      const int parts = tid < rows ? a.node_agg_parts[row0 + m] : 0;
-      s_ia[tid] = a.node_agg_row[row0 + m];
-      s_ib[tid] = parts;
-      // a node whose in-edges run into a second 64-row chunk (one in ~6 on the ER graph): resolve that row ONCE here — in the chunk
-      // loader the lookup is two dependent loads in front of the row load, per chunk
-      if (FULL) s_ic[tid] = parts > 1 ? a.chunk_row0[a.node_agg_chunk[row0 + m] + 1] : -1;
-    } else if (need_idx) {
-      s_ia[tid] = a.idx_a[row0 + m];
-      s_ib[tid] = a.idx_b[row0 + m];
-    }
-  }
-  if (LNOK && a.ln_stats) {
-    if (tid < BM) s_ln[tid] = reinterpret_cast<const float2*>(a.ln_stats + r * a.ln_rep_stride)[row0 + (tid < rows ? tid : rows - 1)];
-    if (tid >= BM && tid < BM + 64) {
-      const int q = tid - BM;
-      const bool in = 4 * q < a.ln_width;
-      s_lng[q] = in ? reinterpret_cast<const float4*>(a.ln_g)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-      s_lnb[q] = in ? reinterpret_cast<const float4*>(a.ln_b)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  // tile bias: b + W[gf rows]^T gf[g], folded once per graph by k_fold_bias (a per-tile fold is a runtime-length chain
-  // of dependent global loads: 32 round trips, more than the tile's whole MFMA time)
-  if (tid < BN) {
-    const int n = n0 + tid;
-    float b = 0.f;
-    if (n < a.OUT) b = bias_g_sel ? bias_g_sel[(r * a.n_graphs + t.g) * (size_t)a.OUT + n] : (bias_sel ? bias_sel[n] : 0.f);
-    s_bias[tid] = b;
-  }
-  __syncthreads();
-
-  f32x16 acc[L::TM][L::TN];
-#pragma unroll
-  for (int i = 0; i < L::TM; ++i)
-#pragma unroll
-    for (int j = 0; j < L::TN; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-
   // ONE register array serves the K loop's chunk staging (A quads, then B quads) and, from the last chunk on, the epilogue's
   // first operand group: declared separately, the compiler keeps both sets alive through the loop and spills
   constexpr int NC4_ = (64 * BN / 4) / WT, GRP_ = NC4_ > GNX_GEMM_GRP ? GNX_GEMM_GRP : NC4_;
@@ -466,6 +413,65 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       }
     }
   };
+  // The first chunk does not wait for the index arrays when its segment is the tile's own rows (mode 0: the loader's index reads are
+  // then unused): its loads go out here, one memory round trip ahead of the index loads' round trip instead of behind it.
+  int si = 0, kc = 0;
+  while (si < a.nseg && a.seg[si].width == 0) ++si;
+  const bool early_first = si < a.nseg && a.seg[si].mode == 0;
+  if (early_first) load_chunk(si, kc);
+  // per-row indices
+  bool need_cp = false, need_idx = false, need_agg = false;
+  for (int s = 0; s < a.nseg; ++s) {
+    need_cp |= a.seg[s].mode == 3;
+    need_idx |= a.seg[s].mode == 1 || a.seg[s].mode == 2;
+    need_agg |= a.seg[s].mode == 4;
+  }
+  for (int s = 0; s < a.npk; ++s) need_idx |= a.pk[s].mode != 0;
+  need_idx |= a.gadd_a != nullptr || a.agg_out != nullptr;
+  if (tid < BM) {
+    const int m = tid < rows ? tid : rows - 1;
+    if (need_cp) {
+      s_ia[tid] = a.cp[row0 + m];
+      s_ib[tid] = tid < rows ? a.cp[row0 + m + 1] : s_ia[tid];
+    } else if (need_agg) {  // (row of the first partial, number of further chunks << 24 | first chunk is resolved in the loader)
+      const int parts = tid < rows ? a.node_agg_parts[row0 + m] : 0;
+      s_ia[tid] = a.node_agg_row[row0 + m];
+      s_ib[tid] = parts;
+      // a node whose in-edges run into a second 64-row chunk (one in ~6 on the ER graph): resolve that row ONCE here — in the chunk
+      // loader the lookup is two dependent loads in front of the row load, per chunk
+      if (FULL) s_ic[tid] = parts > 1 ? a.chunk_row0[a.node_agg_chunk[row0 + m] + 1] : -1;
+    } else if (need_idx) {
+      s_ia[tid] = a.idx_a[row0 + m];
+      s_ib[tid] = a.idx_b[row0 + m];
+    }
+  }
+  if (LNOK && a.ln_stats) {
+    if (tid < BM) s_ln[tid] = reinterpret_cast<const float2*>(a.ln_stats + r * a.ln_rep_stride)[row0 + (tid < rows ? tid : rows - 1)];
+    if (tid >= BM && tid < BM + 64) {
+      const int q = tid - BM;
+      const bool in = 4 * q < a.ln_width;
+      s_lng[q] = in ? reinterpret_cast<const float4*>(a.ln_g)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      s_lnb[q] = in ? reinterpret_cast<const float4*>(a.ln_b)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // tile bias: b + W[gf rows]^T gf[g], folded once per graph by k_fold_bias (a per-tile fold is a runtime-length chain
+  // of dependent global loads: 32 round trips, more than the tile's whole MFMA time)
+  if (tid < BN) {
+    const int n = n0 + tid;
+    float b = 0.f;
+    if (n < a.OUT) b = bias_g_sel ? bias_g_sel[(r * a.n_graphs + t.g) * (size_t)a.OUT + n] : (bias_sel ? bias_sel[n] : 0.f);
+    s_bias[tid] = b;
+  }
+  __syncthreads();
+
+  f32x16 acc[L::TM][L::TN];
+#pragma unroll
+  for (int i = 0; i < L::TM; ++i)
+#pragma unroll
+    for (int j = 0; j < L::TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
   auto store_chunk = [&]() {
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
@@ -551,7 +557,6 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
       }
     }
   };
-  int si = 0, kc = 0;
 #ifdef GNX_WIDE_STAMPS_BUILD
   st[1] = clock64();
   unsigned long long t_sync = 0, t_mfma = 0, t_issue = 0, t_estage = 0, t_egroups = 0, t_eagg = 0;
@@ -580,8 +585,7 @@ __global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
         for (int j = 0; j < L::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
     }
   };
-  while (si < a.nseg && a.seg[si].width == 0) ++si;
-  if (si < a.nseg) load_chunk(si, kc);
+  if (si < a.nseg) { if (!early_first) load_chunk(si, kc); }
   else if (NL > 0) {  // (no K at all: bias / operands only)
     issue_operands(0, 0, 0);
     if (NTG > 1) issue_operands(NGRP > 1 ? 0 : 1, NGRP > 1 ? 1 : 0, 1);
