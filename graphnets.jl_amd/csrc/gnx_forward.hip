@@ -287,16 +287,35 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   }
   if (wide_ln) {
     const float* stats[2] = {l1[0], l1[1]};  // the (unused) gn1 buffers hold the statistics: 2 floats per row
-    for (int t = 0; t < 2; ++t)
-      if ((rc = launch_ln_stats(x[t], rows[t], d[t], p->eps, p->eps_mode, l1[t], s))) return rc;
+    static const bool no_fork0 = getenv("GNX_NO_FORK") != nullptr;
+    const bool fork0 = !no_fork0 && h->aux_stream != nullptr && !profile_enabled();
     if ((rc = launch_layernorm2(x[2], rows[2], d[2], p->ln1[2], p->ln2[2], p->eps, p->eps_mode, l1[2], l2[2], s))) return rc;
+    if (fork0) {
+      // side stream: node statistics, gf fold, node projections (latency / matrix-core work) beside the edge statistics pass (HBM-bound)
+      hipStream_t ax = h->aux_stream;
+      bool took0 = false;
+      GNX_HIP(hipEventRecord(h->aux_fork, s));
+      GNX_HIP(hipStreamWaitEvent(ax, h->aux_fork, 0));
+      rc = launch_ln_stats(x[1], rows[1], d[1], p->eps, p->eps_mode, l1[1], ax);
+      if (rc == GNX_OK) rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, ax, 4, p->ln1, p->eps, p->eps_mode, &took0, stats);
+      const hipError_t e1 = hipEventRecord(h->aux_join, ax);
+      const int32_t rc2 = launch_ln_stats(x[0], rows[0], d[0], p->eps, p->eps_mode, l1[0], s);
+      const hipError_t e2 = hipStreamWaitEvent(s, h->aux_join, 0);
+      if (rc) return rc;
+      if (rc2) return rc2;
+      GNX_HIP(e1);
+      GNX_HIP(e2);
+    } else {
+      for (int t = 0; t < 2; ++t)
+        if ((rc = launch_ln_stats(x[t], rows[t], d[t], p->eps, p->eps_mode, l1[t], s))) return rc;
+    }
     // The graph level of the core — the block's graph update (four 5-us launches) and the G-row FeedForward — is independent of the edge /
     // node FeedForwards that follow the block: it runs on the handle's side stream behind them (fork after the node update, join
     // before returning; inside a capture the side stream joins the captured graph).  GNX_NO_FORK=1: everything on the caller's stream.
     static const bool no_fork = getenv("GNX_NO_FORK") != nullptr;
     const bool fork = !no_fork && h->aux_stream != nullptr && !profile_enabled();
     bool took = false;
-    rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, fork ? 1 : 3, p->ln1, p->eps, p->eps_mode, &took, stats);
+    rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, (fork ? 1 : 3) | (fork0 ? 8 : 0), p->ln1, p->eps, p->eps_mode, &took, stats);
     if (rc) return rc;
     if (!took) return fail(GNX_ERR_INVALID_ARG, "gnx_core_forward: the block declined the form it had accepted");
     if (fork) {
@@ -318,10 +337,14 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
           }
         }
       }
+      // the node FeedForward rides on the side stream too: its workgroups fill the CUs that the edge FeedForward's last, partly
+      // filled round of tiles leaves idle (7813 tiles on 512 slots: 15.26 rounds)
+      static const bool node_ffn_main = getenv("GNX_NODE_FFN_MAIN") != nullptr;
+      if (rc == GNX_OK && !node_ffn_main) rc = launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, ax, l1[1], &p->ln2[1]);
       // the join is recorded even after a failure: a capture must not end with the side stream un-joined
       const hipError_t e1 = hipEventRecord(h->aux_join, ax);
-      int32_t rc2 = GNX_OK;
-      for (int t = 0; t < 2 && rc2 == GNX_OK; ++t) rc2 = launch_ffn_fused(h, t, x[t], d[t], p->ff[t], out[t], x[t], out[t], R, s, l1[t], &p->ln2[t]);
+      int32_t rc2 = launch_ffn_fused(h, 0, x[0], d[0], p->ff[0], out[0], x[0], out[0], R, s, l1[0], &p->ln2[0]);
+      if (rc2 == GNX_OK && node_ffn_main) rc2 = launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, s, l1[1], &p->ln2[1]);
       const hipError_t e2 = hipStreamWaitEvent(s, h->aux_join, 0);
       if (rc) return rc;
       if (rc2) return rc2;

@@ -1208,10 +1208,11 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   // (needs quad outputs, and — with the projections' epilogue operands — an ef whose rows are quads: see launch_gemm's instantiations)
   const bool edge_out_vec = a.oe % 4 == 0 && al16(a.We) && al16(a.ef_out) && ((size_t)a.E * a.oe) % 4 == 0 && ((size_t)a.N * a.oe) % 4 == 0;
   const bool ef_vec = a.de % 4 == 0 && al16(a.ef) && ((size_t)a.E * a.de) % 4 == 0;
-  const bool agg_fuse = !no_agg_fuse && (phase & 1) && a.oe > 0 && a.on > 0 && edge_out_vec && (!project || ef_vec) && h->n_agg_rows > 0 &&
+  const bool agg_fuse = !no_agg_fuse && (phase & 5) && a.oe > 0 && a.on > 0 && edge_out_vec && (!project || ef_vec) && h->n_agg_rows > 0 &&
                         (size_t)h->n_agg_rows * a.oe * sizeof(float) < (1ull << 32);
   int32_t rc = GNX_OK;
-  if ((phase & 1) && a.dg > 0) {  // fold gf into per-graph biases (one tiny launch per update function)
+  const bool prep = (phase & 4) || ((phase & 1) && !(phase & 8));  // gf fold + node projections
+  if (prep && a.dg > 0) {  // fold gf into per-graph biases (one tiny launch per update function)
     ProfScope ps("k_fold_bias", s);
     if (skinny_ok(R * a.G, a.dg, std::max(a.oe, a.on))) {  // a few graphs, wide layers: one round-trip-lean GEMV kernel per function
       if (a.oe > 0 && (rc = launch_skinny(a.gf, a.dg, (int)(R * a.G), a.dg, a.We, a.de + 2 * a.dn, a.oe, a.be, a.oe, GNX_ACT_IDENTITY, bias_e, a.oe, s))) return rc;
@@ -1222,7 +1223,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     }
     GNX_HIP(hipGetLastError());
   }
-  if ((phase & 1) && project) {  // both projections in ONE launch (the second weight block of k_rows_gemm): nf is read once
+  if (prep && project) {  // both projections in ONE launch (the second weight block of k_rows_gemm): nf is read once
     WideArgs w{};
     w.tiles = h->d_ntiles; w.row_kind = 1;
     w.seg[0] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 0, 0};
