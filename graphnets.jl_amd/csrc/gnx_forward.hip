@@ -266,6 +266,8 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   bool fused_ln = false;
   const bool all_narrow = core_narrow_width(d[0]) && core_narrow_width(d[1]) && core_narrow_width(d[2]) && !(flags & GNX_FLAG_FORCE_GENERIC);
   if (all_narrow) {
+    // (the graph level of a NARROW core on the handle's side stream — graph update + the G-row / N-row k_core_post launches behind the
+    // edges' k_core_post — was measured: README ex.3 model 298 vs 271 us; two fork/join pairs cost more than the ~20 us they hide)
     rc = block_forward_impl(h, &b, ef, nf, gf, R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, 3, p->ln1, p->eps, p->eps_mode, &fused_ln);
     if (rc) return rc;
   }
