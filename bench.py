@@ -418,6 +418,8 @@ def main():
         abytes, aflops = algorithmic_bytes(E, N, G, din, dout), algorithmic_flops(E, N, G, din, dout)
         hbm_t, mfma_t = abytes / (HBM_PEAK_GBS * 1e9), aflops / (MFMA_F32_PEAK_TFS * 1e12)
         dims_key = args.dims.replace(":", "_").replace(",", "-") + ("" if workload == "c2" else f"_hetero{G}")
+        if workload != "c2" and args.hetero_edges != 1_000_000:
+            dims_key += f"_{args.hetero_edges}"  # the committed PMC profiles are of the 1M-edge batches: no traffic figure for another size
         traffic, tsrc = load_traffic(dims_key, dom, kernel_source_sha(din, dout))
         if hbm_t >= mfma_t:
             a = abytes / dur_s / 1e9
