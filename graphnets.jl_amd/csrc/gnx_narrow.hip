@@ -35,8 +35,26 @@ static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R,
   const unsigned grid = (unsigned)((a.n_wtiles + 3) / 4);
   if (phase & 1) {
     ProfScope ps("k_block_wave", s);
+#ifdef GNX_WAVE_STAMPS_BUILD  // diagnostic build: GNX_WAVE_STAMPS_DUMP=<file> writes [wave tile][8] shader-clock stamps of every (eager) launch
+    static unsigned long long* d_dbg = nullptr;
+    static size_t dbg_cap = 0;
+    const char* dump = getenv("GNX_WAVE_STAMPS_DUMP");
+    if (dump) {
+      if (dbg_cap < (size_t)a.n_wtiles) { if (d_dbg) (void)hipFree(d_dbg); dbg_cap = (size_t)a.n_wtiles; (void)hipMalloc((void**)&d_dbg, dbg_cap * 64); }
+      (void)hipMemsetAsync(d_dbg, 0, (size_t)a.n_wtiles * 64, s);
+      (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wave_dbg), &d_dbg, sizeof(d_dbg), 0, hipMemcpyHostToDevice, s);
+    }
+#endif
     hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, n_rows);
     GNX_HIP(hipGetLastError());
+#ifdef GNX_WAVE_STAMPS_BUILD
+    if (dump) {
+      (void)hipStreamSynchronize(s);
+      std::vector<unsigned long long> hs((size_t)a.n_wtiles * 8);
+      (void)hipMemcpy(hs.data(), d_dbg, hs.size() * 8, hipMemcpyDeviceToHost);
+      if (FILE* f = fopen(dump, "wb")) { fwrite(hs.data(), 8, hs.size(), f); fclose(f); }
+    }
+#endif
   }
   if ((phase & 2) && a.og > 0) {
     if constexpr (C > 0) {

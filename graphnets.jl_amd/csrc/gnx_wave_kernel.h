@@ -322,6 +322,12 @@ __host__ __device__ constexpr int wave_slice_floats(int OE, int EPT) {
 #ifndef GNX_WAVE_SGPRS
 #define GNX_WAVE_SGPRS 80
 #endif
+#ifdef GNX_WAVE_STAMPS_BUILD  // diagnostic build only (tools/build_variant.sh ... -DGNX_WAVE_STAMPS_BUILD): per-wave shader-clock stamps
+static __device__ unsigned long long* g_wave_dbg = nullptr;  // [n_wtiles][8], set by the launcher
+#define GNX_WSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); wst_[i] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GNX_WSTAMP(i) do { } while (0)
+#endif
 template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_SGPRS))) void k_block_wave(BlockArgs a, int n_rows) {
   constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1, DG1 = DG > 0 ? DG : 1;
@@ -339,6 +345,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
   // straddle two graphs, every wave stores its own row and the kernel has no workgroup barrier at all.  (A template
   // parameter, not a run-time branch: the mere presence of the barrier path cost the multi-graph case 4 %.)
   const bool active = wt < a.n_wtiles;  // wave-uniform
+#ifdef GNX_WAVE_STAMPS_BUILD
+  unsigned long long wst_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  GNX_WSTAMP(0);
   if constexpr (!ONEG) { if (!active) return; }
   float mine = 0.f;  // lane c < C: this wave's total of graph-update column c
   do {
@@ -351,6 +361,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
   const cintp tw = reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.wtiles)) + (size_t)wt * (sizeof(Tile) / sizeof(int));
   const int n0 = tw[0], n1 = tw[1], e0 = tw[2], e1 = tw[3], g = tw[4];  // s_load_dwordx8
   const int nn = n1 - n0, ne = e1 - e0;
+  GNX_WSTAMP(1);  // (the stamp's own s_waitcnt lgkmcnt(0) makes this "tile record arrived")
 
   const size_t r = blockIdx.y;
   const float* __restrict__ ef = DE > 0 ? a.ef + r * (size_t)a.E * DE : nullptr;
@@ -371,6 +382,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
   float x[EPT][DE1];
   float xs[EPT][DN1];
   int src[EPT];
+  // (Order of the requests.  The per-wave stamps of the diagnostic build — tools/wave_stamps.py — show a median wave of C2 spending
+  // ~25 k of its ~43 k shader clocks between "tile record arrived" and "gathers issued": it waits for its source indices, and those
+  // return only when the HBM queues reach them behind the edge rows EVERY wave requested in the first microsecond (46 MB at
+  // ~4.5 TB/s).  Requesting the indices ahead of the edge rows, so that in-order vmcnt lets the gathers go out while the rows still
+  // stream, changes nothing measurable (25.4 vs 26.4 us/step): the indices of a late-dispatched wave still queue behind the rows
+  // of the earlier ones.)
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
     int ec = lane + 64 * i;
@@ -391,6 +408,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
     ln_row<DN>(xn[0], a.ln_g[1], a.ln_b[1], a.ln_eps, a.ln_mode);
     ln_row<DG>(gfr[0], a.ln_g[2], a.ln_b[2], a.ln_eps, a.ln_mode);
   }  // (the edge rows and the gathered rows are normalised at the start of the edge phase: their loads are still in flight)
+  GNX_WSTAMP(2);  // every load issued
   // ---- lanes as nodes: destination index of each in-edge, per-node part of the edge update ----
   //   pd[n] = be + We[:, gf-seg] * gf[g] + We[:, dst-seg] * nf[n]      (edgefninput.jl:5-6 hoisted out of the edge loop)
   if (is_node) {
@@ -407,6 +425,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
     }
   }
   __builtin_amdgcn_wave_barrier();
+  GNX_WSTAMP(3);  // node-side preparation done (needed colptr, own nf row)
 
   // ---- lanes as edges ----
   float psum[OE1];  // single-node tiles only: this lane's share of the node's edge sum
@@ -503,6 +522,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
     }
   }
   __builtin_amdgcn_wave_barrier();
+  GNX_WSTAMP(4);  // edge phase done (needed ef rows, rowval, gathered rows; ef' stores issued)
 
   // ---- lanes as nodes: edge->node sum (nodefninput.jl:3), node update ----
   float v[C1];  // per-lane contribution to the tile's graph-level partial sums: [agg ; nf']
@@ -552,7 +572,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
       }
     }
   }
+  GNX_WSTAMP(5);  // node phase done
   } while (0);
+#ifdef GNX_WAVE_STAMPS_BUILD
+  if (active && g_wave_dbg && lane == 0 && blockIdx.y == 0) {
+    wst_[6] = clock64();
+    unsigned long long* o = g_wave_dbg + (size_t)wt * 8;
+    for (int i = 0; i < 7; ++i) o[i] = wst_[i];
+    o[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);  // XCC_ID, HW_ID
+  }
+#endif
   if (a.og > 0) {
     if constexpr (C > 0) {
       const size_t r = blockIdx.y;
