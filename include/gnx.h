@@ -233,7 +233,12 @@ GNX_API int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p,
                           const float* g_ef_out, const float* g_nf_out, const float* g_gf_out, int64_t n_replicas, float* d_ef,
                           float* d_nf, float* d_gf, const gnx_core_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- forward: replaces (m::GNCore)(x) (src/gncore.jl:56-68); GNCoreList = caller-side fold (gncorelist.jl:43-45) ---- */
+/* ---- forward: replaces (m::GNCore)(x) (src/gncore.jl:56-68); GNCoreList = caller-side fold (gncorelist.jl:43-45) ----
+ * Wide cores (block in the matrix cores' projected form, FeedForward widths 64 / 128): gn1 / gn2 of ef and nf are applied by the
+ * kernels as they load x (one pass of row statistics; bit-identical to the materialised LayerNorm, env GNX_NO_LN_FUSE=1 switches it
+ * off), and the graph level of the core runs on a side stream of the HANDLE that gnx_core_workspace_bytes creates (joined before
+ * gnx_core_forward returns; part of the capture when `stream` is being captured; env GNX_NO_FORK=1: one stream).  Hence: call
+ * gnx_core_workspace_bytes outside a capture (as for every workspace query), and run one forward at a time per handle. */
 GNX_API size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t n_replicas);
 GNX_API int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf,
                          const float* gf, int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out,
