@@ -289,7 +289,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   }
   if (wide_ln) {
     const float* stats[2] = {l1[0], l1[1]};  // the (unused) gn1 buffers hold the statistics: 2 floats per row
-    static const bool no_fork0 = getenv("GNX_NO_FORK") != nullptr;
+    const bool no_fork0 = getenv("GNX_NO_FORK") != nullptr;  // (read per call: tests compare both forms in one process)
     const bool fork0 = !no_fork0 && h->aux_stream != nullptr && !profile_enabled();
     if ((rc = launch_layernorm2(x[2], rows[2], d[2], p->ln1[2], p->ln2[2], p->eps, p->eps_mode, l1[2], l2[2], s))) return rc;
     if (fork0) {
@@ -314,7 +314,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     // The graph level of the core — the block's graph update (four 5-us launches) and the G-row FeedForward — is independent of the edge /
     // node FeedForwards that follow the block: it runs on the handle's side stream behind them (fork after the node update, join
     // before returning; inside a capture the side stream joins the captured graph).  GNX_NO_FORK=1: everything on the caller's stream.
-    static const bool no_fork = getenv("GNX_NO_FORK") != nullptr;
+    const bool no_fork = no_fork0;
     const bool fork = !no_fork && h->aux_stream != nullptr && !profile_enabled();
     bool took = false;
     rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, (fork ? 1 : 3) | (fork0 ? 8 : 0), p->ln1, p->eps, p->eps_mode, &took, stats);

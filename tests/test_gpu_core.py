@@ -144,6 +144,38 @@ def test_core_wide_layernorm_on_load_equals_materialised(gn, R, eps_mode):
         U.assert_close(U.from_jl(got), r, s, name)
 
 
+def test_core_wide_side_stream_equals_single_stream(gn):
+    """A wide GNCore forks its graph level, node projections and node FeedForward onto the handle's side stream (GNX_NO_FORK=1: one
+    stream).  Same kernels, same order of every sum: the results are bit-identical — eagerly, repeatedly (a race would show as a
+    mismatch), and inside a captured hipGraph."""
+    import os
+    import torch
+    rng = np.random.default_rng(4800)
+    dims = (128, 64, 32)
+    graphs = [U.er_csc(rng, n, e) for n, e in ((900, 12000), (300, 2500), (64, 700))]
+    g = gn.GNGraphBatch.from_csc([c for c, _ in graphs], [r for _, r in graphs], [900, 300, 64])
+    p = O.make_core_params(rng, dims)
+    core = U.core_from_params(gn, p)
+    xs = [U.to_nt(gn, g, *U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims)) for _ in range(3)]
+    os.environ["GNX_NO_FORK"] = "1"
+    try:
+        ref = [core(x) for x in xs]
+        ref = [tuple(t.clone() for t in (y.ef, y.nf, y.gf)) for y in ref]
+    finally:
+        del os.environ["GNX_NO_FORK"]
+    for rep in range(20):
+        for x, r in zip(xs, ref):
+            y = core(x)
+            for name, a, b in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), r):
+                assert torch.equal(a, b), f"rep {rep} {name}: side-stream form differs"
+    graphed = gn.Graphed(core, xs[0])
+    for rep in range(5):
+        for x, r in zip(xs, ref):
+            y = graphed(x)
+            for name, a, b in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), r):
+                assert torch.equal(a, b), f"captured, rep {rep} {name}: side-stream form differs"
+
+
 def test_config4_shape_encoder_2cores_decoder_wide(gn):
     """BASELINE config 4 at reduced size: enc (10,5,0)=>(128,64,32), 2 x GNCore(128,64,32), dec =>(3,4,5)."""
     rng = np.random.default_rng(46)
