@@ -174,6 +174,12 @@ def test_core_wide_side_stream_equals_single_stream(gn):
             y = graphed(x)
             for name, a, b in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), r):
                 assert torch.equal(a, b), f"captured, rep {rep} {name}: side-stream form differs"
+    cmodel = gn.Model([core], xs[0])  # the library's own capture (gnx_model_*): the side stream joins that graph too
+    for rep in range(5):
+        for x, r in zip(xs, ref):
+            y = cmodel(x)
+            for name, a, b in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), r):
+                assert torch.equal(a, b), f"gnx_model, rep {rep} {name}: side-stream form differs"
 
 
 def test_config4_shape_encoder_2cores_decoder_wide(gn):
