@@ -25,16 +25,15 @@ namespace gnx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef GNX_GEMM_WAVES  // 3 waves per SIMD = 3 workgroups per CU with a 168-register budget: NO spilled register at BN = 128.  A 4th workgroup
+#ifndef GNX_GEMM_WPE  // 3 waves per SIMD = 3 workgroups per CU with a 168-register budget: NO spilled register at BN = 128.  A 4th workgroup
 // (128 registers, ~20 spilled) is slower once the loads are pipelined: a scratch reload is a vector-memory operation, so the wait
 // in front of its first use also waits for every global load issued before it (edge GEMM 433 vs 462 us).
-#define GNX_GEMM_WAVES __attribute__((amdgpu_waves_per_eu(3)))
+#define GNX_GEMM_WPE 3
 #endif
 #ifndef GNX_GEMM_GRP  // row quads per epilogue operand group (two groups in flight)
 #define GNX_GEMM_GRP 2
 #endif
 constexpr int BM = 128;   // rows (edges or nodes) per workgroup tile
-constexpr int WT = 256;   // threads
 
 struct WSeg {
   const float* base;  // replica 0
@@ -149,12 +148,18 @@ __device__ __forceinline__ void st4(float* ubase, unsigned off, float4 v) {
 // STORE of the wave has been acknowledged — in the epilogue that is a full HBM write round trip per barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifndef GNX_GEMM_W8  // 1: the 128-column tile is computed by 8 waves (32 x 64 per wave, two 8-wave workgroups per CU) instead of 4 (64 x 64, three)
+#define GNX_GEMM_W8 0
+#endif
 template <int BN>
 struct WaveLayout {
-  static constexpr int WM = BN == 32 ? 4 : 2;
-  static constexpr int WN = 4 / WM;
+  static constexpr int WAVES = (BN == 128 && GNX_GEMM_W8) ? 8 : 4;
+  static constexpr int WM = (BN == 32 || WAVES == 8) ? 4 : 2;
+  static constexpr int WN = WAVES / WM;
   static constexpr int TM = BM / (WM * 32);
   static constexpr int TN = BN / (WN * 32);
+  static constexpr int WT = 64 * WAVES;         // threads of the workgroup
+  static constexpr int WPE = WAVES == 8 ? 4 : GNX_GEMM_WPE;  // waves per SIMD asked of the register allocator
 };
 
 // NL = number of epilogue operand streams read from global memory (EPI_* below): 0, 1 or 2 float4 per output quad.  The VEC4
@@ -172,8 +177,9 @@ struct WaveLayout {
 // and a scratch reload waits on vmcnt, i.e. for the global loads just issued): launches whose segments are all quad rows of
 // modes 0-2 (the core's edge update, the FeedForward layers, the projections) get a kernel without them.
 template <int BN, bool VEC4, int KC, int NL, bool TRANS, int LD>
-__global__ __launch_bounds__(WT) GNX_GEMM_WAVES void k_rows_gemm(WideArgs a) {
+__global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per_eu(WaveLayout<BN>::WPE))) void k_rows_gemm(WideArgs a) {
   using L = WaveLayout<BN>;
+  constexpr int WT = L::WT;
   constexpr bool FULL = LD >= 1;   // loader with the row-sum modes 3 / 4
   constexpr bool ELEM = LD >= 2;   // ... and element-wise / packed segments
   constexpr int LDA = KC + 1;               // A row stride: odd => conflict-free ds_read_b32 of the A fragment
@@ -1068,7 +1074,7 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
   const bool trans = w.act > 1;
   // instantiations: quad outputs with the lean loader (every NL), quad outputs with the full loader and no operands (node update,
   // encoder), element outputs with the full loader (every NL; also takes the rare quad-output + full-loader + operands launches)
-#define GNX_GEMM_LAUNCH(V, N, T, F) hipLaunchKernelGGL((k_rows_gemm<BN, V, 32, N, T, F>), grid, dim3(WT), 0, s, wa)
+#define GNX_GEMM_LAUNCH(V, N, T, F) hipLaunchKernelGGL((k_rows_gemm<BN, V, 32, N, T, F>), grid, dim3(WaveLayout<BN>::WT), 0, s, wa)
 #define GNX_GEMM_LAUNCH_N(V, T, F) do { if (nl == 0) GNX_GEMM_LAUNCH(V, 0, T, F); else if (nl == 1) GNX_GEMM_LAUNCH(V, 1, T, F); else GNX_GEMM_LAUNCH(V, 2, T, F); } while (0)
   if (vec4 && ld == 0) { if (trans) GNX_GEMM_LAUNCH_N(true, true, 0); else GNX_GEMM_LAUNCH_N(true, false, 0); }
   else if (vec4 && nl == 0 && ld == 1) { if (trans) GNX_GEMM_LAUNCH(true, 0, true, 1); else GNX_GEMM_LAUNCH(true, 0, false, 1); }
