@@ -159,7 +159,10 @@ struct WaveLayout {
   static constexpr int TM = BM / (WM * 32);
   static constexpr int TN = BN / (WN * 32);
   static constexpr int WT = 64 * WAVES;         // threads of the workgroup
-  static constexpr int WPE = WAVES == 8 ? 4 : GNX_GEMM_WPE;  // waves per SIMD asked of the register allocator
+#ifndef GNX_GEMM_WPE64  // 64-column tiles (the node update at C4's widths): 4 workgroups per CU — 782 node tiles are ONE round on 1024 slots but
+#define GNX_GEMM_WPE64 4  // 1.02 rounds on 768; the ~25 registers the row-sum loader then spills cost less than the second round (66 -> 60 us)
+#endif
+  static constexpr int WPE = WAVES == 8 ? 4 : (BN == 64 ? GNX_GEMM_WPE64 : GNX_GEMM_WPE);  // waves per SIMD asked of the register allocator
 };
 
 // NL = number of epilogue operand streams read from global memory (EPI_* below): 0, 1 or 2 float4 per output quad.  The VEC4
@@ -785,6 +788,11 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
   }
 #endif
 }
+
+#undef ra
+#undef rb
+#undef ex
+#undef ey
 
 // bias'[r][g][n] = b[n] + sum_k W[(w_row0 + k)*OUT + n] * gf[r][g][k]      (the gf segment of edgefninput.jl:6 /
 // nodefninput.jl:5: constant per graph, so it is a rank-1 fold instead of K more columns of every row's GEMM)
