@@ -13,7 +13,9 @@
 // 512 threads = 8 waves as 4 (row blocks) x 2 (column halves); v_mfma_f32_32x32x2_f32 (exact fp32); 58 KB of LDS -> 2 workgroups
 // (16 waves) per CU.
 #include <algorithm>
+#include <cstdio>
 #include <type_traits>
+#include <vector>
 
 #include "gnx_device.h"
 
@@ -59,6 +61,13 @@ struct FfnArgs {
 };
 
 // (4 waves per SIMD = two workgroups per CU: without the attribute the compiler takes 130+ registers and the second workgroup is gone)
+#ifdef GNX_FFN_STAMPS_BUILD  // diagnostic build only (tools/build_variant.sh ffnst gnx_ffn_fused.hip -DGNX_FFN_STAMPS_BUILD): shader-clock stamps of wave 0
+static __device__ unsigned long long* g_ffn_dbg = nullptr;  // [tile][8]
+#define GNX_FSTAMP(acc, t0) do { const unsigned long long t1_ = clock64(); acc += t1_ - t0; t0 = t1_; } while (0)
+#else
+#define GNX_FSTAMP(acc, t0) do { } while (0)
+#endif
+
 template <int D>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_ffn_fused(FfnArgs a) {
   constexpr int H = 4 * D;
@@ -158,6 +167,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     }
   };
 
+#ifdef GNX_FFN_STAMPS_BUILD
+  unsigned long long fs_sync = 0, fs_issue = 0, fs_mma1 = 0, fs_hid = 0, fs_mma2 = 0, fs_t = clock64();
+  const unsigned long long fs_start = fs_t;
+#endif
   load_step(0, 0);
   for (int hs = 0; hs < H / FHS; ++hs) {
     f32x16 accH;
@@ -167,9 +180,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       __syncthreads();  // readers of the previous chunk are done (and, at st == NC1, sH has been written by everyone)
       store_step(st);
       __syncthreads();
+      GNX_FSTAMP(fs_sync, fs_t);
       // prefetch the next step (possibly the first chunk of the next slice)
       if (st + 1 < NSTEP) load_step(hs, st + 1);
       else if (hs + 1 < H / FHS) load_step(hs + 1, 0);
+      GNX_FSTAMP(fs_issue, fs_t);
       if (st < NC1) {
         // GEMM1: accH[32 x 32 per wave] += z chunk * W1 chunk     (wave rows 32*wm.., hidden columns 32*wn..)
 #pragma unroll
@@ -178,6 +193,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
           const float fa = sA[(wm * 32 + l31) * LDA + 2 * kk + hi];
           accH = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, accH, 0, 0, 0);
         }
+        GNX_FSTAMP(fs_mma1, fs_t);
         if (st == NC1 - 1) {
           // hidden slice: bias + activation, parked in LDS as the A operand of GEMM2 (C/D layout: row = (q&3)+8(q>>2)+4hi)
           const int hcol = wn * 32 + l31;
@@ -198,6 +214,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
           }
 #pragma unroll
           for (int q = 0; q < 16; ++q) sH[(wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * hi) * LDH + hcol] = hv[q];
+          GNX_FSTAMP(fs_hid, fs_t);
         }
       } else {
         // GEMM2: accO[64 x D/2 per wave] += sH[:, 32-wide k range] * W2 chunk
@@ -211,9 +228,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
           for (int j = 0; j < TNO; ++j) accO[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb[j], accO[j], 0, 0, 0);
         }
+        GNX_FSTAMP(fs_mma2, fs_t);
       }
     }
   }
+#ifdef GNX_FFN_STAMPS_BUILD
+  const unsigned long long fs_loop_end = clock64();
+#endif
 
   // ---- epilogue: two 64-row passes through LDS -> full-row 16-B stores with bias and the two residuals.  The residual rows of a
   //      pass are requested in one go (unconditional loads of clamped rows) before the pass's LDS traffic, pass 1's before pass 0's
@@ -267,6 +288,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       if (row < rows) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(out_tile) + (((unsigned)row * D + 4u * q4) << 2)) = v[i];
     }
   });
+#ifdef GNX_FFN_STAMPS_BUILD
+  if (g_ffn_dbg && tid == 0 && blockIdx.y == 0) {
+    unsigned long long* o = g_ffn_dbg + (size_t)blockIdx.x * 8;
+    const unsigned long long te = clock64();
+    o[0] = fs_sync; o[1] = fs_issue; o[2] = fs_mma1; o[3] = fs_hid; o[4] = fs_mma2; o[5] = te - fs_loop_end; o[6] = te - fs_start;
+  }
+#endif
 }
 
 // (Round 2 built the variant this structure suggests — z tile RESIDENT in LDS for the whole tile, weights through a two-deep LDS
@@ -300,9 +328,30 @@ int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d,
   const unsigned n_tiles = (unsigned)(entity == 0 ? h->h_etiles.size() : (entity == 1 ? h->h_ntiles.size() : h->h_gtiles.size()));
   if (!a.tiles || !z || !ff.fc1.weight || !ff.fc2.weight || !out) return fail(GNX_ERR_INVALID_ARG, "k_ffn_fused: NULL operand");
   ProfScope ps("k_ffn_fused", s);
+#ifdef GNX_FFN_STAMPS_BUILD
+  static unsigned long long* d_dbg = nullptr;
+  static size_t dbg_cap = 0;
+  const bool stamps = getenv("GNX_FFN_STAMPS") != nullptr;
+  if (stamps) {
+    if (dbg_cap < n_tiles) { if (d_dbg) (void)hipFree(d_dbg); dbg_cap = n_tiles; (void)hipMalloc((void**)&d_dbg, dbg_cap * 64); }
+    (void)hipMemsetAsync(d_dbg, 0, (size_t)n_tiles * 64, s);
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ffn_dbg), &d_dbg, sizeof(d_dbg), 0, hipMemcpyHostToDevice, s);
+  }
+#endif
   if (d == 128) hipLaunchKernelGGL((k_ffn_fused<128>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((k_ffn_fused<64>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
   GNX_HIP(hipGetLastError());
+#ifdef GNX_FFN_STAMPS_BUILD
+  if (stamps) {
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> hs((size_t)n_tiles * 8);
+    (void)hipMemcpy(hs.data(), d_dbg, hs.size() * 8, hipMemcpyDeviceToHost);
+    double m[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < n_tiles; ++i) for (int j = 0; j < 7; ++j) m[j] += (double)hs[i * 8 + j];
+    fprintf(stderr, "[gnx ffn stamps] D=%d tiles=%u: per tile (shader clocks, wave 0): barriers+LDS stores %.0f  load issue %.0f  GEMM1 MFMA sections %.0f  hidden slice -> LDS %.0f  GEMM2 MFMA sections %.0f  epilogue %.0f  total %.0f\n",
+            d, n_tiles, m[0] / n_tiles, m[1] / n_tiles, m[2] / n_tiles, m[3] / n_tiles, m[4] / n_tiles, m[5] / n_tiles, m[6] / n_tiles);
+  }
+#endif
   return GNX_OK;
 }
 
