@@ -41,6 +41,16 @@ int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, 
 // delta[m][j] = (G[m][j] + extra1[i1(m)][o1 + j] + extra2[i2(m)][o2 + j]) * act'(out[m][j]);  one thread per element.
 // kind 0: rows = graphs (no extras); 1: rows = nodes (extra1 = dXg rows by graph); 2: rows = edges (extra1 = dXg by graph,
 // extra2 = dXn by destination node).
+// d/dz of NNlib.gelu's tanh form 0.5 z (1 + tanh(c (z + 0.044715 z^3))): unlike relu / tanh / sigmoid it is not a function of the
+// OUTPUT (gelu is not monotonic), so for a gelu level the pre-activation z = W x + b is recomputed into the delta buffer first
+// (k_fw_dense) and DeltaArgs::out points at it: act code 4 here means "out holds z".
+__device__ __forceinline__ float gelu_grad_pre(float z) {
+  const float c = 0.7978845608028654f, k = 0.044715f;
+  const float t = tanhf(c * (z + k * z * z * z));
+  return 0.5f * (1.f + t) + 0.5f * z * (1.f - t * t) * c * (1.f + 3.f * k * z * z);
+}
+__device__ __forceinline__ float act_grad_bw(float v, int act) { return act == 4 ? gelu_grad_pre(v) : act_grad_from_out(v, act); }
+
 struct DeltaArgs {
   const float* G; const float* out; float* delta;
   const float* ex1; int ex1_stride, ex1_off;
@@ -58,7 +68,7 @@ __global__ void k_bw_delta(DeltaArgs a, size_t ex1_rep, size_t ex2_rep) {
   float g = a.G ? a.G[o] : 0.f;
   if (a.kind >= 1 && a.ex1) g += a.ex1[r * ex1_rep + (size_t)segment_of(a.seg_off, a.n_seg, m) * a.ex1_stride + a.ex1_off + j];
   if (a.kind == 2 && a.ex2) g += a.ex2[r * ex2_rep + (size_t)a.edge_dst[m] * a.ex2_stride + a.ex2_off + j];
-  a.delta[o] = g * act_grad_from_out(a.out[o], a.act);
+  a.delta[o] = g * act_grad_bw(a.out[o], a.act);
 }
 // the same, four columns per thread with 16-B accesses (J % 4 == 0, every base / stride / offset a multiple of 4 floats)
 __global__ void k_bw_delta_v4(DeltaArgs a, size_t ex1_rep, size_t ex2_rep) {
@@ -78,7 +88,7 @@ __global__ void k_bw_delta_v4(DeltaArgs a, size_t ex1_rep, size_t ex2_rep) {
     const float4 u = *reinterpret_cast<const float4*>(a.ex2 + r * ex2_rep + (size_t)a.edge_dst[m] * a.ex2_stride + a.ex2_off + j);
     g.x += u.x; g.y += u.y; g.z += u.z; g.w += u.w;
   }
-  g.x *= act_grad_from_out(y.x, a.act); g.y *= act_grad_from_out(y.y, a.act); g.z *= act_grad_from_out(y.z, a.act); g.w *= act_grad_from_out(y.w, a.act);
+  g.x *= act_grad_bw(y.x, a.act); g.y *= act_grad_bw(y.y, a.act); g.z *= act_grad_bw(y.z, a.act); g.w *= act_grad_bw(y.w, a.act);
   *reinterpret_cast<float4*>(a.delta + o) = g;
 }
 static void launch_delta(const DeltaArgs& a, size_t ex1_rep, size_t ex2_rep, unsigned Ru, hipStream_t s) {
@@ -557,7 +567,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   if ((oe && !ef_out && h->E > 0) || (on && !nf_out) || (og && !gf_out)) return fail(GNX_ERR_INVALID_ARG, "a forward output with non-zero width is NULL");
   const int acts[3] = {p->edgefn.act, p->nodefn.act, p->graphfn.act};
   for (int a : acts)
-    if (a == GNX_ACT_GELU || a < 0 || a > GNX_ACT_GELU) return fail(GNX_ERR_INVALID_ARG, "backward supports identity / relu / tanh / sigmoid");
+    if (a < 0 || a > GNX_ACT_GELU) return fail(GNX_ERR_INVALID_ARG, "unknown activation code");
   const BwLayout L = bw_layout(h, p, R);
   if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_block_backward_workspace_bytes()");
   int32_t rc = gnx_ensure_csr(h);
@@ -587,7 +597,14 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
     hipLaunchKernelGGL(k_bw_colsum2, dim3((unsigned)G, Ru), dim3(64), 0, s, part, d, S, G, out, out_stride, out_off, accumulate);
   };
   // Edge level on the matrix cores: regrouped (see below) — the edge function's input Xe is never materialised.
-  const bool mfma_e = oe > 0 && E > 0 && bw_use_mfma((size_t)R * E, oe, Ke);
+  // (a gelu edge function needs its pre-activation, hence the materialised Xe of the generic form)
+  const bool mfma_e = oe > 0 && E > 0 && acts[0] != GNX_ACT_GELU && bw_use_mfma((size_t)R * E, oe, Ke);
+  // gelu: the level's pre-activation z = W x + b, recomputed into its delta buffer; the delta kernel then reads it in place
+  auto preact = [&](int level, const float* X, const gnx_dense& d, size_t rows, int K, int J, float* z) {
+    if (acts[level] != GNX_ACT_GELU || rows == 0 || J == 0) return;
+    ProfScope ps("bw_gelu_preact", s);
+    hipLaunchKernelGGL(k_fw_dense, blocks(rows * J), dim3(256), 0, s, X, d.weight, d.bias, rows, K, J, GNX_ACT_IDENTITY, z);
+  };
   // function inputs, exactly as the forward's building blocks define them
   { ProfScope ps("bw_fn_inputs", s);
   if (oe && E && !mfma_e && (rc = launch_fn_input(h, 0, ef, de, nf, dn, gf, dg, R, Xe, s))) return rc;
@@ -602,7 +619,8 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   // graph level
   const bool have_g = og > 0;
   if (have_g) {
-    DeltaArgs a{g_gf_out, gf_out, dlt_g, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, og, G, G, acts[2], 0};
+    preact(2, Xg, p->graphfn, (size_t)R * G, Kg, og, dlt_g);
+    DeltaArgs a{g_gf_out, acts[2] == GNX_ACT_GELU ? dlt_g : gf_out, dlt_g, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, og, G, G, acts[2], 0};
     hipLaunchKernelGGL(k_bw_delta, dim3(blocks((size_t)G * og).x, Ru), dim3(256), 0, s, a, (size_t)0, (size_t)0);
     launch_bw_dx(dim3(blocks((size_t)G * Kg).x, Ru), s, dlt_g, p->graphfn.weight, G, og, Kg, dXg, 0, 0, (float*)nullptr, 0);
     if ((rc = dw_reduce(dlt_g, Xg, (size_t)R * G, og, Kg, gr.graphfn, part, s))) return rc;
@@ -610,7 +628,8 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   // node level
   const bool have_n = on > 0;
   if (have_n) {
-    DeltaArgs a{g_nf_out, nf_out, dlt_n, have_g ? dXg : nullptr, Kg, oe, nullptr, 0, 0, h->d_node_off, nullptr, on, N, G, acts[1], 1};
+    preact(1, Xn, p->nodefn, (size_t)R * N, Kn, on, dlt_n);
+    DeltaArgs a{g_nf_out, acts[1] == GNX_ACT_GELU ? dlt_n : nf_out, dlt_n, have_g ? dXg : nullptr, Kg, oe, nullptr, 0, 0, h->d_node_off, nullptr, on, N, G, acts[1], 1};
     launch_delta(a, (size_t)G * Kg, (size_t)0, Ru, s);
     if (bw_use_mfma((size_t)R * N, on, Kn)) {  // matrix cores: dXn = dn Wn^T, dWn = Xn^T dn, dbn = column sums
       if ((rc = dx_mfma(h, 1, dlt_n, p->nodefn.weight, on, Kn, 0, Kn, dXn, R, wt, true, s, "bw_dx_node"))) return rc;
@@ -623,7 +642,8 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   // edge level
   const bool have_e = oe > 0 && E > 0;
   if (have_e) {
-    DeltaArgs a{g_ef_out, ef_out, dlt_e, have_g ? dXg : nullptr, Kg, 0, have_n ? dXn : nullptr, Kn, 0, h->d_edge_off, h->d_edge_dst, oe, E, G, acts[0], 2};
+    preact(0, Xe, p->edgefn, (size_t)R * E, Ke, oe, dlt_e);
+    DeltaArgs a{g_ef_out, acts[0] == GNX_ACT_GELU ? dlt_e : ef_out, dlt_e, have_g ? dXg : nullptr, Kg, 0, have_n ? dXn : nullptr, Kn, 0, h->d_edge_off, h->d_edge_dst, oe, E, G, acts[0], 2};
     { ProfScope ps("bw_delta_edge", s);
     launch_delta(a, (size_t)G * Kg, (size_t)N * Kn, Ru, s); }
     if (mfma_e) {

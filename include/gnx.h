@@ -198,7 +198,8 @@ GNX_API int32_t gnx_chain_block_forward(const gnx_graphs* h, const gnx_chain_blo
  * d_gf, input shapes) and w.r.t. the parameters (grads->*.weight in the (out x in) column-major layout of the weights,
  * grads->*.bias), OVERWRITTEN.  Deterministic: segmented sums in CSC order, the nf[src] gradient is gathered through a
  * CSR view of the same graph (no atomics), weight gradients are two-stage fixed-order reductions.
- * Activations identity / relu / tanh / sigmoid differentiate from the stored outputs; gelu is not supported here. */
+ * Activations identity / relu / tanh / sigmoid differentiate from the stored outputs; gelu (not a function of its output) from the
+ * pre-activation, recomputed per level. */
 typedef struct gnx_dense_grad {
   float* weight; /* (out x in) column-major, device, or NULL */
   float* bias;   /* (out), device, or NULL                   */

@@ -8,7 +8,7 @@ from oracle import gn_oracle as O
 from tests import util as U
 
 pytestmark = pytest.mark.gpu
-ACT = {0: lambda x: x, 1: torch.relu, 2: torch.tanh, 3: torch.sigmoid}
+ACT = {0: lambda x: x, 1: torch.relu, 2: torch.tanh, 3: torch.sigmoid, 4: lambda x: torch.nn.functional.gelu(x, approximate="tanh")}  # 4: NNlib.gelu (tanh form)
 
 
 @pytest.fixture(scope="module")
@@ -76,7 +76,7 @@ def _kink_free(pre_acts, margin=5e-6):
 
 
 @pytest.mark.parametrize("dims", DIMS + BIG_DIMS, ids=[str(d) for d in DIMS] + ["mfma-" + str(d) for d in BIG_DIMS])
-@pytest.mark.parametrize("act", [(0, 0, 0), (1, 2, 3)], ids=["identity", "relu-tanh-sigmoid"])
+@pytest.mark.parametrize("act", [(0, 0, 0), (1, 2, 3), (4, 4, 4)], ids=["identity", "relu-tanh-sigmoid", "gelu"])
 def test_block_backward_matches_torch_autograd(gn, dims, act, request):
     big = "mfma-" in request.node.callspec.id
     if big and act[0] == 1:

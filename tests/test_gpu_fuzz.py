@@ -110,7 +110,7 @@ def test_block_backward_degenerate_widths(gn, din, dout):
 def _check_block_backward(gn, rng, g, din, dout, seed):
     import torch
     from tests.test_gpu_backward import _torch_block
-    p = O.make_block_params(rng, din, dout, act=tuple(int(a) for a in rng.choice([0, 2, 3], 3)))
+    p = O.make_block_params(rng, din, dout, act=tuple(int(a) for a in rng.choice([0, 2, 3, 4], 3)))
     ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, din)
     csc = (*g.csc(), g.node_off, g.edge_off)
     W = {k: torch.tensor(p[k], dtype=torch.float64, requires_grad=True) for k in ("We", "be", "Wn", "bn", "Wg", "bg")}
