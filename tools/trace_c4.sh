@@ -20,6 +20,23 @@ def short(n):
     return n[:70]
 seq = [(short(r['Kernel_Name']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, int(r['Start_Timestamp'])) for r in rows]
 # print the last 70 dispatches with gaps
+# one forward = the dispatches between the last two graph-level kernels of a decoder (k_graph_final / k_skinny_dense at the very end)
+for n, d, _ in seq[-70:]:
+    print(f'{d:9.1f} us  {n}')
+PY'
+import sys, glob, csv
+out = sys.argv[1]
+f = sorted(glob.glob(out + '/kt/**/*kernel_trace.csv', recursive=True))[-1]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+names = [r['Kernel_Name'] for r in rows]
+# the last forward: find the last dispatch whose name starts the sequence (the first kernel name of the list after the build kernels)
+import re
+def short(n):
+    n = re.sub(r'\(.*', '', n); n = n.replace('gnx::', '').replace('void ', '')
+    return n[:70]
+seq = [(short(r['Kernel_Name']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, int(r['Start_Timestamp'])) for r in rows]
+# print the last 70 dispatches with gaps
 tail = seq[-75:]
 prev_end = None
 tot = 0
