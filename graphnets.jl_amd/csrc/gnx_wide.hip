@@ -823,13 +823,18 @@ __global__ void k_fold_bias(const float* __restrict__ W, const float* __restrict
 
 // ---- graph update for the wide path: two-stage fixed-order reduction of the per-tile column sums ----
 // stage 1: out2[r][g][s][c] = sum over the s-th slice of graph g's tile rows of in[r][tile][c]
-__global__ void k_colsum_slices(const float* in, size_t in_rep_stride, const int* tile_off, int C, int S, float* out2, int G) {
+struct ColsumJob { const float* in; size_t in_rep_stride; const int* tile_off; int C; float* out2; };
+// (the edges' and the nodes' sums in ONE launch: blockIdx.z = 2 * replica + job; every launch of this size is ~5 us of latency)
+__global__ void k_colsum_slices(ColsumJob j0, ColsumJob j1, int S, int G) {
+  const ColsumJob j = (blockIdx.z & 1) ? j1 : j0;
+  if (!j.in || j.C == 0) return;
   const int g = blockIdx.x, s = blockIdx.y;
-  const size_t r = blockIdx.z;
-  const int t0 = tile_off[g], t1 = tile_off[g + 1];
+  const size_t r = blockIdx.z >> 1;
+  const int C = j.C;
+  const int t0 = j.tile_off[g], t1 = j.tile_off[g + 1];
   const int per = (t1 - t0 + S - 1) / S;
   const int a0 = t0 + s * per, a1 = min(a0 + per, t1);
-  const float* base = in + r * in_rep_stride;
+  const float* base = j.in + r * j.in_rep_stride;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float acc[16];
 #pragma unroll
@@ -847,7 +852,7 @@ __global__ void k_colsum_slices(const float* in, size_t in_rep_stride, const int
     for (int w = 8; w > 0; w >>= 1)
 #pragma unroll
       for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
-    out2[((r * G + g) * S + s) * (size_t)C + c] = acc[0];
+    j.out2[((r * G + g) * S + s) * (size_t)C + c] = acc[0];
   }
 }
 
@@ -908,8 +913,16 @@ __global__ __launch_bounds__(256) void k_graph_final(const float* pe2, const flo
 // y[m][n] = act(b[n] + sum_k x[m][k] * W[(w_row0 + k) * ldw + n]).  The work is a handful of GEMVs: what matters is the
 // number of dependent memory round trips.  1024 threads = 64 output lanes x 16 K-slices, every thread keeps 8 weight loads
 // in flight (coalesced 256-B rows), the 16 slices are added in a fixed order from LDS.
-__global__ __launch_bounds__(1024) void k_skinny_dense(const float* __restrict__ x, int ldx, int M, int K, const float* __restrict__ W, int w_row0,
-                                                       int ldw, const float* __restrict__ bias, int N, int act, float* __restrict__ y, int ldy) {
+struct SkinnyJob { const float* x; int ldx, M, K; const float* W; int w_row0, ldw; const float* bias; int N, act; float* y; int ldy; };
+// (two jobs per launch — blockIdx.y: the gf folds of the edge and the node function are one launch)
+__global__ __launch_bounds__(1024) void k_skinny_dense(SkinnyJob j0, SkinnyJob j1) {
+  const SkinnyJob j = blockIdx.y ? j1 : j0;
+  if (!j.y || (int)blockIdx.x * 64 >= j.N) return;  // (whole workgroup: before any barrier)
+  const float* __restrict__ x = j.x;
+  const float* __restrict__ W = j.W;
+  const float* __restrict__ bias = j.bias;
+  float* __restrict__ y = j.y;
+  const int ldx = j.ldx, M = j.M, K = j.K, w_row0 = j.w_row0, ldw = j.ldw, N = j.N, act = j.act, ldy = j.ldy;
   extern __shared__ float s_sk[];  // [M][K] inputs, reused as [16][8][64] partial sums
   const int tid = threadIdx.x, lane = tid & 63, ks = tid >> 6;
   const int n = blockIdx.x * 64 + lane;
@@ -947,12 +960,17 @@ __global__ __launch_bounds__(1024) void k_skinny_dense(const float* __restrict__
   }
 }
 static bool skinny_ok(int64_t M, int K, int N) { return M >= 1 && M <= 8 && (size_t)K * N >= 4096 && K >= 16; }
-static int32_t launch_skinny(const float* x, int ldx, int M, int K, const float* W, int w_row0, int ldw, const float* bias, int N, int act, float* y,
-                             int ldy, hipStream_t s) {
-  const size_t lds = sizeof(float) * std::max<size_t>((size_t)M * K, 16 * 8 * 64);
-  hipLaunchKernelGGL(k_skinny_dense, dim3((unsigned)((N + 63) / 64)), dim3(1024), lds, s, x, ldx, M, K, W, w_row0, ldw, bias, N, act, y, ldy);
+static int32_t launch_skinny2(const SkinnyJob& j0, const SkinnyJob& j1, hipStream_t s) {
+  const bool two = j1.y != nullptr;
+  const size_t lds = sizeof(float) * std::max<size_t>(std::max((size_t)j0.M * j0.K, two ? (size_t)j1.M * j1.K : 0), 16 * 8 * 64);
+  const unsigned gx = (unsigned)((std::max(j0.N, two ? j1.N : 0) + 63) / 64);
+  hipLaunchKernelGGL(k_skinny_dense, dim3(gx, two ? 2u : 1u), dim3(1024), lds, s, j0, j1);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
+}
+static int32_t launch_skinny(const float* x, int ldx, int M, int K, const float* W, int w_row0, int ldw, const float* bias, int N, int act, float* y,
+                             int ldy, hipStream_t s) {
+  return launch_skinny2(SkinnyJob{x, ldx, M, K, W, w_row0, ldw, bias, N, act, y, ldy}, SkinnyJob{}, s);
 }
 
 // Xg[r*G + g][:] = [sum_e ef' ; sum_n nf' ; gf_g] from the stage-1 slices (the input of the graph function)
@@ -1229,8 +1247,11 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   if (prep && a.dg > 0) {  // fold gf into per-graph biases (one tiny launch per update function)
     ProfScope ps("k_fold_bias", s);
     if (skinny_ok(R * a.G, a.dg, std::max(a.oe, a.on))) {  // a few graphs, wide layers: one round-trip-lean GEMV kernel per function
-      if (a.oe > 0 && (rc = launch_skinny(a.gf, a.dg, (int)(R * a.G), a.dg, a.We, a.de + 2 * a.dn, a.oe, a.be, a.oe, GNX_ACT_IDENTITY, bias_e, a.oe, s))) return rc;
-      if (a.on > 0 && (rc = launch_skinny(a.gf, a.dg, (int)(R * a.G), a.dg, a.Wn, a.oe + a.dn, a.on, a.bn, a.on, GNX_ACT_IDENTITY, bias_n, a.on, s))) return rc;
+      const SkinnyJob je{a.gf, a.dg, (int)(R * a.G), a.dg, a.We, a.de + 2 * a.dn, a.oe, a.be, a.oe, GNX_ACT_IDENTITY, bias_e, a.oe};
+      const SkinnyJob jn{a.gf, a.dg, (int)(R * a.G), a.dg, a.Wn, a.oe + a.dn, a.on, a.bn, a.on, GNX_ACT_IDENTITY, bias_n, a.on};
+      if (a.oe > 0 && a.on > 0) { if ((rc = launch_skinny2(je, jn, s))) return rc; }  // both gf folds in one launch
+      else if (a.oe > 0) { if ((rc = launch_skinny2(je, SkinnyJob{}, s))) return rc; }
+      else if (a.on > 0) { if ((rc = launch_skinny2(jn, SkinnyJob{}, s))) return rc; }
     } else {
     if (a.oe > 0) hipLaunchKernelGGL(k_fold_bias, dim3((unsigned)a.G, (unsigned)R), dim3(128), 0, s, a.We, a.be, a.gf, a.dg, a.de + 2 * a.dn, a.oe, a.G, bias_e);
     if (a.on > 0) hipLaunchKernelGGL(k_fold_bias, dim3((unsigned)a.G, (unsigned)R), dim3(128), 0, s, a.Wn, a.bn, a.gf, a.dg, a.oe + a.dn, a.on, a.G, bias_n);
@@ -1296,8 +1317,11 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   }
   if ((phase & 2) && a.og > 0) {
     ProfScope ps("k_graph_wide", s);
-    if (a.oe > 0) hipLaunchKernelGGL(k_colsum_slices, dim3((unsigned)a.G, (unsigned)S, (unsigned)R), dim3(128), 0, s, pe, n_et * (size_t)a.oe, h->d_etile_off, a.oe, S, pe2, a.G);
-    if (a.on > 0) hipLaunchKernelGGL(k_colsum_slices, dim3((unsigned)a.G, (unsigned)S, (unsigned)R), dim3(128), 0, s, pn, n_nt * (size_t)a.on, h->d_ntile_off, a.on, S, pn2, a.G);
+    if (a.oe > 0 || a.on > 0) {
+      const ColsumJob je{a.oe > 0 ? pe : nullptr, n_et * (size_t)a.oe, h->d_etile_off, a.oe, pe2};
+      const ColsumJob jn{a.on > 0 ? pn : nullptr, n_nt * (size_t)a.on, h->d_ntile_off, a.on, pn2};
+      hipLaunchKernelGGL(k_colsum_slices, dim3((unsigned)a.G, (unsigned)S, 2u * (unsigned)R), dim3(128), 0, s, je, jn, S, a.G);
+    }
     const int Kg = a.oe + a.on + a.dg;
     if (skinny_ok(R * a.G, Kg, a.og)) {  // small batch, wide layers: assemble Xg, then the round-trip-lean GEMV kernel
       float* xg = reinterpret_cast<float*>(reinterpret_cast<char*>(proj_s) + align_up(sizeof(float) * 2 * (size_t)R * h->N * a.oe, 256));
