@@ -119,6 +119,7 @@ SIGNATURES = {
     "gnx_fn_input": (C.c_int32, [C.c_void_p, C.c_int32, _fp, C.c_int32, _fp, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),
     "gnx_collapse_offsets": (C.c_int32, [C.c_void_p, _i64p]),
     "gnx_collapse_edges": (C.c_int32, [C.c_void_p, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),
+    "gnx_collapse_padded": (C.c_int32, [C.c_void_p, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),
     "gnx_xent_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "gnx_logit_cross_entropy": (C.c_int32, [_fp, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnx_logit_cross_entropy_backward": (C.c_int32, [_fp, _fp, C.c_int32, C.c_int64, _fp, _fp, C.c_void_p]),

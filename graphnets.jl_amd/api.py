@@ -26,7 +26,7 @@ from ._lib import GnxError, check
 __all__ = ["GNGraphBatch", "NT", "batch", "unbatch", "efview", "nfview", "gfview", "flatunpaddednf", "flatunpaddedef",
            "Dense", "Chain", "LayerNorm", "GNBlock", "GNCore", "GNCoreList", "GNFeedForward", "GNGraphNorm", "zerodim2nothing",
            "padded", "GnxError", "getedgefninput", "getnodefninput", "getgraphfninput",
-           "unpaddedcollapsedef", "flatunpaddedcollapsedef", "BlockPlan", "Graphed", "logitcrossentropy"]
+           "collapsef", "unpaddedcollapsedef", "flatunpaddedcollapsedef", "BlockPlan", "Graphed", "logitcrossentropy"]
 
 _KEYS = ("graphs", "ef", "nf", "gf")
 
@@ -431,6 +431,24 @@ def _collapse(t):
         out = torch.empty((R, int(off[-1]), D), dtype=torch.float32, device=g.device)
         check(lib.gnx_collapse_edges(g._h, c.data_ptr(), D, R, out.data_ptr(), torch.cuda.current_stream(g.device).cuda_stream))
     return _jl(out), off
+
+
+def collapsef(t):
+    """`collapsef` (gngraphbatch.jl:83-85): `batched_mul(ef, edge_collapser) / 2` — the padded array form (DE, PN(PN+1)/2, B): for every
+    coordinate (i, j), i >= j, of the padded grid in column-major order the symmetric average of slots i->j and j->i (the diagonal
+    keeps its slot).  Non-edge slots count as 0 (the reference reads whatever its padded array holds there)."""
+    t = _as_nt(t)
+    g, ef = t.graphs, t.ef
+    assert ef is not None, "collapsing needs edge features"
+    lib = _lib.load()
+    with torch.cuda.device(g.device):
+        c = _packed(ef)
+        R, _, D = c.shape
+        B = R if _shared_like(g) else g.n_graphs
+        PN = g.node_block_size
+        out = torch.empty((B, PN * (PN + 1) // 2, D), dtype=torch.float32, device=g.device)
+        check(lib.gnx_collapse_padded(g._h, c.data_ptr(), D, R, out.data_ptr(), torch.cuda.current_stream(g.device).cuda_stream))
+    return _jl(out)
 
 
 def unpaddedcollapsedef(t):

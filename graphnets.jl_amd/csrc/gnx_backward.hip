@@ -543,6 +543,12 @@ static int32_t colsum_all(const float* in, size_t rows, int d, float* out, float
 
 __global__ void k_set_off2(int* off2, int rows) { off2[0] = 0; off2[1] = rows; }
 
+// x <- act(x) in place (a gelu FeedForward keeps its pre-activation until delta1 is formed, then becomes the hidden layer)
+__global__ void k_act_inplace(float* __restrict__ x, size_t n, int act) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) x[idx] = act_apply(x[idx], act);
+}
+
 }  // namespace gnx
 
 using namespace gnx;
@@ -772,7 +778,7 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
   if ((!ef && h->E > 0) || !nf || !gf) return fail(GNX_ERR_INVALID_ARG, "GNCore needs ef, nf and gf");
   if (R <= 0 || (R > 1 && h->G != 1) || R > 65535) return fail(GNX_ERR_INVALID_ARG, "bad n_replicas");
   for (int t = 0; t < 3; ++t) {
-    if (p->ff[t].fc2.act != GNX_ACT_IDENTITY || p->ff[t].fc1.act == GNX_ACT_GELU) return fail(GNX_ERR_INVALID_ARG, "core backward: fc2 must be identity, fc1 not gelu");
+    if (p->ff[t].fc2.act != GNX_ACT_IDENTITY) return fail(GNX_ERR_INVALID_ARG, "core backward: fc2 must be identity");
   }
   const CoreBwLayout L = core_bw_layout(h, p, R);
   if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_core_backward_workspace_bytes()");
@@ -809,32 +815,56 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
       continue;
     }
     float* hbuf = F(L.h); float* dh = F(L.dh);
+    // gelu is not a function of its output: hbuf first holds the PRE-activation z1 = W1 z + b1, delta1 = dh .* gelu'(z1) is formed from
+    // it (act code 4 of the delta kernel = "out holds z"), then hbuf becomes h = gelu(z1) in place for dW2
+    const int act1 = p->ff[t].fc1.act;
+    const bool gelu1 = act1 == GNX_ACT_GELU;
+    gnx_dense fc1_re = p->ff[t].fc1;
+    if (gelu1) fc1_re.act = GNX_ACT_IDENTITY;
+    auto gelu_delta_then_hidden = [&]() {
+      DeltaArgs a{dh, hbuf, dh, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, H, (int)rows[t], 1, GNX_ACT_GELU, 0};
+      { ProfScope ps("bw_delta", s); launch_delta(a, 0, 0, 1, s); }
+      ProfScope ps("bw_gelu_hidden", s);
+      hipLaunchKernelGGL(k_act_inplace, blocks(rows[t] * H), dim3(256), 0, s, hbuf, rows[t] * (size_t)H, GNX_ACT_GELU);
+    };
     if (bw_use_mfma(rows[t], D, H)) {  // matrix cores (gnx_backward_wide.hip); rows[t] = R * (rows of entity t)
       float* wt = F(L.wt);
-      if ((rc = launch_dense_rows(h, t, F(L.l2[t]), D, p->ff[t].fc1, H, nullptr, nullptr, hbuf, R, s, "bw_ff1_recompute"))) return rc;
-      if ((rc = dw_auto(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, off2, s))) return rc;                     // dW2 = h^T g, db2
+      if ((rc = launch_dense_rows(h, t, F(L.l2[t]), D, fc1_re, H, nullptr, nullptr, hbuf, R, s, "bw_ff1_recompute"))) return rc;
+      if (!gelu1 && (rc = dw_auto(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, off2, s))) return rc;           // dW2 = h^T g, db2
       // delta1 = (g W2^T) .* act1'(h) in the GEMM epilogue, with per-tile column sums of delta1 for db1
       int n_tiles = 0;
       const bool dw1_mfma = bw_use_mfma_dw(rows[t], H, D);
-      float* tcs = gr.ff[t].fc1.bias && dw1_mfma ? F(L.tcs) : nullptr;
-      if ((rc = dx_mfma(h, t, gout[t], p->ff[t].fc2.weight, D, H, 0, H, dh, R, wt, true, s, "bw_dx_ff2", hbuf, p->ff[t].fc1.act, tcs, &n_tiles))) return rc;
+      float* tcs = gr.ff[t].fc1.bias && dw1_mfma && !gelu1 ? F(L.tcs) : nullptr;
+      if ((rc = dx_mfma(h, t, gout[t], p->ff[t].fc2.weight, D, H, 0, H, dh, R, wt, true, s, "bw_dx_ff2", gelu1 ? nullptr : hbuf, act1, tcs, &n_tiles))) return rc;
+      if (gelu1) {
+        gelu_delta_then_hidden();
+        if ((rc = dw_auto(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, off2, s))) return rc;
+      }
       if (dw1_mfma) rc = dw_mfma(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1.weight, part, s);                   // dW1 = z^T delta1
       else rc = dw_reduce(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1, part, s);                                   // (+ db1)
       if (rc) return rc;
       if (tcs) {
         ProfScope ps("bw_colsum_all", s);
         hipLaunchKernelGGL(k_bw_colsum_final, dim3((unsigned)((H + 63) / 64)), dim3(256), 0, s, tcs, H, (int)(R * n_tiles), gr.ff[t].fc1.bias);
+      } else if (gelu1 && dw1_mfma && gr.ff[t].fc1.bias) {
+        hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows[t]);
+        if ((rc = colsum_all(dh, rows[t], H, gr.ff[t].fc1.bias, part, off2, s))) return rc;
       }
       if ((rc = dx_mfma(h, t, dh, p->ff[t].fc1.weight, H, D, 0, D, dz2, R, wt, true, s, "bw_dx_ff1"))) return rc;        // dz2 = delta1 W1^T
       GNX_HIP(hipGetLastError());
       continue;
     }
     { ProfScope ps("bw_fw_dense_generic", s);
-    hipLaunchKernelGGL(k_fw_dense, blocks(rows[t] * H), dim3(256), 0, s, F(L.l2[t]), p->ff[t].fc1.weight, p->ff[t].fc1.bias, rows[t], D, H, p->ff[t].fc1.act, hbuf); }
-    if ((rc = dw_reduce(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, s))) return rc;                       // dW2 = g^T h
+    hipLaunchKernelGGL(k_fw_dense, blocks(rows[t] * H), dim3(256), 0, s, F(L.l2[t]), p->ff[t].fc1.weight, p->ff[t].fc1.bias, rows[t], D, H, fc1_re.act, hbuf); }
+    if (!gelu1 && (rc = dw_reduce(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, s))) return rc;             // dW2 = g^T h
     launch_bw_dx(dim3(blocks(rows[t] * H).x, 1), s, gout[t], p->ff[t].fc2.weight, (int)rows[t], D, H, dh, 0, 0, (float*)nullptr, 0);
-    DeltaArgs a{dh, hbuf, dh, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, H, (int)rows[t], 1, p->ff[t].fc1.act, 0};  // delta1 = dh * act1'(h), in place
-    hipLaunchKernelGGL(k_bw_delta, dim3(blocks(rows[t] * H).x, 1), dim3(256), 0, s, a, (size_t)0, (size_t)0);
+    if (gelu1) {
+      gelu_delta_then_hidden();
+      if ((rc = dw_reduce(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, s))) return rc;
+    } else {
+      DeltaArgs a{dh, hbuf, dh, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, H, (int)rows[t], 1, act1, 0};  // delta1 = dh * act1'(h), in place
+      hipLaunchKernelGGL(k_bw_delta, dim3(blocks(rows[t] * H).x, 1), dim3(256), 0, s, a, (size_t)0, (size_t)0);
+    }
     if ((rc = dw_reduce(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1, part, s))) return rc;                      // dW1 = delta1^T z
     launch_bw_dx(dim3(blocks(rows[t] * D).x, 1), s, dh, p->ff[t].fc1.weight, (int)rows[t], H, D, dz2, 0, 0, (float*)nullptr, 0);
     GNX_HIP(hipGetLastError());

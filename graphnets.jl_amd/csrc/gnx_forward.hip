@@ -20,6 +20,7 @@ int xent_blocks(int64_t cols);
 int32_t launch_xent_backward(const float* logits, const float* targets, int d, int64_t cols, const float* upstream, float* dl, hipStream_t s);
 int32_t launch_xent(const float* logits, const float* targets, int d, int64_t cols, float* out, float* ws, hipStream_t s);
 int32_t launch_collapse(const gnx_graphs* h, const float* ef, int d, int64_t R, float* out, hipStream_t s);
+int32_t launch_collapse_padded(const gnx_graphs* h, const float* ef, int d, int64_t R, float* out, hipStream_t s);
 int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, const float* nf, int dn, const float* gf, int dg,
                         int64_t R, float* out, hipStream_t s);
 // returns 1 when the path does not apply to these dims (caller falls through to the next path)
@@ -422,6 +423,13 @@ int32_t gnx_collapse_edges(const gnx_graphs* h, const float* ef, int32_t d, int6
   int32_t rc = gnx_ensure_collapse(h);
   if (rc) return rc;
   return launch_collapse(h, ef, d, R, out, (hipStream_t)stream);
+}
+
+int32_t gnx_collapse_padded(const gnx_graphs* h, const float* ef, int32_t d, int64_t R, float* out, void* stream) {
+  if (!h || !out || (!ef && h->E > 0)) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  if (d <= 0 || R <= 0 || (R > 1 && h->G != 1) || R > 65535 || h->G > 65535) return fail(GNX_ERR_INVALID_ARG, "bad d / n_replicas / more than 65535 graphs");
+  if ((size_t)h->PN * (h->PN + 1) / 2 * (size_t)d >= ((size_t)1 << 31) * 256) return fail(GNX_ERR_TOO_LARGE, "padded triangle too large");
+  return launch_collapse_padded(h, ef, d, R, out, (hipStream_t)stream);
 }
 
 int32_t gnx_fn_input(const gnx_graphs* h, int32_t kind, const float* ef, int32_t de, const float* nf, int32_t dn, const float* gf,

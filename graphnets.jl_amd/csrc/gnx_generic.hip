@@ -510,6 +510,58 @@ int32_t launch_collapse(const gnx_graphs* h, const float* ef, int d, int64_t R, 
   return GNX_OK;
 }
 
+// collapsef, the padded array form (gngraphbatch.jl:83-85 with the edge_collapser of :67-82): for every coordinate (i, j), i >= j, of
+// the PN x PN lower triangle, in column-major order (l = j*PN - j(j-1)/2 + (i - j)), out[b][l][:] = (P[i->j] + P[j->i]) / 2 where P is
+// the zero-padded edge grid (a self loop gives P[i->i]).  Edge i->j of a graph is found by binary search in column j of its CSC.
+__device__ __forceinline__ int find_edge(const int* __restrict__ colptr, const int* __restrict__ rowval, int src, int dst) {
+  int lo = colptr[dst], hi = colptr[dst + 1];
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (rowval[mid] < src) lo = mid + 1; else hi = mid;
+  }
+  return lo < colptr[dst + 1] && rowval[lo] == src ? lo : -1;
+}
+__global__ void k_collapse_padded(const int* __restrict__ colptr, const int* __restrict__ rowval, const int* __restrict__ node_off, int G, int PN,
+                                  int shared, int d, int E, const float* __restrict__ ef, float* __restrict__ out) {
+  const size_t L = (size_t)PN * (PN + 1) / 2;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t b = blockIdx.y;  // graph of the batch, or replica of the shared graph
+  if (idx >= L * d) return;
+  const size_t l = idx / d;
+  const int k = (int)(idx % d);
+  // column j of the triangle: the largest j with j*PN - j(j-1)/2 <= l
+  int j = (int)(((2.0 * PN + 1.0) - sqrt((2.0 * PN + 1.0) * (2.0 * PN + 1.0) - 8.0 * (double)l)) / 2.0);
+  j = j < 0 ? 0 : (j > PN - 1 ? PN - 1 : j);
+  while (j > 0 && (size_t)j * PN - (size_t)j * (j - 1) / 2 > l) --j;
+  while (j + 1 < PN && (size_t)(j + 1) * PN - (size_t)(j + 1) * j / 2 <= l) ++j;
+  const int i = j + (int)(l - ((size_t)j * PN - (size_t)j * (j - 1) / 2));
+  const int g = shared ? 0 : (int)b;
+  const int n0 = node_off[g], nn = node_off[g + 1] - n0;
+  const float* base = ef + (shared ? b * (size_t)E * d : 0);
+  float v = 0.f;
+  if (i < nn && j < nn) {
+    const int e1 = find_edge(colptr, rowval, n0 + i, n0 + j);
+    if (i == j) {
+      if (e1 >= 0) v = base[(size_t)e1 * d + k];
+    } else {
+      const int e2 = find_edge(colptr, rowval, n0 + j, n0 + i);
+      v = ((e1 >= 0 ? base[(size_t)e1 * d + k] : 0.f) + (e2 >= 0 ? base[(size_t)e2 * d + k] : 0.f)) / 2.f;
+    }
+  }
+  out[b * L * d + idx] = v;
+}
+
+int32_t launch_collapse_padded(const gnx_graphs* h, const float* ef, int d, int64_t R, float* out, hipStream_t s) {
+  const size_t L = (size_t)h->PN * (h->PN + 1) / 2;
+  const bool shared = R > 1;
+  const size_t B = shared ? (size_t)R : (size_t)h->G;
+  if (L == 0 || B == 0) return GNX_OK;
+  hipLaunchKernelGGL(k_collapse_padded, dim3((unsigned)((L * d + 255) / 256), (unsigned)B), dim3(256), 0, s, h->d_colptr, h->d_rowval, h->d_node_off,
+                     (int)h->G, (int)h->PN, shared ? 1 : 0, d, (int)h->E, ef, out);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // readout: logitcrossentropy over packed columns (examples/sort/sort.jl:69-81)
 // ---------------------------------------------------------------------------------------------------------

@@ -387,7 +387,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
   // return only when the HBM queues reach them behind the edge rows EVERY wave requested in the first microsecond (46 MB at
   // ~4.5 TB/s).  Requesting the indices ahead of the edge rows, so that in-order vmcnt lets the gathers go out while the rows still
   // stream, changes nothing measurable (25.4 vs 26.4 us/step): the indices of a late-dispatched wave still queue behind the rows
-  // of the earlier ones.)
+  // of the earlier ones.  Round 2 also HELD the edge rows back until the indices had arrived (indices -> wait -> gathers + rows in one
+  // burst, so that the gather's round trip runs under the row stream): slower everywhere — C2 25.9 vs 25.3 us/step, 512 graphs 21.6 vs
+  // 20.8, 4096 graphs 25.2 vs 24.9 (profiles/r02_ab_hold_rows.log): the extra dependent round trip at the start costs more than the
+  // overlap returns.)
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
     int ec = lane + 64 * i;

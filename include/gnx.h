@@ -215,8 +215,9 @@ GNX_API int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* 
 
 /* Backward of (m::GNCore)(x) = x + block(gn1(x)) + ffwd(gn2(x)) (src/gncore.jl:56-68).  Takes the forward's INPUTS and the
  * upstream gradients; the intermediates (both LayerNorms, the block's outputs, the FeedForward hidden activations) are
- * recomputed into the workspace.  Gradient buffers are optional (NULL = not wanted) and overwritten.  FeedForward: fc1 with
- * identity / relu / tanh / sigmoid, fc2 with identity (the reference's Chain(Dense(d,4d,relu), Dense(4d,d))). */
+ * recomputed into the workspace.  Gradient buffers are optional (NULL = not wanted) and overwritten.  FeedForward: fc1 with any
+ * activation code (gelu differentiates from the recomputed pre-activation), fc2 with identity (the reference's
+ * Chain(Dense(d,4d,relu), Dense(4d,d))). */
 typedef struct gnx_layernorm_grad {
   float* gamma;
   float* beta;
@@ -264,6 +265,11 @@ GNX_API int32_t gnx_fn_input(const gnx_graphs* h, int32_t kind, const float* ef,
  * gnx_collapse_edges:   out [R][total][d] from ef [R][E][d]. */
 GNX_API int32_t gnx_collapse_offsets(const gnx_graphs* h, int64_t* off);
 GNX_API int32_t gnx_collapse_edges(const gnx_graphs* h, const float* ef, int32_t d, int64_t n_replicas, float* out, void* stream);
+/* collapsef itself (src/gngraphbatch.jl:83-85: batched_mul(ef, edge_collapser) / 2 with the collapser of :67-82), the PADDED array
+ * form: out [B][L][d], B = graphs of the batch (or n_replicas of a shared graph), L = PN(PN+1)/2 coordinates (i, j), i >= j, of the
+ * padded PN x PN grid in column-major order; out[b][l] = (P[i->j] + P[j->i]) / 2 over the zero-padded edge grid P (P[i->i] on the
+ * diagonal).  = Julia (d, L, B).  The reference reads whatever its padded array holds in non-edge slots; here they are 0. */
+GNX_API int32_t gnx_collapse_padded(const gnx_graphs* h, const float* ef, int32_t d, int64_t n_replicas, float* out, void* stream);
 
 /* ---- readout loss on packed outputs: Flux.logitcrossentropy(yhat, y) over the columns of
  * flatunpaddednf / flatunpaddedef, as used by the reference's only end-to-end workload (examples/sort/sort.jl:69-81):

@@ -14,6 +14,7 @@ module GraphNetsHIP
 
 export GNGraphBatch, GNBlock, GNCore, GNCoreList, Dense, LayerNorm, batch, unbatch,
        efview, nfview, gfview, flatunpaddednf, flatunpaddedef, zerodim2nothing,
+       collapsef, unpaddedcollapsedef, flatunpaddedcollapsedef,
        block_pullback, Model, partition_graphs, DistBlock
 
 const libgnx = get(ENV, "GNX_LIB", joinpath(@__DIR__, "..", "graphnets.jl_amd", "libgnx.so"))
@@ -138,6 +139,38 @@ gfview(t::NamedTuple, d1, d2) = isnothing(t.gf) ? nothing :
     sharedlike(t.graphs) ? view(t.gf, d1, 1, d2) : view(t.gf, d1, d2, 1)
 flatunpaddednf(t::NamedTuple) = reshape(t.nf, size(t.nf, 1), :)       # the packed layout already is it (views.jl:80-88)
 flatunpaddedef(t::NamedTuple) = reshape(t.ef, size(t.ef, 1), :)
+
+# ---- edge collapsing (src/gngraphbatch.jl:56-111) → gnx_collapse_padded / gnx_collapse_offsets / gnx_collapse_edges ----
+function collapsef(t::NamedTuple)                                      # (DE, PN(PN+1)/2, B), padded array form
+    g = t.graphs; ef = t.ef
+    D, R = size(ef, 1), size(ef, 3)
+    B = sharedlike(g) ? R : ngraphs(g)
+    PN = g.node_block_size
+    out = zeros(Float32, D, PN * (PN + 1) ÷ 2, B)
+    d_ef, b_out = upload(ef), DevBuf(sizeof(out))
+    GC.@preserve d_ef b_out check(ccall((:gnx_collapse_padded, libgnx), Int32, (Ptr{Cvoid}, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cvoid}),
+        g.handle, devptr(d_ef), D, R, devptr(b_out), C_NULL))
+    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
+    download!(out, b_out)
+end
+function collapsed_packed(t::NamedTuple)                               # (DE, total, R) over the real lower-triangle edges + offsets
+    g = t.graphs; ef = t.ef
+    D, R = size(ef, 1), size(ef, 3)
+    off = zeros(Int64, ngraphs(g) + 1)
+    check(ccall((:gnx_collapse_offsets, libgnx), Int32, (Ptr{Cvoid}, Ptr{Int64}), g.handle, off))
+    out = zeros(Float32, D, Int(off[end]), R)
+    d_ef, b_out = upload(ef), DevBuf(max(sizeof(out), 4))
+    GC.@preserve d_ef b_out check(ccall((:gnx_collapse_edges, libgnx), Int32, (Ptr{Cvoid}, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cvoid}),
+        g.handle, devptr(d_ef), D, R, devptr(b_out), C_NULL))
+    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
+    download!(out, b_out), off
+end
+function unpaddedcollapsedef(t::NamedTuple)                            # gngraphbatch.jl:87-107
+    out, off = collapsed_packed(t)
+    sharedlike(t.graphs) ? [view(out, :, :, b) for b in 1:size(out, 3)] :
+        [view(out, :, (off[i]+1):off[i+1], 1) for i in 1:ngraphs(t.graphs)]
+end
+flatunpaddedcollapsedef(t::NamedTuple) = reduce(hcat, unpaddedcollapsedef(t))   # gngraphbatch.jl:109-111
 zerodim2nothing(t::NamedTuple) = (graphs=t.graphs, ef=t.ef, nf=t.nf, gf=t.gf)  # zero-width outputs are already `nothing`
 
 # ---- layers ----

@@ -202,6 +202,42 @@ class DenseGraphBatch:
             self.flat_edge_unpadder[b * PN * PN: (b + 1) * PN * PN] = self.padded_adj_mats[:, :, b].flatten(order="F") == 1.0
 
 
+def getlowertriangularcoords(n):
+    """gngraphbatch.jl:56-58: CartesianIndices of an n x n matrix with i >= j, in column-major order (0-based pairs)."""
+    return [(i, j) for j in range(n) for i in range(n) if i >= j]
+
+
+def getedgecollapser(n):
+    """gngraphbatch.jl:67-82: (n^2, n(n+1)/2) matrix; column of coordinate (i, j) has a one at slots (i,j) and (j,i) of the
+    column-major n x n grid — a two on the diagonal, since the reference adds both."""
+    coords = getlowertriangularcoords(n)
+    m = np.zeros((n * n, len(coords)), dtype=F64)
+    for c, (i, j) in enumerate(coords):
+        m[i + n * j, c] += 1
+        m[j + n * i, c] += 1
+    return m
+
+
+def getcollapsededgeidxs(padded):
+    """gngraphbatch.jl:60-65: per graph, positions (0-based) within the lower-triangle coordinate list whose adjacency entry is one."""
+    coords = getlowertriangularcoords(padded.shape[0])
+    return [np.array([c for c, (i, j) in enumerate(coords) if padded[i, j, b] == 1.0], dtype=np.int64) for b in range(padded.shape[2])]
+
+
+def collapsef_dense(x):
+    """gngraphbatch.jl:83-85: batched_mul(graph.ef, graph.graphs.edge_collapser) / Float32(2) on the padded (DE, PN^2, B) array."""
+    return batched_mul(x["ef"], getedgecollapser(x["graphs"].node_block_size)) / 2.0
+
+
+def unpaddedcollapsedef_dense(x):
+    """gngraphbatch.jl:87-107: per batch element, the collapsed columns of the real lower-triangle edges."""
+    c = collapsef_dense(x)
+    idxs = getcollapsededgeidxs(x["graphs"].padded_adj_mats)
+    if len(idxs) == 1:  # shared adjacency: one index list for every batch element
+        return [c[:, idxs[0], b] for b in range(c.shape[2])]
+    return [c[:, idxs[b], b] for b in range(c.shape[2])]
+
+
 def batched_mul(A, Bm):
     """NNlib.batched_mul: C[:,:,k] = A[:,:,k] * B[:,:,k]; a size-1 batch on either side broadcasts."""
     if A.ndim == 2:

@@ -200,12 +200,20 @@ def test_core_backward_matches_torch_autograd(gn, dims, big, eps_mode):
     pytest.fail("no kink-free draw in 20 attempts")
 
 
-def _core_backward_case(gn, dims, big, eps_mode, rng):
+@pytest.mark.parametrize("dims,big", [((10, 5, 3), False), ((40, 36, 33), True), ((64, 32, 16), True)], ids=lambda v: str(v))
+def test_core_backward_with_a_gelu_feedforward(gn, dims, big):
+    """A FeedForward whose hidden activation is gelu (not a function of its output: the pullback keeps the recomputed
+    pre-activation until delta1 is formed) — generic and matrix-core forms against torch float64 autograd."""
+    assert _core_backward_case(gn, dims, big, 0, np.random.default_rng(450 + sum(dims)), hidden_act="gelu")
+
+
+def _core_backward_case(gn, dims, big, eps_mode, rng, hidden_act=None):
     sizes, cps, rvs = _graphs(rng, big)
     g = gn.GNGraphBatch.from_csc(cps, rvs, [int(n) for n in sizes])
     csc = (*g.csc(), g.node_off, g.edge_off)
     p = O.make_core_params(rng, dims, eps_mode=eps_mode)
-    hidden_act = "tanh" if big else "relu"
+    hidden_act = hidden_act or ("tanh" if big else "relu")
+    hidden_fn = {"tanh": torch.tanh, "relu": torch.relu, "gelu": ACT[4]}[hidden_act]
     ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims)
     # reference
     T = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
@@ -219,9 +227,9 @@ def _core_backward_case(gn, dims, big, eps_mode, rng):
     for x, z, b, t in zip(xs, l2, blk, "eng"):
         zh = z @ W[f"ff_{t}_W1"].T + W[f"ff_{t}_b1"]
         pre.append(zh)
-        hdn = torch.tanh(zh) if big else torch.relu(zh)
+        hdn = hidden_fn(zh)
         outs_r.append(x + b + hdn @ W[f"ff_{t}_W2"].T + W[f"ff_{t}_b2"])
-    if not big and not _kink_free(pre):
+    if hidden_act == "relu" and not _kink_free(pre):
         return False
     cot = [torch.from_numpy(rng.standard_normal(tuple(o.shape))) for o in outs_r]
     sum((o * c).sum() for o, c in zip(outs_r, cot)).backward()

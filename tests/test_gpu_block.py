@@ -338,6 +338,30 @@ def test_edge_collapsing(gn):
     np.testing.assert_allclose(gn.flatunpaddedcollapsedef(x).cpu().numpy(), [[1.0, 2.0]])
 
 
+def test_collapsef_padded_array_form(gn):
+    """collapsef (gngraphbatch.jl:83-85) as the padded (DE, PN(PN+1)/2, B) array: against the oracle's literal edge_collapser matmul
+    on random adjacency matrices of different sizes (one-way edges, missing self loops, pad rows), vector and shared mode."""
+    rng = np.random.default_rng(92)
+    adjs = [(rng.random((n, n)) < 0.5).astype(int) for n in (1, 4, 7, 3)]
+    efs = [rng.random((3, int(a.sum())), dtype=np.float32) for a in adjs]
+    got = gn.collapsef(gn.batch(dict(graphs=adjs, ef=efs, nf=None, gf=None))).cpu().numpy()
+    ref = O.collapsef_dense(O.batch_dense(adjs, efs, None, None))
+    assert got.shape == ref.shape == (3, 28, 4)
+    np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7)
+    adj = adjs[2]
+    ef = rng.random((3, int(adj.sum()), 5), dtype=np.float32)  # shared adjacency, batch of 5
+    got = gn.collapsef(gn.batch(dict(graphs=adj, ef=ef, nf=None, gf=None))).cpu().numpy()
+    ref = O.collapsef_dense(O.batch_dense(adj, ef, None, None))
+    assert got.shape == ref.shape == (3, 28, 5)
+    np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-7)
+    # unpaddedcollapsedef = the real lower-triangle columns of collapsef
+    x = gn.batch(dict(graphs=adjs, ef=efs, nf=None, gf=None))
+    full = gn.collapsef(x).cpu().numpy()
+    idxs = O.getcollapsededgeidxs(O.padadjmats([a.astype(float) for a in adjs]))
+    for b, part in enumerate(gn.unpaddedcollapsedef(x)):
+        np.testing.assert_allclose(part.cpu().numpy(), full[:, idxs[b], b], rtol=1e-6, atol=1e-7)
+
+
 def test_device_side_batch_construction(gn):
     """large dense batches are scanned/compacted into CSC on the GPU (gnx_build_device.hip).  The result must
     equal the oracle's column-major edge order (pad.jl:30) for row-major (numpy) and column-major (Julia) input alike,

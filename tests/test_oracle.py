@@ -310,3 +310,23 @@ def test_chain_oracle_reduces_to_the_block_for_one_layer_chains():
     for u, v, su, sv in zip(a, b, sa, sb):
         np.testing.assert_allclose(u, v, rtol=0, atol=1e-13)
         np.testing.assert_allclose(su, sv, rtol=1e-5)
+
+
+def test_edge_collapsing_restatement_satisfies_the_reference_test():
+    """test/runtests.jl:4-59 on the oracle's literal restatement (edge_collapser matmul, gngraphbatch.jl:56-111): the relations the
+    reference asserts between flatunpaddedcollapsedef and the raw padded slots of two stacked blocks on fully connected graphs."""
+    rng = np.random.default_rng(91)
+    enc, dec = O.make_block_params(rng, (0, 2, 0), (2, 2, 2)), O.make_block_params(rng, (2, 2, 2), (2, 2, 2))
+    A, B = np.ones((2, 2)), np.ones((3, 3))
+    x = O.batch_dense([A, B], None, [rng.random((2, 2)), rng.random((2, 3))], None)
+    y = O.block_forward_dense(dec, O.block_forward_dense(enc, x))
+    flat = np.concatenate(O.unpaddedcollapsedef_dense(y), axis=1)
+    ef = y["ef"]
+    s = lambda slot, g: ef[:, slot - 1, g]
+    expect = [s(1, 0), (s(2, 0) + s(4, 0)) / 2, s(5, 0),
+              s(1, 1), (s(2, 1) + s(4, 1)) / 2, (s(3, 1) + s(7, 1)) / 2, s(5, 1), (s(6, 1) + s(8, 1)) / 2, s(9, 1)]
+    assert flat.shape == (2, 9)
+    for c, e in enumerate(expect):
+        np.testing.assert_allclose(flat[:, c], e, rtol=1e-12, atol=1e-12)
+    assert O.collapsef_dense(y).shape == (2, 6, 2)
+    assert O.getedgecollapser(3).shape == (9, 6) and O.getedgecollapser(3)[:, 0].tolist() == [2, 0, 0, 0, 0, 0, 0, 0, 0]
