@@ -1,8 +1,9 @@
 // GNCore at narrow widths (d <= 16, e.g. README ex.3's core_dims (10,5,3)): the parts around the block.
 //   k_ln1_rows<D>  : gn1(x) — LayerNorm over the feature dim of every row (gngraphnorm.jl:19-26); one THREAD per row
-//   k_core_post<D> : out = x + block_out + FeedForward(gn2(x))  (gncore.jl:56-68, gnfeedforward.jl:27-40) in one pass:
-//                    gn2 is recomputed in registers (same mean/std as gn1), the 4D hidden units are produced and consumed
-//                    one at a time (never stored), weights are wave-uniform scalar operands.
+//   k_core_post<D> / k_core_post_s<D> : out = x + block_out + FeedForward(gn2(x))  (gncore.jl:56-68, gnfeedforward.jl:27-40) in one
+//                    pass: gn2 is recomputed in registers (same mean/std as gn1), the 4D hidden units are produced and consumed
+//                    in registers (never stored).  Weights: LDS broadcast (k_core_post; one row per thread, small batches) or
+//                    hand-streamed scalar operands of packed FMAs (k_core_post_s; two rows per thread).
 // At d = 10 a wave-per-row kernel keeps 54 of 64 lanes idle and the hidden tile bounced through LDS; here a row is
 // D registers of one lane and the kernel is a pure stream: x in, (block_out in,) out.
 #include "gnx_device.h"
@@ -114,7 +115,223 @@ __global__ __launch_bounds__(256) void k_core_post(const float* __restrict__ x, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weights as SCALAR operands, streamed by hand.  Left to the compiler, scalar weight loads are hoisted until the SGPR file spills;
+// staged in LDS (k_core_post above), every broadcast ds_read_b128 still moves 64 x 16 B and the LDS runs exactly as long as the
+// VALU (22 reads per 176 FMAs at M = 2: 704 LDS clocks per 704 VALU clocks over four SIMDs).  Here a GROUP of N consecutive
+// weights is fetched by s_load_dwordx{16,8,4,2} issued from inline asm — volatile asm statements keep their order, so the
+// compiler can neither hoist nor merge them — into one of two register sets: the next group is in flight while the FMAs of the
+// current one run (scalar loads return out of order, so the only wait is lgkmcnt(0), placed BEFORE the next issue), and the FMAs
+// take the weight as their SGPR operand.  No LDS, no workgroup barrier, 4*D live weight registers.
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef float v8f_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+
+template <int N>
+struct SGroup {  // N (even, <= 32) consecutive floats held in SGPRs
+  static_assert(N % 2 == 0 && N >= 2 && N <= 32, "group size");
+  static constexpr int N16 = N / 16, N8 = (N % 16) / 8, N4 = (N % 8) / 4, N2 = (N % 4) / 2;
+  v16f_t a, b; v8f_t c; v4f_t d; v2f_t e;
+  __device__ __forceinline__ void issue(cfloatp p) {
+    if constexpr (N16 >= 1) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(a) : "s"(p));
+    if constexpr (N16 >= 2) asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(b) : "s"(p));
+    if constexpr (N8 == 1) asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(c) : "s"(p), "n"(64 * N16));
+    if constexpr (N4 == 1) asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(d) : "s"(p), "n"(64 * N16 + 32 * N8));
+    if constexpr (N2 == 1) asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(e) : "s"(p), "n"(64 * N16 + 32 * N8 + 16 * N4));
+  }
+  // every use of the group is ordered behind this: ONE s_waitcnt, the other pieces are tied to the volatile order by empty statements
+  __device__ __forceinline__ void wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (N16 >= 1) asm volatile("" : "+s"(a));
+    if constexpr (N16 >= 2) asm volatile("" : "+s"(b));
+    if constexpr (N8 == 1) asm volatile("" : "+s"(c));
+    if constexpr (N4 == 1) asm volatile("" : "+s"(d));
+    if constexpr (N2 == 1) asm volatile("" : "+s"(e));
+  }
+  __device__ __forceinline__ v2f_t pair(int q) const {  // floats 2q, 2q+1 = an aligned SGPR pair of the group's registers; q constant
+    v2f_t r;
+    r.x = get(2 * q); r.y = get(2 * q + 1);
+    return r;
+  }
+  __device__ __forceinline__ float get(int i) const {  // i is a constant once the loops are unrolled
+    if (i < 16 * N16) return i < 16 ? a[i & 15] : b[i & 15];
+    i -= 16 * N16;
+    if (i < 8 * N8) return c[i & 7];
+    i -= 8 * N8;
+    if (i < 4 * N4) return d[i & 3];
+    i -= 4 * N4;
+    return e[i & 1];
+  }
+};
+
+// out = x + block_out + W2 act(W1 gn2(x) + b1) + b2, TWO rows per thread held as register pairs: every FMA is one v_pk_fma_f32
+// whose src0 is the SGPR pair holding the weight (op_sel picks its low or high half for both rows) — half the VALU issue of scalar FMAs.
+// The hidden layer is produced and consumed in two halves of HB = 2D units; the weight stream of a half is [b1 half | D rows of W1
+// (2D consecutive hidden units of input k) | D row PAIRS of W2 (2D consecutive floats: hidden units 2g, 2g+1)], every group 2D floats
+// = 2D packed FMAs.  The 2(2D+1) groups are walked by a compile-time recursion (GI = global group index: half, position and
+// register set are constants of each step).  The FMAs are (non-volatile) asm statements too: left as C, the vectoriser packs them
+// itself — with the weight copied into a VGPR pair first — and collects them behind the loads of ALL groups (800 spilled SGPRs).
+typedef v2f_t P2;  // (row 0, row 1) of a lane
+template <bool HI>
+__device__ __forceinline__ void pk_fma_sw(P2& acc, v2f_t wpair, P2 x) {  // acc += w * x, w = low / high half of the SGPR pair
+  if constexpr (!HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(wpair), "v"(x));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(wpair), "v"(x));
+}
+// ties N register pairs into the order of the volatile statements (no instruction)
+template <int N, int O = 0>
+__device__ __forceinline__ void pin_pairs(P2 (&v)[N]) {
+  if constexpr (O + 8 <= N) {
+    asm volatile("" : "+v"(v[O]), "+v"(v[O + 1]), "+v"(v[O + 2]), "+v"(v[O + 3]), "+v"(v[O + 4]), "+v"(v[O + 5]), "+v"(v[O + 6]), "+v"(v[O + 7]));
+    pin_pairs<N, O + 8>(v);
+  } else if constexpr (O + 4 <= N) {
+    asm volatile("" : "+v"(v[O]), "+v"(v[O + 1]), "+v"(v[O + 2]), "+v"(v[O + 3]));
+    pin_pairs<N, O + 4>(v);
+  } else if constexpr (O + 2 <= N) {
+    asm volatile("" : "+v"(v[O]), "+v"(v[O + 1]));
+    pin_pairs<N, O + 2>(v);
+  } else if constexpr (O + 1 <= N) {
+    asm volatile("" : "+v"(v[O]));
+  }
+}
+
+// TRANS = false: both activations are identity / relu (the reference's FeedForward) — the tanh / sigmoid / gelu expansions of a run-time
+// activation switch cost ~60 registers on every path, relu's included.
+template <int D, bool TRANS>
+struct CorePostStream {
+  static constexpr int H = 4 * D, HB = 2 * D, NG = 2 * D + 1, TOTAL = 2 * NG;
+  cfloatp W1, W2, b1;
+  int act1;
+  P2 (&z)[D];
+  P2 (&acc)[D];
+  P2 h[HB];
+  SGroup<HB> G0, G1;
+
+  template <int GI>
+  __device__ __forceinline__ cfloatp group_ptr() const {
+    constexpr int p = GI / NG, i = GI % NG;
+    if constexpr (i == 0) return b1 + p * HB;
+    else if constexpr (i <= D) return W1 + (i - 1) * H + p * HB;
+    else return W2 + (p * HB + 2 * (i - D - 1)) * D;
+  }
+  template <int GI>
+  __device__ __forceinline__ void consume(const SGroup<HB>& cur) {
+    constexpr int i = GI % NG;
+    if constexpr (i == 0) {
+#pragma unroll
+      for (int j = 0; j < HB; ++j) { const float b = cur.get(j); h[j].x = b; h[j].y = b; }
+      pin_pairs<HB>(h);
+    } else if constexpr (i <= D) {
+      constexpr int k = i - 1;
+#pragma unroll
+      for (int q = 0; q < HB / 2; ++q) {
+        const v2f_t w = cur.pair(q);
+        pk_fma_sw<false>(h[2 * q], w, z[k]);
+        pk_fma_sw<true>(h[2 * q + 1], w, z[k]);
+      }
+      if constexpr (i == D) {
+        if constexpr (TRANS) {
+          float t[HB];
+#pragma unroll
+          for (int j = 0; j < HB; ++j) t[j] = h[j].x;
+          act_row<HB>(t, act1);
+#pragma unroll
+          for (int j = 0; j < HB; ++j) { h[j].x = t[j]; t[j] = h[j].y; }
+          act_row<HB>(t, act1);
+#pragma unroll
+          for (int j = 0; j < HB; ++j) h[j].y = t[j];
+        } else if (act1 == 1) {
+#pragma unroll
+          for (int j = 0; j < HB; ++j) { h[j].x = fmaxf(h[j].x, 0.f); h[j].y = fmaxf(h[j].y, 0.f); }
+        }
+      }
+      pin_pairs<HB>(h);
+    } else {
+      constexpr int j = 2 * (i - D - 1);
+#pragma unroll
+      for (int q = 0; q < D; ++q) {  // pair q = weights 2q, 2q+1 of [W2 row j | W2 row j+1]
+        const v2f_t w = cur.pair(q);
+        pk_fma_sw<false>(acc[(2 * q) % D], w, h[j + (2 * q) / D]);
+        pk_fma_sw<true>(acc[(2 * q + 1) % D], w, h[j + (2 * q + 1) / D]);
+      }
+      pin_pairs<D>(acc);
+    }
+  }
+  template <int GI>
+  __device__ __forceinline__ void run() {
+    if constexpr (GI < TOTAL) {
+      if constexpr (GI % 2 == 0) {
+        G0.wait();
+        if constexpr (GI + 1 < TOTAL) G1.issue(group_ptr<GI + 1>());
+        __builtin_amdgcn_sched_barrier(0);
+        consume<GI>(G0);
+      } else {
+        G1.wait();
+        if constexpr (GI + 1 < TOTAL) G0.issue(group_ptr<GI + 1>());
+        __builtin_amdgcn_sched_barrier(0);
+        consume<GI>(G1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      run<GI + 1>();
+    }
+  }
+};
+
+template <int D, bool TRANS>
+__global__ __launch_bounds__(256) void k_core_post_s(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2,
+                                                     gnx_dense fc1, gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out) {
+  constexpr int M = 2;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t row0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (row0 >= rows) return;
+  const cfloatp b2 = as_const(fc2.bias ? fc2.bias : k_zero_bias), g2 = as_const(gamma2), be2 = as_const(beta2);
+  P2 z[D], acc[D];
+  CorePostStream<D, TRANS> st{as_const(fc1.weight), as_const(fc2.weight), as_const(fc1.bias ? fc1.bias : k_zero_bias), fc1.act, z, acc};
+  st.G0.issue(st.template group_ptr<0>());
+  float rs[M][D];
+  size_t row[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const size_t rm = row0 + m * stride;
+    row[m] = rm < rows ? rm : row0;  // clamped: a lane without a second row recomputes its first one (its store is skipped)
+    float zr[D], blk[D];
+    load_row<D>(x + row[m] * D, zr);
+    load_row<D>(out + row[m] * D, blk);  // block(gn1(x)) written by the block forward
+#pragma unroll
+    for (int k = 0; k < D; ++k) rs[m][k] = zr[k] + blk[k];  // the two residual terms (gncore.jl:56-59)
+    normalise<D>(zr, eps, eps_mode);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const float v = fmaf(g2[k], zr[k], be2[k]);
+      if (m == 0) { z[k].x = v; acc[k].x = b2[k]; } else { z[k].y = v; acc[k].y = b2[k]; }
+    }
+  }
+  pin_pairs<D>(z);
+  pin_pairs<D>(acc);
+  st.template run<0>();
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    float o[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) o[k] = m == 0 ? acc[k].x : acc[k].y;
+    if constexpr (TRANS) act_row<D>(o, fc2.act);
+    else if (fc2.act == 1) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) o[k] = fmaxf(o[k], 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) o[k] = rs[m][k] + o[k];
+    if (m == 0 || row0 + m * stride < rows) store_row<D>(out + row[m] * D, o);
+  }
+}
+
+#ifdef GNX_CORE_FEW
+#define GNX_CORE_WIDTHS(X) X(3) X(5) X(10)
+#else
 #define GNX_CORE_WIDTHS(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#endif
 
 bool core_narrow_width(int d) { return d >= 1 && d <= 16; }
 
@@ -138,11 +355,15 @@ int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm
   ProfScope ps("k_core_post", s);
   const char* e = getenv("GNX_CORE_POST_ROWS");
   const int M = (e ? atoi(e) : 2) == 2 && rows >= 65536 ? 2 : 1;  // two rows per thread once there are rows to spare
+  static const bool lds_weights = getenv("GNX_CORE_POST_LDS") != nullptr;  // A/B: the LDS-broadcast form
+  const bool trans = ff.fc1.act > GNX_ACT_RELU || ff.fc2.act > GNX_ACT_RELU;
   const dim3 grid((unsigned)((rows + 256 * (size_t)M - 1) / (256 * (size_t)M)));
   switch (d) {
 #define GNX_CASE(D)                                                                                                                                  \
   case D:                                                                                                                                            \
-    if (M == 2) hipLaunchKernelGGL((k_core_post<D, 2>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out);      \
+    if (!lds_weights && M == 2 && trans) hipLaunchKernelGGL((k_core_post_s<D, true>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out); \
+    else if (!lds_weights && M == 2) hipLaunchKernelGGL((k_core_post_s<D, false>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out); \
+    else if (M == 2) hipLaunchKernelGGL((k_core_post<D, 2>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out); \
     else hipLaunchKernelGGL((k_core_post<D, 1>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out);             \
     break;
     GNX_CORE_WIDTHS(GNX_CASE)
