@@ -48,6 +48,10 @@ class DenseGrad(C.Structure):
     _fields_ = [("weight", _fp), ("bias", _fp)]
 
 
+class ChainBlockGrads(C.Structure):
+    _fields_ = [("edgefn", C.POINTER(DenseGrad)), ("nodefn", C.POINTER(DenseGrad)), ("graphfn", C.POINTER(DenseGrad))]
+
+
 class BlockGrads(C.Structure):
     _fields_ = [("edgefn", DenseGrad), ("nodefn", DenseGrad), ("graphfn", DenseGrad)]
 
@@ -108,6 +112,9 @@ SIGNATURES = {
     "gnx_block_forward": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + _FWD[2:]),
     "gnx_chain_block_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(ChainBlockParams), C.c_int64]),
     "gnx_chain_block_forward": (C.c_int32, [C.c_void_p, C.POINTER(ChainBlockParams)] + _FWD[2:]),
+    "gnx_chain_block_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(ChainBlockParams), C.c_int64]),
+    "gnx_chain_block_backward": (C.c_int32, [C.c_void_p, C.POINTER(ChainBlockParams)] + [_fp] * 6 + [C.c_int64] + [_fp] * 3 +
+                                 [C.POINTER(ChainBlockGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnx_block_graph_update": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams), _fp, C.c_int64, _fp, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "gnx_block_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BlockParams), C.c_int64]),
     "gnx_block_backward": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + [_fp] * 9 + [C.c_int64] + [_fp] * 3 +

@@ -661,24 +661,26 @@ class GNBlock:
     def _as_chain(self, fn):
         return fn if isinstance(fn, Chain) else Chain(fn)
 
-    def _call_chains(self, x, flags):
-        """Update functions that are multi-layer Chains: gnx_chain_block_forward (forward only)."""
-        g, ef, nf, gf, R = _forward_common(x, self.in_dims)
-        lib = _lib.load()
+    def _chain_params(self, keep):
+        """gnx_chain_block_params of this block's update functions (each a Chain of Dense layers) + the chains themselves."""
         chains = [self._as_chain(f) for f in (self.edgefn, self.nodefn, self.graphfn)]
-        keep = []
         p = _lib.ChainBlockParams()
         p.de, p.dn, p.dg = self.in_dims
         outw = []
         for name, ch in zip(("edgefn", "nodefn", "graphfn"), chains):
-            layers = [l for l in ch.layers]
-            widths = [int(l.weight.shape[0]) for l in layers]
-            arr = (_lib.Dense * max(len(layers), 1))(*[l._c(keep) for l in layers])
-            wid = (C.c_int32 * max(len(layers), 1))(*widths)
+            widths = [int(l.weight.shape[0]) for l in ch.layers]
+            arr = (_lib.Dense * max(len(ch.layers), 1))(*[l._c(keep) for l in ch.layers])
+            wid = (C.c_int32 * max(len(ch.layers), 1))(*widths)
             keep += [arr, wid]
             c = getattr(p, name)
-            c.layers, c.widths, c.n_layers = arr, wid, len(layers)
+            c.layers, c.widths, c.n_layers = arr, wid, len(ch.layers)
             outw.append(widths[-1] if widths else 0)
+        return p, chains, outw
+
+    def _chain_forward(self, g, R, flags, ef, nf, gf):
+        lib = _lib.load()
+        keep = []
+        p, chains, outw = self._chain_params(keep)
         dev = g.device
         mk = lambda T, d: torch.empty((R, T, d), dtype=torch.float32, device=dev) if d > 0 else None
         eo, no, go = mk(g.n_edges, outw[0]), mk(g.n_nodes, outw[1]), mk(g.n_graphs, outw[2])
@@ -688,8 +690,20 @@ class GNBlock:
                 raise GnxError(_lib.ERR_DIMS, lib.gnx_last_error().decode("utf-8", "replace"))
             ws = g.workspace(nbytes, ("chain", self.in_dims, tuple(tuple(int(l.weight.shape[0]) for l in ch.layers) for ch in chains), R))
             check(lib.gnx_chain_block_forward(g._h, C.byref(p), _ptr(ef), _ptr(nf), _ptr(gf), R, _ptr(eo), _ptr(no), _ptr(go),
-                                              ws.data_ptr(), ws.numel(), self.flags if flags is None else flags,
-                                              torch.cuda.current_stream(dev).cuda_stream))
+                                              ws.data_ptr(), ws.numel(), flags, torch.cuda.current_stream(dev).cuda_stream))
+        return eo, no, go
+
+    def _call_chains(self, x, flags):
+        """Update functions that are multi-layer Chains: gnx_chain_block_forward; differentiable through gnx_chain_block_backward."""
+        g, ef, nf, gf, R = _forward_common(x, self.in_dims)
+        flags = self.flags if flags is None else flags
+        chains = [self._as_chain(f) for f in (self.edgefn, self.nodefn, self.graphfn)]
+        params = [t for ch in chains for l in ch.layers for t in (l.weight, l.bias)]
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in [ef, nf, gf] + params):
+            outs = iter(_ChainBlockFn.apply(self, g, R, flags, ef, nf, gf, *params))
+            eo, no, go = (next(outs) if ch.out_width > 0 else None for ch in chains)
+        else:
+            eo, no, go = self._chain_forward(g, R, flags, ef, nf, gf)
         return NT(g, _jl(eo), _jl(no), _jl(go))
 
     def __call__(self, x, flags=None):
@@ -775,6 +789,61 @@ class _BlockFn(torch.autograd.Function):
                                          torch.cuda.current_stream(dev).cuda_stream))
         gWt = [None if w is None else w.t() for w in gW]  # (out, in) view with column-major storage, like the weights
         return (None, None, None, None, d_ef, d_nf, d_gf, gWt[0], gb[0], gWt[1], gb[1], gWt[2], gb[2])
+
+
+class _ChainBlockFn(torch.autograd.Function):
+    """autograd node of a GNBlock whose update functions are Chains: forward = gnx_chain_block_forward, backward =
+    gnx_chain_block_backward (which recomputes every layer's output from the inputs)."""
+
+    @staticmethod
+    def forward(ctx, block, g, R, flags, ef, nf, gf, *params):
+        eo, no, go = block._chain_forward(g, R, flags, ef, nf, gf)
+        ctx.block, ctx.g, ctx.R = block, g, R
+        ctx.slots = tuple(t is not None for t in (ef, nf, gf))
+        ctx.save_for_backward(*[t for t in (ef, nf, gf) if t is not None])
+        ctx.present = tuple(o is not None for o in (eo, no, go))
+        return tuple(o for o in (eo, no, go) if o is not None)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        lib = _lib.load()
+        block, g, R = ctx.block, ctx.g, ctx.R
+        sv = iter(ctx.saved_tensors)
+        ef, nf, gf = (next(sv) if present else None for present in ctx.slots)
+        it = iter(gouts)
+        ge, gn_, gg = (next(it) if pr else None for pr in ctx.present)
+        cont = lambda t: None if t is None else t.contiguous()
+        ge, gn_, gg = cont(ge), cont(gn_), cont(gg)
+        keep = []
+        p, chains, _ = block._chain_params(keep)
+        dev = g.device
+        need = ctx.needs_input_grad  # (block, g, R, flags, ef, nf, gf, W, b, W, b, ...)
+        d_ef = torch.empty_like(ef) if ef is not None and need[4] else None
+        d_nf = torch.empty_like(nf) if nf is not None and need[5] else None
+        d_gf = torch.empty_like(gf) if gf is not None and need[6] else None
+        gW, gb, arrays, k = [], [], [], 7
+        for ch in chains:
+            entries = []
+            for l in ch.layers:
+                w = torch.empty((l.weight.shape[1], l.weight.shape[0]), dtype=torch.float32, device=dev) if need[k] else None
+                b = torch.empty_like(l.bias) if (l.bias is not None and need[k + 1]) else None
+                k += 2
+                gW.append(w); gb.append(b)
+                entries.append(_lib.DenseGrad(_ptr(w) if (w is not None and w.numel()) else None, _ptr(b) if (b is not None and b.numel()) else None))
+            arrays.append((_lib.DenseGrad * max(len(entries), 1))(*entries))
+        grads = _lib.ChainBlockGrads(*[C.cast(a, C.POINTER(_lib.DenseGrad)) for a in arrays])
+        with torch.cuda.device(dev):
+            nb = lib.gnx_chain_block_backward_workspace_bytes(g._h, C.byref(p), R)
+            if nb == 0:
+                raise GnxError(_lib.ERR_DIMS, lib.gnx_last_error().decode("utf-8", "replace"))
+            ws = torch.empty(int(nb), dtype=torch.uint8, device=dev)
+            check(lib.gnx_chain_block_backward(g._h, C.byref(p), _ptr(ef), _ptr(nf), _ptr(gf), _ptr(ge), _ptr(gn_), _ptr(gg), R,
+                                               _ptr(d_ef), _ptr(d_nf), _ptr(d_gf), C.byref(grads), ws.data_ptr(), ws.numel(),
+                                               torch.cuda.current_stream(dev).cuda_stream))
+        out = [None, None, None, None, d_ef, d_nf, d_gf]
+        for w, b in zip(gW, gb):
+            out += [None if w is None else w.t(), b]  # (out, in) view with column-major storage, like the weights
+        return tuple(out)
 
 
 class GNFeedForward:

@@ -16,6 +16,7 @@
 #include "gnx_device.h"
 
 extern "C" int32_t gnx_ensure_csr(const gnx_graphs* h);
+extern "C" size_t gnx_chain_block_workspace_bytes(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t R);
 
 namespace gnx {
 
@@ -905,6 +906,220 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
     if ((rc = colsum_all(F(L.dl1[t]), rows[t], d[t], gr.ln1[t].beta, part, off2, s))) return rc;
     if ((rc = colsum_all(t2, rows[t], d[t], gr.ln2[t].gamma, part, off2, s))) return rc;
     if ((rc = colsum_all(F(L.dz2[t]), rows[t], d[t], gr.ln2[t].beta, part, off2, s))) return rc;
+  }
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+}  // extern "C"
+
+// ---- GNBlock with Chain update functions: backward ----
+namespace {
+int chain_out(const gnx_chain& c) { return c.n_layers > 0 ? c.widths[c.n_layers - 1] : 0; }
+int chain_max(const gnx_chain& c) {
+  int m = 0;
+  for (int i = 0; i < c.n_layers; ++i) m = std::max(m, c.widths[i]);
+  return m;
+}
+gnx_block_params chain_edge_block(const gnx_chain_block_params* p) {  // the one-layer block that is the edge chain's first Dense
+  gnx_block_params b{};
+  b.de = p->de; b.dn = p->dn; b.dg = p->dg;
+  b.oe = p->edgefn.widths[0]; b.on = 0; b.og = 0;
+  b.edgefn = p->edgefn.layers[0];
+  return b;
+}
+struct ChainBwLayout {
+  size_t act[3][16];  // stored layer outputs per chain
+  size_t Xn, Xg, dXn, dXg, gbuf[3], blk_fw, blk_fw_bytes, blk_bw, blk_bw_bytes, part, wt, off2, total;
+};
+ChainBwLayout chain_bw_layout(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t R) {
+  ChainBwLayout L{};
+  size_t o = 0;
+  auto take = [&](size_t floats) { const size_t at = o; o += align_up(floats * sizeof(float), 256); return at; };
+  const gnx_chain* ch[3] = {&p->edgefn, &p->nodefn, &p->graphfn};
+  const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
+  const int oe = chain_out(p->edgefn), on = chain_out(p->nodefn), og = chain_out(p->graphfn);
+  const int Kn = oe + p->dn + p->dg, Kg = oe + on + p->dg;
+  const int k0[3] = {p->de + 2 * p->dn + p->dg, Kn, Kg};
+  size_t gmax = 1, pmax = 2048 * 4, wmax = 1;
+  for (int t = 0; t < 3; ++t) {
+    for (int i = 0; i < ch[t]->n_layers; ++i) {
+      L.act[t][i] = take(rows[t] * (size_t)ch[t]->widths[i]);
+      const int J = ch[t]->widths[i], K = i > 0 ? ch[t]->widths[i - 1] : k0[t];
+      const size_t chunks = (rows[t] + BW_CH - 1) / BW_CH;
+      pmax = std::max({pmax, chunks * (size_t)J * (K + 1), (size_t)2048 * J, dw_mfma_partial_floats(rows[t], J, K)});
+      wmax = std::max(wmax, (size_t)J * K);
+    }
+    gmax = std::max(gmax, rows[t] * (size_t)chain_max(*ch[t]));
+  }
+  pmax = std::max(pmax, std::max((size_t)R * h->G * 256, (size_t)2048) * (size_t)std::max({p->dg, oe, 1}));  // column-sum slices
+  L.Xn = take(on > 0 ? rows[1] * Kn : 0); L.dXn = take(on > 0 ? rows[1] * Kn : 0);
+  L.Xg = take(og > 0 ? rows[2] * Kg : 0); L.dXg = take(og > 0 ? rows[2] * Kg : 0);
+  for (int i = 0; i < 3; ++i) L.gbuf[i] = take(gmax);
+  const gnx_block_params b = chain_edge_block(p);
+  L.blk_fw_bytes = gnx_block_workspace_bytes(h, &b, R);
+  L.blk_fw = o; o += align_up(L.blk_fw_bytes, 256);
+  L.blk_bw_bytes = gnx_block_backward_workspace_bytes(h, &b, R);
+  L.blk_bw = o; o += align_up(L.blk_bw_bytes, 256);
+  L.part = take(pmax); L.wt = take(wmax); L.off2 = take(16);
+  L.total = o + 256;
+  return L;
+}
+}  // namespace
+
+extern "C" {
+
+size_t gnx_chain_block_backward_workspace_bytes(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t R) {
+  if (!h || !p || R <= 0 || gnx_chain_block_workspace_bytes(h, p, R) == 0) return 0;  // (the forward's query validates the chains)
+  return chain_bw_layout(h, p, R).total;
+}
+
+int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_params* p, const float* ef, const float* nf, const float* gf,
+                                 const float* g_ef_out, const float* g_nf_out, const float* g_gf_out, int64_t R, float* d_ef, float* d_nf,
+                                 float* d_gf, const gnx_chain_block_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
+  if (gnx_chain_block_workspace_bytes(h, p, R) == 0) return GNX_ERR_DIMS;  // gnx_last_error() holds the reason
+  const gnx_chain* ch[3] = {&p->edgefn, &p->nodefn, &p->graphfn};
+  const int de = p->de, dn = p->dn, dg = p->dg;
+  const int oe = chain_out(p->edgefn), on = chain_out(p->nodefn), og = chain_out(p->graphfn);
+  if ((de > 0 && !ef && h->E > 0) || (dn > 0 && !nf) || (dg > 0 && !gf)) return fail(GNX_ERR_INVALID_ARG, "an input with non-zero width is NULL");
+  if (oe == 0) return fail(GNX_ERR_DIMS, "chain backward: the edge function has no output");
+  const ChainBwLayout L = chain_bw_layout(h, p, R);
+  if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_chain_block_backward_workspace_bytes()");
+  if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");
+  char* base = static_cast<char*>(ws);
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+  const int E = (int)h->E, N = (int)h->N, G = (int)h->G;
+  const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
+  const int trow[3] = {E, N, G};
+  const int Kn = oe + dn + dg, Kg = oe + on + dg;
+  const unsigned Ru = (unsigned)R;
+  auto blocks = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+  float *Xn = F(L.Xn), *Xg = F(L.Xg), *dXn = F(L.dXn), *dXg = F(L.dXg), *part = F(L.part), *wt = F(L.wt);
+  int* off2 = reinterpret_cast<int*>(base + L.off2);
+  const gnx_dense_grad no_grad{nullptr, nullptr};
+  auto grad_of = [&](int t, int i) -> const gnx_dense_grad& {
+    const gnx_dense_grad* a = !grads ? nullptr : (t == 0 ? grads->edgefn : t == 1 ? grads->nodefn : grads->graphfn);
+    return a ? a[i] : no_grad;
+  };
+  auto A = [&](int t, int i) { return F(L.act[t][i]); };
+  const gnx_block_params b1 = chain_edge_block(p);
+  int32_t rc;
+
+  // ---- forward again, every layer's output kept (gnx_chain_block_forward's sequence) ----
+  if (E > 0) {
+    if ((rc = gnx_block_forward(h, &b1, ef, nf, gf, R, A(0, 0), nullptr, nullptr, base + L.blk_fw, L.blk_fw_bytes, 0, stream))) return rc;
+    for (int i = 1; i < ch[0]->n_layers; ++i)
+      if ((rc = launch_dense_rows(h, 0, A(0, i - 1), ch[0]->widths[i - 1], ch[0]->layers[i], ch[0]->widths[i], nullptr, nullptr, A(0, i), R, s, "bw_chain_fw_e"))) return rc;
+  }
+  const float* ef_out = A(0, ch[0]->n_layers - 1);
+  const float* nf_out = on > 0 ? A(1, ch[1]->n_layers - 1) : nullptr;
+  if (on > 0) {
+    if ((rc = launch_fn_input(h, 1, ef_out, oe, nf, dn, gf, dg, R, Xn, s))) return rc;
+    for (int i = 0; i < ch[1]->n_layers; ++i)
+      if ((rc = launch_dense_rows(h, 1, i ? A(1, i - 1) : Xn, i ? ch[1]->widths[i - 1] : Kn, ch[1]->layers[i], ch[1]->widths[i], nullptr, nullptr, A(1, i), R, s, "bw_chain_fw_n"))) return rc;
+  }
+  if (og > 0) {
+    if ((rc = launch_fn_input(h, 2, ef_out, oe, nf_out, on, gf, dg, R, Xg, s))) return rc;
+    for (int i = 0; i < ch[2]->n_layers; ++i)
+      if ((rc = launch_dense_rows(h, 2, i ? A(2, i - 1) : Xg, i ? ch[2]->widths[i - 1] : Kg, ch[2]->layers[i], ch[2]->widths[i], nullptr, nullptr, A(2, i), R, s, "bw_chain_fw_g"))) return rc;
+  }
+
+  // ---- row-wise pullback of layers [first, n) of chain t.  `cur` holds delta of the LAST layer on entry; on exit `*g_first` (rows x K_first)
+  //      holds the gradient w.r.t. the input of layer `first` ----
+  float* gb[3] = {F(L.gbuf[0]), F(L.gbuf[1]), F(L.gbuf[2])};
+  auto delta_rows = [&](int t, int i, float* buf, const float* Ain, int K) {  // buf <- buf .* act'(layer i), all R*T rows, no extras
+    const gnx_dense& d = ch[t]->layers[i];
+    const int J = ch[t]->widths[i];
+    const float* outp = A(t, i);
+    if (d.act == GNX_ACT_GELU) {
+      ProfScope ps("bw_gelu_preact", s);
+      hipLaunchKernelGGL(k_fw_dense, blocks(rows[t] * J), dim3(256), 0, s, Ain, d.weight, d.bias, rows[t], K, J, GNX_ACT_IDENTITY, gb[2]);
+      outp = gb[2];
+    }
+    DeltaArgs a{buf, outp, buf, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, J, (int)rows[t], 1, d.act, 0};
+    ProfScope ps("bw_delta", s);
+    launch_delta(a, 0, 0, 1, s);
+  };
+  auto pull_layers = [&](int t, int first, float* cur, float* other, const float* X0, int K0, float* g_first, float** result) -> int32_t {
+    for (int i = ch[t]->n_layers - 1; i >= first; --i) {
+      const int J = ch[t]->widths[i], K = i > 0 ? ch[t]->widths[i - 1] : K0;
+      const float* Ain = i > 0 ? A(t, i - 1) : X0;
+      float* gin = i == first && g_first ? g_first : other;
+      if (i == first && result) *result = gin;
+      const gnx_dense& d = ch[t]->layers[i];
+      if (rows[t] == 0 || J == 0) continue;
+      int32_t r2;
+      if (bw_use_mfma(rows[t], J, K)) {
+        if (gin && K > 0 && (r2 = dx_mfma(h, t, cur, d.weight, J, K, 0, K, gin, R, wt, true, s, "bw_dx_chain"))) return r2;
+        if ((r2 = dw_auto(cur, Ain, rows[t], J, K, grad_of(t, i), part, off2, s))) return r2;
+      } else {
+        if (gin && K > 0) launch_bw_dx(dim3(blocks(rows[t] * K).x, 1), s, cur, d.weight, (int)rows[t], J, K, gin, 0, 0, (float*)nullptr, 0);
+        if ((r2 = dw_reduce(cur, Ain, rows[t], J, K, grad_of(t, i), part, s))) return r2;
+      }
+      if (i > first) {  // delta of layer i-1 from the gradient w.r.t. its output
+        delta_rows(t, i - 1, gin, i - 1 > 0 ? A(t, i - 2) : X0, i - 1 > 0 ? ch[t]->widths[i - 2] : K0);
+        std::swap(cur, other);
+      }
+    }
+    return GNX_OK;
+  };
+  // delta of a chain's LAST layer: (upstream + the shares of the levels above) .* act'   [kind 0 graphs / 1 nodes / 2 edges]
+  auto last_delta = [&](int t, const float* upstream, float* out, const float* X0, int K0, int act_override) {
+    const int li = ch[t]->n_layers - 1, J = ch[t]->widths[li];
+    const gnx_dense& d = ch[t]->layers[li];
+    const int act = act_override >= 0 ? act_override : d.act;
+    const float* outp = A(t, li);
+    if (act == GNX_ACT_GELU) {
+      const float* Ain = li > 0 ? A(t, li - 1) : X0;
+      const int K = li > 0 ? ch[t]->widths[li - 1] : K0;
+      ProfScope ps("bw_gelu_preact", s);
+      hipLaunchKernelGGL(k_fw_dense, blocks(rows[t] * J), dim3(256), 0, s, Ain, d.weight, d.bias, rows[t], K, J, GNX_ACT_IDENTITY, gb[2]);
+      outp = gb[2];
+    }
+    DeltaArgs a{upstream, outp, out, t >= 1 && og > 0 ? dXg : nullptr, Kg, t == 1 ? oe : 0, t == 0 && on > 0 ? dXn : nullptr, Kn, 0,
+                t == 1 ? h->d_node_off : h->d_edge_off, h->d_edge_dst, J, trow[t], G, act, t == 2 ? 0 : (t == 1 ? 1 : 2)};
+    if (t == 0) { a.ex1 = og > 0 ? dXg : nullptr; a.ex1_off = 0; }
+    ProfScope ps("bw_delta", s);
+    launch_delta(a, (size_t)G * Kg, (size_t)N * Kn, Ru, s);
+  };
+
+  // ---- graph chain ----
+  if (og > 0) {
+    last_delta(2, g_gf_out, gb[0], Xg, Kg, -1);
+    if ((rc = pull_layers(2, 0, gb[0], gb[1], Xg, Kg, dXg, nullptr))) return rc;
+  }
+  // ---- node chain: upstream + dXg[graph of the node][oe : oe+on] ----
+  if (on > 0) {
+    last_delta(1, g_nf_out, gb[0], Xn, Kn, -1);
+    if ((rc = pull_layers(1, 0, gb[0], gb[1], Xn, Kn, dXn, nullptr))) return rc;
+  }
+  // ---- edge chain: upstream + dXg[graph][0:oe] + dXn[dst][0:oe]; tail layers row-wise, the first layer through the block pullback ----
+  float* g_first = gb[0];  // gradient w.r.t. the FIRST layer's output
+  if (E > 0) {
+    if (ch[0]->n_layers == 1) {
+      last_delta(0, g_ef_out, gb[0], nullptr, 0, GNX_ACT_IDENTITY);  // the sum only: the block pullback applies the layer's own act'
+    } else {
+      last_delta(0, g_ef_out, gb[0], nullptr, 0, -1);
+      if ((rc = pull_layers(0, 1, gb[0], gb[1], nullptr, 0, nullptr, &g_first))) return rc;  // g_first: where the last dX went
+    }
+  }
+  gnx_block_grads g1{};
+  g1.edgefn = grad_of(0, 0);
+  if ((rc = gnx_block_backward(h, &b1, ef, nf, gf, A(0, 0), nullptr, nullptr, E > 0 ? g_first : nullptr, nullptr, nullptr, R, d_ef, d_nf, d_gf, &g1,
+                               base + L.blk_bw, L.blk_bw_bytes, stream))) return rc;
+  // ---- the node / graph functions' own shares of d_nf, d_gf ----
+  if (d_nf && dn > 0 && on > 0 && (rc = add_cols(dXn, Kn, oe, rows[1], dn, d_nf, 1, s))) return rc;
+  if (d_gf && dg > 0) {
+    if (on > 0) {
+      int64_t mn = 1;
+      for (int64_t g = 0; g < h->G; ++g) mn = std::max(mn, h->h_node_off[g + 1] - h->h_node_off[g]);
+      const int S = (int)std::min<int64_t>(std::max<int64_t>(mn / 2048, 1), 256);
+      hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S * (unsigned)G, 1, Ru), dim3(256), 0, s, dXn, dg, N, h->d_node_off, S, G, part, Kn, oe + dn);
+      hipLaunchKernelGGL(k_bw_colsum2, dim3((unsigned)G, Ru), dim3(64), 0, s, part, dg, S, G, d_gf, dg, 0, 1);
+    }
+    if (og > 0 && (rc = add_cols(dXg, Kg, oe + on, rows[2], dg, d_gf, 1, s))) return rc;
   }
   GNX_HIP(hipGetLastError());
   return GNX_OK;

@@ -175,7 +175,7 @@ GNX_API int32_t gnx_block_graph_update(const gnx_graphs* h, const gnx_block_para
  * width of layer i; the input width of layer 0 is fixed by the block (de+2dn+dg / oe+dn+dg / oe+on+dg with oe, on = the LAST
  * widths of the edge / node chains); a chain with n_layers = 0 or a last width of 0 <=> that output is `nothing`.
  * The edge function's first layer runs fused with getedgefninput (the fast block kernels); every further layer is a row-wise
- * Dense on the matrix-core GEMM kernel.  Forward only. */
+ * Dense on the matrix-core GEMM kernel.  Backward: gnx_chain_block_backward below. */
 typedef struct gnx_chain {
   const gnx_dense* layers; /* [n_layers] host array of layer descriptors (device weight pointers inside) */
   const int32_t* widths;   /* [n_layers] host array */
@@ -212,6 +212,21 @@ GNX_API int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* 
                            const float* ef_out, const float* nf_out, const float* gf_out, const float* g_ef_out,
                            const float* g_nf_out, const float* g_gf_out, int64_t n_replicas, float* d_ef, float* d_nf,
                            float* d_gf, const gnx_block_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the Chain block: takes the forward's INPUTS and the upstream gradients (NULL = zero); every layer's output is recomputed
+ * into the workspace.  Gradients w.r.t. the inputs (optional) and, per chain, one gnx_dense_grad per layer (host arrays of n_layers
+ * entries, or NULL; entries' pointers optional), all OVERWRITTEN.  The tail layers and the node / graph chains are row-wise Dense
+ * pullbacks (matrix cores for real matrices), the edge chain's first layer goes through gnx_block_backward; fixed summation orders. */
+typedef struct gnx_chain_block_grads {
+  const gnx_dense_grad* edgefn;  /* [edgefn.n_layers]  */
+  const gnx_dense_grad* nodefn;  /* [nodefn.n_layers]  */
+  const gnx_dense_grad* graphfn; /* [graphfn.n_layers] */
+} gnx_chain_block_grads;
+GNX_API size_t gnx_chain_block_backward_workspace_bytes(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t n_replicas);
+GNX_API int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_params* p, const float* ef, const float* nf, const float* gf,
+                                 const float* g_ef_out, const float* g_nf_out, const float* g_gf_out, int64_t n_replicas, float* d_ef,
+                                 float* d_nf, float* d_gf, const gnx_chain_block_grads* grads, void* workspace, size_t workspace_bytes,
+                                 void* stream);
 
 /* Backward of (m::GNCore)(x) = x + block(gn1(x)) + ffwd(gn2(x)) (src/gncore.jl:56-68).  Takes the forward's INPUTS and the
  * upstream gradients; the intermediates (both LayerNorms, the block's outputs, the FeedForward hidden activations) are

@@ -63,3 +63,100 @@ def test_chain_block_shared_graph_replicas_and_errors(gn):
     bad = O.make_chain_block_params(rng, (10, 5, 0), [4, 3], [], [5])
     with pytest.raises(gn.GnxError):
         _block(gn, bad)(gn.batch(dict(graphs=adj, ef=ef, nf=nf, gf=None)))
+
+
+def _torch_chain_block(csc, ef, nf, gf, W):
+    """float64 torch restatement of the block with Chain update functions (one replica); W[name] = list of (weight, bias, act)."""
+    import torch
+    ACT = {0: lambda x: x, 1: torch.relu, 2: torch.tanh, 3: torch.sigmoid, 4: lambda x: torch.nn.functional.gelu(x, approximate="tanh")}
+    colptr, rowval, node_off, edge_off = (torch.from_numpy(np.asarray(a)) for a in csc)
+    N, G = len(colptr) - 1, len(node_off) - 1
+    dst = torch.repeat_interleave(torch.arange(N), colptr[1:] - colptr[:-1])
+    ng = torch.repeat_interleave(torch.arange(G), node_off[1:] - node_off[:-1])
+    eg = torch.repeat_interleave(torch.arange(G), edge_off[1:] - edge_off[:-1])
+    cat = lambda parts: torch.cat([q for q in parts if q is not None], dim=1)
+
+    def chain(x, layers, pre):
+        for w, b, a in layers:
+            z = x @ w.T + b
+            pre.append((z, a))
+            x = ACT[a](z)
+        return x
+
+    pre = []
+    he = chain(cat([ef, None if nf is None else nf[rowval], None if nf is None else nf[dst], None if gf is None else gf[eg]]), W["edge"], pre)
+    hn = hg = None
+    if W["node"]:
+        agg = torch.zeros((N, he.shape[1]), dtype=torch.float64).index_add(0, dst, he)
+        hn = chain(cat([agg, nf, None if gf is None else gf[ng]]), W["node"], pre)
+    if W["graph"]:
+        se = torch.zeros((G, he.shape[1]), dtype=torch.float64).index_add(0, eg, he)
+        sn = torch.zeros((G, hn.shape[1]), dtype=torch.float64).index_add(0, ng, hn)
+        hg = chain(cat([se, sn, gf]), W["graph"], pre)
+    return (he, hn, hg), pre
+
+
+BW_CASES = [
+    ((10, 5, 0), [16, 3], [8, 4], [6, 5], (1, 2, 0), False),
+    ((10, 5, 3), [12, 9, 7], [6], [9, 4], (2, 3, 4), False),        # three edge layers (tanh, sigmoid), gelu hidden layers further down
+    ((0, 4, 2), [8, 5], [5], [], (4, 2, 0), False),                 # ef = nothing, gelu first edge layer, no graph output
+    ((6, 0, 0), [4, 3], [], [], (2, 0, 0), False),                  # edge function only
+    ((48, 24, 8), [64, 40], [48, 24], [32, 16], (2, 3, 2), True),   # matrix-core row-wise pullbacks (>= 4096 rows)
+]
+
+
+@pytest.mark.parametrize("case", BW_CASES, ids=[str(c[:4]) for c in BW_CASES])
+def test_chain_block_backward_matches_torch_autograd(gn, case):
+    """gnx_chain_block_backward through torch autograd against float64 torch autograd of an independent restatement: input gradients and
+    every layer's weight / bias gradient.  Hidden activations are smooth or, for relu, drawn kink-free."""
+    import torch
+    in_dims, ew, nw, gw, acts, big = case
+    for attempt in range(20):
+        rng = np.random.default_rng(700 + sum(in_dims) + 1000 * attempt)
+        if big:
+            sizes = rng.integers(1500, 2200, 3)
+            cs = [U.er_csc(rng, int(n), 4 * int(n)) for n in sizes]
+        else:
+            sizes = rng.integers(3, 30, 5)
+            cs = [U.er_csc(rng, int(n), int(0.2 * n * n) + 1) for n in sizes]
+        g = gn.GNGraphBatch.from_csc([c[0] for c in cs], [c[1] for c in cs], [int(n) for n in sizes])
+        csc = (*g.csc(), g.node_off, g.edge_off)
+        p = O.make_chain_block_params(rng, in_dims, ew, nw, gw, acts=acts)
+        ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, in_dims)
+        T = lambda a: None if a is None else torch.tensor(a[0], dtype=torch.float64, requires_grad=True)
+        xs = [T(ef), T(nf), T(gf)]
+        W = {name: [(torch.tensor(w, dtype=torch.float64, requires_grad=True), torch.tensor(b, dtype=torch.float64, requires_grad=True), a)
+                    for w, b, a in p[name]] for name in ("edge", "node", "graph")}
+        outs_r, pre = _torch_chain_block(csc, *xs, W)
+        if any(a == 1 and float(z.detach().abs().min()) < 5e-6 for z, a in pre if z.numel()):
+            continue  # a relu pre-activation within fp32 rounding of its kink: re-draw
+        cot = [None if o is None else torch.from_numpy(rng.standard_normal(tuple(o.shape))) for o in outs_r]
+        sum((o * c).sum() for o, c in zip(outs_r, cot) if o is not None).backward()
+        # HIP
+        blk = _block(gn, p)
+        leaves = []
+        for ch in (blk.edgefn, blk.nodefn, blk.graphfn):
+            for l in ch.layers:
+                l.weight.requires_grad_(True); l.bias.requires_grad_(True)
+                leaves += [l.weight, l.bias]
+        dev = g.device
+        leaf = lambda a: None if a is None else torch.from_numpy(a).to(dev).requires_grad_(True)
+        xt = [leaf(ef), leaf(nf), leaf(gf)]
+        y = blk(gn.NT(g, *(None if t is None else t.permute(2, 1, 0) for t in xt)))
+        loss = sum((o.permute(2, 1, 0)[0] * c.to(dev).float()).sum() for o, c in zip((y.ef, y.nf, y.gf), cot) if o is not None)
+        loss.backward()
+
+        def close(got, ref, what):
+            ref = ref.detach().numpy(); got = got.detach().double().cpu().numpy()
+            scale = max(1.0, float(np.abs(ref).max()))
+            assert got.shape == ref.shape, (what, got.shape, ref.shape)
+            assert np.max(np.abs(got - ref)) <= 1e-3 * scale, f"{what}: max err {np.max(np.abs(got - ref)):.3e} (scale {scale:.3g})"
+
+        for name, t, r in zip(("d_ef", "d_nf", "d_gf"), xt, xs):
+            if t is not None:
+                close(t.grad[0], r.grad, name)
+        refs = [q.grad for name in ("edge", "node", "graph") for w, b, _ in W[name] for q in (w, b)]
+        for i, (q, r) in enumerate(zip(leaves, refs)):
+            close(q.grad, r, f"param[{i}]")
+        return
+    pytest.fail("no kink-free draw in 20 attempts")
