@@ -125,48 +125,6 @@ __global__ __launch_bounds__(256) void k_core_post(const float* __restrict__ x, 
 // current one run (scalar loads return out of order, so the only wait is lgkmcnt(0), placed BEFORE the next issue), and the FMAs
 // take the weight as their SGPR operand.  No LDS, no workgroup barrier, 4*D live weight registers.
 // ---------------------------------------------------------------------------------------------------------------------------------
-typedef float v2f_t __attribute__((ext_vector_type(2)));
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-typedef float v8f_t __attribute__((ext_vector_type(8)));
-typedef float v16f_t __attribute__((ext_vector_type(16)));
-
-template <int N>
-struct SGroup {  // N (even, <= 32) consecutive floats held in SGPRs
-  static_assert(N % 2 == 0 && N >= 2 && N <= 32, "group size");
-  static constexpr int N16 = N / 16, N8 = (N % 16) / 8, N4 = (N % 8) / 4, N2 = (N % 4) / 2;
-  v16f_t a, b; v8f_t c; v4f_t d; v2f_t e;
-  __device__ __forceinline__ void issue(cfloatp p) {
-    if constexpr (N16 >= 1) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(a) : "s"(p));
-    if constexpr (N16 >= 2) asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(b) : "s"(p));
-    if constexpr (N8 == 1) asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(c) : "s"(p), "n"(64 * N16));
-    if constexpr (N4 == 1) asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(d) : "s"(p), "n"(64 * N16 + 32 * N8));
-    if constexpr (N2 == 1) asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(e) : "s"(p), "n"(64 * N16 + 32 * N8 + 16 * N4));
-  }
-  // every use of the group is ordered behind this: ONE s_waitcnt, the other pieces are tied to the volatile order by empty statements
-  __device__ __forceinline__ void wait() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if constexpr (N16 >= 1) asm volatile("" : "+s"(a));
-    if constexpr (N16 >= 2) asm volatile("" : "+s"(b));
-    if constexpr (N8 == 1) asm volatile("" : "+s"(c));
-    if constexpr (N4 == 1) asm volatile("" : "+s"(d));
-    if constexpr (N2 == 1) asm volatile("" : "+s"(e));
-  }
-  __device__ __forceinline__ v2f_t pair(int q) const {  // floats 2q, 2q+1 = an aligned SGPR pair of the group's registers; q constant
-    v2f_t r;
-    r.x = get(2 * q); r.y = get(2 * q + 1);
-    return r;
-  }
-  __device__ __forceinline__ float get(int i) const {  // i is a constant once the loops are unrolled
-    if (i < 16 * N16) return i < 16 ? a[i & 15] : b[i & 15];
-    i -= 16 * N16;
-    if (i < 8 * N8) return c[i & 7];
-    i -= 8 * N8;
-    if (i < 4 * N4) return d[i & 3];
-    i -= 4 * N4;
-    return e[i & 1];
-  }
-};
-
 // out = x + block_out + W2 act(W1 gn2(x) + b1) + b2, TWO rows per thread held as register pairs: every FMA is one v_pk_fma_f32
 // whose src0 is the SGPR pair holding the weight (op_sel picks its low or high half for both rows) — half the VALU issue of scalar FMAs.
 // The hidden layer is produced and consumed in two halves of HB = 2D units; the weight stream of a half is [b1 half | D rows of W1
@@ -174,29 +132,6 @@ struct SGroup {  // N (even, <= 32) consecutive floats held in SGPRs
 // = 2D packed FMAs.  The 2(2D+1) groups are walked by a compile-time recursion (GI = global group index: half, position and
 // register set are constants of each step).  The FMAs are (non-volatile) asm statements too: left as C, the vectoriser packs them
 // itself — with the weight copied into a VGPR pair first — and collects them behind the loads of ALL groups (800 spilled SGPRs).
-typedef v2f_t P2;  // (row 0, row 1) of a lane
-template <bool HI>
-__device__ __forceinline__ void pk_fma_sw(P2& acc, v2f_t wpair, P2 x) {  // acc += w * x, w = low / high half of the SGPR pair
-  if constexpr (!HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(wpair), "v"(x));
-  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(wpair), "v"(x));
-}
-// ties N register pairs into the order of the volatile statements (no instruction)
-template <int N, int O = 0>
-__device__ __forceinline__ void pin_pairs(P2 (&v)[N]) {
-  if constexpr (O + 8 <= N) {
-    asm volatile("" : "+v"(v[O]), "+v"(v[O + 1]), "+v"(v[O + 2]), "+v"(v[O + 3]), "+v"(v[O + 4]), "+v"(v[O + 5]), "+v"(v[O + 6]), "+v"(v[O + 7]));
-    pin_pairs<N, O + 8>(v);
-  } else if constexpr (O + 4 <= N) {
-    asm volatile("" : "+v"(v[O]), "+v"(v[O + 1]), "+v"(v[O + 2]), "+v"(v[O + 3]));
-    pin_pairs<N, O + 4>(v);
-  } else if constexpr (O + 2 <= N) {
-    asm volatile("" : "+v"(v[O]), "+v"(v[O + 1]));
-    pin_pairs<N, O + 2>(v);
-  } else if constexpr (O + 1 <= N) {
-    asm volatile("" : "+v"(v[O]));
-  }
-}
-
 // TRANS = false: both activations are identity / relu (the reference's FeedForward) — the tanh / sigmoid / gelu expansions of a run-time
 // activation switch cost ~60 registers on every path, relu's included.
 template <int D, bool TRANS>

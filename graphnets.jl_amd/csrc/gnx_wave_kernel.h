@@ -122,6 +122,130 @@ __device__ __forceinline__ void fma_rows(cfloatp W, const float (&x)[M][KX], flo
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Hand-streamed scalar weights + packed FMAs (used by k_core_post_s and by k_block_wave's large edge products).
+// A GROUP of N consecutive weights is fetched by s_load_dwordx{16,8,4,2} issued from inline asm — volatile asm statements keep their
+// order, so the compiler can neither hoist nor merge them — into one of two register sets: the next group is in flight while the FMAs
+// of the current one run (scalar loads return out of order, so the only wait is lgkmcnt(0), placed BEFORE the next issue).  Two rows
+// (edges) of a lane are held as a register PAIR and every FMA is one v_pk_fma_f32 whose src0 is the SGPR pair holding the weight:
+// op_sel picks its low or high half for both rows (tools/experiments/pk_fma_sgpr_probe.hip) — half the VALU issue of scalar FMAs, no LDS.
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef float v8f_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+
+template <int N>
+struct SGroup {  // N (even, <= 32) consecutive floats held in SGPRs
+  static_assert(N % 2 == 0 && N >= 2 && N <= 32, "group size");
+  static constexpr int N16 = N / 16, N8 = (N % 16) / 8, N4 = (N % 8) / 4, N2 = (N % 4) / 2;
+  v16f_t a, b; v8f_t c; v4f_t d; v2f_t e;
+  __device__ __forceinline__ void issue(cfloatp p) {
+    if constexpr (N16 >= 1) asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(a) : "s"(p));
+    if constexpr (N16 >= 2) asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(b) : "s"(p));
+    if constexpr (N8 == 1) asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(c) : "s"(p), "n"(64 * N16));
+    if constexpr (N4 == 1) asm volatile("s_load_dwordx4 %0, %1, %2" : "=s"(d) : "s"(p), "n"(64 * N16 + 32 * N8));
+    if constexpr (N2 == 1) asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(e) : "s"(p), "n"(64 * N16 + 32 * N8 + 16 * N4));
+  }
+  // every use of the group is ordered behind this: ONE s_waitcnt, the other pieces are tied to the volatile order by empty statements
+  __device__ __forceinline__ void wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (N16 >= 1) asm volatile("" : "+s"(a));
+    if constexpr (N16 >= 2) asm volatile("" : "+s"(b));
+    if constexpr (N8 == 1) asm volatile("" : "+s"(c));
+    if constexpr (N4 == 1) asm volatile("" : "+s"(d));
+    if constexpr (N2 == 1) asm volatile("" : "+s"(e));
+  }
+  __device__ __forceinline__ v2f_t pair(int q) const {  // floats 2q, 2q+1 = an aligned SGPR pair of the group's registers; q constant
+    v2f_t r;
+    r.x = get(2 * q); r.y = get(2 * q + 1);
+    return r;
+  }
+  __device__ __forceinline__ float get(int i) const {  // i is a constant once the loops are unrolled
+    if (i < 16 * N16) return i < 16 ? a[i & 15] : b[i & 15];
+    i -= 16 * N16;
+    if (i < 8 * N8) return c[i & 7];
+    i -= 8 * N8;
+    if (i < 4 * N4) return d[i & 3];
+    i -= 4 * N4;
+    return e[i & 1];
+  }
+};
+
+typedef v2f_t P2;  // (row 0, row 1) of a lane
+template <bool HI>
+__device__ __forceinline__ void pk_fma_sw(P2& acc, v2f_t wpair, P2 x) {  // acc += w * x, w = low / high half of the SGPR pair
+  if constexpr (!HI) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(wpair), "v"(x));
+  else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(wpair), "v"(x));
+}
+// ties N register pairs into the order of the volatile statements (no instruction)
+template <int N, int O = 0>
+__device__ __forceinline__ void pin_pairs(P2 (&v)[N]) {
+  if constexpr (O + 8 <= N) {
+    asm volatile("" : "+v"(v[O]), "+v"(v[O + 1]), "+v"(v[O + 2]), "+v"(v[O + 3]), "+v"(v[O + 4]), "+v"(v[O + 5]), "+v"(v[O + 6]), "+v"(v[O + 7]));
+    pin_pairs<N, O + 8>(v);
+  } else if constexpr (O + 4 <= N) {
+    asm volatile("" : "+v"(v[O]), "+v"(v[O + 1]), "+v"(v[O + 2]), "+v"(v[O + 3]));
+    pin_pairs<N, O + 4>(v);
+  } else if constexpr (O + 2 <= N) {
+    asm volatile("" : "+v"(v[O]), "+v"(v[O + 1]));
+    pin_pairs<N, O + 2>(v);
+  } else if constexpr (O + 1 <= N) {
+    asm volatile("" : "+v"(v[O]));
+  }
+}
+
+
+// acc[e % OUT] += W[e] * x[e / OUT] for e in [0, NEL): W = NEL consecutive weights (input k's OUT weights, then input k+1's, ...), x and
+// acc hold BOTH rows of the lane as pairs.  Groups of GS weights, the last one of TAIL; walked by a compile-time recursion.
+#ifndef GNX_PK_GS
+#define GNX_PK_GS 24
+#endif
+template <int NEL, int OUT, int KX, int GS>
+struct PkStream {
+  static_assert(NEL % 2 == 0 && GS % 2 == 0 && NEL >= 2, "even element counts");
+  static constexpr int NGRP = (NEL + GS - 1) / GS, TAIL = NEL - GS * (NGRP - 1);
+  cfloatp W;
+  P2 (&x)[KX];
+  P2 (&acc)[OUT];
+  SGroup<GS> G0, G1;
+  SGroup<TAIL> GT;  // the last group (its own register set: the full sets are dead by the time it is consumed)
+
+  template <int GI>
+  __device__ __forceinline__ void issue() {
+    if constexpr (GI == NGRP - 1) GT.issue(W + GI * GS);
+    else if constexpr (GI % 2 == 0) G0.issue(W + GI * GS);
+    else G1.issue(W + GI * GS);
+  }
+  template <int GI, class GRP>
+  __device__ __forceinline__ void consume(const GRP& cur) {
+    constexpr int n = GI == NGRP - 1 ? TAIL : GS;
+#pragma unroll
+    for (int q = 0; q < n / 2; ++q) {
+      const int e0 = GI * GS + 2 * q, e1 = e0 + 1;
+      const v2f_t w = cur.pair(q);
+      pk_fma_sw<false>(acc[e0 % OUT], w, x[e0 / OUT]);
+      pk_fma_sw<true>(acc[e1 % OUT], w, x[e1 / OUT]);
+    }
+    pin_pairs<OUT>(acc);
+  }
+  template <int GI>
+  __device__ __forceinline__ void run() {
+    if constexpr (GI < NGRP) {
+      if constexpr (GI == NGRP - 1) GT.wait();
+      else if constexpr (GI % 2 == 0) G0.wait();
+      else G1.wait();
+      if constexpr (GI + 1 < NGRP) issue<GI + 1>();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (GI == NGRP - 1) consume<GI>(GT);
+      else if constexpr (GI % 2 == 0) consume<GI>(G0);
+      else consume<GI>(G1);
+      __builtin_amdgcn_sched_barrier(0);
+      run<GI + 1>();
+    }
+  }
+};
+
 // xhat = (x - mu) * rstd over the D registers of a row; eps_mode 0: 1/(sigma+eps) (Flux 0.14 normalise), 1: 1/sqrt(var+eps)
 template <int D>
 __device__ __forceinline__ void normalise(float (&x)[D], float eps, int eps_mode) {
@@ -319,6 +443,9 @@ __host__ __device__ constexpr int wave_slice_floats(int OE, int EPT) {
 // LN: LayerNorm the inputs on load (BlockArgs::ln_*).  ONEG: the batch is ONE graph (see below).
 // SGPR budget: a CU admits floor(800 / (ceil(sgpr/16)*16 + 16)) 256-thread workgroups (MI355X_MICROARCH, residency): 8 up to 80
 // SGPRs, 7 up to 96, 6 beyond.  C2 is 2032 workgroups = ONE round at 8 per CU (2048 slots) but 1.13 rounds at 7.
+#ifndef GNX_WAVE_PK
+#define GNX_WAVE_PK 1  // large edge products of a two-edges-per-lane tile through PkStream (0: fma_rows)
+#endif
 #ifndef GNX_WAVE_SGPRS
 #define GNX_WAVE_SGPRS 80
 #endif
@@ -464,7 +591,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
     }
     constexpr int KE = DE + DN;  // weight rows applied per edge (the dst / gf rows were hoisted into pd)
     if constexpr (OE > 0 && KE * OE > 96) {
-      // Many weights: all EPT edges of the lane advance together over groups of weight rows (fma_rows)
+      // Many weights: all EPT edges of the lane advance together over groups of weight rows
       float acc[EPT][OE1];
       bool valid[EPT];
 #pragma unroll
@@ -476,8 +603,27 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
 #pragma unroll
         for (int j = 0; j < OE; ++j) acc[i][j] = s_pd[dl * OE + j];
       }
-      fma_rows<DE, OE, EPT, DE1>(We, x, acc);
-      fma_rows<DN, OE, EPT, DN1>(We + DE * OE, xs, acc);
+      if constexpr (EPT == 2 && (KE * OE) % 2 == 0 && GNX_WAVE_PK) {
+        // the two edges of the lane as register pairs, the (DE + DN) x OE weights (ef rows then src rows: consecutive in We) streamed
+        // through SGPR groups into packed FMAs (PkStream above)
+        P2 accp[OE1], xp[KE];
+        PkStream<KE * OE, OE, KE, GNX_PK_GS> st{We, xp, accp};
+        st.template issue<0>();
+#pragma unroll
+        for (int j = 0; j < OE; ++j) { accp[j].x = acc[0][j]; accp[j].y = acc[1][j]; }
+#pragma unroll
+        for (int k = 0; k < DE; ++k) { xp[k].x = x[0][k]; xp[k].y = x[1][k]; }
+#pragma unroll
+        for (int k = 0; k < DN; ++k) { xp[DE + k].x = xs[0][k]; xp[DE + k].y = xs[1][k]; }
+        pin_pairs<OE1>(accp);
+        pin_pairs<KE>(xp);
+        st.template run<0>();
+#pragma unroll
+        for (int j = 0; j < OE; ++j) { acc[0][j] = accp[j].x; acc[1][j] = accp[j].y; }
+      } else {
+        fma_rows<DE, OE, EPT, DE1>(We, x, acc);
+        fma_rows<DN, OE, EPT, DN1>(We + DE * OE, xs, acc);
+      }
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
         const int el = lane + 64 * i;
