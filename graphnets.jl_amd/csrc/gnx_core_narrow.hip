@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256) void k_ln1_rows(const float* __restrict__ x, s
 // them with UNIFORM addresses (ds_read_b128 of one address is a broadcast: no bank conflict) into a few VGPRs; M = 2 rows per
 // thread share each read, which keeps the LDS at ~half its rate (D + 4*ceil(D/4)/... reads per 8 D M FMAs).
 template <int D, int M>
-__global__ __launch_bounds__(256) void k_core_post(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2,
-                                                   gnx_dense fc1, gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out) {
+__device__ __forceinline__ void core_post_lds_body(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2, gnx_dense fc1,
+                                                   gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out, unsigned blk, unsigned nblk) {
   constexpr int H = 4 * D;
   constexpr int DP = (D + 3) / 4 * 4;  // padded row of W2 in LDS (16-B reads)
   __shared__ __attribute__((aligned(16))) float s_w1[D * H];   // W1 (4D x D column-major): element (j, k) at k*H + j
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void k_core_post(const float* __restrict__ x, 
   for (int i = threadIdx.x; i < D; i += 256) { s_v[i] = fc2.bias ? fc2.bias[i] : 0.f; s_v[D + i] = gamma2[i]; s_v[2 * D + i] = beta2[i]; }
   __syncthreads();
 
-  const size_t stride = (size_t)gridDim.x * 256;
-  const size_t row0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)nblk * 256;
+  const size_t row0 = (size_t)blk * 256 + threadIdx.x;
   if (row0 >= rows) return;
   float rs[M][D], z[M][D], acc[M][DP];
   size_t row[M];
@@ -115,6 +115,12 @@ __global__ __launch_bounds__(256) void k_core_post(const float* __restrict__ x, 
   }
 }
 
+
+template <int D, int M>
+__global__ __launch_bounds__(256) void k_core_post(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2,
+                                                   gnx_dense fc1, gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out) {
+  core_post_lds_body<D, M>(x, rows, gamma2, beta2, fc1, fc2, eps, eps_mode, out, blockIdx.x, gridDim.x);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Weights as SCALAR operands, streamed by hand.  Left to the compiler, scalar weight loads are hoisted until the SGPR file spills;
@@ -215,11 +221,11 @@ struct CorePostStream {
 };
 
 template <int D, bool TRANS>
-__global__ __launch_bounds__(256) void k_core_post_s(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2,
-                                                     gnx_dense fc1, gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out) {
+__device__ __forceinline__ void core_post_s_body(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2, gnx_dense fc1,
+                                                 gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out, unsigned blk, unsigned nblk) {
   constexpr int M = 2;
-  const size_t stride = (size_t)gridDim.x * 256;
-  const size_t row0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)nblk * 256;
+  const size_t row0 = (size_t)blk * 256 + threadIdx.x;
   if (row0 >= rows) return;
   const cfloatp b2 = as_const(fc2.bias ? fc2.bias : k_zero_bias), g2 = as_const(gamma2), be2 = as_const(beta2);
   P2 z[D], acc[D];
@@ -259,6 +265,43 @@ __global__ __launch_bounds__(256) void k_core_post_s(const float* __restrict__ x
 #pragma unroll
     for (int k = 0; k < D; ++k) o[k] = rs[m][k] + o[k];
     if (m == 0 || row0 + m * stride < rows) store_row<D>(out + row[m] * D, o);
+  }
+}
+template <int D, bool TRANS>
+__global__ __launch_bounds__(256) void k_core_post_s(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2,
+                                                     gnx_dense fc1, gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out) {
+  core_post_s_body<D, TRANS>(x, rows, gamma2, beta2, fc1, fc2, eps, eps_mode, out, blockIdx.x, gridDim.x);
+}
+
+// The three entities of a core in ONE launch (workgroup ranges: edges | nodes | graphs): the node and graph rows ride in the shadow of
+// the edge rows instead of paying two more kernel boundaries (7.3 + 4.7 us of the README ex.3 core on the 1M-edge graph).  Edges and
+// nodes: the streamed two-rows-per-thread body; graphs (few rows): the LDS body, one row per thread.
+struct PostJob {
+  const float* x; size_t rows; const float* gamma; const float* beta; gnx_dense fc1, fc2; float* out; unsigned blocks;
+};
+// GU: the block's graph update (graph_update_rows over the partial-sum rows k_block_wave left) runs HERE, in the graph job's workgroups
+// (one per graph), followed by that graph's FeedForward + residual — the block is launched without its k_graph_t, whose 6.5 us then
+// hide behind the edge rows.
+template <int D0, int D1, int D2, bool GU>
+__global__ __launch_bounds__(256) void k_core_post3(PostJob e, PostJob n, PostJob g, float eps, int eps_mode, BlockArgs a, int n_rows) {
+  // workgroup ranges: graphs | edges | nodes — the graph job (a serial chain of a few microseconds) is dispatched FIRST, so that it runs
+  // beside the edge rows instead of behind them
+  const unsigned b = blockIdx.x;
+  if (b >= g.blocks && b < g.blocks + e.blocks) core_post_s_body<D0, false>(e.x, e.rows, e.gamma, e.beta, e.fc1, e.fc2, eps, eps_mode, e.out, b - g.blocks, e.blocks);
+  else if (b >= g.blocks) core_post_s_body<D1, false>(n.x, n.rows, n.gamma, n.beta, n.fc1, n.fc2, eps, eps_mode, n.out, b - g.blocks - e.blocks, n.blocks);
+  else if constexpr (!GU) core_post_lds_body<D2, 1>(g.x, g.rows, g.gamma, g.beta, g.fc1, g.fc2, eps, eps_mode, g.out, b, g.blocks);
+  else {
+    constexpr int C = D0 + D1, CP = (C + 3) / 4 * 4;
+    __shared__ float s_g[graph_update_lds_floats(C, D2, D2, 256)];
+    const unsigned gb = b;
+    const int gi = (int)(gb % (unsigned)a.G);
+    const size_t r = gb / (unsigned)a.G;
+    const bool oneg = a.G == 1;  // one row per workgroup of k_block_wave, else one per wave tile (gnx_narrow.hip: partial_rows)
+    const int t0 = oneg ? 0 : a.wtile_off[gi], t1 = oneg ? (a.n_wtiles + 3) / 4 : a.wtile_off[gi + 1];
+    graph_update_rows<C, false, 16>(a, a.partials + r * (size_t)n_rows * CP, gi, r, t0, t1, (int)threadIdx.x, 256, s_g);
+    __syncthreads();  // gf' of this graph is in memory (written by this workgroup): the FeedForward below reads it as the block's output
+    const size_t row = r * (size_t)a.G + gi;
+    core_post_lds_body<D2, 1>(g.x + row * D2, 1, g.gamma, g.beta, g.fc1, g.fc2, eps, eps_mode, g.out + row * D2, 0, 1);
   }
 }
 
@@ -305,6 +348,34 @@ int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm
 #undef GNX_CASE
     default: return fail(GNX_ERR_DIMS, "launch_core_post: width not instantiated");
   }
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+// One launch for the three entities of a core when the width triple is instantiated (README ex.3's core widths), the edge and node
+// levels have rows to spare (two rows per thread) and the activations are identity / relu.
+bool core_post3_applies(const size_t rows[3], const int d[3], const gnx_ffn ff[3]) {
+  static const bool off = getenv("GNX_CORE_POST_SPLIT") != nullptr || getenv("GNX_CORE_POST_LDS") != nullptr;
+  if (off || rows[0] < 65536 || rows[1] < 65536 || rows[2] == 0 || rows[2] >= 65536) return false;
+  for (int t = 0; t < 3; ++t)
+    if (ff[t].fc1.act > GNX_ACT_RELU || ff[t].fc2.act > GNX_ACT_RELU) return false;
+  return d[0] == 10 && d[1] == 5 && d[2] == 3;
+}
+// blk != nullptr: the block was launched without its graph update — it runs inside this launch (n_rows = partial-sum rows per replica).
+// 1 = not applicable (three launches).
+int32_t launch_core_post3(const float* const x[3], const size_t rows[3], const int d[3], const gnx_layernorm l2[3], const gnx_ffn ff[3], float eps,
+                          int eps_mode, float* const out[3], hipStream_t s, const BlockArgs* blk, int n_rows) {
+  if (!core_post3_applies(rows, d, ff)) return blk ? fail(GNX_ERR_INVALID_ARG, "internal: deferred graph update without the combined kernel") : 1;
+  PostJob j[3];
+  for (int t = 0; t < 3; ++t) {
+    const size_t per = t < 2 ? 512 : 256;
+    j[t] = PostJob{x[t], rows[t], l2[t].gamma, l2[t].beta, ff[t].fc1, ff[t].fc2, out[t], (unsigned)((rows[t] + per - 1) / per)};
+  }
+  if (blk) j[2].blocks = (unsigned)rows[2];  // one workgroup per graph (and replica)
+  const dim3 grid(j[0].blocks + j[1].blocks + j[2].blocks);
+  ProfScope ps("k_core_post", s);
+  if (blk) hipLaunchKernelGGL((k_core_post3<10, 5, 3, true>), grid, dim3(256), 0, s, j[0], j[1], j[2], eps, eps_mode, *blk, n_rows);
+  else hipLaunchKernelGGL((k_core_post3<10, 5, 3, false>), grid, dim3(256), 0, s, j[0], j[1], j[2], eps, eps_mode, BlockArgs{}, 0);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }

@@ -41,6 +41,9 @@ bool ffn_fused_applies(const float* z, int d, const gnx_ffn& ff, const float* ad
 bool block_wide_ln_applies(const gnx_graphs* h, const BlockArgs& a);
 bool ln_stats_applies(const float* x, int d);
 int32_t launch_ln_stats(const float* x, size_t rows, int d, float eps, int eps_mode, float* stats, hipStream_t s);
+bool core_post3_applies(const size_t rows[3], const int d[3], const gnx_ffn ff[3]);
+int32_t launch_core_post3(const float* const x[3], const size_t rows[3], const int d[3], const gnx_layernorm l2[3], const gnx_ffn ff[3], float eps,
+                          int eps_mode, float* const out[3], hipStream_t s, const BlockArgs* blk, int n_rows);
 int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm& l2, const gnx_ffn& ff, float eps, int eps_mode,
                          float* out, hipStream_t s);
 int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K, const gnx_dense& d, int OUT, const float* add1,
@@ -90,7 +93,8 @@ static BlockWs block_ws(const gnx_graphs* h, const gnx_block_params* p, int64_t 
 static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf,
                                   const float* gf, int64_t R, float* ef_out, float* nf_out, float* gf_out, void* ws,
                                   size_t ws_bytes, uint32_t flags, hipStream_t s, int phase = 3, const gnx_layernorm* ln1 = nullptr,
-                                  float ln_eps = 0.f, int ln_mode = 0, bool* fused_ln = nullptr, const float* const* wide_ln_stats = nullptr) {
+                                  float ln_eps = 0.f, int ln_mode = 0, bool* fused_ln = nullptr, const float* const* wide_ln_stats = nullptr,
+                                  BlockArgs* args_out = nullptr) {
   int32_t rc = check_block(h, p, R);
   if (rc) return rc;
   if (phase & 1) {
@@ -138,6 +142,7 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
     a.ln_eps = ln_eps; a.ln_mode = ln_mode;
     if (!block_narrow_ready(h, a, s)) return GNX_OK;  // nothing launched: the caller runs gn1 as its own kernels
     *fused_ln = true;
+    if (args_out) *args_out = a;
     return launch_block_narrow(h, a, R, s, phase);
   }
   if (!(flags & GNX_FLAG_FORCE_GENERIC)) {
@@ -264,13 +269,19 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   }
   // All three widths narrow: the fused block kernel normalises its inputs as it loads them (gn1 never materialised) when it
   // is available for this width set; gn2 is recomputed inside k_core_post either way.
-  bool fused_ln = false;
+  bool fused_ln = false, defer_gu = false;
+  BlockArgs blk_args{};
   const bool all_narrow = core_narrow_width(d[0]) && core_narrow_width(d[1]) && core_narrow_width(d[2]) && !(flags & GNX_FLAG_FORCE_GENERIC);
   if (all_narrow) {
     // (the graph level of a NARROW core on the handle's side stream — graph update + the G-row / N-row k_core_post launches behind the
     // edges' k_core_post — was measured: README ex.3 model 298 vs 271 us; two fork/join pairs cost more than the ~20 us they hide)
-    rc = block_forward_impl(h, &b, ef, nf, gf, R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, 3, p->ln1, p->eps, p->eps_mode, &fused_ln);
+    // when the three FeedForwards go out as ONE launch (k_core_post3), the block's graph update runs inside it: the block is launched
+    // without its k_graph_t
+    defer_gu = core_post3_applies(rows, d, p->ff) && h->E > 0 && !(flags & GNX_FLAG_DEFER_GRAPH_UPDATE);
+    rc = block_forward_impl(h, &b, ef, nf, gf, R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, defer_gu ? 1 : 3, p->ln1, p->eps,
+                            p->eps_mode, &fused_ln, nullptr, &blk_args);
     if (rc) return rc;
+    defer_gu = defer_gu && fused_ln;
   }
   // Wide edges and nodes: the matrix-core kernels normalise x as they load it (block: gn1, fused FeedForward: gn2) from one pass of
   // row statistics — neither LayerNorm output of ef / nf exists in HBM.  Taken when the block runs in the projected quad-row form
@@ -367,6 +378,11 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     if (rc) return rc;
   }
   float* hidden = reinterpret_cast<float*>(base + off[6]);
+  if (all_narrow) {  // the three entities' FeedForward + residual in one launch when the width triple has the combined kernel
+    const int n_rows = (int)(h->G == 1 ? (h->n_wtiles() + 3) / 4 : h->n_wtiles());  // partial-sum rows of the fused narrow block (gnx_narrow.hip)
+    rc = launch_core_post3(x, rows, d, p->ln2, p->ff, p->eps, p->eps_mode, out, s, defer_gu ? &blk_args : nullptr, n_rows);
+    if (rc != 1) return rc;
+  }
   for (int t = 0; t < 3; ++t) {
     if (ffn_on_mfma(d[t]) && !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA))) {
       // out = block(LN1 x) + x + fc2(relu(fc1(LN2 x)))      (gncore.jl:56-68, gnfeedforward.jl:27-31)
