@@ -138,6 +138,9 @@ __global__ __launch_bounds__(256) void k_core_post(const float* __restrict__ x, 
 // = 2D packed FMAs.  The 2(2D+1) groups are walked by a compile-time recursion (GI = global group index: half, position and
 // register set are constants of each step).  The FMAs are (non-volatile) asm statements too: left as C, the vectoriser packs them
 // itself — with the weight copied into a VGPR pair first — and collects them behind the loads of ALL groups (800 spilled SGPRs).
+#ifndef GNX_CORE_POST_UNITS
+#define GNX_CORE_POST_UNITS 1  // units of two rows per thread of the streamed FeedForward body (2 + the L2 touch loads: 39.6 vs 38.1 us, see below)
+#endif
 // TRANS = false: both activations are identity / relu (the reference's FeedForward) — the tanh / sigmoid / gelu expansions of a run-time
 // activation switch cost ~60 registers on every path, relu's included.
 template <int D, bool TRANS>
@@ -223,49 +226,76 @@ struct CorePostStream {
 template <int D, bool TRANS>
 __device__ __forceinline__ void core_post_s_body(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2, gnx_dense fc1,
                                                  gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out, unsigned blk, unsigned nblk) {
-  constexpr int M = 2;
+  // A thread walks GNX_CORE_POST_UNITS units of two rows (rows row0 + m*stride, m = 2u, 2u+1).  With more than one unit, while a unit's FMAs
+  // run the lines of the thread's NEXT unit are pulled into the L2 by one dword load per row and array whose destination is never read
+  // (kept reserved until the next unit's own loads have returned: loads complete in order), so that the next unit starts from the L2
+  // instead of from HBM.  Measured on the README ex.3 model: 39.6 us per k_core_post3 launch with two units against 38.1 us with one
+  // (half as many, twice as long waves) — not taken, the default is one unit.
+  constexpr int M = 2, U = GNX_CORE_POST_UNITS;
   const size_t stride = (size_t)nblk * 256;
   const size_t row0 = (size_t)blk * 256 + threadIdx.x;
   if (row0 >= rows) return;
   const cfloatp b2 = as_const(fc2.bias ? fc2.bias : k_zero_bias), g2 = as_const(gamma2), be2 = as_const(beta2);
   P2 z[D], acc[D];
   CorePostStream<D, TRANS> st{as_const(fc1.weight), as_const(fc2.weight), as_const(fc1.bias ? fc1.bias : k_zero_bias), fc1.act, z, acc};
-  st.G0.issue(st.template group_ptr<0>());
-  float rs[M][D];
-  size_t row[M];
+  float touched = 0.f;
+#pragma unroll 1
+  for (int u = 0; u < U; ++u) {
+    const size_t rbase = row0 + (size_t)(M * u) * stride;
+    if (rbase >= rows) break;
+    st.G0.issue(st.template group_ptr<0>());
+    float rs[M][D];
+    size_t row[M];
+    float zr[M][D], blkr[M][D];
 #pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const size_t rm = row0 + m * stride;
-    row[m] = rm < rows ? rm : row0;  // clamped: a lane without a second row recomputes its first one (its store is skipped)
-    float zr[D], blk[D];
-    load_row<D>(x + row[m] * D, zr);
-    load_row<D>(out + row[m] * D, blk);  // block(gn1(x)) written by the block forward
-#pragma unroll
-    for (int k = 0; k < D; ++k) rs[m][k] = zr[k] + blk[k];  // the two residual terms (gncore.jl:56-59)
-    normalise<D>(zr, eps, eps_mode);
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      const float v = fmaf(g2[k], zr[k], be2[k]);
-      if (m == 0) { z[k].x = v; acc[k].x = b2[k]; } else { z[k].y = v; acc[k].y = b2[k]; }
-    }
-  }
-  pin_pairs<D>(z);
-  pin_pairs<D>(acc);
-  st.template run<0>();
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    float o[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) o[k] = m == 0 ? acc[k].x : acc[k].y;
-    if constexpr (TRANS) act_row<D>(o, fc2.act);
-    else if (fc2.act == 1) {
-#pragma unroll
-      for (int k = 0; k < D; ++k) o[k] = fmaxf(o[k], 0.f);
+    for (int m = 0; m < M; ++m) {
+      const size_t rm = rbase + m * stride;
+      row[m] = rm < rows ? rm : rbase;  // clamped: a lane without a second row recomputes its first one (its store is skipped)
+      load_row<D>(x + row[m] * D, zr[m]);
+      load_row<D>(out + row[m] * D, blkr[m]);  // block(gn1(x)) written by the block forward
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k) o[k] = rs[m][k] + o[k];
-    if (m == 0 || row0 + m * stride < rows) store_row<D>(out + row[m] * D, o);
+    for (int m = 0; m < M; ++m) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) rs[m][k] = zr[m][k] + blkr[m][k];  // the two residual terms (gncore.jl:56-59)
+      normalise<D>(zr[m], eps, eps_mode);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const float v = fmaf(g2[k], zr[m][k], be2[k]);
+        if (m == 0) { z[k].x = v; acc[k].x = b2[k]; } else { z[k].y = v; acc[k].y = b2[k]; }
+      }
+    }
+    pin_pairs<D>(z);
+    pin_pairs<D>(acc);
+    // (behind the pins: this unit's rows have arrived, so the touch loads are the only requests in flight under the FMAs and the
+    // waits the compiler placed for the unit's own loads did not have to cover them)
+    if (U > 1 && u + 1 < U) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const size_t rn = rbase + (size_t)(M + m) * stride;
+        if (rn < rows) {
+          asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(x + rn * D));
+          asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(out + rn * D));
+        }
+      }
+    }
+    st.template run<0>();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      float o[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) o[k] = m == 0 ? acc[k].x : acc[k].y;
+      if constexpr (TRANS) act_row<D>(o, fc2.act);
+      else if (fc2.act == 1) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) o[k] = fmaxf(o[k], 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k) o[k] = rs[m][k] + o[k];
+      if (m == 0 || rbase + m * stride < rows) store_row<D>(out + row[m] * D, o);
+    }
   }
+  if constexpr (U > 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched));  // the touch loads' destination stays reserved until they have landed
 }
 template <int D, bool TRANS>
 __global__ __launch_bounds__(256) void k_core_post_s(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2,
@@ -327,6 +357,9 @@ int32_t launch_ln1_rows(const float* x, size_t rows, int d, const gnx_layernorm&
   return GNX_OK;
 }
 
+// rows per workgroup of the streamed two-rows-per-thread body
+static size_t core_post_s_rows_per_block() { return (size_t)512 * GNX_CORE_POST_UNITS; }
+
 int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm& l2, const gnx_ffn& ff, float eps, int eps_mode,
                          float* out, hipStream_t s) {
   if (rows == 0) return GNX_OK;
@@ -335,7 +368,9 @@ int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm
   const int M = (e ? atoi(e) : 2) == 2 && rows >= 65536 ? 2 : 1;  // two rows per thread once there are rows to spare
   static const bool lds_weights = getenv("GNX_CORE_POST_LDS") != nullptr;  // A/B: the LDS-broadcast form
   const bool trans = ff.fc1.act > GNX_ACT_RELU || ff.fc2.act > GNX_ACT_RELU;
-  const dim3 grid((unsigned)((rows + 256 * (size_t)M - 1) / (256 * (size_t)M)));
+  const bool streamed = !lds_weights && M == 2;
+  const size_t per_block = streamed ? core_post_s_rows_per_block() : 256 * (size_t)M;
+  const dim3 grid((unsigned)((rows + per_block - 1) / per_block));
   switch (d) {
 #define GNX_CASE(D)                                                                                                                                  \
   case D:                                                                                                                                            \
@@ -368,7 +403,7 @@ int32_t launch_core_post3(const float* const x[3], const size_t rows[3], const i
   if (!core_post3_applies(rows, d, ff)) return blk ? fail(GNX_ERR_INVALID_ARG, "internal: deferred graph update without the combined kernel") : 1;
   PostJob j[3];
   for (int t = 0; t < 3; ++t) {
-    const size_t per = t < 2 ? 512 : 256;
+    const size_t per = t < 2 ? core_post_s_rows_per_block() : 256;
     j[t] = PostJob{x[t], rows[t], l2[t].gamma, l2[t].beta, ff[t].fc1, ff[t].fc2, out[t], (unsigned)((rows[t] + per - 1) / per)};
   }
   if (blk) j[2].blocks = (unsigned)rows[2];  // one workgroup per graph (and replica)
