@@ -14,7 +14,7 @@ module GraphNetsHIP
 
 export GNGraphBatch, GNBlock, GNCore, GNCoreList, Dense, LayerNorm, batch, unbatch,
        efview, nfview, gfview, flatunpaddednf, flatunpaddedef, zerodim2nothing,
-       collapsef, unpaddedcollapsedef, flatunpaddedcollapsedef,
+       collapsef, unpaddedcollapsedef, flatunpaddedcollapsedef, ChainBlock, chain_pullback,
        block_pullback, Model, partition_graphs, DistBlock
 
 const libgnx = get(ENV, "GNX_LIB", joinpath(@__DIR__, "..", "graphnets.jl_amd", "libgnx.so"))
@@ -314,6 +314,70 @@ end
 #                 Tangent{typeof(x)}(ef=g.ef, nf=g.nf, gf=g.gf)))
 #       y, pb
 #   end
+
+# ---- GNBlock whose update functions are Chains of Dense layers (src/gnblock.jl:1-6) → gnx_chain_block_forward / _backward ----
+struct GnxChain; layers::Ptr{GnxDense}; widths::Ptr{Int32}; n_layers::Int32; reserved::Int32; end
+struct GnxChainBlockParams; de::Int32; dn::Int32; dg::Int32; reserved::Int32; edgefn::GnxChain; nodefn::GnxChain; graphfn::GnxChain; end
+struct GnxChainBlockGrads; edgefn::Ptr{GnxDenseGrad}; nodefn::Ptr{GnxDenseGrad}; graphfn::Ptr{GnxDenseGrad}; end
+struct ChainBlock                                                      # GNBlock(Chain(Dense...), Chain(Dense...), Chain(Dense...))
+    edgefn::Vector{Dense}; nodefn::Vector{Dense}; graphfn::Vector{Dense}; in::NTuple{3,Int}
+end
+outwidth(c::Vector{Dense}) = isempty(c) ? 0 : size(c[end].weight, 1)
+# device copies of every layer + the host arrays the parameter struct points at; `keep` holds what must outlive the call
+function chain_params(m::ChainBlock, keep::Vector{Any})
+    function one(c::Vector{Dense})
+        W = [upload(l.weight) for l in c]; B = [upload(l.bias) for l in c]
+        descr = [GnxDense(devptr(W[i]), devptr(B[i]), Int32(actcode(c[i].σ)), 0) for i in eachindex(c)]
+        widths = Int32[size(l.weight, 1) for l in c]
+        push!(keep, W, B, descr, widths)
+        GnxChain(isempty(c) ? C_NULL : pointer(descr), isempty(c) ? C_NULL : pointer(widths), Int32(length(c)), 0)
+    end
+    GnxChainBlockParams(m.in..., 0, one(m.edgefn), one(m.nodefn), one(m.graphfn))
+end
+function (m::ChainBlock)(x)
+    g::GNGraphBatch = x.graphs
+    R = size(something(x.ef, x.nf, x.gf), 3)
+    keep = Any[]
+    p = Ref(chain_params(m, keep))
+    oe, on, og = outwidth(m.edgefn), outwidth(m.nodefn), outwidth(m.graphfn)
+    ins = (upload(x.ef), upload(x.nf), upload(x.gf))
+    o = (zeros(Float32, oe, nedges(g), R), zeros(Float32, on, nnodes(g), R), zeros(Float32, og, ngraphs(g), R))
+    b = (DevBuf(sizeof(o[1])), DevBuf(sizeof(o[2])), DevBuf(sizeof(o[3])))
+    wsb = ccall((:gnx_chain_block_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxChainBlockParams}, Int64), g.handle, p, R)
+    wsb == 0 && error("gnx: ", unsafe_string(ccall((:gnx_last_error, libgnx), Cstring, ())))
+    ws = DevBuf(wsb)
+    GC.@preserve keep ins b ws check(ccall((:gnx_chain_block_forward, libgnx), Int32,
+        (Ptr{Cvoid}, Ptr{GnxChainBlockParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cvoid}, Csize_t, UInt32, Ptr{Cvoid}),
+        g.handle, p, devptr(ins[1]), devptr(ins[2]), devptr(ins[3]), R, devptr(b[1]), devptr(b[2]), devptr(b[3]), ws.ptr, wsb, UInt32(0), C_NULL))
+    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
+    (graphs=g, ef=oe == 0 ? nothing : download!(o[1], b[1]), nf=on == 0 ? nothing : download!(o[2], b[2]), gf=og == 0 ? nothing : download!(o[3], b[3]))
+end
+# pullback: gradients w.r.t. the inputs and every layer's (weight, bias); the forward is recomputed inside the library
+function chain_pullback(m::ChainBlock, x, ȳ)
+    g::GNGraphBatch = x.graphs
+    R = size(something(x.ef, x.nf, x.gf), 3)
+    keep = Any[]
+    p = Ref(chain_params(m, keep))
+    ins = (upload(x.ef), upload(x.nf), upload(x.gf)); cots = (upload(ȳ.ef), upload(ȳ.nf), upload(ȳ.gf))
+    zlike(a) = isnothing(a) ? nothing : DevBuf(sizeof(a))
+    dins = (zlike(x.ef), zlike(x.nf), zlike(x.gf))
+    chains = (m.edgefn, m.nodefn, m.graphfn)
+    gW = [[DevBuf(sizeof(l.weight)) for l in c] for c in chains]; gB = [[DevBuf(sizeof(l.bias)) for l in c] for c in chains]
+    arrs = [[GnxDenseGrad(Ptr{Cfloat}(gW[t][i].ptr), Ptr{Cfloat}(gB[t][i].ptr)) for i in eachindex(chains[t])] for t in 1:3]
+    gp(t) = isempty(arrs[t]) ? Ptr{GnxDenseGrad}(C_NULL) : pointer(arrs[t])
+    grads = Ref(GnxChainBlockGrads(gp(1), gp(2), gp(3)))
+    wsb = ccall((:gnx_chain_block_backward_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxChainBlockParams}, Int64), g.handle, p, R)
+    ws = DevBuf(wsb)
+    GC.@preserve keep ins cots dins gW gB arrs ws check(ccall((:gnx_chain_block_backward, libgnx), Int32,
+        (Ptr{Cvoid}, Ptr{GnxChainBlockParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64,
+         Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{GnxChainBlockGrads}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+        g.handle, p, devptr(ins[1]), devptr(ins[2]), devptr(ins[3]), devptr(cots[1]), devptr(cots[2]), devptr(cots[3]), R,
+        devptr(dins[1]), devptr(dins[2]), devptr(dins[3]), grads, ws.ptr, wsb, C_NULL))
+    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
+    dl(a, b) = isnothing(a) ? nothing : download!(similar(a), b)
+    (ef=dl(x.ef, dins[1]), nf=dl(x.nf, dins[2]), gf=dl(x.gf, dins[3]),
+     params=[[(weight=download!(similar(l.weight), gW[t][i]), bias=download!(similar(l.bias), gB[t][i])) for (i, l) in enumerate(chains[t])] for t in 1:3])
+end
 
 # ---- a chain of layers as ONE hipGraph inside libgnx (gnx_model_*): decoder(core(encoder(x))) of examples/sort/sort.jl:68-75 ----
 struct GnxLayer; kind::Int32; reserved::Int32; params::Ptr{Cvoid}; end
