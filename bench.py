@@ -194,6 +194,12 @@ def bench_c4(args, gn, torch, dev):
                        "launch": "one forward captured into a hipGraph, replayed %d times" % K,
                        "timing": "median of 3 regions (%s ms/step)" % [round(r * 1e3, 4) for r in reps],
                        "eager_ms_per_step": round(dt_eager * 1e3, 4)}}
+    if max(core) < 32:  # narrow widths run on the vector units, not the matrix cores: the model is priced against HBM like a narrow block
+        ab = (algorithmic_bytes(E, N, 1, (10, 5, 0), core) + 2 * algorithmic_bytes(E, N, 1, core, core) + algorithmic_bytes(E, N, 1, core, (3, 4, 5)) +
+              2 * 4 * (3 * 8 * (ce * ce + cn * cn + cg * cg) + 4 * (ce + cn + cg)))  # + the cores' FeedForward and LayerNorm parameters
+        line["roofline"] = {"bound": "hbm", "achieved": round(ab / dt / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ab / dt / 1e9 / HBM_PEAK_GBS, 4),
+                            "counts": "algorithmic bytes of the four layers (every layer's inputs and outputs once, SURVEY 8d; a core = its block's bytes) / whole-step time",
+                            "algorithmic_bytes": ab, "executed_flops": ex, "traffic": None}
     assert line["roofline"]["frac"] <= 1.0
     print(json.dumps(line))
 

@@ -13,10 +13,13 @@ import sys
 from collections import defaultdict
 
 
+FULL_NAMES = "--full-names" in sys.argv  # keep the template arguments of every kernel (one row per instantiation)
+
+
 def short(name):
     """gnx::k_rows_gemm<128, true>(gnx::WideArgs) -> k_rows_gemm<128,true>"""
     name = name.split("(")[0].split("::")[-1].replace(" ", "")
-    return name if name.startswith("k_rows_gemm") else name.split("<")[0]
+    return name if (FULL_NAMES or name.startswith("k_rows_gemm")) else name.split("<")[0]
 
 
 # at core dims (template arguments: BN, quad outputs, K chunk, epilogue operand streams, transcendental activation, loader class)
