@@ -142,6 +142,7 @@ SIGNATURES = {
     "gnx_dist_allgather_gf": (C.c_int32, [C.c_void_p, _pp, _pp, _pp]),
     "gnx_dist_block_forward": (C.c_int32, [C.c_void_p] + [_pp] * 10 + [C.POINTER(C.c_size_t), C.c_uint32, _pp]),
     "gnx_jit_precompile": (C.c_int32, [C.POINTER(BlockParams), C.c_int32, C.POINTER(C.c_size_t)]),
+    "gnx_jit_precompile_core_post": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "gnx_jit_stats": (C.c_int32, [_i64p]),
     "gnx_profile_enable": (C.c_int32, [C.c_int32]),
     "gnx_profile_reset": (C.c_int32, []),

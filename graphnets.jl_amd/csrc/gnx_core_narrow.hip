@@ -8,6 +8,7 @@
 // D registers of one lane and the kernel is a pure stream: x in, (block_out in,) out.
 #include "gnx_device.h"
 #include "gnx_wave_kernel.h"  // load_row / store_row / fma_rows / act_row
+#include "gnx_core_post_kernel.h"  // k_core_post / k_core_post_s / k_core_post3 (also compiled at run time for other width triples)
 
 namespace gnx {
 
@@ -27,312 +28,6 @@ __global__ __launch_bounds__(256) void k_ln1_rows(const float* __restrict__ x, s
 #pragma unroll
   for (int k = 0; k < D; ++k) v[k] = fmaf(g[k], v[k], b[k]);
   store_row<D>(y + row * D, v);
-}
-
-// The FeedForward's 8 D^2 weights (800 at D = 10) do not fit the ~100 scalar registers: as SGPR operands they are streamed in
-// groups, and hipcc's scheduler hoists the scalar loads until it spills (k_core_post<10> with scalar weights: 237 spilled SGPRs,
-// i.e. a v_readlane in front of most FMAs, 126 VGPRs).  Here the workgroup stages the weights in LDS once and every lane reads
-// them with UNIFORM addresses (ds_read_b128 of one address is a broadcast: no bank conflict) into a few VGPRs; M = 2 rows per
-// thread share each read, which keeps the LDS at ~half its rate (D + 4*ceil(D/4)/... reads per 8 D M FMAs).
-template <int D, int M>
-__device__ __forceinline__ void core_post_lds_body(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2, gnx_dense fc1,
-                                                   gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out, unsigned blk, unsigned nblk) {
-  constexpr int H = 4 * D;
-  constexpr int DP = (D + 3) / 4 * 4;  // padded row of W2 in LDS (16-B reads)
-  __shared__ __attribute__((aligned(16))) float s_w1[D * H];   // W1 (4D x D column-major): element (j, k) at k*H + j
-  __shared__ __attribute__((aligned(16))) float s_w2[H * DP];  // W2 (D x 4D column-major): element (k, j) at j*D + k -> row j padded to DP
-  __shared__ __attribute__((aligned(16))) float s_b1[H];
-  __shared__ float s_v[3 * D];                                 // b2 | gamma2 | beta2
-  for (int i = threadIdx.x; i < D * H; i += 256) s_w1[i] = fc1.weight[i];
-  for (int i = threadIdx.x; i < H * DP; i += 256) { const int jrow = i / DP, k = i % DP; s_w2[i] = k < D ? fc2.weight[jrow * D + k] : 0.f; }
-  for (int i = threadIdx.x; i < H; i += 256) s_b1[i] = fc1.bias ? fc1.bias[i] : 0.f;
-  for (int i = threadIdx.x; i < D; i += 256) { s_v[i] = fc2.bias ? fc2.bias[i] : 0.f; s_v[D + i] = gamma2[i]; s_v[2 * D + i] = beta2[i]; }
-  __syncthreads();
-
-  const size_t stride = (size_t)nblk * 256;
-  const size_t row0 = (size_t)blk * 256 + threadIdx.x;
-  if (row0 >= rows) return;
-  float rs[M][D], z[M][D], acc[M][DP];
-  size_t row[M];
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const size_t rm = row0 + m * stride;
-    row[m] = rm < rows ? rm : row0;  // clamped: a lane without an m-th row recomputes its first one (its store is skipped)
-    float blk[D];
-    load_row<D>(x + row[m] * D, z[m]);
-    load_row<D>(out + row[m] * D, blk);  // block(gn1(x)) written by the block forward
-#pragma unroll
-    for (int k = 0; k < D; ++k) rs[m][k] = z[m][k] + blk[k];  // the two residual terms (gncore.jl:56-59)
-    normalise<D>(z[m], eps, eps_mode);
-#pragma unroll
-    for (int k = 0; k < D; ++k) z[m][k] = fmaf(s_v[D + k], z[m][k], s_v[2 * D + k]);
-#pragma unroll
-    for (int k = 0; k < DP; ++k) acc[m][k] = k < D ? s_v[k] : 0.f;
-  }
-  // four hidden units at a time, produced and consumed in registers
-#pragma unroll 1
-  for (int j0 = 0; j0 < H; j0 += 4) {
-    float h[M][4];
-    const float4 bb = *reinterpret_cast<const float4*>(s_b1 + j0);
-#pragma unroll
-    for (int m = 0; m < M; ++m) { h[m][0] = bb.x; h[m][1] = bb.y; h[m][2] = bb.z; h[m][3] = bb.w; }
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      // (left alone the scheduler hoists every weight read of the iteration: 22 float4 = 88 VGPRs; other waves cover the LDS latency)
-      if (k % 4 == 0) __builtin_amdgcn_sched_barrier(0);
-      const float4 w = *reinterpret_cast<const float4*>(s_w1 + k * H + j0);
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        h[m][0] = fmaf(w.x, z[m][k], h[m][0]); h[m][1] = fmaf(w.y, z[m][k], h[m][1]);
-        h[m][2] = fmaf(w.z, z[m][k], h[m][2]); h[m][3] = fmaf(w.w, z[m][k], h[m][3]);
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < M; ++m) act_row<4>(h[m], fc1.act);
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < DP / 4; ++q) {
-        const float4 w = *reinterpret_cast<const float4*>(s_w2 + (j0 + jj) * DP + 4 * q);
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          acc[m][4 * q] = fmaf(w.x, h[m][jj], acc[m][4 * q]); acc[m][4 * q + 1] = fmaf(w.y, h[m][jj], acc[m][4 * q + 1]);
-          acc[m][4 * q + 2] = fmaf(w.z, h[m][jj], acc[m][4 * q + 2]); acc[m][4 * q + 3] = fmaf(w.w, h[m][jj], acc[m][4 * q + 3]);
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    float o[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) o[k] = acc[m][k];
-    act_row<D>(o, fc2.act);
-#pragma unroll
-    for (int k = 0; k < D; ++k) o[k] = rs[m][k] + o[k];
-    if (m == 0 || row0 + m * stride < rows) store_row<D>(out + row[m] * D, o);
-  }
-}
-
-
-template <int D, int M>
-__global__ __launch_bounds__(256) void k_core_post(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2,
-                                                   gnx_dense fc1, gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out) {
-  core_post_lds_body<D, M>(x, rows, gamma2, beta2, fc1, fc2, eps, eps_mode, out, blockIdx.x, gridDim.x);
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Weights as SCALAR operands, streamed by hand.  Left to the compiler, scalar weight loads are hoisted until the SGPR file spills;
-// staged in LDS (k_core_post above), every broadcast ds_read_b128 still moves 64 x 16 B and the LDS runs exactly as long as the
-// VALU (22 reads per 176 FMAs at M = 2: 704 LDS clocks per 704 VALU clocks over four SIMDs).  Here a GROUP of N consecutive
-// weights is fetched by s_load_dwordx{16,8,4,2} issued from inline asm — volatile asm statements keep their order, so the
-// compiler can neither hoist nor merge them — into one of two register sets: the next group is in flight while the FMAs of the
-// current one run (scalar loads return out of order, so the only wait is lgkmcnt(0), placed BEFORE the next issue), and the FMAs
-// take the weight as their SGPR operand.  No LDS, no workgroup barrier, 4*D live weight registers.
-// ---------------------------------------------------------------------------------------------------------------------------------
-// out = x + block_out + W2 act(W1 gn2(x) + b1) + b2, TWO rows per thread held as register pairs: every FMA is one v_pk_fma_f32
-// whose src0 is the SGPR pair holding the weight (op_sel picks its low or high half for both rows) — half the VALU issue of scalar FMAs.
-// The hidden layer is produced and consumed in two halves of HB = 2D units; the weight stream of a half is [b1 half | D rows of W1
-// (2D consecutive hidden units of input k) | D row PAIRS of W2 (2D consecutive floats: hidden units 2g, 2g+1)], every group 2D floats
-// = 2D packed FMAs.  The 2(2D+1) groups are walked by a compile-time recursion (GI = global group index: half, position and
-// register set are constants of each step).  The FMAs are (non-volatile) asm statements too: left as C, the vectoriser packs them
-// itself — with the weight copied into a VGPR pair first — and collects them behind the loads of ALL groups (800 spilled SGPRs).
-#ifndef GNX_CORE_POST_UNITS
-#define GNX_CORE_POST_UNITS 1  // units of two rows per thread of the streamed FeedForward body (2 + the L2 touch loads: 39.6 vs 38.1 us, see below)
-#endif
-// TRANS = false: both activations are identity / relu (the reference's FeedForward) — the tanh / sigmoid / gelu expansions of a run-time
-// activation switch cost ~60 registers on every path, relu's included.
-template <int D, bool TRANS>
-struct CorePostStream {
-  static constexpr int H = 4 * D, HB = 2 * D, NG = 2 * D + 1, TOTAL = 2 * NG;
-  cfloatp W1, W2, b1;
-  int act1;
-  P2 (&z)[D];
-  P2 (&acc)[D];
-  P2 h[HB];
-  SGroup<HB> G0, G1;
-
-  template <int GI>
-  __device__ __forceinline__ cfloatp group_ptr() const {
-    constexpr int p = GI / NG, i = GI % NG;
-    if constexpr (i == 0) return b1 + p * HB;
-    else if constexpr (i <= D) return W1 + (i - 1) * H + p * HB;
-    else return W2 + (p * HB + 2 * (i - D - 1)) * D;
-  }
-  template <int GI>
-  __device__ __forceinline__ void consume(const SGroup<HB>& cur) {
-    constexpr int i = GI % NG;
-    if constexpr (i == 0) {
-#pragma unroll
-      for (int j = 0; j < HB; ++j) { const float b = cur.get(j); h[j].x = b; h[j].y = b; }
-      pin_pairs<HB>(h);
-    } else if constexpr (i <= D) {
-      constexpr int k = i - 1;
-#pragma unroll
-      for (int q = 0; q < HB / 2; ++q) {
-        const v2f_t w = cur.pair(q);
-        pk_fma_sw<false>(h[2 * q], w, z[k]);
-        pk_fma_sw<true>(h[2 * q + 1], w, z[k]);
-      }
-      if constexpr (i == D) {
-        if constexpr (TRANS) {
-          float t[HB];
-#pragma unroll
-          for (int j = 0; j < HB; ++j) t[j] = h[j].x;
-          act_row<HB>(t, act1);
-#pragma unroll
-          for (int j = 0; j < HB; ++j) { h[j].x = t[j]; t[j] = h[j].y; }
-          act_row<HB>(t, act1);
-#pragma unroll
-          for (int j = 0; j < HB; ++j) h[j].y = t[j];
-        } else if (act1 == 1) {
-#pragma unroll
-          for (int j = 0; j < HB; ++j) { h[j].x = fmaxf(h[j].x, 0.f); h[j].y = fmaxf(h[j].y, 0.f); }
-        }
-      }
-      pin_pairs<HB>(h);
-    } else {
-      constexpr int j = 2 * (i - D - 1);
-#pragma unroll
-      for (int q = 0; q < D; ++q) {  // pair q = weights 2q, 2q+1 of [W2 row j | W2 row j+1]
-        const v2f_t w = cur.pair(q);
-        pk_fma_sw<false>(acc[(2 * q) % D], w, h[j + (2 * q) / D]);
-        pk_fma_sw<true>(acc[(2 * q + 1) % D], w, h[j + (2 * q + 1) / D]);
-      }
-      pin_pairs<D>(acc);
-    }
-  }
-  template <int GI>
-  __device__ __forceinline__ void run() {
-    if constexpr (GI < TOTAL) {
-      if constexpr (GI % 2 == 0) {
-        G0.wait();
-        if constexpr (GI + 1 < TOTAL) G1.issue(group_ptr<GI + 1>());
-        __builtin_amdgcn_sched_barrier(0);
-        consume<GI>(G0);
-      } else {
-        G1.wait();
-        if constexpr (GI + 1 < TOTAL) G0.issue(group_ptr<GI + 1>());
-        __builtin_amdgcn_sched_barrier(0);
-        consume<GI>(G1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      run<GI + 1>();
-    }
-  }
-};
-
-template <int D, bool TRANS>
-__device__ __forceinline__ void core_post_s_body(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2, gnx_dense fc1,
-                                                 gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out, unsigned blk, unsigned nblk) {
-  // A thread walks GNX_CORE_POST_UNITS units of two rows (rows row0 + m*stride, m = 2u, 2u+1).  With more than one unit, while a unit's FMAs
-  // run the lines of the thread's NEXT unit are pulled into the L2 by one dword load per row and array whose destination is never read
-  // (kept reserved until the next unit's own loads have returned: loads complete in order), so that the next unit starts from the L2
-  // instead of from HBM.  Measured on the README ex.3 model: 39.6 us per k_core_post3 launch with two units against 38.1 us with one
-  // (half as many, twice as long waves) — not taken, the default is one unit.
-  constexpr int M = 2, U = GNX_CORE_POST_UNITS;
-  const size_t stride = (size_t)nblk * 256;
-  const size_t row0 = (size_t)blk * 256 + threadIdx.x;
-  if (row0 >= rows) return;
-  const cfloatp b2 = as_const(fc2.bias ? fc2.bias : k_zero_bias), g2 = as_const(gamma2), be2 = as_const(beta2);
-  P2 z[D], acc[D];
-  CorePostStream<D, TRANS> st{as_const(fc1.weight), as_const(fc2.weight), as_const(fc1.bias ? fc1.bias : k_zero_bias), fc1.act, z, acc};
-  float touched = 0.f;
-#pragma unroll 1
-  for (int u = 0; u < U; ++u) {
-    const size_t rbase = row0 + (size_t)(M * u) * stride;
-    if (rbase >= rows) break;
-    st.G0.issue(st.template group_ptr<0>());
-    float rs[M][D];
-    size_t row[M];
-    float zr[M][D], blkr[M][D];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const size_t rm = rbase + m * stride;
-      row[m] = rm < rows ? rm : rbase;  // clamped: a lane without a second row recomputes its first one (its store is skipped)
-      load_row<D>(x + row[m] * D, zr[m]);
-      load_row<D>(out + row[m] * D, blkr[m]);  // block(gn1(x)) written by the block forward
-    }
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-#pragma unroll
-      for (int k = 0; k < D; ++k) rs[m][k] = zr[m][k] + blkr[m][k];  // the two residual terms (gncore.jl:56-59)
-      normalise<D>(zr[m], eps, eps_mode);
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const float v = fmaf(g2[k], zr[m][k], be2[k]);
-        if (m == 0) { z[k].x = v; acc[k].x = b2[k]; } else { z[k].y = v; acc[k].y = b2[k]; }
-      }
-    }
-    pin_pairs<D>(z);
-    pin_pairs<D>(acc);
-    // (behind the pins: this unit's rows have arrived, so the touch loads are the only requests in flight under the FMAs and the
-    // waits the compiler placed for the unit's own loads did not have to cover them)
-    if (U > 1 && u + 1 < U) {
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        const size_t rn = rbase + (size_t)(M + m) * stride;
-        if (rn < rows) {
-          asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(x + rn * D));
-          asm volatile("global_load_dword %0, %1, off" : "+v"(touched) : "v"(out + rn * D));
-        }
-      }
-    }
-    st.template run<0>();
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      float o[D];
-#pragma unroll
-      for (int k = 0; k < D; ++k) o[k] = m == 0 ? acc[k].x : acc[k].y;
-      if constexpr (TRANS) act_row<D>(o, fc2.act);
-      else if (fc2.act == 1) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) o[k] = fmaxf(o[k], 0.f);
-      }
-#pragma unroll
-      for (int k = 0; k < D; ++k) o[k] = rs[m][k] + o[k];
-      if (m == 0 || rbase + m * stride < rows) store_row<D>(out + row[m] * D, o);
-    }
-  }
-  if constexpr (U > 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched));  // the touch loads' destination stays reserved until they have landed
-}
-template <int D, bool TRANS>
-__global__ __launch_bounds__(256) void k_core_post_s(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2,
-                                                     gnx_dense fc1, gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out) {
-  core_post_s_body<D, TRANS>(x, rows, gamma2, beta2, fc1, fc2, eps, eps_mode, out, blockIdx.x, gridDim.x);
-}
-
-// The three entities of a core in ONE launch (workgroup ranges: edges | nodes | graphs): the node and graph rows ride in the shadow of
-// the edge rows instead of paying two more kernel boundaries (7.3 + 4.7 us of the README ex.3 core on the 1M-edge graph).  Edges and
-// nodes: the streamed two-rows-per-thread body; graphs (few rows): the LDS body, one row per thread.
-struct PostJob {
-  const float* x; size_t rows; const float* gamma; const float* beta; gnx_dense fc1, fc2; float* out; unsigned blocks;
-};
-// GU: the block's graph update (graph_update_rows over the partial-sum rows k_block_wave left) runs HERE, in the graph job's workgroups
-// (one per graph), followed by that graph's FeedForward + residual — the block is launched without its k_graph_t, whose 6.5 us then
-// hide behind the edge rows.
-template <int D0, int D1, int D2, bool GU>
-__global__ __launch_bounds__(256) void k_core_post3(PostJob e, PostJob n, PostJob g, float eps, int eps_mode, BlockArgs a, int n_rows) {
-  // workgroup ranges: graphs | edges | nodes — the graph job (a serial chain of a few microseconds) is dispatched FIRST, so that it runs
-  // beside the edge rows instead of behind them
-  const unsigned b = blockIdx.x;
-  if (b >= g.blocks && b < g.blocks + e.blocks) core_post_s_body<D0, false>(e.x, e.rows, e.gamma, e.beta, e.fc1, e.fc2, eps, eps_mode, e.out, b - g.blocks, e.blocks);
-  else if (b >= g.blocks) core_post_s_body<D1, false>(n.x, n.rows, n.gamma, n.beta, n.fc1, n.fc2, eps, eps_mode, n.out, b - g.blocks - e.blocks, n.blocks);
-  else if constexpr (!GU) core_post_lds_body<D2, 1>(g.x, g.rows, g.gamma, g.beta, g.fc1, g.fc2, eps, eps_mode, g.out, b, g.blocks);
-  else {
-    constexpr int C = D0 + D1, CP = (C + 3) / 4 * 4;
-    __shared__ float s_g[graph_update_lds_floats(C, D2, D2, 256)];
-    const unsigned gb = b;
-    const int gi = (int)(gb % (unsigned)a.G);
-    const size_t r = gb / (unsigned)a.G;
-    const bool oneg = a.G == 1;  // one row per workgroup of k_block_wave, else one per wave tile (gnx_narrow.hip: partial_rows)
-    const int t0 = oneg ? 0 : a.wtile_off[gi], t1 = oneg ? (a.n_wtiles + 3) / 4 : a.wtile_off[gi + 1];
-    graph_update_rows<C, false, 16>(a, a.partials + r * (size_t)n_rows * CP, gi, r, t0, t1, (int)threadIdx.x, 256, s_g);
-    __syncthreads();  // gf' of this graph is in memory (written by this workgroup): the FeedForward below reads it as the block's output
-    const size_t row = r * (size_t)a.G + gi;
-    core_post_lds_body<D2, 1>(g.x + row * D2, 1, g.gamma, g.beta, g.fc1, g.fc2, eps, eps_mode, g.out + row * D2, 0, 1);
-  }
 }
 
 #ifdef GNX_CORE_FEW
@@ -387,20 +82,28 @@ int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm
   return GNX_OK;
 }
 
-// One launch for the three entities of a core when the width triple is instantiated (README ex.3's core widths), the edge and node
-// levels have rows to spare (two rows per thread) and the activations are identity / relu.
-bool core_post3_applies(const size_t rows[3], const int d[3], const gnx_ffn ff[3]) {
+int32_t jit_get_core_post3(int d0, int d1, int d2, hipStream_t s, hipFunction_t* fn);  // gnx_jit.cpp
+
+// One launch for the three entities of a core: the edge and node levels have rows to spare (two rows per thread), the activations are
+// identity / relu and the combined kernel exists for the width triple — ahead of time for README ex.3's (10,5,3), specialised at run
+// time (hiprtc, like the fused block kernel; never inside a stream capture) for any other triple of narrow widths.  `deferred`: the
+// caller wants to launch the block WITHOUT its graph update (it then runs inside this launch); the run-time specialised kernel
+// exists in that form only.
+bool core_post3_applies(const size_t rows[3], const int d[3], const gnx_ffn ff[3], bool deferred, hipStream_t s) {
   static const bool off = getenv("GNX_CORE_POST_SPLIT") != nullptr || getenv("GNX_CORE_POST_LDS") != nullptr;
   if (off || rows[0] < 65536 || rows[1] < 65536 || rows[2] == 0 || rows[2] >= 65536) return false;
   for (int t = 0; t < 3; ++t)
-    if (ff[t].fc1.act > GNX_ACT_RELU || ff[t].fc2.act > GNX_ACT_RELU) return false;
-  return d[0] == 10 && d[1] == 5 && d[2] == 3;
+    if (ff[t].fc1.act > GNX_ACT_RELU || ff[t].fc2.act > GNX_ACT_RELU || !core_narrow_width(d[t])) return false;
+  if (d[0] == 10 && d[1] == 5 && d[2] == 3) return true;
+  if (!deferred) return false;
+  hipFunction_t fn;
+  return jit_get_core_post3(d[0], d[1], d[2], s, &fn) == GNX_OK;
 }
 // blk != nullptr: the block was launched without its graph update — it runs inside this launch (n_rows = partial-sum rows per replica).
 // 1 = not applicable (three launches).
 int32_t launch_core_post3(const float* const x[3], const size_t rows[3], const int d[3], const gnx_layernorm l2[3], const gnx_ffn ff[3], float eps,
                           int eps_mode, float* const out[3], hipStream_t s, const BlockArgs* blk, int n_rows) {
-  if (!core_post3_applies(rows, d, ff)) return blk ? fail(GNX_ERR_INVALID_ARG, "internal: deferred graph update without the combined kernel") : 1;
+  if (!core_post3_applies(rows, d, ff, blk != nullptr, s)) return blk ? fail(GNX_ERR_INVALID_ARG, "internal: deferred graph update without the combined kernel") : 1;
   PostJob j[3];
   for (int t = 0; t < 3; ++t) {
     const size_t per = t < 2 ? core_post_s_rows_per_block() : 256;
@@ -409,8 +112,16 @@ int32_t launch_core_post3(const float* const x[3], const size_t rows[3], const i
   if (blk) j[2].blocks = (unsigned)rows[2];  // one workgroup per graph (and replica)
   const dim3 grid(j[0].blocks + j[1].blocks + j[2].blocks);
   ProfScope ps("k_core_post", s);
-  if (blk) hipLaunchKernelGGL((k_core_post3<10, 5, 3, true>), grid, dim3(256), 0, s, j[0], j[1], j[2], eps, eps_mode, *blk, n_rows);
-  else hipLaunchKernelGGL((k_core_post3<10, 5, 3, false>), grid, dim3(256), 0, s, j[0], j[1], j[2], eps, eps_mode, BlockArgs{}, 0);
+  if (d[0] == 10 && d[1] == 5 && d[2] == 3) {
+    if (blk) hipLaunchKernelGGL((k_core_post3<10, 5, 3, true>), grid, dim3(256), 0, s, j[0], j[1], j[2], eps, eps_mode, *blk, n_rows);
+    else hipLaunchKernelGGL((k_core_post3<10, 5, 3, false>), grid, dim3(256), 0, s, j[0], j[1], j[2], eps, eps_mode, BlockArgs{}, 0);
+  } else {
+    hipFunction_t fn = nullptr;
+    if (jit_get_core_post3(d[0], d[1], d[2], s, &fn) != GNX_OK) return fail(GNX_ERR_INVALID_ARG, "internal: the combined kernel of this width triple is not loaded");
+    BlockArgs a = *blk;
+    void* params[] = {&j[0], &j[1], &j[2], &eps, &eps_mode, &a, &n_rows};
+    GNX_HIP(hipModuleLaunchKernel(fn, grid.x, 1, 1, 256, 1, 1, 0, s, params, nullptr));
+  }
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }

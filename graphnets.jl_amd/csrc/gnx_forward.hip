@@ -41,7 +41,7 @@ bool ffn_fused_applies(const float* z, int d, const gnx_ffn& ff, const float* ad
 bool block_wide_ln_applies(const gnx_graphs* h, const BlockArgs& a);
 bool ln_stats_applies(const float* x, int d);
 int32_t launch_ln_stats(const float* x, size_t rows, int d, float eps, int eps_mode, float* stats, hipStream_t s);
-bool core_post3_applies(const size_t rows[3], const int d[3], const gnx_ffn ff[3]);
+bool core_post3_applies(const size_t rows[3], const int d[3], const gnx_ffn ff[3], bool deferred, hipStream_t s);
 int32_t launch_core_post3(const float* const x[3], const size_t rows[3], const int d[3], const gnx_layernorm l2[3], const gnx_ffn ff[3], float eps,
                           int eps_mode, float* const out[3], hipStream_t s, const BlockArgs* blk, int n_rows);
 int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm& l2, const gnx_ffn& ff, float eps, int eps_mode,
@@ -223,6 +223,11 @@ size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, i
   ensure_aux(h);
   size_t off[8], total;
   core_ws(h, p, R, off, &total);
+  {  // run-time specialisation of a narrow core's combined FeedForward launch happens here (as for the block: never in a capture)
+    const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
+    const int d[3] = {p->block.de, p->block.dn, p->block.dg};
+    if (h->E > 0 && core_narrow_width(d[0]) && core_narrow_width(d[1]) && core_narrow_width(d[2])) (void)core_post3_applies(rows, d, p->ff, true, nullptr);
+  }
   return total;
 }
 
@@ -277,7 +282,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     // edges' k_core_post — was measured: README ex.3 model 298 vs 271 us; two fork/join pairs cost more than the ~20 us they hide)
     // when the three FeedForwards go out as ONE launch (k_core_post3), the block's graph update runs inside it: the block is launched
     // without its k_graph_t
-    defer_gu = core_post3_applies(rows, d, p->ff) && h->E > 0 && !(flags & GNX_FLAG_DEFER_GRAPH_UPDATE);
+    defer_gu = h->E > 0 && !(flags & GNX_FLAG_DEFER_GRAPH_UPDATE) && core_post3_applies(rows, d, p->ff, true, s);
     rc = block_forward_impl(h, &b, ef, nf, gf, R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, defer_gu ? 1 : 3, p->ln1, p->eps,
                             p->eps_mode, &fused_ln, nullptr, &blk_args);
     if (rc) return rc;

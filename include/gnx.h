@@ -371,6 +371,9 @@ GNX_API int32_t gnx_dist_block_forward(gnx_dist* d, const gnx_graphs* const* h, 
  * gnx_jit_precompile: compile only (no GPU needed) — build-time / CI check; *code_bytes = size of the code object.
  * gnx_jit_stats: out = {compiled, disk-cache hits, failures, first uses inside a capture}. */
 GNX_API int32_t gnx_jit_precompile(const gnx_block_params* p, int32_t wtile_e_cap, size_t* code_bytes);
+/* the same check for the one-launch FeedForward + residual kernel of a narrow GNCore (widths 1..16), which is specialised at run time for
+ * width triples other than README ex.3's (10,5,3) */
+GNX_API int32_t gnx_jit_precompile_core_post(int32_t de, int32_t dn, int32_t dg, size_t* code_bytes);
 GNX_API int32_t gnx_jit_stats(int64_t out[4]);
 
 /* ---- per-kernel HIP-event timing (bench/roofline evidence) ---- */

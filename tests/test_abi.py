@@ -89,6 +89,11 @@ def test_runtime_specialised_kernel_source_compiles_for_gfx950(lib):
     assert lib.gnx_jit_precompile(C.byref(L.BlockParams(24, 4, 0, 3, 4, 5)), 128, C.byref(n)) == 0    # mid widths are eligible
     assert lib.gnx_jit_precompile(C.byref(L.BlockParams(16, 16, 16, 16, 16, 16)), 128, C.byref(n)) == -6  # too many weights: MFMA path
     assert lib.gnx_jit_precompile(C.byref(L.BlockParams(7, 3, 2, 5, 6, 1)), 100, C.byref(n)) == -1
+    # the narrow GNCore's one-launch FeedForward kernel (hand-streamed scalar weights, packed FMAs: inline asm) for another width triple
+    n.value = 0
+    assert lib.gnx_jit_precompile_core_post(6, 4, 2, C.byref(n)) == 0, lib.gnx_last_error()
+    assert n.value > 1000
+    assert lib.gnx_jit_precompile_core_post(17, 4, 2, C.byref(n)) == -6
     st = (C.c_int64 * 4)()
     assert lib.gnx_jit_stats(st) == 0 and st[0] >= 1 and st[2] == 0
 

@@ -275,3 +275,41 @@ def test_c_level_model_graph_matches_eager(gn):
     if not t_model < 1.5 * t_eager:  # (see test_graphed_model_replay_matches_eager: a timing on a shared box is reported, not failed)
         import warnings
         warnings.warn(f"gnx_model replay not faster than eager in this run: {t_model * 1e6:.0f} vs {t_eager * 1e6:.0f} us")
+
+
+@pytest.mark.parametrize("dims,hetero", [((6, 4, 2), False), ((12, 7, 4), True), ((10, 5, 3), True)], ids=lambda v: str(v))
+def test_narrow_core_one_launch_feedforward_other_width_triples(gn, dims, hetero):
+    """Narrow GNCore with rows to spare (>= 65536 edges and nodes): the three entities' FeedForward + residual go out as ONE launch with
+    the block's graph update inside it (k_core_post3) — ahead of time for README ex.3's widths, specialised at run time for any other
+    triple; one big graph and a batch of many graphs (one graph-update workgroup per graph), layer by layer against the oracle."""
+    import ctypes as C
+    rng = np.random.default_rng(900 + sum(dims))
+    if hetero:
+        sizes = rng.integers(150, 400, 300)
+        cs = [U.er_csc(rng, int(n), 3 * int(n)) for n in sizes]
+        cps, rvs, nn = [c[0] for c in cs], [c[1] for c in cs], [int(n) for n in sizes]
+    else:
+        cp, rv = U.er_csc(rng, 70_000, 150_000)
+        cps, rvs, nn = [cp], [rv], [70_000]
+    g = gn.GNGraphBatch.from_csc(cps, rvs, nn)
+    assert g.n_edges >= 65536 and g.n_nodes >= 65536
+    stats0 = (C.c_int64 * 4)()
+    gn._lib.load().gnx_jit_stats(stats0)
+    ps = [O.make_core_params(rng, dims, eps_mode=i) for i in range(2)]
+    model = gn.GNCoreList([U.core_from_params(gn, p) for p in ps])
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims)
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    U.check_chain(gn, g, csc, [("core", p, c) for p, c in zip(ps, model.list)], (ef, nf, gf), f"two GNCore{dims}")
+    stats1 = (C.c_int64 * 4)()
+    gn._lib.load().gnx_jit_stats(stats1)
+    assert stats1[2] == stats0[2], "a run-time compilation failed"
+    # per-kernel timing shows the launch structure: one k_core_post per core and no k_graph_t (the graph update ran inside it)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    model(x)
+    gn.profile_reset(); gn.profile_enable(True)
+    model(x)
+    import torch
+    torch.cuda.synchronize()
+    gn.profile_enable(False)
+    prof = gn.profile_read(); gn.profile_reset()
+    assert prof["k_core_post"]["launches"] == 2 and "k_graph_t" not in prof, prof
