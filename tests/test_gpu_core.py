@@ -313,3 +313,24 @@ def test_narrow_core_one_launch_feedforward_other_width_triples(gn, dims, hetero
     gn.profile_enable(False)
     prof = gn.profile_read(); gn.profile_reset()
     assert prof["k_core_post"]["launches"] == 2 and "k_graph_t" not in prof, prof
+
+
+@pytest.mark.parametrize("dims", [(10, 5, 3), (7, 3, 2)], ids=str)
+def test_narrow_core_one_launch_feedforward_with_replicas(gn, dims):
+    """The same one-launch form on a shared graph with batch_size 2 (replicas: one graph-update workgroup per (graph, replica))."""
+    rng = np.random.default_rng(950 + sum(dims))
+    cp, rv = U.er_csc(rng, 40_000, 90_000)
+    g = gn.GNGraphBatch.from_csc([cp], [rv], [40_000])
+    p = O.make_core_params(rng, dims)
+    core = U.core_from_params(gn, p)
+    ef, nf, gf = U.packed_inputs(rng, 2, g.n_edges, g.n_nodes, 1, dims)  # R * rows >= 65536 on the edge and node level
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    U.check_chain(gn, g, csc, [("core", p, core)], (ef, nf, gf), f"GNCore{dims}, two replicas")
+    x = U.to_nt(gn, g, ef, nf, gf)
+    gn.profile_reset(); gn.profile_enable(True)
+    core(x)
+    import torch
+    torch.cuda.synchronize()
+    gn.profile_enable(False)
+    prof = gn.profile_read(); gn.profile_reset()
+    assert prof["k_core_post"]["launches"] == 1 and "k_graph_t" not in prof, prof
