@@ -249,6 +249,11 @@ struct PkStream {
 // xhat = (x - mu) * rstd over the D registers of a row; eps_mode 0: 1/(sigma+eps) (Flux 0.14 normalise), 1: 1/sqrt(var+eps)
 template <int D>
 __device__ __forceinline__ void normalise(float (&x)[D], float eps, int eps_mode) {
+  // (instruction count matters: these kernels are VALU-bound at core widths and an IEEE division is ~10 instructions.  The run-time eps
+  // convention selects the ARGUMENT of one square root and one division — written as `mode ? 1/(sqrt(v)+eps) : 1/sqrt(v+eps)` the compiler
+  // evaluates both sides and selects: two square roots and two divisions per row.  The two means stay divisions by D: as products with
+  // 1/D they save 20 instructions per row but are not the reference's arithmetic — at D = 3 the extra rounding of the mean showed in a
+  // row with a small sigma.)
   float mu = 0.f;
 #pragma unroll
   for (int k = 0; k < D; ++k) mu += x[k];
@@ -257,7 +262,9 @@ __device__ __forceinline__ void normalise(float (&x)[D], float eps, int eps_mode
 #pragma unroll
   for (int k = 0; k < D; ++k) { x[k] -= mu; var = fmaf(x[k], x[k], var); }
   var /= (float)D;
-  const float rstd = eps_mode == 0 ? 1.f / (sqrtf(var) + eps) : 1.f / sqrtf(var + eps);
+  float sd = sqrtf(eps_mode == 0 ? var : var + eps);
+  sd = eps_mode == 0 ? sd + eps : sd;
+  const float rstd = 1.f / sd;
 #pragma unroll
   for (int k = 0; k < D; ++k) x[k] *= rstd;
 }
@@ -714,11 +721,26 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
   //      Stored transposed [c][tile] so the graph update reads them with 16-B loads. ----
   if (a.og > 0) {
     if constexpr (C > 0) {
+      float sel[(C + 15) / 16];
+#pragma unroll
+      for (int g = 0; g < (C + 15) / 16; ++g) sel[g] = 0.f;
 #pragma unroll
       for (int c = 0; c < C; ++c) {
-        const float tot = wave_sum(v[c]);
-        mine = lane == c ? tot : mine;
+        const float s16 = row16_sum(v[c]);  // (unconditionally: a DPP reduction inside the select's branch would run with a partial EXEC mask)
+        sel[c >> 4] = (lane & 15) == (c & 15) ? s16 : sel[c >> 4];
       }
+      // Lane l of every DPP row now holds its ROW's sum of columns l%16 (+16, +32, +48); the four rows are added as (r0 + r1) + (r2 + r3)
+      // — the association wave_sum() uses, so the bits are the ones the per-column form (4 readlanes + 3 adds + a select per column)
+      // produced — by two lane exchanges per 16 columns instead.
+      float tot = 0.f;
+#pragma unroll
+      for (int g = 0; g < (C + 15) / 16; ++g) {
+        float w = sel[g];
+        w += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __float_as_int(w)));
+        w += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(w)));
+        tot = (lane >> 4) == g ? w : tot;
+      }
+      mine = lane < C ? tot : mine;
     }
   }
   GNX_WSTAMP(5);  // node phase done
