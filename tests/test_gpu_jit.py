@@ -137,3 +137,34 @@ def test_jit_can_be_disabled(gn):
         assert _stats() == before
     finally:
         del os.environ["GNX_JIT"]
+
+
+def test_core_feedforward_kernel_is_kept_on_disk_too(tmp_path):
+    """The run-time specialised one-launch FeedForward kernel of a narrow GNCore (k_core_post3) goes through the same disk cache: a
+    second PROCESS loads the code object instead of compiling it."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, json, ctypes as C, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import graphnets_jl_amd as gn\n"
+        "from oracle import gn_oracle as O\n"
+        "from tests import util as U\n"
+        "rng = np.random.default_rng(3)\n"
+        "cp, rv = U.er_csc(rng, 70000, 140000)\n"
+        "g = gn.GNGraphBatch.from_csc([cp], [rv], [70000])\n"
+        "core = U.core_from_params(gn, O.make_core_params(rng, (5, 4, 3)))\n"
+        "y = core(U.to_nt(gn, g, *U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, 1, (5, 4, 3))))\n"
+        "s = (C.c_int64 * 4)(); gn._lib.load().gnx_jit_stats(s)\n"
+        "print(json.dumps(dict(compiled=s[0], disk_hits=s[1], failures=s[2], ef=float(y.ef.sum()))))\n")
+    env = dict(os.environ, GNX_JIT_CACHE=str(tmp_path))
+    runs = []
+    for _ in range(2):
+        out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        runs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    assert any(f.startswith("gnx_post3_5_4_3_") for f in os.listdir(tmp_path)), os.listdir(tmp_path)
+    assert runs[0]["compiled"] >= 1 and runs[0]["failures"] == 0
+    assert runs[1]["compiled"] == 0 and runs[1]["disk_hits"] >= 1 and runs[1]["failures"] == 0, runs
+    assert runs[0]["ef"] == runs[1]["ef"]
