@@ -139,6 +139,8 @@ SIGNATURES = {
     "gnx_dist_partition": (C.c_int32, [_i64p, C.c_int64, C.c_int32, _i64p, _i64p]),
     "gnx_dist_create": (C.c_int32, [C.POINTER(C.c_int32), C.c_int32, _i64p, _i64p, C.c_int64, C.c_int32, _pp]),
     "gnx_dist_destroy": (C.c_int32, [C.c_void_p]),
+    "gnx_dist_gather_plan": (C.c_int32, [_i64p, _i64p, C.c_int32, C.c_int64, C.POINTER(C.c_int32), _i64p]),
+    "gnx_dist_permute_rows": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gnx_dist_allgather_gf": (C.c_int32, [C.c_void_p, _pp, _pp, _pp]),
     "gnx_dist_block_forward": (C.c_int32, [C.c_void_p] + [_pp] * 10 + [C.POINTER(C.c_size_t), C.c_uint32, _pp]),
     "gnx_jit_precompile": (C.c_int32, [C.POINTER(BlockParams), C.c_int32, C.POINTER(C.c_size_t)]),

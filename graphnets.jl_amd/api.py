@@ -581,7 +581,10 @@ class Chain:
 
     def __init__(self, *layers):
         self.layers = list(layers[0]) if len(layers) == 1 and isinstance(layers[0], (list, tuple)) else list(layers)
-        assert all(isinstance(l, Dense) for l in self.layers), "Chain: only Dense layers are supported"
+        for l in self.layers:  # gnblock.jl:1-6 admits any Flux chain; the HIP path has row-wise Dense layers only
+            if not isinstance(l, Dense):
+                raise NotImplementedError(f"Chain: layer of type {type(l).__name__} is not supported — the update functions of a GNBlock "
+                                          "run as chains of Dense layers (gnx_chain_block_forward); wrap other layers outside the block")
 
     def __len__(self):
         return len(self.layers)
@@ -906,7 +909,16 @@ class GNCore:
     def parameters(self):
         return self._param_list()
 
+    def _training(self, extra=()):
+        return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in list(extra) + self._param_list())
+
     def __call__(self, x, flags=None):
+        # gnfeedforward.jl:27-31: the FeedForward ends in Dropout(p), which Flux applies in training mode (inside a gradient call)
+        # and skips in test mode.  The HIP FeedForward has no dropout: inference (no gradient) is the identity, as in Flux test mode;
+        # a differentiable call with p > 0 would silently train a different model, so it is refused.
+        if self.ffwd.dropout and self.ffwd.dropout > 0 and self._training():
+            raise NotImplementedError(f"GNCore: Dropout(p={self.ffwd.dropout}) in training mode is not implemented (gnfeedforward.jl:27-31); "
+                                      "use dropout=0, or call under torch.no_grad() for Flux's test-mode semantics")
         x = _as_nt(x)
         assert x.ef is not None and x.nf is not None and x.gf is not None, "GNCore needs ef, nf and gf (gncore.jl:61-68)"
         g, ef, nf, gf, R = _forward_common(x, self.dims)

@@ -984,7 +984,7 @@ int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_para
   const int de = p->de, dn = p->dn, dg = p->dg;
   const int oe = chain_out(p->edgefn), on = chain_out(p->nodefn), og = chain_out(p->graphfn);
   if ((de > 0 && !ef && h->E > 0) || (dn > 0 && !nf) || (dg > 0 && !gf)) return fail(GNX_ERR_INVALID_ARG, "an input with non-zero width is NULL");
-  if (oe == 0) return fail(GNX_ERR_DIMS, "chain backward: the edge function has no output");
+  if (oe == 0) return fail(GNX_ERR_DIMS, "chain backward: not implemented for an edge function without output (the forward takes it; train such a block with one-layer update functions)");
   const ChainBwLayout L = chain_bw_layout(h, p, R);
   if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_chain_block_backward_workspace_bytes()");
   if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");

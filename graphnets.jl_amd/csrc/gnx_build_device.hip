@@ -108,14 +108,19 @@ int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int6
     // The G matrices live in G separate pageable host arrays.  One hipMemcpy each is a driver round trip per graph (4096 graphs:
     // ~200 ms); instead they are packed into two pinned staging buffers that alternate — while one travels (asynchronous copy,
     // full PCIe rate) the host fills the other — so the upload costs one host memcpy of the bytes plus a handful of DMA transfers.
+    // The staging buffers are process-wide and PORTABLE pinned memory (usable from every device: a one-process-many-devices host —
+    // gnx_dist_*, a Julia session — builds handles on devices 1..n-1 too); the two events belong to the CURRENT device and live for
+    // this call only (an event of device 0 cannot be recorded on a stream of device r).  A failure to set the staging up is not an
+    // error of the batch: the caller falls back to the host scan (return 1).
     static std::mutex stage_mu;
     static char* stage[2] = {nullptr, nullptr};
-    static hipEvent_t stage_ev[2] = {nullptr, nullptr};
     constexpr size_t STAGE = (size_t)32 << 20;
     std::lock_guard<std::mutex> lk(stage_mu);
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int b = 0; b < 2; ++b) if (e[b]) (void)hipEventDestroy(e[b]); } } ev_guard{stage_ev};
     for (int b = 0; b < 2; ++b) {
-      if (!stage[b]) GNX_TRY(hipHostMalloc((void**)&stage[b], STAGE, hipHostMallocDefault));
-      if (!stage_ev[b]) GNX_TRY(hipEventCreateWithFlags(&stage_ev[b], hipEventDisableTiming));
+      if (!stage[b] && hipHostMalloc((void**)&stage[b], STAGE, hipHostMallocPortable) != hipSuccess) { stage[b] = nullptr; (void)hipGetLastError(); cleanup(); return 1; }
+      if (hipEventCreateWithFlags(&stage_ev[b], hipEventDisableTiming) != hipSuccess) { stage_ev[b] = nullptr; (void)hipGetLastError(); cleanup(); return 1; }
     }
     const size_t bytes_total = (size_t)total * esz;
     size_t done = 0;      // bytes of the packed adjacency stream already handed to a copy

@@ -66,9 +66,8 @@ int32_t check_params(const gnx_graphs* h, const gnx_chain_block_params* p, int64
   if ((rc = check_chain(p->edgefn, "edgefn")) || (rc = check_chain(p->nodefn, "nodefn")) || (rc = check_chain(p->graphfn, "graphfn"))) return rc;
   const int oe = out_width(p->edgefn), on = out_width(p->nodefn), og = out_width(p->graphfn);
   if (oe + on + og == 0) return fail(GNX_ERR_DIMS, "all output widths are 0 (gnblock.jl:49)");
-  // getnodefninput / getgraphfninput always take the updated edge (and node) features (nodefninput.jl:1-24, graphfninput.jl:1-13)
-  if (on > 0 && oe == 0) return fail(GNX_ERR_DIMS, "a node function needs the edge function's output (nodefninput.jl)");
-  if (og > 0 && (oe == 0 || on == 0)) return fail(GNX_ERR_DIMS, "a graph function needs the edge and node functions' outputs (graphfninput.jl)");
+  // A zero-width ef' / nf' is an empty segment of the next function's input, exactly as for one-layer update functions
+  // (gnblock.jl:63-69 computes getnodefninput / getgraphfninput over the 0-row h_ef; width 0 <=> nothing in launch_fn_input).
   return GNX_OK;
 }
 

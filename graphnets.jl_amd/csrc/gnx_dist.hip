@@ -97,28 +97,23 @@ using namespace gnx;
 
 extern "C" {
 
-int32_t gnx_dist_partition(const int64_t* edge_counts, int64_t n_graphs, int32_t n_ranks, int64_t* shard_off, int64_t* shard_graphs) {
-  if (!edge_counts || !shard_off || !shard_graphs) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
-  if (n_graphs <= 0) return fail(GNX_ERR_NO_GRAPHS, "n_graphs must be > 0");
-  if (n_ranks <= 0) return fail(GNX_ERR_INVALID_ARG, "n_ranks must be >= 1");
-  // graphs by edge count, descending (stable: ties keep ascending ids), dealt in snake order: rank 0..R-1, R-1..0, ...
-  std::vector<int64_t> order((size_t)n_graphs);
-  std::iota(order.begin(), order.end(), (int64_t)0);
-  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return edge_counts[a] > edge_counts[b]; });
-  std::vector<std::vector<int64_t>> shards((size_t)n_ranks);
-  for (int64_t i = 0; i < n_graphs; ++i) {
-    const int64_t rnd = i / n_ranks, pos = i % n_ranks;
-    shards[(size_t)(rnd % 2 == 0 ? pos : n_ranks - 1 - pos)].push_back(order[(size_t)i]);
-  }
-  int64_t o = 0;
-  for (int32_t r = 0; r < n_ranks; ++r) {
-    std::sort(shards[(size_t)r].begin(), shards[(size_t)r].end());  // a rank keeps its graphs in original order
-    shard_off[r] = o;
-    for (int64_t gidx : shards[(size_t)r]) shard_graphs[o++] = gidx;
-  }
-  shard_off[n_ranks] = o;
+// out[g][:] = gathered[src_row[g]][:] (device pointers): the step that follows the all-gather, on its own for hosts that run the
+// collective themselves (one process per GPU) and for tests of the plan
+int32_t gnx_dist_permute_rows(const float* gathered, const int32_t* src_row, int64_t n_graphs, int32_t og, float* out, void* stream) {
+  if (!gathered || !src_row || !out) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  if (n_graphs <= 0 || og <= 0 || n_graphs * (int64_t)og >= (int64_t)INT32_MAX) return fail(GNX_ERR_INVALID_ARG, "bad n_graphs / og");
+  const int total = (int)(n_graphs * og);
+  hipLaunchKernelGGL(k_dist_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gathered, src_row, (int)n_graphs, og, out);
+  GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
+
+// restores the caller's current device on every exit path
+struct DeviceRestore {
+  int prev = -1;
+  DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+  ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 int32_t gnx_dist_destroy(gnx_dist* d) {
   if (!d) return GNX_OK;
@@ -143,19 +138,14 @@ int32_t gnx_dist_create(const int32_t* device_ids, int32_t n_devices, const int6
   *out = nullptr;
   if (!device_ids || !shard_off || !shard_graphs) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
   if (n_devices <= 0 || n_graphs <= 0 || og <= 0) return fail(GNX_ERR_INVALID_ARG, "n_devices, n_graphs and og must be >= 1");
-  if (shard_off[0] != 0 || shard_off[n_devices] != n_graphs) return fail(GNX_ERR_INVALID_ARG, "shard_off must run from 0 to n_graphs");
-  std::vector<char> seen((size_t)n_graphs, 0);
-  for (int r = 0; r < n_devices; ++r) {
-    if (shard_off[r + 1] < shard_off[r]) return fail(GNX_ERR_INVALID_ARG, "shard_off must be non-decreasing");
-    for (int64_t i = shard_off[r]; i < shard_off[r + 1]; ++i) {
-      const int64_t gidx = shard_graphs[i];
-      if (gidx < 0 || gidx >= n_graphs || seen[(size_t)gidx]) return fail(GNX_ERR_INVALID_ARG, "shard_graphs must be a permutation of 0..n_graphs-1");
-      seen[(size_t)gidx] = 1;
-    }
+  std::vector<int32_t> src((size_t)n_graphs);
+  int64_t max_count = 0;
+  {
+    const int32_t rc = gnx_dist_gather_plan(shard_off, shard_graphs, n_devices, n_graphs, src.data(), &max_count);
+    if (rc) return rc;
   }
   if (!rccl().ok) return fail(GNX_ERR_INVALID_ARG, "RCCL is not available (librccl.so.1 could not be loaded)");
-  int prev_dev = 0;
-  (void)hipGetDevice(&prev_dev);
+  DeviceRestore restore;
   gnx_dist* d = new gnx_dist();
   d->n = n_devices; d->G = n_graphs; d->og = og;
   d->dev.assign(device_ids, device_ids + n_devices);
@@ -170,15 +160,12 @@ int32_t gnx_dist_create(const int32_t* device_ids, int32_t n_devices, const int6
   d->send.assign((size_t)n_devices, nullptr);
   d->recv.assign((size_t)n_devices, nullptr);
   d->src.assign((size_t)n_devices, nullptr);
-  auto bail = [&](int32_t rc) { gnx_dist_destroy(d); (void)hipSetDevice(prev_dev); return rc; };
+  auto bail = [&](int32_t rc) { gnx_dist_destroy(d); return rc; };
   {
     const ncclResult_t e = rccl().CommInitAll(d->comm.data(), n_devices, d->dev.data());
     if (e != ncclSuccess) return bail(nccl_fail(e, "ncclCommInitAll"));
   }
-  // row of the gathered [n][max_count] table for original graph g
-  std::vector<int> src((size_t)n_graphs);
-  for (int r = 0; r < n_devices; ++r)
-    for (int64_t i = shard_off[r]; i < shard_off[r + 1]; ++i) src[(size_t)shard_graphs[i]] = (int)(r * d->max_count + (i - shard_off[r]));
+  if (d->max_count != max_count) return bail(fail(GNX_ERR_INVALID_ARG, "gnx_dist_create: gather plan mismatch"));
   const size_t row = sizeof(float) * (size_t)og;
   for (int r = 0; r < n_devices; ++r) {
     hipError_t e = hipSetDevice(d->dev[(size_t)r]);
@@ -192,7 +179,6 @@ int32_t gnx_dist_create(const int32_t* device_ids, int32_t n_devices, const int6
     if (e == hipSuccess) e = hipMemcpy(d->src[(size_t)r], src.data(), sizeof(int) * (size_t)n_graphs, hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(hip_fail(e, "gnx_dist_create: per-device setup"));
   }
-  (void)hipSetDevice(prev_dev);
   *out = d;
   return GNX_OK;
 }
@@ -201,8 +187,7 @@ int32_t gnx_dist_allgather_gf(gnx_dist* d, const float* const* gf_local, float* 
   if (!d || !gf_local || !gf_all) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
   for (int r = 0; r < d->n; ++r)
     if ((d->count[(size_t)r] > 0 && !gf_local[r]) || !gf_all[r]) return fail(GNX_ERR_INVALID_ARG, "gf_local / gf_all of a rank is NULL");
-  int prev_dev = 0;
-  (void)hipGetDevice(&prev_dev);
+  DeviceRestore restore;
   const size_t row = sizeof(float) * (size_t)d->og;
   // the producers' streams hand over to the communication streams; local rows go into the (zero padded) send buffers
   for (int r = 0; r < d->n; ++r) {
@@ -229,7 +214,6 @@ int32_t gnx_dist_allgather_gf(gnx_dist* d, const float* const* gf_local, float* 
     GNX_HIP(hipEventRecord(d->ev_out[(size_t)r], d->cstream[(size_t)r]));
     GNX_HIP(hipStreamWaitEvent(streams ? (hipStream_t)streams[r] : nullptr, d->ev_out[(size_t)r], 0));
   }
-  (void)hipSetDevice(prev_dev);
   return GNX_OK;
 }
 
@@ -238,22 +222,22 @@ int32_t gnx_dist_block_forward(gnx_dist* d, const gnx_graphs* const* h, const gn
                                float* const* gf_out_local, float* const* gf_all, void* const* workspace, const size_t* workspace_bytes,
                                uint32_t flags, void* const* streams) {
   if (!d || !h || !p || !workspace || !workspace_bytes) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
-  int prev_dev = 0;
-  (void)hipGetDevice(&prev_dev);
   for (int r = 0; r < d->n; ++r) {
     if (!h[r] || !p[r]) return fail(GNX_ERR_INVALID_ARG, "handle / params of a rank is NULL");
     if (h[r]->G != d->count[(size_t)r]) return fail(GNX_ERR_COUNT_MISMATCH, "a rank's handle does not hold the graphs of its shard");
     if (p[r]->og != d->og) return fail(GNX_ERR_DIMS, "og differs from the communicator's");
     if (h[r]->device != d->dev[(size_t)r]) return fail(GNX_ERR_INVALID_ARG, "a rank's handle lives on another device");
   }
+  {
+  DeviceRestore restore;
   for (int r = 0; r < d->n; ++r) {  // launches are asynchronous: the n devices run concurrently
     GNX_HIP(hipSetDevice(d->dev[(size_t)r]));
     const int32_t rc = gnx_block_forward(h[r], p[r], ef ? ef[r] : nullptr, nf ? nf[r] : nullptr, gf ? gf[r] : nullptr, 1, ef_out ? ef_out[r] : nullptr,
                                          nf_out ? nf_out[r] : nullptr, gf_out_local ? gf_out_local[r] : nullptr, workspace[r], workspace_bytes[r], flags,
                                          streams ? streams[r] : nullptr);
-    if (rc) { (void)hipSetDevice(prev_dev); return rc; }
+    if (rc) return rc;
   }
-  (void)hipSetDevice(prev_dev);
+  }
   return gnx_dist_allgather_gf(d, gf_out_local, gf_all, streams);
 }
 

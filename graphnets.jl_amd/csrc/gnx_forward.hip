@@ -206,6 +206,11 @@ static void ensure_aux(const gnx_graphs* h) {
   std::call_once(h->aux_once, [h]() {
     hipStream_t st = nullptr;
     hipEvent_t e1 = nullptr, e2 = nullptr;
+    // the stream and its events belong to the HANDLE's device, whatever device is current in the querying thread
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev != h->device ? prev : -1};
+    if (prev != h->device && hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return; }
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
         hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess) {
       h->aux_stream = st; h->aux_fork = e1; h->aux_join = e2;
@@ -307,7 +312,10 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   if (wide_ln) {
     const float* stats[2] = {l1[0], l1[1]};  // the (unused) gn1 buffers hold the statistics: 2 floats per row
     const bool no_fork0 = getenv("GNX_NO_FORK") != nullptr;  // (read per call: tests compare both forms in one process)
-    const bool fork0 = !no_fork0 && h->aux_stream != nullptr && !profile_enabled();
+    // The handle has ONE side stream and one pair of events.  A second host thread in this section (same handle, another stream) would
+    // re-record them between this thread's record and wait: whoever does not get the lock runs everything on its own stream instead.
+    std::unique_lock<std::mutex> aux_lk(h->aux_mu, std::try_to_lock);
+    const bool fork0 = !no_fork0 && h->aux_stream != nullptr && !profile_enabled() && aux_lk.owns_lock();
     if ((rc = launch_layernorm2(x[2], rows[2], d[2], p->ln1[2], p->ln2[2], p->eps, p->eps_mode, l1[2], l2[2], s))) return rc;
     if (fork0) {
       // side stream: node statistics, gf fold, node projections (latency / matrix-core work) beside the edge statistics pass (HBM-bound)
@@ -332,7 +340,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     // node FeedForwards that follow the block: it runs on the handle's side stream behind them (fork after the node update, join
     // before returning; inside a capture the side stream joins the captured graph).  GNX_NO_FORK=1: everything on the caller's stream.
     const bool no_fork = no_fork0;
-    const bool fork = !no_fork && h->aux_stream != nullptr && !profile_enabled();
+    const bool fork = !no_fork && h->aux_stream != nullptr && !profile_enabled() && aux_lk.owns_lock();
     bool took = false;
     rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, (fork ? 1 : 3) | (fork0 ? 8 : 0), p->ln1, p->eps, p->eps_mode, &took, stats);
     if (rc) return rc;

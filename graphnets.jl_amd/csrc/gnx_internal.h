@@ -67,6 +67,7 @@ struct gnx_graphs {
   mutable std::once_flag aux_once;
   mutable hipStream_t aux_stream = nullptr;
   mutable hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+  mutable std::mutex aux_mu;  // held while a forward enqueues its fork / join pairs (try_lock: a concurrent caller stays on one stream)
   int64_t n_tiles() const { return (int64_t)h_tiles.size(); }
   int64_t n_wtiles() const { return (int64_t)h_wtiles.size(); }
 };
@@ -94,5 +95,6 @@ struct ProfScope {
 bool profile_enabled();  // per-kernel timing is on: callers keep everything on one stream (overlapped kernels would share their time)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
 
 }  // namespace gnx

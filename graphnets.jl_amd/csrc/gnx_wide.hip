@@ -824,12 +824,12 @@ __global__ void k_fold_bias(const float* __restrict__ W, const float* __restrict
 // ---- graph update for the wide path: two-stage fixed-order reduction of the per-tile column sums ----
 // stage 1: out2[r][g][s][c] = sum over the s-th slice of graph g's tile rows of in[r][tile][c]
 struct ColsumJob { const float* in; size_t in_rep_stride; const int* tile_off; int C; float* out2; };
-// (the edges' and the nodes' sums in ONE launch: blockIdx.z = 2 * replica + job; every launch of this size is ~5 us of latency)
+// (the edges' and the nodes' sums in ONE launch: blockIdx.x = 2 * graph + job; every launch of this size is ~5 us of latency)
 __global__ void k_colsum_slices(ColsumJob j0, ColsumJob j1, int S, int G) {
-  const ColsumJob j = (blockIdx.z & 1) ? j1 : j0;
+  const ColsumJob j = (blockIdx.x & 1) ? j1 : j0;  // (the job rides in grid.x: grid.z is the replica, up to 65535)
   if (!j.in || j.C == 0) return;
-  const int g = blockIdx.x, s = blockIdx.y;
-  const size_t r = blockIdx.z >> 1;
+  const int g = blockIdx.x >> 1, s = blockIdx.y;
+  const size_t r = blockIdx.z;
   const int C = j.C;
   const int t0 = j.tile_off[g], t1 = j.tile_off[g + 1];
   const int per = (t1 - t0 + S - 1) / S;
@@ -1320,7 +1320,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     if (a.oe > 0 || a.on > 0) {
       const ColsumJob je{a.oe > 0 ? pe : nullptr, n_et * (size_t)a.oe, h->d_etile_off, a.oe, pe2};
       const ColsumJob jn{a.on > 0 ? pn : nullptr, n_nt * (size_t)a.on, h->d_ntile_off, a.on, pn2};
-      hipLaunchKernelGGL(k_colsum_slices, dim3((unsigned)a.G, (unsigned)S, 2u * (unsigned)R), dim3(128), 0, s, je, jn, S, a.G);
+      hipLaunchKernelGGL(k_colsum_slices, dim3(2u * (unsigned)a.G, (unsigned)S, (unsigned)R), dim3(128), 0, s, je, jn, S, a.G);
     }
     const int Kg = a.oe + a.on + a.dg;
     if (skinny_ok(R * a.G, Kg, a.og)) {  // small batch, wide layers: assemble Xg, then the round-trip-lean GEMV kernel

@@ -27,6 +27,22 @@ def partition_graphs(edge_counts, world_size):
     return [ids[off[r]:off[r + 1]].copy() for r in range(world_size)]
 
 
+def gather_plan(shards):
+    """`gnx_dist_gather_plan` (host only): validates the partition and returns (src_row[G] int32, max_count) — row of original graph g
+    in the gathered [world * max_count] table.  The plan gnx_dist_create builds, and the one GfGather indexes with."""
+    import ctypes as C
+    from . import _lib
+    off = np.zeros(len(shards) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(s) for s in shards])
+    ids = np.ascontiguousarray(np.concatenate([np.asarray(s, dtype=np.int64) for s in shards]) if len(shards) else np.zeros(0, np.int64))
+    G = int(off[-1])
+    src = np.zeros(G, dtype=np.int32)
+    mc = C.c_int64(0)
+    p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    _lib.check(_lib.load().gnx_dist_gather_plan(p64(off), p64(ids), len(shards), G, src.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(mc)))
+    return src, int(mc.value)
+
+
 class GfGather:
     """All-gather of the per-rank gf' rows into the full (G, DG') table in ORIGINAL graph order.
 
@@ -40,14 +56,12 @@ class GfGather:
     def __init__(self, shards, rank, world_size, dg, device, group=None, overlap=True, stack=1):
         self.shards, self.rank, self.world, self.dg, self.device, self.group = shards, rank, world_size, dg, device, group
         self.stack = int(stack)
-        self.max_count = max(len(s) for s in shards)
+        plan, self.max_count = gather_plan(shards)  # the C boundary's plan (one implementation): row r * max_count + k
         self.G = int(sum(len(s) for s in shards))
         M, mc = self.stack, self.max_count
-        # row of the gathered [world][M][max_count] table for (step m, original graph id)
-        src = np.zeros((M, self.G), dtype=np.int64)
-        for r, s in enumerate(shards):
-            for m in range(M):
-                src[m, s] = (r * M + m) * mc + np.arange(len(s))
+        # row of the gathered [world][M][max_count] table for (step m, original graph id): rank r's M stacked tables are consecutive
+        rank_of, k_of = plan.astype(np.int64) // max(mc, 1), plan.astype(np.int64) % max(mc, 1)
+        src = np.stack([(rank_of * M + m) * mc + k_of for m in range(M)])
         self.src_index = torch.from_numpy(src.reshape(-1)).to(device)
         self.send = torch.zeros((M, mc, dg), dtype=torch.float32, device=device)
         self.recv = torch.empty((world_size * M * mc, dg), dtype=torch.float32, device=device)

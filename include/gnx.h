@@ -356,6 +356,14 @@ GNX_API int32_t gnx_dist_partition(const int64_t* edge_counts, int64_t n_graphs,
 GNX_API int32_t gnx_dist_create(const int32_t* device_ids, int32_t n_devices, const int64_t* shard_off, const int64_t* shard_graphs,
                         int64_t n_graphs, int32_t og, gnx_dist** out);
 GNX_API int32_t gnx_dist_destroy(gnx_dist* d);
+/* the gather plan of a partition, on the host (no device, no RCCL): validates shard_off / shard_graphs (a permutation of the graphs)
+ * and writes src_row[g] = row of original graph g in the gathered [n_ranks * max_count][og] table (every rank contributes max_count rows,
+ * zero padded).  gnx_dist_create builds its plan with this function.  src_row / max_count may be NULL. */
+GNX_API int32_t gnx_dist_gather_plan(const int64_t* shard_off, const int64_t* shard_graphs, int32_t n_ranks, int64_t n_graphs, int32_t* src_row,
+                             int64_t* max_count);
+/* out[g][:] = gathered[src_row[g]][:] on the device (all three device pointers): the permutation back to ORIGINAL graph order that
+ * follows the all-gather, for hosts that run the collective themselves (one process per GPU over torch.distributed / MPI) */
+GNX_API int32_t gnx_dist_permute_rows(const float* gathered, const int32_t* src_row, int64_t n_graphs, int32_t og, float* out, void* stream);
 GNX_API int32_t gnx_dist_allgather_gf(gnx_dist* d, const float* const* gf_local, float* const* gf_all, void* const* streams);
 GNX_API int32_t gnx_dist_block_forward(gnx_dist* d, const gnx_graphs* const* h, const gnx_block_params* const* p, const float* const* ef,
                                const float* const* nf, const float* const* gf, float* const* ef_out, float* const* nf_out,

@@ -12,10 +12,11 @@
 # padded (DE, PN², B); `unbatch`/views/`flatunpadded*` return what the reference returns.
 module GraphNetsHIP
 
-export GNGraphBatch, GNBlock, GNCore, GNCoreList, Dense, LayerNorm, batch, unbatch,
-       efview, nfview, gfview, flatunpaddednf, flatunpaddedef, zerodim2nothing,
-       collapsef, unpaddedcollapsedef, flatunpaddedcollapsedef, ChainBlock, chain_pullback,
-       block_pullback, Model, partition_graphs, DistBlock
+# every name GraphNets.jl exports (src/GraphNets.jl:12-50) ...
+export GNGraphBatch, batch, unbatch, getedgefninput, getnodefninput, getgraphfninput, GNBlock, zerodim2nothing, GNCore, GNCoreList,
+       efview, nfview, gfview, flatunpaddednf, flatunpaddedef, collapsef, unpaddedcollapsedef, flatunpaddedcollapsedef
+# ... plus what the drop-in adds: layers as plain structs, pullbacks, the library-side hipGraph model, the multi-GPU split
+export Dense, LayerNorm, ChainBlock, chain_pullback, block_pullback, core_pullback, Model, partition_graphs, DistBlock
 
 const libgnx = get(ENV, "GNX_LIB", joinpath(@__DIR__, "..", "graphnets.jl_amd", "libgnx.so"))
 const libhip = get(ENV, "GNX_HIP_LIB", "libamdhip64.so")
@@ -65,6 +66,8 @@ struct GnxGraphsInfo
     n_graphs::Int64; n_nodes::Int64; n_edges::Int64; node_block_size::Int64; edge_block_size::Int64
     n_tiles::Int64; max_in_degree::Int64; device::Int32; reserved::Int32
 end
+struct GnxDenseGrad; weight::Ptr{Cfloat}; bias::Ptr{Cfloat}; end
+struct GnxBlockGrads; edgefn::GnxDenseGrad; nodefn::GnxDenseGrad; graphfn::GnxDenseGrad; end
 const ACT = Dict(identity => 0, :relu => 1, :tanh => 2, :sigmoid => 3, :gelu => 4)
 
 # ---- GNGraphBatch(adj_mats)  (replaces src/gngraphbatch.jl:33-54) ----
@@ -92,7 +95,32 @@ mutable struct GNGraphBatch
         finalizer(x -> ccall((:gnx_graphs_destroy, libgnx), Int32, (Ptr{Cvoid},), x.handle), g)
         g
     end
+    # CSC form (API extension: dense N x N matrices cannot hold 100k-node graphs).  colptrs[g] / rowvals[g] are the 1-based `colptr` /
+    # `rowval` of a SparseMatrixCSC whose column j lists the sources i of the edges i -> j — its nz order IS the reference's edge order
+    # (src/pad.jl:30).  adj_mats keeps whatever the caller passed (the sparse matrices), for unbatch.
+    function GNGraphBatch(colptrs::AbstractVector{<:AbstractVector{<:Integer}}, rowvals::AbstractVector{<:AbstractVector{<:Integer}},
+                          n_nodes::AbstractVector{<:Integer}; adj_mats::AbstractVector=collect(zip(colptrs, rowvals, n_nodes)))
+        @assert length(colptrs) > 0 && length(colptrs) == length(rowvals) == length(n_nodes)
+        cps = [Vector{Int64}(c) for c in colptrs]; rvs = [Vector{Int64}(r) for r in rowvals]
+        cp_ptrs = [pointer(c) for c in cps]; rv_ptrs = [pointer(r) for r in rvs]
+        nn = Int64.(n_nodes)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        GC.@preserve cps rvs check(ccall((:gnx_graphs_create_csc, libgnx), Int32,
+            (Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Int64}, Int64, Int32, Ptr{Ptr{Cvoid}}),
+            cp_ptrs, rv_ptrs, nn, length(cps), 1 #=index_base: Julia=#, h))
+        info = Ref{GnxGraphsInfo}()
+        check(ccall((:gnx_graphs_get_info, libgnx), Int32, (Ptr{Cvoid}, Ptr{GnxGraphsInfo}), h[], info))
+        no = zeros(Int64, length(cps) + 1); eo = zeros(Int64, length(cps) + 1)
+        check(ccall((:gnx_graphs_get_offsets, libgnx), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), h[], no, eo))
+        g = new(h[], collect(adj_mats), info[].node_block_size, info[].edge_block_size, no, eo)
+        finalizer(x -> ccall((:gnx_graphs_destroy, libgnx), Int32, (Ptr{Cvoid},), x.handle), g)
+        g
+    end
 end
+# one graph as (colptr, rowval, n); and anything with SparseMatrixCSC's fields (no dependency on SparseArrays: duck-typed)
+GNGraphBatch(colptr::AbstractVector{<:Integer}, rowval::AbstractVector{<:Integer}, n::Integer) = GNGraphBatch([colptr], [rowval], [n])
+issparsecsc(a) = hasproperty(a, :colptr) && hasproperty(a, :rowval) && hasproperty(a, :n)
+sparse_batch(mats::AbstractVector) = GNGraphBatch([m.colptr for m in mats], [m.rowval for m in mats], [m.n for m in mats]; adj_mats=mats)
 nnodes(g::GNGraphBatch) = Int(g.node_off[end]); nedges(g::GNGraphBatch) = Int(g.edge_off[end])
 ngraphs(g::GNGraphBatch) = length(g.adj_mats)
 
@@ -102,13 +130,13 @@ function batch(t::NamedTuple)
     (; graphs, ef, nf, gf) = t
     @assert !isnothing(ef) || !isnothing(nf) || !isnothing(gf)
     if graphs isa AbstractMatrix                                  # shared adjacency: ef (DE,E,B), nf (DN,N,B), gf (DG,B)
-        g = GNGraphBatch([graphs])
+        g = issparsecsc(graphs) ? sparse_batch([graphs]) : GNGraphBatch([graphs])
         isnothing(ef) || @assert ndims(ef) == 3 && size(ef, 2) == nedges(g) "$(size(ef, 2)) != num_edges"
         isnothing(nf) || @assert ndims(nf) == 3 && size(nf, 2) == nnodes(g)
         isnothing(gf) || @assert ndims(gf) == 2
         return (graphs=g, ef=ef, nf=nf, gf=isnothing(gf) ? nothing : reshape(gf, size(gf, 1), 1, size(gf, 2)))
     end
-    g = GNGraphBatch(graphs)                                      # vector of graphs: pack graph-major
+    g = all(issparsecsc, graphs) ? sparse_batch(graphs) : GNGraphBatch(graphs)   # vector of graphs: pack graph-major
     cat2(v) = isnothing(v) ? nothing : reshape(reduce(hcat, v), size(v[1], 1), :, 1)
     isnothing(ef) || @assert length(ef) == ngraphs(g)
     isnothing(nf) || @assert length(nf) == ngraphs(g)
@@ -139,6 +167,27 @@ gfview(t::NamedTuple, d1, d2) = isnothing(t.gf) ? nothing :
     sharedlike(t.graphs) ? view(t.gf, d1, 1, d2) : view(t.gf, d1, d2, 1)
 flatunpaddednf(t::NamedTuple) = reshape(t.nf, size(t.nf, 1), :)       # the packed layout already is it (views.jl:80-88)
 flatunpaddedef(t::NamedTuple) = reshape(t.ef, size(t.ef, 1), :)
+
+# ---- the exported building blocks (src/edgefninput.jl:1-47, nodefninput.jl:1-24, graphfninput.jl:1-13) → gnx_fn_input.
+#      Same argument order as the reference; `graphs` is the GNGraphBatch of a batched tuple; features are the packed (D, T, R) arrays
+#      (`nothing` drops the segment, as the reference's methods do).  Result: (K, T, R) over the real edges / nodes / graphs. ----
+function fninput(kind::Integer, g::GNGraphBatch, ef, nf, gf)
+    @assert !isnothing(ef) || !isnothing(nf) || !isnothing(gf)
+    R = size(something(ef, nf, gf), 3)
+    w(a) = isnothing(a) ? 0 : size(a, 1)
+    T = (nedges(g), nnodes(g), ngraphs(g))[kind + 1]
+    K = w(ef) + (kind == 0 ? 2 : 1) * w(nf) + w(gf)
+    out = zeros(Float32, K, T, R)
+    d_ef, d_nf, d_gf, b_out = upload(ef), upload(nf), upload(gf), DevBuf(sizeof(out))
+    GC.@preserve d_ef d_nf d_gf b_out check(ccall((:gnx_fn_input, libgnx), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Cfloat}, Int32, Ptr{Cfloat}, Int32, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cvoid}),
+        g.handle, kind, devptr(d_ef), w(ef), devptr(d_nf), w(nf), devptr(d_gf), w(gf), R, devptr(b_out), C_NULL))
+    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
+    download!(out, b_out)
+end
+getedgefninput(graphs, edge_features, node_features, graph_features) = fninput(0, graphs, edge_features, node_features, graph_features)
+getnodefninput(graphs, edge_features, node_features, graph_features) = fninput(1, graphs, edge_features, node_features, graph_features)
+getgraphfninput(graphs, edge_features, node_features, graph_features) = fninput(2, graphs, edge_features, node_features, graph_features)
 
 # ---- edge collapsing (src/gngraphbatch.jl:56-111) → gnx_collapse_padded / gnx_collapse_offsets / gnx_collapse_edges ----
 function collapsef(t::NamedTuple)                                      # (DE, PN(PN+1)/2, B), padded array form
@@ -267,6 +316,44 @@ function (m::GNCore)(x)                                                # src/gnc
     (graphs=g, ef=download!(o_ef, b_ef), nf=download!(o_nf, b_nf), gf=download!(o_gf, b_gf))
 end
 
+# pullback of (m::GNCore)(x) → gnx_core_backward: takes the forward's INPUT x and the cotangent ȳ of its output; every intermediate is
+# recomputed inside the library.  Returns ∂ef, ∂nf, ∂gf and the parameter gradients in the order of the struct fields.
+struct GnxLayerNormGrad; gamma::Ptr{Cfloat}; beta::Ptr{Cfloat}; end
+struct GnxFfnGrad; fc1::GnxDenseGrad; fc2::GnxDenseGrad; end
+struct GnxCoreGrads
+    block::GnxBlockGrads
+    ln1::NTuple{3,GnxLayerNormGrad}; ln2::NTuple{3,GnxLayerNormGrad}; ff::NTuple{3,GnxFfnGrad}
+end
+function core_pullback(m::GNCore, x, ȳ)
+    g::GNGraphBatch = x.graphs
+    R = size(x.ef, 3)
+    keep = DevBuf[]
+    up(a) = (b = upload(a); push!(keep, b); devptr(b))
+    dn(d::Dense) = GnxDense(up(d.weight), up(d.bias), Int32(actcode(d.σ)), 0)
+    ln(l::LayerNorm) = GnxLayerNorm(up(l.γ), up(l.β))
+    b = m.block
+    bp = GnxBlockParams(b.in..., b.out..., dn(b.edgefn), dn(b.nodefn), dn(b.graphfn))
+    p = Ref(GnxCoreParams(bp, map(ln, m.gn1), map(ln, m.gn2), map(t -> GnxFfn(dn(t[1]), dn(t[2])), m.ffwd), 1f-5, Int32(0)))
+    gbuf = Any[]                                                       # (host template, device buffer) of every gradient, in struct order
+    gnew(a) = (bf = DevBuf(sizeof(a)); push!(gbuf, (a, bf)); Ptr{Cfloat}(bf.ptr))
+    gd(d::Dense) = GnxDenseGrad(gnew(d.weight), gnew(d.bias))
+    gl(l::LayerNorm) = GnxLayerNormGrad(gnew(l.γ), gnew(l.β))
+    grads = Ref(GnxCoreGrads(GnxBlockGrads(gd(b.edgefn), gd(b.nodefn), gd(b.graphfn)), map(gl, m.gn1), map(gl, m.gn2),
+                             map(t -> GnxFfnGrad(gd(t[1]), gd(t[2])), m.ffwd)))
+    ins = (upload(x.ef), upload(x.nf), upload(x.gf)); cots = (upload(ȳ.ef), upload(ȳ.nf), upload(ȳ.gf))
+    dins = (DevBuf(sizeof(x.ef)), DevBuf(sizeof(x.nf)), DevBuf(sizeof(x.gf)))
+    wsb = ccall((:gnx_core_backward_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxCoreParams}, Int64), g.handle, p, R)
+    ws = DevBuf(wsb)
+    GC.@preserve keep gbuf ins cots dins ws check(ccall((:gnx_core_backward, libgnx), Int32,
+        (Ptr{Cvoid}, Ptr{GnxCoreParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64,
+         Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{GnxCoreGrads}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+        g.handle, p, devptr(ins[1]), devptr(ins[2]), devptr(ins[3]), devptr(cots[1]), devptr(cots[2]), devptr(cots[3]), R,
+        devptr(dins[1]), devptr(dins[2]), devptr(dins[3]), grads, ws.ptr, wsb, C_NULL))
+    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
+    (ef=download!(similar(x.ef), dins[1]), nf=download!(similar(x.nf), dins[2]), gf=download!(similar(x.gf), dins[3]),
+     params=[download!(similar(a), bf) for (a, bf) in gbuf])           # block (W, b) x 3, gn1 (γ, β) x 3, gn2 (γ, β) x 3, ffwd (W1, b1, W2, b2) x 3
+end
+
 # GNCoreList is `foldl((x, f) -> f(x), list; init=x)` exactly as src/gncorelist.jl:43-45.
 struct GNCoreList{T}; list::T; end
 (m::GNCoreList)(x) = foldl((i, fn) -> fn(i), m.list; init=x)
@@ -275,9 +362,6 @@ struct GNCoreList{T}; list::T; end
 #      examples/sort/sort.jl:122-132).  `block_pullback(m, x, y, ȳ)` returns (∂ef, ∂nf, ∂gf, (∂W, ∂b) for the three Dense layers);
 #      with ChainRulesCore loaded it is the body of the rrule below.  (gnx_core_backward is bound the same way; the tested
 #      binding of both is graphnets.jl_amd/api.py: _BlockFn / _CoreFn.) ----
-struct GnxDenseGrad; weight::Ptr{Cfloat}; bias::Ptr{Cfloat}; end
-struct GnxBlockGrads; edgefn::GnxDenseGrad; nodefn::GnxDenseGrad; graphfn::GnxDenseGrad; end
-
 function block_pullback(m::GNBlock, x, y, ȳ)
     g::GNGraphBatch = x.graphs
     R = size(something(x.ef, x.nf, x.gf), 3)
@@ -453,9 +537,55 @@ function DistBlock(block::GNBlock, adj_mats::AbstractVector, devices::AbstractVe
     finalizer(x -> ccall((:gnx_dist_destroy, libgnx), Int32, (Ptr{Cvoid},), x.handle), d)
     d
 end
-# (d::DistBlock)(xs): xs[r] = the batched tuple of rank r's graphs (features of ITS graphs, uploaded to device r); the call is
-# gnx_dist_block_forward with per-rank pointer arrays — handles, parameter structs whose weights live on device r, inputs, outputs,
-# workspaces, gf_all[r] (ngraphs x og on every device) — exactly as tests/test_gpu_dist.py::test_gnx_dist_c_entry_points_world_1
-# drives it through ctypes.
+# (d::DistBlock)(xs): xs[r] = the batched tuple of rank r's graphs (`batch` of ITS graphs, in the order of d.shards[r]).  Every rank's
+# inputs, parameters (replicated), outputs and workspace live on ITS device; the call is ONE gnx_dist_block_forward = per-device
+# gnx_block_forward + one RCCL all-gather of gf' + the permutation back to the ORIGINAL graph order.  Returns (ys, gf_all):
+# ys[r] = rank r's (ef', nf', gf') and gf_all = (DG', n_graphs) of the whole batch (identical on every device; rank 1's copy).
+function (d::DistBlock)(xs::AbstractVector)
+    n = length(d.devices); m = d.block
+    @assert length(xs) == n
+    (oe, on, og) = m.out
+    G = sum(length, d.shards)
+    setdev(r) = hipcheck(ccall((:hipSetDevice, libhip), Cint, (Cint,), d.devices[r]))
+    prev = Ref{Cint}(0); hipcheck(ccall((:hipGetDevice, libhip), Cint, (Ptr{Cint},), prev))
+    keep = Any[]
+    params = Vector{Base.RefValue{GnxBlockParams}}(undef, n)
+    ins = Vector{Any}(undef, n); outs = Vector{Any}(undef, n); hosts = Vector{Any}(undef, n)
+    wss = Vector{DevBuf}(undef, n); wsb = zeros(Csize_t, n); gall = Vector{DevBuf}(undef, n)
+    mk(dl::Dense, w, b) = GnxDense(devptr(w), devptr(b), Int32(actcode(dl.σ)), 0)
+    for r in 1:n
+        setdev(r)                                                      # hipMalloc / hipMemcpy below land on device r
+        g = d.batches[r]; x = xs[r]
+        R = size(something(x.ef, x.nf, x.gf), 3); @assert R == 1      # by-graph sharding: vector batches
+        W = [upload(m.edgefn.weight), upload(m.nodefn.weight), upload(m.graphfn.weight)]
+        B = [upload(m.edgefn.bias), upload(m.nodefn.bias), upload(m.graphfn.bias)]
+        params[r] = Ref(GnxBlockParams(m.in..., m.out..., mk(m.edgefn, W[1], B[1]), mk(m.nodefn, W[2], B[2]), mk(m.graphfn, W[3], B[3])))
+        ins[r] = (upload(x.ef), upload(x.nf), upload(x.gf))
+        hosts[r] = (zeros(Float32, oe, nedges(g), 1), zeros(Float32, on, nnodes(g), 1), zeros(Float32, og, ngraphs(g), 1))
+        outs[r] = (DevBuf(sizeof(hosts[r][1])), DevBuf(sizeof(hosts[r][2])), DevBuf(sizeof(hosts[r][3])))
+        wsb[r] = ccall((:gnx_block_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxBlockParams}, Int64), g.handle, params[r], 1)
+        wss[r] = DevBuf(wsb[r]); gall[r] = DevBuf(4 * G * og)
+        push!(keep, W, B)
+    end
+    col(f) = [f(r) for r in 1:n]
+    hs = col(r -> d.batches[r].handle)
+    ps = col(r -> Base.unsafe_convert(Ptr{GnxBlockParams}, params[r]))
+    efs = col(r -> devptr(ins[r][1])); nfs = col(r -> devptr(ins[r][2])); gfs = col(r -> devptr(ins[r][3]))
+    eos = col(r -> devptr(outs[r][1])); nos = col(r -> devptr(outs[r][2])); gos = col(r -> devptr(outs[r][3]))
+    gas = col(r -> devptr(gall[r])); wsp = col(r -> wss[r].ptr)
+    GC.@preserve keep params ins outs wss gall check(ccall((:gnx_dist_block_forward, libgnx), Int32,
+        (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{GnxBlockParams}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}},
+         Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cvoid}}, Ptr{Csize_t}, UInt32, Ptr{Ptr{Cvoid}}),
+        d.handle, hs, ps, efs, nfs, gfs, eos, nos, gos, gas, wsp, wsb, UInt32(0), C_NULL))
+    ys = map(1:n) do r
+        setdev(r); hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
+        (graphs=d.batches[r], ef=oe == 0 ? nothing : download!(hosts[r][1], outs[r][1]), nf=on == 0 ? nothing : download!(hosts[r][2], outs[r][2]),
+         gf=og == 0 ? nothing : download!(hosts[r][3], outs[r][3]))
+    end
+    setdev(1)
+    gf_all = download!(zeros(Float32, og, G), gall[1])
+    hipcheck(ccall((:hipSetDevice, libhip), Cint, (Cint,), prev[]))
+    ys, gf_all
+end
 
 end # module

@@ -124,6 +124,42 @@ int main() {
     gnx_graphs_info info;
     EXPECT(gnx_graphs_get_info(nullptr, &info) != GNX_OK);
   }
+  // ---- multi-GPU split, host side: partition of 4096 graphs over 8 ranks, gather plans of EQUAL and UNEQUAL shards (the first real
+  //      8-GPU run must not be the first execution of this index arithmetic), rejection of broken partitions ----
+  {
+    const int64_t G = 4096; const int R = 8;
+    std::vector<int64_t> ecount(G), off(R + 1), ids(G);
+    for (auto& e : ecount) e = 1 + (int64_t)(rng() % 5000);
+    EXPECT(gnx_dist_partition(ecount.data(), G, R, off.data(), ids.data()) == GNX_OK);
+    EXPECT(off[0] == 0 && off[R] == G);
+    std::vector<int32_t> src(G);
+    int64_t mc = 0;
+    EXPECT(gnx_dist_gather_plan(off.data(), ids.data(), R, G, src.data(), &mc) == GNX_OK && mc == G / R);
+    for (int r = 0; r < R; ++r)
+      for (int64_t i = off[r]; i < off[r + 1]; ++i) EXPECT(src[(size_t)ids[i]] == (int32_t)(r * mc + (i - off[r])));
+    // 8 unequal shards (sizes 1 .. 2000, one of them EMPTY) of a shuffled permutation
+    const int64_t sizes[8] = {1, 700, 0, 2000, 33, 512, 849, 1};
+    std::vector<int64_t> uoff(9, 0), perm(G);
+    for (int r = 0; r < 8; ++r) uoff[r + 1] = uoff[r] + sizes[r];
+    EXPECT(uoff[8] == G);
+    for (int64_t i = 0; i < G; ++i) perm[i] = i;
+    for (int64_t i = G - 1; i > 0; --i) std::swap(perm[i], perm[(size_t)(rng() % (uint64_t)(i + 1))]);
+    EXPECT(gnx_dist_gather_plan(uoff.data(), perm.data(), 8, G, src.data(), &mc) == GNX_OK && mc == 2000);
+    std::vector<char> hit((size_t)(8 * mc), 0);
+    for (int r = 0; r < 8; ++r)
+      for (int64_t i = uoff[r]; i < uoff[r + 1]; ++i) {
+        const int32_t row = src[(size_t)perm[i]];
+        EXPECT(row == (int32_t)(r * mc + (i - uoff[r])) && !hit[(size_t)row]);
+        hit[(size_t)row] = 1;
+      }
+    EXPECT(gnx_dist_gather_plan(uoff.data(), perm.data(), 8, G, nullptr, nullptr) == GNX_OK);  // validation only
+    perm[5] = perm[6];                                                                         // not a permutation any more
+    EXPECT(gnx_dist_gather_plan(uoff.data(), perm.data(), 8, G, src.data(), &mc) == GNX_ERR_INVALID_ARG);
+    uoff[3] = uoff[2] - 1;                                                                     // decreasing offsets
+    EXPECT(gnx_dist_gather_plan(uoff.data(), ids.data(), 8, G, src.data(), &mc) == GNX_ERR_INVALID_ARG);
+    EXPECT(gnx_dist_gather_plan(nullptr, ids.data(), 8, G, src.data(), &mc) == GNX_ERR_INVALID_ARG);
+    EXPECT(gnx_dist_partition(ecount.data(), G, 0, off.data(), ids.data()) == GNX_ERR_INVALID_ARG);
+  }
   // ---- model descriptors ----
   {
     gnx_model* m = nullptr;

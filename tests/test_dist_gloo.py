@@ -153,3 +153,41 @@ def test_c_partition_equals_the_specified_rule():
         assert len(got) == world
         for a, b in zip(got, want):
             np.testing.assert_array_equal(a, b)
+
+
+def test_c_gather_plan_equals_the_rule_for_eight_unequal_shards():
+    """`gnx_dist_gather_plan` — the index table of gnx_dist_create and of GfGather — against its rule written out in numpy, for 8 UNEQUAL
+    shards (one of them empty) of a shuffled permutation; broken partitions are rejected.  The first real 8-GPU run must not be the first
+    execution of this arithmetic (VERDICT r2 #7)."""
+    from graphnets_jl_amd.dist import gather_plan, GfGather
+    from graphnets_jl_amd._lib import GnxError
+    rng = np.random.default_rng(11)
+    sizes = [1, 700, 0, 2000, 33, 512, 849, 1]
+    G = sum(sizes)
+    perm = rng.permutation(G)
+    shards, o = [], 0
+    for n in sizes:
+        shards.append(perm[o:o + n].astype(np.int64)); o += n
+    src, mc = gather_plan(shards)
+    assert mc == 2000 and src.dtype == np.int32
+    ref = np.empty(G, dtype=np.int64)
+    for r, s in enumerate(shards):
+        ref[s] = r * mc + np.arange(len(s))
+    assert np.array_equal(src, ref)
+    # GfGather's stacked table is that plan applied per step: rank r contributes M consecutive [max_count] tables
+    M = 3
+    ga = GfGather(shards, 0, 8, 5, "cpu", overlap=False, stack=M)
+    want = np.concatenate([(ref // mc * M + m) * mc + ref % mc for m in range(M)])
+    assert np.array_equal(ga.src_index.numpy(), want)
+    wire = torch.arange(8 * M * mc * 5, dtype=torch.float32).reshape(8 * M * mc, 5)
+    ga.recv.copy_(wire)
+    out = ga.result().numpy()
+    for r, s in enumerate(shards):
+        for m in range(M):
+            for k in (0, len(s) - 1):
+                if len(s):
+                    assert np.array_equal(out[m, s[k]], wire[(r * M + m) * mc + k].numpy())
+    bad = [s.copy() for s in shards]
+    bad[1][0] = bad[3][0]  # a graph owned twice
+    with pytest.raises(GnxError):
+        gather_plan(bad)

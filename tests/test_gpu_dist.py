@@ -53,8 +53,8 @@ def _sharded_forward(gn, world, rank, shards, colptrs, rowvals, nn, ef, nf, node
 
 def test_by_graph_sharding_eight_virtual_ranks_equals_the_oracle(gn):
     """The whole N > 1 data path except the wire: 8 shards of the 4096-graph batch run one after the other on this GPU, their
-    send buffers are concatenated exactly as all_gather_into_tensor would, GfGather's index table restores original graph
-    order — gf' of the WHOLE batch (and every shard's ef', nf') equals the oracle's single-process result."""
+    send buffers are concatenated exactly as all_gather_into_tensor would, the C boundary's gather plan (gnx_dist_gather_plan: GfGather's
+    index table AND gnx_dist_permute_rows, the kernel behind gnx_dist_allgather_gf) restores original graph order — gf' of the WHOLE batch (and every shard's ef', nf') equals the oracle's single-process result."""
     import torch
     world, G, E = 8, 4096, 1_000_000
     from graphnets_jl_amd.dist import GfGather, partition_graphs
@@ -73,9 +73,19 @@ def test_by_graph_sharding_eight_virtual_ranks_equals_the_oracle(gn):
     gathers = [GfGather(shards, r, world, 5, "cuda", overlap=False) for r in range(world)]
     outs = [_sharded_forward(gn, world, r, shards, colptrs, rowvals, nn, ef, nf, node_off, edge_off, blk, gathers[r]) for r in range(world)]
     torch.cuda.synchronize()
-    wire = torch.cat([gt.send.view(-1, 5) for gt in gathers], dim=0)  # = all_gather_into_tensor of the 8 send buffers
+    wire = torch.cat([gt.send.view(-1, 5) for gt in gathers], dim=0).contiguous()  # = all_gather_into_tensor of the 8 send buffers
     gathers[0].recv.copy_(wire)
     gf_all = gathers[0].result().cpu().numpy()
+    # the same wire through the C boundary's own plan and kernel (what gnx_dist_allgather_gf runs behind ncclAllGather): bit-equal
+    import ctypes as C
+    from graphnets_jl_amd.dist import gather_plan
+    src, mc = gather_plan(shards)
+    assert mc == G // world
+    src_dev = torch.from_numpy(src).cuda()
+    out_c = torch.empty((G, 5), dtype=torch.float32, device="cuda")
+    gn._lib.check(gn._lib.load().gnx_dist_permute_rows(wire.data_ptr(), src_dev.data_ptr(), G, 5, out_c.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert np.array_equal(out_c.cpu().numpy(), gf_all)
     cp = np.concatenate([[0]] + [c[1:] + edge_off[i] for i, c in enumerate(colptrs)])
     rv = np.concatenate([r + node_off[i] for i, r in enumerate(rowvals)])
     ref, scale = O.block_forward_sparse(p, (cp, rv, node_off, edge_off), ef, nf, None, return_scale=True)

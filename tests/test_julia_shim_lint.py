@@ -1,0 +1,178 @@
+"""Static check of julia/GraphNetsHIP.jl (Julia is not installed in the build image: the shim ships as source).
+
+Every `ccall((:gnx_*, libgnx), Ret, (Args...), ...)` is parsed and held against graphnets.jl_amd/_lib.SIGNATURES (which
+tests/test_abi.py holds against include/gnx.h and the library's exports): symbol exists, arity, return type, scalar-vs-pointer
+class and scalar width of every argument.  Every `struct Gnx*` is laid out with the C rules and its byte size compared with the
+ctypes mirror of the same header struct.  The shim's export list must be a superset of the reference's
+(/root/reference/src/GraphNets.jl:12-50; the names are data of the API contract, listed here).
+"""
+import ctypes as C
+import os
+import re
+
+import graphnets_jl_amd as gn
+
+_lib = gn._lib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = open(os.path.join(ROOT, "julia", "GraphNetsHIP.jl"), encoding="utf-8").read()
+
+# reference exports (src/GraphNets.jl:12,15,18,26,29,32,38,41,44,50)
+REFERENCE_EXPORTS = ["GNGraphBatch", "batch", "unbatch", "getedgefninput", "getnodefninput", "getgraphfninput", "GNBlock", "zerodim2nothing",
+                     "GNCore", "GNCoreList", "efview", "nfview", "gfview", "flatunpaddednf", "flatunpaddedef", "collapsef",
+                     "unpaddedcollapsedef", "flatunpaddedcollapsedef"]
+
+SCALARS = {"Int32": C.c_int32, "Int64": C.c_int64, "UInt32": C.c_uint32, "Csize_t": C.c_size_t, "Cint": C.c_int, "Cfloat": C.c_float,
+           "Cstring": C.c_char_p}
+
+
+def _strip_comments(src):
+    src = re.sub(r"#=.*?=#", "", src, flags=re.S)
+    return "\n".join(line.split("#", 1)[0] if '"' not in line.split("#", 1)[0] or line.split("#", 1)[0].count('"') % 2 == 0 else line
+                     for line in src.splitlines())
+
+
+def _balanced(src, start):
+    """text of the parenthesised group that opens at src[start] == '(' (exclusive of the parentheses)."""
+    assert src[start] == "("
+    depth = 0
+    for i in range(start, len(src)):
+        depth += src[i] == "("
+        depth -= src[i] == ")"
+        if depth == 0:
+            return src[start + 1:i], i
+    raise AssertionError("unbalanced parentheses")
+
+
+def _split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def ccalls():
+    code = _strip_comments(SRC)
+    found = []
+    for m in re.finditer(r"ccall\(\(:(gnx_\w+),\s*libgnx\)", code):
+        body, _ = _balanced(code, code.index("(", m.start()))
+        parts = _split_top(body)
+        # parts[0] = (:name, libgnx), parts[1] = return type, parts[2] = (argtypes...), rest = values
+        argt = parts[2].strip()
+        assert argt.startswith("(") and argt.endswith(")"), (m.group(1), argt)
+        types = _split_top(argt[1:-1])
+        found.append((m.group(1), parts[1].strip(), types, len(parts) - 3))
+    return found
+
+
+def _is_ptr_ctype(t):
+    return t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer))
+
+
+def test_every_ccall_matches_the_ctypes_signature_table():
+    calls = ccalls()
+    assert len(calls) >= 30, "the parser lost the shim's ccalls"
+    for name, ret, types, n_values in calls:
+        assert name in _lib.SIGNATURES, f"{name}: not an export of include/gnx.h"
+        cret, cargs = _lib.SIGNATURES[name]
+        assert len(types) == len(cargs), f"{name}: {len(types)} argument types in the shim, {len(cargs)} in the header"
+        assert n_values == len(types), f"{name}: {n_values} values passed for {len(types)} argument types"
+        if ret in SCALARS:
+            assert C.sizeof(SCALARS[ret]) == C.sizeof(cret) and (ret == "Cstring") == (cret is C.c_char_p), f"{name}: return type {ret}"
+        else:
+            raise AssertionError(f"{name}: unknown return type {ret}")
+        for i, (jt, ct) in enumerate(zip(types, cargs)):
+            if jt.startswith("Ptr{"):
+                assert _is_ptr_ctype(ct), f"{name} arg {i}: shim passes a pointer ({jt}), header takes {ct}"
+            else:
+                assert jt in SCALARS, f"{name} arg {i}: unknown Julia type {jt}"
+                assert not _is_ptr_ctype(ct), f"{name} arg {i}: shim passes {jt}, header takes a pointer"
+                assert C.sizeof(SCALARS[jt]) == C.sizeof(ct), f"{name} arg {i}: {jt} is {C.sizeof(SCALARS[jt])} bytes, header takes {C.sizeof(ct)}"
+                assert (SCALARS[jt] is C.c_float) == (ct is C.c_float), f"{name} arg {i}: float / integer mismatch"
+
+
+def test_the_shim_binds_the_entry_points_of_the_hot_path_and_its_neighbours():
+    bound = {c[0] for c in ccalls()}
+    for name in ("gnx_graphs_create_dense", "gnx_graphs_create_csc", "gnx_block_forward", "gnx_core_forward", "gnx_fn_input", "gnx_block_backward",
+                 "gnx_core_backward", "gnx_chain_block_forward", "gnx_chain_block_backward", "gnx_model_create", "gnx_model_forward",
+                 "gnx_dist_partition", "gnx_dist_create", "gnx_dist_block_forward", "gnx_dist_destroy", "gnx_collapse_edges", "gnx_collapse_padded"):
+        assert name in bound, f"the Julia shim does not bind {name}"
+
+
+STRUCT_MIRRORS = {"GnxDense": _lib.Dense, "GnxBlockParams": _lib.BlockParams, "GnxGraphsInfo": _lib.GraphsInfo, "GnxLayerNorm": _lib.LayerNorm,
+                  "GnxFfn": _lib.Ffn, "GnxCoreParams": _lib.CoreParams, "GnxDenseGrad": _lib.DenseGrad, "GnxBlockGrads": _lib.BlockGrads,
+                  "GnxChain": _lib.Chain, "GnxChainBlockParams": _lib.ChainBlockParams, "GnxChainBlockGrads": _lib.ChainBlockGrads,
+                  "GnxLayer": _lib.Layer, "GnxLayerNormGrad": _lib.LayerNormGrad, "GnxFfnGrad": _lib.FfnGrad, "GnxCoreGrads": _lib.CoreGrads}
+
+
+def julia_structs():
+    code = _strip_comments(SRC)
+    out = {}
+    for m in re.finditer(r"(?<!mutable )struct (Gnx\w+)\b(.*?)\bend\b", code, flags=re.S):
+        fields = [f.strip() for f in re.split(r"[;\n]", m.group(2)) if "::" in f]
+        out[m.group(1)] = [f.split("::", 1)[1].strip() for f in fields]
+    return out
+
+
+def _layout(jtype, structs):
+    """(size, alignment) of a Julia isbits field type under the C layout rules Julia uses for ccall."""
+    prim = {"Int32": 4, "UInt32": 4, "Cfloat": 4, "Float32": 4, "Cint": 4, "Int64": 8, "Csize_t": 8, "Float64": 8}
+    if jtype.startswith("Ptr{"):
+        return 8, 8
+    if jtype in prim:
+        return prim[jtype], prim[jtype]
+    m = re.match(r"NTuple\{(\d+),\s*(\w+)\}", jtype)
+    if m:
+        s, a = _layout(m.group(2), structs)
+        return s * int(m.group(1)), a
+    assert jtype in structs, f"unknown field type {jtype}"
+    off, align = 0, 1
+    for f in structs[jtype]:
+        s, a = _layout(f, structs)
+        off = (off + a - 1) // a * a + s
+        align = max(align, a)
+    return (off + align - 1) // align * align, align
+
+
+def test_struct_sizes_match_the_header_structs():
+    structs = julia_structs()
+    for name, mirror in STRUCT_MIRRORS.items():
+        assert name in structs, f"struct {name} is missing from the shim"
+        size, _ = _layout(name, structs)
+        assert size == C.sizeof(mirror), f"{name}: {size} bytes in the shim, {C.sizeof(mirror)} in include/gnx.h"
+        assert len(structs[name]) == len(mirror._fields_), f"{name}: field count"
+    for name in structs:
+        assert name in STRUCT_MIRRORS, f"struct {name} of the shim has no header struct to be checked against"
+
+
+def test_export_list_is_a_superset_of_the_reference():
+    code = _strip_comments(SRC)
+    names = set()
+    for m in re.finditer(r"^export (.*?)(?=^\S|\Z)", code, flags=re.S | re.M):
+        names |= {n.strip() for n in m.group(1).replace("\n", " ").split(",") if n.strip()}
+    missing = [n for n in REFERENCE_EXPORTS if n not in names]
+    assert not missing, f"GraphNetsHIP.jl does not export {missing}"
+    for n in names:  # an exported name is defined in the module
+        assert re.search(rf"(function\s+{n}\b|^{n}\(|struct\s+{n}\b|^{n}\s*=|\({n}\)|::{n}\))", code, flags=re.M), f"{n} is exported but not defined"
+
+
+def test_begin_end_blocks_balance():
+    """cheap structural lint: every block opener has its `end` (a missing one is the commonest way to break unexercised Julia source).
+    Strings, comments and everything inside [...] (indexing with `end`, comprehensions with `for` / `if`) are removed first."""
+    code = _strip_comments(SRC)
+    code = re.sub(r'"(?:\\.|[^"\\])*"', '""', code)
+    prev = None
+    while prev != code:  # innermost brackets first
+        prev = code
+        code = re.sub(r"\[[^\[\]]*\]", "_", code)
+    openers = re.findall(r"(?<![\w.:@])(?:module|function|struct|if|for|while|let|do|begin|try|quote|macro)\b", code)
+    ends = re.findall(r"(?<![\w.:@])end\b", code)
+    assert len(openers) == len(ends), f"{len(openers)} block openers vs {len(ends)} `end`s"
