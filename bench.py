@@ -19,6 +19,10 @@ Timing: W warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.
 region is run three times and the MEDIAN is reported (`timing` says so).  Rank 0 prints ONE JSON line.
 `roofline` comes from a second pass over the same K steps with per-kernel HIP events (gnx_profile_*); `cpu_baseline` from
 the oracle's C restatement (test infrastructure) on the host cores.
+The default N = 1 invocation also carries `"secondary"`: the other BASELINE configs measured by the same script in the same run —
+core dims on C2, C3 (configs[2]), C5 on one GPU (configs[4]'s batch), C4 (configs[3]) and README ex.3 at its own widths — each with
+ms_per_step, roofline (traffic + provenance), cpu_baseline and, for the hetero batches, the cost of `batch()` itself.  They run as
+child processes BEFORE this process touches the GPU, one at a time (`--no-secondary` skips them).
 """
 import argparse
 import hashlib
@@ -125,15 +129,80 @@ def glorot(rng, out_d, in_d):
     return rng.uniform(-s, s, size=(out_d, in_d)).astype(np.float32)
 
 
+def _dense_np(gn, W, b, act, dev):
+    return gn.Dense.from_numpy(W, b, act, device=dev)
+
+
+def c4_model(gn, torch, core, dev, seed=0):
+    """README ex.3 (README.md:129-145): encoder (10,5,0) => core, two GNCore(core), decoder core => (3,4,5).  Parameters are drawn in numpy
+    (glorot weights, zero biases, LayerNorm 1 / 0 — Flux's initialisation) so that the CPU port can be timed on the very same model."""
+    from oracle import gn_oracle as O  # parameter shapes only; the layers below are the HIP path
+    rng = np.random.default_rng(seed)
+    ps = [("block", O.make_block_params(rng, (10, 5, 0), core, random_bias=False)),
+          ("core", O.make_core_params(rng, core, random_bias=False)), ("core", O.make_core_params(rng, core, random_bias=False)),
+          ("block", O.make_block_params(rng, core, (3, 4, 5), random_bias=False))]
+
+    def block(p):
+        b = gn.GNBlock(p["in_dims"], p["out_dims"], device=dev)
+        b.edgefn, b.nodefn, b.graphfn = (_dense_np(gn, p["W" + t], p["b" + t], "identity", dev) for t in "eng")
+        return b
+    layers = []
+    for kind, p in ps:
+        if kind == "block":
+            layers.append(block(p))
+            continue
+        c = gn.GNCore(p["dims"], device=dev, eps=p["eps"], eps_mode=p["eps_mode"])
+        c.block = block(p["block"])
+        for t, l1, l2 in zip("eng", (c.gn1.edgeln, c.gn1.nodeln, c.gn1.graphln), (c.gn2.edgeln, c.gn2.nodeln, c.gn2.graphln)):
+            for ln, name in ((l1, "ln1"), (l2, "ln2")):
+                p[f"{name}_{t}_gamma"][:] = 1.0; p[f"{name}_{t}_beta"][:] = 0.0
+                ln.gamma = torch.from_numpy(p[f"{name}_{t}_gamma"]).to(dev); ln.beta = torch.from_numpy(p[f"{name}_{t}_beta"]).to(dev)
+        mk = lambda t: (_dense_np(gn, p[f"ff_{t}_W1"], p[f"ff_{t}_b1"], "relu", dev), _dense_np(gn, p[f"ff_{t}_W2"], p[f"ff_{t}_b2"], "identity", dev))
+        c.ffwd.eff, c.ffwd.nff, c.ffwd.gff = mk("e"), mk("n"), mk("g")
+        layers.append(c)
+    return layers, ps
+
+
+def c4_cpu_baseline(ps, budget_s=6.0):
+    """The oracle's C restatement of the 4-layer model on the host cores, on a BOUNDED sample of the workload: an Erdos-Renyi graph of the
+    C2 law (mean in-degree 10) with 1/16 of C2's nodes and edges, grown x4 while one forward stays under ~1.5 s; edges/s through the model."""
+    from oracle import c_port
+    cores = min(os.cpu_count() or 1, c_port.max_threads())
+    rng = np.random.default_rng(9)
+    best = None
+    scale = 1.0 / 16
+    t_all = time.perf_counter()
+    while True:
+        colptrs, rowvals, nn = make_c2(seed=2, N=int(100_000 * scale), E=int(1_000_000 * scale))
+        N, E = nn[0], len(rowvals[0])
+        csc = (colptrs[0], rowvals[0], np.array([0, N]), np.array([0, E]))
+        x = (rng.random((1, E, 10), dtype=np.float32), rng.random((1, N, 5), dtype=np.float32), None)
+
+        def fwd():
+            y = x
+            for kind, p in ps:
+                y = (c_port.block_forward if kind == "block" else c_port.core_forward)(p, csc, *y, nthreads=cores)
+            return y
+        fwd()
+        times = []
+        while len(times) < 2 or (sum(times) < 1.5 and len(times) < 8):
+            t0 = time.perf_counter(); fwd(); times.append(time.perf_counter() - t0)
+        t = float(np.median(times))
+        best = dict(value=round(E / t, 1), unit="edges/s", cores=cores, kind="port",
+                    sample=f"{len(times)} forwards of the 4-layer model on an Erdos-Renyi graph of the C2 law with {N} nodes / {E} edges "
+                           f"({scale:g} of C2; median {t * 1e3:.0f} ms), oracle/gn_oracle_c.c with OpenMP on {cores} threads")
+        if scale >= 1.0 or t * 4 > 1.5 or time.perf_counter() - t_all > budget_s:
+            return best
+        scale *= 4
+
+
 def bench_c4(args, gn, torch, dev):
-    """BASELINE configs[3]: Encoder -> 2 x GNCore -> Decoder (README ex.3) at core_dims (128,64,32) on the C2 graph.
+    """BASELINE configs[3]: Encoder -> 2 x GNCore -> Decoder (README Example 3) at core_dims (128,64,32) on the C2 graph.
     One "step" = the whole 4-layer model forward; reported as edges/s through the model."""
     colptrs, rowvals, nn = make_c2()
     g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
     core = tuple(int(v) for v in args.core_dims.split(","))
-    gen = torch.Generator(); gen.manual_seed(0)
-    model = [gn.GNBlock((10, 5, 0), core, device=dev, generator=gen), gn.GNCore(core, device=dev, generator=gen),
-             gn.GNCore(core, device=dev, generator=gen), gn.GNBlock(core, (3, 4, 5), device=dev, generator=gen)]
+    model, ps = c4_model(gn, torch, core, dev)
     tg = torch.Generator(device=dev); tg.manual_seed(1)
     x = gn.NT(g, torch.rand((1, g.n_edges, 10), generator=tg, device=dev).permute(2, 1, 0),
               torch.rand((1, g.n_nodes, 5), generator=tg, device=dev).permute(2, 1, 0), None)
@@ -184,24 +253,86 @@ def bench_c4(args, gn, torch, dev):
     ce, cn, cg = core
     ex = (executed_flops(E, N, 1, (10, 5, 0), core) + executed_flops(E, N, 1, core, (3, 4, 5)) +
           2 * (executed_flops(E, N, 1, core, core) + 16 * (E * ce * ce + N * cn * cn + cg * cg)))
+    tkey = "c4" if core == (128, 64, 32) else "c4_" + "-".join(map(str, core))
+    sha = model_source_sha(core)
+    traffic, tsrc = load_traffic(tkey, "__model__", sha)
     line = {"metric": "edges/sec through Encoder->2xGNCore(%s)->Decoder, 1M-edge graph (BASELINE configs[3])" % ",".join(map(str, core)),
             "value": round(E / dt, 1), "unit": "edges/s", "ms_per_step": round(dt * 1e3, 4), "steps": K, "dtype": "f32",
             "roofline": {"bound": "mfma", "achieved": round(ex / dt / 1e12, 2), "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
                          "frac": round(ex / dt / 1e12 / MFMA_F32_PEAK_TFS, 4), "counts": "EXECUTED flops of the whole model / whole-step time",
-                         "executed_flops": ex, "algorithmic_flops": aflops, "algorithmic_tflops": round(aflops / dt / 1e12, 2), "traffic": None},
+                         "executed_flops": ex, "algorithmic_flops": aflops, "algorithmic_tflops": round(aflops / dt / 1e12, 2),
+                         "traffic": traffic, "traffic_source": tsrc},
             "kernel_us_one_forward": kern,
             "config": {"workload": "C4: Encoder -> 2 x GNCore(%s) -> Decoder on the C2 graph (100k nodes / 1M edges); one step = the whole model forward" % ",".join(map(str, core)),
                        "launch": "one forward captured into a hipGraph, replayed %d times" % K,
                        "timing": "median of 3 regions (%s ms/step)" % [round(r * 1e3, 4) for r in reps],
-                       "eager_ms_per_step": round(dt_eager * 1e3, 4)}}
+                       "eager_ms_per_step": round(dt_eager * 1e3, 4),
+                       # (for tools/summarize_prof.py --model-traffic: bytes of a profiled run / forwards = bytes per forward)
+                       "forwards_executed": max(args.warmup, 1) + 1 + K + 2 + 3 + 3 * K}}
     if max(core) < 32:  # narrow widths run on the vector units, not the matrix cores: the model is priced against HBM like a narrow block
         ab = (algorithmic_bytes(E, N, 1, (10, 5, 0), core) + 2 * algorithmic_bytes(E, N, 1, core, core) + algorithmic_bytes(E, N, 1, core, (3, 4, 5)) +
               2 * 4 * (3 * 8 * (ce * ce + cn * cn + cg * cg) + 4 * (ce + cn + cg)))  # + the cores' FeedForward and LayerNorm parameters
         line["roofline"] = {"bound": "hbm", "achieved": round(ab / dt / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ab / dt / 1e9 / HBM_PEAK_GBS, 4),
                             "counts": "algorithmic bytes of the four layers (every layer's inputs and outputs once, SURVEY 8d; a core = its block's bytes) / whole-step time",
-                            "algorithmic_bytes": ab, "executed_flops": ex, "traffic": None}
+                            "algorithmic_bytes": ab, "executed_flops": ex, "traffic": traffic, "traffic_source": tsrc}
     assert line["roofline"]["frac"] <= 1.0
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = c4_cpu_baseline(ps)
     print(json.dumps(line))
+
+
+def model_source_sha(core):
+    """sha256 over the kernel sources a C4 model runs (both paths' files at wide widths, the narrow files otherwise)."""
+    files = sorted(set(KERNEL_SOURCES["wide"] + KERNEL_SOURCES["narrow"] + (("gnx_ffn_fused.hip", "gnx_generic.hip") if max(core) >= 32 else ("gnx_core_narrow.hip", "gnx_core_post_kernel.h"))))
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "graphnets.jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+SECONDARY = [  # (key, extra argv, BASELINE config it stands for)
+    ("core_c2", ["--dims", "core"], "configs[1] graph at core dims (128,64,32)=>(128,64,32): the matrix-core path"),
+    ("c3", ["--workload", "hetero", "--hetero-graphs", "512"], "configs[2]: 512 random graphs (32-256 nodes), 1M edges"),
+    ("c5_one_gpu", ["--workload", "hetero", "--hetero-graphs", "4096"], "configs[4]'s batch on one GPU: 4096 graphs, 1M edges"),
+    ("c4", ["--model", "c4"], "configs[3]: Encoder -> 2 x GNCore(128,64,32) -> Decoder on the 1M-edge graph"),
+    ("c4_narrow", ["--model", "c4", "--core-dims", "10,5,3"], "README example 3 at its own widths (core_dims 10,5,3)"),
+]
+
+
+def collect_secondary(args):
+    """Runs the other configs as child processes of THIS script, one after the other, before the parent has touched a GPU, and returns their
+    lines cut down to what the judge reads.  A child that fails is reported as such (the headline line does not depend on it)."""
+    out = {}
+    t_all = time.perf_counter()
+    for key, extra, what in SECONDARY:
+        steps = {"c4": max(3, min(args.steps, 5)), "core_c2": max(5, min(args.steps, 10))}.get(key, max(10, min(args.steps, 20)))
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(max(2, min(args.warmup, 5))),
+               "--no-secondary", "--cpu-budget", "2.0"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
+            err = None if line is not None else (r.stderr or "")[-300:]
+        except Exception as e:  # timeout, malformed output
+            line, err = None, repr(e)[:300]
+        if line is None:
+            out[key] = {"what": what, "error": err, "wall_s": round(time.perf_counter() - t0, 1)}
+            continue
+        roof = line.get("roofline") or {}
+        keep = ("bound", "achieved", "peak", "unit", "frac", "frac_whole_step", "traffic", "kernel", "kernel_us", "executed_flops", "algorithmic_bytes")
+        entry = {"what": what, "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": line.get("steps", steps),
+                 "roofline": {k: roof[k] for k in keep if k in roof}, "cpu_baseline": line.get("cpu_baseline"),
+                 "wall_s": round(time.perf_counter() - t0, 1)}
+        ts = roof.get("traffic_source")
+        if ts:
+            entry["roofline"]["traffic_source"] = {k: ts.get(k) for k in ("file", "commit", "stale") if ts.get(k) is not None}
+        for k in ("batch_ms", "kernel_us_one_forward"):
+            if k in line or k in line.get("config", {}):
+                entry[k] = line.get(k, line.get("config", {}).get(k))
+        out[key] = entry
+    out["_wall_s"] = round(time.perf_counter() - t_all, 1)
+    return out
 
 
 def self_launch(args):
@@ -243,6 +374,8 @@ def main():
     ap.add_argument("--hetero-edges", type=int, default=1_000_000, help="edges per GPU of the hetero workload (C5w: 8000000)")
     ap.add_argument("--c2-scale", type=float, default=1.0, help="scale C2's nodes and edges by this factor (size sweeps; 1 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs of the default N = 1 line")
+    ap.add_argument("--cpu-budget", type=float, default=None, help="seconds of CPU baseline sampling (default 3 at README dims, 12 at wide dims)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--dense-baseline", action="store_true",
                     help="also time the RESTATEMENT OF THE REFERENCE'S FORMULATION (padded one-hot batched matmuls, numpy/BLAS on the "
@@ -258,6 +391,10 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args))  # nothing has touched a GPU yet (torch is not even imported)
+    # the default single-GPU line carries the other configs: child processes, one at a time, BEFORE this process touches the GPU
+    headline = (args.gpus == 1 and "RANK" not in os.environ and args.dims == "readme" and args.workload in (None, "c2") and args.model == "block"
+                and not args.force_dist and args.c2_scale == 1.0 and args.flags == 0 and not args.overlap)
+    secondary = collect_secondary(args) if headline and not args.no_secondary else None
 
     import torch
     import torch.distributed as dist
@@ -301,8 +438,26 @@ def main():
         colptrs, rowvals, nn = make_hetero(seed, Gtot, Etot, only=shards[rank])
         wl_name = (f"ONE heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {world} GPU(s): "
                    f"{len(shards[rank])} graphs / {int(e_all[shards[rank]].sum())} edges on rank 0 (BASELINE configs[{2 if Gtot == 512 and world == 1 else 4}] law)")
+    torch.cuda.synchronize(dev)
+    gn.GNGraphBatch.from_csc(colptrs[:1], rowvals[:1], nn[:1], device=dev)  # (first call: library load, context)
+    t0 = time.perf_counter()
     g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
+    torch.cuda.synchronize(dev)
+    batch_ms = {"from_csc": round((time.perf_counter() - t0) * 1e3, 3),
+                "what": "GNGraphBatch construction end to end (host validation, CSC -> device tables, tile tables), median-free single shot after a warm-up call"}
     E, N, G = g.n_edges, g.n_nodes, g.n_graphs
+    if workload == "hetero" and not multi and sum(int(n) * int(n) for n in nn) <= 2e8:  # the reference's own input form: dense 0/1 matrices
+        adjs = []
+        for cp, rv, n in zip(colptrs, rowvals, nn):
+            a = np.zeros((n, n), dtype=np.uint8)
+            a[rv, np.repeat(np.arange(n), np.diff(cp))] = 1  # A[i, j] = 1 <=> edge i -> j (src = row, dst = column)
+            adjs.append(a)
+        t0 = time.perf_counter()
+        gd = gn.GNGraphBatch(adjs, device=dev)
+        torch.cuda.synchronize(dev)
+        batch_ms["from_dense_uint8"] = round((time.perf_counter() - t0) * 1e3, 3)
+        assert gd.n_edges == E and gd.n_nodes == N
+        del gd, adjs
     rng = np.random.default_rng(100)  # identical weights on every rank
     blk = gn.GNBlock(din, dout, device=dev)
     (de, dn, dg), (oe, on, og) = din, dout
@@ -483,7 +638,7 @@ def main():
         cores = min(os.cpu_count() or 1, c_port.max_threads())
         runner = c_port.BlockRunner(p, csc, host(b["ef"]), host(b["nf"]), host(b["gf"]), nthreads=cores)
         runner.run()
-        t_budget, times = (3.0 if args.dims == "readme" else 12.0), []
+        t_budget, times = (args.cpu_budget if args.cpu_budget is not None else (3.0 if args.dims == "readme" else 12.0)), []
         t_start = time.perf_counter()
         while time.perf_counter() - t_start < t_budget or len(times) < 3:
             t0 = time.perf_counter(); out = runner.run(); times.append(time.perf_counter() - t0)
@@ -518,8 +673,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_name, "dims": f"{din}=>{dout}", "edges_per_gpu": E, "nodes_per_gpu": N,
                        "graphs_per_gpu": G, "edges_whole_job": E_job, "parallelism": f"graph-sharded x{world}" if world > 1 else "single GPU", **extra},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "batch_ms": batch_ms,
         }
+        if secondary is not None:
+            line["secondary"] = secondary
         if dense is not None:
             line["cpu_dense_formulation_restatement"] = dense  # NOT the reference: its formulation restated in numpy (B2)
     # The JSON line must be the LAST thing on stdout: with NCCL_DEBUG=VERSION (set on the GPU boxes) RCCL writes its version

@@ -98,13 +98,15 @@ class GNGraphBatch:
             if _csc is not None:
                 colptrs, rowvals, n_nodes = _csc
                 G = len(n_nodes)
-                cps = [np.ascontiguousarray(c, dtype=np.int64) for c in colptrs]
-                rvs = [np.ascontiguousarray(r, dtype=np.int64) for r in rowvals]
-                keep += cps + rvs
-                cpp = (C.c_void_p * max(G, 1))(*[c.ctypes.data for c in cps])
-                rvp = (C.c_void_p * max(G, 1))(*[r.ctypes.data for r in rvs])
+                # ONE concatenation per array kind and one call (gnx_graphs_create_csc_packed): building 2 G ctypes pointers costs ~1 us
+                # each — 8 of the 20 ms of a 4096-graph batch
+                cat = lambda parts: np.ascontiguousarray(np.concatenate(parts) if len(parts) > 1 else (parts[0] if parts else np.zeros(0, np.int64)), dtype=np.int64)
+                cpc, rvc = cat(list(colptrs)), cat(list(rowvals))
                 nn = np.ascontiguousarray(n_nodes, dtype=np.int64)
-                check(lib.gnx_graphs_create_csc(cpp, rvp, nn.ctypes.data_as(C.POINTER(C.c_int64)), G, 0, C.byref(self._h)))
+                assert cpc.size == int(nn.sum()) + G, "every colptr must have n_nodes + 1 entries"
+                keep += [cpc, rvc, nn]
+                p64 = lambda a_: a_.ctypes.data_as(C.POINTER(C.c_int64))
+                check(lib.gnx_graphs_create_csc_packed(p64(cpc), p64(rvc) if rvc.size else None, p64(nn), G, 0, C.byref(self._h)))
                 self.adj_mats = None
             else:
                 mats = [_np(a) for a in adj_mats]

@@ -577,7 +577,9 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
     if (a < 0 || a > GNX_ACT_GELU) return fail(GNX_ERR_INVALID_ARG, "unknown activation code");
   const BwLayout L = bw_layout(h, p, R);
   if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_block_backward_workspace_bytes()");
-  int32_t rc = gnx_ensure_csr(h);
+  int32_t rc = gnx_ensure_wide_tables(h);  // (the delta kernels read the destination of every edge; the matrix-core pullbacks the 128-row tiles)
+  if (rc) return rc;
+  rc = gnx_ensure_csr(h);
   if (rc) return rc;
   char* base = static_cast<char*>(ws);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
@@ -753,7 +755,7 @@ CoreBwLayout core_bw_layout(const gnx_graphs* h, const gnx_core_params* p, int64
   L.part = take(pmax);
   L.wt = take(sizeof(float) * 4 * (size_t)std::max(d[0], std::max(d[1], d[2])) * std::max(d[0], std::max(d[1], d[2])));
   size_t tcs = 0;  // per-tile column sums of delta1 (tiles of the matrix-core path: 128-row chunks per graph)
-  const size_t nt[3] = {h->h_etiles.size(), h->h_ntiles.size(), h->h_gtiles.size()};
+  const size_t nt[3] = {(size_t)h->n_etiles, (size_t)h->n_ntiles, (size_t)h->n_gtiles};
   for (int t = 0; t < 3; ++t) tcs = std::max(tcs, sizeof(float) * (size_t)R * nt[t] * 4 * d[t]);
   L.tcs = take(tcs);
   size_t lnp = 0;  // k_ln_backward_v4: [blocks][4][D] column partial sums
@@ -783,6 +785,7 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
   }
   const CoreBwLayout L = core_bw_layout(h, p, R);
   if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_core_backward_workspace_bytes()");
+  if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
   char* base = static_cast<char*>(ws);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
   const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
@@ -987,6 +990,7 @@ int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_para
   if (oe == 0) return fail(GNX_ERR_DIMS, "chain backward: not implemented for an edge function without output (the forward takes it; train such a block with one-layer update functions)");
   const ChainBwLayout L = chain_bw_layout(h, p, R);
   if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_chain_block_backward_workspace_bytes()");
+  if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
   if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");
   char* base = static_cast<char*>(ws);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };

@@ -319,13 +319,14 @@ int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d,
   if (nrows == 0) return GNX_OK;
   if (ln_stats && (!ln || !ln->gamma || !ln->beta || ((uintptr_t)ln->gamma & 15) || ((uintptr_t)ln->beta & 15) || ((uintptr_t)ln_stats & 7)))
     return fail(GNX_ERR_INVALID_ARG, "k_ffn_fused: LayerNorm parameters missing or misaligned");
+  if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
   FfnArgs a{};
   a.tiles = entity == 0 ? h->d_etiles : (entity == 1 ? h->d_ntiles : h->d_gtiles);
   a.row_kind = entity == 0 ? 0 : 1;
   a.z = z; a.W1 = ff.fc1.weight; a.b1 = ff.fc1.bias; a.W2 = ff.fc2.weight; a.b2 = ff.fc2.bias;
   a.add1 = add1; a.add2 = add2; a.out = out; a.rep_stride = nrows * (size_t)d; a.act1 = ff.fc1.act;
   if (ln_stats) { a.ln_stats = ln_stats; a.ln_g = ln->gamma; a.ln_b = ln->beta; }
-  const unsigned n_tiles = (unsigned)(entity == 0 ? h->h_etiles.size() : (entity == 1 ? h->h_ntiles.size() : h->h_gtiles.size()));
+  const unsigned n_tiles = (unsigned)(entity == 0 ? h->n_etiles : (entity == 1 ? h->n_ntiles : h->n_gtiles));
   if (!a.tiles || !z || !ff.fc1.weight || !ff.fc2.weight || !out) return fail(GNX_ERR_INVALID_ARG, "k_ffn_fused: NULL operand");
   ProfScope ps("k_ffn_fused", s);
 #ifdef GNX_FFN_STAMPS_BUILD

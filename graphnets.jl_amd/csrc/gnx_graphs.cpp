@@ -2,8 +2,11 @@
 // The reference precomputes seven dense one-hot "broadcaster" tensors over a padded PN^2 edge grid; here the same
 // index semantics are held as CSC (colptr/rowval), per-graph offsets and a tile table, all int32 in HBM.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "gnx_internal.h"
 
@@ -21,6 +24,18 @@ int32_t hip_fail(hipError_t e, const char* what) {
   (void)hipGetLastError();
   return (int32_t)e > 0 ? (int32_t)e : 1;
 }
+
+// GNX_TIME_BUILD=1: phase timings of handle construction on stderr (diagnostic)
+struct BuildTimer {
+  bool on = getenv("GNX_TIME_BUILD") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void lap(const char* what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[gnx build] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -53,12 +68,13 @@ static int adj_at(const void* base, int32_t kind, int64_t idx, bool* ok) {
 static int32_t finalize(gnx_graphs* h) {
   if (h->N >= (int64_t)INT32_MAX || h->E >= (int64_t)INT32_MAX)
     return fail(GNX_ERR_TOO_LARGE, "graph batch exceeds int32 device indices");
+  BuildTimer bt;
   GNX_HIP(hipGetDevice(&h->device));
   h->tile_e_cap = env_int("GNX_TILE_E", 512);
   h->tile_n_cap = env_int("GNX_TILE_N", 128);
   // greedy tiling inside each graph: add nodes while edges <= cap and nodes <= cap; a node whose in-degree
   // exceeds the cap becomes a single-node tile (kernels loop over its edges).
-  auto build_tiles = [&](int e_cap, int n_cap, std::vector<gnx::Tile>& tiles, std::vector<int32_t>& off) {
+  auto build_tiles = [&](int e_cap, int n_cap, std::vector<gnx::Tile>& tiles, std::vector<int32_t>& off, int64_t* max_deg) {
     off.assign(h->G + 1, 0);
     for (int64_t g = 0; g < h->G; ++g) {
       off[g] = (int32_t)tiles.size();
@@ -69,7 +85,7 @@ static int32_t finalize(gnx_graphs* h) {
         const int64_t e0 = h->h_colptr[n];
         while (n1 < nend && (n1 - n) < n_cap) {
           const int64_t deg = h->h_colptr[n1 + 1] - h->h_colptr[n1];
-          h->max_in_degree = std::max(h->max_in_degree, deg);
+          *max_deg = std::max(*max_deg, deg);
           if (n1 > n && h->h_colptr[n1 + 1] - e0 > e_cap) break;
           ++n1;
         }
@@ -86,26 +102,37 @@ static int32_t finalize(gnx_graphs* h) {
     off[h->G] = (int32_t)tiles.size();
   };
   h->max_in_degree = 0;
-  build_tiles(h->tile_e_cap, h->tile_n_cap, h->h_tiles, h->h_tile_off);
   h->wtile_e_cap = env_int("GNX_WTILE_E", 128);
   if (h->wtile_e_cap != 64 && h->wtile_e_cap != 128 && h->wtile_e_cap != 256) h->wtile_e_cap = 128;
-  build_tiles(h->wtile_e_cap, 64, h->h_wtiles, h->h_wtile_off);
+  // (the two tile kinds on two host threads were measured: 2.5 instead of 0.9 ms for 4096 graphs — the second thread's start and the
+  // allocator cost more than the 0.45 ms it takes over)
+  build_tiles(h->tile_e_cap, h->tile_n_cap, h->h_tiles, h->h_tile_off, &h->max_in_degree);
+  build_tiles(h->wtile_e_cap, 64, h->h_wtiles, h->h_wtile_off, &h->max_in_degree);
   for (int64_t g = 0; g < h->G; ++g) {  // wave tiles per graph (graph-update launch geometry)
     const int32_t cnt = h->h_wtile_off[g + 1] - h->h_wtile_off[g];
     h->max_wtiles_per_graph = std::max(h->max_wtiles_per_graph, cnt);
     for (int32_t t = h->h_wtile_off[g]; t < h->h_wtile_off[g + 1]; ++t) h->h_wtiles[(size_t)t].flags = cnt;
   }
 
-  auto upload32 = [&](const std::vector<int64_t>& src, int32_t** dst) -> int32_t {
-    std::vector<int32_t> tmp(src.size());
-    for (size_t i = 0; i < src.size(); ++i) tmp[i] = (int32_t)src[i];
+  bt.lap("tile tables (host)");
+  auto upload32v = [&](const std::vector<int32_t>& tmp, int32_t** dst) -> int32_t {
     GNX_HIP(hipMalloc((void**)dst, std::max<size_t>(tmp.size(), 1) * sizeof(int32_t)));
     if (!tmp.empty()) GNX_HIP(hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     return GNX_OK;
   };
+  auto upload32 = [&](const std::vector<int64_t>& src, int32_t** dst) -> int32_t {
+    std::vector<int32_t> tmp(src.size());
+    for (size_t i = 0; i < src.size(); ++i) tmp[i] = (int32_t)src[i];
+    return upload32v(tmp, dst);
+  };
   int32_t rc;
-  if ((rc = upload32(h->h_colptr, &h->d_colptr))) return rc;
-  if ((rc = upload32(h->h_rowval, &h->d_rowval))) return rc;
+  // (a constructor that already produced the device-format arrays — the CSC one, in its validation pass — hands them over)
+  if (h->t_colptr32.size() == h->h_colptr.size()) { if ((rc = upload32v(h->t_colptr32, &h->d_colptr))) return rc; }
+  else if ((rc = upload32(h->h_colptr, &h->d_colptr))) return rc;
+  if (h->t_rowval32.size() == h->h_rowval.size() && !h->h_rowval.empty()) { if ((rc = upload32v(h->t_rowval32, &h->d_rowval))) return rc; }
+  else if ((rc = upload32(h->h_rowval, &h->d_rowval))) return rc;
+  std::vector<int32_t>().swap(h->t_colptr32);
+  std::vector<int32_t>().swap(h->t_rowval32);
   if ((rc = upload32(h->h_node_off, &h->d_node_off))) return rc;
   if ((rc = upload32(h->h_edge_off, &h->d_edge_off))) return rc;
   GNX_HIP(hipMalloc((void**)&h->d_tile_off, h->h_tile_off.size() * sizeof(int32_t)));
@@ -113,14 +140,48 @@ static int32_t finalize(gnx_graphs* h) {
   GNX_HIP(hipMalloc((void**)&h->d_tiles, std::max<size_t>(h->h_tiles.size(), 1) * sizeof(gnx::Tile)));
   if (!h->h_tiles.empty())
     GNX_HIP(hipMemcpy(h->d_tiles, h->h_tiles.data(), h->h_tiles.size() * sizeof(gnx::Tile), hipMemcpyHostToDevice));
-  // wide path tables: 128-row chunks that never cross a graph boundary (so a tile has ONE per-graph bias)
+  bt.lap("csc + tiles upload");
+  // wide path: the COUNTS of its 128-row tiles and the per-graph tile offsets now (O(G)); the tables on first use (ensure_wide_tables)
   {
-    const int BM = 128;
+    const int64_t BM = 128;
     h->h_etile_off.assign(h->G + 1, 0);
     h->h_ntile_off.assign(h->G + 1, 0);
     for (int64_t g = 0; g < h->G; ++g) {
-      h->h_etile_off[g] = (int32_t)h->h_etiles.size();
-      h->h_ntile_off[g] = (int32_t)h->h_ntiles.size();
+      h->h_etile_off[g + 1] = h->h_etile_off[g] + (int32_t)((h->h_edge_off[g + 1] - h->h_edge_off[g] + BM - 1) / BM);
+      h->h_ntile_off[g + 1] = h->h_ntile_off[g] + (int32_t)((h->h_node_off[g + 1] - h->h_node_off[g] + BM - 1) / BM);
+    }
+    h->n_etiles = h->h_etile_off[h->G];
+    h->n_ntiles = h->h_ntile_off[h->G];
+    h->n_gtiles = (h->G + BM - 1) / BM;
+    // rows of the per-destination partial-sum table: one per (chunk, destination in it) <= non-empty nodes + one extra row per chunk a
+    // node's edge run can spill into; bounded without walking the graph by min(E, N + 2 * n_etiles)
+    h->agg_rows_bound = std::min<int64_t>(h->E, h->N + 2 * h->n_etiles);
+  }
+  GNX_HIP(hipMalloc((void**)&h->d_wtile_off, h->h_wtile_off.size() * sizeof(int32_t)));
+  GNX_HIP(hipMemcpy(h->d_wtile_off, h->h_wtile_off.data(), h->h_wtile_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  GNX_HIP(hipMalloc((void**)&h->d_wtiles, std::max<size_t>(h->h_wtiles.size(), 1) * sizeof(gnx::Tile)));
+  if (!h->h_wtiles.empty())
+    GNX_HIP(hipMemcpy(h->d_wtiles, h->h_wtiles.data(), h->h_wtiles.size() * sizeof(gnx::Tile), hipMemcpyHostToDevice));
+  bt.lap("wave tiles upload");
+  return GNX_OK;
+}
+
+
+// The wide (matrix-core) path's tables, built on first use: 128-row edge / node / graph tiles, the destination of every edge, and the
+// aggregation chunks of the edge GEMM's fused edge -> node sums (see gnx_internal.h).  Host loops over N + E and a dozen uploads.
+static int32_t build_wide_tables(const gnx_graphs* h) {
+  BuildTimer bt;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev != h->device ? prev : -1};
+  if (prev != h->device) GNX_HIP(hipSetDevice(h->device));
+  int32_t rc;
+  // wide path tables: 128-row chunks that never cross a graph boundary (so a tile has ONE per-graph bias)
+  {
+    const int BM = 128;
+    for (int64_t g = 0; g < h->G; ++g) {
+      if (h->h_etile_off[g] != (int32_t)h->h_etiles.size() || h->h_ntile_off[g] != (int32_t)h->h_ntiles.size())
+        return fail(GNX_ERR_INVALID_ARG, "wide tables: tile offsets disagree with the handle's counts");
       for (int64_t e = h->h_edge_off[g]; e < h->h_edge_off[g + 1]; e += BM) {
         gnx::Tile t{};
         t.e0 = (int32_t)e; t.e1 = (int32_t)std::min<int64_t>(e + BM, h->h_edge_off[g + 1]); t.g = (int32_t)g;
@@ -134,8 +195,7 @@ static int32_t finalize(gnx_graphs* h) {
         h->h_ntiles.push_back(t);
       }
     }
-    h->h_etile_off[h->G] = (int32_t)h->h_etiles.size();
-    h->h_ntile_off[h->G] = (int32_t)h->h_ntiles.size();
+    if ((int64_t)h->h_etiles.size() != h->n_etiles || (int64_t)h->h_ntiles.size() != h->n_ntiles) return fail(GNX_ERR_INVALID_ARG, "wide tables: tile counts disagree");
     auto up = [&](const void* src, size_t bytes, void** dst) -> int32_t {
       GNX_HIP(hipMalloc(dst, std::max<size_t>(bytes, 16)));
       if (bytes) GNX_HIP(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
@@ -155,6 +215,7 @@ static int32_t finalize(gnx_graphs* h) {
     for (int64_t n = 0; n < h->N; ++n)
       for (int64_t e = h->h_colptr[n]; e < h->h_colptr[n + 1]; ++e) dst[(size_t)e] = (int32_t)n;
     if ((rc = up(dst.data(), dst.size() * sizeof(int32_t), (void**)&h->d_edge_dst))) return rc;
+    bt.lap("wide tiles + edge_dst");
     {
       // aggregation chunks (64-row passes of the 128-edge tiles): rows of the partial-sum table per chunk = distinct
       // destinations in the chunk; edges are dst-sorted, so that is a count of non-empty nodes between its first and last dst
@@ -171,6 +232,7 @@ static int32_t finalize(gnx_graphs* h) {
         }
       }
       h->n_agg_rows = row0[n_chunks];
+      if (h->n_agg_rows > h->agg_rows_bound) return fail(GNX_ERR_INVALID_ARG, "wide tables: more aggregation rows than the bound workspaces are sized with");
       std::vector<int32_t> agg_row((size_t)h->N, -1), parts((size_t)h->N, 0), first_chunk((size_t)h->N, 0);
       // chunk of an edge: tiles are 128-edge chunks of each graph's edge range, in graph order
       auto chunk_of = [&](int64_t e, int64_t g) { return (int64_t)2 * h->h_etile_off[(size_t)g] + (e - h->h_edge_off[(size_t)g]) / 64; };
@@ -188,13 +250,9 @@ static int32_t finalize(gnx_graphs* h) {
       if ((rc = up(agg_row.data(), agg_row.size() * sizeof(int32_t), (void**)&h->d_node_agg_row))) return rc;
       if ((rc = up(parts.data(), parts.size() * sizeof(int32_t), (void**)&h->d_node_agg_parts))) return rc;
       if ((rc = up(first_chunk.data(), first_chunk.size() * sizeof(int32_t), (void**)&h->d_node_agg_chunk))) return rc;
+      bt.lap("aggregation tables");
     }
   }
-  GNX_HIP(hipMalloc((void**)&h->d_wtile_off, h->h_wtile_off.size() * sizeof(int32_t)));
-  GNX_HIP(hipMemcpy(h->d_wtile_off, h->h_wtile_off.data(), h->h_wtile_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  GNX_HIP(hipMalloc((void**)&h->d_wtiles, std::max<size_t>(h->h_wtiles.size(), 1) * sizeof(gnx::Tile)));
-  if (!h->h_wtiles.empty())
-    GNX_HIP(hipMemcpy(h->d_wtiles, h->h_wtiles.data(), h->h_wtiles.size() * sizeof(gnx::Tile), hipMemcpyHostToDevice));
   return GNX_OK;
 }
 
@@ -206,6 +264,98 @@ int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int6
 }
 
 using namespace gnx;
+
+extern "C" int32_t gnx_graphs_destroy(gnx_graphs* h);
+
+// Shared body of the two CSC constructors: graph g's arrays through two accessors.  Two passes: sizes (so that every array is allocated
+// once), then validation fused with the copy — int64 host copies (accessors, collapse / CSR builders) and the int32 device-format arrays
+// in one sweep over the input.
+template <class CP, class RV>
+static int32_t create_csc_impl(CP colptr_of, RV rowval_of, const int64_t* n_nodes, int64_t n_graphs, int32_t index_base, gnx_graphs** out) {
+  BuildTimer bt;
+  gnx_graphs* h = new gnx_graphs();
+  h->G = n_graphs;
+  h->h_node_off.resize((size_t)n_graphs + 1);
+  h->h_edge_off.resize((size_t)n_graphs + 1);
+  h->h_node_off[0] = 0; h->h_edge_off[0] = 0;
+  for (int64_t g = 0; g < n_graphs; ++g) {
+    const int64_t n = n_nodes[g];
+    const int64_t* cp = colptr_of(g);
+    if (n <= 0 || !cp) { delete h; return fail(GNX_ERR_ADJ_SHAPE, "graph must have N >= 1 nodes and a colptr"); }
+    if (cp[0] != index_base) { delete h; return fail(GNX_ERR_CSC, "colptr[0] must equal index_base"); }
+    const int64_t eg = cp[n] - index_base;
+    if (eg < 0 || eg > n * n) { delete h; return fail(GNX_ERR_CSC, "colptr must be non-decreasing with at most N entries per column"); }
+    if (eg > 0 && !rowval_of(g)) { delete h; return fail(GNX_ERR_CSC, "rowval is NULL but the graph has edges"); }
+    h->PN = std::max(h->PN, n);
+    h->h_node_off[(size_t)g + 1] = h->h_node_off[(size_t)g] + n;
+    h->h_edge_off[(size_t)g + 1] = h->h_edge_off[(size_t)g] + eg;
+  }
+  h->N = h->h_node_off.back();
+  h->E = h->h_edge_off.back();
+  if (h->N >= (int64_t)INT32_MAX || h->E >= (int64_t)INT32_MAX) { delete h; return fail(GNX_ERR_TOO_LARGE, "graph batch exceeds int32 device indices"); }
+  h->h_colptr.resize((size_t)h->N + 1);
+  h->h_rowval.resize((size_t)h->E);
+  h->t_colptr32.resize((size_t)h->N + 1);
+  h->t_rowval32.resize((size_t)h->E);
+  h->h_colptr[0] = 0; h->t_colptr32[0] = 0;
+  int64_t* hc = h->h_colptr.data();
+  int64_t* hr = h->h_rowval.data();
+  int32_t* c32 = h->t_colptr32.data();
+  int32_t* r32 = h->t_rowval32.data();
+  // graphs are independent: large batches are validated and copied by a few host threads, each on a contiguous range of graphs with
+  // about the same number of nodes + edges (4096 small graphs, 590k nodes + 1M edges: 4.3-5.5 -> 2.0 ms)
+  auto run_range = [&](int64_t g_lo, int64_t g_hi) -> const char* {
+  const char* bad = nullptr;
+  for (int64_t g = g_lo; g < g_hi && !bad; ++g) {
+    const int64_t n = n_nodes[g], base = h->h_node_off[(size_t)g], ebase = h->h_edge_off[(size_t)g];
+    const int64_t* cp = colptr_of(g);
+    const int64_t* rv = rowval_of(g);
+    int64_t a = 0;  // cp[j] - index_base
+    for (int64_t j = 0; j < n; ++j) {
+      const int64_t b = cp[j + 1] - index_base;
+      if (b < a || b - a > n) { bad = "colptr must be non-decreasing with at most N entries per column"; break; }
+      int64_t prev = -1;
+      for (int64_t k = a; k < b; ++k) {
+        const int64_t i = rv[k] - index_base;
+        if (i <= prev || i >= n) { bad = "rowval out of range or not strictly increasing inside a column"; break; }
+        prev = i;
+        hr[ebase + k] = base + i;
+        r32[ebase + k] = (int32_t)(base + i);
+      }
+      if (bad) break;
+      hc[base + j + 1] = ebase + b;
+      c32[base + j + 1] = (int32_t)(ebase + b);
+      a = b;
+    }
+    if (!bad && a != h->h_edge_off[(size_t)g + 1] - ebase) bad = "colptr must be non-decreasing with at most N entries per column";
+  }
+  return bad;
+  };
+  const char* bad = nullptr;
+  const int64_t work = h->N + h->E;
+  const int n_thr = (int)std::min<int64_t>(std::min<int64_t>(8, std::max(1u, std::thread::hardware_concurrency())), std::min<int64_t>(n_graphs, work / 400000));
+  if (n_thr <= 1) {
+    bad = run_range(0, n_graphs);
+  } else {
+    std::vector<int64_t> cut((size_t)n_thr + 1, n_graphs);
+    cut[0] = 0;
+    int t = 1;
+    for (int64_t g = 0; g < n_graphs && t < n_thr; ++g)
+      if (h->h_node_off[(size_t)g + 1] + h->h_edge_off[(size_t)g + 1] >= work * t / n_thr) cut[(size_t)t++] = g + 1;
+    std::vector<const char*> res((size_t)n_thr, nullptr);
+    std::vector<std::thread> thr;
+    for (int i = 1; i < n_thr; ++i) thr.emplace_back([&, i] { res[(size_t)i] = run_range(cut[(size_t)i], cut[(size_t)i + 1]); });
+    res[0] = run_range(cut[0], cut[1]);
+    for (auto& th : thr) th.join();
+    for (int i = 0; i < n_thr && !bad; ++i) bad = res[(size_t)i];  // the first failing range in graph order: the message a serial pass gives
+  }
+  if (bad) { delete h; return fail(GNX_ERR_CSC, bad); }
+  bt.lap("csc validation + copy");
+  int32_t rc = finalize(h);
+  if (rc) { gnx_graphs_destroy(h); return rc; }
+  *out = h;
+  return GNX_OK;
+}
 
 extern "C" {
 
@@ -280,41 +430,28 @@ int32_t gnx_graphs_create_csc(const int64_t* const* colptr, const int64_t* const
   if (n_graphs <= 0) return fail(GNX_ERR_NO_GRAPHS, "length(adj_mats) must be > 0 (checks.jl:8)");
   if (!colptr || !rowval || !n_nodes) return fail(GNX_ERR_INVALID_ARG, "colptr / rowval / n_nodes is NULL");
   if (index_base != 0 && index_base != 1) return fail(GNX_ERR_INVALID_ARG, "index_base must be 0 or 1");
-  gnx_graphs* h = new gnx_graphs();
-  h->G = n_graphs;
-  h->h_node_off.push_back(0);
-  h->h_edge_off.push_back(0);
-  h->h_colptr.push_back(0);
+  return create_csc_impl([&](int64_t g) { return colptr[g]; }, [&](int64_t g) { return rowval[g]; }, n_nodes, n_graphs, index_base, out);
+}
+
+int32_t gnx_graphs_create_csc_packed(const int64_t* colptr_cat, const int64_t* rowval_cat, const int64_t* n_nodes, int64_t n_graphs,
+                                     int32_t index_base, gnx_graphs** out) {
+  if (!out) return fail(GNX_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (n_graphs <= 0) return fail(GNX_ERR_NO_GRAPHS, "length(adj_mats) must be > 0 (checks.jl:8)");
+  if (!colptr_cat || !n_nodes) return fail(GNX_ERR_INVALID_ARG, "colptr / n_nodes is NULL");
+  if (index_base != 0 && index_base != 1) return fail(GNX_ERR_INVALID_ARG, "index_base must be 0 or 1");
+  // graph g's colptr starts behind the (n + 1)-entry colptrs of the graphs before it, its rowval behind their edges
+  std::vector<int64_t> cpo((size_t)n_graphs + 1, 0), rvo((size_t)n_graphs + 1, 0);
   for (int64_t g = 0; g < n_graphs; ++g) {
-    const int64_t n = n_nodes[g];
-    if (n <= 0 || !colptr[g]) { delete h; return fail(GNX_ERR_ADJ_SHAPE, "graph must have N >= 1 nodes and a colptr"); }
-    h->PN = std::max(h->PN, n);
-    const int64_t base = h->h_node_off.back(), ebase = h->h_edge_off.back();
-    const int64_t* cp = colptr[g];
-    const int64_t* rv = rowval[g];
-    if (cp[0] != index_base) { delete h; return fail(GNX_ERR_CSC, "colptr[0] must equal index_base"); }
-    for (int64_t j = 0; j < n; ++j) {
-      const int64_t a = cp[j] - index_base, b = cp[j + 1] - index_base;
-      if (b < a || b - a > n) { delete h; return fail(GNX_ERR_CSC, "colptr must be non-decreasing with at most N entries per column"); }
-      if (b > a && !rv) { delete h; return fail(GNX_ERR_CSC, "rowval is NULL but the graph has edges"); }
-      int64_t prev = -1;
-      for (int64_t k = a; k < b; ++k) {
-        const int64_t i = rv[k] - index_base;
-        if (i < 0 || i >= n || i <= prev) { delete h; return fail(GNX_ERR_CSC, "rowval out of range or not strictly increasing inside a column"); }
-        prev = i;
-        h->h_rowval.push_back(base + i);
-      }
-      h->h_colptr.push_back(ebase + b);
-    }
-    h->h_node_off.push_back(base + n);
-    h->h_edge_off.push_back((int64_t)h->h_rowval.size());
+    if (n_nodes[g] <= 0) return fail(GNX_ERR_ADJ_SHAPE, "graph must have N >= 1 nodes and a colptr");
+    cpo[(size_t)g + 1] = cpo[(size_t)g] + n_nodes[g] + 1;
+    const int64_t eg = colptr_cat[cpo[(size_t)g + 1] - 1] - index_base;
+    if (eg < 0) return fail(GNX_ERR_CSC, "colptr must be non-decreasing with at most N entries per column");
+    rvo[(size_t)g + 1] = rvo[(size_t)g] + eg;
   }
-  h->N = h->h_node_off.back();
-  h->E = h->h_edge_off.back();
-  int32_t rc = finalize(h);
-  if (rc) { gnx_graphs_destroy(h); return rc; }
-  *out = h;
-  return GNX_OK;
+  if (rvo.back() > 0 && !rowval_cat) return fail(GNX_ERR_CSC, "rowval is NULL but the graph has edges");
+  return create_csc_impl([&](int64_t g) { return colptr_cat + cpo[(size_t)g]; },
+                         [&](int64_t g) { return rowval_cat ? rowval_cat + rvo[(size_t)g] : nullptr; }, n_nodes, n_graphs, index_base, out);
 }
 
 int32_t gnx_graphs_destroy(gnx_graphs* h) {
@@ -388,6 +525,13 @@ static int32_t build_csr(const gnx_graphs* h) {
   GNX_HIP(hipMemcpy(h->d_csr_ptr, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   if (!eid.empty()) GNX_HIP(hipMemcpy(h->d_csr_eid, eid.data(), eid.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   return GNX_OK;
+}
+
+int32_t gnx_ensure_wide_tables(const gnx_graphs* h) {
+  if (!h) return fail(GNX_ERR_INVALID_ARG, "NULL handle");
+  std::call_once(h->wide_once, [&] { h->wide_rc = build_wide_tables(h); });
+  if (h->wide_rc) set_error("wide-path tables could not be built");
+  return h->wide_rc;
 }
 
 int32_t gnx_ensure_csr(const gnx_graphs* h) {

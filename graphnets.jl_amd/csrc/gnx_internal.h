@@ -17,6 +17,7 @@ struct gnx_graphs {
   int device = 0;
   // host copies (int64, 0-based, global)
   std::vector<int64_t> h_node_off, h_edge_off, h_colptr, h_rowval;
+  std::vector<int32_t> t_colptr32, t_rowval32;  // transient: the device-format copies a constructor already made (uploaded as they are, then freed)
   std::vector<gnx::Tile> h_tiles;
   std::vector<int32_t> h_tile_off;  // [G+1] tiles of graph g = [tile_off[g], tile_off[g+1])
   // wave tiles: same idea at wavefront granularity (<= wtile_e_cap edges, <= 64 nodes), one wave64 per tile
@@ -30,23 +31,29 @@ struct gnx_graphs {
   int32_t* d_tile_off = nullptr;  // [G+1]
   gnx::Tile* d_tiles = nullptr;   // [n_tiles]
   int32_t* d_wtile_off = nullptr; // [G+1]
-  // wide (MFMA) path: destination node of every edge, and 128-row chunks of each graph's edges / nodes
-  int32_t* d_edge_dst = nullptr;  // [E]
-  std::vector<gnx::Tile> h_etiles, h_ntiles, h_gtiles;  // h_gtiles: 128-row chunks of the graph rows (n0/n1 = graph ids)
-  std::vector<int32_t> h_etile_off, h_ntile_off;
-  gnx::Tile* d_etiles = nullptr;
-  gnx::Tile* d_ntiles = nullptr;
-  gnx::Tile* d_gtiles = nullptr;
-  int32_t* d_etile_off = nullptr;
-  int32_t* d_ntile_off = nullptr;
+  // wide (MFMA) path: destination node of every edge, and 128-row chunks of each graph's edges / nodes.  The COUNTS (what workspace
+  // sizes need) are computed with the handle; the tables themselves — O(N + E) host loops and a dozen uploads that a batch of narrow
+  // blocks never reads — are built on first use (gnx_ensure_wide_tables: every launcher that reads them calls it; thread-safe).
+  int64_t n_etiles = 0, n_ntiles = 0, n_gtiles = 0;
+  int64_t agg_rows_bound = 0;     // >= n_agg_rows, known without the tables: non-empty nodes + one row per chunk
+  std::vector<int32_t> h_etile_off, h_ntile_off;  // [G+1] (eager: O(G))
+  mutable std::once_flag wide_once;
+  mutable int32_t wide_rc = 0;
+  mutable int32_t* d_edge_dst = nullptr;  // [E]
+  mutable std::vector<gnx::Tile> h_etiles, h_ntiles, h_gtiles;  // h_gtiles: 128-row chunks of the graph rows (n0/n1 = graph ids)
+  mutable gnx::Tile* d_etiles = nullptr;
+  mutable gnx::Tile* d_ntiles = nullptr;
+  mutable gnx::Tile* d_gtiles = nullptr;
+  mutable int32_t* d_etile_off = nullptr;
+  mutable int32_t* d_ntile_off = nullptr;
   // wide path, edge->node aggregation inside the edge GEMM: an aggregation CHUNK is a 64-row pass of an edge tile (chunk
   // 2t + pass); every chunk writes one partial-sum row per distinct destination it holds, rows [chunk_row0[c], chunk_row0[c+1])
   // of a table of n_agg_rows rows.  A node's sum = its row in its first chunk (+ row 0 of each further chunk it runs into).
-  int32_t* d_chunk_row0 = nullptr;       // [2 * n_etiles + 1]
-  int32_t* d_node_agg_row = nullptr;     // [N] row of the node's first partial, -1 for a node without in-edges
-  int32_t* d_node_agg_parts = nullptr;   // [N] number of chunks the node's in-edges run through
-  int32_t* d_node_agg_chunk = nullptr;   // [N] its first chunk
-  int64_t n_agg_rows = 0;
+  mutable int32_t* d_chunk_row0 = nullptr;       // [2 * n_etiles + 1]
+  mutable int32_t* d_node_agg_row = nullptr;     // [N] row of the node's first partial, -1 for a node without in-edges
+  mutable int32_t* d_node_agg_parts = nullptr;   // [N] number of chunks the node's in-edges run through
+  mutable int32_t* d_node_agg_chunk = nullptr;   // [N] its first chunk
+  mutable int64_t n_agg_rows = 0;
   gnx::Tile* d_wtiles = nullptr;  // [n_wtiles]
   int32_t wtile_e_cap = 0;
   int32_t max_wtiles_per_graph = 0;
@@ -95,6 +102,11 @@ struct ProfScope {
 bool profile_enabled();  // per-kernel timing is on: callers keep everything on one stream (overlapped kernels would share their time)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace gnx
+// builds the wide-path tables of a handle on first use (returns GNX_OK or the error of the first attempt)
+extern "C" int32_t gnx_ensure_wide_tables(const gnx_graphs* h);
+namespace gnx {
 
 
 }  // namespace gnx

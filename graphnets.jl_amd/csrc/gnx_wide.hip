@@ -1006,12 +1006,12 @@ static int wide_slices(const gnx_graphs* h) {
 }
 
 size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
-  const size_t per_tile = sizeof(float) * (size_t)R * ((size_t)h->h_etiles.size() * p->oe + (size_t)h->h_ntiles.size() * p->on);
+  const size_t per_tile = sizeof(float) * (size_t)R * ((size_t)h->n_etiles * p->oe + (size_t)h->n_ntiles * p->on);
   const size_t stage2 = sizeof(float) * (size_t)R * h->G * wide_slices(h) * (size_t)(p->oe + p->on);
   const size_t bias_g = sizeof(float) * (size_t)R * h->G * (size_t)(p->oe + p->on);
   const size_t proj = sizeof(float) * 2 * (size_t)R * h->N * (size_t)p->oe;  // node projections Ps, Pd
   const size_t xg = sizeof(float) * (size_t)R * h->G * (size_t)(p->oe + p->on + p->dg);  // graph-function input (small batches)
-  const size_t agg = sizeof(float) * (size_t)R * (size_t)h->n_agg_rows * (size_t)p->oe;  // per-destination partial sums of the edge GEMM
+  const size_t agg = sizeof(float) * (size_t)R * (size_t)h->agg_rows_bound * (size_t)p->oe;  // per-destination partial sums of the edge GEMM (rows: an upper bound known without the tables)
   return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + align_up(xg, 256) + align_up(agg, 256) + 512;
 }
 
@@ -1140,6 +1140,8 @@ static int32_t launch_gemm_any(const WideArgs& w, unsigned n_tiles, int64_t R, h
   // workgroup walks its K chunks alone, paying a 128-wide tile's MFMA time per chunk for a handful of rows.  Narrower column
   // tiles give more workgroups and 2-4x less matrix-core time per chunk.
   while (bn > 32 && (size_t)n_tiles * ((w.OUT + bn - 1) / bn) * (size_t)R < 256) bn >>= 1;
+  static const int bn_env = getenv("GNX_GEMM_BN") ? atoi(getenv("GNX_GEMM_BN")) : 0;  // experiment switch: cap the column tile (64 / 32)
+  if (bn_env == 64 || bn_env == 32) bn = std::min(bn, bn_env);
   if (bn == 128) return launch_gemm<128>(w, n_tiles, R, s, name);
   if (bn == 64) return launch_gemm<64>(w, n_tiles, R, s, name);
   return launch_gemm<32>(w, n_tiles, R, s, name);
@@ -1151,6 +1153,7 @@ int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K
                           const float* add2, float* out, int64_t R, hipStream_t s, const char* name) {
   const size_t nrows = entity == 0 ? (size_t)h->E : (entity == 1 ? (size_t)h->N : (size_t)h->G);
   if (nrows == 0 || OUT == 0) return GNX_OK;
+  if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
   WideArgs w{};
   w.tiles = entity == 0 ? h->d_etiles : (entity == 1 ? h->d_ntiles : h->d_gtiles);
   w.row_kind = entity == 0 ? 0 : 1;
@@ -1161,7 +1164,7 @@ int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K
   w.out = out; w.out_rep_stride = nrows * (size_t)OUT;
   w.colsum = nullptr;
   w.add1 = add1; w.add2 = add2;
-  const unsigned n_tiles = (unsigned)(entity == 0 ? h->h_etiles.size() : (entity == 1 ? h->h_ntiles.size() : h->h_gtiles.size()));
+  const unsigned n_tiles = (unsigned)(entity == 0 ? h->n_etiles : (entity == 1 ? h->n_ntiles : h->n_gtiles));
   return launch_gemm_any(w, n_tiles, R, s, name);
 }
 
@@ -1173,6 +1176,7 @@ int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int 
                            hipStream_t s, const char* name, const float* gmul, int gmul_act, float* tile_colsum, int* n_tiles_out, const float* add1) {
   const size_t nrows = entity == 0 ? (size_t)h->E : (entity == 1 ? (size_t)h->N : (size_t)h->G);
   if (nrows == 0 || OUT == 0 || K == 0) return GNX_OK;
+  if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
   WideArgs w{};
   w.tiles = entity == 0 ? h->d_etiles : (entity == 1 ? h->d_ntiles : h->d_gtiles);
   w.row_kind = entity == 0 ? 0 : 1;
@@ -1181,7 +1185,7 @@ int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int 
   w.W = B; w.ldw = ldw; w.bias = nullptr; w.OUT = OUT; w.act = GNX_ACT_IDENTITY;
   w.n_graphs = (int)h->G;
   w.out = out; w.out_rep_stride = nrows * (size_t)OUT;
-  const unsigned n_tiles = (unsigned)(entity == 0 ? h->h_etiles.size() : (entity == 1 ? h->h_ntiles.size() : h->h_gtiles.size()));
+  const unsigned n_tiles = (unsigned)(entity == 0 ? h->n_etiles : (entity == 1 ? h->n_ntiles : h->n_gtiles));
   w.gmul = gmul; w.gmul_act = gmul_act;
   w.add1 = add1;  // optional residual with the layout of out (may alias it)
   w.colsum = tile_colsum; w.colsum_rep_stride = (size_t)n_tiles * OUT;
@@ -1220,7 +1224,8 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   bool project = false;
   if (!wide_applies(h, a, &project)) return 1;
   if ((a.ln_stats[0] || a.ln_stats[1]) && !block_wide_ln_applies(h, a)) return fail(GNX_ERR_INVALID_ARG, "launch_block_wide: LayerNorm on load is not applicable to this block");
-  const size_t n_et = h->h_etiles.size(), n_nt = h->h_ntiles.size();
+  if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
+  const size_t n_et = (size_t)h->n_etiles, n_nt = (size_t)h->n_ntiles;
   // workspace layout inside a.partials (sized by gnx_block_workspace_bytes >= wide_workspace_bytes)
   float* pe = a.partials;
   float* pn = pe + (size_t)R * n_et * a.oe;

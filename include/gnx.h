@@ -147,6 +147,11 @@ GNX_API int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n
  * only accepts dense matrices, which cannot hold BASELINE configs 2-5.) */
 GNX_API int32_t gnx_graphs_create_csc(const int64_t* const* colptr, const int64_t* const* rowval, const int64_t* n_nodes,
                               int64_t n_graphs, int32_t index_base, gnx_graphs** out);
+/* the same batch from TWO arrays: colptr_cat = the graphs' colptr arrays one after the other (n_g + 1 entries each, every one starting at
+ * index_base), rowval_cat = their rowval arrays one after the other.  One call and two pointers instead of 2 G pointers: what a host
+ * pays per graph to build pointer arrays (8 ms for 4096 graphs through ctypes) is the larger part of batch() on many small graphs. */
+GNX_API int32_t gnx_graphs_create_csc_packed(const int64_t* colptr_cat, const int64_t* rowval_cat, const int64_t* n_nodes, int64_t n_graphs,
+                                     int32_t index_base, gnx_graphs** out);
 
 GNX_API int32_t gnx_graphs_destroy(gnx_graphs* h);
 GNX_API int32_t gnx_graphs_get_info(const gnx_graphs* h, gnx_graphs_info* out);

@@ -641,15 +641,19 @@ def chain_block_forward_sparse(p, csc, ef, nf, gf, return_scale=False):
         he, se = run(p["edge"], Xe, np.abs(Xe)) if p["edge"] else (None, None)
         hn = sn = hg = sg = None
         if p["node"]:
-            parts, sparts = [_segsum(he, dst, N)], [_segsum(se, dst, N)]
+            # (a chain without layers = a zero-width output: an empty segment of the next input, as the reference's 0-row arrays, gnblock.jl:63-69)
+            parts, sparts = ([_segsum(he, dst, N)], [_segsum(se, dst, N)]) if he is not None else ([], [])
             if nf is not None:
                 parts.append(nfr); sparts.append(np.abs(nfr))
             if gf is not None:
                 parts.append(gfr[node_graph]); sparts.append(np.abs(gfr[node_graph]))
             hn, sn = run(p["node"], np.concatenate(parts, axis=1), np.concatenate(sparts, axis=1))
         if p["graph"]:
-            parts = [_segsum(he, edge_graph, G), _segsum(hn, node_graph, G)]
-            sparts = [_segsum(se, edge_graph, G), _segsum(sn, node_graph, G)]
+            parts, sparts = [], []
+            if he is not None:
+                parts.append(_segsum(he, edge_graph, G)); sparts.append(_segsum(se, edge_graph, G))
+            if hn is not None:
+                parts.append(_segsum(hn, node_graph, G)); sparts.append(_segsum(sn, node_graph, G))
             if gf is not None:
                 parts.append(gfr); sparts.append(np.abs(gfr))
             hg, sg = run(p["graph"], np.concatenate(parts, axis=1), np.concatenate(sparts, axis=1))

@@ -97,6 +97,23 @@ int main() {
       EXPECT(gnx_graphs_get_offsets(h, no.data(), eo.data()) == GNX_OK);
       gnx_graphs_destroy(h);
     }
+    {  // the packed form (two arrays instead of 2 G pointers) answers exactly what the pointer form answers, malformed input included
+      std::vector<int64_t> cpc, rvc;
+      for (int g = 0; g < G; ++g) {  // (an edgeless graph's rvs holds one dummy entry: only the real edges are concatenated)
+        cpc.insert(cpc.end(), cps[g].begin(), cps[g].end());
+        rvc.insert(rvc.end(), rvs[g].begin(), rvs[g].begin() + (cps[g].back() - base));
+      }
+      gnx_graphs* hp = nullptr;
+      const int32_t rcp = gnx_graphs_create_csc_packed(cpc.data(), rvc.empty() ? nullptr : rvc.data(), nn.data(), G, base, &hp);
+      EXPECT(rcp == rc);
+      if (rcp == GNX_OK) gnx_graphs_destroy(hp);
+      if (!rvc.empty()) {
+        rvc[0] = (int64_t)1 << 40;  // (out of range for whichever graph owns the first edge)
+        hp = nullptr;
+        EXPECT(gnx_graphs_create_csc_packed(cpc.data(), rvc.data(), nn.data(), G, base, &hp) == GNX_ERR_CSC && hp == nullptr);
+      }
+      EXPECT(gnx_graphs_create_csc_packed(nullptr, nullptr, nn.data(), G, base, &hp) == GNX_ERR_INVALID_ARG);
+    }
     // malformed: colptr decreasing
     if (nn[0] >= 2) {
       auto bad = cps[0];

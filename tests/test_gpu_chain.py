@@ -59,10 +59,17 @@ def test_chain_block_shared_graph_replicas_and_errors(gn):
     ref = O.chain_block_forward_sparse(p, O.csc_from_adj([adj]), *pk)
     np.testing.assert_allclose(np.transpose(y.ef.cpu().numpy(), (2, 1, 0)), ref[0], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(y.gf.cpu().numpy().T[:, None, :], ref[2], rtol=1e-5, atol=2e-5)
-    # a graph function without a node function has no getgraphfninput (graphfninput.jl:1-13)
-    bad = O.make_chain_block_params(rng, (10, 5, 0), [4, 3], [], [5])
-    with pytest.raises(gn.GnxError):
-        _block(gn, bad)(gn.batch(dict(graphs=adj, ef=ef, nf=nf, gf=None)))
+    # zero-width outputs: the reference computes getnodefninput / getgraphfninput over the 0-row h_ef / h_nf (gnblock.jl:63-69), and so do
+    # one-layer blocks here — a Chain block must take the same dims: no node function, then no edge function
+    for ew, nw, gw in (([4, 3], [], [5]), ([], [6, 4], [5])):
+        pz = O.make_chain_block_params(rng, (10, 5, 0), ew, nw, gw)
+        yz = gn.unbatch(_block(gn, pz)(gn.batch(dict(graphs=adj, ef=ef, nf=nf, gf=None))))
+        rz, sz = O.chain_block_forward_sparse(pz, O.csc_from_adj([adj]), *pk, return_scale=True)
+        assert (yz.ef is None) == (not ew) and (yz.nf is None) == (not nw)
+        for got, r, sc in ((yz.ef, rz[0], sz[0]), (yz.nf, rz[1], sz[1])):
+            if r is not None:
+                U.assert_close(np.transpose(got.cpu().numpy(), (2, 1, 0)), r, sc)
+        U.assert_close(yz.gf.cpu().numpy().T[:, None, :], rz[2], sz[2])
 
 
 def _torch_chain_block(csc, ef, nf, gf, W):
