@@ -327,7 +327,7 @@ def collect_secondary(args):
         ts = roof.get("traffic_source")
         if ts:
             entry["roofline"]["traffic_source"] = {k: ts.get(k) for k in ("file", "commit", "stale") if ts.get(k) is not None}
-        for k in ("batch_ms", "kernel_us_one_forward"):
+        for k in ("batch_ms", "kernel_us_one_forward", "pipelined_two_streams"):
             if k in line or k in line.get("config", {}):
                 entry[k] = line.get(k, line.get("config", {}).get(k))
         out[key] = entry
@@ -440,11 +440,15 @@ def main():
                    f"{len(shards[rank])} graphs / {int(e_all[shards[rank]].sum())} edges on rank 0 (BASELINE configs[{2 if Gtot == 512 and world == 1 else 4}] law)")
     torch.cuda.synchronize(dev)
     gn.GNGraphBatch.from_csc(colptrs[:1], rowvals[:1], nn[:1], device=dev)  # (first call: library load, context)
-    t0 = time.perf_counter()
-    g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
-    torch.cuda.synchronize(dev)
-    batch_ms = {"from_csc": round((time.perf_counter() - t0) * 1e3, 3),
-                "what": "GNGraphBatch construction end to end (host validation, CSC -> device tables, tile tables), median-free single shot after a warm-up call"}
+    tb = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
+        torch.cuda.synchronize(dev)
+        tb.append((time.perf_counter() - t0) * 1e3)
+    batch_ms = {"from_csc": round(min(tb), 3), "from_csc_first_call": round(tb[0], 3),
+                "what": "GNGraphBatch construction from Python, end to end (host validation, CSC -> device tables, tile tables; the matrix-core path's "
+                        "tables are built on its first use): best of 3 calls, and the first call (fresh allocations)"}
     E, N, G = g.n_edges, g.n_nodes, g.n_graphs
     if workload == "hetero" and not multi and sum(int(n) * int(n) for n in nn) <= 2e8:  # the reference's own input form: dense 0/1 matrices
         adjs = []
@@ -452,10 +456,14 @@ def main():
             a = np.zeros((n, n), dtype=np.uint8)
             a[rv, np.repeat(np.arange(n), np.diff(cp))] = 1  # A[i, j] = 1 <=> edge i -> j (src = row, dst = column)
             adjs.append(a)
-        t0 = time.perf_counter()
-        gd = gn.GNGraphBatch(adjs, device=dev)
-        torch.cuda.synchronize(dev)
-        batch_ms["from_dense_uint8"] = round((time.perf_counter() - t0) * 1e3, 3)
+        td = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            gd = gn.GNGraphBatch(adjs, device=dev)
+            torch.cuda.synchronize(dev)
+            td.append((time.perf_counter() - t0) * 1e3)
+        batch_ms["from_dense_uint8"] = round(min(td), 3)
+        batch_ms["from_dense_uint8_first_call"] = round(td[0], 3)  # (includes the one-off allocation of the 64 MB pinned staging buffers)
         assert gd.n_edges == E and gd.n_nodes == N
         del gd, adjs
     rng = np.random.default_rng(100)  # identical weights on every rank
@@ -523,6 +531,7 @@ def main():
     sync_all()
 
     extra = {}
+    pipelined = None
     if not multi:
         def capture(nsteps, rotate):
             cg = torch.cuda.CUDAGraph()
@@ -540,6 +549,29 @@ def main():
         extra["warm_ms_per_step"] = round(sorted(timed(warm.replay) for _ in range(3))[1] / K * 1e3, 6)
         extra["launch"] = (f"hipGraph of {K} steps, {nsets} rotating buffer sets (cache-cold); " +
                            ("single stream" if not args.overlap else "graph update of step i on a 2nd stream, overlapping step i+1 (joined inside the timed region)"))
+        # NOT the headline: the same K steps as TWO hipGraphs (even / odd steps) replayed on two streams.  The steps are independent batches
+        # (different buffer sets), so a serving loop would pipeline them: step i's graph-update launch (~4 us of latency on 83 KB) runs under
+        # step i+1's block kernel, and one kernel's ramp / drain under its neighbour.  Same results bit for bit (tools/experiments/
+        # two_stream_pipeline.py); `value` above stays the single-stream figure, where every step waits for the one before it.
+        if K >= 4 and not args.overlap:
+            def capture_half(par):
+                cg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cg):
+                    for i in range(par, K, 2):
+                        step(i)
+                return cg
+            halves = (capture_half(0), capture_half(1))
+            pstreams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+
+            def run_two():
+                for st, cg in zip(pstreams, halves):
+                    with torch.cuda.stream(st):
+                        cg.replay()
+            run_two(); torch.cuda.synchronize(dev)
+            dt2 = sorted(timed(run_two) for _ in range(3))[1]
+            pipelined = {"ms_per_step": round(dt2 / K * 1e3, 6), "value": round(E / (dt2 / K), 1), "unit": "edges/s",
+                         "what": f"the same {K} steps as two hipGraphs (even / odd steps) on two streams: independent batches pipelined; results bit-identical; not the headline"}
+            del halves
     else:
         assert gf_stack.shape[1] == G or world > 1, "one rank: every graph is local"
         cgs = []
@@ -675,6 +707,8 @@ def main():
                        "graphs_per_gpu": G, "edges_whole_job": E_job, "parallelism": f"graph-sharded x{world}" if world > 1 else "single GPU", **extra},
             "roofline": roof, "cpu_baseline": cpu, "batch_ms": batch_ms,
         }
+        if pipelined is not None:
+            line["pipelined_two_streams"] = pipelined
         if secondary is not None:
             line["secondary"] = secondary
         if dense is not None:

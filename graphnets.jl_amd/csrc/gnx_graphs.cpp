@@ -369,6 +369,7 @@ int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n_nodes, 
   if (n_graphs <= 0) return fail(GNX_ERR_NO_GRAPHS, "length(adj_mats) must be > 0 (checks.jl:8)");
   if (!adj || !n_nodes) return fail(GNX_ERR_INVALID_ARG, "adj / n_nodes is NULL");
   if (elem_kind < GNX_ELEM_U8 || elem_kind > GNX_ELEM_F64) return fail(GNX_ERR_INVALID_ARG, "bad elem_kind");
+  BuildTimer bt;
   gnx_graphs* h = new gnx_graphs();
   h->G = n_graphs;
   h->h_node_off.push_back(0);
@@ -417,6 +418,7 @@ int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n_nodes, 
   }
   h->N = h->h_node_off.back();
   h->E = h->h_edge_off.back();
+  bt.lap("dense -> csc");
   int32_t rc = finalize(h);
   if (rc) { gnx_graphs_destroy(h); return rc; }
   *out = h;
