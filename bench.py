@@ -652,6 +652,17 @@ def main():
                         counts="EXECUTED flops of the whole block / whole-step time (the block is several GEMM launches)",
                         executed_flops=ex, algorithmic_tflops_whole_step=round(aflops / step_s / 1e12, 2),
                         hbm_frac_whole_step=round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 4))
+        if traffic is not None and workload == "c2" and args.dims == "readme" and args.c2_scale == 1.0:
+            # `traffic` counts what leaves the L2s (fabric bytes: Infinity-Cache hits included); the split into HBM bytes and cache hits
+            # comes from a residency A/B (no counter separates them): profiles/traffic_breakdown_readme.json
+            bpath = os.path.join(ROOT, "profiles", "traffic_breakdown_readme.json")
+            if os.path.exists(bpath):
+                with open(bpath) as f:
+                    bd = json.load(f)
+                if dom in bd:
+                    roof["traffic_breakdown"] = {"fabric": traffic, "hbm_estimate": bd[dom]["hbm_bytes_per_launch_estimate"],
+                                                 "infinity_cache_hits_estimate": bd[dom]["infinity_cache_hit_bytes_estimate"],
+                                                 "source": "profiles/traffic_breakdown_readme.json"}
         assert roof["frac"] <= 1.0 and roof["frac_whole_step"] <= 1.0, "a roofline fraction above 1 is an accounting error"
         roof.update(kernel=dom, kernel_us=round(kern[dom], 3), event_bracket_overhead_us=round(overhead, 3),
                     event_calibration=calib, algorithmic_bytes=abytes, algorithmic_flops=aflops,

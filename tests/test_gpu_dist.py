@@ -35,7 +35,7 @@ def test_config5_4096_graphs_1m_edges_one_gpu(gn, dims):
     y = U.block_from_params(gn, p)(U.to_nt(gn, g, ef, nf, gf))
     ref, scale = O.block_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
     for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
-        U.assert_close(U.from_jl(got), r, s, name)
+        U.assert_close(U.from_jl(got), r, s, name, log=f"configs[4] C5 4096 graphs 1M edges {dims[0]}=>{dims[1]} (one GPU)")
 
 
 def _sharded_forward(gn, world, rank, shards, colptrs, rowvals, nn, ef, nf, node_off, edge_off, blk, gather):

@@ -34,7 +34,7 @@ def test_config2_er_100k_nodes_1m_edges(gn, dims):
     y = U.block_from_params(gn, p)(U.to_nt(gn, g, ef, nf, gf))
     ref, scale = O.block_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
     for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
-        U.assert_close(U.from_jl(got), r, s, name)
+        U.assert_close(U.from_jl(got), r, s, name, log=f"configs[1] C2 1M edges {dims[0]}=>{dims[1]}")
 
 
 def test_config3_512_graphs_1m_edges_and_graph_independence(gn):
@@ -52,7 +52,7 @@ def test_config3_512_graphs_1m_edges_and_graph_independence(gn):
     y = blk(U.to_nt(gn, g, ef, nf, gf))
     ref, scale = O.block_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
     for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
-        U.assert_close(U.from_jl(got), r, s, name)
+        U.assert_close(U.from_jl(got), r, s, name, log="configs[2] C3 512 graphs 1M edges (10,5,0)=>(3,4,5)")
     yb = [U.from_jl(a) for a in (y.ef, y.nf, y.gf)]
     for i in (0, 17, 511):
         e0, e1, n0, n1 = g.edge_off[i], g.edge_off[i + 1], g.node_off[i], g.node_off[i + 1]
@@ -111,4 +111,4 @@ def test_core_dims_block_full_size(gn, which):
     y = U.block_from_params(gn, p)(U.to_nt(gn, g, ef, nf, gf))
     ref, scale = O.block_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
     for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
-        U.assert_close(U.from_jl(got), r, s, name)
+        U.assert_close(U.from_jl(got), r, s, name, log=f"core dims (128,64,32)=>(128,64,32) on {which.upper()} (matrix-core path)")

@@ -65,13 +65,20 @@ def from_jl(a):
     return None if a is None else a.permute(2, 1, 0).contiguous().cpu().numpy()
 
 
-def assert_close(got, ref, scale, what=""):
+PARITY_LOG = {}  # label -> {tensor: (worst |diff| / (1e-5·S), plain max|diff| / max|ref|)}: written by the full-size tests, dumped by conftest.py
+
+
+def assert_close(got, ref, scale, what="", log=None):
+    """|got - ref| <= 1e-5 · scale elementwise.  `log`: a label under which the two summary figures of this comparison are recorded —
+    the worst ratio to that bound and the plain normwise error max|diff| / max|ref| (no scale involved) — for the session report."""
     if ref is None:
         assert got is None, f"{what}: expected nothing"
         return
     assert got is not None and got.shape == ref.shape, f"{what}: shape {None if got is None else got.shape} vs {ref.shape}"
     err = np.abs(got.astype(np.float64) - ref)
     bad = err > RTOL * scale + 1e-30
+    if log is not None:
+        PARITY_LOG.setdefault(log, {})[what] = (float(np.max(err / (RTOL * scale + 1e-30))), float(np.max(err) / max(float(np.max(np.abs(ref))), 1e-30)))
     assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} outside 1e-5·scale; worst ratio {np.max(err / (scale + 1e-30)):.3e}"
 
 
