@@ -49,6 +49,10 @@ struct BlockArgs {
   // matrix-core path: row statistics [R][rows][2] (mean, inv) of ef / nf when THEY are to be normalised on load (then ln_g / ln_b
   // hold gamma / beta; gf arrives normalised); nullptr <=> the input is used as it is
   const float* ln_stats[3];
+  // fused narrow path, batches of SMALL graphs: workgroups that own whole graphs (k_block_wave<..., PACK>).  packs[p][8] = the wave tiles
+  // of pack p (-1: empty slot), the tiles of a graph adjacent — the graph update then runs inside the block kernel, from LDS
+  const int* packs;
+  int n_packs;
 };
 
 // activation codes = GNX_ACT_* of include/gnx.h (static_assert'ed in gnx_forward.hip)

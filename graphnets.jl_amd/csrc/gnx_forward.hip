@@ -125,6 +125,7 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
   a.tile_off = h->d_tile_off; a.tiles = h->d_tiles;
   a.wtile_off = h->d_wtile_off; a.wtiles = h->d_wtiles; a.n_wtiles = (int)h->n_wtiles();
   a.N = (int)h->N; a.E = (int)h->E; a.G = (int)h->G; a.n_tiles = (int)h->n_tiles();
+  a.packs = h->d_packs; a.n_packs = h->n_packs;
 
   if (ln1 && wide_ln_stats) {
     // matrix-core path with ef / nf normalised on load from their row statistics (gf arrives normalised).  wide_ln_stats[0] == nullptr:

@@ -157,6 +157,32 @@ static int32_t finalize(gnx_graphs* h) {
     // node's edge run can spill into; bounded without walking the graph by min(E, N + 2 * n_etiles)
     h->agg_rows_bound = std::min<int64_t>(h->E, h->N + 2 * h->n_etiles);
   }
+  // graph-aligned packs for the in-kernel graph update (gnx_narrow.hip): every graph <= 8 wave tiles, more than one graph
+  if (h->G > 1 && h->max_wtiles_per_graph >= 1 && h->max_wtiles_per_graph <= 8) {
+    constexpr int CAP = 8;
+    std::vector<int32_t> order((size_t)h->G);
+    for (int64_t g = 0; g < h->G; ++g) order[(size_t)g] = (int32_t)g;
+    auto cnt_of = [&](int32_t g) { return h->h_wtile_off[(size_t)g + 1] - h->h_wtile_off[(size_t)g]; };
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cnt_of(a) > cnt_of(b); });
+    std::vector<int32_t> packs;                 // [n_packs][CAP]
+    std::vector<int32_t> fill;                  // slots used per pack
+    std::vector<std::vector<int32_t>> open(CAP + 1);  // open[r]: packs with r free slots
+    for (int32_t g : order) {
+      const int c = cnt_of(g);
+      if (c <= 0) continue;  // (a graph always has >= 1 node, hence >= 1 wave tile; kept for safety)
+      int r = c;
+      while (r <= CAP && open[(size_t)r].empty()) ++r;  // best fit: the fullest pack that still takes the graph
+      int32_t pk;
+      if (r > CAP) { pk = (int32_t)fill.size(); fill.push_back(0); packs.insert(packs.end(), CAP, -1); }
+      else { pk = open[(size_t)r].back(); open[(size_t)r].pop_back(); }
+      for (int k = 0; k < c; ++k) packs[(size_t)pk * CAP + fill[(size_t)pk] + k] = h->h_wtile_off[(size_t)g] + k;
+      fill[(size_t)pk] += c;
+      if (fill[(size_t)pk] < CAP) open[(size_t)(CAP - fill[(size_t)pk])].push_back(pk);
+    }
+    h->n_packs = (int32_t)fill.size();
+    GNX_HIP(hipMalloc((void**)&h->d_packs, std::max<size_t>(packs.size(), 1) * sizeof(int32_t)));
+    if (!packs.empty()) GNX_HIP(hipMemcpy(h->d_packs, packs.data(), packs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   GNX_HIP(hipMalloc((void**)&h->d_wtile_off, h->h_wtile_off.size() * sizeof(int32_t)));
   GNX_HIP(hipMemcpy(h->d_wtile_off, h->h_wtile_off.data(), h->h_wtile_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   GNX_HIP(hipMalloc((void**)&h->d_wtiles, std::max<size_t>(h->h_wtiles.size(), 1) * sizeof(gnx::Tile)));
@@ -476,6 +502,7 @@ int32_t gnx_graphs_destroy(gnx_graphs* h) {
   (void)hipFree(h->d_etile_off);
   (void)hipFree(h->d_ntile_off);
   (void)hipFree(h->d_wtiles);
+  (void)hipFree(h->d_packs);
   (void)hipFree(h->d_collapse_edge);
   (void)hipFree(h->d_collapse_rev);
   (void)hipFree(h->d_csr_ptr);

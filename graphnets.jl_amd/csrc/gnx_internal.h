@@ -55,6 +55,10 @@ struct gnx_graphs {
   mutable int32_t* d_node_agg_chunk = nullptr;   // [N] its first chunk
   mutable int64_t n_agg_rows = 0;
   gnx::Tile* d_wtiles = nullptr;  // [n_wtiles]
+  // graph-aligned packs of wave tiles (batches whose graphs all have <= 8 wave tiles): [n_packs][8] tile ids, -1 = empty slot; a graph's
+  // tiles sit in adjacent slots of ONE pack (best-fit decreasing over the graphs).  n_packs = 0: not applicable.
+  int32_t* d_packs = nullptr;
+  int32_t n_packs = 0;
   int32_t wtile_e_cap = 0;
   int32_t max_wtiles_per_graph = 0;
   int32_t tile_e_cap = 0, tile_n_cap = 0;

@@ -68,8 +68,30 @@ static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R,
   return GNX_OK;
 }
 
+// Batches of small graphs (every graph <= 8 wave tiles: the handle has a pack table): ONE launch — 512-thread workgroups that own whole
+// graphs run the graph update themselves (k_block_wave<..., PACK>).  Only for the whole block in one call (phase 3): a caller that
+// splits off the graph update, or a narrow GNCore that runs it inside its FeedForward launch, reads the partial rows of the two-launch form.
+// GNX_NO_PACK=1 (read per call: tests compare the two forms) keeps the two launches.
+template <int DE, int DN, int DG, int OE, int ON, int EPT>
+static bool launch_wave_pack(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase, int32_t* rc) {
+  constexpr int C = OE + ON;
+  if constexpr (EPT != 2 || C == 0) return false;
+  else {
+    if (h->G <= 1 || h->n_packs <= 0 || !a.packs || phase != 3 || a.og <= 0 || getenv("GNX_NO_PACK")) return false;
+    ProfScope ps("k_block_wave", s);
+    hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, false, false, true>), dim3((unsigned)h->n_packs, (unsigned)R), dim3(kPackThreads), 0, s, a, 0);
+    const hipError_t e = hipGetLastError();
+    *rc = e == hipSuccess ? GNX_OK : hip_fail(e, "k_block_wave<PACK>");
+    return true;
+  }
+}
+
 template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false>
 static int32_t launch_wave_t(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
+  if constexpr (!LN) {
+    int32_t rc = GNX_OK;
+    if (launch_wave_pack<DE, DN, DG, OE, ON, EPT>(h, a, R, s, phase, &rc)) return rc;
+  }
   return h->G == 1 ? launch_wave_g<DE, DN, DG, OE, ON, EPT, LN, true>(h, a, R, s, phase) : launch_wave_g<DE, DN, DG, OE, ON, EPT, LN, false>(h, a, R, s, phase);
 }
 

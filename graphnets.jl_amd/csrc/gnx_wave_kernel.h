@@ -426,6 +426,54 @@ __device__ __forceinline__ void graph_update_rows(const BlockArgs& a, const floa
   }
 }
 
+// The graph update of ONE graph by ONE wavefront when the column sums are already in a register (lane c < C holds column c): the tail
+// of graph_update_rows — same input vector [sums ; gf (normalised if asked)], same weights, same order of the FMAs, hence the same bits.
+// Two halves so that the weight loads can be in flight under the workgroup barrier in front of the sums: graph_wave_prefetch (lane
+// j < og: bias + its first KW weights, clamped unconditional loads), then graph_update_wave.  s_x: >= C + dg floats of wave-private LDS.
+constexpr int kGraphWavePrefetch = 8;  // (24 took the README-dims kernel from 58 to 93 registers: 5 instead of 8 waves per SIMD, 23.1 -> 28.8 us/step)
+struct GraphWaveRegs { float bias; float w[kGraphWavePrefetch]; };
+template <int C>
+__device__ __forceinline__ void graph_wave_prefetch(const BlockArgs& a, int lane, GraphWaveRegs& gr) {
+  const int K = C + a.dg, og = a.og;
+  const int j = lane < og ? lane : og - 1;
+  gr.bias = a.bg ? a.bg[j] : 0.f;
+#pragma unroll
+  for (int u = 0; u < kGraphWavePrefetch; ++u) gr.w[u] = a.Wg[(size_t)(u < K ? u : K - 1) * og + j];
+}
+template <int C>
+__device__ __forceinline__ void graph_update_wave(const BlockArgs& a, float xsum, int g, size_t r, int lane, float* s_x, const GraphWaveRegs& gr) {
+  const int K = C + a.dg, og = a.og;
+  if (lane < C) s_x[lane] = xsum;
+  const float* gp = a.dg > 0 ? a.gf + (r * (size_t)a.G + g) * a.dg : nullptr;
+  if (a.ln_g[2] && a.dg > 0) {
+    float mu = 0.f;
+    for (int k = 0; k < a.dg; ++k) mu += gp[k];
+    mu /= (float)a.dg;
+    float var = 0.f;
+    for (int k = 0; k < a.dg; ++k) { const float c = gp[k] - mu; var = fmaf(c, c, var); }
+    var /= (float)a.dg;
+    const float rstd = a.ln_mode == 0 ? 1.f / (sqrtf(var) + a.ln_eps) : 1.f / sqrtf(var + a.ln_eps);
+    for (int k = lane; k < a.dg; k += 64) s_x[C + k] = fmaf(a.ln_g[2][k], (gp[k] - mu) * rstd, a.ln_b[2][k]);
+  } else {
+    for (int k = lane; k < a.dg; k += 64) s_x[C + k] = gp[k];
+  }
+  __builtin_amdgcn_wave_barrier();
+  float* out = a.gf_out + (r * (size_t)a.G + g) * og;
+  if (lane < og) {  // FMAs in the order k = 0, 1, 2, ... (the order of graph_update_rows)
+    float y = gr.bias;
+#pragma unroll
+    for (int u = 0; u < kGraphWavePrefetch; ++u)
+      if (u < K) y = fmaf(gr.w[u], s_x[u], y);
+    for (int k = kGraphWavePrefetch; k < K; ++k) y = fmaf(a.Wg[(size_t)k * og + lane], s_x[k], y);
+    out[lane] = act_apply(y, a.act_g);
+  }
+  for (int j = lane + 64; j < og; j += 64) {  // (graph functions wider than a wavefront: plain loop)
+    float y = a.bg ? a.bg[j] : 0.f;
+    for (int k = 0; k < K; ++k) y = fmaf(a.Wg[(size_t)k * og + j], s_x[k], y);
+    out[j] = act_apply(y, a.act_g);
+  }
+}
+
 // LDS floats graph_update_rows needs with nthr threads
 __host__ __device__ constexpr int graph_update_lds_floats(int C, int dg, int og, int nthr) {
   return (nthr / 16) * C + (C + dg + 4) + (C + dg + 1) * og + 8;
@@ -462,38 +510,58 @@ static __device__ unsigned long long* g_wave_dbg = nullptr;  // [n_wtiles][8], s
 #else
 #define GNX_WSTAMP(i) do { } while (0)
 #endif
-template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_SGPRS))) void k_block_wave(BlockArgs a, int n_rows) {
+// PACK: batches of SMALL graphs (every graph <= 8 wave tiles; BlockArgs::packs).  A 512-thread workgroup = 8 wave tiles that hold WHOLE
+// graphs: after the tiles one barrier, then the wave of a graph's first tile adds the graph's partial rows from LDS — in the association
+// of graph_update_rows for <= 8 rows, ((a0+a1)+(a2+a3))+((a4+a5)+(a6+a7)) — and runs the graph function: no partial rows in HBM, no
+// second launch, bit-identical gf'.
+constexpr int kPackThreads = 512;
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false, bool PACK = false>
+__global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_SGPRS))) void k_block_wave(BlockArgs a, int n_rows) {
+  static_assert(!(PACK && ONEG), "packs are for batches of several graphs");
   constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1, DG1 = DG > 0 ? DG : 1;
   constexpr int TEW = 64 * EPT;
   constexpr int C = OE + ON, C1 = C > 0 ? C : 1;
-  constexpr int WAVES = kThreads / 64;
+  constexpr int WAVES = (PACK ? kPackThreads : kThreads) / 64;
   constexpr int WSL = wave_slice_floats(OE, EPT);
   __shared__ __attribute__((aligned(16))) float s_mem[WAVES * WSL];  // one slice per wave
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wt = __builtin_amdgcn_readfirstlane(xcd_tile(blockIdx.x, gridDim.x) * WAVES + wv);
+  typedef const int __attribute__((address_space(4))) * cintp;
+  int wt;
+  if constexpr (PACK) {  // the wave's tile from the pack table (-1: an empty slot of the pack)
+    const cintp pk = reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.packs)) + (size_t)xcd_tile(blockIdx.x, gridDim.x) * WAVES;
+    wt = pk[wv];
+  } else {
+    wt = __builtin_amdgcn_readfirstlane(xcd_tile(blockIdx.x, gridDim.x) * WAVES + wv);
+  }
   // ONEG (one graph): the four waves of a workgroup all belong to it, so their graph-update partial sums are added in the
   // workgroup (one barrier at the very end) and the graph update reads a quarter of the rows.  Several graphs: a workgroup may
   // straddle two graphs, every wave stores its own row and the kernel has no workgroup barrier at all.  (A template
   // parameter, not a run-time branch: the mere presence of the barrier path cost the multi-graph case 4 %.)
-  const bool active = wt < a.n_wtiles;  // wave-uniform
+  const bool active = PACK ? wt >= 0 : wt < a.n_wtiles;  // wave-uniform
+  int tile_g = -1, tile_cnt = 0;  // PACK: the tile's graph and that graph's number of wave tiles
+  bool owner = false;             // PACK: this wave's tile is the first of its graph (the pack keeps a graph's tiles adjacent): it runs the graph update
 #ifdef GNX_WAVE_STAMPS_BUILD
   unsigned long long wst_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   GNX_WSTAMP(0);
-  if constexpr (!ONEG) { if (!active) return; }
+  if constexpr (!ONEG && !PACK) { if (!active) return; }
   float mine = 0.f;  // lane c < C: this wave's total of graph-update column c
   do {
-  if constexpr (ONEG) { if (!active) break; }
+  if constexpr (ONEG || PACK) { if (!active) break; }
   float* s_out = s_mem + wv * WSL;                                        // ef' of the wave's tile
   float* s_pd = s_out + (TEW * OE + 4);                                   // per node: bias' + We[:, dst-seg]*nf[n]
   unsigned char* s_dst = reinterpret_cast<unsigned char*>(s_pd + (64 * OE + 4));  // tile-local destination of each edge
 
-  typedef const int __attribute__((address_space(4))) * cintp;
   const cintp tw = reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.wtiles)) + (size_t)wt * (sizeof(Tile) / sizeof(int));
   const int n0 = tw[0], n1 = tw[1], e0 = tw[2], e1 = tw[3], g = tw[4];  // s_load_dwordx8
+  if constexpr (PACK) {
+    tile_g = g; tile_cnt = tw[7];
+    const cintp pk = reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.packs)) + (size_t)xcd_tile(blockIdx.x, gridDim.x) * WAVES;
+    const int wprev = wv > 0 ? pk[wv > 0 ? wv - 1 : 0] : -1;  // (a graph's first tile never follows an empty slot: slots fill from the left)
+    owner = wprev < 0 || (reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.wtiles)) + (size_t)wprev * (sizeof(Tile) / sizeof(int)))[4] != g;
+  }
   const int nn = n1 - n0, ne = e1 - e0;
   GNX_WSTAMP(1);  // (the stamp's own s_waitcnt lgkmcnt(0) makes this "tile record arrived")
 
@@ -758,7 +826,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_S
       const size_t r = blockIdx.y;
       constexpr int CP = (C + 3) / 4 * 4;
       float* __restrict__ pbase = a.partials + r * (size_t)n_rows * CP;
-      if constexpr (ONEG) {
+      if constexpr (PACK) {
+        __shared__ float s_rows[WAVES][C1];
+        if (lane < C) s_rows[wv][lane] = active ? mine : 0.f;
+        GraphWaveRegs gr;
+        if (active && owner) graph_wave_prefetch<C>(a, lane, gr);  // in flight under the barrier
+        __syncthreads();
+        if (active && owner) {
+          float rr[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) rr[k] = (k < tile_cnt && wv + k < WAVES && lane < C) ? 0.f + s_rows[(wv + k) < WAVES ? wv + k : 0][lane < C ? lane : 0] : 0.f;
+          const float xs = ((rr[0] + rr[1]) + (rr[2] + rr[3])) + ((rr[4] + rr[5]) + (rr[6] + rr[7]));
+          graph_update_wave<C>(a, xs, tile_g, r, lane, s_mem + wv * WSL, gr);
+        }
+      } else if constexpr (ONEG) {
         __shared__ float s_blk[WAVES][C1];
         if (lane < C) s_blk[wv][lane] = mine;
         __syncthreads();

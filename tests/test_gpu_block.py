@@ -243,6 +243,41 @@ def test_heterogeneous_batch_64_graphs(gn, flags):
     _check_block(gn, p, g, _csc_of(g), ef, nf, gf, flags)
 
 
+@pytest.mark.parametrize("dims", [((10, 5, 0), (3, 4, 5)), ((10, 5, 3), (3, 4, 5)), ((4, 3, 2), (3, 4, 5))])
+def test_small_graph_batches_run_the_graph_update_inside_the_block_kernel(gn, dims, monkeypatch):
+    """Batches whose graphs all have <= 8 wave tiles (here 700 graphs of 1..300 nodes, some without a single edge): workgroups own whole
+    graphs and run the graph update themselves (k_block_wave<..., PACK>) — ONE launch.  Every output is bit-identical to the two-launch
+    form (GNX_NO_PACK=1: partial rows in HBM + k_graph_t) and within 1e-5*S of the oracle."""
+    rng = np.random.default_rng(77)
+    sizes = np.concatenate([rng.integers(1, 301, 690), [1, 1, 2, 300, 300, 64, 65, 128, 129, 3]])
+    colptrs, rowvals = [], []
+    for i, n in enumerate(sizes):
+        n = int(n)
+        e = 0 if i % 50 == 0 else min(n * n, int(rng.integers(0, 3 * n + 1)))
+        cp, rv = U.er_csc(rng, n, e) if e else (np.zeros(n + 1, np.int64), np.zeros(0, np.int64))
+        colptrs.append(cp); rowvals.append(rv)
+    g = gn.GNGraphBatch.from_csc(colptrs, rowvals, [int(n) for n in sizes])
+    p = O.make_block_params(rng, *dims)
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims[0])
+    blk = U.block_from_params(gn, p)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    gn.profile_reset(); gn.profile_enable(True)
+    y1 = blk(x)
+    gn.profile_enable(False)
+    kernels = set(gn.profile_read()); gn.profile_reset()
+    assert "k_block_wave" in kernels and "k_graph_t" not in kernels, kernels  # one launch
+    monkeypatch.setenv("GNX_NO_PACK", "1")
+    gn.profile_enable(True)
+    y2 = blk(x)
+    gn.profile_enable(False)
+    assert "k_graph_t" in set(gn.profile_read()); gn.profile_reset()  # the two-launch form
+    for u, v in ((y1.ef, y2.ef), (y1.nf, y2.nf), (y1.gf, y2.gf)):
+        assert np.array_equal(u.cpu().numpy(), v.cpu().numpy())
+    ref, scale = O.block_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    for name, got, r_, s_ in zip(("ef", "nf", "gf"), (y1.ef, y1.nf, y1.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r_, s_, name)
+
+
 def test_results_are_bitwise_reproducible(gn):
     """Atomic-free, fixed-order reductions: two runs give identical bits."""
     rng = np.random.default_rng(15)
