@@ -22,6 +22,9 @@ struct Tile {
 };
 
 // Everything a block-forward kernel needs, passed by value (lives in SGPRs / kernarg segment).
+// destination rows of the projected edge update staged in LDS per 128-edge tile (k_rows_gemm<..., NL = 3>): 3 workgroups x (38.7 + 28 x 0.5) KB fit a CU's 160 KB
+constexpr int kPdRowsCap = 28;
+
 struct BlockArgs {
   int de, dn, dg;  // effective input widths (0 <=> `nothing`)
   int oe, on, og;

@@ -258,6 +258,10 @@ static int32_t build_wide_tables(const gnx_graphs* h) {
         }
       }
       h->n_agg_rows = row0[n_chunks];
+      int64_t wide_span = 0;
+      for (const gnx::Tile& t : h->h_etiles)
+        if (t.e1 > t.e0 && dst[(size_t)t.e1 - 1] - dst[(size_t)t.e0] + 1 > gnx::kPdRowsCap) ++wide_span;
+      h->n_etiles_wide_span = wide_span;
       if (h->n_agg_rows > h->agg_rows_bound) return fail(GNX_ERR_INVALID_ARG, "wide tables: more aggregation rows than the bound workspaces are sized with");
       std::vector<int32_t> agg_row((size_t)h->N, -1), parts((size_t)h->N, 0), first_chunk((size_t)h->N, 0);
       // chunk of an edge: tiles are 128-edge chunks of each graph's edge range, in graph order

@@ -54,6 +54,9 @@ struct gnx_graphs {
   mutable int32_t* d_node_agg_parts = nullptr;   // [N] number of chunks the node's in-edges run through
   mutable int32_t* d_node_agg_chunk = nullptr;   // [N] its first chunk
   mutable int64_t n_agg_rows = 0;
+  // edge tiles whose destinations span more than gnx::kPdRowsCap consecutive nodes (the edge GEMM stages a tile's destination
+  // projections in LDS when they fit: launch_block_wide picks that kernel when nearly every tile qualifies)
+  mutable int64_t n_etiles_wide_span = 0;
   gnx::Tile* d_wtiles = nullptr;  // [n_wtiles]
   // graph-aligned packs of wave tiles (batches whose graphs all have <= 8 wave tiles): [n_packs][8] tile ids, -1 = empty slot; a graph's
   // tiles sit in adjacent slots of ONE pack (best-fit decreasing over the graphs).  n_packs = 0: not applicable.

@@ -100,6 +100,7 @@ struct WideArgs {
   int ln_width;                // (set by launch_gemm)
   WSeg pk[3];                  // mode 5: the packed segments (modes 0-2), their W rows consecutive from seg[0].w_row0
   int npk;
+  int pd_lds;                  // gathered addends: every tile's destination rows fit the LDS table of the NL = 3 kernel (set by launch_block_wide from the handle's tile statistics)
   int stagger;                 // start delay per residency slot (units of 64*127 clocks), 0 = none (set by launch_gemm)
   unsigned long long* stamps;  // diagnostic builds only (GNX_WIDE_STAMPS): [tile][8] shader-clock stamps of wave 0
 };
@@ -140,6 +141,15 @@ __device__ __forceinline__ float4 ld4(const float* ubase, unsigned off) {
 __device__ __forceinline__ float ld1(const float* ubase, unsigned off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + (off << 2));
 }
+// The same load kept out of the compiler's s_waitcnt bookkeeping (pass 1's source rows of the NL = 3 epilogue): with loads and
+// stores pending on one counter the compiler waits for ALL of them at the load's first use — every row store of pass 0 acknowledged
+// by memory — where the hardware retires the counter in issue order and a counted wait (all but the stores issued since) is enough.
+// The destination counts as written at the statement, so it must not be read, copied or spilled before asm_wait_rows (checked in
+// the .s: no v_mov / scratch access to these registers in between).  s_nop 4: SALU-written base -> VMEM read of it.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ld4_untracked(v4f& dst, const float* ubase, unsigned off) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off << 2), "s"(ubase) : "memory");
+}
 __device__ __forceinline__ void st4(float* ubase, unsigned off, float4 v) {
   *reinterpret_cast<float4*>(reinterpret_cast<char*>(ubase) + (off << 2)) = v;
 }
@@ -165,7 +175,13 @@ struct WaveLayout {
   static constexpr int WPE = WAVES == 8 ? 4 : (BN == 64 ? GNX_GEMM_WPE64 : GNX_GEMM_WPE);  // waves per SIMD asked of the register allocator
 };
 
-// NL = number of epilogue operand streams read from global memory (EPI_* below): 0, 1 or 2 float4 per output quad.  The VEC4
+// NL = number of epilogue operand streams read from global memory (EPI_* below): 0, 1 or 2 float4 per output quad; 3: the gathered
+// addends of the node-projection form with the DESTINATION rows staged in LDS (edges are dst-sorted: a tile's destinations are a
+// short run of consecutive rows of the table, ~14 on the 1M-edge graph, fetched ONCE per tile by LDS-DMA in the prologue instead of
+// once per edge) and the SOURCE rows of a whole 64-row pass requested at once — pass 0's behind the last chunk's loads into the
+// chunk staging registers, pass 1's into the accumulator registers pass 0 has just handed to LDS — so the epilogue waits for one
+// covered round trip instead of four serial ones (two streams, two groups of two row quads in flight: by the stamps 19.5 k of a
+// tile's 82 k clocks).  The VEC4
 // epilogue requests them a GROUP of row quads ahead (straight-line code: the operands of group g+1 are in flight while group g
 // is finished and stored).  Written as one load -> use -> store per quad, every quad paid a full memory round trip (vmcnt
 // counts stores too: the wait for the quad's operands also waited for the previous quad's store) — 16 serial round trips per
@@ -199,6 +215,9 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
   __shared__ int s_ia[BM], s_ib[BM];  // gather indices, or colptr range for the segment-sum mode
   __shared__ int s_ic[FULL ? BM : 1];  // mode 4: row of the node's SECOND partial sum (-1: none)
   __shared__ __attribute__((aligned(16))) float s_bias[BN];
+  constexpr int PD_RPI = 256 / BN;  // destination rows per LDS-DMA piece (one wave instruction writes 64 x 16 B = 1 KiB of LDS: lane-linear)
+  constexpr int PD_ROWS = (kPdRowsCap + PD_RPI - 1) / PD_RPI * PD_RPI;
+  __shared__ __attribute__((aligned(16))) float s_pd[NL == 3 ? PD_ROWS * BN : 4];  // [row - first destination of the tile][BN]
   constexpr bool LNOK = VEC4 && LD <= 1;  // LayerNorm on load: the quad loaders only
   __shared__ float2 s_ln[LNOK ? BM : 1];                               // (mean, inv) of the tile's rows
   __shared__ __attribute__((aligned(16))) float4 s_lng[LNOK ? 64 : 1];  // gamma, beta of the normalised segment (width <= 256)
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
   // ONE register array serves the K loop's chunk staging (A quads, then B quads) and, from the last chunk on, the epilogue's
   // first operand group: declared separately, the compiler keeps both sets alive through the loop and spills
   constexpr int NC4_ = (64 * BN / 4) / WT, GRP_ = NC4_ > GNX_GEMM_GRP ? GNX_GEMM_GRP : NC4_;
-  constexpr int NSTG = NA4 + NB4 > 4 * GRP_ ? NA4 + NB4 : 4 * GRP_;
+  constexpr int NSTG = NL == 3 ? (NA4 + NB4 > NC4_ ? NA4 + NB4 : NC4_) : (NA4 + NB4 > 4 * GRP_ ? NA4 + NB4 : 4 * GRP_);
   float4 stg[NSTG];  // K loop: A quads, B quads; epilogue: two operand buffers of 2 GRP quads each
   float4 rs[FULL ? NA4 : 1];  // mode 4: second partial-sum rows of the chunk
 #define ra(i) stg[i]
@@ -472,6 +491,23 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
     s_bias[tid] = b;
   }
   __syncthreads();
+  int pd_first = 0;
+  if (NL == 3) {
+    // the tile's destination rows, first to last (the host launches this form only when every edge tile's run fits the table):
+    // no register, no wait — the pieces are in LDS once this wave's vmcnt has drained and a barrier has been passed; the K loop's
+    // first __syncthreads() does both (a launch without K chunks waits explicitly below)
+    pd_first = __builtin_amdgcn_readfirstlane(s_ib[0]);
+    const int pd_last = min(__builtin_amdgcn_readfirstlane(s_ib[rows - 1]), pd_first + kPdRowsCap - 1);
+    const float* pdt = a.gadd_b + r * a.gadd_rep_stride;
+    const int span = pd_last - pd_first + 1;
+    const int prow = lane / (BN / 4), pq = lane % (BN / 4);
+    const unsigned pcol = (unsigned)min(n0 + 4 * pq, a.OUT - 4);
+    for (int p = wv; p * PD_RPI < span; p += L::WAVES) {
+      const int row = min(pd_first + p * PD_RPI + prow, pd_last);
+      const float* g = pdt + ((unsigned)row * (unsigned)a.OUT + pcol);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(s_pd + p * 256), 16, 0, 0);
+    }
+  }
 
   f32x16 acc[L::TM][L::TN];
 #pragma unroll
@@ -536,7 +572,7 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
   const float* xb = nullptr;
   const float* yb = nullptr;
   int xk = 0, yk = 0;  // row of the operand: 0 the output row itself, 1 idx_a[row], 2 idx_b[row]
-  if (NL > 0) {
+  if (NL == 1 || NL == 2) {
     const size_t own = r * a.out_rep_stride + (size_t)row0 * a.OUT;  // operands with the layout of `out`: the tile's first row
     switch (a.epi) {
       case EPI_GADD: xb = a.gadd_a + r * a.gadd_rep_stride; yb = a.gadd_b + r * a.gadd_rep_stride; xk = 1; yk = 2; break;
@@ -552,6 +588,24 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
     const int last = a.OUT - 1;
     return make_float4(ld1(ub, rowoff + (unsigned)min(ncol, last)), ld1(ub, rowoff + (unsigned)min(ncol + 1, last)),
                        ld1(ub, rowoff + (unsigned)min(ncol + 2, last)), ld1(ub, rowoff + (unsigned)min(ncol + 3, last)));
+  };
+  // NL = 3: the source rows of a whole pass, into `buf` (pass 0: the staging registers; pass 1: e1)
+  v4f e1[NL == 3 ? NC4 : 1];
+  auto issue_src_rows0 = [&]() {
+    const float* pst = a.gadd_a + r * a.gadd_rep_stride;
+#pragma unroll
+    for (int u = 0; u < NC4; ++u) {
+      const int row = min(lr0 + NG * u, rows - 1);
+      stg[u] = ldq(pst, (unsigned)s_ia[row] * (unsigned)a.OUT);
+    }
+  };
+  auto issue_src_rows1 = [&]() {
+    const float* pst = a.gadd_a + r * a.gadd_rep_stride;
+#pragma unroll
+    for (int u = 0; u < NC4; ++u) {
+      const int row = min(64 + lr0 + NG * u, rows - 1);
+      ld4_untracked(e1[u], pst, (unsigned)s_ia[row] * (unsigned)a.OUT + (unsigned)(col_ok ? ncol : 0));
+    }
   };
   auto issue_operands = [&](int pass, int g, int buf) {  // unconditional loads of clamped rows / columns: nothing to branch around
 #pragma unroll
@@ -595,9 +649,13 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
     }
   };
   if (si < a.nseg) { if (!early_first) load_chunk(si, kc); }
-  else if (NL > 0) {  // (no K at all: bias / operands only)
+  else if (NL == 1 || NL == 2) {  // (no K at all: bias / operands only)
     issue_operands(0, 0, 0);
     if (NTG > 1) issue_operands(NGRP > 1 ? 0 : 1, NGRP > 1 ? 1 : 0, 1);
+  } else if (NL == 3) {
+    __syncthreads();  // the destination rows' LDS-DMA (no K loop barrier drains it; a wait the compiler can see — behind an inline-asm wait it
+                      // still counts the DMA as pending and puts vmcnt(0) in front of every read of s_pd, which waits for the operand loads too)
+    issue_src_rows0();
   }
   while (si < a.nseg) {
 #ifdef GNX_WIDE_STAMPS_BUILD
@@ -618,9 +676,11 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
       while (si < a.nseg && a.seg[si].width == 0) ++si;
     }
     if (si < a.nseg) load_chunk(si, kc);
-    else if (NL > 0) {  // last chunk: the staging registers are free — the epilogue's first two operand groups take them
+    else if (NL == 1 || NL == 2) {  // last chunk: the staging registers are free — the epilogue's first two operand groups take them
       issue_operands(0, 0, 0);
       if (NTG > 1) issue_operands(NGRP > 1 ? 0 : 1, NGRP > 1 ? 1 : 0, 1);
+    } else if (NL == 3) {
+      issue_src_rows0();
     }
 #ifdef GNX_WIDE_STAMPS_BUILD
     t_issue += clock64() - tB;
@@ -668,6 +728,15 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
       }
     }
     lds_barrier();
+    if (NL == 3 && pass == 0) {
+      // pass 0's source rows (requested in front of the last chunk's matrix-core work) are USED here, in front of pass 1's requests:
+      // the wait the compiler places is then vmcnt(0) with nothing younger in flight; placed at their first real use, behind the
+      // requests below, it is vmcnt(0) too (their registers were written on both sides of a branch inside the K loop), i.e. a wait
+      // for the rows just requested
+#pragma unroll
+      for (int u = 0; u < NC4; ++u) asm volatile("" : "+v"(stg[u].x), "+v"(stg[u].y), "+v"(stg[u].z), "+v"(stg[u].w));
+      issue_src_rows1();  // into the registers of the accumulators just handed to LDS
+    }
 #ifdef GNX_WIDE_STAMPS_BUILD
     const unsigned long long te1 = clock64();
     t_estage += te1 - te0;
@@ -690,13 +759,27 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
             v[u].x += p.x + d.x; v[u].y += p.y + d.y; v[u].z += p.z + d.z; v[u].w += p.w + d.w;
           }
         }
+        if (NL == 3) {  // (same association as the two-stream form: (acc + b) + (p + d) — bit-identical outputs)
+          float4 d[GRP];
+#pragma unroll
+          for (int u = 0; u < GRP; ++u) {
+            const int row = min(64 * pass + lr0 + NG * (g * GRP + u), rows - 1);
+            d[u] = *reinterpret_cast<const float4*>(s_pd + min(s_ib[row] - pd_first, PD_ROWS - 1) * BN + 4 * q4);  // (the clamp never acts on a launch the host allows)
+          }
+#pragma unroll
+          for (int u = 0; u < GRP; ++u) {
+            float4 p = stg[g * GRP + u];
+            if (pass == 1) { const v4f q = e1[g * GRP + u]; p = make_float4(q.x, q.y, q.z, q.w); }
+            v[u].x += p.x + d[u].x; v[u].y += p.y + d[u].y; v[u].z += p.z + d[u].z; v[u].w += p.w + d[u].w;
+          }
+        }
         if (TRANS) {
           act_apply_n<4 * GRP>(reinterpret_cast<float*>(v), a.act);
         } else if (a.act == 1) {
 #pragma unroll
           for (int u = 0; u < GRP; ++u) { v[u].x = fmaxf(v[u].x, 0.f); v[u].y = fmaxf(v[u].y, 0.f); v[u].z = fmaxf(v[u].z, 0.f); v[u].w = fmaxf(v[u].w, 0.f); }
         }
-        if (NL > 0 && (a.epi == EPI_GMUL || a.epi == EPI_GMUL_ADD)) {
+        if ((NL == 1 || NL == 2) && (a.epi == EPI_GMUL || a.epi == EPI_GMUL_ADD)) {
 #pragma unroll
           for (int u = 0; u < GRP; ++u) {
             const float4 x = ex(cur, u);
@@ -711,7 +794,7 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
           if (ok) { cs4.x += v[u].x; cs4.y += v[u].y; cs4.z += v[u].z; cs4.w += v[u].w; }  // column sums BEFORE the residual adds
           if (VEC4 && a.agg_out) *reinterpret_cast<float4*>(sC + lr * LDC + 4 * q4) = v[u];       // the finished value, for the per-destination sums below
         }
-        if (NL > 0 && (a.epi == EPI_ADD1 || a.epi == EPI_ADD12)) {
+        if ((NL == 1 || NL == 2) && (a.epi == EPI_ADD1 || a.epi == EPI_ADD12)) {
 #pragma unroll
           for (int u = 0; u < GRP; ++u) { const float4 x = ex(cur, u); v[u].x += x.x; v[u].y += x.y; v[u].z += x.z; v[u].w += x.w; }
         }
@@ -719,7 +802,7 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
 #pragma unroll
           for (int u = 0; u < GRP; ++u) { const float4 y = ey(cur, u); v[u].x += y.x; v[u].y += y.y; v[u].z += y.z; v[u].w += y.w; }
         }
-        if (NL > 0 && tg + 2 < NTG) issue_operands((tg + 2) / NGRP, (tg + 2) % NGRP, cur);  // this buffer is consumed: refill it, BEFORE the stores
+        if ((NL == 1 || NL == 2) && tg + 2 < NTG) issue_operands((tg + 2) / NGRP, (tg + 2) % NGRP, cur);  // this buffer is consumed: refill it, BEFORE the stores
 #pragma unroll
         for (int u = 0; u < GRP; ++u) {
           const int row = 64 * pass + lr0 + NG * (g * GRP + u);
@@ -736,6 +819,22 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
           }
         }
       }
+    }
+    if (NL == 3 && pass == 0) {
+      // pass 1's source rows have had this pass's group work to arrive: wait for all but the row stores issued since — on a full
+      // tile every wave has issued exactly NC4 of them (a wave of a partial tile may have skipped some: it waits for everything)
+      // ONE statement naming every destination (two statements on the sides of a branch make the compiler copy the registers into
+      // each statement's operands in front of the branch, i.e. read them before the wait); the branch is inside the string
+      static_assert(NC4 == 8 || NC4 == 4 || NC4 == 2, "source-row registers named in one statement");
+      const int full = __builtin_amdgcn_readfirstlane((rows == BM && n0 + BN <= a.OUT) ? 1 : 0);  // wave-uniform
+#define GNX_WAIT_ROWS "s_cmp_eq_u32 %[f], 0\n\ts_cbranch_scc1 1f\n\ts_waitcnt vmcnt(%[n])\n\ts_branch 2f\n1:\n\ts_waitcnt vmcnt(0)\n2:"
+      if constexpr (NC4 == 8)
+        asm volatile(GNX_WAIT_ROWS : "+v"(e1[0]), "+v"(e1[1]), "+v"(e1[2]), "+v"(e1[3]), "+v"(e1[4]), "+v"(e1[5]), "+v"(e1[6]), "+v"(e1[7]) : [f] "s"(full), [n] "i"(NC4) : "memory", "scc");
+      else if constexpr (NC4 == 4)
+        asm volatile(GNX_WAIT_ROWS : "+v"(e1[0]), "+v"(e1[1]), "+v"(e1[2]), "+v"(e1[3]) : [f] "s"(full), [n] "i"(NC4) : "memory", "scc");
+      else
+        asm volatile(GNX_WAIT_ROWS : "+v"(e1[0]), "+v"(e1[1]) : [f] "s"(full), [n] "i"(NC4) : "memory", "scc");
+#undef GNX_WAIT_ROWS
     }
 #ifdef GNX_WIDE_STAMPS_BUILD
     const unsigned long long te2 = clock64();
@@ -772,11 +871,13 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
       *reinterpret_cast<float4*>(s_cs + grp * BN + 4 * c4) = cs4;
     }
     lds_barrier();
-    if (tid < BN && n0 + tid < a.OUT) {
+    int tc = tid;  // (re-derived: an LDS address kept since the prologue is parked in scratch memory, and its reload here waits for every store of the tile)
+    asm volatile("" : "+v"(tc));
+    if (tc < BN && n0 + tc < a.OUT) {
       float sum = 0.f;
 #pragma unroll
-      for (int w = 0; w < NG; ++w) sum += s_cs[w * BN + tid];
-      a.colsum[r * a.colsum_rep_stride + (size_t)tile_id * a.OUT + n0 + tid] = sum;
+      for (int w = 0; w < NG; ++w) sum += s_cs[w * BN + tc];
+      a.colsum[r * a.colsum_rep_stride + (size_t)tile_id * a.OUT + n0 + tc] = sum;
     }
   }
 #ifdef GNX_WIDE_STAMPS_BUILD
@@ -1094,7 +1195,11 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
   if (w.gadd_a && (a1 || w.gmul)) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: gathered addends cannot be combined with residual / gmul operands");
   if (w.gmul && a2) return fail(GNX_ERR_INVALID_ARG, "k_rows_gemm: gmul takes at most one residual operand");
   wa.epi = w.gadd_a ? EPI_GADD : (w.gmul ? (a1 ? EPI_GMUL_ADD : EPI_GMUL) : (a2 ? EPI_ADD12 : (a1 ? EPI_ADD1 : EPI_NONE)));
-  const int nl = wa.epi == EPI_NONE ? 0 : ((wa.epi == EPI_ADD1 || wa.epi == EPI_GMUL) ? 1 : 2);
+  int nl = wa.epi == EPI_NONE ? 0 : ((wa.epi == EPI_ADD1 || wa.epi == EPI_GMUL) ? 1 : 2);
+  // gathered addends with quad outputs and the lean loader, on a batch whose edge tiles' destinations are short runs of rows: the
+  // destination rows go through LDS (NL = 3).  GNX_GEMM_PD_LDS=0 keeps both tables as operand streams (NL = 2) for A/B runs.
+  static const bool pd_lds_env = !(getenv("GNX_GEMM_PD_LDS") && atoi(getenv("GNX_GEMM_PD_LDS")) == 0);
+  if (wa.epi == EPI_GADD && vec4 && ld == 0 && w.pd_lds && pd_lds_env && w.OUT >= 4) nl = 3; else wa.pd_lds = 0;
   static const int stagger_env = getenv("GNX_GEMM_STAGGER") ? atoi(getenv("GNX_GEMM_STAGGER")) : 0;
   wa.stagger = (n_tiles >= 2048 && wa.n_ctiles == 1) ? stagger_env : 0;
   const bool trans = w.act > 1;
@@ -1102,7 +1207,8 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
   // encoder), element outputs with the full loader (every NL; also takes the rare quad-output + full-loader + operands launches)
 #define GNX_GEMM_LAUNCH(V, N, T, F) hipLaunchKernelGGL((k_rows_gemm<BN, V, 32, N, T, F>), grid, dim3(WaveLayout<BN>::WT), 0, s, wa)
 #define GNX_GEMM_LAUNCH_N(V, T, F) do { if (nl == 0) GNX_GEMM_LAUNCH(V, 0, T, F); else if (nl == 1) GNX_GEMM_LAUNCH(V, 1, T, F); else GNX_GEMM_LAUNCH(V, 2, T, F); } while (0)
-  if (vec4 && ld == 0) { if (trans) GNX_GEMM_LAUNCH_N(true, true, 0); else GNX_GEMM_LAUNCH_N(true, false, 0); }
+  if (vec4 && ld == 0 && nl == 3) { if (trans) GNX_GEMM_LAUNCH(true, 3, true, 0); else GNX_GEMM_LAUNCH(true, 3, false, 0); }
+  else if (vec4 && ld == 0) { if (trans) GNX_GEMM_LAUNCH_N(true, true, 0); else GNX_GEMM_LAUNCH_N(true, false, 0); }
   else if (vec4 && nl == 0 && ld == 1) { if (trans) GNX_GEMM_LAUNCH(true, 0, true, 1); else GNX_GEMM_LAUNCH(true, 0, false, 1); }
   else if (vec4 && nl == 0) { if (trans) GNX_GEMM_LAUNCH(true, 0, true, 2); else GNX_GEMM_LAUNCH(true, 0, false, 2); }
   else {
@@ -1289,7 +1395,10 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
       w.seg[ns++] = WSeg{a.nf, (size_t)a.N * a.dn, a.dn, 2, a.de + a.dn};
     }
     w.nseg = ns;
-    if (project) { w.gadd_a = proj_s; w.gadd_b = proj_d; w.gadd_rep_stride = (size_t)a.N * a.oe; }
+    if (project) {
+      w.gadd_a = proj_s; w.gadd_b = proj_d; w.gadd_rep_stride = (size_t)a.N * a.oe;
+      w.pd_lds = h->n_etiles_wide_span == 0;  // every edge tile's destinations fit the kernel's LDS table
+    }
     w.idx_a = a.rowval; w.idx_b = h->d_edge_dst; w.cp = a.colptr;
     w.W = a.We; w.bias = project ? nullptr : a.be; w.OUT = a.oe; w.act = a.act_e;
     w.bias_g = (!project && a.dg > 0) ? bias_e : nullptr; w.n_graphs = a.G;

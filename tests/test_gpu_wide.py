@@ -152,3 +152,59 @@ def test_wide_matches_generic_path(gn):
     a, b = blk(x, flags=0), blk(x, flags=1)
     for u, v in ((a.ef, b.ef), (a.nf, b.nf), (a.gf, b.gf)):
         np.testing.assert_allclose(U.from_jl(u), U.from_jl(v), rtol=2e-4, atol=2e-4)
+
+
+def _dense_indegree_csc(rng, N, lo, hi):
+    """every node has lo..hi-1 in-edges: a 128-edge tile's destinations are then a run of at most 128 / lo + 1 consecutive nodes"""
+    colptr = np.zeros(N + 1, dtype=np.int64)
+    rows = []
+    for j in range(N):
+        r = np.sort(rng.choice(N, int(rng.integers(lo, hi)), replace=False))
+        rows.append(r); colptr[j + 1] = colptr[j] + len(r)
+    return colptr, np.concatenate(rows).astype(np.int64)
+
+
+_PD_LDS_CASES = [
+    # (din, dout, R, N)                        what it exercises in k_rows_gemm<..., NL = 3> (launch_gemm_any narrows the column tile of small launches)
+    ((128, 64, 32), (128, 64, 32), 1, 3200),   # > 256 row tiles: 128-column tiles
+    ((64, 32, 8), (192, 32, 8), 2, 500),       # three 64-column tiles, replicas
+    ((32, 16, 0), (160, 16, 4), 1, 500),       # five 32-column tiles
+    ((64, 32, 4), (64, 16, 4), 1, 3200),       # one 64-column tile
+    ((64, 32, 4), (320, 16, 4), 1, 3200),      # three 128-column tiles, the last one half empty
+]
+
+
+def _pd_lds_case(gn, case):
+    din, dout, R, N = _PD_LDS_CASES[case]
+    rng = np.random.default_rng(600 + case)
+    colptr, rowval = _dense_indegree_csc(rng, N, 6, 15)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [N])
+    p = O.make_block_params(rng, din, dout, act=(1, 0, 2))
+    ef, nf, gf = U.packed_inputs(rng, R, len(rowval), N, 1, din)
+    return p, g, ef, nf, gf
+
+
+@pytest.mark.parametrize("case", range(len(_PD_LDS_CASES)))
+def test_wide_projected_edge_update_destination_rows_through_lds(gn, case, tmp_path):
+    """The projected edge update on a graph whose edge tiles' destinations are short runs of rows (every in-degree >= 6: the kernel
+    that stages a tile's destination projections in LDS and requests the source projections a pass at a time) against the oracle, and
+    bit for bit against the two-stream form of the same kernel (GNX_GEMM_PD_LDS=0, read once per process: a child process)."""
+    import os
+    import subprocess
+    import sys
+    p, g, ef, nf, gf = _pd_lds_case(gn, case)
+    y = _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
+    out = str(tmp_path / "two_streams.npz")
+    code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
+            "import graphnets_jl_amd as gn\n"
+            "from tests import util as U\n"
+            "from tests.test_gpu_wide import _pd_lds_case\n"
+            "p, g, ef, nf, gf = _pd_lds_case(gn, %d)\n"
+            "y = U.block_from_params(gn, p)(U.to_nt(gn, g, ef, nf, gf))\n"
+            "np.savez(%r, ef=U.from_jl(y.ef), nf=U.from_jl(y.nf), gf=U.from_jl(y.gf))\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), case, out)
+    env = dict(os.environ, GNX_GEMM_PD_LDS="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(out)
+    for name, got in (("ef", y.ef), ("nf", y.nf), ("gf", y.gf)):
+        np.testing.assert_array_equal(U.from_jl(got), z[name], err_msg=name)
