@@ -135,6 +135,12 @@ __device__ __forceinline__ void act_apply_n(float* v, int act) {
 
 // 16-B access at a wave-uniform base plus a 32-bit element offset: one VGPR of address instead of a 64-bit pair per access
 // (global_load_dwordx4 v, v_off, s[base]).  The hosts keep every table addressed this way below 4 GB (launch_gemm).
+// a pointer the compiler may keep in scalar registers (wave-uniform by construction, e.g. selected by the block index)
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const float*)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ float4 ld4(const float* ubase, unsigned off) {
   return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(ubase) + (off << 2));
 }
@@ -199,6 +205,8 @@ template <int BN, bool VEC4, int KC, int NL, bool TRANS, int LD>
 __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per_eu(WaveLayout<BN>::WPE))) void k_rows_gemm(WideArgs a) {
   using L = WaveLayout<BN>;
   constexpr int WT = L::WT;
+  constexpr bool ONESEG = NL == 3;  // the projected edge update: ONE segment, the tile's own rows (mode 0) — its record stays in scalar registers,
+                                    // no per-row index is read, the chunk loop tests one width (as generic code every chunk paid four serial scalar-load round trips)
   constexpr bool FULL = LD >= 1;   // loader with the row-sum modes 3 / 4
   constexpr bool ELEM = LD >= 2;   // ... and element-wise / packed segments
   constexpr int LDA = KC + 1;               // A row stride: odd => conflict-free ds_read_b32 of the A fragment
@@ -251,6 +259,8 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
     if (ctile >= nct1) { ctile -= nct1; Wsel = a.W2; bias_sel = a.bias2; bias_g_sel = a.bias_g2; out_sel = a.out2; }
   }
   tile_id = __builtin_amdgcn_readfirstlane(tile_id);  // wave-uniform by construction: lets the tile / chunk table reads be scalar loads
+  ctile = __builtin_amdgcn_readfirstlane(ctile);
+  Wsel = uniform_ptr(Wsel); bias_sel = uniform_ptr(bias_sel); bias_g_sel = uniform_ptr(bias_g_sel);  // (the weight chunk's loads: scalar base + one offset register)
   const Tile t = a.tiles[tile_id];
   int agg_row0[2] = {0, 0};  // first partial-sum row of the tile's two 64-row passes (read here: in the epilogue the load would wait for every store in flight)
   if (VEC4 && a.agg_out) { agg_row0[0] = a.chunk_row0[2 * tile_id]; agg_row0[1] = a.chunk_row0[2 * tile_id + 1]; }
@@ -284,20 +294,20 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
   auto load_chunk = [&](int si, int kc) {
     okmask = 0;
     emask = 0;
-    const WSeg sg = a.seg[si];
+    const WSeg sg = a.seg[ONESEG ? 0 : si];
     pend_ln = (LNOK && sg.ln) ? kc : -1;
     const float* base = sg.base + r * sg.rep_stride;
     const int k = kc + 4 * a_c4;
     if (!FULL || (sg.mode <= 2 && (!ELEM || sg.vec))) {
       const bool kok = k < sg.width;
       const int kcl = kok ? k : 0;
-      const float* ub = sg.mode == 0 ? base + (size_t)row0 * sg.width : base;  // uniform: the tile's first row, or the gathered table
+      const float* ub = (ONESEG || sg.mode == 0) ? base + (size_t)row0 * sg.width : base;  // uniform: the tile's first row, or the gathered table
 #pragma unroll
       for (int i = 0; i < NA4; ++i) {
         const int row = a_r + RPP * i;
         const int rc = min(row, rows - 1);
-        const int ia = s_ia[rc], ib = s_ib[rc];
-        const int grow = sg.mode == 0 ? rc : (sg.mode == 1 ? ia : ib);
+        int grow = rc;
+        if (!ONESEG) { const int ia = s_ia[rc], ib = s_ib[rc]; grow = sg.mode == 0 ? rc : (sg.mode == 1 ? ia : ib); }
         ra(i) = ld4(ub, (unsigned)grow * (unsigned)sg.width + (unsigned)kcl);
         const bool ok = kok && row < rows;
         okmask |= ok ? (1u << i) : 0u;
@@ -444,6 +454,7 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
   // The first chunk does not wait for the index arrays when its segment is the tile's own rows (mode 0: the loader's index reads are
   // then unused): its loads go out here, one memory round trip ahead of the index loads' round trip instead of behind it.
   int si = 0, kc = 0;
+  const int seg0_width = a.seg[0].width;
   while (si < a.nseg && a.seg[si].width == 0) ++si;
   const bool early_first = si < a.nseg && a.seg[si].mode == 0;
   if (early_first) load_chunk(si, kc);
@@ -670,7 +681,9 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
 #endif
     // advance and prefetch the next chunk while the matrix cores work on this one
     kc += KC;
-    if (kc >= a.seg[si].width) {
+    if (ONESEG) {
+      if (kc >= seg0_width) si = a.nseg;
+    } else if (kc >= a.seg[si].width) {
       kc = 0;
       ++si;
       while (si < a.nseg && a.seg[si].width == 0) ++si;
@@ -1199,7 +1212,7 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
   // gathered addends with quad outputs and the lean loader, on a batch whose edge tiles' destinations are short runs of rows: the
   // destination rows go through LDS (NL = 3).  GNX_GEMM_PD_LDS=0 keeps both tables as operand streams (NL = 2) for A/B runs.
   static const bool pd_lds_env = !(getenv("GNX_GEMM_PD_LDS") && atoi(getenv("GNX_GEMM_PD_LDS")) == 0);
-  if (wa.epi == EPI_GADD && vec4 && ld == 0 && w.pd_lds && pd_lds_env && w.OUT >= 4) nl = 3; else wa.pd_lds = 0;
+  if (wa.epi == EPI_GADD && vec4 && ld == 0 && w.pd_lds && pd_lds_env && w.OUT >= 4 && wa.nseg <= 1 && (wa.nseg == 0 || wa.seg[0].mode == 0)) nl = 3; else wa.pd_lds = 0;
   static const int stagger_env = getenv("GNX_GEMM_STAGGER") ? atoi(getenv("GNX_GEMM_STAGGER")) : 0;
   wa.stagger = (n_tiles >= 2048 && wa.n_ctiles == 1) ? stagger_env : 0;
   const bool trans = w.act > 1;
