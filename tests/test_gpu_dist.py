@@ -187,3 +187,71 @@ def test_gnx_dist_c_entry_points_world_1(gn):
     bad = order.copy(); bad[0] = bad[1]
     d2 = C.c_void_p()
     assert lib.gnx_dist_create(devs, 1, p64(off), p64(bad), G, 5, C.byref(d2)) == gn._lib.ERR_INVALID_ARG
+
+
+def _n_gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs in one process (the driver's GPU test box has one)")
+def test_gnx_dist_c_entry_points_two_devices(gn):
+    """The sharded path through the C boundary with TWO ranks in one process: gnx_dist_partition over 2 ranks with unequal shards,
+    one handle / parameter set / feature set per device, ncclCommInitAll over both, the grouped all-gather of gf' and the restoration of the
+    original graph order on BOTH devices.  Also the batch constructor's staging path on a device that is not the process's first one."""
+    import ctypes as C
+    import torch
+    lib = gn._lib.load()
+    rng = np.random.default_rng(78)
+    G, n = 30, 2
+    adjs = [(rng.random((k, k)) < 0.3).astype(np.int64) for k in rng.integers(3, 40, G)]
+    e_counts = np.array([int(a.sum()) for a in adjs], dtype=np.int64)
+    p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    off, ids = np.zeros(n + 1, dtype=np.int64), np.zeros(G, dtype=np.int64)
+    gn._lib.check(lib.gnx_dist_partition(p64(e_counts), G, n, p64(off), p64(ids)))
+    assert off[0] == 0 and off[n] == G and sorted(ids.tolist()) == list(range(G))
+    dims = ((4, 3, 2), (3, 4, 5))
+    p = O.make_block_params(rng, *dims)
+    ef = [rng.random((int(a.sum()), 4), dtype=np.float32) for a in adjs]
+    nf = [rng.random((a.shape[0], 3), dtype=np.float32) for a in adjs]
+    gf = rng.random((G, 2), dtype=np.float32)
+    keep, hs, bps, bufs = [], [], [], []
+    for r in range(n):
+        dev = torch.device("cuda", r)
+        mine = ids[off[r]:off[r + 1]]
+        g = gn.GNGraphBatch([adjs[i] for i in mine], device=dev)   # dense adjacency: the device-side constructor on device r
+        assert g.device == dev
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        blk = U.block_from_params(gn, p, device=dev)
+        bp = blk._c(keep)
+        with torch.cuda.device(dev):
+            ws = torch.empty(int(lib.gnx_block_workspace_bytes(g._h, C.byref(bp), 1)), dtype=torch.uint8, device=dev)
+        bufs.append(dict(g=g, ef=t(np.concatenate([ef[i] for i in mine])), nf=t(np.concatenate([nf[i] for i in mine])), gf=t(gf[mine]),
+                         eo=torch.empty((g.n_edges, 3), device=dev), no=torch.empty((g.n_nodes, 4), device=dev),
+                         gl=torch.empty((len(mine), 5), device=dev), gall=torch.full((G, 5), float("nan"), device=dev), ws=ws,
+                         stream=torch.cuda.current_stream(dev).cuda_stream))
+        hs.append(g); bps.append(bp); keep.append(blk)
+    d = C.c_void_p()
+    devs = (C.c_int32 * n)(*range(n))
+    gn._lib.check(lib.gnx_dist_create(devs, n, p64(off), p64(ids), G, 5, C.byref(d)))
+    try:
+        arr = lambda f: (C.c_void_p * n)(*[f(b) for b in bufs])
+        nbytes = (C.c_size_t * n)(*[b["ws"].numel() for b in bufs])
+        bparr = (C.c_void_p * n)(*[C.addressof(bp) for bp in bps])
+        for _ in range(2):
+            gn._lib.check(lib.gnx_dist_block_forward(d, arr(lambda b: b["g"]._h.value), bparr, arr(lambda b: b["ef"].data_ptr()), arr(lambda b: b["nf"].data_ptr()),
+                                                     arr(lambda b: b["gf"].data_ptr()), arr(lambda b: b["eo"].data_ptr()), arr(lambda b: b["no"].data_ptr()),
+                                                     arr(lambda b: b["gl"].data_ptr()), arr(lambda b: b["gall"].data_ptr()), arr(lambda b: b["ws"].data_ptr()),
+                                                     nbytes, 0, arr(lambda b: b["stream"])))
+            for r in range(n):
+                torch.cuda.synchronize(r)
+            ref, scale = O.block_forward_sparse(p, O.csc_from_adj(adjs), np.concatenate(ef)[None], np.concatenate(nf)[None], gf[None], return_scale=True)
+            for r in range(n):
+                U.assert_close(bufs[r]["gall"].cpu().numpy()[None], ref[2], scale[2], f"gf' in original graph order on device {r}")
+        # the current device of the calling thread is what it was
+        assert torch.cuda.current_device() == 0
+    finally:
+        gn._lib.check(lib.gnx_dist_destroy(d))
