@@ -90,7 +90,7 @@ __global__ void k_scan_add(int* out, int n, const int* block_prefix) {
 
 // Returns 1 when the device path does not apply (caller falls back to the host scan).
 int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int64_t G, int32_t elem_kind, int32_t row_major,
-                            std::vector<int64_t>& h_colptr, std::vector<int64_t>& h_rowval, const std::vector<int64_t>& h_node_off) {
+                            gnx::vec_i64& h_colptr, gnx::vec_i64& h_rowval, const std::vector<int64_t>& h_node_off) {
   const int64_t N = h_node_off.back();
   if (N <= 0 || N + 1 > (int64_t)SCAN_B * SCAN_B) return 1;  // two-level scan capacity
   static const size_t esz_tab[5] = {1, 4, 8, 4, 8};

@@ -115,32 +115,18 @@ static int32_t finalize(gnx_graphs* h) {
   }
 
   bt.lap("tile tables (host)");
-  auto upload32v = [&](const std::vector<int32_t>& tmp, int32_t** dst) -> int32_t {
-    GNX_HIP(hipMalloc((void**)dst, std::max<size_t>(tmp.size(), 1) * sizeof(int32_t)));
-    if (!tmp.empty()) GNX_HIP(hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    return GNX_OK;
-  };
-  auto upload32 = [&](const std::vector<int64_t>& src, int32_t** dst) -> int32_t {
-    std::vector<int32_t> tmp(src.size());
-    for (size_t i = 0; i < src.size(); ++i) tmp[i] = (int32_t)src[i];
-    return upload32v(tmp, dst);
-  };
-  int32_t rc;
+  // the eager device arrays live in ONE allocation (256-B aligned slices), filled by one copy each
+  struct Slice { void** dst; const void* src; size_t bytes; size_t off; };
+  std::vector<int32_t> node_off32(h->h_node_off.begin(), h->h_node_off.end()), edge_off32(h->h_edge_off.begin(), h->h_edge_off.end());
+  std::vector<int32_t> colptr32_tmp, rowval32_tmp;
+  const int32_t* colptr32 = nullptr;
+  const int32_t* rowval32 = nullptr;
   // (a constructor that already produced the device-format arrays — the CSC one, in its validation pass — hands them over)
-  if (h->t_colptr32.size() == h->h_colptr.size()) { if ((rc = upload32v(h->t_colptr32, &h->d_colptr))) return rc; }
-  else if ((rc = upload32(h->h_colptr, &h->d_colptr))) return rc;
-  if (h->t_rowval32.size() == h->h_rowval.size() && !h->h_rowval.empty()) { if ((rc = upload32v(h->t_rowval32, &h->d_rowval))) return rc; }
-  else if ((rc = upload32(h->h_rowval, &h->d_rowval))) return rc;
-  std::vector<int32_t>().swap(h->t_colptr32);
-  std::vector<int32_t>().swap(h->t_rowval32);
-  if ((rc = upload32(h->h_node_off, &h->d_node_off))) return rc;
-  if ((rc = upload32(h->h_edge_off, &h->d_edge_off))) return rc;
-  GNX_HIP(hipMalloc((void**)&h->d_tile_off, h->h_tile_off.size() * sizeof(int32_t)));
-  GNX_HIP(hipMemcpy(h->d_tile_off, h->h_tile_off.data(), h->h_tile_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  GNX_HIP(hipMalloc((void**)&h->d_tiles, std::max<size_t>(h->h_tiles.size(), 1) * sizeof(gnx::Tile)));
-  if (!h->h_tiles.empty())
-    GNX_HIP(hipMemcpy(h->d_tiles, h->h_tiles.data(), h->h_tiles.size() * sizeof(gnx::Tile), hipMemcpyHostToDevice));
-  bt.lap("csc + tiles upload");
+  if (h->t_colptr32.size() == h->h_colptr.size()) colptr32 = h->t_colptr32.data();
+  else { colptr32_tmp.assign(h->h_colptr.begin(), h->h_colptr.end()); colptr32 = colptr32_tmp.data(); }
+  if (h->t_rowval32.size() == h->h_rowval.size() && !h->h_rowval.empty()) rowval32 = h->t_rowval32.data();
+  else { rowval32_tmp.assign(h->h_rowval.begin(), h->h_rowval.end()); rowval32 = rowval32_tmp.data(); }
+  std::vector<int32_t> packs;  // [n_packs][8] (filled below when applicable)
   // wide path: the COUNTS of its 128-row tiles and the per-graph tile offsets now (O(G)); the tables on first use (ensure_wide_tables)
   {
     const int64_t BM = 128;
@@ -164,7 +150,6 @@ static int32_t finalize(gnx_graphs* h) {
     for (int64_t g = 0; g < h->G; ++g) order[(size_t)g] = (int32_t)g;
     auto cnt_of = [&](int32_t g) { return h->h_wtile_off[(size_t)g + 1] - h->h_wtile_off[(size_t)g]; };
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cnt_of(a) > cnt_of(b); });
-    std::vector<int32_t> packs;                 // [n_packs][CAP]
     std::vector<int32_t> fill;                  // slots used per pack
     std::vector<std::vector<int32_t>> open(CAP + 1);  // open[r]: packs with r free slots
     for (int32_t g : order) {
@@ -180,15 +165,28 @@ static int32_t finalize(gnx_graphs* h) {
       if (fill[(size_t)pk] < CAP) open[(size_t)(CAP - fill[(size_t)pk])].push_back(pk);
     }
     h->n_packs = (int32_t)fill.size();
-    GNX_HIP(hipMalloc((void**)&h->d_packs, std::max<size_t>(packs.size(), 1) * sizeof(int32_t)));
-    if (!packs.empty()) GNX_HIP(hipMemcpy(h->d_packs, packs.data(), packs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
   }
-  GNX_HIP(hipMalloc((void**)&h->d_wtile_off, h->h_wtile_off.size() * sizeof(int32_t)));
-  GNX_HIP(hipMemcpy(h->d_wtile_off, h->h_wtile_off.data(), h->h_wtile_off.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  GNX_HIP(hipMalloc((void**)&h->d_wtiles, std::max<size_t>(h->h_wtiles.size(), 1) * sizeof(gnx::Tile)));
-  if (!h->h_wtiles.empty())
-    GNX_HIP(hipMemcpy(h->d_wtiles, h->h_wtiles.data(), h->h_wtiles.size() * sizeof(gnx::Tile), hipMemcpyHostToDevice));
-  bt.lap("wave tiles upload");
+  Slice sl[] = {
+      {(void**)&h->d_colptr, colptr32, h->h_colptr.size() * sizeof(int32_t), 0},
+      {(void**)&h->d_rowval, rowval32, h->h_rowval.size() * sizeof(int32_t), 0},
+      {(void**)&h->d_node_off, node_off32.data(), node_off32.size() * sizeof(int32_t), 0},
+      {(void**)&h->d_edge_off, edge_off32.data(), edge_off32.size() * sizeof(int32_t), 0},
+      {(void**)&h->d_tile_off, h->h_tile_off.data(), h->h_tile_off.size() * sizeof(int32_t), 0},
+      {(void**)&h->d_tiles, h->h_tiles.data(), h->h_tiles.size() * sizeof(gnx::Tile), 0},
+      {(void**)&h->d_wtile_off, h->h_wtile_off.data(), h->h_wtile_off.size() * sizeof(int32_t), 0},
+      {(void**)&h->d_wtiles, h->h_wtiles.data(), h->h_wtiles.size() * sizeof(gnx::Tile), 0},
+      {(void**)&h->d_packs, packs.data(), packs.size() * sizeof(int32_t), 0},
+  };
+  size_t total = 0;
+  for (Slice& x : sl) { x.off = total; total += (std::max<size_t>(x.bytes, 16) + 255) / 256 * 256; }
+  GNX_HIP(hipMalloc(&h->d_arena, total));
+  for (Slice& x : sl) {
+    *x.dst = static_cast<char*>(h->d_arena) + x.off;  // (never NULL, as before: an empty array still has its 256-B slice)
+    if (x.bytes) GNX_HIP(hipMemcpy(*x.dst, x.src, x.bytes, hipMemcpyHostToDevice));
+  }
+  gnx::vec_i32().swap(h->t_colptr32);
+  gnx::vec_i32().swap(h->t_rowval32);
+  bt.lap("device arrays (one allocation, nine copies)");
   return GNX_OK;
 }
 
@@ -290,7 +288,7 @@ static int32_t build_wide_tables(const gnx_graphs* h) {
 
 namespace gnx {
 int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int64_t G, int32_t elem_kind, int32_t row_major,
-                            std::vector<int64_t>& h_colptr, std::vector<int64_t>& h_rowval, const std::vector<int64_t>& h_node_off);
+                            gnx::vec_i64& h_colptr, gnx::vec_i64& h_rowval, const std::vector<int64_t>& h_node_off);
 }
 
 using namespace gnx;
@@ -488,13 +486,7 @@ int32_t gnx_graphs_create_csc_packed(const int64_t* colptr_cat, const int64_t* r
 
 int32_t gnx_graphs_destroy(gnx_graphs* h) {
   if (!h) return GNX_OK;
-  (void)hipFree(h->d_colptr);
-  (void)hipFree(h->d_rowval);
-  (void)hipFree(h->d_node_off);
-  (void)hipFree(h->d_edge_off);
-  (void)hipFree(h->d_tile_off);
-  (void)hipFree(h->d_tiles);
-  (void)hipFree(h->d_wtile_off);
+  (void)hipFree(h->d_arena);  // colptr, rowval, node / edge / tile offsets, tiles, wave tiles, packs
   (void)hipFree(h->d_edge_dst);
   (void)hipFree(h->d_chunk_row0);
   (void)hipFree(h->d_node_agg_row);
@@ -505,8 +497,6 @@ int32_t gnx_graphs_destroy(gnx_graphs* h) {
   (void)hipFree(h->d_gtiles);
   (void)hipFree(h->d_etile_off);
   (void)hipFree(h->d_ntile_off);
-  (void)hipFree(h->d_wtiles);
-  (void)hipFree(h->d_packs);
   (void)hipFree(h->d_collapse_edge);
   (void)hipFree(h->d_collapse_rev);
   (void)hipFree(h->d_csr_ptr);

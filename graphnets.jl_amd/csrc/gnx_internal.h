@@ -4,20 +4,41 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "gnx.h"
 
 #include "gnx_device.h"  // gnx::Tile, gnx::BlockArgs
 
+namespace gnx {
+// std::vector whose resize() leaves trivially constructible elements uninitialised: the O(N + E) arrays of a handle are written in full by the
+// pass that follows their allocation — value-initialising them first is a second sweep over (and the first touch of) 19 MB for a 1M-edge batch
+template <class T>
+struct uninit_alloc : std::allocator<T> {
+  template <class U> struct rebind { using other = uninit_alloc<U>; };
+  uninit_alloc() = default;
+  template <class U> uninit_alloc(const uninit_alloc<U>&) {}
+  template <class U, class... A>
+  void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
+using vec_i64 = std::vector<int64_t, uninit_alloc<int64_t>>;
+using vec_i32 = std::vector<int32_t, uninit_alloc<int32_t>>;
+}  // namespace gnx
+
 struct gnx_graphs {
   int64_t G = 0, N = 0, E = 0, PN = 0;
   int64_t max_in_degree = 0;
   int device = 0;
   // host copies (int64, 0-based, global)
-  std::vector<int64_t> h_node_off, h_edge_off, h_colptr, h_rowval;
-  std::vector<int32_t> t_colptr32, t_rowval32;  // transient: the device-format copies a constructor already made (uploaded as they are, then freed)
+  std::vector<int64_t> h_node_off, h_edge_off;
+  gnx::vec_i64 h_colptr, h_rowval;
+  gnx::vec_i32 t_colptr32, t_rowval32;  // transient: the device-format copies a constructor already made (uploaded as they are, then freed)
+  void* d_arena = nullptr;  // ONE device allocation behind the arrays every handle has (colptr .. wave tiles below): a dozen hipMalloc / hipFree pairs cost ~3 ms per handle
   std::vector<gnx::Tile> h_tiles;
   std::vector<int32_t> h_tile_off;  // [G+1] tiles of graph g = [tile_off[g], tile_off[g+1])
   // wave tiles: same idea at wavefront granularity (<= wtile_e_cap edges, <= 64 nodes), one wave64 per tile
