@@ -281,7 +281,14 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
   float4 rs[FULL ? NA4 : 1];  // mode 4: second partial-sum rows of the chunk
 #define ra(i) stg[i]
 #define rb(i) stg[NA4 + (i)]
-  const int a_c4 = tid % C4R, a_r = tid / C4R;
+  const int a_c4_0 = tid % C4R, a_r_0 = tid / C4R;
+  // The row-sum loaders (LD >= 1) run with spilled registers at four workgroups per CU, and what the allocator parks in scratch memory are the
+  // per-row LDS addresses derived from these two — reloaded inside the chunk loader, between its global loads, and a scratch reload waits for
+  // every load in flight (by the .s: four serial memory round trips per chunk of the node update).  Derived afresh from a thread id the compiler
+  // cannot trace back, in each place that needs them, they are a few VALU operations instead of registers held across the K loop.
+#define GNX_LOADER_COORDS                                        \
+  int a_c4 = a_c4_0, a_r = a_r_0;                                \
+  if (FULL) { int tl_ = tid; asm volatile("" : "+v"(tl_)); a_c4 = tl_ % C4R; a_r = tl_ / C4R; }
 
   // The mode is tested ONCE per chunk, outside the row loop, and every mode is straight-line code with unconditional loads of
   // clamped addresses whose validity is recorded in bit masks and applied when the chunk goes to LDS: with a test in front of each
@@ -290,10 +297,15 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
   // went into issuing loads); a select on the loaded value at this point waits for the load just the same.
   unsigned okmask = 0;  // quads: bit i: ra(i) holds data (else zero), bit NA4 + i: rb(i), bit NA4 + NB4 + i: rs[i]
   int pend_ln = -1;     // the chunk in the staging registers is columns [pend_ln, pend_ln + KC) of the normalised segment (-1: plain)
+  unsigned moremask = 0;  // mode 4: bit i: row i of the staged chunk has partial sums beyond the first two (fetched by store_chunk)
+  const float* more_base = nullptr;
+  int more_w = 0, more_k = 0;
   unsigned emask = 0;   // elements of element-wise loaded quads (FULL / !VEC4): bit 4 i + e: ra(i)[e], bit 16 + 4 i + e: rb(i)[e]
   auto load_chunk = [&](int si, int kc) {
+    GNX_LOADER_COORDS
     okmask = 0;
     emask = 0;
+    moremask = 0;
     const WSeg sg = a.seg[ONESEG ? 0 : si];
     pend_ln = (LNOK && sg.ln) ? kc : -1;
     const float* base = sg.base + r * sg.rep_stride;
@@ -398,7 +410,6 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
       // unconditional loads; added when the chunk goes to LDS), the rare further parts (in-degree beyond two chunks) after them
       const bool kok = k < sg.width;
       const int kcl = kok ? k : 0;
-      bool more = false;
 #pragma unroll
       for (int i = 0; i < NA4; ++i) {
         const int rc = min(a_r + RPP * i, rows - 1);
@@ -408,23 +419,12 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
         rs[FULL ? i : 0] = ld4(base, (unsigned)max(p2, 0) * (unsigned)sg.width + (unsigned)kcl);
         emask |= ok ? (15u << (4 * i)) : 0u;
         okmask |= (ok && p2 >= 0) ? (1u << (NA4 + NB4 + i)) : 0u;
-        more |= ok && s_ib[rc] > 2;
+        moremask |= (ok && s_ib[rc] > 2) ? (1u << i) : 0u;  // in-degree beyond two chunks: the further parts are added when the chunk goes to LDS
       }
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < NA4; ++i) {
-          const int rc = min(a_r + RPP * i, rows - 1);
-          const int parts = s_ib[rc];
-          if (((emask >> (4 * i)) & 1u) && parts > 2) {
-            const int c0 = a.node_agg_chunk[row0 + rc];
-            for (int j = 2; j < parts; ++j) {
-              const float4 u = ld4(base, (unsigned)a.chunk_row0[c0 + j] * (unsigned)sg.width + (unsigned)k);
-              float4& t4 = rs[FULL ? i : 0];
-              t4.x += u.x; t4.y += u.y; t4.z += u.z; t4.w += u.w;
-            }
-          }
-        }
-      }
+      more_base = base; more_w = sg.width; more_k = k;
+      // (the further parts used to be fetched HERE, inside an `if (any row has more)`: loads in a branch between this chunk's requests and
+      //  the matrix-core work make the compiler drain vmcnt at the join — every chunk of the node update waited for the loads it had
+      //  just issued, 36 k of a tile's 102 k clocks by the stamps, whether or not any node of the tile had such a degree)
     }
     const int ldw = a.ldw ? a.ldw : a.OUT;
     const float* wb = Wsel + (size_t)(sg.w_row0 + kc) * ldw + n0;  // uniform: first row of the chunk, first column of the tile
@@ -529,6 +529,22 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   auto store_chunk = [&]() {
+    GNX_LOADER_COORDS
+    if (FULL && moremask) {  // rare (a node whose in-edges run through more than two 64-row chunks): synchronous loads, behind the wait for the chunk itself
+#pragma unroll
+      for (int i = 0; i < NA4; ++i) {
+        if ((moremask >> i) & 1u) {
+          const int rc = min(a_r + RPP * i, rows - 1);
+          const int parts = s_ib[rc];
+          const int c0 = a.node_agg_chunk[row0 + rc];
+          for (int j = 2; j < parts; ++j) {
+            const float4 u = ld4(more_base, (unsigned)a.chunk_row0[c0 + j] * (unsigned)more_w + (unsigned)more_k);
+            float4& t4 = rs[FULL ? i : 0];
+            t4.x += u.x; t4.y += u.y; t4.z += u.z; t4.w += u.w;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NA4; ++i) {
       float* d = sA + (a_r + RPP * i) * LDA + 4 * a_c4;
@@ -872,10 +888,10 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
         }
       }
     }
-  }
 #ifdef GNX_WIDE_STAMPS_BUILD
-  // (agg time = epilogue - stage - groups - colsum tail; reported as the remainder)
+    t_eagg += clock64() - te2;  // barrier + per-destination sums of this pass (the column-sum tail is the epilogue's remainder)
 #endif
+  }
   if (a.colsum) {  // fixed-order reduction over the NG row groups that share a column quad
     lds_barrier();
     float* s_cs = sC;  // [NG][BN]
@@ -897,12 +913,13 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
   if (a.stamps && tid == 0 && ctile == 0 && blockIdx.z == 0) {
     unsigned long long* o = a.stamps + (size_t)tile_id * 8;
     o[0] = st[1] - st[0]; o[1] = t_sync; o[2] = t_mfma; o[3] = clock64() - st[2]; o[4] = clock64() - st[0];
-    o[5] = t_estage | (t_egroups << 32); o[6] = t_issue;  // epilogue: staging (barrier, acc -> LDS, barrier) | operand groups; loads issue time (part of o[2])
+    o[5] = t_estage | (t_egroups << 32); o[6] = t_issue | (t_eagg << 32);  // epilogue: staging (barrier, acc -> LDS, barrier) | operand groups; loads issue time (part of o[2])
     o[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);  // XCC_ID, HW_ID
   }
 #endif
 }
 
+#undef GNX_LOADER_COORDS
 #undef ra
 #undef rb
 #undef ex
@@ -1240,13 +1257,14 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
       snprintf(path, sizeof path, "%s_%s.bin", dump, name);  // (the last launch of each name wins)
       if (FILE* f = fopen(path, "wb")) { fwrite(hs.data(), 8, hs.size(), f); fclose(f); }
     }
-    double m[7] = {0, 0, 0, 0, 0, 0, 0}, e_stage = 0, e_groups = 0;
+    double m[7] = {0, 0, 0, 0, 0, 0, 0}, e_stage = 0, e_groups = 0, e_agg = 0;
     for (size_t i = 0; i < n_tiles; ++i) {
-      for (int j = 0; j < 7; ++j) m[j] += (double)hs[i * 8 + j];
+      for (int j = 0; j < 6; ++j) m[j] += (double)hs[i * 8 + j];
+      m[6] += (double)(hs[i * 8 + 6] & 0xffffffffull); e_agg += (double)(hs[i * 8 + 6] >> 32);
       e_stage += (double)(hs[i * 8 + 5] & 0xffffffffull); e_groups += (double)(hs[i * 8 + 5] >> 32);
     }
-    fprintf(stderr, "[gnx stamps] %s BN=%d tiles=%u ctiles=%d: per tile (shader clocks, wave 0 of column tile 0): prologue %.0f  sync+store %.0f  mfma-loop %.0f (of which issuing the next chunk's loads %.0f)  epilogue %.0f (staging %.0f, operand groups + stores %.0f, rest: per-destination / column sums)  total %.0f\n",
-            name, BN, n_tiles, wa.n_ctiles, m[0] / n_tiles, m[1] / n_tiles, m[2] / n_tiles, m[6] / n_tiles, m[3] / n_tiles, e_stage / n_tiles, e_groups / n_tiles, m[4] / n_tiles);
+    fprintf(stderr, "[gnx stamps] %s BN=%d tiles=%u ctiles=%d: per tile (shader clocks, wave 0 of column tile 0): prologue %.0f  sync+store %.0f  mfma-loop %.0f (of which issuing the next chunk's loads %.0f)  epilogue %.0f (staging %.0f, operand groups + stores %.0f, barrier + per-destination sums %.0f, rest: column sums)  total %.0f\n",
+            name, BN, n_tiles, wa.n_ctiles, m[0] / n_tiles, m[1] / n_tiles, m[2] / n_tiles, m[6] / n_tiles, m[3] / n_tiles, e_stage / n_tiles, e_groups / n_tiles, e_agg / n_tiles, m[4] / n_tiles);
   }
 #endif
   GNX_HIP(hipGetLastError());
