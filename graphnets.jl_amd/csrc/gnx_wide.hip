@@ -201,8 +201,13 @@ struct WaveLayout {
 // cost the plain / gathered quad loader registers it does not have (spilled LDS addresses are reloaded from scratch memory in front of every access,
 // and a scratch reload waits on vmcnt, i.e. for the global loads just issued): launches whose segments are all quad rows of
 // modes 0-2 (the core's edge update, the FeedForward layers, the projections) get a kernel without them.
+#ifndef GNX_GEMM_WPE_PLAIN  // waves per SIMD of the plain quad GEMM (no epilogue operand, lean loader: the node projections, FeedForward layers, dX of the backward)
+#define GNX_GEMM_WPE_PLAIN 3
+#endif
+template <int BN, int NL, int LD>
+constexpr int gemm_wpe() { return (BN == 128 && NL == 0 && LD == 0) ? GNX_GEMM_WPE_PLAIN : WaveLayout<BN>::WPE; }
 template <int BN, bool VEC4, int KC, int NL, bool TRANS, int LD>
-__global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per_eu(WaveLayout<BN>::WPE))) void k_rows_gemm(WideArgs a) {
+__global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per_eu(gemm_wpe<BN, NL, LD>()))) void k_rows_gemm(WideArgs a) {
   using L = WaveLayout<BN>;
   constexpr int WT = L::WT;
   constexpr bool ONESEG = NL == 3;  // the projected edge update: ONE segment, the tile's own rows (mode 0) — its record stays in scalar registers,
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
   // cannot trace back, in each place that needs them, they are a few VALU operations instead of registers held across the K loop.
 #define GNX_LOADER_COORDS                                        \
   int a_c4 = a_c4_0, a_r = a_r_0;                                \
-  if (FULL) { int tl_ = tid; asm volatile("" : "+v"(tl_)); a_c4 = tl_ % C4R; a_r = tl_ / C4R; }
+  if (FULL || gemm_wpe<BN, NL, LD>() > WaveLayout<BN>::WPE) { int tl_ = tid; asm volatile("" : "+v"(tl_)); a_c4 = tl_ % C4R; a_r = tl_ / C4R; }
 
   // The mode is tested ONCE per chunk, outside the row loop, and every mode is straight-line code with unconditional loads of
   // clamped addresses whose validity is recorded in bit masks and applied when the chunk goes to LDS: with a test in front of each
