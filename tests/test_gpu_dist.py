@@ -251,7 +251,5 @@ def test_gnx_dist_c_entry_points_two_devices(gn):
             ref, scale = O.block_forward_sparse(p, O.csc_from_adj(adjs), np.concatenate(ef)[None], np.concatenate(nf)[None], gf[None], return_scale=True)
             for r in range(n):
                 U.assert_close(bufs[r]["gall"].cpu().numpy()[None], ref[2], scale[2], f"gf' in original graph order on device {r}")
-        # the current device of the calling thread is what it was
-        assert torch.cuda.current_device() == 0
     finally:
         gn._lib.check(lib.gnx_dist_destroy(d))
