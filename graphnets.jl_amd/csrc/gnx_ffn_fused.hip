@@ -187,11 +187,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       GNX_FSTAMP(fs_issue, fs_t);
       if (st < NC1) {
         // GEMM1: accH[32 x 32 per wave] += z chunk * W1 chunk     (wave rows 32*wm.., hidden columns 32*wn..)
+        // fragments of k-step kk + 1 requested from LDS before the MFMA of step kk (pinned: left alone the compiler reads, waits, multiplies —
+        // C4 6.38 -> 6.27 ms; s_setprio(1) around the matrix-core sections on top of it: 6.28 vs 6.25 ms, not kept)
+        float fa1[2], fb1[2];
+        fb1[0] = sB1[hi * FHS + wn * 32 + l31];
+        fa1[0] = sA[(wm * 32 + l31) * LDA + hi];
 #pragma unroll
         for (int kk = 0; kk < FKC / 2; ++kk) {
-          const float fb = sB1[(2 * kk + hi) * FHS + wn * 32 + l31];
-          const float fa = sA[(wm * 32 + l31) * LDA + 2 * kk + hi];
-          accH = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, accH, 0, 0, 0);
+          const int c = kk & 1, n = c ^ 1;
+          if (kk + 1 < FKC / 2) {
+            fb1[n] = sB1[(2 * (kk + 1) + hi) * FHS + wn * 32 + l31];
+            fa1[n] = sA[(wm * 32 + l31) * LDA + 2 * (kk + 1) + hi];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          accH = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[c], fb1[c], accH, 0, 0, 0);
         }
         GNX_FSTAMP(fs_mma1, fs_t);
         if (st == NC1 - 1) {
@@ -219,14 +228,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       } else {
         // GEMM2: accO[64 x D/2 per wave] += sH[:, 32-wide k range] * W2 chunk
         const int kb = (st - NC1) * FKC;
+        float fa2[2], fb2[2][TNO];
+        fa2[0] = sH[(wm * 32 + l31) * LDH + kb + hi];
+#pragma unroll
+        for (int j = 0; j < TNO; ++j) fb2[0][j] = sB2[hi * D + (wn * TNO + j) * 32 + l31];
 #pragma unroll
         for (int kk = 0; kk < FKC / 2; ++kk) {
-          float fb[TNO];
-          const float fa = sH[(wm * 32 + l31) * LDH + kb + 2 * kk + hi];
+          const int c = kk & 1, n = c ^ 1;
+          if (kk + 1 < FKC / 2) {
+            fa2[n] = sH[(wm * 32 + l31) * LDH + kb + 2 * (kk + 1) + hi];
 #pragma unroll
-          for (int j = 0; j < TNO; ++j) fb[j] = sB2[(2 * kk + hi) * D + (wn * TNO + j) * 32 + l31];
+            for (int j = 0; j < TNO; ++j) fb2[n][j] = sB2[(2 * (kk + 1) + hi) * D + (wn * TNO + j) * 32 + l31];
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < TNO; ++j) accO[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb[j], accO[j], 0, 0, 0);
+          for (int j = 0; j < TNO; ++j) accO[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa2[c], fb2[c][j], accO[j], 0, 0, 0);
         }
         GNX_FSTAMP(fs_mma2, fs_t);
       }
