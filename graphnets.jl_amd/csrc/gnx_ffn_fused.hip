@@ -179,12 +179,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
     for (int st = 0; st < NSTEP; ++st) {
       __syncthreads();  // readers of the previous chunk are done (and, at st == NC1, sH has been written by everyone)
       store_step(st);
-      __syncthreads();
-      GNX_FSTAMP(fs_sync, fs_t);
-      // prefetch the next step (possibly the first chunk of the next slice)
+      // prefetch the next step (possibly the first chunk of the next slice) as soon as the staging registers are free — in front of the
+      // barrier, whose wait is then part of the loads' cover (the barrier orders LDS traffic only; the loads are waited for at the next store_step)
       if (st + 1 < NSTEP) load_step(hs, st + 1);
       else if (hs + 1 < H / FHS) load_step(hs + 1, 0);
       GNX_FSTAMP(fs_issue, fs_t);
+      __syncthreads();
+      GNX_FSTAMP(fs_sync, fs_t);
       if (st < NC1) {
         // GEMM1: accH[32 x 32 per wave] += z chunk * W1 chunk     (wave rows 32*wm.., hidden columns 32*wn..)
         // fragments of k-step kk + 1 requested from LDS before the MFMA of step kk (pinned: left alone the compiler reads, waits, multiplies —
