@@ -178,10 +178,7 @@ struct WaveLayout {
 #ifndef GNX_GEMM_WPE64  // 64-column tiles (the node update at C4's widths): 4 workgroups per CU — 782 node tiles are ONE round on 1024 slots but
 #define GNX_GEMM_WPE64 4  // 1.02 rounds on 768; the ~25 registers the row-sum loader then spills cost less than the second round (66 -> 60 us)
 #endif
-#ifndef GNX_GEMM_WPE32  // 32-column tiles (narrow outputs: the decoder's 3 / 4 columns, small launches): 16 accumulator registers per wave
-#define GNX_GEMM_WPE32 GNX_GEMM_WPE
-#endif
-  static constexpr int WPE = WAVES == 8 ? 4 : (BN == 64 ? GNX_GEMM_WPE64 : (BN == 32 ? GNX_GEMM_WPE32 : GNX_GEMM_WPE));  // waves per SIMD asked of the register allocator
+  static constexpr int WPE = WAVES == 8 ? 4 : (BN == 64 ? GNX_GEMM_WPE64 : GNX_GEMM_WPE);  // waves per SIMD asked of the register allocator
 };
 
 // NL = number of epilogue operand streams read from global memory (EPI_* below): 0, 1 or 2 float4 per output quad; 3: the gathered
