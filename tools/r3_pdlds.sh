@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-3 A/B of the accumulator-start form of the projected edge GEMM (GNX_GEMM_PD_LDS=0: operand streams behind the K loop)
+# round-3 A/B of the projected edge GEMM's destination-rows-through-LDS form (GNX_GEMM_PD_LDS=0: both gathered tables as epilogue operand streams): tests, block and C4 timing, per-phase stamps
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p gpurun_out
 timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "wide or core or fullsize or block or model or chain or backward" > gpurun_out/pdlds_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/pdlds_tests.log
