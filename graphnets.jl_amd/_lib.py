@@ -105,6 +105,7 @@ SIGNATURES = {
     "gnx_graphs_create_dense": (C.c_int32, [_pp, _i64p, C.c_int64, C.c_int32, C.c_int32, _pp]),
     "gnx_graphs_create_csc": (C.c_int32, [_pp, _pp, _i64p, C.c_int64, C.c_int32, _pp]),
     "gnx_graphs_create_csc_packed": (C.c_int32, [_i64p, _i64p, _i64p, C.c_int64, C.c_int32, _pp]),
+    "gnx_graphs_create_csc_cat": (C.c_int32, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, _i64p, C.c_int64, C.c_int32, C.c_int32, _pp]),
     "gnx_graphs_destroy": (C.c_int32, [C.c_void_p]),
     "gnx_graphs_get_info": (C.c_int32, [C.c_void_p, C.POINTER(GraphsInfo)]),
     "gnx_graphs_get_offsets": (C.c_int32, [C.c_void_p, _i64p, _i64p]),

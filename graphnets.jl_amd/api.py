@@ -100,16 +100,29 @@ class GNGraphBatch:
         with torch.cuda.device(self.device):
             if _csc is not None:
                 colptrs, rowvals, n_nodes = _csc
-                G = len(n_nodes)
-                # ONE concatenation per array kind and one call (gnx_graphs_create_csc_packed): building 2 G ctypes pointers costs ~1 us
-                # each — 8 of the 20 ms of a 4096-graph batch
-                cat = lambda parts: np.ascontiguousarray(np.concatenate(parts) if len(parts) > 1 else (parts[0] if parts else np.zeros(0, np.int64)), dtype=np.int64)
-                cpc, rvc = cat(list(colptrs)), cat(list(rowvals))
                 nn = np.ascontiguousarray(n_nodes, dtype=np.int64)
-                assert cpc.size == int(nn.sum()) + G, "every colptr must have n_nodes + 1 entries"
+                G = int(nn.size)
+                # ONE array per kind and one call (gnx_graphs_create_csc_cat): building 2 G ctypes pointers costs ~1 us each — 8 of the
+                # 20 ms of a 4096-graph batch.  A caller that already holds the concatenated arrays (from_csc_packed) passes them as they
+                # are; int32 indices stay int32 (half the bytes to validate and upload).
+                def cat(parts):
+                    if isinstance(parts, np.ndarray) and parts.ndim == 1 and parts.dtype.kind in "iu":
+                        a_ = parts
+                    else:
+                        parts = list(parts)
+                        a_ = np.concatenate(parts) if len(parts) > 1 else (np.asarray(parts[0]) if parts else np.zeros(0, np.int64))
+                    if a_.dtype != np.int32 and a_.dtype != np.int64:
+                        a_ = a_.astype(np.int64)
+                    return np.ascontiguousarray(a_)
+                cpc, rvc = cat(colptrs), cat(rowvals)
+                if rvc.dtype != cpc.dtype:
+                    rvc = rvc.astype(cpc.dtype)
+                if cpc.size != int(nn.sum()) + G:
+                    raise ValueError("every colptr must have n_nodes + 1 entries (colptr_cat: sum(n_nodes) + n_graphs)")
                 keep += [cpc, rvc, nn]
-                p64 = lambda a_: a_.ctypes.data_as(C.POINTER(C.c_int64))
-                check(lib.gnx_graphs_create_csc_packed(p64(cpc), p64(rvc) if rvc.size else None, p64(nn), G, 0, C.byref(self._h)))
+                # (the C entry point checks both lengths against what the colptr arrays announce and never reads past them)
+                check(lib.gnx_graphs_create_csc_cat(cpc.ctypes.data, cpc.size, rvc.ctypes.data if rvc.size else None, rvc.size,
+                                                    nn.ctypes.data_as(C.POINTER(C.c_int64)), G, 0, cpc.dtype.itemsize * 8, C.byref(self._h)))
                 self.adj_mats = None
             else:
                 mats = [_np(a) for a in adj_mats]
@@ -150,6 +163,12 @@ class GNGraphBatch:
         """Per-graph 0-based CSC: colptrs[g] (N_g+1), rowvals[g] = local source index of every edge (sorted inside
         a column).  CSC nz order is the reference edge order (pad.jl:30)."""
         return cls(device=device, _csc=(colptrs, rowvals, n_nodes))
+
+    @classmethod
+    def from_csc_packed(cls, colptr_cat, rowval_cat, n_nodes, device=None):
+        """The same batch from the CONCATENATED arrays (int32 or int64 numpy): colptr_cat = the graphs' 0-based colptr arrays one
+        after the other (N_g + 1 entries each), rowval_cat = their rowval arrays.  No per-graph Python work."""
+        return cls(device=device, _csc=(np.asarray(colptr_cat), np.asarray(rowval_cat), n_nodes))
 
     def __len__(self):
         return self.n_graphs

@@ -558,6 +558,8 @@ extern "C" {
 
 size_t gnx_block_backward_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
   if (!h || !p || R <= 0) return 0;
+  (void)gnx_ensure_wide_tables(h);  // what the backward reads is built here, outside any capture (a failure resurfaces in the backward)
+  (void)gnx_ensure_csr(h);
   return bw_layout(h, p, R).total;
 }
 
@@ -577,7 +579,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
     if (a < 0 || a > GNX_ACT_GELU) return fail(GNX_ERR_INVALID_ARG, "unknown activation code");
   const BwLayout L = bw_layout(h, p, R);
   if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_block_backward_workspace_bytes()");
-  int32_t rc = gnx_ensure_wide_tables(h);  // (the delta kernels read the destination of every edge; the matrix-core pullbacks the 128-row tiles)
+  int32_t rc = gnx_ensure_wide_tables(h, stream);  // (the delta kernels read the destination of every edge; the matrix-core pullbacks the 128-row tiles)
   if (rc) return rc;
   rc = gnx_ensure_csr(h);
   if (rc) return rc;
@@ -768,6 +770,8 @@ CoreBwLayout core_bw_layout(const gnx_graphs* h, const gnx_core_params* p, int64
 
 size_t gnx_core_backward_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t R) {
   if (!h || !p || R <= 0) return 0;
+  (void)gnx_ensure_wide_tables(h);
+  (void)gnx_ensure_csr(h);
   return core_bw_layout(h, p, R).total;
 }
 
@@ -785,7 +789,7 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
   }
   const CoreBwLayout L = core_bw_layout(h, p, R);
   if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_core_backward_workspace_bytes()");
-  if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
+  if (int32_t rcw = gnx_ensure_wide_tables(h, stream)) return rcw;
   char* base = static_cast<char*>(ws);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
   const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
@@ -990,7 +994,7 @@ int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_para
   if (oe == 0) return fail(GNX_ERR_DIMS, "chain backward: not implemented for an edge function without output (the forward takes it; train such a block with one-layer update functions)");
   const ChainBwLayout L = chain_bw_layout(h, p, R);
   if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_chain_block_backward_workspace_bytes()");
-  if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
+  if (int32_t rcw = gnx_ensure_wide_tables(h, stream)) return rcw;
   if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");
   char* base = static_cast<char*>(ws);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };

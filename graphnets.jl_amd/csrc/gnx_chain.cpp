@@ -114,6 +114,8 @@ extern "C" {
 
 size_t gnx_chain_block_workspace_bytes(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t R) {
   if (check_params(h, p, R) != GNX_OK) return 0;
+  // further layers of a chain are row-wise Dense launches on the matrix-core kernel: its tables are built here, outside any capture
+  if (p->edgefn.n_layers > 1 || p->nodefn.n_layers > 1 || p->graphfn.n_layers > 1 || out_width(p->edgefn) == 0) (void)gnx_ensure_wide_tables(h);
   return layout(h, p, R).total;
 }
 

@@ -336,7 +336,7 @@ int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d,
   if (nrows == 0) return GNX_OK;
   if (ln_stats && (!ln || !ln->gamma || !ln->beta || ((uintptr_t)ln->gamma & 15) || ((uintptr_t)ln->beta & 15) || ((uintptr_t)ln_stats & 7)))
     return fail(GNX_ERR_INVALID_ARG, "k_ffn_fused: LayerNorm parameters missing or misaligned");
-  if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
+  if (int32_t rcw = gnx_ensure_wide_tables(h, s)) return rcw;
   FfnArgs a{};
   a.tiles = entity == 0 ? h->d_etiles : (entity == 1 ? h->d_ntiles : h->d_gtiles);
   a.row_kind = entity == 0 ? 0 : 1;

@@ -32,6 +32,7 @@ static_assert(GNX_ACT_IDENTITY == 0 && GNX_ACT_RELU == 1 && GNX_ACT_TANH == 2 &&
               "act_apply (gnx_device.h) hard-codes the activation codes");
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase);
 size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R);
+void warm_block_wide(const gnx_graphs* h, const gnx_block_params* p, bool rows_gemm);
 // narrow-width GNCore kernels (gnx_core_narrow.hip)
 bool core_narrow_width(int d);
 int32_t launch_ln1_rows(const float* x, size_t rows, int d, const gnx_layernorm& l1, float eps, int eps_mode, float* y, hipStream_t s);
@@ -167,7 +168,10 @@ extern "C" {
 
 size_t gnx_block_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
   if (!h || !p || R <= 0) return 0;
-  if (check_block(h, p, R) == GNX_OK) warm_block_narrow(h, p);  // run-time specialisation happens here, not in a capture
+  if (check_block(h, p, R) == GNX_OK) {
+    warm_block_narrow(h, p);        // run-time specialisation happens here, not in a capture
+    warm_block_wide(h, p, false);   // ... and so does the build of the matrix-core tables when these widths take that path
+  }
   return block_ws(h, p, R).total;
 }
 
@@ -227,6 +231,7 @@ static void ensure_aux(const gnx_graphs* h) {
 size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t R) {
   if (!h || !p || R <= 0) return 0;
   ensure_aux(h);
+  warm_block_wide(h, &p->block, ffn_on_mfma(p->block.de) || ffn_on_mfma(p->block.dn) || ffn_on_mfma(p->block.dg));
   size_t off[8], total;
   core_ws(h, p, R, off, &total);
   {  // run-time specialisation of a narrow core's combined FeedForward launch happens here (as for the block: never in a capture)

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void k_fn_input_graph(FnInArgs a) {
 
 int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, const float* nf, int dn, const float* gf, int dg,
                         int64_t R, float* out, hipStream_t s) {
-  if (kind == 0) { if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw; }  // (the edge form reads the destination of every edge)
+  if (kind == 0) { if (int32_t rcw = gnx_ensure_wide_tables(h, s)) return rcw; }  // (the edge form reads the destination of every edge)
   FnInArgs a{ef, nf, gf, de, dn, dg, (int)h->N, (int)h->E, (int)h->G, h->d_colptr, h->d_rowval, h->d_edge_dst, h->d_node_off, h->d_edge_off, out};
   if (kind == 0) {
     const size_t total = (size_t)h->E * (de + 2 * dn + dg);

@@ -338,10 +338,12 @@ static int32_t create_csc_impl(CP colptr_of, RV rowval_of, const int64_t* n_node
     const int64_t n = n_nodes[g], base = h->h_node_off[(size_t)g], ebase = h->h_edge_off[(size_t)g];
     const int64_t* cp = colptr_of(g);
     const int64_t* rv = rowval_of(g);
+    const int64_t eg = h->h_edge_off[(size_t)g + 1] - ebase;  // = cp[n] - index_base: what the arrays were sized with
     int64_t a = 0;  // cp[j] - index_base
     for (int64_t j = 0; j < n; ++j) {
       const int64_t b = cp[j + 1] - index_base;
-      if (b < a || b - a > n) { bad = "colptr must be non-decreasing with at most N entries per column"; break; }
+      // b > eg: a colptr that rises above cp[n] and comes back would be written (and, packed form, read) past the graph's slice
+      if (b < a || b - a > n || b > eg) { bad = "colptr must be non-decreasing with at most N entries per column"; break; }
       int64_t prev = -1;
       for (int64_t k = a; k < b; ++k) {
         const int64_t i = rv[k] - index_base;
@@ -355,7 +357,7 @@ static int32_t create_csc_impl(CP colptr_of, RV rowval_of, const int64_t* n_node
       c32[base + j + 1] = (int32_t)(ebase + b);
       a = b;
     }
-    if (!bad && a != h->h_edge_off[(size_t)g + 1] - ebase) bad = "colptr must be non-decreasing with at most N entries per column";
+    if (!bad && a != eg) bad = "colptr must be non-decreasing with at most N entries per column";
   }
   return bad;
   };
@@ -484,6 +486,39 @@ int32_t gnx_graphs_create_csc_packed(const int64_t* colptr_cat, const int64_t* r
                          [&](int64_t g) { return rowval_cat ? rowval_cat + rvo[(size_t)g] : nullptr; }, n_nodes, n_graphs, index_base, out);
 }
 
+// The length-checked, index-width-tagged form of the packed constructor: what a host binding should call (nothing is read past
+// colptr_len / rowval_len entries, whatever the arrays contain).
+int32_t gnx_graphs_create_csc_cat(const void* colptr_cat, int64_t colptr_len, const void* rowval_cat, int64_t rowval_len, const int64_t* n_nodes,
+                                  int64_t n_graphs, int32_t index_base, int32_t index_bits, gnx_graphs** out) {
+  if (!out) return fail(GNX_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (n_graphs <= 0) return fail(GNX_ERR_NO_GRAPHS, "length(adj_mats) must be > 0 (checks.jl:8)");
+  if (!colptr_cat || !n_nodes) return fail(GNX_ERR_INVALID_ARG, "colptr / n_nodes is NULL");
+  if (index_base != 0 && index_base != 1) return fail(GNX_ERR_INVALID_ARG, "index_base must be 0 or 1");
+  if (index_bits != 32 && index_bits != 64) return fail(GNX_ERR_INVALID_ARG, "index_bits must be 32 or 64");
+  if (colptr_len < 0 || rowval_len < 0) return fail(GNX_ERR_INVALID_ARG, "negative array length");
+  auto cp_at = [&](int64_t i) -> int64_t { return index_bits == 64 ? static_cast<const int64_t*>(colptr_cat)[i] : (int64_t)static_cast<const int32_t*>(colptr_cat)[i]; };
+  int64_t cpo = 0, rvo = 0;
+  for (int64_t g = 0; g < n_graphs; ++g) {
+    if (n_nodes[g] <= 0) return fail(GNX_ERR_ADJ_SHAPE, "graph must have N >= 1 nodes and a colptr");
+    if (n_nodes[g] + 1 > colptr_len - cpo) return fail(GNX_ERR_INVALID_ARG, "colptr_cat is shorter than sum(n_nodes) + n_graphs entries");
+    cpo += n_nodes[g] + 1;
+    const int64_t eg = cp_at(cpo - 1) - index_base;
+    if (eg < 0) return fail(GNX_ERR_CSC, "colptr must be non-decreasing with at most N entries per column");
+    if (eg > rowval_len - rvo) return fail(GNX_ERR_INVALID_ARG, "rowval_cat is shorter than the edges the colptr arrays announce");
+    rvo += eg;
+  }
+  if (cpo != colptr_len) return fail(GNX_ERR_INVALID_ARG, "colptr_cat must hold exactly sum(n_nodes) + n_graphs entries");
+  if (rvo != rowval_len) return fail(GNX_ERR_INVALID_ARG, "rowval_cat must hold exactly the edges the colptr arrays announce");
+  if (rvo > 0 && !rowval_cat) return fail(GNX_ERR_CSC, "rowval is NULL but the graph has edges");
+  if (index_bits == 64) return gnx_graphs_create_csc_packed(static_cast<const int64_t*>(colptr_cat), static_cast<const int64_t*>(rowval_cat), n_nodes, n_graphs, index_base, out);
+  // 32-bit indices on the host path: widened copies (the device-side builder reads them as they are)
+  std::vector<int64_t> c64((size_t)colptr_len), r64((size_t)rowval_len);
+  for (int64_t i = 0; i < colptr_len; ++i) c64[(size_t)i] = static_cast<const int32_t*>(colptr_cat)[i];
+  for (int64_t i = 0; i < rowval_len; ++i) r64[(size_t)i] = static_cast<const int32_t*>(rowval_cat)[i];
+  return gnx_graphs_create_csc_packed(c64.data(), r64.empty() ? nullptr : r64.data(), n_nodes, n_graphs, index_base, out);
+}
+
 int32_t gnx_graphs_destroy(gnx_graphs* h) {
   if (!h) return GNX_OK;
   (void)hipFree(h->d_arena);  // colptr, rowval, node / edge / tile offsets, tiles, wave tiles, packs
@@ -550,11 +585,35 @@ static int32_t build_csr(const gnx_graphs* h) {
   return GNX_OK;
 }
 
-int32_t gnx_ensure_wide_tables(const gnx_graphs* h) {
+// frees whatever a failed build_wide_tables left behind, so that a later call starts from nothing
+static void drop_wide_tables(const gnx_graphs* h) {
+  void** dev[] = {(void**)&h->d_edge_dst, (void**)&h->d_chunk_row0, (void**)&h->d_node_agg_row, (void**)&h->d_node_agg_parts, (void**)&h->d_node_agg_chunk,
+                  (void**)&h->d_etiles, (void**)&h->d_ntiles, (void**)&h->d_gtiles, (void**)&h->d_etile_off, (void**)&h->d_ntile_off};
+  for (void** d : dev) { if (*d) (void)hipFree(*d); *d = nullptr; }
+  h->h_etiles.clear(); h->h_ntiles.clear(); h->h_gtiles.clear();
+  h->n_agg_rows = 0; h->n_etiles_wide_span = 0;
+}
+
+// Built by the workspace queries of every path that reads them (callers run those outside a capture); a launcher that still finds them
+// missing builds them here — unless `stream` is being captured (hipMalloc + synchronous copies are not capturable): that is an error
+// the caller can act on, and it is NOT remembered: the next call outside the capture builds the tables.  A failed build frees its
+// partial allocations, keeps its own message in gnx_last_error() and may be retried.
+int32_t gnx_ensure_wide_tables(const gnx_graphs* h, void* stream) {
   if (!h) return fail(GNX_ERR_INVALID_ARG, "NULL handle");
-  std::call_once(h->wide_once, [&] { h->wide_rc = build_wide_tables(h); });
-  if (h->wide_rc) set_error("wide-path tables could not be built");
-  return h->wide_rc;
+  if (h->wide_built.load(std::memory_order_acquire)) return GNX_OK;
+  if (stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) { (void)hipGetLastError(); st = hipStreamCaptureStatusActive; }
+    if (st != hipStreamCaptureStatusNone)
+      return fail(GNX_ERR_INVALID_ARG, "the matrix-core tables of this handle are not built yet and the stream is being captured: call the "
+                                       "gnx_*_workspace_bytes query of this layer (or one eager forward) before the capture");
+  }
+  std::lock_guard<std::mutex> lk(h->wide_mu);
+  if (h->wide_built.load(std::memory_order_relaxed)) return GNX_OK;
+  const int32_t rc = build_wide_tables(h);
+  if (rc) { drop_wide_tables(h); return rc; }  // (the message of the failing step stays in gnx_last_error())
+  h->wide_built.store(true, std::memory_order_release);
+  return GNX_OK;
 }
 
 int32_t gnx_ensure_csr(const gnx_graphs* h) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 #include <memory>
 #include <string>
@@ -58,8 +59,8 @@ struct gnx_graphs {
   int64_t n_etiles = 0, n_ntiles = 0, n_gtiles = 0;
   int64_t agg_rows_bound = 0;     // >= n_agg_rows, known without the tables: non-empty nodes + one row per chunk
   std::vector<int32_t> h_etile_off, h_ntile_off;  // [G+1] (eager: O(G))
-  mutable std::once_flag wide_once;
-  mutable int32_t wide_rc = 0;
+  mutable std::mutex wide_mu;                 // serialises the build; a failed build leaves nothing behind and may be retried
+  mutable std::atomic<bool> wide_built{false};
   mutable int32_t* d_edge_dst = nullptr;  // [E]
   mutable std::vector<gnx::Tile> h_etiles, h_ntiles, h_gtiles;  // h_gtiles: 128-row chunks of the graph rows (n0/n1 = graph ids)
   mutable gnx::Tile* d_etiles = nullptr;
@@ -132,8 +133,9 @@ bool profile_enabled();  // per-kernel timing is on: callers keep everything on 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace gnx
-// builds the wide-path tables of a handle on first use (returns GNX_OK or the error of the first attempt)
-extern "C" int32_t gnx_ensure_wide_tables(const gnx_graphs* h);
+// builds the wide-path tables of a handle if they do not exist yet (the workspace queries call it; launchers call it with their stream:
+// inside a capture a missing table is an error, not a build).  A failure is not latched.
+extern "C" int32_t gnx_ensure_wide_tables(const gnx_graphs* h, void* stream = nullptr);
 namespace gnx {
 
 

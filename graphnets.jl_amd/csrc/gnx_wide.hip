@@ -1295,7 +1295,7 @@ int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K
                           const float* add2, float* out, int64_t R, hipStream_t s, const char* name) {
   const size_t nrows = entity == 0 ? (size_t)h->E : (entity == 1 ? (size_t)h->N : (size_t)h->G);
   if (nrows == 0 || OUT == 0) return GNX_OK;
-  if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
+  if (int32_t rcw = gnx_ensure_wide_tables(h, s)) return rcw;
   WideArgs w{};
   w.tiles = entity == 0 ? h->d_etiles : (entity == 1 ? h->d_ntiles : h->d_gtiles);
   w.row_kind = entity == 0 ? 0 : 1;
@@ -1318,7 +1318,7 @@ int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int 
                            hipStream_t s, const char* name, const float* gmul, int gmul_act, float* tile_colsum, int* n_tiles_out, const float* add1) {
   const size_t nrows = entity == 0 ? (size_t)h->E : (entity == 1 ? (size_t)h->N : (size_t)h->G);
   if (nrows == 0 || OUT == 0 || K == 0) return GNX_OK;
-  if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
+  if (int32_t rcw = gnx_ensure_wide_tables(h, s)) return rcw;
   WideArgs w{};
   w.tiles = entity == 0 ? h->d_etiles : (entity == 1 ? h->d_ntiles : h->d_gtiles);
   w.row_kind = entity == 0 ? 0 : 1;
@@ -1353,6 +1353,20 @@ static bool wide_applies(const gnx_graphs* h, const BlockArgs& a, bool* project_
   return true;
 }
 
+// Workspace queries (outside any capture) build the handle's matrix-core tables when a forward with these widths can read them: the wide
+// block itself, or a row-wise Dense on the matrix cores (a core's FeedForward from width 32, a Chain's further layers: `rows_gemm`).
+void warm_block_wide(const gnx_graphs* h, const gnx_block_params* p, bool rows_gemm) {
+  bool need = rows_gemm;
+  if (!need && p) {
+    BlockArgs a{};
+    a.de = p->de; a.dn = p->dn; a.dg = p->dg; a.oe = p->oe; a.on = p->on; a.og = p->og;
+    a.N = (int)h->N; a.E = (int)h->E; a.G = (int)h->G;
+    bool project = false;
+    need = wide_applies(h, a, &project);
+  }
+  if (need) (void)gnx_ensure_wide_tables(h);  // a failure is not latched: the forward reports it
+}
+
 // The wide path can normalise ef and nf as it loads them (BlockArgs::ln_stats): every launch that reads them is then a quad-row,
 // quad-output GEMM with the features as mode-0 segments — the projected form with widths that are multiples of 4.
 bool block_wide_ln_applies(const gnx_graphs* h, const BlockArgs& a) {
@@ -1366,7 +1380,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   bool project = false;
   if (!wide_applies(h, a, &project)) return 1;
   if ((a.ln_stats[0] || a.ln_stats[1]) && !block_wide_ln_applies(h, a)) return fail(GNX_ERR_INVALID_ARG, "launch_block_wide: LayerNorm on load is not applicable to this block");
-  if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
+  if (int32_t rcw = gnx_ensure_wide_tables(h, s)) return rcw;
   const size_t n_et = (size_t)h->n_etiles, n_nt = (size_t)h->n_ntiles;
   // workspace layout inside a.partials (sized by gnx_block_workspace_bytes >= wide_workspace_bytes)
   float* pe = a.partials;

@@ -19,9 +19,13 @@
  *   - Dense weights are (out x in) column-major = Flux `Dense.weight` bytes: W[k*out + j]; device pointers.
  *   - The caller owns every buffer; the library owns only gnx_graphs handles (and, for gnx_model, the model's intermediate
  *     tensors).  `stream` is a hipStream_t (NULL = default stream); calls are asynchronous on it and hipGraph-capturable (no
- *     allocation, no sync) with three documented exceptions that happen once, outside any capture: the first use of a width
+ *     allocation, no sync) with four documented exceptions that happen once, outside any capture: the first use of a width
  *     set that needs a run-time specialised kernel (see gnx_jit_*), the first backward / edge-collapsing call on a handle
- *     (builds the CSR / collapse tables of the handle), and gnx_model_forward (which manages its own hipGraph).
+ *     (builds the CSR / collapse tables of the handle), the handle's matrix-core tables (widths from 32: built by the
+ *     gnx_*_workspace_bytes query of the layer — every caller runs that query before a forward, outside a capture; a forward,
+ *     backward or gnx_fn_input(kind 0) that still finds them missing builds them itself, or, when its stream is being captured,
+ *     fails with GNX_ERR_INVALID_ARG and a message saying so — not remembered: the next call outside the capture succeeds), and
+ *     gnx_model_forward (which manages its own hipGraph).
  *   - The library uses the calling thread's current HIP device; a handle lives on the device it was created on.
  */
 #ifndef GNX_H
@@ -152,6 +156,12 @@ GNX_API int32_t gnx_graphs_create_csc(const int64_t* const* colptr, const int64_
  * pays per graph to build pointer arrays (8 ms for 4096 graphs through ctypes) is the larger part of batch() on many small graphs. */
 GNX_API int32_t gnx_graphs_create_csc_packed(const int64_t* colptr_cat, const int64_t* rowval_cat, const int64_t* n_nodes, int64_t n_graphs,
                                      int32_t index_base, gnx_graphs** out);
+
+/* the packed form WITH its array lengths and index width — what a host binding should call: colptr_cat / rowval_cat hold colptr_len /
+ * rowval_len indices of index_bits (32 or 64) bits each; the call fails with GNX_ERR_INVALID_ARG unless colptr_len = sum(n_nodes) + n_graphs
+ * and rowval_len = the edges the colptr arrays announce, and never reads past either length whatever the arrays contain. */
+GNX_API int32_t gnx_graphs_create_csc_cat(const void* colptr_cat, int64_t colptr_len, const void* rowval_cat, int64_t rowval_len,
+                                  const int64_t* n_nodes, int64_t n_graphs, int32_t index_base, int32_t index_bits, gnx_graphs** out);
 
 GNX_API int32_t gnx_graphs_destroy(gnx_graphs* h);
 GNX_API int32_t gnx_graphs_get_info(const gnx_graphs* h, gnx_graphs_info* out);

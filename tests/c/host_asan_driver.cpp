@@ -133,6 +133,40 @@ int main() {
       rvp[0] = rvs[0].data();
     }
   }
+  // ---- malformed: a colptr that rises above colptr[n] and comes back (arrays are sized from colptr[n]; the old per-column
+  //      check let the columns above it be written before the decrease was seen).  As the LAST graph, so the stray writes would fall
+  //      behind the end of the allocation, with rowval sized generously so that only the library's own write can overflow ----
+  for (int base = 0; base < 2; ++base) {
+    std::vector<int64_t> cp0 = {0, 1, 2, 3}, rv0 = {0, 1, 2};            // a well-formed 3-node graph first
+    std::vector<int64_t> cp1 = {0, 4, 8, 4, 4}, rv1(64);                  // n = 4: rises to 8, returns to cp[n] = 4
+    for (size_t i = 0; i < rv1.size(); ++i) rv1[i] = (int64_t)(i % 4);
+    for (auto* v : {&cp0, &rv0, &cp1, &rv1}) for (auto& x : *v) x += base;
+    const int64_t nn[2] = {3, 4};
+    const int64_t* cpp[2] = {cp0.data(), cp1.data()};
+    const int64_t* rvp[2] = {rv0.data(), rv1.data()};
+    gnx_graphs* h = nullptr;
+    EXPECT(gnx_graphs_create_csc(cpp, rvp, nn, 2, base, &h) == GNX_ERR_CSC && h == nullptr);
+    std::vector<int64_t> cpc(cp0), rvc(rv0);
+    cpc.insert(cpc.end(), cp1.begin(), cp1.end());
+    rvc.insert(rvc.end(), rv1.begin(), rv1.begin() + 4);                  // the packed form holds exactly cp[n] entries for the graph
+    h = nullptr;
+    EXPECT(gnx_graphs_create_csc_packed(cpc.data(), rvc.data(), nn, 2, base, &h) == GNX_ERR_CSC && h == nullptr);
+    EXPECT(gnx_graphs_create_csc_cat(cpc.data(), (int64_t)cpc.size(), rvc.data(), (int64_t)rvc.size(), nn, 2, base, 64, &h) == GNX_ERR_CSC && h == nullptr);
+    // the length-checked packed form refuses arrays shorter or longer than the graphs need, and takes 32-bit indices
+    std::vector<int64_t> okc(cp0), okr(rv0);
+    EXPECT(gnx_graphs_create_csc_cat(okc.data(), (int64_t)okc.size() - 1, okr.data(), (int64_t)okr.size(), nn, 1, base, 64, &h) == GNX_ERR_INVALID_ARG && h == nullptr);
+    EXPECT(gnx_graphs_create_csc_cat(okc.data(), (int64_t)okc.size(), okr.data(), (int64_t)okr.size() - 1, nn, 1, base, 64, &h) == GNX_ERR_INVALID_ARG && h == nullptr);
+    EXPECT(gnx_graphs_create_csc_cat(okc.data(), (int64_t)okc.size(), okr.data(), (int64_t)okr.size(), nn, 1, base, 16, &h) == GNX_ERR_INVALID_ARG && h == nullptr);
+    {
+      std::vector<int32_t> c32(cpc.begin(), cpc.end()), r32(rvc.begin(), rvc.end());  // the malformed pair again, as 32-bit indices
+      EXPECT(gnx_graphs_create_csc_cat(c32.data(), (int64_t)c32.size(), r32.data(), (int64_t)r32.size(), nn, 2, base, 32, &h) == GNX_ERR_CSC && h == nullptr);
+      std::vector<int32_t> oc32(okc.begin(), okc.end()), or32(okr.begin(), okr.end());
+      const int32_t rc32 = gnx_graphs_create_csc_cat(oc32.data(), (int64_t)oc32.size(), or32.data(), (int64_t)or32.size(), nn, 1, base, 32, &h);
+      EXPECT((rc32 == GNX_OK) == (h != nullptr) && rc32 >= 0);  // well-formed: a handle, or (no GPU) a HIP error code
+      if (h) gnx_graphs_destroy(h);
+      h = nullptr;
+    }
+  }
   {
     gnx_graphs* h = nullptr;
     EXPECT(gnx_graphs_create_csc(nullptr, nullptr, nullptr, 1, 0, &h) == GNX_ERR_INVALID_ARG);

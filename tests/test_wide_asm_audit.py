@@ -87,3 +87,64 @@ def test_untracked_source_row_loads_are_not_touched_before_their_wait(wide_asm):
                 assert i < regs[r], f"{name}: '{code.strip()}' touches v{r} between its untracked load and the wait"
         audited += 1
     assert audited >= 2
+
+
+def test_lds_dma_of_the_destination_rows_is_retired_before_the_barrier_that_publishes_it(wide_asm):
+    """NL = 3: the tile's destination projections are written into LDS by `global_load_lds` from ONE wave and read by the
+    others.  The source has no explicit wait — the design relies on the `s_waitcnt vmcnt(0)` the compiler places in front of the
+    next workgroup barrier.  This walks the control-flow graph of the compiled kernel from every LDS-DMA instruction: on EVERY path
+    the first `s_barrier` reached must come after an `s_waitcnt` with `vmcnt(0)` (and no later LDS-DMA).  A compiler update that
+    drops or weakens that wait turns into a test failure instead of a silent race."""
+    audited = 0
+    for name, (body, _) in wide_asm.items():
+        if _args(name)[3] != 3:
+            continue
+        lines = [l.split(";")[0].rstrip() for l in body.split("\n")]
+        label_at = {}
+        for i, l in enumerate(lines):
+            m = re.match(r"^(\.LBB\w+):", l)
+            if m:
+                label_at[m.group(1)] = i
+        dma = [i for i, l in enumerate(lines) if "global_load_lds" in l]
+        assert dma, name
+
+        def successors(i):
+            code = lines[i].strip()
+            if code.startswith("s_endpgm"):
+                return []
+            m = re.match(r"s_branch\s+(\.LBB\w+)", code)
+            if m:
+                return [label_at[m.group(1)]]
+            m = re.match(r"s_cbranch_\w+\s+(\.LBB\w+)", code)
+            if m:
+                return [label_at[m.group(1)], i + 1]
+            assert not re.match(r"s_setpc|s_swappc|s_call", code), (name, code)  # no indirect control flow expected
+            return [i + 1] if i + 1 < len(lines) else []
+
+        barriers_checked = 0
+        seen = set()
+        stack = [(i + 1, False) for i in dma]
+        while stack:
+            i, waited = stack.pop()
+            while i < len(lines):
+                if (i, waited) in seen:
+                    break
+                seen.add((i, waited))
+                code = lines[i].strip()
+                if "global_load_lds" in code:
+                    waited = False
+                elif code.startswith("s_waitcnt") and re.search(r"vmcnt\(0\)", code):
+                    waited = True
+                elif code.startswith("s_barrier"):
+                    assert waited, f"{name}: s_barrier at .s line {i} reachable from an LDS-DMA without s_waitcnt vmcnt(0) in between"
+                    barriers_checked += 1
+                    break  # published: later barriers are not this audit's business
+                nxt = successors(i)
+                if not nxt:
+                    break
+                for j in nxt[:-1]:
+                    stack.append((j, waited))
+                i = nxt[-1]
+        assert barriers_checked >= 1, name
+        audited += 1
+    assert audited >= 2

@@ -1,5 +1,7 @@
+#!/bin/bash
 # the driver's invocation (headline + secondary configs in ONE line) and two extra lines, kept under profiles/
-cd $GRAFT_REPO_ROOT
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+mkdir -p gpurun_out
 timeout -k 10 400 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_r03_default.json 2> gpurun_out/bench_r03_default.err; echo "default rc=$?"
 timeout -k 10 300 python bench.py --gpus 1 --steps 200 --warmup 20 --no-secondary > gpurun_out/bench_r03_readme_200.json 2>/dev/null; echo "readme200 rc=$?"
 timeout -k 10 300 python bench.py --force-dist --steps 40 --warmup 5 --no-cpu-baseline > gpurun_out/bench_r03_forcedist.json 2>/dev/null; echo "forcedist rc=$?"
