@@ -196,7 +196,7 @@ def c4_cpu_baseline(ps, budget_s=6.0):
         scale *= 4
 
 
-def bench_c4(args, gn, torch, dev):
+def bench_c4(args, gn, torch, dev, c_abi=None):
     """BASELINE configs[3]: Encoder -> 2 x GNCore -> Decoder (README Example 3) at core_dims (128,64,32) on the C2 graph.
     One "step" = the whole 4-layer model forward; reported as edges/s through the model."""
     colptrs, rowvals, nn = make_c2()
@@ -276,6 +276,11 @@ def bench_c4(args, gn, torch, dev):
                             "counts": "algorithmic bytes of the four layers (every layer's inputs and outputs once, SURVEY 8d; a core = its block's bytes) / whole-step time",
                             "algorithmic_bytes": ab, "executed_flops": ex, "traffic": traffic, "traffic_source": tsrc}
     assert line["roofline"]["frac"] <= 1.0
+    if c_abi is not None:  # the same model as ONE gnx_model driven from plain C (library-owned intermediates and hipGraph)
+        line["c_abi_ms_per_step"] = round(c_abi["model_us_per_step"] * 1e-3, 4) if "model_us_per_step" in c_abi else None
+        line["c_abi"] = ({"vs_torch_captured": round(c_abi["model_us_per_step"] * 1e-3 / (dt * 1e3), 4), "what": c_abi.get("model_what"), "reps_us": c_abi.get("model_reps_us"),
+                          "event_us_per_step": c_abi.get("model_event_us_per_step"), "batch_ms": c_abi.get("batch_ms"), "program": "tests/c/abi_bench.c --mode c4"}
+                         if "model_us_per_step" in c_abi else c_abi)
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = c4_cpu_baseline(ps)
     print(json.dumps(line))
@@ -327,12 +332,39 @@ def collect_secondary(args):
         ts = roof.get("traffic_source")
         if ts:
             entry["roofline"]["traffic_source"] = {k: ts.get(k) for k in ("file", "commit", "stale") if ts.get(k) is not None}
-        for k in ("batch_ms", "kernel_us_one_forward", "pipelined_two_streams"):
+        for k in ("batch_ms", "kernel_us_one_forward", "pipelined_two_streams", "c_abi_ms_per_step", "c_abi"):
             if k in line or k in line.get("config", {}):
                 entry[k] = line.get(k, line.get("config", {}).get(k))
         out[key] = entry
     out["_wall_s"] = round(time.perf_counter() - t_all, 1)
     return out
+
+
+def c_abi_bench(mode, steps, warmup, extra=(), timeout=240):
+    """tests/c/abi_bench.c as a child process (BEFORE this process touches the GPU): the same workload through include/gnx.h from plain C —
+    no Python, no torch in the loop.  Built with gcc on first use (the box has no prebuilt copy when tests/c/_build did not travel).  The C2
+    graph of THIS script goes over as a file, so the C program runs bench.py's exact graph.  Returns abi_bench's JSON line (or an error)."""
+    import tempfile
+    cdir = os.path.join(ROOT, "tests", "c")
+    exe = os.path.join(cdir, "_build", "abi_bench")
+    try:
+        lib = os.path.join(ROOT, "graphnets.jl_amd", "libgnx.so")
+        if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(lib), os.path.getmtime(os.path.join(cdir, "abi_bench.c"))):
+            subprocess.run(["make", "-s", "-C", cdir, exe], check=True, capture_output=True, timeout=120)
+        colptrs, rowvals, nn = make_c2()
+        with tempfile.NamedTemporaryFile(suffix=".c2.bin", delete=False) as f:
+            f.write(np.array([nn[0], len(rowvals[0])], dtype=np.int64).tobytes() + colptrs[0].astype(np.int64).tobytes() + rowvals[0].astype(np.int64).tobytes())
+            path = f.name
+        try:
+            r = subprocess.run([exe, "--mode", mode, "--steps", str(steps), "--warmup", str(warmup), "--csc", path] + list(extra),
+                               capture_output=True, text=True, timeout=timeout)
+        finally:
+            os.unlink(path)
+        if r.returncode != 0 or not r.stdout.strip():
+            return {"error": (r.stderr or r.stdout or "no output")[-300:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # build failure, timeout, malformed output: reported, never fatal for the headline
+        return {"error": repr(e)[:300]}
 
 
 def self_launch(args):
@@ -375,6 +407,7 @@ def main():
     ap.add_argument("--c2-scale", type=float, default=1.0, help="scale C2's nodes and edges by this factor (size sweeps; 1 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs of the default N = 1 line")
+    ap.add_argument("--no-c-abi", action="store_true", help="skip the torch-free C program's leg (c_abi_ms_per_step)")
     ap.add_argument("--cpu-budget", type=float, default=None, help="seconds of CPU baseline sampling (default 3 at README dims, 12 at wide dims)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--dense-baseline", action="store_true",
@@ -395,6 +428,13 @@ def main():
     headline = (args.gpus == 1 and "RANK" not in os.environ and args.dims == "readme" and args.workload in (None, "c2") and args.model == "block"
                 and not args.force_dist and args.c2_scale == 1.0 and args.flags == 0 and not args.overlap)
     secondary = collect_secondary(args) if headline and not args.no_secondary else None
+    # the same workload through the C boundary WITHOUT Python / torch (tests/c/abi_bench.c), as a child process before this one touches the GPU
+    c_abi = None
+    if args.gpus == 1 and "RANK" not in os.environ and not args.no_c_abi and not args.force_dist and args.c2_scale == 1.0 and args.flags == 0 and not args.overlap:
+        if args.model == "c4":
+            c_abi = c_abi_bench("c4", max(3, min(args.steps, 10)), 2, ["--core-dims", args.core_dims])
+        elif args.dims == "readme" and args.workload in (None, "c2"):
+            c_abi = c_abi_bench("block", max(args.steps, 20), max(args.warmup, 8))
 
     import torch
     import torch.distributed as dist
@@ -415,7 +455,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     K, W = args.steps, args.warmup
     if args.model == "c4":
-        return bench_c4(args, gn, torch, dev)
+        return bench_c4(args, gn, torch, dev, c_abi)
     if args.dims in DIMS:
         din, dout = DIMS[args.dims]
     else:
@@ -720,6 +760,15 @@ def main():
                        "graphs_per_gpu": G, "edges_whole_job": E_job, "parallelism": f"graph-sharded x{world}" if world > 1 else "single GPU", **extra},
             "roofline": roof, "cpu_baseline": cpu, "batch_ms": batch_ms,
         }
+        if c_abi is not None:
+            if "captured_us_per_step" in c_abi:
+                line["c_abi_ms_per_step"] = round(c_abi["captured_us_per_step"] * 1e-3, 6)
+                line["c_abi"] = {"vs_torch_captured": round(c_abi["captured_us_per_step"] * 1e-3 / ms_per_step, 4), "what": c_abi.get("captured_what"),
+                                 "reps_us": c_abi.get("captured_reps_us"), "event_us_per_step": c_abi.get("captured_event_us_per_step"),
+                                 "model_forward_ms_per_step": round(c_abi["model_us_per_step"] * 1e-3, 6), "model_forward_what": c_abi.get("model_what"),
+                                 "batch_ms": c_abi.get("batch_ms"), "steps": c_abi.get("steps"), "program": "tests/c/abi_bench.c --mode block"}
+            else:
+                line["c_abi_ms_per_step"], line["c_abi"] = None, c_abi
         if pipelined is not None:
             line["pipelined_two_streams"] = pipelined
         if secondary is not None:

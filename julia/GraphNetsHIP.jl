@@ -2,9 +2,17 @@
 # hot path: GNBlock(in => out), block(x), GNCore, GNCoreList, batch, unbatch, efview/nfview/gfview, flatunpadded*.
 #
 # Status: shipped as source.  Julia is not installed in the build image nor on the GPU box, so this file is NOT
-# exercised by the test-suite; the tested host mirror of the same ABI is graphnets.jl_amd/api.py.  Host `Array`s are
-# staged through `hipMalloc`/`hipMemcpy` (libamdhip64); with AMDGPU.jl, `ROCArray` pointers can be passed straight
-# to the `gnx_*` calls instead (the ABI takes raw device pointers).
+# exercised by the test-suite (tests/test_julia_shim_lint.py holds it to the header statically); the tested host mirror of
+# the same ABI is graphnets.jl_amd/api.py.
+#
+# Device residency (the reference: `x |> batch |> device`, `model |> device`, examples/sort/sort.jl:29,38,44,89; movable fields
+# src/gngraphbatch.jl:19-31; `Functors.@functor GNBlock` src/gnblock.jl:8): `gpu(x)` moves a batched tuple / a layer / a model to
+# the device ONCE — features and weights become `DeviceArray`s (pointer + dims over a pooled hipMalloc block), the GNGraphBatch's
+# tables already live there — and every call operator on device inputs is then ONE asynchronous `gnx_*` call on `STREAM[]`: no
+# hipMalloc (outputs and workspaces come from a size-class pool / a per-batch cache), no hipMemcpy, no synchronisation; its
+# outputs are `DeviceArray`s that the next layer takes as they are.  `cpu(y)` (or `Array(a)`) is where the host waits.
+# Host `Array`s keep working: a call operator given host arrays moves them (and host-resident weights) to the device, runs the
+# same device path and brings the result back — the convenience path, PCIe-bound by construction.
 #
 # Layout note: a Julia `Array{Float32,3}` of size (D, T, B) is byte-identical to the ABI's packed [B][T][D] rows, and
 # `Dense.weight` (out × in, column-major) is byte-identical to `gnx_dense.weight`; nothing is transposed or copied on
@@ -17,6 +25,8 @@ export GNGraphBatch, batch, unbatch, getedgefninput, getnodefninput, getgraphfni
        efview, nfview, gfview, flatunpaddednf, flatunpaddedef, collapsef, unpaddedcollapsedef, flatunpaddedcollapsedef
 # ... plus what the drop-in adds: layers as plain structs, pullbacks, the library-side hipGraph model, the multi-GPU split
 export Dense, LayerNorm, ChainBlock, chain_pullback, block_pullback, core_pullback, Model, partition_graphs, DistBlock
+# ... and device residency: `x |> batch |> gpu`, `model |> gpu`, `y |> cpu` (what Flux's `gpu` / `cpu` are to the reference)
+export DeviceArray, gpu, cpu, synchronize
 
 const libgnx = get(ENV, "GNX_LIB", joinpath(@__DIR__, "..", "graphnets.jl_amd", "libgnx.so"))
 const libhip = get(ENV, "GNX_HIP_LIB", "libamdhip64.so")
@@ -29,30 +39,127 @@ function check(rc::Integer)
 end
 hipcheck(rc) = rc == 0 ? nothing : error("HIP error $(rc)")
 
-# ---- tiny device-buffer helper (replace by AMDGPU.ROCArray if available) ----
+# ---- device memory: a size-class pool over hipMalloc.  Steady state (the same shapes call after call) allocates nothing: a block whose
+#      Julia owner was collected goes back to the free list of its class and the next request of that class takes it.  Everything this
+#      module enqueues runs on ONE stream (STREAM[]; NULL = the default stream), so a recycled block is written by work that is
+#      ordered behind the work that last read it. ----
+const STREAM = Ref{Ptr{Cvoid}}(C_NULL)
+const POOL = Dict{Tuple{Int32,Int},Vector{Ptr{Cvoid}}}()          # (device, class bytes) => free blocks
+const POOL_LOCK = ReentrantLock()
+currentdevice() = (d = Ref{Cint}(0); hipcheck(ccall((:hipGetDevice, libhip), Cint, (Ptr{Cint},), d)); Int32(d[]))
+setdevice(dev::Integer) = hipcheck(ccall((:hipSetDevice, libhip), Cint, (Cint,), dev))
+poolclass(bytes::Integer) = bytes <= 256 ? 256 : (bytes <= (1 << 20) ? nextpow(2, Int(bytes)) : ((Int(bytes) + (1 << 20) - 1) >> 20) << 20)
+function poolmiss(cap::Integer)                                   # the ONLY hipMalloc of this module: a class with no free block
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    hipcheck(ccall((:hipMalloc, libhip), Cint, (Ptr{Ptr{Cvoid}}, Csize_t), p, cap))
+    p[]
+end
 mutable struct DevBuf
     ptr::Ptr{Cvoid}
     bytes::Int
+    cap::Int
+    dev::Int32
     function DevBuf(bytes::Integer)
-        p = Ref{Ptr{Cvoid}}(C_NULL)
-        hipcheck(ccall((:hipMalloc, libhip), Cint, (Ptr{Ptr{Cvoid}}, Csize_t), p, max(bytes, 16)))
-        b = new(p[], bytes)
-        finalizer(x -> ccall((:hipFree, libhip), Cint, (Ptr{Cvoid},), x.ptr), b)
+        dev = currentdevice(); cap = poolclass(bytes)
+        p = lock(POOL_LOCK) do
+            fl = get(POOL, (dev, cap), nothing)
+            (fl === nothing || isempty(fl)) ? C_NULL : pop!(fl)
+        end
+        b = new(p == C_NULL ? poolmiss(cap) : p, Int(bytes), cap, dev)
+        finalizer(release, b)
         b
     end
 end
-function upload(a::Array{Float32})
-    b = DevBuf(sizeof(a))
-    hipcheck(ccall((:hipMemcpy, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), b.ptr, a, sizeof(a), 1))
-    b
+function release(b::DevBuf)                                       # finalizer: back to the pool (never blocks: retried at the next GC)
+    if islocked(POOL_LOCK) || !trylock(POOL_LOCK)
+        finalizer(release, b)
+        return nothing
+    end
+    try
+        push!(get!(() -> Ptr{Cvoid}[], POOL, (b.dev, b.cap)), b.ptr)
+    finally
+        unlock(POOL_LOCK)
+    end
+    nothing
 end
-upload(::Nothing) = nothing
-function download!(a::Array{Float32}, b::DevBuf)
-    hipcheck(ccall((:hipMemcpy, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), a, b.ptr, sizeof(a), 2))
-    a
+function trim_pool!()                                             # give the pooled blocks back to the driver (hipFree waits for the device)
+    lock(POOL_LOCK) do
+        for ((dev, _), fl) in POOL
+            setdevice(dev)
+            foreach(p -> ccall((:hipFree, libhip), Cint, (Ptr{Cvoid},), p), fl)
+            empty!(fl)
+        end
+    end
 end
+synchronize() = hipcheck(ccall((:hipStreamSynchronize, libhip), Cint, (Ptr{Cvoid},), STREAM[]))
+
+# ---- DeviceArray: (D, T, R) Float32 features / weights resident in HBM.  A pointer into a pooled block + dims; `reshape` and the
+#      column-range `view`s that unbatch / efview / nfview / gfview need share the block (packed rows: a graph's columns are contiguous). ----
+struct DeviceArray{N}
+    buf::DevBuf                    # keeps the block alive (views and reshapes share it)
+    offset::Int                    # in elements
+    dims::NTuple{N,Int}
+end
+DeviceArray(dims::Vararg{Integer,N}) where {N} = DeviceArray{N}(DevBuf(4 * prod(dims)), 0, map(Int, dims))   # uninitialised
+Base.size(a::DeviceArray) = a.dims
+Base.size(a::DeviceArray, i::Integer) = i <= length(a.dims) ? a.dims[i] : 1
+Base.ndims(::DeviceArray{N}) where {N} = N
+Base.length(a::DeviceArray) = prod(a.dims)
+Base.sizeof(a::DeviceArray) = 4 * prod(a.dims)
+Base.eltype(::DeviceArray) = Float32
+Base.similar(a::DeviceArray) = DeviceArray(a.dims...)
+function Base.reshape(a::DeviceArray, dims::Union{Integer,Colon}...)
+    known = prod(d -> d isa Colon ? 1 : Int(d), dims)
+    full = map(d -> d isa Colon ? (known == 0 ? 0 : length(a) ÷ known) : Int(d), dims)
+    @assert prod(full) == length(a)
+    DeviceArray{length(full)}(a.buf, a.offset, full)
+end
+Base.reshape(a::DeviceArray, dims::Tuple) = reshape(a, dims...)
+# columns r of slice k of a (D, T, R) array — contiguous in the packed layout — and one column of it
+Base.view(a::DeviceArray{3}, ::Colon, r::AbstractUnitRange{<:Integer}, k::Integer) =
+    DeviceArray{2}(a.buf, a.offset + a.dims[1] * ((first(r) - 1) + a.dims[2] * (Int(k) - 1)), (a.dims[1], length(r)))
+Base.view(a::DeviceArray{3}, ::Colon, ::Colon, k::Integer) = view(a, :, 1:a.dims[2], k)
+Base.view(a::DeviceArray{3}, ::Colon, i::Integer, k::Integer) =
+    DeviceArray{1}(a.buf, a.offset + a.dims[1] * ((Int(i) - 1) + a.dims[2] * (Int(k) - 1)), (a.dims[1],))
+devptr(a::DeviceArray) = Ptr{Cfloat}(a.buf.ptr) + 4 * a.offset
 devptr(b::DevBuf) = Ptr{Cfloat}(b.ptr)
 devptr(::Nothing) = Ptr{Cfloat}(C_NULL)
+
+# ---- host <-> device: the ONLY hipMemcpy calls of this module.  `gpu` / `cpu` are to this shim what Flux's are to the reference:
+#      they map over batched tuples (`(graphs, ef, nf, gf)`: the GNGraphBatch's tables already live on the device — its handle moves
+#      as it is, the analogue of the reference's movable-field list src/gngraphbatch.jl:19-31) and over layers (further below). ----
+function upload(a::Array{Float32,N}) where {N}
+    d = DeviceArray(size(a)...)
+    isempty(a) || hipcheck(ccall((:hipMemcpyAsync, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint, Ptr{Cvoid}), devptr(d), a, sizeof(a), 1, STREAM[]))
+    isempty(a) || synchronize()                                    # (the source is pageable host memory: it may be reused once this returns)
+    d
+end
+upload(::Nothing) = nothing
+function download(d::DeviceArray{N}) where {N}
+    a = Array{Float32,N}(undef, d.dims)
+    prev = currentdevice()
+    prev == d.buf.dev || setdevice(d.buf.dev)
+    synchronize()                                                  # this is where the host waits for the work that produced d
+    isempty(a) || hipcheck(ccall((:hipMemcpy, libhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Cint), a, devptr(d), sizeof(a), 2))
+    prev == d.buf.dev || setdevice(prev)
+    a
+end
+Base.Array(d::DeviceArray) = download(d)
+gpu(::Nothing) = nothing
+gpu(a::DeviceArray) = a
+gpu(a::AbstractArray{<:Real}) = upload(Array{Float32}(a))
+gpu(t::NamedTuple) = map(gpu, t)
+gpu(f::Function) = f
+gpu(x::Number) = x
+cpu(::Nothing) = nothing
+cpu(a::DeviceArray) = download(a)
+cpu(a::AbstractArray) = a
+cpu(t::NamedTuple) = map(cpu, t)
+cpu(f::Function) = f
+cpu(x::Number) = x
+ondevice(a) = a isa DeviceArray
+ondevice(t::NamedTuple) = any(ondevice, (t.ef, t.nf, t.gf))
+back(y, x) = ondevice(x) ? y : cpu(y)                              # results go where the inputs came from
 
 # ---- C structs of include/gnx.h ----
 struct GnxDense
@@ -78,6 +185,7 @@ mutable struct GNGraphBatch
     edge_block_size::Int
     node_off::Vector{Int64}   # 0-based offsets of each graph's nodes / edges in the packed arrays
     edge_off::Vector{Int64}
+    ws::Dict{Any,DevBuf}      # workspaces of the layers that ran on this batch, by (layer kind, widths, replicas): allocated once
     function GNGraphBatch(adj_mats::AbstractVector)
         @assert length(adj_mats) > 0
         mats = [Matrix{Float32}(a) for a in adj_mats]            # column-major, as Julia stores them
@@ -91,7 +199,7 @@ mutable struct GNGraphBatch
         check(ccall((:gnx_graphs_get_info, libgnx), Int32, (Ptr{Cvoid}, Ptr{GnxGraphsInfo}), h[], info))
         no = zeros(Int64, length(mats) + 1); eo = zeros(Int64, length(mats) + 1)
         check(ccall((:gnx_graphs_get_offsets, libgnx), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), h[], no, eo))
-        g = new(h[], collect(adj_mats), info[].node_block_size, info[].edge_block_size, no, eo)
+        g = new(h[], collect(adj_mats), info[].node_block_size, info[].edge_block_size, no, eo, Dict{Any,DevBuf}())
         finalizer(x -> ccall((:gnx_graphs_destroy, libgnx), Int32, (Ptr{Cvoid},), x.handle), g)
         g
     end
@@ -101,18 +209,21 @@ mutable struct GNGraphBatch
     function GNGraphBatch(colptrs::AbstractVector{<:AbstractVector{<:Integer}}, rowvals::AbstractVector{<:AbstractVector{<:Integer}},
                           n_nodes::AbstractVector{<:Integer}; adj_mats::AbstractVector=collect(zip(colptrs, rowvals, n_nodes)))
         @assert length(colptrs) > 0 && length(colptrs) == length(rowvals) == length(n_nodes)
-        cps = [Vector{Int64}(c) for c in colptrs]; rvs = [Vector{Int64}(r) for r in rowvals]
-        cp_ptrs = [pointer(c) for c in cps]; rv_ptrs = [pointer(r) for r in rvs]
+        # ONE array per kind (the graphs' arrays one after the other) and the length-checked entry point: nothing is read past them
+        cpc = Int64[]; rvc = Int64[]
+        for c in colptrs; append!(cpc, c); end
+        for r in rowvals; append!(rvc, r); end
+        cps = colptrs
         nn = Int64.(n_nodes)
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        GC.@preserve cps rvs check(ccall((:gnx_graphs_create_csc, libgnx), Int32,
-            (Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Int64}, Int64, Int32, Ptr{Ptr{Cvoid}}),
-            cp_ptrs, rv_ptrs, nn, length(cps), 1 #=index_base: Julia=#, h))
+        GC.@preserve cpc rvc check(ccall((:gnx_graphs_create_csc_cat, libgnx), Int32,
+            (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Int64}, Int64, Int32, Int32, Ptr{Ptr{Cvoid}}),
+            cpc, length(cpc), rvc, length(rvc), nn, length(nn), 1 #=index_base: Julia=#, 64 #=index_bits=#, h))
         info = Ref{GnxGraphsInfo}()
         check(ccall((:gnx_graphs_get_info, libgnx), Int32, (Ptr{Cvoid}, Ptr{GnxGraphsInfo}), h[], info))
         no = zeros(Int64, length(cps) + 1); eo = zeros(Int64, length(cps) + 1)
         check(ccall((:gnx_graphs_get_offsets, libgnx), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), h[], no, eo))
-        g = new(h[], collect(adj_mats), info[].node_block_size, info[].edge_block_size, no, eo)
+        g = new(h[], collect(adj_mats), info[].node_block_size, info[].edge_block_size, no, eo, Dict{Any,DevBuf}())
         finalizer(x -> ccall((:gnx_graphs_destroy, libgnx), Int32, (Ptr{Cvoid},), x.handle), g)
         g
     end
@@ -123,6 +234,17 @@ issparsecsc(a) = hasproperty(a, :colptr) && hasproperty(a, :rowval) && hasproper
 sparse_batch(mats::AbstractVector) = GNGraphBatch([m.colptr for m in mats], [m.rowval for m in mats], [m.n for m in mats]; adj_mats=mats)
 nnodes(g::GNGraphBatch) = Int(g.node_off[end]); nedges(g::GNGraphBatch) = Int(g.edge_off[end])
 ngraphs(g::GNGraphBatch) = length(g.adj_mats)
+gpu(g::GNGraphBatch) = g                                           # its tables are device-resident from construction (gngraphbatch.jl:19-31)
+cpu(g::GNGraphBatch) = g
+# the workspace of one layer on this batch: sized by the library's query (which also builds what the layer needs outside any
+# capture: specialised kernels, matrix-core tables, the side stream), allocated on first use, reused by every later call
+function workspace!(query::Function, g::GNGraphBatch, key)
+    get!(g.ws, key) do
+        bytes = query()
+        bytes == 0 && error("gnx: ", unsafe_string(ccall((:gnx_last_error, libgnx), Cstring, ())))
+        DevBuf(bytes)
+    end
+end
 
 # ---- batch / unbatch / views  (src/batch.jl:53-64, src/unbatch.jl, src/unpad.jl, src/views.jl) ----
 function batch(t::NamedTuple)
@@ -171,64 +293,74 @@ flatunpaddedef(t::NamedTuple) = reshape(t.ef, size(t.ef, 1), :)
 # ---- the exported building blocks (src/edgefninput.jl:1-47, nodefninput.jl:1-24, graphfninput.jl:1-13) → gnx_fn_input.
 #      Same argument order as the reference; `graphs` is the GNGraphBatch of a batched tuple; features are the packed (D, T, R) arrays
 #      (`nothing` drops the segment, as the reference's methods do).  Result: (K, T, R) over the real edges / nodes / graphs. ----
+width(a) = isnothing(a) ? 0 : size(a, 1)
+replicas(ef, nf, gf) = size(something(ef, nf, gf), 3)
+function fninput_device(kind::Integer, g::GNGraphBatch, ef, nf, gf)
+    R = replicas(ef, nf, gf)
+    T = (nedges(g), nnodes(g), ngraphs(g))[kind + 1]
+    K = width(ef) + (kind == 0 ? 2 : 1) * width(nf) + width(gf)
+    out = DeviceArray(K, T, R)
+    GC.@preserve ef nf gf out check(ccall((:gnx_fn_input, libgnx), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Cfloat}, Int32, Ptr{Cfloat}, Int32, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cvoid}),
+        g.handle, kind, devptr(ef), width(ef), devptr(nf), width(nf), devptr(gf), width(gf), R, devptr(out), STREAM[]))
+    out
+end
 function fninput(kind::Integer, g::GNGraphBatch, ef, nf, gf)
     @assert !isnothing(ef) || !isnothing(nf) || !isnothing(gf)
-    R = size(something(ef, nf, gf), 3)
-    w(a) = isnothing(a) ? 0 : size(a, 1)
-    T = (nedges(g), nnodes(g), ngraphs(g))[kind + 1]
-    K = w(ef) + (kind == 0 ? 2 : 1) * w(nf) + w(gf)
-    out = zeros(Float32, K, T, R)
-    d_ef, d_nf, d_gf, b_out = upload(ef), upload(nf), upload(gf), DevBuf(sizeof(out))
-    GC.@preserve d_ef d_nf d_gf b_out check(ccall((:gnx_fn_input, libgnx), Int32,
-        (Ptr{Cvoid}, Int32, Ptr{Cfloat}, Int32, Ptr{Cfloat}, Int32, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cvoid}),
-        g.handle, kind, devptr(d_ef), w(ef), devptr(d_nf), w(nf), devptr(d_gf), w(gf), R, devptr(b_out), C_NULL))
-    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
-    download!(out, b_out)
+    dev = any(ondevice, (ef, nf, gf))
+    y = fninput_device(kind, g, gpu(ef), gpu(nf), gpu(gf))
+    dev ? y : cpu(y)
 end
 getedgefninput(graphs, edge_features, node_features, graph_features) = fninput(0, graphs, edge_features, node_features, graph_features)
 getnodefninput(graphs, edge_features, node_features, graph_features) = fninput(1, graphs, edge_features, node_features, graph_features)
 getgraphfninput(graphs, edge_features, node_features, graph_features) = fninput(2, graphs, edge_features, node_features, graph_features)
 
 # ---- edge collapsing (src/gngraphbatch.jl:56-111) → gnx_collapse_padded / gnx_collapse_offsets / gnx_collapse_edges ----
-function collapsef(t::NamedTuple)                                      # (DE, PN(PN+1)/2, B), padded array form
-    g = t.graphs; ef = t.ef
+function collapsef_device(g::GNGraphBatch, ef::DeviceArray)            # (DE, PN(PN+1)/2, B), padded array form
     D, R = size(ef, 1), size(ef, 3)
     B = sharedlike(g) ? R : ngraphs(g)
     PN = g.node_block_size
-    out = zeros(Float32, D, PN * (PN + 1) ÷ 2, B)
-    d_ef, b_out = upload(ef), DevBuf(sizeof(out))
-    GC.@preserve d_ef b_out check(ccall((:gnx_collapse_padded, libgnx), Int32, (Ptr{Cvoid}, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cvoid}),
-        g.handle, devptr(d_ef), D, R, devptr(b_out), C_NULL))
-    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
-    download!(out, b_out)
+    out = DeviceArray(D, PN * (PN + 1) ÷ 2, B)
+    GC.@preserve ef out check(ccall((:gnx_collapse_padded, libgnx), Int32, (Ptr{Cvoid}, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cvoid}),
+        g.handle, devptr(ef), D, R, devptr(out), STREAM[]))
+    out
 end
-function collapsed_packed(t::NamedTuple)                               # (DE, total, R) over the real lower-triangle edges + offsets
-    g = t.graphs; ef = t.ef
+collapsef(t::NamedTuple) = back(collapsef_device(t.graphs, gpu(t.ef)), t.ef)
+function collapsed_packed_device(g::GNGraphBatch, ef::DeviceArray)     # (DE, total, R) over the real lower-triangle edges + offsets
     D, R = size(ef, 1), size(ef, 3)
     off = zeros(Int64, ngraphs(g) + 1)
-    check(ccall((:gnx_collapse_offsets, libgnx), Int32, (Ptr{Cvoid}, Ptr{Int64}), g.handle, off))
-    out = zeros(Float32, D, Int(off[end]), R)
-    d_ef, b_out = upload(ef), DevBuf(max(sizeof(out), 4))
-    GC.@preserve d_ef b_out check(ccall((:gnx_collapse_edges, libgnx), Int32, (Ptr{Cvoid}, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cvoid}),
-        g.handle, devptr(d_ef), D, R, devptr(b_out), C_NULL))
-    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
-    download!(out, b_out), off
+    check(ccall((:gnx_collapse_offsets, libgnx), Int32, (Ptr{Cvoid}, Ptr{Int64}), g.handle, off))   # (first call on a batch: builds its collapse tables)
+    out = DeviceArray(D, Int(off[end]), R)
+    GC.@preserve ef out check(ccall((:gnx_collapse_edges, libgnx), Int32, (Ptr{Cvoid}, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cvoid}),
+        g.handle, devptr(ef), D, R, devptr(out), STREAM[]))
+    out, off
 end
 function unpaddedcollapsedef(t::NamedTuple)                            # gngraphbatch.jl:87-107
-    out, off = collapsed_packed(t)
+    out, off = collapsed_packed_device(t.graphs, gpu(t.ef))
+    out = back(out, t.ef)
     sharedlike(t.graphs) ? [view(out, :, :, b) for b in 1:size(out, 3)] :
         [view(out, :, (off[i]+1):off[i+1], 1) for i in 1:ngraphs(t.graphs)]
 end
-flatunpaddedcollapsedef(t::NamedTuple) = reduce(hcat, unpaddedcollapsedef(t))   # gngraphbatch.jl:109-111
+function flatunpaddedcollapsedef(t::NamedTuple)                        # gngraphbatch.jl:109-111: the graphs' collapsed columns side by side
+    out, _ = collapsed_packed_device(t.graphs, gpu(t.ef))
+    @assert size(out, 3) == 1 || sharedlike(t.graphs)
+    back(reshape(out, size(out, 1), :), t.ef)
+end
 zerodim2nothing(t::NamedTuple) = (graphs=t.graphs, ef=t.ef, nf=t.nf, gf=t.gf)  # zero-width outputs are already `nothing`
 
-# ---- layers ----
-struct Dense
-    weight::Matrix{Float32}; bias::Vector{Float32}; σ
+# ---- layers: plain structs whose parameters are host `Array`s or (after `gpu`) `DeviceArray`s — uploaded ONCE, like `model |> device`
+#      in the reference (Functors.@functor GNBlock / GNCore / GNCoreList / GNFeedForward / GNGraphNorm: src/gnblock.jl:8, gncore.jl:8,
+#      gncorelist.jl:41, gnfeedforward.jl:7, gngraphnorm.jl:7) ----
+struct Dense{W,B}
+    weight::W; bias::B; σ
 end
 glorot(out, in) = (rand(Float32, out, in) .* 2f0 .- 1f0) .* sqrt(6f0 / max(in + out, 1))
 Dense(in::Integer, out::Integer, σ=identity) = Dense(glorot(out, in), zeros(Float32, out), σ)
 actcode(σ) = get(ACT, σ, get(ACT, Symbol(σ), nothing))
+gpu(d::Dense) = Dense(gpu(d.weight), gpu(d.bias), d.σ)
+cpu(d::Dense) = Dense(cpu(d.weight), cpu(d.bias), d.σ)
+ondevice(d::Dense) = ondevice(d.weight) && ondevice(d.bias)
+dense_c(d::Dense) = GnxDense(devptr(d.weight), devptr(d.bias), Int32(actcode(d.σ)), 0)      # device-resident layers only
 
 struct GNBlock
     edgefn::Dense; nodefn::Dense; graphfn::Dense; dropout
@@ -239,36 +371,43 @@ function GNBlock((in, out)::Pair; dropout=0)                          # src/gnbl
     (de, dn, dg), (oe, on, og) = in, out
     GNBlock(Dense(de + 2dn + dg, oe), Dense(dn + oe + dg, on), Dense(on + oe + dg, og), dropout, Tuple(in), Tuple(out))
 end
+gpu(m::GNBlock) = ondevice(m) ? m : GNBlock(gpu(m.edgefn), gpu(m.nodefn), gpu(m.graphfn), m.dropout, m.in, m.out)
+cpu(m::GNBlock) = GNBlock(cpu(m.edgefn), cpu(m.nodefn), cpu(m.graphfn), m.dropout, m.in, m.out)
+ondevice(m::GNBlock) = ondevice(m.edgefn) && ondevice(m.nodefn) && ondevice(m.graphfn)
+block_c(m::GNBlock) = GnxBlockParams(m.in..., m.out..., dense_c(m.edgefn), dense_c(m.nodefn), dense_c(m.graphfn))
+outarray(d::Integer, T::Integer, R::Integer) = d == 0 ? nothing : DeviceArray(d, T, R)     # zero-width outputs → nothing (gnblock.jl:71-78)
 
-function (m::GNBlock)(x)                                              # src/gnblock.jl:63-69 → gnx_block_forward
+# The device path of (m::GNBlock)(x): parameters and features are DeviceArrays.  ONE asynchronous gnx_block_forward on STREAM[]; the
+# workspace comes from the batch's cache, the outputs from the pool; nothing is copied and nothing waits.
+function block_device(m::GNBlock, x)
     (; graphs, ef, nf, gf) = x
     g::GNGraphBatch = graphs
-    R = size(something(ef, nf, gf), 3)
+    R = replicas(ef, nf, gf)
     (oe, on, og) = m.out
-    W = [upload(m.edgefn.weight), upload(m.nodefn.weight), upload(m.graphfn.weight)]
-    B = [upload(m.edgefn.bias), upload(m.nodefn.bias), upload(m.graphfn.bias)]
-    mk(d::Dense, w, b) = GnxDense(devptr(w), devptr(b), Int32(actcode(d.σ)), 0)
-    p = Ref(GnxBlockParams(m.in..., m.out..., mk(m.edgefn, W[1], B[1]), mk(m.nodefn, W[2], B[2]), mk(m.graphfn, W[3], B[3])))
-    d_ef, d_nf, d_gf = upload(ef), upload(nf), upload(gf)
-    o_ef, o_nf, o_gf = zeros(Float32, oe, nedges(g), R), zeros(Float32, on, nnodes(g), R), zeros(Float32, og, ngraphs(g), R)
-    b_ef, b_nf, b_gf = DevBuf(sizeof(o_ef)), DevBuf(sizeof(o_nf)), DevBuf(sizeof(o_gf))
-    wsb = ccall((:gnx_block_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxBlockParams}, Int64), g.handle, p, R)
-    ws = DevBuf(wsb)
-    GC.@preserve W B d_ef d_nf d_gf b_ef b_nf b_gf ws check(ccall((:gnx_block_forward, libgnx), Int32,
+    p = Ref(block_c(m))
+    ws = workspace!(g, (:block, m.in, m.out, R)) do
+        ccall((:gnx_block_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxBlockParams}, Int64), g.handle, p, R)
+    end
+    o_ef, o_nf, o_gf = outarray(oe, nedges(g), R), outarray(on, nnodes(g), R), outarray(og, ngraphs(g), R)
+    GC.@preserve m ef nf gf o_ef o_nf o_gf ws check(ccall((:gnx_block_forward, libgnx), Int32,
         (Ptr{Cvoid}, Ptr{GnxBlockParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat},
          Ptr{Cvoid}, Csize_t, UInt32, Ptr{Cvoid}),
-        g.handle, p, devptr(d_ef), devptr(d_nf), devptr(d_gf), R, devptr(b_ef), devptr(b_nf), devptr(b_gf),
-        ws.ptr, wsb, UInt32(0), C_NULL))
-    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
-    (graphs=g, ef=oe == 0 ? nothing : download!(o_ef, b_ef), nf=on == 0 ? nothing : download!(o_nf, b_nf),
-     gf=og == 0 ? nothing : download!(o_gf, b_gf))                    # zero-width outputs → nothing (gnblock.jl:71-78)
+        g.handle, p, devptr(ef), devptr(nf), devptr(gf), R, devptr(o_ef), devptr(o_nf), devptr(o_gf),
+        ws.ptr, ws.cap, UInt32(0), STREAM[]))
+    (graphs=g, ef=o_ef, nf=o_nf, gf=o_gf)
 end
+# src/gnblock.jl:63-69.  Device inputs + a device-resident block: the call above and nothing else.  Host arrays (or a host-resident
+# block) are moved over first and the result comes back to the host: the convenience path.
+(m::GNBlock)(x) = back(block_device(gpu(m), gpu(x)), x)
 
 # ---- GNCore (src/gncore.jl:46-68): core(x) = x + block(gn1(x)) + ffwd(gn2(x)) → gnx_core_forward ----
-struct LayerNorm                                                       # Flux.LayerNorm(d): diag scale γ, bias β
-    γ::Vector{Float32}; β::Vector{Float32}
+struct LayerNorm{V}                                                    # Flux.LayerNorm(d): diag scale γ, bias β
+    γ::V; β::V
 end
 LayerNorm(d::Integer) = LayerNorm(ones(Float32, d), zeros(Float32, d))
+gpu(l::LayerNorm) = LayerNorm(gpu(l.γ), gpu(l.β))
+cpu(l::LayerNorm) = LayerNorm(cpu(l.γ), cpu(l.β))
+ondevice(l::LayerNorm) = ondevice(l.γ) && ondevice(l.β)
 
 struct GnxLayerNorm; gamma::Ptr{Cfloat}; beta::Ptr{Cfloat}; end       # gnx_layernorm
 struct GnxFfn; fc1::GnxDense; fc2::GnxDense; end                       # gnx_ffn
@@ -289,32 +428,30 @@ function GNCore(dims; dropout=0)                                       # src/gnc
     d = Tuple(dims)
     GNCore(GNBlock(d => d; dropout), map(k -> (Dense(k, 4k, :relu), Dense(4k, k)), d), map(LayerNorm, d), map(LayerNorm, d), d)
 end
+ondevice(m::GNCore) = ondevice(m.block) && all(t -> ondevice(t[1]) && ondevice(t[2]), m.ffwd) && all(ondevice, m.gn1) && all(ondevice, m.gn2)
+gpu(m::GNCore) = ondevice(m) ? m : GNCore(gpu(m.block), map(t -> (gpu(t[1]), gpu(t[2])), m.ffwd), map(gpu, m.gn1), map(gpu, m.gn2), m.dims)
+cpu(m::GNCore) = GNCore(cpu(m.block), map(t -> (cpu(t[1]), cpu(t[2])), m.ffwd), map(cpu, m.gn1), map(cpu, m.gn2), m.dims)
+ln_c(l::LayerNorm) = GnxLayerNorm(devptr(l.γ), devptr(l.β))
+core_c(m::GNCore) = GnxCoreParams(block_c(m.block), map(ln_c, m.gn1), map(ln_c, m.gn2), map(t -> GnxFfn(dense_c(t[1]), dense_c(t[2])), m.ffwd), 1f-5, Int32(0))
 
-function (m::GNCore)(x)                                                # src/gncore.jl:56-68
+function core_device(m::GNCore, x)                                     # ONE asynchronous gnx_core_forward; see block_device
     (; graphs, ef, nf, gf) = x
     @assert ef !== nothing && nf !== nothing && gf !== nothing         # graphnetadd needs all three (gncore.jl:61-68)
     g::GNGraphBatch = graphs
     R = size(ef, 3)
-    keep = DevBuf[]                                                    # device copies of every parameter, alive across the ccall
-    up(a) = (b = upload(a); push!(keep, b); devptr(b))
-    dn(d::Dense) = GnxDense(up(d.weight), up(d.bias), Int32(actcode(d.σ)), 0)
-    ln(l::LayerNorm) = GnxLayerNorm(up(l.γ), up(l.β))
-    b = m.block
-    bp = GnxBlockParams(b.in..., b.out..., dn(b.edgefn), dn(b.nodefn), dn(b.graphfn))
-    p = Ref(GnxCoreParams(bp, map(ln, m.gn1), map(ln, m.gn2), map(t -> GnxFfn(dn(t[1]), dn(t[2])), m.ffwd), 1f-5, Int32(0)))
-    d_ef, d_nf, d_gf = upload(ef), upload(nf), upload(gf)
+    p = Ref(core_c(m))
+    ws = workspace!(g, (:core, m.dims, R)) do
+        ccall((:gnx_core_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxCoreParams}, Int64), g.handle, p, R)
+    end
     o_ef, o_nf, o_gf = similar(ef), similar(nf), similar(gf)
-    b_ef, b_nf, b_gf = DevBuf(sizeof(o_ef)), DevBuf(sizeof(o_nf)), DevBuf(sizeof(o_gf))
-    wsb = ccall((:gnx_core_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxCoreParams}, Int64), g.handle, p, R)
-    ws = DevBuf(wsb)
-    GC.@preserve keep d_ef d_nf d_gf b_ef b_nf b_gf ws check(ccall((:gnx_core_forward, libgnx), Int32,
+    GC.@preserve m ef nf gf o_ef o_nf o_gf ws check(ccall((:gnx_core_forward, libgnx), Int32,
         (Ptr{Cvoid}, Ptr{GnxCoreParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat},
          Ptr{Cvoid}, Csize_t, UInt32, Ptr{Cvoid}),
-        g.handle, p, devptr(d_ef), devptr(d_nf), devptr(d_gf), R, devptr(b_ef), devptr(b_nf), devptr(b_gf),
-        ws.ptr, wsb, UInt32(0), C_NULL))
-    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
-    (graphs=g, ef=download!(o_ef, b_ef), nf=download!(o_nf, b_nf), gf=download!(o_gf, b_gf))
+        g.handle, p, devptr(ef), devptr(nf), devptr(gf), R, devptr(o_ef), devptr(o_nf), devptr(o_gf),
+        ws.ptr, ws.cap, UInt32(0), STREAM[]))
+    (graphs=g, ef=o_ef, nf=o_nf, gf=o_gf)
 end
+(m::GNCore)(x) = back(core_device(gpu(m), gpu(x)), x)                  # src/gncore.jl:56-68
 
 # pullback of (m::GNCore)(x) → gnx_core_backward: takes the forward's INPUT x and the cotangent ȳ of its output; every intermediate is
 # recomputed inside the library.  Returns ∂ef, ∂nf, ∂gf and the parameter gradients in the order of the struct fields.
@@ -324,70 +461,65 @@ struct GnxCoreGrads
     block::GnxBlockGrads
     ln1::NTuple{3,GnxLayerNormGrad}; ln2::NTuple{3,GnxLayerNormGrad}; ff::NTuple{3,GnxFfnGrad}
 end
-function core_pullback(m::GNCore, x, ȳ)
+function core_pullback_device(m::GNCore, x, ȳ)
     g::GNGraphBatch = x.graphs
     R = size(x.ef, 3)
-    keep = DevBuf[]
-    up(a) = (b = upload(a); push!(keep, b); devptr(b))
-    dn(d::Dense) = GnxDense(up(d.weight), up(d.bias), Int32(actcode(d.σ)), 0)
-    ln(l::LayerNorm) = GnxLayerNorm(up(l.γ), up(l.β))
-    b = m.block
-    bp = GnxBlockParams(b.in..., b.out..., dn(b.edgefn), dn(b.nodefn), dn(b.graphfn))
-    p = Ref(GnxCoreParams(bp, map(ln, m.gn1), map(ln, m.gn2), map(t -> GnxFfn(dn(t[1]), dn(t[2])), m.ffwd), 1f-5, Int32(0)))
-    gbuf = Any[]                                                       # (host template, device buffer) of every gradient, in struct order
-    gnew(a) = (bf = DevBuf(sizeof(a)); push!(gbuf, (a, bf)); Ptr{Cfloat}(bf.ptr))
+    p = Ref(core_c(m))
+    gbuf = DeviceArray[]                                               # every parameter gradient, in struct order
+    gnew(a) = (d = similar(a); push!(gbuf, d); devptr(d))
     gd(d::Dense) = GnxDenseGrad(gnew(d.weight), gnew(d.bias))
     gl(l::LayerNorm) = GnxLayerNormGrad(gnew(l.γ), gnew(l.β))
+    b = m.block
     grads = Ref(GnxCoreGrads(GnxBlockGrads(gd(b.edgefn), gd(b.nodefn), gd(b.graphfn)), map(gl, m.gn1), map(gl, m.gn2),
                              map(t -> GnxFfnGrad(gd(t[1]), gd(t[2])), m.ffwd)))
-    ins = (upload(x.ef), upload(x.nf), upload(x.gf)); cots = (upload(ȳ.ef), upload(ȳ.nf), upload(ȳ.gf))
-    dins = (DevBuf(sizeof(x.ef)), DevBuf(sizeof(x.nf)), DevBuf(sizeof(x.gf)))
-    wsb = ccall((:gnx_core_backward_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxCoreParams}, Int64), g.handle, p, R)
-    ws = DevBuf(wsb)
-    GC.@preserve keep gbuf ins cots dins ws check(ccall((:gnx_core_backward, libgnx), Int32,
+    dins = (similar(x.ef), similar(x.nf), similar(x.gf))
+    ws = workspace!(g, (:core_backward, m.dims, R)) do
+        ccall((:gnx_core_backward_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxCoreParams}, Int64), g.handle, p, R)
+    end
+    GC.@preserve m x ȳ gbuf dins ws check(ccall((:gnx_core_backward, libgnx), Int32,
         (Ptr{Cvoid}, Ptr{GnxCoreParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64,
          Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{GnxCoreGrads}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-        g.handle, p, devptr(ins[1]), devptr(ins[2]), devptr(ins[3]), devptr(cots[1]), devptr(cots[2]), devptr(cots[3]), R,
-        devptr(dins[1]), devptr(dins[2]), devptr(dins[3]), grads, ws.ptr, wsb, C_NULL))
-    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
-    (ef=download!(similar(x.ef), dins[1]), nf=download!(similar(x.nf), dins[2]), gf=download!(similar(x.gf), dins[3]),
-     params=[download!(similar(a), bf) for (a, bf) in gbuf])           # block (W, b) x 3, gn1 (γ, β) x 3, gn2 (γ, β) x 3, ffwd (W1, b1, W2, b2) x 3
+        g.handle, p, devptr(x.ef), devptr(x.nf), devptr(x.gf), devptr(ȳ.ef), devptr(ȳ.nf), devptr(ȳ.gf), R,
+        devptr(dins[1]), devptr(dins[2]), devptr(dins[3]), grads, ws.ptr, ws.cap, STREAM[]))
+    (ef=dins[1], nf=dins[2], gf=dins[3], params=gbuf)                  # block (W, b) x 3, gn1 (γ, β) x 3, gn2 (γ, β) x 3, ffwd (W1, b1, W2, b2) x 3
+end
+function core_pullback(m::GNCore, x, ȳ)
+    r = core_pullback_device(gpu(m), gpu(x), gpu(ȳ))
+    ondevice(x) ? r : (ef=cpu(r.ef), nf=cpu(r.nf), gf=cpu(r.gf), params=map(cpu, r.params))
 end
 
 # GNCoreList is `foldl((x, f) -> f(x), list; init=x)` exactly as src/gncorelist.jl:43-45.
 struct GNCoreList{T}; list::T; end
 (m::GNCoreList)(x) = foldl((i, fn) -> fn(i), m.list; init=x)
+gpu(m::GNCoreList) = GNCoreList(map(gpu, m.list))
+cpu(m::GNCoreList) = GNCoreList(map(cpu, m.list))
 
 # ---- training: the pullback of (m::GNBlock)(x) = gnx_block_backward (what Flux.withgradient obtains from Zygote in
 #      examples/sort/sort.jl:122-132).  `block_pullback(m, x, y, ȳ)` returns (∂ef, ∂nf, ∂gf, (∂W, ∂b) for the three Dense layers);
 #      with ChainRulesCore loaded it is the body of the rrule below.  (gnx_core_backward is bound the same way; the tested
 #      binding of both is graphnets.jl_amd/api.py: _BlockFn / _CoreFn.) ----
-function block_pullback(m::GNBlock, x, y, ȳ)
+likeof(a) = isnothing(a) ? nothing : similar(a)
+function block_pullback_device(m::GNBlock, x, y, ȳ)
     g::GNGraphBatch = x.graphs
-    R = size(something(x.ef, x.nf, x.gf), 3)
-    W = [upload(m.edgefn.weight), upload(m.nodefn.weight), upload(m.graphfn.weight)]
-    B = [upload(m.edgefn.bias), upload(m.nodefn.bias), upload(m.graphfn.bias)]
-    mk(d::Dense, w, b) = GnxDense(devptr(w), devptr(b), Int32(actcode(d.σ)), 0)
-    p = Ref(GnxBlockParams(m.in..., m.out..., mk(m.edgefn, W[1], B[1]), mk(m.nodefn, W[2], B[2]), mk(m.graphfn, W[3], B[3])))
-    ins = (upload(x.ef), upload(x.nf), upload(x.gf)); outs = (upload(y.ef), upload(y.nf), upload(y.gf))
-    cots = (upload(ȳ.ef), upload(ȳ.nf), upload(ȳ.gf))
-    zlike(a) = isnothing(a) ? nothing : DevBuf(sizeof(a))
-    dins = (zlike(x.ef), zlike(x.nf), zlike(x.gf))
+    R = replicas(x.ef, x.nf, x.gf)
+    p = Ref(block_c(m))
+    dins = (likeof(x.ef), likeof(x.nf), likeof(x.gf))
     layers = (m.edgefn, m.nodefn, m.graphfn)
-    gW = [DevBuf(sizeof(l.weight)) for l in layers]; gB = [DevBuf(sizeof(l.bias)) for l in layers]
-    gptr(b) = Ptr{Cfloat}(b.ptr)
-    grads = Ref(GnxBlockGrads(GnxDenseGrad(gptr(gW[1]), gptr(gB[1])), GnxDenseGrad(gptr(gW[2]), gptr(gB[2])), GnxDenseGrad(gptr(gW[3]), gptr(gB[3]))))
-    wsb = ccall((:gnx_block_backward_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxBlockParams}, Int64), g.handle, p, R)
-    ws = DevBuf(wsb)
-    GC.@preserve W B ins outs cots dins gW gB ws check(ccall((:gnx_block_backward, libgnx), Int32,
+    gW = [similar(l.weight) for l in layers]; gB = [similar(l.bias) for l in layers]
+    grads = Ref(GnxBlockGrads(GnxDenseGrad(devptr(gW[1]), devptr(gB[1])), GnxDenseGrad(devptr(gW[2]), devptr(gB[2])), GnxDenseGrad(devptr(gW[3]), devptr(gB[3]))))
+    ws = workspace!(g, (:block_backward, m.in, m.out, R)) do
+        ccall((:gnx_block_backward_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxBlockParams}, Int64), g.handle, p, R)
+    end
+    GC.@preserve m x y ȳ dins gW gB ws check(ccall((:gnx_block_backward, libgnx), Int32,
         (Ptr{Cvoid}, Ptr{GnxBlockParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat},
          Ptr{Cfloat}, Int64, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{GnxBlockGrads}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-        g.handle, p, devptr(ins[1]), devptr(ins[2]), devptr(ins[3]), devptr(outs[1]), devptr(outs[2]), devptr(outs[3]),
-        devptr(cots[1]), devptr(cots[2]), devptr(cots[3]), R, devptr(dins[1]), devptr(dins[2]), devptr(dins[3]), grads, ws.ptr, wsb, C_NULL))
-    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
-    dl(a, b) = isnothing(a) ? nothing : download!(similar(a), b)
-    (ef=dl(x.ef, dins[1]), nf=dl(x.nf, dins[2]), gf=dl(x.gf, dins[3]),
-     params=[(weight=download!(similar(l.weight), gW[i]), bias=download!(similar(l.bias), gB[i])) for (i, l) in enumerate(layers)])
+        g.handle, p, devptr(x.ef), devptr(x.nf), devptr(x.gf), devptr(y.ef), devptr(y.nf), devptr(y.gf),
+        devptr(ȳ.ef), devptr(ȳ.nf), devptr(ȳ.gf), R, devptr(dins[1]), devptr(dins[2]), devptr(dins[3]), grads, ws.ptr, ws.cap, STREAM[]))
+    (ef=dins[1], nf=dins[2], gf=dins[3], params=[(weight=gW[i], bias=gB[i]) for i in 1:3])
+end
+function block_pullback(m::GNBlock, x, y, ȳ)
+    r = block_pullback_device(gpu(m), gpu(x), gpu(y), gpu(ȳ))
+    ondevice(x) ? r : (ef=cpu(r.ef), nf=cpu(r.nf), gf=cpu(r.gf), params=[map(cpu, q) for q in r.params])
 end
 
 # The rrule a maintainer adds once ChainRulesCore is a dependency (kept as a comment: this module has no dependencies):
@@ -407,83 +539,82 @@ struct ChainBlock                                                      # GNBlock
     edgefn::Vector{Dense}; nodefn::Vector{Dense}; graphfn::Vector{Dense}; in::NTuple{3,Int}
 end
 outwidth(c::Vector{Dense}) = isempty(c) ? 0 : size(c[end].weight, 1)
-# device copies of every layer + the host arrays the parameter struct points at; `keep` holds what must outlive the call
+ondevice(m::ChainBlock) = all(ondevice, m.edgefn) && all(ondevice, m.nodefn) && all(ondevice, m.graphfn)
+gpu(m::ChainBlock) = ondevice(m) ? m : ChainBlock(Dense[gpu(l) for l in m.edgefn], Dense[gpu(l) for l in m.nodefn], Dense[gpu(l) for l in m.graphfn], m.in)
+cpu(m::ChainBlock) = ChainBlock(Dense[cpu(l) for l in m.edgefn], Dense[cpu(l) for l in m.nodefn], Dense[cpu(l) for l in m.graphfn], m.in)
+chainkey(m::ChainBlock) = (m.in, map(c -> Tuple([size(l.weight, 1) for l in c]), (m.edgefn, m.nodefn, m.graphfn)))
+# the host arrays the parameter struct points at (layer descriptors with DEVICE weight pointers, widths); `keep` holds what must outlive the call
 function chain_params(m::ChainBlock, keep::Vector{Any})
     function one(c::Vector{Dense})
-        W = [upload(l.weight) for l in c]; B = [upload(l.bias) for l in c]
-        descr = [GnxDense(devptr(W[i]), devptr(B[i]), Int32(actcode(c[i].σ)), 0) for i in eachindex(c)]
+        descr = [dense_c(l) for l in c]
         widths = Int32[size(l.weight, 1) for l in c]
-        push!(keep, W, B, descr, widths)
+        push!(keep, descr, widths)
         GnxChain(isempty(c) ? C_NULL : pointer(descr), isempty(c) ? C_NULL : pointer(widths), Int32(length(c)), 0)
     end
     GnxChainBlockParams(m.in..., 0, one(m.edgefn), one(m.nodefn), one(m.graphfn))
 end
-function (m::ChainBlock)(x)
+function chain_device(m::ChainBlock, x)
     g::GNGraphBatch = x.graphs
-    R = size(something(x.ef, x.nf, x.gf), 3)
+    R = replicas(x.ef, x.nf, x.gf)
     keep = Any[]
     p = Ref(chain_params(m, keep))
     oe, on, og = outwidth(m.edgefn), outwidth(m.nodefn), outwidth(m.graphfn)
-    ins = (upload(x.ef), upload(x.nf), upload(x.gf))
-    o = (zeros(Float32, oe, nedges(g), R), zeros(Float32, on, nnodes(g), R), zeros(Float32, og, ngraphs(g), R))
-    b = (DevBuf(sizeof(o[1])), DevBuf(sizeof(o[2])), DevBuf(sizeof(o[3])))
-    wsb = ccall((:gnx_chain_block_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxChainBlockParams}, Int64), g.handle, p, R)
-    wsb == 0 && error("gnx: ", unsafe_string(ccall((:gnx_last_error, libgnx), Cstring, ())))
-    ws = DevBuf(wsb)
-    GC.@preserve keep ins b ws check(ccall((:gnx_chain_block_forward, libgnx), Int32,
+    ws = workspace!(g, (:chain, chainkey(m), R)) do
+        ccall((:gnx_chain_block_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxChainBlockParams}, Int64), g.handle, p, R)
+    end
+    o = (outarray(oe, nedges(g), R), outarray(on, nnodes(g), R), outarray(og, ngraphs(g), R))
+    GC.@preserve m keep x o ws check(ccall((:gnx_chain_block_forward, libgnx), Int32,
         (Ptr{Cvoid}, Ptr{GnxChainBlockParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cvoid}, Csize_t, UInt32, Ptr{Cvoid}),
-        g.handle, p, devptr(ins[1]), devptr(ins[2]), devptr(ins[3]), R, devptr(b[1]), devptr(b[2]), devptr(b[3]), ws.ptr, wsb, UInt32(0), C_NULL))
-    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
-    (graphs=g, ef=oe == 0 ? nothing : download!(o[1], b[1]), nf=on == 0 ? nothing : download!(o[2], b[2]), gf=og == 0 ? nothing : download!(o[3], b[3]))
+        g.handle, p, devptr(x.ef), devptr(x.nf), devptr(x.gf), R, devptr(o[1]), devptr(o[2]), devptr(o[3]), ws.ptr, ws.cap, UInt32(0), STREAM[]))
+    (graphs=g, ef=o[1], nf=o[2], gf=o[3])
 end
+(m::ChainBlock)(x) = back(chain_device(gpu(m), gpu(x)), x)
 # pullback: gradients w.r.t. the inputs and every layer's (weight, bias); the forward is recomputed inside the library
-function chain_pullback(m::ChainBlock, x, ȳ)
+function chain_pullback_device(m::ChainBlock, x, ȳ)
     g::GNGraphBatch = x.graphs
-    R = size(something(x.ef, x.nf, x.gf), 3)
+    R = replicas(x.ef, x.nf, x.gf)
     keep = Any[]
     p = Ref(chain_params(m, keep))
-    ins = (upload(x.ef), upload(x.nf), upload(x.gf)); cots = (upload(ȳ.ef), upload(ȳ.nf), upload(ȳ.gf))
-    zlike(a) = isnothing(a) ? nothing : DevBuf(sizeof(a))
-    dins = (zlike(x.ef), zlike(x.nf), zlike(x.gf))
+    dins = (likeof(x.ef), likeof(x.nf), likeof(x.gf))
     chains = (m.edgefn, m.nodefn, m.graphfn)
-    gW = [[DevBuf(sizeof(l.weight)) for l in c] for c in chains]; gB = [[DevBuf(sizeof(l.bias)) for l in c] for c in chains]
-    arrs = [[GnxDenseGrad(Ptr{Cfloat}(gW[t][i].ptr), Ptr{Cfloat}(gB[t][i].ptr)) for i in eachindex(chains[t])] for t in 1:3]
+    gW = [[similar(l.weight) for l in c] for c in chains]; gB = [[similar(l.bias) for l in c] for c in chains]
+    arrs = [[GnxDenseGrad(devptr(gW[t][i]), devptr(gB[t][i])) for i in eachindex(chains[t])] for t in 1:3]
     gp(t) = isempty(arrs[t]) ? Ptr{GnxDenseGrad}(C_NULL) : pointer(arrs[t])
     grads = Ref(GnxChainBlockGrads(gp(1), gp(2), gp(3)))
-    wsb = ccall((:gnx_chain_block_backward_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxChainBlockParams}, Int64), g.handle, p, R)
-    ws = DevBuf(wsb)
-    GC.@preserve keep ins cots dins gW gB arrs ws check(ccall((:gnx_chain_block_backward, libgnx), Int32,
+    ws = workspace!(g, (:chain_backward, chainkey(m), R)) do
+        ccall((:gnx_chain_block_backward_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxChainBlockParams}, Int64), g.handle, p, R)
+    end
+    GC.@preserve m keep x ȳ dins gW gB arrs ws check(ccall((:gnx_chain_block_backward, libgnx), Int32,
         (Ptr{Cvoid}, Ptr{GnxChainBlockParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64,
          Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{GnxChainBlockGrads}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-        g.handle, p, devptr(ins[1]), devptr(ins[2]), devptr(ins[3]), devptr(cots[1]), devptr(cots[2]), devptr(cots[3]), R,
-        devptr(dins[1]), devptr(dins[2]), devptr(dins[3]), grads, ws.ptr, wsb, C_NULL))
-    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
-    dl(a, b) = isnothing(a) ? nothing : download!(similar(a), b)
-    (ef=dl(x.ef, dins[1]), nf=dl(x.nf, dins[2]), gf=dl(x.gf, dins[3]),
-     params=[[(weight=download!(similar(l.weight), gW[t][i]), bias=download!(similar(l.bias), gB[t][i])) for (i, l) in enumerate(chains[t])] for t in 1:3])
+        g.handle, p, devptr(x.ef), devptr(x.nf), devptr(x.gf), devptr(ȳ.ef), devptr(ȳ.nf), devptr(ȳ.gf), R,
+        devptr(dins[1]), devptr(dins[2]), devptr(dins[3]), grads, ws.ptr, ws.cap, STREAM[]))
+    (ef=dins[1], nf=dins[2], gf=dins[3], params=[[(weight=gW[t][i], bias=gB[t][i]) for i in eachindex(chains[t])] for t in 1:3])
+end
+function chain_pullback(m::ChainBlock, x, ȳ)
+    r = chain_pullback_device(gpu(m), gpu(x), gpu(ȳ))
+    ondevice(x) ? r : (ef=cpu(r.ef), nf=cpu(r.nf), gf=cpu(r.gf), params=[[map(cpu, q) for q in c] for c in r.params])
 end
 
-# ---- a chain of layers as ONE hipGraph inside libgnx (gnx_model_*): decoder(core(encoder(x))) of examples/sort/sort.jl:68-75 ----
+# ---- a chain of layers as ONE hipGraph inside libgnx (gnx_model_*): decoder(core(encoder(x))) of examples/sort/sort.jl:68-75.
+#      The model keeps its (device-resident) layers, its output arrays and — inside the library — every intermediate and workspace:
+#      a call with the SAME input arrays is ONE hipGraphLaunch.  Its outputs are overwritten by the next call (copy them to keep them). ----
 struct GnxLayer; kind::Int32; reserved::Int32; params::Ptr{Cvoid}; end
 mutable struct Model
-    handle::Ptr{Cvoid}; graphs::GNGraphBatch; keep::Vector{Any}; outdims::NTuple{3,Int}
+    handle::Ptr{Cvoid}; graphs::GNGraphBatch; keep::Vector{Any}; outdims::NTuple{3,Int}; out::Any
 end
 function Model(layers::AbstractVector, x)
     g::GNGraphBatch = x.graphs
-    R = size(something(x.ef, x.nf, x.gf), 3)
+    R = replicas(x.ef, x.nf, x.gf)
     keep = Any[]
-    up(a) = (b = upload(a); push!(keep, b); devptr(b))
-    dn(d::Dense) = GnxDense(up(d.weight), up(d.bias), Int32(actcode(d.σ)), 0)
-    ln(l::LayerNorm) = GnxLayerNorm(up(l.γ), up(l.β))
-    bparams(b::GNBlock) = GnxBlockParams(b.in..., b.out..., dn(b.edgefn), dn(b.nodefn), dn(b.graphfn))
     descs = GnxLayer[]
-    for l in layers
+    for l0 in layers
+        l = gpu(l0); push!(keep, l)                                    # weights uploaded once, here
         if l isa GNBlock
-            r = Ref(bparams(l)); push!(keep, r)
+            r = Ref(block_c(l)); push!(keep, r)
             push!(descs, GnxLayer(0, 0, Base.unsafe_convert(Ptr{Cvoid}, r)))
         else
-            r = Ref(GnxCoreParams(bparams(l.block), map(ln, l.gn1), map(ln, l.gn2), map(t -> GnxFfn(dn(t[1]), dn(t[2])), l.ffwd), 1f-5, Int32(0)))
-            push!(keep, r)
+            r = Ref(core_c(l)); push!(keep, r)
             push!(descs, GnxLayer(1, 0, Base.unsafe_convert(Ptr{Cvoid}, r)))
         end
     end
@@ -491,35 +622,45 @@ function Model(layers::AbstractVector, x)
     GC.@preserve keep check(ccall((:gnx_model_create, libgnx), Int32, (Ptr{Cvoid}, Ptr{GnxLayer}, Int32, Int64, Ptr{Ptr{Cvoid}}), g.handle, descs, length(descs), R, h))
     dims = zeros(Int32, 3)
     check(ccall((:gnx_model_out_dims, libgnx), Int32, (Ptr{Cvoid}, Ptr{Int32}), h[], dims))
-    m = Model(h[], g, keep, Tuple(Int.(dims)))
+    (oe, on, og) = Tuple(Int.(dims))
+    out = (outarray(oe, nedges(g), R), outarray(on, nnodes(g), R), outarray(og, ngraphs(g), R))
+    m = Model(h[], g, keep, (oe, on, og), out)
     finalizer(x -> ccall((:gnx_model_destroy, libgnx), Int32, (Ptr{Cvoid},), x.handle), m)
     m
 end
-function (m::Model)(x)                                                 # one hipGraphLaunch after the first call with these buffers
-    g = m.graphs; R = size(something(x.ef, x.nf, x.gf), 3)
-    d_ef, d_nf, d_gf = upload(x.ef), upload(x.nf), upload(x.gf)
-    (oe, on, og) = m.outdims
-    o_ef, o_nf, o_gf = zeros(Float32, oe, nedges(g), R), zeros(Float32, on, nnodes(g), R), zeros(Float32, og, ngraphs(g), R)
-    b_ef, b_nf, b_gf = DevBuf(sizeof(o_ef)), DevBuf(sizeof(o_nf)), DevBuf(sizeof(o_gf))
-    GC.@preserve d_ef d_nf d_gf b_ef b_nf b_gf check(ccall((:gnx_model_forward, libgnx), Int32,
+function model_device(m::Model, x)                                     # one hipGraphLaunch after the first call with these arrays
+    o = m.out
+    GC.@preserve m x check(ccall((:gnx_model_forward, libgnx), Int32,
         (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, UInt32, Ptr{Cvoid}),
-        m.handle, devptr(d_ef), devptr(d_nf), devptr(d_gf), devptr(b_ef), devptr(b_nf), devptr(b_gf), UInt32(0), C_NULL))
-    hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
-    (graphs=g, ef=oe == 0 ? nothing : download!(o_ef, b_ef), nf=on == 0 ? nothing : download!(o_nf, b_nf), gf=og == 0 ? nothing : download!(o_gf, b_gf))
+        m.handle, devptr(x.ef), devptr(x.nf), devptr(x.gf), devptr(o[1]), devptr(o[2]), devptr(o[3]), UInt32(0), STREAM[]))
+    (graphs=m.graphs, ef=o[1], nf=o[2], gf=o[3])
 end
+(m::Model)(x) = back(model_device(m, gpu(x)), x)                       # (host inputs: a fresh upload each call = a re-capture; keep x on the device)
 
 # ---- multi-GPU: whole graphs sharded over the devices of this process, gf' all-gathered (gnx_dist_*, SURVEY §8e).
 #      partition_graphs: equal graph counts per rank, snake order by edge count; DistBlock: one GNGraphBatch per device built from
-#      ITS graphs, per-device gnx_block_forward, one RCCL all-gather of gf' restored to the ORIGINAL graph order. ----
+#      ITS graphs, per-device gnx_block_forward, one RCCL all-gather of gf' restored to the ORIGINAL graph order.  Multi-device use
+#      needs STREAM[] == C_NULL (every device's default stream). ----
 function partition_graphs(edge_counts::AbstractVector{<:Integer}, n_ranks::Integer)
     counts = Int64.(edge_counts); G = length(counts)
     off = zeros(Int64, n_ranks + 1); ids = zeros(Int64, G)
     check(ccall((:gnx_dist_partition, libgnx), Int32, (Ptr{Int64}, Int64, Int32, Ptr{Int64}, Ptr{Int64}), counts, G, n_ranks, off, ids))
     [ids[off[r]+1:off[r+1]] .+ 1 for r in 1:n_ranks]               # 1-based original graph ids per rank
 end
+function ondev(f::Function, dev::Integer)                              # run f with `dev` current, restore the caller's device
+    prev = currentdevice()
+    prev == dev || setdevice(dev)
+    try
+        return f()
+    finally
+        prev == dev || setdevice(prev)
+    end
+end
 
 mutable struct DistBlock
-    handle::Ptr{Cvoid}; devices::Vector{Int32}; shards::Vector{Vector{Int64}}; batches::Vector{GNGraphBatch}; block::GNBlock
+    handle::Ptr{Cvoid}; devices::Vector{Int32}; shards::Vector{Vector{Int64}}; batches::Vector{GNGraphBatch}
+    blocks::Vector{GNBlock}                                            # the block's parameters replicated: blocks[r] lives on devices[r]
+    gall::Vector{DeviceArray{2}}                                       # per device: the gathered (DG', n_graphs) table, reused by every call
 end
 function DistBlock(block::GNBlock, adj_mats::AbstractVector, devices::AbstractVector{<:Integer})
     n = length(devices)
@@ -529,63 +670,53 @@ function DistBlock(block::GNBlock, adj_mats::AbstractVector, devices::AbstractVe
     devs = Int32.(devices)
     check(ccall((:gnx_dist_create, libgnx), Int32, (Ptr{Int32}, Int32, Ptr{Int64}, Ptr{Int64}, Int64, Int32, Ptr{Ptr{Cvoid}}),
                 devs, n, off, ids, length(adj_mats), block.out[3], h))
-    batches = map(1:n) do r
-        hipcheck(ccall((:hipSetDevice, libhip), Cint, (Cint,), devs[r]))
-        GNGraphBatch([adj_mats[i] for i in shards[r]])                 # the handle lives on the device that is current at creation
-    end
-    d = DistBlock(h[], devs, shards, batches, block)
+    hostblock = cpu(block)
+    # the handle, the replicated parameters and the gathered table of rank r live on the device that is current at their creation
+    batches = [ondev(() -> GNGraphBatch([adj_mats[i] for i in shards[r]]), devs[r]) for r in 1:n]
+    blocks = [ondev(() -> gpu(hostblock), devs[r]) for r in 1:n]
+    gall = [ondev(() -> DeviceArray(block.out[3], length(adj_mats)), devs[r]) for r in 1:n]
+    d = DistBlock(h[], devs, shards, batches, blocks, gall)
     finalizer(x -> ccall((:gnx_dist_destroy, libgnx), Int32, (Ptr{Cvoid},), x.handle), d)
     d
 end
-# (d::DistBlock)(xs): xs[r] = the batched tuple of rank r's graphs (`batch` of ITS graphs, in the order of d.shards[r]).  Every rank's
-# inputs, parameters (replicated), outputs and workspace live on ITS device; the call is ONE gnx_dist_block_forward = per-device
-# gnx_block_forward + one RCCL all-gather of gf' + the permutation back to the ORIGINAL graph order.  Returns (ys, gf_all):
-# ys[r] = rank r's (ef', nf', gf') and gf_all = (DG', n_graphs) of the whole batch (identical on every device; rank 1's copy).
-function (d::DistBlock)(xs::AbstractVector)
-    n = length(d.devices); m = d.block
+# (d::DistBlock)(xs): xs[r] = the batched tuple of rank r's graphs (`batch` of ITS graphs, in the order of d.shards[r]), moved to
+# devices[r] (`ondev(() -> gpu(x), dev)`).  The call is ONE gnx_dist_block_forward = per-device gnx_block_forward + one RCCL all-gather
+# of gf' + the permutation back to the ORIGINAL graph order: asynchronous on every device — nothing is copied, nothing waits.  Returns
+# (ys, gf_all): ys[r] = rank r's (ef', nf', gf') on devices[r]; gf_all[r] = the (DG', n_graphs) table of the whole batch on devices[r]
+# (identical on every device; overwritten by the next call).  `cpu(ys[r])` / `cpu(gf_all[1])` is where the host waits for device r.
+function dist_device(d::DistBlock, xs::AbstractVector)
+    n = length(d.devices)
     @assert length(xs) == n
-    (oe, on, og) = m.out
-    G = sum(length, d.shards)
-    setdev(r) = hipcheck(ccall((:hipSetDevice, libhip), Cint, (Cint,), d.devices[r]))
-    prev = Ref{Cint}(0); hipcheck(ccall((:hipGetDevice, libhip), Cint, (Ptr{Cint},), prev))
-    keep = Any[]
-    params = Vector{Base.RefValue{GnxBlockParams}}(undef, n)
-    ins = Vector{Any}(undef, n); outs = Vector{Any}(undef, n); hosts = Vector{Any}(undef, n)
-    wss = Vector{DevBuf}(undef, n); wsb = zeros(Csize_t, n); gall = Vector{DevBuf}(undef, n)
-    mk(dl::Dense, w, b) = GnxDense(devptr(w), devptr(b), Int32(actcode(dl.σ)), 0)
+    (oe, on, og) = d.blocks[1].out
+    params = [Ref(block_c(d.blocks[r])) for r in 1:n]
+    wss = Vector{DevBuf}(undef, n); outs = Vector{Any}(undef, n)
     for r in 1:n
-        setdev(r)                                                      # hipMalloc / hipMemcpy below land on device r
         g = d.batches[r]; x = xs[r]
-        R = size(something(x.ef, x.nf, x.gf), 3); @assert R == 1      # by-graph sharding: vector batches
-        W = [upload(m.edgefn.weight), upload(m.nodefn.weight), upload(m.graphfn.weight)]
-        B = [upload(m.edgefn.bias), upload(m.nodefn.bias), upload(m.graphfn.bias)]
-        params[r] = Ref(GnxBlockParams(m.in..., m.out..., mk(m.edgefn, W[1], B[1]), mk(m.nodefn, W[2], B[2]), mk(m.graphfn, W[3], B[3])))
-        ins[r] = (upload(x.ef), upload(x.nf), upload(x.gf))
-        hosts[r] = (zeros(Float32, oe, nedges(g), 1), zeros(Float32, on, nnodes(g), 1), zeros(Float32, og, ngraphs(g), 1))
-        outs[r] = (DevBuf(sizeof(hosts[r][1])), DevBuf(sizeof(hosts[r][2])), DevBuf(sizeof(hosts[r][3])))
-        wsb[r] = ccall((:gnx_block_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxBlockParams}, Int64), g.handle, params[r], 1)
-        wss[r] = DevBuf(wsb[r]); gall[r] = DevBuf(4 * G * og)
-        push!(keep, W, B)
+        @assert replicas(x.ef, x.nf, x.gf) == 1                        # by-graph sharding: vector batches
+        ondev(d.devices[r]) do                                         # pool blocks and the workspace of rank r belong to device r
+            wss[r] = workspace!(g, (:block, d.blocks[r].in, d.blocks[r].out, 1)) do
+                ccall((:gnx_block_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxBlockParams}, Int64), g.handle, params[r], 1)
+            end
+            outs[r] = (outarray(oe, nedges(g), 1), outarray(on, nnodes(g), 1), outarray(og, ngraphs(g), 1))
+        end
     end
     col(f) = [f(r) for r in 1:n]
     hs = col(r -> d.batches[r].handle)
     ps = col(r -> Base.unsafe_convert(Ptr{GnxBlockParams}, params[r]))
-    efs = col(r -> devptr(ins[r][1])); nfs = col(r -> devptr(ins[r][2])); gfs = col(r -> devptr(ins[r][3]))
+    efs = col(r -> devptr(xs[r].ef)); nfs = col(r -> devptr(xs[r].nf)); gfs = col(r -> devptr(xs[r].gf))
     eos = col(r -> devptr(outs[r][1])); nos = col(r -> devptr(outs[r][2])); gos = col(r -> devptr(outs[r][3]))
-    gas = col(r -> devptr(gall[r])); wsp = col(r -> wss[r].ptr)
-    GC.@preserve keep params ins outs wss gall check(ccall((:gnx_dist_block_forward, libgnx), Int32,
+    gas = col(r -> devptr(d.gall[r])); wsp = col(r -> wss[r].ptr); wsb = Csize_t[wss[r].cap for r in 1:n]
+    GC.@preserve d params xs outs wss check(ccall((:gnx_dist_block_forward, libgnx), Int32,
         (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Ptr{Ptr{GnxBlockParams}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}},
          Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cvoid}}, Ptr{Csize_t}, UInt32, Ptr{Ptr{Cvoid}}),
         d.handle, hs, ps, efs, nfs, gfs, eos, nos, gos, gas, wsp, wsb, UInt32(0), C_NULL))
-    ys = map(1:n) do r
-        setdev(r); hipcheck(ccall((:hipDeviceSynchronize, libhip), Cint, ()))
-        (graphs=d.batches[r], ef=oe == 0 ? nothing : download!(hosts[r][1], outs[r][1]), nf=on == 0 ? nothing : download!(hosts[r][2], outs[r][2]),
-         gf=og == 0 ? nothing : download!(hosts[r][3], outs[r][3]))
-    end
-    setdev(1)
-    gf_all = download!(zeros(Float32, og, G), gall[1])
-    hipcheck(ccall((:hipSetDevice, libhip), Cint, (Cint,), prev[]))
-    ys, gf_all
+    [(graphs=d.batches[r], ef=outs[r][1], nf=outs[r][2], gf=outs[r][3]) for r in 1:n], d.gall
+end
+function (d::DistBlock)(xs::AbstractVector)
+    dev = any(ondevice, xs)
+    xd = [ondev(() -> gpu(xs[r]), d.devices[r]) for r in 1:length(xs)]
+    ys, gall = dist_device(d, xd)
+    dev ? (ys, gall) : (map(cpu, ys), cpu(gall[1]))
 end
 
 end # module

@@ -132,3 +132,31 @@ def test_readme_example_1_through_the_c_abi_from_c():
     out = subprocess.run([os.path.join(_make_c_tests(), "abi_smoke")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "max |hip - double|" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_abi_bench_runs_both_modes_without_python_in_the_loop(tmp_path):
+    """tests/c/abi_bench.c — the throughput program bench.py quotes as `c_abi_ms_per_step`: BASELINE configs[1] through
+    gnx_block_forward (captured by the C program) and through gnx_model_forward, and the 4-layer configs[3] model as one gnx_model.
+    Small sizes here (it is the bench line that runs the full ones); a graph handed over as a file takes the --csc path."""
+    import json
+    import subprocess
+    exe = os.path.join(_make_c_tests(), "abi_bench")
+    rng = np.random.default_rng(5)
+    N, E = 3000, 30000
+    k = np.sort(rng.choice(N * N, E, replace=False))
+    cp = np.zeros(N + 1, dtype=np.int64)
+    np.add.at(cp, k // N + 1, 1)
+    path = str(tmp_path / "g.bin")
+    with open(path, "wb") as f:
+        f.write(np.array([N, E], dtype=np.int64).tobytes() + np.cumsum(cp).astype(np.int64).tobytes() + (k % N).astype(np.int64).tobytes())
+    for argv, keys in ((["--mode", "block", "--steps", "16", "--warmup", "4", "--csc", path], ("captured_us_per_step", "model_us_per_step")),
+                       (["--mode", "block", "--steps", "8", "--nodes", "2000", "--edges", "16000"], ("captured_us_per_step", "model_us_per_step")),
+                       (["--mode", "c4", "--steps", "3", "--warmup", "2", "--csc", path], ("model_us_per_step",)),
+                       (["--mode", "c4", "--steps", "3", "--warmup", "2", "--csc", path, "--core-dims", "10,5,3"], ("model_us_per_step",))):
+        out = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        for key in keys:
+            assert 0.5 < line[key] < 1e6, line
+        assert np.isfinite(line["gf_out0"]) and line["batch_ms"] > 0

@@ -101,7 +101,7 @@ def test_every_ccall_matches_the_ctypes_signature_table():
 
 def test_the_shim_binds_the_entry_points_of_the_hot_path_and_its_neighbours():
     bound = {c[0] for c in ccalls()}
-    for name in ("gnx_graphs_create_dense", "gnx_graphs_create_csc", "gnx_block_forward", "gnx_core_forward", "gnx_fn_input", "gnx_block_backward",
+    for name in ("gnx_graphs_create_dense", "gnx_graphs_create_csc_cat", "gnx_block_forward", "gnx_core_forward", "gnx_fn_input", "gnx_block_backward",
                  "gnx_core_backward", "gnx_chain_block_forward", "gnx_chain_block_backward", "gnx_model_create", "gnx_model_forward",
                  "gnx_dist_partition", "gnx_dist_create", "gnx_dist_block_forward", "gnx_dist_destroy", "gnx_collapse_edges", "gnx_collapse_padded"):
         assert name in bound, f"the Julia shim does not bind {name}"
@@ -176,3 +176,109 @@ def test_begin_end_blocks_balance():
     openers = re.findall(r"(?<![\w.:@])(?:module|function|struct|if|for|while|let|do|begin|try|quote|macro)\b", code)
     ends = re.findall(r"(?<![\w.:@])end\b", code)
     assert len(openers) == len(ends), f"{len(openers)} block openers vs {len(ends)} `end`s"
+
+
+# ---- device residency (VERDICT r3 #1a): what a call operator on device inputs can reach ----
+def _functions():
+    """name -> concatenated bodies of every method of that name defined in the shim (long form `function f(...) ... end`, call-operator
+    form `function (m::T)(x) ... end` under the name `(T)`, and short form `f(args) = expr` up to the next top-level definition)."""
+    code = _strip_comments(SRC)
+    code = re.sub(r'"(?:\\.|[^"\\])*"', '""', code)
+    lines = code.split("\n")
+    starts = []  # (line index, name)
+    for i, l in enumerate(lines):
+        m = re.match(r"^function\s+(?:Base\.)?(\w+!?)\s*[({]", l) or re.match(r"^function\s+\(\w+::(\w+)\)\(", l)
+        if m:
+            starts.append((i, m.group(1) if not l.lstrip().startswith("function (") else "(" + m.group(1) + ")"))
+            continue
+        m = re.match(r"^\((\w+)::(\w+)\)\(.*?\)\s*=", l)
+        if m:
+            starts.append((i, "(" + m.group(2) + ")"))
+            continue
+        m = re.match(r"^(?:Base\.)?(\w+!?)\(.*?\)(?:\s+where\s+\{.*?\})?\s*=(?!=)", l)
+        if m:
+            starts.append((i, m.group(1)))
+    tops = [i for i, l in enumerate(lines) if re.match(r"^(function|struct|mutable struct|const|export|end\b|\w[\w.!]*\(.*\)\s*(where\s+\{.*?\})?\s*=(?!=)|\(\w+::\w+\)\()", l)]
+    out = {}
+    for i, l in enumerate(lines):  # inner constructors (`    function T(...) ... end` inside a struct body)
+        m = re.match(r"^(\s+)function\s+(\w+)\(", l)
+        if m:
+            j = i + 1
+            while not re.match(rf"^{m.group(1)}end\b", lines[j]):
+                j += 1
+            out[m.group(2)] = out.get(m.group(2), "") + "\n" + "\n".join(lines[i:j + 1])
+    for i, name in starts:
+        if lines[i].startswith("function"):
+            j = i + 1
+            while not re.match(r"^end\b", lines[j]):
+                j += 1
+            body = "\n".join(lines[i:j + 1])
+        else:
+            nxt = min([t for t in tops if t > i] + [len(lines)])
+            body = "\n".join(lines[i:nxt])
+        out[name] = out.get(name, "") + "\n" + body
+    return out
+
+
+def _reachable(fns, roots):
+    seen, todo = set(), list(roots)
+    while todo:
+        f = todo.pop()
+        if f in seen or f not in fns:
+            continue
+        seen.add(f)
+        # callees: `name(`, and names passed as function values (`map(name, ...)`, `finalizer(name, ...)`, a bare `name,`)
+        for callee in set(re.findall(r"(?<![\w.:])(\w+!?)\s*\(", fns[f])) | set(re.findall(r"(?<![\w.:])(\w+!?)\s*,", fns[f])):
+            if callee in fns and callee not in seen:
+                todo.append(callee)
+    return seen
+
+
+DEVICE_PATH = ("block_device", "core_device", "chain_device", "model_device", "dist_device", "fninput_device", "collapsef_device",
+               "block_pullback_device", "core_pullback_device", "chain_pullback_device")
+
+
+def test_device_path_reaches_no_copy_no_sync_and_allocates_only_through_the_pool():
+    """A call operator on device inputs with a device-resident layer runs `<layer>_device` and nothing else (`gpu` of something that
+    is on the device returns it).  From those functions no hipMemcpy, no synchronisation and no upload / download is reachable, and
+    the only hipMalloc in the whole shim is the pool's miss path."""
+    fns = _functions()
+    for root in DEVICE_PATH:
+        assert root in fns, f"{root} is not defined in the shim"
+    reach = _reachable(fns, DEVICE_PATH)
+    assert {"DevBuf", "poolmiss", "workspace!", "block_c", "DeviceArray"} <= reach, sorted(reach)  # the walker does follow calls, inner constructors included
+    banned_fns = {"upload", "download", "synchronize", "gpu", "cpu", "back", "trim_pool!"}
+    assert not (reach & banned_fns), f"the device path reaches {sorted(reach & banned_fns)}"
+    for f in reach:
+        for sym in ("hipMemcpy", "hipMemcpyAsync", "hipDeviceSynchronize", "hipStreamSynchronize", "hipFree"):
+            assert (":" + sym) not in fns[f], f"{f} (reachable from the device path) calls {sym}"
+        if f != "poolmiss":
+            assert ":hipMalloc" not in fns[f], f"{f} calls hipMalloc outside the pool"
+    code = _strip_comments(SRC)
+    assert len(re.findall(r":hipMalloc\b", code)) == 1 and ":hipMalloc" in fns["poolmiss"], "hipMalloc must appear once: the pool's miss path"
+    assert ":hipDeviceSynchronize" not in code, "the shim synchronises a stream where the host needs data (cpu / Array), never the device"
+    # copies live in upload / download only
+    for f, body in fns.items():
+        if ":hipMemcpy" in body:
+            assert f in ("upload", "download"), f"{f} copies between host and device"
+
+
+def test_call_operators_are_the_device_path_plus_gpu_and_back():
+    """every layer's call operator is `back(<layer>_device(gpu(m), gpu(x)), x)`: device inputs take the device path, host inputs are
+    moved over and the result brought back — one implementation, no second code path to drift."""
+    code = _strip_comments(SRC)
+    for T, dev in (("GNBlock", "block_device"), ("GNCore", "core_device"), ("ChainBlock", "chain_device")):
+        assert re.search(rf"^\(m::{T}\)\(x\) = back\({dev}\(gpu\(m\), gpu\(x\)\), x\)", code, flags=re.M), T
+    assert re.search(r"^\(m::Model\)\(x\) = back\(model_device\(m, gpu\(x\)\), x\)", code, flags=re.M)
+    # gpu / cpu exist for the batched tuple, the batch handle and every layer type (the reference's `|> device`)
+    for T in ("NamedTuple", "GNGraphBatch", "Dense", "GNBlock", "LayerNorm", "GNCore", "GNCoreList", "ChainBlock"):
+        assert re.search(rf"^gpu\(\w+::{T}\)", code, flags=re.M), f"gpu(::{T}) is missing"
+        assert re.search(rf"^cpu\(\w+::{T}\)", code, flags=re.M), f"cpu(::{T}) is missing"
+    # every gnx_* launch of the device path goes to STREAM[] (asynchronous), and workspaces come from the batch's cache
+    fns = _functions()
+    for f in DEVICE_PATH:
+        if f == "dist_device":
+            continue  # (per-device default streams: the C entry point takes a stream ARRAY, NULL = default streams)
+        assert "STREAM[]" in fns[f], f"{f} does not launch on STREAM[]"
+    for f in ("block_device", "core_device", "chain_device", "block_pullback_device", "core_pullback_device", "chain_pullback_device"):
+        assert "workspace!(" in fns[f], f"{f} allocates its workspace per call"
