@@ -163,6 +163,45 @@ def c4_model(gn, torch, core, dev, seed=0):
     return layers, ps
 
 
+CLOCK_WARMUP_MS = 150.0  # untimed load before every timed region (see spin_up)
+
+
+def spin_up(torch, dev, run, ms=None):
+    """UNTIMED: keeps the GPU under the very load that is about to be timed for `ms` milliseconds.  After an idle period (graph capture,
+    host-side setup) the MI355X's power management needs tens of milliseconds of continuous load to settle: in a rocprofv3 trace of this
+    script the same k_rows_gemm launch takes 416 us right after the idle gap, 480-520 us a few milliseconds later and 372-380 us from
+    ~50 ms of load on (profiles/r04_clock_transient_core.txt); a 0.5-6 ms timed region started cold measures that transient, not the
+    kernels.  Replays `run` (batches of 4 between synchronisations, so the queue stays short) until the time is up."""
+    ms = CLOCK_WARMUP_MS if ms is None else ms
+    t0 = time.perf_counter()
+    n = 0
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(4):
+            run()
+        torch.cuda.synchronize(dev)
+        n += 4
+    return n
+
+
+def calibrated_kernel_us(prof, per=None):
+    """Per-scope kernel time in us from gnx_profile_read: dispatch timestamps (hipExtLaunchKernel start / stop events).  Those read a CONSTANT
+    ~3.9 us above rocprofv3's kernel trace on the same launches, whatever the kernel's length (an empty kernel: 7.8 vs 3.98 us; k_block_wave:
+    23.94 vs 20.08; the edge GEMM: 446.6 vs 442.6 — profiles/r04_selfcheck_*.txt), so (empty kernel timed live the same way) - (rocprofv3's
+    figure for it, profiles/calibration.json) is subtracted per KERNEL of a scope.  per = forwards the pass ran (else: per scope entry)."""
+    with open(os.path.join(ROOT, "profiles", "calibration.json")) as f:
+        calib = json.load(f)
+    null = prof.get("__empty_bracket__")
+    null_us = null["total_ms"] / max(null["launches"], 1) * 1e3 if null else calib["null_kernel_rocprof_us"]
+    off = max(null_us - calib["null_kernel_rocprof_us"], 0.0)
+    out = {}
+    for k, v in prof.items():
+        if k == "__empty_bracket__":
+            continue
+        n_kernels = v.get("kernels", v["launches"])
+        out[k] = round(max(v["total_ms"] * 1e3 - off * n_kernels, 0.0) / max(per or v["launches"], 1), 3)
+    return out
+
+
 def c4_cpu_baseline(ps, budget_s=6.0):
     """The oracle's C restatement of the 4-layer model on the host cores, on a BOUNDED sample of the workload: an Erdos-Renyi graph of the
     C2 law (mean in-degree 10) with 1/16 of C2's nodes and edges, grown x4 while one forward stays under ~1.5 s; edges/s through the model."""
@@ -215,10 +254,15 @@ def bench_c4(args, gn, torch, dev, c_abi=None):
     for _ in range(max(args.warmup, 1)):
         fwd()
     torch.cuda.synchronize(dev)
+    spin_up(torch, dev, fwd)  # (the per-kernel figures below are steady-state figures too)
     gn.profile_reset(); gn.profile_enable(True)
-    fwd(); torch.cuda.synchronize(dev)
+    for _ in range(3):
+        fwd()
+    gn.profile_calibrate(20, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
     gn.profile_enable(False)
-    kern = {k: round(v["total_ms"] * 1e3, 1) for k, v in gn.profile_read().items()}; gn.profile_reset()
+    praw = gn.profile_read(); gn.profile_reset()
+    kern = calibrated_kernel_us(praw, per=3)
     K = args.steps
     t0 = time.perf_counter()
     for _ in range(K):
@@ -236,6 +280,7 @@ def bench_c4(args, gn, torch, dev, c_abi=None):
     for _ in range(3):
         graphed.graph.replay()
     torch.cuda.synchronize(dev)
+    spin_up(torch, dev, graphed.graph.replay)
     reps = []
     for _ in range(3):
         t0 = time.perf_counter()
@@ -286,6 +331,71 @@ def bench_c4(args, gn, torch, dev, c_abi=None):
     print(json.dumps(line))
 
 
+def bench_dist_gnx(args):
+    """BASELINE configs[4] through the C boundary's OWN multi-GPU entry (gnx_dist_*): one process, --gpus devices, weak scaling as in the
+    torch path (N*512 graphs / N*1M edges, the product's partitioner, 512 graphs per device).  K steps = K / M calls of
+    gnx_dist_block_forward_steps with M steps each (one hipGraph launch per device + ONE grouped all-gather of the M stacked gf' tables per
+    call).  Timed region: all devices synchronised on both sides; median of three."""
+    import torch
+    import graphnets_jl_amd as gn
+    from graphnets_jl_amd.dist import DistBlockRunner, partition_graphs
+    n = args.gpus
+    assert torch.cuda.device_count() >= n, f"--dist-backend gnx drives {n} devices from this process; {torch.cuda.device_count()} visible"
+    din, dout = DIMS[args.dims] if args.dims in DIMS else tuple(tuple(int(v) for v in part.split(",")) for part in args.dims.split(":"))
+    Gtot, Etot = args.hetero_graphs * n, args.hetero_edges * n
+    seed = 3 if Gtot == 512 else (5 if Gtot == 4096 else 1000 + Gtot)
+    n_all, e_all = hetero_spec(seed, Gtot, Etot)
+    shards = partition_graphs(e_all, n)
+    K, W = args.steps, args.warmup
+    M = max(m for m in range(1, 65) if K % m == 0)
+    rng = np.random.default_rng(100)
+    (de, dn, dg), (oe, on, og) = din, dout
+    Ws = (glorot(rng, oe, de + 2 * dn + dg), glorot(rng, on, oe + dn + dg), glorot(rng, og, oe + on + dg))
+
+    def make_block(dev):
+        blk = gn.GNBlock(din, dout, device=dev)
+        blk.edgefn = gn.Dense.from_numpy(Ws[0], np.zeros(oe, np.float32), device=dev)
+        blk.nodefn = gn.Dense.from_numpy(Ws[1], np.zeros(on, np.float32), device=dev)
+        blk.graphfn = gn.Dense.from_numpy(Ws[2], np.zeros(og, np.float32), device=dev)
+        return blk
+    run = DistBlockRunner(list(range(n)), shards, lambda r: make_hetero(seed, Gtot, Etot, only=shards[r]), make_block, (din, dout), n_sets=NSETS, max_steps=M)
+
+    def region():
+        for j in range(K // M):
+            run.run((j * M) % NSETS, M)
+    for _ in range(max(2, -(-W // M))):  # warm-up: every (first set, M) argument set the region uses gets captured here
+        region()
+    run.synchronize()
+    reps = []
+    for _ in range(3):
+        run.synchronize()
+        t0 = time.perf_counter()
+        region()
+        run.synchronize()
+        reps.append(time.perf_counter() - t0)
+    dt = sorted(reps)[1]
+    # the eager form of the same entry point (no per-device hipGraph): what the replay form saves
+    t0 = time.perf_counter()
+    for j in range(K // M):
+        run.run((j * M) % NSETS, M, flags=gn._lib.FLAG_NO_GRAPH)
+    run.synchronize()
+    dt_eager = time.perf_counter() - t0
+    E = run.edges
+    abytes = sum(algorithmic_bytes(g.n_edges, g.n_nodes, g.n_graphs, din, dout) for g in run.handles)
+    line = {"metric": "edges updated/sec, GNBlock fwd, 1M-edge batch", "value": round(E / (dt / K), 1), "unit": "edges/s", "n_gpus": n, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ONE heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {n} GPU(s) "
+                                   f"driven by ONE process through gnx_dist_block_forward_steps (BASELINE configs[4] law)",
+                       "dims": f"{din}=>{dout}", "edges_whole_job": E, "graphs_per_gpu": [g.n_graphs for g in run.handles], "dist_backend": "gnx",
+                       "launch": f"{K // M} calls of gnx_dist_block_forward_steps per region, {M} steps each: one hipGraphLaunch per device + ONE grouped ncclAllGather of the {M} stacked gf' tables per call",
+                       "timing": f"median of 3 regions ({[round(r / K * 1e6, 2) for r in reps]} us/step)", "eager_ms_per_step": round(dt_eager / K * 1e3, 6)},
+            "roofline": {"bound": "hbm", "achieved": round(abytes / (dt / K) / 1e9, 2), "peak": HBM_PEAK_GBS * n, "unit": "GB/s", "frac": round(abytes / (dt / K) / 1e9 / (HBM_PEAK_GBS * n), 4),
+                         "counts": "algorithmic bytes of every device's shard / whole-step time / (n_gpus x 8 TB/s)", "algorithmic_bytes": abytes}}
+    run.close()
+    _flush_c_stdio()
+    print(json.dumps(line), flush=True)
+
+
 def model_source_sha(core):
     """sha256 over the kernel sources a C4 model runs (both paths' files at wide widths, the narrow files otherwise)."""
     files = sorted(set(KERNEL_SOURCES["wide"] + KERNEL_SOURCES["narrow"] + (("gnx_ffn_fused.hip", "gnx_generic.hip") if max(core) >= 32 else ("gnx_core_narrow.hip", "gnx_core_post_kernel.h"))))
@@ -300,6 +410,12 @@ SECONDARY = [  # (key, extra argv, BASELINE config it stands for)
     ("core_c2", ["--dims", "core"], "configs[1] graph at core dims (128,64,32)=>(128,64,32): the matrix-core path"),
     ("c3", ["--workload", "hetero", "--hetero-graphs", "512"], "configs[2]: 512 random graphs (32-256 nodes), 1M edges"),
     ("c5_one_gpu", ["--workload", "hetero", "--hetero-graphs", "4096"], "configs[4]'s batch on one GPU: 4096 graphs, 1M edges"),
+    ("c5w_one_gpu", ["--workload", "hetero", "--hetero-graphs", "4096", "--hetero-edges", "8000000"],
+     "C5w (SURVEY 8d): configs[4]'s 4096 graphs at configs[2]'s density, 8M edges on one GPU — the block kernel over eight rounds of waves instead of one (its steady state)"),
+    ("c5_dist_gnx", ["--dist-backend", "gnx", "--hetero-graphs", "4096"],
+     "configs[4]'s batch through the C boundary's own multi-GPU entry at one device: gnx_dist_block_forward_steps (hipGraph per device + grouped ncclAllGather + index table)"),
+    ("c5_force_dist", ["--force-dist", "--hetero-graphs", "4096"],
+     "configs[4]'s batch through the N > 1 code path at world size 1 (partitioner, stacked gf' send buffer, RCCL all-gather on a side stream, index table back to graph order)"),
     ("c4", ["--model", "c4"], "configs[3]: Encoder -> 2 x GNCore(128,64,32) -> Decoder on the 1M-edge graph"),
     ("c4_narrow", ["--model", "c4", "--core-dims", "10,5,3"], "README example 3 at its own widths (core_dims 10,5,3)"),
 ]
@@ -332,7 +448,7 @@ def collect_secondary(args):
         ts = roof.get("traffic_source")
         if ts:
             entry["roofline"]["traffic_source"] = {k: ts.get(k) for k in ("file", "commit", "stale") if ts.get(k) is not None}
-        for k in ("batch_ms", "kernel_us_one_forward", "pipelined_two_streams", "c_abi_ms_per_step", "c_abi"):
+        for k in ("batch_ms", "kernel_us_one_forward", "pipelined_two_streams", "c_abi_ms_per_step", "c_abi", "n_gpus"):
             if k in line or k in line.get("config", {}):
                 entry[k] = line.get(k, line.get("config", {}).get(k))
         out[key] = entry
@@ -417,11 +533,17 @@ def main():
                     help="two-phase steps: graph update of step i on a second stream (measured SLOWER inside a hipGraph: the "
                          "fork/join costs more than the 5 us it hides — 35.7 vs 27.7 us/step — so it is off by default)")
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path even with one rank (testing)")
+    ap.add_argument("--dist-backend", choices=["torch", "gnx"], default="torch",
+                    help="torch: one process per GPU, gf' all-gathered by torch.distributed's RCCL (the contract's launch form; default).  gnx: ONE process "
+                         "drives --gpus devices through the C boundary's own sharded path (gnx_dist_block_forward_steps: a hipGraph per device + one "
+                         "grouped ncclAllGather) — what a Julia session does; run it directly, not under torchrun")
     ap.add_argument("--core-dims", type=str, default="128,64,32", help="core widths for --model c4 (README ex.3 uses 10,5,3)")
     ap.add_argument("--model", choices=["block", "c4"], default="block",
                     help="c4: BASELINE configs[3] — encoder -> 2 x GNCore(128,64,32) -> decoder on the C2 graph (extra; not the headline line)")
     args = ap.parse_args()
 
+    if args.dist_backend == "gnx":
+        return bench_dist_gnx(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args))  # nothing has touched a GPU yet (torch is not even imported)
     # the default single-GPU line carries the other configs: child processes, one at a time, BEFORE this process touches the GPU
@@ -582,10 +704,12 @@ def main():
             return cg
         cold = capture(K, True)
         cold.replay(); torch.cuda.synchronize(dev)
+        spin_up(torch, dev, cold.replay)
         reps = sorted(timed(cold.replay) for _ in range(3))
         dt = reps[1]
         warm = capture(K, False)
         warm.replay(); torch.cuda.synchronize(dev)
+        spin_up(torch, dev, warm.replay, 50.0)
         extra["warm_ms_per_step"] = round(sorted(timed(warm.replay) for _ in range(3))[1] / K * 1e3, 6)
         extra["launch"] = (f"hipGraph of {K} steps, {nsets} rotating buffer sets (cache-cold); " +
                            ("single stream" if not args.overlap else "graph update of step i on a 2nd stream, overlapping step i+1 (joined inside the timed region)"))
@@ -610,6 +734,7 @@ def main():
                     with torch.cuda.stream(st):
                         cg.replay()
             run_two(); torch.cuda.synchronize(dev)
+            spin_up(torch, dev, run_two, 50.0)
             dt2 = sorted(timed(run_two) for _ in range(3))[1]
             pipelined = {"ms_per_step": round(dt2 / Kp * 1e3, 6), "value": round(E / (dt2 / Kp), 1), "unit": "edges/s", "steps": Kp,
                          "what": f"{Kp} steps of the same kind as two hipGraphs (even / odd steps) on two streams: independent batches pipelined; results bit-identical; not the headline"}
@@ -633,12 +758,15 @@ def main():
                 gather.start_inplace()
                 copied.record(gather.comm_stream) if gather.comm_stream is not None else copied.record()
         run(); sync_all()
+        t_w = time.perf_counter()
+        while (time.perf_counter() - t_w) * 1e3 < CLOCK_WARMUP_MS:  # (same untimed load as spin_up; every rank runs the same wall time, then the bracket's barrier)
+            run(); sync_all()
         reps = sorted(timed(run) for _ in range(3))
         dt = reps[1]
         gf_all = gather.finish() if gather._ready is not None else gather.result()
         assert tuple(gf_all.reshape(M, -1, og).shape) == (M, gather.G, og) and torch.equal(gf_all.reshape(-1, og), gf_result)
         extra["launch"] = f"hipGraph of {M} steps per replay; one RCCL all-gather of the {M} stacked gf' tables per replay, overlapped on a side stream"
-    extra["timing"] = f"median of 3 runs of the {K}-step region ({[round(r / K * 1e6, 2) for r in reps]} us/step)"
+    extra["timing"] = f"median of 3 runs of the {K}-step region ({[round(r / K * 1e6, 2) for r in reps]} us/step), after {CLOCK_WARMUP_MS:g} ms of the same load, untimed (clock settling: bench.py::spin_up)"
     ms_per_step = dt / K * 1e3
     if multi:  # whole-job edges: every rank's shard
         t = torch.tensor([float(E)], device=dev, dtype=torch.float64)
@@ -652,8 +780,12 @@ def main():
     # so that the events bracket kernel execution, not host launch gaps ----
     roof = None
     if rank == 0:
+        def eager_pass():
+            for i in range(K):
+                b = sets[i % nsets]
+                plan(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"])
+        spin_up(torch, dev, eager_pass)  # the pass below runs at settled clocks, like the timed region
         gn.profile_reset(); gn.profile_enable(True)
-        torch.cuda._sleep(int(2.0e9 * 0.02))
         for i in range(K):
             b = sets[i % nsets]
             plan(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"])
@@ -661,15 +793,9 @@ def main():
         torch.cuda.synchronize(dev)
         gn.profile_enable(False)
         prof = gn.profile_read(); gn.profile_reset()
-        raw = {k: v["total_ms"] / max(v["launches"], 1) * 1e3 for k, v in prof.items()}  # avg µs per launch, event bracket
-        # An event bracket around an EMPTY launch costs `bracket` µs, of which rocprofv3 itself attributes `null_us` to the
-        # (empty) kernel (profiles/calibration.json, with the profile it was read from); the rest is what the bracket adds to
-        # any kernel's duration.
-        with open(os.path.join(ROOT, "profiles", "calibration.json")) as f:
-            calib = json.load(f)
-        bracket = raw.pop("__empty_bracket__", 0.0)
-        overhead = max(bracket - calib["null_kernel_rocprof_us"], 0.0)
-        kern = {k: max(v - overhead, 0.0) for k, v in raw.items()}
+        null_us = (prof.get("__empty_bracket__") or {"total_ms": 0.0, "launches": 1})
+        null_us = null_us["total_ms"] / max(null_us["launches"], 1) * 1e3
+        kern = calibrated_kernel_us(prof)
         dom = max(kern, key=kern.get)
         dur_s = kern[dom] * 1e-6
         step_s = ms_per_step * 1e-3
@@ -706,8 +832,8 @@ def main():
                                                  "infinity_cache_hits_estimate": bd[dom]["infinity_cache_hit_bytes_estimate"],
                                                  "source": "profiles/traffic_breakdown_readme.json"}
         assert roof["frac"] <= 1.0 and roof["frac_whole_step"] <= 1.0, "a roofline fraction above 1 is an accounting error"
-        roof.update(kernel=dom, kernel_us=round(kern[dom], 3), event_bracket_overhead_us=round(overhead, 3),
-                    event_calibration=calib, algorithmic_bytes=abytes, algorithmic_flops=aflops,
+        roof.update(kernel=dom, kernel_us=round(kern[dom], 3), kernel_us_source="dispatch timestamps of every launch of the per-kernel pass (hipExtLaunchKernel start / stop events), averaged, minus the constant (empty kernel timed the same way - rocprofv3's figure for it: profiles/calibration.json)",
+                    null_kernel_us=round(null_us, 3), algorithmic_bytes=abytes, algorithmic_flops=aflops,
                     bytes_per_edge=round(abytes / E, 2), all_kernels_us={k: round(v, 3) for k, v in kern.items()})
 
     # ---- CPU baseline: the oracle's C restatement ("port") on the host cores, rank 0, N = 1 only ----

@@ -86,7 +86,7 @@ class Layer(C.Structure):
 
 
 class ProfileEntry(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double), ("kernels", C.c_int64)]
 
 
 class GnxError(RuntimeError):
@@ -145,6 +145,7 @@ SIGNATURES = {
     "gnx_dist_permute_rows": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "gnx_dist_allgather_gf": (C.c_int32, [C.c_void_p, _pp, _pp, _pp]),
     "gnx_dist_block_forward": (C.c_int32, [C.c_void_p] + [_pp] * 10 + [C.POINTER(C.c_size_t), C.c_uint32, _pp]),
+    "gnx_dist_block_forward_steps": (C.c_int32, [C.c_void_p, C.c_int32] + [_pp] * 9 + [C.POINTER(C.c_size_t), C.c_uint32, _pp]),
     "gnx_jit_precompile": (C.c_int32, [C.POINTER(BlockParams), C.c_int32, C.POINTER(C.c_size_t)]),
     "gnx_jit_precompile_core_post": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "gnx_jit_stats": (C.c_int32, [_i64p]),
@@ -198,4 +199,4 @@ def profile_read():
     n = C.c_int32(0)
     buf = (ProfileEntry * 64)()
     check(lib.gnx_profile_read(buf, 64, C.byref(n)))
-    return {buf[i].name.decode(): dict(launches=buf[i].launches, total_ms=buf[i].total_ms) for i in range(min(n.value, 64))}
+    return {buf[i].name.decode(): dict(launches=buf[i].launches, total_ms=buf[i].total_ms, kernels=buf[i].kernels) for i in range(min(n.value, 64))}

@@ -96,8 +96,8 @@ static void launch_delta(const DeltaArgs& a, size_t ex1_rep, size_t ex2_rep, uns
   const bool al = (((uintptr_t)a.G | (uintptr_t)a.out | (uintptr_t)a.delta | (uintptr_t)a.ex1 | (uintptr_t)a.ex2) & 15) == 0;
   const bool v4 = al && a.J % 4 == 0 && a.ex1_stride % 4 == 0 && a.ex1_off % 4 == 0 && a.ex2_stride % 4 == 0 && a.ex2_off % 4 == 0 && ex1_rep % 4 == 0 &&
                   ex2_rep % 4 == 0;
-  if (v4) hipLaunchKernelGGL(k_bw_delta_v4, dim3((unsigned)(((size_t)a.rows * (a.J / 4) + 255) / 256), Ru), dim3(256), 0, s, a, ex1_rep, ex2_rep);
-  else hipLaunchKernelGGL(k_bw_delta, dim3((unsigned)(((size_t)a.rows * a.J + 255) / 256), Ru), dim3(256), 0, s, a, ex1_rep, ex2_rep);
+  if (v4) GNX_LAUNCH(k_bw_delta_v4, dim3((unsigned)(((size_t)a.rows * (a.J / 4) + 255) / 256), Ru), dim3(256), 0, s, a, ex1_rep, ex2_rep);
+  else GNX_LAUNCH(k_bw_delta, dim3((unsigned)(((size_t)a.rows * a.J + 255) / 256), Ru), dim3(256), 0, s, a, ex1_rep, ex2_rep);
 }
 
 // dX[m][k] = sum_j W[k*J + j] * delta[m][j]   (W is (J x K) column-major); one thread per (m, k)
@@ -277,7 +277,7 @@ static void launch_bw_dx(dim3 grid, hipStream_t s, const float* delta, const flo
                          int direct_w) {
   if (grid.x == 0 || grid.y == 0) return;  // a function without inputs (K = 0: e.g. a node function when oe = dn = dg = 0) has no dX
   ProfScope ps("bw_dx_generic", s);
-  hipLaunchKernelGGL(k_bw_dx, grid, dim3(256), 0, s, delta, W, rows, J, K, dX, k0, k1, direct, direct_w);
+  GNX_LAUNCH(k_bw_dx, grid, dim3(256), 0, s, delta, W, rows, J, K, dX, k0, k1, direct, direct_w);
 }
 
 struct BwLayout {
@@ -312,12 +312,12 @@ static int32_t dw_reduce(const float* delta, const float* X, size_t rows, int J,
   const int P = J * (K + 1);
   ProfScope ps("bw_dw_generic", s);
   if (nchunks <= 2 && P >= 4096) {
-    hipLaunchKernelGGL(k_bw_dw_small, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, delta, X, (int)rows, J, K, g.weight, g.bias);
+    GNX_LAUNCH(k_bw_dw_small, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, delta, X, (int)rows, J, K, g.weight, g.bias);
     GNX_HIP(hipGetLastError());
     return GNX_OK;
   }
-  hipLaunchKernelGGL(k_bw_dw_partial, dim3(nchunks), dim3(256), 0, s, delta, X, rows, J, K, partial);
-  hipLaunchKernelGGL(k_bw_dw_final, dim3(P), dim3(256), 0, s, partial, nchunks, J, K, g.weight, g.bias);
+  GNX_LAUNCH(k_bw_dw_partial, dim3(nchunks), dim3(256), 0, s, delta, X, rows, J, K, partial);
+  GNX_LAUNCH(k_bw_dw_final, dim3(P), dim3(256), 0, s, partial, nchunks, J, K, g.weight, g.bias);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -327,7 +327,7 @@ static int32_t dw_auto(const float* delta, const float* X, size_t rows, int J, i
   if (!bw_use_mfma_dw(rows, J, K)) return dw_reduce(delta, X, rows, J, K, g, partial, s);
   int32_t rc = dw_mfma(delta, X, rows, J, K, g.weight, partial, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows);
+  GNX_LAUNCH(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows);
   return colsum_all(delta, rows, J, g.bias, partial, off2, s);
 }
 
@@ -536,8 +536,8 @@ static int32_t colsum_all(const float* in, size_t rows, int d, float* out, float
   if (rows == 0) { GNX_HIP(hipMemsetAsync(out, 0, sizeof(float) * d, s)); return GNX_OK; }
   ProfScope ps("bw_colsum_all", s);
   const int S = (int)std::min<size_t>(std::max<size_t>(rows / 512, 1), 2048);
-  hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S, 1, 1), dim3(256), 0, s, in, d, (int)rows, d_off2, S, 1, part, d, 0);
-  hipLaunchKernelGGL(k_bw_colsum_final, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, s, part, d, S, out);
+  GNX_LAUNCH(k_bw_colsum1, dim3((unsigned)S, 1, 1), dim3(256), 0, s, in, d, (int)rows, d_off2, S, 1, part, d, 0);
+  GNX_LAUNCH(k_bw_colsum_final, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, s, part, d, S, out, 0);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -604,8 +604,8 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
                     int accumulate) {
     if (d == 0) return;
     const int S = (int)std::min<int64_t>(std::max<int64_t>(max_rows / 2048, 1), 256);
-    hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S * (unsigned)G, 1, Ru), dim3(256), 0, s, in, d, rows_total, off, S, G, part, ld, coff);
-    hipLaunchKernelGGL(k_bw_colsum2, dim3((unsigned)G, Ru), dim3(64), 0, s, part, d, S, G, out, out_stride, out_off, accumulate);
+    GNX_LAUNCH(k_bw_colsum1, dim3((unsigned)S * (unsigned)G, 1, Ru), dim3(256), 0, s, in, d, rows_total, off, S, G, part, ld, coff);
+    GNX_LAUNCH(k_bw_colsum2, dim3((unsigned)G, Ru), dim3(64), 0, s, part, d, S, G, out, out_stride, out_off, accumulate);
   };
   // Edge level on the matrix cores: regrouped (see below) — the edge function's input Xe is never materialised.
   // (a gelu edge function needs its pre-activation, hence the materialised Xe of the generic form)
@@ -614,7 +614,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   auto preact = [&](int level, const float* X, const gnx_dense& d, size_t rows, int K, int J, float* z) {
     if (acts[level] != GNX_ACT_GELU || rows == 0 || J == 0) return;
     ProfScope ps("bw_gelu_preact", s);
-    hipLaunchKernelGGL(k_fw_dense, blocks(rows * J), dim3(256), 0, s, X, d.weight, d.bias, rows, K, J, GNX_ACT_IDENTITY, z);
+    GNX_LAUNCH(k_fw_dense, blocks(rows * J), dim3(256), 0, s, X, d.weight, d.bias, rows, K, J, GNX_ACT_IDENTITY, z);
   };
   // function inputs, exactly as the forward's building blocks define them
   { ProfScope ps("bw_fn_inputs", s);
@@ -623,7 +623,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   if (og) {  // Xg = [sum_e ef' ; sum_n nf' ; gf] with parallel two-stage column sums (one workgroup per graph would walk 1M rows)
     colsum(ef_out, oe, oe, 0, E, h->d_edge_off, me, Xg, Kg, 0, 0);
     colsum(nf_out, on, on, 0, N, h->d_node_off, mn, Xg, Kg, oe, 0);
-    if (dg) hipLaunchKernelGGL(k_bw_copy_gf, blocks((size_t)R * G * dg), dim3(256), 0, s, gf, dg, (int)(R * G), Xg, Kg, oe + on);
+    if (dg) GNX_LAUNCH(k_bw_copy_gf, blocks((size_t)R * G * dg), dim3(256), 0, s, gf, dg, (int)(R * G), Xg, Kg, oe + on);
     GNX_HIP(hipGetLastError());
   }
 
@@ -632,7 +632,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   if (have_g) {
     preact(2, Xg, p->graphfn, (size_t)R * G, Kg, og, dlt_g);
     DeltaArgs a{g_gf_out, acts[2] == GNX_ACT_GELU ? dlt_g : gf_out, dlt_g, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, og, G, G, acts[2], 0};
-    hipLaunchKernelGGL(k_bw_delta, dim3(blocks((size_t)G * og).x, Ru), dim3(256), 0, s, a, (size_t)0, (size_t)0);
+    GNX_LAUNCH(k_bw_delta, dim3(blocks((size_t)G * og).x, Ru), dim3(256), 0, s, a, (size_t)0, (size_t)0);
     launch_bw_dx(dim3(blocks((size_t)G * Kg).x, Ru), s, dlt_g, p->graphfn.weight, G, og, Kg, dXg, 0, 0, (float*)nullptr, 0);
     if ((rc = dw_reduce(dlt_g, Xg, (size_t)R * G, og, Kg, gr.graphfn, part, s))) return rc;
   }
@@ -693,7 +693,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
         if ((rc = dw_any(S_dst, nf, (size_t)R * N, dn, dW + (size_t)(de + dn) * oe))) return rc;
         if ((rc = dw_any(S_g, gf, (size_t)R * G, dg, dW + (size_t)(de + 2 * dn) * oe))) return rc;
       }
-      hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)(R * E));
+      GNX_LAUNCH(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)(R * E));
       if ((rc = colsum_all(dlt_e, (size_t)R * E, oe, gr.edgefn.bias, part, off2, s))) return rc;
     } else {
       launch_bw_dx(dim3(blocks((size_t)E * Ke).x, Ru), s, dlt_e, p->edgefn.weight, E, oe, Ke, dXe, 0, de, d_ef, de);
@@ -711,12 +711,12 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
   // input gradients that need sums
   if (d_nf && dn && !mfma_e) {
     ProfScope ps("bw_dnf", s);
-    hipLaunchKernelGGL(k_bw_dnf, dim3(blocks((size_t)N * dn).x, Ru), dim3(256), 0, s, have_n ? dXn : nullptr, Kn, oe, have_e ? dXe : nullptr, dxe_stride,
+    GNX_LAUNCH(k_bw_dnf, dim3(blocks((size_t)N * dn).x, Ru), dim3(256), 0, s, have_n ? dXn : nullptr, Kn, oe, have_e ? dXe : nullptr, dxe_stride,
                        de - dxe_col0, de + dn - dxe_col0, h->d_colptr, h->d_csr_ptr, h->d_csr_eid, N, E, dn, d_nf);
   }
   if (d_gf && dg) {  // d_gf[g] = dXg[g][gf cols] + sum_{n in g} dXn[n][gf cols] + sum_{e in g} dXe[e][gf cols]
     ProfScope ps("bw_dgf", s);
-    hipLaunchKernelGGL(k_bw_dgf_init, blocks((size_t)R * G * dg), dim3(256), 0, s, have_g ? dXg : nullptr, Kg, oe + on, (int)(R * G), dg, d_gf);
+    GNX_LAUNCH(k_bw_dgf_init, blocks((size_t)R * G * dg), dim3(256), 0, s, have_g ? dXg : nullptr, Kg, oe + on, (int)(R * G), dg, d_gf);
     if (have_n) colsum(dXn, dg, Kn, oe + dn, N, h->d_node_off, mn, d_gf, dg, 0, 1);
     if (have_e && mfma_e) { if ((rc = add_cols(dXe, Ke, de + 2 * dn, (size_t)R * G, dg, d_gf, 1, s))) return rc; }  // dXe holds S_g We^T here
     else if (have_e) colsum(dXe, dg, dxe_stride, de + 2 * dn - dxe_col0, E, h->d_edge_off, me, d_gf, dg, 0, 1);
@@ -833,7 +833,7 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
       DeltaArgs a{dh, hbuf, dh, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, H, (int)rows[t], 1, GNX_ACT_GELU, 0};
       { ProfScope ps("bw_delta", s); launch_delta(a, 0, 0, 1, s); }
       ProfScope ps("bw_gelu_hidden", s);
-      hipLaunchKernelGGL(k_act_inplace, blocks(rows[t] * H), dim3(256), 0, s, hbuf, rows[t] * (size_t)H, GNX_ACT_GELU);
+      GNX_LAUNCH(k_act_inplace, blocks(rows[t] * H), dim3(256), 0, s, hbuf, rows[t] * (size_t)H, GNX_ACT_GELU);
     };
     if (bw_use_mfma(rows[t], D, H)) {  // matrix cores (gnx_backward_wide.hip); rows[t] = R * (rows of entity t)
       float* wt = F(L.wt);
@@ -853,9 +853,9 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
       if (rc) return rc;
       if (tcs) {
         ProfScope ps("bw_colsum_all", s);
-        hipLaunchKernelGGL(k_bw_colsum_final, dim3((unsigned)((H + 63) / 64)), dim3(256), 0, s, tcs, H, (int)(R * n_tiles), gr.ff[t].fc1.bias);
+        GNX_LAUNCH(k_bw_colsum_final, dim3((unsigned)((H + 63) / 64)), dim3(256), 0, s, tcs, H, (int)(R * n_tiles), gr.ff[t].fc1.bias, 0);
       } else if (gelu1 && dw1_mfma && gr.ff[t].fc1.bias) {
-        hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows[t]);
+        GNX_LAUNCH(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows[t]);
         if ((rc = colsum_all(dh, rows[t], H, gr.ff[t].fc1.bias, part, off2, s))) return rc;
       }
       if ((rc = dx_mfma(h, t, dh, p->ff[t].fc1.weight, H, D, 0, D, dz2, R, wt, true, s, "bw_dx_ff1"))) return rc;        // dz2 = delta1 W1^T
@@ -863,7 +863,7 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
       continue;
     }
     { ProfScope ps("bw_fw_dense_generic", s);
-    hipLaunchKernelGGL(k_fw_dense, blocks(rows[t] * H), dim3(256), 0, s, F(L.l2[t]), p->ff[t].fc1.weight, p->ff[t].fc1.bias, rows[t], D, H, fc1_re.act, hbuf); }
+    GNX_LAUNCH(k_fw_dense, blocks(rows[t] * H), dim3(256), 0, s, F(L.l2[t]), p->ff[t].fc1.weight, p->ff[t].fc1.bias, rows[t], D, H, fc1_re.act, hbuf); }
     if (!gelu1 && (rc = dw_reduce(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, s))) return rc;             // dW2 = g^T h
     launch_bw_dx(dim3(blocks(rows[t] * H).x, 1), s, gout[t], p->ff[t].fc2.weight, (int)rows[t], D, H, dh, 0, 0, (float*)nullptr, 0);
     if (gelu1) {
@@ -871,7 +871,7 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
       if ((rc = dw_reduce(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, s))) return rc;
     } else {
       DeltaArgs a{dh, hbuf, dh, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, H, (int)rows[t], 1, act1, 0};  // delta1 = dh * act1'(h), in place
-      hipLaunchKernelGGL(k_bw_delta, dim3(blocks(rows[t] * H).x, 1), dim3(256), 0, s, a, (size_t)0, (size_t)0);
+      GNX_LAUNCH(k_bw_delta, dim3(blocks(rows[t] * H).x, 1), dim3(256), 0, s, a, (size_t)0, (size_t)0);
     }
     if ((rc = dw_reduce(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1, part, s))) return rc;                      // dW1 = delta1^T z
     launch_bw_dx(dim3(blocks(rows[t] * D).x, 1), s, dh, p->ff[t].fc1.weight, (int)rows[t], H, D, dz2, 0, 0, (float*)nullptr, 0);
@@ -892,7 +892,7 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
       {
         ProfScope ps("bw_layernorm", s);
         switch (d[t] / 64) {
-#define GNX_LNB_CASE(Q) case Q: hipLaunchKernelGGL((k_ln_backward_v4<Q>), dim3(nb), dim3(256), 0, s, x[t], rows[t], p->ln1[t].gamma, p->ln2[t].gamma, \
+#define GNX_LNB_CASE(Q) case Q: GNX_LAUNCH((k_ln_backward_v4<Q>), dim3(nb), dim3(256), 0, s, x[t], rows[t], p->ln1[t].gamma, p->ln2[t].gamma, \
                                                    F(L.dl1[t]), F(L.dz2[t]), gout[t], p->eps, p->eps_mode, dxo[t], cpart); break;
           GNX_LNB_CASE(1) GNX_LNB_CASE(2) GNX_LNB_CASE(3) GNX_LNB_CASE(4) GNX_LNB_CASE(5) GNX_LNB_CASE(6) GNX_LNB_CASE(7) GNX_LNB_CASE(8)
 #undef GNX_LNB_CASE
@@ -901,14 +901,14 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
       ProfScope ps("bw_colsum_all", s);
       float* outs[4] = {gr.ln1[t].gamma, gr.ln1[t].beta, gr.ln2[t].gamma, gr.ln2[t].beta};
       for (int w = 0; w < 4; ++w)
-        if (outs[w]) hipLaunchKernelGGL(k_bw_colsum_final, dim3((unsigned)((d[t] + 63) / 64)), dim3(256), 0, s, cpart + (size_t)w * d[t], d[t], (int)nb, outs[w], 4 * d[t]);
+        if (outs[w]) GNX_LAUNCH(k_bw_colsum_final, dim3((unsigned)((d[t] + 63) / 64)), dim3(256), 0, s, cpart + (size_t)w * d[t], d[t], (int)nb, outs[w], 4 * d[t]);
       GNX_HIP(hipGetLastError());
       continue;
     }
     { ProfScope ps("bw_layernorm", s);
-    hipLaunchKernelGGL(k_ln_backward, dim3((unsigned)((rows[t] + 3) / 4)), dim3(256), 0, s, x[t], rows[t], d[t], p->ln1[t].gamma, p->ln2[t].gamma, F(L.dl1[t]),
+    GNX_LAUNCH(k_ln_backward, dim3((unsigned)((rows[t] + 3) / 4)), dim3(256), 0, s, x[t], rows[t], d[t], p->ln1[t].gamma, p->ln2[t].gamma, F(L.dl1[t]),
                        F(L.dz2[t]), gout[t], p->eps, p->eps_mode, dxo[t], t1, t2); }
-    hipLaunchKernelGGL(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows[t]);
+    GNX_LAUNCH(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows[t]);
     if ((rc = colsum_all(t1, rows[t], d[t], gr.ln1[t].gamma, part, off2, s))) return rc;
     if ((rc = colsum_all(F(L.dl1[t]), rows[t], d[t], gr.ln1[t].beta, part, off2, s))) return rc;
     if ((rc = colsum_all(t2, rows[t], d[t], gr.ln2[t].gamma, part, off2, s))) return rc;
@@ -1043,7 +1043,7 @@ int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_para
     const float* outp = A(t, i);
     if (d.act == GNX_ACT_GELU) {
       ProfScope ps("bw_gelu_preact", s);
-      hipLaunchKernelGGL(k_fw_dense, blocks(rows[t] * J), dim3(256), 0, s, Ain, d.weight, d.bias, rows[t], K, J, GNX_ACT_IDENTITY, gb[2]);
+      GNX_LAUNCH(k_fw_dense, blocks(rows[t] * J), dim3(256), 0, s, Ain, d.weight, d.bias, rows[t], K, J, GNX_ACT_IDENTITY, gb[2]);
       outp = gb[2];
     }
     DeltaArgs a{buf, outp, buf, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, J, (int)rows[t], 1, d.act, 0};
@@ -1083,7 +1083,7 @@ int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_para
       const float* Ain = li > 0 ? A(t, li - 1) : X0;
       const int K = li > 0 ? ch[t]->widths[li - 1] : K0;
       ProfScope ps("bw_gelu_preact", s);
-      hipLaunchKernelGGL(k_fw_dense, blocks(rows[t] * J), dim3(256), 0, s, Ain, d.weight, d.bias, rows[t], K, J, GNX_ACT_IDENTITY, gb[2]);
+      GNX_LAUNCH(k_fw_dense, blocks(rows[t] * J), dim3(256), 0, s, Ain, d.weight, d.bias, rows[t], K, J, GNX_ACT_IDENTITY, gb[2]);
       outp = gb[2];
     }
     DeltaArgs a{upstream, outp, out, t >= 1 && og > 0 ? dXg : nullptr, Kg, t == 1 ? oe : 0, t == 0 && on > 0 ? dXn : nullptr, Kn, 0,
@@ -1124,8 +1124,8 @@ int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_para
       int64_t mn = 1;
       for (int64_t g = 0; g < h->G; ++g) mn = std::max(mn, h->h_node_off[g + 1] - h->h_node_off[g]);
       const int S = (int)std::min<int64_t>(std::max<int64_t>(mn / 2048, 1), 256);
-      hipLaunchKernelGGL(k_bw_colsum1, dim3((unsigned)S * (unsigned)G, 1, Ru), dim3(256), 0, s, dXn, dg, N, h->d_node_off, S, G, part, Kn, oe + dn);
-      hipLaunchKernelGGL(k_bw_colsum2, dim3((unsigned)G, Ru), dim3(64), 0, s, part, dg, S, G, d_gf, dg, 0, 1);
+      GNX_LAUNCH(k_bw_colsum1, dim3((unsigned)S * (unsigned)G, 1, Ru), dim3(256), 0, s, dXn, dg, N, h->d_node_off, S, G, part, Kn, oe + dn);
+      GNX_LAUNCH(k_bw_colsum2, dim3((unsigned)G, Ru), dim3(64), 0, s, part, dg, S, G, d_gf, dg, 0, 1);
     }
     if (og > 0 && (rc = add_cols(dXg, Kg, oe + on, rows[2], dg, d_gf, 1, s))) return rc;
   }

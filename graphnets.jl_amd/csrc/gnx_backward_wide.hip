@@ -150,13 +150,13 @@ int32_t dw_mfma(const float* delta, const float* X, size_t rows, int J, int K, f
   const bool v4 = (((uintptr_t)delta | (uintptr_t)X) & 15) == 0 && J % 4 == 0 && K % 4 == 0;
   {
     ProfScope ps("k_dw_gemm", s);
-    if (v4) hipLaunchKernelGGL((k_dw_gemm<true>), grid, dim3(256), 0, s, X, K, delta, J, rows, CH, partial);
-    else hipLaunchKernelGGL((k_dw_gemm<false>), grid, dim3(256), 0, s, X, K, delta, J, rows, CH, partial);
+    if (v4) GNX_LAUNCH((k_dw_gemm<true>), grid, dim3(256), 0, s, X, K, delta, J, rows, CH, partial);
+    else GNX_LAUNCH((k_dw_gemm<false>), grid, dim3(256), 0, s, X, K, delta, J, rows, CH, partial);
   }
   const size_t KJ = (size_t)K * J;
   {
     ProfScope ps("k_dw_final2", s);
-    hipLaunchKernelGGL(k_dw_final2, dim3((unsigned)((KJ + 255) / 256)), dim3(256), 0, s, partial, (int)nch, KJ, dW);
+    GNX_LAUNCH(k_dw_final2, dim3((unsigned)((KJ + 255) / 256)), dim3(256), 0, s, partial, (int)nch, KJ, dW);
   }
   GNX_HIP(hipGetLastError());
   return GNX_OK;
@@ -168,7 +168,7 @@ int32_t dx_mfma(const gnx_graphs* h, int entity, const float* delta, const float
                 float* WT, bool fill, hipStream_t s, const char* name, const float* gmul, int gmul_act, float* tile_colsum, int* n_tiles_out) {
   if (kb <= ka || J == 0) return GNX_OK;
   if (fill) {
-    hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)((K * J + 255) / 256)), dim3(256), 0, s, W, K, J, WT);
+    GNX_LAUNCH(k_transpose_w, dim3((unsigned)((K * J + 255) / 256)), dim3(256), 0, s, W, K, J, WT);
     GNX_HIP(hipGetLastError());
   }
   return launch_rows_matmul(h, entity, delta, J, WT + ka, K, kb - ka, out, R, s, name, gmul, gmul_act, tile_colsum, n_tiles_out, nullptr);
@@ -176,7 +176,7 @@ int32_t dx_mfma(const gnx_graphs* h, int entity, const float* delta, const float
 
 int32_t transpose_w(const float* W, int K, int J, float* WT, hipStream_t s) {
   if (K * J == 0) return GNX_OK;
-  hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)((K * J + 255) / 256)), dim3(256), 0, s, W, K, J, WT);
+  GNX_LAUNCH(k_transpose_w, dim3((unsigned)((K * J + 255) / 256)), dim3(256), 0, s, W, K, J, WT);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -237,8 +237,8 @@ int32_t segsum_rows(const float* src, const int* ptr, const int* idx, int N, int
   const size_t total = (size_t)N * ((D + 3) / 4);
   const dim3 grid((unsigned)((total + 255) / 256), (unsigned)R);
   const bool v4 = D % 4 == 0 && (((uintptr_t)src | (uintptr_t)out) & 15) == 0;
-  if (v4) hipLaunchKernelGGL((k_segsum_rows<true>), grid, dim3(256), 0, s, src, ptr, idx, N, E, D, out);
-  else hipLaunchKernelGGL((k_segsum_rows<false>), grid, dim3(256), 0, s, src, ptr, idx, N, E, D, out);
+  if (v4) GNX_LAUNCH((k_segsum_rows<true>), grid, dim3(256), 0, s, src, ptr, idx, N, E, D, out);
+  else GNX_LAUNCH((k_segsum_rows<false>), grid, dim3(256), 0, s, src, ptr, idx, N, E, D, out);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -252,7 +252,7 @@ __global__ void k_add_cols(const float* __restrict__ in, int ld, int off, size_t
 }
 int32_t add_cols(const float* in, int ld, int off, size_t rows, int d, float* out, int accumulate, hipStream_t s) {
   if (rows * d == 0) return GNX_OK;
-  hipLaunchKernelGGL(k_add_cols, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, s, in, ld, off, rows, d, out, accumulate);
+  GNX_LAUNCH(k_add_cols, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, s, in, ld, off, rows, d, out, accumulate);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }

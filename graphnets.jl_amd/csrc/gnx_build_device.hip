@@ -164,17 +164,17 @@ int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int6
   GNX_TRY(hipMemset(d_bad, 0, sizeof(int32_t)));
   AdjMeta m{d_off, d_n, d_noff, (int)G, elem_kind, row_major};
   const unsigned grid = (unsigned)((N * 64 + 255) / 256);
-  hipLaunchKernelGGL(k_adj_columns<false>, dim3(grid), dim3(256), 0, 0, d_adj, m, (int)N, d_cnt, (int*)nullptr, d_bad);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(nb), dim3(256), 0, 0, d_cnt, (int)(N + 1), d_cp, d_bs);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, 0, d_bs, SCAN_B, d_bp, (int*)nullptr);
-  hipLaunchKernelGGL(k_scan_add, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, 0, d_cp, (int)(N + 1), d_bp);
+  GNX_LAUNCH(k_adj_columns<false>, dim3(grid), dim3(256), 0, 0, d_adj, m, (int)N, d_cnt, (int*)nullptr, d_bad);
+  GNX_LAUNCH(k_scan_blocks, dim3(nb), dim3(256), 0, 0, d_cnt, (int)(N + 1), d_cp, d_bs);
+  GNX_LAUNCH(k_scan_blocks, dim3(1), dim3(256), 0, 0, d_bs, SCAN_B, d_bp, (int*)nullptr);
+  GNX_LAUNCH(k_scan_add, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, 0, d_cp, (int)(N + 1), d_bp);
   GNX_TRY(hipGetLastError());
   int32_t bad = 0, E = 0;
   GNX_TRY(hipMemcpy(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost));
   if (bad) { cleanup(); return fail(GNX_ERR_ADJ_VALUE, "adjacency entries must be exactly 0 or 1 (pad.jl:30, gngraphbatch.jl:207)"); }
   GNX_TRY(hipMemcpy(&E, d_cp + N, sizeof(int32_t), hipMemcpyDeviceToHost));
   GNX_TRY(hipMalloc((void**)&d_rv, std::max<size_t>((size_t)E, 1) * sizeof(int32_t)));
-  hipLaunchKernelGGL(k_adj_columns<true>, dim3(grid), dim3(256), 0, 0, d_adj, m, (int)N, d_cp, d_rv, d_bad);
+  GNX_LAUNCH(k_adj_columns<true>, dim3(grid), dim3(256), 0, 0, d_adj, m, (int)N, d_cp, d_rv, d_bad);
   GNX_TRY(hipGetLastError());
   std::vector<int32_t> cp32(N + 1), rv32((size_t)E);
   GNX_TRY(hipMemcpy(cp32.data(), d_cp, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));

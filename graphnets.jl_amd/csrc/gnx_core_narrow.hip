@@ -43,7 +43,7 @@ int32_t launch_ln1_rows(const float* x, size_t rows, int d, const gnx_layernorm&
   ProfScope ps("k_ln1_rows", s);
   const dim3 grid((unsigned)((rows + 255) / 256));
   switch (d) {
-#define GNX_CASE(D) case D: hipLaunchKernelGGL((k_ln1_rows<D>), grid, dim3(256), 0, s, x, rows, l1.gamma, l1.beta, eps, eps_mode, y); break;
+#define GNX_CASE(D) case D: GNX_LAUNCH((k_ln1_rows<D>), grid, dim3(256), 0, s, x, rows, l1.gamma, l1.beta, eps, eps_mode, y); break;
     GNX_CORE_WIDTHS(GNX_CASE)
 #undef GNX_CASE
     default: return fail(GNX_ERR_DIMS, "launch_ln1_rows: width not instantiated");
@@ -69,10 +69,10 @@ int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm
   switch (d) {
 #define GNX_CASE(D)                                                                                                                                  \
   case D:                                                                                                                                            \
-    if (!lds_weights && M == 2 && trans) hipLaunchKernelGGL((k_core_post_s<D, true>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out); \
-    else if (!lds_weights && M == 2) hipLaunchKernelGGL((k_core_post_s<D, false>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out); \
-    else if (M == 2) hipLaunchKernelGGL((k_core_post<D, 2>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out); \
-    else hipLaunchKernelGGL((k_core_post<D, 1>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out);             \
+    if (!lds_weights && M == 2 && trans) GNX_LAUNCH((k_core_post_s<D, true>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out); \
+    else if (!lds_weights && M == 2) GNX_LAUNCH((k_core_post_s<D, false>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out); \
+    else if (M == 2) GNX_LAUNCH((k_core_post<D, 2>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out); \
+    else GNX_LAUNCH((k_core_post<D, 1>), grid, dim3(256), 0, s, x, rows, l2.gamma, l2.beta, ff.fc1, ff.fc2, eps, eps_mode, out);             \
     break;
     GNX_CORE_WIDTHS(GNX_CASE)
 #undef GNX_CASE
@@ -113,14 +113,14 @@ int32_t launch_core_post3(const float* const x[3], const size_t rows[3], const i
   const dim3 grid(j[0].blocks + j[1].blocks + j[2].blocks);
   ProfScope ps("k_core_post", s);
   if (d[0] == 10 && d[1] == 5 && d[2] == 3) {
-    if (blk) hipLaunchKernelGGL((k_core_post3<10, 5, 3, true>), grid, dim3(256), 0, s, j[0], j[1], j[2], eps, eps_mode, *blk, n_rows);
-    else hipLaunchKernelGGL((k_core_post3<10, 5, 3, false>), grid, dim3(256), 0, s, j[0], j[1], j[2], eps, eps_mode, BlockArgs{}, 0);
+    if (blk) GNX_LAUNCH((k_core_post3<10, 5, 3, true>), grid, dim3(256), 0, s, j[0], j[1], j[2], eps, eps_mode, *blk, n_rows);
+    else GNX_LAUNCH((k_core_post3<10, 5, 3, false>), grid, dim3(256), 0, s, j[0], j[1], j[2], eps, eps_mode, BlockArgs{}, 0);
   } else {
     hipFunction_t fn = nullptr;
     if (jit_get_core_post3(d[0], d[1], d[2], s, &fn) != GNX_OK) return fail(GNX_ERR_INVALID_ARG, "internal: the combined kernel of this width triple is not loaded");
     BlockArgs a = *blk;
     void* params[] = {&j[0], &j[1], &j[2], &eps, &eps_mode, &a, &n_rows};
-    GNX_HIP(hipModuleLaunchKernel(fn, grid.x, 1, 1, 256, 1, 1, 0, s, params, nullptr));
+    GNX_HIP(module_launch(fn, grid.x, 1, 1, 256, 1, 1, 0, s, params));
   }
   GNX_HIP(hipGetLastError());
   return GNX_OK;

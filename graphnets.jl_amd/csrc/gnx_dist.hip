@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -76,6 +77,17 @@ __global__ void k_dist_permute(const float* __restrict__ recv, const int* __rest
   }
 }
 
+// M stacked tables in one wire: rank r contributed [M][max_count][og], so recv is [n][M][max_count][og] and
+// out[m][g][:] = recv[(rank(g) * M + m) * max_count + k(g)][:] with src[g] = rank(g) * max_count + k(g)
+__global__ void k_dist_permute_steps(const float* __restrict__ recv, const int* __restrict__ src, int G, int og, int M, int max_count, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M * G * og) {
+    const int j = i % og, g = (i / og) % G, m = i / (og * G);
+    const int sr = src[g], rank = sr / max_count, k = sr - rank * max_count;
+    out[i] = recv[((size_t)(rank * M + m) * max_count + k) * og + j];
+  }
+}
+
 }  // namespace
 }  // namespace gnx
 
@@ -91,9 +103,28 @@ struct gnx_dist {
   std::vector<hipEvent_t> ev_in, ev_out;
   std::vector<float*> send, recv;      // [max_count][og], [n * max_count][og] on device r
   std::vector<int*> src;               // [G] row of recv for original graph g, on device r
+  // replay form (gnx_dist_block_forward_steps): stacked send / receive buffers for up to steps_cap steps, a capture stream per device,
+  // and the per-device hipGraphs of the launch sequences seen so far (keyed by every pointer the sequence was captured with)
+  int steps_cap = 0;
+  std::vector<float*> ssend, srecv;    // [steps_cap][max_count][og], [n][steps_cap][max_count][og] on device r
+  std::vector<hipStream_t> kstream;    // capture stream of device r
+  struct Replay {
+    std::vector<uintptr_t> key;
+    std::vector<hipGraph_t> graph;
+    std::vector<hipGraphExec_t> exec;
+  };
+  std::vector<Replay> replays;
+  std::mutex mu;
 };
 
 using namespace gnx;
+
+// restores the caller's current device on every exit path
+struct DeviceRestore {
+  int prev = -1;
+  DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+  ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 extern "C" {
 
@@ -103,23 +134,29 @@ int32_t gnx_dist_permute_rows(const float* gathered, const int32_t* src_row, int
   if (!gathered || !src_row || !out) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
   if (n_graphs <= 0 || og <= 0 || n_graphs * (int64_t)og >= (int64_t)INT32_MAX) return fail(GNX_ERR_INVALID_ARG, "bad n_graphs / og");
   const int total = (int)(n_graphs * og);
-  hipLaunchKernelGGL(k_dist_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gathered, src_row, (int)n_graphs, og, out);
+  GNX_LAUNCH(k_dist_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gathered, src_row, (int)n_graphs, og, out);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
 
-// restores the caller's current device on every exit path
-struct DeviceRestore {
-  int prev = -1;
-  DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
-  ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
+static void drop_replays(gnx_dist* d) {
+  for (auto& rp : d->replays) {
+    for (hipGraphExec_t e : rp.exec) if (e) (void)hipGraphExecDestroy(e);
+    for (hipGraph_t g : rp.graph) if (g) (void)hipGraphDestroy(g);
+  }
+  d->replays.clear();
+}
 
 int32_t gnx_dist_destroy(gnx_dist* d) {
   if (!d) return GNX_OK;
+  DeviceRestore restore;
+  drop_replays(d);
   for (int r = 0; r < d->n; ++r) {
     (void)hipSetDevice(d->dev[(size_t)r]);
     if ((size_t)r < d->cstream.size() && d->cstream[(size_t)r]) (void)hipStreamSynchronize(d->cstream[(size_t)r]);
+    if ((size_t)r < d->ssend.size()) (void)hipFree(d->ssend[(size_t)r]);
+    if ((size_t)r < d->srecv.size()) (void)hipFree(d->srecv[(size_t)r]);
+    if ((size_t)r < d->kstream.size() && d->kstream[(size_t)r]) (void)hipStreamDestroy(d->kstream[(size_t)r]);
     if ((size_t)r < d->comm.size() && d->comm[(size_t)r] && rccl().ok) (void)rccl().CommDestroy(d->comm[(size_t)r]);
     if ((size_t)r < d->send.size()) (void)hipFree(d->send[(size_t)r]);
     if ((size_t)r < d->recv.size()) (void)hipFree(d->recv[(size_t)r]);
@@ -208,7 +245,7 @@ int32_t gnx_dist_allgather_gf(gnx_dist* d, const float* const* gf_local, float* 
   for (int r = 0; r < d->n; ++r) {
     GNX_HIP(hipSetDevice(d->dev[(size_t)r]));
     const int total = (int)(d->G * d->og);
-    hipLaunchKernelGGL(k_dist_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d->cstream[(size_t)r], d->recv[(size_t)r], d->src[(size_t)r],
+    GNX_LAUNCH(k_dist_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d->cstream[(size_t)r], d->recv[(size_t)r], d->src[(size_t)r],
                        (int)d->G, d->og, gf_all[r]);
     GNX_HIP(hipGetLastError());
     GNX_HIP(hipEventRecord(d->ev_out[(size_t)r], d->cstream[(size_t)r]));
@@ -239,6 +276,136 @@ int32_t gnx_dist_block_forward(gnx_dist* d, const gnx_graphs* const* h, const gn
   }
   }
   return gnx_dist_allgather_gf(d, gf_out_local, gf_all, streams);
+}
+
+// The replay form.  n_steps block forwards per rank (independent batches of the same graphs: step s of rank r reads ef / nf / gf
+// [s * n + r] and writes ef_out / nf_out [s * n + r]); every step's gf' rows go straight into the communicator's stacked send buffer,
+// ONE grouped all-gather moves the n_steps tables of every rank, and gf_all[r] receives [n_steps][n_graphs][og] in original graph order.
+// The launch sequence of a rank is captured into ONE hipGraph per device the first time a set of arguments is seen and replayed with one
+// hipGraphLaunch per device afterwards: a host thread then issues n graph launches + one grouped collective + n permute kernels per
+// call, whatever n_steps is (the eager form costs ~10 runtime calls per device and step: host-bound at a 23-us step).
+static int32_t dist_steps_buffers(gnx_dist* d, int n_steps) {
+  if (n_steps <= d->steps_cap) return GNX_OK;
+  drop_replays(d);  // they write into the buffers that are about to be replaced
+  const size_t row = sizeof(float) * (size_t)d->og;
+  d->ssend.resize((size_t)d->n, nullptr); d->srecv.resize((size_t)d->n, nullptr); d->kstream.resize((size_t)d->n, nullptr);
+  for (int r = 0; r < d->n; ++r) {
+    GNX_HIP(hipSetDevice(d->dev[(size_t)r]));
+    GNX_HIP(hipDeviceSynchronize());
+    if (d->ssend[(size_t)r]) GNX_HIP(hipFree(d->ssend[(size_t)r]));
+    if (d->srecv[(size_t)r]) GNX_HIP(hipFree(d->srecv[(size_t)r]));
+    d->ssend[(size_t)r] = d->srecv[(size_t)r] = nullptr;
+    GNX_HIP(hipMalloc((void**)&d->ssend[(size_t)r], row * (size_t)d->max_count * (size_t)n_steps));
+    GNX_HIP(hipMemset(d->ssend[(size_t)r], 0, row * (size_t)d->max_count * (size_t)n_steps));  // padding rows stay zero
+    GNX_HIP(hipMalloc((void**)&d->srecv[(size_t)r], row * (size_t)d->max_count * (size_t)n_steps * (size_t)d->n));
+    if (!d->kstream[(size_t)r]) GNX_HIP(hipStreamCreateWithFlags(&d->kstream[(size_t)r], hipStreamNonBlocking));
+  }
+  d->steps_cap = n_steps;
+  return GNX_OK;
+}
+
+int32_t gnx_dist_block_forward_steps(gnx_dist* d, int32_t n_steps, const gnx_graphs* const* h, const gnx_block_params* const* p, const float* const* ef,
+                                     const float* const* nf, const float* const* gf, float* const* ef_out, float* const* nf_out, float* const* gf_all,
+                                     void* const* workspace, const size_t* workspace_bytes, uint32_t flags, void* const* streams) {
+  if (!d || !h || !p || !workspace || !workspace_bytes || !gf_all) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  if (n_steps < 1 || n_steps > 4096) return fail(GNX_ERR_INVALID_ARG, "n_steps must be in 1..4096");
+  const int n = d->n;
+  for (int r = 0; r < n; ++r) {
+    if (!h[r] || !p[r] || !gf_all[r]) return fail(GNX_ERR_INVALID_ARG, "handle / params / gf_all of a rank is NULL");
+    if (h[r]->G != d->count[(size_t)r]) return fail(GNX_ERR_COUNT_MISMATCH, "a rank's handle does not hold the graphs of its shard");
+    if (p[r]->og != d->og) return fail(GNX_ERR_DIMS, "og differs from the communicator's");
+    if (h[r]->device != d->dev[(size_t)r]) return fail(GNX_ERR_INVALID_ARG, "a rank's handle lives on another device");
+  }
+  if ((int64_t)n_steps * d->G * d->og >= (int64_t)INT32_MAX) return fail(GNX_ERR_TOO_LARGE, "n_steps * n_graphs * og exceeds the permute kernel's index range");
+  std::lock_guard<std::mutex> lk(d->mu);
+  DeviceRestore restore;
+  int32_t rc = dist_steps_buffers(d, n_steps);
+  if (rc) return rc;
+  const size_t tab = (size_t)d->max_count * (size_t)d->og;  // floats of one rank's table of one step
+  // the buffers are sized for steps_cap steps; THIS call's wire carries n_steps tables per rank, packed at the front
+  auto run_rank = [&](int r, hipStream_t s) -> int32_t {
+    for (int st = 0; st < n_steps; ++st) {
+      const size_t i = (size_t)st * n + r;
+      const int32_t rr = gnx_block_forward(h[r], p[r], ef ? ef[i] : nullptr, nf ? nf[i] : nullptr, gf ? gf[i] : nullptr, 1, ef_out ? ef_out[i] : nullptr,
+                                           nf_out ? nf_out[i] : nullptr, d->ssend[(size_t)r] + (size_t)st * tab, workspace[i], workspace_bytes[r], flags, s);
+      if (rr) return rr;
+    }
+    return GNX_OK;
+  };
+  const bool eager = (flags & GNX_FLAG_NO_GRAPH) != 0;
+  const uint32_t lflags = flags & ~GNX_FLAG_NO_GRAPH;
+  (void)lflags;
+  gnx_dist::Replay* rp = nullptr;
+  if (!eager) {
+    std::vector<uintptr_t> key;
+    key.push_back((uintptr_t)n_steps); key.push_back((uintptr_t)flags);
+    for (int r = 0; r < n; ++r) { key.push_back((uintptr_t)h[r]); key.push_back((uintptr_t)p[r]); key.push_back((uintptr_t)workspace_bytes[r]); }
+    for (size_t i = 0; i < (size_t)n_steps * n; ++i) {
+      key.push_back((uintptr_t)(ef ? ef[i] : nullptr)); key.push_back((uintptr_t)(nf ? nf[i] : nullptr)); key.push_back((uintptr_t)(gf ? gf[i] : nullptr));
+      key.push_back((uintptr_t)(ef_out ? ef_out[i] : nullptr)); key.push_back((uintptr_t)(nf_out ? nf_out[i] : nullptr)); key.push_back((uintptr_t)workspace[i]);
+    }
+    for (auto& c : d->replays) if (c.key == key) { rp = &c; break; }
+    if (!rp) {
+      // first sight of these arguments: one eager pass (argument errors surface outside any capture, code objects get loaded; it also
+      // produces this call's results), then the capture of every rank's sequence on its capture stream
+      for (int r = 0; r < n; ++r) {
+        GNX_HIP(hipSetDevice(d->dev[(size_t)r]));
+        if ((rc = run_rank(r, streams ? (hipStream_t)streams[r] : nullptr))) return rc;
+      }
+      gnx_dist::Replay fresh;
+      fresh.key = key;
+      fresh.graph.assign((size_t)n, nullptr); fresh.exec.assign((size_t)n, nullptr);
+      for (int r = 0; r < n && !rc; ++r) {
+        hipError_t e = hipSetDevice(d->dev[(size_t)r]);
+        if (e == hipSuccess) e = hipStreamBeginCapture(d->kstream[(size_t)r], hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) { rc = hip_fail(e, "gnx_dist_block_forward_steps: begin capture"); break; }
+        const int32_t rr = run_rank(r, d->kstream[(size_t)r]);
+        e = hipStreamEndCapture(d->kstream[(size_t)r], &fresh.graph[(size_t)r]);
+        if (rr) rc = rr;
+        else if (e != hipSuccess) rc = hip_fail(e, "hipStreamEndCapture");
+        else if ((e = hipGraphInstantiate(&fresh.exec[(size_t)r], fresh.graph[(size_t)r], nullptr, nullptr, 0)) != hipSuccess) rc = hip_fail(e, "hipGraphInstantiate");
+      }
+      if (rc) {
+        for (hipGraphExec_t x : fresh.exec) if (x) (void)hipGraphExecDestroy(x);
+        for (hipGraph_t g : fresh.graph) if (g) (void)hipGraphDestroy(g);
+        return rc;
+      }
+      if (d->replays.size() >= 32) drop_replays(d);  // (a caller that rotates over more argument sets than this re-captures)
+      d->replays.push_back(std::move(fresh));
+    } else {
+      for (int r = 0; r < n; ++r) {
+        GNX_HIP(hipSetDevice(d->dev[(size_t)r]));
+        GNX_HIP(hipGraphLaunch(rp->exec[(size_t)r], streams ? (hipStream_t)streams[r] : nullptr));
+      }
+    }
+  } else {
+    for (int r = 0; r < n; ++r) {
+      GNX_HIP(hipSetDevice(d->dev[(size_t)r]));
+      if ((rc = run_rank(r, streams ? (hipStream_t)streams[r] : nullptr))) return rc;
+    }
+  }
+  // hand over to the communication streams, ONE grouped all-gather of the n_steps stacked tables, permutation into original graph order
+  for (int r = 0; r < n; ++r) {
+    GNX_HIP(hipSetDevice(d->dev[(size_t)r]));
+    GNX_HIP(hipEventRecord(d->ev_in[(size_t)r], streams ? (hipStream_t)streams[r] : nullptr));
+    GNX_HIP(hipStreamWaitEvent(d->cstream[(size_t)r], d->ev_in[(size_t)r], 0));
+  }
+  GNX_NCCL(rccl().GroupStart());
+  for (int r = 0; r < n; ++r) {
+    const ncclResult_t e = rccl().AllGather(d->ssend[(size_t)r], d->srecv[(size_t)r], tab * (size_t)n_steps, ncclFloat, d->comm[(size_t)r], d->cstream[(size_t)r]);
+    if (e != ncclSuccess) { (void)rccl().GroupEnd(); return nccl_fail(e, "ncclAllGather"); }
+  }
+  GNX_NCCL(rccl().GroupEnd());
+  for (int r = 0; r < n; ++r) {
+    GNX_HIP(hipSetDevice(d->dev[(size_t)r]));
+    const int total = (int)((int64_t)n_steps * d->G * d->og);
+    GNX_LAUNCH(k_dist_permute_steps, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d->cstream[(size_t)r], d->srecv[(size_t)r], d->src[(size_t)r], (int)d->G,
+               d->og, (int)n_steps, (int)d->max_count, gf_all[r]);
+    GNX_HIP(hipGetLastError());
+    GNX_HIP(hipEventRecord(d->ev_out[(size_t)r], d->cstream[(size_t)r]));
+    GNX_HIP(hipStreamWaitEvent(streams ? (hipStream_t)streams[r] : nullptr, d->ev_out[(size_t)r], 0));
+  }
+  return GNX_OK;
 }
 
 }  // extern "C"

@@ -356,8 +356,8 @@ int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d,
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ffn_dbg), &d_dbg, sizeof(d_dbg), 0, hipMemcpyHostToDevice, s);
   }
 #endif
-  if (d == 128) hipLaunchKernelGGL((k_ffn_fused<128>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((k_ffn_fused<64>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
+  if (d == 128) GNX_LAUNCH((k_ffn_fused<128>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
+  else GNX_LAUNCH((k_ffn_fused<64>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
   GNX_HIP(hipGetLastError());
 #ifdef GNX_FFN_STAMPS_BUILD
   if (stamps) {

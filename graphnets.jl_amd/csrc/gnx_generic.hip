@@ -165,7 +165,7 @@ size_t graph_kernel_lds_bytes(int oe, int on, int dg) {
 int32_t launch_graph(const BlockArgs& a, int64_t R, hipStream_t s) {
   if (a.og == 0) return GNX_OK;
   ProfScope ps("k_graph", s);
-  hipLaunchKernelGGL(k_graph, dim3((unsigned)a.G, (unsigned)R), dim3(kGraphThreads), graph_kernel_lds_bytes(a.oe, a.on, a.dg), s, a);
+  GNX_LAUNCH(k_graph, dim3((unsigned)a.G, (unsigned)R), dim3(kGraphThreads), graph_kernel_lds_bytes(a.oe, a.on, a.dg), s, a);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -174,12 +174,12 @@ int32_t launch_block_generic(const BlockArgs& a, int64_t R, int tile_n_cap, hipS
   const dim3 grid((unsigned)a.n_tiles, (unsigned)R);
   if ((phase & 1) && a.oe > 0 && a.E > 0) {
     ProfScope ps("k_edge_generic", s);
-    hipLaunchKernelGGL(k_edge_generic, grid, dim3(256), sizeof(int) * (size_t)(tile_n_cap + 1), s, a);
+    GNX_LAUNCH(k_edge_generic, grid, dim3(256), sizeof(int) * (size_t)(tile_n_cap + 1), s, a);
     GNX_HIP(hipGetLastError());
   }
   if (phase & 1) {
     ProfScope ps("k_node_generic", s);
-    hipLaunchKernelGGL(k_node_generic, grid, dim3(256), 0, s, a);
+    GNX_LAUNCH(k_node_generic, grid, dim3(256), 0, s, a);
     GNX_HIP(hipGetLastError());
   }
   return (phase & 2) ? launch_graph(a, R, s) : GNX_OK;
@@ -302,7 +302,7 @@ int32_t launch_ln_stats(const float* x, size_t rows, int d, float eps, int eps_m
   ProfScope ps("k_ln_stats", s);
   const dim3 grid((unsigned)((rows + 15) / 16));
   switch (d / 64) {
-#define GNX_LN_CASE(Q) case Q: hipLaunchKernelGGL((k_ln_stats_v4<Q>), grid, dim3(256), 0, s, x, rows, eps, eps_mode, reinterpret_cast<float2*>(stats)); break;
+#define GNX_LN_CASE(Q) case Q: GNX_LAUNCH((k_ln_stats_v4<Q>), grid, dim3(256), 0, s, x, rows, eps, eps_mode, reinterpret_cast<float2*>(stats)); break;
     GNX_LN_CASE(1) GNX_LN_CASE(2) GNX_LN_CASE(3) GNX_LN_CASE(4) GNX_LN_CASE(5) GNX_LN_CASE(6) GNX_LN_CASE(7) GNX_LN_CASE(8)
 #undef GNX_LN_CASE
   }
@@ -344,14 +344,14 @@ int32_t launch_layernorm2(const float* x, size_t rows, int d, const gnx_layernor
   if (al16 && d % 64 == 0 && d <= 512) {
     const dim3 grid((unsigned)((rows + 15) / 16));
     switch (d / 64) {
-#define GNX_LN_CASE(Q) case Q: hipLaunchKernelGGL((k_layernorm2_v4<Q>), grid, dim3(256), 0, s, x, rows, l1.gamma, l1.beta, l2.gamma, l2.beta, eps, eps_mode, y1, y2); break;
+#define GNX_LN_CASE(Q) case Q: GNX_LAUNCH((k_layernorm2_v4<Q>), grid, dim3(256), 0, s, x, rows, l1.gamma, l1.beta, l2.gamma, l2.beta, eps, eps_mode, y1, y2); break;
       GNX_LN_CASE(1) GNX_LN_CASE(2) GNX_LN_CASE(3) GNX_LN_CASE(4) GNX_LN_CASE(5) GNX_LN_CASE(6) GNX_LN_CASE(7) GNX_LN_CASE(8)
 #undef GNX_LN_CASE
     }
     GNX_HIP(hipGetLastError());
     return GNX_OK;
   }
-  hipLaunchKernelGGL(k_layernorm2, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, d, l1.gamma, l1.beta, l2.gamma,
+  GNX_LAUNCH(k_layernorm2, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, d, l1.gamma, l1.beta, l2.gamma,
                      l2.beta, eps, eps_mode, y1, y2);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
@@ -360,7 +360,7 @@ int32_t launch_layernorm2(const float* x, size_t rows, int d, const gnx_layernor
 int32_t launch_ffn_residual(const float* z, const float* x, size_t rows, int d, const gnx_ffn& ff, float* out, hipStream_t s) {
   if (rows == 0 || d == 0) return GNX_OK;
   ProfScope ps("k_ffn_residual", s);
-  hipLaunchKernelGGL(k_ffn_residual, dim3((unsigned)((rows + 3) / 4)), dim3(256), sizeof(float) * 4 * (size_t)(5 * d), s, z, x, rows,
+  GNX_LAUNCH(k_ffn_residual, dim3((unsigned)((rows + 3) / 4)), dim3(256), sizeof(float) * 4 * (size_t)(5 * d), s, z, x, rows,
                      d, ff.fc1, ff.fc2, out);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
@@ -477,12 +477,12 @@ int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, 
   FnInArgs a{ef, nf, gf, de, dn, dg, (int)h->N, (int)h->E, (int)h->G, h->d_colptr, h->d_rowval, h->d_edge_dst, h->d_node_off, h->d_edge_off, out};
   if (kind == 0) {
     const size_t total = (size_t)h->E * (de + 2 * dn + dg);
-    if (total) hipLaunchKernelGGL(k_fn_input_edge, dim3((unsigned)((total + 255) / 256), (unsigned)R), dim3(256), 0, s, a);
+    if (total) GNX_LAUNCH(k_fn_input_edge, dim3((unsigned)((total + 255) / 256), (unsigned)R), dim3(256), 0, s, a);
   } else if (kind == 1) {
     const size_t total = (size_t)h->N * (de + dn + dg);
-    if (total) hipLaunchKernelGGL(k_fn_input_node, dim3((unsigned)((total + 255) / 256), (unsigned)R), dim3(256), 0, s, a);
+    if (total) GNX_LAUNCH(k_fn_input_node, dim3((unsigned)((total + 255) / 256), (unsigned)R), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL(k_fn_input_graph, dim3((unsigned)h->G, (unsigned)R), dim3(256), 0, s, a);
+    GNX_LAUNCH(k_fn_input_graph, dim3((unsigned)h->G, (unsigned)R), dim3(256), 0, s, a);
   }
   GNX_HIP(hipGetLastError());
   return GNX_OK;
@@ -505,7 +505,7 @@ __global__ void k_collapse(const int* __restrict__ edge, const int* __restrict__
 int32_t launch_collapse(const gnx_graphs* h, const float* ef, int d, int64_t R, float* out, hipStream_t s) {
   const size_t n = (size_t)h->h_collapse_off.back();
   if (n == 0) return GNX_OK;
-  hipLaunchKernelGGL(k_collapse, dim3((unsigned)((n * d + 255) / 256), (unsigned)R), dim3(256), 0, s, h->d_collapse_edge, h->d_collapse_rev,
+  GNX_LAUNCH(k_collapse, dim3((unsigned)((n * d + 255) / 256), (unsigned)R), dim3(256), 0, s, h->d_collapse_edge, h->d_collapse_rev,
                      (int)n, d, (int)h->E, ef, out);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
@@ -557,7 +557,7 @@ int32_t launch_collapse_padded(const gnx_graphs* h, const float* ef, int d, int6
   const bool shared = R > 1;
   const size_t B = shared ? (size_t)R : (size_t)h->G;
   if (L == 0 || B == 0) return GNX_OK;
-  hipLaunchKernelGGL(k_collapse_padded, dim3((unsigned)((L * d + 255) / 256), (unsigned)B), dim3(256), 0, s, h->d_colptr, h->d_rowval, h->d_node_off,
+  GNX_LAUNCH(k_collapse_padded, dim3((unsigned)((L * d + 255) / 256), (unsigned)B), dim3(256), 0, s, h->d_colptr, h->d_rowval, h->d_node_off,
                      (int)h->G, (int)h->PN, shared ? 1 : 0, d, (int)h->E, ef, out);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
@@ -615,7 +615,7 @@ __global__ void k_xent_backward(const float* __restrict__ logits, const float* _
 }
 
 int32_t launch_xent_backward(const float* logits, const float* targets, int d, int64_t cols, const float* upstream, float* dl, hipStream_t s) {
-  hipLaunchKernelGGL(k_xent_backward, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, logits, targets, d, (size_t)cols, upstream, dl);
+  GNX_LAUNCH(k_xent_backward, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, logits, targets, d, (size_t)cols, upstream, dl);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -624,8 +624,8 @@ int xent_blocks(int64_t cols) { return (int)std::min<int64_t>(std::max<int64_t>(
 
 int32_t launch_xent(const float* logits, const float* targets, int d, int64_t cols, float* out, float* ws, hipStream_t s) {
   const int nb = xent_blocks(cols);
-  hipLaunchKernelGGL(k_xent_partial, dim3(nb), dim3(256), 0, s, logits, targets, d, (size_t)cols, ws);
-  hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, s, ws, nb, (size_t)cols, out);
+  GNX_LAUNCH(k_xent_partial, dim3(nb), dim3(256), 0, s, logits, targets, d, (size_t)cols, ws);
+  GNX_LAUNCH(k_xent_final, dim3(1), dim3(256), 0, s, ws, nb, (size_t)cols, out);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -637,7 +637,7 @@ __global__ void k_null() {}
 int32_t launch_calibration(int n, hipStream_t s) {
   for (int i = 0; i < n; ++i) {
     ProfScope ps("__empty_bracket__", s);
-    hipLaunchKernelGGL(k_null, dim3(1), dim3(64), 0, s);
+    GNX_LAUNCH(k_null, dim3(1), dim3(64), 0, s);
   }
   GNX_HIP(hipGetLastError());
   return GNX_OK;
@@ -652,11 +652,11 @@ int32_t launch_pad(const gnx_graphs* h, int kind, bool pad, const float* src, in
   if (total == 0) return GNX_OK;
   const unsigned grid = (unsigned)((total + 255) / 256);
   if (kind == 0) {
-    if (pad) hipLaunchKernelGGL(k_pad_edges<true>, dim3(grid), dim3(256), 0, s, h->d_colptr, h->d_rowval, h->d_node_off, (int)h->N, (int)h->E, (int)h->G, (int)h->PN, d, R, src, dst);
-    else hipLaunchKernelGGL(k_pad_edges<false>, dim3(grid), dim3(256), 0, s, h->d_colptr, h->d_rowval, h->d_node_off, (int)h->N, (int)h->E, (int)h->G, (int)h->PN, d, R, src, dst);
+    if (pad) GNX_LAUNCH(k_pad_edges<true>, dim3(grid), dim3(256), 0, s, h->d_colptr, h->d_rowval, h->d_node_off, (int)h->N, (int)h->E, (int)h->G, (int)h->PN, d, R, src, dst);
+    else GNX_LAUNCH(k_pad_edges<false>, dim3(grid), dim3(256), 0, s, h->d_colptr, h->d_rowval, h->d_node_off, (int)h->N, (int)h->E, (int)h->G, (int)h->PN, d, R, src, dst);
   } else {
-    if (pad) hipLaunchKernelGGL(k_pad_nodes<true>, dim3(grid), dim3(256), 0, s, h->d_node_off, (int)h->N, (int)h->G, (int)h->PN, d, R, src, dst);
-    else hipLaunchKernelGGL(k_pad_nodes<false>, dim3(grid), dim3(256), 0, s, h->d_node_off, (int)h->N, (int)h->G, (int)h->PN, d, R, src, dst);
+    if (pad) GNX_LAUNCH(k_pad_nodes<true>, dim3(grid), dim3(256), 0, s, h->d_node_off, (int)h->N, (int)h->G, (int)h->PN, d, R, src, dst);
+    else GNX_LAUNCH(k_pad_nodes<false>, dim3(grid), dim3(256), 0, s, h->d_node_off, (int)h->N, (int)h->G, (int)h->PN, d, R, src, dst);
   }
   GNX_HIP(hipGetLastError());
   return GNX_OK;

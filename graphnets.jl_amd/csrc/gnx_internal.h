@@ -1,6 +1,9 @@
 // Internal declarations shared by the translation units of libgnx.so (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#if defined(__HIPCC__)
+#include <hip/hip_ext.h>  // hipExtLaunchKernelGGL (device-compiler only: the host sanitizer build of the .cpp units does not launch)
+#endif
 #include <stdint.h>
 
 #include <atomic>
@@ -120,13 +123,36 @@ int32_t hip_fail(hipError_t e, const char* what);
     if (_e != hipSuccess) return gnx::hip_fail(_e, #expr);   \
   } while (0)
 
-// profiling (gnx_profile.cpp)
+// profiling (gnx_profile.cpp): per-kernel DISPATCH timestamps.  A ProfScope names the launches made inside it on this thread; GNX_LAUNCH /
+// GNX_MODULE_LAUNCH then attach a start / stop event pair to each kernel's own dispatch packet (hipExtLaunchKernel): the pair's elapsed
+// time is the kernel's begin -> end as the command processor stamps it — the figure rocprofv3's kernel trace reports — and not a bracket
+// of marker packets around the launch (round 3: such brackets read 8-14 % above rocprofv3 on the same launches; every marker is a
+// barrier with its own cache maintenance, and its cost grows with the kernel it waits for).  Off (the default): plain launches.
 struct ProfScope {
   ProfScope(const char* name, hipStream_t s);
   ~ProfScope();
-  int slot;
-  hipStream_t stream;
+  const char* prev;
 };
+// true (and a fresh event pair, recorded under the innermost ProfScope of this thread) when per-kernel timing is on and a scope is open
+bool prof_take_events(hipEvent_t* start, hipEvent_t* stop);
+
+#if defined(__HIPCC__)
+#define GNX_LAUNCH(kernel, grid, block, lds, stream, ...)                                                              \
+  do {                                                                                                                 \
+    hipEvent_t gnx_e0_ = nullptr, gnx_e1_ = nullptr;                                                                   \
+    if (gnx::prof_take_events(&gnx_e0_, &gnx_e1_))                                                                     \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, gnx_e0_, gnx_e1_, 0, ##__VA_ARGS__);                     \
+    else                                                                                                               \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, ##__VA_ARGS__);                                             \
+  } while (0)
+// run-time compiled kernels (hipFunction_t): grid in BLOCKS like hipModuleLaunchKernel (the Ext form counts work-items)
+inline hipError_t module_launch(hipFunction_t f, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz, unsigned lds, hipStream_t s,
+                                void** params) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof_take_events(&e0, &e1)) return hipExtModuleLaunchKernel(f, gx * bx, gy * by, gz * bz, bx, by, bz, lds, s, params, nullptr, e0, e1, 0);
+  return hipModuleLaunchKernel(f, gx, gy, gz, bx, by, bz, lds, s, params, nullptr);
+}
+#endif  // __HIPCC__
 
 bool profile_enabled();  // per-kernel timing is on: callers keep everything on one stream (overlapped kernels would share their time)
 

@@ -45,7 +45,7 @@ static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R,
       (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wave_dbg), &d_dbg, sizeof(d_dbg), 0, hipMemcpyHostToDevice, s);
     }
 #endif
-    hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, n_rows);
+    GNX_LAUNCH((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, n_rows);
     GNX_HIP(hipGetLastError());
 #ifdef GNX_WAVE_STAMPS_BUILD
     if (dump) {
@@ -61,7 +61,7 @@ static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R,
       const int threads = graph_update_threads(h);
       const size_t lds = sizeof(float) * (size_t)graph_update_lds_floats(C, a.dg, a.og, threads);
       ProfScope ps("k_graph_t", s);
-      hipLaunchKernelGGL((k_graph_t<C, ONEG>), dim3((unsigned)a.G, (unsigned)R), dim3(threads), lds, s, a, n_rows);
+      GNX_LAUNCH((k_graph_t<C, ONEG>), dim3((unsigned)a.G, (unsigned)R), dim3(threads), lds, s, a, n_rows);
       GNX_HIP(hipGetLastError());
     }
   }
@@ -79,7 +79,7 @@ static bool launch_wave_pack(const gnx_graphs* h, const BlockArgs& a, int64_t R,
   else {
     if (h->G <= 1 || h->n_packs <= 0 || !a.packs || phase != 3 || a.og <= 0 || getenv("GNX_NO_PACK")) return false;
     ProfScope ps("k_block_wave", s);
-    hipLaunchKernelGGL((k_block_wave<DE, DN, DG, OE, ON, EPT, false, false, true>), dim3((unsigned)h->n_packs, (unsigned)R), dim3(kPackThreads), 0, s, a, 0);
+    GNX_LAUNCH((k_block_wave<DE, DN, DG, OE, ON, EPT, false, false, true>), dim3((unsigned)h->n_packs, (unsigned)R), dim3(kPackThreads), 0, s, a, 0);
     const hipError_t e = hipGetLastError();
     *rc = e == hipSuccess ? GNX_OK : hip_fail(e, "k_block_wave<PACK>");
     return true;
@@ -134,13 +134,13 @@ static int32_t launch_wave_jit(const gnx_graphs* h, const BlockArgs& a, int64_t 
   void* params[] = {&aa, &n_rows};
   if (phase & 1) {
     ProfScope ps("k_block_wave", s);
-    GNX_HIP(hipModuleLaunchKernel(fb, (unsigned)((a.n_wtiles + 3) / 4), (unsigned)R, 1, kThreads, 1, 1, 0, s, params, nullptr));
+    GNX_HIP(module_launch(fb, (unsigned)((a.n_wtiles + 3) / 4), (unsigned)R, 1, kThreads, 1, 1, 0, s, params));
   }
   if ((phase & 2) && a.og > 0) {
     const int threads = graph_update_threads(h);
     const size_t lds = sizeof(float) * (size_t)graph_update_lds_floats(C, a.dg, a.og, threads);
     ProfScope ps("k_graph_t", s);
-    GNX_HIP(hipModuleLaunchKernel(fg, (unsigned)a.G, (unsigned)R, 1, threads, 1, 1, (unsigned)lds, s, params, nullptr));
+    GNX_HIP(module_launch(fg, (unsigned)a.G, (unsigned)R, 1, threads, 1, 1, (unsigned)lds, s, params));
   }
   return GNX_OK;
 }

@@ -1,5 +1,9 @@
-// Per-kernel HIP-event timing, off by default.  bench.py turns it on for a second pass over the timed region so the
-// roofline line can quote the dominant kernel's measured duration (events are recorded on the launch stream).
+// Per-kernel timing from DISPATCH timestamps, off by default.  bench.py turns it on for a second pass over the timed region so the
+// roofline line can quote the dominant kernel's measured duration.  Every launch made inside a ProfScope (through GNX_LAUNCH /
+// module_launch, gnx_internal.h) carries its own start / stop event pair on its dispatch packet (hipExtLaunchKernel): the elapsed time
+// of the pair is the kernel's begin -> end as the command processor stamps it, i.e. what rocprofv3's kernel trace reports.  An entry of
+// gnx_profile_read is one scope NAME: `launches` = times the scope was entered, `total_ms` = the sum over the kernels launched inside it
+// (a scope with several kernels — the graph level of the wide block — is the sum of their durations, without the gaps between them).
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -17,6 +21,8 @@ static std::mutex g_mu;
 static bool g_enabled = false;
 static std::vector<ProfRecord> g_records;
 static std::vector<hipEvent_t> g_pool;
+static std::map<std::string, int64_t> g_entries;  // scope name -> times entered
+static thread_local const char* t_scope = nullptr;
 
 static hipEvent_t get_event() {
   if (!g_pool.empty()) {
@@ -29,21 +35,26 @@ static hipEvent_t get_event() {
   return e;
 }
 
-ProfScope::ProfScope(const char* name, hipStream_t s) : slot(-1), stream(s) {
+ProfScope::ProfScope(const char* name, hipStream_t) : prev(t_scope) {
   if (!g_enabled) return;
+  t_scope = name;
   std::lock_guard<std::mutex> lk(g_mu);
-  ProfRecord r{name, get_event(), get_event()};
-  (void)hipEventRecord(r.start, s);
-  slot = (int)g_records.size();
-  g_records.push_back(r);
+  g_entries[name] += 1;
 }
+
+ProfScope::~ProfScope() { t_scope = prev; }
 
 bool profile_enabled() { return g_enabled; }
 
-ProfScope::~ProfScope() {
-  if (slot < 0) return;
+bool prof_take_events(hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_enabled || !t_scope) return false;
   std::lock_guard<std::mutex> lk(g_mu);
-  (void)hipEventRecord(g_records[slot].stop, stream);
+  ProfRecord r{t_scope, get_event(), get_event()};
+  if (!r.start || !r.stop) return false;
+  g_records.push_back(r);
+  *start = r.start;
+  *stop = r.stop;
+  return true;
 }
 
 }  // namespace gnx
@@ -66,32 +77,35 @@ int32_t gnx_profile_reset(void) {
     g_pool.push_back(r.stop);
   }
   g_records.clear();
+  g_entries.clear();
   return GNX_OK;
 }
 
 int32_t gnx_profile_read(gnx_profile_entry* out, int32_t max, int32_t* n) {
   std::lock_guard<std::mutex> lk(g_mu);
-  std::map<std::string, std::pair<int64_t, double>> acc;
+  std::map<std::string, double> acc;
+  std::map<std::string, int64_t> nk;
   std::vector<std::string> order;
   for (auto& r : g_records) {
     GNX_HIP(hipEventSynchronize(r.stop));
     float ms = 0.f;
     GNX_HIP(hipEventElapsedTime(&ms, r.start, r.stop));
+    nk[r.name] += 1;
     auto it = acc.find(r.name);
     if (it == acc.end()) {
       order.push_back(r.name);
-      acc[r.name] = {1, (double)ms};
+      acc[r.name] = (double)ms;
     } else {
-      it->second.first += 1;
-      it->second.second += ms;
+      it->second += ms;
     }
   }
   if (n) *n = (int32_t)order.size();
   for (int32_t i = 0; i < (int32_t)order.size() && i < max && out; ++i) {
     memset(&out[i], 0, sizeof(out[i]));
     strncpy(out[i].name, order[i].c_str(), sizeof(out[i].name) - 1);
-    out[i].launches = acc[order[i]].first;
-    out[i].total_ms = acc[order[i]].second;
+    out[i].launches = g_entries[order[i]];
+    out[i].total_ms = acc[order[i]];
+    out[i].kernels = nk[order[i]];
   }
   return GNX_OK;
 }

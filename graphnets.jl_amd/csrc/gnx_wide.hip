@@ -1100,7 +1100,7 @@ static int32_t launch_skinny2(const SkinnyJob& j0, const SkinnyJob& j1, hipStrea
   const bool two = j1.y != nullptr;
   const size_t lds = sizeof(float) * std::max<size_t>(std::max((size_t)j0.M * j0.K, two ? (size_t)j1.M * j1.K : 0), 16 * 8 * 64);
   const unsigned gx = (unsigned)((std::max(j0.N, two ? j1.N : 0) + 63) / 64);
-  hipLaunchKernelGGL(k_skinny_dense, dim3(gx, two ? 2u : 1u), dim3(1024), lds, s, j0, j1);
+  GNX_LAUNCH(k_skinny_dense, dim3(gx, two ? 2u : 1u), dim3(1024), lds, s, j0, j1);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -1240,7 +1240,7 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
   const bool trans = w.act > 1;
   // instantiations: quad outputs with the lean loader (every NL), quad outputs with the full loader and no operands (node update,
   // encoder), element outputs with the full loader (every NL; also takes the rare quad-output + full-loader + operands launches)
-#define GNX_GEMM_LAUNCH(V, N, T, F) hipLaunchKernelGGL((k_rows_gemm<BN, V, 32, N, T, F>), grid, dim3(WaveLayout<BN>::WT), 0, s, wa)
+#define GNX_GEMM_LAUNCH(V, N, T, F) GNX_LAUNCH((k_rows_gemm<BN, V, 32, N, T, F>), grid, dim3(WaveLayout<BN>::WT), 0, s, wa)
 #define GNX_GEMM_LAUNCH_N(V, T, F) do { if (nl == 0) GNX_GEMM_LAUNCH(V, 0, T, F); else if (nl == 1) GNX_GEMM_LAUNCH(V, 1, T, F); else GNX_GEMM_LAUNCH(V, 2, T, F); } while (0)
   if (vec4 && ld == 0 && nl == 3) { if (trans) GNX_GEMM_LAUNCH(true, 3, true, 0); else GNX_GEMM_LAUNCH(true, 3, false, 0); }
   else if (vec4 && ld == 0) { if (trans) GNX_GEMM_LAUNCH_N(true, true, 0); else GNX_GEMM_LAUNCH_N(true, false, 0); }
@@ -1414,8 +1414,8 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
       else if (a.oe > 0) { if ((rc = launch_skinny2(je, SkinnyJob{}, s))) return rc; }
       else if (a.on > 0) { if ((rc = launch_skinny2(jn, SkinnyJob{}, s))) return rc; }
     } else {
-    if (a.oe > 0) hipLaunchKernelGGL(k_fold_bias, dim3((unsigned)a.G, (unsigned)R), dim3(128), 0, s, a.We, a.be, a.gf, a.dg, a.de + 2 * a.dn, a.oe, a.G, bias_e);
-    if (a.on > 0) hipLaunchKernelGGL(k_fold_bias, dim3((unsigned)a.G, (unsigned)R), dim3(128), 0, s, a.Wn, a.bn, a.gf, a.dg, a.oe + a.dn, a.on, a.G, bias_n);
+    if (a.oe > 0) GNX_LAUNCH(k_fold_bias, dim3((unsigned)a.G, (unsigned)R), dim3(128), 0, s, a.We, a.be, a.gf, a.dg, a.de + 2 * a.dn, a.oe, a.G, bias_e);
+    if (a.on > 0) GNX_LAUNCH(k_fold_bias, dim3((unsigned)a.G, (unsigned)R), dim3(128), 0, s, a.Wn, a.bn, a.gf, a.dg, a.oe + a.dn, a.on, a.G, bias_n);
     }
     GNX_HIP(hipGetLastError());
   }
@@ -1484,16 +1484,16 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     if (a.oe > 0 || a.on > 0) {
       const ColsumJob je{a.oe > 0 ? pe : nullptr, n_et * (size_t)a.oe, h->d_etile_off, a.oe, pe2};
       const ColsumJob jn{a.on > 0 ? pn : nullptr, n_nt * (size_t)a.on, h->d_ntile_off, a.on, pn2};
-      hipLaunchKernelGGL(k_colsum_slices, dim3(2u * (unsigned)a.G, (unsigned)S, (unsigned)R), dim3(128), 0, s, je, jn, S, a.G);
+      GNX_LAUNCH(k_colsum_slices, dim3(2u * (unsigned)a.G, (unsigned)S, (unsigned)R), dim3(128), 0, s, je, jn, S, a.G);
     }
     const int Kg = a.oe + a.on + a.dg;
     if (skinny_ok(R * a.G, Kg, a.og)) {  // small batch, wide layers: assemble Xg, then the round-trip-lean GEMV kernel
       float* xg = reinterpret_cast<float*>(reinterpret_cast<char*>(proj_s) + align_up(sizeof(float) * 2 * (size_t)R * h->N * a.oe, 256));
-      hipLaunchKernelGGL(k_graph_x, dim3((unsigned)a.G, (unsigned)R), dim3(256), 0, s, pe2, pn2, S, a, xg);
+      GNX_LAUNCH(k_graph_x, dim3((unsigned)a.G, (unsigned)R), dim3(256), 0, s, pe2, pn2, S, a, xg);
       if ((rc = launch_skinny(xg, Kg, (int)(R * a.G), Kg, a.Wg, 0, a.og, a.bg, a.og, a.act_g, a.gf_out, a.og, s))) return rc;
     } else {
       const size_t lds = sizeof(float) * ((size_t)(a.oe + a.on + a.dg + 4) + 256 * 33 + 4);
-      hipLaunchKernelGGL(k_graph_final, dim3((unsigned)a.G, (unsigned)R), dim3(256), lds, s, pe2, pn2, S, a);
+      GNX_LAUNCH(k_graph_final, dim3((unsigned)a.G, (unsigned)R), dim3(256), lds, s, pe2, pn2, S, a);
     }
     GNX_HIP(hipGetLastError());
   }

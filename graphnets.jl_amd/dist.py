@@ -138,3 +138,88 @@ def sharded_block_forward(forward_fn, x_local, gather: GfGather):
     gf_rows = gf.permute(2, 1, 0)[0] if gf.dim() == 3 else gf  # Julia-shaped (DG, G_local, 1) → (G_local, DG)
     gather.start(gf_rows)
     return y, gather.finish()
+
+
+class DistBlockRunner:
+    """ONE process driving n devices through the C boundary's own sharded path (gnx_dist_*: what the Julia shim's DistBlock binds) —
+    the counterpart of GfGather for hosts that are not one-process-per-GPU.  Builds the communicator (ncclCommInitAll), one graph handle,
+    one replicated parameter set and `n_sets` feature / output / workspace buffer sets per device; `run(first_set, n_steps)` is ONE
+    gnx_dist_block_forward_steps: n_steps forwards per device (buffer sets first_set, first_set + 1, ... modulo n_sets), replayed as one
+    hipGraph per device after the first call with the same sets, one grouped all-gather of the stacked gf' tables, and gf_all[r] =
+    [n_steps][G][og] in ORIGINAL graph order on every device.
+
+    shards: list of int64 arrays (original graph ids per rank, e.g. partition_graphs(...)); graphs_of(r) -> (colptrs, rowvals, n_nodes) of
+    rank r's graphs in shard order; make_block(device) -> a GNBlock with the (replicated) parameters on that device."""
+
+    def __init__(self, devices, shards, graphs_of, make_block, dims, n_sets=8, max_steps=1, seed=1234):
+        import ctypes as C
+        from . import _lib
+        from .api import GNGraphBatch
+        self.lib, self.C, self._lib = _lib.load(), C, _lib
+        self.n = len(devices)
+        self.devices = [torch.device("cuda", int(d)) for d in devices]
+        (de, dn, dg), (oe, on, og) = dims
+        self.dims, self.og, self.n_sets = dims, og, n_sets
+        self.G = int(sum(len(s) for s in shards))
+        off = np.zeros(self.n + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in shards])
+        ids = np.ascontiguousarray(np.concatenate([np.asarray(s, dtype=np.int64) for s in shards]))
+        p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+        self._d = C.c_void_p()
+        devs = (C.c_int32 * self.n)(*[d.index for d in self.devices])
+        _lib.check(self.lib.gnx_dist_create(devs, self.n, p64(off), p64(ids), self.G, og, C.byref(self._d)))
+        self.keep, self.handles, self.params, self.sets, self.gall, self.streams, self.ws_bytes = [], [], [], [], [], [], []
+        self.edges = 0
+        for r, dev in enumerate(self.devices):
+            with torch.cuda.device(dev):
+                colptrs, rowvals, nn = graphs_of(r)
+                g = GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
+                blk = make_block(dev)
+                bp = blk._c(self.keep)
+                wsb = int(self.lib.gnx_block_workspace_bytes(g._h, C.byref(bp), 1))
+                tg = torch.Generator(device=dev); tg.manual_seed(seed + r)
+                mk = lambda T, d: torch.rand((T, d), generator=tg, device=dev, dtype=torch.float32) if d > 0 else None
+                sets = [dict(ef=mk(g.n_edges, de), nf=mk(g.n_nodes, dn), gf=mk(g.n_graphs, dg),
+                             eo=torch.empty((g.n_edges, oe), device=dev) if oe else None, no=torch.empty((g.n_nodes, on), device=dev) if on else None,
+                             ws=torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)) for _ in range(n_sets)]
+                self.handles.append(g); self.params.append(bp); self.keep.append(blk); self.sets.append(sets); self.ws_bytes.append(max(wsb, 256))
+                self.gall.append(torch.empty((max_steps, self.G, og), device=dev))
+                self.streams.append(torch.cuda.Stream(device=dev))
+                self.edges += g.n_edges
+        self.max_steps = max_steps
+
+    def _ptrs(self, first_set, n_steps, key):
+        C = self.C
+        vals = []
+        for s in range(n_steps):
+            for r in range(self.n):
+                t = self.sets[r][(first_set + s) % self.n_sets][key]
+                vals.append(t.data_ptr() if t is not None else None)
+        return (C.c_void_p * len(vals))(*vals)
+
+    def run(self, first_set=0, n_steps=1, flags=0):
+        C = self.C
+        assert 1 <= n_steps <= self.max_steps
+        per_rank = lambda f: (C.c_void_p * self.n)(*[f(r) for r in range(self.n)])
+        nbytes = (C.c_size_t * self.n)(*self.ws_bytes)
+        self._lib.check(self.lib.gnx_dist_block_forward_steps(
+            self._d, n_steps, per_rank(lambda r: self.handles[r]._h.value), per_rank(lambda r: C.addressof(self.params[r])),
+            self._ptrs(first_set, n_steps, "ef"), self._ptrs(first_set, n_steps, "nf"), self._ptrs(first_set, n_steps, "gf"),
+            self._ptrs(first_set, n_steps, "eo"), self._ptrs(first_set, n_steps, "no"), per_rank(lambda r: self.gall[r].data_ptr()),
+            self._ptrs(first_set, n_steps, "ws"), nbytes, flags, per_rank(lambda r: self.streams[r].cuda_stream)))
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()
+
+    def close(self):
+        if self._d:
+            self.synchronize()
+            self._lib.check(self.lib.gnx_dist_destroy(self._d))
+            self._d = self.C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

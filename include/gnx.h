@@ -130,8 +130,9 @@ typedef struct gnx_core_params {
 
 typedef struct gnx_profile_entry {
   char name[48];
-  int64_t launches;
-  double total_ms;
+  int64_t launches; /* times the named scope was entered (one per step for most scopes)                  */
+  double total_ms;  /* sum of the dispatch-timestamp durations of every kernel launched inside the scope */
+  int64_t kernels;  /* kernels launched inside the scope (the graph level of a wide block: three per entry) */
 } gnx_profile_entry;
 
 /* ---- library ---- */
@@ -385,6 +386,19 @@ GNX_API int32_t gnx_dist_block_forward(gnx_dist* d, const gnx_graphs* const* h, 
                                float* const* gf_out_local, float* const* gf_all, void* const* workspace, const size_t* workspace_bytes,
                                uint32_t flags, void* const* streams);
 
+/* The replay form of the sharded forward, for loops over many batches of the same graphs (training / serving): n_steps block forwards
+ * per rank — independent batches: step s of rank r reads ef / nf / gf [s * n_ranks + r] and writes ef_out / nf_out [s * n_ranks + r] with the
+ * workspace [s * n_ranks + r] of workspace_bytes[r] bytes — whose gf' rows go straight into the communicator's stacked send buffer; ONE grouped
+ * all-gather moves the n_steps tables of every rank and gf_all[r] (device r) receives [n_steps][n_graphs][og] in ORIGINAL graph order.
+ * h / p / workspace_bytes / gf_all / streams have one entry per rank.  The launch sequence of a rank is captured into ONE hipGraph per
+ * device the first time a set of arguments is seen (that call runs eagerly and captures; up to 32 argument sets are kept per communicator)
+ * and replayed with one hipGraphLaunch per device afterwards: the host issues n_ranks graph launches + one grouped collective + n_ranks
+ * permute kernels per call, whatever n_steps is.  GNX_FLAG_NO_GRAPH: always eager.  One call at a time per communicator. */
+GNX_API int32_t gnx_dist_block_forward_steps(gnx_dist* d, int32_t n_steps, const gnx_graphs* const* h, const gnx_block_params* const* p,
+                                     const float* const* ef, const float* const* nf, const float* const* gf, float* const* ef_out,
+                                     float* const* nf_out, float* const* gf_all, void* const* workspace, const size_t* workspace_bytes,
+                                     uint32_t flags, void* const* streams);
+
 /* ---- run-time specialisation (the analogue of Julia compiling a GNBlock for its own widths on first use) -----------
  * The fused one-launch kernel is compiled ahead of time for the README / benchmark width sets; for any other width set
  * with every width <= 32 (and at most 1024 weights in the edge and node functions) it is compiled at run time with hiprtc (gfx950), once per process and device, the first time
@@ -399,10 +413,12 @@ GNX_API int32_t gnx_jit_precompile(const gnx_block_params* p, int32_t wtile_e_ca
 GNX_API int32_t gnx_jit_precompile_core_post(int32_t de, int32_t dn, int32_t dg, size_t* code_bytes);
 GNX_API int32_t gnx_jit_stats(int64_t out[4]);
 
-/* ---- per-kernel HIP-event timing (bench/roofline evidence) ---- */
+/* ---- per-kernel timing from dispatch timestamps (bench / roofline evidence): while enabled, every kernel the library launches carries a
+ * start / stop event pair on its own dispatch packet (hipExtLaunchKernel) — the kernel's begin -> end as rocprofv3's kernel trace reports
+ * it, plus a constant ~3.9 us that gnx_profile_calibrate measures on an empty kernel ---- */
 GNX_API int32_t gnx_profile_enable(int32_t on);
 GNX_API int32_t gnx_profile_reset(void);
-/* n empty launches through the same event bracket (entry "__empty_bracket__"): the bracket's own cost */
+/* n launches of an empty kernel timed the same way (entry "__empty_bracket__"): the constant of the method */
 GNX_API int32_t gnx_profile_calibrate(int32_t n, void* stream);
 /* synchronises the recorded events; writes up to `max` entries, returns how many exist in *n */
 GNX_API int32_t gnx_profile_read(gnx_profile_entry* out, int32_t max, int32_t* n);

@@ -12,7 +12,8 @@
  *                            line here); without it the program draws its own graph of the same law (E distinct directed pairs of an
  *                            N-node graph, uniformly, reference edge order).
  *   --steps K --warmup W --nodes N --edges E
- * Prints ONE JSON line.  Timing: wall clock around the K steps between two hipStreamSynchronize (median of 3 regions), and HIP events
+ * Prints ONE JSON line.  Timing: after W warm-up steps and 150 ms of the same load (clock settling), wall clock around the K steps between two
+ * hipStreamSynchronize (median of 3 regions), and HIP events
  * on the same stream.  Features U[0,1), weights glorot-uniform, biases 0, LayerNorm 1 / 0 (Flux's initialisation): as bench.py.
  */
 #define _POSIX_C_SOURCE 200809L
@@ -133,6 +134,12 @@ static timing time_steps(void (*step)(int, void*), void* ctx, int K, int W, hipS
   CHECK_HIP(hipEventCreate(&e0)); CHECK_HIP(hipEventCreate(&e1));
   for (int i = 0; i < W; ++i) step(i, ctx);
   CHECK_HIP(hipStreamSynchronize(s));
+  /* untimed: the same load for 150 ms, so that the timed regions run at settled clocks (after an idle period the MI355X's power management
+   * needs tens of milliseconds of continuous load: bench.py::spin_up has the trace) */
+  for (const double t_w = now_s(); now_s() - t_w < 0.150;) {
+    for (int i = 0; i < (K < 64 ? K : 64); ++i) step(i, ctx);
+    CHECK_HIP(hipStreamSynchronize(s));
+  }
   for (int r = 0; r < 3; ++r) {
     CHECK_HIP(hipStreamSynchronize(s));
     const double t0 = now_s();
@@ -155,6 +162,13 @@ static timing time_steps(void (*step)(int, void*), void* ctx, int K, int W, hipS
 
 typedef struct { hipGraphExec_t exec; hipStream_t s; } replay_ctx;
 static void step_replay(int i, void* c) { (void)i; replay_ctx* r = (replay_ctx*)c; CHECK_HIP(hipGraphLaunch(r->exec, r->s)); }
+
+typedef struct { const gnx_graphs* h; const gnx_block_params* p; const float *ef[NSETS], *nf[NSETS]; float *eo[NSETS], *no[NSETS], *go[NSETS]; void* ws[NSETS]; size_t ws_bytes; hipStream_t s; } eager_ctx;
+static void step_eager(int i, void* c) {
+  eager_ctx* x = (eager_ctx*)c;
+  const int b = i % NSETS;
+  CHECK_GNX(gnx_block_forward(x->h, x->p, x->ef[b], x->nf[b], NULL, 1, x->eo[b], x->no[b], x->go[b], x->ws[b], x->ws_bytes, 0, x->s));
+}
 
 typedef struct { gnx_model* m[NSETS]; int nsets; const float *ef[NSETS], *nf[NSETS]; float *eo[NSETS], *no[NSETS], *go[NSETS]; hipStream_t s; } model_ctx;
 static void step_model(int i, void* c) {
@@ -231,6 +245,11 @@ int main(int argc, char** argv) {
       mc.ef[b] = ef[b]; mc.nf[b] = nf[b]; mc.eo[b] = eo[b]; mc.no[b] = no[b]; mc.go[b] = go[b];
     }
     const timing tb = time_steps(step_model, &mc, K, W > NSETS ? W : NSETS, s);
+    /* (c) no graph at all: one gnx_block_forward (two kernel launches) per step, issued by this thread as fast as it can */
+    eager_ctx ec;
+    ec.h = h; ec.p = &p; ec.ws_bytes = ws_bytes; ec.s = s;
+    for (int b = 0; b < NSETS; ++b) { ec.ef[b] = ef[b]; ec.nf[b] = nf[b]; ec.eo[b] = eo[b]; ec.no[b] = no[b]; ec.go[b] = go[b]; ec.ws[b] = ws[b]; }
+    const timing tc = time_steps(step_eager, &ec, K, W, s);
     float g5[5];
     CHECK_HIP(hipMemcpy(g5, go[0], sizeof g5, hipMemcpyDeviceToHost));
     printf("{\"bench\": \"abi_bench\", \"mode\": \"block\", \"workload\": \"C2%s: %lld nodes / %lld edges, (10,5,0)=>(3,4,5), through include/gnx.h from C (no Python, no torch)\", "
@@ -238,9 +257,11 @@ int main(int argc, char** argv) {
            "\"captured_what\": \"%d gnx_block_forward calls captured by the C program into one hipGraph, %d rotating buffer sets, median of 3 replays\", "
            "\"model_us_per_step\": %.4f, \"model_event_us_per_step\": %.4f, \"model_reps_us\": [%.4f, %.4f, %.4f], "
            "\"model_what\": \"gnx_model_forward per step (library-owned hipGraph of one forward, one hipGraphLaunch per step), %d models over %d buffer sets\", "
+           "\"eager_us_per_step\": %.4f, \"eager_reps_us\": [%.4f, %.4f, %.4f], \"eager_what\": \"one gnx_block_forward per step on the stream, no hipGraph\", "
            "\"batch_ms\": %.3f, \"gf_out0\": %.6g}\n",
            csc ? " (bench.py's graph)" : " law (own draw)", (long long)N, (long long)E, K, ta.wall_us / K, ta.event_us / K, ta.reps_us[0] / K, ta.reps_us[1] / K,
-           ta.reps_us[2] / K, K, NSETS, tb.wall_us, tb.event_us, tb.reps_us[0], tb.reps_us[1], tb.reps_us[2], NSETS, NSETS, t_batch[0], (double)g5[0]);
+           ta.reps_us[2] / K, K, NSETS, tb.wall_us, tb.event_us, tb.reps_us[0], tb.reps_us[1], tb.reps_us[2], NSETS, NSETS, tc.wall_us, tc.reps_us[0], tc.reps_us[1],
+           tc.reps_us[2], t_batch[0], (double)g5[0]);
     for (int b = 0; b < NSETS; ++b) CHECK_GNX(gnx_model_destroy(mc.m[b]));
     CHECK_HIP(hipGraphExecDestroy(rc.exec)); CHECK_HIP(hipGraphDestroy(graph));
   } else if (!strcmp(mode, "c4")) {

@@ -45,7 +45,7 @@ def test_struct_layouts_match_header():
     L = gn._lib
     assert C.sizeof(L.Dense) == 24 and C.sizeof(L.BlockParams) == 24 + 3 * 24
     assert C.sizeof(L.CoreParams) == 96 + 6 * 16 + 3 * 48 + 8
-    assert C.sizeof(L.GraphsInfo) == 64 and C.sizeof(L.ProfileEntry) == 64
+    assert C.sizeof(L.GraphsInfo) == 64 and C.sizeof(L.ProfileEntry) == 72
 
 
 def test_argument_validation_happens_before_any_gpu_work(lib):

@@ -253,3 +253,63 @@ def test_gnx_dist_c_entry_points_two_devices(gn):
                 U.assert_close(bufs[r]["gall"].cpu().numpy()[None], ref[2], scale[2], f"gf' in original graph order on device {r}")
     finally:
         gn._lib.check(lib.gnx_dist_destroy(d))
+
+
+def test_gnx_dist_replay_form_world_1(gn):
+    """gnx_dist_block_forward_steps (the replay form of the sharded forward): n_steps forwards per device captured into ONE hipGraph per
+    device, gf' rows written straight into the stacked send buffer, ONE all-gather (real RCCL, world 1), stacked tables restored to ORIGINAL
+    graph order.  Eager (GNX_FLAG_NO_GRAPH), first call (eager + capture) and replays give the same bits; every step equals the oracle;
+    a second argument set gets its own graphs; growing n_steps re-sizes the stacked buffers."""
+    import torch
+    from graphnets_jl_amd.dist import DistBlockRunner
+    rng = np.random.default_rng(91)
+    G, E = 48, 6000
+    colptrs, rowvals, nn = bench.make_hetero(1234, G, E)
+    order = rng.permutation(G).astype(np.int64)  # the single rank's local order of its graphs: the index table is exercised
+    dims = ((10, 5, 3), (3, 4, 5))
+    p = O.make_block_params(rng, *dims)
+    graphs_of = lambda r: ([colptrs[i] for i in order], [rowvals[i] for i in order], [nn[i] for i in order])
+    run = DistBlockRunner([torch.cuda.current_device()], [order], graphs_of, lambda dev: U.block_from_params(gn, p, device=dev), dims, n_sets=3, max_steps=5)
+    try:
+        g = run.handles[0]
+        csc = (*g.csc(), g.node_off, g.edge_off)
+
+        def oracle_tables(first, n):
+            out = []
+            for s in range(n):
+                b = run.sets[0][(first + s) % 3]
+                ref, scale = O.block_forward_sparse(p, csc, b["ef"].cpu().numpy()[None], b["nf"].cpu().numpy()[None], b["gf"].cpu().numpy()[None], return_scale=True)
+                out.append((ref, scale))
+            return out
+
+        def check(first, n, what):
+            run.synchronize()
+            got = run.gall[0][:n].cpu().numpy()
+            for s, (ref, scale) in enumerate(oracle_tables(first, n)):
+                back = np.empty_like(ref[2][0]); sc = np.empty_like(scale[2][0])
+                back[order] = ref[2][0]; sc[order] = scale[2][0]  # local row k is original graph order[k]
+                U.assert_close(got[s][None], back[None], sc[None], f"{what}: step {s} gf' in original graph order")
+                b = run.sets[0][(first + s) % 3]
+                U.assert_close(b["eo"].cpu().numpy()[None], ref[0], scale[0], f"{what}: step {s} ef'")
+            return got.copy()
+
+        run.run(0, 4, flags=gn._lib.FLAG_NO_GRAPH)
+        eager = check(0, 4, "eager")
+        run.gall[0].fill_(float("nan"))
+        run.run(0, 4)                       # first sight: eager pass + capture
+        first = check(0, 4, "first call")
+        for _ in range(3):                  # replays: one hipGraphLaunch per device
+            run.gall[0].fill_(float("nan"))
+            run.run(0, 4)
+            again = check(0, 4, "replay")
+            assert np.array_equal(again, eager) and np.array_equal(first, eager)
+        run.run(1, 2); check(1, 2, "second argument set")
+        run.run(1, 2); check(1, 2, "second argument set, replay")
+        run.run(0, 4); assert np.array_equal(check(0, 4, "first set again"), eager)
+        run.run(2, 5); check(2, 5, "more steps than the buffers held: re-sized")
+        run.run(2, 5); check(2, 5, "re-sized, replay")
+        # argument checks
+        import ctypes as C
+        assert gn._lib.load().gnx_dist_block_forward_steps(run._d, 0, None, None, None, None, None, None, None, None, None, None, 0, None) == gn._lib.ERR_INVALID_ARG
+    finally:
+        run.close()
