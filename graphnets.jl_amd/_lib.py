@@ -110,6 +110,7 @@ SIGNATURES = {
     "gnx_graphs_get_info": (C.c_int32, [C.c_void_p, C.POINTER(GraphsInfo)]),
     "gnx_graphs_get_offsets": (C.c_int32, [C.c_void_p, _i64p, _i64p]),
     "gnx_graphs_get_csc": (C.c_int32, [C.c_void_p, _i64p, _i64p]),
+    "gnx_graphs_get_table": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, _i64p]),
     "gnx_block_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BlockParams), C.c_int64]),
     "gnx_block_forward": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + _FWD[2:]),
     "gnx_chain_block_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(ChainBlockParams), C.c_int64]),

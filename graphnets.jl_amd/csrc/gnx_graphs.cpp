@@ -64,6 +64,51 @@ static int adj_at(const void* base, int32_t kind, int64_t idx, bool* ok) {
   }
 }
 
+// graph-aligned packs for the in-kernel graph update (gnx_narrow.hip): every graph <= 8 wave tiles, more than one graph.  Best-fit
+// decreasing over the graphs' wave-tile counts (h_wtile_off): a graph's tiles adjacent in ONE pack of 8 slots.
+void build_packs(gnx_graphs* h, std::vector<int32_t>& packs) {
+  packs.clear();
+  h->n_packs = 0;
+  if (!(h->G > 1 && h->max_wtiles_per_graph >= 1 && h->max_wtiles_per_graph <= 8)) return;
+  constexpr int CAP = 8;
+  std::vector<int32_t> order((size_t)h->G);
+  for (int64_t g = 0; g < h->G; ++g) order[(size_t)g] = (int32_t)g;
+  auto cnt_of = [&](int32_t g) { return h->h_wtile_off[(size_t)g + 1] - h->h_wtile_off[(size_t)g]; };
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cnt_of(a) > cnt_of(b); });
+  std::vector<int32_t> fill;                  // slots used per pack
+  std::vector<std::vector<int32_t>> open(CAP + 1);  // open[r]: packs with r free slots
+  for (int32_t g : order) {
+    const int c = cnt_of(g);
+    if (c <= 0) continue;  // (a graph always has >= 1 node, hence >= 1 wave tile; kept for safety)
+    int r = c;
+    while (r <= CAP && open[(size_t)r].empty()) ++r;  // best fit: the fullest pack that still takes the graph
+    int32_t pk;
+    if (r > CAP) { pk = (int32_t)fill.size(); fill.push_back(0); packs.insert(packs.end(), CAP, -1); }
+    else { pk = open[(size_t)r].back(); open[(size_t)r].pop_back(); }
+    for (int k = 0; k < c; ++k) packs[(size_t)pk * CAP + fill[(size_t)pk] + k] = h->h_wtile_off[(size_t)g] + k;
+    fill[(size_t)pk] += c;
+    if (fill[(size_t)pk] < CAP) open[(size_t)(CAP - fill[(size_t)pk])].push_back(pk);
+  }
+  h->n_packs = (int32_t)fill.size();
+}
+
+// wide path: the COUNTS of its 128-row tiles and the per-graph tile offsets (O(G)); the tables themselves on first use (ensure_wide_tables)
+static void fill_wide_counts(gnx_graphs* h) {
+  const int64_t BM = 128;
+  h->h_etile_off.assign(h->G + 1, 0);
+  h->h_ntile_off.assign(h->G + 1, 0);
+  for (int64_t g = 0; g < h->G; ++g) {
+    h->h_etile_off[g + 1] = h->h_etile_off[g] + (int32_t)((h->h_edge_off[g + 1] - h->h_edge_off[g] + BM - 1) / BM);
+    h->h_ntile_off[g + 1] = h->h_ntile_off[g] + (int32_t)((h->h_node_off[g + 1] - h->h_node_off[g] + BM - 1) / BM);
+  }
+  h->n_etiles = h->h_etile_off[h->G];
+  h->n_ntiles = h->h_ntile_off[h->G];
+  h->n_gtiles = (h->G + BM - 1) / BM;
+  // rows of the per-destination partial-sum table: one per (chunk, destination in it) <= non-empty nodes + one extra row per chunk a
+  // node's edge run can spill into; bounded without walking the graph by min(E, N + 2 * n_etiles)
+  h->agg_rows_bound = std::min<int64_t>(h->E, h->N + 2 * h->n_etiles);
+}
+
 // Build tiles, upload, finish the handle.  h_colptr / h_rowval (global) / h_node_off / h_edge_off are filled.
 static int32_t finalize(gnx_graphs* h) {
   if (h->N >= (int64_t)INT32_MAX || h->E >= (int64_t)INT32_MAX)
@@ -108,6 +153,7 @@ static int32_t finalize(gnx_graphs* h) {
   // allocator cost more than the 0.45 ms it takes over)
   build_tiles(h->tile_e_cap, h->tile_n_cap, h->h_tiles, h->h_tile_off, &h->max_in_degree);
   build_tiles(h->wtile_e_cap, 64, h->h_wtiles, h->h_wtile_off, &h->max_in_degree);
+  h->n_tiles_ = (int64_t)h->h_tiles.size(); h->n_wtiles_ = (int64_t)h->h_wtiles.size();
   for (int64_t g = 0; g < h->G; ++g) {  // wave tiles per graph (graph-update launch geometry)
     const int32_t cnt = h->h_wtile_off[g + 1] - h->h_wtile_off[g];
     h->max_wtiles_per_graph = std::max(h->max_wtiles_per_graph, cnt);
@@ -127,45 +173,8 @@ static int32_t finalize(gnx_graphs* h) {
   if (h->t_rowval32.size() == h->h_rowval.size() && !h->h_rowval.empty()) rowval32 = h->t_rowval32.data();
   else { rowval32_tmp.assign(h->h_rowval.begin(), h->h_rowval.end()); rowval32 = rowval32_tmp.data(); }
   std::vector<int32_t> packs;  // [n_packs][8] (filled below when applicable)
-  // wide path: the COUNTS of its 128-row tiles and the per-graph tile offsets now (O(G)); the tables on first use (ensure_wide_tables)
-  {
-    const int64_t BM = 128;
-    h->h_etile_off.assign(h->G + 1, 0);
-    h->h_ntile_off.assign(h->G + 1, 0);
-    for (int64_t g = 0; g < h->G; ++g) {
-      h->h_etile_off[g + 1] = h->h_etile_off[g] + (int32_t)((h->h_edge_off[g + 1] - h->h_edge_off[g] + BM - 1) / BM);
-      h->h_ntile_off[g + 1] = h->h_ntile_off[g] + (int32_t)((h->h_node_off[g + 1] - h->h_node_off[g] + BM - 1) / BM);
-    }
-    h->n_etiles = h->h_etile_off[h->G];
-    h->n_ntiles = h->h_ntile_off[h->G];
-    h->n_gtiles = (h->G + BM - 1) / BM;
-    // rows of the per-destination partial-sum table: one per (chunk, destination in it) <= non-empty nodes + one extra row per chunk a
-    // node's edge run can spill into; bounded without walking the graph by min(E, N + 2 * n_etiles)
-    h->agg_rows_bound = std::min<int64_t>(h->E, h->N + 2 * h->n_etiles);
-  }
-  // graph-aligned packs for the in-kernel graph update (gnx_narrow.hip): every graph <= 8 wave tiles, more than one graph
-  if (h->G > 1 && h->max_wtiles_per_graph >= 1 && h->max_wtiles_per_graph <= 8) {
-    constexpr int CAP = 8;
-    std::vector<int32_t> order((size_t)h->G);
-    for (int64_t g = 0; g < h->G; ++g) order[(size_t)g] = (int32_t)g;
-    auto cnt_of = [&](int32_t g) { return h->h_wtile_off[(size_t)g + 1] - h->h_wtile_off[(size_t)g]; };
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return cnt_of(a) > cnt_of(b); });
-    std::vector<int32_t> fill;                  // slots used per pack
-    std::vector<std::vector<int32_t>> open(CAP + 1);  // open[r]: packs with r free slots
-    for (int32_t g : order) {
-      const int c = cnt_of(g);
-      if (c <= 0) continue;  // (a graph always has >= 1 node, hence >= 1 wave tile; kept for safety)
-      int r = c;
-      while (r <= CAP && open[(size_t)r].empty()) ++r;  // best fit: the fullest pack that still takes the graph
-      int32_t pk;
-      if (r > CAP) { pk = (int32_t)fill.size(); fill.push_back(0); packs.insert(packs.end(), CAP, -1); }
-      else { pk = open[(size_t)r].back(); open[(size_t)r].pop_back(); }
-      for (int k = 0; k < c; ++k) packs[(size_t)pk * CAP + fill[(size_t)pk] + k] = h->h_wtile_off[(size_t)g] + k;
-      fill[(size_t)pk] += c;
-      if (fill[(size_t)pk] < CAP) open[(size_t)(CAP - fill[(size_t)pk])].push_back(pk);
-    }
-    h->n_packs = (int32_t)fill.size();
-  }
+  fill_wide_counts(h);
+  build_packs(h, packs);
   Slice sl[] = {
       {(void**)&h->d_colptr, colptr32, h->h_colptr.size() * sizeof(int32_t), 0},
       {(void**)&h->d_rowval, rowval32, h->h_rowval.size() * sizeof(int32_t), 0},
@@ -179,7 +188,12 @@ static int32_t finalize(gnx_graphs* h) {
   };
   size_t total = 0;
   for (Slice& x : sl) { x.off = total; total += (std::max<size_t>(x.bytes, 16) + 255) / 256 * 256; }
-  GNX_HIP(hipMalloc(&h->d_arena, total));
+  {
+    size_t got = 0;
+    h->d_arena = arena_take(h->device, total, &got);  // a released handle's block of about this size (the device is synchronised first), else a fresh one
+    if (h->d_arena) h->arena_bytes = got;
+    else { GNX_HIP(hipMalloc(&h->d_arena, total)); h->arena_bytes = total; }
+  }
   for (Slice& x : sl) {
     *x.dst = static_cast<char*>(h->d_arena) + x.off;  // (never NULL, as before: an empty array still has its 256-B slice)
     if (x.bytes) GNX_HIP(hipMemcpy(*x.dst, x.src, x.bytes, hipMemcpyHostToDevice));
@@ -387,6 +401,50 @@ static int32_t create_csc_impl(CP colptr_of, RV rowval_of, const int64_t* n_node
   return GNX_OK;
 }
 
+// The device builder's front end: the O(G) part of create_csc_impl's first pass (sizes, per-graph checks that need no sweep) on the host,
+// everything O(N + E) in kernels.  Same error codes and messages as the host builder; 1 = not applicable (the host builder runs).
+template <class CPAT>
+static int32_t create_csc_device(const void* colptr_cat, const void* rowval_cat, const int64_t* n_nodes, int64_t n_graphs, int32_t index_base, int32_t index_bits,
+                                 CPAT cp_at, gnx_graphs** out) {
+  BuildTimer bt;
+  std::unique_ptr<gnx_graphs> h(new gnx_graphs());
+  h->G = n_graphs;
+  h->h_node_off.resize((size_t)n_graphs + 1);
+  h->h_edge_off.resize((size_t)n_graphs + 1);
+  h->h_node_off[0] = 0; h->h_edge_off[0] = 0;
+  h->tile_e_cap = env_int("GNX_TILE_E", 512);
+  h->tile_n_cap = env_int("GNX_TILE_N", 128);
+  h->wtile_e_cap = env_int("GNX_WTILE_E", 128);
+  if (h->wtile_e_cap != 64 && h->wtile_e_cap != 128 && h->wtile_e_cap != 256) h->wtile_e_cap = 128;
+  int64_t cpo = 0, tb = 0, wb = 0, per_graph = 1;
+  for (int64_t g = 0; g < n_graphs; ++g) {
+    const int64_t n = n_nodes[g];
+    if (cp_at(cpo) != index_base) return fail(GNX_ERR_CSC, "colptr[0] must equal index_base");
+    const int64_t eg = cp_at(cpo + n) - index_base;
+    if (eg < 0 || eg > n * n) return fail(GNX_ERR_CSC, "colptr must be non-decreasing with at most N entries per column");
+    cpo += n + 1;
+    h->PN = std::max(h->PN, n);
+    h->h_node_off[(size_t)g + 1] = h->h_node_off[(size_t)g] + n;
+    h->h_edge_off[(size_t)g + 1] = h->h_edge_off[(size_t)g] + eg;
+    // a graph's greedy tiling: at most N_g / n_cap tiles end on the node cap, fewer than 2 E_g / e_cap on the edge cap (a tile that ends on
+    // it holds, with its successor, more than e_cap edges), one on the graph's end
+    const int64_t bt_g = std::min(n, n / h->tile_n_cap + 2 * eg / h->tile_e_cap + 2), bw_g = std::min(n, n / 64 + 2 * eg / h->wtile_e_cap + 2);
+    tb += bt_g; wb += bw_g;
+    per_graph = std::max(per_graph, std::max(bt_g, bw_g));
+  }
+  h->N = h->h_node_off.back();
+  h->E = h->h_edge_off.back();
+  if (h->N >= (int64_t)INT32_MAX || h->E >= (int64_t)INT32_MAX) return fail(GNX_ERR_TOO_LARGE, "graph batch exceeds int32 device indices");
+  GNX_HIP(hipGetDevice(&h->device));
+  fill_wide_counts(h.get());
+  bt.lap("csc: sizes (host, O(G))");
+  const int32_t rc = build_handle_from_csc_on_device(h.get(), colptr_cat, rowval_cat, index_base, index_bits, h->tile_e_cap, h->tile_n_cap, h->wtile_e_cap, tb, wb, per_graph);
+  bt.lap("csc: validation + tables (device)");
+  if (rc) { gnx_graphs_destroy(h.release()); return rc; }
+  *out = h.release();
+  return GNX_OK;
+}
+
 extern "C" {
 
 int32_t gnx_version(void) { return GNX_VERSION; }
@@ -511,6 +569,15 @@ int32_t gnx_graphs_create_csc_cat(const void* colptr_cat, int64_t colptr_len, co
   if (cpo != colptr_len) return fail(GNX_ERR_INVALID_ARG, "colptr_cat must hold exactly sum(n_nodes) + n_graphs entries");
   if (rvo != rowval_len) return fail(GNX_ERR_INVALID_ARG, "rowval_cat must hold exactly the edges the colptr arrays announce");
   if (rvo > 0 && !rowval_cat) return fail(GNX_ERR_CSC, "rowval is NULL but the graph has edges");
+  {
+    // large batches: validation, device-format arrays and both tile tables in kernels (gnx_build_csc.hip); 1 = not applicable here
+    static const bool dev_build = !(getenv("GNX_BUILD_CSC_DEVICE") && atoi(getenv("GNX_BUILD_CSC_DEVICE")) == 0);
+    static const int64_t dev_min = getenv("GNX_BUILD_CSC_DEVICE_MIN") ? atoll(getenv("GNX_BUILD_CSC_DEVICE_MIN")) : 65536;
+    if (dev_build && cpo + rvo >= dev_min) {
+      const int32_t rc = create_csc_device(colptr_cat, rowval_cat, n_nodes, n_graphs, index_base, index_bits, cp_at, out);
+      if (rc != 1) return rc;
+    }
+  }
   if (index_bits == 64) return gnx_graphs_create_csc_packed(static_cast<const int64_t*>(colptr_cat), static_cast<const int64_t*>(rowval_cat), n_nodes, n_graphs, index_base, out);
   // 32-bit indices on the host path: widened copies (the device-side builder reads them as they are)
   std::vector<int64_t> c64((size_t)colptr_len), r64((size_t)rowval_len);
@@ -521,7 +588,7 @@ int32_t gnx_graphs_create_csc_cat(const void* colptr_cat, int64_t colptr_len, co
 
 int32_t gnx_graphs_destroy(gnx_graphs* h) {
   if (!h) return GNX_OK;
-  (void)hipFree(h->d_arena);  // colptr, rowval, node / edge / tile offsets, tiles, wave tiles, packs
+  arena_give(h->device, h->d_arena, h->arena_bytes);  // colptr, rowval, node / edge / tile offsets, tiles, wave tiles, packs: kept for the next handle of this size
   (void)hipFree(h->d_edge_dst);
   (void)hipFree(h->d_chunk_row0);
   (void)hipFree(h->d_node_agg_row);
@@ -610,19 +677,38 @@ int32_t gnx_ensure_wide_tables(const gnx_graphs* h, void* stream) {
   }
   std::lock_guard<std::mutex> lk(h->wide_mu);
   if (h->wide_built.load(std::memory_order_relaxed)) return GNX_OK;
-  const int32_t rc = build_wide_tables(h);
+  int32_t rc = gnx_ensure_host_csc(h);
+  if (!rc) rc = build_wide_tables(h);
   if (rc) { drop_wide_tables(h); return rc; }  // (the message of the failing step stays in gnx_last_error())
   h->wide_built.store(true, std::memory_order_release);
   return GNX_OK;
 }
 
+int32_t gnx_ensure_host_csc(const gnx_graphs* h) {
+  if (!h) return fail(GNX_ERR_INVALID_ARG, "NULL handle");
+  if (!h->csc_on_device_only) return GNX_OK;
+  std::lock_guard<std::mutex> lk(h->host_csc_mu);
+  if (h->h_colptr.size() == (size_t)h->N + 1) return GNX_OK;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev != h->device ? prev : -1};
+  if (prev != h->device) GNX_HIP(hipSetDevice(h->device));
+  gnx::vec_i32 c32((size_t)h->N + 1), r32((size_t)h->E);
+  GNX_HIP(hipMemcpy(c32.data(), h->d_colptr, c32.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (h->E) GNX_HIP(hipMemcpy(r32.data(), h->d_rowval, r32.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  gnx_graphs* m = const_cast<gnx_graphs*>(h);  // (logically const: a cache of what the device arrays hold)
+  m->h_rowval.assign(r32.begin(), r32.end());
+  m->h_colptr.assign(c32.begin(), c32.end());
+  return GNX_OK;
+}
+
 int32_t gnx_ensure_csr(const gnx_graphs* h) {
-  std::call_once(h->csr_once, [&] { h->csr_rc = build_csr(h); });
+  std::call_once(h->csr_once, [&] { h->csr_rc = gnx_ensure_host_csc(h); if (!h->csr_rc) h->csr_rc = build_csr(h); });
   return h->csr_rc;
 }
 
 int32_t gnx_ensure_collapse(const gnx_graphs* h) {
-  std::call_once(h->collapse_once, [&] { h->collapse_rc = build_collapse(h); });
+  std::call_once(h->collapse_once, [&] { h->collapse_rc = gnx_ensure_host_csc(h); if (!h->collapse_rc) h->collapse_rc = build_collapse(h); });
   return h->collapse_rc;
 }
 
@@ -655,8 +741,27 @@ int32_t gnx_graphs_get_offsets(const gnx_graphs* h, int64_t* node_off, int64_t* 
   return GNX_OK;
 }
 
+// diagnostic: the handle's DEVICE tables copied to the host as they are (tests compare the device builder's with the host builder's)
+int32_t gnx_graphs_get_table(const gnx_graphs* h, int32_t which, void* out, int64_t capacity_bytes, int64_t* bytes) {
+  if (!h) return fail(GNX_ERR_INVALID_ARG, "NULL handle");
+  const void* src[9] = {h->d_colptr, h->d_rowval, h->d_node_off, h->d_edge_off, h->d_tile_off, h->d_tiles, h->d_wtile_off, h->d_wtiles, h->d_packs};
+  const size_t sz[9] = {(size_t)(h->N + 1) * 4, (size_t)h->E * 4, (size_t)(h->G + 1) * 4, (size_t)(h->G + 1) * 4, (size_t)(h->G + 1) * 4, (size_t)h->n_tiles() * sizeof(gnx::Tile),
+                        (size_t)(h->G + 1) * 4, (size_t)h->n_wtiles() * sizeof(gnx::Tile), (size_t)h->n_packs * 8 * 4};
+  if (which < 0 || which > 8) return fail(GNX_ERR_INVALID_ARG, "which must be 0..8 (colptr, rowval, node_off, edge_off, tile_off, tiles, wtile_off, wtiles, packs)");
+  if (bytes) *bytes = (int64_t)sz[which];
+  if (!out) return GNX_OK;
+  if (capacity_bytes < (int64_t)sz[which]) return fail(GNX_ERR_INVALID_ARG, "buffer smaller than the table");
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev != h->device ? prev : -1};
+  if (prev != h->device) GNX_HIP(hipSetDevice(h->device));
+  if (sz[which]) GNX_HIP(hipMemcpy(out, src[which], sz[which], hipMemcpyDeviceToHost));
+  return GNX_OK;
+}
+
 int32_t gnx_graphs_get_csc(const gnx_graphs* h, int64_t* colptr, int64_t* rowval) {
   if (!h) return fail(GNX_ERR_INVALID_ARG, "NULL handle");
+  if (int32_t rc = gnx_ensure_host_csc(h)) return rc;
   if (colptr) memcpy(colptr, h->h_colptr.data(), h->h_colptr.size() * sizeof(int64_t));
   if (rowval && !h->h_rowval.empty()) memcpy(rowval, h->h_rowval.data(), h->h_rowval.size() * sizeof(int64_t));
   return GNX_OK;

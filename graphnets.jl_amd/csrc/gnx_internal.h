@@ -43,6 +43,12 @@ struct gnx_graphs {
   gnx::vec_i64 h_colptr, h_rowval;
   gnx::vec_i32 t_colptr32, t_rowval32;  // transient: the device-format copies a constructor already made (uploaded as they are, then freed)
   void* d_arena = nullptr;  // ONE device allocation behind the arrays every handle has (colptr .. wave tiles below): a dozen hipMalloc / hipFree pairs cost ~3 ms per handle
+  size_t arena_bytes = 0;   // its size (a destroyed handle's arena goes to a small process-wide cache: gnx_build_csc.hip)
+  // A handle built on the device (gnx_build_csc.hip) has no host copy of colptr / rowval / the tile tables: the counts are kept, the
+  // int64 host copies (accessors, collapse / CSR / matrix-core table builders) are downloaded on first use (gnx_ensure_host_csc)
+  bool csc_on_device_only = false;
+  mutable std::mutex host_csc_mu;
+  int64_t n_tiles_ = 0, n_wtiles_ = 0;
   std::vector<gnx::Tile> h_tiles;
   std::vector<int32_t> h_tile_off;  // [G+1] tiles of graph g = [tile_off[g], tile_off[g+1])
   // wave tiles: same idea at wavefront granularity (<= wtile_e_cap edges, <= 64 nodes), one wave64 per tile
@@ -107,8 +113,8 @@ struct gnx_graphs {
   mutable hipStream_t aux_stream = nullptr;
   mutable hipEvent_t aux_fork = nullptr, aux_join = nullptr;
   mutable std::mutex aux_mu;  // held while a forward enqueues its fork / join pairs (try_lock: a concurrent caller stays on one stream)
-  int64_t n_tiles() const { return (int64_t)h_tiles.size(); }
-  int64_t n_wtiles() const { return (int64_t)h_wtiles.size(); }
+  int64_t n_tiles() const { return n_tiles_; }
+  int64_t n_wtiles() const { return n_wtiles_; }
 };
 
 namespace gnx {
@@ -158,10 +164,20 @@ bool profile_enabled();  // per-kernel timing is on: callers keep everything on 
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// graph-aligned packs of wave tiles from h->h_wtile_off (gnx_graphs.cpp; both builders): fills `packs` ([n_packs][8]) and h->n_packs
+void build_packs(gnx_graphs* h, std::vector<int32_t>& packs);
+// released handle arenas (gnx_build_csc.hip)
+void* arena_take(int dev, size_t bytes, size_t* got);
+void arena_give(int dev, void* ptr, size_t bytes);
+int32_t build_handle_from_csc_on_device(gnx_graphs* h, const void* colptr_cat, const void* rowval_cat, int32_t index_base, int32_t index_bits, int tile_e_cap, int tile_n_cap,
+                                        int wtile_e_cap, int64_t tiles_bound, int64_t wtiles_bound, int64_t max_tiles_per_graph_bound);
+
 }  // namespace gnx
 // builds the wide-path tables of a handle if they do not exist yet (the workspace queries call it; launchers call it with their stream:
 // inside a capture a missing table is an error, not a build).  A failure is not latched.
 extern "C" int32_t gnx_ensure_wide_tables(const gnx_graphs* h, void* stream = nullptr);
+// int64 host copies of colptr / rowval of a handle that was built on the device (no-op otherwise)
+extern "C" int32_t gnx_ensure_host_csc(const gnx_graphs* h);
 namespace gnx {
 
 

@@ -1,5 +1,6 @@
 // gnx_model: a list of GNBlock / GNCore layers run back to back and replayed as ONE hipGraph (include/gnx.h).
 // Host code only: every launch goes through gnx_block_forward / gnx_core_forward.
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -25,6 +26,7 @@ struct gnx_model {
   hipStream_t cap_stream = nullptr;
   const void* cap_ptrs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   uint32_t cap_flags = 0;
+  bool small = false;  // the captured forward is a handful of kernels: launched one by one (see gnx_model_forward)
   std::mutex mu;
 };
 
@@ -146,11 +148,18 @@ int32_t gnx_model_forward(gnx_model* m, const float* ef, const float* nf, const 
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
     if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
     m->graph = g;
+    // A replay costs ~5 us of launch latency per hipGraphLaunch on top of its kernels, a plain launch ~2-3 us of host time that the GPU does
+    // not wait for while the host stays ahead: a forward of <= 4 kernels (one narrow GNBlock: 2) is faster launched one by one — BASELINE
+    // configs[1] from C: 24.9 us/step eager, 29.9 us/step as a one-forward graph, 25.0 as 200 forwards in ONE graph (tests/c/abi_bench.c)
+    size_t n_nodes = 0;
+    static const size_t min_nodes = getenv("GNX_MODEL_GRAPH_MIN_NODES") ? (size_t)atoi(getenv("GNX_MODEL_GRAPH_MIN_NODES")) : 5;
+    m->small = hipGraphGetNodes(m->graph, nullptr, &n_nodes) == hipSuccess && n_nodes < min_nodes;
     GNX_HIP(hipGraphInstantiate(&m->exec, m->graph, nullptr, nullptr, 0));
     std::memcpy(m->cap_ptrs, ptrs, sizeof ptrs);
     m->cap_flags = lflags;
     return GNX_OK;  // the eager pass above already produced this call's outputs
   }
+  if (m->small) return run_layers(m, ef, nf, gf, ef_out, nf_out, gf_out, lflags, s);
   GNX_HIP(hipGraphLaunch(m->exec, s));
   return GNX_OK;
 }

@@ -172,6 +172,12 @@ GNX_API int32_t gnx_graphs_get_offsets(const gnx_graphs* h, int64_t* node_off, i
 /* host copies, 0-based global CSC: colptr[N+1], rowval[E] (global source node id) */
 GNX_API int32_t gnx_graphs_get_csc(const gnx_graphs* h, int64_t* colptr, int64_t* rowval);
 
+/* diagnostic: one of the handle's DEVICE tables copied to the host as it is — which = 0 colptr [N+1] int32, 1 rowval [E] int32 (global source
+ * ids), 2 node_off, 3 edge_off, 4 tile_off [G+1] int32, 5 workgroup tiles (32-byte records {n0, n1, e0, e1, g, win0, win1, flags}), 6 wtile_off,
+ * 7 wave tiles, 8 packs [n_packs][8] int32.  *bytes = the table's size (out may be NULL to ask for it).  Large batches given as CSC are
+ * validated and tiled by kernels (env GNX_BUILD_CSC_DEVICE=0: on the host); the two builders' tables are bit-identical (tests/test_gpu_build.py). */
+GNX_API int32_t gnx_graphs_get_table(const gnx_graphs* h, int32_t which, void* out, int64_t capacity_bytes, int64_t* bytes);
+
 /* ---- forward: replaces (m::GNBlock)(x) (src/gnblock.jl:63-69) ---- */
 GNX_API size_t gnx_block_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t n_replicas);
 GNX_API int32_t gnx_block_forward(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf,
@@ -331,7 +337,9 @@ GNX_API int32_t gnx_unpad_features(const gnx_graphs* h, int32_t kind, const floa
  * caller's and must stay valid), sizes every intermediate tensor and workspace once (library-owned device memory, freed by
  * gnx_model_destroy) and compiles any run-time specialised kernel.  gnx_model_forward runs the layers back to back on
  * `stream`; the first call with a given set of input/output pointers captures them into a hipGraph (on an internal stream),
- * later calls with the same pointers replay it with one hipGraphLaunch (new pointers: re-capture).  GNX_FLAG_NO_GRAPH runs
+ * later calls with the same pointers replay it with one hipGraphLaunch (new pointers: re-capture) — unless the captured forward is fewer
+ * than five kernels (one narrow GNBlock: two), which is launched kernel by kernel: faster than a replay's launch latency (24.9 vs 29.9
+ * us/step on BASELINE configs[1]; env GNX_MODEL_GRAPH_MIN_NODES).  GNX_FLAG_NO_GRAPH runs
  * eagerly.  Layer i's output widths must equal layer i+1's input widths (GNX_ERR_DIMS).  One forward at a time per model. */
 typedef struct gnx_model gnx_model;
 #define GNX_LAYER_BLOCK 0

@@ -23,6 +23,9 @@ int32_t build_csc_on_device(const void* const*, const int64_t*, int64_t, int32_t
                             const std::vector<int64_t>&) {
   return fail(100, "stub: no device");
 }
+void* arena_take(int, size_t, size_t*) { return nullptr; }
+void arena_give(int, void* p, size_t) { if (p) (void)hipFree(p); }
+int32_t build_handle_from_csc_on_device(gnx_graphs*, const void*, const void*, int32_t, int32_t, int, int, int, int64_t, int64_t, int64_t) { return 1; }  // the host builder runs
 }  // namespace gnx
 extern "C" {
 size_t gnx_block_workspace_bytes(const gnx_graphs*, const gnx_block_params*, int64_t) { return 256; }

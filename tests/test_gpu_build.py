@@ -1,0 +1,138 @@
+"""GNGraphBatch construction from CSC on the device (csrc/gnx_build_csc.hip) against the host builder (csrc/gnx_graphs.cpp::finalize), which
+stays as the validator: every device table bit-identical (colptr, rowval, offsets, both tile tables, the pack table), the same info, the same
+errors for malformed input, and the same forward results.  The host builder runs in a child process with GNX_BUILD_CSC_DEVICE=0 (the switch
+is read once per process)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import bench
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {
+    "c2_small": dict(kind="c2", N=20_000, E=200_000),
+    "c2_full": dict(kind="c2", N=100_000, E=1_000_000),
+    "hetero_512": dict(kind="hetero", seed=3, G=512, E=1_000_000),
+    "hetero_4096": dict(kind="hetero", seed=5, G=4096, E=1_000_000),
+    "hetero_dense": dict(kind="hetero", seed=11, G=300, E=2_000_000),   # in-degrees up to ~190: single-node tiles, wave tiles on the edge cap
+    "edgeless_mix": dict(kind="mix"),
+}
+
+
+def _graphs(spec):
+    if spec["kind"] == "c2":
+        return bench.make_c2(seed=2, N=spec["N"], E=spec["E"])
+    if spec["kind"] == "hetero":
+        return bench.make_hetero(spec["seed"], spec["G"], spec["E"])
+    rng = np.random.default_rng(4)
+    colptrs, rowvals, nn = bench.make_hetero(21, 200, 90_000)
+    for g in rng.choice(200, 40, replace=False):  # graphs without a single edge, single-node graphs, a self loop
+        n = int(rng.integers(1, 4))
+        colptrs[g], rowvals[g], nn[g] = np.zeros(n + 1, dtype=np.int64), np.zeros(0, dtype=np.int64), n
+    colptrs[0], rowvals[0], nn[0] = np.array([0, 1], dtype=np.int64), np.array([0], dtype=np.int64), 1
+    return colptrs, rowvals, nn
+
+
+def _tables(spec, index_dtype="int64"):
+    """sha-free: the raw bytes of the nine device tables + the handle's info, as a dict of numpy arrays"""
+    import graphnets_jl_amd as gn
+    lib = gn._lib.load()
+    colptrs, rowvals, nn = _graphs(spec)
+    cat = lambda parts: np.concatenate(parts).astype(index_dtype)
+    g = gn.GNGraphBatch.from_csc_packed(cat(colptrs), cat(rowvals), nn)
+    out = {}
+    for which, name in enumerate(("colptr", "rowval", "node_off", "edge_off", "tile_off", "tiles", "wtile_off", "wtiles", "packs")):
+        n = C.c_int64(0)
+        gn._lib.check(lib.gnx_graphs_get_table(g._h, which, None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value // 4, 1), dtype=np.int32)
+        gn._lib.check(lib.gnx_graphs_get_table(g._h, which, buf.ctypes.data, buf.nbytes, C.byref(n)))
+        out[name] = buf[: n.value // 4]
+    out["info"] = np.array([g.n_graphs, g.n_nodes, g.n_edges, g.node_block_size, g.n_tiles, g.max_in_degree], dtype=np.int64)
+    cp, rv = g.csc()  # the lazily downloaded int64 host copies
+    out["host_colptr"], out["host_rowval"] = cp, rv
+    return out
+
+
+def _child(name, path):
+    np.savez(path, **_tables(CASES[name]))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_device_builder_tables_are_bit_identical_to_the_host_builders(name, tmp_path):
+    path = str(tmp_path / "host.npz")
+    env = dict(os.environ, GNX_BUILD_CSC_DEVICE="0")
+    r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); from tests import test_gpu_build as T; T._child({name!r}, {path!r})"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    host = np.load(path)
+    for dt in ("int64", "int32"):
+        dev = _tables(CASES[name], dt)
+        for k in host.files:
+            assert dev[k].shape == host[k].shape and np.array_equal(dev[k], host[k]), f"{name} ({dt} indices): table `{k}` differs between the device and the host builder"
+
+
+def test_device_builder_rejects_what_the_host_builder_rejects():
+    """malformed input through the device builder: same status code and message as the host pass, first error in column order"""
+    import graphnets_jl_amd as gn
+    colptrs, rowvals, nn = bench.make_hetero(7, 64, 120_000)
+    cpc, rvc = np.concatenate(colptrs), np.concatenate(rowvals)
+
+    def build(cp, rv):
+        return gn.GNGraphBatch.from_csc_packed(cp, rv, nn)
+    build(cpc, rvc)  # well-formed
+    msgs = {}
+    for what, (cp, rv) in {
+        "rowval out of range": (cpc, np.where(np.arange(rvc.size) == 77_777, 1 << 40, rvc)),
+        "rowval negative": (cpc, np.where(np.arange(rvc.size) == 5, -3, rvc)),
+        "rowval not increasing": (cpc, np.concatenate([rvc[:1000], rvc[999:1000], rvc[1001:]]) if rvc[999] != rvc[1000] else rvc),
+    }.items():
+        with pytest.raises(gn._lib.GnxError) as e:
+            build(cp, rv)
+        assert e.value.code == gn._lib.ERR_CSC and "rowval out of range or not strictly increasing" in str(e.value), what
+        msgs[what] = str(e.value)
+    # colptr: a decrease inside a graph; a rise above colptr[n] that comes back (nothing may be read or written past the graph's slice)
+    off = np.cumsum([0] + [n + 1 for n in nn])
+    bad = cpc.copy(); bad[off[3] + 5] = bad[off[3] + 4] - 1
+    with pytest.raises(gn._lib.GnxError) as e:
+        build(bad, rvc)
+    assert e.value.code == gn._lib.ERR_CSC and "colptr must be non-decreasing" in str(e.value)
+    bad = cpc.copy(); bad[off[63] + 1: off[63] + 3] = bad[off[64] - 1] + 1000
+    with pytest.raises(gn._lib.GnxError) as e:
+        build(bad, rvc)
+    assert e.value.code == gn._lib.ERR_CSC and "colptr must be non-decreasing" in str(e.value)
+    # the FIRST error in column order wins, as in the host pass: a colptr error in graph 10 and a rowval error in graph 2 -> rowval
+    bad = cpc.copy(); bad[off[10] + 2] = bad[off[10] + 1] - 1
+    e_off = np.cumsum([0] + [len(r) for r in rowvals])
+    rbad = rvc.copy(); rbad[e_off[2]] = 10 ** 9
+    with pytest.raises(gn._lib.GnxError) as e:
+        build(bad, rbad)
+    assert "rowval out of range" in str(e.value)
+    # lengths are checked before anything is read
+    with pytest.raises(gn._lib.GnxError):
+        build(cpc, rvc[:-1])
+    with pytest.raises(ValueError):
+        build(cpc[:-1], rvc)
+
+
+def test_forward_on_a_device_built_batch_equals_the_oracle_and_lazy_host_tables_work():
+    import torch
+    import graphnets_jl_amd as gn
+    from oracle import gn_oracle as O
+    from tests import util as U
+    colptrs, rowvals, nn = bench.make_hetero(9, 256, 300_000)
+    g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn)
+    rng = np.random.default_rng(1)
+    for dims in (((10, 5, 3), (3, 4, 5)), ((40, 36, 8), (36, 40, 8))):  # the fused narrow kernel; the matrix-core path (its tables come from the lazily downloaded host CSC)
+        p = O.make_block_params(rng, *dims)
+        ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims[0])
+        y = U.block_from_params(gn, p)(U.to_nt(gn, g, ef, nf, gf))
+        ref, scale = O.block_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+        for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+            U.assert_close(U.from_jl(got), r, s, name)
