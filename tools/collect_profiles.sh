@@ -1,8 +1,8 @@
 #!/bin/bash
 # Copies the summaries tools/profile_round.sh <round> left under gpurun_out/ into profiles/ (tracked): tools/collect_profiles.sh r02
-R=${1:-r03}
+R=${1:-r04}
 cd "$(dirname "$0")/.."
-for t in readme hetero512 hetero4096 core c4 c4_10-5-3; do
+for t in readme hetero512 hetero4096 hetero4096_8M core c4 c4_10-5-3; do
   d=gpurun_out/prof_${R}_$t
   [ -f $d/summary_kernel_stats.csv ] || { echo "missing $d"; continue; }
   cp $d/summary_kernel_stats.csv profiles/${R}_${t}_kernel_stats.csv
