@@ -101,8 +101,9 @@ bool core_post3_applies(const size_t rows[3], const int d[3], const gnx_ffn ff[3
 }
 // blk != nullptr: the block was launched without its graph update — it runs inside this launch (n_rows = partial-sum rows per replica).
 // 1 = not applicable (three launches).
+// skip_edges: the edge rows are final already (k_block_wave<..., FFE> ran their FeedForward and residual): the edge job gets no workgroups
 int32_t launch_core_post3(const float* const x[3], const size_t rows[3], const int d[3], const gnx_layernorm l2[3], const gnx_ffn ff[3], float eps,
-                          int eps_mode, float* const out[3], hipStream_t s, const BlockArgs* blk, int n_rows) {
+                          int eps_mode, float* const out[3], hipStream_t s, const BlockArgs* blk, int n_rows, bool skip_edges) {
   if (!core_post3_applies(rows, d, ff, blk != nullptr, s)) return blk ? fail(GNX_ERR_INVALID_ARG, "internal: deferred graph update without the combined kernel") : 1;
   PostJob j[3];
   for (int t = 0; t < 3; ++t) {
@@ -110,6 +111,7 @@ int32_t launch_core_post3(const float* const x[3], const size_t rows[3], const i
     j[t] = PostJob{x[t], rows[t], l2[t].gamma, l2[t].beta, ff[t].fc1, ff[t].fc2, out[t], (unsigned)((rows[t] + per - 1) / per)};
   }
   if (blk) j[2].blocks = (unsigned)rows[2];  // one workgroup per graph (and replica)
+  if (skip_edges) j[0].blocks = 0;
   const dim3 grid(j[0].blocks + j[1].blocks + j[2].blocks);
   ProfScope ps("k_core_post", s);
   if (d[0] == 10 && d[1] == 5 && d[2] == 3) {

@@ -113,98 +113,7 @@ __global__ __launch_bounds__(256) void k_core_post(const float* __restrict__ x, 
 // current one run (scalar loads return out of order, so the only wait is lgkmcnt(0), placed BEFORE the next issue), and the FMAs
 // take the weight as their SGPR operand.  No LDS, no workgroup barrier, 4*D live weight registers.
 // ---------------------------------------------------------------------------------------------------------------------------------
-// out = x + block_out + W2 act(W1 gn2(x) + b1) + b2, TWO rows per thread held as register pairs: every FMA is one v_pk_fma_f32
-// whose src0 is the SGPR pair holding the weight (op_sel picks its low or high half for both rows) — half the VALU issue of scalar FMAs.
-// The hidden layer is produced and consumed in two halves of HB = 2D units; the weight stream of a half is [b1 half | D rows of W1
-// (2D consecutive hidden units of input k) | D row PAIRS of W2 (2D consecutive floats: hidden units 2g, 2g+1)], every group 2D floats
-// = 2D packed FMAs.  The 2(2D+1) groups are walked by a compile-time recursion (GI = global group index: half, position and
-// register set are constants of each step).  The FMAs are (non-volatile) asm statements too: left as C, the vectoriser packs them
-// itself — with the weight copied into a VGPR pair first — and collects them behind the loads of ALL groups (800 spilled SGPRs).
-#ifndef GNX_CORE_POST_UNITS
-#define GNX_CORE_POST_UNITS 1  // units of two rows per thread of the streamed FeedForward body (2 + the L2 touch loads: 39.6 vs 38.1 us, see below)
-#endif
-// TRANS = false: both activations are identity / relu (the reference's FeedForward) — the tanh / sigmoid / gelu expansions of a run-time
-// activation switch cost ~60 registers on every path, relu's included.
-template <int D, bool TRANS>
-struct CorePostStream {
-  static constexpr int H = 4 * D, HB = 2 * D, NG = 2 * D + 1, TOTAL = 2 * NG;
-  cfloatp W1, W2, b1;
-  int act1;
-  P2 (&z)[D];
-  P2 (&acc)[D];
-  P2 h[HB];
-  SGroup<HB> G0, G1;
-
-  template <int GI>
-  __device__ __forceinline__ cfloatp group_ptr() const {
-    constexpr int p = GI / NG, i = GI % NG;
-    if constexpr (i == 0) return b1 + p * HB;
-    else if constexpr (i <= D) return W1 + (i - 1) * H + p * HB;
-    else return W2 + (p * HB + 2 * (i - D - 1)) * D;
-  }
-  template <int GI>
-  __device__ __forceinline__ void consume(const SGroup<HB>& cur) {
-    constexpr int i = GI % NG;
-    if constexpr (i == 0) {
-#pragma unroll
-      for (int j = 0; j < HB; ++j) { const float b = cur.get(j); h[j].x = b; h[j].y = b; }
-      pin_pairs<HB>(h);
-    } else if constexpr (i <= D) {
-      constexpr int k = i - 1;
-#pragma unroll
-      for (int q = 0; q < HB / 2; ++q) {
-        const v2f_t w = cur.pair(q);
-        pk_fma_sw<false>(h[2 * q], w, z[k]);
-        pk_fma_sw<true>(h[2 * q + 1], w, z[k]);
-      }
-      if constexpr (i == D) {
-        if constexpr (TRANS) {
-          float t[HB];
-#pragma unroll
-          for (int j = 0; j < HB; ++j) t[j] = h[j].x;
-          act_row<HB>(t, act1);
-#pragma unroll
-          for (int j = 0; j < HB; ++j) { h[j].x = t[j]; t[j] = h[j].y; }
-          act_row<HB>(t, act1);
-#pragma unroll
-          for (int j = 0; j < HB; ++j) h[j].y = t[j];
-        } else if (act1 == 1) {
-#pragma unroll
-          for (int j = 0; j < HB; ++j) { h[j].x = fmaxf(h[j].x, 0.f); h[j].y = fmaxf(h[j].y, 0.f); }
-        }
-      }
-      pin_pairs<HB>(h);
-    } else {
-      constexpr int j = 2 * (i - D - 1);
-#pragma unroll
-      for (int q = 0; q < D; ++q) {  // pair q = weights 2q, 2q+1 of [W2 row j | W2 row j+1]
-        const v2f_t w = cur.pair(q);
-        pk_fma_sw<false>(acc[(2 * q) % D], w, h[j + (2 * q) / D]);
-        pk_fma_sw<true>(acc[(2 * q + 1) % D], w, h[j + (2 * q + 1) / D]);
-      }
-      pin_pairs<D>(acc);
-    }
-  }
-  template <int GI>
-  __device__ __forceinline__ void run() {
-    if constexpr (GI < TOTAL) {
-      if constexpr (GI % 2 == 0) {
-        G0.wait();
-        if constexpr (GI + 1 < TOTAL) G1.issue(group_ptr<GI + 1>());
-        __builtin_amdgcn_sched_barrier(0);
-        consume<GI>(G0);
-      } else {
-        G1.wait();
-        if constexpr (GI + 1 < TOTAL) G0.issue(group_ptr<GI + 1>());
-        __builtin_amdgcn_sched_barrier(0);
-        consume<GI>(G1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      run<GI + 1>();
-    }
-  }
-};
-
+// (CorePostStream — the streamed FeedForward of two rows held as register pairs — lives in gnx_wave_kernel.h: k_block_wave<..., FFE> runs it in its edge lanes too)
 template <int D, bool TRANS>
 __device__ __forceinline__ void core_post_s_body(const float* __restrict__ x, size_t rows, const float* gamma2, const float* beta2, gnx_dense fc1,
                                                  gnx_dense fc2, float eps, int eps_mode, float* __restrict__ out, unsigned blk, unsigned nblk) {

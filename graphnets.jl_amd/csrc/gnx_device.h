@@ -56,6 +56,11 @@ struct BlockArgs {
   // of pack p (-1: empty slot), the tiles of a graph adjacent — the graph update then runs inside the block kernel, from LDS
   const int* packs;
   int n_packs;
+  // narrow GNCore, edges: the FeedForward and both residual terms in the block kernel's edge lanes (k_block_wave<..., FFE>):
+  // ef_out receives y = (x + ef') + W2 act1(W1 gn2(x) + b1) + b2 instead of ef' (gncore.jl:56-59, gnfeedforward.jl:27-31); gn2 shares
+  // x-hat with gn1 (ln_eps / ln_mode above).  ffe_w1 == nullptr <=> off.
+  const float *ffe_w1, *ffe_b1, *ffe_w2, *ffe_b2, *ffe_g2, *ffe_be2;
+  int ffe_act1, ffe_act2;
 };
 
 // activation codes = GNX_ACT_* of include/gnx.h (static_assert'ed in gnx_forward.hip)

@@ -28,6 +28,7 @@ int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, 
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase);
 void warm_block_narrow(const gnx_graphs* h, const gnx_block_params* p);
 bool block_narrow_ready(const gnx_graphs* h, const BlockArgs& a, hipStream_t s);
+bool block_narrow_ffe_applies(const gnx_graphs* h, const BlockArgs& a, int act1, int act2);
 static_assert(GNX_ACT_IDENTITY == 0 && GNX_ACT_RELU == 1 && GNX_ACT_TANH == 2 && GNX_ACT_SIGMOID == 3 && GNX_ACT_GELU == 4,
               "act_apply (gnx_device.h) hard-codes the activation codes");
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase);
@@ -44,7 +45,7 @@ bool ln_stats_applies(const float* x, int d);
 int32_t launch_ln_stats(const float* x, size_t rows, int d, float eps, int eps_mode, float* stats, hipStream_t s);
 bool core_post3_applies(const size_t rows[3], const int d[3], const gnx_ffn ff[3], bool deferred, hipStream_t s);
 int32_t launch_core_post3(const float* const x[3], const size_t rows[3], const int d[3], const gnx_layernorm l2[3], const gnx_ffn ff[3], float eps,
-                          int eps_mode, float* const out[3], hipStream_t s, const BlockArgs* blk, int n_rows);
+                          int eps_mode, float* const out[3], hipStream_t s, const BlockArgs* blk, int n_rows, bool skip_edges = false);
 int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm& l2, const gnx_ffn& ff, float eps, int eps_mode,
                          float* out, hipStream_t s);
 int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K, const gnx_dense& d, int OUT, const float* add1,
@@ -95,7 +96,7 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
                                   const float* gf, int64_t R, float* ef_out, float* nf_out, float* gf_out, void* ws,
                                   size_t ws_bytes, uint32_t flags, hipStream_t s, int phase = 3, const gnx_layernorm* ln1 = nullptr,
                                   float ln_eps = 0.f, int ln_mode = 0, bool* fused_ln = nullptr, const float* const* wide_ln_stats = nullptr,
-                                  BlockArgs* args_out = nullptr) {
+                                  BlockArgs* args_out = nullptr, const gnx_ffn* ffe = nullptr, const gnx_layernorm* ffe_ln2 = nullptr, bool* ffe_took = nullptr) {
   int32_t rc = check_block(h, p, R);
   if (rc) return rc;
   if (phase & 1) {
@@ -144,6 +145,12 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
     a.ln_eps = ln_eps; a.ln_mode = ln_mode;
     if (!block_narrow_ready(h, a, s)) return GNX_OK;  // nothing launched: the caller runs gn1 as its own kernels
     *fused_ln = true;
+    if (ffe && ffe_ln2 && ffe_took && (phase & 1) && block_narrow_ffe_applies(h, a, ffe->fc1.act, ffe->fc2.act)) {
+      // narrow core: the edge FeedForward and both residual terms run in the block kernel's edge lanes — ef_out receives the CORE's output
+      a.ffe_w1 = ffe->fc1.weight; a.ffe_b1 = ffe->fc1.bias; a.ffe_w2 = ffe->fc2.weight; a.ffe_b2 = ffe->fc2.bias;
+      a.ffe_g2 = ffe_ln2->gamma; a.ffe_be2 = ffe_ln2->beta; a.ffe_act1 = ffe->fc1.act; a.ffe_act2 = ffe->fc2.act;
+      *ffe_took = true;
+    }
     if (args_out) *args_out = a;
     return launch_block_narrow(h, a, R, s, phase);
   }
@@ -285,7 +292,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   }
   // All three widths narrow: the fused block kernel normalises its inputs as it loads them (gn1 never materialised) when it
   // is available for this width set; gn2 is recomputed inside k_core_post either way.
-  bool fused_ln = false, defer_gu = false;
+  bool fused_ln = false, defer_gu = false, edge_ff_done = false;
   BlockArgs blk_args{};
   const bool all_narrow = core_narrow_width(d[0]) && core_narrow_width(d[1]) && core_narrow_width(d[2]) && !(flags & GNX_FLAG_FORCE_GENERIC);
   if (all_narrow) {
@@ -294,8 +301,9 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     // when the three FeedForwards go out as ONE launch (k_core_post3), the block's graph update runs inside it: the block is launched
     // without its k_graph_t
     defer_gu = h->E > 0 && !(flags & GNX_FLAG_DEFER_GRAPH_UPDATE) && core_post3_applies(rows, d, p->ff, true, s);
+    // (the FeedForward moves into the block kernel only together with the one-launch post kernel, which then skips the edge rows)
     rc = block_forward_impl(h, &b, ef, nf, gf, R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, defer_gu ? 1 : 3, p->ln1, p->eps,
-                            p->eps_mode, &fused_ln, nullptr, &blk_args);
+                            p->eps_mode, &fused_ln, nullptr, &blk_args, defer_gu ? &p->ff[0] : nullptr, &p->ln2[0], &edge_ff_done);
     if (rc) return rc;
     defer_gu = defer_gu && fused_ln;
   }
@@ -399,8 +407,9 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   float* hidden = reinterpret_cast<float*>(base + off[6]);
   if (all_narrow) {  // the three entities' FeedForward + residual in one launch when the width triple has the combined kernel
     const int n_rows = (int)(h->G == 1 ? (h->n_wtiles() + 3) / 4 : h->n_wtiles());  // partial-sum rows of the fused narrow block (gnx_narrow.hip)
-    rc = launch_core_post3(x, rows, d, p->ln2, p->ff, p->eps, p->eps_mode, out, s, defer_gu ? &blk_args : nullptr, n_rows);
+    rc = launch_core_post3(x, rows, d, p->ln2, p->ff, p->eps, p->eps_mode, out, s, defer_gu ? &blk_args : nullptr, n_rows, edge_ff_done);
     if (rc != 1) return rc;
+    if (edge_ff_done) return fail(GNX_ERR_INVALID_ARG, "internal: the edge FeedForward ran in the block kernel but the one-launch post kernel declined");
   }
   for (int t = 0; t < 3; ++t) {
     if (ffn_on_mfma(d[t]) && !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA))) {

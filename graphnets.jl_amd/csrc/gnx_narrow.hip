@@ -28,7 +28,7 @@ static int graph_update_threads(const gnx_graphs* h) {
   return rows <= 256 ? 64 : (rows >= 1024 ? 1024 : 256);
 }
 
-template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN, bool ONEG>
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN, bool ONEG, bool FFE = false>
 static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   constexpr int C = OE + ON;
   const int n_rows = partial_rows(h);
@@ -45,7 +45,7 @@ static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R,
       (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wave_dbg), &d_dbg, sizeof(d_dbg), 0, hipMemcpyHostToDevice, s);
     }
 #endif
-    GNX_LAUNCH((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, n_rows);
+    GNX_LAUNCH((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG, false, FFE>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, n_rows);
     GNX_HIP(hipGetLastError());
 #ifdef GNX_WAVE_STAMPS_BUILD
     if (dump) {
@@ -187,9 +187,20 @@ bool block_narrow_ready(const gnx_graphs* h, const BlockArgs& a, hipStream_t s) 
   return jit_get(a, ept, s, &fb, &fg) == GNX_OK;
 }
 
+// the edge FeedForward + residual of a narrow GNCore inside the block kernel (k_block_wave<..., FFE>): ahead-of-time widths, identity / relu
+// activations.  GNX_NO_FFE=1 (read per call: tests compare the two forms in one process) keeps the FeedForward in k_core_post3.
+bool block_narrow_ffe_applies(const gnx_graphs* h, const BlockArgs& a, int act1, int act2) {
+  return ln_aot(h, a) && a.ln_g[0] && act1 <= GNX_ACT_RELU && act2 <= GNX_ACT_RELU && a.act_e <= GNX_ACT_RELU && h->max_in_degree <= h->wtile_e_cap &&
+         !getenv("GNX_NO_FFE");  // (max_in_degree: every wave tile is ONE chunk of edges — the kernel runs the FeedForward once, at its end)
+}
+
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   if (a.n_wtiles == 0 || a.E == 0) return 1;
   if (wants_ln(a)) {  // only reached after block_narrow_ready(): a miss here would silently drop the LayerNorm
+    if (a.ffe_w1) {   // (set by gnx_core_forward only after block_narrow_ffe_applies())
+      if (!ln_aot(h, a)) return fail(GNX_ERR_INVALID_ARG, "internal: FeedForward-in-the-edge-lanes requested for a width set without that kernel");
+      return h->G == 1 ? launch_wave_g<10, 5, 3, 10, 5, 2, true, true, true>(h, a, R, s, phase) : launch_wave_g<10, 5, 3, 10, 5, 2, true, false, true>(h, a, R, s, phase);
+    }
     if (ln_aot(h, a)) return launch_wave_t<10, 5, 3, 10, 5, 2, true>(h, a, R, s, phase);
     const int32_t rc = launch_wave_jit(h, a, R, s, phase);
     return rc == 1 ? fail(GNX_ERR_INVALID_ARG, "internal: LayerNorm-on-load requested but the fused kernel is not available") : rc;

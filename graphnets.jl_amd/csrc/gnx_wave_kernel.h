@@ -246,6 +246,98 @@ struct PkStream {
   }
 };
 
+// out = x + block_out + W2 act(W1 gn2(x) + b1) + b2, TWO rows per thread held as register pairs: every FMA is one v_pk_fma_f32
+// whose src0 is the SGPR pair holding the weight (op_sel picks its low or high half for both rows) — half the VALU issue of scalar FMAs.
+// The hidden layer is produced and consumed in two halves of HB = 2D units; the weight stream of a half is [b1 half | D rows of W1
+// (2D consecutive hidden units of input k) | D row PAIRS of W2 (2D consecutive floats: hidden units 2g, 2g+1)], every group 2D floats
+// = 2D packed FMAs.  The 2(2D+1) groups are walked by a compile-time recursion (GI = global group index: half, position and
+// register set are constants of each step).  The FMAs are (non-volatile) asm statements too: left as C, the vectoriser packs them
+// itself — with the weight copied into a VGPR pair first — and collects them behind the loads of ALL groups (800 spilled SGPRs).
+#ifndef GNX_CORE_POST_UNITS
+#define GNX_CORE_POST_UNITS 1  // units of two rows per thread of the streamed FeedForward body (2 + the L2 touch loads: 39.6 vs 38.1 us, see below)
+#endif
+// TRANS = false: both activations are identity / relu (the reference's FeedForward) — the tanh / sigmoid / gelu expansions of a run-time
+// activation switch cost ~60 registers on every path, relu's included.
+template <int D, bool TRANS>
+struct CorePostStream {
+  static constexpr int H = 4 * D, HB = 2 * D, NG = 2 * D + 1, TOTAL = 2 * NG;
+  cfloatp W1, W2, b1;
+  int act1;
+  P2 (&z)[D];
+  P2 (&acc)[D];
+  P2 h[HB];
+  SGroup<HB> G0, G1;
+
+  template <int GI>
+  __device__ __forceinline__ cfloatp group_ptr() const {
+    constexpr int p = GI / NG, i = GI % NG;
+    if constexpr (i == 0) return b1 + p * HB;
+    else if constexpr (i <= D) return W1 + (i - 1) * H + p * HB;
+    else return W2 + (p * HB + 2 * (i - D - 1)) * D;
+  }
+  template <int GI>
+  __device__ __forceinline__ void consume(const SGroup<HB>& cur) {
+    constexpr int i = GI % NG;
+    if constexpr (i == 0) {
+#pragma unroll
+      for (int j = 0; j < HB; ++j) { const float b = cur.get(j); h[j].x = b; h[j].y = b; }
+      pin_pairs<HB>(h);
+    } else if constexpr (i <= D) {
+      constexpr int k = i - 1;
+#pragma unroll
+      for (int q = 0; q < HB / 2; ++q) {
+        const v2f_t w = cur.pair(q);
+        pk_fma_sw<false>(h[2 * q], w, z[k]);
+        pk_fma_sw<true>(h[2 * q + 1], w, z[k]);
+      }
+      if constexpr (i == D) {
+        if constexpr (TRANS) {
+          float t[HB];
+#pragma unroll
+          for (int j = 0; j < HB; ++j) t[j] = h[j].x;
+          act_row<HB>(t, act1);
+#pragma unroll
+          for (int j = 0; j < HB; ++j) { h[j].x = t[j]; t[j] = h[j].y; }
+          act_row<HB>(t, act1);
+#pragma unroll
+          for (int j = 0; j < HB; ++j) h[j].y = t[j];
+        } else if (act1 == 1) {
+#pragma unroll
+          for (int j = 0; j < HB; ++j) { h[j].x = fmaxf(h[j].x, 0.f); h[j].y = fmaxf(h[j].y, 0.f); }
+        }
+      }
+      pin_pairs<HB>(h);
+    } else {
+      constexpr int j = 2 * (i - D - 1);
+#pragma unroll
+      for (int q = 0; q < D; ++q) {  // pair q = weights 2q, 2q+1 of [W2 row j | W2 row j+1]
+        const v2f_t w = cur.pair(q);
+        pk_fma_sw<false>(acc[(2 * q) % D], w, h[j + (2 * q) / D]);
+        pk_fma_sw<true>(acc[(2 * q + 1) % D], w, h[j + (2 * q + 1) / D]);
+      }
+      pin_pairs<D>(acc);
+    }
+  }
+  template <int GI>
+  __device__ __forceinline__ void run() {
+    if constexpr (GI < TOTAL) {
+      if constexpr (GI % 2 == 0) {
+        G0.wait();
+        if constexpr (GI + 1 < TOTAL) G1.issue(group_ptr<GI + 1>());
+        __builtin_amdgcn_sched_barrier(0);
+        consume<GI>(G0);
+      } else {
+        G1.wait();
+        if constexpr (GI + 1 < TOTAL) G0.issue(group_ptr<GI + 1>());
+        __builtin_amdgcn_sched_barrier(0);
+        consume<GI>(G1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      run<GI + 1>();
+    }
+  }
+};
+
 // xhat = (x - mu) * rstd over the D registers of a row; eps_mode 0: 1/(sigma+eps) (Flux 0.14 normalise), 1: 1/sqrt(var+eps)
 template <int D>
 __device__ __forceinline__ void normalise(float (&x)[D], float eps, int eps_mode) {
@@ -515,9 +607,19 @@ static __device__ unsigned long long* g_wave_dbg = nullptr;  // [n_wtiles][8], s
 // of graph_update_rows for <= 8 rows, ((a0+a1)+(a2+a3))+((a4+a5)+(a6+a7)) — and runs the graph function: no partial rows in HBM, no
 // second launch, bit-identical gf'.
 constexpr int kPackThreads = 512;
-template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false, bool PACK = false>
+// FFE (narrow GNCore; needs LN, DE == OE, two edges per lane on the streamed-weights path, identity / relu activations, and a batch without
+// a node of more than 64 * EPT in-edges: the launcher checks): the edge lanes also run the core's edge FeedForward and add both residual
+// terms — ef_out receives y = (x + ef') + FF(gn2(x)) (gncore.jl:56-59) instead of ef', so block_out and the second read of x never touch HBM
+// for edges (the two-kernel form moved 120 MB per core for them on the 1M-edge graph).  Register budget (126, four waves per SIMD as
+// before): the FeedForward runs LAST, when nothing of the node phase is live (as a phase of the edge loop: 187 registers); the raw rows
+// wait in the lane's own, still unused ef' slots of the wave's LDS slice while the edge product runs (kept in registers: 134) and ef' is
+// read back from those slots at the end.  gn2 shares x-hat with gn1 (normalise() of the same row: the same bits); the association is
+// k_core_post_s's — (x + ef') + (b2 + W2 h) — so the result is BIT-IDENTICAL to the two-kernel form (tests/test_gpu_core.py).
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false, bool PACK = false, bool FFE = false>
 __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_SGPRS))) void k_block_wave(BlockArgs a, int n_rows) {
   static_assert(!(PACK && ONEG), "packs are for batches of several graphs");
+  static_assert(!FFE || (LN && DE == OE && DE > 0 && EPT == 2 && (DE + DN) * OE > 96 && ((DE + DN) * OE) % 2 == 0 && GNX_WAVE_PK && !PACK),
+                "FFE: a core's block (dims => dims) with LayerNorm on load, two edges per lane, streamed weights");
   constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1, DG1 = DG > 0 ? DG : 1;
   constexpr int TEW = 64 * EPT;
   constexpr int C = OE + ON, C1 = C > 0 ? C : 1;
@@ -548,6 +650,13 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
   GNX_WSTAMP(0);
   if constexpr (!ONEG && !PACK) { if (!active) return; }
   float mine = 0.f;  // lane c < C: this wave's total of graph-update column c
+  // FFE: the raw edge rows and ef' of the lane's two edges, kept until the end of the kernel (the FeedForward runs LAST, when nothing of
+  // the node phase is live any more: 100 of its ~125 registers are its own)
+  float xr[FFE ? EPT : 1][FFE ? DE1 : 1];
+  bool ffv[EPT];
+  size_t ff_row0 = 0;
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) ffv[i] = false;
   do {
   if constexpr (ONEG || PACK) { if (!active) break; }
   float* s_out = s_mem + wv * WSL;                                        // ef' of the wave's tile
@@ -649,6 +758,10 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
           src[i] = a.rowval[e];
           load_row<DN>(nf + (size_t)src[i] * DN, xs[i]);
         }
+        if constexpr (FFE) {
+#pragma unroll
+          for (int k = 0; k < DE; ++k) xr[i][k] = x[i][k];
+        }
         if constexpr (LN) {
           ln_row<DE>(x[i], a.ln_g[0], a.ln_b[0], a.ln_eps, a.ln_mode);
           ln_row<DN>(xs[i], a.ln_g[1], a.ln_b[1], a.ln_eps, a.ln_mode);
@@ -659,6 +772,10 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
       if (c0 == 0) {
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
+          if constexpr (FFE) {
+#pragma unroll
+            for (int k = 0; k < DE; ++k) xr[i][k] = x[i][k];
+          }
           ln_row<DE>(x[i], a.ln_g[0], a.ln_b[0], a.ln_eps, a.ln_mode);
           ln_row<DN>(xs[i], a.ln_g[1], a.ln_b[1], a.ln_eps, a.ln_mode);
         }
@@ -684,6 +801,13 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
         P2 accp[OE1], xp[KE];
         PkStream<KE * OE, OE, KE, GNX_PK_GS> st{We, xp, accp};
         st.template issue<0>();
+        if constexpr (FFE) {  // the raw rows wait in the (still unused) ef' slots of the lane's own two edges while the product runs
+#pragma unroll
+          for (int m = 0; m < EPT; ++m)
+#pragma unroll
+            for (int k = 0; k < DE; ++k) s_out[(lane + 64 * m) * OE + k] = xr[m][k];
+          asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int j = 0; j < OE; ++j) { accp[j].x = acc[0][j]; accp[j].y = acc[1][j]; }
 #pragma unroll
@@ -695,6 +819,14 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
         st.template run<0>();
 #pragma unroll
         for (int j = 0; j < OE; ++j) { acc[0][j] = accp[j].x; acc[1][j] = accp[j].y; }
+        if constexpr (FFE) {
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int m = 0; m < EPT; ++m)
+#pragma unroll
+            for (int k = 0; k < DE; ++k) xr[m][k] = s_out[(lane + 64 * m) * OE + k];
+          asm volatile("" ::: "memory");
+        }
       } else {
         fma_rows<DE, OE, EPT, DE1>(We, x, acc);
         fma_rows<DN, OE, EPT, DN1>(We + DE * OE, xs, acc);
@@ -702,17 +834,30 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
 #pragma unroll
       for (int i = 0; i < EPT; ++i) {
         const int el = lane + 64 * i;
-        act_row<OE1>(acc[i], a.act_e);
+        if constexpr (FFE) {  // (identity / relu only: the transcendental expansions of the run-time switch cost registers on every path)
+          if (a.act_e == 1) {
+#pragma unroll
+            for (int j = 0; j < OE; ++j) acc[i][j] = fmaxf(acc[i][j], 0.f);
+          }
+        } else {
+          act_row<OE1>(acc[i], a.act_e);
+        }
         if (valid[i]) {
-          store_row<OE>(a.ef_out + (r * (size_t)a.E + e0 + c0 + el) * OE, acc[i]);
-          if (nn > 1) {
+          if constexpr (!FFE) store_row<OE>(a.ef_out + (r * (size_t)a.E + e0 + c0 + el) * OE, acc[i]);
+          if (nn > 1 || FFE) {
 #pragma unroll
             for (int j = 0; j < OE; ++j) s_out[el * OE + j] = acc[i][j];
-          } else {
+          }
+          if (nn == 1) {
 #pragma unroll
             for (int j = 0; j < OE; ++j) psum[j] += acc[i][j];
           }
         }
+      }
+      if constexpr (FFE) {  // (the host launches this form only for batches without a node of more than 64 * EPT in-edges: one chunk per tile)
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) ffv[m] = valid[m];
+        ff_row0 = r * (size_t)a.E + e0 + c0 + lane;
       }
     } else
     if constexpr (OE > 0) {
@@ -850,6 +995,44 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
         }
       } else {
         store_partial_row<C>(mine, pbase + (size_t)wt * CP, lane);
+      }
+    }
+  }
+  if constexpr (FFE) {
+    if (active) {
+      // y = (x + ef') + (b2 + W2 act1(W1 gn2(x) + b1)) for the lane's two edges: k_core_post_s's body, fed from registers
+      P2 z[DE1], acc2[DE1];
+      CorePostStream<DE1, false> fs{as_const(a.ffe_w1), as_const(a.ffe_w2), as_const(a.ffe_b1 ? a.ffe_b1 : k_zero_bias), a.ffe_act1, z, acc2};
+      fs.G0.issue(fs.template group_ptr<0>());
+      const cfloatp b2 = as_const(a.ffe_b2 ? a.ffe_b2 : k_zero_bias), g2 = as_const(a.ffe_g2), be2 = as_const(a.ffe_be2);
+      float rs[EPT][DE1];
+      const float* s_ef = s_mem + wv * WSL;  // ef' of the lane's two edges, still in the wave's slice
+#pragma unroll
+      for (int m = 0; m < EPT; ++m) {
+#pragma unroll
+        for (int k = 0; k < DE; ++k) rs[m][k] = xr[m][k] + s_ef[(lane + 64 * m) * OE + k];  // the two residual terms (gncore.jl:56-59)
+        normalise<DE1>(xr[m], a.ln_eps, a.ln_mode);
+#pragma unroll
+        for (int k = 0; k < DE; ++k) {
+          const float v = fmaf(g2[k], xr[m][k], be2[k]);
+          if (m == 0) { z[k].x = v; acc2[k].x = b2[k]; } else { z[k].y = v; acc2[k].y = b2[k]; }
+        }
+      }
+      pin_pairs<DE1>(z);
+      pin_pairs<DE1>(acc2);
+      fs.template run<0>();
+#pragma unroll
+      for (int m = 0; m < EPT; ++m) {
+        float o[DE1];
+#pragma unroll
+        for (int k = 0; k < DE; ++k) o[k] = m == 0 ? acc2[k].x : acc2[k].y;
+        if (a.ffe_act2 == 1) {
+#pragma unroll
+          for (int k = 0; k < DE; ++k) o[k] = fmaxf(o[k], 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < DE; ++k) o[k] = rs[m][k] + o[k];
+        if (ffv[m]) store_row<OE>(a.ef_out + (ff_row0 + 64 * m) * OE, o);
       }
     }
   }

@@ -334,3 +334,63 @@ def test_narrow_core_one_launch_feedforward_with_replicas(gn, dims):
     gn.profile_enable(False)
     prof = gn.profile_read(); gn.profile_reset()
     assert prof["k_core_post"]["launches"] == 1 and "k_graph_t" not in prof, prof
+
+
+@pytest.mark.parametrize("hetero,eps_mode,R", [(False, 0, 1), (True, 1, 1), (False, 0, 2)], ids=["one-graph", "many-graphs-eps1", "replicas"])
+def test_narrow_core_edge_feedforward_in_the_block_kernel_is_bit_identical(gn, hetero, eps_mode, R):
+    """README ex.3's core widths (10,5,3): the edge FeedForward and both residual terms run in k_block_wave's edge lanes
+    (k_block_wave<..., FFE>: block_out and the second read of x never exist in HBM for edges; the post kernel keeps nodes and graphs).
+    Same arithmetic in the same association as the two-kernel form (GNX_NO_FFE=1, read per call) — every output BIT-identical — and
+    within the oracle's bound; relu / identity FeedForward activations; a batch with a hub node (in-degree > 128) keeps the two-kernel form."""
+    import os
+    rng = np.random.default_rng(1200 + eps_mode + R)
+    dims = (10, 5, 3)
+    if hetero:
+        sizes = rng.integers(150, 400, 300)
+        cs = [U.er_csc(rng, int(n), 3 * int(n)) for n in sizes]
+        cps, rvs, nn = [c[0] for c in cs], [c[1] for c in cs], [int(n) for n in sizes]
+    else:
+        n = 70_000 if R == 1 else 40_000
+        cp, rv = U.er_csc(rng, n, 2 * n + 10_000)
+        cps, rvs, nn = [cp], [rv], [n]
+    g = gn.GNGraphBatch.from_csc(cps, rvs, nn)
+    assert g.max_in_degree <= 128
+    p = O.make_core_params(rng, dims, eps_mode=eps_mode)
+    core = U.core_from_params(gn, p)
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, g.n_graphs, dims)
+    ef = ef + 2.0
+    x = U.to_nt(gn, g, ef, nf, gf)
+    y = core(x)
+    os.environ["GNX_NO_FFE"] = "1"
+    try:
+        y0 = core(x)
+    finally:
+        del os.environ["GNX_NO_FFE"]
+    for name, a, b in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), (y0.ef, y0.nf, y0.gf)):
+        assert np.array_equal(U.from_jl(a), U.from_jl(b)), f"{name}: FeedForward in the edge lanes differs from the two-kernel form"
+    ref, scale = O.core_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r, s, name)
+
+
+def test_narrow_core_with_a_hub_node_keeps_the_two_kernel_form(gn):
+    """a node with more than 128 in-edges is a multi-chunk wave tile: the FeedForward-in-the-edge-lanes kernel is not used (it runs the
+    FeedForward once, at its end) and the result still equals the oracle"""
+    rng = np.random.default_rng(1300)
+    n = 70_000
+    cp, rv = U.er_csc(rng, n, 150_000)
+    # rebuild with a hub: node 7 receives an edge from each of the first 400 nodes
+    dst = np.repeat(np.arange(n), np.diff(cp))
+    keys = np.unique(np.concatenate([dst * n + rv, 7 * n + np.arange(400)]))
+    cp2 = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(cp2, keys // n + 1, 1)
+    g = gn.GNGraphBatch.from_csc([np.cumsum(cp2)], [(keys % n).astype(np.int64)], [n])
+    assert g.max_in_degree > 128
+    dims = (10, 5, 3)
+    p = O.make_core_params(rng, dims)
+    core = U.core_from_params(gn, p)
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, 1, dims)
+    y = core(U.to_nt(gn, g, ef, nf, gf))
+    ref, scale = O.core_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r, s, name)

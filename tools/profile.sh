@@ -27,4 +27,6 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MF
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d "$OUT/pmc_mix" -- $BENCH > "$OUT/pmc_mix.log" 2>&1
 fi
 python3 $REPO/tools/summarize_prof.py "$OUT" "$OUT/summary" ${GNX_PROF_DIMS:+--dims $GNX_PROF_DIMS} > "$OUT/summary.txt" 2>&1
+# the raw traces are tens of MB per pass (bench.py's clock warm-up alone is thousands of launches): summaries stay, traces go
+find "$OUT" -name "*_kernel_trace.csv" -delete; find "$OUT" -name "*_counter_collection.csv" -delete; find "$OUT" -name "*_agent_info.csv" -delete
 tail -60 "$OUT/summary.txt"

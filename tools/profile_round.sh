@@ -21,6 +21,7 @@ for M in c4 c4_10-5-3; do
    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1)
   python3 tools/summarize_prof.py $OUT $OUT/summary --model-traffic $M > $OUT/summary.txt 2>&1
+  find "$OUT" -name "*_kernel_trace.csv" -delete; find "$OUT" -name "*_counter_collection.csv" -delete; find "$OUT" -name "*_agent_info.csv" -delete
 done
 for t in readme hetero512 hetero4096 hetero4096_8M core c4 c4_10-5-3; do echo "== $t"; head -12 gpurun_out/prof_${R}_$t/summary_kernel_stats.csv; done
 ls gpurun_out/prof_${R}_readme/ profiles/ | head -40
