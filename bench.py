@@ -456,7 +456,7 @@ def collect_secondary(args):
         ts = roof.get("traffic_source")
         if ts:
             entry["roofline"]["traffic_source"] = {k: ts.get(k) for k in ("file", "commit", "stale") if ts.get(k) is not None}
-        for k in ("batch_ms", "kernel_us_one_forward", "pipelined_two_streams", "c_abi_ms_per_step", "c_abi", "n_gpus"):
+        for k in ("batch_ms", "kernel_us_one_forward", "pipelined_two_streams", "chained_graph_update", "c_abi_ms_per_step", "c_abi", "n_gpus"):
             if k in line or k in line.get("config", {}):
                 entry[k] = line.get(k, line.get("config", {}).get(k))
         out[key] = entry
@@ -727,6 +727,7 @@ def main():
 
     extra = {}
     pipelined = None
+    chained = None
     if not multi:
         def capture(nsteps, rotate):
             cg = torch.cuda.CUDAGraph()
@@ -772,6 +773,27 @@ def main():
             pipelined = {"ms_per_step": round(dt2 / Kp * 1e3, 6), "value": round(E / (dt2 / Kp), 1), "unit": "edges/s", "steps": Kp,
                          "what": f"{Kp} steps of the same kind as two hipGraphs (even / odd steps) on two streams: independent batches pipelined; results bit-identical; not the headline"}
             del halves
+        # NOT the headline either: the chained form (gnx_block_forward_chained) — step i's launch carries step i - 1's graph update in
+        # workgroups at its front, so a loop over batches is ONE launch per step (opt-in: gf' of a step is complete one call later or after
+        # the flush).  Bit-identical outputs (tests/test_gpu_block.py::test_chained_forward...).
+        if not args.overlap and og > 0:
+            def capture_chained():
+                cgc = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cgc):
+                    pend = None
+                    for i in range(K):
+                        b = sets[i % nsets]
+                        pend = plan.chained(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"], prev=pend)
+                    plan.flush(pend)
+                return cgc, pend
+            cgc, last = capture_chained()
+            cgc.replay(); torch.cuda.synchronize(dev)
+            spin_up(torch, dev, cgc.replay, 50.0)
+            dtc = sorted(timed(cgc.replay) for _ in range(3))[1]
+            chained = {"ms_per_step": round(dtc / K * 1e3, 6), "value": round(E / (dtc / K), 1), "unit": "edges/s", "steps": K,
+                       "what": f"gnx_block_forward_chained: {K} steps + one flush in one hipGraph — every step ONE launch (the previous step's graph update rides in "
+                               "workgroups at the front of the next block kernel); opt-in for loops over batches, results bit-identical; not the headline"}
+            del cgc
     else:
         assert gf_stack.shape[1] == G or world > 1, "one rank: every graph is local"
         cgs = []
@@ -930,6 +952,8 @@ def main():
                 line["c_abi_ms_per_step"], line["c_abi"] = None, c_abi
         if pipelined is not None:
             line["pipelined_two_streams"] = pipelined
+        if chained is not None:
+            line["chained_graph_update"] = chained
         if secondary is not None:
             line["secondary"] = secondary
         if dense is not None:

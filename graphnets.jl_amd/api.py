@@ -1051,6 +1051,24 @@ class BlockPlan:
         check(self.lib.gnx_block_forward(self.g._h, C.byref(self.p), _ptr(ef), _ptr(nf), _ptr(gf), self.R, _ptr(eo), _ptr(no),
                                          _ptr(go), ws.data_ptr(), ws.numel(), flags, s))
 
+    def chained(self, ef, nf, gf, eo, no, go, ws, prev=None, stream=None):
+        """`gnx_block_forward_chained`: this call's edge + node update with the graph update of the PREVIOUS chained call (`prev`: the
+        record that call returned, or None) at the front of the same launch.  Returns this call's pending record; `go` is valid after
+        the next chained call on the stream or `flush(pending)`.  `ws` / `go` must differ from the pending call's."""
+        s = torch.cuda.current_stream(self.g.device).cuda_stream if stream is None else stream
+        pending = _lib.PendingUpdate()
+        check(self.lib.gnx_block_forward_chained(self.g._h, C.byref(self.p), _ptr(ef), _ptr(nf), _ptr(gf), self.R, _ptr(eo), _ptr(no), _ptr(go),
+                                                 ws.data_ptr(), ws.numel(), self.flags, s, C.byref(prev) if prev is not None else None, C.byref(pending)))
+        return pending
+
+    def flush(self, pending, stream=None):
+        """finishes a pending graph update (one plain `gnx_block_graph_update` launch); no-op when nothing is pending"""
+        if pending is None or not pending.workspace:
+            return
+        s = torch.cuda.current_stream(self.g.device).cuda_stream if stream is None else stream
+        check(self.lib.gnx_block_graph_update(self.g._h, C.byref(self.p), pending.gf, self.R, pending.gf_out, pending.workspace, pending.workspace_bytes,
+                                              self.flags, s))
+
     def new_workspace(self):
         """A further workspace (one per buffer set when steps on different sets may overlap)."""
         return torch.empty_like(self.ws)

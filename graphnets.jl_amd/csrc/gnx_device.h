@@ -61,6 +61,12 @@ struct BlockArgs {
   // x-hat with gn1 (ln_eps / ln_mode above).  ffe_w1 == nullptr <=> off.
   const float *ffe_w1, *ffe_b1, *ffe_w2, *ffe_b2, *ffe_g2, *ffe_be2;
   int ffe_act1, ffe_act2;
+  // chained calls (gnx_block_forward_chained; k_block_wave<..., CHAIN>): the first prev_blocks workgroups of the launch finish the graph
+  // update of the PREVIOUS call on this handle — its partial rows, its gf, its gf_out — with this call's graph function
+  const float* prev_partials;
+  const float* prev_gf;
+  float* prev_gf_out;
+  int prev_blocks;
 };
 
 // activation codes = GNX_ACT_* of include/gnx.h (static_assert'ed in gnx_forward.hip)

@@ -29,6 +29,8 @@ int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, 
 void warm_block_narrow(const gnx_graphs* h, const gnx_block_params* p);
 bool block_narrow_ready(const gnx_graphs* h, const BlockArgs& a, hipStream_t s);
 bool block_narrow_ffe_applies(const gnx_graphs* h, const BlockArgs& a, int act1, int act2);
+bool block_narrow_chain_applies(const gnx_graphs* h, const BlockArgs& a);
+int32_t launch_block_narrow_chained(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s);
 static_assert(GNX_ACT_IDENTITY == 0 && GNX_ACT_RELU == 1 && GNX_ACT_TANH == 2 && GNX_ACT_SIGMOID == 3 && GNX_ACT_GELU == 4,
               "act_apply (gnx_device.h) hard-codes the activation codes");
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase);
@@ -96,7 +98,8 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
                                   const float* gf, int64_t R, float* ef_out, float* nf_out, float* gf_out, void* ws,
                                   size_t ws_bytes, uint32_t flags, hipStream_t s, int phase = 3, const gnx_layernorm* ln1 = nullptr,
                                   float ln_eps = 0.f, int ln_mode = 0, bool* fused_ln = nullptr, const float* const* wide_ln_stats = nullptr,
-                                  BlockArgs* args_out = nullptr, const gnx_ffn* ffe = nullptr, const gnx_layernorm* ffe_ln2 = nullptr, bool* ffe_took = nullptr) {
+                                  BlockArgs* args_out = nullptr, const gnx_ffn* ffe = nullptr, const gnx_layernorm* ffe_ln2 = nullptr, bool* ffe_took = nullptr,
+                                  const gnx_pending_update* chain_prev = nullptr, bool* chain_took = nullptr) {
   int32_t rc = check_block(h, p, R);
   if (rc) return rc;
   if (phase & 1) {
@@ -154,6 +157,15 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
     if (args_out) *args_out = a;
     return launch_block_narrow(h, a, R, s, phase);
   }
+  if (chain_took) {  // gnx_block_forward_chained: this call's edge + node update with the previous call's graph update at the front of the launch
+    *chain_took = !(flags & (GNX_FLAG_FORCE_GENERIC)) && block_narrow_chain_applies(h, a);
+    if (!*chain_took) return GNX_OK;  // nothing launched: the caller runs the plain form
+    if (chain_prev && chain_prev->workspace) {
+      a.prev_partials = reinterpret_cast<const float*>(static_cast<const char*>(chain_prev->workspace) + w.part_off);
+      a.prev_gf = chain_prev->gf; a.prev_gf_out = chain_prev->gf_out;
+    }
+    return launch_block_narrow_chained(h, a, R, s);
+  }
   if (!(flags & GNX_FLAG_FORCE_GENERIC)) {
     rc = launch_block_narrow(h, a, R, s, phase);  // fused wave-per-tile kernel: ahead-of-time width sets, else specialised at run time
     if (rc != 1) return rc;
@@ -187,6 +199,31 @@ int32_t gnx_block_forward(const gnx_graphs* h, const gnx_block_params* p, const 
                           void* stream) {
   return block_forward_impl(h, p, ef, nf, gf, R, ef_out, nf_out, gf_out, ws, ws_bytes, flags, (hipStream_t)stream,
                             (flags & GNX_FLAG_DEFER_GRAPH_UPDATE) ? 1 : 3);
+}
+
+int32_t gnx_block_forward_chained(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf, const float* gf, int64_t R, float* ef_out,
+                                  float* nf_out, float* gf_out, void* ws, size_t ws_bytes, uint32_t flags, void* stream, const gnx_pending_update* prev,
+                                  gnx_pending_update* pending) {
+  if (!pending) return fail(GNX_ERR_INVALID_ARG, "pending is NULL");
+  if (flags & GNX_FLAG_DEFER_GRAPH_UPDATE) return fail(GNX_ERR_INVALID_ARG, "gnx_block_forward_chained defers the graph update itself");
+  if (prev && prev->workspace && (prev->workspace == ws || (p && p->og > 0 && prev->gf_out == gf_out)))
+    return fail(GNX_ERR_INVALID_ARG, "the pending call's workspace / gf_out must not be this call's (its graph update has not run yet)");
+  bool took = false;
+  int32_t rc = block_forward_impl(h, p, ef, nf, gf, R, ef_out, nf_out, gf_out, ws, ws_bytes, flags, (hipStream_t)stream, 1, nullptr, 0.f, 0, nullptr, nullptr, nullptr,
+                                  nullptr, nullptr, nullptr, prev, &took);
+  if (rc) return rc;
+  if (took) {  // prev's graph update rode in this launch; this call's is pending
+    pending->workspace = ws; pending->workspace_bytes = ws_bytes; pending->gf = gf; pending->gf_out = gf_out;
+    return GNX_OK;
+  }
+  // not the two-launch narrow form (matrix-core / generic kernels, run-time specialised widths, batches of small graphs whose graph update
+  // already runs inside the block kernel): finish the previous call the plain way, run this call whole, nothing stays pending
+  if (prev && prev->workspace) {
+    rc = gnx_block_graph_update(h, p, prev->gf, R, prev->gf_out, const_cast<void*>(prev->workspace), prev->workspace_bytes, flags, stream);
+    if (rc) return rc;
+  }
+  pending->workspace = nullptr; pending->workspace_bytes = 0; pending->gf = nullptr; pending->gf_out = nullptr;
+  return block_forward_impl(h, p, ef, nf, gf, R, ef_out, nf_out, gf_out, ws, ws_bytes, flags, (hipStream_t)stream, 3);
 }
 
 int32_t gnx_block_graph_update(const gnx_graphs* h, const gnx_block_params* p, const float* gf, int64_t R, float* gf_out, void* ws,

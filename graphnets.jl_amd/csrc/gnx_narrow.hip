@@ -28,11 +28,11 @@ static int graph_update_threads(const gnx_graphs* h) {
   return rows <= 256 ? 64 : (rows >= 1024 ? 1024 : 256);
 }
 
-template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN, bool ONEG, bool FFE = false>
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN, bool ONEG, bool FFE = false, bool CHAIN = false>
 static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   constexpr int C = OE + ON;
   const int n_rows = partial_rows(h);
-  const unsigned grid = (unsigned)((a.n_wtiles + 3) / 4);
+  const unsigned grid = (unsigned)((a.n_wtiles + 3) / 4) + (CHAIN ? (unsigned)a.prev_blocks : 0u);
   if (phase & 1) {
     ProfScope ps("k_block_wave", s);
 #ifdef GNX_WAVE_STAMPS_BUILD  // diagnostic build: GNX_WAVE_STAMPS_DUMP=<file> writes [wave tile][8] shader-clock stamps of every (eager) launch
@@ -45,7 +45,7 @@ static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R,
       (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wave_dbg), &d_dbg, sizeof(d_dbg), 0, hipMemcpyHostToDevice, s);
     }
 #endif
-    GNX_LAUNCH((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG, false, FFE>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, n_rows);
+    GNX_LAUNCH((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG, false, FFE, CHAIN>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, n_rows);
     GNX_HIP(hipGetLastError());
 #ifdef GNX_WAVE_STAMPS_BUILD
     if (dump) {
@@ -185,6 +185,39 @@ bool block_narrow_ready(const gnx_graphs* h, const BlockArgs& a, hipStream_t s) 
   if (ept * 64 != h->wtile_e_cap || (ept != 1 && ept != 2 && ept != 4)) return false;
   hipFunction_t fb, fg;
   return jit_get(a, ept, s, &fb, &fg) == GNX_OK;
+}
+
+// gnx_block_forward_chained: can the previous call's graph update ride at the front of this call's block kernel?  The two-launch form of
+// an ahead-of-time width set at the default wave-tile size, graph function small enough for the kernel's LDS, <= 256 partial rows per
+// graph (one wavefront per graph) or one graph.  (Batches that take the pack form run their graph update inside the kernel already.)
+static bool pack_form(const gnx_graphs* h, const BlockArgs& a) { return h->G > 1 && h->n_packs > 0 && a.packs && a.og > 0 && !getenv("GNX_NO_PACK"); }
+bool block_narrow_chain_applies(const gnx_graphs* h, const BlockArgs& a) {
+  if (a.n_wtiles == 0 || a.E == 0 || a.og <= 0 || h->wtile_e_cap != 128 || wants_ln(a) || a.ffe_w1 || pack_form(h, a)) return false;
+  const int C = a.oe + a.on;
+  if (C <= 0) return false;
+  const int wsl = wave_slice_floats(a.oe, 2);
+  if (h->G == 1) { if (graph_update_lds_floats(C, a.dg, a.og, kThreads) > 4 * wsl) return false; }
+  else if (h->max_wtiles_per_graph > 256 || graph_update_lds_floats(C, a.dg, a.og, 64) > wsl) return false;
+#define GNX_CASE(DE, DN, DG, OE, ON) \
+  if (a.de == DE && a.dn == DN && a.dg == DG && a.oe == OE && a.on == ON) return true;
+  GNX_NARROW_DIMS(GNX_CASE)
+#undef GNX_CASE
+  return false;
+}
+// the edge + node update of THIS call with a.prev_* (the previous call's pending graph update) at the front of the same launch
+int32_t launch_block_narrow_chained(const gnx_graphs* h, const BlockArgs& a0, int64_t R, hipStream_t s) {
+  BlockArgs a = a0;
+  a.prev_blocks = a.prev_partials ? (h->G == 1 ? 1 : (int)((h->G + 3) / 4)) : 0;
+#define GNX_CASE(DE, DN, DG, OE, ON)                                                                                               \
+  if (a.de == DE && a.dn == DN && a.dg == DG && a.oe == OE && a.on == ON) {                                                         \
+    if constexpr (OE + ON > 0) {                                                                                                   \
+      return h->G == 1 ? launch_wave_g<DE, DN, DG, OE, ON, 2, false, true, false, true>(h, a, R, s, 1)                              \
+                       : launch_wave_g<DE, DN, DG, OE, ON, 2, false, false, false, true>(h, a, R, s, 1);                            \
+    }                                                                                                                              \
+  }
+  GNX_NARROW_DIMS(GNX_CASE)
+#undef GNX_CASE
+  return fail(GNX_ERR_INVALID_ARG, "internal: chained launch for a width set without that kernel");
 }
 
 // the edge FeedForward + residual of a narrow GNCore inside the block kernel (k_block_wave<..., FFE>): ahead-of-time widths, identity / relu

@@ -615,9 +615,14 @@ constexpr int kPackThreads = 512;
 // wait in the lane's own, still unused ef' slots of the wave's LDS slice while the edge product runs (kept in registers: 134) and ef' is
 // read back from those slots at the end.  gn2 shares x-hat with gn1 (normalise() of the same row: the same bits); the association is
 // k_core_post_s's — (x + ef') + (b2 + W2 h) — so the result is BIT-IDENTICAL to the two-kernel form (tests/test_gpu_core.py).
-template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false, bool PACK = false, bool FFE = false>
+// CHAIN (gnx_block_forward_chained): the first a.prev_blocks workgroups of the launch — dispatched first, so they run beside the tiles — finish
+// the graph update of the PREVIOUS call (graph_update_rows over ITS partial rows: one workgroup for a one-graph batch, one wavefront per
+// graph otherwise), the rest are this call's tiles.  In a loop over batches the second launch of every step disappears (an empty launch is
+// ~4 us of a ~25-us step).  A template parameter: the plain kernel keeps its registers (58 at README widths) and has no barrier.
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false, bool PACK = false, bool FFE = false, bool CHAIN = false>
 __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_SGPRS))) void k_block_wave(BlockArgs a, int n_rows) {
   static_assert(!(PACK && ONEG), "packs are for batches of several graphs");
+  static_assert(!CHAIN || (!PACK && !FFE && !LN && OE + ON > 0), "CHAIN: the two-launch form of a plain block");
   static_assert(!FFE || (LN && DE == OE && DE > 0 && EPT == 2 && (DE + DN) * OE > 96 && ((DE + DN) * OE) % 2 == 0 && GNX_WAVE_PK && !PACK),
                 "FFE: a core's block (dims => dims) with LayerNorm on load, two edges per lane, streamed weights");
   constexpr int OE1 = OE > 0 ? OE : 1, ON1 = ON > 0 ? ON : 1, DE1 = DE > 0 ? DE : 1, DN1 = DN > 0 ? DN : 1, DG1 = DG > 0 ? DG : 1;
@@ -630,12 +635,30 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   typedef const int __attribute__((address_space(4))) * cintp;
+  int bx = blockIdx.x, gx = gridDim.x;  // this call's tiles are the blocks behind the chained ones
+  if constexpr (CHAIN) {
+    if ((int)blockIdx.x < a.prev_blocks) {
+      if (a.og > 0) {
+        constexpr int CPc = (C + 3) / 4 * 4;
+        a.gf = a.prev_gf; a.gf_out = a.prev_gf_out;  // (this workgroup returns below: the kernel's own copy of the arguments is its to change)
+        const float* pbase = a.prev_partials + blockIdx.y * (size_t)n_rows * CPc;
+        if constexpr (ONEG) {
+          graph_update_rows<C, false, 4>(a, pbase, 0, blockIdx.y, 0, (a.n_wtiles + 3) / 4, (int)threadIdx.x, kThreads, s_mem);
+        } else {
+          const int g = (int)blockIdx.x * WAVES + wv;  // one wavefront per graph (the launcher chains only while a graph has <= 256 rows)
+          if (g < a.G) graph_update_rows<C, true, 4>(a, pbase, g, blockIdx.y, a.wtile_off[g], a.wtile_off[g + 1], lane, 64, s_mem + wv * WSL);
+        }
+      }
+      return;
+    }
+    bx -= a.prev_blocks; gx -= a.prev_blocks;
+  }
   int wt;
   if constexpr (PACK) {  // the wave's tile from the pack table (-1: an empty slot of the pack)
-    const cintp pk = reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.packs)) + (size_t)xcd_tile(blockIdx.x, gridDim.x) * WAVES;
+    const cintp pk = reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.packs)) + (size_t)xcd_tile(bx, gx) * WAVES;
     wt = pk[wv];
   } else {
-    wt = __builtin_amdgcn_readfirstlane(xcd_tile(blockIdx.x, gridDim.x) * WAVES + wv);
+    wt = __builtin_amdgcn_readfirstlane(xcd_tile(bx, gx) * WAVES + wv);
   }
   // ONEG (one graph): the four waves of a workgroup all belong to it, so their graph-update partial sums are added in the
   // workgroup (one barrier at the very end) and the graph update reads a quarter of the rows.  Several graphs: a workgroup may
@@ -667,7 +690,7 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
   const int n0 = tw[0], n1 = tw[1], e0 = tw[2], e1 = tw[3], g = tw[4];  // s_load_dwordx8
   if constexpr (PACK) {
     tile_g = g; tile_cnt = tw[7];
-    const cintp pk = reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.packs)) + (size_t)xcd_tile(blockIdx.x, gridDim.x) * WAVES;
+    const cintp pk = reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.packs)) + (size_t)xcd_tile(bx, gx) * WAVES;
     const int wprev = wv > 0 ? pk[wv > 0 ? wv - 1 : 0] : -1;  // (a graph's first tile never follows an empty slot: slots fill from the left)
     owner = wprev < 0 || (reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.wtiles)) + (size_t)wprev * (sizeof(Tile) / sizeof(int)))[4] != g;
   }
@@ -991,7 +1014,7 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
         if (wv == 0) {
           float tot = 0.f;
           if (lane < C) tot = (s_blk[0][lane] + s_blk[1][lane]) + (s_blk[2][lane] + s_blk[3][lane]);
-          store_partial_row<C>(tot, pbase + (size_t)xcd_tile(blockIdx.x, gridDim.x) * CP, lane);
+          store_partial_row<C>(tot, pbase + (size_t)xcd_tile(bx, gx) * CP, lane);
         }
       } else {
         store_partial_row<C>(mine, pbase + (size_t)wt * CP, lane);

@@ -192,6 +192,27 @@ GNX_API int32_t gnx_block_forward(const gnx_graphs* h, const gnx_block_params* p
 GNX_API int32_t gnx_block_graph_update(const gnx_graphs* h, const gnx_block_params* p, const float* gf, int64_t n_replicas,
                                float* gf_out, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
+/* ---- the graph update of call i inside call i + 1: loops over many batches of the same graphs (serving, training) -------------------------
+ * A block forward at README widths is one ~19-us kernel plus a second launch that finishes gf' from a few KB of partial sums (~4 us, what an
+ * EMPTY launch costs, + the boundary).  gnx_block_forward_chained runs this call's edge + node update and — in workgroups at the FRONT of
+ * the same launch — the graph update that the previous chained call left pending (`prev`: that call's workspace, gf and gf_out, as the
+ * library recorded them; NULL or zeroed: nothing pending).  On return *pending describes THIS call's pending graph update: its gf_out is
+ * valid only after the next chained call on this stream or after gnx_block_graph_update(h, p, pending->gf, R, pending->gf_out,
+ * pending->workspace, pending->workspace_bytes, flags, stream) (the flush; pending->workspace == NULL: nothing to flush).  Same handle,
+ * params, n_replicas and flags in consecutive calls; the pending call's workspace and gf_out must differ from this call's (two alternating
+ * buffer sets).  Where the two-launch form is not what runs (matrix-core / generic kernels, run-time specialised widths, batches of small
+ * graphs whose graph update already runs inside the block kernel) the call finishes `prev` and this call the plain way and leaves nothing
+ * pending.  Results are bit-identical to gnx_block_forward's (the same graph_update_rows over the same partial rows). */
+typedef struct gnx_pending_update {
+  const void* workspace;
+  size_t workspace_bytes;
+  const float* gf;
+  float* gf_out;
+} gnx_pending_update;
+GNX_API int32_t gnx_block_forward_chained(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf, const float* gf,
+                                  int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out, void* workspace, size_t workspace_bytes,
+                                  uint32_t flags, void* stream, const gnx_pending_update* prev, gnx_pending_update* pending);
+
 /* ---- GNBlock with Flux `Chain`s of Dense layers as update functions (src/gnblock.jl:1-6: edgefn / nodefn / graphfn are
  * arbitrary Chains; the constructor's default is Chain(Dense), which is what gnx_block_forward fuses).  widths[i] = output
  * width of layer i; the input width of layer 0 is fixed by the block (de+2dn+dg / oe+dn+dg / oe+on+dg with oe, on = the LAST

@@ -451,3 +451,65 @@ def test_readout_logitcrossentropy(gn):
         lse = np.log(np.exp(x - x.max(0)).sum(0)) + x.max(0)
         ref = float(np.mean(-(tgt * (x - lse)).sum(0)))
         assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref))
+
+
+@pytest.mark.parametrize("case", ["one-graph", "many-graphs", "small-graphs(pack form)", "wide(matrix cores)", "runtime-specialised"])
+def test_chained_forward_runs_the_previous_graph_update_inside_the_next_launch(gn, case):
+    """gnx_block_forward_chained: a loop over batches whose step is ONE launch — the edge + node update of batch i with the graph update of
+    batch i - 1 in workgroups at the front of the same kernel (k_block_wave<..., CHAIN>) — and a flush at the end.  Every output of every
+    step is BIT-identical to gnx_block_forward's; where the two-launch narrow form is not what runs the call falls back to the plain
+    form and leaves nothing pending."""
+    import torch
+    rng = np.random.default_rng(300 + len(case))
+    dims = ((10, 5, 0), (3, 4, 5))
+    if case == "one-graph":
+        cp, rv = U.er_csc(rng, 30_000, 200_000)
+        cps, rvs, nn = [cp], [rv], [30_000]
+    elif case == "many-graphs":  # graphs with more than 8 wave tiles: the two-launch form, one wavefront per graph in the chained blocks
+        sizes = rng.integers(300, 700, 37)
+        cs = [U.er_csc(rng, int(n), 12 * int(n)) for n in sizes]
+        cps, rvs, nn = [c[0] for c in cs], [c[1] for c in cs], [int(n) for n in sizes]
+    elif case == "small-graphs(pack form)":
+        sizes = rng.integers(20, 90, 200)
+        cs = [U.er_csc(rng, int(n), 4 * int(n)) for n in sizes]
+        cps, rvs, nn = [c[0] for c in cs], [c[1] for c in cs], [int(n) for n in sizes]
+    else:
+        cp, rv = U.er_csc(rng, 3_000, 20_000)
+        cps, rvs, nn = [cp], [rv], [3_000]
+        dims = ((40, 36, 8), (36, 40, 8)) if case.startswith("wide") else ((7, 3, 2), (5, 6, 1))
+    g = gn.GNGraphBatch.from_csc(cps, rvs, nn)
+    p = O.make_block_params(rng, *dims)
+    blk = U.block_from_params(gn, p)
+    plan = gn.BlockPlan(blk, g)
+    dev = g.device
+    (de, dn, dg), _ = dims
+    mk = lambda T, d: torch.rand((1, T, d), device=dev) if d > 0 else None
+    steps = 7
+    ins = [(mk(g.n_edges, de), mk(g.n_nodes, dn), mk(g.n_graphs, dg)) for _ in range(steps)]
+    ref = []
+    for ef, nf, gf in ins:  # the plain form
+        out = plan.outputs()
+        plan(ef, nf, gf, *out)
+        ref.append(out)
+    torch.cuda.synchronize()
+    outs = [plan.outputs() for _ in range(steps)]
+    wss = [plan.new_workspace(), plan.new_workspace()]
+    pending = None
+    took = []
+    for i, (ef, nf, gf) in enumerate(ins):
+        pending = plan.chained(ef, nf, gf, *outs[i], ws=wss[i & 1], prev=pending)
+        took.append(bool(pending.workspace))
+    plan.flush(pending)
+    torch.cuda.synchronize()
+    expect_chain = case in ("one-graph", "many-graphs")
+    assert all(t == expect_chain for t in took), (case, took)
+    for i in range(steps):
+        for name, a, b in zip(("ef", "nf", "gf"), outs[i], ref[i]):
+            assert torch.equal(a, b), f"{case}: step {i} {name} differs between the chained and the plain form"
+    # the same workspace for two consecutive chained calls is refused (its graph update has not run yet)
+    if expect_chain:
+        pend = plan.chained(*ins[0], *outs[0], ws=wss[0], prev=None)
+        with pytest.raises(gn._lib.GnxError):
+            plan.chained(*ins[1], *outs[1], ws=wss[0], prev=pend)
+        plan.flush(pend)
+        torch.cuda.synchronize()

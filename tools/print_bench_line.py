@@ -6,7 +6,7 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d["roofline"]
 print("headline", d["value"], "ms/step", d["ms_per_step"], "frac", r["frac"], "whole", r.get("frac_whole_step"), "traffic", r.get("traffic"),
       "kernel_us", r.get("kernel_us"), "batch_ms", d.get("batch_ms"), "c_abi", d.get("c_abi_ms_per_step"),
-      "pipelined", (d.get("pipelined_two_streams") or {}).get("ms_per_step"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
+      "pipelined", (d.get("pipelined_two_streams") or {}).get("ms_per_step"), "chained", (d.get("chained_graph_update") or {}).get("ms_per_step"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
 for k, v in (d.get("secondary") or {}).items():
     if isinstance(v, dict):
         rr = v.get("roofline", {})
