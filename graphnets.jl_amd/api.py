@@ -97,29 +97,30 @@ class GNGraphBatch:
         self._ws = {}
         self._masks = None
         keep = []
+        if _csc is not None:  # (array preparation and the length check need no device)
+            colptrs, rowvals, n_nodes = _csc
+            nn = np.ascontiguousarray(n_nodes, dtype=np.int64)
+            G = int(nn.size)
+            # ONE array per kind and one call (gnx_graphs_create_csc_cat): building 2 G ctypes pointers costs ~1 us each — 8 of the
+            # 20 ms of a 4096-graph batch.  A caller that already holds the concatenated arrays (from_csc_packed) passes them as they
+            # are; int32 indices stay int32 (half the bytes to validate and upload).
+            def cat(parts):
+                if isinstance(parts, np.ndarray) and parts.ndim == 1 and parts.dtype.kind in "iu":
+                    a_ = parts
+                else:
+                    parts = list(parts)
+                    a_ = np.concatenate(parts) if len(parts) > 1 else (np.asarray(parts[0]) if parts else np.zeros(0, np.int64))
+                if a_.dtype != np.int32 and a_.dtype != np.int64:
+                    a_ = a_.astype(np.int64)
+                return np.ascontiguousarray(a_)
+            cpc, rvc = cat(colptrs), cat(rowvals)
+            if rvc.dtype != cpc.dtype:
+                rvc = rvc.astype(cpc.dtype)
+            if cpc.size != int(nn.sum()) + G:
+                raise ValueError("every colptr must have n_nodes + 1 entries (colptr_cat: sum(n_nodes) + n_graphs)")
+            keep += [cpc, rvc, nn]
         with torch.cuda.device(self.device):
             if _csc is not None:
-                colptrs, rowvals, n_nodes = _csc
-                nn = np.ascontiguousarray(n_nodes, dtype=np.int64)
-                G = int(nn.size)
-                # ONE array per kind and one call (gnx_graphs_create_csc_cat): building 2 G ctypes pointers costs ~1 us each — 8 of the
-                # 20 ms of a 4096-graph batch.  A caller that already holds the concatenated arrays (from_csc_packed) passes them as they
-                # are; int32 indices stay int32 (half the bytes to validate and upload).
-                def cat(parts):
-                    if isinstance(parts, np.ndarray) and parts.ndim == 1 and parts.dtype.kind in "iu":
-                        a_ = parts
-                    else:
-                        parts = list(parts)
-                        a_ = np.concatenate(parts) if len(parts) > 1 else (np.asarray(parts[0]) if parts else np.zeros(0, np.int64))
-                    if a_.dtype != np.int32 and a_.dtype != np.int64:
-                        a_ = a_.astype(np.int64)
-                    return np.ascontiguousarray(a_)
-                cpc, rvc = cat(colptrs), cat(rowvals)
-                if rvc.dtype != cpc.dtype:
-                    rvc = rvc.astype(cpc.dtype)
-                if cpc.size != int(nn.sum()) + G:
-                    raise ValueError("every colptr must have n_nodes + 1 entries (colptr_cat: sum(n_nodes) + n_graphs)")
-                keep += [cpc, rvc, nn]
                 # (the C entry point checks both lengths against what the colptr arrays announce and never reads past them)
                 check(lib.gnx_graphs_create_csc_cat(cpc.ctypes.data, cpc.size, rvc.ctypes.data if rvc.size else None, rvc.size,
                                                     nn.ctypes.data_as(C.POINTER(C.c_int64)), G, 0, cpc.dtype.itemsize * 8, C.byref(self._h)))

@@ -36,3 +36,38 @@ def test_non_dense_layer_in_a_chain_is_an_explicit_error():
         gn.Chain(d, gn.LayerNorm(3, device="cpu"))
     with pytest.raises(NotImplementedError, match="function"):
         gn.Chain(d, torch.relu)
+
+
+def test_packed_csc_constructor_checks_lengths_before_anything_is_read():
+    """the packed constructor takes both array lengths and the index width; a short colptr / rowval is an argument error (no
+    read past the buffers), in Python a ValueError (not an assert that `python -O` strips).  No GPU needed: the checks precede any device work."""
+    import ctypes as C
+    import numpy as np
+    lib = gn._lib.load()
+    cp = np.array([0, 1, 3, 0, 2], dtype=np.int64)      # two graphs: 2 nodes / 3 edges, 1 node / 2 edges (the second is malformed on purpose below)
+    rv = np.array([0, 0, 1, 0, 0], dtype=np.int64)
+    nn = np.array([2, 1], dtype=np.int64)
+    h = C.c_void_p()
+    p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    call = lambda cpl, rvl, bits=64, base=0: lib.gnx_graphs_create_csc_cat(cp.ctypes.data, cpl, rv.ctypes.data, rvl, p64(nn), 2, base, bits, C.byref(h))
+    assert call(4, 5) == gn._lib.ERR_INVALID_ARG and not h.value            # colptr shorter than sum(n) + G
+    assert call(6, 5) == gn._lib.ERR_INVALID_ARG                            # ... longer
+    assert call(5, 4) == gn._lib.ERR_INVALID_ARG                            # rowval shorter than the colptr arrays announce
+    assert call(5, 6) == gn._lib.ERR_INVALID_ARG                            # ... longer
+    assert call(5, 5, bits=16) == gn._lib.ERR_INVALID_ARG
+    assert call(5, 5, base=2) == gn._lib.ERR_INVALID_ARG
+    assert call(-1, 5) == gn._lib.ERR_INVALID_ARG
+    assert call(5, 5) == gn._lib.ERR_CSC and not h.value                    # a 1-node graph with 2 in-edges: more than N per column (host pass, before the device)
+    with pytest.raises(ValueError, match="n_nodes \\+ 1 entries"):
+        gn.GNGraphBatch.from_csc_packed(cp[:-1], rv, nn)
+
+
+def test_chained_forward_argument_checks():
+    """gnx_block_forward_chained without a record to fill / with the deferral flag is refused before any device work."""
+    import ctypes as C
+    lib = gn._lib.load()
+    pend = gn._lib.PendingUpdate()
+    args = [None, None, None, None, None, 1, None, None, None, None, 0]
+    assert lib.gnx_block_forward_chained(*args, 0, None, None, None) == gn._lib.ERR_INVALID_ARG
+    assert lib.gnx_block_forward_chained(*args, gn._lib.FLAG_DEFER_GRAPH_UPDATE, None, None, C.byref(pend)) == gn._lib.ERR_INVALID_ARG
+    assert lib.gnx_block_forward_chained(*args, 0, None, None, C.byref(pend)) == gn._lib.ERR_INVALID_ARG  # NULL handle / params
