@@ -26,7 +26,7 @@ export GNGraphBatch, batch, unbatch, getedgefninput, getnodefninput, getgraphfni
 # ... plus what the drop-in adds: layers as plain structs, pullbacks, the library-side hipGraph model, the multi-GPU split
 export Dense, LayerNorm, ChainBlock, chain_pullback, block_pullback, core_pullback, Model, partition_graphs, DistBlock
 # ... and device residency: `x |> batch |> gpu`, `model |> gpu`, `y |> cpu` (what Flux's `gpu` / `cpu` are to the reference)
-export DeviceArray, gpu, cpu, synchronize
+export DeviceArray, gpu, cpu, synchronize, chained, flush
 
 const libgnx = get(ENV, "GNX_LIB", joinpath(@__DIR__, "..", "graphnets.jl_amd", "libgnx.so"))
 const libhip = get(ENV, "GNX_HIP_LIB", "libamdhip64.so")
@@ -400,6 +400,48 @@ end
 # block) are moved over first and the result comes back to the host: the convenience path.
 (m::GNBlock)(x) = back(block_device(gpu(m), gpu(x)), x)
 
+# ---- loops over batches of the same graphs: ONE launch per step (gnx_block_forward_chained).  `chained(m, x, prev)` runs the edge + node
+#      update of x and — in workgroups at the front of the same kernel — the graph update the previous chained call left pending (`prev`, or
+#      `nothing`); it returns (y, pending): y.gf is complete after the NEXT chained call on the stream or after `flush(m, y, pending)`.
+#      Consecutive calls must use different output arrays and workspaces: the per-batch workspace cache is keyed by the call's parity. ----
+struct GnxPendingUpdate; workspace::Ptr{Cvoid}; workspace_bytes::Csize_t; gf::Ptr{Cfloat}; gf_out::Ptr{Cfloat}; end
+mutable struct Pending
+    rec::Base.RefValue{GnxPendingUpdate}; parity::Int; keep::Any       # keep: the arrays the pending record points into
+end
+function chained_device(m::GNBlock, x, prev::Union{Nothing,Pending})
+    (; graphs, ef, nf, gf) = x
+    g::GNGraphBatch = graphs
+    R = replicas(ef, nf, gf)
+    (oe, on, og) = m.out
+    p = Ref(block_c(m))
+    parity = prev === nothing ? 0 : 1 - prev.parity
+    ws = workspace!(g, (:block_chained, m.in, m.out, R, parity)) do
+        ccall((:gnx_block_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxBlockParams}, Int64), g.handle, p, R)
+    end
+    o_ef, o_nf, o_gf = outarray(oe, nedges(g), R), outarray(on, nnodes(g), R), outarray(og, ngraphs(g), R)
+    rec = Ref(GnxPendingUpdate(C_NULL, 0, C_NULL, C_NULL))
+    prevp = prev === nothing ? Ptr{GnxPendingUpdate}(C_NULL) : Base.unsafe_convert(Ptr{GnxPendingUpdate}, prev.rec)
+    GC.@preserve m ef nf gf o_ef o_nf o_gf ws prev check(ccall((:gnx_block_forward_chained, libgnx), Int32,
+        (Ptr{Cvoid}, Ptr{GnxBlockParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat},
+         Ptr{Cvoid}, Csize_t, UInt32, Ptr{Cvoid}, Ptr{GnxPendingUpdate}, Ptr{GnxPendingUpdate}),
+        g.handle, p, devptr(ef), devptr(nf), devptr(gf), R, devptr(o_ef), devptr(o_nf), devptr(o_gf),
+        ws.ptr, ws.cap, UInt32(0), STREAM[], prevp, rec))
+    (graphs=g, ef=o_ef, nf=o_nf, gf=o_gf), Pending(rec, parity, (gf, o_gf, ws))
+end
+chained(m::GNBlock, x, prev=nothing) = chained_device(gpu(m), gpu(x), prev)
+function flush_device(m::GNBlock, y, pending::Pending)                  # finishes the last pending graph update: one small launch
+    rec = pending.rec[]
+    rec.workspace == C_NULL && return y
+    g::GNGraphBatch = y.graphs
+    p = Ref(block_c(m))
+    R = replicas(y.ef, y.nf, y.gf)
+    GC.@preserve m y pending check(ccall((:gnx_block_graph_update, libgnx), Int32,
+        (Ptr{Cvoid}, Ptr{GnxBlockParams}, Ptr{Cfloat}, Int64, Ptr{Cfloat}, Ptr{Cvoid}, Csize_t, UInt32, Ptr{Cvoid}),
+        g.handle, p, rec.gf, R, rec.gf_out, rec.workspace, rec.workspace_bytes, UInt32(0), STREAM[]))
+    y
+end
+flush(m::GNBlock, y, pending::Pending) = flush_device(gpu(m), y, pending)
+
 # ---- GNCore (src/gncore.jl:46-68): core(x) = x + block(gn1(x)) + ffwd(gn2(x)) → gnx_core_forward ----
 struct LayerNorm{V}                                                    # Flux.LayerNorm(d): diag scale γ, bias β
     γ::V; β::V
@@ -712,6 +754,42 @@ function dist_device(d::DistBlock, xs::AbstractVector)
         d.handle, hs, ps, efs, nfs, gfs, eos, nos, gos, gas, wsp, wsb, UInt32(0), C_NULL))
     [(graphs=d.batches[r], ef=outs[r][1], nf=outs[r][2], gf=outs[r][3]) for r in 1:n], d.gall
 end
+# The replay form (gnx_dist_block_forward_steps): xss[s][r] = step s's batched tuple of rank r (device-resident; M independent batches of the
+# same graphs).  One hipGraph launch per device + ONE all-gather of the M stacked gf' tables per call, whatever M is: after the first call
+# with the same arrays the host's work does not depend on M.  Returns (yss, gf_all): yss[s][r] = (ef', nf') of step s on devices[r] (gf'
+# travels in the wire), gf_all[r] = (DG', n_graphs, M) in ORIGINAL graph order on devices[r].
+function dist_steps_device(d::DistBlock, xss::AbstractVector)
+    n = length(d.devices); M = length(xss)
+    (oe, on, og) = d.blocks[1].out
+    G = sum(length, d.shards)
+    params = [Ref(block_c(d.blocks[r])) for r in 1:n]
+    wss = Matrix{DevBuf}(undef, n, M); outs = Matrix{Any}(undef, n, M); galls = Vector{DeviceArray{3}}(undef, n)
+    for r in 1:n
+        g = d.batches[r]
+        ondev(d.devices[r]) do
+            for s in 1:M
+                wss[r, s] = workspace!(g, (:block_steps, d.blocks[r].in, d.blocks[r].out, s)) do
+                    ccall((:gnx_block_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxBlockParams}, Int64), g.handle, params[r], 1)
+                end
+                outs[r, s] = (outarray(oe, nedges(g), 1), outarray(on, nnodes(g), 1))
+            end
+            galls[r] = DeviceArray(og, G, M)
+        end
+    end
+    perrank(f) = [f(r) for r in 1:n]
+    steprank(f) = [f(r, s) for s in 1:M for r in 1:n]                 # entry (s - 1) * n + r: the header's [step * n_ranks + rank]
+    hs = perrank(r -> d.batches[r].handle)
+    ps = perrank(r -> Base.unsafe_convert(Ptr{GnxBlockParams}, params[r]))
+    efs = steprank((r, s) -> devptr(xss[s][r].ef)); nfs = steprank((r, s) -> devptr(xss[s][r].nf)); gfs = steprank((r, s) -> devptr(xss[s][r].gf))
+    eos = steprank((r, s) -> devptr(outs[r, s][1])); nos = steprank((r, s) -> devptr(outs[r, s][2]))
+    gas = perrank(r -> devptr(galls[r])); wsp = steprank((r, s) -> wss[r, s].ptr); wsb = Csize_t[minimum(wss[r, s].cap for s in 1:M) for r in 1:n]
+    GC.@preserve d params xss outs wss galls check(ccall((:gnx_dist_block_forward_steps, libgnx), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{GnxBlockParams}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}},
+         Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cvoid}}, Ptr{Csize_t}, UInt32, Ptr{Ptr{Cvoid}}),
+        d.handle, M, hs, ps, efs, nfs, gfs, eos, nos, gas, wsp, wsb, UInt32(0), C_NULL))
+    [[(graphs=d.batches[r], ef=outs[r, s][1], nf=outs[r, s][2], gf=nothing) for r in 1:n] for s in 1:M], galls
+end
+
 function (d::DistBlock)(xs::AbstractVector)
     dev = any(ondevice, xs)
     xd = [ondev(() -> gpu(xs[r]), d.devices[r]) for r in 1:length(xs)]

@@ -103,14 +103,16 @@ def test_the_shim_binds_the_entry_points_of_the_hot_path_and_its_neighbours():
     bound = {c[0] for c in ccalls()}
     for name in ("gnx_graphs_create_dense", "gnx_graphs_create_csc_cat", "gnx_block_forward", "gnx_core_forward", "gnx_fn_input", "gnx_block_backward",
                  "gnx_core_backward", "gnx_chain_block_forward", "gnx_chain_block_backward", "gnx_model_create", "gnx_model_forward",
-                 "gnx_dist_partition", "gnx_dist_create", "gnx_dist_block_forward", "gnx_dist_destroy", "gnx_collapse_edges", "gnx_collapse_padded"):
+                 "gnx_dist_partition", "gnx_dist_create", "gnx_dist_block_forward", "gnx_dist_block_forward_steps", "gnx_dist_destroy", "gnx_collapse_edges",
+                 "gnx_collapse_padded", "gnx_block_forward_chained", "gnx_block_graph_update"):
         assert name in bound, f"the Julia shim does not bind {name}"
 
 
 STRUCT_MIRRORS = {"GnxDense": _lib.Dense, "GnxBlockParams": _lib.BlockParams, "GnxGraphsInfo": _lib.GraphsInfo, "GnxLayerNorm": _lib.LayerNorm,
                   "GnxFfn": _lib.Ffn, "GnxCoreParams": _lib.CoreParams, "GnxDenseGrad": _lib.DenseGrad, "GnxBlockGrads": _lib.BlockGrads,
                   "GnxChain": _lib.Chain, "GnxChainBlockParams": _lib.ChainBlockParams, "GnxChainBlockGrads": _lib.ChainBlockGrads,
-                  "GnxLayer": _lib.Layer, "GnxLayerNormGrad": _lib.LayerNormGrad, "GnxFfnGrad": _lib.FfnGrad, "GnxCoreGrads": _lib.CoreGrads}
+                  "GnxLayer": _lib.Layer, "GnxLayerNormGrad": _lib.LayerNormGrad, "GnxFfnGrad": _lib.FfnGrad, "GnxCoreGrads": _lib.CoreGrads,
+                  "GnxPendingUpdate": _lib.PendingUpdate}
 
 
 def julia_structs():
@@ -234,8 +236,8 @@ def _reachable(fns, roots):
     return seen
 
 
-DEVICE_PATH = ("block_device", "core_device", "chain_device", "model_device", "dist_device", "fninput_device", "collapsef_device",
-               "block_pullback_device", "core_pullback_device", "chain_pullback_device")
+DEVICE_PATH = ("block_device", "core_device", "chain_device", "model_device", "dist_device", "dist_steps_device", "chained_device", "flush_device",
+               "fninput_device", "collapsef_device", "block_pullback_device", "core_pullback_device", "chain_pullback_device")
 
 
 def test_device_path_reaches_no_copy_no_sync_and_allocates_only_through_the_pool():
@@ -277,7 +279,7 @@ def test_call_operators_are_the_device_path_plus_gpu_and_back():
     # every gnx_* launch of the device path goes to STREAM[] (asynchronous), and workspaces come from the batch's cache
     fns = _functions()
     for f in DEVICE_PATH:
-        if f == "dist_device":
+        if f in ("dist_device", "dist_steps_device"):
             continue  # (per-device default streams: the C entry point takes a stream ARRAY, NULL = default streams)
         assert "STREAM[]" in fns[f], f"{f} does not launch on STREAM[]"
     for f in ("block_device", "core_device", "chain_device", "block_pullback_device", "core_pullback_device", "chain_pullback_device"):
