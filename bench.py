@@ -671,6 +671,19 @@ def main():
     blk.nodefn = gn.Dense.from_numpy(glorot(rng, on, oe + dn + dg), np.zeros(on, np.float32), device=dev)
     blk.graphfn = gn.Dense.from_numpy(glorot(rng, og, oe + on + dg), np.zeros(og, np.float32), device=dev)
     plan = gn.BlockPlan(blk, g, R=1, flags=args.flags)
+    if max(din + dout) >= 32 and not multi:
+        # widths that take the matrix-core path: the first workspace query on a NEW handle also builds that path's tables (128-row tiles, the
+        # destination of every edge, the aggregation chunks: kernels over the handle's device arrays) — what a loop that rebuilds its batch pays per batch
+        tw = []
+        for _ in range(3):
+            g2 = gn.GNGraphBatch.from_csc_packed(cpc, rvc, nn, device=dev)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            gn.BlockPlan(blk, g2, R=1, flags=args.flags)
+            torch.cuda.synchronize(dev)
+            tw.append((time.perf_counter() - t0) * 1e3)
+            del g2
+        batch_ms["wide_tables_with_first_workspace_query"] = round(min(tw), 3)
     nsets = 2 if max(din + dout) >= 64 else NSETS
     tg = torch.Generator(device=dev); tg.manual_seed(1234 + rank)
     mk = lambda T, d: torch.rand((1, T, d), generator=tg, device=dev, dtype=torch.float32) if d > 0 else None

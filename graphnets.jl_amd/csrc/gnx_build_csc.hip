@@ -370,4 +370,143 @@ int32_t build_handle_from_csc_on_device(gnx_graphs* h, const void* colptr_cat, c
   return GNX_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The matrix-core path's tables (gnx_internal.h: 128-row edge / node / graph tiles, the destination of every edge, the aggregation
+// chunks of the edge GEMM's fused edge -> node sums) built by kernels from the handle's DEVICE arrays — every handle has those, whatever
+// built it.  The host builder (gnx_graphs.cpp::build_wide_tables: loops over N + E on the lazily downloaded CSC, a dozen allocations
+// and uploads, ~3-6 ms at 1M edges) stays as the validator (GNX_BUILD_WIDE_DEVICE=0) and for batches beyond the scan's capacity.
+// Tables bit-identical (tests/test_gpu_build.py).  A training loop that rebuilds its batch every iteration pays this per iteration.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct WideArgs2 {
+  const int *colptr, *node_off, *edge_off, *etile_off, *ntile_off;
+  int G, N, E, n_etiles, n_ntiles, n_gtiles;
+};
+__device__ __forceinline__ int seg_of(const int* off, int n, int x) {  // i in [0, n) with off[i] <= x < off[i + 1] (off non-decreasing; empty segments skipped)
+  int lo = 0, hi = n;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= x) lo = mid; else hi = mid; }
+  return lo;
+}
+__global__ __launch_bounds__(256) void k_wide_tiles(WideArgs2 a, Tile* __restrict__ etiles, Tile* __restrict__ ntiles, Tile* __restrict__ gtiles) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.n_etiles) {
+    const int g = seg_of(a.etile_off, a.G, i);
+    Tile t{};
+    t.e0 = a.edge_off[g] + (i - a.etile_off[g]) * 128; t.e1 = min(t.e0 + 128, a.edge_off[g + 1]); t.g = g;
+    t.n0 = a.node_off[g]; t.n1 = a.node_off[g + 1];
+    etiles[i] = t;
+  }
+  if (i < a.n_ntiles) {
+    const int g = seg_of(a.ntile_off, a.G, i);
+    Tile t{};
+    t.n0 = a.node_off[g] + (i - a.ntile_off[g]) * 128; t.n1 = min(t.n0 + 128, a.node_off[g + 1]); t.g = g;
+    t.e0 = a.colptr[t.n0]; t.e1 = a.colptr[t.n1];
+    ntiles[i] = t;
+  }
+  if (i < a.n_gtiles) {
+    Tile t{};
+    t.n0 = i * 128; t.n1 = min(i * 128 + 128, a.G); t.g = i * 128;
+    gtiles[i] = t;
+  }
+}
+// dst[e] = the node whose column holds edge e; nz[n] = 1 if node n has in-edges (nz[N] = 0)
+__global__ __launch_bounds__(256) void k_wide_dst(const int* __restrict__ colptr, int N, int* __restrict__ dst, int* __restrict__ nz) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n > N) return;
+  if (n == N) { nz[n] = 0; return; }
+  const int e0 = colptr[n], e1 = colptr[n + 1];
+  nz[n] = e1 > e0;
+  for (int e = e0; e < e1; ++e) dst[e] = n;
+}
+__global__ __launch_bounds__(256) void k_scan_finish(int* __restrict__ out, int S, const int* __restrict__ block_prefix) {  // out[i] += prefix of its 2048-block
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < S) out[i] += block_prefix[i / SCAN2_B];
+}
+// rows of the partial-sum table per aggregation chunk (a 64-edge pass of a 128-edge tile) = distinct destinations in it; tiles whose
+// destinations span more than kPdRowsCap consecutive nodes are counted (the edge GEMM's LDS form needs none)
+__global__ __launch_bounds__(256) void k_wide_chunks(const Tile* __restrict__ etiles, int n_etiles, const int* __restrict__ dst, const int* __restrict__ nonempty,
+                                                     int* __restrict__ cnt, int* __restrict__ stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > 2 * n_etiles) return;
+  if (c == 2 * n_etiles) { cnt[c] = 0; return; }
+  const Tile t = etiles[c >> 1];
+  const int c0 = t.e0 + 64 * (c & 1), c1 = min(c0 + 64, t.e1);
+  cnt[c] = c1 > c0 ? nonempty[dst[c1 - 1] + 1] - nonempty[dst[c0]] : 0;
+  if ((c & 1) == 0 && t.e1 > t.e0 && dst[t.e1 - 1] - dst[t.e0] + 1 > kPdRowsCap) atomicAdd(&stats[1], 1);
+}
+__global__ __launch_bounds__(256) void k_wide_nodes(WideArgs2 a, const int* __restrict__ dst, const int* __restrict__ nonempty, const int* __restrict__ row0,
+                                                    int* __restrict__ agg_row, int* __restrict__ parts, int* __restrict__ first_chunk, int* __restrict__ stats) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n == 0) stats[0] = row0[2 * a.n_etiles];  // n_agg_rows
+  if (n >= a.N) return;
+  const int e0 = a.colptr[n], e1 = a.colptr[n + 1];
+  if (e1 <= e0) { agg_row[n] = -1; parts[n] = 0; first_chunk[n] = 0; return; }
+  const int g = seg_of(a.node_off, a.G, n);
+  const int eb = a.edge_off[g];
+  const int ca = 2 * a.etile_off[g] + (e0 - eb) / 64, cb = 2 * a.etile_off[g] + (e1 - 1 - eb) / 64;
+  const int chunk_e0 = eb + ((e0 - eb) / 64) * 64;  // first edge of chunk ca
+  agg_row[n] = row0[ca] + (nonempty[n] - nonempty[dst[chunk_e0]]);
+  parts[n] = cb - ca + 1;
+  first_chunk[n] = ca;
+}
+
+// 1 = not applicable (the host builder runs); GNX_OK = the handle's wide tables are built (one device allocation: h->d_wide_arena)
+int32_t build_wide_tables_on_device(const gnx_graphs* h) {
+  static const bool on = !(getenv("GNX_BUILD_WIDE_DEVICE") && atoi(getenv("GNX_BUILD_WIDE_DEVICE")) == 0);
+  if (!on) return 1;
+  const int64_t N = h->N, E = h->E, G = h->G, net = h->n_etiles, nnt = h->n_ntiles, ngt = h->n_gtiles;
+  const int64_t S1 = N + 1, S2 = 2 * net + 1;
+  if (S1 > (int64_t)SCAN2_B * SCAN2_B || S2 > (int64_t)SCAN2_B * SCAN2_B) return 1;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t at = off; off += (std::max<size_t>(bytes, 16) + 255) / 256 * 256; return at; };
+  const size_t o_et = take((size_t)net * sizeof(Tile)), o_nt = take((size_t)nnt * sizeof(Tile)), o_gt = take((size_t)ngt * sizeof(Tile));
+  const size_t o_eo = take((size_t)(G + 1) * 4), o_no = take((size_t)(G + 1) * 4), o_dst = take((size_t)E * 4), o_row0 = take((size_t)S2 * 4);
+  const size_t o_ar = take((size_t)N * 4), o_pa = take((size_t)N * 4), o_fc = take((size_t)N * 4);
+  const size_t persistent = off;
+  // scratch behind the persistent part of the same allocation (freed with it: a few MB)
+  const int nb1 = (int)((S1 + SCAN2_B - 1) / SCAN2_B), nb2 = (int)((S2 + SCAN2_B - 1) / SCAN2_B);
+  const size_t o_nz = take((size_t)S1 * 4), o_ne = take((size_t)S1 * 4), o_cnt = take((size_t)S2 * 4), o_bs = take((size_t)std::max(nb1, nb2) * 4), o_st = take(16);
+  (void)persistent;
+  hipStream_t s = nullptr;
+  void* scratch = nullptr;
+  int32_t rc = dev_scratch(h->device, 256, &s, &scratch);  // (the device's build stream)
+  if (rc) return rc;
+  char* base = nullptr;
+  GNX_HIP(hipMalloc((void**)&base, off));
+  h->d_wide_arena = base;
+  h->d_etiles = reinterpret_cast<Tile*>(base + o_et); h->d_ntiles = reinterpret_cast<Tile*>(base + o_nt); h->d_gtiles = reinterpret_cast<Tile*>(base + o_gt);
+  h->d_etile_off = reinterpret_cast<int*>(base + o_eo); h->d_ntile_off = reinterpret_cast<int*>(base + o_no); h->d_edge_dst = reinterpret_cast<int*>(base + o_dst);
+  h->d_chunk_row0 = reinterpret_cast<int*>(base + o_row0); h->d_node_agg_row = reinterpret_cast<int*>(base + o_ar);
+  h->d_node_agg_parts = reinterpret_cast<int*>(base + o_pa); h->d_node_agg_chunk = reinterpret_cast<int*>(base + o_fc);
+  int* nz = reinterpret_cast<int*>(base + o_nz);
+  int* nonempty = reinterpret_cast<int*>(base + o_ne);
+  int* cnt = reinterpret_cast<int*>(base + o_cnt);
+  int* bs = reinterpret_cast<int*>(base + o_bs);
+  int* stats = reinterpret_cast<int*>(base + o_st);
+  GNX_HIP(hipMemcpyAsync(h->d_etile_off, h->h_etile_off.data(), (size_t)(G + 1) * 4, hipMemcpyHostToDevice, s));
+  GNX_HIP(hipMemcpyAsync(h->d_ntile_off, h->h_ntile_off.data(), (size_t)(G + 1) * 4, hipMemcpyHostToDevice, s));
+  GNX_HIP(hipMemsetAsync(stats, 0, 16, s));
+  WideArgs2 a{h->d_colptr, h->d_node_off, h->d_edge_off, h->d_etile_off, h->d_ntile_off, (int)G, (int)N, (int)E, (int)net, (int)nnt, (int)ngt};
+  const int64_t mt = std::max(std::max(net, nnt), std::max<int64_t>(ngt, 1));
+  GNX_LAUNCH(k_wide_tiles, dim3((unsigned)((mt + 255) / 256)), dim3(256), 0, s, a, h->d_etiles, h->d_ntiles, h->d_gtiles);
+  GNX_LAUNCH(k_wide_dst, dim3((unsigned)((S1 + 255) / 256)), dim3(256), 0, s, h->d_colptr, (int)N, h->d_edge_dst, nz);
+  GNX_LAUNCH(k_scan2_blocks, dim3((unsigned)nb1, 1), dim3(256), 0, s, nz, (int)S1, nonempty, bs, nb1);
+  GNX_LAUNCH(k_scan2_sums, dim3(1), dim3(256), 0, s, bs, nb1);
+  GNX_LAUNCH(k_scan_finish, dim3((unsigned)((S1 + 255) / 256)), dim3(256), 0, s, nonempty, (int)S1, bs);
+  GNX_LAUNCH(k_wide_chunks, dim3((unsigned)((S2 + 255) / 256)), dim3(256), 0, s, h->d_etiles, (int)net, h->d_edge_dst, nonempty, cnt, stats);
+  GNX_LAUNCH(k_scan2_blocks, dim3((unsigned)nb2, 1), dim3(256), 0, s, cnt, (int)S2, h->d_chunk_row0, bs, nb2);
+  GNX_LAUNCH(k_scan2_sums, dim3(1), dim3(256), 0, s, bs, nb2);
+  GNX_LAUNCH(k_scan_finish, dim3((unsigned)((S2 + 255) / 256)), dim3(256), 0, s, h->d_chunk_row0, (int)S2, bs);
+  GNX_LAUNCH(k_wide_nodes, dim3((unsigned)((std::max<int64_t>(N, 1) + 255) / 256)), dim3(256), 0, s, a, h->d_edge_dst, nonempty, h->d_chunk_row0, h->d_node_agg_row,
+             h->d_node_agg_parts, h->d_node_agg_chunk, stats);
+  GNX_HIP(hipGetLastError());
+  int out[4] = {0, 0, 0, 0};
+  GNX_HIP(hipMemcpyAsync(out, stats, 16, hipMemcpyDeviceToHost, s));
+  GNX_HIP(hipStreamSynchronize(s));
+  h->n_agg_rows = out[0];
+  h->n_etiles_wide_span = out[1];
+  if (h->n_agg_rows > h->agg_rows_bound) return fail(GNX_ERR_INVALID_ARG, "wide tables: more aggregation rows than the bound workspaces are sized with");
+  return GNX_OK;
+}
+
 }  // namespace gnx

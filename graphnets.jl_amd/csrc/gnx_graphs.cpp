@@ -589,6 +589,11 @@ int32_t gnx_graphs_create_csc_cat(const void* colptr_cat, int64_t colptr_len, co
 int32_t gnx_graphs_destroy(gnx_graphs* h) {
   if (!h) return GNX_OK;
   arena_give(h->device, h->d_arena, h->arena_bytes);  // colptr, rowval, node / edge / tile offsets, tiles, wave tiles, packs: kept for the next handle of this size
+  if (h->d_wide_arena) {
+    (void)hipFree(h->d_wide_arena);
+    h->d_edge_dst = nullptr; h->d_chunk_row0 = nullptr; h->d_node_agg_row = nullptr; h->d_node_agg_parts = nullptr; h->d_node_agg_chunk = nullptr;
+    h->d_etiles = nullptr; h->d_ntiles = nullptr; h->d_gtiles = nullptr; h->d_etile_off = nullptr; h->d_ntile_off = nullptr;
+  }
   (void)hipFree(h->d_edge_dst);
   (void)hipFree(h->d_chunk_row0);
   (void)hipFree(h->d_node_agg_row);
@@ -654,6 +659,12 @@ static int32_t build_csr(const gnx_graphs* h) {
 
 // frees whatever a failed build_wide_tables left behind, so that a later call starts from nothing
 static void drop_wide_tables(const gnx_graphs* h) {
+  if (h->d_wide_arena) {  // device-built: the ten arrays are slices of one allocation
+    (void)hipFree(h->d_wide_arena);
+    h->d_wide_arena = nullptr;
+    h->d_edge_dst = nullptr; h->d_chunk_row0 = nullptr; h->d_node_agg_row = nullptr; h->d_node_agg_parts = nullptr; h->d_node_agg_chunk = nullptr;
+    h->d_etiles = nullptr; h->d_ntiles = nullptr; h->d_gtiles = nullptr; h->d_etile_off = nullptr; h->d_ntile_off = nullptr;
+  }
   void** dev[] = {(void**)&h->d_edge_dst, (void**)&h->d_chunk_row0, (void**)&h->d_node_agg_row, (void**)&h->d_node_agg_parts, (void**)&h->d_node_agg_chunk,
                   (void**)&h->d_etiles, (void**)&h->d_ntiles, (void**)&h->d_gtiles, (void**)&h->d_etile_off, (void**)&h->d_ntile_off};
   for (void** d : dev) { if (*d) (void)hipFree(*d); *d = nullptr; }
@@ -677,8 +688,19 @@ int32_t gnx_ensure_wide_tables(const gnx_graphs* h, void* stream) {
   }
   std::lock_guard<std::mutex> lk(h->wide_mu);
   if (h->wide_built.load(std::memory_order_relaxed)) return GNX_OK;
-  int32_t rc = gnx_ensure_host_csc(h);
-  if (!rc) rc = build_wide_tables(h);
+  int32_t rc;
+  {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev != h->device ? prev : -1};
+    if (prev != h->device && hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return fail(GNX_ERR_INVALID_ARG, "cannot select the handle's device"); }
+    rc = build_wide_tables_on_device(h);  // kernels over the handle's device arrays; 1 = not applicable
+  }
+  if (rc == 1) {
+    drop_wide_tables(h);
+    rc = gnx_ensure_host_csc(h);
+    if (!rc) rc = build_wide_tables(h);
+  }
   if (rc) { drop_wide_tables(h); return rc; }  // (the message of the failing step stays in gnx_last_error())
   h->wide_built.store(true, std::memory_order_release);
   return GNX_OK;
@@ -747,7 +769,26 @@ int32_t gnx_graphs_get_table(const gnx_graphs* h, int32_t which, void* out, int6
   const void* src[9] = {h->d_colptr, h->d_rowval, h->d_node_off, h->d_edge_off, h->d_tile_off, h->d_tiles, h->d_wtile_off, h->d_wtiles, h->d_packs};
   const size_t sz[9] = {(size_t)(h->N + 1) * 4, (size_t)h->E * 4, (size_t)(h->G + 1) * 4, (size_t)(h->G + 1) * 4, (size_t)(h->G + 1) * 4, (size_t)h->n_tiles() * sizeof(gnx::Tile),
                         (size_t)(h->G + 1) * 4, (size_t)h->n_wtiles() * sizeof(gnx::Tile), (size_t)h->n_packs * 8 * 4};
-  if (which < 0 || which > 8) return fail(GNX_ERR_INVALID_ARG, "which must be 0..8 (colptr, rowval, node_off, edge_off, tile_off, tiles, wtile_off, wtiles, packs)");
+  if (which >= 9 && which <= 19) {  // the matrix-core path's tables (built now if they are not yet)
+    if (int32_t rcw = gnx_ensure_wide_tables(h)) return rcw;
+    const int64_t info[5] = {h->n_agg_rows, h->n_etiles_wide_span, h->n_etiles, h->n_ntiles, h->n_gtiles};
+    const void* wsrc[10] = {h->d_etiles, h->d_ntiles, h->d_gtiles, h->d_etile_off, h->d_ntile_off, h->d_edge_dst, h->d_chunk_row0, h->d_node_agg_row, h->d_node_agg_parts,
+                            h->d_node_agg_chunk};
+    const size_t wsz[10] = {(size_t)h->n_etiles * sizeof(gnx::Tile), (size_t)h->n_ntiles * sizeof(gnx::Tile), (size_t)h->n_gtiles * sizeof(gnx::Tile), (size_t)(h->G + 1) * 4,
+                            (size_t)(h->G + 1) * 4, (size_t)h->E * 4, (size_t)(2 * h->n_etiles + 1) * 4, (size_t)h->N * 4, (size_t)h->N * 4, (size_t)h->N * 4};
+    const size_t need = which == 19 ? sizeof info : wsz[which - 9];
+    if (bytes) *bytes = (int64_t)need;
+    if (!out) return GNX_OK;
+    if (capacity_bytes < (int64_t)need) return fail(GNX_ERR_INVALID_ARG, "buffer smaller than the table");
+    if (which == 19) { memcpy(out, info, sizeof info); return GNX_OK; }
+    int prevd = -1;
+    (void)hipGetDevice(&prevd);
+    struct RestoreW { int d; ~RestoreW() { if (d >= 0) (void)hipSetDevice(d); } } restorew{prevd != h->device ? prevd : -1};
+    if (prevd != h->device) GNX_HIP(hipSetDevice(h->device));
+    if (need) GNX_HIP(hipMemcpy(out, wsrc[which - 9], need, hipMemcpyDeviceToHost));
+    return GNX_OK;
+  }
+  if (which < 0 || which > 8) return fail(GNX_ERR_INVALID_ARG, "which must be 0..19 (colptr, rowval, node_off, edge_off, tile_off, tiles, wtile_off, wtiles, packs; 9..19: the matrix-core tables)");
   if (bytes) *bytes = (int64_t)sz[which];
   if (!out) return GNX_OK;
   if (capacity_bytes < (int64_t)sz[which]) return fail(GNX_ERR_INVALID_ARG, "buffer smaller than the table");

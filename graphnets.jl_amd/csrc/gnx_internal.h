@@ -70,6 +70,7 @@ struct gnx_graphs {
   std::vector<int32_t> h_etile_off, h_ntile_off;  // [G+1] (eager: O(G))
   mutable std::mutex wide_mu;                 // serialises the build; a failed build leaves nothing behind and may be retried
   mutable std::atomic<bool> wide_built{false};
+  mutable void* d_wide_arena = nullptr;   // device-built wide tables: ONE allocation behind the ten arrays below (then they are not freed one by one)
   mutable int32_t* d_edge_dst = nullptr;  // [E]
   mutable std::vector<gnx::Tile> h_etiles, h_ntiles, h_gtiles;  // h_gtiles: 128-row chunks of the graph rows (n0/n1 = graph ids)
   mutable gnx::Tile* d_etiles = nullptr;
@@ -169,6 +170,7 @@ void build_packs(gnx_graphs* h, std::vector<int32_t>& packs);
 // released handle arenas (gnx_build_csc.hip)
 void* arena_take(int dev, size_t bytes, size_t* got);
 void arena_give(int dev, void* ptr, size_t bytes);
+int32_t build_wide_tables_on_device(const gnx_graphs* h);  // gnx_build_csc.hip; 1 = not applicable (host builder)
 int32_t build_handle_from_csc_on_device(gnx_graphs* h, const void* colptr_cat, const void* rowval_cat, int32_t index_base, int32_t index_bits, int tile_e_cap, int tile_n_cap,
                                         int wtile_e_cap, int64_t tiles_bound, int64_t wtiles_bound, int64_t max_tiles_per_graph_bound);
 

@@ -174,7 +174,10 @@ GNX_API int32_t gnx_graphs_get_csc(const gnx_graphs* h, int64_t* colptr, int64_t
 
 /* diagnostic: one of the handle's DEVICE tables copied to the host as it is — which = 0 colptr [N+1] int32, 1 rowval [E] int32 (global source
  * ids), 2 node_off, 3 edge_off, 4 tile_off [G+1] int32, 5 workgroup tiles (32-byte records {n0, n1, e0, e1, g, win0, win1, flags}), 6 wtile_off,
- * 7 wave tiles, 8 packs [n_packs][8] int32.  *bytes = the table's size (out may be NULL to ask for it).  Large batches given as CSC are
+ * 7 wave tiles, 8 packs [n_packs][8] int32; 9..18 the matrix-core path's tables (built on the spot if they are not yet: 9 edge tiles, 10 node
+ * tiles, 11 graph tiles, 12 / 13 their per-graph offsets, 14 destination of every edge, 15 first partial-sum row of every aggregation chunk,
+ * 16 / 17 / 18 per node: its partial-sum row, the chunks its in-edges run through, its first chunk), 19 five int64 {partial-sum rows, edge tiles
+ * with a wide destination span, edge / node / graph tile counts}.  *bytes = the table's size (out may be NULL to ask for it).  Large batches given as CSC are
  * validated and tiled by kernels (env GNX_BUILD_CSC_DEVICE=0: on the host); the two builders' tables are bit-identical (tests/test_gpu_build.py). */
 GNX_API int32_t gnx_graphs_get_table(const gnx_graphs* h, int32_t which, void* out, int64_t capacity_bytes, int64_t* bytes);
 

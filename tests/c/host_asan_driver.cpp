@@ -25,6 +25,7 @@ int32_t build_csc_on_device(const void* const*, const int64_t*, int64_t, int32_t
 }
 void* arena_take(int, size_t, size_t*) { return nullptr; }
 void arena_give(int, void* p, size_t) { if (p) (void)hipFree(p); }
+int32_t build_wide_tables_on_device(const gnx_graphs*) { return 1; }
 int32_t build_handle_from_csc_on_device(gnx_graphs*, const void*, const void*, int32_t, int32_t, int, int, int, int64_t, int64_t, int64_t) { return 1; }  // the host builder runs
 }  // namespace gnx
 extern "C" {

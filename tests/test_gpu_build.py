@@ -1,7 +1,8 @@
 """GNGraphBatch construction from CSC on the device (csrc/gnx_build_csc.hip) against the host builder (csrc/gnx_graphs.cpp::finalize), which
 stays as the validator: every device table bit-identical (colptr, rowval, offsets, both tile tables, the pack table), the same info, the same
-errors for malformed input, and the same forward results.  The host builder runs in a child process with GNX_BUILD_CSC_DEVICE=0 (the switch
-is read once per process)."""
+errors for malformed input, and the same forward results — and the matrix-core path's ten tables (csrc/gnx_build_csc.hip::
+build_wide_tables_on_device vs gnx_graphs.cpp::build_wide_tables).  The host builders run in a child process with GNX_BUILD_CSC_DEVICE=0
+GNX_BUILD_WIDE_DEVICE=0 (the switches are read once per process)."""
 import ctypes as C
 import json
 import os
@@ -54,6 +55,14 @@ def _tables(spec, index_dtype="int64"):
         buf = np.zeros(max(n.value // 4, 1), dtype=np.int32)
         gn._lib.check(lib.gnx_graphs_get_table(g._h, which, buf.ctypes.data, buf.nbytes, C.byref(n)))
         out[name] = buf[: n.value // 4]
+    # the matrix-core path's tables (built on the spot): device builder (kernels over the handle's device arrays) vs host builder
+    for which, name in zip(range(9, 20), ("etiles", "ntiles", "gtiles", "etile_off", "ntile_off", "edge_dst", "chunk_row0", "node_agg_row", "node_agg_parts",
+                                          "node_agg_chunk", "wide_info")):
+        n = C.c_int64(0)
+        gn._lib.check(lib.gnx_graphs_get_table(g._h, which, None, 0, C.byref(n)))
+        buf = np.zeros(max(n.value // 4, 1), dtype=np.int32)
+        gn._lib.check(lib.gnx_graphs_get_table(g._h, which, buf.ctypes.data, buf.nbytes, C.byref(n)))
+        out[name] = buf[: n.value // 4]
     out["info"] = np.array([g.n_graphs, g.n_nodes, g.n_edges, g.node_block_size, g.n_tiles, g.max_in_degree], dtype=np.int64)
     cp, rv = g.csc()  # the lazily downloaded int64 host copies
     out["host_colptr"], out["host_rowval"] = cp, rv
@@ -67,7 +76,7 @@ def _child(name, path):
 @pytest.mark.parametrize("name", list(CASES))
 def test_device_builder_tables_are_bit_identical_to_the_host_builders(name, tmp_path):
     path = str(tmp_path / "host.npz")
-    env = dict(os.environ, GNX_BUILD_CSC_DEVICE="0")
+    env = dict(os.environ, GNX_BUILD_CSC_DEVICE="0", GNX_BUILD_WIDE_DEVICE="0")
     r = subprocess.run([sys.executable, "-c", f"import sys; sys.path.insert(0, {ROOT!r}); from tests import test_gpu_build as T; T._child({name!r}, {path!r})"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
