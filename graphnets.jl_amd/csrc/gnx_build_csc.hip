@@ -79,6 +79,18 @@ __global__ __launch_bounds__(256) void k_csc_columns(const IDX* __restrict__ cp_
   if ((threadIdx.x & 63) == 0 && deg > 0) atomicMax(&st->max_deg, deg);
 }
 
+// a CSC that is on the device already (global int32 colptr / rowval: the dense-adjacency builder's output): graph of every node, largest in-degree
+__global__ __launch_bounds__(256) void k_adopt_csc(const int* __restrict__ colptr, CscBuildArgs a, int* __restrict__ node_graph, CscBuildStats* st) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int deg = 0;
+  if (j < a.N) {
+    node_graph[j] = graph_of_node(a.node_off, a.G, j);
+    deg = colptr[j + 1] - colptr[j];
+  }
+  for (int off = 32; off > 0; off >>= 1) deg = max(deg, __shfl_xor(deg, off));
+  if ((threadIdx.x & 63) == 0 && deg > 0) atomicMax(&st->max_deg, deg);
+}
+
 // end of the greedy tile that starts at node j (gnx_graphs.cpp::finalize, build_tiles): nodes are added while the tile has < n_cap nodes
 // and — except for its first node — its edges stay <= e_cap
 __device__ __forceinline__ int tile_end(const int* __restrict__ colptr, int j, int nend, int n_cap, int e_cap) {
@@ -286,7 +298,7 @@ int32_t build_handle_from_csc_on_device(gnx_graphs* h, const void* colptr_cat, c
   if (S > (int64_t)SCAN2_B * SCAN2_B) return 1;  // two-level scan capacity (4 M nodes)
   int levels = 1;
   for (int64_t c = 4; c < max_tiles_per_graph_bound; c *= 4) ++levels;  // 4^levels >= the largest possible number of tiles of a graph
-  const size_t w = index_bits / 8;
+  const size_t w = index_bits / 8;  // 0: colptr_cat / rowval_cat are DEVICE pointers to the global int32 colptr [N + 1] / rowval [E] (nothing to validate or convert)
   // device scratch: raw arrays, node -> graph, next / jump levels, flags, scanned flags, block sums, stats
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) / 256 * 256; return at; };
@@ -318,8 +330,13 @@ int32_t build_handle_from_csc_on_device(gnx_graphs* h, const void* colptr_cat, c
   for (int64_t g = 0; g <= G; ++g) { off32[(size_t)g] = (int32_t)h->h_node_off[(size_t)g]; off32[(size_t)(G + 1 + g)] = (int32_t)h->h_edge_off[(size_t)g]; }
   GNX_HIP(hipMemcpyAsync(h->d_node_off, off32.data(), (size_t)(G + 1) * 4, hipMemcpyHostToDevice, s));
   GNX_HIP(hipMemcpyAsync(h->d_edge_off, off32.data() + (G + 1), (size_t)(G + 1) * 4, hipMemcpyHostToDevice, s));
-  GNX_HIP(hipMemcpyAsync(sb + o_cp, colptr_cat, (size_t)(N + G) * w, hipMemcpyHostToDevice, s));
-  if (E) GNX_HIP(hipMemcpyAsync(sb + o_rv, rowval_cat, (size_t)E * w, hipMemcpyHostToDevice, s));
+  if (index_bits == 0) {
+    GNX_HIP(hipMemcpyAsync(h->d_colptr, colptr_cat, (size_t)S * 4, hipMemcpyDeviceToDevice, s));
+    if (E) GNX_HIP(hipMemcpyAsync(h->d_rowval, rowval_cat, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    GNX_HIP(hipMemcpyAsync(sb + o_cp, colptr_cat, (size_t)(N + G) * w, hipMemcpyHostToDevice, s));
+    if (E) GNX_HIP(hipMemcpyAsync(sb + o_rv, rowval_cat, (size_t)E * w, hipMemcpyHostToDevice, s));
+  }
   CscBuildStats init{};
   init.first_bad = INT_MAX;
   GNX_HIP(hipMemcpyAsync(sb + o_st, &init, sizeof init, hipMemcpyHostToDevice, s));
@@ -331,7 +348,9 @@ int32_t build_handle_from_csc_on_device(gnx_graphs* h, const void* colptr_cat, c
   int* bsum = reinterpret_cast<int*>(sb + o_bs);
   CscBuildStats* st = reinterpret_cast<CscBuildStats*>(sb + o_st);
   const unsigned gN = (unsigned)((N + 255) / 256), gS = (unsigned)((S + 255) / 256);
-  if (index_bits == 64)
+  if (index_bits == 0)
+    GNX_LAUNCH(k_adopt_csc, dim3(gN), dim3(256), 0, s, h->d_colptr, a, node_graph, st);
+  else if (index_bits == 64)
     GNX_LAUNCH((k_csc_columns<long long>), dim3(gN), dim3(256), 0, s, reinterpret_cast<const long long*>(sb + o_cp), reinterpret_cast<const long long*>(sb + o_rv), a, h->d_colptr,
                h->d_rowval, node_graph, st);
   else

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 #include "gnx_internal.h"
 
@@ -88,9 +89,17 @@ __global__ void k_scan_add(int* out, int n, const int* block_prefix) {
   if (i < n) out[i] += block_prefix[i / SCAN_B];
 }
 
+// per-graph edge offsets from the global colptr: edge_off[g] = colptr[node_off[g]]
+__global__ void k_gather_offsets(const int* __restrict__ cp, const int* __restrict__ node_off, int G, int* __restrict__ edge_off) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g <= G) edge_off[g] = cp[node_off[g]];
+}
+
 // Returns 1 when the device path does not apply (caller falls back to the host scan).
+// keep != nullptr: the CSC stays on the device (keep->d_colptr [N+1], keep->d_rowval [E]: the caller frees them) and only the G + 1 edge
+// offsets come back — the handle's tables are then built by the device builder (gnx_build_csc.hip) without a round trip through the host
 int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int64_t G, int32_t elem_kind, int32_t row_major,
-                            gnx::vec_i64& h_colptr, gnx::vec_i64& h_rowval, const std::vector<int64_t>& h_node_off) {
+                            gnx::vec_i64& h_colptr, gnx::vec_i64& h_rowval, const std::vector<int64_t>& h_node_off, DenseCscOnDevice* keep) {
   const int64_t N = h_node_off.back();
   if (N <= 0 || N + 1 > (int64_t)SCAN_B * SCAN_B) return 1;  // two-level scan capacity
   static const size_t esz_tab[5] = {1, 4, 8, 4, 8};
@@ -131,12 +140,31 @@ int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int6
     while (done < bytes_total) {
       if (in_flight[buf]) { GNX_TRY(hipEventSynchronize(stage_ev[buf])); in_flight[buf] = false; }
       size_t fill = 0;
+      struct Seg { char* dst; const char* src; size_t bytes; };
+      std::vector<Seg> segs;
       while (fill < STAGE && g < G) {
         const size_t gbytes = (size_t)(n_nodes[g] * n_nodes[g]) * esz;
         const size_t take = std::min(gbytes - g_done, STAGE - fill);
-        memcpy(stage[buf] + fill, static_cast<const char*>(adj[g]) + g_done, take);
+        segs.push_back({stage[buf] + fill, static_cast<const char*>(adj[g]) + g_done, take});
         fill += take; g_done += take;
         if (g_done == gbytes) { ++g; g_done = 0; }
+      }
+      {
+        // the host copy into the staging buffer is what this upload costs (one thread: ~10 GB/s against the link's ~50): a few threads
+        // take contiguous runs of the segments (about equal bytes each)
+        const int n_thr = fill >= ((size_t)4 << 20) ? (int)std::min<unsigned>(4, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        auto copy_range = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) memcpy(segs[i].dst, segs[i].src, segs[i].bytes); };
+        if (n_thr <= 1) copy_range(0, segs.size());
+        else {
+          std::vector<size_t> cut((size_t)n_thr + 1, segs.size());
+          cut[0] = 0;
+          size_t acc = 0; int t = 1;
+          for (size_t i = 0; i < segs.size() && t < n_thr; ++i) { acc += segs[i].bytes; if (acc >= fill * (size_t)t / n_thr) cut[(size_t)t++] = i + 1; }
+          std::vector<std::thread> thr;
+          for (int i = 1; i < n_thr; ++i) thr.emplace_back(copy_range, cut[(size_t)i], cut[(size_t)i + 1]);
+          copy_range(cut[0], cut[1]);
+          for (auto& th : thr) th.join();
+        }
       }
       GNX_TRY(hipMemcpyAsync(static_cast<char*>(d_adj) + done, stage[buf], fill, hipMemcpyHostToDevice, nullptr));
       GNX_TRY(hipEventRecord(stage_ev[buf], nullptr));
@@ -176,6 +204,19 @@ int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int6
   GNX_TRY(hipMalloc((void**)&d_rv, std::max<size_t>((size_t)E, 1) * sizeof(int32_t)));
   GNX_LAUNCH(k_adj_columns<true>, dim3(grid), dim3(256), 0, 0, d_adj, m, (int)N, d_cp, d_rv, d_bad);
   GNX_TRY(hipGetLastError());
+  if (keep) {
+    int32_t* d_eoff = nullptr;
+    GNX_TRY(hipMalloc((void**)&d_eoff, (G + 1) * sizeof(int32_t)));
+    GNX_LAUNCH(k_gather_offsets, dim3((unsigned)((G + 1 + 255) / 256)), dim3(256), 0, 0, d_cp, d_noff, (int)G, d_eoff);
+    keep->edge_off.resize((size_t)G + 1);
+    const hipError_t ee = hipMemcpy(keep->edge_off.data(), d_eoff, (G + 1) * sizeof(int32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d_eoff);
+    if (ee != hipSuccess) { cleanup(); return hip_fail(ee, "edge offsets"); }
+    keep->d_colptr = d_cp; keep->d_rowval = d_rv; keep->E = E;
+    d_cp = nullptr; d_rv = nullptr;  // (handed over: not freed below)
+    cleanup();
+    return GNX_OK;
+  }
   std::vector<int32_t> cp32(N + 1), rv32((size_t)E);
   GNX_TRY(hipMemcpy(cp32.data(), d_cp, (N + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
   if (E) GNX_TRY(hipMemcpy(rv32.data(), d_rv, (size_t)E * sizeof(int32_t), hipMemcpyDeviceToHost));

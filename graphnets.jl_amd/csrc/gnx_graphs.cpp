@@ -302,7 +302,7 @@ static int32_t build_wide_tables(const gnx_graphs* h) {
 
 namespace gnx {
 int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int64_t G, int32_t elem_kind, int32_t row_major,
-                            gnx::vec_i64& h_colptr, gnx::vec_i64& h_rowval, const std::vector<int64_t>& h_node_off);
+                            gnx::vec_i64& h_colptr, gnx::vec_i64& h_rowval, const std::vector<int64_t>& h_node_off, DenseCscOnDevice* keep);
 }
 
 using namespace gnx;
@@ -476,9 +476,49 @@ int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n_nodes, 
   static const int64_t dev_threshold = getenv("GNX_BUILD_DEVICE_MIN") ? atoll(getenv("GNX_BUILD_DEVICE_MIN")) : (1 << 22);
   bool built = false;
   if (total_entries >= dev_threshold) {
-    const int32_t rc = build_csc_on_device(adj, n_nodes, n_graphs, elem_kind, row_major, h->h_colptr, h->h_rowval, h->h_node_off);
+    // scan + compaction on the GPU; the CSC then STAYS there and the device builder makes the handle's tables from it (no round trip of
+    // 4 (N + E) bytes through the host, no host tiling pass).  GNX_BUILD_CSC_DEVICE=0: the CSC comes back and finalize() runs (the validator)
+    static const bool dev_tables = !(getenv("GNX_BUILD_CSC_DEVICE") && atoi(getenv("GNX_BUILD_CSC_DEVICE")) == 0);
+    DenseCscOnDevice keep;
+    const int32_t rc = build_csc_on_device(adj, n_nodes, n_graphs, elem_kind, row_major, h->h_colptr, h->h_rowval, h->h_node_off, dev_tables ? &keep : nullptr);
     if (rc != 1 && rc != GNX_OK) { delete h; return rc; }
     built = rc == GNX_OK;
+    if (built && dev_tables) {
+      struct Free { DenseCscOnDevice& k; ~Free() { (void)hipFree(k.d_colptr); (void)hipFree(k.d_rowval); } } free_keep{keep};
+      h->tile_e_cap = env_int("GNX_TILE_E", 512);
+      h->tile_n_cap = env_int("GNX_TILE_N", 128);
+      h->wtile_e_cap = env_int("GNX_WTILE_E", 128);
+      if (h->wtile_e_cap != 64 && h->wtile_e_cap != 128 && h->wtile_e_cap != 256) h->wtile_e_cap = 128;
+      h->h_edge_off.assign(keep.edge_off.begin(), keep.edge_off.end());
+      h->N = h->h_node_off.back();
+      h->E = keep.E;
+      int64_t tb = 0, wb = 0, per_graph = 1;
+      for (int64_t g = 0; g < n_graphs; ++g) {
+        const int64_t n = n_nodes[g], eg = h->h_edge_off[(size_t)g + 1] - h->h_edge_off[(size_t)g];
+        const int64_t bt_g = std::min(n, n / h->tile_n_cap + 2 * eg / h->tile_e_cap + 2), bw_g = std::min(n, n / 64 + 2 * eg / h->wtile_e_cap + 2);
+        tb += bt_g; wb += bw_g;
+        per_graph = std::max(per_graph, std::max(bt_g, bw_g));
+      }
+      if (h->N >= (int64_t)INT32_MAX || h->E >= (int64_t)INT32_MAX) { delete h; return fail(GNX_ERR_TOO_LARGE, "graph batch exceeds int32 device indices"); }
+      hipError_t de = hipGetDevice(&h->device);
+      if (de != hipSuccess) { delete h; return hip_fail(de, "hipGetDevice"); }
+      fill_wide_counts(h);
+      bt.lap("dense -> csc (device, kept there)");
+      const int32_t rc2 = build_handle_from_csc_on_device(h, keep.d_colptr, keep.d_rowval, 0, 0 /* device-resident global int32 CSC */, h->tile_e_cap, h->tile_n_cap,
+                                                          h->wtile_e_cap, tb, wb, per_graph);
+      bt.lap("tables (device)");
+      if (rc2 == GNX_OK) { *out = h; return GNX_OK; }
+      if (rc2 != 1) { gnx_graphs_destroy(h); return rc2; }
+      // not applicable there (scan capacity): bring the CSC to the host after all
+      if (h->d_arena) { arena_give(h->device, h->d_arena, h->arena_bytes); h->d_arena = nullptr; }
+      gnx::vec_i32 c32((size_t)h->N + 1), r32((size_t)h->E);
+      hipError_t e1 = hipMemcpy(c32.data(), keep.d_colptr, c32.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+      if (e1 == hipSuccess && h->E) e1 = hipMemcpy(r32.data(), keep.d_rowval, r32.size() * sizeof(int32_t), hipMemcpyDeviceToHost);
+      if (e1 != hipSuccess) { delete h; return hip_fail(e1, "dense batch: CSC to the host"); }
+      h->h_colptr.assign(c32.begin(), c32.end());
+      h->h_rowval.assign(r32.begin(), r32.end());
+      h->h_edge_off.clear();
+    }
   }
   if (built) {
     for (int64_t g = 0; g <= n_graphs; ++g) h->h_edge_off.push_back(h->h_colptr[(size_t)h->h_node_off[g]]);

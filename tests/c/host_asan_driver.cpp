@@ -20,7 +20,7 @@ template <int C, bool ONEG> __global__ void k_graph_t(BlockArgs a, int n) {} }
 
 namespace gnx {
 int32_t build_csc_on_device(const void* const*, const int64_t*, int64_t, int32_t, int32_t, gnx::vec_i64&, gnx::vec_i64&,
-                            const std::vector<int64_t>&) {
+                            const std::vector<int64_t>&, DenseCscOnDevice*) {
   return fail(100, "stub: no device");
 }
 void* arena_take(int, size_t, size_t*) { return nullptr; }

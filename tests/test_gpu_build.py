@@ -24,6 +24,7 @@ CASES = {
     "hetero_4096": dict(kind="hetero", seed=5, G=4096, E=1_000_000),
     "hetero_dense": dict(kind="hetero", seed=11, G=300, E=2_000_000),   # in-degrees up to ~190: single-node tiles, wave tiles on the edge cap
     "edgeless_mix": dict(kind="mix"),
+    "dense_uint8_600": dict(kind="dense", seed=13, G=600, E=400_000),   # the reference's own input form: dense 0/1 matrices (>= 2^22 entries: scan + compaction on the GPU)
 }
 
 
@@ -45,9 +46,19 @@ def _tables(spec, index_dtype="int64"):
     """sha-free: the raw bytes of the nine device tables + the handle's info, as a dict of numpy arrays"""
     import graphnets_jl_amd as gn
     lib = gn._lib.load()
-    colptrs, rowvals, nn = _graphs(spec)
-    cat = lambda parts: np.concatenate(parts).astype(index_dtype)
-    g = gn.GNGraphBatch.from_csc_packed(cat(colptrs), cat(rowvals), nn)
+    if spec["kind"] == "dense":
+        colptrs, rowvals, nn = bench.make_hetero(spec["seed"], spec["G"], spec["E"])
+        adjs = []
+        for cp, rv, n in zip(colptrs, rowvals, nn):
+            a = np.zeros((n, n), dtype=np.uint8 if index_dtype == "int64" else np.float32)  # (two element kinds in place of the two index widths)
+            a[rv, np.repeat(np.arange(n), np.diff(cp))] = 1
+            adjs.append(a)
+        assert sum(a.size for a in adjs) >= 1 << 22
+        g = gn.GNGraphBatch(adjs)
+    else:
+        colptrs, rowvals, nn = _graphs(spec)
+        cat = lambda parts: np.concatenate(parts).astype(index_dtype)
+        g = gn.GNGraphBatch.from_csc_packed(cat(colptrs), cat(rowvals), nn)
     out = {}
     for which, name in enumerate(("colptr", "rowval", "node_off", "edge_off", "tile_off", "tiles", "wtile_off", "wtiles", "packs")):
         n = C.c_int64(0)
