@@ -179,7 +179,7 @@ __device__ __forceinline__ void core_post_s_body(const float* __restrict__ x, si
       if constexpr (TRANS) act_row<D>(o, fc2.act);
       else if (fc2.act == 1) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) o[k] = fmaxf(o[k], 0.f);
+        for (int k = 0; k < D; ++k) o[k] = relu_f(o[k]);
       }
 #pragma unroll
       for (int k = 0; k < D; ++k) o[k] = rs[m][k] + o[k];

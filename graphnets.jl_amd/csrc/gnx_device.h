@@ -69,10 +69,19 @@ struct BlockArgs {
   int prev_blocks;
 };
 
+// relu as ONE v_max_f32.  fmaxf(x, 0.f) compiles to two under the default IEEE mode: a canonicalising v_max_f32 x, x, x in front of the
+// maximum whenever the compiler cannot see that x is the result of an arithmetic instruction (the packed FMAs of the streamed products are
+// inline asm) — 125 of the 3 700 vector instructions of the narrow core kernel.  (NaN: v_max_f32 returns the other operand, as fmaxf does.)
+__device__ __forceinline__ float relu_f(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 // activation codes = GNX_ACT_* of include/gnx.h (static_assert'ed in gnx_forward.hip)
 __device__ __forceinline__ float act_apply(float x, int act) {
   switch (act) {
-    case 1: return fmaxf(x, 0.f);
+    case 1: return relu_f(x);
     case 2: return tanhf(x);
     case 3: return 1.f / (1.f + expf(-x));
     case 4: return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));  // NNlib.gelu (tanh form)

@@ -45,7 +45,8 @@ static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R,
       (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_wave_dbg), &d_dbg, sizeof(d_dbg), 0, hipMemcpyHostToDevice, s);
     }
 #endif
-    GNX_LAUNCH((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG, false, FFE, CHAIN>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, n_rows);
+    if constexpr (FFE) GNX_LAUNCH((k_block_wave_ffe<DE, DN, DG, OE, ON, EPT, ONEG>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, n_rows);
+    else GNX_LAUNCH((k_block_wave<DE, DN, DG, OE, ON, EPT, LN, ONEG, false, false, CHAIN>), dim3(grid, (unsigned)R), dim3(kThreads), 0, s, a, n_rows);
     GNX_HIP(hipGetLastError());
 #ifdef GNX_WAVE_STAMPS_BUILD
     if (dump) {

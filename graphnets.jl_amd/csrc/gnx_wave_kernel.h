@@ -67,7 +67,7 @@ __device__ __forceinline__ void act_row(float (&v)[N], int act) {
     case 0: break;
     case 1:
 #pragma unroll
-      for (int j = 0; j < N; ++j) v[j] = fmaxf(v[j], 0.f);
+      for (int j = 0; j < N; ++j) v[j] = relu_f(v[j]);
       break;
     default:
 #pragma unroll
@@ -279,8 +279,14 @@ struct CorePostStream {
   __device__ __forceinline__ void consume(const SGroup<HB>& cur) {
     constexpr int i = GI % NG;
     if constexpr (i == 0) {
+      // h[j] = (b[j], b[j]): ONE v_pk_mov_b32 per hidden unit — both halves of the destination from the low (op_sel 0,0) or the high
+      // (op_sel 1,1) half of the SGPR pair that holds b[2q], b[2q+1] (one unique scalar operand: within the constant-bus limit)
 #pragma unroll
-      for (int j = 0; j < HB; ++j) { const float b = cur.get(j); h[j].x = b; h[j].y = b; }
+      for (int q = 0; q < HB / 2; ++q) {
+        const v2f_t w = cur.pair(q);
+        asm("v_pk_mov_b32 %0, %1, %1" : "=v"(h[2 * q]) : "s"(w));
+        asm("v_pk_mov_b32 %0, %1, %1 op_sel:[1,1]" : "=v"(h[2 * q + 1]) : "s"(w));
+      }
       pin_pairs<HB>(h);
     } else if constexpr (i <= D) {
       constexpr int k = i - 1;
@@ -303,7 +309,7 @@ struct CorePostStream {
           for (int j = 0; j < HB; ++j) h[j].y = t[j];
         } else if (act1 == 1) {
 #pragma unroll
-          for (int j = 0; j < HB; ++j) { h[j].x = fmaxf(h[j].x, 0.f); h[j].y = fmaxf(h[j].y, 0.f); }
+          for (int j = 0; j < HB; ++j) { h[j].x = relu_f(h[j].x); h[j].y = relu_f(h[j].y); }
         }
       }
       pin_pairs<HB>(h);
@@ -339,8 +345,9 @@ struct CorePostStream {
 };
 
 // xhat = (x - mu) * rstd over the D registers of a row; eps_mode 0: 1/(sigma+eps) (Flux 0.14 normalise), 1: 1/sqrt(var+eps)
+// (mu_o, rstd_o: the row's statistics for a caller that needs x-hat of the SAME row again — (x - mu) * rstd repeats the two operations below, hence the bits)
 template <int D>
-__device__ __forceinline__ void normalise(float (&x)[D], float eps, int eps_mode) {
+__device__ __forceinline__ void normalise_s(float (&x)[D], float eps, int eps_mode, float& mu_o, float& rstd_o) {
   // (instruction count matters: these kernels are VALU-bound at core widths and an IEEE division is ~10 instructions.  The run-time eps
   // convention selects the ARGUMENT of one square root and one division — written as `mode ? 1/(sqrt(v)+eps) : 1/sqrt(v+eps)` the compiler
   // evaluates both sides and selects: two square roots and two divisions per row.  The two means stay divisions by D: as products with
@@ -359,12 +366,20 @@ __device__ __forceinline__ void normalise(float (&x)[D], float eps, int eps_mode
   const float rstd = 1.f / sd;
 #pragma unroll
   for (int k = 0; k < D; ++k) x[k] *= rstd;
+  mu_o = mu; rstd_o = rstd;
+}
+template <int D>
+__device__ __forceinline__ void normalise(float (&x)[D], float eps, int eps_mode) {
+  float mu, rstd;
+  normalise_s<D>(x, eps, eps_mode, mu, rstd);
 }
 // LayerNorm of a register row with scalar-operand affine parameters (gngraphnorm.jl:19-26)
 template <int D>
-__device__ __forceinline__ void ln_row(float (&x)[D > 0 ? D : 1], const float* g, const float* b, float eps, int eps_mode) {
+__device__ __forceinline__ void ln_row(float (&x)[D > 0 ? D : 1], const float* g, const float* b, float eps, int eps_mode, float* stats = nullptr) {
   if constexpr (D > 0) {
-    normalise<D>(x, eps, eps_mode);
+    float mu, rstd;
+    normalise_s<D>(x, eps, eps_mode, mu, rstd);
+    if (stats) { stats[0] = mu; stats[1] = rstd; }
     const cfloatp gc = as_const(g), bc = as_const(b);
 #pragma unroll
     for (int k = 0; k < D; ++k) x[k] = fmaf(gc[k], x[k], bc[k]);
@@ -619,8 +634,27 @@ constexpr int kPackThreads = 512;
 // the graph update of the PREVIOUS call (graph_update_rows over ITS partial rows: one workgroup for a one-graph batch, one wavefront per
 // graph otherwise), the rest are this call's tiles.  In a loop over batches the second launch of every step disappears (an empty launch is
 // ~4 us of a ~25-us step).  A template parameter: the plain kernel keeps its registers (58 at README widths) and has no barrier.
-template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false, bool PACK = false, bool FFE = false, bool CHAIN = false>
-__global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_SGPRS))) void k_block_wave(BlockArgs a, int n_rows) {
+// (The body is a device function so that the kernel can exist under two resource limits: k_block_wave with the 80-SGPR cap that buys the eighth
+// workgroup per CU, k_block_wave_ffe without it — at its 120+ vector registers a CU holds four workgroups whatever the scalar count, and under
+// the cap that form kept ~70 scalars in lanes of a vector register: a v_readlane_b32, often with an s_nop behind it, per use.)
+// The kernel's arguments for one PHASE of the body.  FRESH: a pointer into the kernel-argument segment that the compiler cannot connect to the
+// argument loads of another phase (kernel arguments are lowered to scalar loads at the top of the kernel and then LIVE to their last use: in the
+// FFE form ~60 of them waited in lanes of a vector register, a v_writelane_b32 and one v_readlane_b32 per use each — vector instructions in a
+// kernel bound by their issue; a second s_load_dword is free there).  Otherwise the kernel's own copy.
+typedef const BlockArgs __attribute__((address_space(4))) * cargsp;
+template <bool FRESH>
+__device__ __forceinline__ auto phase_args(const BlockArgs& a) {
+  if constexpr (FRESH) {
+    cargsp p = (cargsp)__builtin_amdgcn_kernarg_segment_ptr();  // (BlockArgs is the kernel's first argument)
+    asm volatile("" : "+s"(p));
+    return p;
+  } else {
+    return &a;
+  }
+}
+
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN, bool ONEG, bool PACK, bool FFE, bool CHAIN>
+__device__ __forceinline__ void block_wave_body(BlockArgs& a, int n_rows) {
   static_assert(!(PACK && ONEG), "packs are for batches of several graphs");
   static_assert(!CHAIN || (!PACK && !FFE && !LN && OE + ON > 0), "CHAIN: the two-launch form of a plain block");
   static_assert(!FFE || (LN && DE == OE && DE > 0 && EPT == 2 && (DE + DN) * OE > 96 && ((DE + DN) * OE) % 2 == 0 && GNX_WAVE_PK && !PACK),
@@ -676,40 +710,40 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
   // FFE: the raw edge rows and ef' of the lane's two edges, kept until the end of the kernel (the FeedForward runs LAST, when nothing of
   // the node phase is live any more: 100 of its ~125 registers are its own)
   float xr[FFE ? EPT : 1][FFE ? DE1 : 1];
+  float xst[2 * EPT];  // FFE: (mean, 1/sigma) of the lane's edge rows from gn1 — gn2 normalises the same rows (parked in the wave's slice beside the rows)
+#pragma unroll
+  for (int i = 0; i < 2 * EPT; ++i) xst[i] = 0.f;
   bool ffv[EPT];
   size_t ff_row0 = 0;
 #pragma unroll
   for (int i = 0; i < EPT; ++i) ffv[i] = false;
   do {
   if constexpr (ONEG || PACK) { if (!active) break; }
+  const auto A0 = phase_args<FFE>(a);  // tile record, loads, LayerNorm of the node-side rows
   float* s_out = s_mem + wv * WSL;                                        // ef' of the wave's tile
   float* s_pd = s_out + (TEW * OE + 4);                                   // per node: bias' + We[:, dst-seg]*nf[n]
   unsigned char* s_dst = reinterpret_cast<unsigned char*>(s_pd + (64 * OE + 4));  // tile-local destination of each edge
 
-  const cintp tw = reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.wtiles)) + (size_t)wt * (sizeof(Tile) / sizeof(int));
+  const cintp tw = reinterpret_cast<cintp>(reinterpret_cast<size_t>(A0->wtiles)) + (size_t)wt * (sizeof(Tile) / sizeof(int));
   const int n0 = tw[0], n1 = tw[1], e0 = tw[2], e1 = tw[3], g = tw[4];  // s_load_dwordx8
   if constexpr (PACK) {
     tile_g = g; tile_cnt = tw[7];
-    const cintp pk = reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.packs)) + (size_t)xcd_tile(bx, gx) * WAVES;
+    const cintp pk = reinterpret_cast<cintp>(reinterpret_cast<size_t>(A0->packs)) + (size_t)xcd_tile(bx, gx) * WAVES;
     const int wprev = wv > 0 ? pk[wv > 0 ? wv - 1 : 0] : -1;  // (a graph's first tile never follows an empty slot: slots fill from the left)
-    owner = wprev < 0 || (reinterpret_cast<cintp>(reinterpret_cast<size_t>(a.wtiles)) + (size_t)wprev * (sizeof(Tile) / sizeof(int)))[4] != g;
+    owner = wprev < 0 || (reinterpret_cast<cintp>(reinterpret_cast<size_t>(A0->wtiles)) + (size_t)wprev * (sizeof(Tile) / sizeof(int)))[4] != g;
   }
   const int nn = n1 - n0, ne = e1 - e0;
   GNX_WSTAMP(1);  // (the stamp's own s_waitcnt lgkmcnt(0) makes this "tile record arrived")
 
   const size_t r = blockIdx.y;
-  const float* __restrict__ ef = DE > 0 ? a.ef + r * (size_t)a.E * DE : nullptr;
-  const float* __restrict__ nf = DN > 0 ? a.nf + r * (size_t)a.N * DN : nullptr;
-  const cfloatp gf = DG > 0 ? as_const(a.gf + (r * (size_t)a.G + g) * DG) : nullptr;
-  const cfloatp We = as_const(a.We);
-  const cfloatp Wn = as_const(a.Wn);
-  const cfloatp be = as_const(a.be ? a.be : k_zero_bias);
-  const cfloatp bn = as_const(a.bn ? a.bn : k_zero_bias);
+  const float* __restrict__ ef = DE > 0 ? A0->ef + r * (size_t)A0->E * DE : nullptr;
+  const float* __restrict__ nf = DN > 0 ? A0->nf + r * (size_t)A0->N * DN : nullptr;
+  const cfloatp gf = DG > 0 ? as_const(A0->gf + (r * (size_t)A0->G + g) * DG) : nullptr;
 
   // ---- issue every load up front, branch-free (indices clamped into the tile; results of clamped lanes unused) ----
   const bool is_node = lane < nn;
   const int nl = lane < nn ? lane : nn - 1;
-  const int cp0 = a.colptr[n0 + nl], cp1 = a.colptr[n0 + nl + 1];
+  const int cp0 = A0->colptr[n0 + nl], cp1 = A0->colptr[n0 + nl + 1];
   float xn[1][DN1];
   if constexpr (DN > 0) load_row<DN>(nf + (size_t)(n0 + nl) * DN, xn[0]);
   const int cn0 = ne < TEW ? ne : TEW;
@@ -730,9 +764,9 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
     int ec = lane + 64 * i;
     ec = ec < cn0 ? ec : cn0 - 1;
     int e = e0 + (ec > 0 ? ec : 0);
-    e = e < a.E ? e : a.E - 1;
+    e = e < A0->E ? e : A0->E - 1;
     if constexpr (DE > 0) load_row<DE>(ef + (size_t)e * DE, x[i]);
-    if constexpr (DN > 0) src[i] = a.rowval[e];
+    if constexpr (DN > 0) src[i] = A0->rowval[e];
   }
   if constexpr (DN > 0) {
 #pragma unroll
@@ -742,10 +776,13 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
 #pragma unroll
   for (int k = 0; k < DG; ++k) gfr[0][k] = gf[k];
   if constexpr (LN) {  // gn1(x) applied in registers: rows are normalised as they arrive (gathered rows once per edge)
-    ln_row<DN>(xn[0], a.ln_g[1], a.ln_b[1], a.ln_eps, a.ln_mode);
-    ln_row<DG>(gfr[0], a.ln_g[2], a.ln_b[2], a.ln_eps, a.ln_mode);
+    ln_row<DN>(xn[0], A0->ln_g[1], A0->ln_b[1], A0->ln_eps, A0->ln_mode);
+    ln_row<DG>(gfr[0], A0->ln_g[2], A0->ln_b[2], A0->ln_eps, A0->ln_mode);
   }  // (the edge rows and the gathered rows are normalised at the start of the edge phase: their loads are still in flight)
   GNX_WSTAMP(2);  // every load issued
+  const auto A1 = phase_args<FFE>(a);  // node-side preparation + edge phase
+  const cfloatp We = as_const(A1->We);
+  const cfloatp be = as_const(A1->be ? A1->be : k_zero_bias);
   // ---- lanes as nodes: destination index of each in-edge, per-node part of the edge update ----
   //   pd[n] = be + We[:, gf-seg] * gf[g] + We[:, dst-seg] * nf[n]      (edgefninput.jl:5-6 hoisted out of the edge loop)
   if (is_node) {
@@ -778,7 +815,7 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
         const int e = e0 + c0 + ec;
         if constexpr (DE > 0) load_row<DE>(ef + (size_t)e * DE, x[i]);
         if constexpr (DN > 0) {
-          src[i] = a.rowval[e];
+          src[i] = A1->rowval[e];
           load_row<DN>(nf + (size_t)src[i] * DN, xs[i]);
         }
         if constexpr (FFE) {
@@ -786,8 +823,8 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
           for (int k = 0; k < DE; ++k) xr[i][k] = x[i][k];
         }
         if constexpr (LN) {
-          ln_row<DE>(x[i], a.ln_g[0], a.ln_b[0], a.ln_eps, a.ln_mode);
-          ln_row<DN>(xs[i], a.ln_g[1], a.ln_b[1], a.ln_eps, a.ln_mode);
+          ln_row<DE>(x[i], A1->ln_g[0], A1->ln_b[0], A1->ln_eps, A1->ln_mode);
+          ln_row<DN>(xs[i], A1->ln_g[1], A1->ln_b[1], A1->ln_eps, A1->ln_mode);
         }
       }
     }
@@ -798,9 +835,11 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
           if constexpr (FFE) {
 #pragma unroll
             for (int k = 0; k < DE; ++k) xr[i][k] = x[i][k];
+            ln_row<DE>(x[i], A1->ln_g[0], A1->ln_b[0], A1->ln_eps, A1->ln_mode, &xst[2 * i]);
+          } else {
+            ln_row<DE>(x[i], A1->ln_g[0], A1->ln_b[0], A1->ln_eps, A1->ln_mode);
           }
-          ln_row<DE>(x[i], a.ln_g[0], a.ln_b[0], a.ln_eps, a.ln_mode);
-          ln_row<DN>(xs[i], a.ln_g[1], a.ln_b[1], a.ln_eps, a.ln_mode);
+          ln_row<DN>(xs[i], A1->ln_g[1], A1->ln_b[1], A1->ln_eps, A1->ln_mode);
         }
       }
     }
@@ -829,6 +868,8 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
           for (int m = 0; m < EPT; ++m)
 #pragma unroll
             for (int k = 0; k < DE; ++k) s_out[(lane + 64 * m) * OE + k] = xr[m][k];
+          // (the per-node rows s_pd were read into acc[] above — LDS operations of one wave execute in order — and are dead from here on)
+          *reinterpret_cast<v4f_t*>(s_pd + 4 * lane) = v4f_t{xst[0], xst[1], xst[2], xst[3]};
           asm volatile("" ::: "memory");
         }
 #pragma unroll
@@ -858,15 +899,15 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
       for (int i = 0; i < EPT; ++i) {
         const int el = lane + 64 * i;
         if constexpr (FFE) {  // (identity / relu only: the transcendental expansions of the run-time switch cost registers on every path)
-          if (a.act_e == 1) {
+          if (A1->act_e == 1) {
 #pragma unroll
-            for (int j = 0; j < OE; ++j) acc[i][j] = fmaxf(acc[i][j], 0.f);
+            for (int j = 0; j < OE; ++j) acc[i][j] = relu_f(acc[i][j]);
           }
         } else {
-          act_row<OE1>(acc[i], a.act_e);
+          act_row<OE1>(acc[i], A1->act_e);
         }
         if (valid[i]) {
-          if constexpr (!FFE) store_row<OE>(a.ef_out + (r * (size_t)a.E + e0 + c0 + el) * OE, acc[i]);
+          if constexpr (!FFE) store_row<OE>(A1->ef_out + (r * (size_t)A1->E + e0 + c0 + el) * OE, acc[i]);
           if (nn > 1 || FFE) {
 #pragma unroll
             for (int j = 0; j < OE; ++j) s_out[el * OE + j] = acc[i][j];
@@ -880,7 +921,7 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
       if constexpr (FFE) {  // (the host launches this form only for batches without a node of more than 64 * EPT in-edges: one chunk per tile)
 #pragma unroll
         for (int m = 0; m < EPT; ++m) ffv[m] = valid[m];
-        ff_row0 = r * (size_t)a.E + e0 + c0 + lane;
+        ff_row0 = r * (size_t)A1->E + e0 + c0 + lane;
       }
     } else
     if constexpr (OE > 0) {
@@ -900,8 +941,8 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
           for (int k = 0; k < DN; ++k)
 #pragma unroll
             for (int j = 0; j < OE; ++j) acc[j] = fmaf(We[(DE + k) * OE + j], xs[i][k], acc[j]);
-          act_row<OE1>(acc, a.act_e);
-          store_row<OE>(a.ef_out + (r * (size_t)a.E + e0 + c0 + el) * OE, acc);
+          act_row<OE1>(acc, A1->act_e);
+          store_row<OE>(A1->ef_out + (r * (size_t)A1->E + e0 + c0 + el) * OE, acc);
           if (nn > 1) {
 #pragma unroll
             for (int j = 0; j < OE; ++j) s_out[el * OE + j] = acc[j];
@@ -912,9 +953,13 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
         }
       }
     }
+    if constexpr (FFE) break;  // (one chunk per tile: the launcher's condition — the reload path and what it keeps alive are not compiled)
   }
   __builtin_amdgcn_wave_barrier();
   GNX_WSTAMP(4);  // edge phase done (needed ef rows, rowval, gathered rows; ef' stores issued)
+  const auto A2 = phase_args<FFE>(a);  // node phase
+  const cfloatp Wn = as_const(A2->Wn);
+  const cfloatp bn = as_const(A2->bn ? A2->bn : k_zero_bias);
 
   // ---- lanes as nodes: edge->node sum (nodefninput.jl:3), node update ----
   float v[C1];  // per-lane contribution to the tile's graph-level partial sums: [agg ; nf']
@@ -946,16 +991,16 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
       for (int k = 0; k < OE; ++k) vin[0][k] = v[k];
       fma_rows<OE, ON, 1, OE1>(Wn, vin, acc1);
       fma_rows<DN, ON, 1, DN1>(Wn + OE * ON, xn, acc1);
-      act_row<ON1>(acc, a.act_n);
+      act_row<ON1>(acc, A2->act_n);
 #pragma unroll
       for (int j = 0; j < ON; ++j) v[OE + j] = acc[j];
-      store_row<ON>(a.nf_out + (r * (size_t)a.N + n0 + lane) * ON, acc);
+      store_row<ON>(A2->nf_out + (r * (size_t)A2->N + n0 + lane) * ON, acc);
     }
   }
 
   // ---- per-tile partial sums for the graph update (graphfninput.jl:3-4): sum_e ef' = sum_n agg[n], sum_n nf'.
   //      Stored transposed [c][tile] so the graph update reads them with 16-B loads. ----
-  if (a.og > 0) {
+  if (A2->og > 0) {
     if constexpr (C > 0) {
       float sel[(C + 15) / 16];
 #pragma unroll
@@ -989,11 +1034,12 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
     o[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);  // XCC_ID, HW_ID
   }
 #endif
-  if (a.og > 0) {
+  const auto A3 = phase_args<FFE>(a);
+  if (A3->og > 0) {
     if constexpr (C > 0) {
       const size_t r = blockIdx.y;
       constexpr int CP = (C + 3) / 4 * 4;
-      float* __restrict__ pbase = a.partials + r * (size_t)n_rows * CP;
+      float* __restrict__ pbase = A3->partials + r * (size_t)n_rows * CP;
       if constexpr (PACK) {
         __shared__ float s_rows[WAVES][C1];
         if (lane < C) s_rows[wv][lane] = active ? mine : 0.f;
@@ -1024,17 +1070,26 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
   if constexpr (FFE) {
     if (active) {
       // y = (x + ef') + (b2 + W2 act1(W1 gn2(x) + b1)) for the lane's two edges: k_core_post_s's body, fed from registers
+      // (its arguments are read from the kernel-argument segment HERE, through a pointer the compiler cannot connect to the loads at the top
+      // of the kernel: held from there, these ~20 scalars sit in lanes of a vector register across the whole block part)
+      const auto ka = phase_args<true>(a);
+      const float* const ffe_b1 = ka->ffe_b1;
+      const float* const ffe_b2 = ka->ffe_b2;
+      const int ffe_act2 = ka->ffe_act2;
+      float* const ef_out_t = ka->ef_out;
       P2 z[DE1], acc2[DE1];
-      CorePostStream<DE1, false> fs{as_const(a.ffe_w1), as_const(a.ffe_w2), as_const(a.ffe_b1 ? a.ffe_b1 : k_zero_bias), a.ffe_act1, z, acc2};
+      CorePostStream<DE1, false> fs{as_const(ka->ffe_w1), as_const(ka->ffe_w2), as_const(ffe_b1 ? ffe_b1 : k_zero_bias), ka->ffe_act1, z, acc2};
       fs.G0.issue(fs.template group_ptr<0>());
-      const cfloatp b2 = as_const(a.ffe_b2 ? a.ffe_b2 : k_zero_bias), g2 = as_const(a.ffe_g2), be2 = as_const(a.ffe_be2);
+      const cfloatp b2 = as_const(ffe_b2 ? ffe_b2 : k_zero_bias), g2 = as_const(ka->ffe_g2), be2 = as_const(ka->ffe_be2);
       float rs[EPT][DE1];
       const float* s_ef = s_mem + wv * WSL;  // ef' of the lane's two edges, still in the wave's slice
+      const v4f_t st4 = *reinterpret_cast<const v4f_t*>(s_ef + (TEW * OE + 4) + 4 * lane);  // (mean, 1/sigma) of the two rows, parked beside them
 #pragma unroll
       for (int m = 0; m < EPT; ++m) {
 #pragma unroll
         for (int k = 0; k < DE; ++k) rs[m][k] = xr[m][k] + s_ef[(lane + 64 * m) * OE + k];  // the two residual terms (gncore.jl:56-59)
-        normalise<DE1>(xr[m], a.ln_eps, a.ln_mode);
+#pragma unroll
+        for (int k = 0; k < DE; ++k) { xr[m][k] -= st4[2 * m]; xr[m][k] *= st4[2 * m + 1]; }  // x-hat: normalise()'s two operations on the same operands
 #pragma unroll
         for (int k = 0; k < DE; ++k) {
           const float v = fmaf(g2[k], xr[m][k], be2[k]);
@@ -1049,16 +1104,26 @@ __global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdg
         float o[DE1];
 #pragma unroll
         for (int k = 0; k < DE; ++k) o[k] = m == 0 ? acc2[k].x : acc2[k].y;
-        if (a.ffe_act2 == 1) {
+        if (ffe_act2 == 1) {
 #pragma unroll
-          for (int k = 0; k < DE; ++k) o[k] = fmaxf(o[k], 0.f);
+          for (int k = 0; k < DE; ++k) o[k] = relu_f(o[k]);
         }
 #pragma unroll
         for (int k = 0; k < DE; ++k) o[k] = rs[m][k] + o[k];
-        if (ffv[m]) store_row<OE>(a.ef_out + (ff_row0 + 64 * m) * OE, o);
+        if (ffv[m]) store_row<OE>(ef_out_t + (ff_row0 + 64 * m) * OE, o);
       }
     }
   }
+}
+
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool LN = false, bool ONEG = false, bool PACK = false, bool FFE = false, bool CHAIN = false>
+__global__ __launch_bounds__(PACK ? kPackThreads : kThreads) __attribute__((amdgpu_num_sgpr(GNX_WAVE_SGPRS))) void k_block_wave(BlockArgs a, int n_rows) {
+  static_assert(!FFE, "the FFE form is k_block_wave_ffe");
+  block_wave_body<DE, DN, DG, OE, ON, EPT, LN, ONEG, PACK, false, CHAIN>(a, n_rows);
+}
+template <int DE, int DN, int DG, int OE, int ON, int EPT, bool ONEG>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void k_block_wave_ffe(BlockArgs a, int n_rows) {
+  block_wave_body<DE, DN, DG, OE, ON, EPT, true, ONEG, false, true, false>(a, n_rows);
 }
 
 // Graph update for the wave path: one workgroup per graph (one wavefront when the graph has <= 256 partial rows).

@@ -116,7 +116,7 @@ __device__ __forceinline__ void act_apply_n(float* v, int act) {
     case 0: break;
     case 1:
 #pragma unroll
-      for (int j = 0; j < N; ++j) v[j] = fmaxf(v[j], 0.f);
+      for (int j = 0; j < N; ++j) v[j] = relu_f(v[j]);
       break;
     case 2:
 #pragma unroll
