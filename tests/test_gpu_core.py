@@ -144,6 +144,42 @@ def test_core_wide_layernorm_on_load_equals_materialised(gn, R, eps_mode):
         U.assert_close(U.from_jl(got), r, s, name)
 
 
+def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gn):
+    """GNCore(128,64,32): the edge FeedForward runs as k_ffn_x6 — every fp32 product as six bf16 matrix-core terms (hi/mid/lo parts hold the
+    24 mantissa bits exactly), fp32 accumulation — unless GNX_FFN_FP32=1 selects the fp32-MFMA kernel.  Against the float64 oracle both
+    must meet the 1e-5·scale bar, and the six-term form must be as accurate as the fp32 instruction: its worst and its mean error within
+    1.25 x the fp32 kernel's (measured: equal to two digits).  Inputs with a mean far from zero, weights of both signs, relu between."""
+    import os
+    rng = np.random.default_rng(5100)
+    dims = (128, 64, 32)
+    colptr, rowval = U.er_csc(rng, 900, 12000)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [900])
+    p = O.make_core_params(rng, dims)
+    ef, nf, gf = U.packed_inputs(rng, 1, 12000, 900, 1, dims)
+    ef = ef * 4.0 + 1.5
+    core = U.core_from_params(gn, p)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    ref, scale = O.core_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    out = {}
+    for which in ("x6", "fp32"):
+        if which == "fp32":
+            os.environ["GNX_FFN_FP32"] = "1"
+        try:
+            gn.profile_reset(); gn.profile_enable(True)
+            y = core(x)
+            gn.profile_enable(False)
+            names = set(gn.profile_read()); gn.profile_reset()
+        finally:
+            os.environ.pop("GNX_FFN_FP32", None)
+        assert ("k_ffn_x6" in names) == (which == "x6"), names
+        for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+            U.assert_close(U.from_jl(got), r, s, f"{which} {name}")
+        err = np.abs(U.from_jl(y.ef).astype(np.float64) - ref[0]) / scale[0]
+        out[which] = (float(err.max()), float(err.mean()))
+    print("edge FeedForward error / scale (worst, mean): six bf16 terms", out["x6"], " fp32 MFMA", out["fp32"])
+    assert out["x6"][0] <= 1.25 * out["fp32"][0] and out["x6"][1] <= 1.25 * out["fp32"][1], out
+
+
 def test_core_wide_side_stream_equals_single_stream(gn):
     """A wide GNCore forks its graph level, node projections and node FeedForward onto the handle's side stream (GNX_NO_FORK=1: one
     stream).  Same kernels, same order of every sum: the results are bit-identical — eagerly, repeatedly (a race would show as a
