@@ -17,8 +17,13 @@
 //   * only the WEIGHT fragments come from LDS — one 1-KB ds_read_b128 fragment per two MFMAs, 64 B/clk per CU of the 256 it delivers — and they
 //     get there by LDS-DMA from a copy prepared once per call in fragment order (k_ffn_x6_prep: split, transposed, slot-permuted), double-buffered
 //     per 32-unit hidden slice: one workgroup barrier per 96 MFMAs of every wave.
-// 512 threads = 8 waves x 32 rows = 256 rows per workgroup, two waves per SIMD (<= 256 registers), 96 KB of LDS: one workgroup per CU.
+// 256 threads = 4 waves x 32 rows = 128 rows per workgroup, <= 256 registers (two waves per SIMD), 74 KB of LDS: TWO workgroups per CU, so that one's
+// prologue (strided z loads, 64 splits per lane) and epilogue (residual loads, stores) run beside the other's matrix instructions — as one 8-wave
+// workgroup per CU they were 50 k of a tile's 166 k clocks with an idle matrix pipe (diagnostic build -DGNX_X6_STAMPS_BUILD).
+#include <algorithm>
 #include <cstdio>
+#include <type_traits>
+#include <vector>
 
 #include "gnx_device.h"
 
@@ -30,7 +35,7 @@ typedef __bf16 bf16x8x __attribute__((ext_vector_type(8)));
 
 namespace {
 constexpr int XR = 32;         // rows per wave
-constexpr int XW = 8;          // waves per workgroup
+constexpr int XW = 4;          // waves per workgroup
 constexpr int XBM = XR * XW;   // rows per workgroup
 constexpr int XHS = 32;        // hidden units per slice
 
@@ -90,21 +95,36 @@ struct FfnX6Args {
   const float* ln_b;
 };
 
-template <int D>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ffn_x6(FfnX6Args a) {
+#ifdef GNX_X6_STAMPS_BUILD  // diagnostic build only (tools/build_variant.sh x6st gnx_ffn_x6.hip -DGNX_X6_STAMPS_BUILD; GNX_X6_STAMPS=1): shader-clock stamps of wave 0
+static __device__ unsigned long long* g_x6_dbg = nullptr;  // [workgroup][4]
+#define GNX_XSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); xst_[i] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GNX_XSTAMP(i) do { } while (0)
+#endif
+
+// TRANS: fc1's activation is tanh / sigmoid / gelu (the run-time switch of act_apply); else identity / relu
+template <int D, bool TRANS>
+__global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ffn_x6(FfnX6Args a) {
   constexpr int H = 4 * D;
   constexpr int KS = D / 16;          // k16-steps of the first product
   constexpr int NOB = D / 32;         // 32-output blocks of the second product
   constexpr int NF = 3 * KS;          // fragments per product and slice
   constexpr int SLB = 2 * NF * 1024;  // bytes per slice
   constexpr int NSL = H / XHS;
-  static_assert((2 * NF) % XW == 0, "fragments of a slice divide over the waves");
-  // (two OBJECTS, and a slice loop unrolled by two: the compiler orders an LDS read behind every LDS-DMA that may alias it — with one array of two
-  // buffers it waits for the NEXT slice's pieces in front of this slice's first fragment read)
-  __shared__ __attribute__((aligned(16))) unsigned char s_w0[SLB];
-  __shared__ __attribute__((aligned(16))) unsigned char s_w1[SLB];
+  static_assert(NF % XW == 0, "fragments of half a slice divide over the waves");
+  // W1 and W2 fragments of a slice travel separately: while a wave multiplies slice hs + 1's W1 fragments (first product) it splits slice hs's
+  // hidden block, then multiplies it (second product) — see the loop.  ONE W1 buffer (restaged behind a barrier in the middle of the step) and two
+  // W2 buffers: 72 KB.  Three OBJECTS, and a loop unrolled by two: the compiler orders an LDS read behind every LDS-DMA that may alias it —
+  // through one array it waits for the NEXT pieces in front of this step's first fragment.
+  __shared__ __attribute__((aligned(16))) unsigned char s_w1[SLB / 2];
+  __shared__ __attribute__((aligned(16))) unsigned char s_w2a[SLB / 2];
+  __shared__ __attribute__((aligned(16))) unsigned char s_w2b[SLB / 2];
   __shared__ float s_b1[H];
 
+#ifdef GNX_X6_STAMPS_BUILD
+  unsigned long long xst_[4] = {0, 0, 0, 0};
+#endif
+  GNX_XSTAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, n = lane & 31;
   const size_t r = blockIdx.y;
@@ -115,18 +135,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const bool row_ok = row0 + n < rows;
   const float* __restrict__ zrow = a.z + (r * rows + rown) * D;
 
-  // slice 0 on its way to LDS: fragment f of the slice is LDS-DMA piece f (lane l writes bytes [16 l, 16 l + 16) of the piece)
-  auto stage = [&](int hs, unsigned char* dst) {
-    const unsigned char* src = reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)hs * SLB;
+  // fragment f of a slice is LDS-DMA piece f (lane l writes bytes [16 l, 16 l + 16) of the piece); which = 0: the W1 half of the slice, 1: the W2 half
+  auto stage = [&](int hs, int which, unsigned char* dst) {
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)hs * SLB + (size_t)which * (SLB / 2);
 #pragma unroll
-    for (int i = 0; i < 2 * NF / XW; ++i) {
+    for (int i = 0; i < NF / XW; ++i) {
       const int pc = wv + XW * i;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)pc * 1024 + lane * 16),
                                        (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
     }
   };
-  stage(0, s_w0);
-  for (int i = tid; i < H; i += 512) s_b1[i] = a.b1 ? a.b1[i] : 0.f;
+  stage(0, 0, s_w1);
+  stage(0, 1, s_w2a);
+  for (int i = tid; i < H; i += 64 * XW) s_b1[i] = a.b1 ? a.b1[i] : 0.f;
 
   // ---- the wave's z rows as B fragments: lane (n, hi) holds k = 16 s + 8 hi + j (j < 8) of row n for every k16-step s, in three parts ----
   bf16x8x zh[KS], zm[KS], zl[KS];
@@ -168,74 +189,124 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int q = 0; q < 16; ++q) accO[ob][q] = 0.f;
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of slice 0 are in LDS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of W1(0), W2(0) are in LDS
   __syncthreads();                                  // ... and everybody else's; s_b1 too
 
-  auto slice = [&](int hs, const unsigned char* cur, unsigned char* nxt) {
-    if (hs + 1 < NSL) stage(hs + 1, nxt);  // into the buffer slice hs - 1 was read from (every wave is past the barrier that ended that slice)
-    const unsigned char* wb = cur + lane * 16;
-    // ---- H^T block (the slice's 32 hidden units x the wave's 32 rows) = b1 + W1^T z^T ----
-    f32x16x accH;
+  // activation + split of ONE pair of a finished H^T block: registers q = 2 u, 2 u + 1 (q = 8 t + j: element j of the B fragment of k16-step t, slot
+  // 16 t + 8 hi + j).  Identity / relu without a branch: max with -inf / 0.
+  const float relu_floor = a.act1 == 1 ? 0.f : -__builtin_inff();
+  auto split_pair = [&](int u, const f32x16x& accH, bf16x8x (&hh)[2], bf16x8x (&hm)[2], bf16x8x (&hl)[2]) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) accH[q] = s_b1[hs * XHS + (q & 3) + 8 * (q >> 2) + 4 * hi];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const bf16x8x Ah = *reinterpret_cast<const bf16x8x*>(wb + (3 * s + 0) * 1024), Am = *reinterpret_cast<const bf16x8x*>(wb + (3 * s + 1) * 1024),
-                    Al = *reinterpret_cast<const bf16x8x*>(wb + (3 * s + 2) * 1024);
-      accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, zm[s], accH, 0, 0, 0);  // small terms first
-      accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, zh[s], accH, 0, 0, 0);
-      accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, zl[s], accH, 0, 0, 0);
-      accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, zh[s], accH, 0, 0, 0);
-      accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, zm[s], accH, 0, 0, 0);
-      accH = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, zh[s], accH, 0, 0, 0);
-    }
-    // ---- activation, split: register q = 8 t + j is element j of the B fragment of k16-step t (slot 16 t + 8 hi + j) ----
-    float hv[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) hv[q] = accH[q];
-    switch (a.act1) {
-      case 0: break;
-      case 1:
-#pragma unroll
-        for (int q = 0; q < 16; ++q) hv[q] = relu_f(hv[q]);
-        break;
-      default:
-#pragma unroll
-        for (int q = 0; q < 16; ++q) hv[q] = act_apply(hv[q], a.act1);
-        break;
-    }
-    bf16x8x hh[2], hm[2], hl[2];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int e = 0; e < 2; ++e) {
+      const int q = 2 * u + e;
+      float v = accH[q];
+      if constexpr (TRANS) v = act_apply(v, a.act1);
+      else v = __builtin_amdgcn_fmed3f(v, relu_floor, __builtin_inff());  // max(x, floor) as one instruction the scheduler can place
       __bf16 x, y, w;
-      split3x(hv[q], x, y, w);
+      split3x(v, x, y, w);
       hh[q >> 3][q & 7] = x; hm[q >> 3][q & 7] = y; hl[q >> 3][q & 7] = w;
     }
-    // ---- out^T (D outputs x the wave's rows) += W2^T[:, the slice's slots] H^T ----
+  };
+  // H^T block of slice hs (its 32 hidden units x the wave's 32 rows) = b1 + W1^T z^T into accN — and, between its matrix instructions, activation
+  // and split of the FINISHED block accC (SPLIT): two independent streams in one schedule.  Per k16-step: the next step's three weight fragments
+  // requested, six MFMAs, one pair split (~12 vector instructions): each matrix instruction is followed by its two — issued while the pipe works on
+  // it.  (Left to the compiler the split is one block of ~100 vector instructions between the two products, in front of an idle matrix pipe in
+  // BOTH waves of the SIMD: they run in step, one barrier per slice.)
+  auto gemm1 = [&](auto split_c, int hs, const unsigned char* w1, f32x16x& accN, const f32x16x& accC, bf16x8x (&hh)[2], bf16x8x (&hm)[2], bf16x8x (&hl)[2]) {
+    constexpr bool SPLIT = decltype(split_c)::value;
+    const unsigned char* wb = w1 + lane * 16;
 #pragma unroll
-    for (int ob = 0; ob < NOB; ++ob) {
+    for (int q = 0; q < 16; ++q) accN[q] = s_b1[hs * XHS + (q & 3) + 8 * (q >> 2) + 4 * hi];
+    bf16x8x A[2][3];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int f = NF + 3 * (2 * ob + t);
-        const bf16x8x Ah = *reinterpret_cast<const bf16x8x*>(wb + (f + 0) * 1024), Am = *reinterpret_cast<const bf16x8x*>(wb + (f + 1) * 1024),
-                      Al = *reinterpret_cast<const bf16x8x*>(wb + (f + 2) * 1024);
-        accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, hm[t], accO[ob], 0, 0, 0);
-        accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, hh[t], accO[ob], 0, 0, 0);
-        accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, hl[t], accO[ob], 0, 0, 0);
-        accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, hh[t], accO[ob], 0, 0, 0);
-        accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, hm[t], accO[ob], 0, 0, 0);
-        accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, hh[t], accO[ob], 0, 0, 0);
+    for (int p3 = 0; p3 < 3; ++p3) A[0][p3] = *reinterpret_cast<const bf16x8x*>(wb + p3 * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int c = s & 1;
+      if (s + 1 < KS) {
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * (s + 1) + p3) * 1024);
       }
+      accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zm[s], accN, 0, 0, 0);  // small terms first
+      accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][2], zh[s], accN, 0, 0, 0);
+      accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zl[s], accN, 0, 0, 0);
+      accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zh[s], accN, 0, 0, 0);
+      accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zm[s], accN, 0, 0, 0);
+      accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zh[s], accN, 0, 0, 0);
+      if constexpr (SPLIT) split_pair(s, accC, hh, hm, hl);
+      if (s + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (SPLIT) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of slice hs + 1 have landed
-    __syncthreads();                                  // every wave is done with slice hs; slice hs + 1 is complete
+  };
+  // out^T (D outputs x the wave's rows) += W2^T[:, the slice's slots] H^T
+  auto gemm2 = [&](const unsigned char* w2, const bf16x8x (&hh)[2], const bf16x8x (&hm)[2], const bf16x8x (&hl)[2]) {
+    const unsigned char* wb = w2 + lane * 16;
+    bf16x8x A[2][3];  // the fragments of group g + 1 are requested in front of the six MFMAs of group g (g = 2 ob + t)
+#pragma unroll
+    for (int p3 = 0; p3 < 3; ++p3) A[0][p3] = *reinterpret_cast<const bf16x8x*>(wb + p3 * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 2 * NOB; ++g) {
+      const int c = g & 1, ob = g >> 1, t = g & 1;
+      if (g + 1 < 2 * NOB) {
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * (g + 1) + p3) * 1024);
+      }
+      accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], hm[t], accO[ob], 0, 0, 0);
+      accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][2], hh[t], accO[ob], 0, 0, 0);
+      accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], hl[t], accO[ob], 0, 0, 0);
+      accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], hh[t], accO[ob], 0, 0, 0);
+      accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], hm[t], accO[ob], 0, 0, 0);
+      accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], hh[t], accO[ob], 0, 0, 0);
+      if (g + 1 < 2 * NOB) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  GNX_XSTAMP(1);  // prologue done: z rows split, first weight pieces in LDS
+  static_assert(KS == 8, "one pair of the 16 hidden registers is split per k16-step of the first product");
+  f32x16x accA, accB;  // H^T blocks: the one being produced and the one being consumed, alternating
+  {
+    bf16x8x hh[2], hm[2], hl[2];
+    gemm1(std::false_type{}, 0, s_w1, accA, accA, hh, hm, hl);
+  }
+  __syncthreads();  // every wave is done with W1(0)
+  stage(1, 0, s_w1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // step hs:  W2(hs + 1) requested  |  first product of slice hs + 1 (W1 buffer) with the split of slice hs between its MFMAs  |  barrier: W1 buffer
+  //           free -> W1(hs + 2) requested  |  second product of slice hs (W2 from w2c)  |  the requests have landed, barrier
+  auto step = [&](int hs, const unsigned char* w2c, unsigned char* w2s, f32x16x& accC, f32x16x& accN) {
+    stage(hs + 1, 1, w2s);
+    bf16x8x hh[2], hm[2], hl[2];
+    gemm1(std::true_type{}, hs + 1, s_w1, accN, accC, hh, hm, hl);
+    __syncthreads();
+    if (hs + 2 < NSL) stage(hs + 2, 0, s_w1);
+    gemm2(w2c, hh, hm, hl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   };
   static_assert(NSL % 2 == 0, "slice loop unrolled by two");
-  for (int hs = 0; hs < NSL; hs += 2) {
-    slice(hs, s_w0, s_w1);
-    slice(hs + 1, s_w1, s_w0);
+  for (int hs = 0; hs + 2 < NSL; hs += 2) {
+    step(hs, s_w2a, s_w2b, accA, accB);
+    step(hs + 1, s_w2b, s_w2a, accB, accA);
+  }
+  step(NSL - 2, s_w2a, s_w2b, accA, accB);
+  {  // the last slice: nothing left to produce
+    bf16x8x hh[2], hm[2], hl[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) split_pair(u, accB, hh, hm, hl);
+    gemm2(s_w2b, hh, hm, hl);
   }
 
+  GNX_XSTAMP(2);  // all slices done
   // ---- epilogue from the C/D layout: lane (n, hi) holds outputs 32 ob + 8 g + 4 hi + (0..3) of its row in registers 4 g .. 4 g + 3 —
   //      one 16-byte access per (ob, g), the two lane halves of a row adjacent ----
   float* __restrict__ orow = a.out + (r * rows + rown) * D;
@@ -262,6 +333,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (row_ok) *reinterpret_cast<f32x4x*>(orow + c) = v;
     }
   }
+#ifdef GNX_X6_STAMPS_BUILD
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GNX_XSTAMP(3);
+  if (g_x6_dbg && tid == 0 && blockIdx.y == 0) {
+    unsigned long long* o = g_x6_dbg + (size_t)blockIdx.x * 4;
+    o[0] = xst_[1] - xst_[0]; o[1] = xst_[2] - xst_[1]; o[2] = xst_[3] - xst_[2]; o[3] = xst_[0];
+  }
+#endif
 }
 
 size_t ffn_x6_scratch_bytes(int d) { return (size_t)3 * d * 4 * d * sizeof(__bf16) * 2; }
@@ -290,9 +369,33 @@ int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, co
   FfnX6Args a{};
   a.z = z; a.Wp = Wp; a.b1 = ff.fc1.bias; a.b2 = ff.fc2.bias; a.add1 = add1; a.add2 = add2; a.out = out; a.rows = nrows; a.act1 = ff.fc1.act;
   if (ln_stats) { a.ln_stats = ln_stats; a.ln_g = ln->gamma; a.ln_b = ln->beta; }
+#ifdef GNX_X6_STAMPS_BUILD
+  static unsigned long long* d_dbg = nullptr;
+  static size_t dbg_cap = 0;
+  const bool stamps = getenv("GNX_X6_STAMPS") != nullptr;
+  const size_t n_wg = (nrows + XBM - 1) / XBM;
+  if (stamps) {
+    if (dbg_cap < n_wg) { if (d_dbg) (void)hipFree(d_dbg); dbg_cap = n_wg; (void)hipMalloc((void**)&d_dbg, dbg_cap * 32); }
+    (void)hipMemsetAsync(d_dbg, 0, n_wg * 32, s);
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_x6_dbg), &d_dbg, sizeof(d_dbg), 0, hipMemcpyHostToDevice, s);
+  }
+#endif
   ProfScope ps("k_ffn_x6", s);
-  GNX_LAUNCH((k_ffn_x6<128>), dim3((unsigned)((nrows + XBM - 1) / XBM), (unsigned)R), dim3(512), 0, s, a);
+  if (ff.fc1.act > GNX_ACT_RELU) GNX_LAUNCH((k_ffn_x6<128, true>), dim3((unsigned)((nrows + XBM - 1) / XBM), (unsigned)R), dim3(64 * XW), 0, s, a);
+  else GNX_LAUNCH((k_ffn_x6<128, false>), dim3((unsigned)((nrows + XBM - 1) / XBM), (unsigned)R), dim3(64 * XW), 0, s, a);
   GNX_HIP(hipGetLastError());
+#ifdef GNX_X6_STAMPS_BUILD
+  if (stamps) {
+    (void)hipStreamSynchronize(s);
+    std::vector<unsigned long long> hs(n_wg * 4);
+    (void)hipMemcpy(hs.data(), d_dbg, hs.size() * 8, hipMemcpyDeviceToHost);
+    double m[3] = {0, 0, 0};
+    unsigned long long t_min = ~0ull, t_max = 0;
+    for (size_t i = 0; i < n_wg; ++i) { for (int j = 0; j < 3; ++j) m[j] += (double)hs[i * 4 + j]; t_min = std::min(t_min, hs[i * 4 + 3]); t_max = std::max(t_max, hs[i * 4 + 3] + hs[i * 4] + hs[i * 4 + 1] + hs[i * 4 + 2]); }
+    fprintf(stderr, "[gnx x6 stamps] %zu workgroups: per workgroup (shader clocks, wave 0): prologue %.0f  slices %.0f  epilogue %.0f;  first start -> last end %llu\n",
+            n_wg, m[0] / n_wg, m[1] / n_wg, m[2] / n_wg, t_max - t_min);
+  }
+#endif
   return GNX_OK;
 }
 
