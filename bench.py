@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFS = 157.3  # exact-f32 MFMA (v_mfma_f32_32x32x2_f32); no xf32 on gfx950
+MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16 MFMA (MI355X_MICROARCH.md); an fp32 product carried by six bf16 terms (k_ffn_x6): / 6
 NSETS = 8                  # rotating buffer sets: 8 x ~60 MB > 256 MiB Infinity Cache
 DIMS = {"readme": ((10, 5, 0), (3, 4, 5)), "core": ((128, 64, 32), (128, 64, 32)),
         "odd": ((7, 3, 2), (5, 6, 1)), "mid": ((20, 10, 4), (12, 9, 3))}  # odd: fused kernel specialised at run time (GNX_JIT=0: generic kernels); mid: generic/MFMA path
@@ -312,10 +313,22 @@ def bench_c4(args, gn, torch, dev, c_abi=None):
     tkey = "c4" if core == (128, 64, 32) else "c4_" + "-".join(map(str, core))
     sha = model_source_sha(core)
     traffic, tsrc = load_traffic(tkey, "__model__", sha)
+    # The roof of the model: its executed flops at the rate of the instruction that carries them.  The two edge FeedForwards at width 128 run as
+    # k_ffn_x6 — every fp32 product as six bf16 matrix-core terms with fp32 accumulation (csrc/gnx_ffn_x6.hip; as accurate as the fp32 MFMA:
+    # tests/test_gpu_core.py) — unless GNX_FFN_FP32=1; everything else on the fp32 MFMA.
+    x6 = ce == 128 and not os.environ.get("GNX_FFN_FP32")
+    x6_flops = 2 * 16 * E * ce * ce if x6 else 0
+    t_roof = x6_flops / (MFMA_BF16_PEAK_TFS / 6 * 1e12) + (ex - x6_flops) / (MFMA_F32_PEAK_TFS * 1e12)
     line = {"metric": "edges/sec through Encoder->2xGNCore(%s)->Decoder, 1M-edge graph (BASELINE configs[3])" % ",".join(map(str, core)),
             "value": round(E / dt, 1), "unit": "edges/s", "ms_per_step": round(dt * 1e3, 4), "steps": K, "dtype": "f32",
-            "roofline": {"bound": "mfma", "achieved": round(ex / dt / 1e12, 2), "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
-                         "frac": round(ex / dt / 1e12 / MFMA_F32_PEAK_TFS, 4), "counts": "EXECUTED flops of the whole model / whole-step time",
+            "roofline": {"bound": "mfma", "achieved": round(ex / dt / 1e12, 2), "peak": round(ex / t_roof / 1e12, 1), "unit": "TFLOP/s",
+                         "frac": round(t_roof / dt, 4),
+                         "counts": "EXECUTED flops of the whole model / whole-step time; peak = the same flops at the rate of the instruction that carries them "
+                                   "(fp32 MFMA %.1f TFLOP/s; the edge FeedForwards as six bf16 terms per fp32 product: %.0f / 6 = %.1f)" % (MFMA_F32_PEAK_TFS, MFMA_BF16_PEAK_TFS, MFMA_BF16_PEAK_TFS / 6),
+                         "frac_of_fp32_mfma_roof": round(ex / dt / 1e12 / MFMA_F32_PEAK_TFS, 4),
+                         "flops_on_bf16_six_terms": x6_flops,
+                         "arithmetic": ("fp32 in, fp32 out, fp32 accumulation; the edge FeedForward's products as hi/mid/lo bf16 parts (24 mantissa bits, exact split), six matrix-core terms" if x6
+                                        else "fp32 MFMA throughout"),
                          "executed_flops": ex, "algorithmic_flops": aflops, "algorithmic_tflops": round(aflops / dt / 1e12, 2),
                          "traffic": traffic, "traffic_source": tsrc},
             "kernel_us_one_forward": kern,
@@ -409,7 +422,7 @@ def bench_dist_gnx(args):
 
 def model_source_sha(core):
     """sha256 over the kernel sources a C4 model runs (both paths' files at wide widths, the narrow files otherwise)."""
-    files = sorted(set(KERNEL_SOURCES["wide"] + KERNEL_SOURCES["narrow"] + (("gnx_ffn_fused.hip", "gnx_generic.hip") if max(core) >= 32 else ("gnx_core_narrow.hip", "gnx_core_post_kernel.h"))))
+    files = sorted(set(KERNEL_SOURCES["wide"] + KERNEL_SOURCES["narrow"] + (("gnx_ffn_fused.hip", "gnx_ffn_x6.hip", "gnx_generic.hip") if max(core) >= 32 else ("gnx_core_narrow.hip", "gnx_core_post_kernel.h"))))
     h = hashlib.sha256()
     for f in files:
         with open(os.path.join(ROOT, "graphnets.jl_amd", "csrc", f), "rb") as fh:

@@ -192,27 +192,45 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of W1(0), W2(0) are in LDS
   __syncthreads();                                  // ... and everybody else's; s_b1 too
 
-  // activation + split of ONE pair of a finished H^T block: registers q = 2 u, 2 u + 1 (q = 8 t + j: element j of the B fragment of k16-step t, slot
-  // 16 t + 8 hi + j).  Identity / relu without a branch: max with -inf / 0.
-  const float relu_floor = a.act1 == 1 ? 0.f : -__builtin_inff();
-  auto split_pair = [&](int u, const f32x16x& accH, bf16x8x (&hh)[2], bf16x8x (&hm)[2], bf16x8x (&hl)[2]) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int q = 2 * u + e;
-      float v = accH[q];
-      if constexpr (TRANS) v = act_apply(v, a.act1);
-      else v = __builtin_amdgcn_fmed3f(v, relu_floor, __builtin_inff());  // max(x, floor) as one instruction the scheduler can place
-      __bf16 x, y, w;
-      split3x(v, x, y, w);
-      hh[q >> 3][q & 7] = x; hm[q >> 3][q & 7] = y; hl[q >> 3][q & 7] = w;
-    }
+  // Activation + split of a finished H^T block, one PAIR of accumulator registers (q = 2 u, 2 u + 1; q = 8 t + j: element j of the B fragment of
+  // k16-step t, slot 16 t + 8 hi + j) at a time, as bit operations on dwords (14 vector instructions per pair):
+  //   X(u): relu as an INTEGER maximum of the float's bits with 0 (identity: with INT_MIN) — one instruction, no canonicalisation; hi = one
+  //         v_cvt_pk_bf16_f32 of the pair = dword u of the hi fragment; its two floats by shift / mask; first remainders
+  //   Y(u): mid = cvt of the remainders; second remainders; lo = their cvt
+  // and as a two-stage pipeline over the k16-steps of the first product: step s runs X(s) beside Y(s - 1), written line by line alternately — two
+  // independent dependency chains, so that consecutive vector instructions between the matrix instructions do not wait for each other.
+  const int relu_floor = a.act1 == 1 ? 0 : (int)0x80000000;
+  unsigned hhw[8], hmw[8], hlw[8];
+  auto cvt2 = [](float x0, float x1) -> unsigned {
+    typedef float f32x2x __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2x __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2x{x0, x1}, bf16x2x));
   };
+  auto relu_bits = [&](float v) -> float {
+    if constexpr (TRANS) return act_apply(v, a.act1);
+    else return __int_as_float(max(__float_as_int(v), relu_floor));
+  };
+  // one k16-step's share: X(ux) if ux >= 0, Y(uy) if uy >= 0; rx / ry: the first remainders of the pair in flight
+  auto split_xy = [&](int ux, int uy, const f32x16x& accH, float (&rx)[2], const float (&ry)[2]) {
+    float m0 = 0.f, m1 = 0.f, q0, q1;
+    unsigned hb = 0, mb = 0;
+    if (ux >= 0) { m0 = relu_bits(accH[2 * ux]); }
+    if (uy >= 0) { mb = cvt2(ry[0], ry[1]); hmw[uy] = mb; }
+    if (ux >= 0) { m1 = relu_bits(accH[2 * ux + 1]); }
+    if (uy >= 0) { q0 = ry[0] - __uint_as_float(mb << 16); }
+    if (ux >= 0) { hb = cvt2(m0, m1); hhw[ux] = hb; }
+    if (uy >= 0) { q1 = ry[1] - __uint_as_float(mb & 0xffff0000u); }
+    if (ux >= 0) { rx[0] = m0 - __uint_as_float(hb << 16); }
+    if (uy >= 0) { hlw[uy] = cvt2(q0, q1); }
+    if (ux >= 0) { rx[1] = m1 - __uint_as_float(hb & 0xffff0000u); }
+  };
+  typedef unsigned u32x4x __attribute__((ext_vector_type(4)));
+  auto frag = [](const unsigned (&w)[8], int t) -> bf16x8x { return __builtin_bit_cast(bf16x8x, u32x4x{w[4 * t], w[4 * t + 1], w[4 * t + 2], w[4 * t + 3]}); };
   // H^T block of slice hs (its 32 hidden units x the wave's 32 rows) = b1 + W1^T z^T into accN — and, between its matrix instructions, activation
   // and split of the FINISHED block accC (SPLIT): two independent streams in one schedule.  Per k16-step: the next step's three weight fragments
-  // requested, six MFMAs, one pair split (~12 vector instructions): each matrix instruction is followed by its two — issued while the pipe works on
-  // it.  (Left to the compiler the split is one block of ~100 vector instructions between the two products, in front of an idle matrix pipe in
-  // BOTH waves of the SIMD: they run in step, one barrier per slice.)
-  auto gemm1 = [&](auto split_c, int hs, const unsigned char* w1, f32x16x& accN, const f32x16x& accC, bf16x8x (&hh)[2], bf16x8x (&hm)[2], bf16x8x (&hl)[2]) {
+  // requested, six MFMAs, 13 vector instructions of the split: every matrix instruction is followed by two of them — issued while the pipe works.
+  // (Left to the compiler the split is one block of ~170 vector instructions between the two products, in front of an idle matrix pipe.)
+  auto gemm1 = [&](auto split_c, int hs, const unsigned char* w1, f32x16x& accN, const f32x16x& accC) {
     constexpr bool SPLIT = decltype(split_c)::value;
     const unsigned char* wb = w1 + lane * 16;
 #pragma unroll
@@ -220,6 +238,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     bf16x8x A[2][3];
 #pragma unroll
     for (int p3 = 0; p3 < 3; ++p3) A[0][p3] = *reinterpret_cast<const bf16x8x*>(wb + p3 * 1024);
+    float rr[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -234,19 +253,28 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zh[s], accN, 0, 0, 0);
       accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zm[s], accN, 0, 0, 0);
       accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zh[s], accN, 0, 0, 0);
-      if constexpr (SPLIT) split_pair(s, accC, hh, hm, hl);
+      if constexpr (SPLIT) {
+        // (instruction selection places pure vector instructions wherever their operands are ready — Y(s - 1) right behind X(s - 1), in the
+        // previous step's region, one dependent chain again; the empty volatile statement pins the remainders to THIS region)
+        if (s > 0) asm volatile("" : "+v"(rr[c ^ 1][0]), "+v"(rr[c ^ 1][1]));
+        split_xy(s, s - 1, accC, rr[c], rr[c ^ 1]);
+      }
       if (s + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < 5; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         if constexpr (SPLIT) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
       }
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if constexpr (SPLIT) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (SPLIT) split_xy(-1, KS - 1, accC, rr[0], rr[(KS - 1) & 1]);  // Y of the last pair (beside the first matrix instructions of the second product)
   };
   // out^T (D outputs x the wave's rows) += W2^T[:, the slice's slots] H^T
-  auto gemm2 = [&](const unsigned char* w2, const bf16x8x (&hh)[2], const bf16x8x (&hm)[2], const bf16x8x (&hl)[2]) {
+  auto gemm2 = [&](const unsigned char* w2) {
     const unsigned char* wb = w2 + lane * 16;
+    const bf16x8x hh[2] = {frag(hhw, 0), frag(hhw, 1)}, hm[2] = {frag(hmw, 0), frag(hmw, 1)}, hl[2] = {frag(hlw, 0), frag(hlw, 1)};
     bf16x8x A[2][3];  // the fragments of group g + 1 are requested in front of the six MFMAs of group g (g = 2 ob + t)
 #pragma unroll
     for (int p3 = 0; p3 < 3; ++p3) A[0][p3] = *reinterpret_cast<const bf16x8x*>(wb + p3 * 1024);
@@ -273,10 +301,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   GNX_XSTAMP(1);  // prologue done: z rows split, first weight pieces in LDS
   static_assert(KS == 8, "one pair of the 16 hidden registers is split per k16-step of the first product");
   f32x16x accA, accB;  // H^T blocks: the one being produced and the one being consumed, alternating
-  {
-    bf16x8x hh[2], hm[2], hl[2];
-    gemm1(std::false_type{}, 0, s_w1, accA, accA, hh, hm, hl);
-  }
+  gemm1(std::false_type{}, 0, s_w1, accA, accA);
   __syncthreads();  // every wave is done with W1(0)
   stage(1, 0, s_w1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -285,11 +310,10 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   //           free -> W1(hs + 2) requested  |  second product of slice hs (W2 from w2c)  |  the requests have landed, barrier
   auto step = [&](int hs, const unsigned char* w2c, unsigned char* w2s, f32x16x& accC, f32x16x& accN) {
     stage(hs + 1, 1, w2s);
-    bf16x8x hh[2], hm[2], hl[2];
-    gemm1(std::true_type{}, hs + 1, s_w1, accN, accC, hh, hm, hl);
+    gemm1(std::true_type{}, hs + 1, s_w1, accN, accC);
     __syncthreads();
     if (hs + 2 < NSL) stage(hs + 2, 0, s_w1);
-    gemm2(w2c, hh, hm, hl);
+    gemm2(w2c);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
@@ -300,10 +324,10 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
   step(NSL - 2, s_w2a, s_w2b, accA, accB);
   {  // the last slice: nothing left to produce
-    bf16x8x hh[2], hm[2], hl[2];
+    float rr[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-    for (int u = 0; u < 8; ++u) split_pair(u, accB, hh, hm, hl);
-    gemm2(s_w2b, hh, hm, hl);
+    for (int u = 0; u <= 8; ++u) split_xy(u < 8 ? u : -1, u - 1, accB, rr[u & 1], rr[(u & 1) ^ 1]);
+    gemm2(s_w2b);
   }
 
   GNX_XSTAMP(2);  // all slices done
