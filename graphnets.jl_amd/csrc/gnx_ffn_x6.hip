@@ -132,7 +132,6 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const size_t rows = a.rows;
   // (waves beyond the last row keep working on the clamped last row — they share the barriers — and store nothing)
   const size_t rown = row0 + n < rows ? row0 + n : rows - 1;
-  const bool row_ok = row0 + n < rows;
   const float* __restrict__ zrow = a.z + (r * rows + rown) * D;
 
   // fragment f of a slice is LDS-DMA piece f (lane l writes bytes [16 l, 16 l + 16) of the piece); which = 0: the W1 half of the slice, 1: the W2 half
@@ -331,30 +330,40 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
 
   GNX_XSTAMP(2);  // all slices done
-  // ---- epilogue from the C/D layout: lane (n, hi) holds outputs 32 ob + 8 g + 4 hi + (0..3) of its row in registers 4 g .. 4 g + 3 —
-  //      one 16-byte access per (ob, g), the two lane halves of a row adjacent ----
-  float* __restrict__ orow = a.out + (r * rows + rown) * D;
-  const float* __restrict__ r1 = a.add1 ? a.add1 + (r * rows + rown) * D : nullptr;
-  const float* __restrict__ r2 = a.add2 ? a.add2 + (r * rows + rown) * D : nullptr;
+  // ---- epilogue.  In the C/D layout lane (n, hi) holds outputs 32 ob + 8 g + 4 hi + (0..3) of ITS row in registers 4 g .. 4 g + 3: accessed from
+  //      there, every instruction touches 32 rows with 32 bytes each.  Instead each 32-output block takes a round trip through a wave-private
+  //      4.5-KB slice of the (now idle) W1 buffer — LDS operations of one wave execute in order, no barrier — and comes back as (row, 16-byte
+  //      quad) = (lane / 8 + 8 i, lane % 8): an instruction then covers 8 rows x 128 contiguous bytes, whole cache lines, for the two residual
+  //      loads and the store alike (same instruction count). ----
+  constexpr int ELD = 36;  // floats per staged row: 32 + 4 (conflict-free 16-byte writes, one 2-way conflict per read phase)
+  float* sE = reinterpret_cast<float*>(s_w1) + wv * (XR * ELD);
+  static_assert(XW * XR * ELD * 4 <= SLB / 2, "epilogue staging fits the W1 buffer");
+  const int er = lane >> 3, eq = lane & 7;
+  const float* __restrict__ r1 = a.add1 ? a.add1 + r * rows * D : nullptr;
+  const float* __restrict__ r2 = a.add2 ? a.add2 + r * rows * D : nullptr;
+  float* __restrict__ ob_out = a.out + r * rows * D;
 #pragma unroll
   for (int ob = 0; ob < NOB; ++ob) {
-    f32x4x u1[4], u2[4], bq[4];
+    f32x4x u1[4], u2[4];
+    const f32x4x zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4x bq = a.b2 ? *reinterpret_cast<const f32x4x*>(a.b2 + 32 * ob + 4 * eq) : zero;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c = 32 * ob + 8 * g + 4 * hi;
-      const f32x4x zero = {0.f, 0.f, 0.f, 0.f};
-      u1[g] = r1 ? *reinterpret_cast<const f32x4x*>(r1 + c) : zero;
-      u2[g] = r2 ? *reinterpret_cast<const f32x4x*>(r2 + c) : zero;
-      bq[g] = a.b2 ? *reinterpret_cast<const f32x4x*>(a.b2 + c) : zero;
+    for (int i = 0; i < 4; ++i) {
+      const size_t grow = row0 + er + 8 * i < rows ? row0 + er + 8 * i : rows - 1;
+      const size_t off = grow * D + 32 * ob + 4 * eq;
+      u1[i] = r1 ? *reinterpret_cast<const f32x4x*>(r1 + off) : zero;
+      u2[i] = r2 ? *reinterpret_cast<const f32x4x*>(r2 + off) : zero;
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c = 32 * ob + 8 * g + 4 * hi;
-      f32x4x v = {accO[ob][4 * g], accO[ob][4 * g + 1], accO[ob][4 * g + 2], accO[ob][4 * g + 3]};
-      v += bq[g];
-      v += u1[g];
-      v += u2[g];
-      if (row_ok) *reinterpret_cast<f32x4x*>(orow + c) = v;
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4x*>(sE + n * ELD + 8 * g + 4 * hi) = f32x4x{accO[ob][4 * g], accO[ob][4 * g + 1], accO[ob][4 * g + 2], accO[ob][4 * g + 3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4x v = *reinterpret_cast<const f32x4x*>(sE + (er + 8 * i) * ELD + 4 * eq);
+      v += bq;
+      v += u1[i];
+      v += u2[i];
+      if (row0 + er + 8 * i < rows) *reinterpret_cast<f32x4x*>(ob_out + (row0 + er + 8 * i) * D + 32 * ob + 4 * eq) = v;
     }
   }
 #ifdef GNX_X6_STAMPS_BUILD
