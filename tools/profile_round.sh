@@ -19,7 +19,9 @@ for M in c4 c4_10-5-3; do
   B="python3 $REPO/bench.py --model c4 --steps 3 --warmup 1 --no-cpu-baseline --no-c-abi $CD"
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $B > $OUT/kt.log 2>&1
    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
-   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1)
+   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1
+   # matrix-core counters of the wide model (k_ffn_x6: bf16 MFMAs at 32 busy cycles each; k_ffn_fused / k_rows_gemm: fp32 MFMAs)
+   [ "$M" = "c4" ] && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -- $B > $OUT/pmc_mfma.log 2>&1)
   python3 tools/summarize_prof.py $OUT $OUT/summary --model-traffic $M > $OUT/summary.txt 2>&1
   find "$OUT" -name "*_kernel_trace.csv" -delete; find "$OUT" -name "*_counter_collection.csv" -delete; find "$OUT" -name "*_agent_info.csv" -delete
 done
