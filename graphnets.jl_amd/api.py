@@ -944,7 +944,7 @@ class GNCore:
         assert x.ef is not None and x.nf is not None and x.gf is not None, "GNCore needs ef, nf and gf (gncore.jl:61-68)"
         g, ef, nf, gf, R = _forward_common(x, self.dims)
         plist = self._param_list()
-        if torch.is_grad_enabled() and any(t.requires_grad for t in [ef, nf, gf] + plist):
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in [ef, nf, gf] + plist):
             eo, no, go = _CoreFn.apply(self, g, R, self.flags if flags is None else flags, ef, nf, gf, *plist)
             return NT(g, _jl(eo), _jl(no), _jl(go))
         lib = _lib.load()

@@ -180,6 +180,38 @@ def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_
     assert out["x6"][0] <= 1.25 * out["fp32"][0] and out["x6"][1] <= 1.25 * out["fp32"][1], out
 
 
+@pytest.mark.parametrize("act,bias,E", [("relu", True, 4137), ("identity", True, 5000), ("tanh", True, 4099), ("relu", False, 4608)])
+def test_core_wide_edge_feedforward_six_term_kernel_ragged_rows_activations_no_bias(gn, act, bias, E):
+    """k_ffn_x6 against the fp32-MFMA kernel (GNX_FFN_FP32=1) on the same inputs: row counts that end inside a workgroup and inside a
+    wavefront (128-row workgroups of four 32-row waves), fc1 activations identity / relu (branch-free) and tanh (the run-time switch), a
+    FeedForward without biases.  Normwise 2e-6 of the output's magnitude — two fp32-accurate evaluations of the same sums."""
+    import os
+    import torch
+    rng = np.random.default_rng(5200 + E)
+    dims = (128, 64, 32)
+    colptr, rowval = U.er_csc(rng, 500, E)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [500])
+    p = O.make_core_params(rng, dims, random_bias=bias)
+    core = U.core_from_params(gn, p)
+    dev = core.gn1.edgeln.gamma.device
+    core.ffwd.eff = (gn.Dense.from_numpy(p["ff_e_W1"], p["ff_e_b1"] if bias else None, act, dev), gn.Dense.from_numpy(p["ff_e_W2"], p["ff_e_b2"] if bias else None, "identity", dev))
+    ef, nf, gf = U.packed_inputs(rng, 1, E, 500, 1, dims)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    gn.profile_reset(); gn.profile_enable(True)
+    y = core(x)
+    gn.profile_enable(False)
+    assert "k_ffn_x6" in set(gn.profile_read()); gn.profile_reset()
+    os.environ["GNX_FFN_FP32"] = "1"
+    try:
+        y0 = core(x)
+    finally:
+        del os.environ["GNX_FFN_FP32"]
+    a, b = y.ef.double(), y0.ef.double()
+    assert torch.isfinite(a).all()
+    assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (act, bias, E, float((a - b).abs().max()), float(b.abs().max()))
+    assert torch.equal(y.nf, y0.nf) and torch.equal(y.gf, y0.gf)  # (nodes and graphs do not go through the six-term kernel)
+
+
 def test_core_wide_side_stream_equals_single_stream(gn):
     """A wide GNCore forks its graph level, node projections and node FeedForward onto the handle's side stream (GNX_NO_FORK=1: one
     stream).  Same kernels, same order of every sum: the results are bit-identical — eagerly, repeatedly (a race would show as a
