@@ -465,7 +465,8 @@ def collect_secondary(args):
             out[key] = {"what": what, "error": err, "wall_s": round(time.perf_counter() - t0, 1)}
             continue
         roof = line.get("roofline") or {}
-        keep = ("bound", "achieved", "peak", "unit", "frac", "frac_whole_step", "traffic", "kernel", "kernel_us", "executed_flops", "algorithmic_bytes")
+        keep = ("bound", "achieved", "peak", "unit", "frac", "frac_whole_step", "traffic", "kernel", "kernel_us", "executed_flops", "algorithmic_bytes",
+                "frac_of_fp32_mfma_roof", "flops_on_bf16_six_terms", "arithmetic")
         entry = {"what": what, "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": line.get("steps", steps),
                  "roofline": {k: roof[k] for k in keep if k in roof}, "cpu_baseline": line.get("cpu_baseline"),
                  "wall_s": round(time.perf_counter() - t0, 1)}
