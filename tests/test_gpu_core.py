@@ -150,6 +150,8 @@ def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_
     must meet the 1e-5·scale bar, and the six-term form must be as accurate as the fp32 instruction: its worst and its mean error within
     1.25 x the fp32 kernel's (measured: equal to two digits).  Inputs with a mean far from zero, weights of both signs, relu between."""
     import os
+    if os.environ.get("GNX_FFN_FP32"):
+        pytest.skip("GNX_FFN_FP32 is set for the whole run: the six-term kernel is switched off")
     rng = np.random.default_rng(5100)
     dims = (128, 64, 32)
     colptr, rowval = U.er_csc(rng, 900, 12000)
@@ -187,6 +189,8 @@ def test_core_wide_edge_feedforward_six_term_kernel_ragged_rows_activations_no_b
     FeedForward without biases.  Normwise 2e-6 of the output's magnitude — two fp32-accurate evaluations of the same sums."""
     import os
     import torch
+    if os.environ.get("GNX_FFN_FP32"):
+        pytest.skip("GNX_FFN_FP32 is set for the whole run: the six-term kernel is switched off")
     rng = np.random.default_rng(5200 + E)
     dims = (128, 64, 32)
     colptr, rowval = U.er_csc(rng, 500, E)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Repeated forwards of the core-dims block (the NL = 3 edge GEMM: LDS-DMA'd destination rows, untracked source-row loads behind a counted wait) and of a GNCore
-(k_ffn_fused) on C2 under load: every repetition must reproduce the first one bit for bit (a visibility / wait-count race would show up as a differing checksum)."""
+(k_ffn_x6 for the edges, k_ffn_fused for the nodes) on C2 under load: every repetition must reproduce the first one bit for bit (a visibility / wait-count race would show up as a differing checksum)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
