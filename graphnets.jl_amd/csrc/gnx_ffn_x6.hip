@@ -33,6 +33,9 @@ typedef float f32x16x __attribute__((ext_vector_type(16)));
 typedef float f32x4x __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8x __attribute__((ext_vector_type(8)));
 
+#ifndef GNX_X6_ADEPTH
+#define GNX_X6_ADEPTH 2
+#endif
 namespace {
 constexpr int XR = 32;         // rows per wave
 constexpr int XW = 4;          // waves per workgroup
@@ -234,17 +237,20 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const unsigned char* wb = w1 + lane * 16;
 #pragma unroll
     for (int q = 0; q < 16; ++q) accN[q] = s_b1[hs * XHS + (q & 3) + 8 * (q >> 2) + 4 * hi];
-    bf16x8x A[2][3];
+    constexpr int AD = GNX_X6_ADEPTH;  // weight fragments in flight: AD - 1 k16-steps ahead of their MFMAs
+    bf16x8x A[AD][3];
 #pragma unroll
-    for (int p3 = 0; p3 < 3; ++p3) A[0][p3] = *reinterpret_cast<const bf16x8x*>(wb + p3 * 1024);
+    for (int d = 0; d < AD - 1; ++d)
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3) A[d][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * d + p3) * 1024);
     float rr[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const int c = s & 1;
-      if (s + 1 < KS) {
+      const int c = s % AD, cr = s & 1;
+      if (s + AD - 1 < KS) {
 #pragma unroll
-        for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * (s + 1) + p3) * 1024);
+        for (int p3 = 0; p3 < 3; ++p3) A[(s + AD - 1) % AD][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * (s + AD - 1) + p3) * 1024);
       }
       accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zm[s], accN, 0, 0, 0);  // small terms first
       accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][2], zh[s], accN, 0, 0, 0);
@@ -255,10 +261,10 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       if constexpr (SPLIT) {
         // (instruction selection places pure vector instructions wherever their operands are ready — Y(s - 1) right behind X(s - 1), in the
         // previous step's region, one dependent chain again; the empty volatile statement pins the remainders to THIS region)
-        if (s > 0) asm volatile("" : "+v"(rr[c ^ 1][0]), "+v"(rr[c ^ 1][1]));
-        split_xy(s, s - 1, accC, rr[c], rr[c ^ 1]);
+        if (s > 0) asm volatile("" : "+v"(rr[cr ^ 1][0]), "+v"(rr[cr ^ 1][1]));
+        split_xy(s, s - 1, accC, rr[cr], rr[cr ^ 1]);
       }
-      if (s + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      if (s + AD - 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -342,18 +348,22 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   const float* __restrict__ r1 = a.add1 ? a.add1 + r * rows * D : nullptr;
   const float* __restrict__ r2 = a.add2 ? a.add2 + r * rows * D : nullptr;
   float* __restrict__ ob_out = a.out + r * rows * D;
+  // every residual quad of the tile is requested HERE, in one go (the z fragments' 96 registers are free): one memory round trip for the
+  // epilogue instead of one per 32-output block
+  f32x4x u1[NOB][4], u2[NOB][4];
+  const f32x4x zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int ob = 0; ob < NOB; ++ob) {
-    f32x4x u1[4], u2[4];
-    const f32x4x zero = {0.f, 0.f, 0.f, 0.f};
-    const f32x4x bq = a.b2 ? *reinterpret_cast<const f32x4x*>(a.b2 + 32 * ob + 4 * eq) : zero;
+  for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const size_t grow = row0 + er + 8 * i < rows ? row0 + er + 8 * i : rows - 1;
       const size_t off = grow * D + 32 * ob + 4 * eq;
-      u1[i] = r1 ? *reinterpret_cast<const f32x4x*>(r1 + off) : zero;
-      u2[i] = r2 ? *reinterpret_cast<const f32x4x*>(r2 + off) : zero;
+      u1[ob][i] = r1 ? *reinterpret_cast<const f32x4x*>(r1 + off) : zero;
+      u2[ob][i] = r2 ? *reinterpret_cast<const f32x4x*>(r2 + off) : zero;
     }
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) {
+    const f32x4x bq = a.b2 ? *reinterpret_cast<const f32x4x*>(a.b2 + 32 * ob + 4 * eq) : zero;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
       *reinterpret_cast<f32x4x*>(sE + n * ELD + 8 * g + 4 * hi) = f32x4x{accO[ob][4 * g], accO[ob][4 * g + 1], accO[ob][4 * g + 2], accO[ob][4 * g + 3]};
@@ -361,8 +371,8 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int i = 0; i < 4; ++i) {
       f32x4x v = *reinterpret_cast<const f32x4x*>(sE + (er + 8 * i) * ELD + 4 * eq);
       v += bq;
-      v += u1[i];
-      v += u2[i];
+      v += u1[ob][i];
+      v += u2[ob][i];
       if (row0 + er + 8 * i < rows) *reinterpret_cast<f32x4x*>(ob_out + (row0 + er + 8 * i) * D + 32 * ob + 4 * eq) = v;
     }
   }
