@@ -566,6 +566,8 @@ def main():
     ap.add_argument("--model", choices=["block", "c4"], default="block",
                     help="c4: BASELINE configs[3] — encoder -> 2 x GNCore(128,64,32) -> decoder on the C2 graph (extra; not the headline line)")
     args = ap.parse_args()
+    if args.steps < 1 or args.steps > 5000 or args.warmup < 0:  # (K steps are captured into ONE hipGraph: six-figure node counts crash the runtime's capture)
+        ap.error("--steps must be in 1..5000 and --warmup >= 0")
 
     if args.dist_backend == "gnx":
         return bench_dist_gnx(args)
