@@ -107,7 +107,7 @@ static __device__ unsigned long long* g_x6_dbg = nullptr;  // [workgroup][4]
 
 // TRANS: fc1's activation is tanh / sigmoid / gelu (the run-time switch of act_apply); else identity / relu
 template <int D, bool TRANS>
-__global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_ffn_x6(FfnX6Args a) {
+__global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D == 128 ? 2 : 3))) void k_ffn_x6(FfnX6Args a) {
   constexpr int H = 4 * D;
   constexpr int KS = D / 16;          // k16-steps of the first product
   constexpr int NOB = D / 32;         // 32-output blocks of the second product
@@ -243,7 +243,12 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int d = 0; d < AD - 1; ++d)
 #pragma unroll
       for (int p3 = 0; p3 < 3; ++p3) A[d][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * d + p3) * 1024);
-    float rr[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    constexpr int PPS = 8 / KS;  // register pairs of the finished block split per k16-step (D = 128: one, D = 64: two)
+    float rr[2][PPS][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < PPS; ++j) rr[i][j][0] = rr[i][j][1] = 0.f;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -261,20 +266,26 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       if constexpr (SPLIT) {
         // (instruction selection places pure vector instructions wherever their operands are ready — Y(s - 1) right behind X(s - 1), in the
         // previous step's region, one dependent chain again; the empty volatile statement pins the remainders to THIS region)
-        if (s > 0) asm volatile("" : "+v"(rr[cr ^ 1][0]), "+v"(rr[cr ^ 1][1]));
-        split_xy(s, s - 1, accC, rr[cr], rr[cr ^ 1]);
+#pragma unroll
+        for (int j = 0; j < PPS; ++j) {
+          if (s > 0) asm volatile("" : "+v"(rr[cr ^ 1][j][0]), "+v"(rr[cr ^ 1][j][1]));
+          split_xy(PPS * s + j, s > 0 ? PPS * (s - 1) + j : -1, accC, rr[cr][j], rr[cr ^ 1][j]);
+        }
       }
       if (s + AD - 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if constexpr (SPLIT) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        if constexpr (SPLIT) { if constexpr (PPS == 1) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if constexpr (SPLIT) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      if constexpr (SPLIT) { if constexpr (PPS == 1) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); else __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (SPLIT) split_xy(-1, KS - 1, accC, rr[0], rr[(KS - 1) & 1]);  // Y of the last pair (beside the first matrix instructions of the second product)
+    if constexpr (SPLIT) {  // Y of the last pair(s) (beside the first matrix instructions of the second product)
+#pragma unroll
+      for (int j = 0; j < PPS; ++j) split_xy(-1, PPS * (KS - 1) + j, accC, rr[0][j], rr[(KS - 1) & 1][j]);
+    }
   };
   // out^T (D outputs x the wave's rows) += W2^T[:, the slice's slots] H^T
   auto gemm2 = [&](const unsigned char* w2) {
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   };
 
   GNX_XSTAMP(1);  // prologue done: z rows split, first weight pieces in LDS
-  static_assert(KS == 8, "one pair of the 16 hidden registers is split per k16-step of the first product");
+  static_assert(KS == 8 || KS == 4, "one or two pairs of the 16 hidden registers are split per k16-step of the first product");
   f32x16x accA, accB;  // H^T blocks: the one being produced and the one being consumed, alternating
   gemm1(std::false_type{}, 0, s_w1, accA, accA);
   __syncthreads();  // every wave is done with W1(0)
@@ -342,8 +353,9 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   //      quad) = (lane / 8 + 8 i, lane % 8): an instruction then covers 8 rows x 128 contiguous bytes, whole cache lines, for the two residual
   //      loads and the store alike (same instruction count). ----
   constexpr int ELD = 36;  // floats per staged row: 32 + 4 (conflict-free 16-byte writes, one 2-way conflict per read phase)
-  float* sE = reinterpret_cast<float*>(s_w1) + wv * (XR * ELD);
-  static_assert(XW * XR * ELD * 4 <= SLB / 2, "epilogue staging fits the W1 buffer");
+  constexpr bool E_IN_W1 = XW * XR * ELD * 4 <= SLB / 2;  // (D = 64: the W1 buffer is 12 KB — the staging gets its own 18 KB)
+  __shared__ __attribute__((aligned(16))) float s_e[E_IN_W1 ? 4 : XW * XR * ELD];
+  float* sE = (E_IN_W1 ? reinterpret_cast<float*>(s_w1) : s_e) + wv * (XR * ELD);
   const int er = lane >> 3, eq = lane & 7;
   const float* __restrict__ r1 = a.add1 ? a.add1 + r * rows * D : nullptr;
   const float* __restrict__ r2 = a.add2 ? a.add2 + r * rows * D : nullptr;
@@ -390,7 +402,7 @@ size_t ffn_x6_scratch_bytes(int d) { return (size_t)3 * d * 4 * d * sizeof(__bf1
 
 bool ffn_x6_applies(const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, const float* out, size_t scratch_bytes) {
   if (getenv("GNX_FFN_FP32") != nullptr) return false;  // (read per call: tests compare the two kernels in one process)
-  if (d != 128 || ff.fc2.act != GNX_ACT_IDENTITY || scratch_bytes < ffn_x6_scratch_bytes(d)) return false;
+  if ((d != 128 && d != 64) || ff.fc2.act != GNX_ACT_IDENTITY || scratch_bytes < ffn_x6_scratch_bytes(d)) return false;
   const uintptr_t al = (uintptr_t)z | (uintptr_t)ff.fc2.bias | (uintptr_t)add1 | (uintptr_t)add2 | (uintptr_t)out;
   return (al & 15) == 0;
 }
@@ -424,8 +436,10 @@ int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, co
   }
 #endif
   ProfScope ps("k_ffn_x6", s);
-  if (ff.fc1.act > GNX_ACT_RELU) GNX_LAUNCH((k_ffn_x6<128, true>), dim3((unsigned)((nrows + XBM - 1) / XBM), (unsigned)R), dim3(64 * XW), 0, s, a);
-  else GNX_LAUNCH((k_ffn_x6<128, false>), dim3((unsigned)((nrows + XBM - 1) / XBM), (unsigned)R), dim3(64 * XW), 0, s, a);
+  const dim3 grid((unsigned)((nrows + XBM - 1) / XBM), (unsigned)R);
+  const bool trans = ff.fc1.act > GNX_ACT_RELU;
+  if (d == 128) { if (trans) GNX_LAUNCH((k_ffn_x6<128, true>), grid, dim3(64 * XW), 0, s, a); else GNX_LAUNCH((k_ffn_x6<128, false>), grid, dim3(64 * XW), 0, s, a); }
+  else { if (trans) GNX_LAUNCH((k_ffn_x6<64, true>), grid, dim3(64 * XW), 0, s, a); else GNX_LAUNCH((k_ffn_x6<64, false>), grid, dim3(64 * XW), 0, s, a); }
   GNX_HIP(hipGetLastError());
 #ifdef GNX_X6_STAMPS_BUILD
   if (stamps) {

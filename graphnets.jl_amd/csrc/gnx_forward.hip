@@ -418,12 +418,12 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       // the node FeedForward rides on the side stream too: its workgroups fill the CUs that the edge FeedForward's last, partly
       // filled round of tiles leaves idle (7813 tiles on 512 slots: 15.26 rounds)
       static const bool node_ffn_main = getenv("GNX_NODE_FFN_MAIN") != nullptr;
-      if (rc == GNX_OK && !node_ffn_main) rc = launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, ax, l1[1], &p->ln2[1]);
+      if (rc == GNX_OK && !node_ffn_main) rc = launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, ax, l1[1], &p->ln2[1], l2[1], sizeof(float) * rows[1] * d[1]);
       // the join is recorded even after a failure: a capture must not end with the side stream un-joined
       const hipError_t e1 = hipEventRecord(h->aux_join, ax);
       // (the edges' gn2 buffer is unused in this form: room for the split weight planes of k_ffn_x6)
       int32_t rc2 = launch_ffn_fused(h, 0, x[0], d[0], p->ff[0], out[0], x[0], out[0], R, s, l1[0], &p->ln2[0], l2[0], sizeof(float) * rows[0] * d[0]);
-      if (rc2 == GNX_OK && node_ffn_main) rc2 = launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, s, l1[1], &p->ln2[1]);
+      if (rc2 == GNX_OK && node_ffn_main) rc2 = launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, s, l1[1], &p->ln2[1], l2[1], sizeof(float) * rows[1] * d[1]);
       const hipError_t e2 = hipStreamWaitEvent(s, h->aux_join, 0);
       if (rc) return rc;
       if (rc2) return rc2;
@@ -453,11 +453,11 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     if (ffn_on_mfma(d[t]) && !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA))) {
       // out = block(LN1 x) + x + fc2(relu(fc1(LN2 x)))      (gncore.jl:56-68, gnfeedforward.jl:27-31)
       if (wide_ln && t < 2) {
-        if ((rc = launch_ffn_fused(h, t, x[t], d[t], p->ff[t], out[t], x[t], out[t], R, s, l1[t], &p->ln2[t], t == 0 ? l2[0] : nullptr, sizeof(float) * rows[0] * d[0]))) return rc;
+        if ((rc = launch_ffn_fused(h, t, x[t], d[t], p->ff[t], out[t], x[t], out[t], R, s, l1[t], &p->ln2[t], l2[t], sizeof(float) * rows[t] * d[t]))) return rc;
         continue;
       }
       // hidden layer never leaves the chip (d = 64, 128); the edges' launch may use the hidden buffer of the two-GEMM form as its scratch
-      rc = launch_ffn_fused(h, t, l2[t], d[t], p->ff[t], out[t], x[t], out[t], R, s, nullptr, nullptr, t == 0 ? hidden : nullptr, sizeof(float) * rows[0] * 4 * (size_t)d[0]);
+      rc = launch_ffn_fused(h, t, l2[t], d[t], p->ff[t], out[t], x[t], out[t], R, s, nullptr, nullptr, t < 2 ? hidden : nullptr, sizeof(float) * rows[t] * 4 * (size_t)d[t]);
       if (rc == GNX_OK) continue;
       if (rc != 1) return rc;
       if ((rc = launch_dense_rows(h, t, l2[t], d[t], p->ff[t].fc1, 4 * d[t], nullptr, nullptr, hidden, R, s, "k_rows_gemm_ff1"))) return rc;

@@ -216,6 +216,40 @@ def test_core_wide_edge_feedforward_six_term_kernel_ragged_rows_activations_no_b
     assert torch.equal(y.nf, y0.nf) and torch.equal(y.gf, y0.gf)  # (nodes and graphs do not go through the six-term kernel)
 
 
+@pytest.mark.parametrize("dims,N,E", [((64, 48, 32), 600, 6000), ((128, 64, 32), 4300, 9000)])
+def test_core_wide_feedforward_six_term_kernel_at_width_64(gn, dims, N, E):
+    """The six-term kernel at D = 64 (two register pairs split per k16-step): the EDGE FeedForward of a (64, 48, 32) core, and the NODE
+    FeedForward of a (128, 64, 32) core with >= 4096 nodes (on the handle's side stream) — against the float64 oracle at 1e-5·scale, and
+    against the fp32-MFMA kernels normwise."""
+    import os
+    import torch
+    if os.environ.get("GNX_FFN_FP32"):
+        pytest.skip("GNX_FFN_FP32 is set for the whole run: the six-term kernel is switched off")
+    rng = np.random.default_rng(5300 + N)
+    colptr, rowval = U.er_csc(rng, N, E)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [N])
+    p = O.make_core_params(rng, dims)
+    ef, nf, gf = U.packed_inputs(rng, 1, E, N, 1, dims)
+    core = U.core_from_params(gn, p)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    gn.profile_reset(); gn.profile_enable(True)
+    y = core(x)
+    gn.profile_enable(False)
+    prof = gn.profile_read(); gn.profile_reset()
+    assert "k_ffn_x6" in set(prof), set(prof)
+    ref, scale = O.core_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    for name, got, r, sc in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r, sc, name)
+    os.environ["GNX_FFN_FP32"] = "1"
+    try:
+        y0 = core(x)
+    finally:
+        del os.environ["GNX_FFN_FP32"]
+    for a, b in ((y.ef, y0.ef), (y.nf, y0.nf)):
+        assert float((a.double() - b.double()).abs().max()) <= 2e-6 * float(b.double().abs().max())
+    assert torch.equal(y.gf, y0.gf)
+
+
 def test_core_wide_side_stream_equals_single_stream(gn):
     """A wide GNCore forks its graph level, node projections and node FeedForward onto the handle's side stream (GNX_NO_FORK=1: one
     stream).  Same kernels, same order of every sum: the results are bit-identical — eagerly, repeatedly (a race would show as a
