@@ -19,7 +19,7 @@ FULL_NAMES = "--full-names" in sys.argv  # keep the template arguments of every 
 def short(name):
     """gnx::k_rows_gemm<128, true>(gnx::WideArgs) -> k_rows_gemm<128,true>"""
     name = name.split("(")[0].split("::")[-1].replace(" ", "")
-    return name if (FULL_NAMES or name.startswith("k_rows_gemm") or name.startswith("k_ffn_fused")) else name.split("<")[0]  # (k_ffn_fused<128> and <64> are different kernels: never averaged together)
+    return name if (FULL_NAMES or name.startswith("k_rows_gemm") or name.startswith("k_ffn_fused") or name.startswith("k_ffn_x6<")) else name.split("<")[0]  # (k_ffn_fused / k_ffn_x6 <128> and <64> are different kernels: never averaged together)
 
 
 # at core dims (template arguments: BN, quad outputs, K chunk, epilogue operand streams (3: destination rows through LDS), transcendental activation, loader class)
