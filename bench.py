@@ -508,10 +508,18 @@ def c_abi_bench(mode, steps, warmup, extra=(), timeout=240):
         return {"error": repr(e)[:300]}
 
 
+def free_port():
+    """A TCP port nobody is bound to right now (the GPU host is shared: a fixed rendezvous port can be somebody else's)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) outside torchrun: start the N ranks as a CHILD job before this process has touched
     a GPU (a process that has initialised HIP must never exec or fork into GPU work), relay its output, exit with its code."""
-    port = int(os.environ.get("MASTER_PORT", 29500 + os.getpid() % 2000))
+    port = int(os.environ.get("MASTER_PORT", 0)) or free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -600,7 +608,7 @@ def main():
     multi = world > 1 or args.force_dist
     if multi:
         if "RANK" not in os.environ:
-            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29511"))
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(free_port()))
         dist.init_process_group("nccl", device_id=dev)
     K, W = args.steps, args.warmup
     if args.model == "c4":

@@ -13,6 +13,14 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+
+def _free_port():
+    """A TCP port nobody is bound to right now (a fixed rendezvous port can be taken on a shared host)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
 def _batch(seed=7, G=11):
     rng = np.random.default_rng(seed)
     adjs = [(rng.random((n, n)) < 0.4).astype(np.int64) for n in rng.integers(2, 9, G)]
@@ -64,7 +72,7 @@ def test_partition_is_balanced_and_complete():
 def test_two_rank_gloo_matches_single_process(tmp_path):
     from oracle import gn_oracle as O
     out = str(tmp_path / "gf_all.npy")
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     adjs, ef, nf = _batch()
     p = O.make_block_params(np.random.default_rng(1), (3, 4, 0), (2, 3, 5))
@@ -98,7 +106,7 @@ def test_stacked_gather_restores_original_graph_order(tmp_path):
     """M stacked gf' tables in one collective, unequal shards: every (step, graph) row lands at its original graph id."""
     from graphnets_jl_amd.dist import partition_graphs
     out = str(tmp_path / "stack.npy")
-    mp.spawn(_stack_worker, args=(2, 29500 + (os.getpid() + 7) % 2000, out), nprocs=2, join=True)
+    mp.spawn(_stack_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     res = np.load(out)
     assert res.shape == (3, 7, 2)
     shards = partition_graphs(np.random.default_rng(3).integers(1, 50, 7), 2)

@@ -102,7 +102,11 @@ def test_gfgather_through_rccl_world_1(gn):
     import torch
     import torch.distributed as dist
     from graphnets_jl_amd.dist import GfGather
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", WORLD_SIZE="1")
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a port nobody holds right now (the GPU host is shared)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         shards = [np.array([3, 0, 2, 1])[np.argsort([3, 0, 2, 1])]]  # one rank owns every graph
