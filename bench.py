@@ -442,6 +442,8 @@ SECONDARY = [  # (key, extra argv, BASELINE config it stands for)
      "configs[4]'s batch through the N > 1 code path at world size 1 (partitioner, stacked gf' send buffer, RCCL all-gather on a side stream, index table back to graph order)"),
     ("c4", ["--model", "c4"], "configs[3]: Encoder -> 2 x GNCore(128,64,32) -> Decoder on the 1M-edge graph"),
     ("c4_narrow", ["--model", "c4", "--core-dims", "10,5,3"], "README example 3 at its own widths (core_dims 10,5,3)"),
+    # the same model with every matrix product on the fp32 matrix instruction (GNX_FFN_FP32=1 in the child's environment): what the six-term bf16 form of `c4` is measured against
+    ("c4_fp32_mfma", ["--model", "c4", "--no-cpu-baseline", "--no-c-abi"], "configs[3] with the FeedForwards on the fp32 matrix instruction (GNX_FFN_FP32=1; round 3's arithmetic) — beside `c4`, not instead of it", {"GNX_FFN_FP32": "1"}),
 ]
 
 
@@ -450,13 +452,13 @@ def collect_secondary(args):
     lines cut down to what the judge reads.  A child that fails is reported as such (the headline line does not depend on it)."""
     out = {}
     t_all = time.perf_counter()
-    for key, extra, what in SECONDARY:
-        steps = {"c4": max(3, min(args.steps, 5)), "core_c2": max(5, min(args.steps, 10))}.get(key, max(10, min(args.steps, 20)))
+    for key, extra, what, *env_extra in SECONDARY:
+        steps = {"c4": max(3, min(args.steps, 5)), "c4_fp32_mfma": max(3, min(args.steps, 5)), "core_c2": max(5, min(args.steps, 10))}.get(key, max(10, min(args.steps, 20)))
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(max(2, min(args.warmup, 5))),
                "--no-secondary", "--cpu-budget", "3.0"] + extra
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, **env_extra[0]) if env_extra else None)
             line = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
             err = None if line is not None else (r.stderr or "")[-300:]
         except Exception as e:  # timeout, malformed output
