@@ -313,6 +313,8 @@ def bench_c4(args, gn, torch, dev, c_abi=None):
     tkey = "c4" if core == (128, 64, 32) else "c4_" + "-".join(map(str, core))
     sha = model_source_sha(core)
     traffic, tsrc = load_traffic(tkey, "__model__", sha)
+    if os.environ.get("GNX_FFN_FP32") and ce == 128:  # (the profiled traffic is the six-term form's)
+        traffic, tsrc = None, {"note": "profiles/traffic_c4.json was measured with k_ffn_x6; round 3 measured this form at 15.8 GB"}
     # The roof of the model: its executed flops at the rate of the instruction that carries them.  The two edge FeedForwards at width 128 run as
     # k_ffn_x6 — every fp32 product as six bf16 matrix-core terms with fp32 accumulation (csrc/gnx_ffn_x6.hip; as accurate as the fp32 MFMA:
     # tests/test_gpu_core.py) — unless GNX_FFN_FP32=1; everything else on the fp32 MFMA.
