@@ -44,7 +44,7 @@ NSETS = 8                  # rotating buffer sets: 8 x ~60 MB > 256 MiB Infinity
 DIMS = {"readme": ((10, 5, 0), (3, 4, 5)), "core": ((128, 64, 32), (128, 64, 32)),
         "odd": ((7, 3, 2), (5, 6, 1)), "mid": ((20, 10, 4), (12, 9, 3))}  # odd: fused kernel specialised at run time (GNX_JIT=0: generic kernels); mid: generic/MFMA path
 KERNEL_SOURCES = {"narrow": ("gnx_wave_kernel.h", "gnx_device.h", "gnx_narrow.hip", "gnx_forward.hip", "gnx_graphs.cpp"),
-                  "wide": ("gnx_wide.hip", "gnx_device.h", "gnx_forward.hip", "gnx_graphs.cpp")}
+                  "wide": ("gnx_wide.hip", "gnx_edge_x6.hip", "gnx_device.h", "gnx_forward.hip", "gnx_graphs.cpp")}
 
 
 def kernel_source_sha(din, dout):
@@ -313,13 +313,15 @@ def bench_c4(args, gn, torch, dev, c_abi=None):
     tkey = "c4" if core == (128, 64, 32) else "c4_" + "-".join(map(str, core))
     sha = model_source_sha(core)
     traffic, tsrc = load_traffic(tkey, "__model__", sha)
-    if os.environ.get("GNX_FFN_FP32") and ce == 128:  # (the profiled traffic is the six-term form's)
+    if (os.environ.get("GNX_FFN_FP32") or os.environ.get("GNX_EDGE_FP32")) and ce == 128:  # (the profiled traffic is the six-term form's)
         traffic, tsrc = None, {"note": "profiles/traffic_c4.json was measured with k_ffn_x6; round 3 measured this form at 15.8 GB"}
     # The roof of the model: its executed flops at the rate of the instruction that carries them.  The two edge FeedForwards at width 128 run as
     # k_ffn_x6 — every fp32 product as six bf16 matrix-core terms with fp32 accumulation (csrc/gnx_ffn_x6.hip; as accurate as the fp32 MFMA:
     # tests/test_gpu_core.py) — unless GNX_FFN_FP32=1; everything else on the fp32 MFMA.
     x6 = ce == 128 and not os.environ.get("GNX_FFN_FP32")
     x6_flops = 2 * 16 * E * ce * ce if x6 else 0
+    if ce == 128 and not os.environ.get("GNX_EDGE_FP32"):
+        x6_flops += 2 * 2 * E * ce * ce  # the cores' projected edge updates (k_edge_x6: K = 128 -> 128 per edge)
     t_roof = x6_flops / (MFMA_BF16_PEAK_TFS / 6 * 1e12) + (ex - x6_flops) / (MFMA_F32_PEAK_TFS * 1e12)
     line = {"metric": "edges/sec through Encoder->2xGNCore(%s)->Decoder, 1M-edge graph (BASELINE configs[3])" % ",".join(map(str, core)),
             "value": round(E / dt, 1), "unit": "edges/s", "ms_per_step": round(dt * 1e3, 4), "steps": K, "dtype": "f32",
@@ -445,7 +447,7 @@ SECONDARY = [  # (key, extra argv, BASELINE config it stands for)
     ("c4", ["--model", "c4"], "configs[3]: Encoder -> 2 x GNCore(128,64,32) -> Decoder on the 1M-edge graph"),
     ("c4_narrow", ["--model", "c4", "--core-dims", "10,5,3"], "README example 3 at its own widths (core_dims 10,5,3)"),
     # the same model with every matrix product on the fp32 matrix instruction (GNX_FFN_FP32=1 in the child's environment): what the six-term bf16 form of `c4` is measured against
-    ("c4_fp32_mfma", ["--model", "c4", "--no-cpu-baseline", "--no-c-abi"], "configs[3] with the FeedForwards on the fp32 matrix instruction (GNX_FFN_FP32=1; round 3's arithmetic) — beside `c4`, not instead of it", {"GNX_FFN_FP32": "1"}),
+    ("c4_fp32_mfma", ["--model", "c4", "--no-cpu-baseline", "--no-c-abi"], "configs[3] with the FeedForwards and the cores' edge updates on the fp32 matrix instruction (GNX_FFN_FP32=1 GNX_EDGE_FP32=1; round 3's arithmetic) — beside `c4`, not instead of it", {"GNX_FFN_FP32": "1", "GNX_EDGE_FP32": "1"}),
 ]
 
 
@@ -914,9 +916,15 @@ def main():
             # reference formulation (every edge multiplies its full [ef; nf_src; nf_dst; gf] row) is reported beside it
             ex = executed_flops(E, N, G, din, dout)
             a = ex / step_s / 1e12
-            roof = dict(bound="mfma", achieved=round(a, 3), peak=MFMA_F32_PEAK_TFS, unit="TFLOP/s", frac=round(a / MFMA_F32_PEAK_TFS, 4),
-                        frac_whole_step=round(a / MFMA_F32_PEAK_TFS, 4), traffic=traffic, traffic_source=tsrc,
-                        counts="EXECUTED flops of the whole block / whole-step time (the block is several GEMM launches)",
+            # the projected edge update at 128 -> 128 runs as six bf16 matrix-core terms per fp32 product (k_edge_x6) unless GNX_EDGE_FP32=1: its
+            # flops are priced at that instruction's rate, the rest at the fp32 MFMA's
+            x6_flops = 2 * E * din[0] * dout[0] if (din[0] == 128 and dout[0] == 128 and din[1] >= 16 and E >= 2 * N and not os.environ.get("GNX_EDGE_FP32")) else 0
+            t_roof = x6_flops / (MFMA_BF16_PEAK_TFS / 6 * 1e12) + (ex - x6_flops) / (MFMA_F32_PEAK_TFS * 1e12)
+            roof = dict(bound="mfma", achieved=round(a, 3), peak=round(ex / t_roof / 1e12, 1), unit="TFLOP/s", frac=round(t_roof / step_s, 4),
+                        frac_whole_step=round(t_roof / step_s, 4), frac_of_fp32_mfma_roof=round(a / MFMA_F32_PEAK_TFS, 4), flops_on_bf16_six_terms=x6_flops,
+                        traffic=traffic, traffic_source=tsrc,
+                        counts="EXECUTED flops of the whole block / whole-step time (the block is several GEMM launches); peak = the same flops at the rate of the instruction "
+                               "that carries them (fp32 MFMA %.1f TFLOP/s; six bf16 terms per fp32 product: %.0f / 6)" % (MFMA_F32_PEAK_TFS, MFMA_BF16_PEAK_TFS),
                         executed_flops=ex, algorithmic_tflops_whole_step=round(aflops / step_s / 1e12, 2),
                         hbm_frac_whole_step=round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 4))
         if traffic is not None and workload == "c2" and args.dims == "readme" and args.c2_scale == 1.0:

@@ -23,6 +23,10 @@
 
 namespace gnx {
 
+int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_t E, const float* ln_stats, const float* ln_g, const float* ln_b, const float* We, int ldw,
+                       const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out,
+                       size_t n_agg_rows, const int* chunk_row0, int64_t R, void* scratch, hipStream_t s);  // gnx_edge_x6.hip
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef GNX_GEMM_WPE  // 3 waves per SIMD = 3 workgroups per CU with a 168-register budget: NO spilled register at BN = 128.  A 4th workgroup
@@ -1148,7 +1152,8 @@ size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int6
   const size_t proj = sizeof(float) * 2 * (size_t)R * h->N * (size_t)p->oe;  // node projections Ps, Pd
   const size_t xg = sizeof(float) * (size_t)R * h->G * (size_t)(p->oe + p->on + p->dg);  // graph-function input (small batches)
   const size_t agg = sizeof(float) * (size_t)R * (size_t)h->agg_rows_bound * (size_t)p->oe;  // per-destination partial sums of the edge GEMM (rows: an upper bound known without the tables)
-  return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + align_up(xg, 256) + align_up(agg, 256) + 512;
+  const size_t x6 = sizeof(__bf16) * 3 * (size_t)p->de * (size_t)p->oe;  // the edge update's weight block as three bf16 planes (k_edge_x6_prep)
+  return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + align_up(xg, 256) + align_up(agg, 256) + align_up(x6, 256) + 512;
 }
 
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -1396,6 +1401,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   float* proj_d = proj_s + (size_t)R * h->N * a.oe;
   float* agg_tab = reinterpret_cast<float*>(reinterpret_cast<char*>(proj_s) + align_up(sizeof(float) * 2 * (size_t)R * h->N * a.oe, 256) +
                                             align_up(sizeof(float) * (size_t)R * h->G * (size_t)(a.oe + a.on + a.dg), 256));
+  void* x6_tab = reinterpret_cast<char*>(agg_tab) + align_up(sizeof(float) * (size_t)R * (size_t)h->agg_rows_bound * (size_t)a.oe, 256);
   // edge -> node sums inside the edge GEMM's epilogue (the node GEMM then reads ~N rows instead of all E rows of ef')
   static const bool no_agg_fuse = getenv("GNX_NO_AGG_FUSE") != nullptr;
   // (needs quad outputs, and — with the projections' epilogue operands — an ef whose rows are quads: see launch_gemm's instantiations)
@@ -1432,6 +1438,15 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     w.out = proj_s; w.out2 = proj_d; w.out_rep_stride = (size_t)a.N * a.oe;
     if ((rc = launch_gemm_any(w, (unsigned)n_nt, R, s, "k_rows_gemm_proj"))) return rc;
   }
+  // the projected edge update at 128 -> 128 as six bf16 matrix-core terms per fp32 product (gnx_edge_x6.hip)
+  // (GNX_EDGE_FP32=1, read per call: k_rows_gemm on the fp32 matrix instruction instead)
+  const bool edge_x6 = (phase & 1) && project && a.de == 128 && a.oe == 128 && a.dn > 0 && edge_out_vec && ef_vec && al16(a.ln_g[0]) && al16(a.ln_b[0]) &&
+                       (agg_fuse || a.on == 0) && getenv("GNX_EDGE_FP32") == nullptr && (size_t)h->E >= 4096;
+  if (edge_x6) {
+    if ((rc = launch_edge_x6(h->d_etiles, n_et, a.ef, (size_t)a.E, a.ln_stats[0], a.ln_g[0], a.ln_b[0], a.We, a.oe, proj_s, proj_d, (size_t)a.N, a.rowval, h->d_edge_dst, a.act_e,
+                             a.ef_out, a.og > 0 ? pe : nullptr, agg_fuse ? agg_tab : nullptr, (size_t)h->n_agg_rows, h->d_chunk_row0, R, x6_tab, s)))
+      return rc;
+  } else
   if ((phase & 1) && a.oe > 0) {
     WideArgs w{};
     w.tiles = h->d_etiles; w.row_kind = 0;

@@ -145,13 +145,15 @@ def test_core_wide_layernorm_on_load_equals_materialised(gn, R, eps_mode):
 
 
 def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gn):
-    """GNCore(128,64,32): the edge FeedForward runs as k_ffn_x6 — every fp32 product as six bf16 matrix-core terms (hi/mid/lo parts hold the
-    24 mantissa bits exactly), fp32 accumulation — unless GNX_FFN_FP32=1 selects the fp32-MFMA kernel.  Against the float64 oracle both
-    must meet the 1e-5·scale bar, and the six-term form must be as accurate as the fp32 instruction: its worst and its mean error within
-    1.25 x the fp32 kernel's (measured: equal to two digits).  Inputs with a mean far from zero, weights of both signs, relu between."""
+    """GNCore(128,64,32): the edge FeedForward (k_ffn_x6) and the projected edge update (k_edge_x6) run every fp32 product as six bf16
+    matrix-core terms (hi/mid/lo parts hold the 24 mantissa bits exactly), fp32 accumulation — unless GNX_FFN_FP32=1 / GNX_EDGE_FP32=1 select
+    the kernels on the fp32 matrix instruction.  Against the float64 oracle both forms must meet the 1e-5·scale bar, and the six-term form must
+    be as accurate as the fp32 instruction: its MEAN error within 1.1 x the fp32 form's (measured: equal to two digits) and its worst element
+    within 1.5 x (the maximum over 1.5M elements moves by ±20 % with any change of summation order).  Inputs with a mean far from zero,
+    weights of both signs, relu between."""
     import os
-    if os.environ.get("GNX_FFN_FP32"):
-        pytest.skip("GNX_FFN_FP32 is set for the whole run: the six-term kernel is switched off")
+    if os.environ.get("GNX_FFN_FP32") or os.environ.get("GNX_EDGE_FP32"):
+        pytest.skip("GNX_FFN_FP32 / GNX_EDGE_FP32 is set for the whole run: a six-term kernel is switched off")
     rng = np.random.default_rng(5100)
     dims = (128, 64, 32)
     colptr, rowval = U.er_csc(rng, 900, 12000)
@@ -166,6 +168,7 @@ def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_
     for which in ("x6", "fp32"):
         if which == "fp32":
             os.environ["GNX_FFN_FP32"] = "1"
+            os.environ["GNX_EDGE_FP32"] = "1"
         try:
             gn.profile_reset(); gn.profile_enable(True)
             y = core(x)
@@ -173,13 +176,14 @@ def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_
             names = set(gn.profile_read()); gn.profile_reset()
         finally:
             os.environ.pop("GNX_FFN_FP32", None)
-        assert ("k_ffn_x6" in names) == (which == "x6"), names
+            os.environ.pop("GNX_EDGE_FP32", None)
+        assert ("k_ffn_x6" in names) == (which == "x6") and ("k_edge_x6_prep" in names) == (which == "x6"), names
         for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
             U.assert_close(U.from_jl(got), r, s, f"{which} {name}")
         err = np.abs(U.from_jl(y.ef).astype(np.float64) - ref[0]) / scale[0]
         out[which] = (float(err.max()), float(err.mean()))
     print("edge FeedForward error / scale (worst, mean): six bf16 terms", out["x6"], " fp32 MFMA", out["fp32"])
-    assert out["x6"][0] <= 1.25 * out["fp32"][0] and out["x6"][1] <= 1.25 * out["fp32"][1], out
+    assert out["x6"][0] <= 1.5 * out["fp32"][0] and out["x6"][1] <= 1.1 * out["fp32"][1], out
 
 
 @pytest.mark.parametrize("act,bias,E", [("relu", True, 4137), ("identity", True, 5000), ("tanh", True, 4099), ("relu", False, 4608)])

@@ -195,7 +195,11 @@ def test_wide_projected_edge_update_destination_rows_through_lds(gn, case, tmp_p
     import subprocess
     import sys
     p, g, ef, nf, gf = _pd_lds_case(gn, case)
-    y = _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
+    os.environ["GNX_EDGE_FP32"] = "1"  # (case 0 is 128 -> 128: this test is about k_rows_gemm's two forms, not about k_edge_x6)
+    try:
+        y = _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
+    finally:
+        del os.environ["GNX_EDGE_FP32"]
     out = str(tmp_path / "two_streams.npz")
     code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
             "import graphnets_jl_amd as gn\n"
@@ -204,7 +208,7 @@ def test_wide_projected_edge_update_destination_rows_through_lds(gn, case, tmp_p
             "p, g, ef, nf, gf = _pd_lds_case(gn, %d)\n"
             "y = U.block_from_params(gn, p)(U.to_nt(gn, g, ef, nf, gf))\n"
             "np.savez(%r, **{k: U.from_jl(v) for k, v in (('ef', y.ef), ('nf', y.nf), ('gf', y.gf)) if v is not None})\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), case, out)
-    env = dict(os.environ, GNX_GEMM_PD_LDS="0")
+    env = dict(os.environ, GNX_GEMM_PD_LDS="0", GNX_EDGE_FP32="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     z = np.load(out)
@@ -213,3 +217,44 @@ def test_wide_projected_edge_update_destination_rows_through_lds(gn, case, tmp_p
             assert name not in z.files
         else:
             np.testing.assert_array_equal(U.from_jl(got), z[name], err_msg=name)
+
+
+_EDGE_X6_CASES = [
+    # (dout, act, R, graphs as (nodes, edges))      what it exercises in k_edge_x6 (the projected edge update at 128 -> 128 as six bf16 terms)
+    ((128, 64, 32), (1, 0, 2), 1, ((900, 12000), (300, 5000), (64, 700))),  # tiles that end at graph boundaries (ragged rows), per-destination sums, column sums
+    ((128, 64, 32), (2, 1, 0), 2, ((700, 9000),)),                          # tanh (the run-time activation switch), replicas
+    ((128, 0, 8), (1, 0, 0), 1, ((800, 10000),)),                           # no node update behind it: no per-destination sums, column sums from the rows
+    ((128, 64, 0), (0, 1, 0), 1, ((800, 10000),)),                          # no graph update: no column sums
+]
+
+
+@pytest.mark.parametrize("case", range(len(_EDGE_X6_CASES)))
+def test_wide_projected_edge_update_on_bf16_matrix_cores(gn, case):
+    """GNBlock (128, 64, 32) => (128, ...): the projected edge update as k_edge_x6 — every fp32 product as six bf16 matrix-core terms —
+    against the float64 oracle at 1e-5·scale (ef', and nf' / gf' which read its per-destination and column sums), and against the
+    fp32-MFMA form (GNX_EDGE_FP32=1: k_rows_gemm) normwise at 2e-6."""
+    import os
+    dout, act, R, graphs = _EDGE_X6_CASES[case]
+    din = (128, 64, 32)
+    rng = np.random.default_rng(700 + case)
+    cs = [U.er_csc(rng, n, e) for n, e in graphs]
+    g = gn.GNGraphBatch.from_csc([c for c, _ in cs], [r for _, r in cs], [n for n, _ in graphs])
+    p = O.make_block_params(rng, din, dout, act=act)
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, g.n_graphs, din)
+    gn.profile_reset(); gn.profile_enable(True)
+    y = _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
+    gn.profile_enable(False)
+    names = set(gn.profile_read()); gn.profile_reset()
+    if not os.environ.get("GNX_EDGE_FP32"):
+        assert "k_edge_x6_prep" in names, names
+    os.environ["GNX_EDGE_FP32"] = "1"
+    try:
+        y0 = U.block_from_params(gn, p)(U.to_nt(gn, g, ef, nf, gf))
+    finally:
+        del os.environ["GNX_EDGE_FP32"]
+    for a, b in ((y.ef, y0.ef), (y.nf, y0.nf), (y.gf, y0.gf)):
+        if a is None:
+            assert b is None
+            continue
+        a, b = U.from_jl(a).astype(np.float64), U.from_jl(b).astype(np.float64)
+        assert np.max(np.abs(a - b)) <= 2e-6 * max(np.max(np.abs(b)), 1e-30)
