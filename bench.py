@@ -472,7 +472,7 @@ def collect_secondary(args):
             continue
         roof = line.get("roofline") or {}
         keep = ("bound", "achieved", "peak", "unit", "frac", "frac_whole_step", "traffic", "kernel", "kernel_us", "executed_flops", "algorithmic_bytes",
-                "frac_of_fp32_mfma_roof", "flops_on_bf16_six_terms", "arithmetic")
+                "frac_of_fp32_mfma_roof", "flops_on_bf16_six_terms", "arithmetic", "matrix_roof_frac")
         entry = {"what": what, "value": line["value"], "unit": line["unit"], "ms_per_step": line["ms_per_step"], "steps": line.get("steps", steps),
                  "roofline": {k: roof[k] for k in keep if k in roof}, "cpu_baseline": line.get("cpu_baseline"),
                  "wall_s": round(time.perf_counter() - t0, 1)}
@@ -902,6 +902,10 @@ def main():
         step_s = ms_per_step * 1e-3
         abytes, aflops = algorithmic_bytes(E, N, G, din, dout), algorithmic_flops(E, N, G, din, dout)
         hbm_t, mfma_t = abytes / (HBM_PEAK_GBS * 1e9), aflops / (MFMA_F32_PEAK_TFS * 1e12)
+        if max(din + dout) > 32:  # matrix-core path: the binding roof is decided on the flops the kernels EXECUTE at the rate of the instruction that carries them
+            ex_ = executed_flops(E, N, G, din, dout)
+            x6_ = 2 * E * din[0] * dout[0] if (din[0] == 128 and dout[0] == 128 and din[1] >= 16 and E >= 2 * N and not os.environ.get("GNX_EDGE_FP32")) else 0
+            mfma_t = x6_ / (MFMA_BF16_PEAK_TFS / 6 * 1e12) + (ex_ - x6_) / (MFMA_F32_PEAK_TFS * 1e12)
         dims_key = args.dims.replace(":", "_").replace(",", "-") + ("" if workload == "c2" else f"_hetero{G}")
         if workload != "c2" and args.hetero_edges != 1_000_000:
             dims_key += f"_{args.hetero_edges}"  # the committed PMC profiles are of the 1M-edge batches: no traffic figure for another size
@@ -911,6 +915,11 @@ def main():
             roof = dict(bound="hbm", achieved=round(a, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(a / HBM_PEAK_GBS, 4),
                         frac_whole_step=round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=tsrc,
                         counts="algorithmic bytes of the whole block / duration of the dominant kernel (frac) or of the whole step (frac_whole_step)")
+            if max(din + dout) > 32:  # a matrix-core block whose matrix time (per carrying instruction) is below its memory time: both fractions on the WHOLE step
+                roof.update(frac=roof["frac_whole_step"], algorithmic_bytes=abytes, executed_flops=ex_, flops_on_bf16_six_terms=x6_,
+                            frac_of_fp32_mfma_roof=round(ex_ / step_s / 1e12 / MFMA_F32_PEAK_TFS, 4), matrix_roof_frac=round(mfma_t / step_s, 4),
+                            counts="algorithmic bytes of the whole block / whole-step time (several launches); matrix_roof_frac: the executed flops at the rate of the "
+                                   "instruction that carries them (fp32 MFMA %.1f TFLOP/s; six bf16 terms per fp32 product: %.0f / 6) / whole-step time" % (MFMA_F32_PEAK_TFS, MFMA_BF16_PEAK_TFS))
         else:
             # MFMA-bound: priced on the flops the kernels EXECUTE (never more than the peak); the algorithmic rate of the
             # reference formulation (every edge multiplies its full [ef; nf_src; nf_dst; gf] row) is reported beside it
