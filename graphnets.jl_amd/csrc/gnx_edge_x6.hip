@@ -236,7 +236,6 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (ob + 1 < ENOB) gather(ob + 1, usn, udn);  // under the sums below and the next slice's matrix instructions
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS traffic only) the finished block of all four waves is in s_e; the next slice's fragments are complete
     const int q4 = tid & 7, grp = tid >> 3;           // 8 quads x 32 row groups
-#ifndef GNX_EX6_EXP_NOSUMS
     f32x4e c4 = {0.f, 0.f, 0.f, 0.f};  // this thread's share of the tile's column sums
     if (a.agg_out) {
       // per-destination sums: groups 0-15 take the runs of pass 0, groups 16-31 those of pass 1 (16 runs per sweep; the 1M-edge graph has ~7 per
@@ -264,7 +263,6 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
     if (a.colsum) *reinterpret_cast<f32x4e*>(s_cs + grp * 32 + 4 * q4) = c4;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // s_e may be overwritten by the next slice; the column-sum partials are complete
-#endif
     if (a.colsum && tid < 32) {  // fixed order: the 32 groups ascending
       float sum = 0.f;
 #pragma unroll
