@@ -307,7 +307,7 @@ GNX_API int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p,
  * evaluated on the bf16 matrix cores as six terms of an EXACT three-way split of both operands (hi + mid + lo bf16 parts = the 24
  * mantissa bits; the dropped terms are <= 2^-23 |a||b|) — as accurate as the fp32 matrix instruction against float64 by test, 2x its
  * speed; inputs that are not finite (or within 0.4 % of the largest finite float) produce NaN where the fp32 instruction may produce an
- * infinity.  env GNX_FFN_FP32=1 (FeedForwards) / GNX_EDGE_FP32=1 (edge update): the kernel on
+ * infinity, and operands below ~1e-33 in magnitude may keep only 16 of their 24 mantissa bits (their low parts are bf16 subnormals).  env GNX_FFN_FP32=1 (FeedForwards) / GNX_EDGE_FP32=1 (edge update): the kernel on
  * the fp32 matrix instruction instead (csrc/gnx_ffn_x6.hip, csrc/gnx_edge_x6.hip; csrc/gnx_ffn_fused.hip, csrc/gnx_wide.hip). */
 GNX_API size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t n_replicas);
 GNX_API int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf,
