@@ -228,6 +228,45 @@ _EDGE_X6_CASES = [
 ]
 
 
+def _hub_csc(rng, N, hubs, hub_deg, lo, hi):
+    """in-degrees lo..hi-1, except `hubs` nodes with hub_deg in-edges (with repetition-free sources): destinations whose runs cross 64-row chunks and whole tiles"""
+    colptr = np.zeros(N + 1, dtype=np.int64)
+    rows = []
+    hub_at = set(int(v) for v in rng.choice(N, hubs, replace=False))
+    for j in range(N):
+        d = hub_deg if j in hub_at else int(rng.integers(lo, hi))
+        r = np.sort(rng.choice(N, min(d, N), replace=False))
+        rows.append(r); colptr[j + 1] = colptr[j] + len(r)
+    return colptr, np.concatenate(rows).astype(np.int64)
+
+
+def test_wide_projected_edge_update_on_bf16_matrix_cores_hub_destinations(gn):
+    """k_edge_x6 with destinations of 150-500 in-edges (runs that cross 64-row chunks and whole 128-edge tiles: the node update then adds a node's
+    first, second and further partial rows) and isolated nodes, GNCore (gn1 on load) and GNBlock, against the oracle."""
+    rng = np.random.default_rng(777)
+    N = 700
+    colptr, rowval = _hub_csc(rng, N, 6, 500, 0, 9)
+    colptr2, rowval2 = _hub_csc(rng, 300, 3, 150, 1, 6)
+    g = gn.GNGraphBatch.from_csc([colptr, colptr2], [rowval, rowval2], [N, 300])
+    assert g.n_edges >= 4096
+    dims = (128, 64, 32)
+    p = O.make_block_params(rng, dims, dims, act=(1, 1, 0))
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims)
+    gn.profile_reset(); gn.profile_enable(True)
+    _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
+    gn.profile_enable(False)
+    names = set(gn.profile_read()); gn.profile_reset()
+    import os
+    if not os.environ.get("GNX_EDGE_FP32"):
+        assert "k_edge_x6_prep" in names, names
+    pc = O.make_core_params(rng, dims)
+    core = U.core_from_params(gn, pc)
+    y = core(U.to_nt(gn, g, ef, nf, gf))
+    ref, scale = O.core_forward_sparse(pc, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    for name, got, r, sc in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r, sc, name)
+
+
 @pytest.mark.parametrize("case", range(len(_EDGE_X6_CASES)))
 def test_wide_projected_edge_update_on_bf16_matrix_cores(gn, case):
     """GNBlock (128, 64, 32) => (128, ...): the projected edge update as k_edge_x6 — every fp32 product as six bf16 matrix-core terms —
