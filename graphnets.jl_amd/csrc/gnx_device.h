@@ -52,6 +52,7 @@ struct BlockArgs {
   // matrix-core path: row statistics [R][rows][2] (mean, inv) of ef / nf when THEY are to be normalised on load (then ln_g / ln_b
   // hold gamma / beta; gf arrives normalised); nullptr <=> the input is used as it is
   const float* ln_stats[3];
+  int ln_inline_e;  // wide path: gn1 of the edge rows with NO statistics table (ln_stats[0] == nullptr) — k_edge_x6 computes them in registers (ln_eps / ln_mode below)
   // fused narrow path, batches of SMALL graphs: workgroups that own whole graphs (k_block_wave<..., PACK>).  packs[p][8] = the wave tiles
   // of pack p (-1: empty slot), the tiles of a graph adjacent — the graph update then runs inside the block kernel, from LDS
   const int* packs;

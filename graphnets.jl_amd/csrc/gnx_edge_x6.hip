@@ -17,6 +17,7 @@
 #include <cstdio>
 
 #include "gnx_device.h"
+#include "gnx_x6_stats.h"
 
 namespace gnx {
 
@@ -77,6 +78,9 @@ struct EdgeX6Args {
   float* agg_out;          // [R][n_agg_rows][128] or nullptr
   size_t n_agg_rows;
   const int* chunk_row0;   // [2 n_tiles + 1]
+  int ln_inline;           // no ln_stats: the row statistics of gn1 are computed here, in registers (gnx_x6_stats.h), with ln_eps / ln_mode
+  float ln_eps;
+  int ln_mode;
 };
 
 __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_edge_x6(EdgeX6Args a) {
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   bf16x8e zh[EKS], zm[EKS], zl[EKS];
   {
     float mu = 0.f, inv = 1.f;
-    const bool ln = a.ln_stats != nullptr;
-    if (ln) {
+    const bool ln = a.ln_stats != nullptr || a.ln_inline != 0;
+    if (a.ln_stats != nullptr) {
       const float2 st = reinterpret_cast<const float2*>(a.ln_stats)[r * a.E + (size_t)row0 + lrc];
       mu = st.x; inv = st.y;
     }
@@ -131,6 +135,7 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       raw[s][0] = *reinterpret_cast<const f32x4e*>(zrow + 16 * s + 8 * hi);
       raw[s][1] = *reinterpret_cast<const f32x4e*>(zrow + 16 * s + 8 * hi + 4);
     }
+    if (a.ln_inline != 0) x6_row_stats(raw, a.ln_eps, a.ln_mode, mu, inv);
     typedef unsigned u32x4e __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int s = 0; s < EKS; ++s) {
@@ -283,7 +288,7 @@ size_t edge_x6_scratch_bytes() { return sizeof(__bf16) * 3 * (size_t)EK * EOUT; 
 
 int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_t E, const float* ln_stats, const float* ln_g, const float* ln_b, const float* We, int ldw,
                        const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out,
-                       size_t n_agg_rows, const int* chunk_row0, int64_t R, void* scratch, hipStream_t s) {
+                       size_t n_agg_rows, const int* chunk_row0, int64_t R, void* scratch, hipStream_t s, bool ln_inline, float ln_eps, int ln_mode) {
   if (n_tiles == 0) return GNX_OK;
   __bf16* Wp = static_cast<__bf16*>(scratch);
   {
@@ -294,6 +299,7 @@ int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_
   EdgeX6Args a{};
   a.tiles = tiles; a.ef = ef; a.E = E; a.ln_stats = ln_stats; a.ln_g = ln_g; a.ln_b = ln_b; a.Wp = Wp; a.psrc = psrc; a.pdst = pdst; a.N = N;
   a.src = src; a.dst = dst; a.act = act; a.out = out; a.colsum = colsum; a.n_tiles = n_tiles; a.agg_out = agg_out; a.n_agg_rows = n_agg_rows; a.chunk_row0 = chunk_row0;
+  if (ln_inline) { if (ln_stats || !ln_g || !ln_b) return fail(GNX_ERR_INVALID_ARG, "k_edge_x6: statistics in the kernel exclude a statistics table and need gamma / beta"); a.ln_inline = 1; a.ln_eps = ln_eps; a.ln_mode = ln_mode; }
   ProfScope ps("k_rows_gemm_edge", s);  // (the name the edge update has in every profile and bench line)
   GNX_LAUNCH(k_edge_x6, dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
   GNX_HIP(hipGetLastError());

@@ -331,17 +331,19 @@ bool ffn_fused_applies(const float* z, int d, const gnx_ffn& ff, const float* ad
 
 bool ffn_x6_applies(const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, const float* out, size_t scratch_bytes);  // gnx_ffn_x6.hip
 int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, const float* add1, const float* add2, float* out, int64_t R, hipStream_t s,
-                      const float* ln_stats, const gnx_layernorm* ln, void* scratch);
+                      const float* ln_stats, const gnx_layernorm* ln, void* scratch, bool ln_inline, float ln_eps, int ln_mode);
 
 // scratch (optional; scratch_bytes of device memory the caller does not need until this launch has run): lets the edge FeedForward at d = 128 run
 // as k_ffn_x6 — the fp32 products carried by six bf16 matrix-core terms (gnx_ffn_x6.hip) — instead of the fp32-MFMA kernel below
 int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, float* out,
-                         int64_t R, hipStream_t s, const float* ln_stats, const gnx_layernorm* ln, void* scratch, size_t scratch_bytes) {
-  if (!ffn_fused_applies(z, d, ff, add1, add2, out)) return ln_stats ? fail(GNX_ERR_INVALID_ARG, "k_ffn_fused: LayerNorm on load asked for a FeedForward it does not take") : 1;
+                         int64_t R, hipStream_t s, const float* ln_stats, const gnx_layernorm* ln, void* scratch, size_t scratch_bytes, bool ln_inline, float ln_eps,
+                         int ln_mode) {
+  if (!ffn_fused_applies(z, d, ff, add1, add2, out)) return (ln_stats || ln_inline) ? fail(GNX_ERR_INVALID_ARG, "k_ffn_fused: LayerNorm on load asked for a FeedForward it does not take") : 1;
   const size_t nrows = entity == 0 ? (size_t)h->E : (entity == 1 ? (size_t)h->N : (size_t)h->G);
   if (nrows == 0) return GNX_OK;
   if (scratch && nrows >= 4096 && ffn_x6_applies(z, d, ff, add1, add2, out, scratch_bytes))
-    return launch_ffn_x6(z, nrows, d, ff, add1, add2, out, R, s, ln_stats, ln, scratch);
+    return launch_ffn_x6(z, nrows, d, ff, add1, add2, out, R, s, ln_stats, ln, scratch, ln_inline, ln_eps, ln_mode);
+  if (ln_inline) return fail(GNX_ERR_INVALID_ARG, "internal: statistics in the kernel asked of the fp32 FeedForward");
   if (ln_stats && (!ln || !ln->gamma || !ln->beta || ((uintptr_t)ln->gamma & 15) || ((uintptr_t)ln->beta & 15) || ((uintptr_t)ln_stats & 7)))
     return fail(GNX_ERR_INVALID_ARG, "k_ffn_fused: LayerNorm parameters missing or misaligned");
   if (int32_t rcw = gnx_ensure_wide_tables(h, s)) return rcw;

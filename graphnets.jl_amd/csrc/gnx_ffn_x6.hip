@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "gnx_device.h"
+#include "gnx_x6_stats.h"
 
 namespace gnx {
 
@@ -96,6 +97,9 @@ struct FfnX6Args {
   const float* ln_stats;   // [R][rows][2] (mean, 1/sigma) from k_ln_stats_v4, or nullptr
   const float* ln_g;
   const float* ln_b;
+  int ln_inline;           // D = 128: no ln_stats — the row statistics are computed here, in registers (gnx_x6_stats.h), with ln_eps / ln_mode
+  float ln_eps;
+  int ln_mode;
 };
 
 #ifdef GNX_X6_STAMPS_BUILD  // diagnostic build only (tools/build_variant.sh x6st gnx_ffn_x6.hip -DGNX_X6_STAMPS_BUILD; GNX_X6_STAMPS=1): shader-clock stamps of wave 0
@@ -155,8 +159,9 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   bf16x8x zh[KS], zm[KS], zl[KS];
   {
     float mu = 0.f, inv = 1.f;
-    const bool ln = a.ln_stats != nullptr;
-    if (ln) {
+    const bool ln_in = D == 128 && a.ln_inline != 0;
+    const bool ln = a.ln_stats != nullptr || ln_in;
+    if (a.ln_stats != nullptr) {
       const float2 st = reinterpret_cast<const float2*>(a.ln_stats)[r * rows + rown];
       mu = st.x; inv = st.y;
     }
@@ -165,6 +170,9 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     for (int s = 0; s < KS; ++s) {
       raw[s][0] = *reinterpret_cast<const f32x4x*>(zrow + 16 * s + 8 * hi);
       raw[s][1] = *reinterpret_cast<const f32x4x*>(zrow + 16 * s + 8 * hi + 4);
+    }
+    if constexpr (D == 128) {
+      if (ln_in) x6_row_stats(raw, a.ln_eps, a.ln_mode, mu, inv);
     }
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -409,12 +417,13 @@ bool ffn_x6_applies(const float* z, int d, const gnx_ffn& ff, const float* add1,
 
 // out = add1 + add2 + fc2(act1(fc1(z))) over `nrows` rows per replica; `scratch`: ffn_x6_scratch_bytes(d), 16-byte aligned, free until the launch has run
 int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, const float* add1, const float* add2, float* out, int64_t R, hipStream_t s,
-                      const float* ln_stats, const gnx_layernorm* ln, void* scratch) {
+                      const float* ln_stats, const gnx_layernorm* ln, void* scratch, bool ln_inline, float ln_eps, int ln_mode) {
   if (nrows == 0) return GNX_OK;
   if (!scratch || ((uintptr_t)scratch & 15)) return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6: scratch missing or misaligned");
   if (!z || !ff.fc1.weight || !ff.fc2.weight || !out) return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6: NULL operand");
-  if (ln_stats && (!ln || !ln->gamma || !ln->beta || ((uintptr_t)ln->gamma & 15) || ((uintptr_t)ln->beta & 15) || ((uintptr_t)ln_stats & 7)))
+  if ((ln_stats || ln_inline) && (!ln || !ln->gamma || !ln->beta || ((uintptr_t)ln->gamma & 15) || ((uintptr_t)ln->beta & 15) || ((uintptr_t)ln_stats & 7)))
     return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6: LayerNorm parameters missing or misaligned");
+  if (ln_inline && (ln_stats || d != 128)) return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6: statistics in the kernel are for width 128 and exclude a statistics table");
   __bf16* Wp = static_cast<__bf16*>(scratch);
   {
     ProfScope ps("k_ffn_x6_prep", s);
@@ -424,6 +433,7 @@ int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, co
   FfnX6Args a{};
   a.z = z; a.Wp = Wp; a.b1 = ff.fc1.bias; a.b2 = ff.fc2.bias; a.add1 = add1; a.add2 = add2; a.out = out; a.rows = nrows; a.act1 = ff.fc1.act;
   if (ln_stats) { a.ln_stats = ln_stats; a.ln_g = ln->gamma; a.ln_b = ln->beta; }
+  if (ln_inline) { a.ln_inline = 1; a.ln_eps = ln_eps; a.ln_mode = ln_mode; a.ln_g = ln->gamma; a.ln_b = ln->beta; }
 #ifdef GNX_X6_STAMPS_BUILD
   static unsigned long long* d_dbg = nullptr;
   static size_t dbg_cap = 0;

@@ -40,7 +40,10 @@ void warm_block_wide(const gnx_graphs* h, const gnx_block_params* p, bool rows_g
 bool core_narrow_width(int d);
 int32_t launch_ln1_rows(const float* x, size_t rows, int d, const gnx_layernorm& l1, float eps, int eps_mode, float* y, hipStream_t s);
 int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, float* out,
-                         int64_t R, hipStream_t s, const float* ln_stats = nullptr, const gnx_layernorm* ln = nullptr, void* scratch = nullptr, size_t scratch_bytes = 0);
+                         int64_t R, hipStream_t s, const float* ln_stats = nullptr, const gnx_layernorm* ln = nullptr, void* scratch = nullptr, size_t scratch_bytes = 0,
+                         bool ln_inline = false, float ln_eps = 0.f, int ln_mode = 0);
+bool ffn_x6_applies(const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, const float* out, size_t scratch_bytes);  // gnx_ffn_x6.hip
+bool block_wide_edge_x6_applies(const gnx_graphs* h, const BlockArgs& a);  // gnx_wide.hip
 bool ffn_fused_applies(const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, const float* out);
 bool block_wide_ln_applies(const gnx_graphs* h, const BlockArgs& a);
 bool ln_stats_applies(const float* x, int d);
@@ -99,7 +102,7 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
                                   size_t ws_bytes, uint32_t flags, hipStream_t s, int phase = 3, const gnx_layernorm* ln1 = nullptr,
                                   float ln_eps = 0.f, int ln_mode = 0, bool* fused_ln = nullptr, const float* const* wide_ln_stats = nullptr,
                                   BlockArgs* args_out = nullptr, const gnx_ffn* ffe = nullptr, const gnx_layernorm* ffe_ln2 = nullptr, bool* ffe_took = nullptr,
-                                  const gnx_pending_update* chain_prev = nullptr, bool* chain_took = nullptr) {
+                                  const gnx_pending_update* chain_prev = nullptr, bool* chain_took = nullptr, bool* edge_x6_out = nullptr, bool ln_inline_e = false) {
   int32_t rc = check_block(h, p, R);
   if (rc) return rc;
   if (phase & 1) {
@@ -137,8 +140,10 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
     // only ASK whether this block takes that form (nothing is launched)
     for (int t = 0; t < 2; ++t) { a.ln_g[t] = ln1[t].gamma; a.ln_b[t] = ln1[t].beta; }
     *fused_ln = !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA)) && block_wide_ln_applies(h, a);
+    if (edge_x6_out) *edge_x6_out = *fused_ln && block_wide_edge_x6_applies(h, a);  // (the caller may then leave the edge rows' statistics to that kernel)
     if (!*fused_ln || !wide_ln_stats[0]) return GNX_OK;
     a.ln_stats[0] = wide_ln_stats[0]; a.ln_stats[1] = wide_ln_stats[1];
+    if (ln_inline_e) { a.ln_stats[0] = nullptr; a.ln_inline_e = 1; a.ln_eps = ln_eps; a.ln_mode = ln_mode; }  // no table for the edges: k_edge_x6 computes them in registers
     return launch_block_wide(h, a, R, s, phase);
   }
   if (ln1) {
@@ -348,7 +353,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   // row statistics — neither LayerNorm output of ef / nf exists in HBM.  Taken when the block runs in the projected quad-row form
   // and both FeedForwards are the fused kernel's; gf (G rows) is normalised by the ordinary kernel.
   const bool no_ln_fuse = getenv("GNX_NO_LN_FUSE") != nullptr;  // (read per call: tests compare the two forms in one process)
-  bool wide_ln = false;
+  bool wide_ln = false, edge_x6 = false;
   if (!fused_ln && !all_narrow && !no_ln_fuse && !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA)) && h->E > 0) {
     const float* ask[2] = {nullptr, nullptr};
     bool ok = true;
@@ -356,10 +361,15 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       ok = ok && ln_stats_applies(x[t], d[t]) && ffn_fused_applies(x[t], d[t], p->ff[t], out[t], x[t], out[t]) &&
            (((uintptr_t)p->ln2[t].gamma | (uintptr_t)p->ln2[t].beta) & 15) == 0;
     if (ok) {
-      rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, 3, p->ln1, p->eps, p->eps_mode, &wide_ln, ask);
+      rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, 3, p->ln1, p->eps, p->eps_mode, &wide_ln, ask,
+                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &edge_x6);
       if (rc) return rc;
     }
   }
+  // Both consumers of the edge rows' statistics hold whole rows in registers when they are the six-term kernels (k_edge_x6: gn1, k_ffn_x6: gn2) and
+  // compute them there, bit-identical to k_ln_stats_v4 (gnx_x6_stats.h): the statistics pass over ef — 512 MB at 1M edges — is not launched.
+  const bool inline_e = wide_ln && edge_x6 && d[0] == 128 && rows[0] >= 4096 && getenv("GNX_LN_STATS_PASS") == nullptr &&
+                        ffn_x6_applies(x[0], d[0], p->ff[0], out[0], x[0], out[0], sizeof(float) * rows[0] * d[0]);
   if (wide_ln) {
     const float* stats[2] = {l1[0], l1[1]};  // the (unused) gn1 buffers hold the statistics: 2 floats per row
     const bool no_fork0 = getenv("GNX_NO_FORK") != nullptr;  // (read per call: tests compare both forms in one process)
@@ -377,14 +387,14 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       rc = launch_ln_stats(x[1], rows[1], d[1], p->eps, p->eps_mode, l1[1], ax);
       if (rc == GNX_OK) rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, ax, 4, p->ln1, p->eps, p->eps_mode, &took0, stats);
       const hipError_t e1 = hipEventRecord(h->aux_join, ax);
-      const int32_t rc2 = launch_ln_stats(x[0], rows[0], d[0], p->eps, p->eps_mode, l1[0], s);
+      const int32_t rc2 = inline_e ? GNX_OK : launch_ln_stats(x[0], rows[0], d[0], p->eps, p->eps_mode, l1[0], s);
       const hipError_t e2 = hipStreamWaitEvent(s, h->aux_join, 0);
       if (rc) return rc;
       if (rc2) return rc2;
       GNX_HIP(e1);
       GNX_HIP(e2);
     } else {
-      for (int t = 0; t < 2; ++t)
+      for (int t = inline_e ? 1 : 0; t < 2; ++t)
         if ((rc = launch_ln_stats(x[t], rows[t], d[t], p->eps, p->eps_mode, l1[t], s))) return rc;
     }
     // The graph level of the core — the block's graph update (four 5-us launches) and the G-row FeedForward — is independent of the edge /
@@ -393,7 +403,8 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     const bool no_fork = no_fork0;
     const bool fork = !no_fork && h->aux_stream != nullptr && !profile_enabled() && aux_lk.owns_lock();
     bool took = false;
-    rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, (fork ? 1 : 3) | (fork0 ? 8 : 0), p->ln1, p->eps, p->eps_mode, &took, stats);
+    rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, (fork ? 1 : 3) | (fork0 ? 8 : 0), p->ln1, p->eps, p->eps_mode, &took, stats,
+                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, inline_e);
     if (rc) return rc;
     if (!took) return fail(GNX_ERR_INVALID_ARG, "gnx_core_forward: the block declined the form it had accepted");
     if (fork) {
@@ -422,7 +433,8 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       // the join is recorded even after a failure: a capture must not end with the side stream un-joined
       const hipError_t e1 = hipEventRecord(h->aux_join, ax);
       // (the edges' gn2 buffer is unused in this form: room for the split weight planes of k_ffn_x6)
-      int32_t rc2 = launch_ffn_fused(h, 0, x[0], d[0], p->ff[0], out[0], x[0], out[0], R, s, l1[0], &p->ln2[0], l2[0], sizeof(float) * rows[0] * d[0]);
+      int32_t rc2 = launch_ffn_fused(h, 0, x[0], d[0], p->ff[0], out[0], x[0], out[0], R, s, inline_e ? nullptr : l1[0], &p->ln2[0], l2[0], sizeof(float) * rows[0] * d[0], inline_e, p->eps,
+                                     p->eps_mode);
       if (rc2 == GNX_OK && node_ffn_main) rc2 = launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, s, l1[1], &p->ln2[1], l2[1], sizeof(float) * rows[1] * d[1]);
       const hipError_t e2 = hipStreamWaitEvent(s, h->aux_join, 0);
       if (rc) return rc;
@@ -453,7 +465,8 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     if (ffn_on_mfma(d[t]) && !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA))) {
       // out = block(LN1 x) + x + fc2(relu(fc1(LN2 x)))      (gncore.jl:56-68, gnfeedforward.jl:27-31)
       if (wide_ln && t < 2) {
-        if ((rc = launch_ffn_fused(h, t, x[t], d[t], p->ff[t], out[t], x[t], out[t], R, s, l1[t], &p->ln2[t], l2[t], sizeof(float) * rows[t] * d[t]))) return rc;
+        const bool inl = t == 0 && inline_e;
+        if ((rc = launch_ffn_fused(h, t, x[t], d[t], p->ff[t], out[t], x[t], out[t], R, s, inl ? nullptr : l1[t], &p->ln2[t], l2[t], sizeof(float) * rows[t] * d[t], inl, p->eps, p->eps_mode))) return rc;
         continue;
       }
       // hidden layer never leaves the chip (d = 64, 128); the edges' launch may use the hidden buffer of the two-GEMM form as its scratch

@@ -25,7 +25,8 @@ namespace gnx {
 
 int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_t E, const float* ln_stats, const float* ln_g, const float* ln_b, const float* We, int ldw,
                        const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out,
-                       size_t n_agg_rows, const int* chunk_row0, int64_t R, void* scratch, hipStream_t s);  // gnx_edge_x6.hip
+                       size_t n_agg_rows, const int* chunk_row0, int64_t R, void* scratch, hipStream_t s, bool ln_inline = false, float ln_eps = 0.f,
+                       int ln_mode = 0);  // gnx_edge_x6.hip
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1381,6 +1382,18 @@ bool block_wide_ln_applies(const gnx_graphs* h, const BlockArgs& a) {
          al16(a.We) && al16(a.Wn) && al16(a.ef_out) && al16(a.nf_out) && al16(a.ln_g[0]) && al16(a.ln_b[0]) && al16(a.ln_g[1]) && al16(a.ln_b[1]);
 }
 
+// does the block's edge update run as k_edge_x6 (gnx_edge_x6.hip)?  One predicate for the launcher and for callers that then leave the edge rows' statistics to that kernel
+bool block_wide_edge_x6_applies(const gnx_graphs* h, const BlockArgs& a) {
+  bool project = false;
+  if (!wide_applies(h, a, &project) || !project) return false;
+  static const bool no_agg_fuse = getenv("GNX_NO_AGG_FUSE") != nullptr;
+  const bool edge_out_vec = a.oe % 4 == 0 && al16(a.We) && al16(a.ef_out) && ((size_t)a.E * a.oe) % 4 == 0 && ((size_t)a.N * a.oe) % 4 == 0;
+  const bool ef_vec = a.de % 4 == 0 && al16(a.ef) && ((size_t)a.E * a.de) % 4 == 0;
+  const bool agg_fuse = !no_agg_fuse && a.oe > 0 && a.on > 0 && edge_out_vec && ef_vec && h->agg_rows_bound > 0 && (size_t)h->agg_rows_bound * a.oe * sizeof(float) < (1ull << 32);
+  return a.de == 128 && a.oe == 128 && a.dn > 0 && edge_out_vec && ef_vec && al16(a.ln_g[0]) && al16(a.ln_b[0]) && (agg_fuse || a.on == 0) && getenv("GNX_EDGE_FP32") == nullptr &&
+         (size_t)h->E >= 4096;
+}
+
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   bool project = false;
   if (!wide_applies(h, a, &project)) return 1;
@@ -1440,11 +1453,12 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   }
   // the projected edge update at 128 -> 128 as six bf16 matrix-core terms per fp32 product (gnx_edge_x6.hip)
   // (GNX_EDGE_FP32=1, read per call: k_rows_gemm on the fp32 matrix instruction instead)
-  const bool edge_x6 = (phase & 1) && project && a.de == 128 && a.oe == 128 && a.dn > 0 && edge_out_vec && ef_vec && al16(a.ln_g[0]) && al16(a.ln_b[0]) &&
-                       (agg_fuse || a.on == 0) && getenv("GNX_EDGE_FP32") == nullptr && (size_t)h->E >= 4096;
+  const bool edge_x6 = (phase & 1) && block_wide_edge_x6_applies(h, a);
+  if (a.ln_inline_e && (phase & 1) && !edge_x6) return fail(GNX_ERR_INVALID_ARG, "internal: edge statistics in the kernel asked of a block that does not run k_edge_x6");
   if (edge_x6) {
     if ((rc = launch_edge_x6(h->d_etiles, n_et, a.ef, (size_t)a.E, a.ln_stats[0], a.ln_g[0], a.ln_b[0], a.We, a.oe, proj_s, proj_d, (size_t)a.N, a.rowval, h->d_edge_dst, a.act_e,
-                             a.ef_out, a.og > 0 ? pe : nullptr, agg_fuse ? agg_tab : nullptr, (size_t)h->n_agg_rows, h->d_chunk_row0, R, x6_tab, s)))
+                             a.ef_out, a.og > 0 ? pe : nullptr, agg_fuse ? agg_tab : nullptr, (size_t)h->n_agg_rows, h->d_chunk_row0, R, x6_tab, s, a.ln_inline_e != 0, a.ln_eps,
+                             a.ln_mode)))
       return rc;
   } else
   if ((phase & 1) && a.oe > 0) {

@@ -144,6 +144,45 @@ def test_core_wide_layernorm_on_load_equals_materialised(gn, R, eps_mode):
         U.assert_close(U.from_jl(got), r, s, name)
 
 
+@pytest.mark.parametrize("R,eps_mode,E", [(1, 0, 9000), (2, 1, 4137), (1, 1, 4096)])
+def test_core_wide_edge_row_statistics_in_the_six_term_kernels_equal_the_statistics_pass(gn, R, eps_mode, E):
+    """GNCore(128,64,32) with >= 4096 edges: k_edge_x6 (gn1) and k_ffn_x6 (gn2) hold whole edge rows in registers and compute their
+    LayerNorm statistics there, so k_ln_stats runs for the node rows only (one launch).  GNX_LN_STATS_PASS=1 brings the pass over ef
+    back (two launches).  The two forms are BIT-identical — the in-register sums follow k_ln_stats_v4's order of additions — for both
+    epsilon conventions, replicas, and an edge count that ends inside a workgroup."""
+    import os
+    if os.environ.get("GNX_FFN_FP32") or os.environ.get("GNX_EDGE_FP32") or os.environ.get("GNX_LN_STATS_PASS"):
+        pytest.skip("a six-term kernel is switched off for the whole run")
+    rng = np.random.default_rng(5300 + E + R)
+    dims = (128, 64, 32)
+    colptr, rowval = U.er_csc(rng, 600, E)
+    g = gn.GNGraphBatch.from_csc([colptr], [rowval], [600])
+    p = O.make_core_params(rng, dims, eps_mode=eps_mode)
+    ef, nf, gf = U.packed_inputs(rng, R, E, 600, 1, dims)
+    ef = ef * 2.0 - 5.0  # statistics that matter: a mean far from zero
+    core = U.core_from_params(gn, p)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    got = {}
+    for which in ("inline", "pass"):
+        if which == "pass":
+            os.environ["GNX_LN_STATS_PASS"] = "1"
+        try:
+            gn.profile_reset(); gn.profile_enable(True)
+            y = core(x)
+            gn.profile_enable(False)
+            prof = gn.profile_read(); gn.profile_reset()
+        finally:
+            os.environ.pop("GNX_LN_STATS_PASS", None)
+        assert "k_ffn_x6" in prof and "k_edge_x6_prep" in prof, prof.keys()
+        assert prof["k_ln_stats"]["launches"] == (1 if which == "inline" else 2), (which, prof["k_ln_stats"])
+        got[which] = [U.from_jl(t) for t in (y.ef, y.nf, y.gf)]
+    for name, a, b in zip(("ef", "nf", "gf"), got["inline"], got["pass"]):
+        assert np.array_equal(a, b), f"{name}: statistics in the kernel differ from the statistics pass"
+    ref, scale = O.core_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    for name, a, r, s in zip(("ef", "nf", "gf"), got["inline"], ref, scale):
+        U.assert_close(a, r, s, name)
+
+
 def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gn):
     """GNCore(128,64,32): the edge FeedForward (k_ffn_x6) and the projected edge update (k_edge_x6) run every fp32 product as six bf16
     matrix-core terms (hi/mid/lo parts hold the 24 mantissa bits exactly), fp32 accumulation — unless GNX_FFN_FP32=1 / GNX_EDGE_FP32=1 select
