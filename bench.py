@@ -44,7 +44,7 @@ NSETS = 8                  # rotating buffer sets: 8 x ~60 MB > 256 MiB Infinity
 DIMS = {"readme": ((10, 5, 0), (3, 4, 5)), "core": ((128, 64, 32), (128, 64, 32)),
         "odd": ((7, 3, 2), (5, 6, 1)), "mid": ((20, 10, 4), (12, 9, 3))}  # odd: fused kernel specialised at run time (GNX_JIT=0: generic kernels); mid: generic/MFMA path
 KERNEL_SOURCES = {"narrow": ("gnx_wave_kernel.h", "gnx_device.h", "gnx_narrow.hip", "gnx_forward.hip", "gnx_graphs.cpp"),
-                  "wide": ("gnx_wide.hip", "gnx_edge_x6.hip", "gnx_device.h", "gnx_forward.hip", "gnx_graphs.cpp")}
+                  "wide": ("gnx_wide.hip", "gnx_edge_x6.hip", "gnx_x6_stats.h", "gnx_device.h", "gnx_forward.hip", "gnx_graphs.cpp")}
 
 
 def kernel_source_sha(din, dout):

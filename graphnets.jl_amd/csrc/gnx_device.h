@@ -60,8 +60,11 @@ struct BlockArgs {
   // narrow GNCore, edges: the FeedForward and both residual terms in the block kernel's edge lanes (k_block_wave<..., FFE>):
   // ef_out receives y = (x + ef') + W2 act1(W1 gn2(x) + b1) + b2 instead of ef' (gncore.jl:56-59, gnfeedforward.jl:27-31); gn2 shares
   // x-hat with gn1 (ln_eps / ln_mode above).  ffe_w1 == nullptr <=> off.
+  // Wide GNCore at 128-wide edges (ln_inline_e): the same fields ask for the edge form of k_ffn_x6 — edge update and edge FeedForward in one launch,
+  // ef' never written; ffe_scratch: ffn_x6_scratch_bytes(128) for the prepared FeedForward weights.
   const float *ffe_w1, *ffe_b1, *ffe_w2, *ffe_b2, *ffe_g2, *ffe_be2;
   int ffe_act1, ffe_act2;
+  void* ffe_scratch;
   // chained calls (gnx_block_forward_chained; k_block_wave<..., CHAIN>): the first prev_blocks workgroups of the launch finish the graph
   // update of the PREVIOUS call on this handle — its partial rows, its gf, its gf_out — with this call's graph function
   const float* prev_partials;

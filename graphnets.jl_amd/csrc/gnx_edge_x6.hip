@@ -286,16 +286,20 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
 size_t edge_x6_scratch_bytes() { return sizeof(__bf16) * 3 * (size_t)EK * EOUT; }
 
+// We ([128][ldw], its first 128 columns) -> the fragments k_edge_x6 (and the edge form of k_ffn_x6) stage per 32-output slice
+int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s) {
+  ProfScope ps("k_edge_x6_prep", s);
+  GNX_LAUNCH(k_edge_x6_prep, dim3((unsigned)((ENOB * EKS * 64 * 4 + 255) / 256)), dim3(256), 0, s, We, ldw, static_cast<__bf16*>(scratch));
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
 int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_t E, const float* ln_stats, const float* ln_g, const float* ln_b, const float* We, int ldw,
                        const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out,
                        size_t n_agg_rows, const int* chunk_row0, int64_t R, void* scratch, hipStream_t s, bool ln_inline, float ln_eps, int ln_mode) {
   if (n_tiles == 0) return GNX_OK;
   __bf16* Wp = static_cast<__bf16*>(scratch);
-  {
-    ProfScope ps("k_edge_x6_prep", s);
-    GNX_LAUNCH(k_edge_x6_prep, dim3((unsigned)((ENOB * EKS * 64 * 4 + 255) / 256)), dim3(256), 0, s, We, ldw, Wp);
-    GNX_HIP(hipGetLastError());
-  }
+  if (const int32_t rc = launch_edge_x6_prep(We, ldw, scratch, s)) return rc;
   EdgeX6Args a{};
   a.tiles = tiles; a.ef = ef; a.E = E; a.ln_stats = ln_stats; a.ln_g = ln_g; a.ln_b = ln_b; a.Wp = Wp; a.psrc = psrc; a.pdst = pdst; a.N = N;
   a.src = src; a.dst = dst; a.act = act; a.out = out; a.colsum = colsum; a.n_tiles = n_tiles; a.agg_out = agg_out; a.n_agg_rows = n_agg_rows; a.chunk_row0 = chunk_row0;

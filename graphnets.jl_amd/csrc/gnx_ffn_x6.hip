@@ -57,6 +57,12 @@ __host__ __device__ inline int x6_hidden_of_slot(int kk) {
 }
 }  // namespace
 
+// (row statistics in registers exist for 128-wide rows: eight k16-steps)
+template <int KSX>
+__device__ __forceinline__ void x6_row_stats_if(const f32x4x (&raw)[KSX][2], float eps, int eps_mode, float& mu, float& inv) {
+  if constexpr (KSX == 8) x6_row_stats(raw, eps, eps_mode, mu, inv);
+}
+
 // Prepared weights, per hidden slice hs (32 units) one contiguous block of 2 * NF fragments (NF = 3 D / 16) of 1 KB = 64 lanes x 8 bf16:
 //   fragment 3 s + p            (s < D/16: k16-step of the first product, p: part)  lane (m, h), j: part_p( W1[16 s + 8 h + j][32 hs + m] )
 //   fragment NF + 3 (2 ob + t) + p   (ob < D/32: output block, t < 2: k16-step)     lane (m, h), j: part_p( W2[32 hs + unit(16 t + 8 h + j)][32 ob + m] )
@@ -84,6 +90,26 @@ __global__ void k_ffn_x6_prep(const float* __restrict__ W1, const float* __restr
   }
 }
 
+// EDGE form (GNCore, D = 128): the projected edge update of the same rows — k_edge_x6's phase (gnx_edge_x6.hip) — runs behind the FeedForward, whose
+// result waits in the out^T accumulator: ef' is added there, slice by slice, and never reaches memory
+struct FfnX6Edge {
+  const Tile* tiles;       // the handle's edge tiles (<= 128 rows): one workgroup each
+  const float* ln1_g;      // gn1 (the statistics are shared with gn2: FfnX6Args::ln_eps / ln_mode)
+  const float* ln1_b;
+  const __bf16* Wpe;       // k_edge_x6_prep's fragments of We
+  const float* psrc;       // [R][N][128]
+  const float* pdst;       // [R][N][128] (bias and gf fold included)
+  size_t N;
+  const int* src;          // rowval [E]
+  const int* dst;          // edge_dst [E]
+  int act;
+  float* colsum;           // [R][n_tiles][128] or nullptr
+  size_t n_tiles;
+  float* agg_out;          // [R][n_agg_rows][128] or nullptr
+  size_t n_agg_rows;
+  const int* chunk_row0;   // [2 n_tiles + 1]
+};
+
 struct FfnX6Args {
   const float* z;          // [R][rows][D]: gn2(x), or x itself with ln_stats (normalised on load)
   const __bf16* Wp;        // prepared weights (k_ffn_x6_prep)
@@ -100,6 +126,7 @@ struct FfnX6Args {
   int ln_inline;           // D = 128: no ln_stats — the row statistics are computed here, in registers (gnx_x6_stats.h), with ln_eps / ln_mode
   float ln_eps;
   int ln_mode;
+  FfnX6Edge e;             // EDGE instantiation only
 };
 
 #ifdef GNX_X6_STAMPS_BUILD  // diagnostic build only (tools/build_variant.sh x6st gnx_ffn_x6.hip -DGNX_X6_STAMPS_BUILD; GNX_X6_STAMPS=1): shader-clock stamps of wave 0
@@ -110,8 +137,10 @@ static __device__ unsigned long long* g_x6_dbg = nullptr;  // [workgroup][4]
 #endif
 
 // TRANS: fc1's activation is tanh / sigmoid / gelu (the run-time switch of act_apply); else identity / relu
-template <int D, bool TRANS>
+// EDGE: see FfnX6Edge
+template <int D, bool TRANS, bool EDGE>
 __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D == 128 ? 2 : 3))) void k_ffn_x6(FfnX6Args a) {
+  static_assert(!EDGE || D == 128, "the edge update in front of the FeedForward is the 128 -> 128 form");
   constexpr int H = 4 * D;
   constexpr int KS = D / 16;          // k16-steps of the first product
   constexpr int NOB = D / 32;         // 32-output blocks of the second product
@@ -127,6 +156,9 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   __shared__ __attribute__((aligned(16))) unsigned char s_w2a[SLB / 2];
   __shared__ __attribute__((aligned(16))) unsigned char s_w2b[SLB / 2];
   __shared__ float s_b1[H];
+  __shared__ int s_src[EDGE ? XBM : 1], s_dst[EDGE ? XBM : 1];
+  __shared__ __attribute__((aligned(16))) float s_ln1[2][EDGE ? D : 4];  // gn1's gamma / beta (read per k16-step when the rows are reloaded: from memory the compiler requests all of them at once — 128 registers)
+  __shared__ int s_seg[2][EDGE ? 66 : 1];  // per 64-row pass: first row of every destination run; [n_seg] = valid rows of the pass; [65] = n_seg
 
 #ifdef GNX_X6_STAMPS_BUILD
   unsigned long long xst_[4] = {0, 0, 0, 0};
@@ -135,10 +167,16 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, n = lane & 31;
   const size_t r = blockIdx.y;
-  const size_t row0 = (size_t)blockIdx.x * XBM + (size_t)wv * XR;
-  const size_t rows = a.rows;
+  const size_t rows = a.rows;  // per replica
+  size_t wg_row0 = (size_t)blockIdx.x * XBM, rend = rows;
+  if constexpr (EDGE) {
+    const Tile t = a.e.tiles[blockIdx.x];
+    if (t.e1 <= t.e0) return;  // (whole workgroup)
+    wg_row0 = (size_t)t.e0; rend = (size_t)t.e1;
+  }
+  const size_t row0 = wg_row0 + (size_t)wv * XR;
   // (waves beyond the last row keep working on the clamped last row — they share the barriers — and store nothing)
-  const size_t rown = row0 + n < rows ? row0 + n : rows - 1;
+  const size_t rown = row0 + n < rend ? row0 + n : rend - 1;
   const float* __restrict__ zrow = a.z + (r * rows + rown) * D;
 
   // fragment f of a slice is LDS-DMA piece f (lane l writes bytes [16 l, 16 l + 16) of the piece); which = 0: the W1 half of the slice, 1: the W2 half
@@ -151,35 +189,61 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
                                        (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
     }
   };
+  // the edge update's weight block of a 32-output slice: a W1-sized set of fragments (K = D)
+  auto stage_e = [&](int ob, unsigned char* dst) {
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(a.e.Wpe) + (size_t)ob * (SLB / 2);
+#pragma unroll
+    for (int i = 0; i < NF / XW; ++i) {
+      const int pc = wv + XW * i;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)pc * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+    }
+  };
   stage(0, 0, s_w1);
   stage(0, 1, s_w2a);
+  if constexpr (EDGE) {
+    if (tid < XBM) {
+      const int trows = (int)(rend - wg_row0), rc = tid < trows ? tid : trows - 1;
+      s_src[tid] = a.e.src[wg_row0 + rc];
+      s_dst[tid] = a.e.dst[wg_row0 + rc];
+      s_ln1[0][tid] = a.e.ln1_g[tid];
+      s_ln1[1][tid] = a.e.ln1_b[tid];
+    }
+  }
   for (int i = tid; i < H; i += 64 * XW) s_b1[i] = a.b1 ? a.b1[i] : 0.f;
 
   // ---- the wave's z rows as B fragments: lane (n, hi) holds k = 16 s + 8 hi + j (j < 8) of row n for every k16-step s, in three parts ----
   bf16x8x zh[KS], zm[KS], zl[KS];
-  {
-    float mu = 0.f, inv = 1.f;
-    const bool ln_in = D == 128 && a.ln_inline != 0;
-    const bool ln = a.ln_stats != nullptr || ln_in;
-    if (a.ln_stats != nullptr) {
-      const float2 st = reinterpret_cast<const float2*>(a.ln_stats)[r * rows + rown];
-      mu = st.x; inv = st.y;
-    }
+  float mu = 0.f, inv = 1.f;
+  // (re)load the wave's rows; STATS: their statistics from the registers (gnx_x6_stats.h); ln: normalise with (g, b); split
+  // HALVES: the k16-steps in two rounds of loads (no statistics: the whole row need not be present at once; half the registers)
+  auto load_z = [&](const float* __restrict__ g, const float* __restrict__ b, bool ln, bool stats, auto halves) {
+    constexpr int NH = decltype(halves)::value ? 2 : 1, KH = KS / NH;
     f32x4x raw[KS][2];
+    // (NH == 2: `tok` is 0, opaque to the compiler and made to depend on each step's last result — the addresses of the next step's reads hang on
+    //  it.  Neither a scheduling barrier nor a memory clobber keeps reads of restrict / non-escaping memory in place: left alone, all 16 row
+    //  quads and all 32 parameter quads are requested up front, 190 registers beside the 64 of out^T.)
+    int tok = 0;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      raw[s][0] = *reinterpret_cast<const f32x4x*>(zrow + 16 * s + 8 * hi);
-      raw[s][1] = *reinterpret_cast<const f32x4x*>(zrow + 16 * s + 8 * hi + 4);
-    }
-    if constexpr (D == 128) {
-      if (ln_in) x6_row_stats(raw, a.ln_eps, a.ln_mode, mu, inv);
-    }
+    for (int hf = 0; hf < NH; ++hf) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
+    for (int s = hf * KH; s < (hf + 1) * KH; ++s) {
+      raw[s][0] = *reinterpret_cast<const f32x4x*>(zrow + tok + 16 * s + 8 * hi);
+      raw[s][1] = *reinterpret_cast<const f32x4x*>(zrow + tok + 16 * s + 8 * hi + 4);
+    }
+    if (NH == 1 && stats) x6_row_stats_if(raw, a.ln_eps, a.ln_mode, mu, inv);
+#pragma unroll
+    for (int s = hf * KH; s < (hf + 1) * KH; ++s) {
       float v[8] = {raw[s][0].x, raw[s][0].y, raw[s][0].z, raw[s][0].w, raw[s][1].x, raw[s][1].y, raw[s][1].z, raw[s][1].w};
       if (ln) {  // (x - mean) * inv, then fma(gamma, ., beta): the arithmetic of k_layernorm2_v4 / k_ffn_fused
-        const f32x4x g0 = *reinterpret_cast<const f32x4x*>(a.ln_g + 16 * s + 8 * hi), g1 = *reinterpret_cast<const f32x4x*>(a.ln_g + 16 * s + 8 * hi + 4);
-        const f32x4x b0 = *reinterpret_cast<const f32x4x*>(a.ln_b + 16 * s + 8 * hi), b1 = *reinterpret_cast<const f32x4x*>(a.ln_b + 16 * s + 8 * hi + 4);
+        f32x4x g0, g1, b0, b1;
+        if constexpr (NH == 2) {  // (the reload of the EDGE form: gn1's parameters from LDS)
+          g0 = *reinterpret_cast<const f32x4x*>(&s_ln1[0][tok + 16 * s + 8 * hi]); g1 = *reinterpret_cast<const f32x4x*>(&s_ln1[0][tok + 16 * s + 8 * hi + 4]);
+          b0 = *reinterpret_cast<const f32x4x*>(&s_ln1[1][tok + 16 * s + 8 * hi]); b1 = *reinterpret_cast<const f32x4x*>(&s_ln1[1][tok + 16 * s + 8 * hi + 4]);
+        } else {
+          g0 = *reinterpret_cast<const f32x4x*>(g + 16 * s + 8 * hi); g1 = *reinterpret_cast<const f32x4x*>(g + 16 * s + 8 * hi + 4);
+          b0 = *reinterpret_cast<const f32x4x*>(b + 16 * s + 8 * hi); b1 = *reinterpret_cast<const f32x4x*>(b + 16 * s + 8 * hi + 4);
+        }
         const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaf(gg[j], (v[j] - mu) * inv, bb[j]);
@@ -190,7 +254,22 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
         split3x(v[j], x, y, w);
         zh[s][j] = x; zm[s][j] = y; zl[s][j] = w;
       }
+      if constexpr (NH == 2) {
+        typedef unsigned u32x4z __attribute__((ext_vector_type(4)));
+        asm volatile("" : "+v"(tok) : "v"(__builtin_bit_cast(u32x4z, zl[s]).w));
+      }
     }
+    }
+  };
+  if constexpr (EDGE) {
+    load_z(a.ln_g, a.ln_b, true, true, std::false_type{});  // gn2(x) for the FeedForward; (mu, inv) stay for gn1
+  } else {
+    const bool ln_in = D == 128 && a.ln_inline != 0;
+    if (a.ln_stats != nullptr) {
+      const float2 st = reinterpret_cast<const float2*>(a.ln_stats)[r * rows + rown];
+      mu = st.x; inv = st.y;
+    }
+    load_z(a.ln_g, a.ln_b, a.ln_stats != nullptr || ln_in, ln_in, std::false_type{});
   }
 
   f32x16x accO[NOB];
@@ -355,6 +434,161 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   }
 
   GNX_XSTAMP(2);  // all slices done
+  if constexpr (EDGE) {
+    // ---- the projected edge update of the tile BEHIND its FeedForward: ef' = act(We^T gn1(x) + Ps[src] + Pd[dst]) per 32-output slice (k_edge_x6's
+    //      scheme: weight slices double-buffered in the two W2 buffers, the staged block / the column-sum partials in the W1 buffer), its per-destination
+    //      sums and column sums written as k_edge_x6 writes them — and ef' itself NOT written: each slice's epilogue adds it to the FeedForward block of
+    //      the same outputs, in the two-launch form's order ((W2^T H + b2) + ef') + x — every output bit-identical to k_edge_x6 + k_ffn_x6. ----
+    stage_e(0, s_w2a);                         // (free since the barrier that ended the last step)
+    load_z(a.e.ln1_g, a.e.ln1_b, true, false, std::true_type{});  // gn1(x): the rows once more (the cache has them), the statistics from the prologue
+    const int trows = (int)(rend - wg_row0);
+    const int tile_id = blockIdx.x;
+    int agg_row0[2] = {0, 0};
+    if (a.e.agg_out) { agg_row0[0] = a.e.chunk_row0[2 * tile_id]; agg_row0[1] = a.e.chunk_row0[2 * tile_id + 1]; }
+    if (a.e.agg_out && wv < 2) {  // destination runs of the two 64-row passes (rows are dst-sorted), by wave 0 and wave 1
+      const int pass = wv;
+      const int nvalid = min(max(trows - 64 * pass, 0), 64);
+      const int d = lane < nvalid ? s_dst[64 * pass + lane] : -1;
+      const int dprev = lane > 0 && lane < nvalid ? s_dst[64 * pass + lane - 1] : -2;
+      const bool head = lane < nvalid && d != dprev;
+      const unsigned long long mask = __ballot(head);
+      const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+      if (head) s_seg[pass][rank] = lane;
+      if (lane == 0) { const int ns = __popcll(mask); s_seg[pass][ns] = nvalid; s_seg[pass][65] = ns; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slice 0's pieces of this wave have landed
+    __syncthreads();  // ... everybody's; every wave is done with the FeedForward's buffers: W1 = staging area, W2b = the next slice's fragments
+    constexpr int ELDE = 36;
+    float* s_e = reinterpret_cast<float*>(s_w1);   // [128][36]
+    float* s_cs = s_e + XBM * ELDE;                // [32][32]
+    static_assert((XBM * ELDE + 32 * 32) * 4 <= SLB / 2, "staging area + column-sum partials fit the W1 buffer");
+    float* sE = s_e + wv * (XR * ELDE);
+    const int er = lane >> 3, eq = lane & 7;  // (row er + 8 i of the wave's 32, 16-byte quad eq of the 32-column block)
+    const float* __restrict__ ps = a.e.psrc + r * a.e.N * D;
+    const float* __restrict__ pd = a.e.pdst + r * a.e.N * D;
+    const float* __restrict__ xres = a.add1 + r * rows * D;
+    float* __restrict__ outp = a.out + r * rows * D;
+    const f32x4x zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto slice = [&](int ob, const unsigned char* cur, unsigned char* nxt, const f32x16x& accF) {
+      if (ob + 1 < NOB) stage_e(ob + 1, nxt);
+      const unsigned char* wb = cur + lane * 16;
+      f32x16x acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      bf16x8x A[2][3];
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3) A[0][p3] = *reinterpret_cast<const bf16x8x*>(wb + p3 * 1024);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int c = s & 1;
+        if (s + 1 < KS) {
+#pragma unroll
+          for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * (s + 1) + p3) * 1024);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zm[s], acc, 0, 0, 0);  // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][2], zh[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zl[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zh[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zm[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zh[s], acc, 0, 0, 0);
+      }
+      // the gathered addends of the slice (8 rows x 128 contiguous bytes per instruction) and the residual quads (x: the cache has the rows) are
+      // requested here — across the matrix instructions they would not fit the register file beside out^T —, and the FeedForward block of these
+      // outputs goes through the wave's slice of the staging area into (row, quad) form while they travel (the other workgroup of the CU has the
+      // matrix pipe meanwhile)
+      f32x4x us[4], ud[4];  // (the source side in front of the matrix instructions — 16 registers instead of 32 across them: same time, A/B on config 4)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gs = s_src[wv * XR + er + 8 * i], gd = s_dst[wv * XR + er + 8 * i];
+        us[i] = *reinterpret_cast<const f32x4x*>(ps + (size_t)gs * D + 32 * ob + 4 * eq);
+        ud[i] = *reinterpret_cast<const f32x4x*>(pd + (size_t)gd * D + 32 * ob + 4 * eq);
+      }
+      f32x4x u1[4], vf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const size_t grow = row0 + er + 8 * i < rend ? row0 + er + 8 * i : rend - 1;
+        u1[i] = *reinterpret_cast<const f32x4x*>(xres + grow * D + 32 * ob + 4 * eq);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4x*>(sE + n * ELDE + 8 * g + 4 * hi) = f32x4x{accF[4 * g], accF[4 * g + 1], accF[4 * g + 2], accF[4 * g + 3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vf[i] = *reinterpret_cast<const f32x4x*>(sE + (er + 8 * i) * ELDE + 4 * eq);
+      // (LDS operations of one wave execute in order: the edge block may follow into the same slice)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4x*>(sE + n * ELDE + 8 * g + 4 * hi) = f32x4x{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the addends — and with them (in-order counter) the next slice's fragments
+      asm volatile("" : "+v"(us[0]), "+v"(us[1]), "+v"(us[2]), "+v"(us[3]), "+v"(ud[0]), "+v"(ud[1]), "+v"(ud[2]), "+v"(ud[3]));
+      asm volatile("" : "+v"(u1[0]), "+v"(u1[1]), "+v"(u1[2]), "+v"(u1[3]));
+      const f32x4x bq = a.b2 ? *reinterpret_cast<const f32x4x*>(a.b2 + 32 * ob + 4 * eq) : zero4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int lr = er + 8 * i;
+        f32x4x v = *reinterpret_cast<const f32x4x*>(sE + lr * ELDE + 4 * eq);
+        v += us[i];
+        v += ud[i];
+        float vv[4] = {v.x, v.y, v.z, v.w};
+        if (a.e.act == 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] = relu_f(vv[e]);
+        } else if (a.e.act > 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[e] = act_apply(vv[e], a.e.act);
+        }
+        v = f32x4x{vv[0], vv[1], vv[2], vv[3]};
+        const bool ok = wv * XR + lr < trows;
+        if (!ok) v = zero4;  // (rows beyond the tile: zero for the sums below)
+        *reinterpret_cast<f32x4x*>(sE + lr * ELDE + 4 * eq) = v;
+        f32x4x o = vf[i];  // the two-launch form's order (gnx_core_forward: add1 = the block's output, add2 = x): ((W2^T H + b2) + ef') + x
+        o += bq;
+        o += v;
+        o += u1[i];
+        if (ok) *reinterpret_cast<f32x4x*>(outp + (row0 + lr) * D + 32 * ob + 4 * eq) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS traffic only) the finished block of all four waves is staged
+      const int q4 = tid & 7, grp = tid >> 3;  // 8 quads x 32 row groups
+      f32x4x c4 = {0.f, 0.f, 0.f, 0.f};        // this thread's share of the tile's column sums
+      if (a.e.agg_out) {
+        // per-destination sums (fixed order; k_edge_x6): groups 0-15 take the runs of pass 0, groups 16-31 those of pass 1
+        const int pass = grp >> 4, g16 = grp & 15;
+        const int n_seg = s_seg[pass][65];
+        float* agg = a.e.agg_out + (r * a.e.n_agg_rows + (size_t)agg_row0[pass]) * D + 32 * ob + 4 * q4;
+        const float* base = s_e + 64 * pass * ELDE + 4 * q4;
+        for (int sgm = g16; sgm < n_seg; sgm += 16) {
+          const int r0 = s_seg[pass][sgm], r1 = s_seg[pass][sgm + 1];
+          f32x4x t4 = {0.f, 0.f, 0.f, 0.f};
+          for (int rr = r0; rr < r1; rr += 4) {
+            f32x4x u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = *reinterpret_cast<const f32x4x*>(base + min(rr + j, r1 - 1) * ELDE);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { if (rr + j < r1) t4 += u[j]; }
+          }
+          *reinterpret_cast<f32x4x*>(agg + (size_t)sgm * D) = t4;
+          c4 += t4;
+        }
+      } else if (a.e.colsum) {  // (no fused aggregation: the rows themselves, grp, grp + 32, .. ascending)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c4 += *reinterpret_cast<const f32x4x*>(s_e + (grp + 32 * i) * ELDE + 4 * q4);
+      }
+      if (a.e.colsum) *reinterpret_cast<f32x4x*>(s_cs + grp * 32 + 4 * q4) = c4;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the staging area may be overwritten; the column-sum partials are complete
+      if (a.e.colsum && tid < 32) {  // fixed order: the 32 groups ascending
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 32; ++w) sum += s_cs[w * 32 + tid];
+        a.e.colsum[(r * a.e.n_tiles + (size_t)tile_id) * D + 32 * ob + tid] = sum;
+      }
+    };
+    static_assert(NOB == 4, "four slices, placed by hand");
+    slice(0, s_w2a, s_w2b, accO[0]);
+    slice(1, s_w2b, s_w2a, accO[1]);
+    slice(2, s_w2a, s_w2b, accO[2]);
+    slice(3, s_w2b, s_w2a, accO[3]);
+    return;
+  }
+
   // ---- epilogue.  In the C/D layout lane (n, hi) holds outputs 32 ob + 8 g + 4 hi + (0..3) of ITS row in registers 4 g .. 4 g + 3: accessed from
   //      there, every instruction touches 32 rows with 32 bytes each.  Instead each 32-output block takes a round trip through a wave-private
   //      4.5-KB slice of the (now idle) W1 buffer — LDS operations of one wave execute in order, no barrier — and comes back as (row, 16-byte
@@ -376,7 +610,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const size_t grow = row0 + er + 8 * i < rows ? row0 + er + 8 * i : rows - 1;
+      const size_t grow = row0 + er + 8 * i < rend ? row0 + er + 8 * i : rend - 1;
       const size_t off = grow * D + 32 * ob + 4 * eq;
       u1[ob][i] = r1 ? *reinterpret_cast<const f32x4x*>(r1 + off) : zero;
       u2[ob][i] = r2 ? *reinterpret_cast<const f32x4x*>(r2 + off) : zero;
@@ -393,7 +627,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       v += bq;
       v += u1[ob][i];
       v += u2[ob][i];
-      if (row0 + er + 8 * i < rows) *reinterpret_cast<f32x4x*>(ob_out + (row0 + er + 8 * i) * D + 32 * ob + 4 * eq) = v;
+      if (row0 + er + 8 * i < rend) *reinterpret_cast<f32x4x*>(ob_out + (row0 + er + 8 * i) * D + 32 * ob + 4 * eq) = v;
     }
   }
 #ifdef GNX_X6_STAMPS_BUILD
@@ -448,8 +682,8 @@ int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, co
   ProfScope ps("k_ffn_x6", s);
   const dim3 grid((unsigned)((nrows + XBM - 1) / XBM), (unsigned)R);
   const bool trans = ff.fc1.act > GNX_ACT_RELU;
-  if (d == 128) { if (trans) GNX_LAUNCH((k_ffn_x6<128, true>), grid, dim3(64 * XW), 0, s, a); else GNX_LAUNCH((k_ffn_x6<128, false>), grid, dim3(64 * XW), 0, s, a); }
-  else { if (trans) GNX_LAUNCH((k_ffn_x6<64, true>), grid, dim3(64 * XW), 0, s, a); else GNX_LAUNCH((k_ffn_x6<64, false>), grid, dim3(64 * XW), 0, s, a); }
+  if (d == 128) { if (trans) GNX_LAUNCH((k_ffn_x6<128, true, false>), grid, dim3(64 * XW), 0, s, a); else GNX_LAUNCH((k_ffn_x6<128, false, false>), grid, dim3(64 * XW), 0, s, a); }
+  else { if (trans) GNX_LAUNCH((k_ffn_x6<64, true, false>), grid, dim3(64 * XW), 0, s, a); else GNX_LAUNCH((k_ffn_x6<64, false, false>), grid, dim3(64 * XW), 0, s, a); }
   GNX_HIP(hipGetLastError());
 #ifdef GNX_X6_STAMPS_BUILD
   if (stamps) {
@@ -463,6 +697,43 @@ int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, co
             n_wg, m[0] / n_wg, m[1] / n_wg, m[2] / n_wg, t_max - t_min);
   }
 #endif
+  return GNX_OK;
+}
+
+int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s);  // gnx_edge_x6.hip
+
+// A GNCore's edge rows in ONE launch (EDGE form of k_ffn_x6): out = x + ef' + FF(gn2(x)), ef' = act(We^T gn1(x) + Ps[src] + Pd[dst]) with its per-destination
+// sums (agg_out) and column sums (colsum) as k_edge_x6 writes them; ef' itself is never written.  Row statistics of x in the kernel.
+// scratch_e: edge_x6_scratch_bytes(), scratch_f: ffn_x6_scratch_bytes(128); both 16-byte aligned and free until the launch has run.
+int32_t launch_core_edge_x6(const Tile* tiles, size_t n_tiles, const float* x, size_t E, const gnx_layernorm* ln1, float ln_eps, int ln_mode, const float* We, int ldw,
+                            const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* colsum, float* agg_out, size_t n_agg_rows,
+                            const int* chunk_row0, const gnx_ffn& ff, const gnx_layernorm* ln2, float* out, int64_t R, void* scratch_e, void* scratch_f, hipStream_t s) {
+  if (n_tiles == 0) return GNX_OK;
+  if (!scratch_e || !scratch_f || (((uintptr_t)scratch_e | (uintptr_t)scratch_f) & 15)) return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6 (edge form): scratch missing or misaligned");
+  if (!tiles || !x || !We || !psrc || !pdst || !src || !dst || !ff.fc1.weight || !ff.fc2.weight || !out) return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6 (edge form): NULL operand");
+  if (!ln1 || !ln2 || !ln1->gamma || !ln1->beta || !ln2->gamma || !ln2->beta ||
+      (((uintptr_t)ln1->gamma | (uintptr_t)ln1->beta | (uintptr_t)ln2->gamma | (uintptr_t)ln2->beta | (uintptr_t)x | (uintptr_t)out | (uintptr_t)psrc | (uintptr_t)pdst | (uintptr_t)ff.fc2.bias |
+        (uintptr_t)agg_out) & 15))
+    return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6 (edge form): LayerNorm parameters missing, or an operand not 16-byte aligned");
+  if (ff.fc2.act != GNX_ACT_IDENTITY) return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6 (edge form): fc2 with an activation");
+  int32_t rc = launch_edge_x6_prep(We, ldw, scratch_e, s);
+  if (rc) return rc;
+  __bf16* Wp = static_cast<__bf16*>(scratch_f);
+  {
+    ProfScope ps("k_ffn_x6_prep", s);
+    GNX_LAUNCH(k_ffn_x6_prep, dim3((unsigned)((128 * 4 * 128 + 255) / 256)), dim3(256), 0, s, ff.fc1.weight, ff.fc2.weight, 128, Wp);
+    GNX_HIP(hipGetLastError());
+  }
+  FfnX6Args a{};
+  a.z = x; a.Wp = Wp; a.b1 = ff.fc1.bias; a.b2 = ff.fc2.bias; a.add1 = x; a.add2 = nullptr; a.out = out; a.rows = E; a.act1 = ff.fc1.act;
+  a.ln_g = ln2->gamma; a.ln_b = ln2->beta; a.ln_eps = ln_eps; a.ln_mode = ln_mode;
+  a.e.tiles = tiles; a.e.ln1_g = ln1->gamma; a.e.ln1_b = ln1->beta; a.e.Wpe = static_cast<const __bf16*>(scratch_e); a.e.psrc = psrc; a.e.pdst = pdst; a.e.N = N; a.e.src = src; a.e.dst = dst;
+  a.e.act = act; a.e.colsum = colsum; a.e.n_tiles = n_tiles; a.e.agg_out = agg_out; a.e.n_agg_rows = n_agg_rows; a.e.chunk_row0 = chunk_row0;
+  ProfScope ps("k_core_edge_x6", s);
+  const dim3 grid((unsigned)n_tiles, (unsigned)R);
+  if (ff.fc1.act > GNX_ACT_RELU) GNX_LAUNCH((k_ffn_x6<128, true, true>), grid, dim3(64 * XW), 0, s, a);
+  else GNX_LAUNCH((k_ffn_x6<128, false, true>), grid, dim3(64 * XW), 0, s, a);
+  GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
 

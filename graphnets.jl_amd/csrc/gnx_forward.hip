@@ -102,7 +102,8 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
                                   size_t ws_bytes, uint32_t flags, hipStream_t s, int phase = 3, const gnx_layernorm* ln1 = nullptr,
                                   float ln_eps = 0.f, int ln_mode = 0, bool* fused_ln = nullptr, const float* const* wide_ln_stats = nullptr,
                                   BlockArgs* args_out = nullptr, const gnx_ffn* ffe = nullptr, const gnx_layernorm* ffe_ln2 = nullptr, bool* ffe_took = nullptr,
-                                  const gnx_pending_update* chain_prev = nullptr, bool* chain_took = nullptr, bool* edge_x6_out = nullptr, bool ln_inline_e = false) {
+                                  const gnx_pending_update* chain_prev = nullptr, bool* chain_took = nullptr, bool* edge_x6_out = nullptr, bool ln_inline_e = false,
+                                  void* ffe_scratch = nullptr) {
   int32_t rc = check_block(h, p, R);
   if (rc) return rc;
   if (phase & 1) {
@@ -144,6 +145,10 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
     if (!*fused_ln || !wide_ln_stats[0]) return GNX_OK;
     a.ln_stats[0] = wide_ln_stats[0]; a.ln_stats[1] = wide_ln_stats[1];
     if (ln_inline_e) { a.ln_stats[0] = nullptr; a.ln_inline_e = 1; a.ln_eps = ln_eps; a.ln_mode = ln_mode; }  // no table for the edges: k_edge_x6 computes them in registers
+    if (ln_inline_e && ffe && ffe_ln2 && ffe_scratch && (phase & 1)) {  // ... and the edge FeedForward + residuals run in that launch too: ef_out receives the CORE's edge output
+      a.ffe_w1 = ffe->fc1.weight; a.ffe_b1 = ffe->fc1.bias; a.ffe_w2 = ffe->fc2.weight; a.ffe_b2 = ffe->fc2.bias;
+      a.ffe_g2 = ffe_ln2->gamma; a.ffe_be2 = ffe_ln2->beta; a.ffe_act1 = ffe->fc1.act; a.ffe_act2 = ffe->fc2.act; a.ffe_scratch = ffe_scratch;
+    }
     return launch_block_wide(h, a, R, s, phase);
   }
   if (ln1) {
@@ -370,6 +375,8 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   // compute them there, bit-identical to k_ln_stats_v4 (gnx_x6_stats.h): the statistics pass over ef — 512 MB at 1M edges — is not launched.
   const bool inline_e = wide_ln && edge_x6 && d[0] == 128 && rows[0] >= 4096 && getenv("GNX_LN_STATS_PASS") == nullptr &&
                         ffn_x6_applies(x[0], d[0], p->ff[0], out[0], x[0], out[0], sizeof(float) * rows[0] * d[0]);
+  // ... and then ONE launch does both (the edge form of k_ffn_x6: ef' stays in the accumulator — never written, never read back; GNX_CORE_EDGE_SPLIT=1: two launches)
+  const bool fuse_e = inline_e && getenv("GNX_CORE_EDGE_SPLIT") == nullptr;
   if (wide_ln) {
     const float* stats[2] = {l1[0], l1[1]};  // the (unused) gn1 buffers hold the statistics: 2 floats per row
     const bool no_fork0 = getenv("GNX_NO_FORK") != nullptr;  // (read per call: tests compare both forms in one process)
@@ -404,7 +411,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     const bool fork = !no_fork && h->aux_stream != nullptr && !profile_enabled() && aux_lk.owns_lock();
     bool took = false;
     rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, (fork ? 1 : 3) | (fork0 ? 8 : 0), p->ln1, p->eps, p->eps_mode, &took, stats,
-                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, inline_e);
+                            nullptr, fuse_e ? &p->ff[0] : nullptr, fuse_e ? &p->ln2[0] : nullptr, nullptr, nullptr, nullptr, nullptr, inline_e, fuse_e ? l2[0] : nullptr);
     if (rc) return rc;
     if (!took) return fail(GNX_ERR_INVALID_ARG, "gnx_core_forward: the block declined the form it had accepted");
     if (fork) {
@@ -433,8 +440,9 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       // the join is recorded even after a failure: a capture must not end with the side stream un-joined
       const hipError_t e1 = hipEventRecord(h->aux_join, ax);
       // (the edges' gn2 buffer is unused in this form: room for the split weight planes of k_ffn_x6)
-      int32_t rc2 = launch_ffn_fused(h, 0, x[0], d[0], p->ff[0], out[0], x[0], out[0], R, s, inline_e ? nullptr : l1[0], &p->ln2[0], l2[0], sizeof(float) * rows[0] * d[0], inline_e, p->eps,
-                                     p->eps_mode);
+      int32_t rc2 = fuse_e ? GNX_OK  // (the block's edge launch was the edge form of k_ffn_x6: out[0] is final)
+                           : launch_ffn_fused(h, 0, x[0], d[0], p->ff[0], out[0], x[0], out[0], R, s, inline_e ? nullptr : l1[0], &p->ln2[0], l2[0], sizeof(float) * rows[0] * d[0], inline_e,
+                                              p->eps, p->eps_mode);
       if (rc2 == GNX_OK && node_ffn_main) rc2 = launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, s, l1[1], &p->ln2[1], l2[1], sizeof(float) * rows[1] * d[1]);
       const hipError_t e2 = hipStreamWaitEvent(s, h->aux_join, 0);
       if (rc) return rc;
@@ -466,6 +474,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       // out = block(LN1 x) + x + fc2(relu(fc1(LN2 x)))      (gncore.jl:56-68, gnfeedforward.jl:27-31)
       if (wide_ln && t < 2) {
         const bool inl = t == 0 && inline_e;
+        if (t == 0 && fuse_e) continue;  // (the block's edge launch was the edge form of k_ffn_x6: out[0] is final)
         if ((rc = launch_ffn_fused(h, t, x[t], d[t], p->ff[t], out[t], x[t], out[t], R, s, inl ? nullptr : l1[t], &p->ln2[t], l2[t], sizeof(float) * rows[t] * d[t], inl, p->eps, p->eps_mode))) return rc;
         continue;
       }

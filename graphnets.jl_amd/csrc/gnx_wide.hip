@@ -27,6 +27,9 @@ int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_
                        const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out,
                        size_t n_agg_rows, const int* chunk_row0, int64_t R, void* scratch, hipStream_t s, bool ln_inline = false, float ln_eps = 0.f,
                        int ln_mode = 0);  // gnx_edge_x6.hip
+int32_t launch_core_edge_x6(const Tile* tiles, size_t n_tiles, const float* x, size_t E, const gnx_layernorm* ln1, float ln_eps, int ln_mode, const float* We, int ldw,
+                            const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* colsum, float* agg_out, size_t n_agg_rows,
+                            const int* chunk_row0, const gnx_ffn& ff, const gnx_layernorm* ln2, float* out, int64_t R, void* scratch_e, void* scratch_f, hipStream_t s);  // gnx_ffn_x6.hip
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1455,6 +1458,15 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   // (GNX_EDGE_FP32=1, read per call: k_rows_gemm on the fp32 matrix instruction instead)
   const bool edge_x6 = (phase & 1) && block_wide_edge_x6_applies(h, a);
   if (a.ln_inline_e && (phase & 1) && !edge_x6) return fail(GNX_ERR_INVALID_ARG, "internal: edge statistics in the kernel asked of a block that does not run k_edge_x6");
+  if (a.ffe_w1 && (phase & 1) && !(edge_x6 && a.ln_inline_e)) return fail(GNX_ERR_INVALID_ARG, "internal: the edge FeedForward inside the edge update asked of a block that does not run k_edge_x6 with its own statistics");
+  if (edge_x6 && a.ffe_w1) {  // GNCore: edge update + edge FeedForward + residuals in one launch (edge form of k_ffn_x6); ef_out receives the CORE's edge output
+    gnx_ffn ff{};
+    ff.fc1.weight = a.ffe_w1; ff.fc1.bias = a.ffe_b1; ff.fc1.act = a.ffe_act1; ff.fc2.weight = a.ffe_w2; ff.fc2.bias = a.ffe_b2; ff.fc2.act = a.ffe_act2;
+    const gnx_layernorm ln1{a.ln_g[0], a.ln_b[0]}, ln2{a.ffe_g2, a.ffe_be2};
+    if ((rc = launch_core_edge_x6(h->d_etiles, n_et, a.ef, (size_t)a.E, &ln1, a.ln_eps, a.ln_mode, a.We, a.oe, proj_s, proj_d, (size_t)a.N, a.rowval, h->d_edge_dst, a.act_e,
+                                  a.og > 0 ? pe : nullptr, agg_fuse ? agg_tab : nullptr, (size_t)h->n_agg_rows, h->d_chunk_row0, ff, &ln2, a.ef_out, R, x6_tab, a.ffe_scratch, s)))
+      return rc;
+  } else
   if (edge_x6) {
     if ((rc = launch_edge_x6(h->d_etiles, n_et, a.ef, (size_t)a.E, a.ln_stats[0], a.ln_g[0], a.ln_b[0], a.We, a.oe, proj_s, proj_d, (size_t)a.N, a.rowval, h->d_edge_dst, a.act_e,
                              a.ef_out, a.og > 0 ? pe : nullptr, agg_fuse ? agg_tab : nullptr, (size_t)h->n_agg_rows, h->d_chunk_row0, R, x6_tab, s, a.ln_inline_e != 0, a.ln_eps,

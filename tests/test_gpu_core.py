@@ -112,7 +112,8 @@ def test_core_wide_dims(gn, flags):
 @pytest.mark.parametrize("R,eps_mode", [(1, 0), (2, 1)])
 def test_core_wide_layernorm_on_load_equals_materialised(gn, R, eps_mode):
     """GNCore(128,64,32): the matrix-core kernels normalise ef / nf as they load them (row statistics from k_ln_stats; gn1 / gn2
-    never written) — bit-identical to the materialised LayerNorm form (GNX_NO_LN_FUSE=1), and within the bound of the oracle."""
+    never written; from 4096 edges on, edge update and edge FeedForward in ONE launch with the statistics computed in it) — bit-identical to the
+    materialised LayerNorm form (GNX_NO_LN_FUSE=1: k_layernorm2, k_edge_x6 / k_rows_gemm, k_ffn_x6), and within the bound of the oracle."""
     import os
     rng = np.random.default_rng(4700 + R)
     dims = (128, 64, 32)
@@ -145,7 +146,7 @@ def test_core_wide_layernorm_on_load_equals_materialised(gn, R, eps_mode):
 
 
 @pytest.mark.parametrize("R,eps_mode,E", [(1, 0, 9000), (2, 1, 4137), (1, 1, 4096)])
-def test_core_wide_edge_row_statistics_in_the_six_term_kernels_equal_the_statistics_pass(gn, R, eps_mode, E):
+def test_core_wide_edge_row_statistics_in_the_six_term_kernels_equal_the_statistics_pass(gn, R, eps_mode, E, monkeypatch):
     """GNCore(128,64,32) with >= 4096 edges: k_edge_x6 (gn1) and k_ffn_x6 (gn2) hold whole edge rows in registers and compute their
     LayerNorm statistics there, so k_ln_stats runs for the node rows only (one launch).  GNX_LN_STATS_PASS=1 brings the pass over ef
     back (two launches).  The two forms are BIT-identical — the in-register sums follow k_ln_stats_v4's order of additions — for both
@@ -153,6 +154,7 @@ def test_core_wide_edge_row_statistics_in_the_six_term_kernels_equal_the_statist
     import os
     if os.environ.get("GNX_FFN_FP32") or os.environ.get("GNX_EDGE_FP32") or os.environ.get("GNX_LN_STATS_PASS"):
         pytest.skip("a six-term kernel is switched off for the whole run")
+    monkeypatch.setenv("GNX_CORE_EDGE_SPLIT", "1")  # (k_edge_x6 and k_ffn_x6 as two launches: the form that exists with a statistics table too)
     rng = np.random.default_rng(5300 + E + R)
     dims = (128, 64, 32)
     colptr, rowval = U.er_csc(rng, 600, E)
@@ -181,6 +183,51 @@ def test_core_wide_edge_row_statistics_in_the_six_term_kernels_equal_the_statist
     ref, scale = O.core_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
     for name, a, r, s in zip(("ef", "nf", "gf"), got["inline"], ref, scale):
         U.assert_close(a, r, s, name)
+
+
+@pytest.mark.parametrize("R,E,N,hetero", [(1, 9000, 700, False), (2, 4137, 300, False), (1, 6000, 200, False), (1, 12000, 1500, True)])
+def test_core_wide_edge_update_and_feedforward_in_one_launch(gn, R, E, N, hetero):
+    """GNCore(128,64,32) from 4096 edges on: the edge form of k_ffn_x6 runs the tile's edge FeedForward, keeps its result in the out^T
+    accumulator, then computes ef' = the block's edge update of the tile (k_edge_x6's phase: same per-destination sums, same column sums) and
+    adds it slice by slice in the two-launch form's order — ef' never reaches memory.  Against the two-launch form (GNX_CORE_EDGE_SPLIT=1:
+    k_edge_x6, then k_ffn_x6) ef, nf and gf are BIT-identical; and within the bound of the oracle.  Replicas, a ragged edge count, 30 in-edges per node, several graphs (hub destinations: tests/test_gpu_wide.py's hub test runs a GNCore)."""
+    import os
+    if os.environ.get("GNX_FFN_FP32") or os.environ.get("GNX_EDGE_FP32") or os.environ.get("GNX_LN_STATS_PASS") or os.environ.get("GNX_CORE_EDGE_SPLIT"):
+        pytest.skip("the one-launch form is switched off for the whole run")
+    rng = np.random.default_rng(5400 + E)
+    dims = (128, 64, 32)
+    if hetero:
+        sizes = [(N // 3, E // 4), (N // 3, E // 2), (N - 2 * (N // 3), E - E // 4 - E // 2)]
+        cs = [U.er_csc(rng, n_, e_) for n_, e_ in sizes]
+        g = gn.GNGraphBatch.from_csc([c[0] for c in cs], [c[1] for c in cs], [n_ for n_, _ in sizes])
+        G = 3
+    else:
+        colptr, rowval = U.er_csc(rng, N, E)
+        g = gn.GNGraphBatch.from_csc([colptr], [rowval], [N])
+        G = 1
+    p = O.make_core_params(rng, dims)
+    ef, nf, gf = U.packed_inputs(rng, R, E, N, G, dims)
+    ef = ef * 1.5 + 0.75
+    core = U.core_from_params(gn, p)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    got = {}
+    for which in ("one", "two"):
+        if which == "two":
+            os.environ["GNX_CORE_EDGE_SPLIT"] = "1"
+        try:
+            gn.profile_reset(); gn.profile_enable(True)
+            y = core(x)
+            gn.profile_enable(False)
+            prof = gn.profile_read(); gn.profile_reset()
+        finally:
+            os.environ.pop("GNX_CORE_EDGE_SPLIT", None)
+        assert ("k_core_edge_x6" in prof) == (which == "one") and ("k_rows_gemm_edge" in prof) == (which == "two"), prof.keys()
+        got[which] = [U.from_jl(t) for t in (y.ef, y.nf, y.gf)]
+    for name, a, b in zip(("ef", "nf", "gf"), got["one"], got["two"]):
+        assert np.isfinite(a).all() and np.array_equal(a, b), f"{name} differs between the one-launch and the two-launch form"
+    ref, scale = O.core_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    for name, t, r_, s_ in zip(("ef", "nf", "gf"), got["one"], ref, scale):
+        U.assert_close(t, r_, s_, name)
 
 
 def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gn):
@@ -216,7 +263,7 @@ def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_
         finally:
             os.environ.pop("GNX_FFN_FP32", None)
             os.environ.pop("GNX_EDGE_FP32", None)
-        assert ("k_ffn_x6" in names) == (which == "x6") and ("k_edge_x6_prep" in names) == (which == "x6"), names
+        assert ("k_core_edge_x6" in names) == (which == "x6") and ("k_edge_x6_prep" in names) == (which == "x6"), names
         for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
             U.assert_close(U.from_jl(got), r, s, f"{which} {name}")
         err = np.abs(U.from_jl(y.ef).astype(np.float64) - ref[0]) / scale[0]
@@ -247,15 +294,25 @@ def test_core_wide_edge_feedforward_six_term_kernel_ragged_rows_activations_no_b
     gn.profile_reset(); gn.profile_enable(True)
     y = core(x)
     gn.profile_enable(False)
-    assert "k_ffn_x6" in set(gn.profile_read()); gn.profile_reset()
+    assert "k_core_edge_x6" in set(gn.profile_read()); gn.profile_reset()  # (edge update + FeedForward in one launch)
+    os.environ["GNX_CORE_EDGE_SPLIT"] = "1"
+    try:
+        gn.profile_enable(True)
+        y1 = core(x)
+        gn.profile_enable(False)
+        assert "k_ffn_x6" in set(gn.profile_read()); gn.profile_reset()
+    finally:
+        del os.environ["GNX_CORE_EDGE_SPLIT"]
     os.environ["GNX_FFN_FP32"] = "1"
     try:
         y0 = core(x)
     finally:
         del os.environ["GNX_FFN_FP32"]
-    a, b = y.ef.double(), y0.ef.double()
-    assert torch.isfinite(a).all()
-    assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (act, bias, E, float((a - b).abs().max()), float(b.abs().max()))
+    b = y0.ef.double()
+    for what, yy in (("one launch", y), ("two launches", y1)):
+        a = yy.ef.double()
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (what, act, bias, E, float((a - b).abs().max()), float(b.abs().max()))
     assert torch.equal(y.nf, y0.nf) and torch.equal(y.gf, y0.gf)  # (nodes and graphs do not go through the six-term kernel)
 
 

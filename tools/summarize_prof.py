@@ -23,7 +23,7 @@ def short(name):
 
 
 # at core dims (template arguments: BN, quad outputs, K chunk, epilogue operand streams (3: destination rows through LDS), transcendental activation, loader class)
-ALIASES = {"k_rows_gemm<128,true,32,2,false,0>": "k_rows_gemm_edge", "k_rows_gemm<128,true,32,3,false,0>": "k_rows_gemm_edge", "k_edge_x6": "k_rows_gemm_edge", "k_rows_gemm<64,true,32,0,false,1>": "k_rows_gemm_node",
+ALIASES = {"k_rows_gemm<128,true,32,2,false,0>": "k_rows_gemm_edge", "k_rows_gemm<128,true,32,3,false,0>": "k_rows_gemm_edge", "k_edge_x6": "k_rows_gemm_edge", "k_ffn_x6<128,false,true>": "k_core_edge_x6", "k_ffn_x6<128,true,true>": "k_core_edge_x6", "k_rows_gemm<64,true,32,0,false,1>": "k_rows_gemm_node",
            "k_rows_gemm<128,true,32,0,false,0>": "k_rows_gemm_proj"}
 
 
