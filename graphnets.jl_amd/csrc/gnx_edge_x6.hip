@@ -47,13 +47,15 @@ __device__ __forceinline__ void esplit2(float x0, float x1, unsigned& h, unsigne
 
 // W ([K = 128][ldw] row-major, the first 128 columns) -> per 32-output slice ob one block of ENF fragments of 1 KB = 64 lanes x 8 bf16:
 //   fragment 3 s + p (s: k16-step, p: part), lane (m, h), j:  part_p( W[16 s + 8 h + j][32 ob + m] )
-__global__ void k_edge_x6_prep(const float* __restrict__ W, int ldw, __bf16* __restrict__ Wp) {
+// (n_out < 32 * n_ob: the columns beyond n_out are zero — the narrow form's single, padded slice)
+__global__ void k_edge_x6_prep(const float* __restrict__ W, int ldw, int n_out, int n_ob, __bf16* __restrict__ Wp) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (ob, s, lane, j pair)
-  if (idx >= ENOB * EKS * 64 * 4) return;
+  if (idx >= n_ob * EKS * 64 * 4) return;
   const int jp = idx & 3, lane = (idx >> 2) & 63, s = (idx >> 8) % EKS, ob = (idx >> 8) / EKS;
   const int m = lane & 31, h = lane >> 5, k = 16 * s + 8 * h + 2 * jp;
   unsigned hh, mm, ll;
-  esplit2(W[(size_t)k * ldw + 32 * ob + m], W[(size_t)(k + 1) * ldw + 32 * ob + m], hh, mm, ll);
+  const bool in = 32 * ob + m < n_out;
+  esplit2(in ? W[(size_t)k * ldw + 32 * ob + m] : 0.f, in ? W[(size_t)(k + 1) * ldw + 32 * ob + m] : 0.f, hh, mm, ll);
   unsigned* o = reinterpret_cast<unsigned*>(Wp) + ((size_t)ob * ENF + 3 * s) * 256 + lane * 4 + jp;
   o[0] = hh; o[256] = mm; o[512] = ll;
 }
@@ -78,12 +80,18 @@ struct EdgeX6Args {
   float* agg_out;          // [R][n_agg_rows][128] or nullptr
   size_t n_agg_rows;
   const int* chunk_row0;   // [2 n_tiles + 1]
+  int oe;                  // NARROW form: output width (1..32); else 128
   int ln_inline;           // no ln_stats: the row statistics of gn1 are computed here, in registers (gnx_x6_stats.h), with ln_eps / ln_mode
   float ln_eps;
   int ln_mode;
 };
 
-__global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_edge_x6(EdgeX6Args a) {
+// NARROW: a block whose edge output is at most 32 wide (config 4's decoder: 128 -> 3) — ONE slice of zero-padded weight fragments, the addends and
+// the outputs as single floats (rows of a.oe), no per-destination sums (the node update of such a block adds up the ef' rows itself: 12 bytes each)
+template <bool NARROW>
+__global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARROW ? 3 : 2))) void k_edge_x6(EdgeX6Args a) {
+  constexpr int NOBK = NARROW ? 1 : ENOB;
+  const int OUTW = NARROW ? a.oe : EOUT;
   __shared__ __attribute__((aligned(16))) unsigned char s_wa[ESLB];
   __shared__ __attribute__((aligned(16))) unsigned char s_wb[ESLB];
   __shared__ __attribute__((aligned(16))) float s_e[EBM * ELDE];  // the finished 32-column block of the tile, [row][36]
@@ -172,9 +180,9 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 
   const int er = lane >> 3, eq = lane & 7;  // (row er + 8 i of the wave's 32, 16-byte quad eq of the 32-column block)
   float* sE = s_e + wv * (ER * ELDE);
-  const float* __restrict__ ps = a.psrc + r * a.N * EOUT;
-  const float* __restrict__ pd = a.pdst + r * a.N * EOUT;
-  float* __restrict__ outp = a.out + (r * a.E + (size_t)row0) * EOUT;
+  const float* __restrict__ ps = a.psrc + r * a.N * OUTW;
+  const float* __restrict__ pd = a.pdst + r * a.N * OUTW;
+  float* __restrict__ outp = a.out + (r * a.E + (size_t)row0) * OUTW;
   int gs[4], gd[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { gs[i] = s_src[wv * ER + er + 8 * i]; gd[i] = s_dst[wv * ER + er + 8 * i]; }
@@ -183,13 +191,25 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, 2)))
   auto gather = [&](int ob, f32x4e (&us)[4], f32x4e (&ud)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      us[i] = *reinterpret_cast<const f32x4e*>(ps + (size_t)gs[i] * EOUT + 32 * ob + 4 * eq);
-      ud[i] = *reinterpret_cast<const f32x4e*>(pd + (size_t)gd[i] * EOUT + 32 * ob + 4 * eq);
+      if constexpr (NARROW) {
+        float s4[4], d4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool in = 4 * eq + j < OUTW;
+          s4[j] = in ? ps[(size_t)gs[i] * OUTW + 4 * eq + j] : 0.f;
+          d4[j] = in ? pd[(size_t)gd[i] * OUTW + 4 * eq + j] : 0.f;
+        }
+        us[i] = f32x4e{s4[0], s4[1], s4[2], s4[3]};
+        ud[i] = f32x4e{d4[0], d4[1], d4[2], d4[3]};
+      } else {
+        us[i] = *reinterpret_cast<const f32x4e*>(ps + (size_t)gs[i] * EOUT + 32 * ob + 4 * eq);
+        ud[i] = *reinterpret_cast<const f32x4e*>(pd + (size_t)gd[i] * EOUT + 32 * ob + 4 * eq);
+      }
     }
   };
   // slice ob: its addends (us, ud) were requested a slice ahead — behind the previous slice's stores, in front of its sums — and the next slice's are requested here
   auto slice = [&](int ob, const unsigned char* cur, unsigned char* nxt, f32x4e (&us)[4], f32x4e (&ud)[4], f32x4e (&usn)[4], f32x4e (&udn)[4]) {
-    if (ob + 1 < ENOB) stage(ob + 1, nxt);
+    if (ob + 1 < NOBK) stage(ob + 1, nxt);
     const unsigned char* wb = cur + lane * 16;
     f32x16e acc;
 #pragma unroll
@@ -236,13 +256,20 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       v = f32x4e{vv[0], vv[1], vv[2], vv[3]};
       if (!ok) v = f32x4e{0.f, 0.f, 0.f, 0.f};  // (rows beyond the tile: zero for the sums below)
       *reinterpret_cast<f32x4e*>(sE + lr * ELDE + 4 * eq) = v;
-      if (ok) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * EOUT + 32 * ob + 4 * eq) = v;
+      if constexpr (NARROW) {
+        const float o4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ok && 4 * eq + j < OUTW) outp[(size_t)(wv * ER + lr) * OUTW + 4 * eq + j] = o4[j];
+      } else {
+        if (ok) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * EOUT + 32 * ob + 4 * eq) = v;
+      }
     }
-    if (ob + 1 < ENOB) gather(ob + 1, usn, udn);  // under the sums below and the next slice's matrix instructions
+    if (ob + 1 < NOBK) gather(ob + 1, usn, udn);  // under the sums below and the next slice's matrix instructions
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS traffic only) the finished block of all four waves is in s_e; the next slice's fragments are complete
     const int q4 = tid & 7, grp = tid >> 3;           // 8 quads x 32 row groups
     f32x4e c4 = {0.f, 0.f, 0.f, 0.f};  // this thread's share of the tile's column sums
-    if (a.agg_out) {
+    if (!NARROW && a.agg_out) {
       // per-destination sums: groups 0-15 take the runs of pass 0, groups 16-31 those of pass 1 (16 runs per sweep; the 1M-edge graph has ~7 per
       // pass), four rows of a run requested at a time.  Every valid row lies in exactly one run: the column sums are the sums of the run sums.
       const int pass = grp >> 4, g16 = grp & 15;
@@ -272,40 +299,48 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, 2)))
       float sum = 0.f;
 #pragma unroll
       for (int w = 0; w < 32; ++w) sum += s_cs[w * 32 + tid];
-      a.colsum[(r * a.n_tiles + (size_t)tile_id) * EOUT + 32 * ob + tid] = sum;
+      if (!NARROW || tid < OUTW) a.colsum[(r * a.n_tiles + (size_t)tile_id) * OUTW + 32 * ob + tid] = sum;
     }
   };
   static_assert(ENOB % 2 == 0, "slice loop unrolled by two");
   f32x4e ua[4], da[4], ub[4], db[4];
   gather(0, ua, da);
-  for (int ob = 0; ob < ENOB; ob += 2) {
-    slice(ob, s_wa, s_wb, ua, da, ub, db);
-    slice(ob + 1, s_wb, s_wa, ub, db, ua, da);
+  if constexpr (NARROW) {
+    slice(0, s_wa, s_wb, ua, da, ub, db);
+  } else {
+    for (int ob = 0; ob < ENOB; ob += 2) {
+      slice(ob, s_wa, s_wb, ua, da, ub, db);
+      slice(ob + 1, s_wb, s_wa, ub, db, ua, da);
+    }
   }
 }
 
 size_t edge_x6_scratch_bytes() { return sizeof(__bf16) * 3 * (size_t)EK * EOUT; }
 
 // We ([128][ldw], its first 128 columns) -> the fragments k_edge_x6 (and the edge form of k_ffn_x6) stage per 32-output slice
-int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s) {
+int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s, int n_out) {
   ProfScope ps("k_edge_x6_prep", s);
-  GNX_LAUNCH(k_edge_x6_prep, dim3((unsigned)((ENOB * EKS * 64 * 4 + 255) / 256)), dim3(256), 0, s, We, ldw, static_cast<__bf16*>(scratch));
+  const int n_ob = (n_out + 31) / 32;
+  GNX_LAUNCH(k_edge_x6_prep, dim3((unsigned)((n_ob * EKS * 64 * 4 + 255) / 256)), dim3(256), 0, s, We, ldw, n_out, n_ob, static_cast<__bf16*>(scratch));
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
 
 int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_t E, const float* ln_stats, const float* ln_g, const float* ln_b, const float* We, int ldw,
                        const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out,
-                       size_t n_agg_rows, const int* chunk_row0, int64_t R, void* scratch, hipStream_t s, bool ln_inline, float ln_eps, int ln_mode) {
+                       size_t n_agg_rows, const int* chunk_row0, int64_t R, void* scratch, hipStream_t s, bool ln_inline, float ln_eps, int ln_mode, int oe) {
   if (n_tiles == 0) return GNX_OK;
+  if (oe != EOUT && (oe < 1 || oe > 32 || agg_out)) return fail(GNX_ERR_INVALID_ARG, "k_edge_x6: output width 128, or 1..32 without per-destination sums");
   __bf16* Wp = static_cast<__bf16*>(scratch);
-  if (const int32_t rc = launch_edge_x6_prep(We, ldw, scratch, s)) return rc;
+  if (const int32_t rc = launch_edge_x6_prep(We, ldw, scratch, s, oe)) return rc;
   EdgeX6Args a{};
   a.tiles = tiles; a.ef = ef; a.E = E; a.ln_stats = ln_stats; a.ln_g = ln_g; a.ln_b = ln_b; a.Wp = Wp; a.psrc = psrc; a.pdst = pdst; a.N = N;
   a.src = src; a.dst = dst; a.act = act; a.out = out; a.colsum = colsum; a.n_tiles = n_tiles; a.agg_out = agg_out; a.n_agg_rows = n_agg_rows; a.chunk_row0 = chunk_row0;
   if (ln_inline) { if (ln_stats || !ln_g || !ln_b) return fail(GNX_ERR_INVALID_ARG, "k_edge_x6: statistics in the kernel exclude a statistics table and need gamma / beta"); a.ln_inline = 1; a.ln_eps = ln_eps; a.ln_mode = ln_mode; }
+  a.oe = oe;
   ProfScope ps("k_rows_gemm_edge", s);  // (the name the edge update has in every profile and bench line)
-  GNX_LAUNCH(k_edge_x6, dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
+  if (oe == EOUT) GNX_LAUNCH(k_edge_x6<false>, dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
+  else GNX_LAUNCH(k_edge_x6<true>, dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }

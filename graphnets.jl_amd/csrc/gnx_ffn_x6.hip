@@ -700,7 +700,7 @@ int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, co
   return GNX_OK;
 }
 
-int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s);  // gnx_edge_x6.hip
+int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s, int n_out);  // gnx_edge_x6.hip
 
 // A GNCore's edge rows in ONE launch (EDGE form of k_ffn_x6): out = x + ef' + FF(gn2(x)), ef' = act(We^T gn1(x) + Ps[src] + Pd[dst]) with its per-destination
 // sums (agg_out) and column sums (colsum) as k_edge_x6 writes them; ef' itself is never written.  Row statistics of x in the kernel.
@@ -716,7 +716,7 @@ int32_t launch_core_edge_x6(const Tile* tiles, size_t n_tiles, const float* x, s
         (uintptr_t)agg_out) & 15))
     return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6 (edge form): LayerNorm parameters missing, or an operand not 16-byte aligned");
   if (ff.fc2.act != GNX_ACT_IDENTITY) return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6 (edge form): fc2 with an activation");
-  int32_t rc = launch_edge_x6_prep(We, ldw, scratch_e, s);
+  int32_t rc = launch_edge_x6_prep(We, ldw, scratch_e, s, 128);
   if (rc) return rc;
   __bf16* Wp = static_cast<__bf16*>(scratch_f);
   {

@@ -26,7 +26,7 @@ namespace gnx {
 int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_t E, const float* ln_stats, const float* ln_g, const float* ln_b, const float* We, int ldw,
                        const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out,
                        size_t n_agg_rows, const int* chunk_row0, int64_t R, void* scratch, hipStream_t s, bool ln_inline = false, float ln_eps = 0.f,
-                       int ln_mode = 0);  // gnx_edge_x6.hip
+                       int ln_mode = 0, int oe = 128);  // gnx_edge_x6.hip
 int32_t launch_core_edge_x6(const Tile* tiles, size_t n_tiles, const float* x, size_t E, const gnx_layernorm* ln1, float ln_eps, int ln_mode, const float* We, int ldw,
                             const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* colsum, float* agg_out, size_t n_agg_rows,
                             const int* chunk_row0, const gnx_ffn& ff, const gnx_layernorm* ln2, float* out, int64_t R, void* scratch_e, void* scratch_f, hipStream_t s);  // gnx_ffn_x6.hip
@@ -1156,7 +1156,7 @@ size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int6
   const size_t proj = sizeof(float) * 2 * (size_t)R * h->N * (size_t)p->oe;  // node projections Ps, Pd
   const size_t xg = sizeof(float) * (size_t)R * h->G * (size_t)(p->oe + p->on + p->dg);  // graph-function input (small batches)
   const size_t agg = sizeof(float) * (size_t)R * (size_t)h->agg_rows_bound * (size_t)p->oe;  // per-destination partial sums of the edge GEMM (rows: an upper bound known without the tables)
-  const size_t x6 = sizeof(__bf16) * 3 * (size_t)p->de * (size_t)p->oe;  // the edge update's weight block as three bf16 planes (k_edge_x6_prep)
+  const size_t x6 = sizeof(__bf16) * 3 * (size_t)p->de * (size_t)((p->oe + 31) / 32 * 32);  // the edge update's weight block as three bf16 planes in 32-output slices (k_edge_x6_prep)
   return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + align_up(xg, 256) + align_up(agg, 256) + align_up(x6, 256) + 512;
 }
 
@@ -1459,6 +1459,15 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   const bool edge_x6 = (phase & 1) && block_wide_edge_x6_applies(h, a);
   if (a.ln_inline_e && (phase & 1) && !edge_x6) return fail(GNX_ERR_INVALID_ARG, "internal: edge statistics in the kernel asked of a block that does not run k_edge_x6");
   if (a.ffe_w1 && (phase & 1) && !(edge_x6 && a.ln_inline_e)) return fail(GNX_ERR_INVALID_ARG, "internal: the edge FeedForward inside the edge update asked of a block that does not run k_edge_x6 with its own statistics");
+  // ... and at 128 -> at most 32 outputs without fused per-destination sums (config 4's decoder: 128 -> 3) its narrow form: one zero-padded slice
+  const bool edge_x6n = (phase & 1) && !edge_x6 && project && a.de == 128 && a.oe >= 1 && a.oe <= 32 && a.dn > 0 && ef_vec && !agg_fuse &&
+                        (!a.ln_stats[0] || (al16(a.ln_g[0]) && al16(a.ln_b[0]))) && getenv("GNX_EDGE_FP32") == nullptr && getenv("GNX_EDGE_NARROW_FP32") == nullptr &&
+                        (size_t)h->E >= 4096;  // (GNX_EDGE_NARROW_FP32=1, read per call: this form alone back on k_rows_gemm)
+  if (edge_x6n) {
+    if ((rc = launch_edge_x6(h->d_etiles, n_et, a.ef, (size_t)a.E, a.ln_stats[0], a.ln_g[0], a.ln_b[0], a.We, a.oe, proj_s, proj_d, (size_t)a.N, a.rowval, h->d_edge_dst, a.act_e,
+                             a.ef_out, a.og > 0 ? pe : nullptr, nullptr, 0, nullptr, R, x6_tab, s, false, 0.f, 0, a.oe)))
+      return rc;
+  } else
   if (edge_x6 && a.ffe_w1) {  // GNCore: edge update + edge FeedForward + residuals in one launch (edge form of k_ffn_x6); ef_out receives the CORE's edge output
     gnx_ffn ff{};
     ff.fc1.weight = a.ffe_w1; ff.fc1.bias = a.ffe_b1; ff.fc1.act = a.ffe_act1; ff.fc2.weight = a.ffe_w2; ff.fc2.bias = a.ffe_b2; ff.fc2.act = a.ffe_act2;

@@ -225,6 +225,11 @@ _EDGE_X6_CASES = [
     ((128, 64, 32), (2, 1, 0), 2, ((700, 9000),)),                          # tanh (the run-time activation switch), replicas
     ((128, 0, 8), (1, 0, 0), 1, ((800, 10000),)),                           # no node update behind it: no per-destination sums, column sums from the rows
     ((128, 64, 0), (0, 1, 0), 1, ((800, 10000),)),                          # no graph update: no column sums
+    # the narrow form (128 -> at most 32 outputs, one zero-padded slice, single-float addends and stores; the node update adds the ef' rows itself)
+    ((3, 4, 5), (1, 1, 0), 1, ((900, 12000), (300, 5000), (64, 700))),      # config 4's decoder widths; ragged tiles, column sums of 3 columns
+    ((3, 4, 5), (0, 0, 0), 2, ((700, 9000),)),                              # identity, replicas
+    ((7, 5, 0), (3, 1, 0), 1, ((800, 10000),)),                             # sigmoid (act(0) != 0 in the padded columns), 7 columns: two quads, no graph update
+    ((30, 0, 2), (1, 0, 1), 1, ((800, 10000),)),                            # 30 columns (last quad partial), no node update
 ]
 
 
