@@ -315,6 +315,175 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
   }
 }
 
+// ---- the node projections that feed it: Ps = Ws^T gn1(nf), Pd = Wd^T gn1(nf) + b (+ gf fold per graph), nf 64 wide, 128 outputs each — both tables in ONE
+//      launch on the same scheme (k_rows_gemm's two-weight-block launch on the fp32 matrix instruction takes 59 us for C2's 100k nodes; 3.3 GFLOP are 21 us
+//      of fp32 matrix time and 8 us as six bf16 terms; the tables are 102 MB written).  Eight 32-output slices (four per table) of 12 prepared fragments,
+//      double-buffered by LDS-DMA; a wave's 32 node rows on the lanes (48 registers); a slice's block through the wave's staging slice into (row, quad)
+//      form, bias quad added on the destination table, 8 rows x 128 contiguous bytes per store.  No sums: one barrier per slice (the weight buffers).
+namespace {
+constexpr int PK = 64, PKS = PK / 16, PNF = 3 * PKS, PSLB = PNF * 1024, PNOB = 8;
+}
+
+// Ws, Wd ([64][ldw] row-major, the first 128 columns of each) -> per slice ob (table ob / 4, outputs 32 (ob % 4) + m) one block of PNF fragments (k_edge_x6_prep's format)
+__global__ void k_proj_x6_prep(const float* __restrict__ Ws, const float* __restrict__ Wd, int ldw, __bf16* __restrict__ Wp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (ob, s, lane, j pair)
+  if (idx >= PNOB * PKS * 64 * 4) return;
+  const int jp = idx & 3, lane = (idx >> 2) & 63, s = (idx >> 8) % PKS, ob = (idx >> 8) / PKS;
+  const int m = lane & 31, h = lane >> 5, k = 16 * s + 8 * h + 2 * jp;
+  const float* __restrict__ W = ob < 4 ? Ws : Wd;
+  const int col = 32 * (ob & 3) + m;
+  unsigned hh, mm, ll;
+  esplit2(W[(size_t)k * ldw + col], W[(size_t)(k + 1) * ldw + col], hh, mm, ll);
+  unsigned* o = reinterpret_cast<unsigned*>(Wp) + ((size_t)ob * PNF + 3 * s) * 256 + lane * 4 + jp;
+  o[0] = hh; o[256] = mm; o[512] = ll;
+}
+
+struct ProjX6Args {
+  const Tile* tiles;       // node tiles: rows [n0, n1) of graph g
+  const float* nf;         // [R][N][64]
+  size_t N;
+  const float* ln_stats;   // [R][N][2] (mean, 1/sigma) or nullptr
+  const float* ln_g;
+  const float* ln_b;
+  const __bf16* Wp;
+  const float* bias;       // [128] or nullptr: the destination table's bias
+  const float* bias_g;     // [R][G][128] (bias + gf fold) or nullptr
+  int G;
+  float* out_s;            // [R][N][128]
+  float* out_d;            // [R][N][128]
+};
+
+__global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_proj_x6(ProjX6Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_wa[PSLB];
+  __shared__ __attribute__((aligned(16))) unsigned char s_wb[PSLB];
+  __shared__ __attribute__((aligned(16))) float s_e[EBM * ELDE];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, n = lane & 31;
+  const size_t r = blockIdx.y;
+  const Tile t = a.tiles[blockIdx.x];
+  const int row0 = t.n0, rows = t.n1 - t.n0;
+  if (rows <= 0) return;  // (whole workgroup)
+  auto stage = [&](int ob, unsigned char* dst) {
+    const unsigned char* srcp = reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)ob * PSLB;
+#pragma unroll
+    for (int i = 0; i < PNF / EW; ++i) {
+      const int pc = wv + EW * i;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcp + (size_t)pc * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+    }
+  };
+  stage(0, s_wa);
+  // ---- the wave's rows as B fragments (gn1 on load), three bf16 parts ----
+  const int lrow = wv * ER + n;
+  const int lrc = lrow < rows ? lrow : rows - 1;
+  const float* __restrict__ zrow = a.nf + (r * a.N + (size_t)row0 + lrc) * PK;
+  bf16x8e zh[PKS], zm[PKS], zl[PKS];
+  {
+    float mu = 0.f, inv = 1.f;
+    const bool ln = a.ln_stats != nullptr;
+    if (ln) {
+      const float2 st = reinterpret_cast<const float2*>(a.ln_stats)[r * a.N + (size_t)row0 + lrc];
+      mu = st.x; inv = st.y;
+    }
+    typedef unsigned u32x4e __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int s = 0; s < PKS; ++s) {
+      const f32x4e r0 = *reinterpret_cast<const f32x4e*>(zrow + 16 * s + 8 * hi), r1 = *reinterpret_cast<const f32x4e*>(zrow + 16 * s + 8 * hi + 4);
+      float v[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+      if (ln) {
+        const f32x4e g0 = *reinterpret_cast<const f32x4e*>(a.ln_g + 16 * s + 8 * hi), g1 = *reinterpret_cast<const f32x4e*>(a.ln_g + 16 * s + 8 * hi + 4);
+        const f32x4e b0 = *reinterpret_cast<const f32x4e*>(a.ln_b + 16 * s + 8 * hi), b1 = *reinterpret_cast<const f32x4e*>(a.ln_b + 16 * s + 8 * hi + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(gg[j], (v[j] - mu) * inv, bb[j]);
+      }
+      unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) esplit2(v[2 * j], v[2 * j + 1], ph[j], pm[j], pl[j]);
+      zh[s] = __builtin_bit_cast(bf16x8e, u32x4e{ph[0], ph[1], ph[2], ph[3]});
+      zm[s] = __builtin_bit_cast(bf16x8e, u32x4e{pm[0], pm[1], pm[2], pm[3]});
+      zl[s] = __builtin_bit_cast(bf16x8e, u32x4e{pl[0], pl[1], pl[2], pl[3]});
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slice 0's pieces of this wave have landed
+  __syncthreads();                                  // ... everybody's
+  const int er = lane >> 3, eq = lane & 7;
+  float* sE = s_e + wv * (ER * ELDE);
+  const float* __restrict__ bp = a.bias_g ? a.bias_g + (r * a.G + (size_t)t.g) * EOUT : a.bias;
+  auto slice = [&](int ob, const unsigned char* cur, unsigned char* nxt) {
+    if (ob + 1 < PNOB) stage(ob + 1, nxt);
+    const unsigned char* wb = cur + lane * 16;
+    f32x16e acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    bf16x8e A[2][3];
+#pragma unroll
+    for (int p3 = 0; p3 < 3; ++p3) A[0][p3] = *reinterpret_cast<const bf16x8e*>(wb + p3 * 1024);
+#pragma unroll
+    for (int s = 0; s < PKS; ++s) {
+      const int c = s & 1;
+      if (s + 1 < PKS) {
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8e*>(wb + (3 * (s + 1) + p3) * 1024);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zm[s], acc, 0, 0, 0);  // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][2], zh[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zl[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zh[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zm[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zh[s], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4e*>(sE + n * ELDE + 8 * g + 4 * hi) = f32x4e{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    const int tab = ob >> 2, c0 = 32 * (ob & 3) + 4 * eq;
+    f32x4e b4 = {0.f, 0.f, 0.f, 0.f};
+    if (tab == 1 && bp) b4 = *reinterpret_cast<const f32x4e*>(bp + c0);
+    float* __restrict__ outp = (tab ? a.out_d : a.out_s) + (r * a.N + (size_t)row0) * EOUT + c0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lr = er + 8 * i;
+      f32x4e v = *reinterpret_cast<const f32x4e*>(sE + lr * ELDE + 4 * eq);
+      v += b4;
+      if (wv * ER + lr < rows) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * EOUT) = v;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next slice's pieces of this wave (the stores too: 2 KB per wave)
+    __syncthreads();                                  // everybody's pieces; everybody is done with `cur`
+  };
+  for (int ob = 0; ob < PNOB; ob += 2) {
+    slice(ob, s_wa, s_wb);
+    slice(ob + 1, s_wb, s_wa);
+  }
+}
+
+size_t proj_x6_scratch_bytes() { return (size_t)PNOB * PSLB; }
+
+bool proj_x6_applies(int dn, int oe, const float* nf, const float* W, const float* out, size_t N) {
+  if (getenv("GNX_EDGE_FP32") != nullptr || getenv("GNX_PROJ_FP32") != nullptr) return false;  // (read per call: the fp32 matrix instruction throughout / for the projections alone)
+  return dn == PK && oe == EOUT && N >= 4096 && (((uintptr_t)nf | (uintptr_t)W | (uintptr_t)out) & 15) == 0;
+}
+
+// Ps = Ws^T z, Pd = Wd^T z + bias (per graph with bias_g), z = nf or gn1(nf) from ln_stats; scratch: proj_x6_scratch_bytes(), 16-byte aligned
+int32_t launch_proj_x6(const Tile* tiles, size_t n_tiles, const float* nf, size_t N, const float* ln_stats, const float* ln_g, const float* ln_b, const float* Ws, const float* Wd,
+                       int ldw, const float* bias, const float* bias_g, int G, float* out_s, float* out_d, int64_t R, void* scratch, hipStream_t s) {
+  if (n_tiles == 0) return GNX_OK;
+  if (!tiles || !nf || !Ws || !Wd || !out_s || !out_d || !scratch || ((uintptr_t)scratch & 15)) return fail(GNX_ERR_INVALID_ARG, "k_proj_x6: NULL operand or misaligned scratch");
+  if (ln_stats && (!ln_g || !ln_b || (((uintptr_t)ln_g | (uintptr_t)ln_b) & 15) || ((uintptr_t)ln_stats & 7))) return fail(GNX_ERR_INVALID_ARG, "k_proj_x6: LayerNorm parameters missing or misaligned");
+  if ((((uintptr_t)bias | (uintptr_t)bias_g | (uintptr_t)out_s | (uintptr_t)out_d) & 15)) return fail(GNX_ERR_INVALID_ARG, "k_proj_x6: operand not 16-byte aligned");
+  __bf16* Wp = static_cast<__bf16*>(scratch);
+  {
+    ProfScope ps("k_proj_x6_prep", s);
+    GNX_LAUNCH(k_proj_x6_prep, dim3((unsigned)((PNOB * PKS * 64 * 4 + 255) / 256)), dim3(256), 0, s, Ws, Wd, ldw, Wp);
+    GNX_HIP(hipGetLastError());
+  }
+  ProjX6Args a{};
+  a.tiles = tiles; a.nf = nf; a.N = N; a.ln_stats = ln_stats; a.ln_g = ln_g; a.ln_b = ln_b; a.Wp = Wp; a.bias = bias; a.bias_g = bias_g; a.G = G; a.out_s = out_s; a.out_d = out_d;
+  ProfScope ps("k_rows_gemm_proj", s);  // (the name the projections have in every profile and bench line)
+  GNX_LAUNCH(k_proj_x6, dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
 size_t edge_x6_scratch_bytes() { return sizeof(__bf16) * 3 * (size_t)EK * EOUT; }
 
 // We ([128][ldw], its first 128 columns) -> the fragments k_edge_x6 (and the edge form of k_ffn_x6) stage per 32-output slice

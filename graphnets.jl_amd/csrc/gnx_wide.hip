@@ -27,6 +27,10 @@ int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_
                        const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out,
                        size_t n_agg_rows, const int* chunk_row0, int64_t R, void* scratch, hipStream_t s, bool ln_inline = false, float ln_eps = 0.f,
                        int ln_mode = 0, int oe = 128);  // gnx_edge_x6.hip
+size_t proj_x6_scratch_bytes();  // gnx_edge_x6.hip
+bool proj_x6_applies(int dn, int oe, const float* nf, const float* W, const float* out, size_t N);
+int32_t launch_proj_x6(const Tile* tiles, size_t n_tiles, const float* nf, size_t N, const float* ln_stats, const float* ln_g, const float* ln_b, const float* Ws, const float* Wd,
+                       int ldw, const float* bias, const float* bias_g, int G, float* out_s, float* out_d, int64_t R, void* scratch, hipStream_t s);
 int32_t launch_core_edge_x6(const Tile* tiles, size_t n_tiles, const float* x, size_t E, const gnx_layernorm* ln1, float ln_eps, int ln_mode, const float* We, int ldw,
                             const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* colsum, float* agg_out, size_t n_agg_rows,
                             const int* chunk_row0, const gnx_ffn& ff, const gnx_layernorm* ln2, float* out, int64_t R, void* scratch_e, void* scratch_f, hipStream_t s);  // gnx_ffn_x6.hip
@@ -1157,7 +1161,8 @@ size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int6
   const size_t xg = sizeof(float) * (size_t)R * h->G * (size_t)(p->oe + p->on + p->dg);  // graph-function input (small batches)
   const size_t agg = sizeof(float) * (size_t)R * (size_t)h->agg_rows_bound * (size_t)p->oe;  // per-destination partial sums of the edge GEMM (rows: an upper bound known without the tables)
   const size_t x6 = sizeof(__bf16) * 3 * (size_t)p->de * (size_t)((p->oe + 31) / 32 * 32);  // the edge update's weight block as three bf16 planes in 32-output slices (k_edge_x6_prep)
-  return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + align_up(xg, 256) + align_up(agg, 256) + align_up(x6, 256) + 512;
+  const size_t x6p = proj_x6_scratch_bytes();  // the node projections' two weight blocks likewise (k_proj_x6_prep)
+  return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + align_up(xg, 256) + align_up(agg, 256) + align_up(x6, 256) + align_up(x6p, 256) + 512;
 }
 
 static bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -1418,6 +1423,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   float* agg_tab = reinterpret_cast<float*>(reinterpret_cast<char*>(proj_s) + align_up(sizeof(float) * 2 * (size_t)R * h->N * a.oe, 256) +
                                             align_up(sizeof(float) * (size_t)R * h->G * (size_t)(a.oe + a.on + a.dg), 256));
   void* x6_tab = reinterpret_cast<char*>(agg_tab) + align_up(sizeof(float) * (size_t)R * (size_t)h->agg_rows_bound * (size_t)a.oe, 256);
+  void* x6p_tab = reinterpret_cast<char*>(x6_tab) + align_up(sizeof(__bf16) * 3 * (size_t)a.de * (size_t)((a.oe + 31) / 32 * 32), 256);
   // edge -> node sums inside the edge GEMM's epilogue (the node GEMM then reads ~N rows instead of all E rows of ef')
   static const bool no_agg_fuse = getenv("GNX_NO_AGG_FUSE") != nullptr;
   // (needs quad outputs, and — with the projections' epilogue operands — an ef whose rows are quads: see launch_gemm's instantiations)
@@ -1441,6 +1447,12 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     }
     GNX_HIP(hipGetLastError());
   }
+  if (prep && project && proj_x6_applies(a.dn, a.oe, a.nf, a.We, proj_s, (size_t)a.N) && (!a.ln_stats[1] || (al16(a.ln_g[1]) && al16(a.ln_b[1]))) && al16(a.be)) {
+    // 64 -> 2 x 128 from 4096 nodes on: both tables in one launch of k_proj_x6 (six bf16 matrix-core terms per fp32 product; gnx_edge_x6.hip)
+    if ((rc = launch_proj_x6(h->d_ntiles, n_nt, a.nf, (size_t)a.N, a.ln_stats[1], a.ln_g[1], a.ln_b[1], a.We + (size_t)a.de * a.oe, a.We + (size_t)(a.de + a.dn) * a.oe, a.oe, a.be,
+                             a.dg > 0 ? bias_e : nullptr, a.G, proj_s, proj_d, R, x6p_tab, s)))
+      return rc;
+  } else
   if (prep && project) {  // both projections in ONE launch (the second weight block of k_rows_gemm): nf is read once
     WideArgs w{};
     w.tiles = h->d_ntiles; w.row_kind = 1;

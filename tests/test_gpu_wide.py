@@ -302,3 +302,50 @@ def test_wide_projected_edge_update_on_bf16_matrix_cores(gn, case):
             continue
         a, b = U.from_jl(a).astype(np.float64), U.from_jl(b).astype(np.float64)
         assert np.max(np.abs(a - b)) <= 2e-6 * max(np.max(np.abs(b)), 1e-30)
+
+
+@pytest.mark.parametrize("R,graphs,core", [(2, ((4300, 9000),), False), (1, ((2500, 6000), (1700, 5000), (300, 700)), False), (1, ((4200, 9500), (150, 400)), True)])
+def test_wide_node_projections_on_bf16_matrix_cores(gn, R, graphs, core):
+    """(128, 64, 32) => (128, ...) from 4096 nodes on: the node projections Ps = Ws^T nf, Pd = Wd^T nf + b (+ gf fold per graph) of the projected edge
+    update run as k_proj_x6 — both tables in one launch, six bf16 matrix-core terms per fp32 product.  GNBlock (replicas of one graph; several graphs: per-graph biases, node
+    tiles that end at graph boundaries) and GNCore (gn1 on load from the statistics table) against the float64 oracle at 1e-5·scale, and
+    against the build's fp32-MFMA form (GNX_EDGE_FP32=1) normwise at 2e-6."""
+    import os
+    if os.environ.get("GNX_EDGE_FP32"):
+        pytest.skip("GNX_EDGE_FP32 is set for the whole run: the six-term kernels are switched off")
+    rng = np.random.default_rng(1300 + R + len(graphs))
+    dims = (128, 64, 32)
+    cs = [U.er_csc(rng, n, e) for n, e in graphs]
+    g = gn.GNGraphBatch.from_csc([c for c, _ in cs], [r for _, r in cs], [n for n, _ in graphs])
+    assert g.n_nodes >= 4096
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, g.n_graphs, dims)
+    nf = nf * 3.0 - 1.0
+    x = U.to_nt(gn, g, ef, nf, gf)
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    if core:
+        p = O.make_core_params(rng, dims)
+        layer = U.core_from_params(gn, p)
+        ref, scale = O.core_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    else:
+        p = O.make_block_params(rng, dims, dims, act=(1, 1, 0))
+        layer = U.block_from_params(gn, p)
+        ref, scale = O.block_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    gn.profile_reset(); gn.profile_enable(True)
+    y = layer(x)
+    gn.profile_enable(False)
+    names = set(gn.profile_read()); gn.profile_reset()
+    assert "k_proj_x6_prep" in names, names
+    for name, got, r_, s_ in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r_, s_, name)
+    os.environ["GNX_EDGE_FP32"] = "1"
+    try:
+        gn.profile_enable(True)
+        y0 = layer(x)
+        gn.profile_enable(False)
+        names0 = set(gn.profile_read()); gn.profile_reset()
+    finally:
+        del os.environ["GNX_EDGE_FP32"]
+    assert "k_proj_x6_prep" not in names0, names0
+    for a, b in ((y.ef, y0.ef), (y.nf, y0.nf), (y.gf, y0.gf)):
+        a, b = U.from_jl(a).astype(np.float64), U.from_jl(b).astype(np.float64)
+        assert np.isfinite(a).all() and np.max(np.abs(a - b)) <= 2e-6 * max(np.max(np.abs(b)), 1e-30)
