@@ -299,6 +299,9 @@ static int32_t dist_steps_buffers(gnx_dist* d, int n_steps) {
     GNX_HIP(hipMemset(d->ssend[(size_t)r], 0, row * (size_t)d->max_count * (size_t)n_steps));  // padding rows stay zero
     GNX_HIP(hipMalloc((void**)&d->srecv[(size_t)r], row * (size_t)d->max_count * (size_t)n_steps * (size_t)d->n));
     if (!d->kstream[(size_t)r]) GNX_HIP(hipStreamCreateWithFlags(&d->kstream[(size_t)r], hipStreamNonBlocking));
+    // the zero fill runs on the NULL stream and returns before it has run; the steps that follow write their rows on the caller's streams, which need not
+    // be ordered behind it (non-blocking streams): without this wait the fill can land on top of the first call's rows (seen once: a table of zeros)
+    GNX_HIP(hipDeviceSynchronize());
   }
   d->steps_cap = n_steps;
   return GNX_OK;
