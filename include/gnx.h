@@ -302,13 +302,17 @@ GNX_API int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p,
  * off), and the graph level of the core runs on a side stream of the HANDLE that gnx_core_workspace_bytes creates (joined before
  * gnx_core_forward returns; part of the capture when `stream` is being captured; env GNX_NO_FORK=1: one stream).  Hence: call
  * gnx_core_workspace_bytes outside a capture (as for every workspace query), and run one forward at a time per handle.
- * Arithmetic of the wide FeedForwards (edges / nodes at width 128 or 64, >= 4096 rows) and of the projected edge update at 128 -> 128
- * (gnx_block_forward too, >= 4096 edges): fp32 in, fp32 out, fp32 accumulation; every fp32 product is
+ * Arithmetic of the wide FeedForwards (edges / nodes at width 128 or 64, >= 4096 rows), of the projected edge update at 128 -> 128 or
+ * 128 -> at most 32 outputs (gnx_block_forward too, >= 4096 edges) and of its node projections at 64-wide nodes (>= 4096 nodes):
+ * fp32 in, fp32 out, fp32 accumulation; every fp32 product is
  * evaluated on the bf16 matrix cores as six terms of an EXACT three-way split of both operands (hi + mid + lo bf16 parts = the 24
  * mantissa bits; the dropped terms are <= 2^-23 |a||b|) — as accurate as the fp32 matrix instruction against float64 by test, 2x its
  * speed; inputs that are not finite (or within 0.4 % of the largest finite float) produce NaN where the fp32 instruction may produce an
- * infinity, and operands below ~1e-33 in magnitude may keep only 16 of their 24 mantissa bits (their low parts are bf16 subnormals).  env GNX_FFN_FP32=1 (FeedForwards) / GNX_EDGE_FP32=1 (edge update): the kernel on
- * the fp32 matrix instruction instead (csrc/gnx_ffn_x6.hip, csrc/gnx_edge_x6.hip; csrc/gnx_ffn_fused.hip, csrc/gnx_wide.hip). */
+ * infinity, and operands below ~1e-33 in magnitude may keep only 16 of their 24 mantissa bits (their low parts are bf16 subnormals).  env GNX_FFN_FP32=1 (FeedForwards) / GNX_EDGE_FP32=1 (edge update and projections): the kernel on
+ * the fp32 matrix instruction instead (csrc/gnx_ffn_x6.hip, csrc/gnx_edge_x6.hip; csrc/gnx_ffn_fused.hip, csrc/gnx_wide.hip).
+ * At 128-wide edges a core's edge update runs inside its edge FeedForward's launch, ef' kept in registers (same bits as two launches:
+ * env GNX_CORE_EDGE_SPLIT=1), and the row statistics of the edge rows are computed in those kernels (same bits as the statistics
+ * pass: env GNX_LN_STATS_PASS=1). */
 GNX_API size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t n_replicas);
 GNX_API int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf,
                          const float* gf, int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out,
