@@ -12,7 +12,7 @@ import graphnets_jl_amd as gn
 
 dev = torch.device("cuda", 0)
 model, _ = bench.c4_model(gn, torch, (128, 64, 32), dev)
-for N in (100_000, 95_000, 90_000, 80_000, 60_000, 120_000, 100_000):
+for N in ([int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else (100_000, 95_000, 90_000, 80_000, 60_000, 120_000, 100_000)):
     colptrs, rowvals, nn = bench.make_c2(N=N, E=10 * N)
     g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
     tg = torch.Generator(device=dev); tg.manual_seed(1)
