@@ -8,11 +8,14 @@ A "step" is one GNBlock forward (edge + node + graph update) over one resident b
           are captured into ONE hipGraph (the step is ~20 µs of GPU work; eager launches from Python would time the
           host) and rotate over NSETS disjoint buffer sets so the footprint (>256 MiB) defeats the Infinity Cache:
           `value` is a cache-cold, HBM-resident number.  `warm_ms_per_step` (two buffer sets, cache-resident) is extra.
-  N > 1 : BASELINE configs[4], weak scaling — ONE heterogeneous batch of N*512 random graphs (32..256 nodes, N*1M edges;
-          4096 graphs at N = 8) is sharded BY GRAPH with the product's partitioner (equal graph counts, snake order by
-          edge count: graphnets.jl_amd/dist.py); every rank builds the handle of its own 512 graphs / ~1M edges; graphs
-          never cross ranks; the only collective is the RCCL all-gather of gf' into original graph order (stacked over the
-          steps of one hipGraph replay, on a side stream).
+  N > 1 : BASELINE configs[4], STRONG scaling of ONE FIXED batch: the 4096-graph heterogeneous batch (32..256 nodes, 1M edges, seed 5 — the
+          metric's "1M-edge batch") is sharded BY GRAPH over the N ranks with the product's partitioner (equal graph counts, snake order by
+          edge count: graphnets.jl_amd/dist.py); every rank builds the handle of its own 4096/N graphs; graphs never cross ranks; the only
+          collective is the RCCL all-gather of gf' into original graph order (stacked over the steps of one hipGraph replay, on a side
+          stream).  The same graphs at every N, so the 1/2/4/8 values are one scaling curve; every line also carries
+          `single_gpu_same_workload` (rank 0 runs the WHOLE batch alone first), `with_allgather` / `without_allgather`, and
+          `secondary.c5w`: the same 4096 graphs at 8M edges through the same ranks.  `--scaling weak` keeps the N x 512-graph /
+          N x 1M-edge form (per-GPU shard fixed).  `--dist-backend gnx`: the same measurement driven by ONE process through gnx_dist_*.
           `python bench.py --gpus N` starts its own N ranks (python -m torch.distributed.run, before anything touches a
           GPU); under an external torchrun (RANK / WORLD_SIZE set) it is one of the ranks.
 Timing: W warm-up steps, then exactly K steps bracketed by barrier + torch.cuda.synchronize(), MAX over ranks; the K-step
@@ -359,67 +362,95 @@ def bench_c4(args, gn, torch, dev, c_abi=None):
     print(json.dumps(line))
 
 
-def bench_dist_gnx(args):
-    """BASELINE configs[4] through the C boundary's OWN multi-GPU entry (gnx_dist_*): one process, --gpus devices, weak scaling as in the
-    torch path (N*512 graphs / N*1M edges, the product's partitioner, 512 graphs per device).  K steps = K / M calls of
-    gnx_dist_block_forward_steps with M steps each (one hipGraph launch per device + ONE grouped all-gather of the M stacked gf' tables per
-    call).  Timed region: all devices synchronised on both sides; median of three."""
-    import torch
-    import graphnets_jl_amd as gn
+def measure_dist_gnx(args, gn, torch, n, din, dout, Gtot, Etot, seed, K, W):
+    """One sharded measurement through gnx_dist_block_forward_steps: the batch partitioned over n devices driven by THIS process; the whole batch on
+    device 0 first (single_gpu_same_workload); then the K-step region with and without the grouped all-gather, median of three each."""
     from graphnets_jl_amd.dist import DistBlockRunner, partition_graphs
-    n = args.gpus
-    assert torch.cuda.device_count() >= n, f"--dist-backend gnx drives {n} devices from this process; {torch.cuda.device_count()} visible"
-    din, dout = DIMS[args.dims] if args.dims in DIMS else tuple(tuple(int(v) for v in part.split(",")) for part in args.dims.split(":"))
-    Gtot, Etot = args.hetero_graphs * n, args.hetero_edges * n
-    seed = 3 if Gtot == 512 else (5 if Gtot == 4096 else 1000 + Gtot)
+    single = None
+    if not args.no_single_gpu_leg:
+        torch.cuda.set_device(0)
+        single = single_gpu_same_workload(gn, torch, torch.device("cuda", 0), seed, Gtot, Etot, din, dout, K, W, args.flags)
     n_all, e_all = hetero_spec(seed, Gtot, Etot)
     shards = partition_graphs(e_all, n)
-    K, W = args.steps, args.warmup
     M = max(m for m in range(1, 65) if K % m == 0)
-    rng = np.random.default_rng(100)
-    (de, dn, dg), (oe, on, og) = din, dout
-    Ws = (glorot(rng, oe, de + 2 * dn + dg), glorot(rng, on, oe + dn + dg), glorot(rng, og, oe + on + dg))
+    per_shard = algorithmic_bytes(Etot // n, int(n_all.sum()) // n, Gtot // n, din, dout)
+    nsets = rotating_sets(per_shard)
+    run = DistBlockRunner(list(range(n)), shards, lambda r: make_hetero(seed, Gtot, Etot, only=shards[r]), lambda dev: bench_weights(gn, din, dout, dev), (din, dout),
+                          n_sets=nsets, max_steps=M)
+    assert run.edges == Etot and sum(g.n_graphs for g in run.handles) == Gtot, "the shards do not add up to the batch"
 
-    def make_block(dev):
-        blk = gn.GNBlock(din, dout, device=dev)
-        blk.edgefn = gn.Dense.from_numpy(Ws[0], np.zeros(oe, np.float32), device=dev)
-        blk.nodefn = gn.Dense.from_numpy(Ws[1], np.zeros(on, np.float32), device=dev)
-        blk.graphfn = gn.Dense.from_numpy(Ws[2], np.zeros(og, np.float32), device=dev)
-        return blk
-    run = DistBlockRunner(list(range(n)), shards, lambda r: make_hetero(seed, Gtot, Etot, only=shards[r]), make_block, (din, dout), n_sets=NSETS, max_steps=M)
-
-    def region():
+    def region(flags=0):
         for j in range(K // M):
-            run.run((j * M) % NSETS, M)
+            run.run((j * M) % nsets, M, flags=flags)
+
+    def timed(flags):
+        reps = []
+        for _ in range(3):
+            run.synchronize()
+            t0 = time.perf_counter()
+            region(flags)
+            run.synchronize()
+            reps.append(time.perf_counter() - t0)
+        return sorted(reps)
     for _ in range(max(2, -(-W // M))):  # warm-up: every (first set, M) argument set the region uses gets captured here
         region()
     run.synchronize()
-    reps = []
-    for _ in range(3):
-        run.synchronize()
-        t0 = time.perf_counter()
-        region()
-        run.synchronize()
-        reps.append(time.perf_counter() - t0)
-    dt = sorted(reps)[1]
+    t_w = time.perf_counter()
+    while (time.perf_counter() - t_w) * 1e3 < CLOCK_WARMUP_MS:  # the same untimed load as spin_up
+        region(); run.synchronize()
+    reps = timed(0)
+    reps_wo = timed(gn._lib.FLAG_DIST_NO_GATHER)
     # the eager form of the same entry point (no per-device hipGraph): what the replay form saves
     t0 = time.perf_counter()
-    for j in range(K // M):
-        run.run((j * M) % NSETS, M, flags=gn._lib.FLAG_NO_GRAPH)
+    region(gn._lib.FLAG_NO_GRAPH)
     run.synchronize()
     dt_eager = time.perf_counter() - t0
-    E = run.edges
-    abytes = sum(algorithmic_bytes(g.n_edges, g.n_nodes, g.n_graphs, din, dout) for g in run.handles)
-    line = {"metric": "edges updated/sec, GNBlock fwd, 1M-edge batch", "value": round(E / (dt / K), 1), "unit": "edges/s", "n_gpus": n, "steps": K, "warmup": W,
-            "ms_per_step": round(dt / K * 1e3, 6), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ONE heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {n} GPU(s) "
-                                   f"driven by ONE process through gnx_dist_block_forward_steps (BASELINE configs[4] law)",
-                       "dims": f"{din}=>{dout}", "edges_whole_job": E, "graphs_per_gpu": [g.n_graphs for g in run.handles], "dist_backend": "gnx",
-                       "launch": f"{K // M} calls of gnx_dist_block_forward_steps per region, {M} steps each: one hipGraphLaunch per device + ONE grouped ncclAllGather of the {M} stacked gf' tables per call",
-                       "timing": f"median of 3 regions ({[round(r / K * 1e6, 2) for r in reps]} us/step)", "eager_ms_per_step": round(dt_eager / K * 1e3, 6)},
+    res = {"E_job": run.edges, "G_job": Gtot, "seed": seed, "M": M, "nsets": nsets, "dt": reps[1], "dt_without": reps_wo[1], "reps": reps, "reps_without": reps_wo,
+           "per_rank": [[g.n_edges, g.n_nodes, g.n_graphs] for g in run.handles], "single": single, "eager_ms_per_step": round(dt_eager / K * 1e3, 6)}
+    run.close()
+    del run
+    torch.cuda.empty_cache()
+    return res
+
+
+def bench_dist_gnx(args):
+    """BASELINE configs[4] through the C boundary's OWN multi-GPU entry (gnx_dist_*): ONE process, --gpus devices.  Default `--scaling strong`: the
+    FIXED 4096-graph / 1M-edge batch (and C5w beside it) partitioned by the product's partitioner over the devices; `--scaling weak`: N x 512 graphs.
+    K steps = K / M calls of gnx_dist_block_forward_steps with M steps each (one hipGraph launch per device + ONE grouped all-gather of the M
+    stacked gf' tables per call).  Timed region: all devices synchronised on both sides; median of three."""
+    import torch
+    import graphnets_jl_amd as gn
+    n = args.gpus
+    assert torch.cuda.device_count() >= n, f"--dist-backend gnx drives {n} devices from this process; {torch.cuda.device_count()} visible"
+    din, dout = DIMS[args.dims] if args.dims in DIMS else tuple(tuple(int(v) for v in part.split(",")) for part in args.dims.split(":"))
+    Gtot, Etot, seed = sharded_workload(args, n)
+    K, W = args.steps, args.warmup
+    res = measure_dist_gnx(args, gn, torch, n, din, dout, Gtot, Etot, seed, K, W)
+    e = sharded_entry(res, K, n)
+    M = res["M"]
+    strong = args.scaling == "strong"
+    abytes = sum(algorithmic_bytes(c[0], c[1], c[2], din, dout) for c in res["per_rank"])
+    dt = res["dt"]
+    line = {"metric": "edges updated/sec, GNBlock fwd, 1M-edge batch", "value": e["value"], "unit": "edges/s", "n_gpus": n, "steps": K, "warmup": W,
+            "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"BASELINE configs[4]: ONE FIXED heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {n} GPU(s) "
+                                    f"— the same graphs at every N (strong scaling) — " if strong else
+                                    f"ONE heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {n} GPU(s) (weak scaling) ") +
+                                   "driven by ONE process through gnx_dist_block_forward_steps",
+                       "dims": f"{din}=>{dout}", "edges_whole_job": e["edges_whole_job"], "graphs_whole_job": e["graphs_whole_job"], "per_rank_edges_nodes_graphs": e["per_rank_edges_nodes_graphs"],
+                       "graphs_per_gpu": [c[2] for c in res["per_rank"]], "dist_backend": "gnx",
+                       "launch": f"{K // M} calls of gnx_dist_block_forward_steps per region, {M} steps each over {res['nsets']} rotating buffer sets: one hipGraphLaunch per device + ONE grouped ncclAllGather of the {M} stacked gf' tables per call",
+                       "timing": f"median of 3 regions ({e['with_allgather']['reps_us_per_step']} us/step)", "eager_ms_per_step": res["eager_ms_per_step"]},
+            "with_allgather": e["with_allgather"], "without_allgather": e["without_allgather"], "single_gpu_same_workload": e["single_gpu_same_workload"],
             "roofline": {"bound": "hbm", "achieved": round(abytes / (dt / K) / 1e9, 2), "peak": HBM_PEAK_GBS * n, "unit": "GB/s", "frac": round(abytes / (dt / K) / 1e9 / (HBM_PEAK_GBS * n), 4),
                          "counts": "algorithmic bytes of every device's shard / whole-step time / (n_gpus x 8 TB/s)", "algorithmic_bytes": abytes}}
-    run.close()
+    if "speedup_vs_single_gpu_same_workload" in e:
+        line["speedup_vs_single_gpu_same_workload"] = e["speedup_vs_single_gpu_same_workload"]
+    if strong and (Gtot, Etot) == (4096, 1_000_000) and not args.no_secondary:
+        c5w = measure_dist_gnx(args, gn, torch, n, din, dout, 4096, 8_000_000, 5, K, W)
+        ew = sharded_entry(c5w, K, n)
+        ew["what"] = "C5w (SURVEY 8e): the same 4096 graphs at configs[2]'s density — 8M edges — sharded over the same devices"
+        line["secondary"] = {"c5w": ew}
     _flush_c_stdio()
     print(json.dumps(line), flush=True)
 
@@ -440,9 +471,9 @@ SECONDARY = [  # (key, extra argv, BASELINE config it stands for)
     ("c5_one_gpu", ["--workload", "hetero", "--hetero-graphs", "4096"], "configs[4]'s batch on one GPU: 4096 graphs, 1M edges"),
     ("c5w_one_gpu", ["--workload", "hetero", "--hetero-graphs", "4096", "--hetero-edges", "8000000"],
      "C5w (SURVEY 8d): configs[4]'s 4096 graphs at configs[2]'s density, 8M edges on one GPU — the block kernel over eight rounds of waves instead of one (its steady state)"),
-    ("c5_dist_gnx", ["--dist-backend", "gnx", "--hetero-graphs", "4096"],
+    ("c5_dist_gnx", ["--dist-backend", "gnx", "--hetero-graphs", "4096", "--no-single-gpu-leg"],
      "configs[4]'s batch through the C boundary's own multi-GPU entry at one device: gnx_dist_block_forward_steps (hipGraph per device + grouped ncclAllGather + index table)"),
-    ("c5_force_dist", ["--force-dist", "--hetero-graphs", "4096"],
+    ("c5_force_dist", ["--force-dist", "--hetero-graphs", "4096", "--no-single-gpu-leg"],
      "configs[4]'s batch through the N > 1 code path at world size 1 (partitioner, stacked gf' send buffer, RCCL all-gather on a side stream, index table back to graph order)"),
     ("c4", ["--model", "c4"], "configs[3]: Encoder -> 2 x GNCore(128,64,32) -> Decoder on the 1M-edge graph"),
     ("c4_narrow", ["--model", "c4", "--core-dims", "10,5,3"], "README example 3 at its own widths (core_dims 10,5,3)"),
@@ -479,7 +510,7 @@ def collect_secondary(args):
         ts = roof.get("traffic_source")
         if ts:
             entry["roofline"]["traffic_source"] = {k: ts.get(k) for k in ("file", "commit", "stale") if ts.get(k) is not None}
-        for k in ("batch_ms", "kernel_us_one_forward", "pipelined_two_streams", "chained_graph_update", "c_abi_ms_per_step", "c_abi", "n_gpus"):
+        for k in ("batch_ms", "kernel_us_one_forward", "pipelined_two_streams", "chained_graph_update", "c_abi_ms_per_step", "c_abi", "n_gpus", "scaling", "with_allgather", "without_allgather"):
             if k in line or k in line.get("config", {}):
                 entry[k] = line.get(k, line.get("config", {}).get(k))
         out[key] = entry
@@ -550,6 +581,321 @@ def load_traffic(dims_key, kernel, sha):
     return t.get(kernel, {}).get("hbm_bytes_per_launch"), src
 
 
+def block_roofline(gn, torch, dev, plan, sets, nsets, K, E, N, G, din, dout, ms_per_step, dims_key, headline_traffic_breakdown=False):
+    """`roofline` of one GNBlock forward: the same K steps again, eagerly, with dispatch timestamps on every launch (gnx_profile_*), at settled
+    clocks; the dominant kernel's average duration prices the block's ALGORITHMIC bytes (or its executed flops where the matrix cores bind)."""
+    def eager_pass():
+        for i in range(K):
+            b = sets[i % nsets]
+            plan(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"])
+    spin_up(torch, dev, eager_pass)  # the pass below runs at settled clocks, like the timed region
+    gn.profile_reset(); gn.profile_enable(True)
+    for i in range(K):
+        b = sets[i % nsets]
+        plan(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"])
+    gn.profile_calibrate(K, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    gn.profile_enable(False)
+    prof = gn.profile_read(); gn.profile_reset()
+    null_us = (prof.get("__empty_bracket__") or {"total_ms": 0.0, "launches": 1})
+    null_us = null_us["total_ms"] / max(null_us["launches"], 1) * 1e3
+    kern = calibrated_kernel_us(prof)
+    dom = max(kern, key=kern.get)
+    dur_s = kern[dom] * 1e-6
+    step_s = ms_per_step * 1e-3
+    abytes, aflops = algorithmic_bytes(E, N, G, din, dout), algorithmic_flops(E, N, G, din, dout)
+    hbm_t, mfma_t = abytes / (HBM_PEAK_GBS * 1e9), aflops / (MFMA_F32_PEAK_TFS * 1e12)
+    if max(din + dout) > 32:  # matrix-core path: the binding roof is decided on the flops the kernels EXECUTE at the rate of the instruction that carries them
+        ex_ = executed_flops(E, N, G, din, dout)
+        x6_ = 2 * E * din[0] * dout[0] if (din[0] == 128 and dout[0] == 128 and din[1] >= 16 and E >= 2 * N and not os.environ.get("GNX_EDGE_FP32")) else 0
+        mfma_t = x6_ / (MFMA_BF16_PEAK_TFS / 6 * 1e12) + (ex_ - x6_) / (MFMA_F32_PEAK_TFS * 1e12)
+    traffic, tsrc = load_traffic(dims_key, dom, kernel_source_sha(din, dout))
+    if hbm_t >= mfma_t:
+        a = abytes / dur_s / 1e9
+        roof = dict(bound="hbm", achieved=round(a, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(a / HBM_PEAK_GBS, 4),
+                    frac_whole_step=round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=tsrc,
+                    counts="algorithmic bytes of the whole block / duration of the dominant kernel (frac) or of the whole step (frac_whole_step)")
+        if max(din + dout) > 32:  # a matrix-core block whose matrix time (per carrying instruction) is below its memory time: both fractions on the WHOLE step
+            roof.update(frac=roof["frac_whole_step"], algorithmic_bytes=abytes, executed_flops=ex_, flops_on_bf16_six_terms=x6_,
+                        frac_of_fp32_mfma_roof=round(ex_ / step_s / 1e12 / MFMA_F32_PEAK_TFS, 4), matrix_roof_frac=round(mfma_t / step_s, 4),
+                        counts="algorithmic bytes of the whole block / whole-step time (several launches); matrix_roof_frac: the executed flops at the rate of the "
+                               "instruction that carries them (fp32 MFMA %.1f TFLOP/s; six bf16 terms per fp32 product: %.0f / 6) / whole-step time" % (MFMA_F32_PEAK_TFS, MFMA_BF16_PEAK_TFS))
+    else:
+        # MFMA-bound: priced on the flops the kernels EXECUTE (never more than the peak); the algorithmic rate of the
+        # reference formulation (every edge multiplies its full [ef; nf_src; nf_dst; gf] row) is reported beside it
+        ex = executed_flops(E, N, G, din, dout)
+        a = ex / step_s / 1e12
+        # the projected edge update at 128 -> 128 runs as six bf16 matrix-core terms per fp32 product (k_edge_x6) unless GNX_EDGE_FP32=1: its
+        # flops are priced at that instruction's rate, the rest at the fp32 MFMA's
+        x6_flops = 2 * E * din[0] * dout[0] if (din[0] == 128 and dout[0] == 128 and din[1] >= 16 and E >= 2 * N and not os.environ.get("GNX_EDGE_FP32")) else 0
+        t_roof = x6_flops / (MFMA_BF16_PEAK_TFS / 6 * 1e12) + (ex - x6_flops) / (MFMA_F32_PEAK_TFS * 1e12)
+        roof = dict(bound="mfma", achieved=round(a, 3), peak=round(ex / t_roof / 1e12, 1), unit="TFLOP/s", frac=round(t_roof / step_s, 4),
+                    frac_whole_step=round(t_roof / step_s, 4), frac_of_fp32_mfma_roof=round(a / MFMA_F32_PEAK_TFS, 4), flops_on_bf16_six_terms=x6_flops,
+                    traffic=traffic, traffic_source=tsrc,
+                    counts="EXECUTED flops of the whole block / whole-step time (the block is several GEMM launches); peak = the same flops at the rate of the instruction "
+                           "that carries them (fp32 MFMA %.1f TFLOP/s; six bf16 terms per fp32 product: %.0f / 6)" % (MFMA_F32_PEAK_TFS, MFMA_BF16_PEAK_TFS),
+                    executed_flops=ex, algorithmic_tflops_whole_step=round(aflops / step_s / 1e12, 2),
+                    hbm_frac_whole_step=round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 4))
+    if traffic is not None and headline_traffic_breakdown:
+        # `traffic` counts what leaves the L2s (fabric bytes: Infinity-Cache hits included); the split into HBM bytes and cache hits
+        # comes from a residency A/B (no counter separates them): profiles/traffic_breakdown_readme.json
+        bpath = os.path.join(ROOT, "profiles", "traffic_breakdown_readme.json")
+        if os.path.exists(bpath):
+            with open(bpath) as f:
+                bd = json.load(f)
+            if dom in bd:
+                roof["traffic_breakdown"] = {"fabric": traffic, "hbm_estimate": bd[dom]["hbm_bytes_per_launch_estimate"],
+                                             "infinity_cache_hits_estimate": bd[dom]["infinity_cache_hit_bytes_estimate"],
+                                             "source": "profiles/traffic_breakdown_readme.json"}
+    assert roof["frac"] <= 1.0 and roof["frac_whole_step"] <= 1.0, "a roofline fraction above 1 is an accounting error"
+    roof.update(kernel=dom, kernel_us=round(kern[dom], 3), kernel_us_source="dispatch timestamps of every launch of the per-kernel pass (hipExtLaunchKernel start / stop events), averaged, minus the constant (empty kernel timed the same way - rocprofv3's figure for it: profiles/calibration.json)",
+                null_kernel_us=round(null_us, 3), algorithmic_bytes=abytes, algorithmic_flops=aflops,
+                bytes_per_edge=round(abytes / E, 2), all_kernels_us={k: round(v, 3) for k, v in kern.items()})
+
+    return roof
+
+
+def sharded_workload(args, world):
+    """Which batch an N-rank run shards (pure arithmetic: the CPU tests call it).  `--scaling strong` (default): ONE FIXED batch whatever N is —
+    BASELINE configs[4]: 4096 graphs (32-256 nodes), 1M edges, seed 5 (`--hetero-graphs` / `--hetero-edges` are then TOTALS of that batch).
+    `--scaling weak`: N x 512 graphs / N x 1M edges (the per-GPU shard is fixed instead).  Returns (G_total, E_total, seed)."""
+    if args.scaling == "strong":
+        Gtot, Etot = args.hetero_graphs or 4096, args.hetero_edges or 1_000_000
+    else:
+        Gtot, Etot = (args.hetero_graphs or 512) * world, (args.hetero_edges or 1_000_000) * world
+    seed = 3 if Gtot == 512 else (5 if Gtot == 4096 else 1000 + Gtot)  # SURVEY §8d: C3 = seed 3, C5 = seed 5
+    return Gtot, Etot, seed
+
+
+def rotating_sets(set_bytes):
+    """Buffer sets a rank rotates over so that its footprint stays above the 256-MiB Infinity Cache (cache-cold steps) however small the shard is."""
+    return int(min(64, max(NSETS, -(-320_000_000 // max(int(set_bytes), 1)))))
+
+
+def bench_weights(gn, din, dout, dev):
+    """The bench's GNBlock: glorot weights from a fixed seed (identical on every rank and device), zero biases."""
+    rng = np.random.default_rng(100)
+    (de, dn, dg), (oe, on, og) = din, dout
+    blk = gn.GNBlock(din, dout, device=dev)
+    blk.edgefn = gn.Dense.from_numpy(glorot(rng, oe, de + 2 * dn + dg), np.zeros(oe, np.float32), device=dev)
+    blk.nodefn = gn.Dense.from_numpy(glorot(rng, on, oe + dn + dg), np.zeros(on, np.float32), device=dev)
+    blk.graphfn = gn.Dense.from_numpy(glorot(rng, og, oe + on + dg), np.zeros(og, np.float32), device=dev)
+    return blk
+
+
+def block_sets(torch, dev, plan, g, din, nsets, seed):
+    (de, dn, dg) = din
+    tg = torch.Generator(device=dev); tg.manual_seed(seed)
+    mk = lambda T, d: torch.rand((1, T, d), generator=tg, device=dev, dtype=torch.float32) if d > 0 else None
+    return [dict(ef=mk(g.n_edges, de), nf=mk(g.n_nodes, dn), gf=mk(g.n_graphs, dg), out=plan.outputs(), ws=plan.new_workspace()) for _ in range(nsets)]
+
+
+def single_gpu_same_workload(gn, torch, dev, seed, Gtot, Etot, din, dout, K, W, flags):
+    """The WHOLE batch of a sharded run on ONE GPU, by the N = 1 procedure (K steps captured into one hipGraph over rotating buffer sets, 150 ms of
+    the same load first, median of three regions): the denominator of a strong-scaling efficiency that compares the same graphs."""
+    colptrs, rowvals, nn = make_hetero(seed, Gtot, Etot)
+    g = gn.GNGraphBatch.from_csc_packed(np.concatenate(colptrs), np.concatenate(rowvals), nn, device=dev)
+    blk = bench_weights(gn, din, dout, dev)
+    plan = gn.BlockPlan(blk, g, R=1, flags=flags)
+    nsets = rotating_sets(algorithmic_bytes(g.n_edges, g.n_nodes, g.n_graphs, din, dout))
+    sets = block_sets(torch, dev, plan, g, din, nsets, 999)
+    step = lambda i: plan(sets[i % nsets]["ef"], sets[i % nsets]["nf"], sets[i % nsets]["gf"], *sets[i % nsets]["out"], ws=sets[i % nsets]["ws"])
+    for i in range(max(W, 2)):
+        step(i)
+    torch.cuda.synchronize(dev)
+    cg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(cg):
+        for i in range(K):
+            step(i)
+    cg.replay(); torch.cuda.synchronize(dev)
+    spin_up(torch, dev, cg.replay)
+    reps = []
+    for _ in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        cg.replay()
+        torch.cuda.synchronize(dev)
+        reps.append(time.perf_counter() - t0)
+    dt = sorted(reps)[1] / K
+    out = {"n_gpus": 1, "ms_per_step": round(dt * 1e3, 6), "value": round(g.n_edges / dt, 1), "unit": "edges/s", "graphs": g.n_graphs, "edges": g.n_edges,
+           "what": f"the same {Gtot} graphs / {g.n_edges} edges as ONE batch on ONE GPU (rank 0, before the sharded measurement; hipGraph of {K} steps over {nsets} rotating buffer sets, median of 3)"}
+    del cg, sets, plan, g
+    torch.cuda.empty_cache()
+    return out
+
+
+def measure_sharded(gn, torch, dist, dev, rank, world, args, din, dout, Gtot, Etot, seed, K, W, want_roofline=True):
+    """ONE heterogeneous batch (G_total graphs, E_total edges) sharded BY GRAPH over `world` ranks (the product's partitioner: equal graph counts,
+    snake order by edge count), every rank a handle of ITS graphs, no data-path collective except the all-gather of gf' (M stacked tables per
+    collective, on a side stream).  Times the K-step region twice — with the all-gather (the whole path: `value`) and without it — each bracketed
+    by barrier + synchronize, MAX over ranks, median of three; rank 0 also runs the whole batch alone first (single_gpu_same_workload)."""
+    from graphnets_jl_amd.dist import GfGather, partition_graphs
+    (de, dn, dg), (oe, on, og) = din, dout
+    single = None
+    if rank == 0 and not args.no_single_gpu_leg:
+        single = single_gpu_same_workload(gn, torch, dev, seed, Gtot, Etot, din, dout, K, W, args.flags)
+    n_all, e_all = hetero_spec(seed, Gtot, Etot)
+    shards = partition_graphs(e_all, world)
+    colptrs, rowvals, nn = make_hetero(seed, Gtot, Etot, only=shards[rank])
+    g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
+    E, N, G = g.n_edges, g.n_nodes, g.n_graphs
+    blk = bench_weights(gn, din, dout, dev)
+    plan = gn.BlockPlan(blk, g, R=1, flags=args.flags)
+    nsets = 2 if max(din + dout) >= 64 else rotating_sets(algorithmic_bytes(E, N, G, din, dout))
+    sets = block_sets(torch, dev, plan, g, din, nsets, 1234 + rank)
+    # M steps of compute are captured into one hipGraph that writes the M gf' tables into a stacked send buffer, and ONE all-gather moves the
+    # whole stack (fewer, larger collectives: the per-step message is G * DG' floats = 10 KB per rank, pure latency on xGMI); the gather runs on
+    # a side stream and overlaps the next M steps.
+    M = max(m for m in range(1, 257) if K % m == 0)
+    gather = GfGather(shards, rank, world, og, dev, stack=M)
+    gf_stack = gather.send  # [M][max_count][og]: the graph update writes straight into the send buffer
+    gf_result = torch.empty((M * gather.G, og), dtype=torch.float32, device=dev)  # gathered tables, ORIGINAL graph order
+    assert gf_stack.shape[1] == G or world > 1, "one rank: every graph is local"
+
+    def step(i, slot):
+        b = sets[i % nsets]
+        plan(b["ef"], b["nf"], b["gf"], b["out"][0], b["out"][1], gf_stack[slot:slot + 1, :G], ws=b["ws"])
+
+    def sync_all():
+        """barrier + torch.cuda.synchronize() (the contract's bracket): the gathered gf' table is waited for first, and the barrier's collective is
+        enqueued asynchronously behind it — one small RCCL kernel and ONE host synchronisation per bracket."""
+        if gather._ready is not None:
+            gather.finish(out=gf_result)
+        work = dist.barrier(async_op=True)
+        torch.cuda.synchronize(dev)
+        work.wait()
+        torch.cuda.synchronize(dev)
+
+    def timed(run):
+        sync_all()
+        t0 = time.perf_counter()
+        run()
+        sync_all()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    for i in range(max(W, 2)):  # warm-up (also loads the code objects: at least two eager steps before any capture)
+        step(i, i % M)
+    sync_all()
+    cgs = []
+    for base in range(0, min(K, nsets * M), M):  # enough distinct graphs to keep rotating over all buffer sets
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            for m in range(M):
+                step(base + m, m)
+        cgs.append(cg)
+    copied = torch.cuda.Event()
+
+    def run_with():
+        for j in range(K // M):
+            torch.cuda.current_stream(dev).wait_event(copied) if j else None  # the previous stack has left the send buffer
+            cgs[j % len(cgs)].replay()
+            gather.start_inplace()
+            copied.record(gather.comm_stream) if gather.comm_stream is not None else copied.record()
+
+    def run_without():
+        for j in range(K // M):
+            cgs[j % len(cgs)].replay()
+
+    def settle(run):
+        run(); sync_all()
+        t_w = time.perf_counter()
+        while True:  # the same untimed load as spin_up; the ranks agree on when to stop (a rank-local clock would leave them in different collectives)
+            run(); sync_all()
+            t = torch.tensor([time.perf_counter() - t_w], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if float(t.item()) * 1e3 >= CLOCK_WARMUP_MS:
+                return
+    settle(run_without)
+    reps_wo = sorted(timed(run_without) for _ in range(3))
+    settle(run_with)
+    reps = sorted(timed(run_with) for _ in range(3))
+    dt, dt_wo = reps[1], reps_wo[1]
+    gf_all = gather.finish() if gather._ready is not None else gather.result()
+    assert tuple(gf_all.reshape(M, -1, og).shape) == (M, gather.G, og) and torch.equal(gf_all.reshape(-1, og), gf_result)
+    # every rank's rows of the gathered table are the rows it computed (original graph order restored)
+    mine = torch.from_numpy(np.asarray(shards[rank], dtype=np.int64)).to(dev)
+    assert torch.equal(gf_all.reshape(M, gather.G, og)[:, mine], gf_stack[:, :G]), "gathered gf' rows differ from the rows this rank wrote"
+    t = torch.tensor([float(E), float(N), float(G)], device=dev, dtype=torch.float64)
+    per_rank = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(per_rank, t)
+    counts = [[int(v) for v in p.tolist()] for p in per_rank]
+    E_job = sum(c[0] for c in counts)
+    assert E_job == Etot and sum(c[2] for c in counts) == Gtot, "the shards do not add up to the batch"
+    res = {"E_job": E_job, "G_job": Gtot, "seed": seed, "M": M, "nsets": nsets, "dt": dt, "dt_without": dt_wo, "reps": reps, "reps_without": reps_wo,
+           "per_rank": counts, "single": single, "E": E, "N": N, "G": G, "roof": None}
+    if rank == 0 and want_roofline:
+        rsets = [dict(b, out=(b["out"][0], b["out"][1], gf_stack[0:1, :G])) for b in sets]
+        dims_key = args.dims.replace(":", "_").replace(",", "-") + f"_hetero{G}" + ("" if E == 1_000_000 else f"_{E}")
+        res["roof"] = block_roofline(gn, torch, dev, plan, rsets, nsets, K, E, N, G, din, dout, dt_wo / K * 1e3, dims_key)
+    del cgs
+    return res
+
+
+def sharded_entry(res, K, world):
+    """The fields of one sharded measurement as they appear in the line (headline of an N > 1 run, and `secondary.c5w`)."""
+    dt, dtw, E = res["dt"] / K, res["dt_without"] / K, res["E_job"]
+    out = {"value": round(E / dt, 1), "unit": "edges/s", "ms_per_step": round(dt * 1e3, 6), "edges_whole_job": E, "graphs_whole_job": res["G_job"],
+           "with_allgather": {"ms_per_step": round(dt * 1e3, 6), "value": round(E / dt, 1), "reps_us_per_step": [round(r / K * 1e6, 2) for r in res["reps"]]},
+           "without_allgather": {"ms_per_step": round(dtw * 1e3, 6), "value": round(E / dtw, 1), "reps_us_per_step": [round(r / K * 1e6, 2) for r in res["reps_without"]],
+                                 "what": "the same hipGraph replays without the RCCL all-gather of gf' (every rank keeps only its own graphs' rows)"},
+           "per_rank_edges_nodes_graphs": res["per_rank"], "single_gpu_same_workload": res["single"]}
+    if res["single"]:
+        out["speedup_vs_single_gpu_same_workload"] = round(res["single"]["ms_per_step"] / (dt * 1e3), 4)
+    return out
+
+
+def bench_sharded(args, gn, torch, dist, dev, rank, world, din, dout):
+    """N > 1 (and --force-dist): BASELINE configs[4].  Default `--scaling strong`: the FIXED 4096-graph / 1M-edge batch (seed 5: the metric's
+    "1M-edge batch") partitioned over the N ranks — the same graphs at every N, so the 1/2/4/8 curve is a scaling curve of ONE workload — with the
+    same 4096 graphs at 8M edges (C5w) beside it as `secondary.c5w`.  Every line carries the whole batch on one GPU (`single_gpu_same_workload`)
+    and the region with and without the all-gather."""
+    K, W = args.steps, args.warmup
+    Gtot, Etot, seed = sharded_workload(args, world)
+    res = measure_sharded(gn, torch, dist, dev, rank, world, args, din, dout, Gtot, Etot, seed, K, W)
+    c5w = None
+    strong_default = args.scaling == "strong" and (Gtot, Etot) == (4096, 1_000_000) and not args.no_secondary
+    if strong_default:
+        torch.cuda.empty_cache()
+        c5w = measure_sharded(gn, torch, dist, dev, rank, world, args, din, dout, 4096, 8_000_000, 5, K, W)
+    line = None
+    if rank == 0:
+        e = sharded_entry(res, K, world)
+        strong = args.scaling == "strong"
+        wl = (f"BASELINE configs[4]: ONE FIXED heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {world} GPU(s) — "
+              f"the same graphs at every N (strong scaling)" if strong else
+              f"ONE heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {world} GPU(s): {Gtot // world} graphs / "
+              f"~{Etot // world} edges per GPU at every N (weak scaling; BASELINE configs[4] law)")
+        line = {"metric": "edges updated/sec, GNBlock fwd, 1M-edge batch", "value": e["value"], "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,
+                "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": wl, "dims": f"{din}=>{dout}", "edges_whole_job": e["edges_whole_job"], "graphs_whole_job": e["graphs_whole_job"],
+                           "edges_per_gpu": res["E"], "nodes_per_gpu": res["N"], "graphs_per_gpu": res["G"], "per_rank_edges_nodes_graphs": e["per_rank_edges_nodes_graphs"],
+                           "parallelism": f"graph-sharded x{world}", "dist_backend": "torch (one process per GPU, RCCL all-gather of gf')",
+                           "launch": f"hipGraph of {res['M']} steps per replay over {res['nsets']} rotating buffer sets per rank; one RCCL all-gather of the {res['M']} stacked gf' tables per replay, on a side stream",
+                           "timing": f"median of 3 runs of the {K}-step region ({e['with_allgather']['reps_us_per_step']} us/step), MAX over ranks, after {CLOCK_WARMUP_MS:g} ms of the same load, untimed"},
+                "with_allgather": e["with_allgather"], "without_allgather": e["without_allgather"], "single_gpu_same_workload": e["single_gpu_same_workload"],
+                "roofline": res["roof"], "cpu_baseline": None}
+        if "speedup_vs_single_gpu_same_workload" in e:
+            line["speedup_vs_single_gpu_same_workload"] = e["speedup_vs_single_gpu_same_workload"]
+        if res["roof"] is not None:
+            ab = sum(algorithmic_bytes(c[0], c[1], c[2], din, dout) for c in res["per_rank"])
+            line["roofline"]["whole_job"] = {"algorithmic_bytes": ab, "achieved": round(ab / (res["dt"] / K) / 1e9, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                             "frac": round(ab / (res["dt"] / K) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                                             "counts": "algorithmic bytes of every rank's shard / whole-step time / (n_gpus x 8 TB/s); the kernel figures above are rank 0's shard"}
+        if c5w is not None:
+            ew = sharded_entry(c5w, K, world)
+            ew["what"] = "C5w (SURVEY 8e): the same 4096 graphs at configs[2]'s density — 8M edges — sharded over the same ranks; strong scaling of a batch eight times larger"
+            ew["roofline"] = c5w["roof"]
+            line["secondary"] = {"c5w": ew}
+    dist.barrier()
+    dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        time.sleep(0.5)  # the other ranks' (already flushed) output reaches the launcher's pipe first
+        print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -557,8 +903,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dims", default="readme", help="a preset (%s) or explicit widths de,dn,dg:oe,on,og" % ", ".join(DIMS))
     ap.add_argument("--workload", choices=["c2", "hetero"], default=None, help="default: c2 at N = 1 (BASELINE configs[1]), hetero at N > 1 (configs[4])")
-    ap.add_argument("--hetero-graphs", type=int, default=512, help="graphs per GPU of the hetero workload (C3: 512; C5 on one GPU: 4096)")
-    ap.add_argument("--hetero-edges", type=int, default=1_000_000, help="edges per GPU of the hetero workload (C5w: 8000000)")
+    ap.add_argument("--hetero-graphs", type=int, default=None,
+                    help="graphs of the hetero workload: on one GPU the batch (default 512 = C3; 4096 = C5 on one GPU); with --scaling strong the TOTAL of the fixed "
+                         "batch (default 4096 = configs[4]); with --scaling weak per GPU (default 512)")
+    ap.add_argument("--hetero-edges", type=int, default=None, help="edges of the hetero workload, counted like --hetero-graphs (default 1000000; C5w: 8000000)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong (default) = ONE fixed batch — BASELINE configs[4]: 4096 graphs / 1M edges, seed 5 — partitioned over the N ranks, C5w (8M edges) "
+                         "beside it; weak = N x 512 graphs / N x 1M edges (the per-GPU shard fixed)")
+    ap.add_argument("--no-single-gpu-leg", action="store_true", help="N > 1: skip rank 0's run of the whole batch on one GPU (single_gpu_same_workload)")
     ap.add_argument("--c2-scale", type=float, default=1.0, help="scale C2's nodes and edges by this factor (size sweeps; 1 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs of the default N = 1 line")
@@ -602,7 +954,6 @@ def main():
     import torch
     import torch.distributed as dist
     import graphnets_jl_amd as gn
-    from graphnets_jl_amd.dist import GfGather, partition_graphs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -624,23 +975,23 @@ def main():
     else:
         din, dout = (tuple(int(v) for v in part.split(",")) for part in args.dims.split(":"))
         assert len(din) == 3 and len(dout) == 3, "--dims de,dn,dg:oe,on,og"
-    workload = args.workload or ("hetero" if multi else "c2")
+    if multi:
+        if args.workload == "c2":
+            raise SystemExit("a single giant graph does not shard (SURVEY 8e: replicas only); N > 1 measures the graph-sharded hetero batch")
+        return bench_sharded(args, gn, torch, dist, dev, rank, world, din, dout)
+    workload = args.workload or "c2"
+    args.hetero_graphs, args.hetero_edges = args.hetero_graphs or 512, args.hetero_edges or 1_000_000
 
-    # ---- synthetic batch (rank-local shard) ----
-    shards = None
+    # ---- synthetic batch ----
     if workload == "c2":
-        colptrs, rowvals, nn = make_c2(seed=2 + rank, N=int(100_000 * args.c2_scale), E=int(1_000_000 * args.c2_scale))
-        shards = [np.asarray([r]) for r in range(world)]
-        wl_name = ("C2: one shared Erdos-Renyi graph, 100k nodes / 1M edges, batch_size=1 (BASELINE configs[1])" if world == 1 else
-                   f"batch of {world} C2-sized Erdos-Renyi graphs (100k nodes / 1M edges each) sharded by graph, one per GPU; gf' all-gathered")
+        colptrs, rowvals, nn = make_c2(seed=2, N=int(100_000 * args.c2_scale), E=int(1_000_000 * args.c2_scale))
+        wl_name = "C2: one shared Erdos-Renyi graph, 100k nodes / 1M edges, batch_size=1 (BASELINE configs[1])"
     else:
-        Gtot, Etot = args.hetero_graphs * world, args.hetero_edges * world
+        Gtot, Etot = args.hetero_graphs, args.hetero_edges
         seed = 3 if Gtot == 512 else (5 if Gtot == 4096 else 1000 + Gtot)  # C3 = seed 3, C5 = seed 5
-        n_all, e_all = hetero_spec(seed, Gtot, Etot)
-        shards = partition_graphs(e_all, world)  # the product's partitioner: equal graph counts, snake order by edge count
-        colptrs, rowvals, nn = make_hetero(seed, Gtot, Etot, only=shards[rank])
-        wl_name = (f"ONE heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {world} GPU(s): "
-                   f"{len(shards[rank])} graphs / {int(e_all[shards[rank]].sum())} edges on rank 0 (BASELINE configs[{2 if Gtot == 512 and world == 1 else 4}] law)")
+        colptrs, rowvals, nn = make_hetero(seed, Gtot, Etot)
+        wl_name = (f"ONE heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) on one GPU "
+                   f"(BASELINE configs[{2 if Gtot == 512 else 4}] law)")
     torch.cuda.synchronize(dev)
     # once per process, not per batch: library load, context, and the device builder's own first use (its kernels' code objects, its stream and
     # scratch buffer) on a graph large enough to take that path; reported as batch_ms.one_time_init
@@ -678,7 +1029,7 @@ def main():
                         "concatenates them: ~2.4 ms for 4096 graphs); from_csc_packed = the concatenated arrays as they are (int64; _int32: int32 indices).  "
                         "Validation, device-format arrays and both tile tables are built by kernels (csrc/gnx_build_csc.hip); the matrix-core path's tables by its workspace query"}
     E, N, G = g.n_edges, g.n_nodes, g.n_graphs
-    if workload == "hetero" and not multi and sum(int(n) * int(n) for n in nn) <= 2e8:  # the reference's own input form: dense 0/1 matrices
+    if workload == "hetero" and sum(int(n) * int(n) for n in nn) <= 2e8:  # the reference's own input form: dense 0/1 matrices
         adjs = []
         for cp, rv, n in zip(colptrs, rowvals, nn):
             a = np.zeros((n, n), dtype=np.uint8)
@@ -694,14 +1045,10 @@ def main():
         batch_ms["from_dense_uint8_first_call"] = round(td[0], 3)  # (includes the one-off allocation of the 64 MB pinned staging buffers)
         assert gd.n_edges == E and gd.n_nodes == N
         del gd, adjs
-    rng = np.random.default_rng(100)  # identical weights on every rank
-    blk = gn.GNBlock(din, dout, device=dev)
+    blk = bench_weights(gn, din, dout, dev)
     (de, dn, dg), (oe, on, og) = din, dout
-    blk.edgefn = gn.Dense.from_numpy(glorot(rng, oe, de + 2 * dn + dg), np.zeros(oe, np.float32), device=dev)
-    blk.nodefn = gn.Dense.from_numpy(glorot(rng, on, oe + dn + dg), np.zeros(on, np.float32), device=dev)
-    blk.graphfn = gn.Dense.from_numpy(glorot(rng, og, oe + on + dg), np.zeros(og, np.float32), device=dev)
     plan = gn.BlockPlan(blk, g, R=1, flags=args.flags)
-    if max(din + dout) >= 32 and not multi:
+    if max(din + dout) >= 32:
         # widths that take the matrix-core path: the first workspace query on a NEW handle also builds that path's tables (128-row tiles, the
         # destination of every edge, the aggregation chunks: kernels over the handle's device arrays) — what a loop that rebuilds its batch pays per batch
         tw = []
@@ -719,21 +1066,12 @@ def main():
     mk = lambda T, d: torch.rand((1, T, d), generator=tg, device=dev, dtype=torch.float32) if d > 0 else None
     sets = [dict(ef=mk(E, de), nf=mk(N, dn), gf=mk(G, dg), out=plan.outputs(), ws=plan.new_workspace()) for _ in range(nsets)]
     side = torch.cuda.Stream(device=dev)  # --overlap: the graph update (a few KB, pure latency) runs here
-    # N > 1: M steps of compute are captured into one hipGraph that writes the M gf' tables into a stacked buffer, and
-    # ONE all-gather moves the whole stack (fewer, larger collectives: the per-step message is only G*DG' floats = 10 KB,
-    # pure latency on xGMI); the gather runs on a side stream and overlaps the next M steps.
-    M = 1
-    if multi:
-        M = max(m for m in range(1, 257) if K % m == 0)
-    gather = GfGather(shards, rank, world, og, dev, stack=M) if multi else None
-    gf_stack = gather.send if multi else None  # [M][max_count][og]: the graph update writes straight into the send buffer
-    gf_result = torch.empty((M * gather.G, og), dtype=torch.float32, device=dev) if multi else None  # gathered table, original graph order
 
-    def step(i, s=None, slot=None, overlap=False):
+    def step(i, s=None, overlap=False):
         """One GNBlock forward.  `overlap`: two-phase form — edge+node update on the current stream, graph update on
         the side stream behind an event, so it leaves the critical path (joined before the timed region ends)."""
         b = sets[i % nsets]
-        go = b["out"][2] if slot is None else gf_stack[slot:slot + 1, :G]
+        go = b["out"][2]
         if not overlap or og == 0:
             plan(b["ef"], b["nf"], b["gf"], b["out"][0], b["out"][1], go, stream=s, ws=b["ws"])
             return
@@ -744,15 +1082,7 @@ def main():
             plan.graph_update(b["gf"], go, ws=b["ws"])
 
     def sync_all():
-        """barrier + torch.cuda.synchronize() (the contract's bracket).  N > 1: the gathered gf' table is waited for first, and the
-        barrier's collective is enqueued asynchronously behind it, so the bracket costs one small RCCL kernel and ONE host
-        synchronisation instead of a host round trip per item (at K = 20 steps the bracket is a tenth of the timed region)."""
-        if gather is not None and gather._ready is not None:
-            gather.finish(out=gf_result)
-        if multi:
-            work = dist.barrier(async_op=True)
-            torch.cuda.synchronize(dev)
-            work.wait()
+        """the contract's bracket at N = 1: torch.cuda.synchronize() (no other rank to wait for)"""
         torch.cuda.synchronize(dev)
 
     def timed(run):
@@ -760,12 +1090,7 @@ def main():
         t0 = time.perf_counter()
         run()
         sync_all()
-        dt = time.perf_counter() - t0
-        if multi:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        return time.perf_counter() - t0
 
     for i in range(max(W, 2)):  # warm-up (also loads the code objects: at least two eager steps before any capture, whatever W is)
         step(i)
@@ -774,187 +1099,88 @@ def main():
     extra = {}
     pipelined = None
     chained = None
-    if not multi:
-        def capture(nsteps, rotate):
+    def capture(nsteps, rotate):
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            for i in range(nsteps):
+                step(i if rotate else (i & 1), overlap=args.overlap)  # warm: 2 sets (120 MB, cache-resident)
+            torch.cuda.current_stream(dev).wait_stream(side)  # join: every graph update is inside the timed region
+        return cg
+    cold = capture(K, True)
+    cold.replay(); torch.cuda.synchronize(dev)
+    spin_up(torch, dev, cold.replay)
+    reps = sorted(timed(cold.replay) for _ in range(3))
+    dt = reps[1]
+    warm = capture(K, False)
+    warm.replay(); torch.cuda.synchronize(dev)
+    spin_up(torch, dev, warm.replay, 50.0)
+    extra["warm_ms_per_step"] = round(sorted(timed(warm.replay) for _ in range(3))[1] / K * 1e3, 6)
+    extra["launch"] = (f"hipGraph of {K} steps, {nsets} rotating buffer sets (cache-cold); " +
+                       ("single stream" if not args.overlap else "graph update of step i on a 2nd stream, overlapping step i+1 (joined inside the timed region)"))
+    # NOT the headline: the same K steps as TWO hipGraphs (even / odd steps) replayed on two streams.  The steps are independent batches
+    # (different buffer sets), so a serving loop would pipeline them: step i's graph-update launch (~4 us of latency on 83 KB) runs under
+    # step i+1's block kernel, and one kernel's ramp / drain under its neighbour.  Same results bit for bit (tools/experiments/
+    # two_stream_pipeline.py); `value` above stays the single-stream figure, where every step waits for the one before it.
+    if K >= 4 and not args.overlap:
+        Kp = max(K, 80)  # (two short graphs would measure their own replay overhead: at least 40 steps per stream)
+
+        def capture_half(par):
             cg = torch.cuda.CUDAGraph()
             with torch.cuda.graph(cg):
-                for i in range(nsteps):
-                    step(i if rotate else (i & 1), overlap=args.overlap)  # warm: 2 sets (120 MB, cache-resident)
-                torch.cuda.current_stream(dev).wait_stream(side)  # join: every graph update is inside the timed region
+                for i in range(par, Kp, 2):
+                    step(i)
             return cg
-        cold = capture(K, True)
-        cold.replay(); torch.cuda.synchronize(dev)
-        spin_up(torch, dev, cold.replay)
-        reps = sorted(timed(cold.replay) for _ in range(3))
-        dt = reps[1]
-        warm = capture(K, False)
-        warm.replay(); torch.cuda.synchronize(dev)
-        spin_up(torch, dev, warm.replay, 50.0)
-        extra["warm_ms_per_step"] = round(sorted(timed(warm.replay) for _ in range(3))[1] / K * 1e3, 6)
-        extra["launch"] = (f"hipGraph of {K} steps, {nsets} rotating buffer sets (cache-cold); " +
-                           ("single stream" if not args.overlap else "graph update of step i on a 2nd stream, overlapping step i+1 (joined inside the timed region)"))
-        # NOT the headline: the same K steps as TWO hipGraphs (even / odd steps) replayed on two streams.  The steps are independent batches
-        # (different buffer sets), so a serving loop would pipeline them: step i's graph-update launch (~4 us of latency on 83 KB) runs under
-        # step i+1's block kernel, and one kernel's ramp / drain under its neighbour.  Same results bit for bit (tools/experiments/
-        # two_stream_pipeline.py); `value` above stays the single-stream figure, where every step waits for the one before it.
-        if K >= 4 and not args.overlap:
-            Kp = max(K, 80)  # (two short graphs would measure their own replay overhead: at least 40 steps per stream)
+        halves = (capture_half(0), capture_half(1))
+        pstreams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
 
-            def capture_half(par):
-                cg = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(cg):
-                    for i in range(par, Kp, 2):
-                        step(i)
-                return cg
-            halves = (capture_half(0), capture_half(1))
-            pstreams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-
-            def run_two():
-                for st, cg in zip(pstreams, halves):
-                    with torch.cuda.stream(st):
-                        cg.replay()
-            run_two(); torch.cuda.synchronize(dev)
-            spin_up(torch, dev, run_two, 50.0)
-            dt2 = sorted(timed(run_two) for _ in range(3))[1]
-            pipelined = {"ms_per_step": round(dt2 / Kp * 1e3, 6), "value": round(E / (dt2 / Kp), 1), "unit": "edges/s", "steps": Kp,
-                         "what": f"{Kp} steps of the same kind as two hipGraphs (even / odd steps) on two streams: independent batches pipelined; results bit-identical; not the headline"}
-            del halves
-        # NOT the headline either: the chained form (gnx_block_forward_chained) — step i's launch carries step i - 1's graph update in
-        # workgroups at its front, so a loop over batches is ONE launch per step (opt-in: gf' of a step is complete one call later or after
-        # the flush).  Bit-identical outputs (tests/test_gpu_block.py::test_chained_forward...).
-        if not args.overlap and og > 0:
-            def capture_chained():
-                cgc = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(cgc):
-                    pend = None
-                    for i in range(K):
-                        b = sets[i % nsets]
-                        pend = plan.chained(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"], prev=pend)
-                    plan.flush(pend)
-                return cgc, pend
-            cgc, last = capture_chained()
-            cgc.replay(); torch.cuda.synchronize(dev)
-            spin_up(torch, dev, cgc.replay, 50.0)
-            dtc = sorted(timed(cgc.replay) for _ in range(3))[1]
-            chained = {"ms_per_step": round(dtc / K * 1e3, 6), "value": round(E / (dtc / K), 1), "unit": "edges/s", "steps": K,
-                       "what": f"gnx_block_forward_chained: {K} steps + one flush in one hipGraph — every step ONE launch (the previous step's graph update rides in "
-                               "workgroups at the front of the next block kernel); opt-in for loops over batches, results bit-identical; not the headline"}
-            del cgc
-    else:
-        assert gf_stack.shape[1] == G or world > 1, "one rank: every graph is local"
-        cgs = []
-        for base in range(0, min(K, nsets * M), M):  # enough distinct graphs to keep rotating over all buffer sets
-            cg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cg):
-                for m in range(M):
-                    step(base + m, slot=m, overlap=args.overlap)
-                torch.cuda.current_stream(dev).wait_stream(side)
-            cgs.append(cg)
-        copied = torch.cuda.Event()
-
-        def run():
-            for j in range(K // M):
-                torch.cuda.current_stream(dev).wait_event(copied) if j else None  # previous stack has left the send buffer
-                cgs[j % len(cgs)].replay()
-                gather.start_inplace()
-                copied.record(gather.comm_stream) if gather.comm_stream is not None else copied.record()
-        run(); sync_all()
-        t_w = time.perf_counter()
-        while (time.perf_counter() - t_w) * 1e3 < CLOCK_WARMUP_MS:  # (same untimed load as spin_up; every rank runs the same wall time, then the bracket's barrier)
-            run(); sync_all()
-        reps = sorted(timed(run) for _ in range(3))
-        dt = reps[1]
-        gf_all = gather.finish() if gather._ready is not None else gather.result()
-        assert tuple(gf_all.reshape(M, -1, og).shape) == (M, gather.G, og) and torch.equal(gf_all.reshape(-1, og), gf_result)
-        extra["launch"] = f"hipGraph of {M} steps per replay; one RCCL all-gather of the {M} stacked gf' tables per replay, overlapped on a side stream"
+        def run_two():
+            for st, cg in zip(pstreams, halves):
+                with torch.cuda.stream(st):
+                    cg.replay()
+        run_two(); torch.cuda.synchronize(dev)
+        spin_up(torch, dev, run_two, 50.0)
+        dt2 = sorted(timed(run_two) for _ in range(3))[1]
+        pipelined = {"ms_per_step": round(dt2 / Kp * 1e3, 6), "value": round(E / (dt2 / Kp), 1), "unit": "edges/s", "steps": Kp,
+                     "what": f"{Kp} steps of the same kind as two hipGraphs (even / odd steps) on two streams: independent batches pipelined; results bit-identical; not the headline"}
+        del halves
+    # NOT the headline either: the chained form (gnx_block_forward_chained) — step i's launch carries step i - 1's graph update in
+    # workgroups at its front, so a loop over batches is ONE launch per step (opt-in: gf' of a step is complete one call later or after
+    # the flush).  Bit-identical outputs (tests/test_gpu_block.py::test_chained_forward...).
+    if not args.overlap and og > 0:
+        def capture_chained():
+            cgc = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cgc):
+                pend = None
+                for i in range(K):
+                    b = sets[i % nsets]
+                    pend = plan.chained(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"], prev=pend)
+                plan.flush(pend)
+            return cgc, pend
+        cgc, last = capture_chained()
+        cgc.replay(); torch.cuda.synchronize(dev)
+        spin_up(torch, dev, cgc.replay, 50.0)
+        dtc = sorted(timed(cgc.replay) for _ in range(3))[1]
+        chained = {"ms_per_step": round(dtc / K * 1e3, 6), "value": round(E / (dtc / K), 1), "unit": "edges/s", "steps": K,
+                   "what": f"gnx_block_forward_chained: {K} steps + one flush in one hipGraph — every step ONE launch (the previous step's graph update rides in "
+                           "workgroups at the front of the next block kernel); opt-in for loops over batches, results bit-identical; not the headline"}
+        del cgc
     extra["timing"] = f"median of 3 runs of the {K}-step region ({[round(r / K * 1e6, 2) for r in reps]} us/step), after {CLOCK_WARMUP_MS:g} ms of the same load, untimed (clock settling: bench.py::spin_up)"
     ms_per_step = dt / K * 1e3
-    if multi:  # whole-job edges: every rank's shard
-        t = torch.tensor([float(E)], device=dev, dtype=torch.float64)
-        dist.all_reduce(t)
-        E_job = int(t.item())
-    else:
-        E_job = E
+    E_job = E
     value = E_job / (dt / K)
 
-    # ---- roofline: the same K steps again with per-kernel HIP events; the GPU is kept busy behind a spin kernel
-    # so that the events bracket kernel execution, not host launch gaps ----
+    # ---- roofline: the same K steps again with per-kernel dispatch timestamps (block_roofline) ----
     roof = None
     if rank == 0:
-        def eager_pass():
-            for i in range(K):
-                b = sets[i % nsets]
-                plan(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"])
-        spin_up(torch, dev, eager_pass)  # the pass below runs at settled clocks, like the timed region
-        gn.profile_reset(); gn.profile_enable(True)
-        for i in range(K):
-            b = sets[i % nsets]
-            plan(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"])
-        gn.profile_calibrate(K, torch.cuda.current_stream(dev).cuda_stream)
-        torch.cuda.synchronize(dev)
-        gn.profile_enable(False)
-        prof = gn.profile_read(); gn.profile_reset()
-        null_us = (prof.get("__empty_bracket__") or {"total_ms": 0.0, "launches": 1})
-        null_us = null_us["total_ms"] / max(null_us["launches"], 1) * 1e3
-        kern = calibrated_kernel_us(prof)
-        dom = max(kern, key=kern.get)
-        dur_s = kern[dom] * 1e-6
-        step_s = ms_per_step * 1e-3
-        abytes, aflops = algorithmic_bytes(E, N, G, din, dout), algorithmic_flops(E, N, G, din, dout)
-        hbm_t, mfma_t = abytes / (HBM_PEAK_GBS * 1e9), aflops / (MFMA_F32_PEAK_TFS * 1e12)
-        if max(din + dout) > 32:  # matrix-core path: the binding roof is decided on the flops the kernels EXECUTE at the rate of the instruction that carries them
-            ex_ = executed_flops(E, N, G, din, dout)
-            x6_ = 2 * E * din[0] * dout[0] if (din[0] == 128 and dout[0] == 128 and din[1] >= 16 and E >= 2 * N and not os.environ.get("GNX_EDGE_FP32")) else 0
-            mfma_t = x6_ / (MFMA_BF16_PEAK_TFS / 6 * 1e12) + (ex_ - x6_) / (MFMA_F32_PEAK_TFS * 1e12)
         dims_key = args.dims.replace(":", "_").replace(",", "-") + ("" if workload == "c2" else f"_hetero{G}")
         if workload != "c2" and args.hetero_edges != 1_000_000:
             dims_key += f"_{args.hetero_edges}"  # the committed PMC profiles are of the 1M-edge batches: no traffic figure for another size
-        traffic, tsrc = load_traffic(dims_key, dom, kernel_source_sha(din, dout))
-        if hbm_t >= mfma_t:
-            a = abytes / dur_s / 1e9
-            roof = dict(bound="hbm", achieved=round(a, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(a / HBM_PEAK_GBS, 4),
-                        frac_whole_step=round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=tsrc,
-                        counts="algorithmic bytes of the whole block / duration of the dominant kernel (frac) or of the whole step (frac_whole_step)")
-            if max(din + dout) > 32:  # a matrix-core block whose matrix time (per carrying instruction) is below its memory time: both fractions on the WHOLE step
-                roof.update(frac=roof["frac_whole_step"], algorithmic_bytes=abytes, executed_flops=ex_, flops_on_bf16_six_terms=x6_,
-                            frac_of_fp32_mfma_roof=round(ex_ / step_s / 1e12 / MFMA_F32_PEAK_TFS, 4), matrix_roof_frac=round(mfma_t / step_s, 4),
-                            counts="algorithmic bytes of the whole block / whole-step time (several launches); matrix_roof_frac: the executed flops at the rate of the "
-                                   "instruction that carries them (fp32 MFMA %.1f TFLOP/s; six bf16 terms per fp32 product: %.0f / 6) / whole-step time" % (MFMA_F32_PEAK_TFS, MFMA_BF16_PEAK_TFS))
-        else:
-            # MFMA-bound: priced on the flops the kernels EXECUTE (never more than the peak); the algorithmic rate of the
-            # reference formulation (every edge multiplies its full [ef; nf_src; nf_dst; gf] row) is reported beside it
-            ex = executed_flops(E, N, G, din, dout)
-            a = ex / step_s / 1e12
-            # the projected edge update at 128 -> 128 runs as six bf16 matrix-core terms per fp32 product (k_edge_x6) unless GNX_EDGE_FP32=1: its
-            # flops are priced at that instruction's rate, the rest at the fp32 MFMA's
-            x6_flops = 2 * E * din[0] * dout[0] if (din[0] == 128 and dout[0] == 128 and din[1] >= 16 and E >= 2 * N and not os.environ.get("GNX_EDGE_FP32")) else 0
-            t_roof = x6_flops / (MFMA_BF16_PEAK_TFS / 6 * 1e12) + (ex - x6_flops) / (MFMA_F32_PEAK_TFS * 1e12)
-            roof = dict(bound="mfma", achieved=round(a, 3), peak=round(ex / t_roof / 1e12, 1), unit="TFLOP/s", frac=round(t_roof / step_s, 4),
-                        frac_whole_step=round(t_roof / step_s, 4), frac_of_fp32_mfma_roof=round(a / MFMA_F32_PEAK_TFS, 4), flops_on_bf16_six_terms=x6_flops,
-                        traffic=traffic, traffic_source=tsrc,
-                        counts="EXECUTED flops of the whole block / whole-step time (the block is several GEMM launches); peak = the same flops at the rate of the instruction "
-                               "that carries them (fp32 MFMA %.1f TFLOP/s; six bf16 terms per fp32 product: %.0f / 6)" % (MFMA_F32_PEAK_TFS, MFMA_BF16_PEAK_TFS),
-                        executed_flops=ex, algorithmic_tflops_whole_step=round(aflops / step_s / 1e12, 2),
-                        hbm_frac_whole_step=round(abytes / step_s / 1e9 / HBM_PEAK_GBS, 4))
-        if traffic is not None and workload == "c2" and args.dims == "readme" and args.c2_scale == 1.0:
-            # `traffic` counts what leaves the L2s (fabric bytes: Infinity-Cache hits included); the split into HBM bytes and cache hits
-            # comes from a residency A/B (no counter separates them): profiles/traffic_breakdown_readme.json
-            bpath = os.path.join(ROOT, "profiles", "traffic_breakdown_readme.json")
-            if os.path.exists(bpath):
-                with open(bpath) as f:
-                    bd = json.load(f)
-                if dom in bd:
-                    roof["traffic_breakdown"] = {"fabric": traffic, "hbm_estimate": bd[dom]["hbm_bytes_per_launch_estimate"],
-                                                 "infinity_cache_hits_estimate": bd[dom]["infinity_cache_hit_bytes_estimate"],
-                                                 "source": "profiles/traffic_breakdown_readme.json"}
-        assert roof["frac"] <= 1.0 and roof["frac_whole_step"] <= 1.0, "a roofline fraction above 1 is an accounting error"
-        roof.update(kernel=dom, kernel_us=round(kern[dom], 3), kernel_us_source="dispatch timestamps of every launch of the per-kernel pass (hipExtLaunchKernel start / stop events), averaged, minus the constant (empty kernel timed the same way - rocprofv3's figure for it: profiles/calibration.json)",
-                    null_kernel_us=round(null_us, 3), algorithmic_bytes=abytes, algorithmic_flops=aflops,
-                    bytes_per_edge=round(abytes / E, 2), all_kernels_us={k: round(v, 3) for k, v in kern.items()})
+        roof = block_roofline(gn, torch, dev, plan, sets, nsets, K, E, N, G, din, dout, ms_per_step, dims_key,
+                              headline_traffic_breakdown=(workload == "c2" and args.dims == "readme" and args.c2_scale == 1.0))
 
     # ---- CPU baseline: the oracle's C restatement ("port") on the host cores, rank 0, N = 1 only ----
     cpu = None
-    if rank == 0 and not multi and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         from oracle import c_port
         p = dict(in_dims=din, out_dims=dout, We=blk.edgefn.weight.cpu().numpy(), be=np.zeros(oe, np.float32),
                  Wn=blk.nodefn.weight.cpu().numpy(), bn=np.zeros(on, np.float32), Wg=blk.graphfn.weight.cpu().numpy(),
@@ -999,7 +1225,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl_name, "dims": f"{din}=>{dout}", "edges_per_gpu": E, "nodes_per_gpu": N,
-                       "graphs_per_gpu": G, "edges_whole_job": E_job, "parallelism": f"graph-sharded x{world}" if world > 1 else "single GPU", **extra},
+                       "graphs_per_gpu": G, "edges_whole_job": E_job, "parallelism": "single GPU", **extra},
             "roofline": roof, "cpu_baseline": cpu, "batch_ms": batch_ms,
         }
         if c_abi is not None:
@@ -1022,13 +1248,8 @@ def main():
     # The JSON line must be the LAST thing on stdout: with NCCL_DEBUG=VERSION (set on the GPU boxes) RCCL writes its version
     # banner through C stdio, which on a pipe is only flushed at exit — after Python's print.  Every rank tears the process
     # group down and flushes C stdio first; rank 0 prints once the others are done.
-    if multi:
-        dist.barrier()
-        dist.destroy_process_group()
     _flush_c_stdio()
     if rank == 0:
-        if multi:
-            time.sleep(0.5)  # the other ranks' (already flushed) output reaches the launcher's pipe first
         print(json.dumps(line), flush=True)
 
 

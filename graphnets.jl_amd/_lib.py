@@ -17,7 +17,7 @@ ERR_INVALID_ARG, ERR_NO_GRAPHS, ERR_ADJ_SHAPE, ERR_ADJ_VALUE, ERR_ALL_NOTHING = 
 ERR_DIMS, ERR_CSC, ERR_WORKSPACE, ERR_TOO_LARGE, ERR_COUNT_MISMATCH = -6, -7, -8, -9, -10
 ACT = dict(identity=0, relu=1, tanh=2, sigmoid=3, gelu=4)
 ELEM_U8, ELEM_I32, ELEM_I64, ELEM_F32, ELEM_F64 = 0, 1, 2, 3, 4
-FLAG_FORCE_GENERIC, FLAG_NO_MFMA, FLAG_DEFER_GRAPH_UPDATE, FLAG_NO_GRAPH = 0x1, 0x2, 0x4, 0x8
+FLAG_FORCE_GENERIC, FLAG_NO_MFMA, FLAG_DEFER_GRAPH_UPDATE, FLAG_NO_GRAPH, FLAG_DIST_NO_GATHER = 0x1, 0x2, 0x4, 0x8, 0x10
 
 _fp = C.c_void_p  # device float*
 

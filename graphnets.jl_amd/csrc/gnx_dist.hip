@@ -336,13 +336,21 @@ int32_t gnx_dist_block_forward_steps(gnx_dist* d, int32_t n_steps, const gnx_gra
     return GNX_OK;
   };
   const bool eager = (flags & GNX_FLAG_NO_GRAPH) != 0;
-  const uint32_t lflags = flags & ~GNX_FLAG_NO_GRAPH;
-  (void)lflags;
+  const bool gather = (flags & GNX_FLAG_DIST_NO_GATHER) == 0;
+  flags &= ~(uint32_t)GNX_FLAG_DIST_NO_GATHER;  // (not a flag of the per-rank forward; the same replay serves both forms)
   gnx_dist::Replay* rp = nullptr;
   if (!eager) {
+    // The captured sequence bakes in the handle's device tables and sizes and the parameters' weight pointers BY VALUE: the key holds what they
+    // are, not where the descriptors live — a handle's process-wide serial (an address can be reused by a later handle) and the CONTENTS of
+    // *p[r] (a caller may rewrite a descriptor in place, or build a fresh one with the same contents for every call).
     std::vector<uintptr_t> key;
     key.push_back((uintptr_t)n_steps); key.push_back((uintptr_t)flags);
-    for (int r = 0; r < n; ++r) { key.push_back((uintptr_t)h[r]); key.push_back((uintptr_t)p[r]); key.push_back((uintptr_t)workspace_bytes[r]); }
+    for (int r = 0; r < n; ++r) {
+      key.push_back((uintptr_t)h[r]->serial); key.push_back((uintptr_t)h[r]->N); key.push_back((uintptr_t)h[r]->E); key.push_back((uintptr_t)workspace_bytes[r]);
+      const gnx_block_params& q = *p[r];
+      for (int32_t w : {q.de, q.dn, q.dg, q.oe, q.on, q.og, q.edgefn.act, q.nodefn.act, q.graphfn.act}) key.push_back((uintptr_t)(uint32_t)w);
+      for (const gnx_dense* fn : {&q.edgefn, &q.nodefn, &q.graphfn}) { key.push_back((uintptr_t)fn->weight); key.push_back((uintptr_t)fn->bias); }
+    }
     for (size_t i = 0; i < (size_t)n_steps * n; ++i) {
       key.push_back((uintptr_t)(ef ? ef[i] : nullptr)); key.push_back((uintptr_t)(nf ? nf[i] : nullptr)); key.push_back((uintptr_t)(gf ? gf[i] : nullptr));
       key.push_back((uintptr_t)(ef_out ? ef_out[i] : nullptr)); key.push_back((uintptr_t)(nf_out ? nf_out[i] : nullptr)); key.push_back((uintptr_t)workspace[i]);
@@ -387,6 +395,7 @@ int32_t gnx_dist_block_forward_steps(gnx_dist* d, int32_t n_steps, const gnx_gra
       if ((rc = run_rank(r, streams ? (hipStream_t)streams[r] : nullptr))) return rc;
     }
   }
+  if (!gather) return GNX_OK;  // every rank keeps its own rows in its send buffer; gf_all is not written
   // hand over to the communication streams, ONE grouped all-gather of the n_steps stacked tables, permutation into original graph order
   for (int r = 0; r < n; ++r) {
     GNX_HIP(hipSetDevice(d->dev[(size_t)r]));

@@ -32,12 +32,19 @@ struct uninit_alloc : std::allocator<T> {
 };
 using vec_i64 = std::vector<int64_t, uninit_alloc<int64_t>>;
 using vec_i32 = std::vector<int32_t, uninit_alloc<int32_t>>;
+// process-wide serial number of a handle: an address can be reused by a later handle (malloc recycles), a serial cannot — caches that bake a
+// handle's device tables into a captured launch sequence key on it (gnx_dist.hip)
+inline uint64_t next_handle_serial() {
+  static std::atomic<uint64_t> counter{0};
+  return ++counter;
+}
 }  // namespace gnx
 
 struct gnx_graphs {
   int64_t G = 0, N = 0, E = 0, PN = 0;
   int64_t max_in_degree = 0;
   int device = 0;
+  const uint64_t serial = gnx::next_handle_serial();
   // host copies (int64, 0-based, global)
   std::vector<int64_t> h_node_off, h_edge_off;
   gnx::vec_i64 h_colptr, h_rowval;

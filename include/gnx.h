@@ -436,7 +436,11 @@ GNX_API int32_t gnx_dist_block_forward(gnx_dist* d, const gnx_graphs* const* h, 
  * h / p / workspace_bytes / gf_all / streams have one entry per rank.  The launch sequence of a rank is captured into ONE hipGraph per
  * device the first time a set of arguments is seen (that call runs eagerly and captures; up to 32 argument sets are kept per communicator)
  * and replayed with one hipGraphLaunch per device afterwards: the host issues n_ranks graph launches + one grouped collective + n_ranks
- * permute kernels per call, whatever n_steps is.  GNX_FLAG_NO_GRAPH: always eager.  One call at a time per communicator. */
+ * permute kernels per call, whatever n_steps is.  GNX_FLAG_NO_GRAPH: always eager.  One call at a time per communicator.
+ * An argument set is identified by what the captured launches contain: every pointer, the handles' identities (a serial number, not
+ * the address) and the CONTENTS of *p[r] — a descriptor rewritten in place, or a handle destroyed and recreated at the same address, is
+ * a new set.  GNX_FLAG_DIST_NO_GATHER: the forwards only (no collective, gf_all untouched) — what the all-gather costs is the difference. */
+#define GNX_FLAG_DIST_NO_GATHER 0x10u
 GNX_API int32_t gnx_dist_block_forward_steps(gnx_dist* d, int32_t n_steps, const gnx_graphs* const* h, const gnx_block_params* const* p,
                                      const float* const* ef, const float* const* nf, const float* const* gf, float* const* ef_out,
                                      float* const* nf_out, float* const* gf_all, void* const* workspace, const size_t* workspace_bytes,

@@ -139,6 +139,61 @@ def test_bench_hetero_generators_and_self_launch(monkeypatch):
     assert "127.0.0.1" in cmd
 
 
+def _strong_worker(rank, world, port, out):
+    """What a rank of `bench.py --gpus N` does before it touches a GPU: pick the sharded workload, partition it, generate ITS graphs."""
+    import argparse
+    import zlib
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    import graphnets_jl_amd  # noqa: F401
+    from graphnets_jl_amd.dist import partition_graphs
+    Gtot, Etot, seed = bench.sharded_workload(argparse.Namespace(scaling="strong", hetero_graphs=None, hetero_edges=None), world)
+    _, e_all = bench.hetero_spec(seed, Gtot, Etot)
+    shards = partition_graphs(e_all, world)
+    cps, rvs, nn = bench.make_hetero(seed, Gtot, Etot, only=shards[rank])
+    # per graph of this rank: (original id, nodes, edges, crc of its CSC arrays)
+    rows = np.array([[int(g), n, len(rv), zlib.crc32(cp.tobytes() + rv.tobytes())] for g, cp, rv, n in zip(shards[rank], cps, rvs, nn)], dtype=np.int64)
+    pad = np.zeros((Gtot, 4), dtype=np.int64)
+    pad[:len(rows)] = rows
+    parts = [torch.zeros((Gtot, 4), dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(parts, torch.from_numpy(pad))
+    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([len(rows)]))
+    if rank == 0:
+        np.save(out, np.concatenate([p.numpy()[:int(c)] for p, c in zip(parts, counts)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bench_strong_scaling_shards_one_fixed_batch(tmp_path):
+    """`bench.py --gpus N` (default --scaling strong) measures BASELINE configs[4]: the SAME 4096 graphs / 1M edges (seed 5) at every N.  Two gloo ranks
+    pick, partition and generate the workload exactly as bench.py's ranks do; together they hold every graph of the one-rank batch once, bit for bit."""
+    import argparse
+    import zlib
+    sys.path.insert(0, ROOT)
+    import bench
+    out = str(tmp_path / "strong.npy")
+    mp.spawn(_strong_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    rows = np.load(out)
+    assert rows.shape == (4096, 4) and sorted(rows[:, 0].tolist()) == list(range(4096)) and int(rows[:, 2].sum()) == 1_000_000
+    # world = 1 picks the same batch: configs[4] (4096 graphs, 1M edges, seed 5), and so does world = 8
+    for world in (1, 8):
+        assert bench.sharded_workload(argparse.Namespace(scaling="strong", hetero_graphs=None, hetero_edges=None), world) == (4096, 1_000_000, 5)
+    cps, rvs, nn = bench.make_hetero(5, 4096, 1_000_000)
+    whole = {g: (n, len(rv), zlib.crc32(cp.tobytes() + rv.tobytes())) for g, (cp, rv, n) in enumerate(zip(cps, rvs, nn))}
+    for g, n, e, crc in rows.tolist():
+        assert whole[g] == (n, e, crc)
+    # the two shards are balanced: 2048 graphs each, edge counts within 1 %
+    half = rows[:2048, 2].sum(), rows[2048:, 2].sum()
+    assert abs(int(half[0]) - int(half[1])) < 10_000
+    # weak scaling (opt-in) keeps the per-GPU shard fixed instead
+    assert bench.sharded_workload(argparse.Namespace(scaling="weak", hetero_graphs=None, hetero_edges=None), 8) == (4096, 8_000_000, 5)
+    assert bench.sharded_workload(argparse.Namespace(scaling="weak", hetero_graphs=None, hetero_edges=None), 2)[:2] == (1024, 2_000_000)
+
+
 def test_c_partition_equals_the_specified_rule():
     """gnx_dist_partition against an independent restatement of its rule: sort by edge count descending (stable), deal in snake
     order, every rank keeps ascending original ids; also odd sizes and more ranks than graphs."""

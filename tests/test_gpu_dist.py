@@ -120,16 +120,51 @@ def test_gfgather_through_rccl_world_1(gn):
         dist.destroy_process_group()
 
 
+def _check_strong_line(line, backend):
+    """the N > 1 line of bench.py: configs[4]'s FIXED batch, strong scaling, the same batch on one GPU beside it, with / without the all-gather"""
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["value"] > 1e9
+    wl = line["config"]["workload"]
+    assert "configs[4]" in wl and "4096 random graphs" in wl and "1M edges" in wl and "seed 5" in wl
+    assert line["config"]["edges_whole_job"] == 1_000_000 and line["config"]["graphs_whole_job"] == 4096
+    assert line["config"]["per_rank_edges_nodes_graphs"][0][0] == 1_000_000 and line["config"]["per_rank_edges_nodes_graphs"][0][2] == 4096
+    single = line["single_gpu_same_workload"]
+    assert single["graphs"] == 4096 and single["edges"] == 1_000_000 and single["value"] > 1e9
+    w, wo = line["with_allgather"], line["without_allgather"]
+    assert w["ms_per_step"] == line["ms_per_step"] and 0 < wo["ms_per_step"] <= w["ms_per_step"] * 1.15  # (the gather never makes the region faster, up to noise)
+    assert line["roofline"]["frac"] <= 1.0
+    c5w = line["secondary"]["c5w"]
+    assert c5w["edges_whole_job"] == 8_000_000 and c5w["graphs_whole_job"] == 4096 and c5w["single_gpu_same_workload"]["edges"] == 8_000_000
+    assert c5w["value"] > line["value"]  # eight times the edges per launch: the larger batch runs closer to the roof
+
+
 @pytest.mark.timeout(900)
 def test_bench_force_dist_runs_the_multi_gpu_code_path():
-    """`bench.py --force-dist`: the N > 1 branch (hetero shard, hipGraphs of stacked steps, RCCL all-gather on a side stream)
-    with one rank, as its own process; the JSON line parses and names configs[4]'s workload."""
+    """`bench.py --force-dist`: the N > 1 branch (configs[4]'s fixed 4096-graph batch sharded by the product's partitioner, hipGraphs of stacked
+    steps, RCCL all-gather on a side stream) with one rank, as its own process; the JSON line parses, names configs[4]'s workload, carries the same
+    batch on one GPU, the region with and without the collective, and C5w beside it."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "16", "--warmup", "2", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=850)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 1 and line["value"] > 1e9 and "sharded by graph" in line["config"]["workload"]
-    assert line["config"]["graphs_per_gpu"] == 512 and line["roofline"]["frac"] <= 1.0
+    _check_strong_line(line, "torch")
+    assert line["config"]["graphs_per_gpu"] == 4096 and line["roofline"]["kernel_us"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_dist_backend_gnx_measures_the_same_fixed_batch():
+    """`bench.py --dist-backend gnx` (one process driving the devices through gnx_dist_block_forward_steps): the same fixed batch, the same fields;
+    its without_allgather leg is GNX_FLAG_DIST_NO_GATHER."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dist-backend", "gnx", "--steps", "16", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=850)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    _check_strong_line(line, "gnx")
+    # weak scaling stays available: N x 512 graphs
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--scaling", "weak", "--steps", "16", "--warmup", "2", "--no-single-gpu-leg"],
+                         capture_output=True, text=True, timeout=850)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["scaling"] == "weak" and line["config"]["graphs_per_gpu"] == 512 and line["single_gpu_same_workload"] is None
 
 
 def test_gnx_dist_c_entry_points_world_1(gn):
