@@ -103,11 +103,14 @@ __device__ __forceinline__ int tile_end(const int* __restrict__ colptr, int j, i
 }
 
 // next[kind][j] for j < N, next[kind][N] = N; flag[kind][j] = 1 for the first node of every graph (the roots of the orbits)
+// (A colptr that k_csc_columns flagged is not monotone: the greedy tiling of such an array has no bound, so nothing of the tiling runs on it —
+// every thread of k_tile_next then writes the trivial orbit "no tile" and k_tile_write returns at once: same stream, so the flag is final.)
 __global__ __launch_bounds__(256) void k_tile_next(const int* __restrict__ colptr, const int* __restrict__ node_graph, CscBuildArgs a, int* __restrict__ next,
-                                                   int* __restrict__ flag) {
+                                                   int* __restrict__ flag, const CscBuildStats* __restrict__ st) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int S = a.N + 1;
   if (j > a.N) return;
+  if (st->first_bad != INT_MAX) { next[j] = a.N; next[S + j] = a.N; flag[j] = 0; flag[S + j] = 0; return; }
   if (j == a.N) { next[j] = a.N; next[S + j] = a.N; flag[j] = 0; flag[S + j] = 0; return; }
   const int g = node_graph[j];
   const int nend = a.node_off[g + 1];
@@ -191,10 +194,10 @@ __global__ __launch_bounds__(256) void k_scan2_sums(int* __restrict__ block_sums
 __global__ __launch_bounds__(256) void k_tile_write(const int* __restrict__ colptr, const int* __restrict__ node_graph, CscBuildArgs a, const int* __restrict__ next,
                                                     const int* __restrict__ flag, const int* __restrict__ pos, const int* __restrict__ block_prefix, int nb,
                                                     Tile* __restrict__ tiles, int* __restrict__ tile_off, Tile* __restrict__ wtiles, int* __restrict__ wtile_off,
-                                                    CscBuildStats* st) {
+                                                    int tiles_bound, int wtiles_bound, CscBuildStats* st) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int S = a.N + 1;
-  if (j > a.N) return;
+  if (j > a.N || st->first_bad != INT_MAX) return;  // (malformed input: the build is abandoned, no table is written)
   auto at = [&](int kind, int x) { return pos[(size_t)kind * S + x] + block_prefix[(size_t)kind * nb + x / SCAN2_B]; };
   if (j == a.N) {
     const int nt = at(0, j), nw = at(1, j);
@@ -214,22 +217,27 @@ __global__ __launch_bounds__(256) void k_tile_write(const int* __restrict__ colp
     const int n1 = next[j];
     Tile t;
     t.n0 = j; t.n1 = n1; t.e0 = colptr[j]; t.e1 = colptr[n1]; t.g = g; t.win0 = n0; t.win1 = nend; t.flags = 0;
-    tiles[at(0, j)] = t;
+    const int slot = at(0, j);
+    if (slot < tiles_bound) tiles[slot] = t;  // (the bound holds for every monotone colptr; the count is checked on the host)
   }
   if (flag[S + j]) {
     const int n1 = next[S + j];
     Tile t;
     t.n0 = j; t.n1 = n1; t.e0 = colptr[j]; t.e1 = colptr[n1]; t.g = g; t.win0 = n0; t.win1 = nend; t.flags = wcount;
-    wtiles[at(1, j)] = t;
+    const int slot = at(1, j);
+    if (slot < wtiles_bound) wtiles[slot] = t;
   }
 }
 
 // ---- process-wide caches: the build stream and scratch buffer of a device, and released handle arenas (hipMalloc / hipFree cost ~0.1-2 ms
 // each and synchronise the device; a training loop builds a batch of the same size every iteration) ----
 namespace {
-struct DevScratch { int dev; hipStream_t stream; void* buf; size_t cap; };
+// One build at a time per device: the scratch buffer and the build stream are shared by every handle built on that device, so a build holds
+// `mu` from dev_scratch() until its last synchronisation (two host threads batching on one device serialise here; their kernels would
+// serialise on the one stream anyway).  The entries are heap nodes: a pointer to one stays valid while another device's entry is added.
+struct DevScratch { int dev; hipStream_t stream; void* buf; size_t cap; std::mutex mu; };
 std::mutex g_cache_mu;
-std::vector<DevScratch> g_scratch;
+std::vector<std::unique_ptr<DevScratch>> g_scratch;
 struct Arena { int dev; void* ptr; size_t bytes; };
 std::vector<Arena> g_arenas;
 size_t g_arena_bytes = 0;
@@ -269,16 +277,18 @@ void arena_give(int dev, void* ptr, size_t bytes) {
   }
 }
 
-static int32_t dev_scratch(int dev, size_t bytes, hipStream_t* stream, void** buf) {
-  std::lock_guard<std::mutex> lk(g_cache_mu);
+static int32_t dev_scratch(int dev, size_t bytes, hipStream_t* stream, void** buf, std::unique_lock<std::mutex>* hold) {
   DevScratch* s = nullptr;
-  for (auto& x : g_scratch) if (x.dev == dev) s = &x;
-  if (!s) {
-    DevScratch n{dev, nullptr, nullptr, 0};
-    GNX_HIP(hipStreamCreateWithFlags(&n.stream, hipStreamNonBlocking));
-    g_scratch.push_back(n);
-    s = &g_scratch.back();
+  {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (auto& x : g_scratch) if (x->dev == dev) s = x.get();
+    if (!s) {
+      g_scratch.emplace_back(new DevScratch{dev, nullptr, nullptr, 0, {}});
+      s = g_scratch.back().get();
+    }
   }
+  *hold = std::unique_lock<std::mutex>(s->mu);  // (released by the caller's return: every exit path of a build)
+  if (!s->stream) GNX_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   if (s->cap < bytes) {
     if (s->buf) { GNX_HIP(hipStreamSynchronize(s->stream)); GNX_HIP(hipFree(s->buf)); s->buf = nullptr; s->cap = 0; }
     const size_t cap = bytes + bytes / 4;
@@ -309,7 +319,8 @@ int32_t build_handle_from_csc_on_device(gnx_graphs* h, const void* colptr_cat, c
   if (off > ((size_t)1 << 30)) return 1;  // (one graph of tens of millions of nodes: the host builder)
   hipStream_t s = nullptr;
   void* scratch = nullptr;
-  int32_t rc = dev_scratch(h->device, off, &s, &scratch);
+  std::unique_lock<std::mutex> build_lock;
+  int32_t rc = dev_scratch(h->device, off, &s, &scratch, &build_lock);
   if (rc) return rc;
   char* sb = static_cast<char*>(scratch);
   // the handle's arena: colptr, rowval, node / edge / tile offsets, tiles, wave tiles, packs (capacity from the bounds)
@@ -356,13 +367,14 @@ int32_t build_handle_from_csc_on_device(gnx_graphs* h, const void* colptr_cat, c
   else
     GNX_LAUNCH((k_csc_columns<int>), dim3(gN), dim3(256), 0, s, reinterpret_cast<const int*>(sb + o_cp), reinterpret_cast<const int*>(sb + o_rv), a, h->d_colptr, h->d_rowval,
                node_graph, st);
-  GNX_LAUNCH(k_tile_next, dim3(gS), dim3(256), 0, s, h->d_colptr, node_graph, a, jump, flag);
+  GNX_LAUNCH(k_tile_next, dim3(gS), dim3(256), 0, s, h->d_colptr, node_graph, a, jump, flag, st);
   for (int l = 1; l < levels; ++l)
     GNX_LAUNCH(k_tile_jump, dim3(gS, 2), dim3(256), 0, s, jump + (size_t)(l - 1) * 2 * S, jump + (size_t)l * 2 * S, (int)S);
   for (int l = levels - 1; l >= 0; --l) GNX_LAUNCH(k_tile_flag, dim3(gS, 2), dim3(256), 0, s, jump + (size_t)l * 2 * S, flag, (int)S);
   GNX_LAUNCH(k_scan2_blocks, dim3((unsigned)nb, 2), dim3(256), 0, s, flag, (int)S, pos, bsum, nb);
   GNX_LAUNCH(k_scan2_sums, dim3(2), dim3(256), 0, s, bsum, nb);
-  GNX_LAUNCH(k_tile_write, dim3(gS), dim3(256), 0, s, h->d_colptr, node_graph, a, jump, flag, pos, bsum, nb, h->d_tiles, h->d_tile_off, h->d_wtiles, h->d_wtile_off, st);
+  GNX_LAUNCH(k_tile_write, dim3(gS), dim3(256), 0, s, h->d_colptr, node_graph, a, jump, flag, pos, bsum, nb, h->d_tiles, h->d_tile_off, h->d_wtiles, h->d_wtile_off,
+             (int)std::min<int64_t>(tiles_bound, INT_MAX), (int)std::min<int64_t>(wtiles_bound, INT_MAX), st);
   GNX_HIP(hipGetLastError());
   CscBuildStats out{};
   GNX_HIP(hipMemcpyAsync(&out, st, sizeof out, hipMemcpyDeviceToHost, s));
@@ -488,7 +500,8 @@ int32_t build_wide_tables_on_device(const gnx_graphs* h) {
   (void)persistent;
   hipStream_t s = nullptr;
   void* scratch = nullptr;
-  int32_t rc = dev_scratch(h->device, 256, &s, &scratch);  // (the device's build stream)
+  std::unique_lock<std::mutex> build_lock;
+  int32_t rc = dev_scratch(h->device, 256, &s, &scratch, &build_lock);  // (the device's build stream)
   if (rc) return rc;
   char* base = nullptr;
   GNX_HIP(hipMalloc((void**)&base, off));

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GNX_VERSION 100 /* 0.1.0 */
+#define GNX_VERSION 110 /* 0.1.1: gnx_profile_entry is 72 bytes (`kernels`); per-call arithmetic flags; prepared parameters; GNX_FLAG_DIST_NO_GATHER */
 
 #if defined(__GNUC__)
 #define GNX_API __attribute__((visibility("default")))

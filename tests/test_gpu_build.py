@@ -80,6 +80,16 @@ def _tables(spec, index_dtype="int64"):
     return out
 
 
+def _table(gn, g, which):
+    """one device table of a handle (gnx_graphs_get_table) as int32 words"""
+    lib = gn._lib.load()
+    n = C.c_int64(0)
+    gn._lib.check(lib.gnx_graphs_get_table(g._h, which, None, 0, C.byref(n)))
+    buf = np.zeros(max(n.value // 4, 1), dtype=np.int32)
+    gn._lib.check(lib.gnx_graphs_get_table(g._h, which, buf.ctypes.data, buf.nbytes, C.byref(n)))
+    return buf[: n.value // 4].copy()
+
+
 def _child(name, path):
     np.savez(path, **_tables(CASES[name]))
 
@@ -139,6 +149,69 @@ def test_device_builder_rejects_what_the_host_builder_rejects():
         build(cpc, rvc[:-1])
     with pytest.raises(ValueError):
         build(cpc[:-1], rvc)
+
+
+def test_device_builder_abandons_the_tiling_of_an_oscillating_colptr():
+    """a colptr that swings between 0 and E passes the O(G) host pre-check (first entry = base, last = E) and would make the greedy
+    tiling emit ~3 tiles per 130 nodes — several times the bound the tile tables are sized with.  The tiling kernels must not run on it: the call is
+    rejected as malformed CSC, nothing is written past the tables (the next, well-formed batch of the same size — which takes the recycled arena —
+    builds the same tables as before), and the device stays usable."""
+    import graphnets_jl_amd as gn
+    n, eg = 100_000, 1000
+    cp = np.zeros(n + 1, dtype=np.int64)
+    pat = np.array([0, 0] + [eg] * 128, dtype=np.int64)
+    cp[1:] = np.tile(pat, n // len(pat) + 1)[:n]
+    cp[0], cp[n] = 0, eg
+    rv = np.arange(eg, dtype=np.int64)  # (every column that announces edges announces rows 0..999: valid; the first error in column order is colptr's first fall)
+    good_cp, good_rv, good_n = bench.make_c2(seed=4, N=n, E=200_000)
+    ref = gn.GNGraphBatch.from_csc_packed(good_cp[0], good_rv[0], good_n)
+    want = [_table(gn, ref, w) for w in (0, 1, 5, 7)]
+    del ref
+    for bits in (np.int64, np.int32):
+        with pytest.raises(gn._lib.GnxError) as e:
+            gn.GNGraphBatch.from_csc_packed(cp.astype(bits), rv.astype(bits), [n])
+        assert e.value.code == gn._lib.ERR_CSC and "colptr must be non-decreasing" in str(e.value)
+        again = gn.GNGraphBatch.from_csc_packed(good_cp[0], good_rv[0], good_n)
+        for w, t in zip((0, 1, 5, 7), want):
+            assert np.array_equal(_table(gn, again, w), t)
+        del again
+
+
+def test_two_host_threads_build_batches_on_one_device_concurrently():
+    """the device builder's scratch buffer and stream are per device, not per handle — two host threads that batch on the same
+    device (data-loader workers) must not see each other's arrays.  Each thread builds its own batches (different sizes, so the scratch is also
+    re-sized under load) many times; every handle's tables equal the ones built alone."""
+    import threading
+    import graphnets_jl_amd as gn
+    import torch
+    specs = [(11, 300, 400_000), (12, 900, 150_000), (13, 64, 700_000), (14, 2000, 90_000)]
+    batches = [bench.make_hetero(*sp) for sp in specs]
+    packed = [(np.concatenate(c), np.concatenate(r), nn) for c, r, nn in batches]
+    which = (0, 1, 4, 5, 6, 7)
+    alone = []
+    for cpc, rvc, nn in packed:
+        g = gn.GNGraphBatch.from_csc_packed(cpc, rvc, nn)
+        alone.append([_table(gn, g, w) for w in which])
+        del g
+    errors = []
+
+    def worker(tid):
+        try:
+            torch.cuda.set_device(0)
+            for it in range(12):
+                k = (tid + 2 * it) % len(packed) if tid else (it * 3 + 1) % len(packed)
+                cpc, rvc, nn = packed[k]
+                g = gn.GNGraphBatch.from_csc_packed(cpc, rvc, nn)
+                for w, t in zip(which, alone[k]):
+                    if not np.array_equal(_table(gn, g, w), t):
+                        errors.append((tid, it, k, w))
+                del g
+        except Exception as ex:  # noqa: BLE001
+            errors.append((tid, repr(ex)))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[:5]
 
 
 def test_forward_on_a_device_built_batch_equals_the_oracle_and_lazy_host_tables_work():
