@@ -179,6 +179,7 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
   }
 
   const int er = lane >> 3, eq = lane & 7;  // (row er + 8 i of the wave's 32, 16-byte quad eq of the 32-column block)
+  const bool wave_full = rows >= (wv + 1) * ER;
   float* sE = s_e + wv * (ER * ELDE);
   const float* __restrict__ ps = a.psrc + r * a.N * OUTW;
   const float* __restrict__ pd = a.pdst + r * a.N * OUTW;
@@ -252,8 +253,10 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
 #pragma unroll
         for (int e = 0; e < 4; ++e) vv[e] = act_apply(vv[e], a.act);
       }
-      const bool ok = wv * ER + lr < rows;
       v = f32x4e{vv[0], vv[1], vv[2], vv[3]};
+      // (wave_full — every row of the wave inside the tile — is wave-uniform: the common case stores without a per-lane predicate.  A predicated
+      //  store is an exec-mask branch around each instruction; round 5 measured what sixteen of them per slice cost k_edge_n: 100 us of 473)
+      const bool ok = wave_full || wv * ER + lr < rows;
       if (!ok) v = f32x4e{0.f, 0.f, 0.f, 0.f};  // (rows beyond the tile: zero for the sums below)
       *reinterpret_cast<f32x4e*>(sE + lr * ELDE + 4 * eq) = v;
       if constexpr (NARROW) {
@@ -262,7 +265,8 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
         for (int j = 0; j < 4; ++j)
           if (ok && 4 * eq + j < OUTW) outp[(size_t)(wv * ER + lr) * OUTW + 4 * eq + j] = o4[j];
       } else {
-        if (ok) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * EOUT + 32 * ob + 4 * eq) = v;
+        if (wave_full) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * EOUT + 32 * ob + 4 * eq) = v;
+        else if (ok) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * EOUT + 32 * ob + 4 * eq) = v;
       }
     }
     if (ob + 1 < NOBK) gather(ob + 1, usn, udn);  // under the sums below and the next slice's matrix instructions
@@ -351,6 +355,11 @@ struct ProjX6Args {
   int G;
   float* out_s;            // [R][N][128]
   float* out_d;            // [R][N][128]
+  // k_edge_n's form (gnx_edge_n.hip): the source side is multiplied per EDGE from the raw 64-wide row, so only the destination table is produced
+  // (only_d: slices 4..7) and the normalised rows gn1(nf) — the very values this kernel splits — are written out as the table the edges gather
+  // (zn_out [R][N][64]; nullptr without a LayerNorm: the edges gather nf itself)
+  float* zn_out;
+  int only_d;
 };
 
 __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_proj_x6(ProjX6Args a) {
@@ -372,7 +381,8 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(3, 4)))
                                        (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
     }
   };
-  stage(0, s_wa);
+  const int ob0 = a.only_d ? 4 : 0;
+  stage(ob0, s_wa);
   // ---- the wave's rows as B fragments (gn1 on load), three bf16 parts ----
   const int lrow = wv * ER + n;
   const int lrc = lrow < rows ? lrow : rows - 1;
@@ -397,6 +407,11 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(3, 4)))
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaf(gg[j], (v[j] - mu) * inv, bb[j]);
       }
+      if (a.zn_out && lrow < rows) {
+        float* __restrict__ zo = a.zn_out + (r * a.N + (size_t)row0 + lrow) * PK + 16 * s + 8 * hi;
+        *reinterpret_cast<f32x4e*>(zo) = f32x4e{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4e*>(zo + 4) = f32x4e{v[4], v[5], v[6], v[7]};
+      }
       unsigned ph[4], pm[4], pl[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) esplit2(v[2 * j], v[2 * j + 1], ph[j], pm[j], pl[j]);
@@ -408,6 +423,7 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(3, 4)))
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slice 0's pieces of this wave have landed
   __syncthreads();                                  // ... everybody's
   const int er = lane >> 3, eq = lane & 7;
+  const bool wave_full = rows >= (wv + 1) * ER;  // (wave-uniform: the common case stores without a per-lane predicate)
   float* sE = s_e + wv * (ER * ELDE);
   const float* __restrict__ bp = a.bias_g ? a.bias_g + (r * a.G + (size_t)t.g) * EOUT : a.bias;
   auto slice = [&](int ob, const unsigned char* cur, unsigned char* nxt) {
@@ -445,12 +461,13 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(3, 4)))
       const int lr = er + 8 * i;
       f32x4e v = *reinterpret_cast<const f32x4e*>(sE + lr * ELDE + 4 * eq);
       v += b4;
-      if (wv * ER + lr < rows) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * EOUT) = v;
+      if (wave_full) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * EOUT) = v;
+      else if (wv * ER + lr < rows) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * EOUT) = v;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next slice's pieces of this wave (the stores too: 2 KB per wave)
     __syncthreads();                                  // everybody's pieces; everybody is done with `cur`
   };
-  for (int ob = 0; ob < PNOB; ob += 2) {
+  for (int ob = ob0; ob < PNOB; ob += 2) {
     slice(ob, s_wa, s_wb);
     slice(ob + 1, s_wb, s_wa);
   }
@@ -465,9 +482,10 @@ bool proj_x6_applies(int dn, int oe, const float* nf, const float* W, const floa
 
 // Ps = Ws^T z, Pd = Wd^T z + bias (per graph with bias_g), z = nf or gn1(nf) from ln_stats; scratch: proj_x6_scratch_bytes(), 16-byte aligned
 int32_t launch_proj_x6(const Tile* tiles, size_t n_tiles, const float* nf, size_t N, const float* ln_stats, const float* ln_g, const float* ln_b, const float* Ws, const float* Wd,
-                       int ldw, const float* bias, const float* bias_g, int G, float* out_s, float* out_d, int64_t R, void* scratch, hipStream_t s) {
+                       int ldw, const float* bias, const float* bias_g, int G, float* out_s, float* out_d, int64_t R, void* scratch, hipStream_t s, bool only_d, float* zn_out) {
   if (n_tiles == 0) return GNX_OK;
-  if (!tiles || !nf || !Ws || !Wd || !out_s || !out_d || !scratch || ((uintptr_t)scratch & 15)) return fail(GNX_ERR_INVALID_ARG, "k_proj_x6: NULL operand or misaligned scratch");
+  if (!tiles || !nf || !Ws || !Wd || (!out_s && !only_d) || !out_d || !scratch || ((uintptr_t)scratch & 15)) return fail(GNX_ERR_INVALID_ARG, "k_proj_x6: NULL operand or misaligned scratch");
+  if ((uintptr_t)zn_out & 15) return fail(GNX_ERR_INVALID_ARG, "k_proj_x6: the table of normalised rows is not 16-byte aligned");
   if (ln_stats && (!ln_g || !ln_b || (((uintptr_t)ln_g | (uintptr_t)ln_b) & 15) || ((uintptr_t)ln_stats & 7))) return fail(GNX_ERR_INVALID_ARG, "k_proj_x6: LayerNorm parameters missing or misaligned");
   if ((((uintptr_t)bias | (uintptr_t)bias_g | (uintptr_t)out_s | (uintptr_t)out_d) & 15)) return fail(GNX_ERR_INVALID_ARG, "k_proj_x6: operand not 16-byte aligned");
   __bf16* Wp = static_cast<__bf16*>(scratch);
@@ -478,6 +496,7 @@ int32_t launch_proj_x6(const Tile* tiles, size_t n_tiles, const float* nf, size_
   }
   ProjX6Args a{};
   a.tiles = tiles; a.nf = nf; a.N = N; a.ln_stats = ln_stats; a.ln_g = ln_g; a.ln_b = ln_b; a.Wp = Wp; a.bias = bias; a.bias_g = bias_g; a.G = G; a.out_s = out_s; a.out_d = out_d;
+  a.zn_out = zn_out; a.only_d = only_d ? 1 : 0;
   ProfScope ps("k_rows_gemm_proj", s);  // (the name the projections have in every profile and bench line)
   GNX_LAUNCH(k_proj_x6, dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
   GNX_HIP(hipGetLastError());

@@ -442,6 +442,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     stage_e(0, s_w2a);                         // (free since the barrier that ended the last step)
     load_z(a.e.ln1_g, a.e.ln1_b, true, false, std::true_type{});  // gn1(x): the rows once more (the cache has them), the statistics from the prologue
     const int trows = (int)(rend - wg_row0);
+    const bool wave_full = trows >= (wv + 1) * XR;
     const int tile_id = blockIdx.x;
     int agg_row0[2] = {0, 0};
     if (a.e.agg_out) { agg_row0[0] = a.e.chunk_row0[2 * tile_id]; agg_row0[1] = a.e.chunk_row0[2 * tile_id + 1]; }
@@ -537,14 +538,16 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
           for (int e = 0; e < 4; ++e) vv[e] = act_apply(vv[e], a.e.act);
         }
         v = f32x4x{vv[0], vv[1], vv[2], vv[3]};
-        const bool ok = wv * XR + lr < trows;
+        const bool ok = wave_full || wv * XR + lr < trows;
         if (!ok) v = zero4;  // (rows beyond the tile: zero for the sums below)
         *reinterpret_cast<f32x4x*>(sE + lr * ELDE + 4 * eq) = v;
         f32x4x o = vf[i];  // the two-launch form's order (gnx_core_forward: add1 = the block's output, add2 = x): ((W2^T H + b2) + ef') + x
         o += bq;
         o += v;
         o += u1[i];
-        if (ok) *reinterpret_cast<f32x4x*>(outp + (row0 + lr) * D + 32 * ob + 4 * eq) = o;
+        // (wave_full is wave-uniform: the common case stores without a per-lane predicate — no exec-mask branch around the instruction)
+        if (wave_full) *reinterpret_cast<f32x4x*>(outp + (row0 + lr) * D + 32 * ob + 4 * eq) = o;
+        else if (ok) *reinterpret_cast<f32x4x*>(outp + (row0 + lr) * D + 32 * ob + 4 * eq) = o;
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS traffic only) the finished block of all four waves is staged
       const int q4 = tid & 7, grp = tid >> 3;  // 8 quads x 32 row groups
@@ -599,6 +602,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   __shared__ __attribute__((aligned(16))) float s_e[E_IN_W1 ? 4 : XW * XR * ELD];
   float* sE = (E_IN_W1 ? reinterpret_cast<float*>(s_w1) : s_e) + wv * (XR * ELD);
   const int er = lane >> 3, eq = lane & 7;
+  const bool wave_full_p = row0 + XR <= rend;  // (wave-uniform: the common case stores without a per-lane predicate)
   const float* __restrict__ r1 = a.add1 ? a.add1 + r * rows * D : nullptr;
   const float* __restrict__ r2 = a.add2 ? a.add2 + r * rows * D : nullptr;
   float* __restrict__ ob_out = a.out + r * rows * D;
@@ -627,7 +631,8 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       v += bq;
       v += u1[ob][i];
       v += u2[ob][i];
-      if (row0 + er + 8 * i < rend) *reinterpret_cast<f32x4x*>(ob_out + (row0 + er + 8 * i) * D + 32 * ob + 4 * eq) = v;
+      if (wave_full_p) *reinterpret_cast<f32x4x*>(ob_out + (row0 + er + 8 * i) * D + 32 * ob + 4 * eq) = v;
+      else if (row0 + er + 8 * i < rend) *reinterpret_cast<f32x4x*>(ob_out + (row0 + er + 8 * i) * D + 32 * ob + 4 * eq) = v;
     }
   }
 #ifdef GNX_X6_STAMPS_BUILD

@@ -44,6 +44,7 @@ int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d,
                          bool ln_inline = false, float ln_eps = 0.f, int ln_mode = 0);
 bool ffn_x6_applies(const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, const float* out, size_t scratch_bytes);  // gnx_ffn_x6.hip
 bool block_wide_edge_x6_applies(const gnx_graphs* h, const BlockArgs& a);  // gnx_wide.hip
+bool edge_n_enabled();  // gnx_edge_n.hip
 bool ffn_fused_applies(const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, const float* out);
 bool block_wide_ln_applies(const gnx_graphs* h, const BlockArgs& a);
 bool ln_stats_applies(const float* x, int d);
@@ -376,7 +377,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   const bool inline_e = wide_ln && edge_x6 && d[0] == 128 && rows[0] >= 4096 && getenv("GNX_LN_STATS_PASS") == nullptr &&
                         ffn_x6_applies(x[0], d[0], p->ff[0], out[0], x[0], out[0], sizeof(float) * rows[0] * d[0]);
   // ... and then ONE launch does both (the edge form of k_ffn_x6: ef' stays in the accumulator — never written, never read back; GNX_CORE_EDGE_SPLIT=1: two launches)
-  const bool fuse_e = inline_e && getenv("GNX_CORE_EDGE_SPLIT") == nullptr;
+  const bool fuse_e = inline_e && getenv("GNX_CORE_EDGE_SPLIT") == nullptr && !(edge_n_enabled() && d[1] == 64);  // (TEMPORARY: until the one-launch form gathers raw source rows too)
   if (wide_ln) {
     const float* stats[2] = {l1[0], l1[1]};  // the (unused) gn1 buffers hold the statistics: 2 floats per row
     const bool no_fork0 = getenv("GNX_NO_FORK") != nullptr;  // (read per call: tests compare both forms in one process)

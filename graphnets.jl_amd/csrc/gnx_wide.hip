@@ -30,7 +30,14 @@ int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_
 size_t proj_x6_scratch_bytes();  // gnx_edge_x6.hip
 bool proj_x6_applies(int dn, int oe, const float* nf, const float* W, const float* out, size_t N);
 int32_t launch_proj_x6(const Tile* tiles, size_t n_tiles, const float* nf, size_t N, const float* ln_stats, const float* ln_g, const float* ln_b, const float* Ws, const float* Wd,
-                       int ldw, const float* bias, const float* bias_g, int G, float* out_s, float* out_d, int64_t R, void* scratch, hipStream_t s);
+                       int ldw, const float* bias, const float* bias_g, int G, float* out_s, float* out_d, int64_t R, void* scratch, hipStream_t s, bool only_d = false,
+                       float* zn_out = nullptr);
+// gnx_edge_n.hip: the edge update with the source side gathered raw (K = 128 + 64) and a register epilogue
+size_t edge_n_scratch_bytes();
+bool edge_n_enabled();
+int32_t launch_edge_n(const Tile* tiles, size_t n_tiles, const float* ef, size_t E, const float* ln_stats, const float* ln_g, const float* ln_b, const float* We, int ldw,
+                      const float* zsrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out, size_t n_agg_rows,
+                      const int* chunk_row0, int64_t R, void* scratch, hipStream_t s, bool ln_inline, float ln_eps, int ln_mode);
 int32_t launch_core_edge_x6(const Tile* tiles, size_t n_tiles, const float* x, size_t E, const gnx_layernorm* ln1, float ln_eps, int ln_mode, const float* We, int ldw,
                             const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* colsum, float* agg_out, size_t n_agg_rows,
                             const int* chunk_row0, const gnx_ffn& ff, const gnx_layernorm* ln2, float* out, int64_t R, void* scratch_e, void* scratch_f, hipStream_t s);  // gnx_ffn_x6.hip
@@ -1153,6 +1160,12 @@ static int wide_slices(const gnx_graphs* h) {
   return S < 1 ? 1 : (S > 64 ? 64 : S);
 }
 
+// the edge update's prepared weight block: three bf16 planes in 32-output slices (k_edge_x6_prep); k_edge_n's adds the source rows' block (K = 128 + 64)
+static size_t x6_tab_bytes(int de, int oe) {
+  const size_t x6 = sizeof(__bf16) * 3 * (size_t)de * (size_t)((oe + 31) / 32 * 32);
+  return (de == 128 && oe == 128) ? std::max(x6, edge_n_scratch_bytes()) : x6;
+}
+
 size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {
   const size_t per_tile = sizeof(float) * (size_t)R * ((size_t)h->n_etiles * p->oe + (size_t)h->n_ntiles * p->on);
   const size_t stage2 = sizeof(float) * (size_t)R * h->G * wide_slices(h) * (size_t)(p->oe + p->on);
@@ -1160,7 +1173,7 @@ size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int6
   const size_t proj = sizeof(float) * 2 * (size_t)R * h->N * (size_t)p->oe;  // node projections Ps, Pd
   const size_t xg = sizeof(float) * (size_t)R * h->G * (size_t)(p->oe + p->on + p->dg);  // graph-function input (small batches)
   const size_t agg = sizeof(float) * (size_t)R * (size_t)h->agg_rows_bound * (size_t)p->oe;  // per-destination partial sums of the edge GEMM (rows: an upper bound known without the tables)
-  const size_t x6 = sizeof(__bf16) * 3 * (size_t)p->de * (size_t)((p->oe + 31) / 32 * 32);  // the edge update's weight block as three bf16 planes in 32-output slices (k_edge_x6_prep)
+  const size_t x6 = x6_tab_bytes(p->de, p->oe);
   const size_t x6p = proj_x6_scratch_bytes();  // the node projections' two weight blocks likewise (k_proj_x6_prep)
   return align_up(per_tile, 256) + align_up(stage2, 256) + align_up(bias_g, 256) + align_up(proj, 256) + align_up(xg, 256) + align_up(agg, 256) + align_up(x6, 256) + align_up(x6p, 256) + 512;
 }
@@ -1402,6 +1415,12 @@ bool block_wide_edge_x6_applies(const gnx_graphs* h, const BlockArgs& a) {
          (size_t)h->E >= 4096;
 }
 
+// ... and as k_edge_n (gnx_edge_n.hip: source rows gathered raw, register epilogue)?  Needs the six-term projection launch (64-wide nodes, from 4096
+// nodes on) — launch_block_wide checks that part; a core whose edge FeedForward rides in the edge launch keeps round 4's form until that kernel is ported
+bool block_wide_edge_n_applies(const gnx_graphs* h, const BlockArgs& a) {
+  return edge_n_enabled() && a.dn == 64 && block_wide_edge_x6_applies(h, a) && al16(a.nf);
+}
+
 int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {
   bool project = false;
   if (!wide_applies(h, a, &project)) return 1;
@@ -1423,7 +1442,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   float* agg_tab = reinterpret_cast<float*>(reinterpret_cast<char*>(proj_s) + align_up(sizeof(float) * 2 * (size_t)R * h->N * a.oe, 256) +
                                             align_up(sizeof(float) * (size_t)R * h->G * (size_t)(a.oe + a.on + a.dg), 256));
   void* x6_tab = reinterpret_cast<char*>(agg_tab) + align_up(sizeof(float) * (size_t)R * (size_t)h->agg_rows_bound * (size_t)a.oe, 256);
-  void* x6p_tab = reinterpret_cast<char*>(x6_tab) + align_up(sizeof(__bf16) * 3 * (size_t)a.de * (size_t)((a.oe + 31) / 32 * 32), 256);
+  void* x6p_tab = reinterpret_cast<char*>(x6_tab) + align_up(x6_tab_bytes(a.de, a.oe), 256);
   // edge -> node sums inside the edge GEMM's epilogue (the node GEMM then reads ~N rows instead of all E rows of ef')
   static const bool no_agg_fuse = getenv("GNX_NO_AGG_FUSE") != nullptr;
   // (needs quad outputs, and — with the projections' epilogue operands — an ef whose rows are quads: see launch_gemm's instantiations)
@@ -1447,10 +1466,15 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     }
     GNX_HIP(hipGetLastError());
   }
-  if (prep && project && proj_x6_applies(a.dn, a.oe, a.nf, a.We, proj_s, (size_t)a.N) && (!a.ln_stats[1] || (al16(a.ln_g[1]) && al16(a.ln_b[1]))) && al16(a.be)) {
+  const bool proj6 = project && proj_x6_applies(a.dn, a.oe, a.nf, a.We, proj_s, (size_t)a.N) && (!a.ln_stats[1] || (al16(a.ln_g[1]) && al16(a.ln_b[1]))) && al16(a.be);
+  // k_edge_n's form (gnx_edge_n.hip): the source side multiplied per edge from the raw 64-wide row — the projection launch then produces the
+  // destination table and, under a LayerNorm, the normalised rows the edges gather (in the source table's place).  One predicate for both launches
+  // (they may run in different calls: phase 4 on the side stream, phase 1 on the caller's): it depends on the block, never on the phase.
+  const bool edge_n = proj6 && block_wide_edge_n_applies(h, a);
+  if (prep && proj6) {
     // 64 -> 2 x 128 from 4096 nodes on: both tables in one launch of k_proj_x6 (six bf16 matrix-core terms per fp32 product; gnx_edge_x6.hip)
     if ((rc = launch_proj_x6(h->d_ntiles, n_nt, a.nf, (size_t)a.N, a.ln_stats[1], a.ln_g[1], a.ln_b[1], a.We + (size_t)a.de * a.oe, a.We + (size_t)(a.de + a.dn) * a.oe, a.oe, a.be,
-                             a.dg > 0 ? bias_e : nullptr, a.G, proj_s, proj_d, R, x6p_tab, s)))
+                             a.dg > 0 ? bias_e : nullptr, a.G, proj_s, proj_d, R, x6p_tab, s, edge_n, edge_n && a.ln_stats[1] ? proj_s : nullptr)))
       return rc;
   } else
   if (prep && project) {  // both projections in ONE launch (the second weight block of k_rows_gemm): nf is read once
@@ -1480,12 +1504,19 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
                              a.ef_out, a.og > 0 ? pe : nullptr, nullptr, 0, nullptr, R, x6_tab, s, false, 0.f, 0, a.oe)))
       return rc;
   } else
+  if (edge_x6 && a.ffe_w1 && edge_n) return fail(GNX_ERR_INVALID_ARG, "internal: the one-launch core form was asked of a block whose projections are k_edge_n's");
   if (edge_x6 && a.ffe_w1) {  // GNCore: edge update + edge FeedForward + residuals in one launch (edge form of k_ffn_x6); ef_out receives the CORE's edge output
     gnx_ffn ff{};
     ff.fc1.weight = a.ffe_w1; ff.fc1.bias = a.ffe_b1; ff.fc1.act = a.ffe_act1; ff.fc2.weight = a.ffe_w2; ff.fc2.bias = a.ffe_b2; ff.fc2.act = a.ffe_act2;
     const gnx_layernorm ln1{a.ln_g[0], a.ln_b[0]}, ln2{a.ffe_g2, a.ffe_be2};
     if ((rc = launch_core_edge_x6(h->d_etiles, n_et, a.ef, (size_t)a.E, &ln1, a.ln_eps, a.ln_mode, a.We, a.oe, proj_s, proj_d, (size_t)a.N, a.rowval, h->d_edge_dst, a.act_e,
                                   a.og > 0 ? pe : nullptr, agg_fuse ? agg_tab : nullptr, (size_t)h->n_agg_rows, h->d_chunk_row0, ff, &ln2, a.ef_out, R, x6_tab, a.ffe_scratch, s)))
+      return rc;
+  } else
+  if (edge_x6 && edge_n) {
+    if ((rc = launch_edge_n(h->d_etiles, n_et, a.ef, (size_t)a.E, a.ln_stats[0], a.ln_g[0], a.ln_b[0], a.We, a.oe, a.ln_stats[1] ? proj_s : a.nf, proj_d, (size_t)a.N, a.rowval,
+                            h->d_edge_dst, a.act_e, a.ef_out, a.og > 0 ? pe : nullptr, agg_fuse ? agg_tab : nullptr, (size_t)h->n_agg_rows, h->d_chunk_row0, R, x6_tab, s,
+                            a.ln_inline_e != 0, a.ln_eps, a.ln_mode)))
       return rc;
   } else
   if (edge_x6) {
