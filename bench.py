@@ -128,6 +128,16 @@ def executed_flops(E, N, G, din, dout):
     return 2 * (edge + N * (oe + dn) * on + G * (oe + on + dg) * og + G * dg * (oe + on))
 
 
+FLAG_FFN_FP32, FLAG_EDGE_FP32 = 0x20, 0x40  # include/gnx.h: the call's arithmetic (GNX_FLAG_FP32_MFMA = both)
+
+
+def fp32_forms(flags):
+    """(FeedForwards on the fp32 matrix instruction?, edge update / projections?) for a run with these call flags: the flags themselves, or the
+    process-wide defaults the library reads from the environment"""
+    return (bool(flags & FLAG_FFN_FP32) or os.environ.get("GNX_FFN_FP32", "0") not in ("", "0"),
+            bool(flags & FLAG_EDGE_FP32) or os.environ.get("GNX_EDGE_FP32", "0") not in ("", "0"))
+
+
 def glorot(rng, out_d, in_d):
     s = np.sqrt(6.0 / max(in_d + out_d, 1))
     return rng.uniform(-s, s, size=(out_d, in_d)).astype(np.float32)
@@ -249,6 +259,9 @@ def bench_c4(args, gn, torch, dev, c_abi=None):
     g = gn.GNGraphBatch.from_csc(colptrs, rowvals, nn, device=dev)
     core = tuple(int(v) for v in args.core_dims.split(","))
     model, ps = c4_model(gn, torch, core, dev)
+    for layer in model:
+        layer.flags = args.flags  # the forms of every call of the run (--flags 96 = GNX_FLAG_FP32_MFMA: every product on the fp32 matrix instruction)
+    ffn_fp32, edge_fp32 = fp32_forms(args.flags)
     tg = torch.Generator(device=dev); tg.manual_seed(1)
     x = gn.NT(g, torch.rand((1, g.n_edges, 10), generator=tg, device=dev).permute(2, 1, 0),
               torch.rand((1, g.n_nodes, 5), generator=tg, device=dev).permute(2, 1, 0), None)
@@ -316,14 +329,14 @@ def bench_c4(args, gn, torch, dev, c_abi=None):
     tkey = "c4" if core == (128, 64, 32) else "c4_" + "-".join(map(str, core))
     sha = model_source_sha(core)
     traffic, tsrc = load_traffic(tkey, "__model__", sha)
-    if (os.environ.get("GNX_FFN_FP32") or os.environ.get("GNX_EDGE_FP32")) and ce == 128:  # (the profiled traffic is the six-term form's)
+    if (ffn_fp32 or edge_fp32) and ce == 128:  # (the profiled traffic is the six-term form's)
         traffic, tsrc = None, {"note": "profiles/traffic_c4.json was measured with k_ffn_x6; round 3 measured this form at 15.8 GB"}
     # The roof of the model: its executed flops at the rate of the instruction that carries them.  The two edge FeedForwards at width 128 run as
     # k_ffn_x6 — every fp32 product as six bf16 matrix-core terms with fp32 accumulation (csrc/gnx_ffn_x6.hip; as accurate as the fp32 MFMA:
-    # tests/test_gpu_core.py) — unless GNX_FFN_FP32=1; everything else on the fp32 MFMA.
-    x6 = ce == 128 and not os.environ.get("GNX_FFN_FP32")
+    # tests/test_gpu_core.py) — unless the calls carry GNX_FLAG_FFN_FP32; everything else on the fp32 MFMA.
+    x6 = ce == 128 and not ffn_fp32
     x6_flops = 2 * 16 * E * ce * ce if x6 else 0
-    if ce == 128 and not os.environ.get("GNX_EDGE_FP32"):
+    if ce == 128 and not edge_fp32:
         x6_flops += 2 * 2 * E * ce * ce  # the cores' projected edge updates (k_edge_x6: K = 128 -> 128 per edge)
     t_roof = x6_flops / (MFMA_BF16_PEAK_TFS / 6 * 1e12) + (ex - x6_flops) / (MFMA_F32_PEAK_TFS * 1e12)
     line = {"metric": "edges/sec through Encoder->2xGNCore(%s)->Decoder, 1M-edge graph (BASELINE configs[3])" % ",".join(map(str, core)),
@@ -477,8 +490,8 @@ SECONDARY = [  # (key, extra argv, BASELINE config it stands for)
      "configs[4]'s batch through the N > 1 code path at world size 1 (partitioner, stacked gf' send buffer, RCCL all-gather on a side stream, index table back to graph order)"),
     ("c4", ["--model", "c4"], "configs[3]: Encoder -> 2 x GNCore(128,64,32) -> Decoder on the 1M-edge graph"),
     ("c4_narrow", ["--model", "c4", "--core-dims", "10,5,3"], "README example 3 at its own widths (core_dims 10,5,3)"),
-    # the same model with every matrix product on the fp32 matrix instruction (GNX_FFN_FP32=1 in the child's environment): what the six-term bf16 form of `c4` is measured against
-    ("c4_fp32_mfma", ["--model", "c4", "--no-cpu-baseline", "--no-c-abi"], "configs[3] with the FeedForwards and the cores' edge updates on the fp32 matrix instruction (GNX_FFN_FP32=1 GNX_EDGE_FP32=1; round 3's arithmetic) — beside `c4`, not instead of it", {"GNX_FFN_FP32": "1", "GNX_EDGE_FP32": "1"}),
+    # the same model with every matrix product on the fp32 matrix instruction (--flags 96: the calls' own GNX_FLAG_FP32_MFMA): what the six-term bf16 form of `c4` is measured against
+    ("c4_fp32_mfma", ["--model", "c4", "--no-cpu-baseline", "--no-c-abi", "--flags", "96"], "configs[3] with the FeedForwards and the cores' edge updates on the fp32 matrix instruction (every call carries GNX_FLAG_FP32_MFMA = 0x60; round 3's arithmetic) — beside `c4`, not instead of it"),
 ]
 
 
@@ -604,10 +617,11 @@ def block_roofline(gn, torch, dev, plan, sets, nsets, K, E, N, G, din, dout, ms_
     dur_s = kern[dom] * 1e-6
     step_s = ms_per_step * 1e-3
     abytes, aflops = algorithmic_bytes(E, N, G, din, dout), algorithmic_flops(E, N, G, din, dout)
+    edge_fp32_ = fp32_forms(plan.flags)[1]
     hbm_t, mfma_t = abytes / (HBM_PEAK_GBS * 1e9), aflops / (MFMA_F32_PEAK_TFS * 1e12)
     if max(din + dout) > 32:  # matrix-core path: the binding roof is decided on the flops the kernels EXECUTE at the rate of the instruction that carries them
         ex_ = executed_flops(E, N, G, din, dout)
-        x6_ = 2 * E * din[0] * dout[0] if (din[0] == 128 and dout[0] == 128 and din[1] >= 16 and E >= 2 * N and not os.environ.get("GNX_EDGE_FP32")) else 0
+        x6_ = 2 * E * din[0] * dout[0] if (din[0] == 128 and dout[0] == 128 and din[1] >= 16 and E >= 2 * N and not edge_fp32_) else 0
         mfma_t = x6_ / (MFMA_BF16_PEAK_TFS / 6 * 1e12) + (ex_ - x6_) / (MFMA_F32_PEAK_TFS * 1e12)
     traffic, tsrc = load_traffic(dims_key, dom, kernel_source_sha(din, dout))
     if hbm_t >= mfma_t:
@@ -627,7 +641,7 @@ def block_roofline(gn, torch, dev, plan, sets, nsets, K, E, N, G, din, dout, ms_
         a = ex / step_s / 1e12
         # the projected edge update at 128 -> 128 runs as six bf16 matrix-core terms per fp32 product (k_edge_x6) unless GNX_EDGE_FP32=1: its
         # flops are priced at that instruction's rate, the rest at the fp32 MFMA's
-        x6_flops = 2 * E * din[0] * dout[0] if (din[0] == 128 and dout[0] == 128 and din[1] >= 16 and E >= 2 * N and not os.environ.get("GNX_EDGE_FP32")) else 0
+        x6_flops = 2 * E * din[0] * dout[0] if (din[0] == 128 and dout[0] == 128 and din[1] >= 16 and E >= 2 * N and not edge_fp32_) else 0
         t_roof = x6_flops / (MFMA_BF16_PEAK_TFS / 6 * 1e12) + (ex - x6_flops) / (MFMA_F32_PEAK_TFS * 1e12)
         roof = dict(bound="mfma", achieved=round(a, 3), peak=round(ex / t_roof / 1e12, 1), unit="TFLOP/s", frac=round(t_roof / step_s, 4),
                     frac_whole_step=round(t_roof / step_s, 4), frac_of_fp32_mfma_roof=round(a / MFMA_F32_PEAK_TFS, 4), flops_on_bf16_six_terms=x6_flops,

@@ -18,6 +18,12 @@ ERR_DIMS, ERR_CSC, ERR_WORKSPACE, ERR_TOO_LARGE, ERR_COUNT_MISMATCH = -6, -7, -8
 ACT = dict(identity=0, relu=1, tanh=2, sigmoid=3, gelu=4)
 ELEM_U8, ELEM_I32, ELEM_I64, ELEM_F32, ELEM_F64 = 0, 1, 2, 3, 4
 FLAG_FORCE_GENERIC, FLAG_NO_MFMA, FLAG_DEFER_GRAPH_UPDATE, FLAG_NO_GRAPH, FLAG_DIST_NO_GATHER = 0x1, 0x2, 0x4, 0x8, 0x10
+# forms of the forward selected per call (include/gnx.h); the environment variables of the same names (GNX_FFN_FP32=1 ...) are the process-wide
+# defaults, read once by the library
+FLAG_FFN_FP32, FLAG_EDGE_FP32, FLAG_PROJ_FP32, FLAG_EDGE_NARROW_FP32 = 0x20, 0x40, 0x80, 0x100
+FLAG_FP32_MFMA = FLAG_FFN_FP32 | FLAG_EDGE_FP32
+FLAG_NO_LN_FUSE, FLAG_LN_STATS_PASS, FLAG_CORE_EDGE_SPLIT, FLAG_NO_FORK = 0x200, 0x400, 0x800, 0x1000
+FLAG_NO_PACK, FLAG_NO_FFE, FLAG_NO_JIT, FLAG_EDGE_N = 0x2000, 0x4000, 0x8000, 0x10000
 
 _fp = C.c_void_p  # device float*
 
@@ -105,6 +111,7 @@ _i64p = C.POINTER(C.c_int64)
 _FWD = [C.c_void_p, C.c_void_p, _fp, _fp, _fp, C.c_int64, _fp, _fp, _fp, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
 SIGNATURES = {
     "gnx_version": (C.c_int32, []),
+    "gnx_default_flags": (C.c_uint32, []),
     "gnx_last_error": (C.c_char_p, []),
     "gnx_graphs_create_dense": (C.c_int32, [_pp, _i64p, C.c_int64, C.c_int32, C.c_int32, _pp]),
     "gnx_graphs_create_csc": (C.c_int32, [_pp, _pp, _i64p, C.c_int64, C.c_int32, _pp]),

@@ -122,6 +122,7 @@ size_t gnx_chain_block_workspace_bytes(const gnx_graphs* h, const gnx_chain_bloc
 int32_t gnx_chain_block_forward(const gnx_graphs* h, const gnx_chain_block_params* p, const float* ef, const float* nf, const float* gf, int64_t R,
                                 float* ef_out, float* nf_out, float* gf_out, void* ws, size_t ws_bytes, uint32_t flags, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  gnx::FormScope forms(flags);  // the forms this call selected (gnx.h: GNX_FLAG_EDGE_FP32 ...)
   int32_t rc = check_params(h, p, R);
   if (rc) return rc;
   const int de = p->de, dn = p->dn, dg = p->dg;

@@ -59,8 +59,8 @@ int32_t launch_core_post(const float* x, size_t rows, int d, const gnx_layernorm
                          float* out, hipStream_t s) {
   if (rows == 0) return GNX_OK;
   ProfScope ps("k_core_post", s);
-  const char* e = getenv("GNX_CORE_POST_ROWS");
-  const int M = (e ? atoi(e) : 2) == 2 && rows >= 65536 ? 2 : 1;  // two rows per thread once there are rows to spare
+  static const int rows_env = getenv("GNX_CORE_POST_ROWS") ? atoi(getenv("GNX_CORE_POST_ROWS")) : 2;  // (A/B switch, read once)
+  const int M = rows_env == 2 && rows >= 65536 ? 2 : 1;  // two rows per thread once there are rows to spare
   static const bool lds_weights = getenv("GNX_CORE_POST_LDS") != nullptr;  // A/B: the LDS-broadcast form
   const bool trans = ff.fc1.act > GNX_ACT_RELU || ff.fc2.act > GNX_ACT_RELU;
   const bool streamed = !lds_weights && M == 2;

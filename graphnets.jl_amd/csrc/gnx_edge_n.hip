@@ -313,10 +313,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 size_t edge_n_scratch_bytes() { return (size_t)NOB * NSL; }
 
 bool edge_n_enabled() {
-  // OPT-IN (GNX_EDGE_N=1).  Measured on the MI355X at 1M edges (profiles/r05_edge_n_ab.log): 375 us against k_edge_x6's 324 — 243 us of it the rows, the split and
+  // OPT-IN (GNX_FLAG_EDGE_N / env GNX_EDGE_N=1).  Measured on the MI355X at 1M edges (profiles/r05_edge_n_ab.log): 375 us against k_edge_x6's 324 — 243 us of it the rows, the split and
   // the 288 matrix instructions per wave (k_edge_x6: 192), the rest the dword-granular epilogue; its lower traffic floor (1.4 GB against 1.66) is not reached.
-  static const bool on = getenv("GNX_EDGE_N") && atoi(getenv("GNX_EDGE_N")) != 0;
-  return on;
+  return form(GNX_FLAG_EDGE_N);
 }
 
 // We ([128 + 64 ..][ldw]: the ef rows, then the source rows) -> scratch: the ef-part fragments (4 x 24 KB), then the source-part fragments (4 x 12 KB)

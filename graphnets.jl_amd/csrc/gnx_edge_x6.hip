@@ -476,7 +476,7 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(3, 4)))
 size_t proj_x6_scratch_bytes() { return (size_t)PNOB * PSLB; }
 
 bool proj_x6_applies(int dn, int oe, const float* nf, const float* W, const float* out, size_t N) {
-  if (getenv("GNX_EDGE_FP32") != nullptr || getenv("GNX_PROJ_FP32") != nullptr) return false;  // (read per call: the fp32 matrix instruction throughout / for the projections alone)
+  if (form(GNX_FLAG_EDGE_FP32) || form(GNX_FLAG_PROJ_FP32)) return false;  // (the call asked for the fp32 matrix instruction throughout / for the projections alone)
   return dn == PK && oe == EOUT && N >= 4096 && (((uintptr_t)nf | (uintptr_t)W | (uintptr_t)out) & 15) == 0;
 }
 

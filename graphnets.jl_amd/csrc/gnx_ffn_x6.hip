@@ -648,7 +648,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
 size_t ffn_x6_scratch_bytes(int d) { return (size_t)3 * d * 4 * d * sizeof(__bf16) * 2; }
 
 bool ffn_x6_applies(const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, const float* out, size_t scratch_bytes) {
-  if (getenv("GNX_FFN_FP32") != nullptr) return false;  // (read per call: tests compare the two kernels in one process)
+  if (form(GNX_FLAG_FFN_FP32)) return false;  // (the call asked for the fp32 matrix instruction)
   if ((d != 128 && d != 64) || ff.fc2.act != GNX_ACT_IDENTITY || scratch_bytes < ffn_x6_scratch_bytes(d)) return false;
   const uintptr_t al = (uintptr_t)z | (uintptr_t)ff.fc2.bias | (uintptr_t)add1 | (uintptr_t)add2 | (uintptr_t)out;
   return (al & 15) == 0;

@@ -105,6 +105,7 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
                                   BlockArgs* args_out = nullptr, const gnx_ffn* ffe = nullptr, const gnx_layernorm* ffe_ln2 = nullptr, bool* ffe_took = nullptr,
                                   const gnx_pending_update* chain_prev = nullptr, bool* chain_took = nullptr, bool* edge_x6_out = nullptr, bool ln_inline_e = false,
                                   void* ffe_scratch = nullptr) {
+  FormScope forms(flags);  // the forms this call selected (gnx.h: GNX_FLAG_FFN_FP32 ...) for every dispatch predicate below
   int32_t rc = check_block(h, p, R);
   if (rc) return rc;
   if (phase & 1) {
@@ -264,21 +265,24 @@ static void core_ws(const gnx_graphs* h, const gnx_core_params* p, int64_t R, si
 // side stream + fork / join events of the handle (see gnx_internal.h); failure just leaves the core on one stream
 static void ensure_aux(const gnx_graphs* h) {
   std::call_once(h->aux_once, [h]() {
-    hipStream_t st = nullptr;
-    hipEvent_t e1 = nullptr, e2 = nullptr;
-    // the stream and its events belong to the HANDLE's device, whatever device is current in the querying thread
+    // the streams and their events belong to the HANDLE's device, whatever device is current in the querying thread
     int prev = -1;
     (void)hipGetDevice(&prev);
     struct Restore { int d; ~Restore() { if (d >= 0) (void)hipSetDevice(d); } } restore{prev != h->device ? prev : -1};
     if (prev != h->device && hipSetDevice(h->device) != hipSuccess) { (void)hipGetLastError(); return; }
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess) {
-      h->aux_stream = st; h->aux_fork = e1; h->aux_join = e2;
-    } else {
-      if (e1) (void)hipEventDestroy(e1);
-      if (e2) (void)hipEventDestroy(e2);
-      if (st) (void)hipStreamDestroy(st);
-      (void)hipGetLastError();
+    for (auto& ax : h->aux) {
+      hipStream_t st = nullptr;
+      hipEvent_t e1 = nullptr, e2 = nullptr;
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
+          hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess) {
+        ax.stream = st; ax.fork = e1; ax.join = e2;
+      } else {
+        if (e1) (void)hipEventDestroy(e1);
+        if (e2) (void)hipEventDestroy(e2);
+        if (st) (void)hipStreamDestroy(st);
+        (void)hipGetLastError();
+        break;
+      }
     }
   });
 }
@@ -302,6 +306,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
                          void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
+  FormScope forms(flags);  // the forms this call selected (gnx.h: GNX_FLAG_FFN_FP32 ...)
   const gnx_block_params& b = p->block;
   // GNFeedForward / GNGraphNorm need all three widths > 0 and graphnetadd needs all three present
   // (gnfeedforward.jl:18, gngraphnorm.jl:10, gncore.jl:61-68); the block maps dims => dims (gncore.jl:49).
@@ -358,7 +363,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   // Wide edges and nodes: the matrix-core kernels normalise x as they load it (block: gn1, fused FeedForward: gn2) from one pass of
   // row statistics — neither LayerNorm output of ef / nf exists in HBM.  Taken when the block runs in the projected quad-row form
   // and both FeedForwards are the fused kernel's; gf (G rows) is normalised by the ordinary kernel.
-  const bool no_ln_fuse = getenv("GNX_NO_LN_FUSE") != nullptr;  // (read per call: tests compare the two forms in one process)
+  const bool no_ln_fuse = form(GNX_FLAG_NO_LN_FUSE);
   bool wide_ln = false, edge_x6 = false;
   if (!fused_ln && !all_narrow && !no_ln_fuse && !(flags & (GNX_FLAG_FORCE_GENERIC | GNX_FLAG_NO_MFMA)) && h->E > 0) {
     const float* ask[2] = {nullptr, nullptr};
@@ -374,29 +379,36 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   }
   // Both consumers of the edge rows' statistics hold whole rows in registers when they are the six-term kernels (k_edge_x6: gn1, k_ffn_x6: gn2) and
   // compute them there, bit-identical to k_ln_stats_v4 (gnx_x6_stats.h): the statistics pass over ef — 512 MB at 1M edges — is not launched.
-  const bool inline_e = wide_ln && edge_x6 && d[0] == 128 && rows[0] >= 4096 && getenv("GNX_LN_STATS_PASS") == nullptr &&
+  const bool inline_e = wide_ln && edge_x6 && d[0] == 128 && rows[0] >= 4096 && !form(GNX_FLAG_LN_STATS_PASS) &&
                         ffn_x6_applies(x[0], d[0], p->ff[0], out[0], x[0], out[0], sizeof(float) * rows[0] * d[0]);
   // ... and then ONE launch does both (the edge form of k_ffn_x6: ef' stays in the accumulator — never written, never read back; GNX_CORE_EDGE_SPLIT=1: two launches)
-  const bool fuse_e = inline_e && getenv("GNX_CORE_EDGE_SPLIT") == nullptr && !(edge_n_enabled() && d[1] == 64);  // (TEMPORARY: until the one-launch form gathers raw source rows too)
+  const bool fuse_e = inline_e && !form(GNX_FLAG_CORE_EDGE_SPLIT) && !(edge_n_enabled() && d[1] == 64);  // (TEMPORARY: until the one-launch form gathers raw source rows too)
   if (wide_ln) {
     const float* stats[2] = {l1[0], l1[1]};  // the (unused) gn1 buffers hold the statistics: 2 floats per row
-    const bool no_fork0 = getenv("GNX_NO_FORK") != nullptr;  // (read per call: tests compare both forms in one process)
-    // The handle has ONE side stream and one pair of events.  A second host thread in this section (same handle, another stream) would
-    // re-record them between this thread's record and wait: whoever does not get the lock runs everything on its own stream instead.
-    std::unique_lock<std::mutex> aux_lk(h->aux_mu, std::try_to_lock);
-    const bool fork0 = !no_fork0 && h->aux_stream != nullptr && !profile_enabled() && aux_lk.owns_lock();
+    const bool no_fork0 = form(GNX_FLAG_NO_FORK);
+    // A side stream and its pair of events from the handle's pool, held while this call enqueues its work (a second host thread in this section —
+    // same handle, another stream, other buffers — takes the next set; with every set taken a caller runs everything on its own stream).
+    std::unique_lock<std::mutex> aux_lk;
+    const gnx_graphs::AuxSet* aux = nullptr;
+    if (!no_fork0 && !profile_enabled())
+      for (auto& ax : h->aux) {
+        if (!ax.stream) break;
+        std::unique_lock<std::mutex> lk(ax.mu, std::try_to_lock);
+        if (lk.owns_lock()) { aux_lk = std::move(lk); aux = &ax; break; }
+      }
+    const bool fork0 = aux != nullptr;
     if ((rc = launch_layernorm2(x[2], rows[2], d[2], p->ln1[2], p->ln2[2], p->eps, p->eps_mode, l1[2], l2[2], s))) return rc;
     if (fork0) {
       // side stream: node statistics, gf fold, node projections (latency / matrix-core work) beside the edge statistics pass (HBM-bound)
-      hipStream_t ax = h->aux_stream;
+      hipStream_t ax = aux->stream;
       bool took0 = false;
-      GNX_HIP(hipEventRecord(h->aux_fork, s));
-      GNX_HIP(hipStreamWaitEvent(ax, h->aux_fork, 0));
+      GNX_HIP(hipEventRecord(aux->fork, s));
+      GNX_HIP(hipStreamWaitEvent(ax, aux->fork, 0));
       rc = launch_ln_stats(x[1], rows[1], d[1], p->eps, p->eps_mode, l1[1], ax);
       if (rc == GNX_OK) rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, ax, 4, p->ln1, p->eps, p->eps_mode, &took0, stats);
-      const hipError_t e1 = hipEventRecord(h->aux_join, ax);
+      const hipError_t e1 = hipEventRecord(aux->join, ax);
       const int32_t rc2 = inline_e ? GNX_OK : launch_ln_stats(x[0], rows[0], d[0], p->eps, p->eps_mode, l1[0], s);
-      const hipError_t e2 = hipStreamWaitEvent(s, h->aux_join, 0);
+      const hipError_t e2 = hipStreamWaitEvent(s, aux->join, 0);
       if (rc) return rc;
       if (rc2) return rc2;
       GNX_HIP(e1);
@@ -409,16 +421,16 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     // node FeedForwards that follow the block: it runs on the handle's side stream behind them (fork after the node update, join
     // before returning; inside a capture the side stream joins the captured graph).  GNX_NO_FORK=1: everything on the caller's stream.
     const bool no_fork = no_fork0;
-    const bool fork = !no_fork && h->aux_stream != nullptr && !profile_enabled() && aux_lk.owns_lock();
+    const bool fork = !no_fork && aux != nullptr;
     bool took = false;
     rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, (fork ? 1 : 3) | (fork0 ? 8 : 0), p->ln1, p->eps, p->eps_mode, &took, stats,
                             nullptr, fuse_e ? &p->ff[0] : nullptr, fuse_e ? &p->ln2[0] : nullptr, nullptr, nullptr, nullptr, nullptr, inline_e, fuse_e ? l2[0] : nullptr);
     if (rc) return rc;
     if (!took) return fail(GNX_ERR_INVALID_ARG, "gnx_core_forward: the block declined the form it had accepted");
     if (fork) {
-      hipStream_t ax = h->aux_stream;
-      GNX_HIP(hipEventRecord(h->aux_fork, s));
-      GNX_HIP(hipStreamWaitEvent(ax, h->aux_fork, 0));
+      hipStream_t ax = aux->stream;
+      GNX_HIP(hipEventRecord(aux->fork, s));
+      GNX_HIP(hipStreamWaitEvent(ax, aux->fork, 0));
       rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, ax, 2, p->ln1, p->eps, p->eps_mode, &took, stats);
       if (rc == GNX_OK) {  // the G-row FeedForward: out = gf' + gf + FF(gn2(gf)); the hidden buffer is its alone (the wide FeedForwards are the fused kernel)
         float* hidden2 = reinterpret_cast<float*>(base + off[6]);
@@ -439,13 +451,13 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       static const bool node_ffn_main = getenv("GNX_NODE_FFN_MAIN") != nullptr;
       if (rc == GNX_OK && !node_ffn_main) rc = launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, ax, l1[1], &p->ln2[1], l2[1], sizeof(float) * rows[1] * d[1]);
       // the join is recorded even after a failure: a capture must not end with the side stream un-joined
-      const hipError_t e1 = hipEventRecord(h->aux_join, ax);
+      const hipError_t e1 = hipEventRecord(aux->join, ax);
       // (the edges' gn2 buffer is unused in this form: room for the split weight planes of k_ffn_x6)
       int32_t rc2 = fuse_e ? GNX_OK  // (the block's edge launch was the edge form of k_ffn_x6: out[0] is final)
                            : launch_ffn_fused(h, 0, x[0], d[0], p->ff[0], out[0], x[0], out[0], R, s, inline_e ? nullptr : l1[0], &p->ln2[0], l2[0], sizeof(float) * rows[0] * d[0], inline_e,
                                               p->eps, p->eps_mode);
       if (rc2 == GNX_OK && node_ffn_main) rc2 = launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, s, l1[1], &p->ln2[1], l2[1], sizeof(float) * rows[1] * d[1]);
-      const hipError_t e2 = hipStreamWaitEvent(s, h->aux_join, 0);
+      const hipError_t e2 = hipStreamWaitEvent(s, aux->join, 0);
       if (rc) return rc;
       if (rc2) return rc2;
       GNX_HIP(e1);

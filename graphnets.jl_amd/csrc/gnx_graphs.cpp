@@ -648,9 +648,11 @@ int32_t gnx_graphs_destroy(gnx_graphs* h) {
   (void)hipFree(h->d_collapse_rev);
   (void)hipFree(h->d_csr_ptr);
   (void)hipFree(h->d_csr_eid);
-  if (h->aux_fork) (void)hipEventDestroy(h->aux_fork);
-  if (h->aux_join) (void)hipEventDestroy(h->aux_join);
-  if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+  for (auto& ax : h->aux) {
+    if (ax.fork) (void)hipEventDestroy(ax.fork);
+    if (ax.join) (void)hipEventDestroy(ax.join);
+    if (ax.stream) (void)hipStreamDestroy(ax.stream);
+  }
   delete h;
   return GNX_OK;
 }

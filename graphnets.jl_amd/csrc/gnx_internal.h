@@ -115,17 +115,31 @@ struct gnx_graphs {
   mutable int32_t* d_csr_ptr = nullptr;  // [N+1]
   mutable int32_t* d_csr_eid = nullptr;  // [E]
   mutable int32_t csr_rc = 0;
-  // side stream for the small graph-level launches of a wide GNCore (forked behind the edge / node FeedForward and joined before the
-  // core returns; created by gnx_core_workspace_bytes, i.e. outside any stream capture).  One forward at a time per handle.
+  // side streams for the small graph-level launches of a wide GNCore (forked behind the edge / node FeedForward and joined before the
+  // core returns; created by gnx_core_workspace_bytes, i.e. outside any stream capture).  A POOL: a forward takes a free (stream, fork event,
+  // join event) set for the time it ENQUEUES its work (an event may be re-recorded once the waits on it have been enqueued: a wait binds to the
+  // record that precedes it), so concurrent forwards on one handle — distinct buffers, distinct streams — each get their side stream; a caller
+  // that finds every set taken runs on its own stream alone.  Apart from the lazily built tables (mutex-guarded) a handle is immutable.
+  static constexpr int kAuxSets = 4;
+  struct AuxSet { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; std::mutex mu; };
   mutable std::once_flag aux_once;
-  mutable hipStream_t aux_stream = nullptr;
-  mutable hipEvent_t aux_fork = nullptr, aux_join = nullptr;
-  mutable std::mutex aux_mu;  // held while a forward enqueues its fork / join pairs (try_lock: a concurrent caller stays on one stream)
+  mutable AuxSet aux[kAuxSets];
   int64_t n_tiles() const { return n_tiles_; }
   int64_t n_wtiles() const { return n_wtiles_; }
 };
 
 namespace gnx {
+
+// forms of the forward selected per call (gnx.h: GNX_FLAG_FFN_FP32 ...), defaults from the environment read once per process (gnx_forms.cpp)
+uint32_t env_form_flags();
+struct FormScope {  // an exported forward opens one: the functions below it read the call's forms with form()
+  explicit FormScope(uint32_t call_flags);
+  ~FormScope();
+  FormScope(const FormScope&) = delete;
+  FormScope& operator=(const FormScope&) = delete;
+  uint32_t prev;
+};
+bool form(uint32_t bit);  // is the form selected for the call this thread is in (outside a call: by the environment's defaults)
 
 void set_error(const std::string& msg);
 int32_t fail(int32_t code, const std::string& msg);

@@ -72,13 +72,13 @@ static int32_t launch_wave_g(const gnx_graphs* h, const BlockArgs& a, int64_t R,
 // Batches of small graphs (every graph <= 8 wave tiles: the handle has a pack table): ONE launch — 512-thread workgroups that own whole
 // graphs run the graph update themselves (k_block_wave<..., PACK>).  Only for the whole block in one call (phase 3): a caller that
 // splits off the graph update, or a narrow GNCore that runs it inside its FeedForward launch, reads the partial rows of the two-launch form.
-// GNX_NO_PACK=1 (read per call: tests compare the two forms) keeps the two launches.
+// GNX_FLAG_NO_PACK keeps the two launches.
 template <int DE, int DN, int DG, int OE, int ON, int EPT>
 static bool launch_wave_pack(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase, int32_t* rc) {
   constexpr int C = OE + ON;
   if constexpr (EPT != 2 || C == 0) return false;
   else {
-    if (h->G <= 1 || h->n_packs <= 0 || !a.packs || phase != 3 || a.og <= 0 || getenv("GNX_NO_PACK")) return false;
+    if (h->G <= 1 || h->n_packs <= 0 || !a.packs || phase != 3 || a.og <= 0 || form(GNX_FLAG_NO_PACK)) return false;
     ProfScope ps("k_block_wave", s);
     GNX_LAUNCH((k_block_wave<DE, DN, DG, OE, ON, EPT, false, false, true>), dim3((unsigned)h->n_packs, (unsigned)R), dim3(kPackThreads), 0, s, a, 0);
     const hipError_t e = hipGetLastError();
@@ -154,7 +154,8 @@ void warm_block_narrow(const gnx_graphs* h, const gnx_block_params* p) {
   a.G = (int)h->G;  // selects the one-graph / several-graphs variant of the kernel
 #define GNX_CASE(DE, DN, DG, OE, ON) \
   if (a.de == DE && a.dn == DN && a.dg == DG && a.oe == OE && a.on == ON) return;
-  if (!getenv("GNX_JIT_ALL")) { GNX_NARROW_DIMS(GNX_CASE) }
+  static const bool jit_all = getenv("GNX_JIT_ALL") != nullptr;  // (diagnostic: specialise even the ahead-of-time width sets; read once)
+  if (!jit_all) { GNX_NARROW_DIMS(GNX_CASE) }
 #undef GNX_CASE
   if (h->n_wtiles() == 0 || h->E == 0) return;
   hipFunction_t fb, fg;
@@ -222,10 +223,10 @@ int32_t launch_block_narrow_chained(const gnx_graphs* h, const BlockArgs& a0, in
 }
 
 // the edge FeedForward + residual of a narrow GNCore inside the block kernel (k_block_wave<..., FFE>): ahead-of-time widths, identity / relu
-// activations.  GNX_NO_FFE=1 (read per call: tests compare the two forms in one process) keeps the FeedForward in k_core_post3.
+// activations.  GNX_FLAG_NO_FFE keeps the FeedForward in k_core_post3.
 bool block_narrow_ffe_applies(const gnx_graphs* h, const BlockArgs& a, int act1, int act2) {
   return ln_aot(h, a) && a.ln_g[0] && act1 <= GNX_ACT_RELU && act2 <= GNX_ACT_RELU && a.act_e <= GNX_ACT_RELU && h->max_in_degree <= h->wtile_e_cap &&
-         !getenv("GNX_NO_FFE");  // (max_in_degree: every wave tile is ONE chunk of edges — the kernel runs the FeedForward once, at its end)
+         !form(GNX_FLAG_NO_FFE);  // (max_in_degree: every wave tile is ONE chunk of edges — the kernel runs the FeedForward once, at its end)
 }
 
 int32_t launch_block_narrow(const gnx_graphs* h, const BlockArgs& a, int64_t R, hipStream_t s, int phase) {

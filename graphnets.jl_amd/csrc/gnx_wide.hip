@@ -1411,7 +1411,7 @@ bool block_wide_edge_x6_applies(const gnx_graphs* h, const BlockArgs& a) {
   const bool edge_out_vec = a.oe % 4 == 0 && al16(a.We) && al16(a.ef_out) && ((size_t)a.E * a.oe) % 4 == 0 && ((size_t)a.N * a.oe) % 4 == 0;
   const bool ef_vec = a.de % 4 == 0 && al16(a.ef) && ((size_t)a.E * a.de) % 4 == 0;
   const bool agg_fuse = !no_agg_fuse && a.oe > 0 && a.on > 0 && edge_out_vec && ef_vec && h->agg_rows_bound > 0 && (size_t)h->agg_rows_bound * a.oe * sizeof(float) < (1ull << 32);
-  return a.de == 128 && a.oe == 128 && a.dn > 0 && edge_out_vec && ef_vec && al16(a.ln_g[0]) && al16(a.ln_b[0]) && (agg_fuse || a.on == 0) && getenv("GNX_EDGE_FP32") == nullptr &&
+  return a.de == 128 && a.oe == 128 && a.dn > 0 && edge_out_vec && ef_vec && al16(a.ln_g[0]) && al16(a.ln_b[0]) && (agg_fuse || a.on == 0) && !form(GNX_FLAG_EDGE_FP32) &&
          (size_t)h->E >= 4096;
 }
 
@@ -1491,14 +1491,14 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     if ((rc = launch_gemm_any(w, (unsigned)n_nt, R, s, "k_rows_gemm_proj"))) return rc;
   }
   // the projected edge update at 128 -> 128 as six bf16 matrix-core terms per fp32 product (gnx_edge_x6.hip)
-  // (GNX_EDGE_FP32=1, read per call: k_rows_gemm on the fp32 matrix instruction instead)
+  // (GNX_FLAG_EDGE_FP32: k_rows_gemm on the fp32 matrix instruction instead)
   const bool edge_x6 = (phase & 1) && block_wide_edge_x6_applies(h, a);
   if (a.ln_inline_e && (phase & 1) && !edge_x6) return fail(GNX_ERR_INVALID_ARG, "internal: edge statistics in the kernel asked of a block that does not run k_edge_x6");
   if (a.ffe_w1 && (phase & 1) && !(edge_x6 && a.ln_inline_e)) return fail(GNX_ERR_INVALID_ARG, "internal: the edge FeedForward inside the edge update asked of a block that does not run k_edge_x6 with its own statistics");
   // ... and at 128 -> at most 32 outputs without fused per-destination sums (config 4's decoder: 128 -> 3) its narrow form: one zero-padded slice
   const bool edge_x6n = (phase & 1) && !edge_x6 && project && a.de == 128 && a.oe >= 1 && a.oe <= 32 && a.dn > 0 && ef_vec && !agg_fuse &&
-                        (!a.ln_stats[0] || (al16(a.ln_g[0]) && al16(a.ln_b[0]))) && getenv("GNX_EDGE_FP32") == nullptr && getenv("GNX_EDGE_NARROW_FP32") == nullptr &&
-                        (size_t)h->E >= 4096;  // (GNX_EDGE_NARROW_FP32=1, read per call: this form alone back on k_rows_gemm)
+                        (!a.ln_stats[0] || (al16(a.ln_g[0]) && al16(a.ln_b[0]))) && !form(GNX_FLAG_EDGE_FP32) && !form(GNX_FLAG_EDGE_NARROW_FP32) &&
+                        (size_t)h->E >= 4096;  // (GNX_FLAG_EDGE_NARROW_FP32: this form alone back on k_rows_gemm)
   if (edge_x6n) {
     if ((rc = launch_edge_x6(h->d_etiles, n_et, a.ef, (size_t)a.E, a.ln_stats[0], a.ln_g[0], a.ln_b[0], a.We, a.oe, proj_s, proj_d, (size_t)a.N, a.rowval, h->d_edge_dst, a.act_e,
                              a.ef_out, a.og > 0 ? pe : nullptr, nullptr, 0, nullptr, R, x6_tab, s, false, 0.f, 0, a.oe)))

@@ -80,6 +80,27 @@ extern "C" {
 #define GNX_FLAG_DEFER_GRAPH_UPDATE 0x4u /* gnx_block_forward stops after the edge+node update and leaves the per-tile
                                           * partial sums in the workspace; gnx_block_graph_update finishes gf' later   */
 
+/* FORMS of the forward, selected PER CALL (every gnx_*_forward / gnx_model_forward / gnx_dist_* takes them in `flags`; the reference's layers
+ * are stateless values, src/gnblock.jl:63-69 — which arithmetic a call runs is an argument of the call, not a property of the process).
+ * Each has an environment variable of the same name (GNX_FFN_FP32=1 ...) that is read ONCE per process, at the first library call, and OR-ed
+ * into every call's flags as the process-wide default (gnx_default_flags() returns that mask); the library never calls getenv() on a forward. */
+#define GNX_FLAG_FFN_FP32 0x20u   /* wide GNCore FeedForwards on the fp32 matrix instruction (k_ffn_fused) instead of six bf16 terms (k_ffn_x6) */
+#define GNX_FLAG_EDGE_FP32 0x40u  /* projected edge update and node projections on the fp32 matrix instruction (k_rows_gemm) instead of six bf16 terms */
+#define GNX_FLAG_FP32_MFMA (GNX_FLAG_FFN_FP32 | GNX_FLAG_EDGE_FP32) /* every matrix product of the call on the fp32 matrix instruction */
+#define GNX_FLAG_PROJ_FP32 0x80u          /* the node projections alone on the fp32 instruction                                             */
+#define GNX_FLAG_EDGE_NARROW_FP32 0x100u  /* the 128 -> (<= 32) edge update alone on the fp32 instruction                                  */
+/* diagnostic forms — same results (bit-identical where the header says so), kept for A/B runs and for the tests that compare two forms */
+#define GNX_FLAG_NO_LN_FUSE 0x200u       /* wide GNCore: materialise gn1 / gn2 (k_layernorm2) instead of normalising on load               */
+#define GNX_FLAG_LN_STATS_PASS 0x400u    /* wide GNCore: row statistics of ef by the statistics pass instead of in the six-term kernels    */
+#define GNX_FLAG_CORE_EDGE_SPLIT 0x800u  /* wide GNCore: edge update and edge FeedForward as two launches                                  */
+#define GNX_FLAG_NO_FORK 0x1000u         /* wide GNCore: everything on the caller's stream (no side stream for the graph level)            */
+#define GNX_FLAG_NO_PACK 0x2000u         /* narrow block on small graphs: graph update as its own launch (k_graph_t)                       */
+#define GNX_FLAG_NO_FFE 0x4000u          /* narrow GNCore: edge FeedForward in k_core_post3 instead of the block kernel's edge lanes       */
+#define GNX_FLAG_NO_JIT 0x8000u          /* never specialise a kernel at run time (generic kernels instead); env GNX_JIT=0 / GNX_NO_JIT=1   */
+#define GNX_FLAG_EDGE_N 0x10000u         /* opt-in: k_edge_n (source rows gathered raw, K = 128 + 64; csrc/gnx_edge_n.hip) for the edge update */
+#define GNX_FLAG_FORMS_MASK 0x1ffe0u
+GNX_API uint32_t gnx_default_flags(void); /* the forms the environment switched on for this process */
+
 typedef struct gnx_graphs gnx_graphs; /* opaque; replaces GNGraphBatch (src/gngraphbatch.jl:1-54) */
 
 typedef struct gnx_graphs_info {
@@ -298,21 +319,26 @@ GNX_API int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p,
 
 /* ---- forward: replaces (m::GNCore)(x) (src/gncore.jl:56-68); GNCoreList = caller-side fold (gncorelist.jl:43-45) ----
  * Wide cores (block in the matrix cores' projected form, FeedForward widths 64 / 128): gn1 / gn2 of ef and nf are applied by the
- * kernels as they load x (one pass of row statistics; bit-identical to the materialised LayerNorm, env GNX_NO_LN_FUSE=1 switches it
- * off), and the graph level of the core runs on a side stream of the HANDLE that gnx_core_workspace_bytes creates (joined before
- * gnx_core_forward returns; part of the capture when `stream` is being captured; env GNX_NO_FORK=1: one stream).  Hence: call
- * gnx_core_workspace_bytes outside a capture (as for every workspace query), and run one forward at a time per handle.
- * Arithmetic of the wide FeedForwards (edges / nodes at width 128 or 64, >= 4096 rows), of the projected edge update at 128 -> 128 or
+ * kernels as they load x (one pass of row statistics; bit-identical to the materialised LayerNorm: GNX_FLAG_NO_LN_FUSE materialises), and
+ * the graph level of the core runs on a side stream (joined before gnx_core_forward returns; part of the capture when `stream` is being
+ * captured; GNX_FLAG_NO_FORK: one stream).  The side streams are a small pool of the HANDLE that gnx_core_workspace_bytes creates — call
+ * it outside a capture, as every workspace query — and a call holds one only while it enqueues its work.
+ * THREADING: a handle is immutable after creation apart from tables built once behind a mutex, so concurrent forwards on ONE handle from
+ * several host threads are allowed — each with its own stream, workspace and output buffers (tests/test_gpu_core.py::
+ * test_two_host_threads_run_core_forwards_on_one_handle_concurrently: bit-identical to the serial run).
+ * ARITHMETIC of the wide FeedForwards (edges / nodes at width 128 or 64, >= 4096 rows), of the projected edge update at 128 -> 128 or
  * 128 -> at most 32 outputs (gnx_block_forward too, >= 4096 edges) and of its node projections at 64-wide nodes (>= 4096 nodes):
- * fp32 in, fp32 out, fp32 accumulation; every fp32 product is
- * evaluated on the bf16 matrix cores as six terms of an EXACT three-way split of both operands (hi + mid + lo bf16 parts = the 24
- * mantissa bits; the dropped terms are <= 2^-23 |a||b|) — as accurate as the fp32 matrix instruction against float64 by test, 2x its
- * speed; inputs that are not finite (or within 0.4 % of the largest finite float) produce NaN where the fp32 instruction may produce an
- * infinity, and operands below ~1e-33 in magnitude may keep only 16 of their 24 mantissa bits (their low parts are bf16 subnormals).  env GNX_FFN_FP32=1 (FeedForwards) / GNX_EDGE_FP32=1 (edge update and projections): the kernel on
- * the fp32 matrix instruction instead (csrc/gnx_ffn_x6.hip, csrc/gnx_edge_x6.hip; csrc/gnx_ffn_fused.hip, csrc/gnx_wide.hip).
+ * fp32 in, fp32 out, fp32 accumulation; every fp32 product is evaluated on the bf16 matrix cores as six terms of an EXACT three-way split
+ * of both operands (hi + mid + lo bf16 parts = the 24 mantissa bits; the dropped terms are <= 2^-23 |a||b|) — as accurate as the fp32
+ * matrix instruction against float64 by test (tests/test_gpu_x6_stress.py: magnitudes over twelve decades, cancellation, a column scaled by
+ * 1e20), 2x its speed; inputs that are not finite (or within 0.4 % of the largest finite float) produce NaN where the fp32 instruction may
+ * produce an infinity, and operands below ~1e-33 in magnitude may keep only 16 of their 24 mantissa bits (their low parts are bf16
+ * subnormals).  The CALL chooses: GNX_FLAG_FFN_FP32 (FeedForwards) / GNX_FLAG_EDGE_FP32 (edge update and projections) / GNX_FLAG_FP32_MFMA
+ * (both) run the kernels on the fp32 matrix instruction instead (csrc/gnx_ffn_fused.hip, csrc/gnx_wide.hip); the environment variables
+ * GNX_FFN_FP32 / GNX_EDGE_FP32 set the process-wide default (read once).
  * At 128-wide edges a core's edge update runs inside its edge FeedForward's launch, ef' kept in registers (same bits as two launches:
- * env GNX_CORE_EDGE_SPLIT=1), and the row statistics of the edge rows are computed in those kernels (same bits as the statistics
- * pass: env GNX_LN_STATS_PASS=1). */
+ * GNX_FLAG_CORE_EDGE_SPLIT), and the row statistics of the edge rows are computed in those kernels (same bits as the statistics pass:
+ * GNX_FLAG_LN_STATS_PASS). */
 GNX_API size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t n_replicas);
 GNX_API int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf,
                          const float* gf, int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out,

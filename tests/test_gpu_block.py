@@ -247,7 +247,7 @@ def test_heterogeneous_batch_64_graphs(gn, flags):
 def test_small_graph_batches_run_the_graph_update_inside_the_block_kernel(gn, dims, monkeypatch):
     """Batches whose graphs all have <= 8 wave tiles (here 700 graphs of 1..300 nodes, some without a single edge): workgroups own whole
     graphs and run the graph update themselves (k_block_wave<..., PACK>) — ONE launch.  Every output is bit-identical to the two-launch
-    form (GNX_NO_PACK=1: partial rows in HBM + k_graph_t) and within 1e-5*S of the oracle."""
+    form (GNX_FLAG_NO_PACK: partial rows in HBM + k_graph_t) and within 1e-5*S of the oracle."""
     rng = np.random.default_rng(77)
     sizes = np.concatenate([rng.integers(1, 301, 690), [1, 1, 2, 300, 300, 64, 65, 128, 129, 3]])
     colptrs, rowvals = [], []
@@ -266,9 +266,8 @@ def test_small_graph_batches_run_the_graph_update_inside_the_block_kernel(gn, di
     gn.profile_enable(False)
     kernels = set(gn.profile_read()); gn.profile_reset()
     assert "k_block_wave" in kernels and "k_graph_t" not in kernels, kernels  # one launch
-    monkeypatch.setenv("GNX_NO_PACK", "1")
     gn.profile_enable(True)
-    y2 = blk(x)
+    y2 = blk(x, flags=gn._lib.FLAG_NO_PACK)
     gn.profile_enable(False)
     assert "k_graph_t" in set(gn.profile_read()); gn.profile_reset()  # the two-launch form
     for u, v in ((y1.ef, y2.ef), (y1.nf, y2.nf), (y1.gf, y2.gf)):

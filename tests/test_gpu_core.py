@@ -113,7 +113,7 @@ def test_core_wide_dims(gn, flags):
 def test_core_wide_layernorm_on_load_equals_materialised(gn, R, eps_mode):
     """GNCore(128,64,32): the matrix-core kernels normalise ef / nf as they load them (row statistics from k_ln_stats; gn1 / gn2
     never written; from 4096 edges on, edge update and edge FeedForward in ONE launch with the statistics computed in it) — bit-identical to the
-    materialised LayerNorm form (GNX_NO_LN_FUSE=1: k_layernorm2, k_edge_x6 / k_rows_gemm, k_ffn_x6), and within the bound of the oracle."""
+    materialised LayerNorm form (GNX_FLAG_NO_LN_FUSE: k_layernorm2, k_edge_x6 / k_rows_gemm, k_ffn_x6), and within the bound of the oracle."""
     import os
     rng = np.random.default_rng(4700 + R)
     dims = (128, 64, 32)
@@ -129,14 +129,11 @@ def test_core_wide_layernorm_on_load_equals_materialised(gn, R, eps_mode):
     gn.profile_enable(False)
     names = set(gn.profile_read()); gn.profile_reset()
     assert "k_ln_stats" in names and "k_ffn_fused" in names, names
-    os.environ["GNX_NO_LN_FUSE"] = "1"
-    try:
+    with U.with_flags(core, gn._lib.FLAG_NO_LN_FUSE):
         gn.profile_enable(True)
         y0 = core(x)
         gn.profile_enable(False)
         names0 = set(gn.profile_read()); gn.profile_reset()
-    finally:
-        del os.environ["GNX_NO_LN_FUSE"]
     assert "k_ln_stats" not in names0 and "k_layernorm2" in names0, names0
     for name, a, b in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), (y0.ef, y0.nf, y0.gf)):
         assert np.array_equal(U.from_jl(a), U.from_jl(b)), f"{name}: LayerNorm on load differs from the materialised form"
@@ -148,13 +145,13 @@ def test_core_wide_layernorm_on_load_equals_materialised(gn, R, eps_mode):
 @pytest.mark.parametrize("R,eps_mode,E", [(1, 0, 9000), (2, 1, 4137), (1, 1, 4096)])
 def test_core_wide_edge_row_statistics_in_the_six_term_kernels_equal_the_statistics_pass(gn, R, eps_mode, E, monkeypatch):
     """GNCore(128,64,32) with >= 4096 edges: k_edge_x6 (gn1) and k_ffn_x6 (gn2) hold whole edge rows in registers and compute their
-    LayerNorm statistics there, so k_ln_stats runs for the node rows only (one launch).  GNX_LN_STATS_PASS=1 brings the pass over ef
+    LayerNorm statistics there, so k_ln_stats runs for the node rows only (one launch).  GNX_FLAG_LN_STATS_PASS brings the pass over ef
     back (two launches).  The two forms are BIT-identical — the in-register sums follow k_ln_stats_v4's order of additions — for both
     epsilon conventions, replicas, and an edge count that ends inside a workgroup."""
     import os
-    if os.environ.get("GNX_FFN_FP32") or os.environ.get("GNX_EDGE_FP32") or os.environ.get("GNX_LN_STATS_PASS"):
+    F = gn._lib
+    if U.default_flags(gn) & (F.FLAG_FFN_FP32 | F.FLAG_EDGE_FP32 | F.FLAG_LN_STATS_PASS):
         pytest.skip("a six-term kernel is switched off for the whole run")
-    monkeypatch.setenv("GNX_CORE_EDGE_SPLIT", "1")  # (k_edge_x6 and k_ffn_x6 as two launches: the form that exists with a statistics table too)
     rng = np.random.default_rng(5300 + E + R)
     dims = (128, 64, 32)
     colptr, rowval = U.er_csc(rng, 600, E)
@@ -163,18 +160,15 @@ def test_core_wide_edge_row_statistics_in_the_six_term_kernels_equal_the_statist
     ef, nf, gf = U.packed_inputs(rng, R, E, 600, 1, dims)
     ef = ef * 2.0 - 5.0  # statistics that matter: a mean far from zero
     core = U.core_from_params(gn, p)
+    core.flags |= F.FLAG_CORE_EDGE_SPLIT  # (k_edge_x6 and k_ffn_x6 as two launches: the form that exists with a statistics table too)
     x = U.to_nt(gn, g, ef, nf, gf)
     got = {}
     for which in ("inline", "pass"):
-        if which == "pass":
-            os.environ["GNX_LN_STATS_PASS"] = "1"
-        try:
+        with U.with_flags(core, F.FLAG_LN_STATS_PASS if which == "pass" else 0):
             gn.profile_reset(); gn.profile_enable(True)
             y = core(x)
             gn.profile_enable(False)
             prof = gn.profile_read(); gn.profile_reset()
-        finally:
-            os.environ.pop("GNX_LN_STATS_PASS", None)
         assert "k_ffn_x6" in prof and "k_edge_x6_prep" in prof, prof.keys()
         assert prof["k_ln_stats"]["launches"] == (1 if which == "inline" else 2), (which, prof["k_ln_stats"])
         got[which] = [U.from_jl(t) for t in (y.ef, y.nf, y.gf)]
@@ -189,10 +183,11 @@ def test_core_wide_edge_row_statistics_in_the_six_term_kernels_equal_the_statist
 def test_core_wide_edge_update_and_feedforward_in_one_launch(gn, R, E, N, hetero):
     """GNCore(128,64,32) from 4096 edges on: the edge form of k_ffn_x6 runs the tile's edge FeedForward, keeps its result in the out^T
     accumulator, then computes ef' = the block's edge update of the tile (k_edge_x6's phase: same per-destination sums, same column sums) and
-    adds it slice by slice in the two-launch form's order — ef' never reaches memory.  Against the two-launch form (GNX_CORE_EDGE_SPLIT=1:
+    adds it slice by slice in the two-launch form's order — ef' never reaches memory.  Against the two-launch form (GNX_FLAG_CORE_EDGE_SPLIT:
     k_edge_x6, then k_ffn_x6) ef, nf and gf are BIT-identical; and within the bound of the oracle.  Replicas, a ragged edge count, 30 in-edges per node, several graphs (hub destinations: tests/test_gpu_wide.py's hub test runs a GNCore)."""
     import os
-    if os.environ.get("GNX_FFN_FP32") or os.environ.get("GNX_EDGE_FP32") or os.environ.get("GNX_LN_STATS_PASS") or os.environ.get("GNX_CORE_EDGE_SPLIT"):
+    F = gn._lib
+    if U.default_flags(gn) & (F.FLAG_FFN_FP32 | F.FLAG_EDGE_FP32 | F.FLAG_LN_STATS_PASS | F.FLAG_CORE_EDGE_SPLIT | F.FLAG_EDGE_N):
         pytest.skip("the one-launch form is switched off for the whole run")
     rng = np.random.default_rng(5400 + E)
     dims = (128, 64, 32)
@@ -212,15 +207,11 @@ def test_core_wide_edge_update_and_feedforward_in_one_launch(gn, R, E, N, hetero
     x = U.to_nt(gn, g, ef, nf, gf)
     got = {}
     for which in ("one", "two"):
-        if which == "two":
-            os.environ["GNX_CORE_EDGE_SPLIT"] = "1"
-        try:
+        with U.with_flags(core, F.FLAG_CORE_EDGE_SPLIT if which == "two" else 0):
             gn.profile_reset(); gn.profile_enable(True)
             y = core(x)
             gn.profile_enable(False)
             prof = gn.profile_read(); gn.profile_reset()
-        finally:
-            os.environ.pop("GNX_CORE_EDGE_SPLIT", None)
         assert ("k_core_edge_x6" in prof) == (which == "one") and ("k_rows_gemm_edge" in prof) == (which == "two"), prof.keys()
         got[which] = [U.from_jl(t) for t in (y.ef, y.nf, y.gf)]
     for name, a, b in zip(("ef", "nf", "gf"), got["one"], got["two"]):
@@ -232,13 +223,14 @@ def test_core_wide_edge_update_and_feedforward_in_one_launch(gn, R, E, N, hetero
 
 def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gn):
     """GNCore(128,64,32): the edge FeedForward (k_ffn_x6) and the projected edge update (k_edge_x6) run every fp32 product as six bf16
-    matrix-core terms (hi/mid/lo parts hold the 24 mantissa bits exactly), fp32 accumulation — unless GNX_FFN_FP32=1 / GNX_EDGE_FP32=1 select
+    matrix-core terms (hi/mid/lo parts hold the 24 mantissa bits exactly), fp32 accumulation — unless the call's GNX_FLAG_FP32_MFMA selects
     the kernels on the fp32 matrix instruction.  Against the float64 oracle both forms must meet the 1e-5·scale bar, and the six-term form must
     be as accurate as the fp32 instruction: its MEAN error within 1.1 x the fp32 form's (measured: equal to two digits) and its worst element
     within 1.5 x (the maximum over 1.5M elements moves by ±20 % with any change of summation order).  Inputs with a mean far from zero,
     weights of both signs, relu between."""
     import os
-    if os.environ.get("GNX_FFN_FP32") or os.environ.get("GNX_EDGE_FP32"):
+    F = gn._lib
+    if U.default_flags(gn) & (F.FLAG_FFN_FP32 | F.FLAG_EDGE_FP32 | F.FLAG_EDGE_N):
         pytest.skip("GNX_FFN_FP32 / GNX_EDGE_FP32 is set for the whole run: a six-term kernel is switched off")
     rng = np.random.default_rng(5100)
     dims = (128, 64, 32)
@@ -252,17 +244,11 @@ def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_
     ref, scale = O.core_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
     out = {}
     for which in ("x6", "fp32"):
-        if which == "fp32":
-            os.environ["GNX_FFN_FP32"] = "1"
-            os.environ["GNX_EDGE_FP32"] = "1"
-        try:
+        with U.with_flags(core, F.FLAG_FP32_MFMA if which == "fp32" else 0):  # (the arithmetic is an argument of the CALL)
             gn.profile_reset(); gn.profile_enable(True)
             y = core(x)
             gn.profile_enable(False)
             names = set(gn.profile_read()); gn.profile_reset()
-        finally:
-            os.environ.pop("GNX_FFN_FP32", None)
-            os.environ.pop("GNX_EDGE_FP32", None)
         assert ("k_core_edge_x6" in names) == (which == "x6") and ("k_edge_x6_prep" in names) == (which == "x6"), names
         for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
             U.assert_close(U.from_jl(got), r, s, f"{which} {name}")
@@ -274,12 +260,13 @@ def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_
 
 @pytest.mark.parametrize("act,bias,E", [("relu", True, 4137), ("identity", True, 5000), ("tanh", True, 4099), ("relu", False, 4608)])
 def test_core_wide_edge_feedforward_six_term_kernel_ragged_rows_activations_no_bias(gn, act, bias, E):
-    """k_ffn_x6 against the fp32-MFMA kernel (GNX_FFN_FP32=1) on the same inputs: row counts that end inside a workgroup and inside a
+    """k_ffn_x6 against the fp32-MFMA kernel (GNX_FLAG_FFN_FP32) on the same inputs: row counts that end inside a workgroup and inside a
     wavefront (128-row workgroups of four 32-row waves), fc1 activations identity / relu (branch-free) and tanh (the run-time switch), a
     FeedForward without biases.  Normwise 2e-6 of the output's magnitude — two fp32-accurate evaluations of the same sums."""
     import os
     import torch
-    if os.environ.get("GNX_FFN_FP32"):
+    F = gn._lib
+    if U.default_flags(gn) & (F.FLAG_FFN_FP32 | F.FLAG_EDGE_N):
         pytest.skip("GNX_FFN_FP32 is set for the whole run: the six-term kernel is switched off")
     rng = np.random.default_rng(5200 + E)
     dims = (128, 64, 32)
@@ -295,19 +282,12 @@ def test_core_wide_edge_feedforward_six_term_kernel_ragged_rows_activations_no_b
     y = core(x)
     gn.profile_enable(False)
     assert "k_core_edge_x6" in set(gn.profile_read()); gn.profile_reset()  # (edge update + FeedForward in one launch)
-    os.environ["GNX_CORE_EDGE_SPLIT"] = "1"
-    try:
+    with U.with_flags(core, F.FLAG_CORE_EDGE_SPLIT):
         gn.profile_enable(True)
         y1 = core(x)
         gn.profile_enable(False)
         assert "k_ffn_x6" in set(gn.profile_read()); gn.profile_reset()
-    finally:
-        del os.environ["GNX_CORE_EDGE_SPLIT"]
-    os.environ["GNX_FFN_FP32"] = "1"
-    try:
-        y0 = core(x)
-    finally:
-        del os.environ["GNX_FFN_FP32"]
+    y0 = core(x, flags=F.FLAG_FFN_FP32)
     b = y0.ef.double()
     for what, yy in (("one launch", y), ("two launches", y1)):
         a = yy.ef.double()
@@ -323,7 +303,7 @@ def test_core_wide_feedforward_six_term_kernel_at_width_64(gn, dims, N, E):
     against the fp32-MFMA kernels normwise."""
     import os
     import torch
-    if os.environ.get("GNX_FFN_FP32"):
+    if U.default_flags(gn) & gn._lib.FLAG_FFN_FP32:
         pytest.skip("GNX_FFN_FP32 is set for the whole run: the six-term kernel is switched off")
     rng = np.random.default_rng(5300 + N)
     colptr, rowval = U.er_csc(rng, N, E)
@@ -340,18 +320,52 @@ def test_core_wide_feedforward_six_term_kernel_at_width_64(gn, dims, N, E):
     ref, scale = O.core_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
     for name, got, r, sc in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
         U.assert_close(U.from_jl(got), r, sc, name)
-    os.environ["GNX_FFN_FP32"] = "1"
-    try:
-        y0 = core(x)
-    finally:
-        del os.environ["GNX_FFN_FP32"]
+    y0 = core(x, flags=gn._lib.FLAG_FFN_FP32)
     for a, b in ((y.ef, y0.ef), (y.nf, y0.nf)):
         assert float((a.double() - b.double()).abs().max()) <= 2e-6 * float(b.double().abs().max())
     assert torch.equal(y.gf, y0.gf)
 
 
+def test_two_host_threads_run_core_forwards_on_one_handle_concurrently(gn):
+    """SURVEY 8b "Threading": handles are immutable after creation, so concurrent forwards on the SAME handle — distinct buffers, distinct
+    streams, one host thread each — are legal (the reference's layers are stateless values, src/gnblock.jl:63-69).  A wide GNCore forks its
+    graph level onto a side stream: the handle keeps a POOL of side streams and a call holds one only while it enqueues.  Two threads x 12
+    forwards each, every result bit-identical to the serial one-stream run of the same inputs."""
+    import threading
+    import torch
+    rng = np.random.default_rng(4900)
+    dims = (128, 64, 32)
+    graphs = [U.er_csc(rng, n, e) for n, e in ((900, 12000), (300, 2500))]
+    g = gn.GNGraphBatch.from_csc([c for c, _ in graphs], [r for _, r in graphs], [900, 300])
+    p = O.make_core_params(rng, dims)
+    core = U.core_from_params(gn, p)
+    xs = [U.to_nt(gn, g, *U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims)) for _ in range(4)]
+    ref = [tuple(t.clone() for t in (y.ef, y.nf, y.gf)) for y in (core(x, flags=gn._lib.FLAG_NO_FORK) for x in xs)]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for it in range(12):
+                    k = (tid + 2 * it) % len(xs)
+                    y = core(xs[k])
+                    st.synchronize()
+                    for name, a, b in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref[k]):
+                        if not torch.equal(a, b):
+                            errors.append((tid, it, k, name))
+        except Exception as ex:  # noqa: BLE001
+            errors.append((tid, repr(ex)))
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[:5]
+
+
 def test_core_wide_side_stream_equals_single_stream(gn):
-    """A wide GNCore forks its graph level, node projections and node FeedForward onto the handle's side stream (GNX_NO_FORK=1: one
+    """A wide GNCore forks its graph level, node projections and node FeedForward onto a side stream of the handle (GNX_FLAG_NO_FORK: one
     stream).  Same kernels, same order of every sum: the results are bit-identical — eagerly, repeatedly (a race would show as a
     mismatch), and inside a captured hipGraph."""
     import os
@@ -363,12 +377,8 @@ def test_core_wide_side_stream_equals_single_stream(gn):
     p = O.make_core_params(rng, dims)
     core = U.core_from_params(gn, p)
     xs = [U.to_nt(gn, g, *U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims)) for _ in range(3)]
-    os.environ["GNX_NO_FORK"] = "1"
-    try:
-        ref = [core(x) for x in xs]
-        ref = [tuple(t.clone() for t in (y.ef, y.nf, y.gf)) for y in ref]
-    finally:
-        del os.environ["GNX_NO_FORK"]
+    ref = [core(x, flags=gn._lib.FLAG_NO_FORK) for x in xs]
+    ref = [tuple(t.clone() for t in (y.ef, y.nf, y.gf)) for y in ref]
     for rep in range(20):
         for x, r in zip(xs, ref):
             y = core(x)
@@ -546,7 +556,7 @@ def test_narrow_core_one_launch_feedforward_with_replicas(gn, dims):
 def test_narrow_core_edge_feedforward_in_the_block_kernel_is_bit_identical(gn, hetero, eps_mode, R):
     """README ex.3's core widths (10,5,3): the edge FeedForward and both residual terms run in k_block_wave's edge lanes
     (k_block_wave<..., FFE>: block_out and the second read of x never exist in HBM for edges; the post kernel keeps nodes and graphs).
-    Same arithmetic in the same association as the two-kernel form (GNX_NO_FFE=1, read per call) — every output BIT-identical — and
+    Same arithmetic in the same association as the two-kernel form (GNX_FLAG_NO_FFE) — every output BIT-identical — and
     within the oracle's bound; relu / identity FeedForward activations; a batch with a hub node (in-degree > 128) keeps the two-kernel form."""
     import os
     rng = np.random.default_rng(1200 + eps_mode + R)
@@ -567,11 +577,7 @@ def test_narrow_core_edge_feedforward_in_the_block_kernel_is_bit_identical(gn, h
     ef = ef + 2.0
     x = U.to_nt(gn, g, ef, nf, gf)
     y = core(x)
-    os.environ["GNX_NO_FFE"] = "1"
-    try:
-        y0 = core(x)
-    finally:
-        del os.environ["GNX_NO_FFE"]
+    y0 = core(x, flags=gn._lib.FLAG_NO_FFE)
     for name, a, b in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), (y0.ef, y0.nf, y0.gf)):
         assert np.array_equal(U.from_jl(a), U.from_jl(b)), f"{name}: FeedForward in the edge lanes differs from the two-kernel form"
     ref, scale = O.core_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)

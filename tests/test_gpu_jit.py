@@ -10,6 +10,8 @@ import pytest
 from oracle import gn_oracle as O
 from tests import util as U
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -126,17 +128,31 @@ def test_code_objects_can_be_kept_on_disk(gn, tmp_path):
 
 
 def test_jit_can_be_disabled(gn):
-    os.environ["GNX_JIT"] = "0"
-    try:
-        rng = np.random.default_rng(80)
-        colptr, rowval = U.er_csc(rng, 300, 2000)
-        g = gn.GNGraphBatch.from_csc([colptr], [rowval], [300])
-        dims = ((2, 9, 1), (3, 3, 3))
-        before = _stats()
-        _check(gn, O.make_block_params(rng, *dims), g, *U.packed_inputs(rng, 1, 2000, 300, 1, dims[0]))
-        assert _stats() == before
-    finally:
-        del os.environ["GNX_JIT"]
+    """Run-time specialisation switched off for a process (env GNX_JIT=0, read once by the library; GNX_FLAG_NO_JIT on a call does the same for
+    that call): nothing is compiled — the statistics do not move — and the generic kernels give the oracle's result."""
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+            "import graphnets_jl_amd as gn\n"
+            "from tests import util as U\n"
+            "from tests.test_gpu_jit import _stats\n"
+            "from oracle import gn_oracle as O\n"
+            "rng = np.random.default_rng(80)\n"
+            "colptr, rowval = U.er_csc(rng, 300, 2000)\n"
+            "g = gn.GNGraphBatch.from_csc([colptr], [rowval], [300])\n"
+            "dims = ((2, 9, 1), (3, 3, 3))\n"
+            "p = O.make_block_params(rng, *dims)\n"
+            "ef, nf, gf = U.packed_inputs(rng, 1, 2000, 300, 1, dims[0])\n"
+            "before = _stats()\n"
+            "y = U.block_from_params(gn, p)(U.to_nt(gn, g, ef, nf, gf))\n"
+            "ref, scale = O.block_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)\n"
+            "[U.assert_close(U.from_jl(a), r, s, n) for n, a, r, s in zip(('ef', 'nf', 'gf'), (y.ef, y.nf, y.gf), ref, scale)]\n"
+            "print(json.dumps([before, _stats(), U.default_flags(gn)]))\n") % ROOT
+    import subprocess
+    import sys
+    import json
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GNX_JIT="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    before, after, dflt = json.loads(r.stdout.strip().splitlines()[-1])
+    assert before == after and dflt & gn._lib.FLAG_NO_JIT  # (the environment's default, read once by that process: nothing was compiled)
 
 
 def test_core_feedforward_kernel_is_kept_on_disk_too(tmp_path):

@@ -195,11 +195,8 @@ def test_wide_projected_edge_update_destination_rows_through_lds(gn, case, tmp_p
     import subprocess
     import sys
     p, g, ef, nf, gf = _pd_lds_case(gn, case)
-    os.environ["GNX_EDGE_FP32"] = "1"  # (case 0 is 128 -> 128: this test is about k_rows_gemm's two forms, not about k_edge_x6)
-    try:
-        y = _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
-    finally:
-        del os.environ["GNX_EDGE_FP32"]
+    # (case 0 is 128 -> 128: this test is about k_rows_gemm's two forms, not about k_edge_x6)
+    y = _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, flags=gn._lib.FLAG_EDGE_FP32)
     out = str(tmp_path / "two_streams.npz")
     code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
             "import graphnets_jl_amd as gn\n"
@@ -261,8 +258,7 @@ def test_wide_projected_edge_update_on_bf16_matrix_cores_hub_destinations(gn):
     _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
     gn.profile_enable(False)
     names = set(gn.profile_read()); gn.profile_reset()
-    import os
-    if not os.environ.get("GNX_EDGE_FP32"):
+    if not U.default_flags(gn) & gn._lib.FLAG_EDGE_FP32:
         assert "k_edge_x6_prep" in names, names
     pc = O.make_core_params(rng, dims)
     core = U.core_from_params(gn, pc)
@@ -276,7 +272,7 @@ def test_wide_projected_edge_update_on_bf16_matrix_cores_hub_destinations(gn):
 def test_wide_projected_edge_update_on_bf16_matrix_cores(gn, case):
     """GNBlock (128, 64, 32) => (128, ...): the projected edge update as k_edge_x6 — every fp32 product as six bf16 matrix-core terms —
     against the float64 oracle at 1e-5·scale (ef', and nf' / gf' which read its per-destination and column sums), and against the
-    fp32-MFMA form (GNX_EDGE_FP32=1: k_rows_gemm) normwise at 2e-6."""
+    fp32-MFMA form (the call's GNX_FLAG_EDGE_FP32: k_rows_gemm) normwise at 2e-6."""
     import os
     dout, act, R, graphs = _EDGE_X6_CASES[case]
     din = (128, 64, 32)
@@ -289,13 +285,9 @@ def test_wide_projected_edge_update_on_bf16_matrix_cores(gn, case):
     y = _check(gn, p, g, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf)
     gn.profile_enable(False)
     names = set(gn.profile_read()); gn.profile_reset()
-    if not os.environ.get("GNX_EDGE_FP32"):
+    if not U.default_flags(gn) & gn._lib.FLAG_EDGE_FP32:
         assert "k_edge_x6_prep" in names, names
-    os.environ["GNX_EDGE_FP32"] = "1"
-    try:
-        y0 = U.block_from_params(gn, p)(U.to_nt(gn, g, ef, nf, gf))
-    finally:
-        del os.environ["GNX_EDGE_FP32"]
+    y0 = U.block_from_params(gn, p)(U.to_nt(gn, g, ef, nf, gf), flags=gn._lib.FLAG_EDGE_FP32)
     for a, b in ((y.ef, y0.ef), (y.nf, y0.nf), (y.gf, y0.gf)):
         if a is None:
             assert b is None
@@ -309,9 +301,9 @@ def test_wide_node_projections_on_bf16_matrix_cores(gn, R, graphs, core):
     """(128, 64, 32) => (128, ...) from 4096 nodes on: the node projections Ps = Ws^T nf, Pd = Wd^T nf + b (+ gf fold per graph) of the projected edge
     update run as k_proj_x6 — both tables in one launch, six bf16 matrix-core terms per fp32 product.  GNBlock (replicas of one graph; several graphs: per-graph biases, node
     tiles that end at graph boundaries) and GNCore (gn1 on load from the statistics table) against the float64 oracle at 1e-5·scale, and
-    against the build's fp32-MFMA form (GNX_EDGE_FP32=1) normwise at 2e-6."""
+    against the build's fp32-MFMA form (GNX_FLAG_EDGE_FP32) normwise at 2e-6."""
     import os
-    if os.environ.get("GNX_EDGE_FP32"):
+    if U.default_flags(gn) & gn._lib.FLAG_EDGE_FP32:
         pytest.skip("GNX_EDGE_FP32 is set for the whole run: the six-term kernels are switched off")
     rng = np.random.default_rng(1300 + R + len(graphs))
     dims = (128, 64, 32)
@@ -337,14 +329,10 @@ def test_wide_node_projections_on_bf16_matrix_cores(gn, R, graphs, core):
     assert "k_proj_x6_prep" in names, names
     for name, got, r_, s_ in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
         U.assert_close(U.from_jl(got), r_, s_, name)
-    os.environ["GNX_EDGE_FP32"] = "1"
-    try:
-        gn.profile_enable(True)
-        y0 = layer(x)
-        gn.profile_enable(False)
-        names0 = set(gn.profile_read()); gn.profile_reset()
-    finally:
-        del os.environ["GNX_EDGE_FP32"]
+    gn.profile_enable(True)
+    y0 = layer(x, flags=gn._lib.FLAG_EDGE_FP32)
+    gn.profile_enable(False)
+    names0 = set(gn.profile_read()); gn.profile_reset()
     assert "k_proj_x6_prep" not in names0, names0
     for a, b in ((y.ef, y0.ef), (y.nf, y0.nf), (y.gf, y0.gf)):
         a, b = U.from_jl(a).astype(np.float64), U.from_jl(b).astype(np.float64)

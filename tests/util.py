@@ -133,3 +133,23 @@ def check_chain(gn, g, csc, layers, x0, what="chain", normwise=1e-5):
         assert rel <= normwise, f"{what}: end-to-end {n}: max|diff| / max|ref| = {rel:.3e} > {normwise:g}"
         out[n] = (worst[n], rel)
     return out
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def with_flags(layer, flags):
+    """`layer` (GNBlock / GNCore of the mirror) runs with these GNX_FLAG_* forms added to its default flags inside the block — the per-call
+    selection of include/gnx.h (round 5: the environment variables of the same names are process-wide defaults read ONCE, no longer per call)."""
+    old = layer.flags
+    layer.flags = old | int(flags)
+    try:
+        yield layer
+    finally:
+        layer.flags = old
+
+
+def default_flags(gn):
+    """forms the environment switched on for this process (gnx_default_flags)"""
+    return int(gn._lib.load().gnx_default_flags())
