@@ -261,6 +261,8 @@ def bench_c4(args, gn, torch, dev, c_abi=None):
     model, ps = c4_model(gn, torch, core, dev)
     for layer in model:
         layer.flags = args.flags  # the forms of every call of the run (--flags 96 = GNX_FLAG_FP32_MFMA: every product on the fp32 matrix instruction)
+        if not args.no_prepare:
+            layer.prepare()  # gnx_block_prepare / gnx_core_prepare: the weight blocks in the kernels' forms, ONCE — as `model |> device` happens once (examples/sort/sort.jl:29,89)
     ffn_fp32, edge_fp32 = fp32_forms(args.flags)
     tg = torch.Generator(device=dev); tg.manual_seed(1)
     x = gn.NT(g, torch.rand((1, g.n_edges, 10), generator=tg, device=dev).permute(2, 1, 0),
@@ -924,6 +926,7 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong (default) = ONE fixed batch — BASELINE configs[4]: 4096 graphs / 1M edges, seed 5 — partitioned over the N ranks, C5w (8M edges) "
                          "beside it; weak = N x 512 graphs / N x 1M edges (the per-GPU shard fixed)")
+    ap.add_argument("--no-prepare", action="store_true", help="--model c4: leave the layers' parameters unprepared (every forward then runs the *_prep launches, as before round 5)")
     ap.add_argument("--no-single-gpu-leg", action="store_true", help="N > 1: skip rank 0's run of the whole batch on one GPU (single_gpu_same_workload)")
     ap.add_argument("--c2-scale", type=float, default=1.0, help="scale C2's nodes and edges by this factor (size sweeps; 1 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -39,7 +39,7 @@ class Dense(C.Structure):
 
 class BlockParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("de", "dn", "dg", "oe", "on", "og")] + \
-               [("edgefn", Dense), ("nodefn", Dense), ("graphfn", Dense)]
+               [("edgefn", Dense), ("nodefn", Dense), ("graphfn", Dense), ("prepared", C.c_void_p)]
 
 
 class Chain(C.Structure):
@@ -84,7 +84,7 @@ class Ffn(C.Structure):
 
 class CoreParams(C.Structure):
     _fields_ = [("block", BlockParams), ("ln1", LayerNorm * 3), ("ln2", LayerNorm * 3), ("ff", Ffn * 3),
-                ("eps", C.c_float), ("eps_mode", C.c_int32)]
+                ("eps", C.c_float), ("eps_mode", C.c_int32), ("prepared", C.c_void_p)]
 
 
 class Layer(C.Structure):
@@ -151,6 +151,12 @@ SIGNATURES = {
     "gnx_model_destroy": (C.c_int32, [C.c_void_p]),
     "gnx_model_out_dims": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "gnx_model_forward": (C.c_int32, [C.c_void_p] + [_fp] * 6 + [C.c_uint32, C.c_void_p]),
+    "gnx_model_refresh_weights": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "gnx_block_prepare": (C.c_int32, [C.POINTER(BlockParams), C.c_void_p, _pp]),
+    "gnx_core_prepare": (C.c_int32, [C.POINTER(CoreParams), C.c_void_p, _pp]),
+    "gnx_prepared_refresh": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "gnx_prepared_destroy": (C.c_int32, [C.c_void_p]),
+    "gnx_prepared_bytes": (C.c_int64, [C.c_void_p]),
     "gnx_dist_partition": (C.c_int32, [_i64p, C.c_int64, C.c_int32, _i64p, _i64p]),
     "gnx_dist_create": (C.c_int32, [C.POINTER(C.c_int32), C.c_int32, _i64p, _i64p, C.c_int64, C.c_int32, _pp]),
     "gnx_dist_destroy": (C.c_int32, [C.c_void_p]),

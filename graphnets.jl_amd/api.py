@@ -629,6 +629,38 @@ class LayerNorm:
         return _lib.LayerNorm(g.data_ptr(), b.data_ptr())
 
 
+class _Prepared:
+    """A layer's prepared parameters (`gnx_block_prepare` / `gnx_core_prepare`, include/gnx.h): the weight blocks in the forms the matrix-core
+    kernels stage, made once — `model |> device` happens once in the reference (examples/sort/sort.jl:29,89).  The mirror remembers the
+    version counter of every tensor the planes were made from: a descriptor built after an in-place update (an optimiser step) refreshes them
+    first (`gnx_prepared_refresh`, stream-ordered with the forward that follows); tensors that were REPLACED make the planes unreachable (they
+    are looked up by the weight pointers), i.e. the forward prepares per call again until `prepare()` is called anew."""
+
+    def __init__(self, handle, device, tensors, keep):
+        self.handle, self.device, self.keep = handle, device, keep
+        self.tensors = [t for t in tensors if t is not None]
+        self.versions = [t._version for t in self.tensors]
+
+    def current(self):
+        """the handle, refreshed if a source tensor was written in place since the planes were made"""
+        if any(t._version != v for t, v in zip(self.tensors, self.versions)):
+            with torch.cuda.device(self.device):
+                check(_lib.load().gnx_prepared_refresh(self.handle, torch.cuda.current_stream(self.device).cuda_stream))
+            self.versions = [t._version for t in self.tensors]
+        return self.handle
+
+    def nbytes(self):
+        return int(_lib.load().gnx_prepared_bytes(self.handle))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().gnx_prepared_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 def _pair(in_dims, out_dims):
     if out_dims is None:
         in_dims, out_dims = in_dims  # GNBlock((in, out)) ~ `in => out`
@@ -676,7 +708,25 @@ class GNBlock:
         p.de, p.dn, p.dg = self.in_dims
         p.oe, p.on, p.og = self.out_dims
         p.edgefn, p.nodefn, p.graphfn = self.edgefn._c(keep), self.nodefn._c(keep), self.graphfn._c(keep)
+        q = getattr(self, "_prepared", None)
+        if q is not None and not (torch.is_grad_enabled() and any(t.requires_grad for t in q.tensors)):  # (a training step rewrites the weights between forwards: per-call preparation)
+            p.prepared = q.current()
         return p
+
+    def prepare(self):
+        """`gnx_block_prepare`: split / transpose / slot-permute this block's weight blocks for the matrix-core kernels ONCE (what `gpu(model)` is
+        in the Julia shim).  Forwards outside autograd then launch no preparation kernel; results are bit-identical.  Returns self."""
+        if isinstance(self.edgefn, Chain) or isinstance(self.nodefn, Chain) or isinstance(self.graphfn, Chain):
+            return self  # (Chain blocks run through gnx_chain_block_forward: nothing to prepare)
+        self._prepared = None
+        keep = []
+        p = self._c(keep)
+        dev = self.edgefn.weight.device
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            check(_lib.load().gnx_block_prepare(C.byref(p), torch.cuda.current_stream(dev).cuda_stream, C.byref(h)))
+        self._prepared = _Prepared(h, dev, [self.edgefn.weight], keep)
+        return self
 
     def _trainable(self, tensors):
         ps = [self.edgefn.weight, self.edgefn.bias, self.nodefn.weight, self.nodefn.bias, self.graphfn.weight, self.graphfn.bias]
@@ -913,7 +963,25 @@ class GNCore:
             p.ln1[i], p.ln2[i] = l1._c(keep), l2._c(keep)
             p.ff[i].fc1, p.ff[i].fc2 = ff[0]._c(keep), ff[1]._c(keep)
         p.eps, p.eps_mode = self.eps, self.eps_mode
+        q = getattr(self, "_prepared", None)
+        if q is not None and not (torch.is_grad_enabled() and any(t.requires_grad for t in q.tensors)):  # (a training step rewrites the weights between forwards: per-call preparation)
+            p.prepared = q.current()
         return p
+
+    def prepare(self):
+        """`gnx_core_prepare`: this core's weight blocks (block and FeedForwards) in the forms the matrix-core kernels stage, made ONCE.
+        Forwards outside autograd then launch no preparation kernel; results are bit-identical.  Returns self."""
+        self._prepared = None
+        self.block._prepared = None  # (the core's object covers its block)
+        keep = []
+        p = self._c(keep)
+        dev = self.block.edgefn.weight.device
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            check(_lib.load().gnx_core_prepare(C.byref(p), torch.cuda.current_stream(dev).cuda_stream, C.byref(h)))
+        src = [self.block.edgefn.weight] + [d.weight for ff in (self.ffwd.eff, self.ffwd.nff, self.ffwd.gff) for d in ff]
+        self._prepared = _Prepared(h, dev, src, keep)
+        return self
 
     def _param_list(self):
         """Order = gnx_core_grads: block (edge, node, graph: weight, bias), ln1 x3 (gamma, beta), ln2 x3, ff x3 (W1, b1, W2, b2)."""
@@ -1125,6 +1193,13 @@ class Model:
             check(_lib.load().gnx_model_forward(self.handle, _ptr(self._in["ef"]), _ptr(self._in["nf"]), _ptr(self._in["gf"]), _ptr(self._out[0]),
                                                 _ptr(self._out[1]), _ptr(self._out[2]), self.flags, torch.cuda.current_stream(dev).cuda_stream))
         return NT(self.g, *(_jl(o) for o in self._out))
+
+    def refresh_weights(self):
+        """`gnx_model_refresh_weights`: the model prepared its layers' weight blocks when it was created; after the weights' VALUES changed in
+        place (an optimiser step) call this before the next forward."""
+        dev = self.g.device
+        with torch.cuda.device(dev):
+            check(_lib.load().gnx_model_refresh_weights(self.handle, torch.cuda.current_stream(dev).cuda_stream))
 
     def __del__(self):
         try:

@@ -350,6 +350,7 @@ int32_t gnx_dist_block_forward_steps(gnx_dist* d, int32_t n_steps, const gnx_gra
       const gnx_block_params& q = *p[r];
       for (int32_t w : {q.de, q.dn, q.dg, q.oe, q.on, q.og, q.edgefn.act, q.nodefn.act, q.graphfn.act}) key.push_back((uintptr_t)(uint32_t)w);
       for (const gnx_dense* fn : {&q.edgefn, &q.nodefn, &q.graphfn}) { key.push_back((uintptr_t)fn->weight); key.push_back((uintptr_t)fn->bias); }
+      key.push_back((uintptr_t)q.prepared);
     }
     for (size_t i = 0; i < (size_t)n_steps * n; ++i) {
       key.push_back((uintptr_t)(ef ? ef[i] : nullptr)); key.push_back((uintptr_t)(nf ? nf[i] : nullptr)); key.push_back((uintptr_t)(gf ? gf[i] : nullptr));

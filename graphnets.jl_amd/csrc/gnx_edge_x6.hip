@@ -475,9 +475,18 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(3, 4)))
 
 size_t proj_x6_scratch_bytes() { return (size_t)PNOB * PSLB; }
 
+
 bool proj_x6_applies(int dn, int oe, const float* nf, const float* W, const float* out, size_t N) {
   if (form(GNX_FLAG_EDGE_FP32) || form(GNX_FLAG_PROJ_FP32)) return false;  // (the call asked for the fp32 matrix instruction throughout / for the projections alone)
   return dn == PK && oe == EOUT && N >= 4096 && (((uintptr_t)nf | (uintptr_t)W | (uintptr_t)out) & 15) == 0;
+}
+
+// Ws, Wd ([64][ldw], the first 128 columns of each) -> the fragments k_proj_x6 stages (scratch: proj_x6_scratch_bytes(), 16-byte aligned)
+int32_t launch_proj_x6_prep(const float* Ws, const float* Wd, int ldw, void* scratch, hipStream_t s) {
+  ProfScope ps("k_proj_x6_prep", s);
+  GNX_LAUNCH(k_proj_x6_prep, dim3((unsigned)((PNOB * PKS * 64 * 4 + 255) / 256)), dim3(256), 0, s, Ws, Wd, ldw, static_cast<__bf16*>(scratch));
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
 }
 
 // Ps = Ws^T z, Pd = Wd^T z + bias (per graph with bias_g), z = nf or gn1(nf) from ln_stats; scratch: proj_x6_scratch_bytes(), 16-byte aligned
@@ -488,11 +497,10 @@ int32_t launch_proj_x6(const Tile* tiles, size_t n_tiles, const float* nf, size_
   if ((uintptr_t)zn_out & 15) return fail(GNX_ERR_INVALID_ARG, "k_proj_x6: the table of normalised rows is not 16-byte aligned");
   if (ln_stats && (!ln_g || !ln_b || (((uintptr_t)ln_g | (uintptr_t)ln_b) & 15) || ((uintptr_t)ln_stats & 7))) return fail(GNX_ERR_INVALID_ARG, "k_proj_x6: LayerNorm parameters missing or misaligned");
   if ((((uintptr_t)bias | (uintptr_t)bias_g | (uintptr_t)out_s | (uintptr_t)out_d) & 15)) return fail(GNX_ERR_INVALID_ARG, "k_proj_x6: operand not 16-byte aligned");
-  __bf16* Wp = static_cast<__bf16*>(scratch);
-  {
-    ProfScope ps("k_proj_x6_prep", s);
-    GNX_LAUNCH(k_proj_x6_prep, dim3((unsigned)((PNOB * PKS * 64 * 4 + 255) / 256)), dim3(256), 0, s, Ws, Wd, ldw, Wp);
-    GNX_HIP(hipGetLastError());
+  const __bf16* Wp = static_cast<const __bf16*>(prepared_planes(PREP_PROJ, Ws, Wd, ldw));  // made once with the layer (gnx_*_prepare) ...
+  if (!Wp) {                                                                                    // ... or by a launch in front of this forward
+    if (const int32_t rc = launch_proj_x6_prep(Ws, Wd, ldw, scratch, s)) return rc;
+    Wp = static_cast<const __bf16*>(scratch);
   }
   ProjX6Args a{};
   a.tiles = tiles; a.nf = nf; a.N = N; a.ln_stats = ln_stats; a.ln_g = ln_g; a.ln_b = ln_b; a.Wp = Wp; a.bias = bias; a.bias_g = bias_g; a.G = G; a.out_s = out_s; a.out_d = out_d;
@@ -519,8 +527,11 @@ int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_
                        size_t n_agg_rows, const int* chunk_row0, int64_t R, void* scratch, hipStream_t s, bool ln_inline, float ln_eps, int ln_mode, int oe) {
   if (n_tiles == 0) return GNX_OK;
   if (oe != EOUT && (oe < 1 || oe > 32 || agg_out)) return fail(GNX_ERR_INVALID_ARG, "k_edge_x6: output width 128, or 1..32 without per-destination sums");
-  __bf16* Wp = static_cast<__bf16*>(scratch);
-  if (const int32_t rc = launch_edge_x6_prep(We, ldw, scratch, s, oe)) return rc;
+  const __bf16* Wp = static_cast<const __bf16*>(prepared_planes(PREP_EDGE, We, nullptr, oe));  // made once with the layer (gnx_*_prepare) ...
+  if (!Wp) {                                                                                        // ... or by a launch in front of this forward
+    if (const int32_t rc = launch_edge_x6_prep(We, ldw, scratch, s, oe)) return rc;
+    Wp = static_cast<const __bf16*>(scratch);
+  }
   EdgeX6Args a{};
   a.tiles = tiles; a.ef = ef; a.E = E; a.ln_stats = ln_stats; a.ln_g = ln_g; a.ln_b = ln_b; a.Wp = Wp; a.psrc = psrc; a.pdst = pdst; a.N = N;
   a.src = src; a.dst = dst; a.act = act; a.out = out; a.colsum = colsum; a.n_tiles = n_tiles; a.agg_out = agg_out; a.n_agg_rows = n_agg_rows; a.chunk_row0 = chunk_row0;

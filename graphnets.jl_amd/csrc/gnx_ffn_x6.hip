@@ -647,6 +647,14 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
 
 size_t ffn_x6_scratch_bytes(int d) { return (size_t)3 * d * 4 * d * sizeof(__bf16) * 2; }
 
+// fc1 / fc2 weights of a FeedForward at width d (64 or 128) -> the fragments k_ffn_x6 stages (scratch: ffn_x6_scratch_bytes(d), 16-byte aligned)
+int32_t launch_ffn_x6_prep(const float* W1, const float* W2, int d, void* scratch, hipStream_t s) {
+  ProfScope ps("k_ffn_x6_prep", s);
+  GNX_LAUNCH(k_ffn_x6_prep, dim3((unsigned)((d * 4 * d + 255) / 256)), dim3(256), 0, s, W1, W2, d, static_cast<__bf16*>(scratch));
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
 bool ffn_x6_applies(const float* z, int d, const gnx_ffn& ff, const float* add1, const float* add2, const float* out, size_t scratch_bytes) {
   if (form(GNX_FLAG_FFN_FP32)) return false;  // (the call asked for the fp32 matrix instruction)
   if ((d != 128 && d != 64) || ff.fc2.act != GNX_ACT_IDENTITY || scratch_bytes < ffn_x6_scratch_bytes(d)) return false;
@@ -663,11 +671,10 @@ int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, co
   if ((ln_stats || ln_inline) && (!ln || !ln->gamma || !ln->beta || ((uintptr_t)ln->gamma & 15) || ((uintptr_t)ln->beta & 15) || ((uintptr_t)ln_stats & 7)))
     return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6: LayerNorm parameters missing or misaligned");
   if (ln_inline && (ln_stats || d != 128)) return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6: statistics in the kernel are for width 128 and exclude a statistics table");
-  __bf16* Wp = static_cast<__bf16*>(scratch);
-  {
-    ProfScope ps("k_ffn_x6_prep", s);
-    GNX_LAUNCH(k_ffn_x6_prep, dim3((unsigned)((d * 4 * d + 255) / 256)), dim3(256), 0, s, ff.fc1.weight, ff.fc2.weight, d, Wp);
-    GNX_HIP(hipGetLastError());
+  const __bf16* Wp = static_cast<const __bf16*>(prepared_planes(PREP_FFN, ff.fc1.weight, ff.fc2.weight, d));  // made once with the layer (gnx_core_prepare) ...
+  if (!Wp) {                                                                                                      // ... or by a launch in front of this forward
+    if (const int32_t rc = launch_ffn_x6_prep(ff.fc1.weight, ff.fc2.weight, d, scratch, s)) return rc;
+    Wp = static_cast<const __bf16*>(scratch);
   }
   FfnX6Args a{};
   a.z = z; a.Wp = Wp; a.b1 = ff.fc1.bias; a.b2 = ff.fc2.bias; a.add1 = add1; a.add2 = add2; a.out = out; a.rows = nrows; a.act1 = ff.fc1.act;
@@ -721,18 +728,22 @@ int32_t launch_core_edge_x6(const Tile* tiles, size_t n_tiles, const float* x, s
         (uintptr_t)agg_out) & 15))
     return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6 (edge form): LayerNorm parameters missing, or an operand not 16-byte aligned");
   if (ff.fc2.act != GNX_ACT_IDENTITY) return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6 (edge form): fc2 with an activation");
-  int32_t rc = launch_edge_x6_prep(We, ldw, scratch_e, s, 128);
-  if (rc) return rc;
-  __bf16* Wp = static_cast<__bf16*>(scratch_f);
-  {
-    ProfScope ps("k_ffn_x6_prep", s);
-    GNX_LAUNCH(k_ffn_x6_prep, dim3((unsigned)((128 * 4 * 128 + 255) / 256)), dim3(256), 0, s, ff.fc1.weight, ff.fc2.weight, 128, Wp);
-    GNX_HIP(hipGetLastError());
+  // both weight blocks: made once with the layer (gnx_core_prepare), or by launches in front of this forward
+  int32_t rc = GNX_OK;
+  const __bf16* Wpe = static_cast<const __bf16*>(prepared_planes(PREP_EDGE, We, nullptr, 128));
+  if (!Wpe) {
+    if ((rc = launch_edge_x6_prep(We, ldw, scratch_e, s, 128))) return rc;
+    Wpe = static_cast<const __bf16*>(scratch_e);
+  }
+  const __bf16* Wp = static_cast<const __bf16*>(prepared_planes(PREP_FFN, ff.fc1.weight, ff.fc2.weight, 128));
+  if (!Wp) {
+    if ((rc = launch_ffn_x6_prep(ff.fc1.weight, ff.fc2.weight, 128, scratch_f, s))) return rc;
+    Wp = static_cast<const __bf16*>(scratch_f);
   }
   FfnX6Args a{};
   a.z = x; a.Wp = Wp; a.b1 = ff.fc1.bias; a.b2 = ff.fc2.bias; a.add1 = x; a.add2 = nullptr; a.out = out; a.rows = E; a.act1 = ff.fc1.act;
   a.ln_g = ln2->gamma; a.ln_b = ln2->beta; a.ln_eps = ln_eps; a.ln_mode = ln_mode;
-  a.e.tiles = tiles; a.e.ln1_g = ln1->gamma; a.e.ln1_b = ln1->beta; a.e.Wpe = static_cast<const __bf16*>(scratch_e); a.e.psrc = psrc; a.e.pdst = pdst; a.e.N = N; a.e.src = src; a.e.dst = dst;
+  a.e.tiles = tiles; a.e.ln1_g = ln1->gamma; a.e.ln1_b = ln1->beta; a.e.Wpe = Wpe; a.e.psrc = psrc; a.e.pdst = pdst; a.e.N = N; a.e.src = src; a.e.dst = dst;
   a.e.act = act; a.e.colsum = colsum; a.e.n_tiles = n_tiles; a.e.agg_out = agg_out; a.e.n_agg_rows = n_agg_rows; a.e.chunk_row0 = chunk_row0;
   ProfScope ps("k_core_edge_x6", s);
   const dim3 grid((unsigned)n_tiles, (unsigned)R);

@@ -106,6 +106,7 @@ static int32_t block_forward_impl(const gnx_graphs* h, const gnx_block_params* p
                                   const gnx_pending_update* chain_prev = nullptr, bool* chain_took = nullptr, bool* edge_x6_out = nullptr, bool ln_inline_e = false,
                                   void* ffe_scratch = nullptr) {
   FormScope forms(flags);  // the forms this call selected (gnx.h: GNX_FLAG_FFN_FP32 ...) for every dispatch predicate below
+  PreparedScope prepared(p ? p->prepared : nullptr);  // the layer's prepared weight planes, if the caller made them (a core passes its own through its block)
   int32_t rc = check_block(h, p, R);
   if (rc) return rc;
   if (phase & 1) {
@@ -307,7 +308,9 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   hipStream_t s = (hipStream_t)stream;
   if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
   FormScope forms(flags);  // the forms this call selected (gnx.h: GNX_FLAG_FFN_FP32 ...)
-  const gnx_block_params& b = p->block;
+  gnx_block_params b = p->block;
+  b.prepared = p->prepared;  // (the core's object holds its block's planes too; block.prepared is ignored)
+  PreparedScope prepared(p->prepared);
   // GNFeedForward / GNGraphNorm need all three widths > 0 and graphnetadd needs all three present
   // (gnfeedforward.jl:18, gngraphnorm.jl:10, gncore.jl:61-68); the block maps dims => dims (gncore.jl:49).
   if (b.de <= 0 || b.dn <= 0 || b.dg <= 0) return fail(GNX_ERR_DIMS, "GNCore needs all(dims .> 0) (gnfeedforward.jl:18)");

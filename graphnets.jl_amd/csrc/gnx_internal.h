@@ -141,6 +141,21 @@ struct FormScope {  // an exported forward opens one: the functions below it rea
 };
 bool form(uint32_t bit);  // is the form selected for the call this thread is in (outside a call: by the environment's defaults)
 
+// Prepared parameters (gnx.h: gnx_block_prepare / gnx_core_prepare; gnx_prepare.cpp): the weight blocks of a layer in the forms the six-term
+// kernels stage — split into bf16 planes, transposed, slot-permuted — made ONCE when the weights are uploaded instead of by a *_prep launch in
+// front of every forward.  An exported forward publishes the layer's prepared object to the launchers below it (PreparedScope); a launcher asks
+// for the planes of the very weight pointers it was handed (prepared_planes: a miss — other weights, another device, no prepared object —
+// means "run the prep launch into the workspace as before").
+enum PreparedKind : int32_t { PREP_EDGE = 1, PREP_PROJ = 2, PREP_FFN = 3 };
+struct PreparedScope {
+  explicit PreparedScope(const gnx_prepared* q);
+  ~PreparedScope();
+  PreparedScope(const PreparedScope&) = delete;
+  PreparedScope& operator=(const PreparedScope&) = delete;
+  const gnx_prepared* prev;
+};
+const void* prepared_planes(PreparedKind kind, const void* w0, const void* w1, int32_t n);
+
 void set_error(const std::string& msg);
 int32_t fail(int32_t code, const std::string& msg);
 int32_t hip_fail(hipError_t e, const char* what);

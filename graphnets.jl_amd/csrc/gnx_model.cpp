@@ -20,6 +20,7 @@ struct gnx_model {
   };
   std::vector<Layer> layers;
   std::vector<void*> owned;  // device allocations
+  std::vector<gnx_prepared*> prepared;  // parameters prepared by the model itself (layers whose descriptor carried none)
   // captured graph and the pointers it was captured with
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
@@ -84,11 +85,20 @@ int32_t gnx_model_create(const gnx_graphs* h, const gnx_layer* layers, int32_t n
     } else {
       return fail(GNX_ERR_INVALID_ARG, "gnx_model_create: unknown layer kind");
     }
+    // parameters prepared once, here, unless the caller brought its own (the weights are device pointers that stay the caller's)
+    {
+      gnx_prepared* q = nullptr;
+      int32_t rcp = GNX_OK;
+      if (L.kind == GNX_LAYER_BLOCK && !L.block.prepared) { rcp = gnx_block_prepare(&L.block, nullptr, &q); L.block.prepared = q; }
+      else if (L.kind == GNX_LAYER_CORE && !L.core.prepared) { rcp = gnx_core_prepare(&L.core, nullptr, &q); L.core.prepared = q; }
+      if (q) m->prepared.push_back(q);
+      if (rcp) { for (gnx_prepared* x : m->prepared) gnx_prepared_destroy(x); return rcp; }
+    }
     const int in[3] = {L.block.de, L.block.dn, L.block.dg}, o[3] = {L.block.oe, L.block.on, L.block.og};
     for (int t = 0; t < 3; ++t) { L.in[t] = in[t]; L.out[t] = o[t]; }
     if (i > 0)
       for (int t = 0; t < 3; ++t)
-        if (m->layers[(size_t)i - 1].out[t] != L.in[t]) return fail(GNX_ERR_DIMS, "gnx_model_create: output widths of a layer differ from the next layer's input widths");
+        if (m->layers[(size_t)i - 1].out[t] != L.in[t]) { for (gnx_prepared* x : m->prepared) gnx_prepared_destroy(x); return fail(GNX_ERR_DIMS, "gnx_model_create: output widths of a layer differ from the next layer's input widths"); }
   }
   // intermediates + workspaces (this also compiles run-time specialised kernels: gnx_block_workspace_bytes)
   auto alloc = [&](size_t bytes, void** p) -> int32_t {
@@ -102,11 +112,11 @@ int32_t gnx_model_create(const gnx_graphs* h, const gnx_layer* layers, int32_t n
   for (int i = 0; i < n_layers; ++i) {
     gnx_model::Layer& L = m->layers[(size_t)i];
     L.ws_bytes = L.kind == GNX_LAYER_BLOCK ? gnx_block_workspace_bytes(h, &L.block, R) : gnx_core_workspace_bytes(h, &L.core, R);
-    if (L.ws_bytes == 0) { for (void* q : m->owned) (void)hipFree(q); return fail(GNX_ERR_DIMS, "gnx_model_create: a layer's parameters were rejected (widths)"); }
+    if (L.ws_bytes == 0) { for (void* q : m->owned) (void)hipFree(q); for (gnx_prepared* x : m->prepared) gnx_prepared_destroy(x); return fail(GNX_ERR_DIMS, "gnx_model_create: a layer's parameters were rejected (widths)"); }
     int32_t rc = alloc(L.ws_bytes, &L.ws);
     if (!rc && i + 1 < n_layers)
       for (int t = 0; t < 3 && !rc; ++t) rc = alloc(sizeof(float) * rows[t] * (size_t)L.out[t], reinterpret_cast<void**>(&L.y[t]));
-    if (rc) { for (void* q : m->owned) (void)hipFree(q); return rc; }
+    if (rc) { for (void* q : m->owned) (void)hipFree(q); for (gnx_prepared* x : m->prepared) gnx_prepared_destroy(x); return rc; }
   }
   *out = m.release();
   return GNX_OK;
@@ -117,8 +127,17 @@ int32_t gnx_model_destroy(gnx_model* m) {
   drop_graph(m);
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
   for (void* q : m->owned) (void)hipFree(q);
+  for (gnx_prepared* q : m->prepared) gnx_prepared_destroy(q);
   delete m;
   return GNX_OK;
+}
+
+int32_t gnx_model_refresh_weights(gnx_model* m, void* stream) {
+  if (!m) return fail(GNX_ERR_INVALID_ARG, "NULL model");
+  std::lock_guard<std::mutex> lk(m->mu);
+  for (gnx_prepared* q : m->prepared)
+    if (const int32_t rc = gnx_prepared_refresh(q, stream)) return rc;
+  return GNX_OK;  // (the captured forward reads the same plane buffers: no re-capture)
 }
 
 int32_t gnx_model_out_dims(const gnx_model* m, int32_t dims[3]) {

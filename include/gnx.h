@@ -123,12 +123,18 @@ typedef struct gnx_dense {
   int32_t reserved;
 } gnx_dense;
 
+/* Prepared parameters (opaque): a layer's weight blocks in the forms the matrix-core kernels stage (bf16 planes of the exact three-way
+ * split, transposed, slot-permuted) — made ONCE per upload of the weights by gnx_block_prepare / gnx_core_prepare below instead of by
+ * preparation launches in front of every forward (`model |> device` happens once: examples/sort/sort.jl:29,89). */
+typedef struct gnx_prepared gnx_prepared;
+
 /* GNBlock((de,dn,dg) => (oe,on,og)) (src/gnblock.jl:47-61): edgefn in = de+2dn+dg, nodefn in = oe+dn+dg
  * (order agg, nf, gf: nodefninput.jl:2-6), graphfn in = oe+on+dg (order edges, nodes, gf: graphfninput.jl:2-6). */
 typedef struct gnx_block_params {
   int32_t de, dn, dg; /* input widths; 0 <=> that input is `nothing` */
   int32_t oe, on, og; /* output widths; 0 <=> that output is `nothing` (gnblock.jl:71-78) */
   gnx_dense edgefn, nodefn, graphfn;
+  const gnx_prepared* prepared; /* gnx_block_prepare's result for THESE weights, or NULL (the forward then prepares them per call) */
 } gnx_block_params;
 
 typedef struct gnx_layernorm { /* Flux LayerNorm(d): gamma .* xhat .+ beta */
@@ -147,6 +153,7 @@ typedef struct gnx_core_params {
   gnx_ffn ff[3];
   float eps;        /* 1e-5 */
   int32_t eps_mode; /* 0: (x-mu)/(sigma+eps) (Flux 0.14 normalise);  1: (x-mu)/sqrt(sigma^2+eps) */
+  const gnx_prepared* prepared; /* gnx_core_prepare's result for THESE weights (block and FeedForwards), or NULL; block.prepared is ignored */
 } gnx_core_params;
 
 typedef struct gnx_profile_entry {
@@ -201,6 +208,20 @@ GNX_API int32_t gnx_graphs_get_csc(const gnx_graphs* h, int64_t* colptr, int64_t
  * with a wide destination span, edge / node / graph tile counts}.  *bytes = the table's size (out may be NULL to ask for it).  Large batches given as CSC are
  * validated and tiled by kernels (env GNX_BUILD_CSC_DEVICE=0: on the host); the two builders' tables are bit-identical (tests/test_gpu_build.py). */
 GNX_API int32_t gnx_graphs_get_table(const gnx_graphs* h, int32_t which, void* out, int64_t capacity_bytes, int64_t* bytes);
+
+/* ---- prepared parameters ----
+ * gnx_block_prepare / gnx_core_prepare read the DEVICE weights the descriptor points at (on `stream`, asynchronously) and return an object
+ * to put into the descriptor's `prepared` field.  A forward whose descriptor carries it launches no preparation kernel (config 4: nine
+ * launches, ~45 us, per forward otherwise); outputs are bit-identical either way.  The planes are looked up by the weight POINTERS the
+ * forward is handed: a prepared object made from other weights, or on another device, is simply not used.  Contract: the weights' VALUES
+ * must not change while a prepared object made from them is in use — after an optimiser step call gnx_prepared_refresh (same stream
+ * order as the update), and destroy the object before the weights are freed.  Widths without a six-term kernel prepare nothing (an empty
+ * object).  gnx_model_create prepares the layers whose descriptors carry none (see gnx_model_refresh_weights). */
+GNX_API int32_t gnx_block_prepare(const gnx_block_params* p, void* stream, gnx_prepared** out);
+GNX_API int32_t gnx_core_prepare(const gnx_core_params* p, void* stream, gnx_prepared** out);
+GNX_API int32_t gnx_prepared_refresh(gnx_prepared* q, void* stream);
+GNX_API int32_t gnx_prepared_destroy(gnx_prepared* q);
+GNX_API int64_t gnx_prepared_bytes(const gnx_prepared* q); /* device memory the object holds */
 
 /* ---- forward: replaces (m::GNBlock)(x) (src/gnblock.jl:63-69) ---- */
 GNX_API size_t gnx_block_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t n_replicas);
@@ -417,6 +438,9 @@ GNX_API int32_t gnx_model_destroy(gnx_model* m);
 GNX_API int32_t gnx_model_out_dims(const gnx_model* m, int32_t dims[3]);
 GNX_API int32_t gnx_model_forward(gnx_model* m, const float* ef, const float* nf, const float* gf, float* ef_out, float* nf_out,
                           float* gf_out, uint32_t flags, void* stream);
+/* gnx_model_create prepares the parameters of every layer whose descriptor carries no `prepared` object (the model owns those objects).
+ * After the weights' VALUES changed (an optimiser step; same pointers) call this before the next gnx_model_forward. */
+GNX_API int32_t gnx_model_refresh_weights(gnx_model* m, void* stream);
 
 /* ---- multi-GPU: whole graphs sharded over the devices of ONE host process, gf' all-gathered ------------
  * The reference has no multi-device code (nothing to cite in /root/reference/src); the contract is BASELINE.json's north_star:

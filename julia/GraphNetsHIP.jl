@@ -168,6 +168,7 @@ end
 struct GnxBlockParams
     de::Int32; dn::Int32; dg::Int32; oe::Int32; on::Int32; og::Int32
     edgefn::GnxDense; nodefn::GnxDense; graphfn::GnxDense
+    prepared::Ptr{Cvoid}                                           # gnx_block_prepare's object for these weights, or C_NULL
 end
 struct GnxGraphsInfo
     n_graphs::Int64; n_nodes::Int64; n_edges::Int64; node_block_size::Int64; edge_block_size::Int64
@@ -371,10 +372,31 @@ function GNBlock((in, out)::Pair; dropout=0)                          # src/gnbl
     (de, dn, dg), (oe, on, og) = in, out
     GNBlock(Dense(de + 2dn + dg, oe), Dense(dn + oe + dg, on), Dense(on + oe + dg, og), dropout, Tuple(in), Tuple(out))
 end
-gpu(m::GNBlock) = ondevice(m) ? m : GNBlock(gpu(m.edgefn), gpu(m.nodefn), gpu(m.graphfn), m.dropout, m.in, m.out)
+gpu(m::GNBlock) = ondevice(m) ? m : prepare!(GNBlock(gpu(m.edgefn), gpu(m.nodefn), gpu(m.graphfn), m.dropout, m.in, m.out))
 cpu(m::GNBlock) = GNBlock(cpu(m.edgefn), cpu(m.nodefn), cpu(m.graphfn), m.dropout, m.in, m.out)
+
+# ---- prepared parameters (gnx_block_prepare / gnx_core_prepare): `model |> gpu` happens once (examples/sort/sort.jl:29,89), and so does the
+# split / transposition of the weight blocks for the matrix-core kernels.  The layers are immutable structs, so the objects live in a table
+# keyed by the device address of the layer's edge weights; EVERY upload goes through gpu(), which prepares anew and thereby replaces whatever
+# an earlier model at a recycled address left behind.  After an in-place update of the weights: refresh!(m).
+const PREPARED = Dict{UInt,Ptr{Cvoid}}()
+prepkey(m) = UInt(devptr(m isa GNBlock ? m.edgefn.weight : m.block.edgefn.weight))
+prepared_of(m) = ondevice(m) ? get(PREPARED, prepkey(m), C_NULL) : C_NULL
+function unprepare!(m)
+    q = pop!(PREPARED, prepkey(m), C_NULL)
+    q == C_NULL || check(ccall((:gnx_prepared_destroy, libgnx), Cint, (Ptr{Cvoid},), q))
+    m
+end
+refresh!(m) = (q = prepared_of(m); q == C_NULL || check(ccall((:gnx_prepared_refresh, libgnx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), q, STREAM[])); m)
+function prepare!(m::GNBlock)
+    unprepare!(m)
+    p = Ref(GnxBlockParams(m.in..., m.out..., dense_c(m.edgefn), dense_c(m.nodefn), dense_c(m.graphfn), C_NULL)); q = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:gnx_block_prepare, libgnx), Cint, (Ptr{GnxBlockParams}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), p, STREAM[], q))
+    PREPARED[prepkey(m)] = q[]
+    m
+end
 ondevice(m::GNBlock) = ondevice(m.edgefn) && ondevice(m.nodefn) && ondevice(m.graphfn)
-block_c(m::GNBlock) = GnxBlockParams(m.in..., m.out..., dense_c(m.edgefn), dense_c(m.nodefn), dense_c(m.graphfn))
+block_c(m::GNBlock) = GnxBlockParams(m.in..., m.out..., dense_c(m.edgefn), dense_c(m.nodefn), dense_c(m.graphfn), prepared_of(m))
 outarray(d::Integer, T::Integer, R::Integer) = d == 0 ? nothing : DeviceArray(d, T, R)     # zero-width outputs → nothing (gnblock.jl:71-78)
 
 # The device path of (m::GNBlock)(x): parameters and features are DeviceArrays.  ONE asynchronous gnx_block_forward on STREAM[]; the
@@ -453,10 +475,11 @@ ondevice(l::LayerNorm) = ondevice(l.γ) && ondevice(l.β)
 
 struct GnxLayerNorm; gamma::Ptr{Cfloat}; beta::Ptr{Cfloat}; end       # gnx_layernorm
 struct GnxFfn; fc1::GnxDense; fc2::GnxDense; end                       # gnx_ffn
-struct GnxCoreParams                                                   # gnx_core_params (344 bytes)
+struct GnxCoreParams                                                   # gnx_core_params (360 bytes)
     block::GnxBlockParams
     ln1::NTuple{3,GnxLayerNorm}; ln2::NTuple{3,GnxLayerNorm}; ff::NTuple{3,GnxFfn}
     eps::Cfloat; eps_mode::Int32
+    prepared::Ptr{Cvoid}                                               # gnx_core_prepare's object for these weights, or C_NULL
 end
 
 struct GNCore
@@ -471,10 +494,18 @@ function GNCore(dims; dropout=0)                                       # src/gnc
     GNCore(GNBlock(d => d; dropout), map(k -> (Dense(k, 4k, :relu), Dense(4k, k)), d), map(LayerNorm, d), map(LayerNorm, d), d)
 end
 ondevice(m::GNCore) = ondevice(m.block) && all(t -> ondevice(t[1]) && ondevice(t[2]), m.ffwd) && all(ondevice, m.gn1) && all(ondevice, m.gn2)
-gpu(m::GNCore) = ondevice(m) ? m : GNCore(gpu(m.block), map(t -> (gpu(t[1]), gpu(t[2])), m.ffwd), map(gpu, m.gn1), map(gpu, m.gn2), m.dims)
+gpu(m::GNCore) = ondevice(m) ? m : prepare!(GNCore(gpu(m.block), map(t -> (gpu(t[1]), gpu(t[2])), m.ffwd), map(gpu, m.gn1), map(gpu, m.gn2), m.dims))
 cpu(m::GNCore) = GNCore(cpu(m.block), map(t -> (cpu(t[1]), cpu(t[2])), m.ffwd), map(cpu, m.gn1), map(cpu, m.gn2), m.dims)
 ln_c(l::LayerNorm) = GnxLayerNorm(devptr(l.γ), devptr(l.β))
-core_c(m::GNCore) = GnxCoreParams(block_c(m.block), map(ln_c, m.gn1), map(ln_c, m.gn2), map(t -> GnxFfn(dense_c(t[1]), dense_c(t[2])), m.ffwd), 1f-5, Int32(0))
+function prepare!(m::GNCore)                                           # the core's object holds its block's planes too
+    unprepare!(m)
+    blk = GnxBlockParams(m.block.in..., m.block.out..., dense_c(m.block.edgefn), dense_c(m.block.nodefn), dense_c(m.block.graphfn), C_NULL)
+    p = Ref(GnxCoreParams(blk, map(ln_c, m.gn1), map(ln_c, m.gn2), map(t -> GnxFfn(dense_c(t[1]), dense_c(t[2])), m.ffwd), 1f-5, Int32(0), C_NULL)); q = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:gnx_core_prepare, libgnx), Cint, (Ptr{GnxCoreParams}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), p, STREAM[], q))
+    PREPARED[prepkey(m)] = q[]
+    m
+end
+core_c(m::GNCore) = GnxCoreParams(block_c(m.block), map(ln_c, m.gn1), map(ln_c, m.gn2), map(t -> GnxFfn(dense_c(t[1]), dense_c(t[2])), m.ffwd), 1f-5, Int32(0), prepared_of(m))
 
 function core_device(m::GNCore, x)                                     # ONE asynchronous gnx_core_forward; see block_device
     (; graphs, ef, nf, gf) = x

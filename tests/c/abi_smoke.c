@@ -40,7 +40,7 @@ static float* to_device(const float* h, size_t n) {
 
 int main(int argc, char** argv) {
   /* layout facts a binding relies on */
-  if (sizeof(gnx_dense) != 24 || sizeof(gnx_block_params) != 96 || sizeof(gnx_graphs_info) != 64 || sizeof(gnx_profile_entry) != 72) {
+  if (sizeof(gnx_dense) != 24 || sizeof(gnx_block_params) != 104 || sizeof(gnx_core_params) != 360 || sizeof(gnx_graphs_info) != 64 || sizeof(gnx_profile_entry) != 72) {
     fprintf(stderr, "struct layout differs from the documented one\n");
     return 1;
   }

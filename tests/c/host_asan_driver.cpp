@@ -35,6 +35,11 @@ int32_t gnx_block_forward(const gnx_graphs*, const gnx_block_params*, const floa
                           size_t, uint32_t, void*) { return 100; }
 int32_t gnx_core_forward(const gnx_graphs*, const gnx_core_params*, const float*, const float*, const float*, int64_t, float*, float*, float*, void*,
                          size_t, uint32_t, void*) { return 100; }
+// prepared parameters (gnx_prepare.cpp launches kernels): the model asks for them at create — "nothing to prepare" here
+int32_t gnx_block_prepare(const gnx_block_params*, void*, gnx_prepared** out) { *out = nullptr; return GNX_OK; }
+int32_t gnx_core_prepare(const gnx_core_params*, void*, gnx_prepared** out) { *out = nullptr; return GNX_OK; }
+int32_t gnx_prepared_refresh(gnx_prepared*, void*) { return GNX_OK; }
+int32_t gnx_prepared_destroy(gnx_prepared*) { return GNX_OK; }
 }
 
 static int failures = 0;

@@ -43,8 +43,8 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_struct_layouts_match_header():
     import graphnets_jl_amd as gn
     L = gn._lib
-    assert C.sizeof(L.Dense) == 24 and C.sizeof(L.BlockParams) == 24 + 3 * 24
-    assert C.sizeof(L.CoreParams) == 96 + 6 * 16 + 3 * 48 + 8
+    assert C.sizeof(L.Dense) == 24 and C.sizeof(L.BlockParams) == 24 + 3 * 24 + 8  # (+ the `prepared` pointer)
+    assert C.sizeof(L.CoreParams) == 104 + 6 * 16 + 3 * 48 + 8 + 8
     assert C.sizeof(L.GraphsInfo) == 64 and C.sizeof(L.ProfileEntry) == 72
 
 
