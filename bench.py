@@ -1044,6 +1044,8 @@ def main():
                 "one_time_init": round(init_ms, 3),
                 "what": "GNGraphBatch construction from Python, end to end: best of the calls, and the first call of this batch (one_time_init = the first build of the PROCESS, on an 80k-edge graph: library load, context, the builder's code objects and scratch).  from_csc = a LIST of per-graph arrays (numpy "
                         "concatenates them: ~2.4 ms for 4096 graphs); from_csc_packed = the concatenated arrays as they are (int64; _int32: int32 indices).  "
+                        "from_dense_uint8 = the reference's own input form, a LIST of dense 0/1 matrices (per-matrix Python work: ~1.5 us each); from_dense_packed = the same matrices as ONE uint8 buffer "
+                        "(pageable numpy memory through the library's pinned staging pair; _pinned: one DMA — dense_bytes over PCIe bound it; _device: a device tensor, read where it is).  "
                         "Validation, device-format arrays and both tile tables are built by kernels (csrc/gnx_build_csc.hip); the matrix-core path's tables by its workspace query"}
     E, N, G = g.n_edges, g.n_nodes, g.n_graphs
     if workload == "hetero" and sum(int(n) * int(n) for n in nn) <= 2e8:  # the reference's own input form: dense 0/1 matrices
@@ -1061,7 +1063,20 @@ def main():
         batch_ms["from_dense_uint8"] = round(min(td), 3)
         batch_ms["from_dense_uint8_first_call"] = round(td[0], 3)  # (includes the one-off allocation of the 64 MB pinned staging buffers)
         assert gd.n_edges == E and gd.n_nodes == N
-        del gd, adjs
+        # the same matrices as ONE buffer (from_dense_packed): pageable numpy memory, a pinned tensor (one DMA), a device tensor (no copy)
+        cat = np.concatenate([a.reshape(-1) for a in adjs])
+        for form, buf in (("from_dense_packed", cat), ("from_dense_packed_pinned", torch.from_numpy(cat).pin_memory()), ("from_dense_packed_device", torch.from_numpy(cat).to(dev))):
+            tpk = []
+            for _ in range(4):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                gd = gn.GNGraphBatch.from_dense_packed(buf, nn, device=dev)
+                torch.cuda.synchronize(dev)
+                tpk.append((time.perf_counter() - t0) * 1e3)
+            batch_ms[form] = round(min(tpk), 3)
+            assert gd.n_edges == E and gd.n_nodes == N
+        batch_ms["dense_bytes"] = int(cat.nbytes)
+        del gd, adjs, cat, buf
     blk = bench_weights(gn, din, dout, dev)
     (de, dn, dg), (oe, on, og) = din, dout
     plan = gn.BlockPlan(blk, g, R=1, flags=args.flags)

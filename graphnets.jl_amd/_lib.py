@@ -114,6 +114,7 @@ SIGNATURES = {
     "gnx_default_flags": (C.c_uint32, []),
     "gnx_last_error": (C.c_char_p, []),
     "gnx_graphs_create_dense": (C.c_int32, [_pp, _i64p, C.c_int64, C.c_int32, C.c_int32, _pp]),
+    "gnx_graphs_create_dense_packed": (C.c_int32, [C.c_void_p, C.c_int64, _i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _pp]),
     "gnx_graphs_create_csc": (C.c_int32, [_pp, _pp, _i64p, C.c_int64, C.c_int32, _pp]),
     "gnx_graphs_create_csc_packed": (C.c_int32, [_i64p, _i64p, _i64p, C.c_int64, C.c_int32, _pp]),
     "gnx_graphs_create_csc_cat": (C.c_int32, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, _i64p, C.c_int64, C.c_int32, C.c_int32, _pp]),

@@ -90,13 +90,22 @@ class GNGraphBatch:
     """`GNGraphBatch(adj_mats)`; `GNGraphBatch.from_csc(colptrs, rowvals, n_nodes)` is the sparse constructor
     (API extension: dense N×N input cannot hold BASELINE configs 2-5)."""
 
-    def __init__(self, adj_mats=None, *, device=None, _csc=None):
+    def __init__(self, adj_mats=None, *, device=None, _csc=None, _dense_packed=None):
         lib = _lib.load()
         self.device = _device(device)
         self._h = C.c_void_p(None)
         self._ws = {}
         self._masks = None
         keep = []
+        if _dense_packed is not None:
+            buf, nn, kind, on_device, nbytes, ptr = _dense_packed
+            with torch.cuda.device(self.device):
+                check(lib.gnx_graphs_create_dense_packed(ptr, nbytes, nn.ctypes.data_as(C.POINTER(C.c_int64)), int(nn.size), kind, 1, 1 if on_device else 0,
+                                                         C.byref(self._h)))
+            self._adj_mats = None
+            self._packed_adj = (buf, nn)  # adj_mats: views of the packed buffer, made when somebody asks (unbatch on a matrix-form batch)
+            self._finish_init(lib)
+            return
         if _csc is not None:  # (array preparation and the length check need no device)
             colptrs, rowvals, n_nodes = _csc
             nn = np.ascontiguousarray(n_nodes, dtype=np.int64)
@@ -124,13 +133,13 @@ class GNGraphBatch:
                 # (the C entry point checks both lengths against what the colptr arrays announce and never reads past them)
                 check(lib.gnx_graphs_create_csc_cat(cpc.ctypes.data, cpc.size, rvc.ctypes.data if rvc.size else None, rvc.size,
                                                     nn.ctypes.data_as(C.POINTER(C.c_int64)), G, 0, cpc.dtype.itemsize * 8, C.byref(self._h)))
-                self.adj_mats = None
+                self._adj_mats = None
             else:
                 mats = [_np(a) for a in adj_mats]
                 for a in mats:
                     assert a.ndim == 2, "adjacency matrix must be 2-D (checks.jl:11)"
                     assert a.shape[0] == a.shape[1], "adjacency matrix must be square"
-                self.adj_mats = mats
+                self._adj_mats = mats
                 conv, kind = [], _lib.ELEM_I64
                 native = _NATIVE_ELEM  # dtype.char -> element kind the ABI reads as it is (a bool / uint8 matrix is 8x fewer bytes than int64)
                 for a in mats:  # (a dict lookup per matrix: the dtype comparisons of the first version cost 10 us each — 41 ms for 4096 graphs)
@@ -149,6 +158,9 @@ class GNGraphBatch:
                 ptrs = (C.c_void_p * max(G, 1))(*[b.ctypes.data for _, b in conv])
                 nn = np.asarray([a.shape[0] for a in mats], dtype=np.int64)
                 check(lib.gnx_graphs_create_dense(ptrs, nn.ctypes.data_as(C.POINTER(C.c_int64)), G, kind, 1, C.byref(self._h)))
+        self._finish_init(lib)
+
+    def _finish_init(self, lib):
         info = _lib.GraphsInfo()
         check(lib.gnx_graphs_get_info(self._h, C.byref(info)))
         self.n_graphs, self.n_nodes, self.n_edges = info.n_graphs, info.n_nodes, info.n_edges
@@ -158,6 +170,52 @@ class GNGraphBatch:
         self.edge_off = np.zeros(self.n_graphs + 1, dtype=np.int64)
         check(lib.gnx_graphs_get_offsets(self._h, self.node_off.ctypes.data_as(C.POINTER(C.c_int64)),
                                          self.edge_off.ctypes.data_as(C.POINTER(C.c_int64))))
+
+    @property
+    def adj_mats(self):
+        """the adjacency matrices the batch was made from (None for CSC input); for a packed dense batch: views of the packed buffer"""
+        if self._adj_mats is None and getattr(self, "_packed_adj", None) is not None:
+            buf, nn = self._packed_adj
+            flat = buf.detach().cpu().numpy() if isinstance(buf, torch.Tensor) else buf
+            offs = np.concatenate([[0], np.cumsum(nn * nn)])
+            self._adj_mats = [flat[offs[i]:offs[i + 1]].reshape(int(n), int(n)) for i, n in enumerate(nn)]
+        return self._adj_mats
+
+    @adj_mats.setter
+    def adj_mats(self, v):
+        self._adj_mats = v
+
+    @classmethod
+    def from_dense_packed(cls, adj_cat, n_nodes, device=None):
+        """`batch`'s input form (dense 0/1 matrices, src/batch.jl:53-64) as ONE buffer: adj_cat = the graphs' matrices one after the other, each
+        row-major (numpy's order; A[i, j] = 1 <=> edge i -> j), as a 1-D numpy array or torch tensor of uint8 / bool / int32 / int64 / float32 /
+        float64 with sum(n_g^2) elements.  No per-graph Python work (a list of 4096 matrices costs ~6 ms of attribute access and pointer
+        extraction before the library is even called).  A CUDA tensor is read where it is (no copy); a pinned CPU tensor travels as one DMA;
+        pageable memory goes through the library's pinned staging buffers."""
+        nn = np.ascontiguousarray(n_nodes, dtype=np.int64)
+        if isinstance(adj_cat, torch.Tensor):
+            t = adj_cat.reshape(-1)
+            if t.dtype == torch.bool:
+                t = t.view(torch.uint8)
+            kind = {torch.uint8: _lib.ELEM_U8, torch.int32: _lib.ELEM_I32, torch.int64: _lib.ELEM_I64, torch.float32: _lib.ELEM_F32, torch.float64: _lib.ELEM_F64}.get(t.dtype)
+            if kind is None:
+                raise ValueError(f"adjacency element type {t.dtype} is not supported")
+            t = t.contiguous()
+            packed = (t, nn, kind, t.is_cuda, t.numel() * t.element_size(), t.data_ptr())
+            device = t.device if t.is_cuda and device is None else device
+        else:
+            a = np.asarray(adj_cat).reshape(-1)
+            kind = _NATIVE_ELEM.get(a.dtype.char)
+            if kind is None:
+                kind, a = (_lib.ELEM_F64, a.astype(np.float64)) if a.dtype.kind == "f" else (_lib.ELEM_I64, a.astype(np.int64))
+            elif a.dtype.char == "?":
+                a = a.view(np.uint8)
+            a = np.ascontiguousarray(a)
+            packed = (a, nn, kind, False, a.nbytes, a.ctypes.data)
+        numel = packed[0].numel() if isinstance(packed[0], torch.Tensor) else packed[0].size
+        if nn.size == 0 or (nn <= 0).any() or numel != int((nn * nn).sum()):
+            raise ValueError("adj_cat must hold sum(n_nodes^2) elements of n_nodes >= 1")
+        return cls(device=device, _dense_packed=packed)
 
     @classmethod
     def from_csc(cls, colptrs, rowvals, n_nodes, device=None):

@@ -95,126 +95,163 @@ __global__ void k_gather_offsets(const int* __restrict__ cp, const int* __restri
   if (g <= G) edge_off[g] = cp[node_off[g]];
 }
 
+// {bad flag, number of edges} in one small readback
+__global__ void k_adj_summary(const int* __restrict__ cp, int N, const int* __restrict__ bad, int* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { out[0] = *bad; out[1] = cp[N]; }
+}
+
 // Returns 1 when the device path does not apply (caller falls back to the host scan).
-// keep != nullptr: the CSC stays on the device (keep->d_colptr [N+1], keep->d_rowval [E]: the caller frees them) and only the G + 1 edge
-// offsets come back — the handle's tables are then built by the device builder (gnx_build_csc.hip) without a round trip through the host
-int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int64_t G, int32_t elem_kind, int32_t row_major,
+// keep != nullptr: the CSC stays on the device (keep->d_colptr [N+1], keep->d_rowval [E], inside blocks the caller hands back to the arena cache
+// with release_dense_csc) and only the G + 1 edge offsets come back — the handle's tables are then built by the device builder
+// (gnx_build_csc.hip) without a round trip through the host.
+// The matrices: adj[g] (G host pointers), or — packed != nullptr — ONE buffer holding them one after the other, on the host (packed_on_device
+// = 0; pinned memory travels as one DMA, pageable memory through the pinned staging pair) or already on the device (1: no copy at all).
+// Device memory comes from the process-wide cache of released blocks (arena_take / arena_give): a loop that batches every iteration
+// allocates nothing after its first build.
+int32_t build_csc_on_device(const void* const* adj, const void* packed, int packed_on_device, const int64_t* n_nodes, int64_t G, int32_t elem_kind, int32_t row_major,
                             gnx::vec_i64& h_colptr, gnx::vec_i64& h_rowval, const std::vector<int64_t>& h_node_off, DenseCscOnDevice* keep) {
   const int64_t N = h_node_off.back();
   if (N <= 0 || N + 1 > (int64_t)SCAN_B * SCAN_B) return 1;  // two-level scan capacity
   static const size_t esz_tab[5] = {1, 4, 8, 4, 8};
   const size_t esz = esz_tab[elem_kind];
-  std::vector<int64_t> adj_off(G);
-  std::vector<int32_t> n32(G), node_off32(G + 1);
+  int dev = 0;
+  { const hipError_t e = hipGetDevice(&dev); if (e != hipSuccess) return hip_fail(e, "hipGetDevice"); }
+  // host-side metadata in ONE array: adj_off [G] int64 | n [G] int32 | node_off [G+1] int32
+  const size_t meta_bytes = align_up((size_t)G * 8, 16) + align_up((size_t)G * 4, 16) + align_up((size_t)(G + 1) * 4, 16);
+  std::vector<char> meta(meta_bytes);
+  int64_t* adj_off = reinterpret_cast<int64_t*>(meta.data());
+  int32_t* n32 = reinterpret_cast<int32_t*>(meta.data() + align_up((size_t)G * 8, 16));
+  int32_t* node_off32 = reinterpret_cast<int32_t*>(meta.data() + align_up((size_t)G * 8, 16) + align_up((size_t)G * 4, 16));
   int64_t total = 0;
   for (int64_t g = 0; g < G; ++g) { adj_off[g] = total; total += n_nodes[g] * n_nodes[g]; n32[g] = (int32_t)n_nodes[g]; node_off32[g] = (int32_t)h_node_off[g]; }
   node_off32[G] = (int32_t)N;
-  void* d_adj = nullptr; int64_t* d_off = nullptr; int32_t *d_n = nullptr, *d_noff = nullptr, *d_cnt = nullptr, *d_cp = nullptr, *d_bs = nullptr, *d_bp = nullptr, *d_rv = nullptr, *d_bad = nullptr;
-  auto cleanup = [&]() { for (void* p : {d_adj, (void*)d_off, (void*)d_n, (void*)d_noff, (void*)d_cnt, (void*)d_cp, (void*)d_bs, (void*)d_bp, (void*)d_rv, (void*)d_bad}) (void)hipFree(p); };
+  const size_t bytes_total = (size_t)total * esz;
+  // one device block for everything temporary: [adjacency (unless it is on the device already) | meta | counts | block sums x 2 | bad | summary | colptr]
+  size_t off = 0;
+  auto take = [&](size_t b) { const size_t at = off; off += align_up(std::max<size_t>(b, 16), 256); return at; };
+  const size_t o_adj = take(packed_on_device ? 16 : bytes_total), o_meta = take(meta_bytes), o_cnt = take((size_t)(N + 1) * 4), o_bs = take(SCAN_B * 4), o_bad = take(16);
+  const size_t o_zero_end = off;  // [o_cnt, o_zero_end) starts as zeros
+  const size_t o_bp = take(SCAN_B * 4), o_sum = take(16), o_cp = take((size_t)(N + 1) * 4), o_eoff = take((size_t)(G + 1) * 4);
+  size_t got = 0;
+  char* blk = static_cast<char*>(arena_take(dev, off, &got));
+  if (!blk) { const hipError_t e = hipMalloc((void**)&blk, off); if (e != hipSuccess) return hip_fail(e, "dense batch: device block"); got = off; }
+  void* rv_blk = nullptr;
+  size_t rv_got = 0;
+  auto cleanup = [&]() { arena_give(dev, blk, got); if (rv_blk) arena_give(dev, rv_blk, rv_got); };
 #define GNX_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { cleanup(); return hip_fail(_e, #expr); } } while (0)
-  GNX_TRY(hipMalloc(&d_adj, (size_t)total * esz));
-  {
-    // The G matrices live in G separate pageable host arrays.  One hipMemcpy each is a driver round trip per graph (4096 graphs:
-    // ~200 ms); instead they are packed into two pinned staging buffers that alternate — while one travels (asynchronous copy,
-    // full PCIe rate) the host fills the other — so the upload costs one host memcpy of the bytes plus a handful of DMA transfers.
-    // The staging buffers are process-wide and PORTABLE pinned memory (usable from every device: a one-process-many-devices host —
-    // gnx_dist_*, a Julia session — builds handles on devices 1..n-1 too); the two events belong to the CURRENT device and live for
-    // this call only (an event of device 0 cannot be recorded on a stream of device r).  A failure to set the staging up is not an
-    // error of the batch: the caller falls back to the host scan (return 1).
-    static std::mutex stage_mu;
-    static char* stage[2] = {nullptr, nullptr};
-    constexpr size_t STAGE = (size_t)32 << 20;
-    std::lock_guard<std::mutex> lk(stage_mu);
-    hipEvent_t stage_ev[2] = {nullptr, nullptr};
-    struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int b = 0; b < 2; ++b) if (e[b]) (void)hipEventDestroy(e[b]); } } ev_guard{stage_ev};
-    for (int b = 0; b < 2; ++b) {
-      if (!stage[b] && hipHostMalloc((void**)&stage[b], STAGE, hipHostMallocPortable) != hipSuccess) { stage[b] = nullptr; (void)hipGetLastError(); cleanup(); return 1; }
-      if (hipEventCreateWithFlags(&stage_ev[b], hipEventDisableTiming) != hipSuccess) { stage_ev[b] = nullptr; (void)hipGetLastError(); cleanup(); return 1; }
-    }
-    const size_t bytes_total = (size_t)total * esz;
-    size_t done = 0;      // bytes of the packed adjacency stream already handed to a copy
-    int64_t g = 0;        // current graph
-    size_t g_done = 0;    // bytes of graph g already staged
-    int buf = 0;
-    bool in_flight[2] = {false, false};
-    while (done < bytes_total) {
-      if (in_flight[buf]) { GNX_TRY(hipEventSynchronize(stage_ev[buf])); in_flight[buf] = false; }
-      size_t fill = 0;
-      struct Seg { char* dst; const char* src; size_t bytes; };
-      std::vector<Seg> segs;
-      while (fill < STAGE && g < G) {
-        const size_t gbytes = (size_t)(n_nodes[g] * n_nodes[g]) * esz;
-        const size_t take = std::min(gbytes - g_done, STAGE - fill);
-        segs.push_back({stage[buf] + fill, static_cast<const char*>(adj[g]) + g_done, take});
-        fill += take; g_done += take;
-        if (g_done == gbytes) { ++g; g_done = 0; }
+  const void* d_adj = packed_on_device ? packed : blk + o_adj;
+  if (!packed_on_device) {
+    hipPointerAttribute_t at{};
+    const bool pinned = packed && hipPointerGetAttributes(&at, packed) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    if (pinned) {
+      GNX_TRY(hipMemcpyAsync(blk + o_adj, packed, bytes_total, hipMemcpyHostToDevice, nullptr));  // one DMA at the link's rate
+    } else {
+      // Pageable host memory (G separate arrays, or one packed buffer).  One hipMemcpy per graph is a driver round trip per graph (4096
+      // graphs: ~200 ms); instead the bytes are packed into two pinned staging buffers that alternate — while one travels (asynchronous copy,
+      // full PCIe rate) the host fills the other — so the upload costs one host memcpy of the bytes plus a handful of DMA transfers.
+      // The staging buffers are process-wide and PORTABLE pinned memory (usable from every device: a one-process-many-devices host —
+      // gnx_dist_*, a Julia session — builds handles on devices 1..n-1 too); the two events belong to the CURRENT device and live for
+      // this call only (an event of device 0 cannot be recorded on a stream of device r).  A failure to set the staging up is not an
+      // error of the batch: the caller falls back to the host scan (return 1).
+      static std::mutex stage_mu;
+      static char* stage[2] = {nullptr, nullptr};
+      constexpr size_t STAGE = (size_t)32 << 20;
+      std::lock_guard<std::mutex> lk(stage_mu);
+      hipEvent_t stage_ev[2] = {nullptr, nullptr};
+      struct EvGuard { hipEvent_t* e; ~EvGuard() { for (int b = 0; b < 2; ++b) if (e[b]) (void)hipEventDestroy(e[b]); } } ev_guard{stage_ev};
+      for (int b = 0; b < 2; ++b) {
+        if (!stage[b] && hipHostMalloc((void**)&stage[b], STAGE, hipHostMallocPortable) != hipSuccess) { stage[b] = nullptr; (void)hipGetLastError(); cleanup(); return 1; }
+        if (hipEventCreateWithFlags(&stage_ev[b], hipEventDisableTiming) != hipSuccess) { stage_ev[b] = nullptr; (void)hipGetLastError(); cleanup(); return 1; }
       }
-      {
-        // the host copy into the staging buffer is what this upload costs (one thread: ~10 GB/s against the link's ~50): a few threads
-        // take contiguous runs of the segments (about equal bytes each)
-        const int n_thr = fill >= ((size_t)4 << 20) ? (int)std::min<unsigned>(4, std::max(1u, std::thread::hardware_concurrency())) : 1;
-        auto copy_range = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) memcpy(segs[i].dst, segs[i].src, segs[i].bytes); };
-        if (n_thr <= 1) copy_range(0, segs.size());
-        else {
-          std::vector<size_t> cut((size_t)n_thr + 1, segs.size());
-          cut[0] = 0;
-          size_t acc = 0; int t = 1;
-          for (size_t i = 0; i < segs.size() && t < n_thr; ++i) { acc += segs[i].bytes; if (acc >= fill * (size_t)t / n_thr) cut[(size_t)t++] = i + 1; }
-          std::vector<std::thread> thr;
-          for (int i = 1; i < n_thr; ++i) thr.emplace_back(copy_range, cut[(size_t)i], cut[(size_t)i + 1]);
-          copy_range(cut[0], cut[1]);
-          for (auto& th : thr) th.join();
+      size_t done = 0;      // bytes of the packed adjacency stream already handed to a copy
+      int64_t g = 0;        // current graph
+      size_t g_done = 0;    // bytes of graph g already staged
+      int buf = 0;
+      bool in_flight[2] = {false, false};
+      const unsigned n_thr_max = std::min<unsigned>(4, std::max(1u, std::thread::hardware_concurrency()));
+      while (done < bytes_total) {
+        if (in_flight[buf]) { GNX_TRY(hipEventSynchronize(stage_ev[buf])); in_flight[buf] = false; }
+        size_t fill = 0;
+        struct Seg { char* dst; const char* src; size_t bytes; };
+        std::vector<Seg> segs;
+        if (packed) {  // one contiguous source: equal pieces for the copy threads
+          fill = std::min(STAGE, bytes_total - done);
+          const size_t piece = align_up((fill + n_thr_max - 1) / n_thr_max, 4096);
+          for (size_t o = 0; o < fill; o += piece) segs.push_back({stage[buf] + o, static_cast<const char*>(packed) + done + o, std::min(piece, fill - o)});
+        } else {
+          while (fill < STAGE && g < G) {
+            const size_t gbytes = (size_t)(n_nodes[g] * n_nodes[g]) * esz;
+            const size_t tk = std::min(gbytes - g_done, STAGE - fill);
+            segs.push_back({stage[buf] + fill, static_cast<const char*>(adj[g]) + g_done, tk});
+            fill += tk; g_done += tk;
+            if (g_done == gbytes) { ++g; g_done = 0; }
+          }
         }
+        {
+          // the host copy into the staging buffer is what this upload costs (one thread: ~10 GB/s against the link's ~50): a few threads
+          // take contiguous runs of the segments (about equal bytes each)
+          const int n_thr = fill >= ((size_t)4 << 20) ? (int)n_thr_max : 1;
+          auto copy_range = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) memcpy(segs[i].dst, segs[i].src, segs[i].bytes); };
+          if (n_thr <= 1) copy_range(0, segs.size());
+          else {
+            std::vector<size_t> cut((size_t)n_thr + 1, segs.size());
+            cut[0] = 0;
+            size_t acc = 0; int t = 1;
+            for (size_t i = 0; i < segs.size() && t < n_thr; ++i) { acc += segs[i].bytes; if (acc >= fill * (size_t)t / n_thr) cut[(size_t)t++] = i + 1; }
+            std::vector<std::thread> thr;
+            for (int i = 1; i < n_thr; ++i) thr.emplace_back(copy_range, cut[(size_t)i], cut[(size_t)i + 1]);
+            copy_range(cut[0], cut[1]);
+            for (auto& th : thr) th.join();
+          }
+        }
+        GNX_TRY(hipMemcpyAsync(blk + o_adj + done, stage[buf], fill, hipMemcpyHostToDevice, nullptr));
+        GNX_TRY(hipEventRecord(stage_ev[buf], nullptr));
+        in_flight[buf] = true;
+        done += fill;
+        buf ^= 1;
       }
-      GNX_TRY(hipMemcpyAsync(static_cast<char*>(d_adj) + done, stage[buf], fill, hipMemcpyHostToDevice, nullptr));
-      GNX_TRY(hipEventRecord(stage_ev[buf], nullptr));
-      in_flight[buf] = true;
-      done += fill;
-      buf ^= 1;
+      for (int b = 0; b < 2; ++b)
+        if (in_flight[b]) GNX_TRY(hipEventSynchronize(stage_ev[b]));
     }
-    for (int b = 0; b < 2; ++b)
-      if (in_flight[b]) GNX_TRY(hipEventSynchronize(stage_ev[b]));
   }
-  GNX_TRY(hipMalloc((void**)&d_off, G * sizeof(int64_t)));
-  GNX_TRY(hipMalloc((void**)&d_n, G * sizeof(int32_t)));
-  GNX_TRY(hipMalloc((void**)&d_noff, (G + 1) * sizeof(int32_t)));
-  GNX_TRY(hipMemcpy(d_off, adj_off.data(), G * sizeof(int64_t), hipMemcpyHostToDevice));
-  GNX_TRY(hipMemcpy(d_n, n32.data(), G * sizeof(int32_t), hipMemcpyHostToDevice));
-  GNX_TRY(hipMemcpy(d_noff, node_off32.data(), (G + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  GNX_TRY(hipMemcpyAsync(blk + o_meta, meta.data(), meta_bytes, hipMemcpyHostToDevice, nullptr));
+  GNX_TRY(hipMemsetAsync(blk + o_cnt, 0, o_zero_end - o_cnt, nullptr));
+  const int64_t* d_off = reinterpret_cast<const int64_t*>(blk + o_meta);
+  const int32_t* d_n = reinterpret_cast<const int32_t*>(blk + o_meta + align_up((size_t)G * 8, 16));
+  const int32_t* d_noff = reinterpret_cast<const int32_t*>(blk + o_meta + align_up((size_t)G * 8, 16) + align_up((size_t)G * 4, 16));
+  int32_t* d_cnt = reinterpret_cast<int32_t*>(blk + o_cnt);
+  int32_t* d_bs = reinterpret_cast<int32_t*>(blk + o_bs);
+  int32_t* d_bad = reinterpret_cast<int32_t*>(blk + o_bad);
+  int32_t* d_bp = reinterpret_cast<int32_t*>(blk + o_bp);
+  int32_t* d_sum = reinterpret_cast<int32_t*>(blk + o_sum);
+  int32_t* d_cp = reinterpret_cast<int32_t*>(blk + o_cp);
   const int nb = (int)((N + 1 + SCAN_B - 1) / SCAN_B);
-  GNX_TRY(hipMalloc((void**)&d_cnt, (N + 1) * sizeof(int32_t)));
-  GNX_TRY(hipMalloc((void**)&d_cp, (N + 1) * sizeof(int32_t)));
-  GNX_TRY(hipMalloc((void**)&d_bs, SCAN_B * sizeof(int32_t)));
-  GNX_TRY(hipMalloc((void**)&d_bp, SCAN_B * sizeof(int32_t)));
-  GNX_TRY(hipMalloc((void**)&d_bad, sizeof(int32_t)));
-  GNX_TRY(hipMemset(d_cnt, 0, (N + 1) * sizeof(int32_t)));
-  GNX_TRY(hipMemset(d_bs, 0, SCAN_B * sizeof(int32_t)));
-  GNX_TRY(hipMemset(d_bad, 0, sizeof(int32_t)));
   AdjMeta m{d_off, d_n, d_noff, (int)G, elem_kind, row_major};
   const unsigned grid = (unsigned)((N * 64 + 255) / 256);
   GNX_LAUNCH(k_adj_columns<false>, dim3(grid), dim3(256), 0, 0, d_adj, m, (int)N, d_cnt, (int*)nullptr, d_bad);
   GNX_LAUNCH(k_scan_blocks, dim3(nb), dim3(256), 0, 0, d_cnt, (int)(N + 1), d_cp, d_bs);
   GNX_LAUNCH(k_scan_blocks, dim3(1), dim3(256), 0, 0, d_bs, SCAN_B, d_bp, (int*)nullptr);
   GNX_LAUNCH(k_scan_add, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, 0, d_cp, (int)(N + 1), d_bp);
+  GNX_LAUNCH(k_adj_summary, dim3(1), dim3(64), 0, 0, d_cp, (int)N, d_bad, d_sum);
   GNX_TRY(hipGetLastError());
-  int32_t bad = 0, E = 0;
-  GNX_TRY(hipMemcpy(&bad, d_bad, sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (bad) { cleanup(); return fail(GNX_ERR_ADJ_VALUE, "adjacency entries must be exactly 0 or 1 (pad.jl:30, gngraphbatch.jl:207)"); }
-  GNX_TRY(hipMemcpy(&E, d_cp + N, sizeof(int32_t), hipMemcpyDeviceToHost));
-  GNX_TRY(hipMalloc((void**)&d_rv, std::max<size_t>((size_t)E, 1) * sizeof(int32_t)));
+  int32_t summary[2] = {0, 0};
+  GNX_TRY(hipMemcpy(summary, d_sum, sizeof summary, hipMemcpyDeviceToHost));
+  if (summary[0]) { cleanup(); return fail(GNX_ERR_ADJ_VALUE, "adjacency entries must be exactly 0 or 1 (pad.jl:30, gngraphbatch.jl:207)"); }
+  const int32_t E = summary[1];
+  const size_t rv_bytes = std::max<size_t>((size_t)E, 4) * sizeof(int32_t);
+  rv_blk = arena_take(dev, rv_bytes, &rv_got);
+  if (!rv_blk) { GNX_TRY(hipMalloc(&rv_blk, rv_bytes)); rv_got = rv_bytes; }
+  int32_t* d_rv = static_cast<int32_t*>(rv_blk);
   GNX_LAUNCH(k_adj_columns<true>, dim3(grid), dim3(256), 0, 0, d_adj, m, (int)N, d_cp, d_rv, d_bad);
   GNX_TRY(hipGetLastError());
   if (keep) {
-    int32_t* d_eoff = nullptr;
-    GNX_TRY(hipMalloc((void**)&d_eoff, (G + 1) * sizeof(int32_t)));
+    int32_t* d_eoff = reinterpret_cast<int32_t*>(blk + o_eoff);
     GNX_LAUNCH(k_gather_offsets, dim3((unsigned)((G + 1 + 255) / 256)), dim3(256), 0, 0, d_cp, d_noff, (int)G, d_eoff);
     keep->edge_off.resize((size_t)G + 1);
-    const hipError_t ee = hipMemcpy(keep->edge_off.data(), d_eoff, (G + 1) * sizeof(int32_t), hipMemcpyDeviceToHost);
-    (void)hipFree(d_eoff);
-    if (ee != hipSuccess) { cleanup(); return hip_fail(ee, "edge offsets"); }
+    GNX_TRY(hipMemcpy(keep->edge_off.data(), d_eoff, (G + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
     keep->d_colptr = d_cp; keep->d_rowval = d_rv; keep->E = E;
-    d_cp = nullptr; d_rv = nullptr;  // (handed over: not freed below)
-    cleanup();
+    keep->device = dev; keep->block = blk; keep->block_bytes = got; keep->rv_block = rv_blk; keep->rv_bytes = rv_got;  // (handed over: release_dense_csc)
     return GNX_OK;
   }
   std::vector<int32_t> cp32(N + 1), rv32((size_t)E);
@@ -225,6 +262,14 @@ int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int6
   h_colptr.assign(cp32.begin(), cp32.end());
   h_rowval.assign(rv32.begin(), rv32.end());
   return GNX_OK;
+}
+
+// the blocks behind a DenseCscOnDevice go back to the cache of released device blocks (the caller's kernels on them have been enqueued on the
+// NULL stream or synchronised: arena_take synchronises the device before a block is written again)
+void release_dense_csc(DenseCscOnDevice& k) {
+  if (k.block) arena_give(k.device, k.block, k.block_bytes);
+  if (k.rv_block) arena_give(k.device, k.rv_block, k.rv_bytes);
+  k.block = k.rv_block = nullptr; k.d_colptr = nullptr; k.d_rowval = nullptr;
 }
 
 }  // namespace gnx

@@ -301,7 +301,7 @@ static int32_t build_wide_tables(const gnx_graphs* h) {
 }  // namespace gnx
 
 namespace gnx {
-int32_t build_csc_on_device(const void* const* adj, const int64_t* n_nodes, int64_t G, int32_t elem_kind, int32_t row_major,
+int32_t build_csc_on_device(const void* const* adj, const void* packed, int packed_on_device, const int64_t* n_nodes, int64_t G, int32_t elem_kind, int32_t row_major,
                             gnx::vec_i64& h_colptr, gnx::vec_i64& h_rowval, const std::vector<int64_t>& h_node_off, DenseCscOnDevice* keep);
 }
 
@@ -450,12 +450,44 @@ extern "C" {
 int32_t gnx_version(void) { return GNX_VERSION; }
 const char* gnx_last_error(void) { return g_last_error.c_str(); }
 
+static int32_t create_dense_impl(const void* const* adj, const void* packed, int packed_on_device, const int64_t* n_nodes, int64_t n_graphs, int32_t elem_kind,
+                                 int32_t row_major, gnx_graphs** out);
+
 int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n_nodes, int64_t n_graphs, int32_t elem_kind,
                                 int32_t row_major, gnx_graphs** out) {
   if (!out) return fail(GNX_ERR_INVALID_ARG, "out is NULL");
   *out = nullptr;
   if (n_graphs <= 0) return fail(GNX_ERR_NO_GRAPHS, "length(adj_mats) must be > 0 (checks.jl:8)");
   if (!adj || !n_nodes) return fail(GNX_ERR_INVALID_ARG, "adj / n_nodes is NULL");
+  return create_dense_impl(adj, nullptr, 0, n_nodes, n_graphs, elem_kind, row_major, out);
+}
+
+// the same batch from ONE buffer holding the matrices one after the other (graph g: n_g x n_g elements of elem_kind): `adj_bytes` must equal
+// sum(n_g^2) * sizeof(element) — nothing is read past it.  on_device = 0: host memory (pinned memory travels as one DMA); 1: device memory of
+// the current device (no copy: the scan reads it where it is).  What a data loader holds — and what the bindings call: one pointer, no per-graph work.
+int32_t gnx_graphs_create_dense_packed(const void* adj_cat, int64_t adj_bytes, const int64_t* n_nodes, int64_t n_graphs, int32_t elem_kind, int32_t row_major,
+                                       int32_t on_device, gnx_graphs** out) {
+  if (!out) return fail(GNX_ERR_INVALID_ARG, "out is NULL");
+  *out = nullptr;
+  if (n_graphs <= 0) return fail(GNX_ERR_NO_GRAPHS, "length(adj_mats) must be > 0 (checks.jl:8)");
+  if (!adj_cat || !n_nodes) return fail(GNX_ERR_INVALID_ARG, "adj_cat / n_nodes is NULL");
+  if (elem_kind < GNX_ELEM_U8 || elem_kind > GNX_ELEM_F64) return fail(GNX_ERR_INVALID_ARG, "bad elem_kind");
+  static const int64_t esz_tab[5] = {1, 4, 8, 4, 8};
+  int64_t total = 0;
+  for (int64_t g = 0; g < n_graphs; ++g) {
+    if (n_nodes[g] <= 0) return fail(GNX_ERR_ADJ_SHAPE, "adjacency matrix must be N x N with N >= 1 (checks.jl:11)");
+    total += n_nodes[g] * n_nodes[g];
+  }
+  if (adj_bytes != total * esz_tab[elem_kind]) return fail(GNX_ERR_INVALID_ARG, "adj_bytes must equal sum(n_nodes^2) elements");
+  if (on_device) return create_dense_impl(nullptr, adj_cat, 1, n_nodes, n_graphs, elem_kind, row_major, out);
+  std::vector<const void*> ptrs((size_t)n_graphs);  // (the host scan of small batches walks per-graph pointers)
+  int64_t at = 0;
+  for (int64_t g = 0; g < n_graphs; ++g) { ptrs[(size_t)g] = static_cast<const char*>(adj_cat) + at * esz_tab[elem_kind]; at += n_nodes[g] * n_nodes[g]; }
+  return create_dense_impl(ptrs.data(), adj_cat, 0, n_nodes, n_graphs, elem_kind, row_major, out);
+}
+
+static int32_t create_dense_impl(const void* const* adj, const void* packed, int packed_on_device, const int64_t* n_nodes, int64_t n_graphs, int32_t elem_kind,
+                                 int32_t row_major, gnx_graphs** out) {
   if (elem_kind < GNX_ELEM_U8 || elem_kind > GNX_ELEM_F64) return fail(GNX_ERR_INVALID_ARG, "bad elem_kind");
   BuildTimer bt;
   gnx_graphs* h = new gnx_graphs();
@@ -464,7 +496,7 @@ int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n_nodes, 
   int64_t total_entries = 0;
   for (int64_t g = 0; g < n_graphs; ++g) {
     const int64_t n = n_nodes[g];
-    if (n <= 0 || !adj[g]) {
+    if (n <= 0 || (adj && !adj[g])) {
       delete h;
       return fail(GNX_ERR_ADJ_SHAPE, "adjacency matrix must be N x N with N >= 1 (checks.jl:11)");
     }
@@ -475,16 +507,18 @@ int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n_nodes, 
   // large dense batches: scan + compaction on the GPU (gnx_build_device.hip); small ones on the host (no launch cost)
   static const int64_t dev_threshold = getenv("GNX_BUILD_DEVICE_MIN") ? atoll(getenv("GNX_BUILD_DEVICE_MIN")) : (1 << 22);
   bool built = false;
-  if (total_entries >= dev_threshold) {
+  if (total_entries >= dev_threshold || packed_on_device) {
     // scan + compaction on the GPU; the CSC then STAYS there and the device builder makes the handle's tables from it (no round trip of
     // 4 (N + E) bytes through the host, no host tiling pass).  GNX_BUILD_CSC_DEVICE=0: the CSC comes back and finalize() runs (the validator)
     static const bool dev_tables = !(getenv("GNX_BUILD_CSC_DEVICE") && atoi(getenv("GNX_BUILD_CSC_DEVICE")) == 0);
     DenseCscOnDevice keep;
-    const int32_t rc = build_csc_on_device(adj, n_nodes, n_graphs, elem_kind, row_major, h->h_colptr, h->h_rowval, h->h_node_off, dev_tables ? &keep : nullptr);
+    const int32_t rc = build_csc_on_device(adj, packed, packed_on_device, n_nodes, n_graphs, elem_kind, row_major, h->h_colptr, h->h_rowval, h->h_node_off,
+                                           dev_tables ? &keep : nullptr);
     if (rc != 1 && rc != GNX_OK) { delete h; return rc; }
+    if (rc == 1 && packed_on_device) { delete h; return fail(GNX_ERR_TOO_LARGE, "a dense batch given in device memory exceeds the device builder's capacity (4M nodes)"); }
     built = rc == GNX_OK;
     if (built && dev_tables) {
-      struct Free { DenseCscOnDevice& k; ~Free() { (void)hipFree(k.d_colptr); (void)hipFree(k.d_rowval); } } free_keep{keep};
+      struct Free { DenseCscOnDevice& k; ~Free() { release_dense_csc(k); } } free_keep{keep};
       h->tile_e_cap = env_int("GNX_TILE_E", 512);
       h->tile_n_cap = env_int("GNX_TILE_N", 128);
       h->wtile_e_cap = env_int("GNX_WTILE_E", 128);

@@ -206,7 +206,11 @@ void build_packs(gnx_graphs* h, std::vector<int32_t>& packs);
 // released handle arenas (gnx_build_csc.hip)
 void* arena_take(int dev, size_t bytes, size_t* got);
 void arena_give(int dev, void* ptr, size_t bytes);
-struct DenseCscOnDevice { int32_t* d_colptr = nullptr; int32_t* d_rowval = nullptr; int64_t E = 0; std::vector<int32_t> edge_off; };  // gnx_build_device.hip
+struct DenseCscOnDevice {  // gnx_build_device.hip: the CSC of a dense batch, left on the device inside two cached blocks (release_dense_csc)
+  int32_t* d_colptr = nullptr; int32_t* d_rowval = nullptr; int64_t E = 0; std::vector<int32_t> edge_off;
+  int device = 0; void* block = nullptr; size_t block_bytes = 0; void* rv_block = nullptr; size_t rv_bytes = 0;
+};
+void release_dense_csc(DenseCscOnDevice& k);
 int32_t build_wide_tables_on_device(const gnx_graphs* h);  // gnx_build_csc.hip; 1 = not applicable (host builder)
 int32_t build_handle_from_csc_on_device(gnx_graphs* h, const void* colptr_cat, const void* rowval_cat, int32_t index_base, int32_t index_bits, int tile_e_cap, int tile_n_cap,
                                         int wtile_e_cap, int64_t tiles_bound, int64_t wtiles_bound, int64_t max_tiles_per_graph_bound);

@@ -174,6 +174,13 @@ GNX_API const char* gnx_last_error(void);
 GNX_API int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n_nodes, int64_t n_graphs, int32_t elem_kind,
                                 int32_t row_major, gnx_graphs** out);
 
+/* The same batch from ONE buffer: the matrices one after the other (graph g: n_g x n_g elements of elem_kind), adj_bytes = sum(n_g^2) *
+ * sizeof(element) — checked; nothing is read past it.  on_device = 0: HOST memory (a pinned buffer travels as one DMA, a pageable one through
+ * the library's pinned staging pair); on_device = 1: DEVICE memory of the current device (no copy).  What a data loader holds and what the
+ * bindings call (GNGraphBatch.from_dense_packed): one pointer instead of G — building G pointers costs a Python / Julia host ~1.5 us each. */
+GNX_API int32_t gnx_graphs_create_dense_packed(const void* adj_cat, int64_t adj_bytes, const int64_t* n_nodes, int64_t n_graphs, int32_t elem_kind,
+                                       int32_t row_major, int32_t on_device, gnx_graphs** out);
+
 /* Per-graph CSC (Julia SparseMatrixCSC colptr / rowval, HOST memory): colptr[g] has n_nodes[g]+1 entries,
  * rowval[g] the local source index of every edge, sorted strictly increasing inside a column; index_base is 1
  * for Julia arrays, 0 for C.  The nz order of CSC *is* the reference edge order.  (API extension: the reference

@@ -187,20 +187,37 @@ mutable struct GNGraphBatch
     node_off::Vector{Int64}   # 0-based offsets of each graph's nodes / edges in the packed arrays
     edge_off::Vector{Int64}
     ws::Dict{Any,DevBuf}      # workspaces of the layers that ran on this batch, by (layer kind, widths, replicas): allocated once
+    # `batch`'s own input form: dense 0/1 matrices (src/batch.jl:53-64).  They travel as ONE buffer of UInt8 — the matrices one after the other,
+    # column-major as Julia stores them — through gnx_graphs_create_dense_packed: one pointer instead of G, a quarter of Float32's bytes.
     function GNGraphBatch(adj_mats::AbstractVector)
         @assert length(adj_mats) > 0
-        mats = [Matrix{Float32}(a) for a in adj_mats]            # column-major, as Julia stores them
-        ptrs = [pointer(m) for m in mats]
-        nn = Int64[size(m, 1) for m in mats]
+        @assert all(a -> ndims(a) == 2 && size(a, 1) == size(a, 2), adj_mats)       # checks.jl:11
+        nn = Int64[size(a, 1) for a in adj_mats]
+        cat = Vector{UInt8}(undef, sum(abs2, nn))
+        o = 0
+        for a in adj_mats
+            @views cat[o+1:o+length(a)] .= UInt8.(vec(a))                            # (an entry that is no small integer throws here; 2, 3, ... are rejected by the library)
+            o += length(a)
+        end
+        GNGraphBatch(cat, nn; adj_mats=collect(adj_mats))
+    end
+    # the packed form itself (a data loader's buffer): adj_cat = the matrices one after the other (column-major each), n_nodes their sizes
+    function GNGraphBatch(adj_cat::Vector{UInt8}, n_nodes::AbstractVector{<:Integer}; adj_mats::AbstractVector=Any[])
+        nn = Int64.(n_nodes)
+        @assert length(nn) > 0 && length(adj_cat) == sum(abs2, nn)
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        GC.@preserve mats check(ccall((:gnx_graphs_create_dense, libgnx), Int32,
-            (Ptr{Ptr{Cvoid}}, Ptr{Int64}, Int64, Int32, Int32, Ptr{Ptr{Cvoid}}),
-            ptrs, nn, length(mats), 3 #=GNX_ELEM_F32=#, 0 #=column-major=#, h))
+        GC.@preserve adj_cat check(ccall((:gnx_graphs_create_dense_packed, libgnx), Int32,
+            (Ptr{Cvoid}, Int64, Ptr{Int64}, Int64, Int32, Int32, Int32, Ptr{Ptr{Cvoid}}),
+            adj_cat, length(adj_cat), nn, length(nn), 0 #=GNX_ELEM_U8=#, 0 #=column-major=#, 0 #=host memory=#, h))
+        if isempty(adj_mats)                                                         # views of the buffer, for unbatch
+            offs = cumsum(vcat(0, abs2.(nn)))
+            adj_mats = [reshape(view(adj_cat, offs[i]+1:offs[i+1]), Int(nn[i]), Int(nn[i])) for i in eachindex(nn)]
+        end
         info = Ref{GnxGraphsInfo}()
         check(ccall((:gnx_graphs_get_info, libgnx), Int32, (Ptr{Cvoid}, Ptr{GnxGraphsInfo}), h[], info))
-        no = zeros(Int64, length(mats) + 1); eo = zeros(Int64, length(mats) + 1)
+        no = zeros(Int64, length(nn) + 1); eo = zeros(Int64, length(nn) + 1)
         check(ccall((:gnx_graphs_get_offsets, libgnx), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), h[], no, eo))
-        g = new(h[], collect(adj_mats), info[].node_block_size, info[].edge_block_size, no, eo, Dict{Any,DevBuf}())
+        g = new(h[], adj_mats, info[].node_block_size, info[].edge_block_size, no, eo, Dict{Any,DevBuf}())
         finalizer(x -> ccall((:gnx_graphs_destroy, libgnx), Int32, (Ptr{Cvoid},), x.handle), g)
         g
     end

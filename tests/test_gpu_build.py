@@ -214,6 +214,48 @@ def test_two_host_threads_build_batches_on_one_device_concurrently():
     assert not errors, errors[:5]
 
 
+def test_dense_packed_input_builds_the_same_batch_from_host_pinned_and_device_memory():
+    """`batch`'s own input form — dense 0/1 matrices (src/batch.jl:53-64) — as ONE buffer (GNGraphBatch.from_dense_packed ->
+    gnx_graphs_create_dense_packed): pageable numpy memory, a pinned tensor (one DMA) and a device tensor (no copy) give the very tables the
+    list-of-matrices constructor gives; bool and float32 elements too; a value other than 0 / 1 and a wrong length are rejected; `adj_mats`
+    of the packed batch are views of the buffer (what unbatch hands back)."""
+    import torch
+    import graphnets_jl_amd as gn
+    colptrs, rowvals, nn = bench.make_hetero(13, 600, 400_000)
+    adjs = []
+    for cp, rv, n in zip(colptrs, rowvals, nn):
+        a = np.zeros((n, n), dtype=np.uint8)
+        a[rv, np.repeat(np.arange(n), np.diff(cp))] = 1
+        adjs.append(a)
+    cat = np.concatenate([a.reshape(-1) for a in adjs])
+    assert cat.size >= 1 << 22  # (the device builder's threshold)
+    which = (0, 1, 2, 3, 4, 5, 6, 7, 8)
+    ref = gn.GNGraphBatch(adjs)
+    want = [_table(gn, ref, w) for w in which]
+    forms = {"pageable": cat, "bool": cat.astype(bool), "float32": cat.astype(np.float32), "pinned": torch.from_numpy(cat).pin_memory(),
+             "device": torch.from_numpy(cat).cuda()}
+    for name, buf in forms.items():
+        g = gn.GNGraphBatch.from_dense_packed(buf, nn)
+        assert (g.n_graphs, g.n_nodes, g.n_edges) == (ref.n_graphs, ref.n_nodes, ref.n_edges), name
+        for w, t in zip(which, want):
+            assert np.array_equal(_table(gn, g, w), t), (name, w)
+        if name == "pageable":
+            assert all(np.array_equal(a, b) for a, b in zip(g.adj_mats[:5] + g.adj_mats[-5:], adjs[:5] + adjs[-5:]))
+        del g
+    small = gn.GNGraphBatch.from_dense_packed(np.concatenate([a.reshape(-1) for a in adjs[:3]]), nn[:3])  # (below the threshold: the host scan)
+    ref3 = gn.GNGraphBatch(adjs[:3])
+    assert np.array_equal(_table(gn, small, 1), _table(gn, ref3, 1))
+    small_dev = gn.GNGraphBatch.from_dense_packed(torch.from_numpy(np.concatenate([a.reshape(-1) for a in adjs[:3]])).cuda(), nn[:3])  # (device memory: always the kernels)
+    assert np.array_equal(_table(gn, small_dev, 1), _table(gn, ref3, 1)) and np.array_equal(_table(gn, small_dev, 7), _table(gn, ref3, 7))
+    bad = cat.copy(); bad[12345] = 2
+    for buf in (bad, torch.from_numpy(bad).cuda()):
+        with pytest.raises(gn._lib.GnxError) as e:
+            gn.GNGraphBatch.from_dense_packed(buf, nn)
+        assert e.value.code == gn._lib.ERR_ADJ_VALUE
+    with pytest.raises(ValueError):
+        gn.GNGraphBatch.from_dense_packed(cat[:-1], nn)
+
+
 def test_forward_on_a_device_built_batch_equals_the_oracle_and_lazy_host_tables_work():
     import torch
     import graphnets_jl_amd as gn

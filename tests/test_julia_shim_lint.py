@@ -101,7 +101,7 @@ def test_every_ccall_matches_the_ctypes_signature_table():
 
 def test_the_shim_binds_the_entry_points_of_the_hot_path_and_its_neighbours():
     bound = {c[0] for c in ccalls()}
-    for name in ("gnx_graphs_create_dense", "gnx_graphs_create_csc_cat", "gnx_block_forward", "gnx_core_forward", "gnx_fn_input", "gnx_block_backward",
+    for name in ("gnx_graphs_create_dense_packed", "gnx_graphs_create_csc_cat", "gnx_block_prepare", "gnx_core_prepare", "gnx_prepared_refresh", "gnx_block_forward", "gnx_core_forward", "gnx_fn_input", "gnx_block_backward",
                  "gnx_core_backward", "gnx_chain_block_forward", "gnx_chain_block_backward", "gnx_model_create", "gnx_model_forward",
                  "gnx_dist_partition", "gnx_dist_create", "gnx_dist_block_forward", "gnx_dist_block_forward_steps", "gnx_dist_destroy", "gnx_collapse_edges",
                  "gnx_collapse_padded", "gnx_block_forward_chained", "gnx_block_graph_update"):
