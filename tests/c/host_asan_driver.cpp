@@ -19,7 +19,8 @@ template <int C, bool ONEG> __global__ void k_graph_t(BlockArgs a, int n) {} }
 )";
 
 namespace gnx {
-int32_t build_csc_on_device(const void* const*, const int64_t*, int64_t, int32_t, int32_t, gnx::vec_i64&, gnx::vec_i64&,
+void release_dense_csc(DenseCscOnDevice&) {}
+int32_t build_csc_on_device(const void* const*, const void*, int, const int64_t*, int64_t, int32_t, int32_t, gnx::vec_i64&, gnx::vec_i64&,
                             const std::vector<int64_t>&, DenseCscOnDevice*) {
   return fail(100, "stub: no device");
 }
@@ -76,6 +77,19 @@ int main() {
     mats32[0][0] = 7;  // not 0/1
     h = nullptr;
     EXPECT(gnx_graphs_create_dense(p32.data(), nn.data(), G, GNX_ELEM_I32, 0, &h) == GNX_ERR_ADJ_VALUE && h == nullptr);
+    // the packed form (one buffer, its byte length checked): the same scan over per-graph windows of the buffer, never past its end
+    mats32[0][0] = 0;
+    std::vector<int32_t> cat;
+    for (int g = 0; g < G; ++g) cat.insert(cat.end(), mats32[g].begin(), mats32[g].end());
+    std::vector<int32_t> exact(cat);  // (an exactly-sized heap block: a read past it is an ASan report)
+    h = nullptr;
+    rc = gnx_graphs_create_dense_packed(exact.data(), (int64_t)(exact.size() * 4), nn.data(), G, GNX_ELEM_I32, trial & 1, 0, &h);
+    EXPECT(rc != GNX_OK || h != nullptr);
+    if (h) gnx_graphs_destroy(h);
+    h = nullptr;
+    EXPECT(gnx_graphs_create_dense_packed(exact.data(), (int64_t)(exact.size() * 4) - 4, nn.data(), G, GNX_ELEM_I32, 0, 0, &h) == GNX_ERR_INVALID_ARG && h == nullptr);
+    exact[exact.size() - 1] = 9;  // not 0/1, in the last entry of the last graph
+    EXPECT(gnx_graphs_create_dense_packed(exact.data(), (int64_t)(exact.size() * 4), nn.data(), G, GNX_ELEM_I32, 0, 0, &h) == GNX_ERR_ADJ_VALUE && h == nullptr);
   }
   // ---- CSC input: well-formed (then the device step fails or succeeds), and every malformation ----
   for (int trial = 0; trial < 50; ++trial) {
