@@ -25,9 +25,13 @@ int32_t hip_fail(hipError_t e, const char* what) {
   return (int32_t)e > 0 ? (int32_t)e : 1;
 }
 
-// GNX_TIME_BUILD=1: phase timings of handle construction on stderr (diagnostic)
+// GNX_TIME_BUILD=1: phase timings of handle construction on stderr (diagnostic; like every switch of the library, read once per process)
+static bool time_build_on() {
+  static const bool on = getenv("GNX_TIME_BUILD") != nullptr;
+  return on;
+}
 struct BuildTimer {
-  bool on = getenv("GNX_TIME_BUILD") != nullptr;
+  bool on = time_build_on();
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   void lap(const char* what) {
     if (!on) return;
@@ -37,6 +41,12 @@ struct BuildTimer {
   }
 };
 
+static int env_int(const char* name, int dflt);
+// the tile caps of a handle (edges / nodes per workgroup tile, edges per wave tile): environment overrides read ONCE per process
+static void tile_caps(int* tile_e, int* tile_n, int* wtile_e) {
+  static const int te = env_int("GNX_TILE_E", 512), tn = env_int("GNX_TILE_N", 128), we = env_int("GNX_WTILE_E", 128);
+  *tile_e = te; *tile_n = tn; *wtile_e = (we == 64 || we == 128 || we == 256) ? we : 128;
+}
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   if (!v || !*v) return dflt;
@@ -115,8 +125,7 @@ static int32_t finalize(gnx_graphs* h) {
     return fail(GNX_ERR_TOO_LARGE, "graph batch exceeds int32 device indices");
   BuildTimer bt;
   GNX_HIP(hipGetDevice(&h->device));
-  h->tile_e_cap = env_int("GNX_TILE_E", 512);
-  h->tile_n_cap = env_int("GNX_TILE_N", 128);
+  { int te, tn, we; tile_caps(&te, &tn, &we); h->tile_e_cap = te; h->tile_n_cap = tn; h->wtile_e_cap = we; }
   // greedy tiling inside each graph: add nodes while edges <= cap and nodes <= cap; a node whose in-degree
   // exceeds the cap becomes a single-node tile (kernels loop over its edges).
   auto build_tiles = [&](int e_cap, int n_cap, std::vector<gnx::Tile>& tiles, std::vector<int32_t>& off, int64_t* max_deg) {
@@ -147,8 +156,6 @@ static int32_t finalize(gnx_graphs* h) {
     off[h->G] = (int32_t)tiles.size();
   };
   h->max_in_degree = 0;
-  h->wtile_e_cap = env_int("GNX_WTILE_E", 128);
-  if (h->wtile_e_cap != 64 && h->wtile_e_cap != 128 && h->wtile_e_cap != 256) h->wtile_e_cap = 128;
   // (the two tile kinds on two host threads were measured: 2.5 instead of 0.9 ms for 4096 graphs — the second thread's start and the
   // allocator cost more than the 0.45 ms it takes over)
   build_tiles(h->tile_e_cap, h->tile_n_cap, h->h_tiles, h->h_tile_off, &h->max_in_degree);
@@ -412,10 +419,7 @@ static int32_t create_csc_device(const void* colptr_cat, const void* rowval_cat,
   h->h_node_off.resize((size_t)n_graphs + 1);
   h->h_edge_off.resize((size_t)n_graphs + 1);
   h->h_node_off[0] = 0; h->h_edge_off[0] = 0;
-  h->tile_e_cap = env_int("GNX_TILE_E", 512);
-  h->tile_n_cap = env_int("GNX_TILE_N", 128);
-  h->wtile_e_cap = env_int("GNX_WTILE_E", 128);
-  if (h->wtile_e_cap != 64 && h->wtile_e_cap != 128 && h->wtile_e_cap != 256) h->wtile_e_cap = 128;
+  { int te, tn, we; tile_caps(&te, &tn, &we); h->tile_e_cap = te; h->tile_n_cap = tn; h->wtile_e_cap = we; }
   int64_t cpo = 0, tb = 0, wb = 0, per_graph = 1;
   for (int64_t g = 0; g < n_graphs; ++g) {
     const int64_t n = n_nodes[g];
@@ -519,10 +523,7 @@ static int32_t create_dense_impl(const void* const* adj, const void* packed, int
     built = rc == GNX_OK;
     if (built && dev_tables) {
       struct Free { DenseCscOnDevice& k; ~Free() { release_dense_csc(k); } } free_keep{keep};
-      h->tile_e_cap = env_int("GNX_TILE_E", 512);
-      h->tile_n_cap = env_int("GNX_TILE_N", 128);
-      h->wtile_e_cap = env_int("GNX_WTILE_E", 128);
-      if (h->wtile_e_cap != 64 && h->wtile_e_cap != 128 && h->wtile_e_cap != 256) h->wtile_e_cap = 128;
+      { int te, tn, we; tile_caps(&te, &tn, &we); h->tile_e_cap = te; h->tile_n_cap = tn; h->wtile_e_cap = we; }
       h->h_edge_off.assign(keep.edge_off.begin(), keep.edge_off.end());
       h->N = h->h_node_off.back();
       h->E = keep.E;

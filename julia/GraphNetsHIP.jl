@@ -612,14 +612,8 @@ function block_pullback(m::GNBlock, x, y, ȳ)
     ondevice(x) ? r : (ef=cpu(r.ef), nf=cpu(r.nf), gf=cpu(r.gf), params=[map(cpu, q) for q in r.params])
 end
 
-# The rrule a maintainer adds once ChainRulesCore is a dependency (kept as a comment: this module has no dependencies):
-#   function ChainRulesCore.rrule(m::GNBlock, x)
-#       y = m(x)
-#       pb(ȳ) = (g = block_pullback(m, x, y, ȳ);
-#                (Tangent{GNBlock}(edgefn=Tangent{Dense}(; g.params[1]...), nodefn=Tangent{Dense}(; g.params[2]...), graphfn=Tangent{Dense}(; g.params[3]...)),
-#                 Tangent{typeof(x)}(ef=g.ef, nf=g.nf, gf=g.gf)))
-#       y, pb
-#   end
+# The ChainRulesCore rules (rrule) of (m::GNBlock)(x) and (m::GNCore)(x) over these pullbacks live in ext/GraphNetsHIPChainRulesExt.jl: a package
+# extension (weak dependency: loaded only where ChainRulesCore is), so that this module keeps no hard dependency.
 
 # ---- GNBlock whose update functions are Chains of Dense layers (src/gnblock.jl:1-6) → gnx_chain_block_forward / _backward ----
 struct GnxChain; layers::Ptr{GnxDense}; widths::Ptr{Int32}; n_layers::Int32; reserved::Int32; end
