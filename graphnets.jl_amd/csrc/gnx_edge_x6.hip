@@ -84,16 +84,27 @@ struct EdgeX6Args {
   int ln_inline;           // no ln_stats: the row statistics of gn1 are computed here, in registers (gnx_x6_stats.h), with ln_eps / ln_mode
   float ln_eps;
   int ln_mode;
+  // ENCODER form (KSX = 2): the UNPROJECTED edge update of a block whose inputs are narrow — (10, 5, .) => 128: README ex.3's / config 4's encoder —
+  // W^T [ef ; nf[src] ; nf[dst]] + b with all 20 inputs of a row assembled in the lane's registers (one zero-padded K = 32)
+  const float* nf;         // [R][N][5]
+  const float* bias;       // [128] or nullptr
+  const float* bias_g;     // [R][G][128] (bias + gf fold) or nullptr
+  int G;
 };
 
 // NARROW: a block whose edge output is at most 32 wide (config 4's decoder: 128 -> 3) — ONE slice of zero-padded weight fragments, the addends and
 // the outputs as single floats (rows of a.oe), no per-destination sums (the node update of such a block adds up the ef' rows itself: 12 bytes each)
-template <bool NARROW>
-__global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARROW ? 3 : 2))) void k_edge_x6(EdgeX6Args a) {
+// KSX: k16-steps of the contraction — 8: the projected form (K = 128 edge inputs, two gathered projection rows as addends); 2: the ENCODER form
+// ((10, 5, .) => 128 unprojected: ef, nf[src], nf[dst] assembled per lane into one zero-padded K = 32, the bias as the only addend)
+template <bool NARROW, int KSX = EKS>
+__global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARROW ? 3 : (KSX == 2 ? 4 : 2)))) void k_edge_x6(EdgeX6Args a) {
+  constexpr bool ENC = KSX == 2;
+  static_assert(KSX == EKS || (KSX == 2 && !NARROW), "K = 128, or the encoder's K = 32");
   constexpr int NOBK = NARROW ? 1 : ENOB;
+  constexpr int NFX = 3 * KSX, SLBX = NFX * 1024;  // fragments / bytes of one 32-output slice of prepared weights
   const int OUTW = NARROW ? a.oe : EOUT;
-  __shared__ __attribute__((aligned(16))) unsigned char s_wa[ESLB];
-  __shared__ __attribute__((aligned(16))) unsigned char s_wb[ESLB];
+  __shared__ __attribute__((aligned(16))) unsigned char s_wa[SLBX];
+  __shared__ __attribute__((aligned(16))) unsigned char s_wb[SLBX];
   __shared__ __attribute__((aligned(16))) float s_e[EBM * ELDE];  // the finished 32-column block of the tile, [row][36]
   __shared__ __attribute__((aligned(16))) float s_cs[32 * 32];    // column-sum partials [row group][column]
   __shared__ int s_src[EBM], s_dst[EBM];
@@ -110,12 +121,13 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
   if (a.agg_out) { agg_row0[0] = a.chunk_row0[2 * tile_id]; agg_row0[1] = a.chunk_row0[2 * tile_id + 1]; }
 
   auto stage = [&](int ob, unsigned char* dst) {
-    const unsigned char* srcp = reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)ob * ESLB;
+    const unsigned char* srcp = reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)ob * SLBX;
 #pragma unroll
-    for (int i = 0; i < ENF / EW; ++i) {
+    for (int i = 0; i < (NFX + EW - 1) / EW; ++i) {
       const int pc = wv + EW * i;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcp + (size_t)pc * 1024 + lane * 16),
-                                       (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+      if (NFX % EW == 0 || pc < NFX)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcp + (size_t)pc * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
     }
   };
   stage(0, s_wa);
@@ -129,8 +141,39 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
   const int lrow = wv * ER + n;
   const int lrc = lrow < rows ? lrow : rows - 1;
   const float* __restrict__ zrow = a.ef + (r * a.E + (size_t)row0 + lrc) * EK;
-  bf16x8e zh[EKS], zm[EKS], zl[EKS];
-  {
+  bf16x8e zh[KSX], zm[KSX], zl[KSX];
+  if constexpr (ENC) {
+    // The row's 20 inputs, lane-local (no LDS hop, no division): k = 16 s + 8 hi + j of the zero-padded K = 32 is
+    //   lane half 0: ef[0..7] (step 0), nf[dst][1..4] + four zeros (step 1);   half 1: ef[8], ef[9], nf[src][0..4], nf[dst][0] (step 0), zeros (step 1)
+    // (k_edge_enc_prep lays the weight rows out in that order).  Rows are 40 / 20 bytes: dword-aligned vector loads.
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+    typedef unsigned u32x4e __attribute__((ext_vector_type(4)));
+    const float* __restrict__ efp = a.ef + (r * a.E + (size_t)row0 + lrc) * 10;
+    const float* __restrict__ nfs = a.nf + (r * a.N + (size_t)a.src[row0 + lrc]) * 5;
+    const float* __restrict__ nfd = a.nf + (r * a.N + (size_t)a.dst[row0 + lrc]) * 5;
+    float v0[8], v1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (hi == 0) {
+      const f32x4u e0 = *reinterpret_cast<const f32x4u*>(efp), e1 = *reinterpret_cast<const f32x4u*>(efp + 4), d1 = *reinterpret_cast<const f32x4u*>(nfd + 1);
+      v0[0] = e0.x; v0[1] = e0.y; v0[2] = e0.z; v0[3] = e0.w; v0[4] = e1.x; v0[5] = e1.y; v0[6] = e1.z; v0[7] = e1.w;
+      v1[0] = d1.x; v1[1] = d1.y; v1[2] = d1.z; v1[3] = d1.w;
+    } else {
+      const f32x2u e2 = *reinterpret_cast<const f32x2u*>(efp + 8);
+      const f32x4u s0 = *reinterpret_cast<const f32x4u*>(nfs);
+      v0[0] = e2.x; v0[1] = e2.y; v0[2] = s0.x; v0[3] = s0.y; v0[4] = s0.z; v0[5] = s0.w; v0[6] = nfs[4]; v0[7] = nfd[0];
+    }
+    unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) esplit2(v0[2 * j], v0[2 * j + 1], ph[j], pm[j], pl[j]);
+    zh[0] = __builtin_bit_cast(bf16x8e, u32x4e{ph[0], ph[1], ph[2], ph[3]});
+    zm[0] = __builtin_bit_cast(bf16x8e, u32x4e{pm[0], pm[1], pm[2], pm[3]});
+    zl[0] = __builtin_bit_cast(bf16x8e, u32x4e{pl[0], pl[1], pl[2], pl[3]});
+#pragma unroll
+    for (int j = 0; j < 4; ++j) esplit2(v1[2 * j], v1[2 * j + 1], ph[j], pm[j], pl[j]);
+    zh[KSX - 1] = __builtin_bit_cast(bf16x8e, u32x4e{ph[0], ph[1], ph[2], ph[3]});
+    zm[KSX - 1] = __builtin_bit_cast(bf16x8e, u32x4e{pm[0], pm[1], pm[2], pm[3]});
+    zl[KSX - 1] = __builtin_bit_cast(bf16x8e, u32x4e{pl[0], pl[1], pl[2], pl[3]});
+  } else {
     float mu = 0.f, inv = 1.f;
     const bool ln = a.ln_stats != nullptr || a.ln_inline != 0;
     if (a.ln_stats != nullptr) {
@@ -146,7 +189,7 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
     if (a.ln_inline != 0) x6_row_stats(raw, a.ln_eps, a.ln_mode, mu, inv);
     typedef unsigned u32x4e __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int s = 0; s < EKS; ++s) {
+    for (int s = 0; s < KSX && s < EKS; ++s) {
       float v[8] = {raw[s][0].x, raw[s][0].y, raw[s][0].z, raw[s][0].w, raw[s][1].x, raw[s][1].y, raw[s][1].z, raw[s][1].w};
       if (ln) {
         const f32x4e g0 = *reinterpret_cast<const f32x4e*>(a.ln_g + 16 * s + 8 * hi), g1 = *reinterpret_cast<const f32x4e*>(a.ln_g + 16 * s + 8 * hi + 4);
@@ -181,8 +224,9 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
   const int er = lane >> 3, eq = lane & 7;  // (row er + 8 i of the wave's 32, 16-byte quad eq of the 32-column block)
   const bool wave_full = rows >= (wv + 1) * ER;
   float* sE = s_e + wv * (ER * ELDE);
-  const float* __restrict__ ps = a.psrc + r * a.N * OUTW;
-  const float* __restrict__ pd = a.pdst + r * a.N * OUTW;
+  const float* __restrict__ ps = ENC ? nullptr : a.psrc + r * a.N * OUTW;
+  const float* __restrict__ pd = ENC ? nullptr : a.pdst + r * a.N * OUTW;
+  const float* __restrict__ benc = !ENC ? nullptr : (a.bias_g ? a.bias_g + (r * a.G + (size_t)t.g) * EOUT : a.bias);  // (an edge tile lies inside one graph)
   float* __restrict__ outp = a.out + (r * a.E + (size_t)row0) * OUTW;
   int gs[4], gd[4];
 #pragma unroll
@@ -190,6 +234,7 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
 
   // the gathered addends of a slice: 8 rows x 128 contiguous bytes per instruction, from both projection tables
   auto gather = [&](int ob, f32x4e (&us)[4], f32x4e (&ud)[4]) {
+    if constexpr (ENC) return;  // (no gathered addends: the slice adds its bias quad itself)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if constexpr (NARROW) {
@@ -219,9 +264,9 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
 #pragma unroll
     for (int p3 = 0; p3 < 3; ++p3) A[0][p3] = *reinterpret_cast<const bf16x8e*>(wb + p3 * 1024);
 #pragma unroll
-    for (int s = 0; s < EKS; ++s) {
+    for (int s = 0; s < KSX; ++s) {
       const int c = s & 1;
-      if (s + 1 < EKS) {
+      if (s + 1 < KSX) {
 #pragma unroll
         for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8e*>(wb + (3 * (s + 1) + p3) * 1024);
       }
@@ -233,8 +278,11 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zh[s], acc, 0, 0, 0);
     }
     // the gathered addends are needed now — and with them (in-order counter) the next slice's fragments have landed; the stores below are never waited for
+    f32x4e bq = {0.f, 0.f, 0.f, 0.f};  // ENCODER form: the slice's bias quad is the only addend (the same for every row; 36 registers instead of the four addend arrays)
+    if constexpr (ENC) { if (benc) bq = *reinterpret_cast<const f32x4e*>(benc + 32 * ob + 4 * eq); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(us[0]), "+v"(us[1]), "+v"(us[2]), "+v"(us[3]), "+v"(ud[0]), "+v"(ud[1]), "+v"(ud[2]), "+v"(ud[3]));  // (their loads were issued a slice ago: the wait above is theirs)
+    if constexpr (!ENC)
+      asm volatile("" : "+v"(us[0]), "+v"(us[1]), "+v"(us[2]), "+v"(us[3]), "+v"(ud[0]), "+v"(ud[1]), "+v"(ud[2]), "+v"(ud[3]));  // (their loads were issued a slice ago: the wait above is theirs)
     // C/D layout (lane (n, hi): outputs 8 g + 4 hi + (0..3) of row n in registers 4 g ..) -> the wave's slice of s_e -> (row, quad)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -243,8 +291,8 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
     for (int i = 0; i < 4; ++i) {
       const int lr = er + 8 * i;
       f32x4e v = *reinterpret_cast<const f32x4e*>(sE + lr * ELDE + 4 * eq);
-      v += us[i];
-      v += ud[i];
+      if constexpr (ENC) v += bq;
+      else { v += us[i]; v += ud[i]; }
       float vv[4] = {v.x, v.y, v.z, v.w};
       if (a.act == 1) {
 #pragma unroll
@@ -513,6 +561,58 @@ int32_t launch_proj_x6(const Tile* tiles, size_t n_tiles, const float* nf, size_
 
 size_t edge_x6_scratch_bytes() { return sizeof(__bf16) * 3 * (size_t)EK * EOUT; }
 
+// ---- the ENCODER form: (10, 5, .) => 128 unprojected ----
+// W ([10 + 5 + 5 (+ dg)][ldw] row-major: the ef rows, the source rows, the destination rows) -> per 32-output slice 6 fragments in k_edge_x6_prep's format over
+// the zero-padded K = 32 of the kernel's lane assembly: k 0..9 = ef rows, 10..14 = source rows, 15 = destination row 0, 16..19 = destination rows 1..4, 20..31 = 0
+__global__ void k_edge_enc_prep(const float* __restrict__ W, int ldw, __bf16* __restrict__ Wp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (ob, s, lane, j pair)
+  if (idx >= ENOB * 2 * 64 * 4) return;
+  const int jp = idx & 3, lane = (idx >> 2) & 63, s = (idx >> 8) & 1, ob = idx >> 9;
+  const int m = lane & 31, h = lane >> 5;
+  auto wrow = [](int k) { return k < 15 ? k : (k == 15 ? 15 : (k < 20 ? k : -1)); };  // (rows 0..9 ef, 10..14 source, 15..19 destination: the weight's own order)
+  float w[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int k = 16 * s + 8 * h + 2 * jp + e, row = wrow(k);
+    w[e] = row >= 0 ? W[(size_t)row * ldw + 32 * ob + m] : 0.f;
+  }
+  unsigned hh, mm, ll;
+  esplit2(w[0], w[1], hh, mm, ll);
+  unsigned* o = reinterpret_cast<unsigned*>(Wp) + ((size_t)ob * 6 + 3 * s) * 256 + lane * 4 + jp;
+  o[0] = hh; o[256] = mm; o[512] = ll;
+}
+
+size_t edge_enc_scratch_bytes() { return (size_t)ENOB * 6 * 1024; }
+
+int32_t launch_edge_enc_prep(const float* We, int ldw, void* scratch, hipStream_t s) {
+  ProfScope ps("k_edge_x6_prep", s);
+  GNX_LAUNCH(k_edge_enc_prep, dim3((unsigned)((ENOB * 2 * 64 * 4 + 255) / 256)), dim3(256), 0, s, We, ldw, static_cast<__bf16*>(scratch));
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+// ef' = act(We^T [ef ; nf[src] ; nf[dst]] + bias) at (10, 5, .) => 128 with the per-destination sums and column sums of k_edge_x6; bias_g: per-graph bias (gf fold)
+int32_t launch_edge_enc(const Tile* tiles, size_t n_tiles, const float* ef, size_t E, const float* nf, size_t N, const float* We, int ldw, const float* bias, const float* bias_g,
+                        int G, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out, size_t n_agg_rows, const int* chunk_row0, int64_t R,
+                        void* scratch, hipStream_t s) {
+  if (n_tiles == 0) return GNX_OK;
+  if (!tiles || !ef || !nf || !We || !src || !dst || !out || !scratch || (((uintptr_t)scratch | (uintptr_t)out | (uintptr_t)bias | (uintptr_t)bias_g | (uintptr_t)agg_out) & 15))
+    return fail(GNX_ERR_INVALID_ARG, "k_edge_x6 (encoder form): NULL or misaligned operand");
+  if (agg_out && !chunk_row0) return fail(GNX_ERR_INVALID_ARG, "k_edge_x6 (encoder form): per-destination sums need the chunk table");
+  const __bf16* Wp = static_cast<const __bf16*>(prepared_planes(PREP_ENC, We, nullptr, ldw));
+  if (!Wp) {
+    if (const int32_t rc = launch_edge_enc_prep(We, ldw, scratch, s)) return rc;
+    Wp = static_cast<const __bf16*>(scratch);
+  }
+  EdgeX6Args a{};
+  a.tiles = tiles; a.ef = ef; a.E = E; a.Wp = Wp; a.N = N; a.src = src; a.dst = dst; a.act = act; a.out = out; a.colsum = colsum; a.n_tiles = n_tiles;
+  a.agg_out = agg_out; a.n_agg_rows = n_agg_rows; a.chunk_row0 = chunk_row0; a.oe = EOUT; a.nf = nf; a.bias = bias; a.bias_g = bias_g; a.G = G;
+  ProfScope ps("k_rows_gemm_edge", s);  // (the name the edge update has in every profile and bench line)
+  GNX_LAUNCH((k_edge_x6<false, 2>), dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
 // We ([128][ldw], its first 128 columns) -> the fragments k_edge_x6 (and the edge form of k_ffn_x6) stage per 32-output slice
 int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s, int n_out) {
   ProfScope ps("k_edge_x6_prep", s);
@@ -538,8 +638,8 @@ int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_
   if (ln_inline) { if (ln_stats || !ln_g || !ln_b) return fail(GNX_ERR_INVALID_ARG, "k_edge_x6: statistics in the kernel exclude a statistics table and need gamma / beta"); a.ln_inline = 1; a.ln_eps = ln_eps; a.ln_mode = ln_mode; }
   a.oe = oe;
   ProfScope ps("k_rows_gemm_edge", s);  // (the name the edge update has in every profile and bench line)
-  if (oe == EOUT) GNX_LAUNCH(k_edge_x6<false>, dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
-  else GNX_LAUNCH(k_edge_x6<true>, dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
+  if (oe == EOUT) GNX_LAUNCH((k_edge_x6<false, EKS>), dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
+  else GNX_LAUNCH((k_edge_x6<true, EKS>), dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }

@@ -15,6 +15,8 @@ int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t
 int32_t launch_proj_x6_prep(const float* Ws, const float* Wd, int ldw, void* scratch, hipStream_t s);  // gnx_edge_x6.hip
 size_t proj_x6_scratch_bytes();
 int32_t launch_ffn_x6_prep(const float* W1, const float* W2, int d, void* scratch, hipStream_t s);     // gnx_ffn_x6.hip
+int32_t launch_edge_enc_prep(const float* We, int ldw, void* scratch, hipStream_t s);                  // gnx_edge_x6.hip
+size_t edge_enc_scratch_bytes();
 size_t ffn_x6_scratch_bytes(int d);
 }  // namespace gnx
 
@@ -56,6 +58,7 @@ int32_t run_entry(const gnx_prepared::Entry& e, hipStream_t s) {
     case PREP_EDGE: return launch_edge_x6_prep(static_cast<const float*>(e.w0), e.ldw, e.planes, s, e.n);
     case PREP_PROJ: return launch_proj_x6_prep(static_cast<const float*>(e.w0), static_cast<const float*>(e.w1), e.n, e.planes, s);
     case PREP_FFN: return launch_ffn_x6_prep(static_cast<const float*>(e.w0), static_cast<const float*>(e.w1), e.n, e.planes, s);
+    case PREP_ENC: return launch_edge_enc_prep(static_cast<const float*>(e.w0), e.n, e.planes, s);
   }
   return fail(GNX_ERR_INVALID_ARG, "prepared parameters: unknown entry");
 }
@@ -72,6 +75,7 @@ int32_t add_entry(gnx_prepared* q, PreparedKind kind, const void* w0, const void
 // the matrix-core forms of a block's edge function: the ef rows' block (128 -> 128 or 128 -> at most 32) and the two node-projection blocks
 int32_t add_block(gnx_prepared* q, const gnx_block_params& p) {
   const float* We = p.edgefn.weight;
+  if (We && p.de == 10 && p.dn == 5 && p.oe == 128) return add_entry(q, PREP_ENC, We, nullptr, p.oe, p.oe, edge_enc_scratch_bytes());  // the encoder form
   if (!We || p.de != 128 || p.dn <= 0 || p.oe <= 0) return GNX_OK;  // (no six-term form: nothing to prepare, the forward runs as before)
   int32_t rc = GNX_OK;
   if (p.oe == 128 || p.oe <= 32) rc = add_entry(q, PREP_EDGE, We, nullptr, p.oe, p.oe, sizeof(uint16_t) * 3 * 128 * (size_t)((p.oe + 31) / 32 * 32));

@@ -32,6 +32,11 @@ bool proj_x6_applies(int dn, int oe, const float* nf, const float* W, const floa
 int32_t launch_proj_x6(const Tile* tiles, size_t n_tiles, const float* nf, size_t N, const float* ln_stats, const float* ln_g, const float* ln_b, const float* Ws, const float* Wd,
                        int ldw, const float* bias, const float* bias_g, int G, float* out_s, float* out_d, int64_t R, void* scratch, hipStream_t s, bool only_d = false,
                        float* zn_out = nullptr);
+// the encoder form of k_edge_x6 ((10, 5, .) => 128 unprojected; gnx_edge_x6.hip)
+size_t edge_enc_scratch_bytes();
+int32_t launch_edge_enc(const Tile* tiles, size_t n_tiles, const float* ef, size_t E, const float* nf, size_t N, const float* We, int ldw, const float* bias, const float* bias_g,
+                        int G, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out, size_t n_agg_rows, const int* chunk_row0, int64_t R,
+                        void* scratch, hipStream_t s);
 // gnx_edge_n.hip: the edge update with the source side gathered raw (K = 128 + 64) and a register epilogue
 size_t edge_n_scratch_bytes();
 bool edge_n_enabled();
@@ -1163,6 +1168,7 @@ static int wide_slices(const gnx_graphs* h) {
 // the edge update's prepared weight block: three bf16 planes in 32-output slices (k_edge_x6_prep); k_edge_n's adds the source rows' block (K = 128 + 64)
 static size_t x6_tab_bytes(int de, int oe) {
   const size_t x6 = sizeof(__bf16) * 3 * (size_t)de * (size_t)((oe + 31) / 32 * 32);
+  if (de == 10 && oe == 128) return std::max(x6, edge_enc_scratch_bytes());  // (the encoder form's zero-padded K = 32)
   return (de == 128 && oe == 128) ? std::max(x6, edge_n_scratch_bytes()) : x6;
 }
 
@@ -1499,12 +1505,23 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
   const bool edge_x6n = (phase & 1) && !edge_x6 && project && a.de == 128 && a.oe >= 1 && a.oe <= 32 && a.dn > 0 && ef_vec && !agg_fuse &&
                         (!a.ln_stats[0] || (al16(a.ln_g[0]) && al16(a.ln_b[0]))) && !form(GNX_FLAG_EDGE_FP32) && !form(GNX_FLAG_EDGE_NARROW_FP32) &&
                         (size_t)h->E >= 4096;  // (GNX_FLAG_EDGE_NARROW_FP32: this form alone back on k_rows_gemm)
+  // the ENCODER form: (10, 5, .) => 128 unprojected (README ex.3's / config 4's encoder) on the six-term scheme with the row's 20 inputs assembled in registers
+  // (k_rows_gemm's packed element loader: 209 us at 1M edges against ~110 us of traffic; GNX_FLAG_EDGE_FP32 keeps it)
+  const bool edge_enc = (phase & 1) && !project && a.de == 10 && a.dn == 5 && a.oe == 128 && !a.ln_stats[0] && !a.ln_inline_e && !a.ffe_w1 && edge_out_vec && (agg_fuse || a.on == 0) &&
+                        al16(a.be) && !form(GNX_FLAG_EDGE_FP32) && (size_t)h->E >= 4096 && a.ef && a.nf;
   if (edge_x6n) {
     if ((rc = launch_edge_x6(h->d_etiles, n_et, a.ef, (size_t)a.E, a.ln_stats[0], a.ln_g[0], a.ln_b[0], a.We, a.oe, proj_s, proj_d, (size_t)a.N, a.rowval, h->d_edge_dst, a.act_e,
                              a.ef_out, a.og > 0 ? pe : nullptr, nullptr, 0, nullptr, R, x6_tab, s, false, 0.f, 0, a.oe)))
       return rc;
   } else
-  if (edge_x6 && a.ffe_w1 && edge_n) return fail(GNX_ERR_INVALID_ARG, "internal: the one-launch core form was asked of a block whose projections are k_edge_n's");
+  if (edge_enc) {
+    if ((rc = launch_edge_enc(h->d_etiles, n_et, a.ef, (size_t)a.E, a.nf, (size_t)a.N, a.We, a.oe, a.be, a.dg > 0 ? bias_e : nullptr, a.G, a.rowval, h->d_edge_dst, a.act_e, a.ef_out,
+                              a.og > 0 ? pe : nullptr, agg_fuse ? agg_tab : nullptr, (size_t)h->n_agg_rows, h->d_chunk_row0, R, x6_tab, s)))
+      return rc;
+  } else
+  if (edge_x6 && a.ffe_w1 && edge_n) {
+    return fail(GNX_ERR_INVALID_ARG, "internal: the one-launch core form was asked of a block whose projections are k_edge_n's");
+  } else
   if (edge_x6 && a.ffe_w1) {  // GNCore: edge update + edge FeedForward + residuals in one launch (edge form of k_ffn_x6); ef_out receives the CORE's edge output
     gnx_ffn ff{};
     ff.fc1.weight = a.ffe_w1; ff.fc1.bias = a.ffe_b1; ff.fc1.act = a.ffe_act1; ff.fc2.weight = a.ffe_w2; ff.fc2.bias = a.ffe_b2; ff.fc2.act = a.ffe_act2;

@@ -337,3 +337,51 @@ def test_wide_node_projections_on_bf16_matrix_cores(gn, R, graphs, core):
     for a, b in ((y.ef, y0.ef), (y.nf, y0.nf), (y.gf, y0.gf)):
         a, b = U.from_jl(a).astype(np.float64), U.from_jl(b).astype(np.float64)
         assert np.isfinite(a).all() and np.max(np.abs(a - b)) <= 2e-6 * max(np.max(np.abs(b)), 1e-30)
+
+
+@pytest.mark.parametrize("din,act,R,graphs", [((10, 5, 0), (0, 0, 0), 1, ((4300, 9000),)), ((10, 5, 3), (1, 1, 0), 1, ((2500, 6000), (1700, 5000), (300, 700))),
+                                             ((10, 5, 0), (2, 0, 0), 2, ((700, 4137),))])
+def test_wide_encoder_edge_update_on_bf16_matrix_cores(gn, din, act, R, graphs):
+    """GNBlock (10, 5, .) => (128, 64, 32) — README ex.3's / config 4's ENCODER — from 4096 edges on: the unprojected edge update
+    W^T [ef ; nf[src] ; nf[dst]] + b runs as the encoder form of k_edge_x6 (the row's 20 inputs assembled in the lane's registers as one zero-padded
+    K = 32, six bf16 matrix-core terms per fp32 product, the per-destination and column sums of the projected form) — against the float64 oracle
+    at 1e-5*scale (ef', and nf' / gf' which read its sums), against the fp32-MFMA form of the same call (GNX_FLAG_EDGE_FP32: k_rows_gemm's packed
+    element loader) normwise at 2e-6, hub destinations (runs that cross chunks and tiles), several graphs with gf (per-graph bias), replicas, a
+    transcendental activation, a ragged edge count — and with prepared parameters (no preparation launch, same bits)."""
+    import torch
+    rng = np.random.default_rng(8800 + din[2] + R)
+    cs = [U.er_csc(rng, n, e) for n, e in graphs]
+    if len(graphs) == 1 and R == 1:  # hub destinations on the single-graph case
+        cs = [_hub_csc(rng, graphs[0][0], 5, 400, 0, 4)]
+    g = gn.GNGraphBatch.from_csc([c for c, _ in cs], [r for _, r in cs], [n for n, _ in graphs])
+    assert g.n_edges >= 4096
+    dout = (128, 64, 32)
+    p = O.make_block_params(rng, din, dout, act=act)
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, g.n_graphs, din)
+    ef, nf = (ef * 2 - 0.5).astype(np.float32), (nf * 3 - 1).astype(np.float32)
+    blk = U.block_from_params(gn, p)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    gn.profile_reset(); gn.profile_enable(True)
+    y = blk(x)
+    gn.profile_enable(False)
+    prof = gn.profile_read(); gn.profile_reset()
+    if not U.default_flags(gn) & gn._lib.FLAG_EDGE_FP32:
+        assert "k_edge_x6_prep" in prof, set(prof)  # (the encoder form's weight preparation goes by that name)
+    ref, scale = O.block_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    for name, got, r_, s_ in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r_, s_, name)
+    gn.profile_enable(True)
+    y0 = blk(x, flags=gn._lib.FLAG_EDGE_FP32)
+    gn.profile_enable(False)
+    assert "k_edge_x6_prep" not in set(gn.profile_read()); gn.profile_reset()
+    for a, b in ((y.ef, y0.ef), (y.nf, y0.nf), (y.gf, y0.gf)):
+        a_, b_ = U.from_jl(a).astype(np.float64), U.from_jl(b).astype(np.float64)
+        assert np.isfinite(a_).all() and np.max(np.abs(a_ - b_)) <= 2e-6 * max(np.max(np.abs(b_)), 1e-30)
+    blk.prepare()
+    assert blk._prepared.nbytes() == 4 * 6 * 1024
+    gn.profile_enable(True)
+    y1 = blk(x)
+    gn.profile_enable(False)
+    assert not {n for n in gn.profile_read() if n.endswith("_prep")}; gn.profile_reset()
+    for a, b in ((y.ef, y1.ef), (y.nf, y1.nf), (y.gf, y1.gf)):
+        assert torch.equal(a, b)
