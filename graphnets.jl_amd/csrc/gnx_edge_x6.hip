@@ -48,14 +48,17 @@ __device__ __forceinline__ void esplit2(float x0, float x1, unsigned& h, unsigne
 // W ([K = 128][ldw] row-major, the first 128 columns) -> per 32-output slice ob one block of ENF fragments of 1 KB = 64 lanes x 8 bf16:
 //   fragment 3 s + p (s: k16-step, p: part), lane (m, h), j:  part_p( W[16 s + 8 h + j][32 ob + m] )
 // (n_out < 32 * n_ob: the columns beyond n_out are zero — the narrow form's single, padded slice)
-__global__ void k_edge_x6_prep(const float* __restrict__ W, int ldw, int n_out, int n_ob, __bf16* __restrict__ Wp) {
+// gamma != nullptr: the rows are scaled by gamma[k] first — a LayerNorm's scale folded into the weights it feeds (W^T (gamma . xhat + beta) =
+// (gamma . W)^T xhat + W^T beta; the constant W^T beta comes from k_fold_beta)
+__global__ void k_edge_x6_prep(const float* __restrict__ W, int ldw, int n_out, int n_ob, __bf16* __restrict__ Wp, const float* __restrict__ gamma) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (ob, s, lane, j pair)
   if (idx >= n_ob * EKS * 64 * 4) return;
   const int jp = idx & 3, lane = (idx >> 2) & 63, s = (idx >> 8) % EKS, ob = (idx >> 8) / EKS;
   const int m = lane & 31, h = lane >> 5, k = 16 * s + 8 * h + 2 * jp;
   unsigned hh, mm, ll;
   const bool in = 32 * ob + m < n_out;
-  esplit2(in ? W[(size_t)k * ldw + 32 * ob + m] : 0.f, in ? W[(size_t)(k + 1) * ldw + 32 * ob + m] : 0.f, hh, mm, ll);
+  const float g0 = gamma ? gamma[k] : 1.f, g1 = gamma ? gamma[k + 1] : 1.f;
+  esplit2(in ? g0 * W[(size_t)k * ldw + 32 * ob + m] : 0.f, in ? g1 * W[(size_t)(k + 1) * ldw + 32 * ob + m] : 0.f, hh, mm, ll);
   unsigned* o = reinterpret_cast<unsigned*>(Wp) + ((size_t)ob * ENF + 3 * s) * 256 + lane * 4 + jp;
   o[0] = hh; o[256] = mm; o[512] = ll;
 }
@@ -614,11 +617,33 @@ int32_t launch_edge_enc(const Tile* tiles, size_t n_tiles, const float* ef, size
 }
 
 // We ([128][ldw], its first 128 columns) -> the fragments k_edge_x6 (and the edge form of k_ffn_x6) stage per 32-output slice
-int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s, int n_out) {
+// out[o] = (bias ? bias[o] : 0) + sum_k beta[k] W[k][o], k ascending (K x n_out weights with row distance ldw): the constant a folded LayerNorm leaves behind
+__global__ void k_fold_beta(const float* __restrict__ W, int ldw, int K, int n_out, const float* __restrict__ beta, const float* __restrict__ bias, float* __restrict__ out) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n_out) return;
+  float acc = bias ? bias[o] : 0.f;
+  for (int k = 0; k < K; ++k) acc = fmaf(beta[k], W[(size_t)k * ldw + o], acc);
+  out[o] = acc;
+}
+int32_t launch_fold_beta(const float* W, int ldw, int K, int n_out, const float* beta, const float* bias, float* out, hipStream_t s) {
+  GNX_LAUNCH(k_fold_beta, dim3((unsigned)((n_out + 127) / 128)), dim3(128), 0, s, W, ldw, K, n_out, beta, bias, out);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+// the folded form's scratch: the planes of (gamma . We), then the 128 floats of We^T beta
+size_t edge_x6_fold_scratch_bytes() { return edge_x6_scratch_bytes() + 128 * sizeof(float); }
+
+// ln_gamma / ln_beta != nullptr (128 -> 128 only): the LayerNorm folded in — planes of (gamma . We) and, behind them (edge_x6_scratch_bytes()), We^T beta
+int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s, int n_out, const float* ln_gamma, const float* ln_beta) {
   ProfScope ps("k_edge_x6_prep", s);
   const int n_ob = (n_out + 31) / 32;
-  GNX_LAUNCH(k_edge_x6_prep, dim3((unsigned)((n_ob * EKS * 64 * 4 + 255) / 256)), dim3(256), 0, s, We, ldw, n_out, n_ob, static_cast<__bf16*>(scratch));
+  GNX_LAUNCH(k_edge_x6_prep, dim3((unsigned)((n_ob * EKS * 64 * 4 + 255) / 256)), dim3(256), 0, s, We, ldw, n_out, n_ob, static_cast<__bf16*>(scratch), ln_gamma);
   GNX_HIP(hipGetLastError());
+  if (ln_gamma) {
+    if (n_out != EOUT || !ln_beta) return fail(GNX_ERR_INVALID_ARG, "k_edge_x6_prep: the folded form is 128 -> 128 with gamma and beta");
+    return launch_fold_beta(We, ldw, EK, EOUT, ln_beta, nullptr, reinterpret_cast<float*>(static_cast<char*>(scratch) + edge_x6_scratch_bytes()), s);
+  }
   return GNX_OK;
 }
 
@@ -629,7 +654,7 @@ int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_
   if (oe != EOUT && (oe < 1 || oe > 32 || agg_out)) return fail(GNX_ERR_INVALID_ARG, "k_edge_x6: output width 128, or 1..32 without per-destination sums");
   const __bf16* Wp = static_cast<const __bf16*>(prepared_planes(PREP_EDGE, We, nullptr, oe));  // made once with the layer (gnx_*_prepare) ...
   if (!Wp) {                                                                                        // ... or by a launch in front of this forward
-    if (const int32_t rc = launch_edge_x6_prep(We, ldw, scratch, s, oe)) return rc;
+    if (const int32_t rc = launch_edge_x6_prep(We, ldw, scratch, s, oe, nullptr, nullptr)) return rc;
     Wp = static_cast<const __bf16*>(scratch);
   }
   EdgeX6Args a{};

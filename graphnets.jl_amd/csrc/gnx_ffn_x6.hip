@@ -67,7 +67,9 @@ __device__ __forceinline__ void x6_row_stats_if(const f32x4x (&raw)[KSX][2], flo
 //   fragment 3 s + p            (s < D/16: k16-step of the first product, p: part)  lane (m, h), j: part_p( W1[16 s + 8 h + j][32 hs + m] )
 //   fragment NF + 3 (2 ob + t) + p   (ob < D/32: output block, t < 2: k16-step)     lane (m, h), j: part_p( W2[32 hs + unit(16 t + 8 h + j)][32 ob + m] )
 // W1 = fc1.weight ((4D x D) column-major == [D][4D] row-major), W2 = fc2.weight ((D x 4D) column-major == [4D][D] row-major).
-__global__ void k_ffn_x6_prep(const float* __restrict__ W1, const float* __restrict__ W2, int D, __bf16* __restrict__ Wp) {
+// gamma != nullptr: W1's rows are scaled by gamma[k] — the LayerNorm in front of the FeedForward folded into its first layer (the constant
+// W1^T beta joins b1: k_fold_beta)
+__global__ void k_ffn_x6_prep(const float* __restrict__ W1, const float* __restrict__ W2, int D, __bf16* __restrict__ Wp, const float* __restrict__ gamma) {
   const int H = 4 * D, NF = 3 * D / 16;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (hs, g, lane, j): g < D/16 groups of three fragments per product
   if (idx >= D * H) return;
@@ -77,7 +79,7 @@ __global__ void k_ffn_x6_prep(const float* __restrict__ W1, const float* __restr
   __bf16 a, b, c;
   {
     const int k = 16 * g + 8 * h + j;
-    split3x(W1[(size_t)k * H + 32 * hs + m], a, b, c);
+    split3x((gamma ? gamma[k] : 1.f) * W1[(size_t)k * H + 32 * hs + m], a, b, c);
     __bf16* f = slice + (size_t)(3 * g) * 512 + lane * 8 + j;
     f[0] = a; f[512] = b; f[1024] = c;
   }
@@ -91,12 +93,16 @@ __global__ void k_ffn_x6_prep(const float* __restrict__ W1, const float* __restr
 }
 
 // EDGE form (GNCore, D = 128): the projected edge update of the same rows — k_edge_x6's phase (gnx_edge_x6.hip) — runs behind the FeedForward, whose
-// result waits in the out^T accumulator: ef' is added there, slice by slice, and never reaches memory
+// result waits in the out^T accumulator: ef' is added there, slice by slice, and never reaches memory.
+// Both LayerNorms of the core's edge rows are FOLDED into the weight planes (round 5): gn1(x) = g1 . xhat + b1' and gn2(x) = g2 . xhat + b2' share
+// xhat = (x - mean) / (sigma + eps), so We^T gn1(x) = (g1 . We)^T xhat + We^T b1' and W1^T gn2(x) + bias1 = (g2 . W1)^T xhat + (W1^T b2' + bias1): the
+// preparation kernels scale the weight rows (k_edge_x6_prep / k_ffn_x6_prep with gamma) and k_fold_beta makes the two constant vectors; the kernel
+// normalises and splits the rows ONCE — the same fragments feed the FeedForward's first product and the edge update; round 4 reloaded, re-normalised and
+// re-split the rows between the two (11 k of a tile's 180 k clocks and a second pass over x)
 struct FfnX6Edge {
   const Tile* tiles;       // the handle's edge tiles (<= 128 rows): one workgroup each
-  const float* ln1_g;      // gn1 (the statistics are shared with gn2: FfnX6Args::ln_eps / ln_mode)
-  const float* ln1_b;
-  const __bf16* Wpe;       // k_edge_x6_prep's fragments of We
+  const float* c1;         // [128] We_e^T beta1: what gn1's shift leaves behind once its scale is folded into the weight planes
+  const __bf16* Wpe;       // k_edge_x6_prep's fragments of (gamma1 . We)
   const float* psrc;       // [R][N][128]
   const float* pdst;       // [R][N][128] (bias and gf fold included)
   size_t N;
@@ -157,7 +163,6 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   __shared__ __attribute__((aligned(16))) unsigned char s_w2b[SLB / 2];
   __shared__ float s_b1[H];
   __shared__ int s_src[EDGE ? XBM : 1], s_dst[EDGE ? XBM : 1];
-  __shared__ __attribute__((aligned(16))) float s_ln1[2][EDGE ? D : 4];  // gn1's gamma / beta (read per k16-step when the rows are reloaded: from memory the compiler requests all of them at once — 128 registers)
   __shared__ int s_seg[2][EDGE ? 66 : 1];  // per 64-row pass: first row of every destination run; [n_seg] = valid rows of the pass; [65] = n_seg
 
 #ifdef GNX_X6_STAMPS_BUILD
@@ -206,8 +211,6 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       const int trows = (int)(rend - wg_row0), rc = tid < trows ? tid : trows - 1;
       s_src[tid] = a.e.src[wg_row0 + rc];
       s_dst[tid] = a.e.dst[wg_row0 + rc];
-      s_ln1[0][tid] = a.e.ln1_g[tid];
-      s_ln1[1][tid] = a.e.ln1_b[tid];
     }
   }
   for (int i = tid; i < H; i += 64 * XW) s_b1[i] = a.b1 ? a.b1[i] : 0.f;
@@ -215,38 +218,29 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   // ---- the wave's z rows as B fragments: lane (n, hi) holds k = 16 s + 8 hi + j (j < 8) of row n for every k16-step s, in three parts ----
   bf16x8x zh[KS], zm[KS], zl[KS];
   float mu = 0.f, inv = 1.f;
-  // (re)load the wave's rows; STATS: their statistics from the registers (gnx_x6_stats.h); ln: normalise with (g, b); split
-  // HALVES: the k16-steps in two rounds of loads (no statistics: the whole row need not be present at once; half the registers)
-  auto load_z = [&](const float* __restrict__ g, const float* __restrict__ b, bool ln, bool stats, auto halves) {
-    constexpr int NH = decltype(halves)::value ? 2 : 1, KH = KS / NH;
+  // load the wave's rows; stats: their statistics from the registers (gnx_x6_stats.h); ln: normalise (and, outside the EDGE form, scale and shift with (g, b)); split
+  auto load_z = [&](const float* __restrict__ g, const float* __restrict__ b, bool ln, bool stats) {
     f32x4x raw[KS][2];
-    // (NH == 2: `tok` is 0, opaque to the compiler and made to depend on each step's last result — the addresses of the next step's reads hang on
-    //  it.  Neither a scheduling barrier nor a memory clobber keeps reads of restrict / non-escaping memory in place: left alone, all 16 row
-    //  quads and all 32 parameter quads are requested up front, 190 registers beside the 64 of out^T.)
-    int tok = 0;
 #pragma unroll
-    for (int hf = 0; hf < NH; ++hf) {
-#pragma unroll
-    for (int s = hf * KH; s < (hf + 1) * KH; ++s) {
-      raw[s][0] = *reinterpret_cast<const f32x4x*>(zrow + tok + 16 * s + 8 * hi);
-      raw[s][1] = *reinterpret_cast<const f32x4x*>(zrow + tok + 16 * s + 8 * hi + 4);
+    for (int s = 0; s < KS; ++s) {
+      raw[s][0] = *reinterpret_cast<const f32x4x*>(zrow + 16 * s + 8 * hi);
+      raw[s][1] = *reinterpret_cast<const f32x4x*>(zrow + 16 * s + 8 * hi + 4);
     }
-    if (NH == 1 && stats) x6_row_stats_if(raw, a.ln_eps, a.ln_mode, mu, inv);
+    if (stats) x6_row_stats_if(raw, a.ln_eps, a.ln_mode, mu, inv);
 #pragma unroll
-    for (int s = hf * KH; s < (hf + 1) * KH; ++s) {
+    for (int s = 0; s < KS; ++s) {
       float v[8] = {raw[s][0].x, raw[s][0].y, raw[s][0].z, raw[s][0].w, raw[s][1].x, raw[s][1].y, raw[s][1].z, raw[s][1].w};
       if (ln) {  // (x - mean) * inv, then fma(gamma, ., beta): the arithmetic of k_layernorm2_v4 / k_ffn_fused
-        f32x4x g0, g1, b0, b1;
-        if constexpr (NH == 2) {  // (the reload of the EDGE form: gn1's parameters from LDS)
-          g0 = *reinterpret_cast<const f32x4x*>(&s_ln1[0][tok + 16 * s + 8 * hi]); g1 = *reinterpret_cast<const f32x4x*>(&s_ln1[0][tok + 16 * s + 8 * hi + 4]);
-          b0 = *reinterpret_cast<const f32x4x*>(&s_ln1[1][tok + 16 * s + 8 * hi]); b1 = *reinterpret_cast<const f32x4x*>(&s_ln1[1][tok + 16 * s + 8 * hi + 4]);
-        } else {
-          g0 = *reinterpret_cast<const f32x4x*>(g + 16 * s + 8 * hi); g1 = *reinterpret_cast<const f32x4x*>(g + 16 * s + 8 * hi + 4);
-          b0 = *reinterpret_cast<const f32x4x*>(b + 16 * s + 8 * hi); b1 = *reinterpret_cast<const f32x4x*>(b + 16 * s + 8 * hi + 4);
-        }
-        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        if constexpr (EDGE) {  // scale and shift live in the prepared weight planes: xhat itself is what both products read
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaf(gg[j], (v[j] - mu) * inv, bb[j]);
+          for (int j = 0; j < 8; ++j) v[j] = (v[j] - mu) * inv;
+        } else {
+          const f32x4x g0 = *reinterpret_cast<const f32x4x*>(g + 16 * s + 8 * hi), g1 = *reinterpret_cast<const f32x4x*>(g + 16 * s + 8 * hi + 4);
+          const f32x4x b0 = *reinterpret_cast<const f32x4x*>(b + 16 * s + 8 * hi), b1 = *reinterpret_cast<const f32x4x*>(b + 16 * s + 8 * hi + 4);
+          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaf(gg[j], (v[j] - mu) * inv, bb[j]);
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -254,22 +248,17 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
         split3x(v[j], x, y, w);
         zh[s][j] = x; zm[s][j] = y; zl[s][j] = w;
       }
-      if constexpr (NH == 2) {
-        typedef unsigned u32x4z __attribute__((ext_vector_type(4)));
-        asm volatile("" : "+v"(tok) : "v"(__builtin_bit_cast(u32x4z, zl[s]).w));
-      }
-    }
     }
   };
   if constexpr (EDGE) {
-    load_z(a.ln_g, a.ln_b, true, true, std::false_type{});  // gn2(x) for the FeedForward; (mu, inv) stay for gn1
+    load_z(nullptr, nullptr, true, true);  // xhat = (x - mean) / (sigma + eps): the operand of the FeedForward's first product AND of the edge update
   } else {
     const bool ln_in = D == 128 && a.ln_inline != 0;
     if (a.ln_stats != nullptr) {
       const float2 st = reinterpret_cast<const float2*>(a.ln_stats)[r * rows + rown];
       mu = st.x; inv = st.y;
     }
-    load_z(a.ln_g, a.ln_b, a.ln_stats != nullptr || ln_in, ln_in, std::false_type{});
+    load_z(a.ln_g, a.ln_b, a.ln_stats != nullptr || ln_in, ln_in);
   }
 
   f32x16x accO[NOB];
@@ -440,7 +429,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     //      sums and column sums written as k_edge_x6 writes them — and ef' itself NOT written: each slice's epilogue adds it to the FeedForward block of
     //      the same outputs, in the two-launch form's order ((W2^T H + b2) + ef') + x — every output bit-identical to k_edge_x6 + k_ffn_x6. ----
     stage_e(0, s_w2a);                         // (free since the barrier that ended the last step)
-    load_z(a.e.ln1_g, a.e.ln1_b, true, false, std::true_type{});  // gn1(x): the rows once more (the cache has them), the statistics from the prologue
+    // (the row fragments of the prologue are still in their registers: xhat feeds the edge update as it fed the FeedForward)
     const int trows = (int)(rend - wg_row0);
     const bool wave_full = trows >= (wv + 1) * XR;
     const int tile_id = blockIdx.x;
@@ -523,10 +512,12 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       asm volatile("" : "+v"(us[0]), "+v"(us[1]), "+v"(us[2]), "+v"(us[3]), "+v"(ud[0]), "+v"(ud[1]), "+v"(ud[2]), "+v"(ud[3]));
       asm volatile("" : "+v"(u1[0]), "+v"(u1[1]), "+v"(u1[2]), "+v"(u1[3]));
       const f32x4x bq = a.b2 ? *reinterpret_cast<const f32x4x*>(a.b2 + 32 * ob + 4 * eq) : zero4;
+      const f32x4x c1q = *reinterpret_cast<const f32x4x*>(a.e.c1 + 32 * ob + 4 * eq);  // We^T beta1 (gn1's shift, folded)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int lr = er + 8 * i;
         f32x4x v = *reinterpret_cast<const f32x4x*>(sE + lr * ELDE + 4 * eq);
+        v += c1q;
         v += us[i];
         v += ud[i];
         float vv[4] = {v.x, v.y, v.z, v.w};
@@ -647,11 +638,21 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
 
 size_t ffn_x6_scratch_bytes(int d) { return (size_t)3 * d * 4 * d * sizeof(__bf16) * 2; }
 
-// fc1 / fc2 weights of a FeedForward at width d (64 or 128) -> the fragments k_ffn_x6 stages (scratch: ffn_x6_scratch_bytes(d), 16-byte aligned)
-int32_t launch_ffn_x6_prep(const float* W1, const float* W2, int d, void* scratch, hipStream_t s) {
+int32_t launch_fold_beta(const float* W, int ldw, int K, int n_out, const float* beta, const float* bias, float* out, hipStream_t s);  // gnx_edge_x6.hip
+
+// the folded form's scratch: the planes with (gamma . W1), then the 4 d floats of b1 + W1^T beta
+size_t ffn_x6_fold_scratch_bytes(int d) { return ffn_x6_scratch_bytes(d) + (size_t)4 * d * sizeof(float); }
+
+// fc1 / fc2 weights of a FeedForward at width d (64 or 128) -> the fragments k_ffn_x6 stages (scratch: ffn_x6_scratch_bytes(d), 16-byte aligned).
+// ln_gamma / ln_beta != nullptr: the LayerNorm in front of it folded in — planes of (gamma . W1) and, behind them, b1 + W1^T beta (ffn_x6_fold_scratch_bytes)
+int32_t launch_ffn_x6_prep(const float* W1, const float* W2, int d, void* scratch, hipStream_t s, const float* ln_gamma, const float* ln_beta, const float* b1) {
   ProfScope ps("k_ffn_x6_prep", s);
-  GNX_LAUNCH(k_ffn_x6_prep, dim3((unsigned)((d * 4 * d + 255) / 256)), dim3(256), 0, s, W1, W2, d, static_cast<__bf16*>(scratch));
+  GNX_LAUNCH(k_ffn_x6_prep, dim3((unsigned)((d * 4 * d + 255) / 256)), dim3(256), 0, s, W1, W2, d, static_cast<__bf16*>(scratch), ln_gamma);
   GNX_HIP(hipGetLastError());
+  if (ln_gamma) {
+    if (!ln_beta) return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6_prep: the folded form needs gamma and beta");
+    return launch_fold_beta(W1, 4 * d, d, 4 * d, ln_beta, b1, reinterpret_cast<float*>(static_cast<char*>(scratch) + ffn_x6_scratch_bytes(d)), s);
+  }
   return GNX_OK;
 }
 
@@ -673,7 +674,7 @@ int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, co
   if (ln_inline && (ln_stats || d != 128)) return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6: statistics in the kernel are for width 128 and exclude a statistics table");
   const __bf16* Wp = static_cast<const __bf16*>(prepared_planes(PREP_FFN, ff.fc1.weight, ff.fc2.weight, d));  // made once with the layer (gnx_core_prepare) ...
   if (!Wp) {                                                                                                      // ... or by a launch in front of this forward
-    if (const int32_t rc = launch_ffn_x6_prep(ff.fc1.weight, ff.fc2.weight, d, scratch, s)) return rc;
+    if (const int32_t rc = launch_ffn_x6_prep(ff.fc1.weight, ff.fc2.weight, d, scratch, s, nullptr, nullptr, nullptr)) return rc;
     Wp = static_cast<const __bf16*>(scratch);
   }
   FfnX6Args a{};
@@ -712,11 +713,13 @@ int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, co
   return GNX_OK;
 }
 
-int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s, int n_out);  // gnx_edge_x6.hip
+int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s, int n_out, const float* ln_gamma, const float* ln_beta);  // gnx_edge_x6.hip
+size_t edge_x6_scratch_bytes();
 
 // A GNCore's edge rows in ONE launch (EDGE form of k_ffn_x6): out = x + ef' + FF(gn2(x)), ef' = act(We^T gn1(x) + Ps[src] + Pd[dst]) with its per-destination
 // sums (agg_out) and column sums (colsum) as k_edge_x6 writes them; ef' itself is never written.  Row statistics of x in the kernel.
-// scratch_e: edge_x6_scratch_bytes(), scratch_f: ffn_x6_scratch_bytes(128); both 16-byte aligned and free until the launch has run.
+// Both LayerNorms are folded into the weight planes (see FfnX6Edge): prepared with the layer (gnx_core_prepare), or here, per call.
+// scratch_e: edge_x6_fold_scratch_bytes(), scratch_f: ffn_x6_fold_scratch_bytes(128); both 16-byte aligned and free until the launch has run.
 int32_t launch_core_edge_x6(const Tile* tiles, size_t n_tiles, const float* x, size_t E, const gnx_layernorm* ln1, float ln_eps, int ln_mode, const float* We, int ldw,
                             const float* psrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* colsum, float* agg_out, size_t n_agg_rows,
                             const int* chunk_row0, const gnx_ffn& ff, const gnx_layernorm* ln2, float* out, int64_t R, void* scratch_e, void* scratch_f, hipStream_t s) {
@@ -728,22 +731,24 @@ int32_t launch_core_edge_x6(const Tile* tiles, size_t n_tiles, const float* x, s
         (uintptr_t)agg_out) & 15))
     return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6 (edge form): LayerNorm parameters missing, or an operand not 16-byte aligned");
   if (ff.fc2.act != GNX_ACT_IDENTITY) return fail(GNX_ERR_INVALID_ARG, "k_ffn_x6 (edge form): fc2 with an activation");
-  // both weight blocks: made once with the layer (gnx_core_prepare), or by launches in front of this forward
+  // both weight blocks with their LayerNorm folded in (planes, then the constant vector): made once with the layer (gnx_core_prepare: looked up
+  // by the weight and the gamma pointer), or by launches in front of this forward
   int32_t rc = GNX_OK;
-  const __bf16* Wpe = static_cast<const __bf16*>(prepared_planes(PREP_EDGE, We, nullptr, 128));
+  const char* Wpe = static_cast<const char*>(prepared_planes(PREP_EDGE, We, ln1->gamma, 128));
   if (!Wpe) {
-    if ((rc = launch_edge_x6_prep(We, ldw, scratch_e, s, 128))) return rc;
-    Wpe = static_cast<const __bf16*>(scratch_e);
+    if ((rc = launch_edge_x6_prep(We, ldw, scratch_e, s, 128, ln1->gamma, ln1->beta))) return rc;
+    Wpe = static_cast<const char*>(scratch_e);
   }
-  const __bf16* Wp = static_cast<const __bf16*>(prepared_planes(PREP_FFN, ff.fc1.weight, ff.fc2.weight, 128));
+  const char* Wp = static_cast<const char*>(prepared_planes(PREP_FFN, ff.fc1.weight, ln2->gamma, 128));
   if (!Wp) {
-    if ((rc = launch_ffn_x6_prep(ff.fc1.weight, ff.fc2.weight, 128, scratch_f, s))) return rc;
-    Wp = static_cast<const __bf16*>(scratch_f);
+    if ((rc = launch_ffn_x6_prep(ff.fc1.weight, ff.fc2.weight, 128, scratch_f, s, ln2->gamma, ln2->beta, ff.fc1.bias))) return rc;
+    Wp = static_cast<const char*>(scratch_f);
   }
   FfnX6Args a{};
-  a.z = x; a.Wp = Wp; a.b1 = ff.fc1.bias; a.b2 = ff.fc2.bias; a.add1 = x; a.add2 = nullptr; a.out = out; a.rows = E; a.act1 = ff.fc1.act;
+  a.z = x; a.Wp = reinterpret_cast<const __bf16*>(Wp); a.b1 = reinterpret_cast<const float*>(Wp + ffn_x6_scratch_bytes(128));  // b1 + W1^T beta2
+  a.b2 = ff.fc2.bias; a.add1 = x; a.add2 = nullptr; a.out = out; a.rows = E; a.act1 = ff.fc1.act;
   a.ln_g = ln2->gamma; a.ln_b = ln2->beta; a.ln_eps = ln_eps; a.ln_mode = ln_mode;
-  a.e.tiles = tiles; a.e.ln1_g = ln1->gamma; a.e.ln1_b = ln1->beta; a.e.Wpe = Wpe; a.e.psrc = psrc; a.e.pdst = pdst; a.e.N = N; a.e.src = src; a.e.dst = dst;
+  a.e.tiles = tiles; a.e.c1 = reinterpret_cast<const float*>(Wpe + edge_x6_scratch_bytes()); a.e.Wpe = reinterpret_cast<const __bf16*>(Wpe); a.e.psrc = psrc; a.e.pdst = pdst; a.e.N = N; a.e.src = src; a.e.dst = dst;
   a.e.act = act; a.e.colsum = colsum; a.e.n_tiles = n_tiles; a.e.agg_out = agg_out; a.e.n_agg_rows = n_agg_rows; a.e.chunk_row0 = chunk_row0;
   ProfScope ps("k_core_edge_x6", s);
   const dim3 grid((unsigned)n_tiles, (unsigned)R);

@@ -11,10 +11,13 @@
 #include "gnx_internal.h"
 
 namespace gnx {
-int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s, int n_out);      // gnx_edge_x6.hip
+int32_t launch_edge_x6_prep(const float* We, int ldw, void* scratch, hipStream_t s, int n_out, const float* ln_gamma, const float* ln_beta);  // gnx_edge_x6.hip
+size_t edge_x6_fold_scratch_bytes();
 int32_t launch_proj_x6_prep(const float* Ws, const float* Wd, int ldw, void* scratch, hipStream_t s);  // gnx_edge_x6.hip
 size_t proj_x6_scratch_bytes();
-int32_t launch_ffn_x6_prep(const float* W1, const float* W2, int d, void* scratch, hipStream_t s);     // gnx_ffn_x6.hip
+int32_t launch_ffn_x6_prep(const float* W1, const float* W2, int d, void* scratch, hipStream_t s, const float* ln_gamma, const float* ln_beta,
+                           const float* b1);  // gnx_ffn_x6.hip
+size_t ffn_x6_fold_scratch_bytes(int d);
 int32_t launch_edge_enc_prep(const float* We, int ldw, void* scratch, hipStream_t s);                  // gnx_edge_x6.hip
 size_t edge_enc_scratch_bytes();
 size_t ffn_x6_scratch_bytes(int d);
@@ -23,8 +26,12 @@ size_t ffn_x6_scratch_bytes(int d);
 struct gnx_prepared {
   struct Entry {
     gnx::PreparedKind kind;
-    const void* w0;  // the weight pointers the planes were made from: what a launcher asks with
+    const void* w0;  // what a launcher asks with: the weight the planes were made from, and (a second weight | the gamma of a folded LayerNorm)
     const void* w1;
+    const void* x0;  // further sources of a folded entry — EDGE: beta; FFN: W2, beta, b1
+    const void* x1;
+    const void* x2;
+    bool folded;     // the LayerNorm in front of the weight block is part of the planes (scaled rows + the constant vector behind them)
     int32_t n;       // EDGE: output width; PROJ: row distance of the weight matrix; FFN: width d
     int32_t ldw;     // EDGE: row distance
     void* planes;
@@ -55,9 +62,14 @@ namespace {
 
 int32_t run_entry(const gnx_prepared::Entry& e, hipStream_t s) {
   switch (e.kind) {
-    case PREP_EDGE: return launch_edge_x6_prep(static_cast<const float*>(e.w0), e.ldw, e.planes, s, e.n);
+    case PREP_EDGE:
+      return e.folded ? launch_edge_x6_prep(static_cast<const float*>(e.w0), e.ldw, e.planes, s, e.n, static_cast<const float*>(e.w1), static_cast<const float*>(e.x0))
+                      : launch_edge_x6_prep(static_cast<const float*>(e.w0), e.ldw, e.planes, s, e.n, nullptr, nullptr);
     case PREP_PROJ: return launch_proj_x6_prep(static_cast<const float*>(e.w0), static_cast<const float*>(e.w1), e.n, e.planes, s);
-    case PREP_FFN: return launch_ffn_x6_prep(static_cast<const float*>(e.w0), static_cast<const float*>(e.w1), e.n, e.planes, s);
+    case PREP_FFN:
+      return e.folded ? launch_ffn_x6_prep(static_cast<const float*>(e.w0), static_cast<const float*>(e.x0), e.n, e.planes, s, static_cast<const float*>(e.w1),
+                                           static_cast<const float*>(e.x1), static_cast<const float*>(e.x2))
+                      : launch_ffn_x6_prep(static_cast<const float*>(e.w0), static_cast<const float*>(e.w1), e.n, e.planes, s, nullptr, nullptr, nullptr);
     case PREP_ENC: return launch_edge_enc_prep(static_cast<const float*>(e.w0), e.n, e.planes, s);
   }
   return fail(GNX_ERR_INVALID_ARG, "prepared parameters: unknown entry");
@@ -66,7 +78,18 @@ int32_t run_entry(const gnx_prepared::Entry& e, hipStream_t s) {
 int32_t add_entry(gnx_prepared* q, PreparedKind kind, const void* w0, const void* w1, int32_t n, int32_t ldw, size_t bytes) {
   for (const auto& e : q->entries)
     if (e.kind == kind && e.w0 == w0 && e.w1 == w1 && e.n == n) return GNX_OK;  // (two layers sharing a weight block)
-  gnx_prepared::Entry e{kind, w0, w1, n, ldw, nullptr, bytes};
+  gnx_prepared::Entry e{kind, w0, w1, nullptr, nullptr, nullptr, false, n, ldw, nullptr, bytes};
+  GNX_HIP(hipMalloc(&e.planes, bytes));
+  q->entries.push_back(e);
+  return GNX_OK;
+}
+
+// the planes of a weight block with the LayerNorm in front of it folded in (asked for with the weight and the gamma pointer)
+int32_t add_folded(gnx_prepared* q, PreparedKind kind, const void* w, const void* gamma, const void* x0, const void* x1, const void* x2, int32_t n, int32_t ldw,
+                   size_t bytes) {
+  for (const auto& e : q->entries)
+    if (e.kind == kind && e.w0 == w && e.w1 == gamma && e.n == n) return GNX_OK;
+  gnx_prepared::Entry e{kind, w, gamma, x0, x1, x2, true, n, ldw, nullptr, bytes};
   GNX_HIP(hipMalloc(&e.planes, bytes));
   q->entries.push_back(e);
   return GNX_OK;
@@ -116,6 +139,15 @@ int32_t gnx_core_prepare(const gnx_core_params* p, void* stream, gnx_prepared** 
   for (int t = 0; t < 3 && rc == GNX_OK; ++t)  // the FeedForwards whose width has the six-term kernel
     if ((d[t] == 128 || d[t] == 64) && p->ff[t].fc1.weight && p->ff[t].fc2.weight)
       rc = add_entry(q, PREP_FFN, p->ff[t].fc1.weight, p->ff[t].fc2.weight, d[t], 0, ffn_x6_scratch_bytes(d[t]));
+  // the one-launch form of a core's edge rows (128-wide edges): both weight blocks with gn1 / gn2 folded in
+  const gnx_block_params& b = p->block;
+  if (rc == GNX_OK && b.de == 128 && b.oe == 128 && b.dn > 0 && b.edgefn.weight && p->ln1[0].gamma && p->ln1[0].beta && p->ln2[0].gamma && p->ln2[0].beta &&
+      p->ff[0].fc1.weight && p->ff[0].fc2.weight) {
+    rc = add_folded(q, PREP_EDGE, b.edgefn.weight, p->ln1[0].gamma, p->ln1[0].beta, nullptr, nullptr, 128, b.oe, edge_x6_fold_scratch_bytes());
+    if (rc == GNX_OK)
+      rc = add_folded(q, PREP_FFN, p->ff[0].fc1.weight, p->ln2[0].gamma, p->ff[0].fc2.weight, p->ln2[0].beta, p->ff[0].fc1.bias, 128, 0,
+                      ffn_x6_fold_scratch_bytes(128));
+  }
   return finish(q, rc, (hipStream_t)stream, out);
 }
 

@@ -39,6 +39,7 @@ int32_t launch_edge_enc(const Tile* tiles, size_t n_tiles, const float* ef, size
                         void* scratch, hipStream_t s);
 // gnx_edge_n.hip: the edge update with the source side gathered raw (K = 128 + 64) and a register epilogue
 size_t edge_n_scratch_bytes();
+size_t edge_x6_fold_scratch_bytes();  // gnx_edge_x6.hip
 bool edge_n_enabled();
 int32_t launch_edge_n(const Tile* tiles, size_t n_tiles, const float* ef, size_t E, const float* ln_stats, const float* ln_g, const float* ln_b, const float* We, int ldw,
                       const float* zsrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out, size_t n_agg_rows,
@@ -1169,7 +1170,7 @@ static int wide_slices(const gnx_graphs* h) {
 static size_t x6_tab_bytes(int de, int oe) {
   const size_t x6 = sizeof(__bf16) * 3 * (size_t)de * (size_t)((oe + 31) / 32 * 32);
   if (de == 10 && oe == 128) return std::max(x6, edge_enc_scratch_bytes());  // (the encoder form's zero-padded K = 32)
-  return (de == 128 && oe == 128) ? std::max(x6, edge_n_scratch_bytes()) : x6;
+  return (de == 128 && oe == 128) ? std::max(edge_x6_fold_scratch_bytes(), edge_n_scratch_bytes()) : x6;  // (the core's one-launch form: + We^T beta)
 }
 
 size_t wide_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p, int64_t R) {

@@ -82,6 +82,17 @@ def assert_close(got, ref, scale, what="", log=None):
     assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} outside 1e-5·scale; worst ratio {np.max(err / (scale + 1e-30)):.3e}"
 
 
+def assert_same_formula(a, b, what="", k=2e-6):
+    """Two fp32 evaluations of the SAME formula in different associations (e.g. a LayerNorm's scale applied to the rows, or folded into the weight
+    planes they are multiplied with): finite, and normwise within a few fp32 roundings — max|a - b| <= k · max|b|.  (The bound against the float64
+    oracle, 1e-5·S elementwise, is asserted separately by the callers.)"""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    assert np.isfinite(a).all() and np.isfinite(b).all(), f"{what}: not finite"
+    d, m = float(np.abs(a - b).max()) if a.size else 0.0, float(np.abs(b).max()) if b.size else 0.0
+    assert d <= k * m + 1e-30, f"{what}: max|a - b| = {d:.3e} against {k:g} · max|b| = {k * m:.3e}"
+
+
 def oracle_layer(kind, p, csc, x, in_scale=None):
     """One layer of the float64 oracle on packed (ef, nf, gf) with its worst-case error scale."""
     if kind == "block":

@@ -17,6 +17,8 @@ d = (128, 64, 32)
 mk = lambda T, w: torch.randn((1, T, w), device=dev).permute(2, 1, 0)
 x = gn.NT(g, mk(g.n_edges, d[0]), mk(g.n_nodes, d[1]), mk(g.n_graphs, d[2]))
 core = gn.GNCore(d, device=dev)
+if "--no-prepare" not in sys.argv:
+    core.prepare()  # (the weight planes made once, as a model's layers have them)
 graphed = gn.Graphed(lambda t: core(t), x)
 bench.spin_up(torch, dev, graphed.graph.replay, 300.0)
 regs = []
