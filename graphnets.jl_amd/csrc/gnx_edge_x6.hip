@@ -99,7 +99,9 @@ struct EdgeX6Args {
 // the outputs as single floats (rows of a.oe), no per-destination sums (the node update of such a block adds up the ef' rows itself: 12 bytes each)
 // KSX: k16-steps of the contraction — 8: the projected form (K = 128 edge inputs, two gathered projection rows as addends); 2: the ENCODER form
 // ((10, 5, .) => 128 unprojected: ef, nf[src], nf[dst] assembled per lane into one zero-padded K = 32, the bias as the only addend)
-template <bool NARROW, int KSX = EKS>
+// TRANS: the activation is tanh / sigmoid / gelu (the run-time switch of act_apply, inlined per slice: three quarters of the kernel's code); else
+// identity / relu
+template <bool NARROW, int KSX, bool TRANS>
 __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARROW ? 3 : (KSX == 2 ? 4 : 2)))) void k_edge_x6(EdgeX6Args a) {
   constexpr bool ENC = KSX == 2;
   static_assert(KSX == EKS || (KSX == 2 && !NARROW), "K = 128, or the encoder's K = 32");
@@ -225,6 +227,7 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
   }
 
   const int er = lane >> 3, eq = lane & 7;  // (row er + 8 i of the wave's 32, 16-byte quad eq of the 32-column block)
+  const int act_floor = a.act == 1 ? 0 : (int)0x80000000;  // relu as an integer maximum of the float's bits with 0 (identity: with INT_MIN)
   const bool wave_full = rows >= (wv + 1) * ER;
   float* sE = s_e + wv * (ER * ELDE);
   const float* __restrict__ ps = ENC ? nullptr : a.psrc + r * a.N * OUTW;
@@ -297,12 +300,10 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, NARR
       if constexpr (ENC) v += bq;
       else { v += us[i]; v += ud[i]; }
       float vv[4] = {v.x, v.y, v.z, v.w};
-      if (a.act == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vv[e] = relu_f(vv[e]);
-      } else if (a.act > 1) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) vv[e] = act_apply(vv[e], a.act);
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (TRANS) vv[e] = act_apply(vv[e], a.act);
+        else vv[e] = __int_as_float(max(__float_as_int(vv[e]), act_floor));
       }
       v = f32x4e{vv[0], vv[1], vv[2], vv[3]};
       // (wave_full — every row of the wave inside the tile — is wave-uniform: the common case stores without a per-lane predicate.  A predicated
@@ -611,7 +612,8 @@ int32_t launch_edge_enc(const Tile* tiles, size_t n_tiles, const float* ef, size
   a.tiles = tiles; a.ef = ef; a.E = E; a.Wp = Wp; a.N = N; a.src = src; a.dst = dst; a.act = act; a.out = out; a.colsum = colsum; a.n_tiles = n_tiles;
   a.agg_out = agg_out; a.n_agg_rows = n_agg_rows; a.chunk_row0 = chunk_row0; a.oe = EOUT; a.nf = nf; a.bias = bias; a.bias_g = bias_g; a.G = G;
   ProfScope ps("k_rows_gemm_edge", s);  // (the name the edge update has in every profile and bench line)
-  GNX_LAUNCH((k_edge_x6<false, 2>), dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
+  if (act > GNX_ACT_RELU) GNX_LAUNCH((k_edge_x6<false, 2, true>), dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
+  else GNX_LAUNCH((k_edge_x6<false, 2, false>), dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }
@@ -663,8 +665,9 @@ int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_
   if (ln_inline) { if (ln_stats || !ln_g || !ln_b) return fail(GNX_ERR_INVALID_ARG, "k_edge_x6: statistics in the kernel exclude a statistics table and need gamma / beta"); a.ln_inline = 1; a.ln_eps = ln_eps; a.ln_mode = ln_mode; }
   a.oe = oe;
   ProfScope ps("k_rows_gemm_edge", s);  // (the name the edge update has in every profile and bench line)
-  if (oe == EOUT) GNX_LAUNCH((k_edge_x6<false, EKS>), dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
-  else GNX_LAUNCH((k_edge_x6<true, EKS>), dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
+  const bool trans = act > GNX_ACT_RELU;
+  if (oe == EOUT) { if (trans) GNX_LAUNCH((k_edge_x6<false, EKS, true>), dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a); else GNX_LAUNCH((k_edge_x6<false, EKS, false>), dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a); }
+  else { if (trans) GNX_LAUNCH((k_edge_x6<true, EKS, true>), dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a); else GNX_LAUNCH((k_edge_x6<true, EKS, false>), dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a); }
   GNX_HIP(hipGetLastError());
   return GNX_OK;
 }

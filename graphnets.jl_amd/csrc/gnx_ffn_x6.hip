@@ -142,7 +142,7 @@ static __device__ unsigned long long* g_x6_dbg = nullptr;  // [workgroup][4]
 #define GNX_XSTAMP(i) do { } while (0)
 #endif
 
-// TRANS: fc1's activation is tanh / sigmoid / gelu (the run-time switch of act_apply); else identity / relu
+// TRANS: fc1's activation — in the EDGE form: or the edge function's — is tanh / sigmoid / gelu (the run-time switch of act_apply); else both are identity / relu
 // EDGE: see FfnX6Edge
 template <int D, bool TRANS, bool EDGE>
 __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D == 128 ? 2 : 3))) void k_ffn_x6(FfnX6Args a) {
@@ -163,7 +163,8 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   __shared__ __attribute__((aligned(16))) unsigned char s_w2b[SLB / 2];
   __shared__ float s_b1[H];
   __shared__ int s_src[EDGE ? XBM : 1], s_dst[EDGE ? XBM : 1];
-  __shared__ int s_seg[2][EDGE ? 66 : 1];  // per 64-row pass: first row of every destination run; [n_seg] = valid rows of the pass; [65] = n_seg
+  __shared__ int s_seg[2][EDGE ? 68 : 1];  // per 64-row pass: first row of every destination run; [n_seg] = valid rows of the pass; [65] = n_seg; [66] = the pass's first row of the partial-sum table
+  __shared__ __attribute__((aligned(16))) float s_bc[EDGE ? 2 * D : 4];  // EDGE: b2 | We^T beta1 — the slices' constant addends (a global load behind each slice's wait was a round trip of its own)
 
 #ifdef GNX_X6_STAMPS_BUILD
   unsigned long long xst_[4] = {0, 0, 0, 0};
@@ -214,6 +215,9 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     }
   }
   for (int i = tid; i < H; i += 64 * XW) s_b1[i] = a.b1 ? a.b1[i] : 0.f;
+  if constexpr (EDGE) {
+    if (tid < D) { s_bc[tid] = a.b2 ? a.b2[tid] : 0.f; s_bc[D + tid] = a.e.c1[tid]; }
+  }
 
   // ---- the wave's z rows as B fragments: lane (n, hi) holds k = 16 s + 8 hi + j (j < 8) of row n for every k16-step s, in three parts ----
   bf16x8x zh[KS], zm[KS], zl[KS];
@@ -433,8 +437,6 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     const int trows = (int)(rend - wg_row0);
     const bool wave_full = trows >= (wv + 1) * XR;
     const int tile_id = blockIdx.x;
-    int agg_row0[2] = {0, 0};
-    if (a.e.agg_out) { agg_row0[0] = a.e.chunk_row0[2 * tile_id]; agg_row0[1] = a.e.chunk_row0[2 * tile_id + 1]; }
     if (a.e.agg_out && wv < 2) {  // destination runs of the two 64-row passes (rows are dst-sorted), by wave 0 and wave 1
       const int pass = wv;
       const int nvalid = min(max(trows - 64 * pass, 0), 64);
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       const unsigned long long mask = __ballot(head);
       const int rank = __popcll(mask & ((1ull << lane) - 1ull));
       if (head) s_seg[pass][rank] = lane;
-      if (lane == 0) { const int ns = __popcll(mask); s_seg[pass][ns] = nvalid; s_seg[pass][65] = ns; }
+      if (lane == 0) { const int ns = __popcll(mask); s_seg[pass][ns] = nvalid; s_seg[pass][65] = ns; s_seg[pass][66] = a.e.chunk_row0[2 * tile_id + pass]; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slice 0's pieces of this wave have landed
     __syncthreads();  // ... everybody's; every wave is done with the FeedForward's buffers: W1 = staging area, W2b = the next slice's fragments
@@ -453,13 +455,21 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     float* s_cs = s_e + XBM * ELDE;                // [32][32]
     static_assert((XBM * ELDE + 32 * 32) * 4 <= SLB / 2, "staging area + column-sum partials fit the W1 buffer");
     float* sE = s_e + wv * (XR * ELDE);
-    const int er = lane >> 3, eq = lane & 7;  // (row er + 8 i of the wave's 32, 16-byte quad eq of the 32-column block)
+    const int er0 = lane >> 3, eq0 = lane & 7;  // (row er + 8 i of the wave's 32, 16-byte quad eq of the 32-column block)
     const float* __restrict__ ps = a.e.psrc + r * a.e.N * D;
     const float* __restrict__ pd = a.e.pdst + r * a.e.N * D;
-    const float* __restrict__ xres = a.add1 + r * rows * D;
-    float* __restrict__ outp = a.out + r * rows * D;
+    // residual rows and output rows of the TILE: a wave-uniform base and 32-bit offsets inside the tile (four 64-bit row addresses per array were what
+    // the register allocator spilled across the slices — 15 registers reloaded from scratch in front of every slice's stores)
+    const float* __restrict__ xres = a.add1 + (r * rows + wg_row0) * D;
+    float* __restrict__ outp = a.out + (r * rows + wg_row0) * D;
     const f32x4x zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int edge_floor = a.e.act == 1 ? 0 : (int)0x80000000;  // relu as an integer maximum of the float's bits with 0 (identity: with INT_MIN)
     auto slice = [&](int ob, const unsigned char* cur, unsigned char* nxt, const f32x16x& accF) {
+      // (the lane's coordinates made opaque per slice: everything derived from them — a dozen offsets and addresses — is then recomputed here, a few
+      //  vector instructions, instead of living across all four slices: the register allocator spilled them, and reloaded them in the middle of the
+      //  matrix instructions behind an s_waitcnt vmcnt(0) each)
+      int er = er0, eq = eq0;
+      asm volatile("" : "+v"(er), "+v"(eq));
       if (ob + 1 < NOB) stage_e(ob + 1, nxt);
       const unsigned char* wb = cur + lane * 16;
       f32x16x acc;
@@ -496,8 +506,8 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       f32x4x u1[4], vf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const size_t grow = row0 + er + 8 * i < rend ? row0 + er + 8 * i : rend - 1;
-        u1[i] = *reinterpret_cast<const f32x4x*>(xres + grow * D + 32 * ob + 4 * eq);
+        const unsigned lrow = (unsigned)min(wv * XR + er + 8 * i, trows - 1);
+        u1[i] = *reinterpret_cast<const f32x4x*>(xres + (lrow * D + 32 * ob + 4 * eq));
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -511,8 +521,8 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the addends — and with them (in-order counter) the next slice's fragments
       asm volatile("" : "+v"(us[0]), "+v"(us[1]), "+v"(us[2]), "+v"(us[3]), "+v"(ud[0]), "+v"(ud[1]), "+v"(ud[2]), "+v"(ud[3]));
       asm volatile("" : "+v"(u1[0]), "+v"(u1[1]), "+v"(u1[2]), "+v"(u1[3]));
-      const f32x4x bq = a.b2 ? *reinterpret_cast<const f32x4x*>(a.b2 + 32 * ob + 4 * eq) : zero4;
-      const f32x4x c1q = *reinterpret_cast<const f32x4x*>(a.e.c1 + 32 * ob + 4 * eq);  // We^T beta1 (gn1's shift, folded)
+      const f32x4x bq = *reinterpret_cast<const f32x4x*>(s_bc + 32 * ob + 4 * eq);
+      const f32x4x c1q = *reinterpret_cast<const f32x4x*>(s_bc + D + 32 * ob + 4 * eq);  // We^T beta1 (gn1's shift, folded)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int lr = er + 8 * i;
@@ -521,12 +531,12 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
         v += us[i];
         v += ud[i];
         float vv[4] = {v.x, v.y, v.z, v.w};
-        if (a.e.act == 1) {
+        // (TRANS covers the edge function's activation too: the run-time switch over the transcendental forms, inlined at the 16 places of the four
+        //  slices, was 3/4 of this kernel's 100 KB of code — more than the instruction cache holds — for an activation the default layers do not have)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) vv[e] = relu_f(vv[e]);
-        } else if (a.e.act > 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) vv[e] = act_apply(vv[e], a.e.act);
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (TRANS) vv[e] = act_apply(vv[e], a.e.act);
+          else vv[e] = __int_as_float(max(__float_as_int(vv[e]), edge_floor));
         }
         v = f32x4x{vv[0], vv[1], vv[2], vv[3]};
         const bool ok = wave_full || wv * XR + lr < trows;
@@ -537,8 +547,9 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
         o += v;
         o += u1[i];
         // (wave_full is wave-uniform: the common case stores without a per-lane predicate — no exec-mask branch around the instruction)
-        if (wave_full) *reinterpret_cast<f32x4x*>(outp + (row0 + lr) * D + 32 * ob + 4 * eq) = o;
-        else if (ok) *reinterpret_cast<f32x4x*>(outp + (row0 + lr) * D + 32 * ob + 4 * eq) = o;
+        const unsigned ooff = (unsigned)(wv * XR + lr) * D + 32 * ob + 4 * eq;
+        if (wave_full) *reinterpret_cast<f32x4x*>(outp + ooff) = o;
+        else if (ok) *reinterpret_cast<f32x4x*>(outp + ooff) = o;
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS traffic only) the finished block of all four waves is staged
       const int q4 = tid & 7, grp = tid >> 3;  // 8 quads x 32 row groups
@@ -547,7 +558,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
         // per-destination sums (fixed order; k_edge_x6): groups 0-15 take the runs of pass 0, groups 16-31 those of pass 1
         const int pass = grp >> 4, g16 = grp & 15;
         const int n_seg = s_seg[pass][65];
-        float* agg = a.e.agg_out + (r * a.e.n_agg_rows + (size_t)agg_row0[pass]) * D + 32 * ob + 4 * q4;
+        float* agg = a.e.agg_out + (r * a.e.n_agg_rows + (size_t)s_seg[pass][66]) * D + 32 * ob + 4 * q4;
         const float* base = s_e + 64 * pass * ELDE + 4 * q4;
         for (int sgm = g16; sgm < n_seg; sgm += 16) {
           const int r0 = s_seg[pass][sgm], r1 = s_seg[pass][sgm + 1];
@@ -752,7 +763,7 @@ int32_t launch_core_edge_x6(const Tile* tiles, size_t n_tiles, const float* x, s
   a.e.act = act; a.e.colsum = colsum; a.e.n_tiles = n_tiles; a.e.agg_out = agg_out; a.e.n_agg_rows = n_agg_rows; a.e.chunk_row0 = chunk_row0;
   ProfScope ps("k_core_edge_x6", s);
   const dim3 grid((unsigned)n_tiles, (unsigned)R);
-  if (ff.fc1.act > GNX_ACT_RELU) GNX_LAUNCH((k_ffn_x6<128, true, true>), grid, dim3(64 * XW), 0, s, a);
+  if (ff.fc1.act > GNX_ACT_RELU || act > GNX_ACT_RELU) GNX_LAUNCH((k_ffn_x6<128, true, true>), grid, dim3(64 * XW), 0, s, a);
   else GNX_LAUNCH((k_ffn_x6<128, false, true>), grid, dim3(64 * XW), 0, s, a);
   GNX_HIP(hipGetLastError());
   return GNX_OK;
