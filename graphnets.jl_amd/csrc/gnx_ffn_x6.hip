@@ -135,9 +135,51 @@ struct FfnX6Args {
   FfnX6Edge e;             // EDGE instantiation only
 };
 
-#ifdef GNX_X6_STAMPS_BUILD  // diagnostic build only (tools/build_variant.sh x6st gnx_ffn_x6.hip -DGNX_X6_STAMPS_BUILD; GNX_X6_STAMPS=1): shader-clock stamps of wave 0
-static __device__ unsigned long long* g_x6_dbg = nullptr;  // [workgroup][4]
-#define GNX_XSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); xst_[i] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// Diagnostic build only (tools/build_variant.sh x6st gnx_ffn_x6.hip -DGNX_X6_STAMPS_BUILD; run with GNX_X6_STAMPS=1, GNX_X6_STAMP_WAVE=<0..3>):
+// shader-clock stamps of ONE wave of every workgroup, written straight to a buffer of their own (32 per workgroup; no output is computed from them,
+// no register array kept for them); the launchers print the average distance between consecutive stamps.  In the real build no stamp executes.
+#ifdef GNX_X6_STAMPS_BUILD
+constexpr int XNST = 32;
+static __device__ unsigned long long* g_x6_dbg = nullptr;  // [workgroup][XNST]
+static __device__ int g_x6_wave = 0;
+#define GNX_XSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (xst_p) xst_p[i] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// stamp buffer of a launch of n_wg workgroups (nullptr: stamps off)
+static unsigned long long* x6_stamps_begin(size_t n_wg, hipStream_t s) {
+  static unsigned long long* d_dbg = nullptr;
+  static size_t dbg_cap = 0;
+  if (!getenv("GNX_X6_STAMPS")) return nullptr;
+  if (dbg_cap < n_wg) { if (d_dbg) (void)hipFree(d_dbg); dbg_cap = n_wg; (void)hipMalloc((void**)&d_dbg, dbg_cap * XNST * 8); }
+  (void)hipMemsetAsync(d_dbg, 0, n_wg * XNST * 8, s);
+  const int wave = getenv("GNX_X6_STAMP_WAVE") ? atoi(getenv("GNX_X6_STAMP_WAVE")) : 0;
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_x6_dbg), &d_dbg, sizeof(d_dbg), 0, hipMemcpyHostToDevice, s);
+  (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_x6_wave), &wave, sizeof(wave), 0, hipMemcpyHostToDevice, s);
+  return d_dbg;
+}
+
+static void x6_stamps_end(const unsigned long long* d_dbg, size_t n_wg, const char* what, const char* const* names, hipStream_t s) {
+  if (!d_dbg) return;
+  (void)hipStreamSynchronize(s);
+  std::vector<unsigned long long> hs(n_wg * XNST);
+  (void)hipMemcpy(hs.data(), d_dbg, hs.size() * 8, hipMemcpyDeviceToHost);
+  double sum[XNST] = {0};
+  size_t cnt[XNST] = {0};
+  unsigned long long t_min = ~0ull, t_max = 0;
+  for (size_t w = 0; w < n_wg; ++w) {
+    unsigned long long prev = 0;
+    for (int i = 0; i < XNST; ++i) {
+      const unsigned long long t = hs[w * XNST + i];
+      if (!t) continue;
+      if (prev) { sum[i] += (double)(t - prev); ++cnt[i]; }
+      prev = t; t_min = std::min(t_min, t); t_max = std::max(t_max, t);
+    }
+  }
+  fprintf(stderr, "[gnx x6 stamps, %s] %zu workgroups, clocks from the previous stamp (average):", what, n_wg);
+  double tot = 0;
+  for (int i = 1; i < XNST; ++i)
+    if (cnt[i]) { fprintf(stderr, "  %s %.0f", names && names[i] ? names[i] : "?", sum[i] / cnt[i]); tot += sum[i] / cnt[i]; }
+  fprintf(stderr, "  | sum %.0f;  first stamp -> last stamp %llu\n", tot, t_max - t_min);
+}
 #else
 #define GNX_XSTAMP(i) do { } while (0)
 #endif
@@ -166,11 +208,11 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   __shared__ int s_seg[2][EDGE ? 68 : 1];  // per 64-row pass: first row of every destination run; [n_seg] = valid rows of the pass; [65] = n_seg; [66] = the pass's first row of the partial-sum table
   __shared__ __attribute__((aligned(16))) float s_bc[EDGE ? 2 * D : 4];  // EDGE: b2 | We^T beta1 — the slices' constant addends (a global load behind each slice's wait was a round trip of its own)
 
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef GNX_X6_STAMPS_BUILD
-  unsigned long long xst_[4] = {0, 0, 0, 0};
+  unsigned long long* xst_p = g_x6_dbg && lane == 0 && wv == g_x6_wave && blockIdx.y == 0 ? g_x6_dbg + (size_t)blockIdx.x * XNST : nullptr;
 #endif
   GNX_XSTAMP(0);
-  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, n = lane & 31;
   const size_t r = blockIdx.y;
   const size_t rows = a.rows;  // per replica
@@ -194,6 +236,14 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)pc * 1024 + lane * 16),
                                        (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
     }
+  };
+  // ONE piece (i < NF / XW) of such a half slice — the FeedForward's loop issues its pieces one per group of six matrix instructions: as a burst of six
+  // behind a barrier they were ~600 clocks of issue in front of an idle matrix pipe, twice per hidden slice (stamps, one workgroup per CU: 70 k clocks
+  // for a FeedForward phase whose 1536 matrix instructions take 49 k)
+  auto stage_piece = [&](int hs, int which, unsigned char* dst, int i) {
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)hs * SLB + (size_t)which * (SLB / 2) + (size_t)(wv + XW * i) * 1024;  // (wave-uniform)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (unsigned)(lane * 16)),
+                                     (__attribute__((address_space(3))) void*)(dst + (wv + XW * i) * 1024), 16, 0, 0);
   };
   // the edge update's weight block of a 32-output slice: a W1-sized set of fragments (K = D)
   auto stage_e = [&](int ob, unsigned char* dst) {
@@ -312,7 +362,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   // and split of the FINISHED block accC (SPLIT): two independent streams in one schedule.  Per k16-step: the next step's three weight fragments
   // requested, six MFMAs, 13 vector instructions of the split: every matrix instruction is followed by two of them — issued while the pipe works.
   // (Left to the compiler the split is one block of ~170 vector instructions between the two products, in front of an idle matrix pipe.)
-  auto gemm1 = [&](auto split_c, int hs, const unsigned char* w1, f32x16x& accN, const f32x16x& accC) {
+  auto gemm1 = [&](auto split_c, int hs, const unsigned char* w1, f32x16x& accN, const f32x16x& accC, auto&& piece) {
     constexpr bool SPLIT = decltype(split_c)::value;
     const unsigned char* wb = w1 + lane * 16;
 #pragma unroll
@@ -337,6 +387,8 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
 #pragma unroll
         for (int p3 = 0; p3 < 3; ++p3) A[(s + AD - 1) % AD][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * (s + AD - 1) + p3) * 1024);
       }
+      constexpr bool PIECE = !std::is_same<std::decay_t<decltype(piece)>, std::nullptr_t>::value;
+      if constexpr (PIECE) { if (s < NF / XW) piece(s); }
       accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zm[s], accN, 0, 0, 0);  // small terms first
       accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][2], zh[s], accN, 0, 0, 0);
       accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zl[s], accN, 0, 0, 0);
@@ -356,6 +408,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (PIECE) { if (i == 0 && s < NF / XW) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }  // the step's LDS-DMA piece behind its first matrix instruction
         if constexpr (SPLIT) { if constexpr (PPS == 1) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -368,7 +421,8 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     }
   };
   // out^T (D outputs x the wave's rows) += W2^T[:, the slice's slots] H^T
-  auto gemm2 = [&](const unsigned char* w2) {
+  auto gemm2 = [&](const unsigned char* w2, auto&& piece) {
+    constexpr bool PIECE = !std::is_same<std::decay_t<decltype(piece)>, std::nullptr_t>::value;
     const unsigned char* wb = w2 + lane * 16;
     const bf16x8x hh[2] = {frag(hhw, 0), frag(hhw, 1)}, hm[2] = {frag(hmw, 0), frag(hmw, 1)}, hl[2] = {frag(hlw, 0), frag(hlw, 1)};
     bf16x8x A[2][3];  // the fragments of group g + 1 are requested in front of the six MFMAs of group g (g = 2 ob + t)
@@ -382,6 +436,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
 #pragma unroll
         for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * (g + 1) + p3) * 1024);
       }
+      if constexpr (PIECE) { if (g < NF / XW) piece(g); }
       accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], hm[t], accO[ob], 0, 0, 0);
       accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][2], hh[t], accO[ob], 0, 0, 0);
       accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], hl[t], accO[ob], 0, 0, 0);
@@ -389,7 +444,12 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], hm[t], accO[ob], 0, 0, 0);
       accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], hh[t], accO[ob], 0, 0, 0);
       if (g + 1 < 2 * NOB) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      if constexpr (PIECE) {
+        if (g < NF / XW) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); }
+        else __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -397,7 +457,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   GNX_XSTAMP(1);  // prologue done: z rows split, first weight pieces in LDS
   static_assert(KS == 8 || KS == 4, "one or two pairs of the 16 hidden registers are split per k16-step of the first product");
   f32x16x accA, accB;  // H^T blocks: the one being produced and the one being consumed, alternating
-  gemm1(std::false_type{}, 0, s_w1, accA, accA);
+  gemm1(std::false_type{}, 0, s_w1, accA, accA, nullptr);
   __syncthreads();  // every wave is done with W1(0)
   stage(1, 0, s_w1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -405,11 +465,12 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   // step hs:  W2(hs + 1) requested  |  first product of slice hs + 1 (W1 buffer) with the split of slice hs between its MFMAs  |  barrier: W1 buffer
   //           free -> W1(hs + 2) requested  |  second product of slice hs (W2 from w2c)  |  the requests have landed, barrier
   auto step = [&](int hs, const unsigned char* w2c, unsigned char* w2s, f32x16x& accC, f32x16x& accN) {
-    stage(hs + 1, 1, w2s);
-    gemm1(std::true_type{}, hs + 1, s_w1, accN, accC);
+    gemm1(std::true_type{}, hs + 1, s_w1, accN, accC, [&](int i) { stage_piece(hs + 1, 1, w2s, i); });
     __syncthreads();
-    if (hs + 2 < NSL) stage(hs + 2, 0, s_w1);
-    gemm2(w2c);
+    // (the last step has no W1(hs + 2): it requests W1(NSL - 1) again — the bytes the buffer holds already, read by nobody — so that the pieces sit
+    //  in straight-line code between the matrix instructions)
+    const int hs2 = hs + 2 < NSL ? hs + 2 : NSL - 1;
+    gemm2(w2c, [&](int i) { stage_piece(hs2, 0, s_w1, i); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
@@ -423,7 +484,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     float rr[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
     for (int u = 0; u <= 8; ++u) split_xy(u < 8 ? u : -1, u - 1, accB, rr[u & 1], rr[(u & 1) ^ 1]);
-    gemm2(s_w2b);
+    gemm2(s_w2b, nullptr);
   }
 
   GNX_XSTAMP(2);  // all slices done
@@ -450,6 +511,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slice 0's pieces of this wave have landed
     __syncthreads();  // ... everybody's; every wave is done with the FeedForward's buffers: W1 = staging area, W2b = the next slice's fragments
+    GNX_XSTAMP(3);
     constexpr int ELDE = 36;
     float* s_e = reinterpret_cast<float*>(s_w1);   // [128][36]
     float* s_cs = s_e + XBM * ELDE;                // [32][32]
@@ -496,6 +558,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       // requested here — across the matrix instructions they would not fit the register file beside out^T —, and the FeedForward block of these
       // outputs goes through the wave's slice of the staging area into (row, quad) form while they travel (the other workgroup of the CU has the
       // matrix pipe meanwhile)
+      GNX_XSTAMP(4 + 6 * ob);  // matrix instructions issued
       f32x4x us[4], ud[4];  // (the source side in front of the matrix instructions — 16 registers instead of 32 across them: same time, A/B on config 4)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -521,6 +584,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the addends — and with them (in-order counter) the next slice's fragments
       asm volatile("" : "+v"(us[0]), "+v"(us[1]), "+v"(us[2]), "+v"(us[3]), "+v"(ud[0]), "+v"(ud[1]), "+v"(ud[2]), "+v"(ud[3]));
       asm volatile("" : "+v"(u1[0]), "+v"(u1[1]), "+v"(u1[2]), "+v"(u1[3]));
+      GNX_XSTAMP(5 + 6 * ob);  // addends (and the next slice's fragments) have arrived
       const f32x4x bq = *reinterpret_cast<const f32x4x*>(s_bc + 32 * ob + 4 * eq);
       const f32x4x c1q = *reinterpret_cast<const f32x4x*>(s_bc + D + 32 * ob + 4 * eq);  // We^T beta1 (gn1's shift, folded)
 #pragma unroll
@@ -551,7 +615,9 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
         if (wave_full) *reinterpret_cast<f32x4x*>(outp + ooff) = o;
         else if (ok) *reinterpret_cast<f32x4x*>(outp + ooff) = o;
       }
+      GNX_XSTAMP(6 + 6 * ob);  // epilogue done
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS traffic only) the finished block of all four waves is staged
+      GNX_XSTAMP(7 + 6 * ob);  // barrier 1 passed
       const int q4 = tid & 7, grp = tid >> 3;  // 8 quads x 32 row groups
       f32x4x c4 = {0.f, 0.f, 0.f, 0.f};        // this thread's share of the tile's column sums
       if (a.e.agg_out) {
@@ -578,7 +644,9 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
         for (int i = 0; i < 4; ++i) c4 += *reinterpret_cast<const f32x4x*>(s_e + (grp + 32 * i) * ELDE + 4 * q4);
       }
       if (a.e.colsum) *reinterpret_cast<f32x4x*>(s_cs + grp * 32 + 4 * q4) = c4;
+      GNX_XSTAMP(8 + 6 * ob);  // per-destination sums done
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the staging area may be overwritten; the column-sum partials are complete
+      GNX_XSTAMP(9 + 6 * ob);  // barrier 2 passed
       if (a.e.colsum && tid < 32) {  // fixed order: the 32 groups ascending
         float sum = 0.f;
 #pragma unroll
@@ -591,6 +659,10 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     slice(1, s_w2b, s_w2a, accO[1]);
     slice(2, s_w2a, s_w2b, accO[2]);
     slice(3, s_w2b, s_w2a, accO[3]);
+#ifdef GNX_X6_STAMPS_BUILD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GNX_XSTAMP(28);
+#endif
     return;
   }
 
@@ -640,10 +712,6 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
 #ifdef GNX_X6_STAMPS_BUILD
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   GNX_XSTAMP(3);
-  if (g_x6_dbg && tid == 0 && blockIdx.y == 0) {
-    unsigned long long* o = g_x6_dbg + (size_t)blockIdx.x * 4;
-    o[0] = xst_[1] - xst_[0]; o[1] = xst_[2] - xst_[1]; o[2] = xst_[3] - xst_[2]; o[3] = xst_[0];
-  }
 #endif
 }
 
@@ -693,15 +761,8 @@ int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, co
   if (ln_stats) { a.ln_stats = ln_stats; a.ln_g = ln->gamma; a.ln_b = ln->beta; }
   if (ln_inline) { a.ln_inline = 1; a.ln_eps = ln_eps; a.ln_mode = ln_mode; a.ln_g = ln->gamma; a.ln_b = ln->beta; }
 #ifdef GNX_X6_STAMPS_BUILD
-  static unsigned long long* d_dbg = nullptr;
-  static size_t dbg_cap = 0;
-  const bool stamps = getenv("GNX_X6_STAMPS") != nullptr;
   const size_t n_wg = (nrows + XBM - 1) / XBM;
-  if (stamps) {
-    if (dbg_cap < n_wg) { if (d_dbg) (void)hipFree(d_dbg); dbg_cap = n_wg; (void)hipMalloc((void**)&d_dbg, dbg_cap * 32); }
-    (void)hipMemsetAsync(d_dbg, 0, n_wg * 32, s);
-    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_x6_dbg), &d_dbg, sizeof(d_dbg), 0, hipMemcpyHostToDevice, s);
-  }
+  const unsigned long long* d_dbg = x6_stamps_begin(n_wg, s);
 #endif
   ProfScope ps("k_ffn_x6", s);
   const dim3 grid((unsigned)((nrows + XBM - 1) / XBM), (unsigned)R);
@@ -710,16 +771,8 @@ int32_t launch_ffn_x6(const float* z, size_t nrows, int d, const gnx_ffn& ff, co
   else { if (trans) GNX_LAUNCH((k_ffn_x6<64, true, false>), grid, dim3(64 * XW), 0, s, a); else GNX_LAUNCH((k_ffn_x6<64, false, false>), grid, dim3(64 * XW), 0, s, a); }
   GNX_HIP(hipGetLastError());
 #ifdef GNX_X6_STAMPS_BUILD
-  if (stamps) {
-    (void)hipStreamSynchronize(s);
-    std::vector<unsigned long long> hs(n_wg * 4);
-    (void)hipMemcpy(hs.data(), d_dbg, hs.size() * 8, hipMemcpyDeviceToHost);
-    double m[3] = {0, 0, 0};
-    unsigned long long t_min = ~0ull, t_max = 0;
-    for (size_t i = 0; i < n_wg; ++i) { for (int j = 0; j < 3; ++j) m[j] += (double)hs[i * 4 + j]; t_min = std::min(t_min, hs[i * 4 + 3]); t_max = std::max(t_max, hs[i * 4 + 3] + hs[i * 4] + hs[i * 4 + 1] + hs[i * 4 + 2]); }
-    fprintf(stderr, "[gnx x6 stamps] %zu workgroups: per workgroup (shader clocks, wave 0): prologue %.0f  slices %.0f  epilogue %.0f;  first start -> last end %llu\n",
-            n_wg, m[0] / n_wg, m[1] / n_wg, m[2] / n_wg, t_max - t_min);
-  }
+  static const char* const names[XNST] = {nullptr, "prologue", "slices", "epilogue"};
+  x6_stamps_end(d_dbg, n_wg, d == 128 ? "k_ffn_x6<128>" : "k_ffn_x6<64>", names, s);
 #endif
   return GNX_OK;
 }
@@ -763,9 +816,21 @@ int32_t launch_core_edge_x6(const Tile* tiles, size_t n_tiles, const float* x, s
   a.e.act = act; a.e.colsum = colsum; a.e.n_tiles = n_tiles; a.e.agg_out = agg_out; a.e.n_agg_rows = n_agg_rows; a.e.chunk_row0 = chunk_row0;
   ProfScope ps("k_core_edge_x6", s);
   const dim3 grid((unsigned)n_tiles, (unsigned)R);
-  if (ff.fc1.act > GNX_ACT_RELU || act > GNX_ACT_RELU) GNX_LAUNCH((k_ffn_x6<128, true, true>), grid, dim3(64 * XW), 0, s, a);
-  else GNX_LAUNCH((k_ffn_x6<128, false, true>), grid, dim3(64 * XW), 0, s, a);
+#ifdef GNX_X6_STAMPS_BUILD
+  const unsigned long long* d_dbg = x6_stamps_begin(n_tiles, s);
+  const unsigned dyn_lds = getenv("GNX_X6_ONE_WG") ? 8192u : 0u;  // (diagnostic: 8 KB of unused dynamic LDS leave room for ONE workgroup per CU — a wave's phases without a partner)
+#else
+  constexpr unsigned dyn_lds = 0;
+#endif
+  if (ff.fc1.act > GNX_ACT_RELU || act > GNX_ACT_RELU) GNX_LAUNCH((k_ffn_x6<128, true, true>), grid, dim3(64 * XW), dyn_lds, s, a);
+  else GNX_LAUNCH((k_ffn_x6<128, false, true>), grid, dim3(64 * XW), dyn_lds, s, a);
   GNX_HIP(hipGetLastError());
+#ifdef GNX_X6_STAMPS_BUILD
+  static const char* const names[XNST] = {nullptr, "prologue", "FeedForward", "transition",
+    "s0:mfma", "s0:addends", "s0:epilogue", "s0:barrier1", "s0:sums", "s0:barrier2", "s1:mfma", "s1:addends", "s1:epilogue", "s1:barrier1", "s1:sums", "s1:barrier2",
+    "s2:mfma", "s2:addends", "s2:epilogue", "s2:barrier1", "s2:sums", "s2:barrier2", "s3:mfma", "s3:addends", "s3:epilogue", "s3:barrier1", "s3:sums", "s3:barrier2", "drain"};
+  x6_stamps_end(d_dbg, n_tiles, "k_core_edge_x6", names, s);
+#endif
   return GNX_OK;
 }
 
