@@ -512,10 +512,22 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slice 0's pieces of this wave have landed
     __syncthreads();  // ... everybody's; every wave is done with the FeedForward's buffers: W1 = staging area, W2b = the next slice's fragments
     GNX_XSTAMP(3);
+    // this thread's first run of the per-destination sums (group grp = tid / 8 takes run grp % 16 of pass grp / 16, then every 16th) and its row of the
+    // partial-sum table: the same for all four slices — read from LDS here, once, not in front of every slice's sums (three dependent LDS round trips
+    // per slice, under the other workgroup's fragment reads: stamps, ~4 k clocks per slice in the sums)
+    int seg_n = 0, seg_r0 = 0, seg_r1 = 0, seg_row0 = 0;
+    if (a.e.agg_out) {
+      const int pass = tid >> 7, g16 = (tid >> 3) & 15;
+      seg_n = s_seg[pass][65];
+      seg_row0 = s_seg[pass][66];
+      if (g16 < seg_n) { seg_r0 = s_seg[pass][g16]; seg_r1 = s_seg[pass][g16 + 1]; }
+    }
     constexpr int ELDE = 36;
     float* s_e = reinterpret_cast<float*>(s_w1);   // [128][36]
     float* s_cs = s_e + XBM * ELDE;                // [32][32]
-    static_assert((XBM * ELDE + 32 * 32) * 4 <= SLB / 2, "staging area + column-sum partials fit the W1 buffer");
+    float* s_zero = s_cs + 32 * 32;                // [32]: a row of zeros — what the sums read for the rows beyond a run's end (no predicate on the data)
+    static_assert((XBM * ELDE + 32 * 32 + 32) * 4 <= SLB / 2, "staging area + column-sum partials + the zero row fit the W1 buffer");
+    if (tid < 32) s_zero[tid] = 0.f;               // (visible to every wave behind slice 0's first barrier)
     float* sE = s_e + wv * (XR * ELDE);
     const int er0 = lane >> 3, eq0 = lane & 7;  // (row er + 8 i of the wave's 32, 16-byte quad eq of the 32-column block)
     const float* __restrict__ ps = a.e.psrc + r * a.e.N * D;
@@ -526,7 +538,18 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     float* __restrict__ outp = a.out + (r * rows + wg_row0) * D;
     const f32x4x zero4 = {0.f, 0.f, 0.f, 0.f};
     const int edge_floor = a.e.act == 1 ? 0 : (int)0x80000000;  // relu as an integer maximum of the float's bits with 0 (identity: with INT_MIN)
-    auto slice = [&](int ob, const unsigned char* cur, unsigned char* nxt, const f32x16x& accF) {
+    // the gathered addends of a slice: 8 rows x 128 contiguous bytes per instruction
+    auto gather = [&](int ob, f32x4x (&us)[4], f32x4x (&ud)[4]) {
+      int er = er0, eq = eq0;
+      asm volatile("" : "+v"(er), "+v"(eq));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gs = s_src[wv * XR + er + 8 * i], gd = s_dst[wv * XR + er + 8 * i];
+        us[i] = *reinterpret_cast<const f32x4x*>(ps + (size_t)gs * D + 32 * ob + 4 * eq);
+        ud[i] = *reinterpret_cast<const f32x4x*>(pd + (size_t)gd * D + 32 * ob + 4 * eq);
+      }
+    };
+    auto slice = [&](int ob, const unsigned char* cur, unsigned char* nxt, const f32x16x& accF, f32x4x (&us)[4], f32x4x (&ud)[4], f32x4x (&usn)[4], f32x4x (&udn)[4]) {
       // (the lane's coordinates made opaque per slice: everything derived from them — a dozen offsets and addresses — is then recomputed here, a few
       //  vector instructions, instead of living across all four slices: the register allocator spilled them, and reloaded them in the middle of the
       //  matrix instructions behind an s_waitcnt vmcnt(0) each)
@@ -559,13 +582,9 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       // outputs goes through the wave's slice of the staging area into (row, quad) form while they travel (the other workgroup of the CU has the
       // matrix pipe meanwhile)
       GNX_XSTAMP(4 + 6 * ob);  // matrix instructions issued
-      f32x4x us[4], ud[4];  // (the source side in front of the matrix instructions — 16 registers instead of 32 across them: same time, A/B on config 4)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gs = s_src[wv * XR + er + 8 * i], gd = s_dst[wv * XR + er + 8 * i];
-        us[i] = *reinterpret_cast<const f32x4x*>(ps + (size_t)gs * D + 32 * ob + 4 * eq);
-        ud[i] = *reinterpret_cast<const f32x4x*>(pd + (size_t)gd * D + 32 * ob + 4 * eq);
-      }
+      // slice 0 requests its gathered addends here (beside out^T's 64 registers they do not fit across the matrix instructions); the later slices'
+      // were requested a slice AHEAD — in front of the previous slice's sums, when its accumulator and weight fragments are dead: they have arrived
+      if (ob == 0) gather(0, us, ud);
       f32x4x u1[4], vf[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -615,6 +634,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
         if (wave_full) *reinterpret_cast<f32x4x*>(outp + ooff) = o;
         else if (ok) *reinterpret_cast<f32x4x*>(outp + ooff) = o;
       }
+      if (ob + 1 < NOB) { gather(ob + 1, usn, udn); __builtin_amdgcn_sched_barrier(0); }
       GNX_XSTAMP(6 + 6 * ob);  // epilogue done
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // (LDS traffic only) the finished block of all four waves is staged
       GNX_XSTAMP(7 + 6 * ob);  // barrier 1 passed
@@ -623,18 +643,19 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       if (a.e.agg_out) {
         // per-destination sums (fixed order; k_edge_x6): groups 0-15 take the runs of pass 0, groups 16-31 those of pass 1
         const int pass = grp >> 4, g16 = grp & 15;
-        const int n_seg = s_seg[pass][65];
-        float* agg = a.e.agg_out + (r * a.e.n_agg_rows + (size_t)s_seg[pass][66]) * D + 32 * ob + 4 * q4;
+        const int n_seg = seg_n;
+        float* agg = a.e.agg_out + (r * a.e.n_agg_rows + (size_t)seg_row0) * D + 32 * ob + 4 * q4;
         const float* base = s_e + 64 * pass * ELDE + 4 * q4;
         for (int sgm = g16; sgm < n_seg; sgm += 16) {
-          const int r0 = s_seg[pass][sgm], r1 = s_seg[pass][sgm + 1];
+          int r0 = seg_r0, r1 = seg_r1;
+          if (sgm != g16) { r0 = s_seg[pass][sgm]; r1 = s_seg[pass][sgm + 1]; }  // (more than 16 runs in a 64-row pass: the later rounds from LDS)
           f32x4x t4 = {0.f, 0.f, 0.f, 0.f};
           for (int rr = r0; rr < r1; rr += 4) {
             f32x4x u[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) u[j] = *reinterpret_cast<const f32x4x*>(base + min(rr + j, r1 - 1) * ELDE);
+            for (int j = 0; j < 4; ++j) u[j] = *reinterpret_cast<const f32x4x*>(rr + j < r1 ? base + (rr + j) * ELDE : s_zero + 4 * q4);  // (x + 0 is x)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { if (rr + j < r1) t4 += u[j]; }
+            for (int j = 0; j < 4; ++j) t4 += u[j];
           }
           *reinterpret_cast<f32x4x*>(agg + (size_t)sgm * D) = t4;
           c4 += t4;
@@ -655,10 +676,11 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       }
     };
     static_assert(NOB == 4, "four slices, placed by hand");
-    slice(0, s_w2a, s_w2b, accO[0]);
-    slice(1, s_w2b, s_w2a, accO[1]);
-    slice(2, s_w2a, s_w2b, accO[2]);
-    slice(3, s_w2b, s_w2a, accO[3]);
+    f32x4x usA[4], udA[4], usB[4], udB[4];
+    slice(0, s_w2a, s_w2b, accO[0], usA, udA, usB, udB);
+    slice(1, s_w2b, s_w2a, accO[1], usB, udB, usA, udA);
+    slice(2, s_w2a, s_w2b, accO[2], usA, udA, usB, udB);
+    slice(3, s_w2b, s_w2a, accO[3], usB, udB, usA, udA);
 #ifdef GNX_X6_STAMPS_BUILD
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GNX_XSTAMP(28);
