@@ -385,7 +385,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
   const bool inline_e = wide_ln && edge_x6 && d[0] == 128 && rows[0] >= 4096 && !form(GNX_FLAG_LN_STATS_PASS) &&
                         ffn_x6_applies(x[0], d[0], p->ff[0], out[0], x[0], out[0], sizeof(float) * rows[0] * d[0]);
   // ... and then ONE launch does both (the edge form of k_ffn_x6: ef' stays in the accumulator — never written, never read back; GNX_CORE_EDGE_SPLIT=1: two launches)
-  const bool fuse_e = inline_e && !form(GNX_FLAG_CORE_EDGE_SPLIT) && !(edge_n_enabled() && d[1] == 64);  // (TEMPORARY: until the one-launch form gathers raw source rows too)
+  const bool fuse_e = inline_e && !form(GNX_FLAG_CORE_EDGE_SPLIT) && !(edge_n_enabled() && d[1] == 64);  // (the opt-in k_edge_n gathers RAW source rows: its projection tables are not the one-launch form's)
   if (wide_ln) {
     const float* stats[2] = {l1[0], l1[1]};  // the (unused) gn1 buffers hold the statistics: 2 floats per row
     const bool no_fork0 = form(GNX_FLAG_NO_FORK);
