@@ -1038,6 +1038,8 @@ class GNCore:
         with torch.cuda.device(dev):
             check(_lib.load().gnx_core_prepare(C.byref(p), torch.cuda.current_stream(dev).cuda_stream, C.byref(h)))
         src = [self.block.edgefn.weight] + [d.weight for ff in (self.ffwd.eff, self.ffwd.nff, self.ffwd.gff) for d in ff]
+        # (the one-launch form of the edge rows folds gn1 / gn2 of the edges and fc1's bias into its planes: they are sources too)
+        src += [self.gn1.edgeln.gamma, self.gn1.edgeln.beta, self.gn2.edgeln.gamma, self.gn2.edgeln.beta, self.ffwd.eff[0].bias]
         self._prepared = _Prepared(h, dev, src, keep)
         return self
 

@@ -90,6 +90,40 @@ def test_in_place_weight_update_is_picked_up_through_the_refresh(gn):
         assert torch.equal(a, b) and torch.equal(a, c)
 
 
+def test_in_place_update_of_the_folded_layernorm_parameters_and_bias_is_picked_up(gn):
+    """the one-launch form of a core's edge rows folds gn1 / gn2 of the edges (scale into the weight planes, shift into constant vectors) and fc1's
+    bias into its prepared planes: an in-place update of any of them refreshes the planes like a weight update does"""
+    import torch
+    rng = np.random.default_rng(9250)
+    dims = (128, 64, 32)
+    g = _batch(gn, rng)
+    p = O.make_core_params(rng, dims)
+    core = U.core_from_params(gn, p).prepare()
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, 1, dims)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    ya = core(x)
+    with torch.no_grad():
+        core.gn1.edgeln.gamma.mul_(1.5)
+        core.gn1.edgeln.beta.add_(0.25)
+        core.gn2.edgeln.gamma.mul_(0.75)
+        core.gn2.edgeln.beta.sub_(0.125)
+        core.ffwd.eff[0].bias.add_(0.5)
+    yb, _ = _profiled(gn, lambda: core(x))
+    assert not torch.equal(ya.ef, yb.ef)
+    p2 = dict(p)
+    p2["ln1_e_gamma"] = p["ln1_e_gamma"] * np.float32(1.5)
+    p2["ln1_e_beta"] = p["ln1_e_beta"] + np.float32(0.25)
+    p2["ln2_e_gamma"] = p["ln2_e_gamma"] * np.float32(0.75)
+    p2["ln2_e_beta"] = p["ln2_e_beta"] - np.float32(0.125)
+    p2["ff_e_b1"] = p["ff_e_b1"] + np.float32(0.5)
+    fresh = U.core_from_params(gn, p2)(x)
+    for a, b in zip((yb.ef, yb.nf, yb.gf), (fresh.ef, fresh.nf, fresh.gf)):
+        assert torch.equal(a, b)
+    ref, scale = O.core_forward_sparse(p2, (*g.csc(), g.node_off, g.edge_off), ef, nf, gf, return_scale=True)
+    for name, got, r_, s_ in zip(("ef", "nf", "gf"), (yb.ef, yb.nf, yb.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r_, s_, name)
+
+
 @pytest.mark.parametrize("dout", [(128, 64, 32), (3, 4, 5)])
 def test_prepared_block(gn, dout):
     """GNBlock (128,64,32) => (128,64,32) (edge block + both projection blocks) and => (3,4,5) (config 4's decoder: the narrow edge form)"""
