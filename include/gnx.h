@@ -220,9 +220,11 @@ GNX_API int32_t gnx_graphs_get_table(const gnx_graphs* h, int32_t which, void* o
  * gnx_block_prepare / gnx_core_prepare read the DEVICE weights the descriptor points at (on `stream`, asynchronously) and return an object
  * to put into the descriptor's `prepared` field.  A forward whose descriptor carries it launches no preparation kernel (config 4: nine
  * launches, ~45 us, per forward otherwise); outputs are bit-identical either way.  The planes are looked up by the weight POINTERS the
- * forward is handed: a prepared object made from other weights, or on another device, is simply not used.  Contract: the weights' VALUES
+ * forward is handed: a prepared object made from other weights, or on another device, is simply not used.  Contract: the parameters' VALUES
  * must not change while a prepared object made from them is in use — after an optimiser step call gnx_prepared_refresh (same stream
- * order as the update), and destroy the object before the weights are freed.  Widths without a six-term kernel prepare nothing (an empty
+ * order as the update), and destroy the object before the parameters are freed.  "Parameters" is the weights and, for a core with 128-wide
+ * edges, gn1 / gn2's gamma and beta of the edges and the edge FeedForward's first bias: the one-launch form of the core's edge rows has
+ * them folded into its planes ((gamma . W)^T xhat + W^T beta; the rows are normalised and split once).  Widths without a six-term kernel prepare nothing (an empty
  * object).  gnx_model_create prepares the layers whose descriptors carry none (see gnx_model_refresh_weights). */
 GNX_API int32_t gnx_block_prepare(const gnx_block_params* p, void* stream, gnx_prepared** out);
 GNX_API int32_t gnx_core_prepare(const gnx_core_params* p, void* stream, gnx_prepared** out);
@@ -347,7 +349,9 @@ GNX_API int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p,
 
 /* ---- forward: replaces (m::GNCore)(x) (src/gncore.jl:56-68); GNCoreList = caller-side fold (gncorelist.jl:43-45) ----
  * Wide cores (block in the matrix cores' projected form, FeedForward widths 64 / 128): gn1 / gn2 of ef and nf are applied by the
- * kernels as they load x (one pass of row statistics; bit-identical to the materialised LayerNorm: GNX_FLAG_NO_LN_FUSE materialises), and
+ * kernels as they load x (one pass of row statistics; GNX_FLAG_NO_LN_FUSE materialises the LayerNorms: bit-identical for the node rows and
+ * for the two-launch form of the edge rows (GNX_FLAG_CORE_EDGE_SPLIT); the one-launch form of the edge rows carries the LayerNorms' scale
+ * in its weight planes and their shift in a constant vector — the same formula in another association, within a few fp32 roundings), and
  * the graph level of the core runs on a side stream (joined before gnx_core_forward returns; part of the capture when `stream` is being
  * captured; GNX_FLAG_NO_FORK: one stream).  The side streams are a small pool of the HANDLE that gnx_core_workspace_bytes creates — call
  * it outside a capture, as every workspace query — and a call holds one only while it enqueues its work.
