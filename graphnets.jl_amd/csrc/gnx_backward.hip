@@ -569,6 +569,7 @@ int32_t gnx_block_backward(const gnx_graphs* h, const gnx_block_params* p, const
                            void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
+  DeviceTurn turn(s, matrix_core_widths(*p));  // (one matrix-core call at a time per device: gnx_internal.h)
   if (R <= 0 || (R > 1 && h->G != 1) || R > 65535) return fail(GNX_ERR_INVALID_ARG, "bad n_replicas");
   const int de = p->de, dn = p->dn, dg = p->dg, oe = p->oe, on = p->on, og = p->og;
   if (de < 0 || dn < 0 || dg < 0 || oe < 0 || on < 0 || og < 0 || de + dn + dg == 0 || oe + on + og == 0) return fail(GNX_ERR_DIMS, "bad widths");
@@ -781,6 +782,7 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
   hipStream_t s = (hipStream_t)stream;
   if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
   const gnx_block_params& b = p->block;
+  DeviceTurn turn(s, matrix_core_widths(b));
   if (b.de <= 0 || b.dn <= 0 || b.dg <= 0 || b.oe != b.de || b.on != b.dn || b.og != b.dg) return fail(GNX_ERR_DIMS, "GNCore needs dims => dims with all(dims .> 0)");
   if ((!ef && h->E > 0) || !nf || !gf) return fail(GNX_ERR_INVALID_ARG, "GNCore needs ef, nf and gf");
   if (R <= 0 || (R > 1 && h->G != 1) || R > 65535) return fail(GNX_ERR_INVALID_ARG, "bad n_replicas");
@@ -986,6 +988,10 @@ int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_para
                                  float* d_gf, const gnx_chain_block_grads* grads, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
+  bool chain_wide = p->de > 32 || p->dn > 32 || p->dg > 32;
+  for (const gnx_chain* c : {&p->edgefn, &p->nodefn, &p->graphfn})
+    for (int i = 0; i < c->n_layers; ++i) chain_wide = chain_wide || (c->widths && c->widths[i] > 32);
+  DeviceTurn turn(s, chain_wide);
   if (gnx_chain_block_workspace_bytes(h, p, R) == 0) return GNX_ERR_DIMS;  // gnx_last_error() holds the reason
   const gnx_chain* ch[3] = {&p->edgefn, &p->nodefn, &p->graphfn};
   const int de = p->de, dn = p->dn, dg = p->dg;

@@ -127,6 +127,10 @@ int32_t gnx_chain_block_forward(const gnx_graphs* h, const gnx_chain_block_param
   if (rc) return rc;
   const int de = p->de, dn = p->dn, dg = p->dg;
   const int oe = out_width(p->edgefn), on = out_width(p->nodefn), og = out_width(p->graphfn);
+  bool chain_wide = de > 32 || dn > 32 || dg > 32;  // (any layer of any chain at matrix-core widths)
+  for (const gnx_chain* c : {&p->edgefn, &p->nodefn, &p->graphfn})
+    for (int i = 0; i < c->n_layers; ++i) chain_wide = chain_wide || (c->widths && c->widths[i] > 32);
+  gnx::DeviceTurn turn(s, chain_wide);
   if ((de > 0 && !ef && h->E > 0) || (dn > 0 && !nf) || (dg > 0 && !gf)) return fail(GNX_ERR_INVALID_ARG, "an input with non-zero width is NULL (width 0 <=> nothing)");
   if ((oe > 0 && !ef_out && h->E > 0) || (on > 0 && !nf_out) || (og > 0 && !gf_out)) return fail(GNX_ERR_INVALID_ARG, "an output with non-zero width is NULL");
   const ChainWs w = layout(h, p, R);

@@ -49,6 +49,52 @@ FormScope::~FormScope() {
 
 bool form(uint32_t bit) { return ((tl_form_depth > 0 ? tl_form_flags : env_form_flags()) & bit) != 0; }
 
+// ---- one matrix-core call at a time per device (gnx_internal.h: DeviceTurn) ----
+namespace {
+struct DeviceChain {
+  std::mutex mu;
+  hipEvent_t done = nullptr;   // recorded at the end of the last matrix-core call
+  hipStream_t last = nullptr;  // the stream it was recorded on
+  bool valid = false;
+};
+constexpr int kMaxDevices = 64;
+DeviceChain g_chains[kMaxDevices];
+thread_local int tl_turn_depth = 0;  // (an entry point that calls another one — the model's layers, the chained forms — takes ONE turn)
+bool overlap_allowed() {
+  static const bool on = env_on("GNX_ALLOW_OVERLAP");
+  return on;
+}
+}  // namespace
+
+DeviceTurn::DeviceTurn(hipStream_t s, bool matrix_core_widths) : stream(s) {
+  if (!matrix_core_widths || overlap_allowed() || tl_turn_depth > 0) return;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) { (void)hipGetLastError(); return; }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  DeviceChain* c = &g_chains[dev];
+  c->mu.lock();
+  chain = c;
+  ++tl_turn_depth;
+  if (cap != hipStreamCaptureStatusNone) return;  // (inside a capture: the lock keeps the enqueue sections apart, the graph orders its own nodes)
+  record = true;
+  if (c->valid && c->last != s) {
+    if (hipStreamWaitEvent(s, c->done, 0) != hipSuccess) (void)hipGetLastError();
+  }
+}
+
+DeviceTurn::~DeviceTurn() {
+  if (!chain) return;
+  DeviceChain* c = static_cast<DeviceChain*>(chain);
+  if (record) {
+    bool ok = c->done != nullptr || hipEventCreateWithFlags(&c->done, hipEventDisableTiming) == hipSuccess;
+    if (ok && hipEventRecord(c->done, stream) == hipSuccess) { c->last = stream; c->valid = true; }
+    else { (void)hipGetLastError(); c->valid = false; }
+  }
+  --tl_turn_depth;
+  c->mu.unlock();
+}
+
 }  // namespace gnx
 
 extern "C" uint32_t gnx_default_flags(void) { return gnx::env_form_flags(); }

@@ -210,6 +210,7 @@ size_t gnx_block_workspace_bytes(const gnx_graphs* h, const gnx_block_params* p,
 int32_t gnx_block_forward(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf, const float* gf,
                           int64_t R, float* ef_out, float* nf_out, float* gf_out, void* ws, size_t ws_bytes, uint32_t flags,
                           void* stream) {
+  DeviceTurn turn((hipStream_t)stream, p && matrix_core_widths(*p));  // (one matrix-core call at a time per device: gnx_internal.h)
   return block_forward_impl(h, p, ef, nf, gf, R, ef_out, nf_out, gf_out, ws, ws_bytes, flags, (hipStream_t)stream,
                             (flags & GNX_FLAG_DEFER_GRAPH_UPDATE) ? 1 : 3);
 }
@@ -218,6 +219,7 @@ int32_t gnx_block_forward_chained(const gnx_graphs* h, const gnx_block_params* p
                                   float* nf_out, float* gf_out, void* ws, size_t ws_bytes, uint32_t flags, void* stream, const gnx_pending_update* prev,
                                   gnx_pending_update* pending) {
   if (!pending) return fail(GNX_ERR_INVALID_ARG, "pending is NULL");
+  DeviceTurn turn((hipStream_t)stream, p && matrix_core_widths(*p));
   if (flags & GNX_FLAG_DEFER_GRAPH_UPDATE) return fail(GNX_ERR_INVALID_ARG, "gnx_block_forward_chained defers the graph update itself");
   if (prev && prev->workspace && (prev->workspace == ws || (p && p->og > 0 && prev->gf_out == gf_out)))
     return fail(GNX_ERR_INVALID_ARG, "the pending call's workspace / gf_out must not be this call's (its graph update has not run yet)");
@@ -307,6 +309,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
                          void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
+  DeviceTurn turn(s, matrix_core_widths(p->block));  // (one matrix-core call at a time per device: gnx_internal.h)
   FormScope forms(flags);  // the forms this call selected (gnx.h: GNX_FLAG_FFN_FP32 ...)
   gnx_block_params b = p->block;
   b.prepared = p->prepared;  // (the core's object holds its block's planes too; block.prepared is ignored)

@@ -141,6 +141,27 @@ struct FormScope {  // an exported forward opens one: the functions below it rea
 };
 bool form(uint32_t bit);  // is the form selected for the call this thread is in (outside a call: by the environment's defaults)
 
+// One matrix-core call at a time per DEVICE (gnx_forms.cpp).  Round 5 found (tools/experiments/thread_race_probe.py, mfma_mix_probe.py; the evidence is
+// profiles/r05_mfma_mix_hazard.log): on the MI355X boxes of this pool a kernel on the fp32 matrix instruction (k_rows_gemm, k_ffn_fused) returns wrong
+// values — one pass of one v_mfma_f32_32x32x2f32: 2 rows x 32 columns of a wave's block — while a dense bf16 matrix kernel runs on ANOTHER stream of
+// the device: the library's own six-term kernels (k_edge_x6) or anybody's (a hipBLASLt bf16 GEMM).  Nothing is shared between the two kernels; the
+// same fp32 kernels beside fp32 or non-matrix work are exact.  Until the cause is understood the library keeps its own matrix-core calls apart: an
+// exported forward / backward at matrix-core widths holds this for its enqueue section — a per-device lock, a wait for the previous such call's end
+// when that ran on another stream, and an event at its own end.  Calls on ONE stream pay a lock and an event record; a stream that is being captured
+// is left alone (a graph replays on one stream).  GNX_ALLOW_OVERLAP=1 (read once) switches it off.
+inline bool matrix_core_widths(const gnx_block_params& b) {  // (the fused narrow kernels take widths up to 32: no matrix instruction)
+  return b.de > 32 || b.dn > 32 || b.dg > 32 || b.oe > 32 || b.on > 32 || b.og > 32;
+}
+struct DeviceTurn {
+  DeviceTurn(hipStream_t s, bool matrix_core_widths);
+  ~DeviceTurn();
+  DeviceTurn(const DeviceTurn&) = delete;
+  DeviceTurn& operator=(const DeviceTurn&) = delete;
+  void* chain = nullptr;  // the device's chain while held
+  hipStream_t stream = nullptr;
+  bool record = false;
+};
+
 // Prepared parameters (gnx.h: gnx_block_prepare / gnx_core_prepare; gnx_prepare.cpp): the weight blocks of a layer in the forms the six-term
 // kernels stage — split into bf16 planes, transposed, slot-permuted — made ONCE when the weights are uploaded instead of by a *_prep launch in
 // front of every forward.  An exported forward publishes the layer's prepared object to the launchers below it (PreparedScope); a launcher asks

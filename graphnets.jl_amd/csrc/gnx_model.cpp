@@ -151,6 +151,9 @@ int32_t gnx_model_forward(gnx_model* m, const float* ef, const float* nf, const 
   if (!m) return fail(GNX_ERR_INVALID_ARG, "NULL model");
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lk(m->mu);
+  bool wide = false;  // (any layer at matrix-core widths: the whole forward — its replayed graph — takes one turn on the device)
+  for (const auto& L : m->layers) wide = wide || matrix_core_widths(L.kind == GNX_LAYER_CORE ? L.core.block : L.block);
+  DeviceTurn turn(s, wide);
   const uint32_t lflags = flags & ~GNX_FLAG_NO_GRAPH;
   if (flags & GNX_FLAG_NO_GRAPH) return run_layers(m, ef, nf, gf, ef_out, nf_out, gf_out, lflags, s);
   const void* ptrs[6] = {ef, nf, gf, ef_out, nf_out, gf_out};

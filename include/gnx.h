@@ -357,7 +357,14 @@ GNX_API int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p,
  * it outside a capture, as every workspace query — and a call holds one only while it enqueues its work.
  * THREADING: a handle is immutable after creation apart from tables built once behind a mutex, so concurrent forwards on ONE handle from
  * several host threads are allowed — each with its own stream, workspace and output buffers (tests/test_gpu_core.py::
- * test_two_host_threads_run_core_forwards_on_one_handle_concurrently: bit-identical to the serial run).
+ * test_two_host_threads_run_core_forwards_on_one_handle_concurrently: bit-identical to the serial run).  Calls at matrix-core widths (any
+ * width above 32) TAKE TURNS ON THE DEVICE: every exported forward / backward holds a per-device lock while it enqueues, waits for the
+ * previous such call's end when that ran on another stream, and records an event at its own end (one stream: a lock and an event record
+ * per call; a stream under capture is left alone).  Reason (profiles/r05_mfma_mix_hazard.log): on the MI355X boxes this was built on, a
+ * kernel on the fp32 matrix instruction returns wrong values now and then — one pass of one instruction: 2 rows x 32 columns — while a
+ * dense bf16 matrix kernel runs on another stream of the device, the library's own six-term kernels or anybody else's (a bf16 GEMM);
+ * nothing is shared between the two.  GNX_ALLOW_OVERLAP=1 (read once) removes the guard.  Matrix kernels of OTHER libraries that the
+ * host runs on other streams beside these calls are the host's to keep apart (an event between the streams).
  * ARITHMETIC of the wide FeedForwards (edges / nodes at width 128 or 64, >= 4096 rows), of the projected edge update at 128 -> 128 or
  * 128 -> at most 32 outputs (gnx_block_forward too, >= 4096 edges) and of its node projections at 64-wide nodes (>= 4096 nodes):
  * fp32 in, fp32 out, fp32 accumulation; every fp32 product is evaluated on the bf16 matrix cores as six terms of an EXACT three-way split

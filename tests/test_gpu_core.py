@@ -117,6 +117,7 @@ def test_core_wide_layernorm_on_load_equals_materialised(gn, R, eps_mode):
     k_edge_x6 / k_rows_gemm, k_ffn_x6) within a few fp32 roundings (round 4's forms scaled the rows in both and were bit-identical; the fold
     rounds gamma . W instead of gamma . xhat), and within the bound of the oracle."""
     import os
+    U.needs_default_forms(gn, "NO_LN_FUSE", "FFN_FP32")
     rng = np.random.default_rng(4700 + R)
     dims = (128, 64, 32)
     colptr, rowval = U.er_csc(rng, 700, 9000)
@@ -152,8 +153,7 @@ def test_core_wide_edge_row_statistics_in_the_six_term_kernels_equal_the_statist
     epsilon conventions, replicas, and an edge count that ends inside a workgroup."""
     import os
     F = gn._lib
-    if U.default_flags(gn) & (F.FLAG_FFN_FP32 | F.FLAG_EDGE_FP32 | F.FLAG_LN_STATS_PASS):
-        pytest.skip("a six-term kernel is switched off for the whole run")
+    U.needs_default_forms(gn, "FFN_FP32", "EDGE_FP32", "LN_STATS_PASS", "NO_LN_FUSE", "EDGE_N")
     rng = np.random.default_rng(5300 + E + R)
     dims = (128, 64, 32)
     colptr, rowval = U.er_csc(rng, 600, E)
@@ -190,8 +190,7 @@ def test_core_wide_edge_update_and_feedforward_in_one_launch(gn, R, E, N, hetero
     fp32 roundings normwise; and within the bound of the oracle.  Replicas, a ragged edge count, 30 in-edges per node, several graphs (hub destinations: tests/test_gpu_wide.py's hub test runs a GNCore)."""
     import os
     F = gn._lib
-    if U.default_flags(gn) & (F.FLAG_FFN_FP32 | F.FLAG_EDGE_FP32 | F.FLAG_LN_STATS_PASS | F.FLAG_CORE_EDGE_SPLIT | F.FLAG_EDGE_N):
-        pytest.skip("the one-launch form is switched off for the whole run")
+    U.needs_default_forms(gn, *U.ONE_LAUNCH_CORE_FORMS)
     rng = np.random.default_rng(5400 + E)
     dims = (128, 64, 32)
     if hetero:
@@ -233,8 +232,7 @@ def test_core_wide_edge_feedforward_on_bf16_matrix_cores_is_as_accurate_as_fp32_
     weights of both signs, relu between."""
     import os
     F = gn._lib
-    if U.default_flags(gn) & (F.FLAG_FFN_FP32 | F.FLAG_EDGE_FP32 | F.FLAG_EDGE_N):
-        pytest.skip("GNX_FFN_FP32 / GNX_EDGE_FP32 is set for the whole run: a six-term kernel is switched off")
+    U.needs_default_forms(gn, *U.ONE_LAUNCH_CORE_FORMS)
     rng = np.random.default_rng(5100)
     dims = (128, 64, 32)
     colptr, rowval = U.er_csc(rng, 900, 12000)
@@ -269,8 +267,7 @@ def test_core_wide_edge_feedforward_six_term_kernel_ragged_rows_activations_no_b
     import os
     import torch
     F = gn._lib
-    if U.default_flags(gn) & (F.FLAG_FFN_FP32 | F.FLAG_EDGE_N):
-        pytest.skip("GNX_FFN_FP32 is set for the whole run: the six-term kernel is switched off")
+    U.needs_default_forms(gn, *U.ONE_LAUNCH_CORE_FORMS)
     rng = np.random.default_rng(5200 + E)
     dims = (128, 64, 32)
     colptr, rowval = U.er_csc(rng, 500, E)
@@ -366,6 +363,66 @@ def test_two_host_threads_run_core_forwards_on_one_handle_concurrently(gn):
     ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
     [t.start() for t in ts]
     [t.join() for t in ts]
+    assert not errors, errors[:5]
+
+
+def test_matrix_core_calls_of_several_threads_take_turns_on_the_device(gn):
+    """Round 5 (profiles/r05_mfma_mix_hazard.log): kernels on the fp32 matrix instruction returned wrong values — one pass of one instruction, 2 rows x
+    32 columns — while a six-term (bf16) edge kernel of ANOTHER thread's forward was resident on the device; nothing is shared between the two.  The
+    exported forwards at matrix-core widths therefore take turns on the device (csrc/gnx_forms.cpp: DeviceTurn).  Three threads: a core on the fp32
+    instruction, a core on the six-term kernels, a prepared six-term GNBlock in a loop (the strongest disturber found: ~1 wrong forward in 5 without
+    the guard) — every result bit-identical to its serial run."""
+    import threading
+    import torch
+    F = gn._lib
+    rng = np.random.default_rng(4950)
+    dims = (128, 64, 32)
+    graphs = [U.er_csc(rng, n, e) for n, e in ((900, 12000), (300, 2500))]
+    g = gn.GNGraphBatch.from_csc([c for c, _ in graphs], [r for _, r in graphs], [900, 300])
+    p = O.make_core_params(rng, dims)
+    core = U.core_from_params(gn, p)
+    blk = U.block_from_params(gn, p["block"]).prepare()
+    xs = [U.to_nt(gn, g, *U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims)) for _ in range(4)]
+    forms = (F.FLAG_FP32_MFMA, 0)
+    refs = {f: [tuple(t.clone() for t in (y.ef, y.nf, y.gf)) for y in (core(x, flags=f | F.FLAG_NO_FORK) for x in xs)] for f in forms}
+    ref_blk = blk(xs[1]); ref_blk = tuple(t.clone() for t in (ref_blk.ef, ref_blk.nf, ref_blk.gf))
+    torch.cuda.synchronize()
+    errors, stop = [], threading.Event()
+
+    def core_worker(tid):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for it in range(60):
+                    k = (tid + 2 * it) % len(xs)
+                    y = core(xs[k], flags=forms[tid])
+                    st.synchronize()
+                    for name, a, b in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), refs[forms[tid]][k]):
+                        if not torch.equal(a, b):
+                            errors.append((tid, it, k, name))
+        except Exception as ex:  # noqa: BLE001
+            errors.append((tid, repr(ex)))
+
+    def block_worker():
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                while not stop.is_set():
+                    y = blk(xs[1])
+                    st.synchronize()
+                    if not all(torch.equal(a, b) for a, b in zip((y.ef, y.nf, y.gf), ref_blk)):
+                        errors.append(("block",))
+        except Exception as ex:  # noqa: BLE001
+            errors.append(("block", repr(ex)))
+    ts = [threading.Thread(target=core_worker, args=(i,)) for i in range(2)]
+    tb = threading.Thread(target=block_worker)
+    tb.start()
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    stop.set()
+    tb.join()
     assert not errors, errors[:5]
 
 

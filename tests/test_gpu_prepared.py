@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def gn():
     import graphnets_jl_amd as gn_
+    # (these tests name the kernels of the DEFAULT forms: which preparation launches exist, that the one-launch core kernel runs)
+    U.needs_default_forms(gn_, *U.ONE_LAUNCH_CORE_FORMS, "PROJ_FP32", "EDGE_NARROW_FP32")
     return gn_
 
 

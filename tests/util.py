@@ -164,3 +164,16 @@ def with_flags(layer, flags):
 def default_flags(gn):
     """forms the environment switched on for this process (gnx_default_flags)"""
     return int(gn._lib.load().gnx_default_flags())
+
+
+def needs_default_forms(gn, *names):
+    """Skips a test that asserts WHICH kernels run (or compares forms that only differ under the default selection) when the process-wide default
+    (the GNX_* environment variables, read once: gnx_default_flags) switches one of the named forms on: the suite stays green under
+    `GNX_FFN_FP32=1 pytest …`, `GNX_CORE_EDGE_SPLIT=1 pytest …` etc., where the remaining tests check that form against the oracle."""
+    import pytest
+    on = [n for n in names if default_flags(gn) & getattr(gn._lib, "FLAG_" + n)]
+    if on:
+        pytest.skip("switched on for the whole run: " + ", ".join("GNX_" + n for n in on))
+
+
+ONE_LAUNCH_CORE_FORMS = ("FFN_FP32", "EDGE_FP32", "LN_STATS_PASS", "CORE_EDGE_SPLIT", "EDGE_N", "NO_LN_FUSE")  # any of these: no k_core_edge_x6

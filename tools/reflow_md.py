@@ -15,6 +15,8 @@ for line in open(path, encoding="utf-8").read().split("\n"):
         fence = not fence
         out.append(line)
         continue
+    if not fence and item.match(line):  # (one space behind a list marker: re-flowing must not widen the hanging indent)
+        line = re.sub(r"^(\s*(?:\*|-|\d+\.))\s+", r"\1 ", line)
     special = fence or not line.strip() or line.startswith("#") or line.startswith("|") or item.match(line)
     prev_joinable = out and out[-1].strip() and not out[-1].startswith("#") and not out[-1].startswith("|") and not out[-1].startswith("```")
     if not special and prev_joinable and not fence:
