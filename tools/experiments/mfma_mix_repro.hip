@@ -1,0 +1,114 @@
+// Stand-alone reproduction attempt of profiles/r05_mfma_mix_hazard.log: does a wave that accumulates with v_mfma_f32_32x32x2f32 get a wrong result
+// while a kernel of dense bf16 matrix instructions runs on ANOTHER stream?  No library code.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_mix_repro tools/experiments/mfma_mix_repro.hip && /tmp/mfma_mix_repro [victim: 0 regs | 1 lds] [aggressor: bf16 | f32 | none] [seconds]
+// Victim: every wave computes C = sum over K of A_k B_k (32 x 32, K = 512 as 256 dependent MFMAs) on small integers (exact in fp32 whatever the order)
+// and compares with the closed form; operands either held in registers or re-read from LDS before every instruction (k_ffn_fused's pattern).
+// Aggressor: waves looping over dependent v_mfma_f32_32x32x16_bf16 (or the fp32 instruction) until a flag is set.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+// A[m][k] = (m + k) % 5 - 2, B[k][n] = (n + 2 k) % 7 - 3: C[m][n] = sum_k A B, |C| < 2^24: exact
+__device__ __host__ inline float a_of(int m, int k) { return (float)((m + k) % 5 - 2); }
+__device__ __host__ inline float b_of(int k, int n) { return (float)((n + 2 * k) % 7 - 3); }
+
+template <bool LDS>
+__global__ __launch_bounds__(256) void k_victim(int K, int reps, unsigned* bad, float* sink) {
+  __shared__ float sA[4][32 * 33];
+  __shared__ float sB[4][32 * 32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
+  unsigned wrong = 0;
+  for (int rep = 0; rep < reps; ++rep) {
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+      if (LDS) {  // stage a 32-deep chunk: A[32 rows][32 k] (stride 33), B[32 k][32 cols]
+        for (int i = lane; i < 32 * 32; i += 64) { sA[wv][(i >> 5) * 33 + (i & 31)] = a_of(i >> 5, k0 + (i & 31)); sB[wv][i] = b_of(k0 + (i >> 5), i & 31); }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        float fa, fb;
+        if (LDS) { fa = sA[wv][l31 * 33 + 2 * kk + hi]; fb = sB[wv][(2 * kk + hi) * 32 + l31]; }
+        else { fa = a_of(l31, k0 + 2 * kk + hi); fb = b_of(k0 + 2 * kk + hi, l31); }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+      }
+      if (LDS) __builtin_amdgcn_wave_barrier();
+    }
+    // check: lane (col l31, hi), register q <-> row (q & 3) + 8 (q >> 2) + 4 hi
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = (q & 3) + 8 * (q >> 2) + 4 * hi;
+      float ref = 0.f;
+      for (int k = 0; k < K; ++k) ref += a_of(m, k) * b_of(k, l31);
+      if (acc[q] != ref) ++wrong;
+    }
+  }
+  if (wrong) atomicAdd(bad, wrong);
+  if (sink && wrong == 0xffffffffu) sink[0] = 1.f;
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_aggressor(const volatile int* stop, float* sink) {
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  bf16x8 a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (threadIdx.x + j)); b[j] = (__bf16)(0.002f * (threadIdx.x % 7 + j)); }
+  const float fa = 0.001f * threadIdx.x, fb = 0.5f;
+  for (int it = 0; it < (1 << 30); ++it) {
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {
+      if (BF16) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+    }
+    if ((it & 15) == 0 && *stop) break;
+  }
+  if (acc[0] == 12345.678f) sink[0] = acc[1];
+}
+
+int main(int argc, char** argv) {
+  const int lds = argc > 1 ? atoi(argv[1]) : 1;
+  const char* agg = argc > 2 ? argv[2] : "bf16";
+  const double secs = argc > 3 ? atof(argv[3]) : 5.0;
+  hipStream_t sv, sa;
+  CK(hipStreamCreateWithFlags(&sv, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+  unsigned* d_bad; float* d_sink; int* stop;
+  CK(hipMalloc(&d_bad, 4)); CK(hipMalloc(&d_sink, 64)); CK(hipMemset(d_bad, 0, 4));
+  CK(hipHostMalloc(&stop, 4, hipHostMallocMapped)); *stop = 0;
+  int* d_stop; CK(hipHostGetDevicePointer((void**)&d_stop, stop, 0));
+  if (strcmp(agg, "none")) {
+    // half the chip's wave slots for the aggressor (256 CUs x 4 SIMDs: 512 workgroups of 4 waves = 2 waves per SIMD), the victim takes the rest
+    if (!strcmp(agg, "bf16")) hipLaunchKernelGGL(k_aggressor<true>, dim3(512), dim3(256), 0, sa, d_stop, d_sink);
+    else hipLaunchKernelGGL(k_aggressor<false>, dim3(512), dim3(256), 0, sa, d_stop, d_sink);
+    CK(hipGetLastError());
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  long launches = 0;
+  while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
+    if (lds) hipLaunchKernelGGL(k_victim<true>, dim3(1024), dim3(256), 0, sv, 512, 4, d_bad, (float*)nullptr);
+    else hipLaunchKernelGGL(k_victim<false>, dim3(1024), dim3(256), 0, sv, 512, 4, d_bad, (float*)nullptr);
+    ++launches;
+    if (launches % 8 == 0) CK(hipStreamSynchronize(sv));
+  }
+  CK(hipStreamSynchronize(sv));
+  *stop = 1;
+  CK(hipDeviceSynchronize());
+  unsigned bad = 0;
+  CK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+  const double elems = (double)launches * 1024 * 4 * 4 * 1024;
+  printf("victim operands from %s, aggressor %s, %.1f s: %ld launches, %.3g result elements checked, %u wrong\n", lds ? "LDS" : "registers", agg, secs, launches, elems, bad);
+  return 0;
+}
