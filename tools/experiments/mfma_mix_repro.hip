@@ -60,19 +60,46 @@ __global__ __launch_bounds__(256) void k_victim(int K, int reps, unsigned* bad, 
 
 template <bool BF16>
 __global__ __launch_bounds__(256) void k_aggressor(const volatile int* stop, float* sink) {
+#ifdef AGG_LDS_KB
+  // the real aggressors read their matrix operands from a large LDS allocation: AGG_LDS_KB KB per workgroup, rewritten and re-read every round
+  __shared__ __attribute__((aligned(16))) unsigned s_big[AGG_LDS_KB * 256];
+#endif
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-  bf16x8 a, b;
+  // operands with random-looking bits (a matrix pipe on zeros / constants draws little power: MI355X_MICROARCH 'DVFS give-back'), eight different
+  // fragments in rotation, the accumulator kept finite by alternating signs
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  bf16x8 a[8], b[8];
+  unsigned h = 0x9e3779b9u * (threadIdx.x + 257u * blockIdx.x + 1u);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (threadIdx.x + j)); b[j] = (__bf16)(0.002f * (threadIdx.x % 7 + j)); }
-  const float fa = 0.001f * threadIdx.x, fb = 0.5f;
+  for (int f = 0; f < 8; ++f) {
+    unsigned w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h ^= h << 13; h ^= h >> 17; h ^= h << 5; w[j] = (h & 0x807f807fu) | 0x3f003f00u; }  // bf16 pairs in [0.5, 1) with random signs / mantissas
+    a[f] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
+    b[f] = __builtin_bit_cast(bf16x8, u32x4{w[4], w[5], w[6], w[7]});
+  }
+  const float fa = __uint_as_float((h & 0x807fffffu) | 0x3f000000u), fb = 0.5f;
   for (int it = 0; it < (1 << 30); ++it) {
+#ifdef AGG_LDS_KB
+    {
+      typedef unsigned u32x4l __attribute__((ext_vector_type(4)));
+      const int nq = AGG_LDS_KB * 64;  // 16-byte quads
+      for (int i = threadIdx.x; i < nq; i += 256) { h ^= h << 13; h ^= h >> 17; h ^= h << 5; reinterpret_cast<u32x4l*>(s_big)[i] = u32x4l{h, h * 3u, h * 5u, h * 7u} & 0x807f807fu | 0x3f003f00u; }
+      __syncthreads();
+#pragma unroll
+      for (int f = 0; f < 8; ++f) a[f] = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4l*>(s_big)[(threadIdx.x + 256 * f + 37 * it) % nq]);
+      __syncthreads();
+    }
+#endif
 #pragma unroll
     for (int u = 0; u < 64; ++u) {
-      if (BF16) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      if (BF16) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 7], b[(u + 3) & 7], acc, 0, 0, 0);
       else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
     }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] *= 0.001f;  // (stays finite)
     if ((it & 15) == 0 && *stop) break;
   }
   if (acc[0] == 12345.678f) sink[0] = acc[1];
