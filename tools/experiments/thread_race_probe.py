@@ -17,8 +17,9 @@ ROUNDS = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 extra = int(os.environ.get("PROBE_FLAGS", "0"))
 rng = np.random.default_rng(4900)
 dims = (128, 64, 32)
-graphs = [U.er_csc(rng, n, e) for n, e in ((900, 12000), (300, 2500))]
-g = gn.GNGraphBatch.from_csc([c for c, _ in graphs], [r for _, r in graphs], [900, 300])
+SIZES = ((5000, 60000), (4500, 40000)) if os.environ.get("PROBE_BIG") else ((900, 12000), (300, 2500))  # PROBE_BIG: >= 4096 nodes (projections and node FeedForward six-term too)
+graphs = [U.er_csc(rng, n, e) for n, e in SIZES]
+g = gn.GNGraphBatch.from_csc([c for c, _ in graphs], [r for _, r in graphs], [n for n, _ in SIZES])
 p = O.make_core_params(rng, dims)
 core = U.core_from_params(gn, p)
 xs = [U.to_nt(gn, g, *U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims)) for _ in range(4)]
