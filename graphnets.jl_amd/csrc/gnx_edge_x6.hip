@@ -563,6 +563,264 @@ int32_t launch_proj_x6(const Tile* tiles, size_t n_tiles, const float* nf, size_
   return GNX_OK;
 }
 
+// ---- the node update of a block at core widths on the same scheme: nf' = act(Wn^T [ sum of the in-edges' ef' (128) | gn1(nf) (64) ] + b (+ gf fold per graph)),
+//      nodefninput.jl:1-7 + gnblock.jl:66.  k_rows_gemm ran it on the fp32 matrix instruction: 45-49 us for C2's 100k nodes against ~20 us of traffic —
+//      and of the forward's kernels at core widths it was the one a foreign bf16 GEMM on another stream was seen to disturb (profiles/r05_mfma_mix_hazard.log).
+//      K = 128 + 64 = 192 (12 k16-steps), 64 outputs = two 32-output slices of 36 prepared fragments; BOTH slices are requested up front (72 KB of LDS, two
+//      workgroups per CU), the finished block goes through the first slice's buffer — idle by then — into (row, quad) form; a wave's 32 node rows on the lanes.
+//      The summed in-edge rows come from the edge kernel's per-destination partial sums: a node's first partial row, plus the first row of every further
+//      64-row chunk its in-edges run through (one node in ~6 on the ER graph has a second part), added in chunk order.
+namespace {
+constexpr int NK = 192, NKS = NK / 16, NNF = 3 * NKS, NSLB = NNF * 1024, NOUT = 64, NNOB = NOUT / 32;
+}
+
+// Wn ([192 (+ dg)][ldw] row-major: the 128 rows of the summed edges, then the 64 node rows; the first 64 columns) -> per slice ob NNF fragments (k_edge_x6_prep's format)
+__global__ void k_node_x6_prep(const float* __restrict__ W, int ldw, __bf16* __restrict__ Wp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (ob, s, lane, j pair)
+  if (idx >= NNOB * NKS * 64 * 4) return;
+  const int jp = idx & 3, lane = (idx >> 2) & 63, s = (idx >> 8) % NKS, ob = (idx >> 8) / NKS;
+  const int m = lane & 31, h = lane >> 5, k = 16 * s + 8 * h + 2 * jp;
+  const int col = 32 * ob + m;
+  unsigned hh, mm, ll;
+  esplit2(W[(size_t)k * ldw + col], W[(size_t)(k + 1) * ldw + col], hh, mm, ll);
+  unsigned* o = reinterpret_cast<unsigned*>(Wp) + ((size_t)ob * NNF + 3 * s) * 256 + lane * 4 + jp;
+  o[0] = hh; o[256] = mm; o[512] = ll;
+}
+
+struct NodeX6Args {
+  const Tile* tiles;       // node tiles: rows [n0, n1) of graph g
+  const float* nf;         // [R][N][64]
+  size_t N;
+  const float* ln_stats;   // [R][N][2] (mean, 1/sigma) or nullptr
+  const float* ln_g;
+  const float* ln_b;
+  const float* agg;        // [R][n_agg_rows][128]: the edge kernel's per-destination partial sums
+  size_t n_agg_rows;
+  const int* agg_row;      // [N] row of the node's first partial, -1 without in-edges
+  const int* agg_parts;    // [N] chunks the node's in-edges run through
+  const int* agg_chunk;    // [N] its first chunk
+  const int* chunk_row0;   // [2 n_etiles + 1]
+  const __bf16* Wp;
+  const float* bias;       // [64] or nullptr
+  const float* bias_g;     // [R][G][64] (bias + gf fold) or nullptr
+  int G;
+  int act;                 // identity / relu
+  float* out;              // [R][N][64]
+  float* colsum;           // [R][n_tiles][64] or nullptr: the tile's column sums (graph update)
+  size_t n_tiles;
+};
+
+__global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_node_x6(NodeX6Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_w0[NSLB];  // slice 0's fragments; then the staging area [128][36] + column-sum partials [32][32]
+  __shared__ __attribute__((aligned(16))) unsigned char s_w1[NSLB];
+  static_assert((EBM * ELDE + 32 * 32) * 4 <= NSLB, "staging area + column-sum partials fit the first weight buffer");
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, n = lane & 31;
+  const size_t r = blockIdx.y;
+  const Tile t = a.tiles[blockIdx.x];
+  const int row0 = t.n0, rows = t.n1 - t.n0;
+  if (rows <= 0) return;  // (whole workgroup)
+  auto stage = [&](int ob, unsigned char* dst) {
+    const unsigned char* srcp = reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)ob * NSLB;
+#pragma unroll
+    for (int i = 0; i < NNF / EW; ++i) {
+      const int pc = wv + EW * i;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcp + (size_t)pc * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + pc * 1024), 16, 0, 0);
+    }
+  };
+  stage(0, s_w0);
+  stage(1, s_w1);
+  // ---- the wave's rows as B fragments, three bf16 parts: k16-steps 0..7 = the summed in-edge rows, 8..11 = gn1(nf) ----
+  typedef unsigned u32x4e __attribute__((ext_vector_type(4)));
+  const int lrow = wv * ER + n;
+  const int lrc = lrow < rows ? lrow : rows - 1;
+  const size_t node = (size_t)row0 + lrc;
+  bf16x8e zh[NKS], zm[NKS], zl[NKS];
+  {
+    // (the three index tables are read together, and the second part's row — one node in ~6 has one: nearly every wave — is looked up beside the first
+    //  part's data: index -> {first rows, second row's index} -> second rows, three round trips instead of five)
+    const int arow = a.agg_row[node], parts_raw = a.agg_parts[node], chunk = a.agg_chunk[node];
+    const int parts = arow >= 0 ? parts_raw : 0;
+    const int prow1 = parts > 1 ? a.chunk_row0[chunk + 1] : 0;
+    const float* __restrict__ aggr = a.agg + r * a.n_agg_rows * EOUT;
+    f32x4e acc8[EKS][2];
+    const f32x4e zero4 = {0.f, 0.f, 0.f, 0.f};
+    {
+      const float* __restrict__ p0 = aggr + (size_t)(arow >= 0 ? arow : 0) * EOUT + 8 * hi;
+#pragma unroll
+      for (int s = 0; s < EKS; ++s) {
+        acc8[s][0] = *reinterpret_cast<const f32x4e*>(p0 + 16 * s);
+        acc8[s][1] = *reinterpret_cast<const f32x4e*>(p0 + 16 * s + 4);
+      }
+      if (arow < 0) {
+#pragma unroll
+        for (int s = 0; s < EKS; ++s) { acc8[s][0] = zero4; acc8[s][1] = zero4; }
+      }
+    }
+    // further parts (in chunk order): the loop runs while ANY row of the wave has one left
+    if (__any(parts > 1)) {
+      for (int p = 1; __any(p < parts); ++p) {
+        const bool has = p < parts;
+        const int prow = p == 1 ? prow1 : (has ? a.chunk_row0[chunk + p] : 0);
+        const float* __restrict__ pp = aggr + (size_t)prow * EOUT + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < EKS; ++s) {
+          const f32x4e u0 = *reinterpret_cast<const f32x4e*>(pp + 16 * s), u1 = *reinterpret_cast<const f32x4e*>(pp + 16 * s + 4);
+          if (has) { acc8[s][0] += u0; acc8[s][1] += u1; }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < EKS; ++s) {
+      const float v[8] = {acc8[s][0].x, acc8[s][0].y, acc8[s][0].z, acc8[s][0].w, acc8[s][1].x, acc8[s][1].y, acc8[s][1].z, acc8[s][1].w};
+      unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) esplit2(v[2 * j], v[2 * j + 1], ph[j], pm[j], pl[j]);
+      zh[s] = __builtin_bit_cast(bf16x8e, u32x4e{ph[0], ph[1], ph[2], ph[3]});
+      zm[s] = __builtin_bit_cast(bf16x8e, u32x4e{pm[0], pm[1], pm[2], pm[3]});
+      zl[s] = __builtin_bit_cast(bf16x8e, u32x4e{pl[0], pl[1], pl[2], pl[3]});
+    }
+    // gn1(nf) (or nf itself)
+    const float* __restrict__ zrow = a.nf + (r * a.N + node) * PK;
+    float mu = 0.f, inv = 1.f;
+    const bool ln = a.ln_stats != nullptr;
+    if (ln) {
+      const float2 st = reinterpret_cast<const float2*>(a.ln_stats)[r * a.N + node];
+      mu = st.x; inv = st.y;
+    }
+#pragma unroll
+    for (int s = 0; s < PKS; ++s) {
+      const f32x4e r0 = *reinterpret_cast<const f32x4e*>(zrow + 16 * s + 8 * hi), r1 = *reinterpret_cast<const f32x4e*>(zrow + 16 * s + 8 * hi + 4);
+      float v[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+      if (ln) {
+        const f32x4e g0 = *reinterpret_cast<const f32x4e*>(a.ln_g + 16 * s + 8 * hi), g1 = *reinterpret_cast<const f32x4e*>(a.ln_g + 16 * s + 8 * hi + 4);
+        const f32x4e b0 = *reinterpret_cast<const f32x4e*>(a.ln_b + 16 * s + 8 * hi), b1 = *reinterpret_cast<const f32x4e*>(a.ln_b + 16 * s + 8 * hi + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(gg[j], (v[j] - mu) * inv, bb[j]);
+      }
+      unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) esplit2(v[2 * j], v[2 * j + 1], ph[j], pm[j], pl[j]);
+      zh[EKS + s] = __builtin_bit_cast(bf16x8e, u32x4e{ph[0], ph[1], ph[2], ph[3]});
+      zm[EKS + s] = __builtin_bit_cast(bf16x8e, u32x4e{pm[0], pm[1], pm[2], pm[3]});
+      zl[EKS + s] = __builtin_bit_cast(bf16x8e, u32x4e{pl[0], pl[1], pl[2], pl[3]});
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // both slices' pieces of this wave have landed
+  __syncthreads();                                  // ... everybody's
+  const int er = lane >> 3, eq = lane & 7;
+  const bool wave_full = rows >= (wv + 1) * ER;
+  float* s_e = reinterpret_cast<float*>(s_w0);      // [128][36] once slice 0's fragments have been read by everyone
+  float* s_cs = s_e + EBM * ELDE;                   // [32][32]
+  float* sE = s_e + wv * (ER * ELDE);
+  const float* __restrict__ bp = a.bias_g ? a.bias_g + (r * a.G + (size_t)t.g) * NOUT : a.bias;
+  const int act_floor = a.act == 1 ? 0 : (int)0x80000000;
+  float* __restrict__ outp = a.out + (r * a.N + (size_t)row0) * NOUT;
+#pragma unroll
+  for (int ob = 0; ob < NNOB; ++ob) {
+    const unsigned char* wb = (ob == 0 ? s_w0 : s_w1) + lane * 16;
+    f32x16e acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    bf16x8e A[2][3];
+#pragma unroll
+    for (int p3 = 0; p3 < 3; ++p3) A[0][p3] = *reinterpret_cast<const bf16x8e*>(wb + p3 * 1024);
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      const int c = s & 1;
+      if (s + 1 < NKS) {
+#pragma unroll
+        for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8e*>(wb + (3 * (s + 1) + p3) * 1024);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zm[s], acc, 0, 0, 0);  // small terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][2], zh[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zl[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zh[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zm[s], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zh[s], acc, 0, 0, 0);
+    }
+    if (ob == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every wave has read slice 0's fragments: their buffer is the staging area now
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<f32x4e*>(sE + n * ELDE + 8 * g + 4 * hi) = f32x4e{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    f32x4e b4 = {0.f, 0.f, 0.f, 0.f};
+    if (bp) b4 = *reinterpret_cast<const f32x4e*>(bp + 32 * ob + 4 * eq);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int lr = er + 8 * i;
+      f32x4e v = *reinterpret_cast<const f32x4e*>(sE + lr * ELDE + 4 * eq);
+      v += b4;
+      float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vv[e] = __int_as_float(max(__float_as_int(vv[e]), act_floor));
+      v = f32x4e{vv[0], vv[1], vv[2], vv[3]};
+      const bool ok = wave_full || wv * ER + lr < rows;
+      if (!ok) v = f32x4e{0.f, 0.f, 0.f, 0.f};  // (rows beyond the tile: zero for the column sums)
+      if (a.colsum) *reinterpret_cast<f32x4e*>(sE + lr * ELDE + 4 * eq) = v;
+      if (wave_full) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * NOUT + 32 * ob + 4 * eq) = v;
+      else if (ok) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * NOUT + 32 * ob + 4 * eq) = v;
+    }
+    if (a.colsum) {  // the tile's column sums of this slice, fixed order: 32 row groups x 4 rows, then the groups ascending
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const int q4 = tid & 7, grp = tid >> 3;
+      f32x4e c4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c4 += *reinterpret_cast<const f32x4e*>(s_e + (grp + 32 * i) * ELDE + 4 * q4);
+      *reinterpret_cast<f32x4e*>(s_cs + grp * 32 + 4 * q4) = c4;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (tid < 32) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 32; ++w) sum += s_cs[w * 32 + tid];
+        a.colsum[(r * a.n_tiles + (size_t)blockIdx.x) * NOUT + 32 * ob + tid] = sum;
+      }
+      if (ob + 1 < NNOB) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the staging area and the partials may be overwritten
+    }
+  }
+}
+
+size_t node_x6_scratch_bytes() { return (size_t)NNOB * NSLB; }
+
+// does the node update of these widths run as k_node_x6?  (the arithmetic flags as for the projections: GNX_FLAG_EDGE_FP32 = the fp32 instruction
+// throughout, GNX_FLAG_PROJ_FP32 = the node-side kernels alone)
+bool node_x6_applies(int oe, int dn, int on, int act, const float* nf, const float* Wn, const float* out, size_t N) {
+  if (form(GNX_FLAG_EDGE_FP32) || form(GNX_FLAG_PROJ_FP32)) return false;
+  return oe == EOUT && dn == PK && on == NOUT && (act == GNX_ACT_IDENTITY || act == GNX_ACT_RELU) && N >= 4096 && (((uintptr_t)nf | (uintptr_t)Wn | (uintptr_t)out) & 15) == 0;
+}
+
+int32_t launch_node_x6_prep(const float* Wn, int ldw, void* scratch, hipStream_t s) {
+  ProfScope ps("k_node_x6_prep", s);
+  GNX_LAUNCH(k_node_x6_prep, dim3((unsigned)((NNOB * NKS * 64 * 4 + 255) / 256)), dim3(256), 0, s, Wn, ldw, static_cast<__bf16*>(scratch));
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
+// nf' = act(Wn^T [sum of the in-edges' ef' | z] + bias (per graph with bias_g)), z = nf or gn1(nf) from ln_stats; scratch: node_x6_scratch_bytes(), 16-byte aligned
+int32_t launch_node_x6(const Tile* tiles, size_t n_tiles, const float* nf, size_t N, const float* ln_stats, const float* ln_g, const float* ln_b, const float* agg,
+                       size_t n_agg_rows, const int* agg_row, const int* agg_parts, const int* agg_chunk, const int* chunk_row0, const float* Wn, int ldw, const float* bias,
+                       const float* bias_g, int G, int act, float* out, float* colsum, int64_t R, void* scratch, hipStream_t s) {
+  if (n_tiles == 0) return GNX_OK;
+  if (!tiles || !nf || !agg || !agg_row || !agg_parts || !agg_chunk || !chunk_row0 || !Wn || !out || !scratch || ((uintptr_t)scratch & 15))
+    return fail(GNX_ERR_INVALID_ARG, "k_node_x6: NULL operand or misaligned scratch");
+  if (ln_stats && (!ln_g || !ln_b || (((uintptr_t)ln_g | (uintptr_t)ln_b) & 15) || ((uintptr_t)ln_stats & 7))) return fail(GNX_ERR_INVALID_ARG, "k_node_x6: LayerNorm parameters missing or misaligned");
+  if ((((uintptr_t)bias | (uintptr_t)bias_g | (uintptr_t)agg | (uintptr_t)out) & 15)) return fail(GNX_ERR_INVALID_ARG, "k_node_x6: operand not 16-byte aligned");
+  if (ldw != NOUT) return fail(GNX_ERR_INVALID_ARG, "k_node_x6: the node function's weight rows are 64 wide");
+  const __bf16* Wp = static_cast<const __bf16*>(prepared_planes(PREP_NODE, Wn, nullptr, ldw));  // made once with the layer (gnx_*_prepare) ...
+  if (!Wp) {                                                                                      // ... or by a launch in front of this forward
+    if (const int32_t rc = launch_node_x6_prep(Wn, ldw, scratch, s)) return rc;
+    Wp = static_cast<const __bf16*>(scratch);
+  }
+  NodeX6Args a{};
+  a.tiles = tiles; a.nf = nf; a.N = N; a.ln_stats = ln_stats; a.ln_g = ln_g; a.ln_b = ln_b; a.agg = agg; a.n_agg_rows = n_agg_rows; a.agg_row = agg_row; a.agg_parts = agg_parts;
+  a.agg_chunk = agg_chunk; a.chunk_row0 = chunk_row0; a.Wp = Wp; a.bias = bias; a.bias_g = bias_g; a.G = G; a.act = act; a.out = out; a.colsum = colsum; a.n_tiles = n_tiles;
+  ProfScope ps("k_rows_gemm_node", s);  // (the name the node update has in every profile and bench line)
+  GNX_LAUNCH(k_node_x6, dim3((unsigned)n_tiles, (unsigned)R), dim3(64 * EW), 0, s, a);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+
 size_t edge_x6_scratch_bytes() { return sizeof(__bf16) * 3 * (size_t)EK * EOUT; }
 
 // ---- the ENCODER form: (10, 5, .) => 128 unprojected ----

@@ -167,7 +167,7 @@ struct DeviceTurn {
 // front of every forward.  An exported forward publishes the layer's prepared object to the launchers below it (PreparedScope); a launcher asks
 // for the planes of the very weight pointers it was handed (prepared_planes: a miss — other weights, another device, no prepared object —
 // means "run the prep launch into the workspace as before").
-enum PreparedKind : int32_t { PREP_EDGE = 1, PREP_PROJ = 2, PREP_FFN = 3, PREP_ENC = 4 };
+enum PreparedKind : int32_t { PREP_EDGE = 1, PREP_PROJ = 2, PREP_FFN = 3, PREP_ENC = 4, PREP_NODE = 5 };
 struct PreparedScope {
   explicit PreparedScope(const gnx_prepared* q);
   ~PreparedScope();

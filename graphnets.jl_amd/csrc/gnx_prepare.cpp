@@ -19,6 +19,8 @@ int32_t launch_ffn_x6_prep(const float* W1, const float* W2, int d, void* scratc
                            const float* b1);  // gnx_ffn_x6.hip
 size_t ffn_x6_fold_scratch_bytes(int d);
 int32_t launch_edge_enc_prep(const float* We, int ldw, void* scratch, hipStream_t s);                  // gnx_edge_x6.hip
+int32_t launch_node_x6_prep(const float* Wn, int ldw, void* scratch, hipStream_t s);                   // gnx_edge_x6.hip
+size_t node_x6_scratch_bytes();
 size_t edge_enc_scratch_bytes();
 size_t ffn_x6_scratch_bytes(int d);
 }  // namespace gnx
@@ -71,6 +73,7 @@ int32_t run_entry(const gnx_prepared::Entry& e, hipStream_t s) {
                                            static_cast<const float*>(e.x1), static_cast<const float*>(e.x2))
                       : launch_ffn_x6_prep(static_cast<const float*>(e.w0), static_cast<const float*>(e.w1), e.n, e.planes, s, nullptr, nullptr, nullptr);
     case PREP_ENC: return launch_edge_enc_prep(static_cast<const float*>(e.w0), e.n, e.planes, s);
+    case PREP_NODE: return launch_node_x6_prep(static_cast<const float*>(e.w0), e.n, e.planes, s);
   }
   return fail(GNX_ERR_INVALID_ARG, "prepared parameters: unknown entry");
 }
@@ -104,6 +107,8 @@ int32_t add_block(gnx_prepared* q, const gnx_block_params& p) {
   if (p.oe == 128 || p.oe <= 32) rc = add_entry(q, PREP_EDGE, We, nullptr, p.oe, p.oe, sizeof(uint16_t) * 3 * 128 * (size_t)((p.oe + 31) / 32 * 32));
   if (rc == GNX_OK && p.dn == 64 && p.oe == 128)
     rc = add_entry(q, PREP_PROJ, We + (size_t)p.de * p.oe, We + (size_t)(p.de + p.dn) * p.oe, p.oe, p.oe, proj_x6_scratch_bytes());
+  if (rc == GNX_OK && p.dn == 64 && p.oe == 128 && p.on == 64 && p.nodefn.weight)  // the node update at core widths (k_node_x6)
+    rc = add_entry(q, PREP_NODE, p.nodefn.weight, nullptr, p.on, p.on, node_x6_scratch_bytes());
   return rc;
 }
 

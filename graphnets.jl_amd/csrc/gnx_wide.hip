@@ -40,6 +40,11 @@ int32_t launch_edge_enc(const Tile* tiles, size_t n_tiles, const float* ef, size
 // gnx_edge_n.hip: the edge update with the source side gathered raw (K = 128 + 64) and a register epilogue
 size_t edge_n_scratch_bytes();
 size_t edge_x6_fold_scratch_bytes();  // gnx_edge_x6.hip
+bool node_x6_applies(int oe, int dn, int on, int act, const float* nf, const float* Wn, const float* out, size_t N);  // gnx_edge_x6.hip
+size_t node_x6_scratch_bytes();
+int32_t launch_node_x6(const Tile* tiles, size_t n_tiles, const float* nf, size_t N, const float* ln_stats, const float* ln_g, const float* ln_b, const float* agg,
+                       size_t n_agg_rows, const int* agg_row, const int* agg_parts, const int* agg_chunk, const int* chunk_row0, const float* Wn, int ldw, const float* bias,
+                       const float* bias_g, int G, int act, float* out, float* colsum, int64_t R, void* scratch, hipStream_t s);
 bool edge_n_enabled();
 int32_t launch_edge_n(const Tile* tiles, size_t n_tiles, const float* ef, size_t E, const float* ln_stats, const float* ln_g, const float* ln_b, const float* We, int ldw,
                       const float* zsrc, const float* pdst, size_t N, const int* src, const int* dst, int act, float* out, float* colsum, float* agg_out, size_t n_agg_rows,
@@ -1568,6 +1573,15 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     if (agg_fuse) { w.agg_out = agg_tab; w.agg_rep_stride = (size_t)h->n_agg_rows * a.oe; w.chunk_row0 = h->d_chunk_row0; }
     if ((rc = launch_gemm_any(w, (unsigned)n_et, R, s, "k_rows_gemm_edge"))) return rc;
   }
+  // the node update at core widths on the six-term scheme (k_node_x6: the summed in-edge rows from the edge kernel's per-destination partial sums);
+  // its weight planes: the layer's prepared ones, or made here in the projections' scratch (their planes were consumed by the projection launch)
+  const bool node_x6 = (phase & 1) && a.on > 0 && agg_fuse && node_x6_applies(a.oe, a.dn, a.on, a.act_n, a.nf, a.Wn, a.nf_out, (size_t)a.N) &&
+                       (!a.ln_stats[1] || (al16(a.ln_g[1]) && al16(a.ln_b[1]))) && al16(a.bn) && node_x6_scratch_bytes() <= proj_x6_scratch_bytes();
+  if (node_x6) {
+    if ((rc = launch_node_x6(h->d_ntiles, n_nt, a.nf, (size_t)a.N, a.ln_stats[1], a.ln_g[1], a.ln_b[1], agg_tab, (size_t)h->n_agg_rows, h->d_node_agg_row, h->d_node_agg_parts,
+                             h->d_node_agg_chunk, h->d_chunk_row0, a.Wn, a.on, a.bn, a.dg > 0 ? bias_n : nullptr, a.G, a.act_n, a.nf_out, a.og > 0 ? pn : nullptr, R, x6p_tab, s)))
+      return rc;
+  } else
   if ((phase & 1) && a.on > 0) {
     WideArgs w{};
     w.tiles = h->d_ntiles; w.row_kind = 1;

@@ -87,7 +87,7 @@ extern "C" {
 #define GNX_FLAG_FFN_FP32 0x20u   /* wide GNCore FeedForwards on the fp32 matrix instruction (k_ffn_fused) instead of six bf16 terms (k_ffn_x6) */
 #define GNX_FLAG_EDGE_FP32 0x40u  /* projected edge update and node projections on the fp32 matrix instruction (k_rows_gemm) instead of six bf16 terms */
 #define GNX_FLAG_FP32_MFMA (GNX_FLAG_FFN_FP32 | GNX_FLAG_EDGE_FP32) /* every matrix product of the call on the fp32 matrix instruction */
-#define GNX_FLAG_PROJ_FP32 0x80u          /* the node projections alone on the fp32 instruction                                             */
+#define GNX_FLAG_PROJ_FP32 0x80u          /* the node-side kernels alone (node projections, node update) on the fp32 instruction            */
 #define GNX_FLAG_EDGE_NARROW_FP32 0x100u  /* the 128 -> (<= 32) edge update alone on the fp32 instruction                                  */
 /* diagnostic forms — same results (bit-identical where the header says so), kept for A/B runs and for the tests that compare two forms */
 #define GNX_FLAG_NO_LN_FUSE 0x200u       /* wide GNCore: materialise gn1 / gn2 (k_layernorm2) instead of normalising on load               */

@@ -339,6 +339,75 @@ def test_wide_node_projections_on_bf16_matrix_cores(gn, R, graphs, core):
         assert np.isfinite(a).all() and np.max(np.abs(a - b)) <= 2e-6 * max(np.max(np.abs(b)), 1e-30)
 
 
+def _csc_with_hubs_and_isolated(rng, N, E, hubs, isolated):
+    """an ER graph whose nodes `hubs` receive an edge from EVERY node (their in-edges run through several 64-row chunks of the edge tiles: several
+    per-destination partial rows to add up) and whose nodes `isolated` receive none"""
+    colptr, rowval = U.er_csc(rng, N, E)
+    cols = [rowval[colptr[j]:colptr[j + 1]] for j in range(N)]
+    for j in hubs:
+        cols[j] = np.arange(N, dtype=np.int64)
+    for j in isolated:
+        cols[j] = np.zeros(0, dtype=np.int64)
+    cp = np.zeros(N + 1, dtype=np.int64)
+    cp[1:] = np.cumsum([len(c) for c in cols])
+    return cp, np.concatenate(cols)
+
+
+@pytest.mark.parametrize("R,act_n,core,graphs", [(1, 1, False, ((4300, 9000),)), (2, 0, False, ((4400, 20000),)), (1, 1, False, ((2500, 6000), (1700, 5000), (300, 700))),
+                                                 (1, 1, True, ((4200, 9500), (150, 400)))])
+def test_wide_node_update_on_bf16_matrix_cores(gn, R, act_n, core, graphs):
+    """(128, 64, 32) => (., 64, .) from 4096 nodes on: the node update nf' = act(Wn^T [sum of in-edge ef' | nf] + b (+ gf fold)) runs as k_node_x6 — six bf16
+    matrix-core terms per fp32 product, the summed rows taken from the edge kernel's per-destination partial sums (hub nodes: several parts in chunk order;
+    nodes without in-edges: zeros), per-tile column sums for the graph update.  GNBlock (replicas; several graphs: per-graph biases, tiles ending at graph
+    boundaries) and GNCore (gn1 on load) against the float64 oracle at 1e-5·scale and against the fp32-instruction form (GNX_FLAG_PROJ_FP32 switches the
+    node-side kernels back) normwise; the prepared form bit-identical and without a preparation launch."""
+    import torch
+    F = gn._lib
+    if U.default_flags(gn) & (F.FLAG_EDGE_FP32 | F.FLAG_PROJ_FP32 | F.FLAG_EDGE_N):
+        pytest.skip("the six-term node-side kernels are switched off for the whole run")
+    rng = np.random.default_rng(1700 + R + len(graphs) + act_n)
+    dims = (128, 64, 32)
+    cs = []
+    for i, (n, e) in enumerate(graphs):
+        cs.append(_csc_with_hubs_and_isolated(rng, n, e, hubs=(7, n // 2) if i == 0 else (), isolated=(0, 3, n - 1)))
+    g = gn.GNGraphBatch.from_csc([c for c, _ in cs], [r for _, r in cs], [n for n, _ in graphs])
+    assert g.n_nodes >= 4096
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, g.n_graphs, dims)
+    nf = nf * 2.0 - 0.5
+    x = U.to_nt(gn, g, ef, nf, gf)
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    if core:
+        p = O.make_core_params(rng, dims)
+        layer = U.core_from_params(gn, p)
+        ref, scale = O.core_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    else:
+        p = O.make_block_params(rng, dims, dims, act=(1, act_n, 0))
+        layer = U.block_from_params(gn, p)
+        ref, scale = O.block_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    gn.profile_reset(); gn.profile_enable(True)
+    y = layer(x)
+    gn.profile_enable(False)
+    names = set(gn.profile_read()); gn.profile_reset()
+    assert "k_node_x6_prep" in names, names
+    for name, got, r_, s_ in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r_, s_, name)
+    gn.profile_enable(True)
+    y0 = layer(x, flags=F.FLAG_PROJ_FP32)
+    gn.profile_enable(False)
+    names0 = set(gn.profile_read()); gn.profile_reset()
+    assert "k_node_x6_prep" not in names0 and "k_proj_x6_prep" not in names0, names0
+    for name, a, b in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), (y0.ef, y0.nf, y0.gf)):
+        U.assert_same_formula(U.from_jl(a), U.from_jl(b), name)
+    layer.prepare()
+    gn.profile_enable(True)
+    yp = layer(x)
+    gn.profile_enable(False)
+    names_p = set(gn.profile_read()); gn.profile_reset()
+    assert not {n_ for n_ in names_p if n_.endswith("_prep")}, names_p
+    for a, b in zip((y.ef, y.nf, y.gf), (yp.ef, yp.nf, yp.gf)):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("din,act,R,graphs", [((10, 5, 0), (0, 0, 0), 1, ((4300, 9000),)), ((10, 5, 3), (1, 1, 0), 1, ((2500, 6000), (1700, 5000), (300, 700))),
                                              ((10, 5, 0), (2, 0, 0), 2, ((700, 4137),))])
 def test_wide_encoder_edge_update_on_bf16_matrix_cores(gn, din, act, R, graphs):
