@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -111,6 +113,37 @@ __global__ __launch_bounds__(256) void k_aggressor(const volatile int* stop, flo
   if (acc[0] == 12345.678f) sink[0] = acc[1];
 }
 
+// "pulse" aggressors: the same dense matrix loop as SHORT kernels launched one after another with idle gaps (a host thread): load steps on and off the
+// chip all the time, as a GEMM loop of another program does — the persistent aggressor above is a steady load
+template <bool BF16>
+__global__ __launch_bounds__(256) void k_pulse(int iters, float* sink) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  bf16x8 a[8], b[8];
+  unsigned h = 0x9e3779b9u * (threadIdx.x + 257u * blockIdx.x + 1u);
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    unsigned w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { h ^= h << 13; h ^= h >> 17; h ^= h << 5; w[j] = (h & 0x807f807fu) | 0x3f003f00u; }
+    a[f] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
+    b[f] = __builtin_bit_cast(bf16x8, u32x4{w[4], w[5], w[6], w[7]});
+  }
+  const float fa = __uint_as_float((h & 0x807fffffu) | 0x3f000000u), fb = 0.5f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 64; ++u) {
+      if (BF16) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 7], b[(u + 3) & 7], acc, 0, 0, 0);
+      else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] *= 0.001f;
+  }
+  if (acc[0] == 12345.678f) sink[0] = acc[1];
+}
+
 int main(int argc, char** argv) {
   const int lds = argc > 1 ? atoi(argv[1]) : 1;
   const char* agg = argc > 2 ? argv[2] : "bf16";
@@ -127,6 +160,23 @@ int main(int argc, char** argv) {
   if (lds) hipLaunchKernelGGL(k_victim<true>, dim3(1), dim3(256), 0, sv, 512, 1, d_bad, d_ref, 1);
   else hipLaunchKernelGGL(k_victim<false>, dim3(1), dim3(256), 0, sv, 512, 1, d_bad, d_ref, 1);
   CK(hipStreamSynchronize(sv));
+  std::atomic<bool> pulse_stop{false};
+  std::thread pulser;
+  const bool pulse = !strncmp(agg, "pulse", 5);
+  if (pulse) {
+    const bool bf = strstr(agg, "f32") == nullptr;
+    pulser = std::thread([&, bf] {
+      CK(hipSetDevice(0));
+      long n = 0;
+      while (!pulse_stop.load()) {
+        // ~20-40 us of dense matrix work on every SIMD (2048 workgroups x 4 waves), then a gap of the same order
+        if (bf) hipLaunchKernelGGL(k_pulse<true>, dim3(2048), dim3(256), 0, sa, 24, d_sink);
+        else hipLaunchKernelGGL(k_pulse<false>, dim3(2048), dim3(256), 0, sa, 12, d_sink);
+        if ((++n & 3) == 0) { (void)hipStreamSynchronize(sa); std::this_thread::sleep_for(std::chrono::microseconds(30)); }
+      }
+      (void)hipStreamSynchronize(sa);
+    });
+  } else
   if (strcmp(agg, "none")) {
     // half the chip's wave slots for the aggressor (256 CUs x 4 SIMDs: 512 workgroups of 4 waves = 2 waves per SIMD), the victim takes the rest
     if (!strcmp(agg, "bf16")) hipLaunchKernelGGL(k_aggressor<true>, dim3(512), dim3(256), 0, sa, d_stop, d_sink);
@@ -135,6 +185,10 @@ int main(int argc, char** argv) {
   }
   const auto t0 = std::chrono::steady_clock::now();
   long launches = 0;
+  if (lds == 2) {  // aggressor only: the victim is another process (the library's forward: tools/experiments/thread_race_probe.py 1 ...)
+    printf("aggressor %s alone for %.0f s\n", agg, secs); fflush(stdout);
+    std::this_thread::sleep_for(std::chrono::milliseconds((long)(secs * 1000)));
+  } else
   while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
     if (lds) hipLaunchKernelGGL(k_victim<true>, dim3(1024), dim3(256), 0, sv, 512, 4, d_bad, d_ref, 0);
     else hipLaunchKernelGGL(k_victim<false>, dim3(1024), dim3(256), 0, sv, 512, 4, d_bad, d_ref, 0);
@@ -142,6 +196,7 @@ int main(int argc, char** argv) {
     if (launches % 8 == 0) CK(hipStreamSynchronize(sv));
   }
   CK(hipStreamSynchronize(sv));
+  if (pulse) { pulse_stop.store(true); pulser.join(); }
   *stop = 1;
   CK(hipDeviceSynchronize());
   unsigned bad = 0;

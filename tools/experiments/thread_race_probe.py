@@ -78,7 +78,25 @@ OTHER = os.environ.get("PROBE_OTHER", "")  # "copy" / "matmul": every thread but
 stop = threading.Event()
 
 
+def agg_worker(tid):
+    """PROBE_OTHER=agg_bf16 | agg_f32 | agg_bf16lds: the stand-alone matrix-instruction load of tools/experiments/mfma_agg.hip (built to /tmp/libmfma_agg.so)
+    as short kernels in a loop on this thread's stream"""
+    import ctypes
+    lib = ctypes.CDLL(os.environ.get("PROBE_AGG_LIB", "/tmp/libmfma_agg.so"))
+    lib.agg_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    kind = {"agg_bf16": 0, "agg_f32": 1, "agg_bf16lds": 2, "agg_bf16hi": 3}[OTHER]
+    torch.cuda.set_device(0)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        while not stop.is_set():
+            for _ in range(4):
+                assert lib.agg_launch(kind, 24 if kind != 1 else 12, 2048, st.cuda_stream) == 0
+            st.synchronize()
+
+
 def other_worker(tid):
+    if OTHER.startswith("agg_"):
+        return agg_worker(tid)
     torch.cuda.set_device(0)
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
