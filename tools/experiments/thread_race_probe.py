@@ -78,6 +78,10 @@ OTHER = os.environ.get("PROBE_OTHER", "")  # "copy" / "matmul": every thread but
 stop = threading.Event()
 
 
+AGG_GRID = int(os.environ.get("PROBE_AGG_GRID", "2048"))   # workgroups of 4 waves per launch (256: one per CU)
+AGG_ITERS = int(os.environ.get("PROBE_AGG_ITERS", "24"))  # x 64 matrix instructions per wave and launch
+
+
 def agg_worker(tid):
     """PROBE_OTHER=agg_bf16 | agg_f32 | agg_bf16lds: the stand-alone matrix-instruction load of tools/experiments/mfma_agg.hip (built to /tmp/libmfma_agg.so)
     as short kernels in a loop on this thread's stream"""
@@ -90,7 +94,7 @@ def agg_worker(tid):
     with torch.cuda.stream(st):
         while not stop.is_set():
             for _ in range(4):
-                assert lib.agg_launch(kind, 24 if kind != 1 else 12, 2048, st.cuda_stream) == 0
+                assert lib.agg_launch(kind, AGG_ITERS if kind != 1 else AGG_ITERS // 2, AGG_GRID, st.cuda_stream) == 0
             st.synchronize()
 
 
