@@ -8,7 +8,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_agg(int iters, float* sink) {
-  __shared__ __attribute__((aligned(16))) unsigned s_img[KIND == 2 ? 16384 : 4];
+  __shared__ __attribute__((aligned(16))) unsigned s_img[KIND == 2 ? 16384 : (KIND == 4 ? 18688 : 4)];  // KIND 4: 73 KB (more than 64 KB per workgroup) + a barrier per round
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void k_agg(int iters, float* sink) {
     a[f] = __builtin_bit_cast(bf16x8, u32x4{w[0], w[1], w[2], w[3]});
     b[f] = __builtin_bit_cast(bf16x8, u32x4{w[4], w[5], w[6], w[7]});
   }
-  if (KIND == 2) {
+  if (KIND == 2 || KIND == 4) {
     for (int i = threadIdx.x; i < 16384; i += 256) { h ^= h << 13; h ^= h >> 17; h ^= h << 5; s_img[i] = (h & 0x807f807fu) | 0x3f003f00u; }
     __syncthreads();
   }
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_agg(int iters, float* sink) {
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 64; ++u) {
-      if (KIND == 2) {
+      if (KIND == 2 || KIND == 4) {
         const bf16x8 al = __builtin_bit_cast(bf16x8, reinterpret_cast<const u32x4*>(s_img)[(threadIdx.x + 67 * u + 131 * it) & 4095]);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[(u + 3) & 7], acc, 0, 0, 0);
       } else if (KIND == 0 || KIND == 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u & 7], b[(u + 3) & 7], acc, 0, 0, 0);
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void k_agg(int iters, float* sink) {
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] *= 0.001f;
+    if (KIND == 4) { s_img[16384 + (threadIdx.x + it) % 2304] = __float_as_uint(acc[it & 15]); __syncthreads(); }
     if (KIND == 3) {  // a 240-register wave that keeps writing its HIGH registers (and runs matrix instructions on them)
       asm volatile(
           "v_mov_b32 v200, %0\n\tv_mov_b32 v201, %0\n\tv_mov_b32 v202, %0\n\tv_mov_b32 v203, %0\n\tv_mov_b32 v204, %0\n\tv_mov_b32 v205, %0\n\tv_mov_b32 v206, %0\n\tv_mov_b32 v207, %0\n\t"
@@ -58,12 +59,143 @@ __global__ __launch_bounds__(256) void k_agg(int iters, float* sink) {
   if (acc[0] == 12345.678f) sink[0] = acc[1];
 }
 
+// KIND 5: the library's k_edge_x6 cut down to what still disturbed the fp32 kernels (profiles/r05_mfma_mix_hazard.log, ablation 463): constant rows split
+// into three bf16 parts, weight fragments read from never-written LDS, 4 slices x 48 dependent matrix instructions, one barrier per slice; the same
+// launch bounds, register budget and LDS footprint (73 232 bytes)
+__device__ __forceinline__ unsigned cvt2(float x0, float x1) {
+  typedef float f2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f2_{x0, x1}, b2_));
+}
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  h = cvt2(x0, x1);
+  const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+  m = cvt2(r0, r1);
+  l = cvt2(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cut_edge(int rounds, float* sink) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_wa[24576];
+  __shared__ __attribute__((aligned(16))) unsigned char s_wb[24576];
+  __shared__ __attribute__((aligned(16))) float s_e[128 * 36];
+  __shared__ __attribute__((aligned(16))) float s_cs[32 * 32];
+  __shared__ int s_src[128], s_dst[128];
+  __shared__ int s_seg[2][66];
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5;
+  if (tid < 128) { s_src[tid] = tid; s_dst[tid] = tid >> 3; }
+  if (tid < 66) { s_seg[0][tid] = tid; s_seg[1][tid] = tid; }
+  if (sink == (float*)1) { s_e[tid] = 1.f; s_cs[tid] = 1.f; }
+#if defined(CUT_FILL)  // the weight fragments: one class of bf16 bit patterns — 0: zeros, 1: +-denormals, 2: +-infinity, 3: NaN, 4: any 16-bit pattern, 5: huge normals (~1e38)
+  { unsigned h = 0x9e3779b9u * (tid + 1u);
+    for (int i = tid; i < 12288; i += 256) {
+      h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+      unsigned w = 0;
+      if (CUT_FILL == 1) w = h & 0x807f807fu;                      // exponent 0: denormals (and a few zeros)
+      else if (CUT_FILL == 2) w = (h & 0x80008000u) | 0x7f807f80u;  // infinities
+      else if (CUT_FILL == 3) w = (h & 0x807f807fu) | 0x7f817f81u;  // NaNs
+      else if (CUT_FILL == 4) w = h;
+      else if (CUT_FILL == 5) w = (h & 0x807f807fu) | 0x7f007f00u;  // ~1e38
+      reinterpret_cast<unsigned*>(s_wa)[i] = w; reinterpret_cast<unsigned*>(s_wb)[i] = w ^ 0x00010001u;
+    } }
+#endif
+#if defined(CUT_V) && (CUT_V & 1)  // the weight fragments: random NORMAL bf16 numbers instead of whatever the LDS held
+  { unsigned h = 0x9e3779b9u * (tid + 1u); for (int i = tid; i < 12288; i += 256) { h ^= h << 13; h ^= h >> 17; h ^= h << 5; const unsigned w = (h & 0x807f807fu) | 0x3f003f00u; reinterpret_cast<unsigned*>(s_wa)[i] = w; reinterpret_cast<unsigned*>(s_wb)[i] = w ^ 0x00010001u; } }
+#endif
+  bf16x8 zh[8], zm[8], zl[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const float v[8] = {0.3f + lane, 0.7f * s, 1.1f, -0.9f, 0.25f, -1.5f + hi, 0.125f * lane, 2.f};
+    unsigned ph[4], pm[4], pl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split2(v[2 * j], v[2 * j + 1], ph[j], pm[j], pl[j]);
+#if defined(CUT_V) && (CUT_V & 2)  // the row fragments: plain numbers in [0.5, 1) in all three parts (no tiny second / third parts)
+    for (int j = 0; j < 4; ++j) { pm[j] = (ph[j] & 0x807f807fu) | 0x3f003f00u; pl[j] = pm[j] ^ 0x00030003u; ph[j] = pm[j] ^ 0x00050005u; }
+#endif
+    zh[s] = __builtin_bit_cast(bf16x8, u32x4{ph[0], ph[1], ph[2], ph[3]});
+    zm[s] = __builtin_bit_cast(bf16x8, u32x4{pm[0], pm[1], pm[2], pm[3]});
+    zl[s] = __builtin_bit_cast(bf16x8, u32x4{pl[0], pl[1], pl[2], pl[3]});
+  }
+  __syncthreads();
+  float keep = 0.f;
+  for (int rd = 0; rd < rounds; ++rd) {
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+      const unsigned char* wb = ((ob & 1) ? s_wb : s_wa) + lane * 16;
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      bf16x8 A[2][3];
+#pragma unroll
+      for (int p3 = 0; p3 < 3; ++p3) A[0][p3] = *reinterpret_cast<const bf16x8*>(wb + p3 * 1024);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int c = s & 1;
+        if (s + 1 < 8) {
+#pragma unroll
+          for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8*>(wb + (3 * (s + 1) + p3) * 1024);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zm[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][2], zh[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zl[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zh[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zm[s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zh[s], acc, 0, 0, 0);
+      }
+      keep += acc[0] + acc[5] + acc[10] + acc[15];
+#if !(defined(CUT_V) && (CUT_V & 4))
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+    }
+  }
+  if (keep == 12345.678f) sink[0] = keep + s_e[tid] + s_cs[tid] + s_src[tid & 127] + s_dst[tid & 127] + s_seg[tid & 1][tid & 63];
+}
+
+// KIND 6 / 7: well-formed back-to-back bf16 matrix instructions written out with EXPLICIT registers — the accumulator in v[2:17] (6: the very
+// registers k_ffn_fused<64> accumulates in) or in v[130:145] (7), operands in v[18:25] / v[146:153]
+template <int LOW>
+__global__ __launch_bounds__(256) void k_regs(int iters, float* sink) {
+  for (int it = 0; it < iters; ++it) {
+    if (LOW) {
+      asm volatile(
+          "v_mov_b32 v18, %0\n\tv_mov_b32 v19, %0\n\tv_mov_b32 v20, %0\n\tv_mov_b32 v21, %0\n\tv_mov_b32 v22, %0\n\tv_mov_b32 v23, %0\n\tv_mov_b32 v24, %0\n\tv_mov_b32 v25, %0\n\t"
+          "v_mov_b32 v2, 0\n\tv_mov_b32 v3, 0\n\tv_mov_b32 v4, 0\n\tv_mov_b32 v5, 0\n\tv_mov_b32 v6, 0\n\tv_mov_b32 v7, 0\n\tv_mov_b32 v8, 0\n\tv_mov_b32 v9, 0\n\t"
+          "v_mov_b32 v10, 0\n\tv_mov_b32 v11, 0\n\tv_mov_b32 v12, 0\n\tv_mov_b32 v13, 0\n\tv_mov_b32 v14, 0\n\tv_mov_b32 v15, 0\n\tv_mov_b32 v16, 0\n\tv_mov_b32 v17, 0\n\t"
+          "s_nop 4\n\t"
+          "v_mfma_f32_32x32x16_bf16 v[2:17], v[18:21], v[22:25], v[2:17]\n\tv_mfma_f32_32x32x16_bf16 v[2:17], v[22:25], v[18:21], v[2:17]\n\t"
+          "v_mfma_f32_32x32x16_bf16 v[2:17], v[18:21], v[22:25], v[2:17]\n\tv_mfma_f32_32x32x16_bf16 v[2:17], v[22:25], v[18:21], v[2:17]\n\t"
+          "v_mfma_f32_32x32x16_bf16 v[2:17], v[18:21], v[22:25], v[2:17]\n\tv_mfma_f32_32x32x16_bf16 v[2:17], v[22:25], v[18:21], v[2:17]\n\t"
+          "v_mfma_f32_32x32x16_bf16 v[2:17], v[18:21], v[22:25], v[2:17]\n\tv_mfma_f32_32x32x16_bf16 v[2:17], v[22:25], v[18:21], v[2:17]\n\t"
+          "s_nop 15\n\ts_nop 15"
+          :: "v"(0x3f803f80u + (unsigned)it)
+          : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25");
+    } else {
+      asm volatile(
+          "v_mov_b32 v146, %0\n\tv_mov_b32 v147, %0\n\tv_mov_b32 v148, %0\n\tv_mov_b32 v149, %0\n\tv_mov_b32 v150, %0\n\tv_mov_b32 v151, %0\n\tv_mov_b32 v152, %0\n\tv_mov_b32 v153, %0\n\t"
+          "v_mov_b32 v130, 0\n\tv_mov_b32 v131, 0\n\tv_mov_b32 v132, 0\n\tv_mov_b32 v133, 0\n\tv_mov_b32 v134, 0\n\tv_mov_b32 v135, 0\n\tv_mov_b32 v136, 0\n\tv_mov_b32 v137, 0\n\t"
+          "v_mov_b32 v138, 0\n\tv_mov_b32 v139, 0\n\tv_mov_b32 v140, 0\n\tv_mov_b32 v141, 0\n\tv_mov_b32 v142, 0\n\tv_mov_b32 v143, 0\n\tv_mov_b32 v144, 0\n\tv_mov_b32 v145, 0\n\t"
+          "s_nop 4\n\t"
+          "v_mfma_f32_32x32x16_bf16 v[130:145], v[146:149], v[150:153], v[130:145]\n\tv_mfma_f32_32x32x16_bf16 v[130:145], v[150:153], v[146:149], v[130:145]\n\t"
+          "v_mfma_f32_32x32x16_bf16 v[130:145], v[146:149], v[150:153], v[130:145]\n\tv_mfma_f32_32x32x16_bf16 v[130:145], v[150:153], v[146:149], v[130:145]\n\t"
+          "v_mfma_f32_32x32x16_bf16 v[130:145], v[146:149], v[150:153], v[130:145]\n\tv_mfma_f32_32x32x16_bf16 v[130:145], v[150:153], v[146:149], v[130:145]\n\t"
+          "v_mfma_f32_32x32x16_bf16 v[130:145], v[146:149], v[150:153], v[130:145]\n\tv_mfma_f32_32x32x16_bf16 v[130:145], v[150:153], v[146:149], v[130:145]\n\t"
+          "s_nop 15\n\ts_nop 15"
+          :: "v"(0x3f803f80u + (unsigned)it)
+          : "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150",
+            "v151", "v152", "v153");
+    }
+  }
+  if (iters < 0) sink[0] = 1.f;
+}
+
 extern "C" int agg_launch(int kind, int iters, int grid, void* stream) {
   static float* sink = nullptr;
   if (!sink && hipMalloc(&sink, 64) != hipSuccess) return 1;
   hipStream_t s = (hipStream_t)stream;
   if (kind == 0) hipLaunchKernelGGL(k_agg<0>, dim3(grid), dim3(256), 0, s, iters, sink);
   else if (kind == 1) hipLaunchKernelGGL(k_agg<1>, dim3(grid), dim3(256), 0, s, iters, sink);
+  else if (kind == 6) hipLaunchKernelGGL(k_regs<1>, dim3(grid), dim3(256), 0, s, iters * 8, sink);
+  else if (kind == 7) hipLaunchKernelGGL(k_regs<0>, dim3(grid), dim3(256), 0, s, iters * 8, sink);
+  else if (kind == 5) hipLaunchKernelGGL(k_cut_edge, dim3(grid), dim3(256), 0, s, iters, sink);
+  else if (kind == 4) hipLaunchKernelGGL(k_agg<4>, dim3(grid), dim3(256), 0, s, iters, sink);
   else if (kind == 3) hipLaunchKernelGGL(k_agg<3>, dim3(grid), dim3(256), 0, s, iters, sink);
   else hipLaunchKernelGGL(k_agg<2>, dim3(grid), dim3(256), 0, s, iters, sink);
   return hipGetLastError() == hipSuccess ? 0 : 2;

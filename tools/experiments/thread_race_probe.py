@@ -88,7 +88,7 @@ def agg_worker(tid):
     import ctypes
     lib = ctypes.CDLL(os.environ.get("PROBE_AGG_LIB", "/tmp/libmfma_agg.so"))
     lib.agg_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-    kind = {"agg_bf16": 0, "agg_f32": 1, "agg_bf16lds": 2, "agg_bf16hi": 3}[OTHER]
+    kind = {"agg_bf16": 0, "agg_f32": 1, "agg_bf16lds": 2, "agg_bf16hi": 3, "agg_bf16lds73": 4, "agg_cut_edge": 5, "agg_acc_low": 6, "agg_acc_high": 7}[OTHER]
     torch.cuda.set_device(0)
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
