@@ -119,6 +119,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int rd = 0; rd < rounds; ++rd) {
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
+#if defined(CUT_V) && (CUT_V & 8)
+      {  // the next slice's 24 one-KB pieces by LDS-DMA (6 per wave), waited for at the slice's end as in k_edge_x6
+        unsigned char* nxt = (ob & 1) ? s_wa : s_wb;
+        const int wv = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int pc = wv + 4 * i;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const unsigned char*>(sink) + 4096 + (size_t)((ob + 1) & 3) * 24576 + pc * 1024 + lane * 16),
+                                           (__attribute__((address_space(3))) void*)(nxt + pc * 1024), 16, 0, 0);
+        }
+      }
+#endif
       const unsigned char* wb = ((ob & 1) ? s_wb : s_wa) + lane * 16;
       f32x16 acc;
 #pragma unroll
@@ -188,7 +200,15 @@ __global__ __launch_bounds__(256) void k_regs(int iters, float* sink) {
 
 extern "C" int agg_launch(int kind, int iters, int grid, void* stream) {
   static float* sink = nullptr;
-  if (!sink && hipMalloc(&sink, 64) != hipSuccess) return 1;
+  if (!sink) {
+    const size_t nb = 4096 + 4 * 24576;
+    if (hipMalloc(&sink, nb) != hipSuccess) return 1;
+    unsigned* h = new unsigned[nb / 4];
+    unsigned x = 12345u;
+    for (size_t i = 0; i < nb / 4; ++i) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; h[i] = (x & 0x807f807fu) | 0x3f003f00u; }
+    (void)hipMemcpy(sink, h, nb, hipMemcpyHostToDevice);
+    delete[] h;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (kind == 0) hipLaunchKernelGGL(k_agg<0>, dim3(grid), dim3(256), 0, s, iters, sink);
   else if (kind == 1) hipLaunchKernelGGL(k_agg<1>, dim3(grid), dim3(256), 0, s, iters, sink);

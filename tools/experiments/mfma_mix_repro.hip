@@ -30,10 +30,27 @@ __device__ __host__ inline float b_of(int k, int n) { return hashf(0x40000000u +
 #endif
 
 // ref: [32 rows][32 cols] of the wave's result (every wave computes the same product); write_ref: store it (the run without an aggressor), else compare bitwise
+// VICT bits (compile time) add features of the library's victims: 1 = workgroup barriers around every 16 matrix instructions (k_ffn_fused's step loop);
+// 2 = a global load in flight under every group of matrix instructions (its register prefetch of the next chunk); 4 = amdgpu_waves_per_eu(4);
+// 8 = 512-thread workgroups
+#ifndef VICT
+#define VICT 0
+#endif
+#if VICT & 8
+#define VTHREADS 512
+#else
+#define VTHREADS 256
+#endif
+#if VICT & 4
+#define VATTR __attribute__((amdgpu_waves_per_eu(4)))
+#else
+#define VATTR
+#endif
 template <bool LDS>
-__global__ __launch_bounds__(256) void k_victim(int K, int reps, unsigned* bad, float* ref, int write_ref) {
-  __shared__ float sA[4][32 * 33];
-  __shared__ float sB[4][32 * 32];
+__global__ __launch_bounds__(VTHREADS) VATTR void k_victim(int K, int reps, unsigned* bad, float* ref, int write_ref) {
+  __shared__ float sA[VTHREADS / 64][32 * 33];
+  __shared__ float sB[VTHREADS / 64][32 * 32];
+  float pre = 0.f;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, hi = lane >> 5;
   unsigned wrong = 0;
   for (int rep = 0; rep < reps; ++rep) {
@@ -46,6 +63,30 @@ __global__ __launch_bounds__(256) void k_victim(int K, int reps, unsigned* bad, 
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
+#if VICT & 2
+      const float pf = ref[(k0 + lane) & 1023];  // (in flight under the matrix instructions below; consumed behind them)
+#endif
+#if VICT & 1
+      __syncthreads();
+#endif
+#if VICT & 16
+      {  // k_ffn_fused's inner loop: the fragments of k-step kk + 1 requested from LDS in front of the matrix instruction of step kk (pinned): their
+         // data arrive in the registers WHILE that instruction runs
+        float fa1[2], fb1[2];
+        fb1[0] = sB[wv][hi * 32 + l31];
+        fa1[0] = sA[wv][l31 * 33 + hi];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const int c = kk & 1, n2 = c ^ 1;
+          if (kk + 1 < 16) {
+            fb1[n2] = sB[wv][(2 * (kk + 1) + hi) * 32 + l31];
+            fa1[n2] = sA[wv][l31 * 33 + 2 * (kk + 1) + hi];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[c], fb1[c], acc, 0, 0, 0);
+        }
+      }
+#else
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
         float fa, fb;
@@ -53,7 +94,14 @@ __global__ __launch_bounds__(256) void k_victim(int K, int reps, unsigned* bad, 
         else { fa = a_of(l31, k0 + 2 * kk + hi); fb = b_of(k0 + 2 * kk + hi, l31); }
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc, 0, 0, 0);
       }
+#endif
       if (LDS) __builtin_amdgcn_wave_barrier();
+#if VICT & 2
+      pre += pf;
+#endif
+#if VICT & 1
+      __syncthreads();
+#endif
     }
     // check: lane (col l31, hi), register q <-> row (q & 3) + 8 (q >> 2) + 4 hi
 #pragma unroll
@@ -64,6 +112,7 @@ __global__ __launch_bounds__(256) void k_victim(int K, int reps, unsigned* bad, 
     }
   }
   if (wrong) atomicAdd(bad, wrong);
+  if (pre == 12345.678f) atomicAdd(bad, 1u);
 }
 
 template <bool BF16>
@@ -144,6 +193,16 @@ __global__ __launch_bounds__(256) void k_pulse(int iters, float* sink) {
   if (acc[0] == 12345.678f) sink[0] = acc[1];
 }
 
+// aggressor "cut": tools/experiments/mfma_agg.hip's k_cut_edge — the one stand-alone kernel that makes the library's fp32 kernels wrong (an ill-formed
+// matrix instruction: undefined source on its destination) — launched in a loop by a host thread
+#define agg_launch agg_launch_unused
+#define f32x16 f32x16_agg
+#define bf16x8 bf16x8_agg
+#include "mfma_agg.hip"
+#undef f32x16
+#undef bf16x8
+#undef agg_launch
+
 int main(int argc, char** argv) {
   const int lds = argc > 1 ? atoi(argv[1]) : 1;
   const char* agg = argc > 2 ? argv[2] : "bf16";
@@ -157,18 +216,20 @@ int main(int argc, char** argv) {
   int* d_stop; CK(hipHostGetDevicePointer((void**)&d_stop, stop, 0));
   float* d_ref; CK(hipMalloc(&d_ref, 32 * 32 * 4));
   // the reference: the victim alone
-  if (lds) hipLaunchKernelGGL(k_victim<true>, dim3(1), dim3(256), 0, sv, 512, 1, d_bad, d_ref, 1);
-  else hipLaunchKernelGGL(k_victim<false>, dim3(1), dim3(256), 0, sv, 512, 1, d_bad, d_ref, 1);
+  if (lds) hipLaunchKernelGGL(k_victim<true>, dim3(1), dim3(VTHREADS), 0, sv, 512, 1, d_bad, d_ref, 1);
+  else hipLaunchKernelGGL(k_victim<false>, dim3(1), dim3(VTHREADS), 0, sv, 512, 1, d_bad, d_ref, 1);
   CK(hipStreamSynchronize(sv));
   std::atomic<bool> pulse_stop{false};
   std::thread pulser;
-  const bool pulse = !strncmp(agg, "pulse", 5);
+  const bool cut = !strcmp(agg, "cut");
+  const bool pulse = !strncmp(agg, "pulse", 5) || cut;
   if (pulse) {
     const bool bf = strstr(agg, "f32") == nullptr;
     pulser = std::thread([&, bf] {
       CK(hipSetDevice(0));
       long n = 0;
       while (!pulse_stop.load()) {
+        if (cut) { hipLaunchKernelGGL(k_cut_edge, dim3(114), dim3(256), 0, sa, 20, d_sink); if ((++n & 3) == 0) (void)hipStreamSynchronize(sa); continue; }
         // ~20-40 us of dense matrix work on every SIMD (2048 workgroups x 4 waves), then a gap of the same order
         if (bf) hipLaunchKernelGGL(k_pulse<true>, dim3(2048), dim3(256), 0, sa, 24, d_sink);
         else hipLaunchKernelGGL(k_pulse<false>, dim3(2048), dim3(256), 0, sa, 12, d_sink);
@@ -190,8 +251,8 @@ int main(int argc, char** argv) {
     std::this_thread::sleep_for(std::chrono::milliseconds((long)(secs * 1000)));
   } else
   while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
-    if (lds) hipLaunchKernelGGL(k_victim<true>, dim3(1024), dim3(256), 0, sv, 512, 4, d_bad, d_ref, 0);
-    else hipLaunchKernelGGL(k_victim<false>, dim3(1024), dim3(256), 0, sv, 512, 4, d_bad, d_ref, 0);
+    if (lds) hipLaunchKernelGGL(k_victim<true>, dim3(1024), dim3(VTHREADS), 0, sv, 512, 4, d_bad, d_ref, 0);
+    else hipLaunchKernelGGL(k_victim<false>, dim3(1024), dim3(VTHREADS), 0, sv, 512, 4, d_bad, d_ref, 0);
     ++launches;
     if (launches % 8 == 0) CK(hipStreamSynchronize(sv));
   }
