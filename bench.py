@@ -696,6 +696,8 @@ def bench_weights(gn, din, dout, dev):
     blk.edgefn = gn.Dense.from_numpy(glorot(rng, oe, de + 2 * dn + dg), np.zeros(oe, np.float32), device=dev)
     blk.nodefn = gn.Dense.from_numpy(glorot(rng, on, oe + dn + dg), np.zeros(on, np.float32), device=dev)
     blk.graphfn = gn.Dense.from_numpy(glorot(rng, og, oe + on + dg), np.zeros(og, np.float32), device=dev)
+    if max(din + dout) > 32:
+        blk.prepare()  # gnx_block_prepare: the matrix-core kernels' weight planes made ONCE, as `model |> device` happens once (examples/sort/sort.jl:29,89)
     return blk
 
 

@@ -87,6 +87,10 @@ class CoreParams(C.Structure):
                 ("eps", C.c_float), ("eps_mode", C.c_int32), ("prepared", C.c_void_p)]
 
 
+class Dropout(C.Structure):  # gnx_dropout
+    _fields_ = [("p", C.c_float), ("reserved", C.c_uint32), ("seed", C.c_uint64)]
+
+
 class Layer(C.Structure):
     _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("params", C.c_void_p)]
 
@@ -139,6 +143,11 @@ SIGNATURES = {
     "gnx_core_backward": (C.c_int32, [C.c_void_p, C.c_void_p] + [_fp] * 6 + [C.c_int64] + [_fp] * 3 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnx_core_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(CoreParams), C.c_int64]),
     "gnx_core_forward": (C.c_int32, [C.c_void_p, C.POINTER(CoreParams)] + _FWD[2:]),
+    "gnx_dropout_mask": (C.c_int32, [C.POINTER(Dropout), C.c_int32, C.c_int64, _fp, C.c_void_p]),
+    "gnx_core_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(CoreParams), C.c_int64]),
+    "gnx_core_forward_train": (C.c_int32, [C.c_void_p, C.POINTER(CoreParams), C.POINTER(Dropout)] + _FWD[2:]),
+    "gnx_core_backward_train": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(Dropout)] + [_fp] * 6 + [C.c_int64] + [_fp] * 3 +
+                                [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnx_fn_input": (C.c_int32, [C.c_void_p, C.c_int32, _fp, C.c_int32, _fp, C.c_int32, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),
     "gnx_collapse_offsets": (C.c_int32, [C.c_void_p, _i64p]),
     "gnx_collapse_edges": (C.c_int32, [C.c_void_p, _fp, C.c_int32, C.c_int64, _fp, C.c_void_p]),

@@ -654,14 +654,48 @@ class Dense:
                           _lib.ACT[self.act], 0)
 
 
+class Dropout:
+    """Flux `Dropout(p)` as a layer value: what ends a FeedForward chain (gnfeedforward.jl:27-31) and what `GNBlock` keeps in its `dropout`
+    field without applying it (gnblock.jl:59, :63-69).  Inside a `Chain` it is the identity in test mode."""
+
+    def __init__(self, p=0.0):
+        assert 0 <= p <= 1, "Dropout: p must lie in [0, 1]"
+        self.p = float(p)
+
+
+_ACT_CALLABLES = {torch.relu: "relu", torch.tanh: "tanh", torch.sigmoid: "sigmoid", torch.nn.functional.relu: "relu"}  # (gelu by name: NNlib's tanh form, not torch's default)
+
+
 class Chain:
-    """Flux `Chain(layers...)` of `Dense` layers — a GNBlock's update functions may be any such chain (gnblock.jl:1-6):
-    `blk.edgefn = Chain(Dense(20, 64, "relu"), Dense(64, 3))`.  (A one-layer chain is the constructor's default, gnblock.jl:55-60.)"""
+    """Flux `Chain(layers...)` — a GNBlock's update functions may be any chain (gnblock.jl:1-6): `blk.edgefn = Chain(Dense(20, 64, "relu"),
+    Dense(64, 3))`.  (A one-layer chain is the constructor's default, gnblock.jl:55-60.)  The HIP path runs row-wise `Dense` layers
+    (gnx_chain_block_forward); the other layer values a Flux user writes between them are folded on the host where that is exact:
+      * an activation function as a layer (`"relu"`, `torch.tanh`, ... — Flux: `Chain(Dense(a => b), relu)`) becomes the activation of the `Dense`
+        in front of it when that one has none — `relu.(W x .+ b)` either way;
+      * `"identity"` / `None` is dropped;
+      * `Dropout(p)` is the identity in test mode and dropped; a differentiable call of a block whose chains hold a Dropout with p > 0 is refused
+        (the training-mode Dropout of this library is the FeedForward's: GNCore(dims; dropout)).
+    Anything else (LayerNorm, BatchNorm, SkipConnection, closures) raises NotImplementedError: wrap such layers outside the block."""
 
     def __init__(self, *layers):
-        self.layers = list(layers[0]) if len(layers) == 1 and isinstance(layers[0], (list, tuple)) else list(layers)
-        for l in self.layers:  # gnblock.jl:1-6 admits any Flux chain; the HIP path has row-wise Dense layers only
-            if not isinstance(l, Dense):
+        given = list(layers[0]) if len(layers) == 1 and isinstance(layers[0], (list, tuple)) else list(layers)
+        self.layers, self.dropout_p = [], 0.0
+        for l in given:
+            if isinstance(l, Dense):
+                self.layers.append(l)
+            elif l is None or l == "identity":
+                continue
+            elif isinstance(l, Dropout):
+                self.dropout_p = max(self.dropout_p, l.p)
+            elif (isinstance(l, str) and l in _lib.ACT) or (callable(l) and l in _ACT_CALLABLES):
+                name = l if isinstance(l, str) else _ACT_CALLABLES[l]
+                if not self.layers or self.layers[-1].act != "identity":
+                    raise NotImplementedError(f"Chain: the activation layer {name!r} does not follow a Dense without activation — only that form folds into "
+                                              "the row-wise Dense launches (gnx_chain_block_forward)")
+                d = Dense.__new__(Dense)  # the same weight / bias tensors, with the activation
+                d.weight, d.bias, d.act = self.layers[-1].weight, self.layers[-1].bias, name
+                self.layers[-1] = d
+            else:  # gnblock.jl:1-6 admits any Flux chain; the HIP path has row-wise Dense layers only
                 raise NotImplementedError(f"Chain: layer of type {type(l).__name__} is not supported — the update functions of a GNBlock "
                                           "run as chains of Dense layers (gnx_chain_block_forward); wrap other layers outside the block")
 
@@ -832,6 +866,9 @@ class GNBlock:
         chains = [self._as_chain(f) for f in (self.edgefn, self.nodefn, self.graphfn)]
         params = [t for ch in chains for l in ch.layers for t in (l.weight, l.bias)]
         if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in [ef, nf, gf] + params):
+            if any(ch.dropout_p > 0 for ch in chains):
+                raise NotImplementedError("GNBlock: a Dropout(p > 0) inside an update-function Chain is the identity in test mode only; a differentiable "
+                                          "call would train another model — use GNCore(dims; dropout = p) for the FeedForward's Dropout")
             outs = iter(_ChainBlockFn.apply(self, g, R, flags, ef, nf, gf, *params))
             eo, no, go = (next(outs) if ch.out_width > 0 else None for ch in chains)
         else:
@@ -840,6 +877,8 @@ class GNBlock:
 
     def __call__(self, x, flags=None):
         if any(isinstance(f, Chain) and len(f) != 1 for f in (self.edgefn, self.nodefn, self.graphfn)):
+            return self._call_chains(x, flags)
+        if any(isinstance(f, Chain) and f.dropout_p > 0 for f in (self.edgefn, self.nodefn, self.graphfn)):
             return self._call_chains(x, flags)
         if any(isinstance(f, Chain) for f in (self.edgefn, self.nodefn, self.graphfn)):  # one-layer chains are plain Dense layers
             self.edgefn, self.nodefn, self.graphfn = (f.layers[0] if isinstance(f, Chain) else f for f in (self.edgefn, self.nodefn, self.graphfn))
@@ -998,7 +1037,9 @@ class GNGraphNorm:
 
 class GNCore:
     """`GNCore(dims; dropout=0)` (gncore.jl:46-54): `core(x) = x + block(gn1(x)) + ffwd(gn2(x))` (gncore.jl:56-59)
-    via gnx_core_forward.  Inference semantics: Dropout is the identity (Flux test mode).
+    via gnx_core_forward.  `dropout = p`: the Dropout(p) ending each FeedForward (gnfeedforward.jl:27-31) is active inside a gradient call
+    (gnx_core_forward_train / gnx_core_backward_train, a fresh seed per call) and the identity otherwise — Flux's automatic mode;
+    `testmode(core)` / `trainmode(core)` force it as `Flux.testmode!` / `trainmode!` do.
     `eps_mode` 0 = Flux 0.14 `normalise` (x-μ)/(σ+ε); 1 = (x-μ)/sqrt(σ²+ε)."""
 
     def __init__(self, dims, dropout=0, device=None, generator=None, eps=1e-5, eps_mode=0):
@@ -1061,48 +1102,92 @@ class GNCore:
     def _training(self, extra=()):
         return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in list(extra) + self._param_list())
 
+    def _dropout_now(self, grad_call):
+        """The Dropout(p) that ends every FeedForward chain (gnfeedforward.jl:27-31) for THIS call: None (identity) or a `_lib.Dropout` with a
+        fresh seed.  Flux's rule: active inside a gradient call, identity otherwise, unless `testmode` / `trainmode` forced it."""
+        p = float(self.ffwd.dropout or 0)
+        forced = getattr(self, "_dropout_mode", None)
+        if p <= 0 or not (grad_call if forced is None else forced):
+            return None
+        assert p <= 1, "Dropout: p must lie in [0, 1]"
+        seed = int(torch.randint(0, 2 ** 63 - 1, (1,), dtype=torch.int64, generator=getattr(self, "rng", None)).item())  # torch.manual_seed reproduces it
+        self.last_dropout = _lib.Dropout(p, 0, seed)  # (tests / debugging: `dropout_mask` turns it into the masks of the call)
+        return self.last_dropout
+
     def __call__(self, x, flags=None):
         # gnfeedforward.jl:27-31: the FeedForward ends in Dropout(p), which Flux applies in training mode (inside a gradient call)
-        # and skips in test mode.  The HIP FeedForward has no dropout: inference (no gradient) is the identity, as in Flux test mode;
-        # a differentiable call with p > 0 would silently train a different model, so it is refused.
-        if self.ffwd.dropout and self.ffwd.dropout > 0 and self._training():
-            raise NotImplementedError(f"GNCore: Dropout(p={self.ffwd.dropout}) in training mode is not implemented (gnfeedforward.jl:27-31); "
-                                      "use dropout=0, or call under torch.no_grad() for Flux's test-mode semantics")
+        # and skips in test mode: gnx_core_forward_train / gnx_core_backward_train with a per-call seed, gnx_core_forward otherwise.
         x = _as_nt(x)
         assert x.ef is not None and x.nf is not None and x.gf is not None, "GNCore needs ef, nf and gf (gncore.jl:61-68)"
         g, ef, nf, gf, R = _forward_common(x, self.dims)
         plist = self._param_list()
-        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in [ef, nf, gf] + plist):
-            eo, no, go = _CoreFn.apply(self, g, R, self.flags if flags is None else flags, ef, nf, gf, *plist)
+        grad_call = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in [ef, nf, gf] + plist)
+        drop = self._dropout_now(grad_call)
+        if grad_call:
+            eo, no, go = _CoreFn.apply(self, g, R, self.flags if flags is None else flags, drop, ef, nf, gf, *plist)
             return NT(g, _jl(eo), _jl(no), _jl(go))
-        lib = _lib.load()
-        keep = []
-        p = self._c(keep)
-        dev = g.device
-        eo, no, go = torch.empty_like(ef), torch.empty_like(nf), torch.empty_like(gf)
-        with torch.cuda.device(dev):
-            ws = g.workspace(lib.gnx_core_workspace_bytes(g._h, C.byref(p), R), ("core", self.dims, R))
-            check(lib.gnx_core_forward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), R, eo.data_ptr(),
-                                       no.data_ptr(), go.data_ptr(), ws.data_ptr(), ws.numel(),
-                                       (self.flags if flags is None else flags), torch.cuda.current_stream(dev).cuda_stream))
+        eo, no, go = _core_forward(self, g, R, self.flags if flags is None else flags, drop, ef, nf, gf)
         return NT(g, _jl(eo), _jl(no), _jl(go))
+
+
+def _core_forward(core, g, R, flags, drop, ef, nf, gf):
+    """gnx_core_forward, or gnx_core_forward_train when a Dropout is active for the call."""
+    lib = _lib.load()
+    keep = []
+    p = core._c(keep)
+    dev = g.device
+    eo, no, go = torch.empty_like(ef), torch.empty_like(nf), torch.empty_like(gf)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if drop is None:
+            ws = g.workspace(lib.gnx_core_workspace_bytes(g._h, C.byref(p), R), ("core", core.dims, R))
+            check(lib.gnx_core_forward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), R, eo.data_ptr(), no.data_ptr(),
+                                       go.data_ptr(), ws.data_ptr(), ws.numel(), flags, stream))
+        else:
+            nb = lib.gnx_core_train_workspace_bytes(g._h, C.byref(p), R)
+            if nb == 0:
+                raise GnxError(_lib.ERR_DIMS, lib.gnx_last_error().decode("utf-8", "replace"))
+            ws = g.workspace(nb, ("core_train", core.dims, R))
+            check(lib.gnx_core_forward_train(g._h, C.byref(p), C.byref(drop), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), R, eo.data_ptr(),
+                                             no.data_ptr(), go.data_ptr(), ws.data_ptr(), ws.numel(), flags, stream))
+    return eo, no, go
+
+
+def dropout_mask(drop, entity, shape, device=None):
+    """The mask `gnx_core_forward_train` applied to entity 0 / 1 / 2 (edges / nodes / graphs) of a call whose Dropout was `drop`
+    (`core.last_dropout`): a (D, T, R) array of 0 and 1 / (1 - p), the layout of the features (gnx_dropout_mask)."""
+    dev = _device(device)
+    d, T, R = (int(v) for v in shape)
+    out = torch.empty((R, T, d), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().gnx_dropout_mask(C.byref(drop), int(entity), out.numel(), out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+    return _jl(out)
+
+
+def testmode(m, mode=True):
+    """`Flux.testmode!(m, mode)`: True = Dropout is the identity whatever the call; False = always active; None = automatic (active inside a
+    gradient call).  Applies to a GNCore, a GNCoreList or any iterable of layers; returns m."""
+    forced = None if mode is None else (not mode)
+    for l in (m.list if isinstance(m, GNCoreList) else (m if isinstance(m, (list, tuple)) else [m])):
+        if isinstance(l, GNCore):
+            l._dropout_mode = forced
+        elif isinstance(l, (GNCoreList, list, tuple)):
+            testmode(l, mode)
+    return m
+
+
+def trainmode(m, mode=True):
+    """`Flux.trainmode!(m, mode)` = testmode!(m, !mode)."""
+    return testmode(m, None if mode is None else (not mode))
 
 
 class _CoreFn(torch.autograd.Function):
     """torch autograd node of one GNCore call: forward = gnx_core_forward, backward = gnx_core_backward."""
 
     @staticmethod
-    def forward(ctx, core, g, R, flags, ef, nf, gf, *params):
-        lib = _lib.load()
-        keep = []
-        p = core._c(keep)
-        dev = g.device
-        eo, no, go = torch.empty_like(ef), torch.empty_like(nf), torch.empty_like(gf)
-        with torch.cuda.device(dev):
-            ws = g.workspace(lib.gnx_core_workspace_bytes(g._h, C.byref(p), R), ("core", core.dims, R))
-            check(lib.gnx_core_forward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), R, eo.data_ptr(), no.data_ptr(),
-                                       go.data_ptr(), ws.data_ptr(), ws.numel(), flags, torch.cuda.current_stream(dev).cuda_stream))
-        ctx.core, ctx.g, ctx.R = core, g, R
+    def forward(ctx, core, g, R, flags, drop, ef, nf, gf, *params):
+        eo, no, go = _core_forward(core, g, R, flags, drop, ef, nf, gf)
+        ctx.core, ctx.g, ctx.R, ctx.drop = core, g, R, drop
         ctx.save_for_backward(ef, nf, gf)
         return eo, no, go
 
@@ -1133,10 +1218,15 @@ class _CoreFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             nb = lib.gnx_core_backward_workspace_bytes(g._h, C.byref(p), R)
             ws = torch.empty(max(int(nb), 256), dtype=torch.uint8, device=dev)
-            check(lib.gnx_core_backward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), _ptr(ge), _ptr(gn_), _ptr(gg), R,
-                                        d_ef.data_ptr(), d_nf.data_ptr(), d_gf.data_ptr(), C.byref(gr), ws.data_ptr(), ws.numel(),
-                                        torch.cuda.current_stream(dev).cuda_stream))
-        return (None, None, None, None, d_ef, d_nf, d_gf, *out)
+            if ctx.drop is None:
+                check(lib.gnx_core_backward(g._h, C.byref(p), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), _ptr(ge), _ptr(gn_), _ptr(gg), R,
+                                            d_ef.data_ptr(), d_nf.data_ptr(), d_gf.data_ptr(), C.byref(gr), ws.data_ptr(), ws.numel(),
+                                            torch.cuda.current_stream(dev).cuda_stream))
+            else:  # the forward's masks, regenerated from the call's seed
+                check(lib.gnx_core_backward_train(g._h, C.byref(p), C.byref(ctx.drop), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), _ptr(ge), _ptr(gn_),
+                                                  _ptr(gg), R, d_ef.data_ptr(), d_nf.data_ptr(), d_gf.data_ptr(), C.byref(gr), ws.data_ptr(), ws.numel(),
+                                                  torch.cuda.current_stream(dev).cuda_stream))
+        return (None, None, None, None, None, d_ef, d_nf, d_gf, *out)
 
 
 class GNCoreList:

@@ -36,6 +36,11 @@ int32_t add_cols(const float* in, int ld, int off, size_t rows, int d, float* ou
 int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K, const gnx_dense& d, int OUT, const float* add1,
                           const float* add2, float* out, int64_t R, hipStream_t s, const char* name);
 
+// csrc/gnx_dropout.hip
+bool dropout_active(const gnx_dropout* d);
+int32_t check_dropout(const gnx_dropout* d);
+int32_t launch_dropout(const gnx_dropout& d, int entity, size_t n, const float* in, float* out, int mode, hipStream_t s);
+
 int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, const float* nf, int dn, const float* gf, int dg,
                         int64_t R, float* out, hipStream_t s);
 
@@ -776,9 +781,14 @@ size_t gnx_core_backward_workspace_bytes(const gnx_graphs* h, const gnx_core_par
   return core_bw_layout(h, p, R).total;
 }
 
-int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf, const float* gf,
-                          const float* g_ef_out, const float* g_nf_out, const float* g_gf_out, int64_t R, float* d_ef, float* d_nf,
-                          float* d_gf, const gnx_core_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+}  // extern "C"
+
+// `dr` (gnx_core_backward_train): the FeedForwards' outputs were multiplied by the Dropout masks of *dr in the forward
+// (gnx_core_forward_train, csrc/gnx_dropout.hip), so the upstream gradient of every FeedForward branch is g_out .* mask — the mask
+// regenerated from (seed, entity, element); the block branch and the residual see g_out as it is.
+static int32_t core_backward_impl(const gnx_graphs* h, const gnx_core_params* p, const gnx_dropout* dr, const float* ef, const float* nf, const float* gf,
+                                  const float* g_ef_out, const float* g_nf_out, const float* g_gf_out, int64_t R, float* d_ef, float* d_nf,
+                                  float* d_gf, const gnx_core_grads* grads, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
   const gnx_block_params& b = p->block;
@@ -825,6 +835,11 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
       continue;
     }
     float* hbuf = F(L.h); float* dh = F(L.dh);
+    const float* gff = gout[t];  // upstream of the FeedForward branch
+    if (dropout_active(dr)) {
+      if ((rc = launch_dropout(*dr, t, rows[t] * (size_t)D, gout[t], F(L.t1), 1, s))) return rc;  // (t1 is free until step 4)
+      gff = F(L.t1);
+    }
     // gelu is not a function of its output: hbuf first holds the PRE-activation z1 = W1 z + b1, delta1 = dh .* gelu'(z1) is formed from
     // it (act code 4 of the delta kernel = "out holds z"), then hbuf becomes h = gelu(z1) in place for dW2
     const int act1 = p->ff[t].fc1.act;
@@ -840,15 +855,15 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
     if (bw_use_mfma(rows[t], D, H)) {  // matrix cores (gnx_backward_wide.hip); rows[t] = R * (rows of entity t)
       float* wt = F(L.wt);
       if ((rc = launch_dense_rows(h, t, F(L.l2[t]), D, fc1_re, H, nullptr, nullptr, hbuf, R, s, "bw_ff1_recompute"))) return rc;
-      if (!gelu1 && (rc = dw_auto(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, off2, s))) return rc;           // dW2 = h^T g, db2
+      if (!gelu1 && (rc = dw_auto(gff, hbuf, rows[t], D, H, gr.ff[t].fc2, part, off2, s))) return rc;           // dW2 = h^T g, db2
       // delta1 = (g W2^T) .* act1'(h) in the GEMM epilogue, with per-tile column sums of delta1 for db1
       int n_tiles = 0;
       const bool dw1_mfma = bw_use_mfma_dw(rows[t], H, D);
       float* tcs = gr.ff[t].fc1.bias && dw1_mfma && !gelu1 ? F(L.tcs) : nullptr;
-      if ((rc = dx_mfma(h, t, gout[t], p->ff[t].fc2.weight, D, H, 0, H, dh, R, wt, true, s, "bw_dx_ff2", gelu1 ? nullptr : hbuf, act1, tcs, &n_tiles))) return rc;
+      if ((rc = dx_mfma(h, t, gff, p->ff[t].fc2.weight, D, H, 0, H, dh, R, wt, true, s, "bw_dx_ff2", gelu1 ? nullptr : hbuf, act1, tcs, &n_tiles))) return rc;
       if (gelu1) {
         gelu_delta_then_hidden();
-        if ((rc = dw_auto(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, off2, s))) return rc;
+        if ((rc = dw_auto(gff, hbuf, rows[t], D, H, gr.ff[t].fc2, part, off2, s))) return rc;
       }
       if (dw1_mfma) rc = dw_mfma(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1.weight, part, s);                   // dW1 = z^T delta1
       else rc = dw_reduce(dh, F(L.l2[t]), rows[t], H, D, gr.ff[t].fc1, part, s);                                   // (+ db1)
@@ -866,11 +881,11 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
     }
     { ProfScope ps("bw_fw_dense_generic", s);
     GNX_LAUNCH(k_fw_dense, blocks(rows[t] * H), dim3(256), 0, s, F(L.l2[t]), p->ff[t].fc1.weight, p->ff[t].fc1.bias, rows[t], D, H, fc1_re.act, hbuf); }
-    if (!gelu1 && (rc = dw_reduce(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, s))) return rc;             // dW2 = g^T h
-    launch_bw_dx(dim3(blocks(rows[t] * H).x, 1), s, gout[t], p->ff[t].fc2.weight, (int)rows[t], D, H, dh, 0, 0, (float*)nullptr, 0);
+    if (!gelu1 && (rc = dw_reduce(gff, hbuf, rows[t], D, H, gr.ff[t].fc2, part, s))) return rc;             // dW2 = g^T h
+    launch_bw_dx(dim3(blocks(rows[t] * H).x, 1), s, gff, p->ff[t].fc2.weight, (int)rows[t], D, H, dh, 0, 0, (float*)nullptr, 0);
     if (gelu1) {
       gelu_delta_then_hidden();
-      if ((rc = dw_reduce(gout[t], hbuf, rows[t], D, H, gr.ff[t].fc2, part, s))) return rc;
+      if ((rc = dw_reduce(gff, hbuf, rows[t], D, H, gr.ff[t].fc2, part, s))) return rc;
     } else {
       DeltaArgs a{dh, hbuf, dh, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, H, (int)rows[t], 1, act1, 0};  // delta1 = dh * act1'(h), in place
       GNX_LAUNCH(k_bw_delta, dim3(blocks(rows[t] * H).x, 1), dim3(256), 0, s, a, (size_t)0, (size_t)0);
@@ -920,6 +935,18 @@ int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const f
   return GNX_OK;
 }
 
+extern "C" {
+int32_t gnx_core_backward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf, const float* gf,
+                          const float* g_ef_out, const float* g_nf_out, const float* g_gf_out, int64_t R, float* d_ef, float* d_nf,
+                          float* d_gf, const gnx_core_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+  return core_backward_impl(h, p, nullptr, ef, nf, gf, g_ef_out, g_nf_out, g_gf_out, R, d_ef, d_nf, d_gf, grads, ws, ws_bytes, stream);
+}
+int32_t gnx_core_backward_train(const gnx_graphs* h, const gnx_core_params* p, const gnx_dropout* dropout, const float* ef, const float* nf,
+                                const float* gf, const float* g_ef_out, const float* g_nf_out, const float* g_gf_out, int64_t R, float* d_ef,
+                                float* d_nf, float* d_gf, const gnx_core_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+  if (int32_t rc = check_dropout(dropout)) return rc;
+  return core_backward_impl(h, p, dropout, ef, nf, gf, g_ef_out, g_nf_out, g_gf_out, R, d_ef, d_nf, d_gf, grads, ws, ws_bytes, stream);
+}
 }  // extern "C"
 
 // ---- GNBlock with Chain update functions: backward ----

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GNX_VERSION 110 /* 0.1.1: gnx_profile_entry is 72 bytes (`kernels`); per-call arithmetic flags; prepared parameters; GNX_FLAG_DIST_NO_GATHER */
+#define GNX_VERSION 120 /* 0.1.2: training-mode Dropout (gnx_dropout, gnx_core_forward_train / _backward_train); 110: gnx_profile_entry is 72 bytes, per-call arithmetic flags, prepared parameters, GNX_FLAG_DIST_NO_GATHER */
 
 #if defined(__GNUC__)
 #define GNX_API __attribute__((visibility("default")))
@@ -382,6 +382,31 @@ GNX_API size_t gnx_core_workspace_bytes(const gnx_graphs* h, const gnx_core_para
 GNX_API int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const float* ef, const float* nf,
                          const float* gf, int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out,
                          void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+
+/* ---- GNCore in TRAINING mode: the Dropout(p) that ends each FeedForward chain (src/gnfeedforward.jl:27-31), applied by Flux inside a
+ * gradient call and skipped in test mode (= gnx_core_forward).  y = x + block(gn1(x)) + m .* ffwd(gn2(x)) with m = u > p ? 1/(1-p) : 0,
+ * u uniform on [0,1), independent per element (Flux._dropout_kernel).  (GNBlock's own `dropout` field is never applied by its forward:
+ * src/gnblock.jl:63-69.)  The masks are never stored: element i of entity t (0 edges, 1 nodes, 2 graphs; i counts the packed
+ * [R][rows][width] floats) is a pure function of (seed, t, i) — Philox-4x32-10 — so the backward regenerates the forward's masks from the
+ * same gnx_dropout value, and gnx_dropout_mask writes them out for a host that wants to check either pass (tests/test_gpu_dropout.py).
+ * The host draws a fresh `seed` per forward call (one per core of a GNCoreList).  dropout = NULL or p = 0: exactly gnx_core_forward /
+ * gnx_core_backward.  The forward is gnx_core_forward (any flags) followed by the correction y += (m - 1) .* f, f recomputed unfused in the
+ * workspace (csrc/gnx_dropout.hip). */
+typedef struct gnx_dropout {
+  float p;          /* drop probability, 0 <= p <= 1 */
+  uint32_t reserved;
+  uint64_t seed;
+} gnx_dropout;
+GNX_API int32_t gnx_dropout_mask(const gnx_dropout* dropout, int32_t entity, int64_t n_elements, float* out, void* stream);
+GNX_API size_t gnx_core_train_workspace_bytes(const gnx_graphs* h, const gnx_core_params* p, int64_t n_replicas);
+GNX_API int32_t gnx_core_forward_train(const gnx_graphs* h, const gnx_core_params* p, const gnx_dropout* dropout, const float* ef, const float* nf,
+                               const float* gf, int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out, void* workspace,
+                               size_t workspace_bytes, uint32_t flags, void* stream);
+/* workspace: gnx_core_backward_workspace_bytes */
+GNX_API int32_t gnx_core_backward_train(const gnx_graphs* h, const gnx_core_params* p, const gnx_dropout* dropout, const float* ef, const float* nf,
+                                const float* gf, const float* g_ef_out, const float* g_nf_out, const float* g_gf_out, int64_t n_replicas,
+                                float* d_ef, float* d_nf, float* d_gf, const gnx_core_grads* grads, void* workspace, size_t workspace_bytes,
+                                void* stream);
 
 /* ---- materialised update-function inputs: the reference's exported building blocks getedgefninput /
  * getnodefninput / getgraphfninput (src/edgefninput.jl:1-47, src/nodefninput.jl:1-24, src/graphfninput.jl:1-13).

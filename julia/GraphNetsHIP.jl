@@ -499,20 +499,24 @@ struct GnxCoreParams                                                   # gnx_cor
     prepared::Ptr{Cvoid}                                               # gnx_core_prepare's object for these weights, or C_NULL
 end
 
+struct GnxDropout; p::Cfloat; reserved::UInt32; seed::UInt64; end      # gnx_dropout
+
 struct GNCore
     block::GNBlock
-    ffwd::NTuple{3,Tuple{Dense,Dense}}                                 # gnfeedforward.jl:17-31: Dense(d => 4d, relu), Dense(4d => d)
+    ffwd::NTuple{3,Tuple{Dense,Dense}}                                 # gnfeedforward.jl:17-31: Dense(d => 4d, relu), Dense(4d => d) [, Dropout(p)]
     gn1::NTuple{3,LayerNorm}; gn2::NTuple{3,LayerNorm}                 # gngraphnorm.jl:9-17
     dims::NTuple{3,Int}
+    dropout::Float32                                                   # p of the Dropout that ends each FeedForward chain (gnfeedforward.jl:30)
 end
 function GNCore(dims; dropout=0)                                       # src/gncore.jl:46-54
     @assert all(dims .> 0)                                             # gnfeedforward.jl:18, gngraphnorm.jl:10
     d = Tuple(dims)
-    GNCore(GNBlock(d => d; dropout), map(k -> (Dense(k, 4k, :relu), Dense(4k, k)), d), map(LayerNorm, d), map(LayerNorm, d), d)
+    @assert 0 <= dropout <= 1                                          # Flux.Dropout
+    GNCore(GNBlock(d => d; dropout), map(k -> (Dense(k, 4k, :relu), Dense(4k, k)), d), map(LayerNorm, d), map(LayerNorm, d), d, Float32(dropout))
 end
 ondevice(m::GNCore) = ondevice(m.block) && all(t -> ondevice(t[1]) && ondevice(t[2]), m.ffwd) && all(ondevice, m.gn1) && all(ondevice, m.gn2)
-gpu(m::GNCore) = ondevice(m) ? m : prepare!(GNCore(gpu(m.block), map(t -> (gpu(t[1]), gpu(t[2])), m.ffwd), map(gpu, m.gn1), map(gpu, m.gn2), m.dims))
-cpu(m::GNCore) = GNCore(cpu(m.block), map(t -> (cpu(t[1]), cpu(t[2])), m.ffwd), map(cpu, m.gn1), map(cpu, m.gn2), m.dims)
+gpu(m::GNCore) = ondevice(m) ? m : prepare!(GNCore(gpu(m.block), map(t -> (gpu(t[1]), gpu(t[2])), m.ffwd), map(gpu, m.gn1), map(gpu, m.gn2), m.dims, m.dropout))
+cpu(m::GNCore) = GNCore(cpu(m.block), map(t -> (cpu(t[1]), cpu(t[2])), m.ffwd), map(cpu, m.gn1), map(cpu, m.gn2), m.dims, m.dropout)
 ln_c(l::LayerNorm) = GnxLayerNorm(devptr(l.γ), devptr(l.β))
 function prepare!(m::GNCore)                                           # the core's object holds its block's planes too
     unprepare!(m)
@@ -524,12 +528,27 @@ function prepare!(m::GNCore)                                           # the cor
 end
 core_c(m::GNCore) = GnxCoreParams(block_c(m.block), map(ln_c, m.gn1), map(ln_c, m.gn2), map(t -> GnxFfn(dense_c(t[1]), dense_c(t[2])), m.ffwd), 1f-5, Int32(0), prepared_of(m))
 
-function core_device(m::GNCore, x)                                     # ONE asynchronous gnx_core_forward; see block_device
+# `drop` (a GnxDropout): the call is the forward of a gradient call — Flux applies the FeedForwards' Dropout(p) there and only there
+# (gnfeedforward.jl:27-31) — gnx_core_forward_train; the pullback regenerates the masks from the same value (core_pullback_device).
+function core_device(m::GNCore, x, drop=nothing)                       # ONE asynchronous gnx_core_forward; see block_device
     (; graphs, ef, nf, gf) = x
     @assert ef !== nothing && nf !== nothing && gf !== nothing         # graphnetadd needs all three (gncore.jl:61-68)
     g::GNGraphBatch = graphs
     R = size(ef, 3)
     p = Ref(core_c(m))
+    if drop !== nothing
+        d = Ref(drop::GnxDropout)
+        ws = workspace!(g, (:core_train, m.dims, R)) do
+            ccall((:gnx_core_train_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxCoreParams}, Int64), g.handle, p, R)
+        end
+        o_ef, o_nf, o_gf = similar(ef), similar(nf), similar(gf)
+        GC.@preserve m ef nf gf o_ef o_nf o_gf ws check(ccall((:gnx_core_forward_train, libgnx), Int32,
+            (Ptr{Cvoid}, Ptr{GnxCoreParams}, Ptr{GnxDropout}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat},
+             Ptr{Cvoid}, Csize_t, UInt32, Ptr{Cvoid}),
+            g.handle, p, d, devptr(ef), devptr(nf), devptr(gf), R, devptr(o_ef), devptr(o_nf), devptr(o_gf),
+            ws.ptr, ws.cap, UInt32(0), STREAM[]))
+        return (graphs=g, ef=o_ef, nf=o_nf, gf=o_gf)
+    end
     ws = workspace!(g, (:core, m.dims, R)) do
         ccall((:gnx_core_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxCoreParams}, Int64), g.handle, p, R)
     end
@@ -541,7 +560,9 @@ function core_device(m::GNCore, x)                                     # ONE asy
         ws.ptr, ws.cap, UInt32(0), STREAM[]))
     (graphs=g, ef=o_ef, nf=o_nf, gf=o_gf)
 end
-(m::GNCore)(x) = back(core_device(gpu(m), gpu(x)), x)                  # src/gncore.jl:56-68
+(m::GNCore)(x) = back(core_device(gpu(m), gpu(x)), x)                  # src/gncore.jl:56-68 (test mode: Dropout is the identity)
+core_train(m::GNCore, x, drop) = back(core_device(gpu(m), gpu(x), drop), x)   # the forward of a gradient call (the rrule of julia/ext)
+newdropout(m::GNCore) = m.dropout > 0 ? GnxDropout(m.dropout, UInt32(0), rand(UInt64)) : nothing   # a fresh mask per call, as Flux draws one
 
 # pullback of (m::GNCore)(x) → gnx_core_backward: takes the forward's INPUT x and the cotangent ȳ of its output; every intermediate is
 # recomputed inside the library.  Returns ∂ef, ∂nf, ∂gf and the parameter gradients in the order of the struct fields.
@@ -551,7 +572,7 @@ struct GnxCoreGrads
     block::GnxBlockGrads
     ln1::NTuple{3,GnxLayerNormGrad}; ln2::NTuple{3,GnxLayerNormGrad}; ff::NTuple{3,GnxFfnGrad}
 end
-function core_pullback_device(m::GNCore, x, ȳ)
+function core_pullback_device(m::GNCore, x, ȳ, drop=nothing)
     g::GNGraphBatch = x.graphs
     R = size(x.ef, 3)
     p = Ref(core_c(m))
@@ -566,15 +587,24 @@ function core_pullback_device(m::GNCore, x, ȳ)
     ws = workspace!(g, (:core_backward, m.dims, R)) do
         ccall((:gnx_core_backward_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxCoreParams}, Int64), g.handle, p, R)
     end
-    GC.@preserve m x ȳ gbuf dins ws check(ccall((:gnx_core_backward, libgnx), Int32,
-        (Ptr{Cvoid}, Ptr{GnxCoreParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64,
-         Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{GnxCoreGrads}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
-        g.handle, p, devptr(x.ef), devptr(x.nf), devptr(x.gf), devptr(ȳ.ef), devptr(ȳ.nf), devptr(ȳ.gf), R,
-        devptr(dins[1]), devptr(dins[2]), devptr(dins[3]), grads, ws.ptr, ws.cap, STREAM[]))
+    if drop === nothing
+        GC.@preserve m x ȳ gbuf dins ws check(ccall((:gnx_core_backward, libgnx), Int32,
+            (Ptr{Cvoid}, Ptr{GnxCoreParams}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64,
+             Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{GnxCoreGrads}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+            g.handle, p, devptr(x.ef), devptr(x.nf), devptr(x.gf), devptr(ȳ.ef), devptr(ȳ.nf), devptr(ȳ.gf), R,
+            devptr(dins[1]), devptr(dins[2]), devptr(dins[3]), grads, ws.ptr, ws.cap, STREAM[]))
+    else                                                               # the forward's masks, regenerated from the call's seed
+        d = Ref(drop::GnxDropout)
+        GC.@preserve m x ȳ gbuf dins ws check(ccall((:gnx_core_backward_train, libgnx), Int32,
+            (Ptr{Cvoid}, Ptr{GnxCoreParams}, Ptr{GnxDropout}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Int64,
+             Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{GnxCoreGrads}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+            g.handle, p, d, devptr(x.ef), devptr(x.nf), devptr(x.gf), devptr(ȳ.ef), devptr(ȳ.nf), devptr(ȳ.gf), R,
+            devptr(dins[1]), devptr(dins[2]), devptr(dins[3]), grads, ws.ptr, ws.cap, STREAM[]))
+    end
     (ef=dins[1], nf=dins[2], gf=dins[3], params=gbuf)                  # block (W, b) x 3, gn1 (γ, β) x 3, gn2 (γ, β) x 3, ffwd (W1, b1, W2, b2) x 3
 end
-function core_pullback(m::GNCore, x, ȳ)
-    r = core_pullback_device(gpu(m), gpu(x), gpu(ȳ))
+function core_pullback(m::GNCore, x, ȳ, drop=nothing)
+    r = core_pullback_device(gpu(m), gpu(x), gpu(ȳ), drop)
     ondevice(x) ? r : (ef=cpu(r.ef), nf=cpu(r.nf), gf=cpu(r.gf), params=map(cpu, r.params))
 end
 

@@ -14,7 +14,7 @@
 module GraphNetsHIPChainRulesExt
 
 using GraphNetsHIP
-using GraphNetsHIP: GNBlock, GNCore, GNCoreList, Dense, LayerNorm, block_pullback, core_pullback
+using GraphNetsHIP: GNBlock, GNCore, GNCoreList, Dense, LayerNorm, block_pullback, core_pullback, core_train, newdropout
 import ChainRulesCore
 using ChainRulesCore: Tangent, NoTangent, ZeroTangent, unthunk
 
@@ -41,11 +41,14 @@ end
 
 # (m::GNCore)(x)  (src/gncore.jl:56-68).  core_pullback returns the parameter gradients in struct order:
 # block (W, b) x 3, gn1 (γ, β) x 3, gn2 (γ, β) x 3, ffwd (W1, b1, W2, b2) x 3
+# A gradient call is Flux's training mode: with GNCore(dims; dropout = p > 0) the FeedForwards' Dropout (gnfeedforward.jl:27-31) is applied —
+# gnx_core_forward_train with a fresh seed — and the pullback regenerates the same masks from it (gnx_core_backward_train).
 function ChainRulesCore.rrule(m::GNCore, x::NamedTuple)
-    y = m(x)
+    drop = newdropout(m)
+    y = drop === nothing ? m(x) : core_train(m, x, drop)
     function core_pb(ȳ_)
         ȳ = upstream(unthunk(ȳ_), y)
-        g = core_pullback(m, x, ȳ)
+        g = core_pullback(m, x, ȳ, drop)
         p = g.params
         b = m.block
         blk = Tangent{typeof(b)}(edgefn=dense_tangent(b.edgefn, p[1], p[2]), nodefn=dense_tangent(b.nodefn, p[3], p[4]), graphfn=dense_tangent(b.graphfn, p[5], p[6]))

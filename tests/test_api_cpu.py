@@ -9,33 +9,54 @@ def _cpu_core(dropout):
     return gn.GNCore((4, 3, 2), dropout=dropout, device="cpu")
 
 
-def test_dropout_in_training_mode_is_refused_not_ignored():
-    """gnfeedforward.jl:27-31: Chain(Dense, Dense, Dropout(p)).  Flux applies the Dropout inside a gradient call; the HIP path has
-    none, so a differentiable call with p > 0 raises instead of silently training another model."""
+def test_dropout_is_active_inside_a_gradient_call_and_the_identity_outside():
+    """gnfeedforward.jl:27-31: Chain(Dense, Dense, Dropout(p)).  Flux applies the Dropout inside a gradient call and skips it in test mode;
+    testmode! / trainmode! force it.  Host logic only (no GPU): which calls get a gnx_dropout, with which seed."""
     core = _cpu_core(0.1)
+    assert core._dropout_now(False) is None                      # test mode: identity
+    d = core._dropout_now(True)                                  # gradient call: active, p as given
+    assert abs(d.p - 0.1) < 1e-7 and core.last_dropout is d
+    torch.manual_seed(3); a = core._dropout_now(True).seed
+    torch.manual_seed(3); b = core._dropout_now(True).seed
+    c = core._dropout_now(True).seed
+    assert a == b and a != c and 0 <= a < 2 ** 63                # reproducible under torch.manual_seed, fresh per call
+    gn.testmode(core)
+    assert core._dropout_now(True) is None
+    gn.trainmode(core)
+    assert core._dropout_now(False) is not None
+    gn.trainmode(core, None)                                     # automatic again
+    assert core._dropout_now(False) is None and core._dropout_now(True) is not None
+    assert _cpu_core(0)._dropout_now(True) is None               # p = 0: never
+    lst = gn.GNCoreList([_cpu_core(0.2), _cpu_core(0.3)])
+    assert gn.testmode(lst) is lst and all(c._dropout_mode is False for c in lst.list)
+    # the call goes on to the ordinary argument checks in either mode
     for t in core.parameters():
         t.requires_grad_(True)
-    with pytest.raises(NotImplementedError, match="Dropout"):
+    with pytest.raises(AssertionError, match="ef, nf and gf"):
         core(dict(graphs=None, ef=None, nf=None, gf=None))
-    # test mode (no gradient): Dropout is the identity in Flux too — the call goes on to the ordinary argument checks
     with torch.no_grad(), pytest.raises(AssertionError, match="ef, nf and gf"):
         core(dict(graphs=None, ef=None, nf=None, gf=None))
-    # p = 0 trains as before (reaches the argument checks)
-    core0 = _cpu_core(0)
-    for t in core0.parameters():
-        t.requires_grad_(True)
-    with pytest.raises(AssertionError, match="ef, nf and gf"):
-        core0(dict(graphs=None, ef=None, nf=None, gf=None))
 
 
-def test_non_dense_layer_in_a_chain_is_an_explicit_error():
-    """gnblock.jl:1-6 allows any Flux chain as an update function; only Dense layers are supported here — and say so."""
+def test_chain_folds_the_layer_values_that_fold_exactly_and_refuses_the_rest():
+    """gnblock.jl:1-6 allows any Flux chain as an update function.  Row-wise Dense layers run; an activation function as a layer folds into the
+    Dense in front of it, identity is dropped, Dropout is the identity in test mode; everything else is an explicit error."""
     d = gn.Dense(4, 3, device="cpu")
     assert len(gn.Chain(d, gn.Dense(3, 2, device="cpu"))) == 2
+    ch = gn.Chain(d, torch.relu, gn.Dense(3, 2, device="cpu"), "identity", "tanh", gn.Dropout(0.25), None)
+    assert len(ch) == 2 and [l.act for l in ch.layers] == ["relu", "tanh"] and ch.dropout_p == 0.25
+    assert ch.layers[0].weight is d.weight and ch.layers[0].bias is d.bias and d.act == "identity"   # the caller's Dense is not modified
+    assert gn.Chain([d, "gelu"]).layers[0].act == "gelu"
     with pytest.raises(NotImplementedError, match="LayerNorm"):
         gn.Chain(d, gn.LayerNorm(3, device="cpu"))
     with pytest.raises(NotImplementedError, match="function"):
-        gn.Chain(d, torch.relu)
+        gn.Chain(d, lambda x: x * 2)
+    with pytest.raises(NotImplementedError, match="does not follow"):
+        gn.Chain(torch.relu, d)                                   # an activation in front of the first Dense does not fold
+    with pytest.raises(NotImplementedError, match="does not follow"):
+        gn.Chain(gn.Dense(4, 3, "relu", device="cpu"), "tanh")    # nor do two activations in a row
+    with pytest.raises(AssertionError):
+        gn.Dropout(1.5)
 
 
 def test_packed_csc_constructor_checks_lengths_before_anything_is_read():

@@ -167,3 +167,42 @@ def test_chain_block_backward_matches_torch_autograd(gn, case):
             close(q.grad, r, f"param[{i}]")
         return
     pytest.fail("no kink-free draw in 20 attempts")
+
+
+def test_chain_with_activation_identity_and_dropout_layer_values(gn):
+    """Flux users write `Chain(Dense(a => b), relu, Dense(b => c), Dropout(p))`: the activation folds into the Dense in front of it, identity is
+    dropped, Dropout is the identity in test mode — the same launches, the same bits as the explicit `Dense(a => b, relu)` form; a differentiable
+    call with a Dropout(p > 0) inside a chain is refused."""
+    import torch
+    rng = np.random.default_rng(11)
+    in_dims = (10, 5, 3)
+    adjs = [(rng.random((n, n)) < 0.3).astype(np.int64) for n in rng.integers(3, 40, 5)]
+    g = gn.GNGraphBatch(adjs)
+    p = O.make_chain_block_params(rng, in_dims, [16, 3], [8, 4], [6, 5])
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, in_dims)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    ref = _block(gn, p)(x)
+    blk = gn.GNBlock(in_dims, (1, 0, 0))
+
+    def spelled_out(layers, extra=()):
+        out = []
+        for W, b, a in layers:
+            out.append(gn.Dense.from_numpy(W, b, "identity"))
+            out.append(U.ACT_NAMES[a] if U.ACT_NAMES[a] != "relu" else torch.relu)
+        return gn.Chain(out + list(extra))
+
+    blk.edgefn, blk.nodefn, blk.graphfn = spelled_out(p["edge"], [gn.Dropout(0.3)]), spelled_out(p["node"], [None]), spelled_out(p["graph"])
+    y = blk(x)
+    for a, b in zip((y.ef, y.nf, y.gf), (ref.ef, ref.nf, ref.gf)):
+        assert torch.equal(a, b)
+    for l in blk.edgefn.layers:
+        l.weight.requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="Dropout"):
+        blk(x)
+    with torch.no_grad():
+        assert torch.equal(blk(x).ef, ref.ef)
+    blk.edgefn = spelled_out(p["edge"])      # without the Dropout the differentiable call runs (gnx_chain_block_backward)
+    for l in blk.edgefn.layers:
+        l.weight.requires_grad_(True)
+    blk(x).ef.sum().backward()
+    assert all(l.weight.grad is not None and bool(torch.isfinite(l.weight.grad).all()) for l in blk.edgefn.layers)

@@ -102,7 +102,7 @@ def test_every_ccall_matches_the_ctypes_signature_table():
 def test_the_shim_binds_the_entry_points_of_the_hot_path_and_its_neighbours():
     bound = {c[0] for c in ccalls()}
     for name in ("gnx_graphs_create_dense_packed", "gnx_graphs_create_csc_cat", "gnx_block_prepare", "gnx_core_prepare", "gnx_prepared_refresh", "gnx_block_forward", "gnx_core_forward", "gnx_fn_input", "gnx_block_backward",
-                 "gnx_core_backward", "gnx_chain_block_forward", "gnx_chain_block_backward", "gnx_model_create", "gnx_model_forward",
+                 "gnx_core_backward", "gnx_core_forward_train", "gnx_core_backward_train", "gnx_chain_block_forward", "gnx_chain_block_backward", "gnx_model_create", "gnx_model_forward",
                  "gnx_dist_partition", "gnx_dist_create", "gnx_dist_block_forward", "gnx_dist_block_forward_steps", "gnx_dist_destroy", "gnx_collapse_edges",
                  "gnx_collapse_padded", "gnx_block_forward_chained", "gnx_block_graph_update"):
         assert name in bound, f"the Julia shim does not bind {name}"
@@ -112,7 +112,7 @@ STRUCT_MIRRORS = {"GnxDense": _lib.Dense, "GnxBlockParams": _lib.BlockParams, "G
                   "GnxFfn": _lib.Ffn, "GnxCoreParams": _lib.CoreParams, "GnxDenseGrad": _lib.DenseGrad, "GnxBlockGrads": _lib.BlockGrads,
                   "GnxChain": _lib.Chain, "GnxChainBlockParams": _lib.ChainBlockParams, "GnxChainBlockGrads": _lib.ChainBlockGrads,
                   "GnxLayer": _lib.Layer, "GnxLayerNormGrad": _lib.LayerNormGrad, "GnxFfnGrad": _lib.FfnGrad, "GnxCoreGrads": _lib.CoreGrads,
-                  "GnxPendingUpdate": _lib.PendingUpdate}
+                  "GnxPendingUpdate": _lib.PendingUpdate, "GnxDropout": _lib.Dropout}
 
 
 def julia_structs():
@@ -126,7 +126,7 @@ def julia_structs():
 
 def _layout(jtype, structs):
     """(size, alignment) of a Julia isbits field type under the C layout rules Julia uses for ccall."""
-    prim = {"Int32": 4, "UInt32": 4, "Cfloat": 4, "Float32": 4, "Cint": 4, "Int64": 8, "Csize_t": 8, "Float64": 8}
+    prim = {"Int32": 4, "UInt32": 4, "Cfloat": 4, "Float32": 4, "Cint": 4, "Int64": 8, "UInt64": 8, "Csize_t": 8, "Float64": 8}
     if jtype.startswith("Ptr{"):
         return 8, 8
     if jtype in prim:
@@ -307,7 +307,7 @@ def test_the_chainrules_extension_wraps_the_pullbacks_the_shim_ships():
         body = re.search(r"struct %s(?:\{[^}]*\})?[^\n]*\n(.*?)\nend" % struct, shim, re.S).group(1)
         for f in want:
             assert re.search(r"\b%s::" % f, body), f"{struct} has no field {f}"
-    assert "block_pullback(m, x, y, ȳ)" in code and "core_pullback(m, x, ȳ)" in code
+    assert "block_pullback(m, x, y, ȳ)" in code and "core_pullback(m, x, ȳ, drop)" in code and "core_train(m, x, drop)" in code and "newdropout(m)" in code
     # the core's 30 parameter gradients: block 1..6, gn1 7..12, gn2 13..18, ffwd 19..30
     idx = lambda f: sorted(f(t) for t in (1, 2, 3))
     assert idx(lambda t: 5 + 2 * t) == [7, 9, 11] and idx(lambda t: 11 + 2 * t) == [13, 15, 17] and idx(lambda t: 15 + 4 * t) == [19, 23, 27]
