@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--width", type=int, default=16)
     ap.add_argument("--lr", type=float, default=3e-3)
     ap.add_argument("--profile", action="store_true", help="per-kernel GPU time of the last iteration (gnx_profile_*)")
+    ap.add_argument("--dropout", type=float, default=0.0, help="GNCore(dims; dropout): the FeedForwards' Dropout, active in the training calls (sort.jl:119 trains with 0)")
     ap.add_argument("--vocab", type=int, default=0, help="one-hot integer inputs like the reference (sort.jl uses 100)")
     ap.add_argument("--reference-config", action="store_true",
                     help="the reference's sizes: vocab 100, 2..10 nodes, core width 384, batch 4, 2 cores (sort.jl:11-16,86-89,116)")
@@ -58,7 +59,7 @@ def main():
     torch.manual_seed(0)
     w = args.width
     enc = gn.GNBlock((0, args.vocab or 1, 0), (w, w, w), device=dev, act=("relu", "relu", "relu"))
-    cores = gn.GNCoreList([gn.GNCore((w, w, w), device=dev) for _ in range(2)])
+    cores = gn.GNCoreList([gn.GNCore((w, w, w), dropout=args.dropout, device=dev) for _ in range(2)])
     dec = gn.GNBlock((w, w, w), (2, 2, 0), device=dev)
     params = []
     for blk in (enc, dec):

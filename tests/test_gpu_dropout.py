@@ -213,3 +213,23 @@ def test_train_entry_points_without_dropout_are_the_plain_ones(gn):
     rc = lib.gnx_core_forward_train(g._h, C.byref(cp), C.byref(act), ef.data_ptr(), nf.data_ptr(), gf.data_ptr(), 1, *(o.data_ptr() for o in outs), ws.data_ptr(),
                                     lib.gnx_core_workspace_bytes(g._h, C.byref(cp), 1), 0, stream)
     assert rc == _lib.ERR_WORKSPACE
+
+
+def test_sort_example_trains_with_dropout(gn):
+    """examples/train_sort.py --dropout 0.1: two GNCores whose FeedForwards drop 10 % in every training call (a fresh mask per core and call)
+    still learn; evaluation calls (no gradient) run without the mask."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_sort.py")
+    spec = importlib.util.spec_from_file_location("train_sort_dropout", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    sys.argv = ["train_sort.py", "--iters", "150", "--graphs", "32", "--n", "6", "--width", "8", "--dropout", "0.1"]
+    try:
+        hist = mod.main()
+    finally:
+        sys.argv = argv
+    assert np.isfinite(hist).all()
+    assert np.mean(hist[-10:]) < 0.8 * np.mean(hist[:5]), (hist[:5], hist[-10:])
