@@ -233,3 +233,34 @@ def test_sort_example_trains_with_dropout(gn):
         sys.argv = argv
     assert np.isfinite(hist).all()
     assert np.mean(hist[-10:]) < 0.8 * np.mean(hist[:5]), (hist[:5], hist[-10:])
+
+
+def test_dropout_on_a_shared_graph_batch_masks_every_replica_independently(gn):
+    """A shared-adjacency batch (src/batch.jl:66: R = the data batch size) — the mask covers the packed [R][rows][width] tensor, so the replicas of one
+    graph draw different masks; y_train - y_test = (m - 1) .* ffwd(gn2(x)) per replica, in float64 from the library's mask."""
+    rng = np.random.default_rng(91)
+    dims, R = (10, 5, 3), 3
+    adj = (rng.random((30, 30)) < 0.2).astype(np.int64)
+    p = O.make_core_params(rng, dims)
+    core = U.core_from_params(gn, p)
+    core.ffwd.dropout = 0.4
+    E, N = int(adj.sum()), 30
+    ef, nf, gf = rng.random((dims[0], E, R), dtype=np.float32), rng.random((dims[1], N, R), dtype=np.float32), rng.random((dims[2], R), dtype=np.float32)
+    x = gn.batch(dict(graphs=adj, ef=ef, nf=nf, gf=gf))
+    y0 = core(x)
+    gn.trainmode(core)
+    y1 = core(x)
+    drop = core.last_dropout
+    for t, (name, a) in enumerate((("ef", x.ef), ("nf", x.nf), ("gf", x.gf))):
+        m = gn.dropout_mask(drop, t, tuple(a.shape), a.device).double().cpu()          # (d, rows, R)
+        assert t == 2 or not torch.equal(m[:, :, 0], m[:, :, 1])              # (three elements per replica of gf can coincide)
+        z = a.double().cpu().permute(2, 1, 0)                                           # [R][rows][d]
+        k = "eng"[t]
+        T = lambda v: torch.from_numpy(np.asarray(v, dtype=np.float64))
+        l2 = _torch_ln(z.reshape(-1, z.shape[2]), T(p[f"ln2_{k}_gamma"]), T(p[f"ln2_{k}_beta"]), p["eps"], 0)
+        f = torch.relu(l2 @ T(p[f"ff_{k}_W1"]).T + T(p[f"ff_{k}_b1"])) @ T(p[f"ff_{k}_W2"]).T + T(p[f"ff_{k}_b2"])
+        f = f.reshape(z.shape).permute(2, 1, 0)
+        got = (getattr(y1, name).double() - getattr(y0, name).double()).cpu()
+        want = (m - 1) * f
+        scale = float(getattr(y0, name).abs().max()) + float(f.abs().max())
+        assert float((got - want).abs().max()) <= 5e-6 * scale, (name, float((got - want).abs().max()), scale)
