@@ -140,6 +140,27 @@ def sharded_block_forward(forward_fn, x_local, gather: GfGather):
     return y, gather.finish()
 
 
+def partition_replicas(n_replicas, world_size):
+    """A shared-adjacency batch (src/batch.jl:66: one graph, R = the data batch size) shards over its DATA BATCH the same way a vector of
+    graphs shards by graph: the replicas are independent units — `batched_mul` never mixes batch indices.  Contiguous slices,
+    equal counts (+-1): every rank keeps the one handle of the shared graph and its slice ef[:, :, r0:r1] / nf / gf.  Returns a list of
+    int64 index arrays (replica ids, ascending) — a partition GfGather takes as it takes a partition of graphs."""
+    R, W = int(n_replicas), int(world_size)
+    assert R >= 0 and W >= 1
+    cuts = [(R * r) // W for r in range(W + 1)]
+    return [np.arange(cuts[r], cuts[r + 1], dtype=np.int64) for r in range(W)]
+
+
+def sharded_replica_forward(forward_fn, x_local, gather: GfGather):
+    """`sharded_block_forward` for a shared-adjacency batch sharded by replica (`partition_replicas`): runs `forward_fn` over this rank's
+    replicas and all-gathers gf' — Julia-shaped (DG, 1, R_local) per rank — into (R, DG) in replica order on every rank."""
+    y = forward_fn(x_local)
+    gf = y.gf if hasattr(y, "gf") else y["gf"]
+    gf_rows = gf.permute(2, 1, 0)[:, 0, :] if gf.dim() == 3 else gf  # (DG, 1, R_local) -> (R_local, DG)
+    gather.start(gf_rows.contiguous())
+    return y, gather.finish()
+
+
 class DistBlockRunner:
     """ONE process driving n devices through the C boundary's own sharded path (gnx_dist_*: what the Julia shim's DistBlock binds) —
     the counterpart of GfGather for hosts that are not one-process-per-GPU.  Builds the communicator (ncclCommInitAll), one graph handle,

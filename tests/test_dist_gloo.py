@@ -254,3 +254,54 @@ def test_c_gather_plan_equals_the_rule_for_eight_unequal_shards():
     bad[1][0] = bad[3][0]  # a graph owned twice
     with pytest.raises(GnxError):
         gather_plan(bad)
+
+
+def _replica_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import graphnets_jl_amd  # noqa: F401
+    from graphnets_jl_amd.dist import GfGather, partition_replicas, sharded_replica_forward
+    from oracle import gn_oracle as O
+    adj, ef, nf, p = _shared_batch()
+    shards = partition_replicas(ef.shape[0], world)
+    mine = shards[rank]
+    csc = O.csc_from_adj([adj])
+
+    def forward(x):  # oracle as the per-rank forward (CPU stand-in for the HIP path); gf' Julia-shaped (DG, 1, R_local)
+        _, _, g = O.block_forward_sparse(p, csc, x["ef"], x["nf"], None)
+        return dict(gf=torch.from_numpy(g.astype(np.float32)).permute(2, 1, 0))
+
+    gather = GfGather(shards, rank, world, dg=5, device="cpu")
+    _, gf_all = sharded_replica_forward(forward, dict(ef=ef[mine], nf=nf[mine]), gather)
+    if rank == 0:
+        np.save(out, gf_all.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _shared_batch(R=5):
+    from oracle import gn_oracle as O
+    rng = np.random.default_rng(17)
+    adj = (rng.random((9, 9)) < 0.4).astype(np.int64)
+    ef = rng.random((R, int(adj.sum()), 3), dtype=np.float32)   # packed [R][E][DE]
+    nf = rng.random((R, 9, 4), dtype=np.float32)
+    return adj, ef, nf, O.make_block_params(np.random.default_rng(2), (3, 4, 0), (2, 3, 5))
+
+
+@pytest.mark.timeout(120)
+def test_shared_graph_batch_shards_over_its_data_batch(tmp_path):
+    """"shared-graph batches shard over the data batch B the same way" — 5 replicas of one graph over 2 gloo ranks (3 + 2),
+    gf' gathered in replica order, equal to the one-process result."""
+    sys.path.insert(0, ROOT)
+    import graphnets_jl_amd  # noqa: F401
+    from graphnets_jl_amd.dist import partition_replicas
+    from oracle import gn_oracle as O
+    parts = partition_replicas(5, 2)
+    assert [p.tolist() for p in parts] == [[0, 1], [2, 3, 4]]
+    assert [len(p) for p in partition_replicas(4096, 8)] == [512] * 8 and sum(len(p) for p in partition_replicas(3, 8)) == 3
+    out = str(tmp_path / "gf_rep.npy")
+    mp.spawn(_replica_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    adj, ef, nf, p = _shared_batch()
+    _, _, gf = O.block_forward_sparse(p, O.csc_from_adj([adj]), ef, nf, None)
+    np.testing.assert_allclose(np.load(out), gf[:, 0, :], rtol=1e-6, atol=1e-6)

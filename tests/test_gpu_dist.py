@@ -352,3 +352,30 @@ def test_gnx_dist_replay_form_world_1(gn):
         assert gn._lib.load().gnx_dist_block_forward_steps(run._d, 0, None, None, None, None, None, None, None, None, None, None, 0, None) == gn._lib.ERR_INVALID_ARG
     finally:
         run.close()
+
+
+def test_shared_graph_batch_sharded_by_replica_three_virtual_ranks(gn):
+    """a shared-adjacency batch shards over its data batch.  7 replicas of one 300-node graph over 3 virtual ranks (2 + 2 + 3) on this GPU:
+    every rank runs the HIP block on ITS replicas with the one shared handle, the padded send tables are concatenated as all_gather_into_tensor
+    would and the C boundary's gather plan restores replica order — ef', nf', gf' bit-identical to the one-call result."""
+    import torch
+    from graphnets_jl_amd.dist import gather_plan, partition_replicas
+    rng = np.random.default_rng(61)
+    dims = ((10, 5, 3), (3, 4, 5))
+    cp, rv = U.er_csc(rng, 300, 3000)
+    g = gn.GNGraphBatch.from_csc([cp], [rv], [300])
+    R, world = 7, 3
+    p = O.make_block_params(rng, *dims)
+    blk = U.block_from_params(gn, p)
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, 1, dims[0])
+    whole = blk(U.to_nt(gn, g, ef, nf, gf))
+    shards = partition_replicas(R, world)
+    assert [len(s) for s in shards] == [2, 2, 3]
+    src, max_count = gather_plan(shards)
+    table = torch.zeros((world * max_count, 5), device=g.device)
+    for rank, mine in enumerate(shards):
+        y = blk(U.to_nt(gn, g, ef[mine], nf[mine], gf[mine]))
+        assert torch.equal(y.ef, whole.ef[:, :, mine[0]:mine[-1] + 1]) and torch.equal(y.nf, whole.nf[:, :, mine[0]:mine[-1] + 1])
+        table[rank * max_count:rank * max_count + len(mine)] = y.gf.permute(2, 1, 0)[:, 0, :]
+    gathered = table[torch.from_numpy(src.astype(np.int64)).to(g.device)]
+    assert torch.equal(gathered, whole.gf.permute(2, 1, 0)[:, 0, :])
