@@ -414,10 +414,12 @@ struct ProjX6Args {
   int only_d;
 };
 
-__global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_proj_x6(ProjX6Args a) {
+__global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_proj_x6(ProjX6Args a) {
   __shared__ __attribute__((aligned(16))) unsigned char s_wa[PSLB];
   __shared__ __attribute__((aligned(16))) unsigned char s_wb[PSLB];
-  __shared__ __attribute__((aligned(16))) float s_e[EBM * ELDE];
+  // the staging area holds HALF a wave's block (16 rows): with all 32 rows the workgroup needs 43 008 bytes of LDS = three workgroups per CU = 768 for the
+  // chip — C2's 100k nodes are 782 tiles, 1.02 rounds: the last 14 tiles ran alone behind the rest.  33 792 bytes = four per CU, one round up to 131k nodes.
+  __shared__ __attribute__((aligned(16))) float s_e[EBM / 2 * ELDE];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, n = lane & 31;
   const size_t r = blockIdx.y;
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(3, 4)))
   __syncthreads();                                  // ... everybody's
   const int er = lane >> 3, eq = lane & 7;
   const bool wave_full = rows >= (wv + 1) * ER;  // (wave-uniform: the common case stores without a per-lane predicate)
-  float* sE = s_e + wv * (ER * ELDE);
+  float* sE = s_e + wv * (ER / 2 * ELDE);
   const float* __restrict__ bp = a.bias_g ? a.bias_g + (r * a.G + (size_t)t.g) * EOUT : a.bias;
   auto slice = [&](int ob, const unsigned char* cur, unsigned char* nxt) {
     if (ob + 1 < PNOB) stage(ob + 1, nxt);
@@ -501,20 +503,26 @@ __global__ __launch_bounds__(64 * EW) __attribute__((amdgpu_waves_per_eu(3, 4)))
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zm[s], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zh[s], acc, 0, 0, 0);
     }
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<f32x4e*>(sE + n * ELDE + 8 * g + 4 * hi) = f32x4e{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
     const int tab = ob >> 2, c0 = 32 * (ob & 3) + 4 * eq;
     f32x4e b4 = {0.f, 0.f, 0.f, 0.f};
     if (tab == 1 && bp) b4 = *reinterpret_cast<const f32x4e*>(bp + c0);
     float* __restrict__ outp = (tab ? a.out_d : a.out_s) + (r * a.N + (size_t)row0) * EOUT + c0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int lr = er + 8 * i;
-      f32x4e v = *reinterpret_cast<const f32x4e*>(sE + lr * ELDE + 4 * eq);
-      v += b4;
-      if (wave_full) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * EOUT) = v;
-      else if (wv * ER + lr < rows) *reinterpret_cast<f32x4e*>(outp + (size_t)(wv * ER + lr) * EOUT) = v;
+    for (int hf = 0; hf < 2; ++hf) {  // rows 0..15 of the wave's block, then 16..31, through the same 16 staged rows (one wave's LDS operations execute in order)
+      if ((n >> 4) == hf) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4e*>(sE + (n & 15) * ELDE + 8 * g + 4 * hi) = f32x4e{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int lr = er + 8 * i;
+        f32x4e v = *reinterpret_cast<const f32x4e*>(sE + lr * ELDE + 4 * eq);
+        v += b4;
+        const int row = wv * ER + 16 * hf + lr;
+        if (wave_full) *reinterpret_cast<f32x4e*>(outp + (size_t)row * EOUT) = v;
+        else if (row < rows) *reinterpret_cast<f32x4e*>(outp + (size_t)row * EOUT) = v;
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next slice's pieces of this wave (the stores too: 2 KB per wave)
     __syncthreads();                                  // everybody's pieces; everybody is done with `cur`
