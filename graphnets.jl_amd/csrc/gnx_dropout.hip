@@ -139,7 +139,7 @@ int32_t gnx_core_forward_train(const gnx_graphs* h, const gnx_core_params* p, co
   if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
   if (int32_t rc = check_dropout(dr)) return rc;
   const size_t core = gnx_core_workspace_bytes(h, p, R);
-  if (core == 0) return GNX_ERR_DIMS;  // (message set by the query)
+  if (core == 0) return fail(GNX_ERR_DIMS, "gnx_core_forward_train: gnx_core_workspace_bytes rejects these parameters (GNCore needs dims => dims, all(dims .> 0), n_replicas >= 1)");
   const TrainLayout L = train_layout(h, p, R, core);
   if (!ws || ws_bytes < (dropout_active(dr) ? L.total : core)) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_core_train_workspace_bytes()");
   if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");

@@ -27,6 +27,8 @@
  *     fails with GNX_ERR_INVALID_ARG and a message saying so — not remembered: the next call outside the capture succeeds), and
  *     gnx_model_forward (which manages its own hipGraph).
  *   - The library uses the calling thread's current HIP device; a handle lives on the device it was created on.
+ *   - Output buffers must not overlap input buffers or the workspace (the kernels read inputs while they write outputs; the training forward
+ *     re-reads x after the outputs exist).  The reference's layers are out-of-place as well (every update allocates its result).
  */
 #ifndef GNX_H
 #define GNX_H
