@@ -1,6 +1,6 @@
 #!/bin/bash
-# same-box A/B of where a wide core's node FeedForward runs: ahead of the block on the side stream, beside the edge kernel (default) against behind the block
-# (GNX_NODE_FFN_BEHIND=1: round 5's earlier place); config 4 and one GNCore replay, interleaved.   -> gpurun_out/ab_node_ffn.log
+# same-box A/B of where a wide core's node FeedForward runs — WITH tools/experiments/node_ffn_ahead.patch applied (rejected, round 5): ahead of the block on the side stream, beside the edge
+# kernel (the patch's default) against behind the block (GNX_NODE_FFN_BEHIND=1: the place it has); config 4 and one GNCore replay, interleaved.   -> gpurun_out/ab_node_ffn.log
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 LOG=$REPO/gpurun_out/ab_node_ffn.log; : > $LOG
 for rep in 1 2 3; do
