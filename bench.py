@@ -374,7 +374,8 @@ def bench_c4(args, gn, torch, dev, c_abi=None):
                          if "model_us_per_step" in c_abi else c_abi)
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = c4_cpu_baseline(ps)
-    print(json.dumps(line))
+    line.update({"n_gpus": 1, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
+    emit(line, args, "c4" if core == (128, 64, 32) else "c4_" + "-".join(map(str, core)))
 
 
 def measure_dist_gnx(args, gn, torch, n, din, dout, Gtot, Etot, seed, K, W):
@@ -466,8 +467,8 @@ def bench_dist_gnx(args):
         ew = sharded_entry(c5w, K, n)
         ew["what"] = "C5w (SURVEY 8e): the same 4096 graphs at configs[2]'s density — 8M edges — sharded over the same devices"
         line["secondary"] = {"c5w": ew}
-    _flush_c_stdio()
-    print(json.dumps(line), flush=True)
+    line["cpu_baseline"] = None
+    emit(line, args, f"dist_gnx_n{n}")
 
 
 def model_source_sha(core):
@@ -478,6 +479,113 @@ def model_source_sha(core):
         with open(os.path.join(ROOT, "graphnets.jl_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+COMPACT_MAX_BYTES = 3072  # the driver parses the LAST stdout line; round 5's 20.6-KB line was not parsed: the headline stays under 3 KB
+
+
+def _short(v, n):
+    """prose cut to n characters (the full text is in the detail file)"""
+    if not isinstance(v, str) or len(v) <= n:
+        return v
+    return v[:n - 1].rstrip() + "…"
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(line, detail_path=None):
+    """The line the driver parses: the contract's keys + `roofline` + `cpu_baseline`, numbers only, every prose field cut short — always below
+    COMPACT_MAX_BYTES whatever the run measured.  Everything else of `line` (secondary configs, batch construction times, the C program's leg, the
+    `what` / `counts` / `timing` texts) goes to the detail file and to an earlier, prefixed stdout line (emit)."""
+    cfg, roof, cpu = line.get("config") or {}, line.get("roofline"), line.get("cpu_baseline")
+    out = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["metric"] = _short(out["metric"], 120)
+    c = {"workload": _short(cfg.get("workload"), 200)}
+    c.update(_pick(cfg, ("dims", "edges_whole_job", "graphs_whole_job", "edges_per_gpu", "nodes_per_gpu", "graphs_per_gpu", "parallelism")))
+    if isinstance(c.get("graphs_per_gpu"), list):
+        c["graphs_per_gpu"] = c["graphs_per_gpu"][:8]
+    c["launch"] = _short(cfg.get("launch"), 160)
+    if "dist_backend" in cfg:
+        c["dist_backend"] = _short(cfg["dist_backend"], 24)
+    out["config"] = c
+    if isinstance(roof, dict):
+        r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "frac_whole_step", "algorithmic_bytes", "kernel", "kernel_us", "executed_flops", "matrix_roof_frac"))
+        r["traffic"] = roof.get("traffic")  # (null stays null: the contract names the key)
+        wj = roof.get("whole_job")
+        if isinstance(wj, dict):
+            r["whole_job"] = _pick(wj, ("algorithmic_bytes", "achieved", "peak", "frac"))
+        out["roofline"] = r
+    else:
+        out["roofline"] = None
+    out["cpu_baseline"] = dict(_pick(cpu, ("value", "unit", "cores", "kind")), sample=_short(cpu.get("sample"), 140)) if isinstance(cpu, dict) else None
+    # the other forms of the same step, as bare numbers (ms per step)
+    for key, src in (("with_allgather_ms", line.get("with_allgather")), ("without_allgather_ms", line.get("without_allgather")),
+                     ("single_gpu_same_workload_ms", line.get("single_gpu_same_workload")), ("two_launch_ms", line.get("two_launch_form")),
+                     ("chained_ms", line.get("chained_graph_update")), ("pipelined_two_streams_ms", line.get("pipelined_two_streams"))):
+        if isinstance(src, dict) and src.get("ms_per_step") is not None:
+            out[key] = src["ms_per_step"]
+    for k in ("c_abi_ms_per_step", "speedup_vs_single_gpu_same_workload"):
+        if line.get(k) is not None:
+            out[k] = line[k]
+    c5w = (line.get("secondary") or {}).get("c5w")
+    if isinstance(c5w, dict) and "value" in c5w:  # N > 1: the 8M-edge batch through the same ranks
+        out["c5w"] = dict(_pick(c5w, ("value", "ms_per_step")), **{k: v["ms_per_step"] for k, v in (("without_allgather_ms", c5w.get("without_allgather")),
+                          ("single_gpu_same_workload_ms", c5w.get("single_gpu_same_workload"))) if isinstance(v, dict) and v.get("ms_per_step") is not None})
+    if detail_path:
+        out["detail"] = detail_path
+    # never above the cap: prose first, then the optional numbers
+    for drop in (("config", "launch"), ("cpu_baseline", "sample"), ("c5w",), ("config", "workload")):
+        if len(json.dumps(out)) <= COMPACT_MAX_BYTES:
+            break
+        if len(drop) == 1:
+            out.pop(drop[0], None)
+        elif isinstance(out.get(drop[0]), dict):
+            out[drop[0]][drop[1]] = _short(out[drop[0]].get(drop[1]), 40)
+    assert len(json.dumps(out)) <= COMPACT_MAX_BYTES, "bench.py: the headline line outgrew its cap"
+    return out
+
+
+def secondary_summary(sec):
+    """`secondary` as numbers only (per config: value, ms_per_step, roofline bound / frac / kernel_us / traffic, CPU figure): the earlier stdout line"""
+    out = {}
+    for k, e in (sec or {}).items():
+        if not isinstance(e, dict):
+            continue
+        if "error" in e:
+            out[k] = {"error": _short(str(e["error"]), 80)}
+            continue
+        r = e.get("roofline") or {}
+        s = _pick(e, ("value", "ms_per_step", "steps", "c_abi_ms_per_step"))
+        s.update({"roof_" + kk: r[kk] for kk in ("bound", "frac", "frac_whole_step", "kernel", "kernel_us", "traffic", "algorithmic_bytes", "executed_flops") if r.get(kk) is not None})
+        if isinstance(e.get("cpu_baseline"), dict):
+            s["cpu_value"] = e["cpu_baseline"].get("value")
+        if isinstance(e.get("kernel_us_one_forward"), dict):
+            s["kernel_us_one_forward"] = e["kernel_us_one_forward"]
+        out[k] = s
+    return out
+
+
+def emit(line, args, tag):
+    """Prints the run's result.  `--full-line` (the secondary children, tools): the whole line, as rounds 1-5 printed it.  Otherwise: (1) the whole
+    line into gpurun_out/bench_detail_<tag>.json, (2) the secondary configs as numbers on a PREFIXED stdout line, (3) the compact headline as the
+    LAST stdout line (COMPACT_MAX_BYTES)."""
+    _flush_c_stdio()
+    if getattr(args, "full_line", False):
+        print(json.dumps(line), flush=True)
+        return
+    rel = os.path.join("gpurun_out", f"bench_detail_{tag}.json")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, rel), "w") as f:
+            json.dump(line, f, indent=1)
+    except OSError:
+        rel = None
+    sec = line.get("secondary")
+    if sec:
+        print("bench-secondary (not the result line): " + json.dumps(secondary_summary(sec)), flush=True)
+    print(json.dumps(compact_line(line, rel)), flush=True)
 
 
 SECONDARY = [  # (key, extra argv, BASELINE config it stands for)
@@ -505,7 +613,7 @@ def collect_secondary(args):
     for key, extra, what, *env_extra in SECONDARY:
         steps = {"c4": max(3, min(args.steps, 5)), "c4_fp32_mfma": max(3, min(args.steps, 5)), "core_c2": max(5, min(args.steps, 10))}.get(key, max(10, min(args.steps, 20)))
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(max(2, min(args.warmup, 5))),
-               "--no-secondary", "--cpu-budget", "3.0"] + extra
+               "--no-secondary", "--full-line", "--cpu-budget", "3.0"] + extra
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, **env_extra[0]) if env_extra else None)
@@ -864,6 +972,39 @@ def sharded_entry(res, K, world):
     return out
 
 
+def sharded_line(args, res, c5w, K, W, world, din, dout):
+    """The whole N > 1 line from rank 0's measurements (pure: the CPU tests assemble it from canned results)."""
+    Gtot, Etot, seed = res["G_job"], res["E_job"], res["seed"]
+    e = sharded_entry(res, K, world)
+    strong = args.scaling == "strong"
+    wl = (f"BASELINE configs[4]: ONE FIXED heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {world} GPU(s) — "
+          f"the same graphs at every N (strong scaling)" if strong else
+          f"ONE heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {world} GPU(s): {Gtot // world} graphs / "
+          f"~{Etot // world} edges per GPU at every N (weak scaling; BASELINE configs[4] law)")
+    line = {"metric": "edges updated/sec, GNBlock fwd, 1M-edge batch", "value": e["value"], "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl, "dims": f"{din}=>{dout}", "edges_whole_job": e["edges_whole_job"], "graphs_whole_job": e["graphs_whole_job"],
+                       "edges_per_gpu": res["E"], "nodes_per_gpu": res["N"], "graphs_per_gpu": res["G"], "per_rank_edges_nodes_graphs": e["per_rank_edges_nodes_graphs"],
+                       "parallelism": f"graph-sharded x{world}", "dist_backend": "torch (one process per GPU, RCCL all-gather of gf')",
+                       "launch": f"hipGraph of {res['M']} steps per replay over {res['nsets']} rotating buffer sets per rank; one RCCL all-gather of the {res['M']} stacked gf' tables per replay, on a side stream",
+                       "timing": f"median of 3 runs of the {K}-step region ({e['with_allgather']['reps_us_per_step']} us/step), MAX over ranks, after {CLOCK_WARMUP_MS:g} ms of the same load, untimed"},
+            "with_allgather": e["with_allgather"], "without_allgather": e["without_allgather"], "single_gpu_same_workload": e["single_gpu_same_workload"],
+            "roofline": res["roof"], "cpu_baseline": None}
+    if "speedup_vs_single_gpu_same_workload" in e:
+        line["speedup_vs_single_gpu_same_workload"] = e["speedup_vs_single_gpu_same_workload"]
+    if res["roof"] is not None:
+        ab = sum(algorithmic_bytes(c[0], c[1], c[2], din, dout) for c in res["per_rank"])
+        line["roofline"]["whole_job"] = {"algorithmic_bytes": ab, "achieved": round(ab / (res["dt"] / K) / 1e9, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                         "frac": round(ab / (res["dt"] / K) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                                         "counts": "algorithmic bytes of every rank's shard / whole-step time / (n_gpus x 8 TB/s); the kernel figures above are rank 0's shard"}
+    if c5w is not None:
+        ew = sharded_entry(c5w, K, world)
+        ew["what"] = "C5w (SURVEY 8e): the same 4096 graphs at configs[2]'s density — 8M edges — sharded over the same ranks; strong scaling of a batch eight times larger"
+        ew["roofline"] = c5w["roof"]
+        line["secondary"] = {"c5w": ew}
+    return line
+
+
 def bench_sharded(args, gn, torch, dist, dev, rank, world, din, dout):
     """N > 1 (and --force-dist): BASELINE configs[4].  Default `--scaling strong`: the FIXED 4096-graph / 1M-edge batch (seed 5: the metric's
     "1M-edge batch") partitioned over the N ranks — the same graphs at every N, so the 1/2/4/8 curve is a scaling curve of ONE workload — with the
@@ -877,41 +1018,13 @@ def bench_sharded(args, gn, torch, dist, dev, rank, world, din, dout):
     if strong_default:
         torch.cuda.empty_cache()
         c5w = measure_sharded(gn, torch, dist, dev, rank, world, args, din, dout, 4096, 8_000_000, 5, K, W)
-    line = None
-    if rank == 0:
-        e = sharded_entry(res, K, world)
-        strong = args.scaling == "strong"
-        wl = (f"BASELINE configs[4]: ONE FIXED heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {world} GPU(s) — "
-              f"the same graphs at every N (strong scaling)" if strong else
-              f"ONE heterogeneous batch of {Gtot} random graphs (32-256 nodes, {Etot / 1e6:g}M edges, seed {seed}) sharded by graph over {world} GPU(s): {Gtot // world} graphs / "
-              f"~{Etot // world} edges per GPU at every N (weak scaling; BASELINE configs[4] law)")
-        line = {"metric": "edges updated/sec, GNBlock fwd, 1M-edge batch", "value": e["value"], "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W,
-                "ms_per_step": e["ms_per_step"], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": wl, "dims": f"{din}=>{dout}", "edges_whole_job": e["edges_whole_job"], "graphs_whole_job": e["graphs_whole_job"],
-                           "edges_per_gpu": res["E"], "nodes_per_gpu": res["N"], "graphs_per_gpu": res["G"], "per_rank_edges_nodes_graphs": e["per_rank_edges_nodes_graphs"],
-                           "parallelism": f"graph-sharded x{world}", "dist_backend": "torch (one process per GPU, RCCL all-gather of gf')",
-                           "launch": f"hipGraph of {res['M']} steps per replay over {res['nsets']} rotating buffer sets per rank; one RCCL all-gather of the {res['M']} stacked gf' tables per replay, on a side stream",
-                           "timing": f"median of 3 runs of the {K}-step region ({e['with_allgather']['reps_us_per_step']} us/step), MAX over ranks, after {CLOCK_WARMUP_MS:g} ms of the same load, untimed"},
-                "with_allgather": e["with_allgather"], "without_allgather": e["without_allgather"], "single_gpu_same_workload": e["single_gpu_same_workload"],
-                "roofline": res["roof"], "cpu_baseline": None}
-        if "speedup_vs_single_gpu_same_workload" in e:
-            line["speedup_vs_single_gpu_same_workload"] = e["speedup_vs_single_gpu_same_workload"]
-        if res["roof"] is not None:
-            ab = sum(algorithmic_bytes(c[0], c[1], c[2], din, dout) for c in res["per_rank"])
-            line["roofline"]["whole_job"] = {"algorithmic_bytes": ab, "achieved": round(ab / (res["dt"] / K) / 1e9, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                                             "frac": round(ab / (res["dt"] / K) / 1e9 / (HBM_PEAK_GBS * world), 4),
-                                             "counts": "algorithmic bytes of every rank's shard / whole-step time / (n_gpus x 8 TB/s); the kernel figures above are rank 0's shard"}
-        if c5w is not None:
-            ew = sharded_entry(c5w, K, world)
-            ew["what"] = "C5w (SURVEY 8e): the same 4096 graphs at configs[2]'s density — 8M edges — sharded over the same ranks; strong scaling of a batch eight times larger"
-            ew["roofline"] = c5w["roof"]
-            line["secondary"] = {"c5w": ew}
+    line = sharded_line(args, res, c5w, K, W, world, din, dout) if rank == 0 else None
     dist.barrier()
     dist.destroy_process_group()
     _flush_c_stdio()
     if rank == 0:
         time.sleep(0.5)  # the other ranks' (already flushed) output reaches the launcher's pipe first
-        print(json.dumps(line), flush=True)
+        emit(line, args, f"sharded_n{world}")
 
 
 def main():
@@ -936,6 +1049,8 @@ def main():
     ap.add_argument("--no-c-abi", action="store_true", help="skip the torch-free C program's leg (c_abi_ms_per_step)")
     ap.add_argument("--cpu-budget", type=float, default=None, help="seconds of CPU baseline sampling (default 3 at README dims, 12 at wide dims)")
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--full-line", action="store_true", help="print the WHOLE result as one JSON line (rounds 1-5's form; the secondary children and the tests of the detail fields use it) "
+                                                              "instead of the compact headline (< 3 KB) + gpurun_out/bench_detail_*.json")
     ap.add_argument("--dense-baseline", action="store_true",
                     help="also time the RESTATEMENT OF THE REFERENCE'S FORMULATION (padded one-hot batched matmuls, numpy/BLAS on the "
                          "host; BASELINE.md B2) on README ex.1 and on a 64-graph batch with PN <= 64")
@@ -1284,7 +1399,7 @@ def main():
     # group down and flushes C stdio first; rank 0 prints once the others are done.
     _flush_c_stdio()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line, args, "default" if headline and secondary is not None else "block")
 
 
 def _flush_c_stdio():

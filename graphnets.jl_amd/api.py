@@ -724,7 +724,10 @@ class LayerNorm:
 class _Prepared:
     """A layer's prepared parameters (`gnx_block_prepare` / `gnx_core_prepare`, include/gnx.h): the weight blocks in the forms the matrix-core
     kernels stage, made once — `model |> device` happens once in the reference (examples/sort/sort.jl:29,89).  The mirror remembers the
-    version counter of every tensor the planes were made from: a descriptor built after an in-place update (an optimiser step) refreshes them
+    version counter of EVERY parameter tensor of the layer (whatever subset the C side bakes into planes today): a descriptor built after an
+    in-place update (an optimiser step, a `copy_`, a partial `load_state_dict`) refreshes them first — also inside a gradient call, whose
+    autograd.Function.forward runs with grad mode off, so the version list is the one thing correctness rests on; writes through `tensor.data`
+    bypass the counter (torch's own caveat): call `prepare()` again after those
     first (`gnx_prepared_refresh`, stream-ordered with the forward that follows); tensors that were REPLACED make the planes unreachable (they
     are looked up by the weight pointers), i.e. the forward prepares per call again until `prepare()` is called anew."""
 
@@ -801,7 +804,7 @@ class GNBlock:
         p.oe, p.on, p.og = self.out_dims
         p.edgefn, p.nodefn, p.graphfn = self.edgefn._c(keep), self.nodefn._c(keep), self.graphfn._c(keep)
         q = getattr(self, "_prepared", None)
-        if q is not None and not (torch.is_grad_enabled() and any(t.requires_grad for t in q.tensors)):  # (a training step rewrites the weights between forwards: per-call preparation)
+        if q is not None:  # (a training step's in-place updates move the version counters of the tracked tensors: q.current() refreshes the planes first)
             p.prepared = q.current()
         return p
 
@@ -817,7 +820,9 @@ class GNBlock:
         h = C.c_void_p()
         with torch.cuda.device(dev):
             check(_lib.load().gnx_block_prepare(C.byref(p), torch.cuda.current_stream(dev).cuda_stream, C.byref(h)))
-        self._prepared = _Prepared(h, dev, [self.edgefn.weight], keep)
+        # every parameter the C side may bake into a plane is a source (the edge planes, the projections, the node planes of k_node_x6, the
+        # folded biases): an in-place change of ANY of them refreshes the planes (nodefn.weight alone used to go unnoticed)
+        self._prepared = _Prepared(h, dev, [t for l in (self.edgefn, self.nodefn, self.graphfn) for t in (l.weight, l.bias)], keep)
         return self
 
     def _trainable(self, tensors):
@@ -1063,7 +1068,7 @@ class GNCore:
             p.ff[i].fc1, p.ff[i].fc2 = ff[0]._c(keep), ff[1]._c(keep)
         p.eps, p.eps_mode = self.eps, self.eps_mode
         q = getattr(self, "_prepared", None)
-        if q is not None and not (torch.is_grad_enabled() and any(t.requires_grad for t in q.tensors)):  # (a training step rewrites the weights between forwards: per-call preparation)
+        if q is not None:  # (see GNBlock._c)
             p.prepared = q.current()
         return p
 
@@ -1078,10 +1083,9 @@ class GNCore:
         h = C.c_void_p()
         with torch.cuda.device(dev):
             check(_lib.load().gnx_core_prepare(C.byref(p), torch.cuda.current_stream(dev).cuda_stream, C.byref(h)))
-        src = [self.block.edgefn.weight] + [d.weight for ff in (self.ffwd.eff, self.ffwd.nff, self.ffwd.gff) for d in ff]
-        # (the one-launch form of the edge rows folds gn1 / gn2 of the edges and fc1's bias into its planes: they are sources too)
-        src += [self.gn1.edgeln.gamma, self.gn1.edgeln.beta, self.gn2.edgeln.gamma, self.gn2.edgeln.beta, self.ffwd.eff[0].bias]
-        self._prepared = _Prepared(h, dev, src, keep)
+        # every parameter of the core is a source: the block's weights (edge, projection AND node planes), the FeedForwards', and the LayerNorm
+        # scales / shifts and biases the one-launch form folds into its planes
+        self._prepared = _Prepared(h, dev, self._param_list(), keep)
         return self
 
     def _param_list(self):

@@ -380,10 +380,29 @@ cpu(d::Dense) = Dense(cpu(d.weight), cpu(d.bias), d.σ)
 ondevice(d::Dense) = ondevice(d.weight) && ondevice(d.bias)
 dense_c(d::Dense) = GnxDense(devptr(d.weight), devptr(d.bias), Int32(actcode(d.σ)), 0)      # device-resident layers only
 
+# A layer's prepared parameters (gnx_block_prepare / gnx_core_prepare): a mutable holder the layer struct CARRIES.  The handle dies with its
+# layer (finalizer), so it can neither leak nor be found again by a later layer at a recycled device address, and no global table (nor its
+# lock) exists.  C_NULL = not prepared: the forward then prepares per call.
+mutable struct Prepared
+    handle::Ptr{Cvoid}
+    function Prepared()
+        q = new(C_NULL)
+        finalizer(destroy!, q)
+        q
+    end
+end
+function destroy!(q::Prepared)
+    q.handle == C_NULL || ccall((:gnx_prepared_destroy, libgnx), Cint, (Ptr{Cvoid},), q.handle)
+    q.handle = C_NULL
+    nothing
+end
+
 struct GNBlock
     edgefn::Dense; nodefn::Dense; graphfn::Dense; dropout
     in::NTuple{3,Int}; out::NTuple{3,Int}
+    prep::Prepared
 end
+GNBlock(edgefn::Dense, nodefn::Dense, graphfn::Dense, dropout, in, out) = GNBlock(edgefn, nodefn, graphfn, dropout, in, out, Prepared())
 function GNBlock((in, out)::Pair; dropout=0)                          # src/gnblock.jl:47-61
     @assert any(in .> (0, 0, 0)); @assert any(out .> (0, 0, 0))
     (de, dn, dg), (oe, on, og) = in, out
@@ -393,23 +412,18 @@ gpu(m::GNBlock) = ondevice(m) ? m : prepare!(GNBlock(gpu(m.edgefn), gpu(m.nodefn
 cpu(m::GNBlock) = GNBlock(cpu(m.edgefn), cpu(m.nodefn), cpu(m.graphfn), m.dropout, m.in, m.out)
 
 # ---- prepared parameters (gnx_block_prepare / gnx_core_prepare): `model |> gpu` happens once (examples/sort/sort.jl:29,89), and so does the
-# split / transposition of the weight blocks for the matrix-core kernels.  The layers are immutable structs, so the objects live in a table
-# keyed by the device address of the layer's edge weights; EVERY upload goes through gpu(), which prepares anew and thereby replaces whatever
-# an earlier model at a recycled address left behind.  After an in-place update of the weights: refresh!(m).
-const PREPARED = Dict{UInt,Ptr{Cvoid}}()
-prepkey(m) = UInt(devptr(m isa GNBlock ? m.edgefn.weight : m.block.edgefn.weight))
-prepared_of(m) = ondevice(m) ? get(PREPARED, prepkey(m), C_NULL) : C_NULL
-function unprepare!(m)
-    q = pop!(PREPARED, prepkey(m), C_NULL)
-    q == C_NULL || check(ccall((:gnx_prepared_destroy, libgnx), Cint, (Ptr{Cvoid},), q))
-    m
-end
+# split / transposition of the weight blocks for the matrix-core kernels: gpu() prepares the layer it uploads, the handle lives in the layer's
+# own `prep` holder (above).  After an in-place update of ANY parameter (an optimiser step): refresh!(m) — the gradient rules do it themselves
+# at the start of every gradient call (ext/GraphNetsHIPChainRulesExt.jl), so a training loop never runs on stale planes.
+prepholder(m) = m isa GNBlock ? m.prep : m.block.prep                  # a core's object holds its block's planes too: one holder for both
+prepared_of(m) = ondevice(m) ? prepholder(m).handle : C_NULL
+unprepare!(m) = (destroy!(prepholder(m)); m)
 refresh!(m) = (q = prepared_of(m); q == C_NULL || check(ccall((:gnx_prepared_refresh, libgnx), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), q, STREAM[])); m)
 function prepare!(m::GNBlock)
     unprepare!(m)
     p = Ref(GnxBlockParams(m.in..., m.out..., dense_c(m.edgefn), dense_c(m.nodefn), dense_c(m.graphfn), C_NULL)); q = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:gnx_block_prepare, libgnx), Cint, (Ptr{GnxBlockParams}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), p, STREAM[], q))
-    PREPARED[prepkey(m)] = q[]
+    m.prep.handle = q[]
     m
 end
 ondevice(m::GNBlock) = ondevice(m.edgefn) && ondevice(m.nodefn) && ondevice(m.graphfn)
@@ -523,7 +537,7 @@ function prepare!(m::GNCore)                                           # the cor
     blk = GnxBlockParams(m.block.in..., m.block.out..., dense_c(m.block.edgefn), dense_c(m.block.nodefn), dense_c(m.block.graphfn), C_NULL)
     p = Ref(GnxCoreParams(blk, map(ln_c, m.gn1), map(ln_c, m.gn2), map(t -> GnxFfn(dense_c(t[1]), dense_c(t[2])), m.ffwd), 1f-5, Int32(0), C_NULL)); q = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:gnx_core_prepare, libgnx), Cint, (Ptr{GnxCoreParams}, Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), p, STREAM[], q))
-    PREPARED[prepkey(m)] = q[]
+    prepholder(m).handle = q[]
     m
 end
 core_c(m::GNCore) = GnxCoreParams(block_c(m.block), map(ln_c, m.gn1), map(ln_c, m.gn2), map(t -> GnxFfn(dense_c(t[1]), dense_c(t[2])), m.ffwd), 1f-5, Int32(0), prepared_of(m))

@@ -9,12 +9,14 @@
 # reference's training loop (/root/reference/examples/sort/sort.jl:122-132) calls these rrules, whose pullbacks are ONE gnx_block_backward /
 # gnx_core_backward each (deterministic, no atomics) — what the Python mirror's torch.autograd.Functions do (graphnets.jl_amd/api.py: _BlockFn,
 # _CoreFn; tests/test_gpu_backward.py checks them against float64 autograd of an independent restatement).
-# An optimiser step rewrites the weights in place: call `GraphNetsHIP.refresh!(layer)` (gnx_prepared_refresh) behind it when the layer was
-# prepared by gpu() — or train on layers that were never prepared (`GraphNetsHIP.unprepare!`): the forward then prepares per call.
+# An optimiser step rewrites the weights in place, and gpu() prepared the layers' weight planes once: every rule below therefore starts with
+# `refresh!(m)` (gnx_prepared_refresh, stream-ordered in front of the forward; a no-op for a layer that was never prepared) — the forward and
+# the pullback's recompute of ONE gradient call see the same, current planes.  Inference calls between optimiser steps on the same layer
+# objects still need `GraphNetsHIP.refresh!(layer)` (or `unprepare!`: the forward then prepares per call).
 module GraphNetsHIPChainRulesExt
 
 using GraphNetsHIP
-using GraphNetsHIP: GNBlock, GNCore, GNCoreList, Dense, LayerNorm, block_pullback, core_pullback, core_train, newdropout
+using GraphNetsHIP: GNBlock, GNCore, GNCoreList, Dense, LayerNorm, block_pullback, core_pullback, core_train, newdropout, refresh!
 import ChainRulesCore
 using ChainRulesCore: Tangent, NoTangent, ZeroTangent, unthunk
 
@@ -26,6 +28,7 @@ zero_or(ȳ, k) = (v = getproperty(ȳ, k); v isa ChainRulesCore.AbstractZero ? no
 
 # (m::GNBlock)(x)  (src/gnblock.jl:63-69): tangents of the three Dense layers and of the batched tuple's ef / nf / gf
 function ChainRulesCore.rrule(m::GNBlock, x::NamedTuple)
+    refresh!(m)
     y = m(x)
     function block_pb(ȳ_)
         ȳ = upstream(unthunk(ȳ_), y)
@@ -44,6 +47,7 @@ end
 # A gradient call is Flux's training mode: with GNCore(dims; dropout = p > 0) the FeedForwards' Dropout (gnfeedforward.jl:27-31) is applied —
 # gnx_core_forward_train with a fresh seed — and the pullback regenerates the same masks from it (gnx_core_backward_train).
 function ChainRulesCore.rrule(m::GNCore, x::NamedTuple)
+    refresh!(m)
     drop = newdropout(m)
     y = drop === nothing ? m(x) : core_train(m, x, drop)
     function core_pb(ȳ_)

@@ -137,35 +137,43 @@ def _check_strong_line(line, backend):
     assert c5w["value"] > line["value"]  # eight times the edges per launch: the larger batch runs closer to the roof
 
 
-@pytest.mark.timeout(900)
-def test_bench_force_dist_runs_the_multi_gpu_code_path():
-    """`bench.py --force-dist`: the N > 1 branch (configs[4]'s fixed 4096-graph batch sharded by the product's partitioner, hipGraphs of stacked
-    steps, RCCL all-gather on a side stream) with one rank, as its own process; the JSON line parses, names configs[4]'s workload, carries the same
-    batch on one GPU, the region with and without the collective, and C5w beside it."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "16", "--warmup", "2", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=850)
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("backend", ["torch", "gnx"])
+def test_bench_sharded_prints_the_compact_line_last(backend):
+    """What the driver's 8-GPU SCALE run will parse: `bench.py --gpus 1 --force-dist` (the N > 1 branch: configs[4]'s fixed 4096-graph batch sharded
+    by the product's partitioner, hipGraphs of stacked steps, RCCL all-gather on a side stream, one rank) and `--dist-backend gnx` (one process
+    driving the devices through gnx_dist_block_forward_steps; its without_allgather leg is GNX_FLAG_DIST_NO_GATHER), started as the driver starts
+    them (no --full-line).  The LAST stdout line is the compact headline — the contract's keys, roofline, the with / without-gather pair, the same
+    batch on one GPU and C5w as numbers, below 3 KB; the secondary line is prefixed; the whole line is in gpurun_out/bench_detail_*.json and names
+    configs[4]'s workload, the same batch on one GPU, the region with and without the collective, and C5w beside it."""
+    from tests.test_bench_line import check_compact
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "16", "--warmup", "2"]
+    cmd += ["--force-dist", "--no-cpu-baseline"] if backend == "torch" else ["--dist-backend", "gnx"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1100)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    _check_strong_line(line, "torch")
-    assert line["config"]["graphs_per_gpu"] == 4096 and line["roofline"]["kernel_us"] > 0
+    lines = out.stdout.strip().splitlines()
+    c = json.loads(lines[-1])
+    check_compact(c, 1)
+    assert c["steps"] == 16 and c["warmup"] == 2 and c["scaling"] == "strong"
+    assert c["config"]["edges_whole_job"] == 1_000_000 and c["config"]["graphs_whole_job"] == 4096 and "configs[4]" in c["config"]["workload"]
+    assert c["with_allgather_ms"] == c["ms_per_step"] and c["without_allgather_ms"] > 0 and c["single_gpu_same_workload_ms"] > 0
+    assert c["c5w"]["value"] > c["value"]
+    assert any(l.startswith("bench-secondary (not the result line): ") for l in lines[:-1])
+    with open(os.path.join(ROOT, c["detail"])) as f:
+        line = json.load(f)
+    _check_strong_line(line, backend)
+    if backend == "torch":
+        assert line["config"]["graphs_per_gpu"] == 4096 and line["roofline"]["kernel_us"] > 0 and c["roofline"]["kernel_us"] == line["roofline"]["kernel_us"]
 
 
 @pytest.mark.timeout(900)
-def test_bench_dist_backend_gnx_measures_the_same_fixed_batch():
-    """`bench.py --dist-backend gnx` (one process driving the devices through gnx_dist_block_forward_steps): the same fixed batch, the same fields;
-    its without_allgather leg is GNX_FLAG_DIST_NO_GATHER."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dist-backend", "gnx", "--steps", "16", "--warmup", "2"],
-                         capture_output=True, text=True, timeout=850)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    _check_strong_line(line, "gnx")
-    # weak scaling stays available: N x 512 graphs
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--scaling", "weak", "--steps", "16", "--warmup", "2", "--no-single-gpu-leg"],
+def test_bench_weak_scaling_stays_available():
+    """`--scaling weak`: N x 512 graphs (the per-GPU shard fixed); `--full-line` prints the whole line as rounds 1-5 did"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--scaling", "weak", "--steps", "16", "--warmup", "2", "--no-single-gpu-leg", "--full-line"],
                          capture_output=True, text=True, timeout=850)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["scaling"] == "weak" and line["config"]["graphs_per_gpu"] == 512 and line["single_gpu_same_workload"] is None
-
 
 def test_gnx_dist_c_entry_points_world_1(gn):
     """The sharded path through the C boundary (what the Julia shim binds): gnx_dist_partition, gnx_dist_create (ncclCommInitAll

@@ -126,6 +126,46 @@ def test_in_place_update_of_the_folded_layernorm_parameters_and_bias_is_picked_u
         U.assert_close(U.from_jl(got), r_, s_, name)
 
 
+def test_in_place_update_of_the_node_weights_alone_is_picked_up(gn):
+    """k_node_x6 stages planes made from nodefn.weight (4300 nodes: the six-term node update runs); a change of THAT tensor alone — frozen
+    edge weights, a partial load_state_dict — must refresh them, for a block and for a core, outside and inside a gradient call (whose
+    autograd.Function.forward runs with grad mode off: the mirror's version list is what the planes' freshness rests on)."""
+    import torch
+    rng = np.random.default_rng(9300)
+    dims = (128, 64, 32)
+    g = _batch(gn, rng)
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, 1, dims)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    # a block
+    pb = O.make_block_params(rng, dims, dims)
+    blk = U.block_from_params(gn, pb).prepare()
+    ya = blk(x)
+    with torch.no_grad():
+        blk.nodefn.weight.mul_(1.5)
+        blk.graphfn.bias.add_(0.25)
+    yb = blk(x)
+    assert not torch.equal(ya.nf, yb.nf) and torch.equal(ya.ef, yb.ef)
+    fresh = U.block_from_params(gn, dict(pb, Wn=pb["Wn"] * np.float32(1.5), bg=pb["bg"] + np.float32(0.25)))(x)
+    for a, b in zip((yb.ef, yb.nf, yb.gf), (fresh.ef, fresh.nf, fresh.gf)):
+        assert torch.equal(a, b)
+    # a core, the second forward inside a gradient call
+    p = O.make_core_params(rng, dims)
+    core = U.core_from_params(gn, p).prepare()
+    ya = core(x)
+    with torch.no_grad():
+        core.block.nodefn.weight.mul_(0.5)
+        core.gn1.nodeln.gamma.mul_(1.25)
+    for t in core.parameters():
+        t.requires_grad_(True)
+    yb = core(x)
+    assert yb.nf.requires_grad and not torch.equal(ya.nf, yb.nf.detach())
+    p2 = dict(p, ln1_n_gamma=p["ln1_n_gamma"] * np.float32(1.25))
+    p2["block"] = dict(p["block"], Wn=p["block"]["Wn"] * np.float32(0.5))
+    fresh = U.core_from_params(gn, p2)(x)
+    for a, b in zip((yb.ef, yb.nf, yb.gf), (fresh.ef, fresh.nf, fresh.gf)):
+        assert torch.equal(a.detach(), b)
+
+
 @pytest.mark.parametrize("dout", [(128, 64, 32), (3, 4, 5)])
 def test_prepared_block(gn, dout):
     """GNBlock (128,64,32) => (128,64,32) (edge block + both projection blocks) and => (3,4,5) (config 4's decoder: the narrow edge form)"""

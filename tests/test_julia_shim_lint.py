@@ -301,7 +301,7 @@ def test_the_chainrules_extension_wraps_the_pullbacks_the_shim_ships():
     assert len(re.findall(r"function ChainRulesCore\.rrule\(m::GNBlock", code)) == 1 and len(re.findall(r"function ChainRulesCore\.rrule\(m::GNCore", code)) == 1
     for name in re.search(r"using GraphNetsHIP: (.*)", code).group(1).split(","):
         name = name.strip()
-        assert re.search(r"(struct|function|^)\s*%s\b" % re.escape(name), shim, re.M), f"the extension imports {name}, which the shim does not define"
+        assert re.search(r"(struct|function|^)\s*%s(?![\w!])" % re.escape(name), shim, re.M), f"the extension imports {name}, which the shim does not define"
     fields = {"Dense": {"weight", "bias"}, "LayerNorm": {"γ", "β"}, "GNBlock": {"edgefn", "nodefn", "graphfn"}, "GNCore": {"block", "ffwd", "gn1", "gn2"}}
     for struct, want in fields.items():
         body = re.search(r"struct %s(?:\{[^}]*\})?[^\n]*\n(.*?)\nend" % struct, shim, re.S).group(1)
@@ -316,3 +316,23 @@ def test_the_chainrules_extension_wraps_the_pullbacks_the_shim_ships():
     opens = len(re.findall(r"^\s*(?:module|function|struct|if|for|while|let|begin|try)\b", code, re.M)) + len(re.findall(r"\bdo\b", code))
     assert opens == len(re.findall(r"^\s*end\b", code, re.M)), "unbalanced blocks in the extension"
     assert "ChainRulesCore.rrule" not in shim  # (no commented-out rule left in the module)
+    # a gradient call never runs on stale planes — each rule refreshes the layer's prepared parameters before its forward
+    for layer in ("GNBlock", "GNCore"):
+        body = re.search(r"function ChainRulesCore\.rrule\(m::%s, x::NamedTuple\)\n(.*?)\n    function " % layer, code, re.S).group(1)
+        assert body.lstrip().startswith("refresh!(m)"), f"the rrule of {layer} does not refresh the prepared planes first"
+
+
+def test_prepared_planes_live_in_a_holder_the_layer_carries():
+    """no address-keyed global table of prepared objects (stale entries at recycled device addresses, leaked device memory,
+    no lock) — the handle sits in a mutable `Prepared` holder that is a FIELD of the layer, destroyed by its finalizer; a core shares its block's."""
+    import re
+    shim = open(os.path.join(ROOT, "julia", "GraphNetsHIP.jl")).read()
+    code = "\n".join(l.split("#")[0] for l in shim.splitlines())
+    assert "PREPARED" not in code and "prepkey" not in code and not re.search(r"const \w+ = Dict\{UInt,Ptr\{Cvoid\}\}", code)
+    holder = re.search(r"mutable struct Prepared\n(.*?)\nend\n", code, re.S).group(1)
+    assert "handle::Ptr{Cvoid}" in holder and "finalizer(destroy!, q)" in holder
+    assert re.search(r"function destroy!\(q::Prepared\).*?gnx_prepared_destroy.*?q\.handle = C_NULL", code, re.S)
+    assert re.search(r"struct GNBlock\n.*?prep::Prepared\nend", code, re.S)
+    assert "prepholder(m) = m isa GNBlock ? m.prep : m.block.prep" in code
+    assert "prepared_of(m) = ondevice(m) ? prepholder(m).handle : C_NULL" in code
+    assert code.count("prepholder(m).handle = q[]") + code.count("m.prep.handle = q[]") == 2  # prepare!(::GNBlock), prepare!(::GNCore)

@@ -68,9 +68,11 @@ def from_jl(a):
 PARITY_LOG = {}  # label -> {tensor: (worst |diff| / (1e-5·S), plain max|diff| / max|ref|)}: written by the full-size tests, dumped by conftest.py
 
 
-def assert_close(got, ref, scale, what="", log=None):
+def assert_close(got, ref, scale, what="", log=None, normwise=None):
     """|got - ref| <= 1e-5 · scale elementwise.  `log`: a label under which the two summary figures of this comparison are recorded —
-    the worst ratio to that bound and the plain normwise error max|diff| / max|ref| (no scale involved) — for the session report."""
+    the worst ratio to that bound and the plain normwise error max|diff| / max|ref| (no scale involved) — for the session report.
+    `normwise` (default: on for the logged = full-size comparisons): ALSO assert the plain bound of BASELINE.json's "within 1e-5 fp32" with no
+    error scale in it — max|got - ref| <= 1e-5 · max|ref| over the tensor."""
     if ref is None:
         assert got is None, f"{what}: expected nothing"
         return
@@ -80,6 +82,9 @@ def assert_close(got, ref, scale, what="", log=None):
     if log is not None:
         PARITY_LOG.setdefault(log, {})[what] = (float(np.max(err / (RTOL * scale + 1e-30))), float(np.max(err) / max(float(np.max(np.abs(ref))), 1e-30)))
     assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} outside 1e-5·scale; worst ratio {np.max(err / (scale + 1e-30)):.3e}"
+    if (log is not None) if normwise is None else normwise:
+        d, m = (float(np.max(err)), float(np.max(np.abs(ref)))) if err.size else (0.0, 0.0)
+        assert d <= RTOL * m + 1e-30, f"{what}: max|diff| = {d:.3e} above the plain bound 1e-5 · max|ref| = {RTOL * m:.3e}"
 
 
 def assert_same_formula(a, b, what="", k=2e-6):
