@@ -99,6 +99,10 @@ class PendingUpdate(C.Structure):
     _fields_ = [("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("gf", _fp), ("gf_out", _fp)]
 
 
+class BlockStep(C.Structure):  # gnx_block_step: one step of gnx_block_forward_steps
+    _fields_ = [("ef", _fp), ("nf", _fp), ("gf", _fp), ("ef_out", _fp), ("nf_out", _fp), ("gf_out", _fp), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 class ProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double), ("kernels", C.c_int64)]
 
@@ -135,6 +139,7 @@ SIGNATURES = {
     "gnx_chain_block_backward": (C.c_int32, [C.c_void_p, C.POINTER(ChainBlockParams)] + [_fp] * 6 + [C.c_int64] + [_fp] * 3 +
                                  [C.POINTER(ChainBlockGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnx_block_forward_chained": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + _FWD[2:] + [C.POINTER(PendingUpdate), C.POINTER(PendingUpdate)]),
+    "gnx_block_forward_steps": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams), C.POINTER(BlockStep), C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]),
     "gnx_block_graph_update": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams), _fp, C.c_int64, _fp, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "gnx_block_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BlockParams), C.c_int64]),
     "gnx_block_backward": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + [_fp] * 9 + [C.c_int64] + [_fp] * 3 +

@@ -1284,6 +1284,18 @@ class BlockPlan:
                                                  ws.data_ptr(), ws.numel(), self.flags, s, C.byref(prev) if prev is not None else None, C.byref(pending)))
         return pending
 
+    def steps(self, sets, stream=None):
+        """`gnx_block_forward_steps`: a LOOP over batches as one call — `sets` is a sequence of dicts / tuples (ef, nf, gf, eo, no, go, ws), one per
+        step, in order.  Exactly `len(sets)` forwards (bit-identical outputs); where the two-launch narrow form runs, step i's graph update rides at
+        the front of step i + 1's launch and the last one is flushed inside the call: every output is complete when the enqueued work is.
+        Consecutive steps must use different workspaces and gf outputs to be chained (else the step simply runs unchained)."""
+        s = torch.cuda.current_stream(self.g.device).cuda_stream if stream is None else stream
+        arr = (_lib.BlockStep * max(len(sets), 1))()
+        for i, b in enumerate(sets):
+            ef, nf, gf, eo, no, go, ws = (b["ef"], b["nf"], b["gf"], *b["out"], b["ws"]) if isinstance(b, dict) else b
+            arr[i] = _lib.BlockStep(_ptr(ef), _ptr(nf), _ptr(gf), _ptr(eo), _ptr(no), _ptr(go), ws.data_ptr(), ws.numel())
+        check(self.lib.gnx_block_forward_steps(self.g._h, C.byref(self.p), arr, len(sets), self.R, self.flags, s))
+
     def flush(self, pending, stream=None):
         """finishes a pending graph update (one plain `gnx_block_graph_update` launch); no-op when nothing is pending"""
         if pending is None or not pending.workspace:

@@ -5,6 +5,7 @@
 #include <algorithm>
 
 #include "gnx_device.h"
+#include "gnx_x6_mma.h"
 
 namespace gnx {
 
@@ -26,7 +27,7 @@ __global__ void k_transpose_w(const float* __restrict__ W, int K, int J, float* 
 // panels (X[32][128], D[32][128], coalesced 16-B loads, next panel prefetched into registers during the MFMAs).  The MFMA
 // reduction index is the ROW: A fragment = X[row 2s+hi][k-col l31], B fragment = D[row 2s+hi][j-col l31] — both are
 // 32 consecutive floats of one LDS row per half-wave: conflict-free without padding.
-template <bool VEC4>
+template <bool VEC4, bool X6>  // X6 (the default form): six bf16 matrix-core terms per product, fragments split on the fly (gnx_x6_mma.h)
 __global__ __launch_bounds__(256) void k_dw_gemm(const float* __restrict__ X, int K, const float* __restrict__ D, int J, size_t rows, int CH,
                                                  float* __restrict__ partial) {
   constexpr int RC = 32;
@@ -77,6 +78,20 @@ __global__ __launch_bounds__(256) void k_dw_gemm(const float* __restrict__ X, in
     }
     __syncthreads();
     if (mb + RC < m1) load(mb + RC);
+    if constexpr (X6) {
+#pragma unroll
+      for (int s16 = 0; s16 < RC / 16; ++s16) {  // lane (l31, hi): rows 16 s16 + 8 hi .. + 7 of the panel, for both operands
+        X6Frag fa6[2], fb6[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa6[i] = x6_frag(sX + (16 * s16 + 8 * hi) * 128 + (wm * 2 + i) * 32 + l31, 128);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb6[j] = x6_frag(sD + (16 * s16 + 8 * hi) * 128 + (wn * 2 + j) * 32 + l31, 128);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = x6_mma(fa6[i], fb6[j], acc[i][j]);
+      }
+    } else
 #pragma unroll
     for (int sp = 0; sp < RC / 2; ++sp) {
       float fa[2], fb[2];
@@ -150,8 +165,13 @@ int32_t dw_mfma(const float* delta, const float* X, size_t rows, int J, int K, f
   const bool v4 = (((uintptr_t)delta | (uintptr_t)X) & 15) == 0 && J % 4 == 0 && K % 4 == 0;
   {
     ProfScope ps("k_dw_gemm", s);
-    if (v4) GNX_LAUNCH((k_dw_gemm<true>), grid, dim3(256), 0, s, X, K, delta, J, rows, CH, partial);
-    else GNX_LAUNCH((k_dw_gemm<false>), grid, dim3(256), 0, s, X, K, delta, J, rows, CH, partial);
+    if (form(GNX_FLAG_FP32_MFMA)) {  // (the backward's entry points carry no flags: the process-wide defaults decide; either bit selects the fp32 instruction)
+      if (v4) GNX_LAUNCH((k_dw_gemm<true, false>), grid, dim3(256), 0, s, X, K, delta, J, rows, CH, partial);
+      else GNX_LAUNCH((k_dw_gemm<false, false>), grid, dim3(256), 0, s, X, K, delta, J, rows, CH, partial);
+    } else {
+      if (v4) GNX_LAUNCH((k_dw_gemm<true, true>), grid, dim3(256), 0, s, X, K, delta, J, rows, CH, partial);
+      else GNX_LAUNCH((k_dw_gemm<false, true>), grid, dim3(256), 0, s, X, K, delta, J, rows, CH, partial);
+    }
   }
   const size_t KJ = (size_t)K * J;
   {

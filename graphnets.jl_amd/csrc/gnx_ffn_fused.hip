@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "gnx_device.h"
+#include "gnx_x6_mma.h"
 
 namespace gnx {
 
@@ -68,7 +69,7 @@ static __device__ unsigned long long* g_ffn_dbg = nullptr;  // [tile][8]
 #define GNX_FSTAMP(acc, t0) do { } while (0)
 #endif
 
-template <int D>
+template <int D, bool X6>  // X6 (the default form): every product as six bf16 matrix-core terms, fragments split on the fly (gnx_x6_mma.h); else v_mfma_f32_32x32x2f32
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k_ffn_fused(FfnArgs a) {
   constexpr int H = 4 * D;
   constexpr int LDA = FKC + 1;                 // z chunk row stride (odd: conflict-free A fragments)
@@ -190,6 +191,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
         // GEMM1: accH[32 x 32 per wave] += z chunk * W1 chunk     (wave rows 32*wm.., hidden columns 32*wn..)
         // fragments of k-step kk + 1 requested from LDS before the MFMA of step kk (pinned: left alone the compiler reads, waits, multiplies —
         // C4 6.38 -> 6.27 ms; s_setprio(1) around the matrix-core sections on top of it: 6.28 vs 6.25 ms, not kept)
+        if constexpr (X6) {
+#pragma unroll
+          for (int s16 = 0; s16 < FKC / 16; ++s16)
+            accH = x6_mma(x6_frag(sA + (wm * 32 + l31) * LDA + 16 * s16 + 8 * hi, 1), x6_frag(sB1 + (16 * s16 + 8 * hi) * FHS + wn * 32 + l31, FHS), accH);
+        } else {
         float fa1[2], fb1[2];
         fb1[0] = sB1[hi * FHS + wn * 32 + l31];
         fa1[0] = sA[(wm * 32 + l31) * LDA + hi];
@@ -202,6 +208,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
           }
           __builtin_amdgcn_sched_barrier(0);
           accH = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[c], fb1[c], accH, 0, 0, 0);
+        }
         }
         GNX_FSTAMP(fs_mma1, fs_t);
         if (st == NC1 - 1) {
@@ -229,6 +236,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
       } else {
         // GEMM2: accO[64 x D/2 per wave] += sH[:, 32-wide k range] * W2 chunk
         const int kb = (st - NC1) * FKC;
+        if constexpr (X6) {
+#pragma unroll
+          for (int s16 = 0; s16 < FKC / 16; ++s16) {
+            const X6Frag fa6 = x6_frag(sH + (wm * 32 + l31) * LDH + kb + 16 * s16 + 8 * hi, 1);
+#pragma unroll
+            for (int j = 0; j < TNO; ++j) accO[j] = x6_mma(fa6, x6_frag(sB2 + (16 * s16 + 8 * hi) * D + (wn * TNO + j) * 32 + l31, D), accO[j]);
+          }
+        } else {
         float fa2[2], fb2[2][TNO];
         fa2[0] = sH[(wm * 32 + l31) * LDH + kb + hi];
 #pragma unroll
@@ -244,6 +259,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int j = 0; j < TNO; ++j) accO[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa2[c], fb2[c][j], accO[j], 0, 0, 0);
+        }
         }
         GNX_FSTAMP(fs_mma2, fs_t);
       }
@@ -366,8 +382,14 @@ int32_t launch_ffn_fused(const gnx_graphs* h, int entity, const float* z, int d,
     (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ffn_dbg), &d_dbg, sizeof(d_dbg), 0, hipMemcpyHostToDevice, s);
   }
 #endif
-  if (d == 128) GNX_LAUNCH((k_ffn_fused<128>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
-  else GNX_LAUNCH((k_ffn_fused<64>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
+  // (the fp32 matrix instruction only where the call asks for it: profiles/r05_mfma_mix_hazard.log)
+  if (form(GNX_FLAG_FFN_FP32)) {
+    if (d == 128) GNX_LAUNCH((k_ffn_fused<128, false>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
+    else GNX_LAUNCH((k_ffn_fused<64, false>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
+  } else {
+    if (d == 128) GNX_LAUNCH((k_ffn_fused<128, true>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
+    else GNX_LAUNCH((k_ffn_fused<64, true>), dim3(n_tiles, (unsigned)R), dim3(512), 0, s, a);
+  }
   GNX_HIP(hipGetLastError());
 #ifdef GNX_FFN_STAMPS_BUILD
   if (stamps) {

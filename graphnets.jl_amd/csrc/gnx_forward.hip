@@ -241,6 +241,36 @@ int32_t gnx_block_forward_chained(const gnx_graphs* h, const gnx_block_params* p
   return block_forward_impl(h, p, ef, nf, gf, R, ef_out, nf_out, gf_out, ws, ws_bytes, flags, (hipStream_t)stream, 3);
 }
 
+int32_t gnx_block_forward_steps(const gnx_graphs* h, const gnx_block_params* p, const gnx_block_step* steps, int64_t n_steps, int64_t R, uint32_t flags,
+                                void* stream) {
+  if (n_steps < 0 || (n_steps > 0 && !steps)) return fail(GNX_ERR_INVALID_ARG, "gnx_block_forward_steps: steps is NULL / n_steps is negative");
+  if (flags & GNX_FLAG_DEFER_GRAPH_UPDATE) return fail(GNX_ERR_INVALID_ARG, "gnx_block_forward_steps finishes every step's graph update itself");
+  DeviceTurn turn((hipStream_t)stream, p && matrix_core_widths(*p));  // (one turn for the whole loop; the calls below nest inside it)
+  gnx_pending_update pend{};
+  auto flush = [&]() -> int32_t {
+    if (!pend.workspace) return GNX_OK;
+    const int32_t rc = gnx_block_graph_update(h, p, pend.gf, R, pend.gf_out, const_cast<void*>(pend.workspace), pend.workspace_bytes, flags, stream);
+    pend = gnx_pending_update{};
+    return rc;
+  };
+  for (int64_t i = 0; i < n_steps; ++i) {
+    const gnx_block_step& st = steps[i];
+    // a step that shares its predecessor's workspace / gf_out cannot start before that one's graph update has run
+    if (pend.workspace && (pend.workspace == st.workspace || (p && p->og > 0 && pend.gf_out == st.gf_out))) {
+      if (int32_t rc = flush()) return rc;
+    }
+    gnx_pending_update next{};
+    if (int32_t rc = gnx_block_forward_chained(h, p, st.ef, st.nf, st.gf, R, st.ef_out, st.nf_out, st.gf_out, st.workspace, st.workspace_bytes, flags, stream,
+                                               pend.workspace ? &pend : nullptr, &next)) {
+      // (an argument error of step i: what is pending belongs to step i - 1, whose arguments were valid — finish it, report the error)
+      (void)flush();
+      return rc;
+    }
+    pend = next;
+  }
+  return flush();
+}
+
 int32_t gnx_block_graph_update(const gnx_graphs* h, const gnx_block_params* p, const float* gf, int64_t R, float* gf_out, void* ws,
                                size_t ws_bytes, uint32_t flags, void* stream) {
   // the kernels of this phase read only gf, the graph function's parameters and the workspace

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "gnx_device.h"
+#include "gnx_x6_mma.h"
 
 namespace gnx {
 
@@ -132,6 +133,8 @@ struct WideArgs {
   int npk;
   int pd_lds;                  // gathered addends: every tile's destination rows fit the LDS table of the NL = 3 kernel (set by launch_block_wide from the handle's tile statistics)
   int stagger;                 // start delay per residency slot (units of 64*127 clocks), 0 = none (set by launch_gemm)
+  int fp32;                    // 1: the products on v_mfma_f32_32x32x2f32 — only where the CALL's flags ask (GNX_FLAG_EDGE_FP32 / _PROJ_FP32 / _EDGE_NARROW_FP32 /
+                               // _FFN_FP32: set by the callers from form()); 0, the default: six bf16 matrix-core terms per product (gnx_x6_mma.h)
   unsigned long long* stamps;  // diagnostic builds only (GNX_WIDE_STAMPS): [tile][8] shader-clock stamps of wave 0
 };
 
@@ -236,7 +239,7 @@ struct WaveLayout {
 #endif
 template <int BN, int NL, int LD>
 constexpr int gemm_wpe() { return (BN == 128 && NL == 0 && LD == 0) ? GNX_GEMM_WPE_PLAIN : WaveLayout<BN>::WPE; }
-template <int BN, bool VEC4, int KC, int NL, bool TRANS, int LD>
+template <int BN, bool VEC4, int KC, int NL, bool TRANS, int LD, bool X6>
 __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per_eu(gemm_wpe<BN, NL, LD>()))) void k_rows_gemm(WideArgs a) {
   using L = WaveLayout<BN>;
   constexpr int WT = L::WT;
@@ -689,6 +692,23 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
   // the matrix-core work of the chunk in LDS.  Fragments of k-step kk+1 are requested from LDS before the MFMAs of step kk are
   // issued (explicit two-deep register pipeline: left to itself the compiler places each ds_read right in front of its first use)
   auto mma_chunk = [&]() {
+    if constexpr (X6) {
+      // the DEFAULT form (gnx_x6_mma.h): the chunk's two 16-steps as six bf16 matrix-core terms each, the fp32 fragments split on the fly — the
+      // same LDS reads as the fp32 form below (eight per 16-step, row and fragment), 6 x 8-pass instead of 8 x 16-pass matrix instructions
+#pragma unroll
+      for (int s16 = 0; s16 < KC / 16; ++s16) {
+        X6Frag fa6[L::TM], fb6[L::TN];
+#pragma unroll
+        for (int i = 0; i < L::TM; ++i) fa6[i] = x6_frag(sA + ((i * L::WM + wm) * 32 + l31) * LDA + 16 * s16 + 8 * hi, 1);
+#pragma unroll
+        for (int j = 0; j < L::TN; ++j) fb6[j] = x6_frag(sB + (16 * s16 + 8 * hi) * BN + (wn * L::TN + j) * 32 + l31, BN);
+#pragma unroll
+        for (int i = 0; i < L::TM; ++i)
+#pragma unroll
+          for (int j = 0; j < L::TN; ++j) acc[i][j] = x6_mma(fa6[i], fb6[j], acc[i][j]);
+      }
+      return;
+    }
     float fa[2][L::TM], fb[2][L::TN];
 #pragma unroll
     for (int i = 0; i < L::TM; ++i) fa[0][i] = sA[((i * L::WM + wm) * 32 + l31) * LDA + hi];
@@ -1279,7 +1299,8 @@ static int32_t launch_gemm(const WideArgs& w, unsigned n_tiles, int64_t R, hipSt
   const bool trans = w.act > 1;
   // instantiations: quad outputs with the lean loader (every NL), quad outputs with the full loader and no operands (node update,
   // encoder), element outputs with the full loader (every NL; also takes the rare quad-output + full-loader + operands launches)
-#define GNX_GEMM_LAUNCH(V, N, T, F) GNX_LAUNCH((k_rows_gemm<BN, V, 32, N, T, F>), grid, dim3(WaveLayout<BN>::WT), 0, s, wa)
+#define GNX_GEMM_LAUNCH(V, N, T, F) do { if (wa.fp32) GNX_LAUNCH((k_rows_gemm<BN, V, 32, N, T, F, false>), grid, dim3(WaveLayout<BN>::WT), 0, s, wa); \
+                                         else GNX_LAUNCH((k_rows_gemm<BN, V, 32, N, T, F, true>), grid, dim3(WaveLayout<BN>::WT), 0, s, wa); } while (0)
 #define GNX_GEMM_LAUNCH_N(V, T, F) do { if (nl == 0) GNX_GEMM_LAUNCH(V, 0, T, F); else if (nl == 1) GNX_GEMM_LAUNCH(V, 1, T, F); else GNX_GEMM_LAUNCH(V, 2, T, F); } while (0)
   if (vec4 && ld == 0 && nl == 3) { if (trans) GNX_GEMM_LAUNCH(true, 3, true, 0); else GNX_GEMM_LAUNCH(true, 3, false, 0); }
   else if (vec4 && ld == 0) { if (trans) GNX_GEMM_LAUNCH_N(true, true, 0); else GNX_GEMM_LAUNCH_N(true, false, 0); }
@@ -1345,6 +1366,7 @@ int32_t launch_dense_rows(const gnx_graphs* h, int entity, const float* A, int K
   w.out = out; w.out_rep_stride = nrows * (size_t)OUT;
   w.colsum = nullptr;
   w.add1 = add1; w.add2 = add2;
+  w.fp32 = form(GNX_FLAG_FFN_FP32);
   const unsigned n_tiles = (unsigned)(entity == 0 ? h->n_etiles : (entity == 1 ? h->n_ntiles : h->n_gtiles));
   return launch_gemm_any(w, n_tiles, R, s, name);
 }
@@ -1370,6 +1392,7 @@ int32_t launch_rows_matmul(const gnx_graphs* h, int entity, const float* A, int 
   w.gmul = gmul; w.gmul_act = gmul_act;
   w.add1 = add1;  // optional residual with the layout of out (may alias it)
   w.colsum = tile_colsum; w.colsum_rep_stride = (size_t)n_tiles * OUT;
+  w.fp32 = form(GNX_FLAG_FP32_MFMA);  // (any of the two bits; the backward's entry points carry no flags: the process-wide defaults decide)
   if (n_tiles_out) *n_tiles_out = (int)n_tiles;
   return launch_gemm_any(w, n_tiles, R, s, name);
 }
@@ -1500,6 +1523,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     w.bias2 = a.be; w.bias_g2 = a.dg > 0 ? bias_e : nullptr; w.n_graphs = a.G;
     w.OUT = a.oe; w.act = GNX_ACT_IDENTITY;
     w.out = proj_s; w.out2 = proj_d; w.out_rep_stride = (size_t)a.N * a.oe;
+    w.fp32 = form(GNX_FLAG_EDGE_FP32 | GNX_FLAG_PROJ_FP32);
     if ((rc = launch_gemm_any(w, (unsigned)n_nt, R, s, "k_rows_gemm_proj"))) return rc;
   }
   // the projected edge update at 128 -> 128 as six bf16 matrix-core terms per fp32 product (gnx_edge_x6.hip)
@@ -1571,6 +1595,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     w.out = a.ef_out; w.out_rep_stride = (size_t)a.E * a.oe;
     w.colsum = a.og > 0 ? pe : nullptr; w.colsum_rep_stride = n_et * (size_t)a.oe;
     if (agg_fuse) { w.agg_out = agg_tab; w.agg_rep_stride = (size_t)h->n_agg_rows * a.oe; w.chunk_row0 = h->d_chunk_row0; }
+    w.fp32 = form(GNX_FLAG_EDGE_FP32) || (a.oe <= 32 && form(GNX_FLAG_EDGE_NARROW_FP32));
     if ((rc = launch_gemm_any(w, (unsigned)n_et, R, s, "k_rows_gemm_edge"))) return rc;
   }
   // the node update at core widths on the six-term scheme (k_node_x6: the summed in-edge rows from the edge kernel's per-destination partial sums);
@@ -1602,6 +1627,7 @@ int32_t launch_block_wide(const gnx_graphs* h, const BlockArgs& a, int64_t R, hi
     w.bias_g = a.dg > 0 ? bias_n : nullptr; w.n_graphs = a.G;
     w.out = a.nf_out; w.out_rep_stride = (size_t)a.N * a.on;
     w.colsum = a.og > 0 ? pn : nullptr; w.colsum_rep_stride = n_nt * (size_t)a.on;
+    w.fp32 = form(GNX_FLAG_EDGE_FP32 | GNX_FLAG_PROJ_FP32);
     if ((rc = launch_gemm_any(w, (unsigned)n_nt, R, s, "k_rows_gemm_node"))) return rc;
   }
   if ((phase & 2) && a.og > 0) {

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define GNX_VERSION 120 /* 0.1.2: training-mode Dropout (gnx_dropout, gnx_core_forward_train / _backward_train); 110: gnx_profile_entry is 72 bytes, per-call arithmetic flags, prepared parameters, GNX_FLAG_DIST_NO_GATHER */
+#define GNX_VERSION 130 /* 0.1.3: gnx_block_forward_steps; no default path on the fp32 matrix instruction; 120: training-mode Dropout (gnx_dropout, gnx_core_forward_train / _backward_train); 110: gnx_profile_entry is 72 bytes, per-call arithmetic flags, prepared parameters, GNX_FLAG_DIST_NO_GATHER */
 
 #if defined(__GNUC__)
 #define GNX_API __attribute__((visibility("default")))
@@ -268,6 +268,28 @@ typedef struct gnx_pending_update {
 GNX_API int32_t gnx_block_forward_chained(const gnx_graphs* h, const gnx_block_params* p, const float* ef, const float* nf, const float* gf,
                                   int64_t n_replicas, float* ef_out, float* nf_out, float* gf_out, void* workspace, size_t workspace_bytes,
                                   uint32_t flags, void* stream, const gnx_pending_update* prev, gnx_pending_update* pending);
+
+/* ---- a LOOP over batches as ONE call (round 6): what `for x in batches; y = block(x); end` is in a serving / evaluation loop over resident
+ * batches of the same graphs (examples/sort/sort.jl:99-108 walks its batches this way).  Exactly n_steps gnx_block_forward calls in order —
+ * the same kernels over the same rows, outputs bit-identical — but the library KNOWS the next step exists, so where the two-launch narrow
+ * form runs it uses the chained form above by itself: step i's graph update rides at the front of step i + 1's launch, the last step's is
+ * flushed before the call returns its work to the stream (ONE launch per step + one flush instead of two launches per step: 22.2 vs 25.1
+ * us/step on BASELINE configs[1]).  Every output of every step is complete once the work this call enqueued is complete.  Consecutive
+ * steps must not share a workspace or a gf_out (step i + 1 starts while step i's graph update is pending): a step that does share them with
+ * its predecessor is simply run unchained.  Other paths (matrix-core / generic kernels, batches of small graphs): n_steps plain forwards.
+ * Capture-safe like gnx_block_forward (bench.py captures K steps into one hipGraph). */
+typedef struct gnx_block_step {
+  const float* ef;
+  const float* nf;
+  const float* gf;
+  float* ef_out;
+  float* nf_out;
+  float* gf_out;
+  void* workspace;
+  size_t workspace_bytes; /* >= gnx_block_workspace_bytes */
+} gnx_block_step;
+GNX_API int32_t gnx_block_forward_steps(const gnx_graphs* h, const gnx_block_params* p, const gnx_block_step* steps, int64_t n_steps,
+                                int64_t n_replicas, uint32_t flags, void* stream);
 
 /* ---- GNBlock with Flux `Chain`s of Dense layers as update functions (src/gnblock.jl:1-6: edgefn / nodefn / graphfn are
  * arbitrary Chains; the constructor's default is Chain(Dense), which is what gnx_block_forward fuses).  widths[i] = output

@@ -26,7 +26,7 @@ export GNGraphBatch, batch, unbatch, getedgefninput, getnodefninput, getgraphfni
 # ... plus what the drop-in adds: layers as plain structs, pullbacks, the library-side hipGraph model, the multi-GPU split
 export Dense, LayerNorm, ChainBlock, chain_pullback, block_pullback, core_pullback, Model, partition_graphs, DistBlock
 # ... and device residency: `x |> batch |> gpu`, `model |> gpu`, `y |> cpu` (what Flux's `gpu` / `cpu` are to the reference)
-export DeviceArray, gpu, cpu, synchronize, chained, flush
+export DeviceArray, gpu, cpu, synchronize, chained, flush, steps
 
 const libgnx = get(ENV, "GNX_LIB", joinpath(@__DIR__, "..", "graphnets.jl_amd", "libgnx.so"))
 const libhip = get(ENV, "GNX_HIP_LIB", "libamdhip64.so")
@@ -494,6 +494,32 @@ function flush_device(m::GNBlock, y, pending::Pending)                  # finish
     y
 end
 flush(m::GNBlock, y, pending::Pending) = flush_device(gpu(m), y, pending)
+
+# ---- `map(m, xs)` over resident batches of the SAME graphs as ONE call (gnx_block_forward_steps): what `for x in batches; y = block(x); end`
+#      is in an evaluation loop (examples/sort/sort.jl:99-108).  The library chains the steps itself (one launch per step + one flush) and
+#      every output is complete when the enqueued work is; per-step workspaces alternate by parity like `chained`'s. ----
+struct GnxBlockStep
+    ef::Ptr{Cfloat}; nf::Ptr{Cfloat}; gf::Ptr{Cfloat}; ef_out::Ptr{Cfloat}; nf_out::Ptr{Cfloat}; gf_out::Ptr{Cfloat}; workspace::Ptr{Cvoid}; workspace_bytes::Csize_t
+end
+function steps_device(m::GNBlock, xs::AbstractVector)
+    isempty(xs) && return NamedTuple[]
+    g::GNGraphBatch = xs[1].graphs
+    @assert all(x -> x.graphs === g, xs)                              # one handle: batches of the same graphs
+    R = replicas(xs[1].ef, xs[1].nf, xs[1].gf)
+    (oe, on, og) = m.out
+    p = Ref(block_c(m))
+    wss = [workspace!(g, (:block_chained, m.in, m.out, R, parity)) do
+               ccall((:gnx_block_workspace_bytes, libgnx), Csize_t, (Ptr{Cvoid}, Ptr{GnxBlockParams}, Int64), g.handle, p, R)
+           end for parity in 0:1]
+    ys = [(graphs=g, ef=outarray(oe, nedges(g), R), nf=outarray(on, nnodes(g), R), gf=outarray(og, ngraphs(g), R)) for _ in xs]
+    recs = [GnxBlockStep(devptr(x.ef), devptr(x.nf), devptr(x.gf), devptr(y.ef), devptr(y.nf), devptr(y.gf), wss[1 + (i - 1) % 2].ptr, wss[1 + (i - 1) % 2].cap)
+            for (i, (x, y)) in enumerate(zip(xs, ys))]
+    GC.@preserve m xs ys wss recs check(ccall((:gnx_block_forward_steps, libgnx), Int32,
+        (Ptr{Cvoid}, Ptr{GnxBlockParams}, Ptr{GnxBlockStep}, Int64, Int64, UInt32, Ptr{Cvoid}),
+        g.handle, p, recs, length(recs), R, UInt32(0), STREAM[]))
+    ys
+end
+steps(m::GNBlock, xs::AbstractVector) = steps_device(gpu(m), map(gpu, xs))
 
 # ---- GNCore (src/gncore.jl:46-68): core(x) = x + block(gn1(x)) + ffwd(gn2(x)) → gnx_core_forward ----
 struct LayerNorm{V}                                                    # Flux.LayerNorm(d): diag scale γ, bias β

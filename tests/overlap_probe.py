@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Are the library's DEFAULT forms independent of what else runs on the GPU?  (profiles/r05_mfma_mix_hazard.log.)
+
+Round 5: kernels on v_mfma_f32_32x32x2f32 (k_rows_gemm, k_ffn_fused, k_dw_gemm) lost one pass of one instruction now and then while a dense bf16
+matrix kernel ran on ANOTHER stream.  Round 6: no default path issues that instruction (csrc/gnx_x6_mma.h).  This probe runs with the library's own
+turn-taking OFF (GNX_ALLOW_OVERLAP=1 — set it in the environment of this process) and checks, bit for bit against serial one-stream results:
+
+  (i)  a GNCore(128,64,32) forward + backward loop (small batch: the general kernels; big batch: >= 4096 nodes, the six-term kernels proper) on one
+       stream while a torch bf16 GEMM loop (2048^3, hipBLASLt) runs on another stream of the same device;
+  (ii) two captured hipGraphs of default-form forwards (two handles of the same batch) replayed concurrently on two streams.
+
+python tests/overlap_probe.py [forms=default|fp32] [iters=40] [big=0|1]      -> one JSON line with the mismatch counts"""
+import json
+import os
+import sys
+import threading
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+forms = sys.argv[1] if len(sys.argv) > 1 else "default"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+big = len(sys.argv) > 3 and sys.argv[3] == "1"
+
+import torch  # noqa: E402
+
+import graphnets_jl_amd as gn  # noqa: E402
+from oracle import gn_oracle as O  # noqa: E402  (parameter shapes only)
+from tests import util as U  # noqa: E402
+
+F = gn._lib
+flags = F.FLAG_FP32_MFMA if forms == "fp32" else 0
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+rng = np.random.default_rng(6100)
+dims = (128, 64, 32)
+sizes = ((3000, 40000), (1500, 16000)) if big else ((900, 12000), (300, 2500))
+graphs = [U.er_csc(rng, n, e) for n, e in sizes]
+mk_batch = lambda: gn.GNGraphBatch.from_csc([c for c, _ in graphs], [r for _, r in graphs], [n for n, _ in sizes])
+g = mk_batch()
+p = O.make_core_params(rng, dims)
+core = U.core_from_params(gn, p)
+core.flags = flags
+packed = [U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, dims) for _ in range(3)]
+
+
+def fwd_bwd(x_np):
+    """forward + backward of sum(y * w): returns (ef, nf, gf, and every gradient) as one tuple of tensors"""
+    x = U.to_nt(gn, g, *x_np)
+    leaves = [t.detach().clone().requires_grad_(True) for t in (x.ef, x.nf, x.gf)]
+    for t in core.parameters():
+        t.requires_grad_(True)
+        t.grad = None
+    y = core(gn.NT(g, *leaves))
+    loss = (y.ef * 0.5).sum() + (y.nf * 0.25).sum() + y.gf.sum()
+    loss.backward()
+    return tuple(t.detach().clone() for t in (y.ef, y.nf, y.gf)) + tuple(t.grad.clone() for t in leaves) + tuple(t.grad.clone() for t in core.parameters())
+
+
+ref = [fwd_bwd(x) for x in packed]
+torch.cuda.synchronize()
+stop = threading.Event()
+bad_fb, n_fb = [], [0]
+
+
+def victim():
+    torch.cuda.set_device(0)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for it in range(iters):
+            k = it % len(packed)
+            out = fwd_bwd(packed[k])
+            st.synchronize()
+            n_fb[0] += 1
+            wrong = [i for i, (a, b) in enumerate(zip(out, ref[k])) if not torch.equal(a, b)]
+            if wrong:
+                bad_fb.append((it, wrong[:6]))
+    stop.set()
+
+
+def aggressor():
+    torch.cuda.set_device(0)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        X = torch.randn(2048, 2048, device=dev).to(torch.bfloat16)
+        while not stop.is_set():
+            X = (X @ X).clamp_(-1, 1)
+            st.synchronize()
+
+
+ts = [threading.Thread(target=victim), threading.Thread(target=aggressor)]
+[t.start() for t in ts]
+[t.join() for t in ts]
+
+# (ii) two captured graphs of the forward, one handle each (a handle's workspace is per handle), replayed on two streams at once
+for t in core.parameters():
+    t.requires_grad_(False)
+g2 = [mk_batch(), mk_batch()]
+caps, refs2 = [], []
+for i, gi in enumerate(g2):
+    x = U.to_nt(gn, gi, *packed[i])
+    yi = core(x)
+    refs2.append(tuple(t.clone() for t in (yi.ef, yi.nf, yi.gf)))
+    caps.append(gn.Graphed(core, x))
+torch.cuda.synchronize()
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+bad_graphs = 0
+for it in range(iters):
+    for st, c in zip(streams, caps):
+        with torch.cuda.stream(st):
+            c.graph.replay()
+    torch.cuda.synchronize()
+    for c, r in zip(caps, refs2):
+        if not all(torch.equal(a, b) for a, b in zip((c._out.ef, c._out.nf, c._out.gf), r)):
+            bad_graphs += 1
+print(json.dumps({"forms": forms, "big": big, "overlap_allowed": os.environ.get("GNX_ALLOW_OVERLAP", "0"), "forward_backward_runs": n_fb[0],
+                  "forward_backward_wrong": len(bad_fb), "first_wrong": bad_fb[:3], "graph_replay_pairs": iters, "graph_replays_wrong": bad_graphs}))

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/gnx.h but not exported by libgnx.so"
     assert set(names) == set(gn._lib.SIGNATURES), "python binding and header disagree"
-    assert lib.gnx_version() == 120
+    assert lib.gnx_version() == 130
     # ... and with the same number of parameters (ctypes would only notice at call time)
     with open(os.path.join(ROOT, "include", "gnx.h")) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)

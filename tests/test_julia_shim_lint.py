@@ -104,7 +104,7 @@ def test_the_shim_binds_the_entry_points_of_the_hot_path_and_its_neighbours():
     for name in ("gnx_graphs_create_dense_packed", "gnx_graphs_create_csc_cat", "gnx_block_prepare", "gnx_core_prepare", "gnx_prepared_refresh", "gnx_block_forward", "gnx_core_forward", "gnx_fn_input", "gnx_block_backward",
                  "gnx_core_backward", "gnx_core_forward_train", "gnx_core_backward_train", "gnx_chain_block_forward", "gnx_chain_block_backward", "gnx_model_create", "gnx_model_forward",
                  "gnx_dist_partition", "gnx_dist_create", "gnx_dist_block_forward", "gnx_dist_block_forward_steps", "gnx_dist_destroy", "gnx_collapse_edges",
-                 "gnx_collapse_padded", "gnx_block_forward_chained", "gnx_block_graph_update"):
+                 "gnx_collapse_padded", "gnx_block_forward_chained", "gnx_block_forward_steps", "gnx_block_graph_update"):
         assert name in bound, f"the Julia shim does not bind {name}"
 
 
@@ -112,7 +112,7 @@ STRUCT_MIRRORS = {"GnxDense": _lib.Dense, "GnxBlockParams": _lib.BlockParams, "G
                   "GnxFfn": _lib.Ffn, "GnxCoreParams": _lib.CoreParams, "GnxDenseGrad": _lib.DenseGrad, "GnxBlockGrads": _lib.BlockGrads,
                   "GnxChain": _lib.Chain, "GnxChainBlockParams": _lib.ChainBlockParams, "GnxChainBlockGrads": _lib.ChainBlockGrads,
                   "GnxLayer": _lib.Layer, "GnxLayerNormGrad": _lib.LayerNormGrad, "GnxFfnGrad": _lib.FfnGrad, "GnxCoreGrads": _lib.CoreGrads,
-                  "GnxPendingUpdate": _lib.PendingUpdate, "GnxDropout": _lib.Dropout}
+                  "GnxPendingUpdate": _lib.PendingUpdate, "GnxBlockStep": _lib.BlockStep, "GnxDropout": _lib.Dropout}
 
 
 def julia_structs():
@@ -236,7 +236,7 @@ def _reachable(fns, roots):
     return seen
 
 
-DEVICE_PATH = ("block_device", "core_device", "chain_device", "model_device", "dist_device", "dist_steps_device", "chained_device", "flush_device",
+DEVICE_PATH = ("block_device", "core_device", "chain_device", "model_device", "dist_device", "dist_steps_device", "chained_device", "flush_device", "steps_device",
                "fninput_device", "collapsef_device", "block_pullback_device", "core_pullback_device", "chain_pullback_device")
 
 
