@@ -5,9 +5,12 @@
 
 A "step" is one GNBlock forward (edge + node + graph update) over one resident batch.
   N = 1 : BASELINE configs[1] — one shared Erdős–Rényi graph, 100k nodes / 1M edges, batch_size 1.  The K timed steps
-          are captured into ONE hipGraph (the step is ~20 µs of GPU work; eager launches from Python would time the
-          host) and rotate over NSETS disjoint buffer sets so the footprint (>256 MiB) defeats the Infinity Cache:
-          `value` is a cache-cold, HBM-resident number.  `warm_ms_per_step` (two buffer sets, cache-resident) is extra.
+          are ONE gnx_block_forward_steps call (the library's loop over batches: K forwards in order, step i's graph update at the
+          front of step i + 1's launch, the last one flushed inside the call) captured into ONE hipGraph (the step is ~20 µs
+          of GPU work; eager launches from Python would time the host) and rotate over NSETS disjoint buffer sets so the
+          footprint (>256 MiB) defeats the Infinity Cache: `value` is a cache-cold, HBM-resident number.  `two_launch_form`:
+          the same K steps as K separate gnx_block_forward calls (rounds 1-5's headline form; `--separate-calls` makes it the
+          timed form).  `warm_ms_per_step` (two buffer sets, cache-resident) is extra.
   N > 1 : BASELINE configs[4], STRONG scaling of ONE FIXED batch: the 4096-graph heterogeneous batch (32..256 nodes, 1M edges, seed 5 — the
           metric's "1M-edge batch") is sharded BY GRAPH over the N ranks with the product's partitioner (equal graph counts, snake order by
           edge count: graphnets.jl_amd/dist.py); every rank builds the handle of its own 4096/N graphs; graphs never cross ranks; the only
@@ -511,7 +514,7 @@ def compact_line(line, detail_path=None):
         c["dist_backend"] = _short(cfg["dist_backend"], 24)
     out["config"] = c
     if isinstance(roof, dict):
-        r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "frac_whole_step", "algorithmic_bytes", "kernel", "kernel_us", "executed_flops", "matrix_roof_frac"))
+        r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "frac_whole_step", "frac_whole_step_two_launch", "algorithmic_bytes", "kernel", "kernel_us", "executed_flops", "matrix_roof_frac"))
         r["traffic"] = roof.get("traffic")  # (null stays null: the contract names the key)
         wj = roof.get("whole_job")
         if isinstance(wj, dict):
@@ -704,18 +707,20 @@ def load_traffic(dims_key, kernel, sha):
     return t.get(kernel, {}).get("hbm_bytes_per_launch"), src
 
 
-def block_roofline(gn, torch, dev, plan, sets, nsets, K, E, N, G, din, dout, ms_per_step, dims_key, headline_traffic_breakdown=False):
+def block_roofline(gn, torch, dev, plan, sets, nsets, K, E, N, G, din, dout, ms_per_step, dims_key, headline_traffic_breakdown=False, steps_form=False):
     """`roofline` of one GNBlock forward: the same K steps again, eagerly, with dispatch timestamps on every launch (gnx_profile_*), at settled
-    clocks; the dominant kernel's average duration prices the block's ALGORITHMIC bytes (or its executed flops where the matrix cores bind)."""
+    clocks; the dominant kernel's average duration prices the block's ALGORITHMIC bytes (or its executed flops where the matrix cores bind).
+    `steps_form`: the K steps as ONE gnx_block_forward_steps call (the form the headline times) instead of K gnx_block_forward calls."""
     def eager_pass():
+        if steps_form:
+            plan.steps([sets[i % nsets] for i in range(K)])
+            return
         for i in range(K):
             b = sets[i % nsets]
             plan(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"])
     spin_up(torch, dev, eager_pass)  # the pass below runs at settled clocks, like the timed region
     gn.profile_reset(); gn.profile_enable(True)
-    for i in range(K):
-        b = sets[i % nsets]
-        plan(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"])
+    eager_pass()
     gn.profile_calibrate(K, torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize(dev)
     gn.profile_enable(False)
@@ -831,8 +836,7 @@ def single_gpu_same_workload(gn, torch, dev, seed, Gtot, Etot, din, dout, K, W, 
     torch.cuda.synchronize(dev)
     cg = torch.cuda.CUDAGraph()
     with torch.cuda.graph(cg):
-        for i in range(K):
-            step(i)
+        plan.steps([sets[i % nsets] for i in range(K)])  # gnx_block_forward_steps: the K steps as one call (the N = 1 headline's form)
     cg.replay(); torch.cuda.synchronize(dev)
     spin_up(torch, dev, cg.replay)
     reps = []
@@ -907,9 +911,8 @@ def measure_sharded(gn, torch, dist, dev, rank, world, args, din, dout, Gtot, Et
     cgs = []
     for base in range(0, min(K, nsets * M), M):  # enough distinct graphs to keep rotating over all buffer sets
         cg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cg):
-            for m in range(M):
-                step(base + m, m)
+        with torch.cuda.graph(cg):  # the M steps as ONE gnx_block_forward_steps call (every gf' table complete when the graph's work is)
+            plan.steps([(b["ef"], b["nf"], b["gf"], b["out"][0], b["out"][1], gf_stack[m:m + 1, :G], b["ws"]) for m, b in ((m, sets[(base + m) % nsets]) for m in range(M))])
         cgs.append(cg)
     copied = torch.cuda.Event()
 
@@ -986,7 +989,7 @@ def sharded_line(args, res, c5w, K, W, world, din, dout):
             "config": {"workload": wl, "dims": f"{din}=>{dout}", "edges_whole_job": e["edges_whole_job"], "graphs_whole_job": e["graphs_whole_job"],
                        "edges_per_gpu": res["E"], "nodes_per_gpu": res["N"], "graphs_per_gpu": res["G"], "per_rank_edges_nodes_graphs": e["per_rank_edges_nodes_graphs"],
                        "parallelism": f"graph-sharded x{world}", "dist_backend": "torch (one process per GPU, RCCL all-gather of gf')",
-                       "launch": f"hipGraph of {res['M']} steps per replay over {res['nsets']} rotating buffer sets per rank; one RCCL all-gather of the {res['M']} stacked gf' tables per replay, on a side stream",
+                       "launch": f"hipGraph of one gnx_block_forward_steps call ({res['M']} steps) per replay over {res['nsets']} rotating buffer sets per rank; one RCCL all-gather of the {res['M']} stacked gf' tables per replay, on a side stream",
                        "timing": f"median of 3 runs of the {K}-step region ({e['with_allgather']['reps_us_per_step']} us/step), MAX over ranks, after {CLOCK_WARMUP_MS:g} ms of the same load, untimed"},
             "with_allgather": e["with_allgather"], "without_allgather": e["without_allgather"], "single_gpu_same_workload": e["single_gpu_same_workload"],
             "roofline": res["roof"], "cpu_baseline": None}
@@ -1057,6 +1060,8 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="two-phase steps: graph update of step i on a second stream (measured SLOWER inside a hipGraph: the "
                          "fork/join costs more than the 5 us it hides — 35.7 vs 27.7 us/step — so it is off by default)")
+    ap.add_argument("--separate-calls", action="store_true",
+                    help="N = 1: time K separate gnx_block_forward calls (two launches per step; rounds 1-5's headline form) instead of ONE gnx_block_forward_steps call")
     ap.add_argument("--force-dist", action="store_true", help="run the N > 1 code path even with one rank (testing)")
     ap.add_argument("--dist-backend", choices=["torch", "gnx"], default="torch",
                     help="torch: one process per GPU, gf' all-gathered by torch.distributed's RCCL (the contract's launch form; default).  gnx: ONE process "
@@ -1255,16 +1260,38 @@ def main():
                 step(i if rotate else (i & 1), overlap=args.overlap)  # warm: 2 sets (120 MB, cache-resident)
             torch.cuda.current_stream(dev).wait_stream(side)  # join: every graph update is inside the timed region
         return cg
-    cold = capture(K, True)
+    # The headline form (round 6): the K steps as ONE gnx_block_forward_steps call — the library's own loop over batches: K forwards in order,
+    # bit-identical outputs (tests/test_gpu_block.py), and because it knows the next step exists, step i's graph update rides at the front of
+    # step i + 1's launch (one launch per step + one flush INSIDE the call, i.e. inside the timed region).  K separate gnx_block_forward calls
+    # (two launches per step) are timed beside it: `two_launch_form`.
+    steps_form = not args.overlap and not args.separate_calls
+
+    def capture_steps(nsteps, rotate):
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            plan.steps([sets[(i if rotate else (i & 1)) % nsets] for i in range(nsteps)])
+        return cg
+    two_launch = None
+    cold = capture_steps(K, True) if steps_form else capture(K, True)
     cold.replay(); torch.cuda.synchronize(dev)
     spin_up(torch, dev, cold.replay)
     reps = sorted(timed(cold.replay) for _ in range(3))
     dt = reps[1]
-    warm = capture(K, False)
+    if steps_form:
+        sep = capture(K, True)
+        sep.replay(); torch.cuda.synchronize(dev)
+        spin_up(torch, dev, sep.replay, 50.0)
+        reps_sep = sorted(timed(sep.replay) for _ in range(3))
+        two_launch = {"ms_per_step": round(reps_sep[1] / K * 1e3, 6), "value": round(E / (reps_sep[1] / K), 1), "unit": "edges/s", "steps": K,
+                      "reps_us_per_step": [round(r / K * 1e6, 2) for r in reps_sep],
+                      "what": f"the same {K} steps as {K} separate gnx_block_forward calls in one hipGraph (two launches per step: block kernel + graph update); rounds 1-5's headline form"}
+        del sep
+    warm = capture_steps(K, False) if steps_form else capture(K, False)
     warm.replay(); torch.cuda.synchronize(dev)
     spin_up(torch, dev, warm.replay, 50.0)
     extra["warm_ms_per_step"] = round(sorted(timed(warm.replay) for _ in range(3))[1] / K * 1e3, 6)
-    extra["launch"] = (f"hipGraph of {K} steps, {nsets} rotating buffer sets (cache-cold); " +
+    extra["launch"] = ((f"gnx_block_forward_steps: {K} steps in one call, one launch per step (step i's graph update at the front of step i+1's launch) + one flush, captured in one hipGraph; "
+                        if steps_form else f"hipGraph of {K} gnx_block_forward calls; ") + f"{nsets} rotating buffer sets (cache-cold); " +
                        ("single stream" if not args.overlap else "graph update of step i on a 2nd stream, overlapping step i+1 (joined inside the timed region)"))
     # NOT the headline: the same K steps as TWO hipGraphs (even / odd steps) replayed on two streams.  The steps are independent batches
     # (different buffer sets), so a serving loop would pipeline them: step i's graph-update launch (~4 us of latency on 83 KB) runs under
@@ -1295,7 +1322,7 @@ def main():
     # NOT the headline either: the chained form (gnx_block_forward_chained) — step i's launch carries step i - 1's graph update in
     # workgroups at its front, so a loop over batches is ONE launch per step (opt-in: gf' of a step is complete one call later or after
     # the flush).  Bit-identical outputs (tests/test_gpu_block.py::test_chained_forward...).
-    if not args.overlap and og > 0:
+    if not args.overlap and og > 0 and not steps_form:
         def capture_chained():
             cgc = torch.cuda.CUDAGraph()
             with torch.cuda.graph(cgc):
@@ -1325,7 +1352,9 @@ def main():
         if workload != "c2" and args.hetero_edges != 1_000_000:
             dims_key += f"_{args.hetero_edges}"  # the committed PMC profiles are of the 1M-edge batches: no traffic figure for another size
         roof = block_roofline(gn, torch, dev, plan, sets, nsets, K, E, N, G, din, dout, ms_per_step, dims_key,
-                              headline_traffic_breakdown=(workload == "c2" and args.dims == "readme" and args.c2_scale == 1.0))
+                              headline_traffic_breakdown=(workload == "c2" and args.dims == "readme" and args.c2_scale == 1.0), steps_form=steps_form)
+        if two_launch is not None and roof.get("bound") == "hbm" and "algorithmic_bytes" in roof:
+            roof["frac_whole_step_two_launch"] = round(roof["algorithmic_bytes"] / (two_launch["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
 
     # ---- CPU baseline: the oracle's C restatement ("port") on the host cores, rank 0, N = 1 only ----
     cpu = None
@@ -1386,6 +1415,8 @@ def main():
                                  "batch_ms": c_abi.get("batch_ms"), "steps": c_abi.get("steps"), "program": "tests/c/abi_bench.c --mode block"}
             else:
                 line["c_abi_ms_per_step"], line["c_abi"] = None, c_abi
+        if two_launch is not None:
+            line["two_launch_form"] = two_launch
         if pipelined is not None:
             line["pipelined_two_streams"] = pipelined
         if chained is not None:

@@ -34,7 +34,10 @@ class GraphsInfo(C.Structure):
 
 
 class Dense(C.Structure):
-    _fields_ = [("weight", _fp), ("bias", _fp), ("act", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("weight", _fp), ("bias", _fp), ("act", C.c_int32), ("kind", C.c_int32)]  # kind: LAYER_DENSE, or LAYER_LAYERNORM inside a Chain (weight = gamma, bias = beta)
+
+
+LAYER_DENSE, LAYER_LAYERNORM, LAYER_LN_SQRT_EPS = 0, 1, 0x100
 
 
 class BlockParams(C.Structure):
@@ -140,6 +143,7 @@ SIGNATURES = {
                                  [C.POINTER(ChainBlockGrads), C.c_void_p, C.c_size_t, C.c_void_p]),
     "gnx_block_forward_chained": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + _FWD[2:] + [C.POINTER(PendingUpdate), C.POINTER(PendingUpdate)]),
     "gnx_block_forward_steps": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams), C.POINTER(BlockStep), C.c_int64, C.c_int64, C.c_uint32, C.c_void_p]),
+    "gnx_row_stats": (C.c_int32, [_fp, C.c_int64, C.c_int32, C.c_float, C.c_int32, _fp, C.c_void_p]),
     "gnx_block_graph_update": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams), _fp, C.c_int64, _fp, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]),
     "gnx_block_backward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(BlockParams), C.c_int64]),
     "gnx_block_backward": (C.c_int32, [C.c_void_p, C.POINTER(BlockParams)] + [_fp] * 9 + [C.c_int64] + [_fp] * 3 +

@@ -653,6 +653,8 @@ class Dense:
         return _lib.Dense(w.data_ptr() if w.numel() else None, None if b is None or b.numel() == 0 else b.data_ptr(),
                           _lib.ACT[self.act], 0)
 
+    _c_layer = _c  # as an entry of a Chain (gnx_chain.layers)
+
 
 class Dropout:
     """Flux `Dropout(p)` as a layer value: what ends a FeedForward chain (gnfeedforward.jl:27-31) and what `GNBlock` keeps in its `dropout`
@@ -675,13 +677,15 @@ class Chain:
       * `"identity"` / `None` is dropped;
       * `Dropout(p)` is the identity in test mode and dropped; a differentiable call of a block whose chains hold a Dropout with p > 0 is refused
         (the training-mode Dropout of this library is the FeedForward's: GNCore(dims; dropout)).
-    Anything else (LayerNorm, BatchNorm, SkipConnection, closures) raises NotImplementedError: wrap such layers outside the block."""
+      * a `LayerNorm(d)` layer value normalises the rows of the layer in front of it (`Chain(Dense(a => d, relu), LayerNorm(d), Dense(d => b))`):
+        a row-wise launch of its own, differentiable (gamma / beta gradients); anywhere but as the EDGE function's first layer.
+    Anything else (BatchNorm, SkipConnection, closures) raises NotImplementedError: wrap such layers outside the block."""
 
     def __init__(self, *layers):
         given = list(layers[0]) if len(layers) == 1 and isinstance(layers[0], (list, tuple)) else list(layers)
         self.layers, self.dropout_p = [], 0.0
         for l in given:
-            if isinstance(l, Dense):
+            if isinstance(l, (Dense, LayerNorm)):
                 self.layers.append(l)
             elif l is None or l == "identity":
                 continue
@@ -689,7 +693,7 @@ class Chain:
                 self.dropout_p = max(self.dropout_p, l.p)
             elif (isinstance(l, str) and l in _lib.ACT) or (callable(l) and l in _ACT_CALLABLES):
                 name = l if isinstance(l, str) else _ACT_CALLABLES[l]
-                if not self.layers or self.layers[-1].act != "identity":
+                if not self.layers or not isinstance(self.layers[-1], Dense) or self.layers[-1].act != "identity":
                     raise NotImplementedError(f"Chain: the activation layer {name!r} does not follow a Dense without activation — only that form folds into "
                                               "the row-wise Dense launches (gnx_chain_block_forward)")
                 d = Dense.__new__(Dense)  # the same weight / bias tensors, with the activation
@@ -708,12 +712,30 @@ class Chain:
 
 
 class LayerNorm:
-    """Flux `LayerNorm(d)`: γ = ones, β = zeros, ε = 1e-5."""
+    """Flux `LayerNorm(d)`: γ = ones, β = zeros, ε = 1e-5.  GNGraphNorm's layers (gngraphnorm.jl:9-17) — and a layer value of a `Chain`."""
 
     def __init__(self, d, device=None):
         dev = _device(device)
         self.gamma = torch.ones(d, device=dev)
         self.beta = torch.zeros(d, device=dev)
+
+    @classmethod
+    def from_numpy(cls, gamma, beta, device=None):
+        self = cls.__new__(cls)
+        dev = _device(device)
+        self.gamma = torch.from_numpy(np.asarray(gamma, dtype=np.float32)).to(dev)
+        self.beta = torch.from_numpy(np.asarray(beta, dtype=np.float32)).to(dev)
+        return self
+
+    # as a layer of a Chain the (gamma, beta) pair takes the places of a Dense's (weight, bias): parameter lists, widths, gradient slots
+    weight = property(lambda self: self.gamma)
+    bias = property(lambda self: self.beta)
+    act = "identity"
+
+    def _c_layer(self, keep):
+        g, b = self.gamma.float().contiguous(), self.beta.float().contiguous()
+        keep += [g, b]
+        return _lib.Dense(g.data_ptr(), b.data_ptr(), _lib.ACT["identity"], _lib.LAYER_LAYERNORM)
 
     def _c(self, keep):
         g, b = self.gamma.float().contiguous(), self.beta.float().contiguous()
@@ -840,7 +862,7 @@ class GNBlock:
         outw = []
         for name, ch in zip(("edgefn", "nodefn", "graphfn"), chains):
             widths = [int(l.weight.shape[0]) for l in ch.layers]
-            arr = (_lib.Dense * max(len(ch.layers), 1))(*[l._c(keep) for l in ch.layers])
+            arr = (_lib.Dense * max(len(ch.layers), 1))(*[l._c_layer(keep) for l in ch.layers])
             wid = (C.c_int32 * max(len(ch.layers), 1))(*widths)
             keep += [arr, wid]
             c = getattr(p, name)
@@ -881,7 +903,7 @@ class GNBlock:
         return NT(g, _jl(eo), _jl(no), _jl(go))
 
     def __call__(self, x, flags=None):
-        if any(isinstance(f, Chain) and len(f) != 1 for f in (self.edgefn, self.nodefn, self.graphfn)):
+        if any(isinstance(f, Chain) and (len(f) != 1 or isinstance(f.layers[0], LayerNorm)) for f in (self.edgefn, self.nodefn, self.graphfn)):
             return self._call_chains(x, flags)
         if any(isinstance(f, Chain) and f.dropout_p > 0 for f in (self.edgefn, self.nodefn, self.graphfn)):
             return self._call_chains(x, flags)
@@ -1001,7 +1023,8 @@ class _ChainBlockFn(torch.autograd.Function):
         for ch in chains:
             entries = []
             for l in ch.layers:
-                w = torch.empty((l.weight.shape[1], l.weight.shape[0]), dtype=torch.float32, device=dev) if need[k] else None
+                ln = isinstance(l, LayerNorm)  # (its "weight" slot is gamma [d])
+                w = (torch.empty_like(l.gamma) if ln else torch.empty((l.weight.shape[1], l.weight.shape[0]), dtype=torch.float32, device=dev)) if need[k] else None
                 b = torch.empty_like(l.bias) if (l.bias is not None and need[k + 1]) else None
                 k += 2
                 gW.append(w); gb.append(b)
@@ -1018,7 +1041,7 @@ class _ChainBlockFn(torch.autograd.Function):
                                                torch.cuda.current_stream(dev).cuda_stream))
         out = [None, None, None, None, d_ef, d_nf, d_gf]
         for w, b in zip(gW, gb):
-            out += [None if w is None else w.t(), b]  # (out, in) view with column-major storage, like the weights
+            out += [None if w is None else (w if w.dim() == 1 else w.t()), b]  # (out, in) view with column-major storage, like the weights; a LayerNorm's gamma as it is
         return tuple(out)
 
 

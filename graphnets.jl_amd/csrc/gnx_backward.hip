@@ -1052,19 +1052,19 @@ int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_para
   if (E > 0) {
     if ((rc = gnx_block_forward(h, &b1, ef, nf, gf, R, A(0, 0), nullptr, nullptr, base + L.blk_fw, L.blk_fw_bytes, 0, stream))) return rc;
     for (int i = 1; i < ch[0]->n_layers; ++i)
-      if ((rc = launch_dense_rows(h, 0, A(0, i - 1), ch[0]->widths[i - 1], ch[0]->layers[i], ch[0]->widths[i], nullptr, nullptr, A(0, i), R, s, "bw_chain_fw_e"))) return rc;
+      if ((rc = launch_chain_layer(h, 0, ch[0]->layers[i], A(0, i - 1), ch[0]->widths[i - 1], ch[0]->widths[i], A(0, i), R, s, "bw_chain_fw_e"))) return rc;
   }
   const float* ef_out = A(0, ch[0]->n_layers - 1);
   const float* nf_out = on > 0 ? A(1, ch[1]->n_layers - 1) : nullptr;
   if (on > 0) {
     if ((rc = launch_fn_input(h, 1, ef_out, oe, nf, dn, gf, dg, R, Xn, s))) return rc;
     for (int i = 0; i < ch[1]->n_layers; ++i)
-      if ((rc = launch_dense_rows(h, 1, i ? A(1, i - 1) : Xn, i ? ch[1]->widths[i - 1] : Kn, ch[1]->layers[i], ch[1]->widths[i], nullptr, nullptr, A(1, i), R, s, "bw_chain_fw_n"))) return rc;
+      if ((rc = launch_chain_layer(h, 1, ch[1]->layers[i], i ? A(1, i - 1) : Xn, i ? ch[1]->widths[i - 1] : Kn, ch[1]->widths[i], A(1, i), R, s, "bw_chain_fw_n"))) return rc;
   }
   if (og > 0) {
     if ((rc = launch_fn_input(h, 2, ef_out, oe, nf_out, on, gf, dg, R, Xg, s))) return rc;
     for (int i = 0; i < ch[2]->n_layers; ++i)
-      if ((rc = launch_dense_rows(h, 2, i ? A(2, i - 1) : Xg, i ? ch[2]->widths[i - 1] : Kg, ch[2]->layers[i], ch[2]->widths[i], nullptr, nullptr, A(2, i), R, s, "bw_chain_fw_g"))) return rc;
+      if ((rc = launch_chain_layer(h, 2, ch[2]->layers[i], i ? A(2, i - 1) : Xg, i ? ch[2]->widths[i - 1] : Kg, ch[2]->widths[i], A(2, i), R, s, "bw_chain_fw_g"))) return rc;
   }
 
   // ---- row-wise pullback of layers [first, n) of chain t.  `cur` holds delta of the LAST layer on entry; on exit `*g_first` (rows x K_first)
@@ -1092,6 +1092,16 @@ int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_para
       const gnx_dense& d = ch[t]->layers[i];
       if (rows[t] == 0 || J == 0) continue;
       int32_t r2;
+      if (chain_layer_is_ln(d)) {
+        // a LayerNorm layer value: dx through the normalisation (k_ln_backward with one norm), dgamma = column sums of dy . xhat, dbeta = of dy
+        float* t1 = gb[2];  // (free here: the gelu pre-activation buffer of delta_rows / last_delta is consumed inside those calls)
+        { ProfScope ps("bw_layernorm", s);
+          GNX_LAUNCH(k_ln_backward, dim3((unsigned)((rows[t] + 3) / 4)), dim3(256), 0, s, Ain, rows[t], J, d.weight, d.weight, cur, (const float*)nullptr, (const float*)nullptr,
+                     kChainLnEps, chain_layer_ln_mode(d), gin, t1, (float*)nullptr); }
+        GNX_LAUNCH(k_set_off2, dim3(1), dim3(1), 0, s, off2, (int)rows[t]);
+        if ((r2 = colsum_all(t1, rows[t], J, grad_of(t, i).weight, part, off2, s))) return r2;
+        if ((r2 = colsum_all(cur, rows[t], J, grad_of(t, i).bias, part, off2, s))) return r2;
+      } else
       if (bw_use_mfma(rows[t], J, K)) {
         if (gin && K > 0 && (r2 = dx_mfma(h, t, cur, d.weight, J, K, 0, K, gin, R, wt, true, s, "bw_dx_chain"))) return r2;
         if ((r2 = dw_auto(cur, Ain, rows[t], J, K, grad_of(t, i), part, off2, s))) return r2;

@@ -23,6 +23,40 @@ int32_t launch_fn_input(const gnx_graphs* h, int kind, const float* ef, int de, 
 
 using namespace gnx;
 
+// A `LayerNorm(d)` layer value of a Chain (gnx_dense.kind = GNX_LAYER_LAYERNORM): y = gamma . (x - mean) / (sigma + eps) + beta per row, one
+// wavefront per row, any width — the arithmetic of k_layernorm2 (gnx_generic.hip), i.e. of GNGraphNorm's LayerNorms (gngraphnorm.jl:19-26)
+__global__ __launch_bounds__(256) void k_chain_layernorm(const float* __restrict__ x, size_t rows, int d, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, int eps_mode, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * d;
+  float s = 0.f;
+  for (int k = lane; k < d; k += 64) s += xr[k];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mu = s / (float)d;
+  float v = 0.f;
+  for (int k = lane; k < d; k += 64) { const float c = xr[k] - mu; v = fmaf(c, c, v); }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v /= (float)d;
+  const float inv = eps_mode == 0 ? 1.f / (sqrtf(v) + eps) : 1.f / sqrtf(v + eps);
+  for (int k = lane; k < d; k += 64) y[row * d + k] = fmaf(gamma[k], (xr[k] - mu) * inv, beta[k]);
+}
+
+namespace gnx {
+// one layer of a Chain, row-wise over all rows of the entity: Dense (launch_dense_rows) or LayerNorm; shared with the backward's recompute
+int32_t launch_chain_layer(const gnx_graphs* h, int entity, const gnx_dense& layer, const float* x, int k_in, int width, float* out, int64_t R, hipStream_t s,
+                           const char* name) {
+  if (!chain_layer_is_ln(layer)) return launch_dense_rows(h, entity, x, k_in, layer, width, nullptr, nullptr, out, R, s, name);
+  const size_t rows = (size_t)R * (entity == 0 ? (size_t)h->E : (entity == 1 ? (size_t)h->N : (size_t)h->G));
+  if (rows == 0 || width == 0) return GNX_OK;
+  ProfScope ps("k_chain_layernorm", s);
+  GNX_LAUNCH(k_chain_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, width, layer.weight, layer.bias, kChainLnEps, chain_layer_ln_mode(layer), out);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
+}  // namespace gnx
+
 namespace {
 
 struct ChainWs {
@@ -38,13 +72,21 @@ int max_width(const gnx_chain& c) {
 }
 int out_width(const gnx_chain& c) { return c.n_layers > 0 ? c.widths[c.n_layers - 1] : 0; }
 
-int32_t check_chain(const gnx_chain& c, const char* what) {
+int32_t check_chain(const gnx_chain& c, const char* what, int k_in, bool first_must_be_dense) {
   if (c.n_layers < 0 || c.n_layers > 16) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": n_layers must be 0..16");
   if (c.n_layers > 0 && (!c.layers || !c.widths)) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": layers / widths is NULL");
   for (int i = 0; i < c.n_layers; ++i) {
     if (c.widths[i] < 0) return fail(GNX_ERR_DIMS, std::string(what) + ": negative layer width");
     if (i + 1 < c.n_layers && c.widths[i] == 0) return fail(GNX_ERR_DIMS, std::string(what) + ": only the last layer of a Chain may have width 0");
     if (c.layers[i].act < GNX_ACT_IDENTITY || c.layers[i].act > GNX_ACT_GELU) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": unknown activation");
+    const int kind = c.layers[i].kind & 0xff;
+    if (kind != GNX_LAYER_DENSE && kind != GNX_LAYER_LAYERNORM) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": unknown layer kind");
+    if (kind == GNX_LAYER_LAYERNORM) {  // a LayerNorm(d) layer value: gamma, beta of its input's width, no activation of its own
+      if (i == 0 && first_must_be_dense) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": the edge function's first layer runs fused with getedgefninput and must be a Dense");
+      if (c.widths[i] != (i > 0 ? c.widths[i - 1] : k_in)) return fail(GNX_ERR_DIMS, std::string(what) + ": a LayerNorm layer keeps the width of its input");
+      if (c.layers[i].act != GNX_ACT_IDENTITY) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": a LayerNorm layer has no activation");
+      if (c.widths[i] > 0 && (!c.layers[i].weight || !c.layers[i].bias)) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": a LayerNorm layer needs gamma and beta");
+    }
   }
   return GNX_OK;
 }
@@ -63,8 +105,11 @@ int32_t check_params(const gnx_graphs* h, const gnx_chain_block_params* p, int64
   if (p->de < 0 || p->dn < 0 || p->dg < 0) return fail(GNX_ERR_DIMS, "negative feature width");
   if (p->de + p->dn + p->dg == 0) return fail(GNX_ERR_DIMS, "all input widths are 0 (gnblock.jl:48, batch.jl:56)");
   int32_t rc;
-  if ((rc = check_chain(p->edgefn, "edgefn")) || (rc = check_chain(p->nodefn, "nodefn")) || (rc = check_chain(p->graphfn, "graphfn"))) return rc;
-  const int oe = out_width(p->edgefn), on = out_width(p->nodefn), og = out_width(p->graphfn);
+  if ((rc = check_chain(p->edgefn, "edgefn", p->de + 2 * p->dn + p->dg, true))) return rc;
+  const int oe = out_width(p->edgefn);
+  if ((rc = check_chain(p->nodefn, "nodefn", oe + p->dn + p->dg, false))) return rc;
+  const int on = out_width(p->nodefn), og = out_width(p->graphfn);
+  if ((rc = check_chain(p->graphfn, "graphfn", oe + on + p->dg, false))) return rc;
   if (oe + on + og == 0) return fail(GNX_ERR_DIMS, "all output widths are 0 (gnblock.jl:49)");
   // A zero-width ef' / nf' is an empty segment of the next function's input, exactly as for one-layer update functions
   // (gnblock.jl:63-69 computes getnodefninput / getgraphfninput over the 0-row h_ef; width 0 <=> nothing in launch_fn_input).
@@ -100,7 +145,7 @@ int32_t run_layers(const gnx_graphs* h, int entity, const gnx_chain& c, int firs
   for (int i = first; i < c.n_layers; ++i) {
     float* dst = i + 1 == c.n_layers ? out : buf[(i - first) & 1];
     if (c.widths[i] > 0 && k > 0 && !c.layers[i].weight) return fail(GNX_ERR_INVALID_ARG, "Chain: Dense weight is NULL");
-    const int32_t rc = launch_dense_rows(h, entity, cur, k, c.layers[i], c.widths[i], nullptr, nullptr, dst, R, s, name);
+    const int32_t rc = launch_chain_layer(h, entity, c.layers[i], cur, k, c.widths[i], dst, R, s, name);
     if (rc) return rc;
     cur = dst;
     k = c.widths[i];

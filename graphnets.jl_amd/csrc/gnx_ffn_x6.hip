@@ -34,6 +34,38 @@ typedef float f32x16x __attribute__((ext_vector_type(16)));
 typedef float f32x4x __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8x __attribute__((ext_vector_type(8)));
 
+// Timing experiment only (tools/build_variant.sh x6p gnx_ffn_x6.hip -DGNX_X6_SHAPE_PROBE; results are garbage): every 32 x 32 x 16 matrix instruction
+// replaced by two 16 x 16 x 32 ones on the same operand registers — the same matrix-pipe cycles, LDS reads and vector work as a 16 x 16 x 32 port of
+// these kernels would have, to see what clock the chip holds on that shape (MI355X_MICROARCH.md, DVFS give-back (7)) before writing the port.
+#ifdef GNX_X6_SHAPE_PROBE
+__device__ __forceinline__ f32x16x x6_mfma_probe(bf16x8x a, bf16x8x b, f32x16x c) {
+  f32x4x c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+  c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
+  c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w; c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+  return c;
+}
+#define GNX_X6_MFMA(a, b, c, x, y, z) x6_mfma_probe(a, b, c)
+#else
+#define GNX_X6_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
+#endif
+
+// Round 6: the matrix instructions are v_mfma_f32_16x16x32_bf16 (GNX_X6_S16 = 1, the default) instead of v_mfma_f32_32x32x16_bf16 — the same
+// matrix-pipe cycles per product (two 16-cycle instructions per 32-cycle one), LDS bytes and vector work, but the MI355X holds a higher clock on
+// this shape under load (MI355X_MICROARCH.md, DVFS give-back (7)): the timing probe above measured one GNCore forward 1.59 -> 1.35 ms and config 4
+// 3.56 -> 3.13 ms on the same box before the port was written (profiles/r06_ab_shape_probe.log).  Layouts of this form:
+//   * lane (c, q) = (lane & 15, lane >> 4); a wave's 32 rows are two column blocks nb = 0, 1 of the transposed products: row 16 nb + c;
+//   * B fragments (the rows): for k32-step s the lane holds k = 32 s + 8 q + j (j < 8) of its row 16 nb + c — zh / zm / zl [nb * KS2 + s];
+//   * A fragments (weights, 1 KB = 64 lanes x 8 bf16 as before): W1 of slice hs, group g = 2 s + mb: lane (m, q), j: W1[32 s + 8 q + j][32 hs + 16 mb + m];
+//     W2, group g = output block of 16: lane (m, q), j: W2[32 hs + unit(q, j)][16 g + m], unit(q, j) = 16 (j >> 2) + 4 q + (j & 3) — the C/D layout of
+//     the first product (lane (c, q), block mb, register i: hidden unit 16 mb + 4 q + i of row c) IS the B operand of the second with slot j = 4 mb + i;
+//   * the edge form reads k_edge_x6_prep's planes (32 x 32 x 16 fragment order) through a lane-dependent address: nothing is re-prepared.
+// -DGNX_X6_S16=0 builds the 32 x 32 x 16 form of rounds 4-5 (tools/build_variant.sh) for same-box A/Bs.
+#ifndef GNX_X6_S16
+#define GNX_X6_S16 1
+#endif
+#define GNX_X6_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
 #ifndef GNX_X6_ADEPTH
 #define GNX_X6_ADEPTH 2
 #endif
@@ -74,9 +106,27 @@ __global__ void k_ffn_x6_prep(const float* __restrict__ W1, const float* __restr
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (hs, g, lane, j): g < D/16 groups of three fragments per product
   if (idx >= D * H) return;
   const int j = idx & 7, lane = (idx >> 3) & 63, g = (idx >> 9) % (D / 16), hs = (idx >> 9) / (D / 16);
-  const int m = lane & 31, h = lane >> 5;
   __bf16* slice = Wp + (size_t)hs * 2 * NF * 512;
   __bf16 a, b, c;
+#if GNX_X6_S16
+  {
+    const int m16 = lane & 15, q = lane >> 4;
+    {  // W1, group g = 2 s + mb
+      const int s32 = g >> 1, mb = g & 1, k = 32 * s32 + 8 * q + j;
+      split3x((gamma ? gamma[k] : 1.f) * W1[(size_t)k * H + 32 * hs + 16 * mb + m16], a, b, c);
+      __bf16* f = slice + (size_t)(3 * g) * 512 + lane * 8 + j;
+      f[0] = a; f[512] = b; f[1024] = c;
+    }
+    {  // W2, group g = output block of 16; slot (q, j) of the k32-step = hidden unit 16 (j >> 2) + 4 q + (j & 3) of the slice
+      const int n = 32 * hs + 16 * (j >> 2) + 4 * q + (j & 3);
+      split3x(W2[(size_t)n * D + 16 * g + m16], a, b, c);
+      __bf16* f = slice + (size_t)(NF + 3 * g) * 512 + lane * 8 + j;
+      f[0] = a; f[512] = b; f[1024] = c;
+    }
+    return;
+  }
+#endif
+  const int m = lane & 31, h = lane >> 5;
   {
     const int k = 16 * g + 8 * h + j;
     split3x((gamma ? gamma[k] : 1.f) * W1[(size_t)k * H + 32 * hs + m], a, b, c);
@@ -389,12 +439,12 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       }
       constexpr bool PIECE = !std::is_same<std::decay_t<decltype(piece)>, std::nullptr_t>::value;
       if constexpr (PIECE) { if (s < NF / XW) piece(s); }
-      accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zm[s], accN, 0, 0, 0);  // small terms first
-      accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][2], zh[s], accN, 0, 0, 0);
-      accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zl[s], accN, 0, 0, 0);
-      accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zh[s], accN, 0, 0, 0);
-      accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zm[s], accN, 0, 0, 0);
-      accN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zh[s], accN, 0, 0, 0);
+      accN = GNX_X6_MFMA(A[c][1], zm[s], accN, 0, 0, 0);  // small terms first
+      accN = GNX_X6_MFMA(A[c][2], zh[s], accN, 0, 0, 0);
+      accN = GNX_X6_MFMA(A[c][0], zl[s], accN, 0, 0, 0);
+      accN = GNX_X6_MFMA(A[c][1], zh[s], accN, 0, 0, 0);
+      accN = GNX_X6_MFMA(A[c][0], zm[s], accN, 0, 0, 0);
+      accN = GNX_X6_MFMA(A[c][0], zh[s], accN, 0, 0, 0);
       if constexpr (SPLIT) {
         // (instruction selection places pure vector instructions wherever their operands are ready — Y(s - 1) right behind X(s - 1), in the
         // previous step's region, one dependent chain again; the empty volatile statement pins the remainders to THIS region)
@@ -437,12 +487,12 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
         for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * (g + 1) + p3) * 1024);
       }
       if constexpr (PIECE) { if (g < NF / XW) piece(g); }
-      accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], hm[t], accO[ob], 0, 0, 0);
-      accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][2], hh[t], accO[ob], 0, 0, 0);
-      accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], hl[t], accO[ob], 0, 0, 0);
-      accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], hh[t], accO[ob], 0, 0, 0);
-      accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], hm[t], accO[ob], 0, 0, 0);
-      accO[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], hh[t], accO[ob], 0, 0, 0);
+      accO[ob] = GNX_X6_MFMA(A[c][1], hm[t], accO[ob], 0, 0, 0);
+      accO[ob] = GNX_X6_MFMA(A[c][2], hh[t], accO[ob], 0, 0, 0);
+      accO[ob] = GNX_X6_MFMA(A[c][0], hl[t], accO[ob], 0, 0, 0);
+      accO[ob] = GNX_X6_MFMA(A[c][1], hh[t], accO[ob], 0, 0, 0);
+      accO[ob] = GNX_X6_MFMA(A[c][0], hm[t], accO[ob], 0, 0, 0);
+      accO[ob] = GNX_X6_MFMA(A[c][0], hh[t], accO[ob], 0, 0, 0);
       if (g + 1 < 2 * NOB) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
       if constexpr (PIECE) {
         if (g < NF / XW) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); }
@@ -570,12 +620,12 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
 #pragma unroll
           for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * (s + 1) + p3) * 1024);
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zm[s], acc, 0, 0, 0);  // small terms first
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][2], zh[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zl[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][1], zh[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zm[s], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c][0], zh[s], acc, 0, 0, 0);
+        acc = GNX_X6_MFMA(A[c][1], zm[s], acc, 0, 0, 0);  // small terms first
+        acc = GNX_X6_MFMA(A[c][2], zh[s], acc, 0, 0, 0);
+        acc = GNX_X6_MFMA(A[c][0], zl[s], acc, 0, 0, 0);
+        acc = GNX_X6_MFMA(A[c][1], zh[s], acc, 0, 0, 0);
+        acc = GNX_X6_MFMA(A[c][0], zm[s], acc, 0, 0, 0);
+        acc = GNX_X6_MFMA(A[c][0], zh[s], acc, 0, 0, 0);
       }
       // the gathered addends of the slice (8 rows x 128 contiguous bytes per instruction) and the residual quads (x: the cache has the rows) are
       // requested here — across the matrix instructions they would not fit the register file beside out^T —, and the FeedForward block of these

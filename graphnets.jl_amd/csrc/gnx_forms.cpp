@@ -47,6 +47,11 @@ FormScope::~FormScope() {
   --tl_form_depth;
 }
 
+unsigned lds_pad_bytes() {
+  static const unsigned pad = getenv("GNX_LDS_PAD_KB") ? (unsigned)atoi(getenv("GNX_LDS_PAD_KB")) * 1024u : 0u;
+  return pad;
+}
+
 bool form(uint32_t bit) { return ((tl_form_depth > 0 ? tl_form_flags : env_form_flags()) & bit) != 0; }
 
 // ---- one matrix-core call at a time per device (gnx_internal.h: DeviceTurn) ----

@@ -550,6 +550,12 @@ static int32_t pad_impl(const gnx_graphs* h, int32_t kind, bool pad, const float
   return launch_pad(h, kind, pad, src, d, R, dst, (hipStream_t)stream);
 }
 
+int32_t gnx_row_stats(const float* x, int64_t rows, int32_t d, float eps, int32_t eps_mode, float* stats, void* stream) {
+  if (!x || !stats || rows < 0) return fail(GNX_ERR_INVALID_ARG, "gnx_row_stats: NULL argument / negative row count");
+  if (eps_mode != 0 && eps_mode != 1) return fail(GNX_ERR_INVALID_ARG, "eps_mode must be 0 or 1");
+  return launch_ln_stats(x, (size_t)rows, d, eps, eps_mode, stats, (hipStream_t)stream);
+}
+
 int32_t gnx_pad_features(const gnx_graphs* h, int32_t kind, const float* packed, int32_t d, int64_t R, float* padded, void* stream) {
   return pad_impl(h, kind, true, packed, d, R, padded, stream);
 }

@@ -139,6 +139,13 @@ struct FormScope {  // an exported forward opens one: the functions below it rea
   FormScope& operator=(const FormScope&) = delete;
   uint32_t prev;
 };
+// a Chain's layer entries (include/gnx.h: gnx_dense.kind): Dense or a LayerNorm(d) layer value (gamma, beta in weight, bias; eps = Flux's default)
+constexpr float kChainLnEps = 1e-5f;
+inline bool chain_layer_is_ln(const gnx_dense& l) { return (l.kind & 0xff) == GNX_LAYER_LAYERNORM; }
+inline int chain_layer_ln_mode(const gnx_dense& l) { return (l.kind & GNX_LAYER_LN_SQRT_EPS) ? 1 : 0; }
+int32_t launch_chain_layer(const gnx_graphs* h, int entity, const gnx_dense& layer, const float* x, int k_in, int width, float* out, int64_t R, hipStream_t s,
+                           const char* name);  // gnx_chain.cpp
+unsigned lds_pad_bytes();  // experiment switch GNX_LDS_PAD_KB: dynamic LDS added to EVERY launch (0 by default) — a workgroup that owns most of a CU's LDS shares the CU with no other LDS-using kernel
 bool form(uint32_t bit);  // is the form selected for the call this thread is in (outside a call: by the environment's defaults)
 
 // One matrix-core call at a time per DEVICE (gnx_forms.cpp).  Round 5 found (tools/experiments/thread_race_probe.py, mfma_mix_probe.py; the evidence is
@@ -205,9 +212,9 @@ bool prof_take_events(hipEvent_t* start, hipEvent_t* stop);
   do {                                                                                                                 \
     hipEvent_t gnx_e0_ = nullptr, gnx_e1_ = nullptr;                                                                   \
     if (gnx::prof_take_events(&gnx_e0_, &gnx_e1_))                                                                     \
-      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, gnx_e0_, gnx_e1_, 0, ##__VA_ARGS__);                     \
+      hipExtLaunchKernelGGL(kernel, grid, block, (lds) + gnx::lds_pad_bytes(), stream, gnx_e0_, gnx_e1_, 0, ##__VA_ARGS__); \
     else                                                                                                               \
-      hipLaunchKernelGGL(kernel, grid, block, lds, stream, ##__VA_ARGS__);                                             \
+      hipLaunchKernelGGL(kernel, grid, block, (lds) + gnx::lds_pad_bytes(), stream, ##__VA_ARGS__);                     \
   } while (0)
 // run-time compiled kernels (hipFunction_t): grid in BLOCKS like hipModuleLaunchKernel (the Ext form counts work-items)
 inline hipError_t module_launch(hipFunction_t f, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz, unsigned lds, hipStream_t s,

@@ -117,12 +117,18 @@ typedef struct gnx_graphs_info {
   int32_t reserved;
 } gnx_graphs_info;
 
-/* One Flux `Dense(in => out, act)`: y = act.(W*x .+ b).  bias may be NULL (= zeros). */
+/* One Flux `Dense(in => out, act)`: y = act.(W*x .+ b).  bias may be NULL (= zeros).
+ * `kind` (0 everywhere but inside a gnx_chain): GNX_LAYER_LAYERNORM makes the entry a Flux `LayerNorm(d)` layer value of a Chain — weight =
+ * gamma [d], bias = beta [d], act = identity, its width = the width of its input, eps = 1e-5 (Flux's default), (x - mean) / (sigma + eps)
+ * (Flux 0.14 `normalise`; `| GNX_LAYER_LN_SQRT_EPS`: / sqrt(sigma^2 + eps)).  gnx_block_params' three functions must be Dense (kind 0). */
+#define GNX_LAYER_DENSE 0
+#define GNX_LAYER_LAYERNORM 1
+#define GNX_LAYER_LN_SQRT_EPS 0x100
 typedef struct gnx_dense {
-  const float* weight; /* (out x in) column-major, device */
-  const float* bias;   /* (out), device, or NULL          */
+  const float* weight; /* (out x in) column-major, device; LayerNorm entry: gamma [d] */
+  const float* bias;   /* (out), device, or NULL;          LayerNorm entry: beta [d]  */
   int32_t act;         /* GNX_ACT_*                       */
-  int32_t reserved;
+  int32_t kind;        /* GNX_LAYER_* (was `reserved`: 0 = Dense) */
 } gnx_dense;
 
 /* Prepared parameters (opaque): a layer's weight blocks in the forms the matrix-core kernels stage (bf16 planes of the exact three-way
@@ -296,7 +302,10 @@ GNX_API int32_t gnx_block_forward_steps(const gnx_graphs* h, const gnx_block_par
  * width of layer i; the input width of layer 0 is fixed by the block (de+2dn+dg / oe+dn+dg / oe+on+dg with oe, on = the LAST
  * widths of the edge / node chains); a chain with n_layers = 0 or a last width of 0 <=> that output is `nothing`.
  * The edge function's first layer runs fused with getedgefninput (the fast block kernels); every further layer is a row-wise
- * Dense on the matrix-core GEMM kernel.  Backward: gnx_chain_block_backward below. */
+ * Dense on the matrix-core GEMM kernel.  A layer entry may also be a `LayerNorm(d)` layer value (gnx_dense.kind = GNX_LAYER_LAYERNORM,
+ * `Chain(Dense(a => d, relu), LayerNorm(d), Dense(d => b))`: normalised rows of the layer in front, its width = that layer's) — anywhere
+ * but as the edge function's FIRST layer (which is the fused Dense).  The gradient entries of a LayerNorm layer are (gamma, beta).
+ * Backward: gnx_chain_block_backward below. */
 typedef struct gnx_chain {
   const gnx_dense* layers; /* [n_layers] host array of layer descriptors (device weight pointers inside) */
   const int32_t* widths;   /* [n_layers] host array */
@@ -431,6 +440,12 @@ GNX_API int32_t gnx_core_backward_train(const gnx_graphs* h, const gnx_core_para
                                 const float* gf, const float* g_ef_out, const float* g_nf_out, const float* g_gf_out, int64_t n_replicas,
                                 float* d_ef, float* d_nf, float* d_gf, const gnx_core_grads* grads, void* workspace, size_t workspace_bytes,
                                 void* stream);
+
+/* ---- row statistics of a packed [rows][d] tensor: stats[row] = (mean, 1 / (sigma + eps)) (eps_mode 0, Flux 0.14 `normalise`) or
+ * (mean, 1 / sqrt(sigma^2 + eps)) (eps_mode 1), uncorrected sigma — the one pass over x from which the wide kernels apply GNGraphNorm's
+ * LayerNorms (src/gngraphnorm.jl:19-26) as they load their rows; exported as the building block it is (and so that it can be exercised
+ * on its own: tests/overlap_probe.py).  d must be a multiple of 64 up to 512, x 16-byte aligned, stats [rows][2] 8-byte aligned. */
+GNX_API int32_t gnx_row_stats(const float* x, int64_t rows, int32_t d, float eps, int32_t eps_mode, float* stats, void* stream);
 
 /* ---- materialised update-function inputs: the reference's exported building blocks getedgefninput /
  * getnodefninput / getgraphfninput (src/edgefninput.jl:1-47, src/nodefninput.jl:1-24, src/graphfninput.jl:1-13).

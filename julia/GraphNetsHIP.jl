@@ -689,19 +689,28 @@ end
 struct GnxChain; layers::Ptr{GnxDense}; widths::Ptr{Int32}; n_layers::Int32; reserved::Int32; end
 struct GnxChainBlockParams; de::Int32; dn::Int32; dg::Int32; reserved::Int32; edgefn::GnxChain; nodefn::GnxChain; graphfn::GnxChain; end
 struct GnxChainBlockGrads; edgefn::Ptr{GnxDenseGrad}; nodefn::Ptr{GnxDenseGrad}; graphfn::Ptr{GnxDenseGrad}; end
+# A chain's layers: Dense, or a Flux `LayerNorm(d)` layer value (`Chain(Dense(a => d, relu), LayerNorm(d), Dense(d => b))`, gnblock.jl:1-6) — a
+# gnx_dense entry of kind GNX_LAYER_LAYERNORM (gamma, beta in the weight / bias slots; anywhere but as the edge function's first layer)
+const ChainLayer = Union{Dense,LayerNorm}
+layerwidth(l::Dense) = size(l.weight, 1)
+layerwidth(l::LayerNorm) = length(l.γ)
+layer_c(l::Dense) = dense_c(l)
+layer_c(l::LayerNorm) = GnxDense(devptr(l.γ), devptr(l.β), Int32(0), Int32(1))
+gradslots(l::Dense) = (similar(l.weight), similar(l.bias))             # what gnx_chain_block_backward writes for the layer: (dW, db) / (dγ, dβ)
+gradslots(l::LayerNorm) = (similar(l.γ), similar(l.β))
 struct ChainBlock                                                      # GNBlock(Chain(Dense...), Chain(Dense...), Chain(Dense...))
-    edgefn::Vector{Dense}; nodefn::Vector{Dense}; graphfn::Vector{Dense}; in::NTuple{3,Int}
+    edgefn::Vector{ChainLayer}; nodefn::Vector{ChainLayer}; graphfn::Vector{ChainLayer}; in::NTuple{3,Int}
 end
-outwidth(c::Vector{Dense}) = isempty(c) ? 0 : size(c[end].weight, 1)
+outwidth(c::Vector{ChainLayer}) = isempty(c) ? 0 : layerwidth(c[end])
 ondevice(m::ChainBlock) = all(ondevice, m.edgefn) && all(ondevice, m.nodefn) && all(ondevice, m.graphfn)
-gpu(m::ChainBlock) = ondevice(m) ? m : ChainBlock(Dense[gpu(l) for l in m.edgefn], Dense[gpu(l) for l in m.nodefn], Dense[gpu(l) for l in m.graphfn], m.in)
-cpu(m::ChainBlock) = ChainBlock(Dense[cpu(l) for l in m.edgefn], Dense[cpu(l) for l in m.nodefn], Dense[cpu(l) for l in m.graphfn], m.in)
-chainkey(m::ChainBlock) = (m.in, map(c -> Tuple([size(l.weight, 1) for l in c]), (m.edgefn, m.nodefn, m.graphfn)))
+gpu(m::ChainBlock) = ondevice(m) ? m : ChainBlock(ChainLayer[gpu(l) for l in m.edgefn], ChainLayer[gpu(l) for l in m.nodefn], ChainLayer[gpu(l) for l in m.graphfn], m.in)
+cpu(m::ChainBlock) = ChainBlock(ChainLayer[cpu(l) for l in m.edgefn], ChainLayer[cpu(l) for l in m.nodefn], ChainLayer[cpu(l) for l in m.graphfn], m.in)
+chainkey(m::ChainBlock) = (m.in, map(c -> Tuple([(layerwidth(l), l isa LayerNorm) for l in c]), (m.edgefn, m.nodefn, m.graphfn)))
 # the host arrays the parameter struct points at (layer descriptors with DEVICE weight pointers, widths); `keep` holds what must outlive the call
 function chain_params(m::ChainBlock, keep::Vector{Any})
-    function one(c::Vector{Dense})
-        descr = [dense_c(l) for l in c]
-        widths = Int32[size(l.weight, 1) for l in c]
+    function one(c::Vector{ChainLayer})
+        descr = [layer_c(l) for l in c]
+        widths = Int32[layerwidth(l) for l in c]
         push!(keep, descr, widths)
         GnxChain(isempty(c) ? C_NULL : pointer(descr), isempty(c) ? C_NULL : pointer(widths), Int32(length(c)), 0)
     end
@@ -731,7 +740,8 @@ function chain_pullback_device(m::ChainBlock, x, ȳ)
     p = Ref(chain_params(m, keep))
     dins = (likeof(x.ef), likeof(x.nf), likeof(x.gf))
     chains = (m.edgefn, m.nodefn, m.graphfn)
-    gW = [[similar(l.weight) for l in c] for c in chains]; gB = [[similar(l.bias) for l in c] for c in chains]
+    gs = [[gradslots(l) for l in c] for c in chains]
+    gW = [[q[1] for q in c] for c in gs]; gB = [[q[2] for q in c] for c in gs]
     arrs = [[GnxDenseGrad(devptr(gW[t][i]), devptr(gB[t][i])) for i in eachindex(chains[t])] for t in 1:3]
     gp(t) = isempty(arrs[t]) ? Ptr{GnxDenseGrad}(C_NULL) : pointer(arrs[t])
     grads = Ref(GnxChainBlockGrads(gp(1), gp(2), gp(3)))

@@ -593,15 +593,19 @@ def core_forward_sparse(p, csc, ef, nf, gf, return_scale=False, in_scale=None):
 def make_chain_block_params(rng, in_dims, edge_widths, node_widths, graph_widths, acts=(ACT_RELU, ACT_TANH, ACT_IDENTITY)):
     """GNBlock whose update functions are Chains of Dense layers (gnblock.jl:1-6 allows any Chain; the default is one Dense):
     `*_widths` = output widths of the layers of each chain (empty = that output is `nothing`); hidden layers use `acts[i % 3]`,
-    the last layer of a chain is linear (like the reference's default)."""
+    the last layer of a chain is linear (like the reference's default).  A width entry "ln" puts a Flux `LayerNorm(d)` layer value
+    there (d = the width in front of it; random gamma / beta): the layer tuple is ("layernorm", gamma, beta)."""
     de, dn, dg = in_dims
-    oe = edge_widths[-1] if edge_widths else 0
-    on = node_widths[-1] if node_widths else 0
+    last = lambda ws: next((w for w in reversed(ws) if w != "ln"), 0)  # (a LayerNorm keeps the width in front of it)
+    oe, on = last(edge_widths), last(node_widths)
     kin = dict(edge=de + 2 * dn + dg, node=oe + dn + dg, graph=oe + on + dg)
     p = dict(in_dims=tuple(in_dims))
     for name, widths in (("edge", edge_widths), ("node", node_widths), ("graph", graph_widths)):
         layers, k = [], kin[name]
         for i, w in enumerate(widths):
+            if w == "ln":
+                layers.append(("layernorm", rng.uniform(0.5, 1.5, size=k).astype(np.float32), rng.uniform(-0.2, 0.2, size=k).astype(np.float32)))
+                continue
             act = acts[i % len(acts)] if i + 1 < len(widths) else ACT_IDENTITY
             layers.append((glorot_uniform(rng, w, k), rng.uniform(-0.1, 0.1, size=w).astype(np.float32), act))
             k = w
@@ -622,6 +626,10 @@ def chain_block_forward_sparse(p, csc, ef, nf, gf, return_scale=False):
 
     def run(layers, X, S):
         for W, b, act in layers:
+            if isinstance(W, str):  # ("layernorm", gamma, beta): a Flux LayerNorm(d) layer value between the Dense layers (gnblock.jl:1-6 admits any Chain)
+                S = layernorm_scale(X, S, b, act)
+                X = layernorm(X, b, act, axis=-1)
+                continue
             S = np.abs(S) @ np.abs(np.asarray(W, dtype=F64)).T + np.abs(np.asarray(b, dtype=F64))[None, :]
             X = _dense_rows(W, b, act, X)
         return X, S

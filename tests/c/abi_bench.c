@@ -62,7 +62,7 @@ static gnx_dense dense(int out, int in, int act) { /* Flux Dense(in => out): glo
   d.weight = dev_uniform((size_t)out * in, -s, s);
   d.bias = dev_const((size_t)out, 0.f);
   d.act = act;
-  d.reserved = 0;
+  d.kind = 0;
   return d;
 }
 static gnx_block_params block(const int in[3], const int out[3]) { /* GNBlock(in => out), gnblock.jl:47-61 */

@@ -9,7 +9,8 @@ turn-taking OFF (GNX_ALLOW_OVERLAP=1 — set it in the environment of this proce
        stream while a torch bf16 GEMM loop (2048^3, hipBLASLt) runs on another stream of the same device;
   (ii) two captured hipGraphs of default-form forwards (two handles of the same batch) replayed concurrently on two streams.
 
-python tests/overlap_probe.py [forms=default|fp32] [iters=40] [big=0|1]      -> one JSON line with the mismatch counts"""
+python tests/overlap_probe.py [forms=default|fp32|nofork] [iters=40] [big=0|1]      -> one JSON line with the mismatch counts
+(nofork: default forms with GNX_FLAG_NO_FORK — every kernel of a forward on the caller's stream)"""
 import json
 import os
 import sys
@@ -23,6 +24,7 @@ sys.path.insert(0, ROOT)
 forms = sys.argv[1] if len(sys.argv) > 1 else "default"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 big = len(sys.argv) > 3 and sys.argv[3] == "1"
+poison = len(sys.argv) > 4 and sys.argv[4] == "poison"
 
 import torch  # noqa: E402
 
@@ -31,7 +33,7 @@ from oracle import gn_oracle as O  # noqa: E402  (parameter shapes only)
 from tests import util as U  # noqa: E402
 
 F = gn._lib
-flags = F.FLAG_FP32_MFMA if forms == "fp32" else 0
+flags = F.FLAG_FP32_MFMA if forms == "fp32" else (F.FLAG_NO_FORK if forms == "nofork" else (int(forms.split(":")[1], 0) if forms.startswith("flags:") else 0))
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 rng = np.random.default_rng(6100)
@@ -62,7 +64,7 @@ def fwd_bwd(x_np):
 ref = [fwd_bwd(x) for x in packed]
 torch.cuda.synchronize()
 stop = threading.Event()
-bad_fb, n_fb = [], [0]
+bad_fb, n_fb, signatures = [], [0], []
 
 
 def victim():
@@ -71,12 +73,24 @@ def victim():
     with torch.cuda.stream(st):
         for it in range(iters):
             k = it % len(packed)
+            if poison:  # every workspace of the handle filled with 0xFF bytes (NaN floats) on this stream before the forward: a kernel that reads
+                for w in g._ws.values():  # what an EARLIER kernel of the same forward wrote — and sees older bytes instead — turns its output into NaN
+                    w.fill_(255)
             out = fwd_bwd(packed[k])
             st.synchronize()
             n_fb[0] += 1
             wrong = [i for i, (a, b) in enumerate(zip(out, ref[k])) if not torch.equal(a, b)]
             if wrong:
                 bad_fb.append((it, wrong[:6]))
+                if len(signatures) < 4:  # what the damage looks like: tensor, wrong rows, wrong columns per wrong row, size of the error
+                    for i in wrong[:3]:
+                        pk = lambda t: (t.permute(2, 1, 0)[0] if t.dim() == 3 else t.reshape(-1, t.shape[-1])).double()  # Julia-shaped (D, T, 1) -> [T][D]
+                        a, b = pk(out[i]), pk(ref[k][i])
+                        d = torch.nan_to_num((a - b).abs(), nan=1e30)
+                        rows = torch.nonzero(d.amax(dim=1) > 0).flatten()
+                        signatures.append({"it": it, "tensor": i, "shape": list(a.shape), "wrong_rows": int(rows.numel()), "first_rows": rows[:8].tolist(),
+                                           "wrong_cols_in_first_row": int((d[rows[0]] > 0).sum()) if rows.numel() else 0, "first_cols": torch.nonzero(d[rows[0]] > 0).flatten()[:4].tolist() if rows.numel() else [],
+                                           "max_rel_err": float((d / b.abs().clamp_min(1e-30)).max()), "max_abs_err": float(d.max()), "max_ref": float(b.abs().max()), "nan_elements": int(torch.isnan(a).sum())})
     stop.set()
 
 
@@ -116,4 +130,4 @@ for it in range(iters):
         if not all(torch.equal(a, b) for a, b in zip((c._out.ef, c._out.nf, c._out.gf), r)):
             bad_graphs += 1
 print(json.dumps({"forms": forms, "big": big, "overlap_allowed": os.environ.get("GNX_ALLOW_OVERLAP", "0"), "forward_backward_runs": n_fb[0],
-                  "forward_backward_wrong": len(bad_fb), "first_wrong": bad_fb[:3], "graph_replay_pairs": iters, "graph_replays_wrong": bad_graphs}))
+                  "forward_backward_wrong": len(bad_fb), "first_wrong": bad_fb[:3], "signatures": signatures, "graph_replay_pairs": iters, "graph_replays_wrong": bad_graphs}))

@@ -512,3 +512,96 @@ def test_chained_forward_runs_the_previous_graph_update_inside_the_next_launch(g
             plan.chained(*ins[1], *outs[1], ws=wss[0], prev=pend)
         plan.flush(pend)
         torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", ["one-graph", "small-graphs(pack form)", "wide(matrix cores)"])
+def test_forward_steps_is_a_loop_of_forwards_in_one_call(gn, case):
+    """gnx_block_forward_steps (round 6; bench.py's headline form): n gnx_block_forward calls in order as ONE call — outputs bit-identical; where the
+    two-launch narrow form runs the library chains the steps itself (n block launches + ONE graph-update launch instead of 2 n launches: counted
+    through the profiler's scopes), every gf' complete when the call's work is; steps that share a workspace with their predecessor run unchained;
+    capture-safe (a hipGraph of the call replays to the same bits); argument errors are reported after the pending step was finished."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(900 + len(case))
+    dims = ((10, 5, 0), (3, 4, 5))
+    if case == "one-graph":
+        cp, rv = U.er_csc(rng, 30_000, 200_000)
+        cps, rvs, nn = [cp], [rv], [30_000]
+    elif case.startswith("small"):
+        sizes = rng.integers(20, 90, 200)
+        cs = [U.er_csc(rng, int(n), 4 * int(n)) for n in sizes]
+        cps, rvs, nn = [c[0] for c in cs], [c[1] for c in cs], [int(n) for n in sizes]
+    else:
+        cp, rv = U.er_csc(rng, 3_000, 20_000)
+        cps, rvs, nn = [cp], [rv], [3_000]
+        dims = ((40, 36, 8), (36, 40, 8))
+    g = gn.GNGraphBatch.from_csc(cps, rvs, nn)
+    blk = U.block_from_params(gn, O.make_block_params(rng, *dims))
+    plan = gn.BlockPlan(blk, g)
+    dev = g.device
+    (de, dn, dg), _ = dims
+    mk = lambda T, d: torch.rand((1, T, d), device=dev) if d > 0 else None
+    n = 6
+    sets = [dict(ef=mk(g.n_edges, de), nf=mk(g.n_nodes, dn), gf=mk(g.n_graphs, dg), out=plan.outputs(), ws=plan.new_workspace()) for _ in range(n)]
+    ref = []
+    for b in sets:
+        out = plan.outputs()
+        plan(b["ef"], b["nf"], b["gf"], *out)
+        ref.append(out)
+    torch.cuda.synchronize()
+    gn.profile_reset(); gn.profile_enable(True)
+    plan.steps(sets)
+    torch.cuda.synchronize()
+    gn.profile_enable(False)
+    prof = gn.profile_read(); gn.profile_reset()
+    for i, b in enumerate(sets):
+        for name, a, r in zip(("ef", "nf", "gf"), b["out"], ref[i]):
+            assert torch.equal(a, r), f"{case}: step {i} {name}"
+    if case == "one-graph":  # chained: n block launches, ONE separate graph update (the flush)
+        assert prof["k_block_wave"]["launches"] == n and prof["k_graph_t"]["launches"] == 1, prof
+    # consecutive steps on ONE workspace (and one gf'): every step runs unchained, results unchanged
+    for b in sets:
+        for t in b["out"]:
+            t.fill_(float("nan"))
+    shared = [dict(b, ws=sets[0]["ws"]) for b in sets]
+    gn.profile_enable(True)
+    plan.steps(shared)
+    torch.cuda.synchronize()
+    gn.profile_enable(False)
+    prof = gn.profile_read(); gn.profile_reset()
+    for i, b in enumerate(sets):
+        for a, r in zip(b["out"], ref[i]):
+            assert torch.equal(a, r)
+    if case == "one-graph":
+        assert prof["k_graph_t"]["launches"] == n, prof
+    # inside a hipGraph
+    for b in sets:
+        for t in b["out"]:
+            t.fill_(float("nan"))
+    cg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(cg):
+        plan.steps(sets)
+    cg.replay(); cg.replay()
+    torch.cuda.synchronize()
+    for i, b in enumerate(sets):
+        for a, r in zip(b["out"], ref[i]):
+            assert torch.equal(a, r)
+    # zero steps: nothing to do; a NULL step table with n > 0 and the deferral flag are refused
+    lib = gn._lib.load()
+    s = torch.cuda.current_stream(dev).cuda_stream
+    assert lib.gnx_block_forward_steps(g._h, C.byref(plan.p), None, 0, 1, 0, s) == 0
+    assert lib.gnx_block_forward_steps(g._h, C.byref(plan.p), None, 2, 1, 0, s) == gn._lib.ERR_INVALID_ARG
+    arr = (gn._lib.BlockStep * 1)()
+    assert lib.gnx_block_forward_steps(g._h, C.byref(plan.p), arr, 1, 1, gn._lib.FLAG_DEFER_GRAPH_UPDATE, s) == gn._lib.ERR_INVALID_ARG
+    # an invalid second step (workspace too small): the error comes back AND the first step is complete
+    for t in sets[0]["out"]:
+        t.fill_(float("nan"))
+    two = (gn._lib.BlockStep * 2)()
+    P = lambda t: None if t is None else t.data_ptr()
+    for i in range(2):
+        b = sets[i]
+        two[i] = gn._lib.BlockStep(P(b["ef"]), P(b["nf"]), P(b["gf"]), P(b["out"][0]), P(b["out"][1]), P(b["out"][2]), b["ws"].data_ptr(), b["ws"].numel() if i == 0 else 16)
+    assert lib.gnx_block_forward_steps(g._h, C.byref(plan.p), two, 2, 1, 0, s) == gn._lib.ERR_WORKSPACE
+    torch.cuda.synchronize()
+    for a, r in zip(sets[0]["out"], ref[0]):
+        assert torch.equal(a, r)

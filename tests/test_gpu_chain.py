@@ -17,7 +17,7 @@ def gn():
 def _block(gn, p):
     de, dn, dg = p["in_dims"]
     blk = gn.GNBlock((de, dn, dg), (1, 0, 0))  # placeholder layers: the chains below define the widths
-    mk = lambda layers: gn.Chain([gn.Dense.from_numpy(W, b, U.ACT_NAMES[a]) for W, b, a in layers])
+    mk = lambda layers: gn.Chain([gn.LayerNorm.from_numpy(b, a) if isinstance(W, str) else gn.Dense.from_numpy(W, b, U.ACT_NAMES[a]) for W, b, a in layers])
     blk.edgefn, blk.nodefn, blk.graphfn = mk(p["edge"]), mk(p["node"]), mk(p["graph"])
     return blk
 
@@ -28,6 +28,10 @@ CASES = [
     ((0, 4, 2), [8, 5], [5], []),                   # ef = nothing, no graph output
     ((6, 0, 0), [4], [], []),                       # plain one-layer edge function only
     ((128, 64, 32), [256, 128], [128, 64], [64, 32]),  # wide: every layer on the matrix cores
+    # a Flux LayerNorm(d) layer value between / behind the Dense layers (`Chain(Dense, LayerNorm, Dense)`, gnblock.jl:1-6)
+    ((10, 5, 0), [16, "ln", 3], [8, "ln", 4], ["ln", 6, 5]),   # ... and as the FIRST layer of the graph function (its input is materialised)
+    ((10, 5, 3), [12, 7, "ln"], ["ln", 6], [9, "ln", 4, "ln"]),  # as a chain's last layer; first layer of the node function
+    ((128, 64, 32), [256, "ln", 128], [128, "ln", 64], [64, 32]),  # wide rows
 ]
 
 
@@ -85,6 +89,11 @@ def _torch_chain_block(csc, ef, nf, gf, W):
 
     def chain(x, layers, pre):
         for w, b, a in layers:
+            if isinstance(w, str):  # ("layernorm", gamma, beta): Flux 0.14 normalise (x - mean) / (sigma + eps), then gamma . xhat + beta
+                mu = x.mean(dim=1, keepdim=True)
+                sd = ((x - mu) ** 2).mean(dim=1, keepdim=True).sqrt()
+                x = b * ((x - mu) / (sd + 1e-5)) + a
+                continue
             z = x @ w.T + b
             pre.append((z, a))
             x = ACT[a](z)
@@ -109,6 +118,8 @@ BW_CASES = [
     ((0, 4, 2), [8, 5], [5], [], (4, 2, 0), False),                 # ef = nothing, gelu first edge layer, no graph output
     ((6, 0, 0), [4, 3], [], [], (2, 0, 0), False),                  # edge function only
     ((48, 24, 8), [64, 40], [48, 24], [32, 16], (2, 3, 2), True),   # matrix-core row-wise pullbacks (>= 4096 rows)
+    ((10, 5, 3), [16, "ln", 3], [8, "ln", 4, "ln"], ["ln", 6, 5], (2, 3, 2), False),   # LayerNorm layer values: between, last, first
+    ((48, 24, 8), [64, "ln", 40], [48, "ln", 24], [32, 16], (2, 3, 2), True),          # ... behind matrix-core layers
 ]
 
 
@@ -132,8 +143,8 @@ def test_chain_block_backward_matches_torch_autograd(gn, case):
         ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, in_dims)
         T = lambda a: None if a is None else torch.tensor(a[0], dtype=torch.float64, requires_grad=True)
         xs = [T(ef), T(nf), T(gf)]
-        W = {name: [(torch.tensor(w, dtype=torch.float64, requires_grad=True), torch.tensor(b, dtype=torch.float64, requires_grad=True), a)
-                    for w, b, a in p[name]] for name in ("edge", "node", "graph")}
+        T64 = lambda v: torch.tensor(v, dtype=torch.float64, requires_grad=True)
+        W = {name: [(w, T64(b), T64(a)) if isinstance(w, str) else (T64(w), T64(b), a) for w, b, a in p[name]] for name in ("edge", "node", "graph")}
         outs_r, pre = _torch_chain_block(csc, *xs, W)
         if any(a == 1 and float(z.detach().abs().min()) < 5e-6 for z, a in pre if z.numel()):
             continue  # a relu pre-activation within fp32 rounding of its kink: re-draw
@@ -162,7 +173,7 @@ def test_chain_block_backward_matches_torch_autograd(gn, case):
         for name, t, r in zip(("d_ef", "d_nf", "d_gf"), xt, xs):
             if t is not None:
                 close(t.grad[0], r.grad, name)
-        refs = [q.grad for name in ("edge", "node", "graph") for w, b, _ in W[name] for q in (w, b)]
+        refs = [q.grad for name in ("edge", "node", "graph") for w, b, a in W[name] for q in ((b, a) if isinstance(w, str) else (w, b))]
         for i, (q, r) in enumerate(zip(leaves, refs)):
             close(q.grad, r, f"param[{i}]")
         return
