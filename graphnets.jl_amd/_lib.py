@@ -23,7 +23,7 @@ FLAG_FORCE_GENERIC, FLAG_NO_MFMA, FLAG_DEFER_GRAPH_UPDATE, FLAG_NO_GRAPH, FLAG_D
 FLAG_FFN_FP32, FLAG_EDGE_FP32, FLAG_PROJ_FP32, FLAG_EDGE_NARROW_FP32 = 0x20, 0x40, 0x80, 0x100
 FLAG_FP32_MFMA = FLAG_FFN_FP32 | FLAG_EDGE_FP32
 FLAG_NO_LN_FUSE, FLAG_LN_STATS_PASS, FLAG_CORE_EDGE_SPLIT, FLAG_NO_FORK = 0x200, 0x400, 0x800, 0x1000
-FLAG_NO_PACK, FLAG_NO_FFE, FLAG_NO_JIT, FLAG_EDGE_N = 0x2000, 0x4000, 0x8000, 0x10000
+FLAG_NO_PACK, FLAG_NO_FFE, FLAG_NO_JIT, FLAG_EDGE_N, FLAG_LN_ON_LOAD = 0x2000, 0x4000, 0x8000, 0x10000, 0x20000
 
 _fp = C.c_void_p  # device float*
 

@@ -87,12 +87,30 @@ __host__ __device__ inline int x6_hidden_of_slot(int kk) {
   const int t = kk >> 4, h = (kk >> 3) & 1, j = kk & 7, q = 8 * t + j;
   return (q & 3) + 8 * (q >> 2) + 4 * h;
 }
+// S16: a 32 x 32 block of a transposed product lives in one f32x16 as four 16 x 16 blocks b = 2 mb + nb (mb: 16 outputs, nb: 16 rows), four registers each
+__device__ __forceinline__ f32x4x x6_sub4(const f32x16x& v, int b) { return f32x4x{v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]}; }
+__device__ __forceinline__ void x6_set4(f32x16x& v, int b, const f32x4x& x) { v[4 * b] = x.x; v[4 * b + 1] = x.y; v[4 * b + 2] = x.z; v[4 * b + 3] = x.w; }
+// six-term product of one 16 x 16 block over one k32-step: small terms first (the order of the 32 x 32 x 16 form)
+__device__ __forceinline__ f32x4x x6_mma16(const bf16x8x (&A)[3], const bf16x8x& bh, const bf16x8x& bm, const bf16x8x& bl, f32x4x acc) {
+  acc = GNX_X6_MFMA16(A[1], bm, acc);
+  acc = GNX_X6_MFMA16(A[2], bh, acc);
+  acc = GNX_X6_MFMA16(A[0], bl, acc);
+  acc = GNX_X6_MFMA16(A[1], bh, acc);
+  acc = GNX_X6_MFMA16(A[0], bm, acc);
+  acc = GNX_X6_MFMA16(A[0], bh, acc);
+  return acc;
+}
 }  // namespace
 
 // (row statistics in registers exist for 128-wide rows: eight k16-steps)
 template <int KSX>
 __device__ __forceinline__ void x6_row_stats_if(const f32x4x (&raw)[KSX][2], float eps, int eps_mode, float& mu, float& inv) {
   if constexpr (KSX == 8) x6_row_stats(raw, eps, eps_mode, mu, inv);
+}
+// ... in the 16 x 16 x 32 form: four k32-steps, four lanes per row
+template <int KS2X>
+__device__ __forceinline__ void x6_row_stats16_if(const f32x4x (&raw)[KS2X][2], float eps, int eps_mode, float& mu, float& inv) {
+  if constexpr (KS2X == 4) x6_row_stats16(raw, eps, eps_mode, mu, inv);
 }
 
 // Prepared weights, per hidden slice hs (32 units) one contiguous block of 2 * NF fragments (NF = 3 D / 16) of 1 KB = 64 lanes x 8 bf16:
@@ -245,6 +263,8 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   constexpr int NF = 3 * KS;          // fragments per product and slice
   constexpr int SLB = 2 * NF * 1024;  // bytes per slice
   constexpr int NSL = H / XHS;
+  constexpr bool S16 = GNX_X6_S16 != 0;  // the 16 x 16 x 32 form (see the top of the file)
+  constexpr int KS2 = D / 32;         // k32-steps of the first product in that form
   static_assert(NF % XW == 0, "fragments of half a slice divide over the waves");
   // W1 and W2 fragments of a slice travel separately: while a wave multiplies slice hs + 1's W1 fragments (first product) it splits slice hs's
   // hidden block, then multiplies it (second product) — see the loop.  ONE W1 buffer (restaged behind a barrier in the middle of the step) and two
@@ -264,6 +284,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
 #endif
   GNX_XSTAMP(0);
   const int hi = lane >> 5, n = lane & 31;
+  const int c16 = lane & 15, q16 = lane >> 4;  // S16: column (row of the batch) within a 16-block, k / output quarter
   const size_t r = blockIdx.y;
   const size_t rows = a.rows;  // per replica
   size_t wg_row0 = (size_t)blockIdx.x * XBM, rend = rows;
@@ -276,6 +297,8 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   // (waves beyond the last row keep working on the clamped last row — they share the barriers — and store nothing)
   const size_t rown = row0 + n < rend ? row0 + n : rend - 1;
   const float* __restrict__ zrow = a.z + (r * rows + rown) * D;
+  // S16: the lane's two rows (column blocks nb = 0, 1 of the wave's 32 rows)
+  const size_t rown16[2] = {row0 + c16 < rend ? row0 + c16 : rend - 1, row0 + 16 + c16 < rend ? row0 + 16 + c16 : rend - 1};
 
   // fragment f of a slice is LDS-DMA piece f (lane l writes bytes [16 l, 16 l + 16) of the piece); which = 0: the W1 half of the slice, 1: the W2 half
   auto stage = [&](int hs, int which, unsigned char* dst) {
@@ -320,10 +343,51 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   }
 
   // ---- the wave's z rows as B fragments: lane (n, hi) holds k = 16 s + 8 hi + j (j < 8) of row n for every k16-step s, in three parts ----
-  bf16x8x zh[KS], zm[KS], zl[KS];
+  bf16x8x zh[KS], zm[KS], zl[KS];  // (S16: index nb * KS2 + s)
   float mu = 0.f, inv = 1.f;
   // load the wave's rows; stats: their statistics from the registers (gnx_x6_stats.h); ln: normalise (and, outside the EDGE form, scale and shift with (g, b)); split
   auto load_z = [&](const float* __restrict__ g, const float* __restrict__ b, bool ln, bool stats) {
+    if constexpr (S16) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const float* __restrict__ zr = a.z + (r * rows + rown16[nb]) * D;
+        f32x4x raw[KS2][2];
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) {
+          raw[s][0] = *reinterpret_cast<const f32x4x*>(zr + 32 * s + 8 * q16);
+          raw[s][1] = *reinterpret_cast<const f32x4x*>(zr + 32 * s + 8 * q16 + 4);
+        }
+        float mu_ = 0.f, inv_ = 1.f;
+        if (a.ln_stats != nullptr && !stats) {
+          const float2 st = reinterpret_cast<const float2*>(a.ln_stats)[r * rows + rown16[nb]];
+          mu_ = st.x; inv_ = st.y;
+        }
+        if (stats) x6_row_stats16_if(raw, a.ln_eps, a.ln_mode, mu_, inv_);
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) {
+          float v[8] = {raw[s][0].x, raw[s][0].y, raw[s][0].z, raw[s][0].w, raw[s][1].x, raw[s][1].y, raw[s][1].z, raw[s][1].w};
+          if (ln) {
+            if constexpr (EDGE) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = (v[j] - mu_) * inv_;
+            } else {
+              const f32x4x g0 = *reinterpret_cast<const f32x4x*>(g + 32 * s + 8 * q16), g1 = *reinterpret_cast<const f32x4x*>(g + 32 * s + 8 * q16 + 4);
+              const f32x4x b0 = *reinterpret_cast<const f32x4x*>(b + 32 * s + 8 * q16), b1 = *reinterpret_cast<const f32x4x*>(b + 32 * s + 8 * q16 + 4);
+              const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = fmaf(gg[j], (v[j] - mu_) * inv_, bb[j]);
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            __bf16 x, y, w;
+            split3x(v[j], x, y, w);
+            zh[nb * KS2 + s][j] = x; zm[nb * KS2 + s][j] = y; zl[nb * KS2 + s][j] = w;
+          }
+        }
+      }
+      return;
+    }
     f32x4x raw[KS][2];
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -393,12 +457,14 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     else return __int_as_float(max(__float_as_int(v), relu_floor));
   };
   // one k16-step's share: X(ux) if ux >= 0, Y(uy) if uy >= 0; rx / ry: the first remainders of the pair in flight
+  // S16: pair U = 4 nb + w is slots j = 2 w, 2 w + 1 of column block nb's B fragment: registers 2 (w & 1), + 1 of block 2 (w >> 1) + nb
+  auto pair_reg = [](int u) -> int { return S16 ? 4 * (2 * ((u & 3) >> 1) + (u >> 2)) + 2 * (u & 1) : 2 * u; };
   auto split_xy = [&](int ux, int uy, const f32x16x& accH, float (&rx)[2], const float (&ry)[2]) {
     float m0 = 0.f, m1 = 0.f, q0, q1;
     unsigned hb = 0, mb = 0;
-    if (ux >= 0) { m0 = relu_bits(accH[2 * ux]); }
+    if (ux >= 0) { m0 = relu_bits(accH[pair_reg(ux)]); }
     if (uy >= 0) { mb = cvt2(ry[0], ry[1]); hmw[uy] = mb; }
-    if (ux >= 0) { m1 = relu_bits(accH[2 * ux + 1]); }
+    if (ux >= 0) { m1 = relu_bits(accH[pair_reg(ux) + 1]); }
     if (uy >= 0) { q0 = ry[0] - __uint_as_float(mb << 16); }
     if (ux >= 0) { hb = cvt2(m0, m1); hhw[ux] = hb; }
     if (uy >= 0) { q1 = ry[1] - __uint_as_float(mb & 0xffff0000u); }
@@ -416,7 +482,8 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
     constexpr bool SPLIT = decltype(split_c)::value;
     const unsigned char* wb = w1 + lane * 16;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) accN[q] = s_b1[hs * XHS + (q & 3) + 8 * (q >> 2) + 4 * hi];
+    for (int q = 0; q < 16; ++q) accN[q] = S16 ? s_b1[hs * XHS + 16 * (q >> 3) + 4 * q16 + (q & 3)]  // block 2 mb + nb = q >> 2: unit 16 mb + 4 q16 + i
+                                               : s_b1[hs * XHS + (q & 3) + 8 * (q >> 2) + 4 * hi];
     constexpr int AD = GNX_X6_ADEPTH;  // weight fragments in flight: AD - 1 k16-steps ahead of their MFMAs
     bf16x8x A[AD][3];
 #pragma unroll
@@ -439,12 +506,20 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       }
       constexpr bool PIECE = !std::is_same<std::decay_t<decltype(piece)>, std::nullptr_t>::value;
       if constexpr (PIECE) { if (s < NF / XW) piece(s); }
+      if constexpr (S16) {  // group s = 2 s32 + mb: the three fragments of (k32-step s32, output block mb) against both column blocks
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const int b = 2 * (s & 1) + nb, zi = nb * KS2 + (s >> 1);
+          x6_set4(accN, b, x6_mma16(A[c], zh[zi], zm[zi], zl[zi], x6_sub4(accN, b)));
+        }
+      } else {
       accN = GNX_X6_MFMA(A[c][1], zm[s], accN, 0, 0, 0);  // small terms first
       accN = GNX_X6_MFMA(A[c][2], zh[s], accN, 0, 0, 0);
       accN = GNX_X6_MFMA(A[c][0], zl[s], accN, 0, 0, 0);
       accN = GNX_X6_MFMA(A[c][1], zh[s], accN, 0, 0, 0);
       accN = GNX_X6_MFMA(A[c][0], zm[s], accN, 0, 0, 0);
       accN = GNX_X6_MFMA(A[c][0], zh[s], accN, 0, 0, 0);
+      }
       if constexpr (SPLIT) {
         // (instruction selection places pure vector instructions wherever their operands are ready — Y(s - 1) right behind X(s - 1), in the
         // previous step's region, one dependent chain again; the empty volatile statement pins the remainders to THIS region)
@@ -455,6 +530,16 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
         }
       }
       if (s + AD - 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+      if constexpr (S16) {  // twelve 16-cycle matrix instructions per group: the same 13 (26) vector instructions of the split spread one (two) per gap
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if constexpr (PIECE) { if (i == 0 && s < NF / XW) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
+          if constexpr (SPLIT) { if constexpr (PPS == 1) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); else __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (SPLIT) { if constexpr (PPS == 1) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); }
+      } else {
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -463,6 +548,7 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       if constexpr (SPLIT) { if constexpr (PPS == 1) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); else __builtin_amdgcn_sched_group_barrier(0x002, 6, 0); }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (SPLIT) {  // Y of the last pair(s) (beside the first matrix instructions of the second product)
@@ -487,18 +573,24 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
         for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * (g + 1) + p3) * 1024);
       }
       if constexpr (PIECE) { if (g < NF / XW) piece(g); }
+      constexpr int NMM = S16 ? 12 : 6;  // matrix instructions of the group
+      if constexpr (S16) {  // group g = output block of 16 (block t = g & 1 of accO[ob]); the slice's 32 hidden units are ONE k32-step: hh / hm / hl [nb]
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) x6_set4(accO[ob], 2 * t + nb, x6_mma16(A[c], hh[nb], hm[nb], hl[nb], x6_sub4(accO[ob], 2 * t + nb)));
+      } else {
       accO[ob] = GNX_X6_MFMA(A[c][1], hm[t], accO[ob], 0, 0, 0);
       accO[ob] = GNX_X6_MFMA(A[c][2], hh[t], accO[ob], 0, 0, 0);
       accO[ob] = GNX_X6_MFMA(A[c][0], hl[t], accO[ob], 0, 0, 0);
       accO[ob] = GNX_X6_MFMA(A[c][1], hh[t], accO[ob], 0, 0, 0);
       accO[ob] = GNX_X6_MFMA(A[c][0], hm[t], accO[ob], 0, 0, 0);
       accO[ob] = GNX_X6_MFMA(A[c][0], hh[t], accO[ob], 0, 0, 0);
+      }
       if (g + 1 < 2 * NOB) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
       if constexpr (PIECE) {
-        if (g < NF / XW) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 5, 0); }
-        else __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        if (g < NF / XW) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, NMM - 1, 0); }
+        else __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
       } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMM, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -606,26 +698,37 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
       int er = er0, eq = eq0;
       asm volatile("" : "+v"(er), "+v"(eq));
       if (ob + 1 < NOB) stage_e(ob + 1, nxt);
-      const unsigned char* wb = cur + lane * 16;
+      // S16: k_edge_x6_prep's planes keep their 32 x 32 x 16 fragment order (fragment 3 s + p, lane (m, h): W[16 s + 8 h + j][32 ob + m]); lane (c16, q16)
+      // of group (s32, mb) needs W[32 s32 + 8 q16 + j][32 ob + 16 mb + c16] = fragment 3 (2 s32 + (q16 >> 1)) + p, lane 16 mb + c16 + 32 (q16 & 1)
+      const unsigned char* wb = S16 ? cur + (3 * (q16 >> 1)) * 1024 + (c16 + 32 * (q16 & 1)) * 16 : cur + lane * 16;
+      auto eoff = [](int g, int p3) -> int { return S16 ? (6 * (g >> 1) + p3) * 1024 + (g & 1) * 256 : (3 * g + p3) * 1024; };
       f32x16x acc;
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.f;
       bf16x8x A[2][3];
 #pragma unroll
-      for (int p3 = 0; p3 < 3; ++p3) A[0][p3] = *reinterpret_cast<const bf16x8x*>(wb + p3 * 1024);
+      for (int p3 = 0; p3 < 3; ++p3) A[0][p3] = *reinterpret_cast<const bf16x8x*>(wb + eoff(0, p3));
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int c = s & 1;
         if (s + 1 < KS) {
 #pragma unroll
-          for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8x*>(wb + (3 * (s + 1) + p3) * 1024);
+          for (int p3 = 0; p3 < 3; ++p3) A[c ^ 1][p3] = *reinterpret_cast<const bf16x8x*>(wb + eoff(s + 1, p3));
         }
+        if constexpr (S16) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const int b = 2 * (s & 1) + nb, zi = nb * KS2 + (s >> 1);
+            x6_set4(acc, b, x6_mma16(A[c], zh[zi], zm[zi], zl[zi], x6_sub4(acc, b)));
+          }
+        } else {
         acc = GNX_X6_MFMA(A[c][1], zm[s], acc, 0, 0, 0);  // small terms first
         acc = GNX_X6_MFMA(A[c][2], zh[s], acc, 0, 0, 0);
         acc = GNX_X6_MFMA(A[c][0], zl[s], acc, 0, 0, 0);
         acc = GNX_X6_MFMA(A[c][1], zh[s], acc, 0, 0, 0);
         acc = GNX_X6_MFMA(A[c][0], zm[s], acc, 0, 0, 0);
         acc = GNX_X6_MFMA(A[c][0], zh[s], acc, 0, 0, 0);
+        }
       }
       // the gathered addends of the slice (8 rows x 128 contiguous bytes per instruction) and the residual quads (x: the cache has the rows) are
       // requested here — across the matrix instructions they would not fit the register file beside out^T —, and the FeedForward block of these
@@ -641,15 +744,19 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
         const unsigned lrow = (unsigned)min(wv * XR + er + 8 * i, trows - 1);
         u1[i] = *reinterpret_cast<const f32x4x*>(xres + (lrow * D + 32 * ob + 4 * eq));
       }
+      // (S16: block b = 2 mb + nb of the container holds outputs 16 mb + 4 q16 + (0..3) of row 16 nb + c16)
+      auto stage_block = [&](const f32x16x& blk) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4x*>(sE + n * ELDE + 8 * g + 4 * hi) = f32x4x{accF[4 * g], accF[4 * g + 1], accF[4 * g + 2], accF[4 * g + 3]};
+        for (int g = 0; g < 4; ++g) {
+          float* d = S16 ? sE + (16 * (g & 1) + c16) * ELDE + 16 * (g >> 1) + 4 * q16 : sE + n * ELDE + 8 * g + 4 * hi;
+          *reinterpret_cast<f32x4x*>(d) = f32x4x{blk[4 * g], blk[4 * g + 1], blk[4 * g + 2], blk[4 * g + 3]};
+        }
+      };
+      stage_block(accF);
 #pragma unroll
       for (int i = 0; i < 4; ++i) vf[i] = *reinterpret_cast<const f32x4x*>(sE + (er + 8 * i) * ELDE + 4 * eq);
       // (LDS operations of one wave execute in order: the edge block may follow into the same slice)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<f32x4x*>(sE + n * ELDE + 8 * g + 4 * hi) = f32x4x{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      stage_block(acc);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the addends — and with them (in-order counter) the next slice's fragments
       asm volatile("" : "+v"(us[0]), "+v"(us[1]), "+v"(us[2]), "+v"(us[3]), "+v"(ud[0]), "+v"(ud[1]), "+v"(ud[2]), "+v"(ud[3]));
       asm volatile("" : "+v"(u1[0]), "+v"(u1[1]), "+v"(u1[2]), "+v"(u1[3]));
@@ -769,8 +876,10 @@ __global__ __launch_bounds__(64 * XW) __attribute__((amdgpu_waves_per_eu(2, D ==
   for (int ob = 0; ob < NOB; ++ob) {
     const f32x4x bq = a.b2 ? *reinterpret_cast<const f32x4x*>(a.b2 + 32 * ob + 4 * eq) : zero;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<f32x4x*>(sE + n * ELD + 8 * g + 4 * hi) = f32x4x{accO[ob][4 * g], accO[ob][4 * g + 1], accO[ob][4 * g + 2], accO[ob][4 * g + 3]};
+    for (int g = 0; g < 4; ++g) {  // (S16: block g = 2 mb + nb: outputs 16 mb + 4 q16 + (0..3) of row 16 nb + c16)
+      float* d = S16 ? sE + (16 * (g & 1) + c16) * ELD + 16 * (g >> 1) + 4 * q16 : sE + n * ELD + 8 * g + 4 * hi;
+      *reinterpret_cast<f32x4x*>(d) = f32x4x{accO[ob][4 * g], accO[ob][4 * g + 1], accO[ob][4 * g + 2], accO[ob][4 * g + 3]};
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f32x4x v = *reinterpret_cast<const f32x4x*>(sE + (er + 8 * i) * ELD + 4 * eq);

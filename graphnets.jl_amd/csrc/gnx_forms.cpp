@@ -29,7 +29,7 @@ uint32_t env_form_flags() {
         {"GNX_FFN_FP32", GNX_FLAG_FFN_FP32},       {"GNX_EDGE_FP32", GNX_FLAG_EDGE_FP32},           {"GNX_PROJ_FP32", GNX_FLAG_PROJ_FP32},
         {"GNX_EDGE_NARROW_FP32", GNX_FLAG_EDGE_NARROW_FP32}, {"GNX_NO_LN_FUSE", GNX_FLAG_NO_LN_FUSE}, {"GNX_LN_STATS_PASS", GNX_FLAG_LN_STATS_PASS},
         {"GNX_CORE_EDGE_SPLIT", GNX_FLAG_CORE_EDGE_SPLIT}, {"GNX_NO_FORK", GNX_FLAG_NO_FORK},       {"GNX_NO_PACK", GNX_FLAG_NO_PACK},
-        {"GNX_NO_FFE", GNX_FLAG_NO_FFE},           {"GNX_EDGE_N", GNX_FLAG_EDGE_N}};
+        {"GNX_NO_FFE", GNX_FLAG_NO_FFE},           {"GNX_EDGE_N", GNX_FLAG_EDGE_N},                 {"GNX_LN_ON_LOAD", GNX_FLAG_LN_ON_LOAD}};
     for (const auto& t : tab)
       if (env_on(t.name)) flags |= t.bit;
     const char* j = getenv("GNX_JIT");  // (GNX_JIT=0 is the historical spelling of "no run-time specialisation")

@@ -419,8 +419,29 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
                         ffn_x6_applies(x[0], d[0], p->ff[0], out[0], x[0], out[0], sizeof(float) * rows[0] * d[0]);
   // ... and then ONE launch does both (the edge form of k_ffn_x6: ef' stays in the accumulator — never written, never read back; GNX_CORE_EDGE_SPLIT=1: two launches)
   const bool fuse_e = inline_e && !form(GNX_FLAG_CORE_EDGE_SPLIT) && !(edge_n_enabled() && d[1] == 64);  // (the opt-in k_edge_n gathers RAW source rows: its projection tables are not the one-launch form's)
+  // Round 6 (profiles/r06_overlap_hazard.log): the GENERAL kernels (k_rows_gemm, k_ffn_fused) come out wrong now and then — accumulator register
+  // pairs of half a wave, on either matrix instruction — while another stream keeps a dense bf16 GEMM resident, but ONLY in calls that normalise
+  // on load from a statistics table; the same kernels on materialised LayerNorm outputs (GNX_FLAG_NO_LN_FUSE: 0 of 240 runs) and the six-term
+  // kernels with their own row handling (0 of 960) were never seen wrong, and the statistics kernel alone is exact (5 500 runs).  The cause is
+  // not established, so the default keeps every general kernel away from a statistics table: an entity whose rows would be normalised on load
+  // by a general kernel gets its LayerNorms MATERIALISED instead (k_layernorm2, one more pass over rows that are few whenever this happens:
+  // below 4096, or widths without a six-term kernel).  GNX_FLAG_LN_ON_LOAD restores the statistics-table forms (the tests of those forms; a
+  // host that owns the device exclusively).
+  const bool ln_on_load = form(GNX_FLAG_LN_ON_LOAD) || form(GNX_FLAG_FP32_MFMA | GNX_FLAG_PROJ_FP32 | GNX_FLAG_LN_STATS_PASS | GNX_FLAG_CORE_EDGE_SPLIT);  // (the diagnostic forms keep their tables)
+  if (wide_ln && !ln_on_load && !inline_e) wide_ln = false;  // the edge rows' table would feed k_rows_gemm / k_ffn_fused: everything materialised (the branch below)
+  const bool node_x6_forms = d[0] == 128 && d[1] == 64 && h->N >= 4096 && p->block.nodefn.act <= GNX_ACT_RELU;  // k_proj_x6, k_node_x6, k_ffn_x6<64> take the node rows
+  const bool node_mat = wide_ln && !ln_on_load && !node_x6_forms;  // edges by the six-term kernels (statistics in registers), node LayerNorms materialised
   if (wide_ln) {
-    const float* stats[2] = {l1[0], l1[1]};  // the (unused) gn1 buffers hold the statistics: 2 floats per row
+    const float* stats[2] = {l1[0], node_mat ? nullptr : l1[1]};  // the (unused) gn1 buffers hold the statistics: 2 floats per row
+    const float* node_in = node_mat ? l1[1] : x[1];              // node_mat: gn1(nf) itself (and l2[1] = gn2(nf) for the FeedForward)
+    auto node_ln = [&](hipStream_t st) -> int32_t {
+      return node_mat ? launch_layernorm2(x[1], rows[1], d[1], p->ln1[1], p->ln2[1], p->eps, p->eps_mode, l1[1], l2[1], st)
+                      : launch_ln_stats(x[1], rows[1], d[1], p->eps, p->eps_mode, l1[1], st);
+    };
+    auto node_ffn = [&](hipStream_t st) -> int32_t {  // out[1] = nf' + nf + FF(gn2(nf))
+      return node_mat ? launch_ffn_fused(h, 1, l2[1], d[1], p->ff[1], out[1], x[1], out[1], R, st)
+                      : launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, st, l1[1], &p->ln2[1], l2[1], sizeof(float) * rows[1] * d[1]);
+    };
     const bool no_fork0 = form(GNX_FLAG_NO_FORK);
     // A side stream and its pair of events from the handle's pool, held while this call enqueues its work (a second host thread in this section —
     // same handle, another stream, other buffers — takes the next set; with every set taken a caller runs everything on its own stream).
@@ -440,8 +461,8 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       bool took0 = false;
       GNX_HIP(hipEventRecord(aux->fork, s));
       GNX_HIP(hipStreamWaitEvent(ax, aux->fork, 0));
-      rc = launch_ln_stats(x[1], rows[1], d[1], p->eps, p->eps_mode, l1[1], ax);
-      if (rc == GNX_OK) rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, ax, 4, p->ln1, p->eps, p->eps_mode, &took0, stats);
+      rc = node_ln(ax);
+      if (rc == GNX_OK) rc = block_forward_impl(h, &b, x[0], node_in, l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, ax, 4, p->ln1, p->eps, p->eps_mode, &took0, stats);
       const hipError_t e1 = hipEventRecord(aux->join, ax);
       const int32_t rc2 = inline_e ? GNX_OK : launch_ln_stats(x[0], rows[0], d[0], p->eps, p->eps_mode, l1[0], s);
       const hipError_t e2 = hipStreamWaitEvent(s, aux->join, 0);
@@ -450,8 +471,8 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       GNX_HIP(e1);
       GNX_HIP(e2);
     } else {
-      for (int t = inline_e ? 1 : 0; t < 2; ++t)
-        if ((rc = launch_ln_stats(x[t], rows[t], d[t], p->eps, p->eps_mode, l1[t], s))) return rc;
+      if (!inline_e && (rc = launch_ln_stats(x[0], rows[0], d[0], p->eps, p->eps_mode, l1[0], s))) return rc;
+      if ((rc = node_ln(s))) return rc;
     }
     // The graph level of the core — the block's graph update (four 5-us launches) and the G-row FeedForward — is independent of the edge /
     // node FeedForwards that follow the block: it runs on the handle's side stream behind them (fork after the node update, join
@@ -459,7 +480,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
     const bool no_fork = no_fork0;
     const bool fork = !no_fork && aux != nullptr;
     bool took = false;
-    rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, (fork ? 1 : 3) | (fork0 ? 8 : 0), p->ln1, p->eps, p->eps_mode, &took, stats,
+    rc = block_forward_impl(h, &b, x[0], node_in, l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, s, (fork ? 1 : 3) | (fork0 ? 8 : 0), p->ln1, p->eps, p->eps_mode, &took, stats,
                             nullptr, fuse_e ? &p->ff[0] : nullptr, fuse_e ? &p->ln2[0] : nullptr, nullptr, nullptr, nullptr, nullptr, inline_e, fuse_e ? l2[0] : nullptr);
     if (rc) return rc;
     if (!took) return fail(GNX_ERR_INVALID_ARG, "gnx_core_forward: the block declined the form it had accepted");
@@ -467,7 +488,7 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       hipStream_t ax = aux->stream;
       GNX_HIP(hipEventRecord(aux->fork, s));
       GNX_HIP(hipStreamWaitEvent(ax, aux->fork, 0));
-      rc = block_forward_impl(h, &b, x[0], x[1], l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, ax, 2, p->ln1, p->eps, p->eps_mode, &took, stats);
+      rc = block_forward_impl(h, &b, x[0], node_in, l1[2], R, out[0], out[1], out[2], base + off[7], ws_bytes - off[7], flags, ax, 2, p->ln1, p->eps, p->eps_mode, &took, stats);
       if (rc == GNX_OK) {  // the G-row FeedForward: out = gf' + gf + FF(gn2(gf)); the hidden buffer is its alone (the wide FeedForwards are the fused kernel)
         float* hidden2 = reinterpret_cast<float*>(base + off[6]);
         rc = launch_ffn_fused(h, 2, l2[2], d[2], p->ff[2], out[2], x[2], out[2], R, ax);
@@ -485,14 +506,14 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       // the node FeedForward rides on the side stream too: its workgroups fill the CUs that the edge FeedForward's last, partly
       // filled round of tiles leaves idle (7813 tiles on 512 slots: 15.26 rounds)
       static const bool node_ffn_main = getenv("GNX_NODE_FFN_MAIN") != nullptr;
-      if (rc == GNX_OK && !node_ffn_main) rc = launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, ax, l1[1], &p->ln2[1], l2[1], sizeof(float) * rows[1] * d[1]);
+      if (rc == GNX_OK && !node_ffn_main) rc = node_ffn(ax);
       // the join is recorded even after a failure: a capture must not end with the side stream un-joined
       const hipError_t e1 = hipEventRecord(aux->join, ax);
       // (the edges' gn2 buffer is unused in this form: room for the split weight planes of k_ffn_x6)
       int32_t rc2 = fuse_e ? GNX_OK  // (the block's edge launch was the edge form of k_ffn_x6: out[0] is final)
                            : launch_ffn_fused(h, 0, x[0], d[0], p->ff[0], out[0], x[0], out[0], R, s, inline_e ? nullptr : l1[0], &p->ln2[0], l2[0], sizeof(float) * rows[0] * d[0], inline_e,
                                               p->eps, p->eps_mode);
-      if (rc2 == GNX_OK && node_ffn_main) rc2 = launch_ffn_fused(h, 1, x[1], d[1], p->ff[1], out[1], x[1], out[1], R, s, l1[1], &p->ln2[1], l2[1], sizeof(float) * rows[1] * d[1]);
+      if (rc2 == GNX_OK && node_ffn_main) rc2 = node_ffn(s);
       const hipError_t e2 = hipStreamWaitEvent(s, aux->join, 0);
       if (rc) return rc;
       if (rc2) return rc2;
@@ -524,6 +545,10 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
       if (wide_ln && t < 2) {
         const bool inl = t == 0 && inline_e;
         if (t == 0 && fuse_e) continue;  // (the block's edge launch was the edge form of k_ffn_x6: out[0] is final)
+        if (t == 1 && node_mat) {        // (materialised node LayerNorms: gn2(nf) is in l2[1])
+          if ((rc = launch_ffn_fused(h, 1, l2[1], d[1], p->ff[1], out[1], x[1], out[1], R, s))) return rc;
+          continue;
+        }
         if ((rc = launch_ffn_fused(h, t, x[t], d[t], p->ff[t], out[t], x[t], out[t], R, s, inl ? nullptr : l1[t], &p->ln2[t], l2[t], sizeof(float) * rows[t] * d[t], inl, p->eps, p->eps_mode))) return rc;
         continue;
       }

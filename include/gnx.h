@@ -100,7 +100,10 @@ extern "C" {
 #define GNX_FLAG_NO_FFE 0x4000u          /* narrow GNCore: edge FeedForward in k_core_post3 instead of the block kernel's edge lanes       */
 #define GNX_FLAG_NO_JIT 0x8000u          /* never specialise a kernel at run time (generic kernels instead); env GNX_JIT=0 / GNX_NO_JIT=1   */
 #define GNX_FLAG_EDGE_N 0x10000u         /* opt-in: k_edge_n (source rows gathered raw, K = 128 + 64; csrc/gnx_edge_n.hip) for the edge update */
-#define GNX_FLAG_FORMS_MASK 0x1ffe0u
+#define GNX_FLAG_LN_ON_LOAD 0x20000u     /* wide GNCore: normalise on load from a row-statistics table also where a GENERAL kernel (k_rows_gemm, k_ffn_fused)
+                                          * consumes it — rounds 2-5's default; round 6 materialises those LayerNorms instead (csrc/gnx_forward.hip,
+                                          * profiles/r06_overlap_hazard.log): use only on a device no other stream shares                        */
+#define GNX_FLAG_FORMS_MASK 0x3ffe0u
 GNX_API uint32_t gnx_default_flags(void); /* the forms the environment switched on for this process */
 
 typedef struct gnx_graphs gnx_graphs; /* opaque; replaces GNGraphBatch (src/gngraphbatch.jl:1-54) */

@@ -127,11 +127,21 @@ def test_core_wide_layernorm_on_load_equals_materialised(gn, R, eps_mode):
     ef = ef + 3.0  # a mean far from zero: the statistics matter
     core = U.core_from_params(gn, p)
     x = U.to_nt(gn, g, ef, nf, gf)
+    # round 6: with 700 nodes the node rows' consumers are the general kernels, whose LayerNorms the DEFAULT materialises (k_layernorm2 for the
+    # node rows, no statistics table: csrc/gnx_forward.hip) — bit-identical in the node rows' arithmetic to the table form, which the flag selects
+    gn.profile_reset(); gn.profile_enable(True)
+    yd = core(x)
+    gn.profile_enable(False)
+    names_d = set(gn.profile_read()); gn.profile_reset()
+    assert "k_ln_stats" not in names_d and "k_layernorm2" in names_d and "k_core_edge_x6" in names_d and "k_ffn_fused" in names_d, names_d
+    core.flags |= gn._lib.FLAG_LN_ON_LOAD
     gn.profile_reset(); gn.profile_enable(True)
     y = core(x)
     gn.profile_enable(False)
     names = set(gn.profile_read()); gn.profile_reset()
     assert "k_ln_stats" in names and "k_ffn_fused" in names, names
+    for name, a, b in zip(("ef", "nf", "gf"), (yd.ef, yd.nf, yd.gf), (y.ef, y.nf, y.gf)):
+        U.assert_same_formula(U.from_jl(a), U.from_jl(b), f"{name}: node LayerNorms materialised (default) against the statistics-table form")
     with U.with_flags(core, gn._lib.FLAG_NO_LN_FUSE):
         gn.profile_enable(True)
         y0 = core(x)
