@@ -64,10 +64,16 @@ def _case(gn, dims, big, rng, pdrop, hidden_act):
         scales.append((x.abs() + b.abs() + (1 + m) * (hidden_fn(zh).abs() @ W[f"ff_{t}_W2"].abs().T + W[f"ff_{t}_b2"].abs())).detach())
     if hidden_act == "relu" and not _kink_free(pre):
         return False
-    for name, got, ref, S in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), outs_r, scales):
-        err = (got.permute(2, 1, 0)[0].detach().double().cpu() - ref.detach()).abs()
-        # 1e-5 of the scale through the core (LayerNorm's 1/sigma amplifies the block's inputs: a flat factor on top of the summed magnitudes)
-        assert float((err / (S + 1.0)).max()) <= 1e-5 * 8, f"forward {name}: {float((err / (S + 1.0)).max()):.3e}"
+    # the bound every forward test uses, 1e-5 . S elementwise with the ORACLE's worst-case scale (|W| . |x| + |b| through every sum and through
+    # LayerNorm's 1 / sigma: O.core_forward_sparse) — the FeedForward term's share counted (1 + 2 / (1 - p)) times: it enters scaled by the mask
+    # (<= 1 / (1 - p)) and the correction y += (m - 1) . f adds and subtracts it once more.  (Until round 6 this compared against the summed output
+    # magnitudes times a flat 8, which a graph-level sum over thousands of rows does not honour: 1.06e-4 on gf after an unrelated re-association.)
+    _, scale_o = O.core_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    for name, got, ref, S, So in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), outs_r, scales, scale_o):
+        err = (got.permute(2, 1, 0)[0].detach().double().cpu() - ref.detach()).abs().numpy()
+        bound = 1e-5 * (1.0 + 2.0 / (1.0 - pdrop)) * np.asarray(So[0], dtype=np.float64) + 1e-30
+        assert float((err / bound).max()) <= 1.0, f"forward {name}: worst ratio to 1e-5 . S {float((err / bound).max()):.3f}"
+        assert float(err.max()) <= 1e-5 * float(ref.detach().abs().max()), f"forward {name}: normwise {float(err.max()) / float(ref.detach().abs().max()):.3e}"
     cot = [torch.from_numpy(rng.standard_normal(tuple(o.shape))) for o in outs_r]
     sum((o * c).sum() for o, c in zip(outs_r, cot)).backward()
     loss = sum((o.permute(2, 1, 0)[0] * c.to(dev).float()).sum() for o, c in zip((y.ef, y.nf, y.gf), cot))

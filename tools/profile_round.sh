@@ -16,7 +16,7 @@ GNX_PROF_SQ=0 GNX_PROF_MFMA=1 GNX_PROF_DIMS=core bash tools/profile.sh ${R}_core
 for M in c4 c4_10-5-3; do
   OUT=$REPO/gpurun_out/prof_${R}_$M; mkdir -p $OUT
   CD=""; [ "$M" = "c4_10-5-3" ] && CD="--core-dims 10,5,3"
-  B="python3 $REPO/bench.py --model c4 --steps 3 --warmup 1 --no-cpu-baseline --no-c-abi $CD"
+  B="python3 $REPO/bench.py --model c4 --steps 3 --warmup 1 --no-cpu-baseline --no-c-abi --full-line $CD"
   (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $B > $OUT/kt.log 2>&1
    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1
