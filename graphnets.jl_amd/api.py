@@ -100,6 +100,8 @@ class GNGraphBatch:
         if _dense_packed is not None:
             buf, nn, kind, on_device, nbytes, ptr = _dense_packed
             with torch.cuda.device(self.device):
+                if on_device:  # the library scans a device buffer on the NULL stream: whatever produced it on torch's current (possibly non-blocking) stream is complete first
+                    torch.cuda.current_stream(self.device).synchronize()
                 check(lib.gnx_graphs_create_dense_packed(ptr, nbytes, nn.ctypes.data_as(C.POINTER(C.c_int64)), int(nn.size), kind, 1, 1 if on_device else 0,
                                                          C.byref(self._h)))
             self._adj_mats = None

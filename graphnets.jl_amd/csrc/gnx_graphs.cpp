@@ -480,9 +480,13 @@ int32_t gnx_graphs_create_dense_packed(const void* adj_cat, int64_t adj_bytes, c
   int64_t total = 0;
   for (int64_t g = 0; g < n_graphs; ++g) {
     if (n_nodes[g] <= 0) return fail(GNX_ERR_ADJ_SHAPE, "adjacency matrix must be N x N with N >= 1 (checks.jl:11)");
-    total += n_nodes[g] * n_nodes[g];
+    // (n^2 and the running total are checked products / sums — n = 2^32 wrapped to 0 and passed the size check below)
+    int64_t sq = 0;
+    if (n_nodes[g] > (int64_t)1 << 31 || __builtin_mul_overflow(n_nodes[g], n_nodes[g], &sq) || __builtin_add_overflow(total, sq, &total))
+      return fail(GNX_ERR_TOO_LARGE, "adjacency matrices too large: sum(n_nodes^2) exceeds the 63-bit element count");
   }
-  if (adj_bytes != total * esz_tab[elem_kind]) return fail(GNX_ERR_INVALID_ARG, "adj_bytes must equal sum(n_nodes^2) elements");
+  int64_t want_bytes = 0;
+  if (__builtin_mul_overflow(total, esz_tab[elem_kind], &want_bytes) || adj_bytes != want_bytes) return fail(GNX_ERR_INVALID_ARG, "adj_bytes must equal sum(n_nodes^2) elements");
   if (on_device) return create_dense_impl(nullptr, adj_cat, 1, n_nodes, n_graphs, elem_kind, row_major, out);
   std::vector<const void*> ptrs((size_t)n_graphs);  // (the host scan of small batches walks per-graph pointers)
   int64_t at = 0;

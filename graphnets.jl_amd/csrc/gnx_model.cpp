@@ -73,6 +73,16 @@ int32_t gnx_model_create(const gnx_graphs* h, const gnx_layer* layers, int32_t n
   m->h = h;
   m->R = R;
   m->layers.resize((size_t)n_layers);
+  // every error path below frees what the model holds so far (the early returns used to leak the prepared objects)
+  struct Cleanup {
+    gnx_model* m;
+    ~Cleanup() {
+      if (!m) return;
+      for (void* q : m->owned) (void)hipFree(q);
+      for (gnx_prepared* x : m->prepared) gnx_prepared_destroy(x);
+      m->owned.clear(); m->prepared.clear();
+    }
+  } cleanup{m.get()};
   for (int i = 0; i < n_layers; ++i) {
     gnx_model::Layer& L = m->layers[(size_t)i];
     if (!layers[i].params) return fail(GNX_ERR_INVALID_ARG, "gnx_model_create: layer params is NULL");
@@ -92,13 +102,13 @@ int32_t gnx_model_create(const gnx_graphs* h, const gnx_layer* layers, int32_t n
       if (L.kind == GNX_LAYER_BLOCK && !L.block.prepared) { rcp = gnx_block_prepare(&L.block, nullptr, &q); L.block.prepared = q; }
       else if (L.kind == GNX_LAYER_CORE && !L.core.prepared) { rcp = gnx_core_prepare(&L.core, nullptr, &q); L.core.prepared = q; }
       if (q) m->prepared.push_back(q);
-      if (rcp) { for (gnx_prepared* x : m->prepared) gnx_prepared_destroy(x); return rcp; }
+      if (rcp) return rcp;
     }
     const int in[3] = {L.block.de, L.block.dn, L.block.dg}, o[3] = {L.block.oe, L.block.on, L.block.og};
     for (int t = 0; t < 3; ++t) { L.in[t] = in[t]; L.out[t] = o[t]; }
     if (i > 0)
       for (int t = 0; t < 3; ++t)
-        if (m->layers[(size_t)i - 1].out[t] != L.in[t]) { for (gnx_prepared* x : m->prepared) gnx_prepared_destroy(x); return fail(GNX_ERR_DIMS, "gnx_model_create: output widths of a layer differ from the next layer's input widths"); }
+        if (m->layers[(size_t)i - 1].out[t] != L.in[t]) return fail(GNX_ERR_DIMS, "gnx_model_create: output widths of a layer differ from the next layer's input widths");
   }
   // intermediates + workspaces (this also compiles run-time specialised kernels: gnx_block_workspace_bytes)
   auto alloc = [&](size_t bytes, void** p) -> int32_t {
@@ -112,12 +122,15 @@ int32_t gnx_model_create(const gnx_graphs* h, const gnx_layer* layers, int32_t n
   for (int i = 0; i < n_layers; ++i) {
     gnx_model::Layer& L = m->layers[(size_t)i];
     L.ws_bytes = L.kind == GNX_LAYER_BLOCK ? gnx_block_workspace_bytes(h, &L.block, R) : gnx_core_workspace_bytes(h, &L.core, R);
-    if (L.ws_bytes == 0) { for (void* q : m->owned) (void)hipFree(q); for (gnx_prepared* x : m->prepared) gnx_prepared_destroy(x); return fail(GNX_ERR_DIMS, "gnx_model_create: a layer's parameters were rejected (widths)"); }
+    if (L.ws_bytes == 0) return fail(GNX_ERR_DIMS, "gnx_model_create: a layer's parameters were rejected (widths)");
     int32_t rc = alloc(L.ws_bytes, &L.ws);
     if (!rc && i + 1 < n_layers)
       for (int t = 0; t < 3 && !rc; ++t) rc = alloc(sizeof(float) * rows[t] * (size_t)L.out[t], reinterpret_cast<void**>(&L.y[t]));
-    if (rc) { for (void* q : m->owned) (void)hipFree(q); for (gnx_prepared* x : m->prepared) gnx_prepared_destroy(x); return rc; }
+    if (rc) return rc;
   }
+  // the planes were made by launches on the NULL stream: they are complete before any forward on ANY stream (a non-blocking one included) reads them
+  if (!m->prepared.empty()) GNX_HIP(hipStreamSynchronize(nullptr));
+  cleanup.m = nullptr;
   *out = m.release();
   return GNX_OK;
 }

@@ -237,10 +237,13 @@ struct WaveLayout {
 #ifndef GNX_GEMM_WPE_PLAIN  // waves per SIMD of the plain quad GEMM (no epilogue operand, lean loader: the node projections, FeedForward layers, dX of the backward)
 #define GNX_GEMM_WPE_PLAIN 3
 #endif
-template <int BN, int NL, int LD>
-constexpr int gemm_wpe() { return (BN == 128 && NL == 0 && LD == 0) ? GNX_GEMM_WPE_PLAIN : WaveLayout<BN>::WPE; }
+#ifndef GNX_GEMM_WPE_X6  // waves per SIMD of the 128-column kernels in the six-term form (three bf16 parts of each fragment: ~25 more live registers than the fp32 form)
+#define GNX_GEMM_WPE_X6 3
+#endif
+template <int BN, int NL, int LD, bool X6 = false>
+constexpr int gemm_wpe() { return (X6 && BN == 128) ? GNX_GEMM_WPE_X6 : ((BN == 128 && NL == 0 && LD == 0) ? GNX_GEMM_WPE_PLAIN : WaveLayout<BN>::WPE); }
 template <int BN, bool VEC4, int KC, int NL, bool TRANS, int LD, bool X6>
-__global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per_eu(gemm_wpe<BN, NL, LD>()))) void k_rows_gemm(WideArgs a) {
+__global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per_eu(gemm_wpe<BN, NL, LD, X6>()))) void k_rows_gemm(WideArgs a) {
   using L = WaveLayout<BN>;
   constexpr int WT = L::WT;
   constexpr bool ONESEG = NL == 3;  // the projected edge update: ONE segment, the tile's own rows (mode 0) — its record stays in scalar registers,
@@ -697,15 +700,16 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
       // same LDS reads as the fp32 form below (eight per 16-step, row and fragment), 6 x 8-pass instead of 8 x 16-pass matrix instructions
 #pragma unroll
       for (int s16 = 0; s16 < KC / 16; ++s16) {
-        X6Frag fa6[L::TM], fb6[L::TN];
-#pragma unroll
-        for (int i = 0; i < L::TM; ++i) fa6[i] = x6_frag(sA + ((i * L::WM + wm) * 32 + l31) * LDA + 16 * s16 + 8 * hi, 1);
+        // (one A fragment alive at a time: with all of a step's fragments split up front the 128-column kernels kept 25-40 registers in scratch memory)
+        X6Frag fb6[L::TN];
 #pragma unroll
         for (int j = 0; j < L::TN; ++j) fb6[j] = x6_frag(sB + (16 * s16 + 8 * hi) * BN + (wn * L::TN + j) * 32 + l31, BN);
 #pragma unroll
-        for (int i = 0; i < L::TM; ++i)
+        for (int i = 0; i < L::TM; ++i) {
+          const X6Frag fa6 = x6_frag(sA + ((i * L::WM + wm) * 32 + l31) * LDA + 16 * s16 + 8 * hi, 1);
 #pragma unroll
-          for (int j = 0; j < L::TN; ++j) acc[i][j] = x6_mma(fa6[i], fb6[j], acc[i][j]);
+          for (int j = 0; j < L::TN; ++j) acc[i][j] = x6_mma(fa6, fb6[j], acc[i][j]);
+        }
       }
       return;
     }

@@ -187,7 +187,9 @@ GNX_API int32_t gnx_graphs_create_dense(const void* const* adj, const int64_t* n
 
 /* The same batch from ONE buffer: the matrices one after the other (graph g: n_g x n_g elements of elem_kind), adj_bytes = sum(n_g^2) *
  * sizeof(element) — checked; nothing is read past it.  on_device = 0: HOST memory (a pinned buffer travels as one DMA, a pageable one through
- * the library's pinned staging pair); on_device = 1: DEVICE memory of the current device (no copy).  What a data loader holds and what the
+ * the library's pinned staging pair); on_device = 1: DEVICE memory of the current device (no copy; the scan runs on the NULL
+ * stream: the buffer must be COMPLETE when the call is made — a producer on a non-blocking stream is synchronised by the caller first, as the
+ * Python mirror does).  What a data loader holds and what the
  * bindings call (GNGraphBatch.from_dense_packed): one pointer instead of G — building G pointers costs a Python / Julia host ~1.5 us each. */
 GNX_API int32_t gnx_graphs_create_dense_packed(const void* adj_cat, int64_t adj_bytes, const int64_t* n_nodes, int64_t n_graphs, int32_t elem_kind,
                                        int32_t row_major, int32_t on_device, gnx_graphs** out);

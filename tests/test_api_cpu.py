@@ -47,8 +47,18 @@ def test_chain_folds_the_layer_values_that_fold_exactly_and_refuses_the_rest():
     assert len(ch) == 2 and [l.act for l in ch.layers] == ["relu", "tanh"] and ch.dropout_p == 0.25
     assert ch.layers[0].weight is d.weight and ch.layers[0].bias is d.bias and d.act == "identity"   # the caller's Dense is not modified
     assert gn.Chain([d, "gelu"]).layers[0].act == "gelu"
-    with pytest.raises(NotImplementedError, match="LayerNorm"):
-        gn.Chain(d, gn.LayerNorm(3, device="cpu"))
+    # round 6: a LayerNorm(d) layer value is a layer of its own (gnx_dense.kind = GNX_LAYER_LAYERNORM: gamma / beta in the weight / bias slots) ...
+    ln = gn.LayerNorm(3, device="cpu")
+    chl = gn.Chain(d, ln, gn.Dense(3, 2, device="cpu"))
+    assert len(chl) == 3 and chl.layers[1] is ln and chl.out_width == 2 and ln.weight is ln.gamma and ln.bias is ln.beta
+    keep = []
+    c = ln._c_layer(keep)
+    assert c.kind == gn._lib.LAYER_LAYERNORM and c.act == gn._lib.ACT["identity"] and c.weight and c.bias
+    assert gn.Chain(d, ln).out_width == 3                          # (as a chain's last layer it keeps the width in front of it)
+    with pytest.raises(NotImplementedError, match="does not follow"):
+        gn.Chain(d, ln, "relu")                                   # ... but an activation behind it has no Dense to fold into
+    with pytest.raises(NotImplementedError, match="BatchNorm"):
+        gn.Chain(d, type("BatchNorm", (), {})())
     with pytest.raises(NotImplementedError, match="function"):
         gn.Chain(d, lambda x: x * 2)
     with pytest.raises(NotImplementedError, match="does not follow"):

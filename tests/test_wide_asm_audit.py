@@ -43,6 +43,11 @@ def _args(name):
     return tuple(int(x) for x in m.groups())
 
 
+def _x6(name):
+    """the seventh template argument: the six-term form (round 6: the default; 0 = v_mfma_f32_32x32x2f32, only where a call's flags ask)"""
+    return int(re.search(r"k_rows_gemmILi\d+ELb[01]ELi\d+ELi\d+ELb[01]ELi\d+ELb([01])E", name).group(1))
+
+
 def test_hot_gemm_kernels_keep_no_register_in_scratch_memory(wide_asm):
     checked = 0
     for name, (_, meta) in wide_asm.items():
@@ -52,12 +57,23 @@ def test_hot_gemm_kernels_keep_no_register_in_scratch_memory(wide_asm):
         if bn == 64 and nl == 2:
             continue  # 64-column two-stream epilogue at four workgroups per CU (small launches only)
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta).group(1))
+        if _x6(name):
+            # the six-term form holds three bf16 parts of every fragment (~25 more live registers): the 64-column loaders with row sums (the
+            # node updates of config 4's encoder / decoder at four workgroups per CU) stay spill-free, the 128-column kernels at three
+            # workgroups per CU keep a bounded handful of registers in scratch memory (measured against two workgroups per CU without any:
+            # profiles/r06_ab_wide_wpe.log)
+            if bn == 64 and ld >= 1:
+                assert scratch == 0, (name, scratch)
+            if bn == 128 and (nl in (0, 3) or ld >= 1):
+                assert scratch <= 64, (name, scratch)
+            checked += 1
+            continue
         if bn == 128 and nl == 0 and ld == 0 and not trans:
             assert scratch == 0, (name, scratch)
         if nl == 3 or ld >= 1:
             assert scratch == 0, (name, scratch)
         checked += 1
-    assert checked >= 10
+    assert checked >= 20
 
 
 def test_untracked_source_row_loads_are_not_touched_before_their_wait(wide_asm):
