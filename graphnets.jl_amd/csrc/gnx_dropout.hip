@@ -144,10 +144,15 @@ int32_t gnx_core_forward_train(const gnx_graphs* h, const gnx_core_params* p, co
   if (!ws || ws_bytes < (dropout_active(dr) ? L.total : core)) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_core_train_workspace_bytes()");
   if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");
   char* base = static_cast<char*>(ws);
+  // (everything that can refuse the call is checked BEFORE the forward writes an output — a refused call leaves the outputs alone)
+  if (dropout_active(dr))
+    for (int t = 0; t < 3; ++t)
+      if (p->ff[t].fc2.act != GNX_ACT_IDENTITY) return fail(GNX_ERR_INVALID_ARG, "core training forward: fc2 must be identity");
   DeviceTurn turn(s, matrix_core_widths(p->block));
   int32_t rc = gnx_core_forward(h, p, ef, nf, gf, R, ef_out, nf_out, gf_out, base + L.core, core, flags, stream);
   if (rc || !dropout_active(dr)) return rc;
   FormScope forms(flags);
+  PreparedScope prepared(p->prepared);  // (the recompute below runs the row-wise Dense launcher: no planes are looked up today, and none is missed if that changes)
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
   const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
   const int d[3] = {p->block.de, p->block.dn, p->block.dg};
@@ -155,7 +160,6 @@ int32_t gnx_core_forward_train(const gnx_graphs* h, const gnx_core_params* p, co
   float* y[3] = {ef_out, nf_out, gf_out};
   for (int t = 0; t < 3; ++t) {
     if (rows[t] == 0) continue;
-    if (p->ff[t].fc2.act != GNX_ACT_IDENTITY) return fail(GNX_ERR_INVALID_ARG, "core training forward: fc2 must be identity");
     if ((rc = launch_layernorm2(x[t], rows[t], d[t], p->ln1[t], p->ln2[t], p->eps, p->eps_mode, F(L.l1), F(L.l2), s))) return rc;
     if ((rc = launch_dense_rows(h, t, F(L.l2), d[t], p->ff[t].fc1, 4 * d[t], nullptr, nullptr, F(L.hid), R, s, "train_ff1"))) return rc;
     if ((rc = launch_dense_rows(h, t, F(L.hid), 4 * d[t], p->ff[t].fc2, d[t], nullptr, nullptr, F(L.f), R, s, "train_ff2"))) return rc;

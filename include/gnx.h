@@ -427,6 +427,8 @@ GNX_API int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, 
  * src/gnblock.jl:63-69.)  The masks are never stored: element i of entity t (0 edges, 1 nodes, 2 graphs; i counts the packed
  * [R][rows][width] floats) is a pure function of (seed, t, i) — Philox-4x32-10 — so the backward regenerates the forward's masks from the
  * same gnx_dropout value, and gnx_dropout_mask writes them out for a host that wants to check either pass (tests/test_gpu_dropout.py).
+ * (A dropped element therefore holds x + block + (f_fused - f_unfused) — two fp32-accurate evaluations of the same FeedForward, ~1e-6 of its
+ * scale apart — not x + block exactly as in Flux; the backward treats its FeedForward gradient as exactly zero.)
  * The host draws a fresh `seed` per forward call (one per core of a GNCoreList).  dropout = NULL or p = 0: exactly gnx_core_forward /
  * gnx_core_backward.  The forward is gnx_core_forward (any flags) followed by the correction y += (m - 1) .* f, f recomputed unfused in the
  * workspace (csrc/gnx_dropout.hip). */
