@@ -236,6 +236,24 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipStreamEndCapture(s, &graph));
     CHECK_HIP(hipGraphInstantiate(&rc.exec, graph, NULL, NULL, 0));
     const timing ta = time_steps(step_replay, &rc, 1, 1, s);
+    /* (a2) the same K steps as ONE gnx_block_forward_steps call (round 6: the library's loop over batches — it chains the steps itself: one
+     * launch per step + one flush inside the call), captured the same way: what bench.py's headline times through the Python mirror */
+    hipGraph_t graph2;
+    replay_ctx rc2;
+    rc2.s = s;
+    gnx_block_step* st = (gnx_block_step*)calloc((size_t)K, sizeof *st);
+    for (int i = 0; i < K; ++i) {
+      const int b = i % NSETS;
+      st[i].ef = ef[b]; st[i].nf = nf[b]; st[i].gf = NULL; st[i].ef_out = eo[b]; st[i].nf_out = no[b]; st[i].gf_out = go[b]; st[i].workspace = ws[b]; st[i].workspace_bytes = ws_bytes;
+    }
+    CHECK_GNX(gnx_block_forward_steps(h, &p, st, K, 1, 0, s));  /* (eager once: argument errors surface here) */
+    CHECK_HIP(hipStreamSynchronize(s));
+    CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    CHECK_GNX(gnx_block_forward_steps(h, &p, st, K, 1, 0, s));
+    CHECK_HIP(hipStreamEndCapture(s, &graph2));
+    CHECK_HIP(hipGraphInstantiate(&rc2.exec, graph2, NULL, NULL, 0));
+    const timing ta2 = time_steps(step_replay, &rc2, 1, 1, s);
+    free(st);
     /* (b) library-owned replay: one one-layer model per buffer set, one gnx_model_forward per step */
     model_ctx mc;
     mc.nsets = NSETS; mc.s = s;
@@ -255,15 +273,17 @@ int main(int argc, char** argv) {
     printf("{\"bench\": \"abi_bench\", \"mode\": \"block\", \"workload\": \"C2%s: %lld nodes / %lld edges, (10,5,0)=>(3,4,5), through include/gnx.h from C (no Python, no torch)\", "
            "\"steps\": %d, \"captured_us_per_step\": %.4f, \"captured_event_us_per_step\": %.4f, \"captured_reps_us\": [%.4f, %.4f, %.4f], "
            "\"captured_what\": \"%d gnx_block_forward calls captured by the C program into one hipGraph, %d rotating buffer sets, median of 3 replays\", "
+           "\"steps_us_per_step\": %.4f, \"steps_reps_us\": [%.4f, %.4f, %.4f], \"steps_what\": \"ONE gnx_block_forward_steps call over the same steps, captured into one hipGraph by the C program\", "
            "\"model_us_per_step\": %.4f, \"model_event_us_per_step\": %.4f, \"model_reps_us\": [%.4f, %.4f, %.4f], "
            "\"model_what\": \"gnx_model_forward per step (library-owned hipGraph of one forward, one hipGraphLaunch per step), %d models over %d buffer sets\", "
            "\"eager_us_per_step\": %.4f, \"eager_reps_us\": [%.4f, %.4f, %.4f], \"eager_what\": \"one gnx_block_forward per step on the stream, no hipGraph\", "
            "\"batch_ms\": %.3f, \"gf_out0\": %.6g}\n",
            csc ? " (bench.py's graph)" : " law (own draw)", (long long)N, (long long)E, K, ta.wall_us / K, ta.event_us / K, ta.reps_us[0] / K, ta.reps_us[1] / K,
-           ta.reps_us[2] / K, K, NSETS, tb.wall_us, tb.event_us, tb.reps_us[0], tb.reps_us[1], tb.reps_us[2], NSETS, NSETS, tc.wall_us, tc.reps_us[0], tc.reps_us[1],
+           ta.reps_us[2] / K, K, NSETS, ta2.wall_us / K, ta2.reps_us[0] / K, ta2.reps_us[1] / K, ta2.reps_us[2] / K, tb.wall_us, tb.event_us, tb.reps_us[0], tb.reps_us[1], tb.reps_us[2], NSETS, NSETS, tc.wall_us, tc.reps_us[0], tc.reps_us[1],
            tc.reps_us[2], t_batch[0], (double)g5[0]);
     for (int b = 0; b < NSETS; ++b) CHECK_GNX(gnx_model_destroy(mc.m[b]));
     CHECK_HIP(hipGraphExecDestroy(rc.exec)); CHECK_HIP(hipGraphDestroy(graph));
+    CHECK_HIP(hipGraphExecDestroy(rc2.exec)); CHECK_HIP(hipGraphDestroy(graph2));
   } else if (!strcmp(mode, "c4")) {
     gnx_block_params enc = block(in0, cd), dec = block(cd, out0);
     gnx_core_params c1 = core(cd), c2 = core(cd);

@@ -150,8 +150,8 @@ def test_c_abi_bench_runs_both_modes_without_python_in_the_loop(tmp_path):
     path = str(tmp_path / "g.bin")
     with open(path, "wb") as f:
         f.write(np.array([N, E], dtype=np.int64).tobytes() + np.cumsum(cp).astype(np.int64).tobytes() + (k % N).astype(np.int64).tobytes())
-    for argv, keys in ((["--mode", "block", "--steps", "16", "--warmup", "4", "--csc", path], ("captured_us_per_step", "model_us_per_step")),
-                       (["--mode", "block", "--steps", "8", "--nodes", "2000", "--edges", "16000"], ("captured_us_per_step", "model_us_per_step")),
+    for argv, keys in ((["--mode", "block", "--steps", "16", "--warmup", "4", "--csc", path], ("captured_us_per_step", "steps_us_per_step", "model_us_per_step")),
+                       (["--mode", "block", "--steps", "8", "--nodes", "2000", "--edges", "16000"], ("captured_us_per_step", "steps_us_per_step", "model_us_per_step")),
                        (["--mode", "c4", "--steps", "3", "--warmup", "2", "--csc", path], ("model_us_per_step",)),
                        (["--mode", "c4", "--steps", "3", "--warmup", "2", "--csc", path, "--core-dims", "10,5,3"], ("model_us_per_step",))):
         out = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=300)
