@@ -113,6 +113,10 @@ __device__ __forceinline__ int segment_of(const int* cp, int n, int e) {
   return lo;
 }
 
+// One row's LayerNorm statistics (mean, 1 / sigma) from the table the statistics kernel wrote (round 6 tried it as a system-scope load: no
+// difference to the hazard it chased — the table is read correctly; profiles/r06_overlap_hazard.log)
+__device__ __forceinline__ float2 ld_stats(const float2* p) { return *p; }
+
 }  // namespace gnx
 
 #ifndef GNX_JIT

@@ -20,6 +20,10 @@
 #include "gnx_device.h"
 #include "gnx_x6_mma.h"
 
+#ifndef GNX_LN_GUARD  // see the LayerNorm branch of store_step (and csrc/gnx_wide.hip)
+#define GNX_LN_GUARD 1
+#endif
+
 namespace gnx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
   for (int i = tid; i < H; i += NT) s_b1[i] = a.b1 ? a.b1[i] : 0.f;  // (visible after the first barrier of the step loop)
   const bool ln = a.ln_stats != nullptr;
   if (ln) {
-    if (tid < FBM) s_ln[tid] = reinterpret_cast<const float2*>(a.ln_stats + r * (a.rep_stride / D) * 2)[row0 + (tid < rows ? tid : rows - 1)];
+    if (tid < FBM) s_ln[tid] = ld_stats(reinterpret_cast<const float2*>(a.ln_stats + r * (a.rep_stride / D) * 2) + row0 + (tid < rows ? tid : rows - 1));
     if (tid >= FBM && tid < FBM + D / 4) { s_lng[tid - FBM] = reinterpret_cast<const f32x4*>(a.ln_g)[tid - FBM]; s_lnb[tid - FBM] = reinterpret_cast<const f32x4*>(a.ln_b)[tid - FBM]; }
   }
   // (s_ln / s_lng / s_lnb / s_b1 are visible after the first barrier of the step loop, which precedes the first store_step)
@@ -155,8 +159,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void k
         if (ln && a_r + 64 * i < rows) {  // (rows beyond the tile stay zero)
           const float2 st2 = s_ln[a_r + 64 * i];
           const f32x4 g = s_lng[st * (FKC / 4) + a_c4], b = s_lnb[st * (FKC / 4) + a_c4];
-          v.x = fmaf(g.x, (v.x - st2.x) * st2.y, b.x); v.y = fmaf(g.y, (v.y - st2.x) * st2.y, b.y);
-          v.z = fmaf(g.z, (v.z - st2.x) * st2.y, b.z); v.w = fmaf(g.w, (v.w - st2.x) * st2.y, b.w);
+          // (the guard of k_rows_gemm's LayerNorm branch, csrc/gnx_wide.hip: the LDS reads retired and sixteen idle issue slots in front of the first use)
+          float sx_ = st2.x, sy_ = st2.y;
+#if GNX_LN_GUARD
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" : "+v"(sx_), "+v"(sy_)::"memory");
+#endif
+          v.x = fmaf(g.x, (v.x - sx_) * sy_, b.x); v.y = fmaf(g.y, (v.y - sx_) * sy_, b.y);
+          v.z = fmaf(g.z, (v.z - sx_) * sy_, b.z); v.w = fmaf(g.w, (v.w - sx_) * sy_, b.w);
         }
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
       }

@@ -65,8 +65,12 @@ struct DeviceChain {
 constexpr int kMaxDevices = 64;
 DeviceChain g_chains[kMaxDevices];
 thread_local int tl_turn_depth = 0;  // (an entry point that calls another one — the model's layers, the chained forms — takes ONE turn)
+// Round 6: the wrong results that made round 5 serialise matrix-core calls were ONE code site — the LayerNorm-on-load branch of the general kernels
+// consuming an LDS read too early on a contended CU (csrc/gnx_wide.hip: GNX_LN_GUARD; profiles/r06_overlap_hazard.log) — and are gone with its guard:
+// calls on different streams overlap again by default.  GNX_TAKE_TURNS=1 brings the per-device turn-taking back (GNX_ALLOW_OVERLAP, round 5's
+// switch the other way round, is accepted and means the default).
 bool overlap_allowed() {
-  static const bool on = env_on("GNX_ALLOW_OVERLAP");
+  static const bool on = !env_on("GNX_TAKE_TURNS");
   return on;
 }
 }  // namespace

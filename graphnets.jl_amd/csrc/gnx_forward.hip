@@ -419,14 +419,12 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
                         ffn_x6_applies(x[0], d[0], p->ff[0], out[0], x[0], out[0], sizeof(float) * rows[0] * d[0]);
   // ... and then ONE launch does both (the edge form of k_ffn_x6: ef' stays in the accumulator — never written, never read back; GNX_CORE_EDGE_SPLIT=1: two launches)
   const bool fuse_e = inline_e && !form(GNX_FLAG_CORE_EDGE_SPLIT) && !(edge_n_enabled() && d[1] == 64);  // (the opt-in k_edge_n gathers RAW source rows: its projection tables are not the one-launch form's)
-  // Round 6 (profiles/r06_overlap_hazard.log): the GENERAL kernels (k_rows_gemm, k_ffn_fused) come out wrong now and then — accumulator register
-  // pairs of half a wave, on either matrix instruction — while another stream keeps a dense bf16 GEMM resident, but ONLY in calls that normalise
-  // on load from a statistics table; the same kernels on materialised LayerNorm outputs (GNX_FLAG_NO_LN_FUSE: 0 of 240 runs) and the six-term
-  // kernels with their own row handling (0 of 960) were never seen wrong, and the statistics kernel alone is exact (5 500 runs).  The cause is
-  // not established, so the default keeps every general kernel away from a statistics table: an entity whose rows would be normalised on load
-  // by a general kernel gets its LayerNorms MATERIALISED instead (k_layernorm2, one more pass over rows that are few whenever this happens:
-  // below 4096, or widths without a six-term kernel).  GNX_FLAG_LN_ON_LOAD restores the statistics-table forms (the tests of those forms; a
-  // host that owns the device exclusively).
+  // Round 6 (profiles/r06_overlap_hazard.log): the GENERAL kernels (k_rows_gemm, k_ffn_fused) came out wrong now and then beside another queue's
+  // matrix kernel, but only in launches that normalise on load from a statistics table; the site was found later in the round (their LayerNorm
+  // branch consumed an LDS read too early on a shared CU) and is guarded (GNX_LN_GUARD).  This rule predates the guard and stays as a second,
+  // independent protection of the path small batches take: a statistics table is consumed by six-term kernels only — an entity whose rows a general
+  // kernel would normalise on load gets its LayerNorms MATERIALISED instead (k_layernorm2, one more pass over rows that are few whenever this
+  // happens: below 4096, or widths without a six-term kernel).  GNX_FLAG_LN_ON_LOAD restores the statistics-table forms (exact too since the guard).
   const bool ln_on_load = form(GNX_FLAG_LN_ON_LOAD) || form(GNX_FLAG_FP32_MFMA | GNX_FLAG_PROJ_FP32 | GNX_FLAG_LN_STATS_PASS | GNX_FLAG_CORE_EDGE_SPLIT);  // (the diagnostic forms keep their tables)
   if (wide_ln && !ln_on_load && !inline_e) wide_ln = false;  // the edge rows' table would feed k_rows_gemm / k_ffn_fused: everything materialised (the branch below)
   const bool node_x6_forms = d[0] == 128 && d[1] == 64 && h->N >= 4096 && p->block.nodefn.act <= GNX_ACT_RELU;  // k_proj_x6, k_node_x6, k_ffn_x6<64> take the node rows

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_ln_stats_v4(const float* __restrict__ x
   }
   var = row16_sum_g(var) * (1.f / (float)D);
   const float inv = eps_mode == 0 ? 1.f / (sqrtf(var) + eps) : 1.f / sqrtf(var + eps);
-  if (live && sub == 0) stats[row] = make_float2(mu, inv);
+  if (live && sub == 0) stats[row] = make_float2(mu, inv);  // (written whole, through lanes 0..3 or behind a fence: no difference to what round 6 chased — profiles/r06_overlap_hazard.log)
 }
 
 // 1: this width / alignment is not covered (the caller materialises the LayerNorm outputs instead)

@@ -148,14 +148,13 @@ int32_t launch_chain_layer(const gnx_graphs* h, int entity, const gnx_dense& lay
 unsigned lds_pad_bytes();  // experiment switch GNX_LDS_PAD_KB: dynamic LDS added to EVERY launch (0 by default) — a workgroup that owns most of a CU's LDS shares the CU with no other LDS-using kernel
 bool form(uint32_t bit);  // is the form selected for the call this thread is in (outside a call: by the environment's defaults)
 
-// One matrix-core call at a time per DEVICE (gnx_forms.cpp).  Round 5 found (tools/experiments/thread_race_probe.py, mfma_mix_probe.py; the evidence is
-// profiles/r05_mfma_mix_hazard.log): on the MI355X boxes of this pool a kernel on the fp32 matrix instruction (k_rows_gemm, k_ffn_fused) returns wrong
-// values — one pass of one v_mfma_f32_32x32x2f32: 2 rows x 32 columns of a wave's block — while a dense bf16 matrix kernel runs on ANOTHER stream of
-// the device: the library's own six-term kernels (k_edge_x6) or anybody's (a hipBLASLt bf16 GEMM).  Nothing is shared between the two kernels; the
-// same fp32 kernels beside fp32 or non-matrix work are exact.  Until the cause is understood the library keeps its own matrix-core calls apart: an
-// exported forward / backward at matrix-core widths holds this for its enqueue section — a per-device lock, a wait for the previous such call's end
-// when that ran on another stream, and an event at its own end.  Calls on ONE stream pay a lock and an event record; a stream that is being captured
-// is left alone (a graph replays on one stream).  GNX_ALLOW_OVERLAP=1 (read once) switches it off.
+// Optional turn-taking of matrix-core calls on a DEVICE (gnx_forms.cpp; OFF by default from round 6 on, GNX_TAKE_TURNS=1 switches it on).  Round 5
+// saw k_rows_gemm / k_ffn_fused return wrong values — row pairs off by ~1 % — while a dense bf16 matrix kernel ran on ANOTHER stream of the device (the
+// library's own k_edge_x6 or a hipBLASLt GEMM), blamed the fp32 matrix instruction and serialised the library's calls at matrix-core widths: a per-device
+// lock over the enqueue section, a wait for the previous such call's end when that ran on another stream, an event at the call's end.  Round 6 found the
+// site (profiles/r06_overlap_hazard.log): the LayerNorm-on-load branch of those kernels consumed an LDS read right behind the compiler's counted wait,
+// and on a CU shared with another kernel's workgroups the last 16 lanes of a wave got the previous values; with the guard there (GNX_LN_GUARD) every
+// scenario that failed is exact with calls overlapping (2 640 forward + backward runs and graph replays, the thread probes: 2 040 forwards).
 inline bool matrix_core_widths(const gnx_block_params& b) {  // (the fused narrow kernels take widths up to 32: no matrix instruction)
   return b.de > 32 || b.dn > 32 || b.dg > 32 || b.oe > 32 || b.on > 32 || b.og > 32;
 }

@@ -22,6 +22,10 @@
 #include "gnx_device.h"
 #include "gnx_x6_mma.h"
 
+#ifndef GNX_LN_GUARD  // see store_chunk's LayerNorm branch
+#define GNX_LN_GUARD 1
+#endif
+
 namespace gnx {
 
 int32_t launch_edge_x6(const Tile* tiles, size_t n_tiles, const float* ef, size_t E, const float* ln_stats, const float* ln_g, const float* ln_b, const float* We, int ldw,
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
     }
   }
   if (LNOK && a.ln_stats) {
-    if (tid < BM) s_ln[tid] = reinterpret_cast<const float2*>(a.ln_stats + r * a.ln_rep_stride)[row0 + (tid < rows ? tid : rows - 1)];
+    if (tid < BM) s_ln[tid] = ld_stats(reinterpret_cast<const float2*>(a.ln_stats + r * a.ln_rep_stride) + row0 + (tid < rows ? tid : rows - 1));
     if (tid >= BM && tid < BM + 64) {
       const int q = tid - BM;
       const bool in = 4 * q < a.ln_width;
@@ -593,8 +597,17 @@ __global__ __launch_bounds__(WaveLayout<BN>::WT) __attribute__((amdgpu_waves_per
       if (LNOK && pend_ln >= 0) {  // (columns beyond the segment read gamma / beta of valid LDS slots and are zeroed by the masks below)
         const float2 st = s_ln[a_r + RPP * i];
         const float4 g = s_lng[((pend_ln >> 2) + a_c4) & 63], b = s_lnb[((pend_ln >> 2) + a_c4) & 63];
-        v.x = fmaf(g.x, (v.x - st.x) * st.y, b.x); v.y = fmaf(g.y, (v.y - st.x) * st.y, b.y);
-        v.z = fmaf(g.z, (v.z - st.x) * st.y, b.z); v.w = fmaf(g.w, (v.w - st.x) * st.y, b.w);
+        // Round 6 (profiles/r06_overlap_hazard.log): with another kernel's workgroups on the CU (a hipBLASLt GEMM through another queue) the LAST 16
+        // LANES of a wave used wrong statistics here now and then — the rows they stage came out normalised with other numbers, ~1 % off — when
+        // the first vector instruction consumed the (8-lanes-per-address) LDS read right behind the compiler's counted wait; every LDS read of the
+        // branch retired plus sixteen idle issue slots in front of the first use: 0 of 360 runs wrong where 54-63 of 120 were.  The cause on the
+        // hardware side is not established; the guard costs a few clocks per staged quad.  (-DGNX_LN_GUARD=0: the unguarded form, A/B runs.)
+        float sx_ = st.x, sy_ = st.y;
+#if GNX_LN_GUARD
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" : "+v"(sx_), "+v"(sy_)::"memory");
+#endif
+        v.x = fmaf(g.x, (v.x - sx_) * sy_, b.x); v.y = fmaf(g.y, (v.y - sx_) * sy_, b.y);
+        v.z = fmaf(g.z, (v.z - sx_) * sy_, b.z); v.w = fmaf(g.w, (v.w - sx_) * sy_, b.w);
       }
       if (FULL) {
         const unsigned m = emask >> (4 * i);

@@ -2,10 +2,10 @@
 // fragments in LDS — the drop-in for eight consecutive v_mfma_f32_32x32x2f32 of the general kernels (k_rows_gemm, k_ffn_fused, k_dw_gemm), whose
 // operands are not prepared planes (gathered rows, sums of rows, transposed weights of the backward, any width).
 //
-// Why: round 5 found kernels on v_mfma_f32_32x32x2f32 losing one pass of one instruction now and then while a dense bf16 matrix kernel is resident
-// on the device through another queue (profiles/r05_mfma_mix_hazard.log; cause not established, six-term kernels never seen hit).  From round 6
-// on NO default path of the library issues the fp32 matrix instruction: the forms on it run only when a call's flags ask (GNX_FLAG_FP32_MFMA and
-// its parts, include/gnx.h).
+// Why: round 5 blamed v_mfma_f32_32x32x2f32 for wrong results beside another queue's bf16 matrix kernel and asked for it to leave every default path;
+// round 6 did that with this header — and found the instruction innocent (the site was an LDS read consumed too early in the LayerNorm-on-load branch:
+// profiles/r06_overlap_hazard.log).  The six-term form stays the default because it is FASTER: 6 x 8-pass instead of 8 x 16-pass matrix instructions
+// per 16-step (config 4 -4 %, forward + backward of a GNCore 15.9 -> 13.1 ms); the fp32 forms run where a call's flags ask (GNX_FLAG_FP32_MFMA).
 //
 // Arithmetic (as gnx_ffn_x6.hip / gnx_edge_x6.hip): x = h + m + l exactly, h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (8 + 8 + 8 mantissa
 // bits, round to nearest each); a·b ~ hh + hm + mh + hl + lh + mm, the three dropped terms are <= 2^-24 |a b| together; fp32 accumulation in the

@@ -102,7 +102,7 @@ extern "C" {
 #define GNX_FLAG_EDGE_N 0x10000u         /* opt-in: k_edge_n (source rows gathered raw, K = 128 + 64; csrc/gnx_edge_n.hip) for the edge update */
 #define GNX_FLAG_LN_ON_LOAD 0x20000u     /* wide GNCore: normalise on load from a row-statistics table also where a GENERAL kernel (k_rows_gemm, k_ffn_fused)
                                           * consumes it — rounds 2-5's default; round 6 materialises those LayerNorms instead (csrc/gnx_forward.hip,
-                                          * profiles/r06_overlap_hazard.log): use only on a device no other stream shares                        */
+                                          * profiles/r06_overlap_hazard.log); the same formula, exact too since that branch is guarded      */
 #define GNX_FLAG_FORMS_MASK 0x3ffe0u
 GNX_API uint32_t gnx_default_flags(void); /* the forms the environment switched on for this process */
 

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Are the library's DEFAULT forms independent of what else runs on the GPU?  (profiles/r05_mfma_mix_hazard.log.)
 
-Round 5: kernels on v_mfma_f32_32x32x2f32 (k_rows_gemm, k_ffn_fused, k_dw_gemm) lost one pass of one instruction now and then while a dense bf16
-matrix kernel ran on ANOTHER stream.  Round 6: no default path issues that instruction (csrc/gnx_x6_mma.h).  This probe runs with the library's own
-turn-taking OFF (GNX_ALLOW_OVERLAP=1 — set it in the environment of this process) and checks, bit for bit against serial one-stream results:
+Round 5: k_rows_gemm / k_ffn_fused came out wrong now and then while a dense bf16 matrix kernel ran on ANOTHER stream.  Round 6: no default path
+issues the fp32 matrix instruction (csrc/gnx_x6_mma.h), the site of the damage is found and guarded (csrc/gnx_wide.hip: GNX_LN_GUARD) and the
+library's calls overlap by default (GNX_TAKE_TURNS=1 in the environment: round 5's turn-taking).  The probe checks, bit for bit against serial
+one-stream results:
 
   (i)  a GNCore(128,64,32) forward + backward loop (small batch: the general kernels; big batch: >= 4096 nodes, the six-term kernels proper) on one
        stream while a torch bf16 GEMM loop (2048^3, hipBLASLt) runs on another stream of the same device;
@@ -129,5 +130,5 @@ for it in range(iters):
     for c, r in zip(caps, refs2):
         if not all(torch.equal(a, b) for a, b in zip((c._out.ef, c._out.nf, c._out.gf), r)):
             bad_graphs += 1
-print(json.dumps({"forms": forms, "big": big, "overlap_allowed": os.environ.get("GNX_ALLOW_OVERLAP", "0"), "forward_backward_runs": n_fb[0],
+print(json.dumps({"forms": forms, "big": big, "turn_taking": "on" if os.environ.get("GNX_TAKE_TURNS", "0") not in ("", "0") else "off", "forward_backward_runs": n_fb[0],
                   "forward_backward_wrong": len(bad_fb), "first_wrong": bad_fb[:3], "signatures": signatures, "graph_replay_pairs": iters, "graph_replays_wrong": bad_graphs}))

@@ -379,12 +379,13 @@ def test_two_host_threads_run_core_forwards_on_one_handle_concurrently(gn):
     assert not errors, errors[:5]
 
 
-def test_matrix_core_calls_of_several_threads_take_turns_on_the_device(gn):
-    """Round 5 (profiles/r05_mfma_mix_hazard.log): kernels on the fp32 matrix instruction returned wrong values — one pass of one instruction, 2 rows x
-    32 columns — while a six-term (bf16) edge kernel of ANOTHER thread's forward was resident on the device; nothing is shared between the two.  The
-    exported forwards at matrix-core widths therefore take turns on the device (csrc/gnx_forms.cpp: DeviceTurn).  Three threads: a core on the fp32
-    instruction, a core on the six-term kernels, a prepared six-term GNBlock in a loop (the strongest disturber found: ~1 wrong forward in 5 without
-    the guard) — every result bit-identical to its serial run."""
+def test_matrix_core_calls_of_several_threads_overlap_on_the_device_and_stay_exact(gn):
+    """Round 5 (profiles/r05_mfma_mix_hazard.log): k_rows_gemm / k_ffn_fused returned wrong values — row pairs ~1 % off — while a six-term (bf16) edge
+    kernel of ANOTHER thread's forward was resident on the device, and the exported forwards at matrix-core widths were made to take turns.  Round 6
+    found the site (the LayerNorm-on-load branch consuming an LDS read too early on a shared CU: profiles/r06_overlap_hazard.log), guarded it, and
+    switched the turn-taking off: the calls of these three threads OVERLAP.  A core on the fp32 instruction (round 5's victim), a core on the six-term
+    kernels, a prepared six-term GNBlock in a loop (the strongest disturber found: ~1 wrong forward in 5 before the guard) — every result
+    bit-identical to its serial run."""
     import threading
     import torch
     F = gn._lib
