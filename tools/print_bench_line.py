@@ -2,7 +2,8 @@
 import json
 import sys
 
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+raw = open(sys.argv[1]).read().strip()
+d = json.loads(raw) if raw.startswith("{\n") or raw.count("\n") > 3 else json.loads(raw.splitlines()[-1])  # a detail file (indented) or a one-line record
 r = d["roofline"]
 print("headline", d["value"], "ms/step", d["ms_per_step"], "frac", r["frac"], "whole", r.get("frac_whole_step"), "traffic", r.get("traffic"),
       "kernel_us", r.get("kernel_us"), "batch_ms", d.get("batch_ms"), "c_abi", d.get("c_abi_ms_per_step"),
