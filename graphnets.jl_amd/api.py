@@ -25,7 +25,7 @@ from ._lib import GnxError, check
 
 __all__ = ["GNGraphBatch", "NT", "batch", "unbatch", "efview", "nfview", "gfview", "flatunpaddednf", "flatunpaddedef",
            "Dense", "Chain", "LayerNorm", "GNBlock", "GNCore", "GNCoreList", "GNFeedForward", "GNGraphNorm", "zerodim2nothing",
-           "padded", "GnxError", "getedgefninput", "getnodefninput", "getgraphfninput",
+           "padded", "unpadded", "GnxError", "getedgefninput", "getnodefninput", "getgraphfninput",
            "collapsef", "unpaddedcollapsedef", "flatunpaddedcollapsedef", "BlockPlan", "Graphed", "logitcrossentropy"]
 
 _KEYS = ("graphs", "ef", "nf", "gf")
@@ -496,6 +496,36 @@ def padded(t):
     gf = t.gf
     if gf is not None and not _shared_like(g):
         gf = gf.permute(0, 2, 1)  # (DG, G, 1) → (DG, 1, G)
+    return NT(g, out["ef"], out["nf"], gf)
+
+
+def unpadded(graphs, ef=None, nf=None, gf=None):
+    """The inverse bridge of `padded()` (unpad.jl:1-17: `unpadef`, `unpadnf`, `unpadgf`): the reference's padded batched arrays —
+    ef (DE, PN², B), nf (DN, PN, B), gf (DG, 1, B) — over a GNGraphBatch become the batch form this package computes on (what `batch`
+    returns).  Whatever the pads hold is dropped."""
+    g = graphs
+    assert isinstance(g, GNGraphBatch), "graphs must be a GNGraphBatch (batch(...).graphs)"
+    lib = _lib.load()
+    stream = torch.cuda.current_stream(g.device).cuda_stream
+    out = {}
+    for key, a, kind, PT, T in (("ef", ef, 0, g.edge_block_size, g.n_edges), ("nf", nf, 1, g.node_block_size, g.n_nodes)):
+        if a is None:
+            out[key] = None
+            continue
+        p = _packed(_dev_f32(a, g.device))  # [B][PT][D]
+        B, pt, D = p.shape
+        assert pt == PT, f"{key}: {pt} padded slots != {PT} (pad.jl:12-64)"
+        R = B if g.n_graphs == 1 else 1
+        assert B == (R if g.n_graphs == 1 else g.n_graphs), f"{key}: {B} slices != {g.n_graphs} graphs"
+        c = torch.empty((R, T, D), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            check(lib.gnx_unpad_features(g._h, kind, p.data_ptr(), D, R, c.data_ptr(), stream))
+        out[key] = _jl(c)
+    if gf is not None:
+        gf = _dev_f32(gf, g.device)
+        assert gf.dim() == 3 and gf.shape[1] == 1, "gf: the padded form is (DG, 1, B) (pad.jl:63-64)"
+        if not _shared_like(g):
+            gf = gf.permute(0, 2, 1)  # (DG, 1, G) → (DG, G, 1)
     return NT(g, out["ef"], out["nf"], gf)
 
 

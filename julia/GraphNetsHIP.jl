@@ -333,6 +333,31 @@ getedgefninput(graphs, edge_features, node_features, graph_features) = fninput(0
 getnodefninput(graphs, edge_features, node_features, graph_features) = fninput(1, graphs, edge_features, node_features, graph_features)
 getgraphfninput(graphs, edge_features, node_features, graph_features) = fninput(2, graphs, edge_features, node_features, graph_features)
 
+# ---- the reference's padded arrays (src/pad.jl:12-64, src/unpad.jl:1-17) → gnx_pad_features / gnx_unpad_features: only for code that insists on
+#      the (D, PN², B) / (D, PN, B) form; kind 0 = edges, 1 = nodes; pads are written as zeros, and dropped on the way back ----
+function padded_device(g::GNGraphBatch, kind::Integer, a::DeviceArray)
+    D, R = size(a, 1), size(a, 3)
+    B = sharedlike(g) ? R : ngraphs(g)
+    out = DeviceArray(D, kind == 0 ? g.edge_block_size : g.node_block_size, B)
+    GC.@preserve a out check(ccall((:gnx_pad_features, libgnx), Int32, (Ptr{Cvoid}, Int32, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cvoid}),
+        g.handle, kind, devptr(a), D, R, devptr(out), STREAM[]))
+    out
+end
+function unpadded_device(g::GNGraphBatch, kind::Integer, a::DeviceArray)
+    D, B = size(a, 1), size(a, 3)
+    @assert size(a, 2) == (kind == 0 ? g.edge_block_size : g.node_block_size)
+    @assert sharedlike(g) || B == ngraphs(g)
+    R = sharedlike(g) ? B : 1
+    out = DeviceArray(D, kind == 0 ? nedges(g) : nnodes(g), R)
+    GC.@preserve a out check(ccall((:gnx_unpad_features, libgnx), Int32, (Ptr{Cvoid}, Int32, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cvoid}),
+        g.handle, kind, devptr(a), D, R, devptr(out), STREAM[]))
+    out
+end
+padef(g::GNGraphBatch, ef) = back(padded_device(g, 0, gpu(ef)), ef)
+padnf(g::GNGraphBatch, nf) = back(padded_device(g, 1, gpu(nf)), nf)
+unpadef(g::GNGraphBatch, ef) = back(unpadded_device(g, 0, gpu(ef)), ef)
+unpadnf(g::GNGraphBatch, nf) = back(unpadded_device(g, 1, gpu(nf)), nf)
+
 # ---- edge collapsing (src/gngraphbatch.jl:56-111) → gnx_collapse_padded / gnx_collapse_offsets / gnx_collapse_edges ----
 function collapsef_device(g::GNGraphBatch, ef::DeviceArray)            # (DE, PN(PN+1)/2, B), padded array form
     D, R = size(ef, 1), size(ef, 3)

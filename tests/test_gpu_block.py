@@ -6,6 +6,7 @@ import itertools
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import gn_oracle as O
 from tests import util as U
@@ -96,6 +97,45 @@ def test_readme_example_2_vector_of_graphs(gn, flags):
         assert np.all(pe[:, ~em[:, b], b] == 0)
     assert np.array_equal(x.graphs.flat_edge_unpadder, dense["graphs"].flat_edge_unpadder)
     assert np.array_equal(x.graphs.flat_node_unpadder, dense["graphs"].flat_node_unpadder)
+
+def test_unpadded_takes_the_references_padded_arrays_back_to_the_batch_form(gn):
+    """unpad.jl:1-17 (`unpadef`, `unpadnf`, `unpadgf`) over gnx_unpad_features: the reference's padded batched arrays (the oracle's dense
+    restatement builds them, pad.jl:12-64) with JUNK in the pads -> exactly what `batch` makes of the per-graph arrays, for a vector of
+    graphs and for the shared-adjacency form (three replicas); `unpadded(padded(x)) == x` bit for bit."""
+    rng = np.random.default_rng(77)
+    adjs = [README_ADJ, README_ADJ2, (rng.random((7, 7)) < 0.4).astype(np.float32)]
+    ef = [rng.standard_normal((6, int(a.sum()))).astype(np.float32) for a in adjs]
+    nf = [rng.standard_normal((3, a.shape[0])).astype(np.float32) for a in adjs]
+    gf = [rng.standard_normal(2).astype(np.float32) for _ in adjs]
+    x = gn.batch(dict(graphs=adjs, ef=ef, nf=nf, gf=gf))
+    dense = O.batch_dense(adjs, ef, nf, gf)
+    g = dense["graphs"]
+    PN, B = g.padded_adj_mats.shape[0], len(adjs)
+    em = g.flat_edge_unpadder.reshape(PN * PN, B, order="F")
+    nm = g.flat_node_unpadder.reshape(PN, B, order="F")
+    pe, pn = dense["ef"].astype(np.float32), dense["nf"].astype(np.float32)
+    for b in range(B):  # what the reference's padded arrays hold in the pads after a block: act(bias) junk
+        pe[:, ~em[:, b], b] = 9.5
+        pn[:, ~nm[:, b], b] = -3.25
+    y = gn.unpadded(x.graphs, ef=pe, nf=pn, gf=dense["gf"].astype(np.float32))
+    assert torch.equal(y.ef, x.ef) and torch.equal(y.nf, x.nf) and torch.equal(y.gf, x.gf)
+    z = gn.unpadded(x.graphs, *list(gn.padded(x))[1:])
+    assert torch.equal(z.ef, x.ef) and torch.equal(z.nf, x.nf) and torch.equal(z.gf, x.gf)
+    only = gn.unpadded(x.graphs, nf=pn)
+    assert only.ef is None and only.gf is None and torch.equal(only.nf, x.nf)
+    with pytest.raises(AssertionError):
+        gn.unpadded(x.graphs, ef=pe[:, :-1, :])
+    # shared adjacency, three replicas (pad.jl:30-41)
+    efs = rng.standard_normal((6, int(README_ADJ.sum()), 3)).astype(np.float32)
+    nfs = rng.standard_normal((3, README_ADJ.shape[0], 3)).astype(np.float32)
+    gfs = rng.standard_normal((2, 3)).astype(np.float32)
+    xs = gn.batch(dict(graphs=README_ADJ, ef=efs, nf=nfs, gf=gfs))
+    ds = O.batch_dense(README_ADJ, efs, nfs, gfs)
+    ys = gn.unpadded(xs.graphs, ef=ds["ef"].astype(np.float32), nf=ds["nf"].astype(np.float32), gf=ds["gf"].astype(np.float32))
+    assert torch.equal(ys.ef, xs.ef) and torch.equal(ys.nf, xs.nf) and torch.equal(ys.gf, xs.gf)
+    zs = gn.unpadded(xs.graphs, *list(gn.padded(xs))[1:])
+    assert torch.equal(zs.ef, xs.ef) and torch.equal(zs.nf, xs.nf) and torch.equal(zs.gf, xs.gf)
+
 
 
 IN_COMBOS = [d for d in itertools.product((0, 3), (0, 2), (0, 4)) if any(d)]
