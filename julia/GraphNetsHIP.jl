@@ -38,6 +38,12 @@ function check(rc::Integer)
     rc < 0 ? throw(AssertionError("gnx $(rc): $(msg)")) : error("gnx HIP error $(rc): $(msg)")
 end
 hipcheck(rc) = rc == 0 ? nothing : error("HIP error $(rc)")
+# the header this file was written against (include/gnx.h: GNX_VERSION); a library of another version has other structs behind the same names
+const GNX_HEADER_VERSION = Int32(130)
+function __init__()
+    v = ccall((:gnx_version, libgnx), Int32, ())
+    v == GNX_HEADER_VERSION || error("libgnx.so is version $(v), GraphNetsHIP.jl binds version $(GNX_HEADER_VERSION) of include/gnx.h")
+end
 
 # ---- device memory: a size-class pool over hipMalloc.  Steady state (the same shapes call after call) allocates nothing: a block whose
 #      Julia owner was collected goes back to the free list of its class and the next request of that class takes it.  Everything this
@@ -389,6 +395,28 @@ function flatunpaddedcollapsedef(t::NamedTuple)                        # gngraph
     @assert size(out, 3) == 1 || sharedlike(t.graphs)
     back(reshape(out, size(out, 1), :), t.ef)
 end
+# ---- readout loss (examples/sort/sort.jl:76-77: Flux.logitcrossentropy over flatunpaddednf / flatunpaddedef) → gnx_logit_cross_entropy (+ _backward):
+#      ŷ, y (d, cols) resident; the loss is ONE device float (read with `cpu`), the pullback's ∂ŷ has ŷ's shape ----
+function logitcrossentropy_device(ŷ::DeviceArray, y::DeviceArray)
+    @assert size(ŷ) == size(y)
+    d, cols = size(ŷ, 1), length(ŷ) ÷ size(ŷ, 1)
+    loss = DeviceArray(1)
+    ws = DevBuf(max(Int(ccall((:gnx_xent_workspace_bytes, libgnx), Csize_t, (Int64,), cols)), 16))
+    GC.@preserve ŷ y loss ws check(ccall((:gnx_logit_cross_entropy, libgnx), Int32,
+        (Ptr{Cfloat}, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+        devptr(ŷ), devptr(y), d, cols, devptr(loss), ws.ptr, ws.bytes, STREAM[]))
+    loss
+end
+function logitcrossentropy_pullback(ŷ::DeviceArray, y::DeviceArray, upstream::DeviceArray)   # upstream: ONE device float
+    d, cols = size(ŷ, 1), length(ŷ) ÷ size(ŷ, 1)
+    dŷ = DeviceArray(size(ŷ)...)
+    GC.@preserve ŷ y upstream dŷ check(ccall((:gnx_logit_cross_entropy_backward, libgnx), Int32,
+        (Ptr{Cfloat}, Ptr{Cfloat}, Int32, Int64, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cvoid}),
+        devptr(ŷ), devptr(y), d, cols, devptr(upstream), devptr(dŷ), STREAM[]))
+    dŷ
+end
+logitcrossentropy(ŷ, y) = only(cpu(logitcrossentropy_device(gpu(ŷ), gpu(y))))
+
 zerodim2nothing(t::NamedTuple) = (graphs=t.graphs, ef=t.ef, nf=t.nf, gf=t.gf)  # zero-width outputs are already `nothing`
 
 # ---- layers: plain structs whose parameters are host `Array`s or (after `gpu`) `DeviceArray`s — uploaded ONCE, like `model |> device`

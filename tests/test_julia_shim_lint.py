@@ -104,8 +104,17 @@ def test_the_shim_binds_the_entry_points_of_the_hot_path_and_its_neighbours():
     for name in ("gnx_graphs_create_dense_packed", "gnx_graphs_create_csc_cat", "gnx_block_prepare", "gnx_core_prepare", "gnx_prepared_refresh", "gnx_block_forward", "gnx_core_forward", "gnx_fn_input", "gnx_block_backward",
                  "gnx_core_backward", "gnx_core_forward_train", "gnx_core_backward_train", "gnx_chain_block_forward", "gnx_chain_block_backward", "gnx_model_create", "gnx_model_forward",
                  "gnx_dist_partition", "gnx_dist_create", "gnx_dist_block_forward", "gnx_dist_block_forward_steps", "gnx_dist_destroy", "gnx_collapse_edges",
-                 "gnx_collapse_padded", "gnx_block_forward_chained", "gnx_block_forward_steps", "gnx_block_graph_update"):
+                 "gnx_collapse_padded", "gnx_block_forward_chained", "gnx_block_forward_steps", "gnx_block_graph_update",
+                 "gnx_pad_features", "gnx_unpad_features", "gnx_logit_cross_entropy", "gnx_logit_cross_entropy_backward", "gnx_version"):
         assert name in bound, f"the Julia shim does not bind {name}"
+
+
+def test_the_shim_checks_the_library_version_it_was_written_against():
+    """include/gnx.h's GNX_VERSION is what `__init__` compares gnx_version() with: a header bump without the shim fails here."""
+    hv = int(re.search(r"#define\s+GNX_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "gnx.h")).read()).group(1))
+    m = re.search(r"const GNX_HEADER_VERSION = Int32\((\d+)\)", SRC)
+    assert m and int(m.group(1)) == hv
+    assert re.search(r"function __init__\(\).*?:gnx_version.*?GNX_HEADER_VERSION.*?\nend", SRC, re.S)
 
 
 STRUCT_MIRRORS = {"GnxDense": _lib.Dense, "GnxBlockParams": _lib.BlockParams, "GnxGraphsInfo": _lib.GraphsInfo, "GnxLayerNorm": _lib.LayerNorm,
