@@ -85,6 +85,74 @@ def test_random_core(gn, seed):
             U.assert_close(U.from_jl(got), r, s, f"seed {seed} dims {dims} R={R} flags={flags} {name}")
 
 
+WIDE_BLOCKS = [((128, 64, 32), (128, 64, 32)), ((128, 64, 0), (128, 64, 0)), ((10, 5, 3), (128, 64, 32)), ((10, 5, 0), (128, 64, 32)),
+               ((128, 64, 32), (3, 4, 2)), ((128, 64, 32), (10, 5, 3)), ((64, 64, 16), (64, 64, 16)), ((64, 64, 8), (128, 64, 4)),
+               ((128, 64, 32), (128, 0, 8)), ((96, 48, 12), (128, 64, 32)), ((128, 128, 0), (128, 64, 0))]
+WIDE_CORES = [(128, 64, 32), (128, 64, 4), (64, 64, 16), (128, 128, 8), (64, 32, 8)]
+
+
+def _random_big_batch(rng, gn):
+    """Batches around the row thresholds of the six-term kernels (4096 edge / node rows) with ragged last tiles: one graph (maybe replicas)
+    or a few, edge counts from below the threshold to a few tiles above it, now and then a hub that takes a third of the edges."""
+    shared = rng.random() < 0.4
+    G = 1 if shared else int(rng.integers(2, 5))
+    cps, rvs, sizes = [], [], []
+    for _ in range(G):
+        n = int(rng.choice([37, 300, 1500, 4095, 4097, 4500, 6001]))
+        e = int(rng.choice([n, 3 * n + 7, 4096, 4099, 9000, 14001])) if n * n > 14001 else int(rng.integers(1, n * n // 2))
+        cp, rv = U.er_csc(rng, n, min(e, n * n // 2))
+        if rng.random() < 0.25 and n > 300:  # a hub: every third edge re-aimed at node n // 2 (order by destination restored)
+            dst = np.repeat(np.arange(n), np.diff(cp))
+            pick = rng.random(dst.size) < 0.33
+            dst[pick] = n // 2
+            key = np.unique(dst * n + rv)
+            dst, rv = key // n, key % n
+            cp = np.zeros(n + 1, dtype=np.int64)
+            np.add.at(cp, dst + 1, 1)
+            cp = np.cumsum(cp)
+        cps.append(cp); rvs.append(rv.astype(np.int64)); sizes.append(n)
+    g = gn.GNGraphBatch.from_csc(cps, rvs, sizes)
+    return g, (int(rng.integers(1, 3)) if shared else 1)
+
+
+@pytest.mark.parametrize("seed", range(10 + EXTRA // 8))
+def test_random_wide_block(gn, seed):
+    """The wide forms (projected edge update, six-term kernels from 4096 rows on, the general kernels below) on random big batches: default
+    forms, the fp32-instruction forms and the generic kernels against the float64 oracle."""
+    rng = np.random.default_rng(9900 + seed)
+    g, R = _random_big_batch(rng, gn)
+    din, dout = WIDE_BLOCKS[int(rng.integers(0, len(WIDE_BLOCKS)))]
+    p = O.make_block_params(rng, din, dout, act=tuple(int(a) for a in rng.integers(0, 5, 3)))
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, g.n_graphs, din)
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    ref, scale = O.block_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    blk = U.block_from_params(gn, p)
+    for flags in (0, gn._lib.FLAG_FP32_MFMA | gn._lib.FLAG_PROJ_FP32 | gn._lib.FLAG_EDGE_NARROW_FP32, 1):
+        y = blk(U.to_nt(gn, g, ef, nf, gf), flags=flags)
+        for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+            if r is None or (hasattr(r, "shape") and 0 in r.shape):
+                continue
+            U.assert_close(U.from_jl(got), r, s, f"seed {seed} dims {din}=>{dout} N={g.n_nodes} E={g.n_edges} G={g.n_graphs} R={R} flags={flags:#x} {name}")
+
+
+@pytest.mark.parametrize("seed", range(8 + EXTRA // 8))
+def test_random_wide_core(gn, seed):
+    """GNCore at wide widths on the same batches: the one-launch edge kernel, the table forms (GNX_FLAG_LN_ON_LOAD), the fp32-instruction
+    forms and the generic kernels."""
+    rng = np.random.default_rng(9950 + seed)
+    g, R = _random_big_batch(rng, gn)
+    dims = WIDE_CORES[int(rng.integers(0, len(WIDE_CORES)))]
+    p = O.make_core_params(rng, dims, eps_mode=int(rng.integers(0, 2)))
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, g.n_graphs, dims)
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    ref, scale = O.core_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    core = U.core_from_params(gn, p)
+    for flags in (0, gn._lib.FLAG_LN_ON_LOAD, gn._lib.FLAG_FP32_MFMA | gn._lib.FLAG_PROJ_FP32 | gn._lib.FLAG_EDGE_NARROW_FP32, 1):
+        y = core(U.to_nt(gn, g, ef, nf, gf), flags=flags)
+        for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+            U.assert_close(U.from_jl(got), r, s, f"seed {seed} dims {dims} N={g.n_nodes} E={g.n_edges} G={g.n_graphs} R={R} flags={flags:#x} {name}")
+
+
 @pytest.mark.parametrize("seed", range(12 + EXTRA // 4))
 def test_random_block_backward(gn, seed):
     """gnx_block_backward on random width sets / batches (smooth activations: no relu kink) against torch float64 autograd."""
