@@ -710,7 +710,8 @@ class Chain:
       * `Dropout(p)` is the identity in test mode and dropped; a differentiable call of a block whose chains hold a Dropout with p > 0 is refused
         (the training-mode Dropout of this library is the FeedForward's: GNCore(dims; dropout)).
       * a `LayerNorm(d)` layer value normalises the rows of the layer in front of it (`Chain(Dense(a => d, relu), LayerNorm(d), Dense(d => b))`):
-        a row-wise launch of its own, differentiable (gamma / beta gradients); anywhere but as the EDGE function's first layer.
+        a row-wise launch of its own, differentiable (gamma / beta gradients); as the EDGE function's first layer it runs behind an identity Dense
+        that the library puts in front (the fused first launch then writes getedgefninput itself).
     Anything else (BatchNorm, SkipConnection, closures) raises NotImplementedError: wrap such layers outside the block."""
 
     def __init__(self, *layers):
@@ -883,6 +884,16 @@ class GNBlock:
         ps = [self.edgefn.weight, self.edgefn.bias, self.nodefn.weight, self.nodefn.bias, self.graphfn.weight, self.graphfn.bias]
         return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in list(tensors) + ps)
 
+    def _sync_dims(self):
+        """The update functions are plain fields (gnblock.jl:1-6: a struct of three functions) that a caller may replace after construction: the
+        output widths are read off the layers, and a function with outputs must take what the block feeds it (Flux's DimensionMismatch)."""
+        de, dn, dg = self.in_dims
+        oe, on, og = (int(f.weight.shape[0]) for f in (self.edgefn, self.nodefn, self.graphfn))
+        for name, f, k in (("edgefn", self.edgefn, de + 2 * dn + dg), ("nodefn", self.nodefn, oe + dn + dg), ("graphfn", self.graphfn, oe + on + dg)):
+            assert f.weight.shape[0] == 0 or int(f.weight.shape[1]) == k, f"{name}: Dense({int(f.weight.shape[1])} => {int(f.weight.shape[0])}) in a block that feeds it {k} rows"
+        assert oe + on + og > 0  # gnblock.jl:49
+        self.out_dims = (oe, on, og)
+
     def _as_chain(self, fn):
         return fn if isinstance(fn, Chain) else Chain(fn)
 
@@ -941,6 +952,7 @@ class GNBlock:
             return self._call_chains(x, flags)
         if any(isinstance(f, Chain) for f in (self.edgefn, self.nodefn, self.graphfn)):  # one-layer chains are plain Dense layers
             self.edgefn, self.nodefn, self.graphfn = (f.layers[0] if isinstance(f, Chain) else f for f in (self.edgefn, self.nodefn, self.graphfn))
+        self._sync_dims()
         g, ef, nf, gf, R = _forward_common(x, self.in_dims)
         if self._trainable((ef, nf, gf)):  # differentiable call: gnx_block_backward is the pullback
             outs = iter(_BlockFn.apply(self, g, R, self.flags if flags is None else flags, ef, nf, gf, self.edgefn.weight, self.edgefn.bias,

@@ -965,10 +965,10 @@ gnx_block_params chain_edge_block(const gnx_chain_block_params* p) {  // the one
   return b;
 }
 struct ChainBwLayout {
-  size_t act[3][16];  // stored layer outputs per chain
-  size_t Xn, Xg, dXn, dXg, gbuf[3], blk_fw, blk_fw_bytes, blk_bw, blk_bw_bytes, part, wt, off2, total;
+  size_t act[3][kChainMaxLayers + 1];  // stored layer outputs per chain
+  size_t Xn, Xg, dXn, dXg, gbuf[3], blk_fw, blk_fw_bytes, blk_bw, blk_bw_bytes, part, wt, off2, ident, total;
 };
-ChainBwLayout chain_bw_layout(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t R) {
+ChainBwLayout chain_bw_layout(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t R, size_t ident_floats) {
   ChainBwLayout L{};
   size_t o = 0;
   auto take = [&](size_t floats) { const size_t at = o; o += align_up(floats * sizeof(float), 256); return at; };
@@ -998,6 +998,7 @@ ChainBwLayout chain_bw_layout(const gnx_graphs* h, const gnx_chain_block_params*
   L.blk_bw_bytes = gnx_block_backward_workspace_bytes(h, &b, R);
   L.blk_bw = o; o += align_up(L.blk_bw_bytes, 256);
   L.part = take(pmax); L.wt = take(wmax); L.off2 = take(16);
+  L.ident = take(ident_floats);  // the identity layer of a LayerNorm-first edge function (gnx_internal.h: ChainLnFirst)
   L.total = o + 256;
   return L;
 }
@@ -1005,32 +1006,41 @@ ChainBwLayout chain_bw_layout(const gnx_graphs* h, const gnx_chain_block_params*
 
 extern "C" {
 
-size_t gnx_chain_block_backward_workspace_bytes(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t R) {
-  if (!h || !p || R <= 0 || gnx_chain_block_workspace_bytes(h, p, R) == 0) return 0;  // (the forward's query validates the chains)
-  return chain_bw_layout(h, p, R).total;
+size_t gnx_chain_block_backward_workspace_bytes(const gnx_graphs* h, const gnx_chain_block_params* p0, int64_t R) {
+  if (!h || !p0 || R <= 0 || gnx_chain_block_workspace_bytes(h, p0, R) == 0) return 0;  // (the forward's query validates the chains)
+  ChainLnFirst lnf;
+  const gnx_chain_block_params* p = lnf.init(p0, nullptr);
+  return chain_bw_layout(h, p, R, lnf.ident_floats()).total;
 }
 
-int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_params* p, const float* ef, const float* nf, const float* gf,
+int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_params* p0, const float* ef, const float* nf, const float* gf,
                                  const float* g_ef_out, const float* g_nf_out, const float* g_gf_out, int64_t R, float* d_ef, float* d_nf,
-                                 float* d_gf, const gnx_chain_block_grads* grads, void* ws, size_t ws_bytes, void* stream) {
+                                 float* d_gf, const gnx_chain_block_grads* grads0, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (!h || !p) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
+  if (!h || !p0) return fail(GNX_ERR_INVALID_ARG, "NULL handle or params");
+  if (gnx_chain_block_workspace_bytes(h, p0, R) == 0) return GNX_ERR_DIMS;  // gnx_last_error() holds the reason
+  ChainLnFirst lnf;  // a LayerNorm as the edge function's first layer: behind an identity Dense (its gradient slot is empty)
+  const gnx_chain_block_params* p = lnf.init(p0, nullptr);
+  const gnx_chain_block_grads* grads = lnf.init_grads(grads0);
   bool chain_wide = p->de > 32 || p->dn > 32 || p->dg > 32;
   for (const gnx_chain* c : {&p->edgefn, &p->nodefn, &p->graphfn})
     for (int i = 0; i < c->n_layers; ++i) chain_wide = chain_wide || (c->widths && c->widths[i] > 32);
   DeviceTurn turn(s, chain_wide);
-  if (gnx_chain_block_workspace_bytes(h, p, R) == 0) return GNX_ERR_DIMS;  // gnx_last_error() holds the reason
   const gnx_chain* ch[3] = {&p->edgefn, &p->nodefn, &p->graphfn};
   const int de = p->de, dn = p->dn, dg = p->dg;
   const int oe = chain_out(p->edgefn), on = chain_out(p->nodefn), og = chain_out(p->graphfn);
   if ((de > 0 && !ef && h->E > 0) || (dn > 0 && !nf) || (dg > 0 && !gf)) return fail(GNX_ERR_INVALID_ARG, "an input with non-zero width is NULL");
   if (oe == 0) return fail(GNX_ERR_DIMS, "chain backward: not implemented for an edge function without output (the forward takes it; train such a block with one-layer update functions)");
-  const ChainBwLayout L = chain_bw_layout(h, p, R);
+  const ChainBwLayout L = chain_bw_layout(h, p, R, lnf.ident_floats());
   if (!ws || ws_bytes < L.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_chain_block_backward_workspace_bytes()");
   if (int32_t rcw = gnx_ensure_wide_tables(h, stream)) return rcw;
   if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");
   char* base = static_cast<char*>(ws);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+  if (lnf.on) {
+    lnf.layers[0].weight = F(L.ident);
+    if (int32_t rci = lnf.fill(F(L.ident), s)) return rci;
+  }
   const int E = (int)h->E, N = (int)h->N, G = (int)h->G;
   const size_t rows[3] = {(size_t)R * h->E, (size_t)R * h->N, (size_t)R * h->G};
   const int trow[3] = {E, N, G};

@@ -4,6 +4,7 @@
 // each (src/gnblock.jl:55-60) and that one-layer form is what gnx_block_forward fuses.  Users replace them by MLPs
 // (`GNBlock(Chain(Dense(20 => 64, relu), Dense(64 => 3)), ...)`): this entry point runs such a block, composed from the pieces the
 // library already has — no new kernels:
+//   (a LayerNorm as the edge function's first layer: run behind an identity Dense — gnx_internal.h, ChainLnFirst)
 //   edge function : its FIRST Dense is the edge update of a one-layer block (gnx_block_forward with node / graph outputs switched
 //                   off: the fused / matrix-core edge kernels, the (K_e, E) input never materialised); further layers are row-wise
 //                   Dense launches (k_rows_gemm) over [E][width] arrays that ping-pong in the workspace;
@@ -43,7 +44,18 @@ __global__ __launch_bounds__(256) void k_chain_layernorm(const float* __restrict
   for (int k = lane; k < d; k += 64) y[row * d + k] = fmaf(gamma[k], (xr[k] - mu) * inv, beta[k]);
 }
 
+__global__ void k_chain_identity(float* __restrict__ w, int k) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)k * k) w[i] = (i / k == i % k) ? 1.f : 0.f;
+}
+
 namespace gnx {
+int32_t ChainLnFirst::fill(float* ident, hipStream_t s) const {
+  if (!on || ke == 0) return GNX_OK;
+  GNX_LAUNCH(k_chain_identity, dim3((unsigned)(((size_t)ke * ke + 255) / 256)), dim3(256), 0, s, ident, ke);
+  GNX_HIP(hipGetLastError());
+  return GNX_OK;
+}
 // one layer of a Chain, row-wise over all rows of the entity: Dense (launch_dense_rows) or LayerNorm; shared with the backward's recompute
 int32_t launch_chain_layer(const gnx_graphs* h, int entity, const gnx_dense& layer, const float* x, int k_in, int width, float* out, int64_t R, hipStream_t s,
                            const char* name) {
@@ -62,6 +74,7 @@ namespace {
 struct ChainWs {
   size_t block_off, block_bytes;  // workspace of the one-layer edge block
   size_t e_buf[2], n_in, n_buf[2], g_in, g_buf[2];
+  size_t ident;  // the identity layer of a LayerNorm-first edge function (ChainLnFirst)
   size_t total;
 };
 
@@ -72,8 +85,8 @@ int max_width(const gnx_chain& c) {
 }
 int out_width(const gnx_chain& c) { return c.n_layers > 0 ? c.widths[c.n_layers - 1] : 0; }
 
-int32_t check_chain(const gnx_chain& c, const char* what, int k_in, bool first_must_be_dense) {
-  if (c.n_layers < 0 || c.n_layers > 16) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": n_layers must be 0..16");
+int32_t check_chain(const gnx_chain& c, const char* what, int k_in) {
+  if (c.n_layers < 0 || c.n_layers > kChainMaxLayers) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": n_layers must be 0..16");
   if (c.n_layers > 0 && (!c.layers || !c.widths)) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": layers / widths is NULL");
   for (int i = 0; i < c.n_layers; ++i) {
     if (c.widths[i] < 0) return fail(GNX_ERR_DIMS, std::string(what) + ": negative layer width");
@@ -82,7 +95,6 @@ int32_t check_chain(const gnx_chain& c, const char* what, int k_in, bool first_m
     const int kind = c.layers[i].kind & 0xff;
     if (kind != GNX_LAYER_DENSE && kind != GNX_LAYER_LAYERNORM) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": unknown layer kind");
     if (kind == GNX_LAYER_LAYERNORM) {  // a LayerNorm(d) layer value: gamma, beta of its input's width, no activation of its own
-      if (i == 0 && first_must_be_dense) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": the edge function's first layer runs fused with getedgefninput and must be a Dense");
       if (c.widths[i] != (i > 0 ? c.widths[i - 1] : k_in)) return fail(GNX_ERR_DIMS, std::string(what) + ": a LayerNorm layer keeps the width of its input");
       if (c.layers[i].act != GNX_ACT_IDENTITY) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": a LayerNorm layer has no activation");
       if (c.widths[i] > 0 && (!c.layers[i].weight || !c.layers[i].bias)) return fail(GNX_ERR_INVALID_ARG, std::string(what) + ": a LayerNorm layer needs gamma and beta");
@@ -105,18 +117,18 @@ int32_t check_params(const gnx_graphs* h, const gnx_chain_block_params* p, int64
   if (p->de < 0 || p->dn < 0 || p->dg < 0) return fail(GNX_ERR_DIMS, "negative feature width");
   if (p->de + p->dn + p->dg == 0) return fail(GNX_ERR_DIMS, "all input widths are 0 (gnblock.jl:48, batch.jl:56)");
   int32_t rc;
-  if ((rc = check_chain(p->edgefn, "edgefn", p->de + 2 * p->dn + p->dg, true))) return rc;
+  if ((rc = check_chain(p->edgefn, "edgefn", p->de + 2 * p->dn + p->dg))) return rc;
   const int oe = out_width(p->edgefn);
-  if ((rc = check_chain(p->nodefn, "nodefn", oe + p->dn + p->dg, false))) return rc;
+  if ((rc = check_chain(p->nodefn, "nodefn", oe + p->dn + p->dg))) return rc;
   const int on = out_width(p->nodefn), og = out_width(p->graphfn);
-  if ((rc = check_chain(p->graphfn, "graphfn", oe + on + p->dg, false))) return rc;
+  if ((rc = check_chain(p->graphfn, "graphfn", oe + on + p->dg))) return rc;
   if (oe + on + og == 0) return fail(GNX_ERR_DIMS, "all output widths are 0 (gnblock.jl:49)");
   // A zero-width ef' / nf' is an empty segment of the next function's input, exactly as for one-layer update functions
   // (gnblock.jl:63-69 computes getnodefninput / getgraphfninput over the 0-row h_ef; width 0 <=> nothing in launch_fn_input).
   return GNX_OK;
 }
 
-ChainWs layout(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t R) {
+ChainWs layout(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t R, size_t ident_floats) {
   ChainWs w{};
   size_t o = 0;
   auto take = [&](size_t floats) { const size_t at = o; o += align_up(sizeof(float) * floats, 256); return at; };
@@ -133,6 +145,7 @@ ChainWs layout(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t R) 
   for (int i = 0; i < 2; ++i) w.n_buf[i] = take(p->nodefn.n_layers > 1 ? rows[1] * max_width(p->nodefn) : 0);
   w.g_in = take(og > 0 ? rows[2] * (size_t)(oe + on + p->dg) : 0);
   for (int i = 0; i < 2; ++i) w.g_buf[i] = take(p->graphfn.n_layers > 1 ? rows[2] * max_width(p->graphfn) : 0);
+  w.ident = take(ident_floats);
   w.total = o + 256;
   return w;
 }
@@ -157,19 +170,27 @@ int32_t run_layers(const gnx_graphs* h, int entity, const gnx_chain& c, int firs
 
 extern "C" {
 
-size_t gnx_chain_block_workspace_bytes(const gnx_graphs* h, const gnx_chain_block_params* p, int64_t R) {
-  if (check_params(h, p, R) != GNX_OK) return 0;
+size_t gnx_chain_block_workspace_bytes(const gnx_graphs* h, const gnx_chain_block_params* p0, int64_t R) {
+  if (check_params(h, p0, R) != GNX_OK) return 0;
+  ChainLnFirst lnf;
+  const gnx_chain_block_params* p = lnf.init(p0, nullptr);
   // further layers of a chain are row-wise Dense launches on the matrix-core kernel: its tables are built here, outside any capture
   if (p->edgefn.n_layers > 1 || p->nodefn.n_layers > 1 || p->graphfn.n_layers > 1 || out_width(p->edgefn) == 0) (void)gnx_ensure_wide_tables(h);
-  return layout(h, p, R).total;
+  return layout(h, p, R, lnf.ident_floats()).total;
 }
 
-int32_t gnx_chain_block_forward(const gnx_graphs* h, const gnx_chain_block_params* p, const float* ef, const float* nf, const float* gf, int64_t R,
+int32_t gnx_chain_block_forward(const gnx_graphs* h, const gnx_chain_block_params* p0, const float* ef, const float* nf, const float* gf, int64_t R,
                                 float* ef_out, float* nf_out, float* gf_out, void* ws, size_t ws_bytes, uint32_t flags, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   gnx::FormScope forms(flags);  // the forms this call selected (gnx.h: GNX_FLAG_EDGE_FP32 ...)
-  int32_t rc = check_params(h, p, R);
+  int32_t rc = check_params(h, p0, R);
   if (rc) return rc;
+  ChainLnFirst lnf;
+  {  // (the identity layer's weights sit at a fixed place of the workspace: the layout does not depend on the pointer)
+    const gnx_chain_block_params* q = lnf.init(p0, nullptr);
+    if (lnf.on && ws) lnf.layers[0].weight = reinterpret_cast<const float*>(static_cast<char*>(ws) + layout(h, q, R, lnf.ident_floats()).ident);
+  }
+  const gnx_chain_block_params* p = lnf.on ? &lnf.p : p0;
   const int de = p->de, dn = p->dn, dg = p->dg;
   const int oe = out_width(p->edgefn), on = out_width(p->nodefn), og = out_width(p->graphfn);
   bool chain_wide = de > 32 || dn > 32 || dg > 32;  // (any layer of any chain at matrix-core widths)
@@ -178,11 +199,12 @@ int32_t gnx_chain_block_forward(const gnx_graphs* h, const gnx_chain_block_param
   gnx::DeviceTurn turn(s, chain_wide);
   if ((de > 0 && !ef && h->E > 0) || (dn > 0 && !nf) || (dg > 0 && !gf)) return fail(GNX_ERR_INVALID_ARG, "an input with non-zero width is NULL (width 0 <=> nothing)");
   if ((oe > 0 && !ef_out && h->E > 0) || (on > 0 && !nf_out) || (og > 0 && !gf_out)) return fail(GNX_ERR_INVALID_ARG, "an output with non-zero width is NULL");
-  const ChainWs w = layout(h, p, R);
+  const ChainWs w = layout(h, p, R, lnf.ident_floats());
   if (!ws || ws_bytes < w.total) return fail(GNX_ERR_WORKSPACE, "workspace missing or smaller than gnx_chain_block_workspace_bytes()");
   if (((uintptr_t)ws & 15) != 0) return fail(GNX_ERR_WORKSPACE, "workspace must be 16-byte aligned");
   char* base = static_cast<char*>(ws);
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+  if ((rc = lnf.fill(F(w.ident), s))) return rc;
   // ---- edge function (gnblock.jl:65): first Dense fused with getedgefninput, the rest row-wise ----
   if (oe > 0 && h->E > 0) {
     const gnx_block_params b = edge_block(p);

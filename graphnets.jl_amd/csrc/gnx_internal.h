@@ -145,6 +145,51 @@ inline bool chain_layer_is_ln(const gnx_dense& l) { return (l.kind & 0xff) == GN
 inline int chain_layer_ln_mode(const gnx_dense& l) { return (l.kind & GNX_LAYER_LN_SQRT_EPS) ? 1 : 0; }
 int32_t launch_chain_layer(const gnx_graphs* h, int entity, const gnx_dense& layer, const float* x, int k_in, int width, float* out, int64_t R, hipStream_t s,
                            const char* name);  // gnx_chain.cpp
+// An edge function whose FIRST layer is a LayerNorm, `Chain(LayerNorm(K_e), Dense ...)`: the chain entry points fuse a chain's first layer with
+// getedgefninput (the (K_e, E) input is never materialised) and that layer must be a Dense — so such a chain runs as Chain(Dense(I), LayerNorm, ...):
+// the identity layer's output IS the function input, bit for bit (x . 1 + 0 in fp32 and in the six-term split: h + m + l = x exactly), and both
+// the forward and the pullback (the scatter of the input gradient into d_ef / d_nf[src] / d_nf[dst] / d_gf included) stay those of a Dense-first
+// chain.  `ident` = K_e x K_e floats in the call's workspace, written by fill() on the call's stream.  Not copyable: p.edgefn points into it.
+constexpr int kChainMaxLayers = 16;
+struct ChainLnFirst {
+  bool on = false;
+  int ke = 0;
+  gnx_dense layers[kChainMaxLayers + 1];
+  int32_t widths[kChainMaxLayers + 1];
+  gnx_dense_grad grads_e[kChainMaxLayers + 1];
+  gnx_chain_block_params p;
+  gnx_chain_block_grads grads;
+  ChainLnFirst() = default;
+  ChainLnFirst(const ChainLnFirst&) = delete;
+  ChainLnFirst& operator=(const ChainLnFirst&) = delete;
+  static bool applies(const gnx_chain_block_params* p0) {
+    return p0 && p0->edgefn.n_layers > 0 && p0->edgefn.n_layers <= kChainMaxLayers && p0->edgefn.layers && p0->edgefn.widths && chain_layer_is_ln(p0->edgefn.layers[0]);
+  }
+  // the parameters the entry point works on: *p0 itself, or the rewritten chain (ident may be NULL for a layout query)
+  const gnx_chain_block_params* init(const gnx_chain_block_params* p0, const float* ident) {
+    if (!applies(p0)) return p0;
+    on = true;
+    ke = p0->de + 2 * p0->dn + p0->dg;
+    p = *p0;
+    layers[0] = gnx_dense{ident, nullptr, GNX_ACT_IDENTITY, GNX_LAYER_DENSE};
+    widths[0] = ke;
+    for (int i = 0; i < p0->edgefn.n_layers; ++i) { layers[i + 1] = p0->edgefn.layers[i]; widths[i + 1] = p0->edgefn.widths[i]; }
+    p.edgefn.layers = layers; p.edgefn.widths = widths; p.edgefn.n_layers = p0->edgefn.n_layers + 1;
+    return &p;
+  }
+  const gnx_chain_block_grads* init_grads(const gnx_chain_block_grads* g0) {  // (after init(): the caller's gradient slots, shifted behind the identity layer's empty one)
+    if (!on || !g0) return g0;
+    grads = *g0;
+    if (g0->edgefn) {
+      grads_e[0] = gnx_dense_grad{nullptr, nullptr};
+      for (int i = 0; i + 1 < p.edgefn.n_layers; ++i) grads_e[i + 1] = g0->edgefn[i];
+      grads.edgefn = grads_e;
+    }
+    return &grads;
+  }
+  size_t ident_floats() const { return on ? (size_t)ke * ke : 0; }
+  int32_t fill(float* ident, hipStream_t s) const;  // gnx_chain.cpp
+};
 unsigned lds_pad_bytes();  // experiment switch GNX_LDS_PAD_KB: dynamic LDS added to EVERY launch (0 by default) — a workgroup that owns most of a CU's LDS shares the CU with no other LDS-using kernel
 bool form(uint32_t bit);  // is the form selected for the call this thread is in (outside a call: by the environment's defaults)
 

@@ -308,8 +308,9 @@ GNX_API int32_t gnx_block_forward_steps(const gnx_graphs* h, const gnx_block_par
  * widths of the edge / node chains); a chain with n_layers = 0 or a last width of 0 <=> that output is `nothing`.
  * The edge function's first layer runs fused with getedgefninput (the fast block kernels); every further layer is a row-wise
  * Dense on the matrix-core GEMM kernel.  A layer entry may also be a `LayerNorm(d)` layer value (gnx_dense.kind = GNX_LAYER_LAYERNORM,
- * `Chain(Dense(a => d, relu), LayerNorm(d), Dense(d => b))`: normalised rows of the layer in front, its width = that layer's) — anywhere
- * but as the edge function's FIRST layer (which is the fused Dense).  The gradient entries of a LayerNorm layer are (gamma, beta).
+ * `Chain(Dense(a => d, relu), LayerNorm(d), Dense(d => b))`: normalised rows of the layer in front, its width = that layer's) — anywhere in a chain;
+ * as the edge function's FIRST layer it runs behind an identity Dense that the library puts in front (the fused launch then writes the
+ * function input itself: K_e x K_e floats more of workspace).  The gradient entries of a LayerNorm layer are (gamma, beta).
  * Backward: gnx_chain_block_backward below. */
 typedef struct gnx_chain {
   const gnx_dense* layers; /* [n_layers] host array of layer descriptors (device weight pointers inside) */

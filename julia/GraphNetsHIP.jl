@@ -743,7 +743,7 @@ struct GnxChain; layers::Ptr{GnxDense}; widths::Ptr{Int32}; n_layers::Int32; res
 struct GnxChainBlockParams; de::Int32; dn::Int32; dg::Int32; reserved::Int32; edgefn::GnxChain; nodefn::GnxChain; graphfn::GnxChain; end
 struct GnxChainBlockGrads; edgefn::Ptr{GnxDenseGrad}; nodefn::Ptr{GnxDenseGrad}; graphfn::Ptr{GnxDenseGrad}; end
 # A chain's layers: Dense, or a Flux `LayerNorm(d)` layer value (`Chain(Dense(a => d, relu), LayerNorm(d), Dense(d => b))`, gnblock.jl:1-6) — a
-# gnx_dense entry of kind GNX_LAYER_LAYERNORM (gamma, beta in the weight / bias slots; anywhere but as the edge function's first layer)
+# gnx_dense entry of kind GNX_LAYER_LAYERNORM (gamma, beta in the weight / bias slots; anywhere in a chain)
 const ChainLayer = Union{Dense,LayerNorm}
 layerwidth(l::Dense) = size(l.weight, 1)
 layerwidth(l::LayerNorm) = length(l.γ)

@@ -596,8 +596,10 @@ def make_chain_block_params(rng, in_dims, edge_widths, node_widths, graph_widths
     the last layer of a chain is linear (like the reference's default).  A width entry "ln" puts a Flux `LayerNorm(d)` layer value
     there (d = the width in front of it; random gamma / beta): the layer tuple is ("layernorm", gamma, beta)."""
     de, dn, dg = in_dims
-    last = lambda ws: next((w for w in reversed(ws) if w != "ln"), 0)  # (a LayerNorm keeps the width in front of it)
-    oe, on = last(edge_widths), last(node_widths)
+    # (a LayerNorm keeps the width in front of it; a chain of LayerNorms alone keeps its input's)
+    last = lambda ws, k: next((w for w in reversed(ws) if w != "ln"), k if ws else 0)
+    oe = last(edge_widths, de + 2 * dn + dg)
+    on = last(node_widths, oe + dn + dg)
     kin = dict(edge=de + 2 * dn + dg, node=oe + dn + dg, graph=oe + on + dg)
     p = dict(in_dims=tuple(in_dims))
     for name, widths in (("edge", edge_widths), ("node", node_widths), ("graph", graph_widths)):

@@ -32,6 +32,10 @@ CASES = [
     ((10, 5, 0), [16, "ln", 3], [8, "ln", 4], ["ln", 6, 5]),   # ... and as the FIRST layer of the graph function (its input is materialised)
     ((10, 5, 3), [12, 7, "ln"], ["ln", 6], [9, "ln", 4, "ln"]),  # as a chain's last layer; first layer of the node function
     ((128, 64, 32), [256, "ln", 128], [128, "ln", 64], [64, 32]),  # wide rows
+    # ... and as the EDGE function's first layer (pre-norm of the concatenated input): behind an identity Dense the library puts in front
+    ((10, 5, 3), ["ln", 12, 7], [6], [4]),
+    ((10, 5, 0), ["ln"], ["ln", 4], []),               # the edge function IS the LayerNorm: ef' = LayerNorm(getedgefninput), 20 wide
+    ((128, 64, 32), ["ln", 128, 64], [64], [32]),      # wide: K_e = 288
 ]
 
 
@@ -120,6 +124,8 @@ BW_CASES = [
     ((48, 24, 8), [64, 40], [48, 24], [32, 16], (2, 3, 2), True),   # matrix-core row-wise pullbacks (>= 4096 rows)
     ((10, 5, 3), [16, "ln", 3], [8, "ln", 4, "ln"], ["ln", 6, 5], (2, 3, 2), False),   # LayerNorm layer values: between, last, first
     ((48, 24, 8), [64, "ln", 40], [48, "ln", 24], [32, 16], (2, 3, 2), True),          # ... behind matrix-core layers
+    ((10, 5, 3), ["ln", 12, 7], [6, "ln"], [4], (2, 3, 2), False),                     # first layer of the EDGE function (identity Dense in front)
+    ((48, 24, 8), ["ln", 64, 40], [24], [16], (2, 3, 2), True),
 ]
 
 
@@ -217,3 +223,22 @@ def test_chain_with_activation_identity_and_dropout_layer_values(gn):
         l.weight.requires_grad_(True)
     blk(x).ef.sum().backward()
     assert all(l.weight.grad is not None and bool(torch.isfinite(l.weight.grad).all()) for l in blk.edgefn.layers)
+
+
+def test_update_functions_replaced_after_construction_set_the_output_widths(gn):
+    """gnblock.jl:1-6: a GNBlock is a struct of three functions; one-layer Chains (or Dense layers) assigned after construction run on the fused
+    block kernels with THEIR widths, not the constructor's (found by the random chain sweep: the mirror kept the placeholder's widths)."""
+    rng = np.random.default_rng(12)
+    adjs = [(rng.random((n, n)) < 0.3).astype(np.int64) for n in (9, 14, 5)]
+    g = gn.GNGraphBatch(adjs)
+    p = O.make_chain_block_params(rng, (6, 4, 3), [8], [5], [7])
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, (6, 4, 3))
+    blk = _block(gn, p)  # built as GNBlock((6, 4, 3) => (1, 0, 0)), then the three one-layer chains assigned
+    y = blk(U.to_nt(gn, g, ef, nf, gf))
+    assert blk.out_dims == (8, 5, 7)
+    ref, scale = O.chain_block_forward_sparse(p, O.csc_from_adj(adjs), ef, nf, gf, return_scale=True)
+    for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        U.assert_close(U.from_jl(got), r, s, name)
+    blk.nodefn = gn.Dense(3, 5)  # a function that does not take what the block feeds it: Flux's DimensionMismatch
+    with pytest.raises(AssertionError):
+        blk(U.to_nt(gn, g, ef, nf, gf))

@@ -153,6 +153,50 @@ def test_random_wide_core(gn, seed):
             U.assert_close(U.from_jl(got), r, s, f"seed {seed} dims {dims} N={g.n_nodes} E={g.n_edges} G={g.n_graphs} R={R} flags={flags:#x} {name}")
 
 
+def _random_chain(rng, widths, first_in):
+    """0-3 Dense layers with LayerNorm layer values sprinkled in (a LayerNorm needs a non-empty input: never in front of a zero-width input)."""
+    n = int(rng.integers(0, 4))
+    out = []
+    for i in range(n):
+        if rng.random() < 0.3 and (i > 0 or first_in > 0):
+            out.append("ln")
+        out.append(int(rng.choice(widths)))
+    if out and rng.random() < 0.2:
+        out.append("ln")
+    return out
+
+
+@pytest.mark.parametrize("seed", range(12 + EXTRA // 4))
+def test_random_chain_block(gn, seed):
+    """GNBlock whose update functions are random Chains of Dense / LayerNorm layers (gnblock.jl:1-6) on random small and big batches."""
+    from tests.test_gpu_chain import _block
+    rng = np.random.default_rng(9700 + seed)
+    big = rng.random() < 0.35
+    g, _ = _random_big_batch(rng, gn) if big else _random_batch(rng, gn)
+    widths = [8, 32, 64, 128] if big else [1, 3, 7, 12, 16, 33]
+    while True:
+        in_dims = tuple(int(rng.choice([0] + widths)) for _ in range(3))
+        if sum(in_dims) > 0:
+            break
+    ew = _random_chain(rng, widths, sum(in_dims))
+    oe = next((w for w in reversed(ew) if w != "ln"), 0)
+    nw = _random_chain(rng, widths, oe + in_dims[1] + in_dims[2]) if oe + in_dims[1] + in_dims[2] > 0 else []  # (nothing to feed it: vcat of nothings)
+    on = next((w for w in reversed(nw) if w != "ln"), 0)
+    gw = _random_chain(rng, widths, oe + on + in_dims[2]) if oe + on + in_dims[2] > 0 else []
+    if not (ew or nw or gw):
+        ew = [int(rng.choice(widths))]
+    p = O.make_chain_block_params(rng, in_dims, ew, nw, gw, acts=tuple(int(a) for a in rng.integers(0, 5, 3)))
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, in_dims)
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    ref, scale = O.chain_block_forward_sparse(p, csc, ef, nf, gf, return_scale=True)
+    y = _block(gn, p)(U.to_nt(gn, g, ef, nf, gf))
+    for name, got, r, s in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        if r is None:
+            assert got is None, f"seed {seed}: {name} should be nothing"
+            continue
+        U.assert_close(U.from_jl(got), r, s, f"seed {seed} in {in_dims} edge {ew} node {nw} graph {gw} N={g.n_nodes} E={g.n_edges} {name}")
+
+
 @pytest.mark.parametrize("seed", range(12 + EXTRA // 4))
 def test_random_block_backward(gn, seed):
     """gnx_block_backward on random width sets / batches (smooth activations: no relu kink) against torch float64 autograd."""
