@@ -153,6 +153,44 @@ def test_random_wide_core(gn, seed):
             U.assert_close(U.from_jl(got), r, s, f"seed {seed} dims {dims} N={g.n_nodes} E={g.n_edges} G={g.n_graphs} R={R} flags={flags:#x} {name}")
 
 
+@pytest.mark.parametrize("seed", range(8 + EXTRA // 8))
+def test_random_model(gn, seed):
+    """encoder block -> 0-2 GNCores -> decoder block at random widths on random batches (README ex.3's shape, sort.jl:68-75), three ways: the
+    eager chain of layer calls against the oracle (layer by layer at 1e-5 of the bound, end to end normwise), and the library's one-hipGraph model
+    (gnx_model_*; captured and eager) bit-identical to the eager chain."""
+    import torch
+    rng = np.random.default_rng(9600 + seed)
+    big = rng.random() < 0.3
+    g, R = _random_big_batch(rng, gn) if big else _random_batch(rng, gn)
+    if g.n_edges == 0:
+        pytest.skip("a batch without edges")
+    din = tuple(int(rng.choice([0, 2, 5, 10])) for _ in range(3))
+    if din[0] + din[1] == 0:
+        din = (4, 3, din[2])
+    core = tuple(int(v) for v in (rng.choice([(128, 64, 32), (64, 64, 16), (128, 64, 8)]) if big else rng.choice([(10, 5, 3), (8, 8, 8), (16, 12, 4), (33, 20, 5), (3, 4, 5)])))
+    dout = tuple(int(rng.choice([1, 3, 4, 7])) for _ in range(3))
+    n_cores = int(rng.integers(0, 3))
+    specs = [("block", O.make_block_params(rng, din, core, act=tuple(int(a) for a in rng.integers(0, 3, 3))))]
+    specs += [("core", O.make_core_params(rng, core, eps_mode=int(rng.integers(0, 2)))) for _ in range(n_cores)]
+    specs += [("block", O.make_block_params(rng, core, dout, act=(0, 0, 0)))]
+    layers = [(k, p, U.block_from_params(gn, p) if k == "block" else U.core_from_params(gn, p)) for k, p in specs]
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, g.n_graphs, din)
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    U.check_chain(gn, g, csc, layers, (ef, nf, gf), f"seed {seed} {din}=>{core} x{n_cores} =>{dout} N={g.n_nodes} E={g.n_edges} G={g.n_graphs} R={R}",
+                  normwise=1e-5 * (1 + n_cores))
+    x = U.to_nt(gn, g, ef, nf, gf)
+    y = x
+    for _, _, layer in layers:
+        y = layer(y)
+    eager = [None if a is None else a.clone() for a in (y.ef, y.nf, y.gf)]
+    for flags in (0, gn._lib.FLAG_NO_GRAPH):
+        m = gn.Model([l for _, _, l in layers], x, flags=flags)
+        for _ in range(2):
+            ym = m(x)
+        for name, a, b in zip(("ef", "nf", "gf"), eager, (ym.ef, ym.nf, ym.gf)):
+            assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), f"seed {seed} model flags {flags:#x}: {name} differs from the eager chain"
+
+
 def _random_chain(rng, widths, first_in):
     """0-3 Dense layers with LayerNorm layer values sprinkled in (a LayerNorm needs a non-empty input: never in front of a zero-width input)."""
     n = int(rng.integers(0, 4))
