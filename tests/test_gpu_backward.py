@@ -207,8 +207,8 @@ def test_core_backward_with_a_gelu_feedforward(gn, dims, big):
     assert _core_backward_case(gn, dims, big, 0, np.random.default_rng(450 + sum(dims)), hidden_act="gelu")
 
 
-def _core_backward_case(gn, dims, big, eps_mode, rng, hidden_act=None):
-    sizes, cps, rvs = _graphs(rng, big)
+def _core_backward_case(gn, dims, big, eps_mode, rng, hidden_act=None, graphs=None):
+    sizes, cps, rvs = graphs if graphs is not None else _graphs(rng, big)
     g = gn.GNGraphBatch.from_csc(cps, rvs, [int(n) for n in sizes])
     csc = (*g.csc(), g.node_off, g.edge_off)
     p = O.make_core_params(rng, dims, eps_mode=eps_mode)

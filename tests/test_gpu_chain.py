@@ -107,11 +107,11 @@ def _torch_chain_block(csc, ef, nf, gf, W):
     he = chain(cat([ef, None if nf is None else nf[rowval], None if nf is None else nf[dst], None if gf is None else gf[eg]]), W["edge"], pre)
     hn = hg = None
     if W["node"]:
-        agg = torch.zeros((N, he.shape[1]), dtype=torch.float64).index_add(0, dst, he)
+        agg = torch.zeros((N, he.shape[1]), dtype=he.dtype).index_add(0, dst, he)
         hn = chain(cat([agg, nf, None if gf is None else gf[ng]]), W["node"], pre)
-    if W["graph"]:
-        se = torch.zeros((G, he.shape[1]), dtype=torch.float64).index_add(0, eg, he)
-        sn = torch.zeros((G, hn.shape[1]), dtype=torch.float64).index_add(0, ng, hn)
+    if W["graph"]:  # (a block without a node function: its zero-width nf' is an empty segment of the graph function's input, gnblock.jl:63-69)
+        se = torch.zeros((G, he.shape[1]), dtype=he.dtype).index_add(0, eg, he)
+        sn = None if hn is None else torch.zeros((G, hn.shape[1]), dtype=he.dtype).index_add(0, ng, hn)
         hg = chain(cat([se, sn, gf]), W["graph"], pre)
     return (he, hn, hg), pre
 
@@ -133,7 +133,6 @@ BW_CASES = [
 def test_chain_block_backward_matches_torch_autograd(gn, case):
     """gnx_chain_block_backward through torch autograd against float64 torch autograd of an independent restatement: input gradients and
     every layer's weight / bias gradient.  Hidden activations are smooth or, for relu, drawn kink-free."""
-    import torch
     in_dims, ew, nw, gw, acts, big = case
     for attempt in range(20):
         rng = np.random.default_rng(700 + sum(in_dims) + 1000 * attempt)
@@ -144,46 +143,72 @@ def test_chain_block_backward_matches_torch_autograd(gn, case):
             sizes = rng.integers(3, 30, 5)
             cs = [U.er_csc(rng, int(n), int(0.2 * n * n) + 1) for n in sizes]
         g = gn.GNGraphBatch.from_csc([c[0] for c in cs], [c[1] for c in cs], [int(n) for n in sizes])
-        csc = (*g.csc(), g.node_off, g.edge_off)
-        p = O.make_chain_block_params(rng, in_dims, ew, nw, gw, acts=acts)
-        ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, in_dims)
-        T = lambda a: None if a is None else torch.tensor(a[0], dtype=torch.float64, requires_grad=True)
-        xs = [T(ef), T(nf), T(gf)]
-        T64 = lambda v: torch.tensor(v, dtype=torch.float64, requires_grad=True)
-        W = {name: [(w, T64(b), T64(a)) if isinstance(w, str) else (T64(w), T64(b), a) for w, b, a in p[name]] for name in ("edge", "node", "graph")}
-        outs_r, pre = _torch_chain_block(csc, *xs, W)
-        if any(a == 1 and float(z.detach().abs().min()) < 5e-6 for z, a in pre if z.numel()):
-            continue  # a relu pre-activation within fp32 rounding of its kink: re-draw
-        cot = [None if o is None else torch.from_numpy(rng.standard_normal(tuple(o.shape))) for o in outs_r]
-        sum((o * c).sum() for o, c in zip(outs_r, cot) if o is not None).backward()
-        # HIP
-        blk = _block(gn, p)
-        leaves = []
-        for ch in (blk.edgefn, blk.nodefn, blk.graphfn):
-            for l in ch.layers:
-                l.weight.requires_grad_(True); l.bias.requires_grad_(True)
-                leaves += [l.weight, l.bias]
-        dev = g.device
-        leaf = lambda a: None if a is None else torch.from_numpy(a).to(dev).requires_grad_(True)
-        xt = [leaf(ef), leaf(nf), leaf(gf)]
-        y = blk(gn.NT(g, *(None if t is None else t.permute(2, 1, 0) for t in xt)))
-        loss = sum((o.permute(2, 1, 0)[0] * c.to(dev).float()).sum() for o, c in zip((y.ef, y.nf, y.gf), cot) if o is not None)
-        loss.backward()
-
-        def close(got, ref, what):
-            ref = ref.detach().numpy(); got = got.detach().double().cpu().numpy()
-            scale = max(1.0, float(np.abs(ref).max()))
-            assert got.shape == ref.shape, (what, got.shape, ref.shape)
-            assert np.max(np.abs(got - ref)) <= 1e-3 * scale, f"{what}: max err {np.max(np.abs(got - ref)):.3e} (scale {scale:.3g})"
-
-        for name, t, r in zip(("d_ef", "d_nf", "d_gf"), xt, xs):
-            if t is not None:
-                close(t.grad[0], r.grad, name)
-        refs = [q.grad for name in ("edge", "node", "graph") for w, b, a in W[name] for q in ((b, a) if isinstance(w, str) else (w, b))]
-        for i, (q, r) in enumerate(zip(leaves, refs)):
-            close(q.grad, r, f"param[{i}]")
-        return
+        if chain_block_backward_case(gn, g, rng, in_dims, ew, nw, gw, acts):
+            return
     pytest.fail("no kink-free draw in 20 attempts")
+
+
+def chain_block_backward_case(gn, g, rng, in_dims, ew, nw, gw, acts, fp32_yardstick=False):
+    """One comparison on batch `g`; False when a relu pre-activation sits within fp32 rounding of its kink (re-draw).  The bar is 1e-3 of the
+    gradient's largest entry; `fp32_yardstick` (the random sweeps: hubs of 150 in-edges in front of a LayerNorm make sums that cancel to 1 % of
+    their terms) also accepts 20 x the error of the SAME restatement evaluated by torch in float32 — a conditioning yardstick, not a looser bar."""
+    import torch
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    p = O.make_chain_block_params(rng, in_dims, ew, nw, gw, acts=acts)
+    ef, nf, gf = U.packed_inputs(rng, 1, g.n_edges, g.n_nodes, g.n_graphs, in_dims)
+
+    def restatement(dt, cot):
+        T = lambda a: None if a is None else torch.tensor(a[0], dtype=dt, requires_grad=True)
+        xs = [T(ef), T(nf), T(gf)]
+        Tw = lambda v: torch.tensor(v, dtype=dt, requires_grad=True)
+        W = {name: [(w, Tw(b), Tw(a)) if isinstance(w, str) else (Tw(w), Tw(b), a) for w, b, a in p[name]] for name in ("edge", "node", "graph")}
+        outs_r, pre = _torch_chain_block(csc, *xs, W)
+        if cot is None:
+            if any(a == 1 and float(z.detach().abs().min()) < 5e-6 for z, a in pre if z.numel()):
+                return None  # a relu pre-activation within fp32 rounding of its kink: re-draw
+            cot = [None if o is None else torch.from_numpy(rng.standard_normal(tuple(o.shape))) for o in outs_r]
+        sum((o * c.to(dt)).sum() for o, c in zip(outs_r, cot) if o is not None).backward()
+        return xs, W, cot
+
+    r64 = restatement(torch.float64, None)
+    if r64 is None:
+        return False
+    xs, W, cot = r64
+    yard = {}
+    if fp32_yardstick:
+        xs32, W32, _ = restatement(torch.float32, cot)
+        g32 = [None if x is None else x.grad for x in xs32] + [q.grad for name in ("edge", "node", "graph") for w, b, a in W32[name] for q in ((b, a) if isinstance(w, str) else (w, b))]
+        g64 = [None if x is None else x.grad for x in xs] + [q.grad for name in ("edge", "node", "graph") for w, b, a in W[name] for q in ((b, a) if isinstance(w, str) else (w, b))]
+        names = ["d_ef", "d_nf", "d_gf"] + [f"param[{i}]" for i in range(len(g64) - 3)]
+        yard = {n: 20.0 * float((a.double() - b).abs().max()) for n, a, b in zip(names, g32, g64) if b is not None and b.numel()}
+    # HIP
+    blk = _block(gn, p)
+    leaves = []
+    for ch in (blk.edgefn, blk.nodefn, blk.graphfn):
+        for l in ch.layers:
+            l.weight.requires_grad_(True); l.bias.requires_grad_(True)
+            leaves += [l.weight, l.bias]
+    dev = g.device
+    leaf = lambda a: None if a is None else torch.from_numpy(a).to(dev).requires_grad_(True)
+    xt = [leaf(ef), leaf(nf), leaf(gf)]
+    y = blk(gn.NT(g, *(None if t is None else t.permute(2, 1, 0) for t in xt)))
+    loss = sum((o.permute(2, 1, 0)[0] * c.to(dev).float()).sum() for o, c in zip((y.ef, y.nf, y.gf), cot) if o is not None)
+    loss.backward()
+
+    def close(got, ref, what):
+        ref = ref.detach().numpy(); got = got.detach().double().cpu().numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert got.shape == ref.shape, (what, got.shape, ref.shape)
+        bar = max(1e-3 * scale, yard.get(what, 0.0))
+        assert np.max(np.abs(got - ref)) <= bar, f"{what}: max err {np.max(np.abs(got - ref)):.3e} (scale {scale:.3g}, bar {bar:.3g})"
+
+    for name, t, r in zip(("d_ef", "d_nf", "d_gf"), xt, xs):
+        if t is not None:
+            close(t.grad[0], r.grad, name)
+    refs = [q.grad for name in ("edge", "node", "graph") for w, b, a in W[name] for q in ((b, a) if isinstance(w, str) else (w, b))]
+    for i, (q, r) in enumerate(zip(leaves, refs)):
+        close(q.grad, r, f"param[{i}]")
+    return True
 
 
 def test_chain_with_activation_identity_and_dropout_layer_values(gn):

@@ -22,6 +22,11 @@ def gn():
 
 
 def _random_batch(rng, gn):
+    cps, rvs, sizes, R = _random_csc(rng)
+    return gn.GNGraphBatch.from_csc(cps, rvs, sizes), R
+
+
+def _random_csc(rng):
     shared = rng.random() < 0.3
     G = 1 if shared else int(rng.integers(1, 7))
     cps, rvs, sizes = [], [], []
@@ -35,9 +40,8 @@ def _random_batch(rng, gn):
         else:
             cp, rv = U.er_csc(rng, n, int(rng.integers(1, max(2, n * n // 3))))
         cps.append(cp); rvs.append(rv); sizes.append(n)
-    g = gn.GNGraphBatch.from_csc(cps, rvs, sizes)
     R = int(rng.integers(1, 4)) if shared else 1
-    return g, R
+    return cps, rvs, sizes, R
 
 
 def _dims(rng, core=False):
@@ -92,6 +96,11 @@ WIDE_CORES = [(128, 64, 32), (128, 64, 4), (64, 64, 16), (128, 128, 8), (64, 32,
 
 
 def _random_big_batch(rng, gn):
+    cps, rvs, sizes, R = _random_big_csc(rng)
+    return gn.GNGraphBatch.from_csc(cps, rvs, sizes), R
+
+
+def _random_big_csc(rng):
     """Batches around the row thresholds of the six-term kernels (4096 edge / node rows) with ragged last tiles: one graph (maybe replicas)
     or a few, edge counts from below the threshold to a few tiles above it, now and then a hub that takes a third of the edges."""
     shared = rng.random() < 0.4
@@ -111,8 +120,7 @@ def _random_big_batch(rng, gn):
             np.add.at(cp, dst + 1, 1)
             cp = np.cumsum(cp)
         cps.append(cp); rvs.append(rv.astype(np.int64)); sizes.append(n)
-    g = gn.GNGraphBatch.from_csc(cps, rvs, sizes)
-    return g, (int(rng.integers(1, 3)) if shared else 1)
+    return cps, rvs, sizes, (int(rng.integers(1, 3)) if shared else 1)
 
 
 @pytest.mark.parametrize("seed", range(10 + EXTRA // 8))
@@ -191,15 +199,17 @@ def test_random_model(gn, seed):
             assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), f"seed {seed} model flags {flags:#x}: {name} differs from the eager chain"
 
 
-def _random_chain(rng, widths, first_in):
-    """0-3 Dense layers with LayerNorm layer values sprinkled in (a LayerNorm needs a non-empty input: never in front of a zero-width input)."""
+def _random_chain(rng, widths, first_in, ln_min=1):
+    """0-3 Dense layers with LayerNorm layer values sprinkled in, each over at least `ln_min` columns (never in front of a zero-width input; the
+    backward sweeps ask for 2: the derivative of sigma at a one-column row is 0 / 0 in the float64 reference too)."""
     n = int(rng.integers(0, 4))
-    out = []
+    out, k = [], first_in
     for i in range(n):
-        if rng.random() < 0.3 and (i > 0 or first_in > 0):
+        if rng.random() < 0.3 and k >= ln_min:
             out.append("ln")
-        out.append(int(rng.choice(widths)))
-    if out and rng.random() < 0.2:
+        k = int(rng.choice(widths))
+        out.append(k)
+    if out and rng.random() < 0.2 and k >= ln_min:
         out.append("ln")
     return out
 
@@ -216,7 +226,7 @@ def test_random_chain_block(gn, seed):
         in_dims = tuple(int(rng.choice([0] + widths)) for _ in range(3))
         if sum(in_dims) > 0:
             break
-    ew = _random_chain(rng, widths, sum(in_dims))
+    ew = _random_chain(rng, widths, in_dims[0] + 2 * in_dims[1] + in_dims[2])
     oe = next((w for w in reversed(ew) if w != "ln"), 0)
     nw = _random_chain(rng, widths, oe + in_dims[1] + in_dims[2]) if oe + in_dims[1] + in_dims[2] > 0 else []  # (nothing to feed it: vcat of nothings)
     on = next((w for w in reversed(nw) if w != "ln"), 0)
@@ -242,6 +252,45 @@ def test_random_block_backward(gn, seed):
     g, _ = _random_batch(rng, gn)
     din, dout = _dims(rng)
     _check_block_backward(gn, rng, g, din, dout, seed)
+
+
+@pytest.mark.parametrize("seed", range(8 + EXTRA // 6))
+def test_random_chain_block_backward(gn, seed):
+    """gnx_chain_block_backward for random Chains of Dense / LayerNorm layers (smooth activations) against torch float64 autograd."""
+    from tests.test_gpu_chain import chain_block_backward_case
+    rng = np.random.default_rng(9750 + seed)
+    big = rng.random() < 0.3
+    g, _ = _random_big_batch(rng, gn) if big else _random_batch(rng, gn)
+    if g.n_edges == 0:
+        pytest.skip("a batch without edges")
+    widths = [8, 24, 48, 64] if big else [1, 3, 7, 12, 16, 33]
+    while True:
+        in_dims = tuple(int(rng.choice([0] + widths)) for _ in range(3))
+        if sum(in_dims) > 0:
+            break
+    ke = in_dims[0] + 2 * in_dims[1] + in_dims[2]
+    ew = _random_chain(rng, widths, ke, 2) or [int(rng.choice(widths))]   # (the chain pullback needs an edge function with outputs)
+    oe = next((w for w in reversed(ew) if w != "ln"), 0)
+    nw = _random_chain(rng, widths, oe + in_dims[1] + in_dims[2], 2)
+    on = next((w for w in reversed(nw) if w != "ln"), 0)
+    gw = _random_chain(rng, widths, oe + on + in_dims[2], 2)
+    acts = tuple(int(a) for a in rng.choice([0, 2, 3, 4], 3))
+    assert chain_block_backward_case(gn, g, rng, in_dims, ew, nw, gw, acts, fp32_yardstick=True), f"seed {seed} in {in_dims} edge {ew} node {nw} graph {gw}"
+
+
+@pytest.mark.parametrize("seed", range(6 + EXTRA // 8))
+def test_random_core_backward(gn, seed):
+    """gnx_core_backward (LayerNorms, block, FeedForward, residual; smooth hidden activation) at random widths on random small and big batches
+    against torch float64 autograd of the independent restatement in tests/test_gpu_backward.py."""
+    from tests.test_gpu_backward import _core_backward_case
+    rng = np.random.default_rng(9850 + seed)
+    big = rng.random() < 0.4
+    cps, rvs, sizes, _ = _random_big_csc(rng) if big else _random_csc(rng)
+    if sum(len(r) for r in rvs) == 0:
+        pytest.skip("a batch without edges")
+    dims = tuple(int(v) for v in (rng.choice([(128, 64, 32), (64, 64, 16), (64, 32, 8), (40, 36, 33)]) if big else rng.choice([(3, 4, 5), (10, 5, 3), (8, 8, 8), (16, 12, 4), (33, 20, 5), (64, 32, 8)])))
+    hidden = str(rng.choice(["tanh", "gelu"]))
+    assert _core_backward_case(gn, dims, big, int(rng.integers(0, 2)), rng, hidden_act=hidden, graphs=(sizes, cps, rvs))
 
 
 @pytest.mark.parametrize("din,dout", [((20, 0, 0), (0, 24, 24)),   # node function without inputs (oe = dn = dg = 0): bias only
