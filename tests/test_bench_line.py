@@ -109,3 +109,25 @@ def test_compact_line_survives_pathological_prose():
     line["cpu_baseline"]["sample"] = "s" * 5000
     line["metric"] = "m" * 1000
     check_compact(bench.compact_line(line, None), 1)
+
+
+def test_live_traffic_falls_back_without_a_gpu_and_the_compact_line_says_where_the_figure_is_from(monkeypatch):
+    """roofline.traffic is measured in the driver's own run (two rocprofv3 counter passes over a child); when that cannot be done — no profiler,
+    no GPU (here), a pass that overruns — the call returns None with the reason and the committed profile's figure stays; the compact line names
+    the origin either way and stays under its cap."""
+    import bench
+    got, rec = bench.live_traffic("k_block_wave", ["--gpus", "1", "--steps", "2", "--warmup", "1"], timeout_s=120)
+    assert got is None and rec["live"] is False and rec["why"]
+    monkeypatch.setattr(__import__("shutil"), "which", lambda name: None)
+    monkeypatch.setattr(bench.os.path, "exists", lambda p, _e=bench.os.path.exists: False if p.endswith("rocprofv3") else _e(p))
+    got, rec = bench.live_traffic("k_block_wave", [], timeout_s=5)
+    assert got is None and rec == {"live": False, "why": "rocprofv3 not found"}
+    monkeypatch.undo()
+    line = json.load(open(os.path.join(ROOT, "profiles", "bench_r06_default.json")))
+    line["roofline"]["traffic"] = 79676633.1
+    line["roofline"]["traffic_source"] = {"live": True, "how": "x" * 500, "committed_profile_figure": 79681095.9}
+    c = bench.compact_line(line, "gpurun_out/bench_detail_default.json")
+    check_compact(c, 1)
+    assert c["roofline"]["traffic"] == 79676633.1 and c["roofline"]["traffic_measured"].startswith("this run")
+    line["roofline"]["traffic_source"] = {"file": "profiles/traffic_readme.json", "commit": None}
+    assert bench.compact_line(line)["roofline"]["traffic_measured"].startswith("profiles/")
