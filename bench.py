@@ -725,6 +725,8 @@ def live_traffic(kernel, bench_args, timeout_s=75.0):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, {"live": False, "why": "rocprofv3 not found"}
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, {"live": False, "why": "this run is itself under a profiler"}  # (no profiler inside a profiler: tools/profile.sh collects the counters of such runs)
     py = os.path.realpath(sys.executable)  # (the interpreter itself behind `--`: no env / shell hop under the profiler)
     means, rec = {}, {"live": True, "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, + --kernel-trace) over a child bench.py of this workload, "
                                             "in this run; KiB -> B, FETCH_SIZE x2 (gfx950 wide-read correction); FETCH_SIZE counts Infinity-Cache hits too"}
