@@ -514,7 +514,7 @@ def compact_line(line, detail_path=None):
         c["dist_backend"] = _short(cfg["dist_backend"], 24)
     out["config"] = c
     if isinstance(roof, dict):
-        r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "frac_whole_step", "frac_whole_step_two_launch", "algorithmic_bytes", "kernel", "kernel_us", "executed_flops", "matrix_roof_frac"))
+        r = _pick(roof, ("bound", "achieved", "peak", "unit", "frac", "frac_whole_step", "frac_whole_step_two_launch", "algorithmic_bytes", "kernel", "kernel_us", "kernel_us_rocprofv3", "executed_flops", "matrix_roof_frac"))
         r["traffic"] = roof.get("traffic")  # (null stays null: the contract names the key)
         ts = roof.get("traffic_source")
         if isinstance(ts, dict):  # where the figure is from: counters collected in THIS run, or the committed profile of the same kernel sources
@@ -731,10 +731,10 @@ def live_traffic(kernel, bench_args, timeout_s=75.0):
     means, rec = {}, {"live": True, "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, + --kernel-trace) over a child bench.py of this workload, "
                                             "in this run; KiB -> B, FETCH_SIZE x2 (gfx950 wide-read correction); FETCH_SIZE counts Infinity-Cache hits too"}
     t0 = time.perf_counter()
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", None):  # (None: a third pass with the kernel trace alone — the profiler's own average duration of the kernel)
         out = tempfile.mkdtemp(prefix="gnx_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--", py, os.path.join(ROOT, "bench.py")] + list(bench_args) + \
-              ["--no-secondary", "--no-cpu-baseline", "--no-c-abi", "--full-line", "--no-live-traffic"]
+        cmd = [exe] + (["--pmc", counter] if counter else []) + ["--kernel-trace", "--output-format", "csv", "-d", out, "--", py, os.path.join(ROOT, "bench.py")] + \
+              list(bench_args) + ["--no-secondary", "--no-cpu-baseline", "--no-c-abi", "--full-line", "--no-live-traffic"]
         try:
             pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
@@ -746,8 +746,20 @@ def live_traffic(kernel, bench_args, timeout_s=75.0):
                     pass
                 pr.wait()
                 shutil.rmtree(out, ignore_errors=True)
+                if counter is None and "FETCH_SIZE" in means and "WRITE_SIZE" in means:
+                    break
                 return None, {"live": False, "why": f"{counter} pass took more than {timeout_s:g} s"}
             vals = []
+            if counter is None:
+                for f in glob.glob(os.path.join(out, "**", "*_kernel_trace.csv"), recursive=True):
+                    with open(f) as fh:
+                        for row in csv.DictReader(fh):
+                            if ("gnx::" + kernel) in row.get("Kernel_Name", ""):
+                                vals.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+                if rc == 0 and vals:
+                    rec["kernel_us_rocprofv3"] = round(sum(vals) / len(vals) / 1e3, 3)
+                    rec["kernel_trace_launches"] = len(vals)
+                continue  # (optional: the traffic figure does not depend on this pass)
             for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
@@ -1422,6 +1434,8 @@ def main():
             quoted = roof.get("traffic")
             if live is not None:
                 roof["traffic"] = live
+                if lrec.get("kernel_us_rocprofv3") is not None:
+                    roof["kernel_us_rocprofv3"] = lrec["kernel_us_rocprofv3"]  # the profiler's average of the same kernel in a child of this run, beside `kernel_us`
                 lrec["committed_profile_figure"] = quoted
                 if quoted:
                     lrec["vs_committed"] = round(live / quoted, 4)
