@@ -566,8 +566,11 @@ int32_t gnx_core_forward(const gnx_graphs* h, const gnx_core_params* p, const fl
 }
 
 static int32_t pad_impl(const gnx_graphs* h, int32_t kind, bool pad, const float* src, int32_t d, int64_t R, float* dst, void* stream) {
-  if (!h || !src || !dst) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  if (!h) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
   if (kind != 0 && kind != 1) return fail(GNX_ERR_INVALID_ARG, "kind must be 0 (edges) or 1 (nodes)");
+  // the packed side of a batch without edges has no rows (its buffer may be NULL, as for the forwards); the padded side always exists
+  const bool packed_empty = (kind == 0 ? h->E : h->N) == 0;
+  if ((pad ? !dst : !src) || ((pad ? !src : !dst) && !packed_empty)) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
   if (d <= 0 || R <= 0) return fail(GNX_ERR_INVALID_ARG, "d and n_replicas must be >= 1");
   if (R > 1 && h->G != 1) return fail(GNX_ERR_INVALID_ARG, "n_replicas > 1 needs a single-graph handle");
   return launch_pad(h, kind, pad, src, d, R, dst, (hipStream_t)stream);
@@ -601,10 +604,12 @@ int32_t gnx_logit_cross_entropy_backward(const float* logits, const float* targe
 }
 
 int32_t gnx_collapse_edges(const gnx_graphs* h, const float* ef, int32_t d, int64_t R, float* out, void* stream) {
-  if (!h || !ef || !out) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
+  if (!h) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
   if (d <= 0 || R <= 0 || (R > 1 && h->G != 1) || R > 65535) return fail(GNX_ERR_INVALID_ARG, "bad d / n_replicas");
   int32_t rc = gnx_ensure_collapse(h);
   if (rc) return rc;
+  if (h->E == 0) return GNX_OK;  // a batch without edges: no collapsed column, nothing to write (ef / out may be NULL)
+  if (!ef || !out) return fail(GNX_ERR_INVALID_ARG, "NULL argument");
   return launch_collapse(h, ef, d, R, out, (hipStream_t)stream);
 }
 

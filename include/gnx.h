@@ -496,7 +496,8 @@ GNX_API int32_t gnx_logit_cross_entropy_backward(const float* logits, const floa
 
 /* ---- reference-layout bridges: padef/padnf and unpadef/unpadnf (src/pad.jl:12-64, src/unpad.jl:1-17) ----
  * kind 0 = edges: packed [R][E][d] <-> padded [B][PN^2][d];  kind 1 = nodes: packed [R][N][d] <-> padded [B][PN][d],
- * where B = R (one graph in the handle) or G (R must be 1).  Pads are written as zeros. */
+ * where B = R (one graph in the handle) or G (R must be 1).  Pads are written as zeros.  `packed` may be NULL for a batch
+ * without edges (E = 0: padef gives an array of zeros, unpadef writes nothing). */
 GNX_API int32_t gnx_pad_features(const gnx_graphs* h, int32_t kind, const float* packed, int32_t d, int64_t n_replicas,
                          float* padded, void* stream);
 GNX_API int32_t gnx_unpad_features(const gnx_graphs* h, int32_t kind, const float* padded, int32_t d, int64_t n_replicas,

@@ -199,6 +199,89 @@ def test_random_model(gn, seed):
             assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), f"seed {seed} model flags {flags:#x}: {name} differs from the eager chain"
 
 
+@pytest.mark.parametrize("seed", range(10 + EXTRA // 4))
+def test_random_batch_views_padding_and_collapse(gn, seed):
+    """The data-format side of the path on random vectors of adjacency matrices (graphs of one node, without edges, one-way edges, missing self
+    loops) and on the shared form: batch -> unbatch is the identity (batch.jl:53-64, unbatch.jl:6-39); efview / nfview / gfview, flatunpadded*,
+    padded() and unpadded() against the oracle's padded arrays (pad.jl, unpad.jl, views.jl); collapsef / unpaddedcollapsedef against the literal
+    edge_collapser product (gngraphbatch.jl:56-111)."""
+    import torch
+    rng = np.random.default_rng(9300 + seed)
+    shared = rng.random() < 0.3
+    de, dn, dg = (int(rng.choice([0, 1, 3, 8])) for _ in range(3))
+    if de + dn + dg == 0:
+        de = 2
+    if shared:
+        n, B = int(rng.choice([1, 2, 5, 9])), int(rng.integers(1, 4))
+        adj = (rng.random((n, n)) < rng.choice([0.0, 0.3, 1.0])).astype(np.int64)
+        ne = int(adj.sum())
+        ef = rng.standard_normal((de, ne, B)).astype(np.float32) if de else None
+        nf = rng.standard_normal((dn, n, B)).astype(np.float32) if dn else None
+        gf = rng.standard_normal((dg, B)).astype(np.float32) if dg else None
+        graphs, adjs = adj, [adj]
+    else:
+        adjs = [(rng.random((n, n)) < rng.choice([0.0, 0.2, 0.6, 1.0])).astype(np.int64) for n in rng.choice([1, 2, 3, 6, 11], int(rng.integers(1, 6)))]
+        ef = [rng.standard_normal((de, int(a.sum()))).astype(np.float32) for a in adjs] if de else None
+        nf = [rng.standard_normal((dn, a.shape[0])).astype(np.float32) for a in adjs] if dn else None
+        gf = [rng.standard_normal(dg).astype(np.float32) for _ in adjs] if dg else None
+        graphs, B = adjs, len(adjs)
+    x = gn.batch(dict(graphs=graphs, ef=ef, nf=nf, gf=gf))
+    xd = O.batch_dense(graphs, ef, nf, gf)
+    gd = xd["graphs"]
+    what = f"seed {seed} shared={shared} dims {(de, dn, dg)} sizes {[a.shape[0] for a in adjs]} edges {[int(a.sum()) for a in adjs]} B={B}"
+    # batch -> unbatch: the identity
+    u = gn.unbatch(x)
+    if not shared and B == 1:  # unbatch.jl:15-17: a GNGraphBatch of ONE graph unbatches through the shared-adjacency branch, whatever batch() was given
+        for name, got, want in (("ef", u.ef, ef), ("nf", u.nf, nf)):
+            assert (got is None) == (want is None), what
+            if want is not None:
+                assert np.array_equal(got.cpu().numpy(), want[0][:, :, None]), f"{what}: unbatch {name} of a one-graph vector"
+        assert (u.gf is None) == (gf is None) and (gf is None or np.array_equal(u.gf.cpu().numpy(), gf[0][:, None])), f"{what}: unbatch gf of a one-graph vector"
+    elif shared:
+        for name, got, want in (("ef", u.ef, ef), ("nf", u.nf, nf), ("gf", u.gf, gf)):
+            assert (got is None) == (want is None), what
+            if want is not None:
+                assert np.array_equal(got.cpu().numpy(), want), f"{what}: unbatch {name}"
+    else:
+        for name, got, want in (("ef", u.ef, ef), ("nf", u.nf, nf), ("gf", u.gf, gf)):
+            assert (got is None) == (want is None), what
+            if want is not None:
+                for i in range(B):
+                    assert np.array_equal(got[i].cpu().numpy(), want[i]), f"{what}: unbatch {name}[{i}]"
+    # views and the flat forms against the padded arrays of the oracle
+    PN = gd.node_block_size
+    em = gd.flat_edge_unpadder.reshape(PN * PN, -1, order="F")
+    nm = gd.flat_node_unpadder.reshape(PN, -1, order="F")
+    for b in range(B):
+        eb, nb = (em[:, 0], nm[:, 0]) if shared else (em[:, b], nm[:, b])
+        if de:
+            assert np.array_equal(gn.efview(x, slice(None), slice(None), b).cpu().numpy(), xd["ef"][:, eb, b].astype(np.float32)), f"{what}: efview {b}"
+        if dn:
+            assert np.array_equal(gn.nfview(x, slice(None), slice(None), b).cpu().numpy(), xd["nf"][:, nb, b].astype(np.float32)), f"{what}: nfview {b}"
+        if dg:
+            assert np.array_equal(gn.gfview(x, slice(None), b).cpu().numpy(), xd["gf"][:, 0, b].astype(np.float32)), f"{what}: gfview {b}"
+    if not shared:
+        if de:
+            assert np.array_equal(gn.flatunpaddedef(x).cpu().numpy(), O.flat_from_dense(xd, "ef").astype(np.float32)), f"{what}: flatunpaddedef"
+        if dn:
+            assert np.array_equal(gn.flatunpaddednf(x).cpu().numpy(), O.flat_from_dense(xd, "nf").astype(np.float32)), f"{what}: flatunpaddednf"
+    # padded() == the oracle's padded arrays (zeros in the pads), unpadded(padded(x)) == x
+    pad = gn.padded(x)
+    for name, got, want in (("ef", pad.ef, xd["ef"]), ("nf", pad.nf, xd["nf"]), ("gf", pad.gf, xd["gf"])):
+        assert (got is None) == (want is None), f"{what}: padded {name}"
+        if want is not None:
+            assert np.array_equal(got.cpu().numpy(), want.astype(np.float32)), f"{what}: padded {name}"
+    back = gn.unpadded(x.graphs, pad.ef, pad.nf, pad.gf)
+    for name in ("ef", "nf", "gf"):
+        a, b_ = getattr(back, name), getattr(x, name)
+        assert (a is None) == (b_ is None) and (a is None or torch.equal(a, b_)), f"{what}: unpadded(padded) {name}"
+    # edge collapsing
+    if de:
+        np.testing.assert_allclose(gn.collapsef(x).cpu().numpy(), O.collapsef_dense(xd), rtol=1e-6, atol=1e-6, err_msg=f"{what}: collapsef")
+        for b, (got, want) in enumerate(zip(gn.unpaddedcollapsedef(x), O.unpaddedcollapsedef_dense(xd))):
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-6, atol=1e-6, err_msg=f"{what}: unpaddedcollapsedef {b}")
+
+
 def _random_chain(rng, widths, first_in, ln_min=1):
     """0-3 Dense layers with LayerNorm layer values sprinkled in, each over at least `ln_min` columns (never in front of a zero-width input; the
     backward sweeps ask for 2: the derivative of sigma at a one-column row is 0 / 0 in the float64 reference too)."""
