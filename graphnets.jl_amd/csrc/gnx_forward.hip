@@ -622,10 +622,12 @@ int32_t gnx_collapse_padded(const gnx_graphs* h, const float* ef, int32_t d, int
 
 int32_t gnx_fn_input(const gnx_graphs* h, int32_t kind, const float* ef, int32_t de, const float* nf, int32_t dn, const float* gf,
                      int32_t dg, int64_t R, float* out, void* stream) {
-  if (!h || !out) return fail(GNX_ERR_INVALID_ARG, "NULL handle or output");
+  if (!h) return fail(GNX_ERR_INVALID_ARG, "NULL handle or output");
   if (kind < 0 || kind > 2) return fail(GNX_ERR_INVALID_ARG, "kind must be 0 (edge), 1 (node) or 2 (graph)");
+  if (kind == 0 && h->E == 0 && de >= 0 && dn >= 0 && dg >= 0) return GNX_OK;  // the edge function input of a batch without edges has no rows (out may be NULL)
+  if (!out) return fail(GNX_ERR_INVALID_ARG, "NULL handle or output");
   if (de < 0 || dn < 0 || dg < 0) return fail(GNX_ERR_DIMS, "negative feature width");
-  if (!ef) de = 0;
+  if (!ef && h->E > 0) de = 0;  // (a batch without edges: its (de, 0) edge features have no buffer — the sums over them are rows of de zeros, as in the reference)
   if (!nf) dn = 0;
   if (!gf) dg = 0;
   if (de + dn + dg == 0) return fail(GNX_ERR_ALL_NOTHING, "ef, nf and gf are all nothing");

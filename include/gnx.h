@@ -13,7 +13,8 @@
  *     (row-major) — byte-identical to Julia's column-major (D, T, R) arrays and, for vector-of-graphs
  *     batches (R = 1), to flatunpaddedef / flatunpaddednf (src/views.jl:80-98).  R = number of replicas of
  *     the graph structure: the data batch size B of a shared-adjacency batch (src/batch.jl:66), 1 otherwise.
- *     E, N, G are totals over the graphs of the handle.  NULL <=> `nothing`.
+ *     E, N, G are totals over the graphs of the handle.  NULL <=> `nothing`; the (DE, 0) edge features of a batch WITHOUT
+ *     edges have no bytes and may be NULL too (their width still counts: sums over them are rows of DE zeros).
  *   - Edge order inside a graph = order of the ones of vec(A) column-major (src/pad.jl:30): sorted by
  *     destination j then source i, A[i,j] = 1 meaning i -> j (src/gngraphbatch.jl:194-211).
  *   - Dense weights are (out x in) column-major = Flux `Dense.weight` bytes: W[k*out + j]; device pointers.

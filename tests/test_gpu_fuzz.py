@@ -170,8 +170,6 @@ def test_random_model(gn, seed):
     rng = np.random.default_rng(9600 + seed)
     big = rng.random() < 0.3
     g, R = _random_big_batch(rng, gn) if big else _random_batch(rng, gn)
-    if g.n_edges == 0:
-        pytest.skip("a batch without edges")
     din = tuple(int(rng.choice([0, 2, 5, 10])) for _ in range(3))
     if din[0] + din[1] == 0:
         din = (4, 3, din[2])
@@ -280,6 +278,54 @@ def test_random_batch_views_padding_and_collapse(gn, seed):
         np.testing.assert_allclose(gn.collapsef(x).cpu().numpy(), O.collapsef_dense(xd), rtol=1e-6, atol=1e-6, err_msg=f"{what}: collapsef")
         for b, (got, want) in enumerate(zip(gn.unpaddedcollapsedef(x), O.unpaddedcollapsedef_dense(xd))):
             np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-6, atol=1e-6, err_msg=f"{what}: unpaddedcollapsedef {b}")
+
+
+@pytest.mark.parametrize("seed", range(10 + EXTRA // 4))
+def test_random_fn_inputs_and_readout_loss(gn, seed):
+    """The exported building blocks on random batches (graphs of one node, without edges): getedgefninput / getnodefninput / getgraphfninput
+    against the oracle's literal one-hot products (edgefninput.jl, nodefninput.jl, graphfninput.jl) for every `nothing` combination they
+    admit, and logitcrossentropy (+ its gradient) against torch on random (d, cols) arrays."""
+    import torch
+    rng = np.random.default_rng(9200 + seed)
+    adjs = [(rng.random((n, n)) < rng.choice([0.0, 0.2, 0.6, 1.0])).astype(np.int64) for n in rng.choice([1, 2, 3, 6, 11, 30], int(rng.integers(1, 6)))]
+    de, dn, dg = (int(rng.choice([0, 1, 3, 8, 33])) for _ in range(3))
+    if de + dn + dg == 0:
+        dn = 4
+    ef = [rng.standard_normal((de, int(a.sum()))).astype(np.float32) for a in adjs] if de else None
+    nf = [rng.standard_normal((dn, a.shape[0])).astype(np.float32) for a in adjs] if dn else None
+    gf = [rng.standard_normal(dg).astype(np.float32) for _ in adjs] if dg else None
+    x = gn.batch(dict(graphs=adjs, ef=ef, nf=nf, gf=gf))
+    xd = O.batch_dense(adjs, ef, nf, gf)
+    g = xd["graphs"]
+    B, PN = len(adjs), g.node_block_size
+    em = g.flat_edge_unpadder.reshape(PN * PN, B, order="F")
+    nm = g.flat_node_unpadder.reshape(PN, B, order="F")
+    what = f"seed {seed} dims {(de, dn, dg)} sizes {[a.shape[0] for a in adjs]} edges {[int(a.sum()) for a in adjs]}"
+    got = gn.getedgefninput(x.graphs, x.ef, x.nf, x.gf).cpu().numpy()[:, :, 0]
+    ref = O._vcat(([xd["ef"]] if de else []) + ([O.batched_mul(xd["nf"], g.srcnode2edge), O.batched_mul(xd["nf"], g.dstnode2edge)] if dn else []) +
+                  ([O.batched_mul(xd["gf"], g.graph2edge)] if dg else []))
+    np.testing.assert_allclose(got, np.concatenate([ref[:, em[:, b], b] for b in range(B)], axis=1), rtol=1e-6, atol=1e-6, err_msg=f"{what}: getedgefninput")
+    if de:  # the node function sees the (updated) edge features; nf / gf optional
+        got = gn.getnodefninput(x.graphs, x.ef, x.nf, x.gf).cpu().numpy()[:, :, 0]
+        ref = O._vcat([O.batched_mul(xd["ef"], g.edge2node)] + ([xd["nf"]] if dn else []) + ([O.batched_mul(xd["gf"], g.graph2node)] if dg else []))
+        np.testing.assert_allclose(got, np.concatenate([ref[:, nm[:, b], b] for b in range(B)], axis=1), rtol=1e-5, atol=1e-5, err_msg=f"{what}: getnodefninput")
+    if de and dn:
+        got = gn.getgraphfninput(x.graphs, x.ef, x.nf, x.gf).cpu().numpy()[:, :, 0]
+        ref = O._vcat([O.batched_mul(xd["ef"], g.edge2graph), O.batched_mul(xd["nf"], g.node2graph)] + ([xd["gf"]] if dg else []))
+        np.testing.assert_allclose(got, ref[:, 0, :], rtol=1e-5, atol=1e-5, err_msg=f"{what}: getgraphfninput")
+    # readout loss
+    d, cols = int(rng.choice([1, 2, 5, 33, 130])), int(rng.choice([1, 3, 64, 257, 5000]))
+    yh = torch.from_numpy((rng.standard_normal((d, cols)) * rng.choice([0.1, 1.0, 30.0])).astype(np.float32))
+    y = torch.softmax(torch.from_numpy(rng.standard_normal((d, cols)).astype(np.float32)), dim=0)
+    a = yh.clone().cuda().requires_grad_(True)
+    loss = gn.logitcrossentropy(a, y.cuda())
+    loss.backward()
+    r = yh.double().clone().requires_grad_(True)
+    lr = -(y.double() * torch.log_softmax(r, dim=0)).sum(dim=0).mean()
+    lr.backward()
+    lv, lrv = float(loss.detach()), float(lr.detach())
+    assert abs(lv - lrv) <= 1e-5 * max(1.0, abs(lrv)), f"{what}: logitcrossentropy ({d}, {cols}): {lv} vs {lrv}"
+    np.testing.assert_allclose(a.grad.cpu().numpy(), r.grad.numpy(), rtol=1e-4, atol=1e-6 / cols + 1e-9, err_msg=f"logitcrossentropy gradient ({d}, {cols})")
 
 
 def _random_chain(rng, widths, first_in, ln_min=1):
