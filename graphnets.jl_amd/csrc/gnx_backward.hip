@@ -824,10 +824,9 @@ static int32_t core_backward_impl(const gnx_graphs* h, const gnx_core_params* p,
   // 2. FeedForward pullback per entity: f = W2 h + b2, h = act1(W1 z + b1), z = gn2(x); upstream of f is g_out
   for (int t = 0; t < 3; ++t) {
     float* dz2 = F(L.dz2[t]);
-    if (rows[t] == 0) continue;
     const int D = d[t], H = 4 * d[t];
-    if (!gout[t]) {  // no upstream gradient on this entity: the FeedForward branch contributes nothing
-      GNX_HIP(hipMemsetAsync(dz2, 0, sizeof(float) * rows[t] * D, s));
+    if (rows[t] == 0 || !gout[t]) {  // an entity without rows (a batch without edges), or no upstream gradient on it: the FeedForward branch contributes nothing
+      if (rows[t]) GNX_HIP(hipMemsetAsync(dz2, 0, sizeof(float) * rows[t] * D, s));
       if (gr.ff[t].fc1.weight) GNX_HIP(hipMemsetAsync(gr.ff[t].fc1.weight, 0, sizeof(float) * (size_t)H * D, s));
       if (gr.ff[t].fc1.bias) GNX_HIP(hipMemsetAsync(gr.ff[t].fc1.bias, 0, sizeof(float) * H, s));
       if (gr.ff[t].fc2.weight) GNX_HIP(hipMemsetAsync(gr.ff[t].fc2.weight, 0, sizeof(float) * (size_t)H * D, s));
@@ -899,7 +898,11 @@ static int32_t core_backward_impl(const gnx_graphs* h, const gnx_core_params* p,
                                F(L.dl1[0]), F(L.dl1[1]), F(L.dl1[2]), &gr.block, base + L.blk_bw, gnx_block_backward_workspace_bytes(h, &b, R), stream))) return rc;
   // 4. LayerNorm pullbacks (both norms at once) + residual; gamma/beta gradients as column sums over all rows
   for (int t = 0; t < 3; ++t) {
-    if (rows[t] == 0) continue;
+    if (rows[t] == 0) {  // (sums over nothing: zeros, not what the buffers held)
+      for (float* o : {gr.ln1[t].gamma, gr.ln1[t].beta, gr.ln2[t].gamma, gr.ln2[t].beta})
+        if (o && d[t] > 0) GNX_HIP(hipMemsetAsync(o, 0, sizeof(float) * (size_t)d[t], s));
+      continue;
+    }
     float* t1 = F(L.t1); float* t2 = F(L.t2);
     const bool al16 = (((uintptr_t)x[t] | (uintptr_t)F(L.dl1[t]) | (uintptr_t)F(L.dz2[t]) | (uintptr_t)gout[t] | (uintptr_t)dxo[t] | (uintptr_t)p->ln1[t].gamma |
                         (uintptr_t)p->ln2[t].gamma) & 15) == 0;
@@ -1093,6 +1096,14 @@ int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_para
     ProfScope ps("bw_delta", s);
     launch_delta(a, 0, 0, 1, s);
   };
+  // an entity without rows (a batch without edges): its layers' parameter gradients are sums over nothing — zeros, not what the buffers held
+  auto zero_layer_grads = [&](int t, int i, int K) -> int32_t {
+    const gnx_dense_grad& gz = grad_of(t, i);
+    const int J = ch[t]->widths[i];
+    if (gz.weight && J > 0) GNX_HIP(hipMemsetAsync(gz.weight, 0, sizeof(float) * (chain_layer_is_ln(ch[t]->layers[i]) ? (size_t)J : (size_t)J * K), s));
+    if (gz.bias && J > 0) GNX_HIP(hipMemsetAsync(gz.bias, 0, sizeof(float) * (size_t)J, s));
+    return GNX_OK;
+  };
   auto pull_layers = [&](int t, int first, float* cur, float* other, const float* X0, int K0, float* g_first, float** result) -> int32_t {
     for (int i = ch[t]->n_layers - 1; i >= first; --i) {
       const int J = ch[t]->widths[i], K = i > 0 ? ch[t]->widths[i - 1] : K0;
@@ -1100,6 +1111,7 @@ int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_para
       float* gin = i == first && g_first ? g_first : other;
       if (i == first && result) *result = gin;
       const gnx_dense& d = ch[t]->layers[i];
+      if (rows[t] == 0 && J > 0) { if (int32_t rz = zero_layer_grads(t, i, K)) return rz; }
       if (rows[t] == 0 || J == 0) continue;
       int32_t r2;
       if (chain_layer_is_ln(d)) {
@@ -1165,6 +1177,9 @@ int32_t gnx_chain_block_backward(const gnx_graphs* h, const gnx_chain_block_para
       last_delta(0, g_ef_out, gb[0], nullptr, 0, -1);
       if ((rc = pull_layers(0, 1, gb[0], gb[1], nullptr, 0, nullptr, &g_first))) return rc;  // g_first: where the last dX went
     }
+  } else {
+    for (int i = 1; i < ch[0]->n_layers; ++i)
+      if ((rc = zero_layer_grads(0, i, ch[0]->widths[i - 1]))) return rc;  // (layer 0: the block pullback below zeroes its own)
   }
   gnx_block_grads g1{};
   g1.edgefn = grad_of(0, 0);

@@ -390,8 +390,6 @@ def test_random_chain_block_backward(gn, seed):
     rng = np.random.default_rng(9750 + seed)
     big = rng.random() < 0.3
     g, _ = _random_big_batch(rng, gn) if big else _random_batch(rng, gn)
-    if g.n_edges == 0:
-        pytest.skip("a batch without edges")
     widths = [8, 24, 48, 64] if big else [1, 3, 7, 12, 16, 33]
     while True:
         in_dims = tuple(int(rng.choice([0] + widths)) for _ in range(3))
@@ -415,8 +413,6 @@ def test_random_core_backward(gn, seed):
     rng = np.random.default_rng(9850 + seed)
     big = rng.random() < 0.4
     cps, rvs, sizes, _ = _random_big_csc(rng) if big else _random_csc(rng)
-    if sum(len(r) for r in rvs) == 0:
-        pytest.skip("a batch without edges")
     dims = tuple(int(v) for v in (rng.choice([(128, 64, 32), (64, 64, 16), (64, 32, 8), (40, 36, 33)]) if big else rng.choice([(3, 4, 5), (10, 5, 3), (8, 8, 8), (16, 12, 4), (33, 20, 5), (64, 32, 8)])))
     hidden = str(rng.choice(["tanh", "gelu"]))
     assert _core_backward_case(gn, dims, big, int(rng.integers(0, 2)), rng, hidden_act=hidden, graphs=(sizes, cps, rvs))
@@ -468,6 +464,9 @@ def _check_block_backward(gn, rng, g, din, dout, seed):
         if ref is None or got is None:
             return
         ref = ref.detach().numpy(); got = got.detach().double().cpu().numpy()
+        if ref.size == 0:  # (the gradient of a (0, d) array: a batch without edges)
+            assert got.shape == ref.shape, (what, got.shape, ref.shape)
+            return
         scale = max(1.0, float(np.abs(ref).max())) if ref.size else 1.0
         assert got.shape == ref.shape and (ref.size == 0 or np.max(np.abs(got - ref)) <= 5e-4 * scale), \
             f"seed {seed} dims {din}=>{dout} {what}: max err {np.max(np.abs(got - ref)) if ref.size else 0:.3e} (scale {scale:.3g})"
