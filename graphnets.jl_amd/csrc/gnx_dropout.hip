@@ -120,8 +120,9 @@ using namespace gnx;
 extern "C" {
 
 int32_t gnx_dropout_mask(const gnx_dropout* d, int32_t entity, int64_t n, float* out, void* stream) {
-  if (!d || !out || n < 0 || entity < 0 || entity > 2) return fail(GNX_ERR_INVALID_ARG, "gnx_dropout_mask: NULL argument, negative length or entity outside 0..2");
+  if (!d || (!out && n > 0) || n < 0 || entity < 0 || entity > 2) return fail(GNX_ERR_INVALID_ARG, "gnx_dropout_mask: NULL argument, negative length or entity outside 0..2");
   if (int32_t rc = check_dropout(d)) return rc;
+  if (n == 0) return GNX_OK;  // (the mask of an entity without rows: a batch without edges)
   return launch_dropout(*d, entity, (size_t)n, nullptr, out, 0, (hipStream_t)stream);
 }
 

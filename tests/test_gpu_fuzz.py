@@ -418,6 +418,18 @@ def test_random_core_backward(gn, seed):
     assert _core_backward_case(gn, dims, big, int(rng.integers(0, 2)), rng, hidden_act=hidden, graphs=(sizes, cps, rvs))
 
 
+@pytest.mark.parametrize("seed", range(4 + EXTRA // 12))
+def test_random_core_training_with_dropout(gn, seed):
+    """Training-mode GNCore (Dropout inside the FeedForward, masks regenerated from the seed) forward and every gradient against float64 with the
+    same masks (tests/test_gpu_dropout.py), at random widths on random batches — batches without edges included."""
+    from tests.test_gpu_dropout import _case
+    rng = np.random.default_rng(9880 + seed)
+    big = rng.random() < 0.3
+    cps, rvs, sizes, _ = _random_big_csc(rng) if big else _random_csc(rng)
+    dims = tuple(int(v) for v in (rng.choice([(64, 32, 16), (40, 36, 33), (64, 64, 8)]) if big else rng.choice([(3, 4, 5), (10, 5, 3), (8, 8, 8), (16, 12, 4), (33, 20, 5)])))
+    _case(gn, dims, big, rng, float(rng.choice([0.1, 0.3, 0.5])), str(rng.choice(["tanh", "gelu"])), graphs=(sizes, cps, rvs))
+
+
 @pytest.mark.parametrize("din,dout", [((20, 0, 0), (0, 24, 24)),   # node function without inputs (oe = dn = dg = 0): bias only
                                       ((0, 0, 7), (3, 0, 2)),     # only graph features in; no node function
                                       ((0, 5, 0), (0, 0, 4)),     # graph function fed by nothing but zero-width sums
