@@ -328,6 +328,44 @@ def test_random_fn_inputs_and_readout_loss(gn, seed):
     np.testing.assert_allclose(a.grad.cpu().numpy(), r.grad.numpy(), rtol=1e-4, atol=1e-6 / cols + 1e-9, err_msg=f"logitcrossentropy gradient ({d}, {cols})")
 
 
+@pytest.mark.parametrize("seed", range(8 + EXTRA // 4))
+def test_random_batch_constructors_agree(gn, seed):
+    """GNGraphBatch (gngraphbatch.jl:33-54, :136-211) through every constructor — a list of dense matrices (the host builder, or the device
+    builder for big ones), ONE packed buffer of several element types in pageable / device memory, per-graph CSC, concatenated CSC — on random
+    batches (one-node graphs, graphs without edges, dense ones, many small ones): the same CSC, offsets, block sizes and unpadder masks, all
+    equal to the oracle's literal construction."""
+    import torch
+    rng = np.random.default_rng(9100 + seed)
+    G = int(rng.choice([1, 2, 5, 40, 300]))
+    sizes = [int(v) for v in rng.choice([1, 2, 3, 7, 20, 64, 130] if G <= 5 else [1, 2, 3, 7, 20], G)]
+    adjs = [(rng.random((n, n)) < rng.choice([0.0, 0.05, 0.3, 1.0])).astype(np.int64) for n in sizes]
+    colptr, rowval, node_off, edge_off = O.csc_from_adj(adjs)
+    what = f"seed {seed} G={G} N={sum(sizes)} E={len(rowval)}"
+    cps, rvs = [], []
+    for g_, n in enumerate(sizes):
+        n0, e0, e1 = node_off[g_], edge_off[g_], edge_off[g_ + 1]
+        cps.append(np.asarray(colptr[n0:n0 + n + 1]) - e0)
+        rvs.append(np.asarray(rowval[e0:e1]) - n0)
+    cat = np.concatenate([a.reshape(-1) for a in adjs])
+    dt = [np.uint8, np.bool_, np.int32, np.int64, np.float32, np.float64][int(rng.integers(0, 6))]
+    built = {
+        "dense list": gn.GNGraphBatch(adjs),
+        "dense list float32": gn.GNGraphBatch([a.astype(np.float32) for a in adjs]),
+        f"packed {np.dtype(dt).name} pageable": gn.GNGraphBatch.from_dense_packed(cat.astype(dt), sizes),
+        "packed uint8 device": gn.GNGraphBatch.from_dense_packed(torch.from_numpy(cat.astype(np.uint8)).cuda(), sizes),
+        "csc": gn.GNGraphBatch.from_csc(cps, rvs, sizes),
+        "csc packed int32": gn.GNGraphBatch.from_csc_packed(np.concatenate(cps).astype(np.int32), np.concatenate(rvs).astype(np.int32) if len(rowval) else np.zeros(0, np.int32), sizes),
+    }
+    dense = O.batch_dense(adjs, None, [np.zeros((1, n), np.float32) for n in sizes], None)["graphs"]
+    for name, g in built.items():
+        cp, rv = g.csc()
+        assert (g.n_graphs, g.n_nodes, g.n_edges) == (G, sum(sizes), len(rowval)), f"{what}: {name}: counts"
+        assert np.array_equal(cp, colptr) and np.array_equal(rv, rowval), f"{what}: {name}: CSC"
+        assert np.array_equal(g.node_off, node_off) and np.array_equal(g.edge_off, edge_off), f"{what}: {name}: offsets"
+        assert g.node_block_size == dense.node_block_size and g.edge_block_size == dense.edge_block_size, f"{what}: {name}: block sizes"
+        assert np.array_equal(g.flat_node_unpadder, dense.flat_node_unpadder) and np.array_equal(g.flat_edge_unpadder, dense.flat_edge_unpadder), f"{what}: {name}: unpadders"
+
+
 def _random_chain(rng, widths, first_in, ln_min=1):
     """0-3 Dense layers with LayerNorm layer values sprinkled in, each over at least `ln_min` columns (never in front of a zero-width input; the
     backward sweeps ask for 2: the derivative of sigma at a one-column row is 0 / 0 in the float64 reference too)."""
