@@ -366,6 +366,62 @@ def test_random_batch_constructors_agree(gn, seed):
         assert np.array_equal(g.flat_node_unpadder, dense.flat_node_unpadder) and np.array_equal(g.flat_edge_unpadder, dense.flat_edge_unpadder), f"{what}: {name}: unpadders"
 
 
+@pytest.mark.parametrize("seed", range(8 + EXTRA // 6))
+def test_random_plan_steps_and_chained_calls_equal_single_forwards(gn, seed):
+    """A loop over resident batches in the library's three forms — gnx_block_forward per step, gnx_block_forward_steps (one call), and the
+    chained calls + flush — on random width sets / batches (replicas, graphs without edges): bit-identical outputs, also when the steps share
+    ONE workspace, and against the oracle once."""
+    import torch
+    rng = np.random.default_rng(9050 + seed)
+    big = rng.random() < 0.25
+    g, R = _random_big_batch(rng, gn) if big else _random_batch(rng, gn)
+    if big:
+        din, dout = WIDE_BLOCKS[int(rng.integers(0, len(WIDE_BLOCKS)))]
+    else:
+        din, dout = _dims(rng)
+        if rng.random() < 0.5:
+            din, dout = ((10, 5, 0), (3, 4, 5)) if rng.random() < 0.5 else ((10, 5, 3), (10, 5, 3))  # (the ahead-of-time sets: the chained form exists for them)
+    p = O.make_block_params(rng, din, dout, act=tuple(int(a) for a in rng.integers(0, 5, 3)))
+    blk = U.block_from_params(gn, p)
+    plan = gn.BlockPlan(blk, g, R=R)
+    dev = g.device
+    mk = lambda T, d: torch.from_numpy(rng.standard_normal((R, T, d)).astype(np.float32)).to(dev) if d > 0 else None
+    n = int(rng.integers(1, 6))
+    sets = [dict(ef=mk(g.n_edges, din[0]), nf=mk(g.n_nodes, din[1]), gf=mk(g.n_graphs, din[2]), out=plan.outputs(), ws=plan.new_workspace()) for _ in range(n)]
+    what = f"seed {seed} dims {din}=>{dout} N={g.n_nodes} E={g.n_edges} G={g.n_graphs} R={R} steps={n}"
+    ref = []
+    for b in sets:
+        out = plan.outputs()
+        plan(b["ef"], b["nf"], b["gf"], *out)
+        ref.append(out)
+    torch.cuda.synchronize()
+
+    def same(tag):
+        torch.cuda.synchronize()
+        for i, b in enumerate(sets):
+            for name, a, r in zip(("ef", "nf", "gf"), b["out"], ref[i]):
+                assert (a is None) == (r is None) and (a is None or torch.equal(a, r)), f"{what}: {tag}: step {i} {name}"
+                if a is not None:
+                    a.fill_(float("nan"))
+    plan.steps(sets)
+    same("steps")
+    plan.steps([dict(b, ws=sets[0]["ws"]) for b in sets])
+    same("steps on one workspace")
+    pend = None
+    for b in sets:
+        pend = plan.chained(b["ef"], b["nf"], b["gf"], *b["out"], ws=b["ws"], prev=pend)
+    plan.flush(pend)
+    same("chained calls + flush")
+    # ... and the values themselves, once
+    b = sets[0]
+    host = lambda t: None if t is None else t.cpu().numpy()
+    r_o, s_o = O.block_forward_sparse(p, (*g.csc(), g.node_off, g.edge_off), host(b["ef"]), host(b["nf"]), host(b["gf"]), return_scale=True)
+    for name, got, r, sc in zip(("ef", "nf", "gf"), ref[0], r_o, s_o):
+        if r is None or 0 in r.shape:
+            continue
+        U.assert_close(got.cpu().numpy(), r, sc, f"{what}: {name}")
+
+
 def _random_chain(rng, widths, first_in, ln_min=1):
     """0-3 Dense layers with LayerNorm layer values sprinkled in, each over at least `ln_min` columns (never in front of a zero-width input; the
     backward sweeps ask for 2: the derivative of sigma at a one-column row is 0 / 0 in the float64 reference too)."""
