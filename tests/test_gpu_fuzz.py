@@ -422,6 +422,69 @@ def test_random_plan_steps_and_chained_calls_equal_single_forwards(gn, seed):
         U.assert_close(got.cpu().numpy(), r, sc, f"{what}: {name}")
 
 
+@pytest.mark.parametrize("seed", range(6 + EXTRA // 8))
+def test_random_by_graph_sharding_over_virtual_ranks(gn, seed):
+    """The N > 1 data path except the wire on random batches and world sizes (shards that differ by one graph, graphs without edges, one graph
+    per rank): gnx_dist_partition's shards run one after the other on this GPU, their padded send buffers concatenated as the all-gather would,
+    the gather plan restores original graph order — gf' of the whole batch and every shard's ef' / nf' equal the single-process oracle; the C
+    boundary's gnx_dist_permute_rows gives the same table."""
+    import torch
+    from graphnets_jl_amd.dist import GfGather, gather_plan, partition_graphs
+    rng = np.random.default_rng(9400 + seed)
+    G = int(rng.choice([1, 2, 3, 9, 40, 130]))
+    world = int(rng.integers(1, min(G, 8) + 1))
+    cps, rvs, sizes = [], [], []
+    for _ in range(G):
+        n = int(rng.choice([1, 2, 5, 17, 60]))
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            cp, rv = np.zeros(n + 1, dtype=np.int64), np.zeros(0, dtype=np.int64)
+        else:
+            cp, rv = U.er_csc(rng, n, int(rng.integers(1, max(2, n * n // 2))))
+        cps.append(cp); rvs.append(rv); sizes.append(n)
+    e_all = np.array([len(r) for r in rvs], dtype=np.int64)
+    shards = partition_graphs(e_all, world)
+    assert sorted(int(i) for s_ in shards for i in s_) == list(range(G)) and max(len(s_) for s_ in shards) - min(len(s_) for s_ in shards) <= 1
+    node_off, edge_off = np.concatenate([[0], np.cumsum(sizes)]), np.concatenate([[0], np.cumsum(e_all)])
+    din, dout = (((10, 5, 0), (3, 4, 5)), ((10, 5, 3), (10, 5, 3)), ((4, 3, 2), (3, 4, 2)), ((33, 20, 5), (7, 12, 3)))[int(rng.integers(0, 4))]
+    p = O.make_block_params(rng, din, dout, act=tuple(int(a) for a in rng.integers(0, 5, 3)))
+    ef, nf, gf = U.packed_inputs(rng, 1, int(edge_off[-1]), int(node_off[-1]), G, din)
+    blk = U.block_from_params(gn, p)
+    og = dout[2]
+    what = f"seed {seed} G={G} world={world} dims {din}=>{dout} N={node_off[-1]} E={edge_off[-1]}"
+    gathers = [GfGather(shards, r, world, og, "cuda", overlap=False) for r in range(world)]
+    outs = []
+    for r in range(world):
+        mine = shards[r]
+        g = gn.GNGraphBatch.from_csc([cps[i] for i in mine], [rvs[i] for i in mine], [sizes[i] for i in mine])
+        take = lambda a, off: None if a is None else torch.from_numpy(np.concatenate([a[0, off[i]:off[i + 1]] for i in mine])[None]).to(g.device)
+        gfl = None if gf is None else torch.from_numpy(gf[0, mine][None]).to(g.device)
+        plan = gn.BlockPlan(blk, g)
+        eo, no, _ = plan.outputs()
+        plan(take(ef, edge_off), take(nf, node_off), gfl, eo, no, gathers[r].send[:, :len(mine)])
+        outs.append((eo, no))
+    torch.cuda.synchronize()
+    wire = torch.cat([gt.send.view(-1, og) for gt in gathers], dim=0).contiguous()
+    gathers[0].recv.copy_(wire)
+    gf_all = gathers[0].result().cpu().numpy()
+    src, mc = gather_plan(shards)
+    assert mc == max(len(s_) for s_ in shards)
+    out_c = torch.empty((G, og), dtype=torch.float32, device="cuda")
+    gn._lib.check(gn._lib.load().gnx_dist_permute_rows(wire.data_ptr(), torch.from_numpy(src).cuda().data_ptr(), G, og, out_c.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert np.array_equal(out_c.cpu().numpy(), gf_all), f"{what}: gnx_dist_permute_rows"
+    cp = np.concatenate([[0]] + [c[1:] + edge_off[i] for i, c in enumerate(cps)])
+    rv = np.concatenate([r_ + node_off[i] for i, r_ in enumerate(rvs)]) if edge_off[-1] else np.zeros(0, dtype=np.int64)
+    ref, scale = O.block_forward_sparse(p, (cp, rv, node_off, edge_off), ef, nf, gf, return_scale=True)
+    U.assert_close(gf_all[None], ref[2], scale[2], f"{what}: gathered gf'")
+    for r in range(world):
+        eidx = np.concatenate([np.arange(edge_off[i], edge_off[i + 1]) for i in shards[r]]).astype(np.int64)
+        nidx = np.concatenate([np.arange(node_off[i], node_off[i + 1]) for i in shards[r]]).astype(np.int64)
+        if len(eidx):
+            U.assert_close(outs[r][0].cpu().numpy(), ref[0][:, eidx], scale[0][:, eidx], f"{what}: ef' of shard {r}")
+        U.assert_close(outs[r][1].cpu().numpy(), ref[1][:, nidx], scale[1][:, nidx], f"{what}: nf' of shard {r}")
+
+
 def _random_chain(rng, widths, first_in, ln_min=1):
     """0-3 Dense layers with LayerNorm layer values sprinkled in, each over at least `ln_min` columns (never in front of a zero-width input; the
     backward sweeps ask for 2: the derivative of sigma at a one-column row is 0 / 0 in the float64 reference too)."""
