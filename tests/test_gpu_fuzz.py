@@ -485,6 +485,48 @@ def test_random_by_graph_sharding_over_virtual_ranks(gn, seed):
         U.assert_close(outs[r][1].cpu().numpy(), ref[1][:, nidx], scale[1][:, nidx], f"{what}: nf' of shard {r}")
 
 
+@pytest.mark.parametrize("seed", range(6 + EXTRA // 8))
+def test_random_prepared_parameters_are_bit_identical_and_follow_in_place_updates(gn, seed):
+    """`prepare()` (gnx_block_prepare / gnx_core_prepare: the weight planes of the matrix-core kernels made once — `model |> device`) on random
+    blocks / cores and batches on both sides of the 4096-row thresholds: the forward is bit-identical to the unprepared layer's, and after an
+    in-place update of a random subset of the parameters the prepared layer equals a FRESH layer built from the updated values."""
+    import torch
+    rng = np.random.default_rng(9000 + seed)
+    g, R = _random_big_batch(rng, gn)
+    is_core = rng.random() < 0.5
+    if is_core:
+        dims = WIDE_CORES[int(rng.integers(0, len(WIDE_CORES)))]
+        p = O.make_core_params(rng, dims, eps_mode=int(rng.integers(0, 2)))
+        mk = lambda: U.core_from_params(gn, p)
+        din = dims
+    else:
+        din, dout = WIDE_BLOCKS[int(rng.integers(0, len(WIDE_BLOCKS)))]
+        p = O.make_block_params(rng, din, dout, act=tuple(int(a) for a in rng.integers(0, 5, 3)))
+        mk = lambda: U.block_from_params(gn, p)
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, g.n_graphs, din)
+    x = U.to_nt(gn, g, ef, nf, gf)
+    what = f"seed {seed} {'core' if is_core else 'block'} {din} N={g.n_nodes} E={g.n_edges} G={g.n_graphs} R={R}"
+
+    def same(a, b, tag):
+        for name in ("ef", "nf", "gf"):
+            u, v = getattr(a, name), getattr(b, name)
+            assert (u is None) == (v is None) and (u is None or torch.equal(u, v)), f"{what}: {tag}: {name}"
+    plain, prepared = mk(), mk().prepare()
+    with torch.no_grad():
+        same(prepared(x), plain(x), "prepared vs unprepared")
+        params = prepared._param_list() if is_core else [t for l in (prepared.edgefn, prepared.nodefn, prepared.graphfn) for t in (l.weight, l.bias)]
+        fresh = mk()
+        fparams = fresh._param_list() if is_core else [t for l in (fresh.edgefn, fresh.nodefn, fresh.graphfn) for t in (l.weight, l.bias)]
+        touched = [i for i in range(len(params)) if rng.random() < 0.4] or [0]
+        for i in touched:
+            if params[i] is None or params[i].numel() == 0:
+                continue
+            delta = torch.from_numpy((rng.standard_normal(tuple(params[i].shape)) * 0.05).astype(np.float32)).to(params[i].device)
+            params[i].add_(delta)    # in place: the version counter moves, the planes are refreshed before the next forward
+            fparams[i].add_(delta)
+        same(prepared(x), fresh(x), f"after in-place updates of parameters {touched}")
+
+
 def _random_chain(rng, widths, first_in, ln_min=1):
     """0-3 Dense layers with LayerNorm layer values sprinkled in, each over at least `ln_min` columns (never in front of a zero-width input; the
     backward sweeps ask for 2: the derivative of sigma at a one-column row is 0 / 0 in the float64 reference too)."""
