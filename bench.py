@@ -621,12 +621,20 @@ def collect_secondary(args):
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(max(2, min(args.warmup, 5))),
                "--no-secondary", "--full-line", "--cpu-budget", "3.0"] + extra
         t0 = time.perf_counter()
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, **env_extra[0]) if env_extra else None)
-            line = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
-            err = None if line is not None else (r.stderr or "")[-300:]
-        except Exception as e:  # timeout, malformed output
-            line, err = None, repr(e)[:300]
+        line = err = None
+        for attempt in (0, 1):  # (a child that dies within seconds — a communicator's start-up now and then does — is started once more; a slow failure is not)
+            t_try = time.perf_counter()
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, **env_extra[0]) if env_extra else None)
+                line = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
+                if line is None:
+                    e_ = (r.stderr or "").strip()
+                    first = next((ln for ln in e_.splitlines() if "Error" in ln or "error" in ln or "what()" in ln), "")
+                    err = (f"exit code {r.returncode}" + (" (second attempt)" if attempt else "") + ": " + first[:300] + " ... " + e_[-300:])[:800]
+            except Exception as e:  # timeout, malformed output
+                line, err = None, repr(e)[:300]
+            if line is not None or time.perf_counter() - t_try > 20.0:
+                break
         if line is None:
             out[key] = {"what": what, "error": err, "wall_s": round(time.perf_counter() - t0, 1)}
             continue
@@ -906,7 +914,7 @@ def single_gpu_same_workload(gn, torch, dev, seed, Gtot, Etot, din, dout, K, W, 
         step(i)
     torch.cuda.synchronize(dev)
     cg = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(cg):
+    with torch.cuda.graph(cg, capture_error_mode="thread_local"):
         plan.steps([sets[i % nsets] for i in range(K)])  # gnx_block_forward_steps: the K steps as one call (the N = 1 headline's form)
     cg.replay(); torch.cuda.synchronize(dev)
     spin_up(torch, dev, cg.replay)
@@ -982,7 +990,10 @@ def measure_sharded(gn, torch, dist, dev, rank, world, args, din, dout, Gtot, Et
     cgs = []
     for base in range(0, min(K, nsets * M), M):  # enough distinct graphs to keep rotating over all buffer sets
         cg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cg):  # the M steps as ONE gnx_block_forward_steps call (every gf' table complete when the graph's work is)
+        # (thread_local: with a process group alive torch's NCCL watchdog THREAD queries the events of collectives in flight — an error inside a
+        #  "global" capture, thrown in that thread: the process aborts.  Seen once in ~20 starts of this path; tools/experiments/capture_vs_watchdog_probe.py
+        #  aborts every time with the default mode and never with this one: profiles/r06_capture_vs_watchdog.log)
+        with torch.cuda.graph(cg, capture_error_mode="thread_local"):  # the M steps as ONE gnx_block_forward_steps call (every gf' table complete when the graph's work is)
             plan.steps([(b["ef"], b["nf"], b["gf"], b["out"][0], b["out"][1], gf_stack[m:m + 1, :G], b["ws"]) for m, b in ((m, sets[(base + m) % nsets]) for m in range(M))])
         cgs.append(cg)
     copied = torch.cuda.Event()
@@ -1177,7 +1188,14 @@ def main():
     if multi:
         if "RANK" not in os.environ:
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(free_port()))
-        dist.init_process_group("nccl", device_id=dev)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+        except RuntimeError:  # (the rendezvous store's port taken between free_port() and the bind, or a transient bootstrap error: once more)
+            if world > 1:
+                raise
+            time.sleep(1.0)
+            os.environ["MASTER_PORT"] = str(free_port())
+            dist.init_process_group("nccl", device_id=dev)
     K, W = args.steps, args.warmup
     if args.model == "c4":
         return bench_c4(args, gn, torch, dev, c_abi)
@@ -1327,7 +1345,7 @@ def main():
     chained = None
     def capture(nsteps, rotate):
         cg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cg):
+        with torch.cuda.graph(cg, capture_error_mode="thread_local"):
             for i in range(nsteps):
                 step(i if rotate else (i & 1), overlap=args.overlap)  # warm: 2 sets (120 MB, cache-resident)
             torch.cuda.current_stream(dev).wait_stream(side)  # join: every graph update is inside the timed region
@@ -1340,7 +1358,7 @@ def main():
 
     def capture_steps(nsteps, rotate):
         cg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cg):
+        with torch.cuda.graph(cg, capture_error_mode="thread_local"):
             plan.steps([sets[(i if rotate else (i & 1)) % nsets] for i in range(nsteps)])
         return cg
     two_launch = None
@@ -1374,7 +1392,7 @@ def main():
 
         def capture_half(par):
             cg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cg):
+            with torch.cuda.graph(cg, capture_error_mode="thread_local"):
                 for i in range(par, Kp, 2):
                     step(i)
             return cg
@@ -1397,7 +1415,7 @@ def main():
     if not args.overlap and og > 0 and not steps_form:
         def capture_chained():
             cgc = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(cgc):
+            with torch.cuda.graph(cgc, capture_error_mode="thread_local"):
                 pend = None
                 for i in range(K):
                     b = sets[i % nsets]

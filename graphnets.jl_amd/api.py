@@ -1467,7 +1467,9 @@ class Graphed:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # (thread_local: a "global" capture turns the event queries of torch's NCCL watchdog thread — any process with a process group — into errors
+        #  that abort the process: profiles/r06_capture_vs_watchdog.log)
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self._out = model(static)
 
     def __call__(self, x):

@@ -387,3 +387,38 @@ def test_shared_graph_batch_sharded_by_replica_three_virtual_ranks(gn):
         table[rank * max_count:rank * max_count + len(mine)] = y.gf.permute(2, 1, 0)[:, 0, :]
     gathered = table[torch.from_numpy(src.astype(np.int64)).to(g.device)]
     assert torch.equal(gathered, whole.gf.permute(2, 1, 0)[:, 0, :])
+
+
+@pytest.mark.timeout(300)
+def test_graphed_captures_beside_a_live_process_group():
+    """api.Graphed (and bench.py) capture with capture_error_mode="thread_local": torch's NCCL watchdog thread polls the events of collectives in
+    flight, which inside a "global" capture is an error thrown in THAT thread — the process aborts (profiles/r06_capture_vs_watchdog.log: the
+    default mode aborts every time).  A child process: one-rank RCCL group, collectives in flight, forty Graphed captures + replays."""
+    child = r"""
+import os, socket, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import graphnets_jl_amd as gn
+with socket.socket() as s:
+    s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+rng = np.random.default_rng(0)
+adjs = [(rng.random((n, n)) < 0.3).astype(np.int64) for n in (9, 14, 30)]
+x = gn.batch(dict(graphs=adjs, ef=[rng.random((10, int(a.sum())), dtype=np.float32) for a in adjs], nf=[rng.random((5, a.shape[0]), dtype=np.float32) for a in adjs], gf=None))
+blk = gn.GNBlock((10, 5, 0), (3, 4, 5))
+ref = blk(x)
+t = torch.ones(1 << 20, device="cuda")
+for i in range(40):
+    works = [dist.all_reduce(t, async_op=True) for _ in range(4)]
+    gr = gn.Graphed(blk, x, warmup=1)
+    y = gr(x)
+    for w in works:
+        w.wait()
+    t.fill_(1.0)
+    assert torch.equal(y.ef, ref.ef) and torch.equal(y.gf, ref.gf)
+torch.cuda.synchronize(); dist.destroy_process_group(); print("ok")
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.returncode, out.stderr[-1500:])
