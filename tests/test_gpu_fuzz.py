@@ -527,6 +527,38 @@ def test_random_prepared_parameters_are_bit_identical_and_follow_in_place_update
         same(prepared(x), fresh(x), f"after in-place updates of parameters {touched}")
 
 
+@pytest.mark.parametrize("seed", range(8 + EXTRA // 8))
+def test_random_magnitudes(gn, seed):
+    """Inputs and weights at random magnitudes, 1e-12 .. 1e10 per tensor (mixed within one call): block and GNCore, narrow and wide forms, against
+    the float64 oracle at 1e-5 of its magnitude bound — the fused FMAs, the LayerNorm statistics (sigma + eps with sigma far below and far above
+    eps) and the six-term split (exponent range of the bf16 parts) away from unit scale."""
+    rng = np.random.default_rng(9500 + 31 * seed)
+    big = rng.random() < 0.4
+    g, R = _random_big_batch(rng, gn) if big else _random_batch(rng, gn)
+    core = rng.random() < 0.5
+    mag = lambda: float(10.0 ** rng.uniform(-12, 10))
+    if core:
+        dims = WIDE_CORES[int(rng.integers(0, len(WIDE_CORES)))] if big else tuple(int(v) for v in rng.choice([(10, 5, 3), (8, 8, 8), (33, 20, 5)]))
+        p = O.make_core_params(rng, dims, eps_mode=int(rng.integers(0, 2)))
+        din = dims
+    else:
+        din, dout = WIDE_BLOCKS[int(rng.integers(0, len(WIDE_BLOCKS)))] if big else _dims(rng)
+        p = O.make_block_params(rng, din, dout, act=tuple(int(a) for a in rng.choice([0, 1], 3)))  # (identity / relu: scale-equivariant, no saturation at 1e10)
+        for k in ("We", "Wn", "Wg"):
+            p[k] = (p[k] * mag() ** 0.5).astype(np.float32)
+    ef, nf, gf = U.packed_inputs(rng, R, g.n_edges, g.n_nodes, g.n_graphs, din)
+    ef, nf, gf = (None if a is None else (a * np.float32(mag())).astype(np.float32) for a in (ef, nf, gf))
+    csc = (*g.csc(), g.node_off, g.edge_off)
+    layer = U.core_from_params(gn, p) if core else U.block_from_params(gn, p)
+    ref, scale = (O.core_forward_sparse if core else O.block_forward_sparse)(p, csc, ef, nf, gf, return_scale=True)
+    y = layer(U.to_nt(gn, g, ef, nf, gf))
+    for name, got, r, s_ in zip(("ef", "nf", "gf"), (y.ef, y.nf, y.gf), ref, scale):
+        if r is None or 0 in r.shape:
+            continue
+        assert np.isfinite(r).all()
+        U.assert_close(U.from_jl(got), r, s_, f"seed {seed} {'core' if core else 'block'} dims {din} N={g.n_nodes} E={g.n_edges} R={R} {name}")
+
+
 def _random_chain(rng, widths, first_in, ln_min=1):
     """0-3 Dense layers with LayerNorm layer values sprinkled in, each over at least `ln_min` columns (never in front of a zero-width input; the
     backward sweeps ask for 2: the derivative of sigma at a one-column row is 0 / 0 in the float64 reference too)."""
